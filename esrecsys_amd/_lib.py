@@ -1,0 +1,101 @@
+"""ctypes binding of libesr_hip.so (include/esr_hip.h).
+
+The library is the ONLY compute backend: there is no CPU or eager-PyTorch fallback.  If the
+shared object is missing or fails to load, every op raises ``EsrLibraryError``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libesr_hip.so")
+
+ESR_OK = 0
+ESR_F32 = 0
+ESR_BF16 = 1
+GLOVE_REFERENCE = 0
+GLOVE_DIAGONAL = 1
+
+c_i32p = ctypes.c_void_p
+c_f32p = ctypes.c_void_p
+c_vp = ctypes.c_void_p
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_f32 = ctypes.c_float
+c_size = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/esr_hip.h one for one.
+SIGNATURES = {
+    "esr_last_error": (ctypes.c_char_p, []),
+    "esr_version": (c_int, []),
+    "esr_device_info": (c_int, [ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_size),
+                                ctypes.c_char_p, c_int]),
+    "esr_gather_rows": (c_int, [c_vp, c_int, c_i64, c_int, c_i32p, c_i64, c_vp, c_vp]),
+    "esr_unpermute_rows": (c_int, [c_vp, c_int, c_int, c_i32p, c_i64, c_vp, c_vp]),
+    "esr_glove_forward": (c_int, [c_f32p, c_f32p, c_i64, c_int, c_i32p, c_i64, c_f32p, c_f32p, c_vp]),
+    "esr_glove_workspace_bytes": (c_size, [c_i64]),
+    "esr_glove_fwd_bwd": (c_int, [c_f32p, c_f32p, c_i64, c_int, c_i32p, c_f32p, c_i64, c_int, c_f32p, c_f32p,
+                                  c_f32p, c_vp, c_size, c_vp]),
+    "esr_triplet_workspace_bytes": (c_size, [c_i64]),
+    "esr_triplet_fwd_bwd": (c_int, [c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_int, c_i32p, c_i32p, c_i32p, c_i64, c_f32, c_f32,
+                                    c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_vp, c_size, c_vp]),
+    "esr_inbatch_workspace_bytes": (c_size, [c_i64, c_int]),
+    "esr_inbatch_softmax_fwd_bwd": (c_int, [c_f32p, c_f32p, c_i64, c_int, c_f32, c_f32, c_f32, c_f32p, c_f32p, c_f32p,
+                                            c_f32p, c_vp, c_size, c_vp]),
+    "esr_segment_sort_workspace_bytes": (c_size, [c_i64]),
+    "esr_segment_sort_ids": (c_int, [c_i32p, c_i64, c_i64, c_i32p, c_i32p, c_vp, c_size, c_vp]),
+    "esr_sparse_adagrad_scatter": (c_int, [c_vp, c_int, c_f32p, c_i64, c_int, c_i32p, c_i32p, c_i64, c_f32p, c_f32,
+                                           c_f32, c_vp]),
+    "esr_sparse_sgd_scatter": (c_int, [c_vp, c_int, c_i64, c_int, c_i32p, c_i32p, c_i64, c_f32p, c_f32, c_vp]),
+    "esr_rows_to_dense": (c_int, [c_f32p, c_i64, c_int, c_i32p, c_i32p, c_i64, c_f32p, c_vp]),
+    "esr_dense_adam": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_f32, c_f32, c_f32, c_f32, c_i64, c_vp]),
+    "esr_score_all": (c_int, [c_f32p, c_i64, c_int, c_i32p, c_int, c_f32p, c_vp]),
+    "esr_argsort_columns_workspace_bytes": (c_size, [c_i64, c_int]),
+    "esr_argsort_columns": (c_int, [c_f32p, c_i64, c_int, c_i32p, c_vp, c_size, c_vp]),
+    "esr_score_topk_workspace_bytes": (c_size, [c_i64, c_i64, c_int]),
+    "esr_score_topk": (c_int, [c_f32p, c_f32p, c_i64, c_i64, c_int, c_int, c_f32p, c_i32p, c_vp, c_size, c_vp]),
+    "esr_bucket_workspace_bytes": (c_size, [c_i64]),
+    "esr_bucket_ids_by_owner": (c_int, [c_i32p, c_i64, c_int, c_i32p, c_i32p, c_vp, c_vp, c_size, c_vp]),
+}
+
+
+class EsrLibraryError(RuntimeError):
+    """libesr_hip.so is missing / failed to load, or a call returned an ESR_E* code."""
+
+
+_lib = None
+
+
+def load(path=None):
+    """Load libesr_hip.so (once).  torch must be imported first so that the HIP runtime the
+    library binds to (soname libamdhip64.so.7) is the one torch already loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise EsrLibraryError(
+            "%s not found: build it with `python -m esrecsys_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback." % path)
+    try:
+        import torch  # noqa: F401  (loads torch's libamdhip64 first)
+    except ImportError:
+        pass
+    try:
+        lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    except OSError as e:  # pragma: no cover
+        raise EsrLibraryError("failed to load %s: %s" % (path, e))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise EsrLibraryError("%s does not export %s (stale build?)" % (path, name))
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != ESR_OK:
+        msg = load().esr_last_error()
+        raise EsrLibraryError("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else "?"))

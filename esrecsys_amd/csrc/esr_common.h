@@ -1,0 +1,161 @@
+// Shared device/host helpers for libesr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <algorithm>
+
+#include "../../include/esr_hip.h"
+
+namespace esr {
+
+constexpr int kWave = 64;          // gfx950 wavefront
+constexpr int kBlock = 256;        // 4 waves, one per SIMD
+constexpr int kMaxGrid = 256 * 8;  // 256 CUs x 8 resident blocks: grid-stride beyond this
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+// out[0] = (float)(scale * sum(part[0..n))), one block, fixed reduction order (defined in esr_core.hip).
+void finalize_scalar(const double* part, int n, double scale, float* out, hipStream_t st);
+
+inline hipStream_t as_stream(esr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define ESR_REQUIRE(cond, ...)        \
+  do {                                \
+    if (!(cond)) {                    \
+      esr::set_error(__VA_ARGS__);    \
+      return ESR_EINVAL;              \
+    }                                 \
+  } while (0)
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Row-group geometry: a row of `nvec` vector chunks is handled by G lanes (power of two,
+// <= 64); a 256-thread block holds 256/G groups.
+struct RowGeom {
+  int vec;    // elements per chunk (4 = float4, 1 = scalar)
+  int nvec;   // chunks per row
+  int G;      // lanes per row group
+  int nch;    // chunks per lane = ceil(nvec / G); register-resident row kernels support <= 4
+};
+inline RowGeom row_geom(int D) {
+  RowGeom g;
+  g.vec = (D % 4 == 0) ? 4 : 1;
+  g.nvec = D / g.vec;
+  int G = 1;
+  while (G < g.nvec && G < kWave) G <<= 1;
+  g.G = G;
+  g.nch = (g.nvec + G - 1) / G;
+  return g;
+}
+constexpr int kMaxChunksPerLane = 4;  // D <= 1024 (float4 rows) or D <= 256 (scalar rows)
+// Expands BODY with constexpr VEC / NCH matching a RowGeom (nch 3 runs as 4 with bounds checks).
+#define ESR_DISPATCH_ROW(geom, ...)                                           \
+  do {                                                                        \
+    if ((geom).vec == 4) {                                                    \
+      if ((geom).nch <= 1) { constexpr int VEC = 4, NCH = 1; __VA_ARGS__; }   \
+      else if ((geom).nch <= 2) { constexpr int VEC = 4, NCH = 2; __VA_ARGS__; } \
+      else { constexpr int VEC = 4, NCH = 4; __VA_ARGS__; }                   \
+    } else {                                                                  \
+      if ((geom).nch <= 1) { constexpr int VEC = 1, NCH = 1; __VA_ARGS__; }   \
+      else if ((geom).nch <= 2) { constexpr int VEC = 1, NCH = 2; __VA_ARGS__; } \
+      else { constexpr int VEC = 1, NCH = 4; __VA_ARGS__; }                   \
+    }                                                                         \
+  } while (0)
+inline int grid_for_groups(int64_t ngroups_needed, int G) {
+  int groups_per_block = kBlock / G;
+  int64_t blocks = cdiv(ngroups_needed, groups_per_block);
+  if (blocks < 1) blocks = 1;
+  if (blocks > kMaxGrid) blocks = kMaxGrid;
+  return (int)blocks;
+}
+
+#ifdef __HIPCC__
+// Sum across the G (power of two) lanes of a row group via xor shuffles; every lane gets the total.
+__device__ __forceinline__ float group_sum(float v, int G) {
+  for (int off = G >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+// Deterministic block-wide double sum (fixed tree); result valid in thread 0.
+// `smem` must hold >= 4 doubles per quantity (256-thread block = 4 waves).
+__device__ __forceinline__ double block_sum_d(double v, double* smem) {
+  v = wave_sum_d(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) smem[wid] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) t += smem[i];
+  }
+  return t;
+}
+
+// A row held in registers by its G-lane group: chunk k of this lane is row chunk lig + k*G.
+// All indices are compile-time so the arrays stay in VGPRs (no scratch).
+template <int VEC, int NCH>
+struct RowRegs {
+  float v[NCH][VEC];
+};
+template <int VEC, int NCH>
+__device__ __forceinline__ void row_load(RowRegs<VEC, NCH>& r, const float* __restrict__ p, int lig,
+                                         int G, int nvec) {
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int c = lig + k * G;
+    if (c < nvec) {
+      if constexpr (VEC == 4) {
+        const float4 a = *reinterpret_cast<const float4*>(p + 4 * c);
+        r.v[k][0] = a.x; r.v[k][1] = a.y; r.v[k][2] = a.z; r.v[k][3] = a.w;
+      } else {
+        r.v[k][0] = p[c];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) r.v[k][e] = 0.f;
+    }
+  }
+}
+template <int VEC, int NCH>
+__device__ __forceinline__ void row_store(const RowRegs<VEC, NCH>& r, float* __restrict__ p, int lig,
+                                          int G, int nvec) {
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int c = lig + k * G;
+    if (c < nvec) {
+      if constexpr (VEC == 4) {
+        *reinterpret_cast<float4*>(p + 4 * c) = make_float4(r.v[k][0], r.v[k][1], r.v[k][2], r.v[k][3]);
+      } else {
+        p[c] = r.v[k][0];
+      }
+    }
+  }
+}
+template <int VEC, int NCH>
+__device__ __forceinline__ float row_dot_partial(const RowRegs<VEC, NCH>& a, const RowRegs<VEC, NCH>& b) {
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc = fmaf(a.v[k][e], b.v[k][e], acc);
+  return acc;
+}
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// round-to-nearest-even, NaN preserved
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+#endif
+
+}  // namespace esr

@@ -1,0 +1,158 @@
+// Error plumbing, device query and the row gather / un-permute kernels.
+#include "esr_common.h"
+#include <string.h>
+
+namespace esr {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return ESR_ELAUNCH;
+  }
+  return ESR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row gather.  One row = `nchunk` chunks of type T (uint4 = 16 B when the row is a multiple of
+// 16 B).  A group of G lanes owns one row at a time; UNROLL rows are kept in flight per group so
+// a wave has UNROLL independent 1 KiB (G=64) loads outstanding -- the gather is pure HBM latency.
+//   SRC_IDX: src row = ids[r], dst row = r      (gather)
+//   else   : src row = r,      dst row = ids[r] (un-permute / scatter of a permutation)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int UNROLL, bool SRC_IDX>
+__global__ __launch_bounds__(kBlock) void move_rows_kernel(const T* __restrict__ src,
+                                                           const int32_t* __restrict__ ids,
+                                                           int64_t n, int nchunk, int G,
+                                                           T* __restrict__ dst) {
+  const int lane_in_group = threadIdx.x & (G - 1);
+  const int64_t groups_per_block = kBlock / G;
+  const int64_t group = (int64_t)blockIdx.x * groups_per_block + threadIdx.x / G;
+  const int64_t ngroups = (int64_t)gridDim.x * groups_per_block;
+  for (int64_t r0 = group; r0 < n; r0 += ngroups * UNROLL) {
+    // Tail rows re-read row n-1 (loads stay unconditional so hipcc keeps all UNROLL loads in
+    // flight under one counted wait); only the store is predicated.
+    int64_t idx[UNROLL], row[UNROLL];
+    bool ok[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t r = r0 + (int64_t)u * ngroups;
+      ok[u] = r < n;
+      row[u] = ok[u] ? r : n - 1;
+      idx[u] = (int64_t)ids[row[u]];
+    }
+    for (int c = lane_in_group; c < nchunk; c += G) {
+      T v[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) v[u] = src[(SRC_IDX ? idx[u] : row[u]) * nchunk + c];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u)
+        if (ok[u]) dst[(SRC_IDX ? row[u] : idx[u]) * nchunk + c] = v[u];
+    }
+  }
+}
+
+template <bool SRC_IDX>
+static int launch_move_rows(const void* src, int dtype, int D, const int32_t* ids, int64_t n,
+                            void* dst, hipStream_t st) {
+  const int64_t row_bytes = (int64_t)D * (dtype == ESR_BF16 ? 2 : 4);
+  if (n == 0) return ESR_OK;
+  auto geom = [&](int chunk_bytes, int& nchunk, int& G) {
+    nchunk = (int)(row_bytes / chunk_bytes);
+    G = 1;
+    while (G < nchunk && G < kWave) G <<= 1;
+  };
+  int nchunk, G;
+  if (row_bytes % 16 == 0) {
+    geom(16, nchunk, G);
+    const int grid = grid_for_groups(cdiv(n, 4), G);
+    hipLaunchKernelGGL((move_rows_kernel<uint4, 4, SRC_IDX>), dim3(grid), dim3(kBlock), 0, st,
+                       (const uint4*)src, ids, n, nchunk, G, (uint4*)dst);
+  } else if (row_bytes % 4 == 0) {
+    geom(4, nchunk, G);
+    const int grid = grid_for_groups(cdiv(n, 4), G);
+    hipLaunchKernelGGL((move_rows_kernel<uint32_t, 4, SRC_IDX>), dim3(grid), dim3(kBlock), 0, st,
+                       (const uint32_t*)src, ids, n, nchunk, G, (uint32_t*)dst);
+  } else {
+    geom(2, nchunk, G);
+    const int grid = grid_for_groups(cdiv(n, 4), G);
+    hipLaunchKernelGGL((move_rows_kernel<uint16_t, 4, SRC_IDX>), dim3(grid), dim3(kBlock), 0, st,
+                       (const uint16_t*)src, ids, n, nchunk, G, (uint16_t*)dst);
+  }
+  return check_launch(SRC_IDX ? "esr_gather_rows" : "esr_unpermute_rows");
+}
+
+// Single block: fixed-order reduction of block partials; out = total * scale.
+__global__ __launch_bounds__(kBlock) void scalar_finalize_kernel(const double* __restrict__ part, int nparts,
+                                                                double scale, float* __restrict__ out) {
+  __shared__ double sm[4];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += kBlock) a += part[i];
+  const double t = block_sum_d(a, sm);
+  if (threadIdx.x == 0) out[0] = (float)(t * scale);
+}
+
+void finalize_scalar(const double* part, int n, double scale, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(scalar_finalize_kernel, dim3(1), dim3(kBlock), 0, st, part, n, scale, out);
+}
+
+}  // namespace esr
+
+using namespace esr;
+
+extern "C" {
+
+const char* esr_last_error(void) { return g_err; }
+
+int esr_version(void) { return 100; }
+
+int esr_device_info(int* cu_count, int* wave_size, size_t* hbm_bytes, char* arch, int arch_len) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    set_error("esr_device_info: no HIP device");
+    return ESR_ENODEVICE;
+  }
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, dev) != hipSuccess) {
+    set_error("esr_device_info: hipGetDeviceProperties failed");
+    return ESR_ENODEVICE;
+  }
+  if (cu_count) *cu_count = p.multiProcessorCount;
+  if (wave_size) *wave_size = p.warpSize;
+  if (hbm_bytes) *hbm_bytes = p.totalGlobalMem;
+  if (arch && arch_len > 0) {
+    strncpy(arch, p.gcnArchName, arch_len - 1);
+    arch[arch_len - 1] = 0;
+  }
+  return ESR_OK;
+}
+
+int esr_gather_rows(const void* table, int dtype, int64_t V, int D, const int32_t* ids, int64_t n,
+                    void* out, esr_stream_t stream) {
+  ESR_REQUIRE(n >= 0 && V >= 0 && D > 0, "esr_gather_rows: bad sizes V=%lld D=%d n=%lld",
+              (long long)V, D, (long long)n);
+  ESR_REQUIRE(dtype == ESR_F32 || dtype == ESR_BF16, "esr_gather_rows: bad dtype %d", dtype);
+  if (n == 0) return ESR_OK;
+  ESR_REQUIRE(table && ids && out, "esr_gather_rows: null pointer");
+  return launch_move_rows<true>(table, dtype, D, ids, n, out, as_stream(stream));
+}
+
+int esr_unpermute_rows(const void* rows, int dtype, int D, const int32_t* perm, int64_t n,
+                       void* out, esr_stream_t stream) {
+  ESR_REQUIRE(n >= 0 && D > 0, "esr_unpermute_rows: bad sizes D=%d n=%lld", D, (long long)n);
+  ESR_REQUIRE(dtype == ESR_F32 || dtype == ESR_BF16, "esr_unpermute_rows: bad dtype %d", dtype);
+  if (n == 0) return ESR_OK;
+  ESR_REQUIRE(rows && perm && out, "esr_unpermute_rows: null pointer");
+  return launch_move_rows<false>(rows, dtype, D, perm, n, out, as_stream(stream));
+}
+
+}  // extern "C"

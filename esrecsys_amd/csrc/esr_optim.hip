@@ -1,0 +1,237 @@
+// Optimizer kernels.
+//
+// Production path (north_star): deterministic row-sparse update.  Occurrence ids have been
+// stably sorted (esr_segment_sort_ids), so the occurrences of one row are a contiguous run of
+// `sorted_ids`.  One row group (G lanes) is launched per sorted position; the group at the head
+// of a run sums the run's gradient rows left to right (== occurrence order, so the result equals
+// a sequential scatter-add bit for bit), then does the read-modify-write of the parameter and
+// accumulator rows exactly once.  No float atomics, no V x D gradient, no host sync.
+// HBM traffic per distinct row: D*4 (grad) + 2*D*s (param RMW) + 2*D*4 (accumulator RMW).
+//
+// Reference-faithful path: esr_rows_to_dense rebuilds the dense V x D gradient that JAX's autodiff
+// produces for nn.Embed (wikipedia/train_cooccurence.py:86-87) and esr_dense_adam applies
+// optax.adam to every element (train_cooccurence.py:99-101,171) [upstream optax 0.1.2].
+#include "esr_common.h"
+
+namespace esr {
+
+enum SegOp { kAdagrad = 0, kSgd = 1, kToDense = 2 };
+
+template <int VEC, int NCH>
+__device__ __forceinline__ void param_load(RowRegs<VEC, NCH>& r, const void* table, int dtype, int64_t row, int D,
+                                           int lig, int G, int nvec) {
+  if (dtype == ESR_F32) {
+    row_load(r, (const float*)table + row * D, lig, G, nvec);
+  } else {
+    const uint16_t* p = (const uint16_t*)table + row * D;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int c = lig + k * G;
+      if (c < nvec) {
+        if constexpr (VEC == 4) {
+          const uint2 u = *reinterpret_cast<const uint2*>(p + 4 * c);
+          r.v[k][0] = __uint_as_float(u.x << 16);
+          r.v[k][1] = __uint_as_float(u.x & 0xffff0000u);
+          r.v[k][2] = __uint_as_float(u.y << 16);
+          r.v[k][3] = __uint_as_float(u.y & 0xffff0000u);
+        } else {
+          r.v[k][0] = bf16_to_f32(p[c]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) r.v[k][e] = 0.f;
+      }
+    }
+  }
+}
+
+template <int VEC, int NCH>
+__device__ __forceinline__ void param_store(const RowRegs<VEC, NCH>& r, void* table, int dtype, int64_t row, int D,
+                                            int lig, int G, int nvec) {
+  if (dtype == ESR_F32) {
+    row_store(r, (float*)table + row * D, lig, G, nvec);
+  } else {
+    uint16_t* p = (uint16_t*)table + row * D;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int c = lig + k * G;
+      if (c < nvec) {
+        if constexpr (VEC == 4) {
+          uint2 u;
+          u.x = (uint32_t)f32_to_bf16(r.v[k][0]) | ((uint32_t)f32_to_bf16(r.v[k][1]) << 16);
+          u.y = (uint32_t)f32_to_bf16(r.v[k][2]) | ((uint32_t)f32_to_bf16(r.v[k][3]) << 16);
+          *reinterpret_cast<uint2*>(p + 4 * c) = u;
+        } else {
+          p[c] = f32_to_bf16(r.v[k][0]);
+        }
+      }
+    }
+  }
+}
+
+template <int VEC, int NCH, int OP>
+__global__ __launch_bounds__(kBlock) void segment_update_kernel(void* __restrict__ table, int dtype,
+                                                               float* __restrict__ accum, int D, int G,
+                                                               const int32_t* __restrict__ sorted_ids,
+                                                               const int32_t* __restrict__ perm, int64_t n,
+                                                               const float* __restrict__ grad_rows, float lr,
+                                                               float eps) {
+  const int lig = threadIdx.x & (G - 1);
+  const int64_t gpb = kBlock / G;
+  const int64_t group = (int64_t)blockIdx.x * gpb + threadIdx.x / G;
+  const int64_t ngroups = (int64_t)gridDim.x * gpb;
+  const int nvec = D / VEC;
+  for (int64_t p = group; p < n; p += ngroups) {
+    const int32_t id = sorted_ids[p];
+    if (p > 0 && sorted_ids[p - 1] == id) continue;  // not the head of its run
+    RowRegs<VEC, NCH> g;
+    row_load(g, grad_rows + (int64_t)perm[p] * D, lig, G, nvec);
+    for (int64_t q = p + 1; q < n && sorted_ids[q] == id; ++q) {
+      RowRegs<VEC, NCH> t;
+      row_load(t, grad_rows + (int64_t)perm[q] * D, lig, G, nvec);
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) g.v[k][e] += t.v[k][e];
+    }
+    if (OP == kToDense) {
+      row_store(g, (float*)table + (int64_t)id * D, lig, G, nvec);
+    } else if (OP == kSgd) {
+      RowRegs<VEC, NCH> w;
+      param_load(w, table, dtype, id, D, lig, G, nvec);
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) w.v[k][e] -= lr * g.v[k][e];
+      param_store(w, table, dtype, id, D, lig, G, nvec);
+    } else {
+      // optax.adagrad [upstream]: acc += g^2 ; p -= lr * g * rsqrt(acc + eps)  (0 where acc == 0)
+      RowRegs<VEC, NCH> w, a;
+      param_load(w, table, dtype, id, D, lig, G, nvec);
+      row_load(a, accum + (int64_t)id * D, lig, G, nvec);
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float gv = g.v[k][e];
+          const float acc = fmaf(gv, gv, a.v[k][e]);
+          a.v[k][e] = acc;
+          const float inv = acc > 0.f ? 1.0f / sqrtf(acc + eps) : 0.f;
+          w.v[k][e] -= lr * gv * inv;
+        }
+      row_store(a, accum + (int64_t)id * D, lig, G, nvec);
+      param_store(w, table, dtype, id, D, lig, G, nvec);
+    }
+  }
+}
+
+template <int OP>
+static int launch_segment_update(const char* who, void* table, int dtype, float* accum, int D,
+                                 const int32_t* sorted_ids, const int32_t* perm, int64_t n, const float* grad_rows,
+                                 float lr, float eps, hipStream_t st) {
+  const RowGeom g = row_geom(D);
+  if (g.nch > kMaxChunksPerLane) {
+    set_error("%s: D=%d not supported", who, D);
+    return ESR_EINVAL;
+  }
+  const int grid = grid_for_groups(n, g.G);
+  ESR_DISPATCH_ROW(g, hipLaunchKernelGGL((segment_update_kernel<VEC, NCH, OP>), dim3(grid), dim3(kBlock), 0, st, table,
+                                         dtype, accum, D, g.G, sorted_ids, perm, n, grad_rows, lr, eps));
+  return check_launch(who);
+}
+
+// optax.adam, elementwise over the whole table.
+__global__ __launch_bounds__(kBlock) void dense_adam_kernel(float* __restrict__ p, float* __restrict__ mu,
+                                                           float* __restrict__ nu, const float* __restrict__ g,
+                                                           int64_t n4, int64_t numel, float lr, float b1, float b2,
+                                                           float eps, float inv_bc1, float inv_bc2) {
+  const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+  auto upd = [&](float& pv, float& m, float& v, float gv) {
+    m = b1 * m + omb1 * gv;
+    v = b2 * v + omb2 * gv * gv;
+    pv -= lr * (m * inv_bc1) / (sqrtf(v * inv_bc2) + eps);
+  };
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
+    float4 pv = reinterpret_cast<float4*>(p)[i];
+    float4 m = reinterpret_cast<float4*>(mu)[i];
+    float4 v = reinterpret_cast<float4*>(nu)[i];
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    upd(pv.x, m.x, v.x, gv.x);
+    upd(pv.y, m.y, v.y, gv.y);
+    upd(pv.z, m.z, v.z, gv.z);
+    upd(pv.w, m.w, v.w, gv.w);
+    reinterpret_cast<float4*>(p)[i] = pv;
+    reinterpret_cast<float4*>(mu)[i] = m;
+    reinterpret_cast<float4*>(nu)[i] = v;
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < numel; i += stride) {
+    float pv = p[i], m = mu[i], v = nu[i];
+    upd(pv, m, v, g[i]);
+    p[i] = pv;
+    mu[i] = m;
+    nu[i] = v;
+  }
+}
+
+}  // namespace esr
+
+using namespace esr;
+
+extern "C" {
+
+int esr_sparse_adagrad_scatter(void* table, int dtype, float* accum, int64_t V, int D, const int32_t* sorted_ids,
+                               const int32_t* perm, int64_t n, const float* grad_rows, float lr, float eps,
+                               esr_stream_t stream) {
+  ESR_REQUIRE(V > 0 && D > 0 && n >= 0, "esr_sparse_adagrad_scatter: bad sizes V=%lld D=%d n=%lld", (long long)V, D,
+              (long long)n);
+  ESR_REQUIRE(dtype == ESR_F32 || dtype == ESR_BF16, "esr_sparse_adagrad_scatter: bad dtype %d", dtype);
+  if (n == 0) return ESR_OK;
+  ESR_REQUIRE(table && accum && sorted_ids && perm && grad_rows, "esr_sparse_adagrad_scatter: null pointer");
+  return launch_segment_update<kAdagrad>("esr_sparse_adagrad_scatter", table, dtype, accum, D, sorted_ids, perm, n,
+                                         grad_rows, lr, eps, as_stream(stream));
+}
+
+int esr_sparse_sgd_scatter(void* table, int dtype, int64_t V, int D, const int32_t* sorted_ids, const int32_t* perm,
+                           int64_t n, const float* grad_rows, float lr, esr_stream_t stream) {
+  ESR_REQUIRE(V > 0 && D > 0 && n >= 0, "esr_sparse_sgd_scatter: bad sizes V=%lld D=%d n=%lld", (long long)V, D,
+              (long long)n);
+  ESR_REQUIRE(dtype == ESR_F32 || dtype == ESR_BF16, "esr_sparse_sgd_scatter: bad dtype %d", dtype);
+  if (n == 0) return ESR_OK;
+  ESR_REQUIRE(table && sorted_ids && perm && grad_rows, "esr_sparse_sgd_scatter: null pointer");
+  return launch_segment_update<kSgd>("esr_sparse_sgd_scatter", table, dtype, nullptr, D, sorted_ids, perm, n,
+                                     grad_rows, lr, 0.f, as_stream(stream));
+}
+
+int esr_rows_to_dense(float* dense, int64_t V, int D, const int32_t* sorted_ids, const int32_t* perm, int64_t n,
+                      const float* grad_rows, esr_stream_t stream) {
+  ESR_REQUIRE(V > 0 && D > 0 && n >= 0, "esr_rows_to_dense: bad sizes V=%lld D=%d n=%lld", (long long)V, D,
+              (long long)n);
+  ESR_REQUIRE(dense, "esr_rows_to_dense: null pointer");
+  hipStream_t st = as_stream(stream);
+  if (hipMemsetAsync(dense, 0, sizeof(float) * (size_t)V * D, st) != hipSuccess)
+    return check_launch("esr_rows_to_dense memset");
+  if (n == 0) return ESR_OK;
+  ESR_REQUIRE(sorted_ids && perm && grad_rows, "esr_rows_to_dense: null pointer");
+  return launch_segment_update<kToDense>("esr_rows_to_dense", dense, ESR_F32, nullptr, D, sorted_ids, perm, n,
+                                         grad_rows, 0.f, 0.f, st);
+}
+
+int esr_dense_adam(float* param, float* mu, float* nu, const float* grad, int64_t numel, float lr, float b1,
+                   float b2, float eps, int64_t step, esr_stream_t stream) {
+  ESR_REQUIRE(numel >= 0 && step >= 1, "esr_dense_adam: bad numel=%lld step=%lld", (long long)numel, (long long)step);
+  if (numel == 0) return ESR_OK;
+  ESR_REQUIRE(param && mu && nu && grad, "esr_dense_adam: null pointer");
+  ESR_REQUIRE((((uintptr_t)param | (uintptr_t)mu | (uintptr_t)nu | (uintptr_t)grad) & 15) == 0,
+              "esr_dense_adam: pointers must be 16-byte aligned");
+  // bias corrections in fp64 on the host, applied as fp32 reciprocals
+  const double bc1 = 1.0 - pow((double)b1, (double)step);
+  const double bc2 = 1.0 - pow((double)b2, (double)step);
+  const int64_t n4 = numel / 4;
+  const int grid = (int)std::min<int64_t>(kMaxGrid, std::max<int64_t>(1, cdiv(n4, kBlock)));
+  hipLaunchKernelGGL(dense_adam_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), param, mu, nu, grad, n4,
+                     numel, lr, b1, b2, eps, (float)(1.0 / bc1), (float)(1.0 / bc2));
+  return check_launch("esr_dense_adam");
+}
+
+}  // extern "C"

@@ -1,0 +1,324 @@
+// Everything that needs a device-wide stable radix sort (rocPRIM, header-only, ships with ROCm):
+//   esr_segment_sort_ids      occurrence ids -> (sorted ids, permutation) for the sparse optimizers
+//   esr_argsort_columns       find_knn's jnp.argsort(scores, axis=0)  (train_cooccurence.py:96)
+//   esr_score_topk            find_top_k's jax.lax.top_k              (make_recommendations.py:64)
+//   esr_bucket_ids_by_owner   row-shard routing (owner = id mod world)
+// The sort itself is a library primitive; the kernels around it are hand-written.
+#include "esr_common.h"
+
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+
+namespace esr {
+
+static inline int bits_for(int64_t n_values) {  // bits needed to represent values in [0, n_values)
+  int b = 1;
+  while (b < 32 && ((int64_t)1 << b) < n_values) ++b;
+  return b;
+}
+
+// rocPRIM temp-storage size for an n-element (32-bit key, 32-bit value) pair sort.  The query
+// needs a device; without one (CPU-only build check) fall back to a generous closed-form bound.
+template <bool DESC, typename Key>
+static size_t pair_sort_temp_bytes(int64_t n) {
+  size_t bytes = 0;
+  hipError_t e;
+  Key* kn = nullptr;
+  int32_t* vn = nullptr;
+  if (DESC)
+    e = rocprim::radix_sort_pairs_desc(nullptr, bytes, kn, kn, rocprim::counting_iterator<int32_t>(0), vn,
+                                       (size_t)n, 0, 8 * sizeof(Key), (hipStream_t)0, false);
+  else
+    e = rocprim::radix_sort_pairs(nullptr, bytes, kn, kn, rocprim::counting_iterator<int32_t>(0), vn, (size_t)n,
+                                  0, 8 * sizeof(Key), (hipStream_t)0, false);
+  if (e != hipSuccess || bytes == 0) {
+    (void)hipGetLastError();
+    bytes = (size_t)n * 16 + (1u << 20);
+  }
+  return align_up(bytes + 256, 256);
+}
+
+__global__ __launch_bounds__(kBlock) void owner_keys_kernel(const int32_t* __restrict__ ids, int64_t n, int world,
+                                                           uint32_t* __restrict__ keys,
+                                                           unsigned long long* __restrict__ counts) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const uint32_t o = (uint32_t)ids[i] % (uint32_t)world;
+    keys[i] = o;
+    atomicAdd(&counts[o], 1ull);  // integer atomics: order-independent result
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void local_rows_kernel(const int32_t* __restrict__ ids,
+                                                           const int32_t* __restrict__ perm, int64_t n, int world,
+                                                           int32_t* __restrict__ local_rows) {
+  for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < n; k += (int64_t)gridDim.x * kBlock)
+    local_rows[k] = (int32_t)((uint32_t)ids[perm[k]] / (uint32_t)world);
+}
+
+// keysT[t][v] = scores[v][t]
+__global__ __launch_bounds__(kBlock) void transpose_cols_kernel(const float* __restrict__ scores, int64_t V, int T,
+                                                               float* __restrict__ keysT) {
+  const int64_t total = V * T;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t v = i / T;
+    const int t = (int)(i - v * T);
+    keysT[(int64_t)t * V + v] = scores[i];
+  }
+}
+// indices[v][t] = idxT[t][v]
+__global__ __launch_bounds__(kBlock) void untranspose_idx_kernel(const int32_t* __restrict__ idxT, int64_t V, int T,
+                                                                int32_t* __restrict__ indices) {
+  const int64_t total = V * T;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t v = i / T;
+    const int t = (int)(i - v * T);
+    indices[i] = idxT[(int64_t)t * V + v];
+  }
+}
+
+// scores[q][n] = queries[q] . candidates[n]; one row group per candidate row, queries staged in LDS.
+// q_ids != NULL: query q is row q_ids[q] of `queries` (Glove.score_all gathers its probes from the table).
+template <int VEC, int NCH>
+__global__ __launch_bounds__(kBlock) void score_rows_kernel(const float* __restrict__ queries,
+                                                           const int32_t* __restrict__ q_ids, int nq,
+                                                           const float* __restrict__ cand, int64_t N, int D, int G,
+                                                           float* __restrict__ out, int64_t out_q_stride,
+                                                           int64_t out_n_stride) {
+  extern __shared__ __attribute__((aligned(16))) float qs[];  // [nq][D]
+  for (int i = threadIdx.x; i < nq * D; i += kBlock) {
+    const int q = i / D;
+    const int64_t row = q_ids ? (int64_t)q_ids[q] : (int64_t)q;
+    qs[i] = queries[row * D + (i - q * D)];
+  }
+  __syncthreads();
+  const int lig = threadIdx.x & (G - 1);
+  const int64_t gpb = kBlock / G;
+  const int64_t group = (int64_t)blockIdx.x * gpb + threadIdx.x / G;
+  const int64_t ngroups = (int64_t)gridDim.x * gpb;
+  const int nvec = D / VEC;
+  for (int64_t r = group; r < N; r += ngroups) {
+    RowRegs<VEC, NCH> c;
+    row_load(c, cand + r * D, lig, G, nvec);
+    for (int q = 0; q < nq; ++q) {
+      RowRegs<VEC, NCH> qq;
+      row_load(qq, qs + (int64_t)q * D, lig, G, nvec);
+      const float d = group_sum(row_dot_partial(c, qq), G);
+      if (lig == 0) out[(int64_t)q * out_q_stride + r * out_n_stride] = d;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void take_k_kernel(const float* __restrict__ keys, const int32_t* __restrict__ idx,
+                                                       int k, float* __restrict__ out_s, int32_t* __restrict__ out_i) {
+  for (int i = threadIdx.x; i < k; i += kBlock) {
+    out_s[i] = keys[i];
+    out_i[i] = idx[i];
+  }
+}
+
+// Queries are staged in <= 48 KB of LDS per launch; more queries = more passes over the candidates.
+static int launch_score_rows(const float* queries, const int32_t* q_ids, int nq, const float* cand, int64_t N,
+                             int D, float* out, int64_t out_q_stride, int64_t out_n_stride, hipStream_t st) {
+  const RowGeom g = row_geom(D);
+  const int grid = grid_for_groups(N, g.G);
+  const int qmax = std::max(1, 12288 / D);
+  for (int q0 = 0; q0 < nq; q0 += qmax) {
+    const int nqc = std::min(qmax, nq - q0);
+    const size_t lds = (size_t)nqc * D * sizeof(float);
+    const float* qbase = q_ids ? queries : queries + (int64_t)q0 * D;
+    const int32_t* qi = q_ids ? q_ids + q0 : nullptr;
+    ESR_DISPATCH_ROW(g, hipLaunchKernelGGL((score_rows_kernel<VEC, NCH>), dim3(grid), dim3(kBlock), lds, st, qbase,
+                                           qi, nqc, cand, N, D, g.G, out + (int64_t)q0 * out_q_stride,
+                                           out_q_stride, out_n_stride));
+  }
+  return check_launch("score_rows");
+}
+
+}  // namespace esr
+
+using namespace esr;
+
+extern "C" {
+
+// ------------------------------------------------------------------------------------------------
+size_t esr_segment_sort_workspace_bytes(int64_t n) {
+  if (n <= 0) return 256;
+  return pair_sort_temp_bytes<false, uint32_t>(n);
+}
+
+int esr_segment_sort_ids(const int32_t* ids, int64_t n, int64_t V, int32_t* sorted_ids, int32_t* perm,
+                         void* workspace, size_t workspace_bytes, esr_stream_t stream) {
+  ESR_REQUIRE(n >= 0 && V > 0 && n < ((int64_t)1 << 31), "esr_segment_sort_ids: bad sizes n=%lld V=%lld",
+              (long long)n, (long long)V);
+  if (n == 0) return ESR_OK;
+  ESR_REQUIRE(ids && sorted_ids && perm && workspace, "esr_segment_sort_ids: null pointer");
+  size_t need = 0;
+  const int end_bit = bits_for(V);
+  const uint32_t* kin = reinterpret_cast<const uint32_t*>(ids);
+  uint32_t* kout = reinterpret_cast<uint32_t*>(sorted_ids);
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, need, kin, kout, rocprim::counting_iterator<int32_t>(0), perm,
+                                           (size_t)n, 0, end_bit, as_stream(stream), false);
+  if (e != hipSuccess) {
+    set_error("esr_segment_sort_ids: rocprim size query: %s", hipGetErrorString(e));
+    return ESR_ELAUNCH;
+  }
+  if (need > workspace_bytes || ((uintptr_t)workspace & 15)) {
+    set_error("esr_segment_sort_ids: workspace %zu bytes < %zu required (or misaligned)", workspace_bytes, need);
+    return ESR_EWORKSPACE;
+  }
+  e = rocprim::radix_sort_pairs(workspace, need, kin, kout, rocprim::counting_iterator<int32_t>(0), perm, (size_t)n,
+                                0, end_bit, as_stream(stream), false);
+  if (e != hipSuccess) {
+    set_error("esr_segment_sort_ids: rocprim sort: %s", hipGetErrorString(e));
+    return ESR_ELAUNCH;
+  }
+  return check_launch("esr_segment_sort_ids");
+}
+
+// ------------------------------------------------------------------------------------------------
+int esr_score_all(const float* emb, int64_t V, int D, const int32_t* token, int T, float* scores,
+                  esr_stream_t stream) {
+  ESR_REQUIRE(V > 0 && D > 0 && T > 0, "esr_score_all: bad sizes V=%lld D=%d T=%d", (long long)V, D, T);
+  ESR_REQUIRE(emb && token && scores, "esr_score_all: null pointer");
+  const RowGeom g = row_geom(D);
+  ESR_REQUIRE(g.nch <= kMaxChunksPerLane, "esr_score_all: D=%d not supported", D);
+  // scores is [V, T] row-major: query stride 1, candidate-row stride T.
+  return launch_score_rows(emb, token, T, emb, V, D, scores, 1, T, as_stream(stream));
+}
+
+static size_t argsort_layout(int64_t V, int T, size_t* keysT, size_t* idxT, size_t* ksorted) {
+  size_t off = 0;
+  *keysT = off;   off += align_up((size_t)V * T * 4, 256);
+  *idxT = off;    off += align_up((size_t)V * T * 4, 256);
+  *ksorted = off; off += align_up((size_t)V * 4, 256);
+  return off;
+}
+
+size_t esr_argsort_columns_workspace_bytes(int64_t V, int T) {
+  if (V <= 0 || T <= 0) return 256;
+  size_t a, b, c;
+  return argsort_layout(V, T, &a, &b, &c) + pair_sort_temp_bytes<false, float>(V);
+}
+
+int esr_argsort_columns(const float* scores, int64_t V, int T, int32_t* indices, void* workspace,
+                        size_t workspace_bytes, esr_stream_t stream) {
+  ESR_REQUIRE(V > 0 && T > 0 && V < ((int64_t)1 << 31), "esr_argsort_columns: bad sizes V=%lld T=%d", (long long)V, T);
+  ESR_REQUIRE(scores && indices && workspace, "esr_argsort_columns: null pointer");
+  if (workspace_bytes < esr_argsort_columns_workspace_bytes(V, T) || ((uintptr_t)workspace & 15)) {
+    set_error("esr_argsort_columns: workspace %zu bytes < %zu required (or misaligned)", workspace_bytes,
+              esr_argsort_columns_workspace_bytes(V, T));
+    return ESR_EWORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  size_t o_keys, o_idx, o_sorted;
+  const size_t fixed = argsort_layout(V, T, &o_keys, &o_idx, &o_sorted);
+  char* base = (char*)workspace;
+  float* keysT = (float*)(base + o_keys);       // [T][V]
+  int32_t* idxT = (int32_t*)(base + o_idx);     // [T][V]
+  float* keys_sorted = (float*)(base + o_sorted);
+  void* temp = base + fixed;
+  const size_t temp_bytes = workspace_bytes - fixed;
+  const int grid = (int)std::min<int64_t>(kMaxGrid, cdiv(V * T, kBlock));
+  hipLaunchKernelGGL(transpose_cols_kernel, dim3(grid), dim3(kBlock), 0, st, scores, V, T, keysT);
+  for (int t = 0; t < T; ++t) {
+    size_t need = temp_bytes;
+    hipError_t e = rocprim::radix_sort_pairs(temp, need, keysT + (int64_t)t * V, keys_sorted,
+                                             rocprim::counting_iterator<int32_t>(0), idxT + (int64_t)t * V,
+                                             (size_t)V, 0, 32, st, false);
+    if (e != hipSuccess) {
+      set_error("esr_argsort_columns: rocprim sort: %s", hipGetErrorString(e));
+      return ESR_ELAUNCH;
+    }
+  }
+  hipLaunchKernelGGL(untranspose_idx_kernel, dim3(grid), dim3(kBlock), 0, st, (const int32_t*)idxT, V, T, indices);
+  return check_launch("esr_argsort_columns");
+}
+
+// ------------------------------------------------------------------------------------------------
+size_t esr_score_topk_workspace_bytes(int64_t nq, int64_t N, int k) {
+  (void)k;
+  if (nq <= 0 || N <= 0) return 256;
+  const size_t row = align_up((size_t)N * 4, 256);
+  return row * (size_t)nq + 2 * row + pair_sort_temp_bytes<true, float>(N);
+}
+
+int esr_score_topk(const float* queries, const float* candidates, int64_t nq, int64_t N, int D, int k,
+                   float* out_scores, int32_t* out_indices, void* workspace, size_t workspace_bytes,
+                   esr_stream_t stream) {
+  ESR_REQUIRE(nq > 0 && N > 0 && D > 0 && k > 0 && k <= N && N < ((int64_t)1 << 31),
+              "esr_score_topk: bad sizes nq=%lld N=%lld D=%d k=%d", (long long)nq, (long long)N, D, k);
+  ESR_REQUIRE(queries && candidates && out_scores && out_indices && workspace, "esr_score_topk: null pointer");
+  const RowGeom g = row_geom(D);
+  ESR_REQUIRE(g.nch <= kMaxChunksPerLane, "esr_score_topk: D=%d not supported", D);
+  if (workspace_bytes < esr_score_topk_workspace_bytes(nq, N, k) || ((uintptr_t)workspace & 15)) {
+    set_error("esr_score_topk: workspace %zu bytes < %zu required (or misaligned)", workspace_bytes,
+              esr_score_topk_workspace_bytes(nq, N, k));
+    return ESR_EWORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  const size_t row = align_up((size_t)N * 4, 256);
+  char* base = (char*)workspace;
+  float* scores = (float*)base;  // [nq][row/4]
+  float* keys_sorted = (float*)(base + row * nq);
+  int32_t* idx_sorted = (int32_t*)(base + row * nq + row);
+  void* temp = base + row * nq + 2 * row;
+  size_t temp_bytes = workspace_bytes - (row * nq + 2 * row);
+  if (int rc = launch_score_rows(queries, nullptr, (int)nq, candidates, N, D, scores, (int64_t)(row / 4), 1, st))
+    return rc;
+  for (int64_t q = 0; q < nq; ++q) {
+    size_t need = temp_bytes;
+    hipError_t e = rocprim::radix_sort_pairs_desc(temp, need, (float*)((char*)scores + row * q), keys_sorted,
+                                                  rocprim::counting_iterator<int32_t>(0), idx_sorted, (size_t)N, 0,
+                                                  32, st, false);
+    if (e != hipSuccess) {
+      set_error("esr_score_topk: rocprim sort: %s", hipGetErrorString(e));
+      return ESR_ELAUNCH;
+    }
+    hipLaunchKernelGGL(take_k_kernel, dim3(1), dim3(kBlock), 0, st, (const float*)keys_sorted,
+                       (const int32_t*)idx_sorted, k, out_scores + q * k, out_indices + q * k);
+  }
+  return check_launch("esr_score_topk");
+}
+
+// ------------------------------------------------------------------------------------------------
+size_t esr_bucket_workspace_bytes(int64_t n) {
+  if (n <= 0) return 256;
+  return align_up((size_t)n * 4, 256) * 2 + pair_sort_temp_bytes<false, uint32_t>(n);
+}
+
+int esr_bucket_ids_by_owner(const int32_t* ids, int64_t n, int world, int32_t* local_rows, int32_t* perm,
+                            int64_t* counts, void* workspace, size_t workspace_bytes, esr_stream_t stream) {
+  ESR_REQUIRE(n >= 0 && world > 0 && n < ((int64_t)1 << 31), "esr_bucket_ids_by_owner: bad sizes n=%lld world=%d",
+              (long long)n, world);
+  ESR_REQUIRE(counts, "esr_bucket_ids_by_owner: null counts");
+  hipStream_t st = as_stream(stream);
+  if (hipMemsetAsync(counts, 0, sizeof(int64_t) * world, st) != hipSuccess) return check_launch("esr_bucket memset");
+  if (n == 0) return ESR_OK;
+  ESR_REQUIRE(ids && local_rows && perm && workspace, "esr_bucket_ids_by_owner: null pointer");
+  if (workspace_bytes < esr_bucket_workspace_bytes(n) || ((uintptr_t)workspace & 15)) {
+    set_error("esr_bucket_ids_by_owner: workspace %zu bytes < %zu required (or misaligned)", workspace_bytes,
+              esr_bucket_workspace_bytes(n));
+    return ESR_EWORKSPACE;
+  }
+  const size_t col = align_up((size_t)n * 4, 256);
+  char* base = (char*)workspace;
+  uint32_t* keys = (uint32_t*)base;
+  uint32_t* keys_sorted = (uint32_t*)(base + col);
+  void* temp = base + 2 * col;
+  size_t temp_bytes = workspace_bytes - 2 * col;
+  const int grid = (int)std::min<int64_t>(kMaxGrid, cdiv(n, kBlock));
+  hipLaunchKernelGGL(owner_keys_kernel, dim3(grid), dim3(kBlock), 0, st, ids, n, world, keys,
+                     reinterpret_cast<unsigned long long*>(counts));
+  hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_sorted, rocprim::counting_iterator<int32_t>(0),
+                                           perm, (size_t)n, 0, bits_for(world), st, false);
+  if (e != hipSuccess) {
+    set_error("esr_bucket_ids_by_owner: rocprim sort: %s", hipGetErrorString(e));
+    return ESR_ELAUNCH;
+  }
+  hipLaunchKernelGGL(local_rows_kernel, dim3(grid), dim3(kBlock), 0, st, ids, (const int32_t*)perm, n, world,
+                     local_rows);
+  return check_launch("esr_bucket_ids_by_owner");
+}
+
+}  // extern "C"

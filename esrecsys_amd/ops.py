@@ -1,0 +1,301 @@
+"""Tensor-level wrappers over the C ABI (include/esr_hip.h).
+
+PyTorch is used for device memory and the current HIP stream only; every computation is a
+libesr_hip.so call.  All functions require CUDA(ROCm) tensors and raise if the library is missing.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ESR_BF16, ESR_F32, GLOVE_DIAGONAL, GLOVE_REFERENCE, check  # noqa: F401
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _req(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError("%s must be a CUDA/ROCm tensor (no CPU fallback exists)" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return t
+
+
+def _table_dtype(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError("%s must be a CUDA/ROCm tensor (no CPU fallback exists)" % name)
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    if t.dtype == torch.float32:
+        return ESR_F32
+    if t.dtype == torch.bfloat16:
+        return ESR_BF16
+    raise TypeError("%s must be float32 or bfloat16, got %s" % (name, t.dtype))
+
+
+def as_ids(x, device, check_range=None):
+    """int ids (numpy / list / torch, any int dtype) -> contiguous int32 tensor on `device`.
+
+    Host inputs are range-checked against `check_range` = V (device inputs are trusted: checking
+    them would force a sync on the hot path)."""
+    if isinstance(x, torch.Tensor):
+        if x.is_cuda:
+            return x.to(torch.int32).contiguous()
+        x = x.numpy()
+    a = np.ascontiguousarray(np.asarray(x), dtype=np.int32)
+    if check_range is not None and a.size and (a.min() < 0 or a.max() >= check_range):
+        raise IndexError("id out of range [0, %d): min %d max %d" % (check_range, a.min(), a.max()))
+    return torch.from_numpy(a).to(device, non_blocking=True)
+
+
+def as_f32(x, device):
+    if isinstance(x, torch.Tensor):
+        return x.to(device=device, dtype=torch.float32).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(x), dtype=np.float32)).to(device, non_blocking=True)
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+_ws_size_cache = {}
+
+
+def _ws_bytes(fn_name, *args):
+    key = (fn_name,) + args
+    v = _ws_size_cache.get(key)
+    if v is None:
+        v = int(getattr(_lib.load(), fn_name)(*args))
+        _ws_size_cache[key] = v
+    return v
+
+
+# ---------------------------------------------------------------------------------------------
+def gather_rows(table, ids, out=None):
+    """out[i] = table[ids[i]]  (bit-exact).  table [V, D] f32/bf16; ids int32 [n]."""
+    lib = _lib.load()
+    dt = _table_dtype(table, "table")
+    ids = _req(ids, torch.int32, "ids")
+    V, D = table.shape
+    n = ids.numel()
+    if out is None:
+        out = torch.empty((n, D), dtype=table.dtype, device=table.device)
+    check(lib.esr_gather_rows(_p(table), dt, V, D, _p(ids), n, _p(out), _stream()), "esr_gather_rows")
+    return out
+
+
+def unpermute_rows(rows, perm, out=None):
+    """out[perm[k]] = rows[k]."""
+    lib = _lib.load()
+    dt = _table_dtype(rows, "rows")
+    perm = _req(perm, torch.int32, "perm")
+    n, D = rows.shape
+    if out is None:
+        out = torch.empty_like(rows)
+    check(lib.esr_unpermute_rows(_p(rows), dt, D, _p(perm), n, _p(out), _stream()), "esr_unpermute_rows")
+    return out
+
+
+def glove_forward(emb, bias, inputs):
+    """(dot[B], s[B]) of Glove.__call__; the reference output is dot[None, :] + s[:, None]."""
+    lib = _lib.load()
+    _req(emb, torch.float32, "emb"), _req(bias, torch.float32, "bias"), _req(inputs, torch.int32, "inputs")
+    V, D = emb.shape
+    B = inputs.shape[1]
+    dot = torch.empty(B, dtype=torch.float32, device=emb.device)
+    s = torch.empty(B, dtype=torch.float32, device=emb.device)
+    check(lib.esr_glove_forward(_p(emb), _p(bias), V, D, _p(inputs), B, _p(dot), _p(s), _stream()),
+          "esr_glove_forward")
+    return dot, s
+
+
+def glove_fwd_bwd(emb, bias, inputs, target, mode=GLOVE_REFERENCE, want_grads=True):
+    """Fused GloVe loss + per-occurrence gradients.  Returns (loss[1], grad_rows[2B, D], grad_bias[2B])."""
+    lib = _lib.load()
+    _req(emb, torch.float32, "emb"), _req(bias, torch.float32, "bias")
+    _req(inputs, torch.int32, "inputs"), _req(target, torch.float32, "target")
+    V, D = emb.shape
+    B = inputs.shape[1]
+    if inputs.shape[0] != 2 or target.numel() != B:
+        raise ValueError("inputs must be [2, B] and target [B]")
+    dev = emb.device
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    grad_rows = torch.empty((2 * B, D), dtype=torch.float32, device=dev) if want_grads else None
+    grad_bias = torch.empty(2 * B, dtype=torch.float32, device=dev) if want_grads else None
+    nb = _ws_bytes("esr_glove_workspace_bytes", B)
+    ws = _ws(nb, dev)
+    check(lib.esr_glove_fwd_bwd(_p(emb), _p(bias), V, D, _p(inputs), _p(target), B, mode, _p(loss), _p(grad_rows),
+                                _p(grad_bias), _p(ws), ws.numel(), _stream()), "esr_glove_fwd_bwd")
+    return loss, grad_rows, grad_bias
+
+
+def triplet_fwd_bwd(scene_table, pos_table, neg_table, scene_ids, pos_ids, neg_ids, B, regularization, batch_size,
+                    with_reg=True, want_grads=True, want_scores=True):
+    """Fused STL head.  ids may be None (= row b).  Returns (loss[1], pos_score, neg_score, g_s, g_p, g_n);
+    g_p and g_n are the two halves of one [2B, D] buffer (``g_p._base``)."""
+    lib = _lib.load()
+    for name, t in (("scene_table", scene_table), ("pos_table", pos_table), ("neg_table", neg_table)):
+        _req(t, torch.float32, name)
+    for name, t in (("scene_ids", scene_ids), ("pos_ids", pos_ids), ("neg_ids", neg_ids)):
+        if t is not None:
+            _req(t, torch.int32, name)
+    Vs, D = scene_table.shape
+    Vp, Vn = pos_table.shape[0], neg_table.shape[0]
+    if pos_table.shape[1] != D or neg_table.shape[1] != D:
+        raise ValueError("tower dims differ")
+    dev = scene_table.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    loss = torch.empty(1, **f32)
+    ps = torch.empty(B, **f32) if want_scores else None
+    ns = torch.empty(B, **f32) if want_scores else None
+    gs = torch.empty((B, D), **f32) if want_grads else None
+    # pos and neg gradient rows share one [2B, D] buffer: both scatter into the product table, so the
+    # optimizer consumes them as a single occurrence list without a concatenation copy.
+    gpn = torch.empty((2 * B, D), **f32) if want_grads else None
+    gp = gpn[:B] if want_grads else None
+    gn = gpn[B:] if want_grads else None
+    ws = _ws(_ws_bytes("esr_triplet_workspace_bytes", B), dev)
+    check(lib.esr_triplet_fwd_bwd(_p(scene_table), Vs, _p(pos_table), Vp, _p(neg_table), Vn, D, _p(scene_ids),
+                                  _p(pos_ids), _p(neg_ids), B, float(regularization), float(batch_size),
+                                  int(bool(with_reg)), _p(loss), _p(ps), _p(ns), _p(gs), _p(gp), _p(gn), _p(ws),
+                                  ws.numel(), _stream()), "esr_triplet_fwd_bwd")
+    return loss, ps, ns, gs, gp, gn
+
+
+def inbatch_softmax_fwd_bwd(Q, C, scale, regularization, batch_size):
+    """In-batch-negative softmax on the FP32 MFMA path.  Returns (loss[1], lse[B], gQ, gC)."""
+    lib = _lib.load()
+    _req(Q, torch.float32, "Q"), _req(C, torch.float32, "C")
+    B, D = Q.shape
+    if C.shape != Q.shape:
+        raise ValueError("Q and C must have the same shape")
+    dev = Q.device
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    lse = torch.empty(B, dtype=torch.float32, device=dev)
+    gQ = torch.empty_like(Q)
+    gC = torch.empty_like(C)
+    ws = _ws(_ws_bytes("esr_inbatch_workspace_bytes", B, D), dev)
+    check(lib.esr_inbatch_softmax_fwd_bwd(_p(Q), _p(C), B, D, float(scale), float(regularization), float(batch_size),
+                                          _p(loss), _p(lse), _p(gQ), _p(gC), _p(ws), ws.numel(), _stream()),
+          "esr_inbatch_softmax_fwd_bwd")
+    return loss, lse, gQ, gC
+
+
+# ---------------------------------------------------------------------------------------------
+def segment_sort(ids, V):
+    """Stable sort of occurrence ids.  Returns (sorted_ids, perm) with sorted_ids == ids[perm]."""
+    lib = _lib.load()
+    ids = _req(ids, torch.int32, "ids")
+    n = ids.numel()
+    sorted_ids = torch.empty_like(ids)
+    perm = torch.empty_like(ids)
+    ws = _ws(_ws_bytes("esr_segment_sort_workspace_bytes", n), ids.device)
+    check(lib.esr_segment_sort_ids(_p(ids), n, V, _p(sorted_ids), _p(perm), _p(ws), ws.numel(), _stream()),
+          "esr_segment_sort_ids")
+    return sorted_ids, perm
+
+
+def sparse_adagrad(table, accum, sorted_ids, perm, grad_rows, lr, eps=1e-7):
+    """In-place row-sparse Adagrad on `table` / `accum` for the rows named by sorted_ids."""
+    lib = _lib.load()
+    dt = _table_dtype(table, "table")
+    _req(accum, torch.float32, "accum"), _req(grad_rows, torch.float32, "grad_rows")
+    V = table.shape[0]
+    D = table.shape[1] if table.dim() > 1 else 1
+    n = sorted_ids.numel()
+    if grad_rows.numel() != n * D or accum.numel() != table.numel():
+        raise ValueError("shape mismatch: grad_rows %s, table %s, accum %s, n %d" %
+                         (tuple(grad_rows.shape), tuple(table.shape), tuple(accum.shape), n))
+    check(lib.esr_sparse_adagrad_scatter(_p(table), dt, _p(accum), V, D, _p(sorted_ids), _p(perm), n, _p(grad_rows),
+                                         float(lr), float(eps), _stream()), "esr_sparse_adagrad_scatter")
+
+
+def sparse_sgd(table, sorted_ids, perm, grad_rows, lr):
+    lib = _lib.load()
+    dt = _table_dtype(table, "table")
+    _req(grad_rows, torch.float32, "grad_rows")
+    V = table.shape[0]
+    D = table.shape[1] if table.dim() > 1 else 1
+    n = sorted_ids.numel()
+    check(lib.esr_sparse_sgd_scatter(_p(table), dt, V, D, _p(sorted_ids), _p(perm), n, _p(grad_rows), float(lr),
+                                     _stream()), "esr_sparse_sgd_scatter")
+
+
+def rows_to_dense(V, D, sorted_ids, perm, grad_rows, out=None):
+    """The dense [V, D] gradient (zero-filled, segment sums scattered) the reference's autodiff yields."""
+    lib = _lib.load()
+    _req(grad_rows, torch.float32, "grad_rows")
+    if out is None:
+        out = torch.empty((V, D), dtype=torch.float32, device=grad_rows.device)
+    n = sorted_ids.numel()
+    check(lib.esr_rows_to_dense(_p(out), V, D, _p(sorted_ids), _p(perm), n, _p(grad_rows), _stream()),
+          "esr_rows_to_dense")
+    return out
+
+
+def dense_adam(param, mu, nu, grad, lr, step, b1=0.9, b2=0.999, eps=1e-8):
+    """In-place optax.adam on every element; `step` is the 1-based count after this update."""
+    lib = _lib.load()
+    for name, t in (("param", param), ("mu", mu), ("nu", nu), ("grad", grad)):
+        _req(t, torch.float32, name)
+    check(lib.esr_dense_adam(_p(param), _p(mu), _p(nu), _p(grad), param.numel(), float(lr), float(b1), float(b2),
+                             float(eps), int(step), _stream()), "esr_dense_adam")
+
+
+# ---------------------------------------------------------------------------------------------
+def score_all(emb, token):
+    """scores[v, t] = emb[v] . emb[token[t]]  -> [V, T]."""
+    lib = _lib.load()
+    _req(emb, torch.float32, "emb"), _req(token, torch.int32, "token")
+    V, D = emb.shape
+    T = token.numel()
+    scores = torch.empty((V, T), dtype=torch.float32, device=emb.device)
+    check(lib.esr_score_all(_p(emb), V, D, _p(token), T, _p(scores), _stream()), "esr_score_all")
+    return scores
+
+
+def argsort_columns(scores):
+    """Stable ascending argsort of every column of scores [V, T] -> int32 [V, T]."""
+    lib = _lib.load()
+    _req(scores, torch.float32, "scores")
+    V, T = scores.shape
+    indices = torch.empty((V, T), dtype=torch.int32, device=scores.device)
+    ws = _ws(_ws_bytes("esr_argsort_columns_workspace_bytes", V, T), scores.device)
+    check(lib.esr_argsort_columns(_p(scores), V, T, _p(indices), _p(ws), ws.numel(), _stream()),
+          "esr_argsort_columns")
+    return indices
+
+
+def score_topk(queries, candidates, k):
+    """Top-k of queries @ candidates^T per query (descending, ties -> lower index)."""
+    lib = _lib.load()
+    _req(queries, torch.float32, "queries"), _req(candidates, torch.float32, "candidates")
+    nq, D = queries.shape
+    N = candidates.shape[0]
+    out_s = torch.empty((nq, k), dtype=torch.float32, device=queries.device)
+    out_i = torch.empty((nq, k), dtype=torch.int32, device=queries.device)
+    ws = _ws(_ws_bytes("esr_score_topk_workspace_bytes", nq, N, k), queries.device)
+    check(lib.esr_score_topk(_p(queries), _p(candidates), nq, N, D, k, _p(out_s), _p(out_i), _p(ws), ws.numel(),
+                             _stream()), "esr_score_topk")
+    return out_s, out_i
+
+
+def bucket_ids_by_owner(ids, world):
+    """Stable bucket by owner = id % world.  Returns (local_rows, perm, counts[world] int64 on device)."""
+    lib = _lib.load()
+    ids = _req(ids, torch.int32, "ids")
+    n = ids.numel()
+    local_rows = torch.empty_like(ids)
+    perm = torch.empty_like(ids)
+    counts = torch.empty(world, dtype=torch.int64, device=ids.device)
+    ws = _ws(_ws_bytes("esr_bucket_workspace_bytes", n), ids.device)
+    check(lib.esr_bucket_ids_by_owner(_p(ids), n, world, _p(local_rows), _p(perm), _p(counts), _p(ws), ws.numel(),
+                                      _stream()), "esr_bucket_ids_by_owner")
+    return local_rows, perm, counts

@@ -1,0 +1,101 @@
+"""Shop-The-Look trainer hot path -- drop-in for ``pinterest/train_shop_the_look.py:72-122``.
+
+``train_step`` / ``eval_step`` / ``generate_triplets`` keep the reference's names, argument order and
+return order.  ``train_step`` with ``neg_product=None`` switches to the north_star in-batch-negative
+sampled-softmax loss (build-defined) on the FP32 MFMA path.
+"""
+import types
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..train_state import RowGrads, SegmentIndex
+
+# Flags with the reference's names and defaults (pinterest/train_shop_the_look.py:46-69).
+FLAGS = types.SimpleNamespace(
+    input_file="STL-Dataset/fashion.json",
+    image_dir="artifacts/shop_the_look:v1",
+    num_neg=5,
+    learning_rate=1e-3,
+    regularization=0.1,
+    output_size=32,
+    batch_size=16,
+    log_every_steps=100,
+    eval_every_steps=2000,
+    checkpoint_every_steps=100000,
+    max_steps=30000,
+    work_dir="/tmp",
+    model_name="pinterest_stl_model",
+    restore_checkpoint=False,
+)
+
+
+def generate_triplets(scene_product, num_neg, seed=0):
+    """Generate positive and negative triplets (pinterest/train_shop_the_look.py:72-91).
+
+    Same protocol: per positive pair ``num_neg`` negatives drawn from ``randint(0, count - 1)`` (upper bound
+    exclusive, so the last item is never a negative -- reference quirk kept), every 10th positive goes to
+    the test split.  JAX's threefry stream is not reproducible without JAX; NumPy PCG64 is used instead."""
+    count = len(scene_product)
+    rng = np.random.default_rng(seed)
+    train, test = [], []
+    for i in range(count):
+        scene, pos = scene_product[i]
+        is_test = i % 10 == 0
+        for neg_idx in rng.integers(0, count - 1, size=num_neg):
+            _, neg = scene_product[int(neg_idx)]
+            (test if is_test else train).append((scene, pos, neg))
+    return train, test
+
+
+def _tables(state):
+    p = state.params["params"] if "params" in state.params else state.params
+    return p, p["scene_tower"]["embedding"], p["product_tower"]["embedding"]
+
+
+def _wrap(state, inner):
+    return {"params": inner} if "params" in state.params else inner
+
+
+def train_step(state, scene, pos_product, neg_product, regularization, batch_size, scale=1.0):
+    """One optimizer step (pinterest/train_shop_the_look.py:93-109).  Returns ``(new_state, loss)``.
+
+    loss = (sum relu(1 + neg - pos) + regularization * sum norm-excess) / batch_size.  One fused HIP launch
+    gathers the three rows per triplet, scores them and writes the three gradient rows; the optimizer
+    update is sort + segment-reduce + RMW.  ``neg_product=None``: in-batch softmax (north_star)."""
+    _, st, pt = _tables(state)
+    dev = st.device
+    sid = ops.as_ids(scene, dev, check_range=st.shape[0]).reshape(-1)
+    pid = ops.as_ids(pos_product, dev, check_range=pt.shape[0]).reshape(-1)
+    B = sid.numel()
+    if neg_product is None:
+        q = ops.gather_rows(st, sid)
+        c = ops.gather_rows(pt, pid)
+        loss, _, gq, gc = ops.inbatch_softmax_fwd_bwd(q, c, scale, regularization, batch_size)
+        g_scene = RowGrads(SegmentIndex(sid, st.shape[0]), gq, st.shape)
+        g_prod = RowGrads(SegmentIndex(pid, pt.shape[0]), gc, pt.shape)
+    else:
+        nid = ops.as_ids(neg_product, dev, check_range=pt.shape[0]).reshape(-1)
+        loss, _, _, gs, gp, gn = ops.triplet_fwd_bwd(st, pt, pt, sid, pid, nid, B, regularization, batch_size,
+                                                     with_reg=True, want_grads=True, want_scores=False)
+        g_scene = RowGrads(SegmentIndex(sid, st.shape[0]), gs, st.shape)
+        g_prod = RowGrads(SegmentIndex(torch.cat([pid, nid]), pt.shape[0]), gp._base, pt.shape)  # [gp ; gn]
+    grads = _wrap(state, {"scene_tower": {"embedding": g_scene}, "product_tower": {"embedding": g_prod}})
+    if getattr(state.tx, "wants_dense", False):
+        from ..train_state import tree_map
+        grads = tree_map(lambda g: g.to_dense(), grads)
+    new_state = state.apply_gradients(grads=grads)
+    return new_state, loss.reshape(())
+
+
+def eval_step(state, scene, pos_product, neg_product):
+    """sum relu(1 + neg - pos): fixed margin, no reg, not divided by the batch size (train_shop_the_look.py:111-122)."""
+    _, st, pt = _tables(state)
+    dev = st.device
+    sid = ops.as_ids(scene, dev, check_range=st.shape[0]).reshape(-1)
+    pid = ops.as_ids(pos_product, dev, check_range=pt.shape[0]).reshape(-1)
+    nid = ops.as_ids(neg_product, dev, check_range=pt.shape[0]).reshape(-1)
+    loss, _, _, _, _, _ = ops.triplet_fwd_bwd(st, pt, pt, sid, pid, nid, sid.numel(), 0.0, 1.0, with_reg=False,
+                                              want_grads=False, want_scores=False)
+    return loss.reshape(())

@@ -1,0 +1,181 @@
+"""TrainState / optimizer objects mirroring what the reference's hot path uses from Flax + Optax.
+
+Reference call sites: ``optax.adam(lr)`` + ``train_state.TrainState.create(apply_fn=..., params=..., tx=tx)``
+(wikipedia/train_cooccurence.py:171-172, pinterest/train_shop_the_look.py:175-177) and
+``state.apply_gradients(grads=grads)`` (train_cooccurence.py:101, train_shop_the_look.py:108).
+
+Differences from JAX, by design (MI355X-first): parameter and optimizer tensors live in HBM and are
+updated IN PLACE by HIP kernels; ``apply_gradients`` returns a new TrainState object that shares those
+buffers (functional call shape, resident memory).  Gradients of embedding tables are row-sparse
+(``RowGrads``) unless the optimizer asks for the reference's dense V x D layout.
+"""
+import torch
+
+from . import ops
+
+
+class SegmentIndex:
+    """Occurrence ids of one gradient scatter, sorted lazily once and shared by every table that is
+    indexed by the same ids (GloVe's embedding + bias tables; STL's pos + neg product rows)."""
+
+    def __init__(self, ids, num_rows):
+        self.ids = ids  # int32 [n] on device
+        self.num_rows = int(num_rows)
+        self._sorted = None
+
+    def sorted(self):
+        if self._sorted is None:
+            self._sorted = ops.segment_sort(self.ids, self.num_rows)
+        return self._sorted
+
+
+class RowGrads:
+    """Row-sparse gradient of a [V, D] table: ``rows[k]`` is the gradient contribution of occurrence k to
+    row ``index.ids[k]``; duplicates accumulate (same meaning as JAX's scatter-add for nn.Embed)."""
+
+    def __init__(self, index, rows, shape):
+        self.index = index
+        self.rows = rows      # f32 [n, D]
+        self.shape = tuple(shape)
+
+    def to_dense(self):
+        """The dense gradient the reference materialises (wikipedia/train_cooccurence.py:86-87)."""
+        sorted_ids, perm = self.index.sorted()
+        V = self.shape[0]
+        D = self.shape[1] if len(self.shape) > 1 else 1
+        return ops.rows_to_dense(V, D, sorted_ids, perm, self.rows.reshape(-1, D)).reshape(self.shape)
+
+
+def tree_leaves_with_path(tree, prefix=()):
+    if isinstance(tree, dict):
+        for k in tree:
+            yield from tree_leaves_with_path(tree[k], prefix + (k,))
+    else:
+        yield prefix, tree
+
+
+def tree_get(tree, path):
+    for k in path:
+        tree = tree[k]
+    return tree
+
+
+def tree_map(fn, tree):
+    if isinstance(tree, dict):
+        return {k: tree_map(fn, v) for k, v in tree.items()}
+    return fn(tree)
+
+
+class GradientTransformation:
+    """Minimal optax-shaped object: ``init(params) -> opt_state`` and an in-place ``apply``."""
+    wants_dense = False
+
+    def init(self, params):
+        raise NotImplementedError
+
+    def apply(self, params, grads, opt_state, step):
+        raise NotImplementedError
+
+
+class _Adam(GradientTransformation):
+    """optax.adam(learning_rate, b1=0.9, b2=0.999, eps=1e-8) [upstream optax 0.1.2] -- dense, every element
+    of every table moves every step (wikipedia/train_cooccurence.py:171)."""
+    wants_dense = True
+
+    def __init__(self, learning_rate, b1=0.9, b2=0.999, eps=1e-8):
+        self.lr, self.b1, self.b2, self.eps = learning_rate, b1, b2, eps
+
+    def init(self, params):
+        return {"count": 0, "mu": tree_map(torch.zeros_like, params), "nu": tree_map(torch.zeros_like, params)}
+
+    def apply(self, params, grads, opt_state, step):
+        count = opt_state["count"] + 1
+        for path, p in tree_leaves_with_path(params):
+            g = tree_get(grads, path)
+            if isinstance(g, RowGrads):
+                g = g.to_dense()
+            ops.dense_adam(p, tree_get(opt_state["mu"], path), tree_get(opt_state["nu"], path), g.reshape(p.shape),
+                           self.lr, count, self.b1, self.b2, self.eps)
+        return {"count": count, "mu": opt_state["mu"], "nu": opt_state["nu"]}
+
+
+class _SparseAdagrad(GradientTransformation):
+    """Row-sparse optax.adagrad(learning_rate, initial_accumulator_value=0.1, eps=1e-7) [upstream] -- the
+    build's production optimizer (north_star).  Identical to dense Adagrad: rows with zero gradient do
+    not move.  Accumulators are fp32 whatever the table dtype."""
+
+    def __init__(self, learning_rate, initial_accumulator_value=0.1, eps=1e-7):
+        self.lr, self.init_acc, self.eps = learning_rate, initial_accumulator_value, eps
+
+    def init(self, params):
+        return {"sum_of_squares": tree_map(
+            lambda p: torch.full(p.shape, self.init_acc, dtype=torch.float32, device=p.device), params)}
+
+    def apply(self, params, grads, opt_state, step):
+        for path, p in tree_leaves_with_path(params):
+            g = tree_get(grads, path)
+            if g is None:
+                continue
+            if not isinstance(g, RowGrads):
+                raise TypeError("sparse_adagrad needs RowGrads leaves (got %s at %s)" % (type(g).__name__, path))
+            sorted_ids, perm = g.index.sorted()
+            ops.sparse_adagrad(p, tree_get(opt_state["sum_of_squares"], path), sorted_ids, perm, g.rows, self.lr,
+                               self.eps)
+        return opt_state
+
+
+class _SparseSgd(GradientTransformation):
+    """Row-sparse optax.sgd(learning_rate) without momentum."""
+
+    def __init__(self, learning_rate):
+        self.lr = learning_rate
+
+    def init(self, params):
+        return {}
+
+    def apply(self, params, grads, opt_state, step):
+        for path, p in tree_leaves_with_path(params):
+            g = tree_get(grads, path)
+            if g is None:
+                continue
+            sorted_ids, perm = g.index.sorted()
+            ops.sparse_sgd(p, sorted_ids, perm, g.rows, self.lr)
+        return opt_state
+
+
+def adam(learning_rate, b1=0.9, b2=0.999, eps=1e-8):
+    return _Adam(learning_rate, b1, b2, eps)
+
+
+def sparse_adagrad(learning_rate, initial_accumulator_value=0.1, eps=1e-7):
+    return _SparseAdagrad(learning_rate, initial_accumulator_value, eps)
+
+
+def sgd(learning_rate):
+    return _SparseSgd(learning_rate)
+
+
+class TrainState:
+    """flax.training.train_state.TrainState look-alike: step, apply_fn, params, tx, opt_state."""
+
+    def __init__(self, step, apply_fn, params, tx, opt_state):
+        self.step = step
+        self.apply_fn = apply_fn
+        self.params = params
+        self.tx = tx
+        self.opt_state = opt_state
+
+    @classmethod
+    def create(cls, *, apply_fn, params, tx, **kwargs):
+        return cls(step=0, apply_fn=apply_fn, params=params, tx=tx, opt_state=tx.init(params))
+
+    def replace(self, **kw):
+        d = dict(step=self.step, apply_fn=self.apply_fn, params=self.params, tx=self.tx, opt_state=self.opt_state)
+        d.update(kw)
+        return TrainState(**d)
+
+    def apply_gradients(self, *, grads, **kwargs):
+        """step += 1 and one optimizer update (flax TrainState.apply_gradients).  The tables are updated in
+        place in HBM; the returned state shares them."""
+        new_opt = self.tx.apply(self.params, grads, self.opt_state, self.step + 1)
+        return self.replace(step=self.step + 1, opt_state=new_opt)

@@ -1,0 +1,118 @@
+"""GloVe trainer hot path -- drop-in for the reference's ``wikipedia/train_cooccurence.py:71-134``.
+
+``apply_model``, ``update_model``, ``train_epoch``, ``find_knn``, ``dump_knn`` and ``save_state`` keep
+the reference's names, argument order and return order.  The step is three fused HIP launches for
+loss + gradients (esr_glove_fwd_bwd) plus a sort + segment-reduce optimizer update; nothing is
+traced or compiled at run time.
+"""
+import logging
+import os
+import types
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..train_state import RowGrads, SegmentIndex
+from .models import Glove
+
+# Flags with the reference's names and defaults (wikipedia/train_cooccurence.py:34-65); absl is not
+# a dependency, so this is a plain namespace a caller may overwrite.
+FLAGS = types.SimpleNamespace(
+    train_input_pattern="data/wikipedia.cooccur.pb.b64.bz2/part-?????.bz2",
+    token_dictionary="data/dictionaries/token.tstat.pb.b64.bz2",
+    max_terms=20,
+    embedding_dim=64,
+    batch_size=2048,
+    seed=1701,
+    shuffle_buffer_size=5000000,
+    terms="news,apple,computer,physics,neural,democracy,singapore,livermore",
+    checkpoint_dir="data/wikipedia_training",
+    checkpoint_every_epochs=20,
+    resume_checkpoint=None,
+    steps_per_epoch=10000,
+    num_epochs=20,
+    learning_rate=0.001,
+)
+
+_MODES = {"reference": ops.GLOVE_REFERENCE, "diagonal": ops.GLOVE_DIAGONAL}
+
+
+def _model_of(state):
+    model = getattr(state.apply_fn, "__self__", None)
+    return model if isinstance(model, Glove) else None
+
+
+def apply_model(state, inputs, target):
+    """Computes the gradients and loss for a single batch (wikipedia/train_cooccurence.py:71-89).
+
+    Returns ``(grads, loss)`` -- grads first, as the reference does.  ``grads`` has the reference's tree
+    ``{'_token_embedding': {'embedding': g}, '_bias': {'embedding': g}}``; the leaves are dense [V, D] /
+    [V, 1] tensors when the optimizer is the reference's dense Adam, else row-sparse ``RowGrads``.
+    ``loss`` is a 0-dim device tensor (float(loss) synchronises, like a JAX device scalar)."""
+    emb = state.params["_token_embedding"]["embedding"]
+    bias = state.params["_bias"]["embedding"]
+    model = _model_of(state)
+    mode = _MODES[model.loss_mode if model is not None else "reference"]
+    V = emb.shape[0]
+    inputs = ops.as_ids(inputs, emb.device, check_range=V)
+    target = ops.as_f32(target, emb.device)
+    loss, grad_rows, grad_bias = ops.glove_fwd_bwd(emb, bias, inputs, target, mode)
+    index = SegmentIndex(inputs.reshape(-1), V)  # occurrence ids = [token1 ; token2]
+    g_emb = RowGrads(index, grad_rows, emb.shape)
+    g_bias = RowGrads(index, grad_bias.reshape(-1, 1), bias.shape)
+    if getattr(state.tx, "wants_dense", False):
+        g_emb, g_bias = g_emb.to_dense(), g_bias.to_dense()
+    grads = {"_token_embedding": {"embedding": g_emb}, "_bias": {"embedding": g_bias}}
+    return grads, loss.reshape(())
+
+
+def find_knn(model, params, token):
+    """scores [V, T] and the full stable ascending argsort over V (wikipedia/train_cooccurence.py:91-97)."""
+    scores = model.apply({"params": params}, token, method=Glove.score_all)
+    indices = ops.argsort_columns(scores)
+    return scores, indices
+
+
+def update_model(state, grads):
+    """wikipedia/train_cooccurence.py:99-101."""
+    return state.apply_gradients(grads=grads)
+
+
+def train_epoch(state, steps_per_epoch, train_it):
+    """Trains for an epoch (wikipedia/train_cooccurence.py:103-112).  Losses stay on the device until the
+    epoch mean is taken, so the loop never synchronises."""
+    epoch_loss = []
+    for _ in range(steps_per_epoch):
+        inputs, targets = next(train_it)
+        grads, loss = apply_model(state, inputs, targets)
+        state = update_model(state, grads)
+        epoch_loss.append(loss)
+    train_loss = float(torch.stack(epoch_loss).mean()) if epoch_loss else float("nan")
+    return state, train_loss
+
+
+def dump_knn(model, params, tokens, token_dictionary):
+    """Dumps the 10 nearest neighbours of each probe token (wikipedia/train_cooccurence.py:114-126)."""
+    scores, indices = find_knn(model, params, tokens)
+    tokens_h = np.asarray(tokens.cpu() if isinstance(tokens, torch.Tensor) else tokens)
+    top = indices[-10:].flip(0).cpu().numpy()                      # rows -1 .. -10
+    top_scores = torch.gather(scores, 0, indices[-10:].flip(0).long()).cpu().numpy()
+    lines = []
+    for i in range(tokens_h.shape[0]):
+        query_word = token_dictionary.get_token_from_embedding_index(int(tokens_h[i]))
+        knn = ["%s:%f" % (token_dictionary.get_token_from_embedding_index(int(top[j, i])), top_scores[j, i])
+               for j in range(top.shape[0])]
+        line = "Nearest neighbors for %s: %s" % (query_word, " ".join(knn))
+        logging.info(line)
+        lines.append(line)
+    return lines
+
+
+def save_state(state, step, checkpoint_dir=None):
+    """Saves the state of the model (wikipedia/train_cooccurence.py:129-134) as ``checkpoint-%05d.flax``."""
+    from ..checkpoint import to_bytes
+    filename = os.path.join(checkpoint_dir or FLAGS.checkpoint_dir, "checkpoint-%05d.flax" % step)
+    with open(filename, "wb") as f:
+        f.write(to_bytes(state))
+    return filename

@@ -1,0 +1,160 @@
+/*
+ * esr_hip.h -- C ABI of libesr_hip.so, the MI355X (gfx950) embedding-training hot path.
+ *
+ * The reference (BBischof/ESRecsys) has no plugin / operator / FFI boundary: its
+ * hot path is a handful of Python functions executed by XLA through JAX/Flax/Optax
+ * (SURVEY.md section 8b).  This header is therefore the boundary a maintainer
+ * would bind from the reference's Python (ctypes -- see INTEGRATION.md); each
+ * entry point cites the reference lines whose arithmetic it replaces.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes; no torch / C++ types.
+ *   - returns ESR_OK (0) or a negative ESR_E* code; never throws.  esr_last_error()
+ *     returns a thread-local message for the last failing call on this thread.
+ *   - every pointer is DEVICE memory owned by the caller unless marked "host".
+ *     The library never allocates, frees or synchronises; work is enqueued on
+ *     `stream` (a hipStream_t passed as void*; NULL = the null stream).
+ *   - scratch memory is passed explicitly: `workspace` of at least the size the
+ *     matching esr_*_workspace_bytes() query returns (16-byte aligned).
+ *   - tables are row-major [V, D]; ids are int32 in [0, V).  Rows are processed
+ *     in 16-byte chunks when D * sizeof(elt) is a multiple of 16, else scalar.
+ *   - re-entrant across streams/threads; no global mutable state.
+ */
+#ifndef ESR_HIP_H_
+#define ESR_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ESR_OK 0
+#define ESR_EINVAL (-1)     /* bad argument (null pointer, negative size, unsupported D/k/...) */
+#define ESR_ELAUNCH (-2)    /* HIP launch / runtime error (message has hipGetErrorString) */
+#define ESR_EWORKSPACE (-3) /* workspace too small or misaligned */
+#define ESR_ENODEVICE (-4)  /* no gfx950 device visible */
+
+#define ESR_F32 0
+#define ESR_BF16 1
+
+#define ESR_GLOVE_REFERENCE 0 /* (B,B)-broadcast loss of wikipedia/train_cooccurence.py:83 */
+#define ESR_GLOVE_DIAGONAL 1  /* textbook per-pair GloVe loss (build-defined option) */
+
+typedef void* esr_stream_t;
+
+const char* esr_last_error(void);
+int esr_version(void);
+/* host out-params; arch_len bytes at arch receive e.g. "gfx950". */
+int esr_device_info(int* cu_count, int* wave_size, size_t* hbm_bytes, char* arch, int arch_len);
+
+/* ---- G2 / S1: embedding-row gather ------------------------------------------------------
+ * nn.Embed lookup == jnp.take(table, ids, axis=0): wikipedia/models.py:31-34 (and the id towers
+ * that replace pinterest/models.py:64-70).  out[i, :] = table[ids[i], :], bit-exact. */
+int esr_gather_rows(const void* table, int dtype, int64_t V, int D, const int32_t* ids, int64_t n,
+                    void* out, esr_stream_t stream);
+
+/* ---- G2: Glove.__call__ pieces -- wikipedia/models.py:30-37 ------------------------------
+ * dot[j] = E[t1[j]] . E[t2[j]],  s[i] = Bias[t1[i]] + Bias[t2[i]];  the (B,B) output is
+ * dot[None,:] + s[:,None].  inputs is int32 [2, B] row-major (cooccurrence_matrix.py:103-104). */
+int esr_glove_forward(const float* emb, const float* bias, int64_t V, int D, const int32_t* inputs,
+                      int64_t B, float* dot, float* s, esr_stream_t stream);
+
+/* ---- G3: apply_model / glove_loss value_and_grad -- wikipedia/train_cooccurence.py:76-89 ---
+ * Fused gather + dot + weighted log10 loss + per-occurrence row gradients.
+ *   loss[0]                       scalar loss
+ *   grad_rows [2B, D]             occurrence j   : dL/ddot_j * E[t2[j]]   (row id t1[j])
+ *                                 occurrence B+j : dL/ddot_j * E[t1[j]]   (row id t2[j])
+ *   grad_bias [2B]                occurrence i and B+i: dL/ds_i
+ * The occurrence ids are simply inputs[0..2B) read as a flat array. */
+size_t esr_glove_workspace_bytes(int64_t B);
+int esr_glove_fwd_bwd(const float* emb, const float* bias, int64_t V, int D, const int32_t* inputs,
+                      const float* target, int64_t B, int mode, float* loss, float* grad_rows,
+                      float* grad_bias, void* workspace, size_t workspace_bytes, esr_stream_t stream);
+
+/* ---- S1-S3: STL score head + triplet loss -- pinterest/models.py:67-72,
+ * pinterest/train_shop_the_look.py:93-122 --------------------------------------------------
+ * Towers are id-embedding tables; pos and neg rows may come from different tables (pass the product
+ * table twice for the id towers).  ids == NULL means "row b of the table", so the three (B,D)
+ * embedding matrices of the reference head can be passed directly as scene/pos/neg tables.
+ *   loss = (sum_b relu(1 + neg_b - pos_b) + regularization * sum_b reg) / batch_size   (train)
+ *   eval_step (:118) = the same call with with_reg = 0, batch_size = 1 and g_* = NULL.
+ * pos_score / neg_score [B] may be NULL.  g_scene/g_pos/g_neg [B, D] per-occurrence gradients. */
+size_t esr_triplet_workspace_bytes(int64_t B);
+int esr_triplet_fwd_bwd(const float* scene_table, int64_t Vs, const float* pos_table, int64_t Vp,
+                        const float* neg_table, int64_t Vn, int D, const int32_t* scene_ids, const int32_t* pos_ids,
+                        const int32_t* neg_ids, int64_t B, float regularization, float batch_size,
+                        int with_reg, float* loss, float* pos_score, float* neg_score,
+                        float* g_scene, float* g_pos, float* g_neg, void* workspace,
+                        size_t workspace_bytes, esr_stream_t stream);
+
+/* ---- north_star: in-batch-negative sampled softmax on the dense B x B score matrix --------
+ * (build-defined; the closest reference precedent is spotify/models.py:74-87).
+ *   S = scale * Q C^T (FP32 MFMA), ce_i = logsumexp_j S_ij - S_ii,
+ *   loss = (sum_i ce_i + regularization * sum_i [reg(q_i) + reg(c_i)]) / batch_size
+ *   gQ = scale * (softmax(S) - I) C / batch_size + dreg ; gC likewise with S^T.
+ * Q, C, gQ, gC are [B, D] row-major; D must be 128 in this build; B a multiple of 32. */
+size_t esr_inbatch_workspace_bytes(int64_t B, int D);
+int esr_inbatch_softmax_fwd_bwd(const float* Q, const float* C, int64_t B, int D, float scale,
+                                float regularization, float batch_size, float* loss, float* lse,
+                                float* gQ, float* gC, void* workspace, size_t workspace_bytes,
+                                esr_stream_t stream);
+
+/* ---- G4 (build's production optimizer): sort + segment-reduce + sparse Adagrad -----------
+ * Replaces the dense V x D gradient + dense optimizer sweep of
+ * wikipedia/train_cooccurence.py:86-101 with a row-sparse update.
+ * esr_segment_sort_ids: stable sort of occurrence ids; perm[k] = original occurrence index. */
+size_t esr_segment_sort_workspace_bytes(int64_t n);
+int esr_segment_sort_ids(const int32_t* ids, int64_t n, int64_t V, int32_t* sorted_ids,
+                         int32_t* perm, void* workspace, size_t workspace_bytes,
+                         esr_stream_t stream);
+/* For each distinct id: G = sum of its grad rows (occurrence order); acc += G*G;
+ * p -= lr * G * rsqrt(acc + eps).  table dtype f32 or bf16 (fp32 accumulator either way). */
+int esr_sparse_adagrad_scatter(void* table, int dtype, float* accum, int64_t V, int D,
+                               const int32_t* sorted_ids, const int32_t* perm, int64_t n,
+                               const float* grad_rows, float lr, float eps, esr_stream_t stream);
+/* Row-sparse SGD (p -= lr * G), same segment reduction. */
+int esr_sparse_sgd_scatter(void* table, int dtype, int64_t V, int D, const int32_t* sorted_ids,
+                           const int32_t* perm, int64_t n, const float* grad_rows, float lr,
+                           esr_stream_t stream);
+/* Reference-faithful dense gradient: dense[V, D] = 0 then dense[id] = segment sum
+ * (the scatter-add JAX's autodiff performs for nn.Embed, train_cooccurence.py:86-87). */
+int esr_rows_to_dense(float* dense, int64_t V, int D, const int32_t* sorted_ids,
+                      const int32_t* perm, int64_t n, const float* grad_rows, esr_stream_t stream);
+/* optax.adam over every element -- wikipedia/train_cooccurence.py:99-101,171.
+ * step = the 1-based count AFTER this update. */
+int esr_dense_adam(float* param, float* mu, float* nu, const float* grad, int64_t numel, float lr,
+                   float b1, float b2, float eps, int64_t step, esr_stream_t stream);
+
+/* ---- G6: Glove.score_all + find_knn -- wikipedia/models.py:50-55, train_cooccurence.py:91-97
+ * scores[v, t] = E[v] . E[token[t]]  ([V, T] row-major, no bias);
+ * indices = stable ascending argsort of every column ([V, T] int32). */
+int esr_score_all(const float* emb, int64_t V, int D, const int32_t* token, int T, float* scores,
+                  esr_stream_t stream);
+size_t esr_argsort_columns_workspace_bytes(int64_t V, int T);
+int esr_argsort_columns(const float* scores, int64_t V, int T, int32_t* indices, void* workspace,
+                        size_t workspace_bytes, esr_stream_t stream);
+
+/* ---- find_top_k -- pinterest/make_recommendations.py:49-65 --------------------------------
+ * scores[q, n] = queries[q] . candidates[n]; top-k per query, descending, ties -> lower index. */
+size_t esr_score_topk_workspace_bytes(int64_t nq, int64_t N, int k);
+int esr_score_topk(const float* queries, const float* candidates, int64_t nq, int64_t N, int D,
+                   int k, float* out_scores, int32_t* out_indices, void* workspace,
+                   size_t workspace_bytes, esr_stream_t stream);
+
+/* ---- 8e: row-shard routing (owner = id mod world, local row = id div world) ---------------
+ * Stable bucket of ids by owner: local_rows[k] = ids[perm[k]] / world, counts[g] = #ids owned by g
+ * (int64, device).  Build-defined; the reference is single-device. */
+size_t esr_bucket_workspace_bytes(int64_t n);
+int esr_bucket_ids_by_owner(const int32_t* ids, int64_t n, int world, int32_t* local_rows,
+                            int32_t* perm, int64_t* counts, void* workspace,
+                            size_t workspace_bytes, esr_stream_t stream);
+/* out[perm[k], :] = rows[k, :]  (undo the bucket order for rows that came back). */
+int esr_unpermute_rows(const void* rows, int dtype, int D, const int32_t* perm, int64_t n, void* out,
+                       esr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESR_HIP_H_ */

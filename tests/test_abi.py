@@ -1,0 +1,78 @@
+"""CPU: the C-ABI library loads, exports every symbol include/esr_hip.h declares, and rejects bad
+arguments with ESR_EINVAL before touching a device (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "esr_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(esr_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from esrecsys_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        from esrecsys_amd.build import build_library
+        build_library()
+    return _lib.load()
+
+
+def test_header_symbols_all_exported(lib):
+    from esrecsys_amd import _lib
+    declared = _declared_symbols()
+    assert len(declared) >= 24
+    for name in declared:
+        assert hasattr(lib, name), "libesr_hip.so does not export %s" % name
+    # the ctypes table binds exactly the header's entry points
+    assert sorted(_lib.SIGNATURES) == declared
+
+
+def test_version_and_error_string(lib):
+    assert lib.esr_version() >= 100
+    assert isinstance(lib.esr_last_error(), bytes)
+
+
+def test_bad_arguments_are_rejected_without_a_device(lib):
+    EINVAL, EWORKSPACE = -1, -3
+    assert lib.esr_gather_rows(None, 0, 10, 4, None, -1, None, None) == EINVAL
+    assert b"esr_gather_rows" in lib.esr_last_error()
+    assert lib.esr_gather_rows(None, 7, 10, 4, None, 1, None, None) == EINVAL      # bad dtype
+    assert lib.esr_gather_rows(None, 0, 10, 4, None, 0, None, None) == 0           # n == 0 is a no-op
+    assert lib.esr_gather_rows(None, 0, 10, 4, None, 5, None, None) == EINVAL      # null pointers
+    assert lib.esr_glove_fwd_bwd(None, None, 10, 4, None, None, 0, 0, None, None, None, None, 0, None) == EINVAL
+    assert lib.esr_inbatch_softmax_fwd_bwd(1, 1, 33, 128, 1.0, 0.0, 33.0, 1, 1, 1, 1, 1, 1 << 20, None) == EINVAL
+    assert b"multiple of 32" in lib.esr_last_error()
+    assert lib.esr_inbatch_softmax_fwd_bwd(16, 16, 64, 100, 1.0, 0.0, 64.0, 16, 16, 16, 16, 16, 1 << 20, None) == EINVAL
+    assert lib.esr_dense_adam(16, 16, 16, 16, 8, 1e-3, 0.9, 0.999, 1e-8, 0, None) == EINVAL  # step must be >= 1
+    # workspace too small is reported before any launch
+    assert lib.esr_glove_fwd_bwd(16, 16, 10, 4, 16, 16, 8, 0, 16, None, None, 16, 8, None) == EWORKSPACE
+    assert lib.esr_score_topk(16, 16, 1, 10, 4, 11, 16, 16, 16, 1 << 20, None) == EINVAL     # k > N
+
+
+def test_workspace_queries_are_monotone(lib):
+    a = lib.esr_glove_workspace_bytes(1024)
+    b = lib.esr_glove_workspace_bytes(65536)
+    assert 0 < a < b
+    assert lib.esr_segment_sort_workspace_bytes(1 << 20) >= lib.esr_segment_sort_workspace_bytes(1 << 10) > 0
+    assert lib.esr_inbatch_workspace_bytes(8192, 128) > 8192 * 4
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    from esrecsys_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(_lib.EsrLibraryError, match="no CPU fallback"):
+        _lib.load(str(tmp_path / "nope.so"))
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from esrecsys_amd import ops
+    with pytest.raises(TypeError, match="no CPU fallback"):
+        ops.gather_rows(torch.zeros(4, 4), torch.zeros(2, dtype=torch.int32))

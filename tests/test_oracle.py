@@ -1,0 +1,132 @@
+"""CPU: the oracle against the committed golden vectors and against the independent autograd
+transliteration (the only pins available -- the reference has no test vectors)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+from oracle import autograd_ref, glove, optim, shard, stl_head, topk
+
+F64 = np.float64
+GLOVE_CASES = ["glove_uniform_d16_b64", "glove_uniform_d64_b128", "glove_same_d16_b64", "glove_zipf_d64_b128"]
+STL_CASES = ["stl_b32_d8_lam0", "stl_b32_d8_lam01", "stl_b128_d32_lam01"]
+INBATCH_CASES = ["inbatch_b64_d32", "inbatch_b96_d64_scale4", "inbatch_b320_d128"]
+
+
+@pytest.mark.parametrize("case", GLOVE_CASES)
+@pytest.mark.parametrize("mode", ["reference", "diagonal"])
+def test_glove_oracle_matches_golden_and_autograd(case, mode):
+    g = load_golden(case)
+    grads, loss = glove.dense_grads(g["emb"].astype(F64), g["bias"].astype(F64), g["inputs"], g["target"], mode, F64)
+    assert abs(loss - g["loss_" + mode]) <= 1e-13
+    assert np.abs(grads["_token_embedding"]["embedding"] - g["gemb_" + mode]).max() <= 1e-13
+    assert np.abs(grads["_bias"]["embedding"] - g["gbias_" + mode]).max() <= 1e-13
+    l2, ge, gb = autograd_ref.glove_value_and_grad(g["emb"], g["bias"], g["inputs"], g["target"], mode)
+    assert abs(loss - l2) <= 1e-12
+    assert np.abs(grads["_token_embedding"]["embedding"] - ge).max() <= 1e-12
+    assert np.abs(grads["_bias"]["embedding"] - gb).max() <= 1e-12
+
+
+@pytest.mark.parametrize("case", GLOVE_CASES)
+def test_glove_bb_broadcast_quirk(case):
+    """The (B,B) output of models.py:37 and the O(B) centred loss agree with the literal O(B^2) mean."""
+    g = load_golden(case)
+    emb, bias = g["emb"].astype(F64), g["bias"].astype(F64)
+    pred = glove.forward(emb, bias, g["inputs"], F64)
+    B = g["inputs"].shape[1]
+    assert pred.shape == (B, B)
+    np.testing.assert_allclose(pred, g["pred_reference"], rtol=0, atol=1e-14)
+    dot, s = glove.pair_terms(emb, bias, g["inputs"], F64)
+    np.testing.assert_allclose(pred[3, 5], dot[5] + s[3], rtol=0, atol=1e-15)
+    lit = glove.loss_literal(emb, bias, g["inputs"], g["target"], F64)
+    assert abs(lit - g["loss_reference"]) <= 1e-13
+
+
+def test_glove_fp32_oracle_close_to_fp64():
+    g = load_golden("glove_uniform_d64_b128")
+    g32, l32 = glove.dense_grads(g["emb"], g["bias"], g["inputs"], g["target"], "reference", np.float32)
+    assert abs(l32 - g["loss_reference"]) / abs(g["loss_reference"]) < 1e-5
+    assert rel_err(g32["_token_embedding"]["embedding"], g["gemb_reference"]) < 1e-5
+
+
+@pytest.mark.parametrize("case", STL_CASES)
+def test_stl_oracle_matches_golden_and_autograd(case):
+    g = load_golden(case)
+    lam, bs = float(g["lam"]), float(g["batch_size"])
+    loss, gs, gp, gn = stl_head.triplet_loss_and_grads(g["scene"], g["pos"], g["neg"], lam, bs, F64)
+    assert abs(loss - g["loss"]) <= 1e-13
+    for a, b in ((gs, g["g_scene"]), (gp, g["g_pos"]), (gn, g["g_neg"])):
+        assert np.abs(a - b).max() <= 1e-13
+    l2, a, b, c = autograd_ref.stl_value_and_grad(g["scene"], g["pos"], g["neg"], lam, bs)
+    assert abs(loss - l2) <= 1e-12 and np.abs(gs - a).max() <= 1e-12
+    assert np.abs(gp - b).max() <= 1e-12 and np.abs(gn - c).max() <= 1e-12
+    assert abs(stl_head.eval_loss(g["scene"], g["pos"], g["neg"], F64) - g["eval_loss"]) <= 1e-13
+
+
+@pytest.mark.parametrize("case", INBATCH_CASES)
+def test_inbatch_oracle_matches_golden_and_autograd(case):
+    g = load_golden(case)
+    lam, bs, scale = float(g["lam"]), float(g["batch_size"]), float(g["scale"])
+    loss, lse, gq, gc = stl_head.inbatch_softmax_loss_and_grads(g["q"], g["c"], lam, bs, scale, F64)
+    assert abs(loss - g["loss"]) <= 1e-13 and np.abs(gq - g["g_q"]).max() <= 1e-13
+    l2, a, b = autograd_ref.inbatch_value_and_grad(g["q"], g["c"], lam, bs, scale)
+    assert abs(loss - l2) <= 1e-12 and np.abs(gq - a).max() <= 1e-12 and np.abs(gc - b).max() <= 1e-12
+
+
+def test_optimizers_match_golden_and_torch():
+    g = load_golden("optim_v64_d8")
+    p0 = g["p0"].astype(F64)
+    st, p = optim.adam_init(p0), p0
+    for k in range(3):
+        p, st = optim.adam_update(p, g["adam_grads"][k].astype(F64), st, 1e-3, dtype=F64)
+        assert np.abs(p - g["adam_params"][k]).max() <= 1e-14
+    assert np.abs(p - autograd_ref.adam_steps(g["p0"], list(g["adam_grads"]), 1e-3)).max() <= 1e-12
+    p, a = p0, optim.adagrad_init(p0)
+    for k in range(3):
+        p, a = optim.sparse_adagrad_update(p, a, g["ada_ids"][k], g["ada_rows"][k].astype(F64), 0.05, dtype=F64)
+    assert np.abs(p - g["ada_param"]).max() <= 1e-14 and np.abs(a - g["ada_accum"]).max() <= 1e-14
+
+
+def test_sparse_adagrad_equals_dense_adagrad():
+    """A zero gradient leaves parameter and accumulator untouched, so the row-sparse update IS optax.adagrad."""
+    rng = np.random.default_rng(5)
+    V, D, n = 40, 4, 25
+    p0 = rng.standard_normal((V, D))
+    ids = rng.integers(0, V, n)
+    rows = rng.standard_normal((n, D))
+    p, a = optim.sparse_adagrad_update(p0, optim.adagrad_init(p0), ids, rows, 0.1, dtype=F64)
+    dense = np.zeros((V, D))
+    np.add.at(dense, ids, rows)
+    pd, ad = autograd_ref.adagrad_steps(p0, [dense], 0.1)
+    assert np.abs(p - pd).max() <= 1e-14 and np.abs(a - ad).max() <= 1e-14
+    untouched = np.setdiff1d(np.arange(V), ids)
+    assert np.array_equal(p[untouched], p0[untouched])
+
+
+def test_topk_and_knn_golden_with_ties():
+    g = load_golden("topk_n500_d8_k10")
+    vals, idx = topk.find_top_k(g["query"], g["cand"], int(g["k"]), F64)
+    assert np.array_equal(idx, g["topk_indices"]) and np.array_equal(vals, g["topk_scores"])
+    assert np.all(np.diff(vals) <= 0)
+    full = (g["cand"].astype(F64) * g["query"].astype(F64)).sum(-1)
+    # ties broken towards the lower index (jax.lax.top_k)
+    for a, b in zip(idx[:-1], idx[1:]):
+        assert full[a] > full[b] or (full[a] == full[b] and a < b)
+    scores, indices = glove.find_knn(g["cand"], g["token"], F64)
+    assert np.array_equal(indices, g["knn_indices"])
+    assert indices.shape == (500, 5) and indices.dtype == np.int32
+    col = scores[indices[:, 2], 2]
+    assert np.all(np.diff(col) >= 0)
+
+
+def test_bucket_by_owner_roundtrip():
+    rng = np.random.default_rng(3)
+    ids = rng.integers(0, 1000, 257).astype(np.int32)
+    for world in (1, 2, 3, 8):
+        local, counts, perm = shard.bucket_by_owner(ids, world)
+        assert counts.sum() == ids.size
+        owners = np.repeat(np.arange(world), counts)
+        assert np.array_equal(local.astype(np.int64) * world + owners, ids[perm])
+        # stability: original order preserved within an owner
+        for g in range(world):
+            pos = perm[owners == g]
+            assert np.all(np.diff(pos) > 0)
