@@ -1,0 +1,269 @@
+"""Headline benchmark: training pairs/sec on BASELINE.json configs[1].
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload inbatch|triplet|glove]
+
+A "step" is one full training step of the hot path on one batch of synthetic input that is already
+resident in HBM: id lookup (row gather) -> dot-product scores -> loss -> row gradients -> sort +
+segment-reduce -> sparse Adagrad read-modify-write of both tower tables.
+
+  inbatch (default, configs[1]): 1M x 128 fp32 scene table + 1M x 128 fp32 product table, B = 8192 pairs,
+          in-batch negatives, sampled-softmax loss on the FP32-MFMA B x B score matrix.
+  triplet: same tables, reference-exact triplet hinge loss with explicit negatives (HBM-bound).
+  glove  : configs[2], V = 465537 (400k + the reference's 65537 reserved rows) x 256, B = 65536.
+
+For N > 1 the driver launches one process per GPU (torch.distributed.run); rows are sharded
+``owner = id mod N`` and ids / rows / gradients are exchanged with RCCL all-to-all (weak scaling:
+every rank draws its own B pairs).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense FP32 matrix peak (v_mfma_f32_32x32x2_f32)
+
+WORKLOADS = {
+    "inbatch": dict(V=1_000_000, D=128, B=8192, rows_per_unit=2, unit="pair"),
+    "triplet": dict(V=1_000_000, D=128, B=8192, rows_per_unit=3, unit="triplet"),
+    "glove": dict(V=400_000 + 65_537, D=256, B=65_536, rows_per_unit=2, unit="pair"),
+}
+LAM, SCALE, LR, SEED = 0.1, 8.0, 0.05, 1701
+
+
+class KernelTimer:
+    """HIP-event timing of the ops.* calls on the stream they are launched on (torch's current stream)."""
+
+    def __init__(self, ops_module, groups):
+        self.ops = ops_module
+        self.groups = groups  # name -> [ops function names]
+        self.events = {g: [] for g in groups}
+        self.enabled = False
+        self._orig = {}
+
+    def install(self):
+        for group, names in self.groups.items():
+            for name in names:
+                orig = getattr(self.ops, name)
+                self._orig[name] = orig
+                setattr(self.ops, name, self._wrap(orig, group))
+
+    def _wrap(self, fn, group):
+        def wrapped(*a, **k):
+            if not self.enabled:
+                return fn(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **k)
+            e1.record()
+            self.events[group].append((e0, e1))
+            return out
+        return wrapped
+
+    def totals_ms(self):
+        return {g: (sum(a.elapsed_time(b) for a, b in ev), len(ev)) for g, ev in self.events.items()}
+
+
+def synth_tables(V, D, dev, gen):
+    t = torch.randn((V, D), generator=gen, device=dev, dtype=torch.float32)
+    return t.mul_(D ** -0.5)
+
+
+def make_state_and_batches(workload, cfg, dev, n_batches, rank):
+    from esrecsys_amd import TrainState, optim
+    V, D, B = cfg["V"], cfg["D"], cfg["B"]
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(SEED)
+    if workload == "glove":
+        from esrecsys_amd.wikipedia.models import Glove
+        model = Glove(num_embeddings=V, features=D, device=dev)
+        params = {"_token_embedding": {"embedding": synth_tables(V, D, dev, gen)},
+                  "_bias": {"embedding": torch.zeros((V, 1), device=dev)}}
+        state = TrainState.create(apply_fn=model.apply, params=params, tx=optim.sparse_adagrad(LR))
+    else:
+        from esrecsys_amd.pinterest.models import STLModel
+        model = STLModel(output_size=D, num_scenes=V, num_products=V, device=dev)
+        params = {"params": {"scene_tower": {"embedding": synth_tables(V, D, dev, gen)},
+                             "product_tower": {"embedding": synth_tables(V, D, dev, gen)}}}
+        state = TrainState.create(apply_fn=model.apply, params=params, tx=optim.sparse_adagrad(LR))
+    gen.manual_seed(SEED + 1 + rank)
+    batches = []
+    for _ in range(n_batches):
+        if workload == "glove":
+            inputs = torch.randint(0, V, (2, B), generator=gen, device=dev, dtype=torch.int32)
+            u = torch.rand(B, generator=gen, device=dev)
+            target = torch.exp(np.log(0.1) + u * (np.log(1000.0) - np.log(0.1)))
+            batches.append((inputs, target))
+        else:
+            ids = torch.randint(0, V, (3, B), generator=gen, device=dev, dtype=torch.int32)
+            batches.append((ids[0].contiguous(), ids[1].contiguous(), ids[2].contiguous()))
+    return state, batches
+
+
+def run_step(workload, state, batch, B):
+    if workload == "glove":
+        from esrecsys_amd.wikipedia.train_cooccurence import apply_model, update_model
+        grads, loss = apply_model(state, batch[0], batch[1])
+        return update_model(state, grads), loss
+    from esrecsys_amd.pinterest.train_shop_the_look import train_step
+    if workload == "inbatch":
+        return train_step(state, batch[0], batch[1], None, LAM, B, scale=SCALE)
+    return train_step(state, batch[0], batch[1], batch[2], LAM, B)
+
+
+def cpu_baseline(workload, cfg, budget_s=15.0):
+    """The oracle's CPU port of the same step (oracle/cpu_port.py), timed on this box's host cores on a bounded
+    sample of the same workload.  A restatement, not the reference's JAX executable (not installable here)."""
+    from oracle import cpu_port
+    V, D, B = cfg["V"], cfg["D"], cfg["B"]
+    gen = torch.Generator().manual_seed(SEED)
+    threads = torch.get_num_threads()
+    if workload == "glove":
+        emb = torch.randn((V, D), generator=gen) * D ** -0.5
+        bias = torch.zeros((V, 1))
+        accs = (torch.full((V, D), 0.1), torch.full((V, 1), 0.1))
+
+        def step():
+            inputs = torch.randint(0, V, (2, B), generator=gen)
+            target = torch.exp(np.log(0.1) + torch.rand(B, generator=gen) * np.log(1e4))
+            return cpu_port.glove_step_(emb, bias, accs[0], accs[1], inputs, target, LR)
+    else:
+        st = torch.randn((V, D), generator=gen) * D ** -0.5
+        pt = torch.randn((V, D), generator=gen) * D ** -0.5
+        a_s, a_p = torch.full((V, D), 0.1), torch.full((V, D), 0.1)
+
+        def step():
+            ids = torch.randint(0, V, (3, B), generator=gen)
+            if workload == "inbatch":
+                return cpu_port.inbatch_step_(st, pt, a_s, a_p, ids[0], ids[1], LAM, float(B), SCALE, LR)
+            return cpu_port.triplet_step_(st, pt, a_s, a_p, ids[0], ids[1], ids[2], LAM, float(B), LR)
+    step()  # warm-up
+    t0 = time.perf_counter()
+    step()
+    one = time.perf_counter() - t0
+    n = int(max(3, min(200, budget_s / max(one, 1e-6))))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    dt = time.perf_counter() - t0
+    return {"value": B * n / dt, "unit": cfg["unit"] + "s/s", "cores": threads, "kind": "port",
+            "sample": "%d steps of the same %s workload (B=%d, V=%d, D=%d) with torch-CPU fp32 ops, %d threads, "
+                      "host has %d logical cpus" % (n, workload, B, V, D, threads, os.cpu_count() or 0)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="inbatch", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X: there is no CPU fallback for the product path"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from esrecsys_amd import _lib, ops
+    _lib.load()
+    cfg = WORKLOADS[args.workload]
+    B, D, V = cfg["B"], cfg["D"], cfg["V"]
+
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+        from bench_sharded import run_sharded  # row-sharded step with RCCL all-to-all
+        return run_sharded(args, cfg, dev, rank, world)
+
+    n_batches = args.steps + args.warmup
+    state, batches = make_state_and_batches(args.workload, cfg, dev, n_batches, rank)
+    timer = KernelTimer(ops, {
+        "gather": ["gather_rows"],
+        "inbatch_mfma": ["inbatch_softmax_fwd_bwd"],
+        "triplet_fused": ["triplet_fwd_bwd"],
+        "glove_fused": ["glove_fwd_bwd"],
+        "segment_sort": ["segment_sort"],
+        "sparse_adagrad": ["sparse_adagrad"],
+    })
+    timer.install()
+
+    for i in range(args.warmup):
+        state, loss = run_step(args.workload, state, batches[i], B)
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_batches):
+        state, loss = run_step(args.workload, state, batches[i], B)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    final_loss = float(loss)
+    assert np.isfinite(final_loss), "non-finite loss"
+
+    K = args.steps
+    totals = timer.totals_ms()
+    kernels = {}
+    for g, (ms, calls) in totals.items():
+        if calls:
+            kernels[g] = {"ms_per_step": ms / K, "launch_groups_per_step": calls / K}
+    rows = cfg["rows_per_unit"]
+    # algorithmic bytes: gather D*4 per row occurrence; sparse Adagrad per updated row
+    # grad read D*4 + param RMW 2*D*4 + accumulator RMW 2*D*4
+    gather_bytes = rows * B * D * 4
+    adagrad_bytes = rows * B * D * 4 * 5
+    if args.workload == "inbatch":
+        flops = 6.0 * B * B * D  # S = QC^T, dQ = PC, dC = P^T Q; the kernel recomputes S once more
+        t = kernels["inbatch_mfma"]["ms_per_step"] * 1e-3
+        roofline = {"kernel": "inbatch_kernel<128,{Q,C}side> (2 launches)", "bound": "mfma",
+                    "achieved": flops / t / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": flops / t / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None}
+    else:
+        name = "triplet_fused" if args.workload == "triplet" else "glove_fused"
+        # fused loss kernel: reads `rows` rows and writes `rows` gradient rows per unit
+        nbytes = rows * B * D * 4 * 2
+        t = kernels[name]["ms_per_step"] * 1e-3
+        roofline = {"kernel": name, "bound": "hbm", "achieved": nbytes / t / 1e9, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": nbytes / t / 1e9 / HBM_PEAK_GBS, "traffic": None}
+    hbm = {}
+    if "gather" in kernels:
+        t = kernels["gather"]["ms_per_step"] * 1e-3
+        hbm["gather_GBps"] = 2 * gather_bytes / t / 1e9  # read + write of every gathered row
+    if "sparse_adagrad" in kernels:
+        t = kernels["sparse_adagrad"]["ms_per_step"] * 1e-3
+        hbm["sparse_adagrad_GBps"] = adagrad_bytes / t / 1e9
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            roofline["traffic"] = json.load(open(pmc)).get(args.workload)
+        except Exception:
+            pass
+
+    out = {
+        "metric": "training pairs/sec", "value": B * K / dt, "unit": cfg["unit"] + "s/s", "n_gpus": 1,
+        "steps": K, "warmup": args.warmup, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: V=%d x D=%d fp32 tables, B=%d, sparse Adagrad" % (args.workload, V, D, B),
+                   "parallelism": "single", "loss": final_loss},
+        "roofline": roofline, "kernels": kernels, "hbm_gather_scatter": hbm,
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.workload, cfg)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,223 @@
+"""GPU: the drop-in Python API (same names / argument order / return order as the reference's
+wikipedia/train_cooccurence.py and pinterest/train_shop_the_look.py) against oracle trajectories."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import glove as o_glove
+from oracle import optim as o_optim
+from oracle import stl_head as o_stl
+from oracle import topk as o_topk
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+F64 = np.float64
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def _glove_state(dev, V, D, tx, loss_mode="reference", seed=1701):
+    from esrecsys_amd import TrainState
+    from esrecsys_amd.wikipedia.models import Glove
+    model = Glove(num_embeddings=V, features=D, loss_mode=loss_mode, device=dev)
+    params = model.init(seed, None)
+    # give the bias table non-zero values so the (B,B) quirk is exercised
+    g = torch.Generator().manual_seed(seed + 1)
+    params["params"]["_bias"]["embedding"].copy_((torch.randn((V, 1), generator=g) * 0.05).to(dev))
+    state = TrainState.create(apply_fn=model.apply, params=params["params"], tx=tx)
+    return model, state
+
+
+def test_glove_init_tree_and_apply_shapes(dev):
+    from esrecsys_amd.wikipedia.models import Glove
+    model = Glove(device=dev)
+    assert (model.num_embeddings, model.features) == (1024, 64)  # reference defaults, models.py:12-13
+    variables = model.init(0, None)
+    p = variables["params"]
+    assert p["_token_embedding"]["embedding"].shape == (1024, 64)
+    assert p["_bias"]["embedding"].shape == (1024, 1) and float(p["_bias"]["embedding"].abs().max()) == 0.0
+    std = float(p["_token_embedding"]["embedding"].std())
+    assert abs(std - 64 ** -0.5) < 0.01  # N(0, 1/D)
+    inputs = np.random.default_rng(0).integers(0, 1024, (2, 48)).astype(np.int32)
+    out = model.apply({"params": p}, inputs)
+    assert out.shape == (48, 48) and out.dtype == torch.float32
+    exp = o_glove.forward(N(p["_token_embedding"]["embedding"]).astype(F64), N(p["_bias"]["embedding"]).astype(F64),
+                          inputs, F64)
+    assert rel_err(N(out), exp) <= TOL
+    with pytest.raises(IndexError):
+        model.apply({"params": p}, np.array([[0], [1024]], np.int32))
+
+
+@pytest.mark.parametrize("loss_mode", ["reference", "diagonal"])
+def test_glove_sparse_adagrad_trajectory(dev, loss_mode):
+    """apply_model -> (grads, loss) (grads FIRST), update_model -> state; 5 steps vs the fp64 oracle."""
+    from esrecsys_amd import RowGrads, optim
+    from esrecsys_amd.wikipedia.train_cooccurence import apply_model, update_model
+    V, D, B, lr = 800, 64, 256, 0.05
+    model, state = _glove_state(dev, V, D, optim.sparse_adagrad(lr), loss_mode)
+    emb = N(state.params["_token_embedding"]["embedding"]).astype(F64)
+    bias = N(state.params["_bias"]["embedding"]).astype(F64)
+    a_emb, a_bias = o_optim.adagrad_init(emb), o_optim.adagrad_init(bias)
+    rng = np.random.default_rng(5)
+    for step in range(5):
+        inputs = rng.integers(0, V, (2, B)).astype(np.int32)
+        inputs[0, :40] = 3  # heavy duplicates
+        target = np.exp(rng.uniform(np.log(0.1), np.log(1000), B)).astype(np.float32)
+        grads, loss = apply_model(state, inputs, target)
+        assert isinstance(grads["_token_embedding"]["embedding"], RowGrads)
+        state = update_model(state, grads)
+        el, gdot, gs = o_glove.loss_and_grads(emb, bias, inputs, target, loss_mode, F64)
+        ids, erows, ebias = o_glove.row_grads(emb, inputs, gdot, gs, F64)
+        emb, a_emb = o_optim.sparse_adagrad_update(emb, a_emb, ids, erows, lr, dtype=F64)
+        bias, a_bias = o_optim.sparse_adagrad_update(bias, a_bias, ids, ebias[:, None], lr, dtype=F64)
+        assert loss.shape == () and abs(float(loss) - el) / abs(el) <= TOL
+        assert state.step == step + 1
+    assert rel_err(N(state.params["_token_embedding"]["embedding"]), emb) <= TOL
+    assert rel_err(N(state.params["_bias"]["embedding"]), bias) <= TOL
+
+
+def test_glove_reference_faithful_dense_adam_trajectory(dev):
+    """The reference's own configuration: dense grads tree + optax.adam on every row (train_cooccurence.py:171)."""
+    from esrecsys_amd import optim
+    from esrecsys_amd.wikipedia.train_cooccurence import apply_model, update_model
+    V, D, B, lr = 300, 16, 64, 1e-3
+    model, state = _glove_state(dev, V, D, optim.adam(lr))
+    emb = N(state.params["_token_embedding"]["embedding"]).astype(F64)
+    bias = N(state.params["_bias"]["embedding"]).astype(F64)
+    emb0 = emb.copy()
+    s_emb, s_bias = o_optim.adam_init(emb), o_optim.adam_init(bias)
+    rng = np.random.default_rng(6)
+    for step in range(4):
+        inputs = rng.integers(0, V, (2, B)).astype(np.int32)
+        target = rng.uniform(0.01, 300, B).astype(np.float32)
+        grads, loss = apply_model(state, inputs, target)
+        ge = grads["_token_embedding"]["embedding"]
+        assert isinstance(ge, torch.Tensor) and ge.shape == (V, D) and grads["_bias"]["embedding"].shape == (V, 1)
+        eg, el = o_glove.dense_grads(emb, bias, inputs, target, "reference", F64)
+        assert rel_err(N(ge), eg["_token_embedding"]["embedding"]) <= TOL
+        assert rel_err(N(grads["_bias"]["embedding"]), eg["_bias"]["embedding"]) <= TOL
+        assert abs(float(loss) - el) / abs(el) <= TOL
+        state = update_model(state, grads)
+        emb, s_emb = o_optim.adam_update(emb, eg["_token_embedding"]["embedding"], s_emb, lr, dtype=F64)
+        bias, s_bias = o_optim.adam_update(bias, eg["_bias"]["embedding"], s_bias, lr, dtype=F64)
+    # Adam's first steps are ~lr * sign(g): compare the DISPLACEMENT, which is what the optimizer computes
+    got = N(state.params["_token_embedding"]["embedding"]).astype(F64)
+    assert rel_err(got - emb0, emb - emb0) <= 1e-3
+    assert rel_err(got, emb) <= 1e-6
+    assert state.opt_state["count"] == 4
+
+
+def test_train_epoch_and_find_knn(dev):
+    from esrecsys_amd import optim
+    from esrecsys_amd.wikipedia.train_cooccurence import find_knn, train_epoch
+    V, D, B = 500, 32, 128
+    model, state = _glove_state(dev, V, D, optim.sparse_adagrad(0.05))
+    rng = np.random.default_rng(1)
+
+    def it():
+        while True:
+            yield (rng.integers(0, V, (2, B)).astype(np.int32), rng.uniform(0.1, 300, B).astype(np.float32))
+
+    gen = it()
+    state, l0 = train_epoch(state, 10, gen)
+    state, l1 = train_epoch(state, 30, gen)
+    assert np.isfinite(l0) and l1 < l0 and state.step == 40  # loss goes down on a stationary stream
+    token = np.array([1, 2, 3, 499, 0, 7, 8, 9], np.int32)
+    scores, indices = find_knn(model, state.params, token)
+    assert scores.shape == (V, 8) and indices.shape == (V, 8) and indices.dtype == torch.int32
+    es, ei = o_glove.find_knn(N(state.params["_token_embedding"]["embedding"]), token, F64)
+    assert rel_err(N(scores), es) <= TOL
+    got = N(scores)
+    for t in range(8):  # ascending along axis 0, a permutation of all rows
+        col = got[N(indices)[:, t], t]
+        assert np.all(np.diff(col) >= 0)
+        assert np.array_equal(np.sort(N(indices)[:, t]), np.arange(V))
+    assert np.mean(N(indices)[-10:] == ei[-10:]) > 0.95  # the 10 nearest the reference prints
+
+
+def _stl_state(dev, Vs, Vp, D, tx, seed=0):
+    from esrecsys_amd import TrainState
+    from esrecsys_amd.pinterest.models import STLModel
+    stl = STLModel(output_size=D, num_scenes=Vs, num_products=Vp, device=dev)
+    params = stl.init(seed, None, None, None)
+    for k in ("scene_tower", "product_tower"):  # norms on both sides of 1 so the regulariser is active
+        params["params"][k]["embedding"].mul_(1.4)
+    return stl, TrainState.create(apply_fn=stl.apply, params=params, tx=tx)
+
+
+def test_stl_model_call_returns_reference_5_tuple(dev):
+    from esrecsys_amd import optim
+    stl, state = _stl_state(dev, 100, 200, 32, optim.sparse_adagrad(0.1))
+    rng = np.random.default_rng(0)
+    sc, po, ne = (rng.integers(0, n, 16).astype(np.int32) for n in (100, 200, 200))
+    result, new_model_state = state.apply_fn(state.params, sc, po, ne, True, mutable=["batch_stats"])
+    pos_score, neg_score, se, pe, nee = result
+    st = N(state.params["params"]["scene_tower"]["embedding"])
+    pt = N(state.params["params"]["product_tower"]["embedding"])
+    assert np.array_equal(N(se), st[sc]) and np.array_equal(N(pe), pt[po]) and np.array_equal(N(nee), pt[ne])
+    eps_, ens_ = o_stl.scores(st[sc], pt[po], pt[ne], F64)
+    assert rel_err(N(pos_score), eps_) <= TOL and rel_err(N(neg_score), ens_) <= TOL
+    from esrecsys_amd.pinterest.models import STLModel, score_head
+    ps2, ns2 = score_head(se, pe, nee)
+    assert torch.equal(ps2, pos_score) and torch.equal(ns2, neg_score)
+    assert torch.equal(stl.apply(state.params, sc, method=STLModel.get_scene_embed), se)
+
+
+def test_stl_train_step_trajectory_and_eval(dev):
+    from esrecsys_amd import optim
+    from esrecsys_amd.pinterest.train_shop_the_look import eval_step, train_step
+    Vs, Vp, D, B, lr, lam = 400, 900, 32, 128, 0.05, 0.1
+    stl, state = _stl_state(dev, Vs, Vp, D, optim.sparse_adagrad(lr))
+    st = N(state.params["params"]["scene_tower"]["embedding"]).astype(F64)
+    pt = N(state.params["params"]["product_tower"]["embedding"]).astype(F64)
+    a_s, a_p = o_optim.adagrad_init(st), o_optim.adagrad_init(pt)
+    rng = np.random.default_rng(2)
+    for step in range(5):
+        sc, po, ne = (rng.integers(0, n, B).astype(np.int32) for n in (Vs, Vp, Vp))
+        po[:20] = ne[:20]  # the same product row as positive and negative of different triplets
+        ev = eval_step(state, sc, po, ne)
+        assert abs(float(ev) - o_stl.eval_loss(st[sc], pt[po], pt[ne], F64)) <= TOL * max(1.0, abs(float(ev)))
+        state, loss = train_step(state, sc, po, ne, lam, B)
+        el, gs, gp, gn = o_stl.triplet_loss_and_grads(st[sc], pt[po], pt[ne], lam, B, F64)
+        assert abs(float(loss) - el) / abs(el) <= TOL
+        st, a_s = o_optim.sparse_adagrad_update(st, a_s, sc, gs, lr, dtype=F64)
+        pt, a_p = o_optim.sparse_adagrad_update(pt, a_p, np.concatenate([po, ne]), np.concatenate([gp, gn]), lr,
+                                                dtype=F64)
+    assert state.step == 5
+    assert rel_err(N(state.params["params"]["scene_tower"]["embedding"]), st) <= TOL
+    assert rel_err(N(state.params["params"]["product_tower"]["embedding"]), pt) <= TOL
+
+
+def test_stl_inbatch_train_step(dev):
+    from esrecsys_amd import optim
+    from esrecsys_amd.pinterest.train_shop_the_look import train_step
+    Vs, Vp, D, B, lr, lam, scale = 3000, 5000, 128, 512, 0.05, 0.1, 4.0
+    stl, state = _stl_state(dev, Vs, Vp, D, optim.sparse_adagrad(lr))
+    st = N(state.params["params"]["scene_tower"]["embedding"]).astype(F64)
+    pt = N(state.params["params"]["product_tower"]["embedding"]).astype(F64)
+    a_s, a_p = o_optim.adagrad_init(st), o_optim.adagrad_init(pt)
+    rng = np.random.default_rng(3)
+    losses = []
+    for step in range(3):
+        sc, po = rng.integers(0, Vs, B).astype(np.int32), rng.integers(0, Vp, B).astype(np.int32)
+        state, loss = train_step(state, sc, po, None, lam, B, scale=scale)
+        el, _, gq, gc = o_stl.inbatch_softmax_loss_and_grads(st[sc], pt[po], lam, B, scale, F64)
+        assert abs(float(loss) - el) / abs(el) <= TOL
+        st, a_s = o_optim.sparse_adagrad_update(st, a_s, sc, gq, lr, dtype=F64)
+        pt, a_p = o_optim.sparse_adagrad_update(pt, a_p, po, gc, lr, dtype=F64)
+        losses.append(float(loss))
+    assert rel_err(N(state.params["params"]["scene_tower"]["embedding"]), st) <= TOL
+    assert rel_err(N(state.params["params"]["product_tower"]["embedding"]), pt) <= TOL
+
+
+def test_find_top_k_drop_in(dev):
+    from esrecsys_amd.pinterest.make_recommendations import find_top_k
+    g = load_golden("topk_n500_d8_k10")
+    scores, idx = find_top_k(g["query"], g["cand"], 10)  # numpy in, like the reference's json-loaded arrays
+    assert scores.shape == (10,) and idx.shape == (10,)
+    assert np.array_equal(N(idx), g["topk_indices"]) and np.array_equal(N(scores), g["topk_scores"].astype(np.float32))
+    es, ei = o_topk.find_top_k(g["query"], g["cand"], 10, F64)
+    assert np.array_equal(N(idx), ei)

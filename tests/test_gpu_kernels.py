@@ -1,0 +1,424 @@
+"""GPU parity tests: every HIP kernel, through the C ABI, against the CPU oracle / golden fixtures.
+
+Bar (north_star): bit-exact for integer / index / gather work; <= 1e-5 relative (max-abs error over the
+max-abs of the expected tensor) for fp32 loss and gradients.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import glove as o_glove
+from oracle import optim as o_optim
+from oracle import shard as o_shard
+from oracle import stl_head as o_stl
+from oracle import topk as o_topk
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5  # fp32 loss / grad tolerance stated by north_star
+F64 = np.float64
+
+
+def T(x, dev, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    return t.to(dtype) if dtype is not None else t
+
+
+def N(t):
+    return t.detach().float().cpu().numpy() if t.dtype == torch.bfloat16 else t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------
+# gather (bit-exact)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D", [1, 3, 32, 64, 96, 128, 256, 512])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gather_rows_bit_exact(dev, D, dtype):
+    from esrecsys_amd import ops
+    g = torch.Generator().manual_seed(D)
+    V, n = 5000, 777  # n not a multiple of 64
+    table = torch.randn((V, D), generator=g).to(dtype).to(dev)
+    ids = torch.randint(0, V, (n,), generator=g, dtype=torch.int32)
+    ids[0], ids[1], ids[2], ids[3] = 0, V - 1, 5, 5  # edge ids + a duplicate
+    out = ops.gather_rows(table, ids.to(dev))
+    exp = table.cpu()[ids.long()]
+    assert torch.equal(out.cpu().view(torch.int16 if dtype == torch.bfloat16 else torch.int32),
+                       exp.view(torch.int16 if dtype == torch.bfloat16 else torch.int32))
+
+
+def test_gather_rows_empty_and_single(dev):
+    from esrecsys_amd import ops
+    table = torch.randn((10, 8), device=dev)
+    assert ops.gather_rows(table, torch.zeros(0, dtype=torch.int32, device=dev)).shape == (0, 8)
+    out = ops.gather_rows(table, torch.tensor([9], dtype=torch.int32, device=dev))
+    assert torch.equal(out[0], table[9])
+
+
+def test_gather_full_size_checksum(dev):
+    """BASELINE config C2 shape: 1M x 128 fp32 table, 2^20 ids; checksum of rows == checksum via torch indexing."""
+    from esrecsys_amd import ops
+    g = torch.Generator(device=dev).manual_seed(1701)
+    V, D, n = 1_000_000, 128, 1 << 20
+    table = torch.randn((V, D), generator=g, device=dev)
+    ids = torch.randint(0, V, (n,), generator=g, device=dev, dtype=torch.int32)
+    out = ops.gather_rows(table, ids)
+    exp = table[ids.long()]
+    assert torch.equal(out.view(torch.int32), exp.view(torch.int32))
+
+
+def test_unpermute_rows(dev):
+    from esrecsys_amd import ops
+    g = torch.Generator().manual_seed(3)
+    n, D = 1000, 128
+    rows = torch.randn((n, D), generator=g).to(dev)
+    perm = torch.randperm(n, generator=g).to(torch.int32).to(dev)
+    out = ops.unpermute_rows(rows, perm)
+    exp = torch.empty_like(rows)
+    exp[perm.long()] = rows
+    assert torch.equal(out, exp)
+
+
+# ------------------------------------------------------------------------------------------------
+# GloVe
+# ------------------------------------------------------------------------------------------------
+GLOVE_CASES = ["glove_uniform_d16_b64", "glove_uniform_d64_b128", "glove_same_d16_b64", "glove_zipf_d64_b128"]
+
+
+def _dense_from_rows(V, D, ids, rows):
+    out = np.zeros((V, D), F64)
+    np.add.at(out, ids.astype(np.int64), rows.astype(F64).reshape(len(ids), D))
+    return out
+
+
+@pytest.mark.parametrize("case", GLOVE_CASES)
+@pytest.mark.parametrize("mode", ["reference", "diagonal"])
+def test_glove_fwd_bwd_vs_golden(dev, case, mode):
+    from esrecsys_amd import ops
+    g = load_golden(case)
+    emb, bias = T(g["emb"], dev), T(g["bias"], dev)
+    inputs, target = T(g["inputs"], dev), T(g["target"], dev)
+    m = ops.GLOVE_REFERENCE if mode == "reference" else ops.GLOVE_DIAGONAL
+    loss, grows, gbias = ops.glove_fwd_bwd(emb, bias, inputs, target, m)
+    assert abs(float(loss) - g["loss_" + mode]) / abs(g["loss_" + mode]) <= TOL
+    V, D = g["emb"].shape
+    ids = g["inputs"].reshape(-1)
+    assert rel_err(_dense_from_rows(V, D, ids, N(grows)), g["gemb_" + mode]) <= TOL
+    assert rel_err(_dense_from_rows(V, 1, ids, N(gbias)), g["gbias_" + mode]) <= TOL
+    # the dense gradient the reference materialises, through sort + segment-sum on the GPU
+    sid, perm = ops.segment_sort(inputs.reshape(-1), V)
+    dense = ops.rows_to_dense(V, D, sid, perm, grows)
+    assert rel_err(N(dense), g["gemb_" + mode]) <= TOL
+
+
+@pytest.mark.parametrize("case", GLOVE_CASES[:2])
+def test_glove_forward_bb_output(dev, case):
+    from esrecsys_amd import ops
+    g = load_golden(case)
+    dot, s = ops.glove_forward(T(g["emb"], dev), T(g["bias"], dev), T(g["inputs"], dev))
+    pred = N(dot)[None, :] + N(s)[:, None]
+    assert pred.shape == g["pred_reference"].shape
+    assert rel_err(pred, g["pred_reference"]) <= TOL
+
+
+@pytest.mark.parametrize("D,B", [(4, 7), (100, 65), (256, 2048), (512, 300), (3, 50), (1024, 64)])
+def test_glove_shapes_vs_oracle(dev, D, B):
+    """D not a power of two / not a multiple of 4, B not a multiple of the block, duplicates."""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(D * 1000 + B)
+    V = 500
+    emb = (rng.standard_normal((V, D)) / np.sqrt(D)).astype(np.float32)
+    bias = (rng.standard_normal((V, 1)) * 0.1).astype(np.float32)
+    inputs = rng.integers(0, V, (2, B)).astype(np.int32)
+    inputs[:, : B // 3] = inputs[:, :1]
+    target = np.exp(rng.uniform(np.log(0.1), np.log(1000), B)).astype(np.float32)
+    for mode, m in (("reference", ops.GLOVE_REFERENCE), ("diagonal", ops.GLOVE_DIAGONAL)):
+        loss, grows, gbias = ops.glove_fwd_bwd(T(emb, dev), T(bias, dev), T(inputs, dev), T(target, dev), m)
+        el, gdot, gs = o_glove.loss_and_grads(emb.astype(F64), bias.astype(F64), inputs, target, mode, F64)
+        _, erows, ebias = o_glove.row_grads(emb.astype(F64), inputs, gdot, gs, F64)
+        assert abs(float(loss) - el) / abs(el) <= TOL
+        assert rel_err(N(grows), erows) <= TOL
+        assert rel_err(N(gbias), ebias) <= TOL
+
+
+def test_glove_config_c3_size_properties(dev):
+    """BASELINE config C3 shape (V=465537, D=256, B=65536): oracle fp64 on the same inputs (loss + a
+    sample of gradient rows), plus linearity: grad rows are gdot * partner row exactly."""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(1701)
+    V, D, B = 400_000 + 65_537, 256, 65_536
+    emb = (rng.standard_normal((V, D), dtype=np.float32) / np.sqrt(D)).astype(np.float32)
+    bias = (rng.standard_normal((V, 1)) * 0.05).astype(np.float32)
+    inputs = rng.integers(0, V, (2, B)).astype(np.int32)
+    target = np.exp(rng.uniform(np.log(0.1), np.log(1000), B)).astype(np.float32)
+    loss, grows, gbias = ops.glove_fwd_bwd(T(emb, dev), T(bias, dev), T(inputs, dev), T(target, dev),
+                                           ops.GLOVE_REFERENCE)
+    el, gdot, gs = o_glove.loss_and_grads(emb, bias, inputs, target, "reference", F64)
+    assert abs(float(loss) - el) / abs(el) <= TOL
+    sel = rng.integers(0, B, 512)
+    exp1 = gdot[sel, None] * emb[inputs[1, sel]].astype(F64)
+    assert rel_err(N(grows[torch.from_numpy(sel).to(dev)]), exp1) <= TOL
+    assert rel_err(N(gbias)[:B], gs) <= TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# STL triplet head
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["stl_b32_d8_lam0", "stl_b32_d8_lam01", "stl_b128_d32_lam01"])
+def test_triplet_head_vs_golden(dev, case):
+    from esrecsys_amd import ops
+    g = load_golden(case)
+    s, p, n = T(g["scene"], dev), T(g["pos"], dev), T(g["neg"], dev)
+    B = s.shape[0]
+    loss, ps, ns, gs, gp, gn = ops.triplet_fwd_bwd(s, p, n, None, None, None, B, float(g["lam"]),
+                                                   float(g["batch_size"]))
+    assert abs(float(loss) - g["loss"]) / abs(g["loss"]) <= TOL
+    assert rel_err(N(ps), g["pos_score"]) <= TOL and rel_err(N(ns), g["neg_score"]) <= TOL
+    assert rel_err(N(gs), g["g_scene"]) <= TOL
+    assert rel_err(N(gp), g["g_pos"]) <= TOL
+    assert rel_err(N(gn), g["g_neg"]) <= TOL
+    # eval_step semantics: plain hinge sum, no reg, not divided (train_shop_the_look.py:118)
+    ev, _, _, _, _, _ = ops.triplet_fwd_bwd(s, p, n, None, None, None, B, 0.0, 1.0, with_reg=False,
+                                            want_grads=False)
+    assert abs(float(ev) - g["eval_loss"]) / abs(g["eval_loss"]) <= TOL
+
+
+@pytest.mark.parametrize("D,B", [(32, 128), (128, 8192), (96, 1000), (64, 33)])
+def test_triplet_with_id_towers_vs_oracle(dev, D, B):
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(D + B)
+    Vs, Vp = 3000, 10_000
+    st = (rng.standard_normal((Vs, D)) * rng.uniform(0.02, 0.25, (Vs, 1))).astype(np.float32)
+    pt = (rng.standard_normal((Vp, D)) * rng.uniform(0.02, 0.25, (Vp, 1))).astype(np.float32)
+    sid = rng.integers(0, Vs, B).astype(np.int32)
+    pid = rng.integers(0, Vp, B).astype(np.int32)
+    nid = rng.integers(0, Vp, B).astype(np.int32)
+    sid[:5], pid[:5], nid[:5] = 0, Vp - 1, Vp - 1
+    loss, ps, ns, gs, gp, gn = ops.triplet_fwd_bwd(T(st, dev), T(pt, dev), T(pt, dev), T(sid, dev), T(pid, dev),
+                                                   T(nid, dev), B, 0.1, B)
+    el, egs, egp, egn = o_stl.triplet_loss_and_grads(st[sid], pt[pid], pt[nid], 0.1, B, F64)
+    assert abs(float(loss) - el) / abs(el) <= TOL
+    assert rel_err(N(gs), egs) <= TOL and rel_err(N(gp), egp) <= TOL and rel_err(N(gn), egn) <= TOL
+    assert gp._base is gn._base and gp._base.shape == (2 * B, D)
+
+
+# ------------------------------------------------------------------------------------------------
+# in-batch softmax (FP32 MFMA)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["inbatch_b64_d32", "inbatch_b96_d64_scale4", "inbatch_b320_d128"])
+def test_inbatch_softmax_vs_golden(dev, case):
+    from esrecsys_amd import ops
+    g = load_golden(case)
+    loss, lse, gq, gc = ops.inbatch_softmax_fwd_bwd(T(g["q"], dev), T(g["c"], dev), float(g["scale"]),
+                                                    float(g["lam"]), float(g["batch_size"]))
+    assert abs(float(loss) - g["loss"]) / abs(g["loss"]) <= TOL
+    assert rel_err(N(lse), g["lse"]) <= TOL
+    assert rel_err(N(gq), g["g_q"]) <= TOL
+    assert rel_err(N(gc), g["g_c"]) <= TOL
+
+
+def test_inbatch_transpose_detecting(dev):
+    """Asymmetric operands: a swapped Q/C role or a transposed MFMA fragment cannot pass."""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(77)
+    B, D = 256, 128
+    q = (rng.standard_normal((B, D)) * 0.3).astype(np.float32)
+    c = (rng.standard_normal((B, D)) * 0.05 + np.linspace(-0.2, 0.2, D)[None, :]).astype(np.float32)
+    q[:, :7] *= 4.0
+    loss, lse, gq, gc = ops.inbatch_softmax_fwd_bwd(T(q, dev), T(c, dev), 3.0, 0.2, B)
+    el, else_, egq, egc = o_stl.inbatch_softmax_loss_and_grads(q, c, 0.2, B, 3.0, F64)
+    assert abs(float(loss) - el) / abs(el) <= TOL
+    assert rel_err(N(lse), else_) <= TOL and rel_err(N(gq), egq) <= TOL and rel_err(N(gc), egc) <= TOL
+
+
+def test_inbatch_config_c2_full_size(dev):
+    """BASELINE config C2: B = 8192, D = 128, fp64 oracle on the same inputs + checksum properties
+    (softmax rows sum to one => column sum of gC vanishes when reg = 0)."""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(1701)
+    B, D = 8192, 128
+    q = (rng.standard_normal((B, D)) / np.sqrt(D)).astype(np.float32)
+    c = (rng.standard_normal((B, D)) / np.sqrt(D)).astype(np.float32)
+    loss, lse, gq, gc = ops.inbatch_softmax_fwd_bwd(T(q, dev), T(c, dev), 8.0, 0.0, B)
+    el, else_, egq, egc = o_stl.inbatch_softmax_loss_and_grads(q, c, 0.0, B, 8.0, F64)
+    assert abs(float(loss) - el) / abs(el) <= TOL
+    assert rel_err(N(lse), else_) <= TOL
+    assert rel_err(N(gq), egq) <= TOL and rel_err(N(gc), egc) <= TOL
+    colsum = N(gc).astype(F64).sum(0)
+    assert np.abs(colsum).max() <= 1e-5 * np.abs(N(gc)).sum(0).max()
+
+
+# ------------------------------------------------------------------------------------------------
+# sort + sparse optimizers
+# ------------------------------------------------------------------------------------------------
+def _ids(kind, rng, V, n):
+    if kind == "uniform":
+        return rng.integers(0, V, n).astype(np.int32)
+    if kind == "same":
+        return np.full(n, V - 1, np.int32)
+    p = 1.0 / np.arange(1, V + 1)
+    return rng.permutation(V)[rng.choice(V, size=n, p=p / p.sum())].astype(np.int32)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "same", "zipf"])
+def test_segment_sort_is_stable_sort(dev, kind):
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(9)
+    V, n = 100_000, 16_384 + 13
+    ids = _ids(kind, rng, V, n)
+    sid, perm = ops.segment_sort(T(ids, dev), V)
+    order = np.argsort(ids, kind="stable")
+    assert np.array_equal(N(perm), order.astype(np.int32))
+    assert np.array_equal(N(sid), ids[order])
+
+
+@pytest.mark.parametrize("kind", ["uniform", "same", "zipf"])
+@pytest.mark.parametrize("D", [1, 16, 128, 256])
+def test_sparse_adagrad_vs_oracle(dev, kind, D):
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(D + len(kind))
+    V, n = 2000, 3000
+    ids = _ids(kind, rng, V, n)
+    p0 = rng.standard_normal((V, D)).astype(np.float32)
+    a0 = np.full((V, D), 0.1, np.float32)
+    rows = (rng.standard_normal((n, D)) * 0.1).astype(np.float32)
+    table, accum = T(p0, dev), T(a0, dev)
+    sid, perm = ops.segment_sort(T(ids, dev), V)
+    ops.sparse_adagrad(table, accum, sid, perm, T(rows, dev), 0.05, 1e-7)
+    ep, ea = o_optim.sparse_adagrad_update(p0, a0, ids, rows, 0.05, 1e-7, np.float32)
+    assert rel_err(N(table), ep) <= TOL and rel_err(N(accum), ea) <= TOL
+    # fp64 oracle as well (the 1e-5 bar is against the exact answer)
+    ep64, ea64 = o_optim.sparse_adagrad_update(p0.astype(F64), a0.astype(F64), ids, rows.astype(F64), 0.05, 1e-7, F64)
+    assert rel_err(N(table), ep64) <= TOL and rel_err(N(accum), ea64) <= TOL
+    untouched = np.setdiff1d(np.arange(V), ids)
+    assert np.array_equal(N(table)[untouched], p0[untouched])  # bit-exact: rows without gradient never move
+
+
+def test_segment_sum_is_bit_exact_sequential(dev):
+    """Duplicate ids are summed left to right in occurrence order == a sequential fp32 scatter-add."""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(4)
+    V, n, D = 50, 4000, 32
+    ids = rng.integers(0, V, n).astype(np.int32)
+    rows = rng.standard_normal((n, D)).astype(np.float32)
+    sid, perm = ops.segment_sort(T(ids, dev), V)
+    dense = N(ops.rows_to_dense(V, D, sid, perm, T(rows, dev)))
+    exp = np.zeros((V, D), np.float32)
+    for k in range(n):
+        exp[ids[k]] = exp[ids[k]] + rows[k]
+    assert np.array_equal(dense, exp)
+
+
+def test_sparse_adagrad_bf16_table(dev):
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(8)
+    V, n, D = 1000, 1500, 128
+    ids = rng.integers(0, V, n).astype(np.int32)
+    p0 = torch.from_numpy(rng.standard_normal((V, D)).astype(np.float32)).to(torch.bfloat16)
+    rows = (rng.standard_normal((n, D)) * 0.1).astype(np.float32)
+    table, accum = p0.to(dev), torch.full((V, D), 0.1, device=dev)
+    sid, perm = ops.segment_sort(T(ids, dev), V)
+    ops.sparse_adagrad(table, accum, sid, perm, T(rows, dev), 0.05, 1e-7)
+    ep, ea = o_optim.sparse_adagrad_update(p0.float().numpy().astype(F64), np.full((V, D), 0.1), ids,
+                                           rows.astype(F64), 0.05, 1e-7, F64)
+    exp_bf16 = torch.from_numpy(ep).to(torch.bfloat16).float().numpy()
+    got = N(table)
+    # result is the fp64 answer rounded to bf16 (RNE), up to one bf16 ulp where fp32 rounding straddles a tie
+    assert np.mean(got == exp_bf16) > 0.999
+    assert rel_err(got, ep) <= 2.0 ** -8
+    assert rel_err(N(accum), ea) <= TOL
+
+
+def test_sparse_sgd_vs_oracle(dev):
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(12)
+    V, n, D = 300, 1000, 64
+    ids = rng.integers(0, V, n).astype(np.int32)
+    p0 = rng.standard_normal((V, D)).astype(np.float32)
+    rows = rng.standard_normal((n, D)).astype(np.float32)
+    table = T(p0, dev)
+    sid, perm = ops.segment_sort(T(ids, dev), V)
+    ops.sparse_sgd(table, sid, perm, T(rows, dev), 0.01)
+    g = np.zeros((V, D), F64)
+    np.add.at(g, ids, rows.astype(F64))
+    assert rel_err(N(table), p0 - 0.01 * g) <= TOL
+
+
+def test_dense_adam_vs_golden(dev):
+    from esrecsys_amd import ops
+    g = load_golden("optim_v64_d8")
+    p = T(g["p0"], dev)
+    mu, nu = torch.zeros_like(p), torch.zeros_like(p)
+    for k in range(3):
+        ops.dense_adam(p, mu, nu, T(g["adam_grads"][k], dev), 1e-3, k + 1)
+        # Adam divides small numbers: compare the UPDATE, not just the parameter
+        assert rel_err(N(p), g["adam_params"][k]) <= 1e-6
+        step_exp = g["adam_params"][k] - (g["adam_params"][k - 1] if k else g["p0"].astype(F64))
+        step_got = N(p).astype(F64) - (g["adam_params"][k - 1] if k else g["p0"].astype(F64))
+        assert np.abs(step_got - step_exp).max() <= 5e-7  # one fp32 ulp of the O(1) parameters
+
+
+def test_dense_adam_odd_length_tail(dev):
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(2)
+    n = 4 * 1000 + 3
+    p0, g = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    p = T(p0, dev)
+    mu, nu = torch.zeros_like(p), torch.zeros_like(p)
+    ops.dense_adam(p, mu, nu, T(g, dev), 1e-2, 1)
+    ep, _ = o_optim.adam_update(p0.astype(F64), g.astype(F64), o_optim.adam_init(p0.astype(F64)), 1e-2, dtype=F64)
+    assert np.abs(N(p) - ep).max() <= 1e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# retrieval
+# ------------------------------------------------------------------------------------------------
+def test_score_all_and_argsort_vs_golden_with_ties(dev):
+    from esrecsys_amd import ops
+    g = load_golden("topk_n500_d8_k10")
+    emb = T(g["cand"], dev)
+    scores = ops.score_all(emb, T(g["token"], dev))
+    assert scores.shape == (500, 5)
+    assert np.array_equal(N(scores), g["knn_scores"].astype(np.float32))  # small integers: exact
+    idx = ops.argsort_columns(scores)
+    assert idx.dtype == torch.int32 and np.array_equal(N(idx), g["knn_indices"])
+
+
+def test_find_top_k_vs_golden_with_ties(dev):
+    from esrecsys_amd import ops
+    g = load_golden("topk_n500_d8_k10")
+    s, i = ops.score_topk(T(g["query"], dev), T(g["cand"], dev), int(g["k"]))
+    assert np.array_equal(N(i)[0], g["topk_indices"])
+    assert np.array_equal(N(s)[0], g["topk_scores"].astype(np.float32))
+
+
+@pytest.mark.parametrize("nq,N_,D,k", [(1, 100_000, 128, 10), (3, 20_000, 512, 500), (5, 999, 96, 999)])
+def test_score_topk_random_vs_oracle(dev, nq, N_, D, k):
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(nq + k)
+    q = rng.standard_normal((nq, D)).astype(np.float32)
+    c = rng.standard_normal((N_, D)).astype(np.float32)
+    s, i = ops.score_topk(T(q, dev), T(c, dev), k)
+    es, ei = o_topk.batched_top_k(q, c, k, F64)
+    got_s = N(s)
+    assert rel_err(got_s, es) <= TOL
+    assert np.all(np.diff(got_s, axis=1) <= 0)
+    # indices may legitimately differ only where fp32 scores tie / nearly tie: check by score instead
+    full = q.astype(F64) @ c.astype(F64).T
+    picked = np.take_along_axis(full, N(i).astype(np.int64), axis=1)
+    assert rel_err(picked, es) <= TOL
+    assert np.mean(N(i) == ei) > 0.99
+
+
+# ------------------------------------------------------------------------------------------------
+# shard routing
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_bucket_ids_by_owner_vs_oracle(dev, world):
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(world)
+    ids = rng.integers(0, 1_000_000, 16_384 + 5).astype(np.int32)
+    local, perm, counts = ops.bucket_ids_by_owner(T(ids, dev), world)
+    el, ec, ep = o_shard.bucket_by_owner(ids, world)
+    assert np.array_equal(N(counts), ec)
+    assert np.array_equal(N(perm), ep)
+    assert np.array_equal(N(local), el)
