@@ -159,6 +159,17 @@ def cpu_baseline(workload, cfg, budget_s=15.0):
                       "host has %d logical cpus" % (n, workload, B, V, D, threads, os.cpu_count() or 0)}
 
 
+def emit(obj):
+    """Print the ONE JSON line last: flush C stdio first (RCCL prints a version banner through printf)."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(obj), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,10 +193,12 @@ def main():
     cfg = WORKLOADS[args.workload]
     B, D, V = cfg["B"], cfg["D"], cfg["V"]
 
-    if world > 1:
+    if world > 1 or os.environ.get("ESR_BENCH_SHARDED") == "1":  # the env switch runs the sharded leg on one rank
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         from bench_sharded import run_sharded  # row-sharded step with RCCL all-to-all
         return run_sharded(args, cfg, dev, rank, world)
 
@@ -262,7 +275,7 @@ def main():
     }
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload, cfg)
-    print(json.dumps(out))
+    emit(out)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,70 @@
+"""TEST DOUBLE (tests/ only): an oracle-backed, CPU implementation of the `kernels` interface that
+esrecsys_amd/sharded.py is written against, so the all-to-all routing logic can be exercised with the
+gloo backend in a GPU-less container.  Never imported by the product."""
+import numpy as np
+import torch
+
+from oracle import glove as o_glove
+from oracle import optim as o_optim
+from oracle import shard as o_shard
+from oracle import stl_head as o_stl
+
+GLOVE_REFERENCE, GLOVE_DIAGONAL = 0, 1
+
+
+def _t(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.to(dtype) if dtype is not None else t
+
+
+def bucket_ids_by_owner(ids, world):
+    local, counts, perm = o_shard.bucket_by_owner(ids.numpy(), world)
+    return _t(local), _t(perm), _t(counts)
+
+
+def gather_rows(table, ids):
+    return table[ids.long()].contiguous()
+
+
+def unpermute_rows(rows, perm):
+    out = torch.empty_like(rows)
+    out[perm.long()] = rows
+    return out
+
+
+def segment_sort(ids, V):
+    order = np.argsort(ids.numpy(), kind="stable").astype(np.int32)
+    return _t(ids.numpy()[order]), _t(order)
+
+
+def sparse_adagrad(table, accum, sorted_ids, perm, grad_rows, lr, eps=1e-7):
+    ids = sorted_ids.numpy()
+    rows = grad_rows.numpy()[perm.numpy()]
+    p, a = o_optim.sparse_adagrad_update(table.numpy(), accum.numpy(), ids, rows.reshape(len(ids), -1), lr, eps,
+                                         np.float64)
+    table.copy_(_t(p.reshape(table.shape)))
+    accum.copy_(_t(a.reshape(accum.shape)))
+
+
+class _Halves(torch.Tensor):
+    pass
+
+
+def triplet_fwd_bwd(s, p, n, sid, pid, nid, B, lam, bs, with_reg=True, want_grads=True, want_scores=True):
+    assert sid is None and pid is None and nid is None
+    loss, gs, gp, gn = o_stl.triplet_loss_and_grads(s.numpy(), p.numpy(), n.numpy(), lam, bs, np.float64)
+    gpn = _t(np.concatenate([gp, gn]))
+    return _t(np.array([loss])), None, None, _t(gs), gpn[:B], gpn[B:]
+
+
+def inbatch_softmax_fwd_bwd(q, c, scale, lam, bs):
+    loss, lse, gq, gc = o_stl.inbatch_softmax_loss_and_grads(q.numpy(), c.numpy(), lam, bs, scale, np.float64)
+    return _t(np.array([loss])), _t(lse), _t(gq), _t(gc)
+
+
+def glove_fwd_bwd(emb, bias, inputs, target, mode=GLOVE_REFERENCE, want_grads=True):
+    m = "reference" if mode == GLOVE_REFERENCE else "diagonal"
+    e, b = emb.numpy().astype(np.float64), bias.numpy().astype(np.float64)
+    loss, gdot, gs = o_glove.loss_and_grads(e, b, inputs.numpy(), target.numpy(), m, np.float64)
+    _, rows, gb = o_glove.row_grads(e, inputs.numpy(), gdot, gs, np.float64)
+    return _t(np.array([loss])), _t(rows), _t(gb)

@@ -1,0 +1,68 @@
+"""GPU: the row-sharded step through RCCL with a world of one rank (the driver owns the 8-GPU runs):
+exercises bucket / all_to_all_single / un-permute / grad routing with the real kernels and checks it is
+identical to the single-device path."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pg(dev):
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    yield dist
+    dist.destroy_process_group()
+
+
+def test_sharded_world1_equals_single_device(dev, pg):
+    from esrecsys_amd import TrainState, ops, optim, sharded
+    from esrecsys_amd.pinterest.models import STLModel
+    from esrecsys_amd.pinterest.train_shop_the_look import train_step
+    Vs, Vp, D, B, lam, lr = 5000, 7000, 128, 1024, 0.1, 0.05
+    stl = STLModel(output_size=D, num_scenes=Vs, num_products=Vp, device=dev)
+    params = stl.init(0)
+    state = TrainState.create(apply_fn=stl.apply, params=params, tx=optim.sparse_adagrad(lr))
+    st = params["params"]["scene_tower"]["embedding"].clone()
+    pt = params["params"]["product_tower"]["embedding"].clone()
+    scene = sharded.RowShardedTable(st, torch.full_like(st, 0.1), Vs, kernels=ops)
+    prod = sharded.RowShardedTable(pt, torch.full_like(pt, 0.1), Vp, kernels=ops)
+    rng = np.random.default_rng(0)
+    for step in range(3):
+        sid, pid, nid = (torch.from_numpy(rng.integers(0, n, B).astype(np.int32)).to(dev) for n in (Vs, Vp, Vp))
+        if step % 2 == 0:
+            l_sh = sharded.sharded_triplet_step(scene, prod, sid, pid, nid, lam, float(B), lr)
+            state, l_1 = train_step(state, sid, pid, nid, lam, B)
+        else:
+            l_sh = sharded.sharded_inbatch_step(scene, prod, sid, pid, lam, float(B), 4.0, lr)
+            state, l_1 = train_step(state, sid, pid, None, lam, B, scale=4.0)
+        assert abs(float(l_sh) - float(l_1)) <= 1e-6 * abs(float(l_1))
+    # same kernels, same occurrence order -> identical tables
+    assert torch.equal(scene.local, state.params["params"]["scene_tower"]["embedding"])
+    assert torch.equal(prod.local, state.params["params"]["product_tower"]["embedding"])
+
+
+def test_sharded_glove_world1(dev, pg):
+    from esrecsys_amd import ops, sharded
+    from oracle import glove as o_glove
+    V, D, B = 3000, 64, 512
+    g = torch.Generator().manual_seed(1)
+    emb0 = (torch.randn((V, D), generator=g) * D ** -0.5)
+    bias0 = torch.randn((V, 1), generator=g) * 0.05
+    emb = sharded.RowShardedTable(emb0.to(dev), torch.full((V, D), 0.1, device=dev), V, kernels=ops)
+    bias = sharded.RowShardedTable(bias0.to(dev), torch.full((V, 1), 0.1, device=dev), V, kernels=ops)
+    rng = np.random.default_rng(2)
+    inputs = rng.integers(0, V, (2, B)).astype(np.int32)
+    target = rng.uniform(0.1, 300, B).astype(np.float32)
+    loss = sharded.sharded_glove_step(emb, bias, torch.from_numpy(inputs).to(dev), torch.from_numpy(target).to(dev),
+                                      ops.GLOVE_REFERENCE, 0.05)
+    el, _, _ = o_glove.loss_and_grads(emb0.numpy().astype(np.float64), bias0.numpy().astype(np.float64), inputs,
+                                      target, "reference", np.float64)
+    assert abs(float(loss) - el) / abs(el) <= 1e-5
+    assert not torch.equal(emb.local.cpu(), emb0)  # rows moved

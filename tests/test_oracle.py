@@ -130,3 +130,44 @@ def test_bucket_by_owner_roundtrip():
         for g in range(world):
             pos = perm[owners == g]
             assert np.all(np.diff(pos) > 0)
+
+
+def test_cpu_port_matches_oracle():
+    """oracle/cpu_port.py (the in-place torch-CPU port bench.py times as cpu_baseline) == the NumPy oracle."""
+    import torch
+    from oracle import cpu_port
+    rng = np.random.default_rng(0)
+    V, D, B, lam, lr = 200, 16, 64, 0.1, 0.05
+    st0, pt0 = (rng.standard_normal((V, D)) * 0.4 for _ in range(2))
+    sid, pid, nid = (rng.integers(0, V, B) for _ in range(3))
+    t = lambda a: torch.from_numpy(a.copy())  # noqa: E731
+    # in-batch
+    st, pt, a_s, a_p = t(st0), t(pt0), torch.full((V, D), 0.1, dtype=torch.float64), torch.full((V, D), 0.1, dtype=torch.float64)
+    loss = cpu_port.inbatch_step_(st, pt, a_s, a_p, t(sid), t(pid), lam, float(B), 2.0, lr)
+    el, _, gq, gc = stl_head.inbatch_softmax_loss_and_grads(st0[sid], pt0[pid], lam, B, 2.0, F64)
+    es, _ = optim.sparse_adagrad_update(st0, np.full((V, D), 0.1), sid, gq, lr, dtype=F64)
+    ep, _ = optim.sparse_adagrad_update(pt0, np.full((V, D), 0.1), pid, gc, lr, dtype=F64)
+    assert abs(float(loss) - el) <= 1e-12 and np.abs(st.numpy() - es).max() <= 1e-12
+    assert np.abs(pt.numpy() - ep).max() <= 1e-12
+    # triplet
+    st, pt, a_s, a_p = t(st0), t(pt0), torch.full((V, D), 0.1, dtype=torch.float64), torch.full((V, D), 0.1, dtype=torch.float64)
+    loss = cpu_port.triplet_step_(st, pt, a_s, a_p, t(sid), t(pid), t(nid), lam, float(B), lr)
+    el, gs, gp, gn = stl_head.triplet_loss_and_grads(st0[sid], pt0[pid], pt0[nid], lam, B, F64)
+    es, _ = optim.sparse_adagrad_update(st0, np.full((V, D), 0.1), sid, gs, lr, dtype=F64)
+    ep, _ = optim.sparse_adagrad_update(pt0, np.full((V, D), 0.1), np.concatenate([pid, nid]),
+                                        np.concatenate([gp, gn]), lr, dtype=F64)
+    assert abs(float(loss) - el) <= 1e-12 and np.abs(st.numpy() - es).max() <= 1e-12
+    assert np.abs(pt.numpy() - ep).max() <= 1e-12
+    # glove
+    emb0, bias0 = rng.standard_normal((V, D)) * 0.3, rng.standard_normal((V, 1)) * 0.05
+    inputs = rng.integers(0, V, (2, B))
+    target = rng.uniform(0.1, 300, B)
+    emb, bias = t(emb0), t(bias0)
+    ae, ab = torch.full((V, D), 0.1, dtype=torch.float64), torch.full((V, 1), 0.1, dtype=torch.float64)
+    loss = cpu_port.glove_step_(emb, bias, ae, ab, t(inputs), t(target), lr)
+    el, gdot, gs_ = glove.loss_and_grads(emb0, bias0, inputs, target, "reference", F64)
+    ids, rows, gb = glove.row_grads(emb0, inputs, gdot, gs_, F64)
+    ee, _ = optim.sparse_adagrad_update(emb0, np.full((V, D), 0.1), ids, rows, lr, dtype=F64)
+    eb, _ = optim.sparse_adagrad_update(bias0, np.full((V, 1), 0.1), ids, gb[:, None], lr, dtype=F64)
+    assert abs(float(loss) - el) <= 1e-12 and np.abs(emb.numpy() - ee).max() <= 1e-12
+    assert np.abs(bias.numpy() - eb).max() <= 1e-12
