@@ -108,6 +108,9 @@ def make_state_and_batches(workload, cfg, dev, n_batches, rank):
     return state, batches
 
 
+PRECISION = "auto"
+
+
 def run_step(workload, state, batch, B):
     if workload == "glove":
         from esrecsys_amd.wikipedia.train_cooccurence import apply_model, update_model
@@ -115,7 +118,7 @@ def run_step(workload, state, batch, B):
         return update_model(state, grads), loss
     from esrecsys_amd.pinterest.train_shop_the_look import train_step
     if workload == "inbatch":
-        return train_step(state, batch[0], batch[1], None, LAM, B, scale=SCALE)
+        return train_step(state, batch[0], batch[1], None, LAM, B, scale=SCALE, precision=PRECISION)
     return train_step(state, batch[0], batch[1], batch[2], LAM, B)
 
 
@@ -177,7 +180,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="inbatch", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="auto", choices=["auto", "f32", "bf16x3"],
+                    help="MFMA path of the in-batch score kernel (both are f32-grade; see DESIGN.md 2.2)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step as one hipGraph (measured slower than eager launches on MI355X: the step "
+                         "is GPU-dependency-bound, not host-bound)")
     args = ap.parse_args()
+    global PRECISION
+    PRECISION = args.precision
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -214,18 +224,47 @@ def main():
     })
     timer.install()
 
+    # ---- timed region: K steps (eager launches; --graph replays the whole step as one hipGraph) ----------------
+    graphed, mode = None, "eager"
+    if args.graph:
+        try:
+            from esrecsys_amd.graph import GraphedStep
+            holder = {"state": state}
+
+            def captured(*tensors):
+                holder["state"], l = run_step(args.workload, holder["state"], tensors, B)
+                return l
+            graphed = GraphedStep(captured, batches[0])
+            mode = "hipgraph"
+        except Exception as e:  # capture is an optimisation, never a requirement
+            graphed, mode = None, "eager (graph capture failed: %s)" % str(e).splitlines()[0][:120]
+            torch.cuda.synchronize()
+
+    def one_step(i):
+        nonlocal state
+        if graphed is not None:
+            return graphed(*batches[i])
+        state, l = run_step(args.workload, state, batches[i], B)
+        return l
+
     for i in range(args.warmup):
-        state, loss = run_step(args.workload, state, batches[i], B)
+        loss = one_step(i)
     torch.cuda.synchronize()
-    timer.enabled = True
     t0 = time.perf_counter()
     for i in range(args.warmup, n_batches):
-        state, loss = run_step(args.workload, state, batches[i], B)
+        loss = one_step(i)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    timer.enabled = False
     final_loss = float(loss)
     assert np.isfinite(final_loss), "non-finite loss"
+
+    # ---- per-kernel HIP-event timing: the same K steps launched eagerly on the same stream (events
+    # cannot be recorded inside a replayed graph; kernel durations are the same either way) ---------
+    timer.enabled = True
+    for i in range(args.warmup, n_batches):
+        state, _ = run_step(args.workload, state, batches[i], B)
+    torch.cuda.synchronize()
+    timer.enabled = False
 
     K = args.steps
     totals = timer.totals_ms()
@@ -270,7 +309,7 @@ def main():
         "steps": K, "warmup": args.warmup, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: V=%d x D=%d fp32 tables, B=%d, sparse Adagrad" % (args.workload, V, D, B),
-                   "parallelism": "single", "loss": final_loss},
+                   "parallelism": "single", "launch": mode, "loss": final_loss},
         "roofline": roofline, "kernels": kernels, "hbm_gather_scatter": hbm,
     }
     if not args.no_cpu_baseline:

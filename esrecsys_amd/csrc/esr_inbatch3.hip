@@ -1,0 +1,671 @@
+// In-batch softmax forward + backward with FP32-EQUIVALENT products on the bf16 matrix cores.
+//
+// Same contract and same flash structure as esr_inbatch.hip (see there for the math), but every
+// f32 operand x is split EXACTLY into three bf16 planes x = x1 + x2 + x3 (8 + 8 + 8 significand bits;
+// x1 = rne_bf16(x), x2 = rne_bf16(x - x1), x3 = x - x1 - x2, all remainders exact in f32) and a product
+// a.b is evaluated as the six leading cross terms a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1 with
+// v_mfma_f32_32x32x16_bf16 (bf16 x bf16 products are exact in the f32 accumulator).  The dropped terms
+// a2b3 + a3b2 + a3b3 are <= 2^-23 |a||b|, i.e. below f32 rounding of the product itself, so the result is
+// f32-grade (tests hold the same 1e-5 bound against the fp64 oracle as the exact-f32 MFMA path).
+// Cost per 32x32x16 block: 6 x 32 cycles instead of 8 x 64 cycles of v_mfma_f32_32x32x2_f32 = 2.67x
+// fewer matrix-pipe cycles.
+//
+// Decomposition (differs from the f32 kernel because both operand layouts of the streamed matrix are
+// needed as 16-bit k-contiguous fragments):
+//   split3 pre-pass : X f32 [B,128] -> row-major planes Xr[3][B][128] bf16 and chunk-transposed planes
+//                     Xt[3][B/32][128][32] bf16 whose last index is the streamed row permuted into the
+//                     order in which the S^T accumulator registers hold it (so P feeds the next MFMA's B
+//                     operand straight from registers, as in the f32 kernel).
+//   rowmax pre-pass : approximate row maximum of S from the hi-plane product alone (1/12 of the MFMA work):
+//                     a FIXED exponent reference per row replaces online-softmax rescaling, so the O
+//                     accumulators are never touched by VALU instructions inside the main loop.
+//   main kernel     : workgroup = 4 waves x 32 owned rows (B operand of both products in VGPRs, 96 regs);
+//                     grid = (B/128) x nsplit, each workgroup streams 1/nsplit of the other matrix in
+//                     32-row chunks through a 3-deep ring of LDS tiles shared by its 4 waves, filled by
+//                     direct global->LDS DMA with a source-side XOR swizzle; software-pipelined (S^T of
+//                     chunk t+1 is issued ahead of the exp / split VALU work of chunk t), one barrier per
+//                     chunk.
+//   merge kernel    : sums the nsplit partial (l, O), applies the -y_i diagonal, the regulariser gradient
+//                     and the 1/batch_size, and reduces the loss.
+#include "esr_common.h"
+
+namespace esr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int k3D = 128;
+constexpr int k3Chunk = 32;
+constexpr int k3Waves = 4;
+constexpr int k3Owned = 32 * k3Waves;  // owned rows per workgroup
+constexpr float k3Log2e = 1.4426950408889634f;
+constexpr float k3Ln2 = 0.6931471805599453f;
+
+// LDS image of one 32-row chunk: three row-major planes [32 rows][256 B] then three transposed planes
+// [128 d][64 B], 48 KB, filled by direct global->LDS DMA (global_load_lds_dwordx4: no staging VGPRs, no
+// ds_write).  The DMA destination is lane-linear, so bank conflicts are removed by an XOR swizzle applied
+// to the per-lane SOURCE address and again on the ds_read_b128 address (same involution on both sides):
+//   row-major   : 16-B segment index ^= (row & 15)
+//   transposed  : 16-B segment index ^= ((d >> 2) & 3)
+constexpr int kPlaneBytes = 8192;
+constexpr int kTOff = 3 * kPlaneBytes;   // 24576
+constexpr int kBufBytes = 6 * kPlaneBytes + 256;  // 49408: six planes + 128 B of streamed-row lse (pass C)
+constexpr int k3Bufs = 3;
+
+__device__ __forceinline__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+// position of streamed row `row` (0..31) inside a transposed chunk: pos = 16 g + 8 h + k  <->
+// row = (k & 3) + 8 (2 g + (k >> 2)) + 4 h   (the S^T accumulator order)
+__device__ __forceinline__ int row_to_pos(int row) {
+  const int k_lo = row & 3, h = (row >> 2) & 1, k_hi = (row >> 3) & 1, g = row >> 4;
+  return 16 * g + 8 * h + 4 * k_hi + k_lo;
+}
+
+__device__ __forceinline__ void split3(float x, __bf16& a, __bf16& b, __bf16& c) {
+  a = (__bf16)x;
+  const float r1 = x - (float)a;
+  b = (__bf16)r1;
+  c = (__bf16)(r1 - (float)b);
+}
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// {bf16(lo), bf16(hi)} packed in one dword (v_cvt_pk_bf16_f32, round-to-nearest-even)
+__device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
+  f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float pk_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float pk_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+// ---------------------------------------------------------------------------------------------------
+// split3 pre-pass: one 256-thread block per 32-row chunk of one matrix (blockIdx.y selects Q or C).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ X0, const float* __restrict__ X1,
+                                                    int64_t B, __bf16* __restrict__ R0, __bf16* __restrict__ T0,
+                                                    __bf16* __restrict__ R1, __bf16* __restrict__ T1) {
+  __shared__ __attribute__((aligned(16))) __bf16 tl[3][128][40];
+  const float* X = blockIdx.y ? X1 : X0;
+  __bf16* R = blockIdx.y ? R1 : R0;
+  __bf16* Tt = blockIdx.y ? T1 : T0;
+  const int chunk = blockIdx.x, t = threadIdx.x;
+  const int row = t >> 3, d0 = (t & 7) * 16;
+  const int64_t grow = (int64_t)chunk * 32 + row;
+  const int pos = row_to_pos(row);
+  float v[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 f = *reinterpret_cast<const float4*>(X + grow * k3D + d0 + 4 * q);
+    v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+  }
+  bf16x8 p[3][2];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    __bf16 a, b, c;
+    split3(v[e], a, b, c);
+    p[0][e >> 3][e & 7] = a; p[1][e >> 3][e & 7] = b; p[2][e >> 3][e & 7] = c;
+    tl[0][d0 + e][pos] = a; tl[1][d0 + e][pos] = b; tl[2][d0 + e][pos] = c;
+  }
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
+    bf16x8* dst = reinterpret_cast<bf16x8*>(R + ((int64_t)pl * B + grow) * k3D + d0);
+    dst[0] = p[pl][0];
+    dst[1] = p[pl][1];
+  }
+  __syncthreads();
+  const int64_t nch = B / 32;
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
+    __bf16* dst = Tt + ((int64_t)pl * nch + chunk) * (k3D * 32);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int piece = t + 256 * k;  // 512 pieces of 8 bf16: d = piece / 4, seg = piece % 4
+      const int d = piece >> 2, seg = piece & 3;
+      *reinterpret_cast<bf16x8*>(dst + d * 32 + seg * 8) = *reinterpret_cast<const bf16x8*>(&tl[pl][d][seg * 8]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// main kernel
+// ---------------------------------------------------------------------------------------------------
+// DMA of one chunk: 3072 16-B pieces, 12 per thread; piece q = t + 256 k lands at LDS byte q * 16
+// (wave-uniform base + lane * 16), and its source segment is un-swizzled here.  Both image kinds advance by
+// exactly 8192 bytes per chunk, so each thread keeps 12 source pointers and bumps them (no per-chunk
+// address arithmetic beyond one 64-bit add per piece).
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// byte offset of piece K of chunk `chunk` from the base of its image array (Yr for K < 6, Yt for K >= 6)
+template <int K>
+__device__ __forceinline__ uint32_t dma_off0(int64_t B, int64_t nch, int64_t chunk, int t) {
+  const int within = (t + 256 * K) & 511;
+  int64_t e;
+  if (K < 6) {
+    const int row = within >> 4, seg = (within & 15) ^ (row & 15);
+    e = ((int64_t)(K >> 1) * B + chunk * 32 + row) * k3D + seg * 8;
+  } else {
+    const int d = within >> 2, seg = (within & 3) ^ ((d >> 2) & 3);
+    e = (((int64_t)((K >> 1) - 3) * nch + chunk) * k3D + d) * 32 + seg * 8;
+  }
+  return (uint32_t)(e * 2);
+}
+// uniform base (SGPR pair) + 32-bit per-lane offset: the saddr form of global_load_lds, 1 VGPR per piece
+template <int K>
+__device__ __forceinline__ void dma_piece(const char* __restrict__ baseR, const char* __restrict__ baseT,
+                                          uint32_t off, char* buf, int w) {
+  const char* src = (K < 6 ? baseR : baseT) + off;
+  char* dst = buf + K * 4096 + w * 1024;  // wave-uniform; the hardware adds lane * 16
+  __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+}
+#define ESR_DMA_INIT(CHUNK)                                                                                \
+  const char* const baseR = reinterpret_cast<const char*>(Yr);                                             \
+  const char* const baseT = reinterpret_cast<const char*>(Yt);                                             \
+  uint32_t g0 = dma_off0<0>(B, nch, (CHUNK), t), g1 = dma_off0<1>(B, nch, (CHUNK), t),                     \
+           g2 = dma_off0<2>(B, nch, (CHUNK), t), g3 = dma_off0<3>(B, nch, (CHUNK), t),                     \
+           g4 = dma_off0<4>(B, nch, (CHUNK), t), g5 = dma_off0<5>(B, nch, (CHUNK), t),                     \
+           g6 = dma_off0<6>(B, nch, (CHUNK), t), g7 = dma_off0<7>(B, nch, (CHUNK), t),                     \
+           g8 = dma_off0<8>(B, nch, (CHUNK), t), g9 = dma_off0<9>(B, nch, (CHUNK), t),                     \
+           g10 = dma_off0<10>(B, nch, (CHUNK), t), g11 = dma_off0<11>(B, nch, (CHUNK), t);
+#define ESR_DP(K, G, BUF) dma_piece<K>(baseR, baseT, G, (BUF), w)
+// issue the 12 pieces of the chunk the offsets currently address, then advance them to the next chunk
+#define ESR_DMA_CHUNK(BUF)                                                                                 \
+  ESR_DP(0, g0, BUF); ESR_DP(1, g1, BUF); ESR_DP(2, g2, BUF); ESR_DP(3, g3, BUF); ESR_DP(4, g4, BUF);       \
+  ESR_DP(5, g5, BUF); ESR_DP(6, g6, BUF); ESR_DP(7, g7, BUF); ESR_DP(8, g8, BUF); ESR_DP(9, g9, BUF);       \
+  ESR_DP(10, g10, BUF); ESR_DP(11, g11, BUF);                                                              \
+  ESR_DMA_ADVANCE();
+// step the 12 offsets to the next chunk of this split's ring (wraps from the last chunk to the first)
+#define ESR_DMA_ADVANCE()                                                                                  \
+  {                                                                                                        \
+    const uint32_t step_ = (dpos + 1 == nc) ? (uint32_t)(8192 - nc * 8192) : 8192u;                        \
+    dpos = (dpos + 1 == nc) ? 0 : dpos + 1;                                                                \
+    g0 += step_; g1 += step_; g2 += step_; g3 += step_; g4 += step_; g5 += step_;                          \
+    g6 += step_; g7 += step_; g8 += step_; g9 += step_; g10 += step_; g11 += step_;                        \
+  }
+
+#ifdef ESR_IB3_TIMING
+__device__ unsigned long long esr_ib3_dbg[4096];
+#define ESR_TICK(VAR) { ESR_SB(); VAR = __builtin_readcyclecounter(); ESR_SB(); }
+#else
+#define ESR_TICK(VAR)
+#endif
+#define ESR_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+// One S^T block (48 MFMAs, one accumulator chain) of the chunk in NBUF.  When VALU_ON, the exp + three-plane
+// bf16 split of the PREVIOUS chunk's 16 raw scores (p[], references in rf[]) is threaded through it: an
+// in-order wave cannot issue VALU work behind an MFMA that is still waiting for the matrix pipe, so the
+// ~3 VALU instructions that follow each MFMA are pinned there with sched_barrier(0); the scheduler's own
+// choice was "all MFMAs, then all VALU", i.e. no overlap.  k-step s handles the score pair (2s, 2s+1).
+#define ESR_SB() __builtin_amdgcn_sched_barrier(0)
+#define ESR_S_PHASE(NBUF, SA, VALU_ON)                                                                    \
+  {                                                                                                       \
+    _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) SA[r_] = 0.f;                                       \
+    const char* ap0_ = (NBUF) + j * 256;                                                                  \
+    const int sw_ = j & 15;                                                                               \
+    bf16x8 a1_ = *reinterpret_cast<const bf16x8*>(ap0_ + ((h ^ sw_) << 4));                               \
+    bf16x8 a2_ = *reinterpret_cast<const bf16x8*>(ap0_ + ((h ^ sw_) << 4) + kPlaneBytes);                 \
+    bf16x8 a3_ = *reinterpret_cast<const bf16x8*>(ap0_ + ((h ^ sw_) << 4) + 2 * kPlaneBytes);             \
+    _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) {                                                    \
+      bf16x8 n1_ = a1_, n2_ = a2_, n3_ = a3_;                                                             \
+      if (s_ < 7) {                                                                                       \
+        const int off_ = (((2 * (s_ + 1) + h) ^ sw_) << 4);                                               \
+        n1_ = *reinterpret_cast<const bf16x8*>(ap0_ + off_);                                              \
+        n2_ = *reinterpret_cast<const bf16x8*>(ap0_ + off_ + kPlaneBytes);                                \
+        n3_ = *reinterpret_cast<const bf16x8*>(ap0_ + off_ + 2 * kPlaneBytes);                            \
+      }                                                                                                   \
+      float e0_ = 0.f, e1_ = 0.f, q0_ = 0.f, q1_ = 0.f;                                                   \
+      uint32_t pa_ = 0, pq_ = 0;                                                                          \
+      ESR_SB();                                                                                           \
+      SA = ESR_MFMA_BF16(a3_, bx[0][s_], SA);                                                             \
+      ESR_SB();                                                                                           \
+      if (VALU_ON) { e0_ = fmaf(p[2 * s_], sl2, -rf[2 * s_]); e1_ = fmaf(p[2 * s_ + 1], sl2, -rf[2 * s_ + 1]); } \
+      ESR_SB();                                                                                           \
+      SA = ESR_MFMA_BF16(a1_, bx[2][s_], SA);                                                             \
+      ESR_SB();                                                                                           \
+      if (VALU_ON) { e0_ = __builtin_amdgcn_exp2f(e0_); e1_ = __builtin_amdgcn_exp2f(e1_); }              \
+      ESR_SB();                                                                                           \
+      SA = ESR_MFMA_BF16(a2_, bx[1][s_], SA);                                                             \
+      ESR_SB();                                                                                           \
+      if (VALU_ON) { l += e0_ + e1_; pa_ = pk_bf16(e0_, e1_); }                                           \
+      ESR_SB();                                                                                           \
+      SA = ESR_MFMA_BF16(a2_, bx[0][s_], SA);                                                             \
+      ESR_SB();                                                                                           \
+      if (VALU_ON) { q0_ = e0_ - pk_lo(pa_); q1_ = e1_ - pk_hi(pa_); pq_ = pk_bf16(q0_, q1_); }           \
+      ESR_SB();                                                                                           \
+      SA = ESR_MFMA_BF16(a1_, bx[1][s_], SA);                                                             \
+      ESR_SB();                                                                                           \
+      if (VALU_ON) {                                                                                      \
+        pw[0][s_] = pa_; pw[1][s_] = pq_;                                                                 \
+        pw[2][s_] = pk_bf16(q0_ - pk_lo(pq_), q1_ - pk_hi(pq_));                                          \
+      }                                                                                                   \
+      ESR_SB();                                                                                           \
+      SA = ESR_MFMA_BF16(a1_, bx[0][s_], SA);                                                             \
+      ESR_SB();                                                                                           \
+      a1_ = n1_; a2_ = n2_; a3_ = n3_;                                                                    \
+    }                                                                                                     \
+  }
+
+// Main kernel.  No online-softmax rescaling: the exponent reference is FIXED per owned row (pass Q: an
+// approximate row maximum from the rowmax pre-pass, exact enough for range safety; pass C: the lse of
+// the streamed row), so the O accumulators are touched by MFMAs only and stay in AGPRs, and the loop is
+// software-pipelined: the S^T MFMAs of chunk t+1 are issued before the exp / bf16-split VALU work of
+// chunk t, whose results feed the O^T MFMAs of chunk t.  Three LDS buffers: chunk t (transposed image
+// for O^T), chunk t+1 (row-major image for S^T), chunk t+2 (DMA in flight); one barrier per chunk.
+template <bool QSIDE>
+__global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict__ Xr, const __bf16* __restrict__ Yr,
+                                                      const __bf16* __restrict__ Yt, int64_t B, int nsplit, float sl2,
+                                                      const float* __restrict__ ref, float* __restrict__ part_O,
+                                                      float* __restrict__ part_l) {
+  __shared__ __attribute__((aligned(16))) char lds[k3Bufs * kBufBytes];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);  // provably wave-uniform: DMA bases stay in SGPRs
+  const int j = lane & 31, h = lane >> 5;
+  const int ob = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
+  const int64_t xrow = (int64_t)ob * k3Owned + w * 32 + j;  // this lane's owned row
+  const int nc = (int)(B / k3Chunk) / nsplit;               // chunks per split
+  const int64_t c0 = (int64_t)split * nc;
+  const int64_t nch = B / 32;
+
+  // owned rows -> B operand: bx[p][s] = Xr[p][xrow][16 s + 8 h .. +7]
+  bf16x8 bx[3][8];
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      bx[p][s] = *reinterpret_cast<const bf16x8*>(Xr + ((int64_t)p * B + xrow) * k3D + 16 * s + 8 * h);
+  float refv = 0.f;
+  if (QSIDE) {
+    refv = ref[xrow];
+    for (int s = 1; s < nsplit; ++s) refv = fmaxf(refv, ref[(int64_t)s * B + xrow]);
+  }
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[db][r] = 0.f;
+  float l = 0.f;
+
+  // pass C needs lse2 of the 32 streamed rows of each chunk: it rides along as a 128-B DMA (an ordinary
+  // global load inside the loop would make hipcc drain the whole DMA queue with vmcnt(0) at its use)
+#define ESR_DMA_ALL(BUF)                                                                                 \
+  {                                                                                                      \
+    ESR_DMA_LSE((BUF));                                                                                  \
+    ESR_DMA_CHUNK((BUF));                                                                                \
+  }
+// references of the 16 scores of the chunk in BUF: pass Q = the owned row's fixed reference, pass C = the lse
+// of each streamed row (DMA'd next to the tile)
+#define ESR_LOAD_REFS(BUF)                                                                               \
+  if (QSIDE) {                                                                                           \
+    _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) rf[r_] = refv;                                     \
+  } else {                                                                                               \
+    _Pragma("unroll") for (int g4_ = 0; g4_ < 4; ++g4_) {                                                \
+      const float4 lv_ = *reinterpret_cast<const float4*>((BUF) + 6 * kPlaneBytes + (8 * g4_ + 4 * h) * 4); \
+      rf[4 * g4_] = lv_.x; rf[4 * g4_ + 1] = lv_.y; rf[4 * g4_ + 2] = lv_.z; rf[4 * g4_ + 3] = lv_.w;    \
+    }                                                                                                    \
+  }
+// O^T += Y_chunk^T P^T : acc[db][r'] <-> O[owned xrow][d = 32 db + acc_row(r', h)]; product-major /
+// d-block-minor order so consecutive MFMAs hit four different accumulators.  When DMA_ON, the 12 LDS-DMA
+// pieces of chunk it+2 are issued one per 4 MFMAs (pinned with sched_barrier): an LDS-DMA costs ~100+ cycles
+// of issue time, which is hidden only while the matrix pipe is busy.
+#define ESR_O_ROW(PL_A, PL_P, G)                                                                          \
+  _Pragma("unroll") for (int db_ = 0; db_ < 4; ++db_) acc[db_] = ESR_MFMA_BF16(ta_[db_][PL_A], pb[PL_P][G], acc[db_]);
+#define ESR_O_PHASE(BUF, DMA_ON, DBUF)                                                                    \
+  {                                                                                                       \
+    bf16x8 pb[3][2];                                                                                      \
+    _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_)                                                      \
+      _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_) {                                                  \
+        const u32x4 u_ = {pw[q_][4 * g_], pw[q_][4 * g_ + 1], pw[q_][4 * g_ + 2], pw[q_][4 * g_ + 3]};    \
+        pb[q_][g_] = __builtin_bit_cast(bf16x8, u_);                                                      \
+      }                                                                                                   \
+    bf16x8 ta_[4][3];                                                                                     \
+    ESR_O_LOAD(BUF, 0, 2); ESR_O_LOAD(BUF, 0, 0); ESR_O_LOAD(BUF, 0, 1);                                  \
+    ESR_SB(); ESR_O_ROW(2, 0, 0); ESR_SB(); if (DMA_ON) { ESR_DP(0, g0, DBUF); }                  \
+    ESR_SB(); ESR_O_ROW(0, 2, 0); ESR_SB(); if (DMA_ON) { ESR_DP(1, g1, DBUF); }                  \
+    ESR_SB(); ESR_O_ROW(1, 1, 0); ESR_SB(); if (DMA_ON) { ESR_DP(2, g2, DBUF); }                  \
+    ESR_SB(); ESR_O_ROW(1, 0, 0); ESR_SB(); if (DMA_ON) { ESR_DP(3, g3, DBUF); }                  \
+    ESR_SB(); ESR_O_ROW(0, 1, 0); ESR_SB(); if (DMA_ON) { ESR_DP(4, g4, DBUF); }                  \
+    ESR_SB(); ESR_O_ROW(0, 0, 0); ESR_SB(); if (DMA_ON) { ESR_DP(5, g5, DBUF); }                  \
+    ESR_O_LOAD(BUF, 1, 2); ESR_O_LOAD(BUF, 1, 0); ESR_O_LOAD(BUF, 1, 1);                                  \
+    ESR_SB(); ESR_O_ROW(2, 0, 1); ESR_SB(); if (DMA_ON) { ESR_DP(6, g6, DBUF); }                  \
+    ESR_SB(); ESR_O_ROW(0, 2, 1); ESR_SB(); if (DMA_ON) { ESR_DP(7, g7, DBUF); }                  \
+    ESR_SB(); ESR_O_ROW(1, 1, 1); ESR_SB(); if (DMA_ON) { ESR_DP(8, g8, DBUF); }                  \
+    ESR_SB(); ESR_O_ROW(1, 0, 1); ESR_SB(); if (DMA_ON) { ESR_DP(9, g9, DBUF); }                  \
+    ESR_SB(); ESR_O_ROW(0, 1, 1); ESR_SB(); if (DMA_ON) { ESR_DP(10, g10, DBUF); }                \
+    ESR_SB(); ESR_O_ROW(0, 0, 1); ESR_SB(); if (DMA_ON) { ESR_DP(11, g11, DBUF); }                \
+    if (DMA_ON) ESR_DMA_ADVANCE();                                                                        \
+  }
+#define ESR_O_LOAD(BUF, G, PL)                                                                            \
+  _Pragma("unroll") for (int db_ = 0; db_ < 4; ++db_)                                                     \
+    ta_[db_][PL] = *reinterpret_cast<const bf16x8*>((BUF) + kTOff + (PL) * kPlaneBytes + (db_ * 32 + j) * 64 + \
+                                                    (((2 * (G) + h) ^ ((j >> 2) & 3)) << 4));
+// the 128-B lse block of pass C rides with the tile
+// (issued by every wave and every lane, branch-free: lanes 32-63 and waves 1-3 rewrite the same values; a
+// branch here splits the loop body into blocks and costs 64 accumulator-register moves at the join)
+#define ESR_DMA_LSE(BUF)                                                                                  \
+  if (!QSIDE)                                                                                             \
+    __builtin_amdgcn_global_load_lds((gptr_t)(ref + (c0 + dpos) * 32 + (lane & 31)),                      \
+                                     (lptr_t)((BUF) + 6 * kPlaneBytes), 4, 0, 0);
+
+  // Every workgroup of an XCD streams the same split; walking it in the same order at the same time
+  // funnels all 32 CUs onto the same few L2 channels (measured: ~8 B/clk/CU, the kernel was bound by it).
+  // Each workgroup therefore starts at its own rotation of the chunk ring (the fixed exponent reference
+  // makes the result independent of chunk order).
+  const int wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = (gridDim.x + 7) >> 3;
+  int dpos = (int)(((int64_t)wg_in_xcd * nc) / wgs_per_xcd) % nc;  // ring position of the next chunk to fetch
+  ESR_DMA_INIT(c0 + dpos);
+  ESR_DMA_ALL(lds);
+  if (nc > 1) ESR_DMA_ALL(lds + kBufBytes);
+  __syncthreads();  // an LDS-DMA in flight makes the barrier's fence wait vmcnt(0): both tiles have landed
+
+  f32x16 sa;
+  float p[16], rf[16];
+  uint32_t pw[3][8];  // packed bf16 pairs of P: pw[plane][pair s] = (r = 2s, 2s+1); 4 dwords per 8-row k-group
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { p[r] = 0.f; rf[r] = 0.f; }
+  ESR_S_PHASE(lds, sa, false);
+
+#ifdef ESR_IB3_TIMING
+  unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0, tacc0 = 0, tacc1 = 0, tacc2 = 0;
+  const unsigned long long tstart = __builtin_readcyclecounter();
+#endif
+  int cur = 0;  // ring slot of chunk `it`
+  // steady state (straight-line body: conditional DMA made hipcc split the block and shuffle the 64
+  // accumulator registers at every join)
+  for (int it = 0; it + 2 < nc; ++it) {
+    const int nxt = cur == k3Bufs - 1 ? 0 : cur + 1;
+    const int nn = nxt == k3Bufs - 1 ? 0 : nxt + 1;
+    // every wave is done with chunk it-1 (its slot is the DMA target below) and chunk it+1 has landed
+    ESR_TICK(tk0);
+    __syncthreads();
+    ESR_TICK(tk1);
+    const char* buf = lds + cur * kBufBytes;
+    const char* nbuf = lds + nxt * kBufBytes;
+    char* dbuf = lds + nn * kBufBytes;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[r] = sa[r];
+    ESR_LOAD_REFS(buf);
+    ESR_S_PHASE(nbuf, sa, true);  // S^T of chunk it+1 with the exp / split of chunk it threaded through
+    ESR_TICK(tk2);
+    ESR_DMA_LSE(dbuf);
+    ESR_O_PHASE(buf, true, dbuf);  // O^T of chunk it with the DMA of chunk it+2 threaded through
+    ESR_TICK(tk3);
+#ifdef ESR_IB3_TIMING
+    tacc0 += tk1 - tk0; tacc1 += tk2 - tk1; tacc2 += tk3 - tk2;
+#endif
+    cur = nxt;
+  }
+  if (nc >= 2) {  // chunk nc-2: the last S^T prefetch, nothing left to DMA
+    const int nxt = cur == k3Bufs - 1 ? 0 : cur + 1;
+    __syncthreads();
+    const char* buf = lds + cur * kBufBytes;
+    const char* nbuf = lds + nxt * kBufBytes;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[r] = sa[r];
+    ESR_LOAD_REFS(buf);
+    ESR_S_PHASE(nbuf, sa, true);
+    ESR_O_PHASE(buf, false, lds);
+    cur = nxt;
+  }
+  {  // last chunk: nothing left to prefetch; run its exp / split alone
+    __syncthreads();
+    const char* buf = lds + cur * kBufBytes;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[r] = sa[r];
+    ESR_LOAD_REFS(buf);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float e0 = __builtin_amdgcn_exp2f(fmaf(p[2 * s], sl2, -rf[2 * s]));
+      const float e1 = __builtin_amdgcn_exp2f(fmaf(p[2 * s + 1], sl2, -rf[2 * s + 1]));
+      l += e0 + e1;
+      const uint32_t pa = pk_bf16(e0, e1);
+      const float q0 = e0 - pk_lo(pa), q1 = e1 - pk_hi(pa);
+      const uint32_t pq = pk_bf16(q0, q1);
+      pw[0][s] = pa; pw[1][s] = pq;
+      pw[2][s] = pk_bf16(q0 - pk_lo(pq), q1 - pk_hi(pq));
+    }
+    ESR_O_PHASE(buf, false, lds);
+  }
+
+#ifdef ESR_IB3_TIMING
+  if (lane == 0 && blockIdx.x < 256) {
+    unsigned long long* d = esr_ib3_dbg + ((blockIdx.x * 4 + w) * 4);
+    d[0] = tacc0; d[1] = tacc1; d[2] = tacc2; d[3] = __builtin_readcyclecounter() - tstart;
+  }
+#endif
+  // ---- write this split's partial: O rows (float4 over 4 consecutive d) and l ----
+  float* orow = part_O + ((int64_t)split * B + xrow) * k3D;
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float4*>(orow + 32 * db + 8 * q + 4 * h) =
+          make_float4(acc[db][4 * q], acc[db][4 * q + 1], acc[db][4 * q + 2], acc[db][4 * q + 3]);
+  if (QSIDE) {
+    const float ltot = l + __shfl_xor(l, 32, 64);
+    if (h == 0) part_l[(int64_t)split * B + xrow] = ltot;
+  }
+}
+
+// Row-max pre-pass for pass Q: S~ = hi-plane product only (one bf16 MFMA term, error ~2^-8 |q||c| scale,
+// irrelevant for an exponent reference), running max per owned row over this split's chunks.  The work per
+// chunk is tiny (8 MFMAs), so kRmGroup chunks share one barrier / DMA round trip (the loop is DMA-latency
+// bound: 32 us with one chunk per barrier).
+constexpr int kRmGroup = 4;
+__global__ __launch_bounds__(256) void inbatch3_rowmax_kernel(const __bf16* __restrict__ Xr,
+                                                             const __bf16* __restrict__ Yr, int64_t B, int nsplit,
+                                                             float sl2, float* __restrict__ part_m) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * kRmGroup * kPlaneBytes];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int ob = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
+  const int64_t xrow = (int64_t)ob * k3Owned + w * 32 + j;
+  const int nc = (int)(B / k3Chunk) / nsplit;
+  const int64_t c0 = (int64_t)split * nc;
+  const int64_t nch = B / 32;
+  const char* const baseR = reinterpret_cast<const char*>(Yr);
+  const char* const baseT = baseR;
+  bf16x8 bx0[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) bx0[s] = *reinterpret_cast<const bf16x8*>(Xr + xrow * k3D + 16 * s + 8 * h);
+  float m = -INFINITY;
+  uint32_t g0 = dma_off0<0>(B, nch, c0, t), g1 = dma_off0<1>(B, nch, c0, t);  // plane 0 of chunk c0
+  const int ngroups = (nc + kRmGroup - 1) / kRmGroup;
+  // fetch group 0
+#pragma unroll
+  for (int k = 0; k < kRmGroup; ++k)
+    if (k < nc) {
+      ESR_DP(0, g0 + k * 8192, lds + k * kPlaneBytes);
+      ESR_DP(1, g1 + k * 8192, lds + k * kPlaneBytes);
+    }
+  for (int gi = 0; gi < ngroups; ++gi) {
+    __syncthreads();  // group gi landed; everyone is done with the other half
+    const char* gbuf = lds + (gi & 1) * (kRmGroup * kPlaneBytes);
+    if (gi + 1 < ngroups) {
+      char* nb = lds + ((gi + 1) & 1) * (kRmGroup * kPlaneBytes);
+      const int cbase = (gi + 1) * kRmGroup;
+#pragma unroll
+      for (int k = 0; k < kRmGroup; ++k)
+        if (cbase + k < nc) {
+          ESR_DP(0, g0 + (uint32_t)(cbase + k) * 8192u, nb + k * kPlaneBytes);
+          ESR_DP(1, g1 + (uint32_t)(cbase + k) * 8192u, nb + k * kPlaneBytes);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kRmGroup; ++k) {
+      if (gi * kRmGroup + k < nc) {
+        const char* buf = gbuf + k * kPlaneBytes;
+        f32x16 sa;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sa[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(buf + j * 256 + (((2 * s + h) ^ (j & 15)) << 4));
+          sa = ESR_MFMA_BF16(a1, bx0[s], sa);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, sa[r]);
+      }
+    }
+  }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  if (h == 0) part_m[(int64_t)split * B + xrow] = m * sl2;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// merge: one 32-lane group per owned row
+// ---------------------------------------------------------------------------------------------------
+template <bool QSIDE>
+__global__ __launch_bounds__(kBlock) void inbatch3_merge_kernel(
+    const float* __restrict__ X, const float* __restrict__ Y, int64_t B, int nsplit, const float* __restrict__ part_O,
+    const float* __restrict__ part_m, const float* __restrict__ part_l, float scale, float lam, float inv_bs,
+    float* __restrict__ lse2, float* __restrict__ lse_nat, float* __restrict__ gX, double* __restrict__ loss_part) {
+  __shared__ double sm[4];
+  constexpr int G = 32;
+  const int lig = threadIdx.x & (G - 1);
+  const int64_t gpb = kBlock / G;
+  const int64_t group = (int64_t)blockIdx.x * gpb + threadIdx.x / G;
+  const int64_t ngroups = (int64_t)gridDim.x * gpb;
+  double acc_loss = 0.0;
+  for (int64_t row = group; row < B; row += ngroups) {
+    float M = 0.f, L = 1.f;
+    if (QSIDE) {  // every split used the same fixed reference M = max_s part_m[s][row]
+      M = part_m[row];
+      for (int s = 1; s < nsplit; ++s) M = fmaxf(M, part_m[(int64_t)s * B + row]);
+      L = 0.f;
+      for (int s = 0; s < nsplit; ++s) L += part_l[(int64_t)s * B + row];
+    }
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < nsplit; ++s) {
+      const float4 v = *reinterpret_cast<const float4*>(part_O + ((int64_t)s * B + row) * k3D + 4 * lig);
+      o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+    }
+    const float invL = 1.0f / L;
+    const float4 x = *reinterpret_cast<const float4*>(X + row * k3D + 4 * lig);
+    const float4 y = *reinterpret_cast<const float4*>(Y + row * k3D + 4 * lig);
+    const float xn2 = group_sum(x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w, G);
+    const float xnorm = sqrtf(xn2);
+    const float creg = xnorm > 1.f ? lam / xnorm : 0.f;
+    float4 g;
+    g.x = (scale * (o.x * invL - y.x) + creg * x.x) * inv_bs;
+    g.y = (scale * (o.y * invL - y.y) + creg * x.y) * inv_bs;
+    g.z = (scale * (o.z * invL - y.z) + creg * x.z) * inv_bs;
+    g.w = (scale * (o.w * invL - y.w) + creg * x.w) * inv_bs;
+    *reinterpret_cast<float4*>(gX + row * k3D + 4 * lig) = g;
+    float row_loss = lam * fmaxf(xnorm - 1.f, 0.f);
+    if (QSIDE) {
+      const float diag = group_sum(x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w, G);
+      const float l2v = M + __builtin_amdgcn_logf(L);
+      if (lig == 0) {
+        lse2[row] = l2v;
+        if (lse_nat) lse_nat[row] = l2v * k3Ln2;
+      }
+      row_loss += l2v * k3Ln2 - scale * diag;
+    }
+    if (lig == 0) acc_loss += (double)row_loss;
+  }
+  const double tsum = block_sum_d(acc_loss, sm);
+  if (threadIdx.x == 0) loss_part[blockIdx.x] = tsum;
+}
+
+constexpr int k3MergeBlocks = 512;
+
+struct Inbatch3Ws {
+  __bf16 *Qr, *Qt, *Cr, *Ct;
+  float *part_O, *part_m, *part_l, *lse2;
+  double* loss_part;  // [2 * k3MergeBlocks]
+};
+static size_t inbatch3_ws_layout(int64_t B, int nsplit, char* base, Inbatch3Ws* ws) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += align_up(bytes, 256);
+    return p;
+  };
+  const size_t plane = (size_t)3 * B * k3D * 2;
+  Inbatch3Ws w;
+  w.Qr = (__bf16*)take(plane); w.Qt = (__bf16*)take(plane);
+  w.Cr = (__bf16*)take(plane); w.Ct = (__bf16*)take(plane);
+  w.part_O = (float*)take((size_t)nsplit * B * k3D * 4);
+  w.part_m = (float*)take((size_t)nsplit * B * 4);
+  w.part_l = (float*)take((size_t)nsplit * B * 4);
+  w.lse2 = (float*)take((size_t)B * 4);
+  w.loss_part = (double*)take(sizeof(double) * 2 * k3MergeBlocks);
+  if (ws) *ws = w;
+  return off;
+}
+
+// largest split count <= 8 that divides the chunk count and keeps the grid near one workgroup per CU
+static int inbatch3_nsplit(int64_t B) {
+  const int64_t owned_blocks = B / k3Owned, nchunks = B / k3Chunk;
+  int best = 1;
+  for (int s = 1; s <= 8; ++s)
+    if (nchunks % s == 0 && owned_blocks * s <= 320) best = s;
+  return best;
+}
+
+}  // namespace esr
+
+using namespace esr;
+
+extern "C" {
+
+#ifdef ESR_IB3_TIMING
+int esr_ib3_debug_read(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(esr_ib3_dbg), sizeof(unsigned long long) * 4096);
+}
+#endif
+
+size_t esr_inbatch3_workspace_bytes(int64_t B, int D) {
+  (void)D;
+  if (B <= 0) return 256;
+  return inbatch3_ws_layout(B, 8, nullptr, nullptr);
+}
+
+int esr_inbatch_softmax_fwd_bwd_bf16x3(const float* Q, const float* C, int64_t B, int D, float scale,
+                                       float regularization, float batch_size, float* loss, float* lse, float* gQ,
+                                       float* gC, void* workspace, size_t workspace_bytes, esr_stream_t stream) {
+  ESR_REQUIRE(B > 0 && B % k3Owned == 0, "esr_inbatch_softmax_fwd_bwd_bf16x3: B=%lld must be a positive multiple of 128",
+              (long long)B);
+  ESR_REQUIRE(D == k3D, "esr_inbatch_softmax_fwd_bwd_bf16x3: D=%d not supported (128 only; use the f32 entry point)", D);
+  ESR_REQUIRE(Q && C && loss && gQ && gC, "esr_inbatch_softmax_fwd_bwd_bf16x3: null pointer");
+  ESR_REQUIRE(batch_size != 0.f, "esr_inbatch_softmax_fwd_bwd_bf16x3: batch_size must be non-zero");
+  ESR_REQUIRE((((uintptr_t)Q | (uintptr_t)C | (uintptr_t)gQ | (uintptr_t)gC) & 15) == 0,
+              "esr_inbatch_softmax_fwd_bwd_bf16x3: matrices must be 16-byte aligned");
+  if (!workspace || workspace_bytes < esr_inbatch3_workspace_bytes(B, D) || ((uintptr_t)workspace & 15)) {
+    set_error("esr_inbatch_softmax_fwd_bwd_bf16x3: workspace %zu bytes < %zu required (or misaligned)",
+              workspace_bytes, esr_inbatch3_workspace_bytes(B, D));
+    return ESR_EWORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  const int nsplit = inbatch3_nsplit(B);
+  Inbatch3Ws ws;
+  inbatch3_ws_layout(B, 8, (char*)workspace, &ws);
+  const float inv_bs = 1.0f / batch_size, sl2 = scale * k3Log2e;
+  const int nchunks = (int)(B / k3Chunk), grid = (int)(B / k3Owned) * nsplit;
+  const int mgrid = (int)std::min<int64_t>(k3MergeBlocks, cdiv(B, kBlock / 32));
+  hipLaunchKernelGGL(split3_kernel, dim3(nchunks, 2), dim3(256), 0, st, Q, C, B, ws.Qr, ws.Qt, ws.Cr, ws.Ct);
+  // pass Q: owned = Q, streamed = C
+  hipLaunchKernelGGL(inbatch3_rowmax_kernel, dim3(grid), dim3(256), 0, st, (const __bf16*)ws.Qr, (const __bf16*)ws.Cr, B,
+                     nsplit, sl2, ws.part_m);
+  hipLaunchKernelGGL((inbatch3_kernel<true>), dim3(grid), dim3(256), 0, st, (const __bf16*)ws.Qr, (const __bf16*)ws.Cr,
+                     (const __bf16*)ws.Ct, B, nsplit, sl2, (const float*)ws.part_m, ws.part_O, ws.part_l);
+  hipLaunchKernelGGL((inbatch3_merge_kernel<true>), dim3(mgrid), dim3(kBlock), 0, st, Q, C, B, nsplit,
+                     (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale, regularization,
+                     inv_bs, ws.lse2, lse, gQ, ws.loss_part);
+  // pass C: owned = C, streamed = Q
+  hipLaunchKernelGGL((inbatch3_kernel<false>), dim3(grid), dim3(256), 0, st, (const __bf16*)ws.Cr,
+                     (const __bf16*)ws.Qr, (const __bf16*)ws.Qt, B, nsplit, sl2, (const float*)ws.lse2, ws.part_O,
+                     ws.part_l);
+  hipLaunchKernelGGL((inbatch3_merge_kernel<false>), dim3(mgrid), dim3(kBlock), 0, st, C, Q, B, nsplit,
+                     (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale, regularization,
+                     inv_bs, ws.lse2, (float*)nullptr, gC, ws.loss_part + k3MergeBlocks);
+  // the two merge launches wrote mgrid partials each at [0, mgrid) and [k3MergeBlocks, k3MergeBlocks + mgrid)
+  if (mgrid < k3MergeBlocks)
+    (void)hipMemsetAsync(ws.loss_part + mgrid, 0, sizeof(double) * (k3MergeBlocks - mgrid), st);
+  finalize_scalar(ws.loss_part, k3MergeBlocks + mgrid, 1.0 / (double)batch_size, loss, st);
+  return check_launch("esr_inbatch_softmax_fwd_bwd_bf16x3");
+}
+
+}  // extern "C"

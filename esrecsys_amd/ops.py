@@ -169,22 +169,39 @@ def triplet_fwd_bwd(scene_table, pos_table, neg_table, scene_ids, pos_ids, neg_i
     return loss, ps, ns, gs, gp, gn
 
 
-def inbatch_softmax_fwd_bwd(Q, C, scale, regularization, batch_size):
-    """In-batch-negative softmax on the FP32 MFMA path.  Returns (loss[1], lse[B], gQ, gC)."""
+INBATCH_PRECISIONS = ("auto", "f32", "bf16x3")
+
+
+def inbatch_softmax_fwd_bwd(Q, C, scale, regularization, batch_size, precision="auto"):
+    """In-batch-negative softmax on the matrix cores.  Returns (loss[1], lse[B], gQ, gC).
+
+    precision "f32": exact-f32 MFMA (v_mfma_f32_32x32x2_f32).  "bf16x3": f32-equivalent products from three
+    exact bf16 planes per operand (six v_mfma_f32_32x32x16_bf16 per block, error <= 2^-23 per product; needs
+    D == 128 and B % 128 == 0).  "auto": bf16x3 where it applies, else f32.  Both hold the 1e-5 bound."""
     lib = _lib.load()
     _req(Q, torch.float32, "Q"), _req(C, torch.float32, "C")
     B, D = Q.shape
     if C.shape != Q.shape:
         raise ValueError("Q and C must have the same shape")
+    if precision not in INBATCH_PRECISIONS:
+        raise ValueError("precision must be one of %s" % (INBATCH_PRECISIONS,))
+    split_ok = D == 128 and B % 128 == 0
+    if precision == "bf16x3" and not split_ok:
+        raise ValueError("precision='bf16x3' needs D == 128 and B %% 128 == 0 (got B=%d, D=%d)" % (B, D))
+    use_split = split_ok and precision in ("auto", "bf16x3")
     dev = Q.device
     loss = torch.empty(1, dtype=torch.float32, device=dev)
     lse = torch.empty(B, dtype=torch.float32, device=dev)
     gQ = torch.empty_like(Q)
     gC = torch.empty_like(C)
-    ws = _ws(_ws_bytes("esr_inbatch_workspace_bytes", B, D), dev)
-    check(lib.esr_inbatch_softmax_fwd_bwd(_p(Q), _p(C), B, D, float(scale), float(regularization), float(batch_size),
-                                          _p(loss), _p(lse), _p(gQ), _p(gC), _p(ws), ws.numel(), _stream()),
-          "esr_inbatch_softmax_fwd_bwd")
+    if use_split:
+        ws = _ws(_ws_bytes("esr_inbatch3_workspace_bytes", B, D), dev)
+        fn, name = lib.esr_inbatch_softmax_fwd_bwd_bf16x3, "esr_inbatch_softmax_fwd_bwd_bf16x3"
+    else:
+        ws = _ws(_ws_bytes("esr_inbatch_workspace_bytes", B, D), dev)
+        fn, name = lib.esr_inbatch_softmax_fwd_bwd, "esr_inbatch_softmax_fwd_bwd"
+    check(fn(_p(Q), _p(C), B, D, float(scale), float(regularization), float(batch_size), _p(loss), _p(lse), _p(gQ),
+             _p(gC), _p(ws), ws.numel(), _stream()), name)
     return loss, lse, gQ, gC
 
 

@@ -58,29 +58,38 @@ def _wrap(state, inner):
     return {"params": inner} if "params" in state.params else inner
 
 
-def train_step(state, scene, pos_product, neg_product, regularization, batch_size, scale=1.0):
+def train_step(state, scene, pos_product, neg_product, regularization, batch_size, scale=1.0, precision="auto"):
     """One optimizer step (pinterest/train_shop_the_look.py:93-109).  Returns ``(new_state, loss)``.
 
     loss = (sum relu(1 + neg - pos) + regularization * sum norm-excess) / batch_size.  One fused HIP launch
     gathers the three rows per triplet, scores them and writes the three gradient rows; the optimizer
-    update is sort + segment-reduce + RMW.  ``neg_product=None``: in-batch softmax (north_star)."""
+    update is sort + segment-reduce + RMW.  ``neg_product=None``: in-batch softmax (north_star) with
+    temperature ``scale``; ``precision`` picks its MFMA path (see ops.inbatch_softmax_fwd_bwd)."""
     _, st, pt = _tables(state)
     dev = st.device
     sid = ops.as_ids(scene, dev, check_range=st.shape[0]).reshape(-1)
     pid = ops.as_ids(pos_product, dev, check_range=pt.shape[0]).reshape(-1)
     B = sid.numel()
+    sparse = not getattr(state.tx, "wants_dense", False)
+    idx_scene = SegmentIndex(sid, st.shape[0])
     if neg_product is None:
+        idx_prod = SegmentIndex(pid, pt.shape[0])
+        if sparse:  # the sorts only need the ids: run them beside the gather / MFMA kernels
+            idx_scene.presort(), idx_prod.presort()
         q = ops.gather_rows(st, sid)
         c = ops.gather_rows(pt, pid)
-        loss, _, gq, gc = ops.inbatch_softmax_fwd_bwd(q, c, scale, regularization, batch_size)
-        g_scene = RowGrads(SegmentIndex(sid, st.shape[0]), gq, st.shape)
-        g_prod = RowGrads(SegmentIndex(pid, pt.shape[0]), gc, pt.shape)
+        loss, _, gq, gc = ops.inbatch_softmax_fwd_bwd(q, c, scale, regularization, batch_size, precision=precision)
+        g_scene = RowGrads(idx_scene, gq, st.shape)
+        g_prod = RowGrads(idx_prod, gc, pt.shape)
     else:
         nid = ops.as_ids(neg_product, dev, check_range=pt.shape[0]).reshape(-1)
+        idx_prod = SegmentIndex(torch.cat([pid, nid]), pt.shape[0])
+        if sparse:
+            idx_scene.presort(), idx_prod.presort()
         loss, _, _, gs, gp, gn = ops.triplet_fwd_bwd(st, pt, pt, sid, pid, nid, B, regularization, batch_size,
                                                      with_reg=True, want_grads=True, want_scores=False)
-        g_scene = RowGrads(SegmentIndex(sid, st.shape[0]), gs, st.shape)
-        g_prod = RowGrads(SegmentIndex(torch.cat([pid, nid]), pt.shape[0]), gp._base, pt.shape)  # [gp ; gn]
+        g_scene = RowGrads(idx_scene, gs, st.shape)
+        g_prod = RowGrads(idx_prod, gp._base, pt.shape)  # [gp ; gn]
     grads = _wrap(state, {"scene_tower": {"embedding": g_scene}, "product_tower": {"embedding": g_prod}})
     if getattr(state.tx, "wants_dense", False):
         from ..train_state import tree_map

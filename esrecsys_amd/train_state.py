@@ -14,18 +14,52 @@ import torch
 from . import ops
 
 
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
 class SegmentIndex:
-    """Occurrence ids of one gradient scatter, sorted lazily once and shared by every table that is
-    indexed by the same ids (GloVe's embedding + bias tables; STL's pos + neg product rows)."""
+    """Occurrence ids of one gradient scatter, sorted once and shared by every table that is indexed by
+    the same ids (GloVe's embedding + bias tables; STL's pos + neg product rows).
+
+    The sort depends on the ids only, not on the gradients, so ``presort()`` launches it on a side stream
+    at the top of the step where it overlaps the gather / loss kernels (the device-wide radix sort is a
+    chain of ~6 short launches, 25 us of pure latency at these sizes -- profiles/r1); ``sorted()`` makes the
+    consuming stream wait on its event."""
 
     def __init__(self, ids, num_rows):
         self.ids = ids  # int32 [n] on device
         self.num_rows = int(num_rows)
         self._sorted = None
+        self._event = None
+
+    def presort(self):
+        if self._sorted is not None or not self.ids.is_cuda:
+            return self
+        main = torch.cuda.current_stream(self.ids.device)
+        side = _side_stream(self.ids.device)
+        side.wait_stream(main)  # the ids are produced on the main stream
+        with torch.cuda.stream(side):
+            self._sorted = ops.segment_sort(self.ids, self.num_rows)
+            self._event = torch.cuda.Event()
+            self._event.record(side)
+        self.ids.record_stream(side)
+        for t in self._sorted:
+            t.record_stream(main)
+        return self
 
     def sorted(self):
         if self._sorted is None:
             self._sorted = ops.segment_sort(self.ids, self.num_rows)
+        elif self._event is not None:
+            torch.cuda.current_stream(self.ids.device).wait_event(self._event)
+            self._event = None
         return self._sorted
 
 

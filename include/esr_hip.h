@@ -101,6 +101,15 @@ int esr_inbatch_softmax_fwd_bwd(const float* Q, const float* C, int64_t B, int D
                                 float* gQ, float* gC, void* workspace, size_t workspace_bytes,
                                 esr_stream_t stream);
 
+/* Same contract with FP32-EQUIVALENT products on the bf16 matrix cores: every operand is split exactly
+ * into three bf16 planes and a product is the six leading cross terms (dropped terms <= 2^-23 |a||b|),
+ * 2.67x fewer matrix-pipe cycles than v_mfma_f32_32x32x2_f32.  D must be 128, B a multiple of 128. */
+size_t esr_inbatch3_workspace_bytes(int64_t B, int D);
+int esr_inbatch_softmax_fwd_bwd_bf16x3(const float* Q, const float* C, int64_t B, int D, float scale,
+                                       float regularization, float batch_size, float* loss, float* lse,
+                                       float* gQ, float* gC, void* workspace, size_t workspace_bytes,
+                                       esr_stream_t stream);
+
 /* ---- G4 (build's production optimizer): sort + segment-reduce + sparse Adagrad -----------
  * Replaces the dense V x D gradient + dense optimizer sweep of
  * wikipedia/train_cooccurence.py:86-101 with a row-sparse update.

@@ -221,3 +221,41 @@ def test_find_top_k_drop_in(dev):
     assert np.array_equal(N(idx), g["topk_indices"]) and np.array_equal(N(scores), g["topk_scores"].astype(np.float32))
     es, ei = o_topk.find_top_k(g["query"], g["cand"], 10, F64)
     assert np.array_equal(N(idx), ei)
+
+
+def test_graphed_step_equals_eager(dev):
+    """hipGraph replay of the whole train step gives bit-identical tables to eager launches."""
+    from esrecsys_amd import optim
+    from esrecsys_amd.graph import GraphedStep
+    from esrecsys_amd.pinterest.train_shop_the_look import train_step
+    Vs, Vp, D, B = 4000, 6000, 128, 1024
+    rng = np.random.default_rng(11)
+    batches = [tuple(torch.from_numpy(rng.integers(0, n, B).astype(np.int32)).to(dev) for n in (Vs, Vp, Vp))
+               for _ in range(6)]
+    results = []
+    for use_graph in (False, True):
+        stl, state = _stl_state(dev, Vs, Vp, D, optim.sparse_adagrad(0.05), seed=3)
+        holder = {"s": state}
+
+        def step(sc, po, ne):
+            holder["s"], l1 = train_step(holder["s"], sc, po, ne, 0.1, B)          # triplet loss
+            holder["s"], l2 = train_step(holder["s"], sc, po, None, 0.1, B, scale=4.0)  # in-batch loss
+            return torch.stack([l1, l2])
+        losses = []
+        if use_graph:
+            # GraphedStep warms up by RUNNING the step twice on its example inputs (capture itself executes
+            # nothing): give the eager arm the same two extra updates so both arms see identical histories
+            g = GraphedStep(step, batches[0], warmup=2)
+            for b in batches:
+                losses.append(g(*b).clone())
+        else:
+            for _ in range(2):
+                step(*batches[0])
+            for b in batches:
+                losses.append(step(*b))
+        torch.cuda.synchronize()
+        p = holder["s"].params["params"]
+        results.append((torch.stack(losses).cpu(), p["scene_tower"]["embedding"].clone(),
+                        p["product_tower"]["embedding"].clone()))
+    assert torch.equal(results[0][0], results[1][0])
+    assert torch.equal(results[0][1], results[1][1]) and torch.equal(results[0][2], results[1][2])

@@ -216,7 +216,8 @@ def test_inbatch_softmax_vs_golden(dev, case):
     assert rel_err(N(gc), g["g_c"]) <= TOL
 
 
-def test_inbatch_transpose_detecting(dev):
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_inbatch_transpose_detecting(dev, precision):
     """Asymmetric operands: a swapped Q/C role or a transposed MFMA fragment cannot pass."""
     from esrecsys_amd import ops
     rng = np.random.default_rng(77)
@@ -224,13 +225,14 @@ def test_inbatch_transpose_detecting(dev):
     q = (rng.standard_normal((B, D)) * 0.3).astype(np.float32)
     c = (rng.standard_normal((B, D)) * 0.05 + np.linspace(-0.2, 0.2, D)[None, :]).astype(np.float32)
     q[:, :7] *= 4.0
-    loss, lse, gq, gc = ops.inbatch_softmax_fwd_bwd(T(q, dev), T(c, dev), 3.0, 0.2, B)
+    loss, lse, gq, gc = ops.inbatch_softmax_fwd_bwd(T(q, dev), T(c, dev), 3.0, 0.2, B, precision=precision)
     el, else_, egq, egc = o_stl.inbatch_softmax_loss_and_grads(q, c, 0.2, B, 3.0, F64)
     assert abs(float(loss) - el) / abs(el) <= TOL
     assert rel_err(N(lse), else_) <= TOL and rel_err(N(gq), egq) <= TOL and rel_err(N(gc), egc) <= TOL
 
 
-def test_inbatch_config_c2_full_size(dev):
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_inbatch_config_c2_full_size(dev, precision):
     """BASELINE config C2: B = 8192, D = 128, fp64 oracle on the same inputs + checksum properties
     (softmax rows sum to one => column sum of gC vanishes when reg = 0)."""
     from esrecsys_amd import ops
@@ -238,13 +240,48 @@ def test_inbatch_config_c2_full_size(dev):
     B, D = 8192, 128
     q = (rng.standard_normal((B, D)) / np.sqrt(D)).astype(np.float32)
     c = (rng.standard_normal((B, D)) / np.sqrt(D)).astype(np.float32)
-    loss, lse, gq, gc = ops.inbatch_softmax_fwd_bwd(T(q, dev), T(c, dev), 8.0, 0.0, B)
+    loss, lse, gq, gc = ops.inbatch_softmax_fwd_bwd(T(q, dev), T(c, dev), 8.0, 0.0, B, precision=precision)
     el, else_, egq, egc = o_stl.inbatch_softmax_loss_and_grads(q, c, 0.0, B, 8.0, F64)
     assert abs(float(loss) - el) / abs(el) <= TOL
     assert rel_err(N(lse), else_) <= TOL
     assert rel_err(N(gq), egq) <= TOL and rel_err(N(gc), egc) <= TOL
     colsum = N(gc).astype(F64).sum(0)
     assert np.abs(colsum).max() <= 1e-5 * np.abs(N(gc)).sum(0).max()
+
+
+@pytest.mark.parametrize("B", [128, 384, 1024, 2176])
+def test_inbatch_bf16x3_shapes_and_hard_inputs(dev, B):
+    """bf16x3 path on split counts 1..8, wide score range (scale 12: |S| up to ~25), big-norm rows, duplicate
+    rows; also reports how close each precision is to the fp64 oracle (both must hold the 1e-5 bound; at
+    much larger |S| fp32 itself leaves it: exp(x) amplifies the ulp(|x|) rounding of the score)."""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(B)
+    D = 128
+    q = (rng.standard_normal((B, D)) * rng.uniform(0.02, 0.3, (B, 1))).astype(np.float32)
+    c = (rng.standard_normal((B, D)) * rng.uniform(0.02, 0.3, (B, 1))).astype(np.float32)
+    c[5] = c[6]          # duplicate candidate
+    q[7] *= 3.0          # a dominant row: sharp softmax, forces online-max rescales late in the stream
+    c[B - 1] = q[7]
+    el, else_, egq, egc = o_stl.inbatch_softmax_loss_and_grads(q, c, 0.1, B, 12.0, F64)
+    errs = {}
+    for precision in ("f32", "bf16x3"):
+        loss, lse, gq, gc = ops.inbatch_softmax_fwd_bwd(T(q, dev), T(c, dev), 12.0, 0.1, B, precision=precision)
+        errs[precision] = (abs(float(loss) - el) / abs(el), rel_err(N(lse), else_), rel_err(N(gq), egq),
+                           rel_err(N(gc), egc))
+    print("inbatch B=%d rel.err vs fp64 (loss, lse, gQ, gC): f32 %s | bf16x3 %s" % (
+        B, " ".join("%.1e" % e for e in errs["f32"]), " ".join("%.1e" % e for e in errs["bf16x3"])))
+    for precision in errs:
+        assert max(errs[precision]) <= TOL, (precision, errs)
+
+
+def test_inbatch_golden_b320_falls_back_to_f32_when_not_splittable(dev):
+    from esrecsys_amd import ops
+    g = load_golden("inbatch_b320_d128")  # 320 % 128 != 0 -> "auto" must use the f32 kernel
+    loss, _, _, _ = ops.inbatch_softmax_fwd_bwd(T(g["q"], dev), T(g["c"], dev), float(g["scale"]), float(g["lam"]),
+                                                float(g["batch_size"]), precision="auto")
+    assert abs(float(loss) - g["loss"]) / abs(g["loss"]) <= TOL
+    with pytest.raises(ValueError):
+        ops.inbatch_softmax_fwd_bwd(T(g["q"], dev), T(g["c"], dev), 1.0, 0.0, 320.0, precision="bf16x3")
 
 
 # ------------------------------------------------------------------------------------------------
