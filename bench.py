@@ -30,6 +30,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense FP32 matrix peak (v_mfma_f32_32x32x2_f32)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense BF16 matrix peak (v_mfma_f32_32x32x16_bf16)
 
 WORKLOADS = {
     "inbatch": dict(V=1_000_000, D=128, B=8192, rows_per_unit=2, unit="pair"),
@@ -278,11 +279,23 @@ def main():
     gather_bytes = rows * B * D * 4
     adagrad_bytes = rows * B * D * 4 * 5
     if args.workload == "inbatch":
-        flops = 6.0 * B * B * D  # S = QC^T, dQ = PC, dC = P^T Q; the kernel recomputes S once more
         t = kernels["inbatch_mfma"]["ms_per_step"] * 1e-3
-        roofline = {"kernel": "inbatch_kernel<128,{Q,C}side> (2 launches)", "bound": "mfma",
-                    "achieved": flops / t / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": flops / t / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None}
+        alg = 6.0 * B * B * D  # S = QC^T, dQ = PC, dC = P^T Q in f32
+        split = PRECISION != "f32" and D == 128 and B % 128 == 0
+        if split:
+            # bf16x3 path: every f32 product = 6 bf16 MFMA terms; S is recomputed in pass C (4 GEMM units) and the
+            # row-max pre-pass adds one hi-plane term: (4 * 6 + 1) * 2 B^2 D executed bf16 flops
+            executed = (4 * 6 + 1) * 2.0 * B * B * D
+            roofline = {"kernel": "split3 + inbatch3_rowmax + inbatch3_kernel<Q> + merge + inbatch3_kernel<C> + merge",
+                        "bound": "mfma", "achieved": executed / t / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": executed / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                        "dtype": "bf16 x3 split, f32 accumulate (f32-equivalent products)",
+                        "f32_equivalent_TFLOPs": alg / t / 1e12,
+                        "f32_equivalent_vs_f32_mfma_peak": alg / t / 1e12 / MFMA_F32_PEAK_TFLOPS}
+        else:
+            roofline = {"kernel": "inbatch_kernel<128,{Q,C}side> (2 launches)", "bound": "mfma",
+                        "achieved": alg / t / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": alg / t / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None}
     else:
         name = "triplet_fused" if args.workload == "triplet" else "glove_fused"
         # fused loss kernel: reads `rows` rows and writes `rows` gradient rows per unit
@@ -300,7 +313,8 @@ def main():
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            roofline["traffic"] = json.load(open(pmc)).get(args.workload)
+            key = args.workload + ("_f32" if args.workload == "inbatch" and PRECISION == "f32" else "")
+            roofline["traffic"] = json.load(open(pmc)).get(key)
         except Exception:
             pass
 
@@ -309,6 +323,7 @@ def main():
         "steps": K, "warmup": args.warmup, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: V=%d x D=%d fp32 tables, B=%d, sparse Adagrad" % (args.workload, V, D, B),
+                   "score_precision": PRECISION,
                    "parallelism": "single", "launch": mode, "loss": final_loss},
         "roofline": roofline, "kernels": kernels, "hbm_gather_scatter": hbm,
     }

@@ -76,11 +76,7 @@ __global__ __launch_bounds__(kIbWaves * 64, 2) void inbatch_kernel(
   float m2 = -INFINITY, l = 0.f;
 
   const int nchunks = (int)(B / kIbRows);
-  // Rotate each workgroup's walk over the streamed matrix: workgroups of one XCD that sweep the same
-  // addresses in lockstep pile onto the same few L2 channels (online softmax is order-independent).
-  const int rot = (int)(((int64_t)(blockIdx.x >> 3) * nchunks) / ((gridDim.x + 7) >> 3)) % nchunks;
-  for (int t0 = w; t0 < nchunks; t0 += kIbWaves) {
-    const int t = t0 + rot < nchunks ? t0 + rot : t0 + rot - nchunks;
+  for (int t = w; t < nchunks; t += kIbWaves) {
     const int64_t y0 = (int64_t)t * kIbRows;
     // ---- stage the chunk: coalesced 16 B loads -> padded LDS tile (wave-private) ----
     {

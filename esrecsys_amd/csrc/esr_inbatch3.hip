@@ -347,12 +347,10 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
     __builtin_amdgcn_global_load_lds((gptr_t)(ref + (c0 + dpos) * 32 + (lane & 31)),                      \
                                      (lptr_t)((BUF) + 6 * kPlaneBytes), 4, 0, 0);
 
-  // Every workgroup of an XCD streams the same split; walking it in the same order at the same time
-  // funnels all 32 CUs onto the same few L2 channels (measured: ~8 B/clk/CU, the kernel was bound by it).
-  // Each workgroup therefore starts at its own rotation of the chunk ring (the fixed exponent reference
-  // makes the result independent of chunk order).
-  const int wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = (gridDim.x + 7) >> 3;
-  int dpos = (int)(((int64_t)wg_in_xcd * nc) / wgs_per_xcd) % nc;  // ring position of the next chunk to fetch
+  // All workgroups of an XCD stream the same split in the same order, so a chunk is fetched from HBM/MALL once
+  // and hit in that XCD's L2 by the other 31 CUs (measured 92 % TCC hit rate; rotating each workgroup's start
+  // position was tried against L2-channel hot-spotting and was 5 % slower).
+  int dpos = 0;  // ring position of the next chunk to fetch
   ESR_DMA_INIT(c0 + dpos);
   ESR_DMA_ALL(lds);
   if (nc > 1) ESR_DMA_ALL(lds + kBufBytes);

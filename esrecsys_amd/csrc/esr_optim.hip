@@ -125,6 +125,94 @@ __global__ __launch_bounds__(kBlock) void segment_update_kernel(void* __restrict
   }
 }
 
+// Several tables updated by ONE sorted occurrence list: occurrence ids are "virtual rows" vid = row_offset[t] + id
+// of a concatenation of up to kMaxFusedTables tables with the same D (the two towers of one step), so a
+// step needs one sort chain and one update launch instead of one per table -- at the reference's batch sizes
+// the step is bound by the number of dependent launches, not by bytes (profiles/r1/triplet_kernel_stats.csv).
+constexpr int kMaxFusedTables = 4;
+struct FusedTables {
+  void* table[kMaxFusedTables];
+  float* accum[kMaxFusedTables];
+  int64_t row_offset[kMaxFusedTables + 1];
+  int n;
+};
+
+template <int VEC, int NCH>
+__global__ __launch_bounds__(kBlock) void segment_adagrad_multi_kernel(FusedTables ft, int dtype, int D, int G,
+                                                                      const int32_t* __restrict__ sorted_vids,
+                                                                      const int32_t* __restrict__ perm, int64_t n,
+                                                                      const float* __restrict__ grad_rows, float lr,
+                                                                      float eps) {
+  const int lig = threadIdx.x & (G - 1);
+  const int64_t gpb = kBlock / G;
+  const int64_t group = (int64_t)blockIdx.x * gpb + threadIdx.x / G;
+  const int64_t ngroups = (int64_t)gridDim.x * gpb;
+  const int nvec = D / VEC;
+  for (int64_t p = group; p < n; p += ngroups) {
+    const int32_t vid = sorted_vids[p];
+    if (p > 0 && sorted_vids[p - 1] == vid) continue;  // not the head of its run
+    RowRegs<VEC, NCH> g;
+    row_load(g, grad_rows + (int64_t)perm[p] * D, lig, G, nvec);
+    for (int64_t q = p + 1; q < n && sorted_vids[q] == vid; ++q) {
+      RowRegs<VEC, NCH> t;
+      row_load(t, grad_rows + (int64_t)perm[q] * D, lig, G, nvec);
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) g.v[k][e] += t.v[k][e];
+    }
+    // select chain with constant indices (a runtime index into the kernarg struct would go through scratch)
+    void* table = ft.table[0];
+    float* accum = ft.accum[0];
+    int64_t base = ft.row_offset[0];
+#pragma unroll
+    for (int k = 1; k < kMaxFusedTables; ++k)
+      if (k < ft.n && (int64_t)vid >= ft.row_offset[k]) {
+        table = ft.table[k];
+        accum = ft.accum[k];
+        base = ft.row_offset[k];
+      }
+    const int64_t id = (int64_t)vid - base;
+    RowRegs<VEC, NCH> w, a;
+    param_load(w, table, dtype, id, D, lig, G, nvec);
+    row_load(a, accum + id * D, lig, G, nvec);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float gv = g.v[k][e];
+        const float acc = fmaf(gv, gv, a.v[k][e]);
+        a.v[k][e] = acc;
+        const float inv = acc > 0.f ? 1.0f / sqrtf(acc + eps) : 0.f;
+        w.v[k][e] -= lr * gv * inv;
+      }
+    row_store(a, accum + id * D, lig, G, nvec);
+    param_store(w, table, dtype, id, D, lig, G, nvec);
+  }
+}
+
+struct IdSegments {
+  const int32_t* ids[kMaxFusedTables];
+  int64_t start[kMaxFusedTables + 1];  // output position of each segment
+  int64_t offset[kMaxFusedTables];     // added to every id of the segment
+  int n;
+};
+__global__ __launch_bounds__(kBlock) void concat_offset_ids_kernel(IdSegments sg, int32_t* __restrict__ out) {
+  const int64_t total = sg.start[sg.n];
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    const int32_t* src = sg.ids[0];
+    int64_t start = 0, off = sg.offset[0];
+#pragma unroll
+    for (int k = 1; k < kMaxFusedTables; ++k)
+      if (k < sg.n && i >= sg.start[k]) {
+        src = sg.ids[k];
+        start = sg.start[k];
+        off = sg.offset[k];
+      }
+    out[i] = (int32_t)((int64_t)src[i - start] + off);
+  }
+}
+
 template <int OP>
 static int launch_segment_update(const char* who, void* table, int dtype, float* accum, int D,
                                  const int32_t* sorted_ids, const int32_t* perm, int64_t n, const float* grad_rows,
@@ -215,6 +303,62 @@ int esr_rows_to_dense(float* dense, int64_t V, int D, const int32_t* sorted_ids,
   ESR_REQUIRE(sorted_ids && perm && grad_rows, "esr_rows_to_dense: null pointer");
   return launch_segment_update<kToDense>("esr_rows_to_dense", dense, ESR_F32, nullptr, D, sorted_ids, perm, n,
                                          grad_rows, 0.f, 0.f, st);
+}
+
+int esr_concat_offset_ids(const int32_t* const* ids, const int64_t* counts, const int64_t* offsets, int nseg,
+                          int32_t* out, esr_stream_t stream) {
+  ESR_REQUIRE(nseg >= 1 && nseg <= kMaxFusedTables, "esr_concat_offset_ids: nseg=%d not in [1, %d]", nseg,
+              kMaxFusedTables);
+  ESR_REQUIRE(ids && counts && offsets && out, "esr_concat_offset_ids: null pointer");
+  IdSegments sg;
+  sg.n = nseg;
+  sg.start[0] = 0;
+  for (int i = 0; i < kMaxFusedTables; ++i) {
+    sg.ids[i] = i < nseg ? ids[i] : nullptr;
+    sg.offset[i] = i < nseg ? offsets[i] : 0;
+    sg.start[i + 1] = sg.start[i] + (i < nseg ? counts[i] : 0);
+    if (i < nseg) {
+      ESR_REQUIRE(counts[i] >= 0 && (counts[i] == 0 || ids[i]), "esr_concat_offset_ids: bad segment %d", i);
+    }
+  }
+  const int64_t total = sg.start[nseg];
+  if (total == 0) return ESR_OK;
+  const int grid = (int)std::min<int64_t>(kMaxGrid, cdiv(total, kBlock));
+  hipLaunchKernelGGL(concat_offset_ids_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), sg, out);
+  return check_launch("esr_concat_offset_ids");
+}
+
+int esr_sparse_adagrad_scatter_multi(void* const* tables, float* const* accums, const int64_t* row_offsets,
+                                     int ntables, int dtype, int D, const int32_t* sorted_vids, const int32_t* perm,
+                                     int64_t n, const float* grad_rows, float lr, float eps, esr_stream_t stream) {
+  ESR_REQUIRE(ntables >= 1 && ntables <= kMaxFusedTables, "esr_sparse_adagrad_scatter_multi: ntables=%d not in [1, %d]",
+              ntables, kMaxFusedTables);
+  ESR_REQUIRE(D > 0 && n >= 0, "esr_sparse_adagrad_scatter_multi: bad sizes D=%d n=%lld", D, (long long)n);
+  ESR_REQUIRE(dtype == ESR_F32 || dtype == ESR_BF16, "esr_sparse_adagrad_scatter_multi: bad dtype %d", dtype);
+  if (n == 0) return ESR_OK;
+  ESR_REQUIRE(tables && accums && row_offsets && sorted_vids && perm && grad_rows,
+              "esr_sparse_adagrad_scatter_multi: null pointer");
+  FusedTables ft;
+  ft.n = ntables;
+  for (int i = 0; i < kMaxFusedTables; ++i) {
+    ft.table[i] = i < ntables ? tables[i] : nullptr;
+    ft.accum[i] = i < ntables ? accums[i] : nullptr;
+    ft.row_offset[i] = i <= ntables ? row_offsets[i] : row_offsets[ntables];
+    if (i < ntables) {
+      ESR_REQUIRE(tables[i] && accums[i] && row_offsets[i + 1] >= row_offsets[i],
+                  "esr_sparse_adagrad_scatter_multi: bad table %d", i);
+    }
+  }
+  ft.row_offset[kMaxFusedTables] = row_offsets[ntables];
+  ESR_REQUIRE(row_offsets[ntables] < ((int64_t)1 << 31), "esr_sparse_adagrad_scatter_multi: %lld virtual rows >= 2^31",
+              (long long)row_offsets[ntables]);
+  const RowGeom g = row_geom(D);
+  ESR_REQUIRE(g.nch <= kMaxChunksPerLane, "esr_sparse_adagrad_scatter_multi: D=%d not supported", D);
+  const int grid = grid_for_groups(n, g.G);
+  ESR_DISPATCH_ROW(g, hipLaunchKernelGGL((segment_adagrad_multi_kernel<VEC, NCH>), dim3(grid), dim3(kBlock), 0,
+                                         as_stream(stream), ft, dtype, D, g.G, sorted_vids, perm, n, grad_rows, lr,
+                                         eps));
+  return check_launch("esr_sparse_adagrad_scatter_multi");
 }
 
 int esr_dense_adam(float* param, float* mu, float* nu, const float* grad, int64_t numel, float lr, float b1,

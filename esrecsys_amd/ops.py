@@ -139,7 +139,7 @@ def glove_fwd_bwd(emb, bias, inputs, target, mode=GLOVE_REFERENCE, want_grads=Tr
 def triplet_fwd_bwd(scene_table, pos_table, neg_table, scene_ids, pos_ids, neg_ids, B, regularization, batch_size,
                     with_reg=True, want_grads=True, want_scores=True):
     """Fused STL head.  ids may be None (= row b).  Returns (loss[1], pos_score, neg_score, g_s, g_p, g_n);
-    g_p and g_n are the two halves of one [2B, D] buffer (``g_p._base``)."""
+    the three gradients are consecutive slices of one [3B, D] buffer (``g_s._base``)."""
     lib = _lib.load()
     for name, t in (("scene_table", scene_table), ("pos_table", pos_table), ("neg_table", neg_table)):
         _req(t, torch.float32, name)
@@ -155,12 +155,12 @@ def triplet_fwd_bwd(scene_table, pos_table, neg_table, scene_ids, pos_ids, neg_i
     loss = torch.empty(1, **f32)
     ps = torch.empty(B, **f32) if want_scores else None
     ns = torch.empty(B, **f32) if want_scores else None
-    gs = torch.empty((B, D), **f32) if want_grads else None
-    # pos and neg gradient rows share one [2B, D] buffer: both scatter into the product table, so the
-    # optimizer consumes them as a single occurrence list without a concatenation copy.
-    gpn = torch.empty((2 * B, D), **f32) if want_grads else None
-    gp = gpn[:B] if want_grads else None
-    gn = gpn[B:] if want_grads else None
+    # scene / pos / neg gradient rows share one [3B, D] buffer ([scene ; pos ; neg]): the optimizer consumes
+    # them as a single occurrence list (``g_s._base``; ``g_s._base[B:]`` = the product rows) with no copy.
+    gall = torch.empty((3 * B, D), **f32) if want_grads else None
+    gs = gall[:B] if want_grads else None
+    gp = gall[B:2 * B] if want_grads else None
+    gn = gall[2 * B:] if want_grads else None
     ws = _ws(_ws_bytes("esr_triplet_workspace_bytes", B), dev)
     check(lib.esr_triplet_fwd_bwd(_p(scene_table), Vs, _p(pos_table), Vp, _p(neg_table), Vn, D, _p(scene_ids),
                                   _p(pos_ids), _p(neg_ids), B, float(regularization), float(batch_size),
@@ -192,8 +192,8 @@ def inbatch_softmax_fwd_bwd(Q, C, scale, regularization, batch_size, precision="
     dev = Q.device
     loss = torch.empty(1, dtype=torch.float32, device=dev)
     lse = torch.empty(B, dtype=torch.float32, device=dev)
-    gQ = torch.empty_like(Q)
-    gC = torch.empty_like(C)
+    gQC = torch.empty((2 * B, D), dtype=torch.float32, device=dev)  # [gQ ; gC]: one occurrence list downstream
+    gQ, gC = gQC[:B], gQC[B:]
     if use_split:
         ws = _ws(_ws_bytes("esr_inbatch3_workspace_bytes", B, D), dev)
         fn, name = lib.esr_inbatch_softmax_fwd_bwd_bf16x3, "esr_inbatch_softmax_fwd_bwd_bf16x3"
@@ -232,6 +232,45 @@ def sparse_adagrad(table, accum, sorted_ids, perm, grad_rows, lr, eps=1e-7):
                          (tuple(grad_rows.shape), tuple(table.shape), tuple(accum.shape), n))
     check(lib.esr_sparse_adagrad_scatter(_p(table), dt, _p(accum), V, D, _p(sorted_ids), _p(perm), n, _p(grad_rows),
                                          float(lr), float(eps), _stream()), "esr_sparse_adagrad_scatter")
+
+
+def concat_offset_ids(id_tensors, offsets):
+    """[ids_0 + offsets[0] ; ids_1 + offsets[1] ; ...] as one int32 tensor (virtual rows of concatenated tables)."""
+    import ctypes
+    lib = _lib.load()
+    n = len(id_tensors)
+    for t in id_tensors:
+        _req(t, torch.int32, "ids")
+    counts = [int(t.numel()) for t in id_tensors]
+    out = torch.empty(sum(counts), dtype=torch.int32, device=id_tensors[0].device)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in id_tensors])
+    cnt = (ctypes.c_int64 * n)(*counts)
+    off = (ctypes.c_int64 * n)(*[int(o) for o in offsets])
+    check(lib.esr_concat_offset_ids(ptrs, cnt, off, n, _p(out), _stream()), "esr_concat_offset_ids")
+    return out
+
+
+def sparse_adagrad_multi(tables, accums, row_offsets, sorted_vids, perm, grad_rows, lr, eps=1e-7):
+    """One launch of row-sparse Adagrad over several same-width tables addressed by virtual rows."""
+    import ctypes
+    lib = _lib.load()
+    n_t = len(tables)
+    dts = {_table_dtype(t, "table") for t in tables}
+    if len(dts) != 1:
+        raise TypeError("fused tables must share a dtype")
+    D = tables[0].shape[1] if tables[0].dim() > 1 else 1
+    for t, a in zip(tables, accums):
+        _req(a, torch.float32, "accum")
+        if (t.shape[1] if t.dim() > 1 else 1) != D or a.numel() != t.numel():
+            raise ValueError("fused tables must share D and have matching accumulators")
+    _req(grad_rows, torch.float32, "grad_rows")
+    n = sorted_vids.numel()
+    tp = (ctypes.c_void_p * n_t)(*[t.data_ptr() for t in tables])
+    ap = (ctypes.c_void_p * n_t)(*[a.data_ptr() for a in accums])
+    ro = (ctypes.c_int64 * (n_t + 1))(*[int(o) for o in row_offsets])
+    check(lib.esr_sparse_adagrad_scatter_multi(tp, ap, ro, n_t, dts.pop(), D, _p(sorted_vids), _p(perm), n,
+                                               _p(grad_rows), float(lr), float(eps), _stream()),
+          "esr_sparse_adagrad_scatter_multi")
 
 
 def sparse_sgd(table, sorted_ids, perm, grad_rows, lr):

@@ -63,14 +63,44 @@ class SegmentIndex:
         return self._sorted
 
 
+class FusedScatter:
+    """The gradients of several same-width tables as ONE occurrence list: ``rows`` is the concatenation of the
+    per-segment gradient rows and the ids are virtual rows ``row_offsets[slot] + id`` of the concatenated
+    tables, so a step needs one sort chain and one optimizer launch for all its towers.
+
+    id_tensors[i] indexes table ``slots[i]``; ``num_rows[t]`` / ``paths[t]`` describe table t (its row count
+    and the path of its parameter leaf)."""
+
+    def __init__(self, id_tensors, slots, num_rows, rows, paths):
+        offs = [0]
+        for v in num_rows:
+            offs.append(offs[-1] + int(v))
+        self.row_offsets = offs
+        self.paths = [tuple(p) for p in paths]
+        self.rows = rows  # f32 [sum n_i, D]; may be filled in later (the ids are known before the gradients)
+        vids = ops.concat_offset_ids(list(id_tensors), [offs[s] for s in slots])
+        self.index = SegmentIndex(vids, offs[-1])
+
+
 class RowGrads:
     """Row-sparse gradient of a [V, D] table: ``rows[k]`` is the gradient contribution of occurrence k to
-    row ``index.ids[k]``; duplicates accumulate (same meaning as JAX's scatter-add for nn.Embed)."""
+    row ``index.ids[k]``; duplicates accumulate (same meaning as JAX's scatter-add for nn.Embed).
+    ``index`` may be given as a list of id tensors (concatenated on first use).  ``fused`` (optional) is the
+    FusedScatter this leaf is a member of."""
 
-    def __init__(self, index, rows, shape):
-        self.index = index
+    def __init__(self, index, rows, shape, fused=None):
+        self._index = index
         self.rows = rows      # f32 [n, D]
         self.shape = tuple(shape)
+        self.fused = fused
+
+    @property
+    def index(self):
+        if not isinstance(self._index, SegmentIndex):
+            parts = list(self._index)
+            ids = parts[0] if len(parts) == 1 else torch.cat(parts)
+            self._index = SegmentIndex(ids, self.shape[0])
+        return self._index
 
     def to_dense(self):
         """The dense gradient the reference materialises (wikipedia/train_cooccurence.py:86-87)."""
@@ -146,12 +176,23 @@ class _SparseAdagrad(GradientTransformation):
             lambda p: torch.full(p.shape, self.init_acc, dtype=torch.float32, device=p.device), params)}
 
     def apply(self, params, grads, opt_state, step):
+        done = set()
         for path, p in tree_leaves_with_path(params):
             g = tree_get(grads, path)
             if g is None:
                 continue
             if not isinstance(g, RowGrads):
                 raise TypeError("sparse_adagrad needs RowGrads leaves (got %s at %s)" % (type(g).__name__, path))
+            f = g.fused
+            if f is not None and tuple(path) in f.paths:
+                if id(f) in done:
+                    continue
+                done.add(id(f))  # all members of the fused scatter in one sort + one launch
+                sorted_vids, perm = f.index.sorted()
+                ops.sparse_adagrad_multi([tree_get(params, q) for q in f.paths],
+                                         [tree_get(opt_state["sum_of_squares"], q) for q in f.paths],
+                                         f.row_offsets, sorted_vids, perm, f.rows, self.lr, self.eps)
+                continue
             sorted_ids, perm = g.index.sorted()
             ops.sparse_adagrad(p, tree_get(opt_state["sum_of_squares"], path), sorted_ids, perm, g.rows, self.lr,
                                self.eps)

@@ -58,7 +58,6 @@ def apply_model(state, inputs, target):
     inputs = ops.as_ids(inputs, emb.device, check_range=V)
     target = ops.as_f32(target, emb.device)
     index = SegmentIndex(inputs.reshape(-1), V)  # occurrence ids = [token1 ; token2]
-    index.presort()  # needs the ids only: overlaps the fused loss kernels on a side stream
     loss, grad_rows, grad_bias = ops.glove_fwd_bwd(emb, bias, inputs, target, mode)
     g_emb = RowGrads(index, grad_rows, emb.shape)
     g_bias = RowGrads(index, grad_bias.reshape(-1, 1), bias.shape)

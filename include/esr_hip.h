@@ -123,6 +123,17 @@ int esr_segment_sort_ids(const int32_t* ids, int64_t n, int64_t V, int32_t* sort
 int esr_sparse_adagrad_scatter(void* table, int dtype, float* accum, int64_t V, int D,
                                const int32_t* sorted_ids, const int32_t* perm, int64_t n,
                                const float* grad_rows, float lr, float eps, esr_stream_t stream);
+/* Several tables (same D, same dtype) updated from ONE sorted occurrence list: ids are virtual rows
+ * vid = row_offsets[t] + id of the concatenation of <= 4 tables, so a two-tower step needs one sort chain
+ * and one update launch.  tables / accums / row_offsets (ntables + 1 entries) are HOST arrays of device
+ * pointers / int64.  esr_concat_offset_ids builds the virtual ids: out = [ids[0] + offsets[0] ; ids[1] + ...]
+ * (ids / counts / offsets are host arrays; the id buffers are device memory). */
+int esr_concat_offset_ids(const int32_t* const* ids, const int64_t* counts, const int64_t* offsets, int nseg,
+                          int32_t* out, esr_stream_t stream);
+int esr_sparse_adagrad_scatter_multi(void* const* tables, float* const* accums, const int64_t* row_offsets,
+                                     int ntables, int dtype, int D, const int32_t* sorted_vids,
+                                     const int32_t* perm, int64_t n, const float* grad_rows, float lr, float eps,
+                                     esr_stream_t stream);
 /* Row-sparse SGD (p -= lr * G), same segment reduction. */
 int esr_sparse_sgd_scatter(void* table, int dtype, int64_t V, int D, const int32_t* sorted_ids,
                            const int32_t* perm, int64_t n, const float* grad_rows, float lr,

@@ -53,8 +53,8 @@ class _Halves(torch.Tensor):
 def triplet_fwd_bwd(s, p, n, sid, pid, nid, B, lam, bs, with_reg=True, want_grads=True, want_scores=True):
     assert sid is None and pid is None and nid is None
     loss, gs, gp, gn = o_stl.triplet_loss_and_grads(s.numpy(), p.numpy(), n.numpy(), lam, bs, np.float64)
-    gpn = _t(np.concatenate([gp, gn]))
-    return _t(np.array([loss])), None, None, _t(gs), gpn[:B], gpn[B:]
+    gall = _t(np.concatenate([gs, gp, gn]))
+    return _t(np.array([loss])), None, None, gall[:B], gall[B:2 * B], gall[2 * B:]
 
 
 def inbatch_softmax_fwd_bwd(q, c, scale, lam, bs):

@@ -198,7 +198,7 @@ def test_triplet_with_id_towers_vs_oracle(dev, D, B):
     el, egs, egp, egn = o_stl.triplet_loss_and_grads(st[sid], pt[pid], pt[nid], 0.1, B, F64)
     assert abs(float(loss) - el) / abs(el) <= TOL
     assert rel_err(N(gs), egs) <= TOL and rel_err(N(gp), egp) <= TOL and rel_err(N(gn), egn) <= TOL
-    assert gp._base is gn._base and gp._base.shape == (2 * B, D)
+    assert gs._base is gn._base and gs._base.shape == (3 * B, D)  # [scene ; pos ; neg] in one buffer
 
 
 # ------------------------------------------------------------------------------------------------
@@ -363,6 +363,37 @@ def test_sparse_adagrad_bf16_table(dev):
     assert np.mean(got == exp_bf16) > 0.999
     assert rel_err(got, ep) <= 2.0 ** -8
     assert rel_err(N(accum), ea) <= TOL
+
+
+def test_fused_multi_table_adagrad_equals_per_table(dev):
+    """concat_offset_ids + one sort + esr_sparse_adagrad_scatter_multi == the per-table path, bit for bit."""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(21)
+    V0, V1, D, B = 700, 1100, 128, 600
+    t0, t1 = rng.standard_normal((V0, D)).astype(np.float32), rng.standard_normal((V1, D)).astype(np.float32)
+    i0 = rng.integers(0, V0, B).astype(np.int32)
+    i1 = rng.integers(0, V1, B).astype(np.int32)
+    i2 = rng.integers(0, V1, B).astype(np.int32)
+    i0[:50], i1[:50], i2[:50] = 0, V1 - 1, V1 - 1  # duplicates, shared rows between segments 1 and 2, edge rows
+    rows = (rng.standard_normal((3 * B, D)) * 0.1).astype(np.float32)
+    # fused: segments [i0 -> table0, i1 -> table1, i2 -> table1]
+    f0, f1 = T(t0, dev), T(t1, dev)
+    a0, a1 = torch.full((V0, D), 0.1, device=dev), torch.full((V1, D), 0.1, device=dev)
+    vids = ops.concat_offset_ids([T(i0, dev), T(i1, dev), T(i2, dev)], [0, V0, V0])
+    assert np.array_equal(N(vids), np.concatenate([i0, i1 + V0, i2 + V0]))
+    sv, perm = ops.segment_sort(vids, V0 + V1)
+    ops.sparse_adagrad_multi([f0, f1], [a0, a1], [0, V0, V0 + V1], sv, perm, T(rows, dev), 0.05, 1e-7)
+    # per-table reference path
+    p0, p1 = T(t0, dev), T(t1, dev)
+    b0, b1 = torch.full((V0, D), 0.1, device=dev), torch.full((V1, D), 0.1, device=dev)
+    s0, q0 = ops.segment_sort(T(i0, dev), V0)
+    ops.sparse_adagrad(p0, b0, s0, q0, T(rows[:B], dev), 0.05, 1e-7)
+    s1, q1 = ops.segment_sort(T(np.concatenate([i1, i2]), dev), V1)
+    ops.sparse_adagrad(p1, b1, s1, q1, T(rows[B:], dev), 0.05, 1e-7)
+    assert torch.equal(f0, p0) and torch.equal(f1, p1) and torch.equal(a0, b0) and torch.equal(a1, b1)
+    e1, _ = o_optim.sparse_adagrad_update(t1.astype(F64), np.full((V1, D), 0.1), np.concatenate([i1, i2]),
+                                          rows[B:].astype(F64), 0.05, 1e-7, F64)
+    assert rel_err(N(f1), e1) <= TOL
 
 
 def test_sparse_sgd_vs_oracle(dev):

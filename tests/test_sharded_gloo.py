@@ -124,3 +124,65 @@ def test_sharded_inbatch_matches_per_rank_oracle():
                                                 dtype=np.float64)
     assert np.abs(_reassemble(outs, "scene", V_S) - st).max() <= 1e-12
     assert np.abs(_reassemble(outs, "prod", V_P) - pt).max() <= 1e-12
+
+
+def _glove_worker(rank, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    import _cpu_kernels as K
+    from esrecsys_amd import sharded
+    rng = np.random.default_rng(11)
+    V, Dg, Bg = 97, 8, 20
+    emb0, bias0 = rng.standard_normal((V, Dg)) * 0.3, rng.standard_normal((V, 1)) * 0.05
+    mk = lambda full: torch.from_numpy(np.ascontiguousarray(full[rank::WORLD]))  # noqa: E731
+    emb = sharded.RowShardedTable(mk(emb0), torch.full_like(mk(emb0), 0.1), V, kernels=K)
+    bias = sharded.RowShardedTable(mk(bias0), torch.full_like(mk(bias0), 0.1), V, kernels=K)
+    brng = np.random.default_rng(100 + rank)
+    batches = [(brng.integers(0, V, (2, Bg)).astype(np.int32), brng.uniform(0.1, 300, Bg)) for _ in range(3)]
+    # prefetch the routing plan of the next batch right after each step, as the bench loop does
+    nxt = sharded.plan_glove(emb, bias, torch.from_numpy(batches[0][0]))
+    for i, (inp, tgt) in enumerate(batches):
+        cur = nxt
+        sharded.sharded_glove_step(emb, bias, torch.from_numpy(inp), torch.from_numpy(tgt), K.GLOVE_DIAGONAL, 0.05,
+                                   plans=cur)
+        if i + 1 < len(batches):
+            nxt = sharded.plan_glove(emb, bias, torch.from_numpy(batches[i + 1][0]))
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), emb=emb.local.numpy(), bias=bias.local.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_glove_with_prefetched_plans_equals_single_device():
+    """Diagonal-mode GloVe is a sum over pairs with a 1/B factor: G ranks x B pairs with the per-rank 1/B
+    equals a single device applying each rank's batch gradients to one table."""
+    import socket
+    from oracle import glove as o_glove
+    from oracle import optim as o_optim
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_glove_worker, args=(port, d), nprocs=WORLD, join=True)
+        outs = [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(WORLD)]
+    rng = np.random.default_rng(11)
+    V, Dg, Bg = 97, 8, 20
+    emb, bias = rng.standard_normal((V, Dg)) * 0.3, rng.standard_normal((V, 1)) * 0.05
+    a_e, a_b = np.full_like(emb, 0.1), np.full_like(bias, 0.1)
+    brngs = [np.random.default_rng(100 + r) for r in range(WORLD)]
+    per_rank = [[(g.integers(0, V, (2, Bg)).astype(np.int32), g.uniform(0.1, 300, Bg)) for _ in range(3)] for g in brngs]
+    for step in range(3):
+        ids_all, rows_all, gb_all = [], [], []
+        for r in range(WORLD):
+            inp, tgt = per_rank[r][step]
+            _, gdot, gs = o_glove.loss_and_grads(emb, bias, inp, tgt, "diagonal", np.float64)
+            ids, rows, gb = o_glove.row_grads(emb, inp, gdot, gs, np.float64)
+            ids_all.append(ids), rows_all.append(rows), gb_all.append(gb)
+        ids_c = np.concatenate(ids_all)
+        emb, a_e = o_optim.sparse_adagrad_update(emb, a_e, ids_c, np.concatenate(rows_all), 0.05, dtype=np.float64)
+        bias, a_b = o_optim.sparse_adagrad_update(bias, a_b, ids_c, np.concatenate(gb_all)[:, None], 0.05,
+                                                  dtype=np.float64)
+    full_e, full_b = np.zeros((V, Dg)), np.zeros((V, 1))
+    for r in range(WORLD):
+        full_e[r::WORLD], full_b[r::WORLD] = outs[r]["emb"], outs[r]["bias"]
+    assert np.abs(full_e - emb).max() <= 1e-12 and np.abs(full_b - bias).max() <= 1e-12
