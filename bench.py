@@ -221,7 +221,7 @@ def main():
         "triplet_fused": ["triplet_fwd_bwd"],
         "glove_fused": ["glove_fwd_bwd"],
         "segment_sort": ["segment_sort"],
-        "sparse_adagrad": ["sparse_adagrad"],
+        "sparse_adagrad": ["sparse_adagrad", "sparse_adagrad_multi"],
     })
     timer.install()
 

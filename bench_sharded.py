@@ -20,13 +20,15 @@ def run_sharded(args, cfg, dev, rank, world):
     def shard(num_rows, dim):
         n = sharded.RowShardedTable.local_rows_for(num_rows, world, rank)
         t = torch.randn((n, dim), generator=gen, device=dev, dtype=torch.float32).mul_(dim ** -0.5)
-        return sharded.RowShardedTable(t, torch.full((n, dim), 0.1, device=dev), num_rows, kernels=ops)
+        return sharded.RowShardedTable(t, torch.full((n, dim), 0.1, device=dev), num_rows)
 
     if args.workload == "glove":
-        emb, bias = shard(V, D), shard(V, 1)
-        bias.local.zero_()
+        emb_t, bias_t = shard(V, D), shard(V, 1)
+        bias_t.local.zero_()
+        emb = sharded.ShardedTableGroup([emb_t], kernels=ops)
+        bias = sharded.ShardedTableGroup([bias_t], kernels=ops)
     else:
-        scene, prod = shard(V, D), shard(V, D)
+        towers = sharded.ShardedTableGroup([shard(V, D), shard(V, D)], kernels=ops)  # scene, product
     n_batches = args.steps + args.warmup
     batches = []
     for _ in range(n_batches):
@@ -41,17 +43,17 @@ def run_sharded(args, cfg, dev, rank, world):
 
     def plan(b):
         if args.workload == "glove":
-            return sharded.plan_glove(emb, bias, b[0])
+            return sharded.plan_glove(emb, b[0])
         if args.workload == "inbatch":
-            return sharded.plan_inbatch(scene, prod, b[0], b[1])
-        return sharded.plan_triplet(scene, prod, b[0], b[1], b[2])
+            return sharded.plan_inbatch(towers, b[0], b[1])
+        return sharded.plan_triplet(towers, b[0], b[1], b[2])
 
     def step(b, plans):
         if args.workload == "glove":
-            return sharded.sharded_glove_step(emb, bias, b[0], b[1], ops.GLOVE_REFERENCE, LR, plans=plans)
+            return sharded.sharded_glove_step(emb, bias, b[0], b[1], ops.GLOVE_REFERENCE, LR, plan=plans)
         if args.workload == "inbatch":
-            return sharded.sharded_inbatch_step(scene, prod, b[0], b[1], LAM, gb, SCALE, LR, plans=plans)
-        return sharded.sharded_triplet_step(scene, prod, b[0], b[1], b[2], LAM, gb, LR, plans=plans)
+            return sharded.sharded_inbatch_step(towers, b[0], b[1], LAM, gb, SCALE, LR, plan=plans)
+        return sharded.sharded_triplet_step(towers, b[0], b[1], b[2], LAM, gb, LR, plan=plans)
 
     # The routing plan of batch k+1 (bucket + counts all-to-all + the one host read-back + ids all-to-all)
     # only needs its ids: it is built right after step k has been enqueued, inside the timed region, so the

@@ -191,6 +191,30 @@ __global__ __launch_bounds__(kBlock) void segment_adagrad_multi_kernel(FusedTabl
   }
 }
 
+// out[i, :] = tables[t][vid - row_offset[t], :] for virtual rows of up to kMaxFusedTables same-width tables
+// (the owner side of a fused two-tower lookup).  16-byte chunks, one row group per output row.
+__global__ __launch_bounds__(kBlock) void gather_rows_multi_kernel(FusedTables ft, int nchunk, int G,
+                                                                  const int32_t* __restrict__ vids, int64_t n,
+                                                                  uint4* __restrict__ out) {
+  const int lig = threadIdx.x & (G - 1);
+  const int64_t gpb = kBlock / G;
+  const int64_t group = (int64_t)blockIdx.x * gpb + threadIdx.x / G;
+  const int64_t ngroups = (int64_t)gridDim.x * gpb;
+  for (int64_t r = group; r < n; r += ngroups) {
+    const int64_t vid = vids[r];
+    const uint4* table = reinterpret_cast<const uint4*>(ft.table[0]);
+    int64_t base = ft.row_offset[0];
+#pragma unroll
+    for (int k = 1; k < kMaxFusedTables; ++k)
+      if (k < ft.n && vid >= ft.row_offset[k]) {
+        table = reinterpret_cast<const uint4*>(ft.table[k]);
+        base = ft.row_offset[k];
+      }
+    const uint4* src = table + (vid - base) * nchunk;
+    for (int c = lig; c < nchunk; c += G) out[r * nchunk + c] = src[c];
+  }
+}
+
 struct IdSegments {
   const int32_t* ids[kMaxFusedTables];
   int64_t start[kMaxFusedTables + 1];  // output position of each segment
@@ -326,6 +350,34 @@ int esr_concat_offset_ids(const int32_t* const* ids, const int64_t* counts, cons
   const int grid = (int)std::min<int64_t>(kMaxGrid, cdiv(total, kBlock));
   hipLaunchKernelGGL(concat_offset_ids_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), sg, out);
   return check_launch("esr_concat_offset_ids");
+}
+
+int esr_gather_rows_multi(const void* const* tables, const int64_t* row_offsets, int ntables, int dtype, int D,
+                          const int32_t* vids, int64_t n, void* out, esr_stream_t stream) {
+  ESR_REQUIRE(ntables >= 1 && ntables <= kMaxFusedTables, "esr_gather_rows_multi: ntables=%d not in [1, %d]", ntables,
+              kMaxFusedTables);
+  ESR_REQUIRE(dtype == ESR_F32 || dtype == ESR_BF16, "esr_gather_rows_multi: bad dtype %d", dtype);
+  ESR_REQUIRE(D > 0 && n >= 0, "esr_gather_rows_multi: bad sizes D=%d n=%lld", D, (long long)n);
+  const int64_t row_bytes = (int64_t)D * (dtype == ESR_BF16 ? 2 : 4);
+  ESR_REQUIRE(row_bytes % 16 == 0, "esr_gather_rows_multi: row of %lld bytes is not a multiple of 16", (long long)row_bytes);
+  if (n == 0) return ESR_OK;
+  ESR_REQUIRE(tables && row_offsets && vids && out, "esr_gather_rows_multi: null pointer");
+  FusedTables ft;
+  ft.n = ntables;
+  for (int i = 0; i < kMaxFusedTables; ++i) {
+    ft.table[i] = i < ntables ? const_cast<void*>(tables[i]) : nullptr;
+    ft.accum[i] = nullptr;
+    ft.row_offset[i] = i <= ntables ? row_offsets[i] : row_offsets[ntables];
+    if (i < ntables) ESR_REQUIRE(tables[i], "esr_gather_rows_multi: null table %d", i);
+  }
+  ft.row_offset[kMaxFusedTables] = row_offsets[ntables];
+  const int nchunk = (int)(row_bytes / 16);
+  int G = 1;
+  while (G < nchunk && G < kWave) G <<= 1;
+  const int grid = grid_for_groups(n, G);
+  hipLaunchKernelGGL(gather_rows_multi_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), ft, nchunk, G, vids, n,
+                     (uint4*)out);
+  return check_launch("esr_gather_rows_multi");
 }
 
 int esr_sparse_adagrad_scatter_multi(void* const* tables, float* const* accums, const int64_t* row_offsets,

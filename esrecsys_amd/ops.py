@@ -250,6 +250,26 @@ def concat_offset_ids(id_tensors, offsets):
     return out
 
 
+def gather_rows_multi(tables, row_offsets, vids, out=None):
+    """out[i] = tables[t][vids[i] - row_offsets[t]] for virtual rows of several same-width tables."""
+    import ctypes
+    lib = _lib.load()
+    n_t = len(tables)
+    dts = {_table_dtype(t, "table") for t in tables}
+    if len(dts) != 1:
+        raise TypeError("fused tables must share a dtype")
+    D = tables[0].shape[1] if tables[0].dim() > 1 else 1
+    vids = _req(vids, torch.int32, "vids")
+    n = vids.numel()
+    if out is None:
+        out = torch.empty((n, D), dtype=tables[0].dtype, device=vids.device)
+    tp = (ctypes.c_void_p * n_t)(*[t.data_ptr() for t in tables])
+    ro = (ctypes.c_int64 * (n_t + 1))(*[int(o) for o in row_offsets])
+    check(lib.esr_gather_rows_multi(tp, ro, n_t, dts.pop(), D, _p(vids), n, _p(out), _stream()),
+          "esr_gather_rows_multi")
+    return out
+
+
 def sparse_adagrad_multi(tables, accums, row_offsets, sorted_vids, perm, grad_rows, lr, eps=1e-7):
     """One launch of row-sparse Adagrad over several same-width tables addressed by virtual rows."""
     import ctypes

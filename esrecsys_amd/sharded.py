@@ -1,20 +1,23 @@
 """Row-sharded embedding tables across the GPUs of one node (build-defined -- the
 reference is single-device and has no collective anywhere).
 
-Partitioning: ``owner = id mod G``, ``local_row = id div G``; every rank holds V/G rows of the table and
-of the optimizer accumulator.  The batch is data-parallel (each rank draws its own pairs).  Per step and
-per table there are three exchanges over RCCL all-to-all (xGMI is a full mesh, so every peer slice rides
-its own link):
+Partitioning: ``owner = id mod G``, ``local_row = id div G``; every rank holds V/G rows of each table and
+of its optimizer accumulator.  The batch is data-parallel (each rank draws its own pairs).
 
-    ids   -> owners      (bucket_ids_by_owner kernel, all_to_all_single of int32 local rows)
-    rows  <- owners      (gather kernel on the owner, all_to_all_single of [n, D] rows, un-permute kernel)
-    grads -> owners      (permute kernel, all_to_all_single, then the usual sort + segment-reduce + Adagrad)
+Tables of the same width that are used by the same step (the two towers) form a ``ShardedTableGroup`` and
+travel together: their ids become *virtual ids* ``voff[t] + id`` with every ``voff[t]`` a multiple of G, so
+``owner = vid mod G`` is still the table-local owner and ``vid div G`` is a virtual local row that the
+owner maps back to (table, local row).  One step of a group is then four collectives over RCCL all-to-all
+(xGMI is a full mesh: every peer slice rides its own link) instead of three per table:
 
-Routing depends on the ids only, so it is split off as a *plan* (``make_plans``): bucket every lookup of
-the step, exchange all per-peer counts in ONE all-to-all and read them back with ONE host
-synchronisation (all_to_all_single needs host-side split sizes).  A training loop builds the plan for
-batch k+1 right after it has enqueued step k, so the read-back waits behind useful GPU work instead of
-draining the queue in the middle of a step.
+    counts -> peers      int64 [G, L]                      \\  the routing PLAN: depends on the ids only, built
+    vids   -> owners     int32 virtual local rows          /   for batch k+1 right after step k is enqueued
+    rows   <- owners     [n, D]  (multi-table gather kernel on the owner, un-permute kernel on return)
+    grads  -> owners     [n, D]  (permute kernel; then ONE fused sort + segment-reduce + Adagrad launch)
+
+The plan phase holds the step's single host synchronisation (``all_to_all_single`` needs host-side split
+sizes); a training loop issues it one batch ahead so the read-back waits behind useful GPU work.  The
+owner-side sort of the received ids is part of the plan as well.
 
 ``torch.distributed`` is plumbing (backend "nccl" == RCCL on ROCm; "gloo" in the CPU tests); the kernels
 are libesr_hip.so.  ``kernels`` is the module that provides them -- always ``esrecsys_amd.ops`` in the
@@ -24,99 +27,17 @@ import torch
 import torch.distributed as dist
 
 
-class RoutingPlan:
-    """Where the ids of one lookup go: everything that does not depend on table contents."""
-
-    def __init__(self, table, n, local_rows, perm, send_counts, recv_counts):
-        self.table = table
-        self.n = n
-        self.local_rows = local_rows        # int32 [n]: ids // G in bucket (owner-major, stable) order
-        self.perm = perm                    # int32 [n]: bucket order -> original position
-        self.send_counts = send_counts      # python ints per peer: ids this rank asks of that peer
-        self.recv_counts = recv_counts      # python ints per peer: ids that peer asks of this rank
-        self.recv_local_rows = None         # int32 [sum(recv_counts)]: filled by exchange_ids()
-        self.owner_sorted = None            # (sorted local rows, permutation) of recv_local_rows, for the update
-
-    def exchange_ids(self):
-        """ids -> owners.  Separate from make_plans so it can be issued ahead of the step as well."""
-        if self.recv_local_rows is None:
-            t = self.table
-            self.recv_local_rows = torch.empty(sum(self.recv_counts), dtype=torch.int32, device=self.local_rows.device)
-            dist.all_to_all_single(self.recv_local_rows, self.local_rows, self.recv_counts, self.send_counts,
-                                   group=t.group)
-            if self.recv_local_rows.numel():  # the owner-side sort needs the ids only: do it ahead of the step
-                self.owner_sorted = t.k.segment_sort(self.recv_local_rows, t.local.shape[0])
-        return self.recv_local_rows
-
-
-def make_plans(lookups):
-    """lookups: list of (RowShardedTable, global ids int32 [n]).  One counts all-to-all and one host sync
-    for the whole list.  Returns one RoutingPlan per lookup (ids already exchanged)."""
-    if not lookups:
-        return []
-    t0 = lookups[0][0]
-    k, G, group = t0.k, t0.world, t0.group
-    parts = []
-    for table, ids in lookups:
-        local_rows, perm, counts = k.bucket_ids_by_owner(ids, G)
-        parts.append((table, ids.numel(), local_rows, perm, counts))
-    # counts laid out [peer][lookup] so that all_to_all_single hands every peer its L counts
-    send = torch.stack([p[4] for p in parts], dim=1).contiguous()          # [G, L] int64
-    recv = torch.empty_like(send)
-    dist.all_to_all_single(recv, send, group=group)
-    both = torch.stack([send, recv]).cpu()                                  # the step's one host sync
-    plans = []
-    for i, (table, n, local_rows, perm, _) in enumerate(parts):
-        plans.append(RoutingPlan(table, n, local_rows, perm, both[0, :, i].tolist(), both[1, :, i].tolist()))
-    for p in plans:
-        p.exchange_ids()
-    return plans
-
-
 class RowShardedTable:
-    def __init__(self, local_table, local_accum, num_rows, group=None, kernels=None):
-        if kernels is None:
-            from . import ops as kernels
-        self.k = kernels
+    """This rank's shard of one table: rows rank, rank + G, rank + 2G, ... and their fp32 accumulator."""
+
+    def __init__(self, local_table, local_accum, num_rows):
         self.local = local_table      # [ceil((V - rank) / G), D]
         self.accum = local_accum      # fp32, same shape
         self.num_rows = int(num_rows)
-        self.group = group
-        self.world = dist.get_world_size(group)
-        self.rank = dist.get_rank(group)
 
     @staticmethod
     def local_rows_for(num_rows, world, rank):
         return (num_rows - rank + world - 1) // world
-
-    def lookup(self, plan_or_ids):
-        """rows[i] = table[ids[i]] for global ids on this rank -> ([n, D] rows in the order of ids, plan)."""
-        plan = plan_or_ids if isinstance(plan_or_ids, RoutingPlan) else make_plans([(self, plan_or_ids)])[0]
-        k = self.k
-        recv_ids = plan.exchange_ids()
-        served = k.gather_rows(self.local, recv_ids)                            # [sum(recv), D]
-        back = torch.empty((plan.n, self.local.shape[1]), dtype=self.local.dtype, device=served.device)
-        dist.all_to_all_single(back, served, plan.send_counts, plan.recv_counts, group=self.group)
-        rows = k.unpermute_rows(back, plan.perm)                                # bucket order -> id order
-        return rows, plan
-
-    def route_grads(self, plan, grad_rows):
-        """Per-occurrence gradient rows (order of the looked-up ids) -> (local_row_ids, rows) on the owners."""
-        k = self.k
-        D = grad_rows.shape[1]
-        bucketed = k.gather_rows(grad_rows, plan.perm)                          # id order -> bucket order
-        recv = torch.empty((sum(plan.recv_counts), D), dtype=grad_rows.dtype, device=grad_rows.device)
-        dist.all_to_all_single(recv, bucketed, plan.recv_counts, plan.send_counts, group=self.group)
-        return plan.recv_local_rows, recv
-
-    def apply_sparse_adagrad(self, plan, grad_rows, lr, eps=1e-7):
-        """Route the gradients to their owners and update the local shard (sort + segment-reduce + RMW)."""
-        k = self.k
-        local_ids, rows = self.route_grads(plan, grad_rows)
-        if local_ids.numel() == 0:
-            return
-        sorted_ids, perm = plan.owner_sorted
-        k.sparse_adagrad(self.local, self.accum, sorted_ids, perm, rows, lr, eps)
 
 
 def shard_of(table, world, rank):
@@ -124,60 +45,175 @@ def shard_of(table, world, rank):
     return table[rank::world].contiguous()
 
 
-def plan_inbatch(scene, product, scene_ids, pos_ids):
-    return make_plans([(scene, scene_ids), (product, pos_ids)])
+class RoutingPlan:
+    """Where the ids of one group lookup go: everything that does not depend on table contents."""
+
+    def __init__(self, group, n, local_rows, perm, send_counts, recv_counts):
+        self.group = group
+        self.n = n
+        self.local_rows = local_rows        # int32 [n]: vid // G in bucket (owner-major, stable) order
+        self.perm = perm                    # int32 [n]: bucket order -> original position
+        self.send_counts = send_counts      # python ints per peer: ids this rank asks of that peer
+        self.recv_counts = recv_counts      # python ints per peer: ids that peer asks of this rank
+        self.recv_local_rows = None         # int32 [sum(recv_counts)]: virtual local rows requested of this rank
+        self.owner_sorted = None            # (sorted, permutation) of recv_local_rows, for the update
+
+    def exchange_ids(self):
+        if self.recv_local_rows is None:
+            g = self.group
+            self.recv_local_rows = torch.empty(sum(self.recv_counts), dtype=torch.int32, device=self.local_rows.device)
+            dist.all_to_all_single(self.recv_local_rows, self.local_rows, self.recv_counts, self.send_counts,
+                                   group=g.pg)
+            if self.recv_local_rows.numel():  # the owner-side sort needs the ids only: do it ahead of the step
+                self.owner_sorted = g.k.segment_sort(self.recv_local_rows, g.loff[-1])
+        return self.recv_local_rows
 
 
-def plan_triplet(scene, product, scene_ids, pos_ids, neg_ids):
-    return make_plans([(scene, scene_ids), (product, torch.cat([pos_ids, neg_ids]))])
+def make_plans(lookups):
+    """lookups: list of (ShardedTableGroup, virtual ids int32 [n]).  One counts all-to-all and one host sync
+    for the whole list.  Returns one RoutingPlan per lookup (ids exchanged, owner-side sort done)."""
+    if not lookups:
+        return []
+    g0 = lookups[0][0]
+    k, G, pg = g0.k, g0.world, g0.pg
+    parts = []
+    for group, vids in lookups:
+        local_rows, perm, counts = k.bucket_ids_by_owner(vids, G)
+        parts.append((group, vids.numel(), local_rows, perm, counts))
+    # counts laid out [peer][lookup] so that all_to_all_single hands every peer its L counts
+    send = torch.stack([p[4] for p in parts], dim=1).contiguous()          # [G, L] int64
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=pg)
+    both = torch.stack([send, recv]).cpu()                                  # the step's one host sync
+    plans = [RoutingPlan(group, n, local_rows, perm, both[0, :, i].tolist(), both[1, :, i].tolist())
+             for i, (group, n, local_rows, perm, _) in enumerate(parts)]
+    for p in plans:
+        p.exchange_ids()
+    return plans
 
 
-def plan_glove(emb, bias, inputs):
+class ShardedTableGroup:
+    """Same-width, same-dtype row-sharded tables that one step looks up and updates together."""
+
+    def __init__(self, tables, group=None, kernels=None):
+        if kernels is None:
+            from . import ops as kernels
+        self.k = kernels
+        self.tables = list(tables)
+        self.pg = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        G = self.world
+        self.voff = [0]                     # global virtual offsets, multiples of G
+        for t in self.tables:
+            self.voff.append(self.voff[-1] + G * ((t.num_rows + G - 1) // G))
+        self.loff = [o // G for o in self.voff]  # the same boundaries in virtual LOCAL rows
+        self.dim = self.tables[0].local.shape[1] if self.tables[0].local.dim() > 1 else 1
+
+    def virtual_ids(self, id_tensors, slots):
+        """[ids_i + voff[slots[i]]] concatenated: id_tensors[i] indexes table slots[i]."""
+        if len(self.tables) == 1 and len(id_tensors) == 1:
+            return id_tensors[0]
+        return self.k.concat_offset_ids(list(id_tensors), [self.voff[s] for s in slots])
+
+    def plan(self, vids):
+        return make_plans([(self, vids)])[0]
+
+    def lookup(self, plan):
+        """rows[i] = table_of(vid_i)[id_i] for this rank's virtual ids -> [n, D] in the order of the ids."""
+        k = self.k
+        recv = plan.exchange_ids()
+        if len(self.tables) == 1:
+            served = k.gather_rows(self.tables[0].local, recv)
+        else:
+            served = k.gather_rows_multi([t.local for t in self.tables], self.loff, recv)
+        back = torch.empty((plan.n, self.dim), dtype=served.dtype, device=served.device)
+        dist.all_to_all_single(back, served, plan.send_counts, plan.recv_counts, group=self.pg)
+        return k.unpermute_rows(back, plan.perm)                                # bucket order -> id order
+
+    def route_grads(self, plan, grad_rows):
+        """Per-occurrence gradient rows (order of the looked-up ids) -> rows on their owners."""
+        k = self.k
+        bucketed = k.gather_rows(grad_rows, plan.perm)                          # id order -> bucket order
+        recv = torch.empty((sum(plan.recv_counts), grad_rows.shape[1]), dtype=grad_rows.dtype,
+                           device=grad_rows.device)
+        dist.all_to_all_single(recv, bucketed, plan.recv_counts, plan.send_counts, group=self.pg)
+        return recv
+
+    def apply_sparse_adagrad(self, plan, grad_rows, lr, eps=1e-7):
+        """Route the gradients to their owners and update the local shards: one fused segment-reduce + RMW."""
+        k = self.k
+        rows = self.route_grads(plan, grad_rows)
+        if rows.shape[0] == 0:
+            return
+        sorted_rows, perm = plan.owner_sorted
+        if len(self.tables) == 1:
+            t = self.tables[0]
+            k.sparse_adagrad(t.local, t.accum, sorted_rows, perm, rows, lr, eps)
+        else:
+            k.sparse_adagrad_multi([t.local for t in self.tables], [t.accum for t in self.tables], self.loff,
+                                   sorted_rows, perm, rows, lr, eps)
+
+
+def plan_inbatch(towers, scene_ids, pos_ids):
+    return towers.plan(towers.virtual_ids([scene_ids, pos_ids], [0, 1]))
+
+
+def plan_triplet(towers, scene_ids, pos_ids, neg_ids):
+    return towers.plan(towers.virtual_ids([scene_ids, pos_ids, neg_ids], [0, 1, 1]))
+
+
+def plan_glove(emb_group, inputs):
     """The embedding and bias tables are indexed by the same ids and sharded the same way: one routing."""
-    p = make_plans([(emb, inputs.reshape(-1))])[0]
-    return [p, p]
+    return emb_group.plan(inputs.reshape(-1))
 
 
-def sharded_inbatch_step(scene, product, scene_ids, pos_ids, regularization, global_batch_size, scale, lr,
-                         plans=None):
-    """Data-parallel in-batch-softmax step on row-sharded towers.  Negatives are the local batch; gradients
-    are normalised by the GLOBAL batch size, so the sum of the per-rank losses is the global mean loss."""
-    k = scene.k
-    p_q, p_c = plans if plans is not None else plan_inbatch(scene, product, scene_ids, pos_ids)
-    q, _ = scene.lookup(p_q)
-    c, _ = product.lookup(p_c)
-    loss, _, gq, gc = k.inbatch_softmax_fwd_bwd(q, c, scale, regularization, global_batch_size)
-    scene.apply_sparse_adagrad(p_q, gq, lr)
-    product.apply_sparse_adagrad(p_c, gc, lr)
+def _joined(first, *rest):
+    """The single buffer the gradient slices are views of, else their concatenation."""
+    base = getattr(first, "_base", None)
+    n = first.shape[0] + sum(r.shape[0] for r in rest)
+    if base is not None and base.shape[0] == n:
+        return base
+    return torch.cat((first,) + rest)
+
+
+def sharded_inbatch_step(towers, scene_ids, pos_ids, regularization, global_batch_size, scale, lr, plan=None):
+    """Data-parallel in-batch-softmax step on row-sharded towers (group = [scene table, product table]).
+    Negatives are the local batch; gradients are normalised by the GLOBAL batch size, so the sum of the
+    per-rank losses is the global mean loss."""
+    k = towers.k
+    B = scene_ids.numel()
+    plan = plan if plan is not None else plan_inbatch(towers, scene_ids, pos_ids)
+    rows = towers.lookup(plan)                     # [q ; c]
+    loss, _, gq, gc = k.inbatch_softmax_fwd_bwd(rows[:B], rows[B:], scale, regularization, global_batch_size)
+    towers.apply_sparse_adagrad(plan, _joined(gq, gc), lr)
     return loss
 
 
-def sharded_triplet_step(scene, product, scene_ids, pos_ids, neg_ids, regularization, global_batch_size, lr,
-                         plans=None):
+def sharded_triplet_step(towers, scene_ids, pos_ids, neg_ids, regularization, global_batch_size, lr, plan=None):
     """Reference triplet loss (pinterest/train_shop_the_look.py:93-109) on row-sharded towers.  The loss is a
     sum over triplets, so G ranks x B triplets == one device with G*B triplets and batch_size = G*B."""
-    k = scene.k
+    k = towers.k
     B = scene_ids.numel()
-    p_s, p_pn = plans if plans is not None else plan_triplet(scene, product, scene_ids, pos_ids, neg_ids)
-    s, _ = scene.lookup(p_s)
-    pn, _ = product.lookup(p_pn)
-    loss, _, _, gs, gp, gn = k.triplet_fwd_bwd(s, pn[:B], pn[B:], None, None, None, B, regularization,
-                                               global_batch_size, with_reg=True, want_grads=True, want_scores=False)
-    scene.apply_sparse_adagrad(p_s, gs, lr)
-    gpn = gs._base[B:] if getattr(gs, "_base", None) is not None else torch.cat([gp, gn])  # [pos ; neg] rows
-    product.apply_sparse_adagrad(p_pn, gpn, lr)
+    plan = plan if plan is not None else plan_triplet(towers, scene_ids, pos_ids, neg_ids)
+    rows = towers.lookup(plan)                     # [scene ; pos ; neg]
+    loss, _, _, gs, gp, gn = k.triplet_fwd_bwd(rows[:B], rows[B:2 * B], rows[2 * B:], None, None, None, B,
+                                               regularization, global_batch_size, with_reg=True, want_grads=True,
+                                               want_scores=False)
+    towers.apply_sparse_adagrad(plan, _joined(gs, gp, gn), lr)
     return loss
 
 
-def sharded_glove_step(emb, bias, inputs, target, mode, lr, plans=None):
-    """GloVe step on row-sharded embedding + bias tables; the loss is over the local batch."""
-    k = emb.k
+def sharded_glove_step(emb_group, bias_group, inputs, target, mode, lr, plan=None):
+    """GloVe step on row-sharded embedding + bias tables (two single-table groups sharing one routing plan:
+    same ids, same sharding, different widths); the loss is over the local batch."""
+    k = emb_group.k
     B = inputs.shape[1]
-    p_e, p_b = plans if plans is not None else plan_glove(emb, bias, inputs)
-    rows, _ = emb.lookup(p_e)          # [2B, D]: E[t1] ; E[t2]
-    brow, _ = bias.lookup(p_b)         # [2B, 1]
+    plan = plan if plan is not None else plan_glove(emb_group, inputs)
+    rows = emb_group.lookup(plan)           # [2B, D]: E[t1] ; E[t2]
+    brow = bias_group.lookup(plan)          # [2B, 1]
     local_inputs = torch.arange(2 * B, dtype=torch.int32, device=rows.device).reshape(2, B)
     loss, grad_rows, grad_bias = k.glove_fwd_bwd(rows, brow, local_inputs, target, mode)
-    emb.apply_sparse_adagrad(p_e, grad_rows, lr)
-    bias.apply_sparse_adagrad(p_b, grad_bias.reshape(-1, 1), lr)
+    emb_group.apply_sparse_adagrad(plan, grad_rows, lr)
+    bias_group.apply_sparse_adagrad(plan, grad_bias.reshape(-1, 1), lr)
     return loss

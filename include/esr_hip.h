@@ -130,6 +130,9 @@ int esr_sparse_adagrad_scatter(void* table, int dtype, float* accum, int64_t V, 
  * (ids / counts / offsets are host arrays; the id buffers are device memory). */
 int esr_concat_offset_ids(const int32_t* const* ids, const int64_t* counts, const int64_t* offsets, int nseg,
                           int32_t* out, esr_stream_t stream);
+/* out[i, :] = tables[t][vids[i] - row_offsets[t], :] (row bytes must be a multiple of 16). */
+int esr_gather_rows_multi(const void* const* tables, const int64_t* row_offsets, int ntables, int dtype, int D,
+                          const int32_t* vids, int64_t n, void* out, esr_stream_t stream);
 int esr_sparse_adagrad_scatter_multi(void* const* tables, float* const* accums, const int64_t* row_offsets,
                                      int ntables, int dtype, int D, const int32_t* sorted_vids,
                                      const int32_t* perm, int64_t n, const float* grad_rows, float lr, float eps,

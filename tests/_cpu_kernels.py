@@ -26,6 +26,38 @@ def gather_rows(table, ids):
     return table[ids.long()].contiguous()
 
 
+def concat_offset_ids(id_tensors, offsets):
+    return torch.cat([t + int(o) for t, o in zip(id_tensors, offsets)]).to(torch.int32)
+
+
+def _locate(row_offsets, vids):
+    v = vids.numpy().astype(np.int64)
+    t = np.searchsorted(np.asarray(row_offsets[1:-1], np.int64), v, side="right") if len(row_offsets) > 2 else \
+        np.zeros_like(v)
+    return t, v - np.asarray(row_offsets, np.int64)[t]
+
+
+def gather_rows_multi(tables, row_offsets, vids):
+    t, r = _locate(row_offsets, vids)
+    out = torch.empty((len(t), tables[0].shape[1]), dtype=tables[0].dtype)
+    for k, tab in enumerate(tables):
+        m = torch.from_numpy(t == k)
+        out[m] = tab[torch.from_numpy(r[t == k])]
+    return out
+
+
+def sparse_adagrad_multi(tables, accums, row_offsets, sorted_vids, perm, grad_rows, lr, eps=1e-7):
+    t, r = _locate(row_offsets, sorted_vids)
+    rows = grad_rows.numpy()[perm.numpy()]
+    for k, (tab, acc) in enumerate(zip(tables, accums)):
+        m = t == k
+        if not m.any():
+            continue
+        p, a = o_optim.sparse_adagrad_update(tab.numpy(), acc.numpy(), r[m], rows[m], lr, eps, np.float64)
+        tab.copy_(_t(p))
+        acc.copy_(_t(a))
+
+
 def unpermute_rows(rows, perm):
     out = torch.empty_like(rows)
     out[perm.long()] = rows
@@ -59,7 +91,9 @@ def triplet_fwd_bwd(s, p, n, sid, pid, nid, B, lam, bs, with_reg=True, want_grad
 
 def inbatch_softmax_fwd_bwd(q, c, scale, lam, bs):
     loss, lse, gq, gc = o_stl.inbatch_softmax_loss_and_grads(q.numpy(), c.numpy(), lam, bs, scale, np.float64)
-    return _t(np.array([loss])), _t(lse), _t(gq), _t(gc)
+    gqc = _t(np.concatenate([gq, gc]))
+    B = gq.shape[0]
+    return _t(np.array([loss])), _t(lse), gqc[:B], gqc[B:]
 
 
 def glove_fwd_bwd(emb, bias, inputs, target, mode=GLOVE_REFERENCE, want_grads=True):

@@ -365,6 +365,20 @@ def test_sparse_adagrad_bf16_table(dev):
     assert rel_err(N(accum), ea) <= TOL
 
 
+def test_gather_rows_multi(dev):
+    from esrecsys_amd import ops
+    g = torch.Generator().manual_seed(5)
+    t0, t1, t2 = (torch.randn((n, 128), generator=g).to(dev) for n in (300, 500, 64))
+    offs = [0, 304, 808, 872]  # padded boundaries, as the sharded groups use
+    vids = torch.cat([torch.randint(0, 300, (100,), generator=g), 304 + torch.randint(0, 500, (150,), generator=g),
+                      808 + torch.randint(0, 64, (33,), generator=g)]).to(torch.int32)
+    vids = vids[torch.randperm(vids.numel(), generator=g)]
+    out = ops.gather_rows_multi([t0, t1, t2], offs, vids.to(dev))
+    full = torch.zeros((872, 128))
+    full[0:300], full[304:804], full[808:872] = t0.cpu(), t1.cpu(), t2.cpu()
+    assert torch.equal(out.cpu(), full[vids.long()])
+
+
 def test_fused_multi_table_adagrad_equals_per_table(dev):
     """concat_offset_ids + one sort + esr_sparse_adagrad_scatter_multi == the per-table path, bit for bit."""
     from esrecsys_amd import ops
@@ -480,11 +494,13 @@ def test_score_topk_random_vs_oracle(dev, nq, N_, D, k):
 # ------------------------------------------------------------------------------------------------
 # shard routing
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("world", [1, 2, 3, 8])
-def test_bucket_ids_by_owner_vs_oracle(dev, world):
+@pytest.mark.parametrize("world,n", [(1, 16_389), (2, 16_389), (3, 16_389), (8, 16_389), (8, 7), (8, 65_536),
+                                     (8, 100_003), (16, 16_389)])
+def test_bucket_ids_by_owner_vs_oracle(dev, world, n):
+    """single-launch bucket kernel (n <= 65536, world <= 8) and the device-radix-sort path beyond it"""
     from esrecsys_amd import ops
     rng = np.random.default_rng(world)
-    ids = rng.integers(0, 1_000_000, 16_384 + 5).astype(np.int32)
+    ids = rng.integers(0, 1_000_000, n).astype(np.int32)
     local, perm, counts = ops.bucket_ids_by_owner(T(ids, dev), world)
     el, ec, ep = o_shard.bucket_by_owner(ids, world)
     assert np.array_equal(N(counts), ec)

@@ -31,16 +31,17 @@ def test_sharded_world1_equals_single_device(dev, pg):
     state = TrainState.create(apply_fn=stl.apply, params=params, tx=optim.sparse_adagrad(lr))
     st = params["params"]["scene_tower"]["embedding"].clone()
     pt = params["params"]["product_tower"]["embedding"].clone()
-    scene = sharded.RowShardedTable(st, torch.full_like(st, 0.1), Vs, kernels=ops)
-    prod = sharded.RowShardedTable(pt, torch.full_like(pt, 0.1), Vp, kernels=ops)
+    scene = sharded.RowShardedTable(st, torch.full_like(st, 0.1), Vs)
+    prod = sharded.RowShardedTable(pt, torch.full_like(pt, 0.1), Vp)
+    towers = sharded.ShardedTableGroup([scene, prod], kernels=ops)
     rng = np.random.default_rng(0)
     for step in range(3):
         sid, pid, nid = (torch.from_numpy(rng.integers(0, n, B).astype(np.int32)).to(dev) for n in (Vs, Vp, Vp))
         if step % 2 == 0:
-            l_sh = sharded.sharded_triplet_step(scene, prod, sid, pid, nid, lam, float(B), lr)
+            l_sh = sharded.sharded_triplet_step(towers, sid, pid, nid, lam, float(B), lr)
             state, l_1 = train_step(state, sid, pid, nid, lam, B)
         else:
-            l_sh = sharded.sharded_inbatch_step(scene, prod, sid, pid, lam, float(B), 4.0, lr)
+            l_sh = sharded.sharded_inbatch_step(towers, sid, pid, lam, float(B), 4.0, lr)
             state, l_1 = train_step(state, sid, pid, None, lam, B, scale=4.0)
         assert abs(float(l_sh) - float(l_1)) <= 1e-6 * abs(float(l_1))
     # same kernels, same occurrence order -> identical tables
@@ -55,8 +56,10 @@ def test_sharded_glove_world1(dev, pg):
     g = torch.Generator().manual_seed(1)
     emb0 = (torch.randn((V, D), generator=g) * D ** -0.5)
     bias0 = torch.randn((V, 1), generator=g) * 0.05
-    emb = sharded.RowShardedTable(emb0.to(dev), torch.full((V, D), 0.1, device=dev), V, kernels=ops)
-    bias = sharded.RowShardedTable(bias0.to(dev), torch.full((V, 1), 0.1, device=dev), V, kernels=ops)
+    emb_t = sharded.RowShardedTable(emb0.to(dev), torch.full((V, D), 0.1, device=dev), V)
+    emb = sharded.ShardedTableGroup([emb_t], kernels=ops)
+    bias = sharded.ShardedTableGroup([sharded.RowShardedTable(bias0.to(dev), torch.full((V, 1), 0.1, device=dev), V)],
+                                     kernels=ops)
     rng = np.random.default_rng(2)
     inputs = rng.integers(0, V, (2, B)).astype(np.int32)
     target = rng.uniform(0.1, 300, B).astype(np.float32)
@@ -65,4 +68,4 @@ def test_sharded_glove_world1(dev, pg):
     el, _, _ = o_glove.loss_and_grads(emb0.numpy().astype(np.float64), bias0.numpy().astype(np.float64), inputs,
                                       target, "reference", np.float64)
     assert abs(float(loss) - el) / abs(el) <= 1e-5
-    assert not torch.equal(emb.local.cpu(), emb0)  # rows moved
+    assert not torch.equal(emb_t.local.cpu(), emb0)  # rows moved

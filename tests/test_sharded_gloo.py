@@ -43,16 +43,18 @@ def _worker(rank, port, outdir, workload):
     from esrecsys_amd import sharded
     st, pt = _full_tables()
     mk = lambda full: torch.from_numpy(np.ascontiguousarray(full[rank::WORLD]))  # noqa: E731
-    scene = sharded.RowShardedTable(mk(st), torch.full_like(mk(st), 0.1), V_S, kernels=K)
-    prod = sharded.RowShardedTable(mk(pt), torch.full_like(mk(pt), 0.1), V_P, kernels=K)
+    scene = sharded.RowShardedTable(mk(st), torch.full_like(mk(st), 0.1), V_S)
+    prod = sharded.RowShardedTable(mk(pt), torch.full_like(mk(pt), 0.1), V_P)
+    towers = sharded.ShardedTableGroup([scene, prod], kernels=K)
     assert scene.local.shape[0] == sharded.RowShardedTable.local_rows_for(V_S, WORLD, rank)
+    assert towers.voff[1] % WORLD == 0 and towers.voff[1] >= V_S
     losses = []
     for step in range(STEPS):
         sid, pid, nid = (torch.from_numpy(x) for x in _batch(step, rank))
         if workload == "triplet":
-            loss = sharded.sharded_triplet_step(scene, prod, sid, pid, nid, LAM, float(WORLD * B), LR)
+            loss = sharded.sharded_triplet_step(towers, sid, pid, nid, LAM, float(WORLD * B), LR)
         else:
-            loss = sharded.sharded_inbatch_step(scene, prod, sid, pid, LAM, float(WORLD * B), 2.0, LR)
+            loss = sharded.sharded_inbatch_step(towers, sid, pid, LAM, float(WORLD * B), 2.0, LR)
         total = loss.clone()
         dist.all_reduce(total)
         losses.append(float(total))
@@ -135,19 +137,21 @@ def _glove_worker(rank, port, outdir):
     V, Dg, Bg = 97, 8, 20
     emb0, bias0 = rng.standard_normal((V, Dg)) * 0.3, rng.standard_normal((V, 1)) * 0.05
     mk = lambda full: torch.from_numpy(np.ascontiguousarray(full[rank::WORLD]))  # noqa: E731
-    emb = sharded.RowShardedTable(mk(emb0), torch.full_like(mk(emb0), 0.1), V, kernels=K)
-    bias = sharded.RowShardedTable(mk(bias0), torch.full_like(mk(bias0), 0.1), V, kernels=K)
+    emb_t = sharded.RowShardedTable(mk(emb0), torch.full_like(mk(emb0), 0.1), V)
+    bias_t = sharded.RowShardedTable(mk(bias0), torch.full_like(mk(bias0), 0.1), V)
+    emb = sharded.ShardedTableGroup([emb_t], kernels=K)
+    bias = sharded.ShardedTableGroup([bias_t], kernels=K)
     brng = np.random.default_rng(100 + rank)
     batches = [(brng.integers(0, V, (2, Bg)).astype(np.int32), brng.uniform(0.1, 300, Bg)) for _ in range(3)]
     # prefetch the routing plan of the next batch right after each step, as the bench loop does
-    nxt = sharded.plan_glove(emb, bias, torch.from_numpy(batches[0][0]))
+    nxt = sharded.plan_glove(emb, torch.from_numpy(batches[0][0]))
     for i, (inp, tgt) in enumerate(batches):
         cur = nxt
         sharded.sharded_glove_step(emb, bias, torch.from_numpy(inp), torch.from_numpy(tgt), K.GLOVE_DIAGONAL, 0.05,
-                                   plans=cur)
+                                   plan=cur)
         if i + 1 < len(batches):
-            nxt = sharded.plan_glove(emb, bias, torch.from_numpy(batches[i + 1][0]))
-    np.savez(os.path.join(outdir, "rank%d.npz" % rank), emb=emb.local.numpy(), bias=bias.local.numpy())
+            nxt = sharded.plan_glove(emb, torch.from_numpy(batches[i + 1][0]))
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), emb=emb_t.local.numpy(), bias=bias_t.local.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
