@@ -189,6 +189,15 @@ __device__ unsigned long long esr_ib3_dbg[4096];
 #else
 #define ESR_TICK(VAR)
 #endif
+// Barrier that publishes LDS-DMA'd tiles: every wave first waits for ITS OWN outstanding DMAs (vmcnt(0)),
+// then the workgroup barrier makes all of them visible.  The wait is written by hand: hipcc emits it for a
+// __syncthreads() that directly follows the DMA builtins, but dropped it at the top of the software-pipelined
+// loop (DMAs issued in the previous iteration), which let waves read tiles that had not landed yet.
+#define ESR_DMA_BARRIER()                                   \
+  {                                                         \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        \
+    __syncthreads();                                        \
+  }
 #define ESR_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
 // One S^T block (48 MFMAs, one accumulator chain) of the chunk in NBUF.  When VALU_ON, the exp + three-plane
@@ -354,7 +363,7 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
   ESR_DMA_INIT(c0 + dpos);
   ESR_DMA_ALL(lds);
   if (nc > 1) ESR_DMA_ALL(lds + kBufBytes);
-  __syncthreads();  // an LDS-DMA in flight makes the barrier's fence wait vmcnt(0): both tiles have landed
+  ESR_DMA_BARRIER();  // an LDS-DMA in flight makes the barrier's fence wait vmcnt(0): both tiles have landed
 
   f32x16 sa;
   float p[16], rf[16];
@@ -375,7 +384,7 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
     const int nn = nxt == k3Bufs - 1 ? 0 : nxt + 1;
     // every wave is done with chunk it-1 (its slot is the DMA target below) and chunk it+1 has landed
     ESR_TICK(tk0);
-    __syncthreads();
+    ESR_DMA_BARRIER();
     ESR_TICK(tk1);
     const char* buf = lds + cur * kBufBytes;
     const char* nbuf = lds + nxt * kBufBytes;
@@ -395,7 +404,7 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
   }
   if (nc >= 2) {  // chunk nc-2: the last S^T prefetch, nothing left to DMA
     const int nxt = cur == k3Bufs - 1 ? 0 : cur + 1;
-    __syncthreads();
+    ESR_DMA_BARRIER();
     const char* buf = lds + cur * kBufBytes;
     const char* nbuf = lds + nxt * kBufBytes;
 #pragma unroll
@@ -406,7 +415,7 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
     cur = nxt;
   }
   {  // last chunk: nothing left to prefetch; run its exp / split alone
-    __syncthreads();
+    ESR_DMA_BARRIER();
     const char* buf = lds + cur * kBufBytes;
 #pragma unroll
     for (int r = 0; r < 16; ++r) p[r] = sa[r];
@@ -478,7 +487,7 @@ __global__ __launch_bounds__(256) void inbatch3_rowmax_kernel(const __bf16* __re
       ESR_DP(1, g1 + k * 8192, lds + k * kPlaneBytes);
     }
   for (int gi = 0; gi < ngroups; ++gi) {
-    __syncthreads();  // group gi landed; everyone is done with the other half
+    ESR_DMA_BARRIER();  // group gi landed; everyone is done with the other half
     const char* gbuf = lds + (gi & 1) * (kRmGroup * kPlaneBytes);
     if (gi + 1 < ngroups) {
       char* nb = lds + ((gi + 1) & 1) * (kRmGroup * kPlaneBytes);

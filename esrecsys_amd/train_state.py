@@ -9,6 +9,7 @@ updated IN PLACE by HIP kernels; ``apply_gradients`` returns a new TrainState ob
 buffers (functional call shape, resident memory).  Gradients of embedding tables are row-sparse
 (``RowGrads``) unless the optimizer asks for the reference's dense V x D layout.
 """
+import numpy as np
 import torch
 
 from . import ops
@@ -152,6 +153,14 @@ class _Adam(GradientTransformation):
     def init(self, params):
         return {"count": 0, "mu": tree_map(torch.zeros_like, params), "nu": tree_map(torch.zeros_like, params)}
 
+    # optax.adam's state is (ScaleByAdamState(count, mu, nu), EmptyState()) -> {'0': {...}, '1': {}} on the wire
+    def to_optax_state(self, opt_state):
+        return {"0": {"count": np.asarray(opt_state["count"], np.int32), "mu": opt_state["mu"], "nu": opt_state["nu"]},
+                "1": {}}
+
+    def from_optax_state(self, tree):
+        return {"count": int(np.asarray(tree["0"]["count"])), "mu": tree["0"]["mu"], "nu": tree["0"]["nu"]}
+
     def apply(self, params, grads, opt_state, step):
         count = opt_state["count"] + 1
         for path, p in tree_leaves_with_path(params):
@@ -174,6 +183,13 @@ class _SparseAdagrad(GradientTransformation):
     def init(self, params):
         return {"sum_of_squares": tree_map(
             lambda p: torch.full(p.shape, self.init_acc, dtype=torch.float32, device=p.device), params)}
+
+    # optax.adagrad's state is (ScaleByRssState(sum_of_squares), EmptyState())
+    def to_optax_state(self, opt_state):
+        return {"0": {"sum_of_squares": opt_state["sum_of_squares"]}, "1": {}}
+
+    def from_optax_state(self, tree):
+        return {"sum_of_squares": tree["0"]["sum_of_squares"]}
 
     def apply(self, params, grads, opt_state, step):
         done = set()

@@ -274,6 +274,24 @@ def test_inbatch_bf16x3_shapes_and_hard_inputs(dev, B):
         assert max(errs[precision]) <= TOL, (precision, errs)
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_inbatch_repeatable_under_load(dev, precision):
+    """Race screen for the LDS-DMA ring: 60 back-to-back launches at the headline size must be bit-identical
+    (a tile read before its DMA landed shows up as run-to-run differences; an earlier build that relied on
+    the compiler's implicit vmcnt(0) at the loop-top barrier failed exactly this way after ~200 steps)."""
+    from esrecsys_amd import ops
+    g = torch.Generator(device=dev).manual_seed(3)
+    B, D = 8192, 128
+    q = torch.randn((B, D), generator=g, device=dev) * D ** -0.5
+    c = torch.randn((B, D), generator=g, device=dev) * D ** -0.5
+    first = [t.clone() for t in ops.inbatch_softmax_fwd_bwd(q, c, 8.0, 0.1, float(B), precision=precision)]
+    assert all(bool(torch.isfinite(t).all()) for t in first)
+    for _ in range(60):
+        out = ops.inbatch_softmax_fwd_bwd(q, c, 8.0, 0.1, float(B), precision=precision)
+        for a, b in zip(first, out):
+            assert torch.equal(a, b)
+
+
 def test_inbatch_golden_b320_falls_back_to_f32_when_not_splittable(dev):
     from esrecsys_amd import ops
     g = load_golden("inbatch_b320_d128")  # 320 % 128 != 0 -> "auto" must use the f32 kernel

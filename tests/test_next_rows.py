@@ -1,0 +1,129 @@
+"""CPU: the "next" rows either side of the hot path: N2 co-occurrence file reader against a
+fixture written by the reference's own protobuf class, N4 Flax-msgpack checkpoints."""
+import os
+
+import msgpack
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+FIXTURE = os.path.join(GOLDEN, "tiny.cooccur.pb.b64.bz2")
+
+
+def _expected():
+    z = np.load(os.path.join(GOLDEN, "tiny_cooccur_expected.npz"))
+    return z["index"], z["other"], z["count"]
+
+
+def test_reader_decodes_reference_written_file():
+    from esrecsys_amd.wikipedia.cooccurrence_matrix import CooccurrenceGenerator
+    idx, oth, cnt = _expected()
+    gen = CooccurrenceGenerator(FIXTURE).get_item()
+    n = len(idx)
+    items = [next(gen) for _ in range(2 * n)]  # two passes: the generator cycles over its files forever
+    for rep in range(2):
+        got = items[rep * n:(rep + 1) * n]
+        assert [g[0] for g in got] == idx.tolist() and [g[1] for g in got] == oth.tolist()
+        assert np.array_equal(np.array([g[2] for g in got], np.float32), cnt)  # bit-exact floats
+
+
+def test_known_wire_bytes():
+    """The serialisation of CooccurrenceRow{index=300, other=[1,128,70000], count=[.5,1.25,3]} produced by the
+    reference's generated class in the build container, plus the unpacked (proto2-style) encoding."""
+    from esrecsys_amd.wikipedia.cooccurrence_matrix import parse_cooccurrence_row
+    packed = bytes.fromhex("08ac021206018001f0a2041a0c0000003f0000a03f00004040")
+    assert parse_cooccurrence_row(packed) == (300, [1, 128, 70000], [0.5, 1.25, 3.0])
+    unpacked = bytes.fromhex("08ac02" "1001" "108001" "10f0a204" "1d0000003f" "1d0000a03f" "1d00004040")
+    assert parse_cooccurrence_row(unpacked) == (300, [1, 128, 70000], [0.5, 1.25, 3.0])
+    assert parse_cooccurrence_row(b"") == (0, [], [])
+
+
+def test_batches_have_the_reference_layout_and_shuffle_semantics():
+    from esrecsys_amd.wikipedia.cooccurrence_matrix import AUTOTUNE, CooccurrenceGenerator
+    idx, oth, cnt = _expected()
+    g = CooccurrenceGenerator(FIXTURE)
+    x, y = next(g.get_batch(32))
+    assert isinstance(x, list) and x[0].dtype == np.int32 and x[0].shape == (32,) and y.dtype == np.float32
+    assert np.array_equal(x[0], idx[:32]) and np.array_equal(x[1], oth[:32]) and np.array_equal(y, cnt[:32])
+    # shuffle: fill `shuffle_size` items, np.random.shuffle (global RNG), drain -- cooccurrence_matrix.py:80-87
+    np.random.seed(5)
+    xs, ys = next(g.get_batch(50, shuffle_size=100))
+    np.random.seed(5)
+    items = list(zip(idx[:100].tolist(), oth[:100].tolist(), cnt[:100].tolist()))
+    np.random.shuffle(items)
+    assert xs[0].tolist() == [i[0] for i in items[:50]] and xs[1].tolist() == [i[1] for i in items[:50]]
+    # tf.data call shape used by the trainer: get_dataset(B, shuffle).prefetch(AUTOTUNE).as_numpy_iterator()
+    it = g.get_dataset(16).prefetch(AUTOTUNE).as_numpy_iterator()
+    inputs, targets = next(it)
+    assert inputs.shape == (2, 16) and inputs.dtype == np.int32 and targets.shape == (16,)
+    assert np.array_equal(inputs[0], idx[:16])
+    inputs2, _ = next(it)
+    assert np.array_equal(inputs2[1], oth[16:32])
+
+
+def _state(tx):
+    from esrecsys_amd import TrainState
+    g = torch.Generator().manual_seed(1)
+    params = {"_token_embedding": {"embedding": torch.randn((6, 4), generator=g)},
+              "_bias": {"embedding": torch.randn((6, 1), generator=g)}}
+    return TrainState.create(apply_fn=None, params=params, tx=tx)
+
+
+@pytest.mark.parametrize("opt", ["adam", "sparse_adagrad"])
+def test_checkpoint_roundtrip_and_flax_layout(opt):
+    from esrecsys_amd import checkpoint, optim
+    tx = optim.adam(1e-3) if opt == "adam" else optim.sparse_adagrad(0.1)
+    st = _state(tx).replace(step=12)
+    if opt == "adam":
+        st.opt_state["count"] = 12
+        st.opt_state["mu"]["_bias"]["embedding"].fill_(0.25)
+    else:
+        st.opt_state["sum_of_squares"]["_token_embedding"]["embedding"].fill_(0.7)
+    data = checkpoint.to_bytes(st)
+    # layout: plain msgpack map; arrays = ExtType(1, packb((shape, dtype.name, bytes)))
+    raw = msgpack.unpackb(data, raw=False, strict_map_key=False)
+    assert sorted(raw) == ["opt_state", "params", "step"] and raw["step"] == 12
+    leaf = raw["params"]["_token_embedding"]["embedding"]
+    assert isinstance(leaf, msgpack.ExtType) and leaf.code == 1
+    shape, dtype_name, payload = msgpack.unpackb(leaf.data, raw=False)
+    assert shape == [6, 4] and dtype_name == "float32" and len(payload) == 6 * 4 * 4
+    assert np.array_equal(np.frombuffer(payload, np.float32).reshape(6, 4),
+                          st.params["_token_embedding"]["embedding"].numpy())
+    assert sorted(raw["opt_state"]) == ["0", "1"] and raw["opt_state"]["1"] == {}
+    assert sorted(raw["opt_state"]["0"]) == (["count", "mu", "nu"] if opt == "adam" else ["sum_of_squares"])
+    # restore INTO a fresh state (the reference's resume discards the result; ours returns the restored state)
+    fresh = _state(tx)
+    for leaf in (fresh.params["_token_embedding"]["embedding"], fresh.params["_bias"]["embedding"]):
+        leaf.zero_()
+    keep_ptr = fresh.params["_token_embedding"]["embedding"].data_ptr()
+    restored = checkpoint.from_bytes(fresh, data)
+    assert restored.step == 12
+    assert restored.params["_token_embedding"]["embedding"].data_ptr() == keep_ptr  # restored in place
+    assert torch.equal(restored.params["_token_embedding"]["embedding"], st.params["_token_embedding"]["embedding"])
+    if opt == "adam":
+        assert restored.opt_state["count"] == 12
+        assert torch.equal(restored.opt_state["mu"]["_bias"]["embedding"], st.opt_state["mu"]["_bias"]["embedding"])
+    else:
+        assert float(restored.opt_state["sum_of_squares"]["_token_embedding"]["embedding"][0, 0]) == pytest.approx(0.7)
+    with pytest.raises(ValueError):
+        checkpoint.from_bytes(_state(optim.adam(1e-3) if opt != "adam" else optim.sparse_adagrad(0.1)), data)
+
+
+def test_checkpoint_chunks_large_arrays(monkeypatch):
+    from esrecsys_amd import checkpoint
+    monkeypatch.setattr(checkpoint, "_MAX_CHUNK_BYTES", 64)
+    tree = {"w": torch.arange(100, dtype=torch.float32).reshape(10, 10)}
+    data = checkpoint.to_bytes(tree)
+    raw = msgpack.unpackb(data, raw=False, strict_map_key=False)
+    assert raw["w"]["__msgpack_chunked_array__"] is True and len(raw["w"]["chunks"]) == 7
+    back = checkpoint.from_bytes({"w": torch.zeros(10, 10)}, data)
+    assert torch.equal(back["w"], tree["w"])
+
+
+def test_save_state_writes_reference_filename(tmp_path):
+    from esrecsys_amd import optim
+    from esrecsys_amd.wikipedia.train_cooccurence import save_state
+    path = save_state(_state(optim.sparse_adagrad(0.1)), 20, checkpoint_dir=str(tmp_path))
+    assert os.path.basename(path) == "checkpoint-00020.flax" and os.path.getsize(path) > 100
