@@ -61,6 +61,25 @@ __global__ __launch_bounds__(kBlock) void move_rows_kernel(const T* __restrict__
   }
 }
 
+// out[perm[k], :] = (float) rows_bf16[k, :]: the requester side of a sharded lookup on a bf16 table
+// (rows cross xGMI as bf16, the loss kernels consume f32).  One 8-byte chunk (4 bf16) -> one float4 per lane.
+__global__ __launch_bounds__(kBlock) void unpermute_bf16_to_f32_kernel(const uint2* __restrict__ src,
+                                                                      const int32_t* __restrict__ perm, int64_t n,
+                                                                      int nchunk, int G, float4* __restrict__ dst) {
+  const int lig = threadIdx.x & (G - 1);
+  const int64_t gpb = kBlock / G;
+  const int64_t group = (int64_t)blockIdx.x * gpb + threadIdx.x / G;
+  const int64_t ngroups = (int64_t)gridDim.x * gpb;
+  for (int64_t r = group; r < n; r += ngroups) {
+    const int64_t d = perm ? (int64_t)perm[r] : r;
+    for (int c = lig; c < nchunk; c += G) {
+      const uint2 u = src[r * nchunk + c];
+      dst[d * nchunk + c] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                                        __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+    }
+  }
+}
+
 template <bool SRC_IDX>
 static int launch_move_rows(const void* src, int dtype, int D, const int32_t* ids, int64_t n,
                             void* dst, hipStream_t st) {
@@ -144,6 +163,21 @@ int esr_gather_rows(const void* table, int dtype, int64_t V, int D, const int32_
   if (n == 0) return ESR_OK;
   ESR_REQUIRE(table && ids && out, "esr_gather_rows: null pointer");
   return launch_move_rows<true>(table, dtype, D, ids, n, out, as_stream(stream));
+}
+
+int esr_unpermute_rows_bf16_to_f32(const void* rows_bf16, int D, const int32_t* perm, int64_t n, float* out,
+                                   esr_stream_t stream) {
+  ESR_REQUIRE(n >= 0 && D > 0 && D % 4 == 0, "esr_unpermute_rows_bf16_to_f32: bad sizes D=%d (multiple of 4) n=%lld", D,
+              (long long)n);
+  if (n == 0) return ESR_OK;
+  ESR_REQUIRE(rows_bf16 && out, "esr_unpermute_rows_bf16_to_f32: null pointer");
+  const int nchunk = D / 4;
+  int G = 1;
+  while (G < nchunk && G < kWave) G <<= 1;
+  const int grid = grid_for_groups(n, G);
+  hipLaunchKernelGGL(unpermute_bf16_to_f32_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream),
+                     (const uint2*)rows_bf16, perm, n, nchunk, G, (float4*)out);
+  return check_launch("esr_unpermute_rows_bf16_to_f32");
 }
 
 int esr_unpermute_rows(const void* rows, int dtype, int D, const int32_t* perm, int64_t n,

@@ -18,7 +18,7 @@
 namespace esr {
 
 constexpr int kStatBlocks = 256;   // K_A grid cap  -> 2 doubles per block
-constexpr int kPairBlocks = 1024;  // K_B grid cap  -> 3 doubles per block
+constexpr int kPairBlocks = 2048;  // K_B grid cap (256 CUs x 8 resident blocks) -> 3 doubles per block
 
 struct GloveWs {
   double* stat_part;  // [kStatBlocks][2]

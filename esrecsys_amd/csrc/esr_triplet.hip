@@ -15,7 +15,7 @@
 
 namespace esr {
 
-constexpr int kTripletBlocks = 1024;
+constexpr int kTripletBlocks = 2048;  // 256 CUs x 8 resident blocks
 
 template <int VEC, int NCH, bool GRADS>
 __global__ __launch_bounds__(kBlock) void triplet_kernel(

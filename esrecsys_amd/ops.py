@@ -103,6 +103,20 @@ def unpermute_rows(rows, perm, out=None):
     return out
 
 
+def unpermute_rows_to_f32(rows, perm, out=None):
+    """out[perm[k]] = float32(rows[k]); rows may be bf16 (converted on the fly) or f32."""
+    if rows.dtype == torch.float32:
+        return rows if perm is None else unpermute_rows(rows, perm, out)
+    lib = _lib.load()
+    _req(rows, torch.bfloat16, "rows")
+    n, D = rows.shape
+    if out is None:
+        out = torch.empty((n, D), dtype=torch.float32, device=rows.device)
+    check(lib.esr_unpermute_rows_bf16_to_f32(_p(rows), D, _p(perm), n, _p(out), _stream()),
+          "esr_unpermute_rows_bf16_to_f32")
+    return out
+
+
 def glove_forward(emb, bias, inputs):
     """(dot[B], s[B]) of Glove.__call__; the reference output is dot[None, :] + s[:, None]."""
     lib = _lib.load()

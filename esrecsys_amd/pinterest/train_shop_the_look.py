@@ -80,6 +80,8 @@ def train_step(state, scene, pos_product, neg_product, regularization, batch_siz
             fused.index.presort()
         q = ops.gather_rows(st, sid)
         c = ops.gather_rows(pt, pid)
+        if q.dtype != torch.float32:  # bf16 towers (fp32 accumulators): scores and gradients are computed in f32
+            q, c = ops.unpermute_rows_to_f32(q, None), ops.unpermute_rows_to_f32(c, None)
         loss, _, gq, gc = ops.inbatch_softmax_fwd_bwd(q, c, scale, regularization, batch_size, precision=precision)
         if fused is not None:
             fused.rows = gq._base  # [gQ ; gC]

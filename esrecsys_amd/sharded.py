@@ -129,7 +129,8 @@ class ShardedTableGroup:
             served = k.gather_rows_multi([t.local for t in self.tables], self.loff, recv)
         back = torch.empty((plan.n, self.dim), dtype=served.dtype, device=served.device)
         dist.all_to_all_single(back, served, plan.send_counts, plan.recv_counts, group=self.pg)
-        return k.unpermute_rows(back, plan.perm)                                # bucket order -> id order
+        # bucket order -> id order; bf16 tables (config 4) cross xGMI as bf16 and become f32 here
+        return k.unpermute_rows_to_f32(back, plan.perm)
 
     def route_grads(self, plan, grad_rows):
         """Per-occurrence gradient rows (order of the looked-up ids) -> rows on their owners."""

@@ -177,6 +177,11 @@ int esr_bucket_ids_by_owner(const int32_t* ids, int64_t n, int world, int32_t* l
 int esr_unpermute_rows(const void* rows, int dtype, int D, const int32_t* perm, int64_t n, void* out,
                        esr_stream_t stream);
 
+/* out[perm[k], :] = (float) rows_bf16[k, :] (perm == NULL: identity).  Requester side of a sharded lookup on a
+ * bf16 table (BASELINE config 4): rows cross xGMI as bf16, the loss kernels consume f32.  D % 4 == 0. */
+int esr_unpermute_rows_bf16_to_f32(const void* rows_bf16, int D, const int32_t* perm, int64_t n, float* out,
+                                   esr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

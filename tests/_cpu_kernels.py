@@ -64,6 +64,10 @@ def unpermute_rows(rows, perm):
     return out
 
 
+def unpermute_rows_to_f32(rows, perm):
+    return unpermute_rows(rows, perm)
+
+
 def segment_sort(ids, V):
     order = np.argsort(ids.numpy(), kind="stable").astype(np.int32)
     return _t(ids.numpy()[order]), _t(order)

@@ -259,3 +259,27 @@ def test_graphed_step_equals_eager(dev):
                         p["product_tower"]["embedding"].clone()))
     assert torch.equal(results[0][0], results[1][0])
     assert torch.equal(results[0][1], results[1][1]) and torch.equal(results[0][2], results[1][2])
+
+
+def test_inbatch_train_step_bf16_towers(dev):
+    """bf16 tower tables with fp32 accumulators through the drop-in train_step (single device)."""
+    from esrecsys_amd import TrainState, optim
+    from esrecsys_amd.pinterest.models import STLModel
+    from esrecsys_amd.pinterest.train_shop_the_look import train_step
+    Vs, Vp, D, B, lam, lr, scale = 3000, 5000, 128, 256, 0.1, 0.05, 4.0
+    stl = STLModel(output_size=D, num_scenes=Vs, num_products=Vp, device=dev)
+    params = stl.init(5)
+    for k in ("scene_tower", "product_tower"):
+        params["params"][k]["embedding"] = params["params"][k]["embedding"].to(torch.bfloat16)
+    state = TrainState.create(apply_fn=stl.apply, params=params, tx=optim.sparse_adagrad(lr))
+    assert state.opt_state["sum_of_squares"]["params"]["scene_tower"]["embedding"].dtype == torch.float32
+    st0 = params["params"]["scene_tower"]["embedding"].float().cpu().numpy().astype(F64)
+    pt0 = params["params"]["product_tower"]["embedding"].float().cpu().numpy().astype(F64)
+    rng = np.random.default_rng(8)
+    sc, po = rng.integers(0, Vs, B).astype(np.int32), rng.integers(0, Vp, B).astype(np.int32)
+    state, loss = train_step(state, sc, po, None, lam, B, scale=scale)
+    el, _, gq, gc = o_stl.inbatch_softmax_loss_and_grads(st0[sc], pt0[po], lam, B, scale, F64)
+    assert abs(float(loss) - el) / abs(el) <= TOL
+    ep, _ = o_optim.sparse_adagrad_update(pt0, np.full_like(pt0, 0.1), po, gc, lr, dtype=F64)
+    got = state.params["params"]["product_tower"]["embedding"].float().cpu().numpy()
+    assert np.mean(got == torch.from_numpy(ep).to(torch.bfloat16).float().numpy()) > 0.999

@@ -69,3 +69,32 @@ def test_sharded_glove_world1(dev, pg):
                                       target, "reference", np.float64)
     assert abs(float(loss) - el) / abs(el) <= 1e-5
     assert not torch.equal(emb_t.local.cpu(), emb0)  # rows moved
+
+
+def test_sharded_bf16_towers_world1(dev, pg):
+    """BASELINE config 4 shape in miniature: bf16 tables + fp32 accumulators, row-sharded in-batch step.
+    Rows cross the exchange as bf16 and are widened exactly; the update rounds to bf16 (RNE)."""
+    from esrecsys_amd import ops, sharded
+    from oracle import optim as o_optim
+    from oracle import stl_head as o_stl
+    Vs, Vp, D, B, lam, lr, scale = 4000, 6000, 128, 256, 0.1, 0.05, 4.0
+    g = torch.Generator().manual_seed(9)
+    st0 = (torch.randn((Vs, D), generator=g) * 0.12).to(torch.bfloat16)
+    pt0 = (torch.randn((Vp, D), generator=g) * 0.12).to(torch.bfloat16)
+    scene = sharded.RowShardedTable(st0.to(dev), torch.full((Vs, D), 0.1, device=dev), Vs)
+    prod = sharded.RowShardedTable(pt0.to(dev), torch.full((Vp, D), 0.1, device=dev), Vp)
+    towers = sharded.ShardedTableGroup([scene, prod], kernels=ops)
+    rng = np.random.default_rng(4)
+    sid = rng.integers(0, Vs, B).astype(np.int32)
+    pid = rng.integers(0, Vp, B).astype(np.int32)
+    loss = sharded.sharded_inbatch_step(towers, torch.from_numpy(sid).to(dev), torch.from_numpy(pid).to(dev), lam,
+                                        float(B), scale, lr)
+    q, c = st0.float().numpy()[sid].astype(np.float64), pt0.float().numpy()[pid].astype(np.float64)
+    el, _, gq, gc = o_stl.inbatch_softmax_loss_and_grads(q, c, lam, B, scale, np.float64)
+    assert abs(float(loss) - el) / abs(el) <= 1e-5
+    es, ea = o_optim.sparse_adagrad_update(st0.float().numpy().astype(np.float64), np.full((Vs, D), 0.1), sid, gq, lr,
+                                           dtype=np.float64)
+    got = scene.local.float().cpu().numpy()
+    exp_bf16 = torch.from_numpy(es).to(torch.bfloat16).float().numpy()
+    assert scene.local.dtype == torch.bfloat16 and np.mean(got == exp_bf16) > 0.999
+    assert np.abs(scene.accum.cpu().numpy() - ea).max() <= 1e-5 * np.abs(ea).max()
