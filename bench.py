@@ -73,6 +73,48 @@ class KernelTimer:
         return {g: (sum(a.elapsed_time(b) for a, b in ev), len(ev)) for g, ev in self.events.items()}
 
 
+def roofline_for(workload, kernels, B, D, rows, precision, occ_n=0, uniq=0):
+    """The `roofline` object for the dominant kernel of one rank's step.  `kernels` = HIP-event ms per step per
+    kernel group; occ_n / uniq = row occurrences and distinct rows the sparse Adagrad launch of the last batch saw."""
+    if workload == "inbatch":
+        t = kernels["inbatch_mfma"]["ms_per_step"] * 1e-3
+        alg = 6.0 * B * B * D  # S = QC^T, dQ = PC, dC = P^T Q in f32 (SURVEY 8d)
+        if precision != "f32" and D == 128 and B % 128 == 0:
+            # bf16x3 path: every f32 product = 6 bf16 MFMA terms; S is recomputed in pass C (4 GEMM units) and the
+            # row-max pre-pass adds one hi-plane term: (4 * 6 + 1) * 2 B^2 D executed bf16 flops
+            executed = (4 * 6 + 1) * 2.0 * B * B * D
+            return {"kernel": "split3 + inbatch3_rowmax + inbatch3_kernel<Q> + merge + inbatch3_kernel<C> + merge",
+                    "bound": "mfma", "achieved": executed / t / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": executed / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                    "dtype": "bf16 x3 split, f32 accumulate (f32-equivalent products)",
+                    "f32_equivalent_TFLOPs": alg / t / 1e12,
+                    "f32_equivalent_vs_f32_mfma_peak": alg / t / 1e12 / MFMA_F32_PEAK_TFLOPS}
+        return {"kernel": "inbatch_kernel<128,{Q,C}side> (2 launches)", "bound": "mfma",
+                "achieved": alg / t / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": alg / t / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None}
+    # HBM-bound workloads: the dominant kernel is whichever of {fused loss kernel, sparse Adagrad} took longer
+    fused_name = "triplet_fused" if workload == "triplet" else "glove_fused"
+    fused_bytes = rows * B * D * 4 * 2  # reads `rows` rows and writes `rows` gradient rows per unit
+    ada_bytes = (occ_n + 4 * uniq) * D * 4  # grad row read per occurrence + param/accum RMW per distinct row
+    cands = {fused_name: fused_bytes, "sparse_adagrad": ada_bytes}
+    name = max(cands, key=lambda k: kernels[k]["ms_per_step"])
+    t = kernels[name]["ms_per_step"] * 1e-3
+    return {"kernel": name, "bound": "hbm", "achieved": cands[name] / t / 1e9, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": cands[name] / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "other": {k: {"GBps": cands[k] / (kernels[k]["ms_per_step"] * 1e-3) / 1e9,
+                          "ms_per_step": kernels[k]["ms_per_step"]} for k in cands if k != name}}
+
+
+TIMED_GROUPS = {
+    "gather": ["gather_rows", "gather_rows_multi"],
+    "inbatch_mfma": ["inbatch_softmax_fwd_bwd"],
+    "triplet_fused": ["triplet_fwd_bwd"],
+    "glove_fused": ["glove_fwd_bwd"],
+    "segment_sort": ["segment_sort"],
+    "sparse_adagrad": ["sparse_adagrad", "sparse_adagrad_multi"],
+}
+
+
 def synth_tables(V, D, dev, gen):
     t = torch.randn((V, D), generator=gen, device=dev, dtype=torch.float32)
     return t.mul_(D ** -0.5)
@@ -179,7 +221,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="inbatch", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="inbatch", choices=sorted(WORKLOADS) + ["retrieve"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="auto", choices=["auto", "f32", "bf16x3"],
                     help="MFMA path of the in-batch score kernel (both are f32-grade; see DESIGN.md 2.2)")
@@ -198,6 +240,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    if args.workload == "retrieve":  # config 5 (not the headline): batch score GEMM + top-k
+        from bench_retrieve import run_retrieve
+        return run_retrieve(args, emit)
     assert torch.cuda.is_available(), "bench.py needs an MI355X: there is no CPU fallback for the product path"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -218,14 +263,7 @@ def main():
 
     n_batches = args.steps + args.warmup
     state, batches = make_state_and_batches(args.workload, cfg, dev, n_batches, rank)
-    timer = KernelTimer(ops, {
-        "gather": ["gather_rows"],
-        "inbatch_mfma": ["inbatch_softmax_fwd_bwd"],
-        "triplet_fused": ["triplet_fwd_bwd"],
-        "glove_fused": ["glove_fwd_bwd"],
-        "segment_sort": ["segment_sort"],
-        "sparse_adagrad": ["sparse_adagrad", "sparse_adagrad_multi"],
-    })
+    timer = KernelTimer(ops, TIMED_GROUPS)
     timer.install()
 
     # ---- timed region: K steps (eager launches; --graph replays the whole step as one hipGraph) ----------------
@@ -288,40 +326,14 @@ def main():
     adagrad_bytes = rows * B * D * 4 * 5
     if args.no_kernel_timing:
         roofline = None
-    elif args.workload == "inbatch":
-        t = kernels["inbatch_mfma"]["ms_per_step"] * 1e-3
-        alg = 6.0 * B * B * D  # S = QC^T, dQ = PC, dC = P^T Q in f32
-        split = PRECISION != "f32" and D == 128 and B % 128 == 0
-        if split:
-            # bf16x3 path: every f32 product = 6 bf16 MFMA terms; S is recomputed in pass C (4 GEMM units) and the
-            # row-max pre-pass adds one hi-plane term: (4 * 6 + 1) * 2 B^2 D executed bf16 flops
-            executed = (4 * 6 + 1) * 2.0 * B * B * D
-            roofline = {"kernel": "split3 + inbatch3_rowmax + inbatch3_kernel<Q> + merge + inbatch3_kernel<C> + merge",
-                        "bound": "mfma", "achieved": executed / t / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": executed / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
-                        "dtype": "bf16 x3 split, f32 accumulate (f32-equivalent products)",
-                        "f32_equivalent_TFLOPs": alg / t / 1e12,
-                        "f32_equivalent_vs_f32_mfma_peak": alg / t / 1e12 / MFMA_F32_PEAK_TFLOPS}
-        else:
-            roofline = {"kernel": "inbatch_kernel<128,{Q,C}side> (2 launches)", "bound": "mfma",
-                        "achieved": alg / t / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": alg / t / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None}
     else:
-        # HBM-bound workloads: the dominant kernel is whichever of {fused loss kernel, sparse Adagrad} took longer
-        fused_name = "triplet_fused" if args.workload == "triplet" else "glove_fused"
-        fused_bytes = rows * B * D * 4 * 2  # reads `rows` rows and writes `rows` gradient rows per unit
-        last = batches[-1]
-        occ = torch.cat([last[0].reshape(-1)] if args.workload == "glove" else
-                        [last[0], last[1] + V, last[2] + V])  # the two towers are different tables
-        uniq = int(torch.unique(occ).numel())
-        ada_bytes = (occ.numel() + 4 * uniq) * D * 4  # grad row read per occurrence + param/accum RMW per distinct row
-        cands = {fused_name: fused_bytes, "sparse_adagrad": ada_bytes}
-        name = max(cands, key=lambda k: kernels[k]["ms_per_step"])
-        t = kernels[name]["ms_per_step"] * 1e-3
-        roofline = {"kernel": name, "bound": "hbm", "achieved": cands[name] / t / 1e9, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": cands[name] / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                    "other": {k: {"GBps": cands[k] / (kernels[k]["ms_per_step"] * 1e-3) / 1e9,
-                                  "ms_per_step": kernels[k]["ms_per_step"]} for k in cands if k != name}}
+        occ_n = uniq = 0
+        if args.workload != "inbatch":
+            last = batches[-1]
+            occ = torch.cat([last[0].reshape(-1)] if args.workload == "glove" else
+                            [last[0], last[1] + V, last[2] + V])  # the two towers are different tables
+            occ_n, uniq = occ.numel(), int(torch.unique(occ).numel())
+        roofline = roofline_for(args.workload, kernels, B, D, rows, PRECISION, occ_n, uniq)
     hbm = {}
     if "gather" in kernels:
         t = kernels["gather"]["ms_per_step"] * 1e-3

@@ -1,0 +1,106 @@
+"""`bench.py --workload retrieve`: BASELINE config 5 -- D = 512 batch score GEMM + top-k, brute force (exact) and
+the bf16 candidate stage + exact re-rank ("ann"), candidates row-sharded over the GPUs (id mod N).
+A step = one batch of 8192 queries per GPU against ALL 1 048 576 candidates (each GPU scores every rank's queries
+against its own shard, then the per-shard answers are exchanged and merged: esrecsys_amd/sharded.py)."""
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+NQ, N_TOTAL, D, K = 8192, 1_048_576, 512, 500
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def run_retrieve(args, emit):
+    from esrecsys_amd import ops, sharded
+    from esrecsys_amd.pinterest.make_recommendations import find_top_k_batch, recall_at_k
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    # weak scaling would grow the candidate set with N; config 5 fixes it at 1M rows, so at N = 1 one GPU holds
+    # the share it would hold in the 8-GPU job (131 072 rows) and N GPUs hold N such shares
+    n_local = N_TOTAL // 8
+    g = torch.Generator(device=dev).manual_seed(1701 + rank)
+    q = torch.randn((NQ, D), generator=g, device=dev) * D ** -0.5
+    c = torch.randn((n_local, D), generator=g, device=dev) * D ** -0.5
+    mode = "exact" if args.precision in ("auto", "f32") else "bf16"
+
+    def step():
+        if world == 1:
+            return ops.retrieve_topk(q, c, K, mode=mode)
+        return sharded.sharded_find_top_k(q, c, K, mode=mode)
+
+    for _ in range(max(args.warmup, 1)):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    # dominant kernel = the score GEMM; HIP events around the op on the launch stream (rank 0)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    qq = q if world == 1 else q.repeat(world, 1)
+    e0.record()
+    ops.retrieve_topk(qq, c, K, mode=mode)
+    e1.record()
+    torch.cuda.synchronize()
+    t_op = e0.elapsed_time(e1) * 1e-3
+    planes = 6 if mode == "exact" else 1
+    flops = 2.0 * qq.shape[0] * n_local * D
+    extra = {}
+    if world == 1 and not args.no_cpu_baseline:
+        a_s, a_i = find_top_k_batch(q, c, K, approximate=True)
+        extra["ann_recall_at_k_vs_brute_force"] = recall_at_k(a_i, out[1])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        find_top_k_batch(q, c, K, approximate=True)
+        torch.cuda.synchronize()
+        extra["ann_ms"] = (time.perf_counter() - t1) * 1e3
+        from oracle import topk as o_topk          # CPU baseline leg: the oracle on a bounded sample
+        import numpy as np
+        ns = 64
+        qs, cs = q[:ns].cpu().numpy(), c.cpu().numpy()
+        t1 = time.perf_counter()
+        o_topk.batched_top_k(qs, cs, K, np.float32)
+        cpu_dt = time.perf_counter() - t1
+        extra_cpu = {"value": ns / cpu_dt, "unit": "queries/s", "cores": torch.get_num_threads(), "kind": "port",
+                     "sample": "%d queries x %d candidates x D=%d, numpy f32 GEMM + stable argsort" % (ns, n_local, D)}
+    else:
+        extra_cpu = None
+    if rank == 0:
+        emit({
+            "metric": "retrieval queries/sec (top-%d of N candidates, brute force)" % K,
+            "value": world * NQ * args.steps / dt, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16x3 (f32-equivalent)" if mode == "exact" else "bf16",
+            "data": "synthetic",
+            "config": {"workload": "retrieve: %d queries/GPU x %d candidates (%d per GPU, id mod N) x D=%d, k=%d"
+                                   % (NQ, n_local * world, n_local, D, K), "mode": mode,
+                       "parallelism": "single" if world == 1 else "candidates row-sharded x%d, all-gather queries + "
+                                                                  "all-to-all partial top-k" % world, **extra},
+            "roofline": {"kernel": "score_gemm_kernel (+ split, select)", "bound": "mfma",
+                         "achieved": planes * flops / t_op / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": planes * flops / t_op / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                         "f32_equivalent_TFLOPs": flops / t_op / 1e12,
+                         "f32_equivalent_vs_f32_mfma_peak": flops / t_op / 1e12 / MFMA_F32_PEAK_TFLOPS},
+            "cpu_baseline": extra_cpu,
+        })
+    if world > 1:
+        dist.destroy_process_group()

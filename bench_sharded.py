@@ -80,6 +80,29 @@ def run_sharded(args, cfg, dev, rank, world):
     total = loss.clone()
     dist.all_reduce(total)
     dt = float(dt)
+
+    # per-kernel HIP-event pass (every rank runs it: the collectives must match; rank 0 reports its own kernels)
+    roofline, kernels = None, {}
+    if not args.no_kernel_timing:
+        from bench import KernelTimer, TIMED_GROUPS, roofline_for
+        timer = KernelTimer(ops, TIMED_GROUPS)
+        timer.install()
+        timer.enabled = True
+        nxt = plan(batches[args.warmup])
+        for i in range(args.warmup, n_batches):
+            cur, nxt = nxt, None
+            step(batches[i], cur)
+            if i + 1 < n_batches:
+                nxt = plan(batches[i + 1])
+        torch.cuda.synchronize()
+        timer.enabled = False
+        for g_, (ms, calls) in timer.totals_ms().items():
+            if calls:
+                kernels[g_] = {"ms_per_step": ms / args.steps, "launch_groups_per_step": calls / args.steps}
+        rows_served = cur.recv_local_rows
+        roofline = roofline_for(args.workload, kernels, B, D, cfg["rows_per_unit"], "auto",
+                                int(rows_served.numel()), int(torch.unique(rows_served).numel()))
+        roofline["rank"] = 0
     if rank == 0:
         K = args.steps
         from bench import emit
@@ -91,6 +114,6 @@ def run_sharded(args, cfg, dev, rank, world):
                                    % (args.workload, V, D, world, B),
                        "parallelism": "row-sharded x%d, all-to-all ids/rows/grads over RCCL" % world,
                        "loss": float(total)},
-            "roofline": None, "cpu_baseline": None,
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": None,
         })
     dist.destroy_process_group()

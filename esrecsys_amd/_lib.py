@@ -14,6 +14,8 @@ ESR_F32 = 0
 ESR_BF16 = 1
 GLOVE_REFERENCE = 0
 GLOVE_DIAGONAL = 1
+RETRIEVE_EXACT = 0
+RETRIEVE_BF16 = 1
 
 c_i32p = ctypes.c_void_p
 c_f32p = ctypes.c_void_p
@@ -61,6 +63,12 @@ SIGNATURES = {
     "esr_argsort_columns": (c_int, [c_f32p, c_i64, c_int, c_i32p, c_vp, c_size, c_vp]),
     "esr_score_topk_workspace_bytes": (c_size, [c_i64, c_i64, c_int]),
     "esr_score_topk": (c_int, [c_f32p, c_f32p, c_i64, c_i64, c_int, c_int, c_f32p, c_i32p, c_vp, c_size, c_vp]),
+    "esr_retrieve_workspace_bytes": (c_size, [c_i64, c_i64, c_int, c_int, c_int]),
+    "esr_retrieve_topk": (c_int, [c_f32p, c_f32p, c_i64, c_i64, c_int, c_int, c_int, ctypes.c_int32, ctypes.c_int32,
+                                  c_f32p, c_i32p, c_vp, c_size, c_vp]),
+    "esr_rescore_candidates": (c_int, [c_f32p, c_f32p, c_i64, c_i64, c_int, c_i32p, c_int, ctypes.c_int32,
+                                       ctypes.c_int32, c_f32p, c_vp]),
+    "esr_topk_merge": (c_int, [c_f32p, c_i32p, c_i64, c_int, c_int, c_f32p, c_i32p, c_vp]),
     "esr_bucket_workspace_bytes": (c_size, [c_i64]),
     "esr_bucket_ids_by_owner": (c_int, [c_i32p, c_i64, c_int, c_i32p, c_i32p, c_vp, c_vp, c_size, c_vp]),
 }

@@ -1,0 +1,702 @@
+// esr_retrieve.hip -- batched brute-force retrieval (BASELINE config 5):
+//   scores[q, n] = queries[q] . candidates[n]   for nq queries x N candidates, then top-k per query,
+//   descending, ties -> lower index (jax.lax.top_k: pinterest/make_recommendations.py:62-65, batched over the
+//   scenes of :123-132; spotify/train_spotify.py:120 top_k(500) over all tracks).
+//
+// The score matrix is MFMA-bound (2 nq N D flop against (nq + N) D bytes) and is never materialised in full:
+//   split   f32 rows -> bf16 planes (1 plane = "bf16" mode; 3 exact planes = f32-equivalent mode, six cross terms
+//           a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1 as in esr_inbatch3.hip), zero-padded to tile multiples;
+//   gemm    256 x 128 tiles, 8 waves (64 x 64 each, v_mfma_f32_32x32x16_bf16), K in 32-element stages that are
+//           DMA'd global -> LDS (global_load_lds_dwordx4, XOR-swizzled on the source address), XCD-aware tile
+//           order (the 32 tiles resident on one XCD form a 4 x 8 block and share their operand rows in L2);
+//           epilogue of the FIRST candidate chunk stores the tile densely; every later chunk only appends the
+//           (score, index) pairs that reach the query's current k-th best score (tau) to a per-query list;
+//   select  one workgroup per query: MSB-first radix select (11-bit digits) on the 64-bit composite
+//           (order-preserving score key, ~index) -- unique composites, so ties need no special case -- then a
+//           bitonic sort of the k survivors in LDS; it rewrites the list head = running top-k and tau.
+// The result is a pure function of the inputs: the append order is not deterministic, the selected SET and its
+// final order are (total order on the composite).
+#include "esr_common.h"
+
+#include <algorithm>
+
+namespace esr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int kGM = 256, kGN = 128, kGK = 32;  // tile rows (queries), tile cols (candidates), k per stage
+constexpr int kGThreads = 512;
+constexpr int kTileRowBytes = kGK * 2;                      // 64 B of one plane row per stage
+constexpr int kPlaneStage = (kGM + kGN) * kTileRowBytes;    // 24576 B: A tile then B tile of one plane
+constexpr int kGroupM = 4;                                  // tile-order group height (tiles)
+constexpr int kSelThreads = 256;
+constexpr int kSelMaxK = 1024;
+constexpr int kFirstChunk = 8192;
+
+// ---------------------------------------------------------------------------------------------------
+// f32 rows -> P bf16 planes [P][rows_pad][Dp], zero padded (rows >= n_rows, cols >= D)
+// ---------------------------------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(kBlock) void split_planes_kernel(const float* __restrict__ X, int64_t n_rows, int D,
+                                                             int64_t rows_pad, int Dp, int64_t plane_elems,
+                                                             __bf16* __restrict__ out) {
+  const int quads = Dp >> 2;
+  const int64_t total = rows_pad * quads;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t r = i / quads;
+    const int c = (int)(i - r * quads) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r < n_rows) {
+      if ((D & 3) == 0 && c + 3 < D) {
+        const float4 f = *reinterpret_cast<const float4*>(X + r * D + c);
+        v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c + e < D) v[e] = X[r * D + c + e];
+      }
+    }
+    bf16x4 p1, p2, p3;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const __bf16 a = (__bf16)v[e];
+      p1[e] = a;
+      if (P == 3) {
+        const float r1 = v[e] - (float)a;
+        const __bf16 b = (__bf16)r1;
+        p2[e] = b;
+        p3[e] = (__bf16)(r1 - (float)b);
+      }
+    }
+    __bf16* dst = out + r * Dp + c;
+    *reinterpret_cast<bf16x4*>(dst) = p1;
+    if (P == 3) {
+      *reinterpret_cast<bf16x4*>(dst + plane_elems) = p2;
+      *reinterpret_cast<bf16x4*>(dst + 2 * plane_elems) = p3;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// score GEMM
+// ---------------------------------------------------------------------------------------------------
+struct GemmOut {
+  float* S;            // dense: [M][ldS]
+  int64_t ldS;
+  const float* tau;    // filtered: per-query threshold
+  int32_t* cnt;        // per-query list length
+  int2* pairs;         // [M][ppitch] (score bits, index)
+  int64_t ppitch;
+  int32_t gbase, gstep;  // global index of local candidate n = gbase + n * gstep
+};
+
+// Wait until at most N of this wave's DMAs are outstanding, then the workgroup barrier.  Written by hand:
+// __syncthreads() carries a release fence that makes hipcc wait vmcnt(0), i.e. for the stages that were issued
+// only to be in flight across this barrier.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+#define ESR_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+template <int P, bool DENSE>
+__global__ __launch_bounds__(kGThreads) void score_gemm_kernel(const __bf16* __restrict__ Ap, int64_t a_plane,
+                                                              const __bf16* __restrict__ Bp, int64_t b_plane, int Dp,
+                                                              int tm, int tn, int M, int nvalid, GemmOut o) {
+  constexpr int NS = (P == 3) ? 2 : 4;           // LDS stages
+  constexpr int kStage = P * kPlaneStage;        // 73728 / 24576 B
+  constexpr int IPS = 3 * P;                     // DMA instructions per wave per stage
+  __shared__ __attribute__((aligned(16))) char lds[NS * kStage];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+
+  // XCD-aware order: workgroup b runs on XCD b % 8; each XCD walks its own contiguous range of logical tiles,
+  // logical tiles are ordered in groups of kGroupM tile-rows x all tile-columns, column-major inside a group.
+  const int T = tm * tn, per = (T + 7) >> 3;
+  const int L = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (L >= T) return;
+  const int g = L / (kGroupM * tn), rem = L - g * kGroupM * tn;
+  const int gm = min(kGroupM, tm - g * kGroupM);
+  const int n_t = rem / gm, m_t = g * kGroupM + (rem - n_t * gm);
+  const int m0 = m_t * kGM, n0 = n_t * kGN;
+
+  // ---- DMA addressing: one wave instruction moves 16 rows x 64 B; lane -> (row = lane / 4, 16-B piece) with the
+  // piece XOR-swizzled by (row / 4) % 4 so that the MFMA fragment reads below are bank-conflict free.
+  const uint32_t lane_off = (uint32_t)(((lane >> 2) * Dp + (((lane & 3) ^ ((lane >> 4) & 3)) << 3)) * 2);
+  const char* srcA0 = reinterpret_cast<const char*>(Ap + (int64_t)(m0 + 16 * w) * Dp);
+  const char* srcA1 = reinterpret_cast<const char*>(Ap + (int64_t)(m0 + 16 * (w + 8)) * Dp);
+  const char* srcB = reinterpret_cast<const char*>(Bp + (int64_t)(n0 + 16 * w) * Dp);
+  const int64_t a_pb = a_plane * 2, b_pb = b_plane * 2;
+  const int nk = Dp / kGK;
+
+  auto issue = [&](int kt) {
+    char* st = lds + (kt % NS) * kStage;
+    const uint32_t off = lane_off + (uint32_t)kt * (kGK * 2);
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      char* ps = st + p * kPlaneStage;
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcA0 + p * a_pb + off), (lptr_t)(ps + w * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcA1 + p * a_pb + off), (lptr_t)(ps + (w + 8) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcB + p * b_pb + off), (lptr_t)(ps + kGM * kTileRowBytes + w * 1024),
+                                       16, 0, 0);
+    }
+  };
+
+  // ---- fragment addressing: wave (wm, wn) owns rows wm*64.. of A and wn*64.. of B, two 32-row tiles each
+  const int wm = w >> 1, wn = w & 1;
+  const int l31 = lane & 31, h = lane >> 5, swz = (l31 >> 2) & 3;
+  const int fragA = (wm * 64 + l31) * kTileRowBytes;
+  const int fragB = kGM * kTileRowBytes + (wn * 64 + l31) * kTileRowBytes;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nk) issue(s);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    // stage kt has landed once at most the younger stages' DMAs are outstanding; in the tail wait for all
+    // afterwards stage kt is visible to every wave and every wave is done with stage kt-1's buffer
+    if (kt + NS - 1 <= nk) wait_vmcnt_barrier<IPS * (NS - 2)>();
+    else wait_vmcnt_barrier<0>();
+    if (kt + NS - 1 < nk) issue(kt + NS - 1);
+    const char* st = lds + (kt % NS) * kStage;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int po = ((ks * 2 + h) ^ swz) << 4;
+      bf16x8 a[P][2], b[P][2];
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          a[p][r] = *reinterpret_cast<const bf16x8*>(st + p * kPlaneStage + fragA + r * 32 * kTileRowBytes + po);
+          b[p][r] = *reinterpret_cast<const bf16x8*>(st + p * kPlaneStage + fragB + r * 32 * kTileRowBytes + po);
+        }
+      // small terms first; consecutive MFMAs go to different accumulators
+#define ESR_TERM(PA, PB)                                                          \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
+      acc[i][j] = ESR_MFMA(a[PA][i], b[PB][j], acc[i][j]);
+      if (P == 3) {
+        ESR_TERM(P - 1, 0)
+        ESR_TERM(0, P - 1)
+        ESR_TERM(P == 3 ? 1 : 0, P == 3 ? 1 : 0)
+        ESR_TERM(P == 3 ? 1 : 0, 0)
+        ESR_TERM(0, P == 3 ? 1 : 0)
+      }
+      ESR_TERM(0, 0)
+#undef ESR_TERM
+    }
+  }
+
+  // ---- epilogue: acc[i][j][e] = S[m0 + wm*64 + i*32 + 8*(e/4) + 4*h + e%4][n0 + wn*64 + j*32 + l31]
+  if (DENSE) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + i * 32 + 8 * (e >> 2) + 4 * h + (e & 3);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int n = n0 + wn * 64 + j * 32 + l31;
+          if (m < M && n < nvalid) o.S[(int64_t)m * o.ldS + n] = acc[i][j][e];
+        }
+      }
+  } else {
+    // Filtered append.  A half-wave (h) holds, for each of its 32 rows r = i*16 + e, the 64 candidates
+    // (j, l31) of ONE query.  Pass 1 counts the survivors of every row with ballots and parks row r's count in
+    // lane r; ONE atomic per row (all 64 of a wave in flight together) reserves the slots; pass 2 writes the
+    // survivors side by side.  An atomic per (row, ballot) with its returned value needed at once serialised
+    // 64 round trips per tile (measured: +45 % on the whole kernel).
+    const bool c_ok0 = n0 + wn * 64 + l31 < nvalid, c_ok1 = n0 + wn * 64 + 32 + l31 < nvalid;
+    float tau_r[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + i * 32 + 8 * (e >> 2) + 4 * h + (e & 3);
+        tau_r[i][e] = m < M ? o.tau[m] : INFINITY;
+      }
+    int my_cnt = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const unsigned long long b0 = __ballot(c_ok0 && acc[i][0][e] >= tau_r[i][e]);
+        const unsigned long long b1 = __ballot(c_ok1 && acc[i][1][e] >= tau_r[i][e]);
+        const int c = __popc((uint32_t)(b0 >> (32 * h))) + __popc((uint32_t)(b1 >> (32 * h)));
+        if (l31 == i * 16 + e) my_cnt = c;
+      }
+    const int my_m = m0 + wm * 64 + (l31 >> 4) * 32 + 8 * ((l31 & 15) >> 2) + 4 * h + (l31 & 3);
+    int my_slot = 0;
+    if (my_cnt > 0) my_slot = atomicAdd(o.cnt + my_m, my_cnt);
+    if (__ballot(my_cnt > 0)) {
+      const uint32_t below = (1u << l31) - 1u;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const bool p0 = c_ok0 && acc[i][0][e] >= tau_r[i][e];
+          const bool p1 = c_ok1 && acc[i][1][e] >= tau_r[i][e];
+          const unsigned long long b0 = __ballot(p0), b1 = __ballot(p1);
+          if ((b0 | b1) == 0) continue;  // wave-uniform
+          const uint32_t h0 = (uint32_t)(b0 >> (32 * h)), h1 = (uint32_t)(b1 >> (32 * h));
+          const int slot = __shfl(my_slot, 32 * h + i * 16 + e, 64);
+          const int m = m0 + wm * 64 + i * 32 + 8 * (e >> 2) + 4 * h + (e & 3);
+          int2* dst = o.pairs + (int64_t)m * o.ppitch + slot;
+          const int n = n0 + wn * 64 + l31;
+          if (p0) dst[__popc(h0 & below)] = make_int2(__float_as_int(acc[i][0][e]), o.gbase + n * o.gstep);
+          if (p1)
+            dst[__popc(h0) + __popc(h1 & below)] =
+                make_int2(__float_as_int(acc[i][1][e]), o.gbase + (n + 32) * o.gstep);
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per-query top-k select
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t score_key(float v) {  // larger float <=> larger key; -0 == +0
+  v += 0.0f;
+  const uint32_t u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_score(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+struct SelIn {
+  const float* vals;   // element c of row r at vals[r * vpitch + c * stride]
+  int64_t vpitch;
+  const int32_t* idx;  // explicit index (same pitch / stride, in int32 elements) or null
+  int stride;
+  int32_t ibase, istep;  // implicit index = ibase + c * istep
+  const int32_t* n_per_row;  // list length per row, or null -> n_fixed
+  int n_fixed;
+};
+struct SelOut {
+  int2* pairs;         // running top-k list head [rows][ppitch], or null
+  int64_t ppitch;
+  int32_t* cnt;        // list length after the call = min(n, k)
+  float* tau;          // k-th best score (or -inf while fewer than k)
+  float* scores;       // [rows][k] or null
+  int32_t* indices;    // [rows][k] or null
+};
+
+// inclusive scan over the 256 threads of the block (wave shuffles + 4 partials)
+__device__ __forceinline__ int block_incl_scan(int v, int* part4, int t) {
+  const int lane = t & 63, w = t >> 6;
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  if (lane == 63) part4[w] = x;
+  __syncthreads();
+  int add = 0;
+  for (int j = 0; j < w; ++j) add += part4[j];
+  __syncthreads();
+  return x + add;
+}
+
+constexpr int kSelBatch = 8;   // elements per thread of a row that stays in registers (rows <= 2048)
+constexpr int kSelStream = 4;  // independent loads in flight per thread when a longer row is streamed
+
+// One workgroup per query.  n <= k: everything is kept.  Otherwise an MSB-first radix select runs on
+// D = composite - min(composite), starting at the highest bit in which the row's composites differ: the lists a
+// merge sees are the survivors of a threshold, i.e. crowded into a sliver of the float range, and digits taken from
+// fixed bit positions put them all into two or three bins (measured: same-address LDS atomics made a 2 500-element
+// merge take 180 us).  Range-relative digits spread them over the 2048 bins, so one histogram pass usually isolates
+// the bucket of the k-th largest; passes continue (11 bits each) until that bucket is needed whole -- at the latest
+// when all bits are used, composites being unique -- which yields exactly the top-k SET.  It is compacted into
+// LDS; only a call that delivers the answer (out.scores) sorts it (bitonic, 64-bit keys): the running list of an
+// intermediate merge need not be ordered, only tau must be exact.
+__global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void topk_select_kernel(
+    SelIn in, int k, SelOut out) {
+  __shared__ unsigned long long sel[kSelMaxK];
+  __shared__ int hist[2048];
+  __shared__ int part4[4];
+  __shared__ int s_digit, s_above, s_cnt, s_nsel;
+  __shared__ unsigned long long s_min, s_lo, s_hi;
+  const int row = blockIdx.x, t = threadIdx.x;
+  const int n = in.n_per_row ? in.n_per_row[row] : in.n_fixed;
+  const bool final = out.scores != nullptr;
+  if (n <= k && !final) {  // nothing was appended (or the list is still short): the running state stands
+    if (t == 0) {
+      if (out.cnt) out.cnt[row] = n;
+      if (out.tau && n < k) out.tau[row] = -INFINITY;
+    }
+    return;
+  }
+  const float* v = in.vals + (int64_t)row * in.vpitch;
+  const int32_t* ix = in.idx ? in.idx + (int64_t)row * in.vpitch : nullptr;
+  const bool paired = in.stride == 2 && ix == reinterpret_cast<const int32_t*>(v) + 1;  // (score, index) records
+  auto comp = [&](int c) -> unsigned long long {
+    uint32_t key, gi;
+    if (paired) {
+      const int2 pr = *reinterpret_cast<const int2*>(v + 2 * (int64_t)c);
+      key = score_key(__int_as_float(pr.x));
+      gi = (uint32_t)pr.y;
+    } else {
+      key = score_key(v[(int64_t)c * in.stride]);
+      gi = (uint32_t)(ix ? ix[(int64_t)c * in.stride] : in.ibase + c * in.istep);
+    }
+    return ((unsigned long long)key << 32) | (0xFFFFFFFFu - gi);
+  };
+  // a row of up to 2048 elements is read once and stays in registers; longer rows are re-read (L2) every sweep
+  const bool cached = n <= kSelThreads * kSelBatch;
+  unsigned long long R[kSelBatch];
+  if (cached) {
+#pragma unroll
+    for (int u = 0; u < kSelBatch; ++u) {
+      const int c = u * kSelThreads + t;
+      R[u] = c < n ? comp(c) : 0ull;
+    }
+  }
+  auto sweep = [&](auto&& fn) {
+    if (cached) {
+#pragma unroll
+      for (int u = 0; u < kSelBatch; ++u) fn(R[u], u * kSelThreads + t < n);
+    } else {
+      for (int c0 = 0; c0 < n; c0 += kSelThreads * kSelStream) {
+        unsigned long long C[kSelStream];
+#pragma unroll
+        for (int u = 0; u < kSelStream; ++u) {
+          const int c = c0 + u * kSelThreads + t;
+          C[u] = c < n ? comp(c) : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < kSelStream; ++u) fn(C[u], c0 + u * kSelThreads + t < n);
+      }
+    }
+  };
+  const int nsel = min(n, k);
+  if (t == 0) {
+    s_nsel = 0;
+    s_min = ~0ull;
+    s_lo = ~0ull;
+    s_hi = 0ull;
+  }
+  __syncthreads();
+  unsigned long long thr = 0;
+  if (n > k) {
+    unsigned long long lo = ~0ull, hi = 0ull;
+    sweep([&](unsigned long long C, bool valid) {
+      lo = (valid && C < lo) ? C : lo;
+      hi = (valid && C > hi) ? C : hi;
+    });
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long a = __shfl_xor(lo, o, 64), b2 = __shfl_xor(hi, o, 64);
+      lo = a < lo ? a : lo;
+      hi = b2 > hi ? b2 : hi;
+    }
+    if ((t & 63) == 0) {
+      atomicMin(&s_lo, lo);
+      atomicMax(&s_hi, hi);
+    }
+    __syncthreads();
+    lo = s_lo;
+    const int L = 64 - __clzll((long long)(s_hi - lo));  // >= 1: n > k >= 1 distinct composites
+    unsigned long long prefix = 0;
+    int bits_done = 0, need = k;
+    while (bits_done < L) {
+      const int wbits = min(11, L - bits_done);
+      const int shift = L - bits_done - wbits;
+      for (int b = t; b < 2048; b += kSelThreads) hist[b] = 0;
+      __syncthreads();
+      sweep([&](unsigned long long C, bool valid) {
+        const unsigned long long Dv = C - lo;
+        if (valid && (bits_done == 0 || (Dv >> (L - bits_done)) == prefix))
+          atomicAdd(&hist[(int)((Dv >> shift) & ((1u << wbits) - 1))], 1);
+      });
+      __syncthreads();
+      // thread t owns bins 2047-8t .. 2040-8t (descending)
+      int local = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) local += hist[2047 - 8 * t - j];
+      const int incl = block_incl_scan(local, part4, t), excl = incl - local;
+      if (excl < need && need <= incl) {
+        int run = excl;
+        for (int j = 0; j < 8; ++j) {
+          const int hv = hist[2047 - 8 * t - j];
+          if (run + hv >= need) {
+            s_digit = 2047 - 8 * t - j;
+            s_above = run;
+            s_cnt = hv;
+            break;
+          }
+          run += hv;
+        }
+      }
+      __syncthreads();
+      prefix = (prefix << wbits) | (unsigned long long)s_digit;
+      need -= s_above;
+      bits_done += wbits;
+      const bool whole_bucket = (s_cnt == need);
+      __syncthreads();  // s_* consumed before the next pass overwrites them
+      if (whole_bucket) break;
+    }
+    thr = lo + (prefix << (L - bits_done));
+  }
+  // compact the composites >= thr (exactly nsel of them) into LDS: one slot reservation per wave instruction
+  // (a same-address LDS atomic per element serialises: 500 survivors cost more than the whole radix select)
+  unsigned long long my_min = ~0ull;
+  sweep([&](unsigned long long C, bool valid) {
+    const bool pass = valid && C >= thr;
+    const unsigned long long mask = __ballot(pass);
+    if (mask) {
+      const int lane = t & 63;
+      int base = 0;
+      if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(&s_nsel, __popcll(mask));
+      base = __shfl(base, __ffsll((long long)mask) - 1, 64);
+      if (pass) {
+        const int p = base + __popcll(mask & ((1ull << lane) - 1ull));
+        if (p < kSelMaxK) sel[p] = C;
+        my_min = C < my_min ? C : my_min;
+      }
+    }
+  });
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long a = __shfl_xor(my_min, o, 64);
+    my_min = a < my_min ? a : my_min;
+  }
+  if ((t & 63) == 0) atomicMin(&s_min, my_min);
+  if (final) {
+    int np2 = 1;
+    while (np2 < nsel) np2 <<= 1;
+    __syncthreads();
+    for (int c = nsel + t; c < np2; c += kSelThreads) sel[c] = 0ull;
+    for (int size = 2; size <= np2; size <<= 1) {  // bitonic sort, descending
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        __syncthreads();
+        for (int i = t; i < (np2 >> 1); i += kSelThreads) {
+          const int pos = 2 * i - (i & (stride - 1));
+          const int j = pos + stride;
+          const bool desc = (pos & size) == 0;
+          const unsigned long long x = sel[pos], y = sel[j];
+          if ((x < y) == desc) {
+            sel[pos] = y;
+            sel[j] = x;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();  // every read of this row's list is done: its head may be overwritten
+  for (int c = t; c < k; c += kSelThreads) {
+    const bool valid = c < nsel;
+    const unsigned long long C = valid ? sel[c] : 0ull;
+    const float s = valid ? key_score((uint32_t)(C >> 32)) : -INFINITY;
+    const int32_t gi = valid ? (int32_t)(0xFFFFFFFFu - (uint32_t)C) : -1;
+    if (out.pairs && valid) out.pairs[(int64_t)row * out.ppitch + c] = make_int2(__float_as_int(s), gi);
+    if (out.scores) out.scores[(int64_t)row * k + c] = s;
+    if (out.indices) out.indices[(int64_t)row * k + c] = gi;
+  }
+  if (t == 0) {
+    if (out.cnt) out.cnt[row] = nsel;
+    if (out.tau) out.tau[row] = (n >= k) ? key_score((uint32_t)(s_min >> 32)) : -INFINITY;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// exact f32 re-score of candidate lists (the second stage of the bf16 "ANN" path)
+// scores[q, j] = queries[q] . candidates[(idx[q, j] - base) / step], one wave per (q, j)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void rescore_kernel(const float* __restrict__ Q, const float* __restrict__ C,
+                                                        int64_t N, int D, const int32_t* __restrict__ idx,
+                                                        int64_t total, int kc, int32_t base, int32_t step,
+                                                        float* __restrict__ scores) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
+  for (int64_t p = wave; p < total; p += nwaves) {
+    const int64_t q = p / kc;
+    const int32_t gi = idx[p];
+    float acc = 0.f;
+    if (gi >= 0) {
+      const int64_t r = ((int64_t)gi - base) / step;
+      const float* qa = Q + q * D;
+      const float* ca = C + r * D;
+      if ((D & 3) == 0) {
+        for (int d = lane * 4; d < D; d += 256) {
+          const float4 x = *reinterpret_cast<const float4*>(qa + d);
+          const float4 y = *reinterpret_cast<const float4*>(ca + d);
+          acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
+        }
+      } else {
+        for (int d = lane; d < D; d += 64) acc = fmaf(qa[d], ca[d], acc);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) scores[p] = gi >= 0 ? acc : -INFINITY;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+struct RetrievePlan {
+  int P, Dp;
+  int64_t Mp, chunk, chunk_pad, first;
+  size_t off_A, off_B, off_S, off_pairs, off_cnt, off_tau, total;
+  int64_t ppitch;
+};
+
+static RetrievePlan retrieve_plan(int64_t nq, int64_t N, int D, int k, int mode) {
+  RetrievePlan p;
+  p.P = (mode == 0) ? 3 : 1;
+  p.Dp = (int)(cdiv(D, kGK) * kGK);
+  p.Mp = cdiv(nq, kGM) * kGM;
+  p.first = std::min<int64_t>(N, std::max<int64_t>(kFirstChunk, 16 * (int64_t)k));
+  // later chunks: the per-query append list must hold a whole chunk (worst case every candidate passes tau);
+  // keep the list buffer around 2 GiB and the 32-bit DMA offsets inside one plane set
+  int64_t chunk = ((int64_t)1 << 28) / std::max<int64_t>(nq, 1);
+  chunk = std::min<int64_t>(chunk, ((int64_t)1 << 30) / ((int64_t)p.Dp * 2 * p.P));
+  chunk = std::max<int64_t>(kGN, std::min<int64_t>(65536, chunk / kGN * kGN));
+  p.chunk = chunk;
+  p.chunk_pad = std::max(cdiv(p.chunk, kGN) * kGN, cdiv(p.first, kGN) * kGN);
+  p.ppitch = (int64_t)k + p.chunk;
+  size_t o = 0;
+  p.off_A = o; o += align_up((size_t)p.P * p.Mp * p.Dp * 2, 256);
+  p.off_B = o; o += align_up((size_t)p.P * p.chunk_pad * p.Dp * 2, 256);
+  p.off_S = o; o += align_up((size_t)nq * p.first * 4, 256);
+  p.off_pairs = o; o += align_up((size_t)nq * p.ppitch * 8, 256);
+  p.off_cnt = o; o += align_up((size_t)nq * 4, 256);
+  p.off_tau = o; o += align_up((size_t)nq * 4, 256);
+  p.total = o;
+  return p;
+}
+
+template <int P>
+static void launch_split(const float* X, int64_t n_rows, int D, int64_t rows_pad, int Dp, int64_t plane_elems,
+                         __bf16* out, hipStream_t st) {
+  const int64_t total = rows_pad * (Dp >> 2);
+  const int grid = (int)std::min<int64_t>(cdiv(total, kBlock), 8192);
+  hipLaunchKernelGGL((split_planes_kernel<P>), dim3(grid), dim3(kBlock), 0, st, X, n_rows, D, rows_pad, Dp, plane_elems,
+                     out);
+}
+
+template <int P, bool DENSE>
+static void launch_gemm(const __bf16* A, int64_t a_plane, const __bf16* B, int64_t b_plane, int Dp, int64_t Mp,
+                        int64_t n_pad, int M, int nvalid, const GemmOut& o, hipStream_t st) {
+  const int tm = (int)(Mp / kGM), tn = (int)(n_pad / kGN);
+  const int per = (tm * tn + 7) / 8;
+  hipLaunchKernelGGL((score_gemm_kernel<P, DENSE>), dim3(per * 8), dim3(kGThreads), 0, st, A, a_plane, B, b_plane, Dp, tm,
+                     tn, M, nvalid, o);
+}
+
+}  // namespace esr
+
+using namespace esr;
+
+extern "C" {
+
+size_t esr_retrieve_workspace_bytes(int64_t nq, int64_t N, int D, int k, int mode) {
+  if (nq <= 0 || N <= 0 || D <= 0 || k <= 0) return 256;
+  return retrieve_plan(nq, N, D, k, mode).total;
+}
+
+int esr_retrieve_topk(const float* queries, const float* candidates, int64_t nq, int64_t N, int D, int k, int mode,
+                      int32_t index_base, int32_t index_step, float* out_scores, int32_t* out_indices, void* workspace,
+                      size_t workspace_bytes, esr_stream_t stream) {
+  ESR_REQUIRE(nq > 0 && N > 0 && D > 0 && k > 0 && k <= N && k <= kSelMaxK && N < ((int64_t)1 << 31) &&
+                  nq < ((int64_t)1 << 24),
+              "esr_retrieve_topk: bad sizes nq=%lld N=%lld D=%d k=%d (k <= min(N, %d))", (long long)nq, (long long)N, D,
+              k, kSelMaxK);
+  ESR_REQUIRE(mode == 0 || mode == 1, "esr_retrieve_topk: mode %d (0 = exact bf16x3, 1 = bf16)", mode);
+  ESR_REQUIRE(index_step > 0 && (int64_t)index_base + (N - 1) * (int64_t)index_step < ((int64_t)1 << 31),
+              "esr_retrieve_topk: index_base/index_step overflow int32");
+  ESR_REQUIRE(queries && candidates && out_scores && out_indices && workspace, "esr_retrieve_topk: null pointer");
+  const RetrievePlan p = retrieve_plan(nq, N, D, k, mode);
+  if (workspace_bytes < p.total || ((uintptr_t)workspace & 15)) {
+    set_error("esr_retrieve_topk: workspace %zu bytes < %zu required (or misaligned)", workspace_bytes, p.total);
+    return ESR_EWORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  char* base = (char*)workspace;
+  __bf16* A = (__bf16*)(base + p.off_A);
+  __bf16* B = (__bf16*)(base + p.off_B);
+  float* S = (float*)(base + p.off_S);
+  int2* pairs = (int2*)(base + p.off_pairs);
+  int32_t* cnt = (int32_t*)(base + p.off_cnt);
+  float* tau = (float*)(base + p.off_tau);
+  const int64_t a_plane = p.Mp * p.Dp, b_plane = p.chunk_pad * p.Dp;
+  if (p.P == 3) launch_split<3>(queries, nq, D, p.Mp, p.Dp, a_plane, A, st);
+  else launch_split<1>(queries, nq, D, p.Mp, p.Dp, a_plane, A, st);
+
+  int64_t c0 = 0;
+  bool first = true;
+  while (c0 < N) {
+    const int64_t nc = std::min<int64_t>(first ? p.first : p.chunk, N - c0);
+    const int64_t n_pad = cdiv(nc, kGN) * kGN;
+    const bool last = (c0 + nc == N);
+    if (p.P == 3) launch_split<3>(candidates + c0 * D, nc, D, n_pad, p.Dp, b_plane, B, st);
+    else launch_split<1>(candidates + c0 * D, nc, D, n_pad, p.Dp, b_plane, B, st);
+    GemmOut o;
+    o.S = S; o.ldS = p.first; o.tau = tau; o.cnt = cnt; o.pairs = pairs; o.ppitch = p.ppitch;
+    o.gbase = index_base + (int32_t)c0 * index_step; o.gstep = index_step;
+    SelIn in;
+    SelOut so;
+    so.pairs = pairs; so.ppitch = p.ppitch; so.cnt = cnt; so.tau = tau;
+    so.scores = last ? out_scores : nullptr;
+    so.indices = last ? out_indices : nullptr;
+    if (first) {
+      if (p.P == 3) launch_gemm<3, true>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
+      else launch_gemm<1, true>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
+      in.vals = S; in.vpitch = p.first; in.idx = nullptr; in.stride = 1; in.ibase = o.gbase; in.istep = index_step;
+      in.n_per_row = nullptr; in.n_fixed = (int)nc;
+    } else {
+      if (p.P == 3) launch_gemm<3, false>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
+      else launch_gemm<1, false>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
+      in.vals = (const float*)pairs; in.vpitch = 2 * p.ppitch; in.idx = (const int32_t*)pairs + 1; in.stride = 2;
+      in.ibase = 0; in.istep = 0; in.n_per_row = cnt; in.n_fixed = 0;
+    }
+    hipLaunchKernelGGL(topk_select_kernel, dim3((int)nq), dim3(kSelThreads), 0, st, in, k, so);
+    c0 += nc;
+    first = false;
+  }
+  return check_launch("esr_retrieve_topk");
+}
+
+int esr_rescore_candidates(const float* queries, const float* candidates, int64_t nq, int64_t N, int D,
+                           const int32_t* indices, int kc, int32_t index_base, int32_t index_step, float* scores,
+                           esr_stream_t stream) {
+  ESR_REQUIRE(nq > 0 && N > 0 && D > 0 && kc > 0 && index_step > 0, "esr_rescore_candidates: bad sizes");
+  ESR_REQUIRE(queries && candidates && indices && scores, "esr_rescore_candidates: null pointer");
+  const int64_t total = nq * kc;
+  const int grid = (int)std::min<int64_t>(cdiv(total, kBlock / 64), 16384);
+  hipLaunchKernelGGL(rescore_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), queries, candidates, N, D, indices,
+                     total, kc, index_base, index_step, scores);
+  return check_launch("esr_rescore_candidates");
+}
+
+int esr_topk_merge(const float* scores, const int32_t* indices, int64_t nq, int n, int k, float* out_scores,
+                   int32_t* out_indices, esr_stream_t stream) {
+  ESR_REQUIRE(nq > 0 && n > 0 && k > 0 && k <= n && k <= kSelMaxK, "esr_topk_merge: bad sizes nq=%lld n=%d k=%d",
+              (long long)nq, n, k);
+  ESR_REQUIRE(scores && indices && out_scores && out_indices, "esr_topk_merge: null pointer");
+  SelIn in;
+  in.vals = scores; in.vpitch = n; in.idx = indices; in.stride = 1; in.ibase = 0; in.istep = 0;
+  in.n_per_row = nullptr; in.n_fixed = n;
+  SelOut so;
+  so.pairs = nullptr; so.ppitch = 0; so.cnt = nullptr; so.tau = nullptr; so.scores = out_scores; so.indices = out_indices;
+  hipLaunchKernelGGL(topk_select_kernel, dim3((int)nq), dim3(kSelThreads), 0, as_stream(stream), in, k, so);
+  return check_launch("esr_topk_merge");
+}
+
+}  // extern "C"

@@ -377,6 +377,51 @@ def score_topk(queries, candidates, k):
     return out_s, out_i
 
 
+_RETRIEVE_MODES = {"exact": _lib.RETRIEVE_EXACT, "f32": _lib.RETRIEVE_EXACT, "bf16": _lib.RETRIEVE_BF16}
+
+
+def retrieve_topk(queries, candidates, k, mode="exact", index_base=0, index_step=1):
+    """Batched brute-force top-k of queries @ candidates^T (descending, ties -> lower index) on MFMA.
+    mode "exact": f32-equivalent products (three exact bf16 planes); "bf16": one plane (approximate).
+    Reported indices are index_base + n * index_step for local candidate row n."""
+    lib = _lib.load()
+    _req(queries, torch.float32, "queries"), _req(candidates, torch.float32, "candidates")
+    nq, D = queries.shape
+    N = candidates.shape[0]
+    m = _RETRIEVE_MODES[mode]
+    out_s = torch.empty((nq, k), dtype=torch.float32, device=queries.device)
+    out_i = torch.empty((nq, k), dtype=torch.int32, device=queries.device)
+    ws = _ws(_ws_bytes("esr_retrieve_workspace_bytes", nq, N, D, k, m), queries.device)
+    check(lib.esr_retrieve_topk(_p(queries), _p(candidates), nq, N, D, k, m, index_base, index_step, _p(out_s),
+                                _p(out_i), _p(ws), ws.numel(), _stream()), "esr_retrieve_topk")
+    return out_s, out_i
+
+
+def rescore_candidates(queries, candidates, indices, index_base=0, index_step=1):
+    """scores[q, j] = queries[q] . candidates[(indices[q, j] - index_base) // index_step] in f32."""
+    lib = _lib.load()
+    _req(queries, torch.float32, "queries"), _req(candidates, torch.float32, "candidates")
+    indices = _req(indices, torch.int32, "indices")
+    nq, D = queries.shape
+    out = torch.empty(indices.shape, dtype=torch.float32, device=queries.device)
+    check(lib.esr_rescore_candidates(_p(queries), _p(candidates), nq, candidates.shape[0], D, _p(indices),
+                                     indices.shape[1], index_base, index_step, _p(out), _stream()),
+          "esr_rescore_candidates")
+    return out
+
+
+def topk_merge(scores, indices, k):
+    """Top-k of per-query (score, index) lists [nq, n] (descending, ties -> lower index)."""
+    lib = _lib.load()
+    scores = _req(scores, torch.float32, "scores")
+    indices = _req(indices, torch.int32, "indices")
+    nq, n = scores.shape
+    out_s = torch.empty((nq, k), dtype=torch.float32, device=scores.device)
+    out_i = torch.empty((nq, k), dtype=torch.int32, device=scores.device)
+    check(lib.esr_topk_merge(_p(scores), _p(indices), nq, n, k, _p(out_s), _p(out_i), _stream()), "esr_topk_merge")
+    return out_s, out_i
+
+
 def bucket_ids_by_owner(ids, world):
     """Stable bucket by owner = id % world.  Returns (local_rows, perm, counts[world] int64 on device)."""
     lib = _lib.load()

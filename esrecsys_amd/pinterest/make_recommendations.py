@@ -17,3 +17,32 @@ def find_top_k(scene_embedding, product_embeddings, k):
     q2 = q.reshape(-1, p.shape[1])
     s, i = ops.score_topk(q2, p, int(k))
     return (s[0], i[0]) if single else (s, i)
+
+
+def find_top_k_batch(scene_embeddings, product_embeddings, k, approximate=False, probe=None):
+    """``find_top_k`` for a batch of scenes in one call (the loop of make_recommendations.py:123-132; the
+    score-everything-then-top_k eval of spotify/train_spotify.py:113-121): [Q, D] x [N, D] -> ([Q, k], [Q, k]).
+
+    approximate=False: brute force with f32-equivalent scores on MFMA (three exact bf16 planes per operand).
+    approximate=True : candidate stage in plain bf16 (one plane, 6x fewer MFMA flops) keeps ``probe`` >= k
+    candidates per scene (default k + max(64, k/2), at most 1024), which are re-scored in f32 and re-ranked -- the reference has
+    no ANN index; this is the build's approximate path and ``recall_at_k`` below measures it against brute force."""
+    dev = product_embeddings.device if isinstance(product_embeddings, torch.Tensor) and product_embeddings.is_cuda \
+        else torch.device("cuda", torch.cuda.current_device())
+    q = ops.as_f32(scene_embeddings, dev)
+    p = ops.as_f32(product_embeddings, dev)
+    q = q.reshape(-1, p.shape[1])
+    k = int(k)
+    if not approximate:
+        return ops.retrieve_topk(q, p, k, mode="exact")
+    probe = min(p.shape[0], 1024, max(k, int(probe) if probe is not None else k + max(64, k // 2)))
+    _, cand = ops.retrieve_topk(q, p, probe, mode="bf16")
+    exact = ops.rescore_candidates(q, p, cand)
+    return ops.topk_merge(exact, cand, k)
+
+
+def recall_at_k(approx_indices, exact_indices):
+    """Mean fraction of the brute-force top-k that the approximate top-k also returned."""
+    a, e = approx_indices.long(), exact_indices.long()
+    hit = (a.unsqueeze(2) == e.unsqueeze(1)).any(dim=1)
+    return float(hit.float().mean())

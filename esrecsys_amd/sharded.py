@@ -218,3 +218,25 @@ def sharded_glove_step(emb_group, bias_group, inputs, target, mode, lr, plan=Non
     emb_group.apply_sparse_adagrad(plan, grad_rows, lr)
     bias_group.apply_sparse_adagrad(plan, grad_bias.reshape(-1, 1), lr)
     return loss
+
+
+def sharded_find_top_k(queries, local_candidates, k, group=None, kernels=None, mode="exact"):
+    """Brute-force top-k over candidates that are row-sharded like the tables (this rank holds rows rank,
+    rank + G, ...; BASELINE config 5).  Every rank brings its own [nq, D] queries (same nq on every rank):
+    all-gather the queries, score ALL of them against the local shard, all-to-all the per-shard answers back to
+    the rank that asked, merge the G lists.  Returns ([nq, k] scores, [nq, k] global row indices)."""
+    if kernels is None:
+        from . import ops as kernels
+    G, rank = dist.get_world_size(group), dist.get_rank(group)
+    nq, D = queries.shape
+    if G == 1:
+        return kernels.retrieve_topk(queries, local_candidates, k, mode=mode)
+    everyone = torch.empty((G * nq, D), dtype=queries.dtype, device=queries.device)
+    dist.all_gather_into_tensor(everyone, queries.contiguous(), group=group)
+    s, i = kernels.retrieve_topk(everyone, local_candidates, k, mode=mode, index_base=rank, index_step=G)
+    rs, ri = torch.empty_like(s), torch.empty_like(i)        # [G (shard), nq, k] after the exchange
+    dist.all_to_all_single(rs, s, group=group)
+    dist.all_to_all_single(ri, i, group=group)
+    rs = rs.reshape(G, nq, k).permute(1, 0, 2).reshape(nq, G * k).contiguous()
+    ri = ri.reshape(G, nq, k).permute(1, 0, 2).reshape(nq, G * k).contiguous()
+    return kernels.topk_merge(rs, ri, k)

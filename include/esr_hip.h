@@ -166,6 +166,32 @@ int esr_score_topk(const float* queries, const float* candidates, int64_t nq, in
                    int k, float* out_scores, int32_t* out_indices, void* workspace,
                    size_t workspace_bytes, esr_stream_t stream);
 
+/* ---- N3 / config 5: batched brute-force retrieval ------------------------------------------
+ * find_top_k (pinterest/make_recommendations.py:49-65) for a BATCH of queries -- the scenes loop of
+ * :123-132 in one call -- and the eval of spotify/train_spotify.py:120 (top_k(500) over every track):
+ *   scores[q, n] = queries[q] . candidates[n];  per query the k best, descending, ties -> lower index.
+ * queries f32 [nq, D], candidates f32 [N, D], k <= min(N, 1024).  The reported index of local candidate
+ * n is index_base + n * index_step (row-sharded candidates: base = rank, step = world).
+ * mode ESR_RETRIEVE_EXACT: products from three exact bf16 planes per operand (six MFMA cross terms,
+ *   f32 accumulate) -- f32-equivalent scores, the brute-force answer.
+ * mode ESR_RETRIEVE_BF16: one bf16 plane per operand -- the approximate candidate stage; follow with
+ *   esr_rescore_candidates + esr_topk_merge for an exact re-rank of k' > k candidates. */
+#define ESR_RETRIEVE_EXACT 0
+#define ESR_RETRIEVE_BF16 1
+size_t esr_retrieve_workspace_bytes(int64_t nq, int64_t N, int D, int k, int mode);
+int esr_retrieve_topk(const float* queries, const float* candidates, int64_t nq, int64_t N, int D, int k,
+                      int mode, int32_t index_base, int32_t index_step, float* out_scores,
+                      int32_t* out_indices, void* workspace, size_t workspace_bytes, esr_stream_t stream);
+/* scores[q, j] = queries[q] . candidates[(indices[q, j] - index_base) / index_step] in f32 (fmaf chain per
+ * lane, wave reduction); indices < 0 give -inf.  indices int32 [nq, kc]. */
+int esr_rescore_candidates(const float* queries, const float* candidates, int64_t nq, int64_t N, int D,
+                           const int32_t* indices, int kc, int32_t index_base, int32_t index_step,
+                           float* scores, esr_stream_t stream);
+/* top-k of per-query (score, index) lists [nq, n] -> [nq, k], descending, ties -> lower index: the merge
+ * of the shards' answers (after an all-gather) and of re-scored candidate lists. */
+int esr_topk_merge(const float* scores, const int32_t* indices, int64_t nq, int n, int k,
+                   float* out_scores, int32_t* out_indices, esr_stream_t stream);
+
 /* ---- 8e: row-shard routing (owner = id mod world, local row = id div world) ---------------
  * Stable bucket of ids by owner: local_rows[k] = ids[perm[k]] / world, counts[g] = #ids owned by g
  * (int64, device).  Build-defined; the reference is single-device. */

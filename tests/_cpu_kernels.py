@@ -8,6 +8,7 @@ from oracle import glove as o_glove
 from oracle import optim as o_optim
 from oracle import shard as o_shard
 from oracle import stl_head as o_stl
+from oracle import topk as o_topk
 
 GLOVE_REFERENCE, GLOVE_DIAGONAL = 0, 1
 
@@ -106,3 +107,14 @@ def glove_fwd_bwd(emb, bias, inputs, target, mode=GLOVE_REFERENCE, want_grads=Tr
     loss, gdot, gs = o_glove.loss_and_grads(e, b, inputs.numpy(), target.numpy(), m, np.float64)
     _, rows, gb = o_glove.row_grads(e, inputs.numpy(), gdot, gs, np.float64)
     return _t(np.array([loss])), _t(rows), _t(gb)
+
+
+def retrieve_topk(queries, candidates, k, mode="exact", index_base=0, index_step=1):
+    s, i = o_topk.batched_top_k(queries.numpy(), candidates.numpy(), k)
+    return _t(s), _t(index_base + i.astype(np.int64) * index_step, torch.int32)
+
+
+def topk_merge(scores, indices, k):
+    s, i = scores.numpy(), indices.numpy().astype(np.int64)
+    order = np.lexsort((i, -s), axis=-1)[:, :k]        # score descending, then index ascending
+    return _t(np.take_along_axis(s, order, -1)), _t(np.take_along_axis(i, order, -1), torch.int32)

@@ -190,3 +190,39 @@ def test_sharded_glove_with_prefetched_plans_equals_single_device():
     for r in range(WORLD):
         full_e[r::WORLD], full_b[r::WORLD] = outs[r]["emb"], outs[r]["bias"]
     assert np.abs(full_e - emb).max() <= 1e-12 and np.abs(full_b - bias).max() <= 1e-12
+
+
+def _topk_worker(rank, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    import _cpu_kernels as K
+    from esrecsys_amd import sharded
+    rng = np.random.default_rng(21)
+    N, Dq, nq, k = 301, 16, 7, 9
+    cands = np.round(rng.standard_normal((N, Dq)) * 4) / 4         # coarse grid: exact ties across shards
+    queries = np.round(np.random.default_rng(50 + rank).standard_normal((nq, Dq)) * 4) / 4
+    local = torch.from_numpy(np.ascontiguousarray(cands[rank::WORLD]))
+    s, i = sharded.sharded_find_top_k(torch.from_numpy(queries), local, k, kernels=K)
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), s=s.numpy(), i=i.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_top_k_equals_single_device():
+    """Candidates row-sharded id mod G, every rank asks its own queries: the merged answer equals brute force
+    over the full candidate set, including the tie rule (lower GLOBAL index first) across shards."""
+    import socket
+    from oracle import topk as o_topk
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_topk_worker, args=(port, d), nprocs=WORLD, join=True)
+        outs = [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(WORLD)]
+    rng = np.random.default_rng(21)
+    cands = np.round(rng.standard_normal((301, 16)) * 4) / 4
+    for r in range(WORLD):
+        queries = np.round(np.random.default_rng(50 + r).standard_normal((7, 16)) * 4) / 4
+        es, ei = o_topk.batched_top_k(queries, cands, 9)
+        assert np.array_equal(outs[r]["i"], ei) and np.array_equal(outs[r]["s"], es)
