@@ -1,0 +1,65 @@
+// esr_probe.hip -- measurement probes (not on the hot path): what the matrix pipes of THIS box sustain, so that a
+// roofline fraction quoted against the data-sheet peak (MI355X_MICROARCH.md) can be read next to the ceiling a
+// register-only MFMA loop reaches under the clocks the part actually holds.
+#include "esr_common.h"
+
+namespace esr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// every wave: `iters` rounds of 4 independent accumulator chains, operands in registers, no memory traffic
+__global__ __launch_bounds__(256) void mfma_bf16_probe_kernel(int iters, float* __restrict__ sink) {
+  bf16x8 a, b;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    a[e] = (__bf16)(1.0f + 0.001f * (threadIdx.x & 7));
+    b[e] = (__bf16)(0.5f);
+  }
+  f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+  for (int i = 0; i < iters; ++i) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c3, 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s += c0[e] + c1[e] + c2[e] + c3[e];
+  if (s == 12345.678f) sink[0] = s;  // keeps the chains alive; never true
+}
+
+__global__ __launch_bounds__(256) void mfma_f32_probe_kernel(int iters, float* __restrict__ sink) {
+  const float a = 1.0f + 0.001f * (threadIdx.x & 7), b = 0.5f;
+  f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+  for (int i = 0; i < iters; ++i) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c3, 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s += c0[e] + c1[e] + c2[e] + c3[e];
+  if (s == 12345.678f) sink[0] = s;
+}
+
+}  // namespace esr
+
+using namespace esr;
+
+extern "C" {
+
+int esr_probe_mfma(int dtype, int workgroups, int iters, float* sink, double* flops_out, esr_stream_t stream) {
+  ESR_REQUIRE(workgroups > 0 && iters > 0 && sink && flops_out, "esr_probe_mfma: bad arguments");
+  ESR_REQUIRE(dtype == ESR_F32 || dtype == ESR_BF16, "esr_probe_mfma: dtype %d", dtype);
+  const double per_mfma = 2.0 * 32 * 32 * (dtype == ESR_BF16 ? 16 : 2);
+  *flops_out = per_mfma * 4.0 * (double)iters * 4.0 * (double)workgroups;  // 4 chains x iters x 4 waves x grid
+  if (dtype == ESR_BF16)
+    hipLaunchKernelGGL(mfma_bf16_probe_kernel, dim3(workgroups), dim3(256), 0, as_stream(stream), iters, sink);
+  else
+    hipLaunchKernelGGL(mfma_f32_probe_kernel, dim3(workgroups), dim3(256), 0, as_stream(stream), iters, sink);
+  return check_launch("esr_probe_mfma");
+}
+
+}  // extern "C"

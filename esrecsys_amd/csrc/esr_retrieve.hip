@@ -104,6 +104,13 @@ __device__ __forceinline__ void wait_vmcnt_barrier() {
 
 #define ESR_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
+#ifdef ESR_GEMM_TIMING  // debug build only (scripts/gemm_timing.py): per-workgroup phase stamps
+__device__ unsigned long long esr_gemm_dbg[8 * 1024];
+#define ESR_GT(VAR) { __builtin_amdgcn_sched_barrier(0); VAR = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define ESR_GT(VAR)
+#endif
+
 template <int P, bool DENSE>
 __global__ __launch_bounds__(kGThreads) void score_gemm_kernel(const __bf16* __restrict__ Ap, int64_t a_plane,
                                                               const __bf16* __restrict__ Bp, int64_t b_plane, int Dp,
@@ -111,9 +118,14 @@ __global__ __launch_bounds__(kGThreads) void score_gemm_kernel(const __bf16* __r
   constexpr int NS = (P == 3) ? 2 : 4;           // LDS stages
   constexpr int kStage = P * kPlaneStage;        // 73728 / 24576 B
   constexpr int IPS = 3 * P;                     // DMA instructions per wave per stage
-  __shared__ __attribute__((aligned(16))) char lds[NS * kStage];
+  __shared__ __attribute__((aligned(16))) char lds[NS * kStage + 8 * 1024];  // + one dummy DMA slot per wave
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+#ifdef ESR_GEMM_TIMING
+  unsigned long long g0 = 0, g1 = 0, g2 = 0, g3 = 0;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  ESR_GT(g0);
+#endif
 
   // XCD-aware order: workgroup b runs on XCD b % 8; each XCD walks its own contiguous range of logical tiles,
   // logical tiles are ordered in groups of kGroupM tile-rows x all tile-columns, column-major inside a group.
@@ -134,17 +146,20 @@ __global__ __launch_bounds__(kGThreads) void score_gemm_kernel(const __bf16* __r
   const int64_t a_pb = a_plane * 2, b_pb = b_plane * 2;
   const int nk = Dp / kGK;
 
-  auto issue = [&](int kt) {
-    char* st = lds + (kt % NS) * kStage;
-    const uint32_t off = lane_off + (uint32_t)kt * (kGK * 2);
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-      char* ps = st + p * kPlaneStage;
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcA0 + p * a_pb + off), (lptr_t)(ps + w * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcA1 + p * a_pb + off), (lptr_t)(ps + (w + 8) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcB + p * b_pb + off), (lptr_t)(ps + kGM * kTileRowBytes + w * 1024),
-                                       16, 0, 0);
-    }
+  // DMA piece j of a stage (j = 3 * plane + {A rows 16w.., A rows 16(w+8).., B rows 16w..}).  Pieces are issued
+  // one at a time BETWEEN MFMAs (an LDS-DMA costs the issuing wave ~60-180 cycles; a burst of all 3P right after
+  // the barrier stalled both waves of a SIMD at the same moment).  Past the last stage the piece is still issued
+  // -- into a dummy LDS slot, from a valid address -- so the loop body is branch-free and vmcnt counts uniformly.
+  char* const dummy = lds + NS * kStage + w * 1024;
+  auto issue_piece = [&](int j, int kt_target) {
+    const bool real = kt_target < nk;
+    const int ktc = real ? kt_target : nk - 1;
+    const int p = j / 3, r = j % 3;
+    const char* src = (r == 0 ? srcA0 + p * a_pb : r == 1 ? srcA1 + p * a_pb : srcB + p * b_pb) + lane_off +
+                      (uint32_t)ktc * (kGK * 2);
+    char* st = lds + (ktc % NS) * kStage + p * kPlaneStage +
+               (r == 0 ? w * 1024 : r == 1 ? (w + 8) * 1024 : kGM * kTileRowBytes + w * 1024);
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(real ? st : dummy), 16, 0, 0);
   };
 
   // ---- fragment addressing: wave (wm, wn) owns rows wm*64.. of A and wn*64.. of B, two 32-row tiles each
@@ -163,14 +178,18 @@ __global__ __launch_bounds__(kGThreads) void score_gemm_kernel(const __bf16* __r
 
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
-    if (s < nk) issue(s);
+#pragma unroll
+    for (int j = 0; j < IPS; ++j) issue_piece(j, s);
 
+  constexpr int kTerms = (P == 3) ? 6 : 1;
+  constexpr int kPieceEvery = (P == 3) ? 2 : 1;  // one DMA piece after every kPieceEvery-th MFMA of k-step 0
   for (int kt = 0; kt < nk; ++kt) {
-    // stage kt has landed once at most the younger stages' DMAs are outstanding; in the tail wait for all
-    // afterwards stage kt is visible to every wave and every wave is done with stage kt-1's buffer
-    if (kt + NS - 1 <= nk) wait_vmcnt_barrier<IPS * (NS - 2)>();
-    else wait_vmcnt_barrier<0>();
-    if (kt + NS - 1 < nk) issue(kt + NS - 1);
+    // stage kt has landed once at most the NS-2 younger stages' DMAs are outstanding; after the barrier it is
+    // visible to every wave and every wave is done with stage kt-1's buffer (refilled below with stage kt+NS-1)
+    wait_vmcnt_barrier<IPS * (NS - 2)>();
+#ifdef ESR_GEMM_TIMING
+    if (kt == 0) ESR_GT(g1);
+#endif
     const char* st = lds + (kt % NS) * kStage;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -183,22 +202,28 @@ __global__ __launch_bounds__(kGThreads) void score_gemm_kernel(const __bf16* __r
           a[p][r] = *reinterpret_cast<const bf16x8*>(st + p * kPlaneStage + fragA + r * 32 * kTileRowBytes + po);
           b[p][r] = *reinterpret_cast<const bf16x8*>(st + p * kPlaneStage + fragB + r * 32 * kTileRowBytes + po);
         }
-      // small terms first; consecutive MFMAs go to different accumulators
-#define ESR_TERM(PA, PB)                                                          \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
-      acc[i][j] = ESR_MFMA(a[PA][i], b[PB][j], acc[i][j]);
-      if (P == 3) {
-        ESR_TERM(P - 1, 0)
-        ESR_TERM(0, P - 1)
-        ESR_TERM(P == 3 ? 1 : 0, P == 3 ? 1 : 0)
-        ESR_TERM(P == 3 ? 1 : 0, 0)
-        ESR_TERM(0, P == 3 ? 1 : 0)
+      // six cross terms, small ones first; consecutive MFMAs go to different accumulators
+#pragma unroll
+      for (int term = 0; term < kTerms; ++term) {
+        const int pa = (P == 3) ? (term == 0 ? 2 : term == 2 || term == 3 ? 1 : 0) : 0;
+        const int pb = (P == 3) ? (term == 1 ? 2 : term == 2 || term == 4 ? 1 : 0) : 0;
+#pragma unroll
+        for (int ij = 0; ij < 4; ++ij) {
+          acc[ij >> 1][ij & 1] = ESR_MFMA(a[pa][ij >> 1], b[pb][ij & 1], acc[ij >> 1][ij & 1]);
+          const int nth = term * 4 + ij;  // MFMA number inside this k-step
+          if (ks == 0 && nth % kPieceEvery == kPieceEvery - 1 && nth / kPieceEvery < IPS) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue_piece(nth / kPieceEvery, kt + NS - 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
       }
-      ESR_TERM(0, 0)
-#undef ESR_TERM
     }
   }
 
+#ifdef ESR_GEMM_TIMING
+  ESR_GT(g2);
+#endif
   // ---- epilogue: acc[i][j][e] = S[m0 + wm*64 + i*32 + 8*(e/4) + 4*h + e%4][n0 + wn*64 + j*32 + l31]
   if (DENSE) {
 #pragma unroll
@@ -262,6 +287,14 @@ __global__ __launch_bounds__(kGThreads) void score_gemm_kernel(const __bf16* __r
         }
     }
   }
+#ifdef ESR_GEMM_TIMING
+  __builtin_amdgcn_s_waitcnt(0);
+  ESR_GT(g3);
+  if (t == 0 && blockIdx.x < 1024) {
+    unsigned long long* d = esr_gemm_dbg + blockIdx.x * 8;
+    d[0] = g1 - g0; d[1] = g2 - g1; d[2] = g3 - g2; d[3] = __builtin_amdgcn_s_memrealtime() - r0; d[4] = nk;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -672,6 +705,12 @@ int esr_retrieve_topk(const float* queries, const float* candidates, int64_t nq,
   }
   return check_launch("esr_retrieve_topk");
 }
+
+#ifdef ESR_GEMM_TIMING
+int esr_gemm_debug_read(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(esr_gemm_dbg), sizeof(unsigned long long) * 8 * 1024);
+}
+#endif
 
 int esr_rescore_candidates(const float* queries, const float* candidates, int64_t nq, int64_t N, int D,
                            const int32_t* indices, int kc, int32_t index_base, int32_t index_step, float* scores,

@@ -49,6 +49,12 @@ int esr_version(void);
 /* host out-params; arch_len bytes at arch receive e.g. "gfx950". */
 int esr_device_info(int* cu_count, int* wave_size, size_t* hbm_bytes, char* arch, int arch_len);
 
+/* Measurement probe (not on the hot path): `workgroups` x 4 waves each run `iters` rounds of four independent
+ * register-only MFMA chains (dtype ESR_BF16: v_mfma_f32_32x32x16_bf16, ESR_F32: v_mfma_f32_32x32x2_f32).
+ * *flops_out (host) = flops the launch executes; time it on `stream` to get the matrix ceiling this box sustains.
+ * sink: one device float (never written). */
+int esr_probe_mfma(int dtype, int workgroups, int iters, float* sink, double* flops_out, esr_stream_t stream);
+
 /* ---- G2 / S1: embedding-row gather ------------------------------------------------------
  * nn.Embed lookup == jnp.take(table, ids, axis=0): wikipedia/models.py:31-34 (and the id towers
  * that replace pinterest/models.py:64-70).  out[i, :] = table[ids[i], :], bit-exact. */
