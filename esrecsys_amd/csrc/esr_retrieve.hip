@@ -28,17 +28,19 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-constexpr int kGM = 256, kGN = 128, kGK = 32;  // tile rows (queries), tile cols (candidates), k per stage
+constexpr int kGM = 256, kGN = 128, kGK = 16;  // tile rows (queries), tile cols (candidates), k per stage
 constexpr int kGThreads = 512;
-constexpr int kTileRowBytes = kGK * 2;                      // 64 B of one plane row per stage
-constexpr int kPlaneStage = (kGM + kGN) * kTileRowBytes;    // 24576 B: A tile then B tile of one plane
+constexpr int kTileRowBytes = kGK * 2;                      // 32 B of one plane row per stage
+constexpr int kPlaneStage = (kGM + kGN) * kTileRowBytes;    // 12288 B: A tile then B tile of one plane
+constexpr int kPiecesPerPlane = kPlaneStage / 1024;         // 12 DMA instructions (32 rows x 32 B each)
 constexpr int kGroupM = 4;                                  // tile-order group height (tiles)
 constexpr int kSelThreads = 256;
 constexpr int kSelMaxK = 1024;
 constexpr int kFirstChunk = 8192;
 
 // ---------------------------------------------------------------------------------------------------
-// f32 rows -> P bf16 planes [P][rows_pad][Dp], zero padded (rows >= n_rows, cols >= D)
+// f32 rows -> P bf16 planes, zero padded (rows >= n_rows, cols >= D), K-BLOCK-MAJOR: plane[kb][row][16] with
+// kb = d / 16 -- the 32 rows x 16 k that one DMA instruction moves are 1 KiB of contiguous global memory
 // ---------------------------------------------------------------------------------------------------
 template <int P>
 __global__ __launch_bounds__(kBlock) void split_planes_kernel(const float* __restrict__ X, int64_t n_rows, int D,
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(kBlock) void split_planes_kernel(const float* __res
         p3[e] = (__bf16)(r1 - (float)b);
       }
     }
-    __bf16* dst = out + r * Dp + c;
+    __bf16* dst = out + ((int64_t)(c >> 4) * rows_pad + r) * 16 + (c & 15);
     *reinterpret_cast<bf16x4*>(dst) = p1;
     if (P == 3) {
       *reinterpret_cast<bf16x4*>(dst + plane_elems) = p2;
@@ -112,13 +114,16 @@ __device__ unsigned long long esr_gemm_dbg[8 * 1024];
 #endif
 
 template <int P, bool DENSE>
-__global__ __launch_bounds__(kGThreads) void score_gemm_kernel(const __bf16* __restrict__ Ap, int64_t a_plane,
-                                                              const __bf16* __restrict__ Bp, int64_t b_plane, int Dp,
-                                                              int tm, int tn, int M, int nvalid, GemmOut o) {
-  constexpr int NS = (P == 3) ? 2 : 4;           // LDS stages
-  constexpr int kStage = P * kPlaneStage;        // 73728 / 24576 B
-  constexpr int IPS = 3 * P;                     // DMA instructions per wave per stage
-  __shared__ __attribute__((aligned(16))) char lds[NS * kStage + 8 * 1024];  // + one dummy DMA slot per wave
+__global__ __launch_bounds__(kGThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void score_gemm_kernel(const __bf16* __restrict__ Ap, int64_t a_plane,
+                                                                 int64_t a_rows, const __bf16* __restrict__ Bp,
+                                                                 int64_t b_plane, int64_t b_rows, int Dp, int tm,
+                                                                 int tn, int M, int nvalid, GemmOut o) {
+  constexpr int NS = (P == 3) ? 2 : 4;            // LDS stages (one 16-wide k-step each)
+  constexpr int kStage = P * kPlaneStage;         // 36864 / 12288 B -> two workgroups per CU
+  constexpr int kPieces = P * kPiecesPerPlane;    // DMA instructions per stage, dealt round-robin to the 8 waves
+  constexpr int NPW = (kPieces + 7) / 8;          // 5 / 2: waves 0-3 issue NPW, waves 4-7 NPW - 1
+  static_assert(kPieces % 8 == 4, "piece dealing below assumes 8 * (NPW - 1) + 4 pieces");
+  __shared__ __attribute__((aligned(16))) char lds[NS * kStage];
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
 #ifdef ESR_GEMM_TIMING
@@ -136,37 +141,42 @@ __global__ __launch_bounds__(kGThreads) void score_gemm_kernel(const __bf16* __r
   const int gm = min(kGroupM, tm - g * kGroupM);
   const int n_t = rem / gm, m_t = g * kGroupM + (rem - n_t * gm);
   const int m0 = m_t * kGM, n0 = n_t * kGN;
-
-  // ---- DMA addressing: one wave instruction moves 16 rows x 64 B; lane -> (row = lane / 4, 16-B piece) with the
-  // piece XOR-swizzled by (row / 4) % 4 so that the MFMA fragment reads below are bank-conflict free.
-  const uint32_t lane_off = (uint32_t)(((lane >> 2) * Dp + (((lane & 3) ^ ((lane >> 4) & 3)) << 3)) * 2);
-  const char* srcA0 = reinterpret_cast<const char*>(Ap + (int64_t)(m0 + 16 * w) * Dp);
-  const char* srcA1 = reinterpret_cast<const char*>(Ap + (int64_t)(m0 + 16 * (w + 8)) * Dp);
-  const char* srcB = reinterpret_cast<const char*>(Bp + (int64_t)(n0 + 16 * w) * Dp);
-  const int64_t a_pb = a_plane * 2, b_pb = b_plane * 2;
   const int nk = Dp / kGK;
 
-  // DMA piece j of a stage (j = 3 * plane + {A rows 16w.., A rows 16(w+8).., B rows 16w..}).  Pieces are issued
-  // one at a time BETWEEN MFMAs (an LDS-DMA costs the issuing wave ~60-180 cycles; a burst of all 3P right after
-  // the barrier stalled both waves of a SIMD at the same moment).  Past the last stage the piece is still issued
-  // -- into a dummy LDS slot, from a valid address -- so the loop body is branch-free and vmcnt counts uniformly.
-  char* const dummy = lds + NS * kStage + w * 1024;
+  // ---- DMA: piece q of a stage = plane q / 12, 32-row group q % 12 of the [A tile; B tile] image.  In the
+  // k-block-major planes those 32 rows x 32 B are 1 KiB of contiguous memory.  The LDS image of a group is
+  // [half][row][16 B] (lane l of the DMA fetches row l % 32, half l / 32), so an MFMA fragment read -- lane =
+  // (half, row) -- is lane-linear: conflict-free without a swizzle.
+  const uint32_t lane_src = (uint32_t)((lane & 31) * 32 + (lane >> 5) * 16);
+  const char* pbase[NPW];
+  uint32_t pstep[NPW];
+  int pdst[NPW];
+#pragma unroll
+  for (int j = 0; j < NPW; ++j) {
+    const int q = min(w + 8 * j, kPieces - 1);
+    const int pl = q / kPiecesPerPlane, sub = q - pl * kPiecesPerPlane;
+    const bool isA = sub < kGM / 32;
+    const int64_t row0 = isA ? m0 + 32 * sub : n0 + 32 * (sub - kGM / 32);
+    pbase[j] = reinterpret_cast<const char*>((isA ? Ap + pl * a_plane : Bp + pl * b_plane) + row0 * 16);
+    pstep[j] = (uint32_t)((isA ? a_rows : b_rows) * 32);
+    pdst[j] = pl * kPlaneStage + sub * 1024;
+  }
+  const bool has_last = w < 4;  // waves 0-3 own a piece in round NPW - 1
+  // Pieces are issued one at a time BETWEEN MFMAs (an LDS-DMA costs the issuing wave ~60-180 cycles).  Past the
+  // last stage a piece is still issued (from a valid address) into the ring slot nobody reads any more, so the
+  // loop body is branch-free and vmcnt counts uniformly.
   auto issue_piece = [&](int j, int kt_target) {
-    const bool real = kt_target < nk;
-    const int ktc = real ? kt_target : nk - 1;
-    const int p = j / 3, r = j % 3;
-    const char* src = (r == 0 ? srcA0 + p * a_pb : r == 1 ? srcA1 + p * a_pb : srcB + p * b_pb) + lane_off +
-                      (uint32_t)ktc * (kGK * 2);
-    char* st = lds + (ktc % NS) * kStage + p * kPlaneStage +
-               (r == 0 ? w * 1024 : r == 1 ? (w + 8) * 1024 : kGM * kTileRowBytes + w * 1024);
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(real ? st : dummy), 16, 0, 0);
+    if (j == NPW - 1 && !has_last) return;
+    const int ktc = min(kt_target, nk - 1);
+    __builtin_amdgcn_global_load_lds((gptr_t)(pbase[j] + (uint32_t)ktc * pstep[j] + lane_src),
+                                     (lptr_t)(lds + (kt_target % NS) * kStage + pdst[j]), 16, 0, 0);
   };
 
-  // ---- fragment addressing: wave (wm, wn) owns rows wm*64.. of A and wn*64.. of B, two 32-row tiles each
+  // ---- fragment addressing: wave (wm, wn) owns rows wm*64.. of A and wn*64.. of B, two 32-row groups each
   const int wm = w >> 1, wn = w & 1;
-  const int l31 = lane & 31, h = lane >> 5, swz = (l31 >> 2) & 3;
-  const int fragA = (wm * 64 + l31) * kTileRowBytes;
-  const int fragB = kGM * kTileRowBytes + (wn * 64 + l31) * kTileRowBytes;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int fragA = wm * 64 * kTileRowBytes + lane * 16;
+  const int fragB = (kGM + wn * 64) * kTileRowBytes + lane * 16;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -179,43 +189,41 @@ __global__ __launch_bounds__(kGThreads) void score_gemm_kernel(const __bf16* __r
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
 #pragma unroll
-    for (int j = 0; j < IPS; ++j) issue_piece(j, s);
+    for (int j = 0; j < NPW; ++j) issue_piece(j, s);
 
   constexpr int kTerms = (P == 3) ? 6 : 1;
-  constexpr int kPieceEvery = (P == 3) ? 2 : 1;  // one DMA piece after every kPieceEvery-th MFMA of k-step 0
+  constexpr int kPieceEvery = (P == 3) ? 4 : 2;  // a DMA piece after MFMA 1, 5, 9, ... (P = 3) / 0, 2 (P = 1)
+  constexpr int kPieceFirst = (P == 3) ? 1 : 0;
   for (int kt = 0; kt < nk; ++kt) {
     // stage kt has landed once at most the NS-2 younger stages' DMAs are outstanding; after the barrier it is
-    // visible to every wave and every wave is done with stage kt-1's buffer (refilled below with stage kt+NS-1)
-    wait_vmcnt_barrier<IPS * (NS - 2)>();
+    // visible to every wave and every wave is done with stage kt-1's ring slot (refilled below with kt+NS-1)
+    if (has_last) wait_vmcnt_barrier<NPW * (NS - 2)>();
+    else wait_vmcnt_barrier<(NPW - 1) * (NS - 2)>();
 #ifdef ESR_GEMM_TIMING
     if (kt == 0) ESR_GT(g1);
 #endif
     const char* st = lds + (kt % NS) * kStage;
+    bf16x8 a[P][2], b[P][2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int po = ((ks * 2 + h) ^ swz) << 4;
-      bf16x8 a[P][2], b[P][2];
+    for (int p = 0; p < P; ++p)
 #pragma unroll
-      for (int p = 0; p < P; ++p)
+      for (int r = 0; r < 2; ++r) {
+        a[p][r] = *reinterpret_cast<const bf16x8*>(st + p * kPlaneStage + fragA + r * 32 * kTileRowBytes);
+        b[p][r] = *reinterpret_cast<const bf16x8*>(st + p * kPlaneStage + fragB + r * 32 * kTileRowBytes);
+      }
+    // six cross terms, small ones first; consecutive MFMAs go to different accumulators
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          a[p][r] = *reinterpret_cast<const bf16x8*>(st + p * kPlaneStage + fragA + r * 32 * kTileRowBytes + po);
-          b[p][r] = *reinterpret_cast<const bf16x8*>(st + p * kPlaneStage + fragB + r * 32 * kTileRowBytes + po);
-        }
-      // six cross terms, small ones first; consecutive MFMAs go to different accumulators
+    for (int term = 0; term < kTerms; ++term) {
+      const int pa = (P == 3) ? (term == 0 ? 2 : term == 2 || term == 3 ? 1 : 0) : 0;
+      const int pb = (P == 3) ? (term == 1 ? 2 : term == 2 || term == 4 ? 1 : 0) : 0;
 #pragma unroll
-      for (int term = 0; term < kTerms; ++term) {
-        const int pa = (P == 3) ? (term == 0 ? 2 : term == 2 || term == 3 ? 1 : 0) : 0;
-        const int pb = (P == 3) ? (term == 1 ? 2 : term == 2 || term == 4 ? 1 : 0) : 0;
-#pragma unroll
-        for (int ij = 0; ij < 4; ++ij) {
-          acc[ij >> 1][ij & 1] = ESR_MFMA(a[pa][ij >> 1], b[pb][ij & 1], acc[ij >> 1][ij & 1]);
-          const int nth = term * 4 + ij;  // MFMA number inside this k-step
-          if (ks == 0 && nth % kPieceEvery == kPieceEvery - 1 && nth / kPieceEvery < IPS) {
-            __builtin_amdgcn_sched_barrier(0);
-            issue_piece(nth / kPieceEvery, kt + NS - 1);
-            __builtin_amdgcn_sched_barrier(0);
-          }
+      for (int ij = 0; ij < 4; ++ij) {
+        acc[ij >> 1][ij & 1] = ESR_MFMA(a[pa][ij >> 1], b[pb][ij & 1], acc[ij >> 1][ij & 1]);
+        const int nth = term * 4 + ij;  // MFMA number inside this k-step
+        if (nth % kPieceEvery == kPieceFirst && nth / kPieceEvery < NPW) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue_piece(nth / kPieceEvery, kt + NS - 1);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
@@ -244,40 +252,46 @@ __global__ __launch_bounds__(kGThreads) void score_gemm_kernel(const __bf16* __r
     // survivors side by side.  An atomic per (row, ballot) with its returned value needed at once serialised
     // 64 round trips per tile (measured: +45 % on the whole kernel).
     const bool c_ok0 = n0 + wn * 64 + l31 < nvalid, c_ok1 = n0 + wn * 64 + 32 + l31 < nvalid;
-    float tau_r[2][16];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * 64 + i * 32 + 8 * (e >> 2) + 4 * h + (e & 3);
-        tau_r[i][e] = m < M ? o.tau[m] : INFINITY;
-      }
+    const int mrow = m0 + wm * 64 + 4 * h;  // + i*32 + 8*(e/4) + e%4
     int my_cnt = 0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+      float tau_r[16];  // 16 thresholds at a time: the kernel must stay within 128 VGPRs (two workgroups per CU)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const unsigned long long b0 = __ballot(c_ok0 && acc[i][0][e] >= tau_r[i][e]);
-        const unsigned long long b1 = __ballot(c_ok1 && acc[i][1][e] >= tau_r[i][e]);
+        const int m = mrow + i * 32 + 8 * (e >> 2) + (e & 3);
+        tau_r[e] = m < M ? o.tau[m] : INFINITY;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const unsigned long long b0 = __ballot(c_ok0 && acc[i][0][e] >= tau_r[e]);
+        const unsigned long long b1 = __ballot(c_ok1 && acc[i][1][e] >= tau_r[e]);
         const int c = __popc((uint32_t)(b0 >> (32 * h))) + __popc((uint32_t)(b1 >> (32 * h)));
         if (l31 == i * 16 + e) my_cnt = c;
       }
-    const int my_m = m0 + wm * 64 + (l31 >> 4) * 32 + 8 * ((l31 & 15) >> 2) + 4 * h + (l31 & 3);
+    }
+    const int my_m = mrow + (l31 >> 4) * 32 + 8 * ((l31 & 15) >> 2) + (l31 & 3);
     int my_slot = 0;
     if (my_cnt > 0) my_slot = atomicAdd(o.cnt + my_m, my_cnt);
     if (__ballot(my_cnt > 0)) {
       const uint32_t below = (1u << l31) - 1u;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i) {
+        float tau_r[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const bool p0 = c_ok0 && acc[i][0][e] >= tau_r[i][e];
-          const bool p1 = c_ok1 && acc[i][1][e] >= tau_r[i][e];
+          const int m = mrow + i * 32 + 8 * (e >> 2) + (e & 3);
+          tau_r[e] = m < M ? o.tau[m] : INFINITY;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const bool p0 = c_ok0 && acc[i][0][e] >= tau_r[e];
+          const bool p1 = c_ok1 && acc[i][1][e] >= tau_r[e];
           const unsigned long long b0 = __ballot(p0), b1 = __ballot(p1);
           if ((b0 | b1) == 0) continue;  // wave-uniform
           const uint32_t h0 = (uint32_t)(b0 >> (32 * h)), h1 = (uint32_t)(b1 >> (32 * h));
           const int slot = __shfl(my_slot, 32 * h + i * 16 + e, 64);
-          const int m = m0 + wm * 64 + i * 32 + 8 * (e >> 2) + 4 * h + (e & 3);
+          const int m = mrow + i * 32 + 8 * (e >> 2) + (e & 3);
           int2* dst = o.pairs + (int64_t)m * o.ppitch + slot;
           const int n = n0 + wn * 64 + l31;
           if (p0) dst[__popc(h0 & below)] = make_int2(__float_as_int(acc[i][0][e]), o.gbase + n * o.gstep);
@@ -285,6 +299,7 @@ __global__ __launch_bounds__(kGThreads) void score_gemm_kernel(const __bf16* __r
             dst[__popc(h0) + __popc(h1 & below)] =
                 make_int2(__float_as_int(acc[i][1][e]), o.gbase + (n + 32) * o.gstep);
         }
+      }
     }
   }
 #ifdef ESR_GEMM_TIMING
@@ -627,10 +642,11 @@ static void launch_split(const float* X, int64_t n_rows, int D, int64_t rows_pad
 template <int P, bool DENSE>
 static void launch_gemm(const __bf16* A, int64_t a_plane, const __bf16* B, int64_t b_plane, int Dp, int64_t Mp,
                         int64_t n_pad, int M, int nvalid, const GemmOut& o, hipStream_t st) {
+  // planes are k-block-major over Mp query rows / n_pad candidate rows (this chunk's padded row count)
   const int tm = (int)(Mp / kGM), tn = (int)(n_pad / kGN);
   const int per = (tm * tn + 7) / 8;
-  hipLaunchKernelGGL((score_gemm_kernel<P, DENSE>), dim3(per * 8), dim3(kGThreads), 0, st, A, a_plane, B, b_plane, Dp, tm,
-                     tn, M, nvalid, o);
+  hipLaunchKernelGGL((score_gemm_kernel<P, DENSE>), dim3(per * 8), dim3(kGThreads), 0, st, A, a_plane, Mp, B, b_plane, n_pad,
+                     Dp, tm, tn, M, nvalid, o);
 }
 
 }  // namespace esr
