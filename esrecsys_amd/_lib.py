@@ -70,6 +70,18 @@ SIGNATURES = {
     "esr_rescore_candidates": (c_int, [c_f32p, c_f32p, c_i64, c_i64, c_int, c_i32p, c_int, ctypes.c_int32,
                                        ctypes.c_int32, c_f32p, c_vp]),
     "esr_topk_merge": (c_int, [c_f32p, c_i32p, c_i64, c_int, c_int, c_f32p, c_i32p, c_vp]),
+    "esr_spotify_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int]),
+    "esr_spotify_get_embeddings": (c_int, [c_f32p, c_i64, c_f32p, c_i64, c_int, c_i32p, c_i32p, c_i64, c_f32p, c_f32p,
+                                           c_vp]),
+    "esr_spotify_forward": (c_int, [c_f32p, c_i64, c_f32p, c_i64, c_int, c_i32p, c_i32p, c_int, c_int, c_int, c_f32p,
+                                    c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_vp, c_size, c_vp]),
+    "esr_spotify_fwd_bwd": (c_int, [c_f32p, c_i64, c_f32p, c_i64, c_int, c_i32p, c_i32p, c_int, c_int, c_int, c_f32,
+                                    c_f32p, c_i32p, c_f32p, c_f32p, c_vp, c_size, c_vp]),
+    "esr_spotify_affinity_all": (c_int, [c_f32p, c_i64, c_f32p, c_i64, c_int, c_i32p, c_i32p, c_int, c_i32p, c_i32p,
+                                         c_i64, c_f32p, c_vp]),
+    "esr_dense_momentum_decay": (c_int, [c_f32p, c_f32p, c_i64, c_f32, c_f32, c_vp]),
+    "esr_sparse_momentum_scatter": (c_int, [c_f32p, c_f32p, c_i64, c_int, c_i32p, c_i32p, c_i64, c_f32p, c_f32,
+                                            c_vp]),
     "esr_bucket_workspace_bytes": (c_size, [c_i64]),
     "esr_bucket_ids_by_owner": (c_int, [c_i32p, c_i64, c_int, c_i32p, c_i32p, c_vp, c_vp, c_size, c_vp]),
 }

@@ -13,9 +13,11 @@
 // optax.adam to every element (train_cooccurence.py:99-101,171) [upstream optax 0.1.2].
 #include "esr_common.h"
 
+#include <algorithm>
+
 namespace esr {
 
-enum SegOp { kAdagrad = 0, kSgd = 1, kToDense = 2 };
+enum SegOp { kAdagrad = 0, kSgd = 1, kToDense = 2, kMomentum = 3 };
 
 template <int VEC, int NCH>
 __device__ __forceinline__ void param_load(RowRegs<VEC, NCH>& r, const void* table, int dtype, int64_t row, int D,
@@ -96,6 +98,20 @@ __global__ __launch_bounds__(kBlock) void segment_update_kernel(void* __restrict
     }
     if (OP == kToDense) {
       row_store(g, (float*)table + (int64_t)id * D, lig, G, nvec);
+    } else if (OP == kMomentum) {
+      // the gradient half of optax.sgd(lr, momentum): trace += g ; p -= lr * g  (the decay half is dense)
+      RowRegs<VEC, NCH> w, a;
+      param_load(w, table, dtype, id, D, lig, G, nvec);
+      row_load(a, accum + (int64_t)id * D, lig, G, nvec);
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          a.v[k][e] += g.v[k][e];
+          w.v[k][e] -= lr * g.v[k][e];
+        }
+      row_store(a, accum + (int64_t)id * D, lig, G, nvec);
+      param_store(w, table, dtype, id, D, lig, G, nvec);
     } else if (OP == kSgd) {
       RowRegs<VEC, NCH> w;
       param_load(w, table, dtype, id, D, lig, G, nvec);
@@ -286,11 +302,54 @@ __global__ __launch_bounds__(kBlock) void dense_adam_kernel(float* __restrict__ 
   }
 }
 
+// the decay half of optax.sgd(lr, momentum) over a whole table: trace *= momentum ; p -= lr * trace
+__global__ __launch_bounds__(kBlock) void momentum_decay_kernel(float* __restrict__ p, float* __restrict__ tr,
+                                                               int64_t n4, int64_t numel, float lr, float momentum) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
+    float4 pv = reinterpret_cast<float4*>(p)[i];
+    float4 t = reinterpret_cast<float4*>(tr)[i];
+    t.x *= momentum; t.y *= momentum; t.z *= momentum; t.w *= momentum;
+    pv.x -= lr * t.x; pv.y -= lr * t.y; pv.z -= lr * t.z; pv.w -= lr * t.w;
+    reinterpret_cast<float4*>(p)[i] = pv;
+    reinterpret_cast<float4*>(tr)[i] = t;
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < numel; i += stride) {
+    const float t = tr[i] * momentum;
+    tr[i] = t;
+    p[i] -= lr * t;
+  }
+}
+
 }  // namespace esr
 
 using namespace esr;
 
 extern "C" {
+
+int esr_dense_momentum_decay(float* param, float* trace, int64_t count, float lr, float momentum,
+                             esr_stream_t stream) {
+  ESR_REQUIRE(count >= 0, "esr_dense_momentum_decay: bad count %lld", (long long)count);
+  if (count == 0) return ESR_OK;
+  ESR_REQUIRE(param && trace, "esr_dense_momentum_decay: null pointer");
+  ESR_REQUIRE((((uintptr_t)param | (uintptr_t)trace) & 15) == 0, "esr_dense_momentum_decay: pointers must be 16-byte aligned");
+  const int64_t n4 = count / 4;
+  const int grid = (int)std::min<int64_t>(std::max<int64_t>(cdiv(n4, kBlock), 1), 8192);
+  hipLaunchKernelGGL(momentum_decay_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), param, trace, n4, count, lr,
+                     momentum);
+  return check_launch("esr_dense_momentum_decay");
+}
+
+int esr_sparse_momentum_scatter(float* table, float* trace, int64_t V, int D, const int32_t* sorted_ids,
+                                const int32_t* perm, int64_t n, const float* grad_rows, float lr,
+                                esr_stream_t stream) {
+  ESR_REQUIRE(V > 0 && D > 0 && n >= 0, "esr_sparse_momentum_scatter: bad sizes V=%lld D=%d n=%lld", (long long)V, D,
+              (long long)n);
+  if (n == 0) return ESR_OK;
+  ESR_REQUIRE(table && trace && sorted_ids && perm && grad_rows, "esr_sparse_momentum_scatter: null pointer");
+  return launch_segment_update<kMomentum>("esr_sparse_momentum_scatter", table, ESR_F32, trace, D, sorted_ids, perm, n,
+                                          grad_rows, lr, 0.f, as_stream(stream));
+}
 
 int esr_sparse_adagrad_scatter(void* table, int dtype, float* accum, int64_t V, int D, const int32_t* sorted_ids,
                                const int32_t* perm, int64_t n, const float* grad_rows, float lr, float eps,

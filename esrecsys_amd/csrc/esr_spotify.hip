@@ -1,0 +1,414 @@
+// esr_spotify.hip -- the Spotify id-embedding two-tower: spotify/models.py:27-90 and the
+// loss of spotify/train_spotify.py:77-107, forward + backward, plus the score-every-track eval of :113-119.
+//
+// One step is ONE playlist: n context tracks (5), m next tracks (a few to ~250), o sampled negatives (64); a
+// track's embedding is concat(album_embed[album mod A], artist_embed[artist]) (2F = 64 floats).  The work is a
+// few hundred rows, so the step is latency-bound: four small launches, no atomics, fixed summation orders.
+//   gather     one wave per row: E[r] = concat(...), l2[r], hashed album row
+//   affinity   one workgroup: raw = [next; neg] . ctx^T, row max (+0.1 isin boosts), the mean / extremal triplet
+//              terms and d loss / d raw (the VJP of max and min splits evenly over ties -- two context tracks of one
+//              album + artist have identical embeddings, so ties are real)
+//   rowgrad    one wave per row b: the three self-affinity losses reduce to  mean_{a,b} f(E_a . E_b)  over a
+//              group (the flip only permutes the matrix), so  d/dE_b = (2 / R^2) sum_a f'(E_a . E_b) E_a ; plus the
+//              affinity terms through d raw and the norm term; writes the per-occurrence gradient rows
+//   finalize   fixed-order fp64 sum of the loss partials
+#include "esr_common.h"
+
+#include <algorithm>
+
+namespace esr {
+
+constexpr int kSpMaxCtx = 32;     // context rows (reference: 5)
+constexpr int kSpMaxDim = 256;    // 2F
+constexpr float kSpBoost = 0.1f;  // spotify/models.py:76-81
+
+struct SpShape {
+  int n, m, o, F;  // R = n + m + o rows, D2 = 2F
+};
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// E[r][0:F] = album_table[album[r] mod A], E[r][F:2F] = artist_table[artist[r]]; l2[r]; hashed[r]
+__global__ __launch_bounds__(kBlock) void spotify_gather_kernel(const float* __restrict__ album_table, int64_t A,
+                                                               const float* __restrict__ artist_table, int F,
+                                                               const int32_t* __restrict__ album,
+                                                               const int32_t* __restrict__ artist, int R,
+                                                               float* __restrict__ E, float* __restrict__ l2,
+                                                               int32_t* __restrict__ hashed) {
+  const int lane = threadIdx.x & 63;
+  const int r = (int)((blockIdx.x * (int64_t)kBlock + threadIdx.x) >> 6);
+  if (r >= R) return;
+  const int64_t ha = (int64_t)album[r] % A, ar = artist[r];
+  const int D2 = 2 * F;
+  float ss = 0.f;
+  for (int d = lane; d < D2; d += 64) {
+    const float v = d < F ? album_table[ha * F + d] : artist_table[ar * F + (d - F)];
+    E[(int64_t)r * D2 + d] = v;
+    ss = fmaf(v, v, ss);
+  }
+  ss = wave_sum_f(ss);
+  if (lane == 0) {
+    l2[r] = sqrtf(ss);
+    if (hashed) hashed[r] = (int32_t)ha;
+  }
+}
+
+// raw[i][c] = E[n + i] . E[c] for the m + o scored rows; aff = rowmax + boosts; W[i][c] = d loss / d raw[i][c]
+// (only when W != null); head[0] = relu(mean triplet) + relu(extremal triplet).
+__global__ __launch_bounds__(kBlock) void spotify_affinity_kernel(const float* __restrict__ E, SpShape sh,
+                                                                 const int32_t* __restrict__ album,
+                                                                 const int32_t* __restrict__ artist,
+                                                                 float* __restrict__ raw, float* __restrict__ aff,
+                                                                 float* __restrict__ W, double* __restrict__ head) {
+  __shared__ double sm[kBlock / 64 + 1];
+  __shared__ double s_sum_pos, s_sum_neg;
+  __shared__ float s_min_pos, s_max_neg;
+  __shared__ int s_cnt_min, s_cnt_max;
+  const int n = sh.n, m = sh.m, o = sh.o, D2 = 2 * sh.F, S = m + o, t = threadIdx.x;
+  double sum_pos = 0.0, sum_neg = 0.0;
+  for (int i = t; i < S; i += kBlock) {
+    const float* z = E + (int64_t)(n + i) * D2;
+    float best = -INFINITY;
+    for (int c = 0; c < n; ++c) {
+      const float* x = E + (int64_t)c * D2;
+      float s = 0.f;
+      for (int d = 0; d < D2; ++d) s = fmaf(z[d], x[d], s);
+      raw[i * n + c] = s;
+      best = fmaxf(best, s);
+    }
+    bool in_album = false, in_artist = false;
+    for (int c = 0; c < n; ++c) {
+      in_album |= album[n + i] == album[c];
+      in_artist |= artist[n + i] == artist[c];
+    }
+    const float a = best + (in_album ? kSpBoost : 0.f) + (in_artist ? kSpBoost : 0.f);
+    aff[i] = a;
+    if (i < m) sum_pos += a; else sum_neg += a;
+  }
+  sum_pos = block_sum_d(sum_pos, sm);  // valid in thread 0
+  sum_neg = block_sum_d(sum_neg, sm);
+  __syncthreads();  // aff[] visible
+  if (t == 0) {
+    s_sum_pos = sum_pos;
+    s_sum_neg = sum_neg;
+    float mn = INFINITY, mx = -INFINITY;
+    int cmn = 0, cmx = 0;
+    for (int i = 0; i < m; ++i) {
+      const float a = aff[i];
+      if (a < mn) { mn = a; cmn = 1; } else if (a == mn) ++cmn;
+    }
+    for (int i = m; i < S; ++i) {
+      const float a = aff[i];
+      if (a > mx) { mx = a; cmx = 1; } else if (a == mx) ++cmx;
+    }
+    s_min_pos = mn; s_max_neg = mx; s_cnt_min = cmn; s_cnt_max = cmx;
+  }
+  __syncthreads();
+  const float mt_arg = 1.0f + (float)(s_sum_neg / o) - (float)(s_sum_pos / m);
+  const float et_arg = 1.0f + s_max_neg - s_min_pos;
+  if (t == 0) head[0] = (double)fmaxf(mt_arg, 0.f) + (double)fmaxf(et_arg, 0.f);
+  if (!W) return;
+  for (int i = t; i < S; i += kBlock) {
+    const float a = aff[i];
+    float d = 0.f;
+    if (i < m) {
+      if (mt_arg > 0.f) d -= 1.0f / m;
+      if (et_arg > 0.f && a == s_min_pos) d -= 1.0f / s_cnt_min;
+    } else {
+      if (mt_arg > 0.f) d += 1.0f / o;
+      if (et_arg > 0.f && a == s_max_neg) d += 1.0f / s_cnt_max;
+    }
+    float best = -INFINITY;
+    for (int c = 0; c < n; ++c) best = fmaxf(best, raw[i * n + c]);
+    int ties = 0;
+    for (int c = 0; c < n; ++c) ties += raw[i * n + c] == best;
+    for (int c = 0; c < n; ++c) W[i * n + c] = raw[i * n + c] == best ? d / ties : 0.f;
+  }
+}
+
+// one wave per row b; lane holds dims lane, lane + 64, ... (NCH = ceil(2F / 64) of them)
+template <int NCH>
+__global__ __launch_bounds__(kBlock) void spotify_rowgrad_kernel(const float* __restrict__ E, SpShape sh,
+                                                                const float* __restrict__ l2,
+                                                                const float* __restrict__ W, float regularization,
+                                                                float* __restrict__ g_album,
+                                                                float* __restrict__ g_artist,
+                                                                double* __restrict__ partial) {
+  const int n = sh.n, m = sh.m, o = sh.o, F = sh.F, D2 = 2 * F, R = n + m + o;
+  const int lane = threadIdx.x & 63;
+  const int b = (int)((blockIdx.x * (int64_t)kBlock + threadIdx.x) >> 6);
+  if (b >= R) return;
+  auto load = [&](int r, float (&v)[NCH]) {
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int d = lane + 64 * k;
+      v[k] = d < D2 ? E[(int64_t)r * D2 + d] : 0.f;
+    }
+  };
+  auto dot = [&](const float (&x)[NCH], const float (&y)[NCH]) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) s = fmaf(x[k], y[k], s);
+    return wave_sum_f(s);
+  };
+  float z[NCH], acc[NCH];
+  load(b, z);
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) acc[k] = 0.f;
+  // ---- self-affinity of b's group: pull (context, next): f = relu(0.5 - s); push (neg): f = relu(s)
+  const int g0 = b < n ? 0 : b < n + m ? n : n + m;
+  const int Rg = b < n ? n : b < n + m ? m : o;
+  const bool push = b >= n + m;
+  double lsum = 0.0;
+  for (int a0 = 0; a0 < Rg; a0 += 4) {  // four rows per round: their wave reductions overlap
+    float za[4][NCH], s[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load(g0 + min(a0 + u, Rg - 1), za[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] = dot(za[u], z);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (a0 + u >= Rg) continue;
+      const float f = push ? fmaxf(s[u], 0.f) : fmaxf(0.5f - s[u], 0.f);
+      const float fp = push ? (s[u] > 0.f ? 1.f : 0.f) : (s[u] < 0.5f ? -1.f : 0.f);
+      lsum += (double)f;
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) acc[k] = fmaf(fp, za[u][k], acc[k]);
+    }
+  }
+  const float inv = 1.0f / ((float)Rg * (float)Rg);
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) acc[k] *= 2.0f * inv;
+  double part = lsum / ((double)Rg * (double)Rg);
+  // ---- affinity terms through W = d loss / d raw
+  if (b < n) {
+    for (int i = 0; i < m + o; ++i) {
+      const float w = W[i * n + b];
+      if (w == 0.f) continue;  // wave-uniform
+      float x[NCH];
+      load(n + i, x);
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) acc[k] = fmaf(w, x[k], acc[k]);
+    }
+  } else {
+    for (int c = 0; c < n; ++c) {
+      const float w = W[(b - n) * n + c];
+      if (w == 0.f) continue;
+      float x[NCH];
+      load(c, x);
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) acc[k] = fmaf(w, x[k], acc[k]);
+    }
+  }
+  // ---- norm term: relu(|E_b| - regularization)
+  const float nb = l2[b];
+  if (nb > regularization) {
+    part += (double)(nb - regularization);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) acc[k] += z[k] / nb;
+  }
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int d = lane + 64 * k;
+    if (d < F) g_album[(int64_t)b * F + d] = acc[k];
+    else if (d < D2) g_artist[(int64_t)b * F + (d - F)] = acc[k];
+  }
+  if (lane == 0) partial[b] = part;
+}
+
+// out[a][b] = E[g0 + Rg - 1 - a] . E[g0 + b]   (jnp.dot(jnp.flip(x, -2), x.T))
+__global__ __launch_bounds__(kBlock) void spotify_self_affinity_kernel(const float* __restrict__ E, int D2, int g0,
+                                                                      int Rg, float* __restrict__ out) {
+  const int64_t total = (int64_t)Rg * Rg;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    const int a = (int)(i / Rg), b = (int)(i - (int64_t)a * Rg);
+    const float* x = E + (int64_t)(g0 + Rg - 1 - a) * D2;
+    const float* y = E + (int64_t)(g0 + b) * D2;
+    float s = 0.f;
+    for (int d = 0; d < D2; ++d) s = fmaf(x[d], y[d], s);
+    out[i] = s;
+  }
+}
+
+// eval: aff[t] = max_c concat(album_table[album[t] mod A], artist_table[artist[t]]) . ctx[c] + boosts, every track
+// 16 lanes per track (float4 chunks); the n context rows are staged in LDS
+__global__ __launch_bounds__(kBlock) void spotify_affinity_all_kernel(const float* __restrict__ album_table, int64_t A,
+                                                                     const float* __restrict__ artist_table, int F,
+                                                                     const int32_t* __restrict__ ctx_album,
+                                                                     const int32_t* __restrict__ ctx_artist, int n,
+                                                                     const int32_t* __restrict__ all_albums,
+                                                                     const int32_t* __restrict__ all_artists,
+                                                                     int64_t T, float* __restrict__ aff) {
+  __shared__ float ctx[kSpMaxCtx * kSpMaxDim];
+  __shared__ int32_t c_album[kSpMaxCtx], c_artist[kSpMaxCtx];
+  const int D2 = 2 * F;
+  for (int i = threadIdx.x; i < n * D2; i += kBlock) {
+    const int c = i / D2, d = i - c * D2;
+    ctx[i] = d < F ? album_table[((int64_t)ctx_album[c] % A) * F + d] : artist_table[(int64_t)ctx_artist[c] * F + d - F];
+  }
+  if (threadIdx.x < n) {
+    c_album[threadIdx.x] = ctx_album[threadIdx.x];
+    c_artist[threadIdx.x] = ctx_artist[threadIdx.x];
+  }
+  __syncthreads();
+  const int lig = threadIdx.x & 15;
+  const int64_t group = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 4;
+  const int64_t ngroups = ((int64_t)gridDim.x * kBlock) >> 4;
+  for (int64_t t = group; t < T; t += ngroups) {
+    const int32_t al = all_albums[t], ar = all_artists[t];
+    const float* pa = album_table + ((int64_t)al % A) * F;
+    const float* pr = artist_table + (int64_t)ar * F;
+    float best = -INFINITY;
+    for (int c = 0; c < n; ++c) {
+      float s = 0.f;
+      for (int d = lig; d < D2; d += 16) s = fmaf(d < F ? pa[d] : pr[d - F], ctx[c * D2 + d], s);
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
+      best = fmaxf(best, s);
+    }
+    if (lig == 0) {
+      bool in_album = false, in_artist = false;
+      for (int c = 0; c < n; ++c) {
+        in_album |= al == c_album[c];
+        in_artist |= ar == c_artist[c];
+      }
+      aff[t] = best + (in_album ? kSpBoost : 0.f) + (in_artist ? kSpBoost : 0.f);
+    }
+  }
+}
+
+struct SpWs {
+  float *E, *l2, *raw, *aff, *W;
+  double* partial;  // [R] row partials then [1] head
+  size_t total;
+};
+static SpWs sp_layout(char* base, int n, int m, int o, int F) {
+  const size_t R = (size_t)n + m + o, S = (size_t)m + o;
+  SpWs w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };
+  w.E = (float*)take(R * 2 * F * 4);
+  w.l2 = (float*)take(R * 4);
+  w.raw = (float*)take(S * n * 4);
+  w.aff = (float*)take(S * 4);
+  w.W = (float*)take(S * n * 4);
+  w.partial = (double*)take((R + 1) * 8);
+  w.total = off;
+  return w;
+}
+
+static int sp_check(const char* who, int n, int m, int o, int F, int64_t A, int64_t n_artists) {
+  if (!(n > 0 && m > 0 && o > 0 && F > 0 && A > 0 && n_artists > 0 && n <= kSpMaxCtx && 2 * F <= kSpMaxDim)) {
+    set_error("%s: bad sizes n=%d m=%d o=%d F=%d (n <= %d, 2F <= %d)", who, n, m, o, F, kSpMaxCtx, kSpMaxDim);
+    return ESR_EINVAL;
+  }
+  return ESR_OK;
+}
+
+}  // namespace esr
+
+using namespace esr;
+
+extern "C" {
+
+size_t esr_spotify_workspace_bytes(int n, int m, int o, int F) {
+  if (n <= 0 || m <= 0 || o <= 0 || F <= 0) return 256;
+  return sp_layout(nullptr, n, m, o, F).total;
+}
+
+int esr_spotify_get_embeddings(const float* album_table, int64_t n_album_rows, const float* artist_table,
+                               int64_t n_artists, int F, const int32_t* album_ids, const int32_t* artist_ids,
+                               int64_t count, float* out, float* l2, esr_stream_t stream) {
+  ESR_REQUIRE(n_album_rows > 0 && n_artists > 0 && F > 0 && count >= 0 && count < ((int64_t)1 << 24),
+              "esr_spotify_get_embeddings: bad sizes");
+  if (count == 0) return ESR_OK;
+  ESR_REQUIRE(album_table && artist_table && album_ids && artist_ids && out && l2,
+              "esr_spotify_get_embeddings: null pointer");
+  hipLaunchKernelGGL(spotify_gather_kernel, dim3((int)cdiv(count, kBlock / 64)), dim3(kBlock), 0, as_stream(stream),
+                     album_table, n_album_rows, artist_table, F, album_ids, artist_ids, (int)count, out, l2,
+                     (int32_t*)nullptr);
+  return check_launch("esr_spotify_get_embeddings");
+}
+
+int esr_spotify_forward(const float* album_table, int64_t n_album_rows, const float* artist_table, int64_t n_artists,
+                        int F, const int32_t* album_ids, const int32_t* artist_ids, int n, int m, int o, float* pos,
+                        float* neg, float* ctx_self, float* next_self, float* neg_self, float* l2, void* workspace,
+                        size_t workspace_bytes, esr_stream_t stream) {
+  if (int rc = sp_check("esr_spotify_forward", n, m, o, F, n_album_rows, n_artists)) return rc;
+  ESR_REQUIRE(album_table && artist_table && album_ids && artist_ids && pos && neg && ctx_self && next_self &&
+                  neg_self && l2 && workspace, "esr_spotify_forward: null pointer");
+  const SpWs w = sp_layout((char*)workspace, n, m, o, F);
+  if (workspace_bytes < w.total || ((uintptr_t)workspace & 15)) {
+    set_error("esr_spotify_forward: workspace %zu bytes < %zu required (or misaligned)", workspace_bytes, w.total);
+    return ESR_EWORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  const int R = n + m + o, D2 = 2 * F;
+  const SpShape sh{n, m, o, F};
+  hipLaunchKernelGGL(spotify_gather_kernel, dim3((int)cdiv(R, kBlock / 64)), dim3(kBlock), 0, st, album_table,
+                     n_album_rows, artist_table, F, album_ids, artist_ids, R, w.E, l2, (int32_t*)nullptr);
+  hipLaunchKernelGGL(spotify_affinity_kernel, dim3(1), dim3(kBlock), 0, st, (const float*)w.E, sh, album_ids, artist_ids,
+                     w.raw, w.aff, (float*)nullptr, w.partial + R);
+  (void)hipMemcpyAsync(pos, w.aff, sizeof(float) * m, hipMemcpyDeviceToDevice, st);
+  (void)hipMemcpyAsync(neg, w.aff + m, sizeof(float) * o, hipMemcpyDeviceToDevice, st);
+  const int g0s[3] = {0, n, n + m}, rgs[3] = {n, m, o};
+  float* outs[3] = {ctx_self, next_self, neg_self};
+  for (int g = 0; g < 3; ++g) {
+    const int grid = (int)std::min<int64_t>(cdiv((int64_t)rgs[g] * rgs[g], kBlock), 4096);
+    hipLaunchKernelGGL(spotify_self_affinity_kernel, dim3(grid), dim3(kBlock), 0, st, (const float*)w.E, D2, g0s[g],
+                       rgs[g], outs[g]);
+  }
+  return check_launch("esr_spotify_forward");
+}
+
+int esr_spotify_fwd_bwd(const float* album_table, int64_t n_album_rows, const float* artist_table, int64_t n_artists,
+                        int F, const int32_t* album_ids, const int32_t* artist_ids, int n, int m, int o,
+                        float regularization, float* loss, int32_t* album_rows, float* g_album_rows,
+                        float* g_artist_rows, void* workspace, size_t workspace_bytes, esr_stream_t stream) {
+  if (int rc = sp_check("esr_spotify_fwd_bwd", n, m, o, F, n_album_rows, n_artists)) return rc;
+  ESR_REQUIRE(album_table && artist_table && album_ids && artist_ids && loss && album_rows && g_album_rows &&
+                  g_artist_rows && workspace, "esr_spotify_fwd_bwd: null pointer");
+  const SpWs w = sp_layout((char*)workspace, n, m, o, F);
+  if (workspace_bytes < w.total || ((uintptr_t)workspace & 15)) {
+    set_error("esr_spotify_fwd_bwd: workspace %zu bytes < %zu required (or misaligned)", workspace_bytes, w.total);
+    return ESR_EWORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  const int R = n + m + o, D2 = 2 * F;
+  const SpShape sh{n, m, o, F};
+  const int wgrid = (int)cdiv(R, kBlock / 64);
+  hipLaunchKernelGGL(spotify_gather_kernel, dim3(wgrid), dim3(kBlock), 0, st, album_table, n_album_rows, artist_table, F,
+                     album_ids, artist_ids, R, w.E, w.l2, album_rows);
+  hipLaunchKernelGGL(spotify_affinity_kernel, dim3(1), dim3(kBlock), 0, st, (const float*)w.E, sh, album_ids, artist_ids,
+                     w.raw, w.aff, w.W, w.partial + R);
+  const int nch = (int)cdiv(D2, 64);
+#define ESR_SP_ROWGRAD(NCH)                                                                                         \
+  hipLaunchKernelGGL((spotify_rowgrad_kernel<NCH>), dim3(wgrid), dim3(kBlock), 0, st, (const float*)w.E, sh,         \
+                     (const float*)w.l2, (const float*)w.W, regularization, g_album_rows, g_artist_rows, w.partial)
+  if (nch == 1) ESR_SP_ROWGRAD(1);
+  else if (nch == 2) ESR_SP_ROWGRAD(2);
+  else ESR_SP_ROWGRAD(4);
+#undef ESR_SP_ROWGRAD
+  finalize_scalar(w.partial, R + 1, 1.0, loss, st);
+  return check_launch("esr_spotify_fwd_bwd");
+}
+
+int esr_spotify_affinity_all(const float* album_table, int64_t n_album_rows, const float* artist_table,
+                             int64_t n_artists, int F, const int32_t* ctx_album, const int32_t* ctx_artist, int n,
+                             const int32_t* all_albums, const int32_t* all_artists, int64_t T, float* affinity,
+                             esr_stream_t stream) {
+  if (int rc = sp_check("esr_spotify_affinity_all", n, 1, 1, F, n_album_rows, n_artists)) return rc;
+  ESR_REQUIRE(T > 0, "esr_spotify_affinity_all: T=%lld", (long long)T);
+  ESR_REQUIRE(album_table && artist_table && ctx_album && ctx_artist && all_albums && all_artists && affinity,
+              "esr_spotify_affinity_all: null pointer");
+  const int grid = (int)std::min<int64_t>(cdiv(T, kBlock / 16), 4096);
+  hipLaunchKernelGGL(spotify_affinity_all_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), album_table,
+                     n_album_rows, artist_table, F, ctx_album, ctx_artist, n, all_albums, all_artists, T, affinity);
+  return check_launch("esr_spotify_affinity_all");
+}
+
+}  // extern "C"

@@ -318,6 +318,87 @@ def sparse_sgd(table, sorted_ids, perm, grad_rows, lr):
                                      _stream()), "esr_sparse_sgd_scatter")
 
 
+def dense_momentum_decay(param, trace, lr, momentum):
+    """In place over the whole table: trace *= momentum ; param -= lr * trace (the decay half of optax.sgd)."""
+    lib = _lib.load()
+    _req(param, torch.float32, "param"), _req(trace, torch.float32, "trace")
+    check(lib.esr_dense_momentum_decay(_p(param), _p(trace), param.numel(), float(lr), float(momentum), _stream()),
+          "esr_dense_momentum_decay")
+
+
+def sparse_momentum(table, trace, sorted_ids, perm, grad_rows, lr):
+    """In place on the touched rows: trace[row] += g ; table[row] -= lr * g (duplicates summed first)."""
+    lib = _lib.load()
+    _req(table, torch.float32, "table"), _req(trace, torch.float32, "trace"), _req(grad_rows, torch.float32, "grad_rows")
+    V = table.shape[0]
+    D = table.shape[1] if table.dim() > 1 else 1
+    check(lib.esr_sparse_momentum_scatter(_p(table), _p(trace), V, D, _p(sorted_ids), _p(perm), sorted_ids.numel(),
+                                          _p(grad_rows), float(lr), _stream()), "esr_sparse_momentum_scatter")
+
+
+def spotify_get_embeddings(album_table, artist_table, album_ids, artist_ids):
+    """[count, 2F] = concat(album_table[album mod rows], artist_table[artist]) (spotify/models.py:37-51)."""
+    lib = _lib.load()
+    _req(album_table, torch.float32, "album_table"), _req(artist_table, torch.float32, "artist_table")
+    album_ids, artist_ids = _req(album_ids, torch.int32, "album_ids"), _req(artist_ids, torch.int32, "artist_ids")
+    count, F = album_ids.numel(), album_table.shape[1]
+    out = torch.empty((count, 2 * F), dtype=torch.float32, device=album_table.device)
+    l2 = torch.empty(count, dtype=torch.float32, device=album_table.device)
+    check(lib.esr_spotify_get_embeddings(_p(album_table), album_table.shape[0], _p(artist_table),
+                                         artist_table.shape[0], F, _p(album_ids), _p(artist_ids), count, _p(out),
+                                         _p(l2), _stream()), "esr_spotify_get_embeddings")
+    return out
+
+
+def spotify_forward(album_table, artist_table, album_ids, artist_ids, n, m, o):
+    """SpotifyModel.__call__ (spotify/models.py:53-90) on occurrence ids ordered context, next, neg."""
+    lib = _lib.load()
+    _req(album_table, torch.float32, "album_table"), _req(artist_table, torch.float32, "artist_table")
+    album_ids, artist_ids = _req(album_ids, torch.int32, "album_ids"), _req(artist_ids, torch.int32, "artist_ids")
+    F, dev = album_table.shape[1], album_table.device
+    f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
+    pos, neg, cs, ns, gs, l2 = f(m), f(o), f(n, n), f(m, m), f(o, o), f(n + m + o)
+    ws = _ws(_ws_bytes("esr_spotify_workspace_bytes", n, m, o, F), dev)
+    check(lib.esr_spotify_forward(_p(album_table), album_table.shape[0], _p(artist_table), artist_table.shape[0], F,
+                                  _p(album_ids), _p(artist_ids), n, m, o, _p(pos), _p(neg), _p(cs), _p(ns), _p(gs),
+                                  _p(l2), _p(ws), ws.numel(), _stream()), "esr_spotify_forward")
+    return pos, neg, cs, ns, gs, l2
+
+
+def spotify_fwd_bwd(album_table, artist_table, album_ids, artist_ids, n, m, o, regularization):
+    """loss and per-occurrence gradient rows of train_spotify.py:78-109.
+    Returns (loss[1], album_rows[R] (hashed ids), g_album_rows[R, F], g_artist_rows[R, F])."""
+    lib = _lib.load()
+    _req(album_table, torch.float32, "album_table"), _req(artist_table, torch.float32, "artist_table")
+    album_ids, artist_ids = _req(album_ids, torch.int32, "album_ids"), _req(artist_ids, torch.int32, "artist_ids")
+    F, dev, R = album_table.shape[1], album_table.device, n + m + o
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    rows = torch.empty(R, dtype=torch.int32, device=dev)
+    ga = torch.empty((R, F), dtype=torch.float32, device=dev)
+    gr = torch.empty((R, F), dtype=torch.float32, device=dev)
+    ws = _ws(_ws_bytes("esr_spotify_workspace_bytes", n, m, o, F), dev)
+    check(lib.esr_spotify_fwd_bwd(_p(album_table), album_table.shape[0], _p(artist_table), artist_table.shape[0], F,
+                                  _p(album_ids), _p(artist_ids), n, m, o, float(regularization), _p(loss), _p(rows),
+                                  _p(ga), _p(gr), _p(ws), ws.numel(), _stream()), "esr_spotify_fwd_bwd")
+    return loss, rows, ga, gr
+
+
+def spotify_affinity_all(album_table, artist_table, ctx_album, ctx_artist, all_albums, all_artists):
+    """Affinity [T] of every track to the context (train_spotify.py:113-119, result[1])."""
+    lib = _lib.load()
+    _req(album_table, torch.float32, "album_table"), _req(artist_table, torch.float32, "artist_table")
+    for t, name in ((ctx_album, "ctx_album"), (ctx_artist, "ctx_artist"), (all_albums, "all_albums"),
+                    (all_artists, "all_artists")):
+        _req(t, torch.int32, name)
+    T = all_albums.numel()
+    out = torch.empty(T, dtype=torch.float32, device=album_table.device)
+    check(lib.esr_spotify_affinity_all(_p(album_table), album_table.shape[0], _p(artist_table), artist_table.shape[0],
+                                       album_table.shape[1], _p(ctx_album), _p(ctx_artist), ctx_album.numel(),
+                                       _p(all_albums), _p(all_artists), T, _p(out), _stream()),
+          "esr_spotify_affinity_all")
+    return out
+
+
 def rows_to_dense(V, D, sorted_ids, perm, grad_rows, out=None):
     """The dense [V, D] gradient (zero-filled, segment sums scattered) the reference's autodiff yields."""
     lib = _lib.load()

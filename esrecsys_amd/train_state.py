@@ -234,6 +234,38 @@ class _SparseSgd(GradientTransformation):
         return opt_state
 
 
+class _SgdMomentum(GradientTransformation):
+    """optax.sgd(learning_rate, momentum) [upstream] (spotify/train_spotify.py:238-241): trace = g + momentum * trace,
+    p -= lr * trace on EVERY element -- rows without a gradient keep coasting on their trace, so the decay half is
+    a dense pass; the gradient half touches only the rows of the RowGrads (no dense gradient is materialised)."""
+
+    def __init__(self, learning_rate, momentum):
+        self.lr, self.momentum = learning_rate, momentum
+
+    def init(self, params):
+        return {"trace": tree_map(torch.zeros_like, params)}
+
+    # optax.sgd's state is (TraceState(trace), EmptyState())
+    def to_optax_state(self, opt_state):
+        return {"0": {"trace": opt_state["trace"]}, "1": {}}
+
+    def from_optax_state(self, tree):
+        return {"trace": tree["0"]["trace"]}
+
+    def apply(self, params, grads, opt_state, step):
+        for path, p in tree_leaves_with_path(params):
+            tr = tree_get(opt_state["trace"], path)
+            ops.dense_momentum_decay(p, tr, self.lr, self.momentum)
+            g = tree_get(grads, path)
+            if g is None:
+                continue
+            if not isinstance(g, RowGrads):
+                raise TypeError("sgd(momentum) needs RowGrads leaves (got %s at %s)" % (type(g).__name__, path))
+            sorted_ids, perm = g.index.sorted()
+            ops.sparse_momentum(p, tr, sorted_ids, perm, g.rows, self.lr)
+        return opt_state
+
+
 def adam(learning_rate, b1=0.9, b2=0.999, eps=1e-8):
     return _Adam(learning_rate, b1, b2, eps)
 
@@ -242,7 +274,13 @@ def sparse_adagrad(learning_rate, initial_accumulator_value=0.1, eps=1e-7):
     return _SparseAdagrad(learning_rate, initial_accumulator_value, eps)
 
 
-def sgd(learning_rate):
+def sgd(learning_rate, momentum=None):
+    if momentum is not None:
+        return _SgdMomentum(learning_rate, momentum)
+    return _sgd_plain(learning_rate)
+
+
+def _sgd_plain(learning_rate):
     return _SparseSgd(learning_rate)
 
 

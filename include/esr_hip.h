@@ -198,6 +198,44 @@ int esr_rescore_candidates(const float* queries, const float* candidates, int64_
 int esr_topk_merge(const float* scores, const int32_t* indices, int64_t nq, int n, int k,
                    float* out_scores, int32_t* out_indices, esr_stream_t stream);
 
+/* ---- N1: Spotify id-embedding two-tower -- spotify/models.py:27-90, spotify/train_spotify.py:77-131 ----
+ * A track embeds as concat(album_table[album mod n_album_rows], artist_table[artist]) ([.., 2F]).  One call is one
+ * playlist: album_ids / artist_ids are int32 [n + m + o] = context, next, neg occurrences in that order (raw ids:
+ * the +0.1 isin boosts of models.py:76-81 compare un-hashed ids).  n <= 32, 2F <= 256. */
+size_t esr_spotify_workspace_bytes(int n, int m, int o, int F);
+/* SpotifyModel.get_embeddings (models.py:37-51): out [count, 2F] = concat(album row (hashed), artist row); l2 [count]. */
+int esr_spotify_get_embeddings(const float* album_table, int64_t n_album_rows, const float* artist_table,
+                               int64_t n_artists, int F, const int32_t* album_ids, const int32_t* artist_ids,
+                               int64_t count, float* out, float* l2, esr_stream_t stream);
+/* SpotifyModel.__call__: pos [m], neg [o], the three flipped self-affinity matrices [n,n] [m,m] [o,o], l2 [n+m+o]. */
+int esr_spotify_forward(const float* album_table, int64_t n_album_rows, const float* artist_table,
+                        int64_t n_artists, int F, const int32_t* album_ids, const int32_t* artist_ids, int n,
+                        int m, int o, float* pos, float* neg, float* ctx_self, float* next_self,
+                        float* neg_self, float* l2, void* workspace, size_t workspace_bytes,
+                        esr_stream_t stream);
+/* value_and_grad of train_step's loss_fn (train_spotify.py:78-109): loss [1]; the gradient as per-occurrence rows
+ * g_album_rows / g_artist_rows [n+m+o, F] (occurrence r -> album row album_rows[r] = hashed id, artist row
+ * artist_ids[r]).  max / min split their cotangent evenly over ties; relu'(0) = 0 [upstream jax]. */
+int esr_spotify_fwd_bwd(const float* album_table, int64_t n_album_rows, const float* artist_table,
+                        int64_t n_artists, int F, const int32_t* album_ids, const int32_t* artist_ids, int n,
+                        int m, int o, float regularization, float* loss, int32_t* album_rows,
+                        float* g_album_rows, float* g_artist_rows, void* workspace, size_t workspace_bytes,
+                        esr_stream_t stream);
+/* eval_step's result[1] (train_spotify.py:113-119): affinity [T] of every track of the corpus to the n context
+ * tracks (row max over the context + boosts). */
+int esr_spotify_affinity_all(const float* album_table, int64_t n_album_rows, const float* artist_table,
+                             int64_t n_artists, int F, const int32_t* ctx_album, const int32_t* ctx_artist,
+                             int n, const int32_t* all_albums, const int32_t* all_artists, int64_t T,
+                             float* affinity, esr_stream_t stream);
+/* optax.sgd(lr, momentum) [upstream] in two halves: the decay over the whole table (trace *= momentum;
+ * p -= lr * trace) and the row-sparse gradient (trace[row] += g; p[row] -= lr * g, duplicates summed in
+ * occurrence order first).  Together: trace' = g + momentum * trace, p' = p - lr * trace'. */
+int esr_dense_momentum_decay(float* param, float* trace, int64_t count, float lr, float momentum,
+                             esr_stream_t stream);
+int esr_sparse_momentum_scatter(float* table, float* trace, int64_t V, int D, const int32_t* sorted_ids,
+                                const int32_t* perm, int64_t n, const float* grad_rows, float lr,
+                                esr_stream_t stream);
+
 /* ---- 8e: row-shard routing (owner = id mod world, local row = id div world) ---------------
  * Stable bucket of ids by owner: local_rows[k] = ids[perm[k]] / world, counts[g] = #ids owned by g
  * (int64, device).  Build-defined; the reference is single-device. */

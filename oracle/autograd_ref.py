@@ -87,3 +87,42 @@ def adagrad_steps(param, grads, lr, initial_accumulator_value=0.1, eps=1e-7):
         acc = acc + g * g
         p = p - lr * g * torch.where(acc > 0, torch.rsqrt(acc + eps), torch.zeros_like(acc))
     return p.numpy(), acc.numpy()
+
+
+def spotify_value_and_grad(album_table, artist_table, x, regularization):
+    """spotify/models.py:37-90 + spotify/train_spotify.py:78-107 written one-for-one with torch ops; autograd
+    differentiates it.  torch's amax / amin backward splits the gradient evenly over ties like JAX's max / min;
+    torch.relu'(0) = 0 like jax.nn.relu."""
+    at = torch.tensor(album_table, dtype=torch.float64, requires_grad=True)
+    rt = torch.tensor(artist_table, dtype=torch.float64, requires_grad=True)
+    L = lambda v: torch.as_tensor(v, dtype=torch.long)  # noqa: E731
+
+    def get_embeddings(album, artist):
+        album_modded = torch.remainder(L(album), 100000)
+        return torch.cat([at[album_modded], rt[L(artist)]], dim=-1)
+
+    context_embed = get_embeddings(x["album_context"], x["artist_context"])
+    next_embed = get_embeddings(x["next_album"], x["next_artist"])
+    neg_embed = get_embeddings(x["neg_album"], x["neg_artist"])
+    pos_affinity = torch.amax(next_embed @ context_embed.T, dim=-1)
+    pos_affinity = pos_affinity + 0.1 * torch.isin(L(x["next_album"]), L(x["album_context"]))
+    pos_affinity = pos_affinity + 0.1 * torch.isin(L(x["next_artist"]), L(x["artist_context"]))
+    neg_affinity = torch.amax(neg_embed @ context_embed.T, dim=-1)
+    neg_affinity = neg_affinity + 0.1 * torch.isin(L(x["neg_album"]), L(x["album_context"]))
+    neg_affinity = neg_affinity + 0.1 * torch.isin(L(x["neg_artist"]), L(x["artist_context"]))
+    all_embeddings = torch.cat([context_embed, next_embed, neg_embed], dim=-2)
+    all_embeddings_l2 = torch.sqrt(torch.sum(torch.square(all_embeddings), dim=-1))
+    context_self_affinity = torch.flip(context_embed, dims=[-2]) @ context_embed.T
+    next_self_affinity = torch.flip(next_embed, dims=[-2]) @ next_embed.T
+    neg_self_affinity = torch.flip(neg_embed, dims=[-2]) @ neg_embed.T
+
+    mean_triplet_loss = torch.relu(1.0 + torch.mean(neg_affinity) - torch.mean(pos_affinity))
+    extremal_triplet_loss = torch.relu(1.0 + torch.amax(neg_affinity) - torch.amin(pos_affinity))
+    context_self_affinity_loss = torch.mean(torch.relu(0.5 - context_self_affinity))
+    next_self_affinity_loss = torch.mean(torch.relu(0.5 - next_self_affinity))
+    neg_self_affinity_loss = torch.mean(torch.relu(neg_self_affinity))
+    reg_loss = torch.sum(torch.relu(all_embeddings_l2 - regularization))
+    loss = (extremal_triplet_loss + mean_triplet_loss + reg_loss + context_self_affinity_loss +
+            next_self_affinity_loss + neg_self_affinity_loss)
+    loss.backward()
+    return loss.item(), at.grad.numpy(), rt.grad.numpy()
