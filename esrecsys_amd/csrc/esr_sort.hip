@@ -39,6 +39,40 @@ static size_t pair_sort_temp_bytes(int64_t n) {
   return align_up(bytes + 256, 256);
 }
 
+// Short occurrence lists (one playlist of the Spotify step, the reference's own batch sizes of 16-128): one
+// workgroup, bitonic sort of (id << 32 | position) in LDS -- stable by construction, one launch instead of the
+// device radix sort's chain of ~6.
+constexpr int kSmallSortMax = 4096;
+constexpr int kSmallSortThreads = 1024;
+__global__ __launch_bounds__(kSmallSortThreads) void segment_sort_small_kernel(const int32_t* __restrict__ ids, int n,
+                                                                              int32_t* __restrict__ sorted_ids,
+                                                                              int32_t* __restrict__ perm) {
+  __shared__ unsigned long long key[kSmallSortMax];
+  const int t = threadIdx.x;
+  int np2 = 1;
+  while (np2 < n) np2 <<= 1;
+  for (int i = t; i < np2; i += kSmallSortThreads)
+    key[i] = i < n ? (((unsigned long long)(uint32_t)ids[i]) << 32) | (uint32_t)i : ~0ull;
+  for (int size = 2; size <= np2; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int i = t; i < (np2 >> 1); i += kSmallSortThreads) {
+        const int pos = 2 * i - (i & (stride - 1)), j = pos + stride;
+        const bool asc = (pos & size) == 0;
+        const unsigned long long x = key[pos], y = key[j];
+        if ((x > y) == asc) {
+          key[pos] = y;
+          key[j] = x;
+        }
+      }
+    }
+  __syncthreads();
+  for (int i = t; i < n; i += kSmallSortThreads) {
+    sorted_ids[i] = (int32_t)(key[i] >> 32);
+    perm[i] = (int32_t)(uint32_t)key[i];
+  }
+}
+
 // owner key of every id + the per-owner totals.  The totals are privatised per workgroup in LDS (one global
 // atomic per owner per workgroup): with every thread hitting the same few global counters the kernel took
 // 1.5 ms for 131072 ids (profiles/r1 sharded GloVe).  Integer atomics: order-independent result.
@@ -249,6 +283,11 @@ int esr_segment_sort_ids(const int32_t* ids, int64_t n, int64_t V, int32_t* sort
               (long long)n, (long long)V);
   if (n == 0) return ESR_OK;
   ESR_REQUIRE(ids && sorted_ids && perm && workspace, "esr_segment_sort_ids: null pointer");
+  if (n <= kSmallSortMax) {
+    hipLaunchKernelGGL(segment_sort_small_kernel, dim3(1), dim3(kSmallSortThreads), 0, as_stream(stream), ids, (int)n,
+                       sorted_ids, perm);
+    return check_launch("esr_segment_sort_ids(small)");
+  }
   size_t need = 0;
   const int end_bit = bits_for(V);
   const uint32_t* kin = reinterpret_cast<const uint32_t*>(ids);

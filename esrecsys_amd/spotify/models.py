@@ -5,6 +5,7 @@ its album and artist rows.  ``__call__`` returns the reference's 6-tuple.  Compu
 (esr_spotify_forward); there is no torch fallback."""
 import copy
 
+import numpy as np
 import torch
 
 from .. import ops
@@ -62,9 +63,18 @@ class SpotifyModel:
     def occurrence_ids(self, album_context, artist_context, next_album, next_artist, neg_album, neg_artist):
         """(album_ids, artist_ids, n, m, o): the int32 occurrence lists (context, next, neg) the kernels take."""
         at, rt = self._tables()
-        parts_a = [ops.as_ids(v, at.device).reshape(-1) for v in (album_context, next_album, neg_album)]
-        parts_r = [ops.as_ids(v, rt.device, check_range=rt.shape[0]).reshape(-1)
-                   for v in (artist_context, next_artist, neg_artist)]
+        groups_a, groups_r = (album_context, next_album, neg_album), (artist_context, next_artist, neg_artist)
+        if not any(isinstance(v, torch.Tensor) for v in groups_a + groups_r):
+            # host features (the reference's numpy iterator): pack both lists into ONE transfer
+            a = np.concatenate([np.asarray(v).reshape(-1) for v in groups_a]).astype(np.int32)
+            r = np.concatenate([np.asarray(v).reshape(-1) for v in groups_r]).astype(np.int32)
+            if r.size and (r.min() < 0 or r.max() >= rt.shape[0]):
+                raise IndexError("artist id out of range [0, %d)" % rt.shape[0])
+            both = torch.from_numpy(np.stack([a, r])).to(at.device, non_blocking=True)
+            n, m, o = (int(np.asarray(v).size) for v in groups_a)
+            return both[0], both[1], n, m, o
+        parts_a = [ops.as_ids(v, at.device).reshape(-1) for v in groups_a]
+        parts_r = [ops.as_ids(v, rt.device, check_range=rt.shape[0]).reshape(-1) for v in groups_r]
         n, m, o = (p.numel() for p in parts_a)
         return torch.cat(parts_a), torch.cat(parts_r), n, m, o
 

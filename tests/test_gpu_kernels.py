@@ -314,11 +314,12 @@ def _ids(kind, rng, V, n):
     return rng.permutation(V)[rng.choice(V, size=n, p=p / p.sum())].astype(np.int32)
 
 
+@pytest.mark.parametrize("n", [16_384 + 13, 4096, 4095, 1000, 74, 1])   # <= 4096: the one-workgroup sort
 @pytest.mark.parametrize("kind", ["uniform", "same", "zipf"])
-def test_segment_sort_is_stable_sort(dev, kind):
+def test_segment_sort_is_stable_sort(dev, kind, n):
     from esrecsys_amd import ops
     rng = np.random.default_rng(9)
-    V, n = 100_000, 16_384 + 13
+    V = 100_000
     ids = _ids(kind, rng, V, n)
     sid, perm = ops.segment_sort(T(ids, dev), V)
     order = np.argsort(ids, kind="stable")
