@@ -314,7 +314,7 @@ def _ids(kind, rng, V, n):
     return rng.permutation(V)[rng.choice(V, size=n, p=p / p.sum())].astype(np.int32)
 
 
-@pytest.mark.parametrize("n", [16_384 + 13, 4096, 4095, 1000, 74, 1])   # <= 4096: the one-workgroup sort
+@pytest.mark.parametrize("n", [40_000, 32_768, 24_576, 16_384 + 13, 4097, 4096, 4095, 1000, 74, 1])  # three sort paths
 @pytest.mark.parametrize("kind", ["uniform", "same", "zipf"])
 def test_segment_sort_is_stable_sort(dev, kind, n):
     from esrecsys_amd import ops
@@ -325,6 +325,18 @@ def test_segment_sort_is_stable_sort(dev, kind, n):
     order = np.argsort(ids, kind="stable")
     assert np.array_equal(N(perm), order.astype(np.int32))
     assert np.array_equal(N(sid), ids[order])
+
+
+def test_segment_sort_wide_ids_take_the_radix_path(dev):
+    """ids >= 2^21 do not fit the 32-bit tile composites: mid-size lists fall back to the device radix sort"""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(10)
+    V, n = 50_000_000, 20_000
+    ids = rng.integers(0, V, n).astype(np.int32)
+    ids[::7] = V - 1
+    sid, perm = ops.segment_sort(T(ids, dev), V)
+    order = np.argsort(ids, kind="stable")
+    assert np.array_equal(N(perm), order.astype(np.int32)) and np.array_equal(N(sid), ids[order])
 
 
 @pytest.mark.parametrize("kind", ["uniform", "same", "zipf"])
