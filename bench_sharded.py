@@ -41,12 +41,12 @@ def run_sharded(args, cfg, dev, rank, world):
             batches.append((ids[0].contiguous(), ids[1].contiguous(), ids[2].contiguous()))
     gb = float(world * B)
 
-    def plan(b):
+    def begin(b):  # the device half of the routing plan of one batch: no host wait
         if args.workload == "glove":
-            return sharded.plan_glove(emb, b[0])
+            return sharded.begin_plan_glove(emb, b[0])
         if args.workload == "inbatch":
-            return sharded.plan_inbatch(towers, b[0], b[1])
-        return sharded.plan_triplet(towers, b[0], b[1], b[2])
+            return sharded.begin_plan_inbatch(towers, b[0], b[1])
+        return sharded.begin_plan_triplet(towers, b[0], b[1], b[2])
 
     def step(b, plans):
         if args.workload == "glove":
@@ -55,23 +55,28 @@ def run_sharded(args, cfg, dev, rank, world):
             return sharded.sharded_inbatch_step(towers, b[0], b[1], LAM, gb, SCALE, LR, plan=plans)
         return sharded.sharded_triplet_step(towers, b[0], b[1], b[2], LAM, gb, LR, plan=plans)
 
-    # The routing plan of batch k+1 (bucket + counts all-to-all + the one host read-back + ids all-to-all)
-    # only needs its ids: it is built right after step k has been enqueued, inside the timed region, so the
-    # read-back waits behind step k's kernels instead of idling the GPU in the middle of a step.
-    nxt = plan(batches[0])
-    for i in range(args.warmup):
-        cur, nxt = nxt, None
-        loss = step(batches[i], cur)
-        nxt = plan(batches[i + 1])
+    # Routing plans are pipelined two batches deep.  begin(k+2) -- bucket kernel, counts all-to-all, asynchronous copy
+    # of the counts to pinned memory -- is enqueued right after step k; the host half of plan k+1 (wait for ITS copy,
+    # issued one iteration earlier; then the ids all-to-all and the owner-side sort, whose split sizes the host must
+    # know) runs while the GPU still has step k queued.  The host therefore never blocks an idle GPU, and everything
+    # stays inside the timed region.
+    def run(lo, hi, timed_loss=None):
+        cur = begin(batches[lo]).finish()
+        pend = begin(batches[lo + 1]) if lo + 1 < hi else None
+        loss = None
+        for i in range(lo, hi):
+            loss = step(batches[i], cur)
+            nxt_pend = begin(batches[i + 2]) if i + 2 < hi else None
+            cur = pend.finish() if pend is not None else None
+            pend = nxt_pend
+        return loss
+
+    loss = run(0, args.warmup)
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.warmup, n_batches):
-        cur, nxt = nxt, None
-        loss = step(batches[i], cur)
-        if i + 1 < n_batches:
-            nxt = plan(batches[i + 1])
+    loss = run(args.warmup, n_batches)
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
@@ -88,18 +93,13 @@ def run_sharded(args, cfg, dev, rank, world):
         timer = KernelTimer(ops, TIMED_GROUPS)
         timer.install()
         timer.enabled = True
-        nxt = plan(batches[args.warmup])
-        for i in range(args.warmup, n_batches):
-            cur, nxt = nxt, None
-            step(batches[i], cur)
-            if i + 1 < n_batches:
-                nxt = plan(batches[i + 1])
+        run(args.warmup, n_batches)
         torch.cuda.synchronize()
         timer.enabled = False
         for g_, (ms, calls) in timer.totals_ms().items():
             if calls:
                 kernels[g_] = {"ms_per_step": ms / args.steps, "launch_groups_per_step": calls / args.steps}
-        rows_served = cur.recv_local_rows
+        rows_served = begin(batches[-1]).finish().recv_local_rows
         roofline = roofline_for(args.workload, kernels, B, D, cfg["rows_per_unit"], "auto",
                                 int(rows_served.numel()), int(torch.unique(rows_served).numel()))
         roofline["rank"] = 0

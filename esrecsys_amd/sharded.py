@@ -57,6 +57,20 @@ class RoutingPlan:
         self.recv_counts = recv_counts      # python ints per peer: ids that peer asks of this rank
         self.recv_local_rows = None         # int32 [sum(recv_counts)]: virtual local rows requested of this rank
         self.owner_sorted = None            # (sorted, permutation) of recv_local_rows, for the update
+        self.ready = None                   # event recorded on the planning stream once everything above exists
+
+    def wait_ready(self):
+        """Make the current stream wait for a plan that was built on a side stream (no-op otherwise)."""
+        if self.ready is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(self.ready)
+            tensors = [self.local_rows, self.perm, self.recv_local_rows]
+            if self.owner_sorted is not None:
+                tensors += list(self.owner_sorted)
+            for t in tensors:  # allocated on the planning stream, consumed here: keep the allocator from recycling
+                if t is not None and t.is_cuda:
+                    t.record_stream(cur)
+            self.ready = None
 
     def exchange_ids(self):
         if self.recv_local_rows is None:
@@ -69,11 +83,45 @@ class RoutingPlan:
         return self.recv_local_rows
 
 
-def make_plans(lookups):
-    """lookups: list of (ShardedTableGroup, virtual ids int32 [n]).  One counts all-to-all and one host sync
-    for the whole list.  Returns one RoutingPlan per lookup (ids exchanged, owner-side sort done)."""
-    if not lookups:
-        return []
+_pinned_ring = {}
+
+
+def _pinned_like(t, depth=8):
+    """A pinned host buffer of t's shape from a small ring (pinning memory per step costs ~100 us)."""
+    key = (tuple(t.shape), t.dtype)
+    ring = _pinned_ring.setdefault(key, [[], 0])
+    if len(ring[0]) < depth:
+        ring[0].append(torch.empty(t.shape, dtype=t.dtype, pin_memory=True))
+        return ring[0][-1]
+    ring[1] = (ring[1] + 1) % depth
+    return ring[0][ring[1]]
+
+
+class PendingPlans:
+    """The device half of make_plans, already enqueued: bucket kernels, the counts all-to-all and an asynchronous
+    copy of the counts to pinned host memory.  ``finish()`` waits for that copy only -- a training loop calls it
+    one step later, after the NEXT step's kernels are in the queue, so the host never stalls an idle GPU."""
+
+    def __init__(self, parts, both_dev, both_host, event):
+        self.parts, self.both_dev, self.both_host, self.event = parts, both_dev, both_host, event
+        self.plans = None
+
+    def finish(self):
+        if self.plans is None:
+            if self.event is not None:
+                self.event.synchronize()
+            both = self.both_host
+            self.plans = [RoutingPlan(group, n, local_rows, perm, both[0, :, i].tolist(), both[1, :, i].tolist())
+                          for i, (group, n, local_rows, perm, _) in enumerate(self.parts)]
+            for p in self.plans:
+                p.exchange_ids()
+            self.parts = self.both_dev = None
+        return self.plans
+
+
+def begin_plans(lookups):
+    """lookups: list of (ShardedTableGroup, virtual ids int32 [n]).  Enqueues everything of the routing plans that
+    needs no host knowledge and returns a PendingPlans."""
     g0 = lookups[0][0]
     k, G, pg = g0.k, g0.world, g0.pg
     parts = []
@@ -84,12 +132,39 @@ def make_plans(lookups):
     send = torch.stack([p[4] for p in parts], dim=1).contiguous()          # [G, L] int64
     recv = torch.empty_like(send)
     dist.all_to_all_single(recv, send, group=pg)
-    both = torch.stack([send, recv]).cpu()                                  # the step's one host sync
-    plans = [RoutingPlan(group, n, local_rows, perm, both[0, :, i].tolist(), both[1, :, i].tolist())
-             for i, (group, n, local_rows, perm, _) in enumerate(parts)]
-    for p in plans:
-        p.exchange_ids()
-    return plans
+    both = torch.stack([send, recv])
+    if both.is_cuda:
+        host = _pinned_like(both)
+        host.copy_(both, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return PendingPlans(parts, both, host, ev)
+    return PendingPlans(parts, both, both, None)
+
+
+def make_plans(lookups, stream=None, ids_ready=False):
+    """lookups: list of (ShardedTableGroup, virtual ids int32 [n]).  One counts all-to-all and one host sync
+    for the whole list.  Returns one RoutingPlan per lookup (ids exchanged, owner-side sort done).
+
+    `stream`: optionally a side HIP stream to plan on (`ids_ready=True` promises that the ids are already resident,
+    so that stream does not wait for the main one).  A training loop should prefer begin_plans / finish one step
+    apart: see bench_sharded.py."""
+    if not lookups:
+        return []
+    if stream is not None:
+        if not ids_ready:
+            stream.wait_stream(torch.cuda.current_stream())  # the ids may have been produced on the main stream
+        with torch.cuda.stream(stream):
+            plans = make_plans(lookups)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        for p in plans:
+            p.ready = ev
+        for _, vids in lookups:
+            if vids.is_cuda:
+                vids.record_stream(stream)
+        return plans
+    return begin_plans(lookups).finish()
 
 
 class ShardedTableGroup:
@@ -116,12 +191,13 @@ class ShardedTableGroup:
             return id_tensors[0]
         return self.k.concat_offset_ids(list(id_tensors), [self.voff[s] for s in slots])
 
-    def plan(self, vids):
-        return make_plans([(self, vids)])[0]
+    def plan(self, vids, stream=None, ids_ready=False):
+        return make_plans([(self, vids)], stream=stream, ids_ready=ids_ready)[0]
 
     def lookup(self, plan):
         """rows[i] = table_of(vid_i)[id_i] for this rank's virtual ids -> [n, D] in the order of the ids."""
         k = self.k
+        plan.wait_ready()
         recv = plan.exchange_ids()
         if len(self.tables) == 1:
             served = k.gather_rows(self.tables[0].local, recv)
@@ -156,17 +232,51 @@ class ShardedTableGroup:
                                    sorted_rows, perm, rows, lr, eps)
 
 
-def plan_inbatch(towers, scene_ids, pos_ids):
-    return towers.plan(towers.virtual_ids([scene_ids, pos_ids], [0, 1]))
+def _on(stream):
+    import contextlib
+    return torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
 
 
-def plan_triplet(towers, scene_ids, pos_ids, neg_ids):
-    return towers.plan(towers.virtual_ids([scene_ids, pos_ids, neg_ids], [0, 1, 1]))
+def plan_inbatch(towers, scene_ids, pos_ids, stream=None, ids_ready=False):
+    if stream is not None and not ids_ready:
+        stream.wait_stream(torch.cuda.current_stream())
+    with _on(stream):
+        vids = towers.virtual_ids([scene_ids, pos_ids], [0, 1])
+    return towers.plan(vids, stream=stream, ids_ready=True)
 
 
-def plan_glove(emb_group, inputs):
+def plan_triplet(towers, scene_ids, pos_ids, neg_ids, stream=None, ids_ready=False):
+    if stream is not None and not ids_ready:
+        stream.wait_stream(torch.cuda.current_stream())
+    with _on(stream):
+        vids = towers.virtual_ids([scene_ids, pos_ids, neg_ids], [0, 1, 1])
+    return towers.plan(vids, stream=stream, ids_ready=True)
+
+
+def plan_glove(emb_group, inputs, stream=None, ids_ready=False):
     """The embedding and bias tables are indexed by the same ids and sharded the same way: one routing."""
-    return emb_group.plan(inputs.reshape(-1))
+    return emb_group.plan(inputs.reshape(-1), stream=stream, ids_ready=ids_ready)
+
+
+class _Pending1:
+    def __init__(self, pending):
+        self.pending = pending
+
+    def finish(self):
+        return self.pending.finish()[0]
+
+
+def begin_plan_inbatch(towers, scene_ids, pos_ids):
+    """Non-blocking half of plan_inbatch; ``.finish()`` returns the RoutingPlan."""
+    return _Pending1(begin_plans([(towers, towers.virtual_ids([scene_ids, pos_ids], [0, 1]))]))
+
+
+def begin_plan_triplet(towers, scene_ids, pos_ids, neg_ids):
+    return _Pending1(begin_plans([(towers, towers.virtual_ids([scene_ids, pos_ids, neg_ids], [0, 1, 1]))]))
+
+
+def begin_plan_glove(emb_group, inputs):
+    return _Pending1(begin_plans([(emb_group, inputs.reshape(-1))]))
 
 
 def _joined(first, *rest):
