@@ -143,14 +143,15 @@ def _glove_worker(rank, port, outdir):
     bias = sharded.ShardedTableGroup([bias_t], kernels=K)
     brng = np.random.default_rng(100 + rank)
     batches = [(brng.integers(0, V, (2, Bg)).astype(np.int32), brng.uniform(0.1, 300, Bg)) for _ in range(3)]
-    # prefetch the routing plan of the next batch right after each step, as the bench loop does
-    nxt = sharded.plan_glove(emb, torch.from_numpy(batches[0][0]))
+    # routing plans pipelined two batches deep, as the bench loop does: begin(k+2) after step k, finish(k+1) after it
+    cur = sharded.begin_plan_glove(emb, torch.from_numpy(batches[0][0])).finish()
+    pend = sharded.begin_plan_glove(emb, torch.from_numpy(batches[1][0]))
     for i, (inp, tgt) in enumerate(batches):
-        cur = nxt
         sharded.sharded_glove_step(emb, bias, torch.from_numpy(inp), torch.from_numpy(tgt), K.GLOVE_DIAGONAL, 0.05,
                                    plan=cur)
-        if i + 1 < len(batches):
-            nxt = sharded.plan_glove(emb, torch.from_numpy(batches[i + 1][0]))
+        nxt_pend = sharded.begin_plan_glove(emb, torch.from_numpy(batches[i + 2][0])) if i + 2 < len(batches) else None
+        cur = pend.finish() if pend is not None else None
+        pend = nxt_pend
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), emb=emb_t.local.numpy(), bias=bias_t.local.numpy())
     dist.barrier()
     dist.destroy_process_group()
