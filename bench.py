@@ -115,9 +115,10 @@ TIMED_GROUPS = {
 }
 
 
-def synth_tables(V, D, dev, gen):
+def synth_tables(V, D, dev, gen, dtype="f32"):
     t = torch.randn((V, D), generator=gen, device=dev, dtype=torch.float32)
-    return t.mul_(D ** -0.5)
+    t.mul_(D ** -0.5)
+    return t.to(torch.bfloat16) if dtype == "bf16" else t
 
 
 def make_state_and_batches(workload, cfg, dev, n_batches, rank):
@@ -134,8 +135,12 @@ def make_state_and_batches(workload, cfg, dev, n_batches, rank):
     else:
         from esrecsys_amd.pinterest.models import STLModel
         model = STLModel(output_size=D, num_scenes=V, num_products=V, device=dev)
-        params = {"params": {"scene_tower": {"embedding": synth_tables(V, D, dev, gen)},
-                             "product_tower": {"embedding": synth_tables(V, D, dev, gen)}}}
+        td = cfg.get("table_dtype", "f32")
+        if td == "bf16" and workload != "inbatch":
+            raise SystemExit("bf16 tables: the fused triplet / GloVe kernels read fp32 tables; use --workload inbatch "
+                             "or the row-sharded leg (--gpus N / ESR_BENCH_SHARDED=1)")
+        params = {"params": {"scene_tower": {"embedding": synth_tables(V, D, dev, gen, td)},
+                             "product_tower": {"embedding": synth_tables(V, D, dev, gen, td)}}}
         state = TrainState.create(apply_fn=model.apply, params=params, tx=optim.sparse_adagrad(LR))
     gen.manual_seed(SEED + 1 + rank)
     batches = []
@@ -223,6 +228,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="inbatch", choices=sorted(WORKLOADS) + ["retrieve"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rows", type=int, default=None,
+                    help="rows per table instead of the workload's (BASELINE config 4: --gpus 8 --rows 100000000 "
+                         "--table-dtype bf16)")
+    ap.add_argument("--table-dtype", default="f32", choices=["f32", "bf16"],
+                    help="table storage (accumulators stay fp32); bf16 needs the in-batch workload or the sharded leg")
     ap.add_argument("--precision", default="auto", choices=["auto", "f32", "bf16x3"],
                     help="MFMA path of the in-batch score kernel (both are f32-grade; see DESIGN.md 2.2)")
     ap.add_argument("--no-kernel-timing", action="store_true",
@@ -249,7 +259,10 @@ def main():
 
     from esrecsys_amd import _lib, ops
     _lib.load()
-    cfg = WORKLOADS[args.workload]
+    cfg = dict(WORKLOADS[args.workload])
+    if args.rows:
+        cfg["V"] = int(args.rows)
+    cfg["table_dtype"] = args.table_dtype
     B, D, V = cfg["B"], cfg["D"], cfg["V"]
 
     if world > 1 or os.environ.get("ESR_BENCH_SHARDED") == "1":  # the env switch runs the sharded leg on one rank
@@ -353,7 +366,8 @@ def main():
         "metric": "training pairs/sec", "value": B * K / dt, "unit": cfg["unit"] + "s/s", "n_gpus": 1,
         "steps": K, "warmup": args.warmup, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: V=%d x D=%d fp32 tables, B=%d, sparse Adagrad" % (args.workload, V, D, B),
+        "config": {"workload": "%s: V=%d x D=%d %s tables, B=%d, sparse Adagrad"
+                               % (args.workload, V, D, "bf16" if args.table_dtype == "bf16" else "fp32", B),
                    "score_precision": PRECISION,
                    "parallelism": "single", "launch": mode, "loss": final_loss},
         "roofline": roofline, "kernels": kernels, "hbm_gather_scatter": hbm,

@@ -20,6 +20,8 @@ def run_sharded(args, cfg, dev, rank, world):
     def shard(num_rows, dim):
         n = sharded.RowShardedTable.local_rows_for(num_rows, world, rank)
         t = torch.randn((n, dim), generator=gen, device=dev, dtype=torch.float32).mul_(dim ** -0.5)
+        if cfg.get("table_dtype") == "bf16" and dim > 1:   # the GloVe bias column stays fp32
+            t = t.to(torch.bfloat16)
         return sharded.RowShardedTable(t, torch.full((n, dim), 0.1, device=dev), num_rows)
 
     if args.workload == "glove":
@@ -110,8 +112,9 @@ def run_sharded(args, cfg, dev, rank, world):
             "metric": "training pairs/sec", "value": world * B * K / dt, "unit": cfg["unit"] + "s/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": dt / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: V=%d x D=%d fp32 tables row-sharded id mod %d, B=%d per GPU, sparse Adagrad"
-                                   % (args.workload, V, D, world, B),
+            "config": {"workload": "%s: V=%d x D=%d %s tables row-sharded id mod %d, B=%d per GPU, sparse Adagrad"
+                                   % (args.workload, V, D, "bf16" if cfg.get("table_dtype") == "bf16" else "fp32",
+                                      world, B),
                        "parallelism": "row-sharded x%d, all-to-all ids/rows/grads over RCCL" % world,
                        "loss": float(total)},
             "roofline": roofline, "kernels": kernels, "cpu_baseline": None,
