@@ -356,9 +356,10 @@ def main():
         hbm["sparse_adagrad_GBps"] = adagrad_bytes / t / 1e9
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc) and roofline is not None:
-        try:
+        try:  # HBM bytes per launch of the dominant kernel group, from the committed --pmc passes
             key = args.workload + ("_f32" if args.workload == "inbatch" and PRECISION == "f32" else "")
-            roofline["traffic"] = json.load(open(pmc)).get(key)
+            entry = json.load(open(pmc)).get(key)
+            roofline["traffic"] = entry.get(roofline["kernel"]) if isinstance(entry, dict) else entry
         except Exception:
             pass
 

@@ -64,6 +64,14 @@ def run_retrieve(args, emit):
     t_op = e0.elapsed_time(e1) * 1e-3
     planes = 6 if mode == "exact" else 1
     flops = 2.0 * qq.shape[0] * n_local * D
+    traffic = None
+    try:
+        import json
+        if world == 1 and mode == "exact":
+            traffic = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                                  "pmc_traffic.json"))).get("retrieve")
+    except Exception:
+        pass
     extra = {}
     if world == 1 and not args.no_cpu_baseline:
         a_s, a_i = find_top_k_batch(q, c, K, approximate=True)
@@ -97,7 +105,7 @@ def run_retrieve(args, emit):
                                                                   "all-to-all partial top-k" % world, **extra},
             "roofline": {"kernel": "score_gemm_kernel (+ split, select)", "bound": "mfma",
                          "achieved": planes * flops / t_op / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": planes * flops / t_op / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                         "frac": planes * flops / t_op / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
                          "f32_equivalent_TFLOPs": flops / t_op / 1e12,
                          "f32_equivalent_vs_f32_mfma_peak": flops / t_op / 1e12 / MFMA_F32_PEAK_TFLOPS},
             "cpu_baseline": extra_cpu,
