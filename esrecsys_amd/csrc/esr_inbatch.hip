@@ -38,8 +38,12 @@ __device__ __forceinline__ constexpr int mfma_row(int r, int h) { return (r & 3)
 
 template <int D, bool QSIDE>
 __global__ __launch_bounds__(kIbWaves * 64, 2) void inbatch_kernel(
-    const float* __restrict__ X, const float* __restrict__ Y, int64_t B, float scale, float lam, float inv_bs,
-    float* __restrict__ lse2, float* __restrict__ lse_nat, float* __restrict__ gX, double* __restrict__ loss_part) {
+    const float* __restrict__ X, const float* __restrict__ Y, int64_t B, int64_t nv, float scale, float lam,
+    float inv_bs, float* __restrict__ lse2, float* __restrict__ lse_nat, float* __restrict__ gX,
+    double* __restrict__ loss_part) {
+  // B = rows rounded up to a multiple of 32 (tiling); nv = rows that exist.  Rows >= nv are padding: their loads are
+  // clamped to the last real row, as streamed rows they are masked out of every softmax (score -inf in pass Q,
+  // lse = +inf in pass C), as owned rows they produce no output.
   constexpr int KK = D / 8;        // S-phase k-groups (4 MFMAs each)
   constexpr int DB = D / 32;       // output d-blocks
   constexpr int STRIDE = D + 4;    // LDS row stride in floats (+16 B)
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(kIbWaves * 64, 2) void inbatch_kernel(
   // Owned rows -> B operand registers: xr[kk][m] = X[x0 + j][8 kk + 4 h + m]
   float xr[KK][4];
   {
-    const float* xp = X + (x0 + j) * D + 4 * h;
+    const float* xp = X + min(x0 + j, nv - 1) * D + 4 * h;
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
       const float4 v = *reinterpret_cast<const float4*>(xp + 8 * kk);
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(kIbWaves * 64, 2) void inbatch_kernel(
       for (int q = 0; q < NLD; ++q) {
         const int idx = q * 64 + lane;
         const int row = idx / (D / 4), c4 = idx % (D / 4);
-        st[q] = *reinterpret_cast<const float4*>(Y + (y0 + row) * D + 4 * c4);
+        st[q] = *reinterpret_cast<const float4*>(Y + min(y0 + row, nv - 1) * D + 4 * c4);
       }
 #pragma unroll
       for (int q = 0; q < NLD; ++q) {
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(kIbWaves * 64, 2) void inbatch_kernel(
       float mloc = -INFINITY;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        s[r] *= sl2;
+        s[r] = (y0 + mfma_row(r, h) < nv) ? s[r] * sl2 : -INFINITY;  // padding candidates leave the softmax
         mloc = fmaxf(mloc, s[r]);
       }
       mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));  // both halves hold the same owned row
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(kIbWaves * 64, 2) void inbatch_kernel(
 
   float diag = 0.f;  // x_j . y_j (the positive pair), QSIDE wave 0 only
   if (QSIDE && w == 0) {
-    const float* yp = Y + (x0 + j) * D + 4 * h;
+    const float* yp = Y + min(x0 + j, nv - 1) * D + 4 * h;
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
       const float4 v = *reinterpret_cast<const float4*>(yp + 8 * kk);
@@ -212,18 +216,19 @@ __global__ __launch_bounds__(kIbWaves * 64, 2) void inbatch_kernel(
     f = __builtin_amdgcn_exp2f(m2 - M) / L;
     if (w == 0) {
       const float lse_l2 = M + __builtin_amdgcn_logf(L);  // v_log_f32 = log2
+      const bool real = x0 + j < nv;
       if (h == 0) {
-        lse2[x0 + j] = lse_l2;
-        if (lse_nat) lse_nat[x0 + j] = lse_l2 * kLn2;
+        lse2[x0 + j] = real ? lse_l2 : INFINITY;  // pass C: exp2(s - inf) = 0 for a padding query
+        if (lse_nat && real) lse_nat[x0 + j] = lse_l2 * kLn2;
       }
       // loss partial: sum_j ce_j + lam * reg(q_j)
       double part = 0.0;
-      if (h == 0) part = (double)(lse_l2 * kLn2) - (double)(scale * diag) + (double)(lam * fmaxf(xnorm - 1.f, 0.f));
+      if (h == 0 && real) part = (double)(lse_l2 * kLn2) - (double)(scale * diag) + (double)(lam * fmaxf(xnorm - 1.f, 0.f));
       part = wave_sum_d(part);
       if (lane == 0) loss_part[blockIdx.x] = part;
     }
   } else if (w == 0) {
-    double part = (h == 0) ? (double)(lam * fmaxf(xnorm - 1.f, 0.f)) : 0.0;
+    double part = (h == 0 && x0 + j < nv) ? (double)(lam * fmaxf(xnorm - 1.f, 0.f)) : 0.0;
     part = wave_sum_d(part);
     if (lane == 0) loss_part[blockIdx.x] = part;
   }
@@ -242,6 +247,7 @@ __global__ __launch_bounds__(kIbWaves * 64, 2) void inbatch_kernel(
   for (int it = tid; it < 16 * 64; it += kIbWaves * 64) {
     const int r = it >> 6, ln = it & 63;
     const int row = ln & 31, d0 = DB * mfma_row(r, ln >> 5);
+    if (x0 + row >= nv) continue;  // padding row: no gradient row exists
     float v[DB];
 #pragma unroll
     for (int db = 0; db < DB; ++db) {
@@ -286,13 +292,13 @@ static size_t inbatch_ws_layout(int64_t B, char* base, InbatchWs* ws) {
 }
 
 template <int D>
-static void inbatch_launch(const float* Q, const float* C, int64_t B, float scale, float lam, float inv_bs,
+static void inbatch_launch(const float* Q, const float* C, int64_t B, int64_t nv, float scale, float lam, float inv_bs,
                            float* lse_nat, float* gQ, float* gC, const InbatchWs& ws, hipStream_t st) {
   const int nblk = (int)(B / kIbRows);
-  hipLaunchKernelGGL((inbatch_kernel<D, true>), dim3(nblk), dim3(kIbWaves * 64), 0, st, Q, C, B, scale, lam, inv_bs,
-                     ws.lse2, lse_nat, gQ, ws.loss_part);
-  hipLaunchKernelGGL((inbatch_kernel<D, false>), dim3(nblk), dim3(kIbWaves * 64), 0, st, C, Q, B, scale, lam, inv_bs,
-                     ws.lse2, (float*)nullptr, gC, ws.loss_part + nblk);
+  hipLaunchKernelGGL((inbatch_kernel<D, true>), dim3(nblk), dim3(kIbWaves * 64), 0, st, Q, C, B, nv, scale, lam,
+                     inv_bs, ws.lse2, lse_nat, gQ, ws.loss_part);
+  hipLaunchKernelGGL((inbatch_kernel<D, false>), dim3(nblk), dim3(kIbWaves * 64), 0, st, C, Q, B, nv, scale, lam,
+                     inv_bs, ws.lse2, (float*)nullptr, gC, ws.loss_part + nblk);
 }
 
 }  // namespace esr
@@ -304,14 +310,13 @@ extern "C" {
 size_t esr_inbatch_workspace_bytes(int64_t B, int D) {
   (void)D;
   if (B <= 0) return 256;
-  return inbatch_ws_layout(B, nullptr, nullptr);
+  return inbatch_ws_layout(cdiv(B, kIbRows) * kIbRows, nullptr, nullptr);
 }
 
 int esr_inbatch_softmax_fwd_bwd(const float* Q, const float* C, int64_t B, int D, float scale, float regularization,
                                 float batch_size, float* loss, float* lse, float* gQ, float* gC, void* workspace,
                                 size_t workspace_bytes, esr_stream_t stream) {
-  ESR_REQUIRE(B > 0 && B % kIbRows == 0, "esr_inbatch_softmax_fwd_bwd: B=%lld must be a positive multiple of 32",
-              (long long)B);
+  ESR_REQUIRE(B > 0, "esr_inbatch_softmax_fwd_bwd: B=%lld must be positive", (long long)B);
   ESR_REQUIRE(D == 32 || D == 64 || D == 128, "esr_inbatch_softmax_fwd_bwd: D=%d not supported (32, 64 or 128)", D);
   ESR_REQUIRE(Q && C && loss && gQ && gC, "esr_inbatch_softmax_fwd_bwd: null pointer");
   ESR_REQUIRE(batch_size != 0.f, "esr_inbatch_softmax_fwd_bwd: batch_size must be non-zero");
@@ -324,15 +329,16 @@ int esr_inbatch_softmax_fwd_bwd(const float* Q, const float* C, int64_t B, int D
   }
   hipStream_t st = as_stream(stream);
   InbatchWs ws;
-  inbatch_ws_layout(B, (char*)workspace, &ws);
+  const int64_t Bp = cdiv(B, kIbRows) * kIbRows;  // tiles of 32 rows; rows >= B are masked padding
+  inbatch_ws_layout(Bp, (char*)workspace, &ws);
   const float inv_bs = 1.0f / batch_size;
   if (D == 128)
-    inbatch_launch<128>(Q, C, B, scale, regularization, inv_bs, lse, gQ, gC, ws, st);
+    inbatch_launch<128>(Q, C, Bp, B, scale, regularization, inv_bs, lse, gQ, gC, ws, st);
   else if (D == 64)
-    inbatch_launch<64>(Q, C, B, scale, regularization, inv_bs, lse, gQ, gC, ws, st);
+    inbatch_launch<64>(Q, C, Bp, B, scale, regularization, inv_bs, lse, gQ, gC, ws, st);
   else
-    inbatch_launch<32>(Q, C, B, scale, regularization, inv_bs, lse, gQ, gC, ws, st);
-  const int nblk = (int)(B / kIbRows);
+    inbatch_launch<32>(Q, C, Bp, B, scale, regularization, inv_bs, lse, gQ, gC, ws, st);
+  const int nblk = (int)(Bp / kIbRows);
   finalize_scalar(ws.loss_part, 2 * nblk, 1.0 / (double)batch_size, loss, st);
   return check_launch("esr_inbatch_softmax_fwd_bwd");
 }

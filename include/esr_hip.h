@@ -100,7 +100,8 @@ int esr_triplet_fwd_bwd(const float* scene_table, int64_t Vs, const float* pos_t
  *   S = scale * Q C^T (FP32 MFMA), ce_i = logsumexp_j S_ij - S_ii,
  *   loss = (sum_i ce_i + regularization * sum_i [reg(q_i) + reg(c_i)]) / batch_size
  *   gQ = scale * (softmax(S) - I) C / batch_size + dreg ; gC likewise with S^T.
- * Q, C, gQ, gC are [B, D] row-major; D must be 128 in this build; B a multiple of 32. */
+ * Q, C, gQ, gC are [B, D] row-major, any B >= 1 (tiles of 32 rows; a ragged last tile is masked out of every
+ * softmax); D is 32, 64 or 128. */
 size_t esr_inbatch_workspace_bytes(int64_t B, int D);
 int esr_inbatch_softmax_fwd_bwd(const float* Q, const float* C, int64_t B, int D, float scale,
                                 float regularization, float batch_size, float* loss, float* lse,

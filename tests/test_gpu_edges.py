@@ -1,0 +1,106 @@
+"""GPU: edge cases and error behaviour through the C ABI -- empty and one-element inputs, ragged sizes, maximum k,
+argument errors that must raise instead of launching ('returns 0 / negative ESR_E* code, never throws';
+the Python layer turns the code into EsrLibraryError with esr_last_error()'s text)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import optim as o_optim
+from oracle import stl_head as o_stl
+from oracle import topk as o_topk
+
+pytestmark = pytest.mark.gpu
+F64 = np.float64
+
+
+def T(x, dev, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    return t.to(dtype) if dtype is not None else t
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def test_empty_occurrence_lists_are_no_ops(dev):
+    from esrecsys_amd import ops
+    table = torch.randn((100, 16), device=dev)
+    before = table.clone()
+    accum = torch.full((100, 16), 0.1, device=dev)
+    ids = torch.empty(0, dtype=torch.int32, device=dev)
+    assert ops.gather_rows(table, ids).shape == (0, 16)
+    sid, perm = ops.segment_sort(ids, 100)
+    assert sid.numel() == 0 and perm.numel() == 0
+    ops.sparse_adagrad(table, accum, sid, perm, torch.empty((0, 16), device=dev), 0.1)
+    local, p2, counts = ops.bucket_ids_by_owner(ids, 8)
+    assert local.numel() == 0 and int(counts.sum()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(table, before) and bool((accum == 0.1).all())
+
+
+def test_single_pair_and_single_triplet(dev):
+    """B = 1: the in-batch softmax over one candidate has loss 0 + reg and zero score gradient"""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(0)
+    q, c, n = (rng.standard_normal((1, 32)).astype(np.float32) for _ in range(3))
+    loss, lse, gq, gc = ops.inbatch_softmax_fwd_bwd(T(q, dev), T(c, dev), 2.0, 0.0, 1.0)
+    assert abs(float(loss)) <= 1e-6 and float(gq.abs().max()) <= 1e-6 and float(gc.abs().max()) <= 1e-6
+    st, pt = T(q, dev), T(np.concatenate([c, n]), dev)
+    z = torch.zeros(1, dtype=torch.int32, device=dev)
+    o = torch.ones(1, dtype=torch.int32, device=dev)
+    out = ops.triplet_fwd_bwd(st, pt, pt, z, z, o, 1, 0.1, 1.0)
+    el, gs, gp, gn = o_stl.triplet_loss_and_grads(q.astype(F64), c.astype(F64), n.astype(F64), 0.1, 1, F64)
+    assert abs(float(out[0]) - el) <= 1e-5 * max(1.0, abs(el))
+    assert np.abs(N(out[3]) - gs).max() <= 1e-5 * max(1e-6, np.abs(gs).max())
+
+
+def test_all_occurrences_hit_one_row(dev):
+    """every id equal: one segment of length n; the update equals the oracle's left-to-right sum"""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(1)
+    V, D, n = 50, 64, 5000
+    table = rng.standard_normal((V, D)).astype(np.float32)
+    rows = rng.standard_normal((n, D)).astype(np.float32)
+    ids = np.full(n, 17, np.int32)
+    t, a = T(table, dev), torch.full((V, D), 0.1, device=dev)
+    sid, perm = ops.segment_sort(T(ids, dev), V)
+    ops.sparse_adagrad(t, a, sid, perm, T(rows, dev), 0.05)
+    ep, ea = o_optim.sparse_adagrad_update(table.astype(F64), np.full((V, D), 0.1), ids, rows.astype(F64), 0.05, dtype=F64)
+    assert np.abs(N(t) - ep).max() <= 1e-4 * np.abs(ep).max()     # 5000-term f32 sum against f64
+    assert np.array_equal(N(t)[np.arange(V) != 17], table[np.arange(V) != 17])  # other rows untouched, bit for bit
+
+
+def test_retrieve_one_query_k_one_and_k_max(dev):
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(2)
+    q = (rng.integers(-8, 9, (1, 48)) / 4.0).astype(np.float32)
+    c = (rng.integers(-8, 9, (3000, 48)) / 4.0).astype(np.float32)
+    for k in (1, 1024):
+        s, i = ops.retrieve_topk(T(q, dev), T(c, dev), k)
+        es, ei = o_topk.batched_top_k(q, c, k, F64)
+        assert np.array_equal(N(i), ei) and np.array_equal(N(s), es.astype(np.float32))
+
+
+def test_argument_errors_raise_with_a_message(dev):
+    from esrecsys_amd import _lib, ops
+    q = torch.randn((4, 32), device=dev)
+    c = torch.randn((100, 32), device=dev)
+    with pytest.raises(_lib.EsrLibraryError, match="k"):
+        ops.retrieve_topk(q, c, 101)             # k > N
+    with pytest.raises(_lib.EsrLibraryError, match="k"):
+        ops.retrieve_topk(q, torch.randn((5000, 32), device=dev), 2000)   # k > 1024
+    with pytest.raises(ValueError, match="128"):
+        ops.inbatch_softmax_fwd_bwd(torch.randn((100, 128), device=dev), torch.randn((100, 128), device=dev), 1.0, 0.0,
+                                    100.0, precision="bf16x3")            # B not a multiple of 128
+    with pytest.raises(_lib.EsrLibraryError, match="not supported"):
+        ops.inbatch_softmax_fwd_bwd(torch.randn((64, 96), device=dev), torch.randn((64, 96), device=dev), 1.0, 0.0, 64.0)
+    with pytest.raises(TypeError):
+        ops.gather_rows(c, torch.zeros(3, dtype=torch.int64, device=dev))  # ids must be int32
+    with pytest.raises(TypeError, match="no CPU fallback"):
+        ops.gather_rows(c.cpu(), torch.zeros(3, dtype=torch.int32))
+    with pytest.raises(_lib.EsrLibraryError):
+        ops.spotify_fwd_bwd(torch.randn((100, 200), device=dev), torch.randn((10, 200), device=dev),
+                            torch.zeros(3, dtype=torch.int32, device=dev), torch.zeros(3, dtype=torch.int32, device=dev),
+                            1, 1, 1, 1.0)                                  # 2F > 256
+    # the failed calls left the library usable
+    assert ops.gather_rows(c, torch.zeros(3, dtype=torch.int32, device=dev)).shape == (3, 32)

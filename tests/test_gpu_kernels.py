@@ -231,6 +231,21 @@ def test_inbatch_transpose_detecting(dev, precision):
     assert rel_err(N(lse), else_) <= TOL and rel_err(N(gq), egq) <= TOL and rel_err(N(gc), egc) <= TOL
 
 
+@pytest.mark.parametrize("B,D", [(1, 32), (2, 128), (31, 64), (33, 128), (100, 32), (1000, 128), (4099, 64)])
+def test_inbatch_ragged_batch_vs_oracle(dev, B, D):
+    """batch sizes that are not a multiple of the 32-row tile: the ragged last tile is masked, not padded"""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(B)
+    q = (rng.standard_normal((B, D)) * 0.2).astype(np.float32)
+    c = (rng.standard_normal((B, D)) * 0.2).astype(np.float32)
+    loss, lse, gq, gc = ops.inbatch_softmax_fwd_bwd(T(q, dev), T(c, dev), 3.0, 0.2, float(B))
+    el, else_, egq, egc = o_stl.inbatch_softmax_loss_and_grads(q, c, 0.2, B, 3.0, F64)
+    assert abs(float(loss) - el) <= TOL * max(abs(el), 1e-3)
+    assert rel_err(N(lse), else_) <= TOL
+    assert np.abs(N(gq) - egq).max() <= TOL * max(np.abs(egq).max(), 1e-6)
+    assert np.abs(N(gc) - egc).max() <= TOL * max(np.abs(egc).max(), 1e-6)
+
+
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 def test_inbatch_config_c2_full_size(dev, precision):
     """BASELINE config C2: B = 8192, D = 128, fp64 oracle on the same inputs + checksum properties
