@@ -47,8 +47,11 @@ def test_bad_arguments_are_rejected_without_a_device(lib):
     assert lib.esr_gather_rows(None, 0, 10, 4, None, 0, None, None) == 0           # n == 0 is a no-op
     assert lib.esr_gather_rows(None, 0, 10, 4, None, 5, None, None) == EINVAL      # null pointers
     assert lib.esr_glove_fwd_bwd(None, None, 10, 4, None, None, 0, 0, None, None, None, None, 0, None) == EINVAL
-    assert lib.esr_inbatch_softmax_fwd_bwd(1, 1, 33, 128, 1.0, 0.0, 33.0, 1, 1, 1, 1, 1, 1 << 20, None) == EINVAL
-    assert b"multiple of 32" in lib.esr_last_error()
+    assert lib.esr_inbatch_softmax_fwd_bwd(16, 16, 0, 128, 1.0, 0.0, 33.0, 16, 16, 16, 16, 16, 1 << 20, None) == EINVAL
+    assert b"must be positive" in lib.esr_last_error()
+    assert lib.esr_inbatch_softmax_fwd_bwd_bf16x3(16, 16, 33, 128, 1.0, 0.0, 33.0, 16, 16, 16, 16, 16, 1 << 20,
+                                                  None) == EINVAL
+    assert b"multiple of 128" in lib.esr_last_error()
     assert lib.esr_inbatch_softmax_fwd_bwd(16, 16, 64, 100, 1.0, 0.0, 64.0, 16, 16, 16, 16, 16, 1 << 20, None) == EINVAL
     assert lib.esr_dense_adam(16, 16, 16, 16, 8, 1e-3, 0.9, 0.999, 1e-8, 0, None) == EINVAL  # step must be >= 1
     # workspace too small is reported before any launch
