@@ -58,6 +58,13 @@ def _wrap(state, inner):
     return {"params": inner} if "params" in state.params else inner
 
 
+import os as _os
+# Sorting the occurrence ids on a side stream beside the gather / MFMA kernels paid off while the sort was rocPRIM's
+# ~6-launch radix chain (13.4 vs 12.0 M pairs/s).  With the two-launch tile sort (21 us) the side stream only steals
+# bandwidth from the split kernel it overlaps: in line it is 0.406 ms per step, on the side stream 0.418.
+_PRESORT = _os.environ.get("ESR_INBATCH_PRESORT", "0") == "1"
+
+
 def train_step(state, scene, pos_product, neg_product, regularization, batch_size, scale=1.0, precision="auto"):
     """One optimizer step (pinterest/train_shop_the_look.py:93-109).  Returns ``(new_state, loss)``.
 
@@ -76,7 +83,7 @@ def train_step(state, scene, pos_product, neg_product, regularization, batch_siz
     Vs, Vp = st.shape[0], pt.shape[0]
     if neg_product is None:
         fused = FusedScatter([sid, pid], [0, 1], [Vs, Vp], None, paths) if sparse else None
-        if fused is not None:  # the sort only needs the ids: run it beside the gather / MFMA kernels
+        if fused is not None and _PRESORT:
             fused.index.presort()
         q = ops.gather_rows(st, sid)
         c = ops.gather_rows(pt, pid)
