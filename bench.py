@@ -107,7 +107,7 @@ def roofline_for(workload, kernels, B, D, rows, precision, occ_n=0, uniq=0):
 
 TIMED_GROUPS = {
     "gather": ["gather_rows", "gather_rows_multi"],
-    "inbatch_mfma": ["inbatch_softmax_fwd_bwd"],
+    "inbatch_mfma": ["inbatch_softmax_fwd_bwd", "inbatch_towers_fwd_bwd"],
     "triplet_fused": ["triplet_fwd_bwd"],
     "glove_fused": ["glove_fwd_bwd"],
     "segment_sort": ["segment_sort"],

@@ -79,14 +79,32 @@ __device__ __forceinline__ float pk_lo(uint32_t u) { return __uint_as_float(u <<
 __device__ __forceinline__ float pk_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
 // ---------------------------------------------------------------------------------------------------
+// Where the rows of Q / C come from: a dense [B, 128] f32 matrix (idx == null), or rows idx[i] of a tower table
+// (f32 or bf16) -- the gather is then folded into the split pre-pass and the merge kernels, and the step needs no
+// materialised Q / C at all.
+struct RowSrc {
+  const void* base;
+  const int32_t* idx;
+  int bf16;
+};
+__device__ __forceinline__ float4 rowsrc_load4(const RowSrc& s, int64_t row, int d) {  // elements d .. d+3 of row
+  const int64_t r = s.idx ? (int64_t)s.idx[row] : row;
+  if (s.bf16) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(s.base) + r * k3D + d);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xFFFF0000u));
+  }
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(s.base) + r * k3D + d);
+}
+
 // split3 pre-pass: one 256-thread block per 32-row chunk of one matrix (blockIdx.y selects Q or C).
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ X0, const float* __restrict__ X1,
+__global__ __launch_bounds__(256) void split3_kernel(RowSrc X0, RowSrc X1,
                                                     int64_t B, __bf16* __restrict__ R0, __bf16* __restrict__ T0,
                                                     __bf16* __restrict__ R1, __bf16* __restrict__ T1,
                                                     uint32_t* __restrict__ nrm) {
   __shared__ __attribute__((aligned(16))) __bf16 tl[3][128][40];
-  const float* X = blockIdx.y ? X1 : X0;
+  const RowSrc X = blockIdx.y ? X1 : X0;
   __bf16* R = blockIdx.y ? R1 : R0;
   __bf16* Tt = blockIdx.y ? T1 : T0;
   const int chunk = blockIdx.x, t = threadIdx.x;
@@ -96,7 +114,7 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ X
   float v[16];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const float4 f = *reinterpret_cast<const float4*>(X + grow * k3D + d0 + 4 * q);
+    const float4 f = rowsrc_load4(X, grow, d0 + 4 * q);
     v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
   }
   {  // largest squared row norm of this matrix: nrm[blockIdx.y] (non-negative floats order like their bit patterns)
@@ -550,7 +568,7 @@ __global__ __launch_bounds__(256) void inbatch3_rowmax_kernel(const __bf16* __re
 // ---------------------------------------------------------------------------------------------------
 template <bool QSIDE>
 __global__ __launch_bounds__(kBlock) void inbatch3_merge_kernel(
-    const float* __restrict__ X, const float* __restrict__ Y, int64_t B, int nsplit, const float* __restrict__ part_O,
+    RowSrc X, RowSrc Y, int64_t B, int nsplit, const float* __restrict__ part_O,
     const float* __restrict__ part_m, const float* __restrict__ part_l, float scale, float lam, float inv_bs,
     float* __restrict__ lse2, float* __restrict__ lse_nat, float* __restrict__ gX, double* __restrict__ loss_part) {
   __shared__ double sm[4];
@@ -574,8 +592,8 @@ __global__ __launch_bounds__(kBlock) void inbatch3_merge_kernel(
       o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
     }
     const float invL = 1.0f / L;
-    const float4 x = *reinterpret_cast<const float4*>(X + row * k3D + 4 * lig);
-    const float4 y = *reinterpret_cast<const float4*>(Y + row * k3D + 4 * lig);
+    const float4 x = rowsrc_load4(X, row, 4 * lig);
+    const float4 y = rowsrc_load4(Y, row, 4 * lig);
     const float xn2 = group_sum(x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w, G);
     const float xnorm = sqrtf(xn2);
     const float creg = xnorm > 1.f ? lam / xnorm : 0.f;
@@ -657,19 +675,32 @@ size_t esr_inbatch3_workspace_bytes(int64_t B, int D) {
   return inbatch3_ws_layout(B, 8, nullptr, nullptr);
 }
 
-int esr_inbatch_softmax_fwd_bwd_bf16x3(const float* Q, const float* C, int64_t B, int D, float scale,
-                                       float regularization, float batch_size, float* loss, float* lse, float* gQ,
-                                       float* gC, void* workspace, size_t workspace_bytes, esr_stream_t stream) {
-  ESR_REQUIRE(B > 0 && B % k3Owned == 0, "esr_inbatch_softmax_fwd_bwd_bf16x3: B=%lld must be a positive multiple of 128",
-              (long long)B);
-  ESR_REQUIRE(D == k3D, "esr_inbatch_softmax_fwd_bwd_bf16x3: D=%d not supported (128 only; use the f32 entry point)", D);
-  ESR_REQUIRE(Q && C && loss && gQ && gC, "esr_inbatch_softmax_fwd_bwd_bf16x3: null pointer");
-  ESR_REQUIRE(batch_size != 0.f, "esr_inbatch_softmax_fwd_bwd_bf16x3: batch_size must be non-zero");
-  ESR_REQUIRE((((uintptr_t)Q | (uintptr_t)C | (uintptr_t)gQ | (uintptr_t)gC) & 15) == 0,
-              "esr_inbatch_softmax_fwd_bwd_bf16x3: matrices must be 16-byte aligned");
+static int inbatch3_run(const char* who, RowSrc Qs, RowSrc Cs, int64_t B, int D, float scale, float regularization,
+                        float batch_size, float* loss, float* lse, float* gQ, float* gC, void* workspace,
+                        size_t workspace_bytes, esr_stream_t stream) {
+  if (!(B > 0 && B % k3Owned == 0)) {
+    set_error("%s: B=%lld must be a positive multiple of 128", who, (long long)B);
+    return ESR_EINVAL;
+  }
+  if (D != k3D) {
+    set_error("%s: D=%d not supported (128 only; use the f32 entry point)", who, D);
+    return ESR_EINVAL;
+  }
+  if (!(Qs.base && Cs.base && loss && gQ && gC)) {
+    set_error("%s: null pointer", who);
+    return ESR_EINVAL;
+  }
+  if (batch_size == 0.f) {
+    set_error("%s: batch_size must be non-zero", who);
+    return ESR_EINVAL;
+  }
+  if ((((uintptr_t)Qs.base | (uintptr_t)Cs.base | (uintptr_t)gQ | (uintptr_t)gC) & 15) != 0) {
+    set_error("%s: matrices must be 16-byte aligned", who);
+    return ESR_EINVAL;
+  }
   if (!workspace || workspace_bytes < esr_inbatch3_workspace_bytes(B, D) || ((uintptr_t)workspace & 15)) {
-    set_error("esr_inbatch_softmax_fwd_bwd_bf16x3: workspace %zu bytes < %zu required (or misaligned)",
-              workspace_bytes, esr_inbatch3_workspace_bytes(B, D));
+    set_error("%s: workspace %zu bytes < %zu required (or misaligned)", who, workspace_bytes,
+              esr_inbatch3_workspace_bytes(B, D));
     return ESR_EWORKSPACE;
   }
   hipStream_t st = as_stream(stream);
@@ -680,27 +711,46 @@ int esr_inbatch_softmax_fwd_bwd_bf16x3(const float* Q, const float* C, int64_t B
   const int nchunks = (int)(B / k3Chunk), grid = (int)(B / k3Owned) * nsplit;
   const int mgrid = (int)std::min<int64_t>(k3MergeBlocks, cdiv(B, kBlock / 32));
   (void)hipMemsetAsync(ws.nrm, 0, 8, st);
-  hipLaunchKernelGGL(split3_kernel, dim3(nchunks, 2), dim3(256), 0, st, Q, C, B, ws.Qr, ws.Qt, ws.Cr, ws.Ct, ws.nrm);
+  hipLaunchKernelGGL(split3_kernel, dim3(nchunks, 2), dim3(256), 0, st, Qs, Cs, B, ws.Qr, ws.Qt, ws.Cr, ws.Ct, ws.nrm);
   // pass Q: owned = Q, streamed = C
   hipLaunchKernelGGL(inbatch3_rowmax_kernel, dim3(grid), dim3(256), 0, st, (const __bf16*)ws.Qr, (const __bf16*)ws.Cr, B,
                      nsplit, sl2, (const uint32_t*)ws.nrm, ws.part_m);
   hipLaunchKernelGGL((inbatch3_kernel<true>), dim3(grid), dim3(256), 0, st, (const __bf16*)ws.Qr, (const __bf16*)ws.Cr,
                      (const __bf16*)ws.Ct, B, nsplit, sl2, (const float*)ws.part_m, ws.part_O, ws.part_l);
-  hipLaunchKernelGGL((inbatch3_merge_kernel<true>), dim3(mgrid), dim3(kBlock), 0, st, Q, C, B, nsplit,
+  hipLaunchKernelGGL((inbatch3_merge_kernel<true>), dim3(mgrid), dim3(kBlock), 0, st, Qs, Cs, B, nsplit,
                      (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale, regularization,
                      inv_bs, ws.lse2, lse, gQ, ws.loss_part);
   // pass C: owned = C, streamed = Q
   hipLaunchKernelGGL((inbatch3_kernel<false>), dim3(grid), dim3(256), 0, st, (const __bf16*)ws.Cr,
                      (const __bf16*)ws.Qr, (const __bf16*)ws.Qt, B, nsplit, sl2, (const float*)ws.lse2, ws.part_O,
                      ws.part_l);
-  hipLaunchKernelGGL((inbatch3_merge_kernel<false>), dim3(mgrid), dim3(kBlock), 0, st, C, Q, B, nsplit,
+  hipLaunchKernelGGL((inbatch3_merge_kernel<false>), dim3(mgrid), dim3(kBlock), 0, st, Cs, Qs, B, nsplit,
                      (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale, regularization,
                      inv_bs, ws.lse2, (float*)nullptr, gC, ws.loss_part + k3MergeBlocks);
   // the two merge launches wrote mgrid partials each at [0, mgrid) and [k3MergeBlocks, k3MergeBlocks + mgrid)
   if (mgrid < k3MergeBlocks)
     (void)hipMemsetAsync(ws.loss_part + mgrid, 0, sizeof(double) * (k3MergeBlocks - mgrid), st);
   finalize_scalar(ws.loss_part, k3MergeBlocks + mgrid, 1.0 / (double)batch_size, loss, st);
-  return check_launch("esr_inbatch_softmax_fwd_bwd_bf16x3");
+  return check_launch(who);
+}
+
+int esr_inbatch_softmax_fwd_bwd_bf16x3(const float* Q, const float* C, int64_t B, int D, float scale,
+                                       float regularization, float batch_size, float* loss, float* lse, float* gQ,
+                                       float* gC, void* workspace, size_t workspace_bytes, esr_stream_t stream) {
+  return inbatch3_run("esr_inbatch_softmax_fwd_bwd_bf16x3", RowSrc{Q, nullptr, 0}, RowSrc{C, nullptr, 0}, B, D, scale,
+                      regularization, batch_size, loss, lse, gQ, gC, workspace, workspace_bytes, stream);
+}
+
+int esr_inbatch_towers_fwd_bwd_bf16x3(const void* query_table, int64_t Vq, const void* cand_table, int64_t Vc,
+                                      int dtype, int D, const int32_t* query_ids, const int32_t* cand_ids, int64_t B,
+                                      float scale, float regularization, float batch_size, float* loss, float* lse,
+                                      float* gQ, float* gC, void* workspace, size_t workspace_bytes,
+                                      esr_stream_t stream) {
+  ESR_REQUIRE(Vq > 0 && Vc > 0 && query_ids && cand_ids, "esr_inbatch_towers_fwd_bwd_bf16x3: bad tables / ids");
+  ESR_REQUIRE(dtype == ESR_F32 || dtype == ESR_BF16, "esr_inbatch_towers_fwd_bwd_bf16x3: bad dtype %d", dtype);
+  return inbatch3_run("esr_inbatch_towers_fwd_bwd_bf16x3", RowSrc{query_table, query_ids, dtype == ESR_BF16},
+                      RowSrc{cand_table, cand_ids, dtype == ESR_BF16}, B, D, scale, regularization, batch_size, loss,
+                      lse, gQ, gC, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

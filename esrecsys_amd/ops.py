@@ -503,6 +503,28 @@ def topk_merge(scores, indices, k):
     return out_s, out_i
 
 
+def inbatch_towers_fwd_bwd(query_table, cand_table, query_ids, cand_ids, scale, regularization, batch_size):
+    """In-batch softmax step head straight from the tower tables (no materialised Q / C): rows query_table[query_ids],
+    cand_table[cand_ids]; tables f32 or bf16 [V, 128], B % 128 == 0.  Returns (loss[1], lse[B], gQ, gC) like
+    inbatch_softmax_fwd_bwd (bf16x3 path)."""
+    lib = _lib.load()
+    dt = _table_dtype(query_table, "query_table")
+    if _table_dtype(cand_table, "cand_table") != dt:
+        raise TypeError("both tower tables must have the same dtype")
+    query_ids, cand_ids = _req(query_ids, torch.int32, "query_ids"), _req(cand_ids, torch.int32, "cand_ids")
+    B, D, dev = query_ids.numel(), query_table.shape[1], query_table.device
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    lse = torch.empty(B, dtype=torch.float32, device=dev)
+    gQC = torch.empty((2 * B, D), dtype=torch.float32, device=dev)
+    ws = _ws(_ws_bytes("esr_inbatch3_workspace_bytes", B, D), dev)
+    check(lib.esr_inbatch_towers_fwd_bwd_bf16x3(_p(query_table), query_table.shape[0], _p(cand_table),
+                                                cand_table.shape[0], dt, D, _p(query_ids), _p(cand_ids), B, float(scale),
+                                                float(regularization), float(batch_size), _p(loss), _p(lse), _p(gQC[:B]),
+                                                _p(gQC[B:]), _p(ws), ws.numel(), _stream()),
+          "esr_inbatch_towers_fwd_bwd_bf16x3")
+    return loss, lse, gQC[:B], gQC[B:]
+
+
 def bucket_ids_by_owner(ids, world):
     """Stable bucket by owner = id % world.  Returns (local_rows, perm, counts[world] int64 on device)."""
     lib = _lib.load()

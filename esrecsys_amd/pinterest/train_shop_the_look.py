@@ -85,11 +85,15 @@ def train_step(state, scene, pos_product, neg_product, regularization, batch_siz
         fused = FusedScatter([sid, pid], [0, 1], [Vs, Vp], None, paths) if sparse else None
         if fused is not None and _PRESORT:
             fused.index.presort()
-        q = ops.gather_rows(st, sid)
-        c = ops.gather_rows(pt, pid)
-        if q.dtype != torch.float32:  # bf16 towers (fp32 accumulators): scores and gradients are computed in f32
-            q, c = ops.unpermute_rows_to_f32(q, None), ops.unpermute_rows_to_f32(c, None)
-        loss, _, gq, gc = ops.inbatch_softmax_fwd_bwd(q, c, scale, regularization, batch_size, precision=precision)
+        if precision in ("auto", "bf16x3") and st.shape[1] == 128 and B % 128 == 0 and st.dtype == pt.dtype:
+            # the bf16x3 path reads the tower rows itself (gather folded into its split and merge kernels)
+            loss, _, gq, gc = ops.inbatch_towers_fwd_bwd(st, pt, sid, pid, scale, regularization, batch_size)
+        else:
+            q = ops.gather_rows(st, sid)
+            c = ops.gather_rows(pt, pid)
+            if q.dtype != torch.float32:  # bf16 towers (fp32 accumulators): scores and gradients are computed in f32
+                q, c = ops.unpermute_rows_to_f32(q, None), ops.unpermute_rows_to_f32(c, None)
+            loss, _, gq, gc = ops.inbatch_softmax_fwd_bwd(q, c, scale, regularization, batch_size, precision=precision)
         if fused is not None:
             fused.rows = gq._base  # [gQ ; gC]
         g_scene = RowGrads([sid], gq, st.shape, fused)

@@ -116,6 +116,15 @@ int esr_inbatch_softmax_fwd_bwd_bf16x3(const float* Q, const float* C, int64_t B
                                        float regularization, float batch_size, float* loss, float* lse,
                                        float* gQ, float* gC, void* workspace, size_t workspace_bytes,
                                        esr_stream_t stream);
+/* The whole in-batch step head without materialised Q / C: row i of Q is query_table[query_ids[i]], row i of C is
+ * cand_table[cand_ids[i]] (tables f32 or bf16, dtype = ESR_F32 / ESR_BF16; the id-embedding towers that replace
+ * pinterest/models.py:64-70).  The gather is folded into the bf16-plane split and into the merge kernels; gQ / gC
+ * are the per-occurrence gradient rows [B, 128].  Same workspace as above. */
+int esr_inbatch_towers_fwd_bwd_bf16x3(const void* query_table, int64_t Vq, const void* cand_table, int64_t Vc,
+                                      int dtype, int D, const int32_t* query_ids, const int32_t* cand_ids,
+                                      int64_t B, float scale, float regularization, float batch_size,
+                                      float* loss, float* lse, float* gQ, float* gC, void* workspace,
+                                      size_t workspace_bytes, esr_stream_t stream);
 
 /* ---- G4 (build's production optimizer): sort + segment-reduce + sparse Adagrad -----------
  * Replaces the dense V x D gradient + dense optimizer sweep of

@@ -246,6 +246,26 @@ def test_inbatch_ragged_batch_vs_oracle(dev, B, D):
     assert np.abs(N(gc) - egc).max() <= TOL * max(np.abs(egc).max(), 1e-6)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_inbatch_towers_gather_folded_in(dev, dtype):
+    """the step head that reads the tower rows itself == gather + dense head, bit for bit; and vs the oracle"""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(21)
+    Vq, Vc, D, B = 3000, 7000, 128, 640
+    qt = T((rng.standard_normal((Vq, D)) * 0.1).astype(np.float32), dev, dtype)
+    ct = T((rng.standard_normal((Vc, D)) * 0.1).astype(np.float32), dev, dtype)
+    qi = rng.integers(0, Vq, B).astype(np.int32)
+    ci = rng.integers(0, Vc, B).astype(np.int32)
+    ci[3] = ci[2]                                   # the same candidate row twice in the batch
+    loss, lse, gq, gc = ops.inbatch_towers_fwd_bwd(qt, ct, T(qi, dev), T(ci, dev), 6.0, 0.1, float(B))
+    q = ops.unpermute_rows_to_f32(ops.gather_rows(qt, T(qi, dev)), None)
+    c = ops.unpermute_rows_to_f32(ops.gather_rows(ct, T(ci, dev)), None)
+    l2, lse2, gq2, gc2 = ops.inbatch_softmax_fwd_bwd(q, c, 6.0, 0.1, float(B), precision="bf16x3")
+    assert torch.equal(loss, l2) and torch.equal(lse, lse2) and torch.equal(gq, gq2) and torch.equal(gc, gc2)
+    el, else_, egq, egc = o_stl.inbatch_softmax_loss_and_grads(N(q).astype(F64), N(c).astype(F64), 0.1, B, 6.0, F64)
+    assert abs(float(loss) - el) / abs(el) <= TOL and rel_err(N(gq), egq) <= TOL and rel_err(N(gc), egc) <= TOL
+
+
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 def test_inbatch_config_c2_full_size(dev, precision):
     """BASELINE config C2: B = 8192, D = 128, fp64 oracle on the same inputs + checksum properties
