@@ -102,7 +102,7 @@ __device__ __forceinline__ float4 rowsrc_load4(const RowSrc& s, int64_t row, int
 __global__ __launch_bounds__(256) void split3_kernel(RowSrc X0, RowSrc X1,
                                                     int64_t B, __bf16* __restrict__ R0, __bf16* __restrict__ T0,
                                                     __bf16* __restrict__ R1, __bf16* __restrict__ T1,
-                                                    uint32_t* __restrict__ nrm) {
+                                                    float* __restrict__ nrm) {
   __shared__ __attribute__((aligned(16))) __bf16 tl[3][128][40];
   const RowSrc X = blockIdx.y ? X1 : X0;
   __bf16* R = blockIdx.y ? R1 : R0;
@@ -117,17 +117,18 @@ __global__ __launch_bounds__(256) void split3_kernel(RowSrc X0, RowSrc X1,
     const float4 f = rowsrc_load4(X, grow, d0 + 4 * q);
     v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
   }
-  {  // largest squared row norm of this matrix: nrm[blockIdx.y] (non-negative floats order like their bit patterns)
+  {  // largest squared row norm of the four waves' rows -> nrm[matrix][chunk][wave]
     float ss = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) ss = fmaf(v[e], v[e], ss);
     ss += __shfl_xor(ss, 1, 64);
     ss += __shfl_xor(ss, 2, 64);
     ss += __shfl_xor(ss, 4, 64);
-    ss = fmaxf(ss, __shfl_xor(ss, 8, 64));   // one atomic per wave, not per row: 16 384 atomics on two addresses
-    ss = fmaxf(ss, __shfl_xor(ss, 16, 64));  // serialised and tripled the kernel's time
+    ss = fmaxf(ss, __shfl_xor(ss, 8, 64));
+    ss = fmaxf(ss, __shfl_xor(ss, 16, 64));
     ss = fmaxf(ss, __shfl_xor(ss, 32, 64));
-    if ((t & 63) == 0) atomicMax(nrm + blockIdx.y, __float_as_uint(ss));
+    // one slot per wave (no atomics, nothing to zero beforehand); the row-max kernel reduces the 8 * nchunks slots
+    if ((t & 63) == 0) nrm[((int64_t)blockIdx.y * gridDim.x + chunk) * 4 + (t >> 6)] = ss;
   }
   bf16x8 p[3][2];
 #pragma unroll
@@ -493,7 +494,7 @@ constexpr int kRmGroup = 4;
 constexpr float kRmSafeBound = 28.0f;  // log2 units: every exp2 argument then lies in [-56, 0]
 __global__ __launch_bounds__(256) void inbatch3_rowmax_kernel(const __bf16* __restrict__ Xr,
                                                              const __bf16* __restrict__ Yr, int64_t B, int nsplit,
-                                                             float sl2, const uint32_t* __restrict__ nrm,
+                                                             float sl2, const float* __restrict__ nrm,
                                                              float* __restrict__ part_m) {
   __shared__ __attribute__((aligned(16))) char lds[2 * kRmGroup * kPlaneBytes];
   const int t = threadIdx.x, lane = t & 63;
@@ -505,7 +506,18 @@ __global__ __launch_bounds__(256) void inbatch3_rowmax_kernel(const __bf16* __re
     // Cauchy-Schwarz: |s_ij| * sl2 <= bound for every pair.  When the whole score range is narrow (norm-regularised
     // towers at the usual temperatures) the bound itself is a safe fixed exponent reference and the row-max GEMM
     // (26 us at B = 8192) is skipped; otherwise fall through to the exact row maxima.
-    const float bound = sqrtf(__uint_as_float(nrm[0]) * __uint_as_float(nrm[1])) * fabsf(sl2);
+    const int nslots = (int)(B / k3Chunk) * 4;  // per matrix
+    float mq = 0.f, mc = 0.f;
+    for (int i = lane; i < nslots; i += 64) {
+      mq = fmaxf(mq, nrm[i]);
+      mc = fmaxf(mc, nrm[nslots + i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mq = fmaxf(mq, __shfl_xor(mq, o, 64));
+      mc = fmaxf(mc, __shfl_xor(mc, o, 64));
+    }
+    const float bound = sqrtf(mq * mc) * fabsf(sl2);
     if (bound <= kRmSafeBound) {
       if (h == 0) part_m[(int64_t)split * B + xrow] = bound;
       return;
@@ -625,7 +637,7 @@ struct Inbatch3Ws {
   __bf16 *Qr, *Qt, *Cr, *Ct;
   float *part_O, *part_m, *part_l, *lse2;
   double* loss_part;  // [2 * k3MergeBlocks]
-  uint32_t* nrm;      // [2]: bit patterns of the largest squared row norm of Q and of C
+  float* nrm;         // [2][B / 32][4]: largest squared row norm per (matrix, chunk, wave) of the split pre-pass
 };
 static size_t inbatch3_ws_layout(int64_t B, int nsplit, char* base, Inbatch3Ws* ws) {
   size_t off = 0;
@@ -643,7 +655,7 @@ static size_t inbatch3_ws_layout(int64_t B, int nsplit, char* base, Inbatch3Ws* 
   w.part_l = (float*)take((size_t)nsplit * B * 4);
   w.lse2 = (float*)take((size_t)B * 4);
   w.loss_part = (double*)take(sizeof(double) * 2 * k3MergeBlocks);
-  w.nrm = (uint32_t*)take(256);
+  w.nrm = (float*)take((size_t)2 * (B / k3Chunk) * 4 * sizeof(float));
   if (ws) *ws = w;
   return off;
 }
@@ -710,11 +722,10 @@ static int inbatch3_run(const char* who, RowSrc Qs, RowSrc Cs, int64_t B, int D,
   const float inv_bs = 1.0f / batch_size, sl2 = scale * k3Log2e;
   const int nchunks = (int)(B / k3Chunk), grid = (int)(B / k3Owned) * nsplit;
   const int mgrid = (int)std::min<int64_t>(k3MergeBlocks, cdiv(B, kBlock / 32));
-  (void)hipMemsetAsync(ws.nrm, 0, 8, st);
   hipLaunchKernelGGL(split3_kernel, dim3(nchunks, 2), dim3(256), 0, st, Qs, Cs, B, ws.Qr, ws.Qt, ws.Cr, ws.Ct, ws.nrm);
   // pass Q: owned = Q, streamed = C
   hipLaunchKernelGGL(inbatch3_rowmax_kernel, dim3(grid), dim3(256), 0, st, (const __bf16*)ws.Qr, (const __bf16*)ws.Cr, B,
-                     nsplit, sl2, (const uint32_t*)ws.nrm, ws.part_m);
+                     nsplit, sl2, (const float*)ws.nrm, ws.part_m);
   hipLaunchKernelGGL((inbatch3_kernel<true>), dim3(grid), dim3(256), 0, st, (const __bf16*)ws.Qr, (const __bf16*)ws.Cr,
                      (const __bf16*)ws.Ct, B, nsplit, sl2, (const float*)ws.part_m, ws.part_O, ws.part_l);
   hipLaunchKernelGGL((inbatch3_merge_kernel<true>), dim3(mgrid), dim3(kBlock), 0, st, Qs, Cs, B, nsplit,
