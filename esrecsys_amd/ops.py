@@ -10,7 +10,15 @@ from . import _lib
 from ._lib import ESR_BF16, ESR_F32, GLOVE_DIAGONAL, GLOVE_REFERENCE, check  # noqa: F401
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream on the current device.  torch.cuda.current_stream() builds a Stream
+    object through several Python layers (~2 us, four or more times per step on launch-bound steps); the raw getter
+    is one C call."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
