@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256) void inbatch3_rowmax_kernel(const __bf16* __re
 // ---------------------------------------------------------------------------------------------------
 template <bool QSIDE>
 __global__ __launch_bounds__(kBlock) void inbatch3_merge_kernel(
-    RowSrc X, RowSrc Y, int64_t B, int nsplit, const float* __restrict__ part_O,
+    RowSrc X, RowSrc Y, const int32_t* __restrict__ out_idx, int64_t B, int nsplit, const float* __restrict__ part_O,
     const float* __restrict__ part_m, const float* __restrict__ part_l, float scale, float lam, float inv_bs,
     float* __restrict__ lse2, float* __restrict__ lse_nat, float* __restrict__ gX, double* __restrict__ loss_part) {
   __shared__ double sm[4];
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(kBlock) void inbatch3_merge_kernel(
     g.y = (scale * (o.y * invL - y.y) + creg * x.y) * inv_bs;
     g.z = (scale * (o.z * invL - y.z) + creg * x.z) * inv_bs;
     g.w = (scale * (o.w * invL - y.w) + creg * x.w) * inv_bs;
-    *reinterpret_cast<float4*>(gX + row * k3D + 4 * lig) = g;
+    *reinterpret_cast<float4*>(gX + (out_idx ? (int64_t)out_idx[row] : row) * k3D + 4 * lig) = g;
     float row_loss = lam * fmaxf(xnorm - 1.f, 0.f);
     if (QSIDE) {
       const float diag = group_sum(x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w, G);
@@ -687,7 +687,8 @@ size_t esr_inbatch3_workspace_bytes(int64_t B, int D) {
   return inbatch3_ws_layout(B, 8, nullptr, nullptr);
 }
 
-static int inbatch3_run(const char* who, RowSrc Qs, RowSrc Cs, int64_t B, int D, float scale, float regularization,
+static int inbatch3_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* gq_rows, const int32_t* gc_rows, int64_t B,
+                        int D, float scale, float regularization,
                         float batch_size, float* loss, float* lse, float* gQ, float* gC, void* workspace,
                         size_t workspace_bytes, esr_stream_t stream) {
   if (!(B > 0 && B % k3Owned == 0)) {
@@ -728,14 +729,14 @@ static int inbatch3_run(const char* who, RowSrc Qs, RowSrc Cs, int64_t B, int D,
                      nsplit, sl2, (const float*)ws.nrm, ws.part_m);
   hipLaunchKernelGGL((inbatch3_kernel<true>), dim3(grid), dim3(256), 0, st, (const __bf16*)ws.Qr, (const __bf16*)ws.Cr,
                      (const __bf16*)ws.Ct, B, nsplit, sl2, (const float*)ws.part_m, ws.part_O, ws.part_l);
-  hipLaunchKernelGGL((inbatch3_merge_kernel<true>), dim3(mgrid), dim3(kBlock), 0, st, Qs, Cs, B, nsplit,
+  hipLaunchKernelGGL((inbatch3_merge_kernel<true>), dim3(mgrid), dim3(kBlock), 0, st, Qs, Cs, gq_rows, B, nsplit,
                      (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale, regularization,
                      inv_bs, ws.lse2, lse, gQ, ws.loss_part);
   // pass C: owned = C, streamed = Q
   hipLaunchKernelGGL((inbatch3_kernel<false>), dim3(grid), dim3(256), 0, st, (const __bf16*)ws.Cr,
                      (const __bf16*)ws.Qr, (const __bf16*)ws.Qt, B, nsplit, sl2, (const float*)ws.lse2, ws.part_O,
                      ws.part_l);
-  hipLaunchKernelGGL((inbatch3_merge_kernel<false>), dim3(mgrid), dim3(kBlock), 0, st, Cs, Qs, B, nsplit,
+  hipLaunchKernelGGL((inbatch3_merge_kernel<false>), dim3(mgrid), dim3(kBlock), 0, st, Cs, Qs, gc_rows, B, nsplit,
                      (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale, regularization,
                      inv_bs, ws.lse2, (float*)nullptr, gC, ws.loss_part + k3MergeBlocks);
   // the two merge launches wrote mgrid partials each at [0, mgrid) and [k3MergeBlocks, k3MergeBlocks + mgrid)
@@ -748,19 +749,22 @@ static int inbatch3_run(const char* who, RowSrc Qs, RowSrc Cs, int64_t B, int D,
 int esr_inbatch_softmax_fwd_bwd_bf16x3(const float* Q, const float* C, int64_t B, int D, float scale,
                                        float regularization, float batch_size, float* loss, float* lse, float* gQ,
                                        float* gC, void* workspace, size_t workspace_bytes, esr_stream_t stream) {
-  return inbatch3_run("esr_inbatch_softmax_fwd_bwd_bf16x3", RowSrc{Q, nullptr, 0}, RowSrc{C, nullptr, 0}, B, D, scale,
+  return inbatch3_run("esr_inbatch_softmax_fwd_bwd_bf16x3", RowSrc{Q, nullptr, 0}, RowSrc{C, nullptr, 0}, nullptr, nullptr,
+                      B, D, scale,
                       regularization, batch_size, loss, lse, gQ, gC, workspace, workspace_bytes, stream);
 }
 
 int esr_inbatch_towers_fwd_bwd_bf16x3(const void* query_table, int64_t Vq, const void* cand_table, int64_t Vc,
-                                      int dtype, int D, const int32_t* query_ids, const int32_t* cand_ids, int64_t B,
+                                      int dtype, int D, const int32_t* query_ids, const int32_t* cand_ids,
+                                      const int32_t* gq_rows, const int32_t* gc_rows, int64_t B,
                                       float scale, float regularization, float batch_size, float* loss, float* lse,
                                       float* gQ, float* gC, void* workspace, size_t workspace_bytes,
                                       esr_stream_t stream) {
   ESR_REQUIRE(Vq > 0 && Vc > 0 && query_ids && cand_ids, "esr_inbatch_towers_fwd_bwd_bf16x3: bad tables / ids");
   ESR_REQUIRE(dtype == ESR_F32 || dtype == ESR_BF16, "esr_inbatch_towers_fwd_bwd_bf16x3: bad dtype %d", dtype);
   return inbatch3_run("esr_inbatch_towers_fwd_bwd_bf16x3", RowSrc{query_table, query_ids, dtype == ESR_BF16},
-                      RowSrc{cand_table, cand_ids, dtype == ESR_BF16}, B, D, scale, regularization, batch_size, loss,
+                      RowSrc{cand_table, cand_ids, dtype == ESR_BF16}, gq_rows, gc_rows, B, D, scale, regularization,
+                      batch_size, loss,
                       lse, gQ, gC, workspace, workspace_bytes, stream);
 }
 

@@ -187,6 +187,7 @@ constexpr int kBucketMaxWorld = 8;  // one MI355X node
 constexpr int kBucketMaxN = 32768;
 constexpr int kBucketMaxPerThread = kBucketMaxN / kBucketThreads;  // 64
 __global__ __launch_bounds__(kBucketThreads) void bucket_small_kernel(const int32_t* __restrict__ ids, int n, int world,
+                                                                     int32_t* __restrict__ inverse,
                                                                      int32_t* __restrict__ local_rows,
                                                                      int32_t* __restrict__ perm,
                                                                      int64_t* __restrict__ counts) {
@@ -254,14 +255,19 @@ __global__ __launch_bounds__(kBucketThreads) void bucket_small_kernel(const int3
       }
     local_rows[pos] = (int32_t)(id / (uint32_t)world);
     perm[pos] = lo + i;
+    if (inverse) inverse[lo + i] = pos;
   }
 }
 
 __global__ __launch_bounds__(kBlock) void local_rows_kernel(const int32_t* __restrict__ ids,
                                                            const int32_t* __restrict__ perm, int64_t n, int world,
-                                                           int32_t* __restrict__ local_rows) {
-  for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < n; k += (int64_t)gridDim.x * kBlock)
-    local_rows[k] = (int32_t)((uint32_t)ids[perm[k]] / (uint32_t)world);
+                                                           int32_t* __restrict__ local_rows,
+                                                           int32_t* __restrict__ inverse) {
+  for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < n; k += (int64_t)gridDim.x * kBlock) {
+    const int32_t i = perm[k];
+    local_rows[k] = (int32_t)((uint32_t)ids[i] / (uint32_t)world);
+    if (inverse) inverse[i] = (int32_t)k;
+  }
 }
 
 // keysT[t][v] = scores[v][t]
@@ -514,15 +520,16 @@ size_t esr_bucket_workspace_bytes(int64_t n) {
 }
 
 int esr_bucket_ids_by_owner(const int32_t* ids, int64_t n, int world, int32_t* local_rows, int32_t* perm,
-                            int64_t* counts, void* workspace, size_t workspace_bytes, esr_stream_t stream) {
+                            int32_t* inverse, int64_t* counts, void* workspace, size_t workspace_bytes,
+                            esr_stream_t stream) {
   ESR_REQUIRE(n >= 0 && world > 0 && n < ((int64_t)1 << 31), "esr_bucket_ids_by_owner: bad sizes n=%lld world=%d",
               (long long)n, world);
   ESR_REQUIRE(counts, "esr_bucket_ids_by_owner: null counts");
   hipStream_t st = as_stream(stream);
   if (n > 0 && n <= kBucketMaxN && world <= kBucketMaxWorld) {
     ESR_REQUIRE(ids && local_rows && perm, "esr_bucket_ids_by_owner: null pointer");
-    hipLaunchKernelGGL(bucket_small_kernel, dim3(1), dim3(kBucketThreads), 0, st, ids, (int)n, world, local_rows, perm,
-                       counts);
+    hipLaunchKernelGGL(bucket_small_kernel, dim3(1), dim3(kBucketThreads), 0, st, ids, (int)n, world, inverse,
+                       local_rows, perm, counts);
     return check_launch("esr_bucket_ids_by_owner(small)");
   }
   if (hipMemsetAsync(counts, 0, sizeof(int64_t) * world, st) != hipSuccess) return check_launch("esr_bucket memset");
@@ -549,7 +556,7 @@ int esr_bucket_ids_by_owner(const int32_t* ids, int64_t n, int world, int32_t* l
     return ESR_ELAUNCH;
   }
   hipLaunchKernelGGL(local_rows_kernel, dim3(grid), dim3(kBlock), 0, st, ids, (const int32_t*)perm, n, world,
-                     local_rows);
+                     local_rows, inverse);
   return check_launch("esr_bucket_ids_by_owner");
 }
 

@@ -511,10 +511,12 @@ def topk_merge(scores, indices, k):
     return out_s, out_i
 
 
-def inbatch_towers_fwd_bwd(query_table, cand_table, query_ids, cand_ids, scale, regularization, batch_size):
+def inbatch_towers_fwd_bwd(query_table, cand_table, query_ids, cand_ids, scale, regularization, batch_size,
+                           grad_positions=None):
     """In-batch softmax step head straight from the tower tables (no materialised Q / C): rows query_table[query_ids],
     cand_table[cand_ids]; tables f32 or bf16 [V, 128], B % 128 == 0.  Returns (loss[1], lse[B], gQ, gC) like
-    inbatch_softmax_fwd_bwd (bf16x3 path)."""
+    inbatch_softmax_fwd_bwd (bf16x3 path).  grad_positions = (gq_rows, gc_rows) int32 [B] each: the gradient rows
+    are scattered into ONE [2B, 128] buffer at those rows instead (returned as gQ, with gC = None)."""
     lib = _lib.load()
     dt = _table_dtype(query_table, "query_table")
     if _table_dtype(cand_table, "cand_table") != dt:
@@ -525,23 +527,35 @@ def inbatch_towers_fwd_bwd(query_table, cand_table, query_ids, cand_ids, scale, 
     lse = torch.empty(B, dtype=torch.float32, device=dev)
     gQC = torch.empty((2 * B, D), dtype=torch.float32, device=dev)
     ws = _ws(_ws_bytes("esr_inbatch3_workspace_bytes", B, D), dev)
+    if grad_positions is not None:
+        gqr, gcr = _req(grad_positions[0], torch.int32, "gq_rows"), _req(grad_positions[1], torch.int32, "gc_rows")
+        gq_ptr = gc_ptr = _p(gQC)
+    else:
+        gqr = gcr = None
+        gq_ptr, gc_ptr = _p(gQC[:B]), _p(gQC[B:])
     check(lib.esr_inbatch_towers_fwd_bwd_bf16x3(_p(query_table), query_table.shape[0], _p(cand_table),
-                                                cand_table.shape[0], dt, D, _p(query_ids), _p(cand_ids), B, float(scale),
-                                                float(regularization), float(batch_size), _p(loss), _p(lse), _p(gQC[:B]),
-                                                _p(gQC[B:]), _p(ws), ws.numel(), _stream()),
+                                                cand_table.shape[0], dt, D, _p(query_ids), _p(cand_ids), _p(gqr), _p(gcr),
+                                                B, float(scale), float(regularization), float(batch_size), _p(loss),
+                                                _p(lse), gq_ptr, gc_ptr, _p(ws), ws.numel(), _stream()),
           "esr_inbatch_towers_fwd_bwd_bf16x3")
+    if grad_positions is not None:
+        return loss, lse, gQC, None
     return loss, lse, gQC[:B], gQC[B:]
 
 
-def bucket_ids_by_owner(ids, world):
-    """Stable bucket by owner = id % world.  Returns (local_rows, perm, counts[world] int64 on device)."""
+def bucket_ids_by_owner(ids, world, want_inverse=False):
+    """Stable bucket by owner = id % world.  Returns (local_rows, perm, counts[world] int64 on device) and, with
+    want_inverse, also inverse with inverse[perm[k]] = k."""
     lib = _lib.load()
     ids = _req(ids, torch.int32, "ids")
     n = ids.numel()
     local_rows = torch.empty_like(ids)
     perm = torch.empty_like(ids)
+    inverse = torch.empty_like(ids) if want_inverse else None
     counts = torch.empty(world, dtype=torch.int64, device=ids.device)
     ws = _ws(_ws_bytes("esr_bucket_workspace_bytes", n), ids.device)
-    check(lib.esr_bucket_ids_by_owner(_p(ids), n, world, _p(local_rows), _p(perm), _p(counts), _p(ws), ws.numel(),
-                                      _stream()), "esr_bucket_ids_by_owner")
+    check(lib.esr_bucket_ids_by_owner(_p(ids), n, world, _p(local_rows), _p(perm), _p(inverse), _p(counts), _p(ws),
+                                      ws.numel(), _stream()), "esr_bucket_ids_by_owner")
+    if want_inverse:
+        return local_rows, perm, counts, inverse
     return local_rows, perm, counts

@@ -27,6 +27,15 @@ import torch
 import torch.distributed as dist
 
 
+def _a2a(group, out, inp, out_splits=None, in_splits=None):
+    """all_to_all_single of a ShardedTableGroup: RCCL send / recv on the current stream when available
+    (esrecsys_amd/rccl.py: no stream hand-overs), else torch.distributed."""
+    x = group.exchange()
+    if x is not None:
+        return x.all_to_all_single(out, inp, out_splits, in_splits)
+    return dist.all_to_all_single(out, inp, out_splits, in_splits, group=group.pg)
+
+
 class RowShardedTable:
     """This rank's shard of one table: rows rank, rank + G, rank + 2G, ... and their fp32 accumulator."""
 
@@ -48,11 +57,12 @@ def shard_of(table, world, rank):
 class RoutingPlan:
     """Where the ids of one group lookup go: everything that does not depend on table contents."""
 
-    def __init__(self, group, n, local_rows, perm, send_counts, recv_counts):
+    def __init__(self, group, n, local_rows, perm, send_counts, recv_counts, inv=None):
         self.group = group
         self.n = n
         self.local_rows = local_rows        # int32 [n]: vid // G in bucket (owner-major, stable) order
         self.perm = perm                    # int32 [n]: bucket order -> original position
+        self.inv = inv                      # int32 [n]: original position -> bucket order (inv[perm[k]] = k)
         self.send_counts = send_counts      # python ints per peer: ids this rank asks of that peer
         self.recv_counts = recv_counts      # python ints per peer: ids that peer asks of this rank
         self.recv_local_rows = None         # int32 [sum(recv_counts)]: virtual local rows requested of this rank
@@ -76,8 +86,7 @@ class RoutingPlan:
         if self.recv_local_rows is None:
             g = self.group
             self.recv_local_rows = torch.empty(sum(self.recv_counts), dtype=torch.int32, device=self.local_rows.device)
-            dist.all_to_all_single(self.recv_local_rows, self.local_rows, self.recv_counts, self.send_counts,
-                                   group=g.pg)
+            _a2a(g, self.recv_local_rows, self.local_rows, self.recv_counts, self.send_counts)
             if self.recv_local_rows.numel():  # the owner-side sort needs the ids only: do it ahead of the step
                 self.owner_sorted = g.k.segment_sort(self.recv_local_rows, g.loff[-1])
         return self.recv_local_rows
@@ -111,8 +120,8 @@ class PendingPlans:
             if self.event is not None:
                 self.event.synchronize()
             both = self.both_host
-            self.plans = [RoutingPlan(group, n, local_rows, perm, both[0, :, i].tolist(), both[1, :, i].tolist())
-                          for i, (group, n, local_rows, perm, _) in enumerate(self.parts)]
+            self.plans = [RoutingPlan(group, n, local_rows, perm, both[0, :, i].tolist(), both[1, :, i].tolist(), inv)
+                          for i, (group, n, local_rows, perm, _, inv) in enumerate(self.parts)]
             for p in self.plans:
                 p.exchange_ids()
             self.parts = self.both_dev = None
@@ -126,12 +135,12 @@ def begin_plans(lookups):
     k, G, pg = g0.k, g0.world, g0.pg
     parts = []
     for group, vids in lookups:
-        local_rows, perm, counts = k.bucket_ids_by_owner(vids, G)
-        parts.append((group, vids.numel(), local_rows, perm, counts))
+        local_rows, perm, counts, inv = k.bucket_ids_by_owner(vids, G, want_inverse=True)
+        parts.append((group, vids.numel(), local_rows, perm, counts, inv))
     # counts laid out [peer][lookup] so that all_to_all_single hands every peer its L counts
     send = torch.stack([p[4] for p in parts], dim=1).contiguous()          # [G, L] int64
     recv = torch.empty_like(send)
-    dist.all_to_all_single(recv, send, group=pg)
+    _a2a(g0, recv, send)
     both = torch.stack([send, recv])
     if both.is_cuda:
         host = _pinned_like(both)
@@ -184,6 +193,17 @@ class ShardedTableGroup:
             self.voff.append(self.voff[-1] + G * ((t.num_rows + G - 1) // G))
         self.loff = [o // G for o in self.voff]  # the same boundaries in virtual LOCAL rows
         self.dim = self.tables[0].local.shape[1] if self.tables[0].local.dim() > 1 else 1
+        self._xch = False  # DirectExchange, None (use torch.distributed) or False (not resolved yet)
+
+    def exchange(self):
+        if self._xch is False:
+            dev = self.tables[0].local.device
+            if dev.type == "cuda":
+                from . import rccl
+                self._xch = rccl.exchange_for(self.pg, dev)
+            else:
+                self._xch = None
+        return self._xch
 
     def virtual_ids(self, id_tensors, slots):
         """[ids_i + voff[slots[i]]] concatenated: id_tensors[i] indexes table slots[i]."""
@@ -194,8 +214,9 @@ class ShardedTableGroup:
     def plan(self, vids, stream=None, ids_ready=False):
         return make_plans([(self, vids)], stream=stream, ids_ready=ids_ready)[0]
 
-    def lookup(self, plan):
-        """rows[i] = table_of(vid_i)[id_i] for this rank's virtual ids -> [n, D] in the order of the ids."""
+    def lookup_bucketed(self, plan):
+        """The looked-up rows in BUCKET order (row plan.inv[i] belongs to virtual id i), in the tables' dtype --
+        for consumers that can index them themselves and so skip the un-permute pass."""
         k = self.k
         plan.wait_ready()
         recv = plan.exchange_ids()
@@ -204,23 +225,29 @@ class ShardedTableGroup:
         else:
             served = k.gather_rows_multi([t.local for t in self.tables], self.loff, recv)
         back = torch.empty((plan.n, self.dim), dtype=served.dtype, device=served.device)
-        dist.all_to_all_single(back, served, plan.send_counts, plan.recv_counts, group=self.pg)
-        # bucket order -> id order; bf16 tables (config 4) cross xGMI as bf16 and become f32 here
-        return k.unpermute_rows_to_f32(back, plan.perm)
+        _a2a(self, back, served, plan.send_counts, plan.recv_counts)
+        return back
 
-    def route_grads(self, plan, grad_rows):
-        """Per-occurrence gradient rows (order of the looked-up ids) -> rows on their owners."""
+    def lookup(self, plan):
+        """rows[i] = table_of(vid_i)[id_i] for this rank's virtual ids -> [n, D] in the order of the ids."""
+        # bucket order -> id order; bf16 tables (config 4) cross xGMI as bf16 and become f32 here
+        return self.k.unpermute_rows_to_f32(self.lookup_bucketed(plan), plan.perm)
+
+    def route_grads(self, plan, grad_rows, bucketed=False):
+        """Per-occurrence gradient rows (order of the looked-up ids, or already in bucket order) -> rows on their
+        owners."""
         k = self.k
-        bucketed = k.gather_rows(grad_rows, plan.perm)                          # id order -> bucket order
+        if not bucketed:
+            grad_rows = k.gather_rows(grad_rows, plan.perm)                     # id order -> bucket order
         recv = torch.empty((sum(plan.recv_counts), grad_rows.shape[1]), dtype=grad_rows.dtype,
                            device=grad_rows.device)
-        dist.all_to_all_single(recv, bucketed, plan.recv_counts, plan.send_counts, group=self.pg)
+        _a2a(self, recv, grad_rows, plan.recv_counts, plan.send_counts)
         return recv
 
-    def apply_sparse_adagrad(self, plan, grad_rows, lr, eps=1e-7):
+    def apply_sparse_adagrad(self, plan, grad_rows, lr, eps=1e-7, bucketed=False):
         """Route the gradients to their owners and update the local shards: one fused segment-reduce + RMW."""
         k = self.k
-        rows = self.route_grads(plan, grad_rows)
+        rows = self.route_grads(plan, grad_rows, bucketed=bucketed)
         if rows.shape[0] == 0:
             return
         sorted_rows, perm = plan.owner_sorted
@@ -295,6 +322,18 @@ def sharded_inbatch_step(towers, scene_ids, pos_ids, regularization, global_batc
     k = towers.k
     B = scene_ids.numel()
     plan = plan if plan is not None else plan_inbatch(towers, scene_ids, pos_ids)
+    folded = getattr(k, "inbatch_towers_fwd_bwd", None)
+    if folded is not None and plan.inv is not None and (getattr(k, "TOWERS_ANY_SHAPE", False) or
+                                                        (towers.dim == 128 and B % 128 == 0)):
+        # The score head reads the exchanged rows where they landed (bucket order, table dtype) through the inverse
+        # permutation and writes its gradient rows straight into bucket order: no un-permute, no widening pass, no
+        # permute before the gradient all-to-all.
+        back = towers.lookup_bucketed(plan)
+        iq, ic = plan.inv[:B], plan.inv[B:]
+        loss, _, gbuf, _ = folded(back, back, iq, ic, scale, regularization, global_batch_size,
+                                  grad_positions=(iq, ic))
+        towers.apply_sparse_adagrad(plan, gbuf, lr, bucketed=True)
+        return loss
     rows = towers.lookup(plan)                     # [q ; c]
     loss, _, gq, gc = k.inbatch_softmax_fwd_bwd(rows[:B], rows[B:], scale, regularization, global_batch_size)
     towers.apply_sparse_adagrad(plan, _joined(gq, gc), lr)

@@ -119,12 +119,16 @@ int esr_inbatch_softmax_fwd_bwd_bf16x3(const float* Q, const float* C, int64_t B
 /* The whole in-batch step head without materialised Q / C: row i of Q is query_table[query_ids[i]], row i of C is
  * cand_table[cand_ids[i]] (tables f32 or bf16, dtype = ESR_F32 / ESR_BF16; the id-embedding towers that replace
  * pinterest/models.py:64-70).  The gather is folded into the bf16-plane split and into the merge kernels; gQ / gC
- * are the per-occurrence gradient rows [B, 128].  Same workspace as above. */
+ * are the per-occurrence gradient rows [B, 128].  gq_rows / gc_rows (optional, may be NULL): gradient row i is
+ * written at gQ[gq_rows[i]] / gC[gc_rows[i]] instead of row i -- the row-sharded step passes the bucket positions
+ * of the occurrences, with gQ == gC == the buffer that goes straight into the gradient all-to-all.
+ * Same workspace as above. */
 int esr_inbatch_towers_fwd_bwd_bf16x3(const void* query_table, int64_t Vq, const void* cand_table, int64_t Vc,
                                       int dtype, int D, const int32_t* query_ids, const int32_t* cand_ids,
-                                      int64_t B, float scale, float regularization, float batch_size,
-                                      float* loss, float* lse, float* gQ, float* gC, void* workspace,
-                                      size_t workspace_bytes, esr_stream_t stream);
+                                      const int32_t* gq_rows, const int32_t* gc_rows, int64_t B, float scale,
+                                      float regularization, float batch_size, float* loss, float* lse,
+                                      float* gQ, float* gC, void* workspace, size_t workspace_bytes,
+                                      esr_stream_t stream);
 
 /* ---- G4 (build's production optimizer): sort + segment-reduce + sparse Adagrad -----------
  * Replaces the dense V x D gradient + dense optimizer sweep of
@@ -248,10 +252,11 @@ int esr_sparse_momentum_scatter(float* table, float* trace, int64_t V, int D, co
 
 /* ---- 8e: row-shard routing (owner = id mod world, local row = id div world) ---------------
  * Stable bucket of ids by owner: local_rows[k] = ids[perm[k]] / world, counts[g] = #ids owned by g
- * (int64, device).  Build-defined; the reference is single-device. */
+ * (int64, device); inverse (optional, may be NULL): inverse[perm[k]] = k, the bucket position of occurrence i.
+ * Build-defined; the reference is single-device. */
 size_t esr_bucket_workspace_bytes(int64_t n);
 int esr_bucket_ids_by_owner(const int32_t* ids, int64_t n, int world, int32_t* local_rows,
-                            int32_t* perm, int64_t* counts, void* workspace,
+                            int32_t* perm, int32_t* inverse, int64_t* counts, void* workspace,
                             size_t workspace_bytes, esr_stream_t stream);
 /* out[perm[k], :] = rows[k, :]  (undo the bucket order for rows that came back). */
 int esr_unpermute_rows(const void* rows, int dtype, int D, const int32_t* perm, int64_t n, void* out,

@@ -18,9 +18,28 @@ def _t(a, dtype=None):
     return t.to(dtype) if dtype is not None else t
 
 
-def bucket_ids_by_owner(ids, world):
+TOWERS_ANY_SHAPE = True  # the double has no tile-size constraints: let the sharded step take the folded path
+
+
+def bucket_ids_by_owner(ids, world, want_inverse=False):
     local, counts, perm = o_shard.bucket_by_owner(ids.numpy(), world)
+    if want_inverse:
+        inv = np.empty_like(perm)
+        inv[perm] = np.arange(len(perm), dtype=perm.dtype)
+        return _t(local), _t(perm), _t(counts), _t(inv)
     return _t(local), _t(perm), _t(counts)
+
+
+def inbatch_towers_fwd_bwd(query_table, cand_table, query_ids, cand_ids, scale, lam, bs, grad_positions=None):
+    q = query_table.numpy().astype(np.float64)[query_ids.numpy()]
+    c = cand_table.numpy().astype(np.float64)[cand_ids.numpy()]
+    loss, lse, gq, gc = o_stl.inbatch_softmax_loss_and_grads(q, c, lam, bs, scale, np.float64)
+    if grad_positions is None:
+        return _t(np.array([loss])), _t(lse), _t(gq), _t(gc)
+    buf = np.zeros((2 * len(q), q.shape[1]))
+    buf[grad_positions[0].numpy()] = gq
+    buf[grad_positions[1].numpy()] = gc
+    return _t(np.array([loss])), _t(lse), _t(buf), None
 
 
 def gather_rows(table, ids):

@@ -567,7 +567,8 @@ def test_bucket_ids_by_owner_vs_oracle(dev, world, n):
     from esrecsys_amd import ops
     rng = np.random.default_rng(world)
     ids = rng.integers(0, 1_000_000, n).astype(np.int32)
-    local, perm, counts = ops.bucket_ids_by_owner(T(ids, dev), world)
+    local, perm, counts, inv = ops.bucket_ids_by_owner(T(ids, dev), world, want_inverse=True)
+    assert np.array_equal(N(inv)[N(perm)], np.arange(n, dtype=np.int32))
     el, ec, ep = o_shard.bucket_by_owner(ids, world)
     assert np.array_equal(N(counts), ec)
     assert np.array_equal(N(perm), ep)
