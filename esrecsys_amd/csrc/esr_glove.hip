@@ -93,6 +93,8 @@ __global__ __launch_bounds__(kBlock) void glove_pairs_kernel(
     const double* __restrict__ stat_part, const float* __restrict__ s_in, float* __restrict__ dot_out,
     float* __restrict__ grad_rows, float* __restrict__ grad_bias, double* __restrict__ pair_part) {
   __shared__ double sm[16];
+  const bool at_ids = (mode & ESR_GRADS_AT_IDS) != 0;  // gradient rows go where their table rows came from
+  mode &= ~ESR_GRADS_AT_IDS;
   double sum_s = 0.0, sum_s2 = 0.0;
   if (LOSS && mode == ESR_GLOVE_REFERENCE) reduce_stat_parts(stat_part, nstat, sm, &sum_s, &sum_s2);
   const float sbar = (float)(sum_s / (double)B);
@@ -128,8 +130,8 @@ __global__ __launch_bounds__(kBlock) void glove_pairs_kernel(
       acc_wr += (double)w * (double)r;
       acc_wq += (double)w * q * q;
       if (GRADS && mode == ESR_GLOVE_DIAGONAL) {
-        grad_bias[j] = gdot;
-        grad_bias[B + j] = gdot;
+        grad_bias[at_ids ? t1 : j] = gdot;
+        grad_bias[at_ids ? t2 : B + j] = gdot;
       }
     }
     if (GRADS) {
@@ -141,8 +143,8 @@ __global__ __launch_bounds__(kBlock) void glove_pairs_kernel(
           g1.v[k][e] = gdot * e2.v[k][e];
           g2.v[k][e] = gdot * e1.v[k][e];
         }
-      row_store(g1, grad_rows + j * D, lig, G, nvec);
-      row_store(g2, grad_rows + (B + j) * D, lig, G, nvec);
+      row_store(g1, grad_rows + (at_ids ? t1 : j) * D, lig, G, nvec);
+      row_store(g2, grad_rows + (at_ids ? t2 : B + j) * D, lig, G, nvec);
     }
   }
   if (LOSS) {
@@ -161,9 +163,11 @@ __global__ __launch_bounds__(kBlock) void glove_pairs_kernel(
 // all blocks write grad_bias for their slice (reference mode).
 __global__ __launch_bounds__(kBlock) void glove_finalize_kernel(
     int64_t B, int mode, int nstat, int npair, const double* __restrict__ stat_part,
-    const double* __restrict__ pair_part, const float* __restrict__ s_in, float* __restrict__ loss,
-    float* __restrict__ grad_bias) {
+    const double* __restrict__ pair_part, const float* __restrict__ s_in, const int32_t* __restrict__ inputs,
+    float* __restrict__ loss, float* __restrict__ grad_bias) {
   __shared__ double sm[20];
+  const bool at_ids = (mode & ESR_GRADS_AT_IDS) != 0;
+  mode &= ~ESR_GRADS_AT_IDS;
   double sum_s = 0.0, sum_s2 = 0.0;
   if (mode == ESR_GLOVE_REFERENCE) reduce_stat_parts(stat_part, nstat, sm, &sum_s, &sum_s2);
   double a = 0.0, b = 0.0, c = 0.0;
@@ -199,8 +203,8 @@ __global__ __launch_bounds__(kBlock) void glove_finalize_kernel(
     const float fSw = (float)Sw, fSwr = (float)Swr;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < B; i += (int64_t)gridDim.x * kBlock) {
       const float gs = -k * (fSwr - s_in[i] * fSw);
-      grad_bias[i] = gs;
-      grad_bias[B + i] = gs;
+      grad_bias[at_ids ? (int64_t)inputs[i] : i] = gs;
+      grad_bias[at_ids ? (int64_t)inputs[B + i] : B + i] = gs;
     }
   }
 }
@@ -251,7 +255,8 @@ int esr_glove_fwd_bwd(const float* emb, const float* bias, int64_t V, int D, con
                       float* grad_bias, void* workspace, size_t workspace_bytes, esr_stream_t stream) {
   ESR_REQUIRE(B > 0 && V > 0 && D > 0, "esr_glove_fwd_bwd: bad sizes V=%lld D=%d B=%lld", (long long)V, D,
               (long long)B);
-  ESR_REQUIRE(mode == ESR_GLOVE_REFERENCE || mode == ESR_GLOVE_DIAGONAL, "esr_glove_fwd_bwd: bad mode %d", mode);
+  ESR_REQUIRE((mode & ~ESR_GRADS_AT_IDS) == ESR_GLOVE_REFERENCE || (mode & ~ESR_GRADS_AT_IDS) == ESR_GLOVE_DIAGONAL,
+              "esr_glove_fwd_bwd: bad mode %d", mode);
   ESR_REQUIRE(emb && bias && inputs && target && loss, "esr_glove_fwd_bwd: null pointer");
   ESR_REQUIRE((grad_rows == nullptr) == (grad_bias == nullptr),
               "esr_glove_fwd_bwd: grad_rows and grad_bias must both be set or both be NULL");
@@ -282,7 +287,7 @@ int esr_glove_fwd_bwd(const float* emb, const float* bias, int64_t V, int D, con
   }
   const int nfin = (int)std::min<int64_t>(256, cdiv(B, kBlock));
   hipLaunchKernelGGL(glove_finalize_kernel, dim3(nfin), dim3(kBlock), 0, st, B, mode, nstat, npair,
-                     (const double*)ws.stat_part, (const double*)ws.pair_part, (const float*)ws.s, loss,
+                     (const double*)ws.stat_part, (const double*)ws.pair_part, (const float*)ws.s, inputs, loss,
                      grad_bias);
   return check_launch("esr_glove_fwd_bwd");
 }

@@ -31,6 +31,8 @@ __global__ __launch_bounds__(kBlock) void triplet_kernel(
   const int64_t group = (int64_t)blockIdx.x * gpb + threadIdx.x / G;
   const int64_t ngroups = (int64_t)gridDim.x * gpb;
   const int nvec = D / VEC;
+  const bool at_ids = (with_reg & ESR_GRADS_AT_IDS) != 0;  // gradient rows go where their table rows came from
+  with_reg &= 1;
 
   double acc = 0.0;
   for (int64_t b = group; b < B; b += ngroups) {
@@ -73,9 +75,9 @@ __global__ __launch_bounds__(kBlock) void triplet_kernel(
           gp.v[k][e] = (-m * sv + cp * pv) * inv_bs;
           gn.v[k][e] = (m * sv + cn * nv) * inv_bs;
         }
-      row_store(gs, g_scene + b * D, lig, G, nvec);
-      row_store(gp, g_pos + b * D, lig, G, nvec);
-      row_store(gn, g_neg + b * D, lig, G, nvec);
+      row_store(gs, g_scene + (at_ids ? is : b) * D, lig, G, nvec);
+      row_store(gp, g_pos + (at_ids ? ip : b) * D, lig, G, nvec);
+      row_store(gn, g_neg + (at_ids ? in : b) * D, lig, G, nvec);
     }
   }
   const double t = block_sum_d(acc, sm);

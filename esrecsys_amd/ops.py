@@ -138,8 +138,10 @@ def glove_forward(emb, bias, inputs):
     return dot, s
 
 
-def glove_fwd_bwd(emb, bias, inputs, target, mode=GLOVE_REFERENCE, want_grads=True):
-    """Fused GloVe loss + per-occurrence gradients.  Returns (loss[1], grad_rows[2B, D], grad_bias[2B])."""
+def glove_fwd_bwd(emb, bias, inputs, target, mode=GLOVE_REFERENCE, want_grads=True, grads_at_ids=False):
+    """Fused GloVe loss + per-occurrence gradients.  Returns (loss[1], grad_rows[2B, D], grad_bias[2B]).
+    grads_at_ids: emb / bias are a [2B, .] copy of the looked-up rows (one row per occurrence, any order) and the
+    gradient of the occurrence that read row r is written at row r."""
     lib = _lib.load()
     _req(emb, torch.float32, "emb"), _req(bias, torch.float32, "bias")
     _req(inputs, torch.int32, "inputs"), _req(target, torch.float32, "target")
@@ -153,15 +155,23 @@ def glove_fwd_bwd(emb, bias, inputs, target, mode=GLOVE_REFERENCE, want_grads=Tr
     grad_bias = torch.empty(2 * B, dtype=torch.float32, device=dev) if want_grads else None
     nb = _ws_bytes("esr_glove_workspace_bytes", B)
     ws = _ws(nb, dev)
+    if grads_at_ids and want_grads:
+        mode = mode | GRADS_AT_IDS
     check(lib.esr_glove_fwd_bwd(_p(emb), _p(bias), V, D, _p(inputs), _p(target), B, mode, _p(loss), _p(grad_rows),
                                 _p(grad_bias), _p(ws), ws.numel(), _stream()), "esr_glove_fwd_bwd")
     return loss, grad_rows, grad_bias
 
 
+GRADS_AT_IDS = 0x100  # include/esr_hip.h ESR_GRADS_AT_IDS
+
+
 def triplet_fwd_bwd(scene_table, pos_table, neg_table, scene_ids, pos_ids, neg_ids, B, regularization, batch_size,
-                    with_reg=True, want_grads=True, want_scores=True):
+                    with_reg=True, want_grads=True, want_scores=True, grads_at_ids=False):
     """Fused STL head.  ids may be None (= row b).  Returns (loss[1], pos_score, neg_score, g_s, g_p, g_n);
-    the three gradients are consecutive slices of one [3B, D] buffer (``g_s._base``)."""
+    the three gradients are consecutive slices of one [3B, D] buffer (``g_s._base``).
+    grads_at_ids: the three "tables" are ONE [3B, D] copy of the looked-up rows (one row per occurrence, any order)
+    and every gradient row is written at the row its table row came from: returns g_s = that [3B, D] buffer,
+    g_p = g_n = None."""
     lib = _lib.load()
     for name, t in (("scene_table", scene_table), ("pos_table", pos_table), ("neg_table", neg_table)):
         _req(t, torch.float32, name)
@@ -180,14 +190,21 @@ def triplet_fwd_bwd(scene_table, pos_table, neg_table, scene_ids, pos_ids, neg_i
     # scene / pos / neg gradient rows share one [3B, D] buffer ([scene ; pos ; neg]): the optimizer consumes
     # them as a single occurrence list (``g_s._base``; ``g_s._base[B:]`` = the product rows) with no copy.
     gall = torch.empty((3 * B, D), **f32) if want_grads else None
-    gs = gall[:B] if want_grads else None
-    gp = gall[B:2 * B] if want_grads else None
-    gn = gall[2 * B:] if want_grads else None
+    flags = int(bool(with_reg))
+    if grads_at_ids and want_grads:
+        flags |= GRADS_AT_IDS
+        gs = gp = gn = gall
+    else:
+        gs = gall[:B] if want_grads else None
+        gp = gall[B:2 * B] if want_grads else None
+        gn = gall[2 * B:] if want_grads else None
     ws = _ws(_ws_bytes("esr_triplet_workspace_bytes", B), dev)
     check(lib.esr_triplet_fwd_bwd(_p(scene_table), Vs, _p(pos_table), Vp, _p(neg_table), Vn, D, _p(scene_ids),
                                   _p(pos_ids), _p(neg_ids), B, float(regularization), float(batch_size),
-                                  int(bool(with_reg)), _p(loss), _p(ps), _p(ns), _p(gs), _p(gp), _p(gn), _p(ws),
+                                  flags, _p(loss), _p(ps), _p(ns), _p(gs), _p(gp), _p(gn), _p(ws),
                                   ws.numel(), _stream()), "esr_triplet_fwd_bwd")
+    if grads_at_ids and want_grads:
+        return loss, ps, ns, gall, None, None
     return loss, ps, ns, gs, gp, gn
 
 

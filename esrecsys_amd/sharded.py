@@ -306,6 +306,10 @@ def begin_plan_glove(emb_group, inputs):
     return _Pending1(begin_plans([(emb_group, inputs.reshape(-1))]))
 
 
+def _is_f32(group):
+    return all(t.local.dtype == torch.float32 for t in group.tables)
+
+
 def _joined(first, *rest):
     """The single buffer the gradient slices are views of, else their concatenation."""
     base = getattr(first, "_base", None)
@@ -346,6 +350,16 @@ def sharded_triplet_step(towers, scene_ids, pos_ids, neg_ids, regularization, gl
     k = towers.k
     B = scene_ids.numel()
     plan = plan if plan is not None else plan_triplet(towers, scene_ids, pos_ids, neg_ids)
+    if plan.inv is not None and getattr(k, "GRADS_AT_IDS", None) is not None and _is_f32(towers):
+        # the loss kernel indexes the exchanged rows where they landed (bucket order) through the inverse
+        # permutation and writes every gradient row back at that position: no un-permute / permute passes
+        back = towers.lookup_bucketed(plan)
+        inv = plan.inv
+        loss, _, _, gbuf, _, _ = k.triplet_fwd_bwd(back, back, back, inv[:B], inv[B:2 * B], inv[2 * B:], B,
+                                                   regularization, global_batch_size, with_reg=True, want_grads=True,
+                                                   want_scores=False, grads_at_ids=True)
+        towers.apply_sparse_adagrad(plan, gbuf, lr, bucketed=True)
+        return loss
     rows = towers.lookup(plan)                     # [scene ; pos ; neg]
     loss, _, _, gs, gp, gn = k.triplet_fwd_bwd(rows[:B], rows[B:2 * B], rows[2 * B:], None, None, None, B,
                                                regularization, global_batch_size, with_reg=True, want_grads=True,
@@ -360,6 +374,15 @@ def sharded_glove_step(emb_group, bias_group, inputs, target, mode, lr, plan=Non
     k = emb_group.k
     B = inputs.shape[1]
     plan = plan if plan is not None else plan_glove(emb_group, inputs)
+    if plan.inv is not None and getattr(k, "GRADS_AT_IDS", None) is not None and _is_f32(emb_group) and \
+            _is_f32(bias_group):
+        rows = emb_group.lookup_bucketed(plan)      # [2B, D] in exchange order
+        brow = bias_group.lookup_bucketed(plan)     # [2B, 1]
+        loss, grad_rows, grad_bias = k.glove_fwd_bwd(rows, brow, plan.inv.reshape(2, B), target, mode,
+                                                     grads_at_ids=True)
+        emb_group.apply_sparse_adagrad(plan, grad_rows, lr, bucketed=True)
+        bias_group.apply_sparse_adagrad(plan, grad_bias.reshape(-1, 1), lr, bucketed=True)
+        return loss
     rows = emb_group.lookup(plan)           # [2B, D]: E[t1] ; E[t2]
     brow = bias_group.lookup(plan)          # [2B, 1]
     local_inputs = torch.arange(2 * B, dtype=torch.int32, device=rows.device).reshape(2, B)

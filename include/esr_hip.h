@@ -41,6 +41,12 @@ extern "C" {
 
 #define ESR_GLOVE_REFERENCE 0 /* (B,B)-broadcast loss of wikipedia/train_cooccurence.py:83 */
 #define ESR_GLOVE_DIAGONAL 1  /* textbook per-pair GloVe loss (build-defined option) */
+/* OR-ed into esr_glove_fwd_bwd's `mode` / esr_triplet_fwd_bwd's `with_reg`: the gradient of the occurrence that read
+ * table row r is written at output row r instead of at its occurrence index.  For "tables" that are a private copy
+ * of the looked-up rows with one row per occurrence (the row-sharded step: rows in exchange order, ids = the inverse
+ * routing permutation) this emits the gradients directly in exchange order; the three triplet gradient pointers may
+ * then alias one buffer. */
+#define ESR_GRADS_AT_IDS 0x100
 
 typedef void* esr_stream_t;
 

@@ -106,9 +106,17 @@ class _Halves(torch.Tensor):
     pass
 
 
-def triplet_fwd_bwd(s, p, n, sid, pid, nid, B, lam, bs, with_reg=True, want_grads=True, want_scores=True):
-    assert sid is None and pid is None and nid is None
-    loss, gs, gp, gn = o_stl.triplet_loss_and_grads(s.numpy(), p.numpy(), n.numpy(), lam, bs, np.float64)
+GRADS_AT_IDS = 0x100
+
+
+def triplet_fwd_bwd(s, p, n, sid, pid, nid, B, lam, bs, with_reg=True, want_grads=True, want_scores=True,
+                    grads_at_ids=False):
+    rows = lambda t, i: t.numpy() if i is None else t.numpy()[i.numpy()]  # noqa: E731
+    loss, gs, gp, gn = o_stl.triplet_loss_and_grads(rows(s, sid), rows(p, pid), rows(n, nid), lam, bs, np.float64)
+    if grads_at_ids:
+        buf = np.zeros((3 * B, gs.shape[1]))
+        buf[sid.numpy()], buf[pid.numpy()], buf[nid.numpy()] = gs, gp, gn
+        return _t(np.array([loss])), None, None, _t(buf), None, None
     gall = _t(np.concatenate([gs, gp, gn]))
     return _t(np.array([loss])), None, None, gall[:B], gall[B:2 * B], gall[2 * B:]
 
@@ -120,11 +128,16 @@ def inbatch_softmax_fwd_bwd(q, c, scale, lam, bs):
     return _t(np.array([loss])), _t(lse), gqc[:B], gqc[B:]
 
 
-def glove_fwd_bwd(emb, bias, inputs, target, mode=GLOVE_REFERENCE, want_grads=True):
+def glove_fwd_bwd(emb, bias, inputs, target, mode=GLOVE_REFERENCE, want_grads=True, grads_at_ids=False):
     m = "reference" if mode == GLOVE_REFERENCE else "diagonal"
     e, b = emb.numpy().astype(np.float64), bias.numpy().astype(np.float64)
     loss, gdot, gs = o_glove.loss_and_grads(e, b, inputs.numpy(), target.numpy(), m, np.float64)
     _, rows, gb = o_glove.row_grads(e, inputs.numpy(), gdot, gs, np.float64)
+    if grads_at_ids:  # occurrence o read row inputs.flat[o]: its gradient goes to that row
+        at = inputs.numpy().reshape(-1)
+        r2, b2 = np.zeros_like(rows), np.zeros_like(gb)
+        r2[at], b2[at] = rows, gb
+        rows, gb = r2, b2
     return _t(np.array([loss])), _t(rows), _t(gb)
 
 

@@ -246,6 +246,32 @@ def test_inbatch_ragged_batch_vs_oracle(dev, B, D):
     assert np.abs(N(gc) - egc).max() <= TOL * max(np.abs(egc).max(), 1e-6)
 
 
+def test_fused_heads_write_grads_at_ids(dev):
+    """ESR_GRADS_AT_IDS: with a private [n, D] copy of the looked-up rows in any order and ids = positions in it,
+    the triplet / GloVe heads emit their gradient rows at those positions (what the row-sharded step feeds the
+    gradient exchange) -- equal to the plain call after the same permutation, bit for bit."""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(33)
+    B, D = 1000, 128
+    rows = T(rng.standard_normal((3 * B, D)).astype(np.float32) * 0.3, dev)
+    inv = T(rng.permutation(3 * B).astype(np.int32), dev)               # occurrence o reads row inv[o]
+    plain = ops.triplet_fwd_bwd(rows, rows, rows, inv[:B], inv[B:2 * B], inv[2 * B:], B, 0.1, float(B),
+                                want_scores=False)
+    at = ops.triplet_fwd_bwd(rows, rows, rows, inv[:B], inv[B:2 * B], inv[2 * B:], B, 0.1, float(B),
+                             want_scores=False, grads_at_ids=True)
+    assert torch.equal(plain[0], at[0]) and at[4] is None
+    assert torch.equal(at[3][inv.long()], plain[3]._base)
+    emb = T(rng.standard_normal((2 * B, D)).astype(np.float32) * 0.3, dev)
+    bias = T(rng.standard_normal((2 * B, 1)).astype(np.float32) * 0.05, dev)
+    inv2 = T(rng.permutation(2 * B).astype(np.int32).reshape(2, B), dev)
+    tgt = T(rng.uniform(0.1, 300, B).astype(np.float32), dev)
+    for mode in (ops.GLOVE_REFERENCE, ops.GLOVE_DIAGONAL):
+        l0, g0, b0 = ops.glove_fwd_bwd(emb, bias, inv2, tgt, mode)
+        l1, g1, b1 = ops.glove_fwd_bwd(emb, bias, inv2, tgt, mode, grads_at_ids=True)
+        idx = inv2.reshape(-1).long()
+        assert torch.equal(l0, l1) and torch.equal(g1[idx], g0) and torch.equal(b1[idx], b0)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_inbatch_towers_gather_folded_in(dev, dtype):
     """the step head that reads the tower rows itself == gather + dense head, bit for bit; and vs the oracle"""
