@@ -53,6 +53,19 @@ class DirectExchange:
         ctypes.memmove(ctypes.byref(uid), bytes(raw.cpu().numpy().tobytes()), 128)
         self.comm = ctypes.c_void_p()
         self._check(self.lib.ncclCommInitRank(ctypes.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
+        self._self_test()
+
+    def _self_test(self):
+        """One uneven all-to-all with known contents: rank r sends (peer + 1) rows of value 1000 r + peer to `peer`."""
+        G, r = self.world, self.rank
+        send_rows = [p + 1 for p in range(G)]
+        recv_rows = [r + 1] * G
+        send = torch.cat([torch.full((p + 1, 3), 1000 * r + p, dtype=torch.int32) for p in range(G)]).to(self.device)
+        recv = torch.full((sum(recv_rows), 3), -1, dtype=torch.int32, device=self.device)
+        self.all_to_all_single(recv, send, recv_rows, send_rows)
+        want = torch.cat([torch.full((r + 1, 3), 1000 * p + r, dtype=torch.int32) for p in range(G)])
+        if not torch.equal(recv.cpu(), want):
+            raise RuntimeError("direct all-to-all self-test returned wrong data")
 
     def _check(self, rc, what):
         if rc != 0:
