@@ -177,85 +177,113 @@ __global__ __launch_bounds__(kBlock) void owner_keys_kernel(const int32_t* __res
   }
 }
 
-// Single-launch stable bucket for the sizes of a training step (n <= 32768 ids, world <= 8): one 512-thread
-// workgroup; thread t owns the contiguous slice [t c, (t+1) c), counts its ids per owner, an intra-wave scan +
-// a 16-wave LDS hand-off give every (thread, owner) its exclusive prefix, and a second pass over the slice
-// writes (local row, original position) at owner_base + prefix.  Stable by construction.  Replaces a memset +
-// 2 kernels + a 5-launch device radix sort (~60 us of dependent launch latency per lookup).
-constexpr int kBucketThreads = 512;
+// Single-launch stable bucket for the sizes of a training step (n <= 32768 ids, world <= 8).  Stable by
+// construction.  Replaces a memset + 2 kernels + a 5-launch device radix sort (~60 us of dependent launch latency
+// per lookup).
 constexpr int kBucketMaxWorld = 8;  // one MI355X node
 constexpr int kBucketMaxN = 32768;
-constexpr int kBucketMaxPerThread = kBucketMaxN / kBucketThreads;  // 64
+constexpr int kBucketThreads = 1024;
+constexpr int kBucketRounds = kBucketMaxN / kBucketThreads;  // 32
+// One workgroup, ids taken round by round (round r = ids [1024 r, 1024 r + 1024), thread t = one id): every access
+// is coalesced.  Stable position of an id = owner base + ids of the same owner in earlier (round, wave) cells +
+// same-owner lanes below it in its own wave (ballot + popcount).  The 32 x 16 cell totals per owner are prefix-
+// summed by one thread per owner.  (Earlier versions gave each thread a contiguous slice: either the loads or the
+// stores were then 64 distinct lines per wave instruction and the kernel took ~30 us for 16 384 ids.)
 __global__ __launch_bounds__(kBucketThreads) void bucket_small_kernel(const int32_t* __restrict__ ids, int n, int world,
                                                                      int32_t* __restrict__ inverse,
                                                                      int32_t* __restrict__ local_rows,
                                                                      int32_t* __restrict__ perm,
                                                                      int64_t* __restrict__ counts) {
-  // ids staged with coalesced loads; thread t then walks its contiguous slice from LDS.  The slice stride is
-  // forced odd so the 64 lanes of a wave hit 32 different banks.
-  __shared__ uint32_t sid[kBucketThreads * (kBucketMaxPerThread + 1)];
-  __shared__ int wave_tot[kBucketThreads / 64][kBucketMaxWorld];
+  constexpr int kWaves = kBucketThreads / 64;
+  __shared__ int cell[kBucketMaxWorld][kBucketRounds * kWaves + 1];  // per owner: totals, then exclusive prefixes
+  __shared__ int owner_base[kBucketMaxWorld];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int c = (n + kBucketThreads - 1) / kBucketThreads;
-  const int cs = c | 1;  // padded (odd) slice stride in LDS
-  for (int i = t; i < n; i += kBucketThreads) sid[(i / c) * cs + (i % c)] = (uint32_t)ids[i];
-  __syncthreads();
-  const int lo = min(n, t * c), hi = min(n, lo + c);
-  const uint32_t* mine = sid + t * cs;
-  int cnt[kBucketMaxWorld];
+  const bool pow2 = (world & (world - 1)) == 0;
+  const int rounds = (n + kBucketThreads - 1) / kBucketThreads;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  // pass 1: per (round, wave) cell and owner, how many ids.  Both passes batch four rounds so that four loads are in
+  // flight (a rolled loop serialised 16 global-load latencies: 19 us).  Pass 2 re-reads the ids (L2) and re-derives
+  // the in-wave ranks instead of keeping 64 values per thread in registers.
+#pragma unroll 1
+  for (int r0 = 0; r0 < rounds; r0 += 4) {
+    uint32_t idv[4];
 #pragma unroll
-  for (int g = 0; g < kBucketMaxWorld; ++g) cnt[g] = 0;
-  for (int i = 0; i < hi - lo; ++i) {
-    const int o = (int)(mine[i] % (uint32_t)world);
+    for (int u = 0; u < 4; ++u) {
+      const int j = (r0 + u) * kBucketThreads + t;
+      idv[u] = (r0 + u < rounds && j < n) ? (uint32_t)ids[j] : 0xFFFFFFFFu;
+    }
 #pragma unroll
-    for (int g = 0; g < kBucketMaxWorld; ++g) cnt[g] += (o == g);
+    for (int u = 0; u < 4; ++u) {
+      if (r0 + u >= rounds) break;  // uniform
+      const int j = (r0 + u) * kBucketThreads + t;
+      const int own = j < n ? (int)(pow2 ? idv[u] & (uint32_t)(world - 1) : idv[u] % (uint32_t)world) : -1;
+#pragma unroll
+      for (int g = 0; g < kBucketMaxWorld; ++g) {
+        const unsigned long long m = __ballot(own == g);
+        if (lane == 0) cell[g][(r0 + u) * kWaves + w] = __popcll(m);
+      }
+    }
   }
-  // inclusive scan of cnt[g] across the 64 lanes of this wave
-  int pre[kBucketMaxWorld];
+  __syncthreads();
+  if (w < kBucketMaxWorld) {  // one WAVE per owner: exclusive prefix over its (round, wave) cells
+    constexpr int kPer = kBucketRounds * kWaves / 64;  // 8 consecutive cells per lane
+    int v[kPer], sum = 0;
 #pragma unroll
-  for (int g = 0; g < kBucketMaxWorld; ++g) {
-    int v = cnt[g];
+    for (int i = 0; i < kPer; ++i) {
+      v[i] = cell[w][lane * kPer + i];  // cells beyond rounds * kWaves were never written: mask them
+      if (lane * kPer + i >= rounds * kWaves) v[i] = 0;
+      sum += v[i];
+    }
+    int incl = sum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-      const int u = __shfl_up(v, off, 64);
-      if (lane >= off) v += u;
+      const int u = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += u;
     }
-    pre[g] = v - cnt[g];  // exclusive within the wave
-    if (lane == 63) wave_tot[w][g] = v;
+    int run = incl - sum;
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      cell[w][lane * kPer + i] = run;
+      run += v[i];
+    }
+    if (lane == 63) cell[w][kBucketRounds * kWaves] = incl;  // owner total
   }
   __syncthreads();
-  int before[kBucketMaxWorld], total[kBucketMaxWorld];
-#pragma unroll
-  for (int g = 0; g < kBucketMaxWorld; ++g) { before[g] = 0; total[g] = 0; }
-#pragma unroll 1
-  for (int ww = 0; ww < kBucketThreads / 64; ++ww) {
-#pragma unroll
+  if (t == 0) {
+    int base = 0;
     for (int g = 0; g < kBucketMaxWorld; ++g) {
-      const int x = wave_tot[ww][g];
-      before[g] += (ww < w) ? x : 0;
-      total[g] += x;
+      owner_base[g] = base;
+      const int tot = cell[g][kBucketRounds * kWaves];
+      if (g < world) counts[g] = tot;
+      base += tot;
     }
   }
-  int base = 0;  // running owner base (exclusive scan over owners of the block totals)
+  __syncthreads();
+#pragma unroll 1
+  for (int r0 = 0; r0 < rounds; r0 += 4) {
+    uint32_t idv[4];
 #pragma unroll
-  for (int g = 0; g < kBucketMaxWorld; ++g) {
-    pre[g] += base + before[g];
-    if (t == 0 && g < world) counts[g] = total[g];
-    base += total[g];
-  }
-  for (int i = 0; i < hi - lo; ++i) {
-    const uint32_t id = mine[i];
-    const int o = (int)(id % (uint32_t)world);
-    int pos = 0;
+    for (int u = 0; u < 4; ++u) {
+      const int j = (r0 + u) * kBucketThreads + t;
+      idv[u] = (r0 + u < rounds && j < n) ? (uint32_t)ids[j] : 0xFFFFFFFFu;
+    }
 #pragma unroll
-    for (int g = 0; g < kBucketMaxWorld; ++g)
-      if (o == g) {
-        pos = pre[g];
-        pre[g] += 1;
+    for (int u = 0; u < 4; ++u) {
+      if (r0 + u >= rounds) break;  // uniform
+      const int r = r0 + u, j = r * kBucketThreads + t;
+      const int own = j < n ? (int)(pow2 ? idv[u] & (uint32_t)(world - 1) : idv[u] % (uint32_t)world) : -1;
+      int pos = -1;
+#pragma unroll
+      for (int g = 0; g < kBucketMaxWorld; ++g) {
+        const unsigned long long m = __ballot(own == g);
+        if (own == g) pos = owner_base[g] + cell[g][r * kWaves + w] + __popcll(m & below);
       }
-    local_rows[pos] = (int32_t)(id / (uint32_t)world);
-    perm[pos] = lo + i;
-    if (inverse) inverse[lo + i] = pos;
+      if (pos >= 0) {
+        perm[pos] = j;
+        local_rows[pos] = (int32_t)(pow2 ? idv[u] >> __builtin_ctz(world) : idv[u] / (uint32_t)world);
+        if (inverse) inverse[j] = pos;
+      }
+    }
   }
 }
 
