@@ -144,14 +144,25 @@ def make_state_and_batches(workload, cfg, dev, n_batches, rank):
         state = TrainState.create(apply_fn=model.apply, params=params, tx=optim.sparse_adagrad(LR))
     gen.manual_seed(SEED + 1 + rank)
     batches = []
+    if cfg.get("ids") == "zipf":  # P(rank k) ~ 1/k over a random permutation of the rows
+        w = 1.0 / torch.arange(1, V + 1, device=dev, dtype=torch.float64)
+        cdf = torch.cumsum(w / w.sum(), 0)
+        relabel = torch.randperm(V, generator=gen, device=dev).to(torch.int32)
+
+        def draw(shape):
+            u = torch.rand(shape, generator=gen, device=dev, dtype=torch.float64)
+            return relabel[torch.searchsorted(cdf, u).clamp_(max=V - 1)]
+    else:
+        def draw(shape):
+            return torch.randint(0, V, shape, generator=gen, device=dev, dtype=torch.int32)
     for _ in range(n_batches):
         if workload == "glove":
-            inputs = torch.randint(0, V, (2, B), generator=gen, device=dev, dtype=torch.int32)
+            inputs = draw((2, B))
             u = torch.rand(B, generator=gen, device=dev)
             target = torch.exp(np.log(0.1) + u * (np.log(1000.0) - np.log(0.1)))
             batches.append((inputs, target))
         else:
-            ids = torch.randint(0, V, (3, B), generator=gen, device=dev, dtype=torch.int32)
+            ids = draw((3, B))
             batches.append((ids[0].contiguous(), ids[1].contiguous(), ids[2].contiguous()))
     return state, batches
 
@@ -231,6 +242,9 @@ def main():
     ap.add_argument("--rows", type=int, default=None,
                     help="rows per table instead of the workload's (BASELINE config 4: --gpus 8 --rows 100000000 "
                          "--table-dtype bf16)")
+    ap.add_argument("--ids", default="uniform", choices=["uniform", "zipf"],
+                    help="id distribution of the synthetic batches: uniform (headline) or Zipf(s=1) over a random "
+                         "permutation of the rows (SURVEY 8d secondary: stresses duplicate ids in the sparse update)")
     ap.add_argument("--table-dtype", default="f32", choices=["f32", "bf16"],
                     help="table storage (accumulators stay fp32); bf16 needs the in-batch workload or the sharded leg")
     ap.add_argument("--precision", default="auto", choices=["auto", "f32", "bf16x3"],
@@ -263,6 +277,7 @@ def main():
     if args.rows:
         cfg["V"] = int(args.rows)
     cfg["table_dtype"] = args.table_dtype
+    cfg["ids"] = args.ids
     B, D, V = cfg["B"], cfg["D"], cfg["V"]
 
     if world > 1 or os.environ.get("ESR_BENCH_SHARDED") == "1":  # the env switch runs the sharded leg on one rank
@@ -369,7 +384,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: V=%d x D=%d %s tables, B=%d, sparse Adagrad"
                                % (args.workload, V, D, "bf16" if args.table_dtype == "bf16" else "fp32", B),
-                   "score_precision": PRECISION,
+                   "score_precision": PRECISION, "ids": args.ids,
                    "parallelism": "single", "launch": mode, "loss": final_loss},
         "roofline": roofline, "kernels": kernels, "hbm_gather_scatter": hbm,
     }

@@ -3,9 +3,12 @@
 // Production path (north_star): deterministic row-sparse update.  Occurrence ids have been
 // stably sorted (esr_segment_sort_ids), so the occurrences of one row are a contiguous run of
 // `sorted_ids`.  One row group (G lanes) is launched per sorted position; the group at the head
-// of a run sums the run's gradient rows left to right (== occurrence order, so the result equals
-// a sequential scatter-add bit for bit), then does the read-modify-write of the parameter and
-// accumulator rows exactly once.  No float atomics, no V x D gradient, no host sync.
+// of a run sums the run's gradient rows left to right (== occurrence order, so for a run inside
+// one 32-position chunk the result equals a sequential scatter-add bit for bit), then does the
+// read-modify-write of the parameter and accumulator rows exactly once.  Runs that cross a chunk
+// boundary (hot rows of skewed batches) are summed chunk-wise in parallel and combined in a fixed
+// order by a second kernel.  No float atomics, no V x D gradient, no host sync; the result never
+// depends on scheduling.  The gradient-row buffer doubles as scratch for the chunk partials.
 // HBM traffic per distinct row: D*4 (grad) + 2*D*s (param RMW) + 2*D*4 (accumulator RMW).
 //
 // Reference-faithful path: esr_rows_to_dense rebuilds the dense V x D gradient that JAX's autodiff
@@ -71,80 +74,10 @@ __device__ __forceinline__ void param_store(const RowRegs<VEC, NCH>& r, void* ta
   }
 }
 
-template <int VEC, int NCH, int OP>
-__global__ __launch_bounds__(kBlock) void segment_update_kernel(void* __restrict__ table, int dtype,
-                                                               float* __restrict__ accum, int D, int G,
-                                                               const int32_t* __restrict__ sorted_ids,
-                                                               const int32_t* __restrict__ perm, int64_t n,
-                                                               const float* __restrict__ grad_rows, float lr,
-                                                               float eps) {
-  const int lig = threadIdx.x & (G - 1);
-  const int64_t gpb = kBlock / G;
-  const int64_t group = (int64_t)blockIdx.x * gpb + threadIdx.x / G;
-  const int64_t ngroups = (int64_t)gridDim.x * gpb;
-  const int nvec = D / VEC;
-  for (int64_t p = group; p < n; p += ngroups) {
-    const int32_t id = sorted_ids[p];
-    if (p > 0 && sorted_ids[p - 1] == id) continue;  // not the head of its run
-    RowRegs<VEC, NCH> g;
-    row_load(g, grad_rows + (int64_t)perm[p] * D, lig, G, nvec);
-    for (int64_t q = p + 1; q < n && sorted_ids[q] == id; ++q) {
-      RowRegs<VEC, NCH> t;
-      row_load(t, grad_rows + (int64_t)perm[q] * D, lig, G, nvec);
-#pragma unroll
-      for (int k = 0; k < NCH; ++k)
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) g.v[k][e] += t.v[k][e];
-    }
-    if (OP == kToDense) {
-      row_store(g, (float*)table + (int64_t)id * D, lig, G, nvec);
-    } else if (OP == kMomentum) {
-      // the gradient half of optax.sgd(lr, momentum): trace += g ; p -= lr * g  (the decay half is dense)
-      RowRegs<VEC, NCH> w, a;
-      param_load(w, table, dtype, id, D, lig, G, nvec);
-      row_load(a, accum + (int64_t)id * D, lig, G, nvec);
-#pragma unroll
-      for (int k = 0; k < NCH; ++k)
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          a.v[k][e] += g.v[k][e];
-          w.v[k][e] -= lr * g.v[k][e];
-        }
-      row_store(a, accum + (int64_t)id * D, lig, G, nvec);
-      param_store(w, table, dtype, id, D, lig, G, nvec);
-    } else if (OP == kSgd) {
-      RowRegs<VEC, NCH> w;
-      param_load(w, table, dtype, id, D, lig, G, nvec);
-#pragma unroll
-      for (int k = 0; k < NCH; ++k)
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) w.v[k][e] -= lr * g.v[k][e];
-      param_store(w, table, dtype, id, D, lig, G, nvec);
-    } else {
-      // optax.adagrad [upstream]: acc += g^2 ; p -= lr * g * rsqrt(acc + eps)  (0 where acc == 0)
-      RowRegs<VEC, NCH> w, a;
-      param_load(w, table, dtype, id, D, lig, G, nvec);
-      row_load(a, accum + (int64_t)id * D, lig, G, nvec);
-#pragma unroll
-      for (int k = 0; k < NCH; ++k)
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          const float gv = g.v[k][e];
-          const float acc = fmaf(gv, gv, a.v[k][e]);
-          a.v[k][e] = acc;
-          const float inv = acc > 0.f ? 1.0f / sqrtf(acc + eps) : 0.f;
-          w.v[k][e] -= lr * gv * inv;
-        }
-      row_store(a, accum + (int64_t)id * D, lig, G, nvec);
-      param_store(w, table, dtype, id, D, lig, G, nvec);
-    }
-  }
-}
-
-// Several tables updated by ONE sorted occurrence list: occurrence ids are "virtual rows" vid = row_offset[t] + id
-// of a concatenation of up to kMaxFusedTables tables with the same D (the two towers of one step), so a
-// step needs one sort chain and one update launch instead of one per table -- at the reference's batch sizes
-// the step is bound by the number of dependent launches, not by bytes (profiles/r1/triplet_kernel_stats.csv).
+// Several tables may be updated by ONE sorted occurrence list: occurrence ids are then "virtual rows"
+// vid = row_offset[t] + id of a concatenation of up to kMaxFusedTables tables with the same D (the two towers of one
+// step), so a step needs one sort and one update instead of one per table -- at the reference's batch sizes the step
+// is bound by the number of dependent launches, not by bytes.  A single table is the n = 1 case.
 constexpr int kMaxFusedTables = 4;
 struct FusedTables {
   void* table[kMaxFusedTables];
@@ -153,42 +86,48 @@ struct FusedTables {
   int n;
 };
 
-template <int VEC, int NCH>
-__global__ __launch_bounds__(kBlock) void segment_adagrad_multi_kernel(FusedTables ft, int dtype, int D, int G,
-                                                                      const int32_t* __restrict__ sorted_vids,
-                                                                      const int32_t* __restrict__ perm, int64_t n,
-                                                                      const float* __restrict__ grad_rows, float lr,
-                                                                      float eps) {
-  const int lig = threadIdx.x & (G - 1);
-  const int64_t gpb = kBlock / G;
-  const int64_t group = (int64_t)blockIdx.x * gpb + threadIdx.x / G;
-  const int64_t ngroups = (int64_t)gridDim.x * gpb;
-  const int nvec = D / VEC;
-  for (int64_t p = group; p < n; p += ngroups) {
-    const int32_t vid = sorted_vids[p];
-    if (p > 0 && sorted_vids[p - 1] == vid) continue;  // not the head of its run
-    RowRegs<VEC, NCH> g;
-    row_load(g, grad_rows + (int64_t)perm[p] * D, lig, G, nvec);
-    for (int64_t q = p + 1; q < n && sorted_vids[q] == vid; ++q) {
-      RowRegs<VEC, NCH> t;
-      row_load(t, grad_rows + (int64_t)perm[q] * D, lig, G, nvec);
+// the read-modify-write of one table row with the summed gradient g of its occurrences
+template <int VEC, int NCH, int OP>
+__device__ __forceinline__ void seg_apply(const FusedTables& ft, int dtype, int32_t vid, const RowRegs<VEC, NCH>& g,
+                                          int D, int lig, int G, int nvec, float lr, float eps) {
+  // select chain with constant indices (a runtime index into the kernarg struct would go through scratch)
+  void* table = ft.table[0];
+  float* accum = ft.accum[0];
+  int64_t base = ft.row_offset[0];
 #pragma unroll
-      for (int k = 0; k < NCH; ++k)
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) g.v[k][e] += t.v[k][e];
+  for (int k = 1; k < kMaxFusedTables; ++k)
+    if (k < ft.n && (int64_t)vid >= ft.row_offset[k]) {
+      table = ft.table[k];
+      accum = ft.accum[k];
+      base = ft.row_offset[k];
     }
-    // select chain with constant indices (a runtime index into the kernarg struct would go through scratch)
-    void* table = ft.table[0];
-    float* accum = ft.accum[0];
-    int64_t base = ft.row_offset[0];
+  const int64_t id = (int64_t)vid - base;
+  if (OP == kToDense) {
+    row_store(g, (float*)table + id * D, lig, G, nvec);
+  } else if (OP == kMomentum) {
+    // the gradient half of optax.sgd(lr, momentum): trace += g ; p -= lr * g  (the decay half is dense)
+    RowRegs<VEC, NCH> w, a;
+    param_load(w, table, dtype, id, D, lig, G, nvec);
+    row_load(a, accum + id * D, lig, G, nvec);
 #pragma unroll
-    for (int k = 1; k < kMaxFusedTables; ++k)
-      if (k < ft.n && (int64_t)vid >= ft.row_offset[k]) {
-        table = ft.table[k];
-        accum = ft.accum[k];
-        base = ft.row_offset[k];
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        a.v[k][e] += g.v[k][e];
+        w.v[k][e] -= lr * g.v[k][e];
       }
-    const int64_t id = (int64_t)vid - base;
+    row_store(a, accum + id * D, lig, G, nvec);
+    param_store(w, table, dtype, id, D, lig, G, nvec);
+  } else if (OP == kSgd) {
+    RowRegs<VEC, NCH> w;
+    param_load(w, table, dtype, id, D, lig, G, nvec);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) w.v[k][e] -= lr * g.v[k][e];
+    param_store(w, table, dtype, id, D, lig, G, nvec);
+  } else {
+    // optax.adagrad [upstream]: acc += g^2 ; p -= lr * g * rsqrt(acc + eps)  (0 where acc == 0)
     RowRegs<VEC, NCH> w, a;
     param_load(w, table, dtype, id, D, lig, G, nvec);
     row_load(a, accum + id * D, lig, G, nvec);
@@ -204,6 +143,139 @@ __global__ __launch_bounds__(kBlock) void segment_adagrad_multi_kernel(FusedTabl
       }
     row_store(a, accum + id * D, lig, G, nvec);
     param_store(w, table, dtype, id, D, lig, G, nvec);
+  }
+}
+
+// Kernel 1.  A run of equal ids is cut into chunks only if it is long: the head chunk extends from the head of the run
+// to the first multiple of kSegChunk that is at least kSegChunk positions later (32 - 63 occurrences); further
+// chunks start at every following multiple of kSegChunk.  A run that fits its head chunk -- every run of a batch
+// with few duplicate ids -- is summed left to right by the head's group and applied at once, exactly as a sequential
+// scatter-add would, whatever its alignment.  A longer run -- hot rows of a Zipf-distributed batch: the most
+// popular of 10^6 rows draws ~1 200 of 16 384 ids -- leaves one partial sum per chunk in the gradient buffer itself
+// (in the row of the chunk's first occurrence, which nobody else reads) for kernel 2.  One group walking such a run
+// alone took 0.23 - 5.8 ms per step.
+constexpr int kSegChunk = 32;
+template <int VEC, int NCH, int OP>
+__global__ __launch_bounds__(kBlock) void segment_update_kernel(FusedTables ft, int dtype, int D, int G,
+                                                               const int32_t* __restrict__ sorted_ids,
+                                                               const int32_t* __restrict__ perm, int64_t n,
+                                                               float* __restrict__ grad_rows, float lr, float eps) {
+  const int lig = threadIdx.x & (G - 1);
+  const int64_t gpb = kBlock / G;
+  const int64_t group = (int64_t)blockIdx.x * gpb + threadIdx.x / G;
+  const int64_t ngroups = (int64_t)gridDim.x * gpb;
+  const int nvec = D / VEC;
+  for (int64_t p = group; p < n; p += ngroups) {
+    const int32_t id = sorted_ids[p];
+    const bool head = p == 0 || sorted_ids[p - 1] != id;
+    // a continuation chunk starts at a multiple of kSegChunk whose whole previous block belongs to the run
+    if (!head && ((p & (kSegChunk - 1)) != 0 || sorted_ids[p - kSegChunk] != id)) continue;
+    const int64_t stop = min(head ? ((p + 2 * kSegChunk - 1) / kSegChunk) * kSegChunk : p + kSegChunk, n);
+    RowRegs<VEC, NCH> g;
+    row_load(g, grad_rows + (int64_t)perm[p] * D, lig, G, nvec);
+    int64_t q = p + 1;
+    for (; q < stop && sorted_ids[q] == id; ++q) {
+      RowRegs<VEC, NCH> t;
+      row_load(t, grad_rows + (int64_t)perm[q] * D, lig, G, nvec);
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) g.v[k][e] += t.v[k][e];
+    }
+    const bool ends = q == n || sorted_ids[q] != id;
+    if (head && ends)
+      seg_apply<VEC, NCH, OP>(ft, dtype, id, g, D, lig, G, nvec, lr, eps);
+    else
+      row_store(g, grad_rows + (int64_t)perm[p] * D, lig, G, nvec);  // partial sum of a long run
+  }
+}
+
+// Kernel 2: the long runs.  Their first continuation chunk is found by screening the chunk boundaries (three loads
+// per boundary; in a batch without hot rows that is all this kernel does).  A workgroup then combines one run at a
+// time: its row groups sum the run's chunk partials round-robin, the group sums are added in group order through
+// LDS, and the row is updated once.  Fixed association: the result does not depend on scheduling.
+template <int VEC, int NCH, int OP>
+__global__ __launch_bounds__(kBlock) void segment_long_kernel(FusedTables ft, int dtype, int D, int G,
+                                                             const int32_t* __restrict__ sorted_ids,
+                                                             const int32_t* __restrict__ perm, int64_t n,
+                                                             const float* __restrict__ grad_rows, float lr,
+                                                             float eps) {
+  __shared__ float red[kBlock * VEC * NCH];  // [groups][lanes][NCH][VEC]
+  constexpr int kPass = 16;                  // chunk boundaries screened per workgroup pass (long runs are then
+                                             // spread over many workgroups instead of queueing in a few)
+  __shared__ long long s_long[kPass];        // chunk boundaries at which a long run leaves its first chunk
+  __shared__ int s_nlong, s_hoff;
+  const int tid = threadIdx.x, lig = tid & (G - 1), gidx = tid / G, NG = kBlock / G;
+  const int nvec = D / VEC;
+  const int64_t nbound = (n - 1) / kSegChunk;  // boundaries kSegChunk, 2 kSegChunk, ... < n
+  for (int64_t b0 = (int64_t)blockIdx.x * kPass; b0 < nbound; b0 += (int64_t)gridDim.x * kPass) {
+    __syncthreads();  // red / s_* of the previous pass are no longer read
+    if (tid == 0) s_nlong = 0;
+    __syncthreads();
+    // screening, one thread per chunk boundary B: B is the FIRST continuation chunk of a long run iff the whole
+    // block before it belongs to the run (ids at B - 32 and B equal) and the block before that does not
+    {
+      const int64_t B = (b0 + tid + 1) * kSegChunk;
+      if (tid < kPass && b0 + tid < nbound) {
+        const int32_t id_b = sorted_ids[B];
+        const bool first = B < 2 * kSegChunk || sorted_ids[B - 2 * kSegChunk] != id_b;
+        if (sorted_ids[B - kSegChunk] == id_b && first) s_long[atomicAdd(&s_nlong, 1)] = B;
+      }
+    }
+    __syncthreads();
+    const int nlong = s_nlong;
+    for (int li = 0; li < nlong; ++li) {  // rare: the whole workgroup combines one long run at a time
+      // (the order of the list is arbitrary; it affects no result: every run is combined independently)
+      const int64_t nxt = s_long[li];
+      const int32_t id = sorted_ids[nxt];
+      const int64_t win = max<int64_t>(nxt - 2 * kSegChunk + 1, 0);  // the head lies in [nxt - 63, nxt - 32]
+      if (tid < 64) {
+        const int64_t pos = win + tid;
+        const bool is_head = pos <= nxt - kSegChunk && sorted_ids[pos] == id && (pos == 0 || sorted_ids[pos - 1] != id);
+        const unsigned long long m = __ballot(is_head);
+        if (tid == 0) s_hoff = __ffsll((long long)m) - 1;
+      }
+      __syncthreads();
+      const int64_t h = win + s_hoff;
+      // K = number of continuation chunks (chunk starts nxt, nxt + 32, ... that still carry this id)
+      int64_t K = 0;
+      for (int64_t k0 = 0;; k0 += kBlock) {
+        const int64_t pos = nxt + (k0 + tid) * kSegChunk;
+        const int cnt = __syncthreads_count(pos < n && sorted_ids[pos] == id);
+        K += cnt;
+        if (cnt < kBlock) break;
+      }
+      // partial 0 sits at perm[h]; partial i >= 1 at perm[nxt + (i - 1) * kSegChunk]
+      RowRegs<VEC, NCH> acc;
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc.v[k][e] = 0.f;
+      for (int64_t i = gidx; i <= K; i += NG) {
+        const int64_t pos = i == 0 ? h : nxt + (i - 1) * kSegChunk;
+        RowRegs<VEC, NCH> t;
+        row_load(t, grad_rows + (int64_t)perm[pos] * D, lig, G, nvec);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc.v[k][e] += t.v[k][e];
+      }
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) red[((gidx * G + lig) * NCH + k) * VEC + e] = acc.v[k][e];
+      __syncthreads();
+      if (gidx == 0) {
+        const int used = (int)min<int64_t>(NG, K + 1);
+        for (int gg = 1; gg < used; ++gg)
+#pragma unroll
+          for (int k = 0; k < NCH; ++k)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc.v[k][e] += red[((gg * G + lig) * NCH + k) * VEC + e];
+        seg_apply<VEC, NCH, OP>(ft, dtype, id, acc, D, lig, G, nvec, lr, eps);
+      }
+      __syncthreads();  // red is rewritten by the next long run
+    }
   }
 }
 
@@ -254,18 +326,40 @@ __global__ __launch_bounds__(kBlock) void concat_offset_ids_kernel(IdSegments sg
 }
 
 template <int OP>
-static int launch_segment_update(const char* who, void* table, int dtype, float* accum, int D,
-                                 const int32_t* sorted_ids, const int32_t* perm, int64_t n, const float* grad_rows,
-                                 float lr, float eps, hipStream_t st) {
+static int launch_segment_tables(const char* who, const FusedTables& ft, int dtype, int D, const int32_t* sorted_ids,
+                                 const int32_t* perm, int64_t n, float* grad_rows, float lr, float eps,
+                                 hipStream_t st) {
   const RowGeom g = row_geom(D);
   if (g.nch > kMaxChunksPerLane) {
     set_error("%s: D=%d not supported", who, D);
     return ESR_EINVAL;
   }
   const int grid = grid_for_groups(n, g.G);
-  ESR_DISPATCH_ROW(g, hipLaunchKernelGGL((segment_update_kernel<VEC, NCH, OP>), dim3(grid), dim3(kBlock), 0, st, table,
-                                         dtype, accum, D, g.G, sorted_ids, perm, n, grad_rows, lr, eps));
+  const int grid2 = (int)std::min<int64_t>(kMaxGrid, cdiv(cdiv(n, kSegChunk), 16));  // 16 chunk boundaries per pass
+  ESR_DISPATCH_ROW(g, {
+    hipLaunchKernelGGL((segment_update_kernel<VEC, NCH, OP>), dim3(grid), dim3(kBlock), 0, st, ft, dtype, D, g.G,
+                       sorted_ids, perm, n, grad_rows, lr, eps);
+    if (n > kSegChunk)
+      hipLaunchKernelGGL((segment_long_kernel<VEC, NCH, OP>), dim3(grid2), dim3(kBlock), 0, st, ft, dtype, D, g.G,
+                         sorted_ids, perm, n, (const float*)grad_rows, lr, eps);
+  });
   return check_launch(who);
+}
+
+template <int OP>
+static int launch_segment_update(const char* who, void* table, int dtype, float* accum, int D,
+                                 const int32_t* sorted_ids, const int32_t* perm, int64_t n, const float* grad_rows,
+                                 float lr, float eps, hipStream_t st) {
+  FusedTables ft;
+  ft.n = 1;
+  for (int i = 0; i < kMaxFusedTables; ++i) {
+    ft.table[i] = i == 0 ? table : nullptr;
+    ft.accum[i] = i == 0 ? accum : nullptr;
+    ft.row_offset[i] = 0;
+  }
+  ft.row_offset[kMaxFusedTables] = 0;
+  // the gradient rows double as scratch for the partial sums of long runs (see segment_update_kernel)
+  return launch_segment_tables<OP>(who, ft, dtype, D, sorted_ids, perm, n, const_cast<float*>(grad_rows), lr, eps, st);
 }
 
 // optax.adam, elementwise over the whole table.
@@ -463,13 +557,8 @@ int esr_sparse_adagrad_scatter_multi(void* const* tables, float* const* accums, 
   ft.row_offset[kMaxFusedTables] = row_offsets[ntables];
   ESR_REQUIRE(row_offsets[ntables] < ((int64_t)1 << 31), "esr_sparse_adagrad_scatter_multi: %lld virtual rows >= 2^31",
               (long long)row_offsets[ntables]);
-  const RowGeom g = row_geom(D);
-  ESR_REQUIRE(g.nch <= kMaxChunksPerLane, "esr_sparse_adagrad_scatter_multi: D=%d not supported", D);
-  const int grid = grid_for_groups(n, g.G);
-  ESR_DISPATCH_ROW(g, hipLaunchKernelGGL((segment_adagrad_multi_kernel<VEC, NCH>), dim3(grid), dim3(kBlock), 0,
-                                         as_stream(stream), ft, dtype, D, g.G, sorted_vids, perm, n, grad_rows, lr,
-                                         eps));
-  return check_launch("esr_sparse_adagrad_scatter_multi");
+  return launch_segment_tables<kAdagrad>("esr_sparse_adagrad_scatter_multi", ft, dtype, D, sorted_vids, perm, n,
+                                         const_cast<float*>(grad_rows), lr, eps, as_stream(stream));
 }
 
 int esr_dense_adam(float* param, float* mu, float* nu, const float* grad, int64_t numel, float lr, float b1,

@@ -139,7 +139,9 @@ int esr_inbatch_towers_fwd_bwd_bf16x3(const void* query_table, int64_t Vq, const
 /* ---- G4 (build's production optimizer): sort + segment-reduce + sparse Adagrad -----------
  * Replaces the dense V x D gradient + dense optimizer sweep of
  * wikipedia/train_cooccurence.py:86-101 with a row-sparse update.
- * esr_segment_sort_ids: stable sort of occurrence ids; perm[k] = original occurrence index. */
+ * esr_segment_sort_ids: stable sort of occurrence ids; perm[k] = original occurrence index.
+ * The scatter entry points below may OVERWRITE grad_rows: runs of equal ids that cross a 32-position boundary are
+ * summed chunk-wise, the partial sums parked in the gradient rows themselves, and combined in a fixed order. */
 size_t esr_segment_sort_workspace_bytes(int64_t n);
 int esr_segment_sort_ids(const int32_t* ids, int64_t n, int64_t V, int32_t* sorted_ids,
                          int32_t* perm, void* workspace, size_t workspace_bytes,

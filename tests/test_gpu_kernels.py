@@ -422,19 +422,56 @@ def test_sparse_adagrad_vs_oracle(dev, kind, D):
     assert np.array_equal(N(table)[untouched], p0[untouched])  # bit-exact: rows without gradient never move
 
 
-def test_segment_sum_is_bit_exact_sequential(dev):
-    """Duplicate ids are summed left to right in occurrence order == a sequential fp32 scatter-add."""
+def test_segment_sum_order_is_fixed(dev):
+    """Duplicate ids are summed in a FIXED order: a run of up to 32 occurrences (up to 63, depending on where it
+    starts) left to right == a sequential fp32 scatter-add, bit for bit; a longer run as chunk partials (head chunk
+    up to the first multiple of 32 at least 32 positions on, then 32 at a time), the partials round-robin over the
+    row groups and then in group order.  Restated here in numpy, compared bit for bit; same bits on a second launch."""
     from esrecsys_amd import ops
     rng = np.random.default_rng(4)
-    V, n, D = 50, 4000, 32
+    V, n, D = 50, 4000, 32        # ~80 occurrences per row: every run crosses chunk boundaries
     ids = rng.integers(0, V, n).astype(np.int32)
+    ids[:7] = V - 1               # (every row has ~80 occurrences here; short runs are covered by the Adagrad tests)
     rows = rng.standard_normal((n, D)).astype(np.float32)
     sid, perm = ops.segment_sort(T(ids, dev), V)
     dense = N(ops.rows_to_dense(V, D, sid, perm, T(rows, dev)))
+    again = N(ops.rows_to_dense(V, D, sid, perm, T(rows, dev)))
+    assert np.array_equal(dense, again)
+    order = np.argsort(ids, kind="stable")
+    sids = ids[order]
     exp = np.zeros((V, D), np.float32)
-    for k in range(n):
-        exp[ids[k]] = exp[ids[k]] + rows[k]
+    NG = 256 // 8                 # D = 32 -> 8 lanes per row group -> 32 groups per workgroup
+    p = 0
+    while p < n:
+        q = p
+        while q < n and sids[q] == sids[p]:
+            q += 1
+        parts, c = [], p          # chunk partials: head chunk, then aligned chunks of 32
+        while c < q:
+            e = min(((c + 63) // 32) * 32 if c == p else c + 32, q)
+            acc = rows[order[c]].copy()
+            for k in range(c + 1, e):
+                acc = acc + rows[order[k]]
+            parts.append(acc)
+            c = e
+        if len(parts) == 1:
+            total = parts[0]
+        else:
+            sums = []
+            for g in range(min(NG, len(parts))):
+                acc = np.zeros(D, np.float32)
+                for i in range(g, len(parts), NG):
+                    acc = acc + parts[i]
+                sums.append(acc)
+            total = sums[0]
+            for g in range(1, len(sums)):
+                total = total + sums[g]
+        exp[sids[p]] = total
+        p = q
     assert np.array_equal(dense, exp)
+    seq = np.zeros((V, D), np.float64)
+    np.add.at(seq, ids, rows.astype(np.float64))
+    assert rel_err(dense, seq) <= 1e-6
 
 
 def test_sparse_adagrad_bf16_table(dev):
@@ -472,7 +509,9 @@ def test_gather_rows_multi(dev):
 
 
 def test_fused_multi_table_adagrad_equals_per_table(dev):
-    """concat_offset_ids + one sort + esr_sparse_adagrad_scatter_multi == the per-table path, bit for bit."""
+    """concat_offset_ids + one sort + esr_sparse_adagrad_scatter_multi == the per-table path (bit for bit on rows whose
+    occurrences sit in one 32-position chunk in both layouts; to fp32 rounding on the 50-fold duplicated rows, whose
+    chunk boundaries fall differently in the concatenated list)."""
     from esrecsys_amd import ops
     rng = np.random.default_rng(21)
     V0, V1, D, B = 700, 1100, 128, 600
@@ -496,7 +535,10 @@ def test_fused_multi_table_adagrad_equals_per_table(dev):
     ops.sparse_adagrad(p0, b0, s0, q0, T(rows[:B], dev), 0.05, 1e-7)
     s1, q1 = ops.segment_sort(T(np.concatenate([i1, i2]), dev), V1)
     ops.sparse_adagrad(p1, b1, s1, q1, T(rows[B:], dev), 0.05, 1e-7)
-    assert torch.equal(f0, p0) and torch.equal(f1, p1) and torch.equal(a0, b0) and torch.equal(a1, b1)
+    hot0, hot1 = np.arange(V0) == 0, np.arange(V1) == V1 - 1
+    assert np.array_equal(N(f0)[~hot0], N(p0)[~hot0]) and np.array_equal(N(f1)[~hot1], N(p1)[~hot1])
+    assert np.array_equal(N(a0)[~hot0], N(b0)[~hot0]) and np.array_equal(N(a1)[~hot1], N(b1)[~hot1])
+    assert rel_err(N(f0), N(p0)) <= 1e-6 and rel_err(N(f1), N(p1)) <= 1e-6
     e1, _ = o_optim.sparse_adagrad_update(t1.astype(F64), np.full((V1, D), 0.1), np.concatenate([i1, i2]),
                                           rows[B:].astype(F64), 0.05, 1e-7, F64)
     assert rel_err(N(f1), e1) <= TOL
