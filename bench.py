@@ -110,7 +110,7 @@ TIMED_GROUPS = {
     "inbatch_mfma": ["inbatch_softmax_fwd_bwd", "inbatch_towers_fwd_bwd"],
     "triplet_fused": ["triplet_fwd_bwd"],
     "glove_fused": ["glove_fwd_bwd"],
-    "segment_sort": ["segment_sort"],
+    "segment_sort": ["segment_sort", "segment_sort_multi"],
     "sparse_adagrad": ["sparse_adagrad", "sparse_adagrad_multi"],
 }
 

@@ -40,12 +40,38 @@ static size_t pair_sort_temp_bytes(int64_t n) {
   return align_up(bytes + 256, 256);
 }
 
+// The occurrence ids may come as up to four segments [ids_k + offset_k] (the towers of one step as virtual rows of
+// their concatenation): the sort kernels read them in place, so no concatenated copy is written first.
+constexpr int kMaxSortSegs = 4;
+struct SortSegs {
+  const int32_t* ids[kMaxSortSegs];
+  int64_t start[kMaxSortSegs + 1];  // position of each segment in the virtual list
+  int64_t offset[kMaxSortSegs];     // added to every id of the segment
+  int n;
+};
+__device__ __forceinline__ int32_t seg_id(const SortSegs& sg, int64_t i) {
+  const int32_t* src = sg.ids[0];
+  int64_t start = 0, off = sg.offset[0];
+#pragma unroll
+  for (int k = 1; k < kMaxSortSegs; ++k)
+    if (k < sg.n && i >= sg.start[k]) {
+      src = sg.ids[k];
+      start = sg.start[k];
+      off = sg.offset[k];
+    }
+  return (int32_t)((int64_t)src[i - start] + off);
+}
+__global__ __launch_bounds__(kBlock) void concat_segs_kernel(SortSegs sg, int64_t n, int32_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+    out[i] = seg_id(sg, i);
+}
+
 // Short occurrence lists (one playlist of the Spotify step, the reference's own batch sizes of 16-128): one
 // workgroup, bitonic sort of (id << 32 | position) in LDS -- stable by construction, one launch instead of the
 // device radix sort's chain of ~6.
 constexpr int kSmallSortMax = 4096;
 constexpr int kSmallSortThreads = 1024;
-__global__ __launch_bounds__(kSmallSortThreads) void segment_sort_small_kernel(const int32_t* __restrict__ ids, int n,
+__global__ __launch_bounds__(kSmallSortThreads) void segment_sort_small_kernel(SortSegs ids, int n,
                                                                               int32_t* __restrict__ sorted_ids,
                                                                               int32_t* __restrict__ perm) {
   __shared__ unsigned long long key[kSmallSortMax];
@@ -53,7 +79,7 @@ __global__ __launch_bounds__(kSmallSortThreads) void segment_sort_small_kernel(c
   int np2 = 1;
   while (np2 < n) np2 <<= 1;
   for (int i = t; i < np2; i += kSmallSortThreads)
-    key[i] = i < n ? (((unsigned long long)(uint32_t)ids[i]) << 32) | (uint32_t)i : ~0ull;
+    key[i] = i < n ? (((unsigned long long)(uint32_t)seg_id(ids, i)) << 32) | (uint32_t)i : ~0ull;
   for (int size = 2; size <= np2; size <<= 1)
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
       __syncthreads();
@@ -82,13 +108,13 @@ __global__ __launch_bounds__(kSmallSortThreads) void segment_sort_small_kernel(c
 constexpr int kTile = 2048, kTileBits = 11, kMidTiles = 16;
 constexpr int kMidSortMax = kTile * kMidTiles;
 constexpr int kMidIdBits = 32 - kTileBits;
-__global__ __launch_bounds__(kSmallSortThreads) void tile_sort_kernel(const int32_t* __restrict__ ids, int n,
+__global__ __launch_bounds__(kSmallSortThreads) void tile_sort_kernel(SortSegs ids, int n,
                                                                      uint32_t* __restrict__ tiles) {
   __shared__ uint32_t key[kTile];
   const int t = threadIdx.x, base = blockIdx.x * kTile;
   for (int i = t; i < kTile; i += kSmallSortThreads) {
     const int g = base + i;
-    key[i] = g < n ? ((uint32_t)ids[g] << kTileBits) | (uint32_t)i : 0xFFFFFFFFu;
+    key[i] = g < n ? ((uint32_t)seg_id(ids, g) << kTileBits) | (uint32_t)i : 0xFFFFFFFFu;
   }
   for (int size = 2; size <= kTile; size <<= 1)
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -387,7 +413,65 @@ extern "C" {
 size_t esr_segment_sort_workspace_bytes(int64_t n) {
   if (n <= 0) return 256;
   const size_t tiles = n <= kMidSortMax ? align_up((size_t)cdiv(n, kTile) * kTile * 4, 256) : 0;
-  return std::max(pair_sort_temp_bytes<false, uint32_t>(n), tiles);
+  // + one column for the concatenated ids of a segmented list on the radix path
+  return std::max(pair_sort_temp_bytes<false, uint32_t>(n) + align_up((size_t)n * 4, 256), tiles);
+}
+
+static int segment_sort_segs(const char* who, const SortSegs& sg, int64_t n, int64_t V, int32_t* sorted_ids,
+                             int32_t* perm, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  if (n <= kSmallSortMax) {
+    hipLaunchKernelGGL(segment_sort_small_kernel, dim3(1), dim3(kSmallSortThreads), 0, st, sg, (int)n, sorted_ids, perm);
+    return check_launch(who);
+  }
+  if (n <= kMidSortMax && V <= ((int64_t)1 << kMidIdBits)) {
+    const int ntiles = (int)cdiv(n, kTile);
+    if ((size_t)ntiles * kTile * 4 > workspace_bytes || ((uintptr_t)workspace & 15)) {
+      set_error("%s: workspace %zu bytes too small (or misaligned)", who, workspace_bytes);
+      return ESR_EWORKSPACE;
+    }
+    uint32_t* tiles = (uint32_t*)workspace;
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(ntiles), dim3(kSmallSortThreads), 0, st, sg, (int)n, tiles);
+    hipLaunchKernelGGL(tile_rank_kernel, dim3((int)cdiv((int64_t)ntiles * kTile * kMidTiles, kBlock)), dim3(kBlock), 0,
+                       st, (const uint32_t*)tiles, (int)n, ntiles, sorted_ids, perm);
+    return check_launch(who);
+  }
+  // device radix sort: needs the ids as one array (materialised at the head of the workspace when segmented)
+  const uint32_t* kin = reinterpret_cast<const uint32_t*>(sg.ids[0]);
+  char* temp = (char*)workspace;
+  size_t temp_bytes = workspace_bytes;
+  if (sg.n > 1 || sg.offset[0] != 0) {
+    const size_t col = align_up((size_t)n * 4, 256);
+    if (col > workspace_bytes || ((uintptr_t)workspace & 15)) {
+      set_error("%s: workspace %zu bytes too small (or misaligned)", who, workspace_bytes);
+      return ESR_EWORKSPACE;
+    }
+    hipLaunchKernelGGL(concat_segs_kernel, dim3((int)std::min<int64_t>(kMaxGrid, cdiv(n, kBlock))), dim3(kBlock), 0, st,
+                       sg, n, (int32_t*)workspace);
+    kin = (const uint32_t*)workspace;
+    temp += col;
+    temp_bytes -= col;
+  }
+  size_t need = 0;
+  const int end_bit = bits_for(V);
+  uint32_t* kout = reinterpret_cast<uint32_t*>(sorted_ids);
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, need, kin, kout, rocprim::counting_iterator<int32_t>(0), perm,
+                                           (size_t)n, 0, end_bit, st, false);
+  if (e != hipSuccess) {
+    set_error("%s: rocprim size query: %s", who, hipGetErrorString(e));
+    return ESR_ELAUNCH;
+  }
+  if (need > temp_bytes || ((uintptr_t)temp & 15)) {
+    set_error("%s: workspace %zu bytes < %zu required (or misaligned)", who, workspace_bytes,
+              need + (size_t)(temp - (char*)workspace));
+    return ESR_EWORKSPACE;
+  }
+  e = rocprim::radix_sort_pairs(temp, need, kin, kout, rocprim::counting_iterator<int32_t>(0), perm, (size_t)n, 0,
+                                end_bit, st, false);
+  if (e != hipSuccess) {
+    set_error("%s: rocprim sort: %s", who, hipGetErrorString(e));
+    return ESR_ELAUNCH;
+  }
+  return check_launch(who);
 }
 
 int esr_segment_sort_ids(const int32_t* ids, int64_t n, int64_t V, int32_t* sorted_ids, int32_t* perm,
@@ -396,44 +480,39 @@ int esr_segment_sort_ids(const int32_t* ids, int64_t n, int64_t V, int32_t* sort
               (long long)n, (long long)V);
   if (n == 0) return ESR_OK;
   ESR_REQUIRE(ids && sorted_ids && perm && workspace, "esr_segment_sort_ids: null pointer");
-  if (n <= kSmallSortMax) {
-    hipLaunchKernelGGL(segment_sort_small_kernel, dim3(1), dim3(kSmallSortThreads), 0, as_stream(stream), ids, (int)n,
-                       sorted_ids, perm);
-    return check_launch("esr_segment_sort_ids(small)");
+  SortSegs sg;
+  sg.n = 1;
+  for (int i = 0; i < kMaxSortSegs; ++i) {
+    sg.ids[i] = i == 0 ? ids : nullptr;
+    sg.offset[i] = 0;
+    sg.start[i] = i == 0 ? 0 : n;
   }
-  if (n <= kMidSortMax && V <= ((int64_t)1 << kMidIdBits)) {
-    const int ntiles = (int)cdiv(n, kTile);
-    if ((size_t)ntiles * kTile * 4 > workspace_bytes || ((uintptr_t)workspace & 15)) {
-      set_error("esr_segment_sort_ids: workspace %zu bytes too small (or misaligned)", workspace_bytes);
-      return ESR_EWORKSPACE;
-    }
-    uint32_t* tiles = (uint32_t*)workspace;
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(ntiles), dim3(kSmallSortThreads), 0, as_stream(stream), ids, (int)n, tiles);
-    hipLaunchKernelGGL(tile_rank_kernel, dim3((int)cdiv((int64_t)ntiles * kTile * kMidTiles, kBlock)), dim3(kBlock), 0,
-                       as_stream(stream), (const uint32_t*)tiles, (int)n, ntiles, sorted_ids, perm);
-    return check_launch("esr_segment_sort_ids(tiles)");
+  sg.start[kMaxSortSegs] = n;
+  return segment_sort_segs("esr_segment_sort_ids", sg, n, V, sorted_ids, perm, workspace, workspace_bytes,
+                           as_stream(stream));
+}
+
+int esr_segment_sort_ids_multi(const int32_t* const* ids, const int64_t* counts, const int64_t* offsets, int nseg,
+                               int64_t V, int32_t* sorted_ids, int32_t* perm, void* workspace, size_t workspace_bytes,
+                               esr_stream_t stream) {
+  ESR_REQUIRE(nseg >= 1 && nseg <= kMaxSortSegs && ids && counts && offsets && V > 0,
+              "esr_segment_sort_ids_multi: nseg=%d not in [1, %d] or null argument", nseg, kMaxSortSegs);
+  SortSegs sg;
+  sg.n = nseg;
+  sg.start[0] = 0;
+  for (int i = 0; i < kMaxSortSegs; ++i) {
+    ESR_REQUIRE(i >= nseg || (counts[i] >= 0 && (counts[i] == 0 || ids[i])), "esr_segment_sort_ids_multi: bad segment %d",
+                i);
+    sg.ids[i] = i < nseg ? ids[i] : nullptr;
+    sg.offset[i] = i < nseg ? offsets[i] : 0;
+    sg.start[i + 1] = sg.start[i] + (i < nseg ? counts[i] : 0);
   }
-  size_t need = 0;
-  const int end_bit = bits_for(V);
-  const uint32_t* kin = reinterpret_cast<const uint32_t*>(ids);
-  uint32_t* kout = reinterpret_cast<uint32_t*>(sorted_ids);
-  hipError_t e = rocprim::radix_sort_pairs(nullptr, need, kin, kout, rocprim::counting_iterator<int32_t>(0), perm,
-                                           (size_t)n, 0, end_bit, as_stream(stream), false);
-  if (e != hipSuccess) {
-    set_error("esr_segment_sort_ids: rocprim size query: %s", hipGetErrorString(e));
-    return ESR_ELAUNCH;
-  }
-  if (need > workspace_bytes || ((uintptr_t)workspace & 15)) {
-    set_error("esr_segment_sort_ids: workspace %zu bytes < %zu required (or misaligned)", workspace_bytes, need);
-    return ESR_EWORKSPACE;
-  }
-  e = rocprim::radix_sort_pairs(workspace, need, kin, kout, rocprim::counting_iterator<int32_t>(0), perm, (size_t)n,
-                                0, end_bit, as_stream(stream), false);
-  if (e != hipSuccess) {
-    set_error("esr_segment_sort_ids: rocprim sort: %s", hipGetErrorString(e));
-    return ESR_ELAUNCH;
-  }
-  return check_launch("esr_segment_sort_ids");
+  const int64_t n = sg.start[nseg];
+  ESR_REQUIRE(n < ((int64_t)1 << 31), "esr_segment_sort_ids_multi: n=%lld", (long long)n);
+  if (n == 0) return ESR_OK;
+  ESR_REQUIRE(sorted_ids && perm && workspace, "esr_segment_sort_ids_multi: null pointer");
+  return segment_sort_segs("esr_segment_sort_ids_multi", sg, n, V, sorted_ids, perm, workspace, workspace_bytes,
+                           as_stream(stream));
 }
 
 // ------------------------------------------------------------------------------------------------

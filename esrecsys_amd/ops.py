@@ -258,6 +258,27 @@ def segment_sort(ids, V):
     return sorted_ids, perm
 
 
+def segment_sort_multi(id_tensors, offsets, V):
+    """Stable sort of the virtual list [ids_0 + offsets[0] ; ids_1 + offsets[1] ; ...] without materialising it.
+    Returns (sorted virtual ids, perm)."""
+    import ctypes
+    lib = _lib.load()
+    k = len(id_tensors)
+    for t in id_tensors:
+        _req(t, torch.int32, "ids")
+    counts = [int(t.numel()) for t in id_tensors]
+    n, dev = sum(counts), id_tensors[0].device
+    sorted_ids = torch.empty(n, dtype=torch.int32, device=dev)
+    perm = torch.empty(n, dtype=torch.int32, device=dev)
+    ws = _ws(_ws_bytes("esr_segment_sort_workspace_bytes", n), dev)
+    ptrs = (ctypes.c_void_p * k)(*[t.data_ptr() for t in id_tensors])
+    cnt = (ctypes.c_int64 * k)(*counts)
+    off = (ctypes.c_int64 * k)(*[int(x) for x in offsets])
+    check(lib.esr_segment_sort_ids_multi(ptrs, cnt, off, k, V, _p(sorted_ids), _p(perm), _p(ws), ws.numel(), _stream()),
+          "esr_segment_sort_ids_multi")
+    return sorted_ids, perm
+
+
 def sparse_adagrad(table, accum, sorted_ids, perm, grad_rows, lr, eps=1e-7):
     """In-place row-sparse Adagrad on `table` / `accum` for the rows named by sorted_ids."""
     lib = _lib.load()

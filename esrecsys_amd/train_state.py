@@ -34,11 +34,18 @@ class SegmentIndex:
     chain of ~6 short launches, 25 us of pure latency at these sizes -- profiles/r1); ``sorted()`` makes the
     consuming stream wait on its event."""
 
-    def __init__(self, ids, num_rows):
-        self.ids = ids  # int32 [n] on device
+    def __init__(self, ids, num_rows, segments=None):
+        self._ids = ids  # int32 [n] on device, or None while only `segments` is known
+        self.segments = segments  # optional ([id tensors], [offsets]): the list is their virtual concatenation
         self.num_rows = int(num_rows)
         self._sorted = None
         self._event = None
+
+    @property
+    def ids(self):
+        if self._ids is None:
+            self._ids = ops.concat_offset_ids(list(self.segments[0]), list(self.segments[1]))
+        return self._ids
 
     def presort(self):
         if self._sorted is not None or not self.ids.is_cuda:
@@ -57,7 +64,10 @@ class SegmentIndex:
 
     def sorted(self):
         if self._sorted is None:
-            self._sorted = ops.segment_sort(self.ids, self.num_rows)
+            if self._ids is None and self.segments is not None:  # sort the segments in place: no concatenated copy
+                self._sorted = ops.segment_sort_multi(self.segments[0], self.segments[1], self.num_rows)
+            else:
+                self._sorted = ops.segment_sort(self.ids, self.num_rows)
         elif self._event is not None:
             torch.cuda.current_stream(self.ids.device).wait_event(self._event)
             self._event = None
@@ -79,8 +89,7 @@ class FusedScatter:
         self.row_offsets = offs
         self.paths = [tuple(p) for p in paths]
         self.rows = rows  # f32 [sum n_i, D]; may be filled in later (the ids are known before the gradients)
-        vids = ops.concat_offset_ids(list(id_tensors), [offs[s] for s in slots])
-        self.index = SegmentIndex(vids, offs[-1])
+        self.index = SegmentIndex(None, offs[-1], segments=(list(id_tensors), [offs[s] for s in slots]))
 
 
 class RowGrads:

@@ -146,6 +146,12 @@ size_t esr_segment_sort_workspace_bytes(int64_t n);
 int esr_segment_sort_ids(const int32_t* ids, int64_t n, int64_t V, int32_t* sorted_ids,
                          int32_t* perm, void* workspace, size_t workspace_bytes,
                          esr_stream_t stream);
+/* The same sort over a list given as up to four segments [ids_k + offsets[k]] (the towers of one step as virtual rows
+ * offsets[k] + id of their concatenation): read in place, no concatenated copy.  Same workspace query with
+ * n = the sum of the counts. */
+int esr_segment_sort_ids_multi(const int32_t* const* ids, const int64_t* counts, const int64_t* offsets, int nseg,
+                               int64_t V, int32_t* sorted_ids, int32_t* perm, void* workspace,
+                               size_t workspace_bytes, esr_stream_t stream);
 /* For each distinct id: G = sum of its grad rows (occurrence order); acc += G*G;
  * p -= lr * G * rsqrt(acc + eps).  table dtype f32 or bf16 (fp32 accumulator either way). */
 int esr_sparse_adagrad_scatter(void* table, int dtype, float* accum, int64_t V, int D,

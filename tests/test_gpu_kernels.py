@@ -527,6 +527,12 @@ def test_fused_multi_table_adagrad_equals_per_table(dev):
     vids = ops.concat_offset_ids([T(i0, dev), T(i1, dev), T(i2, dev)], [0, V0, V0])
     assert np.array_equal(N(vids), np.concatenate([i0, i1 + V0, i2 + V0]))
     sv, perm = ops.segment_sort(vids, V0 + V1)
+    sv2, perm2 = ops.segment_sort_multi([T(i0, dev), T(i1, dev), T(i2, dev)], [0, V0, V0], V0 + V1)   # no concat copy
+    assert torch.equal(sv, sv2) and torch.equal(perm, perm2)
+    big = [T(rng.integers(0, 5_000_000, 30_000).astype(np.int32), dev) for _ in range(2)]              # radix path
+    sb, pb = ops.segment_sort_multi(big, [0, 5_000_000], 10_000_000)
+    sb1, pb1 = ops.segment_sort(ops.concat_offset_ids(big, [0, 5_000_000]), 10_000_000)
+    assert torch.equal(sb, sb1) and torch.equal(pb, pb1)
     ops.sparse_adagrad_multi([f0, f1], [a0, a1], [0, V0, V0 + V1], sv, perm, T(rows, dev), 0.05, 1e-7)
     # per-table reference path
     p0, p1 = T(t0, dev), T(t1, dev)
