@@ -10,14 +10,18 @@ travel together: their ids become *virtual ids* ``voff[t] + id`` with every ``vo
 owner maps back to (table, local row).  One step of a group is then four collectives over RCCL all-to-all
 (xGMI is a full mesh: every peer slice rides its own link) instead of three per table:
 
-    counts -> peers      int64 [G, L]                      \\  the routing PLAN: depends on the ids only, built
-    vids   -> owners     int32 virtual local rows          /   for batch k+1 right after step k is enqueued
-    rows   <- owners     [n, D]  (multi-table gather kernel on the owner, un-permute kernel on return)
-    grads  -> owners     [n, D]  (permute kernel; then ONE fused sort + segment-reduce + Adagrad launch)
+    counts -> peers      int64 [G, L]                      \\  the routing PLAN: depends on the ids only, pipelined
+    vids   -> owners     int32 virtual local rows          /   two batches deep (begin_plans / PendingPlans.finish)
+    rows   <- owners     [n, D]  (multi-table gather kernel on the owner; the rows stay in exchange order and
+                                  the loss kernels index them through the inverse routing permutation)
+    grads  -> owners     [n, D]  (written by the loss kernels directly in exchange order; then ONE fused
+                                  segment-reduce + Adagrad on the owner, its sort done in the plan phase)
 
-The plan phase holds the step's single host synchronisation (``all_to_all_single`` needs host-side split
-sizes); a training loop issues it one batch ahead so the read-back waits behind useful GPU work.  The
-owner-side sort of the received ids is part of the plan as well.
+The plan phase holds the step's single host read-back (all-to-all-v needs host-side split sizes): begin_plans
+enqueues the bucket kernel, the counts exchange and an asynchronous copy to pinned memory; finish() -- called one
+step later, when the next step's kernels are already queued -- waits for that copy only, then exchanges the ids
+and sorts them on the owner.  The exchange itself is RCCL send / recv on the compute stream (esrecsys_amd/rccl.py),
+falling back to torch.distributed.all_to_all_single.
 
 ``torch.distributed`` is plumbing (backend "nccl" == RCCL on ROCm; "gloo" in the CPU tests); the kernels
 are libesr_hip.so.  ``kernels`` is the module that provides them -- always ``esrecsys_amd.ops`` in the
@@ -67,20 +71,6 @@ class RoutingPlan:
         self.recv_counts = recv_counts      # python ints per peer: ids that peer asks of this rank
         self.recv_local_rows = None         # int32 [sum(recv_counts)]: virtual local rows requested of this rank
         self.owner_sorted = None            # (sorted, permutation) of recv_local_rows, for the update
-        self.ready = None                   # event recorded on the planning stream once everything above exists
-
-    def wait_ready(self):
-        """Make the current stream wait for a plan that was built on a side stream (no-op otherwise)."""
-        if self.ready is not None:
-            cur = torch.cuda.current_stream()
-            cur.wait_event(self.ready)
-            tensors = [self.local_rows, self.perm, self.recv_local_rows]
-            if self.owner_sorted is not None:
-                tensors += list(self.owner_sorted)
-            for t in tensors:  # allocated on the planning stream, consumed here: keep the allocator from recycling
-                if t is not None and t.is_cuda:
-                    t.record_stream(cur)
-            self.ready = None
 
     def exchange_ids(self):
         if self.recv_local_rows is None:
@@ -151,28 +141,12 @@ def begin_plans(lookups):
     return PendingPlans(parts, both, both, None)
 
 
-def make_plans(lookups, stream=None, ids_ready=False):
-    """lookups: list of (ShardedTableGroup, virtual ids int32 [n]).  One counts all-to-all and one host sync
-    for the whole list.  Returns one RoutingPlan per lookup (ids exchanged, owner-side sort done).
-
-    `stream`: optionally a side HIP stream to plan on (`ids_ready=True` promises that the ids are already resident,
-    so that stream does not wait for the main one).  A training loop should prefer begin_plans / finish one step
-    apart: see bench_sharded.py."""
+def make_plans(lookups):
+    """lookups: list of (ShardedTableGroup, virtual ids int32 [n]).  One counts all-to-all and one host sync for the
+    whole list.  Returns one RoutingPlan per lookup (ids exchanged, owner-side sort done).  A training loop should
+    call begin_plans / finish one step apart instead (see bench_sharded.py): the host wait then never stalls the GPU."""
     if not lookups:
         return []
-    if stream is not None:
-        if not ids_ready:
-            stream.wait_stream(torch.cuda.current_stream())  # the ids may have been produced on the main stream
-        with torch.cuda.stream(stream):
-            plans = make_plans(lookups)
-            ev = torch.cuda.Event()
-            ev.record(stream)
-        for p in plans:
-            p.ready = ev
-        for _, vids in lookups:
-            if vids.is_cuda:
-                vids.record_stream(stream)
-        return plans
     return begin_plans(lookups).finish()
 
 
@@ -211,14 +185,13 @@ class ShardedTableGroup:
             return id_tensors[0]
         return self.k.concat_offset_ids(list(id_tensors), [self.voff[s] for s in slots])
 
-    def plan(self, vids, stream=None, ids_ready=False):
-        return make_plans([(self, vids)], stream=stream, ids_ready=ids_ready)[0]
+    def plan(self, vids):
+        return make_plans([(self, vids)])[0]
 
     def lookup_bucketed(self, plan):
         """The looked-up rows in BUCKET order (row plan.inv[i] belongs to virtual id i), in the tables' dtype --
         for consumers that can index them themselves and so skip the un-permute pass."""
         k = self.k
-        plan.wait_ready()
         recv = plan.exchange_ids()
         if len(self.tables) == 1:
             served = k.gather_rows(self.tables[0].local, recv)
@@ -259,30 +232,17 @@ class ShardedTableGroup:
                                    sorted_rows, perm, rows, lr, eps)
 
 
-def _on(stream):
-    import contextlib
-    return torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+def plan_inbatch(towers, scene_ids, pos_ids):
+    return towers.plan(towers.virtual_ids([scene_ids, pos_ids], [0, 1]))
 
 
-def plan_inbatch(towers, scene_ids, pos_ids, stream=None, ids_ready=False):
-    if stream is not None and not ids_ready:
-        stream.wait_stream(torch.cuda.current_stream())
-    with _on(stream):
-        vids = towers.virtual_ids([scene_ids, pos_ids], [0, 1])
-    return towers.plan(vids, stream=stream, ids_ready=True)
+def plan_triplet(towers, scene_ids, pos_ids, neg_ids):
+    return towers.plan(towers.virtual_ids([scene_ids, pos_ids, neg_ids], [0, 1, 1]))
 
 
-def plan_triplet(towers, scene_ids, pos_ids, neg_ids, stream=None, ids_ready=False):
-    if stream is not None and not ids_ready:
-        stream.wait_stream(torch.cuda.current_stream())
-    with _on(stream):
-        vids = towers.virtual_ids([scene_ids, pos_ids, neg_ids], [0, 1, 1])
-    return towers.plan(vids, stream=stream, ids_ready=True)
-
-
-def plan_glove(emb_group, inputs, stream=None, ids_ready=False):
+def plan_glove(emb_group, inputs):
     """The embedding and bias tables are indexed by the same ids and sharded the same way: one routing."""
-    return emb_group.plan(inputs.reshape(-1), stream=stream, ids_ready=ids_ready)
+    return emb_group.plan(inputs.reshape(-1))
 
 
 class _Pending1:
