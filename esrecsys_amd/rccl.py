@@ -112,9 +112,13 @@ def exchange_for(group, device):
         return None
     key = (id(group), device.index)
     if key not in _cache:
+        x = None
         try:
-            _cache[key] = DirectExchange(group, device)
-        except Exception as e:  # a missing symbol / failed bootstrap must not take the step down
-            print("esrecsys_amd.rccl: direct exchange unavailable (%s); using torch.distributed" % e)
-            _cache[key] = None
+            x = DirectExchange(group, device)
+        except Exception as e:  # a missing symbol / failed bootstrap / wrong self-test data must not take the step down
+            print("esrecsys_amd.rccl: direct exchange unavailable on rank %d (%s)" % (dist.get_rank(group), e))
+        # every rank must take the same path: one failing rank sends all of them back to torch.distributed
+        ok = torch.tensor([1 if x is not None else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        _cache[key] = x if int(ok) == 1 else None
     return _cache[key]
