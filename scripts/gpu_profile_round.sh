@@ -7,6 +7,9 @@ for w in inbatch triplet glove retrieve; do
   (timeout 400 python bench.py --workload $w 2>&1 | grep -v amdgpu.ids | tail -1) > $R/bench_$w.json
 done
 (timeout 300 python bench.py --precision f32 --no-cpu-baseline 2>&1 | grep -v amdgpu.ids | tail -1) > $R/bench_inbatch_f32.json
+for w in inbatch triplet glove; do
+  (timeout 300 python bench.py --workload $w --ids zipf --no-cpu-baseline 2>&1 | grep -v amdgpu.ids | tail -1) > $R/bench_${w}_zipf.json
+done
 (timeout 300 python bench.py --workload triplet --graph --no-cpu-baseline 2>&1 | grep -v amdgpu.ids | tail -1) > $R/bench_triplet_hipgraph.json
 (timeout 300 python bench.py --table-dtype bf16 --no-cpu-baseline 2>&1 | grep -v amdgpu.ids | tail -1) > $R/bench_inbatch_bf16_tables.json
 for w in inbatch triplet glove; do
