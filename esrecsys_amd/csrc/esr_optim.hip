@@ -220,7 +220,7 @@ __global__ __launch_bounds__(kBlock) void segment_long_kernel(FusedTables ft, in
                                                              const float* __restrict__ grad_rows, float lr,
                                                              float eps) {
   __shared__ float red[kBlock * VEC * NCH];  // [groups][lanes][NCH][VEC]
-  constexpr int kPass = 16;                  // chunk boundaries screened per workgroup pass (long runs are then
+  constexpr int kPass = 4;                   // chunk boundaries screened per workgroup pass (long runs are then
                                              // spread over many workgroups instead of queueing in a few)
   __shared__ long long s_long[kPass];        // chunk boundaries at which a long run leaves its first chunk
   __shared__ int s_nlong, s_hoff;
@@ -367,7 +367,7 @@ static int launch_segment_tables(const char* who, const FusedTables& ft, int dty
     return ESR_EINVAL;
   }
   const int grid = grid_for_groups(n, g.G);
-  const int grid2 = (int)std::min<int64_t>(kMaxGrid, cdiv(cdiv(n, kSegChunk), 16));  // 16 chunk boundaries per pass
+  const int grid2 = (int)std::min<int64_t>(kMaxGrid, cdiv(cdiv(n, kSegChunk), 4));  // 4 chunk boundaries per pass
   ESR_DISPATCH_ROW(g, {
     hipLaunchKernelGGL((segment_update_kernel<VEC, NCH, OP>), dim3(grid), dim3(kBlock), 0, st, ft, dtype, D, g.G,
                        sorted_ids, perm, n, grad_rows, lr, eps);
