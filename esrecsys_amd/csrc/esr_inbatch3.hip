@@ -48,8 +48,27 @@ constexpr float k3Ln2 = 0.6931471805599453f;
 //   row-major   : 16-B segment index ^= (row & 15)
 //   transposed  : 16-B segment index ^= ((d >> 2) & 3)
 constexpr int kPlaneBytes = 8192;
-constexpr int kTOff = 3 * kPlaneBytes;   // 24576
-constexpr int kBufBytes = 6 * kPlaneBytes + 256;  // 49408: six planes + 128 B of streamed-row lse (pass C)
+// kUseTr: the O^T phase takes its A operand (Y^T) from the ROW-MAJOR image with the transposing LDS read
+// ds_read_b64_tr_b16 (four k-rows x 16 d-columns per 16-lane group, delivered column-per-lane), so the transposed
+// image -- half of every chunk's DMA pieces and half of the LDS ring -- is not needed.
+constexpr bool kUseTr = true;
+constexpr int kTOff = 3 * kPlaneBytes;   // 24576 (transposed planes, only without kUseTr)
+constexpr int kLseOff = (kUseTr ? 3 : 6) * kPlaneBytes;  // 128 B of streamed-row lse (pass C) behind the planes
+constexpr int kBufBytes = kLseOff + 256;
+// 16-B segment swizzle of a row-major row.  j & 15 serves the ds_read_b128 fragment reads (16 distinct rows per lane
+// group); the transposing reads touch 4 consecutive rows x 4 consecutive segments per 16-lane group and need the 4
+// rows on 4 different segment quads: swap the two bit pairs (still a bijection on 0..15, so b128 stays conflict-free).
+__device__ __forceinline__ constexpr int swz16(int row) {
+  return kUseTr ? (((row & 3) << 2) | ((row >> 2) & 3)) : (row & 15);
+}
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+// ds_read_b64_tr_b16 as inline assembly (see ESR_O_LOAD for why not the builtin); result valid after lgkmcnt(0)
+__device__ __forceinline__ s16x4 tr_read(uint32_t lds_addr) {
+  s16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr));
+  return v;
+}
 constexpr int k3Bufs = 3;
 
 __device__ __forceinline__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -136,7 +155,7 @@ __global__ __launch_bounds__(256) void split3_kernel(RowSrc X0, RowSrc X1,
     __bf16 a, b, c;
     split3(v[e], a, b, c);
     p[0][e >> 3][e & 7] = a; p[1][e >> 3][e & 7] = b; p[2][e >> 3][e & 7] = c;
-    tl[0][d0 + e][pos] = a; tl[1][d0 + e][pos] = b; tl[2][d0 + e][pos] = c;
+    if (!kUseTr) { tl[0][d0 + e][pos] = a; tl[1][d0 + e][pos] = b; tl[2][d0 + e][pos] = c; }
   }
 #pragma unroll
   for (int pl = 0; pl < 3; ++pl) {
@@ -144,6 +163,7 @@ __global__ __launch_bounds__(256) void split3_kernel(RowSrc X0, RowSrc X1,
     dst[0] = p[pl][0];
     dst[1] = p[pl][1];
   }
+  if (kUseTr) return;  // the main kernel reads Y^T out of the row-major image
   __syncthreads();
   const int64_t nch = B / 32;
 #pragma unroll
@@ -174,7 +194,7 @@ __device__ __forceinline__ uint32_t dma_off0(int64_t B, int64_t nch, int64_t chu
   const int within = (t + 256 * K) & 511;
   int64_t e;
   if (K < 6) {
-    const int row = within >> 4, seg = (within & 15) ^ (row & 15);
+    const int row = within >> 4, seg = (within & 15) ^ swz16(row);
     e = ((int64_t)(K >> 1) * B + chunk * 32 + row) * k3D + seg * 8;
   } else {
     const int d = within >> 2, seg = (within & 3) ^ ((d >> 2) & 3);
@@ -203,8 +223,9 @@ __device__ __forceinline__ void dma_piece(const char* __restrict__ baseR, const 
 // issue the 12 pieces of the chunk the offsets currently address, then advance them to the next chunk
 #define ESR_DMA_CHUNK(BUF)                                                                                 \
   ESR_DP(0, g0, BUF); ESR_DP(1, g1, BUF); ESR_DP(2, g2, BUF); ESR_DP(3, g3, BUF); ESR_DP(4, g4, BUF);       \
-  ESR_DP(5, g5, BUF); ESR_DP(6, g6, BUF); ESR_DP(7, g7, BUF); ESR_DP(8, g8, BUF); ESR_DP(9, g9, BUF);       \
-  ESR_DP(10, g10, BUF); ESR_DP(11, g11, BUF);                                                              \
+  ESR_DP(5, g5, BUF);                                                                                      \
+  if (!kUseTr) { ESR_DP(6, g6, BUF); ESR_DP(7, g7, BUF); ESR_DP(8, g8, BUF); ESR_DP(9, g9, BUF);            \
+                 ESR_DP(10, g10, BUF); ESR_DP(11, g11, BUF); }                                             \
   ESR_DMA_ADVANCE();
 // step the 12 offsets to the next chunk of this split's ring (wraps from the last chunk to the first)
 #define ESR_DMA_ADVANCE()                                                                                  \
@@ -242,7 +263,7 @@ __device__ unsigned long long esr_ib3_dbg[4096];
   {                                                                                                       \
     _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) SA[r_] = 0.f;                                       \
     const char* ap0_ = (NBUF) + j * 256;                                                                  \
-    const int sw_ = j & 15;                                                                               \
+    const int sw_ = swz16(j);                                                                             \
     bf16x8 a1_ = *reinterpret_cast<const bf16x8*>(ap0_ + ((h ^ sw_) << 4));                               \
     bf16x8 a2_ = *reinterpret_cast<const bf16x8*>(ap0_ + ((h ^ sw_) << 4) + kPlaneBytes);                 \
     bf16x8 a3_ = *reinterpret_cast<const bf16x8*>(ap0_ + ((h ^ sw_) << 4) + 2 * kPlaneBytes);             \
@@ -301,6 +322,13 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);  // provably wave-uniform: DMA bases stay in SGPRs
   const int j = lane & 31, h = lane >> 5;
+  // transposing-read addressing of the O^T phase (see ESR_O_LOAD): byte offsets inside a row-major plane
+  const int tr_a = (lane & 15) >> 2;
+  const int tr_e = (2 * ((lane >> 4) & 1)) + ((lane & 3) >> 1), tr_low = (lane & 1) * 8;
+  // k-value kk of half h and k-step G is streamed row 16 G + 4 h + (kk & 3) + 8 (kk >> 2) (the order in which the
+  // S^T accumulators hand over P): the two reads fetch rows 16 G + 4 h + 0..3 and 16 G + 8 + 4 h + 0..3
+  const int tr_row0 = (4 * h + tr_a) * 256, tr_row1 = (4 * h + 8 + tr_a) * 256;
+  const int tr_l0 = ((tr_e ^ (h & 3)) << 4) | tr_low, tr_l1 = ((tr_e ^ ((h + 2) & 3)) << 4) | tr_low;
   const int ob = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
   const int64_t xrow = (int64_t)ob * k3Owned + w * 32 + j;  // this lane's owned row
   const int nc = (int)(B / k3Chunk) / nsplit;               // chunks per split
@@ -341,7 +369,7 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
     _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) rf[r_] = refv;                                     \
   } else {                                                                                               \
     _Pragma("unroll") for (int g4_ = 0; g4_ < 4; ++g4_) {                                                \
-      const float4 lv_ = *reinterpret_cast<const float4*>((BUF) + 6 * kPlaneBytes + (8 * g4_ + 4 * h) * 4); \
+      const float4 lv_ = *reinterpret_cast<const float4*>((BUF) + kLseOff + (8 * g4_ + 4 * h) * 4);       \
       rf[4 * g4_] = lv_.x; rf[4 * g4_ + 1] = lv_.y; rf[4 * g4_ + 2] = lv_.z; rf[4 * g4_ + 3] = lv_.w;    \
     }                                                                                                    \
   }
@@ -360,7 +388,9 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
         pb[q_][g_] = __builtin_bit_cast(bf16x8, u_);                                                      \
       }                                                                                                   \
     bf16x8 ta_[4][3];                                                                                     \
+    const uint32_t obuf_lds_ = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(BUF);  \
     ESR_O_LOAD(BUF, 0, 2); ESR_O_LOAD(BUF, 0, 0); ESR_O_LOAD(BUF, 0, 1);                                  \
+    if (kUseTr) ESR_TR_WAIT();                                                                            \
     ESR_SB(); ESR_O_ROW(2, 0, 0); ESR_SB(); if (DMA_ON) { ESR_DP(0, g0, DBUF); }                  \
     ESR_SB(); ESR_O_ROW(0, 2, 0); ESR_SB(); if (DMA_ON) { ESR_DP(1, g1, DBUF); }                  \
     ESR_SB(); ESR_O_ROW(1, 1, 0); ESR_SB(); if (DMA_ON) { ESR_DP(2, g2, DBUF); }                  \
@@ -368,25 +398,45 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
     ESR_SB(); ESR_O_ROW(0, 1, 0); ESR_SB(); if (DMA_ON) { ESR_DP(4, g4, DBUF); }                  \
     ESR_SB(); ESR_O_ROW(0, 0, 0); ESR_SB(); if (DMA_ON) { ESR_DP(5, g5, DBUF); }                  \
     ESR_O_LOAD(BUF, 1, 2); ESR_O_LOAD(BUF, 1, 0); ESR_O_LOAD(BUF, 1, 1);                                  \
-    ESR_SB(); ESR_O_ROW(2, 0, 1); ESR_SB(); if (DMA_ON) { ESR_DP(6, g6, DBUF); }                  \
-    ESR_SB(); ESR_O_ROW(0, 2, 1); ESR_SB(); if (DMA_ON) { ESR_DP(7, g7, DBUF); }                  \
-    ESR_SB(); ESR_O_ROW(1, 1, 1); ESR_SB(); if (DMA_ON) { ESR_DP(8, g8, DBUF); }                  \
-    ESR_SB(); ESR_O_ROW(1, 0, 1); ESR_SB(); if (DMA_ON) { ESR_DP(9, g9, DBUF); }                  \
-    ESR_SB(); ESR_O_ROW(0, 1, 1); ESR_SB(); if (DMA_ON) { ESR_DP(10, g10, DBUF); }                \
-    ESR_SB(); ESR_O_ROW(0, 0, 1); ESR_SB(); if (DMA_ON) { ESR_DP(11, g11, DBUF); }                \
+    if (kUseTr) ESR_TR_WAIT();                                                                            \
+    ESR_SB(); ESR_O_ROW(2, 0, 1); ESR_SB(); if (DMA_ON && !kUseTr) { ESR_DP(6, g6, DBUF); }                  \
+    ESR_SB(); ESR_O_ROW(0, 2, 1); ESR_SB(); if (DMA_ON && !kUseTr) { ESR_DP(7, g7, DBUF); }                  \
+    ESR_SB(); ESR_O_ROW(1, 1, 1); ESR_SB(); if (DMA_ON && !kUseTr) { ESR_DP(8, g8, DBUF); }                  \
+    ESR_SB(); ESR_O_ROW(1, 0, 1); ESR_SB(); if (DMA_ON && !kUseTr) { ESR_DP(9, g9, DBUF); }                  \
+    ESR_SB(); ESR_O_ROW(0, 1, 1); ESR_SB(); if (DMA_ON && !kUseTr) { ESR_DP(10, g10, DBUF); }                \
+    ESR_SB(); ESR_O_ROW(0, 0, 1); ESR_SB(); if (DMA_ON && !kUseTr) { ESR_DP(11, g11, DBUF); }                \
     if (DMA_ON) ESR_DMA_ADVANCE();                                                                        \
   }
+// A fragment of the O^T phase: lane (j, h) needs Y[16 G + 4 h + {0..3, 8..11}][32 db + j] of plane PL.  Transposed
+// image (columns pre-permuted by row_to_pos): one ds_read_b128.  Row-major image + ds_read_b64_tr_b16: lane l =
+// (16-lane group g16 = (l / 16) % 2, i16 = l % 16) passes the address of Y[r0 + i16 / 4][32 db + 16 g16 + 4 (i16 % 4)
+// .. + 3] and receives rows r0 .. r0 + 3 of column 32 db + 16 g16 + i16 (= 32 db + j); two reads (r0 = 16 G + 4 h and
+// + 8) make the eight k-values.
+// The transposing read is issued as inline assembly: through the builtin, hipcc treats it as possibly aliasing the
+// LDS-DMA pieces issued a few instructions earlier and stalls the wave on s_waitcnt vmcnt(0) in the middle of the
+// phase (O phase 3018 cycles per chunk instead of 2295).  The asm is opaque to that analysis; its results are
+// fenced by ESR_TR_WAIT() before the first MFMA that consumes them.
+#define ESR_TR_WAIT() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ESR_SB(); }
 #define ESR_O_LOAD(BUF, G, PL)                                                                            \
-  _Pragma("unroll") for (int db_ = 0; db_ < 4; ++db_)                                                     \
-    ta_[db_][PL] = *reinterpret_cast<const bf16x8*>((BUF) + kTOff + (PL) * kPlaneBytes + (db_ * 32 + j) * 64 + \
-                                                    (((2 * (G) + h) ^ ((j >> 2) & 3)) << 4));
+  _Pragma("unroll") for (int db_ = 0; db_ < 4; ++db_) {                                                   \
+    if (kUseTr) {                                                                                         \
+      const uint32_t pb_ = obuf_lds_ + (PL) * kPlaneBytes + (16 * (G)) * 256;                             \
+      const s16x4 lo_ = tr_read(pb_ + tr_row0 + (((db_ ^ tr_a) << 6) | tr_l0));                           \
+      const s16x4 hi_ = tr_read(pb_ + tr_row1 + (((db_ ^ tr_a) << 6) | tr_l1));                           \
+      const s16x8 both_ = {lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]};               \
+      ta_[db_][PL] = __builtin_bit_cast(bf16x8, both_);                                                   \
+    } else {                                                                                              \
+      ta_[db_][PL] = *reinterpret_cast<const bf16x8*>((BUF) + kTOff + (PL) * kPlaneBytes +                \
+                                                      (db_ * 32 + j) * 64 + (((2 * (G) + h) ^ ((j >> 2) & 3)) << 4)); \
+    }                                                                                                     \
+  }
 // the 128-B lse block of pass C rides with the tile
 // (issued by every wave and every lane, branch-free: lanes 32-63 and waves 1-3 rewrite the same values; a
 // branch here splits the loop body into blocks and costs 64 accumulator-register moves at the join)
 #define ESR_DMA_LSE(BUF)                                                                                  \
   if (!QSIDE)                                                                                             \
     __builtin_amdgcn_global_load_lds((gptr_t)(ref + (c0 + dpos) * 32 + (lane & 31)),                      \
-                                     (lptr_t)((BUF) + 6 * kPlaneBytes), 4, 0, 0);
+                                     (lptr_t)((BUF) + kLseOff), 4, 0, 0);
 
   // All workgroups of an XCD stream the same split in the same order, so a chunk is fetched from HBM/MALL once
   // and hit in that XCD's L2 by the other 31 CUs (measured 92 % TCC hit rate; rotating each workgroup's start
@@ -563,7 +613,7 @@ __global__ __launch_bounds__(256) void inbatch3_rowmax_kernel(const __bf16* __re
         for (int r = 0; r < 16; ++r) sa[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-          const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(buf + j * 256 + (((2 * s + h) ^ (j & 15)) << 4));
+          const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(buf + j * 256 + (((2 * s + h) ^ swz16(j)) << 4));
           sa = ESR_MFMA_BF16(a1, bx0[s], sa);
         }
 #pragma unroll
