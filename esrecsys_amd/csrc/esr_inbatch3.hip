@@ -51,7 +51,10 @@ constexpr int kPlaneBytes = 8192;
 // kUseTr: the O^T phase takes its A operand (Y^T) from the ROW-MAJOR image with the transposing LDS read
 // ds_read_b64_tr_b16 (four k-rows x 16 d-columns per 16-lane group, delivered column-per-lane), so the transposed
 // image -- half of every chunk's DMA pieces and half of the LDS ring -- is not needed.
-constexpr bool kUseTr = true;
+#ifndef ESR_IB3_USE_TR
+#define ESR_IB3_USE_TR 1
+#endif
+constexpr bool kUseTr = ESR_IB3_USE_TR != 0;
 constexpr int kTOff = 3 * kPlaneBytes;   // 24576 (transposed planes, only without kUseTr)
 constexpr int kLseOff = (kUseTr ? 3 : 6) * kPlaneBytes;  // 128 B of streamed-row lse (pass C) behind the planes
 constexpr int kBufBytes = kLseOff + 256;
@@ -64,10 +67,38 @@ __device__ __forceinline__ constexpr int swz16(int row) {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 // ds_read_b64_tr_b16 as inline assembly (see ESR_O_LOAD for why not the builtin); result valid after lgkmcnt(0)
+template <int OFF>
 __device__ __forceinline__ s16x4 tr_read(uint32_t lds_addr) {
   s16x4 v;
-  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF));
   return v;
+}
+// A fragment F (0..11: plane (F / 4 + 2) % 3 -- the order the O^T rows use them -- column block F % 4) of k-step G:
+// two transposing reads from the per-lane bases of this chunk (tc[db][0 / 1], see the kernel), the plane and
+// k-step as the instruction's immediate offset so that no address arithmetic is left between the MFMAs.
+template <int G, int F, class TA>
+__device__ __forceinline__ void tr_frag(TA& ta, const uint32_t (&tc)[4][2]) {
+  constexpr int PL = (F / 4 + 2) % 3, DB = F % 4, OFF = PL * kPlaneBytes + 16 * G * 256;
+  const s16x4 lo = tr_read<OFF>(tc[DB][0]), hi = tr_read<OFF>(tc[DB][1]);
+  const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  ta[G][DB][PL] = __builtin_bit_cast(bf16x8, both);
+}
+template <int G, class TA>
+__device__ __forceinline__ void tr_frag_n(int f, TA& ta, const uint32_t (&tc)[4][2]) {  // f is an unrolled constant
+  switch (f) {
+    case 0: tr_frag<G, 0>(ta, tc); break;
+    case 1: tr_frag<G, 1>(ta, tc); break;
+    case 2: tr_frag<G, 2>(ta, tc); break;
+    case 3: tr_frag<G, 3>(ta, tc); break;
+    case 4: tr_frag<G, 4>(ta, tc); break;
+    case 5: tr_frag<G, 5>(ta, tc); break;
+    case 6: tr_frag<G, 6>(ta, tc); break;
+    case 7: tr_frag<G, 7>(ta, tc); break;
+    case 8: tr_frag<G, 8>(ta, tc); break;
+    case 9: tr_frag<G, 9>(ta, tc); break;
+    case 10: tr_frag<G, 10>(ta, tc); break;
+    default: tr_frag<G, 11>(ta, tc); break;
+  }
 }
 constexpr int k3Bufs = 3;
 
@@ -237,7 +268,7 @@ __device__ __forceinline__ void dma_piece(const char* __restrict__ baseR, const 
   }
 
 #ifdef ESR_IB3_TIMING
-__device__ unsigned long long esr_ib3_dbg[4096];
+__device__ unsigned long long esr_ib3_dbg[5120];
 #define ESR_TICK(VAR) { ESR_SB(); VAR = __builtin_readcyclecounter(); ESR_SB(); }
 #else
 #define ESR_TICK(VAR)
@@ -290,6 +321,14 @@ __device__ unsigned long long esr_ib3_dbg[4096];
       ESR_SB();                                                                                           \
       if (VALU_ON) { l += e0_ + e1_; pa_ = pk_bf16(e0_, e1_); }                                           \
       ESR_SB();                                                                                           \
+      /* the 12 G = 0 A fragments of the coming O^T phase, 1 or 2 per k-step, in the MIDDLE of the step: the  \
+         compiler's own s_waitcnt lgkmcnt(3) at the top of the next step (it counts its three ds_read_b128   \
+         only) then finds these reads ~100 clocks old instead of waiting on loads it has just issued */      \
+      if (kUseTr && (VALU_ON)) {                                                                          \
+        _Pragma("unroll") for (int f_ = (3 * s_) / 2; f_ < (3 * s_ + 3) / 2; ++f_)                        \
+          tr_frag_n<0>(f_, ta2_, trc_);                                                                   \
+      }                                                                                                   \
+      ESR_SB();                                                                                           \
       SA = ESR_MFMA_BF16(a2_, bx[0][s_], SA);                                                             \
       ESR_SB();                                                                                           \
       if (VALU_ON) { q0_ = e0_ - pk_lo(pa_); q1_ = e1_ - pk_hi(pa_); pq_ = pk_bf16(q0_, q1_); }           \
@@ -329,6 +368,12 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
   // S^T accumulators hand over P): the two reads fetch rows 16 G + 4 h + 0..3 and 16 G + 8 + 4 h + 0..3
   const int tr_row0 = (4 * h + tr_a) * 256, tr_row1 = (4 * h + 8 + tr_a) * 256;
   const int tr_l0 = ((tr_e ^ (h & 3)) << 4) | tr_low, tr_l1 = ((tr_e ^ ((h + 2) & 3)) << 4) | tr_low;
+  uint32_t trb_[4][2], trc_[4][2];  // per-lane bases inside a ring slot / inside the slot of the current chunk
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    trb_[db][0] = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds + tr_row0 + (((db ^ tr_a) << 6) | tr_l0);
+    trb_[db][1] = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds + tr_row1 + (((db ^ tr_a) << 6) | tr_l1);
+  }
   const int ob = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
   const int64_t xrow = (int64_t)ob * k3Owned + w * 32 + j;  // this lane's owned row
   const int nc = (int)(B / k3Chunk) / nsplit;               // chunks per split
@@ -378,7 +423,22 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
 // pieces of chunk it+2 are issued one per 4 MFMAs (pinned with sched_barrier): an LDS-DMA costs ~100+ cycles
 // of issue time, which is hidden only while the matrix pipe is busy.
 #define ESR_O_ROW(PL_A, PL_P, G)                                                                          \
-  _Pragma("unroll") for (int db_ = 0; db_ < 4; ++db_) acc[db_] = ESR_MFMA_BF16(ta_[db_][PL_A], pb[PL_P][G], acc[db_]);
+  _Pragma("unroll") for (int db_ = 0; db_ < 4; ++db_)                                                     \
+    acc[db_] = ESR_MFMA_BF16(ta2_[kUseTr ? (G) : 0][db_][PL_A], pb[PL_P][G], acc[db_]);
+// The A fragments of the O^T phase are requested ahead of the MFMAs that use them, a few reads per MFMA group so
+// the LDS pipe stays evenly loaded (all 48 reads inside the S^T phase would saturate it: 4 waves x (3 ds_read_b128
+// + 6 tr reads) = 192 LDS clocks per 192-clock k-step): the 12 fragments of G = 0 during the S^T phase of the same
+// iteration (they only need the chunk that landed two barriers ago), the 12 of G = 1 between the MFMA rows of
+// G = 0.  One wave per SIMD leaves the registers free (96 more VGPRs).  ESR_O_PREFETCH is the burst form of the
+// G = 0 half for the last chunk, which has no S^T phase beside it.
+#define ESR_O_PREFETCH(BUF)                                                                               \
+  if (kUseTr) {                                                                                           \
+    ESR_O_LOAD(BUF, 0, 2); ESR_O_LOAD(BUF, 0, 0); ESR_O_LOAD(BUF, 0, 1);                                  \
+  }
+// G = 1 fragments F0 .. F1 - 1 (issued after G = 0 MFMA rows 0 .. 4 as 3, 3, 2, 2, 2: the last ones are a full
+// MFMA row old when ESR_TR_WAIT() ahead of the G = 1 rows asks for them)
+#define ESR_O_G1(F0, F1)                                                                                  \
+  if (kUseTr) { _Pragma("unroll") for (int f_ = (F0); f_ < (F1); ++f_) tr_frag_n<1>(f_, ta2_, trc_); }
 #define ESR_O_PHASE(BUF, DMA_ON, DBUF)                                                                    \
   {                                                                                                       \
     bf16x8 pb[3][2];                                                                                      \
@@ -387,18 +447,22 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
         const u32x4 u_ = {pw[q_][4 * g_], pw[q_][4 * g_ + 1], pw[q_][4 * g_ + 2], pw[q_][4 * g_ + 3]};    \
         pb[q_][g_] = __builtin_bit_cast(bf16x8, u_);                                                      \
       }                                                                                                   \
-    bf16x8 ta_[4][3];                                                                                     \
-    const uint32_t obuf_lds_ = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(BUF);  \
-    ESR_O_LOAD(BUF, 0, 2); ESR_O_LOAD(BUF, 0, 0); ESR_O_LOAD(BUF, 0, 1);                                  \
-    if (kUseTr) ESR_TR_WAIT();                                                                            \
-    ESR_SB(); ESR_O_ROW(2, 0, 0); ESR_SB(); if (DMA_ON) { ESR_DP(0, g0, DBUF); }                  \
-    ESR_SB(); ESR_O_ROW(0, 2, 0); ESR_SB(); if (DMA_ON) { ESR_DP(1, g1, DBUF); }                  \
-    ESR_SB(); ESR_O_ROW(1, 1, 0); ESR_SB(); if (DMA_ON) { ESR_DP(2, g2, DBUF); }                  \
-    ESR_SB(); ESR_O_ROW(1, 0, 0); ESR_SB(); if (DMA_ON) { ESR_DP(3, g3, DBUF); }                  \
-    ESR_SB(); ESR_O_ROW(0, 1, 0); ESR_SB(); if (DMA_ON) { ESR_DP(4, g4, DBUF); }                  \
-    ESR_SB(); ESR_O_ROW(0, 0, 0); ESR_SB(); if (DMA_ON) { ESR_DP(5, g5, DBUF); }                  \
-    ESR_O_LOAD(BUF, 1, 2); ESR_O_LOAD(BUF, 1, 0); ESR_O_LOAD(BUF, 1, 1);                                  \
-    if (kUseTr) ESR_TR_WAIT();                                                                            \
+    if (kUseTr) {                                                                                         \
+      ESR_TR_WAIT(); /* the G = 0 fragments were requested during the S^T phase (or by ESR_O_PREFETCH) */ \
+    } else {                                                                                              \
+      ESR_O_LOAD(BUF, 0, 2); ESR_O_LOAD(BUF, 0, 0); ESR_O_LOAD(BUF, 0, 1);                                \
+    }                                                                                                     \
+    ESR_SB(); ESR_O_ROW(2, 0, 0); ESR_SB(); ESR_O_G1(0, 3); if (DMA_ON) { ESR_DP(0, g0, DBUF); }                  \
+    ESR_SB(); ESR_O_ROW(0, 2, 0); ESR_SB(); ESR_O_G1(3, 6); if (DMA_ON) { ESR_DP(1, g1, DBUF); }                  \
+    ESR_SB(); ESR_O_ROW(1, 1, 0); ESR_SB(); ESR_O_G1(6, 8); if (DMA_ON) { ESR_DP(2, g2, DBUF); }                  \
+    ESR_SB(); ESR_O_ROW(1, 0, 0); ESR_SB(); ESR_O_G1(8, 10); if (DMA_ON) { ESR_DP(3, g3, DBUF); }                  \
+    ESR_SB(); ESR_O_ROW(0, 1, 0); ESR_SB(); ESR_O_G1(10, 12); if (DMA_ON) { ESR_DP(4, g4, DBUF); }                  \
+    ESR_SB(); ESR_O_ROW(0, 0, 0); ESR_SB(); ESR_O_G1(12, 12); if (DMA_ON) { ESR_DP(5, g5, DBUF); }                  \
+    if (kUseTr) {                                                                                         \
+      ESR_TR_WAIT();                                                                                      \
+    } else {                                                                                              \
+      ESR_O_LOAD(BUF, 1, 2); ESR_O_LOAD(BUF, 1, 0); ESR_O_LOAD(BUF, 1, 1);                                \
+    }                                                                                                     \
     ESR_SB(); ESR_O_ROW(2, 0, 1); ESR_SB(); if (DMA_ON && !kUseTr) { ESR_DP(6, g6, DBUF); }                  \
     ESR_SB(); ESR_O_ROW(0, 2, 1); ESR_SB(); if (DMA_ON && !kUseTr) { ESR_DP(7, g7, DBUF); }                  \
     ESR_SB(); ESR_O_ROW(1, 1, 1); ESR_SB(); if (DMA_ON && !kUseTr) { ESR_DP(8, g8, DBUF); }                  \
@@ -417,16 +481,18 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
 // phase (O phase 3018 cycles per chunk instead of 2295).  The asm is opaque to that analysis; its results are
 // fenced by ESR_TR_WAIT() before the first MFMA that consumes them.
 #define ESR_TR_WAIT() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ESR_SB(); }
+// point the per-lane bases at the ring slot of the chunk whose O^T phase comes next (8 v_add per chunk)
+#define ESR_TR_BASES(BUF)                                                                                 \
+  if (kUseTr) {                                                                                           \
+    const uint32_t slot_ = (uint32_t)((BUF) - lds);                                                       \
+    _Pragma("unroll") for (int db_ = 0; db_ < 4; ++db_) { trc_[db_][0] = trb_[db_][0] + slot_; trc_[db_][1] = trb_[db_][1] + slot_; } \
+  }
 #define ESR_O_LOAD(BUF, G, PL)                                                                            \
   _Pragma("unroll") for (int db_ = 0; db_ < 4; ++db_) {                                                   \
     if (kUseTr) {                                                                                         \
-      const uint32_t pb_ = obuf_lds_ + (PL) * kPlaneBytes + (16 * (G)) * 256;                             \
-      const s16x4 lo_ = tr_read(pb_ + tr_row0 + (((db_ ^ tr_a) << 6) | tr_l0));                           \
-      const s16x4 hi_ = tr_read(pb_ + tr_row1 + (((db_ ^ tr_a) << 6) | tr_l1));                           \
-      const s16x8 both_ = {lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]};               \
-      ta_[db_][PL] = __builtin_bit_cast(bf16x8, both_);                                                   \
+      tr_frag_n<G>((((PL) + 1) % 3) * 4 + db_, ta2_, trc_);                                               \
     } else {                                                                                              \
-      ta_[db_][PL] = *reinterpret_cast<const bf16x8*>((BUF) + kTOff + (PL) * kPlaneBytes +                \
+      ta2_[0][db_][PL] = *reinterpret_cast<const bf16x8*>((BUF) + kTOff + (PL) * kPlaneBytes +            \
                                                       (db_ * 32 + j) * 64 + (((2 * (G) + h) ^ ((j >> 2) & 3)) << 4)); \
     }                                                                                                     \
   }
@@ -450,6 +516,7 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
   f32x16 sa;
   float p[16], rf[16];
   uint32_t pw[3][8];  // packed bf16 pairs of P: pw[plane][pair s] = (r = 2s, 2s+1); 4 dwords per 8-row k-group
+  bf16x8 ta2_[2][4][3];  // A fragments of the O^T phase (both k-steps when they are prefetched)
 #pragma unroll
   for (int r = 0; r < 16; ++r) { p[r] = 0.f; rf[r] = 0.f; }
   ESR_S_PHASE(lds, sa, false);
@@ -457,6 +524,7 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
 #ifdef ESR_IB3_TIMING
   unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0, tacc0 = 0, tacc1 = 0, tacc2 = 0;
   const unsigned long long tstart = __builtin_readcyclecounter();
+  const unsigned long long rstart = __builtin_amdgcn_s_memrealtime();
 #endif
   int cur = 0;  // ring slot of chunk `it`
   // steady state (straight-line body: conditional DMA made hipcc split the block and shuffle the 64
@@ -474,6 +542,7 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
 #pragma unroll
     for (int r = 0; r < 16; ++r) p[r] = sa[r];
     ESR_LOAD_REFS(buf);
+    ESR_TR_BASES(buf);
     ESR_S_PHASE(nbuf, sa, true);  // S^T of chunk it+1 with the exp / split of chunk it threaded through
     ESR_TICK(tk2);
     ESR_DMA_LSE(dbuf);
@@ -492,6 +561,7 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
 #pragma unroll
     for (int r = 0; r < 16; ++r) p[r] = sa[r];
     ESR_LOAD_REFS(buf);
+    ESR_TR_BASES(buf);
     ESR_S_PHASE(nbuf, sa, true);
     ESR_O_PHASE(buf, false, lds);
     cur = nxt;
@@ -502,6 +572,8 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
 #pragma unroll
     for (int r = 0; r < 16; ++r) p[r] = sa[r];
     ESR_LOAD_REFS(buf);
+    ESR_TR_BASES(buf);
+    ESR_O_PREFETCH(buf);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const float e0 = __builtin_amdgcn_exp2f(fmaf(p[2 * s], sl2, -rf[2 * s]));
@@ -520,6 +592,7 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
   if (lane == 0 && blockIdx.x < 256) {
     unsigned long long* d = esr_ib3_dbg + ((blockIdx.x * 4 + w) * 4);
     d[0] = tacc0; d[1] = tacc1; d[2] = tacc2; d[3] = __builtin_readcyclecounter() - tstart;
+    esr_ib3_dbg[4096 + blockIdx.x * 4 + w] = __builtin_amdgcn_s_memrealtime() - rstart;  // 100 MHz
   }
 #endif
   // ---- write this split's partial: O rows (float4 over 4 consecutive d) and l ----
@@ -727,7 +800,7 @@ extern "C" {
 
 #ifdef ESR_IB3_TIMING
 int esr_ib3_debug_read(unsigned long long* host) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(esr_ib3_dbg), sizeof(unsigned long long) * 4096);
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(esr_ib3_dbg), sizeof(unsigned long long) * 5120);
 }
 #endif
 

@@ -1,1 +1,5 @@
-cd esrecsys_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DESR_IB3_TIMING -I../../include esr_inbatch3.hip esr_core.hip -o ../../scripts/libib3dbg.so && cd ../.. && python scripts/ib3_timing.py 2>&1 | grep -v amdgpu.ids
+# Phase stamps of inbatch3_kernel: debug builds with -DESR_IB3_TIMING, transposing-read variant and the
+# transposed-image variant (-DESR_IB3_USE_TR=0) side by side
+for tr in 1 0; do
+  (cd esrecsys_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DESR_IB3_TIMING -DESR_IB3_USE_TR=$tr -I../../include esr_inbatch3.hip esr_core.hip -o ../../scripts/libib3dbg.so) && echo "USE_TR=$tr" && python scripts/ib3_timing.py 2>&1 | grep -v amdgpu.ids
+done

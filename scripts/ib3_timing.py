@@ -19,10 +19,12 @@ for _ in range(3):
         P(ws.data_ptr()), ctypes.c_size_t(ws.numel()), None)
     assert rc == 0
 torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * 4096)()
+buf = (ctypes.c_ulonglong * 5120)()
 lib.esr_ib3_debug_read(buf)
-a = np.array(buf[:], dtype=np.float64).reshape(256, 4, 4)  # last launch = pass C kernel
+rt = np.array(buf[4096:], dtype=np.float64)
+a = np.array(buf[:4096], dtype=np.float64).reshape(256, 4, 4)  # last launch = pass C kernel
 print("per-wave mean cycles over 63 pipelined iterations: barrier %.0f  S-phase(+VALU) %.0f  O-phase(+DMA) %.0f  total kernel %.0f"
       % tuple(a[..., k].mean() for k in range(4)))
 print("per-iteration: barrier %.0f  S %.0f  O %.0f" % tuple(a[..., k].mean() / 63 for k in range(3)))
 print("min/max total", a[..., 3].min(), a[..., 3].max(), " loss", float(loss))
+print("loop wall time %.1f us (s_memrealtime, 100 MHz) -> shader clock %.0f MHz" % (rt.mean() / 100, a[..., 3].mean() / (rt.mean() / 100)))
