@@ -268,7 +268,7 @@ __device__ __forceinline__ void dma_piece(const char* __restrict__ baseR, const 
   }
 
 #ifdef ESR_IB3_TIMING
-__device__ unsigned long long esr_ib3_dbg[5120];
+__device__ unsigned long long esr_ib3_dbg[8192];
 #define ESR_TICK(VAR) { ESR_SB(); VAR = __builtin_readcyclecounter(); ESR_SB(); }
 #else
 #define ESR_TICK(VAR)
@@ -311,15 +311,18 @@ __device__ unsigned long long esr_ib3_dbg[5120];
       ESR_SB();                                                                                           \
       SA = ESR_MFMA_BF16(a3_, bx[0][s_], SA);                                                             \
       ESR_SB();                                                                                           \
-      if (VALU_ON) { e0_ = fmaf(p[2 * s_], sl2, -rf[2 * s_]); e1_ = fmaf(p[2 * s_ + 1], sl2, -rf[2 * s_ + 1]); } \
+      if (VALU_ON) {                                                                                      \
+        e0_ = __builtin_amdgcn_exp2f(fmaf(p[2 * s_], sl2, -rf[2 * s_]));                                  \
+        e1_ = fmaf(p[2 * s_ + 1], sl2, -rf[2 * s_ + 1]);                                                  \
+      }                                                                                                   \
       ESR_SB();                                                                                           \
       SA = ESR_MFMA_BF16(a1_, bx[2][s_], SA);                                                             \
       ESR_SB();                                                                                           \
-      if (VALU_ON) { e0_ = __builtin_amdgcn_exp2f(e0_); e1_ = __builtin_amdgcn_exp2f(e1_); }              \
+      if (VALU_ON) { e1_ = __builtin_amdgcn_exp2f(e1_); pa_ = pk_bf16(e0_, e1_); }                        \
       ESR_SB();                                                                                           \
       SA = ESR_MFMA_BF16(a2_, bx[1][s_], SA);                                                             \
       ESR_SB();                                                                                           \
-      if (VALU_ON) { l += e0_ + e1_; pa_ = pk_bf16(e0_, e1_); }                                           \
+      if (VALU_ON) l += e0_ + e1_;                                                                        \
       ESR_SB();                                                                                           \
       /* the 12 G = 0 A fragments of the coming O^T phase, 1 or 2 per k-step, in the MIDDLE of the step: the  \
          compiler's own s_waitcnt lgkmcnt(3) at the top of the next step (it counts its three ds_read_b128   \
@@ -358,6 +361,9 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
                                                       const float* __restrict__ ref, float* __restrict__ part_O,
                                                       float* __restrict__ part_l) {
   __shared__ __attribute__((aligned(16))) char lds[k3Bufs * kBufBytes];
+#ifdef ESR_IB3_TIMING
+  const unsigned long long rentry = __builtin_amdgcn_s_memrealtime();
+#endif
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);  // provably wave-uniform: DMA bases stay in SGPRs
   const int j = lane & 31, h = lane >> 5;
@@ -592,8 +598,10 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
   if (lane == 0 && blockIdx.x < 256) {
     unsigned long long* d = esr_ib3_dbg + ((blockIdx.x * 4 + w) * 4);
     d[0] = tacc0; d[1] = tacc1; d[2] = tacc2; d[3] = __builtin_readcyclecounter() - tstart;
-    esr_ib3_dbg[4096 + blockIdx.x * 4 + w] = __builtin_amdgcn_s_memrealtime() - rstart;  // 100 MHz
+    unsigned long long* e = esr_ib3_dbg + 4096 + ((blockIdx.x * 4 + w) * 4);  // 100 MHz wall clock, absolute
+    e[0] = rentry; e[1] = rstart; e[2] = __builtin_amdgcn_s_memrealtime();
   }
+  const int dbg_w = w;
 #endif
   // ---- write this split's partial: O rows (float4 over 4 consecutive d) and l ----
   float* orow = part_O + ((int64_t)split * B + xrow) * k3D;
@@ -607,6 +615,10 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
     const float ltot = l + __shfl_xor(l, 32, 64);
     if (h == 0) part_l[(int64_t)split * B + xrow] = ltot;
   }
+#ifdef ESR_IB3_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0 && blockIdx.x < 256) esr_ib3_dbg[4096 + ((blockIdx.x * 4 + dbg_w) * 4) + 3] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // Row-max pre-pass for pass Q: S~ = hi-plane product only (one bf16 MFMA term, error ~2^-8 |q||c| scale,
@@ -800,7 +812,7 @@ extern "C" {
 
 #ifdef ESR_IB3_TIMING
 int esr_ib3_debug_read(unsigned long long* host) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(esr_ib3_dbg), sizeof(unsigned long long) * 5120);
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(esr_ib3_dbg), sizeof(unsigned long long) * 8192);
 }
 #endif
 

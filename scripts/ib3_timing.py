@@ -19,12 +19,23 @@ for _ in range(3):
         P(ws.data_ptr()), ctypes.c_size_t(ws.numel()), None)
     assert rc == 0
 torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * 5120)()
+buf = (ctypes.c_ulonglong * 8192)()
 lib.esr_ib3_debug_read(buf)
-rt = np.array(buf[4096:], dtype=np.float64)
+e = np.array(buf[4096:], dtype=np.float64).reshape(1024, 4)
+rt = e[:, 2] - e[:, 1]
 a = np.array(buf[:4096], dtype=np.float64).reshape(256, 4, 4)  # last launch = pass C kernel
 print("per-wave mean cycles over 63 pipelined iterations: barrier %.0f  S-phase(+VALU) %.0f  O-phase(+DMA) %.0f  total kernel %.0f"
       % tuple(a[..., k].mean() for k in range(4)))
 print("per-iteration: barrier %.0f  S %.0f  O %.0f" % tuple(a[..., k].mean() / 63 for k in range(3)))
 print("min/max total", a[..., 3].min(), a[..., 3].max(), " loss", float(loss))
 print("loop wall time %.1f us (s_memrealtime, 100 MHz) -> shader clock %.0f MHz" % (rt.mean() / 100, a[..., 3].mean() / (rt.mean() / 100)))
+t0 = e[:, 0].min()
+print("wall clock (us from the first wave's entry): entry %.1f..%.1f  loop start %.1f..%.1f  loop end %.1f..%.1f  stores done %.1f..%.1f"
+      % tuple(x / 100 for c in range(4) for x in ((e[:, c] - t0).min(), (e[:, c] - t0).max())))
+d = (e[:, 2] - e[:, 1]).reshape(256, 4).mean(1) / 100  # per workgroup loop time, us
+print("loop us by XCD (blockIdx % 8):", np.round([d[x::8].mean() for x in range(8)], 1))
+print("loop us by split (blockIdx % 4):", np.round([d[x::4].mean() for x in range(4)], 1))
+print("loop us min/max over workgroups: %.1f %.1f; by blockIdx // 32:" % (d.min(), d.max()), np.round(d.reshape(8, 32).mean(1), 1))
+cyc = a[..., 3].mean(1)
+print("shader MHz by XCD:", np.round([(cyc[x::8] / d[x::8]).mean() for x in range(8)], 0))
+print("loop cycles by XCD:", np.round([cyc[x::8].mean() for x in range(8)], 0))
