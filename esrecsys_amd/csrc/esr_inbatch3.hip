@@ -12,10 +12,12 @@
 //
 // Decomposition (differs from the f32 kernel because both operand layouts of the streamed matrix are
 // needed as 16-bit k-contiguous fragments):
-//   split3 pre-pass : X f32 [B,128] -> row-major planes Xr[3][B][128] bf16 and chunk-transposed planes
-//                     Xt[3][B/32][128][32] bf16 whose last index is the streamed row permuted into the
-//                     order in which the S^T accumulator registers hold it (so P feeds the next MFMA's B
-//                     operand straight from registers, as in the f32 kernel).
+//   split3 pre-pass : X f32 [B,128] -> row-major planes Xr[3][B][128] bf16.  The O^T phase needs the streamed
+//                     rows along k in the order in which the S^T accumulator registers hold them (so P feeds
+//                     the next MFMA's B operand straight from registers, as in the f32 kernel): its A fragments
+//                     are read from the row-major LDS tile with ds_read_b64_tr_b16 (kUseTr).  The A/B build
+//                     -DESR_IB3_USE_TR=0 instead DMAs a second, chunk-transposed image Xt[3][B/32][128][32]
+//                     written by split3 (twice the DMA pieces and LDS; kept for scripts/gpu_ib3_timing.sh).
 //   rowmax pre-pass : approximate row maximum of S from the hi-plane product alone (1/12 of the MFMA work):
 //                     a FIXED exponent reference per row replaces online-softmax rescaling, so the O
 //                     accumulators are never touched by VALU instructions inside the main loop.
@@ -41,11 +43,11 @@ constexpr int k3Owned = 32 * k3Waves;  // owned rows per workgroup
 constexpr float k3Log2e = 1.4426950408889634f;
 constexpr float k3Ln2 = 0.6931471805599453f;
 
-// LDS image of one 32-row chunk: three row-major planes [32 rows][256 B] then three transposed planes
-// [128 d][64 B], 48 KB, filled by direct global->LDS DMA (global_load_lds_dwordx4: no staging VGPRs, no
+// LDS image of one 32-row chunk: three row-major planes [32 rows][256 B] (24 KB; without kUseTr three transposed
+// planes [128 d][64 B] follow, 48 KB), filled by direct global->LDS DMA (global_load_lds_dwordx4: no staging VGPRs, no
 // ds_write).  The DMA destination is lane-linear, so bank conflicts are removed by an XOR swizzle applied
 // to the per-lane SOURCE address and again on the ds_read_b128 address (same involution on both sides):
-//   row-major   : 16-B segment index ^= (row & 15)
+//   row-major   : 16-B segment index ^= swz16(row)
 //   transposed  : 16-B segment index ^= ((d >> 2) & 3)
 constexpr int kPlaneBytes = 8192;
 // kUseTr: the O^T phase takes its A operand (Y^T) from the ROW-MAJOR image with the transposing LDS read
@@ -353,8 +355,8 @@ __device__ unsigned long long esr_ib3_dbg[8192];
 // approximate row maximum from the rowmax pre-pass, exact enough for range safety; pass C: the lse of
 // the streamed row), so the O accumulators are touched by MFMAs only and stay in AGPRs, and the loop is
 // software-pipelined: the S^T MFMAs of chunk t+1 are issued before the exp / bf16-split VALU work of
-// chunk t, whose results feed the O^T MFMAs of chunk t.  Three LDS buffers: chunk t (transposed image
-// for O^T), chunk t+1 (row-major image for S^T), chunk t+2 (DMA in flight); one barrier per chunk.
+// chunk t, whose results feed the O^T MFMAs of chunk t.  Three LDS buffers: chunk t (read by the
+// O^T phase), chunk t+1 (read by the S^T phase), chunk t+2 (DMA in flight); one barrier per chunk.
 template <bool QSIDE>
 __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict__ Xr, const __bf16* __restrict__ Yr,
                                                       const __bf16* __restrict__ Yt, int64_t B, int nsplit, float sl2,
