@@ -103,6 +103,7 @@ __device__ __forceinline__ void tr_frag_n(int f, TA& ta, const uint32_t (&tc)[4]
   }
 }
 constexpr int k3Bufs = 3;
+constexpr int k3MergeBlocks = 512;  // most workgroups of a merge launch (= loss partials per launch)
 
 __device__ __forceinline__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 // position of streamed row `row` (0..31) inside a transposed chunk: pos = 16 g + 8 h + k  <->
@@ -645,7 +646,7 @@ __global__ __launch_bounds__(256) void inbatch3_rowmax_kernel(const __bf16* __re
     // (26 us at B = 8192) is skipped; otherwise fall through to the exact row maxima.
     const int nslots = (int)(B / k3Chunk) * 4;  // per matrix
     float mq = 0.f, mc = 0.f;
-    for (int i = lane; i < nslots; i += 64) {
+    for (int i = t; i < nslots; i += 256) {  // the whole workgroup, one coalesced sweep (a per-wave walk cost 7 us)
       mq = fmaxf(mq, nrm[i]);
       mc = fmaxf(mc, nrm[nslots + i]);
     }
@@ -654,6 +655,12 @@ __global__ __launch_bounds__(256) void inbatch3_rowmax_kernel(const __bf16* __re
       mq = fmaxf(mq, __shfl_xor(mq, o, 64));
       mc = fmaxf(mc, __shfl_xor(mc, o, 64));
     }
+    float* red = reinterpret_cast<float*>(lds);
+    if (lane == 0) { red[w] = mq; red[4 + w] = mc; }
+    __syncthreads();
+    mq = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    mc = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    __syncthreads();  // the slow path reuses lds as the DMA ring
     const float bound = sqrtf(mq * mc) * fabsf(sl2);
     if (bound <= kRmSafeBound) {
       if (h == 0) part_m[(int64_t)split * B + xrow] = bound;
@@ -768,7 +775,6 @@ __global__ __launch_bounds__(kBlock) void inbatch3_merge_kernel(
   if (threadIdx.x == 0) loss_part[blockIdx.x] = tsum;
 }
 
-constexpr int k3MergeBlocks = 512;
 
 struct Inbatch3Ws {
   __bf16 *Qr, *Qt, *Cr, *Ct;
@@ -876,7 +882,9 @@ static int inbatch3_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* gq
   hipLaunchKernelGGL((inbatch3_merge_kernel<false>), dim3(mgrid), dim3(kBlock), 0, st, Cs, Qs, gc_rows, B, nsplit,
                      (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale, regularization,
                      inv_bs, ws.lse2, (float*)nullptr, gC, ws.loss_part + k3MergeBlocks);
-  // the two merge launches wrote mgrid partials each at [0, mgrid) and [k3MergeBlocks, k3MergeBlocks + mgrid)
+  // the two merge launches wrote mgrid partials each at [0, mgrid) and [k3MergeBlocks, k3MergeBlocks + mgrid); a
+  // last-workgroup reduction inside the second merge (ticket + __threadfence) was measured 7 us SLOWER than this
+  // extra launch: the agent-scope release makes every workgroup write its XCD's L2 back
   if (mgrid < k3MergeBlocks)
     (void)hipMemsetAsync(ws.loss_part + mgrid, 0, sizeof(double) * (k3MergeBlocks - mgrid), st);
   finalize_scalar(ws.loss_part, k3MergeBlocks + mgrid, 1.0 / (double)batch_size, loss, st);
