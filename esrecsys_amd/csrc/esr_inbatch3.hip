@@ -103,7 +103,7 @@ __device__ __forceinline__ void tr_frag_n(int f, TA& ta, const uint32_t (&tc)[4]
   }
 }
 constexpr int k3Bufs = 3;
-constexpr int k3MergeBlocks = 512;  // most workgroups of a merge launch (= loss partials per launch)
+constexpr int k3MergeBlocks = 1024;  // most workgroups of a merge launch (= loss partials per launch)
 
 __device__ __forceinline__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 // position of streamed row `row` (0..31) inside a transposed chunk: pos = 16 g + 8 h + k  <->
@@ -735,21 +735,38 @@ __global__ __launch_bounds__(kBlock) void inbatch3_merge_kernel(
   const int64_t ngroups = (int64_t)gridDim.x * gpb;
   double acc_loss = 0.0;
   for (int64_t row = group; row < B; row += ngroups) {
-    float M = 0.f, L = 1.f;
-    if (QSIDE) {  // every split used the same fixed reference M = max_s part_m[s][row]
-      M = part_m[row];
-      for (int s = 1; s < nsplit; ++s) M = fmaxf(M, part_m[(int64_t)s * B + row]);
-      L = 0.f;
-      for (int s = 0; s < nsplit; ++s) L += part_l[(int64_t)s * B + row];
+    // every load of the row is issued before the first use (nsplit <= 8 is a run-time value: the plain loops waited
+    // for one memory latency per split and array, ~12 in a row); the sums keep the split order
+    float pm[8], pl[8];
+    float4 po[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      pm[s] = -INFINITY; pl[s] = 0.f; po[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (s < nsplit) {
+        if (QSIDE) {
+          pm[s] = part_m[(int64_t)s * B + row];
+          pl[s] = part_l[(int64_t)s * B + row];
+        }
+        po[s] = *reinterpret_cast<const float4*>(part_O + ((int64_t)s * B + row) * k3D + 4 * lig);
+      }
     }
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < nsplit; ++s) {
-      const float4 v = *reinterpret_cast<const float4*>(part_O + ((int64_t)s * B + row) * k3D + 4 * lig);
-      o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
-    }
-    const float invL = 1.0f / L;
     const float4 x = rowsrc_load4(X, row, 4 * lig);
     const float4 y = rowsrc_load4(Y, row, 4 * lig);
+    float M = 0.f, L = 1.f;
+    if (QSIDE) {  // every split used the same fixed reference M = max_s part_m[s][row]
+      M = pm[0];
+      L = 0.f;
+#pragma unroll
+      for (int s = 1; s < 8; ++s) M = fmaxf(M, pm[s]);
+#pragma unroll
+      for (int s = 0; s < 8; ++s) L += pl[s];
+    }
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (s < nsplit) { o.x += po[s].x; o.y += po[s].y; o.z += po[s].z; o.w += po[s].w; }
+    }
+    const float invL = 1.0f / L;
     const float xn2 = group_sum(x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w, G);
     const float xnorm = sqrtf(xn2);
     const float creg = xnorm > 1.f ? lam / xnorm : 0.f;
