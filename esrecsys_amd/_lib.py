@@ -88,6 +88,8 @@ SIGNATURES = {
                                             c_vp]),
     "esr_bucket_workspace_bytes": (c_size, [c_i64]),
     "esr_bucket_ids_by_owner": (c_int, [c_i32p, c_i64, c_int, c_i32p, c_i32p, c_i32p, c_vp, c_vp, c_size, c_vp]),
+    "esr_bucket_ids_by_owner_multi": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_i32p, c_i32p, c_i32p, c_vp, c_vp, c_size,
+                                              c_vp]),
 }
 
 

@@ -210,6 +210,112 @@ constexpr int kBucketMaxWorld = 8;  // one MI355X node
 constexpr int kBucketMaxN = 32768;
 constexpr int kBucketThreads = 1024;
 constexpr int kBucketRounds = kBucketMaxN / kBucketThreads;  // 32
+// Tiled bucket, two launches, for lists of up to kBucketTileMax tiles of 1024 ids (the one-workgroup kernel below took
+// 16.5 us for the 16 384 ids of a sharded in-batch step -- the longest kernel of its routing plan).  Thread t of
+// workgroup `tile` owns id 1024 tile + t; the stable position of an id is
+//   owner base + same-owner ids in earlier tiles + same-owner ids in earlier waves of its tile + same-owner lanes below
+// Launch 1 writes the per-(tile, wave, owner) counts and per-(tile, owner) totals; launch 2 turns them into the three
+// offsets (every workgroup reduces the tile totals itself: <= 1024 x 8 integers) and scatters.  Both are pure
+// integer work with coalesced loads; ranks inside a wave come from ballots, so there is no atomic and the result
+// is the stable order by construction.
+constexpr int kBucketTileMax = 1024;  // n <= 1 Mi ids
+__device__ __forceinline__ int owner_of(uint32_t id, int world, bool pow2) {
+  return (int)(pow2 ? id & (uint32_t)(world - 1) : id % (uint32_t)world);
+}
+__global__ __launch_bounds__(kBucketThreads) void bucket_count_kernel(SortSegs ids, int n, int world,
+                                                                     int* __restrict__ wave_cells,   // [T][16][8]
+                                                                     int* __restrict__ tile_tot) {   // [T][8]
+  constexpr int kWaves = kBucketThreads / 64;
+  __shared__ int cnt[kWaves][kBucketMaxWorld];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, tile = blockIdx.x;
+  const bool pow2 = (world & (world - 1)) == 0;
+  const int j = tile * kBucketThreads + t;
+  const int own = j < n ? owner_of((uint32_t)seg_id(ids, j), world, pow2) : -1;
+#pragma unroll
+  for (int g = 0; g < kBucketMaxWorld; ++g) {
+    const int c = __popcll(__ballot(own == g));
+    if (lane == 0) {
+      cnt[w][g] = c;
+      wave_cells[(tile * kWaves + w) * kBucketMaxWorld + g] = c;
+    }
+  }
+  __syncthreads();
+  if (t < kBucketMaxWorld) {
+    int tot = 0;
+#pragma unroll
+    for (int x = 0; x < kWaves; ++x) tot += cnt[x][t];
+    tile_tot[tile * kBucketMaxWorld + t] = tot;
+  }
+}
+__global__ __launch_bounds__(kBucketThreads) void bucket_scatter_kernel(SortSegs ids, int n, int world,
+                                                                       const int* __restrict__ wave_cells,
+                                                                       const int* __restrict__ tile_tot,
+                                                                       int32_t* __restrict__ inverse,
+                                                                       int32_t* __restrict__ local_rows,
+                                                                       int32_t* __restrict__ perm,
+                                                                       int64_t* __restrict__ counts) {
+  constexpr int kWaves = kBucketThreads / 64;
+  __shared__ int red[2][kWaves][kBucketMaxWorld];  // [all tiles | earlier tiles] per wave and owner
+  __shared__ int tot_s[kBucketMaxWorld], bef_s[kBucketMaxWorld];
+  __shared__ int wcell[kWaves][kBucketMaxWorld], wpre[kWaves][kBucketMaxWorld];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, tile = blockIdx.x, ntiles = gridDim.x;
+  const bool pow2 = (world & (world - 1)) == 0;
+  const int j = tile * kBucketThreads + t;
+  const uint32_t id = j < n ? (uint32_t)seg_id(ids, j) : 0u;  // in flight while the offsets are worked out
+  // thread t holds the totals of tile t (ntiles <= 1024)
+  int all[kBucketMaxWorld], before[kBucketMaxWorld];
+#pragma unroll
+  for (int g = 0; g < kBucketMaxWorld; ++g) {
+    const int v = t < ntiles ? tile_tot[t * kBucketMaxWorld + g] : 0;
+    all[g] = v;
+    before[g] = t < tile ? v : 0;
+  }
+  if (t < kWaves * kBucketMaxWorld) wcell[t / kBucketMaxWorld][t % kBucketMaxWorld] = wave_cells[tile * kWaves * kBucketMaxWorld + t];
+#pragma unroll
+  for (int g = 0; g < kBucketMaxWorld; ++g) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      all[g] += __shfl_xor(all[g], o, 64);
+      before[g] += __shfl_xor(before[g], o, 64);
+    }
+    if (lane == 0) { red[0][w][g] = all[g]; red[1][w][g] = before[g]; }
+  }
+  __syncthreads();
+  if (t < kBucketMaxWorld) {  // one thread per owner: totals over all tiles / over the earlier tiles
+    int tot = 0, bef = 0;
+#pragma unroll
+    for (int x = 0; x < kWaves; ++x) { tot += red[0][x][t]; bef += red[1][x][t]; }
+    tot_s[t] = tot;
+    bef_s[t] = bef;
+    if (tile == 0 && t < world) counts[t] = tot;
+  } else if (t >= 64 && t < 64 + kWaves * kBucketMaxWorld) {  // same-owner ids in the earlier waves of this tile
+    const int ww = (t - 64) / kBucketMaxWorld, g = (t - 64) % kBucketMaxWorld;
+    int a = 0;
+    for (int x = 0; x < ww; ++x) a += wcell[x][g];
+    wpre[ww][g] = a;
+  }
+  __syncthreads();
+  const int own = j < n ? owner_of(id, world, pow2) : -1;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int pos = -1;
+#pragma unroll
+  for (int g = 0; g < kBucketMaxWorld; ++g) {
+    const unsigned long long m = __ballot(own == g);
+    if (own == g) pos = __popcll(m & below);
+  }
+  if (pos >= 0) {
+    pos += bef_s[own] + wpre[w][own];
+#pragma unroll
+    for (int g = 0; g < kBucketMaxWorld; ++g)
+      if (g < own) pos += tot_s[g];
+  }
+  if (pos >= 0) {
+    perm[pos] = j;
+    local_rows[pos] = (int32_t)(pow2 ? id >> __builtin_ctz(world) : id / (uint32_t)world);
+    if (inverse) inverse[j] = pos;
+  }
+}
+
 // One workgroup, ids taken round by round (round r = ids [1024 r, 1024 r + 1024), thread t = one id): every access
 // is coalesced.  Stable position of an id = owner base + ids of the same owner in earlier (round, wave) cells +
 // same-owner lanes below it in its own wave (ballot + popcount).  The 32 x 16 cell totals per owner are prefix-
@@ -621,33 +727,48 @@ int esr_score_topk(const float* queries, const float* candidates, int64_t nq, in
 }
 
 // ------------------------------------------------------------------------------------------------
+// Workspace: the larger of the tiled path's counts and the radix path's key columns + rocPRIM temp, behind a column
+// for the concatenated ids of the segmented entry point when it has to fall back to the radix path.
 size_t esr_bucket_workspace_bytes(int64_t n) {
   if (n <= 0) return 256;
-  return align_up((size_t)n * 4, 256) * 2 + pair_sort_temp_bytes<false, uint32_t>(n);
+  const size_t tiled = (size_t)cdiv(n, kBucketThreads) * (kBucketThreads / 64 + 1) * kBucketMaxWorld * sizeof(int);
+  return align_up((size_t)n * 4, 256) +
+         std::max(tiled, align_up((size_t)n * 4, 256) * 2 + pair_sort_temp_bytes<false, uint32_t>(n));
 }
 
-int esr_bucket_ids_by_owner(const int32_t* ids, int64_t n, int world, int32_t* local_rows, int32_t* perm,
-                            int32_t* inverse, int64_t* counts, void* workspace, size_t workspace_bytes,
-                            esr_stream_t stream) {
-  ESR_REQUIRE(n >= 0 && world > 0 && n < ((int64_t)1 << 31), "esr_bucket_ids_by_owner: bad sizes n=%lld world=%d",
-              (long long)n, world);
-  ESR_REQUIRE(counts, "esr_bucket_ids_by_owner: null counts");
-  hipStream_t st = as_stream(stream);
+// tiled two-launch path; false when it does not apply (then nothing was launched)
+static bool bucket_tiled(const SortSegs& sg, int64_t n, int world, int32_t* local_rows, int32_t* perm, int32_t* inverse,
+                         int64_t* counts, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  const int64_t ntiles = cdiv(n, kBucketThreads);
+  const size_t need = (size_t)ntiles * (kBucketThreads / 64 + 1) * kBucketMaxWorld * sizeof(int);
+  if (!(n > 2048 && ntiles <= kBucketTileMax && world <= kBucketMaxWorld && workspace && workspace_bytes >= need &&
+        ((uintptr_t)workspace & 15) == 0))
+    return false;
+  int* wave_cells = (int*)workspace;
+  int* tile_tot = wave_cells + ntiles * (kBucketThreads / 64) * kBucketMaxWorld;
+  hipLaunchKernelGGL(bucket_count_kernel, dim3((int)ntiles), dim3(kBucketThreads), 0, st, sg, (int)n, world, wave_cells,
+                     tile_tot);
+  hipLaunchKernelGGL(bucket_scatter_kernel, dim3((int)ntiles), dim3(kBucketThreads), 0, st, sg, (int)n, world,
+                     (const int*)wave_cells, (const int*)tile_tot, inverse, local_rows, perm, counts);
+  return true;
+}
+
+// one-workgroup kernel (n <= 32768) or device radix sort; ids is one device array
+static int bucket_plain(const char* who, const int32_t* ids, int64_t n, int world, int32_t* local_rows, int32_t* perm,
+                        int32_t* inverse, int64_t* counts, void* workspace, size_t workspace_bytes, hipStream_t st) {
   if (n > 0 && n <= kBucketMaxN && world <= kBucketMaxWorld) {
-    ESR_REQUIRE(ids && local_rows && perm, "esr_bucket_ids_by_owner: null pointer");
     hipLaunchKernelGGL(bucket_small_kernel, dim3(1), dim3(kBucketThreads), 0, st, ids, (int)n, world, inverse,
                        local_rows, perm, counts);
-    return check_launch("esr_bucket_ids_by_owner(small)");
+    return check_launch(who);
   }
-  if (hipMemsetAsync(counts, 0, sizeof(int64_t) * world, st) != hipSuccess) return check_launch("esr_bucket memset");
+  if (hipMemsetAsync(counts, 0, sizeof(int64_t) * world, st) != hipSuccess) return check_launch(who);
   if (n == 0) return ESR_OK;
-  ESR_REQUIRE(ids && local_rows && perm && workspace, "esr_bucket_ids_by_owner: null pointer");
-  if (workspace_bytes < esr_bucket_workspace_bytes(n) || ((uintptr_t)workspace & 15)) {
-    set_error("esr_bucket_ids_by_owner: workspace %zu bytes < %zu required (or misaligned)", workspace_bytes,
-              esr_bucket_workspace_bytes(n));
+  const size_t col = align_up((size_t)n * 4, 256);
+  const size_t need = 2 * col + pair_sort_temp_bytes<false, uint32_t>(n);
+  if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) {
+    set_error("%s: workspace %zu bytes < %zu required (or misaligned)", who, workspace_bytes, need);
     return ESR_EWORKSPACE;
   }
-  const size_t col = align_up((size_t)n * 4, 256);
   char* base = (char*)workspace;
   uint32_t* keys = (uint32_t*)base;
   uint32_t* keys_sorted = (uint32_t*)(base + col);
@@ -659,12 +780,67 @@ int esr_bucket_ids_by_owner(const int32_t* ids, int64_t n, int world, int32_t* l
   hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_sorted, rocprim::counting_iterator<int32_t>(0),
                                            perm, (size_t)n, 0, bits_for(world), st, false);
   if (e != hipSuccess) {
-    set_error("esr_bucket_ids_by_owner: rocprim sort: %s", hipGetErrorString(e));
+    set_error("%s: rocprim sort: %s", who, hipGetErrorString(e));
     return ESR_ELAUNCH;
   }
   hipLaunchKernelGGL(local_rows_kernel, dim3(grid), dim3(kBlock), 0, st, ids, (const int32_t*)perm, n, world,
                      local_rows, inverse);
-  return check_launch("esr_bucket_ids_by_owner");
+  return check_launch(who);
+}
+
+int esr_bucket_ids_by_owner(const int32_t* ids, int64_t n, int world, int32_t* local_rows, int32_t* perm,
+                            int32_t* inverse, int64_t* counts, void* workspace, size_t workspace_bytes,
+                            esr_stream_t stream) {
+  ESR_REQUIRE(n >= 0 && world > 0 && n < ((int64_t)1 << 31), "esr_bucket_ids_by_owner: bad sizes n=%lld world=%d",
+              (long long)n, world);
+  ESR_REQUIRE(counts, "esr_bucket_ids_by_owner: null counts");
+  ESR_REQUIRE(n == 0 || (ids && local_rows && perm), "esr_bucket_ids_by_owner: null pointer");
+  hipStream_t st = as_stream(stream);
+  SortSegs sg = {};
+  sg.n = 1;
+  sg.ids[0] = ids;
+  for (int i = 1; i <= kMaxSortSegs; ++i) sg.start[i] = n;
+  if (bucket_tiled(sg, n, world, local_rows, perm, inverse, counts, workspace, workspace_bytes, st))
+    return check_launch("esr_bucket_ids_by_owner(tiled)");
+  return bucket_plain("esr_bucket_ids_by_owner", ids, n, world, local_rows, perm, inverse, counts, workspace,
+                      workspace_bytes, st);
+}
+
+int esr_bucket_ids_by_owner_multi(const int32_t* const* ids, const int64_t* seg_counts, const int64_t* offsets, int nseg,
+                                  int world, int32_t* local_rows, int32_t* perm, int32_t* inverse, int64_t* counts,
+                                  void* workspace, size_t workspace_bytes, esr_stream_t stream) {
+  ESR_REQUIRE(nseg >= 1 && nseg <= kMaxSortSegs && ids && seg_counts && offsets && world > 0 && counts,
+              "esr_bucket_ids_by_owner_multi: nseg=%d not in [1, %d], world=%d or null argument", nseg, kMaxSortSegs,
+              world);
+  SortSegs sg;
+  sg.n = nseg;
+  sg.start[0] = 0;
+  for (int i = 0; i < kMaxSortSegs; ++i) {
+    ESR_REQUIRE(i >= nseg || (seg_counts[i] >= 0 && (seg_counts[i] == 0 || ids[i])),
+                "esr_bucket_ids_by_owner_multi: bad segment %d", i);
+    sg.ids[i] = i < nseg ? ids[i] : nullptr;
+    sg.offset[i] = i < nseg ? offsets[i] : 0;
+    sg.start[i + 1] = sg.start[i] + (i < nseg ? seg_counts[i] : 0);
+  }
+  const int64_t n = sg.start[nseg];
+  ESR_REQUIRE(n < ((int64_t)1 << 31), "esr_bucket_ids_by_owner_multi: n=%lld", (long long)n);
+  ESR_REQUIRE(n == 0 || (local_rows && perm), "esr_bucket_ids_by_owner_multi: null pointer");
+  hipStream_t st = as_stream(stream);
+  if (bucket_tiled(sg, n, world, local_rows, perm, inverse, counts, workspace, workspace_bytes, st))
+    return check_launch("esr_bucket_ids_by_owner_multi(tiled)");
+  // the other paths want one array: materialise the virtual ids at the head of the workspace
+  const size_t col = align_up((size_t)std::max<int64_t>(n, 1) * 4, 256);
+  if (n > 0 && (!workspace || workspace_bytes < col || ((uintptr_t)workspace & 15))) {
+    set_error("esr_bucket_ids_by_owner_multi: workspace %zu bytes < %zu required (or misaligned)", workspace_bytes,
+              esr_bucket_workspace_bytes(n));
+    return ESR_EWORKSPACE;
+  }
+  int32_t* vids = (int32_t*)workspace;
+  if (n > 0)
+    hipLaunchKernelGGL(concat_segs_kernel, dim3((int)std::min<int64_t>(kMaxGrid, cdiv(n, kBlock))), dim3(kBlock), 0, st, sg,
+                       n, vids);
+  return bucket_plain("esr_bucket_ids_by_owner_multi", vids, n, world, local_rows, perm, inverse, counts,
+                      n > 0 ? (char*)workspace + col : nullptr, n > 0 ? workspace_bytes - col : 0, st);
 }
 
 }  // extern "C"

@@ -581,19 +581,42 @@ def inbatch_towers_fwd_bwd(query_table, cand_table, query_ids, cand_ids, scale, 
     return loss, lse, gQC[:B], gQC[B:]
 
 
-def bucket_ids_by_owner(ids, world, want_inverse=False):
+def bucket_ids_by_owner(ids, world, want_inverse=False, offsets=None, counts_out=None):
     """Stable bucket by owner = id % world.  Returns (local_rows, perm, counts[world] int64 on device) and, with
-    want_inverse, also inverse with inverse[perm[k]] = k."""
+    want_inverse, also inverse with inverse[perm[k]] = k.  `ids` may be a list of int32 tensors with `offsets`: the
+    virtual list [ids_0 + offsets[0] ; ids_1 + offsets[1] ; ...] is bucketed in place (no concatenated copy).
+    `counts_out` (contiguous int64 [world] on the device) receives the counts instead of a fresh tensor."""
+    import ctypes
     lib = _lib.load()
-    ids = _req(ids, torch.int32, "ids")
-    n = ids.numel()
-    local_rows = torch.empty_like(ids)
-    perm = torch.empty_like(ids)
-    inverse = torch.empty_like(ids) if want_inverse else None
-    counts = torch.empty(world, dtype=torch.int64, device=ids.device)
-    ws = _ws(_ws_bytes("esr_bucket_workspace_bytes", n), ids.device)
-    check(lib.esr_bucket_ids_by_owner(_p(ids), n, world, _p(local_rows), _p(perm), _p(inverse), _p(counts), _p(ws),
-                                      ws.numel(), _stream()), "esr_bucket_ids_by_owner")
+    segs = list(ids) if isinstance(ids, (list, tuple)) else None
+    if segs is None:
+        ids = _req(ids, torch.int32, "ids")
+        n, dev = ids.numel(), ids.device
+    else:
+        for t in segs:
+            _req(t, torch.int32, "ids")
+        n, dev = sum(int(t.numel()) for t in segs), segs[0].device
+    local_rows = torch.empty(n, dtype=torch.int32, device=dev)
+    perm = torch.empty(n, dtype=torch.int32, device=dev)
+    inverse = torch.empty(n, dtype=torch.int32, device=dev) if want_inverse else None
+    if counts_out is None:
+        counts = torch.empty(world, dtype=torch.int64, device=dev)
+    else:
+        counts = _req(counts_out, torch.int64, "counts_out")
+        if counts.numel() != world:
+            raise ValueError("counts_out must hold %d int64" % world)
+    ws = _ws(_ws_bytes("esr_bucket_workspace_bytes", n), dev)
+    if segs is None:
+        check(lib.esr_bucket_ids_by_owner(_p(ids), n, world, _p(local_rows), _p(perm), _p(inverse), _p(counts), _p(ws),
+                                          ws.numel(), _stream()), "esr_bucket_ids_by_owner")
+    else:
+        k = len(segs)
+        ptrs = (ctypes.c_void_p * k)(*[t.data_ptr() for t in segs])
+        cnt = (ctypes.c_int64 * k)(*[int(t.numel()) for t in segs])
+        off = (ctypes.c_int64 * k)(*[int(x) for x in (offsets if offsets is not None else [0] * k)])
+        check(lib.esr_bucket_ids_by_owner_multi(ptrs, cnt, off, k, world, _p(local_rows), _p(perm), _p(inverse),
+                                                _p(counts), _p(ws), ws.numel(), _stream()),
+              "esr_bucket_ids_by_owner_multi")
     if want_inverse:
         return local_rows, perm, counts, inverse
     return local_rows, perm, counts

@@ -119,19 +119,29 @@ class PendingPlans:
 
 
 def begin_plans(lookups):
-    """lookups: list of (ShardedTableGroup, virtual ids int32 [n]).  Enqueues everything of the routing plans that
-    needs no host knowledge and returns a PendingPlans."""
+    """lookups: list of (ShardedTableGroup, virtual ids) -- an int32 [n] tensor or the (id tensors, offsets) pair of
+    ShardedTableGroup.virtual_id_segments.  Enqueues everything of the routing plans that needs no host knowledge and
+    returns a PendingPlans."""
     g0 = lookups[0][0]
-    k, G, pg = g0.k, g0.world, g0.pg
+    k, G, L = g0.k, g0.world, len(lookups)
+    dev = g0.tables[0].local.device
+    # [send | recv][peer][lookup]: all_to_all_single hands every peer its L counts; with one lookup (every step of this
+    # package) the bucket kernel writes its counts straight into the send half -- no stack / cat / copy launches
+    both = torch.empty((2, G, L), dtype=torch.int64, device=dev)
     parts = []
     for group, vids in lookups:
-        local_rows, perm, counts, inv = k.bucket_ids_by_owner(vids, G, want_inverse=True)
-        parts.append((group, vids.numel(), local_rows, perm, counts, inv))
-    # counts laid out [peer][lookup] so that all_to_all_single hands every peer its L counts
-    send = torch.stack([p[4] for p in parts], dim=1).contiguous()          # [G, L] int64
-    recv = torch.empty_like(send)
-    _a2a(g0, recv, send)
-    both = torch.stack([send, recv])
+        out = both[0, :, 0] if L == 1 else None
+        if isinstance(vids, tuple):   # (id tensors, virtual offsets): bucketed in place, never concatenated
+            n = sum(int(t.numel()) for t in vids[0])
+            local_rows, perm, counts, inv = k.bucket_ids_by_owner(list(vids[0]), G, want_inverse=True, offsets=vids[1],
+                                                                  counts_out=out)
+        else:
+            n = vids.numel()
+            local_rows, perm, counts, inv = k.bucket_ids_by_owner(vids, G, want_inverse=True, counts_out=out)
+        parts.append((group, n, local_rows, perm, counts, inv))
+    if L > 1:
+        both[0].copy_(torch.stack([p[4] for p in parts], dim=1))
+    _a2a(g0, both[1], both[0])
     if both.is_cuda:
         host = _pinned_like(both)
         host.copy_(both, non_blocking=True)
@@ -185,6 +195,13 @@ class ShardedTableGroup:
             return id_tensors[0]
         return self.k.concat_offset_ids(list(id_tensors), [self.voff[s] for s in slots])
 
+    def virtual_id_segments(self, id_tensors, slots):
+        """The same virtual list as (id tensors, offsets) for begin_plans / make_plans: bucketed without the
+        concatenated copy."""
+        if len(self.tables) == 1 and len(id_tensors) == 1:
+            return id_tensors[0]
+        return (list(id_tensors), [self.voff[s] for s in slots])
+
     def plan(self, vids):
         return make_plans([(self, vids)])[0]
 
@@ -233,11 +250,11 @@ class ShardedTableGroup:
 
 
 def plan_inbatch(towers, scene_ids, pos_ids):
-    return towers.plan(towers.virtual_ids([scene_ids, pos_ids], [0, 1]))
+    return towers.plan(towers.virtual_id_segments([scene_ids, pos_ids], [0, 1]))
 
 
 def plan_triplet(towers, scene_ids, pos_ids, neg_ids):
-    return towers.plan(towers.virtual_ids([scene_ids, pos_ids, neg_ids], [0, 1, 1]))
+    return towers.plan(towers.virtual_id_segments([scene_ids, pos_ids, neg_ids], [0, 1, 1]))
 
 
 def plan_glove(emb_group, inputs):
@@ -255,11 +272,11 @@ class _Pending1:
 
 def begin_plan_inbatch(towers, scene_ids, pos_ids):
     """Non-blocking half of plan_inbatch; ``.finish()`` returns the RoutingPlan."""
-    return _Pending1(begin_plans([(towers, towers.virtual_ids([scene_ids, pos_ids], [0, 1]))]))
+    return _Pending1(begin_plans([(towers, towers.virtual_id_segments([scene_ids, pos_ids], [0, 1]))]))
 
 
 def begin_plan_triplet(towers, scene_ids, pos_ids, neg_ids):
-    return _Pending1(begin_plans([(towers, towers.virtual_ids([scene_ids, pos_ids, neg_ids], [0, 1, 1]))]))
+    return _Pending1(begin_plans([(towers, towers.virtual_id_segments([scene_ids, pos_ids, neg_ids], [0, 1, 1]))]))
 
 
 def begin_plan_glove(emb_group, inputs):

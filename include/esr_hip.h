@@ -272,6 +272,12 @@ size_t esr_bucket_workspace_bytes(int64_t n);
 int esr_bucket_ids_by_owner(const int32_t* ids, int64_t n, int world, int32_t* local_rows,
                             int32_t* perm, int32_t* inverse, int64_t* counts, void* workspace,
                             size_t workspace_bytes, esr_stream_t stream);
+/* The same bucket over a list given as up to four segments [ids_k + offsets[k]] (the lookups of one step as virtual
+ * rows of the concatenated tables), read in place; perm / inverse index the concatenation.  ids / seg_counts /
+ * offsets are host arrays as in esr_concat_offset_ids; workspace query with n = the sum of the counts. */
+int esr_bucket_ids_by_owner_multi(const int32_t* const* ids, const int64_t* seg_counts, const int64_t* offsets,
+                                  int nseg, int world, int32_t* local_rows, int32_t* perm, int32_t* inverse,
+                                  int64_t* counts, void* workspace, size_t workspace_bytes, esr_stream_t stream);
 /* out[perm[k], :] = rows[k, :]  (undo the bucket order for rows that came back). */
 int esr_unpermute_rows(const void* rows, int dtype, int D, const int32_t* perm, int64_t n, void* out,
                        esr_stream_t stream);

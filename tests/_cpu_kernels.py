@@ -21,8 +21,14 @@ def _t(a, dtype=None):
 TOWERS_ANY_SHAPE = True  # the double has no tile-size constraints: let the sharded step take the folded path
 
 
-def bucket_ids_by_owner(ids, world, want_inverse=False):
+def bucket_ids_by_owner(ids, world, want_inverse=False, offsets=None, counts_out=None):
+    if isinstance(ids, (list, tuple)):
+        offsets = offsets if offsets is not None else [0] * len(ids)
+        ids = torch.cat([t + int(o) for t, o in zip(ids, offsets)])
     local, counts, perm = o_shard.bucket_by_owner(ids.numpy(), world)
+    if counts_out is not None:
+        counts_out.copy_(_t(counts))
+        counts = counts_out.numpy()
     if want_inverse:
         inv = np.empty_like(perm)
         inv[perm] = np.arange(len(perm), dtype=perm.dtype)

@@ -634,10 +634,33 @@ def test_score_topk_random_vs_oracle(dev, nq, N_, D, k):
 # ------------------------------------------------------------------------------------------------
 # shard routing
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("world,n", [(1, 16_389), (2, 16_389), (3, 16_389), (8, 16_389), (8, 7), (8, 65_536),
-                                     (8, 100_003), (16, 16_389)])
+@pytest.mark.parametrize("world,sizes", [(8, (8192, 8192)), (8, (8192, 8192, 8192)), (3, (5000, 1, 70000)),
+                                         (8, (700, 900)), (8, (600_000, 600_000)), (2, (0, 4096, 0, 100))])
+def test_bucket_ids_by_owner_segments_vs_oracle(dev, world, sizes):
+    """the segmented entry point == the plain one on the concatenated virtual ids, on every path (tiled, one
+    workgroup, radix), with the counts written into a caller buffer"""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(len(sizes) * 100 + world)
+    offsets = [int(x) for x in np.cumsum([0] + [1_000_000 + 8 * i for i in range(len(sizes) - 1)])]
+    segs = [rng.integers(0, 1_000_000, n).astype(np.int32) for n in sizes]
+    vids = np.concatenate([s + o for s, o in zip(segs, offsets)]).astype(np.int32)
+    co = torch.full((world,), -1, dtype=torch.int64, device=dev)
+    local, perm, counts, inv = ops.bucket_ids_by_owner([T(s, dev) for s in segs], world, want_inverse=True,
+                                                       offsets=offsets, counts_out=co)
+    assert counts.data_ptr() == co.data_ptr()
+    el, ec, ep = o_shard.bucket_by_owner(vids, world)
+    assert np.array_equal(N(co), ec)
+    assert np.array_equal(N(perm), ep)
+    assert np.array_equal(N(local), el)
+    assert np.array_equal(N(inv)[N(perm)], np.arange(len(vids), dtype=np.int32))
+
+
+
+@pytest.mark.parametrize("world,n", [(1, 16_389), (2, 16_389), (3, 16_389), (8, 16_389), (8, 7), (8, 2048), (8, 2049),
+                                     (5, 3000), (8, 65_536), (8, 100_003), (7, 1_048_576), (8, 1_048_577),
+                                     (16, 16_389)])
 def test_bucket_ids_by_owner_vs_oracle(dev, world, n):
-    """single-launch bucket kernel (n <= 65536, world <= 8) and the device-radix-sort path beyond it"""
+    """one-workgroup kernel (n <= 2048), tiled two-launch path (<= 1 Mi ids, world <= 8), device radix sort beyond"""
     from esrecsys_amd import ops
     rng = np.random.default_rng(world)
     ids = rng.integers(0, 1_000_000, n).astype(np.int32)
