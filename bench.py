@@ -73,6 +73,26 @@ class KernelTimer:
         return {g: (sum(a.elapsed_time(b) for a, b in ev), len(ev)) for g, ev in self.events.items()}
 
 
+def sustained_bf16_mfma_tflops(dev, iters=100000):
+    """What a register-only v_mfma_f32_32x32x16_bf16 loop with full-entropy operands sustains on THIS box right now
+    (esr_probe_mfma | ESR_PROBE_LIVE_DATA, ~60 ms): the part holds ~1.75 GHz under its power limit with live data,
+    not the 2.4 GHz the 2.5 PFLOP/s data-sheet peak assumes (constant operands do reach 2.45 PFLOP/s)."""
+    import ctypes
+    from esrecsys_amd import _lib
+    lib = _lib.load()
+    sink = torch.zeros(1, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    flops = ctypes.c_double()
+    dt = _lib.ESR_BF16 | _lib.ESR_PROBE_LIVE_DATA
+    _lib.check(lib.esr_probe_mfma(dt, 2048, 2000, sink.data_ptr(), ctypes.byref(flops), st), "probe")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _lib.check(lib.esr_probe_mfma(dt, 2048, iters, sink.data_ptr(), ctypes.byref(flops), st), "probe")
+    e1.record()
+    torch.cuda.synchronize()
+    return flops.value / e0.elapsed_time(e1) / 1e9
+
+
 def roofline_for(workload, kernels, B, D, rows, precision, occ_n=0, uniq=0):
     """The `roofline` object for the dominant kernel of one rank's step.  `kernels` = HIP-event ms per step per
     kernel group; occ_n / uniq = row occurrences and distinct rows the sparse Adagrad launch of the last batch saw."""
@@ -362,6 +382,10 @@ def main():
                             [last[0], last[1] + V, last[2] + V])  # the two towers are different tables
             occ_n, uniq = occ.numel(), int(torch.unique(occ).numel())
         roofline = roofline_for(args.workload, kernels, B, D, rows, PRECISION, occ_n, uniq)
+        if roofline.get("bound") == "mfma" and roofline.get("peak") == MFMA_BF16_PEAK_TFLOPS:
+            live = sustained_bf16_mfma_tflops(dev)  # after the timed region
+            roofline["sustained_live_data_TFLOPs"] = live
+            roofline["frac_of_sustained"] = roofline["achieved"] / live
     hbm = {}
     if "gather" in kernels:
         t = kernels["gather"]["ms_per_step"] * 1e-3

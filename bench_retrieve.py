@@ -93,6 +93,8 @@ def run_retrieve(args, emit):
     else:
         extra_cpu = None
     if rank == 0:
+        from bench import sustained_bf16_mfma_tflops
+        live = sustained_bf16_mfma_tflops(dev)
         emit({
             "metric": "retrieval queries/sec (top-%d of N candidates, brute force)" % K,
             "value": world * NQ * args.steps / dt, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
@@ -106,6 +108,7 @@ def run_retrieve(args, emit):
             "roofline": {"kernel": "score_gemm_kernel (+ split, select)", "bound": "mfma",
                          "achieved": planes * flops / t_op / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": planes * flops / t_op / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
+                         "sustained_live_data_TFLOPs": live, "frac_of_sustained": planes * flops / t_op / 1e12 / live,
                          "f32_equivalent_TFLOPs": flops / t_op / 1e12,
                          "f32_equivalent_vs_f32_mfma_peak": flops / t_op / 1e12 / MFMA_F32_PEAK_TFLOPS},
             "cpu_baseline": extra_cpu,

@@ -17,8 +17,14 @@ def main():
     dev = torch.device("cuda", 0)
     sink = torch.zeros(1, device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    for name, dtype, peak in (("bf16 32x32x16", _lib.ESR_BF16, 2500.0), ("f32 32x32x2", _lib.ESR_F32, 157.3)):
-        for wgs, iters in ((256 * 8, 20000), (256 * 8, 100000)):
+    # constants: the pipes' issue ceiling; live data, run long enough (~0.5 s) for the power controller to settle: the
+    # ceiling a real bf16 GEMM can reach on this box
+    for name, dtype, peak, runs in (
+            ("bf16 32x32x16", _lib.ESR_BF16, 2500.0, ((256 * 8, 20000), (256 * 8, 100000))),
+            ("bf16 32x32x16 live data", _lib.ESR_BF16 | _lib.ESR_PROBE_LIVE_DATA, 2500.0,
+             ((256 * 8, 20000), (256 * 8, 100000), (256 * 8, 1000000))),
+            ("f32 32x32x2", _lib.ESR_F32, 157.3, ((256 * 8, 20000), (256 * 8, 100000)))):
+        for wgs, iters in runs:
             flops = ctypes.c_double()
             _lib.check(lib.esr_probe_mfma(dtype, wgs, 1000, sink.data_ptr(), ctypes.byref(flops), st), "probe")
             torch.cuda.synchronize()

@@ -58,7 +58,10 @@ int esr_device_info(int* cu_count, int* wave_size, size_t* hbm_bytes, char* arch
 /* Measurement probe (not on the hot path): `workgroups` x 4 waves each run `iters` rounds of four independent
  * register-only MFMA chains (dtype ESR_BF16: v_mfma_f32_32x32x16_bf16, ESR_F32: v_mfma_f32_32x32x2_f32).
  * *flops_out (host) = flops the launch executes; time it on `stream` to get the matrix ceiling this box sustains.
- * sink: one device float (never written). */
+ * sink: one device float (never written).  dtype | ESR_PROBE_LIVE_DATA feeds the chains full-entropy operands that
+ * change every instruction instead of constants: switching activity, and with it the clock the part holds under
+ * its power limit, is that of a real GEMM (constants measured 2.44 PFLOP/s bf16; see profiles/). */
+#define ESR_PROBE_LIVE_DATA 0x100
 int esr_probe_mfma(int dtype, int workgroups, int iters, float* sink, double* flops_out, esr_stream_t stream);
 
 /* ---- G2 / S1: embedding-row gather ------------------------------------------------------
