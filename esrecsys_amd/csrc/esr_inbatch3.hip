@@ -103,6 +103,7 @@ __device__ __forceinline__ void tr_frag_n(int f, TA& ta, const uint32_t (&tc)[4]
   }
 }
 constexpr int k3Bufs = 3;
+constexpr int kLossWords = 64;        // first-level accumulators of the merge kernels' loss reduction
 constexpr int k3MergeBlocks = 1024;  // most workgroups of a merge launch (= loss partials per launch)
 
 __device__ __forceinline__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -155,8 +156,10 @@ __device__ __forceinline__ float4 rowsrc_load4(const RowSrc& s, int64_t row, int
 __global__ __launch_bounds__(256) void split3_kernel(RowSrc X0, RowSrc X1,
                                                     int64_t B, __bf16* __restrict__ R0, __bf16* __restrict__ T0,
                                                     __bf16* __restrict__ R1, __bf16* __restrict__ T1,
-                                                    float* __restrict__ nrm) {
+                                                    float* __restrict__ nrm,
+                                                    unsigned long long* __restrict__ loss_acc) {
   __shared__ __attribute__((aligned(16))) __bf16 tl[3][128][40];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x <= kLossWords) loss_acc[threadIdx.x * 16] = 0ull;  // see merge
   const RowSrc X = blockIdx.y ? X1 : X0;
   __bf16* R = blockIdx.y ? R1 : R0;
   __bf16* Tt = blockIdx.y ? T1 : T0;
@@ -726,7 +729,8 @@ template <bool QSIDE>
 __global__ __launch_bounds__(kBlock) void inbatch3_merge_kernel(
     RowSrc X, RowSrc Y, const int32_t* __restrict__ out_idx, int64_t B, int nsplit, const float* __restrict__ part_O,
     const float* __restrict__ part_m, const float* __restrict__ part_l, float scale, float lam, float inv_bs,
-    float* __restrict__ lse2, float* __restrict__ lse_nat, float* __restrict__ gX, double* __restrict__ loss_part) {
+    float* __restrict__ lse2, float* __restrict__ lse_nat, float* __restrict__ gX,
+    unsigned long long* __restrict__ loss_acc, double loss_scale, float* __restrict__ loss_out) {
   __shared__ double sm[4];
   constexpr int G = 32;
   const int lig = threadIdx.x & (G - 1);
@@ -789,14 +793,37 @@ __global__ __launch_bounds__(kBlock) void inbatch3_merge_kernel(
     if (lig == 0) acc_loss += (double)row_loss;
   }
   const double tsum = block_sum_d(acc_loss, sm);
-  if (threadIdx.x == 0) loss_part[blockIdx.x] = tsum;
+  // The loss scalar without a finalize launch and without a fence.  Every workgroup of both merge launches adds
+  // (its partial in 2^-28 fixed point) << 11 | 1 to a 64-bit word with ONE atomic -- integer addition is exact and
+  // order-free, so the sum is bit-reproducible, and the atomic's return value tells the workgroup whether it was the
+  // last to arrive.  Two levels, because 2048 atomics on one address serialise (measured: +15 us): kLossWords words
+  // 128 B apart take workgroups blockIdx % kLossWords; the last arrival of a word forwards that word's total to the
+  // master word; the last arrival there writes the loss.  Data flows only through atomic return values, so no
+  // ordering between addresses is needed.  split3_kernel zeroed the words.  (A ticket + __threadfence() reduction of
+  // double partials was 7 us slower than the finalize launch: the agent-scope release writes the XCD's L2 back.)
+  // Range: |sum| < 2^24 = 1.6e7 nats; resolution 3.7e-9 per workgroup partial.
+  if (threadIdx.x == 0) {
+    const unsigned wd = blockIdx.x % kLossWords;
+    const unsigned per_launch = (gridDim.x - wd + kLossWords - 1) / kLossWords;  // workgroups of one launch on word wd
+    const unsigned nwords = gridDim.x < (unsigned)kLossWords ? gridDim.x : (unsigned)kLossWords;
+    const unsigned long long add = ((unsigned long long)__double2ll_rn(tsum * 268435456.0) << 11);
+    const unsigned long long old = atomicAdd(loss_acc + 16 * (1 + wd), add + 1ull);
+    if ((unsigned)(old & 2047ull) == 2 * per_launch - 1) {
+      const unsigned long long word_total = ((old + add) >> 11) << 11;  // this word's sum, count bits cleared
+      const unsigned long long m = atomicAdd(loss_acc, word_total + 1ull);
+      if ((unsigned)(m & 2047ull) == nwords - 1) {
+        const long long tot = ((long long)(m + word_total)) >> 11;  // arithmetic shift: signed sum
+        loss_out[0] = (float)((double)tot * (1.0 / 268435456.0) * loss_scale);
+      }
+    }
+  }
 }
 
 
 struct Inbatch3Ws {
   __bf16 *Qr, *Qt, *Cr, *Ct;
   float *part_O, *part_m, *part_l, *lse2;
-  double* loss_part;  // [2 * k3MergeBlocks]
+  unsigned long long* loss_acc;  // [(1 + kLossWords) * 16]: master word, then kLossWords words 128 B apart
   float* nrm;         // [2][B / 32][4]: largest squared row norm per (matrix, chunk, wave) of the split pre-pass
 };
 static size_t inbatch3_ws_layout(int64_t B, int nsplit, char* base, Inbatch3Ws* ws) {
@@ -814,7 +841,7 @@ static size_t inbatch3_ws_layout(int64_t B, int nsplit, char* base, Inbatch3Ws* 
   w.part_m = (float*)take((size_t)nsplit * B * 4);
   w.part_l = (float*)take((size_t)nsplit * B * 4);
   w.lse2 = (float*)take((size_t)B * 4);
-  w.loss_part = (double*)take(sizeof(double) * 2 * k3MergeBlocks);
+  w.loss_acc = (unsigned long long*)take(sizeof(unsigned long long) * 16 * (1 + kLossWords));
   w.nrm = (float*)take((size_t)2 * (B / k3Chunk) * 4 * sizeof(float));
   if (ws) *ws = w;
   return off;
@@ -883,7 +910,8 @@ static int inbatch3_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* gq
   const float inv_bs = 1.0f / batch_size, sl2 = scale * k3Log2e;
   const int nchunks = (int)(B / k3Chunk), grid = (int)(B / k3Owned) * nsplit;
   const int mgrid = (int)std::min<int64_t>(k3MergeBlocks, cdiv(B, kBlock / 32));
-  hipLaunchKernelGGL(split3_kernel, dim3(nchunks, 2), dim3(256), 0, st, Qs, Cs, B, ws.Qr, ws.Qt, ws.Cr, ws.Ct, ws.nrm);
+  hipLaunchKernelGGL(split3_kernel, dim3(nchunks, 2), dim3(256), 0, st, Qs, Cs, B, ws.Qr, ws.Qt, ws.Cr, ws.Ct, ws.nrm,
+                     ws.loss_acc);
   // pass Q: owned = Q, streamed = C
   hipLaunchKernelGGL(inbatch3_rowmax_kernel, dim3(grid), dim3(256), 0, st, (const __bf16*)ws.Qr, (const __bf16*)ws.Cr, B,
                      nsplit, sl2, (const float*)ws.nrm, ws.part_m);
@@ -891,20 +919,14 @@ static int inbatch3_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* gq
                      (const __bf16*)ws.Ct, B, nsplit, sl2, (const float*)ws.part_m, ws.part_O, ws.part_l);
   hipLaunchKernelGGL((inbatch3_merge_kernel<true>), dim3(mgrid), dim3(kBlock), 0, st, Qs, Cs, gq_rows, B, nsplit,
                      (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale, regularization,
-                     inv_bs, ws.lse2, lse, gQ, ws.loss_part);
+                     inv_bs, ws.lse2, lse, gQ, ws.loss_acc, 1.0 / (double)batch_size, loss);
   // pass C: owned = C, streamed = Q
   hipLaunchKernelGGL((inbatch3_kernel<false>), dim3(grid), dim3(256), 0, st, (const __bf16*)ws.Cr,
                      (const __bf16*)ws.Qr, (const __bf16*)ws.Qt, B, nsplit, sl2, (const float*)ws.lse2, ws.part_O,
                      ws.part_l);
   hipLaunchKernelGGL((inbatch3_merge_kernel<false>), dim3(mgrid), dim3(kBlock), 0, st, Cs, Qs, gc_rows, B, nsplit,
                      (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale, regularization,
-                     inv_bs, ws.lse2, (float*)nullptr, gC, ws.loss_part + k3MergeBlocks);
-  // the two merge launches wrote mgrid partials each at [0, mgrid) and [k3MergeBlocks, k3MergeBlocks + mgrid); a
-  // last-workgroup reduction inside the second merge (ticket + __threadfence) was measured 7 us SLOWER than this
-  // extra launch: the agent-scope release makes every workgroup write its XCD's L2 back
-  if (mgrid < k3MergeBlocks)
-    (void)hipMemsetAsync(ws.loss_part + mgrid, 0, sizeof(double) * (k3MergeBlocks - mgrid), st);
-  finalize_scalar(ws.loss_part, k3MergeBlocks + mgrid, 1.0 / (double)batch_size, loss, st);
+                     inv_bs, ws.lse2, (float*)nullptr, gC, ws.loss_acc, 1.0 / (double)batch_size, loss);
   return check_launch(who);
 }
 
