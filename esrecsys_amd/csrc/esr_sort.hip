@@ -101,20 +101,23 @@ __global__ __launch_bounds__(kSmallSortThreads) void segment_sort_small_kernel(S
 }
 
 // Mid-size lists (4096 < n <= 32768, ids < 2^21: the occurrence ids of one C2 step): two launches instead of the
-// radix sort's ~6.  (1) every workgroup bitonic-sorts one 2048-key tile of 32-bit composites
-// (id << 11 | position in tile) in LDS; (2) every element finds its final rank = its index in its own tile + for
+// radix sort's ~6.  (1) every workgroup bitonic-sorts one tile (512 / 1024 / 2048 keys) of 32-bit composites
+// (id << log2(tile) | position in tile) in LDS; (2) every element finds its final rank = its index in its own tile + for
 // each EARLIER tile the number of ids <= its id + for each LATER tile the number of ids < its id (binary searches
 // that advance in lockstep so their dependent loads overlap).  Ranks are exact and the sort is stable.
-constexpr int kTile = 2048, kTileBits = 11, kMidTiles = 16;
-constexpr int kMidSortMax = kTile * kMidTiles;
-constexpr int kMidIdBits = 32 - kTileBits;
-__global__ __launch_bounds__(kSmallSortThreads) void tile_sort_kernel(SortSegs ids, int n,
-                                                                     uint32_t* __restrict__ tiles) {
+// The tile is the smallest power of two >= 512 that covers the list with kMidTiles tiles (16 384 ids: 16 tiles of 1024
+// -- sixteen workgroups sort instead of eight and every one of the rank kernel's 16 lanes per element has a tile to
+// search; 2048-key tiles at every size left half of them idle there: 10.9 + 6.3 us -> see profiles/).
+constexpr int kMidTiles = 16, kMaxTileBits = 11;
+constexpr int kMidSortMax = (1 << kMaxTileBits) * kMidTiles;
+template <int TB>
+__global__ __launch_bounds__((1 << TB) / 2) void tile_sort_kernel(SortSegs ids, int n, uint32_t* __restrict__ tiles) {
+  constexpr int kTile = 1 << TB, kThreads = kTile / 2;
   __shared__ uint32_t key[kTile];
   const int t = threadIdx.x, base = blockIdx.x * kTile;
-  for (int i = t; i < kTile; i += kSmallSortThreads) {
+  for (int i = t; i < kTile; i += kThreads) {
     const int g = base + i;
-    key[i] = g < n ? ((uint32_t)seg_id(ids, g) << kTileBits) | (uint32_t)i : 0xFFFFFFFFu;
+    key[i] = g < n ? ((uint32_t)seg_id(ids, g) << TB) | (uint32_t)i : 0xFFFFFFFFu;
   }
   for (int size = 2; size <= kTile; size <<= 1)
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -129,28 +132,30 @@ __global__ __launch_bounds__(kSmallSortThreads) void tile_sort_kernel(SortSegs i
       }
     }
   __syncthreads();
-  for (int i = t; i < kTile; i += kSmallSortThreads) tiles[base + i] = key[i];
+  for (int i = t; i < kTile; i += kThreads) tiles[base + i] = key[i];
 }
 
-// Two-level search: the last id of every 32-key block of every tile ("splitters", 4 KB) is staged in LDS and
+// Two-level search: the last id of every 32-key block of every tile ("splitters", <= 4 KB) is staged in LDS and
 // searched there; only the final 32-key window -- one 128-byte line -- is searched in global memory.  A plain
 // binary search over the tiles touched ~12 scattered lines per (element, tile) and was bound by L1 line rate.
-constexpr int kSplitEvery = 32, kSplitPerTile = kTile / kSplitEvery;
+constexpr int kSplitEvery = 32;
 // 16 lanes per element, one per tile: the searches of one element run side by side and their counts are summed
 // with shuffles (one thread walking all tiles was latency-bound at one wave per SIMD: 26 us for 24 576 keys).
+template <int TB>
 __global__ __launch_bounds__(kBlock) void tile_rank_kernel(const uint32_t* __restrict__ tiles, int n, int ntiles,
                                                           int32_t* __restrict__ sorted_ids,
                                                           int32_t* __restrict__ perm) {
+  constexpr int kTile = 1 << TB, kSplitPerTile = kTile / kSplitEvery;
   __shared__ uint32_t spl[kMidTiles * kSplitPerTile];
   for (int i = threadIdx.x; i < ntiles * kSplitPerTile; i += kBlock)
-    spl[i] = tiles[i * kSplitEvery + kSplitEvery - 1] >> kTileBits;
+    spl[i] = tiles[i * kSplitEvery + kSplitEvery - 1] >> TB;
   __syncthreads();
   const int u = threadIdx.x & (kMidTiles - 1);                                 // the tile this lane searches
   const int g = (blockIdx.x * kBlock + threadIdx.x) / kMidTiles;                // slot g of the tiled array
   const int mine = g / kTile;
   const bool live = g < ntiles * kTile && g - mine * kTile < n - mine * kTile;  // not padding
   const uint32_t c = live ? tiles[g] : 0u;
-  const uint32_t id = c >> kTileBits;
+  const uint32_t id = c >> TB;
   int cnt = 0;
   if (live && u < ntiles && u != mine) {
     int lo = 0, hi = kSplitPerTile;  // level 1 (LDS): whole 32-key blocks that precede this element
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void tile_rank_kernel(const uint32_t* __res
     int lo2 = 0, hi2 = base < kTile ? kSplitEvery : 0;  // level 2 (global): inside that block, one 128-B line
     while (lo2 < hi2) {
       const int mid = (lo2 + hi2) >> 1;
-      const uint32_t x = tiles[u * kTile + base + mid] >> kTileBits;
+      const uint32_t x = tiles[u * kTile + base + mid] >> TB;
       if (u < mine ? x <= id : x < id) lo2 = mid + 1; else hi2 = mid;
     }
     cnt = min(base + lo2, n - u * kTile);  // never count the padding
@@ -175,6 +180,15 @@ __global__ __launch_bounds__(kBlock) void tile_rank_kernel(const uint32_t* __res
     sorted_ids[rank] = (int32_t)id;
     perm[rank] = mine * kTile + (int)(c & (kTile - 1));
   }
+}
+template <int TB>
+static void launch_tile_sort(const SortSegs& sg, int n, uint32_t* tiles, int32_t* sorted_ids, int32_t* perm,
+                             hipStream_t st) {
+  constexpr int kTile = 1 << TB;
+  const int ntiles = (int)cdiv(n, kTile);
+  hipLaunchKernelGGL((tile_sort_kernel<TB>), dim3(ntiles), dim3(kTile / 2), 0, st, sg, n, tiles);
+  hipLaunchKernelGGL((tile_rank_kernel<TB>), dim3((int)cdiv((int64_t)ntiles * kTile * kMidTiles, kBlock)), dim3(kBlock), 0,
+                     st, (const uint32_t*)tiles, n, ntiles, sorted_ids, perm);
 }
 
 // owner key of every id + the per-owner totals.  The totals are privatised per workgroup in LDS (one global
@@ -518,7 +532,7 @@ extern "C" {
 // ------------------------------------------------------------------------------------------------
 size_t esr_segment_sort_workspace_bytes(int64_t n) {
   if (n <= 0) return 256;
-  const size_t tiles = n <= kMidSortMax ? align_up((size_t)cdiv(n, kTile) * kTile * 4, 256) : 0;
+  const size_t tiles = n <= kMidSortMax ? align_up((size_t)kMidSortMax * 4, 256) : 0;
   // + one column for the concatenated ids of a segmented list on the radix path
   return std::max(pair_sort_temp_bytes<false, uint32_t>(n) + align_up((size_t)n * 4, 256), tiles);
 }
@@ -529,16 +543,15 @@ static int segment_sort_segs(const char* who, const SortSegs& sg, int64_t n, int
     hipLaunchKernelGGL(segment_sort_small_kernel, dim3(1), dim3(kSmallSortThreads), 0, st, sg, (int)n, sorted_ids, perm);
     return check_launch(who);
   }
-  if (n <= kMidSortMax && V <= ((int64_t)1 << kMidIdBits)) {
-    const int ntiles = (int)cdiv(n, kTile);
-    if ((size_t)ntiles * kTile * 4 > workspace_bytes || ((uintptr_t)workspace & 15)) {
+  if (n <= kMidSortMax && V <= ((int64_t)1 << (32 - kMaxTileBits))) {
+    if ((size_t)kMidSortMax * 4 > workspace_bytes || ((uintptr_t)workspace & 15)) {
       set_error("%s: workspace %zu bytes too small (or misaligned)", who, workspace_bytes);
       return ESR_EWORKSPACE;
     }
     uint32_t* tiles = (uint32_t*)workspace;
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(ntiles), dim3(kSmallSortThreads), 0, st, sg, (int)n, tiles);
-    hipLaunchKernelGGL(tile_rank_kernel, dim3((int)cdiv((int64_t)ntiles * kTile * kMidTiles, kBlock)), dim3(kBlock), 0,
-                       st, (const uint32_t*)tiles, (int)n, ntiles, sorted_ids, perm);
+    if (n <= 512 * kMidTiles) launch_tile_sort<9>(sg, (int)n, tiles, sorted_ids, perm, st);
+    else if (n <= 1024 * kMidTiles) launch_tile_sort<10>(sg, (int)n, tiles, sorted_ids, perm, st);
+    else launch_tile_sort<11>(sg, (int)n, tiles, sorted_ids, perm, st);
     return check_launch(who);
   }
   // device radix sort: needs the ids as one array (materialised at the head of the workspace when segmented)
