@@ -159,7 +159,10 @@ __global__ __launch_bounds__(256) void split3_kernel(RowSrc X0, RowSrc X1,
                                                     float* __restrict__ nrm,
                                                     unsigned long long* __restrict__ loss_acc) {
   __shared__ __attribute__((aligned(16))) __bf16 tl[3][128][40];
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x <= kLossWords) loss_acc[threadIdx.x * 16] = 0ull;  // see merge
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x <= kLossWords) {  // see inbatch3_merge_kernel
+    loss_acc[threadIdx.x * 16] = 0ull;
+    if (threadIdx.x == 0) loss_acc[8] = 0ull;  // poison word
+  }
   const RowSrc X = blockIdx.y ? X1 : X0;
   __bf16* R = blockIdx.y ? R1 : R0;
   __bf16* Tt = blockIdx.y ? T1 : T0;
@@ -801,19 +804,28 @@ __global__ __launch_bounds__(kBlock) void inbatch3_merge_kernel(
   // master word; the last arrival there writes the loss.  Data flows only through atomic return values, so no
   // ordering between addresses is needed.  split3_kernel zeroed the words.  (A ticket + __threadfence() reduction of
   // double partials was 7 us slower than the finalize launch: the agent-scope release writes the XCD's L2 back.)
-  // Range: |sum| < 2^24 = 1.6e7 nats; resolution 3.7e-9 per workgroup partial.
+  // Range: |sum| < 2^24 = 1.6e7 nats (a partial beyond it, or a non-finite one, poisons the result: NaN); resolution
+  // 3.7e-9 per workgroup partial.
   if (threadIdx.x == 0) {
     const unsigned wd = blockIdx.x % kLossWords;
     const unsigned per_launch = (gridDim.x - wd + kLossWords - 1) / kLossWords;  // workgroups of one launch on word wd
     const unsigned nwords = gridDim.x < (unsigned)kLossWords ? gridDim.x : (unsigned)kLossWords;
-    const unsigned long long add = ((unsigned long long)__double2ll_rn(tsum * 268435456.0) << 11);
+    unsigned long long add = ((unsigned long long)__double2ll_rn(tsum * 268435456.0) << 11);
+    if (!(fabs(tsum) < 16777216.0)) {  // non-finite or out of range: the loss must come out NaN, not a wrapped number
+      // raise the poison word BEFORE this workgroup is counted: the add below consumes the atomic's return value, so
+      // it cannot be issued until the OR has been performed (r is 0 or 1; r >> 1 is the dependence, not a value)
+      const unsigned r = atomicOr(reinterpret_cast<unsigned*>(loss_acc + 8), 1u);
+      add = (unsigned long long)(r >> 1);
+    }
     const unsigned long long old = atomicAdd(loss_acc + 16 * (1 + wd), add + 1ull);
     if ((unsigned)(old & 2047ull) == 2 * per_launch - 1) {
       const unsigned long long word_total = ((old + add) >> 11) << 11;  // this word's sum, count bits cleared
       const unsigned long long m = atomicAdd(loss_acc, word_total + 1ull);
       if ((unsigned)(m & 2047ull) == nwords - 1) {
         const long long tot = ((long long)(m + word_total)) >> 11;  // arithmetic shift: signed sum
-        loss_out[0] = (float)((double)tot * (1.0 / 268435456.0) * loss_scale);
+        // every workgroup was counted before this branch was taken, hence after its OR (if any) was performed
+        const bool poisoned = atomicOr(reinterpret_cast<unsigned*>(loss_acc + 8), 0u) != 0u;
+        loss_out[0] = poisoned ? __builtin_nanf("") : (float)((double)tot * (1.0 / 268435456.0) * loss_scale);
       }
     }
   }
@@ -823,7 +835,7 @@ __global__ __launch_bounds__(kBlock) void inbatch3_merge_kernel(
 struct Inbatch3Ws {
   __bf16 *Qr, *Qt, *Cr, *Ct;
   float *part_O, *part_m, *part_l, *lse2;
-  unsigned long long* loss_acc;  // [(1 + kLossWords) * 16]: master word, then kLossWords words 128 B apart
+  unsigned long long* loss_acc;  // [(1 + kLossWords) * 16]: master word (+ poison word at [8]), then kLossWords words 128 B apart
   float* nrm;         // [2][B / 32][4]: largest squared row norm per (matrix, chunk, wave) of the split pre-pass
 };
 static size_t inbatch3_ws_layout(int64_t B, int nsplit, char* base, Inbatch3Ws* ws) {

@@ -104,3 +104,22 @@ def test_argument_errors_raise_with_a_message(dev):
                             1, 1, 1, 1.0)                                  # 2F > 256
     # the failed calls left the library usable
     assert ops.gather_rows(c, torch.zeros(3, dtype=torch.int32, device=dev)).shape == (3, 32)
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_inbatch_bf16x3_nonfinite_input_gives_nan_loss(dev, bad):
+    """the bf16x3 path reduces its loss in fixed point through integer atomics: a non-finite partial must still come
+    out as NaN (poison word), and the next call on the same workspace must be clean again"""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(3)
+    B, D = 256, 128
+    q = (rng.standard_normal((B, D)) * D ** -0.5).astype(np.float32)
+    c = (rng.standard_normal((B, D)) * D ** -0.5).astype(np.float32)
+    qb = q.copy()
+    qb[77, 5] = bad
+    loss, _, _, _ = ops.inbatch_softmax_fwd_bwd(T(qb, dev), T(c, dev), 4.0, 0.1, float(B), precision="bf16x3")
+    assert np.isnan(float(loss))
+    loss2, _, gq, gc = ops.inbatch_softmax_fwd_bwd(T(q, dev), T(c, dev), 4.0, 0.1, float(B), precision="bf16x3")
+    el, _, egq, egc = o_stl.inbatch_softmax_loss_and_grads(q.astype(F64), c.astype(F64), 0.1, float(B), 4.0, F64)
+    assert abs(float(loss2) - el) <= 1e-5 * abs(el)
+    assert np.max(np.abs(N(gq) - egq)) <= 1e-5 * np.max(np.abs(egq))
