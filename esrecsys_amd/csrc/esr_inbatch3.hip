@@ -535,6 +535,9 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
 #pragma unroll
   for (int r = 0; r < 16; ++r) { p[r] = 0.f; rf[r] = 0.f; }
   ESR_S_PHASE(lds, sa, false);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) p[r] = sa[r];
+  ESR_LOAD_REFS(lds);
 
 #ifdef ESR_IB3_TIMING
   unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0, tacc0 = 0, tacc1 = 0, tacc2 = 0;
@@ -554,14 +557,16 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
     const char* buf = lds + cur * kBufBytes;
     const char* nbuf = lds + nxt * kBufBytes;
     char* dbuf = lds + nn * kBufBytes;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) p[r] = sa[r];
-    ESR_LOAD_REFS(buf);
     ESR_TR_BASES(buf);
     ESR_S_PHASE(nbuf, sa, true);  // S^T of chunk it+1 with the exp / split of chunk it threaded through
     ESR_TICK(tk2);
+    // the next iteration's raw scores and references are fetched here, behind the O^T MFMAs, not after the barrier
+    // (p and rf are dead once the S^T phase is over; chunk it+1's lse block has been visible since this barrier)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[r] = sa[r];
     ESR_DMA_LSE(dbuf);
     ESR_O_PHASE(buf, true, dbuf);  // O^T of chunk it with the DMA of chunk it+2 threaded through
+    ESR_LOAD_REFS(nbuf);
     ESR_TICK(tk3);
 #ifdef ESR_IB3_TIMING
     tacc0 += tk1 - tk0; tacc1 += tk2 - tk1; tacc2 += tk3 - tk2;
@@ -573,20 +578,17 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
     ESR_DMA_BARRIER();
     const char* buf = lds + cur * kBufBytes;
     const char* nbuf = lds + nxt * kBufBytes;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) p[r] = sa[r];
-    ESR_LOAD_REFS(buf);
     ESR_TR_BASES(buf);
     ESR_S_PHASE(nbuf, sa, true);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[r] = sa[r];
     ESR_O_PHASE(buf, false, lds);
+    ESR_LOAD_REFS(nbuf);
     cur = nxt;
   }
   {  // last chunk: nothing left to prefetch; run its exp / split alone
     ESR_DMA_BARRIER();
     const char* buf = lds + cur * kBufBytes;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) p[r] = sa[r];
-    ESR_LOAD_REFS(buf);
     ESR_TR_BASES(buf);
     ESR_O_PREFETCH(buf);
 #pragma unroll
