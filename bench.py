@@ -93,6 +93,39 @@ def sustained_bf16_mfma_tflops(dev, iters=100000):
     return flops.value / e0.elapsed_time(e1) / 1e9
 
 
+def saturating_gather_scatter(dev, V, D, n=131072, reps=20):
+    """Gather and sparse-Adagrad scatter of the SAME kernels on a V x D fp32 table at a launch large enough to fill
+    the chip (n uniform occurrences): BASELINE.json's ">= 60 % of HBM roofline on embedding gather + scatter" is a
+    statement about the kernels, and one step's 2 x B rows (8 MB of gather at B = 8192) finish inside the launch
+    ramp.  Algorithmic bytes as in SURVEY 8d: gather 2 n D 4; scatter (n + 4 distinct) D 4."""
+    from esrecsys_amd import ops
+    g = torch.Generator(device=dev).manual_seed(1701)
+    table = torch.randn((V, D), generator=g, device=dev)
+    accum = torch.full((V, D), 0.1, device=dev)
+    ids = torch.randint(0, V, (n,), generator=g, device=dev, dtype=torch.int32)
+    grads = torch.randn((n, D), generator=g, device=dev) * 0.01
+    out = torch.empty((n, D), device=dev)
+    sid, perm = ops.segment_sort(ids, V)
+    uniq = int(torch.unique(ids).numel())
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    tg = timed(lambda: ops.gather_rows(table, ids, out=out))
+    ts = timed(lambda: ops.sparse_adagrad(table, accum, sid, perm, grads, 0.01))
+    gb, sb = 2.0 * n * D * 4, (n + 4.0 * uniq) * D * 4
+    return {"rows_per_launch": n, "gather_GBps": gb / tg / 1e9, "gather_frac_of_8TBps": gb / tg / 1e9 / HBM_PEAK_GBS,
+            "sparse_adagrad_GBps": sb / ts / 1e9, "sparse_adagrad_frac_of_8TBps": sb / ts / 1e9 / HBM_PEAK_GBS}
+
+
 def roofline_for(workload, kernels, B, D, rows, precision, occ_n=0, uniq=0):
     """The `roofline` object for the dominant kernel of one rank's step.  `kernels` = HIP-event ms per step per
     kernel group; occ_n / uniq = row occurrences and distinct rows the sparse Adagrad launch of the last batch saw."""
@@ -393,6 +426,8 @@ def main():
     if "sparse_adagrad" in kernels:
         t = kernels["sparse_adagrad"]["ms_per_step"] * 1e-3
         hbm["sparse_adagrad_GBps"] = adagrad_bytes / t / 1e9
+    if hbm and not args.no_kernel_timing:
+        hbm["saturating_launch"] = saturating_gather_scatter(dev, min(V, 4_000_000), D)  # own table + accumulator
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc) and roofline is not None:
         try:  # HBM bytes per launch of the dominant kernel group, from the committed --pmc passes
