@@ -123,3 +123,30 @@ def test_inbatch_bf16x3_nonfinite_input_gives_nan_loss(dev, bad):
     el, _, egq, egc = o_stl.inbatch_softmax_loss_and_grads(q.astype(F64), c.astype(F64), 0.1, float(B), 4.0, F64)
     assert abs(float(loss2) - el) <= 1e-5 * abs(el)
     assert np.max(np.abs(N(gq) - egq)) <= 1e-5 * np.max(np.abs(egq))
+
+
+@pytest.mark.parametrize("n,D", [(100_000, 128), (70_001, 256), (33, 16)])
+def test_sparse_adagrad_one_row_takes_every_gradient(dev, n, D):
+    """the worst hot row: every occurrence is the same id (one run of n, thousands of chunk partials)"""
+    import time
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(n)
+    V = 1000
+    ids = np.full(n, 123, np.int32)
+    p0 = rng.standard_normal((V, D)).astype(np.float32)
+    a0 = np.full((V, D), 0.1, np.float32)
+    rows = (rng.standard_normal((n, D)) * 0.01).astype(np.float32)
+    table, accum, grads = T(p0, dev), T(a0, dev), T(rows, dev)
+    sid, perm = ops.segment_sort(T(ids, dev), V)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ops.sparse_adagrad(table, accum, sid, perm, grads, 0.05, 1e-7)
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 0.5   # seconds: chunked, not one thread walking the run
+    g = rows.astype(F64).sum(0)
+    ea = a0[123].astype(F64) + g * g
+    ep = p0[123].astype(F64) - 0.05 * g / np.sqrt(ea + 1e-7)
+    assert np.max(np.abs(N(accum)[123] - ea)) <= 1e-5 * np.max(np.abs(ea))
+    assert np.max(np.abs(N(table)[123] - ep)) <= 1e-5 * np.max(np.abs(ep))
+    keep = np.arange(V) != 123
+    assert np.array_equal(N(table)[keep], p0[keep]) and np.array_equal(N(accum)[keep], a0[keep])
