@@ -105,9 +105,16 @@ def run_sharded(args, cfg, dev, rank, world):
         roofline = roofline_for(args.workload, kernels, B, D, cfg["rows_per_unit"], "auto",
                                 int(rows_served.numel()), int(torch.unique(rows_served).numel()))
         roofline["rank"] = 0
+    grp = emb if args.workload == "glove" else towers
+    exchange = "RCCL ncclSend/ncclRecv on the compute stream (esrecsys_amd/rccl.py)" if grp.exchange() is not None \
+        else "torch.distributed all_to_all_single"
     if rank == 0:
         K = args.steps
-        from bench import emit
+        from bench import emit, sustained_bf16_mfma_tflops, MFMA_BF16_PEAK_TFLOPS
+        if roofline is not None and roofline.get("bound") == "mfma" and roofline.get("peak") == MFMA_BF16_PEAK_TFLOPS:
+            live = sustained_bf16_mfma_tflops(dev)
+            roofline["sustained_live_data_TFLOPs"] = live
+            roofline["frac_of_sustained"] = roofline["achieved"] / live
         emit({
             "metric": "training pairs/sec", "value": world * B * K / dt, "unit": cfg["unit"] + "s/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": dt / K * 1e3,
@@ -116,6 +123,7 @@ def run_sharded(args, cfg, dev, rank, world):
                                    % (args.workload, V, D, "bf16" if cfg.get("table_dtype") == "bf16" else "fp32",
                                       world, B),
                        "parallelism": "row-sharded x%d, all-to-all ids/rows/grads over RCCL" % world,
+                       "exchange": exchange,
                        "loss": float(total)},
             "roofline": roofline, "kernels": kernels, "cpu_baseline": None,
         })
