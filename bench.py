@@ -69,14 +69,24 @@ class KernelTimer:
             return out
         return wrapped
 
-    def totals_ms(self):
-        """Per group: (median elapsed x calls, calls).  The median, because an event pair also spans any time the
-        HOST spent between recording the first event and launching the kernel: one allocator call or page fault
-        inside a wrapped call (seen: 50 ms once in 100 steps) would otherwise pass for kernel time."""
+    def totals_ms(self, steps=None):
+        """Per group: (estimated total ms, calls).  With `steps`, the calls of a group are taken to repeat with period
+        calls / steps (e.g. GloVe's embedding and bias updates alternate) and the total is steps x the sum of the
+        per-slot MEDIANS: an event pair also spans any time the HOST spent between recording the first event and
+        launching the kernel, and one allocator call or page fault inside a wrapped call (seen: 50 ms once in 100
+        steps) would otherwise pass for kernel time."""
         out = {}
         for g, ev in self.events.items():
-            ts = sorted(a.elapsed_time(b) for a, b in ev)
-            out[g] = ((ts[len(ts) // 2] * len(ts)) if ts else 0.0, len(ts))
+            ts = [a.elapsed_time(b) for a, b in ev]
+            if not ts or not steps or len(ts) % steps:
+                out[g] = (sum(ts), len(ts))
+                continue
+            per = len(ts) // steps
+            tot = 0.0
+            for k in range(per):
+                slot = sorted(ts[k::per])
+                tot += slot[len(slot) // 2]
+            out[g] = (tot * steps, len(ts))
         return out
 
 
@@ -402,7 +412,7 @@ def main():
     timer.enabled = False
 
     K = args.steps
-    totals = timer.totals_ms()
+    totals = timer.totals_ms(K)
     kernels = {}
     for g, (ms, calls) in totals.items():
         if calls:

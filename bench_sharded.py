@@ -98,7 +98,7 @@ def run_sharded(args, cfg, dev, rank, world):
         run(args.warmup, n_batches)
         torch.cuda.synchronize()
         timer.enabled = False
-        for g_, (ms, calls) in timer.totals_ms().items():
+        for g_, (ms, calls) in timer.totals_ms(args.steps).items():
             if calls:
                 kernels[g_] = {"ms_per_step": ms / args.steps, "launch_groups_per_step": calls / args.steps}
         rows_served = begin(batches[-1]).finish().recv_local_rows
