@@ -52,8 +52,10 @@ class DirectExchange:
         dist.broadcast(raw, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         ctypes.memmove(ctypes.byref(uid), bytes(raw.cpu().numpy().tobytes()), 128)
         self.comm = ctypes.c_void_p()
-        self._check(self.lib.ncclCommInitRank(ctypes.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
-        self._self_test()
+        with torch.cuda.device(self.device):  # the communicator binds to the calling thread's current HIP device
+            self._check(self.lib.ncclCommInitRank(ctypes.byref(self.comm), self.world, uid, self.rank),
+                        "ncclCommInitRank")
+            self._self_test()
 
     def _self_test(self):
         """One uneven all-to-all with known contents: rank r sends (peer + 1) rows of value 1000 r + peer to `peer`."""
