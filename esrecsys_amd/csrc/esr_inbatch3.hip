@@ -395,18 +395,8 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
   const int64_t c0 = (int64_t)split * nc;
   const int64_t nch = B / 32;
 
-  // owned rows -> B operand: bx[p][s] = Xr[p][xrow][16 s + 8 h .. +7]
-  bf16x8 bx[3][8];
-#pragma unroll
-  for (int p = 0; p < 3; ++p)
-#pragma unroll
-    for (int s = 0; s < 8; ++s)
-      bx[p][s] = *reinterpret_cast<const bf16x8*>(Xr + ((int64_t)p * B + xrow) * k3D + 16 * s + 8 * h);
+  bf16x8 bx[3][8];  // owned rows -> B operand (loaded below, behind the first tiles' DMA)
   float refv = 0.f;
-  if (QSIDE) {
-    refv = ref[xrow];
-    for (int s = 1; s < nsplit; ++s) refv = fmaxf(refv, ref[(int64_t)s * B + xrow]);
-  }
 
   f32x16 acc[4];
 #pragma unroll
@@ -526,6 +516,21 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
   ESR_DMA_INIT(c0 + dpos);
   ESR_DMA_ALL(lds);
   if (nc > 1) ESR_DMA_ALL(lds + kBufBytes);
+  // the owned rows and their references travel while the first two tiles do: bx[p][s] = Xr[p][xrow][16 s + 8 h .. +7].
+  // All reference loads are issued before the first use (nsplit <= 8 is a run-time value; a rolled loop waited one
+  // memory latency per split, and sat in front of the DMA issue).
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      bx[p][s] = *reinterpret_cast<const bf16x8*>(Xr + ((int64_t)p * B + xrow) * k3D + 16 * s + 8 * h);
+  if (QSIDE) {
+    float rv[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) rv[s] = s < nsplit ? ref[(int64_t)s * B + xrow] : -INFINITY;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) refv = s == 0 ? rv[0] : fmaxf(refv, rv[s]);
+  }
   ESR_DMA_BARRIER();  // an LDS-DMA in flight makes the barrier's fence wait vmcnt(0): both tiles have landed
 
   f32x16 sa;
