@@ -59,5 +59,22 @@ def build_library(force=False, verbose=False):
     return LIB_PATH
 
 
+IO_LIB_PATH = os.path.join(HERE, "libesr_io.so")
+
+
+def build_io_library(force=False, verbose=False):
+    """Compile the host-side input decoder (plain C, gcc) into libesr_io.so.  Returns its path."""
+    src = os.path.join(CSRC, "esr_io.c")
+    if force or _stale(IO_LIB_PATH, [src]):
+        cmd = [os.environ.get("CC", "gcc"), "-O3", "-std=c11", "-fPIC", "-shared", "-Wall", "-o", IO_LIB_PATH, src]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("gcc failed for esr_io.c:\n%s\n%s" % (r.stdout, r.stderr))
+    if verbose:
+        print("built", IO_LIB_PATH)
+    return IO_LIB_PATH
+
+
 if __name__ == "__main__":
     build_library(force="--force" in sys.argv, verbose=True)
+    build_io_library(force="--force" in sys.argv, verbose=True)

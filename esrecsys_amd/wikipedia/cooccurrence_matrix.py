@@ -13,12 +13,53 @@ Batches have the reference's layout: ``([int32[B], int32[B]], float32[B])`` from
 """
 import base64
 import bz2
+import ctypes
 import glob
+import os
 import queue
 import struct
 import threading
 
 import numpy as np
+
+_IO_LIB = None
+
+
+def _io_lib():
+    """libesr_io.so (esrecsys_amd/csrc/esr_io.c, built by esrecsys_amd/build.py): the same wire decoder in C."""
+    global _IO_LIB
+    if _IO_LIB is None:
+        from ..build import IO_LIB_PATH, build_io_library
+        if not os.path.exists(IO_LIB_PATH):
+            build_io_library()
+        lib = ctypes.CDLL(IO_LIB_PATH)
+        lib.esr_cooccur_decode_lines.restype = ctypes.c_int64
+        lib.esr_cooccur_decode_lines.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                                 ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                                 ctypes.POINTER(ctypes.c_int64)]
+        _IO_LIB = lib
+    return _IO_LIB
+
+
+def decode_lines(text, cap=None):
+    """All complete base64 lines of `text` (bytes) -> (index int32[n], other int32[n], count float32[n], consumed).
+    The C counterpart of parse_cooccurrence_row over a whole buffer; a row of more than `cap` pairs (default: enough
+    for any row the buffer can hold) is never split."""
+    lib = _io_lib()
+    n = len(text)
+    cap = int(cap) if cap else max(1024, n // 2)   # >= 2 base64 bytes per pair even for 1-byte ids and no counts
+    t1 = np.empty(cap, np.int32)
+    t2 = np.empty(cap, np.int32)
+    cnt = np.empty(cap, np.float32)
+    scratch = np.empty(n + 8, np.uint8)
+    consumed = ctypes.c_int64(0)
+    buf = (ctypes.c_char * n).from_buffer_copy(text) if not isinstance(text, (bytearray, memoryview)) else \
+        (ctypes.c_char * n).from_buffer(text)
+    got = lib.esr_cooccur_decode_lines(ctypes.addressof(buf), n, t1.ctypes.data, t2.ctypes.data, cnt.ctypes.data, cap,
+                                       scratch.ctypes.data, ctypes.byref(consumed))
+    if got < 0:
+        raise ValueError("malformed CooccurrenceRow line at byte %d of the buffer" % consumed.value)
+    return t1[:got], t2[:got], cnt[:got], consumed.value
 
 
 def _varint(buf, pos):
@@ -117,6 +158,67 @@ class CooccurrenceGenerator:
                         for i in range(len(others)):
                             yield (index, others[i], counts[i])
 
+    @staticmethod
+    def _file_blocks(input_file, chunk_bytes):
+        """One file -> blocks (index int32[k], other int32[k], count float32[k]) in file order."""
+        tail = b""
+        with bz2.open(input_file, "rb") as file:
+            while True:
+                chunk = file.read(chunk_bytes)
+                data = tail + chunk
+                if not chunk and data and not data.endswith(b"\n"):
+                    data += b"\n"  # a last line without a newline is still a line
+                if not data:
+                    break
+                t1, t2, cnt, used = decode_lines(data)
+                if used == 0 and not chunk:
+                    break
+                tail = data[used:]
+                if len(t1):
+                    yield t1, t2, cnt
+                if not chunk:
+                    break
+
+    def get_item_blocks(self, chunk_bytes=1 << 22, workers=None):
+        """The same stream as get_item, as blocks of arrays (index int32[k], other int32[k], count float32[k]):
+        files are decompressed `chunk_bytes` at a time and decoded by libesr_io.so, whole lines at a time.
+        bz2 decompression (~20 MB/s of text per core, GIL released) is what bounds one file, so with several
+        files the next `workers` of them are decoded ahead on threads (default: up to 8, half the cores) and handed
+        over in file order -- the item order of the reference's sequential walk is kept; memory: up to `workers`
+        decoded files (12 bytes per pair)."""
+        if not self._input_files:
+            raise FileNotFoundError("no co-occurrence files match the input pattern")
+        files = self._input_files
+        if workers is None:
+            workers = min(8, max(1, (os.cpu_count() or 2) // 2), len(files))
+        if workers <= 1 or len(files) == 1:
+            while True:
+                for input_file in files:
+                    yield from self._file_blocks(input_file, chunk_bytes)
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=workers)
+        window, nxt = deque(), 0
+        while True:
+            while len(window) < workers:
+                window.append(pool.submit(lambda f: list(self._file_blocks(f, chunk_bytes)), files[nxt % len(files)]))
+                nxt += 1
+            yield from window.popleft().result()
+
+    def _take(self, blocks, pending, n):
+        """n items from the block stream (pending = leftover arrays of the last block) -> three arrays, new pending."""
+        parts, have = [], 0
+        while have < n:
+            if pending is None or len(pending[0]) == 0:
+                pending = next(blocks)
+            k = min(n - have, len(pending[0]))
+            parts.append(tuple(a[:k] for a in pending))
+            pending = tuple(a[k:] for a in pending)
+            have += k
+        if len(parts) == 1:
+            return parts[0], pending
+        return tuple(np.concatenate([p[i] for p in parts]) for i in range(3)), pending
+
     def get_shuffled_items(self, num_items):
         """Pre-fetches and shuffles num_items of stuff (cooccurrence_matrix.py:80-87; global NumPy RNG, as there)."""
         iterator = self.get_item()
@@ -127,7 +229,37 @@ class CooccurrenceGenerator:
                 yield item
 
     def get_batch(self, batch_size, shuffle_size=0):
-        """cooccurrence_matrix.py:89-106."""
+        """cooccurrence_matrix.py:89-106.  Same batches as the reference's item-at-a-time loop -- including the
+        buffer shuffle: fill `shuffle_size` items, np.random.shuffle (global NumPy RNG, one call per buffer: a
+        permutation of positions drawn exactly as shuffling the item list draws it), drain -- built from array
+        blocks decoded in C instead of one Python tuple per pair."""
+        blocks = self.get_item_blocks()
+        pending = None
+        if not shuffle_size:
+            while True:
+                (t1, t2, cnt), pending = self._take(blocks, pending, batch_size)
+                yield ([np.ascontiguousarray(t1), np.ascontiguousarray(t2)], np.ascontiguousarray(cnt))
+        buf, pos = None, 0
+        while True:
+            out = [np.empty(batch_size, np.int32), np.empty(batch_size, np.int32), np.empty(batch_size, np.float32)]
+            filled = 0
+            while filled < batch_size:
+                if buf is None or pos == shuffle_size:
+                    buf, pending = self._take(blocks, pending, shuffle_size)
+                    order = np.arange(shuffle_size)
+                    np.random.shuffle(order)
+                    buf = tuple(a[order] for a in buf)
+                    pos = 0
+                k = min(batch_size - filled, shuffle_size - pos)
+                for o, a in zip(out, buf):
+                    o[filled:filled + k] = a[pos:pos + k]
+                filled += k
+                pos += k
+            yield ([out[0], out[1]], out[2])
+
+    def get_batch_reference_loop(self, batch_size, shuffle_size=0):
+        """The reference's loop verbatim in structure (one item per next()): the restatement get_batch is tested
+        against."""
         iterator = self.get_shuffled_items(shuffle_size) if shuffle_size else self.get_item()
         while True:
             token1 = np.empty(batch_size, np.int32)

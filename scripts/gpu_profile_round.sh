@@ -19,6 +19,7 @@ done
 (timeout 600 python benchmarks/hbm_micro.py 2>&1 | grep -v amdgpu.ids) > $R/hbm_micro.jsonl
 (timeout 600 python benchmarks/retrieve_bench.py 2>&1 | grep -v amdgpu.ids) > $R/retrieve_bench.jsonl
 (timeout 300 python benchmarks/mfma_peak.py 2>&1 | grep -v amdgpu.ids) > $R/mfma_peak.jsonl
+(timeout 300 python benchmarks/reader_bench.py 2>&1 | grep -v amdgpu.ids) > $R/reader_bench.jsonl
 (timeout 600 python benchmarks/spotify_step.py 2>&1 | grep -v amdgpu.ids | tail -1) > $R/spotify_step.json
 for w in inbatch triplet glove retrieve; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/stats_$w -o $w -- python bench.py --workload $w --steps 50 --warmup 5 --no-cpu-baseline --no-kernel-timing > gpurun_out/prof_stats_$w.log 2>&1

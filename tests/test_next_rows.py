@@ -127,3 +127,99 @@ def test_save_state_writes_reference_filename(tmp_path):
     from esrecsys_amd.wikipedia.train_cooccurence import save_state
     path = save_state(_state(optim.sparse_adagrad(0.1)), 20, checkpoint_dir=str(tmp_path))
     assert os.path.basename(path) == "checkpoint-00020.flax" and os.path.getsize(path) > 100
+
+
+# ------------------------------------------------------------------------------------------------
+# the C decoder (esrecsys_amd/csrc/esr_io.c) against the Python restatement of the wire format
+# ------------------------------------------------------------------------------------------------
+def _vint(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _row(rng, index, k, packed_ids=True, packed_counts=True, extra=False):
+    import struct
+    others = [int(x) for x in rng.integers(0, 500_000, k)]
+    counts = rng.random(k).astype(np.float32) * 300
+    msg = b"\x08" + _vint(index)
+    if extra:
+        msg += b"\x21" + b"\x00" * 8          # an unknown 64-bit field is skipped
+    if packed_ids:
+        body = b"".join(_vint(o) for o in others)
+        msg += b"\x12" + _vint(len(body)) + body
+    else:
+        msg += b"".join(b"\x10" + _vint(o) for o in others)
+    if packed_counts:
+        msg += b"\x1a" + _vint(4 * k) + counts.tobytes()
+    else:
+        msg += b"".join(b"\x1d" + struct.pack("<f", c) for c in counts)
+    return msg
+
+
+def _write_lines(path, rows, final_newline=True):
+    import base64
+    import bz2
+    text = b"\n".join(base64.b64encode(r) for r in rows) + (b"\n" if final_newline else b"")
+    with open(path, "wb") as f:
+        f.write(bz2.compress(text))
+    return text
+
+
+def test_c_decoder_equals_python_decoder(tmp_path):
+    from esrecsys_amd.wikipedia.cooccurrence_matrix import CooccurrenceGenerator, decode_lines, parse_cooccurrence_row
+    rng = np.random.default_rng(11)
+    rows = []
+    for i in range(300):
+        k = int(rng.integers(0, 40)) if i % 17 else 0
+        rows.append(_row(rng, int(rng.integers(1, 2 ** 31 - 1)), k, packed_ids=i % 3 != 0, packed_counts=i % 5 != 0,
+                         extra=i % 7 == 0))
+    exp = [(idx, o, c) for r in rows for (idx, os_, cs) in [parse_cooccurrence_row(r)] for o, c in zip(os_, cs)]
+    text = _write_lines(tmp_path / "a.cooccur.pb.b64.bz2", rows, final_newline=False)
+    t1, t2, cnt, used = decode_lines(text + b"\n")
+    assert used == len(text) + 1 and len(t1) == len(exp)
+    assert t1.tolist() == [e[0] for e in exp] and t2.tolist() == [e[1] for e in exp]
+    assert np.array_equal(cnt, np.array([e[2] for e in exp], np.float32))
+    # an incomplete last line is left for the next call; a row is never split when the output is short
+    t1b, _, _, used_b = decode_lines(text)
+    assert used_b < len(text) and len(t1b) < len(t1)
+    few = decode_lines(text + b"\n", cap=64)
+    assert 0 < len(few[0]) <= 64 and few[3] < len(text)
+    # the streaming reader: tiny chunks (lines straddle them), no trailing newline in the file, wrap-around
+    g = CooccurrenceGenerator(str(tmp_path / "a.cooccur.pb.b64.bz2"))
+    blocks = g.get_item_blocks(chunk_bytes=97)
+    got = [np.concatenate(x) for x in zip(*[next(blocks) for _ in range(400)])]
+    n = len(exp)
+    assert len(got[0]) > n
+    assert got[0][:n].tolist() == [e[0] for e in exp] and got[1][n:n + 5].tolist() == [e[1] for e in exp[:5]]
+
+
+def test_fast_batches_equal_the_reference_loop(tmp_path):
+    from esrecsys_amd.wikipedia.cooccurrence_matrix import CooccurrenceGenerator
+    rng = np.random.default_rng(12)
+    _write_lines(tmp_path / "a.cooccur.pb.b64.bz2", [_row(rng, i + 1, int(rng.integers(1, 30))) for i in range(120)])
+    _write_lines(tmp_path / "b.cooccur.pb.b64.bz2", [_row(rng, 1000 + i, int(rng.integers(1, 9))) for i in range(50)])
+    g = CooccurrenceGenerator(str(tmp_path / "*.cooccur.pb.b64.bz2"))
+    for bs, sh in ((64, 0), (100, 250), (37, 37), (300, 1000)):
+        np.random.seed(99)
+        fast = g.get_batch(bs, sh)
+        a = [next(fast) for _ in range(40)]
+        np.random.seed(99)
+        slow = g.get_batch_reference_loop(bs, sh)
+        b = [next(slow) for _ in range(40)]
+        for (xa, ya), (xb, yb) in zip(a, b):
+            assert np.array_equal(xa[0], xb[0]) and np.array_equal(xa[1], xb[1]) and np.array_equal(ya, yb)
+
+
+def test_c_decoder_rejects_malformed_lines():
+    from esrecsys_amd.wikipedia.cooccurrence_matrix import decode_lines
+    with pytest.raises(ValueError, match="malformed"):
+        decode_lines(b"!!!not base64!!!\n")
+    with pytest.raises(ValueError, match="malformed"):
+        decode_lines(b"EgX/////\n")    # a packed field longer than the message
