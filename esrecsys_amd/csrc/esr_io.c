@@ -12,6 +12,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include "../../include/esr_io.h"
+
 #define ESR_IO_EFORMAT (-1) /* malformed base64 / wire data; *consumed = offset of the offending line */
 
 static int8_t b64val[256];

@@ -79,3 +79,16 @@ def test_ops_refuse_cpu_tensors():
     from esrecsys_amd import ops
     with pytest.raises(TypeError, match="no CPU fallback"):
         ops.gather_rows(torch.zeros(4, 4), torch.zeros(2, dtype=torch.int32))
+
+
+def test_io_library_exports_its_header():
+    """libesr_io.so (host-side input decoder, gcc) exports what include/esr_io.h declares"""
+    from esrecsys_amd.build import build_io_library
+    text = open(os.path.join(ROOT, "include", "esr_io.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(esr_[a-z0-9_]+)\s*\(", text)))
+    assert declared == ["esr_cooccur_decode_lines", "esr_io_version"]
+    lib = ctypes.CDLL(build_io_library())
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.esr_io_version() >= 100
