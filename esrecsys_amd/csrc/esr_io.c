@@ -17,12 +17,11 @@
 #define ESR_IO_EFORMAT (-1) /* malformed base64 / wire data; *consumed = offset of the offending line */
 
 static int8_t b64val[256];
-static int b64_ready = 0;
-static void b64_init(void) {
+/* filled when the library is loaded: decoder calls come from several reader threads at once */
+__attribute__((constructor)) static void b64_init(void) {
   memset(b64val, -1, sizeof(b64val));
   const char* a = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
   for (int i = 0; i < 64; ++i) b64val[(uint8_t)a[i]] = (int8_t)i;
-  b64_ready = 1;
 }
 
 /* decode one base64 line (no newline) into out; returns decoded length or -1 */
@@ -121,7 +120,6 @@ static int64_t row_pairs(const uint8_t* b, int64_t n, int32_t* t1, int32_t* t2, 
  * text used (always a whole number of lines).  scratch: at least (longest line) * 3 / 4 + 4 bytes -- pass len. */
 int64_t esr_cooccur_decode_lines(const uint8_t* text, int64_t len, int32_t* t1, int32_t* t2, float* cnt, int64_t cap,
                                  uint8_t* scratch, int64_t* consumed) {
-  if (!b64_ready) b64_init();
   int64_t pos = 0, npairs = 0;
   *consumed = 0;
   while (pos < len) {
