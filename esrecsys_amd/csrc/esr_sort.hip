@@ -110,29 +110,74 @@ __global__ __launch_bounds__(kSmallSortThreads) void segment_sort_small_kernel(S
 // search; 2048-key tiles at every size left half of them idle there: 10.9 + 6.3 us -> see profiles/).
 constexpr int kMidTiles = 16, kMaxTileBits = 11;
 constexpr int kMidSortMax = (1 << kMaxTileBits) * kMidTiles;
+// value of lane (lane ^ stride), stride a compile-time power of two < 64 after unrolling: DPP where the pattern exists
+// on gfx9 (quad_perm for 1 and 2, row_ror:8 for 8), the LDS crossbar without an address for 4 and 16 (ds_swizzle,
+// bit mode), v_permlane32_swap for 32
+__device__ __forceinline__ uint32_t xor_lane(uint32_t v, int stride) {
+  switch (stride) {
+    case 1: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+    case 2: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2, 3, 0, 1]
+    case 8: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true);  // row_ror:8
+    case 4: return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (4 << 10));
+    case 16: return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (16 << 10));
+    case 32: {  // gfx950: one v_permlane32_swap (upper half of a copy <-> lower half of another) + a select
+      const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);  // r[0] = [lo, lo], r[1] = [hi, hi]
+      return (threadIdx.x & 32) ? r[0] : r[1];
+    }
+    default: return (uint32_t)__shfl_xor((int)v, stride, 64);
+  }
+}
+
 template <int TB>
 __global__ __launch_bounds__((1 << TB) / 2) void tile_sort_kernel(SortSegs ids, int n, uint32_t* __restrict__ tiles) {
-  constexpr int kTile = 1 << TB, kThreads = kTile / 2;
-  __shared__ uint32_t key[kTile];
+  // Bitonic network over kTile keys, two per thread: thread t holds positions t and t + kTile / 2.  A compare-exchange
+  // with stride < 64 has its partner in the same wave (lane ^ stride) and is one cross-lane move per key -- 51 of the 66
+  // steps of a 2048-key tile; the stride kTile / 2 pairs the thread's own two registers; only the strides in between go
+  // through LDS and a barrier (14 steps).  With every step in LDS behind a barrier the 2048-key tile took 11 us.
+  constexpr int kTile = 1 << TB, kHalf = kTile / 2;
+  __shared__ uint32_t key[2 * kTile];
   const int t = threadIdx.x, base = blockIdx.x * kTile;
-  for (int i = t; i < kTile; i += kThreads) {
-    const int g = base + i;
-    key[i] = g < n ? ((uint32_t)seg_id(ids, g) << TB) | (uint32_t)i : 0xFFFFFFFFu;
+  int flip = 0;
+  uint32_t k0, k1;
+  {
+    const int g0 = base + t, g1 = base + t + kHalf;
+    k0 = g0 < n ? ((uint32_t)seg_id(ids, g0) << TB) | (uint32_t)t : 0xFFFFFFFFu;
+    k1 = g1 < n ? ((uint32_t)seg_id(ids, g1) << TB) | (uint32_t)(t + kHalf) : 0xFFFFFFFFu;
   }
-  for (int size = 2; size <= kTile; size <<= 1)
+  // new value of the key at position p after meeting its partner's key o at distance `stride` inside a run of `size`
+  auto cx = [](uint32_t mine, uint32_t other, int p, int stride, int size) {
+    const bool lower = (p & stride) == 0, asc = (p & size) == 0;
+    const uint32_t mn = mine < other ? mine : other, mx = mine < other ? other : mine;
+    return lower == asc ? mn : mx;
+  };
+#pragma unroll
+  for (int size = 2; size <= kTile; size <<= 1) {
+#pragma unroll
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      __syncthreads();
-      const int i = t;  // kTile / 2 compare-exchanges, one per thread
-      const int pos = 2 * i - (i & (stride - 1)), j = pos + stride;
-      const bool asc = (pos & size) == 0;
-      const uint32_t x = key[pos], y = key[j];
-      if ((x > y) == asc) {
-        key[pos] = y;
-        key[j] = x;
+      if (stride == kHalf) {  // only for size == kTile: ascending, partner = the other register
+        const uint32_t mn = k0 < k1 ? k0 : k1, mx = k0 < k1 ? k1 : k0;
+        k0 = mn;
+        k1 = mx;
+      } else if (stride >= 64) {
+        // two LDS images used alternately: the next exchange writes the other one, so a single barrier per step
+        // orders everything (a thread can be at most one step ahead of the slowest reader)
+        uint32_t* img = key + (flip ? kTile : 0);
+        flip ^= 1;
+        img[t] = k0;
+        img[t + kHalf] = k1;
+        __syncthreads();
+        const uint32_t o0 = img[t ^ stride], o1 = img[(t ^ stride) + kHalf];
+        k0 = cx(k0, o0, t, stride, size);
+        k1 = cx(k1, o1, t + kHalf, stride, size);
+      } else {
+        const uint32_t o0 = xor_lane(k0, stride), o1 = xor_lane(k1, stride);
+        k0 = cx(k0, o0, t, stride, size);
+        k1 = cx(k1, o1, t + kHalf, stride, size);
       }
     }
-  __syncthreads();
-  for (int i = t; i < kTile; i += kThreads) tiles[base + i] = key[i];
+  }
+  tiles[base + t] = k0;
+  tiles[base + t + kHalf] = k1;
 }
 
 // Two-level search: the last id of every 32-key block of every tile ("splitters", <= 4 KB) is staged in LDS and
