@@ -109,6 +109,7 @@ __global__ __launch_bounds__(kSmallSortThreads) void segment_sort_small_kernel(S
 // -- sixteen workgroups sort instead of eight and every one of the rank kernel's 16 lanes per element has a tile to
 // search; 2048-key tiles at every size left half of them idle there: 10.9 + 6.3 us -> see profiles/).
 constexpr int kMidTiles = 16, kMaxTileBits = 11;
+constexpr int kSplitEvery = 32;  // one splitter (its last key) per 32-key block of a sorted tile
 constexpr int kMidSortMax = (1 << kMaxTileBits) * kMidTiles;
 // value of lane (lane ^ stride), stride a compile-time power of two < 64 after unrolling: DPP where the pattern exists
 // on gfx9 (quad_perm for 1 and 2, row_ror:8 for 8), the LDS crossbar without an address for 4 and 16 (ds_swizzle,
@@ -129,7 +130,8 @@ __device__ __forceinline__ uint32_t xor_lane(uint32_t v, int stride) {
 }
 
 template <int TB>
-__global__ __launch_bounds__((1 << TB) / 2) void tile_sort_kernel(SortSegs ids, int n, uint32_t* __restrict__ tiles) {
+__global__ __launch_bounds__((1 << TB) / 2) void tile_sort_kernel(SortSegs ids, int n, uint32_t* __restrict__ tiles,
+                                                                 uint32_t* __restrict__ splitters) {
   // Bitonic network over kTile keys, two per thread: thread t holds positions t and t + kTile / 2.  A compare-exchange
   // with stride < 64 has its partner in the same wave (lane ^ stride) and is one cross-lane move per key -- 51 of the 66
   // steps of a 2048-key tile; the stride kTile / 2 pairs the thread's own two registers; only the strides in between go
@@ -178,22 +180,28 @@ __global__ __launch_bounds__((1 << TB) / 2) void tile_sort_kernel(SortSegs ids, 
   }
   tiles[base + t] = k0;
   tiles[base + t + kHalf] = k1;
+  // the last key of every 32-key block, packed: the rank kernel stages these (it used to gather them from the tiles,
+  // one cache line per splitter and workgroup)
+  if ((t & (kSplitEvery - 1)) == kSplitEvery - 1) {
+    constexpr int kSplitPerTile = kTile / kSplitEvery;
+    splitters[blockIdx.x * kSplitPerTile + t / kSplitEvery] = k0;
+    splitters[blockIdx.x * kSplitPerTile + (t + kHalf) / kSplitEvery] = k1;
+  }
 }
 
 // Two-level search: the last id of every 32-key block of every tile ("splitters", <= 4 KB) is staged in LDS and
 // searched there; only the final 32-key window -- one 128-byte line -- is searched in global memory.  A plain
 // binary search over the tiles touched ~12 scattered lines per (element, tile) and was bound by L1 line rate.
-constexpr int kSplitEvery = 32;
 // 16 lanes per element, one per tile: the searches of one element run side by side and their counts are summed
 // with shuffles (one thread walking all tiles was latency-bound at one wave per SIMD: 26 us for 24 576 keys).
 template <int TB>
-__global__ __launch_bounds__(kBlock) void tile_rank_kernel(const uint32_t* __restrict__ tiles, int n, int ntiles,
+__global__ __launch_bounds__(kBlock) void tile_rank_kernel(const uint32_t* __restrict__ tiles,
+                                                          const uint32_t* __restrict__ splitters, int n, int ntiles,
                                                           int32_t* __restrict__ sorted_ids,
                                                           int32_t* __restrict__ perm) {
   constexpr int kTile = 1 << TB, kSplitPerTile = kTile / kSplitEvery;
   __shared__ uint32_t spl[kMidTiles * kSplitPerTile];
-  for (int i = threadIdx.x; i < ntiles * kSplitPerTile; i += kBlock)
-    spl[i] = tiles[i * kSplitEvery + kSplitEvery - 1] >> TB;
+  for (int i = threadIdx.x; i < ntiles * kSplitPerTile; i += kBlock) spl[i] = splitters[i] >> TB;
   __syncthreads();
   const int u = threadIdx.x & (kMidTiles - 1);                                 // the tile this lane searches
   const int g = (blockIdx.x * kBlock + threadIdx.x) / kMidTiles;                // slot g of the tiled array
@@ -231,9 +239,10 @@ static void launch_tile_sort(const SortSegs& sg, int n, uint32_t* tiles, int32_t
                              hipStream_t st) {
   constexpr int kTile = 1 << TB;
   const int ntiles = (int)cdiv(n, kTile);
-  hipLaunchKernelGGL((tile_sort_kernel<TB>), dim3(ntiles), dim3(kTile / 2), 0, st, sg, n, tiles);
+  uint32_t* splitters = tiles + kMidSortMax;  // [ntiles][kTile / 32], behind the tiles
+  hipLaunchKernelGGL((tile_sort_kernel<TB>), dim3(ntiles), dim3(kTile / 2), 0, st, sg, n, tiles, splitters);
   hipLaunchKernelGGL((tile_rank_kernel<TB>), dim3((int)cdiv((int64_t)ntiles * kTile * kMidTiles, kBlock)), dim3(kBlock), 0,
-                     st, (const uint32_t*)tiles, n, ntiles, sorted_ids, perm);
+                     st, (const uint32_t*)tiles, (const uint32_t*)splitters, n, ntiles, sorted_ids, perm);
 }
 
 // owner key of every id + the per-owner totals.  The totals are privatised per workgroup in LDS (one global
@@ -577,7 +586,7 @@ extern "C" {
 // ------------------------------------------------------------------------------------------------
 size_t esr_segment_sort_workspace_bytes(int64_t n) {
   if (n <= 0) return 256;
-  const size_t tiles = n <= kMidSortMax ? align_up((size_t)kMidSortMax * 4, 256) : 0;
+  const size_t tiles = n <= kMidSortMax ? align_up((size_t)(kMidSortMax + kMidSortMax / kSplitEvery) * 4, 256) : 0;
   // + one column for the concatenated ids of a segmented list on the radix path
   return std::max(pair_sort_temp_bytes<false, uint32_t>(n) + align_up((size_t)n * 4, 256), tiles);
 }
@@ -589,7 +598,7 @@ static int segment_sort_segs(const char* who, const SortSegs& sg, int64_t n, int
     return check_launch(who);
   }
   if (n <= kMidSortMax && V <= ((int64_t)1 << (32 - kMaxTileBits))) {
-    if ((size_t)kMidSortMax * 4 > workspace_bytes || ((uintptr_t)workspace & 15)) {
+    if ((size_t)(kMidSortMax + kMidSortMax / kSplitEvery) * 4 > workspace_bytes || ((uintptr_t)workspace & 15)) {
       set_error("%s: workspace %zu bytes too small (or misaligned)", who, workspace_bytes);
       return ESR_EWORKSPACE;
     }
