@@ -150,3 +150,25 @@ def test_sparse_adagrad_one_row_takes_every_gradient(dev, n, D):
     assert np.max(np.abs(N(table)[123] - ep)) <= 1e-5 * np.max(np.abs(ep))
     keep = np.arange(V) != 123
     assert np.array_equal(N(table)[keep], p0[keep]) and np.array_equal(N(accum)[keep], a0[keep])
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("scale", [-6.0, 0.0, 1e-3])
+def test_inbatch_odd_temperatures(dev, precision, scale):
+    """negative temperature (the softmax prefers the LEAST similar candidate), zero (uniform: loss = log B + reg) and a
+    tiny one; batch_size != B as the reference's caller may pass any divisor (train_shop_the_look.py:104)"""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(21)
+    B, D, bs = 256, 128, 77.0
+    q = (rng.standard_normal((B, D)) * 0.2).astype(np.float32)
+    c = (rng.standard_normal((B, D)) * 0.2).astype(np.float32)
+    loss, lse, gq, gc = ops.inbatch_softmax_fwd_bwd(T(q, dev), T(c, dev), scale, 0.1, bs, precision=precision)
+    el, else_, egq, egc = o_stl.inbatch_softmax_loss_and_grads(q.astype(F64), c.astype(F64), 0.1, bs, scale, F64)
+    assert abs(float(loss) - el) <= 1e-5 * abs(el)
+    assert np.max(np.abs(N(lse) - else_)) <= 1e-5 * np.max(np.abs(else_))
+    assert np.max(np.abs(N(gq) - egq)) <= 1e-5 * np.max(np.abs(egq))
+    assert np.max(np.abs(N(gc) - egc)) <= 1e-5 * np.max(np.abs(egc))
+    if scale == 0.0:
+        reg = 0.1 * (np.maximum(np.linalg.norm(q.astype(F64), axis=1) - 1, 0).sum()
+                     + np.maximum(np.linalg.norm(c.astype(F64), axis=1) - 1, 0).sum())
+        assert abs(float(loss) - (B * np.log(B) + reg) / bs) <= 1e-5 * abs(el)
