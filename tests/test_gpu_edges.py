@@ -172,3 +172,29 @@ def test_inbatch_odd_temperatures(dev, precision, scale):
         reg = 0.1 * (np.maximum(np.linalg.norm(q.astype(F64), axis=1) - 1, 0).sum()
                      + np.maximum(np.linalg.norm(c.astype(F64), axis=1) - 1, 0).sum())
         assert abs(float(loss) - (B * np.log(B) + reg) / bs) <= 1e-5 * abs(el)
+
+
+def test_triplet_head_on_the_kinks(dev):
+    """relu at exactly 0 (jax.nn.relu has derivative 0 there): margin 1 + neg - pos == 0 contributes no
+    gradient; a row of norm exactly 1 has no regulariser gradient, a row just above has; an all-zero row does not
+    produce NaN (the reference's sqrt'(0) * 0 does: DESIGN 5)."""
+    from esrecsys_amd import ops
+    D, B = 4, 4
+    scene = np.array([[1, 0, 0, 0], [1, 0, 0, 0], [0, 0, 1, 0], [0, 0, 0, 0]], np.float32)
+    pos = np.array([[1, 0, 0, 0], [0.5, 0, 0, 0], [0, 0, 2, 0], [1, 1, 1, 1]], np.float32)
+    neg = np.array([[0, 0, 0, 0], [0.5, 0, 0, 0], [0, 0, 0, 3], [1, 0, 0, 0]], np.float32)
+    # row 0: 1 + 0 - 1 == 0 exactly -> no triplet gradient; row 1: 1 + .5 - .5 = 1 > 0; row 2: scene norm exactly 1
+    loss, ps, ns, gs, gp, gn = ops.triplet_fwd_bwd(T(scene, dev), T(pos, dev), T(neg, dev), None, None, None, B, 0.5,
+                                                   float(B))
+    gs, gp, gn = N(gs), N(gp), N(gn)
+    assert np.all(np.isfinite(gs)) and np.all(np.isfinite(gp)) and np.all(np.isfinite(gn)) and np.isfinite(float(loss))
+    assert np.array_equal(gs[0], np.zeros(D)) and np.array_equal(gp[0], np.zeros(D))      # on the kink: nothing
+    assert np.allclose(gs[1], (neg[1] - pos[1]) / B) and np.allclose(gp[1], -scene[1] / B) and np.allclose(gn[1], scene[1] / B)
+    # row 2: margin 1 + 0 - 2 < 0: only regularisers; scene norm == 1 -> none; pos norm 2 -> lam * p / |p| / B
+    assert np.array_equal(gs[2], np.zeros(D))
+    assert np.allclose(gp[2], 0.5 * pos[2] / 2.0 / B) and np.allclose(gn[2], 0.5 * neg[2] / 3.0 / B)
+    assert np.array_equal(gs[3], (neg[3] - pos[3]) / B)                                   # zero row: margin 1 > 0
+    exp_loss = (0.0 + 1.0 + 0.0 + 1.0 + 0.5 * ((2 - 1) + (3 - 1) + (2 - 1))) / B
+    assert abs(float(loss) - exp_loss) <= 1e-6
+    el, egs, egp, egn = o_stl.triplet_loss_and_grads(scene, pos, neg, 0.5, float(B))
+    assert abs(el - exp_loss) <= 1e-12 and np.allclose(gs, egs) and np.allclose(gp, egp) and np.allclose(gn, egn)
