@@ -198,3 +198,30 @@ def test_triplet_head_on_the_kinks(dev):
     assert abs(float(loss) - exp_loss) <= 1e-6
     el, egs, egp, egn = o_stl.triplet_loss_and_grads(scene, pos, neg, 0.5, float(B))
     assert abs(el - exp_loss) <= 1e-12 and np.allclose(gs, egs) and np.allclose(gp, egp) and np.allclose(gn, egn)
+
+
+@pytest.mark.parametrize("mode", ["reference", "diagonal"])
+def test_glove_weight_function_corners(dev, mode):
+    """counts on the corners of w = min(1, c / 100) ** 0.75 and log10(1 + c) (train_cooccurence.py:79-82): zero (weight 0,
+    target 0), the knee at exactly 100 and one float on either side, very large and denormal-small counts; t1 == t2 pairs
+    (a token co-occurring with itself: both occurrences hit the same row)"""
+    from esrecsys_amd import ops
+    from oracle import glove as o_glove
+    rng = np.random.default_rng(31)
+    V, D, B = 50, 64, 16
+    emb = (rng.standard_normal((V, D)) * 0.3).astype(np.float32)
+    bias = (rng.standard_normal((V, 1)) * 0.1).astype(np.float32)
+    inputs = rng.integers(0, V, (2, B)).astype(np.int32)
+    inputs[1, :4] = inputs[0, :4]
+    hundred = np.float32(100.0)
+    target = np.array([0.0, 100.0, np.nextafter(hundred, np.float32(0)), np.nextafter(hundred, np.float32(1e9)), 1e6,
+                       3.0e38, 1e-38, 1e-45, 1.0, 99.0, 101.0, 0.5, 7.25, 250.0, 1e-3, 50.0], np.float32)
+    loss, grows, gbias = ops.glove_fwd_bwd(T(emb, dev), T(bias, dev), T(inputs, dev), T(target, dev),
+                                           ops.GLOVE_REFERENCE if mode == "reference" else ops.GLOVE_DIAGONAL)
+    el, gdot, gs = o_glove.loss_and_grads(emb, bias, inputs, target, mode, F64)
+    _, erows, ebias = o_glove.row_grads(emb, inputs, gdot, gs, F64)
+    assert np.isfinite(float(loss)) and abs(float(loss) - el) <= 1e-5 * abs(el)
+    assert np.max(np.abs(N(grows) - erows)) <= 1e-5 * np.max(np.abs(erows))
+    assert np.max(np.abs(N(gbias).reshape(-1) - ebias)) <= 1e-5 * np.max(np.abs(ebias))
+    if mode == "diagonal":   # a zero count has zero weight: its pair contributes no gradient at all
+        assert np.array_equal(N(grows)[0], np.zeros(D)) and np.array_equal(N(grows)[B], np.zeros(D))
