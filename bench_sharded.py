@@ -127,4 +127,5 @@ def run_sharded(args, cfg, dev, rank, world):
                        "loss": float(total)},
             "roofline": roofline, "kernels": kernels, "cpu_baseline": None,
         })
+    dist.barrier()  # rank 0 may still be measuring its MFMA ceiling: leave the group together
     dist.destroy_process_group()
