@@ -143,20 +143,26 @@ def saturating_gather_scatter(dev, V, D, n=131072, reps=20):
             "sparse_adagrad_GBps": sb / ts / 1e9, "sparse_adagrad_frac_of_8TBps": sb / ts / 1e9 / HBM_PEAK_GBS}
 
 
-def roofline_for(workload, kernels, B, D, rows, precision, occ_n=0, uniq=0):
+def roofline_for(workload, kernels, B, D, rows, precision, occ_n=0, uniq=0, bf16_tables=False, rowmax_gemm=False):
     """The `roofline` object for the dominant kernel of one rank's step.  `kernels` = HIP-event ms per step per
-    kernel group; occ_n / uniq = row occurrences and distinct rows the sparse Adagrad launch of the last batch saw."""
+    kernel group; occ_n / uniq = row occurrences and distinct rows the sparse Adagrad launch of the last batch saw.
+    bf16_tables: both towers bf16 (one-plane kernels); rowmax_gemm: the score range needs the row-max pre-pass."""
     if workload == "inbatch":
         t = kernels["inbatch_mfma"]["ms_per_step"] * 1e-3
         alg = 6.0 * B * B * D  # S = QC^T, dQ = PC, dC = P^T Q in f32 (SURVEY 8d)
         if precision != "f32" and D == 128 and B % 128 == 0:
-            # bf16x3 path: every f32 product = 6 bf16 MFMA terms; S is recomputed in pass C (4 GEMM units) and the
-            # row-max pre-pass adds one hi-plane term: (4 * 6 + 1) * 2 B^2 D executed bf16 flops
-            executed = (4 * 6 + 1) * 2.0 * B * B * D
+            # bf16x3 path: every f32 product = 6 bf16 MFMA terms and S is recomputed in pass C: 4 GEMM units x 6
+            # terms x 2 B^2 D executed bf16 flops; the row-max pre-pass (one hi-plane term) only runs when the
+            # Cauchy-Schwarz bound on the scores is too wide (not on these inputs).  bf16-exact operands (bf16
+            # tables): the zero planes are skipped -- 1 live term in each S^T, 3 in each O^T.
+            terms = (2 * (1 + 3)) if bf16_tables else 4 * 6
+            executed = (terms + (1 if rowmax_gemm else 0)) * 2.0 * B * B * D
             return {"kernel": "split3 + inbatch3_rowmax + inbatch3_kernel<Q> + merge + inbatch3_kernel<C> + merge",
                     "bound": "mfma", "achieved": executed / t / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": executed / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
-                    "dtype": "bf16 x3 split, f32 accumulate (f32-equivalent products)",
+                    "dtype": "bf16 x3 split, f32 accumulate (f32-equivalent products)" +
+                             ("; bf16-exact operands: %d of 24 cross terms are live" % terms if bf16_tables else ""),
+                    "executed_cross_terms": terms + (1 if rowmax_gemm else 0),
                     "f32_equivalent_TFLOPs": alg / t / 1e12,
                     "f32_equivalent_vs_f32_mfma_peak": alg / t / 1e12 / MFMA_F32_PEAK_TFLOPS}
         return {"kernel": "inbatch_kernel<128,{Q,C}side> (2 launches)", "bound": "mfma",
@@ -361,6 +367,13 @@ def main():
 
     n_batches = args.steps + args.warmup
     state, batches = make_state_and_batches(args.workload, cfg, dev, n_batches, rank)
+    needs_rowmax = False
+    if args.workload == "inbatch":
+        # the kernel's own criterion (esr_inbatch3.hip, kRmSafeBound), on the table-wide norm maxima (>= any batch's)
+        pr = state.params["params"]
+        mq = float(pr["scene_tower"]["embedding"].float().pow(2).sum(1).max())
+        mc = float(pr["product_tower"]["embedding"].float().pow(2).sum(1).max())
+        needs_rowmax = (mq * mc) ** 0.5 * abs(SCALE) * 1.4426950408889634 > 28.0
     timer = KernelTimer(ops, TIMED_GROUPS)
     timer.install()
 
@@ -431,7 +444,8 @@ def main():
             occ = torch.cat([last[0].reshape(-1)] if args.workload == "glove" else
                             [last[0], last[1] + V, last[2] + V])  # the two towers are different tables
             occ_n, uniq = occ.numel(), int(torch.unique(occ).numel())
-        roofline = roofline_for(args.workload, kernels, B, D, rows, PRECISION, occ_n, uniq)
+        roofline = roofline_for(args.workload, kernels, B, D, rows, PRECISION, occ_n, uniq,
+                                bf16_tables=args.table_dtype == "bf16", rowmax_gemm=needs_rowmax)
         if roofline.get("bound") == "mfma" and roofline.get("peak") == MFMA_BF16_PEAK_TFLOPS:
             live = sustained_bf16_mfma_tflops(dev)  # after the timed region
             roofline["sustained_live_data_TFLOPs"] = live

@@ -103,7 +103,8 @@ def run_sharded(args, cfg, dev, rank, world):
                 kernels[g_] = {"ms_per_step": ms / args.steps, "launch_groups_per_step": calls / args.steps}
         rows_served = begin(batches[-1]).finish().recv_local_rows
         roofline = roofline_for(args.workload, kernels, B, D, cfg["rows_per_unit"], "auto",
-                                int(rows_served.numel()), int(torch.unique(rows_served).numel()))
+                                int(rows_served.numel()), int(torch.unique(rows_served).numel()),
+                                bf16_tables=cfg.get("table_dtype") == "bf16")
         roofline["rank"] = 0
     grp = emb if args.workload == "glove" else towers
     exchange = "RCCL ncclSend/ncclRecv on the compute stream (esrecsys_amd/rccl.py)" if grp.exchange() is not None \

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void split3_kernel(RowSrc X0, RowSrc X1,
                                                     int64_t B, __bf16* __restrict__ R0, __bf16* __restrict__ T0,
                                                     __bf16* __restrict__ R1, __bf16* __restrict__ T1,
                                                     float* __restrict__ nrm,
-                                                    unsigned long long* __restrict__ loss_acc) {
+                                                    unsigned long long* __restrict__ loss_acc, int planes) {
   __shared__ __attribute__((aligned(16))) __bf16 tl[3][128][40];
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x <= kLossWords) {  // see inbatch3_merge_kernel
     loss_acc[threadIdx.x * 16] = 0ull;
@@ -199,6 +199,7 @@ __global__ __launch_bounds__(256) void split3_kernel(RowSrc X0, RowSrc X1,
   }
 #pragma unroll
   for (int pl = 0; pl < 3; ++pl) {
+    if (pl >= planes) break;  // bf16-exact inputs: planes 2 and 3 are zero and the ONEP kernels never read them
     bf16x8* dst = reinterpret_cast<bf16x8*>(R + ((int64_t)pl * B + grow) * k3D + d0);
     dst[0] = p[pl][0];
     dst[1] = p[pl][1];
@@ -262,8 +263,8 @@ __device__ __forceinline__ void dma_piece(const char* __restrict__ baseR, const 
 #define ESR_DP(K, G, BUF) dma_piece<K>(baseR, baseT, G, (BUF), w)
 // issue the 12 pieces of the chunk the offsets currently address, then advance them to the next chunk
 #define ESR_DMA_CHUNK(BUF)                                                                                 \
-  ESR_DP(0, g0, BUF); ESR_DP(1, g1, BUF); ESR_DP(2, g2, BUF); ESR_DP(3, g3, BUF); ESR_DP(4, g4, BUF);       \
-  ESR_DP(5, g5, BUF);                                                                                      \
+  ESR_DP(0, g0, BUF); ESR_DP(1, g1, BUF);                                                                  \
+  if (!ONEP) { ESR_DP(2, g2, BUF); ESR_DP(3, g3, BUF); ESR_DP(4, g4, BUF); ESR_DP(5, g5, BUF); }            \
   if (!kUseTr) { ESR_DP(6, g6, BUF); ESR_DP(7, g7, BUF); ESR_DP(8, g8, BUF); ESR_DP(9, g9, BUF);            \
                  ESR_DP(10, g10, BUF); ESR_DP(11, g11, BUF); }                                             \
   ESR_DMA_ADVANCE();
@@ -305,31 +306,36 @@ __device__ unsigned long long esr_ib3_dbg[8192];
     const char* ap0_ = (NBUF) + j * 256;                                                                  \
     const int sw_ = swz16(j);                                                                             \
     bf16x8 a1_ = *reinterpret_cast<const bf16x8*>(ap0_ + ((h ^ sw_) << 4));                               \
-    bf16x8 a2_ = *reinterpret_cast<const bf16x8*>(ap0_ + ((h ^ sw_) << 4) + kPlaneBytes);                 \
-    bf16x8 a3_ = *reinterpret_cast<const bf16x8*>(ap0_ + ((h ^ sw_) << 4) + 2 * kPlaneBytes);             \
+    bf16x8 a2_ = a1_, a3_ = a1_;                                                                          \
+    if (!ONEP) {                                                                                          \
+      a2_ = *reinterpret_cast<const bf16x8*>(ap0_ + ((h ^ sw_) << 4) + kPlaneBytes);                      \
+      a3_ = *reinterpret_cast<const bf16x8*>(ap0_ + ((h ^ sw_) << 4) + 2 * kPlaneBytes);                  \
+    }                                                                                                     \
     _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) {                                                    \
       bf16x8 n1_ = a1_, n2_ = a2_, n3_ = a3_;                                                             \
       if (s_ < 7) {                                                                                       \
         const int off_ = (((2 * (s_ + 1) + h) ^ sw_) << 4);                                               \
         n1_ = *reinterpret_cast<const bf16x8*>(ap0_ + off_);                                              \
-        n2_ = *reinterpret_cast<const bf16x8*>(ap0_ + off_ + kPlaneBytes);                                \
-        n3_ = *reinterpret_cast<const bf16x8*>(ap0_ + off_ + 2 * kPlaneBytes);                            \
+        if (!ONEP) {                                                                                      \
+          n2_ = *reinterpret_cast<const bf16x8*>(ap0_ + off_ + kPlaneBytes);                              \
+          n3_ = *reinterpret_cast<const bf16x8*>(ap0_ + off_ + 2 * kPlaneBytes);                          \
+        }                                                                                                 \
       }                                                                                                   \
       float e0_ = 0.f, e1_ = 0.f, q0_ = 0.f, q1_ = 0.f;                                                   \
       uint32_t pa_ = 0, pq_ = 0;                                                                          \
       ESR_SB();                                                                                           \
-      SA = ESR_MFMA_BF16(a3_, bx[0][s_], SA);                                                             \
+      if (!ONEP) SA = ESR_MFMA_BF16(a3_, bx[0][s_], SA);                                                  \
       ESR_SB();                                                                                           \
       if (VALU_ON) {                                                                                      \
         e0_ = __builtin_amdgcn_exp2f(fmaf(p[2 * s_], sl2, -rf[2 * s_]));                                  \
         e1_ = fmaf(p[2 * s_ + 1], sl2, -rf[2 * s_ + 1]);                                                  \
       }                                                                                                   \
       ESR_SB();                                                                                           \
-      SA = ESR_MFMA_BF16(a1_, bx[2][s_], SA);                                                             \
+      if (!ONEP) SA = ESR_MFMA_BF16(a1_, bx[2][s_], SA);                                                  \
       ESR_SB();                                                                                           \
       if (VALU_ON) { e1_ = __builtin_amdgcn_exp2f(e1_); pa_ = pk_bf16(e0_, e1_); }                        \
       ESR_SB();                                                                                           \
-      SA = ESR_MFMA_BF16(a2_, bx[1][s_], SA);                                                             \
+      if (!ONEP) SA = ESR_MFMA_BF16(a2_, bx[1][s_], SA);                                                  \
       ESR_SB();                                                                                           \
       if (VALU_ON) l += e0_ + e1_;                                                                        \
       ESR_SB();                                                                                           \
@@ -337,15 +343,19 @@ __device__ unsigned long long esr_ib3_dbg[8192];
          compiler's own s_waitcnt lgkmcnt(3) at the top of the next step (it counts its three ds_read_b128   \
          only) then finds these reads ~100 clocks old instead of waiting on loads it has just issued */      \
       if (kUseTr && (VALU_ON)) {                                                                          \
-        _Pragma("unroll") for (int f_ = (3 * s_) / 2; f_ < (3 * s_ + 3) / 2; ++f_)                        \
-          tr_frag_n<0>(f_, ta2_, trc_);                                                                   \
+        if (ONEP) { /* only the four plane-1 fragments (F = 4 .. 7), one every other k-step */             \
+          if ((s_ & 1) == 0) tr_frag_n<0>(4 + s_ / 2, ta2_, trc_);                                        \
+        } else {                                                                                          \
+          _Pragma("unroll") for (int f_ = (3 * s_) / 2; f_ < (3 * s_ + 3) / 2; ++f_)                      \
+            tr_frag_n<0>(f_, ta2_, trc_);                                                                 \
+        }                                                                                                 \
       }                                                                                                   \
       ESR_SB();                                                                                           \
-      SA = ESR_MFMA_BF16(a2_, bx[0][s_], SA);                                                             \
+      if (!ONEP) SA = ESR_MFMA_BF16(a2_, bx[0][s_], SA);                                                  \
       ESR_SB();                                                                                           \
       if (VALU_ON) { q0_ = e0_ - pk_lo(pa_); q1_ = e1_ - pk_hi(pa_); pq_ = pk_bf16(q0_, q1_); }           \
       ESR_SB();                                                                                           \
-      SA = ESR_MFMA_BF16(a1_, bx[1][s_], SA);                                                             \
+      if (!ONEP) SA = ESR_MFMA_BF16(a1_, bx[1][s_], SA);                                                  \
       ESR_SB();                                                                                           \
       if (VALU_ON) {                                                                                      \
         pw[0][s_] = pa_; pw[1][s_] = pq_;                                                                 \
@@ -364,7 +374,12 @@ __device__ unsigned long long esr_ib3_dbg[8192];
 // software-pipelined: the S^T MFMAs of chunk t+1 are issued before the exp / bf16-split VALU work of
 // chunk t, whose results feed the O^T MFMAs of chunk t.  Three LDS buffers: chunk t (read by the
 // O^T phase), chunk t+1 (read by the S^T phase), chunk t+2 (DMA in flight); one barrier per chunk.
-template <bool QSIDE>
+// ONEP: both operands are bf16-exact (bf16 tables, BASELINE config 4): planes 2 and 3 of X and Y are identically
+// zero, so five of the six cross terms of S^T and three of the six of O^T add exact zeros.  The ONEP kernel issues
+// only the live ones -- Y1 X1 for S^T; Y1 P1, Y1 P2, Y1 P3 for O^T, in the order the full sequence has them, so
+// the results are bit-identical to it -- and streams / stages / fetches plane 1 only: a third of the MFMA work
+// (the S^T phase is then bound by the exp / split VALU work, no longer by the matrix pipe).
+template <bool QSIDE, bool ONEP = false>
 __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict__ Xr, const __bf16* __restrict__ Yr,
                                                       const __bf16* __restrict__ Yt, int64_t B, int nsplit, float sl2,
                                                       const float* __restrict__ ref, float* __restrict__ part_O,
@@ -438,7 +453,9 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
 // G = 0 half for the last chunk, which has no S^T phase beside it.
 #define ESR_O_PREFETCH(BUF)                                                                               \
   if (kUseTr) {                                                                                           \
-    ESR_O_LOAD(BUF, 0, 2); ESR_O_LOAD(BUF, 0, 0); ESR_O_LOAD(BUF, 0, 1);                                  \
+    if (!ONEP) { ESR_O_LOAD(BUF, 0, 2); }                                                                 \
+    ESR_O_LOAD(BUF, 0, 0);                                                                                \
+    if (!ONEP) { ESR_O_LOAD(BUF, 0, 1); }                                                                 \
   }
 // G = 1 fragments F0 .. F1 - 1 (issued after G = 0 MFMA rows 0 .. 4 as 3, 3, 2, 2, 2: the last ones are a full
 // MFMA row old when ESR_TR_WAIT() ahead of the G = 1 rows asks for them)
@@ -457,23 +474,34 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
     } else {                                                                                              \
       ESR_O_LOAD(BUF, 0, 2); ESR_O_LOAD(BUF, 0, 0); ESR_O_LOAD(BUF, 0, 1);                                \
     }                                                                                                     \
-    ESR_SB(); ESR_O_ROW(2, 0, 0); ESR_SB(); ESR_O_G1(0, 3); if (DMA_ON) { ESR_DP(0, g0, DBUF); }                  \
-    ESR_SB(); ESR_O_ROW(0, 2, 0); ESR_SB(); ESR_O_G1(3, 6); if (DMA_ON) { ESR_DP(1, g1, DBUF); }                  \
-    ESR_SB(); ESR_O_ROW(1, 1, 0); ESR_SB(); ESR_O_G1(6, 8); if (DMA_ON) { ESR_DP(2, g2, DBUF); }                  \
-    ESR_SB(); ESR_O_ROW(1, 0, 0); ESR_SB(); ESR_O_G1(8, 10); if (DMA_ON) { ESR_DP(3, g3, DBUF); }                  \
-    ESR_SB(); ESR_O_ROW(0, 1, 0); ESR_SB(); ESR_O_G1(10, 12); if (DMA_ON) { ESR_DP(4, g4, DBUF); }                  \
-    ESR_SB(); ESR_O_ROW(0, 0, 0); ESR_SB(); ESR_O_G1(12, 12); if (DMA_ON) { ESR_DP(5, g5, DBUF); }                  \
-    if (kUseTr) {                                                                                         \
+    if (ONEP) {                                                                                           \
+      /* bf16-exact operands: only the Y1 rows are live (same relative order as below); plane-1 fragments only */ \
+      ESR_SB(); ESR_O_ROW(0, 2, 0); ESR_SB(); ESR_O_G1(4, 6); if (DMA_ON) { ESR_DP(0, g0, DBUF); }          \
+      ESR_SB(); ESR_O_ROW(0, 1, 0); ESR_SB(); ESR_O_G1(6, 8); if (DMA_ON) { ESR_DP(1, g1, DBUF); }          \
+      ESR_SB(); ESR_O_ROW(0, 0, 0); ESR_SB();                                                             \
       ESR_TR_WAIT();                                                                                      \
+      ESR_SB(); ESR_O_ROW(0, 2, 1); ESR_SB();                                                             \
+      ESR_SB(); ESR_O_ROW(0, 1, 1); ESR_SB();                                                             \
+      ESR_SB(); ESR_O_ROW(0, 0, 1); ESR_SB();                                                             \
     } else {                                                                                              \
-      ESR_O_LOAD(BUF, 1, 2); ESR_O_LOAD(BUF, 1, 0); ESR_O_LOAD(BUF, 1, 1);                                \
+      ESR_SB(); ESR_O_ROW(2, 0, 0); ESR_SB(); ESR_O_G1(0, 3); if (DMA_ON) { ESR_DP(0, g0, DBUF); }        \
+      ESR_SB(); ESR_O_ROW(0, 2, 0); ESR_SB(); ESR_O_G1(3, 6); if (DMA_ON) { ESR_DP(1, g1, DBUF); }        \
+      ESR_SB(); ESR_O_ROW(1, 1, 0); ESR_SB(); ESR_O_G1(6, 8); if (DMA_ON) { ESR_DP(2, g2, DBUF); }        \
+      ESR_SB(); ESR_O_ROW(1, 0, 0); ESR_SB(); ESR_O_G1(8, 10); if (DMA_ON) { ESR_DP(3, g3, DBUF); }       \
+      ESR_SB(); ESR_O_ROW(0, 1, 0); ESR_SB(); ESR_O_G1(10, 12); if (DMA_ON) { ESR_DP(4, g4, DBUF); }      \
+      ESR_SB(); ESR_O_ROW(0, 0, 0); ESR_SB(); ESR_O_G1(12, 12); if (DMA_ON) { ESR_DP(5, g5, DBUF); }      \
+      if (kUseTr) {                                                                                       \
+        ESR_TR_WAIT();                                                                                    \
+      } else {                                                                                            \
+        ESR_O_LOAD(BUF, 1, 2); ESR_O_LOAD(BUF, 1, 0); ESR_O_LOAD(BUF, 1, 1);                              \
+      }                                                                                                   \
+      ESR_SB(); ESR_O_ROW(2, 0, 1); ESR_SB(); if (DMA_ON && !kUseTr) { ESR_DP(6, g6, DBUF); }             \
+      ESR_SB(); ESR_O_ROW(0, 2, 1); ESR_SB(); if (DMA_ON && !kUseTr) { ESR_DP(7, g7, DBUF); }             \
+      ESR_SB(); ESR_O_ROW(1, 1, 1); ESR_SB(); if (DMA_ON && !kUseTr) { ESR_DP(8, g8, DBUF); }             \
+      ESR_SB(); ESR_O_ROW(1, 0, 1); ESR_SB(); if (DMA_ON && !kUseTr) { ESR_DP(9, g9, DBUF); }             \
+      ESR_SB(); ESR_O_ROW(0, 1, 1); ESR_SB(); if (DMA_ON && !kUseTr) { ESR_DP(10, g10, DBUF); }           \
+      ESR_SB(); ESR_O_ROW(0, 0, 1); ESR_SB(); if (DMA_ON && !kUseTr) { ESR_DP(11, g11, DBUF); }           \
     }                                                                                                     \
-    ESR_SB(); ESR_O_ROW(2, 0, 1); ESR_SB(); if (DMA_ON && !kUseTr) { ESR_DP(6, g6, DBUF); }                  \
-    ESR_SB(); ESR_O_ROW(0, 2, 1); ESR_SB(); if (DMA_ON && !kUseTr) { ESR_DP(7, g7, DBUF); }                  \
-    ESR_SB(); ESR_O_ROW(1, 1, 1); ESR_SB(); if (DMA_ON && !kUseTr) { ESR_DP(8, g8, DBUF); }                  \
-    ESR_SB(); ESR_O_ROW(1, 0, 1); ESR_SB(); if (DMA_ON && !kUseTr) { ESR_DP(9, g9, DBUF); }                  \
-    ESR_SB(); ESR_O_ROW(0, 1, 1); ESR_SB(); if (DMA_ON && !kUseTr) { ESR_DP(10, g10, DBUF); }                \
-    ESR_SB(); ESR_O_ROW(0, 0, 1); ESR_SB(); if (DMA_ON && !kUseTr) { ESR_DP(11, g11, DBUF); }                \
     if (DMA_ON) ESR_DMA_ADVANCE();                                                                        \
   }
 // A fragment of the O^T phase: lane (j, h) needs Y[16 G + 4 h + {0..3, 8..11}][32 db + j] of plane PL.  Transposed
@@ -520,7 +548,7 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
   // All reference loads are issued before the first use (nsplit <= 8 is a run-time value; a rolled loop waited one
   // memory latency per split, and sat in front of the DMA issue).
 #pragma unroll
-  for (int p = 0; p < 3; ++p)
+  for (int p = 0; p < (ONEP ? 1 : 3); ++p)
 #pragma unroll
     for (int s = 0; s < 8; ++s)
       bx[p][s] = *reinterpret_cast<const bf16x8*>(Xr + ((int64_t)p * B + xrow) * k3D + 16 * s + 8 * h);
@@ -929,20 +957,33 @@ static int inbatch3_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* gq
   const float inv_bs = 1.0f / batch_size, sl2 = scale * k3Log2e;
   const int nchunks = (int)(B / k3Chunk), grid = (int)(B / k3Owned) * nsplit;
   const int mgrid = (int)std::min<int64_t>(k3MergeBlocks, cdiv(B, kBlock / 32));
+  // bf16 tables on both sides (BASELINE config 4): planes 2 and 3 are zero -> the one-plane kernels (bit-identical)
+  const bool onep = kUseTr && Qs.bf16 && Cs.bf16;
   hipLaunchKernelGGL(split3_kernel, dim3(nchunks, 2), dim3(256), 0, st, Qs, Cs, B, ws.Qr, ws.Qt, ws.Cr, ws.Ct, ws.nrm,
-                     ws.loss_acc);
+                     ws.loss_acc, onep ? 1 : 3);
   // pass Q: owned = Q, streamed = C
   hipLaunchKernelGGL(inbatch3_rowmax_kernel, dim3(grid), dim3(256), 0, st, (const __bf16*)ws.Qr, (const __bf16*)ws.Cr, B,
                      nsplit, sl2, (const float*)ws.nrm, ws.part_m);
-  hipLaunchKernelGGL((inbatch3_kernel<true>), dim3(grid), dim3(256), 0, st, (const __bf16*)ws.Qr, (const __bf16*)ws.Cr,
-                     (const __bf16*)ws.Ct, B, nsplit, sl2, (const float*)ws.part_m, ws.part_O, ws.part_l);
+  if (onep)
+    hipLaunchKernelGGL((inbatch3_kernel<true, true>), dim3(grid), dim3(256), 0, st, (const __bf16*)ws.Qr,
+                       (const __bf16*)ws.Cr, (const __bf16*)ws.Ct, B, nsplit, sl2, (const float*)ws.part_m, ws.part_O,
+                       ws.part_l);
+  else
+    hipLaunchKernelGGL((inbatch3_kernel<true, false>), dim3(grid), dim3(256), 0, st, (const __bf16*)ws.Qr,
+                       (const __bf16*)ws.Cr, (const __bf16*)ws.Ct, B, nsplit, sl2, (const float*)ws.part_m, ws.part_O,
+                       ws.part_l);
   hipLaunchKernelGGL((inbatch3_merge_kernel<true>), dim3(mgrid), dim3(kBlock), 0, st, Qs, Cs, gq_rows, B, nsplit,
                      (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale, regularization,
                      inv_bs, ws.lse2, lse, gQ, ws.loss_acc, 1.0 / (double)batch_size, loss);
   // pass C: owned = C, streamed = Q
-  hipLaunchKernelGGL((inbatch3_kernel<false>), dim3(grid), dim3(256), 0, st, (const __bf16*)ws.Cr,
-                     (const __bf16*)ws.Qr, (const __bf16*)ws.Qt, B, nsplit, sl2, (const float*)ws.lse2, ws.part_O,
-                     ws.part_l);
+  if (onep)
+    hipLaunchKernelGGL((inbatch3_kernel<false, true>), dim3(grid), dim3(256), 0, st, (const __bf16*)ws.Cr,
+                       (const __bf16*)ws.Qr, (const __bf16*)ws.Qt, B, nsplit, sl2, (const float*)ws.lse2, ws.part_O,
+                       ws.part_l);
+  else
+    hipLaunchKernelGGL((inbatch3_kernel<false, false>), dim3(grid), dim3(256), 0, st, (const __bf16*)ws.Cr,
+                       (const __bf16*)ws.Qr, (const __bf16*)ws.Qt, B, nsplit, sl2, (const float*)ws.lse2, ws.part_O,
+                       ws.part_l);
   hipLaunchKernelGGL((inbatch3_merge_kernel<false>), dim3(mgrid), dim3(kBlock), 0, st, Cs, Qs, gc_rows, B, nsplit,
                      (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale, regularization,
                      inv_bs, ws.lse2, (float*)nullptr, gC, ws.loss_acc, 1.0 / (double)batch_size, loss);
