@@ -13,10 +13,20 @@ c = torch.randn((B, D), generator=g, device=dev) * D ** -0.5
 loss = torch.empty(1, device=dev); lse = torch.empty(B, device=dev); gq = torch.empty_like(q); gc = torch.empty_like(c)
 ws = torch.empty(lib.esr_inbatch3_workspace_bytes(B, D), dtype=torch.uint8, device=dev)
 P = ctypes.c_void_p
+BF16 = os.environ.get("IB3_BF16", "0") == "1"   # bf16 tables -> the one-plane kernels
+if BF16:
+    qt, ct = q.to(torch.bfloat16), c.to(torch.bfloat16)
+    ids = torch.arange(B, dtype=torch.int32, device=dev)
 for _ in range(3):
-    rc = lib.esr_inbatch_softmax_fwd_bwd_bf16x3(P(q.data_ptr()), P(c.data_ptr()), ctypes.c_int64(B), D, ctypes.c_float(8.0),
-        ctypes.c_float(0.1), ctypes.c_float(B), P(loss.data_ptr()), P(lse.data_ptr()), P(gq.data_ptr()), P(gc.data_ptr()),
-        P(ws.data_ptr()), ctypes.c_size_t(ws.numel()), None)
+    if BF16:
+        rc = lib.esr_inbatch_towers_fwd_bwd_bf16x3(P(qt.data_ptr()), ctypes.c_int64(B), P(ct.data_ptr()), ctypes.c_int64(B), 1, D,
+            P(ids.data_ptr()), P(ids.data_ptr()), None, None, ctypes.c_int64(B), ctypes.c_float(8.0), ctypes.c_float(0.1),
+            ctypes.c_float(B), P(loss.data_ptr()), P(lse.data_ptr()), P(gq.data_ptr()), P(gc.data_ptr()),
+            P(ws.data_ptr()), ctypes.c_size_t(ws.numel()), None)
+    else:
+        rc = lib.esr_inbatch_softmax_fwd_bwd_bf16x3(P(q.data_ptr()), P(c.data_ptr()), ctypes.c_int64(B), D, ctypes.c_float(8.0),
+            ctypes.c_float(0.1), ctypes.c_float(B), P(loss.data_ptr()), P(lse.data_ptr()), P(gq.data_ptr()), P(gc.data_ptr()),
+            P(ws.data_ptr()), ctypes.c_size_t(ws.numel()), None)
     assert rc == 0
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 8192)()
