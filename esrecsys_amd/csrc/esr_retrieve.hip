@@ -251,6 +251,13 @@ __global__ __launch_bounds__(kGThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
     // lane r; ONE atomic per row (all 64 of a wave in flight together) reserves the slots; pass 2 writes the
     // survivors side by side.  An atomic per (row, ballot) with its returned value needed at once serialised
     // 64 round trips per tile (measured: +45 % on the whole kernel).
+    // the tile's 256 thresholds through LDS (the staging ring is idle now): the two passes below used to fetch them
+    // from global memory, 32 loads per lane and pass, in front of every ballot
+    float* tau_s = reinterpret_cast<float*>(lds);
+    __syncthreads();
+    if (t < 256) tau_s[t] = m0 + t < M ? o.tau[m0 + t] : INFINITY;
+    __syncthreads();
+    const float* tau_w = tau_s + wm * 64 + 4 * h;
     const bool c_ok0 = n0 + wn * 64 + l31 < nvalid, c_ok1 = n0 + wn * 64 + 32 + l31 < nvalid;
     const int mrow = m0 + wm * 64 + 4 * h;  // + i*32 + 8*(e/4) + e%4
     int my_cnt = 0;
@@ -258,10 +265,7 @@ __global__ __launch_bounds__(kGThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
     for (int i = 0; i < 2; ++i) {
       float tau_r[16];  // 16 thresholds at a time: the kernel must stay within 128 VGPRs (two workgroups per CU)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = mrow + i * 32 + 8 * (e >> 2) + (e & 3);
-        tau_r[e] = m < M ? o.tau[m] : INFINITY;
-      }
+      for (int e = 0; e < 16; ++e) tau_r[e] = tau_w[i * 32 + 8 * (e >> 2) + (e & 3)];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const unsigned long long b0 = __ballot(c_ok0 && acc[i][0][e] >= tau_r[e]);
@@ -279,10 +283,7 @@ __global__ __launch_bounds__(kGThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
       for (int i = 0; i < 2; ++i) {
         float tau_r[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = mrow + i * 32 + 8 * (e >> 2) + (e & 3);
-          tau_r[e] = m < M ? o.tau[m] : INFINITY;
-        }
+        for (int e = 0; e < 16; ++e) tau_r[e] = tau_w[i * 32 + 8 * (e >> 2) + (e & 3)];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const bool p0 = c_ok0 && acc[i][0][e] >= tau_r[e];
