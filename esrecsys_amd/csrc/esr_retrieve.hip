@@ -362,6 +362,7 @@ __device__ __forceinline__ int block_incl_scan(int v, int* part4, int t) {
 
 constexpr int kSelBatch = 8;   // elements per thread of a row that stays in registers (rows <= 2048)
 constexpr int kSelStream = 4;  // independent loads in flight per thread when a longer row is streamed
+constexpr int kSelLdsWords = 8192;  // 32 KB of dynamic LDS for the row cache of the launches that have long rows
 
 // One workgroup per query.  n <= k: everything is kept.  Otherwise an MSB-first radix select runs on
 // D = composite - min(composite), starting at the highest bit in which the row's composites differ: the lists a
@@ -373,7 +374,12 @@ constexpr int kSelStream = 4;  // independent loads in flight per thread when a 
 // LDS; only a call that delivers the answer (out.scores) sorts it (bitonic, 64-bit keys): the running list of an
 // intermediate merge need not be ordered, only tau must be exact.
 __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void topk_select_kernel(
-    SelIn in, int k, SelOut out) {
+    SelIn in, int k, SelOut out, int lds_words) {
+  // lds_words 32-bit words of dynamic LDS (0 or kSelLdsWords): a row that does not fit the registers (> 2048 elements)
+  // but fits here -- 8192 dense scores as 32-bit keys, or 4096 (score, index) records as 64-bit composites -- is
+  // read from global memory once; every later sweep of the radix select (5 - 6 of them) reads LDS.  Without it the
+  // select of the dense first chunk re-read 268 MB per sweep.
+  extern __shared__ __attribute__((aligned(16))) uint32_t lrow[];
   __shared__ unsigned long long sel[kSelMaxK];
   __shared__ int hist[2048];
   __shared__ int part4[4];
@@ -406,6 +412,29 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(4, 
   };
   // a row of up to 2048 elements is read once and stays in registers; longer rows are re-read (L2) every sweep
   const bool cached = n <= kSelThreads * kSelBatch;
+  const bool dense = !paired && ix == nullptr && in.stride == 1;
+  const bool lds_row = !cached && ((dense && n <= lds_words) || (!dense && 2 * n <= lds_words));
+  if (lds_row) {
+    if (dense) {
+      for (int c = t; c < n; c += kSelThreads) lrow[c] = score_key(v[c]);
+    } else {
+      unsigned long long* l64 = reinterpret_cast<unsigned long long*>(lrow);
+      for (int c0 = 0; c0 < n; c0 += kSelThreads * kSelStream) {
+        unsigned long long C[kSelStream];
+#pragma unroll
+        for (int u = 0; u < kSelStream; ++u) {
+          const int c = c0 + u * kSelThreads + t;
+          C[u] = c < n ? comp(c) : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < kSelStream; ++u) {
+          const int c = c0 + u * kSelThreads + t;
+          if (c < n) l64[c] = C[u];
+        }
+      }
+    }
+    __syncthreads();
+  }
   unsigned long long R[kSelBatch];
   if (cached) {
 #pragma unroll
@@ -418,6 +447,16 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(4, 
     if (cached) {
 #pragma unroll
       for (int u = 0; u < kSelBatch; ++u) fn(R[u], u * kSelThreads + t < n);
+    } else if (lds_row) {
+      const unsigned long long* l64 = reinterpret_cast<const unsigned long long*>(lrow);
+      for (int c = t; c < n + (kSelThreads - 1 - (n - 1) % kSelThreads); c += kSelThreads) {  // whole waves: fn ballots
+        const bool valid = c < n;
+        unsigned long long C = 0ull;
+        if (valid)
+          C = dense ? (((unsigned long long)lrow[c] << 32) | (0xFFFFFFFFu - (uint32_t)(in.ibase + c * in.istep)))
+                    : l64[c];
+        fn(C, valid);
+      }
     } else {
       for (int c0 = 0; c0 < n; c0 += kSelThreads * kSelStream) {
         unsigned long long C[kSelStream];
@@ -690,6 +729,7 @@ int esr_retrieve_topk(const float* queries, const float* candidates, int64_t nq,
   else launch_split<1>(queries, nq, D, p.Mp, p.Dp, a_plane, A, st);
 
   int64_t c0 = 0;
+  int ncall = 0;
   bool first = true;
   while (c0 < N) {
     const int64_t nc = std::min<int64_t>(first ? p.first : p.chunk, N - c0);
@@ -716,7 +756,11 @@ int esr_retrieve_topk(const float* queries, const float* candidates, int64_t nq,
       in.vals = (const float*)pairs; in.vpitch = 2 * p.ppitch; in.idx = (const int32_t*)pairs + 1; in.stride = 2;
       in.ibase = 0; in.istep = 0; in.n_per_row = cnt; in.n_fixed = 0;
     }
-    hipLaunchKernelGGL(topk_select_kernel, dim3((int)nq), dim3(kSelThreads), 0, st, in, k, so);
+    // long rows only in the first two selects (the dense first chunk; the lists filtered by its weak threshold)
+    const int lds_words = ncall < 2 ? kSelLdsWords : 0;
+    hipLaunchKernelGGL(topk_select_kernel, dim3((int)nq), dim3(kSelThreads), lds_words * sizeof(uint32_t), st, in, k, so,
+                       lds_words);
+    ++ncall;
     c0 += nc;
     first = false;
   }
@@ -751,7 +795,9 @@ int esr_topk_merge(const float* scores, const int32_t* indices, int64_t nq, int 
   in.n_per_row = nullptr; in.n_fixed = n;
   SelOut so;
   so.pairs = nullptr; so.ppitch = 0; so.cnt = nullptr; so.tau = nullptr; so.scores = out_scores; so.indices = out_indices;
-  hipLaunchKernelGGL(topk_select_kernel, dim3((int)nq), dim3(kSelThreads), 0, as_stream(stream), in, k, so);
+  const int lds_words = n > kSelThreads * kSelBatch && 2 * n <= kSelLdsWords ? kSelLdsWords : 0;
+  hipLaunchKernelGGL(topk_select_kernel, dim3((int)nq), dim3(kSelThreads), lds_words * sizeof(uint32_t),
+                     as_stream(stream), in, k, so, lds_words);
   return check_launch("esr_topk_merge");
 }
 
