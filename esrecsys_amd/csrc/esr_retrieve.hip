@@ -414,9 +414,20 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(4, 
   const bool cached = n <= kSelThreads * kSelBatch;
   const bool dense = !paired && ix == nullptr && in.stride == 1;
   const bool lds_row = !cached && ((dense && n <= lds_words) || (!dense && 2 * n <= lds_words));
+  // the fill also yields the row's value range (the first sweep of the select otherwise): bounds, not necessarily
+  // attained -- the range-relative digits only need lo <= every composite <= hi
+  unsigned long long fill_lo = ~0ull, fill_hi = 0ull;
   if (lds_row) {
     if (dense) {
-      for (int c = t; c < n; c += kSelThreads) lrow[c] = score_key(v[c]);
+      uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+      for (int c = t; c < n; c += kSelThreads) {
+        const uint32_t key = score_key(v[c]);
+        lrow[c] = key;
+        kmin = key < kmin ? key : kmin;
+        kmax = key > kmax ? key : kmax;
+      }
+      fill_lo = (unsigned long long)kmin << 32;
+      fill_hi = ((unsigned long long)kmax << 32) | 0xFFFFFFFFull;
     } else {
       unsigned long long* l64 = reinterpret_cast<unsigned long long*>(lrow);
       for (int c0 = 0; c0 < n; c0 += kSelThreads * kSelStream) {
@@ -429,7 +440,11 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(4, 
 #pragma unroll
         for (int u = 0; u < kSelStream; ++u) {
           const int c = c0 + u * kSelThreads + t;
-          if (c < n) l64[c] = C[u];
+          if (c < n) {
+            l64[c] = C[u];
+            fill_lo = C[u] < fill_lo ? C[u] : fill_lo;
+            fill_hi = C[u] > fill_hi ? C[u] : fill_hi;
+          }
         }
       }
     }
@@ -480,11 +495,12 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(4, 
   __syncthreads();
   unsigned long long thr = 0;
   if (n > k) {
-    unsigned long long lo = ~0ull, hi = 0ull;
-    sweep([&](unsigned long long C, bool valid) {
-      lo = (valid && C < lo) ? C : lo;
-      hi = (valid && C > hi) ? C : hi;
-    });
+    unsigned long long lo = fill_lo, hi = fill_hi;
+    if (!lds_row)
+      sweep([&](unsigned long long C, bool valid) {
+        lo = (valid && C < lo) ? C : lo;
+        hi = (valid && C > hi) ? C : hi;
+      });
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const unsigned long long a = __shfl_xor(lo, o, 64), b2 = __shfl_xor(hi, o, 64);
