@@ -420,11 +420,26 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(4, 
   if (lds_row) {
     if (dense) {
       uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
-      for (int c = t; c < n; c += kSelThreads) {
-        const uint32_t key = score_key(v[c]);
-        lrow[c] = key;
-        kmin = key < kmin ? key : kmin;
-        kmax = key > kmax ? key : kmax;
+      // 16 bytes per thread and load where the row allows it (a rolled loop of dword loads waited one memory latency
+      // per 256 elements, 32 in a row for the dense first chunk)
+      const bool vec = (n & 3) == 0 && (reinterpret_cast<uintptr_t>(v) & 15) == 0;
+      if (vec) {
+        for (int c4 = t; c4 < n / 4; c4 += kSelThreads) {
+          const float4 x = reinterpret_cast<const float4*>(v)[c4];
+          const uint32_t k0 = score_key(x.x), k1 = score_key(x.y), k2 = score_key(x.z), k3 = score_key(x.w);
+          *reinterpret_cast<uint4*>(lrow + 4 * c4) = make_uint4(k0, k1, k2, k3);
+          const uint32_t a = k0 < k1 ? k0 : k1, b = k2 < k3 ? k2 : k3, c = k0 > k1 ? k0 : k1, d = k2 > k3 ? k2 : k3;
+          const uint32_t mn = a < b ? a : b, mx = c > d ? c : d;
+          kmin = mn < kmin ? mn : kmin;
+          kmax = mx > kmax ? mx : kmax;
+        }
+      } else {
+        for (int c = t; c < n; c += kSelThreads) {
+          const uint32_t key = score_key(v[c]);
+          lrow[c] = key;
+          kmin = key < kmin ? key : kmin;
+          kmax = key > kmax ? key : kmax;
+        }
       }
       fill_lo = (unsigned long long)kmin << 32;
       fill_hi = ((unsigned long long)kmax << 32) | 0xFFFFFFFFull;
@@ -521,11 +536,31 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(4, 
       const int shift = L - bits_done - wbits;
       for (int b = t; b < 2048; b += kSelThreads) hist[b] = 0;
       __syncthreads();
-      sweep([&](unsigned long long C, bool valid) {
-        const unsigned long long Dv = C - lo;
-        if (valid && (bits_done == 0 || (Dv >> (L - bits_done)) == prefix))
-          atomicAdd(&hist[(int)((Dv >> shift) & ((1u << wbits) - 1))], 1);
-      });
+      if (lds_row && dense && shift >= 32) {
+        // a digit that lies entirely in the score key (the upper word of the composite; lo's lower word is zero, so
+        // nothing borrows): 32-bit arithmetic straight on the staged keys, ~6 instructions per element instead of ~20
+        const uint32_t lok = (uint32_t)(lo >> 32), pfx = (uint32_t)prefix, msk = (1u << wbits) - 1u;
+        const int sh = shift - 32, psh = L - bits_done - 32;
+        for (int c0 = 0; c0 < n; c0 += kSelThreads * 4) {
+          uint32_t d[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * kSelThreads + t;
+            d[u] = c < n ? lrow[c] - lok : 0u;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * kSelThreads + t;
+            if (c < n && (bits_done == 0 || (d[u] >> psh) == pfx)) atomicAdd(&hist[(int)((d[u] >> sh) & msk)], 1);
+          }
+        }
+      } else {
+        sweep([&](unsigned long long C, bool valid) {
+          const unsigned long long Dv = C - lo;
+          if (valid && (bits_done == 0 || (Dv >> (L - bits_done)) == prefix))
+            atomicAdd(&hist[(int)((Dv >> shift) & ((1u << wbits) - 1))], 1);
+        });
+      }
       __syncthreads();
       // thread t owns bins 2047-8t .. 2040-8t (descending)
       int local = 0;
@@ -558,8 +593,7 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(4, 
   // compact the composites >= thr (exactly nsel of them) into LDS: one slot reservation per wave instruction
   // (a same-address LDS atomic per element serialises: 500 survivors cost more than the whole radix select)
   unsigned long long my_min = ~0ull;
-  sweep([&](unsigned long long C, bool valid) {
-    const bool pass = valid && C >= thr;
+  auto keep = [&](unsigned long long C, bool pass) {  // called by whole waves
     const unsigned long long mask = __ballot(pass);
     if (mask) {
       const int lane = t & 63;
@@ -572,7 +606,8 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(4, 
         my_min = C < my_min ? C : my_min;
       }
     }
-  });
+  };
+  sweep([&](unsigned long long C, bool valid) { keep(C, valid && C >= thr); });
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const unsigned long long a = __shfl_xor(my_min, o, 64);
