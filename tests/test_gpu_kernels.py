@@ -292,6 +292,26 @@ def test_inbatch_towers_gather_folded_in(dev, dtype):
     assert abs(float(loss) - el) / abs(el) <= TOL and rel_err(N(gq), egq) <= TOL and rel_err(N(gc), egc) <= TOL
 
 
+@pytest.mark.parametrize("B", [128, 512, 1024, 2176, 8192])
+def test_inbatch_one_plane_kernels_equal_the_full_ones(dev, B):
+    """bf16 towers take the one-plane kernels (8 live cross terms of 24): same bits as the full kernels on the same
+    (bf16-valued) rows, at chunk counts per split of 1, 2, 4, 17 and 64 -- every arm of the pipelined loop"""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(B)
+    V, D = 5000, 128
+    qt = T((rng.standard_normal((V, D)) * 0.12).astype(np.float32), dev, torch.bfloat16)
+    ct = T((rng.standard_normal((V, D)) * 0.12).astype(np.float32), dev, torch.bfloat16)
+    qi = T(rng.integers(0, V, B).astype(np.int32), dev)
+    ci = T(rng.integers(0, V, B).astype(np.int32), dev)
+    loss, lse, gq, gc = ops.inbatch_towers_fwd_bwd(qt, ct, qi, ci, 7.0, 0.1, float(B))
+    l2, lse2, gq2, gc2 = ops.inbatch_towers_fwd_bwd(qt.float(), ct.float(), qi, ci, 7.0, 0.1, float(B))
+    assert torch.equal(loss, l2) and torch.equal(lse, lse2) and torch.equal(gq, gq2) and torch.equal(gc, gc2)
+    if B <= 2176:
+        q, c = N(qt.float())[N(qi)].astype(F64), N(ct.float())[N(ci)].astype(F64)
+        el, _, egq, egc = o_stl.inbatch_softmax_loss_and_grads(q, c, 0.1, B, 7.0, F64)
+        assert abs(float(loss) - el) / abs(el) <= TOL and rel_err(N(gq), egq) <= TOL and rel_err(N(gc), egc) <= TOL
+
+
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 def test_inbatch_config_c2_full_size(dev, precision):
     """BASELINE config C2: B = 8192, D = 128, fp64 oracle on the same inputs + checksum properties
