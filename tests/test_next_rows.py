@@ -223,3 +223,30 @@ def test_c_decoder_rejects_malformed_lines():
         decode_lines(b"!!!not base64!!!\n")
     with pytest.raises(ValueError, match="malformed"):
         decode_lines(b"EgX/////\n")    # a packed field longer than the message
+
+
+def test_c_decoder_survives_random_bytes():
+    """fuzz: random wire bytes never crash the C decoder and never disagree with the Python one about what a line holds"""
+    import base64
+    from esrecsys_amd.wikipedia.cooccurrence_matrix import decode_lines, parse_cooccurrence_row
+    rng = np.random.default_rng(13)
+    agree = 0
+    for _ in range(3000):
+        raw = rng.integers(0, 256, int(rng.integers(0, 40)), dtype=np.uint8).tobytes()
+        try:
+            idx, others, counts = parse_cooccurrence_row(raw)
+            exp = [(idx & 0xFFFFFFFF, o & 0xFFFFFFFF, c) for o, c in zip(others, counts)] if len(counts) >= len(others) else None
+        except Exception:
+            exp = None
+        try:
+            t1, t2, cnt, _ = decode_lines(base64.b64encode(raw) + b"\n")
+            got = list(zip((t1.astype(np.int64) & 0xFFFFFFFF).tolist(), (t2.astype(np.int64) & 0xFFFFFFFF).tolist(),
+                           cnt.tolist()))
+        except ValueError:
+            got = None
+        if exp is not None and got is not None:
+            assert len(got) == len(exp)
+            for g, e in zip(got, exp):
+                assert g[0] == e[0] and g[1] == e[1] and (g[2] == np.float32(e[2]) or (g[2] != g[2] and e[2] != e[2]))
+            agree += 1
+    assert agree > 100
