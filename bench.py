@@ -308,6 +308,20 @@ def emit(obj):
     print(json.dumps(obj), flush=True)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-exec this command line under torch.distributed.run, one rank
+    per GPU on 127.0.0.1 (the container hostname may not resolve).  exec keeps stdout: rank 0's JSON line is ours."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -338,8 +352,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)  # plain `python bench.py --gpus N`: become N ranks under torch.distributed.run
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d" % (args.gpus, world, args.gpus))
     if args.workload == "retrieve":  # config 5 (not the headline): batch score GEMM + top-k
         from bench_retrieve import run_retrieve
         return run_retrieve(args, emit)

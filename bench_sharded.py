@@ -107,8 +107,10 @@ def run_sharded(args, cfg, dev, rank, world):
                                 bf16_tables=cfg.get("table_dtype") == "bf16")
         roofline["rank"] = 0
     grp = emb if args.workload == "glove" else towers
-    exchange = "RCCL ncclSend/ncclRecv on the compute stream (esrecsys_amd/rccl.py)" if grp.exchange() is not None \
-        else "torch.distributed all_to_all_single"
+    xch = grp.exchange()
+    exchange = "direct RCCL: grouped ncclSend/ncclRecv on the compute stream (esr_alltoall_*, esrecsys_amd/rccl.py)" \
+        if xch is not None else "fallback: torch.distributed all_to_all_single"
+    rccl_ranks = xch.ranks_seen()[0] if xch is not None else None  # ncclCommCount of the exchange communicator
     if rank == 0:
         K = args.steps
         from bench import emit, sustained_bf16_mfma_tflops, MFMA_BF16_PEAK_TFLOPS
@@ -124,7 +126,7 @@ def run_sharded(args, cfg, dev, rank, world):
                                    % (args.workload, V, D, "bf16" if cfg.get("table_dtype") == "bf16" else "fp32",
                                       world, B),
                        "parallelism": "row-sharded x%d, all-to-all ids/rows/grads over RCCL" % world,
-                       "exchange": exchange,
+                       "exchange": exchange, "rccl_ranks": rccl_ranks, "world_size": world,
                        "loss": float(total)},
             "roofline": roofline, "kernels": kernels, "cpu_baseline": None,
         })

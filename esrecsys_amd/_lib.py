@@ -91,6 +91,17 @@ SIGNATURES = {
     "esr_bucket_ids_by_owner": (c_int, [c_i32p, c_i64, c_int, c_i32p, c_i32p, c_i32p, c_vp, c_vp, c_size, c_vp]),
     "esr_bucket_ids_by_owner_multi": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_i32p, c_i32p, c_i32p, c_vp, c_vp, c_size,
                                               c_vp]),
+    "esr_comm_load": (c_int, [ctypes.c_char_p]),
+    "esr_comm_unique_id": (c_int, [c_vp]),
+    "esr_comm_init": (c_int, [c_vp, c_int, c_int, ctypes.POINTER(c_vp)]),
+    "esr_comm_count": (c_int, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "esr_comm_async_error": (c_int, [c_vp]),
+    "esr_comm_abort": (c_int, [c_vp]),
+    "esr_comm_destroy": (c_int, [c_vp]),
+    "esr_alltoall_bytes": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "esr_alltoall_ids": (c_int, [c_vp, c_i32p, c_vp, c_i32p, c_vp, c_vp]),
+    "esr_alltoall_rows": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "esr_alltoall_grads": (c_int, [c_vp, c_f32p, c_int, c_vp, c_f32p, c_vp, c_vp]),
 }
 
 

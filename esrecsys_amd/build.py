@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ_DIR = os.path.join(CSRC, "build")
 LIB_PATH = os.path.join(HERE, "libesr_hip.so")
 SOURCES = ["esr_core.hip", "esr_glove.hip", "esr_triplet.hip", "esr_inbatch.hip", "esr_inbatch3.hip", "esr_optim.hip", "esr_sort.hip",
-           "esr_retrieve.hip", "esr_probe.hip", "esr_spotify.hip"]
+           "esr_retrieve.hip", "esr_probe.hip", "esr_spotify.hip", "esr_comm.hip"]
 HEADERS = [os.path.join(CSRC, "esr_common.h"), os.path.join(HERE, "..", "include", "esr_hip.h")]
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -50,7 +50,7 @@ def build_library(force=False, verbose=False):
     if _stale(LIB_PATH, objs):
         # No rpath on purpose: in a torch process libamdhip64.so.7 is already loaded (torch's bundled
         # copy) and the loader binds to it by soname, so device pointers are shared with torch.
-        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))

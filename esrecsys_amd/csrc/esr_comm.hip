@@ -1,0 +1,242 @@
+// 8e: the row-shard exchange itself -- RCCL grouped send / recv over xGMI, issued on the caller's stream.
+//
+// The reference is single-device: nothing here replaces reference code.  RCCL is bound at run time
+// with dlopen (the process usually has torch's bundled librccl.so.1 loaded already; binding to THAT copy keeps one
+// RCCL per process), so libesr_hip.so carries no link-time dependency on it and loads on boxes without RCCL.
+//
+// On the 8-GPU xGMI full mesh every peer slice of an all-to-all rides its own direct link; the call pattern is
+// ncclGroupStart ; per peer ncclSend + ncclRecv ; ncclGroupEnd, in stream order with the kernels around it.
+#include <dlfcn.h>
+#include <string.h>
+#include <mutex>
+
+#include "esr_common.h"
+
+namespace {
+
+struct NcclUid {
+  char internal[128];
+};
+typedef void* nccl_comm_t;
+typedef int (*fn_get_uid)(NcclUid*);
+typedef int (*fn_init_rank)(nccl_comm_t*, int, NcclUid, int);
+typedef int (*fn_sendrecv)(const void*, size_t, int, int, nccl_comm_t, hipStream_t);
+typedef int (*fn_recv)(void*, size_t, int, int, nccl_comm_t, hipStream_t);
+typedef int (*fn_void)(void);
+typedef int (*fn_comm)(nccl_comm_t);
+typedef int (*fn_count)(nccl_comm_t, int*);
+typedef int (*fn_async)(nccl_comm_t, int*);
+typedef const char* (*fn_errstr)(int);
+
+struct Rccl {
+  void* handle = nullptr;
+  fn_get_uid get_uid = nullptr;
+  fn_init_rank init_rank = nullptr;
+  fn_sendrecv send = nullptr;
+  fn_recv recv = nullptr;
+  fn_void group_start = nullptr, group_end = nullptr;
+  fn_comm destroy = nullptr, abort = nullptr;
+  fn_count count = nullptr, user_rank = nullptr;
+  fn_async async_error = nullptr;
+  fn_errstr errstr = nullptr;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+
+struct EsrComm {
+  nccl_comm_t comm;
+  int world, rank;
+};
+
+constexpr int kNcclInt8 = 0;  // ncclInt8 / ncclChar: every exchange is counted in bytes
+
+int bind(const char* path) {
+  std::lock_guard<std::mutex> lk(g_rccl_mu);
+  if (g_rccl.handle) return ESR_OK;
+  void* h = nullptr;
+  if (path && path[0]) {
+    h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) {
+      esr::set_error("esr_comm_load: dlopen(%s) failed: %s", path, dlerror());
+      return ESR_ENODEVICE;
+    }
+  } else {
+    h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);  // the copy already in the process
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) {
+      esr::set_error("esr_comm_load: no librccl.so.1 in the process or on the loader path: %s", dlerror());
+      return ESR_ENODEVICE;
+    }
+  }
+  Rccl r;
+  r.handle = h;
+#define ESR_SYM(field, type, name)                                       \
+  r.field = reinterpret_cast<type>(dlsym(h, name));                      \
+  if (!r.field) {                                                        \
+    esr::set_error("esr_comm_load: %s not exported by librccl", name);   \
+    return ESR_ENODEVICE;                                                \
+  }
+  ESR_SYM(get_uid, fn_get_uid, "ncclGetUniqueId");
+  ESR_SYM(init_rank, fn_init_rank, "ncclCommInitRank");
+  ESR_SYM(send, fn_sendrecv, "ncclSend");
+  ESR_SYM(recv, fn_recv, "ncclRecv");
+  ESR_SYM(group_start, fn_void, "ncclGroupStart");
+  ESR_SYM(group_end, fn_void, "ncclGroupEnd");
+  ESR_SYM(destroy, fn_comm, "ncclCommDestroy");
+  ESR_SYM(abort, fn_comm, "ncclCommAbort");
+  ESR_SYM(count, fn_count, "ncclCommCount");
+  ESR_SYM(user_rank, fn_count, "ncclCommUserRank");
+  ESR_SYM(async_error, fn_async, "ncclCommGetAsyncError");
+  ESR_SYM(errstr, fn_errstr, "ncclGetErrorString");
+#undef ESR_SYM
+  g_rccl = r;
+  return ESR_OK;
+}
+
+int nccl_fail(const char* what, int rc) {
+  esr::set_error("%s: %s (ncclResult %d)", what, g_rccl.errstr ? g_rccl.errstr(rc) : "?", rc);
+  return ESR_ELAUNCH;
+}
+
+#define ESR_NCCL(call, what)                   \
+  do {                                         \
+    int rc_ = (call);                          \
+    if (rc_ != 0) return nccl_fail(what, rc_); \
+  } while (0)
+
+// One all-to-all(v): slice p of `send` (send_bytes[p] bytes) goes to peer p, slice p of `recv` comes from it.
+// Every argument is validated BEFORE ncclGroupStart, so nothing can leave a group open.
+int alltoall(const char* who, esr_comm_t comm_, const void* send, const int64_t* send_counts, void* recv,
+             const int64_t* recv_counts, int64_t unit, esr_stream_t stream) {
+  EsrComm* c = reinterpret_cast<EsrComm*>(comm_);
+  ESR_REQUIRE(c && c->comm, "%s: null communicator", who);
+  ESR_REQUIRE(send_counts && recv_counts, "%s: null count arrays (host int64 [world])", who);
+  ESR_REQUIRE(unit > 0, "%s: element size must be positive", who);
+  int64_t st = 0, rt = 0;
+  for (int p = 0; p < c->world; ++p) {
+    ESR_REQUIRE(send_counts[p] >= 0 && recv_counts[p] >= 0, "%s: negative count for peer %d", who, p);
+    st += send_counts[p];
+    rt += recv_counts[p];
+  }
+  ESR_REQUIRE(st == 0 || send, "%s: null send buffer", who);
+  ESR_REQUIRE(rt == 0 || recv, "%s: null recv buffer", who);
+  if (st == 0 && rt == 0) return ESR_OK;
+  hipStream_t s = esr::as_stream(stream);
+  const char* sp = static_cast<const char*>(send);
+  char* rp = static_cast<char*>(recv);
+  ESR_NCCL(g_rccl.group_start(), who);
+  int first = 0;
+  for (int p = 0; p < c->world; ++p) {
+    const size_t sb = (size_t)(send_counts[p] * unit), rb = (size_t)(recv_counts[p] * unit);
+    if (sb && !first) first = g_rccl.send(sp, sb, kNcclInt8, p, c->comm, s);
+    if (rb && !first) first = g_rccl.recv(rp, rb, kNcclInt8, p, c->comm, s);
+    sp += sb;
+    rp += rb;
+  }
+  const int end = g_rccl.group_end();  // always closed, also after a failed send / recv
+  if (first) return nccl_fail(who, first);
+  if (end) return nccl_fail(who, end);
+  return ESR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int esr_comm_load(const char* librccl_path) { return bind(librccl_path); }
+
+int esr_comm_unique_id(void* uid128) {
+  ESR_REQUIRE(uid128, "esr_comm_unique_id: null output (host, 128 bytes)");
+  if (int rc = bind(nullptr)) return rc;
+  NcclUid uid;
+  ESR_NCCL(g_rccl.get_uid(&uid), "esr_comm_unique_id");
+  memcpy(uid128, uid.internal, sizeof(uid.internal));
+  return ESR_OK;
+}
+
+int esr_comm_init(const void* uid128, int world, int rank, esr_comm_t* comm) {
+  ESR_REQUIRE(uid128 && comm, "esr_comm_init: null argument");
+  ESR_REQUIRE(world >= 1 && rank >= 0 && rank < world, "esr_comm_init: need 0 <= rank < world (got %d, %d)", rank,
+              world);
+  if (int rc = bind(nullptr)) return rc;
+  NcclUid uid;
+  memcpy(uid.internal, uid128, sizeof(uid.internal));
+  nccl_comm_t nc = nullptr;
+  ESR_NCCL(g_rccl.init_rank(&nc, world, uid, rank), "esr_comm_init");
+  int seen = 0;
+  ESR_NCCL(g_rccl.count(nc, &seen), "esr_comm_init (ncclCommCount)");
+  if (seen != world) {
+    g_rccl.abort(nc);
+    esr::set_error("esr_comm_init: communicator has %d ranks, expected %d", seen, world);
+    return ESR_ELAUNCH;
+  }
+  EsrComm* c = new EsrComm{nc, world, rank};
+  *comm = c;
+  return ESR_OK;
+}
+
+int esr_comm_count(esr_comm_t comm, int* world, int* rank) {
+  EsrComm* c = reinterpret_cast<EsrComm*>(comm);
+  ESR_REQUIRE(c && c->comm, "esr_comm_count: null communicator");
+  int w = 0, r = 0;
+  ESR_NCCL(g_rccl.count(c->comm, &w), "esr_comm_count");
+  ESR_NCCL(g_rccl.user_rank(c->comm, &r), "esr_comm_count (ncclCommUserRank)");
+  if (world) *world = w;
+  if (rank) *rank = r;
+  return ESR_OK;
+}
+
+int esr_comm_async_error(esr_comm_t comm) {
+  EsrComm* c = reinterpret_cast<EsrComm*>(comm);
+  ESR_REQUIRE(c && c->comm, "esr_comm_async_error: null communicator");
+  int err = 0;
+  ESR_NCCL(g_rccl.async_error(c->comm, &err), "esr_comm_async_error");
+  if (err) return nccl_fail("esr_comm_async_error: asynchronous failure", err);
+  return ESR_OK;
+}
+
+int esr_comm_abort(esr_comm_t comm) {
+  EsrComm* c = reinterpret_cast<EsrComm*>(comm);
+  if (!c) return ESR_OK;
+  int rc = c->comm ? g_rccl.abort(c->comm) : 0;
+  delete c;
+  if (rc) return nccl_fail("esr_comm_abort", rc);
+  return ESR_OK;
+}
+
+int esr_comm_destroy(esr_comm_t comm) {
+  EsrComm* c = reinterpret_cast<EsrComm*>(comm);
+  if (!c) return ESR_OK;
+  int rc = c->comm ? g_rccl.destroy(c->comm) : 0;
+  delete c;
+  if (rc) return nccl_fail("esr_comm_destroy", rc);
+  return ESR_OK;
+}
+
+int esr_alltoall_bytes(esr_comm_t comm, const void* send, const int64_t* send_bytes, void* recv,
+                       const int64_t* recv_bytes, esr_stream_t stream) {
+  return alltoall("esr_alltoall_bytes", comm, send, send_bytes, recv, recv_bytes, 1, stream);
+}
+
+int esr_alltoall_ids(esr_comm_t comm, const int32_t* send_ids, const int64_t* send_counts, int32_t* recv_ids,
+                     const int64_t* recv_counts, esr_stream_t stream) {
+  return alltoall("esr_alltoall_ids", comm, send_ids, send_counts, recv_ids, recv_counts, 4, stream);
+}
+
+int esr_alltoall_rows(esr_comm_t comm, const void* send_rows, int dtype, int D, const int64_t* send_counts,
+                      void* recv_rows, const int64_t* recv_counts, esr_stream_t stream) {
+  ESR_REQUIRE(dtype == ESR_F32 || dtype == ESR_BF16, "esr_alltoall_rows: dtype must be ESR_F32 or ESR_BF16");
+  ESR_REQUIRE(D > 0, "esr_alltoall_rows: D must be positive");
+  return alltoall("esr_alltoall_rows", comm, send_rows, send_counts, recv_rows, recv_counts,
+                  (int64_t)D * (dtype == ESR_BF16 ? 2 : 4), stream);
+}
+
+int esr_alltoall_grads(esr_comm_t comm, const float* send_grads, int D, const int64_t* send_counts,
+                       float* recv_grads, const int64_t* recv_counts, esr_stream_t stream) {
+  ESR_REQUIRE(D > 0, "esr_alltoall_grads: D must be positive");
+  return alltoall("esr_alltoall_grads", comm, send_grads, send_counts, recv_grads, recv_counts, (int64_t)D * 4,
+                  stream);
+}
+
+}  // extern "C"

@@ -290,6 +290,41 @@ int esr_unpermute_rows(const void* rows, int dtype, int D, const int32_t* perm, 
 int esr_unpermute_rows_bf16_to_f32(const void* rows_bf16, int D, const int32_t* perm, int64_t n, float* out,
                                    esr_stream_t stream);
 
+/* ---- 8e: the exchange itself -- all-to-all(v) of ids / rows / gradient rows over RCCL (xGMI) -------------------
+ * Build-defined (the reference is single-device).  RCCL is bound at run time with dlopen: the library
+ * has no link-time dependency on it.  An exchange is ncclGroupStart ; per peer ncclSend + ncclRecv ; ncclGroupEnd
+ * enqueued on `stream`, i.e. in stream order with the kernels around it (no internal stream, no hand-over events);
+ * on the xGMI full mesh every peer slice rides its own direct link.
+ *   esr_comm_load       host: bind librccl (path NULL/"" = the librccl.so.1 already loaded in the process, else the
+ *                       loader path).  Optional: the other entry points call it with NULL on first use.
+ *   esr_comm_unique_id  host: 128 bytes of ncclUniqueId (rank 0 calls it and hands the bytes to every rank).
+ *   esr_comm_init       COLLECTIVE over the `world` ranks, on the calling thread's current HIP device.
+ *   esr_comm_count      host out-params: what RCCL itself reports for this communicator.
+ *   esr_comm_async_error  ESR_OK or ESR_ELAUNCH when RCCL has recorded an asynchronous failure.
+ *   esr_comm_abort / esr_comm_destroy  free the communicator (abort also terminates enqueued operations).
+ * send_counts / recv_counts are HOST int64 [world] arrays: slice p of the send buffer (send_counts[p] ids / rows)
+ * goes to peer p, slice p of the receive buffer comes from peer p.  Arguments are validated before the group opens
+ * and the group is always closed, so a failing call never leaves peers inside an open group. */
+typedef void* esr_comm_t;
+int esr_comm_load(const char* librccl_path);
+int esr_comm_unique_id(void* uid128);
+int esr_comm_init(const void* uid128, int world, int rank, esr_comm_t* comm);
+int esr_comm_count(esr_comm_t comm, int* world, int* rank);
+int esr_comm_async_error(esr_comm_t comm);
+int esr_comm_abort(esr_comm_t comm);
+int esr_comm_destroy(esr_comm_t comm);
+int esr_alltoall_bytes(esr_comm_t comm, const void* send, const int64_t* send_bytes, void* recv,
+                       const int64_t* recv_bytes, esr_stream_t stream);
+/* int32 virtual local rows -> their owners (step 2 of SURVEY 8e). */
+int esr_alltoall_ids(esr_comm_t comm, const int32_t* send_ids, const int64_t* send_counts, int32_t* recv_ids,
+                     const int64_t* recv_counts, esr_stream_t stream);
+/* looked-up rows [n, D] in the table dtype, owners -> requesters (step 3). */
+int esr_alltoall_rows(esr_comm_t comm, const void* send_rows, int dtype, int D, const int64_t* send_counts,
+                      void* recv_rows, const int64_t* recv_counts, esr_stream_t stream);
+/* fp32 gradient rows [n, D], requesters -> owners (step 5). */
+int esr_alltoall_grads(esr_comm_t comm, const float* send_grads, int D, const int64_t* send_counts,
+                       float* recv_grads, const int64_t* recv_counts, esr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

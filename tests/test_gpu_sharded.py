@@ -18,6 +18,8 @@ def pg(dev):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     yield dist
+    from esrecsys_amd import rccl
+    rccl.reset()
     dist.destroy_process_group()
 
 
