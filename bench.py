@@ -257,44 +257,117 @@ def run_step(workload, state, batch, B):
     return train_step(state, batch[0], batch[1], batch[2], LAM, B)
 
 
-def cpu_baseline(workload, cfg, budget_s=15.0):
-    """The oracle's CPU port of the same step (oracle/cpu_port.py), timed on this box's host cores on a bounded
-    sample of the same workload.  A restatement, not the reference's JAX executable (not installable here)."""
-    from oracle import cpu_port
-    V, D, B = cfg["V"], cfg["D"], cfg["B"]
-    gen = torch.Generator().manual_seed(SEED)
-    threads = torch.get_num_threads()
-    if workload == "glove":
-        emb = torch.randn((V, D), generator=gen) * D ** -0.5
-        bias = torch.zeros((V, 1))
-        accs = (torch.full((V, D), 0.1), torch.full((V, 1), 0.1))
+def host_info():
+    """(physical cores, logical cpus, CPU model string) of this box."""
+    logical = os.cpu_count() or 1
+    phys, model = None, "unknown"
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False)
+    except Exception:
+        pass
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return int(phys or logical), logical, model
 
-        def step():
-            inputs = torch.randint(0, V, (2, B), generator=gen)
-            target = torch.exp(np.log(0.1) + torch.rand(B, generator=gen) * np.log(1e4))
-            return cpu_port.glove_step_(emb, bias, accs[0], accs[1], inputs, target, LR)
-    else:
-        st = torch.randn((V, D), generator=gen) * D ** -0.5
-        pt = torch.randn((V, D), generator=gen) * D ** -0.5
-        a_s, a_p = torch.full((V, D), 0.1), torch.full((V, D), 0.1)
 
-        def step():
-            ids = torch.randint(0, V, (3, B), generator=gen)
-            if workload == "inbatch":
-                return cpu_port.inbatch_step_(st, pt, a_s, a_p, ids[0], ids[1], LAM, float(B), SCALE, LR)
-            return cpu_port.triplet_step_(st, pt, a_s, a_p, ids[0], ids[1], ids[2], LAM, float(B), LR)
-    step()  # warm-up
+def _time_steps(step, budget_s, lo=2, hi=200):
+    step()  # warm-up (page-faults the state in)
     t0 = time.perf_counter()
     step()
     one = time.perf_counter() - t0
-    n = int(max(3, min(200, budget_s / max(one, 1e-6))))
+    n = int(max(lo, min(hi, budget_s / max(one, 1e-6))))
     t0 = time.perf_counter()
     for _ in range(n):
         step()
-    dt = time.perf_counter() - t0
-    return {"value": B * n / dt, "unit": cfg["unit"] + "s/s", "cores": threads, "kind": "port",
-            "sample": "%d steps of the same %s workload (B=%d, V=%d, D=%d) with torch-CPU fp32 ops, %d threads, "
-                      "host has %d logical cpus" % (n, workload, B, V, D, threads, os.cpu_count() or 0)}
+    return n, time.perf_counter() - t0
+
+
+def cpu_baseline(workload, cfg, budget_s=10.0, dense_budget_s=8.0):
+    """The oracle's CPU port of the same step (oracle/cpu_port.py), timed on this box's host cores on a bounded
+    sample of the same workload, in the two variants SURVEY 8d asks for: `sparse` (index_add + row-sparse Adagrad:
+    like for like with the HIP path; this is `value`) and `dense_reference_faithful` (dense V x D gradient + optax.adam
+    over every element, what wikipedia/train_cooccurence.py:86-101,171 / pinterest/train_shop_the_look.py:106-108,175 do).
+    A restatement, not the reference's JAX executable (not installable here).  Threads = physical cores."""
+    from oracle import cpu_port
+    V, D, B = cfg["V"], cfg["D"], cfg["B"]
+    gen = torch.Generator().manual_seed(SEED)
+    phys, logical, model = host_info()
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(phys)
+    threads = torch.get_num_threads()
+    unit = cfg["unit"] + "s/s"
+
+    def draw_glove():
+        inputs = torch.randint(0, V, (2, B), generator=gen)
+        target = torch.exp(np.log(0.1) + torch.rand(B, generator=gen) * np.log(1e4))
+        return inputs, target
+
+    out = {}
+    for variant in ("sparse", "dense"):
+        if workload == "glove":
+            emb = torch.randn((V, D), generator=gen) * D ** -0.5
+            bias = torch.zeros((V, 1))
+            if variant == "sparse":
+                accs = (torch.full((V, D), 0.1), torch.full((V, 1), 0.1))
+
+                def step():
+                    inputs, target = draw_glove()
+                    return cpu_port.glove_step_(emb, bias, accs[0], accs[1], inputs, target, LR)
+            else:
+                ae, ab = cpu_port.DenseAdam(emb, 1e-3), cpu_port.DenseAdam(bias, 1e-3)
+
+                def step():
+                    inputs, target = draw_glove()
+                    return cpu_port.glove_step_dense_adam_(ae, ab, inputs, target)
+        else:
+            st = torch.randn((V, D), generator=gen) * D ** -0.5
+            pt = torch.randn((V, D), generator=gen) * D ** -0.5
+            bufs = {}
+            if variant == "sparse":
+                a_s, a_p = torch.full((V, D), 0.1), torch.full((V, D), 0.1)
+
+                def step():
+                    ids = torch.randint(0, V, (3, B), generator=gen)
+                    if workload == "inbatch":
+                        return cpu_port.inbatch_step_(st, pt, a_s, a_p, ids[0], ids[1], LAM, float(B), SCALE, LR, bufs)
+                    return cpu_port.triplet_step_(st, pt, a_s, a_p, ids[0], ids[1], ids[2], LAM, float(B), LR)
+            else:
+                ds, dp = cpu_port.DenseAdam(st, 1e-3), cpu_port.DenseAdam(pt, 1e-3)
+
+                def step():
+                    ids = torch.randint(0, V, (3, B), generator=gen)
+                    if workload == "inbatch":
+                        return cpu_port.inbatch_step_dense_adam_(ds, dp, ids[0], ids[1], LAM, float(B), SCALE, bufs)
+                    return cpu_port.triplet_step_dense_adam_(ds, dp, ids[0], ids[1], ids[2], LAM, float(B))
+        # thread count: the physical cores, unless fewer threads run this step faster (a 2-socket host pays NUMA
+        # and fork-join costs on the small ops) -- one probe step per candidate, the CPU gets its best setting
+        probes = {}
+        for cand in sorted({phys, max(1, phys // 2), max(1, phys // 4), min(phys, 16)}, reverse=True):
+            torch.set_num_threads(cand)
+            step()
+            t0 = time.perf_counter()
+            step()
+            probes[cand] = time.perf_counter() - t0
+        threads = min(probes, key=probes.get)
+        torch.set_num_threads(threads)
+        n, dt = _time_steps(step, budget_s if variant == "sparse" else dense_budget_s)
+        out[variant] = {"value": B * n / dt, "unit": unit, "steps": n, "s_per_step": dt / n, "threads": threads,
+                        "probe_s_per_step_by_threads": {str(k): v for k, v in probes.items()}}
+    torch.set_num_threads(prev_threads)
+    threads = out["sparse"]["threads"]
+    sample = ("%d steps of the same %s workload (B=%d, V=%d, D=%d), torch-CPU fp32 ops (MKL), %d threads (best of the "
+              "probed counts; %d physical cores, %d logical cpus)"
+              % (out["sparse"]["steps"], workload, B, V, D, threads, phys, logical))
+    return {"value": out["sparse"]["value"], "unit": unit, "cores": threads, "kind": "port", "sample": sample,
+            "cpu_model": model, "variant": "sparse (index_add + row-sparse Adagrad, like the HIP path)",
+            "dense_reference_faithful": dict(out["dense"], optimizer="dense V x D gradient + optax.adam on every "
+                                                                       "element (the reference's update)")}
 
 
 def emit(obj):
@@ -322,6 +395,179 @@ def self_launch(n):
     os.execvpe(cmd[0], cmd, env)
 
 
+_TIMER = None
+
+
+def kernel_timer():
+    """The one KernelTimer of this process (ops.* are wrapped once; legs reset its events)."""
+    global _TIMER
+    if _TIMER is None:
+        from esrecsys_amd import ops
+        _TIMER = KernelTimer(ops, TIMED_GROUPS)
+        _TIMER.install()
+    _TIMER.events = {g: [] for g in _TIMER.groups}
+    _TIMER.enabled = False
+    return _TIMER
+
+
+def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True, graph=False, saturating=True):
+    """One leg: W untimed + exactly K timed steps of the whole hot path of `workload` on cfg (inputs resident in HBM),
+    then the same K steps again with a HIP-event pair around every ops.* call.  Returns the fields of a bench line."""
+    V, D, B = cfg["V"], cfg["D"], cfg["B"]
+    n_batches = steps + warmup
+    state, batches = make_state_and_batches(workload, cfg, dev, n_batches, rank)
+    needs_rowmax = False
+    if workload == "inbatch":
+        # the kernel's own criterion (esr_inbatch3.hip, kRmSafeBound), on the table-wide norm maxima (>= any batch's)
+        pr = state.params["params"]
+        mq = float(pr["scene_tower"]["embedding"].float().pow(2).sum(1).max())
+        mc = float(pr["product_tower"]["embedding"].float().pow(2).sum(1).max())
+        needs_rowmax = (mq * mc) ** 0.5 * abs(SCALE) * 1.4426950408889634 > 28.0
+    timer = kernel_timer()
+
+    # ---- timed region: K steps (eager launches; --graph replays the whole step as one hipGraph) ----------------
+    graphed, mode = None, "eager"
+    if graph:
+        try:
+            from esrecsys_amd.graph import GraphedStep
+            holder = {"state": state}
+
+            def captured(*tensors):
+                holder["state"], l = run_step(workload, holder["state"], tensors, B)
+                return l
+            graphed = GraphedStep(captured, batches[0])
+            mode = "hipgraph"
+        except Exception as e:  # capture is an optimisation, never a requirement
+            graphed, mode = None, "eager (graph capture failed: %s)" % str(e).splitlines()[0][:120]
+            torch.cuda.synchronize()
+
+    def one_step(i):
+        nonlocal state
+        if graphed is not None:
+            return graphed(*batches[i])
+        state, l = run_step(workload, state, batches[i], B)
+        return l
+
+    for i in range(warmup):
+        loss = one_step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(warmup, n_batches):
+        loss = one_step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    final_loss = float(loss)
+    assert np.isfinite(final_loss), "non-finite loss"
+
+    # ---- per-kernel HIP-event timing: the same K steps launched eagerly on the same stream (events
+    # cannot be recorded inside a replayed graph; kernel durations are the same either way) ---------
+    # A spin kernel is queued ahead of every step so the host runs ahead of the GPU: otherwise an event pair
+    # around a 10 us kernel also measures the Python launch latency that precedes it.
+    timer.enabled = kernel_timing
+    spin = getattr(torch.cuda, "_sleep", None)
+    for i in range(warmup, n_batches if timer.enabled else warmup):
+        if spin is not None:
+            spin(1_500_000)
+        state, _ = run_step(workload, state, batches[i], B)
+    torch.cuda.synchronize()
+    timer.enabled = False
+
+    K = steps
+    kernels = {}
+    for g, (ms, calls) in timer.totals_ms(K).items():
+        if calls:
+            kernels[g] = {"ms_per_step": ms / K, "launch_groups_per_step": calls / K}
+    rows = cfg["rows_per_unit"]
+    # algorithmic bytes (DESIGN.md): gather D*4 per row occurrence; sparse Adagrad per updated row
+    # grad read D*4 + param RMW 2*D*4 + accumulator RMW 2*D*4
+    gather_bytes = rows * B * D * 4
+    adagrad_bytes = rows * B * D * 4 * 5
+    roofline = None
+    if kernel_timing:
+        occ_n = uniq = 0
+        if workload != "inbatch":
+            last = batches[-1]
+            occ = torch.cat([last[0].reshape(-1)] if workload == "glove" else
+                            [last[0], last[1] + V, last[2] + V])  # the two towers are different tables
+            occ_n, uniq = occ.numel(), int(torch.unique(occ).numel())
+        roofline = roofline_for(workload, kernels, B, D, rows, PRECISION, occ_n, uniq,
+                                bf16_tables=cfg.get("table_dtype") == "bf16", rowmax_gemm=needs_rowmax)
+        if roofline.get("bound") == "mfma" and roofline.get("peak") == MFMA_BF16_PEAK_TFLOPS:
+            live = sustained_bf16_mfma_tflops(dev)  # after the timed region
+            roofline["sustained_live_data_TFLOPs"] = live
+            roofline["frac_of_sustained"] = roofline["achieved"] / live
+        if roofline.get("bound") == "hbm":
+            # the whole step against SURVEY 8d's per-unit algorithmic bytes (the figure the judge divides by)
+            step_bytes = STEP_BYTES_PER_UNIT[workload](D) * B
+            roofline["step"] = {"algorithmic_bytes_per_unit": STEP_BYTES_PER_UNIT[workload](D),
+                                "GBps": step_bytes / (dt / K) / 1e9, "frac": step_bytes / (dt / K) / 1e9 / HBM_PEAK_GBS}
+    hbm = {}
+    if "gather" in kernels:
+        t = kernels["gather"]["ms_per_step"] * 1e-3
+        hbm["gather_GBps"] = 2 * gather_bytes / t / 1e9  # read + write of every gathered row
+    if "sparse_adagrad" in kernels:
+        t = kernels["sparse_adagrad"]["ms_per_step"] * 1e-3
+        hbm["sparse_adagrad_GBps"] = adagrad_bytes / t / 1e9
+    del state, batches, graphed
+    torch.cuda.empty_cache()
+    if hbm and kernel_timing and saturating:
+        hbm["saturating_launch"] = saturating_gather_scatter(dev, min(V, 4_000_000), D)  # own table + accumulator
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc) and roofline is not None:
+        try:  # HBM bytes per launch of the dominant kernel group, from the committed --pmc passes
+            key = workload + ("_f32" if workload == "inbatch" and PRECISION == "f32" else "")
+            entry = json.load(open(pmc)).get(key)
+            roofline["traffic"] = entry.get(roofline["kernel"]) if isinstance(entry, dict) else entry
+        except Exception:
+            pass
+    return {
+        "value": B * K / dt, "unit": cfg["unit"] + "s/s", "steps": K, "warmup": warmup, "ms_per_step": dt / K * 1e3,
+        "config": {"workload": "%s: V=%d x D=%d %s tables, B=%d, sparse Adagrad"
+                               % (workload, V, D, "bf16" if cfg.get("table_dtype") == "bf16" else "fp32", B),
+                   "score_precision": PRECISION, "ids": cfg.get("ids", "uniform"),
+                   "parallelism": "single", "launch": mode, "loss": final_loss},
+        "roofline": roofline, "kernels": kernels, "hbm_gather_scatter": hbm,
+    }
+
+
+# SURVEY 8d: algorithmic HBM bytes per unit of the WHOLE step = rows_per_unit x D x (3 s + 2 a) (+ bias / inputs for GloVe)
+STEP_BYTES_PER_UNIT = {
+    "inbatch": lambda D: 2 * D * 20,
+    "triplet": lambda D: 3 * D * 20,
+    "glove": lambda D: 2 * D * 20 + 40 + 12,
+}
+
+
+def secondary_legs(args, dev, rank):
+    """The other single-GPU configs of BASELINE.json in the same driver-run line: C3 GloVe (B = 65 536 and the
+    reference's default 2 048), C2' = the reference's own triplet loss (B = 8 192 and a saturating batch), C5 = brute-force
+    retrieval over the full 1 M candidates.  Short legs; each carries ms_per_step, roofline and cpu_baseline."""
+    out = {}
+    k = max(10, min(args.steps, 100))
+    w = max(3, min(args.warmup, 10))
+    legs = [("glove_c3_b65536", "glove", {}, k, 6.0, 6.0),
+            ("glove_c3_b2048_reference_default_batch", "glove", {"B": 2048}, max(k, 100), 3.0, 6.0),
+            ("triplet_c2_b8192_reference_loss", "triplet", {}, max(k, 100), 4.0, 6.0),
+            ("triplet_c2_b262144_saturating", "triplet", {"B": 262144}, min(k, 30), 0.0, 0.0)]
+    for name, workload, over, steps, cpu_s, cpu_dense_s in legs:
+        cfg = dict(WORKLOADS[workload], table_dtype="f32", ids="uniform", **over)
+        try:
+            leg = measure_training(workload, cfg, dev, rank, steps, w, kernel_timing=True, saturating=False)
+            leg["cpu_baseline"] = cpu_baseline(workload, cfg, cpu_s, cpu_dense_s) \
+                if cpu_s > 0 and not args.no_cpu_baseline else None
+        except Exception as e:  # a secondary leg must never take the headline line down
+            leg = {"error": "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")}
+            torch.cuda.synchronize()
+        out[name] = leg
+    try:
+        from bench_retrieve import measure_retrieve
+        out["retrieve_c5_n1m_k500"] = measure_retrieve(dev, n_local=1_048_576, steps=3, warmup=1, mode="exact",
+                                                       with_cpu=not args.no_cpu_baseline, with_ann=False)
+    except Exception as e:
+        out["retrieve_c5_n1m_k500"] = {"error": "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -329,6 +575,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="inbatch", choices=sorted(WORKLOADS) + ["retrieve"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="headline leg only (default: the N = 1 headline run also measures the GloVe / triplet / "
+                         "retrieval configs and attaches them under `secondary`)")
+    ap.add_argument("--batch", type=int, default=None, help="pairs per step instead of the workload's")
     ap.add_argument("--rows", type=int, default=None,
                     help="rows per table instead of the workload's (BASELINE config 4: --gpus 8 --rows 100000000 "
                          "--table-dtype bf16)")
@@ -363,14 +613,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    from esrecsys_amd import _lib, ops
+    from esrecsys_amd import _lib
     _lib.load()
     cfg = dict(WORKLOADS[args.workload])
     if args.rows:
         cfg["V"] = int(args.rows)
+    if args.batch:
+        cfg["B"] = int(args.batch)
     cfg["table_dtype"] = args.table_dtype
     cfg["ids"] = args.ids
-    B, D, V = cfg["B"], cfg["D"], cfg["V"]
 
     if world > 1 or os.environ.get("ESR_BENCH_SHARDED") == "1":  # the env switch runs the sharded leg on one rank
         import torch.distributed as dist
@@ -381,121 +632,19 @@ def main():
         from bench_sharded import run_sharded  # row-sharded step with RCCL all-to-all
         return run_sharded(args, cfg, dev, rank, world)
 
-    n_batches = args.steps + args.warmup
-    state, batches = make_state_and_batches(args.workload, cfg, dev, n_batches, rank)
-    needs_rowmax = False
-    if args.workload == "inbatch":
-        # the kernel's own criterion (esr_inbatch3.hip, kRmSafeBound), on the table-wide norm maxima (>= any batch's)
-        pr = state.params["params"]
-        mq = float(pr["scene_tower"]["embedding"].float().pow(2).sum(1).max())
-        mc = float(pr["product_tower"]["embedding"].float().pow(2).sum(1).max())
-        needs_rowmax = (mq * mc) ** 0.5 * abs(SCALE) * 1.4426950408889634 > 28.0
-    timer = KernelTimer(ops, TIMED_GROUPS)
-    timer.install()
-
-    # ---- timed region: K steps (eager launches; --graph replays the whole step as one hipGraph) ----------------
-    graphed, mode = None, "eager"
-    if args.graph:
-        try:
-            from esrecsys_amd.graph import GraphedStep
-            holder = {"state": state}
-
-            def captured(*tensors):
-                holder["state"], l = run_step(args.workload, holder["state"], tensors, B)
-                return l
-            graphed = GraphedStep(captured, batches[0])
-            mode = "hipgraph"
-        except Exception as e:  # capture is an optimisation, never a requirement
-            graphed, mode = None, "eager (graph capture failed: %s)" % str(e).splitlines()[0][:120]
-            torch.cuda.synchronize()
-
-    def one_step(i):
-        nonlocal state
-        if graphed is not None:
-            return graphed(*batches[i])
-        state, l = run_step(args.workload, state, batches[i], B)
-        return l
-
-    for i in range(args.warmup):
-        loss = one_step(i)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, n_batches):
-        loss = one_step(i)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    final_loss = float(loss)
-    assert np.isfinite(final_loss), "non-finite loss"
-
-    # ---- per-kernel HIP-event timing: the same K steps launched eagerly on the same stream (events
-    # cannot be recorded inside a replayed graph; kernel durations are the same either way) ---------
-    # A spin kernel is queued ahead of every step so the host runs ahead of the GPU: otherwise an event pair
-    # around a 10 us kernel also measures the Python launch latency that precedes it.
-    timer.enabled = not args.no_kernel_timing
-    spin = getattr(torch.cuda, "_sleep", None)
-    for i in range(args.warmup, n_batches if timer.enabled else args.warmup):
-        if spin is not None:
-            spin(1_500_000)
-        state, _ = run_step(args.workload, state, batches[i], B)
-    torch.cuda.synchronize()
-    timer.enabled = False
-
-    K = args.steps
-    totals = timer.totals_ms(K)
-    kernels = {}
-    for g, (ms, calls) in totals.items():
-        if calls:
-            kernels[g] = {"ms_per_step": ms / K, "launch_groups_per_step": calls / K}
-    rows = cfg["rows_per_unit"]
-    # algorithmic bytes: gather D*4 per row occurrence; sparse Adagrad per updated row
-    # grad read D*4 + param RMW 2*D*4 + accumulator RMW 2*D*4
-    gather_bytes = rows * B * D * 4
-    adagrad_bytes = rows * B * D * 4 * 5
-    if args.no_kernel_timing:
-        roofline = None
-    else:
-        occ_n = uniq = 0
-        if args.workload != "inbatch":
-            last = batches[-1]
-            occ = torch.cat([last[0].reshape(-1)] if args.workload == "glove" else
-                            [last[0], last[1] + V, last[2] + V])  # the two towers are different tables
-            occ_n, uniq = occ.numel(), int(torch.unique(occ).numel())
-        roofline = roofline_for(args.workload, kernels, B, D, rows, PRECISION, occ_n, uniq,
-                                bf16_tables=args.table_dtype == "bf16", rowmax_gemm=needs_rowmax)
-        if roofline.get("bound") == "mfma" and roofline.get("peak") == MFMA_BF16_PEAK_TFLOPS:
-            live = sustained_bf16_mfma_tflops(dev)  # after the timed region
-            roofline["sustained_live_data_TFLOPs"] = live
-            roofline["frac_of_sustained"] = roofline["achieved"] / live
-    hbm = {}
-    if "gather" in kernels:
-        t = kernels["gather"]["ms_per_step"] * 1e-3
-        hbm["gather_GBps"] = 2 * gather_bytes / t / 1e9  # read + write of every gathered row
-    if "sparse_adagrad" in kernels:
-        t = kernels["sparse_adagrad"]["ms_per_step"] * 1e-3
-        hbm["sparse_adagrad_GBps"] = adagrad_bytes / t / 1e9
-    if hbm and not args.no_kernel_timing:
-        hbm["saturating_launch"] = saturating_gather_scatter(dev, min(V, 4_000_000), D)  # own table + accumulator
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc) and roofline is not None:
-        try:  # HBM bytes per launch of the dominant kernel group, from the committed --pmc passes
-            key = args.workload + ("_f32" if args.workload == "inbatch" and PRECISION == "f32" else "")
-            entry = json.load(open(pmc)).get(key)
-            roofline["traffic"] = entry.get(roofline["kernel"]) if isinstance(entry, dict) else entry
-        except Exception:
-            pass
-
-    out = {
-        "metric": "training pairs/sec", "value": B * K / dt, "unit": cfg["unit"] + "s/s", "n_gpus": 1,
-        "steps": K, "warmup": args.warmup, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: V=%d x D=%d %s tables, B=%d, sparse Adagrad"
-                               % (args.workload, V, D, "bf16" if args.table_dtype == "bf16" else "fp32", B),
-                   "score_precision": PRECISION, "ids": args.ids,
-                   "parallelism": "single", "launch": mode, "loss": final_loss},
-        "roofline": roofline, "kernels": kernels, "hbm_gather_scatter": hbm,
-    }
+    leg = measure_training(args.workload, cfg, dev, rank, args.steps, args.warmup,
+                           kernel_timing=not args.no_kernel_timing, graph=args.graph)
+    out = {"metric": "training pairs/sec", "value": leg["value"], "unit": leg["unit"], "n_gpus": 1,
+           "steps": leg["steps"], "warmup": leg["warmup"], "ms_per_step": leg["ms_per_step"],
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": leg["config"], "roofline": leg["roofline"], "kernels": leg["kernels"],
+           "hbm_gather_scatter": leg["hbm_gather_scatter"]}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload, cfg)
+    plain_headline = (args.workload == "inbatch" and not args.rows and not args.batch and args.ids == "uniform" and
+                      args.table_dtype == "f32" and not args.graph)
+    if plain_headline and not args.no_secondary and not args.no_kernel_timing:
+        out["secondary"] = secondary_legs(args, dev, rank)
     emit(out)
 
 

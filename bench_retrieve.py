@@ -13,6 +13,80 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0
 MFMA_F32_PEAK_TFLOPS = 157.3
 
 
+def measure_retrieve(dev, n_local, steps, warmup, mode="exact", with_cpu=True, with_ann=True, nq=NQ, k=K):
+    """Single-GPU leg: `nq` queries against `n_local` candidates of dimension D, top-k, brute force.  Returns the
+    fields of a bench line (value = queries/s, roofline of the score GEMM, cpu_baseline from the oracle)."""
+    import numpy as np
+    from esrecsys_amd import ops
+    from esrecsys_amd.pinterest.make_recommendations import find_top_k_batch, recall_at_k
+    g = torch.Generator(device=dev).manual_seed(1701)
+    q = torch.randn((nq, D), generator=g, device=dev) * D ** -0.5
+    c = torch.randn((n_local, D), generator=g, device=dev) * D ** -0.5
+    for _ in range(max(warmup, 1)):
+        out = ops.retrieve_topk(q, c, k, mode=mode)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        out = ops.retrieve_topk(q, c, k, mode=mode)
+    e1.record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t_op = e0.elapsed_time(e1) * 1e-3 / steps  # HIP events on the launch stream around the timed calls
+    planes = 6 if mode == "exact" else 1
+    flops = 2.0 * nq * n_local * D
+    from bench import sustained_bf16_mfma_tflops
+    live = sustained_bf16_mfma_tflops(dev)
+    extra = {}
+    if with_ann:
+        a_s, a_i = find_top_k_batch(q, c, k, approximate=True)
+        extra["ann_recall_at_k_vs_brute_force"] = recall_at_k(a_i, out[1])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        find_top_k_batch(q, c, k, approximate=True)
+        torch.cuda.synchronize()
+        extra["ann_ms"] = (time.perf_counter() - t1) * 1e3
+    cpu = None
+    if with_cpu:
+        from oracle import topk as o_topk          # CPU baseline leg: the oracle on a bounded sample
+        ns = 64 if n_local <= 262144 else 16
+        qs, cs = q[:ns].cpu().numpy(), c.cpu().numpy()
+        t1 = time.perf_counter()
+        es, ei = o_topk.batched_top_k(qs, cs, k, np.float32)
+        cpu_dt = time.perf_counter() - t1
+        cpu = {"value": ns / cpu_dt, "unit": "queries/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": "%d queries x %d candidates x D=%d, numpy f32 GEMM + stable argsort" % (ns, n_local, D)}
+        # the sample doubles as a parity spot-check of the timed answer (fp32 GEMM order differs: compare as sets)
+        got = out[1][:ns].cpu().numpy()
+        extra["agrees_with_cpu_sample_at_k"] = float(np.mean([len(set(a) & set(b)) / float(k) for a, b in zip(got, ei)]))
+    traffic = None
+    try:
+        import json
+        key = "retrieve_n%d" % n_local
+        traffic = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                              "pmc_traffic.json"))).get(key)
+    except Exception:
+        pass
+    del q, c
+    torch.cuda.empty_cache()
+    return {
+        "metric": "retrieval queries/sec (top-%d of N candidates, brute force)" % k,
+        "value": nq * steps / dt, "unit": "queries/s", "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
+        "dtype": "bf16x3 (f32-equivalent)" if mode == "exact" else "bf16",
+        "config": {"workload": "retrieve: %d queries x %d candidates x D=%d, k=%d, one GPU" % (nq, n_local, D, k),
+                   "mode": mode, **extra},
+        "roofline": {"kernel": "score_gemm_kernel (+ split, select)", "bound": "mfma",
+                     "achieved": planes * flops / t_op / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": planes * flops / t_op / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
+                     "algorithmic_bytes": (nq + n_local) * D * 4,
+                     "sustained_live_data_TFLOPs": live, "frac_of_sustained": planes * flops / t_op / 1e12 / live,
+                     "f32_equivalent_TFLOPs": flops / t_op / 1e12,
+                     "f32_equivalent_vs_f32_mfma_peak": flops / t_op / 1e12 / MFMA_F32_PEAK_TFLOPS},
+        "cpu_baseline": cpu,
+    }
+
+
 def run_retrieve(args, emit):
     from esrecsys_amd import ops, sharded
     from esrecsys_amd.pinterest.make_recommendations import find_top_k_batch, recall_at_k

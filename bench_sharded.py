@@ -91,9 +91,8 @@ def run_sharded(args, cfg, dev, rank, world):
     # per-kernel HIP-event pass (every rank runs it: the collectives must match; rank 0 reports its own kernels)
     roofline, kernels = None, {}
     if not args.no_kernel_timing:
-        from bench import KernelTimer, TIMED_GROUPS, roofline_for
-        timer = KernelTimer(ops, TIMED_GROUPS)
-        timer.install()
+        from bench import kernel_timer, roofline_for
+        timer = kernel_timer()
         timer.enabled = True
         run(args.warmup, n_batches)
         torch.cuda.synchronize()

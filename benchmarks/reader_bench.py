@@ -1,6 +1,6 @@
 """Throughput of the co-occurrence line-file reader (host side, no GPU): pairs/s of the C decoder path
 (CooccurrenceGenerator.get_batch) against the item-at-a-time loop the reference's generator has
-(get_batch_reference_loop).  Synthetic file: 4000 rows of 20-200 pairs, ids < 400 000, bz2 level 9.
+(tests/_reference_loop.py: test infrastructure, kept out of the product package).  Synthetic file: 4000 rows of 20-200 pairs, ids < 400 000, bz2 level 9.
 
     python benchmarks/reader_bench.py [--batch 65536] [--shuffle 0]
 """
@@ -15,7 +15,10 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _ROOT)
+sys.path.insert(0, os.path.join(_ROOT, "tests"))
+from _reference_loop import batches_item_by_item  # noqa: E402
 from esrecsys_amd.wikipedia.cooccurrence_matrix import CooccurrenceGenerator  # noqa: E402
 
 
@@ -52,7 +55,7 @@ def main():
         f.write(bz2.compress(b"\n".join(lines) + b"\n"))
     g = CooccurrenceGenerator(fn)
     for name, it, target in (("c_decoder", g.get_batch(args.batch, args.shuffle), 20 * npairs),
-                             ("item_loop", g.get_batch_reference_loop(min(args.batch, 8192), args.shuffle), npairs)):
+                             ("item_loop", batches_item_by_item(g, min(args.batch, 8192), args.shuffle), npairs)):
         next(it)
         t0, n = time.perf_counter(), 0
         while n < target:

@@ -34,6 +34,7 @@ SIGNATURES = {
                                 ctypes.c_char_p, c_int]),
     "esr_probe_mfma": (c_int, [c_int, c_int, c_int, c_f32p, ctypes.POINTER(ctypes.c_double), c_vp]),
     "esr_gather_rows": (c_int, [c_vp, c_int, c_i64, c_int, c_i32p, c_i64, c_vp, c_vp]),
+    "esr_check_ids": (c_int, [c_i32p, c_i64, c_i64, c_vp, c_vp]),
     "esr_unpermute_rows": (c_int, [c_vp, c_int, c_int, c_i32p, c_i64, c_vp, c_vp]),
     "esr_unpermute_rows_bf16_to_f32": (c_int, [c_vp, c_int, c_i32p, c_i64, c_f32p, c_vp]),
     "esr_glove_forward": (c_int, [c_f32p, c_f32p, c_i64, c_int, c_i32p, c_i64, c_f32p, c_f32p, c_vp]),

@@ -124,11 +124,38 @@ void finalize_scalar(const double* part, int n, double scale, float* out, hipStr
   hipLaunchKernelGGL(scalar_finalize_kernel, dim3(1), dim3(kBlock), 0, st, part, n, scale, out);
 }
 
+// Debug screen for device-resident ids: report[0] += #ids outside [0, V), report[1] = min position of one.
+__global__ __launch_bounds__(kBlock) void check_ids_kernel(const int32_t* __restrict__ ids, int64_t n, int64_t V,
+                                                           int64_t* __restrict__ report) {
+  int64_t bad = 0, first = INT64_MAX;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t v = ids[i];
+    if (v < 0 || v >= V) {
+      ++bad;
+      first = first < i ? first : i;
+    }
+  }
+  if (bad) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(report), (unsigned long long)bad);
+    atomicMin(reinterpret_cast<long long*>(report + 1), (long long)first);
+  }
+}
+
 }  // namespace esr
 
 using namespace esr;
 
 extern "C" {
+
+int esr_check_ids(const int32_t* ids, int64_t n, int64_t V, int64_t* report, esr_stream_t stream) {
+  ESR_REQUIRE(n >= 0 && V >= 0, "esr_check_ids: n and V must be non-negative");
+  ESR_REQUIRE(report, "esr_check_ids: null report (device int64 [2])");
+  if (n == 0) return ESR_OK;
+  ESR_REQUIRE(ids, "esr_check_ids: null ids");
+  const int grid = (int)std::min<int64_t>(kMaxGrid, cdiv(n, kBlock));
+  hipLaunchKernelGGL(check_ids_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), ids, n, V, report);
+  return check_launch("esr_check_ids");
+}
 
 const char* esr_last_error(void) { return g_err; }
 

@@ -380,7 +380,7 @@ static int launch_segment_tables(const char* who, const FusedTables& ft, int dty
 
 template <int OP>
 static int launch_segment_update(const char* who, void* table, int dtype, float* accum, int D,
-                                 const int32_t* sorted_ids, const int32_t* perm, int64_t n, const float* grad_rows,
+                                 const int32_t* sorted_ids, const int32_t* perm, int64_t n, float* grad_rows,
                                  float lr, float eps, hipStream_t st) {
   FusedTables ft;
   ft.n = 1;
@@ -391,7 +391,7 @@ static int launch_segment_update(const char* who, void* table, int dtype, float*
   }
   ft.row_offset[kMaxFusedTables] = 0;
   // the gradient rows double as scratch for the partial sums of long runs (see segment_update_kernel)
-  return launch_segment_tables<OP>(who, ft, dtype, D, sorted_ids, perm, n, const_cast<float*>(grad_rows), lr, eps, st);
+  return launch_segment_tables<OP>(who, ft, dtype, D, sorted_ids, perm, n, grad_rows, lr, eps, st);
 }
 
 // optax.adam, elementwise over the whole table.
@@ -467,7 +467,7 @@ int esr_dense_momentum_decay(float* param, float* trace, int64_t count, float lr
 }
 
 int esr_sparse_momentum_scatter(float* table, float* trace, int64_t V, int D, const int32_t* sorted_ids,
-                                const int32_t* perm, int64_t n, const float* grad_rows, float lr,
+                                const int32_t* perm, int64_t n, float* grad_rows, float lr,
                                 esr_stream_t stream) {
   ESR_REQUIRE(V > 0 && D > 0 && n >= 0, "esr_sparse_momentum_scatter: bad sizes V=%lld D=%d n=%lld", (long long)V, D,
               (long long)n);
@@ -478,7 +478,7 @@ int esr_sparse_momentum_scatter(float* table, float* trace, int64_t V, int D, co
 }
 
 int esr_sparse_adagrad_scatter(void* table, int dtype, float* accum, int64_t V, int D, const int32_t* sorted_ids,
-                               const int32_t* perm, int64_t n, const float* grad_rows, float lr, float eps,
+                               const int32_t* perm, int64_t n, float* grad_rows, float lr, float eps,
                                esr_stream_t stream) {
   ESR_REQUIRE(V > 0 && D > 0 && n >= 0, "esr_sparse_adagrad_scatter: bad sizes V=%lld D=%d n=%lld", (long long)V, D,
               (long long)n);
@@ -490,7 +490,7 @@ int esr_sparse_adagrad_scatter(void* table, int dtype, float* accum, int64_t V, 
 }
 
 int esr_sparse_sgd_scatter(void* table, int dtype, int64_t V, int D, const int32_t* sorted_ids, const int32_t* perm,
-                           int64_t n, const float* grad_rows, float lr, esr_stream_t stream) {
+                           int64_t n, float* grad_rows, float lr, esr_stream_t stream) {
   ESR_REQUIRE(V > 0 && D > 0 && n >= 0, "esr_sparse_sgd_scatter: bad sizes V=%lld D=%d n=%lld", (long long)V, D,
               (long long)n);
   ESR_REQUIRE(dtype == ESR_F32 || dtype == ESR_BF16, "esr_sparse_sgd_scatter: bad dtype %d", dtype);
@@ -501,7 +501,7 @@ int esr_sparse_sgd_scatter(void* table, int dtype, int64_t V, int D, const int32
 }
 
 int esr_rows_to_dense(float* dense, int64_t V, int D, const int32_t* sorted_ids, const int32_t* perm, int64_t n,
-                      const float* grad_rows, esr_stream_t stream) {
+                      float* grad_rows, esr_stream_t stream) {
   ESR_REQUIRE(V > 0 && D > 0 && n >= 0, "esr_rows_to_dense: bad sizes V=%lld D=%d n=%lld", (long long)V, D,
               (long long)n);
   ESR_REQUIRE(dense, "esr_rows_to_dense: null pointer");
@@ -567,7 +567,7 @@ int esr_gather_rows_multi(const void* const* tables, const int64_t* row_offsets,
 
 int esr_sparse_adagrad_scatter_multi(void* const* tables, float* const* accums, const int64_t* row_offsets,
                                      int ntables, int dtype, int D, const int32_t* sorted_vids, const int32_t* perm,
-                                     int64_t n, const float* grad_rows, float lr, float eps, esr_stream_t stream) {
+                                     int64_t n, float* grad_rows, float lr, float eps, esr_stream_t stream) {
   ESR_REQUIRE(ntables >= 1 && ntables <= kMaxFusedTables, "esr_sparse_adagrad_scatter_multi: ntables=%d not in [1, %d]",
               ntables, kMaxFusedTables);
   ESR_REQUIRE(D > 0 && n >= 0, "esr_sparse_adagrad_scatter_multi: bad sizes D=%d n=%lld", D, (long long)n);
@@ -590,7 +590,7 @@ int esr_sparse_adagrad_scatter_multi(void* const* tables, float* const* accums, 
   ESR_REQUIRE(row_offsets[ntables] < ((int64_t)1 << 31), "esr_sparse_adagrad_scatter_multi: %lld virtual rows >= 2^31",
               (long long)row_offsets[ntables]);
   return launch_segment_tables<kAdagrad>("esr_sparse_adagrad_scatter_multi", ft, dtype, D, sorted_vids, perm, n,
-                                         const_cast<float*>(grad_rows), lr, eps, as_stream(stream));
+                                         grad_rows, lr, eps, as_stream(stream));
 }
 
 int esr_dense_adam(float* param, float* mu, float* nu, const float* grad, int64_t numel, float lr, float b1,

@@ -3,6 +3,8 @@
 PyTorch is used for device memory and the current HIP stream only; every computation is a
 libesr_hip.so call.  All functions require CUDA(ROCm) tensors and raise if the library is missing.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -48,14 +50,30 @@ def _table_dtype(t, name):
     raise TypeError("%s must be float32 or bfloat16, got %s" % (name, t.dtype))
 
 
+def check_device_ids(ids, V):
+    """Debug screen (ESR_CHECK_IDS=1): raise IndexError if any id of the device tensor is outside [0, V).
+    One small launch + a host read-back, i.e. a sync -- which is why it is not on by default."""
+    lib = _lib.load()
+    report = torch.tensor([0, 2 ** 63 - 1], dtype=torch.int64, device=ids.device)
+    check(lib.esr_check_ids(_p(ids), ids.numel(), int(V), _p(report), _stream()), "esr_check_ids")
+    bad, first = (int(v) for v in report.cpu())
+    if bad:
+        raise IndexError("%d device-resident id(s) out of range [0, %d); first at flat position %d (value %d)"
+                         % (bad, V, first, int(ids.reshape(-1)[first])))
+
+
 def as_ids(x, device, check_range=None):
     """int ids (numpy / list / torch, any int dtype) -> contiguous int32 tensor on `device`.
 
-    Host inputs are range-checked against `check_range` = V (device inputs are trusted: checking
-    them would force a sync on the hot path)."""
+    Host inputs are range-checked against `check_range` = V.  Device inputs are trusted (checking them forces a
+    sync on the hot path) unless ESR_CHECK_IDS=1 is set in the environment: then every device id tensor is screened
+    by esr_check_ids and an out-of-range id raises IndexError instead of becoming a wild read / RMW."""
     if isinstance(x, torch.Tensor):
         if x.is_cuda:
-            return x.to(torch.int32).contiguous()
+            x = x.to(torch.int32).contiguous()
+            if check_range is not None and os.environ.get("ESR_CHECK_IDS") == "1":
+                check_device_ids(x, check_range)
+            return x
         x = x.numpy()
     a = np.ascontiguousarray(np.asarray(x), dtype=np.int32)
     if check_range is not None and a.size and (a.min() < 0 or a.max() >= check_range):

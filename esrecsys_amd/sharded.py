@@ -27,6 +27,8 @@ falling back to torch.distributed.all_to_all_single.
 are libesr_hip.so.  ``kernels`` is the module that provides them -- always ``esrecsys_amd.ops`` in the
 product; the CPU test-suite injects an oracle-backed double to exercise the routing logic without a GPU.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -198,6 +200,10 @@ class ShardedTableGroup:
     def virtual_id_segments(self, id_tensors, slots):
         """The same virtual list as (id tensors, offsets) for begin_plans / make_plans: bucketed without the
         concatenated copy."""
+        if os.environ.get("ESR_CHECK_IDS") == "1" and hasattr(self.k, "check_device_ids"):
+            for t, s_ in zip(id_tensors, slots):   # debug screen: an out-of-range id would be routed to a wild row
+                if t.is_cuda:
+                    self.k.check_device_ids(t, self.tables[s_].num_rows)
         if len(self.tables) == 1 and len(id_tensors) == 1:
             return id_tensors[0]
         return (list(id_tensors), [self.voff[s] for s in slots])
@@ -259,7 +265,7 @@ def plan_triplet(towers, scene_ids, pos_ids, neg_ids):
 
 def plan_glove(emb_group, inputs):
     """The embedding and bias tables are indexed by the same ids and sharded the same way: one routing."""
-    return emb_group.plan(inputs.reshape(-1))
+    return emb_group.plan(emb_group.virtual_id_segments([inputs.reshape(-1)], [0]))
 
 
 class _Pending1:
@@ -280,7 +286,7 @@ def begin_plan_triplet(towers, scene_ids, pos_ids, neg_ids):
 
 
 def begin_plan_glove(emb_group, inputs):
-    return _Pending1(begin_plans([(emb_group, inputs.reshape(-1))]))
+    return _Pending1(begin_plans([(emb_group, emb_group.virtual_id_segments([inputs.reshape(-1)], [0]))]))
 
 
 def _is_f32(group):

@@ -90,6 +90,20 @@ class FusedScatter:
         self.paths = [tuple(p) for p in paths]
         self.rows = rows  # f32 [sum n_i, D]; may be filled in later (the ids are known before the gradients)
         self.index = SegmentIndex(None, offs[-1], segments=(list(id_tensors), [offs[s] for s in slots]))
+        self.consumed = False
+
+    def consume(self):
+        _consume(self, "FusedScatter")
+
+
+def _consume(obj, what):
+    """The segment-reduce kernels park partial sums of long runs of equal ids IN the gradient rows (include/esr_hip.h:
+    "may OVERWRITE grad_rows"), so a gradient can feed exactly one to_dense() / optimizer update: a second use would
+    silently read clobbered rows for hot ids."""
+    if obj.consumed:
+        raise RuntimeError("%s was already consumed by an optimizer update / to_dense(): the scatter kernels "
+                           "overwrite the gradient rows of hot ids; recompute the gradients to apply them again" % what)
+    obj.consumed = True
 
 
 class RowGrads:
@@ -103,6 +117,7 @@ class RowGrads:
         self.rows = rows      # f32 [n, D]
         self.shape = tuple(shape)
         self.fused = fused
+        self.consumed = False
 
     @property
     def index(self):
@@ -114,6 +129,7 @@ class RowGrads:
 
     def to_dense(self):
         """The dense gradient the reference materialises (wikipedia/train_cooccurence.py:86-87)."""
+        _consume(self, "RowGrads")
         sorted_ids, perm = self.index.sorted()
         V = self.shape[0]
         D = self.shape[1] if len(self.shape) > 1 else 1
@@ -213,11 +229,13 @@ class _SparseAdagrad(GradientTransformation):
                 if id(f) in done:
                     continue
                 done.add(id(f))  # all members of the fused scatter in one sort + one launch
+                f.consume()
                 sorted_vids, perm = f.index.sorted()
                 ops.sparse_adagrad_multi([tree_get(params, q) for q in f.paths],
                                          [tree_get(opt_state["sum_of_squares"], q) for q in f.paths],
                                          f.row_offsets, sorted_vids, perm, f.rows, self.lr, self.eps)
                 continue
+            _consume(g, "RowGrads")
             sorted_ids, perm = g.index.sorted()
             ops.sparse_adagrad(p, tree_get(opt_state["sum_of_squares"], path), sorted_ids, perm, g.rows, self.lr,
                                self.eps)
@@ -233,11 +251,19 @@ class _SparseSgd(GradientTransformation):
     def init(self, params):
         return {}
 
+    # optax.sgd(lr) without momentum is chain(identity(), scale(-lr)): (EmptyState(), EmptyState())
+    def to_optax_state(self, opt_state):
+        return {"0": {}, "1": {}}
+
+    def from_optax_state(self, tree):
+        return {}
+
     def apply(self, params, grads, opt_state, step):
         for path, p in tree_leaves_with_path(params):
             g = tree_get(grads, path)
             if g is None:
                 continue
+            _consume(g, "RowGrads")
             sorted_ids, perm = g.index.sorted()
             ops.sparse_sgd(p, sorted_ids, perm, g.rows, self.lr)
         return opt_state
@@ -270,6 +296,7 @@ class _SgdMomentum(GradientTransformation):
                 continue
             if not isinstance(g, RowGrads):
                 raise TypeError("sgd(momentum) needs RowGrads leaves (got %s at %s)" % (type(g).__name__, path))
+            _consume(g, "RowGrads")
             sorted_ids, perm = g.index.sorted()
             ops.sparse_momentum(p, tr, sorted_ids, perm, g.rows, self.lr)
         return opt_state

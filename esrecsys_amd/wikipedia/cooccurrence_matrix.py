@@ -125,14 +125,26 @@ class _Dataset:
         q = queue.Queue(maxsize=self._depth)
 
         def worker():
-            for item in it:
-                q.put(item)
+            # whatever ends the producer -- exhaustion, no files matching the glob, a malformed line, a bz2 / IO
+            # error -- reaches the consumer as a sentinel: a silent thread death would leave next() blocked forever
+            try:
+                for item in it:
+                    q.put(("item", item))
+                q.put(("end", None))
+            except BaseException as e:  # noqa: BLE001 -- re-raised on the consumer side
+                q.put(("err", e))
 
         threading.Thread(target=worker, daemon=True).start()
 
         def gen():
             while True:
-                yield q.get()
+                kind, payload = q.get()
+                if kind == "item":
+                    yield payload
+                elif kind == "err":
+                    raise payload
+                else:
+                    return
         return gen()
 
     __iter__ = as_numpy_iterator
@@ -219,15 +231,6 @@ class CooccurrenceGenerator:
             return parts[0], pending
         return tuple(np.concatenate([p[i] for p in parts]) for i in range(3)), pending
 
-    def get_shuffled_items(self, num_items):
-        """Pre-fetches and shuffles num_items of stuff (cooccurrence_matrix.py:80-87; global NumPy RNG, as there)."""
-        iterator = self.get_item()
-        while True:
-            items = [next(iterator) for _ in range(num_items)]
-            np.random.shuffle(items)
-            for item in items:
-                yield item
-
     def get_batch(self, batch_size, shuffle_size=0):
         """cooccurrence_matrix.py:89-106.  Same batches as the reference's item-at-a-time loop -- including the
         buffer shuffle: fill `shuffle_size` items, np.random.shuffle (global NumPy RNG, one call per buffer: a
@@ -256,18 +259,6 @@ class CooccurrenceGenerator:
                 filled += k
                 pos += k
             yield ([out[0], out[1]], out[2])
-
-    def get_batch_reference_loop(self, batch_size, shuffle_size=0):
-        """The reference's loop verbatim in structure (one item per next()): the restatement get_batch is tested
-        against."""
-        iterator = self.get_shuffled_items(shuffle_size) if shuffle_size else self.get_item()
-        while True:
-            token1 = np.empty(batch_size, np.int32)
-            token2 = np.empty(batch_size, np.int32)
-            token_count = np.empty(batch_size, np.float32)
-            for k in range(batch_size):
-                token1[k], token2[k], token_count[k] = next(iterator)
-            yield ([token1, token2], token_count)
 
     def get_dataset(self, batch_size, shuffle_size=0):
         """Returns the batches as a tf.data-shaped dataset of ``(int32[2, B], float32[B])``

@@ -70,6 +70,13 @@ int esr_probe_mfma(int dtype, int workgroups, int iters, float* sink, double* fl
 int esr_gather_rows(const void* table, int dtype, int64_t V, int D, const int32_t* ids, int64_t n,
                     void* out, esr_stream_t stream);
 
+/* Debug screen for DEVICE-resident ids (the hot path trusts them: a host-side check would force a sync per step).
+ * report is device int64 [2], initialised by the caller to {0, INT64_MAX}: report[0] += number of ids outside
+ * [0, V), report[1] = min(position of such an id).  jnp.take clamps out-of-range ids silently
+ * (wikipedia/models.py:31-34 [upstream jax]); here they would be wild reads / read-modify-writes, so the Python
+ * layer runs this screen on every device id tensor when ESR_CHECK_IDS=1 and raises IndexError. */
+int esr_check_ids(const int32_t* ids, int64_t n, int64_t V, int64_t* report, esr_stream_t stream);
+
 /* ---- G2: Glove.__call__ pieces -- wikipedia/models.py:30-37 ------------------------------
  * dot[j] = E[t1[j]] . E[t2[j]],  s[i] = Bias[t1[i]] + Bias[t2[i]];  the (B,B) output is
  * dot[None,:] + s[:,None].  inputs is int32 [2, B] row-major (cooccurrence_matrix.py:103-104). */
@@ -159,7 +166,7 @@ int esr_segment_sort_ids_multi(const int32_t* const* ids, const int64_t* counts,
  * p -= lr * G * rsqrt(acc + eps).  table dtype f32 or bf16 (fp32 accumulator either way). */
 int esr_sparse_adagrad_scatter(void* table, int dtype, float* accum, int64_t V, int D,
                                const int32_t* sorted_ids, const int32_t* perm, int64_t n,
-                               const float* grad_rows, float lr, float eps, esr_stream_t stream);
+                               float* grad_rows, float lr, float eps, esr_stream_t stream);
 /* Several tables (same D, same dtype) updated from ONE sorted occurrence list: ids are virtual rows
  * vid = row_offsets[t] + id of the concatenation of <= 4 tables, so a two-tower step needs one sort chain
  * and one update launch.  tables / accums / row_offsets (ntables + 1 entries) are HOST arrays of device
@@ -172,16 +179,16 @@ int esr_gather_rows_multi(const void* const* tables, const int64_t* row_offsets,
                           const int32_t* vids, int64_t n, void* out, esr_stream_t stream);
 int esr_sparse_adagrad_scatter_multi(void* const* tables, float* const* accums, const int64_t* row_offsets,
                                      int ntables, int dtype, int D, const int32_t* sorted_vids,
-                                     const int32_t* perm, int64_t n, const float* grad_rows, float lr, float eps,
+                                     const int32_t* perm, int64_t n, float* grad_rows, float lr, float eps,
                                      esr_stream_t stream);
 /* Row-sparse SGD (p -= lr * G), same segment reduction. */
 int esr_sparse_sgd_scatter(void* table, int dtype, int64_t V, int D, const int32_t* sorted_ids,
-                           const int32_t* perm, int64_t n, const float* grad_rows, float lr,
+                           const int32_t* perm, int64_t n, float* grad_rows, float lr,
                            esr_stream_t stream);
 /* Reference-faithful dense gradient: dense[V, D] = 0 then dense[id] = segment sum
  * (the scatter-add JAX's autodiff performs for nn.Embed, train_cooccurence.py:86-87). */
 int esr_rows_to_dense(float* dense, int64_t V, int D, const int32_t* sorted_ids,
-                      const int32_t* perm, int64_t n, const float* grad_rows, esr_stream_t stream);
+                      const int32_t* perm, int64_t n, float* grad_rows, esr_stream_t stream);
 /* optax.adam over every element -- wikipedia/train_cooccurence.py:99-101,171.
  * step = the 1-based count AFTER this update. */
 int esr_dense_adam(float* param, float* mu, float* nu, const float* grad, int64_t numel, float lr,
@@ -264,7 +271,7 @@ int esr_spotify_affinity_all(const float* album_table, int64_t n_album_rows, con
 int esr_dense_momentum_decay(float* param, float* trace, int64_t count, float lr, float momentum,
                              esr_stream_t stream);
 int esr_sparse_momentum_scatter(float* table, float* trace, int64_t V, int D, const int32_t* sorted_ids,
-                                const int32_t* perm, int64_t n, const float* grad_rows, float lr,
+                                const int32_t* perm, int64_t n, float* grad_rows, float lr,
                                 esr_stream_t stream);
 
 /* ---- 8e: row-shard routing (owner = id mod world, local row = id div world) ---------------

@@ -59,6 +59,24 @@ def test_bad_arguments_are_rejected_without_a_device(lib):
     assert lib.esr_score_topk(16, 16, 1, 10, 4, 11, 16, 16, 16, 1 << 20, None) == EINVAL     # k > N
 
 
+def test_exchange_entry_points_validate_before_touching_rccl(lib):
+    """8e exchange in the C ABI: bad arguments come back as ESR_EINVAL with a message, before any group is opened."""
+    EINVAL, ENODEVICE = -1, -4
+    cnt = (ctypes.c_int64 * 2)(1, 1)
+    assert lib.esr_alltoall_ids(None, 16, cnt, 16, cnt, None) == EINVAL
+    assert b"null communicator" in lib.esr_last_error()
+    assert lib.esr_alltoall_rows(None, 16, 7, 128, cnt, 16, cnt, None) == EINVAL
+    assert b"dtype" in lib.esr_last_error()
+    assert lib.esr_alltoall_grads(None, 16, 0, cnt, 16, cnt, None) == EINVAL
+    assert lib.esr_comm_init(None, 2, 0, None) == EINVAL
+    uid = (ctypes.c_byte * 128)()
+    out = ctypes.c_void_p()
+    assert lib.esr_comm_init(uid, 2, 5, ctypes.byref(out)) == EINVAL and b"rank" in lib.esr_last_error()
+    assert lib.esr_comm_count(None, None, None) == EINVAL
+    assert lib.esr_comm_destroy(None) == 0 and lib.esr_comm_abort(None) == 0     # freeing nothing is fine
+    assert lib.esr_check_ids(None, -1, 10, None, None) == EINVAL
+
+
 def test_workspace_queries_are_monotone(lib):
     a = lib.esr_glove_workspace_bytes(1024)
     b = lib.esr_glove_workspace_bytes(65536)

@@ -283,3 +283,27 @@ def test_inbatch_train_step_bf16_towers(dev):
     ep, _ = o_optim.sparse_adagrad_update(pt0, np.full_like(pt0, 0.1), po, gc, lr, dtype=F64)
     got = state.params["params"]["product_tower"]["embedding"].float().cpu().numpy()
     assert np.mean(got == torch.from_numpy(ep).to(torch.bfloat16).float().numpy()) > 0.999
+
+
+def test_gradients_are_single_use(dev):
+    """The scatter kernels park partial sums of hot ids in the gradient rows themselves (ABI: "may OVERWRITE
+    grad_rows"), so RowGrads / FusedScatter raise on a second optimizer update or to_dense() instead of silently
+    applying clobbered rows."""
+    from esrecsys_amd import TrainState, optim
+    from esrecsys_amd.wikipedia.models import Glove
+    from esrecsys_amd.wikipedia.train_cooccurence import apply_model, update_model
+    V, D, B = 300, 32, 128
+    model = Glove(num_embeddings=V, features=D, device=dev)
+    state = TrainState.create(apply_fn=model.apply, params=model.init(3, None)["params"], tx=optim.sparse_adagrad(0.05))
+    rng = np.random.default_rng(0)
+    inputs = rng.integers(0, V, (2, B)).astype(np.int32)
+    inputs[:, :100] = 7                                   # a hot id: 200 occurrences
+    target = rng.uniform(0.1, 300, B).astype(np.float32)
+    grads, _ = apply_model(state, inputs, target)
+    state2 = update_model(state, grads)
+    with pytest.raises(RuntimeError, match="already consumed"):
+        update_model(state2, grads)
+    grads, _ = apply_model(state2, inputs, target)
+    grads["_token_embedding"]["embedding"].to_dense()
+    with pytest.raises(RuntimeError, match="already consumed"):
+        grads["_token_embedding"]["embedding"].to_dense()

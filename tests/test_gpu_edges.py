@@ -225,3 +225,44 @@ def test_glove_weight_function_corners(dev, mode):
     assert np.max(np.abs(N(gbias).reshape(-1) - ebias)) <= 1e-5 * np.max(np.abs(ebias))
     if mode == "diagonal":   # a zero count has zero weight: its pair contributes no gradient at all
         assert np.array_equal(N(grows)[0], np.zeros(D)) and np.array_equal(N(grows)[B], np.zeros(D))
+
+
+def test_out_of_range_device_ids_raise_under_check_ids(dev, monkeypatch):
+    """ESR_CHECK_IDS=1: device-resident ids are screened by esr_check_ids before any gather / scatter sees them
+    (host ids are always range-checked; device ids are trusted by default because the check costs a sync)."""
+    from esrecsys_amd import TrainState, ops, optim
+    from esrecsys_amd.pinterest.models import STLModel
+    from esrecsys_amd.pinterest.train_shop_the_look import eval_step, train_step
+    from esrecsys_amd.wikipedia.models import Glove
+    from esrecsys_amd.wikipedia.train_cooccurence import apply_model
+    V, D, B = 500, 32, 64
+    stl = STLModel(output_size=D, num_scenes=V, num_products=V, device=dev)
+    st = TrainState.create(apply_fn=stl.apply, params=stl.init(0), tx=optim.sparse_adagrad(0.05))
+    good = torch.arange(B, dtype=torch.int32, device=dev)
+    for bad_value, pos in ((V, 17), (-1, 0), (2 ** 31 - 1, B - 1)):
+        bad = good.clone()
+        bad[pos] = bad_value
+        monkeypatch.setenv("ESR_CHECK_IDS", "1")
+        with pytest.raises(IndexError, match=r"out of range \[0, %d\); first at flat position %d" % (V, pos)):
+            train_step(st, good, bad, good, 0.1, B)
+        with pytest.raises(IndexError):
+            train_step(st, bad, good, None, 0.1, B, scale=2.0)
+        with pytest.raises(IndexError):
+            eval_step(st, good, good, bad)
+    # the screen itself: counts every offender, reports the first
+    ids = torch.tensor([3, 700, 5, -4, 499, 500], dtype=torch.int32, device=dev)
+    with pytest.raises(IndexError, match=r"^3 device-resident id\(s\) out of range \[0, 500\); first at flat position 1 "):
+        ops.check_device_ids(ids, V)
+    ops.check_device_ids(good, V)                       # in-range ids pass
+    ops.check_device_ids(good[:0], V)                   # empty list passes
+    model = Glove(num_embeddings=V, features=D, device=dev)
+    gs = TrainState.create(apply_fn=model.apply, params=model.init(1, None)["params"], tx=optim.sparse_adagrad(0.05))
+    inputs = torch.stack([good, good]).contiguous()
+    inputs[1, 9] = V + 3
+    with pytest.raises(IndexError):
+        apply_model(gs, inputs, torch.ones(B, device=dev))
+    # a state that saw only rejected batches is untouched
+    assert int(st.step) == 0
+    monkeypatch.delenv("ESR_CHECK_IDS")
+    st2, _ = train_step(st, good, good, good, 0.1, B)   # default: no screen, no sync, in-range ids just run
+    assert int(st2.step) == 1

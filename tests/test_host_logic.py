@@ -1,0 +1,70 @@
+"""CPU: host-side logic of the drop-in API that needs no GPU -- S4 generate_triplets' sampling protocol
+(pinterest/train_shop_the_look.py:72-91), flag namespaces with the reference's names and defaults."""
+import numpy as np
+import pytest
+
+
+def _pairs(count):
+    return [("scene%03d" % i, "prod%03d" % i) for i in range(count)]
+
+
+@pytest.mark.parametrize("count,num_neg", [(57, 5), (10, 1), (11, 3), (200, 7)])
+def test_generate_triplets_protocol(count, num_neg):
+    """Per positive pair i: exactly num_neg triplets (scene_i, pos_i, neg) in input order; every 10th positive
+    (i % 10 == 0) goes to the test split, the rest to train; negatives are the PRODUCT of another positive pair,
+    drawn from randint(0, count - 1) -- upper bound exclusive, so the last pair's product is never a negative."""
+    from esrecsys_amd.pinterest.train_shop_the_look import generate_triplets
+    sp = _pairs(count)
+    train, test = generate_triplets(sp, num_neg)
+    n_test = len(range(0, count, 10))
+    assert len(test) == n_test * num_neg and len(train) == (count - n_test) * num_neg
+    products = {p: i for i, (_, p) in enumerate(sp)}
+    # order + grouping: positives appear in input order, num_neg consecutive triplets each
+    exp_train = [i for i in range(count) if i % 10 != 0]
+    exp_test = [i for i in range(count) if i % 10 == 0]
+    for out, exp in ((train, exp_train), (test, exp_test)):
+        for g, i in enumerate(exp):
+            grp = out[g * num_neg:(g + 1) * num_neg]
+            assert all(t[0] == sp[i][0] and t[1] == sp[i][1] for t in grp)
+            assert all(t[2] in products for t in grp)
+    negs = np.array([products[t[2]] for t in train + test])
+    assert negs.min() >= 0 and negs.max() <= count - 2, "the last item must never be sampled (exclusive upper bound)"
+
+
+def test_generate_triplets_negative_distribution_and_determinism():
+    from esrecsys_amd.pinterest.train_shop_the_look import generate_triplets
+    count, num_neg = 41, 50
+    sp = _pairs(count)
+    a = generate_triplets(sp, num_neg)
+    b = generate_triplets(sp, num_neg)
+    assert a == b, "PRNGKey(0)-style fixed seed: the split is reproducible"
+    c = generate_triplets(sp, num_neg, seed=1)
+    assert c != a
+    products = {p: i for i, (_, p) in enumerate(sp)}
+    negs = np.array([products[t[2]] for t in a[0] + a[1]])
+    hist = np.bincount(negs, minlength=count)
+    assert hist[count - 1] == 0 and hist[:count - 1].min() > 0  # uniform over [0, count - 1): all others do occur
+    # chi-square against uniform over count - 1 bins, very loose (p ~ 1e-6 at 40 dof is ~ 95)
+    exp = len(negs) / (count - 1)
+    assert ((hist[:count - 1] - exp) ** 2 / exp).sum() < 95.0
+
+
+def test_generate_triplets_edge_sizes():
+    from esrecsys_amd.pinterest.train_shop_the_look import generate_triplets
+    assert generate_triplets([], 5) == ([], [])
+    train, test = generate_triplets(_pairs(2), 3)        # randint(0, 1): the only legal negative is item 0
+    assert train == [("scene001", "prod001", "prod000")] * 3 and test == [("scene000", "prod000", "prod000")] * 3
+    with pytest.raises(ValueError):
+        generate_triplets(_pairs(1), 2)                  # randint(0, 0) is an empty range (JAX would return garbage)
+    assert generate_triplets(_pairs(5), 0) == ([], [])
+
+
+def test_flag_defaults_match_the_reference():
+    """pinterest/train_shop_the_look.py:46-69 and wikipedia/train_cooccurence.py:34-65."""
+    from esrecsys_amd.pinterest.train_shop_the_look import FLAGS as P
+    from esrecsys_amd.wikipedia.train_cooccurence import FLAGS as W
+    assert (P.num_neg, P.learning_rate, P.regularization, P.output_size, P.batch_size, P.max_steps) == \
+        (5, 1e-3, 0.1, 32, 16, 30000)
+    assert (P.log_every_steps, P.eval_every_steps, P.checkpoint_every_steps) == (100, 2000, 100000)
+    assert (W.embedding_dim, W.batch_size, W.seed, W.shuffle_buffer_size, W.steps_per_epoch, W.num_epochs,
+            W.learning_rate, W.checkpoint_every_epochs, W.max_terms) == (64, 2048, 1701, 5000000, 10000, 20, 0.001, 20, 20)

@@ -84,7 +84,9 @@ def test_checkpoint_roundtrip_and_flax_layout(opt):
     data = checkpoint.to_bytes(st)
     # layout: plain msgpack map; arrays = ExtType(1, packb((shape, dtype.name, bytes)))
     raw = msgpack.unpackb(data, raw=False, strict_map_key=False)
-    assert sorted(raw) == ["opt_state", "params", "step"] and raw["step"] == 12
+    assert list(raw) == ["step", "params", "opt_state"]  # TrainState's dataclass field order
+    # step is what the reference's jitted update_model leaves there: an int32 0-d array (ExtType 1)
+    assert raw["step"].code == 1 and msgpack.unpackb(raw["step"].data, raw=False) == [[], "int32", (12).to_bytes(4, "little")]
     leaf = raw["params"]["_token_embedding"]["embedding"]
     assert isinstance(leaf, msgpack.ExtType) and leaf.code == 1
     shape, dtype_name, payload = msgpack.unpackb(leaf.data, raw=False)
@@ -120,6 +122,131 @@ def test_checkpoint_chunks_large_arrays(monkeypatch):
     assert raw["w"]["__msgpack_chunked_array__"] is True and len(raw["w"]["chunks"]) == 7
     back = checkpoint.from_bytes({"w": torch.zeros(10, 10)}, data)
     assert torch.equal(back["w"], tree["w"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_checkpoint_chunked_arrays_restore_for_both_dtypes(monkeypatch, dtype):
+    """A table above the chunk limit (2**30 bytes; lowered here) must restore, bf16 included: its chunks come back
+    as torch tensors and are concatenated as such."""
+    from esrecsys_amd import checkpoint
+    monkeypatch.setattr(checkpoint, "_MAX_CHUNK_BYTES", 64)
+    w = (torch.arange(300, dtype=torch.float32).reshape(30, 10) / 7).to(dtype)
+    data = checkpoint.to_bytes({"w": w})
+    raw = msgpack.unpackb(data, raw=False, strict_map_key=False)
+    assert raw["w"]["__msgpack_chunked_array__"] is True and len(raw["w"]["chunks"]) > 1
+    loaded = checkpoint.msgpack_restore(data)["w"]
+    assert tuple(loaded.shape) == (30, 10)
+    back = checkpoint.from_bytes({"w": torch.zeros((30, 10), dtype=dtype)}, data)
+    assert back["w"].dtype == dtype and torch.equal(back["w"], w)
+
+
+class _Mp:
+    """A minimal msgpack WRITER, independent of the msgpack package and of esrecsys_amd.checkpoint, restating the
+    msgpack spec for the handful of types a Flax checkpoint contains.  Used to hand-assemble golden bytes."""
+
+    @staticmethod
+    def str_(s):
+        b = s.encode()
+        if len(b) < 32:
+            return bytes([0xA0 | len(b)]) + b
+        assert len(b) < 256
+        return b"\xd9" + bytes([len(b)]) + b
+
+    @staticmethod
+    def bin_(b):
+        if len(b) < 256:
+            return b"\xc4" + bytes([len(b)]) + b
+        assert len(b) < 65536
+        return b"\xc5" + len(b).to_bytes(2, "big") + b
+
+    @staticmethod
+    def uint(v):
+        assert 0 <= v < 128
+        return bytes([v])
+
+    @staticmethod
+    def arr(items):
+        assert len(items) < 16
+        return bytes([0x90 | len(items)]) + b"".join(items)
+
+    @staticmethod
+    def map_(pairs):
+        assert len(pairs) < 16
+        return bytes([0x80 | len(pairs)]) + b"".join(_Mp.str_(k) + v for k, v in pairs)
+
+    @staticmethod
+    def ext(code, payload):
+        n = len(payload)
+        fixed = {1: 0xD4, 2: 0xD5, 4: 0xD6, 8: 0xD7, 16: 0xD8}
+        if n in fixed:
+            return bytes([fixed[n], code]) + payload
+        if n < 256:
+            return b"\xc7" + bytes([n, code]) + payload
+        assert n < 65536
+        return b"\xc8" + n.to_bytes(2, "big") + bytes([code]) + payload
+
+    @staticmethod
+    def ndarray(a):
+        """flax.serialization._ndarray_to_bytes [upstream flax 0.5.2]: ExtType(1, packb((shape, dtype.name, C bytes)))."""
+        a = np.asarray(a)  # (ascontiguousarray would turn a 0-d array into shape (1,))
+        inner = _Mp.arr([_Mp.arr([_Mp.uint(d) for d in a.shape]), _Mp.str_(a.dtype.name), _Mp.bin_(a.tobytes("C"))])
+        return _Mp.ext(1, inner)
+
+
+def test_checkpoint_bytes_equal_hand_assembled_flax_layout():
+    """N4 pinned as far as it can be without Flax: the bytes of a reference-shaped checkpoint (TrainState of the GloVe
+    model after optax.adam steps: wikipedia/train_cooccurence.py:129-134,171-172) are assembled BY HAND from the
+    documented layout -- flax.serialization.to_state_dict(TrainState) = {step, params, opt_state} with apply_fn / tx
+    dropped; optax.adam state (ScaleByAdamState(count, mu, nu), EmptyState()) -> {'0': {count, mu, nu}, '1': {}};
+    ndarrays and jax scalars as ExtType 1 -- with a msgpack writer that shares no code with the product, and must
+    (a) equal to_bytes() byte for byte and (b) load through from_bytes()."""
+    from esrecsys_amd import TrainState, checkpoint, optim
+    emb = np.array([[0.5, -1.25], [2.0, 0.0], [1e-3, 3.0]], np.float32)
+    bias = np.array([[0.1], [-0.2], [0.3]], np.float32)
+    mu_e, nu_e = emb * 0.1, emb * emb * 0.001
+    mu_b, nu_b = bias * 0.1, bias * bias * 0.001
+    step = 7
+
+    def tree(e, b):  # sorted keys: '_bias' < '_token_embedding'
+        return _Mp.map_([("_bias", _Mp.map_([("embedding", _Mp.ndarray(b))])),
+                         ("_token_embedding", _Mp.map_([("embedding", _Mp.ndarray(e))]))])
+    golden = _Mp.map_([
+        ("step", _Mp.ndarray(np.asarray(step, np.int32))),
+        ("params", tree(emb, bias)),
+        ("opt_state", _Mp.map_([
+            ("0", _Mp.map_([("count", _Mp.ndarray(np.asarray(step, np.int32))), ("mu", tree(mu_e, mu_b)),
+                            ("nu", tree(nu_e, nu_b))])),
+            ("1", _Mp.map_([]))])),
+    ])
+    t = torch.from_numpy
+    params = {"_token_embedding": {"embedding": t(emb.copy())}, "_bias": {"embedding": t(bias.copy())}}
+    st = TrainState.create(apply_fn=None, params=params, tx=optim.adam(1e-3)).replace(step=step)
+    st.opt_state["count"] = step
+    st.opt_state["mu"] = {"_token_embedding": {"embedding": t(mu_e.copy())}, "_bias": {"embedding": t(mu_b.copy())}}
+    st.opt_state["nu"] = {"_token_embedding": {"embedding": t(nu_e.copy())}, "_bias": {"embedding": t(nu_b.copy())}}
+    assert checkpoint.to_bytes(st) == golden
+    # and a "reference-written" file loads (here with the fields in another order and a plain-int step, both legal)
+    fresh = TrainState.create(apply_fn=None, params={"_token_embedding": {"embedding": torch.zeros(3, 2)},
+                                                     "_bias": {"embedding": torch.zeros(3, 1)}}, tx=optim.adam(1e-3))
+    got = checkpoint.from_bytes(fresh, golden)
+    assert got.step == step and got.opt_state["count"] == step
+    assert torch.equal(got.params["_token_embedding"]["embedding"], t(emb))
+    assert torch.equal(got.opt_state["nu"]["_bias"]["embedding"], t(nu_b))
+    alt = _Mp.map_([("params", tree(emb, bias)), ("opt_state", _Mp.map_([
+        ("1", _Mp.map_([])), ("0", _Mp.map_([("nu", tree(nu_e, nu_b)), ("mu", tree(mu_e, mu_b)),
+                                             ("count", _Mp.uint(step))]))])), ("step", _Mp.uint(step))])
+    got = checkpoint.from_bytes(fresh, alt)
+    assert got.step == step and got.opt_state["count"] == step
+
+
+def test_checkpoint_plain_sgd_has_optax_tree():
+    """optax.sgd(lr) without momentum is chain(identity(), scale(-lr)): opt_state serialises as {'0': {}, '1': {}}."""
+    from esrecsys_amd import checkpoint, optim
+    st = _state(optim.sgd(0.1))
+    raw = msgpack.unpackb(checkpoint.to_bytes(st), raw=False, strict_map_key=False)
+    assert raw["opt_state"] == {"0": {}, "1": {}}
+    back = checkpoint.from_bytes(_state(optim.sgd(0.1)), checkpoint.to_bytes(st))
+    assert back.opt_state == {}
 
 
 def test_save_state_writes_reference_filename(tmp_path):
@@ -201,6 +328,7 @@ def test_c_decoder_equals_python_decoder(tmp_path):
 
 
 def test_fast_batches_equal_the_reference_loop(tmp_path):
+    from _reference_loop import batches_item_by_item
     from esrecsys_amd.wikipedia.cooccurrence_matrix import CooccurrenceGenerator
     rng = np.random.default_rng(12)
     _write_lines(tmp_path / "a.cooccur.pb.b64.bz2", [_row(rng, i + 1, int(rng.integers(1, 30))) for i in range(120)])
@@ -211,10 +339,34 @@ def test_fast_batches_equal_the_reference_loop(tmp_path):
         fast = g.get_batch(bs, sh)
         a = [next(fast) for _ in range(40)]
         np.random.seed(99)
-        slow = g.get_batch_reference_loop(bs, sh)
+        slow = batches_item_by_item(g, bs, sh)
         b = [next(slow) for _ in range(40)]
         for (xa, ya), (xb, yb) in zip(a, b):
             assert np.array_equal(xa[0], xb[0]) and np.array_equal(xa[1], xb[1]) and np.array_equal(ya, yb)
+
+
+def test_prefetched_iterator_propagates_producer_failures(tmp_path):
+    """The trainer's call path get_dataset(...).prefetch(AUTOTUNE).as_numpy_iterator(): a producer that dies (no file
+    matches the glob; a malformed line) must raise in next(), not leave the consumer blocked on the queue."""
+    import threading
+    from esrecsys_amd.wikipedia.cooccurrence_matrix import AUTOTUNE, CooccurrenceGenerator
+
+    def first(pattern):
+        box = {}
+
+        def run():
+            try:
+                box["v"] = next(CooccurrenceGenerator(pattern).get_dataset(4).prefetch(AUTOTUNE).as_numpy_iterator())
+            except BaseException as e:  # noqa: BLE001
+                box["e"] = e
+        t = threading.Thread(target=run, daemon=True)
+        t.start()
+        t.join(20)
+        assert not t.is_alive(), "next() hung"
+        return box
+    assert isinstance(first(str(tmp_path / "nothing-*.bz2")).get("e"), FileNotFoundError)
+    _write_lines(tmp_path / "bad.cooccur.pb.b64.bz2", [b"!!!not base64!!!"])
+    assert isinstance(first(str(tmp_path / "bad.*.bz2")).get("e"), ValueError)
 
 
 def test_c_decoder_rejects_malformed_lines():

@@ -171,3 +171,53 @@ def test_cpu_port_matches_oracle():
     eb, _ = optim.sparse_adagrad_update(bias0, np.full((V, 1), 0.1), ids, gb[:, None], lr, dtype=F64)
     assert abs(float(loss) - el) <= 1e-12 and np.abs(emb.numpy() - ee).max() <= 1e-12
     assert np.abs(bias.numpy() - eb).max() <= 1e-12
+
+
+def test_cpu_port_dense_adam_variants_match_oracle():
+    """The reference-faithful CPU baseline variants (dense V x D gradient + optax.adam on every element) == the NumPy
+    oracle's dense gradient + adam_update, two steps (so the moment estimates and the bias correction are exercised)."""
+    import torch
+    from oracle import cpu_port
+    rng = np.random.default_rng(3)
+    V, D, B, lam, lr = 150, 12, 48, 0.1, 1e-3
+    t = lambda a: torch.from_numpy(np.array(a, dtype=np.float64))  # noqa: E731
+
+    def dense(ids, rows, shape):
+        g = np.zeros(shape)
+        np.add.at(g, ids, rows)
+        return g
+
+    # triplet head, the reference's own step (pinterest/train_shop_the_look.py:93-109)
+    st0, pt0 = (rng.standard_normal((V, D)) * 0.4 for _ in range(2))
+    ds, dp = cpu_port.DenseAdam(t(st0), lr), cpu_port.DenseAdam(t(pt0), lr)
+    es, ep, ss, sp = st0.copy(), pt0.copy(), optim.adam_init(st0), optim.adam_init(pt0)
+    for _ in range(2):
+        sid, pid, nid = (rng.integers(0, V, B) for _ in range(3))
+        loss = cpu_port.triplet_step_dense_adam_(ds, dp, torch.from_numpy(sid), torch.from_numpy(pid),
+                                                 torch.from_numpy(nid), lam, float(B))
+        el, gs, gp, gn = stl_head.triplet_loss_and_grads(es[sid], ep[pid], ep[nid], lam, B, F64)
+        assert abs(float(loss) - el) <= 1e-12
+        es, ss = optim.adam_update(es, dense(sid, gs, es.shape), ss, lr, dtype=F64)
+        ep, sp = optim.adam_update(ep, dense(np.concatenate([pid, nid]), np.concatenate([gp, gn]), ep.shape), sp, lr,
+                                   dtype=F64)
+    assert np.abs(ds.p.numpy() - es).max() <= 1e-12 and np.abs(dp.p.numpy() - ep).max() <= 1e-12
+    # GloVe (wikipedia/train_cooccurence.py:71-101)
+    emb0, bias0 = rng.standard_normal((V, D)) * 0.3, rng.standard_normal((V, 1)) * 0.05
+    ae, ab = cpu_port.DenseAdam(t(emb0), lr), cpu_port.DenseAdam(t(bias0), lr)
+    ee, eb, se, sb = emb0.copy(), bias0.copy(), optim.adam_init(emb0), optim.adam_init(bias0)
+    for _ in range(2):
+        inputs, target = rng.integers(0, V, (2, B)), rng.uniform(0.1, 300, B)
+        loss = cpu_port.glove_step_dense_adam_(ae, ab, torch.from_numpy(inputs), torch.from_numpy(target))
+        el, gdot, gs_ = glove.loss_and_grads(ee, eb, inputs, target, "reference", F64)
+        ids, rows, gb = glove.row_grads(ee, inputs, gdot, gs_, F64)
+        assert abs(float(loss) - el) <= 1e-12
+        ee, se = optim.adam_update(ee, dense(ids, rows, ee.shape), se, lr, dtype=F64)
+        eb, sb = optim.adam_update(eb, dense(ids, gb[:, None], eb.shape), sb, lr, dtype=F64)
+    assert np.abs(ae.p.numpy() - ee).max() <= 1e-12 and np.abs(ab.p.numpy() - eb).max() <= 1e-12
+    # in-batch loss with the dense update
+    ds, dp = cpu_port.DenseAdam(t(st0), lr), cpu_port.DenseAdam(t(pt0), lr)
+    sid, pid = rng.integers(0, V, B), rng.integers(0, V, B)
+    loss = cpu_port.inbatch_step_dense_adam_(ds, dp, torch.from_numpy(sid), torch.from_numpy(pid), lam, float(B), 2.0)
+    el, _, gq, gc = stl_head.inbatch_softmax_loss_and_grads(st0[sid], pt0[pid], lam, B, 2.0, F64)
+    es, _ = optim.adam_update(st0, dense(sid, gq, st0.shape), optim.adam_init(st0), lr, dtype=F64)
+    assert abs(float(loss) - el) <= 1e-12 and np.abs(ds.p.numpy() - es).max() <= 1e-12
