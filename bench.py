@@ -169,6 +169,17 @@ def roofline_for(workload, kernels, B, D, rows, precision, occ_n=0, uniq=0, bf16
                 "achieved": alg / t / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": alg / t / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None}
     # HBM-bound workloads: the dominant kernel is whichever of {fused loss kernel, sparse Adagrad} took longer
+    if workload == "glove" and "glove_step" in kernels:
+        # one-pass step (sort + plan + update + long + finalize in ONE ops call): the whole step against SURVEY 8d's
+        # algorithmic bytes; the bytes its update kernel actually needs are the partner row per occurrence + per
+        # distinct row the own row read, the rewrite and the accumulator RMW
+        t = kernels["glove_step"]["ms_per_step"] * 1e-3
+        alg = STEP_BYTES_PER_UNIT["glove"](D) * B
+        moved = (occ_n + 4 * uniq) * D * 4
+        return {"kernel": "esr_glove_train_step (sort + glove_plan + glove_step + glove_step_long + finalize)",
+                "bound": "hbm", "achieved": alg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": alg / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "bytes_the_update_needs_per_step": moved, "those_bytes_GBps": moved / t / 1e9}
     fused_name = "triplet_fused" if workload == "triplet" else "glove_fused"
     fused_bytes = rows * B * D * 4 * 2  # reads `rows` rows and writes `rows` gradient rows per unit
     ada_bytes = (occ_n + 4 * uniq) * D * 4  # grad row read per occurrence + param/accum RMW per distinct row
@@ -186,6 +197,7 @@ TIMED_GROUPS = {
     "inbatch_mfma": ["inbatch_softmax_fwd_bwd", "inbatch_towers_fwd_bwd"],
     "triplet_fused": ["triplet_fwd_bwd"],
     "glove_fused": ["glove_fwd_bwd"],
+    "glove_step": ["glove_train_step"],
     "segment_sort": ["segment_sort", "segment_sort_multi"],
     "sparse_adagrad": ["sparse_adagrad", "sparse_adagrad_multi"],
 }
@@ -248,9 +260,10 @@ PRECISION = "auto"
 
 def run_step(workload, state, batch, B):
     if workload == "glove":
-        from esrecsys_amd.wikipedia.train_cooccurence import apply_model, update_model
-        grads, loss = apply_model(state, batch[0], batch[1])
-        return update_model(state, grads), loss
+        # the step train_epoch runs (wikipedia/train_cooccurence.py:103-112): one pass under the build's sparse Adagrad,
+        # apply_model + update_model when ESR_GLOVE_FUSED=0
+        from esrecsys_amd.wikipedia.train_cooccurence import train_step as glove_train_step
+        return glove_train_step(state, batch[0], batch[1])
     from esrecsys_amd.pinterest.train_shop_the_look import train_step
     if workload == "inbatch":
         return train_step(state, batch[0], batch[1], None, LAM, B, scale=SCALE, precision=PRECISION)

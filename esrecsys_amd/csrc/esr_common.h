@@ -148,6 +148,16 @@ __device__ __forceinline__ float row_dot_partial(const RowRegs<VEC, NCH>& a, con
   return acc;
 }
 
+// optax.adagrad [upstream]: acc += g^2 ; p -= lr * g * rsqrt(acc + eps)  (0 where acc == 0).  ONE definition for every
+// kernel that applies it (esr_optim.hip, esr_glove_step.hip), so their results are bit-identical.
+__device__ __forceinline__ void adagrad_elem(float& w, float& a, float gv, float lr, float eps) {
+  // explicit roundings: no fused multiply-add may be formed here, whatever kernel this is inlined into
+  const float acc = __fmaf_rn(gv, gv, a);
+  a = acc;
+  const float inv = acc > 0.f ? __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(acc, eps))) : 0.f;
+  w = __fsub_rn(w, __fmul_rn(__fmul_rn(lr, gv), inv));
+}
+
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 // round-to-nearest-even, NaN preserved
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) {

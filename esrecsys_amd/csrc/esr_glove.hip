@@ -209,6 +209,472 @@ __global__ __launch_bounds__(kBlock) void glove_finalize_kernel(
   }
 }
 
+// =====================================================================================================================
+// The whole train step in one pass over the rows: esr_glove_train_step (G3 + G4 + the build's sparse Adagrad).
+//
+// The three-kernel path above materialises a [2B, D] gradient (written once, read once by the optimizer): 7 row
+// transfers per occurrence where the algorithm needs ~4.5 (read the partner row; read, rewrite the own row once per
+// DISTINCT row; read-modify-write its accumulator).  Producing the gradient inside the update instead runs into a
+// hazard: occurrence (row a, partner b) needs the PRE-step value of b while another workgroup may already have
+// rewritten b.  288 GB of HBM buy the way out: the table is kept in TWO buffers with a per-row byte `loc` that says
+// which one holds the row's current value.  The step reads rows where `loc` pointed when the step began (resolved
+// up front by the plan kernel, so the update kernel has no dependent index chain and no race on `loc`), writes every
+// updated row into the OTHER buffer and flips its byte.  Readers and writers of one step never touch the same bytes,
+// no gradient row and no snapshot ever goes to memory, and untouched rows cost nothing.  esr_rows_consolidate copies
+// the rows whose byte is set back into the primary buffer when somebody needs a plain [V, D] table (eval, kNN,
+// checkpoint).
+//
+//   sort      occurrence ids [t1 ; t2] -> (sorted, perm)                       esr_segment_sort_ids
+//   plan      per sorted position: partner row (id | loc bit | side bit), w_j, log10(1 + c_j), s_j; own row code;
+//             the bias statistics of K_A in K_A's own summation order
+//   update    one row group per sorted position, the head of a run walks it: dot with each partner row, gdot,
+//             G += gdot * partner (left to right, products rounded as the gradient rows used to be: bit-identical
+//             tables), Adagrad once per distinct row; loss partials; per-run bias sums
+//   long      runs longer than a chunk (hot tokens): chunk partials combined in a fixed order
+//   finalize  loss scalar; bias Adagrad (needs the global sum of w r, known only now)
+// =====================================================================================================================
+constexpr int kStepChunk = 32;  // == kSegChunk of esr_optim.hip: same cut points, same association, same bits
+constexpr uint32_t kLocBit = 0x80000000u, kSideBit = 0x40000000u, kIdMask = 0x3FFFFFFFu;
+
+struct StepWs {
+  int32_t* sorted_ids;   // [n]
+  int32_t* perm;         // [n]
+  uint32_t* own_code;    // [n]  id | loc bit of the row that sorted position p updates
+  float4* meta;          // [n]  {partner code (bits), w, log10(1 + c), s}
+  double2* bias_info;    // [n]  per run head / chunk start: {sum over its occurrences of s (reference) or gdot, count}
+  double* stat_part;     // [kStatBlocks][2]
+  double* pair_part;     // [kPairBlocks][3]
+  double* pair_tot;      // [3]   sum w, sum w r, sum w (r - center)^2 over the batch
+  float* chunk_rows;     // [2 * ceil(n / 32)][D]  partial sums of long runs (slot 2c: chunk starting at 32c; 2c + 1:
+                         //                        the head chunk whose head lies in block c)
+  void* sort_ws;
+  size_t sort_ws_bytes;
+};
+
+static size_t step_ws_layout(int64_t B, int D, char* base, StepWs* ws) {
+  const int64_t n = 2 * B;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += align_up(bytes, 256);
+    return p;
+  };
+  StepWs w;
+  w.sorted_ids = (int32_t*)take(sizeof(int32_t) * (size_t)n);
+  w.perm = (int32_t*)take(sizeof(int32_t) * (size_t)n);
+  w.own_code = (uint32_t*)take(sizeof(uint32_t) * (size_t)n);
+  w.meta = (float4*)take(sizeof(float4) * (size_t)n);
+  w.bias_info = (double2*)take(sizeof(double2) * (size_t)n);
+  w.stat_part = (double*)take(sizeof(double) * 2 * kStatBlocks);
+  w.pair_part = (double*)take(sizeof(double) * 3 * kPairBlocks);
+  w.pair_tot = (double*)take(sizeof(double) * 4);
+  w.chunk_rows = (float*)take(sizeof(float) * 2 * (size_t)cdiv(n, kStepChunk) * (size_t)D);
+  w.sort_ws_bytes = esr_segment_sort_workspace_bytes(n);
+  w.sort_ws = take(w.sort_ws_bytes);
+  if (ws) *ws = w;
+  return off;
+}
+
+// plan: blocks [0, nstat) first redo K_A's loop over the pairs (same grid, same per-thread order: the bias statistics,
+// hence sbar and every gdot, are bit-identical to the three-kernel path); then every block resolves its sorted positions.
+__global__ __launch_bounds__(kBlock) void glove_plan_kernel(const int32_t* __restrict__ sorted_ids,
+                                                           const int32_t* __restrict__ perm,
+                                                           const int32_t* __restrict__ inputs,
+                                                           const float* __restrict__ target,
+                                                           const float* __restrict__ bias,
+                                                           const uint8_t* __restrict__ loc, int64_t B, int nstat,
+                                                           uint32_t* __restrict__ own_code, float4* __restrict__ meta,
+                                                           double* __restrict__ stat_part) {
+  __shared__ double sm[8];
+  if ((int)blockIdx.x < nstat) {
+    double a = 0.0, a2 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < B; i += (int64_t)nstat * kBlock) {
+      const float s = bias[inputs[i]] + bias[inputs[B + i]];
+      a += (double)s;
+      a2 += (double)s * (double)s;
+    }
+    const double t = block_sum_d(a, sm);
+    const double t2 = block_sum_d(a2, sm + 4);
+    if (threadIdx.x == 0) {
+      stat_part[2 * blockIdx.x] = t;
+      stat_part[2 * blockIdx.x + 1] = t2;
+    }
+  }
+  const int64_t n = 2 * B;
+  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock) {
+    const int32_t id = sorted_ids[p];
+    const int64_t o = perm[p];
+    const bool side = o >= B;
+    const int64_t j = side ? o - B : o;
+    const int32_t t1 = inputs[j], t2 = inputs[B + j];
+    const int32_t partner = side ? t1 : t2;
+    const float c_j = target[j];
+    float4 m;
+    m.x = __uint_as_float((uint32_t)partner | (loc[partner] ? kLocBit : 0u) | (side ? kSideBit : 0u));
+    m.y = powf(fminf(1.0f, c_j / 100.0f), 0.75f);  // weight = min(1, c/100)^0.75   (train_cooccurence.py:79-81)
+    m.z = log10f(1.0f + c_j);                      // log10(1 + c)                  (train_cooccurence.py:82)
+    m.w = bias[t1] + bias[t2];
+    meta[p] = m;
+    own_code[p] = (uint32_t)id | (loc[id] ? kLocBit : 0u);
+  }
+}
+
+template <int VEC, int NCH>
+__device__ __forceinline__ void row_zero(RowRegs<VEC, NCH>& r) {
+#pragma unroll
+  for (int k = 0; k < NCH; ++k)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) r.v[k][e] = 0.f;
+}
+
+// the versioned read-modify-write of one row with its summed gradient g: the row was read where `code` says it lives
+// (`own`), its new value goes to the OTHER buffer and the byte flips (nobody reads `loc` during this launch: the plan
+// kernel resolved every address).  `a` = the row's accumulator, loaded by the caller next to `own`.
+template <int VEC, int NCH>
+__device__ __forceinline__ void step_apply(float* __restrict__ emb0, float* __restrict__ emb1, uint8_t* __restrict__ loc,
+                                           float* __restrict__ accum, uint32_t code, const RowRegs<VEC, NCH>& own,
+                                           RowRegs<VEC, NCH>& a, const RowRegs<VEC, NCH>& g, int D, int lig, int G,
+                                           int nvec, float lr, float eps) {
+  const int64_t id = code & kIdMask;
+  RowRegs<VEC, NCH> w = own;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) adagrad_elem(w.v[k][e], a.v[k][e], g.v[k][e], lr, eps);
+  row_store(a, accum + id * D, lig, G, nvec);
+  row_store(w, ((code & kLocBit) ? emb0 : emb1) + id * D, lig, G, nvec);
+  if (lig == 0) loc[id] = (code & kLocBit) ? 0 : 1;
+}
+
+// update: the structure of segment_update_kernel (esr_optim.hip) with the gradient rows produced on the fly.
+// A group's critical path per position is ONE memory round trip: the position's code and plan record are fetched one
+// iteration ahead, and the own row, its accumulator and the first partner row are requested together (the accumulator
+// speculatively: a chunk of a long run does not need it).  Written naively -- code, then own row and record, then
+// partner row, then accumulator -- the same loop was four dependent round trips and ran at 3.2 TB/s.
+template <int VEC, int NCH>
+__global__ __launch_bounds__(kBlock) void glove_step_kernel(
+    float* __restrict__ emb0, float* __restrict__ emb1, uint8_t* __restrict__ loc, float* __restrict__ accum, int D,
+    int G, const uint32_t* __restrict__ own_code, const float4* __restrict__ meta, int64_t n, int64_t B, int mode,
+    int nstat, const double* __restrict__ stat_part, float lr, float eps, float* __restrict__ chunk_rows,
+    double2* __restrict__ bias_info, double* __restrict__ pair_part) {
+  __shared__ double sm[16];
+  const int lig = threadIdx.x & (G - 1);
+  const int64_t gpb = kBlock / G;
+  const int64_t group = (int64_t)blockIdx.x * gpb + threadIdx.x / G;
+  const int64_t ngroups = (int64_t)gridDim.x * gpb;
+  const int nvec = D / VEC;
+  const int64_t per = (n + ngroups - 1) / ngroups;  // contiguous slices (see segment_update_kernel)
+  const int64_t p_begin = group * per, p_end = min(n, (group + 1) * per);
+  // the first position's records are requested before the statistics are reduced
+  uint32_t code_n = 0, prev_n = 0xFFFFFFFFu;
+  float4 m_n = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p_begin < p_end) {
+    code_n = own_code[p_begin];
+    if (p_begin > 0) prev_n = own_code[p_begin - 1];
+    m_n = meta[p_begin];
+  }
+  double sum_s = 0.0, sum_s2 = 0.0;
+  if (mode == ESR_GLOVE_REFERENCE) reduce_stat_parts(stat_part, nstat, sm, &sum_s, &sum_s2);
+  const float sbar = (float)(sum_s / (double)B);
+  const float two_over_B = 2.0f / (float)B;
+  double acc_w = 0.0, acc_wr = 0.0, acc_wq = 0.0;
+
+  for (int64_t p = p_begin; p < p_end; ++p) {
+    const uint32_t code = code_n, prev = prev_n;
+    const float4 m_first = m_n;
+    const bool more = p + 1 < n;
+    if (more) {  // next position's records (also tells where this run ends)
+      code_n = own_code[p + 1];
+      m_n = meta[p + 1];
+    }
+    prev_n = code;
+    const uint32_t id = code & kIdMask;
+    const bool head = (prev & kIdMask) != id;  // prev = all ones at p == 0: no id equals kIdMask
+    if (!head && ((p & (kStepChunk - 1)) != 0 || (own_code[p - kStepChunk] & kIdMask) != id)) continue;
+    const int64_t stop = min(head ? ((p + 2 * kStepChunk - 1) / kStepChunk) * kStepChunk : p + kStepChunk, n);
+    auto part_ptr = [&](const float4& m) {
+      const uint32_t c = __float_as_uint(m.x);
+      return ((c & kLocBit) ? emb1 : emb0) + (int64_t)(c & kIdMask) * D;
+    };
+    RowRegs<VEC, NCH> own, a, g, first;
+    row_load(own, ((code & kLocBit) ? emb1 : emb0) + (int64_t)id * D, lig, G, nvec);
+    row_load(first, part_ptr(m_first), lig, G, nvec);
+    row_load(a, accum + (int64_t)id * D, lig, G, nvec);
+    int64_t e_run = p + 1;
+    if (more && (code_n & kIdMask) == id) {  // a run of several occurrences: find the end of this chunk
+      ++e_run;
+      while (e_run < stop && (own_code[e_run] & kIdMask) == id) ++e_run;
+      if (e_run > stop) e_run = stop;
+    }
+    row_zero(g);
+    double bsum = 0.0;  // fp64: a hot token's bias gradient is a sum over thousands of occurrences
+    // one occurrence: gdot from the dot with its partner row; G += gdot * partner, the product rounded to f32 first
+    // (it used to be stored as a gradient row) and the additions strictly left to right
+    auto occ = [&](const float4& m, const RowRegs<VEC, NCH>& part) {
+      const float dot = group_sum(row_dot_partial(own, part), G);
+      const float r = m.z - dot;
+      const float center = (mode == ESR_GLOVE_REFERENCE) ? sbar : m.w;
+      const float gdot = -(two_over_B * m.y) * (r - center);
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) g.v[k][e] = __fadd_rn(g.v[k][e], __fmul_rn(gdot, part.v[k][e]));
+      bsum += (double)((mode == ESR_GLOVE_REFERENCE) ? m.w : gdot);
+      if (lig == 0 && !(__float_as_uint(m.x) & kSideBit)) {  // every pair is seen from both sides: count it once
+        const double q = (double)r - (double)center;
+        acc_w += (double)m.y;
+        acc_wr += (double)m.y * (double)r;
+        acc_wq += (double)m.y * q * q;
+      }
+    };
+    occ(m_first, first);
+    int64_t q = p + 1;
+    for (; q + 4 <= e_run; q += 4) {  // four partner rows in flight
+      const float4 m0 = meta[q], m1 = meta[q + 1], m2 = meta[q + 2], m3 = meta[q + 3];
+      RowRegs<VEC, NCH> t0, t1, t2, t3;
+      row_load(t0, part_ptr(m0), lig, G, nvec);
+      row_load(t1, part_ptr(m1), lig, G, nvec);
+      row_load(t2, part_ptr(m2), lig, G, nvec);
+      row_load(t3, part_ptr(m3), lig, G, nvec);
+      occ(m0, t0);
+      occ(m1, t1);
+      occ(m2, t2);
+      occ(m3, t3);
+    }
+    for (; q < e_run; ++q) {
+      const float4 m = meta[q];
+      RowRegs<VEC, NCH> t;
+      row_load(t, part_ptr(m), lig, G, nvec);
+      occ(m, t);
+    }
+    const bool ends = q == n || (own_code[q] & kIdMask) != id;
+    if (lig == 0) bias_info[p] = make_double2(bsum, (double)(e_run - p));
+    if (head && ends) {
+      step_apply<VEC, NCH>(emb0, emb1, loc, accum, code, own, a, g, D, lig, G, nvec, lr, eps);
+    } else {  // a chunk of a long run: park the partial sum for glove_step_long_kernel
+      const int64_t slot = 2 * (p / kStepChunk) + (head ? 1 : 0);
+      row_store(g, chunk_rows + slot * D, lig, G, nvec);
+    }
+  }
+  const double tw = block_sum_d(acc_w, sm);
+  const double twr = block_sum_d(acc_wr, sm + 4);
+  const double twq = block_sum_d(acc_wq, sm + 8);
+  if (threadIdx.x == 0) {
+    pair_part[3 * blockIdx.x] = tw;
+    pair_part[3 * blockIdx.x + 1] = twr;
+    pair_part[3 * blockIdx.x + 2] = twq;
+  }
+}
+
+// long: segment_long_kernel's screening and fixed-order combination over the parked chunk partials; also folds the
+// chunks' bias sums into the head's bias_info entry.
+template <int VEC, int NCH>
+__global__ __launch_bounds__(kBlock) void glove_step_long_kernel(
+    float* __restrict__ emb0, float* __restrict__ emb1, uint8_t* __restrict__ loc, float* __restrict__ accum, int D,
+    int G, const uint32_t* __restrict__ own_code, int64_t n, float lr, float eps,
+    const float* __restrict__ chunk_rows, double2* __restrict__ bias_info, int npair,
+    const double* __restrict__ pair_part, double* __restrict__ pair_tot) {
+  // the last workgroup also reduces the update kernel's loss partials (fixed order) to three doubles, so that the
+  // finalize kernel's workgroups read three numbers instead of re-reducing a thousand partials each
+  if (blockIdx.x == gridDim.x - 1) {
+    __shared__ double smp[12];
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < npair; i += kBlock) {
+      a += pair_part[3 * i];
+      b += pair_part[3 * i + 1];
+      c += pair_part[3 * i + 2];
+    }
+    const double tw = block_sum_d(a, smp);
+    const double twr = block_sum_d(b, smp + 4);
+    const double twq = block_sum_d(c, smp + 8);
+    if (threadIdx.x == 0) {
+      pair_tot[0] = tw;
+      pair_tot[1] = twr;
+      pair_tot[2] = twq;
+    }
+  }
+  __shared__ float red[kBlock * VEC * NCH];
+  __shared__ double smd[8];
+  constexpr int kPass = 4;
+  __shared__ long long s_long[kPass];
+  __shared__ int s_nlong, s_hoff;
+  const int tid = threadIdx.x, lig = tid & (G - 1), gidx = tid / G, NG = kBlock / G;
+  const int nvec = D / VEC;
+  auto id_at = [&](int64_t pos) { return own_code[pos] & kIdMask; };
+  const int64_t nbound = (n - 1) / kStepChunk;
+  for (int64_t b0 = (int64_t)blockIdx.x * kPass; b0 < nbound; b0 += (int64_t)gridDim.x * kPass) {
+    __syncthreads();
+    if (tid == 0) s_nlong = 0;
+    __syncthreads();
+    {
+      const int64_t Bd = (b0 + tid + 1) * kStepChunk;
+      if (tid < kPass && b0 + tid < nbound) {
+        const uint32_t id_b = id_at(Bd);
+        const bool first = Bd < 2 * kStepChunk || id_at(Bd - 2 * kStepChunk) != id_b;
+        if (id_at(Bd - kStepChunk) == id_b && first) s_long[atomicAdd(&s_nlong, 1)] = Bd;
+      }
+    }
+    __syncthreads();
+    const int nlong = s_nlong;
+    for (int li = 0; li < nlong; ++li) {
+      const int64_t nxt = s_long[li];
+      const uint32_t id = id_at(nxt);
+      const int64_t win = max<int64_t>(nxt - 2 * kStepChunk + 1, 0);
+      if (tid < 64) {
+        const int64_t pos = win + tid;
+        const bool is_head = pos <= nxt - kStepChunk && id_at(pos) == id && (pos == 0 || id_at(pos - 1) != id);
+        const unsigned long long m = __ballot(is_head);
+        if (tid == 0) s_hoff = __ffsll((long long)m) - 1;
+      }
+      __syncthreads();
+      const int64_t h = win + s_hoff;
+      int64_t K = 0;  // continuation chunks
+      for (int64_t k0 = 0;; k0 += kBlock) {
+        const int64_t pos = nxt + (k0 + tid) * kStepChunk;
+        const int cnt = __syncthreads_count(pos < n && id_at(pos) == id);
+        K += cnt;
+        if (cnt < kBlock) break;
+      }
+      auto part_row = [&](int64_t i) {
+        return (i == 0 ? 2 * (h / kStepChunk) + 1 : 2 * ((nxt + (i - 1) * kStepChunk) / kStepChunk)) * (int64_t)D;
+      };
+      auto part_pos = [&](int64_t i) { return i == 0 ? h : nxt + (i - 1) * kStepChunk; };
+      RowRegs<VEC, NCH> acc;
+      row_zero(acc);
+      int64_t i = gidx;
+      for (; i + 3 * NG <= K; i += 4 * NG) {
+        RowRegs<VEC, NCH> t0, t1, t2, t3;
+        row_load(t0, chunk_rows + part_row(i), lig, G, nvec);
+        row_load(t1, chunk_rows + part_row(i + NG), lig, G, nvec);
+        row_load(t2, chunk_rows + part_row(i + 2 * NG), lig, G, nvec);
+        row_load(t3, chunk_rows + part_row(i + 3 * NG), lig, G, nvec);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e)
+            acc.v[k][e] = (((acc.v[k][e] + t0.v[k][e]) + t1.v[k][e]) + t2.v[k][e]) + t3.v[k][e];
+      }
+      for (; i <= K; i += NG) {
+        RowRegs<VEC, NCH> t;
+        row_load(t, chunk_rows + part_row(i), lig, G, nvec);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc.v[k][e] += t.v[k][e];
+      }
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) red[((gidx * G + lig) * NCH + k) * VEC + e] = acc.v[k][e];
+      // the run's bias sums: chunk entries added in a fixed tree (fp64 carries them exactly enough to be order-free)
+      double bs = 0.0, bc = 0.0;
+      for (int64_t c = tid; c <= K; c += kBlock) {
+        const double2 v = bias_info[part_pos(c)];
+        bs += v.x;
+        bc += v.y;
+      }
+      const double tbs = block_sum_d(bs, smd);  // (its barriers also publish `red`)
+      const double tbc = block_sum_d(bc, smd + 4);
+      if (tid == 0) bias_info[h] = make_double2(tbs, tbc);
+      if (gidx == 0) {
+        const int used = (int)min<int64_t>(NG, K + 1);
+        for (int gg = 1; gg < used; ++gg)
+#pragma unroll
+          for (int k = 0; k < NCH; ++k)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc.v[k][e] += red[((gg * G + lig) * NCH + k) * VEC + e];
+        const uint32_t code = own_code[h];
+        RowRegs<VEC, NCH> own, a;
+        row_load(own, ((code & kLocBit) ? emb1 : emb0) + (int64_t)id * D, lig, G, nvec);
+        row_load(a, accum + (int64_t)id * D, lig, G, nvec);
+        step_apply<VEC, NCH>(emb0, emb1, loc, accum, code, own, a, acc, D, lig, G, nvec, lr, eps);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// finalize: the loss (same formula as glove_finalize_kernel) and the bias table's Adagrad step, one thread per sorted
+// position; a run head holds its run's sums.  Reference mode: sum over the run of dL/ds = -(2/B^2) (cnt * Swr - Sw *
+// sum s); diagonal mode: the sum of gdot itself.
+__global__ __launch_bounds__(kBlock) void glove_step_finalize_kernel(
+    int64_t B, int mode, int nstat, const double* __restrict__ stat_part, const double* __restrict__ pair_tot,
+    const uint32_t* __restrict__ own_code, const double2* __restrict__ bias_info, float* __restrict__ bias,
+    float* __restrict__ bias_accum, float lr, float eps, float* __restrict__ loss) {
+  __shared__ double sm[20];
+  // this thread's position: everything it needs from memory is requested before the reductions below
+  const int64_t n = 2 * B;
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  uint32_t id = 0;
+  bool head = false;
+  double2 v = make_double2(0.0, 0.0);
+  float w = 0.f, acc = 0.f;
+  if (p < n) {
+    id = own_code[p] & kIdMask;
+    head = p == 0 || (own_code[p - 1] & kIdMask) != id;
+    if (head) {
+      v = bias_info[p];
+      w = bias[id];
+      acc = bias_accum[id];
+    }
+  }
+  const double Sw = pair_tot[0], Swr = pair_tot[1], Swq = pair_tot[2];
+  const double Bd = (double)B;
+  if (blockIdx.x == 0) {
+    double sum_s = 0.0, sum_s2 = 0.0;
+    if (mode == ESR_GLOVE_REFERENCE) reduce_stat_parts(stat_part, nstat, sm, &sum_s, &sum_s2);
+    if (threadIdx.x == 0) {
+      double L;
+      if (mode == ESR_GLOVE_REFERENCE) {
+        double SS = sum_s2 - sum_s * sum_s / Bd;
+        if (SS < 0.0) SS = 0.0;
+        L = (Bd * Swq + Sw * SS) / (Bd * Bd);
+      } else {
+        L = Swq / Bd;
+      }
+      loss[0] = (float)L;
+    }
+  }
+  if (head) {
+    const double k = 2.0 / (Bd * Bd);
+    const float gb = (float)((mode == ESR_GLOVE_REFERENCE) ? -k * (v.y * Swr - Sw * v.x) : v.x);
+    adagrad_elem(w, acc, gb, lr, eps);
+    bias[id] = w;
+    bias_accum[id] = acc;
+  }
+}
+
+// rows whose byte is set live in `shadow`: copy them back into `primary` and clear the byte (T = float4 or float)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void rows_consolidate_kernel(T* __restrict__ primary, const T* __restrict__ shadow,
+                                                                 uint8_t* __restrict__ loc, int64_t V, int nchunk,
+                                                                 int G) {
+  const int lig = threadIdx.x & (G - 1);
+  const int64_t gpb = kBlock / G;
+  const int64_t group = (int64_t)blockIdx.x * gpb + threadIdx.x / G;
+  const int64_t ngroups = (int64_t)gridDim.x * gpb;
+  for (int64_t r = group; r < V; r += ngroups) {
+    if (!loc[r]) continue;
+    for (int c = lig; c < nchunk; c += G) primary[r * nchunk + c] = shadow[r * nchunk + c];
+    if (lig == 0) loc[r] = 0;
+  }
+}
+
+// blocks of `kernel` (kBlock threads, no dynamic LDS) the whole device holds at once; kMaxGrid if the query fails
+static int resident_blocks(const void* kernel) {
+  int per_cu = 0, dev = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || per_cu < 1) {
+    (void)hipGetLastError();
+    return kMaxGrid;
+  }
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
+    (void)hipGetLastError();
+    return kMaxGrid;
+  }
+  return std::min(kMaxGrid, per_cu * cus);
+}
+
 static int check_dim(const char* who, int D) {
   const RowGeom g = row_geom(D);
   if (g.nch > kMaxChunksPerLane) {
@@ -290,6 +756,79 @@ int esr_glove_fwd_bwd(const float* emb, const float* bias, int64_t V, int D, con
                      (const double*)ws.stat_part, (const double*)ws.pair_part, (const float*)ws.s, inputs, loss,
                      grad_bias);
   return check_launch("esr_glove_fwd_bwd");
+}
+
+size_t esr_glove_step_workspace_bytes(int64_t B, int D) {
+  if (B <= 0 || D <= 0) return 0;
+  return step_ws_layout(B, D, nullptr, nullptr);
+}
+
+int esr_glove_train_step(float* emb, float* emb_shadow, uint8_t* emb_loc, float* emb_accum, float* bias,
+                         float* bias_accum, int64_t V, int D, const int32_t* inputs, const float* target, int64_t B,
+                         int mode, float lr, float eps, float* loss, void* workspace, size_t workspace_bytes,
+                         esr_stream_t stream) {
+  ESR_REQUIRE(B > 0 && V > 0 && D > 0, "esr_glove_train_step: bad sizes V=%lld D=%d B=%lld", (long long)V, D,
+              (long long)B);
+  ESR_REQUIRE(V <= (int64_t)kIdMask, "esr_glove_train_step: V=%lld exceeds 2^30 - 1 rows", (long long)V);
+  ESR_REQUIRE(2 * B < ((int64_t)1 << 31), "esr_glove_train_step: B=%lld too large", (long long)B);
+  ESR_REQUIRE(mode == ESR_GLOVE_REFERENCE || mode == ESR_GLOVE_DIAGONAL, "esr_glove_train_step: bad mode %d", mode);
+  ESR_REQUIRE(emb && emb_shadow && emb_loc && emb_accum && bias && bias_accum && inputs && target && loss,
+              "esr_glove_train_step: null pointer");
+  ESR_REQUIRE(emb != emb_shadow, "esr_glove_train_step: the shadow table must be a second buffer");
+  if (int rc = check_dim("esr_glove_train_step", D)) return rc;
+  if (!workspace || workspace_bytes < esr_glove_step_workspace_bytes(B, D) || ((uintptr_t)workspace & 15)) {
+    set_error("esr_glove_train_step: workspace %zu bytes < %zu required (or misaligned)", workspace_bytes,
+              esr_glove_step_workspace_bytes(B, D));
+    return ESR_EWORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  StepWs ws;
+  step_ws_layout(B, D, (char*)workspace, &ws);
+  const int64_t n = 2 * B;
+  if (int rc = esr_segment_sort_ids(inputs, n, V, ws.sorted_ids, ws.perm, ws.sort_ws, ws.sort_ws_bytes, stream)) return rc;
+  const RowGeom g = row_geom(D);
+  const int nstat = (int)std::min<int64_t>(kStatBlocks, cdiv(B, kBlock));
+  const int nplan = (int)std::max<int64_t>(nstat, std::min<int64_t>(kMaxGrid, cdiv(n, kBlock)));
+  hipLaunchKernelGGL(glove_plan_kernel, dim3(nplan), dim3(kBlock), 0, st, (const int32_t*)ws.sorted_ids,
+                     (const int32_t*)ws.perm, inputs, target, (const float*)bias, (const uint8_t*)emb_loc, B, nstat,
+                     ws.own_code, ws.meta, ws.stat_part);
+  int grid = grid_for_groups(n, g.G);
+  const int grid2 = (int)std::min<int64_t>(kMaxGrid, cdiv(cdiv(n, kStepChunk), 4));
+  ESR_DISPATCH_ROW(g, {
+    // one resident wave-set: every group walks a contiguous slice, so a grid larger than what the chip holds at once
+    // only adds a second, partly filled round (94 VGPRs -> 5 blocks per CU: 2048 blocks ran as 1280 + 768)
+    grid = std::min(grid, resident_blocks((const void*)glove_step_kernel<VEC, NCH>));
+    hipLaunchKernelGGL((glove_step_kernel<VEC, NCH>), dim3(grid), dim3(kBlock), 0, st, emb, emb_shadow, emb_loc,
+                       emb_accum, D, g.G, (const uint32_t*)ws.own_code, (const float4*)ws.meta, n, B, mode, nstat,
+                       (const double*)ws.stat_part, lr, eps, ws.chunk_rows, ws.bias_info, ws.pair_part);
+    // (always launched: its last workgroup reduces the loss partials for the finalize kernel)
+    hipLaunchKernelGGL((glove_step_long_kernel<VEC, NCH>), dim3(grid2), dim3(kBlock), 0, st, emb, emb_shadow, emb_loc,
+                       emb_accum, D, g.G, (const uint32_t*)ws.own_code, n, lr, eps, (const float*)ws.chunk_rows,
+                       ws.bias_info, grid, (const double*)ws.pair_part, ws.pair_tot);
+  });
+  const int nfin = (int)cdiv(n, kBlock);  // one thread per sorted position
+  hipLaunchKernelGGL(glove_step_finalize_kernel, dim3(nfin), dim3(kBlock), 0, st, B, mode, nstat,
+                     (const double*)ws.stat_part, (const double*)ws.pair_tot, (const uint32_t*)ws.own_code,
+                     (const double2*)ws.bias_info, bias, bias_accum, lr, eps, loss);
+  return check_launch("esr_glove_train_step");
+}
+
+int esr_rows_consolidate(float* primary, const float* shadow, uint8_t* loc, int64_t V, int D, esr_stream_t stream) {
+  ESR_REQUIRE(V >= 0 && D > 0, "esr_rows_consolidate: bad sizes V=%lld D=%d", (long long)V, D);
+  if (V == 0) return ESR_OK;
+  ESR_REQUIRE(primary && shadow && loc, "esr_rows_consolidate: null pointer");
+  const bool vec = D % 4 == 0;
+  const int nchunk = vec ? D / 4 : D;
+  int G = 1;
+  while (G < nchunk && G < kWave) G <<= 1;
+  const int grid = grid_for_groups(V, G);
+  if (vec)
+    hipLaunchKernelGGL(rows_consolidate_kernel<float4>, dim3(grid), dim3(kBlock), 0, as_stream(stream), (float4*)primary,
+                       (const float4*)shadow, loc, V, nchunk, G);
+  else
+    hipLaunchKernelGGL(rows_consolidate_kernel<float>, dim3(grid), dim3(kBlock), 0, as_stream(stream), primary, shadow,
+                       loc, V, nchunk, G);
+  return check_launch("esr_rows_consolidate");
 }
 
 }  // extern "C"

@@ -134,13 +134,7 @@ __device__ __forceinline__ void seg_apply(const FusedTables& ft, int dtype, int3
 #pragma unroll
     for (int k = 0; k < NCH; ++k)
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        const float gv = g.v[k][e];
-        const float acc = fmaf(gv, gv, a.v[k][e]);
-        a.v[k][e] = acc;
-        const float inv = acc > 0.f ? 1.0f / sqrtf(acc + eps) : 0.f;
-        w.v[k][e] -= lr * gv * inv;
-      }
+      for (int e = 0; e < VEC; ++e) adagrad_elem(w.v[k][e], a.v[k][e], g.v[k][e], lr, eps);
     row_store(a, accum + id * D, lig, G, nvec);
     param_store(w, table, dtype, id, D, lig, G, nvec);
   }

@@ -129,23 +129,16 @@ __device__ __forceinline__ uint32_t xor_lane(uint32_t v, int stride) {
   }
 }
 
+// Bitonic network over kTile = 2^TB keys held two per thread: thread t holds positions t (k0) and t + kTile / 2 (k1).
+// A compare-exchange with stride < 64 has its partner in the same wave (lane ^ stride) and is one cross-lane move per key
+// -- 51 of the 66 steps of a 2048-key tile; the stride kTile / 2 pairs the thread's own two registers; only the strides
+// in between go through LDS and a barrier (14 steps).  With every step in LDS behind a barrier the 2048-key tile took
+// 11 us.  `key` = 2 * kTile words of LDS.
 template <int TB>
-__global__ __launch_bounds__((1 << TB) / 2) void tile_sort_kernel(SortSegs ids, int n, uint32_t* __restrict__ tiles,
-                                                                 uint32_t* __restrict__ splitters) {
-  // Bitonic network over kTile keys, two per thread: thread t holds positions t and t + kTile / 2.  A compare-exchange
-  // with stride < 64 has its partner in the same wave (lane ^ stride) and is one cross-lane move per key -- 51 of the 66
-  // steps of a 2048-key tile; the stride kTile / 2 pairs the thread's own two registers; only the strides in between go
-  // through LDS and a barrier (14 steps).  With every step in LDS behind a barrier the 2048-key tile took 11 us.
+__device__ __forceinline__ void tile_bitonic(uint32_t& k0, uint32_t& k1, uint32_t* key) {
   constexpr int kTile = 1 << TB, kHalf = kTile / 2;
-  __shared__ uint32_t key[2 * kTile];
-  const int t = threadIdx.x, base = blockIdx.x * kTile;
+  const int t = threadIdx.x;
   int flip = 0;
-  uint32_t k0, k1;
-  {
-    const int g0 = base + t, g1 = base + t + kHalf;
-    k0 = g0 < n ? ((uint32_t)seg_id(ids, g0) << TB) | (uint32_t)t : 0xFFFFFFFFu;
-    k1 = g1 < n ? ((uint32_t)seg_id(ids, g1) << TB) | (uint32_t)(t + kHalf) : 0xFFFFFFFFu;
-  }
   // new value of the key at position p after meeting its partner's key o at distance `stride` inside a run of `size`
   auto cx = [](uint32_t mine, uint32_t other, int p, int stride, int size) {
     const bool lower = (p & stride) == 0, asc = (p & size) == 0;
@@ -178,6 +171,21 @@ __global__ __launch_bounds__((1 << TB) / 2) void tile_sort_kernel(SortSegs ids, 
       }
     }
   }
+}
+
+template <int TB>
+__global__ __launch_bounds__((1 << TB) / 2) void tile_sort_kernel(SortSegs ids, int n, uint32_t* __restrict__ tiles,
+                                                                 uint32_t* __restrict__ splitters) {
+  constexpr int kTile = 1 << TB, kHalf = kTile / 2;
+  __shared__ uint32_t key[2 * kTile];
+  const int t = threadIdx.x, base = blockIdx.x * kTile;
+  uint32_t k0, k1;
+  {
+    const int g0 = base + t, g1 = base + t + kHalf;
+    k0 = g0 < n ? ((uint32_t)seg_id(ids, g0) << TB) | (uint32_t)t : 0xFFFFFFFFu;
+    k1 = g1 < n ? ((uint32_t)seg_id(ids, g1) << TB) | (uint32_t)(t + kHalf) : 0xFFFFFFFFu;
+  }
+  tile_bitonic<TB>(k0, k1, key);
   tiles[base + t] = k0;
   tiles[base + t + kHalf] = k1;
   // the last key of every 32-key block, packed: the rank kernel stages these (it used to gather them from the tiles,
@@ -243,6 +251,177 @@ static void launch_tile_sort(const SortSegs& sg, int n, uint32_t* tiles, int32_t
   hipLaunchKernelGGL((tile_sort_kernel<TB>), dim3(ntiles), dim3(kTile / 2), 0, st, sg, n, tiles, splitters);
   hipLaunchKernelGGL((tile_rank_kernel<TB>), dim3((int)cdiv((int64_t)ntiles * kTile * kMidTiles, kBlock)), dim3(kBlock), 0,
                      st, (const uint32_t*)tiles, (const uint32_t*)splitters, n, ntiles, sorted_ids, perm);
+}
+
+// Long lists (32 768 < n <= 262 144: the 131 072 occurrence ids of a GloVe step at B = 65 536, the 196 608 of a triplet
+// step at that batch): least-significant-digit radix sort with 11-bit digits, two launches per pass, two passes for ids
+// below 2^22.  rocPRIM's device sort is a chain of ~10 short launches here (55 us for 131 072 keys, all launch latency).
+//   pass launch 1: every workgroup bitonic-sorts its 2048-key tile by (digit << 11 | position in tile) -- stable -- writes
+//                  the sorted composites and the tile's digit histogram (from the run boundaries: no atomics);
+//   pass launch 2: every workgroup turns the histograms into its own digit offsets (digits below + same digit in earlier
+//                  tiles: it re-reduces the whole [tiles x 2048] matrix, <= 1 MB out of L2) and scatters its tile;
+//                  rank inside a digit = index in the sorted tile - first index of the digit.
+// Stable by construction; pure integer work.
+constexpr int kRadixBits = 11, kRadixTile = 1 << kRadixBits, kRadixThreads = kRadixTile / 2;
+constexpr int kRadixMaxN = 1 << 18, kRadixMaxTiles = kRadixMaxN / kRadixTile;
+constexpr int kRadixMaxPasses = 3;
+
+// FIRST: keys come from the id segments and the value is the position itself; else from (keys_in, vals_in)
+template <bool FIRST>
+__global__ __launch_bounds__(kRadixThreads) void radix_tile_kernel(SortSegs ids, const uint32_t* __restrict__ keys_in,
+                                                                  int n, int shift, uint32_t* __restrict__ tiles,
+                                                                  int32_t* __restrict__ hist) {
+  __shared__ uint32_t key[2 * kRadixTile];
+  __shared__ int bstart[kRadixTile], bend[kRadixTile];
+  const int t = threadIdx.x, base = blockIdx.x * kRadixTile;
+  constexpr uint32_t kMask = kRadixTile - 1;
+  uint32_t k0, k1;
+  {
+    const int g0 = base + t, g1 = base + t + kRadixThreads;
+    const uint32_t a = g0 < n ? (FIRST ? (uint32_t)seg_id(ids, g0) : keys_in[g0]) : 0u;
+    const uint32_t b = g1 < n ? (FIRST ? (uint32_t)seg_id(ids, g1) : keys_in[g1]) : 0u;
+    k0 = g0 < n ? (((a >> shift) & kMask) << kRadixBits) | (uint32_t)t : 0xFFFFFFFFu;
+    k1 = g1 < n ? (((b >> shift) & kMask) << kRadixBits) | (uint32_t)(t + kRadixThreads) : 0xFFFFFFFFu;
+  }
+  bstart[t] = 0;
+  bstart[t + kRadixThreads] = 0;
+  bend[t] = 0;
+  bend[t + kRadixThreads] = 0;
+  tile_bitonic<kRadixBits>(k0, k1, key);
+  __syncthreads();  // the network's last LDS reads are done; `key` is free (and the zeroed histograms are visible)
+  key[t] = k0;
+  key[t + kRadixThreads] = k1;
+  tiles[base + t] = k0;
+  tiles[base + t + kRadixThreads] = k1;
+  __syncthreads();
+  const int live = min(kRadixTile, n - base);  // padding (all ones) sorts to the end
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int i = t + h * kRadixThreads;
+    if (i < live) {
+      const uint32_t d = key[i] >> kRadixBits;
+      if (i == 0 || (key[i - 1] >> kRadixBits) != d) bstart[d] = i;
+      if (i == live - 1 || (key[i + 1] >> kRadixBits) != d) bend[d] = i + 1;
+    }
+  }
+  __syncthreads();
+  hist[(int64_t)blockIdx.x * kRadixTile + t] = bend[t] - bstart[t];
+  hist[(int64_t)blockIdx.x * kRadixTile + t + kRadixThreads] = bend[t + kRadixThreads] - bstart[t + kRadixThreads];
+}
+
+// LAST: write (sorted ids, perm) as int32; else the ping-pong (keys, vals) of the next pass
+template <bool FIRST>
+__global__ __launch_bounds__(kRadixThreads) void radix_scatter_kernel(SortSegs ids, const uint32_t* __restrict__ keys_in,
+                                                                     const uint32_t* __restrict__ vals_in, int n,
+                                                                     int ntiles, const uint32_t* __restrict__ tiles,
+                                                                     const int32_t* __restrict__ hist,
+                                                                     uint32_t* __restrict__ keys_out,
+                                                                     uint32_t* __restrict__ vals_out) {
+  __shared__ uint32_t comp[kRadixTile];
+  __shared__ int offs[kRadixTile], bstart[kRadixTile];
+  __shared__ int wave_tot[kRadixThreads / 64];
+  const int t = threadIdx.x, tile = blockIdx.x, base = tile * kRadixTile;
+  comp[t] = tiles[base + t];
+  comp[t + kRadixThreads] = tiles[base + t + kRadixThreads];
+  // digits 2t and 2t + 1: totals over all tiles and over the tiles before this one
+  int tot0 = 0, tot1 = 0, pre0 = 0, pre1 = 0;
+  const int2* h2 = reinterpret_cast<const int2*>(hist);
+  // (unrolled: the loads of a pass over the matrix are independent; one at a time this loop WAS the kernel, 16 us)
+#pragma unroll 32
+  for (int u = 0; u < ntiles; ++u) {
+    const int2 c = h2[(int64_t)u * (kRadixTile / 2) + t];
+    tot0 += c.x;
+    tot1 += c.y;
+    pre0 += u < tile ? c.x : 0;
+    pre1 += u < tile ? c.y : 0;
+  }
+  // exclusive scan of the 2048 totals: pair sums -> wave scan -> wave totals
+  const int pair = tot0 + tot1;
+  int incl = pair;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o, 64);
+    if ((t & 63) >= o) incl += v;
+  }
+  if ((t & 63) == 63) wave_tot[t >> 6] = incl;
+  __syncthreads();
+  int wbase = 0;
+  for (int w = 0; w < (t >> 6); ++w) wbase += wave_tot[w];
+  const int excl = wbase + incl - pair;
+  offs[2 * t] = excl + pre0;
+  offs[2 * t + 1] = excl + tot0 + pre1;
+  const int live = min(kRadixTile, n - base);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int i = t + h * kRadixThreads;
+    if (i < live) {
+      const uint32_t d = comp[i] >> kRadixBits;
+      if (i == 0 || (comp[i - 1] >> kRadixBits) != d) bstart[d] = i;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int i = t + h * kRadixThreads;
+    if (i < live) {
+      const uint32_t c = comp[i], d = c >> kRadixBits;
+      const int src = base + (int)(c & (kRadixTile - 1));
+      const int dst = offs[d] + (i - bstart[d]);
+      keys_out[dst] = FIRST ? (uint32_t)seg_id(ids, src) : keys_in[src];
+      vals_out[dst] = FIRST ? (uint32_t)src : vals_in[src];
+    }
+  }
+}
+
+struct RadixWs {
+  uint32_t* tiles;  // [ntiles * 2048]
+  int32_t* hist;    // [ntiles][2048]
+  uint32_t* keys[2];
+  uint32_t* vals[2];
+};
+static size_t radix_ws_layout(int64_t n, char* base, RadixWs* ws) {
+  const int64_t ntiles = cdiv(n, kRadixTile);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += align_up(bytes, 256);
+    return p;
+  };
+  RadixWs w;
+  w.tiles = (uint32_t*)take(sizeof(uint32_t) * (size_t)ntiles * kRadixTile);
+  w.hist = (int32_t*)take(sizeof(int32_t) * (size_t)ntiles * kRadixTile);
+  for (int i = 0; i < 2; ++i) {
+    w.keys[i] = (uint32_t*)take(sizeof(uint32_t) * (size_t)n);
+    w.vals[i] = (uint32_t*)take(sizeof(uint32_t) * (size_t)n);
+  }
+  if (ws) *ws = w;
+  return off;
+}
+static void launch_radix_sort(const SortSegs& sg, int n, int key_bits, const RadixWs& ws, int32_t* sorted_ids,
+                              int32_t* perm, hipStream_t st) {
+  const int ntiles = (int)cdiv(n, kRadixTile);
+  const int passes = std::max(1, (int)cdiv(key_bits, kRadixBits));
+  const uint32_t* kin = nullptr;
+  const uint32_t* vin = nullptr;
+  for (int p = 0; p < passes; ++p) {
+    const bool last = p == passes - 1;
+    uint32_t* kout = last ? reinterpret_cast<uint32_t*>(sorted_ids) : ws.keys[p & 1];
+    uint32_t* vout = last ? reinterpret_cast<uint32_t*>(perm) : ws.vals[p & 1];
+    const int shift = p * kRadixBits;
+    if (p == 0) {
+      hipLaunchKernelGGL(radix_tile_kernel<true>, dim3(ntiles), dim3(kRadixThreads), 0, st, sg, kin, n, shift, ws.tiles,
+                         ws.hist);
+      hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(ntiles), dim3(kRadixThreads), 0, st, sg, kin, vin, n, ntiles,
+                         (const uint32_t*)ws.tiles, (const int32_t*)ws.hist, kout, vout);
+    } else {
+      hipLaunchKernelGGL(radix_tile_kernel<false>, dim3(ntiles), dim3(kRadixThreads), 0, st, sg, kin, n, shift, ws.tiles,
+                         ws.hist);
+      hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(ntiles), dim3(kRadixThreads), 0, st, sg, kin, vin, n, ntiles,
+                         (const uint32_t*)ws.tiles, (const int32_t*)ws.hist, kout, vout);
+    }
+    kin = kout;
+    vin = vout;
+  }
 }
 
 // owner key of every id + the per-owner totals.  The totals are privatised per workgroup in LDS (one global
@@ -587,8 +766,9 @@ extern "C" {
 size_t esr_segment_sort_workspace_bytes(int64_t n) {
   if (n <= 0) return 256;
   const size_t tiles = n <= kMidSortMax ? align_up((size_t)(kMidSortMax + kMidSortMax / kSplitEvery) * 4, 256) : 0;
-  // + one column for the concatenated ids of a segmented list on the radix path
-  return std::max(pair_sort_temp_bytes<false, uint32_t>(n) + align_up((size_t)n * 4, 256), tiles);
+  const size_t radix = n <= kRadixMaxN ? radix_ws_layout(n, nullptr, nullptr) : 0;
+  // + one column for the concatenated ids of a segmented list on the device-sort path
+  return std::max({pair_sort_temp_bytes<false, uint32_t>(n) + align_up((size_t)n * 4, 256), tiles, radix});
 }
 
 static int segment_sort_segs(const char* who, const SortSegs& sg, int64_t n, int64_t V, int32_t* sorted_ids,
@@ -606,6 +786,16 @@ static int segment_sort_segs(const char* who, const SortSegs& sg, int64_t n, int
     if (n <= 512 * kMidTiles) launch_tile_sort<9>(sg, (int)n, tiles, sorted_ids, perm, st);
     else if (n <= 1024 * kMidTiles) launch_tile_sort<10>(sg, (int)n, tiles, sorted_ids, perm, st);
     else launch_tile_sort<11>(sg, (int)n, tiles, sorted_ids, perm, st);
+    return check_launch(who);
+  }
+  if (n <= kRadixMaxN && bits_for(V) <= kRadixMaxPasses * kRadixBits) {
+    if (radix_ws_layout(n, nullptr, nullptr) > workspace_bytes || ((uintptr_t)workspace & 15)) {
+      set_error("%s: workspace %zu bytes too small (or misaligned)", who, workspace_bytes);
+      return ESR_EWORKSPACE;
+    }
+    RadixWs ws;
+    radix_ws_layout(n, (char*)workspace, &ws);
+    launch_radix_sort(sg, (int)n, bits_for(V), ws, sorted_ids, perm, st);
     return check_launch(who);
   }
   // device radix sort: needs the ids as one array (materialised at the head of the workspace when segmented)

@@ -183,6 +183,39 @@ def glove_fwd_bwd(emb, bias, inputs, target, mode=GLOVE_REFERENCE, want_grads=Tr
 GRADS_AT_IDS = 0x100  # include/esr_hip.h ESR_GRADS_AT_IDS
 
 
+def glove_train_step(emb, shadow, loc, accum, bias, bias_accum, inputs, target, mode, lr, eps=1e-7):
+    """One whole GloVe training step (loss + gradients + sparse Adagrad on both tables) without materialised
+    gradients: esr_glove_train_step.  `emb` / `shadow` are the two buffers of the double-buffered embedding table and
+    `loc` (uint8 [V]) says which one holds each row; all three are updated.  Returns loss[1]."""
+    lib = _lib.load()
+    for name, t in (("emb", emb), ("shadow", shadow), ("accum", accum), ("bias", bias), ("bias_accum", bias_accum),
+                    ("target", target)):
+        _req(t, torch.float32, name)
+    _req(loc, torch.uint8, "loc"), _req(inputs, torch.int32, "inputs")
+    V, D = emb.shape
+    B = inputs.shape[1]
+    if inputs.shape[0] != 2 or target.numel() != B:
+        raise ValueError("inputs must be [2, B] and target [B]")
+    if shadow.shape != emb.shape or accum.shape != emb.shape or loc.numel() != V or bias.numel() != V or \
+            bias_accum.numel() != V:
+        raise ValueError("shadow / accum / loc / bias shapes do not match the embedding table")
+    loss = torch.empty(1, dtype=torch.float32, device=emb.device)
+    ws = _ws(_ws_bytes("esr_glove_step_workspace_bytes", B, D), emb.device)
+    check(lib.esr_glove_train_step(_p(emb), _p(shadow), _p(loc), _p(accum), _p(bias), _p(bias_accum), V, D, _p(inputs),
+                                   _p(target), B, mode, float(lr), float(eps), _p(loss), _p(ws), ws.numel(), _stream()),
+          "esr_glove_train_step")
+    return loss
+
+
+def rows_consolidate(primary, shadow, loc):
+    """Copy the rows of a double-buffered table whose current value lives in `shadow` (loc[row] == 1) back into
+    `primary` and clear their bytes: afterwards `primary` is the plain [V, D] table."""
+    lib = _lib.load()
+    _req(primary, torch.float32, "primary"), _req(shadow, torch.float32, "shadow"), _req(loc, torch.uint8, "loc")
+    V, D = primary.shape
+    check(lib.esr_rows_consolidate(_p(primary), _p(shadow), _p(loc), V, D, _stream()), "esr_rows_consolidate")
+
+
 def triplet_fwd_bwd(scene_table, pos_table, neg_table, scene_ids, pos_ids, neg_ids, B, regularization, batch_size,
                     with_reg=True, want_grads=True, want_scores=True, grads_at_ids=False):
     """Fused STL head.  ids may be None (= row b).  Returns (loss[1], pos_score, neg_score, g_s, g_p, g_n);

@@ -320,22 +320,65 @@ def _sgd_plain(learning_rate):
     return _SparseSgd(learning_rate)
 
 
+class RowVersions:
+    """The second buffer of a double-buffered table and the per-row bytes that say where each row's current value
+    lives (0 = the parameter tensor itself, 1 = `shadow`).  Fused train steps (ops.glove_train_step) read rows where
+    the bytes point, write updated rows into the other buffer and flip the bytes, so they never need a gradient or a
+    snapshot in memory.  Lives in the optimizer state (``opt_state['_versions'][path]``); ``TrainState.params``
+    consolidates before handing the tables to anybody else."""
+
+    def __init__(self, table):
+        self.shadow = torch.empty_like(table)
+        self.loc = torch.zeros(table.shape[0], dtype=torch.uint8, device=table.device)
+        self.dirty = False
+
+    def consolidate(self, table):
+        if self.dirty:
+            ops.rows_consolidate(table, self.shadow, self.loc)
+            self.dirty = False
+
+
+def row_versions(state, path):
+    """The RowVersions of the table at `path` of state's parameter tree (created on first use: a second [V, D] buffer)."""
+    versions = state.opt_state.setdefault("_versions", {})
+    path = tuple(path)
+    if path not in versions:
+        versions[path] = RowVersions(tree_get(state.raw_params, path))
+    return versions[path]
+
+
 class TrainState:
-    """flax.training.train_state.TrainState look-alike: step, apply_fn, params, tx, opt_state."""
+    """flax.training.train_state.TrainState look-alike: step, apply_fn, params, tx, opt_state.
+
+    ``params`` is always the plain parameter tree: if a fused step left rows of a double-buffered table in its second
+    buffer (RowVersions), reading ``params`` first copies them back (one launch over the touched rows).  The hot loop
+    uses ``raw_params`` and never pays for that."""
 
     def __init__(self, step, apply_fn, params, tx, opt_state):
         self.step = step
         self.apply_fn = apply_fn
-        self.params = params
+        self._params = params
         self.tx = tx
         self.opt_state = opt_state
+
+    @property
+    def raw_params(self):
+        return self._params
+
+    @property
+    def params(self):
+        versions = self.opt_state.get("_versions") if isinstance(self.opt_state, dict) else None
+        if versions:
+            for path, rv in versions.items():
+                rv.consolidate(tree_get(self._params, path))
+        return self._params
 
     @classmethod
     def create(cls, *, apply_fn, params, tx, **kwargs):
         return cls(step=0, apply_fn=apply_fn, params=params, tx=tx, opt_state=tx.init(params))
 
     def replace(self, **kw):
-        d = dict(step=self.step, apply_fn=self.apply_fn, params=self.params, tx=self.tx, opt_state=self.opt_state)
+        d = dict(step=self.step, apply_fn=self.apply_fn, params=self._params, tx=self.tx, opt_state=self.opt_state)
         d.update(kw)
         return TrainState(**d)
 

@@ -79,14 +79,57 @@ def update_model(state, grads):
     return state.apply_gradients(grads=grads)
 
 
+def fused_step_available(state):
+    """True when ``train_step`` can run the whole step in one pass (esr_glove_train_step): the build's row-sparse
+    Adagrad on fp32 tables.  ``ESR_GLOVE_FUSED=0`` forces the apply_model + update_model path."""
+    from ..train_state import _SparseAdagrad
+    if os.environ.get("ESR_GLOVE_FUSED", "1") != "1" or not isinstance(state.tx, _SparseAdagrad):
+        return False
+    p = state.raw_params
+    try:
+        emb, bias = p["_token_embedding"]["embedding"], p["_bias"]["embedding"]
+    except (KeyError, TypeError):
+        return False
+    return emb.is_cuda and emb.dtype == torch.float32 and bias.dtype == torch.float32 and emb.shape[0] < (1 << 30)
+
+
+def train_step(state, inputs, target):
+    """``apply_model`` + ``update_model`` (wikipedia/train_cooccurence.py:71-101) in ONE pass over the rows, for the
+    build's sparse Adagrad: returns ``(new_state, loss)``.  No gradient is materialised -- the update kernel re-reads
+    each occurrence's partner row and forms its gradient on chip -- which the double-buffered embedding table makes
+    safe (train_state.RowVersions; ``state.params`` consolidates on access).  Tables and accumulators come out
+    bit-identical to the two-call path on the embedding table, to f32 rounding on the bias table and the loss."""
+    from ..train_state import row_versions
+    if not fused_step_available(state):
+        grads, loss = apply_model(state, inputs, target)
+        return update_model(state, grads), loss
+    p = state.raw_params
+    emb, bias = p["_token_embedding"]["embedding"], p["_bias"]["embedding"]
+    model = _model_of(state)
+    mode = _MODES[model.loss_mode if model is not None else "reference"]
+    inputs = ops.as_ids(inputs, emb.device, check_range=emb.shape[0])
+    target = ops.as_f32(target, emb.device)
+    rv = row_versions(state, ("_token_embedding", "embedding"))
+    acc = state.opt_state["sum_of_squares"]
+    rv.dirty = True
+    loss = ops.glove_train_step(emb, rv.shadow, rv.loc, acc["_token_embedding"]["embedding"], bias,
+                                acc["_bias"]["embedding"], inputs, target, mode, state.tx.lr, state.tx.eps)
+    return state.replace(step=state.step + 1), loss.reshape(())
+
+
 def train_epoch(state, steps_per_epoch, train_it):
     """Trains for an epoch (wikipedia/train_cooccurence.py:103-112).  Losses stay on the device until the
-    epoch mean is taken, so the loop never synchronises."""
+    epoch mean is taken, so the loop never synchronises.  With the build's sparse Adagrad every step is the
+    one-pass ``train_step``; with the reference's dense Adam it is apply_model + update_model as there."""
     epoch_loss = []
+    fused = fused_step_available(state)
     for _ in range(steps_per_epoch):
         inputs, targets = next(train_it)
-        grads, loss = apply_model(state, inputs, targets)
-        state = update_model(state, grads)
+        if fused:
+            state, loss = train_step(state, inputs, targets)
+        else:
+            grads, loss = apply_model(state, inputs, targets)
+            state = update_model(state, grads)
         epoch_loss.append(loss)
     train_loss = float(torch.stack(epoch_loss).mean()) if epoch_loss else float("nan")
     return state, train_loss

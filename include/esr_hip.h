@@ -95,6 +95,25 @@ int esr_glove_fwd_bwd(const float* emb, const float* bias, int64_t V, int D, con
                       const float* target, int64_t B, int mode, float* loss, float* grad_rows,
                       float* grad_bias, void* workspace, size_t workspace_bytes, esr_stream_t stream);
 
+/* ---- G3 + G4 in one pass: loss, gradients and the sparse Adagrad update of BOTH tables ------------------------
+ * (wikipedia/train_cooccurence.py:71-101 with the build's row-sparse Adagrad in place of dense optax.adam.)
+ * No gradient row is ever written to memory: the update kernel walks the sorted occurrences of every distinct row,
+ * re-reads each occurrence's partner row, forms gdot and accumulates gdot * partner on chip, then does the row's one
+ * read-modify-write.  Reading partner rows while other rows are being rewritten is made safe by DOUBLE-BUFFERING
+ * the embedding table: `emb` and `emb_shadow` are two [V, D] buffers and emb_loc [V] (bytes, 0 / 1) says which one
+ * holds each row's current value.  The step reads every row where emb_loc pointed when it began, writes each updated
+ * row into the OTHER buffer and flips its byte.  Callers that need a plain [V, D] table run esr_rows_consolidate
+ * (copies the rows whose byte is 1 from `shadow` into `primary`, clears the bytes).  A fresh state is emb_loc = 0.
+ * The result (tables, accumulators) is bit-identical to esr_glove_fwd_bwd + esr_sparse_adagrad_scatter on the embedding
+ * table; the bias table and the loss agree to f32 rounding (their sums are associated differently).
+ * loss [1]; bias / bias_accum [V] are updated in place (every bias read of a step precedes its bias writes). */
+size_t esr_glove_step_workspace_bytes(int64_t B, int D);
+int esr_glove_train_step(float* emb, float* emb_shadow, uint8_t* emb_loc, float* emb_accum, float* bias,
+                         float* bias_accum, int64_t V, int D, const int32_t* inputs, const float* target, int64_t B,
+                         int mode, float lr, float eps, float* loss, void* workspace, size_t workspace_bytes,
+                         esr_stream_t stream);
+int esr_rows_consolidate(float* primary, const float* shadow, uint8_t* loc, int64_t V, int D, esr_stream_t stream);
+
 /* ---- S1-S3: STL score head + triplet loss -- pinterest/models.py:67-72,
  * pinterest/train_shop_the_look.py:93-122 --------------------------------------------------
  * Towers are id-embedding tables; pos and neg rows may come from different tables (pass the product

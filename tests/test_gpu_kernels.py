@@ -408,8 +408,39 @@ def test_segment_sort_is_stable_sort(dev, kind, n):
     assert np.array_equal(N(sid), ids[order])
 
 
+@pytest.mark.parametrize("n,V", [(131_072, 465_537), (196_608 + 5, 2_000_000), (262_144, 1_000), (262_145, 465_537),
+                                 (40_001, 2_047), (50_000, 2_048), (100_000, 30_000_000), (2_049 + 32_768, 2 ** 22 + 1)])
+@pytest.mark.parametrize("kind", ["uniform", "same", "zipf"])
+def test_segment_sort_hand_written_radix_path(dev, kind, n, V):
+    """32 768 < n <= 262 144: the two-launches-per-pass LSD radix sort (11-bit digits; 1, 2 or 3 passes by the id range;
+    one more than 262 144 falls through to the device sort).  Stable: perm == numpy's stable argsort."""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(n % 1000 + 1)
+    if kind == "zipf" and V > 5_000_000:
+        ids = np.where(rng.random(n) < 0.3, V - 7, rng.integers(0, V, n)).astype(np.int32)  # one hot id, wide range
+    else:
+        ids = _ids(kind, rng, V, n)
+    sid, perm = ops.segment_sort(T(ids, dev), V)
+    order = np.argsort(ids, kind="stable")
+    assert np.array_equal(N(perm), order.astype(np.int32))
+    assert np.array_equal(N(sid), ids[order])
+
+
+def test_segment_sort_multi_segments_on_the_radix_path(dev):
+    """the towers of one step as segments with offsets (virtual rows), read in place by the radix kernels"""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(77)
+    sizes, tables = (65_536, 65_536, 65_536), (1_000_000, 1_000_000)
+    segs = [rng.integers(0, tables[min(i, 1)], s).astype(np.int32) for i, s in enumerate(sizes)]
+    offsets = [0, tables[0], tables[0]]
+    virt = np.concatenate([s.astype(np.int64) + o for s, o in zip(segs, offsets)])
+    sid, perm = ops.segment_sort_multi([T(s, dev) for s in segs], offsets, sum(tables))
+    order = np.argsort(virt, kind="stable")
+    assert np.array_equal(N(perm), order.astype(np.int32)) and np.array_equal(N(sid).astype(np.int64), virt[order])
+
+
 def test_segment_sort_wide_ids_take_the_radix_path(dev):
-    """ids >= 2^21 do not fit the 32-bit tile composites: mid-size lists fall back to the device radix sort"""
+    """ids >= 2^21 do not fit the 32-bit tile composites: mid-size lists take the radix path (three passes here)"""
     from esrecsys_amd import ops
     rng = np.random.default_rng(10)
     V, n = 50_000_000, 20_000
