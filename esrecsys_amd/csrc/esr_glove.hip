@@ -365,46 +365,68 @@ __global__ __launch_bounds__(kBlock) void glove_step_kernel(
   const int nvec = D / VEC;
   const int64_t per = (n + ngroups - 1) / ngroups;  // contiguous slices (see segment_update_kernel)
   const int64_t p_begin = group * per, p_end = min(n, (group + 1) * per);
-  // the first position's records are requested before the statistics are reduced
-  uint32_t code_n = 0, prev_n = 0xFFFFFFFFu;
-  float4 m_n = make_float4(0.f, 0.f, 0.f, 0.f);
+  // the records of the first two positions are requested before the statistics are reduced
+  uint32_t c0 = 0, c1 = 0, prev_n = 0xFFFFFFFFu;
+  float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0;
   if (p_begin < p_end) {
-    code_n = own_code[p_begin];
+    c0 = own_code[p_begin];
     if (p_begin > 0) prev_n = own_code[p_begin - 1];
-    m_n = meta[p_begin];
+    m0 = meta[p_begin];
+    if (p_begin + 1 < n) {
+      c1 = own_code[p_begin + 1];
+      m1 = meta[p_begin + 1];
+    }
   }
   double sum_s = 0.0, sum_s2 = 0.0;
   if (mode == ESR_GLOVE_REFERENCE) reduce_stat_parts(stat_part, nstat, sm, &sum_s, &sum_s2);
   const float sbar = (float)(sum_s / (double)B);
   const float two_over_B = 2.0f / (float)B;
   double acc_w = 0.0, acc_wr = 0.0, acc_wq = 0.0;
+  auto part_ptr = [&](const float4& m) {
+    const uint32_t c = __float_as_uint(m.x);
+    return ((c & kLocBit) ? emb1 : emb0) + (int64_t)(c & kIdMask) * D;
+  };
+  // rows of the NEXT position, requested before this position is computed (records run two positions ahead, rows one):
+  // a group always has one position's three rows in flight while it works on another
+  bool have_next = false;
+  RowRegs<VEC, NCH> nown, nfirst, na;
 
   for (int64_t p = p_begin; p < p_end; ++p) {
-    const uint32_t code = code_n, prev = prev_n;
-    const float4 m_first = m_n;
+    const uint32_t code = c0, prev = prev_n, code_n = c1;
+    const float4 m_first = m0, m_next = m1;
     const bool more = p + 1 < n;
-    if (more) {  // next position's records (also tells where this run ends)
-      code_n = own_code[p + 1];
-      m_n = meta[p + 1];
+    c0 = c1;
+    m0 = m1;
+    if (p + 2 < n) {
+      c1 = own_code[p + 2];
+      m1 = meta[p + 2];
     }
     prev_n = code;
     const uint32_t id = code & kIdMask;
     const bool head = (prev & kIdMask) != id;  // prev = all ones at p == 0: no id equals kIdMask
     if (!head && ((p & (kStepChunk - 1)) != 0 || (own_code[p - kStepChunk] & kIdMask) != id)) continue;
     const int64_t stop = min(head ? ((p + 2 * kStepChunk - 1) / kStepChunk) * kStepChunk : p + kStepChunk, n);
-    auto part_ptr = [&](const float4& m) {
-      const uint32_t c = __float_as_uint(m.x);
-      return ((c & kLocBit) ? emb1 : emb0) + (int64_t)(c & kIdMask) * D;
-    };
     RowRegs<VEC, NCH> own, a, g, first;
-    row_load(own, ((code & kLocBit) ? emb1 : emb0) + (int64_t)id * D, lig, G, nvec);
-    row_load(first, part_ptr(m_first), lig, G, nvec);
-    row_load(a, accum + (int64_t)id * D, lig, G, nvec);
+    if (have_next) {
+      own = nown;
+      first = nfirst;
+      a = na;
+    } else {
+      row_load(own, ((code & kLocBit) ? emb1 : emb0) + (int64_t)id * D, lig, G, nvec);
+      row_load(first, part_ptr(m_first), lig, G, nvec);
+      row_load(a, accum + (int64_t)id * D, lig, G, nvec);
+    }
+    have_next = false;
     int64_t e_run = p + 1;
     if (more && (code_n & kIdMask) == id) {  // a run of several occurrences: find the end of this chunk
       ++e_run;
       while (e_run < stop && (own_code[e_run] & kIdMask) == id) ++e_run;
       if (e_run > stop) e_run = stop;
+    } else if (p + 1 < p_end) {  // the usual case, a run of one: position p + 1 heads the next run -- request its rows now
+      row_load(nown, ((code_n & kLocBit) ? emb1 : emb0) + (int64_t)(code_n & kIdMask) * D, lig, G, nvec);
+      row_load(nfirst, part_ptr(m_next), lig, G, nvec);
+      row_load(na, accum + (int64_t)(code_n & kIdMask) * D, lig, G, nvec);
+      have_next = true;
     }
     row_zero(g);
     double bsum = 0.0;  // fp64: a hot token's bias gradient is a sum over thousands of occurrences
@@ -661,12 +683,13 @@ __global__ __launch_bounds__(kBlock) void rows_consolidate_kernel(T* __restrict_
 }
 
 // blocks of `kernel` (kBlock threads, no dynamic LDS) the whole device holds at once; kMaxGrid if the query fails
-static int resident_blocks(const void* kernel) {
+static int resident_blocks(const void* kernel, int cap_per_cu = 0) {
   int per_cu = 0, dev = 0, cus = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || per_cu < 1) {
     (void)hipGetLastError();
     return kMaxGrid;
   }
+  if (cap_per_cu > 0) per_cu = std::min(per_cu, cap_per_cu);
   if (hipGetDevice(&dev) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
     (void)hipGetLastError();
@@ -765,7 +788,8 @@ size_t esr_glove_step_workspace_bytes(int64_t B, int D) {
 
 int esr_glove_train_step(float* emb, float* emb_shadow, uint8_t* emb_loc, float* emb_accum, float* bias,
                          float* bias_accum, int64_t V, int D, const int32_t* inputs, const float* target, int64_t B,
-                         int mode, float lr, float eps, float* loss, void* workspace, size_t workspace_bytes,
+                         int mode, float lr, float eps, const int32_t* presorted_ids, const int32_t* presorted_perm,
+                         int blocks_per_cu, float* loss, void* workspace, size_t workspace_bytes,
                          esr_stream_t stream) {
   ESR_REQUIRE(B > 0 && V > 0 && D > 0, "esr_glove_train_step: bad sizes V=%lld D=%d B=%lld", (long long)V, D,
               (long long)B);
@@ -785,19 +809,26 @@ int esr_glove_train_step(float* emb, float* emb_shadow, uint8_t* emb_loc, float*
   StepWs ws;
   step_ws_layout(B, D, (char*)workspace, &ws);
   const int64_t n = 2 * B;
-  if (int rc = esr_segment_sort_ids(inputs, n, V, ws.sorted_ids, ws.perm, ws.sort_ws, ws.sort_ws_bytes, stream)) return rc;
+  ESR_REQUIRE((presorted_ids == nullptr) == (presorted_perm == nullptr),
+              "esr_glove_train_step: presorted_ids and presorted_perm must both be set or both be NULL");
+  const int32_t* sorted_ids = presorted_ids;
+  const int32_t* perm = presorted_perm;
+  if (!sorted_ids) {
+    if (int rc = esr_segment_sort_ids(inputs, n, V, ws.sorted_ids, ws.perm, ws.sort_ws, ws.sort_ws_bytes, stream)) return rc;
+    sorted_ids = ws.sorted_ids;
+    perm = ws.perm;
+  }
   const RowGeom g = row_geom(D);
   const int nstat = (int)std::min<int64_t>(kStatBlocks, cdiv(B, kBlock));
   const int nplan = (int)std::max<int64_t>(nstat, std::min<int64_t>(kMaxGrid, cdiv(n, kBlock)));
-  hipLaunchKernelGGL(glove_plan_kernel, dim3(nplan), dim3(kBlock), 0, st, (const int32_t*)ws.sorted_ids,
-                     (const int32_t*)ws.perm, inputs, target, (const float*)bias, (const uint8_t*)emb_loc, B, nstat,
+  hipLaunchKernelGGL(glove_plan_kernel, dim3(nplan), dim3(kBlock), 0, st, sorted_ids, perm, inputs, target, (const float*)bias, (const uint8_t*)emb_loc, B, nstat,
                      ws.own_code, ws.meta, ws.stat_part);
   int grid = grid_for_groups(n, g.G);
   const int grid2 = (int)std::min<int64_t>(kMaxGrid, cdiv(cdiv(n, kStepChunk), 4));
   ESR_DISPATCH_ROW(g, {
     // one resident wave-set: every group walks a contiguous slice, so a grid larger than what the chip holds at once
     // only adds a second, partly filled round (94 VGPRs -> 5 blocks per CU: 2048 blocks ran as 1280 + 768)
-    grid = std::min(grid, resident_blocks((const void*)glove_step_kernel<VEC, NCH>));
+    grid = std::min(grid, resident_blocks((const void*)glove_step_kernel<VEC, NCH>, blocks_per_cu));
     hipLaunchKernelGGL((glove_step_kernel<VEC, NCH>), dim3(grid), dim3(kBlock), 0, st, emb, emb_shadow, emb_loc,
                        emb_accum, D, g.G, (const uint32_t*)ws.own_code, (const float4*)ws.meta, n, B, mode, nstat,
                        (const double*)ws.stat_part, lr, eps, ws.chunk_rows, ws.bias_info, ws.pair_part);

@@ -262,80 +262,86 @@ static void launch_tile_sort(const SortSegs& sg, int n, uint32_t* tiles, int32_t
 //                  tiles: it re-reduces the whole [tiles x 2048] matrix, <= 1 MB out of L2) and scatters its tile;
 //                  rank inside a digit = index in the sorted tile - first index of the digit.
 // Stable by construction; pure integer work.
-constexpr int kRadixBits = 11, kRadixTile = 1 << kRadixBits, kRadixThreads = kRadixTile / 2;
-constexpr int kRadixMaxN = 1 << 18, kRadixMaxTiles = kRadixMaxN / kRadixTile;
+// The digit width is also the tile size (TB bits; 11: 64 workgroups of 1024 threads for 131 072 ids).  Measured and
+// dropped: TB = 9 (256-thread workgroups, three passes) on a second stream BESIDE the GloVe update kernel, sized to fit
+// the wave slots and registers that kernel leaves free -- the step went from 0.181 to 0.235 ms; capping the update
+// kernel's residency to make room for the 1024-thread version cost more than the hidden sort returned (0.202 ms at
+// three of four workgroups per CU).  What does pay is the plain sort of batch k + 1 on the second stream: it fills the
+// gaps around batch k's short kernels (0.194 -> 0.181 ms).
+constexpr int kRadixMaxN = 1 << 18;
 constexpr int kRadixMaxPasses = 3;
 
 // FIRST: keys come from the id segments and the value is the position itself; else from (keys_in, vals_in)
-template <bool FIRST>
-__global__ __launch_bounds__(kRadixThreads) void radix_tile_kernel(SortSegs ids, const uint32_t* __restrict__ keys_in,
+template <int TB, bool FIRST>
+__global__ __launch_bounds__((1 << TB) / 2) void radix_tile_kernel(SortSegs ids, const uint32_t* __restrict__ keys_in,
                                                                   int n, int shift, uint32_t* __restrict__ tiles,
                                                                   int32_t* __restrict__ hist) {
-  __shared__ uint32_t key[2 * kRadixTile];
-  __shared__ int bstart[kRadixTile], bend[kRadixTile];
-  const int t = threadIdx.x, base = blockIdx.x * kRadixTile;
-  constexpr uint32_t kMask = kRadixTile - 1;
+  constexpr int kTile = 1 << TB, kThreads = kTile / 2;
+  __shared__ uint32_t key[2 * kTile];
+  __shared__ int bstart[kTile], bend[kTile];
+  const int t = threadIdx.x, base = blockIdx.x * kTile;
+  constexpr uint32_t kMask = kTile - 1;
   uint32_t k0, k1;
   {
-    const int g0 = base + t, g1 = base + t + kRadixThreads;
+    const int g0 = base + t, g1 = base + t + kThreads;
     const uint32_t a = g0 < n ? (FIRST ? (uint32_t)seg_id(ids, g0) : keys_in[g0]) : 0u;
     const uint32_t b = g1 < n ? (FIRST ? (uint32_t)seg_id(ids, g1) : keys_in[g1]) : 0u;
-    k0 = g0 < n ? (((a >> shift) & kMask) << kRadixBits) | (uint32_t)t : 0xFFFFFFFFu;
-    k1 = g1 < n ? (((b >> shift) & kMask) << kRadixBits) | (uint32_t)(t + kRadixThreads) : 0xFFFFFFFFu;
+    k0 = g0 < n ? (((a >> shift) & kMask) << TB) | (uint32_t)t : 0xFFFFFFFFu;
+    k1 = g1 < n ? (((b >> shift) & kMask) << TB) | (uint32_t)(t + kThreads) : 0xFFFFFFFFu;
   }
   bstart[t] = 0;
-  bstart[t + kRadixThreads] = 0;
+  bstart[t + kThreads] = 0;
   bend[t] = 0;
-  bend[t + kRadixThreads] = 0;
-  tile_bitonic<kRadixBits>(k0, k1, key);
+  bend[t + kThreads] = 0;
+  tile_bitonic<TB>(k0, k1, key);
   __syncthreads();  // the network's last LDS reads are done; `key` is free (and the zeroed histograms are visible)
   key[t] = k0;
-  key[t + kRadixThreads] = k1;
+  key[t + kThreads] = k1;
   tiles[base + t] = k0;
-  tiles[base + t + kRadixThreads] = k1;
+  tiles[base + t + kThreads] = k1;
   __syncthreads();
-  const int live = min(kRadixTile, n - base);  // padding (all ones) sorts to the end
+  const int live = min(kTile, n - base);  // padding (all ones) sorts to the end
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const int i = t + h * kRadixThreads;
+    const int i = t + h * kThreads;
     if (i < live) {
-      const uint32_t d = key[i] >> kRadixBits;
-      if (i == 0 || (key[i - 1] >> kRadixBits) != d) bstart[d] = i;
-      if (i == live - 1 || (key[i + 1] >> kRadixBits) != d) bend[d] = i + 1;
+      const uint32_t d = key[i] >> TB;
+      if (i == 0 || (key[i - 1] >> TB) != d) bstart[d] = i;
+      if (i == live - 1 || (key[i + 1] >> TB) != d) bend[d] = i + 1;
     }
   }
   __syncthreads();
-  hist[(int64_t)blockIdx.x * kRadixTile + t] = bend[t] - bstart[t];
-  hist[(int64_t)blockIdx.x * kRadixTile + t + kRadixThreads] = bend[t + kRadixThreads] - bstart[t + kRadixThreads];
+  hist[(int64_t)blockIdx.x * kTile + t] = bend[t] - bstart[t];
+  hist[(int64_t)blockIdx.x * kTile + t + kThreads] = bend[t + kThreads] - bstart[t + kThreads];
 }
 
-// LAST: write (sorted ids, perm) as int32; else the ping-pong (keys, vals) of the next pass
-template <bool FIRST>
-__global__ __launch_bounds__(kRadixThreads) void radix_scatter_kernel(SortSegs ids, const uint32_t* __restrict__ keys_in,
+template <int TB, bool FIRST>
+__global__ __launch_bounds__((1 << TB) / 2) void radix_scatter_kernel(SortSegs ids, const uint32_t* __restrict__ keys_in,
                                                                      const uint32_t* __restrict__ vals_in, int n,
                                                                      int ntiles, const uint32_t* __restrict__ tiles,
                                                                      const int32_t* __restrict__ hist,
                                                                      uint32_t* __restrict__ keys_out,
                                                                      uint32_t* __restrict__ vals_out) {
-  __shared__ uint32_t comp[kRadixTile];
-  __shared__ int offs[kRadixTile], bstart[kRadixTile];
-  __shared__ int wave_tot[kRadixThreads / 64];
-  const int t = threadIdx.x, tile = blockIdx.x, base = tile * kRadixTile;
+  constexpr int kTile = 1 << TB, kThreads = kTile / 2;
+  __shared__ uint32_t comp[kTile];
+  __shared__ int offs[kTile], bstart[kTile];
+  __shared__ int wave_tot[kThreads / 64];
+  const int t = threadIdx.x, tile = blockIdx.x, base = tile * kTile;
   comp[t] = tiles[base + t];
-  comp[t + kRadixThreads] = tiles[base + t + kRadixThreads];
+  comp[t + kThreads] = tiles[base + t + kThreads];
   // digits 2t and 2t + 1: totals over all tiles and over the tiles before this one
+  // (unrolled: the loads of a pass over the matrix are independent; one at a time this loop WAS the kernel, 16 us)
   int tot0 = 0, tot1 = 0, pre0 = 0, pre1 = 0;
   const int2* h2 = reinterpret_cast<const int2*>(hist);
-  // (unrolled: the loads of a pass over the matrix are independent; one at a time this loop WAS the kernel, 16 us)
 #pragma unroll 32
   for (int u = 0; u < ntiles; ++u) {
-    const int2 c = h2[(int64_t)u * (kRadixTile / 2) + t];
+    const int2 c = h2[(int64_t)u * (kTile / 2) + t];
     tot0 += c.x;
     tot1 += c.y;
     pre0 += u < tile ? c.x : 0;
     pre1 += u < tile ? c.y : 0;
   }
-  // exclusive scan of the 2048 totals: pair sums -> wave scan -> wave totals
+  // exclusive scan of the totals: pair sums -> wave scan -> wave totals
   const int pair = tot0 + tot1;
   int incl = pair;
 #pragma unroll
@@ -350,22 +356,22 @@ __global__ __launch_bounds__(kRadixThreads) void radix_scatter_kernel(SortSegs i
   const int excl = wbase + incl - pair;
   offs[2 * t] = excl + pre0;
   offs[2 * t + 1] = excl + tot0 + pre1;
-  const int live = min(kRadixTile, n - base);
+  const int live = min(kTile, n - base);
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const int i = t + h * kRadixThreads;
+    const int i = t + h * kThreads;
     if (i < live) {
-      const uint32_t d = comp[i] >> kRadixBits;
-      if (i == 0 || (comp[i - 1] >> kRadixBits) != d) bstart[d] = i;
+      const uint32_t d = comp[i] >> TB;
+      if (i == 0 || (comp[i - 1] >> TB) != d) bstart[d] = i;
     }
   }
   __syncthreads();
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const int i = t + h * kRadixThreads;
+    const int i = t + h * kThreads;
     if (i < live) {
-      const uint32_t c = comp[i], d = c >> kRadixBits;
-      const int src = base + (int)(c & (kRadixTile - 1));
+      const uint32_t c = comp[i], d = c >> TB;
+      const int src = base + (int)(c & (kTile - 1));
       const int dst = offs[d] + (i - bstart[d]);
       keys_out[dst] = FIRST ? (uint32_t)seg_id(ids, src) : keys_in[src];
       vals_out[dst] = FIRST ? (uint32_t)src : vals_in[src];
@@ -374,13 +380,14 @@ __global__ __launch_bounds__(kRadixThreads) void radix_scatter_kernel(SortSegs i
 }
 
 struct RadixWs {
-  uint32_t* tiles;  // [ntiles * 2048]
-  int32_t* hist;    // [ntiles][2048]
+  uint32_t* tiles;  // [ntiles << TB]
+  int32_t* hist;    // [ntiles][1 << TB]
   uint32_t* keys[2];
   uint32_t* vals[2];
 };
+// one layout for every tile size: ntiles << TB <= n rounded up to the largest tile
 static size_t radix_ws_layout(int64_t n, char* base, RadixWs* ws) {
-  const int64_t ntiles = cdiv(n, kRadixTile);
+  const size_t padded = (size_t)cdiv(n, 2048) * 2048;
   size_t off = 0;
   auto take = [&](size_t bytes) {
     char* p = base ? base + off : nullptr;
@@ -388,8 +395,8 @@ static size_t radix_ws_layout(int64_t n, char* base, RadixWs* ws) {
     return p;
   };
   RadixWs w;
-  w.tiles = (uint32_t*)take(sizeof(uint32_t) * (size_t)ntiles * kRadixTile);
-  w.hist = (int32_t*)take(sizeof(int32_t) * (size_t)ntiles * kRadixTile);
+  w.tiles = (uint32_t*)take(sizeof(uint32_t) * padded);
+  w.hist = (int32_t*)take(sizeof(int32_t) * padded);
   for (int i = 0; i < 2; ++i) {
     w.keys[i] = (uint32_t*)take(sizeof(uint32_t) * (size_t)n);
     w.vals[i] = (uint32_t*)take(sizeof(uint32_t) * (size_t)n);
@@ -397,26 +404,28 @@ static size_t radix_ws_layout(int64_t n, char* base, RadixWs* ws) {
   if (ws) *ws = w;
   return off;
 }
+template <int TB>
 static void launch_radix_sort(const SortSegs& sg, int n, int key_bits, const RadixWs& ws, int32_t* sorted_ids,
                               int32_t* perm, hipStream_t st) {
-  const int ntiles = (int)cdiv(n, kRadixTile);
-  const int passes = std::max(1, (int)cdiv(key_bits, kRadixBits));
+  constexpr int kTile = 1 << TB, kThreads = kTile / 2;
+  const int ntiles = (int)cdiv(n, kTile);
+  const int passes = std::max(1, (int)cdiv(key_bits, TB));
   const uint32_t* kin = nullptr;
   const uint32_t* vin = nullptr;
   for (int p = 0; p < passes; ++p) {
     const bool last = p == passes - 1;
     uint32_t* kout = last ? reinterpret_cast<uint32_t*>(sorted_ids) : ws.keys[p & 1];
     uint32_t* vout = last ? reinterpret_cast<uint32_t*>(perm) : ws.vals[p & 1];
-    const int shift = p * kRadixBits;
+    const int shift = p * TB;
     if (p == 0) {
-      hipLaunchKernelGGL(radix_tile_kernel<true>, dim3(ntiles), dim3(kRadixThreads), 0, st, sg, kin, n, shift, ws.tiles,
+      hipLaunchKernelGGL((radix_tile_kernel<TB, true>), dim3(ntiles), dim3(kThreads), 0, st, sg, kin, n, shift, ws.tiles,
                          ws.hist);
-      hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(ntiles), dim3(kRadixThreads), 0, st, sg, kin, vin, n, ntiles,
+      hipLaunchKernelGGL((radix_scatter_kernel<TB, true>), dim3(ntiles), dim3(kThreads), 0, st, sg, kin, vin, n, ntiles,
                          (const uint32_t*)ws.tiles, (const int32_t*)ws.hist, kout, vout);
     } else {
-      hipLaunchKernelGGL(radix_tile_kernel<false>, dim3(ntiles), dim3(kRadixThreads), 0, st, sg, kin, n, shift, ws.tiles,
+      hipLaunchKernelGGL((radix_tile_kernel<TB, false>), dim3(ntiles), dim3(kThreads), 0, st, sg, kin, n, shift, ws.tiles,
                          ws.hist);
-      hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(ntiles), dim3(kRadixThreads), 0, st, sg, kin, vin, n, ntiles,
+      hipLaunchKernelGGL((radix_scatter_kernel<TB, false>), dim3(ntiles), dim3(kThreads), 0, st, sg, kin, vin, n, ntiles,
                          (const uint32_t*)ws.tiles, (const int32_t*)ws.hist, kout, vout);
     }
     kin = kout;
@@ -788,14 +797,14 @@ static int segment_sort_segs(const char* who, const SortSegs& sg, int64_t n, int
     else launch_tile_sort<11>(sg, (int)n, tiles, sorted_ids, perm, st);
     return check_launch(who);
   }
-  if (n <= kRadixMaxN && bits_for(V) <= kRadixMaxPasses * kRadixBits) {
+  if (n <= kRadixMaxN && bits_for(V) <= kRadixMaxPasses * 11) {
     if (radix_ws_layout(n, nullptr, nullptr) > workspace_bytes || ((uintptr_t)workspace & 15)) {
       set_error("%s: workspace %zu bytes too small (or misaligned)", who, workspace_bytes);
       return ESR_EWORKSPACE;
     }
     RadixWs ws;
     radix_ws_layout(n, (char*)workspace, &ws);
-    launch_radix_sort(sg, (int)n, bits_for(V), ws, sorted_ids, perm, st);
+    launch_radix_sort<11>(sg, (int)n, bits_for(V), ws, sorted_ids, perm, st);
     return check_launch(who);
   }
   // device radix sort: needs the ids as one array (materialised at the head of the workspace when segmented)

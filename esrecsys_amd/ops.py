@@ -183,10 +183,13 @@ def glove_fwd_bwd(emb, bias, inputs, target, mode=GLOVE_REFERENCE, want_grads=Tr
 GRADS_AT_IDS = 0x100  # include/esr_hip.h ESR_GRADS_AT_IDS
 
 
-def glove_train_step(emb, shadow, loc, accum, bias, bias_accum, inputs, target, mode, lr, eps=1e-7):
+def glove_train_step(emb, shadow, loc, accum, bias, bias_accum, inputs, target, mode, lr, eps=1e-7, presorted=None,
+                     blocks_per_cu=0):
     """One whole GloVe training step (loss + gradients + sparse Adagrad on both tables) without materialised
     gradients: esr_glove_train_step.  `emb` / `shadow` are the two buffers of the double-buffered embedding table and
-    `loc` (uint8 [V]) says which one holds each row; all three are updated.  Returns loss[1]."""
+    `loc` (uint8 [V]) says which one holds each row; all three are updated.  presorted = (sorted_ids, perm) of
+    inputs.reshape(-1) from segment_sort (computed ahead, e.g. on a second stream), else the sort runs here.
+    Returns loss[1]."""
     lib = _lib.load()
     for name, t in (("emb", emb), ("shadow", shadow), ("accum", accum), ("bias", bias), ("bias_accum", bias_accum),
                     ("target", target)):
@@ -201,8 +204,14 @@ def glove_train_step(emb, shadow, loc, accum, bias, bias_accum, inputs, target, 
         raise ValueError("shadow / accum / loc / bias shapes do not match the embedding table")
     loss = torch.empty(1, dtype=torch.float32, device=emb.device)
     ws = _ws(_ws_bytes("esr_glove_step_workspace_bytes", B, D), emb.device)
+    sid = perm = None
+    if presorted is not None:
+        sid, perm = _req(presorted[0], torch.int32, "sorted_ids"), _req(presorted[1], torch.int32, "perm")
+        if sid.numel() != 2 * B or perm.numel() != 2 * B:
+            raise ValueError("presorted ids / perm must have 2 B entries")
     check(lib.esr_glove_train_step(_p(emb), _p(shadow), _p(loc), _p(accum), _p(bias), _p(bias_accum), V, D, _p(inputs),
-                                   _p(target), B, mode, float(lr), float(eps), _p(loss), _p(ws), ws.numel(), _stream()),
+                                   _p(target), B, mode, float(lr), float(eps), _p(sid), _p(perm), int(blocks_per_cu),
+                                   _p(loss), _p(ws), ws.numel(), _stream()),
           "esr_glove_train_step")
     return loss
 

@@ -93,13 +93,57 @@ def fused_step_available(state):
     return emb.is_cuda and emb.dtype == torch.float32 and bias.dtype == torch.float32 and emb.shape[0] < (1 << 30)
 
 
+class PresortedInputs:
+    """The occurrence ids of a batch, already on the device and sorted on the side stream (``presort_inputs``): the sort
+    needs the ids only, so ``train_epoch`` runs it for batch k + 1 while batch k's update kernel streams the rows."""
+
+    def __init__(self, inputs, sorted_ids, perm, event):
+        self.inputs, self.sorted_ids, self.perm, self.event = inputs, sorted_ids, perm, event
+
+    def take(self):
+        """(sorted_ids, perm) for the current stream (waits for the side stream's event, once)."""
+        if self.event is not None:
+            torch.cuda.current_stream(self.inputs.device).wait_event(self.event)
+            self.event = None
+        return self.sorted_ids, self.perm
+
+
+# ESR_GLOVE_PRESORT=0 sorts in line instead of one batch ahead on the side stream.  ESR_GLOVE_STEP_BLOCKS_PER_CU caps the
+# update kernel's residency (experiment knob: making room for the sort to run BESIDE it measured slower, DESIGN.md).
+_PRESORT = os.environ.get("ESR_GLOVE_PRESORT", "1") == "1"
+_STEP_BLOCKS_PER_CU = int(os.environ.get("ESR_GLOVE_STEP_BLOCKS_PER_CU", "0"))
+
+
+def presort_inputs(state, inputs):
+    """Move `inputs` to the device and sort its occurrence ids on the side stream.  Returns a PresortedInputs to pass as
+    ``train_step(..., inputs=that)``."""
+    from ..train_state import _side_stream
+    emb = state.raw_params["_token_embedding"]["embedding"]
+    V = emb.shape[0]
+    ids = ops.as_ids(inputs, emb.device, check_range=V)
+    main = torch.cuda.current_stream(emb.device)
+    side = _side_stream(emb.device)
+    side.wait_stream(main)  # the ids may have been produced (copied) on the main stream
+    with torch.cuda.stream(side):
+        sorted_ids, perm = ops.segment_sort(ids.reshape(-1), V)
+        event = torch.cuda.Event()
+        event.record(side)
+    ids.record_stream(side)
+    sorted_ids.record_stream(main)
+    perm.record_stream(main)
+    return PresortedInputs(ids, sorted_ids, perm, event)
+
+
 def train_step(state, inputs, target):
     """``apply_model`` + ``update_model`` (wikipedia/train_cooccurence.py:71-101) in ONE pass over the rows, for the
-    build's sparse Adagrad: returns ``(new_state, loss)``.  No gradient is materialised -- the update kernel re-reads
-    each occurrence's partner row and forms its gradient on chip -- which the double-buffered embedding table makes
-    safe (train_state.RowVersions; ``state.params`` consolidates on access).  Tables and accumulators come out
-    bit-identical to the two-call path on the embedding table, to f32 rounding on the bias table and the loss."""
+    build's sparse Adagrad: returns ``(new_state, loss)``.  `inputs` may be a PresortedInputs (see presort_inputs).
+    No gradient is materialised -- the update kernel re-reads each occurrence's partner row and forms its gradient on
+    chip -- which the double-buffered embedding table makes safe (train_state.RowVersions; ``state.params``
+    consolidates on access).  Tables, accumulators and loss agree with the two-call path to an f32 rounding."""
     from ..train_state import row_versions
+    presorted = None
+    if isinstance(inputs, PresortedInputs):
+        presorted, inputs = inputs, inputs.inputs
     if not fused_step_available(state):
         grads, loss = apply_model(state, inputs, target)
         return update_model(state, grads), loss
@@ -113,8 +157,18 @@ def train_step(state, inputs, target):
     acc = state.opt_state["sum_of_squares"]
     rv.dirty = True
     loss = ops.glove_train_step(emb, rv.shadow, rv.loc, acc["_token_embedding"]["embedding"], bias,
-                                acc["_bias"]["embedding"], inputs, target, mode, state.tx.lr, state.tx.eps)
+                                acc["_bias"]["embedding"], inputs, target, mode, state.tx.lr, state.tx.eps,
+                                presorted=presorted.take() if presorted is not None else None,
+                                blocks_per_cu=_STEP_BLOCKS_PER_CU if presorted is not None else 0)
     return state.replace(step=state.step + 1), loss.reshape(())
+
+
+_PRESORT_MIN_IDS = 4096
+
+
+def _ids_count(inputs):
+    x = inputs.inputs if isinstance(inputs, PresortedInputs) else inputs
+    return int(np.prod(x.shape)) if hasattr(x, "shape") else 2 * len(x[0])
 
 
 def train_epoch(state, steps_per_epoch, train_it):
@@ -123,9 +177,18 @@ def train_epoch(state, steps_per_epoch, train_it):
     one-pass ``train_step``; with the reference's dense Adam it is apply_model + update_model as there."""
     epoch_loss = []
     fused = fused_step_available(state)
-    for _ in range(steps_per_epoch):
-        inputs, targets = next(train_it)
+    # batches are fetched one ahead so that batch k + 1's ids can be sorted (side stream) under batch k's update kernel;
+    # worth it only when the list is long enough for the sort to be a chain of launches (> 4096 ids: B > 2048)
+    ahead = None
+    for k in range(steps_per_epoch):
+        inputs, targets = ahead if ahead is not None else next(train_it)
+        ahead = None
         if fused:
+            if _PRESORT and k == 0 and _ids_count(inputs) > _PRESORT_MIN_IDS:
+                inputs = presort_inputs(state, inputs)
+            if _PRESORT and k + 1 < steps_per_epoch and _ids_count(inputs) > _PRESORT_MIN_IDS:
+                nxt_inputs, nxt_targets = next(train_it)
+                ahead = (presort_inputs(state, nxt_inputs), nxt_targets)
             state, loss = train_step(state, inputs, targets)
         else:
             grads, loss = apply_model(state, inputs, targets)

@@ -104,13 +104,18 @@ int esr_glove_fwd_bwd(const float* emb, const float* bias, int64_t V, int D, con
  * holds each row's current value.  The step reads every row where emb_loc pointed when it began, writes each updated
  * row into the OTHER buffer and flips its byte.  Callers that need a plain [V, D] table run esr_rows_consolidate
  * (copies the rows whose byte is 1 from `shadow` into `primary`, clears the bytes).  A fresh state is emb_loc = 0.
- * The result (tables, accumulators) is bit-identical to esr_glove_fwd_bwd + esr_sparse_adagrad_scatter on the embedding
- * table; the bias table and the loss agree to f32 rounding (their sums are associated differently).
- * loss [1]; bias / bias_accum [V] are updated in place (every bias read of a step precedes its bias writes). */
+ * Same sort, same cut points and the same association of every sum as esr_glove_fwd_bwd + esr_sparse_adagrad_scatter:
+ * tables, accumulators and loss agree with that path to an f32 rounding (bias sums are carried in fp64 here).
+ * loss [1]; bias / bias_accum [V] are updated in place (every bias read of a step precedes its bias writes).
+ * presorted_ids / presorted_perm (both or neither): the output of esr_segment_sort_ids on inputs[0 .. 2B) -- the sort
+ * depends on the ids only, so a training loop runs it for batch k + 1 on a second stream while batch k's update
+ * kernel streams the rows; NULL = sort here.  blocks_per_cu > 0 caps the update kernel's residency (workgroups per
+ * CU; an experiment knob: leaving room for a concurrent sort measured slower than filling the chip); 0 = fill it. */
 size_t esr_glove_step_workspace_bytes(int64_t B, int D);
 int esr_glove_train_step(float* emb, float* emb_shadow, uint8_t* emb_loc, float* emb_accum, float* bias,
                          float* bias_accum, int64_t V, int D, const int32_t* inputs, const float* target, int64_t B,
-                         int mode, float lr, float eps, float* loss, void* workspace, size_t workspace_bytes,
+                         int mode, float lr, float eps, const int32_t* presorted_ids, const int32_t* presorted_perm,
+                         int blocks_per_cu, float* loss, void* workspace, size_t workspace_bytes,
                          esr_stream_t stream);
 int esr_rows_consolidate(float* primary, const float* shadow, uint8_t* loc, int64_t V, int D, esr_stream_t stream);
 

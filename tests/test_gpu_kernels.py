@@ -420,8 +420,8 @@ def test_segment_sort_hand_written_radix_path(dev, kind, n, V):
         ids = np.where(rng.random(n) < 0.3, V - 7, rng.integers(0, V, n)).astype(np.int32)  # one hot id, wide range
     else:
         ids = _ids(kind, rng, V, n)
-    sid, perm = ops.segment_sort(T(ids, dev), V)
     order = np.argsort(ids, kind="stable")
+    sid, perm = ops.segment_sort(T(ids, dev), V)
     assert np.array_equal(N(perm), order.astype(np.int32))
     assert np.array_equal(N(sid), ids[order])
 
