@@ -180,6 +180,17 @@ def roofline_for(workload, kernels, B, D, rows, precision, occ_n=0, uniq=0, bf16
                 "bound": "hbm", "achieved": alg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": alg / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
                 "bytes_the_update_needs_per_step": moved, "those_bytes_GBps": moved / t / 1e9}
+    if workload == "triplet" and "triplet_step" in kernels:
+        # one-pass step (plan + update + long in ONE ops call; the sort is in it too unless it ran ahead on the side
+        # stream): against SURVEY 8d's algorithmic bytes; the update kernel itself needs per occurrence its two partner
+        # rows and per distinct row the own-row read, the rewrite and the accumulator RMW
+        t = kernels["triplet_step"]["ms_per_step"] * 1e-3
+        alg = STEP_BYTES_PER_UNIT["triplet"](D) * B
+        moved = (2 * occ_n + 4 * uniq) * D * 4
+        return {"kernel": "esr_triplet_train_step (triplet_plan + triplet_step + triplet_step_long)",
+                "bound": "hbm", "achieved": alg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": alg / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "bytes_the_update_needs_per_step": moved, "those_bytes_GBps": moved / t / 1e9}
     fused_name = "triplet_fused" if workload == "triplet" else "glove_fused"
     fused_bytes = rows * B * D * 4 * 2  # reads `rows` rows and writes `rows` gradient rows per unit
     ada_bytes = (occ_n + 4 * uniq) * D * 4  # grad row read per occurrence + param/accum RMW per distinct row
@@ -198,6 +209,7 @@ TIMED_GROUPS = {
     "triplet_fused": ["triplet_fwd_bwd"],
     "glove_fused": ["glove_fwd_bwd"],
     "glove_step": ["glove_train_step"],
+    "triplet_step": ["triplet_train_step"],
     "segment_sort": ["segment_sort", "segment_sort_multi"],
     "sparse_adagrad": ["sparse_adagrad", "sparse_adagrad_multi"],
 }
@@ -472,6 +484,32 @@ def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True
         state, final_loss = train_epoch(state, steps, iter(batches[warmup:]))  # returns the epoch's mean loss (syncs)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+    elif workload == "triplet" and graphed is None and os.environ.get("ESR_STL_PRESORT", "1") == "1":
+        # the reference's training loop (pinterest/train_shop_the_look.py:195-204) with the ids of batch k + 1 sorted on
+        # a second stream while batch k's three kernels run
+        from esrecsys_amd.pinterest.train_shop_the_look import fused_triplet_step_available, presort_triplets, train_step
+        mode = "eager, ids of the next batch sorted on a side stream"
+        use = fused_triplet_step_available(state)
+
+        def run(lo, hi):
+            nonlocal state
+            ahead = presort_triplets(state, *batches[lo]) if use else None
+            l = None
+            for i in range(lo, hi):
+                cur = ahead
+                ahead = presort_triplets(state, *batches[i + 1]) if use and i + 1 < hi else None
+                if use:
+                    state, l = train_step(state, cur, None, None, LAM, B)
+                else:
+                    state, l = train_step(state, *batches[i], LAM, B)
+            return l
+        run(0, warmup)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss = run(warmup, n_batches)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        final_loss = float(loss)
     else:
         for i in range(warmup):
             loss = one_step(i)

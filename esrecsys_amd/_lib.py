@@ -48,6 +48,10 @@ SIGNATURES = {
     "esr_triplet_workspace_bytes": (c_size, [c_i64]),
     "esr_triplet_fwd_bwd": (c_int, [c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_int, c_i32p, c_i32p, c_i32p, c_i64, c_f32, c_f32,
                                     c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_vp, c_size, c_vp]),
+    "esr_triplet_step_workspace_bytes": (c_size, [c_i64, c_int]),
+    "esr_triplet_train_step": (c_int, [c_f32p, c_f32p, c_vp, c_f32p, c_i64, c_f32p, c_f32p, c_vp, c_f32p, c_i64, c_int,
+                                       c_i32p, c_i32p, c_i32p, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32p, c_i32p,
+                                       c_f32p, c_vp, c_size, c_vp]),
     "esr_inbatch_workspace_bytes": (c_size, [c_i64, c_int]),
     "esr_inbatch_softmax_fwd_bwd": (c_int, [c_f32p, c_f32p, c_i64, c_int, c_f32, c_f32, c_f32, c_f32p, c_f32p, c_f32p,
                                             c_f32p, c_vp, c_size, c_vp]),

@@ -73,9 +73,31 @@ inline int grid_for_groups(int64_t ngroups_needed, int G) {
 }
 
 #ifdef __HIPCC__
-// Sum across the G (power of two) lanes of a row group via xor shuffles; every lane gets the total.
+// value of lane (lane ^ stride), stride a compile-time power of two < 64 after inlining: DPP where the pattern exists
+// on gfx9 (quad_perm for 1 and 2, row_ror:8 for 8), the LDS crossbar without an address for 4 and 16 (ds_swizzle,
+// bit mode), v_permlane32_swap for 32.  A __shfl_xor is a ds_bpermute with a computed address per step.
+__device__ __forceinline__ uint32_t xor_lane(uint32_t v, int stride) {
+  switch (stride) {
+    case 1: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+    case 2: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2, 3, 0, 1]
+    case 8: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true);  // row_ror:8
+    case 4: return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (4 << 10));
+    case 16: return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (16 << 10));
+    case 32: {  // gfx950: one v_permlane32_swap (upper half of a copy <-> lower half of another) + a select
+      const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);  // r[0] = [lo, lo], r[1] = [hi, hi]
+      return (threadIdx.x & 32) ? r[0] : r[1];
+    }
+    default: return (uint32_t)__shfl_xor((int)v, stride, 64);
+  }
+}
+// Sum across the G (power of two) lanes of a row group, butterfly from stride 1 up; every lane gets the total.
 __device__ __forceinline__ float group_sum(float v, int G) {
-  for (int off = G >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+  if (G > 1) v += __uint_as_float(xor_lane(__float_as_uint(v), 1));
+  if (G > 2) v += __uint_as_float(xor_lane(__float_as_uint(v), 2));
+  if (G > 4) v += __uint_as_float(xor_lane(__float_as_uint(v), 4));
+  if (G > 8) v += __uint_as_float(xor_lane(__float_as_uint(v), 8));
+  if (G > 16) v += __uint_as_float(xor_lane(__float_as_uint(v), 16));
+  if (G > 32) v += __uint_as_float(xor_lane(__float_as_uint(v), 32));
   return v;
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
@@ -156,6 +178,13 @@ __device__ __forceinline__ void adagrad_elem(float& w, float& a, float gv, float
   a = acc;
   const float inv = acc > 0.f ? __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(acc, eps))) : 0.f;
   w = __fsub_rn(w, __fmul_rn(__fmul_rn(lr, gv), inv));
+}
+
+// One element of a Shop-The-Look gradient row: (a x + c own) / B with a = +-[margin > 0], x = the
+// partner term (n - p for the scene row, s for the product rows), c = lam [|own| > 1] / |own|.  ONE definition with
+// explicit roundings for esr_triplet.hip and esr_triplet_step.hip: the two paths produce the same bits.
+__device__ __forceinline__ float trip_grad(float a, float x, float c, float own, float inv_bs) {
+  return __fmul_rn(__fadd_rn(__fmul_rn(a, x), __fmul_rn(c, own)), inv_bs);
 }
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }

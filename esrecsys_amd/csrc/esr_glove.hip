@@ -14,6 +14,7 @@
 //                    (sum w, sum w r, sum w (r - center)^2)
 //   K_C finalize   : loss scalar + grad_bias (reference mode needs sum w r / sum w, known only now)
 #include "esr_common.h"
+#include "esr_versioned.h"
 
 namespace esr {
 
@@ -233,8 +234,6 @@ __global__ __launch_bounds__(kBlock) void glove_finalize_kernel(
 //   long      runs longer than a chunk (hot tokens): chunk partials combined in a fixed order
 //   finalize  loss scalar; bias Adagrad (needs the global sum of w r, known only now)
 // =====================================================================================================================
-constexpr int kStepChunk = 32;  // == kSegChunk of esr_optim.hip: same cut points, same association, same bits
-constexpr uint32_t kLocBit = 0x80000000u, kSideBit = 0x40000000u, kIdMask = 0x3FFFFFFFu;
 
 struct StepWs {
   int32_t* sorted_ids;   // [n]
@@ -317,14 +316,6 @@ __global__ __launch_bounds__(kBlock) void glove_plan_kernel(const int32_t* __res
     meta[p] = m;
     own_code[p] = (uint32_t)id | (loc[id] ? kLocBit : 0u);
   }
-}
-
-template <int VEC, int NCH>
-__device__ __forceinline__ void row_zero(RowRegs<VEC, NCH>& r) {
-#pragma unroll
-  for (int k = 0; k < NCH; ++k)
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) r.v[k][e] = 0.f;
 }
 
 // the versioned read-modify-write of one row with its summed gradient g: the row was read where `code` says it lives
@@ -680,22 +671,6 @@ __global__ __launch_bounds__(kBlock) void rows_consolidate_kernel(T* __restrict_
     for (int c = lig; c < nchunk; c += G) primary[r * nchunk + c] = shadow[r * nchunk + c];
     if (lig == 0) loc[r] = 0;
   }
-}
-
-// blocks of `kernel` (kBlock threads, no dynamic LDS) the whole device holds at once; kMaxGrid if the query fails
-static int resident_blocks(const void* kernel, int cap_per_cu = 0) {
-  int per_cu = 0, dev = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || per_cu < 1) {
-    (void)hipGetLastError();
-    return kMaxGrid;
-  }
-  if (cap_per_cu > 0) per_cu = std::min(per_cu, cap_per_cu);
-  if (hipGetDevice(&dev) != hipSuccess ||
-      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
-    (void)hipGetLastError();
-    return kMaxGrid;
-  }
-  return std::min(kMaxGrid, per_cu * cus);
 }
 
 static int check_dim(const char* who, int D) {

@@ -111,24 +111,6 @@ __global__ __launch_bounds__(kSmallSortThreads) void segment_sort_small_kernel(S
 constexpr int kMidTiles = 16, kMaxTileBits = 11;
 constexpr int kSplitEvery = 32;  // one splitter (its last key) per 32-key block of a sorted tile
 constexpr int kMidSortMax = (1 << kMaxTileBits) * kMidTiles;
-// value of lane (lane ^ stride), stride a compile-time power of two < 64 after unrolling: DPP where the pattern exists
-// on gfx9 (quad_perm for 1 and 2, row_ror:8 for 8), the LDS crossbar without an address for 4 and 16 (ds_swizzle,
-// bit mode), v_permlane32_swap for 32
-__device__ __forceinline__ uint32_t xor_lane(uint32_t v, int stride) {
-  switch (stride) {
-    case 1: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
-    case 2: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2, 3, 0, 1]
-    case 8: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true);  // row_ror:8
-    case 4: return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (4 << 10));
-    case 16: return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (16 << 10));
-    case 32: {  // gfx950: one v_permlane32_swap (upper half of a copy <-> lower half of another) + a select
-      const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);  // r[0] = [lo, lo], r[1] = [hi, hi]
-      return (threadIdx.x & 32) ? r[0] : r[1];
-    }
-    default: return (uint32_t)__shfl_xor((int)v, stride, 64);
-  }
-}
-
 // Bitonic network over kTile = 2^TB keys held two per thread: thread t holds positions t (k0) and t + kTile / 2 (k1).
 // A compare-exchange with stride < 64 has its partner in the same wave (lane ^ stride) and is one cross-lane move per key
 // -- 51 of the 66 steps of a 2048-key tile; the stride kTile / 2 pairs the thread's own two registers; only the strides

@@ -71,9 +71,9 @@ __global__ __launch_bounds__(kBlock) void triplet_kernel(
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           const float sv = s.v[k][e], pv = p.v[k][e], nv = n.v[k][e];
-          gs.v[k][e] = (m * (nv - pv) + cs * sv) * inv_bs;
-          gp.v[k][e] = (-m * sv + cp * pv) * inv_bs;
-          gn.v[k][e] = (m * sv + cn * nv) * inv_bs;
+          gs.v[k][e] = trip_grad(m, __fsub_rn(nv, pv), cs, sv, inv_bs);
+          gp.v[k][e] = trip_grad(-m, sv, cp, pv, inv_bs);
+          gn.v[k][e] = trip_grad(m, sv, cn, nv, inv_bs);
         }
       row_store(gs, g_scene + (at_ids ? is : b) * D, lig, G, nvec);
       row_store(gp, g_pos + (at_ids ? ip : b) * D, lig, G, nvec);

@@ -216,6 +216,42 @@ def glove_train_step(emb, shadow, loc, accum, bias, bias_accum, inputs, target, 
     return loss
 
 
+def triplet_train_step(scene, scene_shadow, scene_loc, scene_accum, product, product_shadow, product_loc,
+                       product_accum, scene_ids, pos_ids, neg_ids, regularization, batch_size, lr, eps=1e-7,
+                       presorted=None):
+    """One whole Shop-The-Look training step (triplet loss + on-chip gradients + sparse Adagrad on both double-buffered
+    towers): esr_triplet_train_step.  presorted = (sorted virtual ids, perm) of [scene ; Vs + pos ; Vs + neg] from
+    segment_sort_multi, else the sort runs here.  Returns loss[1]."""
+    lib = _lib.load()
+    for name, t in (("scene", scene), ("scene_shadow", scene_shadow), ("scene_accum", scene_accum),
+                    ("product", product), ("product_shadow", product_shadow), ("product_accum", product_accum)):
+        _req(t, torch.float32, name)
+    _req(scene_loc, torch.uint8, "scene_loc"), _req(product_loc, torch.uint8, "product_loc")
+    for name, t in (("scene_ids", scene_ids), ("pos_ids", pos_ids), ("neg_ids", neg_ids)):
+        _req(t, torch.int32, name)
+    Vs, D = scene.shape
+    Vp = product.shape[0]
+    B = scene_ids.numel()
+    if product.shape[1] != D or pos_ids.numel() != B or neg_ids.numel() != B:
+        raise ValueError("tower dims / id counts differ")
+    if scene_shadow.shape != scene.shape or scene_accum.shape != scene.shape or scene_loc.numel() != Vs or \
+            product_shadow.shape != product.shape or product_accum.shape != product.shape or product_loc.numel() != Vp:
+        raise ValueError("shadow / accum / loc shapes do not match their towers")
+    sid = perm = None
+    if presorted is not None:
+        sid, perm = _req(presorted[0], torch.int32, "sorted_ids"), _req(presorted[1], torch.int32, "perm")
+        if sid.numel() != 3 * B or perm.numel() != 3 * B:
+            raise ValueError("presorted ids / perm must have 3 B entries")
+    loss = torch.empty(1, dtype=torch.float32, device=scene.device)
+    ws = _ws(_ws_bytes("esr_triplet_step_workspace_bytes", B, D), scene.device)
+    check(lib.esr_triplet_train_step(_p(scene), _p(scene_shadow), _p(scene_loc), _p(scene_accum), Vs, _p(product),
+                                     _p(product_shadow), _p(product_loc), _p(product_accum), Vp, D, _p(scene_ids),
+                                     _p(pos_ids), _p(neg_ids), B, float(regularization), float(batch_size), float(lr),
+                                     float(eps), _p(sid), _p(perm), _p(loss), _p(ws), ws.numel(), _stream()),
+          "esr_triplet_train_step")
+    return loss
+
+
 def rows_consolidate(primary, shadow, loc):
     """Copy the rows of a double-buffered table whose current value lives in `shadow` (loc[row] == 1) back into
     `primary` and clear their bytes: afterwards `primary` is the plain [V, D] table."""

@@ -65,6 +65,77 @@ import os as _os
 _PRESORT = _os.environ.get("ESR_INBATCH_PRESORT", "0") == "1"
 
 
+class PresortedTriplets:
+    """The ids of one triplet batch on the device with their occurrence list [scene ; Vs + pos ; Vs + neg] already sorted
+    on the side stream (``presort_triplets``): pass it as ``train_step(state, that, None, None, ...)``.  The sort needs
+    the ids only, so a training loop runs it for batch k + 1 while batch k's kernels are in flight."""
+
+    def __init__(self, scene, pos, neg, sorted_ids, perm, event):
+        self.scene, self.pos, self.neg = scene, pos, neg
+        self.sorted_ids, self.perm, self.event = sorted_ids, perm, event
+
+    def take(self):
+        if self.event is not None:
+            torch.cuda.current_stream(self.scene.device).wait_event(self.event)
+            self.event = None
+        return self.sorted_ids, self.perm
+
+
+def fused_triplet_step_available(state):
+    """True when the triplet ``train_step`` can run in one pass (esr_triplet_train_step): the build's row-sparse Adagrad
+    on fp32 towers of equal width.  ``ESR_STL_FUSED=0`` forces the fwd_bwd + sort + scatter path."""
+    from ..train_state import _SparseAdagrad
+    if _os.environ.get("ESR_STL_FUSED", "1") != "1" or not isinstance(state.tx, _SparseAdagrad):
+        return False
+    try:
+        p = state.raw_params["params"] if "params" in state.raw_params else state.raw_params
+        st, pt = p["scene_tower"]["embedding"], p["product_tower"]["embedding"]
+    except (KeyError, TypeError):
+        return False
+    return (st.is_cuda and st.dtype == torch.float32 and pt.dtype == torch.float32 and st.shape[1] == pt.shape[1] and
+            st.shape[0] + pt.shape[0] < (1 << 30))
+
+
+def presort_triplets(state, scene, pos_product, neg_product):
+    """Move the ids of a triplet batch to the device and sort their occurrence list on the side stream."""
+    from ..train_state import _side_stream
+    p = state.raw_params["params"] if "params" in state.raw_params else state.raw_params
+    st, pt = p["scene_tower"]["embedding"], p["product_tower"]["embedding"]
+    dev = st.device
+    sid = ops.as_ids(scene, dev, check_range=st.shape[0]).reshape(-1)
+    pid = ops.as_ids(pos_product, dev, check_range=pt.shape[0]).reshape(-1)
+    nid = ops.as_ids(neg_product, dev, check_range=pt.shape[0]).reshape(-1)
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(dev)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        Vs = st.shape[0]
+        sorted_ids, perm = ops.segment_sort_multi([sid, pid, nid], [0, Vs, Vs], Vs + pt.shape[0])
+        event = torch.cuda.Event()
+        event.record(side)
+    for t in (sid, pid, nid):
+        t.record_stream(side)
+    sorted_ids.record_stream(main)
+    perm.record_stream(main)
+    return PresortedTriplets(sid, pid, nid, sorted_ids, perm, event)
+
+
+def _fused_triplet_step(state, sid, pid, nid, regularization, batch_size, presorted):
+    from ..train_state import row_versions
+    prefix = ("params",) if "params" in state.raw_params else ()
+    p = state.raw_params["params"] if prefix else state.raw_params
+    st, pt = p["scene_tower"]["embedding"], p["product_tower"]["embedding"]
+    acc = state.opt_state["sum_of_squares"]
+    acc = acc["params"] if prefix else acc
+    rs = row_versions(state, prefix + ("scene_tower", "embedding"))
+    rp = row_versions(state, prefix + ("product_tower", "embedding"))
+    rs.dirty = rp.dirty = True
+    loss = ops.triplet_train_step(st, rs.shadow, rs.loc, acc["scene_tower"]["embedding"], pt, rp.shadow, rp.loc,
+                                  acc["product_tower"]["embedding"], sid, pid, nid, regularization, batch_size,
+                                  state.tx.lr, state.tx.eps, presorted=presorted)
+    return state.replace(step=state.step + 1), loss.reshape(())
+
+
 def train_step(state, scene, pos_product, neg_product, regularization, batch_size, scale=1.0, precision="auto"):
     """One optimizer step (pinterest/train_shop_the_look.py:93-109).  Returns ``(new_state, loss)``.
 
@@ -72,6 +143,19 @@ def train_step(state, scene, pos_product, neg_product, regularization, batch_siz
     gathers the three rows per triplet, scores them and writes the three gradient rows; the optimizer
     update is sort + segment-reduce + RMW.  ``neg_product=None``: in-batch softmax (north_star) with
     temperature ``scale``; ``precision`` picks its MFMA path (see ops.inbatch_softmax_fwd_bwd)."""
+    presorted = None
+    if isinstance(scene, PresortedTriplets):
+        presorted, scene, pos_product, neg_product = scene, scene.scene, scene.pos, scene.neg
+    if neg_product is not None and fused_triplet_step_available(state):
+        # the reference's own loss with the build's sparse Adagrad: the whole step in one pass (esr_triplet_train_step)
+        p = state.raw_params["params"] if "params" in state.raw_params else state.raw_params
+        st, pt = p["scene_tower"]["embedding"], p["product_tower"]["embedding"]
+        dev = st.device
+        sid = ops.as_ids(scene, dev, check_range=st.shape[0]).reshape(-1)
+        pid = ops.as_ids(pos_product, dev, check_range=pt.shape[0]).reshape(-1)
+        nid = ops.as_ids(neg_product, dev, check_range=pt.shape[0]).reshape(-1)
+        return _fused_triplet_step(state, sid, pid, nid, regularization, batch_size,
+                                   presorted.take() if presorted is not None else None)
     _, st, pt = _tables(state)
     dev = st.device
     sid = ops.as_ids(scene, dev, check_range=st.shape[0]).reshape(-1)

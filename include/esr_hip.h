@@ -135,6 +135,25 @@ int esr_triplet_fwd_bwd(const float* scene_table, int64_t Vs, const float* pos_t
                         float* g_scene, float* g_pos, float* g_neg, void* workspace,
                         size_t workspace_bytes, esr_stream_t stream);
 
+/* ---- S2 in one pass: train_step (pinterest/train_shop_the_look.py:93-109) = loss + gradients + sparse Adagrad ----
+ * on both id towers, three launches (plan, update, long-run combine) after the id sort, no [3B, D] gradient in memory:
+ * the update kernel walks the sorted occurrences of every distinct row and forms each occurrence's gradient row on chip
+ * from the two OTHER rows of its triplet (both partner rows give the pos / neg scores and the hinge mask; the own row
+ * gives the regulariser term).  Both towers are DOUBLE-BUFFERED as in esr_glove_train_step: `scene` / `scene_shadow` +
+ * scene_loc [Vs] bytes, `product` / `product_shadow` + product_loc [Vp]; rows are read where the bytes pointed when the
+ * step began, updated rows go to the other buffer, esr_rows_consolidate gives plain tables back.  Occurrence ids are the
+ * virtual rows [scene_ids ; Vs + pos_ids ; Vs + neg_ids]; presorted_ids / presorted_perm (both or neither) = their
+ * esr_segment_sort_ids_multi output computed ahead (second stream), NULL = sort here.  Same element arithmetic
+ * (trip_grad, adagrad_elem), same sort and the same association of every sum as esr_triplet_fwd_bwd +
+ * esr_sparse_adagrad_scatter_multi.  loss [1] = (sum_b relu(1 + neg_b - pos_b) + regularization * reg) / batch_size. */
+size_t esr_triplet_step_workspace_bytes(int64_t B, int D);
+int esr_triplet_train_step(float* scene, float* scene_shadow, uint8_t* scene_loc, float* scene_accum, int64_t Vs,
+                           float* product, float* product_shadow, uint8_t* product_loc, float* product_accum,
+                           int64_t Vp, int D, const int32_t* scene_ids, const int32_t* pos_ids,
+                           const int32_t* neg_ids, int64_t B, float regularization, float batch_size, float lr,
+                           float eps, const int32_t* presorted_ids, const int32_t* presorted_perm, float* loss,
+                           void* workspace, size_t workspace_bytes, esr_stream_t stream);
+
 /* ---- north_star: in-batch-negative sampled softmax on the dense B x B score matrix --------
  * (build-defined; the closest reference precedent is spotify/models.py:74-87).
  *   S = scale * Q C^T (FP32 MFMA), ce_i = logsumexp_j S_ij - S_ii,

@@ -1,0 +1,134 @@
+"""GPU: the one-pass Shop-The-Look train step (esr_triplet_train_step: plan + update + long-run combine on
+double-buffered towers, gradients formed on chip) against (a) the six-launch path esr_triplet_fwd_bwd + sort +
+esr_sparse_adagrad_scatter_multi and (b) the fp64 oracle of pinterest/train_shop_the_look.py:93-109 + sparse Adagrad."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _ids(kind, V, n, rng):
+    if kind == "uniform":
+        return rng.integers(0, V, n).astype(np.int32)
+    if kind == "same":
+        return np.full(n, 3 % V, np.int32)
+    w = 1.0 / np.arange(1, V + 1)
+    return rng.permutation(V)[rng.choice(V, size=n, p=w / w.sum())].astype(np.int32)
+
+
+def _state(Vs, Vp, D, dev, seed=2, lr=0.05, scale=1.0):
+    from esrecsys_amd import TrainState, optim
+    from esrecsys_amd.pinterest.models import STLModel
+    stl = STLModel(output_size=D, num_scenes=Vs, num_products=Vp, device=dev)
+    params = stl.init(seed)
+    if scale != 1.0:  # rows with |e| > 1 so that the regulariser and its gradient are live
+        for t in ("scene_tower", "product_tower"):
+            params["params"][t]["embedding"].mul_(scale)
+    return TrainState.create(apply_fn=stl.apply, params=params, tx=optim.sparse_adagrad(lr))
+
+
+def _tables(state):
+    p = state.params["params"]
+    return p["scene_tower"]["embedding"], p["product_tower"]["embedding"]
+
+
+@pytest.mark.parametrize("kind", ["uniform", "zipf", "same"])
+@pytest.mark.parametrize("Vs,Vp,D,B", [(5000, 7000, 128, 8192), (300, 200, 32, 128), (2000, 1000, 96, 1000),
+                                       (50, 60, 6, 33), (40000, 30000, 64, 30000)])
+def test_fused_triplet_step_equals_six_launch_path(dev, monkeypatch, kind, Vs, Vp, D, B):
+    from esrecsys_amd.pinterest.train_shop_the_look import fused_triplet_step_available, train_step
+    rng = np.random.default_rng(Vs + B)
+    a, b = _state(Vs, Vp, D, dev, scale=3.0), _state(Vs, Vp, D, dev, scale=3.0)
+    assert fused_triplet_step_available(a)
+    lam = 0.1
+    for step in range(3):
+        sid, pid, nid = _ids(kind, Vs, B, rng), _ids(kind, Vp, B, rng), _ids("uniform", Vp, B, rng)
+        monkeypatch.setenv("ESR_STL_FUSED", "1")
+        a, la = train_step(a, sid, pid, nid, lam, B)
+        monkeypatch.setenv("ESR_STL_FUSED", "0")
+        b, lb = train_step(b, sid, pid, nid, lam, B)
+        assert abs(float(la) - float(lb)) <= 2e-6 * abs(float(lb)), (step, float(la), float(lb))
+    versions = a.opt_state["_versions"]
+    assert len(versions) == 2 and all(v.dirty for v in versions.values())
+    assert "_versions" not in b.opt_state
+    (sa, pa), (sb, pb) = _tables(a), _tables(b)
+    assert not any(v.dirty for v in versions.values()) and all(int(v.loc.sum()) == 0 for v in versions.values())
+    assert int(a.step) == int(b.step) == 3
+    assert rel_err(sa.cpu().numpy(), sb.cpu().numpy()) <= 1e-6 and rel_err(pa.cpu().numpy(), pb.cpu().numpy()) <= 1e-6
+    for t in ("scene_tower", "product_tower"):
+        assert rel_err(a.opt_state["sum_of_squares"]["params"][t]["embedding"].cpu().numpy(),
+                       b.opt_state["sum_of_squares"]["params"][t]["embedding"].cpu().numpy()) <= 1e-6
+
+
+def test_fused_triplet_trajectory_vs_fp64_oracle(dev):
+    from esrecsys_amd.pinterest.train_shop_the_look import eval_step, train_step
+    from oracle import optim as o_optim
+    from oracle import stl_head as o_stl
+    Vs, Vp, D, B, lam, lr = 400, 600, 32, 256, 0.1, 0.05
+    state = _state(Vs, Vp, D, dev, lr=lr, scale=2.5)
+    st, pt = (t.cpu().numpy().astype(np.float64) for t in _tables(state))
+    a_s, a_p = np.full_like(st, 0.1), np.full_like(pt, 0.1)
+    rng = np.random.default_rng(11)
+    for step in range(4):
+        kind = "zipf" if step % 2 else "uniform"
+        sid, pid, nid = _ids(kind, Vs, B, rng), _ids(kind, Vp, B, rng), _ids("uniform", Vp, B, rng)
+        state, loss = train_step(state, sid, pid, nid, lam, B)
+        el, gs, gp, gn = o_stl.triplet_loss_and_grads(st[sid], pt[pid], pt[nid], lam, B, np.float64)
+        assert abs(float(loss) - el) <= 1e-5 * abs(el)
+        st, a_s = o_optim.sparse_adagrad_update(st, a_s, sid, gs, lr, dtype=np.float64)
+        pt, a_p = o_optim.sparse_adagrad_update(pt, a_p, np.concatenate([pid, nid]), np.concatenate([gp, gn]), lr,
+                                                dtype=np.float64)
+    gs_, gp_ = _tables(state)
+    assert rel_err(gs_.cpu().numpy(), st) <= 1e-5 and rel_err(gp_.cpu().numpy(), pt) <= 1e-5
+    # eval_step after fused steps reads the consolidated towers (train_shop_the_look.py:111-122)
+    sid, pid, nid = _ids("uniform", Vs, B, rng), _ids("uniform", Vp, B, rng), _ids("uniform", Vp, B, rng)
+    want = np.maximum(1.0 + (st[sid] * pt[nid]).sum(1) - (st[sid] * pt[pid]).sum(1), 0.0).sum()
+    assert abs(float(eval_step(state, sid, pid, nid)) - want) <= 1e-5 * abs(want)
+
+
+def test_presorted_triplets_equal_inline_sort(dev):
+    """the sort of batch k + 1 on the side stream gives the same step as sorting in line"""
+    from esrecsys_amd.pinterest.train_shop_the_look import presort_triplets, train_step
+    Vs, Vp, D, B = 3000, 2000, 128, 4096
+    rng = np.random.default_rng(4)
+    a, b = _state(Vs, Vp, D, dev, scale=2.0), _state(Vs, Vp, D, dev, scale=2.0)
+    batches = [(_ids("uniform", Vs, B, rng), _ids("zipf", Vp, B, rng), _ids("uniform", Vp, B, rng)) for _ in range(4)]
+    ahead = presort_triplets(a, *batches[0])
+    for k, bt in enumerate(batches):
+        cur = ahead
+        ahead = presort_triplets(a, *batches[k + 1]) if k + 1 < len(batches) else None
+        a, la = train_step(a, cur, None, None, 0.1, B)
+        b, lb = train_step(b, *bt, 0.1, B)
+        assert float(la) == float(lb)
+    for ta, tb in zip(_tables(a), _tables(b)):
+        assert torch.equal(ta, tb)
+
+
+def test_config_c2_triplet_full_size_fused_step(dev):
+    """BASELINE configs[1] tables (1 M x 128 per tower), B = 8192, the reference's own loss: fused == six-launch path to
+    an f32 rounding; rows no triplet touches keep their bits."""
+    import os
+    from esrecsys_amd.pinterest.train_shop_the_look import train_step
+    V, D, B = 1_000_000, 128, 8192
+    a, b = _state(V, V, D, dev, scale=1.2), _state(V, V, D, dev, scale=1.2)
+    before = _tables(a)[1].clone()
+    g = torch.Generator(device=dev).manual_seed(5)
+    touched = torch.zeros(V, dtype=torch.bool, device=dev)
+    for _ in range(2):
+        ids = torch.randint(0, V, (3, B), generator=g, device=dev, dtype=torch.int32)
+        os.environ["ESR_STL_FUSED"] = "1"
+        a, la = train_step(a, ids[0].contiguous(), ids[1].contiguous(), ids[2].contiguous(), 0.1, B)
+        os.environ["ESR_STL_FUSED"] = "0"
+        try:
+            b, lb = train_step(b, ids[0].contiguous(), ids[1].contiguous(), ids[2].contiguous(), 0.1, B)
+        finally:
+            os.environ["ESR_STL_FUSED"] = "1"
+        touched[ids[1].long()] = True
+        touched[ids[2].long()] = True
+        assert abs(float(la) - float(lb)) <= 2e-6 * abs(float(lb))
+    (sa, pa), (sb, pb) = _tables(a), _tables(b)
+    assert rel_err(sa.cpu().numpy(), sb.cpu().numpy()) <= 1e-6 and rel_err(pa.cpu().numpy(), pb.cpu().numpy()) <= 1e-6
+    assert torch.equal(pa[~touched], before[~touched]) and not torch.equal(pa[touched], before[touched])
