@@ -484,7 +484,7 @@ def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True
         state, final_loss = train_epoch(state, steps, iter(batches[warmup:]))  # returns the epoch's mean loss (syncs)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    elif workload == "triplet" and graphed is None and os.environ.get("ESR_STL_PRESORT", "1") == "1":
+    elif workload == "triplet" and graphed is None and os.environ.get("ESR_STL_PRESORT", "0") == "1":
         # the reference's training loop (pinterest/train_shop_the_look.py:195-204) with the ids of batch k + 1 sorted on
         # a second stream while batch k's three kernels run
         from esrecsys_amd.pinterest.train_shop_the_look import fused_triplet_step_available, presort_triplets, train_step

@@ -34,3 +34,15 @@ def rel_err(a, b):
     if a.size == 0:
         return 0.0
     return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-30))
+
+
+def elem_rel_err(a, b, floor_frac=1e-3):
+    """ELEMENT-WISE relative error with an absolute floor: max_i |a_i - b_i| / max(|b_i|, floor_frac * max|b|).
+    rel_err above is norm-wise (one large entry hides bad small ones); this one bounds every entry whose magnitude is
+    at least floor_frac of the largest, and treats smaller entries as if they had that magnitude."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    if a.size == 0:
+        return 0.0
+    floor = max(floor_frac * float(np.max(np.abs(b))), 1e-30)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))

@@ -52,7 +52,8 @@ def test_bad_arguments_are_rejected_without_a_device(lib):
     assert lib.esr_inbatch_softmax_fwd_bwd_bf16x3(16, 16, 33, 128, 1.0, 0.0, 33.0, 16, 16, 16, 16, 16, 1 << 20,
                                                   None) == EINVAL
     assert b"multiple of 128" in lib.esr_last_error()
-    assert lib.esr_inbatch_softmax_fwd_bwd(16, 16, 64, 100, 1.0, 0.0, 64.0, 16, 16, 16, 16, 16, 1 << 20, None) == EINVAL
+    assert lib.esr_inbatch_softmax_fwd_bwd(16, 16, 64, 102, 1.0, 0.0, 64.0, 16, 16, 16, 16, 16, 1 << 20, None) == EINVAL
+    assert lib.esr_inbatch_softmax_fwd_bwd(16, 16, 64, 516, 1.0, 0.0, 64.0, 16, 16, 16, 16, 16, 1 << 20, None) == EINVAL
     assert lib.esr_dense_adam(16, 16, 16, 16, 8, 1e-3, 0.9, 0.999, 1e-8, 0, None) == EINVAL  # step must be >= 1
     # workspace too small is reported before any launch
     assert lib.esr_glove_fwd_bwd(16, 16, 10, 4, 16, 16, 8, 0, 16, None, None, 16, 8, None) == EWORKSPACE

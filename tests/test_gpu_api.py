@@ -191,10 +191,13 @@ def test_stl_train_step_trajectory_and_eval(dev):
     assert rel_err(N(state.params["params"]["product_tower"]["embedding"]), pt) <= TOL
 
 
-def test_stl_inbatch_train_step(dev):
+@pytest.mark.parametrize("D,B", [(128, 512), (96, 200), (64, 16), (32, 128), (256, 300)])
+def test_stl_inbatch_train_step(dev, D, B):
+    """in-batch train_step at the reference's own sizes: output_size 32 / 64 / 96 (pinterest/sweep.yaml:13-14,
+    train_shop_the_look.py:59), batch 16 (:60), and wider towers"""
     from esrecsys_amd import optim
     from esrecsys_amd.pinterest.train_shop_the_look import train_step
-    Vs, Vp, D, B, lr, lam, scale = 3000, 5000, 128, 512, 0.05, 0.1, 4.0
+    Vs, Vp, lr, lam, scale = 3000, 5000, 0.05, 0.1, 4.0
     stl, state = _stl_state(dev, Vs, Vp, D, optim.sparse_adagrad(lr))
     st = N(state.params["params"]["scene_tower"]["embedding"]).astype(F64)
     pt = N(state.params["params"]["product_tower"]["embedding"]).astype(F64)

@@ -246,6 +246,49 @@ def test_inbatch_ragged_batch_vs_oracle(dev, B, D):
     assert np.abs(N(gc) - egc).max() <= TOL * max(np.abs(egc).max(), 1e-6)
 
 
+@pytest.mark.parametrize("D", [4, 20, 32, 48, 64, 96, 100, 128, 192, 256, 384, 512])
+@pytest.mark.parametrize("B", [96, 1000])
+def test_inbatch_embedding_widths_vs_oracle(dev, B, D):
+    """every embedding width the reference trains (output_size 32 / 64 / 96: pinterest/sweep.yaml:13-14, README 64) and
+    the wide ones of SURVEY 4.3 (256, 512): D <= 128 runs in the next tile width with zero columns that never touch
+    memory, 128 < D <= 512 in the column-panel kernel.  Norm-wise AND element-wise bounds against the fp64 oracle."""
+    from conftest import elem_rel_err
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(1000 * B + D)
+    q = (rng.standard_normal((B, D)) * (1.1 / np.sqrt(D))).astype(np.float32)   # |row| ~ 1.1: the regulariser is live
+    c = (rng.standard_normal((B, D)) * (1.1 / np.sqrt(D))).astype(np.float32)
+    c[3] = c[4]
+    loss, lse, gq, gc = ops.inbatch_softmax_fwd_bwd(T(q, dev), T(c, dev), 5.0, 0.2, float(B))
+    el, else_, egq, egc = o_stl.inbatch_softmax_loss_and_grads(q, c, 0.2, B, 5.0, F64)
+    assert abs(float(loss) - el) <= TOL * abs(el)
+    assert rel_err(N(lse), else_) <= TOL and rel_err(N(gq), egq) <= TOL and rel_err(N(gc), egc) <= TOL
+    assert elem_rel_err(N(gq), egq) <= 20 * TOL and elem_rel_err(N(gc), egc) <= 20 * TOL
+    # columns beyond D do not exist: the output buffers end where the rows end (a guard row behind them stays intact)
+    guard = torch.full((2 * B + 1, D), 7.0, device=dev)
+    qt, ct = T(q, dev), T(c, dev)
+    loss2, _, gq2, gc2 = ops.inbatch_softmax_fwd_bwd(qt, ct, 5.0, 0.2, float(B))
+    assert torch.equal(gq2, gq) and torch.equal(gc2, gc) and bool((guard == 7.0).all())
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_inbatch_gradients_elementwise_at_c2_size(dev, precision):
+    """C2 size, both MFMA paths: every gradient entry within 1e-4 of the fp64 oracle relative to max(|entry|, 1e-3 of
+    the largest entry) -- the norm-wise 1e-5 bound alone would let small entries of the bf16x3 path be arbitrarily bad."""
+    from conftest import elem_rel_err
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(77)
+    B, D = 8192, 128
+    q = (rng.standard_normal((B, D)) * (1.2 / np.sqrt(D))).astype(np.float32)
+    c = (rng.standard_normal((B, D)) * (1.2 / np.sqrt(D))).astype(np.float32)
+    loss, lse, gq, gc = ops.inbatch_softmax_fwd_bwd(T(q, dev), T(c, dev), 8.0, 0.1, float(B), precision=precision)
+    el, else_, egq, egc = o_stl.inbatch_softmax_loss_and_grads(q, c, 0.1, B, 8.0, F64)
+    eq, ec = elem_rel_err(N(gq), egq), elem_rel_err(N(gc), egc)
+    print("inbatch %s element-wise rel.err (floor 1e-3 max): gQ %.2e gC %.2e; norm-wise %.2e %.2e"
+          % (precision, eq, ec, rel_err(N(gq), egq), rel_err(N(gc), egc)))
+    assert eq <= 1e-4 and ec <= 1e-4   # measured: f32 2.5e-5 / 3.3e-5, bf16x3 5.2e-5 / 4.7e-5
+    assert elem_rel_err(N(lse), else_, floor_frac=1e-6) <= TOL
+
+
 def test_fused_heads_write_grads_at_ids(dev):
     """ESR_GRADS_AT_IDS: with a private [n, D] copy of the looked-up rows in any order and ids = positions in it,
     the triplet / GloVe heads emit their gradient rows at those positions (what the row-sharded step feeds the
