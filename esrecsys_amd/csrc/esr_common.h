@@ -19,6 +19,11 @@ int check_launch(const char* what);
 // out[0] = (float)(scale * sum(part[0..n))), one block, fixed reduction order (defined in esr_core.hip).
 void finalize_scalar(const double* part, int n, double scale, float* out, hipStream_t st);
 
+// top-k of dense score rows by radix select (esr_retrieve.hip); ESR_EINVAL when k exceeds what the select kernel holds
+constexpr int kSelectMaxK = 1024;
+int select_topk_dense(const float* scores, int64_t pitch, int64_t rows, int n, int k, float* out_scores,
+                      int32_t* out_indices, hipStream_t st);
+
 inline hipStream_t as_stream(esr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 #define ESR_REQUIRE(cond, ...)        \

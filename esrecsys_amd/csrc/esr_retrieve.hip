@@ -721,6 +721,23 @@ static RetrievePlan retrieve_plan(int64_t nq, int64_t N, int D, int k, int mode)
   return p;
 }
 
+// top-k of dense score rows [rows][pitch] (index = column), descending, ties -> lower index: the radix select with the
+// final bitonic sort of the k survivors.  Used by esr_score_topk (esr_sort.hip) instead of a full sort of every row.
+static_assert(kSelectMaxK == kSelMaxK, "esr_common.h advertises the select kernel's k limit");
+int select_topk_dense(const float* scores, int64_t pitch, int64_t rows, int n, int k, float* out_scores,
+                      int32_t* out_indices, hipStream_t st) {
+  if (k > kSelMaxK) return ESR_EINVAL;
+  SelIn in;
+  in.vals = scores; in.vpitch = pitch; in.idx = nullptr; in.stride = 1; in.ibase = 0; in.istep = 1;
+  in.n_per_row = nullptr; in.n_fixed = n;
+  SelOut so;
+  so.pairs = nullptr; so.ppitch = 0; so.cnt = nullptr; so.tau = nullptr; so.scores = out_scores; so.indices = out_indices;
+  const int lds_words = n > kSelThreads * kSelBatch && n <= kSelLdsWords ? kSelLdsWords : 0;
+  hipLaunchKernelGGL(topk_select_kernel, dim3((int)rows), dim3(kSelThreads), lds_words * sizeof(uint32_t), st, in, k, so,
+                     lds_words);
+  return check_launch("select_topk_dense");
+}
+
 template <int P>
 static void launch_split(const float* X, int64_t n_rows, int D, int64_t rows_pad, int Dp, int64_t plane_elems,
                          __bf16* out, hipStream_t st) {

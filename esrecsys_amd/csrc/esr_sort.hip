@@ -959,6 +959,10 @@ int esr_score_topk(const float* queries, const float* candidates, int64_t nq, in
   size_t temp_bytes = workspace_bytes - (row * nq + 2 * row);
   if (int rc = launch_score_rows(queries, nullptr, (int)nq, candidates, N, D, scores, (int64_t)(row / 4), 1, st))
     return rc;
+  // jax.lax.top_k (pinterest/make_recommendations.py:64) asks for the k best only: a radix select per query row (one
+  // launch for all queries; only the k survivors are sorted) instead of a full device sort of all N scores per query
+  if (k <= kSelectMaxK)
+    return select_topk_dense(scores, (int64_t)(row / 4), nq, (int)N, k, out_scores, out_indices, st);
   for (int64_t q = 0; q < nq; ++q) {
     size_t need = temp_bytes;
     hipError_t e = rocprim::radix_sort_pairs_desc(temp, need, (float*)((char*)scores + row * q), keys_sorted,

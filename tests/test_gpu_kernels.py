@@ -707,7 +707,8 @@ def test_find_top_k_vs_golden_with_ties(dev):
     assert np.array_equal(N(s)[0], g["topk_scores"].astype(np.float32))
 
 
-@pytest.mark.parametrize("nq,N_,D,k", [(1, 100_000, 128, 10), (3, 20_000, 512, 500), (5, 999, 96, 999)])
+@pytest.mark.parametrize("nq,N_,D,k", [(1, 100_000, 128, 10), (3, 20_000, 512, 500), (5, 999, 96, 999),
+                                       (2, 5_000, 64, 1024), (2, 5_000, 64, 1025), (1, 1_000_000, 32, 500)])
 def test_score_topk_random_vs_oracle(dev, nq, N_, D, k):
     from esrecsys_amd import ops
     rng = np.random.default_rng(nq + k)
