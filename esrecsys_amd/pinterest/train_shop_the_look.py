@@ -97,23 +97,25 @@ def fused_triplet_step_available(state):
 
 
 def presort_triplets(state, scene, pos_product, neg_product):
-    """Move the ids of a triplet batch to the device and sort their occurrence list on the side stream."""
+    """Move the ids of a batch to the device and sort their occurrence list on the side stream.  neg_product = None:
+    an in-batch batch, occurrence list [scene ; Vs + pos]."""
     from ..train_state import _side_stream
     p = state.raw_params["params"] if "params" in state.raw_params else state.raw_params
     st, pt = p["scene_tower"]["embedding"], p["product_tower"]["embedding"]
     dev = st.device
     sid = ops.as_ids(scene, dev, check_range=st.shape[0]).reshape(-1)
     pid = ops.as_ids(pos_product, dev, check_range=pt.shape[0]).reshape(-1)
-    nid = ops.as_ids(neg_product, dev, check_range=pt.shape[0]).reshape(-1)
+    nid = ops.as_ids(neg_product, dev, check_range=pt.shape[0]).reshape(-1) if neg_product is not None else None
     main = torch.cuda.current_stream(dev)
     side = _side_stream(dev)
     side.wait_stream(main)
     with torch.cuda.stream(side):
         Vs = st.shape[0]
-        sorted_ids, perm = ops.segment_sort_multi([sid, pid, nid], [0, Vs, Vs], Vs + pt.shape[0])
+        segs, offs = ([sid, pid, nid], [0, Vs, Vs]) if nid is not None else ([sid, pid], [0, Vs])
+        sorted_ids, perm = ops.segment_sort_multi(segs, offs, Vs + pt.shape[0])
         event = torch.cuda.Event()
         event.record(side)
-    for t in (sid, pid, nid):
+    for t in segs:
         t.record_stream(side)
     sorted_ids.record_stream(main)
     perm.record_stream(main)
@@ -167,7 +169,9 @@ def train_step(state, scene, pos_product, neg_product, regularization, batch_siz
     Vs, Vp = st.shape[0], pt.shape[0]
     if neg_product is None:
         fused = FusedScatter([sid, pid], [0, 1], [Vs, Vp], None, paths) if sparse else None
-        if fused is not None and _PRESORT:
+        if fused is not None and presorted is not None:
+            fused.index._sorted = presorted.take()  # sorted one batch ahead on the side stream (presort_triplets)
+        elif fused is not None and _PRESORT:
             fused.index.presort()
         if precision in ("auto", "bf16x3") and st.shape[1] == 128 and B % 128 == 0 and st.dtype == pt.dtype:
             # the bf16x3 path reads the tower rows itself (gather folded into its split and merge kernels)
