@@ -179,6 +179,29 @@ __global__ __launch_bounds__((1 << TB) / 2) void tile_sort_kernel(SortSegs ids, 
   }
 }
 
+// A list that fits ONE tile: the same network, the sorted composites unpacked straight into (sorted ids, perm) -- one
+// launch, ~5 us.  The one-workgroup kernel above (64-bit keys in LDS, a barrier per step) took 39 us for the 4096 ids of a
+// GloVe step at the reference's default batch (wikipedia/train_cooccurence.py:45): more than the rest of that step.
+template <int TB>
+__global__ __launch_bounds__((1 << TB) / 2) void tile_sort_single_kernel(SortSegs ids, int n,
+                                                                        int32_t* __restrict__ sorted_ids,
+                                                                        int32_t* __restrict__ perm) {
+  constexpr int kTile = 1 << TB, kHalf = kTile / 2;
+  __shared__ uint32_t key[2 * kTile];
+  const int t = threadIdx.x;
+  uint32_t k0 = t < n ? ((uint32_t)seg_id(ids, t) << TB) | (uint32_t)t : 0xFFFFFFFFu;
+  uint32_t k1 = t + kHalf < n ? ((uint32_t)seg_id(ids, t + kHalf) << TB) | (uint32_t)(t + kHalf) : 0xFFFFFFFFu;
+  tile_bitonic<TB>(k0, k1, key);
+  if (t < n) {
+    sorted_ids[t] = (int32_t)(k0 >> TB);
+    perm[t] = (int32_t)(k0 & (kTile - 1));
+  }
+  if (t + kHalf < n) {
+    sorted_ids[t + kHalf] = (int32_t)(k1 >> TB);
+    perm[t + kHalf] = (int32_t)(k1 & (kTile - 1));
+  }
+}
+
 // Two-level search: the last id of every 32-key block of every tile ("splitters", <= 4 KB) is staged in LDS and
 // searched there; only the final 32-key window -- one 128-byte line -- is searched in global memory.  A plain
 // binary search over the tiles touched ~12 scattered lines per (element, tile) and was bound by L1 line rate.
@@ -764,11 +787,18 @@ size_t esr_segment_sort_workspace_bytes(int64_t n) {
 
 static int segment_sort_segs(const char* who, const SortSegs& sg, int64_t n, int64_t V, int32_t* sorted_ids,
                              int32_t* perm, void* workspace, size_t workspace_bytes, hipStream_t st) {
-  if (n <= kSmallSortMax) {
+  const bool fits32 = V <= ((int64_t)1 << (32 - kMaxTileBits));  // (id << 11 | position) is a 32-bit composite
+  if (fits32 && n <= (1 << kMaxTileBits)) {  // one tile: one launch
+    if (n <= 512) hipLaunchKernelGGL(tile_sort_single_kernel<9>, dim3(1), dim3(256), 0, st, sg, (int)n, sorted_ids, perm);
+    else if (n <= 1024) hipLaunchKernelGGL(tile_sort_single_kernel<10>, dim3(1), dim3(512), 0, st, sg, (int)n, sorted_ids, perm);
+    else hipLaunchKernelGGL(tile_sort_single_kernel<11>, dim3(1), dim3(1024), 0, st, sg, (int)n, sorted_ids, perm);
+    return check_launch(who);
+  }
+  if (n <= kSmallSortMax && !fits32) {  // short list of wide ids: 64-bit composites in one workgroup's LDS
     hipLaunchKernelGGL(segment_sort_small_kernel, dim3(1), dim3(kSmallSortThreads), 0, st, sg, (int)n, sorted_ids, perm);
     return check_launch(who);
   }
-  if (n <= kMidSortMax && V <= ((int64_t)1 << (32 - kMaxTileBits))) {
+  if (n <= kMidSortMax && fits32) {
     if ((size_t)(kMidSortMax + kMidSortMax / kSplitEvery) * 4 > workspace_bytes || ((uintptr_t)workspace & 15)) {
       set_error("%s: workspace %zu bytes too small (or misaligned)", who, workspace_bytes);
       return ESR_EWORKSPACE;

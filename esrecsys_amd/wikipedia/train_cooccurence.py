@@ -171,28 +171,85 @@ def _ids_count(inputs):
     return int(np.prod(x.shape)) if hasattr(x, "shape") else 2 * len(x[0])
 
 
+class _FusedEpoch:
+    """What the one-pass step needs that does not change from batch to batch, resolved once per epoch: table / accumulator
+    / RowVersions pointers, the library entry point, one loss slot per step and a reusable workspace.  At the reference's
+    default batch (2048 pairs: wikipedia/train_cooccurence.py:45) the step is five short kernels and the per-step Python
+    of ``train_step`` (state lookups, argument checks, two allocations) took longer than they do."""
+
+    def __init__(self, state, steps):
+        from .. import _lib
+        from ..train_state import row_versions
+        p = state.raw_params
+        self.emb, self.bias = p["_token_embedding"]["embedding"], p["_bias"]["embedding"]
+        acc = state.opt_state["sum_of_squares"]
+        self.acc_e, self.acc_b = acc["_token_embedding"]["embedding"], acc["_bias"]["embedding"]
+        self.rv = row_versions(state, ("_token_embedding", "embedding"))
+        model = _model_of(state)
+        self.mode = _MODES[model.loss_mode if model is not None else "reference"]
+        self.lr, self.eps = float(state.tx.lr), float(state.tx.eps)
+        self.V, self.D = self.emb.shape
+        self.dev = self.emb.device
+        self.lib = _lib.load()
+        self.check = _lib.check
+        self.losses = torch.empty(max(steps, 1), dtype=torch.float32, device=self.dev)
+        self.ws, self.ws_B = None, -1
+        self.fixed = (self.emb.data_ptr(), self.rv.shadow.data_ptr(), self.rv.loc.data_ptr(), self.acc_e.data_ptr(),
+                      self.bias.data_ptr(), self.acc_b.data_ptr(), self.V, self.D)
+
+    def step(self, k, inputs, target):
+        presorted = None
+        if isinstance(inputs, PresortedInputs):
+            presorted, inputs = inputs.take(), inputs.inputs
+        if not (type(inputs) is torch.Tensor and inputs.is_cuda and inputs.dtype == torch.int32 and
+                inputs.is_contiguous()):
+            inputs = ops.as_ids(inputs, self.dev, check_range=self.V)
+        elif os.environ.get("ESR_CHECK_IDS") == "1":
+            ops.check_device_ids(inputs, self.V)
+        if not (type(target) is torch.Tensor and target.is_cuda and target.dtype == torch.float32 and
+                target.is_contiguous()):
+            target = ops.as_f32(target, self.dev)
+        B = inputs.shape[1]
+        if inputs.shape[0] != 2 or target.numel() != B:
+            raise ValueError("inputs must be [2, B] and target [B]")
+        if B != self.ws_B:
+            self.ws = ops._ws(ops._ws_bytes("esr_glove_step_workspace_bytes", B, self.D), self.dev)
+            self.ws_B = B
+        sid, perm = (presorted[0].data_ptr(), presorted[1].data_ptr()) if presorted is not None else (0, 0)
+        self.rv.dirty = True
+        self.check(self.lib.esr_glove_train_step(*self.fixed, inputs.data_ptr(), target.data_ptr(), B, self.mode,
+                                                 self.lr, self.eps, sid, perm, 0, self.losses.data_ptr() + 4 * k,
+                                                 self.ws.data_ptr(), self.ws.numel(), ops._stream()),
+                   "esr_glove_train_step")
+
+
 def train_epoch(state, steps_per_epoch, train_it):
     """Trains for an epoch (wikipedia/train_cooccurence.py:103-112).  Losses stay on the device until the
     epoch mean is taken, so the loop never synchronises.  With the build's sparse Adagrad every step is the
-    one-pass ``train_step``; with the reference's dense Adam it is apply_model + update_model as there."""
-    epoch_loss = []
-    fused = fused_step_available(state)
-    # batches are fetched one ahead so that batch k + 1's ids can be sorted (side stream) under batch k's update kernel;
-    # worth it only when the list is long enough for the sort to be a chain of launches (> 4096 ids: B > 2048)
-    ahead = None
-    for k in range(steps_per_epoch):
-        inputs, targets = ahead if ahead is not None else next(train_it)
+    one-pass step (``train_step``'s kernels, driven through a per-epoch context that keeps the per-step Python to one
+    library call); with the reference's dense Adam it is apply_model + update_model as there."""
+    if fused_step_available(state) and steps_per_epoch > 0:
+        ctx = _FusedEpoch(state, steps_per_epoch)
+        # batches are fetched one ahead so that batch k + 1's ids can be sorted (side stream) under batch k's update
+        # kernel; worth it only when the list is long enough for the sort to be a chain of launches (> 4096 ids)
         ahead = None
-        if fused:
-            if _PRESORT and k == 0 and _ids_count(inputs) > _PRESORT_MIN_IDS:
-                inputs = presort_inputs(state, inputs)
-            if _PRESORT and k + 1 < steps_per_epoch and _ids_count(inputs) > _PRESORT_MIN_IDS:
-                nxt_inputs, nxt_targets = next(train_it)
-                ahead = (presort_inputs(state, nxt_inputs), nxt_targets)
-            state, loss = train_step(state, inputs, targets)
-        else:
-            grads, loss = apply_model(state, inputs, targets)
-            state = update_model(state, grads)
+        for k in range(steps_per_epoch):
+            inputs, targets = ahead if ahead is not None else next(train_it)
+            ahead = None
+            if _PRESORT and _ids_count(inputs) > _PRESORT_MIN_IDS:
+                if k == 0:
+                    inputs = presort_inputs(state, inputs)
+                if k + 1 < steps_per_epoch:
+                    nxt_inputs, nxt_targets = next(train_it)
+                    ahead = (presort_inputs(state, nxt_inputs), nxt_targets)
+            ctx.step(k, inputs, targets)
+        state = state.replace(step=state.step + steps_per_epoch)
+        return state, float(ctx.losses[:steps_per_epoch].mean())
+    epoch_loss = []
+    for _ in range(steps_per_epoch):
+        inputs, targets = next(train_it)
+        grads, loss = apply_model(state, inputs, targets)
+        state = update_model(state, grads)
         epoch_loss.append(loss)
     train_loss = float(torch.stack(epoch_loss).mean()) if epoch_loss else float("nan")
     return state, train_loss

@@ -438,7 +438,8 @@ def _ids(kind, rng, V, n):
     return rng.permutation(V)[rng.choice(V, size=n, p=p / p.sum())].astype(np.int32)
 
 
-@pytest.mark.parametrize("n", [40_000, 32_768, 24_576, 16_384 + 13, 4097, 4096, 4095, 1000, 74, 1])  # three sort paths
+@pytest.mark.parametrize("n", [40_000, 32_768, 24_576, 16_384 + 13, 8193, 8192, 4097, 4096, 4095, 2049, 2048, 2047, 1025,
+                               1024, 1000, 513, 512, 511, 74, 2, 1])  # single tile (3 sizes) / tiles + rank / radix
 @pytest.mark.parametrize("kind", ["uniform", "same", "zipf"])
 def test_segment_sort_is_stable_sort(dev, kind, n):
     from esrecsys_amd import ops
@@ -480,6 +481,19 @@ def test_segment_sort_multi_segments_on_the_radix_path(dev):
     sid, perm = ops.segment_sort_multi([T(s, dev) for s in segs], offsets, sum(tables))
     order = np.argsort(virt, kind="stable")
     assert np.array_equal(N(perm), order.astype(np.int32)) and np.array_equal(N(sid).astype(np.int64), virt[order])
+
+
+@pytest.mark.parametrize("n", [1, 48, 600, 4096])
+def test_segment_sort_short_lists_of_wide_ids(dev, n):
+    """ids that do not fit the 32-bit tile composites, short list: the one-workgroup 64-bit bitonic kernel"""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(n)
+    V = 50_000_000
+    ids = rng.integers(0, V, n).astype(np.int32)
+    ids[::5] = V - 1
+    sid, perm = ops.segment_sort(T(ids, dev), V)
+    order = np.argsort(ids, kind="stable")
+    assert np.array_equal(N(perm), order.astype(np.int32)) and np.array_equal(N(sid), ids[order])
 
 
 def test_segment_sort_wide_ids_take_the_radix_path(dev):
