@@ -143,7 +143,8 @@ def saturating_gather_scatter(dev, V, D, n=131072, reps=20):
             "sparse_adagrad_GBps": sb / ts / 1e9, "sparse_adagrad_frac_of_8TBps": sb / ts / 1e9 / HBM_PEAK_GBS}
 
 
-def roofline_for(workload, kernels, B, D, rows, precision, occ_n=0, uniq=0, bf16_tables=False, rowmax_gemm=False):
+def roofline_for(workload, kernels, B, D, rows, precision, occ_n=0, uniq=0, bf16_tables=False, rowmax_gemm=False,
+                 step_s=None):
     """The `roofline` object for the dominant kernel of one rank's step.  `kernels` = HIP-event ms per step per
     kernel group; occ_n / uniq = row occurrences and distinct rows the sparse Adagrad launch of the last batch saw.
     bf16_tables: both towers bf16 (one-plane kernels); rowmax_gemm: the score range needs the row-max pre-pass."""
@@ -173,7 +174,9 @@ def roofline_for(workload, kernels, B, D, rows, precision, occ_n=0, uniq=0, bf16
         # one-pass step (sort + plan + update + long + finalize in ONE ops call): the whole step against SURVEY 8d's
         # algorithmic bytes; the bytes its update kernel actually needs are the partner row per occurrence + per
         # distinct row the own row read, the rewrite and the accumulator RMW
-        t = kernels["glove_step"]["ms_per_step"] * 1e-3
+        # time = the timed region's step (the one-pass op IS the step; its HIP-event time in the second pass, taken
+        # with a spin kernel ahead of every step, is reported next to it)
+        t = step_s if step_s else kernels["glove_step"]["ms_per_step"] * 1e-3
         alg = STEP_BYTES_PER_UNIT["glove"](D) * B
         moved = (occ_n + 4 * uniq) * D * 4
         return {"kernel": "esr_glove_train_step (sort + glove_plan + glove_step + glove_step_long + finalize)",
@@ -184,7 +187,7 @@ def roofline_for(workload, kernels, B, D, rows, precision, occ_n=0, uniq=0, bf16
         # one-pass step (plan + update + long in ONE ops call; the sort is in it too unless it ran ahead on the side
         # stream): against SURVEY 8d's algorithmic bytes; the update kernel itself needs per occurrence its two partner
         # rows and per distinct row the own-row read, the rewrite and the accumulator RMW
-        t = kernels["triplet_step"]["ms_per_step"] * 1e-3
+        t = step_s if step_s else kernels["triplet_step"]["ms_per_step"] * 1e-3
         alg = STEP_BYTES_PER_UNIT["triplet"](D) * B
         moved = (2 * occ_n + 4 * uniq) * D * 4
         return {"kernel": "esr_triplet_train_step (triplet_plan + triplet_step + triplet_step_long)",
@@ -578,7 +581,7 @@ def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True
                             [last[0], last[1] + V, last[2] + V])  # the two towers are different tables
             occ_n, uniq = occ.numel(), int(torch.unique(occ).numel())
         roofline = roofline_for(workload, kernels, B, D, rows, PRECISION, occ_n, uniq,
-                                bf16_tables=cfg.get("table_dtype") == "bf16", rowmax_gemm=needs_rowmax)
+                                bf16_tables=cfg.get("table_dtype") == "bf16", rowmax_gemm=needs_rowmax, step_s=dt / K)
         if roofline.get("bound") == "mfma" and roofline.get("peak") == MFMA_BF16_PEAK_TFLOPS:
             live = sustained_bf16_mfma_tflops(dev)  # after the timed region
             roofline["sustained_live_data_TFLOPs"] = live

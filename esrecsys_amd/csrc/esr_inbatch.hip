@@ -38,14 +38,17 @@ __device__ __forceinline__ constexpr int mfma_row(int r, int h) { return (r & 3)
 
 // DP = the tile width (32, 64 or 128); D = the real embedding width, a multiple of 4 with D <= DP: columns D .. DP - 1
 // are zero padding that never touches memory (D = 96, pinterest/sweep.yaml:13-14, runs as DP = 128).
-template <int DP, bool QSIDE>
+// PAD = false is the D == DP instantiation: no column test survives in its loads (with the test in place the D = 128
+// kernel went from 280 us to 400 us per pass).
+template <int DP, bool QSIDE, bool PAD>
 __global__ __launch_bounds__(kIbWaves * 64, 2) void inbatch_kernel(
-    const float* __restrict__ X, const float* __restrict__ Y, int64_t B, int64_t nv, int D, float scale, float lam,
+    const float* __restrict__ X, const float* __restrict__ Y, int64_t B, int64_t nv, int D_, float scale, float lam,
     float inv_bs, float* __restrict__ lse2, float* __restrict__ lse_nat, float* __restrict__ gX,
     double* __restrict__ loss_part) {
   // B = rows rounded up to a multiple of 32 (tiling); nv = rows that exist.  Rows >= nv are padding: their loads are
   // clamped to the last real row, as streamed rows they are masked out of every softmax (score -inf in pass Q,
   // lse = +inf in pass C), as owned rows they produce no output.
+  const int D = PAD ? D_ : DP;     // a compile-time constant without padding
   constexpr int KK = DP / 8;       // S-phase k-groups (4 MFMAs each)
   constexpr int DB = DP / 32;      // output d-blocks
   constexpr int STRIDE = DP + 4;   // LDS row stride in floats (+16 B)
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(kIbWaves * 64, 2) void inbatch_kernel(
     const float* xp = X + min(x0 + j, nv - 1) * D + 4 * h;
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
-      const float4 v = (8 * kk + 4 * h < D) ? *reinterpret_cast<const float4*>(xp + 8 * kk) : zero4;
+      const float4 v = (!PAD || 8 * kk + 4 * h < D) ? *reinterpret_cast<const float4*>(xp + 8 * kk) : zero4;
       xr[kk][0] = v.x; xr[kk][1] = v.y; xr[kk][2] = v.z; xr[kk][3] = v.w;
     }
   }
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(kIbWaves * 64, 2) void inbatch_kernel(
       for (int q = 0; q < NLD; ++q) {
         const int idx = q * 64 + lane;
         const int row = idx / (DP / 4), c4 = idx % (DP / 4);
-        st[q] = (4 * c4 < D) ? *reinterpret_cast<const float4*>(Y + min(y0 + row, nv - 1) * D + 4 * c4) : zero4;
+        st[q] = (!PAD || 4 * c4 < D) ? *reinterpret_cast<const float4*>(Y + min(y0 + row, nv - 1) * D + 4 * c4) : zero4;
       }
 #pragma unroll
       for (int q = 0; q < NLD; ++q) {
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(kIbWaves * 64, 2) void inbatch_kernel(
     const float* yp = Y + min(x0 + j, nv - 1) * D + 4 * h;
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
-      const float4 v = (8 * kk + 4 * h < D) ? *reinterpret_cast<const float4*>(yp + 8 * kk) : zero4;
+      const float4 v = (!PAD || 8 * kk + 4 * h < D) ? *reinterpret_cast<const float4*>(yp + 8 * kk) : zero4;
       diag = fmaf(xr[kk][0], v.x, diag);
       diag = fmaf(xr[kk][1], v.y, diag);
       diag = fmaf(xr[kk][2], v.z, diag);
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(kIbWaves * 64, 2) void inbatch_kernel(
   for (int it = tid; it < 16 * 64; it += kIbWaves * 64) {
     const int r = it >> 6, ln = it & 63;
     const int row = ln & 31, d0 = DB * mfma_row(r, ln >> 5);
-    if (x0 + row >= nv || d0 >= D) continue;  // padding row / padding columns: no gradient exists
+    if (x0 + row >= nv || (PAD && d0 >= D)) continue;  // padding row / padding columns: no gradient exists
     float v[DB];
 #pragma unroll
     for (int db = 0; db < DB; ++db) {
@@ -488,10 +491,17 @@ static void inbatch_launch(const float* Q, const float* C, int64_t B, int64_t nv
                            float inv_bs, float* lse_nat, float* gQ, float* gC, const InbatchWs& ws, hipStream_t st) {
   const int nblk = (int)(B / kIbRows);
   if constexpr (DP <= 128) {
-    hipLaunchKernelGGL((inbatch_kernel<DP, true>), dim3(nblk), dim3(kIbWaves * 64), 0, st, Q, C, B, nv, D, scale, lam,
-                       inv_bs, ws.lse2, lse_nat, gQ, ws.loss_part);
-    hipLaunchKernelGGL((inbatch_kernel<DP, false>), dim3(nblk), dim3(kIbWaves * 64), 0, st, C, Q, B, nv, D, scale, lam,
-                       inv_bs, ws.lse2, (float*)nullptr, gC, ws.loss_part + nblk);
+    if (D == DP) {
+      hipLaunchKernelGGL((inbatch_kernel<DP, true, false>), dim3(nblk), dim3(kIbWaves * 64), 0, st, Q, C, B, nv, D, scale,
+                         lam, inv_bs, ws.lse2, lse_nat, gQ, ws.loss_part);
+      hipLaunchKernelGGL((inbatch_kernel<DP, false, false>), dim3(nblk), dim3(kIbWaves * 64), 0, st, C, Q, B, nv, D, scale,
+                         lam, inv_bs, ws.lse2, (float*)nullptr, gC, ws.loss_part + nblk);
+    } else {
+      hipLaunchKernelGGL((inbatch_kernel<DP, true, true>), dim3(nblk), dim3(kIbWaves * 64), 0, st, Q, C, B, nv, D, scale,
+                         lam, inv_bs, ws.lse2, lse_nat, gQ, ws.loss_part);
+      hipLaunchKernelGGL((inbatch_kernel<DP, false, true>), dim3(nblk), dim3(kIbWaves * 64), 0, st, C, Q, B, nv, D, scale,
+                         lam, inv_bs, ws.lse2, (float*)nullptr, gC, ws.loss_part + nblk);
+    }
   } else {
     hipLaunchKernelGGL((inbatch_wide_kernel<DP, true>), dim3(nblk), dim3(kIbWaves * 64), 0, st, Q, C, B, nv, D, scale,
                        lam, inv_bs, ws.lse2, lse_nat, gQ, ws.loss_part);

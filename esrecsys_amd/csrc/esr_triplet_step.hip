@@ -20,6 +20,11 @@
 namespace esr {
 
 constexpr int kTripStepBlocks = kMaxGrid;
+// Cut points of long runs: every 8 positions instead of the 32 of the other segment kernels.  An occurrence costs this
+// kernel two dependent round trips (plan record -> two partner rows), so a hot row is a LONG sequential walk per chunk:
+// with 32-position chunks a Zipf(1) batch of 8192 triplets took 131 us (99 us before this kernel existed); shorter
+// chunks spread the walk over four times as many row groups.
+constexpr int kTripChunk = 8;
 
 struct TwoTowers {
   float* s0;  // scene tower, primary buffer            virtual rows [0, Vs)
@@ -65,7 +70,7 @@ static size_t trip_ws_layout(int64_t B, int D, char* base, TripWs* ws) {
   w.own_code = (uint32_t*)take(sizeof(uint32_t) * (size_t)n);
   w.meta = (uint4*)take(sizeof(uint4) * (size_t)n);
   w.loss_part = (double*)take(sizeof(double) * kTripStepBlocks);
-  w.chunk_rows = (float*)take(sizeof(float) * 2 * (size_t)cdiv(n, kStepChunk) * (size_t)D);
+  w.chunk_rows = (float*)take(sizeof(float) * 2 * (size_t)cdiv(n, kTripChunk) * (size_t)D);
   w.sort_ws_bytes = esr_segment_sort_workspace_bytes(n);
   w.sort_ws = take(w.sort_ws_bytes);
   if (ws) *ws = w;
@@ -158,8 +163,8 @@ __global__ __launch_bounds__(kBlock) void triplet_step_kernel(TwoTowers tt, int 
     prev_n = code;
     const uint32_t id = code & kIdMask;
     const bool head = (prev & kIdMask) != id;
-    if (!head && ((p & (kStepChunk - 1)) != 0 || (own_code[p - kStepChunk] & kIdMask) != id)) continue;
-    const int64_t stop = min(head ? ((p + 2 * kStepChunk - 1) / kStepChunk) * kStepChunk : p + kStepChunk, n);
+    if (!head && ((p & (kTripChunk - 1)) != 0 || (own_code[p - kTripChunk] & kIdMask) != id)) continue;
+    const int64_t stop = min(head ? ((p + 2 * kTripChunk - 1) / kTripChunk) * kTripChunk : p + kTripChunk, n);
     RowRegs<VEC, NCH> own, a, g, fA, fB;
     if (have_next) {
       own = nown;
@@ -233,18 +238,22 @@ __global__ __launch_bounds__(kBlock) void triplet_step_kernel(TwoTowers tt, int 
       occ(ma, a0, b0);
       occ(mb, a1, b1);
     }
-    for (; q < e_run; ++q) {
-      const uint4 m = meta[q];
-      RowRegs<VEC, NCH> a0, b0;
-      row_load(a0, tower_row(tt, m.y, D), lig, G, nvec);
-      row_load(b0, tower_row(tt, m.z, D), lig, G, nvec);
-      occ(m, a0, b0);
+    if (q < e_run) {  // the plan record of the next occurrence travels while this one's rows do
+      uint4 mq = meta[q];
+      for (; q < e_run; ++q) {
+        const uint4 m = mq;
+        if (q + 1 < e_run) mq = meta[q + 1];
+        RowRegs<VEC, NCH> a0, b0;
+        row_load(a0, tower_row(tt, m.y, D), lig, G, nvec);
+        row_load(b0, tower_row(tt, m.z, D), lig, G, nvec);
+        occ(m, a0, b0);
+      }
     }
     const bool ends = q == n || (own_code[q] & kIdMask) != id;
     if (head && ends) {
       step_apply2<VEC, NCH>(tt, code, own, a, g, D, lig, G, nvec, lr, eps);
     } else {
-      const int64_t slot = 2 * (p / kStepChunk) + (head ? 1 : 0);
+      const int64_t slot = 2 * (p / kTripChunk) + (head ? 1 : 0);
       row_store(g, chunk_rows + slot * D, lig, G, nvec);
     }
   }
@@ -273,17 +282,17 @@ __global__ __launch_bounds__(kBlock) void triplet_step_long_kernel(TwoTowers tt,
   const int tid = threadIdx.x, lig = tid & (G - 1), gidx = tid / G, NG = kBlock / G;
   const int nvec = D / VEC;
   auto id_at = [&](int64_t pos) { return own_code[pos] & kIdMask; };
-  const int64_t nbound = (n - 1) / kStepChunk;
+  const int64_t nbound = (n - 1) / kTripChunk;
   for (int64_t b0 = (int64_t)blockIdx.x * kPass; b0 < nbound; b0 += (int64_t)gridDim.x * kPass) {
     __syncthreads();
     if (tid == 0) s_nlong = 0;
     __syncthreads();
     {
-      const int64_t Bd = (b0 + tid + 1) * kStepChunk;
+      const int64_t Bd = (b0 + tid + 1) * kTripChunk;
       if (tid < kPass && b0 + tid < nbound) {
         const uint32_t id_b = id_at(Bd);
-        const bool first = Bd < 2 * kStepChunk || id_at(Bd - 2 * kStepChunk) != id_b;
-        if (id_at(Bd - kStepChunk) == id_b && first) s_long[atomicAdd(&s_nlong, 1)] = Bd;
+        const bool first = Bd < 2 * kTripChunk || id_at(Bd - 2 * kTripChunk) != id_b;
+        if (id_at(Bd - kTripChunk) == id_b && first) s_long[atomicAdd(&s_nlong, 1)] = Bd;
       }
     }
     __syncthreads();
@@ -291,10 +300,10 @@ __global__ __launch_bounds__(kBlock) void triplet_step_long_kernel(TwoTowers tt,
     for (int li = 0; li < nlong; ++li) {
       const int64_t nxt = s_long[li];
       const uint32_t id = id_at(nxt);
-      const int64_t win = max<int64_t>(nxt - 2 * kStepChunk + 1, 0);
+      const int64_t win = max<int64_t>(nxt - 2 * kTripChunk + 1, 0);
       if (tid < 64) {
         const int64_t pos = win + tid;
-        const bool is_head = pos <= nxt - kStepChunk && id_at(pos) == id && (pos == 0 || id_at(pos - 1) != id);
+        const bool is_head = pos <= nxt - kTripChunk && id_at(pos) == id && (pos == 0 || id_at(pos - 1) != id);
         const unsigned long long m = __ballot(is_head);
         if (tid == 0) s_hoff = __ffsll((long long)m) - 1;
       }
@@ -302,13 +311,13 @@ __global__ __launch_bounds__(kBlock) void triplet_step_long_kernel(TwoTowers tt,
       const int64_t h = win + s_hoff;
       int64_t K = 0;
       for (int64_t k0 = 0;; k0 += kBlock) {
-        const int64_t pos = nxt + (k0 + tid) * kStepChunk;
+        const int64_t pos = nxt + (k0 + tid) * kTripChunk;
         const int cnt = __syncthreads_count(pos < n && id_at(pos) == id);
         K += cnt;
         if (cnt < kBlock) break;
       }
       auto part_row = [&](int64_t i) {
-        return (i == 0 ? 2 * (h / kStepChunk) + 1 : 2 * ((nxt + (i - 1) * kStepChunk) / kStepChunk)) * (int64_t)D;
+        return (i == 0 ? 2 * (h / kTripChunk) + 1 : 2 * ((nxt + (i - 1) * kTripChunk) / kTripChunk)) * (int64_t)D;
       };
       RowRegs<VEC, NCH> acc;
       row_zero(acc);
@@ -412,7 +421,7 @@ int esr_triplet_train_step(float* scene, float* scene_shadow, uint8_t* scene_loc
   hipLaunchKernelGGL(triplet_plan_kernel, dim3(nplan), dim3(kBlock), 0, st, perm, scene_ids, pos_ids, neg_ids,
                      (const uint8_t*)scene_loc, (const uint8_t*)product_loc, B, Vs, ws.own_code, ws.meta);
   int grid = grid_for_groups(n, g.G);
-  const int grid2 = (int)std::min<int64_t>(kMaxGrid, cdiv(cdiv(n, kStepChunk), 4));
+  const int grid2 = (int)std::min<int64_t>(kMaxGrid, cdiv(cdiv(n, kTripChunk), 4));
   const float inv_bs = 1.0f / batch_size;
   ESR_DISPATCH_ROW(g, {
     grid = std::min(grid, resident_blocks((const void*)triplet_step_kernel<VEC, NCH>));
