@@ -30,6 +30,7 @@
 //   merge kernel    : sums the nsplit partial (l, O), applies the -y_i diagonal, the regulariser gradient
 //                     and the 1/batch_size, and reduces the loss.
 #include "esr_common.h"
+#include <stdlib.h>
 
 namespace esr {
 
@@ -360,12 +361,20 @@ __device__ unsigned long long esr_ib3_dbg[8192];
       if (VALU_ON) {                                                                                      \
         pw[0][s_] = pa_; pw[1][s_] = pq_;                                                                 \
         pw[2][s_] = pk_bf16(q0_ - pk_lo(pq_), q1_ - pk_hi(pq_));                                          \
+        /* PMODE 1: the probabilities leave for pass C as they are formed, TRANSPOSED (Pt[streamed][owned]): one  \
+           dword store per value straight from its register -- lanes are consecutive owned rows, so every store  \
+           instruction writes two whole 128-byte lines; no staging registers, no data movement */              \
+        if (PMODE == 1) {                                                                                 \
+          pst_[(int64_t)(((2 * s_) & 3) + 8 * ((2 * s_) >> 2)) * B] = e0_;                                \
+          pst_[(int64_t)(((2 * s_ + 1) & 3) + 8 * ((2 * s_ + 1) >> 2)) * B] = e1_;                        \
+        }                                                                                                 \
       }                                                                                                   \
       ESR_SB();                                                                                           \
       SA = ESR_MFMA_BF16(a1_, bx[0][s_], SA);                                                             \
       ESR_SB();                                                                                           \
       a1_ = n1_; a2_ = n2_; a3_ = n3_;                                                                    \
     }                                                                                                     \
+    if (PMODE == 1 && (VALU_ON)) pst_ += 32 * B;                                                          \
   }
 
 // Main kernel.  No online-softmax rescaling: the exponent reference is FIXED per owned row (pass Q: an
@@ -379,11 +388,13 @@ __device__ unsigned long long esr_ib3_dbg[8192];
 // only the live ones -- Y1 X1 for S^T; Y1 P1, Y1 P2, Y1 P3 for O^T, in the order the full sequence has them, so
 // the results are bit-identical to it -- and streams / stages / fetches plane 1 only: a third of the MFMA work
 // (the S^T phase is then bound by the exp / split VALU work, no longer by the matrix pipe).
-template <bool QSIDE, bool ONEP = false>
+// PMODE 1 (pass Q only): the unnormalised probabilities p_ij = exp2(s_ij sl2 - ref_i) are also written to
+// Pmat[i][j] (B x B f32) as they are formed, so that pass C need not recompute S^T (inbatch3_pc_kernel below).
+template <bool QSIDE, bool ONEP = false, int PMODE = 0>
 __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict__ Xr, const __bf16* __restrict__ Yr,
                                                       const __bf16* __restrict__ Yt, int64_t B, int nsplit, float sl2,
                                                       const float* __restrict__ ref, float* __restrict__ part_O,
-                                                      float* __restrict__ part_l) {
+                                                      float* __restrict__ part_l, float* __restrict__ Pmat) {
   __shared__ __attribute__((aligned(16))) char lds[k3Bufs * kBufBytes];
 #ifdef ESR_IB3_TIMING
   const unsigned long long rentry = __builtin_amdgcn_s_memrealtime();
@@ -412,6 +423,9 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
 
   bf16x8 bx[3][8];  // owned rows -> B operand (loaded below, behind the first tiles' DMA)
   float refv = 0.f;
+  // PMODE 1: where this lane's probabilities of the chunk whose exp is being formed go (advances 32 columns per chunk)
+  // Pt[streamed row][owned row]: this lane's column, at the first streamed row of its half (advances 32 rows per chunk)
+  float* pst_ = PMODE == 1 ? Pmat + (c0 * 32 + 4 * h) * B + xrow : nullptr;
 
   f32x16 acc[4];
 #pragma unroll
@@ -634,6 +648,10 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
       const uint32_t pq = pk_bf16(q0, q1);
       pw[0][s] = pa; pw[1][s] = pq;
       pw[2][s] = pk_bf16(q0 - pk_lo(pq), q1 - pk_hi(pq));
+      if (PMODE == 1) {
+        pst_[(int64_t)(((2 * s) & 3) + 8 * ((2 * s) >> 2)) * B] = e0;
+        pst_[(int64_t)(((2 * s + 1) & 3) + 8 * ((2 * s + 1) >> 2)) * B] = e1;
+      }
     }
     ESR_O_PHASE(buf, false, lds);
   }
@@ -663,6 +681,202 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (lane == 0 && blockIdx.x < 256) esr_ib3_dbg[4096 + ((blockIdx.x * 4 + dbg_w) * 4) + 3] = __builtin_amdgcn_s_memrealtime();
 #endif
+}
+
+// Pass C without the S^T recomputation (the "stored P" path, B <= kPStoreMaxB).  Pass Q (PMODE 1) left the
+// unnormalised probabilities p_ij = exp2(s_ij sl2 - ref_i) TRANSPOSED in Pmat[j][i] and merge<Q> their normalisers
+// 1 / l_i, so pass C -- owned rows = C rows j, streamed rows = Q rows i -- reads its 32 x 128 tile straight into the S^T
+// accumulator layout (lane = owned row j, registers 4g .. 4g + 3 = streamed rows 8g + 4h + 0..3: four 16-byte loads per
+// lane and chunk), scales by 1 / l_i, splits into the three bf16 planes and runs the O^T phase alone.  A quarter of the whole
+// op's MFMA work disappears (6 of 24 cross-term GEMMs) for 2 x B^2 x 4 bytes of extra HBM traffic that rides under
+// MFMA-bound kernels (268 MB each way at B = 8192).  The loads of chunk it + 1 are issued right after the barrier of
+// chunk it and consumed after the next barrier, whose vmcnt(0) they share with the tile DMAs -- no extra drain.
+// `ref` = the normalisers 1 / l_i (they ride into LDS like the lse block of the recompute path).
+template <bool ONEP>
+__global__ __launch_bounds__(256) void inbatch3_pc_kernel(const __bf16* __restrict__ Yr, const __bf16* __restrict__ Yt,
+                                                         int64_t B, int nsplit, const float* __restrict__ ref,
+                                                         const float* __restrict__ Pmat, float* __restrict__ part_O) {
+  constexpr bool QSIDE = false;
+  constexpr int PMODE = 2;
+  (void)PMODE;
+  __shared__ __attribute__((aligned(16))) char lds[k3Bufs * kBufBytes];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int tr_a = (lane & 15) >> 2;
+  const int tr_e = (2 * ((lane >> 4) & 1)) + ((lane & 3) >> 1), tr_low = (lane & 1) * 8;
+  const int tr_row0 = (4 * h + tr_a) * 256, tr_row1 = (4 * h + 8 + tr_a) * 256;
+  const int tr_l0 = ((tr_e ^ (h & 3)) << 4) | tr_low, tr_l1 = ((tr_e ^ ((h + 2) & 3)) << 4) | tr_low;
+  uint32_t trb_[4][2], trc_[4][2];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    trb_[db][0] = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds + tr_row0 + (((db ^ tr_a) << 6) | tr_l0);
+    trb_[db][1] = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds + tr_row1 + (((db ^ tr_a) << 6) | tr_l1);
+  }
+  const int ob = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
+  const int64_t xrow = (int64_t)ob * k3Owned + w * 32 + j;
+  const int nc = (int)(B / k3Chunk) / nsplit;
+  const int64_t c0 = (int64_t)split * nc;
+  const int64_t nch = B / 32;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[db][r] = 0.f;
+
+  int dpos = 0;
+  ESR_DMA_INIT(c0 + dpos);
+  ESR_DMA_ALL(lds);
+  if (nc > 1) ESR_DMA_ALL(lds + kBufBytes);
+  // Pt[j][i] (pass Q wrote it transposed): this lane's owned row j = xrow, streamed rows i = chunk row0 + 8g + 4h + 0..3
+  const float* pcol = Pmat + xrow * B + 4 * h;  // per-lane part of the address
+  float pn[16], p[16], rf[16];
+  const float refv = 0.f;  // (named by ESR_LOAD_REFS's pass-Q branch, which is compiled out here)
+  uint32_t pw[3][8];
+  bf16x8 ta2_[2][4][3];
+#define ESR_P_LOAD(CH)                                                                                    \
+  {                                                                                                       \
+    const float* base_ = pcol + (c0 + (CH)) * 32;                                                         \
+    _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                    \
+      const float4 v_ = *reinterpret_cast<const float4*>(base_ + 8 * g_);                                 \
+      pn[4 * g_] = v_.x; pn[4 * g_ + 1] = v_.y; pn[4 * g_ + 2] = v_.z; pn[4 * g_ + 3] = v_.w;             \
+    }                                                                                                     \
+  }
+// scale by 1 / l_i and split into the three bf16 planes (what the S^T phase threads between its MFMAs on the
+// recompute path; here it runs ahead of the O^T phase)
+#define ESR_P_SPLIT()                                                                                     \
+  _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) {                                                      \
+    const float e0_ = p[2 * s_] * rf[2 * s_], e1_ = p[2 * s_ + 1] * rf[2 * s_ + 1];                       \
+    const uint32_t pa_ = pk_bf16(e0_, e1_);                                                               \
+    const float q0_ = e0_ - pk_lo(pa_), q1_ = e1_ - pk_hi(pa_);                                           \
+    const uint32_t pq_ = pk_bf16(q0_, q1_);                                                               \
+    pw[0][s_] = pa_; pw[1][s_] = pq_;                                                                     \
+    pw[2][s_] = pk_bf16(q0_ - pk_lo(pq_), q1_ - pk_hi(pq_));                                              \
+  }
+  // ---- software pipeline -------------------------------------------------------------------------------------------
+  // At the top of iteration `it` (after its barrier): pw = the three planes of chunk it's probabilities, ta2_[0] = its
+  // G = 0 fragments (requested during the previous iteration), pn = the raw P^T tile of chunk it + 1 (landed), ring
+  // slot of chunk it + 1 landed, slot of chunk it + 2 free.  The iteration issues the loads of chunk it + 2's P^T tile,
+  // reads chunk it + 1's 1 / l block, and threads through the O^T MFMAs of chunk it: the G = 1 fragments of chunk it,
+  // the tile DMA of chunk it + 2, the scale + split of chunk it + 1 (one register pair per MFMA row) and, once the
+  // G = 0 rows are done with them, the G = 0 fragments of chunk it + 1.  Nothing but the barrier and ~30 instructions
+  // of set-up is left outside the matrix pipe's shadow (the unpipelined form spent 0.7 us of 1.9 us per chunk there).
+  uint32_t trn_[4][2];
+  uint32_t pwn[3][8];
+  float p1[16];
+#define ESR_PC_SPLIT1(S)                                                                                  \
+  {                                                                                                       \
+    const float e0_ = p1[2 * (S)] * rf[2 * (S)], e1_ = p1[2 * (S) + 1] * rf[2 * (S) + 1];                 \
+    const uint32_t pa_ = pk_bf16(e0_, e1_);                                                               \
+    const float q0_ = e0_ - pk_lo(pa_), q1_ = e1_ - pk_hi(pa_);                                           \
+    const uint32_t pq_ = pk_bf16(q0_, q1_);                                                               \
+    pwn[0][S] = pa_; pwn[1][S] = pq_;                                                                     \
+    pwn[2][S] = pk_bf16(q0_ - pk_lo(pq_), q1_ - pk_hi(pq_));                                              \
+  }
+#define ESR_PC_NEXT_G0(F0, F1)                                                                            \
+  { _Pragma("unroll") for (int f_ = (F0); f_ < (F1); ++f_) tr_frag_n<0>(f_, ta2_, trn_); }
+#define ESR_PC_ITER(BUF, NBUF, DBUF, DMA_ON, NEXT_ON)                                                     \
+  {                                                                                                       \
+    bf16x8 pb[3][2];                                                                                      \
+    _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_)                                                      \
+      _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_) {                                                  \
+        const u32x4 u_ = {pw[q_][4 * g_], pw[q_][4 * g_ + 1], pw[q_][4 * g_ + 2], pw[q_][4 * g_ + 3]};    \
+        pb[q_][g_] = __builtin_bit_cast(bf16x8, u_);                                                      \
+      }                                                                                                   \
+    if (NEXT_ON) {                                                                                        \
+      _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) p1[r_] = pn[r_];                                  \
+      ESR_LOAD_REFS(NBUF);                                                                                \
+      const uint32_t slot_ = (uint32_t)((NBUF) - lds);                                                    \
+      _Pragma("unroll") for (int db_ = 0; db_ < 4; ++db_) { trn_[db_][0] = trb_[db_][0] + slot_; trn_[db_][1] = trb_[db_][1] + slot_; } \
+    }                                                                                                     \
+    if (DMA_ON) { ESR_P_LOAD_NEXT(); ESR_DMA_LSE(DBUF); }                                                 \
+    ESR_TR_WAIT(); /* this chunk's G = 0 fragments (requested one iteration ago, or by the prologue) */    \
+    if (ONEP) {                                                                                           \
+      ESR_SB(); ESR_O_ROW(0, 2, 0); ESR_SB(); ESR_O_G1(4, 6); if (DMA_ON) { ESR_DP(0, g0, DBUF); }        \
+      if (NEXT_ON) { ESR_PC_SPLIT1(0); ESR_PC_SPLIT1(1); }                                                \
+      ESR_SB(); ESR_O_ROW(0, 1, 0); ESR_SB(); ESR_O_G1(6, 8); if (DMA_ON) { ESR_DP(1, g1, DBUF); }        \
+      if (NEXT_ON) { ESR_PC_SPLIT1(2); ESR_PC_SPLIT1(3); }                                                \
+      ESR_SB(); ESR_O_ROW(0, 0, 0); ESR_SB();                                                             \
+      if (NEXT_ON) { ESR_PC_SPLIT1(4); ESR_PC_SPLIT1(5); }                                                \
+      ESR_TR_WAIT();                                                                                      \
+      ESR_SB(); ESR_O_ROW(0, 2, 1); ESR_SB(); if (NEXT_ON) { ESR_PC_NEXT_G0(4, 6); ESR_PC_SPLIT1(6); }    \
+      ESR_SB(); ESR_O_ROW(0, 1, 1); ESR_SB(); if (NEXT_ON) { ESR_PC_NEXT_G0(6, 8); ESR_PC_SPLIT1(7); }    \
+      ESR_SB(); ESR_O_ROW(0, 0, 1); ESR_SB();                                                             \
+    } else {                                                                                              \
+      ESR_SB(); ESR_O_ROW(2, 0, 0); ESR_SB(); ESR_O_G1(0, 3); if (DMA_ON) { ESR_DP(0, g0, DBUF); }        \
+      if (NEXT_ON) ESR_PC_SPLIT1(0);                                                                      \
+      ESR_SB(); ESR_O_ROW(0, 2, 0); ESR_SB(); ESR_O_G1(3, 6); if (DMA_ON) { ESR_DP(1, g1, DBUF); }        \
+      if (NEXT_ON) ESR_PC_SPLIT1(1);                                                                      \
+      ESR_SB(); ESR_O_ROW(1, 1, 0); ESR_SB(); ESR_O_G1(6, 8); if (DMA_ON) { ESR_DP(2, g2, DBUF); }        \
+      if (NEXT_ON) ESR_PC_SPLIT1(2);                                                                      \
+      ESR_SB(); ESR_O_ROW(1, 0, 0); ESR_SB(); ESR_O_G1(8, 10); if (DMA_ON) { ESR_DP(3, g3, DBUF); }       \
+      if (NEXT_ON) ESR_PC_SPLIT1(3);                                                                      \
+      ESR_SB(); ESR_O_ROW(0, 1, 0); ESR_SB(); ESR_O_G1(10, 12); if (DMA_ON) { ESR_DP(4, g4, DBUF); }      \
+      if (NEXT_ON) ESR_PC_SPLIT1(4);                                                                      \
+      ESR_SB(); ESR_O_ROW(0, 0, 0); ESR_SB(); if (DMA_ON) { ESR_DP(5, g5, DBUF); }                        \
+      if (NEXT_ON) ESR_PC_SPLIT1(5);                                                                      \
+      ESR_TR_WAIT();                                                                                      \
+      ESR_SB(); ESR_O_ROW(2, 0, 1); ESR_SB(); if (NEXT_ON) { ESR_PC_NEXT_G0(0, 2); ESR_PC_SPLIT1(6); }    \
+      ESR_SB(); ESR_O_ROW(0, 2, 1); ESR_SB(); if (NEXT_ON) { ESR_PC_NEXT_G0(2, 4); ESR_PC_SPLIT1(7); }    \
+      ESR_SB(); ESR_O_ROW(1, 1, 1); ESR_SB(); if (NEXT_ON) { ESR_PC_NEXT_G0(4, 6); }                      \
+      ESR_SB(); ESR_O_ROW(1, 0, 1); ESR_SB(); if (NEXT_ON) { ESR_PC_NEXT_G0(6, 8); }                      \
+      ESR_SB(); ESR_O_ROW(0, 1, 1); ESR_SB(); if (NEXT_ON) { ESR_PC_NEXT_G0(8, 10); }                     \
+      ESR_SB(); ESR_O_ROW(0, 0, 1); ESR_SB(); if (NEXT_ON) { ESR_PC_NEXT_G0(10, 12); }                    \
+    }                                                                                                     \
+    if (DMA_ON) ESR_DMA_ADVANCE();                                                                        \
+    if (NEXT_ON) {                                                                                        \
+      _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_)                                                    \
+        _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) pw[q_][s_] = pwn[q_][s_];                        \
+    }                                                                                                     \
+  }
+  int pl_next = 2;  // chunk whose P^T tile the next ESR_P_LOAD_NEXT fetches
+#define ESR_P_LOAD_NEXT() { ESR_P_LOAD(pl_next); ++pl_next; }
+
+  // prologue: P^T tiles of chunks 0 and 1 in flight with the two ring tiles
+  ESR_P_LOAD(0);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) p[r] = pn[r];
+  if (nc > 1) ESR_P_LOAD(1);
+  ESR_DMA_BARRIER();  // tiles 0 and 1, their 1 / l blocks and both P^T tiles have landed
+  ESR_TR_BASES(lds);
+  ESR_O_PREFETCH(lds);
+  ESR_LOAD_REFS(lds);
+  ESR_P_SPLIT();
+
+  int cur = 0;
+  for (int it = 0; it + 2 < nc; ++it) {
+    const int nxt = cur == k3Bufs - 1 ? 0 : cur + 1;
+    const int nn = nxt == k3Bufs - 1 ? 0 : nxt + 1;
+    if (it > 0) ESR_DMA_BARRIER();  // chunk it + 1 (tile, 1 / l block, P^T tile) is here; slot nn is free again
+    const char* buf = lds + cur * kBufBytes;
+    const char* nbuf = lds + nxt * kBufBytes;
+    char* dbuf = lds + nn * kBufBytes;
+    ESR_TR_BASES(buf);
+    ESR_PC_ITER(buf, nbuf, dbuf, true, true);
+    cur = nxt;
+  }
+  if (nc >= 2) {  // chunk nc - 2: nothing left to fetch, chunk nc - 1 still to prepare
+    const int nxt = cur == k3Bufs - 1 ? 0 : cur + 1;
+    if (nc > 2) ESR_DMA_BARRIER();
+    const char* buf = lds + cur * kBufBytes;
+    const char* nbuf = lds + nxt * kBufBytes;
+    ESR_TR_BASES(buf);
+    ESR_PC_ITER(buf, nbuf, lds, false, true);
+    cur = nxt;
+  }
+  {  // last chunk (no barrier: its tile landed two barriers ago, nothing is overwritten any more)
+    const char* buf = lds + cur * kBufBytes;
+    ESR_TR_BASES(buf);
+    ESR_PC_ITER(buf, buf, lds, false, false);
+  }
+  float* orow = part_O + ((int64_t)split * B + xrow) * k3D;
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float4*>(orow + 32 * db + 8 * q + 4 * h) =
+          make_float4(acc[db][4 * q], acc[db][4 * q + 1], acc[db][4 * q + 2], acc[db][4 * q + 3]);
 }
 
 // Row-max pre-pass for pass Q: S~ = hi-plane product only (one bf16 MFMA term, error ~2^-8 |q||c| scale,
@@ -768,7 +982,8 @@ __global__ __launch_bounds__(kBlock) void inbatch3_merge_kernel(
     RowSrc X, RowSrc Y, const int32_t* __restrict__ out_idx, int64_t B, int nsplit, const float* __restrict__ part_O,
     const float* __restrict__ part_m, const float* __restrict__ part_l, float scale, float lam, float inv_bs,
     float* __restrict__ lse2, float* __restrict__ lse_nat, float* __restrict__ gX,
-    unsigned long long* __restrict__ loss_acc, double loss_scale, float* __restrict__ loss_out) {
+    unsigned long long* __restrict__ loss_acc, double loss_scale, float* __restrict__ loss_out,
+    float* __restrict__ invl) {
   __shared__ double sm[4];
   constexpr int G = 32;
   const int lig = threadIdx.x & (G - 1);
@@ -824,6 +1039,7 @@ __global__ __launch_bounds__(kBlock) void inbatch3_merge_kernel(
       const float l2v = M + __builtin_amdgcn_logf(L);
       if (lig == 0) {
         lse2[row] = l2v;
+        if (invl) invl[row] = invL;  // the stored-P pass C normalises with it
         if (lse_nat) lse_nat[row] = l2v * k3Ln2;
       }
       row_loss += l2v * k3Ln2 - scale * diag;
@@ -869,10 +1085,15 @@ __global__ __launch_bounds__(kBlock) void inbatch3_merge_kernel(
 
 struct Inbatch3Ws {
   __bf16 *Qr, *Qt, *Cr, *Ct;
-  float *part_O, *part_m, *part_l, *lse2;
+  float *part_O, *part_m, *part_l, *lse2, *invl, *Pmat;
   unsigned long long* loss_acc;  // [(1 + kLossWords) * 16]: master word (+ poison word at [8]), then kLossWords words 128 B apart
   float* nrm;         // [2][B / 32][4]: largest squared row norm per (matrix, chunk, wave) of the split pre-pass
 };
+// stored-P path: pass Q writes the B x B probabilities, pass C reads them instead of recomputing S^T.  Up to 1 GiB of
+// workspace (B = 16384); larger batches recompute.
+constexpr int64_t kPStoreMaxB = 16384;
+static bool pstore_ok(int64_t B) { return B <= kPStoreMaxB; }
+
 static size_t inbatch3_ws_layout(int64_t B, int nsplit, char* base, Inbatch3Ws* ws) {
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -888,6 +1109,8 @@ static size_t inbatch3_ws_layout(int64_t B, int nsplit, char* base, Inbatch3Ws* 
   w.part_m = (float*)take((size_t)nsplit * B * 4);
   w.part_l = (float*)take((size_t)nsplit * B * 4);
   w.lse2 = (float*)take((size_t)B * 4);
+  w.invl = (float*)take((size_t)B * 4);
+  w.Pmat = pstore_ok(B) ? (float*)take((size_t)B * B * 4) : nullptr;
   w.loss_acc = (unsigned long long*)take(sizeof(unsigned long long) * 16 * (1 + kLossWords));
   w.nrm = (float*)take((size_t)2 * (B / k3Chunk) * 4 * sizeof(float));
   if (ws) *ws = w;
@@ -959,34 +1182,51 @@ static int inbatch3_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* gq
   const int mgrid = (int)std::min<int64_t>(k3MergeBlocks, cdiv(B, kBlock / 32));
   // bf16 tables on both sides (BASELINE config 4): planes 2 and 3 are zero -> the one-plane kernels (bit-identical)
   const bool onep = kUseTr && Qs.bf16 && Cs.bf16;
+  // stored-P path (default where the B x B matrix fits the workspace; ESR_IB3_PSTORE=0 keeps the recompute path)
+  static const bool pstore_env = []() { const char* e = getenv("ESR_IB3_PSTORE"); return !(e && e[0] == '0'); }();
+  const bool pstore = kUseTr && pstore_ok(B) && pstore_env && ws.Pmat != nullptr && !onep;
   hipLaunchKernelGGL(split3_kernel, dim3(nchunks, 2), dim3(256), 0, st, Qs, Cs, B, ws.Qr, ws.Qt, ws.Cr, ws.Ct, ws.nrm,
                      ws.loss_acc, onep ? 1 : 3);
   // pass Q: owned = Q, streamed = C
   hipLaunchKernelGGL(inbatch3_rowmax_kernel, dim3(grid), dim3(256), 0, st, (const __bf16*)ws.Qr, (const __bf16*)ws.Cr, B,
                      nsplit, sl2, (const float*)ws.nrm, ws.part_m);
-  if (onep)
-    hipLaunchKernelGGL((inbatch3_kernel<true, true>), dim3(grid), dim3(256), 0, st, (const __bf16*)ws.Qr,
-                       (const __bf16*)ws.Cr, (const __bf16*)ws.Ct, B, nsplit, sl2, (const float*)ws.part_m, ws.part_O,
-                       ws.part_l);
-  else
-    hipLaunchKernelGGL((inbatch3_kernel<true, false>), dim3(grid), dim3(256), 0, st, (const __bf16*)ws.Qr,
-                       (const __bf16*)ws.Cr, (const __bf16*)ws.Ct, B, nsplit, sl2, (const float*)ws.part_m, ws.part_O,
-                       ws.part_l);
+#define ESR_IB3_LAUNCH_Q(ONEP_, PM_)                                                                            \
+  hipLaunchKernelGGL((inbatch3_kernel<true, ONEP_, PM_>), dim3(grid), dim3(256), 0, st, (const __bf16*)ws.Qr,     \
+                     (const __bf16*)ws.Cr, (const __bf16*)ws.Ct, B, nsplit, sl2, (const float*)ws.part_m,        \
+                     ws.part_O, ws.part_l, ws.Pmat)
+  if (onep) { if (pstore) ESR_IB3_LAUNCH_Q(true, 1); else ESR_IB3_LAUNCH_Q(true, 0); }
+  else { if (pstore) ESR_IB3_LAUNCH_Q(false, 1); else ESR_IB3_LAUNCH_Q(false, 0); }
+#undef ESR_IB3_LAUNCH_Q
   hipLaunchKernelGGL((inbatch3_merge_kernel<true>), dim3(mgrid), dim3(kBlock), 0, st, Qs, Cs, gq_rows, B, nsplit,
                      (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale, regularization,
-                     inv_bs, ws.lse2, lse, gQ, ws.loss_acc, 1.0 / (double)batch_size, loss);
+                     inv_bs, ws.lse2, lse, gQ, ws.loss_acc, 1.0 / (double)batch_size, loss, pstore ? ws.invl : nullptr);
   // pass C: owned = C, streamed = Q
-  if (onep)
-    hipLaunchKernelGGL((inbatch3_kernel<false, true>), dim3(grid), dim3(256), 0, st, (const __bf16*)ws.Cr,
+  int nsplit_c = nsplit;
+  if (pstore) {
+    // The stored-P kernel is not MFMA-bound: its P^T loads come from HBM and every barrier drains them.  TWO workgroups
+    // per CU (twice the splits; 146 KB of LDS, 2 waves per SIMD) cover each other's waits.
+    static const int pc_splits = []() { const char* e = getenv("ESR_IB3_PC_SPLITS"); return e ? atoi(e) : 2; }();
+    if (pc_splits > 1 && nsplit * pc_splits <= 8 && (B / k3Chunk) % (nsplit * pc_splits) == 0) nsplit_c = nsplit * pc_splits;
+    const int grid_c = (int)(B / k3Owned) * nsplit_c;
+    if (onep)
+      hipLaunchKernelGGL((inbatch3_pc_kernel<true>), dim3(grid_c), dim3(256), 0, st, (const __bf16*)ws.Qr,
+                         (const __bf16*)ws.Qt, B, nsplit_c, (const float*)ws.invl, (const float*)ws.Pmat, ws.part_O);
+    else
+      hipLaunchKernelGGL((inbatch3_pc_kernel<false>), dim3(grid_c), dim3(256), 0, st, (const __bf16*)ws.Qr,
+                         (const __bf16*)ws.Qt, B, nsplit_c, (const float*)ws.invl, (const float*)ws.Pmat, ws.part_O);
+  } else if (onep) {
+    hipLaunchKernelGGL((inbatch3_kernel<false, true, 0>), dim3(grid), dim3(256), 0, st, (const __bf16*)ws.Cr,
                        (const __bf16*)ws.Qr, (const __bf16*)ws.Qt, B, nsplit, sl2, (const float*)ws.lse2, ws.part_O,
-                       ws.part_l);
-  else
-    hipLaunchKernelGGL((inbatch3_kernel<false, false>), dim3(grid), dim3(256), 0, st, (const __bf16*)ws.Cr,
+                       ws.part_l, (float*)nullptr);
+  } else {
+    hipLaunchKernelGGL((inbatch3_kernel<false, false, 0>), dim3(grid), dim3(256), 0, st, (const __bf16*)ws.Cr,
                        (const __bf16*)ws.Qr, (const __bf16*)ws.Qt, B, nsplit, sl2, (const float*)ws.lse2, ws.part_O,
-                       ws.part_l);
-  hipLaunchKernelGGL((inbatch3_merge_kernel<false>), dim3(mgrid), dim3(kBlock), 0, st, Cs, Qs, gc_rows, B, nsplit,
+                       ws.part_l, (float*)nullptr);
+  }
+  hipLaunchKernelGGL((inbatch3_merge_kernel<false>), dim3(mgrid), dim3(kBlock), 0, st, Cs, Qs, gc_rows, B, nsplit_c,
                      (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale, regularization,
-                     inv_bs, ws.lse2, (float*)nullptr, gC, ws.loss_acc, 1.0 / (double)batch_size, loss);
+                     inv_bs, ws.lse2, (float*)nullptr, gC, ws.loss_acc, 1.0 / (double)batch_size, loss,
+                     (float*)nullptr);
   return check_launch(who);
 }
 

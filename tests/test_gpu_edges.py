@@ -93,7 +93,8 @@ def test_argument_errors_raise_with_a_message(dev):
         ops.inbatch_softmax_fwd_bwd(torch.randn((100, 128), device=dev), torch.randn((100, 128), device=dev), 1.0, 0.0,
                                     100.0, precision="bf16x3")            # B not a multiple of 128
     with pytest.raises(_lib.EsrLibraryError, match="not supported"):
-        ops.inbatch_softmax_fwd_bwd(torch.randn((64, 96), device=dev), torch.randn((64, 96), device=dev), 1.0, 0.0, 64.0)
+        ops.inbatch_softmax_fwd_bwd(torch.randn((64, 98), device=dev), torch.randn((64, 98), device=dev), 1.0, 0.0,
+                                    64.0)                                 # D must be a multiple of 4 (96 is fine now)
     with pytest.raises(TypeError):
         ops.gather_rows(c, torch.zeros(3, dtype=torch.int64, device=dev))  # ids must be int32
     with pytest.raises(TypeError, match="no CPU fallback"):

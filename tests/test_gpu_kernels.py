@@ -330,7 +330,10 @@ def test_inbatch_towers_gather_folded_in(dev, dtype):
     q = ops.unpermute_rows_to_f32(ops.gather_rows(qt, T(qi, dev)), None)
     c = ops.unpermute_rows_to_f32(ops.gather_rows(ct, T(ci, dev)), None)
     l2, lse2, gq2, gc2 = ops.inbatch_softmax_fwd_bwd(q, c, 6.0, 0.1, float(B), precision="bf16x3")
-    assert torch.equal(loss, l2) and torch.equal(lse, lse2) and torch.equal(gq, gq2) and torch.equal(gc, gc2)
+    assert torch.equal(loss, l2) and torch.equal(lse, lse2) and torch.equal(gq, gq2)
+    # pass C: bf16 towers recompute S^T (one-plane kernels), f32 rows take the stored-P kernel, which normalises p / l
+    # instead of forming exp2(s - lse): the same probabilities to an f32 rounding
+    assert torch.equal(gc, gc2) if dtype == torch.float32 else rel_err(N(gc), N(gc2)) <= 1e-6
     el, else_, egq, egc = o_stl.inbatch_softmax_loss_and_grads(N(q).astype(F64), N(c).astype(F64), 0.1, B, 6.0, F64)
     assert abs(float(loss) - el) / abs(el) <= TOL and rel_err(N(gq), egq) <= TOL and rel_err(N(gc), egc) <= TOL
 
@@ -348,7 +351,8 @@ def test_inbatch_one_plane_kernels_equal_the_full_ones(dev, B):
     ci = T(rng.integers(0, V, B).astype(np.int32), dev)
     loss, lse, gq, gc = ops.inbatch_towers_fwd_bwd(qt, ct, qi, ci, 7.0, 0.1, float(B))
     l2, lse2, gq2, gc2 = ops.inbatch_towers_fwd_bwd(qt.float(), ct.float(), qi, ci, 7.0, 0.1, float(B))
-    assert torch.equal(loss, l2) and torch.equal(lse, lse2) and torch.equal(gq, gq2) and torch.equal(gc, gc2)
+    assert torch.equal(loss, l2) and torch.equal(lse, lse2) and torch.equal(gq, gq2)
+    assert rel_err(N(gc), N(gc2)) <= 1e-6   # (pass C of the full path reads stored probabilities; see above)
     if B <= 2176:
         q, c = N(qt.float())[N(qi)].astype(F64), N(ct.float())[N(ci)].astype(F64)
         el, _, egq, egc = o_stl.inbatch_softmax_loss_and_grads(q, c, 0.1, B, 7.0, F64)

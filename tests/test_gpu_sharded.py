@@ -46,9 +46,11 @@ def test_sharded_world1_equals_single_device(dev, pg):
             l_sh = sharded.sharded_inbatch_step(towers, sid, pid, lam, float(B), 4.0, lr)
             state, l_1 = train_step(state, sid, pid, None, lam, B, scale=4.0)
         assert abs(float(l_sh) - float(l_1)) <= 1e-6 * abs(float(l_1))
-    # same kernels, same occurrence order -> identical tables
-    assert torch.equal(scene.local, state.params["params"]["scene_tower"]["embedding"])
-    assert torch.equal(prod.local, state.params["params"]["product_tower"]["embedding"])
+    # same occurrence order, same element arithmetic; the single-device triplet step is the one-pass kernel (its dots are
+    # reduced over 8 lanes, the sharded path's over 32): tables agree to an f32 rounding
+    from conftest import rel_err
+    assert rel_err(scene.local.cpu().numpy(), state.params["params"]["scene_tower"]["embedding"].cpu().numpy()) <= 1e-6
+    assert rel_err(prod.local.cpu().numpy(), state.params["params"]["product_tower"]["embedding"].cpu().numpy()) <= 1e-6
 
 
 def test_sharded_glove_world1(dev, pg):
