@@ -365,8 +365,8 @@ __device__ unsigned long long esr_ib3_dbg[8192];
            dword store per value straight from its register -- lanes are consecutive owned rows, so every store  \
            instruction writes two whole 128-byte lines; no staging registers, no data movement */              \
         if (PMODE == 1) {                                                                                 \
-          pst_[(int64_t)(((2 * s_) & 3) + 8 * ((2 * s_) >> 2)) * B] = e0_;                                \
-          pst_[(int64_t)(((2 * s_ + 1) & 3) + 8 * ((2 * s_ + 1) >> 2)) * B] = e1_;                        \
+          ESR_P_ST(((2 * s_) & 3) + 8 * ((2 * s_) >> 2), e0_);                                            \
+          ESR_P_ST(((2 * s_ + 1) & 3) + 8 * ((2 * s_ + 1) >> 2), e1_);                                    \
         }                                                                                                 \
       }                                                                                                   \
       ESR_SB();                                                                                           \
@@ -374,7 +374,7 @@ __device__ unsigned long long esr_ib3_dbg[8192];
       ESR_SB();                                                                                           \
       a1_ = n1_; a2_ = n2_; a3_ = n3_;                                                                    \
     }                                                                                                     \
-    if (PMODE == 1 && (VALU_ON)) pst_ += 32 * B;                                                          \
+    if (PMODE == 1 && (VALU_ON)) pst_u += 32 * B * 4;                                                     \
   }
 
 // Main kernel.  No online-softmax rescaling: the exponent reference is FIXED per owned row (pass Q: an
@@ -424,8 +424,12 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
   bf16x8 bx[3][8];  // owned rows -> B operand (loaded below, behind the first tiles' DMA)
   float refv = 0.f;
   // PMODE 1: where this lane's probabilities of the chunk whose exp is being formed go (advances 32 columns per chunk)
-  // Pt[streamed row][owned row]: this lane's column, at the first streamed row of its half (advances 32 rows per chunk)
-  float* pst_ = PMODE == 1 ? Pmat + (c0 * 32 + 4 * h) * B + xrow : nullptr;
+  // Pt[streamed row][owned row].  Address = wave-uniform row base (scalar registers, advanced 32 rows per chunk)
+  // + a fixed 32-bit per-lane offset: the store's saddr form -- with a per-lane 64-bit pointer every one of the 16
+  // stores of a chunk cost two VALU adds inside the S^T phase, whose VALU slots are what bounds it.
+  char* pst_u = PMODE == 1 ? reinterpret_cast<char*>(Pmat) + c0 * 32 * B * 4 : nullptr;
+  const uint32_t pst_v = (uint32_t)((4 * h * B + xrow) * 4);
+#define ESR_P_ST(K, VAL) *reinterpret_cast<float*>(pst_u + (int64_t)(K) * B * 4 + pst_v) = (VAL)
 
   f32x16 acc[4];
 #pragma unroll
@@ -649,8 +653,8 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
       pw[0][s] = pa; pw[1][s] = pq;
       pw[2][s] = pk_bf16(q0 - pk_lo(pq), q1 - pk_hi(pq));
       if (PMODE == 1) {
-        pst_[(int64_t)(((2 * s) & 3) + 8 * ((2 * s) >> 2)) * B] = e0;
-        pst_[(int64_t)(((2 * s + 1) & 3) + 8 * ((2 * s + 1) >> 2)) * B] = e1;
+        ESR_P_ST(((2 * s) & 3) + 8 * ((2 * s) >> 2), e0);
+        ESR_P_ST(((2 * s + 1) & 3) + 8 * ((2 * s + 1) >> 2), e1);
       }
     }
     ESR_O_PHASE(buf, false, lds);
