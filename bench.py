@@ -156,9 +156,14 @@ def roofline_for(workload, kernels, B, D, rows, precision, occ_n=0, uniq=0, bf16
             # terms x 2 B^2 D executed bf16 flops; the row-max pre-pass (one hi-plane term) only runs when the
             # Cauchy-Schwarz bound on the scores is too wide (not on these inputs).  bf16-exact operands (bf16
             # tables): the zero planes are skipped -- 1 live term in each S^T, 3 in each O^T.
-            terms = (2 * (1 + 3)) if bf16_tables else 4 * 6
+            # Stored-P path (fp32 tables, B <= 16384; esr_inbatch3.hip pstore_ok): pass C reads the probabilities
+            # pass Q wrote instead of recomputing S^T -- 3 GEMM units x 6 terms.
+            stored_p = (not bf16_tables) and B <= 16384 and os.environ.get("ESR_IB3_PSTORE", "1") != "0"
+            terms = (2 * (1 + 3)) if bf16_tables else (3 * 6 if stored_p else 4 * 6)
             executed = (terms + (1 if rowmax_gemm else 0)) * 2.0 * B * B * D
-            return {"kernel": "split3 + inbatch3_rowmax + inbatch3_kernel<Q> + merge + inbatch3_kernel<C> + merge",
+            return {"kernel": "split3 + inbatch3_rowmax + inbatch3_kernel<Q> + merge + " +
+                              ("inbatch3_pc_kernel" if stored_p else "inbatch3_kernel<C>") + " + merge",
+                    "pass_c": "reads stored P (B*B*4 bytes written by pass Q)" if stored_p else "recomputes S^T",
                     "bound": "mfma", "achieved": executed / t / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": executed / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
                     "dtype": "bf16 x3 split, f32 accumulate (f32-equivalent products)" +

@@ -374,7 +374,7 @@ __device__ unsigned long long esr_ib3_dbg[8192];
       ESR_SB();                                                                                           \
       a1_ = n1_; a2_ = n2_; a3_ = n3_;                                                                    \
     }                                                                                                     \
-    if (PMODE == 1 && (VALU_ON)) pst_u += 32 * B * 4;                                                     \
+    if (PMODE == 1 && (VALU_ON)) pst_u += nch * 4096;                                                     \
   }
 
 // Main kernel.  No online-softmax rescaling: the exponent reference is FIXED per owned row (pass Q: an
@@ -427,9 +427,13 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
   // Pt[streamed row][owned row].  Address = wave-uniform row base (scalar registers, advanced 32 rows per chunk)
   // + a fixed 32-bit per-lane offset: the store's saddr form -- with a per-lane 64-bit pointer every one of the 16
   // stores of a chunk cost two VALU adds inside the S^T phase, whose VALU slots are what bounds it.
-  char* pst_u = PMODE == 1 ? reinterpret_cast<char*>(Pmat) + c0 * 32 * B * 4 : nullptr;
-  const uint32_t pst_v = (uint32_t)((4 * h * B + xrow) * 4);
-#define ESR_P_ST(K, VAL) *reinterpret_cast<float*>(pst_u + (int64_t)(K) * B * 4 + pst_v) = (VAL)
+  // Layout: 32 x 32 TILES, tile (streamed block jt, owned block it) at float offset (jt * B/32 + it) * 1024, inside
+  // it [streamed row][owned row]: the 16 stores of a chunk fill ONE contiguous 4 KB block (row-major B x B put them
+  // on 32 rows 4 B bytes apart -- 32 DRAM pages per wave and chunk, on both the writing and the reading side), and
+  // the row part of the address is the store's immediate offset.
+  char* pst_u = PMODE == 1 ? reinterpret_cast<char*>(Pmat) + (c0 * nch + (xrow >> 5)) * 4096 : nullptr;
+  const uint32_t pst_v = (uint32_t)((4 * h * 32 + j) * 4);
+#define ESR_P_ST(K, VAL) *reinterpret_cast<float*>(pst_u + (K) * 128 + pst_v) = (VAL)
 
   f32x16 acc[4];
 #pragma unroll
@@ -734,14 +738,15 @@ __global__ __launch_bounds__(256) void inbatch3_pc_kernel(const __bf16* __restri
   ESR_DMA_ALL(lds);
   if (nc > 1) ESR_DMA_ALL(lds + kBufBytes);
   // Pt[j][i] (pass Q wrote it transposed): this lane's owned row j = xrow, streamed rows i = chunk row0 + 8g + 4h + 0..3
-  const float* pcol = Pmat + xrow * B + 4 * h;  // per-lane part of the address
+  // tile (jt = xrow / 32, it = chunk) at (jt * B/32 + it) * 1024 floats, [j % 32][i % 32] inside (see pass Q)
+  const float* pcol = Pmat + (xrow >> 5) * nch * 1024 + j * 32 + 4 * h;  // per-lane part of the address
   float pn[16], p[16], rf[16];
   const float refv = 0.f;  // (named by ESR_LOAD_REFS's pass-Q branch, which is compiled out here)
   uint32_t pw[3][8];
   bf16x8 ta2_[2][4][3];
 #define ESR_P_LOAD(CH)                                                                                    \
   {                                                                                                       \
-    const float* base_ = pcol + (c0 + (CH)) * 32;                                                         \
+    const float* base_ = pcol + (c0 + (CH)) * 1024;                                                         \
     _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                    \
       const float4 v_ = *reinterpret_cast<const float4*>(base_ + 8 * g_);                                 \
       pn[4 * g_] = v_.x; pn[4 * g_ + 1] = v_.y; pn[4 * g_ + 2] = v_.z; pn[4 * g_ + 3] = v_.w;             \
@@ -1187,7 +1192,8 @@ static int inbatch3_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* gq
   // bf16 tables on both sides (BASELINE config 4): planes 2 and 3 are zero -> the one-plane kernels (bit-identical)
   const bool onep = kUseTr && Qs.bf16 && Cs.bf16;
   // stored-P path (default where the B x B matrix fits the workspace; ESR_IB3_PSTORE=0 keeps the recompute path)
-  static const bool pstore_env = []() { const char* e = getenv("ESR_IB3_PSTORE"); return !(e && e[0] == '0'); }();
+  const char* pstore_e = getenv("ESR_IB3_PSTORE");  // read per call: the parity test flips it between two calls
+  const bool pstore_env = !(pstore_e && pstore_e[0] == '0');
   const bool pstore = kUseTr && pstore_ok(B) && pstore_env && ws.Pmat != nullptr && !onep;
   hipLaunchKernelGGL(split3_kernel, dim3(nchunks, 2), dim3(256), 0, st, Qs, Cs, B, ws.Qr, ws.Qt, ws.Cr, ws.Ct, ws.nrm,
                      ws.loss_acc, onep ? 1 : 3);

@@ -359,6 +359,33 @@ def test_inbatch_one_plane_kernels_equal_the_full_ones(dev, B):
         assert abs(float(loss) - el) / abs(el) <= TOL and rel_err(N(gq), egq) <= TOL and rel_err(N(gc), egc) <= TOL
 
 
+@pytest.mark.parametrize("B", [128, 256, 1024, 2176, 8192, 16384])
+def test_inbatch_pstore_matches_recompute(dev, B, monkeypatch):
+    """fp32 towers: pass C reading the probabilities pass Q stored (default) against pass C recomputing S^T
+    (ESR_IB3_PSTORE=0).  Loss, lse and gQ come from the same pass-Q arithmetic (bit-equal); gC differs by f32 roundings
+    of p (exp2(s - ref) / l against exp2(s - lse)).  B = 16384 is the largest stored-P batch."""
+    from conftest import elem_rel_err
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(B + 7)
+    V, D = 20000, 128
+    qt = T((rng.standard_normal((V, D)) * 0.12).astype(np.float32), dev)
+    ct = T((rng.standard_normal((V, D)) * 0.12).astype(np.float32), dev)
+    qi = T(rng.integers(0, V, B).astype(np.int32), dev)
+    ci = T(rng.integers(0, V, B).astype(np.int32), dev)
+    monkeypatch.setenv("ESR_IB3_PSTORE", "1")
+    loss, lse, gq, gc = [x.clone() for x in ops.inbatch_towers_fwd_bwd(qt, ct, qi, ci, 7.0, 0.1, float(B))]
+    monkeypatch.setenv("ESR_IB3_PSTORE", "0")
+    l2, lse2, gq2, gc2 = ops.inbatch_towers_fwd_bwd(qt, ct, qi, ci, 7.0, 0.1, float(B))
+    assert torch.equal(loss, l2) and torch.equal(lse, lse2) and torch.equal(gq, gq2)
+    # element-wise with the floor at 1e-3 of the largest entry: 1e-6 norm-wise allows up to 1e-3 there
+    assert rel_err(N(gc), N(gc2)) <= 1e-6 and elem_rel_err(N(gc), N(gc2)) <= 5e-4
+    if B <= 2176:
+        q, c = N(qt)[N(qi)].astype(F64), N(ct)[N(ci)].astype(F64)
+        el, _, egq, egc = o_stl.inbatch_softmax_loss_and_grads(q, c, 0.1, B, 7.0, F64)
+        for g in (gc, gc2):
+            assert rel_err(N(g), egc) <= TOL
+
+
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 def test_inbatch_config_c2_full_size(dev, precision):
     """BASELINE config C2: B = 8192, D = 128, fp64 oracle on the same inputs + checksum properties
