@@ -1,0 +1,793 @@
+// In-batch softmax forward + backward with FP32-GRADE products from TWO fp16 planes per operand.
+//
+// Same contract, flash structure and kernel skeleton as esr_inbatch3.hip (bf16 x 3 planes, read that first), half the
+// matrix-core work.  The bf16 x 3 kernels run at the chip's POWER limit (1.7-1.8 GHz under them, profiles/r2): wall
+// time follows the number of MFMAs, not the cycles a schedule wastes, so the lever is fewer MFMAs per product:
+//
+//   x' = x * 2^e (e per matrix, from the batch's largest |element|: max |x'| in [2^13, 2^14))
+//   x1 = rn_f16(x'),  x2 = rn_f16(x' - x1)          |x' - x1 - x2| <= 2^-24 |x'|  (11 + 1 bits per plane with
+//                                                     round-to-nearest; x2 is subnormal only below 2^-16 of the
+//                                                     matrix maximum, absolute error then <= 2^-25 * 2^-e)
+//   a.b ~= a2 b1 + a1 b2 + a1 b1                     dropped a2 b2 <= 2^-24 |a||b|
+//
+// i.e. THREE v_mfma_f32_32x32x16_f16 per product instead of six bf16 ones, error <= ~3 * 2^-24 |a||b| per elementary
+// product -- the f32 rounding of the product itself (measured against the fp64 oracle: at or below the exact-f32 MFMA
+// path, tests/test_gpu_kernels.py).  What fp16 costs is RANGE, and it is handled where it arises:
+//   * operands: the per-matrix power-of-two scale above (absmax pre-pass, 8 MB read); undone by exact power-of-two
+//     factors in the exponent argument and in the merge kernels;
+//   * probabilities of pass Q: p' = exp2(s - M_i) must lie in fp16's range for every j, so M_i is tied to the TRUE row
+//     maximum: M_i = max_j s_ij - 14 (hi-plane product, 1 / 9 of the MFMA work) => max_j p' = 2^14 exactly where it
+//     matters, anything below 2^-28 of the row maximum goes subnormal (absolute error 2^-39 of the maximum).  When the
+//     Cauchy-Schwarz bound on |s| is <= 14 (log2 units) the bound itself is safe (p' in [2^-14, 2^14]) and the row-max
+//     GEMM is skipped;
+//   * probabilities of pass C: true probabilities p / l in [0, 1] with a row maximum >= 1 / B, scaled by 2^14.
+// Pass C always reads the probabilities pass Q stored (see inbatch3_pc_kernel): B <= 16384; larger batches and bf16
+// tables take the bf16 x 3 path (bf16 tables are one-plane there already).
+#include "esr_inbatch_mfma.h"
+
+namespace esr {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kHLseOff = 2 * kPlaneBytes;   // two row-major planes, then 128 B of per-streamed-row factors (pass C)
+constexpr int kHBufBytes = kHLseOff + 256;
+constexpr int kHBufs = 3;
+constexpr float kHPexp = 14.0f;             // probabilities are carried as p * 2^14
+constexpr float kHBoundSafe = 14.0f;        // Cauchy-Schwarz bound (log2 units) below which no row maximum is needed
+constexpr int kHScaleWords = 8;             // device-side scale block: see split2h_kernel
+
+#define H_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#define H_SB() __builtin_amdgcn_sched_barrier(0)
+#define H_DMA_BARRIER()                                 \
+  {                                                     \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    \
+    __syncthreads();                                    \
+  }
+#define H_TR_WAIT() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); H_SB(); }
+
+__device__ __forceinline__ f16x2 pk_f16(float lo, float hi) {  // v_cvt_pk_f16_f32, round-to-nearest-even
+  const f32x2 v = {lo, hi};
+  return __builtin_convertvector(v, f16x2);
+}
+
+// A fragment F (0..7: plane (F / 4 + 1) % 2 -- the order the O^T rows use them -- column block F % 4) of k-step G
+template <int G, int F, class TA>
+__device__ __forceinline__ void trh_frag(TA& ta, const uint32_t (&tc)[4][2]) {
+  constexpr int PL = (F / 4 + 1) % 2, DB = F % 4, OFF = PL * kPlaneBytes + 16 * G * 256;
+  const s16x4 lo = tr_read<OFF>(tc[DB][0]), hi = tr_read<OFF>(tc[DB][1]);
+  const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  ta[G][DB][PL] = __builtin_bit_cast(f16x8, both);
+}
+template <int G, class TA>
+__device__ __forceinline__ void trh_frag_n(int f, TA& ta, const uint32_t (&tc)[4][2]) {  // f is an unrolled constant
+  switch (f) {
+    case 0: trh_frag<G, 0>(ta, tc); break;
+    case 1: trh_frag<G, 1>(ta, tc); break;
+    case 2: trh_frag<G, 2>(ta, tc); break;
+    case 3: trh_frag<G, 3>(ta, tc); break;
+    case 4: trh_frag<G, 4>(ta, tc); break;
+    case 5: trh_frag<G, 5>(ta, tc); break;
+    case 6: trh_frag<G, 6>(ta, tc); break;
+    default: trh_frag<G, 7>(ta, tc); break;
+  }
+}
+
+// byte offset of DMA piece K (0..3: plane K / 2, half K % 2) of chunk `chunk` from the base of the plane array
+template <int K>
+__device__ __forceinline__ uint32_t dmah_off0(int64_t B, int64_t chunk, int t) {
+  const int within = (t + 256 * K) & 511;
+  const int row = within >> 4, seg = (within & 15) ^ swz16(row);
+  return (uint32_t)((((int64_t)(K >> 1) * B + chunk * 32 + row) * k3D + seg * 8) * 2);
+}
+template <int K>
+__device__ __forceinline__ void dmah_piece(const char* __restrict__ base, uint32_t off, char* buf, int w) {
+  __builtin_amdgcn_global_load_lds((gptr_t)(base + off), (lptr_t)(buf + K * 4096 + w * 1024), 16, 0, 0);
+}
+#define H_DP(K, G, BUF) dmah_piece<K>(baseY, G, (BUF), w)
+#define H_DMA_ADVANCE()                                                                    \
+  {                                                                                        \
+    const uint32_t step_ = (dpos + 1 == nc) ? (uint32_t)(8192 - nc * 8192) : 8192u;        \
+    dpos = (dpos + 1 == nc) ? 0 : dpos + 1;                                                \
+    g0 += step_; g1 += step_; g2 += step_; g3 += step_;                                    \
+  }
+#define H_DMA_CHUNK(BUF) { H_DP(0, g0, BUF); H_DP(1, g1, BUF); H_DP(2, g2, BUF); H_DP(3, g3, BUF); H_DMA_ADVANCE(); }
+
+// -----------------------------------------------------------------------------------------------------------------
+// absmax pre-pass: largest |element| of the 32 rows of one chunk of one matrix -> amax[matrix][chunk]
+// -----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void absmax2h_kernel(RowSrc X0, RowSrc X1, float* __restrict__ amax) {
+  __shared__ float red[4];
+  const RowSrc X = blockIdx.y ? X1 : X0;
+  const int t = threadIdx.x;
+  const int64_t grow = (int64_t)blockIdx.x * 32 + (t >> 3);
+  const int d0 = (t & 7) * 16;
+  float m = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 f = rowsrc_load4(X, grow, d0 + 4 * q);
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(f.x), fabsf(f.y)), fmaxf(fabsf(f.z), fabsf(f.w))));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((t & 63) == 0) red[t >> 6] = m;
+  __syncthreads();
+  if (t == 0) amax[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// exponent e with amax * 2^e in [2^13, 2^14) (0 for an all-zero or non-finite matrix)
+__device__ __forceinline__ int scale_exp(float amax) {
+  if (!(amax > 0.f) || !(amax < INFINITY)) return 0;
+  int x;
+  frexpf(amax, &x);  // amax = m 2^x, m in [0.5, 1)
+  const int e = 14 - x;
+  return e < -100 ? -100 : (e > 100 ? 100 : e);
+}
+
+// split pre-pass: one 256-thread block per 32-row chunk of one matrix (blockIdx.y selects Q or C): two row-major fp16
+// planes of x * 2^e, the largest squared row norm per wave (unscaled, as in split3_kernel), and -- block (0, 0) -- the
+// scale block the later kernels read:  sc[0] = 2^-(eq + ec) (S' -> S),  sc[1] = 2^-ec (pass Q's O'),  sc[2] = 2^-(eq + 14)
+// (pass C's O'), sc[3] / sc[4] = 2^eq / 2^ec.
+__global__ __launch_bounds__(256) void split2h_kernel(RowSrc X0, RowSrc X1, int64_t B, _Float16* __restrict__ R0,
+                                                     _Float16* __restrict__ R1, const float* __restrict__ amax,
+                                                     float* __restrict__ nrm, float* __restrict__ sc,
+                                                     unsigned long long* __restrict__ loss_acc) {
+  __shared__ float red[8];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x <= kLossWords) {  // see inbatch3_merge_kernel
+    loss_acc[threadIdx.x * 16] = 0ull;
+    if (threadIdx.x == 0) loss_acc[8] = 0ull;  // poison word
+  }
+  const int t = threadIdx.x, nchunks = gridDim.x;
+  float mq = 0.f, mc = 0.f;
+  for (int i = t; i < nchunks; i += 256) {
+    mq = fmaxf(mq, amax[i]);
+    mc = fmaxf(mc, amax[nchunks + i]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mq = fmaxf(mq, __shfl_xor(mq, o, 64));
+    mc = fmaxf(mc, __shfl_xor(mc, o, 64));
+  }
+  if ((t & 63) == 0) { red[t >> 6] = mq; red[4 + (t >> 6)] = mc; }
+  __syncthreads();
+  mq = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  mc = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+  const int eq = scale_exp(mq), ec = scale_exp(mc);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && t == 0) {
+    sc[0] = ldexpf(1.f, -(eq + ec));
+    sc[1] = ldexpf(1.f, -ec);
+    sc[2] = ldexpf(1.f, -(eq + (int)kHPexp));
+    sc[3] = ldexpf(1.f, eq);
+    sc[4] = ldexpf(1.f, ec);
+  }
+  const RowSrc X = blockIdx.y ? X1 : X0;
+  _Float16* R = blockIdx.y ? R1 : R0;
+  const float mul = ldexpf(1.f, blockIdx.y ? ec : eq);
+  const int chunk = blockIdx.x;
+  const int row = t >> 3, d0 = (t & 7) * 16;
+  const int64_t grow = (int64_t)chunk * 32 + row;
+  float v[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 f = rowsrc_load4(X, grow, d0 + 4 * q);
+    v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+  }
+  {
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) ss = fmaf(v[e], v[e], ss);
+    ss += __shfl_xor(ss, 1, 64);
+    ss += __shfl_xor(ss, 2, 64);
+    ss += __shfl_xor(ss, 4, 64);
+    ss = fmaxf(ss, __shfl_xor(ss, 8, 64));
+    ss = fmaxf(ss, __shfl_xor(ss, 16, 64));
+    ss = fmaxf(ss, __shfl_xor(ss, 32, 64));
+    if ((t & 63) == 0) nrm[((int64_t)blockIdx.y * gridDim.x + chunk) * 4 + (t >> 6)] = ss;
+  }
+  f16x8 p[2][2];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const float xs = v[e] * mul;  // exact (power of two)
+    const _Float16 a = (_Float16)xs;
+    const _Float16 b = (_Float16)(xs - (float)a);
+    p[0][e >> 3][e & 7] = a;
+    p[1][e >> 3][e & 7] = b;
+  }
+#pragma unroll
+  for (int pl = 0; pl < 2; ++pl) {
+    f16x8* dst = reinterpret_cast<f16x8*>(R + ((int64_t)pl * B + grow) * k3D + d0);
+    dst[0] = p[pl][0];
+    dst[1] = p[pl][1];
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// Row reference for pass Q: part_m[split][row] = M with p' = exp2(s sl2 - M) <= 2^14 (+ the hi-plane product's error).
+// bound <= kHBoundSafe: M = bound - 14 (no GEMM).  Otherwise the row maximum of the hi-plane product (error <= 2^-10
+// |q||c| sl2 in log2 units: fp16's range above 2^14 absorbs it up to bounds of ~2000; beyond that -- scores whose exp
+// over- or underflows f32 anyway -- the second-order planes are added to the product).
+// -----------------------------------------------------------------------------------------------------------------
+constexpr int kHRmGroup = 4;
+__global__ __launch_bounds__(256) void rowmax2h_kernel(const _Float16* __restrict__ Xr, const _Float16* __restrict__ Yr,
+                                                      int64_t B, int nsplit, float sl2, const float* __restrict__ nrm,
+                                                      const float* __restrict__ sc, float* __restrict__ part_m) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * kHRmGroup * 2 * kPlaneBytes];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int ob = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
+  const int64_t xrow = (int64_t)ob * k3Owned + w * 32 + j;
+  float bound;
+  {
+    const int nslots = (int)(B / k3Chunk) * 4;  // per matrix
+    float mq = 0.f, mc = 0.f;
+    for (int i = t; i < nslots; i += 256) {
+      mq = fmaxf(mq, nrm[i]);
+      mc = fmaxf(mc, nrm[nslots + i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mq = fmaxf(mq, __shfl_xor(mq, o, 64));
+      mc = fmaxf(mc, __shfl_xor(mc, o, 64));
+    }
+    float* red = reinterpret_cast<float*>(lds);
+    if (lane == 0) { red[w] = mq; red[4 + w] = mc; }
+    __syncthreads();
+    mq = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    mc = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    __syncthreads();  // the slow path reuses lds as the DMA ring
+    bound = sqrtf(mq * mc) * fabsf(sl2);
+    if (bound <= kHBoundSafe) {
+      if (h == 0) part_m[(int64_t)split * B + xrow] = bound - kHPexp;
+      return;
+    }
+  }
+  const bool full = !(bound <= 1024.f);  // absurd score ranges: all three terms (wave-uniform)
+  const float sl2s = sl2 * sc[0];
+  const float sgn = sl2 < 0.f ? -1.f : 1.f;  // a negative temperature turns the maximum of s sl2 into the minimum of s
+  const int nc = (int)(B / k3Chunk) / nsplit;
+  const int64_t c0 = (int64_t)split * nc;
+  const char* const baseY = reinterpret_cast<const char*>(Yr);
+  f16x8 bx0[8], bx1[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    bx0[s] = *reinterpret_cast<const f16x8*>(Xr + xrow * k3D + 16 * s + 8 * h);
+    bx1[s] = *reinterpret_cast<const f16x8*>(Xr + ((int64_t)B + xrow) * k3D + 16 * s + 8 * h);
+    if (sgn < 0.f) { bx0[s] = -bx0[s]; bx1[s] = -bx1[s]; }
+  }
+  float m = -INFINITY;
+  const uint32_t g0 = dmah_off0<0>(B, c0, t), g1 = dmah_off0<1>(B, c0, t);
+  const uint32_t g2 = dmah_off0<2>(B, c0, t), g3 = dmah_off0<3>(B, c0, t);
+  const int ngroups = (nc + kHRmGroup - 1) / kHRmGroup;
+  constexpr int kSlot = 2 * kPlaneBytes;  // one chunk: plane 0, plane 1 (plane 1 only fetched when `full`)
+#define H_RM_FETCH(GI, HALF)                                                                 \
+  _Pragma("unroll") for (int k = 0; k < kHRmGroup; ++k)                                     \
+    if ((GI) * kHRmGroup + k < nc) {                                                        \
+      char* dst_ = lds + ((HALF) * kHRmGroup + k) * kSlot;                                  \
+      const uint32_t adv_ = (uint32_t)((GI) * kHRmGroup + k) * 8192u;                       \
+      H_DP(0, g0 + adv_, dst_); H_DP(1, g1 + adv_, dst_);                                   \
+      if (full) { H_DP(2, g2 + adv_, dst_); H_DP(3, g3 + adv_, dst_); }                     \
+    }
+  H_RM_FETCH(0, 0);
+  for (int gi = 0; gi < ngroups; ++gi) {
+    H_DMA_BARRIER();  // group gi landed; everyone is done with the other half
+    if (gi + 1 < ngroups) { H_RM_FETCH(gi + 1, (gi + 1) & 1); }
+#pragma unroll
+    for (int k = 0; k < kHRmGroup; ++k) {
+      if (gi * kHRmGroup + k < nc) {
+        const char* buf = lds + ((gi & 1) * kHRmGroup + k) * kSlot;
+        f32x16 sa;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sa[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const int off = j * 256 + (((2 * s + h) ^ swz16(j)) << 4);
+          const f16x8 a1 = *reinterpret_cast<const f16x8*>(buf + off);
+          if (full) {
+            const f16x8 a2 = *reinterpret_cast<const f16x8*>(buf + off + kPlaneBytes);
+            sa = H_MFMA(a2, bx0[s], sa);
+            sa = H_MFMA(a1, bx1[s], sa);
+          }
+          sa = H_MFMA(a1, bx0[s], sa);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, sa[r]);
+      }
+    }
+  }
+#undef H_RM_FETCH
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  if (h == 0) part_m[(int64_t)split * B + xrow] = m * fabsf(sl2s) - kHPexp;
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// Pass Q: owned = Q rows (B operand of both products, 64 VGPRs), streamed = C rows in 32-row chunks through a 3-deep
+// LDS ring.  Per chunk and wave: 24 MFMAs of S^T (k = d) + 24 of O^T (k = streamed row), software-pipelined exactly as
+// inbatch3_kernel: the S^T MFMAs of chunk t + 1 carry the exp / two-plane split / P store of chunk t between them, the
+// O^T MFMAs of chunk t carry the second k-step's A fragments and the DMA of chunk t + 2.  The unnormalised
+// probabilities p' = exp2(s sl2 - M_i) go to Pmat (f32, 32 x 32 tiles, transposed) for pass C.
+// -----------------------------------------------------------------------------------------------------------------
+#define H_S_PHASE(NBUF, SA, VALU_ON)                                                                      \
+  {                                                                                                       \
+    _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) SA[r_] = 0.f;                                       \
+    const char* ap0_ = (NBUF) + j * 256;                                                                  \
+    const int sw_ = swz16(j);                                                                             \
+    f16x8 a1_ = *reinterpret_cast<const f16x8*>(ap0_ + ((h ^ sw_) << 4));                                 \
+    f16x8 a2_ = *reinterpret_cast<const f16x8*>(ap0_ + ((h ^ sw_) << 4) + kPlaneBytes);                   \
+    _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) {                                                    \
+      f16x8 n1_ = a1_, n2_ = a2_;                                                                         \
+      if (s_ < 7) {                                                                                       \
+        const int off_ = (((2 * (s_ + 1) + h) ^ sw_) << 4);                                               \
+        n1_ = *reinterpret_cast<const f16x8*>(ap0_ + off_);                                               \
+        n2_ = *reinterpret_cast<const f16x8*>(ap0_ + off_ + kPlaneBytes);                                 \
+      }                                                                                                   \
+      float e0_ = 0.f, e1_ = 0.f;                                                                         \
+      f16x2 pa_ = {0, 0};                                                                                 \
+      H_SB();                                                                                             \
+      SA = H_MFMA(a2_, bx[0][s_], SA);                                                                    \
+      H_SB();                                                                                             \
+      if (VALU_ON) {                                                                                      \
+        e0_ = __builtin_amdgcn_exp2f(fmaf(p[2 * s_], sl2, -refv));                                        \
+        e1_ = __builtin_amdgcn_exp2f(fmaf(p[2 * s_ + 1], sl2, -refv));                                    \
+        trh_frag_n<0>(s_, ta2_, trc_); /* one of the 8 G = 0 fragments of the coming O^T phase */          \
+      }                                                                                                   \
+      H_SB();                                                                                             \
+      SA = H_MFMA(a1_, bx[1][s_], SA);                                                                    \
+      H_SB();                                                                                             \
+      if (VALU_ON) {                                                                                      \
+        pa_ = pk_f16(e0_, e1_);                                                                           \
+        l += e0_ + e1_;                                                                                   \
+        H_P_ST(((2 * s_) & 3) + 8 * ((2 * s_) >> 2), e0_);                                                \
+        H_P_ST(((2 * s_ + 1) & 3) + 8 * ((2 * s_ + 1) >> 2), e1_);                                        \
+      }                                                                                                   \
+      H_SB();                                                                                             \
+      SA = H_MFMA(a1_, bx[0][s_], SA);                                                                    \
+      H_SB();                                                                                             \
+      if (VALU_ON) {                                                                                      \
+        const f16x2 pq_ = pk_f16(e0_ - (float)pa_[0], e1_ - (float)pa_[1]);                               \
+        pw[0][s_] = __builtin_bit_cast(uint32_t, pa_);                                                    \
+        pw[1][s_] = __builtin_bit_cast(uint32_t, pq_);                                                    \
+      }                                                                                                   \
+      H_SB();                                                                                             \
+      a1_ = n1_; a2_ = n2_;                                                                               \
+    }                                                                                                     \
+    if (VALU_ON) pst_u += nch * 4096;                                                                     \
+  }
+// O^T += Y_chunk^T P^T (see ESR_O_ROW): rows in the order small terms first
+#define H_O_ROW(PL_A, PL_P, G)                                                                            \
+  _Pragma("unroll") for (int db_ = 0; db_ < 4; ++db_)                                                     \
+    acc[db_] = H_MFMA(ta2_[G][db_][PL_A], pb[PL_P][G], acc[db_]);
+#define H_O_G1(F0, F1) { _Pragma("unroll") for (int f_ = (F0); f_ < (F1); ++f_) trh_frag_n<1>(f_, ta2_, trc_); }
+#define H_PB()                                                                                            \
+  f16x8 pb[2][2];                                                                                         \
+  _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_)                                                        \
+    _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_) {                                                    \
+      const u32x4 u_ = {pw[q_][4 * g_], pw[q_][4 * g_ + 1], pw[q_][4 * g_ + 2], pw[q_][4 * g_ + 3]};      \
+      pb[q_][g_] = __builtin_bit_cast(f16x8, u_);                                                         \
+    }
+#define H_O_PHASE(DMA_ON, DBUF)                                                                           \
+  {                                                                                                       \
+    H_PB();                                                                                               \
+    H_TR_WAIT(); /* the G = 0 fragments were requested during the S^T phase (or by the burst below) */    \
+    H_SB(); H_O_ROW(1, 0, 0); H_SB(); H_O_G1(0, 3); if (DMA_ON) { H_DP(0, g0, DBUF); }                    \
+    H_SB(); H_O_ROW(0, 1, 0); H_SB(); H_O_G1(3, 6); if (DMA_ON) { H_DP(1, g1, DBUF); }                    \
+    H_SB(); H_O_ROW(0, 0, 0); H_SB(); H_O_G1(6, 8); if (DMA_ON) { H_DP(2, g2, DBUF); }                    \
+    H_TR_WAIT();                                                                                          \
+    H_SB(); H_O_ROW(1, 0, 1); H_SB(); if (DMA_ON) { H_DP(3, g3, DBUF); }                                  \
+    H_SB(); H_O_ROW(0, 1, 1); H_SB();                                                                     \
+    H_SB(); H_O_ROW(0, 0, 1); H_SB();                                                                     \
+    if (DMA_ON) H_DMA_ADVANCE();                                                                          \
+  }
+#define H_TR_BASES(BUF)                                                                                   \
+  {                                                                                                       \
+    const uint32_t slot_ = (uint32_t)((BUF) - lds);                                                       \
+    _Pragma("unroll") for (int db_ = 0; db_ < 4; ++db_) { trc_[db_][0] = trb_[db_][0] + slot_; trc_[db_][1] = trb_[db_][1] + slot_; } \
+  }
+#define H_TR_SETUP()                                                                                      \
+  const int tr_a = (lane & 15) >> 2;                                                                      \
+  const int tr_e = (2 * ((lane >> 4) & 1)) + ((lane & 3) >> 1), tr_low = (lane & 1) * 8;                  \
+  const int tr_row0 = (4 * h + tr_a) * 256, tr_row1 = (4 * h + 8 + tr_a) * 256;                           \
+  const int tr_l0 = ((tr_e ^ (h & 3)) << 4) | tr_low, tr_l1 = ((tr_e ^ ((h + 2) & 3)) << 4) | tr_low;     \
+  uint32_t trb_[4][2], trc_[4][2];                                                                        \
+  _Pragma("unroll") for (int db = 0; db < 4; ++db) {                                                      \
+    trb_[db][0] = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds + tr_row0 + (((db ^ tr_a) << 6) | tr_l0); \
+    trb_[db][1] = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds + tr_row1 + (((db ^ tr_a) << 6) | tr_l1); \
+  }
+
+__global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __restrict__ Xr, const _Float16* __restrict__ Yr,
+                                                         int64_t B, int nsplit, float sl2_in,
+                                                         const float* __restrict__ sc, const float* __restrict__ ref,
+                                                         float* __restrict__ part_O, float* __restrict__ part_l,
+                                                         float* __restrict__ Pmat) {
+  __shared__ __attribute__((aligned(16))) char lds[kHBufs * kHBufBytes];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  H_TR_SETUP();
+  const int ob = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
+  const int64_t xrow = (int64_t)ob * k3Owned + w * 32 + j;
+  const int nc = (int)(B / k3Chunk) / nsplit;
+  const int64_t c0 = (int64_t)split * nc;
+  const int64_t nch = B / 32;
+  const float sl2 = sl2_in * sc[0];  // the planes carry 2^(eq + ec) S
+
+  // P'^T tiles: see inbatch3_kernel (PMODE 1)
+  char* pst_u = reinterpret_cast<char*>(Pmat) + (c0 * nch + (xrow >> 5)) * 4096;
+  const uint32_t pst_v = (uint32_t)((4 * h * 32 + j) * 4);
+#define H_P_ST(K, VAL) *reinterpret_cast<float*>(pst_u + (K) * 128 + pst_v) = (VAL)
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[db][r] = 0.f;
+  float l = 0.f;
+
+  int dpos = 0;
+  const char* const baseY = reinterpret_cast<const char*>(Yr);
+  uint32_t g0 = dmah_off0<0>(B, c0, t), g1 = dmah_off0<1>(B, c0, t), g2 = dmah_off0<2>(B, c0, t),
+           g3 = dmah_off0<3>(B, c0, t);
+  H_DMA_CHUNK(lds);
+  if (nc > 1) H_DMA_CHUNK(lds + kHBufBytes);
+  f16x8 bx[2][8];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      bx[p][s] = *reinterpret_cast<const f16x8*>(Xr + ((int64_t)p * B + xrow) * k3D + 16 * s + 8 * h);
+  float refv;
+  {
+    float rv[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) rv[s] = s < nsplit ? ref[(int64_t)s * B + xrow] : -INFINITY;
+    refv = rv[0];
+#pragma unroll
+    for (int s = 1; s < 8; ++s) refv = fmaxf(refv, rv[s]);
+  }
+  H_DMA_BARRIER();
+
+  f32x16 sa;
+  float p[16];
+  uint32_t pw[2][8];
+  f16x8 ta2_[2][4][2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) p[r] = 0.f;
+  H_S_PHASE(lds, sa, false);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) p[r] = sa[r];
+
+  int cur = 0;
+  for (int it = 0; it + 2 < nc; ++it) {
+    const int nxt = cur == kHBufs - 1 ? 0 : cur + 1;
+    const int nn = nxt == kHBufs - 1 ? 0 : nxt + 1;
+    H_DMA_BARRIER();
+    const char* buf = lds + cur * kHBufBytes;
+    const char* nbuf = lds + nxt * kHBufBytes;
+    char* dbuf = lds + nn * kHBufBytes;
+    H_TR_BASES(buf);
+    H_S_PHASE(nbuf, sa, true);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[r] = sa[r];
+    H_O_PHASE(true, dbuf);
+    cur = nxt;
+  }
+  if (nc >= 2) {
+    const int nxt = cur == kHBufs - 1 ? 0 : cur + 1;
+    H_DMA_BARRIER();
+    const char* buf = lds + cur * kHBufBytes;
+    const char* nbuf = lds + nxt * kHBufBytes;
+    H_TR_BASES(buf);
+    H_S_PHASE(nbuf, sa, true);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[r] = sa[r];
+    H_O_PHASE(false, lds);
+    cur = nxt;
+  }
+  {  // last chunk: nothing left to prefetch; run its exp / split alone
+    H_DMA_BARRIER();
+    const char* buf = lds + cur * kHBufBytes;
+    H_TR_BASES(buf);
+#pragma unroll
+    for (int f = 0; f < 8; ++f) trh_frag_n<0>(f, ta2_, trc_);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float e0 = __builtin_amdgcn_exp2f(fmaf(p[2 * s], sl2, -refv));
+      const float e1 = __builtin_amdgcn_exp2f(fmaf(p[2 * s + 1], sl2, -refv));
+      l += e0 + e1;
+      const f16x2 pa = pk_f16(e0, e1);
+      const f16x2 pq = pk_f16(e0 - (float)pa[0], e1 - (float)pa[1]);
+      pw[0][s] = __builtin_bit_cast(uint32_t, pa);
+      pw[1][s] = __builtin_bit_cast(uint32_t, pq);
+      H_P_ST(((2 * s) & 3) + 8 * ((2 * s) >> 2), e0);
+      H_P_ST(((2 * s + 1) & 3) + 8 * ((2 * s + 1) >> 2), e1);
+    }
+    H_O_PHASE(false, lds);
+  }
+#undef H_P_ST
+  float* orow = part_O + ((int64_t)split * B + xrow) * k3D;
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float4*>(orow + 32 * db + 8 * q + 4 * h) =
+          make_float4(acc[db][4 * q], acc[db][4 * q + 1], acc[db][4 * q + 2], acc[db][4 * q + 3]);
+  const float ltot = l + __shfl_xor(l, 32, 64);
+  if (h == 0) part_l[(int64_t)split * B + xrow] = ltot;
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// Pass C: owned = C rows j, streamed = Q rows i; reads P'^T tiles (pass Q) and 2^14 / l'_i (merge<Q>), forms the true
+// probabilities * 2^14 in two fp16 planes and runs the O^T phase alone (24 MFMAs per chunk and wave).  Same software
+// pipeline as inbatch3_pc_kernel; two (or more) workgroups per CU.
+// -----------------------------------------------------------------------------------------------------------------
+#define H_DMA_LSE(BUF)                                                                                    \
+  __builtin_amdgcn_global_load_lds((gptr_t)(ref + (c0 + dpos) * 32 + (lane & 31)), (lptr_t)((BUF) + kHLseOff), 4, 0, 0);
+#define H_LOAD_REFS(BUF)                                                                                  \
+  _Pragma("unroll") for (int g4_ = 0; g4_ < 4; ++g4_) {                                                   \
+    const float4 lv_ = *reinterpret_cast<const float4*>((BUF) + kHLseOff + (8 * g4_ + 4 * h) * 4);         \
+    rf[4 * g4_] = lv_.x; rf[4 * g4_ + 1] = lv_.y; rf[4 * g4_ + 2] = lv_.z; rf[4 * g4_ + 3] = lv_.w;       \
+  }
+__global__ __launch_bounds__(256, 2) void inbatch2h_pc_kernel(const _Float16* __restrict__ Yr, int64_t B, int nsplit,
+                                                             const float* __restrict__ ref,
+                                                             const float* __restrict__ Pmat,
+                                                             float* __restrict__ part_O) {
+  __shared__ __attribute__((aligned(16))) char lds[kHBufs * kHBufBytes];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  H_TR_SETUP();
+  const int ob = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
+  const int64_t xrow = (int64_t)ob * k3Owned + w * 32 + j;
+  const int nc = (int)(B / k3Chunk) / nsplit;
+  const int64_t c0 = (int64_t)split * nc;
+  const int64_t nch = B / 32;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[db][r] = 0.f;
+
+  int dpos = 0;
+  const char* const baseY = reinterpret_cast<const char*>(Yr);
+  uint32_t g0 = dmah_off0<0>(B, c0, t), g1 = dmah_off0<1>(B, c0, t), g2 = dmah_off0<2>(B, c0, t),
+           g3 = dmah_off0<3>(B, c0, t);
+  { H_DMA_LSE(lds); H_DMA_CHUNK(lds); }
+  if (nc > 1) { H_DMA_LSE(lds + kHBufBytes); H_DMA_CHUNK(lds + kHBufBytes); }
+  const float* pcol = Pmat + (xrow >> 5) * nch * 1024 + j * 32 + 4 * h;
+  float pn[16], p1[16], rf[16];
+  uint32_t pw[2][8], pwn[2][8];
+  f16x8 ta2_[2][4][2];
+  uint32_t trn_[4][2];
+#define H_P_LOAD(CH)                                                                                      \
+  {                                                                                                       \
+    const float* base_ = pcol + (c0 + (CH)) * 1024;                                                       \
+    _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                    \
+      const float4 v_ = *reinterpret_cast<const float4*>(base_ + 8 * g_);                                 \
+      pn[4 * g_] = v_.x; pn[4 * g_ + 1] = v_.y; pn[4 * g_ + 2] = v_.z; pn[4 * g_ + 3] = v_.w;             \
+    }                                                                                                     \
+  }
+#define H_PC_SPLIT1(PW, S)                                                                                \
+  {                                                                                                       \
+    const float e0_ = p1[2 * (S)] * rf[2 * (S)], e1_ = p1[2 * (S) + 1] * rf[2 * (S) + 1];                 \
+    const f16x2 pa_ = pk_f16(e0_, e1_);                                                                   \
+    const f16x2 pq_ = pk_f16(e0_ - (float)pa_[0], e1_ - (float)pa_[1]);                                   \
+    PW[0][S] = __builtin_bit_cast(uint32_t, pa_);                                                         \
+    PW[1][S] = __builtin_bit_cast(uint32_t, pq_);                                                         \
+  }
+#define H_PC_NEXT_G0(F0, F1) { _Pragma("unroll") for (int f_ = (F0); f_ < (F1); ++f_) trh_frag_n<0>(f_, ta2_, trn_); }
+// one chunk: O^T MFMAs of chunk it with, threaded through them, this chunk's G = 1 fragments, the DMA of chunk it + 2,
+// the scale + split of chunk it + 1 and (behind the G = 0 rows) the G = 0 fragments of chunk it + 1
+#define H_PC_ITER(NBUF, DBUF, DMA_ON, NEXT_ON)                                                            \
+  {                                                                                                       \
+    H_PB();                                                                                               \
+    if (NEXT_ON) {                                                                                        \
+      _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) p1[r_] = pn[r_];                                  \
+      H_LOAD_REFS(NBUF);                                                                                  \
+      const uint32_t slot_ = (uint32_t)((NBUF) - lds);                                                    \
+      _Pragma("unroll") for (int db_ = 0; db_ < 4; ++db_) { trn_[db_][0] = trb_[db_][0] + slot_; trn_[db_][1] = trb_[db_][1] + slot_; } \
+    }                                                                                                     \
+    if (DMA_ON) { H_P_LOAD(pl_next); ++pl_next; H_DMA_LSE(DBUF); }                                        \
+    H_TR_WAIT();                                                                                          \
+    H_SB(); H_O_ROW(1, 0, 0); H_SB(); H_O_G1(0, 3); if (DMA_ON) { H_DP(0, g0, DBUF); }                    \
+    if (NEXT_ON) { H_PC_SPLIT1(pwn, 0); H_PC_SPLIT1(pwn, 1); }                                            \
+    H_SB(); H_O_ROW(0, 1, 0); H_SB(); H_O_G1(3, 6); if (DMA_ON) { H_DP(1, g1, DBUF); }                    \
+    if (NEXT_ON) { H_PC_SPLIT1(pwn, 2); H_PC_SPLIT1(pwn, 3); }                                            \
+    H_SB(); H_O_ROW(0, 0, 0); H_SB(); H_O_G1(6, 8); if (DMA_ON) { H_DP(2, g2, DBUF); }                    \
+    if (NEXT_ON) { H_PC_SPLIT1(pwn, 4); H_PC_SPLIT1(pwn, 5); }                                            \
+    H_TR_WAIT();                                                                                          \
+    H_SB(); H_O_ROW(1, 0, 1); H_SB(); if (DMA_ON) { H_DP(3, g3, DBUF); }                                  \
+    if (NEXT_ON) { H_PC_NEXT_G0(0, 4); H_PC_SPLIT1(pwn, 6); }                                             \
+    H_SB(); H_O_ROW(0, 1, 1); H_SB();                                                                     \
+    if (NEXT_ON) { H_PC_SPLIT1(pwn, 7); }                                                                 \
+    H_SB(); H_O_ROW(0, 0, 1); H_SB();                                                                     \
+    if (NEXT_ON) { H_PC_NEXT_G0(4, 8); }                                                                  \
+    if (DMA_ON) H_DMA_ADVANCE();                                                                          \
+    if (NEXT_ON) {                                                                                        \
+      _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_)                                                    \
+        _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) pw[q_][s_] = pwn[q_][s_];                        \
+    }                                                                                                     \
+  }
+  int pl_next = 2;
+  H_P_LOAD(0);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) p1[r] = pn[r];
+  if (nc > 1) H_P_LOAD(1);
+  H_DMA_BARRIER();
+  H_TR_BASES(lds);
+#pragma unroll
+  for (int f = 0; f < 8; ++f) trh_frag_n<0>(f, ta2_, trc_);
+  H_LOAD_REFS(lds);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) H_PC_SPLIT1(pw, s);
+
+  int cur = 0;
+  for (int it = 0; it + 2 < nc; ++it) {
+    const int nxt = cur == kHBufs - 1 ? 0 : cur + 1;
+    const int nn = nxt == kHBufs - 1 ? 0 : nxt + 1;
+    if (it > 0) H_DMA_BARRIER();
+    const char* buf = lds + cur * kHBufBytes;
+    const char* nbuf = lds + nxt * kHBufBytes;
+    char* dbuf = lds + nn * kHBufBytes;
+    H_TR_BASES(buf);
+    H_PC_ITER(nbuf, dbuf, true, true);
+    cur = nxt;
+  }
+  if (nc >= 2) {
+    const int nxt = cur == kHBufs - 1 ? 0 : cur + 1;
+    if (nc > 2) H_DMA_BARRIER();
+    const char* buf = lds + cur * kHBufBytes;
+    const char* nbuf = lds + nxt * kHBufBytes;
+    H_TR_BASES(buf);
+    H_PC_ITER(nbuf, lds, false, true);
+    cur = nxt;
+  }
+  {
+    const char* buf = lds + cur * kHBufBytes;
+    H_TR_BASES(buf);
+    H_PC_ITER(buf, lds, false, false);
+  }
+  float* orow = part_O + ((int64_t)split * B + xrow) * k3D;
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float4*>(orow + 32 * db + 8 * q + 4 * h) =
+          make_float4(acc[db][4 * q], acc[db][4 * q + 1], acc[db][4 * q + 2], acc[db][4 * q + 3]);
+}
+
+struct InbatchHWs {
+  _Float16 *Qh, *Ch;
+  float *part_O, *part_m, *part_l, *lse2, *invl, *Pmat, *nrm, *amax, *sc;
+  unsigned long long* loss_acc;
+};
+constexpr int64_t kHMaxB = 16384;  // B x B x 4 bytes of stored probabilities: 1 GiB
+
+static size_t inbatch2h_ws_layout(int64_t B, char* base, InbatchHWs* ws) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += align_up(bytes, 256);
+    return p;
+  };
+  const size_t planes = (size_t)2 * B * k3D * 2;
+  InbatchHWs w;
+  w.Qh = (_Float16*)take(planes);
+  w.Ch = (_Float16*)take(planes);
+  w.part_O = (float*)take((size_t)8 * B * k3D * 4);
+  w.part_m = (float*)take((size_t)8 * B * 4);
+  w.part_l = (float*)take((size_t)8 * B * 4);
+  w.lse2 = (float*)take((size_t)B * 4);
+  w.invl = (float*)take((size_t)B * 4);
+  w.Pmat = (float*)take((size_t)B * B * 4);
+  w.loss_acc = (unsigned long long*)take(sizeof(unsigned long long) * 16 * (1 + kLossWords));
+  w.nrm = (float*)take((size_t)2 * (B / k3Chunk) * 4 * sizeof(float));
+  w.amax = (float*)take((size_t)2 * (B / k3Chunk) * sizeof(float));
+  w.sc = (float*)take(kHScaleWords * sizeof(float));
+  if (ws) *ws = w;
+  return off;
+}
+
+// largest split count <= 8 that divides the chunk count and keeps the grid near `per_cu` workgroups per CU
+static int inbatch2h_nsplit(int64_t B, int per_cu) {
+  const int64_t owned_blocks = B / k3Owned, nchunks = B / k3Chunk;
+  int best = 1;
+  for (int s = 1; s <= 8; ++s)
+    if (nchunks % s == 0 && owned_blocks * s <= 320 * per_cu) best = s;
+  return best;
+}
+
+}  // namespace esr
+
+using namespace esr;
+
+extern "C" {
+
+size_t esr_inbatch2h_workspace_bytes(int64_t B, int D) {
+  (void)D;
+  if (B <= 0 || B > kHMaxB) return 256;
+  return inbatch2h_ws_layout(B, nullptr, nullptr);
+}
+
+static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* gq_rows, const int32_t* gc_rows, int64_t B,
+                         int D, float scale, float regularization, float batch_size, float* loss, float* lse,
+                         float* gQ, float* gC, void* workspace, size_t workspace_bytes, esr_stream_t stream) {
+  if (!(B > 0 && B % k3Owned == 0 && B <= kHMaxB)) {
+    set_error("%s: B=%lld must be a positive multiple of 128, at most %lld (larger batches: the bf16x3 entry point)",
+              who, (long long)B, (long long)kHMaxB);
+    return ESR_EINVAL;
+  }
+  if (D != k3D) {
+    set_error("%s: D=%d not supported (128 only; use the f32 entry point)", who, D);
+    return ESR_EINVAL;
+  }
+  if (!(Qs.base && Cs.base && loss && gQ && gC)) {
+    set_error("%s: null pointer", who);
+    return ESR_EINVAL;
+  }
+  if (batch_size == 0.f) {
+    set_error("%s: batch_size must be non-zero", who);
+    return ESR_EINVAL;
+  }
+  if ((((uintptr_t)Qs.base | (uintptr_t)Cs.base | (uintptr_t)gQ | (uintptr_t)gC) & 15) != 0) {
+    set_error("%s: matrices must be 16-byte aligned", who);
+    return ESR_EINVAL;
+  }
+  if (!workspace || workspace_bytes < esr_inbatch2h_workspace_bytes(B, D) || ((uintptr_t)workspace & 15)) {
+    set_error("%s: workspace %zu bytes < %zu required (or misaligned)", who, workspace_bytes,
+              esr_inbatch2h_workspace_bytes(B, D));
+    return ESR_EWORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  InbatchHWs ws;
+  inbatch2h_ws_layout(B, (char*)workspace, &ws);
+  const float inv_bs = 1.0f / batch_size, sl2 = scale * k3Log2e;
+  const int nchunks = (int)(B / k3Chunk);
+  const int nsplit_q = inbatch2h_nsplit(B, 1);
+  const char* pcs = getenv("ESR_IB2H_PC_PER_CU");
+  const int nsplit_c = inbatch2h_nsplit(B, pcs ? std::max(1, atoi(pcs)) : 2);
+  const int grid_q = (int)(B / k3Owned) * nsplit_q, grid_c = (int)(B / k3Owned) * nsplit_c;
+  const int mgrid = (int)std::min<int64_t>(k3MergeBlocks, cdiv(B, kBlock / 32));
+  hipLaunchKernelGGL(absmax2h_kernel, dim3(nchunks, 2), dim3(256), 0, st, Qs, Cs, ws.amax);
+  hipLaunchKernelGGL(split2h_kernel, dim3(nchunks, 2), dim3(256), 0, st, Qs, Cs, B, ws.Qh, ws.Ch, (const float*)ws.amax,
+                     ws.nrm, ws.sc, ws.loss_acc);
+  hipLaunchKernelGGL(rowmax2h_kernel, dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Qh, (const _Float16*)ws.Ch, B,
+                     nsplit_q, sl2, (const float*)ws.nrm, (const float*)ws.sc, ws.part_m);
+  hipLaunchKernelGGL(inbatch2h_q_kernel, dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Qh, (const _Float16*)ws.Ch,
+                     B, nsplit_q, sl2, (const float*)ws.sc, (const float*)ws.part_m, ws.part_O, ws.part_l, ws.Pmat);
+  // O_Q' = 2^ec 2^14 sum p c, l' = 2^14 l: o / l needs 2^-ec (sc[1]); the stored normaliser carries pass C's 2^14
+  hipLaunchKernelGGL((inbatch3_merge_kernel<true>), dim3(mgrid), dim3(kBlock), 0, st, Qs, Cs, gq_rows, B, nsplit_q,
+                     (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale, regularization,
+                     inv_bs, ws.lse2, lse, gQ, ws.loss_acc, 1.0 / (double)batch_size, loss, ws.invl,
+                     (const float*)(ws.sc + 1), ldexpf(1.f, (int)kHPexp));
+  hipLaunchKernelGGL(inbatch2h_pc_kernel, dim3(grid_c), dim3(256), 0, st, (const _Float16*)ws.Qh, B, nsplit_c,
+                     (const float*)ws.invl, (const float*)ws.Pmat, ws.part_O);
+  // O_C' = 2^(eq + 14) sum_i (p_ij / l_i) q_i
+  hipLaunchKernelGGL((inbatch3_merge_kernel<false>), dim3(mgrid), dim3(kBlock), 0, st, Cs, Qs, gc_rows, B, nsplit_c,
+                     (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale, regularization,
+                     inv_bs, ws.lse2, (float*)nullptr, gC, ws.loss_acc, 1.0 / (double)batch_size, loss,
+                     (float*)nullptr, (const float*)(ws.sc + 2), 1.0f);
+  return check_launch(who);
+}
+
+int esr_inbatch_softmax_fwd_bwd_f16x2(const float* Q, const float* C, int64_t B, int D, float scale,
+                                      float regularization, float batch_size, float* loss, float* lse, float* gQ,
+                                      float* gC, void* workspace, size_t workspace_bytes, esr_stream_t stream) {
+  return inbatch2h_run("esr_inbatch_softmax_fwd_bwd_f16x2", RowSrc{Q, nullptr, 0}, RowSrc{C, nullptr, 0}, nullptr,
+                       nullptr, B, D, scale, regularization, batch_size, loss, lse, gQ, gC, workspace, workspace_bytes,
+                       stream);
+}
+
+int esr_inbatch_towers_fwd_bwd_f16x2(const void* query_table, int64_t Vq, const void* cand_table, int64_t Vc, int dtype,
+                                     int D, const int32_t* query_ids, const int32_t* cand_ids, const int32_t* gq_rows,
+                                     const int32_t* gc_rows, int64_t B, float scale, float regularization,
+                                     float batch_size, float* loss, float* lse, float* gQ, float* gC, void* workspace,
+                                     size_t workspace_bytes, esr_stream_t stream) {
+  ESR_REQUIRE(Vq > 0 && Vc > 0 && query_ids && cand_ids, "esr_inbatch_towers_fwd_bwd_f16x2: bad tables / ids");
+  ESR_REQUIRE(dtype == ESR_F32 || dtype == ESR_BF16, "esr_inbatch_towers_fwd_bwd_f16x2: bad dtype %d", dtype);
+  return inbatch2h_run("esr_inbatch_towers_fwd_bwd_f16x2", RowSrc{query_table, query_ids, dtype == ESR_BF16},
+                       RowSrc{cand_table, cand_ids, dtype == ESR_BF16}, gq_rows, gc_rows, B, D, scale, regularization,
+                       batch_size, loss, lse, gQ, gC, workspace, workspace_bytes, stream);
+}
+
+}  // extern "C"

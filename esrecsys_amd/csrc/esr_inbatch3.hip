@@ -29,128 +29,9 @@
 //                     chunk.
 //   merge kernel    : sums the nsplit partial (l, O), applies the -y_i diagonal, the regulariser gradient
 //                     and the 1/batch_size, and reduces the loss.
-#include "esr_common.h"
-#include <stdlib.h>
+#include "esr_inbatch_mfma.h"
 
 namespace esr {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int k3D = 128;
-constexpr int k3Chunk = 32;
-constexpr int k3Waves = 4;
-constexpr int k3Owned = 32 * k3Waves;  // owned rows per workgroup
-constexpr float k3Log2e = 1.4426950408889634f;
-constexpr float k3Ln2 = 0.6931471805599453f;
-
-// LDS image of one 32-row chunk: three row-major planes [32 rows][256 B] (24 KB; without kUseTr three transposed
-// planes [128 d][64 B] follow, 48 KB), filled by direct global->LDS DMA (global_load_lds_dwordx4: no staging VGPRs, no
-// ds_write).  The DMA destination is lane-linear, so bank conflicts are removed by an XOR swizzle applied
-// to the per-lane SOURCE address and again on the ds_read_b128 address (same involution on both sides):
-//   row-major   : 16-B segment index ^= swz16(row)
-//   transposed  : 16-B segment index ^= ((d >> 2) & 3)
-constexpr int kPlaneBytes = 8192;
-// kUseTr: the O^T phase takes its A operand (Y^T) from the ROW-MAJOR image with the transposing LDS read
-// ds_read_b64_tr_b16 (four k-rows x 16 d-columns per 16-lane group, delivered column-per-lane), so the transposed
-// image -- half of every chunk's DMA pieces and half of the LDS ring -- is not needed.
-#ifndef ESR_IB3_USE_TR
-#define ESR_IB3_USE_TR 1
-#endif
-constexpr bool kUseTr = ESR_IB3_USE_TR != 0;
-constexpr int kTOff = 3 * kPlaneBytes;   // 24576 (transposed planes, only without kUseTr)
-constexpr int kLseOff = (kUseTr ? 3 : 6) * kPlaneBytes;  // 128 B of streamed-row lse (pass C) behind the planes
-constexpr int kBufBytes = kLseOff + 256;
-// 16-B segment swizzle of a row-major row.  j & 15 serves the ds_read_b128 fragment reads (16 distinct rows per lane
-// group); the transposing reads touch 4 consecutive rows x 4 consecutive segments per 16-lane group and need the 4
-// rows on 4 different segment quads: swap the two bit pairs (still a bijection on 0..15, so b128 stays conflict-free).
-__device__ __forceinline__ constexpr int swz16(int row) {
-  return kUseTr ? (((row & 3) << 2) | ((row >> 2) & 3)) : (row & 15);
-}
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-// ds_read_b64_tr_b16 as inline assembly (see ESR_O_LOAD for why not the builtin); result valid after lgkmcnt(0)
-template <int OFF>
-__device__ __forceinline__ s16x4 tr_read(uint32_t lds_addr) {
-  s16x4 v;
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF));
-  return v;
-}
-// A fragment F (0..11: plane (F / 4 + 2) % 3 -- the order the O^T rows use them -- column block F % 4) of k-step G:
-// two transposing reads from the per-lane bases of this chunk (tc[db][0 / 1], see the kernel), the plane and
-// k-step as the instruction's immediate offset so that no address arithmetic is left between the MFMAs.
-template <int G, int F, class TA>
-__device__ __forceinline__ void tr_frag(TA& ta, const uint32_t (&tc)[4][2]) {
-  constexpr int PL = (F / 4 + 2) % 3, DB = F % 4, OFF = PL * kPlaneBytes + 16 * G * 256;
-  const s16x4 lo = tr_read<OFF>(tc[DB][0]), hi = tr_read<OFF>(tc[DB][1]);
-  const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  ta[G][DB][PL] = __builtin_bit_cast(bf16x8, both);
-}
-template <int G, class TA>
-__device__ __forceinline__ void tr_frag_n(int f, TA& ta, const uint32_t (&tc)[4][2]) {  // f is an unrolled constant
-  switch (f) {
-    case 0: tr_frag<G, 0>(ta, tc); break;
-    case 1: tr_frag<G, 1>(ta, tc); break;
-    case 2: tr_frag<G, 2>(ta, tc); break;
-    case 3: tr_frag<G, 3>(ta, tc); break;
-    case 4: tr_frag<G, 4>(ta, tc); break;
-    case 5: tr_frag<G, 5>(ta, tc); break;
-    case 6: tr_frag<G, 6>(ta, tc); break;
-    case 7: tr_frag<G, 7>(ta, tc); break;
-    case 8: tr_frag<G, 8>(ta, tc); break;
-    case 9: tr_frag<G, 9>(ta, tc); break;
-    case 10: tr_frag<G, 10>(ta, tc); break;
-    default: tr_frag<G, 11>(ta, tc); break;
-  }
-}
-constexpr int k3Bufs = 3;
-constexpr int kLossWords = 64;        // first-level accumulators of the merge kernels' loss reduction
-constexpr int k3MergeBlocks = 1024;  // most workgroups of a merge launch (= loss partials per launch)
-
-__device__ __forceinline__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-// position of streamed row `row` (0..31) inside a transposed chunk: pos = 16 g + 8 h + k  <->
-// row = (k & 3) + 8 (2 g + (k >> 2)) + 4 h   (the S^T accumulator order)
-__device__ __forceinline__ int row_to_pos(int row) {
-  const int k_lo = row & 3, h = (row >> 2) & 1, k_hi = (row >> 3) & 1, g = row >> 4;
-  return 16 * g + 8 * h + 4 * k_hi + k_lo;
-}
-
-__device__ __forceinline__ void split3(float x, __bf16& a, __bf16& b, __bf16& c) {
-  a = (__bf16)x;
-  const float r1 = x - (float)a;
-  b = (__bf16)r1;
-  c = (__bf16)(r1 - (float)b);
-}
-
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-// {bf16(lo), bf16(hi)} packed in one dword (v_cvt_pk_bf16_f32, round-to-nearest-even)
-__device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
-  f32x2 v = {lo, hi};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ float pk_lo(uint32_t u) { return __uint_as_float(u << 16); }
-__device__ __forceinline__ float pk_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
-
-// ---------------------------------------------------------------------------------------------------
-// Where the rows of Q / C come from: a dense [B, 128] f32 matrix (idx == null), or rows idx[i] of a tower table
-// (f32 or bf16) -- the gather is then folded into the split pre-pass and the merge kernels, and the step needs no
-// materialised Q / C at all.
-struct RowSrc {
-  const void* base;
-  const int32_t* idx;
-  int bf16;
-};
-__device__ __forceinline__ float4 rowsrc_load4(const RowSrc& s, int64_t row, int d) {  // elements d .. d+3 of row
-  const int64_t r = s.idx ? (int64_t)s.idx[row] : row;
-  if (s.bf16) {
-    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(s.base) + r * k3D + d);
-    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
-                       __uint_as_float(u.y & 0xFFFF0000u));
-  }
-  return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(s.base) + r * k3D + d);
-}
 
 // split3 pre-pass: one 256-thread block per 32-row chunk of one matrix (blockIdx.y selects Q or C).
 // ---------------------------------------------------------------------------------------------------
@@ -227,8 +108,6 @@ __global__ __launch_bounds__(256) void split3_kernel(RowSrc X0, RowSrc X1,
 // (wave-uniform base + lane * 16), and its source segment is un-swizzled here.  Both image kinds advance by
 // exactly 8192 bytes per chunk, so each thread keeps 12 source pointers and bumps them (no per-chunk
 // address arithmetic beyond one 64-bit add per piece).
-typedef __attribute__((address_space(1))) const void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
 
 // byte offset of piece K of chunk `chunk` from the base of its image array (Yr for K < 6, Yt for K >= 6)
 template <int K>
@@ -281,6 +160,8 @@ __device__ __forceinline__ void dma_piece(const char* __restrict__ baseR, const 
 #ifdef ESR_IB3_TIMING
 __device__ unsigned long long esr_ib3_dbg[8192];
 #define ESR_TICK(VAR) { ESR_SB(); VAR = __builtin_readcyclecounter(); ESR_SB(); }
+// -DESR_IB3_TIMING=1: the pass-Q kernel writes the stamps; any other value: the pass-C kernel (recompute or stored-P)
+#define ESR_TIMING_SIDE_Q ((ESR_IB3_TIMING + 0) == 1)
 #else
 #define ESR_TICK(VAR)
 #endif
@@ -665,7 +546,7 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
   }
 
 #ifdef ESR_IB3_TIMING
-  if (lane == 0 && blockIdx.x < 256) {
+  if (lane == 0 && blockIdx.x < 256 && QSIDE == ESR_TIMING_SIDE_Q) {
     unsigned long long* d = esr_ib3_dbg + ((blockIdx.x * 4 + w) * 4);
     d[0] = tacc0; d[1] = tacc1; d[2] = tacc2; d[3] = __builtin_readcyclecounter() - tstart;
     unsigned long long* e = esr_ib3_dbg + 4096 + ((blockIdx.x * 4 + w) * 4);  // 100 MHz wall clock, absolute
@@ -687,7 +568,7 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
   }
 #ifdef ESR_IB3_TIMING
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (lane == 0 && blockIdx.x < 256) esr_ib3_dbg[4096 + ((blockIdx.x * 4 + dbg_w) * 4) + 3] = __builtin_amdgcn_s_memrealtime();
+  if (lane == 0 && blockIdx.x < 256 && QSIDE == ESR_TIMING_SIDE_Q) esr_ib3_dbg[4096 + ((blockIdx.x * 4 + dbg_w) * 4) + 3] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 
@@ -708,6 +589,10 @@ __global__ __launch_bounds__(256) void inbatch3_pc_kernel(const __bf16* __restri
   constexpr int PMODE = 2;
   (void)PMODE;
   __shared__ __attribute__((aligned(16))) char lds[k3Bufs * kBufBytes];
+#ifdef ESR_IB3_TIMING
+  const unsigned long long rentry = __builtin_amdgcn_s_memrealtime();
+  unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0, tacc0 = 0, tacc1 = 0, tacc2 = 0;
+#endif
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int j = lane & 31, h = lane >> 5;
@@ -801,6 +686,7 @@ __global__ __launch_bounds__(256) void inbatch3_pc_kernel(const __bf16* __restri
     }                                                                                                     \
     if (DMA_ON) { ESR_P_LOAD_NEXT(); ESR_DMA_LSE(DBUF); }                                                 \
     ESR_TR_WAIT(); /* this chunk's G = 0 fragments (requested one iteration ago, or by the prologue) */    \
+    ESR_TICK(tk2);                                                                                        \
     if (ONEP) {                                                                                           \
       ESR_SB(); ESR_O_ROW(0, 2, 0); ESR_SB(); ESR_O_G1(4, 6); if (DMA_ON) { ESR_DP(0, g0, DBUF); }        \
       if (NEXT_ON) { ESR_PC_SPLIT1(0); ESR_PC_SPLIT1(1); }                                                \
@@ -853,16 +739,26 @@ __global__ __launch_bounds__(256) void inbatch3_pc_kernel(const __bf16* __restri
   ESR_LOAD_REFS(lds);
   ESR_P_SPLIT();
 
+#ifdef ESR_IB3_TIMING
+  const unsigned long long tstart = __builtin_readcyclecounter();
+  const unsigned long long rstart = __builtin_amdgcn_s_memrealtime();
+#endif
   int cur = 0;
   for (int it = 0; it + 2 < nc; ++it) {
     const int nxt = cur == k3Bufs - 1 ? 0 : cur + 1;
     const int nn = nxt == k3Bufs - 1 ? 0 : nxt + 1;
+    ESR_TICK(tk0);
     if (it > 0) ESR_DMA_BARRIER();  // chunk it + 1 (tile, 1 / l block, P^T tile) is here; slot nn is free again
+    ESR_TICK(tk1);
     const char* buf = lds + cur * kBufBytes;
     const char* nbuf = lds + nxt * kBufBytes;
     char* dbuf = lds + nn * kBufBytes;
     ESR_TR_BASES(buf);
     ESR_PC_ITER(buf, nbuf, dbuf, true, true);
+    ESR_TICK(tk3);
+#ifdef ESR_IB3_TIMING
+    tacc0 += tk1 - tk0; tacc1 += tk2 - tk1; tacc2 += tk3 - tk2;
+#endif
     cur = nxt;
   }
   if (nc >= 2) {  // chunk nc - 2: nothing left to fetch, chunk nc - 1 still to prepare
@@ -879,6 +775,14 @@ __global__ __launch_bounds__(256) void inbatch3_pc_kernel(const __bf16* __restri
     ESR_TR_BASES(buf);
     ESR_PC_ITER(buf, buf, lds, false, false);
   }
+#ifdef ESR_IB3_TIMING
+  if (lane == 0 && blockIdx.x < 256 && !ESR_TIMING_SIDE_Q) {  // (the first 256 of the 2 x 256 workgroups)
+    unsigned long long* d = esr_ib3_dbg + ((blockIdx.x * 4 + w) * 4);
+    d[0] = tacc0; d[1] = tacc1; d[2] = tacc2; d[3] = __builtin_readcyclecounter() - tstart;
+    unsigned long long* e = esr_ib3_dbg + 4096 + ((blockIdx.x * 4 + w) * 4);
+    e[0] = rentry; e[1] = rstart; e[2] = __builtin_amdgcn_s_memrealtime(); e[3] = e[2];
+  }
+#endif
   float* orow = part_O + ((int64_t)split * B + xrow) * k3D;
 #pragma unroll
   for (int db = 0; db < 4; ++db)
@@ -982,115 +886,6 @@ __global__ __launch_bounds__(256) void inbatch3_rowmax_kernel(const __bf16* __re
   m = fmaxf(m, __shfl_xor(m, 32, 64));
   if (h == 0) part_m[(int64_t)split * B + xrow] = m * sl2;
 }
-
-// ---------------------------------------------------------------------------------------------------
-// merge: one 32-lane group per owned row
-// ---------------------------------------------------------------------------------------------------
-template <bool QSIDE>
-__global__ __launch_bounds__(kBlock) void inbatch3_merge_kernel(
-    RowSrc X, RowSrc Y, const int32_t* __restrict__ out_idx, int64_t B, int nsplit, const float* __restrict__ part_O,
-    const float* __restrict__ part_m, const float* __restrict__ part_l, float scale, float lam, float inv_bs,
-    float* __restrict__ lse2, float* __restrict__ lse_nat, float* __restrict__ gX,
-    unsigned long long* __restrict__ loss_acc, double loss_scale, float* __restrict__ loss_out,
-    float* __restrict__ invl) {
-  __shared__ double sm[4];
-  constexpr int G = 32;
-  const int lig = threadIdx.x & (G - 1);
-  const int64_t gpb = kBlock / G;
-  const int64_t group = (int64_t)blockIdx.x * gpb + threadIdx.x / G;
-  const int64_t ngroups = (int64_t)gridDim.x * gpb;
-  double acc_loss = 0.0;
-  for (int64_t row = group; row < B; row += ngroups) {
-    // every load of the row is issued before the first use (nsplit <= 8 is a run-time value: the plain loops waited
-    // for one memory latency per split and array, ~12 in a row); the sums keep the split order
-    float pm[8], pl[8];
-    float4 po[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      pm[s] = -INFINITY; pl[s] = 0.f; po[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (s < nsplit) {
-        if (QSIDE) {
-          pm[s] = part_m[(int64_t)s * B + row];
-          pl[s] = part_l[(int64_t)s * B + row];
-        }
-        po[s] = *reinterpret_cast<const float4*>(part_O + ((int64_t)s * B + row) * k3D + 4 * lig);
-      }
-    }
-    const float4 x = rowsrc_load4(X, row, 4 * lig);
-    const float4 y = rowsrc_load4(Y, row, 4 * lig);
-    float M = 0.f, L = 1.f;
-    if (QSIDE) {  // every split used the same fixed reference M = max_s part_m[s][row]
-      M = pm[0];
-      L = 0.f;
-#pragma unroll
-      for (int s = 1; s < 8; ++s) M = fmaxf(M, pm[s]);
-#pragma unroll
-      for (int s = 0; s < 8; ++s) L += pl[s];
-    }
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      if (s < nsplit) { o.x += po[s].x; o.y += po[s].y; o.z += po[s].z; o.w += po[s].w; }
-    }
-    const float invL = 1.0f / L;
-    const float xn2 = group_sum(x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w, G);
-    const float xnorm = sqrtf(xn2);
-    const float creg = xnorm > 1.f ? lam / xnorm : 0.f;
-    float4 g;
-    g.x = (scale * (o.x * invL - y.x) + creg * x.x) * inv_bs;
-    g.y = (scale * (o.y * invL - y.y) + creg * x.y) * inv_bs;
-    g.z = (scale * (o.z * invL - y.z) + creg * x.z) * inv_bs;
-    g.w = (scale * (o.w * invL - y.w) + creg * x.w) * inv_bs;
-    *reinterpret_cast<float4*>(gX + (out_idx ? (int64_t)out_idx[row] : row) * k3D + 4 * lig) = g;
-    float row_loss = lam * fmaxf(xnorm - 1.f, 0.f);
-    if (QSIDE) {
-      const float diag = group_sum(x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w, G);
-      const float l2v = M + __builtin_amdgcn_logf(L);
-      if (lig == 0) {
-        lse2[row] = l2v;
-        if (invl) invl[row] = invL;  // the stored-P pass C normalises with it
-        if (lse_nat) lse_nat[row] = l2v * k3Ln2;
-      }
-      row_loss += l2v * k3Ln2 - scale * diag;
-    }
-    if (lig == 0) acc_loss += (double)row_loss;
-  }
-  const double tsum = block_sum_d(acc_loss, sm);
-  // The loss scalar without a finalize launch and without a fence.  Every workgroup of both merge launches adds
-  // (its partial in 2^-28 fixed point) << 11 | 1 to a 64-bit word with ONE atomic -- integer addition is exact and
-  // order-free, so the sum is bit-reproducible, and the atomic's return value tells the workgroup whether it was the
-  // last to arrive.  Two levels, because 2048 atomics on one address serialise (measured: +15 us): kLossWords words
-  // 128 B apart take workgroups blockIdx % kLossWords; the last arrival of a word forwards that word's total to the
-  // master word; the last arrival there writes the loss.  Data flows only through atomic return values, so no
-  // ordering between addresses is needed.  split3_kernel zeroed the words.  (A ticket + __threadfence() reduction of
-  // double partials was 7 us slower than the finalize launch: the agent-scope release writes the XCD's L2 back.)
-  // Range: |sum| < 2^24 = 1.6e7 nats (a partial beyond it, or a non-finite one, poisons the result: NaN); resolution
-  // 3.7e-9 per workgroup partial.
-  if (threadIdx.x == 0) {
-    const unsigned wd = blockIdx.x % kLossWords;
-    const unsigned per_launch = (gridDim.x - wd + kLossWords - 1) / kLossWords;  // workgroups of one launch on word wd
-    const unsigned nwords = gridDim.x < (unsigned)kLossWords ? gridDim.x : (unsigned)kLossWords;
-    unsigned long long add = ((unsigned long long)__double2ll_rn(tsum * 268435456.0) << 11);
-    if (!(fabs(tsum) < 16777216.0)) {  // non-finite or out of range: the loss must come out NaN, not a wrapped number
-      // raise the poison word BEFORE this workgroup is counted: the add below consumes the atomic's return value, so
-      // it cannot be issued until the OR has been performed (r is 0 or 1; r >> 1 is the dependence, not a value)
-      const unsigned r = atomicOr(reinterpret_cast<unsigned*>(loss_acc + 8), 1u);
-      add = (unsigned long long)(r >> 1);
-    }
-    const unsigned long long old = atomicAdd(loss_acc + 16 * (1 + wd), add + 1ull);
-    if ((unsigned)(old & 2047ull) == 2 * per_launch - 1) {
-      const unsigned long long word_total = ((old + add) >> 11) << 11;  // this word's sum, count bits cleared
-      const unsigned long long m = atomicAdd(loss_acc, word_total + 1ull);
-      if ((unsigned)(m & 2047ull) == nwords - 1) {
-        const long long tot = ((long long)(m + word_total)) >> 11;  // arithmetic shift: signed sum
-        // every workgroup was counted before this branch was taken, hence after its OR (if any) was performed
-        const bool poisoned = atomicOr(reinterpret_cast<unsigned*>(loss_acc + 8), 0u) != 0u;
-        loss_out[0] = poisoned ? __builtin_nanf("") : (float)((double)tot * (1.0 / 268435456.0) * loss_scale);
-      }
-    }
-  }
-}
-
 
 struct Inbatch3Ws {
   __bf16 *Qr, *Qt, *Cr, *Ct;

@@ -304,7 +304,41 @@ def triplet_fwd_bwd(scene_table, pos_table, neg_table, scene_ids, pos_ids, neg_i
     return loss, ps, ns, gs, gp, gn
 
 
-INBATCH_PRECISIONS = ("auto", "f32", "bf16x3")
+INBATCH_PRECISIONS = ("auto", "f32", "bf16x3", "f16x2")
+INBATCH_F16X2_MAX_B = 16384  # esr_inbatch2h.hip keeps the B x B probabilities between its two passes
+
+
+def _inbatch_auto_split():
+    """What "auto" resolves to where both split-precision paths apply (ESR_INBATCH_AUTO=bf16x3 keeps the older one)."""
+    import os
+    v = os.environ.get("ESR_INBATCH_AUTO", "f16x2")
+    if v not in ("f16x2", "bf16x3"):
+        raise ValueError("ESR_INBATCH_AUTO must be f16x2 or bf16x3")
+    return v
+
+
+def inbatch_split_path(precision, B, D, bf16_tables=False):
+    """The split-precision MFMA path `precision` selects for a [B, D] in-batch head: "f16x2", "bf16x3" or None (exact
+    f32).  f16x2: two fp16 planes per operand, three MFMAs per product (esr_inbatch2h.hip; fp32 rows, B <= 16384);
+    bf16x3: three bf16 planes, six MFMAs (esr_inbatch3.hip; also bf16 tables, where only one plane is live)."""
+    if precision not in INBATCH_PRECISIONS:
+        raise ValueError("precision must be one of %s" % (INBATCH_PRECISIONS,))
+    split_ok = D == 128 and B % 128 == 0 and B > 0
+    h_ok = split_ok and B <= INBATCH_F16X2_MAX_B and not bf16_tables
+    if precision == "f32":
+        return None
+    if precision == "bf16x3":
+        if not split_ok:
+            raise ValueError("precision='bf16x3' needs D == 128 and B %% 128 == 0 (got B=%d, D=%d)" % (B, D))
+        return "bf16x3"
+    if precision == "f16x2":
+        if not h_ok:
+            raise ValueError("precision='f16x2' needs D == 128, B %% 128 == 0, B <= %d and fp32 rows (got B=%d, D=%d)"
+                             % (INBATCH_F16X2_MAX_B, B, D))
+        return "f16x2"
+    if not split_ok:
+        return None
+    return "f16x2" if h_ok and _inbatch_auto_split() == "f16x2" else "bf16x3"
 
 
 def inbatch_softmax_fwd_bwd(Q, C, scale, regularization, batch_size, precision="auto"):
@@ -312,24 +346,24 @@ def inbatch_softmax_fwd_bwd(Q, C, scale, regularization, batch_size, precision="
 
     precision "f32": exact-f32 MFMA (v_mfma_f32_32x32x2_f32).  "bf16x3": f32-equivalent products from three
     exact bf16 planes per operand (six v_mfma_f32_32x32x16_bf16 per block, error <= 2^-23 per product; needs
-    D == 128 and B % 128 == 0).  "auto": bf16x3 where it applies, else f32.  Both hold the 1e-5 bound."""
+    D == 128 and B % 128 == 0).  "f16x2": two scaled fp16 planes per operand (three v_mfma_f32_32x32x16_f16 per block,
+    error <= ~2^-22 per product; also B <= 16384).  "auto": f16x2 where it applies, else bf16x3, else f32.  All hold
+    the 1e-5 bound."""
     lib = _lib.load()
     _req(Q, torch.float32, "Q"), _req(C, torch.float32, "C")
     B, D = Q.shape
     if C.shape != Q.shape:
         raise ValueError("Q and C must have the same shape")
-    if precision not in INBATCH_PRECISIONS:
-        raise ValueError("precision must be one of %s" % (INBATCH_PRECISIONS,))
-    split_ok = D == 128 and B % 128 == 0
-    if precision == "bf16x3" and not split_ok:
-        raise ValueError("precision='bf16x3' needs D == 128 and B %% 128 == 0 (got B=%d, D=%d)" % (B, D))
-    use_split = split_ok and precision in ("auto", "bf16x3")
+    path = inbatch_split_path(precision, B, D)
     dev = Q.device
     loss = torch.empty(1, dtype=torch.float32, device=dev)
     lse = torch.empty(B, dtype=torch.float32, device=dev)
     gQC = torch.empty((2 * B, D), dtype=torch.float32, device=dev)  # [gQ ; gC]: one occurrence list downstream
     gQ, gC = gQC[:B], gQC[B:]
-    if use_split:
+    if path == "f16x2":
+        ws = _ws(_ws_bytes("esr_inbatch2h_workspace_bytes", B, D), dev)
+        fn, name = lib.esr_inbatch_softmax_fwd_bwd_f16x2, "esr_inbatch_softmax_fwd_bwd_f16x2"
+    elif path == "bf16x3":
         ws = _ws(_ws_bytes("esr_inbatch3_workspace_bytes", B, D), dev)
         fn, name = lib.esr_inbatch_softmax_fwd_bwd_bf16x3, "esr_inbatch_softmax_fwd_bwd_bf16x3"
     else:
@@ -646,32 +680,40 @@ def topk_merge(scores, indices, k):
 
 
 def inbatch_towers_fwd_bwd(query_table, cand_table, query_ids, cand_ids, scale, regularization, batch_size,
-                           grad_positions=None):
+                           grad_positions=None, precision="auto"):
     """In-batch softmax step head straight from the tower tables (no materialised Q / C): rows query_table[query_ids],
     cand_table[cand_ids]; tables f32 or bf16 [V, 128], B % 128 == 0.  Returns (loss[1], lse[B], gQ, gC) like
-    inbatch_softmax_fwd_bwd (bf16x3 path).  grad_positions = (gq_rows, gc_rows) int32 [B] each: the gradient rows
-    are scattered into ONE [2B, 128] buffer at those rows instead (returned as gQ, with gC = None)."""
+    inbatch_softmax_fwd_bwd.  precision: "auto" / "f16x2" / "bf16x3" (see inbatch_split_path; bf16 tables always take
+    the bf16x3 kernels, where they are one-plane).  grad_positions = (gq_rows, gc_rows) int32 [B] each: the gradient
+    rows are scattered into ONE [2B, 128] buffer at those rows instead (returned as gQ, with gC = None)."""
     lib = _lib.load()
     dt = _table_dtype(query_table, "query_table")
     if _table_dtype(cand_table, "cand_table") != dt:
         raise TypeError("both tower tables must have the same dtype")
     query_ids, cand_ids = _req(query_ids, torch.int32, "query_ids"), _req(cand_ids, torch.int32, "cand_ids")
     B, D, dev = query_ids.numel(), query_table.shape[1], query_table.device
+    path = inbatch_split_path(precision, B, D, bf16_tables=query_table.dtype == torch.bfloat16)
+    if path is None:
+        raise ValueError("inbatch_towers_fwd_bwd needs D == 128 and B %% 128 == 0 (got B=%d, D=%d) and a split precision"
+                         % (B, D))
     loss = torch.empty(1, dtype=torch.float32, device=dev)
     lse = torch.empty(B, dtype=torch.float32, device=dev)
     gQC = torch.empty((2 * B, D), dtype=torch.float32, device=dev)
-    ws = _ws(_ws_bytes("esr_inbatch3_workspace_bytes", B, D), dev)
+    if path == "f16x2":
+        ws = _ws(_ws_bytes("esr_inbatch2h_workspace_bytes", B, D), dev)
+        fn, name = lib.esr_inbatch_towers_fwd_bwd_f16x2, "esr_inbatch_towers_fwd_bwd_f16x2"
+    else:
+        ws = _ws(_ws_bytes("esr_inbatch3_workspace_bytes", B, D), dev)
+        fn, name = lib.esr_inbatch_towers_fwd_bwd_bf16x3, "esr_inbatch_towers_fwd_bwd_bf16x3"
     if grad_positions is not None:
         gqr, gcr = _req(grad_positions[0], torch.int32, "gq_rows"), _req(grad_positions[1], torch.int32, "gc_rows")
         gq_ptr = gc_ptr = _p(gQC)
     else:
         gqr = gcr = None
         gq_ptr, gc_ptr = _p(gQC[:B]), _p(gQC[B:])
-    check(lib.esr_inbatch_towers_fwd_bwd_bf16x3(_p(query_table), query_table.shape[0], _p(cand_table),
-                                                cand_table.shape[0], dt, D, _p(query_ids), _p(cand_ids), _p(gqr), _p(gcr),
-                                                B, float(scale), float(regularization), float(batch_size), _p(loss),
-                                                _p(lse), gq_ptr, gc_ptr, _p(ws), ws.numel(), _stream()),
-          "esr_inbatch_towers_fwd_bwd_bf16x3")
+    check(fn(_p(query_table), query_table.shape[0], _p(cand_table), cand_table.shape[0], dt, D, _p(query_ids),
+             _p(cand_ids), _p(gqr), _p(gcr), B, float(scale), float(regularization), float(batch_size), _p(loss),
+             _p(lse), gq_ptr, gc_ptr, _p(ws), ws.numel(), _stream()), name)
     if grad_positions is not None:
         return loss, lse, gQC, None
     return loss, lse, gQC[:B], gQC[B:]

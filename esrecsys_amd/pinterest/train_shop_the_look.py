@@ -173,9 +173,10 @@ def train_step(state, scene, pos_product, neg_product, regularization, batch_siz
             fused.index._sorted = presorted.take()  # sorted one batch ahead on the side stream (presort_triplets)
         elif fused is not None and _PRESORT:
             fused.index.presort()
-        if precision in ("auto", "bf16x3") and st.shape[1] == 128 and B % 128 == 0 and st.dtype == pt.dtype:
-            # the bf16x3 path reads the tower rows itself (gather folded into its split and merge kernels)
-            loss, _, gq, gc = ops.inbatch_towers_fwd_bwd(st, pt, sid, pid, scale, regularization, batch_size)
+        if precision != "f32" and st.shape[1] == 128 and B % 128 == 0 and st.dtype == pt.dtype:
+            # the split-precision paths read the tower rows themselves (gather folded into their split and merge kernels)
+            loss, _, gq, gc = ops.inbatch_towers_fwd_bwd(st, pt, sid, pid, scale, regularization, batch_size,
+                                                         precision=precision)
         else:
             q = ops.gather_rows(st, sid)
             c = ops.gather_rows(pt, pid)

@@ -189,6 +189,25 @@ int esr_inbatch_towers_fwd_bwd_bf16x3(const void* query_table, int64_t Vq, const
                                       float* gQ, float* gC, void* workspace, size_t workspace_bytes,
                                       esr_stream_t stream);
 
+/* Same two contracts with the products formed from TWO fp16 planes per operand (x * 2^e = x1 + x2 to 2^-24 relative with
+ * round-to-nearest planes; a.b ~= a2 b1 + a1 b2 + a1 b1, dropped term <= 2^-24 |a||b|): three v_mfma_f32_32x32x16_f16 per
+ * product instead of six bf16 ones, i.e. half the matrix-core work of the bf16x3 entry points at the same f32-grade
+ * error (the kernels run at the chip's power limit, so fewer MFMAs is what shortens the step).  fp16's narrow range is
+ * handled inside: a per-matrix power-of-two scale from the batch's largest |element|, and an exponent reference tied
+ * to the true row maximum.  Pass C reads the B x B probabilities pass Q stored: D must be 128, B a multiple of 128 and
+ * <= 16384 (workspace ~ 4 B^2 bytes); esr_inbatch2h_workspace_bytes returns 256 for a B it cannot serve. */
+size_t esr_inbatch2h_workspace_bytes(int64_t B, int D);
+int esr_inbatch_softmax_fwd_bwd_f16x2(const float* Q, const float* C, int64_t B, int D, float scale,
+                                      float regularization, float batch_size, float* loss, float* lse,
+                                      float* gQ, float* gC, void* workspace, size_t workspace_bytes,
+                                      esr_stream_t stream);
+int esr_inbatch_towers_fwd_bwd_f16x2(const void* query_table, int64_t Vq, const void* cand_table, int64_t Vc,
+                                     int dtype, int D, const int32_t* query_ids, const int32_t* cand_ids,
+                                     const int32_t* gq_rows, const int32_t* gc_rows, int64_t B, float scale,
+                                     float regularization, float batch_size, float* loss, float* lse,
+                                     float* gQ, float* gC, void* workspace, size_t workspace_bytes,
+                                     esr_stream_t stream);
+
 /* ---- G4 (build's production optimizer): sort + segment-reduce + sparse Adagrad -----------
  * Replaces the dense V x D gradient + dense optimizer sweep of
  * wikipedia/train_cooccurence.py:86-101 with a row-sparse update.

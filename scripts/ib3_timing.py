@@ -2,7 +2,8 @@
 import ctypes, os, sys
 import numpy as np, torch
 here = os.path.dirname(os.path.abspath(__file__))
-lib = ctypes.CDLL(os.path.join(here, "libib3dbg.so"))
+lib = ctypes.CDLL(os.path.join(here, os.environ.get("IB3_LIB", "libib3dbg.so")))
+ITERS = int(os.environ.get("IB3_ITERS", "62"))  # pipelined iterations per workgroup: chunks per split - 2
 lib.esr_inbatch3_workspace_bytes.restype = ctypes.c_size_t
 lib.esr_inbatch3_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int]
 dev = torch.device("cuda", 0)
@@ -34,9 +35,9 @@ lib.esr_ib3_debug_read(buf)
 e = np.array(buf[4096:], dtype=np.float64).reshape(1024, 4)
 rt = e[:, 2] - e[:, 1]
 a = np.array(buf[:4096], dtype=np.float64).reshape(256, 4, 4)  # last launch = pass C kernel
-print("per-wave mean cycles over 63 pipelined iterations: barrier %.0f  S-phase(+VALU) %.0f  O-phase(+DMA) %.0f  total kernel %.0f"
+print("per-wave mean cycles over the pipelined iterations: barrier %.0f  S-phase(+VALU) %.0f  O-phase(+DMA) %.0f  total kernel %.0f"
       % tuple(a[..., k].mean() for k in range(4)))
-print("per-iteration: barrier %.0f  S %.0f  O %.0f" % tuple(a[..., k].mean() / 63 for k in range(3)))
+print("per-iteration: barrier %.0f  S %.0f  O %.0f" % tuple(a[..., k].mean() / ITERS for k in range(3)))
 print("min/max total", a[..., 3].min(), a[..., 3].max(), " loss", float(loss))
 print("loop wall time %.1f us (s_memrealtime, 100 MHz) -> shader clock %.0f MHz" % (rt.mean() / 100, a[..., 3].mean() / (rt.mean() / 100)))
 t0 = e[:, 0].min()

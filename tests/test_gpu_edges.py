@@ -107,8 +107,9 @@ def test_argument_errors_raise_with_a_message(dev):
     assert ops.gather_rows(c, torch.zeros(3, dtype=torch.int32, device=dev)).shape == (3, 32)
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("bad", [float("nan"), float("inf")])
-def test_inbatch_bf16x3_nonfinite_input_gives_nan_loss(dev, bad):
+def test_inbatch_bf16x3_nonfinite_input_gives_nan_loss(dev, bad, precision):
     """the bf16x3 path reduces its loss in fixed point through integer atomics: a non-finite partial must still come
     out as NaN (poison word), and the next call on the same workspace must be clean again"""
     from esrecsys_amd import ops
@@ -118,9 +119,9 @@ def test_inbatch_bf16x3_nonfinite_input_gives_nan_loss(dev, bad):
     c = (rng.standard_normal((B, D)) * D ** -0.5).astype(np.float32)
     qb = q.copy()
     qb[77, 5] = bad
-    loss, _, _, _ = ops.inbatch_softmax_fwd_bwd(T(qb, dev), T(c, dev), 4.0, 0.1, float(B), precision="bf16x3")
+    loss, _, _, _ = ops.inbatch_softmax_fwd_bwd(T(qb, dev), T(c, dev), 4.0, 0.1, float(B), precision=precision)
     assert np.isnan(float(loss))
-    loss2, _, gq, gc = ops.inbatch_softmax_fwd_bwd(T(q, dev), T(c, dev), 4.0, 0.1, float(B), precision="bf16x3")
+    loss2, _, gq, gc = ops.inbatch_softmax_fwd_bwd(T(q, dev), T(c, dev), 4.0, 0.1, float(B), precision=precision)
     el, _, egq, egc = o_stl.inbatch_softmax_loss_and_grads(q.astype(F64), c.astype(F64), 0.1, float(B), 4.0, F64)
     assert abs(float(loss2) - el) <= 1e-5 * abs(el)
     assert np.max(np.abs(N(gq) - egq)) <= 1e-5 * np.max(np.abs(egq))
@@ -153,7 +154,7 @@ def test_sparse_adagrad_one_row_takes_every_gradient(dev, n, D):
     assert np.array_equal(N(table)[keep], p0[keep]) and np.array_equal(N(accum)[keep], a0[keep])
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2"])
 @pytest.mark.parametrize("scale", [-6.0, 0.0, 1e-3])
 def test_inbatch_odd_temperatures(dev, precision, scale):
     """negative temperature (the softmax prefers the LEAST similar candidate), zero (uniform: loss = log B + reg) and a

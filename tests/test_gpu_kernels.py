@@ -216,7 +216,7 @@ def test_inbatch_softmax_vs_golden(dev, case):
     assert rel_err(N(gc), g["g_c"]) <= TOL
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2"])
 def test_inbatch_transpose_detecting(dev, precision):
     """Asymmetric operands: a swapped Q/C role or a transposed MFMA fragment cannot pass."""
     from esrecsys_amd import ops
@@ -270,7 +270,7 @@ def test_inbatch_embedding_widths_vs_oracle(dev, B, D):
     assert torch.equal(gq2, gq) and torch.equal(gc2, gc) and bool((guard == 7.0).all())
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2"])
 def test_inbatch_gradients_elementwise_at_c2_size(dev, precision):
     """C2 size, both MFMA paths: every gradient entry within 1e-4 of the fp64 oracle relative to max(|entry|, 1e-3 of
     the largest entry) -- the norm-wise 1e-5 bound alone would let small entries of the bf16x3 path be arbitrarily bad."""
@@ -315,8 +315,9 @@ def test_fused_heads_write_grads_at_ids(dev):
         assert torch.equal(l0, l1) and torch.equal(g1[idx], g0) and torch.equal(b1[idx], b0)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_inbatch_towers_gather_folded_in(dev, dtype):
+@pytest.mark.parametrize("dtype,precision", [(torch.float32, "bf16x3"), (torch.float32, "f16x2"),
+                                             (torch.bfloat16, "bf16x3"), (torch.bfloat16, "auto")])
+def test_inbatch_towers_gather_folded_in(dev, dtype, precision):
     """the step head that reads the tower rows itself == gather + dense head, bit for bit; and vs the oracle"""
     from esrecsys_amd import ops
     rng = np.random.default_rng(21)
@@ -326,10 +327,12 @@ def test_inbatch_towers_gather_folded_in(dev, dtype):
     qi = rng.integers(0, Vq, B).astype(np.int32)
     ci = rng.integers(0, Vc, B).astype(np.int32)
     ci[3] = ci[2]                                   # the same candidate row twice in the batch
-    loss, lse, gq, gc = ops.inbatch_towers_fwd_bwd(qt, ct, T(qi, dev), T(ci, dev), 6.0, 0.1, float(B))
+    loss, lse, gq, gc = ops.inbatch_towers_fwd_bwd(qt, ct, T(qi, dev), T(ci, dev), 6.0, 0.1, float(B),
+                                                   precision=precision)
     q = ops.unpermute_rows_to_f32(ops.gather_rows(qt, T(qi, dev)), None)
     c = ops.unpermute_rows_to_f32(ops.gather_rows(ct, T(ci, dev)), None)
-    l2, lse2, gq2, gc2 = ops.inbatch_softmax_fwd_bwd(q, c, 6.0, 0.1, float(B), precision="bf16x3")
+    l2, lse2, gq2, gc2 = ops.inbatch_softmax_fwd_bwd(q, c, 6.0, 0.1, float(B),
+                                                     precision="bf16x3" if precision == "auto" else precision)
     assert torch.equal(loss, l2) and torch.equal(lse, lse2) and torch.equal(gq, gq2)
     # pass C: bf16 towers recompute S^T (one-plane kernels), f32 rows take the stored-P kernel, which normalises p / l
     # instead of forming exp2(s - lse): the same probabilities to an f32 rounding
@@ -350,7 +353,8 @@ def test_inbatch_one_plane_kernels_equal_the_full_ones(dev, B):
     qi = T(rng.integers(0, V, B).astype(np.int32), dev)
     ci = T(rng.integers(0, V, B).astype(np.int32), dev)
     loss, lse, gq, gc = ops.inbatch_towers_fwd_bwd(qt, ct, qi, ci, 7.0, 0.1, float(B))
-    l2, lse2, gq2, gc2 = ops.inbatch_towers_fwd_bwd(qt.float(), ct.float(), qi, ci, 7.0, 0.1, float(B))
+    l2, lse2, gq2, gc2 = ops.inbatch_towers_fwd_bwd(qt.float(), ct.float(), qi, ci, 7.0, 0.1, float(B),
+                                                    precision="bf16x3")
     assert torch.equal(loss, l2) and torch.equal(lse, lse2) and torch.equal(gq, gq2)
     assert rel_err(N(gc), N(gc2)) <= 1e-6   # (pass C of the full path reads stored probabilities; see above)
     if B <= 2176:
@@ -373,9 +377,10 @@ def test_inbatch_pstore_matches_recompute(dev, B, monkeypatch):
     qi = T(rng.integers(0, V, B).astype(np.int32), dev)
     ci = T(rng.integers(0, V, B).astype(np.int32), dev)
     monkeypatch.setenv("ESR_IB3_PSTORE", "1")
-    loss, lse, gq, gc = [x.clone() for x in ops.inbatch_towers_fwd_bwd(qt, ct, qi, ci, 7.0, 0.1, float(B))]
+    loss, lse, gq, gc = [x.clone() for x in ops.inbatch_towers_fwd_bwd(qt, ct, qi, ci, 7.0, 0.1, float(B),
+                                                                       precision="bf16x3")]
     monkeypatch.setenv("ESR_IB3_PSTORE", "0")
-    l2, lse2, gq2, gc2 = ops.inbatch_towers_fwd_bwd(qt, ct, qi, ci, 7.0, 0.1, float(B))
+    l2, lse2, gq2, gc2 = ops.inbatch_towers_fwd_bwd(qt, ct, qi, ci, 7.0, 0.1, float(B), precision="bf16x3")
     assert torch.equal(loss, l2) and torch.equal(lse, lse2) and torch.equal(gq, gq2)
     # element-wise with the floor at 1e-3 of the largest entry: 1e-6 norm-wise allows up to 1e-3 there
     assert rel_err(N(gc), N(gc2)) <= 1e-6 and elem_rel_err(N(gc), N(gc2)) <= 5e-4
@@ -386,7 +391,7 @@ def test_inbatch_pstore_matches_recompute(dev, B, monkeypatch):
             assert rel_err(N(g), egc) <= TOL
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2"])
 def test_inbatch_config_c2_full_size(dev, precision):
     """BASELINE config C2: B = 8192, D = 128, fp64 oracle on the same inputs + checksum properties
     (softmax rows sum to one => column sum of gC vanishes when reg = 0)."""
@@ -419,17 +424,52 @@ def test_inbatch_bf16x3_shapes_and_hard_inputs(dev, B):
     c[B - 1] = q[7]
     el, else_, egq, egc = o_stl.inbatch_softmax_loss_and_grads(q, c, 0.1, B, 12.0, F64)
     errs = {}
-    for precision in ("f32", "bf16x3"):
+    for precision in ("f32", "bf16x3", "f16x2"):
         loss, lse, gq, gc = ops.inbatch_softmax_fwd_bwd(T(q, dev), T(c, dev), 12.0, 0.1, B, precision=precision)
         errs[precision] = (abs(float(loss) - el) / abs(el), rel_err(N(lse), else_), rel_err(N(gq), egq),
                            rel_err(N(gc), egc))
-    print("inbatch B=%d rel.err vs fp64 (loss, lse, gQ, gC): f32 %s | bf16x3 %s" % (
-        B, " ".join("%.1e" % e for e in errs["f32"]), " ".join("%.1e" % e for e in errs["bf16x3"])))
+    print("inbatch B=%d rel.err vs fp64 (loss, lse, gQ, gC): f32 %s | bf16x3 %s | f16x2 %s" % (
+        B, " ".join("%.1e" % e for e in errs["f32"]), " ".join("%.1e" % e for e in errs["bf16x3"]),
+        " ".join("%.1e" % e for e in errs["f16x2"])))
     for precision in errs:
         assert max(errs[precision]) <= TOL, (precision, errs)
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("mag_q,mag_c,scale", [(1e-4, 1e-4, 5e6), (3e-3, 40.0, 4.0), (200.0, 150.0, 2e-4),
+                                               (0.09, 0.09, 8.0), (0.09, 0.09, 40.0), (0.3, 0.3, 30.0)])
+def test_inbatch_f16x2_operand_and_score_ranges(dev, mag_q, mag_c, scale):
+    """fp16's range is what the two-plane path has to manage: element magnitudes from 1e-4 to 200 (per-matrix
+    power-of-two scale), score ranges on both sides of the bound that decides between "Cauchy-Schwarz bound as exponent
+    reference" (<= 14 log2 units) and the true row maximum, rows whose scores are ALL far below zero (anti-aligned
+    with every candidate: the probabilities must not underflow fp16), a dominant pair and exact zeros."""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(int(scale * 7) % 1000 + 1)
+    B, D = 1024, 128
+    q = (rng.standard_normal((B, D)) * mag_q).astype(np.float32)
+    c = (rng.standard_normal((B, D)) * mag_c).astype(np.float32)
+    common = rng.standard_normal(D).astype(np.float32) * mag_c
+    c[: B // 2] += 2.0 * common                  # half of the candidates share a direction ...
+    q[11] = -3.0 * (mag_q / mag_c) * common      # ... and this query opposes it (and is small against the rest)
+    q[12] = 0.0                                  # exact zeros
+    c[13, ::2] = 0.0
+    c[B - 2] = q[17] * (mag_c / mag_q) * 2.0     # a dominant pair
+    el, else_, egq, egc = o_stl.inbatch_softmax_loss_and_grads(q.astype(F64), c.astype(F64), 0.1, float(B), scale, F64)
+    errs = {}
+    for precision in ("f32", "f16x2"):
+        loss, lse, gq, gc = ops.inbatch_softmax_fwd_bwd(T(q, dev), T(c, dev), scale, 0.1, float(B), precision=precision)
+        errs[precision] = (abs(float(loss) - el) / abs(el), rel_err(N(lse), else_), rel_err(N(gq), egq),
+                           rel_err(N(gc), egc))
+    print("inbatch ranges |q|~%g |c|~%g scale %g: f32 %s | f16x2 %s" % (
+        mag_q, mag_c, scale, " ".join("%.1e" % e for e in errs["f32"]), " ".join("%.1e" % e for e in errs["f16x2"])))
+    # wherever exact f32 arithmetic holds the bound, so must the two-plane path (at extreme |S| the f32 rounding of the
+    # score itself, amplified by exp, leaves 1e-5: both paths then have to stay within 4x of each other)
+    if max(errs["f32"]) <= TOL:
+        assert max(errs["f16x2"]) <= TOL, errs
+    else:
+        assert max(errs["f16x2"]) <= 4 * max(errs["f32"]), errs
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2"])
 def test_inbatch_repeatable_under_load(dev, precision):
     """Race screen for the LDS-DMA ring: 60 back-to-back launches at the headline size must be bit-identical
     (a tile read before its DMA landed shows up as run-to-run differences; an earlier build that relied on
