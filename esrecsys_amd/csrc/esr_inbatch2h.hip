@@ -45,6 +45,30 @@ constexpr int kHScaleWords = 8;             // device-side scale block: see spli
     __syncthreads();                                    \
   }
 #define H_TR_WAIT() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); H_SB(); }
+#ifdef H_TIMING  // debug build (scripts/gpu_ib2h_timing.sh): per-wave phase stamps; H_TIMING=1 pass Q, else pass C
+__device__ unsigned long long esr_ib2h_dbg[8192];
+#define H_TICK(VAR) { H_SB(); VAR = __builtin_readcyclecounter(); H_SB(); }
+#define H_TIMING_Q ((H_TIMING + 0) == 1)
+#define H_TIMING_DECL()                                                                     \
+  const unsigned long long rentry = __builtin_amdgcn_s_memrealtime();                       \
+  unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0, tacc0 = 0, tacc1 = 0, tacc2 = 0;   \
+  unsigned long long tstart = 0, rstart = 0;
+#define H_TIMING_START() { tstart = __builtin_readcyclecounter(); rstart = __builtin_amdgcn_s_memrealtime(); }
+#define H_TIMING_ACC() { tacc0 += tk1 - tk0; tacc1 += tk2 - tk1; tacc2 += tk3 - tk2; }
+#define H_TIMING_WRITE(ON)                                                                  \
+  if (lane == 0 && blockIdx.x < 256 && (ON)) {                                              \
+    unsigned long long* d = esr_ib2h_dbg + ((blockIdx.x * 4 + w) * 4);                      \
+    d[0] = tacc0; d[1] = tacc1; d[2] = tacc2; d[3] = __builtin_readcyclecounter() - tstart; \
+    unsigned long long* e = esr_ib2h_dbg + 4096 + ((blockIdx.x * 4 + w) * 4);               \
+    e[0] = rentry; e[1] = rstart; e[2] = __builtin_amdgcn_s_memrealtime(); e[3] = e[2];     \
+  }
+#else
+#define H_TICK(VAR)
+#define H_TIMING_DECL()
+#define H_TIMING_START()
+#define H_TIMING_ACC()
+#define H_TIMING_WRITE(ON)
+#endif
 
 __device__ __forceinline__ f16x2 pk_f16(float lo, float hi) {  // v_cvt_pk_f16_f32, round-to-nearest-even
   const f32x2 v = {lo, hi};
@@ -202,21 +226,94 @@ __global__ __launch_bounds__(256) void split2h_kernel(RowSrc X0, RowSrc X1, int6
 }
 
 // -----------------------------------------------------------------------------------------------------------------
-// Row reference for pass Q: part_m[split][row] = M with p' = exp2(s sl2 - M) <= 2^14 (+ the hi-plane product's error).
+// Row reference for pass Q: part_mr[split][row] = M with p' = exp2(s sl2 - M) <= 2^14 (+ the hi-plane product's error).
 // bound <= kHBoundSafe: M = bound - 14 (no GEMM).  Otherwise the row maximum of the hi-plane product (error <= 2^-10
-// |q||c| sl2 in log2 units: fp16's range above 2^14 absorbs it up to bounds of ~2000; beyond that -- scores whose exp
+// |q||c| sl2 in log2 units: fp16's range above 2^14 absorbs it up to bounds of ~1000; beyond that -- scores whose exp
 // over- or underflows f32 anyway -- the second-order planes are added to the product).
+//
+// The GEMM is 1 / 9 of the main kernels' MFMA work and all about moving the streamed hi plane: each WAVE owns 64 rows
+// (two B operands per A fragment read from LDS), a workgroup 256, so the plane is streamed B / 256 times (67 MB at
+// B = 8192); the tiles come in GROUPS of kHRmGroup chunks through a ring of kHRmRing slots with kHRmRing - 1 groups in
+// flight (LDS-DMAs complete in order: s_waitcnt vmcnt(<DMAs of the younger groups>) waits for the oldest group only).
+// With one group in flight the kernel took 40 us: the DMA round trip (~2 us under 256 workgroups reading the same
+// lines) was exposed once per group.
 // -----------------------------------------------------------------------------------------------------------------
-constexpr int kHRmGroup = 4;
+constexpr int kHRmGroup = 4, kHRmRing = 4, kHRmOwned = 256;
+template <bool FULL>
+__device__ __forceinline__ float rowmax2h_sweep(const char* __restrict__ baseY, char* lds, int64_t B, int64_t c0, int nc,
+                                                const f16x8 (&bx0)[2][8], const f16x8 (&bx1)[2][8], int t, int w, int j,
+                                                int h) {
+  // (the three-term variant also streams plane 2: half as many chunks per group, same slot size and DMA count)
+  constexpr int kG = FULL ? kHRmGroup / 2 : kHRmGroup;
+  constexpr int kSlotChunk = (FULL ? 2 : 1) * kPlaneBytes, kSlot = kG * kSlotChunk;
+  constexpr int kDmaPerGroup = kG * (FULL ? 4 : 2);
+  const uint32_t g0 = dmah_off0<0>(B, c0, t), g1 = dmah_off0<1>(B, c0, t);
+  const uint32_t g2 = dmah_off0<2>(B, c0, t), g3 = dmah_off0<3>(B, c0, t);
+  const int ngroups = (nc + kG - 1) / kG;
+  // group GI -> ring slot GI % kHRmRing; chunks past the end re-fetch the last one (the DMA count per group stays
+  // constant, which is what the partial vmcnt wait counts on)
+#define H_RM_FETCH(GI)                                                                       \
+  _Pragma("unroll") for (int k = 0; k < kG; ++k) {                                          \
+    const int ch_ = min((GI) * kG + k, nc - 1);                                             \
+    char* dst_ = lds + ((GI) % kHRmRing) * kSlot + k * kSlotChunk;                          \
+    const uint32_t adv_ = (uint32_t)ch_ * 8192u;                                            \
+    H_DP(0, g0 + adv_, dst_); H_DP(1, g1 + adv_, dst_);                                     \
+    if (FULL) { H_DP(2, g2 + adv_, dst_); H_DP(3, g3 + adv_, dst_); }                       \
+  }
+#pragma unroll
+  for (int gi = 0; gi < kHRmRing - 1; ++gi) { H_RM_FETCH(gi); }
+  float ma = -INFINITY, mb = -INFINITY;  // running maxima of this lane's two owned rows over ITS half of the streamed rows
+  for (int gi = 0; gi < ngroups; ++gi) {
+    // group gi has landed (the kHRmRing - 2 younger groups may still be in flight) and everyone is done with the slot
+    // group gi + kHRmRing - 1 goes to (it held group gi - 1)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kHRmRing - 2) * kDmaPerGroup) : "memory");
+    __syncthreads();
+    H_RM_FETCH(gi + kHRmRing - 1);
+#pragma unroll
+    for (int k = 0; k < kG; ++k) {
+      if (gi * kG + k < nc) {
+        const char* buf = lds + (gi % kHRmRing) * kSlot + k * kSlotChunk;
+        f32x16 sa = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 sb = sa;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const int off = j * 256 + (((2 * s + h) ^ swz16(j)) << 4);
+          const f16x8 a1 = *reinterpret_cast<const f16x8*>(buf + off);
+          if (FULL) {
+            const f16x8 a2 = *reinterpret_cast<const f16x8*>(buf + off + kPlaneBytes);
+            sa = H_MFMA(a2, bx0[0][s], sa);
+            sb = H_MFMA(a2, bx0[1][s], sb);
+            sa = H_MFMA(a1, bx1[0][s], sa);
+            sb = H_MFMA(a1, bx1[1][s], sb);
+          }
+          sa = H_MFMA(a1, bx0[0][s], sa);
+          sb = H_MFMA(a1, bx0[1][s], sb);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ma = fmaxf(ma, sa[r]); mb = fmaxf(mb, sb[r]); }
+      }
+    }
+  }
+#undef H_RM_FETCH
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped re-fetches of the tail
+  // lane (j, h) holds rows j (ma) and 32 + j (mb) of the wave's 64 against the streamed rows of half h: lane h = 0
+  // reports row j, lane h = 1 row 32 + j, each taking the other half's value across
+  const float mine = h == 0 ? ma : mb, other = h == 0 ? mb : ma;
+  return fmaxf(mine, __shfl_xor(other, 32, 64));
+}
+
 __global__ __launch_bounds__(256) void rowmax2h_kernel(const _Float16* __restrict__ Xr, const _Float16* __restrict__ Yr,
                                                       int64_t B, int nsplit, float sl2, const float* __restrict__ nrm,
-                                                      const float* __restrict__ sc, float* __restrict__ part_m) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * kHRmGroup * 2 * kPlaneBytes];
+                                                      const float* __restrict__ sc, float* __restrict__ part_mr) {
+  __shared__ __attribute__((aligned(16))) char lds[kHRmRing * kHRmGroup * kPlaneBytes];
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int j = lane & 31, h = lane >> 5;
   const int ob = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
-  const int64_t xrow = (int64_t)ob * k3Owned + w * 32 + j;
+  // this lane reports row xrow = block base + 64 w + 32 h + j
+  const int64_t wrow = (int64_t)ob * kHRmOwned + w * 64;
+  const int64_t xrow = wrow + 32 * h + j;
+  const bool live = wrow < B;  // B is a multiple of 128: the last block's upper two waves may own nothing
   float bound;
   {
     const int nslots = (int)(B / k3Chunk) * 4;  // per matrix
@@ -238,66 +335,31 @@ __global__ __launch_bounds__(256) void rowmax2h_kernel(const _Float16* __restric
     __syncthreads();  // the slow path reuses lds as the DMA ring
     bound = sqrtf(mq * mc) * fabsf(sl2);
     if (bound <= kHBoundSafe) {
-      if (h == 0) part_m[(int64_t)split * B + xrow] = bound - kHPexp;
+      if (live) part_mr[(int64_t)split * B + xrow] = bound - kHPexp;
       return;
     }
   }
-  const bool full = !(bound <= 1024.f);  // absurd score ranges: all three terms (wave-uniform)
+  const bool full = !(bound <= 1024.f);  // absurd score ranges: all three terms (workgroup-uniform)
   const float sl2s = sl2 * sc[0];
-  const float sgn = sl2 < 0.f ? -1.f : 1.f;  // a negative temperature turns the maximum of s sl2 into the minimum of s
   const int nc = (int)(B / k3Chunk) / nsplit;
   const int64_t c0 = (int64_t)split * nc;
   const char* const baseY = reinterpret_cast<const char*>(Yr);
-  f16x8 bx0[8], bx1[8];
+  f16x8 bx0[2][8], bx1[2][8];
 #pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    bx0[s] = *reinterpret_cast<const f16x8*>(Xr + xrow * k3D + 16 * s + 8 * h);
-    bx1[s] = *reinterpret_cast<const f16x8*>(Xr + ((int64_t)B + xrow) * k3D + 16 * s + 8 * h);
-    if (sgn < 0.f) { bx0[s] = -bx0[s]; bx1[s] = -bx1[s]; }
-  }
-  float m = -INFINITY;
-  const uint32_t g0 = dmah_off0<0>(B, c0, t), g1 = dmah_off0<1>(B, c0, t);
-  const uint32_t g2 = dmah_off0<2>(B, c0, t), g3 = dmah_off0<3>(B, c0, t);
-  const int ngroups = (nc + kHRmGroup - 1) / kHRmGroup;
-  constexpr int kSlot = 2 * kPlaneBytes;  // one chunk: plane 0, plane 1 (plane 1 only fetched when `full`)
-#define H_RM_FETCH(GI, HALF)                                                                 \
-  _Pragma("unroll") for (int k = 0; k < kHRmGroup; ++k)                                     \
-    if ((GI) * kHRmGroup + k < nc) {                                                        \
-      char* dst_ = lds + ((HALF) * kHRmGroup + k) * kSlot;                                  \
-      const uint32_t adv_ = (uint32_t)((GI) * kHRmGroup + k) * 8192u;                       \
-      H_DP(0, g0 + adv_, dst_); H_DP(1, g1 + adv_, dst_);                                   \
-      if (full) { H_DP(2, g2 + adv_, dst_); H_DP(3, g3 + adv_, dst_); }                     \
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int64_t r = live ? wrow + 32 * u + j : 0;
+      bx0[u][s] = *reinterpret_cast<const f16x8*>(Xr + r * k3D + 16 * s + 8 * h);
+      bx1[u][s] = *reinterpret_cast<const f16x8*>(Xr + ((int64_t)B + r) * k3D + 16 * s + 8 * h);
+      // a negative temperature turns the maximum of s sl2 into the minimum of s
+      if (sl2 < 0.f) { bx0[u][s] = -bx0[u][s]; bx1[u][s] = -bx1[u][s]; }
     }
-  H_RM_FETCH(0, 0);
-  for (int gi = 0; gi < ngroups; ++gi) {
-    H_DMA_BARRIER();  // group gi landed; everyone is done with the other half
-    if (gi + 1 < ngroups) { H_RM_FETCH(gi + 1, (gi + 1) & 1); }
-#pragma unroll
-    for (int k = 0; k < kHRmGroup; ++k) {
-      if (gi * kHRmGroup + k < nc) {
-        const char* buf = lds + ((gi & 1) * kHRmGroup + k) * kSlot;
-        f32x16 sa;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sa[r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          const int off = j * 256 + (((2 * s + h) ^ swz16(j)) << 4);
-          const f16x8 a1 = *reinterpret_cast<const f16x8*>(buf + off);
-          if (full) {
-            const f16x8 a2 = *reinterpret_cast<const f16x8*>(buf + off + kPlaneBytes);
-            sa = H_MFMA(a2, bx0[s], sa);
-            sa = H_MFMA(a1, bx1[s], sa);
-          }
-          sa = H_MFMA(a1, bx0[s], sa);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) m = fmaxf(m, sa[r]);
-      }
-    }
-  }
-#undef H_RM_FETCH
-  m = fmaxf(m, __shfl_xor(m, 32, 64));
-  if (h == 0) part_m[(int64_t)split * B + xrow] = m * fabsf(sl2s) - kHPexp;
+  // (plane 1 of the streamed matrix is only fetched -- and the ring only holds it -- in the three-term variant; the
+  // ring is sized for the one-term variant and the three-term one runs with half-size groups)
+  const float m = full ? rowmax2h_sweep<true>(baseY, lds, B, c0, nc, bx0, bx1, t, w, j, h)
+                       : rowmax2h_sweep<false>(baseY, lds, B, c0, nc, bx0, bx1, t, w, j, h);
+  if (live) part_mr[(int64_t)split * B + xrow] = m * fabsf(sl2s) - kHPexp;
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -397,9 +459,11 @@ __global__ __launch_bounds__(256) void rowmax2h_kernel(const _Float16* __restric
 __global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __restrict__ Xr, const _Float16* __restrict__ Yr,
                                                          int64_t B, int nsplit, float sl2_in,
                                                          const float* __restrict__ sc, const float* __restrict__ ref,
+                                                         int nsplit_ref, float* __restrict__ part_m,
                                                          float* __restrict__ part_O, float* __restrict__ part_l,
                                                          float* __restrict__ Pmat) {
   __shared__ __attribute__((aligned(16))) char lds[kHBufs * kHBufBytes];
+  H_TIMING_DECL();
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int j = lane & 31, h = lane >> 5;
@@ -414,7 +478,11 @@ __global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __rest
   // P'^T tiles: see inbatch3_kernel (PMODE 1)
   char* pst_u = reinterpret_cast<char*>(Pmat) + (c0 * nch + (xrow >> 5)) * 4096;
   const uint32_t pst_v = (uint32_t)((4 * h * 32 + j) * 4);
+#if defined(H_PROBE_Q_NOSTORE)  /* timing probe only: pass Q without its P stores */
+#define H_P_ST(K, VAL)
+#else
 #define H_P_ST(K, VAL) *reinterpret_cast<float*>(pst_u + (K) * 128 + pst_v) = (VAL)
+#endif
 
   f32x16 acc[4];
 #pragma unroll
@@ -439,10 +507,11 @@ __global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __rest
   {
     float rv[8];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) rv[s] = s < nsplit ? ref[(int64_t)s * B + xrow] : -INFINITY;
+    for (int s = 0; s < 8; ++s) rv[s] = s < nsplit_ref ? ref[(int64_t)s * B + xrow] : -INFINITY;
     refv = rv[0];
 #pragma unroll
     for (int s = 1; s < 8; ++s) refv = fmaxf(refv, rv[s]);
+    if (h == 0) part_m[(int64_t)split * B + xrow] = refv;  // what merge<Q> adds back (the row-max pass has its own splits)
   }
   H_DMA_BARRIER();
 
@@ -456,19 +525,25 @@ __global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __rest
 #pragma unroll
   for (int r = 0; r < 16; ++r) p[r] = sa[r];
 
+  H_TIMING_START();
   int cur = 0;
   for (int it = 0; it + 2 < nc; ++it) {
     const int nxt = cur == kHBufs - 1 ? 0 : cur + 1;
     const int nn = nxt == kHBufs - 1 ? 0 : nxt + 1;
+    H_TICK(tk0);
     H_DMA_BARRIER();
+    H_TICK(tk1);
     const char* buf = lds + cur * kHBufBytes;
     const char* nbuf = lds + nxt * kHBufBytes;
     char* dbuf = lds + nn * kHBufBytes;
     H_TR_BASES(buf);
     H_S_PHASE(nbuf, sa, true);
+    H_TICK(tk2);
 #pragma unroll
     for (int r = 0; r < 16; ++r) p[r] = sa[r];
     H_O_PHASE(true, dbuf);
+    H_TICK(tk3);
+    H_TIMING_ACC();
     cur = nxt;
   }
   if (nc >= 2) {
@@ -504,6 +579,7 @@ __global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __rest
     H_O_PHASE(false, lds);
   }
 #undef H_P_ST
+  H_TIMING_WRITE(H_TIMING_Q);
   float* orow = part_O + ((int64_t)split * B + xrow) * k3D;
 #pragma unroll
   for (int db = 0; db < 4; ++db)
@@ -532,6 +608,7 @@ __global__ __launch_bounds__(256, 2) void inbatch2h_pc_kernel(const _Float16* __
                                                              const float* __restrict__ Pmat,
                                                              float* __restrict__ part_O) {
   __shared__ __attribute__((aligned(16))) char lds[kHBufs * kHBufBytes];
+  H_TIMING_DECL();
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int j = lane & 31, h = lane >> 5;
@@ -559,11 +636,16 @@ __global__ __launch_bounds__(256, 2) void inbatch2h_pc_kernel(const _Float16* __
   uint32_t pw[2][8], pwn[2][8];
   f16x8 ta2_[2][4][2];
   uint32_t trn_[4][2];
+#if defined(H_PROBE_PC_LINEAR)  /* timing probe only (wrong values): fully coalesced 1 KB per instruction */
+#define H_P_ADDR(g_) (base_ - (j * 32 + 4 * h) + lane * 4 + 256 * (g_))
+#else
+#define H_P_ADDR(g_) (base_ + 8 * (g_))
+#endif
 #define H_P_LOAD(CH)                                                                                      \
   {                                                                                                       \
     const float* base_ = pcol + (c0 + (CH)) * 1024;                                                       \
     _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                    \
-      const float4 v_ = *reinterpret_cast<const float4*>(base_ + 8 * g_);                                 \
+      const float4 v_ = *reinterpret_cast<const float4*>(H_P_ADDR(g_));                                   \
       pn[4 * g_] = v_.x; pn[4 * g_ + 1] = v_.y; pn[4 * g_ + 2] = v_.z; pn[4 * g_ + 3] = v_.w;             \
     }                                                                                                     \
   }
@@ -589,6 +671,7 @@ __global__ __launch_bounds__(256, 2) void inbatch2h_pc_kernel(const _Float16* __
     }                                                                                                     \
     if (DMA_ON) { H_P_LOAD(pl_next); ++pl_next; H_DMA_LSE(DBUF); }                                        \
     H_TR_WAIT();                                                                                          \
+    H_TICK(tk2);                                                                                          \
     H_SB(); H_O_ROW(1, 0, 0); H_SB(); H_O_G1(0, 3); if (DMA_ON) { H_DP(0, g0, DBUF); }                    \
     if (NEXT_ON) { H_PC_SPLIT1(pwn, 0); H_PC_SPLIT1(pwn, 1); }                                            \
     H_SB(); H_O_ROW(0, 1, 0); H_SB(); H_O_G1(3, 6); if (DMA_ON) { H_DP(1, g1, DBUF); }                    \
@@ -621,16 +704,21 @@ __global__ __launch_bounds__(256, 2) void inbatch2h_pc_kernel(const _Float16* __
 #pragma unroll
   for (int s = 0; s < 8; ++s) H_PC_SPLIT1(pw, s);
 
+  H_TIMING_START();
   int cur = 0;
   for (int it = 0; it + 2 < nc; ++it) {
     const int nxt = cur == kHBufs - 1 ? 0 : cur + 1;
     const int nn = nxt == kHBufs - 1 ? 0 : nxt + 1;
+    H_TICK(tk0);
     if (it > 0) H_DMA_BARRIER();
+    H_TICK(tk1);
     const char* buf = lds + cur * kHBufBytes;
     const char* nbuf = lds + nxt * kHBufBytes;
     char* dbuf = lds + nn * kHBufBytes;
     H_TR_BASES(buf);
     H_PC_ITER(nbuf, dbuf, true, true);
+    H_TICK(tk3);
+    H_TIMING_ACC();
     cur = nxt;
   }
   if (nc >= 2) {
@@ -647,6 +735,7 @@ __global__ __launch_bounds__(256, 2) void inbatch2h_pc_kernel(const _Float16* __
     H_TR_BASES(buf);
     H_PC_ITER(buf, lds, false, false);
   }
+  H_TIMING_WRITE(!H_TIMING_Q);
   float* orow = part_O + ((int64_t)split * B + xrow) * k3D;
 #pragma unroll
   for (int db = 0; db < 4; ++db)
@@ -658,7 +747,7 @@ __global__ __launch_bounds__(256, 2) void inbatch2h_pc_kernel(const _Float16* __
 
 struct InbatchHWs {
   _Float16 *Qh, *Ch;
-  float *part_O, *part_m, *part_l, *lse2, *invl, *Pmat, *nrm, *amax, *sc;
+  float *part_O, *part_m, *part_mr, *part_l, *lse2, *invl, *Pmat, *nrm, *amax, *sc;
   unsigned long long* loss_acc;
 };
 constexpr int64_t kHMaxB = 16384;  // B x B x 4 bytes of stored probabilities: 1 GiB
@@ -676,6 +765,7 @@ static size_t inbatch2h_ws_layout(int64_t B, char* base, InbatchHWs* ws) {
   w.Ch = (_Float16*)take(planes);
   w.part_O = (float*)take((size_t)8 * B * k3D * 4);
   w.part_m = (float*)take((size_t)8 * B * 4);
+  w.part_mr = (float*)take((size_t)8 * B * 4);
   w.part_l = (float*)take((size_t)8 * B * 4);
   w.lse2 = (float*)take((size_t)B * 4);
   w.invl = (float*)take((size_t)B * 4);
@@ -702,6 +792,12 @@ static int inbatch2h_nsplit(int64_t B, int per_cu) {
 using namespace esr;
 
 extern "C" {
+
+#ifdef H_TIMING
+int esr_ib2h_debug_read(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(esr_ib2h_dbg), sizeof(unsigned long long) * 8192);
+}
+#endif
 
 size_t esr_inbatch2h_workspace_bytes(int64_t B, int D) {
   (void)D;
@@ -743,7 +839,8 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
   inbatch2h_ws_layout(B, (char*)workspace, &ws);
   const float inv_bs = 1.0f / batch_size, sl2 = scale * k3Log2e;
   const int nchunks = (int)(B / k3Chunk);
-  const int nsplit_q = inbatch2h_nsplit(B, 1);
+  const char* qcs = getenv("ESR_IB2H_Q_PER_CU");
+  const int nsplit_q = inbatch2h_nsplit(B, qcs ? std::max(1, atoi(qcs)) : 2);  // 252 registers, 50 KB of LDS: two per CU
   const char* pcs = getenv("ESR_IB2H_PC_PER_CU");
   const int nsplit_c = inbatch2h_nsplit(B, pcs ? std::max(1, atoi(pcs)) : 2);
   const int grid_q = (int)(B / k3Owned) * nsplit_q, grid_c = (int)(B / k3Owned) * nsplit_c;
@@ -751,10 +848,15 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
   hipLaunchKernelGGL(absmax2h_kernel, dim3(nchunks, 2), dim3(256), 0, st, Qs, Cs, ws.amax);
   hipLaunchKernelGGL(split2h_kernel, dim3(nchunks, 2), dim3(256), 0, st, Qs, Cs, B, ws.Qh, ws.Ch, (const float*)ws.amax,
                      ws.nrm, ws.sc, ws.loss_acc);
-  hipLaunchKernelGGL(rowmax2h_kernel, dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Qh, (const _Float16*)ws.Ch, B,
-                     nsplit_q, sl2, (const float*)ws.nrm, (const float*)ws.sc, ws.part_m);
+  const int rm_blocks = (int)cdiv(B, kHRmOwned);
+  int nsplit_r = 1;
+  for (int sp = 1; sp <= 8; ++sp)
+    if (nchunks % sp == 0 && rm_blocks * sp <= 320) nsplit_r = sp;
+  hipLaunchKernelGGL(rowmax2h_kernel, dim3(rm_blocks * nsplit_r), dim3(256), 0, st, (const _Float16*)ws.Qh,
+                     (const _Float16*)ws.Ch, B, nsplit_r, sl2, (const float*)ws.nrm, (const float*)ws.sc, ws.part_mr);
   hipLaunchKernelGGL(inbatch2h_q_kernel, dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Qh, (const _Float16*)ws.Ch,
-                     B, nsplit_q, sl2, (const float*)ws.sc, (const float*)ws.part_m, ws.part_O, ws.part_l, ws.Pmat);
+                     B, nsplit_q, sl2, (const float*)ws.sc, (const float*)ws.part_mr, nsplit_r, ws.part_m, ws.part_O,
+                     ws.part_l, ws.Pmat);
   // O_Q' = 2^ec 2^14 sum p c, l' = 2^14 l: o / l needs 2^-ec (sc[1]); the stored normaliser carries pass C's 2^14
   hipLaunchKernelGGL((inbatch3_merge_kernel<true>), dim3(mgrid), dim3(kBlock), 0, st, Qs, Cs, gq_rows, B, nsplit_q,
                      (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale, regularization,
