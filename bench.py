@@ -151,7 +151,27 @@ def roofline_for(workload, kernels, B, D, rows, precision, occ_n=0, uniq=0, bf16
     if workload == "inbatch":
         t = kernels["inbatch_mfma"]["ms_per_step"] * 1e-3
         alg = 6.0 * B * B * D  # S = QC^T, dQ = PC, dC = P^T Q in f32
-        if precision != "f32" and D == 128 and B % 128 == 0:
+        split_path = None
+        if D == 128 and B % 128 == 0:
+            from esrecsys_amd import ops as _ops
+            split_path = _ops.inbatch_split_path(precision, B, D, bf16_tables=bf16_tables)
+        if split_path == "f16x2":
+            # fp16 x 2 path (esr_inbatch2h.hip): three MFMA terms per f32-grade product, pass C reads the stored
+            # probabilities: 3 GEMM units x 3 terms x 2 B^2 D executed fp16 flops (+ one hi-plane term for the row
+            # maxima when the Cauchy-Schwarz bound on the scores exceeds 14 log2 units)
+            terms = 3 * 3 + (1 if rowmax_gemm else 0)
+            executed = terms * 2.0 * B * B * D
+            return {"kernel": "absmax + split2h + rowmax2h + inbatch2h_q_kernel + merge + inbatch2h_pc_kernel + merge",
+                    "pass_c": "reads stored P (B*B*4 bytes written by pass Q)",
+                    "bound": "mfma", "achieved": executed / t / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": executed / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                    "dtype": "fp16 x2 split, f32 accumulate (f32-grade products; the dense fp16 MFMA peak equals the "
+                             "bf16 one)",
+                    "executed_cross_terms": terms,
+                    "executed_cross_terms_of_the_bf16x3_path": 18 + (1 if rowmax_gemm else 0),
+                    "f32_equivalent_TFLOPs": alg / t / 1e12,
+                    "f32_equivalent_vs_f32_mfma_peak": alg / t / 1e12 / MFMA_F32_PEAK_TFLOPS}
+        if split_path == "bf16x3":
             # bf16x3 path: every f32 product = 6 bf16 MFMA terms and S is recomputed in pass C: 4 GEMM units x 6
             # terms x 2 B^2 D executed bf16 flops; the row-max pre-pass (one hi-plane term) only runs when the
             # Cauchy-Schwarz bound on the scores is too wide (not on these inputs).  bf16-exact operands (bf16
@@ -450,12 +470,17 @@ def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True
     n_batches = steps + warmup
     state, batches = make_state_and_batches(workload, cfg, dev, n_batches, rank)
     needs_rowmax = False
+    path = None
     if workload == "inbatch":
         # the kernel's own criterion (esr_inbatch3.hip, kRmSafeBound), on the table-wide norm maxima (>= any batch's)
         pr = state.params["params"]
         mq = float(pr["scene_tower"]["embedding"].float().pow(2).sum(1).max())
         mc = float(pr["product_tower"]["embedding"].float().pow(2).sum(1).max())
-        needs_rowmax = (mq * mc) ** 0.5 * abs(SCALE) * 1.4426950408889634 > 28.0
+        from esrecsys_amd import ops as _ops
+        path = _ops.inbatch_split_path(PRECISION, B, D, bf16_tables=cfg.get("table_dtype") == "bf16") \
+            if D == 128 and B % 128 == 0 else None
+        # (kRmSafeBound = 28 in esr_inbatch3.hip; kHBoundSafe = 14 in esr_inbatch2h.hip, fp16's narrower exponent range)
+        needs_rowmax = (mq * mc) ** 0.5 * abs(SCALE) * 1.4426950408889634 > (14.0 if path == "f16x2" else 28.0)
     timer = kernel_timer()
 
     # ---- timed region: K steps (eager launches; --graph replays the whole step as one hipGraph) ----------------
@@ -619,7 +644,8 @@ def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True
         "value": B * K / dt, "unit": cfg["unit"] + "s/s", "steps": K, "warmup": warmup, "ms_per_step": dt / K * 1e3,
         "config": {"workload": "%s: V=%d x D=%d %s tables, B=%d, sparse Adagrad"
                                % (workload, V, D, "bf16" if cfg.get("table_dtype") == "bf16" else "fp32", B),
-                   "score_precision": PRECISION, "ids": cfg.get("ids", "uniform"),
+                   "score_precision": PRECISION if workload != "inbatch" else "%s -> %s" % (PRECISION, path or "f32"),
+                   "ids": cfg.get("ids", "uniform"),
                    "parallelism": "single", "launch": mode, "loss": final_loss},
         "roofline": roofline, "kernels": kernels, "hbm_gather_scatter": hbm,
     }
@@ -682,7 +708,7 @@ def main():
                          "permutation of the rows (SURVEY 8d secondary: stresses duplicate ids in the sparse update)")
     ap.add_argument("--table-dtype", default="f32", choices=["f32", "bf16"],
                     help="table storage (accumulators stay fp32); bf16 needs the in-batch workload or the sharded leg")
-    ap.add_argument("--precision", default="auto", choices=["auto", "f32", "bf16x3"],
+    ap.add_argument("--precision", default="auto", choices=["auto", "f32", "bf16x3", "f16x2"],
                     help="MFMA path of the in-batch score kernel (both are f32-grade; see DESIGN.md 2.2)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="skip the per-kernel HIP-event pass (used under rocprofv3 so the spin kernel of that pass "

@@ -75,6 +75,33 @@ __device__ __forceinline__ f16x2 pk_f16(float lo, float hi) {  // v_cvt_pk_f16_f
   return __builtin_convertvector(v, f16x2);
 }
 
+// x - (float)h in one instruction (v_fma_mix_f32: the fp16 operand is widened inside the FMA; exact, the difference of
+// an f32 and its own fp16 rounding is representable)
+__device__ __forceinline__ float resid_f16(float x, _Float16 hval) { return __builtin_fmaf((float)hval, -1.0f, x); }
+// The same on the two halves of a packed pair, written as the instruction itself: hipcc turns the C form back into
+// v_cvt_f32_f16 + v_sub (5 VALU instructions per pair of probabilities instead of 3, in a phase bound by VALU issue)
+__device__ __forceinline__ float resid_lo(float x, f16x2 pk) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(x));
+  return r;
+}
+__device__ __forceinline__ float resid_hi(float x, f16x2 pk) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(x));
+  return r;
+}
+// packed f32 arithmetic on register pairs (the compiler scalarises the vector form when the pair is not already adjacent)
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+  f32x2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // A fragment F (0..7: plane (F / 4 + 1) % 2 -- the order the O^T rows use them -- column block F % 4) of k-step G
 template <int G, int F, class TA>
 __device__ __forceinline__ void trh_frag(TA& ta, const uint32_t (&tc)[4][2]) {
@@ -389,8 +416,9 @@ __global__ __launch_bounds__(256) void rowmax2h_kernel(const _Float16* __restric
       SA = H_MFMA(a2_, bx[0][s_], SA);                                                                    \
       H_SB();                                                                                             \
       if (VALU_ON) {                                                                                      \
-        e0_ = __builtin_amdgcn_exp2f(fmaf(p[2 * s_], sl2, -refv));                                        \
-        e1_ = __builtin_amdgcn_exp2f(fmaf(p[2 * s_ + 1], sl2, -refv));                                    \
+        const f32x2 arg_ = pk_fma(f32x2{p[2 * s_], p[2 * s_ + 1]}, sl2v, nrefv);                          \
+        e0_ = __builtin_amdgcn_exp2f(arg_[0]);                                                            \
+        e1_ = __builtin_amdgcn_exp2f(arg_[1]);                                                            \
         trh_frag_n<0>(s_, ta2_, trc_); /* one of the 8 G = 0 fragments of the coming O^T phase */          \
       }                                                                                                   \
       H_SB();                                                                                             \
@@ -398,7 +426,7 @@ __global__ __launch_bounds__(256) void rowmax2h_kernel(const _Float16* __restric
       H_SB();                                                                                             \
       if (VALU_ON) {                                                                                      \
         pa_ = pk_f16(e0_, e1_);                                                                           \
-        l += e0_ + e1_;                                                                                   \
+        l2 = pk_add(l2, f32x2{e0_, e1_});                                                                 \
         H_P_ST(((2 * s_) & 3) + 8 * ((2 * s_) >> 2), e0_);                                                \
         H_P_ST(((2 * s_ + 1) & 3) + 8 * ((2 * s_ + 1) >> 2), e1_);                                        \
       }                                                                                                   \
@@ -406,7 +434,7 @@ __global__ __launch_bounds__(256) void rowmax2h_kernel(const _Float16* __restric
       SA = H_MFMA(a1_, bx[0][s_], SA);                                                                    \
       H_SB();                                                                                             \
       if (VALU_ON) {                                                                                      \
-        const f16x2 pq_ = pk_f16(e0_ - (float)pa_[0], e1_ - (float)pa_[1]);                               \
+        const f16x2 pq_ = pk_f16(resid_lo(e0_, pa_), resid_hi(e1_, pa_));                                 \
         pw[0][s_] = __builtin_bit_cast(uint32_t, pa_);                                                    \
         pw[1][s_] = __builtin_bit_cast(uint32_t, pq_);                                                    \
       }                                                                                                   \
@@ -489,7 +517,7 @@ __global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __rest
   for (int db = 0; db < 4; ++db)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[db][r] = 0.f;
-  float l = 0.f;
+  f32x2 l2 = {0.f, 0.f};  // even / odd score pairs; added in a fixed order at the end
 
   int dpos = 0;
   const char* const baseY = reinterpret_cast<const char*>(Yr);
@@ -513,6 +541,7 @@ __global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __rest
     for (int s = 1; s < 8; ++s) refv = fmaxf(refv, rv[s]);
     if (h == 0) part_m[(int64_t)split * B + xrow] = refv;  // what merge<Q> adds back (the row-max pass has its own splits)
   }
+  const f32x2 sl2v = {sl2, sl2}, nrefv = {-refv, -refv};
   H_DMA_BARRIER();
 
   f32x16 sa;
@@ -566,11 +595,12 @@ __global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __rest
     for (int f = 0; f < 8; ++f) trh_frag_n<0>(f, ta2_, trc_);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      const float e0 = __builtin_amdgcn_exp2f(fmaf(p[2 * s], sl2, -refv));
-      const float e1 = __builtin_amdgcn_exp2f(fmaf(p[2 * s + 1], sl2, -refv));
-      l += e0 + e1;
+      const f32x2 arg = f32x2{p[2 * s], p[2 * s + 1]} * sl2v + nrefv;
+      const float e0 = __builtin_amdgcn_exp2f(arg[0]);
+      const float e1 = __builtin_amdgcn_exp2f(arg[1]);
+      l2 += f32x2{e0, e1};
       const f16x2 pa = pk_f16(e0, e1);
-      const f16x2 pq = pk_f16(e0 - (float)pa[0], e1 - (float)pa[1]);
+      const f16x2 pq = pk_f16(resid_f16(e0, pa[0]), resid_f16(e1, pa[1]));
       pw[0][s] = __builtin_bit_cast(uint32_t, pa);
       pw[1][s] = __builtin_bit_cast(uint32_t, pq);
       H_P_ST(((2 * s) & 3) + 8 * ((2 * s) >> 2), e0);
@@ -587,6 +617,7 @@ __global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __rest
     for (int q = 0; q < 4; ++q)
       *reinterpret_cast<float4*>(orow + 32 * db + 8 * q + 4 * h) =
           make_float4(acc[db][4 * q], acc[db][4 * q + 1], acc[db][4 * q + 2], acc[db][4 * q + 3]);
+  const float l = l2[0] + l2[1];
   const float ltot = l + __shfl_xor(l, 32, 64);
   if (h == 0) part_l[(int64_t)split * B + xrow] = ltot;
 }
@@ -653,7 +684,7 @@ __global__ __launch_bounds__(256, 2) void inbatch2h_pc_kernel(const _Float16* __
   {                                                                                                       \
     const float e0_ = p1[2 * (S)] * rf[2 * (S)], e1_ = p1[2 * (S) + 1] * rf[2 * (S) + 1];                 \
     const f16x2 pa_ = pk_f16(e0_, e1_);                                                                   \
-    const f16x2 pq_ = pk_f16(e0_ - (float)pa_[0], e1_ - (float)pa_[1]);                                   \
+    const f16x2 pq_ = pk_f16(resid_f16(e0_, pa_[0]), resid_f16(e1_, pa_[1]));                             \
     PW[0][S] = __builtin_bit_cast(uint32_t, pa_);                                                         \
     PW[1][S] = __builtin_bit_cast(uint32_t, pq_);                                                         \
   }
