@@ -30,8 +30,10 @@ namespace esr {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kHLseOff = 2 * kPlaneBytes;   // two row-major planes, then 128 B of per-streamed-row factors (pass C)
-constexpr int kHBufBytes = kHLseOff + 256;
+constexpr int kHLseOff = 2 * kPlaneBytes;   // two row-major planes, then (pass C) one 256-B block of per-streamed-row
+constexpr int kHBufBytes = kHLseOff + 4 * 256;  // factors PER WAVE (a 4-byte LDS-DMA writes 64 lanes x 4 B)
+constexpr float kHOptHead = 4.0f;           // optimistic reference: p' = 2^4 at the reference score, overflow 12 binades up
+constexpr float kHOverflow = 60000.0f;      // a probability beyond it does not fit fp16 (max 65504): redo the block
 constexpr int kHBufs = 3;
 constexpr float kHPexp = 14.0f;             // probabilities are carried as p * 2^14
 constexpr float kHBoundSafe = 14.0f;        // Cauchy-Schwarz bound (log2 units) below which no row maximum is needed
@@ -145,25 +147,40 @@ __device__ __forceinline__ void dmah_piece(const char* __restrict__ base, uint32
 #define H_DMA_CHUNK(BUF) { H_DP(0, g0, BUF); H_DP(1, g1, BUF); H_DP(2, g2, BUF); H_DP(3, g3, BUF); H_DMA_ADVANCE(); }
 
 // -----------------------------------------------------------------------------------------------------------------
-// absmax pre-pass: largest |element| of the 32 rows of one chunk of one matrix -> amax[matrix][chunk]
+// prep pre-pass, one block per 32-row chunk: largest |element| of the chunk's Q rows and of its C rows
+// -> amax[matrix][chunk] (the operand scales), and the diagonal scores diag[i] = q_i . c_i in f32 (pass Q's optimistic
+// exponent reference: the positive pair is the score most likely to dominate its row).
 // -----------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void absmax2h_kernel(RowSrc X0, RowSrc X1, float* __restrict__ amax) {
-  __shared__ float red[4];
-  const RowSrc X = blockIdx.y ? X1 : X0;
+__global__ __launch_bounds__(256) void prep2h_kernel(RowSrc X0, RowSrc X1, float* __restrict__ amax,
+                                                    float* __restrict__ diag) {
+  __shared__ float red[8];
   const int t = threadIdx.x;
   const int64_t grow = (int64_t)blockIdx.x * 32 + (t >> 3);
   const int d0 = (t & 7) * 16;
-  float m = 0.f;
+  float mq = 0.f, mc = 0.f, dot = 0.f;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const float4 f = rowsrc_load4(X, grow, d0 + 4 * q);
-    m = fmaxf(m, fmaxf(fmaxf(fabsf(f.x), fabsf(f.y)), fmaxf(fabsf(f.z), fabsf(f.w))));
+    const float4 f = rowsrc_load4(X0, grow, d0 + 4 * q);
+    const float4 g = rowsrc_load4(X1, grow, d0 + 4 * q);
+    mq = fmaxf(mq, fmaxf(fmaxf(fabsf(f.x), fabsf(f.y)), fmaxf(fabsf(f.z), fabsf(f.w))));
+    mc = fmaxf(mc, fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w))));
+    dot = fmaf(f.x, g.x, fmaf(f.y, g.y, fmaf(f.z, g.z, fmaf(f.w, g.w, dot))));
   }
+  dot += __shfl_xor(dot, 1, 64);
+  dot += __shfl_xor(dot, 2, 64);
+  dot += __shfl_xor(dot, 4, 64);
+  if ((t & 7) == 0) diag[grow] = dot;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((t & 63) == 0) red[t >> 6] = m;
+  for (int o = 32; o > 0; o >>= 1) {
+    mq = fmaxf(mq, __shfl_xor(mq, o, 64));
+    mc = fmaxf(mc, __shfl_xor(mc, o, 64));
+  }
+  if ((t & 63) == 0) { red[t >> 6] = mq; red[4 + (t >> 6)] = mc; }
   __syncthreads();
-  if (t == 0) amax[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  if (t == 0) {
+    amax[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    amax[gridDim.x + blockIdx.x] = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+  }
 }
 
 // exponent e with amax * 2^e in [2^13, 2^14) (0 for an all-zero or non-finite matrix)
@@ -182,8 +199,11 @@ __device__ __forceinline__ int scale_exp(float amax) {
 __global__ __launch_bounds__(256) void split2h_kernel(RowSrc X0, RowSrc X1, int64_t B, _Float16* __restrict__ R0,
                                                      _Float16* __restrict__ R1, const float* __restrict__ amax,
                                                      float* __restrict__ nrm, float* __restrict__ sc,
-                                                     unsigned long long* __restrict__ loss_acc) {
+                                                     unsigned long long* __restrict__ loss_acc,
+                                                     int* __restrict__ flags, int nflags) {
   __shared__ float red[8];
+  if (blockIdx.x == 0 && blockIdx.y == 1)  // pass Q's "redo this block" flags
+    for (int i = threadIdx.x; i < nflags; i += 256) flags[i] = 0;
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x <= kLossWords) {  // see inbatch3_merge_kernel
     loss_acc[threadIdx.x * 16] = 0ull;
     if (threadIdx.x == 0) loss_acc[8] = 0ull;  // poison word
@@ -427,6 +447,7 @@ __global__ __launch_bounds__(256) void rowmax2h_kernel(const _Float16* __restric
       if (VALU_ON) {                                                                                      \
         pa_ = pk_f16(e0_, e1_);                                                                           \
         l2 = pk_add(l2, f32x2{e0_, e1_});                                                                 \
+        emax = __builtin_fmaxf(emax, __builtin_fmaxf(e0_, e1_)); /* v_max3_f32 */                          \
         H_P_ST(((2 * s_) & 3) + 8 * ((2 * s_) >> 2), e0_);                                                \
         H_P_ST(((2 * s_ + 1) & 3) + 8 * ((2 * s_ + 1) >> 2), e1_);                                        \
       }                                                                                                   \
@@ -484,13 +505,25 @@ __global__ __launch_bounds__(256) void rowmax2h_kernel(const _Float16* __restric
     trb_[db][1] = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds + tr_row1 + (((db ^ tr_a) << 6) | tr_l1); \
   }
 
+// The exponent reference M of a (128-row block, split) workgroup, `mode`:
+//   0  from the row-max pass (part_mr, its own splits): exact, costs that pass (28 us at B = 8192);
+//   1  OPTIMISTIC: M = max(diagonal score, largest score of the workgroup's first chunk) - 4.  Exact whenever no score
+//      of the workgroup's range exceeds that reference by 12 binades (a candidate 4000 x more probable than both the
+//      positive pair and the best of 32 others); the kernel tracks its largest probability, and a workgroup that saw
+//      one beyond fp16's range raises flags[blockIdx.x];
+//   FIX (second launch of the same grid, one load and exit for unflagged workgroups): the flagged ones sweep their
+//      range for the exact score maximum and run again.  Nothing downstream depends on which launch produced a block:
+//      merge<Q> combines splits with different references, and pass C takes its factors per (row, split).
+template <bool FIX>
 __global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __restrict__ Xr, const _Float16* __restrict__ Yr,
                                                          int64_t B, int nsplit, float sl2_in,
                                                          const float* __restrict__ sc, const float* __restrict__ ref,
-                                                         int nsplit_ref, float* __restrict__ part_m,
+                                                         int nsplit_ref, const float* __restrict__ diag, int mode,
+                                                         int* __restrict__ flags, float* __restrict__ part_m,
                                                          float* __restrict__ part_O, float* __restrict__ part_l,
                                                          float* __restrict__ Pmat) {
   __shared__ __attribute__((aligned(16))) char lds[kHBufs * kHBufBytes];
+  if (FIX && flags[blockIdx.x] == 0) return;
   H_TIMING_DECL();
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -523,36 +556,60 @@ __global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __rest
   const char* const baseY = reinterpret_cast<const char*>(Yr);
   uint32_t g0 = dmah_off0<0>(B, c0, t), g1 = dmah_off0<1>(B, c0, t), g2 = dmah_off0<2>(B, c0, t),
            g3 = dmah_off0<3>(B, c0, t);
-  H_DMA_CHUNK(lds);
-  if (nc > 1) H_DMA_CHUNK(lds + kHBufBytes);
   f16x8 bx[2][8];
 #pragma unroll
   for (int p = 0; p < 2; ++p)
 #pragma unroll
     for (int s = 0; s < 8; ++s)
       bx[p][s] = *reinterpret_cast<const f16x8*>(Xr + ((int64_t)p * B + xrow) * k3D + 16 * s + 8 * h);
-  float refv;
-  {
+  f32x16 sa;
+  float p[16];
+  uint32_t pw[2][8];
+  f16x8 ta2_[2][4][2];
+  float emax = 0.f;
+  float refv = -INFINITY;
+  const f32x2 sl2v = {sl2, sl2};
+  f32x2 nrefv = {0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < 16; ++r) p[r] = 0.f;
+  if (FIX) {
+    // exact maximum of s sl2 over this workgroup's chunks (one tile at a time; this path runs for flagged blocks only).
+    // The DMA offsets wrap after nc chunks: the ring state is back at chunk 0 afterwards.
+    float m = -INFINITY;
+    for (int c = 0; c < nc; ++c) {
+      H_DMA_CHUNK(lds);
+      H_DMA_BARRIER();
+      H_S_PHASE(lds, sa, false);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, sa[r] * sl2);
+      __syncthreads();  // the next tile overwrites this one
+    }
+    refv = fmaxf(m, __shfl_xor(m, 32, 64)) - kHPexp;
+  }
+  H_DMA_CHUNK(lds);
+  if (nc > 1) H_DMA_CHUNK(lds + kHBufBytes);
+  if (!FIX && mode == 0) {
     float rv[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) rv[s] = s < nsplit_ref ? ref[(int64_t)s * B + xrow] : -INFINITY;
     refv = rv[0];
 #pragma unroll
     for (int s = 1; s < 8; ++s) refv = fmaxf(refv, rv[s]);
-    if (h == 0) part_m[(int64_t)split * B + xrow] = refv;  // what merge<Q> adds back (the row-max pass has its own splits)
   }
-  const f32x2 sl2v = {sl2, sl2}, nrefv = {-refv, -refv};
+  const float dref = (!FIX && mode == 1) ? diag[xrow] * sl2_in : -INFINITY;
   H_DMA_BARRIER();
 
-  f32x16 sa;
-  float p[16];
-  uint32_t pw[2][8];
-  f16x8 ta2_[2][4][2];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) p[r] = 0.f;
   H_S_PHASE(lds, sa, false);
 #pragma unroll
   for (int r = 0; r < 16; ++r) p[r] = sa[r];
+  if (!FIX && mode == 1) {
+    float m = dref;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m = fmaxf(m, sa[r] * sl2);
+    refv = fmaxf(m, __shfl_xor(m, 32, 64)) - kHOptHead;
+  }
+  if (h == 0) part_m[(int64_t)split * B + xrow] = refv;  // what merge<Q> adds back
+  nrefv = f32x2{-refv, -refv};
 
   H_TIMING_START();
   int cur = 0;
@@ -599,8 +656,9 @@ __global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __rest
       const float e0 = __builtin_amdgcn_exp2f(arg[0]);
       const float e1 = __builtin_amdgcn_exp2f(arg[1]);
       l2 += f32x2{e0, e1};
+      emax = fmaxf(emax, fmaxf(e0, e1));
       const f16x2 pa = pk_f16(e0, e1);
-      const f16x2 pq = pk_f16(resid_f16(e0, pa[0]), resid_f16(e1, pa[1]));
+      const f16x2 pq = pk_f16(resid_lo(e0, pa), resid_hi(e1, pa));
       pw[0][s] = __builtin_bit_cast(uint32_t, pa);
       pw[1][s] = __builtin_bit_cast(uint32_t, pq);
       H_P_ST(((2 * s) & 3) + 8 * ((2 * s) >> 2), e0);
@@ -620,6 +678,8 @@ __global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __rest
   const float l = l2[0] + l2[1];
   const float ltot = l + __shfl_xor(l, 32, 64);
   if (h == 0) part_l[(int64_t)split * B + xrow] = ltot;
+  // a probability that does not fit fp16 (or a forced redo: mode 2 is the test hook): the FIX launch redoes this block
+  if (!FIX && (mode == 2 || !(emax <= kHOverflow))) flags[blockIdx.x] = 1;
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -628,14 +688,15 @@ __global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __rest
 // pipeline as inbatch3_pc_kernel; two (or more) workgroups per CU.
 // -----------------------------------------------------------------------------------------------------------------
 #define H_DMA_LSE(BUF)                                                                                    \
-  __builtin_amdgcn_global_load_lds((gptr_t)(ref + (c0 + dpos) * 32 + (lane & 31)), (lptr_t)((BUF) + kHLseOff), 4, 0, 0);
+  __builtin_amdgcn_global_load_lds((gptr_t)(ref + (c0 + dpos) * 32 + (lane & 31)),                        \
+                                   (lptr_t)((BUF) + kHLseOff + w * 256), 4, 0, 0);
 #define H_LOAD_REFS(BUF)                                                                                  \
   _Pragma("unroll") for (int g4_ = 0; g4_ < 4; ++g4_) {                                                   \
-    const float4 lv_ = *reinterpret_cast<const float4*>((BUF) + kHLseOff + (8 * g4_ + 4 * h) * 4);         \
+    const float4 lv_ = *reinterpret_cast<const float4*>((BUF) + kHLseOff + w * 256 + (8 * g4_ + 4 * h) * 4); \
     rf[4 * g4_] = lv_.x; rf[4 * g4_ + 1] = lv_.y; rf[4 * g4_ + 2] = lv_.z; rf[4 * g4_ + 3] = lv_.w;       \
   }
 __global__ __launch_bounds__(256, 2) void inbatch2h_pc_kernel(const _Float16* __restrict__ Yr, int64_t B, int nsplit,
-                                                             const float* __restrict__ ref,
+                                                             const float* __restrict__ fac, int nc_q,
                                                              const float* __restrict__ Pmat,
                                                              float* __restrict__ part_O) {
   __shared__ __attribute__((aligned(16))) char lds[kHBufs * kHBufBytes];
@@ -649,6 +710,9 @@ __global__ __launch_bounds__(256, 2) void inbatch2h_pc_kernel(const _Float16* __
   const int nc = (int)(B / k3Chunk) / nsplit;
   const int64_t c0 = (int64_t)split * nc;
   const int64_t nch = B / 32;
+  // this wave's 32 owned rows j were one streamed chunk of pass Q, in split (chunk index) / nc_q: its probabilities
+  // carry that split's exponent reference, and merge<Q> left the matching factors 2^14 2^(M_split - M) / l in fac[split]
+  const float* ref = fac + (int64_t)((ob * 4 + w) / nc_q) * B;
 
   f32x16 acc[4];
 #pragma unroll
@@ -684,7 +748,7 @@ __global__ __launch_bounds__(256, 2) void inbatch2h_pc_kernel(const _Float16* __
   {                                                                                                       \
     const float e0_ = p1[2 * (S)] * rf[2 * (S)], e1_ = p1[2 * (S) + 1] * rf[2 * (S) + 1];                 \
     const f16x2 pa_ = pk_f16(e0_, e1_);                                                                   \
-    const f16x2 pq_ = pk_f16(resid_f16(e0_, pa_[0]), resid_f16(e1_, pa_[1]));                             \
+    const f16x2 pq_ = pk_f16(resid_lo(e0_, pa_), resid_hi(e1_, pa_));                                     \
     PW[0][S] = __builtin_bit_cast(uint32_t, pa_);                                                         \
     PW[1][S] = __builtin_bit_cast(uint32_t, pq_);                                                         \
   }
@@ -778,7 +842,8 @@ __global__ __launch_bounds__(256, 2) void inbatch2h_pc_kernel(const _Float16* __
 
 struct InbatchHWs {
   _Float16 *Qh, *Ch;
-  float *part_O, *part_m, *part_mr, *part_l, *lse2, *invl, *Pmat, *nrm, *amax, *sc;
+  float *part_O, *part_m, *part_mr, *part_l, *lse2, *fac, *Pmat, *nrm, *amax, *sc, *diag;
+  int* flags;
   unsigned long long* loss_acc;
 };
 constexpr int64_t kHMaxB = 16384;  // B x B x 4 bytes of stored probabilities: 1 GiB
@@ -799,7 +864,9 @@ static size_t inbatch2h_ws_layout(int64_t B, char* base, InbatchHWs* ws) {
   w.part_mr = (float*)take((size_t)8 * B * 4);
   w.part_l = (float*)take((size_t)8 * B * 4);
   w.lse2 = (float*)take((size_t)B * 4);
-  w.invl = (float*)take((size_t)B * 4);
+  w.fac = (float*)take((size_t)8 * B * 4);
+  w.diag = (float*)take((size_t)B * 4);
+  w.flags = (int*)take((size_t)8 * (B / k3Owned) * sizeof(int));
   w.Pmat = (float*)take((size_t)B * B * 4);
   w.loss_acc = (unsigned long long*)take(sizeof(unsigned long long) * 16 * (1 + kLossWords));
   w.nrm = (float*)take((size_t)2 * (B / k3Chunk) * 4 * sizeof(float));
@@ -876,25 +943,35 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
   const int nsplit_c = inbatch2h_nsplit(B, pcs ? std::max(1, atoi(pcs)) : 2);
   const int grid_q = (int)(B / k3Owned) * nsplit_q, grid_c = (int)(B / k3Owned) * nsplit_c;
   const int mgrid = (int)std::min<int64_t>(k3MergeBlocks, cdiv(B, kBlock / 32));
-  hipLaunchKernelGGL(absmax2h_kernel, dim3(nchunks, 2), dim3(256), 0, st, Qs, Cs, ws.amax);
+  // exponent reference of pass Q: optimistic + redo launch (default), or the row-max pass (ESR_IB2H_REF=rowmax);
+  // ESR_IB2H_REF=redo forces every block through the redo launch (test hook)
+  const char* refe = getenv("ESR_IB2H_REF");
+  const int mode = (refe && refe[0] == 'r' && refe[1] == 'o') ? 0 : ((refe && refe[0] == 'r' && refe[1] == 'e') ? 2 : 1);
+  hipLaunchKernelGGL(prep2h_kernel, dim3(nchunks), dim3(256), 0, st, Qs, Cs, ws.amax, ws.diag);
   hipLaunchKernelGGL(split2h_kernel, dim3(nchunks, 2), dim3(256), 0, st, Qs, Cs, B, ws.Qh, ws.Ch, (const float*)ws.amax,
-                     ws.nrm, ws.sc, ws.loss_acc);
-  const int rm_blocks = (int)cdiv(B, kHRmOwned);
+                     ws.nrm, ws.sc, ws.loss_acc, ws.flags, grid_q);
   int nsplit_r = 1;
-  for (int sp = 1; sp <= 8; ++sp)
-    if (nchunks % sp == 0 && rm_blocks * sp <= 320) nsplit_r = sp;
-  hipLaunchKernelGGL(rowmax2h_kernel, dim3(rm_blocks * nsplit_r), dim3(256), 0, st, (const _Float16*)ws.Qh,
-                     (const _Float16*)ws.Ch, B, nsplit_r, sl2, (const float*)ws.nrm, (const float*)ws.sc, ws.part_mr);
-  hipLaunchKernelGGL(inbatch2h_q_kernel, dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Qh, (const _Float16*)ws.Ch,
-                     B, nsplit_q, sl2, (const float*)ws.sc, (const float*)ws.part_mr, nsplit_r, ws.part_m, ws.part_O,
-                     ws.part_l, ws.Pmat);
-  // O_Q' = 2^ec 2^14 sum p c, l' = 2^14 l: o / l needs 2^-ec (sc[1]); the stored normaliser carries pass C's 2^14
+  if (mode == 0) {
+    const int rm_blocks = (int)cdiv(B, kHRmOwned);
+    for (int sp = 1; sp <= 8; ++sp)
+      if (nchunks % sp == 0 && rm_blocks * sp <= 320) nsplit_r = sp;
+    hipLaunchKernelGGL(rowmax2h_kernel, dim3(rm_blocks * nsplit_r), dim3(256), 0, st, (const _Float16*)ws.Qh,
+                       (const _Float16*)ws.Ch, B, nsplit_r, sl2, (const float*)ws.nrm, (const float*)ws.sc, ws.part_mr);
+  }
+  hipLaunchKernelGGL((inbatch2h_q_kernel<false>), dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Qh,
+                     (const _Float16*)ws.Ch, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)ws.part_mr, nsplit_r,
+                     (const float*)ws.diag, mode, ws.flags, ws.part_m, ws.part_O, ws.part_l, ws.Pmat);
+  if (mode != 0)  // redo launch: workgroups whose block is not flagged (normally all of them) exit after one load
+    hipLaunchKernelGGL((inbatch2h_q_kernel<true>), dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Qh,
+                       (const _Float16*)ws.Ch, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)ws.part_mr, nsplit_r,
+                       (const float*)ws.diag, mode, ws.flags, ws.part_m, ws.part_O, ws.part_l, ws.Pmat);
+  // O_Q' = 2^ec sum p' c, l' = sum p': o / l needs 2^-ec (sc[1]); the stored factors carry pass C's 2^14
   hipLaunchKernelGGL((inbatch3_merge_kernel<true>), dim3(mgrid), dim3(kBlock), 0, st, Qs, Cs, gq_rows, B, nsplit_q,
                      (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale, regularization,
-                     inv_bs, ws.lse2, lse, gQ, ws.loss_acc, 1.0 / (double)batch_size, loss, ws.invl,
-                     (const float*)(ws.sc + 1), ldexpf(1.f, (int)kHPexp));
+                     inv_bs, ws.lse2, lse, gQ, ws.loss_acc, 1.0 / (double)batch_size, loss, (float*)nullptr,
+                     (const float*)(ws.sc + 1), ldexpf(1.f, (int)kHPexp), ws.fac);
   hipLaunchKernelGGL(inbatch2h_pc_kernel, dim3(grid_c), dim3(256), 0, st, (const _Float16*)ws.Qh, B, nsplit_c,
-                     (const float*)ws.invl, (const float*)ws.Pmat, ws.part_O);
+                     (const float*)ws.fac, nchunks / nsplit_q, (const float*)ws.Pmat, ws.part_O);
   // O_C' = 2^(eq + 14) sum_i (p_ij / l_i) q_i
   hipLaunchKernelGGL((inbatch3_merge_kernel<false>), dim3(mgrid), dim3(kBlock), 0, st, Cs, Qs, gc_rows, B, nsplit_c,
                      (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale, regularization,

@@ -138,7 +138,10 @@ __global__ __launch_bounds__(kBlock) void inbatch3_merge_kernel(
     const float* __restrict__ part_m, const float* __restrict__ part_l, float scale, float lam, float inv_bs,
     float* __restrict__ lse2, float* __restrict__ lse_nat, float* __restrict__ gX,
     unsigned long long* __restrict__ loss_acc, double loss_scale, float* __restrict__ loss_out,
-    float* __restrict__ invl, const float* __restrict__ oscale_ptr = nullptr, float invl_scale = 1.0f) {
+    float* __restrict__ invl, const float* __restrict__ oscale_ptr = nullptr, float invl_scale = 1.0f,
+    float* __restrict__ fac = nullptr) {
+  // fac (fp16 x 2 path, QSIDE): [nsplit][B] factors invl_scale * 2^(M_split - M) / l for the stored-P pass C, whose
+  // probabilities carry the reference of the split that wrote them
   // oscale_ptr (fp16 x 2 path): a power of two that undoes the plane scaling of the partial O rows (device-side: it
   // depends on the largest |element| of the batch); invl_scale: a power of two folded into the stored 1 / l_i
   __shared__ double sm[4];
@@ -168,18 +171,28 @@ __global__ __launch_bounds__(kBlock) void inbatch3_merge_kernel(
     const float4 x = rowsrc_load4(X, row, 4 * lig);
     const float4 y = rowsrc_load4(Y, row, 4 * lig);
     float M = 0.f, L = 1.f;
-    if (QSIDE) {  // every split used the same fixed reference M = max_s part_m[s][row]
+    float wt[8];  // 2^(M_s - M): 1 for every split when they shared one reference (the bf16 x 3 path), 0 for s >= nsplit
+#pragma unroll
+    for (int s = 0; s < 8; ++s) wt[s] = 1.f;
+    if (QSIDE) {  // fp16 x 2 path: split s used the fixed reference part_m[s][row]; the row's is the largest of them
       M = pm[0];
       L = 0.f;
 #pragma unroll
       for (int s = 1; s < 8; ++s) M = fmaxf(M, pm[s]);
 #pragma unroll
-      for (int s = 0; s < 8; ++s) L += pl[s];
+      for (int s = 0; s < 8; ++s) {
+        // (fac == null: the bf16 x 3 path -- part_m[s] is split s's share of the row maximum there, and every split
+        // exponentiated against the maximum of them: weight 1)
+        wt[s] = (fac == nullptr || pm[s] == M) ? 1.f : __builtin_amdgcn_exp2f(pm[s] - M);
+        L += pl[s] * wt[s];
+      }
     }
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      if (s < nsplit) { o.x += po[s].x; o.y += po[s].y; o.z += po[s].z; o.w += po[s].w; }
+      if (s < nsplit) {
+        o.x += po[s].x * wt[s]; o.y += po[s].y * wt[s]; o.z += po[s].z * wt[s]; o.w += po[s].w * wt[s];
+      }
     }
     const float invL1 = 1.0f / L;
     const float invL = invL1 * oscale;  // (exact: oscale is a power of two)
@@ -199,6 +212,11 @@ __global__ __launch_bounds__(kBlock) void inbatch3_merge_kernel(
       if (lig == 0) {
         lse2[row] = l2v;
         if (invl) invl[row] = invL1 * invl_scale;  // the stored-P pass C normalises with it
+        if (fac) {
+#pragma unroll
+          for (int s = 0; s < 8; ++s)
+            if (s < nsplit) fac[(int64_t)s * B + row] = invL1 * invl_scale * wt[s];
+        }
         if (lse_nat) lse_nat[row] = l2v * k3Ln2;
       }
       row_loss += l2v * k3Ln2 - scale * diag;

@@ -469,6 +469,29 @@ def test_inbatch_f16x2_operand_and_score_ranges(dev, mag_q, mag_c, scale):
         assert max(errs["f16x2"]) <= 4 * max(errs["f32"]), errs
 
 
+@pytest.mark.parametrize("ref_mode", ["opt", "redo", "rowmax"])
+@pytest.mark.parametrize("B", [128, 1024, 2176])
+def test_inbatch_f16x2_exponent_reference_modes(dev, B, ref_mode, monkeypatch):
+    """The two-plane path's exponent reference: optimistic (diagonal + first chunk; default), every block through the
+    redo launch (exact maximum of the block's range), and the row-max pass.  All three against the fp64 oracle, on
+    inputs where a late candidate beats the positive pair and the whole first chunk by ~30 binades (the optimistic
+    reference overflows fp16 there and the redo launch has to repair exactly those blocks)."""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(B + 3)
+    D, scale = 128, 8.0
+    q = (rng.standard_normal((B, D)) * D ** -0.5).astype(np.float32)
+    c = (rng.standard_normal((B, D)) * D ** -0.5).astype(np.float32)
+    late = B - 24                                  # not in the first chunk of any split
+    c[late] = 3.0 * q[5] / np.linalg.norm(q[5])    # score 3 |q_5| ~ 3 against ~0 for the rest: +35 binades at scale 8
+    c[B // 2 + 40] = 2.5 * q[B // 2] / np.linalg.norm(q[B // 2])
+    monkeypatch.setenv("ESR_IB2H_REF", ref_mode)
+    loss, lse, gq, gc = ops.inbatch_softmax_fwd_bwd(T(q, dev), T(c, dev), scale, 0.1, float(B), precision="f16x2")
+    el, else_, egq, egc = o_stl.inbatch_softmax_loss_and_grads(q.astype(F64), c.astype(F64), 0.1, float(B), scale, F64)
+    assert np.isfinite(N(gq)).all() and np.isfinite(N(gc)).all()
+    assert abs(float(loss) - el) / abs(el) <= TOL and rel_err(N(lse), else_) <= TOL
+    assert rel_err(N(gq), egq) <= TOL and rel_err(N(gc), egc) <= TOL
+
+
 @pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2"])
 def test_inbatch_repeatable_under_load(dev, precision):
     """Race screen for the LDS-DMA ring: 60 back-to-back launches at the headline size must be bit-identical
