@@ -635,7 +635,9 @@ def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc) and roofline is not None:
         try:  # HBM bytes per launch of the dominant kernel group, from the committed --pmc passes
-            key = workload + ("_f32" if workload == "inbatch" and PRECISION == "f32" else "")
+            key = workload
+            if workload == "inbatch" and path != "f16x2":  # the committed counters are the default (f16x2) path's
+                key = "inbatch_" + (path or "f32")
             entry = json.load(open(pmc)).get(key)
             roofline["traffic"] = entry.get(roofline["kernel"]) if isinstance(entry, dict) else entry
         except Exception:

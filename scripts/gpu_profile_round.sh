@@ -7,6 +7,8 @@ for w in inbatch triplet glove retrieve; do
   (timeout 400 python bench.py --workload $w 2>&1 | grep -v amdgpu.ids | tail -1) > $R/bench_$w.json
 done
 (timeout 300 python bench.py --precision f32 --no-cpu-baseline 2>&1 | grep -v amdgpu.ids | tail -1) > $R/bench_inbatch_f32.json
+(timeout 300 python bench.py --precision bf16x3 --no-cpu-baseline --no-secondary 2>&1 | grep -v amdgpu.ids | tail -1) > $R/bench_inbatch_bf16x3.json
+(ESR_IB2H_REF=rowmax timeout 300 python bench.py --no-cpu-baseline --no-secondary 2>&1 | grep -v amdgpu.ids | tail -1) > $R/bench_inbatch_f16x2_rowmax_pass.json
 for w in inbatch triplet glove; do
   (timeout 300 python bench.py --workload $w --ids zipf --no-cpu-baseline 2>&1 | grep -v amdgpu.ids | tail -1) > $R/bench_${w}_zipf.json
 done
@@ -21,6 +23,8 @@ done
 (timeout 300 python benchmarks/mfma_peak.py 2>&1 | grep -v amdgpu.ids) > $R/mfma_peak.jsonl
 (timeout 300 python benchmarks/reader_bench.py 2>&1 | grep -v amdgpu.ids) > $R/reader_bench.jsonl
 (timeout 600 python benchmarks/spotify_step.py 2>&1 | grep -v amdgpu.ids | tail -1) > $R/spotify_step.json
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/stats_inbatch_bf16x3 -o x -- python bench.py --precision bf16x3 --steps 50 --warmup 5 --no-cpu-baseline --no-kernel-timing > gpurun_out/prof_stats_inbatch_bf16x3.log 2>&1
+f=$(find gpurun_out/prof/stats_inbatch_bf16x3 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $R/inbatch_bf16x3_kernel_stats.csv
 for w in inbatch triplet glove retrieve; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/stats_$w -o $w -- python bench.py --workload $w --steps 50 --warmup 5 --no-cpu-baseline --no-kernel-timing > gpurun_out/prof_stats_$w.log 2>&1
   f=$(find gpurun_out/prof/stats_$w -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $R/${w}_kernel_stats.csv
