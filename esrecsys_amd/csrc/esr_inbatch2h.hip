@@ -465,9 +465,16 @@ __global__ __launch_bounds__(256) void rowmax2h_kernel(const _Float16* __restric
     if (VALU_ON) pst_u += nch * 4096;                                                                     \
   }
 // O^T += Y_chunk^T P^T (see ESR_O_ROW): rows in the order small terms first
+#if defined(H_PROBE_NOMFMA)  /* timing probe only: the O^T phase without its MFMAs (what the data movement alone costs) */
+#define H_O_ROW(PL_A, PL_P, G)                                                                            \
+  _Pragma("unroll") for (int db_ = 0; db_ < 4; ++db_) {                                                   \
+    acc[db_][0] += (float)ta2_[G][db_][PL_A][0] * (float)pb[PL_P][G][0];                                  \
+  }
+#else
 #define H_O_ROW(PL_A, PL_P, G)                                                                            \
   _Pragma("unroll") for (int db_ = 0; db_ < 4; ++db_)                                                     \
     acc[db_] = H_MFMA(ta2_[G][db_][PL_A], pb[PL_P][G], acc[db_]);
+#endif
 #define H_O_G1(F0, F1) { _Pragma("unroll") for (int f_ = (F0); f_ < (F1); ++f_) trh_frag_n<1>(f_, ta2_, trc_); }
 #define H_PB()                                                                                            \
   f16x8 pb[2][2];                                                                                         \
@@ -541,8 +548,12 @@ __global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __rest
   const uint32_t pst_v = (uint32_t)((4 * h * 32 + j) * 4);
 #if defined(H_PROBE_Q_NOSTORE)  /* timing probe only: pass Q without its P stores */
 #define H_P_ST(K, VAL)
-#else
+#elif defined(H_P_PLAIN_STORE)  /* A/B: ordinary stores */
 #define H_P_ST(K, VAL) *reinterpret_cast<float*>(pst_u + (K) * 128 + pst_v) = (VAL)
+#else
+// streaming (non-temporal) stores: the B x B probabilities are written once and read once, and at 268 MB (B = 8192) do
+// not fit the 256 MB Infinity Cache anyway; with nt on both sides pass C runs in 79 us instead of 85 (pass Q +1)
+#define H_P_ST(K, VAL) __builtin_nontemporal_store((VAL), reinterpret_cast<float*>(pst_u + (K) * 128 + pst_v))
 #endif
 
   f32x16 acc[4];
@@ -840,6 +851,177 @@ __global__ __launch_bounds__(256, 2) void inbatch2h_pc_kernel(const _Float16* __
           make_float4(acc[db][4 * q], acc[db][4 * q + 1], acc[db][4 * q + 2], acc[db][4 * q + 3]);
 }
 
+// -----------------------------------------------------------------------------------------------------------------
+// Pass C, 8-wave form (default): one 512-thread workgroup owns 256 rows, so a plane tile is fetched once for eight
+// waves (half the L2 -> LDS traffic of two 4-wave workgroups per CU, two DMA instructions per wave and chunk instead of
+// four), and the P'^T tiles come through LDS too: pass Q leaves a tile as 32 rows (this pass's owned rows j) of 128
+// bytes (32 streamed rows i), lane (j, h) needs 16 bytes of row j per load -- a quarter of each line per instruction
+// when loaded straight into registers (H_PROBE_PC_LINEAR: 81 -> 70 us with coalesced loads).  As an LDS-DMA the tile is
+// four fully coalesced 1 KB instructions per wave, asynchronous and as deep in flight as the plane tiles (no staging
+// registers), and the transposition is the ds_read_b128 of row j (16-byte segments XOR-swizzled by the row on the
+// source side, as for the planes: conflict-free).  Ring slot = planes (16 KB) + per wave [P tile 4 KB | factors 256 B].
+// -----------------------------------------------------------------------------------------------------------------
+constexpr int kPc8Wave = 4096 + 256;
+constexpr int kPc8Buf = 2 * kPlaneBytes + 8 * kPc8Wave;  // 51200: three of them are 150 KB of the CU's 160
+constexpr int kPc8Owned = 256;
+template <int K>
+__device__ __forceinline__ uint32_t dmah8_off0(int64_t B, int64_t chunk, int t) {  // piece K = plane K, 512 threads
+  const int row = t >> 4, seg = (t & 15) ^ swz16(row);
+  return (uint32_t)((((int64_t)K * B + chunk * 32 + row) * k3D + seg * 8) * 2);
+}
+__global__ __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __restrict__ Yr, int64_t B, int nsplit,
+                                                           const float* __restrict__ fac, int nc_q,
+                                                           const float* __restrict__ Pmat,
+                                                           float* __restrict__ part_O) {
+  __shared__ __attribute__((aligned(16))) char lds[kHBufs * kPc8Buf];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  H_TR_SETUP();
+  const int ob = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
+  const int64_t wrow = (int64_t)ob * kPc8Owned + w * 32;
+  const bool live = wrow < B;  // B is a multiple of 128: the last block's upper four waves may own nothing
+  const int64_t xrow = wrow + j;
+  const int nc = (int)(B / k3Chunk) / nsplit;
+  const int64_t c0 = (int64_t)split * nc;
+  const int64_t nch = B / 32;
+  const int64_t jt = live ? (wrow >> 5) : 0;  // (idle waves fetch block 0's tiles: valid addresses, results dropped)
+  const float* ref = fac + (int64_t)(jt / nc_q) * B;
+  const char* const pw_base = reinterpret_cast<const char*>(Pmat) + (jt * nch + c0) * 4096;
+  // per-lane source offset inside a tile for LDS position g * 1024 + lane * 16: row g * 8 + lane / 8, segment swizzled
+  const uint32_t p_off = (uint32_t)((lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4));
+  const int wave_off = 2 * kPlaneBytes + w * kPc8Wave;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[db][r] = 0.f;
+
+  int dpos = 0;
+  const char* const baseY = reinterpret_cast<const char*>(Yr);
+  uint32_t g0 = dmah8_off0<0>(B, c0, t), g1 = dmah8_off0<1>(B, c0, t);
+#if defined(H_PROBE_PC_NOPLANES)  /* timing probe only: no plane tiles (stale LDS), only the P stream */
+#define H8_DP(K, G, BUF)
+#else
+#define H8_DP(K, G, BUF) \
+  __builtin_amdgcn_global_load_lds((gptr_t)(baseY + (G)), (lptr_t)((BUF) + (K) * kPlaneBytes + w * 1024), 16, 0, 0)
+#endif
+#ifndef H_P_LOAD_AUX
+#define H_P_LOAD_AUX 2  /* cache-policy bits of the P tile loads: nt (see H_P_ST); 0 for an A/B build */
+#endif
+#define H8_DMA_P(G4, BUF)                                                                                 \
+  __builtin_amdgcn_global_load_lds((gptr_t)(pw_base + (int64_t)dpos * 4096 + (G4) * 1024 + p_off),        \
+                                   (lptr_t)((BUF) + wave_off + (G4) * 1024), 16, 0, H_P_LOAD_AUX)
+#define H8_DMA_FAC(BUF)                                                                                   \
+  __builtin_amdgcn_global_load_lds((gptr_t)(ref + (c0 + dpos) * 32 + (lane & 31)),                        \
+                                   (lptr_t)((BUF) + wave_off + 4096), 4, 0, 0)
+#define H8_ADVANCE()                                                                                      \
+  {                                                                                                       \
+    const uint32_t step_ = (dpos + 1 == nc) ? (uint32_t)(8192 - nc * 8192) : 8192u;                       \
+    dpos = (dpos + 1 == nc) ? 0 : dpos + 1;                                                               \
+    g0 += step_; g1 += step_;                                                                             \
+  }
+#define H8_DMA_ALL(BUF)                                                                                   \
+  {                                                                                                       \
+    H8_DMA_FAC(BUF); H8_DP(0, g0, BUF); H8_DP(1, g1, BUF);                                                \
+    H8_DMA_P(0, BUF); H8_DMA_P(1, BUF); H8_DMA_P(2, BUF); H8_DMA_P(3, BUF);                               \
+    H8_ADVANCE();                                                                                         \
+  }
+  H8_DMA_ALL(lds);
+  if (nc > 1) H8_DMA_ALL(lds + kPc8Buf);
+  float p1[16], rf[16];
+  uint32_t pw[2][8], pwn[2][8];
+  f16x8 ta2_[2][4][2];
+  uint32_t trn_[4][2];
+  // this lane's 16 probabilities of the chunk in BUF (row j of the tile, segments 2 g + h) and their 16 factors
+  const int p_rd = wave_off + j * 128;
+#define H8_LOAD_P(BUF)                                                                                    \
+  _Pragma("unroll") for (int g4_ = 0; g4_ < 4; ++g4_) {                                                   \
+    const float4 v_ = *reinterpret_cast<const float4*>((BUF) + p_rd + (((2 * g4_ + h) ^ (j & 7)) << 4));   \
+    p1[4 * g4_] = v_.x; p1[4 * g4_ + 1] = v_.y; p1[4 * g4_ + 2] = v_.z; p1[4 * g4_ + 3] = v_.w;           \
+  }
+#define H8_LOAD_REFS(BUF)                                                                                 \
+  _Pragma("unroll") for (int g4_ = 0; g4_ < 4; ++g4_) {                                                   \
+    const float4 lv_ = *reinterpret_cast<const float4*>((BUF) + wave_off + 4096 + (8 * g4_ + 4 * h) * 4); \
+    rf[4 * g4_] = lv_.x; rf[4 * g4_ + 1] = lv_.y; rf[4 * g4_ + 2] = lv_.z; rf[4 * g4_ + 3] = lv_.w;       \
+  }
+#define H8_ITER(NBUF, DBUF, DMA_ON, NEXT_ON)                                                              \
+  {                                                                                                       \
+    H_PB();                                                                                               \
+    if (NEXT_ON) {                                                                                        \
+      H8_LOAD_P(NBUF);                                                                                    \
+      H8_LOAD_REFS(NBUF);                                                                                 \
+      const uint32_t slot_ = (uint32_t)((NBUF) - lds);                                                    \
+      _Pragma("unroll") for (int db_ = 0; db_ < 4; ++db_) { trn_[db_][0] = trb_[db_][0] + slot_; trn_[db_][1] = trb_[db_][1] + slot_; } \
+    }                                                                                                     \
+    if (DMA_ON) { H8_DMA_FAC(DBUF); }                                                                     \
+    H_TR_WAIT();                                                                                          \
+    H_SB(); H_O_ROW(1, 0, 0); H_SB(); H_O_G1(0, 3); if (DMA_ON) { H8_DP(0, g0, DBUF); }                   \
+    if (NEXT_ON) { H_PC_SPLIT1(pwn, 0); H_PC_SPLIT1(pwn, 1); }                                            \
+    H_SB(); H_O_ROW(0, 1, 0); H_SB(); H_O_G1(3, 6); if (DMA_ON) { H8_DP(1, g1, DBUF); }                   \
+    if (NEXT_ON) { H_PC_SPLIT1(pwn, 2); H_PC_SPLIT1(pwn, 3); }                                            \
+    H_SB(); H_O_ROW(0, 0, 0); H_SB(); H_O_G1(6, 8); if (DMA_ON) { H8_DMA_P(0, DBUF); H8_DMA_P(1, DBUF); } \
+    if (NEXT_ON) { H_PC_SPLIT1(pwn, 4); H_PC_SPLIT1(pwn, 5); }                                            \
+    H_TR_WAIT();                                                                                          \
+    H_SB(); H_O_ROW(1, 0, 1); H_SB(); if (DMA_ON) { H8_DMA_P(2, DBUF); H8_DMA_P(3, DBUF); }               \
+    if (NEXT_ON) { H_PC_NEXT_G0(0, 4); H_PC_SPLIT1(pwn, 6); }                                             \
+    H_SB(); H_O_ROW(0, 1, 1); H_SB();                                                                     \
+    if (NEXT_ON) { H_PC_SPLIT1(pwn, 7); }                                                                 \
+    H_SB(); H_O_ROW(0, 0, 1); H_SB();                                                                     \
+    if (NEXT_ON) { H_PC_NEXT_G0(4, 8); }                                                                  \
+    if (DMA_ON) H8_ADVANCE();                                                                             \
+    if (NEXT_ON) {                                                                                        \
+      _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_)                                                    \
+        _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) pw[q_][s_] = pwn[q_][s_];                        \
+    }                                                                                                     \
+  }
+  H_DMA_BARRIER();
+  H_TR_BASES(lds);
+#pragma unroll
+  for (int f = 0; f < 8; ++f) trh_frag_n<0>(f, ta2_, trc_);
+  H8_LOAD_P(lds);
+  H8_LOAD_REFS(lds);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) H_PC_SPLIT1(pw, s);
+
+  int cur = 0;
+  for (int it = 0; it + 2 < nc; ++it) {
+    const int nxt = cur == kHBufs - 1 ? 0 : cur + 1;
+    const int nn = nxt == kHBufs - 1 ? 0 : nxt + 1;
+    if (it > 0) H_DMA_BARRIER();
+    const char* buf = lds + cur * kPc8Buf;
+    const char* nbuf = lds + nxt * kPc8Buf;
+    char* dbuf = lds + nn * kPc8Buf;
+    H_TR_BASES(buf);
+    H8_ITER(nbuf, dbuf, true, true);
+    cur = nxt;
+  }
+  if (nc >= 2) {
+    const int nxt = cur == kHBufs - 1 ? 0 : cur + 1;
+    if (nc > 2) H_DMA_BARRIER();
+    const char* buf = lds + cur * kPc8Buf;
+    const char* nbuf = lds + nxt * kPc8Buf;
+    H_TR_BASES(buf);
+    H8_ITER(nbuf, lds, false, true);
+    cur = nxt;
+  }
+  {
+    const char* buf = lds + cur * kPc8Buf;
+    H_TR_BASES(buf);
+    H8_ITER(buf, lds, false, false);
+  }
+  if (live) {
+    float* orow = part_O + ((int64_t)split * B + xrow) * k3D;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(orow + 32 * db + 8 * q + 4 * h) =
+            make_float4(acc[db][4 * q], acc[db][4 * q + 1], acc[db][4 * q + 2], acc[db][4 * q + 3]);
+  }
+}
+
 struct InbatchHWs {
   _Float16 *Qh, *Ch;
   float *part_O, *part_m, *part_mr, *part_l, *lse2, *fac, *Pmat, *nrm, *amax, *sc, *diag;
@@ -940,8 +1122,19 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
   const char* qcs = getenv("ESR_IB2H_Q_PER_CU");
   const int nsplit_q = inbatch2h_nsplit(B, qcs ? std::max(1, atoi(qcs)) : 2);  // 252 registers, 50 KB of LDS: two per CU
   const char* pcs = getenv("ESR_IB2H_PC_PER_CU");
-  const int nsplit_c = inbatch2h_nsplit(B, pcs ? std::max(1, atoi(pcs)) : 2);
-  const int grid_q = (int)(B / k3Owned) * nsplit_q, grid_c = (int)(B / k3Owned) * nsplit_c;
+  // pass C: 8-wave workgroups (256 owned rows, one per CU) unless ESR_IB2H_PC=4w asks for the 4-wave form (two per CU)
+  const char* pcf = getenv("ESR_IB2H_PC");
+  const bool pc8 = !(pcf && pcf[0] == '4');
+  int nsplit_c = inbatch2h_nsplit(B, pcs ? std::max(1, atoi(pcs)) : 2);
+  int grid_c = (int)(B / k3Owned) * nsplit_c;
+  if (pc8) {
+    const int blocks = (int)cdiv(B, kPc8Owned);
+    nsplit_c = 1;
+    for (int sp = 1; sp <= 8; ++sp)
+      if (nchunks % sp == 0 && blocks * sp <= 320) nsplit_c = sp;
+    grid_c = blocks * nsplit_c;
+  }
+  const int grid_q = (int)(B / k3Owned) * nsplit_q;
   const int mgrid = (int)std::min<int64_t>(k3MergeBlocks, cdiv(B, kBlock / 32));
   // exponent reference of pass Q: optimistic + redo launch (default), or the row-max pass (ESR_IB2H_REF=rowmax);
   // ESR_IB2H_REF=redo forces every block through the redo launch (test hook)
@@ -970,8 +1163,12 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
                      (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale, regularization,
                      inv_bs, ws.lse2, lse, gQ, ws.loss_acc, 1.0 / (double)batch_size, loss, (float*)nullptr,
                      (const float*)(ws.sc + 1), ldexpf(1.f, (int)kHPexp), ws.fac);
-  hipLaunchKernelGGL(inbatch2h_pc_kernel, dim3(grid_c), dim3(256), 0, st, (const _Float16*)ws.Qh, B, nsplit_c,
-                     (const float*)ws.fac, nchunks / nsplit_q, (const float*)ws.Pmat, ws.part_O);
+  if (pc8)
+    hipLaunchKernelGGL(inbatch2h_pc8_kernel, dim3(grid_c), dim3(512), 0, st, (const _Float16*)ws.Qh, B, nsplit_c,
+                       (const float*)ws.fac, nchunks / nsplit_q, (const float*)ws.Pmat, ws.part_O);
+  else
+    hipLaunchKernelGGL(inbatch2h_pc_kernel, dim3(grid_c), dim3(256), 0, st, (const _Float16*)ws.Qh, B, nsplit_c,
+                       (const float*)ws.fac, nchunks / nsplit_q, (const float*)ws.Pmat, ws.part_O);
   // O_C' = 2^(eq + 14) sum_i (p_ij / l_i) q_i
   hipLaunchKernelGGL((inbatch3_merge_kernel<false>), dim3(mgrid), dim3(kBlock), 0, st, Cs, Qs, gc_rows, B, nsplit_c,
                      (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale, regularization,
