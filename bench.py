@@ -139,8 +139,15 @@ def saturating_gather_scatter(dev, V, D, n=131072, reps=20):
     tg = timed(lambda: ops.gather_rows(table, ids, out=out))
     ts = timed(lambda: ops.sparse_adagrad(table, accum, sid, perm, grads, 0.01))
     gb, sb = 2.0 * n * D * 4, (n + 4.0 * uniq) * D * 4
+    # what the box's HBM does for a plain stream, by direction (torch kernels over the whole table: V x D x 4 bytes,
+    # larger than the 256 MB Infinity Cache for the bench's tables): context for every "frac of 8 TB/s" in the line
+    tr = timed(lambda: table.sum())
+    tw = timed(lambda: accum.fill_(0.1))
+    tb = float(V) * D * 4
     return {"rows_per_launch": n, "gather_GBps": gb / tg / 1e9, "gather_frac_of_8TBps": gb / tg / 1e9 / HBM_PEAK_GBS,
-            "sparse_adagrad_GBps": sb / ts / 1e9, "sparse_adagrad_frac_of_8TBps": sb / ts / 1e9 / HBM_PEAK_GBS}
+            "sparse_adagrad_GBps": sb / ts / 1e9, "sparse_adagrad_frac_of_8TBps": sb / ts / 1e9 / HBM_PEAK_GBS,
+            "box_stream_read_GBps": tb / tr / 1e9, "box_stream_write_GBps": tb / tw / 1e9,
+            "box_stream_bytes": tb}
 
 
 def roofline_for(workload, kernels, B, D, rows, precision, occ_n=0, uniq=0, bf16_tables=False, rowmax_gemm=False,
