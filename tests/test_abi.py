@@ -52,6 +52,20 @@ def test_bad_arguments_are_rejected_without_a_device(lib):
     assert lib.esr_inbatch_softmax_fwd_bwd_bf16x3(16, 16, 33, 128, 1.0, 0.0, 33.0, 16, 16, 16, 16, 16, 1 << 20,
                                                   None) == EINVAL
     assert b"multiple of 128" in lib.esr_last_error()
+    # the fp16 x 2 entry points: B a multiple of 128, at most 16384 (B x B probabilities in the workspace), D = 128
+    assert lib.esr_inbatch_softmax_fwd_bwd_f16x2(16, 16, 33, 128, 1.0, 0.0, 33.0, 16, 16, 16, 16, 16, 1 << 20,
+                                                 None) == EINVAL
+    assert b"multiple of 128" in lib.esr_last_error()
+    assert lib.esr_inbatch_softmax_fwd_bwd_f16x2(16, 16, 32768, 128, 1.0, 0.0, 1.0, 16, 16, 16, 16, 16, 1 << 20,
+                                                 None) == EINVAL
+    assert b"at most 16384" in lib.esr_last_error()
+    assert lib.esr_inbatch_softmax_fwd_bwd_f16x2(16, 16, 256, 64, 1.0, 0.0, 1.0, 16, 16, 16, 16, 16, 1 << 20,
+                                                 None) == EINVAL
+    assert lib.esr_inbatch_softmax_fwd_bwd_f16x2(16, 16, 256, 128, 1.0, 0.0, 1.0, 16, 16, 16, 16, 16, 1 << 10,
+                                                 None) == EWORKSPACE
+    assert lib.esr_inbatch2h_workspace_bytes(32768, 128) == 256 and lib.esr_inbatch2h_workspace_bytes(8192, 128) > 4 * 8192 * 8192
+    assert lib.esr_inbatch_towers_fwd_bwd_f16x2(16, 0, 16, 10, 0, 128, 16, 16, None, None, 256, 1.0, 0.0, 1.0, 16, 16, 16,
+                                                16, 16, 1 << 20, None) == EINVAL
     assert lib.esr_inbatch_softmax_fwd_bwd(16, 16, 64, 102, 1.0, 0.0, 64.0, 16, 16, 16, 16, 16, 1 << 20, None) == EINVAL
     assert lib.esr_inbatch_softmax_fwd_bwd(16, 16, 64, 516, 1.0, 0.0, 64.0, 16, 16, 16, 16, 16, 1 << 20, None) == EINVAL
     assert lib.esr_dense_adam(16, 16, 16, 16, 8, 1e-3, 0.9, 0.999, 1e-8, 0, None) == EINVAL  # step must be >= 1
