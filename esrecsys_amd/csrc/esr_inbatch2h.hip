@@ -423,6 +423,7 @@ __global__ __launch_bounds__(256) void rowmax2h_kernel(const _Float16* __restric
     const int sw_ = swz16(j);                                                                             \
     f16x8 a1_ = *reinterpret_cast<const f16x8*>(ap0_ + ((h ^ sw_) << 4));                                 \
     f16x8 a2_ = *reinterpret_cast<const f16x8*>(ap0_ + ((h ^ sw_) << 4) + kPlaneBytes);                   \
+    float ek0_ = 0.f, ek1_ = 0.f;                                                                         \
     _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) {                                                    \
       f16x8 n1_ = a1_, n2_ = a2_;                                                                         \
       if (s_ < 7) {                                                                                       \
@@ -448,8 +449,8 @@ __global__ __launch_bounds__(256) void rowmax2h_kernel(const _Float16* __restric
         pa_ = pk_f16(e0_, e1_);                                                                           \
         l2 = pk_add(l2, f32x2{e0_, e1_});                                                                 \
         emax = __builtin_fmaxf(emax, __builtin_fmaxf(e0_, e1_)); /* v_max3_f32 */                          \
-        H_P_ST(((2 * s_) & 3) + 8 * ((2 * s_) >> 2), e0_);                                                \
-        H_P_ST(((2 * s_ + 1) & 3) + 8 * ((2 * s_ + 1) >> 2), e1_);                                        \
+        /* four consecutive streamed rows (k-steps 2m, 2m + 1) leave as one 16-byte store: see H_P_ST4 */   \
+        if ((s_ & 1) == 0) { ek0_ = e0_; ek1_ = e1_; } else { H_P_ST4(s_ >> 1, ek0_, ek1_, e0_, e1_); }      \
       }                                                                                                   \
       H_SB();                                                                                             \
       SA = H_MFMA(a1_, bx[0][s_], SA);                                                                    \
@@ -543,17 +544,21 @@ __global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __rest
   const int64_t nch = B / 32;
   const float sl2 = sl2_in * sc[0];  // the planes carry 2^(eq + ec) S
 
-  // P'^T tiles: see inbatch3_kernel (PMODE 1)
+  // The probabilities leave for pass C in the S^T accumulator's own order: lane (a = owned row, h) holds streamed rows
+  // 8 m + 4 h + 0..3 in registers 4 m .. 4 m + 3, so a 32 x 32 tile (streamed chunk jt, owned block it; 4 KB at
+  // (jt * B/32 + it) * 4096) is stored as 16-byte pieces [m][h][a] = P'[8 m + 4 h + 0..3][a]: FOUR fully coalesced 1 KB
+  // stores per chunk and wave (as 16 dword stores to a [streamed][owned] tile, two 128-byte lines each, the stores cost
+  // pass Q 16 us).  The transposition happens on the reading side, in LDS (inbatch2h_pc8_kernel).
   char* pst_u = reinterpret_cast<char*>(Pmat) + (c0 * nch + (xrow >> 5)) * 4096;
-  const uint32_t pst_v = (uint32_t)((4 * h * 32 + j) * 4);
+  const uint32_t pst_v = (uint32_t)((h * 32 + j) * 16);
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
 #if defined(H_PROBE_Q_NOSTORE)  /* timing probe only: pass Q without its P stores */
-#define H_P_ST(K, VAL)
-#elif defined(H_P_PLAIN_STORE)  /* A/B: ordinary stores */
-#define H_P_ST(K, VAL) *reinterpret_cast<float*>(pst_u + (K) * 128 + pst_v) = (VAL)
+#define H_P_ST4(M, V0, V1, V2, V3)
 #else
 // streaming (non-temporal) stores: the B x B probabilities are written once and read once, and at 268 MB (B = 8192) do
-// not fit the 256 MB Infinity Cache anyway; with nt on both sides pass C runs in 79 us instead of 85 (pass Q +1)
-#define H_P_ST(K, VAL) __builtin_nontemporal_store((VAL), reinterpret_cast<float*>(pst_u + (K) * 128 + pst_v))
+// not fit the 256 MB Infinity Cache anyway
+#define H_P_ST4(M, V0, V1, V2, V3) \
+  __builtin_nontemporal_store(f32x4{(V0), (V1), (V2), (V3)}, reinterpret_cast<f32x4*>(pst_u + (M) * 1024 + pst_v))
 #endif
 
   f32x16 acc[4];
@@ -661,6 +666,7 @@ __global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __rest
     H_TR_BASES(buf);
 #pragma unroll
     for (int f = 0; f < 8; ++f) trh_frag_n<0>(f, ta2_, trc_);
+    float ek0 = 0.f, ek1 = 0.f;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const f32x2 arg = f32x2{p[2 * s], p[2 * s + 1]} * sl2v + nrefv;
@@ -672,12 +678,11 @@ __global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __rest
       const f16x2 pq = pk_f16(resid_lo(e0, pa), resid_hi(e1, pa));
       pw[0][s] = __builtin_bit_cast(uint32_t, pa);
       pw[1][s] = __builtin_bit_cast(uint32_t, pq);
-      H_P_ST(((2 * s) & 3) + 8 * ((2 * s) >> 2), e0);
-      H_P_ST(((2 * s + 1) & 3) + 8 * ((2 * s + 1) >> 2), e1);
+      if ((s & 1) == 0) { ek0 = e0; ek1 = e1; } else { H_P_ST4(s >> 1, ek0, ek1, e0, e1); }
     }
     H_O_PHASE(false, lds);
   }
-#undef H_P_ST
+#undef H_P_ST4
   H_TIMING_WRITE(H_TIMING_Q);
   float* orow = part_O + ((int64_t)split * B + xrow) * k3D;
 #pragma unroll
@@ -694,67 +699,20 @@ __global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __rest
 }
 
 // -----------------------------------------------------------------------------------------------------------------
-// Pass C: owned = C rows j, streamed = Q rows i; reads P'^T tiles (pass Q) and 2^14 / l'_i (merge<Q>), forms the true
-// probabilities * 2^14 in two fp16 planes and runs the O^T phase alone (24 MFMAs per chunk and wave).  Same software
-// pipeline as inbatch3_pc_kernel; two (or more) workgroups per CU.
+// Pass C: owned = C rows j, streamed = Q rows i; reads the P' tiles of pass Q and the factors 2^14 2^(M_split - M) / l'_i
+// of merge<Q>, forms the true probabilities * 2^14 in two fp16 planes and runs the O^T phase alone (24 MFMAs per chunk
+// and wave), software-pipelined like inbatch3_pc_kernel.  One 512-thread workgroup owns 256 rows: a plane tile is
+// fetched once for eight waves (two DMA instructions per wave and chunk).  The P' tiles come through LDS too: pass Q
+// stored them in ITS register order (16-byte pieces [m][h][a] = P'[streamed 8 m + 4 h + 0..3][owned a]); here the
+// roles are swapped -- this lane's owned row j is pass Q's streamed row (m, h, c) = (j / 8, j / 4 % 2, j % 4), and it
+// needs the 16 values of pass Q's owned rows a = 8 g + 4 h' + e.  As LDS-DMAs the tile is four fully coalesced 1 KB
+// instructions per wave, asynchronous and as deep in flight as the plane tiles (no staging registers), and the
+// transposition is sixteen ds_read_b32 (piece index XOR-swizzled on the source side so that the 32 lanes of a half
+// wave, which differ in (m, h, c), fall on 32 banks).  Ring slot = planes (16 KB) + per wave [P' tile 4 KB | factors
+// 256 B].  Measured forms of this pass (all 79-85 us, i.e. bound by reading B^2 x 4 bytes at the box's 4.0 TB/s):
+// 4-wave workgroups with the tile loaded straight into registers from a [streamed][owned] layout, two to four per CU;
+// this form with that layout (ds_read_b128 of row j); this form.
 // -----------------------------------------------------------------------------------------------------------------
-#define H_DMA_LSE(BUF)                                                                                    \
-  __builtin_amdgcn_global_load_lds((gptr_t)(ref + (c0 + dpos) * 32 + (lane & 31)),                        \
-                                   (lptr_t)((BUF) + kHLseOff + w * 256), 4, 0, 0);
-#define H_LOAD_REFS(BUF)                                                                                  \
-  _Pragma("unroll") for (int g4_ = 0; g4_ < 4; ++g4_) {                                                   \
-    const float4 lv_ = *reinterpret_cast<const float4*>((BUF) + kHLseOff + w * 256 + (8 * g4_ + 4 * h) * 4); \
-    rf[4 * g4_] = lv_.x; rf[4 * g4_ + 1] = lv_.y; rf[4 * g4_ + 2] = lv_.z; rf[4 * g4_ + 3] = lv_.w;       \
-  }
-__global__ __launch_bounds__(256, 2) void inbatch2h_pc_kernel(const _Float16* __restrict__ Yr, int64_t B, int nsplit,
-                                                             const float* __restrict__ fac, int nc_q,
-                                                             const float* __restrict__ Pmat,
-                                                             float* __restrict__ part_O) {
-  __shared__ __attribute__((aligned(16))) char lds[kHBufs * kHBufBytes];
-  H_TIMING_DECL();
-  const int t = threadIdx.x, lane = t & 63;
-  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int j = lane & 31, h = lane >> 5;
-  H_TR_SETUP();
-  const int ob = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
-  const int64_t xrow = (int64_t)ob * k3Owned + w * 32 + j;
-  const int nc = (int)(B / k3Chunk) / nsplit;
-  const int64_t c0 = (int64_t)split * nc;
-  const int64_t nch = B / 32;
-  // this wave's 32 owned rows j were one streamed chunk of pass Q, in split (chunk index) / nc_q: its probabilities
-  // carry that split's exponent reference, and merge<Q> left the matching factors 2^14 2^(M_split - M) / l in fac[split]
-  const float* ref = fac + (int64_t)((ob * 4 + w) / nc_q) * B;
-
-  f32x16 acc[4];
-#pragma unroll
-  for (int db = 0; db < 4; ++db)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[db][r] = 0.f;
-
-  int dpos = 0;
-  const char* const baseY = reinterpret_cast<const char*>(Yr);
-  uint32_t g0 = dmah_off0<0>(B, c0, t), g1 = dmah_off0<1>(B, c0, t), g2 = dmah_off0<2>(B, c0, t),
-           g3 = dmah_off0<3>(B, c0, t);
-  { H_DMA_LSE(lds); H_DMA_CHUNK(lds); }
-  if (nc > 1) { H_DMA_LSE(lds + kHBufBytes); H_DMA_CHUNK(lds + kHBufBytes); }
-  const float* pcol = Pmat + (xrow >> 5) * nch * 1024 + j * 32 + 4 * h;
-  float pn[16], p1[16], rf[16];
-  uint32_t pw[2][8], pwn[2][8];
-  f16x8 ta2_[2][4][2];
-  uint32_t trn_[4][2];
-#if defined(H_PROBE_PC_LINEAR)  /* timing probe only (wrong values): fully coalesced 1 KB per instruction */
-#define H_P_ADDR(g_) (base_ - (j * 32 + 4 * h) + lane * 4 + 256 * (g_))
-#else
-#define H_P_ADDR(g_) (base_ + 8 * (g_))
-#endif
-#define H_P_LOAD(CH)                                                                                      \
-  {                                                                                                       \
-    const float* base_ = pcol + (c0 + (CH)) * 1024;                                                       \
-    _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                    \
-      const float4 v_ = *reinterpret_cast<const float4*>(H_P_ADDR(g_));                                   \
-      pn[4 * g_] = v_.x; pn[4 * g_ + 1] = v_.y; pn[4 * g_ + 2] = v_.z; pn[4 * g_ + 3] = v_.w;             \
-    }                                                                                                     \
-  }
 #define H_PC_SPLIT1(PW, S)                                                                                \
   {                                                                                                       \
     const float e0_ = p1[2 * (S)] * rf[2 * (S)], e1_ = p1[2 * (S) + 1] * rf[2 * (S) + 1];                 \
@@ -764,103 +722,6 @@ __global__ __launch_bounds__(256, 2) void inbatch2h_pc_kernel(const _Float16* __
     PW[1][S] = __builtin_bit_cast(uint32_t, pq_);                                                         \
   }
 #define H_PC_NEXT_G0(F0, F1) { _Pragma("unroll") for (int f_ = (F0); f_ < (F1); ++f_) trh_frag_n<0>(f_, ta2_, trn_); }
-// one chunk: O^T MFMAs of chunk it with, threaded through them, this chunk's G = 1 fragments, the DMA of chunk it + 2,
-// the scale + split of chunk it + 1 and (behind the G = 0 rows) the G = 0 fragments of chunk it + 1
-#define H_PC_ITER(NBUF, DBUF, DMA_ON, NEXT_ON)                                                            \
-  {                                                                                                       \
-    H_PB();                                                                                               \
-    if (NEXT_ON) {                                                                                        \
-      _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) p1[r_] = pn[r_];                                  \
-      H_LOAD_REFS(NBUF);                                                                                  \
-      const uint32_t slot_ = (uint32_t)((NBUF) - lds);                                                    \
-      _Pragma("unroll") for (int db_ = 0; db_ < 4; ++db_) { trn_[db_][0] = trb_[db_][0] + slot_; trn_[db_][1] = trb_[db_][1] + slot_; } \
-    }                                                                                                     \
-    if (DMA_ON) { H_P_LOAD(pl_next); ++pl_next; H_DMA_LSE(DBUF); }                                        \
-    H_TR_WAIT();                                                                                          \
-    H_TICK(tk2);                                                                                          \
-    H_SB(); H_O_ROW(1, 0, 0); H_SB(); H_O_G1(0, 3); if (DMA_ON) { H_DP(0, g0, DBUF); }                    \
-    if (NEXT_ON) { H_PC_SPLIT1(pwn, 0); H_PC_SPLIT1(pwn, 1); }                                            \
-    H_SB(); H_O_ROW(0, 1, 0); H_SB(); H_O_G1(3, 6); if (DMA_ON) { H_DP(1, g1, DBUF); }                    \
-    if (NEXT_ON) { H_PC_SPLIT1(pwn, 2); H_PC_SPLIT1(pwn, 3); }                                            \
-    H_SB(); H_O_ROW(0, 0, 0); H_SB(); H_O_G1(6, 8); if (DMA_ON) { H_DP(2, g2, DBUF); }                    \
-    if (NEXT_ON) { H_PC_SPLIT1(pwn, 4); H_PC_SPLIT1(pwn, 5); }                                            \
-    H_TR_WAIT();                                                                                          \
-    H_SB(); H_O_ROW(1, 0, 1); H_SB(); if (DMA_ON) { H_DP(3, g3, DBUF); }                                  \
-    if (NEXT_ON) { H_PC_NEXT_G0(0, 4); H_PC_SPLIT1(pwn, 6); }                                             \
-    H_SB(); H_O_ROW(0, 1, 1); H_SB();                                                                     \
-    if (NEXT_ON) { H_PC_SPLIT1(pwn, 7); }                                                                 \
-    H_SB(); H_O_ROW(0, 0, 1); H_SB();                                                                     \
-    if (NEXT_ON) { H_PC_NEXT_G0(4, 8); }                                                                  \
-    if (DMA_ON) H_DMA_ADVANCE();                                                                          \
-    if (NEXT_ON) {                                                                                        \
-      _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_)                                                    \
-        _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) pw[q_][s_] = pwn[q_][s_];                        \
-    }                                                                                                     \
-  }
-  int pl_next = 2;
-  H_P_LOAD(0);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) p1[r] = pn[r];
-  if (nc > 1) H_P_LOAD(1);
-  H_DMA_BARRIER();
-  H_TR_BASES(lds);
-#pragma unroll
-  for (int f = 0; f < 8; ++f) trh_frag_n<0>(f, ta2_, trc_);
-  H_LOAD_REFS(lds);
-#pragma unroll
-  for (int s = 0; s < 8; ++s) H_PC_SPLIT1(pw, s);
-
-  H_TIMING_START();
-  int cur = 0;
-  for (int it = 0; it + 2 < nc; ++it) {
-    const int nxt = cur == kHBufs - 1 ? 0 : cur + 1;
-    const int nn = nxt == kHBufs - 1 ? 0 : nxt + 1;
-    H_TICK(tk0);
-    if (it > 0) H_DMA_BARRIER();
-    H_TICK(tk1);
-    const char* buf = lds + cur * kHBufBytes;
-    const char* nbuf = lds + nxt * kHBufBytes;
-    char* dbuf = lds + nn * kHBufBytes;
-    H_TR_BASES(buf);
-    H_PC_ITER(nbuf, dbuf, true, true);
-    H_TICK(tk3);
-    H_TIMING_ACC();
-    cur = nxt;
-  }
-  if (nc >= 2) {
-    const int nxt = cur == kHBufs - 1 ? 0 : cur + 1;
-    if (nc > 2) H_DMA_BARRIER();
-    const char* buf = lds + cur * kHBufBytes;
-    const char* nbuf = lds + nxt * kHBufBytes;
-    H_TR_BASES(buf);
-    H_PC_ITER(nbuf, lds, false, true);
-    cur = nxt;
-  }
-  {
-    const char* buf = lds + cur * kHBufBytes;
-    H_TR_BASES(buf);
-    H_PC_ITER(buf, lds, false, false);
-  }
-  H_TIMING_WRITE(!H_TIMING_Q);
-  float* orow = part_O + ((int64_t)split * B + xrow) * k3D;
-#pragma unroll
-  for (int db = 0; db < 4; ++db)
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      *reinterpret_cast<float4*>(orow + 32 * db + 8 * q + 4 * h) =
-          make_float4(acc[db][4 * q], acc[db][4 * q + 1], acc[db][4 * q + 2], acc[db][4 * q + 3]);
-}
-
-// -----------------------------------------------------------------------------------------------------------------
-// Pass C, 8-wave form (default): one 512-thread workgroup owns 256 rows, so a plane tile is fetched once for eight
-// waves (half the L2 -> LDS traffic of two 4-wave workgroups per CU, two DMA instructions per wave and chunk instead of
-// four), and the P'^T tiles come through LDS too: pass Q leaves a tile as 32 rows (this pass's owned rows j) of 128
-// bytes (32 streamed rows i), lane (j, h) needs 16 bytes of row j per load -- a quarter of each line per instruction
-// when loaded straight into registers (H_PROBE_PC_LINEAR: 81 -> 70 us with coalesced loads).  As an LDS-DMA the tile is
-// four fully coalesced 1 KB instructions per wave, asynchronous and as deep in flight as the plane tiles (no staging
-// registers), and the transposition is the ds_read_b128 of row j (16-byte segments XOR-swizzled by the row on the
-// source side, as for the planes: conflict-free).  Ring slot = planes (16 KB) + per wave [P tile 4 KB | factors 256 B].
-// -----------------------------------------------------------------------------------------------------------------
 constexpr int kPc8Wave = 4096 + 256;
 constexpr int kPc8Buf = 2 * kPlaneBytes + 8 * kPc8Wave;  // 51200: three of them are 150 KB of the CU's 160
 constexpr int kPc8Owned = 256;
@@ -888,8 +749,14 @@ __global__ __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __re
   const int64_t jt = live ? (wrow >> 5) : 0;  // (idle waves fetch block 0's tiles: valid addresses, results dropped)
   const float* ref = fac + (int64_t)(jt / nc_q) * B;
   const char* const pw_base = reinterpret_cast<const char*>(Pmat) + (jt * nch + c0) * 4096;
-  // per-lane source offset inside a tile for LDS position g * 1024 + lane * 16: row g * 8 + lane / 8, segment swizzled
-  const uint32_t p_off = (uint32_t)((lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4));
+  // LDS piece u = mh * 32 + x holds tile piece (mh, a = x ^ 2 mh) (mh = 2 m + h of pass Q): DMA instruction G4 writes
+  // pieces u = 64 G4 + lane, i.e. mh = 2 G4 + lane / 32, x = lane % 32
+  uint32_t p_off[4];
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    const int mh = 2 * g4 + (lane >> 5);
+    p_off[g4] = (uint32_t)((mh * 32 + ((lane & 31) ^ (2 * mh))) * 16);
+  }
   const int wave_off = 2 * kPlaneBytes + w * kPc8Wave;
 
   f32x16 acc[4];
@@ -911,7 +778,7 @@ __global__ __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __re
 #define H_P_LOAD_AUX 2  /* cache-policy bits of the P tile loads: nt (see H_P_ST); 0 for an A/B build */
 #endif
 #define H8_DMA_P(G4, BUF)                                                                                 \
-  __builtin_amdgcn_global_load_lds((gptr_t)(pw_base + (int64_t)dpos * 4096 + (G4) * 1024 + p_off),        \
+  __builtin_amdgcn_global_load_lds((gptr_t)(pw_base + (int64_t)dpos * 4096 + p_off[G4]),                  \
                                    (lptr_t)((BUF) + wave_off + (G4) * 1024), 16, 0, H_P_LOAD_AUX)
 #define H8_DMA_FAC(BUF)                                                                                   \
   __builtin_amdgcn_global_load_lds((gptr_t)(ref + (c0 + dpos) * 32 + (lane & 31)),                        \
@@ -934,13 +801,14 @@ __global__ __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __re
   uint32_t pw[2][8], pwn[2][8];
   f16x8 ta2_[2][4][2];
   uint32_t trn_[4][2];
-  // this lane's 16 probabilities of the chunk in BUF (row j of the tile, segments 2 g + h) and their 16 factors
-  const int p_rd = wave_off + j * 128;
+  // this lane's 16 probabilities of the chunk in BUF: component j % 4 of pieces (mh = j / 4, a = 8 g + 4 h + e), at LDS
+  // piece mh * 32 + (a ^ 2 mh); and their 16 factors
+  const int p_mh = j >> 2;
+  const int p_rd = wave_off + p_mh * 512 + (j & 3) * 4;
+  const int p_x = (4 * h) ^ (2 * p_mh);  // (8 g + e) ^ p_x == (8 g + 4 h + e) ^ 2 mh: the three fields do not overlap
 #define H8_LOAD_P(BUF)                                                                                    \
-  _Pragma("unroll") for (int g4_ = 0; g4_ < 4; ++g4_) {                                                   \
-    const float4 v_ = *reinterpret_cast<const float4*>((BUF) + p_rd + (((2 * g4_ + h) ^ (j & 7)) << 4));   \
-    p1[4 * g4_] = v_.x; p1[4 * g4_ + 1] = v_.y; p1[4 * g4_ + 2] = v_.z; p1[4 * g4_ + 3] = v_.w;           \
-  }
+  _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_)                                                       \
+    p1[r_] = *reinterpret_cast<const float*>((BUF) + p_rd + (((8 * (r_ >> 2) + (r_ & 3)) ^ p_x) << 4));
 #define H8_LOAD_REFS(BUF)                                                                                 \
   _Pragma("unroll") for (int g4_ = 0; g4_ < 4; ++g4_) {                                                   \
     const float4 lv_ = *reinterpret_cast<const float4*>((BUF) + wave_off + 4096 + (8 * g4_ + 4 * h) * 4); \
@@ -1121,19 +989,12 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
   const int nchunks = (int)(B / k3Chunk);
   const char* qcs = getenv("ESR_IB2H_Q_PER_CU");
   const int nsplit_q = inbatch2h_nsplit(B, qcs ? std::max(1, atoi(qcs)) : 2);  // 252 registers, 50 KB of LDS: two per CU
-  const char* pcs = getenv("ESR_IB2H_PC_PER_CU");
-  // pass C: 8-wave workgroups (256 owned rows, one per CU) unless ESR_IB2H_PC=4w asks for the 4-wave form (two per CU)
-  const char* pcf = getenv("ESR_IB2H_PC");
-  const bool pc8 = !(pcf && pcf[0] == '4');
-  int nsplit_c = inbatch2h_nsplit(B, pcs ? std::max(1, atoi(pcs)) : 2);
-  int grid_c = (int)(B / k3Owned) * nsplit_c;
-  if (pc8) {
-    const int blocks = (int)cdiv(B, kPc8Owned);
-    nsplit_c = 1;
-    for (int sp = 1; sp <= 8; ++sp)
-      if (nchunks % sp == 0 && blocks * sp <= 320) nsplit_c = sp;
-    grid_c = blocks * nsplit_c;
-  }
+  // pass C: 8-wave workgroups, 256 owned rows each
+  const int pc_blocks = (int)cdiv(B, kPc8Owned);
+  int nsplit_c = 1;
+  for (int sp = 1; sp <= 8; ++sp)
+    if (nchunks % sp == 0 && pc_blocks * sp <= 320) nsplit_c = sp;
+  const int grid_c = pc_blocks * nsplit_c;
   const int grid_q = (int)(B / k3Owned) * nsplit_q;
   const int mgrid = (int)std::min<int64_t>(k3MergeBlocks, cdiv(B, kBlock / 32));
   // exponent reference of pass Q: optimistic + redo launch (default), or the row-max pass (ESR_IB2H_REF=rowmax);
@@ -1163,12 +1024,8 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
                      (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale, regularization,
                      inv_bs, ws.lse2, lse, gQ, ws.loss_acc, 1.0 / (double)batch_size, loss, (float*)nullptr,
                      (const float*)(ws.sc + 1), ldexpf(1.f, (int)kHPexp), ws.fac);
-  if (pc8)
-    hipLaunchKernelGGL(inbatch2h_pc8_kernel, dim3(grid_c), dim3(512), 0, st, (const _Float16*)ws.Qh, B, nsplit_c,
-                       (const float*)ws.fac, nchunks / nsplit_q, (const float*)ws.Pmat, ws.part_O);
-  else
-    hipLaunchKernelGGL(inbatch2h_pc_kernel, dim3(grid_c), dim3(256), 0, st, (const _Float16*)ws.Qh, B, nsplit_c,
-                       (const float*)ws.fac, nchunks / nsplit_q, (const float*)ws.Pmat, ws.part_O);
+  hipLaunchKernelGGL(inbatch2h_pc8_kernel, dim3(grid_c), dim3(512), 0, st, (const _Float16*)ws.Qh, B, nsplit_c,
+                     (const float*)ws.fac, nchunks / nsplit_q, (const float*)ws.Pmat, ws.part_O);
   // O_C' = 2^(eq + 14) sum_i (p_ij / l_i) q_i
   hipLaunchKernelGGL((inbatch3_merge_kernel<false>), dim3(mgrid), dim3(kBlock), 0, st, Cs, Qs, gc_rows, B, nsplit_c,
                      (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale, regularization,
