@@ -111,6 +111,7 @@ class PresortedInputs:
 # ESR_GLOVE_PRESORT=0 sorts in line instead of one batch ahead on the side stream.  ESR_GLOVE_STEP_BLOCKS_PER_CU caps the
 # update kernel's residency (experiment knob: making room for the sort to run BESIDE it measured slower).
 _PRESORT = os.environ.get("ESR_GLOVE_PRESORT", "1") == "1"
+_PRESORT_DEPTH = max(1, int(os.environ.get("ESR_GLOVE_PRESORT_DEPTH", "2")))  # batches sorted ahead (train_epoch)
 _STEP_BLOCKS_PER_CU = int(os.environ.get("ESR_GLOVE_STEP_BLOCKS_PER_CU", "0"))
 
 
@@ -230,18 +231,21 @@ def train_epoch(state, steps_per_epoch, train_it):
     library call); with the reference's dense Adam it is apply_model + update_model as there."""
     if fused_step_available(state) and steps_per_epoch > 0:
         ctx = _FusedEpoch(state, steps_per_epoch)
-        # batches are fetched one ahead so that batch k + 1's ids can be sorted (side stream) under batch k's update
-        # kernel; worth it only when the list is long enough for the sort to be a chain of launches (> 4096 ids)
-        ahead = None
+        # Batches are fetched _PRESORT_DEPTH ahead so that their ids can be sorted on the side stream under the update
+        # kernels of the batches before them; worth it only when the list is long enough for the sort to be a chain of
+        # launches (> 4096 ids).  Two ahead, not one: the update kernel fills every wave slot, so a sort issued beside
+        # step k mostly runs in the gaps after it -- one ahead, its second radix pass (23 us) still sat between step k
+        # and step k + 1 (profiles/r2/glove_kernel_stats.csv: the first scatter "takes" 106 us, stretched over the step).
+        from collections import deque
+        queue, fetched = deque(), 0
         for k in range(steps_per_epoch):
-            inputs, targets = ahead if ahead is not None else next(train_it)
-            ahead = None
-            if _PRESORT and _ids_count(inputs) > _PRESORT_MIN_IDS:
-                if k == 0:
+            while fetched < steps_per_epoch and len(queue) < _PRESORT_DEPTH + 1:
+                inputs, targets = next(train_it)
+                fetched += 1
+                if _PRESORT and _ids_count(inputs) > _PRESORT_MIN_IDS:
                     inputs = presort_inputs(state, inputs)
-                if k + 1 < steps_per_epoch:
-                    nxt_inputs, nxt_targets = next(train_it)
-                    ahead = (presort_inputs(state, nxt_inputs), nxt_targets)
+                queue.append((inputs, targets))
+            inputs, targets = queue.popleft()
             ctx.step(k, inputs, targets)
         state = state.replace(step=state.step + steps_per_epoch)
         return state, float(ctx.losses[:steps_per_epoch].mean())
