@@ -528,6 +528,19 @@ def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True
         state, final_loss = train_epoch(state, steps, iter(batches[warmup:]))  # returns the epoch's mean loss (syncs)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+    elif workload == "triplet" and graphed is None and os.environ.get("ESR_STL_LOOP", "1") == "1" and \
+            os.environ.get("ESR_STL_PRESORT", "0") != "1" and cfg["B"] <= 65536:
+        # the reference's training loop body (pinterest/train_shop_the_look.py:195-204) through the build's loop helper:
+        # one-pass steps, the id sort of the coming batches on a second stream, two library calls per step
+        from esrecsys_amd.pinterest.train_shop_the_look import train_steps
+        mode = "eager, train_steps (one library call per step)"
+        state, _ = train_steps(state, iter(batches[:warmup]), warmup, LAM, B)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        state, losses = train_steps(state, iter(batches[warmup:]), steps, LAM, B)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        final_loss = float(losses[-1])
     elif workload == "inbatch" and graphed is None and os.environ.get("ESR_INBATCH_AHEAD", "0") == "1" and \
             cfg.get("table_dtype") in (None, "f32", "bf16"):
         # experiment knob (default off): the ids of batch k + 1 sorted on a second stream while batch k's MFMA kernels
@@ -559,15 +572,19 @@ def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True
         mode = "eager, ids of the next batch sorted on a side stream"
         use = fused_triplet_step_available(state)
 
+        depth = max(1, int(os.environ.get("ESR_STL_PRESORT_DEPTH", "2")))
+
         def run(lo, hi):
             nonlocal state
-            ahead = presort_triplets(state, *batches[lo]) if use else None
+            from collections import deque
+            queue, nxt = deque(), lo
             l = None
             for i in range(lo, hi):
-                cur = ahead
-                ahead = presort_triplets(state, *batches[i + 1]) if use and i + 1 < hi else None
+                while use and nxt < hi and len(queue) < depth + 1:
+                    queue.append(presort_triplets(state, *batches[nxt]))
+                    nxt += 1
                 if use:
-                    state, l = train_step(state, cur, None, None, LAM, B)
+                    state, l = train_step(state, queue.popleft(), None, None, LAM, B)
                 else:
                     state, l = train_step(state, *batches[i], LAM, B)
             return l

@@ -206,6 +206,140 @@ def train_step(state, scene, pos_product, neg_product, regularization, batch_siz
     return new_state, loss.reshape(())
 
 
+class _FusedTripletLoop:
+    """What the one-pass triplet step needs that does not change from batch to batch, resolved once: tower / accumulator
+    / RowVersions pointers, the library entry points, a loss slot per step, and a ring of id-sort buffers on the side
+    stream.  At the reference's batch sizes the step is three short kernels behind a two-launch id sort; the sort needs
+    the ids only, so it runs `depth` batches ahead on a second stream (same idea as wikipedia.train_epoch), and the
+    per-step Python is two library calls and three event operations."""
+
+    def __init__(self, state, steps, depth):
+        import ctypes
+        from .. import _lib
+        from ..train_state import _side_stream, row_versions
+        prefix = ("params",) if "params" in state.raw_params else ()
+        p = state.raw_params["params"] if prefix else state.raw_params
+        acc = state.opt_state["sum_of_squares"]
+        acc = acc["params"] if prefix else acc
+        self.st, self.pt = p["scene_tower"]["embedding"], p["product_tower"]["embedding"]
+        self.rs = row_versions(state, prefix + ("scene_tower", "embedding"))
+        self.rp = row_versions(state, prefix + ("product_tower", "embedding"))
+        self.acc_s, self.acc_p = acc["scene_tower"]["embedding"], acc["product_tower"]["embedding"]
+        self.Vs, self.D = self.st.shape
+        self.Vp = self.pt.shape[0]
+        self.dev = self.st.device
+        self.lr, self.eps = float(state.tx.lr), float(state.tx.eps)
+        self.lib, self.check, self.ct = _lib.load(), _lib.check, ctypes
+        self.losses = torch.empty(max(steps, 1), dtype=torch.float32, device=self.dev)
+        self.main = torch.cuda.current_stream(self.dev)
+        self.side = _side_stream(self.dev)
+        self.depth = depth
+        self.ring, self.B = [], -1
+        self.ws = None
+        self.fixed_s = (self.st.data_ptr(), self.rs.shadow.data_ptr(), self.rs.loc.data_ptr(), self.acc_s.data_ptr(),
+                        self.Vs)
+        self.fixed_p = (self.pt.data_ptr(), self.rp.shadow.data_ptr(), self.rp.loc.data_ptr(), self.acc_p.data_ptr(),
+                        self.Vp)
+
+    def _sized(self, B):
+        if B == self.B:
+            return
+        n = 3 * B
+        self.ring = []
+        for _ in range(self.depth + 1):
+            self.ring.append({
+                "sorted": torch.empty(n, dtype=torch.int32, device=self.dev),
+                "perm": torch.empty(n, dtype=torch.int32, device=self.dev),
+                "ws": torch.empty(ops._ws_bytes("esr_segment_sort_workspace_bytes", n), dtype=torch.uint8,
+                                  device=self.dev),
+                "done": torch.cuda.Event(), "ids_ready": torch.cuda.Event(), "free": torch.cuda.Event()})
+        self.ws = ops._ws(ops._ws_bytes("esr_triplet_step_workspace_bytes", B, self.D), self.dev)
+        self.cnt = (self.ct.c_int64 * 3)(B, B, B)
+        self.off = (self.ct.c_int64 * 3)(0, self.Vs, self.Vs)
+        self.B = B
+
+    def ids(self, scene, pos, neg):
+        sid = ops.as_ids(scene, self.dev, check_range=self.Vs).reshape(-1)
+        pid = ops.as_ids(pos, self.dev, check_range=self.Vp).reshape(-1)
+        nid = ops.as_ids(neg, self.dev, check_range=self.Vp).reshape(-1)
+        return sid, pid, nid
+
+    def presort(self, slot_index, sid, pid, nid):
+        """Sort [scene ; Vs + pos ; Vs + neg] of a coming batch on the side stream into ring slot `slot_index`."""
+        self._sized(sid.numel())
+        slot = self.ring[slot_index]
+        slot["ids_ready"].record(self.main)          # the ids may have been copied / produced on the main stream
+        self.side.wait_event(slot["ids_ready"])
+        self.side.wait_event(slot["free"])           # the step that last read this slot's buffers has been issued
+        ptrs = (self.ct.c_void_p * 3)(sid.data_ptr(), pid.data_ptr(), nid.data_ptr())
+        self.check(self.lib.esr_segment_sort_ids_multi(ptrs, self.cnt, self.off, 3, self.Vs + self.Vp,
+                                                       slot["sorted"].data_ptr(), slot["perm"].data_ptr(),
+                                                       slot["ws"].data_ptr(), slot["ws"].numel(),
+                                                       self.side.cuda_stream), "esr_segment_sort_ids_multi")
+        slot["done"].record(self.side)
+        return (slot_index, sid, pid, nid)
+
+    def step(self, k, handle, regularization, batch_size):
+        slot_index, sid, pid, nid = handle
+        sorted_ptr = perm_ptr = 0  # in-line sort inside the library call
+        slot = None
+        if slot_index is not None:
+            slot = self.ring[slot_index]
+            self.main.wait_event(slot["done"])
+            sorted_ptr, perm_ptr = slot["sorted"].data_ptr(), slot["perm"].data_ptr()
+        else:
+            self._sized(sid.numel())
+        self.rs.dirty = self.rp.dirty = True
+        self.check(self.lib.esr_triplet_train_step(*self.fixed_s, *self.fixed_p, self.D, sid.data_ptr(), pid.data_ptr(),
+                                                   nid.data_ptr(), self.B, float(regularization), float(batch_size),
+                                                   self.lr, self.eps, sorted_ptr, perm_ptr,
+                                                   self.losses.data_ptr() + 4 * k, self.ws.data_ptr(), self.ws.numel(),
+                                                   self.main.cuda_stream), "esr_triplet_train_step")
+        if slot is not None:
+            slot["free"].record(self.main)
+
+
+# Batches whose ids are sorted ahead on the side stream; 0 = the sort runs in line, inside the step's library call.
+# Default 0: measured with depth 2 at B = 8192 the loop is host-bound (52 us per step against 41 us in line: three event
+# operations and a second library call per step cost more than the 15 us sort they hide), and at B = 262 144 the sort
+# beside the HBM-bound update kernel slows that kernel by more than its own length (0.689 against 0.640 ms) -- the same
+# finding as for the GloVe step, where only filling the gaps BETWEEN steps pays (wikipedia.train_epoch).
+_LOOP_DEPTH = max(0, int(_os.environ.get("ESR_STL_PRESORT_DEPTH", "0")))
+
+
+def train_steps(state, batches, num_steps, regularization, batch_size):
+    """`num_steps` iterations of the reference's training loop body (pinterest/train_shop_the_look.py:195-204:
+    ``state, loss = train_step(state, scene, pos, neg, regularization, batch_size)`` for each batch of the iterator
+    `batches`, yielding ``(scene, pos_product, neg_product)``).  Returns ``(state, losses)`` with the per-step losses
+    as one device tensor -- the loop never synchronises.  Under ``optim.sparse_adagrad`` every step is the one-pass step
+    driven through a per-loop context (one library call per step; ``ESR_STL_PRESORT_DEPTH=n`` sorts the ids of the next
+    n batches on a second stream -- measured slower, see _LOOP_DEPTH); otherwise it is ``train_step`` as is."""
+    it = iter(batches)
+    if not fused_triplet_step_available(state) or num_steps <= 0:
+        losses = []
+        for _ in range(max(num_steps, 0)):
+            scene, pos, neg = next(it)
+            state, loss = train_step(state, scene, pos, neg, regularization, batch_size)
+            losses.append(loss)
+        dev = _tables(state)[1].device
+        return state, (torch.stack(losses) if losses else torch.empty(0, device=dev))
+    from collections import deque
+    ctx = _FusedTripletLoop(state, num_steps, _LOOP_DEPTH)
+    if _LOOP_DEPTH == 0:
+        for k in range(num_steps):
+            scene, pos, neg = next(it)
+            ctx.step(k, (None,) + ctx.ids(scene, pos, neg), regularization, batch_size)
+        return state.replace(step=state.step + num_steps), ctx.losses[:num_steps]
+    queue, fetched = deque(), 0
+    for k in range(num_steps):
+        while fetched < num_steps and len(queue) < _LOOP_DEPTH + 1:
+            scene, pos, neg = next(it)
+            queue.append(ctx.presort(fetched % (_LOOP_DEPTH + 1), *ctx.ids(scene, pos, neg)))
+            fetched += 1
+        ctx.step(k, queue.popleft(), regularization, batch_size)
+    return state.replace(step=state.step + num_steps), ctx.losses[:num_steps]
+
+
 def eval_step(state, scene, pos_product, neg_product):
     """sum relu(1 + neg - pos): fixed margin, no reg, not divided by the batch size (train_shop_the_look.py:111-122)."""
     _, st, pt = _tables(state)

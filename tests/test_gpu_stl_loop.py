@@ -1,0 +1,68 @@
+"""GPU: the Shop-The-Look loop helper (train_steps: one-pass triplet steps with the id sort running ahead on a second
+stream) against step-by-step train_step on the same batches -- same towers, accumulators and losses."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _state(dev, Vs, Vp, D, seed):
+    from esrecsys_amd import TrainState, optim
+    from esrecsys_amd.pinterest.models import STLModel
+    g = torch.Generator(device=dev).manual_seed(seed)
+    params = {"params": {"scene_tower": {"embedding": torch.randn((Vs, D), generator=g, device=dev) * D ** -0.5},
+                         "product_tower": {"embedding": torch.randn((Vp, D), generator=g, device=dev) * D ** -0.5}}}
+    model = STLModel(output_size=D, num_scenes=Vs, num_products=Vp, device=dev)
+    return TrainState.create(apply_fn=model.apply, params=params, tx=optim.sparse_adagrad(0.05))
+
+
+@pytest.mark.parametrize("depth", [0, 2])
+@pytest.mark.parametrize("B,steps,ids", [(256, 7, "uniform"), (2048, 5, "hot"), (64, 1, "uniform")])
+def test_train_steps_equals_stepwise_train_step(dev, B, steps, ids, depth, monkeypatch):
+    import esrecsys_amd.pinterest.train_shop_the_look as stl
+    from esrecsys_amd.pinterest.train_shop_the_look import train_step, train_steps
+    monkeypatch.setattr(stl, "_LOOP_DEPTH", depth)  # 0: sort in line (default); 2: two batches ahead on the side stream
+    Vs, Vp, D = 3000, 5000, 64
+    rng = np.random.default_rng(B + steps)
+
+    def draw(V):
+        if ids == "hot":  # a few very popular rows: long runs, the chunked hot-row path
+            return np.where(rng.random(B) < 0.4, rng.integers(0, 3, B), rng.integers(0, V, B)).astype(np.int32)
+        return rng.integers(0, V, B).astype(np.int32)
+    batches = [(torch.from_numpy(draw(Vs)).to(dev), torch.from_numpy(draw(Vp)).to(dev),
+                torch.from_numpy(draw(Vp)).to(dev)) for _ in range(steps)]
+    a, b = _state(dev, Vs, Vp, D, 3), _state(dev, Vs, Vp, D, 3)
+    a, losses = train_steps(a, iter(batches), steps, 0.1, float(B))
+    ref = []
+    for scene, pos, neg in batches:
+        b, l = train_step(b, scene, pos, neg, 0.1, float(B))
+        ref.append(l)
+    assert losses.shape == (steps,) and int(a.step) == int(b.step) == steps
+    assert torch.equal(losses, torch.stack(ref))
+    for tower in ("scene_tower", "product_tower"):
+        assert torch.equal(a.params["params"][tower]["embedding"], b.params["params"][tower]["embedding"])
+        assert torch.equal(a.opt_state["sum_of_squares"]["params"][tower]["embedding"],
+                           b.opt_state["sum_of_squares"]["params"][tower]["embedding"])
+
+
+def test_train_steps_host_batches_and_other_optimizer(dev):
+    """NumPy batches (copied per step) and the fallback for an optimizer without the one-pass step"""
+    from esrecsys_amd import TrainState, optim
+    from esrecsys_amd.pinterest.train_shop_the_look import train_step, train_steps
+    Vs, Vp, D, B, steps = 500, 700, 32, 128, 3
+    rng = np.random.default_rng(5)
+    batches = [(rng.integers(0, Vs, B), rng.integers(0, Vp, B), rng.integers(0, Vp, B)) for _ in range(steps)]
+    a, b = _state(dev, Vs, Vp, D, 1), _state(dev, Vs, Vp, D, 1)
+    a, losses = train_steps(a, iter(batches), steps, 0.1, float(B))
+    for scene, pos, neg in batches:
+        b, l = train_step(b, scene, pos, neg, 0.1, float(B))
+    assert abs(float(losses[-1]) - float(l)) <= 1e-6 * abs(float(l))
+    assert rel_err(a.params["params"]["scene_tower"]["embedding"].cpu().numpy(),
+                   b.params["params"]["scene_tower"]["embedding"].cpu().numpy()) <= 1e-6
+    c = _state(dev, Vs, Vp, D, 1)
+    c = TrainState.create(apply_fn=c.apply_fn, params=c.params, tx=optim.sgd(0.1))
+    c, losses_c = train_steps(c, iter(batches), steps, 0.1, float(B))
+    assert losses_c.shape == (steps,) and bool(torch.isfinite(losses_c).all())
