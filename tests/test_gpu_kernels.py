@@ -469,6 +469,26 @@ def test_inbatch_f16x2_operand_and_score_ranges(dev, mag_q, mag_c, scale):
         assert max(errs["f16x2"]) <= 4 * max(errs["f32"]), errs
 
 
+def test_inbatch_f16x2_largest_batch_against_exact_f32(dev):
+    """B = 16384 is the largest batch of the two-plane path (1 GiB of stored probabilities): against the exact-f32 MFMA
+    kernel on the same inputs (the fp64 oracle needs 2 GiB per B x B matrix at this size), plus the column-sum property
+    of gC when the regulariser is off (softmax rows sum to one)."""
+    from esrecsys_amd import ops
+    g = torch.Generator(device=dev).manual_seed(11)
+    B, D = 16384, 128
+    q = torch.randn((B, D), generator=g, device=dev) * D ** -0.5
+    c = torch.randn((B, D), generator=g, device=dev) * D ** -0.5
+    loss, lse, gq, gc = [t.clone() for t in ops.inbatch_softmax_fwd_bwd(q, c, 8.0, 0.0, float(B), precision="f16x2")]
+    l2, lse2, gq2, gc2 = ops.inbatch_softmax_fwd_bwd(q, c, 8.0, 0.0, float(B), precision="f32")
+    assert abs(float(loss) - float(l2)) <= 2e-6 * abs(float(l2))
+    assert rel_err(N(lse), N(lse2)) <= 2e-6 and rel_err(N(gq), N(gq2)) <= 5e-6 and rel_err(N(gc), N(gc2)) <= 5e-6
+    colsum = N(gc).astype(F64).sum(0)
+    assert np.abs(colsum).max() <= 1e-5 * np.abs(N(gc)).sum(0).max()
+    with pytest.raises(ValueError):
+        ops.inbatch_softmax_fwd_bwd(torch.zeros((16512, D), device=dev), torch.zeros((16512, D), device=dev), 1.0, 0.0,
+                                    1.0, precision="f16x2")  # beyond the stored-P limit: bf16x3 / auto take it
+
+
 @pytest.mark.parametrize("ref_mode", ["opt", "redo", "rowmax"])
 @pytest.mark.parametrize("B", [128, 1024, 2176])
 def test_inbatch_f16x2_exponent_reference_modes(dev, B, ref_mode, monkeypatch):
