@@ -416,23 +416,49 @@ __global__ __launch_bounds__(256) void rowmax2h_kernel(const _Float16* __restric
 // O^T MFMAs of chunk t carry the second k-step's A fragments and the DMA of chunk t + 2.  The unnormalised
 // probabilities p' = exp2(s sl2 - M_i) go to Pmat (f32, 32 x 32 tiles, transposed) for pass C.
 // -----------------------------------------------------------------------------------------------------------------
+// The A fragments of the S^T phase are read with ds_read_b128 written as inline assembly and waited for by hand: hipcc's
+// own s_waitcnt does not count the transposing reads (also assembly) that are issued between a fragment pair and its
+// use, and came out as lgkmcnt(2) / lgkmcnt(0) on alternating k-steps -- every other k-step waited for the pair it had
+// JUST issued, one exposed LDS latency each.  LDS operations return in order; before the first MFMA of k-step s the
+// outstanding ones are, oldest first: pair s (issued a k-step ago), the two transposing reads of k-step s - 1 (VALU_ON,
+// s >= 1) and pair s + 1 (s < 7): the wait lets everything but pair s stay in flight.
+#ifndef H_S_ASM_LOADS
+#define H_S_ASM_LOADS 1
+#endif
+template <int OFF>
+__device__ __forceinline__ f16x8 lds_b128(uint32_t addr) {
+  f16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+#if H_S_ASM_LOADS
+#define H_S_LD(P, OFFB) lds_b128<(P) * kPlaneBytes>(ap32_ + (uint32_t)(OFFB))
+#define H_S_WAIT(N) { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+#else
+#define H_S_LD(P, OFFB) (*reinterpret_cast<const f16x8*>(ap0_ + (OFFB) + (P) * kPlaneBytes))
+#define H_S_WAIT(N)
+#endif
 #define H_S_PHASE(NBUF, SA, VALU_ON)                                                                      \
   {                                                                                                       \
     _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) SA[r_] = 0.f;                                       \
     const char* ap0_ = (NBUF) + j * 256;                                                                  \
+    const uint32_t ap32_ = lds32 + (uint32_t)((NBUF) - lds) + (uint32_t)(j * 256);                        \
+    (void)ap0_; (void)ap32_;                                                                              \
     const int sw_ = swz16(j);                                                                             \
-    f16x8 a1_ = *reinterpret_cast<const f16x8*>(ap0_ + ((h ^ sw_) << 4));                                 \
-    f16x8 a2_ = *reinterpret_cast<const f16x8*>(ap0_ + ((h ^ sw_) << 4) + kPlaneBytes);                   \
+    f16x8 a1_ = H_S_LD(0, (h ^ sw_) << 4);                                                                \
+    f16x8 a2_ = H_S_LD(1, (h ^ sw_) << 4);                                                                \
     float ek0_ = 0.f, ek1_ = 0.f;                                                                         \
     _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) {                                                    \
       f16x8 n1_ = a1_, n2_ = a2_;                                                                         \
       if (s_ < 7) {                                                                                       \
         const int off_ = (((2 * (s_ + 1) + h) ^ sw_) << 4);                                               \
-        n1_ = *reinterpret_cast<const f16x8*>(ap0_ + off_);                                               \
-        n2_ = *reinterpret_cast<const f16x8*>(ap0_ + off_ + kPlaneBytes);                                 \
+        n1_ = H_S_LD(0, off_);                                                                            \
+        n2_ = H_S_LD(1, off_);                                                                            \
       }                                                                                                   \
       float e0_ = 0.f, e1_ = 0.f;                                                                         \
       f16x2 pa_ = {0, 0};                                                                                 \
+      H_SB();                                                                                             \
+      H_S_WAIT((s_ < 7 ? 2 : 0) + (((VALU_ON) && s_ >= 1) ? 2 : 0));                                      \
       H_SB();                                                                                             \
       SA = H_MFMA(a2_, bx[0][s_], SA);                                                                    \
       H_SB();                                                                                             \
@@ -537,6 +563,8 @@ __global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __rest
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int j = lane & 31, h = lane >> 5;
   H_TR_SETUP();
+  const uint32_t lds32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds;
+  (void)lds32;
   const int ob = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
   const int64_t xrow = (int64_t)ob * k3Owned + w * 32 + j;
   const int nc = (int)(B / k3Chunk) / nsplit;
