@@ -34,7 +34,8 @@ def measure_retrieve(dev, n_local, steps, warmup, mode="exact", with_cpu=True, w
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     t_op = e0.elapsed_time(e1) * 1e-3 / steps  # HIP events on the launch stream around the timed calls
-    planes = 6 if mode == "exact" else 1
+    exact_path = os.environ.get("ESR_RETRIEVE_EXACT", "f16x2")  # what "exact" resolves to (ops._retrieve_mode)
+    planes = (3 if exact_path == "f16x2" else 6) if mode == "exact" else 1  # MFMA cross terms per product
     flops = 2.0 * nq * n_local * D
     from bench import sustained_bf16_mfma_tflops
     live = sustained_bf16_mfma_tflops(dev)
@@ -73,7 +74,8 @@ def measure_retrieve(dev, n_local, steps, warmup, mode="exact", with_cpu=True, w
     return {
         "metric": "retrieval queries/sec (top-%d of N candidates, brute force)" % k,
         "value": nq * steps / dt, "unit": "queries/s", "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
-        "dtype": "bf16x3 (f32-equivalent)" if mode == "exact" else "bf16",
+        "dtype": ("f16x2" if os.environ.get("ESR_RETRIEVE_EXACT", "f16x2") == "f16x2" else "bf16x3") +
+                 " (f32-equivalent)" if mode == "exact" else "bf16",
         "config": {"workload": "retrieve: %d queries x %d candidates x D=%d, k=%d, one GPU" % (nq, n_local, D, k),
                    "mode": mode, **extra},
         "roofline": {"kernel": "score_gemm_kernel (+ split, select)", "bound": "mfma",
@@ -136,7 +138,8 @@ def run_retrieve(args, emit):
     e1.record()
     torch.cuda.synchronize()
     t_op = e0.elapsed_time(e1) * 1e-3
-    planes = 6 if mode == "exact" else 1
+    exact_path = os.environ.get("ESR_RETRIEVE_EXACT", "f16x2")  # what "exact" resolves to (ops._retrieve_mode)
+    planes = (3 if exact_path == "f16x2" else 6) if mode == "exact" else 1  # MFMA cross terms per product
     flops = 2.0 * qq.shape[0] * n_local * D
     traffic = None
     try:
@@ -173,7 +176,8 @@ def run_retrieve(args, emit):
             "metric": "retrieval queries/sec (top-%d of N candidates, brute force)" % K,
             "value": world * NQ * args.steps / dt, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16x3 (f32-equivalent)" if mode == "exact" else "bf16",
+            "scaling": "weak", "vs_baseline": None, "dtype": ("f16x2" if os.environ.get("ESR_RETRIEVE_EXACT", "f16x2") == "f16x2" else "bf16x3") +
+                 " (f32-equivalent)" if mode == "exact" else "bf16",
             "data": "synthetic",
             "config": {"workload": "retrieve: %d queries/GPU x %d candidates (%d per GPU, id mod N) x D=%d, k=%d"
                                    % (NQ, n_local * world, n_local, D, K), "mode": mode,

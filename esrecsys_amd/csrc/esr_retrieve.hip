@@ -27,6 +27,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kGM = 256, kGN = 128, kGK = 16;  // tile rows (queries), tile cols (candidates), k per stage
 constexpr int kGThreads = 512;
@@ -39,13 +41,67 @@ constexpr int kSelMaxK = 1024;
 constexpr int kFirstChunk = 8192;
 
 // ---------------------------------------------------------------------------------------------------
+// P == 2 (mode 2, "f16x2"): two fp16 planes of x * 2^e instead of three bf16 ones -- x * 2^e = x1 + x2 to 2^-24 relative
+// with round-to-nearest planes, a.b ~= a2 b1 + a1 b2 + a1 b1 (three MFMAs per product instead of six; see
+// esr_inbatch2h.hip).  e is one exponent per matrix, from its largest |element| (max |x * 2^e| in [2^13, 2^14)):
+// absmax_part_kernel -> slots, absmax_exp_kernel -> the exponent word the split and the GEMM epilogue read.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kAbsBlocks = 1024;
+__global__ __launch_bounds__(kBlock) void absmax_part_kernel(const float* __restrict__ X, int64_t n,
+                                                            float* __restrict__ slots) {
+  __shared__ float red[kBlock / 64];
+  float m = 0.f;
+  const bool vec = ((uintptr_t)X & 15) == 0;
+  const int64_t n4 = vec ? n >> 2 : 0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+    const float4 f = reinterpret_cast<const float4*>(X)[i];
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(f.x), fabsf(f.y)), fmaxf(fabsf(f.z), fabsf(f.w))));
+  }
+  for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+    m = fmaxf(m, fabsf(X[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = red[0];
+    for (int i = 1; i < kBlock / 64; ++i) t = fmaxf(t, red[i]);
+    slots[blockIdx.x] = t;
+  }
+}
+__global__ __launch_bounds__(kBlock) void absmax_exp_kernel(const float* __restrict__ slots, int nslots,
+                                                           int* __restrict__ exp_out) {
+  __shared__ float red[kBlock / 64];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < nslots; i += kBlock) m = fmaxf(m, slots[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = red[0];
+    for (int i = 1; i < kBlock / 64; ++i) t = fmaxf(t, red[i]);
+    int e = 0;
+    if (t > 0.f && t < INFINITY) {
+      int x;
+      frexpf(t, &x);  // t = m 2^x, m in [0.5, 1)
+      e = 14 - x;
+      e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    }
+    exp_out[0] = e;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // f32 rows -> P bf16 planes, zero padded (rows >= n_rows, cols >= D), K-BLOCK-MAJOR: plane[kb][row][16] with
 // kb = d / 16 -- the 32 rows x 16 k that one DMA instruction moves are 1 KiB of contiguous global memory
 // ---------------------------------------------------------------------------------------------------
 template <int P>
 __global__ __launch_bounds__(kBlock) void split_planes_kernel(const float* __restrict__ X, int64_t n_rows, int D,
                                                              int64_t rows_pad, int Dp, int64_t plane_elems,
-                                                             __bf16* __restrict__ out) {
+                                                             __bf16* __restrict__ out,
+                                                             const int* __restrict__ exp_ptr = nullptr) {
+  const float mul = (P == 2) ? ldexpf(1.f, exp_ptr[0]) : 1.f;
   const int quads = Dp >> 2;
   const int64_t total = rows_pad * quads;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
@@ -62,6 +118,20 @@ __global__ __launch_bounds__(kBlock) void split_planes_kernel(const float* __res
           if (c + e < D) v[e] = X[r * D + c + e];
       }
     }
+    __bf16* dst = out + ((int64_t)(c >> 4) * rows_pad + r) * 16 + (c & 15);
+    if (P == 2) {
+      f16x4 h1, h2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xs = v[e] * mul;  // exact: power of two
+        const _Float16 a = (_Float16)xs;
+        h1[e] = a;
+        h2[e] = (_Float16)(xs - (float)a);
+      }
+      *reinterpret_cast<f16x4*>(dst) = h1;
+      *reinterpret_cast<f16x4*>(dst + plane_elems) = h2;
+      continue;
+    }
     bf16x4 p1, p2, p3;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -74,7 +144,6 @@ __global__ __launch_bounds__(kBlock) void split_planes_kernel(const float* __res
         p3[e] = (__bf16)(r1 - (float)b);
       }
     }
-    __bf16* dst = out + ((int64_t)(c >> 4) * rows_pad + r) * 16 + (c & 15);
     *reinterpret_cast<bf16x4*>(dst) = p1;
     if (P == 3) {
       *reinterpret_cast<bf16x4*>(dst + plane_elems) = p2;
@@ -94,6 +163,7 @@ struct GemmOut {
   int2* pairs;         // [M][ppitch] (score bits, index)
   int64_t ppitch;
   int32_t gbase, gstep;  // global index of local candidate n = gbase + n * gstep
+  const int* exps;       // P == 2: {eq, ec}, the plane exponents (scores = accumulators * 2^-(eq + ec))
 };
 
 // Wait until at most N of this wave's DMAs are outstanding, then the workgroup barrier.  Written by hand:
@@ -118,11 +188,11 @@ __global__ __launch_bounds__(kGThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
                                                                  int64_t a_rows, const __bf16* __restrict__ Bp,
                                                                  int64_t b_plane, int64_t b_rows, int Dp, int tm,
                                                                  int tn, int M, int nvalid, GemmOut o) {
-  constexpr int NS = (P == 3) ? 2 : 4;            // LDS stages (one 16-wide k-step each)
-  constexpr int kStage = P * kPlaneStage;         // 36864 / 12288 B -> two workgroups per CU
+  constexpr int NS = (P == 3) ? 2 : (P == 2 ? 3 : 4);  // LDS stages (one 16-wide k-step each)
+  constexpr int kStage = P * kPlaneStage;         // 36864 / 24576 / 12288 B -> two workgroups per CU
   constexpr int kPieces = P * kPiecesPerPlane;    // DMA instructions per stage, dealt round-robin to the 8 waves
-  constexpr int NPW = (kPieces + 7) / 8;          // 5 / 2: waves 0-3 issue NPW, waves 4-7 NPW - 1
-  static_assert(kPieces % 8 == 4, "piece dealing below assumes 8 * (NPW - 1) + 4 pieces");
+  constexpr int NPW = (kPieces + 7) / 8;          // 5 / 3 / 2: waves below kLastWaves issue NPW, the others NPW - 1
+  constexpr int kLastWaves = kPieces - 8 * (NPW - 1);  // 4 (P = 3, 1) or 8 (P = 2: every wave issues NPW)
   __shared__ __attribute__((aligned(16))) char lds[NS * kStage];
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -161,7 +231,7 @@ __global__ __launch_bounds__(kGThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
     pstep[j] = (uint32_t)((isA ? a_rows : b_rows) * 32);
     pdst[j] = pl * kPlaneStage + sub * 1024;
   }
-  const bool has_last = w < 4;  // waves 0-3 own a piece in round NPW - 1
+  const bool has_last = w < kLastWaves;  // these waves own a piece in round NPW - 1
   // Pieces are issued one at a time BETWEEN MFMAs (an LDS-DMA costs the issuing wave ~60-180 cycles).  Past the
   // last stage a piece is still issued (from a valid address) into the ring slot nobody reads any more, so the
   // loop body is branch-free and vmcnt counts uniformly.
@@ -191,9 +261,9 @@ __global__ __launch_bounds__(kGThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
 #pragma unroll
     for (int j = 0; j < NPW; ++j) issue_piece(j, s);
 
-  constexpr int kTerms = (P == 3) ? 6 : 1;
-  constexpr int kPieceEvery = (P == 3) ? 4 : 2;  // a DMA piece after MFMA 1, 5, 9, ... (P = 3) / 0, 2 (P = 1)
-  constexpr int kPieceFirst = (P == 3) ? 1 : 0;
+  constexpr int kTerms = (P == 3) ? 6 : (P == 2 ? 3 : 1);
+  constexpr int kPieceEvery = (P == 1) ? 2 : 4;  // a DMA piece after MFMA 1, 5, 9, ... (P = 3, 2) / 0, 2 (P = 1)
+  constexpr int kPieceFirst = (P == 1) ? 0 : 1;
   for (int kt = 0; kt < nk; ++kt) {
     // stage kt has landed once at most the NS-2 younger stages' DMAs are outstanding; after the barrier it is
     // visible to every wave and every wave is done with stage kt-1's ring slot (refilled below with kt+NS-1)
@@ -214,11 +284,17 @@ __global__ __launch_bounds__(kGThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
     // six cross terms, small ones first; consecutive MFMAs go to different accumulators
 #pragma unroll
     for (int term = 0; term < kTerms; ++term) {
-      const int pa = (P == 3) ? (term == 0 ? 2 : term == 2 || term == 3 ? 1 : 0) : 0;
-      const int pb = (P == 3) ? (term == 1 ? 2 : term == 2 || term == 4 ? 1 : 0) : 0;
+      // P = 3: a3 b1, a1 b3, a2 b2, a2 b1, a1 b2, a1 b1;  P = 2 (fp16 planes): a2 b1, a1 b2, a1 b1
+      const int pa = (P == 3) ? (term == 0 ? 2 : term == 2 || term == 3 ? 1 : 0) : (P == 2 ? (term == 0 ? 1 : 0) : 0);
+      const int pb = (P == 3) ? (term == 1 ? 2 : term == 2 || term == 4 ? 1 : 0) : (P == 2 ? (term == 1 ? 1 : 0) : 0);
 #pragma unroll
       for (int ij = 0; ij < 4; ++ij) {
-        acc[ij >> 1][ij & 1] = ESR_MFMA(a[pa][ij >> 1], b[pb][ij & 1], acc[ij >> 1][ij & 1]);
+        if (P == 2)
+          acc[ij >> 1][ij & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+              __builtin_bit_cast(f16x8, a[pa][ij >> 1]), __builtin_bit_cast(f16x8, b[pb][ij & 1]), acc[ij >> 1][ij & 1],
+              0, 0, 0);
+        else
+          acc[ij >> 1][ij & 1] = ESR_MFMA(a[pa][ij >> 1], b[pb][ij & 1], acc[ij >> 1][ij & 1]);
         const int nth = term * 4 + ij;  // MFMA number inside this k-step
         if (nth % kPieceEvery == kPieceFirst && nth / kPieceEvery < NPW) {
           __builtin_amdgcn_sched_barrier(0);
@@ -233,6 +309,15 @@ __global__ __launch_bounds__(kGThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
   ESR_GT(g2);
 #endif
   // ---- epilogue: acc[i][j][e] = S[m0 + wm*64 + i*32 + 8*(e/4) + 4*h + e%4][n0 + wn*64 + j*32 + l31]
+  if (P == 2) {  // undo the plane scales (exact: a power of two)
+    const float sscale = ldexpf(1.f, -(o.exps[0] + o.exps[1]));
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] *= sscale;
+  }
   if (DENSE) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -692,13 +777,13 @@ __global__ __launch_bounds__(kBlock) void rescore_kernel(const float* __restrict
 struct RetrievePlan {
   int P, Dp;
   int64_t Mp, chunk, chunk_pad, first;
-  size_t off_A, off_B, off_S, off_pairs, off_cnt, off_tau, total;
+  size_t off_A, off_B, off_S, off_pairs, off_cnt, off_tau, off_abs, total;
   int64_t ppitch;
 };
 
 static RetrievePlan retrieve_plan(int64_t nq, int64_t N, int D, int k, int mode) {
   RetrievePlan p;
-  p.P = (mode == 0) ? 3 : 1;
+  p.P = (mode == 0) ? 3 : (mode == 2 ? 2 : 1);
   p.Dp = (int)(cdiv(D, kGK) * kGK);
   p.Mp = cdiv(nq, kGM) * kGM;
   p.first = std::min<int64_t>(N, std::max<int64_t>(kFirstChunk, 16 * (int64_t)k));
@@ -717,6 +802,7 @@ static RetrievePlan retrieve_plan(int64_t nq, int64_t N, int D, int k, int mode)
   p.off_pairs = o; o += align_up((size_t)nq * p.ppitch * 8, 256);
   p.off_cnt = o; o += align_up((size_t)nq * 4, 256);
   p.off_tau = o; o += align_up((size_t)nq * 4, 256);
+  p.off_abs = o; o += align_up((size_t)(kAbsBlocks + 64) * 4, 256);  // absmax slots, then the two exponent words
   p.total = o;
   return p;
 }
@@ -740,11 +826,17 @@ int select_topk_dense(const float* scores, int64_t pitch, int64_t rows, int n, i
 
 template <int P>
 static void launch_split(const float* X, int64_t n_rows, int D, int64_t rows_pad, int Dp, int64_t plane_elems,
-                         __bf16* out, hipStream_t st) {
+                         __bf16* out, hipStream_t st, const int* exp_ptr = nullptr) {
   const int64_t total = rows_pad * (Dp >> 2);
   const int grid = (int)std::min<int64_t>(cdiv(total, kBlock), 8192);
   hipLaunchKernelGGL((split_planes_kernel<P>), dim3(grid), dim3(kBlock), 0, st, X, n_rows, D, rows_pad, Dp, plane_elems,
-                     out);
+                     out, exp_ptr);
+}
+// exponent word of matrix X (n elements) -> exp_out; `slots` holds kAbsBlocks floats
+static void launch_absmax(const float* X, int64_t n, float* slots, int* exp_out, hipStream_t st) {
+  const int grid = (int)std::min<int64_t>(kAbsBlocks, std::max<int64_t>(1, cdiv(n, (int64_t)kBlock * 16)));
+  hipLaunchKernelGGL(absmax_part_kernel, dim3(grid), dim3(kBlock), 0, st, X, n, slots);
+  hipLaunchKernelGGL(absmax_exp_kernel, dim3(1), dim3(kBlock), 0, st, (const float*)slots, grid, exp_out);
 }
 
 template <int P, bool DENSE>
@@ -775,7 +867,8 @@ int esr_retrieve_topk(const float* queries, const float* candidates, int64_t nq,
                   nq < ((int64_t)1 << 24),
               "esr_retrieve_topk: bad sizes nq=%lld N=%lld D=%d k=%d (k <= min(N, %d))", (long long)nq, (long long)N, D,
               k, kSelMaxK);
-  ESR_REQUIRE(mode == 0 || mode == 1, "esr_retrieve_topk: mode %d (0 = exact bf16x3, 1 = bf16)", mode);
+  ESR_REQUIRE(mode == 0 || mode == 1 || mode == 2,
+              "esr_retrieve_topk: mode %d (0 = exact bf16x3, 1 = bf16, 2 = exact-grade f16x2)", mode);
   ESR_REQUIRE(index_step > 0 && (int64_t)index_base + (N - 1) * (int64_t)index_step < ((int64_t)1 << 31),
               "esr_retrieve_topk: index_base/index_step overflow int32");
   ESR_REQUIRE(queries && candidates && out_scores && out_indices && workspace, "esr_retrieve_topk: null pointer");
@@ -793,7 +886,14 @@ int esr_retrieve_topk(const float* queries, const float* candidates, int64_t nq,
   int32_t* cnt = (int32_t*)(base + p.off_cnt);
   float* tau = (float*)(base + p.off_tau);
   const int64_t a_plane = p.Mp * p.Dp, b_plane = p.chunk_pad * p.Dp;
-  if (p.P == 3) launch_split<3>(queries, nq, D, p.Mp, p.Dp, a_plane, A, st);
+  float* abs_slots = (float*)(base + p.off_abs);
+  int* exps = (int*)(abs_slots + kAbsBlocks);  // {eq, ec}
+  if (p.P == 2) {
+    // one exponent per matrix; the candidates' covers ALL chunks (one 4 N D-byte read, ~1 % of the call at N = 1 M)
+    launch_absmax(queries, nq * (int64_t)D, abs_slots, exps, st);
+    launch_absmax(candidates, N * (int64_t)D, abs_slots, exps + 1, st);
+    launch_split<2>(queries, nq, D, p.Mp, p.Dp, a_plane, A, st, exps);
+  } else if (p.P == 3) launch_split<3>(queries, nq, D, p.Mp, p.Dp, a_plane, A, st);
   else launch_split<1>(queries, nq, D, p.Mp, p.Dp, a_plane, A, st);
 
   int64_t c0 = 0;
@@ -803,9 +903,11 @@ int esr_retrieve_topk(const float* queries, const float* candidates, int64_t nq,
     const int64_t nc = std::min<int64_t>(first ? p.first : p.chunk, N - c0);
     const int64_t n_pad = cdiv(nc, kGN) * kGN;
     const bool last = (c0 + nc == N);
-    if (p.P == 3) launch_split<3>(candidates + c0 * D, nc, D, n_pad, p.Dp, b_plane, B, st);
+    if (p.P == 2) launch_split<2>(candidates + c0 * D, nc, D, n_pad, p.Dp, b_plane, B, st, exps + 1);
+    else if (p.P == 3) launch_split<3>(candidates + c0 * D, nc, D, n_pad, p.Dp, b_plane, B, st);
     else launch_split<1>(candidates + c0 * D, nc, D, n_pad, p.Dp, b_plane, B, st);
     GemmOut o;
+    o.exps = exps;
     o.S = S; o.ldS = p.first; o.tau = tau; o.cnt = cnt; o.pairs = pairs; o.ppitch = p.ppitch;
     o.gbase = index_base + (int32_t)c0 * index_step; o.gstep = index_step;
     SelIn in;
@@ -814,12 +916,14 @@ int esr_retrieve_topk(const float* queries, const float* candidates, int64_t nq,
     so.scores = last ? out_scores : nullptr;
     so.indices = last ? out_indices : nullptr;
     if (first) {
-      if (p.P == 3) launch_gemm<3, true>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
+      if (p.P == 2) launch_gemm<2, true>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
+      else if (p.P == 3) launch_gemm<3, true>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
       else launch_gemm<1, true>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
       in.vals = S; in.vpitch = p.first; in.idx = nullptr; in.stride = 1; in.ibase = o.gbase; in.istep = index_step;
       in.n_per_row = nullptr; in.n_fixed = (int)nc;
     } else {
-      if (p.P == 3) launch_gemm<3, false>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
+      if (p.P == 2) launch_gemm<2, false>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
+      else if (p.P == 3) launch_gemm<3, false>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
       else launch_gemm<1, false>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
       in.vals = (const float*)pairs; in.vpitch = 2 * p.ppitch; in.idx = (const int32_t*)pairs + 1; in.stride = 2;
       in.ibase = 0; in.istep = 0; in.n_per_row = cnt; in.n_fixed = 0;

@@ -634,18 +634,29 @@ def score_topk(queries, candidates, k):
     return out_s, out_i
 
 
-_RETRIEVE_MODES = {"exact": _lib.RETRIEVE_EXACT, "f32": _lib.RETRIEVE_EXACT, "bf16": _lib.RETRIEVE_BF16}
+_RETRIEVE_MODES = {"bf16x3": _lib.RETRIEVE_EXACT, "f16x2": _lib.RETRIEVE_F16X2, "bf16": _lib.RETRIEVE_BF16}
+
+
+def _retrieve_mode(mode):
+    """"exact" / "f32": the f32-grade brute-force answer -- two fp16 planes per operand (three MFMA terms per product),
+    or, with ESR_RETRIEVE_EXACT=bf16x3, three bf16 planes (six terms)."""
+    if mode in ("exact", "f32"):
+        mode = os.environ.get("ESR_RETRIEVE_EXACT", "f16x2")
+    if mode not in _RETRIEVE_MODES:
+        raise ValueError("retrieval mode must be exact / f32 / f16x2 / bf16x3 / bf16, got %r" % (mode,))
+    return _RETRIEVE_MODES[mode]
 
 
 def retrieve_topk(queries, candidates, k, mode="exact", index_base=0, index_step=1):
     """Batched brute-force top-k of queries @ candidates^T (descending, ties -> lower index) on MFMA.
-    mode "exact": f32-equivalent products (three exact bf16 planes); "bf16": one plane (approximate).
+    mode "exact": f32-grade products ("f16x2": two scaled fp16 planes per operand, the default; "bf16x3": three exact
+    bf16 planes); "bf16": one plane (approximate).
     Reported indices are index_base + n * index_step for local candidate row n."""
     lib = _lib.load()
     _req(queries, torch.float32, "queries"), _req(candidates, torch.float32, "candidates")
     nq, D = queries.shape
     N = candidates.shape[0]
-    m = _RETRIEVE_MODES[mode]
+    m = _retrieve_mode(mode)
     out_s = torch.empty((nq, k), dtype=torch.float32, device=queries.device)
     out_i = torch.empty((nq, k), dtype=torch.int32, device=queries.device)
     ws = _ws(_ws_bytes("esr_retrieve_workspace_bytes", nq, N, D, k, m), queries.device)

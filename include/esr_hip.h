@@ -281,9 +281,13 @@ int esr_score_topk(const float* queries, const float* candidates, int64_t nq, in
  * mode ESR_RETRIEVE_EXACT: products from three exact bf16 planes per operand (six MFMA cross terms,
  *   f32 accumulate) -- f32-equivalent scores, the brute-force answer.
  * mode ESR_RETRIEVE_BF16: one bf16 plane per operand -- the approximate candidate stage; follow with
- *   esr_rescore_candidates + esr_topk_merge for an exact re-rank of k' > k candidates. */
+ *   esr_rescore_candidates + esr_topk_merge for an exact re-rank of k' > k candidates.
+ * mode ESR_RETRIEVE_F16X2: products from two fp16 planes of x * 2^e per operand (e per matrix, from its largest
+ *   |element|; three MFMA cross terms, f32 accumulate) -- f32-grade scores (<= ~3 * 2^-24 |a||b| per elementary product)
+ *   at half the matrix-core work of ESR_RETRIEVE_EXACT; one extra read of both matrices for the scales. */
 #define ESR_RETRIEVE_EXACT 0
 #define ESR_RETRIEVE_BF16 1
+#define ESR_RETRIEVE_F16X2 2
 size_t esr_retrieve_workspace_bytes(int64_t nq, int64_t N, int D, int k, int mode);
 int esr_retrieve_topk(const float* queries, const float* candidates, int64_t nq, int64_t N, int D, int k,
                       int mode, int32_t index_base, int32_t index_step, float* out_scores,
