@@ -273,7 +273,8 @@ static void launch_tile_sort(const SortSegs& sg, int n, uint32_t* tiles, int32_t
 // kernel's residency to make room for the 1024-thread version cost more than the hidden sort returned (0.202 ms at
 // three of four workgroups per CU).  What does pay is the plain sort of batch k + 1 on the second stream: it fills the
 // gaps around batch k's short kernels (0.194 -> 0.181 ms).
-constexpr int kRadixMaxN = 1 << 18;
+constexpr int kRadixMaxN = 1 << 18;   // up to here a scatter workgroup re-reduces the histogram matrix itself
+constexpr int kRadixLongN = 1 << 21;  // beyond kRadixMaxN: segment sums first (three launches per pass)
 constexpr int kRadixMaxPasses = 3;
 
 // FIRST: keys come from the id segments and the value is the position itself; else from (keys_in, vals_in)
@@ -320,13 +321,35 @@ __global__ __launch_bounds__((1 << TB) / 2) void radix_tile_kernel(SortSegs ids,
   hist[(int64_t)blockIdx.x * kTile + t + kThreads] = bend[t + kThreads] - bstart[t + kThreads];
 }
 
+// long lists: per-segment column sums of the [tiles][digits] histogram matrix, one workgroup per (segment, 512 digits)
+constexpr int kRadixSeg = 32;
+template <int TB>
+__global__ __launch_bounds__(kBlock) void radix_segsum_kernel(const int32_t* __restrict__ hist, int ntiles,
+                                                             int32_t* __restrict__ segsum) {
+  constexpr int kTile = 1 << TB;
+  const int seg = blockIdx.y;
+  const int d2 = blockIdx.x * kBlock + threadIdx.x;  // digit pair
+  if (d2 >= kTile / 2) return;
+  const int2* h2 = reinterpret_cast<const int2*>(hist);
+  int a = 0, b = 0;
+  const int u1 = min(ntiles, (seg + 1) * kRadixSeg);
+#pragma unroll 8
+  for (int u = seg * kRadixSeg; u < u1; ++u) {
+    const int2 c = h2[(int64_t)u * (kTile / 2) + d2];
+    a += c.x;
+    b += c.y;
+  }
+  reinterpret_cast<int2*>(segsum)[(int64_t)seg * (kTile / 2) + d2] = make_int2(a, b);
+}
+
 template <int TB, bool FIRST>
 __global__ __launch_bounds__((1 << TB) / 2) void radix_scatter_kernel(SortSegs ids, const uint32_t* __restrict__ keys_in,
                                                                      const uint32_t* __restrict__ vals_in, int n,
                                                                      int ntiles, const uint32_t* __restrict__ tiles,
                                                                      const int32_t* __restrict__ hist,
                                                                      uint32_t* __restrict__ keys_out,
-                                                                     uint32_t* __restrict__ vals_out) {
+                                                                     uint32_t* __restrict__ vals_out,
+                                                                     const int32_t* __restrict__ segsum = nullptr) {
   constexpr int kTile = 1 << TB, kThreads = kTile / 2;
   __shared__ uint32_t comp[kTile];
   __shared__ int offs[kTile], bstart[kTile];
@@ -338,13 +361,34 @@ __global__ __launch_bounds__((1 << TB) / 2) void radix_scatter_kernel(SortSegs i
   // (unrolled: the loads of a pass over the matrix are independent; one at a time this loop WAS the kernel, 16 us)
   int tot0 = 0, tot1 = 0, pre0 = 0, pre1 = 0;
   const int2* h2 = reinterpret_cast<const int2*>(hist);
+  if (segsum) {
+    // long lists (> kRadixMaxN ids): the histogram matrix is too tall to re-reduce in every workgroup (384 tiles x 8 KB
+    // per workgroup at 786 432 ids); radix_segsum_kernel summed it over segments of kRadixSeg tiles first
+    const int2* s2 = reinterpret_cast<const int2*>(segsum);
+    const int nseg = (ntiles + kRadixSeg - 1) / kRadixSeg, myseg = tile / kRadixSeg;
+#pragma unroll 8
+    for (int sgi = 0; sgi < nseg; ++sgi) {
+      const int2 c = s2[(int64_t)sgi * (kTile / 2) + t];
+      tot0 += c.x;
+      tot1 += c.y;
+      pre0 += sgi < myseg ? c.x : 0;
+      pre1 += sgi < myseg ? c.y : 0;
+    }
+#pragma unroll 8
+    for (int u = myseg * kRadixSeg; u < tile; ++u) {
+      const int2 c = h2[(int64_t)u * (kTile / 2) + t];
+      pre0 += c.x;
+      pre1 += c.y;
+    }
+  } else {
 #pragma unroll 32
-  for (int u = 0; u < ntiles; ++u) {
-    const int2 c = h2[(int64_t)u * (kTile / 2) + t];
-    tot0 += c.x;
-    tot1 += c.y;
-    pre0 += u < tile ? c.x : 0;
-    pre1 += u < tile ? c.y : 0;
+    for (int u = 0; u < ntiles; ++u) {
+      const int2 c = h2[(int64_t)u * (kTile / 2) + t];
+      tot0 += c.x;
+      tot1 += c.y;
+      pre0 += u < tile ? c.x : 0;
+      pre1 += u < tile ? c.y : 0;
+    }
   }
   // exclusive scan of the totals: pair sums -> wave scan -> wave totals
   const int pair = tot0 + tot1;
@@ -387,6 +431,7 @@ __global__ __launch_bounds__((1 << TB) / 2) void radix_scatter_kernel(SortSegs i
 struct RadixWs {
   uint32_t* tiles;  // [ntiles << TB]
   int32_t* hist;    // [ntiles][1 << TB]
+  int32_t* segsum;  // [ntiles / kRadixSeg][1 << TB] (long lists)
   uint32_t* keys[2];
   uint32_t* vals[2];
 };
@@ -402,6 +447,7 @@ static size_t radix_ws_layout(int64_t n, char* base, RadixWs* ws) {
   RadixWs w;
   w.tiles = (uint32_t*)take(sizeof(uint32_t) * padded);
   w.hist = (int32_t*)take(sizeof(int32_t) * padded);
+  w.segsum = (int32_t*)take(sizeof(int32_t) * (size_t)cdiv((int64_t)(padded / 2048), kRadixSeg) * 2048);
   for (int i = 0; i < 2; ++i) {
     w.keys[i] = (uint32_t*)take(sizeof(uint32_t) * (size_t)n);
     w.vals[i] = (uint32_t*)take(sizeof(uint32_t) * (size_t)n);
@@ -422,16 +468,25 @@ static void launch_radix_sort(const SortSegs& sg, int n, int key_bits, const Rad
     uint32_t* kout = last ? reinterpret_cast<uint32_t*>(sorted_ids) : ws.keys[p & 1];
     uint32_t* vout = last ? reinterpret_cast<uint32_t*>(perm) : ws.vals[p & 1];
     const int shift = p * TB;
+    const bool tall = ntiles > (kRadixMaxN >> TB);  // more tiles than a scatter workgroup should re-reduce itself
+    const int32_t* segsum = tall ? ws.segsum : nullptr;
+    const dim3 seg_grid((kTile / 2 + kBlock - 1) / kBlock, (ntiles + kRadixSeg - 1) / kRadixSeg);
     if (p == 0) {
       hipLaunchKernelGGL((radix_tile_kernel<TB, true>), dim3(ntiles), dim3(kThreads), 0, st, sg, kin, n, shift, ws.tiles,
                          ws.hist);
+      if (tall)
+        hipLaunchKernelGGL((radix_segsum_kernel<TB>), seg_grid, dim3(kBlock), 0, st, (const int32_t*)ws.hist, ntiles,
+                           ws.segsum);
       hipLaunchKernelGGL((radix_scatter_kernel<TB, true>), dim3(ntiles), dim3(kThreads), 0, st, sg, kin, vin, n, ntiles,
-                         (const uint32_t*)ws.tiles, (const int32_t*)ws.hist, kout, vout);
+                         (const uint32_t*)ws.tiles, (const int32_t*)ws.hist, kout, vout, segsum);
     } else {
       hipLaunchKernelGGL((radix_tile_kernel<TB, false>), dim3(ntiles), dim3(kThreads), 0, st, sg, kin, n, shift, ws.tiles,
                          ws.hist);
+      if (tall)
+        hipLaunchKernelGGL((radix_segsum_kernel<TB>), seg_grid, dim3(kBlock), 0, st, (const int32_t*)ws.hist, ntiles,
+                           ws.segsum);
       hipLaunchKernelGGL((radix_scatter_kernel<TB, false>), dim3(ntiles), dim3(kThreads), 0, st, sg, kin, vin, n, ntiles,
-                         (const uint32_t*)ws.tiles, (const int32_t*)ws.hist, kout, vout);
+                         (const uint32_t*)ws.tiles, (const int32_t*)ws.hist, kout, vout, segsum);
     }
     kin = kout;
     vin = vout;
@@ -780,7 +835,7 @@ extern "C" {
 size_t esr_segment_sort_workspace_bytes(int64_t n) {
   if (n <= 0) return 256;
   const size_t tiles = n <= kMidSortMax ? align_up((size_t)(kMidSortMax + kMidSortMax / kSplitEvery) * 4, 256) : 0;
-  const size_t radix = n <= kRadixMaxN ? radix_ws_layout(n, nullptr, nullptr) : 0;
+  const size_t radix = n <= kRadixLongN ? radix_ws_layout(n, nullptr, nullptr) : 0;
   // + one column for the concatenated ids of a segmented list on the device-sort path
   return std::max({pair_sort_temp_bytes<false, uint32_t>(n) + align_up((size_t)n * 4, 256), tiles, radix});
 }
@@ -809,7 +864,7 @@ static int segment_sort_segs(const char* who, const SortSegs& sg, int64_t n, int
     else launch_tile_sort<11>(sg, (int)n, tiles, sorted_ids, perm, st);
     return check_launch(who);
   }
-  if (n <= kRadixMaxN && bits_for(V) <= kRadixMaxPasses * 11) {
+  if (n <= kRadixLongN && bits_for(V) <= kRadixMaxPasses * 11) {
     if (radix_ws_layout(n, nullptr, nullptr) > workspace_bytes || ((uintptr_t)workspace & 15)) {
       set_error("%s: workspace %zu bytes too small (or misaligned)", who, workspace_bytes);
       return ESR_EWORKSPACE;

@@ -567,11 +567,14 @@ def test_segment_sort_is_stable_sort(dev, kind, n):
 
 
 @pytest.mark.parametrize("n,V", [(131_072, 465_537), (196_608 + 5, 2_000_000), (262_144, 1_000), (262_145, 465_537),
-                                 (40_001, 2_047), (50_000, 2_048), (100_000, 30_000_000), (2_049 + 32_768, 2 ** 22 + 1)])
+                                 (40_001, 2_047), (50_000, 2_048), (100_000, 30_000_000), (2_049 + 32_768, 2 ** 22 + 1),
+                                 (786_432, 2_000_000), (300_001, 1_500), (2 ** 21, 465_537), (2 ** 21 + 1, 465_537),
+                                 (1_000_003, 2 ** 31 - 1)])
 @pytest.mark.parametrize("kind", ["uniform", "same", "zipf"])
 def test_segment_sort_hand_written_radix_path(dev, kind, n, V):
-    """32 768 < n <= 262 144: the two-launches-per-pass LSD radix sort (11-bit digits; 1, 2 or 3 passes by the id range;
-    one more than 262 144 falls through to the device sort).  Stable: perm == numpy's stable argsort."""
+    """32 768 < n <= 262 144: the two-launches-per-pass LSD radix sort (11-bit digits; 1, 2 or 3 passes by the id range);
+    up to 2 097 152 ids (the 786 432 of a triplet step at B = 262 144) the same with the histogram matrix summed over
+    32-tile segments first; one more falls through to the device sort.  Stable: perm == numpy's stable argsort."""
     from esrecsys_amd import ops
     rng = np.random.default_rng(n % 1000 + 1)
     if kind == "zipf" and V > 5_000_000:
