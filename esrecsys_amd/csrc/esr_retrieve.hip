@@ -309,15 +309,11 @@ __global__ __launch_bounds__(kGThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
   ESR_GT(g2);
 #endif
   // ---- epilogue: acc[i][j][e] = S[m0 + wm*64 + i*32 + 8*(e/4) + 4*h + e%4][n0 + wn*64 + j*32 + l31]
-  if (P == 2) {  // undo the plane scales (exact: a power of two)
-    const float sscale = ldexpf(1.f, -(o.exps[0] + o.exps[1]));
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] *= sscale;
-  }
+  // P == 2: the accumulators carry 2^(eq + ec) x the scores.  The factor is undone where a score leaves the kernel
+  // and the thresholds are scaled UP for the comparisons instead (exact either way: a power of two) -- scaling the 64
+  // accumulators in place made hipcc spill 80 registers in the filtered epilogue (1.3 GB of scratch writes per launch).
+  const float sscale = (P == 2) ? ldexpf(1.f, -(o.exps[0] + o.exps[1])) : 1.f;
+  const float tscale = (P == 2) ? ldexpf(1.f, o.exps[0] + o.exps[1]) : 1.f;
   if (DENSE) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -327,7 +323,7 @@ __global__ __launch_bounds__(kGThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int n = n0 + wn * 64 + j * 32 + l31;
-          if (m < M && n < nvalid) o.S[(int64_t)m * o.ldS + n] = acc[i][j][e];
+          if (m < M && n < nvalid) o.S[(int64_t)m * o.ldS + n] = acc[i][j][e] * sscale;
         }
       }
   } else {
@@ -340,7 +336,7 @@ __global__ __launch_bounds__(kGThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
     // from global memory, 32 loads per lane and pass, in front of every ballot
     float* tau_s = reinterpret_cast<float*>(lds);
     __syncthreads();
-    if (t < 256) tau_s[t] = m0 + t < M ? o.tau[m0 + t] : INFINITY;
+    if (t < 256) tau_s[t] = m0 + t < M ? o.tau[m0 + t] * tscale : INFINITY;
     __syncthreads();
     const float* tau_w = tau_s + wm * 64 + 4 * h;
     const bool c_ok0 = n0 + wn * 64 + l31 < nvalid, c_ok1 = n0 + wn * 64 + 32 + l31 < nvalid;
@@ -380,10 +376,10 @@ __global__ __launch_bounds__(kGThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
           const int m = mrow + i * 32 + 8 * (e >> 2) + (e & 3);
           int2* dst = o.pairs + (int64_t)m * o.ppitch + slot;
           const int n = n0 + wn * 64 + l31;
-          if (p0) dst[__popc(h0 & below)] = make_int2(__float_as_int(acc[i][0][e]), o.gbase + n * o.gstep);
+          if (p0) dst[__popc(h0 & below)] = make_int2(__float_as_int(acc[i][0][e] * sscale), o.gbase + n * o.gstep);
           if (p1)
             dst[__popc(h0) + __popc(h1 & below)] =
-                make_int2(__float_as_int(acc[i][1][e]), o.gbase + (n + 32) * o.gstep);
+                make_int2(__float_as_int(acc[i][1][e] * sscale), o.gbase + (n + 32) * o.gstep);
         }
       }
     }
