@@ -15,13 +15,14 @@
 // path, tests/test_gpu_kernels.py).  What fp16 costs is RANGE, and it is handled where it arises:
 //   * operands: the per-matrix power-of-two scale above (absmax pre-pass, 8 MB read); undone by exact power-of-two
 //     factors in the exponent argument and in the merge kernels;
-//   * probabilities of pass Q: p' = exp2(s - M_i) must lie in fp16's range for every j, so M_i is tied to the TRUE row
-//     maximum: M_i = max_j s_ij - 14 (hi-plane product, 1 / 9 of the MFMA work) => max_j p' = 2^14 exactly where it
-//     matters, anything below 2^-28 of the row maximum goes subnormal (absolute error 2^-39 of the maximum).  When the
-//     Cauchy-Schwarz bound on |s| is <= 14 (log2 units) the bound itself is safe (p' in [2^-14, 2^14]) and the row-max
-//     GEMM is skipped;
+//   * probabilities of pass Q: p' = exp2(s - M) must lie in fp16's range for every j of the row, with the row's largest
+//     p' >= ~4.  Default: an OPTIMISTIC reference per (128-row block, split) workgroup, M = max(diagonal score, largest
+//     score of the workgroup's first chunk) - 4, with an overflow flag and a redo launch that reruns the flagged
+//     workgroups against the exact maximum of their range (see inbatch2h_q_kernel).  ESR_IB2H_REF=rowmax: the exact row
+//     maxima from a hi-plane GEMM pre-pass instead (rowmax2h_kernel, 28 us at B = 8192; skipped when the
+//     Cauchy-Schwarz bound on |s| is <= 14 log2 units, where the bound itself is a safe reference);
 //   * probabilities of pass C: true probabilities p / l in [0, 1] with a row maximum >= 1 / B, scaled by 2^14.
-// Pass C always reads the probabilities pass Q stored (see inbatch3_pc_kernel): B <= 16384; larger batches and bf16
+// Pass C always reads the probabilities pass Q stored (inbatch2h_pc8_kernel): B <= 16384; larger batches and bf16
 // tables take the bf16 x 3 path (bf16 tables are one-plane there already).
 #include "esr_inbatch_mfma.h"
 
