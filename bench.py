@@ -172,7 +172,7 @@ def roofline_for(workload, kernels, B, D, rows, precision, occ_n=0, uniq=0, bf16
             terms = 3 * 3 + (1 if rowmax_pass else 0)
             executed = terms * 2.0 * B * B * D
             return {"kernel": "prep2h + split2h + " + ("rowmax2h + " if rowmax_pass else "") +
-                              "inbatch2h_q_kernel (+ redo launch) + merge + inbatch2h_pc_kernel + merge",
+                              "inbatch2h_q_kernel (+ redo launch) + merge + inbatch2h_pc8_kernel + merge",
                     "pass_c": "reads stored P (B*B*4 bytes written by pass Q)",
                     "bound": "mfma", "achieved": executed / t / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": executed / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
