@@ -68,3 +68,41 @@ def test_flag_defaults_match_the_reference():
     assert (P.log_every_steps, P.eval_every_steps, P.checkpoint_every_steps) == (100, 2000, 100000)
     assert (W.embedding_dim, W.batch_size, W.seed, W.shuffle_buffer_size, W.steps_per_epoch, W.num_epochs,
             W.learning_rate, W.checkpoint_every_epochs, W.max_terms) == (64, 2048, 1701, 5000000, 10000, 20, 0.001, 20, 20)
+
+
+def test_inbatch_split_path_resolution(monkeypatch):
+    """which MFMA path a precision string selects (host logic only): the two-plane fp16 path needs fp32 rows, D = 128,
+    B % 128 == 0 and B <= 16384; bf16 tables and larger batches fall to the three-plane bf16 path; other shapes to f32"""
+    from esrecsys_amd import ops
+    monkeypatch.delenv("ESR_INBATCH_AUTO", raising=False)
+    assert ops.inbatch_split_path("auto", 8192, 128) == "f16x2"
+    assert ops.inbatch_split_path("auto", 16384, 128) == "f16x2"
+    assert ops.inbatch_split_path("auto", 16512, 128) == "bf16x3"
+    assert ops.inbatch_split_path("auto", 8192, 128, bf16_tables=True) == "bf16x3"
+    assert ops.inbatch_split_path("auto", 8192, 64) is None and ops.inbatch_split_path("auto", 8200, 128) is None
+    assert ops.inbatch_split_path("f32", 8192, 128) is None
+    assert ops.inbatch_split_path("bf16x3", 256, 128) == "bf16x3"
+    with pytest.raises(ValueError):
+        ops.inbatch_split_path("f16x2", 32768, 128)
+    with pytest.raises(ValueError):
+        ops.inbatch_split_path("f16x2", 256, 128, bf16_tables=True)
+    with pytest.raises(ValueError):
+        ops.inbatch_split_path("bf16x3", 100, 128)
+    with pytest.raises(ValueError):
+        ops.inbatch_split_path("fp8", 256, 128)
+    monkeypatch.setenv("ESR_INBATCH_AUTO", "bf16x3")
+    assert ops.inbatch_split_path("auto", 8192, 128) == "bf16x3"
+    monkeypatch.setenv("ESR_INBATCH_AUTO", "nonsense")
+    with pytest.raises(ValueError):
+        ops.inbatch_split_path("auto", 8192, 128)
+
+
+def test_retrieve_mode_resolution(monkeypatch):
+    from esrecsys_amd import _lib, ops
+    monkeypatch.delenv("ESR_RETRIEVE_EXACT", raising=False)
+    assert ops._retrieve_mode("exact") == _lib.RETRIEVE_F16X2 == 2
+    assert ops._retrieve_mode("bf16") == _lib.RETRIEVE_BF16 and ops._retrieve_mode("bf16x3") == _lib.RETRIEVE_EXACT
+    monkeypatch.setenv("ESR_RETRIEVE_EXACT", "bf16x3")
+    assert ops._retrieve_mode("f32") == _lib.RETRIEVE_EXACT
+    with pytest.raises(ValueError):
+        ops._retrieve_mode("int8")
