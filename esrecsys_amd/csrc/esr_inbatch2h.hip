@@ -728,6 +728,272 @@ __global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __rest
 }
 
 // -----------------------------------------------------------------------------------------------------------------
+// Pass Q, 64 owned rows per wave (inbatch2h_q2_kernel; B % 256 == 0): two 32-row sets u = 0, 1 share every A fragment
+// read from LDS -- S^T: 6 MFMAs per pair of ds_read_b128, O^T: 8 per fragment -- and the four waves of a workgroup (256
+// rows) share a plane tile, so LDS reads and DMA traffic per MFMA are half those of inbatch2h_q_kernel.  The step runs at
+// the package power cap: bytes moved per MFMA are time.  One wave per SIMD (B operands 128, O^T
+// accumulators 128 registers), everything else as in inbatch2h_q_kernel.
+// -----------------------------------------------------------------------------------------------------------------
+#define Q2_S_PHASE(NBUF, VALU_ON)                                                                         \
+  {                                                                                                       \
+    _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_)                                                      \
+      _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) sa[u_][r_] = 0.f;                                 \
+    const uint32_t ap32_ = lds32 + (uint32_t)((NBUF) - lds) + (uint32_t)(j * 256);                        \
+    const int sw_ = swz16(j);                                                                             \
+    f16x8 a1_ = lds_b128<0>(ap32_ + (uint32_t)((h ^ sw_) << 4));                                          \
+    f16x8 a2_ = lds_b128<kPlaneBytes>(ap32_ + (uint32_t)((h ^ sw_) << 4));                                \
+    float ek_[2][2] = {{0.f, 0.f}, {0.f, 0.f}};                                                           \
+    _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) {                                                    \
+      f16x8 n1_ = a1_, n2_ = a2_;                                                                         \
+      if (s_ < 7) {                                                                                       \
+        const uint32_t off_ = (uint32_t)(((2 * (s_ + 1) + h) ^ sw_) << 4);                                \
+        n1_ = lds_b128<0>(ap32_ + off_);                                                                  \
+        n2_ = lds_b128<kPlaneBytes>(ap32_ + off_);                                                        \
+      }                                                                                                   \
+      float e_[2][2] = {{0.f, 0.f}, {0.f, 0.f}};                                                          \
+      f16x2 pa_[2] = {{0, 0}, {0, 0}};                                                                    \
+      H_SB();                                                                                             \
+      H_S_WAIT((s_ < 7 ? 2 : 0) + (((VALU_ON) && s_ >= 1) ? 2 : 0));                                      \
+      H_SB();                                                                                             \
+      sa[0] = H_MFMA(a2_, bx[0][0][s_], sa[0]);                                                           \
+      sa[1] = H_MFMA(a2_, bx[1][0][s_], sa[1]);                                                           \
+      H_SB();                                                                                             \
+      if (VALU_ON) {                                                                                      \
+        _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_) {                                                \
+          const f32x2 arg_ = pk_fma(f32x2{p[u_][2 * s_], p[u_][2 * s_ + 1]}, sl2v, nrefv[u_]);            \
+          e_[u_][0] = __builtin_amdgcn_exp2f(arg_[0]);                                                    \
+          e_[u_][1] = __builtin_amdgcn_exp2f(arg_[1]);                                                    \
+        }                                                                                                 \
+        trh_frag_n<0>(s_, ta2_, trc_);                                                                    \
+      }                                                                                                   \
+      H_SB();                                                                                             \
+      sa[0] = H_MFMA(a1_, bx[0][1][s_], sa[0]);                                                           \
+      sa[1] = H_MFMA(a1_, bx[1][1][s_], sa[1]);                                                           \
+      H_SB();                                                                                             \
+      if (VALU_ON) {                                                                                      \
+        _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_) {                                                \
+          pa_[u_] = pk_f16(e_[u_][0], e_[u_][1]);                                                         \
+          l2[u_] = pk_add(l2[u_], f32x2{e_[u_][0], e_[u_][1]});                                           \
+          emax = __builtin_fmaxf(emax, __builtin_fmaxf(e_[u_][0], e_[u_][1]));                            \
+          if ((s_ & 1) == 0) { ek_[u_][0] = e_[u_][0]; ek_[u_][1] = e_[u_][1]; }                          \
+          else { Q2_P_ST4(u_, s_ >> 1, ek_[u_][0], ek_[u_][1], e_[u_][0], e_[u_][1]); }                   \
+        }                                                                                                 \
+      }                                                                                                   \
+      H_SB();                                                                                             \
+      sa[0] = H_MFMA(a1_, bx[0][0][s_], sa[0]);                                                           \
+      sa[1] = H_MFMA(a1_, bx[1][0][s_], sa[1]);                                                           \
+      H_SB();                                                                                             \
+      if (VALU_ON) {                                                                                      \
+        _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_) {                                                \
+          const f16x2 pq_ = pk_f16(resid_lo(e_[u_][0], pa_[u_]), resid_hi(e_[u_][1], pa_[u_]));           \
+          pw[u_][0][s_] = __builtin_bit_cast(uint32_t, pa_[u_]);                                          \
+          pw[u_][1][s_] = __builtin_bit_cast(uint32_t, pq_);                                              \
+        }                                                                                                 \
+      }                                                                                                   \
+      H_SB();                                                                                             \
+      a1_ = n1_; a2_ = n2_;                                                                               \
+    }                                                                                                     \
+    if (VALU_ON) { pst_u[0] += nch * 4096; pst_u[1] += nch * 4096; }                                      \
+  }
+#define Q2_O_ROW(PL_A, PL_P, G)                                                                           \
+  _Pragma("unroll") for (int db_ = 0; db_ < 4; ++db_) {                                                   \
+    acc[0][db_] = H_MFMA(ta2_[G][db_][PL_A], pb[0][PL_P][G], acc[0][db_]);                                \
+    acc[1][db_] = H_MFMA(ta2_[G][db_][PL_A], pb[1][PL_P][G], acc[1][db_]);                                \
+  }
+#define Q2_O_PHASE(DMA_ON, DBUF)                                                                          \
+  {                                                                                                       \
+    f16x8 pb[2][2][2];                                                                                    \
+    _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_)                                                      \
+      _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_)                                                    \
+        _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_) {                                                \
+          const u32x4 v_ = {pw[u_][q_][4 * g_], pw[u_][q_][4 * g_ + 1], pw[u_][q_][4 * g_ + 2],           \
+                            pw[u_][q_][4 * g_ + 3]};                                                      \
+          pb[u_][q_][g_] = __builtin_bit_cast(f16x8, v_);                                                 \
+        }                                                                                                 \
+    H_TR_WAIT();                                                                                          \
+    H_SB(); Q2_O_ROW(1, 0, 0); H_SB(); H_O_G1(0, 3); if (DMA_ON) { H_DP(0, g0, DBUF); }                   \
+    H_SB(); Q2_O_ROW(0, 1, 0); H_SB(); H_O_G1(3, 6); if (DMA_ON) { H_DP(1, g1, DBUF); }                   \
+    H_SB(); Q2_O_ROW(0, 0, 0); H_SB(); H_O_G1(6, 8); if (DMA_ON) { H_DP(2, g2, DBUF); }                   \
+    H_TR_WAIT();                                                                                          \
+    H_SB(); Q2_O_ROW(1, 0, 1); H_SB(); if (DMA_ON) { H_DP(3, g3, DBUF); }                                 \
+    H_SB(); Q2_O_ROW(0, 1, 1); H_SB();                                                                    \
+    H_SB(); Q2_O_ROW(0, 0, 1); H_SB();                                                                    \
+    if (DMA_ON) H_DMA_ADVANCE();                                                                          \
+  }
+template <bool FIX>
+__global__ __launch_bounds__(256) void inbatch2h_q2_kernel(const _Float16* __restrict__ Xr, const _Float16* __restrict__ Yr,
+                                                          int64_t B, int nsplit, float sl2_in,
+                                                          const float* __restrict__ sc, const float* __restrict__ diag,
+                                                          int mode, int* __restrict__ flags, float* __restrict__ part_m,
+                                                          float* __restrict__ part_O, float* __restrict__ part_l,
+                                                          float* __restrict__ Pmat) {
+  __shared__ __attribute__((aligned(16))) char lds[kHBufs * kHBufBytes];
+  if (FIX && flags[blockIdx.x] == 0) return;
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  H_TR_SETUP();
+  const uint32_t lds32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds;
+  const int ob = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
+  int64_t xrow[2];
+  xrow[0] = (int64_t)ob * 256 + w * 64 + j;
+  xrow[1] = xrow[0] + 32;
+  const int nc = (int)(B / k3Chunk) / nsplit;
+  const int64_t c0 = (int64_t)split * nc;
+  const int64_t nch = B / 32;
+  const float sl2 = sl2_in * sc[0];
+  char* pst_u[2];
+  pst_u[0] = reinterpret_cast<char*>(Pmat) + (c0 * nch + (xrow[0] >> 5)) * 4096;
+  pst_u[1] = pst_u[0] + 4096;
+  const uint32_t pst_v = (uint32_t)((h * 32 + j) * 16);
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define Q2_P_ST4(U, M, V0, V1, V2, V3) \
+  __builtin_nontemporal_store(f32x4{(V0), (V1), (V2), (V3)}, reinterpret_cast<f32x4*>(pst_u[U] + (M) * 1024 + pst_v))
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[u][db][r] = 0.f;
+  f32x2 l2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+
+  int dpos = 0;
+  const char* const baseY = reinterpret_cast<const char*>(Yr);
+  uint32_t g0 = dmah_off0<0>(B, c0, t), g1 = dmah_off0<1>(B, c0, t), g2 = dmah_off0<2>(B, c0, t),
+           g3 = dmah_off0<3>(B, c0, t);
+  f16x8 bx[2][2][8];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+        bx[u][p][s] = *reinterpret_cast<const f16x8*>(Xr + ((int64_t)p * B + xrow[u]) * k3D + 16 * s + 8 * h);
+  f32x16 sa[2];
+  float p[2][16];
+  uint32_t pw[2][2][8];
+  f16x8 ta2_[2][4][2];
+  float emax = 0.f;
+  float refv[2] = {-INFINITY, -INFINITY};
+  const f32x2 sl2v = {sl2, sl2};
+  f32x2 nrefv[2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[u][r] = 0.f;
+  if (FIX) {
+    float m[2] = {-INFINITY, -INFINITY};
+    for (int c = 0; c < nc; ++c) {
+      H_DMA_CHUNK(lds);
+      H_DMA_BARRIER();
+      Q2_S_PHASE(lds, false);
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m[u] = fmaxf(m[u], sa[u][r] * sl2);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) refv[u] = fmaxf(m[u], __shfl_xor(m[u], 32, 64)) - kHPexp;
+  }
+  H_DMA_CHUNK(lds);
+  if (nc > 1) H_DMA_CHUNK(lds + kHBufBytes);
+  float dref[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) dref[u] = (!FIX) ? diag[xrow[u]] * sl2_in : -INFINITY;
+  H_DMA_BARRIER();
+
+  Q2_S_PHASE(lds, false);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[u][r] = sa[u][r];
+    if (!FIX) {
+      float m = dref[u];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, sa[u][r] * sl2);
+      refv[u] = fmaxf(m, __shfl_xor(m, 32, 64)) - kHOptHead;
+    }
+    if (h == 0) part_m[(int64_t)split * B + xrow[u]] = refv[u];
+    nrefv[u] = f32x2{-refv[u], -refv[u]};
+  }
+
+  int cur = 0;
+  for (int it = 0; it + 2 < nc; ++it) {
+    const int nxt = cur == kHBufs - 1 ? 0 : cur + 1;
+    const int nn = nxt == kHBufs - 1 ? 0 : nxt + 1;
+    H_DMA_BARRIER();
+    const char* buf = lds + cur * kHBufBytes;
+    const char* nbuf = lds + nxt * kHBufBytes;
+    char* dbuf = lds + nn * kHBufBytes;
+    H_TR_BASES(buf);
+    Q2_S_PHASE(nbuf, true);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) p[u][r] = sa[u][r];
+    Q2_O_PHASE(true, dbuf);
+    cur = nxt;
+  }
+  if (nc >= 2) {
+    const int nxt = cur == kHBufs - 1 ? 0 : cur + 1;
+    H_DMA_BARRIER();
+    const char* buf = lds + cur * kHBufBytes;
+    const char* nbuf = lds + nxt * kHBufBytes;
+    H_TR_BASES(buf);
+    Q2_S_PHASE(nbuf, true);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) p[u][r] = sa[u][r];
+    Q2_O_PHASE(false, lds);
+    cur = nxt;
+  }
+  {  // last chunk: nothing left to prefetch; run its exp / split alone
+    H_DMA_BARRIER();
+    const char* buf = lds + cur * kHBufBytes;
+    H_TR_BASES(buf);
+#pragma unroll
+    for (int f = 0; f < 8; ++f) trh_frag_n<0>(f, ta2_, trc_);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float ek0 = 0.f, ek1 = 0.f;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const f32x2 arg = f32x2{p[u][2 * s], p[u][2 * s + 1]} * sl2v + nrefv[u];
+        const float e0 = __builtin_amdgcn_exp2f(arg[0]);
+        const float e1 = __builtin_amdgcn_exp2f(arg[1]);
+        l2[u] += f32x2{e0, e1};
+        emax = fmaxf(emax, fmaxf(e0, e1));
+        const f16x2 pa = pk_f16(e0, e1);
+        const f16x2 pq = pk_f16(resid_lo(e0, pa), resid_hi(e1, pa));
+        pw[u][0][s] = __builtin_bit_cast(uint32_t, pa);
+        pw[u][1][s] = __builtin_bit_cast(uint32_t, pq);
+        if ((s & 1) == 0) { ek0 = e0; ek1 = e1; } else { Q2_P_ST4(u, s >> 1, ek0, ek1, e0, e1); }
+      }
+    }
+    Q2_O_PHASE(false, lds);
+  }
+#undef Q2_P_ST4
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    float* orow = part_O + ((int64_t)split * B + xrow[u]) * k3D;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(orow + 32 * db + 8 * q + 4 * h) =
+            make_float4(acc[u][db][4 * q], acc[u][db][4 * q + 1], acc[u][db][4 * q + 2], acc[u][db][4 * q + 3]);
+    const float l = l2[u][0] + l2[u][1];
+    const float ltot = l + __shfl_xor(l, 32, 64);
+    if (h == 0) part_l[(int64_t)split * B + xrow[u]] = ltot;
+  }
+  if (!FIX && (mode == 2 || !(emax <= kHOverflow))) flags[blockIdx.x] = 1;
+}
+
+// -----------------------------------------------------------------------------------------------------------------
 // Pass C: owned = C rows j, streamed = Q rows i; reads the P' tiles of pass Q and the factors 2^14 2^(M_split - M) / l'_i
 // of merge<Q>, forms the true probabilities * 2^14 in two fp16 planes and runs the O^T phase alone (24 MFMAs per chunk
 // and wave), software-pipelined like inbatch3_pc_kernel.  One 512-thread workgroup owns 256 rows: a plane tile is
@@ -1017,19 +1283,36 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
   const float inv_bs = 1.0f / batch_size, sl2 = scale * k3Log2e;
   const int nchunks = (int)(B / k3Chunk);
   const char* qcs = getenv("ESR_IB2H_Q_PER_CU");
-  const int nsplit_q = inbatch2h_nsplit(B, qcs ? std::max(1, atoi(qcs)) : 2);  // 252 registers, 50 KB of LDS: two per CU
+  int nsplit_q = inbatch2h_nsplit(B, qcs ? std::max(1, atoi(qcs)) : 2);  // 252 registers, 50 KB of LDS: two per CU
   // pass C: 8-wave workgroups, 256 owned rows each
   const int pc_blocks = (int)cdiv(B, kPc8Owned);
   int nsplit_c = 1;
   for (int sp = 1; sp <= 8; ++sp)
     if (nchunks % sp == 0 && pc_blocks * sp <= 320) nsplit_c = sp;
   const int grid_c = pc_blocks * nsplit_c;
-  const int grid_q = (int)(B / k3Owned) * nsplit_q;
+  int grid_q = (int)(B / k3Owned) * nsplit_q;
+  // pass Q with 64 owned rows per wave (256 per workgroup, one workgroup per CU): ESR_IB2H_Q=64; needs B % 256 == 0 and
+  // the optimistic reference
+  const char* qf = getenv("ESR_IB2H_Q");
+  const bool q2_env = qf && qf[0] == '6';
+  bool q2 = q2_env && B % 256 == 0;
+  if (q2) {
+    const int blocks = (int)(B / 256);
+    nsplit_q = 1;
+    for (int sp = 1; sp <= 8; ++sp)
+      if (nchunks % sp == 0 && blocks * sp <= 320) nsplit_q = sp;
+    grid_q = blocks * nsplit_q;
+  }
   const int mgrid = (int)std::min<int64_t>(k3MergeBlocks, cdiv(B, kBlock / 32));
   // exponent reference of pass Q: optimistic + redo launch (default), or the row-max pass (ESR_IB2H_REF=rowmax);
   // ESR_IB2H_REF=redo forces every block through the redo launch (test hook)
   const char* refe = getenv("ESR_IB2H_REF");
   const int mode = (refe && refe[0] == 'r' && refe[1] == 'o') ? 0 : ((refe && refe[0] == 'r' && refe[1] == 'e') ? 2 : 1);
+  if (mode == 0) q2 = false;
+  if (!q2 && q2_env) {  // fell back: restore the 32-row geometry
+    nsplit_q = inbatch2h_nsplit(B, qcs ? std::max(1, atoi(qcs)) : 2);
+    grid_q = (int)(B / k3Owned) * nsplit_q;
+  }
   hipLaunchKernelGGL(prep2h_kernel, dim3(nchunks), dim3(256), 0, st, Qs, Cs, ws.amax, ws.diag);
   hipLaunchKernelGGL(split2h_kernel, dim3(nchunks, 2), dim3(256), 0, st, Qs, Cs, B, ws.Qh, ws.Ch, (const float*)ws.amax,
                      ws.nrm, ws.sc, ws.loss_acc, ws.flags, grid_q);
@@ -1041,6 +1324,14 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
     hipLaunchKernelGGL(rowmax2h_kernel, dim3(rm_blocks * nsplit_r), dim3(256), 0, st, (const _Float16*)ws.Qh,
                        (const _Float16*)ws.Ch, B, nsplit_r, sl2, (const float*)ws.nrm, (const float*)ws.sc, ws.part_mr);
   }
+  if (q2) {
+    hipLaunchKernelGGL((inbatch2h_q2_kernel<false>), dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Qh,
+                       (const _Float16*)ws.Ch, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)ws.diag, mode,
+                       ws.flags, ws.part_m, ws.part_O, ws.part_l, ws.Pmat);
+    hipLaunchKernelGGL((inbatch2h_q2_kernel<true>), dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Qh,
+                       (const _Float16*)ws.Ch, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)ws.diag, mode,
+                       ws.flags, ws.part_m, ws.part_O, ws.part_l, ws.Pmat);
+  } else {
   hipLaunchKernelGGL((inbatch2h_q_kernel<false>), dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Qh,
                      (const _Float16*)ws.Ch, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)ws.part_mr, nsplit_r,
                      (const float*)ws.diag, mode, ws.flags, ws.part_m, ws.part_O, ws.part_l, ws.Pmat);
@@ -1048,6 +1339,7 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
     hipLaunchKernelGGL((inbatch2h_q_kernel<true>), dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Qh,
                        (const _Float16*)ws.Ch, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)ws.part_mr, nsplit_r,
                        (const float*)ws.diag, mode, ws.flags, ws.part_m, ws.part_O, ws.part_l, ws.Pmat);
+  }
   // O_Q' = 2^ec sum p' c, l' = sum p': o / l needs 2^-ec (sc[1]); the stored factors carry pass C's 2^14
   hipLaunchKernelGGL((inbatch3_merge_kernel<true>), dim3(mgrid), dim3(kBlock), 0, st, Qs, Cs, gq_rows, B, nsplit_q,
                      (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale, regularization,

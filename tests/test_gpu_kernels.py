@@ -469,6 +469,25 @@ def test_inbatch_f16x2_operand_and_score_ranges(dev, mag_q, mag_c, scale):
         assert max(errs["f16x2"]) <= 4 * max(errs["f32"]), errs
 
 
+@pytest.mark.parametrize("B", [256, 1024, 8192])
+def test_inbatch_f16x2_64_row_waves_equal_32_row_waves(dev, B, monkeypatch):
+    """ESR_IB2H_Q=64: pass Q with two 32-row sets per wave (half the LDS reads and DMA traffic per MFMA; measured the
+    same 111-113 us -- the pass is bound by MFMA energy at the power cap).  Same arithmetic per row, different split
+    geometry: equal to the default to f32 roundings of the split merge."""
+    from esrecsys_amd import ops
+    g = torch.Generator(device=dev).manual_seed(B)
+    D = 128
+    q = torch.randn((B, D), generator=g, device=dev) * D ** -0.5
+    c = torch.randn((B, D), generator=g, device=dev) * D ** -0.5
+    c[B - 40] = 3.0 * q[7] / q[7].norm()   # a late dominant candidate: the redo launch of the 64-row kernel too
+    monkeypatch.delenv("ESR_IB2H_Q", raising=False)
+    ref = [t.clone() for t in ops.inbatch_softmax_fwd_bwd(q, c, 8.0, 0.1, float(B), precision="f16x2")]
+    monkeypatch.setenv("ESR_IB2H_Q", "64")
+    out = ops.inbatch_softmax_fwd_bwd(q, c, 8.0, 0.1, float(B), precision="f16x2")
+    for a, b in zip(ref, out):
+        assert bool(torch.isfinite(b).all()) and rel_err(N(b), N(a)) <= 2e-6
+
+
 def test_inbatch_f16x2_largest_batch_against_exact_f32(dev):
     """B = 16384 is the largest batch of the two-plane path (1 GiB of stored probabilities): against the exact-f32 MFMA
     kernel on the same inputs (the fp64 oracle needs 2 GiB per B x B matrix at this size), plus the column-sum property
