@@ -90,7 +90,7 @@ class KernelTimer:
         return out
 
 
-def sustained_bf16_mfma_tflops(dev, iters=100000):
+def sustained_bf16_mfma_tflops(dev, iters=100000, f16=False):
     """What a register-only v_mfma_f32_32x32x16_bf16 loop with full-entropy operands sustains on THIS box right now
     (esr_probe_mfma | ESR_PROBE_LIVE_DATA, ~60 ms): the part holds ~1.75 GHz under its power limit with live data,
     not the 2.4 GHz the 2.5 PFLOP/s data-sheet peak assumes (constant operands do reach 2.45 PFLOP/s)."""
@@ -100,7 +100,7 @@ def sustained_bf16_mfma_tflops(dev, iters=100000):
     sink = torch.zeros(1, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     flops = ctypes.c_double()
-    dt = _lib.ESR_BF16 | _lib.ESR_PROBE_LIVE_DATA
+    dt = (_lib.ESR_PROBE_F16 if f16 else _lib.ESR_BF16) | _lib.ESR_PROBE_LIVE_DATA  # f16: the planes of the f16x2 paths
     _lib.check(lib.esr_probe_mfma(dt, 2048, 2000, sink.data_ptr(), ctypes.byref(flops), st), "probe")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -641,7 +641,7 @@ def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True
         roofline = roofline_for(workload, kernels, B, D, rows, PRECISION, occ_n, uniq,
                                 bf16_tables=cfg.get("table_dtype") == "bf16", rowmax_gemm=needs_rowmax, step_s=dt / K)
         if roofline.get("bound") == "mfma" and roofline.get("peak") == MFMA_BF16_PEAK_TFLOPS:
-            live = sustained_bf16_mfma_tflops(dev)  # after the timed region
+            live = sustained_bf16_mfma_tflops(dev, f16=str(roofline.get("dtype", "")).startswith("fp16"))  # after the timed region
             roofline["sustained_live_data_TFLOPs"] = live
             roofline["frac_of_sustained"] = roofline["achieved"] / live
         if roofline.get("bound") == "hbm":

@@ -23,6 +23,8 @@ def main():
             ("bf16 32x32x16", _lib.ESR_BF16, 2500.0, ((256 * 8, 20000), (256 * 8, 100000))),
             ("bf16 32x32x16 live data", _lib.ESR_BF16 | _lib.ESR_PROBE_LIVE_DATA, 2500.0,
              ((256 * 8, 20000), (256 * 8, 100000), (256 * 8, 1000000))),
+            ("f16 32x32x16 live data", _lib.ESR_PROBE_F16 | _lib.ESR_PROBE_LIVE_DATA, 2500.0,
+             ((256 * 8, 20000), (256 * 8, 100000), (256 * 8, 1000000))),
             ("f32 32x32x2", _lib.ESR_F32, 157.3, ((256 * 8, 20000), (256 * 8, 100000)))):
         for wgs, iters in runs:
             flops = ctypes.c_double()

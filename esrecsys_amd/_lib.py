@@ -12,7 +12,8 @@ LIB_PATH = os.path.join(_HERE, "libesr_hip.so")
 ESR_OK = 0
 ESR_F32 = 0
 ESR_BF16 = 1
-ESR_PROBE_LIVE_DATA = 0x100  # esr_probe_mfma: dtype | this = full-entropy operands
+ESR_PROBE_LIVE_DATA = 0x100
+ESR_PROBE_F16 = 2  # esr_probe_mfma: dtype | this = full-entropy operands
 GLOVE_REFERENCE = 0
 GLOVE_DIAGONAL = 1
 RETRIEVE_EXACT = 0

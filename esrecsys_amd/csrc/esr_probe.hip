@@ -59,6 +59,33 @@ __global__ __launch_bounds__(256) void mfma_bf16_live_probe_kernel(int iters, fl
   if (s == 12345.678f) sink[0] = s;
 }
 
+// fp16 planes of the two-plane split paths (esr_inbatch2h.hip, esr_retrieve.hip mode 2): the same loop with
+// v_mfma_f32_32x32x16_f16 and full-entropy fp16 operands in (-1, 1)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void mfma_f16_live_probe_kernel(int iters, float* __restrict__ sink) {
+  f16x8 a[4], b[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const uint32_t ha = probe_hash((blockIdx.x * 256 + threadIdx.x) * 64 + q * 16 + e);
+      const uint32_t hb = probe_hash(ha + 0x9e3779b9u);
+      a[q][e] = (_Float16)((float)(int)(ha & 0xffff) * (1.0f / 32768.f) - 1.0f);
+      b[q][e] = (_Float16)((float)(int)(hb & 0xffff) * (1.0f / 32768.f) - 1.0f);
+    }
+  f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+  for (int i = 0; i < iters; ++i) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[2], c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2], b[3], c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[3], b[0], c3, 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s += c0[e] + c1[e] + c2[e] + c3[e];
+  if (s == 12345.678f) sink[0] = s;
+}
+
 __global__ __launch_bounds__(256) void mfma_f32_probe_kernel(int iters, float* __restrict__ sink) {
   const float a = 1.0f + 0.001f * (threadIdx.x & 7), b = 0.5f;
   f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
@@ -84,11 +111,14 @@ int esr_probe_mfma(int dtype, int workgroups, int iters, float* sink, double* fl
   ESR_REQUIRE(workgroups > 0 && iters > 0 && sink && flops_out, "esr_probe_mfma: bad arguments");
   const bool live = (dtype & ESR_PROBE_LIVE_DATA) != 0;
   dtype &= ~ESR_PROBE_LIVE_DATA;
-  ESR_REQUIRE(dtype == ESR_F32 || dtype == ESR_BF16, "esr_probe_mfma: dtype %d", dtype);
-  ESR_REQUIRE(!live || dtype == ESR_BF16, "esr_probe_mfma: ESR_PROBE_LIVE_DATA is for ESR_BF16");
-  const double per_mfma = 2.0 * 32 * 32 * (dtype == ESR_BF16 ? 16 : 2);
+  ESR_REQUIRE(dtype == ESR_F32 || dtype == ESR_BF16 || dtype == ESR_PROBE_F16, "esr_probe_mfma: dtype %d", dtype);
+  ESR_REQUIRE(!live || dtype != ESR_F32, "esr_probe_mfma: ESR_PROBE_LIVE_DATA is for ESR_BF16 / ESR_PROBE_F16");
+  ESR_REQUIRE(dtype != ESR_PROBE_F16 || live, "esr_probe_mfma: ESR_PROBE_F16 has the live-data form only");
+  const double per_mfma = 2.0 * 32 * 32 * (dtype == ESR_F32 ? 2 : 16);
   *flops_out = per_mfma * 4.0 * (double)iters * 4.0 * (double)workgroups;  // 4 chains x iters x 4 waves x grid
-  if (live)
+  if (dtype == ESR_PROBE_F16)
+    hipLaunchKernelGGL(mfma_f16_live_probe_kernel, dim3(workgroups), dim3(256), 0, as_stream(stream), iters, sink);
+  else if (live)
     hipLaunchKernelGGL(mfma_bf16_live_probe_kernel, dim3(workgroups), dim3(256), 0, as_stream(stream), iters, sink);
   else if (dtype == ESR_BF16)
     hipLaunchKernelGGL(mfma_bf16_probe_kernel, dim3(workgroups), dim3(256), 0, as_stream(stream), iters, sink);

@@ -62,6 +62,7 @@ int esr_device_info(int* cu_count, int* wave_size, size_t* hbm_bytes, char* arch
  * change every instruction instead of constants: switching activity, and with it the clock the part holds under
  * its power limit, is that of a real GEMM (constants measured 2.44 PFLOP/s bf16; see profiles/). */
 #define ESR_PROBE_LIVE_DATA 0x100
+#define ESR_PROBE_F16 2 /* v_mfma_f32_32x32x16_f16 (with ESR_PROBE_LIVE_DATA): the planes of the f16x2 paths */
 int esr_probe_mfma(int dtype, int workgroups, int iters, float* sink, double* flops_out, esr_stream_t stream);
 
 /* ---- G2 / S1: embedding-row gather ------------------------------------------------------
