@@ -38,7 +38,7 @@ def measure_retrieve(dev, n_local, steps, warmup, mode="exact", with_cpu=True, w
     planes = (3 if exact_path == "f16x2" else 6) if mode == "exact" else 1  # MFMA cross terms per product
     flops = 2.0 * nq * n_local * D
     from bench import sustained_bf16_mfma_tflops
-    live = sustained_bf16_mfma_tflops(dev)
+    live = sustained_bf16_mfma_tflops(dev, f16=(mode == "exact" and os.environ.get("ESR_RETRIEVE_EXACT", "f16x2") == "f16x2"))
     extra = {}
     if with_ann:
         a_s, a_i = find_top_k_batch(q, c, k, approximate=True)
@@ -171,7 +171,7 @@ def run_retrieve(args, emit):
         extra_cpu = None
     if rank == 0:
         from bench import sustained_bf16_mfma_tflops
-        live = sustained_bf16_mfma_tflops(dev)
+        live = sustained_bf16_mfma_tflops(dev, f16=(mode == "exact" and os.environ.get("ESR_RETRIEVE_EXACT", "f16x2") == "f16x2"))
         emit({
             "metric": "retrieval queries/sec (top-%d of N candidates, brute force)" % K,
             "value": world * NQ * args.steps / dt, "unit": "queries/s", "n_gpus": world, "steps": args.steps,

@@ -114,7 +114,7 @@ def run_sharded(args, cfg, dev, rank, world):
         K = args.steps
         from bench import emit, sustained_bf16_mfma_tflops, MFMA_BF16_PEAK_TFLOPS
         if roofline is not None and roofline.get("bound") == "mfma" and roofline.get("peak") == MFMA_BF16_PEAK_TFLOPS:
-            live = sustained_bf16_mfma_tflops(dev)
+            live = sustained_bf16_mfma_tflops(dev, f16=str(roofline.get("dtype", "")).startswith("fp16"))
             roofline["sustained_live_data_TFLOPs"] = live
             roofline["frac_of_sustained"] = roofline["achieved"] / live
         emit({
