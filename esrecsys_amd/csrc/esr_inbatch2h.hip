@@ -1256,8 +1256,8 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
               who, (long long)B, (long long)kHMaxB);
     return ESR_EINVAL;
   }
-  if (D != k3D) {
-    set_error("%s: D=%d not supported (128 only; use the f32 entry point)", who, D);
+  if (!(D > 0 && D <= k3D && D % 4 == 0)) {  // narrower rows run in the 128-column tile, zero-padded
+    set_error("%s: D=%d not supported (a multiple of 4, at most 128; wider rows: the f32 entry point)", who, D);
     return ESR_EINVAL;
   }
   if (!(Qs.base && Cs.base && loss && gQ && gC)) {
@@ -1358,7 +1358,7 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
 int esr_inbatch_softmax_fwd_bwd_f16x2(const float* Q, const float* C, int64_t B, int D, float scale,
                                       float regularization, float batch_size, float* loss, float* lse, float* gQ,
                                       float* gC, void* workspace, size_t workspace_bytes, esr_stream_t stream) {
-  return inbatch2h_run("esr_inbatch_softmax_fwd_bwd_f16x2", RowSrc{Q, nullptr, 0}, RowSrc{C, nullptr, 0}, nullptr,
+  return inbatch2h_run("esr_inbatch_softmax_fwd_bwd_f16x2", RowSrc{Q, nullptr, 0, D}, RowSrc{C, nullptr, 0, D}, nullptr,
                        nullptr, B, D, scale, regularization, batch_size, loss, lse, gQ, gC, workspace, workspace_bytes,
                        stream);
 }
@@ -1370,8 +1370,8 @@ int esr_inbatch_towers_fwd_bwd_f16x2(const void* query_table, int64_t Vq, const 
                                      size_t workspace_bytes, esr_stream_t stream) {
   ESR_REQUIRE(Vq > 0 && Vc > 0 && query_ids && cand_ids, "esr_inbatch_towers_fwd_bwd_f16x2: bad tables / ids");
   ESR_REQUIRE(dtype == ESR_F32 || dtype == ESR_BF16, "esr_inbatch_towers_fwd_bwd_f16x2: bad dtype %d", dtype);
-  return inbatch2h_run("esr_inbatch_towers_fwd_bwd_f16x2", RowSrc{query_table, query_ids, dtype == ESR_BF16},
-                       RowSrc{cand_table, cand_ids, dtype == ESR_BF16}, gq_rows, gc_rows, B, D, scale, regularization,
+  return inbatch2h_run("esr_inbatch_towers_fwd_bwd_f16x2", RowSrc{query_table, query_ids, dtype == ESR_BF16, D},
+                       RowSrc{cand_table, cand_ids, dtype == ESR_BF16, D}, gq_rows, gc_rows, B, D, scale, regularization,
                        batch_size, loss, lse, gQ, gC, workspace, workspace_bytes, stream);
 }
 

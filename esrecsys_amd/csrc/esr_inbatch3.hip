@@ -956,8 +956,8 @@ static int inbatch3_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* gq
     set_error("%s: B=%lld must be a positive multiple of 128", who, (long long)B);
     return ESR_EINVAL;
   }
-  if (D != k3D) {
-    set_error("%s: D=%d not supported (128 only; use the f32 entry point)", who, D);
+  if (!(D > 0 && D <= k3D && D % 4 == 0)) {  // narrower rows run in the 128-column tile, zero-padded
+    set_error("%s: D=%d not supported (a multiple of 4, at most 128; wider rows: the f32 entry point)", who, D);
     return ESR_EINVAL;
   }
   if (!(Qs.base && Cs.base && loss && gQ && gC)) {
@@ -1038,7 +1038,7 @@ static int inbatch3_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* gq
 int esr_inbatch_softmax_fwd_bwd_bf16x3(const float* Q, const float* C, int64_t B, int D, float scale,
                                        float regularization, float batch_size, float* loss, float* lse, float* gQ,
                                        float* gC, void* workspace, size_t workspace_bytes, esr_stream_t stream) {
-  return inbatch3_run("esr_inbatch_softmax_fwd_bwd_bf16x3", RowSrc{Q, nullptr, 0}, RowSrc{C, nullptr, 0}, nullptr, nullptr,
+  return inbatch3_run("esr_inbatch_softmax_fwd_bwd_bf16x3", RowSrc{Q, nullptr, 0, D}, RowSrc{C, nullptr, 0, D}, nullptr, nullptr,
                       B, D, scale,
                       regularization, batch_size, loss, lse, gQ, gC, workspace, workspace_bytes, stream);
 }
@@ -1051,8 +1051,8 @@ int esr_inbatch_towers_fwd_bwd_bf16x3(const void* query_table, int64_t Vq, const
                                       esr_stream_t stream) {
   ESR_REQUIRE(Vq > 0 && Vc > 0 && query_ids && cand_ids, "esr_inbatch_towers_fwd_bwd_bf16x3: bad tables / ids");
   ESR_REQUIRE(dtype == ESR_F32 || dtype == ESR_BF16, "esr_inbatch_towers_fwd_bwd_bf16x3: bad dtype %d", dtype);
-  return inbatch3_run("esr_inbatch_towers_fwd_bwd_bf16x3", RowSrc{query_table, query_ids, dtype == ESR_BF16},
-                      RowSrc{cand_table, cand_ids, dtype == ESR_BF16}, gq_rows, gc_rows, B, D, scale, regularization,
+  return inbatch3_run("esr_inbatch_towers_fwd_bwd_bf16x3", RowSrc{query_table, query_ids, dtype == ESR_BF16, D},
+                      RowSrc{cand_table, cand_ids, dtype == ESR_BF16, D}, gq_rows, gc_rows, B, D, scale, regularization,
                       batch_size, loss,
                       lse, gQ, gC, workspace, workspace_bytes, stream);
 }

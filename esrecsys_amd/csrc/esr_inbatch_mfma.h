@@ -114,15 +114,17 @@ struct RowSrc {
   const void* base;
   const int32_t* idx;
   int bf16;
+  int ld;  // row length of the source = number of valid columns (a multiple of 4, <= 128); columns beyond it read as 0
 };
 __device__ __forceinline__ float4 rowsrc_load4(const RowSrc& s, int64_t row, int d) {  // elements d .. d+3 of row
+  if (d >= s.ld) return make_float4(0.f, 0.f, 0.f, 0.f);  // zero padding up to the 128-column tile
   const int64_t r = s.idx ? (int64_t)s.idx[row] : row;
   if (s.bf16) {
-    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(s.base) + r * k3D + d);
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(s.base) + r * s.ld + d);
     return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
                        __uint_as_float(u.y & 0xFFFF0000u));
   }
-  return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(s.base) + r * k3D + d);
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(s.base) + r * s.ld + d);
 }
 
 
@@ -204,7 +206,8 @@ __global__ __launch_bounds__(kBlock) void inbatch3_merge_kernel(
     g.y = (scale * (o.y * invL - y.y) + creg * x.y) * inv_bs;
     g.z = (scale * (o.z * invL - y.z) + creg * x.z) * inv_bs;
     g.w = (scale * (o.w * invL - y.w) + creg * x.w) * inv_bs;
-    *reinterpret_cast<float4*>(gX + (out_idx ? (int64_t)out_idx[row] : row) * k3D + 4 * lig) = g;
+    if (4 * lig < X.ld)  // gradient rows have the source's width
+      *reinterpret_cast<float4*>(gX + (out_idx ? (int64_t)out_idx[row] : row) * X.ld + 4 * lig) = g;
     float row_loss = lam * fmaxf(xnorm - 1.f, 0.f);
     if (QSIDE) {
       const float diag = group_sum(x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w, G);

@@ -320,23 +320,26 @@ def _inbatch_auto_split():
 def inbatch_split_path(precision, B, D, bf16_tables=False):
     """The split-precision MFMA path `precision` selects for a [B, D] in-batch head: "f16x2", "bf16x3" or None (exact
     f32).  f16x2: two fp16 planes per operand, three MFMAs per product (esr_inbatch2h.hip; fp32 rows, B <= 16384);
-    bf16x3: three bf16 planes, six MFMAs (esr_inbatch3.hip; also bf16 tables, where only one plane is live)."""
+    bf16x3: three bf16 planes, six MFMAs (esr_inbatch3.hip; also bf16 tables, where only one plane is live).  Both work
+    on 128-column tiles: D <= 128, a multiple of 4 (narrower rows are zero-padded); "auto" takes them from D = 64 up
+    (ESR_INBATCH_SPLIT_MIN_D), the exact-f32 kernel's own 32- / 64-column tiles below."""
     if precision not in INBATCH_PRECISIONS:
         raise ValueError("precision must be one of %s" % (INBATCH_PRECISIONS,))
-    split_ok = D == 128 and B % 128 == 0 and B > 0
-    h_ok = split_ok and B <= INBATCH_F16X2_MAX_B and not bf16_tables
+    shape_ok = D % 4 == 0 and 0 < D <= 128 and B % 128 == 0 and B > 0
+    h_ok = shape_ok and B <= INBATCH_F16X2_MAX_B and not bf16_tables
     if precision == "f32":
         return None
     if precision == "bf16x3":
-        if not split_ok:
-            raise ValueError("precision='bf16x3' needs D == 128 and B %% 128 == 0 (got B=%d, D=%d)" % (B, D))
+        if not shape_ok:
+            raise ValueError("precision='bf16x3' needs D <= 128 (a multiple of 4) and B %% 128 == 0 (got B=%d, D=%d)"
+                             % (B, D))
         return "bf16x3"
     if precision == "f16x2":
         if not h_ok:
-            raise ValueError("precision='f16x2' needs D == 128, B %% 128 == 0, B <= %d and fp32 rows (got B=%d, D=%d)"
-                             % (INBATCH_F16X2_MAX_B, B, D))
+            raise ValueError("precision='f16x2' needs D <= 128 (a multiple of 4), B %% 128 == 0, B <= %d and fp32 rows "
+                             "(got B=%d, D=%d)" % (INBATCH_F16X2_MAX_B, B, D))
         return "f16x2"
-    if not split_ok:
+    if not shape_ok or D < int(os.environ.get("ESR_INBATCH_SPLIT_MIN_D", "64")):
         return None
     return "f16x2" if h_ok and _inbatch_auto_split() == "f16x2" else "bf16x3"
 
@@ -705,7 +708,7 @@ def inbatch_towers_fwd_bwd(query_table, cand_table, query_ids, cand_ids, scale, 
     B, D, dev = query_ids.numel(), query_table.shape[1], query_table.device
     path = inbatch_split_path(precision, B, D, bf16_tables=query_table.dtype == torch.bfloat16)
     if path is None:
-        raise ValueError("inbatch_towers_fwd_bwd needs D == 128 and B %% 128 == 0 (got B=%d, D=%d) and a split precision"
+        raise ValueError("inbatch_towers_fwd_bwd needs D <= 128 (a multiple of 4) and B %% 128 == 0 (got B=%d, D=%d) and a split precision"
                          % (B, D))
     loss = torch.empty(1, dtype=torch.float32, device=dev)
     lse = torch.empty(B, dtype=torch.float32, device=dev)

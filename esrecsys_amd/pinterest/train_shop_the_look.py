@@ -173,7 +173,8 @@ def train_step(state, scene, pos_product, neg_product, regularization, batch_siz
             fused.index._sorted = presorted.take()  # sorted one batch ahead on the side stream (presort_triplets)
         elif fused is not None and _PRESORT:
             fused.index.presort()
-        if precision != "f32" and st.shape[1] == 128 and B % 128 == 0 and st.dtype == pt.dtype:
+        if precision != "f32" and st.dtype == pt.dtype and \
+                ops.inbatch_split_path(precision, B, st.shape[1], bf16_tables=st.dtype == torch.bfloat16) is not None:
             # the split-precision paths read the tower rows themselves (gather folded into their split and merge kernels)
             loss, _, gq, gc = ops.inbatch_towers_fwd_bwd(st, pt, sid, pid, scale, regularization, batch_size,
                                                          precision=precision)

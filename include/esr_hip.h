@@ -170,7 +170,8 @@ int esr_inbatch_softmax_fwd_bwd(const float* Q, const float* C, int64_t B, int D
 
 /* Same contract with FP32-EQUIVALENT products on the bf16 matrix cores: every operand is split exactly
  * into three bf16 planes and a product is the six leading cross terms (dropped terms <= 2^-23 |a||b|),
- * 2.67x fewer matrix-pipe cycles than v_mfma_f32_32x32x2_f32.  D must be 128, B a multiple of 128. */
+ * 2.67x fewer matrix-pipe cycles than v_mfma_f32_32x32x2_f32.  D <= 128 and a multiple of 4 (narrower rows are
+ * zero-padded into the 128-column tiles), B a multiple of 128. */
 size_t esr_inbatch3_workspace_bytes(int64_t B, int D);
 int esr_inbatch_softmax_fwd_bwd_bf16x3(const float* Q, const float* C, int64_t B, int D, float scale,
                                        float regularization, float batch_size, float* loss, float* lse,
@@ -195,8 +196,8 @@ int esr_inbatch_towers_fwd_bwd_bf16x3(const void* query_table, int64_t Vq, const
  * product instead of six bf16 ones, i.e. half the matrix-core work of the bf16x3 entry points at the same f32-grade
  * error (the kernels run at the chip's power limit, so fewer MFMAs is what shortens the step).  fp16's narrow range is
  * handled inside: a per-matrix power-of-two scale from the batch's largest |element|, and an exponent reference tied
- * to the true row maximum.  Pass C reads the B x B probabilities pass Q stored: D must be 128, B a multiple of 128 and
- * <= 16384 (workspace ~ 4 B^2 bytes); esr_inbatch2h_workspace_bytes returns 256 for a B it cannot serve. */
+ * to the true row maximum.  Pass C reads the B x B probabilities pass Q stored: D <= 128 and a multiple of 4 (narrower
+ * rows are zero-padded into the 128-column tiles; gQ / gC are [B, D]), B a multiple of 128 and <= 16384 (workspace ~ 4 B^2 bytes); esr_inbatch2h_workspace_bytes returns 256 for a B it cannot serve. */
 size_t esr_inbatch2h_workspace_bytes(int64_t B, int D);
 int esr_inbatch_softmax_fwd_bwd_f16x2(const float* Q, const float* C, int64_t B, int D, float scale,
                                       float regularization, float batch_size, float* loss, float* lse,

@@ -59,8 +59,12 @@ def test_bad_arguments_are_rejected_without_a_device(lib):
     assert lib.esr_inbatch_softmax_fwd_bwd_f16x2(16, 16, 32768, 128, 1.0, 0.0, 1.0, 16, 16, 16, 16, 16, 1 << 20,
                                                  None) == EINVAL
     assert b"at most 16384" in lib.esr_last_error()
-    assert lib.esr_inbatch_softmax_fwd_bwd_f16x2(16, 16, 256, 64, 1.0, 0.0, 1.0, 16, 16, 16, 16, 16, 1 << 20,
+    assert lib.esr_inbatch_softmax_fwd_bwd_f16x2(16, 16, 256, 136, 1.0, 0.0, 1.0, 16, 16, 16, 16, 16, 1 << 20,
+                                                 None) == EINVAL   # D <= 128, a multiple of 4
+    assert lib.esr_inbatch_softmax_fwd_bwd_f16x2(16, 16, 256, 98, 1.0, 0.0, 1.0, 16, 16, 16, 16, 16, 1 << 20,
                                                  None) == EINVAL
+    assert lib.esr_inbatch_softmax_fwd_bwd_f16x2(16, 16, 256, 64, 1.0, 0.0, 1.0, 16, 16, 16, 16, 16, 1 << 10,
+                                                 None) == EWORKSPACE  # narrower rows are accepted (zero-padded tiles)
     assert lib.esr_inbatch_softmax_fwd_bwd_f16x2(16, 16, 256, 128, 1.0, 0.0, 1.0, 16, 16, 16, 16, 16, 1 << 10,
                                                  None) == EWORKSPACE
     assert lib.esr_inbatch2h_workspace_bytes(32768, 128) == 256 and lib.esr_inbatch2h_workspace_bytes(8192, 128) > 4 * 8192 * 8192

@@ -270,6 +270,33 @@ def test_inbatch_embedding_widths_vs_oracle(dev, B, D):
     assert torch.equal(gq2, gq) and torch.equal(gc2, gc) and bool((guard == 7.0).all())
 
 
+@pytest.mark.parametrize("precision", ["f16x2", "bf16x3", "auto"])
+@pytest.mark.parametrize("D", [32, 64, 96, 100, 124])
+def test_inbatch_split_paths_on_narrow_rows(dev, D, precision):
+    """the reference's own embedding widths (output_size 32 / 64 / 96: pinterest/sweep.yaml:13-14, README 64) on the
+    split-precision MFMA paths: rows narrower than the 128-column tile are zero-padded inside the split kernels, the
+    gradient rows come back D wide.  Dense entry and tower entry (gather folded in), against the fp64 oracle."""
+    from conftest import elem_rel_err
+    from esrecsys_amd import ops
+    B, V = 1024, 5000
+    rng = np.random.default_rng(D)
+    qt = (rng.standard_normal((V, D)) * (1.1 / np.sqrt(D))).astype(np.float32)
+    ct = (rng.standard_normal((V, D)) * (1.1 / np.sqrt(D))).astype(np.float32)
+    qi, ci = rng.integers(0, V, B).astype(np.int32), rng.integers(0, V, B).astype(np.int32)
+    q, c = qt[qi], ct[ci]
+    el, else_, egq, egc = o_stl.inbatch_softmax_loss_and_grads(q.astype(F64), c.astype(F64), 0.2, float(B), 6.0, F64)
+    guard = torch.full((2 * B + 1, D), 7.0, device=dev)
+    loss, lse, gq, gc = ops.inbatch_softmax_fwd_bwd(T(q, dev), T(c, dev), 6.0, 0.2, float(B), precision=precision)
+    assert gq.shape == (B, D) and gc.shape == (B, D) and bool((guard == 7.0).all())
+    assert abs(float(loss) - el) <= TOL * abs(el) and rel_err(N(lse), else_) <= TOL
+    assert rel_err(N(gq), egq) <= TOL and rel_err(N(gc), egc) <= TOL
+    assert elem_rel_err(N(gq), egq) <= 20 * TOL and elem_rel_err(N(gc), egc) <= 20 * TOL
+    if precision != "auto":
+        l2, lse2, gq2, gc2 = ops.inbatch_towers_fwd_bwd(T(qt, dev), T(ct, dev), T(qi, dev), T(ci, dev), 6.0, 0.2, float(B),
+                                                        precision=precision)
+        assert torch.equal(l2, loss) and torch.equal(gq2, gq) and torch.equal(gc2, gc)
+
+
 @pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2"])
 def test_inbatch_gradients_elementwise_at_c2_size(dev, precision):
     """C2 size, both MFMA paths: every gradient entry within 1e-4 of the fp64 oracle relative to max(|entry|, 1e-3 of

@@ -79,7 +79,12 @@ def test_inbatch_split_path_resolution(monkeypatch):
     assert ops.inbatch_split_path("auto", 16384, 128) == "f16x2"
     assert ops.inbatch_split_path("auto", 16512, 128) == "bf16x3"
     assert ops.inbatch_split_path("auto", 8192, 128, bf16_tables=True) == "bf16x3"
-    assert ops.inbatch_split_path("auto", 8192, 64) is None and ops.inbatch_split_path("auto", 8200, 128) is None
+    assert ops.inbatch_split_path("auto", 8200, 128) is None
+    # narrower rows ride in the 128-column tiles from D = 64 up; below (and for wider or odd widths) the exact-f32 kernel
+    assert ops.inbatch_split_path("auto", 8192, 64) == "f16x2" and ops.inbatch_split_path("auto", 8192, 96) == "f16x2"
+    assert ops.inbatch_split_path("auto", 8192, 32) is None and ops.inbatch_split_path("auto", 8192, 256) is None
+    assert ops.inbatch_split_path("auto", 8192, 98) is None
+    assert ops.inbatch_split_path("f16x2", 256, 32) == "f16x2"   # an explicit request is honoured at any D <= 128
     assert ops.inbatch_split_path("f32", 8192, 128) is None
     assert ops.inbatch_split_path("bf16x3", 256, 128) == "bf16x3"
     with pytest.raises(ValueError):
