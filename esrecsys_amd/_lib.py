@@ -35,6 +35,7 @@ SIGNATURES = {
     "esr_device_info": (c_int, [ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_size),
                                 ctypes.c_char_p, c_int]),
     "esr_probe_mfma": (c_int, [c_int, c_int, c_int, c_f32p, ctypes.POINTER(ctypes.c_double), c_vp]),
+    "esr_probe_hbm_read": (c_int, [c_vp, c_i64, c_int, c_int, c_f32p, c_vp]),
     "esr_gather_rows": (c_int, [c_vp, c_int, c_i64, c_int, c_i32p, c_i64, c_vp, c_vp]),
     "esr_check_ids": (c_int, [c_i32p, c_i64, c_i64, c_vp, c_vp]),
     "esr_unpermute_rows": (c_int, [c_vp, c_int, c_int, c_i32p, c_i64, c_vp, c_vp]),

@@ -1025,11 +1025,22 @@ __device__ __forceinline__ uint32_t dmah8_off0(int64_t B, int64_t chunk, int t) 
   const int row = t >> 4, seg = (t & 15) ^ swz16(row);
   return (uint32_t)((((int64_t)K * B + chunk * 32 + row) * k3D + seg * 8) * 2);
 }
+// STAGE (default): the P' tiles go through REGISTERS on their way to LDS -- four coalesced 16-byte loads per lane and
+// chunk issued three chunks ahead, written to a wave-private 4 KB LDS tile one chunk before use.  As LDS-DMAs into the
+// 3-slot ring they could only be one chunk ahead (the slot of chunk it + 1 is read during iteration it), every barrier
+// waited for them (vmcnt(0)), and the pass ran at 3.8 TB/s of the 7.0-7.2 TB/s a read-only kernel reaches on the box
+// (esr_probe_hbm_read): a burst per iteration, then the wait for its tail.  With the staged loads the barrier waits
+// vmcnt(4) -- the four youngest loads stay in flight across it -- and the ring holds planes and factors only.
+template <bool STAGE>
 __global__ __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __restrict__ Yr, int64_t B, int nsplit,
                                                            const float* __restrict__ fac, int nc_q,
                                                            const float* __restrict__ Pmat,
                                                            float* __restrict__ part_O) {
-  __shared__ __attribute__((aligned(16))) char lds[kHBufs * kPc8Buf];
+  constexpr int kWaveArea = STAGE ? 256 : kPc8Wave;               // per-wave part of a ring slot: factors (+ P' tile)
+  constexpr int kBuf = 2 * kPlaneBytes + 8 * kWaveArea;           // ring slot
+  constexpr int kFacOff = STAGE ? 0 : 4096;                       // factors inside the per-wave part
+  constexpr int kPArea = kHBufs * kBuf;                           // STAGE: the wave-private P' tiles behind the ring
+  __shared__ __attribute__((aligned(16))) char lds[kHBufs * kBuf + (STAGE ? 8 * 4096 : 0)];
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int j = lane & 31, h = lane >> 5;
@@ -1052,7 +1063,9 @@ __global__ __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __re
     const int mh = 2 * g4 + (lane >> 5);
     p_off[g4] = (uint32_t)((mh * 32 + ((lane & 31) ^ (2 * mh))) * 16);
   }
-  const int wave_off = 2 * kPlaneBytes + w * kPc8Wave;
+  const int wave_off = 2 * kPlaneBytes + w * kWaveArea;
+  const uint32_t lds32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds;
+  (void)lds32;
 
   f32x16 acc[4];
 #pragma unroll
@@ -1077,7 +1090,7 @@ __global__ __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __re
                                    (lptr_t)((BUF) + wave_off + (G4) * 1024), 16, 0, H_P_LOAD_AUX)
 #define H8_DMA_FAC(BUF)                                                                                   \
   __builtin_amdgcn_global_load_lds((gptr_t)(ref + (c0 + dpos) * 32 + (lane & 31)),                        \
-                                   (lptr_t)((BUF) + wave_off + 4096), 4, 0, 0)
+                                   (lptr_t)((BUF) + wave_off + kFacOff), 4, 0, 0)
 #define H8_ADVANCE()                                                                                      \
   {                                                                                                       \
     const uint32_t step_ = (dpos + 1 == nc) ? (uint32_t)(8192 - nc * 8192) : 8192u;                       \
@@ -1087,11 +1100,29 @@ __global__ __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __re
 #define H8_DMA_ALL(BUF)                                                                                   \
   {                                                                                                       \
     H8_DMA_FAC(BUF); H8_DP(0, g0, BUF); H8_DP(1, g1, BUF);                                                \
-    H8_DMA_P(0, BUF); H8_DMA_P(1, BUF); H8_DMA_P(2, BUF); H8_DMA_P(3, BUF);                               \
+    if (!STAGE) { H8_DMA_P(0, BUF); H8_DMA_P(1, BUF); H8_DMA_P(2, BUF); H8_DMA_P(3, BUF); }               \
     H8_ADVANCE();                                                                                         \
   }
+  typedef float pf4 __attribute__((ext_vector_type(4)));
+  pf4 stg0[4], stg1[4];  // STAGE: the P' tiles of two coming chunks, as loaded (lane-linear 16-byte pieces)
+// chunk CH of this wave's tile column (clamped: past the end the last tile is loaded again and never used)
+// (inline assembly: as compiler-visible loads hipcc waited vmcnt(0) in front of the LDS write that consumes them -- it
+// does not order plain loads against the LDS-DMAs in flight -- which drained the loads issued a moment earlier; the
+// waits are written by hand: H8S_WAIT_WR below and the vmcnt(4) of the iteration barrier.  Loads return in order.)
+#define H8S_LOAD(STG, CH)                                                                                 \
+  {                                                                                                       \
+    const char* src_ = pw_base + (int64_t)min((int)(CH), nc - 1) * 4096;                                  \
+    _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_)                                                      \
+      asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(STG[g_]) : "v"(p_off[g_]), "s"(src_));      \
+  }
+// the set loaded ONE iteration ago has landed: behind it are only this iteration's 3 DMAs and 4 staged loads
+#define H8S_WAIT_WR() { H_SB(); asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); H_SB(); }
+#define H8S_WRITE(STG)                                                                                    \
+  _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_)                                                        \
+    *reinterpret_cast<pf4*>(lds + kPArea + w * 4096 + g_ * 1024 + lane * 16) = STG[g_];
   H8_DMA_ALL(lds);
-  if (nc > 1) H8_DMA_ALL(lds + kPc8Buf);
+  if (nc > 1) H8_DMA_ALL(lds + kBuf);
+  if (STAGE) { H8S_LOAD(stg0, 0); H8S_LOAD(stg1, 1); }
   float p1[16], rf[16];
   uint32_t pw[2][8], pwn[2][8];
   f16x8 ta2_[2][4][2];
@@ -1099,17 +1130,25 @@ __global__ __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __re
   // this lane's 16 probabilities of the chunk in BUF: component j % 4 of pieces (mh = j / 4, a = 8 g + 4 h + e), at LDS
   // piece mh * 32 + (a ^ 2 mh); and their 16 factors
   const int p_mh = j >> 2;
-  const int p_rd = wave_off + p_mh * 512 + (j & 3) * 4;
+  const int p_rd = (STAGE ? kPArea + w * 4096 : wave_off) + p_mh * 512 + (j & 3) * 4;
   const int p_x = (4 * h) ^ (2 * p_mh);  // (8 g + e) ^ p_x == (8 g + 4 h + e) ^ 2 mh: the three fields do not overlap
 #define H8_LOAD_P(BUF)                                                                                    \
   _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_)                                                       \
-    p1[r_] = *reinterpret_cast<const float*>((BUF) + p_rd + (((8 * (r_ >> 2) + (r_ & 3)) ^ p_x) << 4));
+    p1[r_] = *reinterpret_cast<const float*>((STAGE ? lds : (BUF)) + p_rd + (((8 * (r_ >> 2) + (r_ & 3)) ^ p_x) << 4));
+// (STAGE: inline-assembly reads, valid after the H_TR_WAIT() that follows in H8_ITER -- hipcc puts s_waitcnt vmcnt(0) in
+// front of a plain read of LDS that an LDS-DMA may have written, which would drain the staged loads in flight)
 #define H8_LOAD_REFS(BUF)                                                                                 \
   _Pragma("unroll") for (int g4_ = 0; g4_ < 4; ++g4_) {                                                   \
-    const float4 lv_ = *reinterpret_cast<const float4*>((BUF) + wave_off + 4096 + (8 * g4_ + 4 * h) * 4); \
+    float4 lv_;                                                                                           \
+    if (STAGE) {                                                                                          \
+      const f16x8 raw_ = lds_b128<0>(lds32 + (uint32_t)((BUF) - lds) + (uint32_t)(wave_off + kFacOff + (8 * g4_ + 4 * h) * 4)); \
+      lv_ = __builtin_bit_cast(float4, raw_);                                                             \
+    } else {                                                                                              \
+      lv_ = *reinterpret_cast<const float4*>((BUF) + wave_off + kFacOff + (8 * g4_ + 4 * h) * 4);          \
+    }                                                                                                     \
     rf[4 * g4_] = lv_.x; rf[4 * g4_ + 1] = lv_.y; rf[4 * g4_ + 2] = lv_.z; rf[4 * g4_ + 3] = lv_.w;       \
   }
-#define H8_ITER(NBUF, DBUF, DMA_ON, NEXT_ON)                                                              \
+#define H8_ITER(NBUF, DBUF, DMA_ON, NEXT_ON, STG_LD, STG_WR, IT)                                           \
   {                                                                                                       \
     H_PB();                                                                                               \
     if (NEXT_ON) {                                                                                        \
@@ -1124,10 +1163,13 @@ __global__ __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __re
     if (NEXT_ON) { H_PC_SPLIT1(pwn, 0); H_PC_SPLIT1(pwn, 1); }                                            \
     H_SB(); H_O_ROW(0, 1, 0); H_SB(); H_O_G1(3, 6); if (DMA_ON) { H8_DP(1, g1, DBUF); }                   \
     if (NEXT_ON) { H_PC_SPLIT1(pwn, 2); H_PC_SPLIT1(pwn, 3); }                                            \
-    H_SB(); H_O_ROW(0, 0, 0); H_SB(); H_O_G1(6, 8); if (DMA_ON) { H8_DMA_P(0, DBUF); H8_DMA_P(1, DBUF); } \
+    H_SB(); H_O_ROW(0, 0, 0); H_SB(); H_O_G1(6, 8);                                                       \
+    if ((DMA_ON) && !STAGE) { H8_DMA_P(0, DBUF); H8_DMA_P(1, DBUF); }                                     \
     if (NEXT_ON) { H_PC_SPLIT1(pwn, 4); H_PC_SPLIT1(pwn, 5); }                                            \
     H_TR_WAIT();                                                                                          \
-    H_SB(); H_O_ROW(1, 0, 1); H_SB(); if (DMA_ON) { H8_DMA_P(2, DBUF); H8_DMA_P(3, DBUF); }               \
+    H_SB(); H_O_ROW(1, 0, 1); H_SB();                                                                     \
+    if ((DMA_ON) && !STAGE) { H8_DMA_P(2, DBUF); H8_DMA_P(3, DBUF); }                                     \
+    if ((DMA_ON) && STAGE) { H8S_LOAD(STG_LD, (IT) + 3); } /* behind this iteration's plane DMAs: vmcnt order */ \
     if (NEXT_ON) { H_PC_NEXT_G0(0, 4); H_PC_SPLIT1(pwn, 6); }                                             \
     H_SB(); H_O_ROW(0, 1, 1); H_SB();                                                                     \
     if (NEXT_ON) { H_PC_SPLIT1(pwn, 7); }                                                                 \
@@ -1138,41 +1180,81 @@ __global__ __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __re
       _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_)                                                    \
         _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) pw[q_][s_] = pwn[q_][s_];                        \
     }                                                                                                     \
+    /* the tile of chunk IT + 2 (loaded one iteration ago) replaces the one read at the top of this iteration */ \
+    if (STAGE && (DMA_ON)) { H8S_WAIT_WR(); H8S_WRITE(STG_WR); }                                          \
   }
   H_DMA_BARRIER();
   H_TR_BASES(lds);
 #pragma unroll
   for (int f = 0; f < 8; ++f) trh_frag_n<0>(f, ta2_, trc_);
+  if (STAGE) { H8S_WRITE(stg0); }  // chunk 0's tile
   H8_LOAD_P(lds);
   H8_LOAD_REFS(lds);
+  H_TR_WAIT();  // (the assembly reads above: fragments and, with STAGE, the factors)
 #pragma unroll
   for (int s = 0; s < 8; ++s) H_PC_SPLIT1(pw, s);
+  if (STAGE) {  // chunk 1's tile takes its place (LDS operations of a wave execute in order); chunk 2's starts its way
+    H8S_WRITE(stg1);
+    H8S_LOAD(stg1, 2);
+  }
+// the barrier that opens an iteration: the plane / factor DMAs of the previous iteration have landed; with STAGE the
+// four register loads issued behind them stay in flight
+#ifndef H8_BAR_VM
+#define H8_BAR_VM 4
+#endif
+// (STAGE: the barrier instruction itself -- __syncthreads() carries a fence for which hipcc waits vmcnt(0))
+#define H8_BARRIER()                                                                        \
+  {                                                                                         \
+    if (STAGE) {                                                                            \
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(H8_BAR_VM) : "memory"); \
+    } else {                                                                                \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
+      __syncthreads();                                                                      \
+    }                                                                                       \
+  }
 
   int cur = 0;
-  for (int it = 0; it + 2 < nc; ++it) {
-    const int nxt = cur == kHBufs - 1 ? 0 : cur + 1;
-    const int nn = nxt == kHBufs - 1 ? 0 : nxt + 1;
-    if (it > 0) H_DMA_BARRIER();
-    const char* buf = lds + cur * kPc8Buf;
-    const char* nbuf = lds + nxt * kPc8Buf;
-    char* dbuf = lds + nn * kPc8Buf;
-    H_TR_BASES(buf);
-    H8_ITER(nbuf, dbuf, true, true);
-    cur = nxt;
+  // (two iterations per trip: the staging sets swap roles -- even iterations load into stg0 and hand stg1 to LDS)
+  for (int it = 0; it + 2 < nc; it += 2) {
+    {
+      const int nxt = cur == kHBufs - 1 ? 0 : cur + 1;
+      const int nn = nxt == kHBufs - 1 ? 0 : nxt + 1;
+      if (it > 0) H8_BARRIER();
+      const char* buf = lds + cur * kBuf;
+      const char* nbuf = lds + nxt * kBuf;
+      char* dbuf = lds + nn * kBuf;
+      H_TR_BASES(buf);
+      H8_ITER(nbuf, dbuf, true, true, stg0, stg1, it);
+      cur = nxt;
+    }
+    if (it + 3 < nc) {
+      const int nxt = cur == kHBufs - 1 ? 0 : cur + 1;
+      const int nn = nxt == kHBufs - 1 ? 0 : nxt + 1;
+      H8_BARRIER();
+      const char* buf = lds + cur * kBuf;
+      const char* nbuf = lds + nxt * kBuf;
+      char* dbuf = lds + nn * kBuf;
+      H_TR_BASES(buf);
+      H8_ITER(nbuf, dbuf, true, true, stg1, stg0, it + 1);
+      cur = nxt;
+    }
   }
+  // The staged loads of the last steady iteration (and the prologue's, for nc <= 2) are past the end and never used:
+  // they must land before their registers are given to anything else.
+  if (STAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (nc >= 2) {
     const int nxt = cur == kHBufs - 1 ? 0 : cur + 1;
-    if (nc > 2) H_DMA_BARRIER();
-    const char* buf = lds + cur * kPc8Buf;
-    const char* nbuf = lds + nxt * kPc8Buf;
+    if (nc > 2) H8_BARRIER();
+    const char* buf = lds + cur * kBuf;
+    const char* nbuf = lds + nxt * kBuf;
     H_TR_BASES(buf);
-    H8_ITER(nbuf, lds, false, true);
+    H8_ITER(nbuf, lds, false, true, stg0, stg0, 0);
     cur = nxt;
   }
   {
-    const char* buf = lds + cur * kPc8Buf;
+    const char* buf = lds + cur * kBuf;
     H_TR_BASES(buf);
-    H8_ITER(buf, lds, false, false);
+    H8_ITER(buf, lds, false, false, stg0, stg0, 0);
   }
   if (live) {
     float* orow = part_O + ((int64_t)split * B + xrow) * k3D;
@@ -1345,8 +1427,13 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
                      (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale, regularization,
                      inv_bs, ws.lse2, lse, gQ, ws.loss_acc, 1.0 / (double)batch_size, loss, (float*)nullptr,
                      (const float*)(ws.sc + 1), ldexpf(1.f, (int)kHPexp), ws.fac);
-  hipLaunchKernelGGL(inbatch2h_pc8_kernel, dim3(grid_c), dim3(512), 0, st, (const _Float16*)ws.Qh, B, nsplit_c,
-                     (const float*)ws.fac, nchunks / nsplit_q, (const float*)ws.Pmat, ws.part_O);
+  const char* pcm = getenv("ESR_IB2H_PC");  // "dma": the P' tiles as LDS-DMAs (one chunk ahead); default: staged loads
+  if (pcm && pcm[0] == 'd')
+    hipLaunchKernelGGL((inbatch2h_pc8_kernel<false>), dim3(grid_c), dim3(512), 0, st, (const _Float16*)ws.Qh, B, nsplit_c,
+                       (const float*)ws.fac, nchunks / nsplit_q, (const float*)ws.Pmat, ws.part_O);
+  else
+    hipLaunchKernelGGL((inbatch2h_pc8_kernel<true>), dim3(grid_c), dim3(512), 0, st, (const _Float16*)ws.Qh, B, nsplit_c,
+                       (const float*)ws.fac, nchunks / nsplit_q, (const float*)ws.Pmat, ws.part_O);
   // O_C' = 2^(eq + 14) sum_i (p_ij / l_i) q_i
   hipLaunchKernelGGL((inbatch3_merge_kernel<false>), dim3(mgrid), dim3(kBlock), 0, st, Cs, Qs, gc_rows, B, nsplit_c,
                      (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale, regularization,

@@ -101,6 +101,29 @@ __global__ __launch_bounds__(256) void mfma_f32_probe_kernel(int iters, float* _
   if (s == 12345.678f) sink[0] = s;
 }
 
+// Pure-read HBM bandwidth: every workgroup streams its own contiguous slice with `UNROLL` 16-byte loads in flight per
+// lane (nt = streaming loads).  What a read-only kernel can reach on this box (pass C of the fp16 in-batch path reads the
+// B x B probabilities at 3.8 TB/s).
+typedef float pf4 __attribute__((ext_vector_type(4)));
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(256) void hbm_read_probe_kernel(const pf4* __restrict__ x, int64_t n16, float* sink) {
+  const int64_t per = (n16 + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = (int64_t)blockIdx.x * per, hi = min(n16, lo + per);
+  pf4 a = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t i = lo + threadIdx.x; i < hi; i += (int64_t)256 * UNROLL) {
+    pf4 v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t k = i + (int64_t)256 * u;
+      const pf4 z = {0.f, 0.f, 0.f, 0.f};
+      v[u] = k < hi ? (NT ? __builtin_nontemporal_load(x + k) : x[k]) : z;
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) a += v[u];
+  }
+  if (a[0] + a[1] + a[2] + a[3] == 12345.678f) sink[0] = a[0];
+}
+
 }  // namespace esr
 
 using namespace esr;
@@ -125,6 +148,18 @@ int esr_probe_mfma(int dtype, int workgroups, int iters, float* sink, double* fl
   else
     hipLaunchKernelGGL(mfma_f32_probe_kernel, dim3(workgroups), dim3(256), 0, as_stream(stream), iters, sink);
   return check_launch("esr_probe_mfma");
+}
+
+int esr_probe_hbm_read(const void* x, int64_t bytes, int workgroups, int nontemporal, float* sink, esr_stream_t stream) {
+  ESR_REQUIRE(x && bytes >= 16 && workgroups > 0 && sink && ((uintptr_t)x & 15) == 0, "esr_probe_hbm_read: bad arguments");
+  const int64_t n16 = bytes / 16;
+  if (nontemporal)
+    hipLaunchKernelGGL((hbm_read_probe_kernel<8, true>), dim3(workgroups), dim3(256), 0, as_stream(stream),
+                       (const pf4*)x, n16, sink);
+  else
+    hipLaunchKernelGGL((hbm_read_probe_kernel<8, false>), dim3(workgroups), dim3(256), 0, as_stream(stream),
+                       (const pf4*)x, n16, sink);
+  return check_launch("esr_probe_hbm_read");
 }
 
 }  // extern "C"
