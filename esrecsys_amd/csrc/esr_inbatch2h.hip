@@ -503,7 +503,11 @@ __device__ __forceinline__ f16x8 lds_b128(uint32_t addr) {
   _Pragma("unroll") for (int db_ = 0; db_ < 4; ++db_)                                                     \
     acc[db_] = H_MFMA(ta2_[G][db_][PL_A], pb[PL_P][G], acc[db_]);
 #endif
+#if defined(H_PROBE_PC_NOFRAG)
+#define H_O_G1(F0, F1)
+#else
 #define H_O_G1(F0, F1) { _Pragma("unroll") for (int f_ = (F0); f_ < (F1); ++f_) trh_frag_n<1>(f_, ta2_, trc_); }
+#endif
 #define H_PB()                                                                                            \
   f16x8 pb[2][2];                                                                                         \
   _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_)                                                        \
@@ -1008,6 +1012,9 @@ __global__ __launch_bounds__(256) void inbatch2h_q2_kernel(const _Float16* __res
 // 4-wave workgroups with the tile loaded straight into registers from a [streamed][owned] layout, two to four per CU;
 // this form with that layout (ds_read_b128 of row j); this form.
 // -----------------------------------------------------------------------------------------------------------------
+#if defined(H_PROBE_PC_NOSPLIT)  /* timing probe only: pass C without the fp16 split of its probabilities */
+#define H_PC_SPLIT1(PW, S) { PW[0][S] = __float_as_uint(p1[2 * (S)]); PW[1][S] = __float_as_uint(rf[2 * (S) + 1]); }
+#else
 #define H_PC_SPLIT1(PW, S)                                                                                \
   {                                                                                                       \
     const float e0_ = p1[2 * (S)] * rf[2 * (S)], e1_ = p1[2 * (S) + 1] * rf[2 * (S) + 1];                 \
@@ -1016,7 +1023,12 @@ __global__ __launch_bounds__(256) void inbatch2h_q2_kernel(const _Float16* __res
     PW[0][S] = __builtin_bit_cast(uint32_t, pa_);                                                         \
     PW[1][S] = __builtin_bit_cast(uint32_t, pq_);                                                         \
   }
+#endif
+#if defined(H_PROBE_PC_NOFRAG)  /* timing probe only: pass C without the transposing fragment reads (stale A operands) */
+#define H_PC_NEXT_G0(F0, F1)
+#else
 #define H_PC_NEXT_G0(F0, F1) { _Pragma("unroll") for (int f_ = (F0); f_ < (F1); ++f_) trh_frag_n<0>(f_, ta2_, trn_); }
+#endif
 constexpr int kPc8Wave = 4096 + 256;
 constexpr int kPc8Buf = 2 * kPlaneBytes + 8 * kPc8Wave;  // 51200: three of them are 150 KB of the CU's 160
 constexpr int kPc8Owned = 256;
@@ -1039,8 +1051,13 @@ __global__ __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __re
   constexpr int kWaveArea = STAGE ? 256 : kPc8Wave;               // per-wave part of a ring slot: factors (+ P' tile)
   constexpr int kBuf = 2 * kPlaneBytes + 8 * kWaveArea;           // ring slot
   constexpr int kFacOff = STAGE ? 0 : 4096;                       // factors inside the per-wave part
-  constexpr int kPArea = kHBufs * kBuf;                           // STAGE: the wave-private P' tiles behind the ring
-  __shared__ __attribute__((aligned(16))) char lds[kHBufs * kBuf + (STAGE ? 8 * 4096 : 0)];
+  // STAGE: a 4-slot ring, planes and factors fetched THREE chunks ahead.  Two ahead (3 slots), the DMAs issued during
+  // iteration it were needed right after the barrier that ends it: the stamps (H_TIMING=2) showed 1042 of 3001 cycles
+  // per iteration waiting there.
+  constexpr int kRing = STAGE ? 4 : kHBufs;
+  constexpr int kAheadSlots = kRing - 1;
+  constexpr int kPArea = kRing * kBuf;                            // STAGE: the wave-private P' tiles behind the ring
+  __shared__ __attribute__((aligned(16))) char lds[kRing * kBuf + (STAGE ? 8 * 4096 : 0)];
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int j = lane & 31, h = lane >> 5;
@@ -1122,6 +1139,7 @@ __global__ __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __re
     *reinterpret_cast<pf4*>(lds + kPArea + w * 4096 + g_ * 1024 + lane * 16) = STG[g_];
   H8_DMA_ALL(lds);
   if (nc > 1) H8_DMA_ALL(lds + kBuf);
+  if (STAGE && nc > 2) H8_DMA_ALL(lds + 2 * kBuf);
   if (STAGE) { H8S_LOAD(stg0, 0); H8S_LOAD(stg1, 1); }
   float p1[16], rf[16];
   uint32_t pw[2][8], pwn[2][8];
@@ -1148,17 +1166,17 @@ __global__ __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __re
     }                                                                                                     \
     rf[4 * g4_] = lv_.x; rf[4 * g4_ + 1] = lv_.y; rf[4 * g4_ + 2] = lv_.z; rf[4 * g4_ + 3] = lv_.w;       \
   }
-#define H8_ITER(NBUF, DBUF, DMA_ON, NEXT_ON, STG_LD, STG_WR, IT)                                           \
+#define H8_ITER(NBUF, N2BUF, DBUF, DMA_ON, NEXT_ON, STG_LD, STG_WR, IT)                                          \
   {                                                                                                       \
     H_PB();                                                                                               \
     if (NEXT_ON) {                                                                                        \
-      H8_LOAD_P(NBUF);                                                                                    \
-      H8_LOAD_REFS(NBUF);                                                                                 \
+      if (!STAGE) { H8_LOAD_P(NBUF); H8_LOAD_REFS(NBUF); }                                                \
       const uint32_t slot_ = (uint32_t)((NBUF) - lds);                                                    \
       _Pragma("unroll") for (int db_ = 0; db_ < 4; ++db_) { trn_[db_][0] = trb_[db_][0] + slot_; trn_[db_][1] = trb_[db_][1] + slot_; } \
     }                                                                                                     \
     if (DMA_ON) { H8_DMA_FAC(DBUF); }                                                                     \
-    H_TR_WAIT();                                                                                          \
+    if (!STAGE) { H_TR_WAIT(); }                                                                          \
+    if (DMA_ON) { H_TICK(tk2); }                                                                          \
     H_SB(); H_O_ROW(1, 0, 0); H_SB(); H_O_G1(0, 3); if (DMA_ON) { H8_DP(0, g0, DBUF); }                   \
     if (NEXT_ON) { H_PC_SPLIT1(pwn, 0); H_PC_SPLIT1(pwn, 1); }                                            \
     H_SB(); H_O_ROW(0, 1, 0); H_SB(); H_O_G1(3, 6); if (DMA_ON) { H8_DP(1, g1, DBUF); }                   \
@@ -1167,6 +1185,7 @@ __global__ __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __re
     if ((DMA_ON) && !STAGE) { H8_DMA_P(0, DBUF); H8_DMA_P(1, DBUF); }                                     \
     if (NEXT_ON) { H_PC_SPLIT1(pwn, 4); H_PC_SPLIT1(pwn, 5); }                                            \
     H_TR_WAIT();                                                                                          \
+    if (DMA_ON) { H_TICK(tk3); H_TIMING_ACC(); }                                                          \
     H_SB(); H_O_ROW(1, 0, 1); H_SB();                                                                     \
     if ((DMA_ON) && !STAGE) { H8_DMA_P(2, DBUF); H8_DMA_P(3, DBUF); }                                     \
     if ((DMA_ON) && STAGE) { H8S_LOAD(STG_LD, (IT) + 3); } /* behind this iteration's plane DMAs: vmcnt order */ \
@@ -1181,7 +1200,10 @@ __global__ __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __re
         _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) pw[q_][s_] = pwn[q_][s_];                        \
     }                                                                                                     \
     /* the tile of chunk IT + 2 (loaded one iteration ago) replaces the one read at the top of this iteration */ \
-    if (STAGE && (DMA_ON)) { H8S_WAIT_WR(); H8S_WRITE(STG_WR); }                                          \
+    /* ... and is read back at once, with the factors of that chunk (both wave-private: no barrier in between), so   \
+       that the LDS latency of these 20 reads falls into the wait at the barrier, not behind it where all eight      \
+       waves would sit it out together (stamps: 515 cycles per iteration) */                                        \
+    if (STAGE && (DMA_ON)) { H8S_WAIT_WR(); H8S_WRITE(STG_WR); H8_LOAD_P(lds); H8_LOAD_REFS(N2BUF); H_TR_WAIT(); } \
   }
   H_DMA_BARRIER();
   H_TR_BASES(lds);
@@ -1196,11 +1218,15 @@ __global__ __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __re
   if (STAGE) {  // chunk 1's tile takes its place (LDS operations of a wave execute in order); chunk 2's starts its way
     H8S_WRITE(stg1);
     H8S_LOAD(stg1, 2);
+    H8_LOAD_P(lds);
+    H8_LOAD_REFS(lds + kBuf);
+    H_TR_WAIT();
   }
-// the barrier that opens an iteration: the plane / factor DMAs of the previous iteration have landed; with STAGE the
-// four register loads issued behind them stay in flight
+// the barrier that opens an iteration.  Without STAGE: the plane / factor / tile DMAs of the previous iteration have
+// landed.  With STAGE the chunk read next was fetched two iterations ago, in front of the staged loads that
+// H8S_WAIT_WR has just waited for: everything the previous iteration issued (3 DMAs + 4 loads) stays in flight
 #ifndef H8_BAR_VM
-#define H8_BAR_VM 4
+#define H8_BAR_VM 7
 #endif
 // (STAGE: the barrier instruction itself -- __syncthreads() carries a fence for which hipcc waits vmcnt(0))
 #define H8_BARRIER()                                                                        \
@@ -1213,29 +1239,35 @@ __global__ __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __re
     }                                                                                       \
   }
 
+  H_TIMING_DECL();
+  H_TIMING_START();
   int cur = 0;
   // (two iterations per trip: the staging sets swap roles -- even iterations load into stg0 and hand stg1 to LDS)
   for (int it = 0; it + 2 < nc; it += 2) {
     {
-      const int nxt = cur == kHBufs - 1 ? 0 : cur + 1;
-      const int nn = nxt == kHBufs - 1 ? 0 : nxt + 1;
+      const int nxt = cur == kRing - 1 ? 0 : cur + 1;
+      const int nn = (cur + kAheadSlots) % kRing;
+      H_TICK(tk0);
       if (it > 0) H8_BARRIER();
+      H_TICK(tk1);
       const char* buf = lds + cur * kBuf;
       const char* nbuf = lds + nxt * kBuf;
       char* dbuf = lds + nn * kBuf;
       H_TR_BASES(buf);
-      H8_ITER(nbuf, dbuf, true, true, stg0, stg1, it);
+      H8_ITER(nbuf, lds + ((cur + 2) % kRing) * kBuf, dbuf, true, true, stg0, stg1, it);
       cur = nxt;
     }
     if (it + 3 < nc) {
-      const int nxt = cur == kHBufs - 1 ? 0 : cur + 1;
-      const int nn = nxt == kHBufs - 1 ? 0 : nxt + 1;
+      const int nxt = cur == kRing - 1 ? 0 : cur + 1;
+      const int nn = (cur + kAheadSlots) % kRing;
+      H_TICK(tk0);
       H8_BARRIER();
+      H_TICK(tk1);
       const char* buf = lds + cur * kBuf;
       const char* nbuf = lds + nxt * kBuf;
       char* dbuf = lds + nn * kBuf;
       H_TR_BASES(buf);
-      H8_ITER(nbuf, dbuf, true, true, stg1, stg0, it + 1);
+      H8_ITER(nbuf, lds + ((cur + 2) % kRing) * kBuf, dbuf, true, true, stg1, stg0, it + 1);
       cur = nxt;
     }
   }
@@ -1243,19 +1275,20 @@ __global__ __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __re
   // they must land before their registers are given to anything else.
   if (STAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (nc >= 2) {
-    const int nxt = cur == kHBufs - 1 ? 0 : cur + 1;
+    const int nxt = cur == kRing - 1 ? 0 : cur + 1;
     if (nc > 2) H8_BARRIER();
     const char* buf = lds + cur * kBuf;
     const char* nbuf = lds + nxt * kBuf;
     H_TR_BASES(buf);
-    H8_ITER(nbuf, lds, false, true, stg0, stg0, 0);
+    H8_ITER(nbuf, lds, lds, false, true, stg0, stg0, 0);
     cur = nxt;
   }
   {
     const char* buf = lds + cur * kBuf;
     H_TR_BASES(buf);
-    H8_ITER(buf, lds, false, false, stg0, stg0, 0);
+    H8_ITER(buf, lds, lds, false, false, stg0, stg0, 0);
   }
+  H_TIMING_WRITE(!H_TIMING_Q && w < 4);
   if (live) {
     float* orow = part_O + ((int64_t)split * B + xrow) * k3D;
 #pragma unroll

@@ -327,9 +327,15 @@ def train_steps(state, batches, num_steps, regularization, batch_size):
     from collections import deque
     ctx = _FusedTripletLoop(state, num_steps, _LOOP_DEPTH)
     if _LOOP_DEPTH == 0:
+        import time
+        t_host = time.perf_counter()
         for k in range(num_steps):
             scene, pos, neg = next(it)
             ctx.step(k, (None,) + ctx.ids(scene, pos, neg), regularization, batch_size)
+        if _os.environ.get("ESR_TRACE_HOST") == "1":  # is the loop issuing steps faster than the GPU retires them?
+            import logging
+            logging.warning("train_steps: host issued %d steps in %.1f us each (no sync yet)", num_steps,
+                            (time.perf_counter() - t_host) / num_steps * 1e6)
         return state.replace(step=state.step + num_steps), ctx.losses[:num_steps]
     queue, fetched = deque(), 0
     for k in range(num_steps):

@@ -237,7 +237,9 @@ def train_epoch(state, steps_per_epoch, train_it):
         # step k mostly runs in the gaps after it -- one ahead, its second radix pass (23 us) still sat between step k
         # and step k + 1 (profiles/r2/glove_kernel_stats.csv: the first scatter "takes" 106 us, stretched over the step).
         from collections import deque
+        import time
         queue, fetched = deque(), 0
+        t_host = time.perf_counter()
         for k in range(steps_per_epoch):
             while fetched < steps_per_epoch and len(queue) < _PRESORT_DEPTH + 1:
                 inputs, targets = next(train_it)
@@ -247,6 +249,9 @@ def train_epoch(state, steps_per_epoch, train_it):
                 queue.append((inputs, targets))
             inputs, targets = queue.popleft()
             ctx.step(k, inputs, targets)
+        if os.environ.get("ESR_TRACE_HOST") == "1":  # is the loop issuing steps faster than the GPU retires them?
+            logging.warning("train_epoch: host issued %d steps in %.1f us each (no sync yet)", steps_per_epoch,
+                            (time.perf_counter() - t_host) / steps_per_epoch * 1e6)
         state = state.replace(step=state.step + steps_per_epoch)
         return state, float(ctx.losses[:steps_per_epoch].mean())
     epoch_loss = []

@@ -5,4 +5,4 @@ done
 cd ../..
 echo "pass Q, 1 WG/CU"; ESR_IB2H_Q_PER_CU=1 IB2H_LIB=libib2h_t1.so IB2H_ITERS=62 timeout 120 python scripts/ib2h_timing.py 2>&1 | grep -v amdgpu.ids
 echo "pass Q, 2 WG/CU"; ESR_IB2H_Q_PER_CU=2 IB2H_LIB=libib2h_t1.so IB2H_ITERS=30 timeout 120 python scripts/ib2h_timing.py 2>&1 | grep -v amdgpu.ids
-# (pass C: the 8-wave kernel carries no stamps; its bound is the HBM read of P, scripts/read_bw_probe.py)
+echo "pass C (phases: barrier wait / top of the iteration up to the first LDS wait / from there to the second; the rest of the sum is the second half)"; IB2H_LIB=libib2h_t2.so IB2H_ITERS=30 timeout 120 python scripts/ib2h_timing.py 2>&1 | grep -v amdgpu.ids

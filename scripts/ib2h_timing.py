@@ -25,6 +25,7 @@ lib.esr_ib2h_debug_read(buf)
 e = np.array(buf[4096:], dtype=np.float64).reshape(1024, 4)
 a = np.array(buf[:4096], dtype=np.float64).reshape(256, 4, 4)
 rt = e[:, 2] - e[:, 1]
+print("total per iteration %.0f cycles" % (a[..., 3].mean() / ITERS))
 print("per-iteration cycles: barrier %.0f  phase1 %.0f  phase2 %.0f  (sum %.0f); loop %.1f us at %.0f MHz; kernel entry->loop end %.1f..%.1f us"
       % (a[..., 0].mean() / ITERS, a[..., 1].mean() / ITERS, a[..., 2].mean() / ITERS, a[..., :3].sum(-1).mean() / ITERS,
          rt.mean() / 100, a[..., 3].mean() / (rt.mean() / 100), (e[:, 2] - e[:, 0].min()).min() / 100,
