@@ -1004,13 +1004,11 @@ __global__ __launch_bounds__(256) void inbatch2h_q2_kernel(const _Float16* __res
 // fetched once for eight waves (two DMA instructions per wave and chunk).  The P' tiles come through LDS too: pass Q
 // stored them in ITS register order (16-byte pieces [m][h][a] = P'[streamed 8 m + 4 h + 0..3][owned a]); here the
 // roles are swapped -- this lane's owned row j is pass Q's streamed row (m, h, c) = (j / 8, j / 4 % 2, j % 4), and it
-// needs the 16 values of pass Q's owned rows a = 8 g + 4 h' + e.  As LDS-DMAs the tile is four fully coalesced 1 KB
-// instructions per wave, asynchronous and as deep in flight as the plane tiles (no staging registers), and the
-// transposition is sixteen ds_read_b32 (piece index XOR-swizzled on the source side so that the 32 lanes of a half
-// wave, which differ in (m, h, c), fall on 32 banks).  Ring slot = planes (16 KB) + per wave [P' tile 4 KB | factors
-// 256 B].  Measured forms of this pass (all 79-85 us, i.e. bound by reading B^2 x 4 bytes at the box's 4.0 TB/s):
-// 4-wave workgroups with the tile loaded straight into registers from a [streamed][owned] layout, two to four per CU;
-// this form with that layout (ds_read_b128 of row j); this form.
+// needs the 16 values of pass Q's owned rows a = 8 g + 4 h' + e.  The tile lands in LDS as 16-byte pieces (piece index
+// XOR-swizzled on the source side so that the 32 lanes of a half wave, which differ in (m, h, c), fall on 32 banks) and
+// the transposition is sixteen ds_read_b32.  Two ways into LDS (template parameter STAGE, see the kernel).
+// Clock and phases: scripts/gpu_ib2h_timing.sh (-DH_TIMING=2); read ceiling of the box: esr_probe_hbm_read (7.0-7.2
+// TB/s -- the "4.0 TB/s read bound" of earlier notes was torch.sum's rate).
 // -----------------------------------------------------------------------------------------------------------------
 #if defined(H_PROBE_PC_NOSPLIT)  /* timing probe only: pass C without the fp16 split of its probabilities */
 #define H_PC_SPLIT1(PW, S) { PW[0][S] = __float_as_uint(p1[2 * (S)]); PW[1][S] = __float_as_uint(rf[2 * (S) + 1]); }
@@ -1041,8 +1039,9 @@ __device__ __forceinline__ uint32_t dmah8_off0(int64_t B, int64_t chunk, int t) 
 // chunk issued three chunks ahead, written to a wave-private 4 KB LDS tile one chunk before use.  As LDS-DMAs into the
 // 3-slot ring they could only be one chunk ahead (the slot of chunk it + 1 is read during iteration it), every barrier
 // waited for them (vmcnt(0)), and the pass ran at 3.8 TB/s of the 7.0-7.2 TB/s a read-only kernel reaches on the box
-// (esr_probe_hbm_read): a burst per iteration, then the wait for its tail.  With the staged loads the barrier waits
-// vmcnt(4) -- the four youngest loads stay in flight across it -- and the ring holds planes and factors only.
+// (esr_probe_hbm_read): a burst per iteration, then the wait for its tail.  With the staged loads the ring holds
+// planes and factors only, has four slots (fetched three chunks ahead) and its barrier waits vmcnt(7): everything the
+// previous iteration issued stays in flight across it.
 template <bool STAGE>
 __global__ __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __restrict__ Yr, int64_t B, int nsplit,
                                                            const float* __restrict__ fac, int nc_q,
