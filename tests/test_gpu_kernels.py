@@ -515,6 +515,35 @@ def test_inbatch_f16x2_64_row_waves_equal_32_row_waves(dev, B, monkeypatch):
         assert bool(torch.isfinite(b).all()) and rel_err(N(b), N(a)) <= 2e-6
 
 
+@pytest.mark.parametrize("B", [128, 256, 384, 768, 1280, 1664, 4096])
+def test_inbatch_f16x2_pass_c_forms_agree(dev, B, monkeypatch):
+    """Pass C streams the stored probabilities either through registers three chunks ahead (default) or as LDS-DMAs one
+    chunk ahead (ESR_IB2H_PC=dma): the same values reach the same MFMAs in the same order, so the two forms must agree
+    BIT FOR BIT -- at chunk counts per split of 1, 2, 3, 5, 13 and 16 (prologue only, one or two tail iterations, odd and
+    even trips of the two-iteration loop) -- and both with the exact-f32 kernel to the path's tolerance.  A staged load
+    left in flight past the end of a column once corrupted the epilogue of the 1- and 2-chunk launches."""
+    from esrecsys_amd import ops
+    g = torch.Generator(device=dev).manual_seed(7 * B)
+    D = 128
+    q = torch.randn((B, D), generator=g, device=dev) * D ** -0.5
+    c = torch.randn((B, D), generator=g, device=dev) * D ** -0.5
+    outs = {}
+    for form in ("stage", "dma"):
+        monkeypatch.setenv("ESR_IB2H_PC", form)
+        for rep in range(3):  # repeated: a dangling load shows up as run-to-run differences
+            cur = [t.clone() for t in ops.inbatch_softmax_fwd_bwd(q, c, -6.0, 0.1, 77.0, precision="f16x2")]
+            assert all(bool(torch.isfinite(t).all()) for t in cur)
+            if form in outs:
+                assert all(torch.equal(a, b) for a, b in zip(outs[form], cur)), (form, rep)
+            outs[form] = cur
+    for a, b in zip(outs["stage"], outs["dma"]):
+        assert torch.equal(a, b)
+    monkeypatch.delenv("ESR_IB2H_PC", raising=False)
+    ref = ops.inbatch_softmax_fwd_bwd(q, c, -6.0, 0.1, 77.0, precision="f32")
+    for a, b in zip(outs["stage"], ref):
+        assert rel_err(N(a), N(b)) <= 1e-5
+
+
 def test_inbatch_f16x2_largest_batch_against_exact_f32(dev):
     """B = 16384 is the largest batch of the two-plane path (1 GiB of stored probabilities): against the exact-f32 MFMA
     kernel on the same inputs (the fp64 oracle needs 2 GiB per B x B matrix at this size), plus the column-sum property
