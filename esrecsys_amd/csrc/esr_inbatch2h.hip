@@ -1027,8 +1027,7 @@ __global__ __launch_bounds__(256) void inbatch2h_q2_kernel(const _Float16* __res
 #else
 #define H_PC_NEXT_G0(F0, F1) { _Pragma("unroll") for (int f_ = (F0); f_ < (F1); ++f_) trh_frag_n<0>(f_, ta2_, trn_); }
 #endif
-constexpr int kPc8Wave = 4096 + 256;
-constexpr int kPc8Buf = 2 * kPlaneBytes + 8 * kPc8Wave;  // 51200: three of them are 150 KB of the CU's 160
+constexpr int kPc8Wave = 4096 + 256;  // without STAGE: three ring slots of 2 planes + 8 of these are 150 KB of the CU's 160
 constexpr int kPc8Owned = 256;
 template <int K>
 __device__ __forceinline__ uint32_t dmah8_off0(int64_t B, int64_t chunk, int t) {  // piece K = plane K, 512 threads
