@@ -73,6 +73,8 @@ SIGNATURES = {
     "esr_segment_sort_workspace_bytes": (c_size, [c_i64]),
     "esr_segment_sort_ids": (c_int, [c_i32p, c_i64, c_i64, c_i32p, c_i32p, c_vp, c_size, c_vp]),
     "esr_segment_sort_ids_multi": (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_i32p, c_i32p, c_vp, c_size, c_vp]),
+    "esr_segment_sort_batched_workspace_bytes": (c_size, [c_i64, c_int]),
+    "esr_segment_sort_ids_batched": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_i64, c_i32p, c_i32p, c_vp, c_size, c_vp]),
     "esr_sparse_adagrad_scatter": (c_int, [c_vp, c_int, c_f32p, c_i64, c_int, c_i32p, c_i32p, c_i64, c_f32p, c_f32,
                                            c_f32, c_vp]),
     "esr_concat_offset_ids": (c_int, [c_vp, c_vp, c_vp, c_int, c_i32p, c_vp]),

@@ -155,12 +155,17 @@ __device__ __forceinline__ void tile_bitonic(uint32_t& k0, uint32_t& k1, uint32_
   }
 }
 
+// (bodies shared by the one-list kernels and the batched ones, where blockIdx.y picks the list: `bx` = the workgroup's
+// index inside its own list)
+constexpr int kMaxSortBatch = 8;
+struct SortSegsBatch {
+  SortSegs b[kMaxSortBatch];
+};
 template <int TB>
-__global__ __launch_bounds__((1 << TB) / 2) void tile_sort_kernel(SortSegs ids, int n, uint32_t* __restrict__ tiles,
-                                                                 uint32_t* __restrict__ splitters) {
+__device__ __forceinline__ void tile_sort_body(const SortSegs& ids, int n, uint32_t* __restrict__ tiles,
+                                               uint32_t* __restrict__ splitters, uint32_t* key, int bx) {
   constexpr int kTile = 1 << TB, kHalf = kTile / 2;
-  __shared__ uint32_t key[2 * kTile];
-  const int t = threadIdx.x, base = blockIdx.x * kTile;
+  const int t = threadIdx.x, base = bx * kTile;
   uint32_t k0, k1;
   {
     const int g0 = base + t, g1 = base + t + kHalf;
@@ -174,20 +179,34 @@ __global__ __launch_bounds__((1 << TB) / 2) void tile_sort_kernel(SortSegs ids, 
   // one cache line per splitter and workgroup)
   if ((t & (kSplitEvery - 1)) == kSplitEvery - 1) {
     constexpr int kSplitPerTile = kTile / kSplitEvery;
-    splitters[blockIdx.x * kSplitPerTile + t / kSplitEvery] = k0;
-    splitters[blockIdx.x * kSplitPerTile + (t + kHalf) / kSplitEvery] = k1;
+    splitters[bx * kSplitPerTile + t / kSplitEvery] = k0;
+    splitters[bx * kSplitPerTile + (t + kHalf) / kSplitEvery] = k1;
   }
+}
+template <int TB>
+__global__ __launch_bounds__((1 << TB) / 2) void tile_sort_kernel(SortSegs ids, int n, uint32_t* __restrict__ tiles,
+                                                                 uint32_t* __restrict__ splitters) {
+  __shared__ uint32_t key[2 << TB];
+  tile_sort_body<TB>(ids, n, tiles, splitters, key, blockIdx.x);
+}
+// ws_stride: words between the (tiles | splitters) areas of consecutive lists
+template <int TB>
+__global__ __launch_bounds__((1 << TB) / 2) void tile_sort_batched_kernel(SortSegsBatch sb, int n,
+                                                                         uint32_t* __restrict__ tiles,
+                                                                         uint32_t* __restrict__ splitters,
+                                                                         int64_t ws_stride) {
+  __shared__ uint32_t key[2 << TB];
+  const int y = blockIdx.y;
+  tile_sort_body<TB>(sb.b[y], n, tiles + y * ws_stride, splitters + y * ws_stride, key, blockIdx.x);
 }
 
 // A list that fits ONE tile: the same network, the sorted composites unpacked straight into (sorted ids, perm) -- one
 // launch, ~5 us.  The one-workgroup kernel above (64-bit keys in LDS, a barrier per step) took 39 us for the 4096 ids of a
 // GloVe step at the reference's default batch (wikipedia/train_cooccurence.py:45): more than the rest of that step.
 template <int TB>
-__global__ __launch_bounds__((1 << TB) / 2) void tile_sort_single_kernel(SortSegs ids, int n,
-                                                                        int32_t* __restrict__ sorted_ids,
-                                                                        int32_t* __restrict__ perm) {
+__device__ __forceinline__ void tile_sort_single_body(const SortSegs& ids, int n, int32_t* __restrict__ sorted_ids,
+                                                      int32_t* __restrict__ perm, uint32_t* key) {
   constexpr int kTile = 1 << TB, kHalf = kTile / 2;
-  __shared__ uint32_t key[2 * kTile];
   const int t = threadIdx.x;
   uint32_t k0 = t < n ? ((uint32_t)seg_id(ids, t) << TB) | (uint32_t)t : 0xFFFFFFFFu;
   uint32_t k1 = t + kHalf < n ? ((uint32_t)seg_id(ids, t + kHalf) << TB) | (uint32_t)(t + kHalf) : 0xFFFFFFFFu;
@@ -201,6 +220,21 @@ __global__ __launch_bounds__((1 << TB) / 2) void tile_sort_single_kernel(SortSeg
     perm[t + kHalf] = (int32_t)(k1 & (kTile - 1));
   }
 }
+template <int TB>
+__global__ __launch_bounds__((1 << TB) / 2) void tile_sort_single_kernel(SortSegs ids, int n,
+                                                                        int32_t* __restrict__ sorted_ids,
+                                                                        int32_t* __restrict__ perm) {
+  __shared__ uint32_t key[2 << TB];
+  tile_sort_single_body<TB>(ids, n, sorted_ids, perm, key);
+}
+template <int TB>
+__global__ __launch_bounds__((1 << TB) / 2) void tile_sort_single_batched_kernel(SortSegsBatch sb, int n,
+                                                                                int32_t* __restrict__ sorted_ids,
+                                                                                int32_t* __restrict__ perm) {
+  __shared__ uint32_t key[2 << TB];
+  const int y = blockIdx.x;
+  tile_sort_single_body<TB>(sb.b[y], n, sorted_ids + (int64_t)y * n, perm + (int64_t)y * n, key);
+}
 
 // Two-level search: the last id of every 32-key block of every tile ("splitters", <= 4 KB) is staged in LDS and
 // searched there; only the final 32-key window -- one 128-byte line -- is searched in global memory.  A plain
@@ -208,16 +242,15 @@ __global__ __launch_bounds__((1 << TB) / 2) void tile_sort_single_kernel(SortSeg
 // 16 lanes per element, one per tile: the searches of one element run side by side and their counts are summed
 // with shuffles (one thread walking all tiles was latency-bound at one wave per SIMD: 26 us for 24 576 keys).
 template <int TB>
-__global__ __launch_bounds__(kBlock) void tile_rank_kernel(const uint32_t* __restrict__ tiles,
-                                                          const uint32_t* __restrict__ splitters, int n, int ntiles,
-                                                          int32_t* __restrict__ sorted_ids,
-                                                          int32_t* __restrict__ perm) {
+__device__ __forceinline__ void tile_rank_body(const uint32_t* __restrict__ tiles,
+                                               const uint32_t* __restrict__ splitters, int n, int ntiles,
+                                               int32_t* __restrict__ sorted_ids, int32_t* __restrict__ perm,
+                                               uint32_t* spl, int bx) {
   constexpr int kTile = 1 << TB, kSplitPerTile = kTile / kSplitEvery;
-  __shared__ uint32_t spl[kMidTiles * kSplitPerTile];
   for (int i = threadIdx.x; i < ntiles * kSplitPerTile; i += kBlock) spl[i] = splitters[i] >> TB;
   __syncthreads();
   const int u = threadIdx.x & (kMidTiles - 1);                                 // the tile this lane searches
-  const int g = (blockIdx.x * kBlock + threadIdx.x) / kMidTiles;                // slot g of the tiled array
+  const int g = (bx * kBlock + threadIdx.x) / kMidTiles;                        // slot g of the tiled array
   const int mine = g / kTile;
   const bool live = g < ntiles * kTile && g - mine * kTile < n - mine * kTile;  // not padding
   const uint32_t c = live ? tiles[g] : 0u;
@@ -248,6 +281,25 @@ __global__ __launch_bounds__(kBlock) void tile_rank_kernel(const uint32_t* __res
   }
 }
 template <int TB>
+__global__ __launch_bounds__(kBlock) void tile_rank_kernel(const uint32_t* __restrict__ tiles,
+                                                          const uint32_t* __restrict__ splitters, int n, int ntiles,
+                                                          int32_t* __restrict__ sorted_ids,
+                                                          int32_t* __restrict__ perm) {
+  __shared__ uint32_t spl[kMidTiles * ((1 << TB) / kSplitEvery)];
+  tile_rank_body<TB>(tiles, splitters, n, ntiles, sorted_ids, perm, spl, blockIdx.x);
+}
+template <int TB>
+__global__ __launch_bounds__(kBlock) void tile_rank_batched_kernel(const uint32_t* __restrict__ tiles,
+                                                                  const uint32_t* __restrict__ splitters, int n,
+                                                                  int ntiles, int64_t ws_stride,
+                                                                  int32_t* __restrict__ sorted_ids,
+                                                                  int32_t* __restrict__ perm) {
+  __shared__ uint32_t spl[kMidTiles * ((1 << TB) / kSplitEvery)];
+  const int y = blockIdx.y;
+  tile_rank_body<TB>(tiles + y * ws_stride, splitters + y * ws_stride, n, ntiles, sorted_ids + (int64_t)y * n,
+                     perm + (int64_t)y * n, spl, blockIdx.x);
+}
+template <int TB>
 static void launch_tile_sort(const SortSegs& sg, int n, uint32_t* tiles, int32_t* sorted_ids, int32_t* perm,
                              hipStream_t st) {
   constexpr int kTile = 1 << TB;
@@ -256,6 +308,20 @@ static void launch_tile_sort(const SortSegs& sg, int n, uint32_t* tiles, int32_t
   hipLaunchKernelGGL((tile_sort_kernel<TB>), dim3(ntiles), dim3(kTile / 2), 0, st, sg, n, tiles, splitters);
   hipLaunchKernelGGL((tile_rank_kernel<TB>), dim3((int)cdiv((int64_t)ntiles * kTile * kMidTiles, kBlock)), dim3(kBlock), 0,
                      st, (const uint32_t*)tiles, (const uint32_t*)splitters, n, ntiles, sorted_ids, perm);
+}
+
+constexpr int64_t kMidWsWords = kMidSortMax + kMidSortMax / kSplitEvery;  // one list's (tiles | splitters) area
+template <int TB>
+static void launch_tile_sort_batched(const SortSegsBatch& sb, int nbatch, int n, uint32_t* tiles, int32_t* sorted_ids,
+                                     int32_t* perm, hipStream_t st) {
+  constexpr int kTile = 1 << TB;
+  const int ntiles = (int)cdiv(n, kTile);
+  uint32_t* splitters = tiles + kMidSortMax;
+  hipLaunchKernelGGL((tile_sort_batched_kernel<TB>), dim3(ntiles, nbatch), dim3(kTile / 2), 0, st, sb, n, tiles,
+                     splitters, kMidWsWords);
+  hipLaunchKernelGGL((tile_rank_batched_kernel<TB>), dim3((int)cdiv((int64_t)ntiles * kTile * kMidTiles, kBlock), nbatch),
+                     dim3(kBlock), 0, st, (const uint32_t*)tiles, (const uint32_t*)splitters, n, ntiles, kMidWsWords,
+                     sorted_ids, perm);
 }
 
 // Long lists (32 768 < n <= 262 144: the 131 072 occurrence ids of a GloVe step at B = 65 536, the 196 608 of a triplet
@@ -952,6 +1018,70 @@ int esr_segment_sort_ids_multi(const int32_t* const* ids, const int64_t* counts,
   ESR_REQUIRE(sorted_ids && perm && workspace, "esr_segment_sort_ids_multi: null pointer");
   return segment_sort_segs("esr_segment_sort_ids_multi", sg, n, V, sorted_ids, perm, workspace, workspace_bytes,
                            as_stream(stream));
+}
+
+size_t esr_segment_sort_batched_workspace_bytes(int64_t n, int nbatch) {
+  if (n <= 0 || nbatch <= 0) return 256;
+  const size_t one = esr_segment_sort_workspace_bytes(n);  // the fallback sorts list after list in this much
+  const size_t mid = n <= kMidSortMax ? align_up((size_t)nbatch * kMidWsWords * 4, 256) : 0;
+  return std::max(one, mid);
+}
+
+int esr_segment_sort_ids_batched(const int32_t* const* ids, const int64_t* counts, const int64_t* offsets, int nseg,
+                                 int nbatch, int64_t V, int32_t* sorted_ids, int32_t* perm, void* workspace,
+                                 size_t workspace_bytes, esr_stream_t stream) {
+  ESR_REQUIRE(nseg >= 1 && nseg <= kMaxSortSegs && nbatch >= 1 && nbatch <= kMaxSortBatch && ids && counts && offsets &&
+                  V > 0,
+              "esr_segment_sort_ids_batched: nseg=%d not in [1, %d], nbatch=%d not in [1, %d], or null argument", nseg,
+              kMaxSortSegs, nbatch, kMaxSortBatch);
+  SortSegsBatch sb;
+  int64_t n = 0;
+  for (int b = 0; b < nbatch; ++b) {
+    SortSegs& sg = sb.b[b];
+    sg.n = nseg;
+    sg.start[0] = 0;
+    for (int i = 0; i < kMaxSortSegs; ++i) {
+      const int32_t* src = i < nseg ? ids[(size_t)b * nseg + i] : nullptr;
+      ESR_REQUIRE(i >= nseg || (counts[i] >= 0 && (counts[i] == 0 || src)),
+                  "esr_segment_sort_ids_batched: bad segment %d of list %d", i, b);
+      sg.ids[i] = src;
+      sg.offset[i] = i < nseg ? offsets[i] : 0;
+      sg.start[i + 1] = sg.start[i] + (i < nseg ? counts[i] : 0);
+    }
+    n = sg.start[nseg];
+  }
+  for (int b = nbatch; b < kMaxSortBatch; ++b) sb.b[b] = sb.b[0];
+  ESR_REQUIRE(n < ((int64_t)1 << 31), "esr_segment_sort_ids_batched: n=%lld", (long long)n);
+  if (n == 0) return ESR_OK;
+  ESR_REQUIRE(sorted_ids && perm && workspace, "esr_segment_sort_ids_batched: null pointer");
+  if (workspace_bytes < esr_segment_sort_batched_workspace_bytes(n, nbatch) || ((uintptr_t)workspace & 15)) {
+    set_error("esr_segment_sort_ids_batched: workspace %zu bytes < %zu required (or misaligned)", workspace_bytes,
+              esr_segment_sort_batched_workspace_bytes(n, nbatch));
+    return ESR_EWORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  const bool fits32 = V <= ((int64_t)1 << (32 - kMaxTileBits));
+  if (fits32 && n <= (1 << kMaxTileBits)) {  // every list is one tile: one launch for all of them
+    if (n <= 512)
+      hipLaunchKernelGGL(tile_sort_single_batched_kernel<9>, dim3(nbatch), dim3(256), 0, st, sb, (int)n, sorted_ids, perm);
+    else if (n <= 1024)
+      hipLaunchKernelGGL(tile_sort_single_batched_kernel<10>, dim3(nbatch), dim3(512), 0, st, sb, (int)n, sorted_ids, perm);
+    else
+      hipLaunchKernelGGL(tile_sort_single_batched_kernel<11>, dim3(nbatch), dim3(1024), 0, st, sb, (int)n, sorted_ids, perm);
+    return check_launch("esr_segment_sort_ids_batched");
+  }
+  if (fits32 && n <= kMidSortMax) {  // two launches for all the lists
+    uint32_t* tiles = (uint32_t*)workspace;
+    if (n <= 512 * kMidTiles) launch_tile_sort_batched<9>(sb, nbatch, (int)n, tiles, sorted_ids, perm, st);
+    else if (n <= 1024 * kMidTiles) launch_tile_sort_batched<10>(sb, nbatch, (int)n, tiles, sorted_ids, perm, st);
+    else launch_tile_sort_batched<11>(sb, nbatch, (int)n, tiles, sorted_ids, perm, st);
+    return check_launch("esr_segment_sort_ids_batched");
+  }
+  for (int b = 0; b < nbatch; ++b)  // longer lists: one after the other (stream order: the workspace is reused)
+    if (int rc = segment_sort_segs("esr_segment_sort_ids_batched", sb.b[b], n, V, sorted_ids + (int64_t)b * n,
+                                   perm + (int64_t)b * n, workspace, workspace_bytes, st))
+      return rc;
+  return ESR_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

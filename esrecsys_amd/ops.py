@@ -733,6 +733,35 @@ def inbatch_towers_fwd_bwd(query_table, cand_table, query_ids, cand_ids, scale, 
     return loss, lse, gQC[:B], gQC[B:]
 
 
+def segment_sort_batched(id_lists, offsets, num_rows, out=None):
+    """The occurrence lists of several coming batches sorted in one launch sequence (esr_segment_sort_ids_batched).
+    id_lists: per batch, the int32 segments of its virtual list [ids_k + offsets[k]] (same lengths in every batch).
+    Returns (sorted_ids, perm), each [len(id_lists), n]: row b is what segment_sort / the multi-segment sort gives for
+    batch b alone.  out = (sorted_ids, perm, workspace) to reuse buffers."""
+    import ctypes
+    lib = _lib.load()
+    nb, nseg = len(id_lists), len(id_lists[0])
+    dev = id_lists[0][0].device
+    counts = [int(t.numel()) for t in id_lists[0]]
+    for segs in id_lists:
+        if len(segs) != nseg or [int(t.numel()) for t in segs] != counts:
+            raise ValueError("every batch must have the same segment lengths")
+    id_lists = [[_req(t, torch.int32, "ids") for t in segs] for segs in id_lists]
+    n = sum(counts)
+    if out is None:
+        sorted_ids = torch.empty((nb, n), dtype=torch.int32, device=dev)
+        perm = torch.empty((nb, n), dtype=torch.int32, device=dev)
+        ws = _ws(_ws_bytes("esr_segment_sort_batched_workspace_bytes", n, nb), dev)
+    else:
+        sorted_ids, perm, ws = out
+    ptrs = (ctypes.c_void_p * (nb * nseg))(*[t.data_ptr() for segs in id_lists for t in segs])
+    cnt = (ctypes.c_int64 * nseg)(*counts)
+    off = (ctypes.c_int64 * nseg)(*[int(x) for x in offsets])
+    check(lib.esr_segment_sort_ids_batched(ptrs, cnt, off, nseg, nb, int(num_rows), _p(sorted_ids), _p(perm), _p(ws),
+                                           ws.numel(), _stream()), "esr_segment_sort_ids_batched")
+    return sorted_ids, perm
+
+
 def bucket_ids_by_owner(ids, world, want_inverse=False, offsets=None, counts_out=None):
     """Stable bucket by owner = id % world.  Returns (local_rows, perm, counts[world] int64 on device) and, with
     want_inverse, also inverse with inverse[perm[k]] = k.  `ids` may be a list of int32 tensors with `offsets`: the

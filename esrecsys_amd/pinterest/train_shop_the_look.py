@@ -237,6 +237,7 @@ class _FusedTripletLoop:
         self.depth = depth
         self.ring, self.B = [], -1
         self.ws = None
+        self.batch_buf, self.sort_batch_max = None, _SORT_BATCH
         self.fixed_s = (self.st.data_ptr(), self.rs.shadow.data_ptr(), self.rs.loc.data_ptr(), self.acc_s.data_ptr(),
                         self.Vs)
         self.fixed_p = (self.pt.data_ptr(), self.rp.shadow.data_ptr(), self.rp.loc.data_ptr(), self.acc_p.data_ptr(),
@@ -280,11 +281,31 @@ class _FusedTripletLoop:
         slot["done"].record(self.side)
         return (slot_index, sid, pid, nid)
 
+    def sort_batch(self, group):
+        """The id lists of the next len(group) batches (each (sid, pid, nid)) sorted by ONE library call on the main
+        stream (esr_segment_sort_ids_batched): handles for ``step``.  At the reference's batch sizes the two-launch
+        sort is 16 us of latency whether it sorts one list or eight."""
+        B = group[0][0].numel()
+        self._sized(B)
+        nb, n = len(group), 3 * B
+        if self.batch_buf is None or self.batch_buf[0].shape != (self.sort_batch_max, n):
+            self.batch_buf = (torch.empty((self.sort_batch_max, n), dtype=torch.int32, device=self.dev),
+                              torch.empty((self.sort_batch_max, n), dtype=torch.int32, device=self.dev),
+                              ops._ws(ops._ws_bytes("esr_segment_sort_batched_workspace_bytes", n, self.sort_batch_max),
+                                      self.dev))
+        srt, prm, ws = self.batch_buf
+        ops.segment_sort_batched([list(g) for g in group], (0, self.Vs, self.Vs), self.Vs + self.Vp,
+                                 out=(srt[:nb], prm[:nb], ws))
+        return [(("ptr", srt[j].data_ptr(), prm[j].data_ptr()),) + tuple(g) for j, g in enumerate(group)]
+
     def step(self, k, handle, regularization, batch_size):
         slot_index, sid, pid, nid = handle
         sorted_ptr = perm_ptr = 0  # in-line sort inside the library call
         slot = None
-        if slot_index is not None:
+        if isinstance(slot_index, tuple):  # sorted by sort_batch, earlier on this stream
+            _, sorted_ptr, perm_ptr = slot_index
+            self._sized(sid.numel())
+        elif slot_index is not None:
             slot = self.ring[slot_index]
             self.main.wait_event(slot["done"])
             sorted_ptr, perm_ptr = slot["sorted"].data_ptr(), slot["perm"].data_ptr()
@@ -306,6 +327,11 @@ class _FusedTripletLoop:
 # beside the HBM-bound update kernel slows that kernel by more than its own length (0.689 against 0.640 ms) -- the same
 # finding as for the GloVe step, where only filling the gaps BETWEEN steps pays (wikipedia.train_epoch).
 _LOOP_DEPTH = max(0, int(_os.environ.get("ESR_STL_PRESORT_DEPTH", "0")))
+# Batches whose id lists are sorted together, by one library call on the main stream, before the first of them is
+# stepped (esr_segment_sort_ids_batched; ESR_STL_SORT_BATCH=1: every step sorts its own list in line).  Lists beyond the
+# two-launch sort's 32 768 ids gain nothing (they are work, not latency) and stay in line.
+_SORT_BATCH = min(8, max(1, int(_os.environ.get("ESR_STL_SORT_BATCH", "8"))))
+_SORT_BATCH_MAX_IDS = 32768
 
 
 def train_steps(state, batches, num_steps, regularization, batch_size):
@@ -329,9 +355,20 @@ def train_steps(state, batches, num_steps, regularization, batch_size):
     if _LOOP_DEPTH == 0:
         import time
         t_host = time.perf_counter()
-        for k in range(num_steps):
-            scene, pos, neg = next(it)
-            ctx.step(k, (None,) + ctx.ids(scene, pos, neg), regularization, batch_size)
+        k = 0
+        while k < num_steps:
+            first = ctx.ids(*next(it))
+            if _SORT_BATCH > 1 and 3 * first[0].numel() <= _SORT_BATCH_MAX_IDS and num_steps - k > 1:
+                group = [first] + [ctx.ids(*next(it)) for _ in range(min(_SORT_BATCH, num_steps - k) - 1)]
+                if any(g[0].numel() != first[0].numel() for g in group):  # ragged batches: each sorts its own list
+                    handles = [(None,) + g for g in group]
+                else:
+                    handles = ctx.sort_batch(group)
+            else:
+                handles = [(None,) + first]
+            for h in handles:
+                ctx.step(k, h, regularization, batch_size)
+                k += 1
         if _os.environ.get("ESR_TRACE_HOST") == "1":  # is the loop issuing steps faster than the GPU retires them?
             import logging
             logging.warning("train_steps: host issued %d steps in %.1f us each (no sync yet)", num_steps,

@@ -230,6 +230,16 @@ int esr_segment_sort_ids(const int32_t* ids, int64_t n, int64_t V, int32_t* sort
 int esr_segment_sort_ids_multi(const int32_t* const* ids, const int64_t* counts, const int64_t* offsets, int nseg,
                                int64_t V, int32_t* sorted_ids, int32_t* perm, void* workspace,
                                size_t workspace_bytes, esr_stream_t stream);
+/* The lists of `nbatch` (<= 8) coming batches sorted in ONE launch sequence: a training loop knows the ids of the next
+ * batches before it needs them (the reference's loop draws them from its data iterator,
+ * pinterest/train_shop_the_look.py:195-204), and at the reference's batch sizes the two-launch sort is latency, not
+ * work -- eight lists cost what one does.  ids[b * nseg + k] = segment k of list b; counts / offsets are the same for
+ * every list (n = their sum); sorted_ids / perm are [nbatch][n], list b exactly what esr_segment_sort_ids_multi would
+ * give for it (perm indexes list b's own occurrences).  Lists longer than 32 768 ids are sorted one after the other. */
+size_t esr_segment_sort_batched_workspace_bytes(int64_t n, int nbatch);
+int esr_segment_sort_ids_batched(const int32_t* const* ids, const int64_t* counts, const int64_t* offsets, int nseg,
+                                 int nbatch, int64_t V, int32_t* sorted_ids, int32_t* perm, void* workspace,
+                                 size_t workspace_bytes, esr_stream_t stream);
 /* For each distinct id: G = sum of its grad rows (occurrence order); acc += G*G;
  * p -= lr * G * rsqrt(acc + eps).  table dtype f32 or bf16 (fp32 accumulator either way). */
 int esr_sparse_adagrad_scatter(void* table, int dtype, float* accum, int64_t V, int D,

@@ -971,3 +971,25 @@ def test_bucket_ids_by_owner_vs_oracle(dev, world, n):
     assert np.array_equal(N(counts), ec)
     assert np.array_equal(N(perm), ep)
     assert np.array_equal(N(local), el)
+
+
+@pytest.mark.parametrize("n_seg,nb", [((100, 100, 100), 8), ((683, 683, 682), 5), ((2048,), 3), ((2049,), 2),
+                                      ((2048, 2048, 2048), 8), ((8192, 8192, 8192), 8), ((8192, 8192, 8192), 1),
+                                      ((10923, 10923, 10922), 4), ((20000, 20000), 3)])
+def test_segment_sort_batched_equals_list_by_list(dev, n_seg, nb):
+    """esr_segment_sort_ids_batched: one-tile lists (one launch for all), mid lists (two launches for all: the triplet
+    step's 24 576 ids; the largest, 32 768), longer ones (list after list) -- every list exactly what the one-list sort
+    gives, which is the stable sort of [ids_k + offset_k]."""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(sum(n_seg) + nb)
+    V = 1_000_000
+    offsets = [0, V, V][:len(n_seg)]
+    lists = [[torch.from_numpy(np.where(rng.random(n) < 0.2, rng.integers(0, 5, n), rng.integers(0, V, n)).astype(np.int32)).to(dev)
+              for n in n_seg] for _ in range(nb)]
+    srt, prm = ops.segment_sort_batched(lists, offsets, 2 * V)
+    assert srt.shape == (nb, sum(n_seg)) and prm.shape == srt.shape
+    for b, segs in enumerate(lists):
+        virt = np.concatenate([N(t).astype(np.int64) + o for t, o in zip(segs, offsets)])
+        order = np.argsort(virt, kind="stable")
+        assert np.array_equal(N(prm[b]), order.astype(np.int32))
+        assert np.array_equal(N(srt[b]), virt[order].astype(np.int32))

@@ -1,5 +1,5 @@
-"""GPU: the Shop-The-Look loop helper (train_steps: one-pass triplet steps with the id sort running ahead on a second
-stream) against step-by-step train_step on the same batches -- same towers, accumulators and losses."""
+"""GPU: the Shop-The-Look loop helper (train_steps: one-pass triplet steps, the id lists of the coming batches sorted
+together ahead of them) against step-by-step train_step on the same batches -- same towers, accumulators and losses."""
 import numpy as np
 import pytest
 import torch
@@ -19,12 +19,15 @@ def _state(dev, Vs, Vp, D, seed):
     return TrainState.create(apply_fn=model.apply, params=params, tx=optim.sparse_adagrad(0.05))
 
 
-@pytest.mark.parametrize("depth", [0, 2])
-@pytest.mark.parametrize("B,steps,ids", [(256, 7, "uniform"), (2048, 5, "hot"), (64, 1, "uniform")])
-def test_train_steps_equals_stepwise_train_step(dev, B, steps, ids, depth, monkeypatch):
+@pytest.mark.parametrize("depth,sort_batch", [(0, 8), (0, 3), (0, 1), (2, 1)])
+@pytest.mark.parametrize("B,steps,ids", [(256, 7, "uniform"), (2048, 11, "hot"), (64, 1, "uniform"), (8192, 9, "uniform")])
+def test_train_steps_equals_stepwise_train_step(dev, B, steps, ids, depth, sort_batch, monkeypatch):
     import esrecsys_amd.pinterest.train_shop_the_look as stl
     from esrecsys_amd.pinterest.train_shop_the_look import train_step, train_steps
-    monkeypatch.setattr(stl, "_LOOP_DEPTH", depth)  # 0: sort in line (default); 2: two batches ahead on the side stream
+    # depth 0: sorts on the main stream -- the lists of `sort_batch` coming batches by one batched call (default 8; groups
+    # of 8 + 3, 3 + 3 + ..., or every step its own); depth 2: two batches ahead on the side stream
+    monkeypatch.setattr(stl, "_LOOP_DEPTH", depth)
+    monkeypatch.setattr(stl, "_SORT_BATCH", sort_batch)
     Vs, Vp, D = 3000, 5000, 64
     rng = np.random.default_rng(B + steps)
 
