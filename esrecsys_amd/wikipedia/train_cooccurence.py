@@ -112,6 +112,7 @@ class PresortedInputs:
 # update kernel's residency (experiment knob: making room for the sort to run BESIDE it measured slower).
 _PRESORT = os.environ.get("ESR_GLOVE_PRESORT", "1") == "1"
 _PRESORT_DEPTH = max(1, int(os.environ.get("ESR_GLOVE_PRESORT_DEPTH", "2")))  # batches sorted ahead (train_epoch)
+_SORT_BATCH = min(8, max(1, int(os.environ.get("ESR_GLOVE_SORT_BATCH", "8"))))  # short lists sorted together (train_epoch)
 _STEP_BLOCKS_PER_CU = int(os.environ.get("ESR_GLOVE_STEP_BLOCKS_PER_CU", "0"))
 
 
@@ -198,6 +199,16 @@ class _FusedEpoch:
         self.fixed = (self.emb.data_ptr(), self.rv.shadow.data_ptr(), self.rv.loc.data_ptr(), self.acc_e.data_ptr(),
                       self.bias.data_ptr(), self.acc_b.data_ptr(), self.V, self.D)
 
+    def sort_batch(self, group):
+        """[(inputs, target), ...] of the coming batches -> the same list with PresortedInputs, their id lists sorted by
+        one batched call on the current stream (batches of unequal size or longer than the two-launch sort takes: as is)."""
+        ids = [ops.as_ids(inp, self.dev, check_range=self.V) for inp, _ in group]
+        n = ids[0].numel()
+        if n > 32768 or any(t.numel() != n for t in ids) or any(t.dim() != 2 or t.shape[0] != 2 for t in ids):
+            return [(i, t) for i, (_, t) in zip(ids, group)]
+        srt, prm = ops.segment_sort_batched([[i.reshape(-1)] for i in ids], (0,), self.V)
+        return [(PresortedInputs(i, srt[b], prm[b], None), t) for b, (i, (_, t)) in enumerate(zip(ids, group))]
+
     def step(self, k, inputs, target):
         presorted = None
         if isinstance(inputs, PresortedInputs):
@@ -236,17 +247,30 @@ def train_epoch(state, steps_per_epoch, train_it):
         # launches (> 4096 ids).  Two ahead, not one: the update kernel fills every wave slot, so a sort issued beside
         # step k mostly runs in the gaps after it -- one ahead, its second radix pass (23 us) still sat between step k
         # and step k + 1 (profiles/r2/glove_kernel_stats.csv: the first scatter "takes" 106 us, stretched over the step).
+        # Short lists (the reference's default batch of 2048 pairs: wikipedia/train_cooccurence.py:45) are pure launch
+        # latency to sort: the lists of up to _SORT_BATCH coming batches go through ONE batched sort on the main stream
+        # (esr_segment_sort_ids_batched) in front of their steps.
         from collections import deque
         import time
         queue, fetched = deque(), 0
         t_host = time.perf_counter()
+        grouped = False  # short lists: refill only when the queue has run dry, a whole group at a time
         for k in range(steps_per_epoch):
-            while fetched < steps_per_epoch and len(queue) < _PRESORT_DEPTH + 1:
+            while fetched < steps_per_epoch and (not queue if grouped else len(queue) < _PRESORT_DEPTH + 1):
                 inputs, targets = next(train_it)
                 fetched += 1
                 if _PRESORT and _ids_count(inputs) > _PRESORT_MIN_IDS:
-                    inputs = presort_inputs(state, inputs)
-                queue.append((inputs, targets))
+                    grouped = False
+                    queue.append((presort_inputs(state, inputs), targets))
+                elif _SORT_BATCH > 1 and not queue:
+                    grouped = True
+                    group = [(inputs, targets)]
+                    while len(group) < _SORT_BATCH and fetched < steps_per_epoch:
+                        group.append(next(train_it))
+                        fetched += 1
+                    queue.extend(ctx.sort_batch(group) if len(group) > 1 else group)
+                else:
+                    queue.append((inputs, targets))
             inputs, targets = queue.popleft()
             ctx.step(k, inputs, targets)
         if os.environ.get("ESR_TRACE_HOST") == "1":  # is the loop issuing steps faster than the GPU retires them?

@@ -146,3 +146,22 @@ def test_config_c3_full_size_fused_step(dev):
     ea, eb = a.params["_token_embedding"]["embedding"], b.params["_token_embedding"]["embedding"]
     assert rel_err(ea.cpu().numpy(), eb.cpu().numpy()) <= 1e-6
     assert torch.equal(ea[~touched], before[~touched]) and not torch.equal(ea[touched], before[touched])
+
+
+@pytest.mark.parametrize("B,K", [(1024, 11), (2048, 8), (16, 3), (3000, 5)])
+def test_train_epoch_batched_sort_equals_in_line_sort(dev, B, K, monkeypatch):
+    """Short id lists (the reference's default batch of 2048 pairs) are sorted eight batches at a time by one batched
+    call (esr_segment_sort_ids_batched); the epoch must be bit-identical to the one that sorts every list inside its
+    own step -- groups of 8 + 3, exactly 8, fewer than a group; 6000 ids (beyond 4096) keep the side-stream sort."""
+    import esrecsys_amd.wikipedia.train_cooccurence as tc
+    V, D = 3000, 64
+    rng = np.random.default_rng(B + K)
+    batches = [(_ids("uniform", V, (2, B), rng), rng.uniform(0.1, 300.0, B).astype(np.float32)) for _ in range(K)]
+    monkeypatch.setattr(tc, "_SORT_BATCH", 8)
+    a, la = tc.train_epoch(_make_state(V, D, "reference", dev), K, iter(batches))
+    monkeypatch.setattr(tc, "_SORT_BATCH", 1)
+    monkeypatch.setattr(tc, "_PRESORT", False)
+    b, lb = tc.train_epoch(_make_state(V, D, "reference", dev), K, iter(batches))
+    assert la == lb
+    assert torch.equal(a.params["_token_embedding"]["embedding"], b.params["_token_embedding"]["embedding"])
+    assert torch.equal(a.params["_bias"]["embedding"], b.params["_bias"]["embedding"])
