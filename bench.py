@@ -528,7 +528,8 @@ def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True
         # G5: the reference's own epoch loop (wikipedia/train_cooccurence.py:103-112) is the unit that is timed: it runs
         # the one-pass step and sorts batch k + 1's ids on a second stream under batch k's update kernel
         from esrecsys_amd.wikipedia.train_cooccurence import train_epoch
-        mode = "eager, train_epoch (ids of the next batch sorted on a side stream)"
+        mode = ("eager, train_epoch (ids of the next batches sorted on a side stream)" if 2 * cfg["B"] > 4096 else
+                "eager, train_epoch (id lists of eight coming batches sorted by one batched call)")
         state, _ = train_epoch(state, warmup, iter(batches[:warmup]))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -540,7 +541,8 @@ def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True
         # the reference's training loop body (pinterest/train_shop_the_look.py:195-204) through the build's loop helper:
         # one-pass steps, the id sort of the coming batches on a second stream, two library calls per step
         from esrecsys_amd.pinterest.train_shop_the_look import train_steps
-        mode = "eager, train_steps (one library call per step)"
+        mode = ("eager, train_steps (one library call per step; id lists of eight coming batches sorted by one batched call)"
+                if 3 * cfg["B"] <= 32768 else "eager, train_steps (one library call per step)")
         state, _ = train_steps(state, iter(batches[:warmup]), warmup, LAM, B)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -460,7 +460,10 @@ __global__ __launch_bounds__(kBlock) void glove_step_kernel(
       row_load(t, part_ptr(m), lig, G, nvec);
       occ(m, t);
     }
-    const bool ends = q == n || (own_code[q] & kIdMask) != id;
+    // (a run of one ends at p + 1, whose code is already in a register: the reload was a dependent round trip per
+    // position in front of the stores -- +7 % on the whole step.  The same shortcut for meta[p + 1] and own_code[p + 2]
+    // in the walk of longer runs measured 5 % SLOWER here (same box, alternating runs) and is not used)
+    const bool ends = q == n || ((q == p + 1 ? code_n : own_code[q]) & kIdMask) != id;
     if (lig == 0) bias_info[p] = make_double2(bsum, (double)(e_run - p));
     if (head && ends) {
       step_apply<VEC, NCH>(emb0, emb1, loc, accum, code, own, a, g, D, lig, G, nvec, lr, eps);

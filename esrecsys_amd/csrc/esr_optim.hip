@@ -173,7 +173,14 @@ __global__ __launch_bounds__(kBlock) void segment_update_kernel(FusedTables ft, 
     RowRegs<VEC, NCH> g;
     row_load(g, grad_rows + (int64_t)perm[p] * D, lig, G, nvec);
     int64_t q = p + 1, e_run = p + 1;
-    while (e_run < stop && sorted_ids[e_run] == id) ++e_run;  // end of this chunk (ids are contiguous: one line)
+    bool run_over = false;  // the walk met a different id: the run ends inside this chunk (no reload further down)
+    while (e_run < stop) {  // end of this chunk (ids are contiguous: one line)
+      if (sorted_ids[e_run] != id) {
+        run_over = true;
+        break;
+      }
+      ++e_run;
+    }
     // rows are added strictly left to right, but four loads are kept in flight: a 32-row chunk walked one dependent
     // load at a time made this kernel 2.5x slower on Zipf ids than on uniform ones
     for (; q + 4 <= e_run; q += 4) {
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(kBlock) void segment_update_kernel(FusedTables ft, 
 #pragma unroll
         for (int e = 0; e < VEC; ++e) g.v[k][e] += t.v[k][e];
     }
-    const bool ends = q == n || sorted_ids[q] != id;
+    const bool ends = run_over || q == n || sorted_ids[q] != id;
     if (head && ends)
       seg_apply<VEC, NCH, OP>(ft, dtype, id, g, D, lig, G, nvec, lr, eps);
     else

@@ -181,7 +181,10 @@ __global__ __launch_bounds__(kBlock) void triplet_step_kernel(TwoTowers tt, int 
     int64_t e_run = p + 1;
     if (more && (code_n & kIdMask) == id) {
       ++e_run;
-      while (e_run < stop && (own_code[e_run] & kIdMask) == id) ++e_run;
+      if (e_run < stop && (c1 & kIdMask) == id) {  // (position p + 2's record is already on its way into c1)
+        ++e_run;
+        while (e_run < stop && (own_code[e_run] & kIdMask) == id) ++e_run;
+      }
       if (e_run > stop) e_run = stop;
     } else if (kAhead && p + 1 < p_end) {  // a run of one: position p + 1 heads the next run -- request its rows now
       const uint32_t idn = code_n & kIdMask;
@@ -228,8 +231,12 @@ __global__ __launch_bounds__(kBlock) void triplet_step_kernel(TwoTowers tt, int 
     };
     occ(m_first, fA, fB);
     int64_t q = p + 1;
+    auto meta_at = [&](int64_t qq) -> uint4 {  // position p + 1's record is in a register
+      if (qq == p + 1) return m_next;
+      return meta[qq];
+    };
     for (; kAhead && q + 2 <= e_run; q += 2) {  // two occurrences = four partner rows in flight
-      const uint4 ma = meta[q], mb = meta[q + 1];
+      const uint4 ma = meta_at(q), mb = meta[q + 1];
       RowRegs<VEC, NCH> a0, b0, a1, b1;
       row_load(a0, tower_row(tt, ma.y, D), lig, G, nvec);
       row_load(b0, tower_row(tt, ma.z, D), lig, G, nvec);
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(kBlock) void triplet_step_kernel(TwoTowers tt, int 
       occ(mb, a1, b1);
     }
     if (q < e_run) {  // the plan record of the next occurrence travels while this one's rows do
-      uint4 mq = meta[q];
+      uint4 mq = meta_at(q);
       for (; q < e_run; ++q) {
         const uint4 m = mq;
         if (q + 1 < e_run) mq = meta[q + 1];
@@ -249,7 +256,9 @@ __global__ __launch_bounds__(kBlock) void triplet_step_kernel(TwoTowers tt, int 
         occ(m, a0, b0);
       }
     }
-    const bool ends = q == n || (own_code[q] & kIdMask) != id;
+    // (a run of one -- nearly every run of a uniform batch -- ends at p + 1, whose code is already in a register: the
+    // reload was a dependent L2 round trip in front of the stores of a kernel that is one latency chain per group)
+    const bool ends = q == n || ((q == p + 1 ? code_n : own_code[q]) & kIdMask) != id;
     if (head && ends) {
       step_apply2<VEC, NCH>(tt, code, own, a, g, D, lig, G, nvec, lr, eps);
     } else {
