@@ -339,8 +339,10 @@ def train_steps(state, batches, num_steps, regularization, batch_size):
     ``state, loss = train_step(state, scene, pos, neg, regularization, batch_size)`` for each batch of the iterator
     `batches`, yielding ``(scene, pos_product, neg_product)``).  Returns ``(state, losses)`` with the per-step losses
     as one device tensor -- the loop never synchronises.  Under ``optim.sparse_adagrad`` every step is the one-pass step
-    driven through a per-loop context (one library call per step; ``ESR_STL_PRESORT_DEPTH=n`` sorts the ids of the next
-    n batches on a second stream -- measured slower, see _LOOP_DEPTH); otherwise it is ``train_step`` as is."""
+    driven through a per-loop context: one library call per step, and the id lists of up to eight coming batches are
+    drawn from the iterator and sorted together by one batched call in front of their steps (``ESR_STL_SORT_BATCH``;
+    ``ESR_STL_PRESORT_DEPTH=n`` instead sorts the ids of the next n batches on a second stream -- measured slower, see
+    _LOOP_DEPTH); otherwise it is ``train_step`` as is."""
     it = iter(batches)
     if not fused_triplet_step_available(state) or num_steps <= 0:
         losses = []
@@ -355,12 +357,20 @@ def train_steps(state, batches, num_steps, regularization, batch_size):
     if _LOOP_DEPTH == 0:
         import time
         t_host = time.perf_counter()
-        k = 0
+        k, dry = 0, False
         while k < num_steps:
+            if dry:  # the iterator ended early: as the reference's loop, after the steps it did feed
+                raise StopIteration("train_steps: the batch iterator ended after %d of %d steps" % (k, num_steps))
             first = ctx.ids(*next(it))
             if _SORT_BATCH > 1 and 3 * first[0].numel() <= _SORT_BATCH_MAX_IDS and num_steps - k > 1:
-                group = [first] + [ctx.ids(*next(it)) for _ in range(min(_SORT_BATCH, num_steps - k) - 1)]
-                if any(g[0].numel() != first[0].numel() for g in group):  # ragged batches: each sorts its own list
+                group = [first]
+                for _ in range(min(_SORT_BATCH, num_steps - k) - 1):
+                    try:
+                        group.append(ctx.ids(*next(it)))
+                    except StopIteration:
+                        dry = True
+                        break
+                if any(g[0].numel() != first[0].numel() for g in group) or len(group) == 1:  # ragged: own sorts
                     handles = [(None,) + g for g in group]
                 else:
                     handles = ctx.sort_batch(group)

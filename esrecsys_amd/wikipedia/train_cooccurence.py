@@ -266,7 +266,10 @@ def train_epoch(state, steps_per_epoch, train_it):
                     grouped = True
                     group = [(inputs, targets)]
                     while len(group) < _SORT_BATCH and fetched < steps_per_epoch:
-                        group.append(next(train_it))
+                        try:
+                            group.append(next(train_it))
+                        except StopIteration:  # ended early: the steps it did feed run, then the loop's own next() raises
+                            break
                         fetched += 1
                     queue.extend(ctx.sort_batch(group) if len(group) > 1 else group)
                 else:
