@@ -69,3 +69,16 @@ def test_train_steps_host_batches_and_other_optimizer(dev):
     c = TrainState.create(apply_fn=c.apply_fn, params=c.params, tx=optim.sgd(0.1))
     c, losses_c = train_steps(c, iter(batches), steps, 0.1, float(B))
     assert losses_c.shape == (steps,) and bool(torch.isfinite(losses_c).all())
+
+
+def test_train_steps_iterator_that_ends_early(dev):
+    """The reference's loop raises StopIteration at the step whose next() finds the iterator empty; the loop helper
+    prefetches groups of eight but must do the same (after running the steps it was fed), not die inside the prefetch."""
+    from esrecsys_amd.pinterest.train_shop_the_look import train_steps
+    Vs, Vp, D, B = 500, 700, 32, 256
+    rng = np.random.default_rng(9)
+    batches = [tuple(torch.from_numpy(rng.integers(0, V, B).astype(np.int32)).to(dev) for V in (Vs, Vp, Vp))
+               for _ in range(5)]
+    with pytest.raises(StopIteration):
+        train_steps(_state(dev, Vs, Vp, D, 2), iter(batches), 9, 0.1, float(B))
+    torch.cuda.synchronize()
