@@ -34,6 +34,8 @@ def test_empty_occurrence_lists_are_no_ops(dev):
     ops.sparse_adagrad(table, accum, sid, perm, torch.empty((0, 16), device=dev), 0.1)
     local, p2, counts = ops.bucket_ids_by_owner(ids, 8)
     assert local.numel() == 0 and int(counts.sum()) == 0
+    srt, prm = ops.segment_sort_batched([[ids, ids], [ids, ids]], (0, 100), 200)   # two empty two-segment lists
+    assert srt.shape == (2, 0) and prm.shape == (2, 0)
     torch.cuda.synchronize()
     assert torch.equal(table, before) and bool((accum == 0.1).all())
 
@@ -97,6 +99,11 @@ def test_argument_errors_raise_with_a_message(dev):
                                     64.0)                                 # D must be a multiple of 4 (96 is fine now)
     with pytest.raises(TypeError):
         ops.gather_rows(c, torch.zeros(3, dtype=torch.int64, device=dev))  # ids must be int32
+    three = torch.zeros(3, dtype=torch.int32, device=dev)
+    with pytest.raises(_lib.EsrLibraryError, match="nbatch"):
+        ops.segment_sort_batched([[three]] * 9, (0,), 10)                  # at most eight lists per call
+    with pytest.raises(ValueError, match="same segment lengths"):
+        ops.segment_sort_batched([[three], [torch.zeros(4, dtype=torch.int32, device=dev)]], (0,), 10)
     with pytest.raises(TypeError, match="no CPU fallback"):
         ops.gather_rows(c.cpu(), torch.zeros(3, dtype=torch.int32))
     with pytest.raises(_lib.EsrLibraryError):
