@@ -232,12 +232,15 @@ class _FusedTripletLoop:
         self.lr, self.eps = float(state.tx.lr), float(state.tx.eps)
         self.lib, self.check, self.ct = _lib.load(), _lib.check, ctypes
         self.losses = torch.empty(max(steps, 1), dtype=torch.float32, device=self.dev)
+        self.losses_ptr = self.losses.data_ptr()
         self.main = torch.cuda.current_stream(self.dev)
+        self.main_raw = self.main.cuda_stream
         self.side = _side_stream(self.dev)
         self.depth = depth
         self.ring, self.B = [], -1
         self.ws = None
         self.batch_buf, self.sort_batch_max = None, _SORT_BATCH
+        self.batch_ptrs = (ctypes.c_void_p * (3 * _SORT_BATCH))()
         self.fixed_s = (self.st.data_ptr(), self.rs.shadow.data_ptr(), self.rs.loc.data_ptr(), self.acc_s.data_ptr(),
                         self.Vs)
         self.fixed_p = (self.pt.data_ptr(), self.rp.shadow.data_ptr(), self.rp.loc.data_ptr(), self.acc_p.data_ptr(),
@@ -256,6 +259,7 @@ class _FusedTripletLoop:
                                   device=self.dev),
                 "done": torch.cuda.Event(), "ids_ready": torch.cuda.Event(), "free": torch.cuda.Event()})
         self.ws = ops._ws(ops._ws_bytes("esr_triplet_step_workspace_bytes", B, self.D), self.dev)
+        self.ws_ptr, self.ws_n = self.ws.data_ptr(), self.ws.numel()
         self.cnt = (self.ct.c_int64 * 3)(B, B, B)
         self.off = (self.ct.c_int64 * 3)(0, self.Vs, self.Vs)
         self.B = B
@@ -294,18 +298,35 @@ class _FusedTripletLoop:
                               ops._ws(ops._ws_bytes("esr_segment_sort_batched_workspace_bytes", n, self.sort_batch_max),
                                       self.dev))
         srt, prm, ws = self.batch_buf
-        ops.segment_sort_batched([list(g) for g in group], (0, self.Vs, self.Vs), self.Vs + self.Vp,
-                                 out=(srt[:nb], prm[:nb], ws))
-        return [(("ptr", srt[j].data_ptr(), prm[j].data_ptr()),) + tuple(g) for j, g in enumerate(group)]
+        # (the library call itself, not ops.segment_sort_batched: its per-tensor checks and ctypes arrays were 67 us per
+        # group -- the ids were validated by ``ids``, the arrays are kept)
+        ptrs = self.batch_ptrs
+        i = 0
+        for g in group:
+            ptrs[i], ptrs[i + 1], ptrs[i + 2] = g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr()
+            i += 3
+        self.check(self.lib.esr_segment_sort_ids_batched(ptrs, self.cnt, self.off, 3, nb, self.Vs + self.Vp,
+                                                         srt.data_ptr(), prm.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                         self.main_raw), "esr_segment_sort_ids_batched")
+        # everything ``step`` would look up per batch is resolved here, once per group: at the reference's own batch
+        # sizes (16 - 128 triplets: train_shop_the_look.py:60) the step is ~12 us of kernels and the loop is host-bound
+        sp, pp, row = srt.data_ptr(), prm.data_ptr(), 4 * n
+        return [(("ptr", sp + j * row, pp + j * row, g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), B),) + tuple(g)
+                for j, g in enumerate(group)]
 
     def step(self, k, handle, regularization, batch_size):
         slot_index, sid, pid, nid = handle
+        if type(slot_index) is tuple:  # sorted and resolved by sort_batch, earlier on this stream
+            _, sorted_ptr, perm_ptr, sp_, pp_, np_, B = slot_index
+            self.rs.dirty = self.rp.dirty = True
+            self.check(self.lib.esr_triplet_train_step(*self.fixed_s, *self.fixed_p, self.D, sp_, pp_, np_, B,
+                                                       regularization, batch_size, self.lr, self.eps, sorted_ptr,
+                                                       perm_ptr, self.losses_ptr + 4 * k, self.ws_ptr, self.ws_n,
+                                                       self.main_raw), "esr_triplet_train_step")
+            return
         sorted_ptr = perm_ptr = 0  # in-line sort inside the library call
         slot = None
-        if isinstance(slot_index, tuple):  # sorted by sort_batch, earlier on this stream
-            _, sorted_ptr, perm_ptr = slot_index
-            self._sized(sid.numel())
-        elif slot_index is not None:
+        if slot_index is not None:
             slot = self.ring[slot_index]
             self.main.wait_event(slot["done"])
             sorted_ptr, perm_ptr = slot["sorted"].data_ptr(), slot["perm"].data_ptr()
@@ -354,6 +375,7 @@ def train_steps(state, batches, num_steps, regularization, batch_size):
         return state, (torch.stack(losses) if losses else torch.empty(0, device=dev))
     from collections import deque
     ctx = _FusedTripletLoop(state, num_steps, _LOOP_DEPTH)
+    regularization, batch_size = float(regularization), float(batch_size)
     if _LOOP_DEPTH == 0:
         import time
         t_host = time.perf_counter()

@@ -208,6 +208,9 @@ class _FusedEpoch:
         self.losses_ptr = self.losses.data_ptr()
         self.ws, self.ws_B = None, -1
         self.sort_buf = None
+        import ctypes
+        self.sort_ptrs = (ctypes.c_void_p * _SORT_BATCH)()
+        self.sort_cnt, self.sort_off = (ctypes.c_int64 * 1)(0), (ctypes.c_int64 * 1)(0)
         self.check_ids = os.environ.get("ESR_CHECK_IDS") == "1"
         self.fixed = (self.emb.data_ptr(), self.rv.shadow.data_ptr(), self.rv.loc.data_ptr(), self.acc_e.data_ptr(),
                       self.bias.data_ptr(), self.acc_b.data_ptr(), self.V, self.D)
@@ -230,7 +233,13 @@ class _FusedEpoch:
                              torch.empty((_SORT_BATCH, n), dtype=torch.int32, device=self.dev),
                              ops._ws(ops._ws_bytes("esr_segment_sort_batched_workspace_bytes", n, _SORT_BATCH), self.dev))
         srt, prm, ws = self.sort_buf
-        ops.segment_sort_batched([[i.reshape(-1)] for i in ids], (0,), self.V, out=(srt[:nb], prm[:nb], ws))
+        # (the library call itself: ops.segment_sort_batched re-validates every tensor and rebuilds its ctypes arrays)
+        for b, i in enumerate(ids):
+            self.sort_ptrs[b] = i.data_ptr()
+        self.sort_cnt[0] = n
+        self.check(self.lib.esr_segment_sort_ids_batched(self.sort_ptrs, self.sort_cnt, self.sort_off, 1, nb, self.V,
+                                                         srt.data_ptr(), prm.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                         ops._stream()), "esr_segment_sort_ids_batched")
         row = 4 * n
         sp, pp = srt.data_ptr(), prm.data_ptr()
         out = []
