@@ -550,6 +550,20 @@ def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         final_loss = float(losses[-1])
+    elif workload == "inbatch" and graphed is None and os.environ.get("ESR_INBATCH_LOOP", "1") == "1" and \
+            os.environ.get("ESR_INBATCH_AHEAD", "0") != "1":
+        # the reference's training loop body (pinterest/train_shop_the_look.py:195-204) through the build's loop helper:
+        # train_step per batch, the id lists of eight coming batches sorted by one batched call in front of their steps
+        from esrecsys_amd.pinterest.train_shop_the_look import train_steps
+        mode = "eager, train_steps (train_step per batch; id lists of eight coming batches sorted by one batched call)"
+        wb = [(b[0], b[1], None) for b in batches]
+        state, _ = train_steps(state, iter(wb[:warmup]), warmup, LAM, B, scale=SCALE, precision=PRECISION)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        state, losses = train_steps(state, iter(wb[warmup:]), steps, LAM, B, scale=SCALE, precision=PRECISION)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        final_loss = float(losses[-1])
     elif workload == "inbatch" and graphed is None and os.environ.get("ESR_INBATCH_AHEAD", "0") == "1" and \
             cfg.get("table_dtype") in (None, "f32", "bf16"):
         # experiment knob (default off): the ids of batch k + 1 sorted on a second stream while batch k's MFMA kernels

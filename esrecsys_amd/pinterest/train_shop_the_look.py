@@ -355,16 +355,65 @@ _SORT_BATCH = min(8, max(1, int(_os.environ.get("ESR_STL_SORT_BATCH", "8"))))
 _SORT_BATCH_MAX_IDS = 32768
 
 
-def train_steps(state, batches, num_steps, regularization, batch_size):
+def _inbatch_steps(state, it, first, num_steps, regularization, batch_size, scale, precision):
+    """train_steps for in-batch batches ``(scene, pos, None)``: ``train_step`` per batch, the occurrence lists
+    [scene ; Vs + pos] of up to eight coming batches sorted by one batched call in front of their steps."""
+    _, st, pt = _tables(state)
+    dev, Vs, Vp = st.device, st.shape[0], pt.shape[0]
+    sparse = not getattr(state.tx, "wants_dense", False)
+
+    def ids_of(batch):
+        return (ops.as_ids(batch[0], dev, check_range=Vs).reshape(-1), ops.as_ids(batch[1], dev, check_range=Vp).reshape(-1))
+    losses, k, pending, dry = [], 0, [ids_of(first)], False
+    while k < num_steps:
+        if not pending:
+            if dry:
+                raise StopIteration("train_steps: the batch iterator ended after %d of %d steps" % (k, num_steps))
+            pending = [ids_of(next(it))]
+        want = min(_SORT_BATCH, num_steps - k)
+        while len(pending) < want and not dry:
+            try:
+                pending.append(ids_of(next(it)))
+            except StopIteration:
+                dry = True
+        group, pending = pending[:want], pending[want:]
+        n = 2 * group[0][0].numel()
+        if sparse and _SORT_BATCH > 1 and len(group) > 1 and n <= _SORT_BATCH_MAX_IDS and \
+                all(g[0].numel() == group[0][0].numel() == g[1].numel() for g in group):
+            srt, prm = ops.segment_sort_batched([list(g) for g in group], (0, Vs), Vs + Vp)
+            handles = [PresortedTriplets(g[0], g[1], None, srt[j], prm[j], None) for j, g in enumerate(group)]
+        else:
+            handles = [PresortedTriplets(g[0], g[1], None, None, None, None) for g in group]
+        for h in handles:
+            if h.sorted_ids is None:
+                state, loss = train_step(state, h.scene, h.pos, None, regularization, batch_size, scale=scale,
+                                         precision=precision)
+            else:
+                state, loss = train_step(state, h, None, None, regularization, batch_size, scale=scale,
+                                         precision=precision)
+            losses.append(loss)
+            k += 1
+    return state, torch.stack(losses)
+
+
+def train_steps(state, batches, num_steps, regularization, batch_size, scale=1.0, precision="auto"):
     """`num_steps` iterations of the reference's training loop body (pinterest/train_shop_the_look.py:195-204:
     ``state, loss = train_step(state, scene, pos, neg, regularization, batch_size)`` for each batch of the iterator
     `batches`, yielding ``(scene, pos_product, neg_product)``).  Returns ``(state, losses)`` with the per-step losses
-    as one device tensor -- the loop never synchronises.  Under ``optim.sparse_adagrad`` every step is the one-pass step
+    as one device tensor -- the loop never synchronises.  Batches with ``neg_product = None`` are in-batch-softmax steps
+    (``scale`` / ``precision`` as for ``train_step``), their id lists sorted eight batches at a time as well.  Under
+    ``optim.sparse_adagrad`` every triplet step is the one-pass step
     driven through a per-loop context: one library call per step, and the id lists of up to eight coming batches are
     drawn from the iterator and sorted together by one batched call in front of their steps (``ESR_STL_SORT_BATCH``;
     ``ESR_STL_PRESORT_DEPTH=n`` instead sorts the ids of the next n batches on a second stream -- measured slower, see
     _LOOP_DEPTH); otherwise it is ``train_step`` as is."""
     it = iter(batches)
+    if num_steps > 0:
+        first = next(it)
+        if first[2] is None:  # in-batch batches (north_star): scale / precision as for train_step
+            return _inbatch_steps(state, it, first, num_steps, regularization, batch_size, scale, precision)
+        import itertools
+        it = itertools.chain([first], it)
     if not fused_triplet_step_available(state) or num_steps <= 0:
         losses = []
         for _ in range(max(num_steps, 0)):

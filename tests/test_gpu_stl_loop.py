@@ -82,3 +82,27 @@ def test_train_steps_iterator_that_ends_early(dev):
     with pytest.raises(StopIteration):
         train_steps(_state(dev, Vs, Vp, D, 2), iter(batches), 9, 0.1, float(B))
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("B,D,steps", [(256, 128, 11), (128, 64, 3), (100, 32, 9)])
+def test_train_steps_inbatch_equals_stepwise_train_step(dev, B, D, steps):
+    """Batches with neg = None are in-batch-softmax steps: the loop helper runs train_step per batch with the occurrence
+    lists [scene ; Vs + pos] of up to eight coming batches sorted by one batched call -- towers, accumulators and losses
+    bit-identical to the stepwise loop (fp16 x 2 head at B % 128 = 0, D >= 64; exact-f32 head otherwise)."""
+    from esrecsys_amd.pinterest.train_shop_the_look import train_step, train_steps
+    Vs, Vp = 3000, 5000
+    rng = np.random.default_rng(B + steps)
+    batches = [(torch.from_numpy(rng.integers(0, Vs, B).astype(np.int32)).to(dev),
+                torch.from_numpy(rng.integers(0, Vp, B).astype(np.int32)).to(dev), None) for _ in range(steps)]
+    a, b = _state(dev, Vs, Vp, D, 4), _state(dev, Vs, Vp, D, 4)
+    a, losses = train_steps(a, iter(batches), steps, 0.1, float(B), scale=6.0)
+    ref = []
+    for scene, pos, _ in batches:
+        b, l = train_step(b, scene, pos, None, 0.1, float(B), scale=6.0)
+        ref.append(l)
+    assert losses.shape == (steps,) and int(a.step) == int(b.step) == steps
+    assert torch.equal(losses, torch.stack(ref))
+    for tower in ("scene_tower", "product_tower"):
+        assert torch.equal(a.params["params"][tower]["embedding"], b.params["params"][tower]["embedding"])
+        assert torch.equal(a.opt_state["sum_of_squares"]["params"][tower]["embedding"],
+                           b.opt_state["sum_of_squares"]["params"][tower]["embedding"])
