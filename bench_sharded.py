@@ -63,15 +63,17 @@ def run_sharded(args, cfg, dev, rank, world):
     # know) runs while the GPU still has step k queued.  The host therefore never blocks an idle GPU, and everything
     # stays inside the timed region.
     def run(lo, hi, timed_loss=None):
-        cur = begin(batches[lo]).finish()
-        pend = begin(batches[lo + 1]) if lo + 1 < hi else None
-        loss = None
-        for i in range(lo, hi):
-            loss = step(batches[i], cur)
-            nxt_pend = begin(batches[i + 2]) if i + 2 < hi else None
-            cur = pend.finish() if pend is not None else None
-            pend = nxt_pend
-        return loss
+        from esrecsys_amd.train_state import quiet_gc
+        with quiet_gc():  # as the loop helpers: a full cyclic collection inside the loop is a 40 ms hole in the launches
+            cur = begin(batches[lo]).finish()
+            pend = begin(batches[lo + 1]) if lo + 1 < hi else None
+            loss = None
+            for i in range(lo, hi):
+                loss = step(batches[i], cur)
+                nxt_pend = begin(batches[i + 2]) if i + 2 < hi else None
+                cur = pend.finish() if pend is not None else None
+                pend = nxt_pend
+            return loss
 
     loss = run(0, args.warmup)
     torch.cuda.synchronize()

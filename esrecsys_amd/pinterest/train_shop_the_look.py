@@ -407,6 +407,12 @@ def train_steps(state, batches, num_steps, regularization, batch_size, scale=1.0
     drawn from the iterator and sorted together by one batched call in front of their steps (``ESR_STL_SORT_BATCH``;
     ``ESR_STL_PRESORT_DEPTH=n`` instead sorts the ids of the next n batches on a second stream -- measured slower, see
     _LOOP_DEPTH); otherwise it is ``train_step`` as is."""
+    from ..train_state import quiet_gc
+    with quiet_gc():
+        return _train_steps(state, batches, num_steps, regularization, batch_size, scale, precision)
+
+
+def _train_steps(state, batches, num_steps, regularization, batch_size, scale, precision):
     it = iter(batches)
     if num_steps > 0:
         first = next(it)

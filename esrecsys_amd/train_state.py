@@ -18,6 +18,28 @@ from . import ops
 _side_streams = {}
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def quiet_gc():
+    """For the loop helpers (train_epoch, train_steps): everything alive at entry is parked in the collector's permanent
+    generation for the duration (``gc.freeze``, O(1)), so a cyclic collection that falls into the loop only walks the
+    loop's own few objects.  A full collection walks ~10^6 objects once torch is imported -- 37-40 ms measured, during
+    which nothing is launched: in a 200-step in-batch run (47 ms of GPU work) ONE such pause cut the throughput from 34
+    to 20-30 M pairs/s.  ``ESR_LOOP_GC_FREEZE=0`` leaves the collector alone."""
+    import gc
+    import os
+    if os.environ.get("ESR_LOOP_GC_FREEZE", "1") != "1" or not hasattr(gc, "freeze"):
+        yield
+        return
+    gc.freeze()
+    try:
+        yield
+    finally:
+        gc.unfreeze()
+
+
 def _side_stream(device):
     key = (device.type, device.index)
     if key not in _side_streams:

@@ -293,6 +293,12 @@ def train_epoch(state, steps_per_epoch, train_it):
     epoch mean is taken, so the loop never synchronises.  With the build's sparse Adagrad every step is the
     one-pass step (``train_step``'s kernels, driven through a per-epoch context that keeps the per-step Python to one
     library call); with the reference's dense Adam it is apply_model + update_model as there."""
+    from ..train_state import quiet_gc
+    with quiet_gc():  # (a full cyclic collection inside the loop is a 40 ms hole in the launch stream)
+        return _train_epoch(state, steps_per_epoch, train_it)
+
+
+def _train_epoch(state, steps_per_epoch, train_it):
     if fused_step_available(state) and steps_per_epoch > 0:
         ctx = _FusedEpoch(state, steps_per_epoch)
         # Batches are fetched _PRESORT_DEPTH ahead so that their ids can be sorted on the side stream under the update

@@ -111,3 +111,22 @@ def test_retrieve_mode_resolution(monkeypatch):
     assert ops._retrieve_mode("f32") == _lib.RETRIEVE_EXACT
     with pytest.raises(ValueError):
         ops._retrieve_mode("int8")
+
+
+def test_quiet_gc_parks_and_restores(monkeypatch):
+    """The loop helpers run under train_state.quiet_gc: live objects parked in the permanent generation for the duration
+    (a full collection inside the loop is then cheap), everything back afterwards, also when the body raises."""
+    import gc
+    from esrecsys_amd.train_state import quiet_gc
+    assert gc.get_freeze_count() == 0
+    with quiet_gc():
+        assert gc.get_freeze_count() > 0
+        gc.collect()           # walks only what was created inside
+    assert gc.get_freeze_count() == 0
+    with pytest.raises(ValueError):
+        with quiet_gc():
+            raise ValueError("x")
+    assert gc.get_freeze_count() == 0
+    monkeypatch.setenv("ESR_LOOP_GC_FREEZE", "0")
+    with quiet_gc():
+        assert gc.get_freeze_count() == 0
