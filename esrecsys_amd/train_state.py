@@ -30,8 +30,8 @@ def quiet_gc():
     to 20-30 M pairs/s.  ``ESR_LOOP_GC_FREEZE=0`` leaves the collector alone."""
     import gc
     import os
-    if os.environ.get("ESR_LOOP_GC_FREEZE", "1") != "1" or not hasattr(gc, "freeze"):
-        yield
+    if os.environ.get("ESR_LOOP_GC_FREEZE", "1") != "1" or not hasattr(gc, "freeze") or gc.get_freeze_count() > 0:
+        yield  # switched off, or somebody (the application, an enclosing loop helper) has frozen the heap already
         return
     gc.freeze()
     try:
