@@ -2,6 +2,7 @@
 for the id / row / gradient exchange (esrecsys_amd/sharded.py).  Weak scaling: every rank draws its own B
 pairs per step; value = N * B * K / max-over-ranks time."""
 import json
+import sys
 import time
 
 import numpy as np
@@ -84,6 +85,10 @@ def run_sharded(args, cfg, dev, rank, world):
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
+    if sharded._trace is not None and rank == 0:
+        print("sharded loop: %.1f us per step wall, %.1f us of it waiting for the routing-plan copy (%d waits)" % (
+            (time.perf_counter() - t0) / args.steps * 1e6, sharded._trace[0] / max(1, sharded._trace[1]) * 1e6,
+            sharded._trace[1]), file=sys.stderr)
     dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     total = loss.clone()

@@ -85,6 +85,9 @@ class RoutingPlan:
 
 
 _pinned_ring = {}
+# ESR_TRACE_HOST=1: [seconds the host spent waiting for the counts copies, number of waits] -- is a sharded loop bound by
+# the host (no waiting: it cannot keep up) or by the GPU (it waits every step)?
+_trace = [0.0, 0] if os.environ.get("ESR_TRACE_HOST") == "1" else None
 
 
 def _pinned_like(t, depth=8):
@@ -110,7 +113,14 @@ class PendingPlans:
     def finish(self):
         if self.plans is None:
             if self.event is not None:
-                self.event.synchronize()
+                if _trace is not None:
+                    import time
+                    t0 = time.perf_counter()
+                    self.event.synchronize()
+                    _trace[0] += time.perf_counter() - t0
+                    _trace[1] += 1
+                else:
+                    self.event.synchronize()
             both = self.both_host
             self.plans = [RoutingPlan(group, n, local_rows, perm, both[0, :, i].tolist(), both[1, :, i].tolist(), inv)
                           for i, (group, n, local_rows, perm, _, inv) in enumerate(self.parts)]
