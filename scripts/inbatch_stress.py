@@ -1,0 +1,40 @@
+"""Randomised parity sweep of the in-batch head (all precisions the shapes allow) against the fp64 oracle: B, D, temperature
+and operand magnitudes drawn at random, a late dominant candidate in a third of the cases (the redo launch of the fp16
+path).  Prints the worst relative error per precision and every case beyond 1e-5 (north_star's bound)."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from esrecsys_amd import ops
+from oracle import stl_head as o_stl
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-30))
+
+dev = torch.device("cuda", 0)
+rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
+worst, bad = {}, 0
+N = int(os.environ.get("CASES", "60"))
+for case in range(N):
+    B = int(rng.choice([128, 256, 384, 640, 1024, 1408, 2048, 3072, 4096]))
+    D = int(rng.choice([64, 96, 100, 124, 128]))
+    scale = float(rng.choice([-12.0, -3.0, 0.5, 1.0, 4.0, 8.0, 16.0]))
+    mq, mc = float(10 ** rng.uniform(-2, 0.5)), float(10 ** rng.uniform(-2, 0.5))
+    q = (rng.standard_normal((B, D)) * mq / np.sqrt(D)).astype(np.float32)
+    c = (rng.standard_normal((B, D)) * mc / np.sqrt(D)).astype(np.float32)
+    if case % 3 == 0:
+        j = int(rng.integers(B // 2, B))
+        c[j] = (3.0 * mc) * q[7] / max(np.linalg.norm(q[7]), 1e-20) * (1 if scale > 0 else -1)
+    bs = float(rng.choice([B, 77.0, 2 * B]))
+    el, else_, egq, egc = o_stl.inbatch_softmax_loss_and_grads(q.astype(np.float64), c.astype(np.float64), 0.1, bs, scale, np.float64)
+    for prec in ("f32", "bf16x3", "f16x2"):
+        if prec != "f32" and ops.inbatch_split_path(prec, B, D, bf16_tables=False) is None:
+            continue
+        loss, lse, gq, gc = ops.inbatch_softmax_fwd_bwd(torch.from_numpy(q).to(dev), torch.from_numpy(c).to(dev), scale, 0.1, bs, precision=prec)
+        errs = (abs(float(loss) - el) / abs(el), rel(lse.cpu().numpy(), else_), rel(gq.cpu().numpy(), egq), rel(gc.cpu().numpy(), egc))
+        e = max(errs)
+        worst[prec] = max(worst.get(prec, 0.0), e)
+        if not np.isfinite(e) or e > 1e-5:
+            bad += 1
+            print("BEYOND 1e-5:", prec, dict(B=B, D=D, scale=scale, mq=mq, mc=mc, bs=bs, case=case), ["%.2e" % x for x in errs])
+print("cases", N, "worst relative error per precision:", {k: "%.2e" % v for k, v in worst.items()}, "beyond bound:", bad)
