@@ -2,6 +2,7 @@
 for the id / row / gradient exchange (esrecsys_amd/sharded.py).  Weak scaling: every rank draws its own B
 pairs per step; value = N * B * K / max-over-ranks time."""
 import json
+import os
 import sys
 import time
 
@@ -51,6 +52,21 @@ def run_sharded(args, cfg, dev, rank, world):
             return sharded.begin_plan_inbatch(towers, b[0], b[1])
         return sharded.begin_plan_triplet(towers, b[0], b[1], b[2])
 
+    def lookup(b):  # (group, virtual id segments) of one batch, for begin_plans
+        if args.workload == "glove":
+            return (emb, emb.virtual_id_segments([b[0].reshape(-1)], [0]))
+        if args.workload == "inbatch":
+            return (towers, towers.virtual_id_segments([b[0], b[1]], [0, 1]))
+        return (towers, towers.virtual_id_segments([b[0], b[1], b[2]], [0, 1, 1]))
+
+    # ESR_SHARDED_PLAN_GROUP=K (> 1): the routing plans of K coming batches are made together -- K bucket kernels, ONE
+    # counts all-to-all, ONE copy to pinned memory and ONE host wait per K steps instead of one each per step -- and the
+    # next group's are enqueued in front of this group's steps, K steps before the host needs them.
+    # (1: a plan per step, pipelined two batches deep -- the loop of round 1.  World 1, B = 8192: in-batch step 27.6 ->
+    # 28.1 M pairs/s, triplet 52.2 -> 60.6 M triplets/s, GloVe 110.9 -> 114.3 M pairs/s; the counts exchange it saves
+    # costs more across ranks than as the self-copy it is there.)
+    plan_group = max(1, int(os.environ.get("ESR_SHARDED_PLAN_GROUP", "8")))
+
     def step(b, plans):
         if args.workload == "glove":
             return sharded.sharded_glove_step(emb, bias, b[0], b[1], ops.GLOVE_REFERENCE, LR, plan=plans)
@@ -65,6 +81,18 @@ def run_sharded(args, cfg, dev, rank, world):
     # stays inside the timed region.
     def run(lo, hi, timed_loss=None):
         from esrecsys_amd.train_state import quiet_gc
+        if plan_group > 1:
+            with quiet_gc():
+                groups = [(a, min(a + plan_group, hi)) for a in range(lo, hi, plan_group)]
+                pend = sharded.begin_plans([lookup(batches[i]) for i in range(*groups[0])])
+                loss = None
+                for gi, (a, b_) in enumerate(groups):
+                    plans = pend.finish()  # ids all-to-alls + owner-side sorts of the whole group, ahead of its steps
+                    pend = sharded.begin_plans([lookup(batches[i]) for i in range(*groups[gi + 1])]) \
+                        if gi + 1 < len(groups) else None
+                    for i in range(a, b_):
+                        loss = step(batches[i], plans[i - a])
+                return loss
         with quiet_gc():  # as the loop helpers: a full cyclic collection inside the loop is a 40 ms hole in the launches
             cur = begin(batches[lo]).finish()
             pend = begin(batches[lo + 1]) if lo + 1 < hi else None

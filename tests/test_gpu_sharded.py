@@ -102,3 +102,40 @@ def test_sharded_bf16_towers_world1(dev, pg):
     exp_bf16 = torch.from_numpy(es).to(torch.bfloat16).float().numpy()
     assert scene.local.dtype == torch.bfloat16 and np.mean(got == exp_bf16) > 0.999
     assert np.abs(scene.accum.cpu().numpy() - ea).max() <= 1e-5 * np.abs(ea).max()
+
+
+@pytest.mark.parametrize("workload", ["inbatch", "triplet"])
+def test_sharded_routing_plans_made_in_groups(dev, pg, workload):
+    """begin_plans with several lookups (bench_sharded.py's ESR_SHARDED_PLAN_GROUP): the plans of six batches made
+    together -- one counts exchange, one host wait -- give the same tables and losses, bit for bit, as six plans made
+    one at a time."""
+    from esrecsys_amd import ops, sharded
+    V, D, B, lam, lr, steps = 20000, 128, 1024, 0.1, 0.05, 6
+    g = torch.Generator().manual_seed(9)
+    t0 = torch.randn((V, D), generator=g) * D ** -0.5
+    t1 = torch.randn((V, D), generator=g) * D ** -0.5
+    rng = np.random.default_rng(10)
+    batches = [[torch.from_numpy(rng.integers(0, V, B).astype(np.int32)).to(dev) for _ in range(3)] for _ in range(steps)]
+
+    def run(grouped):
+        tabs = [sharded.RowShardedTable(t.clone().to(dev), torch.full(t.shape, 0.1, device=dev), V) for t in (t0, t1)]
+        towers = sharded.ShardedTableGroup(tabs, kernels=ops)
+        segs = (lambda b: (b, [0, 1, 1])) if workload == "triplet" else (lambda b: (b[:2], [0, 1]))
+        plans = None
+        if grouped:
+            plans = sharded.begin_plans([(towers, towers.virtual_id_segments(*segs(b))) for b in batches]).finish()
+        losses = []
+        for i, b in enumerate(batches):
+            plan = plans[i] if plans is not None else None
+            if workload == "triplet":
+                losses.append(sharded.sharded_triplet_step(towers, *b, lam, float(B), lr, plan=plan))
+            else:
+                losses.append(sharded.sharded_inbatch_step(towers, b[0], b[1], lam, float(B), 8.0, lr, plan=plan))
+        torch.cuda.synchronize()
+        return [t.local.clone() for t in tabs] + [t.accum.clone() for t in tabs], torch.stack([l.reshape(()) for l in losses])
+
+    tabs_a, loss_a = run(True)
+    tabs_b, loss_b = run(False)
+    assert torch.equal(loss_a, loss_b)
+    for a, b in zip(tabs_a, tabs_b):
+        assert torch.equal(a, b)

@@ -36,7 +36,7 @@ def _batch(step, rank):
     return sid, pid, nid
 
 
-def _worker(rank, port, outdir, workload):
+def _worker(rank, port, outdir, workload, grouped=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     import _cpu_kernels as K
@@ -49,12 +49,24 @@ def _worker(rank, port, outdir, workload):
     assert scene.local.shape[0] == sharded.RowShardedTable.local_rows_for(V_S, WORLD, rank)
     assert towers.voff[1] % WORLD == 0 and towers.voff[1] >= V_S
     losses = []
+    plans = None
+    if grouped:
+        # the routing plans of ALL the batches made together (bench_sharded.py, ESR_SHARDED_PLAN_GROUP): one counts
+        # all-to-all and one host wait for the group, the ids exchanges and owner-side sorts ahead of the steps
+        lookups = []
+        for step in range(STEPS):
+            sid, pid, nid = (torch.from_numpy(x) for x in _batch(step, rank))
+            segs = ([sid, pid, nid], [0, 1, 1]) if workload == "triplet" else ([sid, pid], [0, 1])
+            lookups.append((towers, towers.virtual_id_segments(*segs)))
+        plans = sharded.begin_plans(lookups).finish()
+        assert len(plans) == STEPS
     for step in range(STEPS):
         sid, pid, nid = (torch.from_numpy(x) for x in _batch(step, rank))
+        plan = plans[step] if plans is not None else None
         if workload == "triplet":
-            loss = sharded.sharded_triplet_step(towers, sid, pid, nid, LAM, float(WORLD * B), LR)
+            loss = sharded.sharded_triplet_step(towers, sid, pid, nid, LAM, float(WORLD * B), LR, plan=plan)
         else:
-            loss = sharded.sharded_inbatch_step(towers, sid, pid, LAM, float(WORLD * B), 2.0, LR)
+            loss = sharded.sharded_inbatch_step(towers, sid, pid, LAM, float(WORLD * B), 2.0, LR, plan=plan)
         total = loss.clone()
         dist.all_reduce(total)
         losses.append(float(total))
@@ -64,13 +76,13 @@ def _worker(rank, port, outdir, workload):
     dist.destroy_process_group()
 
 
-def _run(workload):
+def _run(workload, grouped=False):
     import socket
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(port, d, workload), nprocs=WORLD, join=True)
+        mp.spawn(_worker, args=(port, d, workload, grouped), nprocs=WORLD, join=True)
         outs = [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(WORLD)]
     return outs
 
@@ -83,10 +95,11 @@ def _reassemble(outs, key, V):
 
 
 @pytest.mark.timeout(300)
-def test_sharded_triplet_equals_single_device():
+@pytest.mark.parametrize("grouped", [False, True])
+def test_sharded_triplet_equals_single_device(grouped):
     from oracle import optim as o_optim
     from oracle import stl_head as o_stl
-    outs = _run("triplet")
+    outs = _run("triplet", grouped)
     st, pt = _full_tables()
     a_s, a_p = np.full_like(st, 0.1), np.full_like(pt, 0.1)
     for step in range(STEPS):
@@ -104,12 +117,13 @@ def test_sharded_triplet_equals_single_device():
 
 
 @pytest.mark.timeout(300)
-def test_sharded_inbatch_matches_per_rank_oracle():
+@pytest.mark.parametrize("grouped", [False, True])
+def test_sharded_inbatch_matches_per_rank_oracle(grouped):
     """In-batch negatives are per rank, so the single-device equivalent is: each rank's local-batch
     gradients (normalised by the global batch), scattered into one shared table."""
     from oracle import optim as o_optim
     from oracle import stl_head as o_stl
-    outs = _run("inbatch")
+    outs = _run("inbatch", grouped)
     st, pt = _full_tables()
     a_s, a_p = np.full_like(st, 0.1), np.full_like(pt, 0.1)
     for step in range(STEPS):
