@@ -10,8 +10,8 @@ travel together: their ids become *virtual ids* ``voff[t] + id`` with every ``vo
 owner maps back to (table, local row).  One step of a group is then four collectives over RCCL all-to-all
 (xGMI is a full mesh: every peer slice rides its own link) instead of three per table:
 
-    counts -> peers      int64 [G, L]                      \\  the routing PLAN: depends on the ids only, pipelined
-    vids   -> owners     int32 virtual local rows          /   two batches deep (begin_plans / PendingPlans.finish)
+    counts -> peers      int64 [G, L]                      \\  the routing PLAN: depends on the ids only, made ahead --
+    vids   -> owners     int32 virtual local rows          /   begin_plans (L lookups = L coming batches) / finish
     rows   <- owners     [n, D]  (multi-table gather kernel on the owner; the rows stay in exchange order and
                                   the loss kernels index them through the inverse routing permutation)
     grads  -> owners     [n, D]  (written by the loss kernels directly in exchange order; then ONE fused
@@ -19,7 +19,8 @@ owner maps back to (table, local row).  One step of a group is then four collect
 
 The plan phase holds the step's single host read-back (all-to-all-v needs host-side split sizes): begin_plans
 enqueues the bucket kernel, the counts exchange and an asynchronous copy to pinned memory; finish() -- called one
-step later, when the next step's kernels are already queued -- waits for that copy only, then exchanges the ids
+step later (or, with the plans of a whole group of coming batches made by one begin_plans call, a group of steps
+later: bench_sharded.py), when the next kernels are already queued -- waits for that copy only, then exchanges the ids
 and sorts them on the owner.  The exchange itself is RCCL send / recv on the compute stream (esrecsys_amd/rccl.py),
 falling back to torch.distributed.all_to_all_single.
 
