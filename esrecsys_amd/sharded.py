@@ -111,6 +111,9 @@ class PendingPlans:
         self.parts, self.both_dev, self.both_host, self.event = parts, both_dev, both_host, event
         self.plans = None
 
+    def _exchange_ids_grouped(self):
+        return _grouped_owner_sort(self.plans)
+
     def finish(self):
         if self.plans is None:
             if self.event is not None:
@@ -125,10 +128,37 @@ class PendingPlans:
             both = self.both_host
             self.plans = [RoutingPlan(group, n, local_rows, perm, both[0, :, i].tolist(), both[1, :, i].tolist(), inv)
                           for i, (group, n, local_rows, perm, _, inv) in enumerate(self.parts)]
-            for p in self.plans:
-                p.exchange_ids()
+            if not self._exchange_ids_grouped():
+                for p in self.plans:
+                    p.exchange_ids()
             self.parts = self.both_dev = None
         return self.plans
+
+
+def _grouped_owner_sort(plans):
+    """The ids exchanges of a group of plans of ONE table group, and their owner-side sorts as ONE batched sort
+    (esr_segment_sort_ids_batched): the lists a rank is asked for differ in length from batch to batch, so they are
+    received into rows of one [L, n_max] buffer pre-filled with a sentinel row id that sorts behind every real one --
+    list b's sorted ids / permutation are the first n_b entries of row b.  Returns False when the kernels, the sizes or
+    the groups do not allow it (the caller then sorts plan by plan)."""
+    g = plans[0].group
+    k = g.k
+    L = len(plans)
+    dev = plans[0].local_rows.device
+    if L < 2 or L > 8 or dev.type != "cuda" or not hasattr(k, "segment_sort_batched") or any(p.group is not g for p in plans):
+        return False
+    ns = [sum(p.recv_counts) for p in plans]
+    n_max, sentinel = max(ns), g.loff[-1]
+    if n_max == 0 or n_max > 32768 or sentinel + 1 > (1 << 21):
+        return False
+    buf = torch.full((L, n_max), sentinel, dtype=torch.int32, device=dev)
+    for i, p in enumerate(plans):
+        p.recv_local_rows = buf[i, :ns[i]]
+        _a2a(g, p.recv_local_rows, p.local_rows, p.recv_counts, p.send_counts)
+    srt, prm = k.segment_sort_batched([[buf[i]] for i in range(L)], (0,), sentinel + 1)
+    for i, p in enumerate(plans):
+        p.owner_sorted = (srt[i, :ns[i]], prm[i, :ns[i]]) if ns[i] else None
+    return True
 
 
 def begin_plans(lookups):
