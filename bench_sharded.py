@@ -62,9 +62,10 @@ def run_sharded(args, cfg, dev, rank, world):
     # ESR_SHARDED_PLAN_GROUP=K (> 1): the routing plans of K coming batches are made together -- K bucket kernels, ONE
     # counts all-to-all, ONE copy to pinned memory and ONE host wait per K steps instead of one each per step -- and the
     # next group's are enqueued in front of this group's steps, K steps before the host needs them.
-    # (1: a plan per step, pipelined two batches deep -- the loop of round 1.  World 1, B = 8192: in-batch step 27.6 ->
-    # 28.1 M pairs/s, triplet 52.2 -> 60.6 M triplets/s, GloVe 110.9 -> 114.3 M pairs/s; the counts exchange it saves
-    # costs more across ranks than as the self-copy it is there.)
+    # (1: a plan per step, pipelined two batches deep -- the loop of round 1.  World 1, B = 8192, with the group's bucket
+    # kernels and owner-side sorts batched as well: in-batch step 27.6 -> 30.4 M pairs/s, triplet 52.2 -> 82-88 M
+    # triplets/s, GloVe 110.9 -> 114 M pairs/s; the counts exchange it saves costs more across ranks than as the
+    # self-copy it is there.)
     plan_group = max(1, int(os.environ.get("ESR_SHARDED_PLAN_GROUP", "8")))
 
     def step(b, plans):

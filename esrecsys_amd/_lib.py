@@ -111,6 +111,9 @@ SIGNATURES = {
     "esr_bucket_ids_by_owner": (c_int, [c_i32p, c_i64, c_int, c_i32p, c_i32p, c_i32p, c_vp, c_vp, c_size, c_vp]),
     "esr_bucket_ids_by_owner_multi": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_i32p, c_i32p, c_i32p, c_vp, c_vp, c_size,
                                               c_vp]),
+    "esr_bucket_batched_workspace_bytes": (c_size, [c_i64, c_int]),
+    "esr_bucket_ids_by_owner_batched": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_i32p, c_i32p, c_i32p, c_vp, c_vp,
+                                                c_size, c_vp]),
     "esr_comm_load": (c_int, [ctypes.c_char_p]),
     "esr_comm_unique_id": (c_int, [c_vp]),
     "esr_comm_init": (c_int, [c_vp, c_int, c_int, ctypes.POINTER(c_vp)]),

@@ -604,12 +604,13 @@ constexpr int kBucketTileMax = 1024;  // n <= 1 Mi ids
 __device__ __forceinline__ int owner_of(uint32_t id, int world, bool pow2) {
   return (int)(pow2 ? id & (uint32_t)(world - 1) : id % (uint32_t)world);
 }
-__global__ __launch_bounds__(kBucketThreads) void bucket_count_kernel(SortSegs ids, int n, int world,
-                                                                     int* __restrict__ wave_cells,   // [T][16][8]
-                                                                     int* __restrict__ tile_tot) {   // [T][8]
+__device__ __forceinline__ void bucket_count_body(const SortSegs& ids, int n, int world,
+                                                  int* __restrict__ wave_cells,   // [T][16][8]
+                                                  int* __restrict__ tile_tot,     // [T][8]
+                                                  int tile) {
   constexpr int kWaves = kBucketThreads / 64;
   __shared__ int cnt[kWaves][kBucketMaxWorld];
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, tile = blockIdx.x;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const bool pow2 = (world & (world - 1)) == 0;
   const int j = tile * kBucketThreads + t;
   const int own = j < n ? owner_of((uint32_t)seg_id(ids, j), world, pow2) : -1;
@@ -629,18 +630,30 @@ __global__ __launch_bounds__(kBucketThreads) void bucket_count_kernel(SortSegs i
     tile_tot[tile * kBucketMaxWorld + t] = tot;
   }
 }
-__global__ __launch_bounds__(kBucketThreads) void bucket_scatter_kernel(SortSegs ids, int n, int world,
-                                                                       const int* __restrict__ wave_cells,
-                                                                       const int* __restrict__ tile_tot,
-                                                                       int32_t* __restrict__ inverse,
-                                                                       int32_t* __restrict__ local_rows,
-                                                                       int32_t* __restrict__ perm,
-                                                                       int64_t* __restrict__ counts) {
+__global__ __launch_bounds__(kBucketThreads) void bucket_count_kernel(SortSegs ids, int n, int world,
+                                                                     int* __restrict__ wave_cells,
+                                                                     int* __restrict__ tile_tot) {
+  bucket_count_body(ids, n, world, wave_cells, tile_tot, blockIdx.x);
+}
+// the lists of several coming batches at once (blockIdx.y = the list; cells: ints between the lists' workspaces)
+__global__ __launch_bounds__(kBucketThreads) void bucket_count_batched_kernel(SortSegsBatch sb, int n, int world,
+                                                                             int* __restrict__ wave_cells,
+                                                                             int* __restrict__ tile_tot,
+                                                                             int64_t cells) {
+  const int y = blockIdx.y;
+  bucket_count_body(sb.b[y], n, world, wave_cells + y * cells, tile_tot + y * cells, blockIdx.x);
+}
+__device__ __forceinline__ void bucket_scatter_body(const SortSegs& ids, int n, int world,
+                                                    const int* __restrict__ wave_cells,
+                                                    const int* __restrict__ tile_tot,
+                                                    int32_t* __restrict__ inverse, int32_t* __restrict__ local_rows,
+                                                    int32_t* __restrict__ perm, int64_t* __restrict__ counts,
+                                                    int tile, int ntiles) {
   constexpr int kWaves = kBucketThreads / 64;
   __shared__ int red[2][kWaves][kBucketMaxWorld];  // [all tiles | earlier tiles] per wave and owner
   __shared__ int tot_s[kBucketMaxWorld], bef_s[kBucketMaxWorld];
   __shared__ int wcell[kWaves][kBucketMaxWorld], wpre[kWaves][kBucketMaxWorld];
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, tile = blockIdx.x, ntiles = gridDim.x;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const bool pow2 = (world & (world - 1)) == 0;
   const int j = tile * kBucketThreads + t;
   const uint32_t id = j < n ? (uint32_t)seg_id(ids, j) : 0u;  // in flight while the offsets are worked out
@@ -696,6 +709,28 @@ __global__ __launch_bounds__(kBucketThreads) void bucket_scatter_kernel(SortSegs
     local_rows[pos] = (int32_t)(pow2 ? id >> __builtin_ctz(world) : id / (uint32_t)world);
     if (inverse) inverse[j] = pos;
   }
+}
+__global__ __launch_bounds__(kBucketThreads) void bucket_scatter_kernel(SortSegs ids, int n, int world,
+                                                                       const int* __restrict__ wave_cells,
+                                                                       const int* __restrict__ tile_tot,
+                                                                       int32_t* __restrict__ inverse,
+                                                                       int32_t* __restrict__ local_rows,
+                                                                       int32_t* __restrict__ perm,
+                                                                       int64_t* __restrict__ counts) {
+  bucket_scatter_body(ids, n, world, wave_cells, tile_tot, inverse, local_rows, perm, counts, blockIdx.x, gridDim.x);
+}
+__global__ __launch_bounds__(kBucketThreads) void bucket_scatter_batched_kernel(SortSegsBatch sb, int n, int world,
+                                                                               const int* __restrict__ wave_cells,
+                                                                               const int* __restrict__ tile_tot,
+                                                                               int64_t cells,
+                                                                               int32_t* __restrict__ inverse,
+                                                                               int32_t* __restrict__ local_rows,
+                                                                               int32_t* __restrict__ perm,
+                                                                               int64_t* __restrict__ counts) {
+  const int y = blockIdx.y;
+  bucket_scatter_body(sb.b[y], n, world, wave_cells + y * cells, tile_tot + y * cells,
+                      inverse ? inverse + (int64_t)y * n : nullptr, local_rows + (int64_t)y * n, perm + (int64_t)y * n,
+                      counts + (int64_t)y * world, blockIdx.x, gridDim.x);
 }
 
 // One workgroup, ids taken round by round (round r = ids [1024 r, 1024 r + 1024), thread t = one id): every access
@@ -1309,5 +1344,67 @@ int esr_bucket_ids_by_owner_multi(const int32_t* const* ids, const int64_t* seg_
   return bucket_plain("esr_bucket_ids_by_owner_multi", vids, n, world, local_rows, perm, inverse, counts,
                       n > 0 ? (char*)workspace + col : nullptr, n > 0 ? workspace_bytes - col : 0, st);
 }
+
+size_t esr_bucket_batched_workspace_bytes(int64_t n, int nbatch) {
+  if (n <= 0 || nbatch <= 0) return 256;
+  const size_t tiled = (size_t)cdiv(n, kBucketThreads) * (kBucketThreads / 64 + 1) * kBucketMaxWorld * sizeof(int);
+  return std::max(esr_bucket_workspace_bytes(n), align_up((size_t)nbatch * tiled, 256));
+}
+
+int esr_bucket_ids_by_owner_batched(const int32_t* const* ids, const int64_t* seg_counts, const int64_t* offsets,
+                                    int nseg, int nbatch, int world, int32_t* local_rows, int32_t* perm,
+                                    int32_t* inverse, int64_t* counts, void* workspace, size_t workspace_bytes,
+                                    esr_stream_t stream) {
+  ESR_REQUIRE(nseg >= 1 && nseg <= kMaxSortSegs && nbatch >= 1 && nbatch <= kMaxSortBatch && ids && seg_counts &&
+                  offsets && world > 0 && counts,
+              "esr_bucket_ids_by_owner_batched: nseg=%d not in [1, %d], nbatch=%d not in [1, %d], world=%d or null "
+              "argument", nseg, kMaxSortSegs, nbatch, kMaxSortBatch, world);
+  SortSegsBatch sb;
+  int64_t n = 0;
+  for (int b = 0; b < nbatch; ++b) {
+    SortSegs& sg = sb.b[b];
+    sg.n = nseg;
+    sg.start[0] = 0;
+    for (int i = 0; i < kMaxSortSegs; ++i) {
+      const int32_t* src = i < nseg ? ids[(size_t)b * nseg + i] : nullptr;
+      ESR_REQUIRE(i >= nseg || (seg_counts[i] >= 0 && (seg_counts[i] == 0 || src)),
+                  "esr_bucket_ids_by_owner_batched: bad segment %d of list %d", i, b);
+      sg.ids[i] = src;
+      sg.offset[i] = i < nseg ? offsets[i] : 0;
+      sg.start[i + 1] = sg.start[i] + (i < nseg ? seg_counts[i] : 0);
+    }
+    n = sg.start[nseg];
+  }
+  for (int b = nbatch; b < kMaxSortBatch; ++b) sb.b[b] = sb.b[0];
+  ESR_REQUIRE(n < ((int64_t)1 << 31), "esr_bucket_ids_by_owner_batched: n=%lld", (long long)n);
+  ESR_REQUIRE(n == 0 || (local_rows && perm), "esr_bucket_ids_by_owner_batched: null pointer");
+  if (workspace_bytes < esr_bucket_batched_workspace_bytes(n, nbatch) || (n > 0 && (!workspace || ((uintptr_t)workspace & 15)))) {
+    set_error("esr_bucket_ids_by_owner_batched: workspace %zu bytes < %zu required (or misaligned)", workspace_bytes,
+              esr_bucket_batched_workspace_bytes(n, nbatch));
+    return ESR_EWORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  const int64_t ntiles = cdiv(n, kBucketThreads);
+  if (n > 2048 && ntiles <= kBucketTileMax && world <= kBucketMaxWorld) {  // two launches for all the lists
+    const int64_t cells = ntiles * (kBucketThreads / 64 + 1) * kBucketMaxWorld;
+    int* wave_cells = (int*)workspace;
+    int* tile_tot = wave_cells + ntiles * (kBucketThreads / 64) * kBucketMaxWorld;
+    hipLaunchKernelGGL(bucket_count_batched_kernel, dim3((int)ntiles, nbatch), dim3(kBucketThreads), 0, st, sb, (int)n,
+                       world, wave_cells, tile_tot, cells);
+    hipLaunchKernelGGL(bucket_scatter_batched_kernel, dim3((int)ntiles, nbatch), dim3(kBucketThreads), 0, st, sb, (int)n,
+                       world, (const int*)wave_cells, (const int*)tile_tot, cells, inverse, local_rows, perm, counts);
+    return check_launch("esr_bucket_ids_by_owner_batched");
+  }
+  for (int b = 0; b < nbatch; ++b) {  // short or very long lists: one after the other (the workspace is reused)
+    const int32_t* segs[kMaxSortSegs];
+    for (int i = 0; i < nseg; ++i) segs[i] = ids[(size_t)b * nseg + i];
+    if (int rc = esr_bucket_ids_by_owner_multi(segs, seg_counts, offsets, nseg, world, local_rows + (int64_t)b * n,
+                                               perm + (int64_t)b * n, inverse ? inverse + (int64_t)b * n : nullptr,
+                                               counts + (int64_t)b * world, workspace, workspace_bytes, stream))
+      return rc;
+  }
+  return ESR_OK;
+}
+
 
 }  // extern "C"

@@ -733,6 +733,34 @@ def inbatch_towers_fwd_bwd(query_table, cand_table, query_ids, cand_ids, scale, 
     return loss, lse, gQC[:B], gQC[B:]
 
 
+def bucket_ids_by_owner_batched(id_lists, world, offsets):
+    """bucket_ids_by_owner for the lists of several coming batches in one launch pair (esr_bucket_ids_by_owner_batched).
+    id_lists: per batch, the int32 segments of its virtual list [ids_k + offsets[k]] (same lengths in every batch).
+    Returns (local_rows [L, n], perm [L, n], counts [L, world] int64, inverse [L, n])."""
+    import ctypes
+    lib = _lib.load()
+    nb, nseg = len(id_lists), len(id_lists[0])
+    dev = id_lists[0][0].device
+    seg_counts = [int(t.numel()) for t in id_lists[0]]
+    for segs in id_lists:
+        if len(segs) != nseg or [int(t.numel()) for t in segs] != seg_counts:
+            raise ValueError("every batch must have the same segment lengths")
+    id_lists = [[_req(t, torch.int32, "ids") for t in segs] for segs in id_lists]
+    n = sum(seg_counts)
+    local_rows = torch.empty((nb, n), dtype=torch.int32, device=dev)
+    perm = torch.empty((nb, n), dtype=torch.int32, device=dev)
+    inverse = torch.empty((nb, n), dtype=torch.int32, device=dev)
+    counts = torch.empty((nb, world), dtype=torch.int64, device=dev)
+    ws = _ws(_ws_bytes("esr_bucket_batched_workspace_bytes", n, nb), dev)
+    ptrs = (ctypes.c_void_p * (nb * nseg))(*[t.data_ptr() for segs in id_lists for t in segs])
+    cnt = (ctypes.c_int64 * nseg)(*seg_counts)
+    off = (ctypes.c_int64 * nseg)(*[int(x) for x in offsets])
+    check(lib.esr_bucket_ids_by_owner_batched(ptrs, cnt, off, nseg, nb, int(world), _p(local_rows), _p(perm), _p(inverse),
+                                              _p(counts), _p(ws), ws.numel(), _stream()),
+          "esr_bucket_ids_by_owner_batched")
+    return local_rows, perm, counts, inverse
+
+
 def segment_sort_batched(id_lists, offsets, num_rows, out=None):
     """The occurrence lists of several coming batches sorted in one launch sequence (esr_segment_sort_ids_batched).
     id_lists: per batch, the int32 segments of its virtual list [ids_k + offsets[k]] (same lengths in every batch).

@@ -161,6 +161,25 @@ def _grouped_owner_sort(plans):
     return True
 
 
+def _bucket_grouped(lookups, both):
+    """The bucket kernels of a group of lookups as ONE launch pair (esr_bucket_ids_by_owner_batched) when they are the
+    (id tensors, offsets) kind with identical shapes and the kernels provide it; else None.  Fills both[0] ([G, L])."""
+    g0 = lookups[0][0]
+    k, G, L = g0.k, g0.world, len(lookups)
+    if L < 2 or L > 8 or not hasattr(k, "bucket_ids_by_owner_batched") or not both.is_cuda:
+        return None
+    if not all(isinstance(v, tuple) for _, v in lookups):
+        return None
+    offs = list(lookups[0][1][1])
+    shapes = [int(t.numel()) for t in lookups[0][1][0]]
+    if any(list(v[1]) != offs or [int(t.numel()) for t in v[0]] != shapes for _, v in lookups):
+        return None
+    local_rows, perm, counts, inv = k.bucket_ids_by_owner_batched([list(v[0]) for _, v in lookups], G, offs)
+    both[0].copy_(counts.t())
+    n = sum(shapes)
+    return [(group, n, local_rows[i], perm[i], counts[i], inv[i]) for i, (group, _) in enumerate(lookups)]
+
+
 def begin_plans(lookups):
     """lookups: list of (ShardedTableGroup, virtual ids) -- an int32 [n] tensor or the (id tensors, offsets) pair of
     ShardedTableGroup.virtual_id_segments.  Enqueues everything of the routing plans that needs no host knowledge and
@@ -171,8 +190,9 @@ def begin_plans(lookups):
     # [send | recv][peer][lookup]: all_to_all_single hands every peer its L counts; with one lookup (every step of this
     # package) the bucket kernel writes its counts straight into the send half -- no stack / cat / copy launches
     both = torch.empty((2, G, L), dtype=torch.int64, device=dev)
-    parts = []
-    for group, vids in lookups:
+    grouped = _bucket_grouped(lookups, both)  # one launch pair for all the lookups (fills both[0]), or None
+    parts = grouped if grouped is not None else []
+    for group, vids in (lookups if grouped is None else []):
         out = both[0, :, 0] if L == 1 else None
         if isinstance(vids, tuple):   # (id tensors, virtual offsets): bucketed in place, never concatenated
             n = sum(int(t.numel()) for t in vids[0])
@@ -182,7 +202,7 @@ def begin_plans(lookups):
             n = vids.numel()
             local_rows, perm, counts, inv = k.bucket_ids_by_owner(vids, G, want_inverse=True, counts_out=out)
         parts.append((group, n, local_rows, perm, counts, inv))
-    if L > 1:
+    if L > 1 and grouped is None:
         both[0].copy_(torch.stack([p[4] for p in parts], dim=1))
     _a2a(g0, both[1], both[0])
     if both.is_cuda:

@@ -370,6 +370,15 @@ int esr_bucket_ids_by_owner(const int32_t* ids, int64_t n, int world, int32_t* l
 int esr_bucket_ids_by_owner_multi(const int32_t* const* ids, const int64_t* seg_counts, const int64_t* offsets,
                                   int nseg, int world, int32_t* local_rows, int32_t* perm, int32_t* inverse,
                                   int64_t* counts, void* workspace, size_t workspace_bytes, esr_stream_t stream);
+/* The lists of `nbatch` (<= 8) coming batches bucketed in ONE launch pair (row-sharded loops make the routing plans of
+ * several batches at once: esrecsys_amd/sharded.py begin_plans).  ids[b * nseg + k] = segment k of list b; seg_counts /
+ * offsets are common to the lists (n = their sum); local_rows / perm / inverse are [nbatch][n], counts [nbatch][world]:
+ * list b exactly what esr_bucket_ids_by_owner_multi gives for it. */
+size_t esr_bucket_batched_workspace_bytes(int64_t n, int nbatch);
+int esr_bucket_ids_by_owner_batched(const int32_t* const* ids, const int64_t* seg_counts, const int64_t* offsets,
+                                    int nseg, int nbatch, int world, int32_t* local_rows, int32_t* perm,
+                                    int32_t* inverse, int64_t* counts, void* workspace, size_t workspace_bytes,
+                                    esr_stream_t stream);
 /* out[perm[k], :] = rows[k, :]  (undo the bucket order for rows that came back). */
 int esr_unpermute_rows(const void* rows, int dtype, int D, const int32_t* perm, int64_t n, void* out,
                        esr_stream_t stream);

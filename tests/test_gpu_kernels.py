@@ -993,3 +993,28 @@ def test_segment_sort_batched_equals_list_by_list(dev, n_seg, nb):
         order = np.argsort(virt, kind="stable")
         assert np.array_equal(N(prm[b]), order.astype(np.int32))
         assert np.array_equal(N(srt[b]), virt[order].astype(np.int32))
+
+
+@pytest.mark.parametrize("n_seg,nb,world", [((8192, 8192), 8, 8), ((8192, 8192, 8192), 8, 2), ((3000, 3001), 3, 5),
+                                            ((500, 500), 4, 8), ((1100,), 2, 7), ((40000,), 2, 8)])
+def test_bucket_ids_by_owner_batched_equals_list_by_list(dev, n_seg, nb, world):
+    """esr_bucket_ids_by_owner_batched (the routing plans of several coming batches in one launch pair): every list
+    exactly what bucket_ids_by_owner gives for it alone -- stable order by owner = id mod world, local rows, inverse and
+    counts -- on the tiled path (n > 2048) and on the list-after-list fallback (short lists)."""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(sum(n_seg) + nb + world)
+    V = 1_000_000
+    offsets = [0, 8 * ((V + 7) // 8), 8 * ((V + 7) // 8)][:len(n_seg)]
+    offsets = [o - o % world + (world if o % world else 0) if o else 0 for o in offsets]  # multiples of the world size
+    lists = [[torch.from_numpy(rng.integers(0, V, n).astype(np.int32)).to(dev) for n in n_seg] for _ in range(nb)]
+    local, perm, counts, inv = ops.bucket_ids_by_owner_batched(lists, world, offsets)
+    n = sum(n_seg)
+    assert local.shape == perm.shape == inv.shape == (nb, n) and counts.shape == (nb, world)
+    for b, segs in enumerate(lists):
+        l1, p1, c1, i1 = ops.bucket_ids_by_owner(list(segs), world, want_inverse=True, offsets=offsets)
+        assert torch.equal(local[b], l1) and torch.equal(perm[b], p1) and torch.equal(counts[b], c1)
+        assert torch.equal(inv[b], i1)
+        virt = np.concatenate([N(t).astype(np.int64) + o for t, o in zip(segs, offsets)])
+        order = np.argsort(virt % world, kind="stable")
+        assert np.array_equal(N(perm[b]), order.astype(np.int32))
+        assert np.array_equal(N(local[b]), (virt[order] // world).astype(np.int32))
