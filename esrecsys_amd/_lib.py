@@ -122,6 +122,7 @@ SIGNATURES = {
     "esr_comm_abort": (c_int, [c_vp]),
     "esr_comm_destroy": (c_int, [c_vp]),
     "esr_alltoall_bytes": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "esr_alltoall_bytes_multi": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "esr_alltoall_ids": (c_int, [c_vp, c_i32p, c_vp, c_i32p, c_vp, c_vp]),
     "esr_alltoall_rows": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "esr_alltoall_grads": (c_int, [c_vp, c_f32p, c_int, c_vp, c_f32p, c_vp, c_vp]),

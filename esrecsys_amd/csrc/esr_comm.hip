@@ -140,6 +140,48 @@ int alltoall(const char* who, esr_comm_t comm_, const void* send, const int64_t*
   return ESR_OK;
 }
 
+// Several all-to-all(v)s as ONE RCCL group (one kernel): operation o moves slice p of send[o] (send_bytes[o * world + p]
+// bytes) to peer p and receives slice p of recv[o] from it.  Sends and receives between a pair of ranks match in issue
+// order, which is the same on every rank: operation by operation, peer by peer.
+int alltoall_multi(const char* who, esr_comm_t comm_, int n_ops, const void* const* send, const int64_t* send_bytes,
+                   void* const* recv, const int64_t* recv_bytes, esr_stream_t stream) {
+  EsrComm* c = reinterpret_cast<EsrComm*>(comm_);
+  ESR_REQUIRE(c && c->comm, "%s: null communicator", who);
+  ESR_REQUIRE(n_ops >= 0 && (n_ops == 0 || (send && recv && send_bytes && recv_bytes)), "%s: null arrays", who);
+  bool any = false;
+  for (int o = 0; o < n_ops; ++o) {
+    int64_t st = 0, rt = 0;
+    for (int p = 0; p < c->world; ++p) {
+      const int64_t sb = send_bytes[(size_t)o * c->world + p], rb = recv_bytes[(size_t)o * c->world + p];
+      ESR_REQUIRE(sb >= 0 && rb >= 0, "%s: negative count for peer %d of operation %d", who, p, o);
+      st += sb;
+      rt += rb;
+    }
+    ESR_REQUIRE(st == 0 || send[o], "%s: null send buffer of operation %d", who, o);
+    ESR_REQUIRE(rt == 0 || recv[o], "%s: null recv buffer of operation %d", who, o);
+    any = any || st > 0 || rt > 0;
+  }
+  if (!any) return ESR_OK;
+  hipStream_t s = esr::as_stream(stream);
+  ESR_NCCL(g_rccl.group_start(), who);
+  int first = 0;
+  for (int o = 0; o < n_ops; ++o) {
+    const char* sp = static_cast<const char*>(send[o]);
+    char* rp = static_cast<char*>(recv[o]);
+    for (int p = 0; p < c->world; ++p) {
+      const size_t sb = (size_t)send_bytes[(size_t)o * c->world + p], rb = (size_t)recv_bytes[(size_t)o * c->world + p];
+      if (sb && !first) first = g_rccl.send(sp, sb, kNcclInt8, p, c->comm, s);
+      if (rb && !first) first = g_rccl.recv(rp, rb, kNcclInt8, p, c->comm, s);
+      sp += sb;
+      rp += rb;
+    }
+  }
+  const int end = g_rccl.group_end();  // always closed, also after a failed send / recv
+  if (first) return nccl_fail(who, first);
+  if (end) return nccl_fail(who, end);
+  return ESR_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -217,6 +259,11 @@ int esr_comm_destroy(esr_comm_t comm) {
 int esr_alltoall_bytes(esr_comm_t comm, const void* send, const int64_t* send_bytes, void* recv,
                        const int64_t* recv_bytes, esr_stream_t stream) {
   return alltoall("esr_alltoall_bytes", comm, send, send_bytes, recv, recv_bytes, 1, stream);
+}
+
+int esr_alltoall_bytes_multi(esr_comm_t comm, int n_ops, const void* const* send, const int64_t* send_bytes,
+                             void* const* recv, const int64_t* recv_bytes, esr_stream_t stream) {
+  return alltoall_multi("esr_alltoall_bytes_multi", comm, n_ops, send, send_bytes, recv, recv_bytes, stream);
 }
 
 int esr_alltoall_ids(esr_comm_t comm, const int32_t* send_ids, const int64_t* send_counts, int32_t* recv_ids,

@@ -97,6 +97,22 @@ class DirectExchange:
         want = torch.cat([torch.full((r + 1, 3), 1000 * p + r, dtype=torch.int32) for p in range(G)])
         if not torch.equal(recv.cpu(), want):
             raise RuntimeError("direct all-to-all self-test returned wrong data")
+        # the same exchange twice inside ONE group (all_to_all_multi: the ids exchanges of a group of routing plans)
+        send2 = send + 7
+        r1, r2 = torch.full_like(recv, -1), torch.full_like(recv, -1)
+        with torch.cuda.device(self.device):
+            self.all_to_all_multi([(r1, send, recv_rows, send_rows), (r2, send2, recv_rows, send_rows)])
+            done = torch.cuda.Event()
+            done.record()
+            t0 = time.monotonic()
+            while not done.query():
+                if time.monotonic() - t0 > self.timeout:
+                    self._abort()
+                    raise RuntimeError("self-test multi all-to-all did not complete within %.0f s" % self.timeout)
+                time.sleep(0.001)
+            _lib.check(self.lib.esr_comm_async_error(self.comm), "esr_comm_async_error")
+        if not (torch.equal(r1.cpu(), want) and torch.equal(r2.cpu(), want + 7)):
+            raise RuntimeError("direct multi all-to-all self-test returned wrong data")
 
     def ranks_seen(self):
         """(world, rank) as RCCL itself reports them for this communicator (ncclCommCount / ncclCommUserRank)."""
@@ -120,6 +136,29 @@ class DirectExchange:
         _lib.check(self.lib.esr_alltoall_bytes(self.comm, inp.data_ptr(), sb, out.data_ptr(), rb, stream),
                    "esr_alltoall_bytes")
         return out
+
+    def all_to_all_multi(self, ops_):
+        """Several all_to_all_single calls -- [(out, inp, out_splits, in_splits), ...] -- as ONE RCCL group on the current
+        stream (one kernel instead of len(ops_)): the ids exchanges of a group of routing plans."""
+        G, n = self.world, len(ops_)
+        if n == 0:
+            return
+        sp, rp = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
+        sb, rb = (ctypes.c_int64 * (n * G))(), (ctypes.c_int64 * (n * G))()
+        for o, (out, inp, out_splits, in_splits) in enumerate(ops_):
+            row = inp.element_size()
+            for d in inp.shape[1:]:
+                row *= int(d)
+            if in_splits is None:
+                in_splits = [inp.shape[0] // G] * G
+            if out_splits is None:
+                out_splits = [out.shape[0] // G] * G
+            sp[o], rp[o] = inp.data_ptr(), out.data_ptr()
+            for p in range(G):
+                sb[o * G + p] = int(in_splits[p]) * row
+                rb[o * G + p] = int(out_splits[p]) * row
+        stream = torch._C._cuda_getCurrentRawStream(self.device.index)
+        _lib.check(self.lib.esr_alltoall_bytes_multi(self.comm, n, sp, sb, rp, rb, stream), "esr_alltoall_bytes_multi")
 
     def close(self):
         if self.comm:

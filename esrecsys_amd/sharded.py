@@ -154,7 +154,12 @@ def _grouped_owner_sort(plans):
     buf = torch.full((L, n_max), sentinel, dtype=torch.int32, device=dev)
     for i, p in enumerate(plans):
         p.recv_local_rows = buf[i, :ns[i]]
-        _a2a(g, p.recv_local_rows, p.local_rows, p.recv_counts, p.send_counts)
+    x = g.exchange()
+    if x is not None and hasattr(x, "all_to_all_multi"):  # the L ids exchanges as one RCCL group (one kernel)
+        x.all_to_all_multi([(p.recv_local_rows, p.local_rows, p.recv_counts, p.send_counts) for p in plans])
+    else:
+        for p in plans:
+            _a2a(g, p.recv_local_rows, p.local_rows, p.recv_counts, p.send_counts)
     srt, prm = k.segment_sort_batched([[buf[i]] for i in range(L)], (0,), sentinel + 1)
     for i, p in enumerate(plans):
         p.owner_sorted = (srt[i, :ns[i]], prm[i, :ns[i]]) if ns[i] else None

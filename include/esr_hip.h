@@ -413,6 +413,10 @@ int esr_comm_abort(esr_comm_t comm);
 int esr_comm_destroy(esr_comm_t comm);
 int esr_alltoall_bytes(esr_comm_t comm, const void* send, const int64_t* send_bytes, void* recv,
                        const int64_t* recv_bytes, esr_stream_t stream);
+/* n_ops all-to-all(v)s as ONE RCCL group: operation o sends slice p of send[o] (send_bytes[o * world + p] bytes, host
+ * arrays) to peer p and receives slice p of recv[o] from it.  The ids exchanges of a group of routing plans. */
+int esr_alltoall_bytes_multi(esr_comm_t comm, int n_ops, const void* const* send, const int64_t* send_bytes,
+                             void* const* recv, const int64_t* recv_bytes, esr_stream_t stream);
 /* int32 virtual local rows -> their owners (step 2 of SURVEY 8e). */
 int esr_alltoall_ids(esr_comm_t comm, const int32_t* send_ids, const int64_t* send_counts, int32_t* recv_ids,
                      const int64_t* recv_counts, esr_stream_t stream);
