@@ -72,12 +72,18 @@ def _worker(rank, port, outdir):
         assert x is not None, "the direct RCCL exchange must be the path under test"
         assert x.ranks_seen() == (WORLD, rank)
         losses = []
+        plans = None
+        if workload == "inbatch":
+            # the routing plans of all the batches made together, as bench_sharded.py's loop does: one batched bucket
+            # launch pair, one counts exchange, the ids exchanges as one RCCL group, one batched owner-side sort
+            ids = [[torch.from_numpy(a).to(dev) for a in _batch(step, rank)[:2]] for step in range(STEPS)]
+            plans = sharded.begin_plans([(towers, towers.virtual_id_segments(b, [0, 1])) for b in ids]).finish()
         for step in range(STEPS):
             sid, pid, nid = (torch.from_numpy(a).to(dev) for a in _batch(step, rank))
             if workload == "triplet":
                 loss = sharded.sharded_triplet_step(towers, sid, pid, nid, LAM, float(WORLD * B), LR)
             else:
-                loss = sharded.sharded_inbatch_step(towers, sid, pid, LAM, float(WORLD * B), SCALE, LR)
+                loss = sharded.sharded_inbatch_step(towers, sid, pid, LAM, float(WORLD * B), SCALE, LR, plan=plans[step])
             total = loss.clone()
             dist.all_reduce(total)
             losses.append(float(total))
