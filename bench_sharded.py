@@ -162,6 +162,9 @@ def run_sharded(args, cfg, dev, rank, world):
                                       world, B),
                        "parallelism": "row-sharded x%d, all-to-all ids/rows/grads over RCCL" % world,
                        "exchange": exchange, "rccl_ranks": rccl_ranks, "world_size": world,
+                       "routing_plans": ("made for %d coming batches at a time (one bucket launch pair, one counts "
+                                         "all-to-all, one RCCL group of ids exchanges, one owner-side sort per group)"
+                                         % plan_group) if plan_group > 1 else "one per step, pipelined two batches deep",
                        "loss": float(total)},
             "roofline": roofline, "kernels": kernels, "cpu_baseline": None,
         })
