@@ -173,13 +173,12 @@ def _bucket_grouped(lookups, both):
     k, G, L = g0.k, g0.world, len(lookups)
     if L < 2 or L > 8 or not hasattr(k, "bucket_ids_by_owner_batched") or not both.is_cuda:
         return None
-    if not all(isinstance(v, tuple) for _, v in lookups):
+    vids = [v if isinstance(v, tuple) else ([v.reshape(-1)], [0]) for _, v in lookups]  # a plain id tensor: one segment
+    offs = list(vids[0][1])
+    shapes = [int(t.numel()) for t in vids[0][0]]
+    if any(list(v[1]) != offs or [int(t.numel()) for t in v[0]] != shapes for v in vids):
         return None
-    offs = list(lookups[0][1][1])
-    shapes = [int(t.numel()) for t in lookups[0][1][0]]
-    if any(list(v[1]) != offs or [int(t.numel()) for t in v[0]] != shapes for _, v in lookups):
-        return None
-    local_rows, perm, counts, inv = k.bucket_ids_by_owner_batched([list(v[0]) for _, v in lookups], G, offs)
+    local_rows, perm, counts, inv = k.bucket_ids_by_owner_batched([list(v[0]) for v in vids], G, offs)
     both[0].copy_(counts.t())
     n = sum(shapes)
     return [(group, n, local_rows[i], perm[i], counts[i], inv[i]) for i, (group, _) in enumerate(lookups)]
