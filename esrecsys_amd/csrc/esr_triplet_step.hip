@@ -51,6 +51,7 @@ struct TripWs {
   uint32_t* own_code;   // [n]
   uint4* meta;          // [n]  {slot, partner a code, partner b code, triplet index}
   double* loss_part;    // [kTripStepBlocks]
+  int* long_flag;       // [1]  set by the update kernel when it parks a chunk partial: the batch has a long run
   float* chunk_rows;    // [2 * ceil(n / 32)][D]
   void* sort_ws;
   size_t sort_ws_bytes;
@@ -70,6 +71,7 @@ static size_t trip_ws_layout(int64_t B, int D, char* base, TripWs* ws) {
   w.own_code = (uint32_t*)take(sizeof(uint32_t) * (size_t)n);
   w.meta = (uint4*)take(sizeof(uint4) * (size_t)n);
   w.loss_part = (double*)take(sizeof(double) * kTripStepBlocks);
+  w.long_flag = (int*)take(sizeof(int));
   w.chunk_rows = (float*)take(sizeof(float) * 2 * (size_t)cdiv(n, kTripChunk) * (size_t)D);
   w.sort_ws_bytes = esr_segment_sort_workspace_bytes(n);
   w.sort_ws = take(w.sort_ws_bytes);
@@ -85,8 +87,10 @@ __global__ __launch_bounds__(kBlock) void triplet_plan_kernel(const int32_t* __r
                                                              const int32_t* __restrict__ neg_ids,
                                                              const uint8_t* __restrict__ sloc,
                                                              const uint8_t* __restrict__ ploc, int64_t B, int64_t Vs,
-                                                             uint32_t* __restrict__ own_code, uint4* __restrict__ meta) {
+                                                             uint32_t* __restrict__ own_code, uint4* __restrict__ meta,
+                                                             int* __restrict__ long_flag) {
   const int64_t n = 3 * B;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *long_flag = 0;
   for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock) {
     const int64_t o = perm[p];
     const int slot = o >= 2 * B ? 2 : (o >= B ? 1 : 0);
@@ -124,7 +128,8 @@ __global__ __launch_bounds__(kBlock) void triplet_step_kernel(TwoTowers tt, int 
                                                              const uint4* __restrict__ meta, int64_t n, float lam,
                                                              float inv_bs, int with_reg, float lr, float eps,
                                                              float* __restrict__ chunk_rows,
-                                                             double* __restrict__ loss_part) {
+                                                             double* __restrict__ loss_part,
+                                                             int* __restrict__ long_flag) {
   __shared__ double sm[8];
   const int lig = threadIdx.x & (G - 1);
   const int64_t gpb = kBlock / G;
@@ -264,6 +269,7 @@ __global__ __launch_bounds__(kBlock) void triplet_step_kernel(TwoTowers tt, int 
     } else {
       const int64_t slot = 2 * (p / kTripChunk) + (head ? 1 : 0);
       row_store(g, chunk_rows + slot * D, lig, G, nvec);
+      if (lig == 0) *long_flag = 1;  // (every writer stores the same value)
     }
   }
   const double t = block_sum_d(acc_loss, sm);
@@ -276,7 +282,8 @@ __global__ __launch_bounds__(kBlock) void triplet_step_long_kernel(TwoTowers tt,
                                                                   float lr, float eps,
                                                                   const float* __restrict__ chunk_rows, int npart,
                                                                   const double* __restrict__ loss_part,
-                                                                  double inv_batch_size, float* __restrict__ loss) {
+                                                                  double inv_batch_size, float* __restrict__ loss,
+                                                                  const int* __restrict__ long_flag) {
   if (blockIdx.x == gridDim.x - 1) {  // the loss: partials of the update kernel in a fixed order
     __shared__ double smp[4];
     double a = 0.0;
@@ -284,6 +291,9 @@ __global__ __launch_bounds__(kBlock) void triplet_step_long_kernel(TwoTowers tt,
     const double t = block_sum_d(a, smp);
     if (threadIdx.x == 0) loss[0] = (float)(t * inv_batch_size);
   }
+  // no run of the batch outgrew its head chunk (every batch of uniform ids): nothing to combine -- one load instead of
+  // the screening of the chunk boundaries (three dependent loads and three barriers per workgroup)
+  if (*long_flag == 0) return;
   __shared__ float red[kBlock * VEC * NCH];
   constexpr int kPass = 4;
   __shared__ long long s_long[kPass];
@@ -428,7 +438,7 @@ int esr_triplet_train_step(float* scene, float* scene_shadow, uint8_t* scene_loc
   TwoTowers tt{scene, scene_shadow, product, product_shadow, scene_loc, product_loc, scene_accum, product_accum, Vs};
   const int nplan = (int)std::min<int64_t>(kMaxGrid, cdiv(n, kBlock));
   hipLaunchKernelGGL(triplet_plan_kernel, dim3(nplan), dim3(kBlock), 0, st, perm, scene_ids, pos_ids, neg_ids,
-                     (const uint8_t*)scene_loc, (const uint8_t*)product_loc, B, Vs, ws.own_code, ws.meta);
+                     (const uint8_t*)scene_loc, (const uint8_t*)product_loc, B, Vs, ws.own_code, ws.meta, ws.long_flag);
   int grid = grid_for_groups(n, g.G);
   const int grid2 = (int)std::min<int64_t>(kMaxGrid, cdiv(cdiv(n, kTripChunk), 4));
   const float inv_bs = 1.0f / batch_size;
@@ -436,10 +446,10 @@ int esr_triplet_train_step(float* scene, float* scene_shadow, uint8_t* scene_loc
     grid = std::min(grid, resident_blocks((const void*)triplet_step_kernel<VEC, NCH>));
     hipLaunchKernelGGL((triplet_step_kernel<VEC, NCH>), dim3(grid), dim3(kBlock), 0, st, tt, D, g.G,
                        (const uint32_t*)ws.own_code, (const uint4*)ws.meta, n, regularization, inv_bs, 1, lr, eps,
-                       ws.chunk_rows, ws.loss_part);
+                       ws.chunk_rows, ws.loss_part, ws.long_flag);
     hipLaunchKernelGGL((triplet_step_long_kernel<VEC, NCH>), dim3(grid2), dim3(kBlock), 0, st, tt, D, g.G,
                        (const uint32_t*)ws.own_code, n, lr, eps, (const float*)ws.chunk_rows, grid,
-                       (const double*)ws.loss_part, 1.0 / (double)batch_size, loss);
+                       (const double*)ws.loss_part, 1.0 / (double)batch_size, loss, (const int*)ws.long_flag);
   });
   return check_launch("esr_triplet_train_step");
 }
