@@ -243,7 +243,7 @@ struct StepWs {
   double2* bias_info;    // [n]  per run head / chunk start: {sum over its occurrences of s (reference) or gdot, count}
   double* stat_part;     // [kStatBlocks][2]
   double* pair_part;     // [kPairBlocks][3]
-  double* pair_tot;      // [3]   sum w, sum w r, sum w (r - center)^2 over the batch
+  double* pair_tot;      // [3]   sum w, sum w r, sum w (r - center)^2 over the batch; [3] holds the long-run flag (int)
   float* chunk_rows;     // [2 * ceil(n / 32)][D]  partial sums of long runs (slot 2c: chunk starting at 32c; 2c + 1:
                          //                        the head chunk whose head lies in block c)
   void* sort_ws;
@@ -283,8 +283,9 @@ __global__ __launch_bounds__(kBlock) void glove_plan_kernel(const int32_t* __res
                                                            const float* __restrict__ bias,
                                                            const uint8_t* __restrict__ loc, int64_t B, int nstat,
                                                            uint32_t* __restrict__ own_code, float4* __restrict__ meta,
-                                                           double* __restrict__ stat_part) {
+                                                           double* __restrict__ stat_part, int* __restrict__ long_flag) {
   __shared__ double sm[8];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *long_flag = 0;  // set by the update kernel when it parks a chunk partial
   if ((int)blockIdx.x < nstat) {
     double a = 0.0, a2 = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < B; i += (int64_t)nstat * kBlock) {
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(kBlock) void glove_step_kernel(
     float* __restrict__ emb0, float* __restrict__ emb1, uint8_t* __restrict__ loc, float* __restrict__ accum, int D,
     int G, const uint32_t* __restrict__ own_code, const float4* __restrict__ meta, int64_t n, int64_t B, int mode,
     int nstat, const double* __restrict__ stat_part, float lr, float eps, float* __restrict__ chunk_rows,
-    double2* __restrict__ bias_info, double* __restrict__ pair_part) {
+    double2* __restrict__ bias_info, double* __restrict__ pair_part, int* __restrict__ long_flag) {
   __shared__ double sm[16];
   const int lig = threadIdx.x & (G - 1);
   const int64_t gpb = kBlock / G;
@@ -470,6 +471,7 @@ __global__ __launch_bounds__(kBlock) void glove_step_kernel(
     } else {  // a chunk of a long run: park the partial sum for glove_step_long_kernel
       const int64_t slot = 2 * (p / kStepChunk) + (head ? 1 : 0);
       row_store(g, chunk_rows + slot * D, lig, G, nvec);
+      if (lig == 0) *long_flag = 1;  // (every writer stores the same value)
     }
   }
   const double tw = block_sum_d(acc_w, sm);
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(kBlock) void glove_step_long_kernel(
     float* __restrict__ emb0, float* __restrict__ emb1, uint8_t* __restrict__ loc, float* __restrict__ accum, int D,
     int G, const uint32_t* __restrict__ own_code, int64_t n, float lr, float eps,
     const float* __restrict__ chunk_rows, double2* __restrict__ bias_info, int npair,
-    const double* __restrict__ pair_part, double* __restrict__ pair_tot) {
+    const double* __restrict__ pair_part, double* __restrict__ pair_tot, const int* __restrict__ long_flag) {
   // the last workgroup also reduces the update kernel's loss partials (fixed order) to three doubles, so that the
   // finalize kernel's workgroups read three numbers instead of re-reducing a thousand partials each
   if (blockIdx.x == gridDim.x - 1) {
@@ -509,6 +511,8 @@ __global__ __launch_bounds__(kBlock) void glove_step_long_kernel(
       pair_tot[2] = twq;
     }
   }
+  // no run of the batch outgrew its head chunk: nothing to combine -- one load instead of screening the chunk boundaries
+  if (*long_flag == 0) return;
   __shared__ float red[kBlock * VEC * NCH];
   __shared__ double smd[8];
   constexpr int kPass = 4;
@@ -800,7 +804,7 @@ int esr_glove_train_step(float* emb, float* emb_shadow, uint8_t* emb_loc, float*
   const int nstat = (int)std::min<int64_t>(kStatBlocks, cdiv(B, kBlock));
   const int nplan = (int)std::max<int64_t>(nstat, std::min<int64_t>(kMaxGrid, cdiv(n, kBlock)));
   hipLaunchKernelGGL(glove_plan_kernel, dim3(nplan), dim3(kBlock), 0, st, sorted_ids, perm, inputs, target, (const float*)bias, (const uint8_t*)emb_loc, B, nstat,
-                     ws.own_code, ws.meta, ws.stat_part);
+                     ws.own_code, ws.meta, ws.stat_part, reinterpret_cast<int*>(ws.pair_tot + 3));
   int grid = grid_for_groups(n, g.G);
   const int grid2 = (int)std::min<int64_t>(kMaxGrid, cdiv(cdiv(n, kStepChunk), 4));
   ESR_DISPATCH_ROW(g, {
@@ -809,11 +813,13 @@ int esr_glove_train_step(float* emb, float* emb_shadow, uint8_t* emb_loc, float*
     grid = std::min(grid, resident_blocks((const void*)glove_step_kernel<VEC, NCH>, blocks_per_cu));
     hipLaunchKernelGGL((glove_step_kernel<VEC, NCH>), dim3(grid), dim3(kBlock), 0, st, emb, emb_shadow, emb_loc,
                        emb_accum, D, g.G, (const uint32_t*)ws.own_code, (const float4*)ws.meta, n, B, mode, nstat,
-                       (const double*)ws.stat_part, lr, eps, ws.chunk_rows, ws.bias_info, ws.pair_part);
+                       (const double*)ws.stat_part, lr, eps, ws.chunk_rows, ws.bias_info, ws.pair_part,
+                       reinterpret_cast<int*>(ws.pair_tot + 3));
     // (always launched: its last workgroup reduces the loss partials for the finalize kernel)
     hipLaunchKernelGGL((glove_step_long_kernel<VEC, NCH>), dim3(grid2), dim3(kBlock), 0, st, emb, emb_shadow, emb_loc,
                        emb_accum, D, g.G, (const uint32_t*)ws.own_code, n, lr, eps, (const float*)ws.chunk_rows,
-                       ws.bias_info, grid, (const double*)ws.pair_part, ws.pair_tot);
+                       ws.bias_info, grid, (const double*)ws.pair_part, ws.pair_tot,
+                       reinterpret_cast<const int*>(ws.pair_tot + 3));
   });
   const int nfin = (int)cdiv(n, kBlock);  // one thread per sorted position
   hipLaunchKernelGGL(glove_step_finalize_kernel, dim3(nfin), dim3(kBlock), 0, st, B, mode, nstat,
