@@ -370,7 +370,12 @@ def _inbatch_steps(state, it, first, num_steps, regularization, batch_size, scal
             if dry:
                 raise StopIteration("train_steps: the batch iterator ended after %d of %d steps" % (k, num_steps))
             pending = [ids_of(next(it))]
-        want = min(_SORT_BATCH, num_steps - k)
+        # the FIRST step goes out alone, sorting its own list in line: the GPU starts after one batch's worth of host work,
+        # and the first group of eight is drawn and sorted while that step runs (drawing eight batches first left the
+        # device idle for ~0.2 ms at the head of every call -- 4 % of a 20-step run)
+        # (then groups of 2, 4, 8: drawing and sorting a group of eight is ~0.2 ms of host work, more than the one step
+        # that is in flight behind it)
+        want = min(_SORT_BATCH, num_steps - k, 1 if k == 0 else (2 if k < 3 else (4 if k < 7 else _SORT_BATCH)))
         while len(pending) < want and not dry:
             try:
                 pending.append(ids_of(next(it)))
@@ -439,7 +444,8 @@ def _train_steps(state, batches, num_steps, regularization, batch_size, scale, p
             if dry:  # the iterator ended early: as the reference's loop, after the steps it did feed
                 raise StopIteration("train_steps: the batch iterator ended after %d of %d steps" % (k, num_steps))
             first = ctx.ids(*next(it))
-            if _SORT_BATCH > 1 and 3 * first[0].numel() <= _SORT_BATCH_MAX_IDS and num_steps - k > 1:
+            # (k == 0: the first step goes out alone with its sort in line, see _inbatch_steps)
+            if _SORT_BATCH > 1 and 3 * first[0].numel() <= _SORT_BATCH_MAX_IDS and num_steps - k > 1 and k > 0:
                 group = [first]
                 for _ in range(min(_SORT_BATCH, num_steps - k) - 1):
                     try:

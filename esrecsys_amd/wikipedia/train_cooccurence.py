@@ -321,7 +321,7 @@ def _train_epoch(state, steps_per_epoch, train_it):
                 if _PRESORT and _ids_count(inputs) > _PRESORT_MIN_IDS:
                     grouped = False
                     queue.append((presort_inputs(state, inputs), targets))
-                elif _SORT_BATCH > 1 and not queue:
+                elif _SORT_BATCH > 1 and not queue and k > 0:  # (the first step goes out alone: the GPU starts at once)
                     grouped = True
                     group = [(inputs, targets)]
                     while len(group) < _SORT_BATCH and fetched < steps_per_epoch:
@@ -332,6 +332,7 @@ def _train_epoch(state, steps_per_epoch, train_it):
                         fetched += 1
                     queue.extend(ctx.sort_batch(group) if len(group) > 1 else group)
                 else:
+                    grouped = _SORT_BATCH > 1  # short lists: refill when the queue has run dry (then a group at a time)
                     queue.append((inputs, targets))
             inputs, targets = queue.popleft()
             ctx.step(k, inputs, targets)
