@@ -223,7 +223,9 @@ def roofline_for(workload, kernels, B, D, rows, precision, occ_n=0, uniq=0, bf16
         t = step_s if step_s else kernels["glove_step"]["ms_per_step"] * 1e-3
         alg = STEP_BYTES_PER_UNIT["glove"](D) * B
         moved = (occ_n + 4 * uniq) * D * 4
-        return {"kernel": "esr_glove_train_step (sort + glove_plan + glove_step + glove_step_long + finalize)",
+        return {"kernel": "esr_glove_train_step (lists > 32768 ids: sort + glove_resolve + glove_step_resolved + "
+                          "glove_step_long + finalize; shorter: sort + plan made ahead for eight batches, then "
+                          "glove_step + finalize per step)",
                 "bound": "hbm", "achieved": alg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": alg / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
                 "bytes_the_update_needs_per_step": moved, "those_bytes_GBps": moved / t / 1e9}
@@ -234,7 +236,8 @@ def roofline_for(workload, kernels, B, D, rows, precision, occ_n=0, uniq=0, bf16
         t = step_s if step_s else kernels["triplet_step"]["ms_per_step"] * 1e-3
         alg = STEP_BYTES_PER_UNIT["triplet"](D) * B
         moved = (2 * occ_n + 4 * uniq) * D * 4
-        return {"kernel": "esr_triplet_train_step (triplet_plan + triplet_step + triplet_step_long)",
+        return {"kernel": "esr_triplet_train_step (sort + triplet_plan made ahead for eight batches; per step "
+                          "triplet_step, + triplet_step_long only when a run of equal ids is long)",
                 "bound": "hbm", "achieved": alg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": alg / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
                 "bytes_the_update_needs_per_step": moved, "those_bytes_GBps": moved / t / 1e9}

@@ -25,6 +25,8 @@ c_f32p = ctypes.c_void_p
 c_vp = ctypes.c_void_p
 c_i64 = ctypes.c_int64
 c_int = ctypes.c_int
+c_int32 = ctypes.c_int32
+c_uint32 = ctypes.c_uint32
 c_f32 = ctypes.c_float
 c_size = ctypes.c_size_t
 
@@ -46,15 +48,28 @@ SIGNATURES = {
                                   c_f32p, c_vp, c_size, c_vp]),
     "esr_glove_step_workspace_bytes": (c_size, [c_i64, c_int]),
     "esr_glove_train_step": (c_int, [c_f32p, c_f32p, c_vp, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_i32p, c_f32p, c_i64,
-                                     c_int, c_f32, c_f32, c_i32p, c_i32p, c_int, c_f32p, c_vp, c_size, c_vp]),
+                                     c_int, c_f32, c_f32, c_uint32, c_i32p, c_i32p, c_vp, c_int, c_int, c_f32p, c_vp,
+                                     c_size, c_vp]),
+    "esr_glove_train_steps": (c_int, [c_f32p, c_f32p, c_vp, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_int, c_vp, c_vp, c_i64,
+                                      c_int, c_f32, c_f32, c_uint32, c_i32p, c_i32p, c_vp, c_vp, c_f32p, c_vp, c_size,
+                                      c_vp]),
+    "esr_glove_plan_bytes": (c_size, [c_i64]),
+    "esr_glove_plan": (c_int, [c_vp, c_vp, c_int, c_i64, c_i32p, c_i32p, c_vp, c_vp, c_int32, c_vp]),
+    "esr_long_run_hint": (c_int, [c_i32p, c_i64, c_int, c_vp, c_int32, c_vp]),
     "esr_rows_consolidate": (c_int, [c_f32p, c_f32p, c_vp, c_i64, c_int, c_vp]),
+    "esr_rows_restamp": (c_int, [c_vp, c_i64, c_vp]),
     "esr_triplet_workspace_bytes": (c_size, [c_i64]),
     "esr_triplet_fwd_bwd": (c_int, [c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_int, c_i32p, c_i32p, c_i32p, c_i64, c_f32, c_f32,
                                     c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_vp, c_size, c_vp]),
     "esr_triplet_step_workspace_bytes": (c_size, [c_i64, c_int]),
     "esr_triplet_train_step": (c_int, [c_f32p, c_f32p, c_vp, c_f32p, c_i64, c_f32p, c_f32p, c_vp, c_f32p, c_i64, c_int,
-                                       c_i32p, c_i32p, c_i32p, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32p, c_i32p,
-                                       c_f32p, c_vp, c_size, c_vp]),
+                                       c_i32p, c_i32p, c_i32p, c_i64, c_f32, c_f32, c_f32, c_f32, c_uint32, c_i32p,
+                                       c_i32p, c_vp, c_int, c_f32p, c_vp, c_size, c_vp]),
+    "esr_triplet_train_steps": (c_int, [c_f32p, c_f32p, c_vp, c_f32p, c_i64, c_f32p, c_f32p, c_vp, c_f32p, c_i64, c_int,
+                                        c_int, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_uint32, c_i32p, c_i32p, c_vp,
+                                        c_vp, c_f32p, c_vp, c_size, c_vp]),
+    "esr_triplet_plan_bytes": (c_size, [c_i64]),
+    "esr_triplet_plan": (c_int, [c_vp, c_int, c_i64, c_i64, c_i32p, c_i32p, c_vp, c_vp, c_int32, c_vp]),
     "esr_inbatch_workspace_bytes": (c_size, [c_i64, c_int]),
     "esr_inbatch_softmax_fwd_bwd": (c_int, [c_f32p, c_f32p, c_i64, c_int, c_f32, c_f32, c_f32, c_f32p, c_f32p, c_f32p,
                                             c_f32p, c_vp, c_size, c_vp]),

@@ -35,7 +35,7 @@ inline hipStream_t as_stream(esr_stream_t s) { return reinterpret_cast<hipStream
   } while (0)
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
-inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+__host__ __device__ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // Row-group geometry: a row of `nvec` vector chunks is handled by G lanes (power of two,
 // <= 64); a 256-thread block holds 256/G groups.

@@ -218,34 +218,71 @@ __global__ __launch_bounds__(kBlock) void glove_finalize_kernel(
 // DISTINCT row; read-modify-write its accumulator).  Producing the gradient inside the update instead runs into a
 // hazard: occurrence (row a, partner b) needs the PRE-step value of b while another workgroup may already have
 // rewritten b.  288 GB of HBM buy the way out: the table is kept in TWO buffers with a per-row byte `loc` that says
-// which one holds the row's current value.  The step reads rows where `loc` pointed when the step began (resolved
-// up front by the plan kernel, so the update kernel has no dependent index chain and no race on `loc`), writes every
-// updated row into the OTHER buffer and flips its byte.  Readers and writers of one step never touch the same bytes,
-// no gradient row and no snapshot ever goes to memory, and untouched rows cost nothing.  esr_rows_consolidate copies
-// the rows whose byte is set back into the primary buffer when somebody needs a plain [V, D] table (eval, kNN,
-// checkpoint).
+// which one holds the row's current value and which step last moved it (esr_versioned.h).  The step reads every row
+// where it lived when the step began, writes every updated row into the OTHER buffer and stamps its byte.  Readers and
+// writers of one step never touch the same bytes, no gradient row and no snapshot ever goes to memory, and untouched
+// rows cost nothing.  esr_rows_consolidate copies the rows that live in the second buffer back into the primary one
+// when somebody needs a plain [V, D] table (eval, kNN, checkpoint).
 //
-//   sort      occurrence ids [t1 ; t2] -> (sorted, perm)                       esr_segment_sort_ids
-//   plan      per sorted position: partner row (id | loc bit | side bit), w_j, log10(1 + c_j), s_j; own row code;
-//             the bias statistics of K_A in K_A's own summation order
-//   update    one row group per sorted position, the head of a run walks it: dot with each partner row, gdot,
-//             G += gdot * partner (left to right, products rounded as the gradient rows used to be: bit-identical
-//             tables), Adagrad once per distinct row; loss partials; per-run bias sums
-//   long      runs longer than a chunk (hot tokens): chunk partials combined in a fixed order
+//   sort      occurrence ids [t1 ; t2] -> (sorted, perm)                       } ids + counts only: made AHEAD
+//   plan      per sorted position: partner row (id | side bit), w_j, log10(1 + c_j);  } (esr_glove_plan, with the sort)
+//             "may a run outgrow its head chunk?" -- the host's reason to launch `long`
+//   update    prologue: the first workgroups sum the bias statistics of K_A into integer words and every workgroup
+//             waits for them (round 3: no separate launch); then one row group per sorted position, the head of a run
+//             walks it: row locations from the stamped bytes (esr_versioned.h), s_j from the bias table, dot with each
+//             partner row, gdot, G += gdot * partner (left to right, products rounded as the gradient rows used to be),
+//             Adagrad once per distinct row; loss partials; per-run bias sums
+//   long      only when a run outgrew its head chunk (hot tokens): chunk partials combined in a fixed order
 //   finalize  loss scalar; bias Adagrad (needs the global sum of w r, known only now)
+// Round 2 ran plan -> update -> long -> finalize per step; a step of uniform ids is now update -> finalize.
 // =====================================================================================================================
+
+constexpr int kStatBlocksStep = 256;  // workgroups of the update kernel that sum the bias statistics first
+// Two ways to learn where rows live.  Lists up to this many ids (the reference's batch sizes: launch-bound steps): the
+// update kernel reads the stamped bytes and the bias values itself -- no launch in front of it.  Longer lists (the
+// update kernel is tens of microseconds of streaming): a resolve launch in front of every step writes row codes with
+// the location bits in them (round 2's plan kernel), because the extra dependent stage in the update kernel's walk and
+// the wait for the in-kernel statistics cost that kernel 20 % at V = 465 537 x 256, B = 65 536 (111 -> 135 us) -- more
+// than the 9 us launch they replace.
+constexpr int64_t kResolveMinIds = 32768;
+
+// the plan of one batch (esr_glove_plan): header + one record per sorted position
+struct GlovePlan {
+  int* flags;                  // [0] parked: set by the update kernel when it parks a chunk partial
+  unsigned long long* stat;    // 16-byte-apart words at 128 B stride: [0] sum s hi, [16] lo, [32] sum s^2 hi, [48] lo,
+                               // [64] arrivals, [80] poison; zero before the update kernel
+  float4* meta;                // [n]  {partner id | side bit (bits), w, log10(1 + c), unused}
+};
+constexpr int kStatWords = 96;
+static size_t glove_plan_layout(int64_t B, char* base, GlovePlan* out) {
+  const int64_t n = 2 * B;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += align_up(bytes, 256);
+    return p;
+  };
+  GlovePlan pl;
+  pl.flags = (int*)take(sizeof(int) * 64);
+  pl.stat = (unsigned long long*)take(sizeof(unsigned long long) * kStatWords);
+  pl.meta = (float4*)take(sizeof(float4) * (size_t)n);
+  if (out) *out = pl;
+  return off;
+}
 
 struct StepWs {
   int32_t* sorted_ids;   // [n]
   int32_t* perm;         // [n]
-  uint32_t* own_code;    // [n]  id | loc bit of the row that sorted position p updates
-  float4* meta;          // [n]  {partner code (bits), w, log10(1 + c), s}
   double2* bias_info;    // [n]  per run head / chunk start: {sum over its occurrences of s (reference) or gdot, count}
-  double* stat_part;     // [kStatBlocks][2]
   double* pair_part;     // [kPairBlocks][3]
-  double* pair_tot;      // [3]   sum w, sum w r, sum w (r - center)^2 over the batch; [3] holds the long-run flag (int)
+  uint32_t* own_code;    // [n]  resolved mode: id | loc bit of the row that sorted position p updates
+  float4* meta_res;      // [n]  resolved mode: {partner code (id | loc bit | side bit), w, log10(1 + c), s}
+  double* stat_part;     // [kStatBlocks][2]  resolved mode: K_A's partials
+  int* res_flags;        // [64] resolved mode: [0] parked
+  double* pair_tot;      // [3]  resolved mode: sum w, sum w r, sum w (r - center)^2 over the batch
   float* chunk_rows;     // [2 * ceil(n / 32)][D]  partial sums of long runs (slot 2c: chunk starting at 32c; 2c + 1:
                          //                        the head chunk whose head lies in block c)
+  char* plan;            // glove_plan_layout(B) bytes: the in-line plan of a call that brings none
   void* sort_ws;
   size_t sort_ws_bytes;
 };
@@ -261,31 +298,81 @@ static size_t step_ws_layout(int64_t B, int D, char* base, StepWs* ws) {
   StepWs w;
   w.sorted_ids = (int32_t*)take(sizeof(int32_t) * (size_t)n);
   w.perm = (int32_t*)take(sizeof(int32_t) * (size_t)n);
-  w.own_code = (uint32_t*)take(sizeof(uint32_t) * (size_t)n);
-  w.meta = (float4*)take(sizeof(float4) * (size_t)n);
   w.bias_info = (double2*)take(sizeof(double2) * (size_t)n);
-  w.stat_part = (double*)take(sizeof(double) * 2 * kStatBlocks);
   w.pair_part = (double*)take(sizeof(double) * 3 * kPairBlocks);
+  // the resolved mode's records exist for long lists only (kResolveMinIds); short ones resolve inside the update kernel
+  const bool res = n > kResolveMinIds;
+  w.own_code = (uint32_t*)take(res ? sizeof(uint32_t) * (size_t)n : 0);
+  w.meta_res = (float4*)take(res ? sizeof(float4) * (size_t)n : 0);
+  w.stat_part = (double*)take(sizeof(double) * 2 * kStatBlocks);
+  w.res_flags = (int*)take(sizeof(int) * 64);
   w.pair_tot = (double*)take(sizeof(double) * 4);
   w.chunk_rows = (float*)take(sizeof(float) * 2 * (size_t)cdiv(n, kStepChunk) * (size_t)D);
+  w.plan = take(glove_plan_layout(B, nullptr, nullptr));
   w.sort_ws_bytes = esr_segment_sort_workspace_bytes(n);
   w.sort_ws = take(w.sort_ws_bytes);
   if (ws) *ws = w;
   return off;
 }
 
-// plan: blocks [0, nstat) first redo K_A's loop over the pairs (same grid, same per-thread order: the bias statistics,
-// hence sbar and every gdot, are bit-identical to the three-kernel path); then every block resolves its sorted positions.
-__global__ __launch_bounds__(kBlock) void glove_plan_kernel(const int32_t* __restrict__ sorted_ids,
-                                                           const int32_t* __restrict__ perm,
-                                                           const int32_t* __restrict__ inputs,
-                                                           const float* __restrict__ target,
-                                                           const float* __restrict__ bias,
-                                                           const uint8_t* __restrict__ loc, int64_t B, int nstat,
-                                                           uint32_t* __restrict__ own_code, float4* __restrict__ meta,
-                                                           double* __restrict__ stat_part, int* __restrict__ long_flag) {
+constexpr int kMaxGlovePlanBatch = 8;
+struct GlovePlanBatch {
+  const int32_t* inputs[kMaxGlovePlanBatch];
+  const float* target[kMaxGlovePlanBatch];
+};
+
+// plan: one thread per sorted position of list blockIdx.y; nothing here reads a table.  hints[list] = gen when some run
+// of equal ids is longer than kStepChunk positions (only then can the update kernel park a chunk partial).
+__global__ __launch_bounds__(kBlock) void glove_plan_kernel(GlovePlanBatch pb, const int32_t* __restrict__ sorted_all,
+                                                           const int32_t* __restrict__ perm_all, int64_t B,
+                                                           char* __restrict__ plans, size_t plan_stride,
+                                                           int* __restrict__ hints, int gen) {
+  const int list = blockIdx.y;
+  const int64_t n = 2 * B;
+  const int32_t* __restrict__ sorted = sorted_all + (int64_t)list * n;
+  const int32_t* __restrict__ perm = perm_all + (int64_t)list * n;
+  const int32_t* __restrict__ inputs = pb.inputs[list];
+  const float* __restrict__ target = pb.target[list];
+  char* base = plans + (size_t)list * plan_stride;
+  int* flags = (int*)base;
+  unsigned long long* stat = (unsigned long long*)(base + 256);
+  float4* meta = (float4*)(base + 256 + align_up(sizeof(unsigned long long) * kStatWords, 256));
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < 64) flags[threadIdx.x] = 0;
+    if (threadIdx.x < kStatWords) stat[threadIdx.x] = 0ull;
+  }
+  bool long_run = false;
+  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock) {
+    const int64_t o = perm[p];
+    const bool side = o >= B;
+    const int64_t j = side ? o - B : o;
+    const int32_t partner = side ? inputs[j] : inputs[B + j];
+    const float c_j = target[j];
+    float4 m;
+    m.x = __uint_as_float((uint32_t)partner | (side ? kSideBit : 0u));
+    m.y = powf(fminf(1.0f, c_j / 100.0f), 0.75f);  // weight = min(1, c/100)^0.75   (train_cooccurence.py:79-81)
+    m.z = log10f(1.0f + c_j);                      // log10(1 + c)                  (train_cooccurence.py:82)
+    m.w = 0.f;
+    meta[p] = m;
+    if (p + kStepChunk < n && sorted[p] == sorted[p + kStepChunk]) long_run = true;
+  }
+  if (hints && __any(long_run) && (threadIdx.x & 63) == 0) hints[list] = gen;  // (every writer stores the same value)
+}
+
+// resolve (long lists, every step): blocks [0, nstat) first redo K_A's loop over the pairs (same grid, same per-thread
+// order: the bias statistics, hence sbar and every gdot, are bit-identical to the three-kernel path); then every block
+// resolves its sorted positions: own and partner row codes with the location bit the bytes show NOW (between two steps:
+// nobody is writing them), weight, log10(1 + c) and the bias sum s.
+__global__ __launch_bounds__(kBlock) void glove_resolve_kernel(const int32_t* __restrict__ sorted_ids,
+                                                              const int32_t* __restrict__ perm,
+                                                              const int32_t* __restrict__ inputs,
+                                                              const float* __restrict__ target,
+                                                              const float* __restrict__ bias,
+                                                              const uint8_t* __restrict__ loc, int64_t B, int nstat,
+                                                              uint32_t* __restrict__ own_code, float4* __restrict__ meta,
+                                                              double* __restrict__ stat_part, int* __restrict__ flags) {
   __shared__ double sm[8];
-  if (blockIdx.x == 0 && threadIdx.x == 0) *long_flag = 0;  // set by the update kernel when it parks a chunk partial
+  if (blockIdx.x == 0 && threadIdx.x == 0) flags[0] = 0;  // parked: set by the update kernel
   if ((int)blockIdx.x < nstat) {
     double a = 0.0, a2 = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < B; i += (int64_t)nstat * kBlock) {
@@ -310,12 +397,265 @@ __global__ __launch_bounds__(kBlock) void glove_plan_kernel(const int32_t* __res
     const int32_t partner = side ? t1 : t2;
     const float c_j = target[j];
     float4 m;
-    m.x = __uint_as_float((uint32_t)partner | (loc[partner] ? kLocBit : 0u) | (side ? kSideBit : 0u));
+    m.x = __uint_as_float((uint32_t)partner | ((loc[partner] & 1) ? kLocBit : 0u) | (side ? kSideBit : 0u));
     m.y = powf(fminf(1.0f, c_j / 100.0f), 0.75f);  // weight = min(1, c/100)^0.75   (train_cooccurence.py:79-81)
     m.z = log10f(1.0f + c_j);                      // log10(1 + c)                  (train_cooccurence.py:82)
     m.w = bias[t1] + bias[t2];
     meta[p] = m;
-    own_code[p] = (uint32_t)id | (loc[id] ? kLocBit : 0u);
+    own_code[p] = (uint32_t)id | ((loc[id] & 1) ? kLocBit : 0u);
+  }
+}
+
+// the versioned read-modify-write of one row with its summed gradient g: the row was read where `code` says it lived
+// when the step began (`own`), its new value goes to the OTHER buffer and the byte takes this step's stamp.
+// `a` = the row's accumulator, loaded by the caller next to `own`.
+template <int VEC, int NCH>
+__device__ __forceinline__ void step_apply(float* __restrict__ emb0, float* __restrict__ emb1, uint8_t* __restrict__ loc,
+                                           float* __restrict__ accum, uint32_t code, uint32_t T,
+                                           const RowRegs<VEC, NCH>& own, RowRegs<VEC, NCH>& a,
+                                           const RowRegs<VEC, NCH>& g, int D, int lig, int G, int nvec, float lr,
+                                           float eps) {
+  const int64_t id = code & kIdMask;
+  RowRegs<VEC, NCH> w = own;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) adagrad_elem(w.v[k][e], a.v[k][e], g.v[k][e], lr, eps);
+  row_store(a, accum + id * D, lig, G, nvec);
+  row_store(w, ((code & kLocBit) ? emb0 : emb1) + id * D, lig, G, nvec);
+  if (lig == 0) loc[id] = loc_written((code & kLocBit) ? 0u : 1u, T);
+}
+
+// one position's plan record with what the tables add to it: location bytes and bias values of own and partner row
+struct GloveRec {
+  uint32_t id;     // own row
+  float4 m;        // {partner | side bit, w, log10(1 + c), -}
+  uint32_t y0, y1; // location bytes of own and partner row (as loaded)
+  float b0, b1;    // bias of own and partner row
+};
+__device__ __forceinline__ void glove_rec_tables(const uint8_t* __restrict__ loc, const float* __restrict__ bias,
+                                                 GloveRec& r) {
+  const uint32_t partner = __float_as_uint(r.m.x) & kIdMask;
+  r.y0 = loc[r.id];
+  r.y1 = loc[partner];
+  r.b0 = bias[r.id];
+  r.b1 = bias[partner];
+}
+
+// update: the structure of segment_update_kernel (esr_optim.hip) with the gradient rows produced on the fly.
+// A group's critical path per position is ONE memory round trip: plan records run three positions ahead, the bytes and
+// bias values they point at two, and the own row, its accumulator and the first partner row of the NEXT position are
+// requested before the current one is computed.  Written naively -- record, then bytes, then rows, then accumulator --
+// the loop is a chain of dependent round trips and ran at 3.2 TB/s.
+template <int VEC, int NCH>
+__global__ __launch_bounds__(kBlock) void glove_step_kernel(
+    float* __restrict__ emb0, float* __restrict__ emb1, uint8_t* __restrict__ loc, float* __restrict__ accum,
+    const float* __restrict__ bias, int D, int G, const int32_t* __restrict__ sorted_ids,
+    const float4* __restrict__ meta, const int32_t* __restrict__ inputs, int64_t n, int64_t B, int mode, uint32_t T,
+    int nstat, unsigned long long* __restrict__ stat, float lr, float eps, float* __restrict__ chunk_rows,
+    double2* __restrict__ bias_info, double* __restrict__ pair_part, int* __restrict__ parked) {
+  __shared__ double sm[16];
+  const int lig = threadIdx.x & (G - 1);
+  const int64_t gpb = kBlock / G;
+  const int64_t group = (int64_t)blockIdx.x * gpb + threadIdx.x / G;
+  const int64_t ngroups = (int64_t)gridDim.x * gpb;
+  const int nvec = D / VEC;
+  const int64_t per = (n + ngroups - 1) / ngroups;  // contiguous slices (see segment_update_kernel)
+  const int64_t p_begin = group * per, p_end = min(n, (group + 1) * per);
+  // the records of the first three positions are requested before the statistics are summed
+  GloveRec r0{0, make_float4(0.f, 0.f, 0.f, 0.f), 0, 0, 0.f, 0.f}, r1 = r0, r2 = r0;
+  uint32_t prev_n = 0xFFFFFFFFu;
+  if (p_begin < p_end) {
+    r0.id = (uint32_t)sorted_ids[p_begin];
+    r0.m = meta[p_begin];
+    if (p_begin > 0) prev_n = (uint32_t)sorted_ids[p_begin - 1];
+    if (p_begin + 1 < n) {
+      r1.id = (uint32_t)sorted_ids[p_begin + 1];
+      r1.m = meta[p_begin + 1];
+    }
+    if (p_begin + 2 < n) {
+      r2.id = (uint32_t)sorted_ids[p_begin + 2];
+      r2.m = meta[p_begin + 2];
+    }
+  }
+  // ---- prologue (reference mode): sum s and sum s^2 over the pairs, s_i = Bias[t1_i] + Bias[t2_i] ------------------
+  // The first nstat workgroups add their partials to two-word integer sums and count themselves in; every workgroup
+  // (those too) then waits for the count.  Workgroups are dispatched in index order, so the ones everybody waits for
+  // are never behind a waiting one; the data travels in the atomics, so no fence is needed.
+  double sum_s = 0.0;
+  if (mode == ESR_GLOVE_REFERENCE) {
+    if ((int)blockIdx.x < nstat) {
+      double a = 0.0, a2 = 0.0;
+      const int64_t stride = (int64_t)nstat * kBlock;
+      for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < B; i0 += 4 * stride) {
+        // four pairs per trip: all eight ids requested together, then all eight bias values (two round trips, not eight)
+        int32_t t1[4], t2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t i = i0 + u * stride;
+          t1[u] = i < B ? inputs[i] : -1;
+          t2[u] = i < B ? inputs[B + i] : -1;
+        }
+        float b1[4], b2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          b1[u] = t1[u] >= 0 ? bias[t1[u]] : 0.f;
+          b2[u] = t1[u] >= 0 ? bias[t2[u]] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float s = b1[u] + b2[u];
+          a += (double)s;
+          a2 += (double)s * (double)s;
+        }
+      }
+      const double t = block_sum_d(a, sm);
+      const double t2 = block_sum_d(a2, sm + 4);
+      if (threadIdx.x == 0) {
+        if (!(fabs(t) < 2.7e11) || !(t2 < 2.7e11)) {  // 2^38: beyond the words' range, or not finite
+          atomicOr(reinterpret_cast<unsigned*>(stat + 80), 1u);
+        } else {
+          fixed2_add2(stat + 0, stat + 16, t, stat + 32, stat + 48, t2);
+        }
+        atomicAdd(stat + 64, 1ull);  // (fixed2_add2 returns after its adds have been performed)
+      }
+    }
+    if (p_begin < p_end) {  // (the first positions' table reads travel while the statistics are awaited)
+      glove_rec_tables(loc, bias, r0);
+      if (p_begin + 1 < n) glove_rec_tables(loc, bias, r1);
+    }
+    if (threadIdx.x == 0) {
+      while (coherent_load(stat + 64) < (unsigned long long)nstat) __builtin_amdgcn_s_sleep(2);
+      const double v = fixed2_value(coherent_load(stat + 0), coherent_load(stat + 16));
+      sm[12] = coherent_load(reinterpret_cast<const unsigned*>(stat + 80)) ? __builtin_nan("") : v;
+    }
+    __syncthreads();
+    sum_s = sm[12];
+  } else if (p_begin < p_end) {
+    glove_rec_tables(loc, bias, r0);
+    if (p_begin + 1 < n) glove_rec_tables(loc, bias, r1);
+  }
+  const float sbar = (float)(sum_s / (double)B);
+  const float two_over_B = 2.0f / (float)B;
+  double acc_w = 0.0, acc_wr = 0.0, acc_wq = 0.0;
+  auto emb_row = [&](uint32_t id, uint32_t byte) {
+    return (loc_at_step_begin(byte, T) ? emb1 : emb0) + (int64_t)id * D;
+  };
+  auto part_row = [&](const GloveRec& r) { return emb_row(__float_as_uint(r.m.x) & kIdMask, r.y1); };
+  // rows of the NEXT position, requested before this position is computed
+  bool have_next = false;
+  RowRegs<VEC, NCH> nown, nfirst, na;
+
+  for (int64_t p = p_begin; p < p_end; ++p) {
+    const GloveRec cur = r0, nxt = r1;
+    const uint32_t prev = prev_n;
+    const bool more = p + 1 < n;
+    r0 = r1;
+    r1 = r2;
+    if (p + 2 < n) glove_rec_tables(loc, bias, r1);  // position p + 2's record arrived an iteration ago
+    if (p + 3 < n) {
+      r2.id = (uint32_t)sorted_ids[p + 3];
+      r2.m = meta[p + 3];
+    }
+    prev_n = cur.id;
+    const uint32_t id = cur.id;
+    const bool head = prev != id;  // prev = all ones at p == 0: no id equals it
+    if (!head && ((p & (kStepChunk - 1)) != 0 || (uint32_t)sorted_ids[p - kStepChunk] != id)) continue;
+    const int64_t stop = min(head ? ((p + 2 * kStepChunk - 1) / kStepChunk) * kStepChunk : p + kStepChunk, n);
+    const uint32_t code = id | (loc_at_step_begin(cur.y0, T) ? kLocBit : 0u);
+    RowRegs<VEC, NCH> own, a, g, first;
+    if (have_next) {
+      own = nown;
+      first = nfirst;
+      a = na;
+    } else {
+      row_load(own, emb_row(id, cur.y0), lig, G, nvec);
+      row_load(first, part_row(cur), lig, G, nvec);
+      row_load(a, accum + (int64_t)id * D, lig, G, nvec);
+    }
+    have_next = false;
+    int64_t e_run = p + 1;
+    if (more && nxt.id == id) {  // a run of several occurrences: find the end of this chunk
+      ++e_run;
+      while (e_run < stop && (uint32_t)sorted_ids[e_run] == id) ++e_run;
+      if (e_run > stop) e_run = stop;
+    } else if (p + 1 < p_end) {  // the usual case, a run of one: position p + 1 heads the next run -- request its rows now
+      row_load(nown, emb_row(nxt.id, nxt.y0), lig, G, nvec);
+      row_load(nfirst, part_row(nxt), lig, G, nvec);
+      row_load(na, accum + (int64_t)nxt.id * D, lig, G, nvec);
+      have_next = true;
+    }
+    row_zero(g);
+    double bsum = 0.0;  // fp64: a hot token's bias gradient is a sum over thousands of occurrences
+    // one occurrence: gdot from the dot with its partner row; G += gdot * partner, the product rounded to f32 first
+    // (it used to be stored as a gradient row) and the additions strictly left to right
+    auto occ = [&](const GloveRec& r, const RowRegs<VEC, NCH>& part) {
+      const float dot = group_sum(row_dot_partial(own, part), G);
+      const float rr = r.m.z - dot;
+      const float s = r.b0 + r.b1;  // Bias[t1] + Bias[t2] (an f32 addition commutes: either side gives K_A's bits)
+      const float center = (mode == ESR_GLOVE_REFERENCE) ? sbar : s;
+      const float gdot = -(two_over_B * r.m.y) * (rr - center);
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) g.v[k][e] = __fadd_rn(g.v[k][e], __fmul_rn(gdot, part.v[k][e]));
+      bsum += (double)((mode == ESR_GLOVE_REFERENCE) ? s : gdot);
+      if (lig == 0 && !(__float_as_uint(r.m.x) & kSideBit)) {  // every pair is seen from both sides: count it once
+        const double q = (double)rr - (double)center;
+        acc_w += (double)r.m.y;
+        acc_wr += (double)r.m.y * (double)rr;
+        acc_wq += (double)r.m.y * q * q;
+      }
+    };
+    occ(cur, first);
+    int64_t q = p + 1;
+    auto rec_at = [&](int64_t qq) {  // record of a later occurrence of this run (own row's byte / bias: the run's)
+      GloveRec r;
+      r.id = id;
+      r.m = meta[qq];
+      r.y0 = cur.y0;
+      r.b0 = cur.b0;
+      const uint32_t partner = __float_as_uint(r.m.x) & kIdMask;
+      r.y1 = loc[partner];
+      r.b1 = bias[partner];
+      return r;
+    };
+    for (; q + 4 <= e_run; q += 4) {  // four partner rows in flight
+      const GloveRec g0 = rec_at(q), g1 = rec_at(q + 1), g2 = rec_at(q + 2), g3 = rec_at(q + 3);
+      RowRegs<VEC, NCH> t0, t1, t2, t3;
+      row_load(t0, part_row(g0), lig, G, nvec);
+      row_load(t1, part_row(g1), lig, G, nvec);
+      row_load(t2, part_row(g2), lig, G, nvec);
+      row_load(t3, part_row(g3), lig, G, nvec);
+      occ(g0, t0);
+      occ(g1, t1);
+      occ(g2, t2);
+      occ(g3, t3);
+    }
+    for (; q < e_run; ++q) {
+      const GloveRec gq = rec_at(q);
+      RowRegs<VEC, NCH> t;
+      row_load(t, part_row(gq), lig, G, nvec);
+      occ(gq, t);
+    }
+    // (a run of one ends at p + 1, whose id is already in a register)
+    const bool ends = q == n || (q == p + 1 ? nxt.id : (uint32_t)sorted_ids[q]) != id;
+    if (lig == 0) bias_info[p] = make_double2(bsum, (double)(e_run - p));
+    if (head && ends) {
+      step_apply<VEC, NCH>(emb0, emb1, loc, accum, code, T, own, a, g, D, lig, G, nvec, lr, eps);
+    } else {  // a chunk of a long run: park the partial sum for glove_step_long_kernel
+      const int64_t slot = 2 * (p / kStepChunk) + (head ? 1 : 0);
+      row_store(g, chunk_rows + slot * D, lig, G, nvec);
+      if (lig == 0) *parked = 1;  // (every writer stores the same value)
+    }
+  }
+  const double tw = block_sum_d(acc_w, sm);
+  const double twr = block_sum_d(acc_wr, sm + 4);
+  const double twq = block_sum_d(acc_wq, sm + 8);
+  if (threadIdx.x == 0) {
+    pair_part[3 * blockIdx.x] = tw;
+    pair_part[3 * blockIdx.x + 1] = twr;
+    pair_part[3 * blockIdx.x + 2] = twq;
   }
 }
 
@@ -323,7 +663,7 @@ __global__ __launch_bounds__(kBlock) void glove_plan_kernel(const int32_t* __res
 // (`own`), its new value goes to the OTHER buffer and the byte flips (nobody reads `loc` during this launch: the plan
 // kernel resolved every address).  `a` = the row's accumulator, loaded by the caller next to `own`.
 template <int VEC, int NCH>
-__device__ __forceinline__ void step_apply(float* __restrict__ emb0, float* __restrict__ emb1, uint8_t* __restrict__ loc,
+__device__ __forceinline__ void step_apply_resolved(float* __restrict__ emb0, float* __restrict__ emb1, uint8_t* __restrict__ loc,
                                            float* __restrict__ accum, uint32_t code, const RowRegs<VEC, NCH>& own,
                                            RowRegs<VEC, NCH>& a, const RowRegs<VEC, NCH>& g, int D, int lig, int G,
                                            int nvec, float lr, float eps) {
@@ -338,13 +678,16 @@ __device__ __forceinline__ void step_apply(float* __restrict__ emb0, float* __re
   if (lig == 0) loc[id] = (code & kLocBit) ? 0 : 1;
 }
 
-// update: the structure of segment_update_kernel (esr_optim.hip) with the gradient rows produced on the fly.
+// update, RESOLVED records (long lists; round 2's kernel as it was: the templated in-kernel-resolution variant below
+// measured 0.169 ms per step at C3 against this one's 0.148 on the same box, alternating runs -- its third record in
+// flight and the in-kernel statistics make it more sensitive to the sort that runs beside it on the second stream):
+// the structure of segment_update_kernel (esr_optim.hip) with the gradient rows produced on the fly.
 // A group's critical path per position is ONE memory round trip: the position's code and plan record are fetched one
 // iteration ahead, and the own row, its accumulator and the first partner row are requested together (the accumulator
 // speculatively: a chunk of a long run does not need it).  Written naively -- code, then own row and record, then
 // partner row, then accumulator -- the same loop was four dependent round trips and ran at 3.2 TB/s.
 template <int VEC, int NCH>
-__global__ __launch_bounds__(kBlock) void glove_step_kernel(
+__global__ __launch_bounds__(kBlock) void glove_step_resolved_kernel(
     float* __restrict__ emb0, float* __restrict__ emb1, uint8_t* __restrict__ loc, float* __restrict__ accum, int D,
     int G, const uint32_t* __restrict__ own_code, const float4* __restrict__ meta, int64_t n, int64_t B, int mode,
     int nstat, const double* __restrict__ stat_part, float lr, float eps, float* __restrict__ chunk_rows,
@@ -467,7 +810,7 @@ __global__ __launch_bounds__(kBlock) void glove_step_kernel(
     const bool ends = q == n || ((q == p + 1 ? code_n : own_code[q]) & kIdMask) != id;
     if (lig == 0) bias_info[p] = make_double2(bsum, (double)(e_run - p));
     if (head && ends) {
-      step_apply<VEC, NCH>(emb0, emb1, loc, accum, code, own, a, g, D, lig, G, nvec, lr, eps);
+      step_apply_resolved<VEC, NCH>(emb0, emb1, loc, accum, code, own, a, g, D, lig, G, nvec, lr, eps);
     } else {  // a chunk of a long run: park the partial sum for glove_step_long_kernel
       const int64_t slot = 2 * (p / kStepChunk) + (head ? 1 : 0);
       row_store(g, chunk_rows + slot * D, lig, G, nvec);
@@ -485,16 +828,17 @@ __global__ __launch_bounds__(kBlock) void glove_step_kernel(
 }
 
 // long: segment_long_kernel's screening and fixed-order combination over the parked chunk partials; also folds the
-// chunks' bias sums into the head's bias_info entry.
+// chunks' bias sums into the head's bias_info entry.  Launched only when a run may have outgrown its head chunk.
 template <int VEC, int NCH>
 __global__ __launch_bounds__(kBlock) void glove_step_long_kernel(
     float* __restrict__ emb0, float* __restrict__ emb1, uint8_t* __restrict__ loc, float* __restrict__ accum, int D,
-    int G, const uint32_t* __restrict__ own_code, int64_t n, float lr, float eps,
-    const float* __restrict__ chunk_rows, double2* __restrict__ bias_info, int npair,
-    const double* __restrict__ pair_part, double* __restrict__ pair_tot, const int* __restrict__ long_flag) {
-  // the last workgroup also reduces the update kernel's loss partials (fixed order) to three doubles, so that the
-  // finalize kernel's workgroups read three numbers instead of re-reducing a thousand partials each
-  if (blockIdx.x == gridDim.x - 1) {
+    int G, const int32_t* __restrict__ sorted_ids, int64_t n, uint32_t T, float lr, float eps,
+    const float* __restrict__ chunk_rows, double2* __restrict__ bias_info, const int* __restrict__ parked, int npair,
+    const double* __restrict__ pair_part, double* __restrict__ pair_tot) {
+  // resolved mode (this launch is always made there): the last workgroup reduces the update kernel's loss partials
+  // (fixed order) to three doubles, so that the finalize kernel's workgroups read three numbers instead of re-reducing
+  // a thousand partials each
+  if (pair_tot && blockIdx.x == gridDim.x - 1) {
     __shared__ double smp[12];
     double a = 0.0, b = 0.0, c = 0.0;
     for (int i = threadIdx.x; i < npair; i += kBlock) {
@@ -512,7 +856,7 @@ __global__ __launch_bounds__(kBlock) void glove_step_long_kernel(
     }
   }
   // no run of the batch outgrew its head chunk: nothing to combine -- one load instead of screening the chunk boundaries
-  if (*long_flag == 0) return;
+  if (*parked == 0) return;
   __shared__ float red[kBlock * VEC * NCH];
   __shared__ double smd[8];
   constexpr int kPass = 4;
@@ -520,7 +864,7 @@ __global__ __launch_bounds__(kBlock) void glove_step_long_kernel(
   __shared__ int s_nlong, s_hoff;
   const int tid = threadIdx.x, lig = tid & (G - 1), gidx = tid / G, NG = kBlock / G;
   const int nvec = D / VEC;
-  auto id_at = [&](int64_t pos) { return own_code[pos] & kIdMask; };
+  auto id_at = [&](int64_t pos) { return (uint32_t)sorted_ids[pos]; };
   const int64_t nbound = (n - 1) / kStepChunk;
   for (int64_t b0 = (int64_t)blockIdx.x * kPass; b0 < nbound; b0 += (int64_t)gridDim.x * kPass) {
     __syncthreads();
@@ -603,11 +947,12 @@ __global__ __launch_bounds__(kBlock) void glove_step_long_kernel(
           for (int k = 0; k < NCH; ++k)
 #pragma unroll
             for (int e = 0; e < VEC; ++e) acc.v[k][e] += red[((gg * G + lig) * NCH + k) * VEC + e];
-        const uint32_t code = own_code[h];
+        // (nobody has rewritten this row during the step: its head parked its partial instead)
+        const uint32_t code = id | (loc_at_step_begin(loc[id], T) ? kLocBit : 0u);
         RowRegs<VEC, NCH> own, a;
         row_load(own, ((code & kLocBit) ? emb1 : emb0) + (int64_t)id * D, lig, G, nvec);
         row_load(a, accum + (int64_t)id * D, lig, G, nvec);
-        step_apply<VEC, NCH>(emb0, emb1, loc, accum, code, own, a, acc, D, lig, G, nvec, lr, eps);
+        step_apply<VEC, NCH>(emb0, emb1, loc, accum, code, T, own, a, acc, D, lig, G, nvec, lr, eps);
       }
       __syncthreads();
     }
@@ -616,12 +961,14 @@ __global__ __launch_bounds__(kBlock) void glove_step_long_kernel(
 
 // finalize: the loss (same formula as glove_finalize_kernel) and the bias table's Adagrad step, one thread per sorted
 // position; a run head holds its run's sums.  Reference mode: sum over the run of dL/ds = -(2/B^2) (cnt * Swr - Sw *
-// sum s); diagonal mode: the sum of gdot itself.
+// sum s); diagonal mode: the sum of gdot itself.  Every workgroup re-reduces the update kernel's <= 2048 x 3 loss
+// partials in the same fixed order (48 KB out of L2), so it depends on no other launch.
 __global__ __launch_bounds__(kBlock) void glove_step_finalize_kernel(
-    int64_t B, int mode, int nstat, const double* __restrict__ stat_part, const double* __restrict__ pair_tot,
-    const uint32_t* __restrict__ own_code, const double2* __restrict__ bias_info, float* __restrict__ bias,
+    int64_t B, int mode, const unsigned long long* __restrict__ stat, int nstat, const double* __restrict__ stat_part,
+    int npair, const double* __restrict__ pair_part, const double* __restrict__ pair_tot,
+    const int32_t* __restrict__ sorted_ids, const double2* __restrict__ bias_info, float* __restrict__ bias,
     float* __restrict__ bias_accum, float lr, float eps, float* __restrict__ loss) {
-  __shared__ double sm[20];
+  __shared__ double sm[16];
   // this thread's position: everything it needs from memory is requested before the reductions below
   const int64_t n = 2 * B;
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -630,30 +977,56 @@ __global__ __launch_bounds__(kBlock) void glove_step_finalize_kernel(
   double2 v = make_double2(0.0, 0.0);
   float w = 0.f, acc = 0.f;
   if (p < n) {
-    id = own_code[p] & kIdMask;
-    head = p == 0 || (own_code[p - 1] & kIdMask) != id;
+    id = (uint32_t)sorted_ids[p];
+    head = p == 0 || (uint32_t)sorted_ids[p - 1] != id;
     if (head) {
       v = bias_info[p];
       w = bias[id];
       acc = bias_accum[id];
     }
   }
-  const double Sw = pair_tot[0], Swr = pair_tot[1], Swq = pair_tot[2];
-  const double Bd = (double)B;
-  if (blockIdx.x == 0) {
-    double sum_s = 0.0, sum_s2 = 0.0;
-    if (mode == ESR_GLOVE_REFERENCE) reduce_stat_parts(stat_part, nstat, sm, &sum_s, &sum_s2);
-    if (threadIdx.x == 0) {
-      double L;
-      if (mode == ESR_GLOVE_REFERENCE) {
-        double SS = sum_s2 - sum_s * sum_s / Bd;
-        if (SS < 0.0) SS = 0.0;
-        L = (Bd * Swq + Sw * SS) / (Bd * Bd);
-      } else {
-        L = Swq / Bd;
-      }
-      loss[0] = (float)L;
+  double Sw, Swr, Swq;
+  if (pair_tot) {  // reduced by the long-run launch
+    Sw = pair_tot[0];
+    Swr = pair_tot[1];
+    Swq = pair_tot[2];
+  } else {
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < npair; i += kBlock) {
+      a += pair_part[3 * i];
+      b += pair_part[3 * i + 1];
+      c += pair_part[3 * i + 2];
     }
+    const double tw = block_sum_d(a, sm);
+    const double twr = block_sum_d(b, sm + 4);
+    const double twq = block_sum_d(c, sm + 8);
+    if (threadIdx.x == 0) {
+      sm[12] = tw;
+      sm[13] = twr;
+      sm[14] = twq;
+    }
+    __syncthreads();
+    Sw = sm[12];
+    Swr = sm[13];
+    Swq = sm[14];
+  }
+  const double Bd = (double)B;
+  double rs = 0.0, rs2 = 0.0;
+  if (blockIdx.x == 0 && stat_part && mode == ESR_GLOVE_REFERENCE)  // resolved mode: K_A's partials, K_A's order
+    reduce_stat_parts(stat_part, nstat, sm, &rs, &rs2);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    double L;
+    if (mode == ESR_GLOVE_REFERENCE) {
+      const bool poisoned = !stat_part && *reinterpret_cast<const unsigned*>(stat + 80) != 0u;
+      const double sum_s = stat_part ? rs : fixed2_value(stat[0], stat[16]);
+      const double sum_s2 = stat_part ? rs2 : fixed2_value(stat[32], stat[48]);
+      double SS = sum_s2 - sum_s * sum_s / Bd;
+      if (SS < 0.0) SS = 0.0;
+      L = poisoned ? __builtin_nan("") : (Bd * Swq + Sw * SS) / (Bd * Bd);
+    } else {
+      L = Swq / Bd;
+    }
+    loss[0] = (float)L;
   }
   if (head) {
     const double k = 2.0 / (Bd * Bd);
@@ -664,7 +1037,7 @@ __global__ __launch_bounds__(kBlock) void glove_step_finalize_kernel(
   }
 }
 
-// rows whose byte is set live in `shadow`: copy them back into `primary` and clear the byte (T = float4 or float)
+// rows whose byte has bit 0 set live in `shadow`: copy them back into `primary`; every byte is cleared (T = float4 or float)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void rows_consolidate_kernel(T* __restrict__ primary, const T* __restrict__ shadow,
                                                                  uint8_t* __restrict__ loc, int64_t V, int nchunk,
@@ -674,9 +1047,11 @@ __global__ __launch_bounds__(kBlock) void rows_consolidate_kernel(T* __restrict_
   const int64_t group = (int64_t)blockIdx.x * gpb + threadIdx.x / G;
   const int64_t ngroups = (int64_t)gridDim.x * gpb;
   for (int64_t r = group; r < V; r += ngroups) {
-    if (!loc[r]) continue;
-    for (int c = lig; c < nchunk; c += G) primary[r * nchunk + c] = shadow[r * nchunk + c];
-    if (lig == 0) loc[r] = 0;
+    const uint8_t b = loc[r];
+    if (!b) continue;
+    if (b & 1)
+      for (int c = lig; c < nchunk; c += G) primary[r * nchunk + c] = shadow[r * nchunk + c];
+    if (lig == 0) loc[r] = 0;  // (the stamp goes too)
   }
 }
 
@@ -768,64 +1143,205 @@ size_t esr_glove_step_workspace_bytes(int64_t B, int D) {
   return step_ws_layout(B, D, nullptr, nullptr);
 }
 
+size_t esr_glove_plan_bytes(int64_t B) {
+  if (B <= 0) return 0;
+  return glove_plan_layout(B, nullptr, nullptr);
+}
+
+static void launch_glove_plan(const int32_t* const* inputs, const float* const* targets, int nbatch,
+                              const int32_t* sorted_ids, const int32_t* perm, int64_t B, char* plans, size_t stride,
+                              int* hints, int gen, hipStream_t st) {
+  GlovePlanBatch pb;
+  for (int b = 0; b < kMaxGlovePlanBatch; ++b) {
+    pb.inputs[b] = inputs[b < nbatch ? b : 0];
+    pb.target[b] = targets[b < nbatch ? b : 0];
+  }
+  const int gx = (int)std::min<int64_t>(kMaxGrid, cdiv(2 * B, kBlock));
+  hipLaunchKernelGGL(glove_plan_kernel, dim3(gx, nbatch), dim3(kBlock), 0, st, pb, sorted_ids, perm, B, plans, stride,
+                     hints, gen);
+}
+
+// hint[0] = gen when sorted_ids has a run of equal ids longer than `chunk` positions
+__global__ __launch_bounds__(kBlock) void long_run_hint_kernel(const int32_t* __restrict__ sorted_ids, int64_t n, int chunk,
+                                                              int* __restrict__ hint, int gen) {
+  bool long_run = false;
+  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p + chunk < n; p += (int64_t)gridDim.x * kBlock)
+    if (sorted_ids[p] == sorted_ids[p + chunk]) long_run = true;
+  if (__any(long_run) && (threadIdx.x & 63) == 0) hint[0] = gen;
+}
+
+int esr_long_run_hint(const int32_t* sorted_ids, int64_t n, int chunk, int32_t* hint, int32_t gen, esr_stream_t stream) {
+  ESR_REQUIRE(n >= 0 && chunk > 0 && hint && (n == 0 || sorted_ids), "esr_long_run_hint: bad arguments");
+  if (n <= chunk) return ESR_OK;
+  const int grid = (int)std::min<int64_t>(kMaxGrid, cdiv(n, kBlock));
+  hipLaunchKernelGGL(long_run_hint_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), sorted_ids, n, chunk, hint, gen);
+  return check_launch("esr_long_run_hint");
+}
+
+int esr_glove_plan(const int32_t* const* inputs, const float* const* targets, int nbatch, int64_t B,
+                   const int32_t* sorted_ids, const int32_t* perm, void* plans, int32_t* hints, int32_t gen,
+                   esr_stream_t stream) {
+  ESR_REQUIRE(nbatch >= 1 && nbatch <= kMaxGlovePlanBatch && B > 0 && 2 * B < ((int64_t)1 << 31),
+              "esr_glove_plan: nbatch=%d not in [1, %d] or bad B=%lld", nbatch, kMaxGlovePlanBatch, (long long)B);
+  ESR_REQUIRE(inputs && targets && sorted_ids && perm && plans && !((uintptr_t)plans & 255),
+              "esr_glove_plan: null or misaligned pointer");
+  for (int i = 0; i < nbatch; ++i) ESR_REQUIRE(inputs[i] && targets[i], "esr_glove_plan: null list %d", i);
+  launch_glove_plan(inputs, targets, nbatch, sorted_ids, perm, B, (char*)plans, esr_glove_plan_bytes(B), hints, gen,
+                    as_stream(stream));
+  return check_launch("esr_glove_plan");
+}
+
+}  // extern "C"
+
+struct GloveTables {
+  float* emb;
+  float* emb_shadow;
+  uint8_t* emb_loc;
+  float* emb_accum;
+  float* bias;
+  float* bias_accum;
+  int D;
+};
+
+// one step's launches (arguments validated by the callers)
+static void launch_glove_step(const GloveTables& t, const int32_t* inputs, const float* target, int64_t B, int mode,
+                              float lr, float eps, uint32_t stamp, const int32_t* sorted_ids, const int32_t* perm,
+                              void* plan, int long_runs, int blocks_per_cu, float* loss, const StepWs& ws,
+                              hipStream_t st) {
+  const int64_t n = 2 * B;
+  const int D = t.D;
+  const RowGeom g = row_geom(D);
+  int grid = grid_for_groups(n, g.G);
+  const int grid2 = (int)std::min<int64_t>(kMaxGrid, cdiv(cdiv(n, kStepChunk), 4));
+  const int nfin = (int)cdiv(n, kBlock);  // one thread per sorted position
+  if (n > kResolveMinIds) {
+    // long list: a resolve launch (round 2's plan kernel: row codes with the location bits, w, log10(1 + c), s and K_A's
+    // statistics) in front of the update kernel, which then walks resolved records -- see kResolveMinIds.  A plan made
+    // ahead is not used here (its records carry no locations).
+    const int nstat = (int)std::min<int64_t>(kStatBlocks, cdiv(B, kBlock));
+    const int nres = (int)std::max<int64_t>(nstat, std::min<int64_t>(kMaxGrid, cdiv(n, kBlock)));
+    hipLaunchKernelGGL(glove_resolve_kernel, dim3(nres), dim3(kBlock), 0, st, sorted_ids, perm, inputs, target,
+                       (const float*)t.bias, (const uint8_t*)t.emb_loc, B, nstat, ws.own_code, ws.meta_res, ws.stat_part,
+                       ws.res_flags);
+    ESR_DISPATCH_ROW(g, {
+      static const int resident_all = resident_blocks((const void*)glove_step_resolved_kernel<VEC, NCH>, 0);
+      const int resident = blocks_per_cu > 0
+                               ? resident_blocks((const void*)glove_step_resolved_kernel<VEC, NCH>, blocks_per_cu)
+                               : resident_all;
+      grid = std::min(grid, resident);
+      hipLaunchKernelGGL((glove_step_resolved_kernel<VEC, NCH>), dim3(grid), dim3(kBlock), 0, st, t.emb, t.emb_shadow,
+                         t.emb_loc, t.emb_accum, D, g.G, (const uint32_t*)ws.own_code, (const float4*)ws.meta_res, n, B,
+                         mode, nstat, (const double*)ws.stat_part, lr, eps, ws.chunk_rows, ws.bias_info, ws.pair_part,
+                         ws.res_flags);
+      // (always launched here: its last workgroup reduces the loss partials for the finalize kernel)
+      hipLaunchKernelGGL((glove_step_long_kernel<VEC, NCH>), dim3(grid2), dim3(kBlock), 0, st, t.emb, t.emb_shadow,
+                         t.emb_loc, t.emb_accum, D, g.G, sorted_ids, n, stamp, lr, eps, (const float*)ws.chunk_rows,
+                         ws.bias_info, (const int*)ws.res_flags, grid, (const double*)ws.pair_part, ws.pair_tot);
+    });
+    hipLaunchKernelGGL(glove_step_finalize_kernel, dim3(nfin), dim3(kBlock), 0, st, B, mode,
+                       (const unsigned long long*)nullptr, nstat, (const double*)ws.stat_part, grid,
+                       (const double*)ws.pair_part, (const double*)ws.pair_tot, sorted_ids,
+                       (const double2*)ws.bias_info, t.bias, t.bias_accum, lr, eps, loss);
+    return;
+  }
+  if (!plan) {  // no plan made ahead: make it here (and nobody told us whether a run is long: screen for it)
+    launch_glove_plan(&inputs, &target, 1, sorted_ids, perm, B, ws.plan, 0, nullptr, 0, st);
+    plan = ws.plan;
+    long_runs = -1;
+  }
+  GlovePlan pl;
+  glove_plan_layout(B, (char*)plan, &pl);
+  const int nstat = mode == ESR_GLOVE_REFERENCE ? (int)std::min<int64_t>(kStatBlocksStep, cdiv(B, kBlock)) : 0;
+  ESR_DISPATCH_ROW(g, {
+    // one resident wave-set: every group walks a contiguous slice, so a grid larger than what the chip holds at once
+    // only adds a second, partly filled round (94 VGPRs -> 5 blocks per CU: 2048 blocks ran as 1280 + 768); the
+    // prologue's wait also relies on the workgroups it waits for having been dispatched (they have: index order)
+    static const int resident_all = resident_blocks((const void*)glove_step_kernel<VEC, NCH>, 0);  // (one query)
+    const int resident = blocks_per_cu > 0 ? resident_blocks((const void*)glove_step_kernel<VEC, NCH>, blocks_per_cu)
+                                           : resident_all;
+    grid = std::max(nstat, std::min(grid, resident));
+    hipLaunchKernelGGL((glove_step_kernel<VEC, NCH>), dim3(grid), dim3(kBlock), 0, st, t.emb, t.emb_shadow, t.emb_loc,
+                       t.emb_accum, (const float*)t.bias, D, g.G, sorted_ids, (const float4*)pl.meta, inputs, n, B, mode,
+                       stamp, nstat, pl.stat, lr, eps, ws.chunk_rows, ws.bias_info, ws.pair_part, pl.flags);
+    if (long_runs != 0)  // 0 = the caller knows (esr_glove_plan's hint) that no run outgrows its head chunk
+      hipLaunchKernelGGL((glove_step_long_kernel<VEC, NCH>), dim3(grid2), dim3(kBlock), 0, st, t.emb, t.emb_shadow,
+                         t.emb_loc, t.emb_accum, D, g.G, sorted_ids, n, stamp, lr, eps, (const float*)ws.chunk_rows,
+                         ws.bias_info, (const int*)pl.flags, 0, (const double*)nullptr, (double*)nullptr);
+  });
+  hipLaunchKernelGGL(glove_step_finalize_kernel, dim3(nfin), dim3(kBlock), 0, st, B, mode,
+                     (const unsigned long long*)pl.stat, 0, (const double*)nullptr, grid, (const double*)ws.pair_part,
+                     (const double*)nullptr, sorted_ids, (const double2*)ws.bias_info, t.bias, t.bias_accum, lr, eps,
+                     loss);
+}
+
+#define ESR_GLOVE_STEP_CHECKS(who)                                                                                    \
+  ESR_REQUIRE(B > 0 && V > 0 && D > 0, who ": bad sizes V=%lld D=%d B=%lld", (long long)V, D, (long long)B);          \
+  ESR_REQUIRE(V <= (int64_t)kIdMask, who ": V=%lld exceeds 2^30 - 1 rows", (long long)V);                             \
+  ESR_REQUIRE(2 * B < ((int64_t)1 << 31), who ": B=%lld too large", (long long)B);                                    \
+  ESR_REQUIRE(mode == ESR_GLOVE_REFERENCE || mode == ESR_GLOVE_DIAGONAL, who ": bad mode %d", mode);                  \
+  ESR_REQUIRE(emb && emb_shadow && emb_loc && emb_accum && bias && bias_accum, who ": null table pointer");           \
+  ESR_REQUIRE(emb != emb_shadow, who ": the shadow table must be a second buffer");                                   \
+  if (int rc = check_dim(who, D)) return rc;                                                                          \
+  if (!workspace || workspace_bytes < esr_glove_step_workspace_bytes(B, D) || ((uintptr_t)workspace & 15)) {          \
+    set_error(who ": workspace %zu bytes < %zu required (or misaligned)", workspace_bytes,                            \
+              esr_glove_step_workspace_bytes(B, D));                                                                  \
+    return ESR_EWORKSPACE;                                                                                            \
+  }
+
+extern "C" {
+
 int esr_glove_train_step(float* emb, float* emb_shadow, uint8_t* emb_loc, float* emb_accum, float* bias,
                          float* bias_accum, int64_t V, int D, const int32_t* inputs, const float* target, int64_t B,
-                         int mode, float lr, float eps, const int32_t* presorted_ids, const int32_t* presorted_perm,
-                         int blocks_per_cu, float* loss, void* workspace, size_t workspace_bytes,
-                         esr_stream_t stream) {
-  ESR_REQUIRE(B > 0 && V > 0 && D > 0, "esr_glove_train_step: bad sizes V=%lld D=%d B=%lld", (long long)V, D,
-              (long long)B);
-  ESR_REQUIRE(V <= (int64_t)kIdMask, "esr_glove_train_step: V=%lld exceeds 2^30 - 1 rows", (long long)V);
-  ESR_REQUIRE(2 * B < ((int64_t)1 << 31), "esr_glove_train_step: B=%lld too large", (long long)B);
-  ESR_REQUIRE(mode == ESR_GLOVE_REFERENCE || mode == ESR_GLOVE_DIAGONAL, "esr_glove_train_step: bad mode %d", mode);
-  ESR_REQUIRE(emb && emb_shadow && emb_loc && emb_accum && bias && bias_accum && inputs && target && loss,
-              "esr_glove_train_step: null pointer");
-  ESR_REQUIRE(emb != emb_shadow, "esr_glove_train_step: the shadow table must be a second buffer");
-  if (int rc = check_dim("esr_glove_train_step", D)) return rc;
-  if (!workspace || workspace_bytes < esr_glove_step_workspace_bytes(B, D) || ((uintptr_t)workspace & 15)) {
-    set_error("esr_glove_train_step: workspace %zu bytes < %zu required (or misaligned)", workspace_bytes,
-              esr_glove_step_workspace_bytes(B, D));
-    return ESR_EWORKSPACE;
-  }
+                         int mode, float lr, float eps, uint32_t stamp, const int32_t* presorted_ids,
+                         const int32_t* presorted_perm, void* plan, int long_runs, int blocks_per_cu, float* loss,
+                         void* workspace, size_t workspace_bytes, esr_stream_t stream) {
+  ESR_GLOVE_STEP_CHECKS("esr_glove_train_step")
+  ESR_REQUIRE(inputs && target && loss, "esr_glove_train_step: null pointer");
+  ESR_REQUIRE(stamp >= 1 && stamp <= kStampMax, "esr_glove_train_step: stamp %u not in [1, %u]", stamp, kStampMax);
+  ESR_REQUIRE((presorted_ids == nullptr) == (presorted_perm == nullptr),
+              "esr_glove_train_step: presorted_ids and presorted_perm must both be set or both be NULL");
+  ESR_REQUIRE(!plan || presorted_ids, "esr_glove_train_step: a plan goes with the sorted ids it was made from");
+  ESR_REQUIRE(!plan || !((uintptr_t)plan & 255), "esr_glove_train_step: misaligned plan");
   hipStream_t st = as_stream(stream);
   StepWs ws;
   step_ws_layout(B, D, (char*)workspace, &ws);
-  const int64_t n = 2 * B;
-  ESR_REQUIRE((presorted_ids == nullptr) == (presorted_perm == nullptr),
-              "esr_glove_train_step: presorted_ids and presorted_perm must both be set or both be NULL");
   const int32_t* sorted_ids = presorted_ids;
   const int32_t* perm = presorted_perm;
   if (!sorted_ids) {
-    if (int rc = esr_segment_sort_ids(inputs, n, V, ws.sorted_ids, ws.perm, ws.sort_ws, ws.sort_ws_bytes, stream)) return rc;
+    if (int rc = esr_segment_sort_ids(inputs, 2 * B, V, ws.sorted_ids, ws.perm, ws.sort_ws, ws.sort_ws_bytes, stream))
+      return rc;
     sorted_ids = ws.sorted_ids;
     perm = ws.perm;
   }
-  const RowGeom g = row_geom(D);
-  const int nstat = (int)std::min<int64_t>(kStatBlocks, cdiv(B, kBlock));
-  const int nplan = (int)std::max<int64_t>(nstat, std::min<int64_t>(kMaxGrid, cdiv(n, kBlock)));
-  hipLaunchKernelGGL(glove_plan_kernel, dim3(nplan), dim3(kBlock), 0, st, sorted_ids, perm, inputs, target, (const float*)bias, (const uint8_t*)emb_loc, B, nstat,
-                     ws.own_code, ws.meta, ws.stat_part, reinterpret_cast<int*>(ws.pair_tot + 3));
-  int grid = grid_for_groups(n, g.G);
-  const int grid2 = (int)std::min<int64_t>(kMaxGrid, cdiv(cdiv(n, kStepChunk), 4));
-  ESR_DISPATCH_ROW(g, {
-    // one resident wave-set: every group walks a contiguous slice, so a grid larger than what the chip holds at once
-    // only adds a second, partly filled round (94 VGPRs -> 5 blocks per CU: 2048 blocks ran as 1280 + 768)
-    grid = std::min(grid, resident_blocks((const void*)glove_step_kernel<VEC, NCH>, blocks_per_cu));
-    hipLaunchKernelGGL((glove_step_kernel<VEC, NCH>), dim3(grid), dim3(kBlock), 0, st, emb, emb_shadow, emb_loc,
-                       emb_accum, D, g.G, (const uint32_t*)ws.own_code, (const float4*)ws.meta, n, B, mode, nstat,
-                       (const double*)ws.stat_part, lr, eps, ws.chunk_rows, ws.bias_info, ws.pair_part,
-                       reinterpret_cast<int*>(ws.pair_tot + 3));
-    // (always launched: its last workgroup reduces the loss partials for the finalize kernel)
-    hipLaunchKernelGGL((glove_step_long_kernel<VEC, NCH>), dim3(grid2), dim3(kBlock), 0, st, emb, emb_shadow, emb_loc,
-                       emb_accum, D, g.G, (const uint32_t*)ws.own_code, n, lr, eps, (const float*)ws.chunk_rows,
-                       ws.bias_info, grid, (const double*)ws.pair_part, ws.pair_tot,
-                       reinterpret_cast<const int*>(ws.pair_tot + 3));
-  });
-  const int nfin = (int)cdiv(n, kBlock);  // one thread per sorted position
-  hipLaunchKernelGGL(glove_step_finalize_kernel, dim3(nfin), dim3(kBlock), 0, st, B, mode, nstat,
-                     (const double*)ws.stat_part, (const double*)ws.pair_tot, (const uint32_t*)ws.own_code,
-                     (const double2*)ws.bias_info, bias, bias_accum, lr, eps, loss);
+  const GloveTables t{emb, emb_shadow, emb_loc, emb_accum, bias, bias_accum, D};
+  launch_glove_step(t, inputs, target, B, mode, lr, eps, stamp, sorted_ids, perm, plan, long_runs, blocks_per_cu, loss,
+                    ws, st);
   return check_launch("esr_glove_train_step");
+}
+
+int esr_glove_train_steps(float* emb, float* emb_shadow, uint8_t* emb_loc, float* emb_accum, float* bias,
+                          float* bias_accum, int64_t V, int D, int nbatch, const int32_t* const* inputs,
+                          const float* const* targets, int64_t B, int mode, float lr, float eps, uint32_t first_stamp,
+                          const int32_t* sorted_ids, const int32_t* perm, void* plans, const int32_t* long_runs,
+                          float* losses, void* workspace, size_t workspace_bytes, esr_stream_t stream) {
+  ESR_GLOVE_STEP_CHECKS("esr_glove_train_steps")
+  ESR_REQUIRE(nbatch >= 1 && nbatch <= kMaxGlovePlanBatch && inputs && targets && sorted_ids && perm && plans && losses &&
+                  !((uintptr_t)plans & 255),
+              "esr_glove_train_steps: nbatch=%d not in [1, %d], or a null / misaligned pointer", nbatch,
+              kMaxGlovePlanBatch);
+  ESR_REQUIRE(first_stamp >= 1 && first_stamp + (uint32_t)nbatch - 1 <= kStampMax,
+              "esr_glove_train_steps: stamps %u .. %u leave [1, %u]", first_stamp, first_stamp + nbatch - 1, kStampMax);
+  for (int i = 0; i < nbatch; ++i) ESR_REQUIRE(inputs[i] && targets[i], "esr_glove_train_steps: null list %d", i);
+  hipStream_t st = as_stream(stream);
+  StepWs ws;
+  step_ws_layout(B, D, (char*)workspace, &ws);
+  const size_t stride = esr_glove_plan_bytes(B);
+  const GloveTables t{emb, emb_shadow, emb_loc, emb_accum, bias, bias_accum, D};
+  for (int b = 0; b < nbatch; ++b)
+    launch_glove_step(t, inputs[b], targets[b], B, mode, lr, eps, first_stamp + (uint32_t)b,
+                      sorted_ids + (int64_t)b * 2 * B, perm + (int64_t)b * 2 * B, (char*)plans + (size_t)b * stride,
+                      long_runs ? long_runs[b] : -1, 0, losses + b, ws, st);
+  return check_launch("esr_glove_train_steps");
 }
 
 int esr_rows_consolidate(float* primary, const float* shadow, uint8_t* loc, int64_t V, int D, esr_stream_t stream) {

@@ -7,24 +7,29 @@
 // Here the gradient of an occurrence is formed on chip inside the update kernel from the two OTHER rows of its triplet,
 // which the double-buffered towers (esr_versioned.h) make safe to read while rows are being rewritten:
 //
-//   sort      virtual occurrence ids [scene ; Vs + pos ; Vs + neg] -> (sorted, perm)   (ahead, on a second stream, or here)
-//   plan      per sorted position: own row code, the two partner row codes, the occurrence's slot
-//   update    one row group per sorted position, the head of a run walks it: both partner rows -> pos / neg score,
-//             hinge mask, own norm -> this occurrence's gradient row; summed left to right; Adagrad once per distinct
-//             row into the other buffer.  The scene occurrence of a triplet also contributes its loss term.
-//   long      runs longer than a chunk (hot rows): chunk partials combined in a fixed order; its last workgroup
-//             reduces the loss
+//   sort      virtual occurrence ids [scene ; Vs + pos ; Vs + neg] -> (sorted, perm)        } ids only: made AHEAD,
+//   plan      per sorted position: the occurrence's slot and its two partner rows;           } for several batches
+//             "may a run outgrow its head chunk?" (the host's reason to launch `long` at all) } by one launch each
+//   update    one row group per sorted position, the head of a run walks it: row locations resolved from the stamped
+//             bytes (round 3: no per-step plan launch), both partner rows -> pos / neg score, hinge mask, own norm ->
+//             this occurrence's gradient row; summed left to right; Adagrad once per distinct row into the other
+//             buffer.  The scene occurrence of a triplet also contributes its loss term; the loss leaves the kernel
+//             through an exact fixed-point reduction (no finalize launch).
+//   long      only when a run outgrew its head chunk (hot rows): chunk partials combined in a fixed order
+//
+// Round 2 ran plan -> update -> long per step (4.7 + 18.1 + 4.5 us at B = 8192); a step of uniform ids is now the
+// update kernel alone.
 #include "esr_common.h"
 #include "esr_versioned.h"
 
 namespace esr {
 
-constexpr int kTripStepBlocks = kMaxGrid;
 // Cut points of long runs: every 8 positions instead of the 32 of the other segment kernels.  An occurrence costs this
 // kernel two dependent round trips (plan record -> two partner rows), so a hot row is a LONG sequential walk per chunk:
 // with 32-position chunks a Zipf(1) batch of 8192 triplets took 131 us (99 us before this kernel existed); shorter
 // chunks spread the walk over four times as many row groups.
 constexpr int kTripChunk = 8;
+constexpr uint32_t kSlotShift = 30;  // plan record .x = partner A's virtual row | slot << 30
 
 struct TwoTowers {
   float* s0;  // scene tower, primary buffer            virtual rows [0, Vs)
@@ -36,6 +41,7 @@ struct TwoTowers {
   float* sacc;
   float* pacc;
   int64_t Vs;
+  uint32_t stamp;  // this step's stamp (esr_versioned.h)
 };
 
 __device__ __forceinline__ const float* tower_row(const TwoTowers& tt, uint32_t code, int D) {
@@ -44,15 +50,45 @@ __device__ __forceinline__ const float* tower_row(const TwoTowers& tt, uint32_t 
   const float* base = prod ? (second ? tt.p1 : tt.p0) : (second ? tt.s1 : tt.s0);
   return base + (prod ? vid - tt.Vs : vid) * D;
 }
+__device__ __forceinline__ const float* tower_acc(const TwoTowers& tt, uint32_t vid, int D) {
+  return vid >= tt.Vs ? tt.pacc + (int64_t)(vid - tt.Vs) * D : tt.sacc + (int64_t)vid * D;
+}
+// the location byte of virtual row vid, as it reads now
+__device__ __forceinline__ uint32_t loc_byte(const TwoTowers& tt, uint32_t vid) {
+  return vid >= tt.Vs ? tt.ploc[vid - tt.Vs] : tt.sloc[vid];
+}
+// row code (id | buffer bit) of the value the row had when this step began
+__device__ __forceinline__ uint32_t code_of(uint32_t vid, uint32_t byte, uint32_t T) {
+  return vid | (loc_at_step_begin(byte, T) ? kLocBit : 0u);
+}
+
+// ---- the plan of one batch: everything the update kernel needs besides the tables, from the ids alone ----------------
+struct TripPlan {
+  int* flags;                   // [0] parked: set by the update kernel when it parks a chunk partial; [1 .. 63] unused
+  unsigned long long* loss_acc; // [kFixAccWords]  fixed-point loss accumulator, zero before the update kernel
+  uint2* meta;                  // [n]  {partner A | slot << 30, partner B}
+};
+static size_t trip_plan_layout(int64_t B, char* base, TripPlan* out) {
+  const int64_t n = 3 * B;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += align_up(bytes, 256);
+    return p;
+  };
+  TripPlan pl;
+  pl.flags = (int*)take(sizeof(int) * 64);
+  pl.loss_acc = (unsigned long long*)take(sizeof(unsigned long long) * kFixAccWords);
+  pl.meta = (uint2*)take(sizeof(uint2) * (size_t)n);
+  if (out) *out = pl;
+  return off;
+}
 
 struct TripWs {
   int32_t* sorted_ids;  // [n]
   int32_t* perm;        // [n]
-  uint32_t* own_code;   // [n]
-  uint4* meta;          // [n]  {slot, partner a code, partner b code, triplet index}
-  double* loss_part;    // [kTripStepBlocks]
-  int* long_flag;       // [1]  set by the update kernel when it parks a chunk partial: the batch has a long run
-  float* chunk_rows;    // [2 * ceil(n / 32)][D]
+  float* chunk_rows;    // [2 * ceil(n / 8)][D]
+  char* plan;           // trip_plan_layout(B) bytes: the in-line plan of a call that brings none
   void* sort_ws;
   size_t sort_ws_bytes;
 };
@@ -68,40 +104,55 @@ static size_t trip_ws_layout(int64_t B, int D, char* base, TripWs* ws) {
   TripWs w;
   w.sorted_ids = (int32_t*)take(sizeof(int32_t) * (size_t)n);
   w.perm = (int32_t*)take(sizeof(int32_t) * (size_t)n);
-  w.own_code = (uint32_t*)take(sizeof(uint32_t) * (size_t)n);
-  w.meta = (uint4*)take(sizeof(uint4) * (size_t)n);
-  w.loss_part = (double*)take(sizeof(double) * kTripStepBlocks);
-  w.long_flag = (int*)take(sizeof(int));
   w.chunk_rows = (float*)take(sizeof(float) * 2 * (size_t)cdiv(n, kTripChunk) * (size_t)D);
+  w.plan = take(trip_plan_layout(B, nullptr, nullptr));
   w.sort_ws_bytes = esr_segment_sort_workspace_bytes(n);
   w.sort_ws = take(w.sort_ws_bytes);
   if (ws) *ws = w;
   return off;
 }
 
-// plan: one thread per sorted position.  Occurrence o = perm[p]: slot = o / B (0 scene, 1 pos, 2 neg), triplet b = o % B.
-// Partners: scene -> (pos, neg); pos -> (scene, neg); neg -> (scene, pos).
-__global__ __launch_bounds__(kBlock) void triplet_plan_kernel(const int32_t* __restrict__ perm,
-                                                             const int32_t* __restrict__ scene_ids,
-                                                             const int32_t* __restrict__ pos_ids,
-                                                             const int32_t* __restrict__ neg_ids,
-                                                             const uint8_t* __restrict__ sloc,
-                                                             const uint8_t* __restrict__ ploc, int64_t B, int64_t Vs,
-                                                             uint32_t* __restrict__ own_code, uint4* __restrict__ meta,
-                                                             int* __restrict__ long_flag) {
+constexpr int kMaxPlanBatch = 8;
+struct PlanBatch {
+  const int32_t* scene[kMaxPlanBatch];
+  const int32_t* pos[kMaxPlanBatch];
+  const int32_t* neg[kMaxPlanBatch];
+};
+
+// plan: one thread per sorted position of list blockIdx.y.  Occurrence o = perm[p]: slot = o / B (0 scene, 1 pos, 2 neg),
+// triplet b = o % B.  Partners: scene -> (pos, neg); pos -> (scene, neg); neg -> (scene, pos).  hints[list] = gen when
+// some run of equal ids is longer than kTripChunk positions -- only then can the update kernel park a chunk partial and
+// need the `long` launch (a head chunk covers at least kTripChunk positions).  `gen` is the caller's call counter: a
+// word that need not be cleared.
+__global__ __launch_bounds__(kBlock) void triplet_plan_kernel(PlanBatch pb, const int32_t* __restrict__ sorted_all,
+                                                             const int32_t* __restrict__ perm_all, int64_t B,
+                                                             int64_t Vs, char* __restrict__ plans, size_t plan_stride,
+                                                             int* __restrict__ hints, int gen) {
+  const int list = blockIdx.y;
   const int64_t n = 3 * B;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *long_flag = 0;
+  const int32_t* __restrict__ sorted = sorted_all + (int64_t)list * n;
+  const int32_t* __restrict__ perm = perm_all + (int64_t)list * n;
+  const int32_t* __restrict__ scene_ids = pb.scene[list];
+  const int32_t* __restrict__ pos_ids = pb.pos[list];
+  const int32_t* __restrict__ neg_ids = pb.neg[list];
+  char* base = plans + (size_t)list * plan_stride;
+  int* flags = (int*)base;
+  unsigned long long* loss_acc = (unsigned long long*)(base + 256);
+  uint2* meta = (uint2*)(base + 256 + align_up(sizeof(unsigned long long) * kFixAccWords, 256));
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < 64) flags[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < kFixAccWords; i += kBlock) loss_acc[i] = 0ull;
+  }
+  bool long_run = false;
   for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock) {
     const int64_t o = perm[p];
     const int slot = o >= 2 * B ? 2 : (o >= B ? 1 : 0);
     const int64_t b = o - slot * B;
-    const int32_t sid = scene_ids[b], pid = pos_ids[b], nid = neg_ids[b];
-    const uint32_t sc = (uint32_t)sid | (sloc[sid] ? kLocBit : 0u);
-    const uint32_t pc = (uint32_t)(Vs + pid) | (ploc[pid] ? kLocBit : 0u);
-    const uint32_t nc = (uint32_t)(Vs + nid) | (ploc[nid] ? kLocBit : 0u);
-    own_code[p] = slot == 0 ? sc : (slot == 1 ? pc : nc);
-    meta[p] = make_uint4((uint32_t)slot, slot == 0 ? pc : sc, slot == 2 ? pc : nc, (uint32_t)b);
+    const uint32_t sc = (uint32_t)scene_ids[b], pc = (uint32_t)(Vs + pos_ids[b]), nc = (uint32_t)(Vs + neg_ids[b]);
+    meta[p] = make_uint2((slot == 0 ? pc : sc) | ((uint32_t)slot << kSlotShift), slot == 2 ? pc : nc);
+    if (p + kTripChunk < n && sorted[p] == sorted[p + kTripChunk]) long_run = true;
   }
+  if (hints && __any(long_run) && (threadIdx.x & 63) == 0) hints[list] = gen;  // (every writer stores the same value)
 }
 
 template <int VEC, int NCH>
@@ -119,17 +170,29 @@ __device__ __forceinline__ void step_apply2(const TwoTowers& tt, uint32_t code, 
   row_store(a, (prod ? tt.pacc : tt.sacc) + id * D, lig, G, nvec);
   float* dst = prod ? (second ? tt.p0 : tt.p1) : (second ? tt.s0 : tt.s1);  // the OTHER buffer
   row_store(w, dst + id * D, lig, G, nvec);
-  if (lig == 0) (prod ? tt.ploc : tt.sloc)[id] = second ? 0 : 1;
+  if (lig == 0) (prod ? tt.ploc : tt.sloc)[id] = loc_written(second ? 0u : 1u, tt.stamp);
+}
+
+// one position's plan record with the location bytes of its three rows
+struct TripRec {
+  uint32_t id;      // own virtual row
+  uint2 m;          // {A | slot << 30, B}
+  uint32_t y0, ya, yb;  // location bytes of own, A, B (as loaded)
+};
+__device__ __forceinline__ void rec_bytes(const TwoTowers& tt, TripRec& r) {
+  r.y0 = loc_byte(tt, r.id);
+  r.ya = loc_byte(tt, r.m.x & kIdMask);
+  r.yb = loc_byte(tt, r.m.y);
 }
 
 template <int VEC, int NCH>
 __global__ __launch_bounds__(kBlock) void triplet_step_kernel(TwoTowers tt, int D, int G,
-                                                             const uint32_t* __restrict__ own_code,
-                                                             const uint4* __restrict__ meta, int64_t n, float lam,
+                                                             const int32_t* __restrict__ sorted_ids,
+                                                             const uint2* __restrict__ meta, int64_t n, float lam,
                                                              float inv_bs, int with_reg, float lr, float eps,
-                                                             float* __restrict__ chunk_rows,
-                                                             double* __restrict__ loss_part,
-                                                             int* __restrict__ long_flag) {
+                                                             float* __restrict__ chunk_rows, int* __restrict__ parked,
+                                                             unsigned long long* __restrict__ loss_acc, int frac,
+                                                             double inv_batch_size, float* __restrict__ loss) {
   __shared__ double sm[8];
   const int lig = threadIdx.x & (G - 1);
   const int64_t gpb = kBlock / G;
@@ -138,16 +201,25 @@ __global__ __launch_bounds__(kBlock) void triplet_step_kernel(TwoTowers tt, int 
   const int nvec = D / VEC;
   const int64_t per = (n + ngroups - 1) / ngroups;
   const int64_t p_begin = group * per, p_end = min(n, (group + 1) * per);
-  uint32_t c0 = 0, c1 = 0, prev_n = 0xFFFFFFFFu;
-  uint4 m0 = make_uint4(0, 0, 0, 0), m1 = m0;
+  const uint32_t T = tt.stamp;
+  // Pipeline per group: records run THREE positions ahead, location bytes two, rows one.  r0 = position p (bytes
+  // landed), r1 = p + 1 (bytes requested an iteration ago), r2 = p + 2 (record requested an iteration ago).
+  TripRec r0{0, make_uint2(0, 0), 0, 0, 0}, r1 = r0, r2 = r0;
+  uint32_t prev_n = 0xFFFFFFFFu;
   if (p_begin < p_end) {
-    c0 = own_code[p_begin];
-    if (p_begin > 0) prev_n = own_code[p_begin - 1];
-    m0 = meta[p_begin];
+    r0.id = (uint32_t)sorted_ids[p_begin];
+    r0.m = meta[p_begin];
+    if (p_begin > 0) prev_n = (uint32_t)sorted_ids[p_begin - 1];
     if (p_begin + 1 < n) {
-      c1 = own_code[p_begin + 1];
-      m1 = meta[p_begin + 1];
+      r1.id = (uint32_t)sorted_ids[p_begin + 1];
+      r1.m = meta[p_begin + 1];
     }
+    if (p_begin + 2 < n) {
+      r2.id = (uint32_t)sorted_ids[p_begin + 2];
+      r2.m = meta[p_begin + 2];
+    }
+    rec_bytes(tt, r0);
+    if (p_begin + 1 < n) rec_bytes(tt, r1);
   }
   double acc_loss = 0.0;
   // rows of the next position requested ahead only while rows are short in registers (four rows of NCH * VEC floats)
@@ -156,20 +228,22 @@ __global__ __launch_bounds__(kBlock) void triplet_step_kernel(TwoTowers tt, int 
   RowRegs<VEC, NCH> nown, na, nA, nB;
 
   for (int64_t p = p_begin; p < p_end; ++p) {
-    const uint32_t code = c0, prev = prev_n, code_n = c1;
-    const uint4 m_first = m0, m_next = m1;
+    const TripRec cur = r0, nxt = r1;
+    const uint32_t prev = prev_n;
     const bool more = p + 1 < n;
-    c0 = c1;
-    m0 = m1;
-    if (p + 2 < n) {
-      c1 = own_code[p + 2];
-      m1 = meta[p + 2];
+    r0 = r1;
+    r1 = r2;
+    if (p + 2 < n) rec_bytes(tt, r1);  // bytes of position p + 2 (its record arrived an iteration ago)
+    if (p + 3 < n) {
+      r2.id = (uint32_t)sorted_ids[p + 3];
+      r2.m = meta[p + 3];
     }
-    prev_n = code;
-    const uint32_t id = code & kIdMask;
-    const bool head = (prev & kIdMask) != id;
-    if (!head && ((p & (kTripChunk - 1)) != 0 || (own_code[p - kTripChunk] & kIdMask) != id)) continue;
+    prev_n = cur.id;
+    const uint32_t id = cur.id;
+    const bool head = prev != id;  // prev = all ones at p == 0: no id equals it
+    if (!head && ((p & (kTripChunk - 1)) != 0 || (uint32_t)sorted_ids[p - kTripChunk] != id)) continue;
     const int64_t stop = min(head ? ((p + 2 * kTripChunk - 1) / kTripChunk) * kTripChunk : p + kTripChunk, n);
+    const uint32_t code = code_of(id, cur.y0, T);
     RowRegs<VEC, NCH> own, a, g, fA, fB;
     if (have_next) {
       own = nown;
@@ -178,25 +252,24 @@ __global__ __launch_bounds__(kBlock) void triplet_step_kernel(TwoTowers tt, int 
       fB = nB;
     } else {
       row_load(own, tower_row(tt, code, D), lig, G, nvec);
-      row_load(fA, tower_row(tt, m_first.y, D), lig, G, nvec);
-      row_load(fB, tower_row(tt, m_first.z, D), lig, G, nvec);
-      row_load(a, (id >= tt.Vs ? tt.pacc + (int64_t)(id - tt.Vs) * D : tt.sacc + (int64_t)id * D), lig, G, nvec);
+      row_load(fA, tower_row(tt, code_of(cur.m.x & kIdMask, cur.ya, T), D), lig, G, nvec);
+      row_load(fB, tower_row(tt, code_of(cur.m.y, cur.yb, T), D), lig, G, nvec);
+      row_load(a, tower_acc(tt, id, D), lig, G, nvec);
     }
     have_next = false;
     int64_t e_run = p + 1;
-    if (more && (code_n & kIdMask) == id) {
+    if (more && nxt.id == id) {
       ++e_run;
-      if (e_run < stop && (c1 & kIdMask) == id) {  // (position p + 2's record is already on its way into c1)
+      if (e_run < stop && r1.id == id && p + 2 < n) {  // (position p + 2's record is in r1 by now)
         ++e_run;
-        while (e_run < stop && (own_code[e_run] & kIdMask) == id) ++e_run;
+        while (e_run < stop && (uint32_t)sorted_ids[e_run] == id) ++e_run;
       }
       if (e_run > stop) e_run = stop;
     } else if (kAhead && p + 1 < p_end) {  // a run of one: position p + 1 heads the next run -- request its rows now
-      const uint32_t idn = code_n & kIdMask;
-      row_load(nown, tower_row(tt, code_n, D), lig, G, nvec);
-      row_load(nA, tower_row(tt, m_next.y, D), lig, G, nvec);
-      row_load(nB, tower_row(tt, m_next.z, D), lig, G, nvec);
-      row_load(na, (idn >= tt.Vs ? tt.pacc + (int64_t)(idn - tt.Vs) * D : tt.sacc + (int64_t)idn * D), lig, G, nvec);
+      row_load(nown, tower_row(tt, code_of(nxt.id, nxt.y0, T), D), lig, G, nvec);
+      row_load(nA, tower_row(tt, code_of(nxt.m.x & kIdMask, nxt.ya, T), D), lig, G, nvec);
+      row_load(nB, tower_row(tt, code_of(nxt.m.y, nxt.yb, T), D), lig, G, nvec);
+      row_load(na, tower_acc(tt, nxt.id, D), lig, G, nvec);
       have_next = true;
     }
     row_zero(g);
@@ -206,8 +279,7 @@ __global__ __launch_bounds__(kBlock) void triplet_step_kernel(TwoTowers tt, int 
       own_norm = sqrtf(group_sum(row_dot_partial(own, own), G));
       c = own_norm > 1.f ? lam / own_norm : 0.f;
     }
-    auto occ = [&](const uint4& m, const RowRegs<VEC, NCH>& A, const RowRegs<VEC, NCH>& Bq) {
-      const uint32_t slot = m.x;
+    auto occ = [&](uint32_t slot, const RowRegs<VEC, NCH>& A, const RowRegs<VEC, NCH>& Bq) {
       // scene: A = pos, B = neg ; pos: A = scene, B = neg ; neg: A = scene, B = pos
       const float d_oa = group_sum(row_dot_partial(own, A), G);
       const float d_ob = group_sum(row_dot_partial(own, Bq), G);
@@ -234,73 +306,81 @@ __global__ __launch_bounds__(kBlock) void triplet_step_kernel(TwoTowers tt, int 
         if (lig == 0) acc_loss += (double)loss_b;
       }
     };
-    occ(m_first, fA, fB);
+    occ(cur.m.x >> kSlotShift, fA, fB);
     int64_t q = p + 1;
-    auto meta_at = [&](int64_t qq) -> uint4 {  // position p + 1's record is in a register
-      if (qq == p + 1) return m_next;
-      return meta[qq];
-    };
-    for (; kAhead && q + 2 <= e_run; q += 2) {  // two occurrences = four partner rows in flight
-      const uint4 ma = meta_at(q), mb = meta[q + 1];
-      RowRegs<VEC, NCH> a0, b0, a1, b1;
-      row_load(a0, tower_row(tt, ma.y, D), lig, G, nvec);
-      row_load(b0, tower_row(tt, ma.z, D), lig, G, nvec);
-      row_load(a1, tower_row(tt, mb.y, D), lig, G, nvec);
-      row_load(b1, tower_row(tt, mb.z, D), lig, G, nvec);
-      occ(ma, a0, b0);
-      occ(mb, a1, b1);
-    }
-    if (q < e_run) {  // the plan record of the next occurrence travels while this one's rows do
-      uint4 mq = meta_at(q);
-      for (; q < e_run; ++q) {
-        const uint4 m = mq;
-        if (q + 1 < e_run) mq = meta[q + 1];
-        RowRegs<VEC, NCH> a0, b0;
-        row_load(a0, tower_row(tt, m.y, D), lig, G, nvec);
-        row_load(b0, tower_row(tt, m.z, D), lig, G, nvec);
-        occ(m, a0, b0);
+    // the rest of the run: record -> location bytes -> rows are three dependent round trips, so two occurrences (four
+    // partner rows) travel together; position p + 1's record and bytes are in registers already
+    for (; q < e_run; q += 2) {
+      const bool two = q + 1 < e_run;
+      TripRec ra, rb;
+      if (q == p + 1) {
+        ra = nxt;
+      } else {
+        ra.id = id;
+        ra.m = meta[q];
+      }
+      rb.id = id;
+      rb.m = two ? meta[q + 1] : ra.m;
+      if (q != p + 1) {
+        ra.ya = loc_byte(tt, ra.m.x & kIdMask);
+        ra.yb = loc_byte(tt, ra.m.y);
+      }
+      rb.ya = loc_byte(tt, rb.m.x & kIdMask);
+      rb.yb = loc_byte(tt, rb.m.y);
+      RowRegs<VEC, NCH> a0, b0;
+      row_load(a0, tower_row(tt, code_of(ra.m.x & kIdMask, ra.ya, T), D), lig, G, nvec);
+      row_load(b0, tower_row(tt, code_of(ra.m.y, ra.yb, T), D), lig, G, nvec);
+      if (two && kAhead) {
+        RowRegs<VEC, NCH> a1, b1;
+        row_load(a1, tower_row(tt, code_of(rb.m.x & kIdMask, rb.ya, T), D), lig, G, nvec);
+        row_load(b1, tower_row(tt, code_of(rb.m.y, rb.yb, T), D), lig, G, nvec);
+        occ(ra.m.x >> kSlotShift, a0, b0);
+        occ(rb.m.x >> kSlotShift, a1, b1);
+      } else {
+        occ(ra.m.x >> kSlotShift, a0, b0);
+        if (two) {
+          row_load(a0, tower_row(tt, code_of(rb.m.x & kIdMask, rb.ya, T), D), lig, G, nvec);
+          row_load(b0, tower_row(tt, code_of(rb.m.y, rb.yb, T), D), lig, G, nvec);
+          occ(rb.m.x >> kSlotShift, a0, b0);
+        }
       }
     }
-    // (a run of one -- nearly every run of a uniform batch -- ends at p + 1, whose code is already in a register: the
-    // reload was a dependent L2 round trip in front of the stores of a kernel that is one latency chain per group)
-    const bool ends = q == n || ((q == p + 1 ? code_n : own_code[q]) & kIdMask) != id;
+    q = e_run;
+    // (a run of one -- nearly every run of a uniform batch -- ends at p + 1, whose id is already in a register)
+    const bool ends = q == n || (q == p + 1 ? nxt.id : (uint32_t)sorted_ids[q]) != id;
     if (head && ends) {
       step_apply2<VEC, NCH>(tt, code, own, a, g, D, lig, G, nvec, lr, eps);
     } else {
       const int64_t slot = 2 * (p / kTripChunk) + (head ? 1 : 0);
       row_store(g, chunk_rows + slot * D, lig, G, nvec);
-      if (lig == 0) *long_flag = 1;  // (every writer stores the same value)
+      if (lig == 0) *parked = 1;  // (every writer stores the same value)
     }
   }
   const double t = block_sum_d(acc_loss, sm);
-  if (threadIdx.x == 0) loss_part[blockIdx.x] = t;
+  if (threadIdx.x == 0) {
+    double total;
+    unsigned flags;
+    if (fixed_sum_arrive(loss_acc, t, frac, gridDim.x, &total, &flags))
+      loss[0] = (flags & 1u) ? __builtin_nanf("") : ((flags & 2u) ? __builtin_inff() : (float)(total * inv_batch_size));
+  }
 }
 
 template <int VEC, int NCH>
 __global__ __launch_bounds__(kBlock) void triplet_step_long_kernel(TwoTowers tt, int D, int G,
-                                                                  const uint32_t* __restrict__ own_code, int64_t n,
+                                                                  const int32_t* __restrict__ sorted_ids, int64_t n,
                                                                   float lr, float eps,
-                                                                  const float* __restrict__ chunk_rows, int npart,
-                                                                  const double* __restrict__ loss_part,
-                                                                  double inv_batch_size, float* __restrict__ loss,
-                                                                  const int* __restrict__ long_flag) {
-  if (blockIdx.x == gridDim.x - 1) {  // the loss: partials of the update kernel in a fixed order
-    __shared__ double smp[4];
-    double a = 0.0;
-    for (int i = threadIdx.x; i < npart; i += kBlock) a += loss_part[i];
-    const double t = block_sum_d(a, smp);
-    if (threadIdx.x == 0) loss[0] = (float)(t * inv_batch_size);
-  }
+                                                                  const float* __restrict__ chunk_rows,
+                                                                  const int* __restrict__ parked) {
   // no run of the batch outgrew its head chunk (every batch of uniform ids): nothing to combine -- one load instead of
   // the screening of the chunk boundaries (three dependent loads and three barriers per workgroup)
-  if (*long_flag == 0) return;
+  if (*parked == 0) return;
   __shared__ float red[kBlock * VEC * NCH];
   constexpr int kPass = 4;
   __shared__ long long s_long[kPass];
   __shared__ int s_nlong, s_hoff;
   const int tid = threadIdx.x, lig = tid & (G - 1), gidx = tid / G, NG = kBlock / G;
   const int nvec = D / VEC;
-  auto id_at = [&](int64_t pos) { return own_code[pos] & kIdMask; };
+  auto id_at = [&](int64_t pos) { return (uint32_t)sorted_ids[pos]; };
   const int64_t nbound = (n - 1) / kTripChunk;
   for (int64_t b0 = (int64_t)blockIdx.x * kPass; b0 < nbound; b0 += (int64_t)gridDim.x * kPass) {
     __syncthreads();
@@ -373,15 +453,56 @@ __global__ __launch_bounds__(kBlock) void triplet_step_long_kernel(TwoTowers tt,
           for (int k = 0; k < NCH; ++k)
 #pragma unroll
             for (int e = 0; e < VEC; ++e) acc.v[k][e] += red[((gg * G + lig) * NCH + k) * VEC + e];
-        const uint32_t code = own_code[h];
+        // (nobody has rewritten this row during the step: its head parked its partial instead)
+        const uint32_t code = code_of(id, loc_byte(tt, id), tt.stamp);
         RowRegs<VEC, NCH> own, a;
         row_load(own, tower_row(tt, code, D), lig, G, nvec);
-        row_load(a, (id >= tt.Vs ? tt.pacc + (int64_t)(id - tt.Vs) * D : tt.sacc + (int64_t)id * D), lig, G, nvec);
+        row_load(a, tower_acc(tt, id, D), lig, G, nvec);
         step_apply2<VEC, NCH>(tt, code, own, a, acc, D, lig, G, nvec, lr, eps);
       }
       __syncthreads();
     }
   }
+}
+
+// clear the stamps of a location array (bit 0 stays): 16 bytes per thread
+__global__ __launch_bounds__(kBlock) void rows_restamp_kernel(uint8_t* __restrict__ loc, int64_t V) {
+  const int64_t nv = V / 16;
+  uint4* v = reinterpret_cast<uint4*>(loc);
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += (int64_t)gridDim.x * kBlock) {
+    uint4 x = v[i];
+    x.x &= 0x01010101u;
+    x.y &= 0x01010101u;
+    x.z &= 0x01010101u;
+    x.w &= 0x01010101u;
+    v[i] = x;
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = nv * 16 + threadIdx.x; i < V; i += kBlock) loc[i] &= 1;
+}
+
+static int launch_trip_plan(const int32_t* const* ids, int nbatch, const int32_t* sorted_ids, const int32_t* perm,
+                            int64_t B, int64_t Vs, char* plans, size_t stride, int* hints, int gen, hipStream_t st) {
+  PlanBatch pb;
+  for (int b = 0; b < kMaxPlanBatch; ++b) {
+    const int s = b < nbatch ? b : 0;
+    pb.scene[b] = ids[3 * s];
+    pb.pos[b] = ids[3 * s + 1];
+    pb.neg[b] = ids[3 * s + 2];
+  }
+  const int64_t n = 3 * B;
+  const int gx = (int)std::min<int64_t>(kMaxGrid, cdiv(n, kBlock));
+  hipLaunchKernelGGL(triplet_plan_kernel, dim3(gx, nbatch), dim3(kBlock), 0, st, pb, sorted_ids, perm, B, Vs, plans, stride,
+                     hints, gen);
+  return ESR_OK;
+}
+
+// fraction bits of the fixed-point loss accumulator: the SUM over the batch must stay below 2^(52 - frac); with
+// frac = 41 - ceil(log2 B) a mean loss below 2048 fits for every B (beyond: the loss comes out +inf)
+static int loss_frac_bits(int64_t B) {
+  int lg = 0;
+  while (((int64_t)1 << lg) < B) ++lg;
+  return std::max(8, std::min(36, 41 - lg));
 }
 
 }  // namespace esr
@@ -395,63 +516,145 @@ size_t esr_triplet_step_workspace_bytes(int64_t B, int D) {
   return trip_ws_layout(B, D, nullptr, nullptr);
 }
 
+size_t esr_triplet_plan_bytes(int64_t B) {
+  if (B <= 0) return 0;
+  return trip_plan_layout(B, nullptr, nullptr);
+}
+
+int esr_triplet_plan(const int32_t* const* ids, int nbatch, int64_t B, int64_t Vs, const int32_t* sorted_ids,
+                     const int32_t* perm, void* plans, int32_t* hints, int32_t gen, esr_stream_t stream) {
+  ESR_REQUIRE(nbatch >= 1 && nbatch <= kMaxPlanBatch && B > 0 && Vs > 0 && 3 * B < ((int64_t)1 << 31),
+              "esr_triplet_plan: nbatch=%d not in [1, %d] or bad sizes B=%lld Vs=%lld", nbatch, kMaxPlanBatch,
+              (long long)B, (long long)Vs);
+  ESR_REQUIRE(ids && sorted_ids && perm && plans && !((uintptr_t)plans & 255), "esr_triplet_plan: null or misaligned pointer");
+  for (int i = 0; i < 3 * nbatch; ++i) ESR_REQUIRE(ids[i], "esr_triplet_plan: null id list %d", i);
+  launch_trip_plan(ids, nbatch, sorted_ids, perm, B, Vs, (char*)plans, esr_triplet_plan_bytes(B), hints, gen,
+                   as_stream(stream));
+  return check_launch("esr_triplet_plan");
+}
+
+int esr_rows_restamp(uint8_t* loc, int64_t V, esr_stream_t stream) {
+  ESR_REQUIRE(V >= 0, "esr_rows_restamp: V=%lld", (long long)V);
+  if (V == 0) return ESR_OK;
+  ESR_REQUIRE(loc && !((uintptr_t)loc & 15), "esr_rows_restamp: null or misaligned pointer");
+  const int grid = (int)std::min<int64_t>(kMaxGrid, std::max<int64_t>(1, cdiv(V / 16, kBlock)));
+  hipLaunchKernelGGL(rows_restamp_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), loc, V);
+  return check_launch("esr_rows_restamp");
+}
+
+}  // extern "C"
+
+// one step's launches (arguments validated by the callers)
+static int launch_trip_step(const TwoTowers& tt, int D, const RowGeom& g, const int32_t* scene_ids, const int32_t* pos_ids,
+                            const int32_t* neg_ids, int64_t B, float regularization, float batch_size, float lr, float eps,
+                            const int32_t* sorted, const int32_t* perm, void* plan, int long_runs, float* loss,
+                            const TripWs& ws, hipStream_t st) {
+  const int64_t n = 3 * B;
+  if (!plan) {  // no plan made ahead: make it here (and nobody told us whether a run is long: screen for it)
+    const int32_t* ids3[3] = {scene_ids, pos_ids, neg_ids};
+    launch_trip_plan(ids3, 1, sorted, perm, B, tt.Vs, ws.plan, 0, nullptr, 0, st);
+    plan = ws.plan;
+    long_runs = -1;
+  }
+  TripPlan pl;
+  trip_plan_layout(B, (char*)plan, &pl);
+  int grid = grid_for_groups(n, g.G);
+  const int grid2 = (int)std::min<int64_t>(kMaxGrid, cdiv(cdiv(n, kTripChunk), 4));
+  const float inv_bs = 1.0f / batch_size;
+  ESR_DISPATCH_ROW(g, {
+    static const int resident = resident_blocks((const void*)triplet_step_kernel<VEC, NCH>);  // (one query per process)
+    grid = std::min(grid, resident);
+    hipLaunchKernelGGL((triplet_step_kernel<VEC, NCH>), dim3(grid), dim3(kBlock), 0, st, tt, D, g.G, sorted,
+                       (const uint2*)pl.meta, n, regularization, inv_bs, 1, lr, eps, ws.chunk_rows, pl.flags,
+                       pl.loss_acc, loss_frac_bits(B), 1.0 / (double)batch_size, loss);
+    if (long_runs != 0)  // 0 = the caller knows (esr_triplet_plan's hint) that no run outgrows its head chunk
+      hipLaunchKernelGGL((triplet_step_long_kernel<VEC, NCH>), dim3(grid2), dim3(kBlock), 0, st, tt, D, g.G, sorted, n,
+                         lr, eps, (const float*)ws.chunk_rows, (const int*)pl.flags);
+  });
+  return ESR_OK;
+}
+
+#define ESR_TRIP_STEP_CHECKS(who)                                                                                      \
+  ESR_REQUIRE(B > 0 && D > 0 && Vs > 0 && Vp > 0, who ": bad sizes Vs=%lld Vp=%lld D=%d B=%lld", (long long)Vs,        \
+              (long long)Vp, D, (long long)B);                                                                         \
+  ESR_REQUIRE(Vs + Vp <= (int64_t)kIdMask, who ": %lld virtual rows exceed 2^30 - 1", (long long)(Vs + Vp));           \
+  ESR_REQUIRE(3 * B < ((int64_t)1 << 31), who ": B=%lld too large", (long long)B);                                     \
+  ESR_REQUIRE(scene && scene_shadow && scene_loc && scene_accum && product && product_shadow && product_loc &&        \
+                  product_accum,                                                                                       \
+              who ": null table pointer");                                                                             \
+  ESR_REQUIRE(scene != scene_shadow && product != product_shadow, who ": a shadow table must be a second buffer");     \
+  ESR_REQUIRE(batch_size != 0.f, who ": batch_size must be non-zero");                                                 \
+  const RowGeom g = step_geom_few_lanes(D);                                                                            \
+  ESR_REQUIRE(g.nch <= kMaxChunksPerLane, who ": D=%d not supported", D);                                              \
+  if (!workspace || workspace_bytes < esr_triplet_step_workspace_bytes(B, D) || ((uintptr_t)workspace & 15)) {         \
+    set_error(who ": workspace %zu bytes < %zu required (or misaligned)", workspace_bytes,                             \
+              esr_triplet_step_workspace_bytes(B, D));                                                                 \
+    return ESR_EWORKSPACE;                                                                                             \
+  }
+
+extern "C" {
+
 int esr_triplet_train_step(float* scene, float* scene_shadow, uint8_t* scene_loc, float* scene_accum, int64_t Vs,
                            float* product, float* product_shadow, uint8_t* product_loc, float* product_accum,
                            int64_t Vp, int D, const int32_t* scene_ids, const int32_t* pos_ids,
                            const int32_t* neg_ids, int64_t B, float regularization, float batch_size, float lr,
-                           float eps, const int32_t* presorted_ids, const int32_t* presorted_perm, float* loss,
-                           void* workspace, size_t workspace_bytes, esr_stream_t stream) {
-  ESR_REQUIRE(B > 0 && D > 0 && Vs > 0 && Vp > 0, "esr_triplet_train_step: bad sizes Vs=%lld Vp=%lld D=%d B=%lld",
-              (long long)Vs, (long long)Vp, D, (long long)B);
-  ESR_REQUIRE(Vs + Vp <= (int64_t)kIdMask, "esr_triplet_train_step: %lld virtual rows exceed 2^30 - 1",
-              (long long)(Vs + Vp));
-  ESR_REQUIRE(3 * B < ((int64_t)1 << 31), "esr_triplet_train_step: B=%lld too large", (long long)B);
-  ESR_REQUIRE(scene && scene_shadow && scene_loc && scene_accum && product && product_shadow && product_loc &&
-                  product_accum && scene_ids && pos_ids && neg_ids && loss,
-              "esr_triplet_train_step: null pointer");
-  ESR_REQUIRE(scene != scene_shadow && product != product_shadow,
-              "esr_triplet_train_step: a shadow table must be a second buffer");
-  ESR_REQUIRE(batch_size != 0.f, "esr_triplet_train_step: batch_size must be non-zero");
+                           float eps, uint32_t stamp, const int32_t* presorted_ids, const int32_t* presorted_perm,
+                           void* plan, int long_runs, float* loss, void* workspace, size_t workspace_bytes,
+                           esr_stream_t stream) {
+  ESR_TRIP_STEP_CHECKS("esr_triplet_train_step")
+  ESR_REQUIRE(scene_ids && pos_ids && neg_ids && loss, "esr_triplet_train_step: null pointer");
+  ESR_REQUIRE(stamp >= 1 && stamp <= kStampMax, "esr_triplet_train_step: stamp %u not in [1, %u]", stamp, kStampMax);
   ESR_REQUIRE((presorted_ids == nullptr) == (presorted_perm == nullptr),
               "esr_triplet_train_step: presorted_ids and presorted_perm must both be set or both be NULL");
-  const RowGeom g = step_geom_few_lanes(D);
-  ESR_REQUIRE(g.nch <= kMaxChunksPerLane, "esr_triplet_train_step: D=%d not supported", D);
-  if (!workspace || workspace_bytes < esr_triplet_step_workspace_bytes(B, D) || ((uintptr_t)workspace & 15)) {
-    set_error("esr_triplet_train_step: workspace %zu bytes < %zu required (or misaligned)", workspace_bytes,
-              esr_triplet_step_workspace_bytes(B, D));
-    return ESR_EWORKSPACE;
-  }
+  ESR_REQUIRE(!plan || presorted_ids, "esr_triplet_train_step: a plan goes with the sorted ids it was made from");
+  ESR_REQUIRE(!plan || !((uintptr_t)plan & 255), "esr_triplet_train_step: misaligned plan");
   hipStream_t st = as_stream(stream);
   TripWs ws;
   trip_ws_layout(B, D, (char*)workspace, &ws);
-  const int64_t n = 3 * B;
+  const int32_t* sorted = presorted_ids;
   const int32_t* perm = presorted_perm;
-  if (!presorted_ids) {
+  if (!sorted) {
     const int32_t* segs[3] = {scene_ids, pos_ids, neg_ids};
     const int64_t counts[3] = {B, B, B};
     const int64_t offsets[3] = {0, Vs, Vs};
     if (int rc = esr_segment_sort_ids_multi(segs, counts, offsets, 3, Vs + Vp, ws.sorted_ids, ws.perm, ws.sort_ws,
                                             ws.sort_ws_bytes, stream))
       return rc;
+    sorted = ws.sorted_ids;
     perm = ws.perm;
   }
-  TwoTowers tt{scene, scene_shadow, product, product_shadow, scene_loc, product_loc, scene_accum, product_accum, Vs};
-  const int nplan = (int)std::min<int64_t>(kMaxGrid, cdiv(n, kBlock));
-  hipLaunchKernelGGL(triplet_plan_kernel, dim3(nplan), dim3(kBlock), 0, st, perm, scene_ids, pos_ids, neg_ids,
-                     (const uint8_t*)scene_loc, (const uint8_t*)product_loc, B, Vs, ws.own_code, ws.meta, ws.long_flag);
-  int grid = grid_for_groups(n, g.G);
-  const int grid2 = (int)std::min<int64_t>(kMaxGrid, cdiv(cdiv(n, kTripChunk), 4));
-  const float inv_bs = 1.0f / batch_size;
-  ESR_DISPATCH_ROW(g, {
-    grid = std::min(grid, resident_blocks((const void*)triplet_step_kernel<VEC, NCH>));
-    hipLaunchKernelGGL((triplet_step_kernel<VEC, NCH>), dim3(grid), dim3(kBlock), 0, st, tt, D, g.G,
-                       (const uint32_t*)ws.own_code, (const uint4*)ws.meta, n, regularization, inv_bs, 1, lr, eps,
-                       ws.chunk_rows, ws.loss_part, ws.long_flag);
-    hipLaunchKernelGGL((triplet_step_long_kernel<VEC, NCH>), dim3(grid2), dim3(kBlock), 0, st, tt, D, g.G,
-                       (const uint32_t*)ws.own_code, n, lr, eps, (const float*)ws.chunk_rows, grid,
-                       (const double*)ws.loss_part, 1.0 / (double)batch_size, loss, (const int*)ws.long_flag);
-  });
+  TwoTowers tt{scene, scene_shadow, product, product_shadow, scene_loc, product_loc, scene_accum, product_accum, Vs,
+               stamp};
+  launch_trip_step(tt, D, g, scene_ids, pos_ids, neg_ids, B, regularization, batch_size, lr, eps, sorted, perm, plan,
+                   long_runs, loss, ws, st);
   return check_launch("esr_triplet_train_step");
+}
+
+int esr_triplet_train_steps(float* scene, float* scene_shadow, uint8_t* scene_loc, float* scene_accum, int64_t Vs,
+                            float* product, float* product_shadow, uint8_t* product_loc, float* product_accum,
+                            int64_t Vp, int D, int nbatch, const int32_t* const* ids, int64_t B, float regularization,
+                            float batch_size, float lr, float eps, uint32_t first_stamp, const int32_t* sorted_ids,
+                            const int32_t* perm, void* plans, const int32_t* long_runs, float* losses, void* workspace,
+                            size_t workspace_bytes, esr_stream_t stream) {
+  ESR_TRIP_STEP_CHECKS("esr_triplet_train_steps")
+  ESR_REQUIRE(nbatch >= 1 && nbatch <= kMaxPlanBatch && ids && sorted_ids && perm && plans && losses &&
+                  !((uintptr_t)plans & 255),
+              "esr_triplet_train_steps: nbatch=%d not in [1, %d], or a null / misaligned pointer", nbatch, kMaxPlanBatch);
+  ESR_REQUIRE(first_stamp >= 1 && first_stamp + (uint32_t)nbatch - 1 <= kStampMax,
+              "esr_triplet_train_steps: stamps %u .. %u leave [1, %u]", first_stamp, first_stamp + nbatch - 1, kStampMax);
+  for (int i = 0; i < 3 * nbatch; ++i) ESR_REQUIRE(ids[i], "esr_triplet_train_steps: null id list %d", i);
+  hipStream_t st = as_stream(stream);
+  TripWs ws;
+  trip_ws_layout(B, D, (char*)workspace, &ws);
+  const size_t stride = esr_triplet_plan_bytes(B);
+  for (int b = 0; b < nbatch; ++b) {
+    TwoTowers tt{scene, scene_shadow, product, product_shadow, scene_loc, product_loc, scene_accum, product_accum, Vs,
+                 first_stamp + (uint32_t)b};
+    launch_trip_step(tt, D, g, ids[3 * b], ids[3 * b + 1], ids[3 * b + 2], B, regularization, batch_size, lr, eps,
+                     sorted_ids + (int64_t)b * 3 * B, perm + (int64_t)b * 3 * B, (char*)plans + (size_t)b * stride,
+                     long_runs ? long_runs[b] : -1, losses + b, ws, st);
+  }
+  return check_launch("esr_triplet_train_steps");
 }
 
 }  // extern "C"

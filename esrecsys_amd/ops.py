@@ -3,6 +3,7 @@
 PyTorch is used for device memory and the current HIP stream only; every computation is a
 libesr_hip.so call.  All functions require CUDA(ROCm) tensors and raise if the library is missing.
 """
+import ctypes
 import os
 
 import numpy as np
@@ -184,17 +185,21 @@ GRADS_AT_IDS = 0x100  # include/esr_hip.h ESR_GRADS_AT_IDS
 
 
 def glove_train_step(emb, shadow, loc, accum, bias, bias_accum, inputs, target, mode, lr, eps=1e-7, presorted=None,
-                     blocks_per_cu=0):
+                     blocks_per_cu=0, stamp=None, plan=None, long_runs=-1):
     """One whole GloVe training step (loss + gradients + sparse Adagrad on both tables) without materialised
     gradients: esr_glove_train_step.  `emb` / `shadow` are the two buffers of the double-buffered embedding table and
-    `loc` (uint8 [V]) says which one holds each row; all three are updated.  presorted = (sorted_ids, perm) of
-    inputs.reshape(-1) from segment_sort (computed ahead, e.g. on a second stream), else the sort runs here.
+    `loc` (uint8 [V]) holds each row's stamped location byte; all three are updated.  `stamp` (1 .. 127): this step's
+    stamp on that table (train_state.next_stamp hands them out and clears the bytes' stamps when the counter wraps).
+    presorted = (sorted_ids, perm) of inputs.reshape(-1) from segment_sort (computed ahead), else the sort runs here;
+    plan = this batch's glove_plan record (needs presorted), long_runs = 0 when its hint said no run is long.
     Returns loss[1]."""
     lib = _lib.load()
     for name, t in (("emb", emb), ("shadow", shadow), ("accum", accum), ("bias", bias), ("bias_accum", bias_accum),
                     ("target", target)):
         _req(t, torch.float32, name)
     _req(loc, torch.uint8, "loc"), _req(inputs, torch.int32, "inputs")
+    if stamp is None:
+        raise ValueError("glove_train_step needs the step's stamp (train_state.next_stamp(row_versions))")
     V, D = emb.shape
     B = inputs.shape[1]
     if inputs.shape[0] != 2 or target.numel() != B:
@@ -209,19 +214,88 @@ def glove_train_step(emb, shadow, loc, accum, bias, bias_accum, inputs, target, 
         sid, perm = _req(presorted[0], torch.int32, "sorted_ids"), _req(presorted[1], torch.int32, "perm")
         if sid.numel() != 2 * B or perm.numel() != 2 * B:
             raise ValueError("presorted ids / perm must have 2 B entries")
+    if plan is not None and (plan.dtype != torch.uint8 or plan.numel() < _ws_bytes("esr_glove_plan_bytes", B)):
+        raise ValueError("plan must be the uint8 record glove_plan made for a batch of this size")
     check(lib.esr_glove_train_step(_p(emb), _p(shadow), _p(loc), _p(accum), _p(bias), _p(bias_accum), V, D, _p(inputs),
-                                   _p(target), B, mode, float(lr), float(eps), _p(sid), _p(perm), int(blocks_per_cu),
-                                   _p(loss), _p(ws), ws.numel(), _stream()),
+                                   _p(target), B, mode, float(lr), float(eps), int(stamp), _p(sid), _p(perm), _p(plan),
+                                   int(long_runs), int(blocks_per_cu), _p(loss), _p(ws), ws.numel(), _stream()),
           "esr_glove_train_step")
     return loss
 
 
+def _aligned_bytes(nbytes, device, align=256):
+    """uint8 tensor of nbytes whose data pointer is `align`-aligned (torch's allocator hands out 512-byte blocks)."""
+    t = torch.empty(nbytes + align, dtype=torch.uint8, device=device)
+    off = (-t.data_ptr()) % align
+    return t[off:off + nbytes]
+
+
+def glove_plan(inputs_list, targets_list, sorted_ids, perm, hints=None, gen=0):
+    """Plan records of up to eight coming GloVe batches by one launch (esr_glove_plan): inputs_list[b] int32 [2, B],
+    targets_list[b] f32 [B], sorted_ids / perm int32 [nb, 2B].  Returns a uint8 [nb, plan_bytes] tensor (row b feeds
+    exactly one glove_train_step).  hints: optional int32 [nb] device tensor that receives `gen` where list b has a run
+    longer than a chunk."""
+    lib = _lib.load()
+    nb = len(inputs_list)
+    B = inputs_list[0].shape[1]
+    for i, t in zip(inputs_list, targets_list):
+        _req(i, torch.int32, "inputs"), _req(t, torch.float32, "target")
+        if i.shape != (2, B) or t.numel() != B:
+            raise ValueError("every batch of a plan group must be [2, B] / [B] with the same B")
+    _req(sorted_ids, torch.int32, "sorted_ids"), _req(perm, torch.int32, "perm")
+    if sorted_ids.numel() != nb * 2 * B or perm.numel() != nb * 2 * B:
+        raise ValueError("sorted_ids / perm must be [nb, 2B]")
+    pb = _ws_bytes("esr_glove_plan_bytes", B)
+    plans = _aligned_bytes(nb * pb, inputs_list[0].device).view(nb, pb)
+    ip = (ctypes.c_void_p * nb)(*[i.data_ptr() for i in inputs_list])
+    tp = (ctypes.c_void_p * nb)(*[t.data_ptr() for t in targets_list])
+    check(lib.esr_glove_plan(ip, tp, nb, B, _p(sorted_ids), _p(perm), _p(plans), _p(hints), int(gen), _stream()),
+          "esr_glove_plan")
+    return plans
+
+
+def long_run_hint(sorted_ids, chunk, hint, gen):
+    """hint[0] = gen when sorted_ids has a run of equal ids longer than `chunk` positions (esr_long_run_hint); `hint` is
+    an int32 tensor on the device or in pinned host memory."""
+    lib = _lib.load()
+    _req(sorted_ids, torch.int32, "sorted_ids")
+    if hint.dtype != torch.int32 or not (hint.is_cuda or hint.is_pinned()):
+        raise TypeError("hint must be an int32 tensor on the device or in pinned host memory")
+    check(lib.esr_long_run_hint(_p(sorted_ids), sorted_ids.numel(), int(chunk), hint.data_ptr(), int(gen), _stream()),
+          "esr_long_run_hint")
+
+
+def triplet_plan(id_lists, Vs, sorted_ids, perm, hints=None, gen=0):
+    """Plan records of up to eight coming triplet batches by one launch (esr_triplet_plan): id_lists[b] = (scene, pos,
+    neg) int32 [B] each, sorted_ids / perm int32 [nb, 3B].  Returns a uint8 [nb, plan_bytes] tensor."""
+    lib = _lib.load()
+    nb = len(id_lists)
+    B = id_lists[0][0].numel()
+    flat = []
+    for trip in id_lists:
+        for t in trip:
+            _req(t, torch.int32, "ids")
+            if t.numel() != B:
+                raise ValueError("every id list of a plan group must have B entries")
+            flat.append(t.data_ptr())
+    _req(sorted_ids, torch.int32, "sorted_ids"), _req(perm, torch.int32, "perm")
+    if sorted_ids.numel() != nb * 3 * B or perm.numel() != nb * 3 * B:
+        raise ValueError("sorted_ids / perm must be [nb, 3B]")
+    pb = _ws_bytes("esr_triplet_plan_bytes", B)
+    plans = _aligned_bytes(nb * pb, id_lists[0][0].device).view(nb, pb)
+    ptrs = (ctypes.c_void_p * (3 * nb))(*flat)
+    check(lib.esr_triplet_plan(ptrs, nb, B, int(Vs), _p(sorted_ids), _p(perm), _p(plans), _p(hints), int(gen),
+                               _stream()), "esr_triplet_plan")
+    return plans
+
+
 def triplet_train_step(scene, scene_shadow, scene_loc, scene_accum, product, product_shadow, product_loc,
                        product_accum, scene_ids, pos_ids, neg_ids, regularization, batch_size, lr, eps=1e-7,
-                       presorted=None):
+                       presorted=None, stamp=None, plan=None, long_runs=-1):
     """One whole Shop-The-Look training step (triplet loss + on-chip gradients + sparse Adagrad on both double-buffered
-    towers): esr_triplet_train_step.  presorted = (sorted virtual ids, perm) of [scene ; Vs + pos ; Vs + neg] from
-    segment_sort_multi, else the sort runs here.  Returns loss[1]."""
+    towers): esr_triplet_train_step.  `stamp`: this step's stamp on both towers (train_state.next_stamp).  presorted =
+    (sorted virtual ids, perm) of [scene ; Vs + pos ; Vs + neg] from segment_sort_multi, else the sort runs here; plan /
+    long_runs as for glove_train_step (triplet_plan).  Returns loss[1]."""
     lib = _lib.load()
     for name, t in (("scene", scene), ("scene_shadow", scene_shadow), ("scene_accum", scene_accum),
                     ("product", product), ("product_shadow", product_shadow), ("product_accum", product_accum)):
@@ -229,6 +303,8 @@ def triplet_train_step(scene, scene_shadow, scene_loc, scene_accum, product, pro
     _req(scene_loc, torch.uint8, "scene_loc"), _req(product_loc, torch.uint8, "product_loc")
     for name, t in (("scene_ids", scene_ids), ("pos_ids", pos_ids), ("neg_ids", neg_ids)):
         _req(t, torch.int32, name)
+    if stamp is None:
+        raise ValueError("triplet_train_step needs the step's stamp (train_state.next_stamp(row_versions...))")
     Vs, D = scene.shape
     Vp = product.shape[0]
     B = scene_ids.numel()
@@ -242,12 +318,15 @@ def triplet_train_step(scene, scene_shadow, scene_loc, scene_accum, product, pro
         sid, perm = _req(presorted[0], torch.int32, "sorted_ids"), _req(presorted[1], torch.int32, "perm")
         if sid.numel() != 3 * B or perm.numel() != 3 * B:
             raise ValueError("presorted ids / perm must have 3 B entries")
+    if plan is not None and (plan.dtype != torch.uint8 or plan.numel() < _ws_bytes("esr_triplet_plan_bytes", B)):
+        raise ValueError("plan must be the uint8 record triplet_plan made for a batch of this size")
     loss = torch.empty(1, dtype=torch.float32, device=scene.device)
     ws = _ws(_ws_bytes("esr_triplet_step_workspace_bytes", B, D), scene.device)
     check(lib.esr_triplet_train_step(_p(scene), _p(scene_shadow), _p(scene_loc), _p(scene_accum), Vs, _p(product),
                                      _p(product_shadow), _p(product_loc), _p(product_accum), Vp, D, _p(scene_ids),
                                      _p(pos_ids), _p(neg_ids), B, float(regularization), float(batch_size), float(lr),
-                                     float(eps), _p(sid), _p(perm), _p(loss), _p(ws), ws.numel(), _stream()),
+                                     float(eps), int(stamp), _p(sid), _p(perm), _p(plan), int(long_runs), _p(loss),
+                                     _p(ws), ws.numel(), _stream()),
           "esr_triplet_train_step")
     return loss
 
@@ -259,6 +338,14 @@ def rows_consolidate(primary, shadow, loc):
     _req(primary, torch.float32, "primary"), _req(shadow, torch.float32, "shadow"), _req(loc, torch.uint8, "loc")
     V, D = primary.shape
     check(lib.esr_rows_consolidate(_p(primary), _p(shadow), _p(loc), V, D, _stream()), "esr_rows_consolidate")
+
+
+def rows_restamp(loc):
+    """Forget the step stamps of a double-buffered table's location bytes (bit 0, the location, stays): run when the
+    caller's stamp counter wraps (esr_rows_restamp; train_state.next_stamp does)."""
+    lib = _lib.load()
+    _req(loc, torch.uint8, "loc")
+    check(lib.esr_rows_restamp(_p(loc), loc.numel(), _stream()), "esr_rows_restamp")
 
 
 def triplet_fwd_bwd(scene_table, pos_table, neg_table, scene_ids, pos_ids, neg_ids, B, regularization, batch_size,

@@ -92,8 +92,13 @@ def fused_triplet_step_available(state):
         st, pt = p["scene_tower"]["embedding"], p["product_tower"]["embedding"]
     except (KeyError, TypeError):
         return False
-    return (st.is_cuda and st.dtype == torch.float32 and pt.dtype == torch.float32 and st.shape[1] == pt.shape[1] and
-            st.shape[0] + pt.shape[0] < (1 << 30))
+    if not (st.is_cuda and st.dtype == torch.float32 and pt.dtype == torch.float32 and st.shape[1] == pt.shape[1] and
+            st.shape[0] + pt.shape[0] < (1 << 30)):
+        return False
+    # the one-pass step keeps both towers double-buffered: without room for the second buffers the six-launch path runs
+    from ..train_state import can_double_buffer
+    prefix = ("params",) if "params" in state.raw_params else ()
+    return can_double_buffer(state, [prefix + ("scene_tower", "embedding"), prefix + ("product_tower", "embedding")])
 
 
 def presort_triplets(state, scene, pos_product, neg_product):
@@ -123,7 +128,7 @@ def presort_triplets(state, scene, pos_product, neg_product):
 
 
 def _fused_triplet_step(state, sid, pid, nid, regularization, batch_size, presorted):
-    from ..train_state import row_versions
+    from ..train_state import next_stamp, row_versions
     prefix = ("params",) if "params" in state.raw_params else ()
     p = state.raw_params["params"] if prefix else state.raw_params
     st, pt = p["scene_tower"]["embedding"], p["product_tower"]["embedding"]
@@ -131,10 +136,9 @@ def _fused_triplet_step(state, sid, pid, nid, regularization, batch_size, presor
     acc = acc["params"] if prefix else acc
     rs = row_versions(state, prefix + ("scene_tower", "embedding"))
     rp = row_versions(state, prefix + ("product_tower", "embedding"))
-    rs.dirty = rp.dirty = True
     loss = ops.triplet_train_step(st, rs.shadow, rs.loc, acc["scene_tower"]["embedding"], pt, rp.shadow, rp.loc,
                                   acc["product_tower"]["embedding"], sid, pid, nid, regularization, batch_size,
-                                  state.tx.lr, state.tx.eps, presorted=presorted)
+                                  state.tx.lr, state.tx.eps, presorted=presorted, stamp=next_stamp(rs, rp))
     return state.replace(step=state.step + 1), loss.reshape(())
 
 
@@ -207,6 +211,15 @@ def train_step(state, scene, pos_product, neg_product, regularization, batch_siz
     return new_state, loss.reshape(())
 
 
+class _Group:
+    """A group of batches whose id lists were sorted and planned together (``_FusedTripletLoop.sort_batch``)."""
+    __slots__ = ("nb", "B", "ptrs", "sorted_ptr", "perm_ptr", "plans_ptr", "which", "gen", "keep")
+
+    def __init__(self, nb, B, ptrs, sorted_ptr, perm_ptr, plans_ptr, which, gen, keep):
+        self.nb, self.B, self.ptrs, self.sorted_ptr, self.perm_ptr = nb, B, ptrs, sorted_ptr, perm_ptr
+        self.plans_ptr, self.which, self.gen, self.keep = plans_ptr, which, gen, keep  # keep: the id tensors, alive
+
+
 class _FusedTripletLoop:
     """What the one-pass triplet step needs that does not change from batch to batch, resolved once: tower / accumulator
     / RowVersions pointers, the library entry points, a loss slot per step, and a ring of id-sort buffers on the side
@@ -217,7 +230,8 @@ class _FusedTripletLoop:
     def __init__(self, state, steps, depth):
         import ctypes
         from .. import _lib
-        from ..train_state import _side_stream, row_versions
+        from ..train_state import _side_stream, next_stamp, row_versions
+        self.next_stamp = next_stamp
         prefix = ("params",) if "params" in state.raw_params else ()
         p = state.raw_params["params"] if prefix else state.raw_params
         acc = state.opt_state["sum_of_squares"]
@@ -239,8 +253,17 @@ class _FusedTripletLoop:
         self.depth = depth
         self.ring, self.B = [], -1
         self.ws = None
-        self.batch_buf, self.sort_batch_max = None, _SORT_BATCH
-        self.batch_ptrs = (ctypes.c_void_p * (3 * _SORT_BATCH))()
+        self.batch_buf, self.sort_batch_max = [None, None], _SORT_BATCH  # two sets: group g + 1 is made before g steps
+        self.batch_ptrs = [(ctypes.c_void_p * (3 * _SORT_BATCH))(), (ctypes.c_void_p * (3 * _SORT_BATCH))()]
+        self.long_arr = (ctypes.c_int32 * _SORT_BATCH)()
+        # esr_triplet_plan's hints ("list b has a run longer than a chunk": only then is the long-run launch needed),
+        # written by the plan kernel straight into pinned host memory; a group is planned one group ahead of its steps,
+        # so the words have landed when they are issued (if they have not, the launch is simply made)
+        self.hints_host = torch.zeros((2, _SORT_BATCH), dtype=torch.int32).pin_memory()
+        self.hints_event = [torch.cuda.Event(), torch.cuda.Event()]
+        self.drawn_event = [torch.cuda.Event(), torch.cuda.Event()]
+        self.hints_known = [None, None]  # per set: list of long_runs values once the event has been seen complete
+        self.gen = 0
         self.fixed_s = (self.st.data_ptr(), self.rs.shadow.data_ptr(), self.rs.loc.data_ptr(), self.acc_s.data_ptr(),
                         self.Vs)
         self.fixed_p = (self.pt.data_ptr(), self.rp.shadow.data_ptr(), self.rp.loc.data_ptr(), self.acc_p.data_ptr(),
@@ -285,45 +308,71 @@ class _FusedTripletLoop:
         slot["done"].record(self.side)
         return (slot_index, sid, pid, nid)
 
-    def sort_batch(self, group):
-        """The id lists of the next len(group) batches (each (sid, pid, nid)) sorted by ONE library call on the main
-        stream (esr_segment_sort_ids_batched): handles for ``step``.  At the reference's batch sizes the two-launch
-        sort is 16 us of latency whether it sorts one list or eight."""
+    def sort_batch(self, group, which=0):
+        """The id lists of the next len(group) batches (each (sid, pid, nid)) sorted by ONE library call and planned by
+        one more (esr_segment_sort_ids_batched, esr_triplet_plan) on the main stream, into buffer set `which`: handles
+        for ``step``.  At the reference's batch sizes the two-launch sort is 16 us of latency whether it sorts one list
+        or eight, and nothing a plan holds depends on the tables."""
         B = group[0][0].numel()
         self._sized(B)
         nb, n = len(group), 3 * B
-        if self.batch_buf is None or self.batch_buf[0].shape != (self.sort_batch_max, n):
-            self.batch_buf = (torch.empty((self.sort_batch_max, n), dtype=torch.int32, device=self.dev),
-                              torch.empty((self.sort_batch_max, n), dtype=torch.int32, device=self.dev),
-                              ops._ws(ops._ws_bytes("esr_segment_sort_batched_workspace_bytes", n, self.sort_batch_max),
-                                      self.dev))
-        srt, prm, ws = self.batch_buf
+        pb = ops._ws_bytes("esr_triplet_plan_bytes", B)
+        if self.batch_buf[which] is None or self.batch_buf[which][0].shape != (self.sort_batch_max, n):
+            self.batch_buf[which] = (torch.empty((self.sort_batch_max, n), dtype=torch.int32, device=self.dev),
+                                     torch.empty((self.sort_batch_max, n), dtype=torch.int32, device=self.dev),
+                                     ops._ws(ops._ws_bytes("esr_segment_sort_batched_workspace_bytes", n,
+                                                           self.sort_batch_max), self.dev),
+                                     ops._aligned_bytes(self.sort_batch_max * pb, self.dev))
+        srt, prm, ws, plans = self.batch_buf[which]
         # (the library call itself, not ops.segment_sort_batched: its per-tensor checks and ctypes arrays were 67 us per
         # group -- the ids were validated by ``ids``, the arrays are kept)
-        ptrs = self.batch_ptrs
+        ptrs = self.batch_ptrs[which]
         i = 0
         for g in group:
             ptrs[i], ptrs[i + 1], ptrs[i + 2] = g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr()
             i += 3
+        stream, raw = self.main, self.main_raw
+        if _PLAN_ON_SIDE:
+            # sort + plan of group g + 1 beside the steps of group g: the side stream waits for what the main stream held
+            # when the group was drawn (the steps of group g - 1, whose buffers this set reuses; id copies), the main
+            # stream waits for the plan before the group's first step (step_group)
+            stream, raw = self.side, self.side.cuda_stream
+            self.drawn_event[which].record(self.main)
+            self.side.wait_event(self.drawn_event[which])
         self.check(self.lib.esr_segment_sort_ids_batched(ptrs, self.cnt, self.off, 3, nb, self.Vs + self.Vp,
                                                          srt.data_ptr(), prm.data_ptr(), ws.data_ptr(), ws.numel(),
-                                                         self.main_raw), "esr_segment_sort_ids_batched")
-        # everything ``step`` would look up per batch is resolved here, once per group: at the reference's own batch
-        # sizes (16 - 128 triplets: train_shop_the_look.py:60) the step is ~12 us of kernels and the loop is host-bound
-        sp, pp, row = srt.data_ptr(), prm.data_ptr(), 4 * n
-        return [(("ptr", sp + j * row, pp + j * row, g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), B),) + tuple(g)
-                for j, g in enumerate(group)]
+                                                         raw), "esr_segment_sort_ids_batched")
+        self.gen += 1
+        self.check(self.lib.esr_triplet_plan(ptrs, nb, B, self.Vs, srt.data_ptr(), prm.data_ptr(), plans.data_ptr(),
+                                             self.hints_host[which].data_ptr(), self.gen, raw),
+                   "esr_triplet_plan")
+        self.hints_event[which].record(stream)
+        self.hints_known[which] = None
+        # the whole group is stepped by ONE library call (esr_triplet_train_steps): at the reference's own batch sizes
+        # (16 - 128 triplets: train_shop_the_look.py:60) a step is ~12 us of kernels, at 8192 it is 21 us -- less than
+        # a 29-argument foreign call plus the Python around it
+        return _Group(nb, B, ptrs, srt.data_ptr(), prm.data_ptr(), plans.data_ptr(), which, self.gen, group)
+
+    def step_group(self, k, gr, regularization, batch_size):
+        """Steps k .. k + gr.nb - 1: the batches of a sorted and planned group, issued by one library call."""
+        if _PLAN_ON_SIDE:
+            self.main.wait_event(self.hints_event[gr.which])
+        known = self.hints_known[gr.which]
+        if known is None and self.hints_event[gr.which].query():
+            known = self.hints_known[gr.which] = self.hints_host[gr.which].tolist()
+        long_runs = None
+        if known is not None:  # (else: the hint has not reached the host; the library makes every long-run launch)
+            long_runs = self.long_arr
+            for j in range(gr.nb):
+                long_runs[j] = 1 if known[j] == gr.gen else 0
+        self.check(self.lib.esr_triplet_train_steps(*self.fixed_s, *self.fixed_p, self.D, gr.nb, gr.ptrs, gr.B,
+                                                    regularization, batch_size, self.lr, self.eps,
+                                                    self.next_stamp(self.rs, self.rp, count=gr.nb), gr.sorted_ptr,
+                                                    gr.perm_ptr, gr.plans_ptr, long_runs, self.losses_ptr + 4 * k,
+                                                    self.ws_ptr, self.ws_n, self.main_raw), "esr_triplet_train_steps")
 
     def step(self, k, handle, regularization, batch_size):
         slot_index, sid, pid, nid = handle
-        if type(slot_index) is tuple:  # sorted and resolved by sort_batch, earlier on this stream
-            _, sorted_ptr, perm_ptr, sp_, pp_, np_, B = slot_index
-            self.rs.dirty = self.rp.dirty = True
-            self.check(self.lib.esr_triplet_train_step(*self.fixed_s, *self.fixed_p, self.D, sp_, pp_, np_, B,
-                                                       regularization, batch_size, self.lr, self.eps, sorted_ptr,
-                                                       perm_ptr, self.losses_ptr + 4 * k, self.ws_ptr, self.ws_n,
-                                                       self.main_raw), "esr_triplet_train_step")
-            return
         sorted_ptr = perm_ptr = 0  # in-line sort inside the library call
         slot = None
         if slot_index is not None:
@@ -332,12 +381,12 @@ class _FusedTripletLoop:
             sorted_ptr, perm_ptr = slot["sorted"].data_ptr(), slot["perm"].data_ptr()
         else:
             self._sized(sid.numel())
-        self.rs.dirty = self.rp.dirty = True
         self.check(self.lib.esr_triplet_train_step(*self.fixed_s, *self.fixed_p, self.D, sid.data_ptr(), pid.data_ptr(),
                                                    nid.data_ptr(), self.B, float(regularization), float(batch_size),
-                                                   self.lr, self.eps, sorted_ptr, perm_ptr,
-                                                   self.losses.data_ptr() + 4 * k, self.ws.data_ptr(), self.ws.numel(),
-                                                   self.main.cuda_stream), "esr_triplet_train_step")
+                                                   self.lr, self.eps, self.next_stamp(self.rs, self.rp), sorted_ptr,
+                                                   perm_ptr, 0, -1, self.losses.data_ptr() + 4 * k,
+                                                   self.ws.data_ptr(), self.ws.numel(), self.main.cuda_stream),
+                   "esr_triplet_train_step")
         if slot is not None:
             slot["free"].record(self.main)
 
@@ -353,6 +402,8 @@ _LOOP_DEPTH = max(0, int(_os.environ.get("ESR_STL_PRESORT_DEPTH", "0")))
 # two-launch sort's 32 768 ids gain nothing (they are work, not latency) and stay in line.
 _SORT_BATCH = min(8, max(1, int(_os.environ.get("ESR_STL_SORT_BATCH", "8"))))
 _SORT_BATCH_MAX_IDS = 32768
+# ESR_STL_PLAN_STREAM=side: the sort + plan of a group on the second stream, beside the steps of the group before it
+_PLAN_ON_SIDE = _os.environ.get("ESR_STL_PLAN_STREAM", "main") == "side"
 
 
 def _inbatch_steps(state, it, first, num_steps, regularization, batch_size, scale, precision):
@@ -401,7 +452,7 @@ def _inbatch_steps(state, it, first, num_steps, regularization, batch_size, scal
     return state, torch.stack(losses)
 
 
-def train_steps(state, batches, num_steps, regularization, batch_size, scale=1.0, precision="auto"):
+def train_steps(state, batches, num_steps, regularization, batch_size, scale=1.0, precision="auto", consolidate=True):
     """`num_steps` iterations of the reference's training loop body (pinterest/train_shop_the_look.py:195-204:
     ``state, loss = train_step(state, scene, pos, neg, regularization, batch_size)`` for each batch of the iterator
     `batches`, yielding ``(scene, pos_product, neg_product)``).  Returns ``(state, losses)`` with the per-step losses
@@ -411,10 +462,14 @@ def train_steps(state, batches, num_steps, regularization, batch_size, scale=1.0
     driven through a per-loop context: one library call per step, and the id lists of up to eight coming batches are
     drawn from the iterator and sorted together by one batched call in front of their steps (``ESR_STL_SORT_BATCH``;
     ``ESR_STL_PRESORT_DEPTH=n`` instead sorts the ids of the next n batches on a second stream -- measured slower, see
-    _LOOP_DEPTH); otherwise it is ``train_step`` as is."""
+    _LOOP_DEPTH); otherwise it is ``train_step`` as is.  consolidate (default): the towers are plain tables again when the
+    loop returns (TrainState.consolidate)."""
     from ..train_state import quiet_gc
     with quiet_gc():
-        return _train_steps(state, batches, num_steps, regularization, batch_size, scale, precision)
+        state, losses = _train_steps(state, batches, num_steps, regularization, batch_size, scale, precision)
+    if consolidate:  # rows the one-pass steps left in the towers' second buffers go back: aliases of the tables are current
+        state.consolidate()
+    return state, losses
 
 
 def _train_steps(state, batches, num_steps, regularization, batch_size, scale, precision):
@@ -439,29 +494,52 @@ def _train_steps(state, batches, num_steps, regularization, batch_size, scale, p
     if _LOOP_DEPTH == 0:
         import time
         t_host = time.perf_counter()
-        k, dry = 0, False
+        state_ = {"drawn": 0, "dry": False, "which": 0}
+
+        def draw_group(first_alone):
+            """Handles of the next group of steps (None when nothing is left to draw): the group's id lists sorted and
+            planned by one call pair, or single batches that sort and plan inside their own step."""
+            left = num_steps - state_["drawn"]
+            if left <= 0 or state_["dry"]:
+                return None
+            try:
+                first = ctx.ids(*next(it))
+            except StopIteration:
+                state_["dry"] = True
+                return None
+            state_["drawn"] += 1
+            # (the very first step goes out alone with its sort in line, see _inbatch_steps)
+            if first_alone or _SORT_BATCH <= 1 or 3 * first[0].numel() > _SORT_BATCH_MAX_IDS or left <= 1:
+                return [(None,) + first]
+            group = [first]
+            for _ in range(min(_SORT_BATCH, left) - 1):
+                try:
+                    group.append(ctx.ids(*next(it)))
+                except StopIteration:
+                    state_["dry"] = True
+                    break
+                state_["drawn"] += 1
+            if any(g[0].numel() != first[0].numel() for g in group) or len(group) == 1:  # ragged: own sorts
+                return [(None,) + g for g in group]
+            state_["which"] ^= 1
+            return ctx.sort_batch(group, state_["which"])
+
+        k = 0
+        handles = draw_group(True)
         while k < num_steps:
-            if dry:  # the iterator ended early: as the reference's loop, after the steps it did feed
+            if handles is None:  # the iterator ended early: as the reference's loop, after the steps it did feed
                 raise StopIteration("train_steps: the batch iterator ended after %d of %d steps" % (k, num_steps))
-            first = ctx.ids(*next(it))
-            # (k == 0: the first step goes out alone with its sort in line, see _inbatch_steps)
-            if _SORT_BATCH > 1 and 3 * first[0].numel() <= _SORT_BATCH_MAX_IDS and num_steps - k > 1 and k > 0:
-                group = [first]
-                for _ in range(min(_SORT_BATCH, num_steps - k) - 1):
-                    try:
-                        group.append(ctx.ids(*next(it)))
-                    except StopIteration:
-                        dry = True
-                        break
-                if any(g[0].numel() != first[0].numel() for g in group) or len(group) == 1:  # ragged: own sorts
-                    handles = [(None,) + g for g in group]
-                else:
-                    handles = ctx.sort_batch(group)
+            # the NEXT group is drawn, sorted and planned before this one is stepped: its long-run hints reach the host
+            # a whole group ahead of the steps that ask for them
+            following = draw_group(False)
+            if type(handles) is _Group:
+                ctx.step_group(k, handles, regularization, batch_size)
+                k += handles.nb
             else:
-                handles = [(None,) + first]
-            for h in handles:
-                ctx.step(k, h, regularization, batch_size)
-                k += 1
+                for h in handles:
+                    ctx.step(k, h, regularization, batch_size)
+                    k += 1
+            handles = following
         if _os.environ.get("ESR_TRACE_HOST") == "1":  # is the loop issuing steps faster than the GPU retires them?
             import logging
             logging.warning("train_steps: host issued %d steps in %.1f us each (no sync yet)", num_steps,

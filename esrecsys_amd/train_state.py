@@ -343,56 +343,129 @@ def _sgd_plain(learning_rate):
 
 
 class RowVersions:
-    """The second buffer of a double-buffered table and the per-row bytes that say where each row's current value
-    lives (0 = the parameter tensor itself, 1 = `shadow`).  Fused train steps (ops.glove_train_step) read rows where
-    the bytes point, write updated rows into the other buffer and flip the bytes, so they never need a gradient or a
-    snapshot in memory.  Lives in the optimizer state (``opt_state['_versions'][path]``); ``TrainState.params``
-    consolidates before handing the tables to anybody else."""
+    """The second buffer of a double-buffered table and the per-row STAMPED bytes that say where each row's current
+    value lives (bit 0: 0 = the parameter tensor itself, 1 = `shadow`) and which step last moved it (bits 1..7, see
+    esr_versioned.h).  Fused train steps (ops.glove_train_step, ops.triplet_train_step) read rows where they lived
+    when the step began, write updated rows into the other buffer and stamp the bytes, so they never need a gradient
+    or a snapshot in memory.  Lives on the TrainState (``state.versions[path]``); ``TrainState.params`` consolidates
+    before handing the tables to anybody else.  `stamp` = the last stamp a step used on this table."""
 
     def __init__(self, table):
         self.shadow = torch.empty_like(table)
         self.loc = torch.zeros(table.shape[0], dtype=torch.uint8, device=table.device)
         self.dirty = False
+        self.stamp = 0
 
     def consolidate(self, table):
         if self.dirty:
-            ops.rows_consolidate(table, self.shadow, self.loc)
+            ops.rows_consolidate(table, self.shadow, self.loc)  # (zeroes every byte: the stamps start over)
             self.dirty = False
+            self.stamp = 0
 
 
-def row_versions(state, path):
-    """The RowVersions of the table at `path` of state's parameter tree (created on first use: a second [V, D] buffer)."""
-    versions = state.opt_state.setdefault("_versions", {})
+STAMP_MAX = 127
+
+
+def next_stamp(*versions, count=1):
+    """The stamp of the next fused step on the table(s) of `versions` (several RowVersions = the tables one step
+    updates together: they share the stamp).  Stamps run 1 .. 127; when the counter would pass 127 -- or the tables'
+    counters disagree -- the bytes' stamps are cleared first (ops.rows_restamp: one pass over V bytes) and counting
+    starts over.  count = n reserves n consecutive stamps (a loop that issues n steps) and returns the first."""
+    first = versions[0].stamp
+    if first + count > STAMP_MAX or any(v.stamp != first for v in versions):
+        for v in versions:
+            ops.rows_restamp(v.loc)
+            v.stamp = 0
+        first = 0
+    if count > STAMP_MAX:
+        raise ValueError("at most %d stamps can be reserved at once" % STAMP_MAX)
+    for v in versions:
+        v.stamp = first + count
+        v.dirty = True
+    return first + 1
+
+
+class ShadowMemoryError(RuntimeError):
+    """There is not enough free HBM for the second buffer of a double-buffered table."""
+
+
+def shadow_fits(table, reserve=1 << 30):
+    """True when a second [V, D] buffer for `table` (+ one byte per row) fits in the device's free memory with `reserve`
+    bytes to spare.  The one-pass steps DOUBLE the memory of every table they update: on a 288 GB MI355X with fp32 rows and
+    fp32 accumulators (3 x V x D x 4 bytes per table with its shadow) that is V <= ~180 M rows of D = 128 per GPU for one
+    table, half of it per tower for two -- BASELINE config 4's 12.5 M-row shares fit, a table filling the card does not
+    and takes the gradient-row path instead."""
+    if not table.is_cuda:
+        return False
+    need = table.numel() * table.element_size() + table.shape[0]
+    free, _ = torch.cuda.mem_get_info(table.device)
+    free += torch.cuda.memory_reserved(table.device) - torch.cuda.memory_allocated(table.device)  # torch's own cache
+    return need + reserve <= free
+
+
+def row_versions(state, path, create=True):
+    """The RowVersions of the table at `path` of state's parameter tree (created on first use: a second [V, D] buffer;
+    None when it does not exist and create is False).  They live on the TrainState (``state.versions``) and follow it
+    through ``replace``."""
     path = tuple(path)
-    if path not in versions:
-        versions[path] = RowVersions(tree_get(state.raw_params, path))
-    return versions[path]
+    rv = state.versions.get(path)
+    if rv is None and create:
+        table = tree_get(state.raw_params, path)
+        if not shadow_fits(table):
+            raise ShadowMemoryError("no room for the second buffer of the table at %s (%d x %d): the one-pass step needs "
+                                    "it; use the gradient-row path (ESR_GLOVE_FUSED=0 / ESR_STL_FUSED=0)"
+                                    % ("/".join(path), table.shape[0], table.shape[1]))
+        rv = state.versions[path] = RowVersions(table)
+    return rv
+
+
+def can_double_buffer(state, paths):
+    """True when every table at `paths` already has its second buffer or there is room to give it one."""
+    for path in paths:
+        if tuple(path) not in state.versions and not shadow_fits(tree_get(state.raw_params, path)):
+            return False
+    return True
 
 
 class TrainState:
     """flax.training.train_state.TrainState look-alike: step, apply_fn, params, tx, opt_state.
 
-    ``params`` is always the plain parameter tree: if a fused step left rows of a double-buffered table in its second
-    buffer (RowVersions), reading ``params`` first copies them back (one launch over the touched rows).  The hot loop
-    uses ``raw_params`` and never pays for that."""
+    Tables are updated IN PLACE by the optimizer; the states returned by ``apply_gradients`` / ``train_step`` share them.
+    The one-pass train steps (GloVe ``train_step`` / ``train_epoch``, Shop-The-Look triplet ``train_step`` /
+    ``train_steps`` under ``optim.sparse_adagrad``) keep every table they update DOUBLE-BUFFERED: a second [V, D] buffer
+    and one byte per row (``versions[path]``, a RowVersions) say where each row's current value lives.  Contract:
 
-    def __init__(self, step, apply_fn, params, tx, opt_state):
+    * ``state.params`` is always the plain parameter tree: reading it first copies displaced rows back (one launch over
+      the touched rows); ``state.consolidate()`` does the same explicitly.  The loop helpers consolidate when they
+      return, so a tensor taken from ``params`` before a loop is current again after it.
+    * ``state.raw_params`` is the tree WITHOUT that copy: between one-pass steps a table tensor taken from it (or an alias
+      kept from before the steps) may hold stale rows -- only the hot loop uses it.
+    * ``versions`` follows the state through ``replace``; replacing ``params`` by OTHER tensors consolidates the old
+      ones first and starts the new ones plain."""
+
+    def __init__(self, step, apply_fn, params, tx, opt_state, versions=None):
         self.step = step
         self.apply_fn = apply_fn
         self._params = params
         self.tx = tx
         self.opt_state = opt_state
+        self.versions = versions if versions is not None else {}
 
     @property
     def raw_params(self):
         return self._params
 
+    def consolidate(self):
+        """Copy every row that lives in a second buffer back into its table: afterwards the parameter tensors are plain
+        [V, D] tables whoever holds them.  No-op when no one-pass step has run since the last call."""
+        for path, rv in self.versions.items():
+            rv.consolidate(tree_get(self._params, path))
+        return self
+
     @property
     def params(self):
-        versions = self.opt_state.get("_versions") if isinstance(self.opt_state, dict) else None
-        if versions:
-            for path, rv in versions.items():
-                rv.consolidate(tree_get(self._params, path))
+        if self.versions:
+            self.consolidate()
         return self._params
 
     @classmethod
@@ -400,7 +473,16 @@ class TrainState:
         return cls(step=0, apply_fn=apply_fn, params=params, tx=tx, opt_state=tx.init(params))
 
     def replace(self, **kw):
-        d = dict(step=self.step, apply_fn=self.apply_fn, params=self._params, tx=self.tx, opt_state=self.opt_state)
+        versions = self.versions
+        if "params" in kw and kw["params"] is not self._params:
+            same = all(a is b for (_, a), (_, b) in zip(tree_leaves_with_path(self._params),
+                                                        tree_leaves_with_path(kw["params"]))) \
+                if _same_tree(self._params, kw["params"]) else False
+            if not same:  # other tensors: the old ones become plain, the new ones start without second buffers
+                self.consolidate()
+                versions = {}
+        d = dict(step=self.step, apply_fn=self.apply_fn, params=self._params, tx=self.tx, opt_state=self.opt_state,
+                 versions=versions)
         d.update(kw)
         return TrainState(**d)
 
@@ -409,3 +491,11 @@ class TrainState:
         place in HBM; the returned state shares them."""
         new_opt = self.tx.apply(self.params, grads, self.opt_state, self.step + 1)
         return self.replace(step=self.step + 1, opt_state=new_opt)
+
+
+def _same_tree(a, b):
+    if isinstance(a, dict) != isinstance(b, dict):
+        return False
+    if isinstance(a, dict):
+        return list(a.keys()) == list(b.keys()) and all(_same_tree(a[k], b[k]) for k in a)
+    return True

@@ -90,15 +90,24 @@ def fused_step_available(state):
         emb, bias = p["_token_embedding"]["embedding"], p["_bias"]["embedding"]
     except (KeyError, TypeError):
         return False
-    return emb.is_cuda and emb.dtype == torch.float32 and bias.dtype == torch.float32 and emb.shape[0] < (1 << 30)
+    if not (emb.is_cuda and emb.dtype == torch.float32 and bias.dtype == torch.float32 and emb.shape[0] < (1 << 30)):
+        return False
+    # the one-pass step keeps the embedding table double-buffered: without room for the second buffer (a table that
+    # fills the card) the gradient-row path runs instead
+    from ..train_state import can_double_buffer
+    return can_double_buffer(state, [("_token_embedding", "embedding")])
 
 
 class PresortedInputs:
     """The occurrence ids of a batch, already on the device and sorted on the side stream (``presort_inputs``): the sort
-    needs the ids only, so ``train_epoch`` runs it for batch k + 1 while batch k's update kernel streams the rows."""
+    needs the ids only, so ``train_epoch`` runs it for batch k + 1 while batch k's update kernel streams the rows.  With
+    the batch's counts at hand the step's plan record is made there too (``plan``; ``hint`` = (pinned int32 [1], gen):
+    the word equals gen when a token has a run longer than a chunk -- only then does the step need its long-run launch)."""
 
-    def __init__(self, inputs, sorted_ids, perm, event):
+    def __init__(self, inputs, sorted_ids, perm, event, plan=None, hint=None, target=None):
         self.inputs, self.sorted_ids, self.perm, self.event = inputs, sorted_ids, perm, event
+        self.plan, self.hint, self.target = plan, hint, target
+        self._done = event
 
     def take(self):
         """(sorted_ids, perm) for the current stream (waits for the side stream's event, once)."""
@@ -106,6 +115,12 @@ class PresortedInputs:
             torch.cuda.current_stream(self.inputs.device).wait_event(self.event)
             self.event = None
         return self.sorted_ids, self.perm
+
+    def long_runs(self):
+        """0 / 1 from the plan's hint once it has reached the host, -1 while it has not (or without a plan)."""
+        if self.hint is None or self._done is None or not self._done.query():
+            return -1
+        return 1 if int(self.hint[0][0]) == self.hint[1] else 0
 
 
 # ESR_GLOVE_PRESORT=0 sorts in line instead of one batch ahead on the side stream.  ESR_GLOVE_STEP_BLOCKS_PER_CU caps the
@@ -116,24 +131,55 @@ _SORT_BATCH = min(8, max(1, int(os.environ.get("ESR_GLOVE_SORT_BATCH", "8"))))  
 _STEP_BLOCKS_PER_CU = int(os.environ.get("ESR_GLOVE_STEP_BLOCKS_PER_CU", "0"))
 
 
-def presort_inputs(state, inputs):
-    """Move `inputs` to the device and sort its occurrence ids on the side stream.  Returns a PresortedInputs to pass as
-    ``train_step(..., inputs=that)``."""
+_hint_ring = {}  # device -> [pinned int32 [R], next slot, next gen]
+_RESOLVE_MIN_IDS = 32768  # esr_glove.hip kResolveMinIds: longer lists resolve their records per step, plans are unused
+
+
+def _hint_slot(dev):
+    """One word of a small ring of PINNED host memory for a long-run hint: (view [1], gen).  The kernels write the word
+    themselves (pinned memory is mapped into the device's address space): no copy launch."""
+    R = 16
+    key = (dev.type, dev.index)
+    if key not in _hint_ring:
+        _hint_ring[key] = [torch.zeros(R, dtype=torch.int32).pin_memory(), 0, 1]
+    ring = _hint_ring[key]
+    i, gen = ring[1], ring[2]
+    ring[1], ring[2] = (i + 1) % R, gen + 1 if gen < 2 ** 31 - 2 else 1
+    return ring[0][i:i + 1], gen
+
+
+def presort_inputs(state, inputs, target=None):
+    """Move `inputs` to the device and sort its occurrence ids on the side stream; with `target` (the batch's counts) the
+    step's plan record is made there as well (ops.glove_plan: it needs ids and counts only).  Returns a PresortedInputs
+    to pass as ``train_step(..., inputs=that)``."""
     from ..train_state import _side_stream
     emb = state.raw_params["_token_embedding"]["embedding"]
     V = emb.shape[0]
     ids = ops.as_ids(inputs, emb.device, check_range=V)
+    tgt = ops.as_f32(target, emb.device) if target is not None else None
     main = torch.cuda.current_stream(emb.device)
     side = _side_stream(emb.device)
     side.wait_stream(main)  # the ids may have been produced (copied) on the main stream
+    plan = hint = None
     with torch.cuda.stream(side):
         sorted_ids, perm = ops.segment_sort(ids.reshape(-1), V)
+        if tgt is not None and ids.dim() == 2 and ids.shape[0] == 2 and tgt.numel() == ids.shape[1]:
+            # (longer lists: the step resolves its own records in front of its update kernel and makes every launch --
+            # its long-run launch also reduces the loss partials -- so neither a plan nor the hint is of use)
+            if ids.numel() <= _RESOLVE_MIN_IDS:
+                hh, gen = _hint_slot(emb.device)
+                plan = ops.glove_plan([ids], [tgt], sorted_ids, perm, hints=hh, gen=gen)
+                hint = (hh, gen)
         event = torch.cuda.Event()
         event.record(side)
     ids.record_stream(side)
     sorted_ids.record_stream(main)
     perm.record_stream(main)
-    return PresortedInputs(ids, sorted_ids, perm, event)
+    if plan is not None:
+        plan.record_stream(main)
+    if tgt is not None:
+        tgt.record_stream(side)
+    return PresortedInputs(ids, sorted_ids, perm, event, plan, hint, tgt)
 
 
 def train_step(state, inputs, target):
@@ -142,7 +188,7 @@ def train_step(state, inputs, target):
     No gradient is materialised -- the update kernel re-reads each occurrence's partner row and forms its gradient on
     chip -- which the double-buffered embedding table makes safe (train_state.RowVersions; ``state.params``
     consolidates on access).  Tables, accumulators and loss agree with the two-call path to an f32 rounding."""
-    from ..train_state import row_versions
+    from ..train_state import next_stamp, row_versions
     presorted = None
     if isinstance(inputs, PresortedInputs):
         presorted, inputs = inputs, inputs.inputs
@@ -157,11 +203,12 @@ def train_step(state, inputs, target):
     target = ops.as_f32(target, emb.device)
     rv = row_versions(state, ("_token_embedding", "embedding"))
     acc = state.opt_state["sum_of_squares"]
-    rv.dirty = True
     loss = ops.glove_train_step(emb, rv.shadow, rv.loc, acc["_token_embedding"]["embedding"], bias,
                                 acc["_bias"]["embedding"], inputs, target, mode, state.tx.lr, state.tx.eps,
                                 presorted=presorted.take() if presorted is not None else None,
-                                blocks_per_cu=_STEP_BLOCKS_PER_CU if presorted is not None else 0)
+                                blocks_per_cu=_STEP_BLOCKS_PER_CU if presorted is not None else 0,
+                                stamp=next_stamp(rv), plan=presorted.plan if presorted is not None else None,
+                                long_runs=presorted.long_runs() if presorted is not None else -1)
     return state.replace(step=state.step + 1), loss.reshape(())
 
 
@@ -170,17 +217,20 @@ _PRESORT_MIN_IDS = 4096
 
 def _ids_count(inputs):
     x = inputs.inputs if isinstance(inputs, PresortedInputs) else inputs
+    if type(x) is torch.Tensor:
+        return x.numel()
     return int(np.prod(x.shape)) if hasattr(x, "shape") else 2 * len(x[0])
 
 
-class _Ready:
-    """One batch of a group whose id lists were sorted together (``_FusedEpoch.sort_batch``): tensors kept alive and
-    the raw pointers of everything the library call takes."""
-    __slots__ = ("inputs", "target", "inputs_ptr", "target_ptr", "sorted_ptr", "perm_ptr", "B")
+class _Group:
+    """A group of batches whose id lists were sorted and planned together (``_FusedEpoch.sort_batch``): the raw pointers
+    of everything esr_glove_train_steps takes, and the tensors, kept alive."""
+    __slots__ = ("nb", "B", "in_ptrs", "tgt_ptrs", "sorted_ptr", "perm_ptr", "plans_ptr", "which", "gen", "keep")
 
-    def __init__(self, inputs, target, inputs_ptr, target_ptr, sorted_ptr, perm_ptr, B):
-        self.inputs, self.target, self.inputs_ptr, self.target_ptr = inputs, target, inputs_ptr, target_ptr
-        self.sorted_ptr, self.perm_ptr, self.B = sorted_ptr, perm_ptr, B
+    def __init__(self, nb, B, in_ptrs, tgt_ptrs, sorted_ptr, perm_ptr, plans_ptr, which, gen, keep):
+        self.nb, self.B, self.in_ptrs, self.tgt_ptrs = nb, B, in_ptrs, tgt_ptrs
+        self.sorted_ptr, self.perm_ptr, self.plans_ptr = sorted_ptr, perm_ptr, plans_ptr
+        self.which, self.gen, self.keep = which, gen, keep
 
 
 class _FusedEpoch:
@@ -191,7 +241,8 @@ class _FusedEpoch:
 
     def __init__(self, state, steps):
         from .. import _lib
-        from ..train_state import row_versions
+        from ..train_state import next_stamp, row_versions
+        self.next_stamp = next_stamp
         p = state.raw_params
         self.emb, self.bias = p["_token_embedding"]["embedding"], p["_bias"]["embedding"]
         acc = state.opt_state["sum_of_squares"]
@@ -207,64 +258,100 @@ class _FusedEpoch:
         self.losses = torch.empty(max(steps, 1), dtype=torch.float32, device=self.dev)
         self.losses_ptr = self.losses.data_ptr()
         self.ws, self.ws_B = None, -1
-        self.sort_buf = None
+        self.sort_buf = [None, None]  # two sets: a group is sorted and planned while the one before it is stepped
+        self.which = 0
         import ctypes
-        self.sort_ptrs = (ctypes.c_void_p * _SORT_BATCH)()
+        self.sort_ptrs = [(ctypes.c_void_p * _SORT_BATCH)(), (ctypes.c_void_p * _SORT_BATCH)()]
+        self.tgt_ptrs = [(ctypes.c_void_p * _SORT_BATCH)(), (ctypes.c_void_p * _SORT_BATCH)()]
+        self.long_arr = (ctypes.c_int32 * _SORT_BATCH)()
+        # esr_glove_plan's long-run hints, copied to pinned memory behind the plan launch (see _FusedTripletLoop)
+        self.hints_host = torch.zeros((2, _SORT_BATCH), dtype=torch.int32).pin_memory()  # written by the plan kernel
+        self.hints_event = [torch.cuda.Event(), torch.cuda.Event()]
+        self.hints_known = [None, None]
+        self.gen = 0
         self.sort_cnt, self.sort_off = (ctypes.c_int64 * 1)(0), (ctypes.c_int64 * 1)(0)
         self.check_ids = os.environ.get("ESR_CHECK_IDS") == "1"
         self.fixed = (self.emb.data_ptr(), self.rv.shadow.data_ptr(), self.rv.loc.data_ptr(), self.acc_e.data_ptr(),
                       self.bias.data_ptr(), self.acc_b.data_ptr(), self.V, self.D)
 
     def sort_batch(self, group):
-        """[(inputs, target), ...] of the coming batches -> the same list with their id lists sorted by one batched call
-        on the current stream (batches of unequal size or longer than the two-launch sort takes: as is).  The entries
-        are _Ready records: everything ``step`` would look up per batch (pointers, B, validated tensors) is resolved
-        here, once per group -- at 2048 pairs the step is 27 us of kernels and the per-step Python was 28."""
+        """[(inputs, target), ...] of the coming batches -> a _Group: their id lists sorted by one batched call and their
+        plan records made by one more on the current stream, everything ``step_group`` hands the library resolved here
+        (batches of unequal size or longer than the two-launch sort takes: the list as it is, every step on its own)."""
         ids = [ops.as_ids(inp, self.dev, check_range=self.V) for inp, _ in group]
         n = ids[0].numel()
         if n > 32768 or any(t.numel() != n for t in ids) or any(t.dim() != 2 or t.shape[0] != 2 for t in ids):
-            return [(i, t) for i, (_, t) in zip(ids, group)]
+            return [(i, t) for i, (_, t) in zip(ids, group)]  # as they are: every step sorts and plans its own
         if self.check_ids:
             for i in ids:
                 ops.check_device_ids(i, self.V)
         nb = len(ids)
-        if self.sort_buf is None or self.sort_buf[0].shape[1] != n or self.sort_buf[0].shape[0] < nb:
-            self.sort_buf = (torch.empty((_SORT_BATCH, n), dtype=torch.int32, device=self.dev),
-                             torch.empty((_SORT_BATCH, n), dtype=torch.int32, device=self.dev),
-                             ops._ws(ops._ws_bytes("esr_segment_sort_batched_workspace_bytes", n, _SORT_BATCH), self.dev))
-        srt, prm, ws = self.sort_buf
-        # (the library call itself: ops.segment_sort_batched re-validates every tensor and rebuilds its ctypes arrays)
-        for b, i in enumerate(ids):
-            self.sort_ptrs[b] = i.data_ptr()
-        self.sort_cnt[0] = n
-        self.check(self.lib.esr_segment_sort_ids_batched(self.sort_ptrs, self.sort_cnt, self.sort_off, 1, nb, self.V,
-                                                         srt.data_ptr(), prm.data_ptr(), ws.data_ptr(), ws.numel(),
-                                                         ops._stream()), "esr_segment_sort_ids_batched")
-        row = 4 * n
-        sp, pp = srt.data_ptr(), prm.data_ptr()
-        out = []
-        for b, (i, (_, t)) in enumerate(zip(ids, group)):
+        self.which ^= 1
+        which = self.which
+        B = n // 2
+        pbytes = ops._ws_bytes("esr_glove_plan_bytes", B)
+        if self.sort_buf[which] is None or self.sort_buf[which][0].shape[1] != n:
+            self.sort_buf[which] = (torch.empty((_SORT_BATCH, n), dtype=torch.int32, device=self.dev),
+                                    torch.empty((_SORT_BATCH, n), dtype=torch.int32, device=self.dev),
+                                    ops._ws(ops._ws_bytes("esr_segment_sort_batched_workspace_bytes", n, _SORT_BATCH),
+                                            self.dev),
+                                    ops._aligned_bytes(_SORT_BATCH * pbytes, self.dev))
+        srt, prm, ws, plans = self.sort_buf[which]
+        tgts = []
+        for _, t in group:
             if not (type(t) is torch.Tensor and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
                 t = ops.as_f32(t, self.dev)
             if t.numel() * 2 != n:
                 raise ValueError("inputs must be [2, B] and target [B]")
-            out.append((_Ready(i, t, i.data_ptr(), t.data_ptr(), sp + b * row, pp + b * row, n // 2), t))
-        return out
+            tgts.append(t)
+        # (the library calls themselves: ops.segment_sort_batched re-validates every tensor and rebuilds its ctypes arrays)
+        sort_ptrs, tgt_ptrs = self.sort_ptrs[which], self.tgt_ptrs[which]
+        for b, (i, t) in enumerate(zip(ids, tgts)):
+            sort_ptrs[b] = i.data_ptr()
+            tgt_ptrs[b] = t.data_ptr()
+        self.sort_cnt[0] = n
+        st = ops._stream()
+        self.check(self.lib.esr_segment_sort_ids_batched(sort_ptrs, self.sort_cnt, self.sort_off, 1, nb, self.V,
+                                                         srt.data_ptr(), prm.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                         st), "esr_segment_sort_ids_batched")
+        self.gen += 1
+        self.check(self.lib.esr_glove_plan(sort_ptrs, tgt_ptrs, nb, B, srt.data_ptr(), prm.data_ptr(),
+                                           plans.data_ptr(), self.hints_host[which].data_ptr(), self.gen, st),
+                   "esr_glove_plan")
+        self.hints_event[which].record()
+        self.hints_known[which] = None
+        # the whole group is stepped by ONE library call (esr_glove_train_steps): at 2048 pairs a step is ~20 us of
+        # kernels, less than a 25-argument foreign call plus the Python around it
+        return _Group(nb, B, self.sort_ptrs[which], self.tgt_ptrs[which], srt.data_ptr(), prm.data_ptr(),
+                      plans.data_ptr(), which, self.gen, (ids, tgts))
+
+    def step_group(self, k, gr):
+        """Steps k .. k + gr.nb - 1: the batches of a sorted and planned group, issued by one library call."""
+        known = self.hints_known[gr.which]
+        if known is None and self.hints_event[gr.which].query():
+            known = self.hints_known[gr.which] = self.hints_host[gr.which].tolist()
+        long_runs = None
+        if known is not None:  # (else: the hint has not reached the host; the library makes every long-run launch)
+            long_runs = self.long_arr
+            for j in range(gr.nb):
+                long_runs[j] = 1 if known[j] == gr.gen else 0
+        if gr.B != self.ws_B:
+            self.ws = ops._ws(ops._ws_bytes("esr_glove_step_workspace_bytes", gr.B, self.D), self.dev)
+            self.ws_B = gr.B
+        self.check(self.lib.esr_glove_train_steps(*self.fixed, gr.nb, gr.in_ptrs, gr.tgt_ptrs, gr.B, self.mode, self.lr,
+                                                  self.eps, self.next_stamp(self.rv, count=gr.nb), gr.sorted_ptr,
+                                                  gr.perm_ptr, gr.plans_ptr, long_runs, self.losses_ptr + 4 * k,
+                                                  self.ws.data_ptr(), self.ws.numel(), ops._stream()),
+                   "esr_glove_train_steps")
 
     def step(self, k, inputs, target):
-        if type(inputs) is _Ready:  # resolved by sort_batch: one library call, no per-batch lookups
-            r = inputs
-            if r.B != self.ws_B:
-                self.ws = ops._ws(ops._ws_bytes("esr_glove_step_workspace_bytes", r.B, self.D), self.dev)
-                self.ws_B = r.B
-            self.rv.dirty = True
-            self.check(self.lib.esr_glove_train_step(*self.fixed, r.inputs_ptr, r.target_ptr, r.B, self.mode, self.lr,
-                                                     self.eps, r.sorted_ptr, r.perm_ptr, 0,
-                                                     self.losses_ptr + 4 * k, self.ws.data_ptr(), self.ws.numel(),
-                                                     ops._stream()), "esr_glove_train_step")
-            return
-        presorted = None
+        presorted, plan_ptr, long_runs = None, 0, -1
         if isinstance(inputs, PresortedInputs):
+            long_runs = inputs.long_runs()
+            if inputs.plan is not None:
+                plan_ptr = inputs.plan.data_ptr()
+            if inputs.target is not None:
+                target = inputs.target
             presorted, inputs = inputs.take(), inputs.inputs
         if not (type(inputs) is torch.Tensor and inputs.is_cuda and inputs.dtype == torch.int32 and
                 inputs.is_contiguous()):
@@ -281,21 +368,26 @@ class _FusedEpoch:
             self.ws = ops._ws(ops._ws_bytes("esr_glove_step_workspace_bytes", B, self.D), self.dev)
             self.ws_B = B
         sid, perm = (presorted[0].data_ptr(), presorted[1].data_ptr()) if presorted is not None else (0, 0)
-        self.rv.dirty = True
         self.check(self.lib.esr_glove_train_step(*self.fixed, inputs.data_ptr(), target.data_ptr(), B, self.mode,
-                                                 self.lr, self.eps, sid, perm, 0, self.losses.data_ptr() + 4 * k,
-                                                 self.ws.data_ptr(), self.ws.numel(), ops._stream()),
+                                                 self.lr, self.eps, self.next_stamp(self.rv), sid, perm, plan_ptr,
+                                                 long_runs, 0, self.losses.data_ptr() + 4 * k, self.ws.data_ptr(),
+                                                 self.ws.numel(), ops._stream()),
                    "esr_glove_train_step")
 
 
-def train_epoch(state, steps_per_epoch, train_it):
+def train_epoch(state, steps_per_epoch, train_it, consolidate=True):
     """Trains for an epoch (wikipedia/train_cooccurence.py:103-112).  Losses stay on the device until the
     epoch mean is taken, so the loop never synchronises.  With the build's sparse Adagrad every step is the
     one-pass step (``train_step``'s kernels, driven through a per-epoch context that keeps the per-step Python to one
-    library call); with the reference's dense Adam it is apply_model + update_model as there."""
+    library call per group of steps); with the reference's dense Adam it is apply_model + update_model as there.
+    consolidate (default): rows the one-pass steps left in the embedding table's second buffer are copied back before
+    the epoch returns, so every holder of the table tensor sees current rows (one launch over the displaced rows)."""
     from ..train_state import quiet_gc
     with quiet_gc():  # (a full cyclic collection inside the loop is a 40 ms hole in the launch stream)
-        return _train_epoch(state, steps_per_epoch, train_it)
+        state, loss = _train_epoch(state, steps_per_epoch, train_it)
+    if consolidate:
+        state.consolidate()
+    return state, loss
 
 
 def _train_epoch(state, steps_per_epoch, train_it):
@@ -311,18 +403,22 @@ def _train_epoch(state, steps_per_epoch, train_it):
         # (esr_segment_sort_ids_batched) in front of their steps.
         from collections import deque
         import time
-        queue, fetched = deque(), 0
+        queue, fetched, queued = deque(), 0, 0  # queue items: (inputs, targets) of one step, or a _Group; queued = steps
         t_host = time.perf_counter()
-        grouped = False  # short lists: refill only when the queue has run dry, a whole group at a time
-        for k in range(steps_per_epoch):
-            while fetched < steps_per_epoch and (not queue if grouped else len(queue) < _PRESORT_DEPTH + 1):
+        grouped = False  # short lists: a whole group is drawn, sorted and planned at a time
+        k = 0
+        while k < steps_per_epoch:
+            # (grouped: the next group is sorted and planned while the one before it is still queued, so its long-run
+            # hints reach the host a whole group ahead of the steps that ask for them)
+            while fetched < steps_per_epoch and (queued <= (_SORT_BATCH if k > 1 else 0) if grouped
+                                                 else queued < _PRESORT_DEPTH + 1):
                 inputs, targets = next(train_it)
                 fetched += 1
                 if _PRESORT and _ids_count(inputs) > _PRESORT_MIN_IDS:
                     grouped = False
-                    queue.append((presort_inputs(state, inputs), targets))
-                elif _SORT_BATCH > 1 and not queue and k > 0:  # (the first step goes out alone: the GPU starts at once)
-                    grouped = True
+                    queue.append((presort_inputs(state, inputs, targets), targets))
+                    queued += 1
+                elif _SORT_BATCH > 1 and grouped and k > 0:  # (the first step goes out alone: the GPU starts at once)
                     group = [(inputs, targets)]
                     while len(group) < _SORT_BATCH and fetched < steps_per_epoch:
                         try:
@@ -330,12 +426,25 @@ def _train_epoch(state, steps_per_epoch, train_it):
                         except StopIteration:  # ended early: the steps it did feed run, then the loop's own next() raises
                             break
                         fetched += 1
-                    queue.extend(ctx.sort_batch(group) if len(group) > 1 else group)
+                    made = ctx.sort_batch(group) if len(group) > 1 else group
+                    if type(made) is _Group:
+                        queue.append(made)
+                    else:
+                        queue.extend(made)
+                    queued += len(group)
                 else:
-                    grouped = _SORT_BATCH > 1  # short lists: refill when the queue has run dry (then a group at a time)
+                    grouped = _SORT_BATCH > 1  # short lists: refill when the queue has run low (then a group at a time)
                     queue.append((inputs, targets))
-            inputs, targets = queue.popleft()
-            ctx.step(k, inputs, targets)
+                    queued += 1
+            item = queue.popleft()
+            if type(item) is _Group:
+                ctx.step_group(k, item)
+                k += item.nb
+                queued -= item.nb
+            else:
+                ctx.step(k, item[0], item[1])
+                k += 1
+                queued -= 1
         if os.environ.get("ESR_TRACE_HOST") == "1":  # is the loop issuing steps faster than the GPU retires them?
             logging.warning("train_epoch: host issued %d steps in %.1f us each (no sync yet)", steps_per_epoch,
                             (time.perf_counter() - t_host) / steps_per_epoch * 1e6)

@@ -105,24 +105,58 @@ int esr_glove_fwd_bwd(const float* emb, const float* bias, int64_t V, int D, con
  * No gradient row is ever written to memory: the update kernel walks the sorted occurrences of every distinct row,
  * re-reads each occurrence's partner row, forms gdot and accumulates gdot * partner on chip, then does the row's one
  * read-modify-write.  Reading partner rows while other rows are being rewritten is made safe by DOUBLE-BUFFERING
- * the embedding table: `emb` and `emb_shadow` are two [V, D] buffers and emb_loc [V] (bytes, 0 / 1) says which one
- * holds each row's current value.  The step reads every row where emb_loc pointed when it began, writes each updated
- * row into the OTHER buffer and flips its byte.  Callers that need a plain [V, D] table run esr_rows_consolidate
- * (copies the rows whose byte is 1 from `shadow` into `primary`, clears the bytes).  A fresh state is emb_loc = 0.
- * Same sort, same cut points and the same association of every sum as esr_glove_fwd_bwd + esr_sparse_adagrad_scatter:
- * tables, accumulators and loss agree with that path to an f32 rounding (bias sums are carried in fp64 here).
+ * the embedding table: `emb` and `emb_shadow` are two [V, D] buffers and emb_loc [V] holds one STAMPED byte per row:
+ * bit 0 = the buffer with the row's current value, bits 1..7 = the stamp of the step that last moved the row (0 = long
+ * ago).  The step reads every row where it lived when the step began -- a byte that already carries THIS step's stamp
+ * says "moved during this step, the old value is in the other buffer" -- writes each updated row into the other
+ * buffer and stamps its byte.  `stamp`: 1 .. 127, a value no byte of the table carries from an EARLIER step: count the
+ * steps on a table 1, 2, ... 127 and call esr_rows_restamp (one pass over V bytes, clears the stamps) before starting
+ * over at 1.  Callers that need a plain [V, D] table run esr_rows_consolidate (copies the rows that live in `shadow`
+ * into `primary`, zeroes every byte).  A fresh state is emb_loc = 0.
+ * Same sort, same cut points and the same association of every row sum as esr_glove_fwd_bwd +
+ * esr_sparse_adagrad_scatter: tables and accumulators agree with that path to an f32 rounding (bias sums are carried
+ * in fp64 here; the bias statistics sum s, sum s^2 of K_A in exact integer arithmetic).
  * loss [1]; bias / bias_accum [V] are updated in place (every bias read of a step precedes its bias writes).
  * presorted_ids / presorted_perm (both or neither): the output of esr_segment_sort_ids on inputs[0 .. 2B) -- the sort
- * depends on the ids only, so a training loop runs it for batch k + 1 on a second stream while batch k's update
- * kernel streams the rows; NULL = sort here.  blocks_per_cu > 0 caps the update kernel's residency (workgroups per
- * CU; an experiment knob: leaving room for a concurrent sort measured slower than filling the chip); 0 = fill it. */
+ * depends on the ids only, so a training loop runs it ahead; NULL = sort here.  plan (optional, needs the presorted
+ * arrays): esr_glove_plan's record of this batch, made ahead as well -- it holds what the step needs from ids and
+ * counts alone and the zeroed accumulators of ONE step (a plan feeds exactly one esr_glove_train_step); NULL = made
+ * here.  long_runs: 0 = the caller knows from esr_glove_plan's hint that no run of equal ids outgrows a 32-position
+ * chunk, and the long-run launch is skipped; anything else = launched (it returns at once when nothing was parked).
+ * Launches per step with a plan and uniform ids: update, finalize.  blocks_per_cu > 0 caps the update kernel's
+ * residency (experiment knob); 0 = fill the chip. */
 size_t esr_glove_step_workspace_bytes(int64_t B, int D);
 int esr_glove_train_step(float* emb, float* emb_shadow, uint8_t* emb_loc, float* emb_accum, float* bias,
                          float* bias_accum, int64_t V, int D, const int32_t* inputs, const float* target, int64_t B,
-                         int mode, float lr, float eps, const int32_t* presorted_ids, const int32_t* presorted_perm,
-                         int blocks_per_cu, float* loss, void* workspace, size_t workspace_bytes,
-                         esr_stream_t stream);
+                         int mode, float lr, float eps, uint32_t stamp, const int32_t* presorted_ids,
+                         const int32_t* presorted_perm, void* plan, int long_runs, int blocks_per_cu, float* loss,
+                         void* workspace, size_t workspace_bytes, esr_stream_t stream);
+/* The steps of nbatch <= 8 planned batches issued by ONE call (a training loop's per-step host work is then one
+ * foreign call per group: at the reference's batch of 2048 pairs a step is ~20 us of kernels, less than a ctypes call
+ * with 25 arguments plus the Python around it).  inputs / targets / sorted_ids / perm / plans as esr_glove_plan took and
+ * made them; stamps first_stamp, first_stamp + 1, ... (all <= 127); long_runs: host int32 [nbatch] (0 / 1 / -1 as above)
+ * or NULL = unknown; losses [nbatch]. */
+int esr_glove_train_steps(float* emb, float* emb_shadow, uint8_t* emb_loc, float* emb_accum, float* bias,
+                          float* bias_accum, int64_t V, int D, int nbatch, const int32_t* const* inputs,
+                          const float* const* targets, int64_t B, int mode, float lr, float eps, uint32_t first_stamp,
+                          const int32_t* sorted_ids, const int32_t* perm, void* plans, const int32_t* long_runs,
+                          float* losses, void* workspace, size_t workspace_bytes, esr_stream_t stream);
+/* Plans of nbatch <= 8 coming batches of B pairs in one launch: inputs[b] = int32 [2, B], targets[b] = f32 [B],
+ * sorted_ids / perm = [nbatch, 2B] (esr_segment_sort_ids_batched layout, or one esr_segment_sort_ids result with
+ * nbatch = 1), plans = nbatch x esr_glove_plan_bytes(B) bytes, 256-byte aligned.  hints (optional) [nbatch]:
+ * hints[b] = gen when a run of equal ids in list b is longer than 32 positions -- compare with `gen` (any value the
+ * caller has not passed for this array before) after the stream has passed the call; words need no clearing. */
+size_t esr_glove_plan_bytes(int64_t B);
+int esr_glove_plan(const int32_t* const* inputs, const float* const* targets, int nbatch, int64_t B,
+                   const int32_t* sorted_ids, const int32_t* perm, void* plans, int32_t* hints, int32_t gen,
+                   esr_stream_t stream);
+/* The hint alone, for lists whose steps resolve their records themselves (more than 32 768 ids: esr_glove_train_step
+ * then ignores `plan`): hint[0] = gen when sorted_ids [n] has a run of equal ids longer than `chunk` positions (32 for
+ * the GloVe step, 8 for the triplet step).  `hint` may be device memory or pinned host memory. */
+int esr_long_run_hint(const int32_t* sorted_ids, int64_t n, int chunk, int32_t* hint, int32_t gen, esr_stream_t stream);
 int esr_rows_consolidate(float* primary, const float* shadow, uint8_t* loc, int64_t V, int D, esr_stream_t stream);
+/* loc[r] &= 1 for every row: forget the stamps, keep the locations (see esr_glove_train_step's `stamp`). */
+int esr_rows_restamp(uint8_t* loc, int64_t V, esr_stream_t stream);
 
 /* ---- S1-S3: STL score head + triplet loss -- pinterest/models.py:67-72,
  * pinterest/train_shop_the_look.py:93-122 --------------------------------------------------
@@ -141,23 +175,40 @@ int esr_triplet_fwd_bwd(const float* scene_table, int64_t Vs, const float* pos_t
                         size_t workspace_bytes, esr_stream_t stream);
 
 /* ---- S2 in one pass: train_step (pinterest/train_shop_the_look.py:93-109) = loss + gradients + sparse Adagrad ----
- * on both id towers, three launches (plan, update, long-run combine) after the id sort, no [3B, D] gradient in memory:
- * the update kernel walks the sorted occurrences of every distinct row and forms each occurrence's gradient row on chip
- * from the two OTHER rows of its triplet (both partner rows give the pos / neg scores and the hinge mask; the own row
- * gives the regulariser term).  Both towers are DOUBLE-BUFFERED as in esr_glove_train_step: `scene` / `scene_shadow` +
- * scene_loc [Vs] bytes, `product` / `product_shadow` + product_loc [Vp]; rows are read where the bytes pointed when the
- * step began, updated rows go to the other buffer, esr_rows_consolidate gives plain tables back.  Occurrence ids are the
- * virtual rows [scene_ids ; Vs + pos_ids ; Vs + neg_ids]; presorted_ids / presorted_perm (both or neither) = their
- * esr_segment_sort_ids_multi output computed ahead (second stream), NULL = sort here.  Same element arithmetic
- * (trip_grad, adagrad_elem), same sort and the same association of every sum as esr_triplet_fwd_bwd +
- * esr_sparse_adagrad_scatter_multi.  loss [1] = (sum_b relu(1 + neg_b - pos_b) + regularization * reg) / batch_size. */
+ * on both id towers, no [3B, D] gradient in memory: the update kernel walks the sorted occurrences of every distinct row
+ * and forms each occurrence's gradient row on chip from the two OTHER rows of its triplet (both partner rows give the
+ * pos / neg scores and the hinge mask; the own row gives the regulariser term).  Both towers are DOUBLE-BUFFERED with
+ * stamped location bytes as in esr_glove_train_step (`scene` / `scene_shadow` + scene_loc [Vs], `product` /
+ * `product_shadow` + product_loc [Vp]; one `stamp` per step for both; esr_rows_restamp / esr_rows_consolidate per
+ * table).  Occurrence ids are the virtual rows [scene_ids ; Vs + pos_ids ; Vs + neg_ids]; presorted_ids /
+ * presorted_perm (both or neither) = their esr_segment_sort_ids_multi output computed ahead, NULL = sort here; plan /
+ * long_runs as for esr_glove_train_step (esr_triplet_plan; chunks of 8 positions here).  With a plan and uniform ids a
+ * step is ONE launch: the loss leaves the update kernel through an exact integer reduction (a mean loss beyond 2048
+ * comes out +inf).  Same element arithmetic (trip_grad, adagrad_elem), same sort and the same association of every row
+ * sum as esr_triplet_fwd_bwd + esr_sparse_adagrad_scatter_multi.
+ * loss [1] = (sum_b relu(1 + neg_b - pos_b) + regularization * reg) / batch_size. */
 size_t esr_triplet_step_workspace_bytes(int64_t B, int D);
 int esr_triplet_train_step(float* scene, float* scene_shadow, uint8_t* scene_loc, float* scene_accum, int64_t Vs,
                            float* product, float* product_shadow, uint8_t* product_loc, float* product_accum,
                            int64_t Vp, int D, const int32_t* scene_ids, const int32_t* pos_ids,
                            const int32_t* neg_ids, int64_t B, float regularization, float batch_size, float lr,
-                           float eps, const int32_t* presorted_ids, const int32_t* presorted_perm, float* loss,
-                           void* workspace, size_t workspace_bytes, esr_stream_t stream);
+                           float eps, uint32_t stamp, const int32_t* presorted_ids, const int32_t* presorted_perm,
+                           void* plan, int long_runs, float* loss, void* workspace, size_t workspace_bytes,
+                           esr_stream_t stream);
+/* The steps of nbatch <= 8 planned batches by one call (see esr_glove_train_steps): ids[3 b + {0, 1, 2}] as for
+ * esr_triplet_plan, losses [nbatch]. */
+int esr_triplet_train_steps(float* scene, float* scene_shadow, uint8_t* scene_loc, float* scene_accum, int64_t Vs,
+                            float* product, float* product_shadow, uint8_t* product_loc, float* product_accum,
+                            int64_t Vp, int D, int nbatch, const int32_t* const* ids, int64_t B, float regularization,
+                            float batch_size, float lr, float eps, uint32_t first_stamp, const int32_t* sorted_ids,
+                            const int32_t* perm, void* plans, const int32_t* long_runs, float* losses, void* workspace,
+                            size_t workspace_bytes, esr_stream_t stream);
+/* Plans of nbatch <= 8 coming batches of B triplets in one launch: ids[3 b + {0, 1, 2}] = scene / pos / neg id lists
+ * of batch b, sorted_ids / perm = [nbatch, 3B] (esr_segment_sort_ids_batched layout), plans = nbatch x
+ * esr_triplet_plan_bytes(B) bytes, 256-byte aligned; hints / gen as for esr_glove_plan (runs longer than 8 positions). */
+size_t esr_triplet_plan_bytes(int64_t B);
+int esr_triplet_plan(const int32_t* const* ids, int nbatch, int64_t B, int64_t Vs, const int32_t* sorted_ids,
+                     const int32_t* perm, void* plans, int32_t* hints, int32_t gen, esr_stream_t stream);
 
 /* ---- north_star: in-batch-negative sampled softmax on the dense B x B score matrix --------
  * (build-defined; the closest reference precedent is spotify/models.py:74-87).

@@ -1,0 +1,10 @@
+mkdir -p gpurun_out/trace
+export TMPDIR=/tmp
+tr() { name=$1; key=$2; shift; shift; rm -rf /tmp/tr_$name
+  timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_$name -o t -- python bench.py "$@" --no-cpu-baseline --no-kernel-timing --no-secondary --no-steady > gpurun_out/trace/$name.log 2>&1
+  echo "== $name $(grep -v amdgpu.ids gpurun_out/trace/$name.log | grep '^{' | tail -1 | cut -c1-120)"
+  python3 scripts/trace_gaps.py /tmp/tr_$name $key ${SKIP:-60} ${COUNT:-40} | tee gpurun_out/trace/$name.txt
+}
+tr triplet triplet_step_kernel --workload triplet --steps 200 --warmup 20
+tr glove2048 glove_step_kernel --workload glove --batch 2048 --steps 400 --warmup 20
+SKIP=30 tr glove glove_step_kernel --workload glove --steps 60 --warmup 10

@@ -45,8 +45,8 @@ def test_fused_step_equals_two_call_path(dev, mode, kind, V, D, B):
         grads, lb = apply_model(b, inputs, target)
         b = update_model(b, grads)
         assert abs(float(la) - float(lb)) <= 2e-6 * abs(float(lb)), (step, float(la), float(lb))
-    rv = a.opt_state["_versions"][("_token_embedding", "embedding")]
-    assert rv.dirty and int(rv.loc.sum()) > 0, "some rows must live in the second buffer before consolidation"
+    rv = a.versions[("_token_embedding", "embedding")]
+    assert rv.dirty and int((rv.loc & 1).sum()) > 0, "some rows must live in the second buffer before consolidation"
     pa, pb = a.params, b.params            # reading .params consolidates
     assert not rv.dirty and int(rv.loc.sum()) == 0
     assert int(a.step) == int(b.step) == 3
@@ -95,10 +95,10 @@ def test_train_epoch_takes_the_fused_step_and_params_stay_plain(dev, monkeypatch
     rng = np.random.default_rng(8)
     batches = [(_ids("uniform", V, (2, B), rng), rng.uniform(0.1, 300.0, B).astype(np.float32)) for _ in range(K)]
     a, la = train_epoch(_make_state(V, D, "reference", dev), K, iter(batches))
-    assert "_versions" in a.opt_state
+    assert a.versions
     monkeypatch.setenv("ESR_GLOVE_FUSED", "0")
     b, lb = train_epoch(_make_state(V, D, "reference", dev), K, iter(batches))
-    assert "_versions" not in b.opt_state
+    assert not b.versions
     assert abs(la - lb) <= 2e-6 * abs(lb)
     token = torch.tensor([1, 5, 9], dtype=torch.int32, device=dev)
     model = a.apply_fn.__self__
@@ -121,9 +121,38 @@ def test_rows_consolidate(dev):
         primary = torch.randn((V, D), generator=g, device=dev)
         shadow = torch.randn((V, D), generator=g, device=dev)
         loc = (torch.rand(V, generator=g, device=dev) < 0.3).to(torch.uint8)
-        want = torch.where(loc.bool()[:, None], shadow, primary)
+        # stamped bytes (esr_versioned.h): bit 0 = the location, bits 1..7 = the stamp of the step that moved the row
+        loc |= (torch.randint(0, 128, (V,), generator=g, device=dev, dtype=torch.int32) << 1).to(torch.uint8)
+        want = torch.where((loc & 1).bool()[:, None], shadow, primary)
+        keep = loc & 1
+        stamped = loc.clone()
+        ops.rows_restamp(stamped)
+        assert torch.equal(stamped, keep), "restamp clears the stamps and keeps the locations"
         ops.rows_consolidate(primary, shadow, loc)
         assert torch.equal(primary, want) and int(loc.sum()) == 0
+
+
+@pytest.mark.parametrize("kind", ["uniform", "zipf"])
+def test_stamps_wrap_around(dev, kind):
+    """140 one-pass steps (the stamp counter passes 127 and the bytes are re-stamped) leave the same bits as 140 steps
+    with the table consolidated after every one (stamps always 1): the stamps only say WHERE a row is read, never what
+    is computed."""
+    from esrecsys_amd.wikipedia.train_cooccurence import train_step
+    V, D, B = 400, 64, 150
+    rng = np.random.default_rng(9)
+    a, b = _make_state(V, D, "reference", dev), _make_state(V, D, "reference", dev)
+    stamps = []
+    for step in range(140):
+        inputs = _ids(kind, V, (2, B), rng)
+        target = np.exp(rng.uniform(np.log(0.1), np.log(1000.0), B)).astype(np.float32)
+        a, la = train_step(a, inputs, target)
+        stamps.append(a.versions[("_token_embedding", "embedding")].stamp)
+        b, lb = train_step(b, inputs, target)
+        _ = b.params  # consolidates: every byte back to 0
+        assert float(la) == float(lb), step
+    assert max(stamps) == 127 and stamps[127] == 1, "the counter wrapped"
+    assert torch.equal(a.params["_token_embedding"]["embedding"], b.params["_token_embedding"]["embedding"])
+    assert torch.equal(a.params["_bias"]["embedding"], b.params["_bias"]["embedding"])
 
 
 def test_config_c3_full_size_fused_step(dev):
@@ -148,15 +177,16 @@ def test_config_c3_full_size_fused_step(dev):
     assert torch.equal(ea[~touched], before[~touched]) and not torch.equal(ea[touched], before[touched])
 
 
-@pytest.mark.parametrize("B,K", [(1024, 11), (2048, 8), (16, 3), (3000, 5)])
-def test_train_epoch_batched_sort_equals_in_line_sort(dev, B, K, monkeypatch):
+@pytest.mark.parametrize("kind", ["uniform", "zipf"])
+@pytest.mark.parametrize("B,K", [(1024, 11), (2048, 8), (16, 3), (3000, 5), (2048, 27), (64, 140)])
+def test_train_epoch_batched_sort_equals_in_line_sort(dev, B, K, kind, monkeypatch):
     """Short id lists (the reference's default batch of 2048 pairs) are sorted eight batches at a time by one batched
     call (esr_segment_sort_ids_batched); the epoch must be bit-identical to the one that sorts every list inside its
     own step -- groups of 8 + 3, exactly 8, fewer than a group; 6000 ids (beyond 4096) keep the side-stream sort."""
     import esrecsys_amd.wikipedia.train_cooccurence as tc
     V, D = 3000, 64
     rng = np.random.default_rng(B + K)
-    batches = [(_ids("uniform", V, (2, B), rng), rng.uniform(0.1, 300.0, B).astype(np.float32)) for _ in range(K)]
+    batches = [(_ids(kind, V, (2, B), rng), rng.uniform(0.1, 300.0, B).astype(np.float32)) for _ in range(K)]
     monkeypatch.setattr(tc, "_SORT_BATCH", 8)
     a, la = tc.train_epoch(_make_state(V, D, "reference", dev), K, iter(batches))
     monkeypatch.setattr(tc, "_SORT_BATCH", 1)

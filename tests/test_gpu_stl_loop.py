@@ -20,7 +20,8 @@ def _state(dev, Vs, Vp, D, seed):
 
 
 @pytest.mark.parametrize("depth,sort_batch", [(0, 8), (0, 3), (0, 1), (2, 1)])
-@pytest.mark.parametrize("B,steps,ids", [(256, 7, "uniform"), (2048, 11, "hot"), (64, 1, "uniform"), (8192, 9, "uniform")])
+@pytest.mark.parametrize("B,steps,ids", [(256, 7, "uniform"), (2048, 11, "hot"), (64, 1, "uniform"), (8192, 9, "uniform"),
+                                         (128, 150, "hot"), (512, 27, "mixed")])  # 150 steps: the stamps wrap
 def test_train_steps_equals_stepwise_train_step(dev, B, steps, ids, depth, sort_batch, monkeypatch):
     import esrecsys_amd.pinterest.train_shop_the_look as stl
     from esrecsys_amd.pinterest.train_shop_the_look import train_step, train_steps
@@ -32,7 +33,9 @@ def test_train_steps_equals_stepwise_train_step(dev, B, steps, ids, depth, sort_
     rng = np.random.default_rng(B + steps)
 
     def draw(V):
-        if ids == "hot":  # a few very popular rows: long runs, the chunked hot-row path
+        # a few very popular rows: long runs, the chunked hot-row path ("mixed": only some batches have them, so the
+        # long-run launch is made for some steps of a group and skipped for others)
+        if ids == "hot" or (ids == "mixed" and rng.random() < 0.5):
             return np.where(rng.random(B) < 0.4, rng.integers(0, 3, B), rng.integers(0, V, B)).astype(np.int32)
         return rng.integers(0, V, B).astype(np.int32)
     batches = [(torch.from_numpy(draw(Vs)).to(dev), torch.from_numpy(draw(Vp)).to(dev),

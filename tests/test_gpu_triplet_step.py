@@ -51,9 +51,9 @@ def test_fused_triplet_step_equals_six_launch_path(dev, monkeypatch, kind, Vs, V
         monkeypatch.setenv("ESR_STL_FUSED", "0")
         b, lb = train_step(b, sid, pid, nid, lam, B)
         assert abs(float(la) - float(lb)) <= 2e-6 * abs(float(lb)), (step, float(la), float(lb))
-    versions = a.opt_state["_versions"]
+    versions = a.versions
     assert len(versions) == 2 and all(v.dirty for v in versions.values())
-    assert "_versions" not in b.opt_state
+    assert not b.versions
     (sa, pa), (sb, pb) = _tables(a), _tables(b)
     assert not any(v.dirty for v in versions.values()) and all(int(v.loc.sum()) == 0 for v in versions.values())
     assert int(a.step) == int(b.step) == 3
