@@ -759,7 +759,7 @@ def secondary_legs(args, dev, rank):
         PRECISION = keep
     try:
         from bench_retrieve import measure_retrieve
-        out["retrieve_c5_n1m_k500"] = measure_retrieve(dev, n_local=1_048_576, steps=3, warmup=1, mode="exact",
+        out["retrieve_c5_n1m_k500"] = measure_retrieve(dev, n_local=1_048_576, steps=3, warmup=1, mode="f16x2",
                                                        with_cpu=not args.no_cpu_baseline, with_ann=False)
     except Exception as e:
         out["retrieve_c5_n1m_k500"] = {"error": "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")}

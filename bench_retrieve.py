@@ -13,7 +13,13 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0
 MFMA_F32_PEAK_TFLOPS = 157.3
 
 
-def measure_retrieve(dev, n_local, steps, warmup, mode="exact", with_cpu=True, with_ann=True, nq=NQ, k=K):
+def _planes(mode):
+    """MFMA cross terms per product and whether the planes are fp16, for a retrieve_topk mode name."""
+    m = os.environ.get("ESR_RETRIEVE_EXACT", "bf16x3") if mode in ("exact", "f32") else mode
+    return {"f16x2": (3, True), "bf16x3": (6, False), "bf16": (1, False)}[m] + (m,)
+
+
+def measure_retrieve(dev, n_local, steps, warmup, mode="f16x2", with_cpu=True, with_ann=True, nq=NQ, k=K):
     """Single-GPU leg: `nq` queries against `n_local` candidates of dimension D, top-k, brute force.  Returns the
     fields of a bench line (value = queries/s, roofline of the score GEMM, cpu_baseline from the oracle)."""
     import numpy as np
@@ -34,11 +40,10 @@ def measure_retrieve(dev, n_local, steps, warmup, mode="exact", with_cpu=True, w
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     t_op = e0.elapsed_time(e1) * 1e-3 / steps  # HIP events on the launch stream around the timed calls
-    exact_path = os.environ.get("ESR_RETRIEVE_EXACT", "f16x2")  # what "exact" resolves to (ops._retrieve_mode)
-    planes = (3 if exact_path == "f16x2" else 6) if mode == "exact" else 1  # MFMA cross terms per product
+    planes, f16_planes, exact_path = _planes(mode)  # MFMA cross terms per product
     flops = 2.0 * nq * n_local * D
     from bench import sustained_bf16_mfma_tflops
-    live = sustained_bf16_mfma_tflops(dev, f16=(mode == "exact" and os.environ.get("ESR_RETRIEVE_EXACT", "f16x2") == "f16x2"))
+    live = sustained_bf16_mfma_tflops(dev, f16=f16_planes)
     extra = {}
     if with_ann:
         a_s, a_i = find_top_k_batch(q, c, k, approximate=True)
@@ -74,8 +79,8 @@ def measure_retrieve(dev, n_local, steps, warmup, mode="exact", with_cpu=True, w
     return {
         "metric": "retrieval queries/sec (top-%d of N candidates, brute force)" % k,
         "value": nq * steps / dt, "unit": "queries/s", "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
-        "dtype": ("f16x2" if os.environ.get("ESR_RETRIEVE_EXACT", "f16x2") == "f16x2" else "bf16x3") +
-                 " (f32-equivalent)" if mode == "exact" else "bf16",
+        "dtype": exact_path + (" (f32-grade: two fp16 planes of x 2^e, one exponent per matrix)" if exact_path == "f16x2" else
+                               " (exact split: three bf16 planes)" if exact_path == "bf16x3" else ""),
         "config": {"workload": "retrieve: %d queries x %d candidates x D=%d, k=%d, one GPU" % (nq, n_local, D, k),
                    "mode": mode, **extra},
         "roofline": {"kernel": "score_gemm_kernel (+ split, select)", "bound": "mfma",
@@ -105,7 +110,8 @@ def run_retrieve(args, emit):
     g = torch.Generator(device=dev).manual_seed(1701 + rank)
     q = torch.randn((NQ, D), generator=g, device=dev) * D ** -0.5
     c = torch.randn((n_local, D), generator=g, device=dev) * D ** -0.5
-    mode = "exact" if args.precision in ("auto", "f32") else "bf16"
+    # auto: the f32-grade fp16 x 2 planes (asked for by name); f32: the exact split (three bf16 planes); else one plane
+    mode = {"auto": "f16x2", "f16x2": "f16x2", "f32": "exact", "bf16x3": "bf16x3"}.get(args.precision, "bf16")
 
     def step():
         if world == 1:
@@ -138,13 +144,12 @@ def run_retrieve(args, emit):
     e1.record()
     torch.cuda.synchronize()
     t_op = e0.elapsed_time(e1) * 1e-3
-    exact_path = os.environ.get("ESR_RETRIEVE_EXACT", "f16x2")  # what "exact" resolves to (ops._retrieve_mode)
-    planes = (3 if exact_path == "f16x2" else 6) if mode == "exact" else 1  # MFMA cross terms per product
+    planes, f16_planes, exact_path = _planes(mode)  # MFMA cross terms per product
     flops = 2.0 * qq.shape[0] * n_local * D
     traffic = None
     try:
         import json
-        if world == 1 and mode == "exact":
+        if world == 1 and mode != "bf16":
             traffic = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
                                                   "pmc_traffic.json"))).get("retrieve")
     except Exception:
@@ -171,13 +176,14 @@ def run_retrieve(args, emit):
         extra_cpu = None
     if rank == 0:
         from bench import sustained_bf16_mfma_tflops
-        live = sustained_bf16_mfma_tflops(dev, f16=(mode == "exact" and os.environ.get("ESR_RETRIEVE_EXACT", "f16x2") == "f16x2"))
+        live = sustained_bf16_mfma_tflops(dev, f16=f16_planes)
         emit({
             "metric": "retrieval queries/sec (top-%d of N candidates, brute force)" % K,
             "value": world * NQ * args.steps / dt, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": ("f16x2" if os.environ.get("ESR_RETRIEVE_EXACT", "f16x2") == "f16x2" else "bf16x3") +
-                 " (f32-equivalent)" if mode == "exact" else "bf16",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": exact_path + (" (f32-grade: two fp16 planes of x 2^e, one exponent per matrix)" if exact_path == "f16x2"
+                                   else " (exact split: three bf16 planes)" if exact_path == "bf16x3" else ""),
             "data": "synthetic",
             "config": {"workload": "retrieve: %d queries/GPU x %d candidates (%d per GPU, id mod N) x D=%d, k=%d"
                                    % (NQ, n_local * world, n_local, D, K), "mode": mode,

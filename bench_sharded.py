@@ -26,13 +26,25 @@ def run_sharded(args, cfg, dev, rank, world):
             t = t.to(torch.bfloat16)
         return sharded.RowShardedTable(t, torch.full((n, dim), 0.1, device=dev), num_rows)
 
-    if args.workload == "glove":
+    # ESR_BENCH_PARALLELISM=replicated: every rank holds the FULL tables, gathers all ranks' ids + gradient rows and
+    # applies one global sparse update (esrecsys_amd/replicated.py) -- SURVEY 8e's other mode, for tables that fit a GPU
+    replicated_mode = os.environ.get("ESR_BENCH_PARALLELISM", "sharded") == "replicated" and args.workload != "glove"
+    rep = None
+    if replicated_mode:
+        from esrecsys_amd import replicated
+        g_all = torch.Generator(device=dev).manual_seed(SEED)  # the SAME tables on every rank
+        full = [torch.randn((V, D), generator=g_all, device=dev).mul_(D ** -0.5) for _ in range(2)]
+        rep = replicated.ReplicatedTables(full, [torch.full((V, D), 0.1, device=dev) for _ in range(2)], kernels=ops)
+    elif args.workload == "glove":
         emb_t, bias_t = shard(V, D), shard(V, 1)
         bias_t.local.zero_()
         emb = sharded.ShardedTableGroup([emb_t], kernels=ops)
         bias = sharded.ShardedTableGroup([bias_t], kernels=ops)
     else:
         towers = sharded.ShardedTableGroup([shard(V, D), shard(V, D)], kernels=ops)  # scene, product
+    grp0 = None if replicated_mode else (emb if args.workload == "glove" else towers)
+    # no routing plans where nothing is routed: the replicated mode, and a world of one rank taking the single-GPU steps
+    no_plans = replicated_mode or grp0.world1_direct
     n_batches = args.steps + args.warmup
     batches = []
     for _ in range(n_batches):
@@ -69,6 +81,10 @@ def run_sharded(args, cfg, dev, rank, world):
     plan_group = max(1, int(os.environ.get("ESR_SHARDED_PLAN_GROUP", "8")))
 
     def step(b, plans):
+        if replicated_mode:
+            if args.workload == "inbatch":
+                return replicated.replicated_inbatch_step(rep, b[0], b[1], LAM, gb, SCALE, LR)
+            return replicated.replicated_triplet_step(rep, b[0], b[1], b[2], LAM, gb, LR)
         if args.workload == "glove":
             return sharded.sharded_glove_step(emb, bias, b[0], b[1], ops.GLOVE_REFERENCE, LR, plan=plans)
         if args.workload == "inbatch":
@@ -82,6 +98,12 @@ def run_sharded(args, cfg, dev, rank, world):
     # stays inside the timed region.
     def run(lo, hi, timed_loss=None):
         from esrecsys_amd.train_state import quiet_gc
+        if no_plans:
+            with quiet_gc():
+                loss = None
+                for i in range(lo, hi):
+                    loss = step(batches[i], None)
+                return loss
         if plan_group > 1:
             with quiet_gc():
                 groups = [(a, min(a + plan_group, hi)) for a in range(lo, hi, plan_group)]
@@ -136,13 +158,17 @@ def run_sharded(args, cfg, dev, rank, world):
         for g_, (ms, calls) in timer.totals_ms(args.steps).items():
             if calls:
                 kernels[g_] = {"ms_per_step": ms / args.steps, "launch_groups_per_step": calls / args.steps}
-        rows_served = begin(batches[-1]).finish().recv_local_rows
+        if no_plans:
+            last = batches[-1]
+            rows_served = torch.cat([last[0].reshape(-1)] if args.workload == "glove" else
+                                    [last[0], last[1] + V] + ([last[2] + V] if args.workload == "triplet" else []))
+        else:
+            rows_served = begin(batches[-1]).finish().recv_local_rows
         roofline = roofline_for(args.workload, kernels, B, D, cfg["rows_per_unit"], "auto",
                                 int(rows_served.numel()), int(torch.unique(rows_served).numel()),
-                                bf16_tables=cfg.get("table_dtype") == "bf16")
+                                bf16_tables=cfg.get("table_dtype") == "bf16", step_s=dt / args.steps)
         roofline["rank"] = 0
-    grp = emb if args.workload == "glove" else towers
-    xch = grp.exchange()
+    xch = grp0.exchange() if grp0 is not None else rep.coll.x
     exchange = "direct RCCL: grouped ncclSend/ncclRecv on the compute stream (esr_alltoall_*, esrecsys_amd/rccl.py)" \
         if xch is not None else "fallback: torch.distributed all_to_all_single"
     rccl_ranks = xch.ranks_seen()[0] if xch is not None else None  # ncclCommCount of the exchange communicator
@@ -153,6 +179,17 @@ def run_sharded(args, cfg, dev, rank, world):
             live = sustained_bf16_mfma_tflops(dev, f16=str(roofline.get("dtype", "")).startswith("fp16"))
             roofline["sustained_live_data_TFLOPs"] = live
             roofline["frac_of_sustained"] = roofline["achieved"] / live
+        cpu = None
+        if not args.no_cpu_baseline:  # the same host-side restatement the N = 1 line carries (rank 0's host cores)
+            from bench import cpu_baseline
+            cpu = cpu_baseline(args.workload, cfg, budget_s=6.0, dense_budget_s=4.0)
+        if replicated_mode:
+            par = "replicated x%d: full tables per rank, all-gather of ids + gradient rows, one global sparse update" % world
+        elif grp0.world1_direct:
+            par = "row-sharded x1: a world of one rank takes the single-GPU steps on its shard (nothing is exchanged)"
+        else:
+            par = "row-sharded x%d, all-to-all ids/rows/grads over RCCL%s" % (
+                world, ", every distinct row once (unique plans)" if grp0.unique else "")
         emit({
             "metric": "training pairs/sec", "value": world * B * K / dt, "unit": cfg["unit"] + "s/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": dt / K * 1e3,
@@ -160,13 +197,13 @@ def run_sharded(args, cfg, dev, rank, world):
             "config": {"workload": "%s: V=%d x D=%d %s tables row-sharded id mod %d, B=%d per GPU, sparse Adagrad"
                                    % (args.workload, V, D, "bf16" if cfg.get("table_dtype") == "bf16" else "fp32",
                                       world, B),
-                       "parallelism": "row-sharded x%d, all-to-all ids/rows/grads over RCCL" % world,
+                       "parallelism": par,
                        "exchange": exchange, "rccl_ranks": rccl_ranks, "world_size": world,
                        "routing_plans": ("made for %d coming batches at a time (one bucket launch pair, one counts "
                                          "all-to-all, one RCCL group of ids exchanges, one owner-side sort per group)"
                                          % plan_group) if plan_group > 1 else "one per step, pipelined two batches deep",
                        "loss": float(total)},
-            "roofline": roofline, "kernels": kernels, "cpu_baseline": None,
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
         })
     dist.barrier()  # rank 0 may still be measuring its MFMA ceiling: leave the group together
     dist.destroy_process_group()

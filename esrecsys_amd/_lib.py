@@ -55,6 +55,10 @@ SIGNATURES = {
                                       c_vp]),
     "esr_glove_plan_bytes": (c_size, [c_i64]),
     "esr_glove_plan": (c_int, [c_vp, c_vp, c_int, c_i64, c_i32p, c_i32p, c_vp, c_vp, c_int32, c_vp]),
+    "esr_segment_sum_rows": (c_int, [c_f32p, c_i64, c_int, c_i32p, c_i32p, c_i64, c_f32p, c_vp]),
+    "esr_unique_by_owner_workspace_bytes": (c_size, [c_i64]),
+    "esr_unique_by_owner": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_i64, c_i32p, c_i32p, c_i32p, c_i32p, c_vp, c_vp,
+                                    c_size, c_vp]),
     "esr_long_run_hint": (c_int, [c_i32p, c_i64, c_int, c_vp, c_int32, c_vp]),
     "esr_rows_consolidate": (c_int, [c_f32p, c_f32p, c_vp, c_i64, c_int, c_vp]),
     "esr_rows_restamp": (c_int, [c_vp, c_i64, c_vp]),
@@ -138,6 +142,7 @@ SIGNATURES = {
     "esr_comm_destroy": (c_int, [c_vp]),
     "esr_alltoall_bytes": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "esr_alltoall_bytes_multi": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "esr_allgather_bytes": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     "esr_alltoall_ids": (c_int, [c_vp, c_i32p, c_vp, c_i32p, c_vp, c_vp]),
     "esr_alltoall_rows": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "esr_alltoall_grads": (c_int, [c_vp, c_f32p, c_int, c_vp, c_f32p, c_vp, c_vp]),

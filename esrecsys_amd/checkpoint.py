@@ -51,13 +51,14 @@ def _encode(obj, keep_order=False):
         keys = list(obj) if keep_order else sorted(obj, key=str)
         return {str(k): _encode(obj[k]) for k in keys}
     if isinstance(obj, (list, tuple)):
-        return _encode(_tuple_to_dict(obj))
+        return _encode(_tuple_to_dict(obj), keep_order=True)  # index maps stay in NUMERIC order ('10' after '9', not '1')
     if isinstance(obj, (torch.Tensor, np.ndarray)):
         arr, name = _to_numpy(obj)
         if arr.nbytes > _MAX_CHUNK_BYTES:
             per = max(1, _MAX_CHUNK_BYTES // arr.dtype.itemsize)
             flat = arr.reshape(-1)
             chunks = [flat[i:i + per] for i in range(0, flat.size, per)]
+            # (a literal dict: the 'shape' / 'chunks' index maps are emitted as built, in numeric order)
             return {"__msgpack_chunked_array__": True, "shape": _tuple_to_dict(list(arr.shape)),
                     "chunks": {str(i): _pack_array(c, name) for i, c in enumerate(chunks)}}
         return _pack_array(arr, name)

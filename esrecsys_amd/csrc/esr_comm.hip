@@ -122,15 +122,33 @@ int alltoall(const char* who, esr_comm_t comm_, const void* send, const int64_t*
   ESR_REQUIRE(st == 0 || send, "%s: null send buffer", who);
   ESR_REQUIRE(rt == 0 || recv, "%s: null recv buffer", who);
   if (st == 0 && rt == 0) return ESR_OK;
+  ESR_REQUIRE(send_counts[c->rank] == recv_counts[c->rank], "%s: the rank sends itself %lld and expects %lld", who,
+              (long long)send_counts[c->rank], (long long)recv_counts[c->rank]);
   hipStream_t s = esr::as_stream(stream);
   const char* sp = static_cast<const char*>(send);
   char* rp = static_cast<char*>(recv);
+  // the slice addressed to this rank itself never enters RCCL (see alltoall_multi): one hipMemcpyAsync on the stream
+  {
+    size_t so = 0, ro = 0;
+    for (int p = 0; p < c->rank; ++p) {
+      so += (size_t)(send_counts[p] * unit);
+      ro += (size_t)(recv_counts[p] * unit);
+    }
+    const size_t self = (size_t)(send_counts[c->rank] * unit);
+    if (self && hipMemcpyAsync(rp + ro, sp + so, self, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+      esr::set_error("%s: self copy failed", who);
+      return ESR_ELAUNCH;
+    }
+    if (st == send_counts[c->rank] && rt == recv_counts[c->rank]) return ESR_OK;  // nothing for anybody else
+  }
   ESR_NCCL(g_rccl.group_start(), who);
   int first = 0;
   for (int p = 0; p < c->world; ++p) {
     const size_t sb = (size_t)(send_counts[p] * unit), rb = (size_t)(recv_counts[p] * unit);
-    if (sb && !first) first = g_rccl.send(sp, sb, kNcclInt8, p, c->comm, s);
-    if (rb && !first) first = g_rccl.recv(rp, rb, kNcclInt8, p, c->comm, s);
+    if (p != c->rank) {
+      if (sb && !first) first = g_rccl.send(sp, sb, kNcclInt8, p, c->comm, s);
+      if (rb && !first) first = g_rccl.recv(rp, rb, kNcclInt8, p, c->comm, s);
+    }
     sp += sb;
     rp += rb;
   }
@@ -290,6 +308,35 @@ int esr_alltoall_bytes(esr_comm_t comm, const void* send, const int64_t* send_by
 int esr_alltoall_bytes_multi(esr_comm_t comm, int n_ops, const void* const* send, const int64_t* send_bytes,
                              void* const* recv, const int64_t* recv_bytes, esr_stream_t stream) {
   return alltoall_multi("esr_alltoall_bytes_multi", comm, n_ops, send, send_bytes, recv, recv_bytes, stream);
+}
+
+int esr_allgather_bytes(esr_comm_t comm_, const void* send, int64_t bytes, void* recv, esr_stream_t stream) {
+  EsrComm* c = reinterpret_cast<EsrComm*>(comm_);
+  ESR_REQUIRE(c && c->comm, "esr_allgather_bytes: null communicator");
+  ESR_REQUIRE(bytes >= 0, "esr_allgather_bytes: negative size");
+  if (bytes == 0) return ESR_OK;
+  ESR_REQUIRE(send && recv, "esr_allgather_bytes: null buffer");
+  hipStream_t s = esr::as_stream(stream);
+  char* rp = static_cast<char*>(recv);
+  // this rank's own block is a plain copy; every other block is one send / recv pair of the same grouped call the
+  // all-to-alls use (on the xGMI full mesh each pair rides its own link, exactly like a slice of an all-to-all)
+  if (rp + (size_t)c->rank * bytes != send &&
+      hipMemcpyAsync(rp + (size_t)c->rank * bytes, send, (size_t)bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+    esr::set_error("esr_allgather_bytes: self copy failed");
+    return ESR_ELAUNCH;
+  }
+  if (c->world == 1) return ESR_OK;
+  ESR_NCCL(g_rccl.group_start(), "esr_allgather_bytes");
+  int first = 0;
+  for (int p = 0; p < c->world; ++p) {
+    if (p == c->rank) continue;
+    if (!first) first = g_rccl.send(send, (size_t)bytes, kNcclInt8, p, c->comm, s);
+    if (!first) first = g_rccl.recv(rp + (size_t)p * bytes, (size_t)bytes, kNcclInt8, p, c->comm, s);
+  }
+  const int end = g_rccl.group_end();
+  if (first) return nccl_fail("esr_allgather_bytes", first);
+  if (end) return nccl_fail("esr_allgather_bytes", end);
+  return ESR_OK;
 }
 
 int esr_alltoall_ids(esr_comm_t comm, const int32_t* send_ids, const int64_t* send_counts, int32_t* recv_ids,

@@ -515,6 +515,16 @@ int esr_rows_to_dense(float* dense, int64_t V, int D, const int32_t* sorted_ids,
                                          grad_rows, 0.f, 0.f, st);
 }
 
+int esr_segment_sum_rows(float* out, int64_t rows_out, int D, const int32_t* sorted_ids, const int32_t* perm, int64_t n,
+                         float* grad_rows, esr_stream_t stream) {
+  ESR_REQUIRE(rows_out > 0 && D > 0 && n >= 0, "esr_segment_sum_rows: bad sizes rows=%lld D=%d n=%lld", (long long)rows_out,
+              D, (long long)n);
+  if (n == 0) return ESR_OK;
+  ESR_REQUIRE(out && sorted_ids && perm && grad_rows, "esr_segment_sum_rows: null pointer");
+  return launch_segment_update<kToDense>("esr_segment_sum_rows", out, ESR_F32, nullptr, D, sorted_ids, perm, n, grad_rows,
+                                         0.f, 0.f, as_stream(stream));
+}
+
 int esr_concat_offset_ids(const int32_t* const* ids, const int64_t* counts, const int64_t* offsets, int nseg,
                           int32_t* out, esr_stream_t stream) {
   ESR_REQUIRE(nseg >= 1 && nseg <= kMaxFusedTables, "esr_concat_offset_ids: nseg=%d not in [1, %d]", nseg,

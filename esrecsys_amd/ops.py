@@ -254,6 +254,45 @@ def glove_plan(inputs_list, targets_list, sorted_ids, perm, hints=None, gen=0):
     return plans
 
 
+def unique_by_owner(id_tensors, world, local_rows, offsets=None):
+    """The distinct rows of an occurrence list, routed by owner (esr_unique_by_owner): id_tensors = int32 segments (or one
+    tensor), offsets = their virtual-row offsets.  Returns (ulocal [n] -- first sum(ucounts) entries valid --, ucounts
+    int64 [world] on the device, uidx [n], sorted_uidx [n], perm [n])."""
+    lib = _lib.load()
+    if isinstance(id_tensors, torch.Tensor):
+        id_tensors = [id_tensors.reshape(-1)]
+    offsets = list(offsets) if offsets is not None else [0] * len(id_tensors)
+    for t in id_tensors:
+        _req(t, torch.int32, "ids")
+    dev = id_tensors[0].device
+    k = len(id_tensors)
+    counts = [int(t.numel()) for t in id_tensors]
+    n = sum(counts)
+    ulocal = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    uidx, sorted_uidx, perm = torch.empty_like(ulocal), torch.empty_like(ulocal), torch.empty_like(ulocal)
+    ucounts = torch.empty(world, dtype=torch.int64, device=dev)
+    ws = _ws(_ws_bytes("esr_unique_by_owner_workspace_bytes", n), dev)
+    ptrs = (ctypes.c_void_p * k)(*[t.data_ptr() for t in id_tensors])
+    cnt = (ctypes.c_int64 * k)(*counts)
+    off = (ctypes.c_int64 * k)(*[int(x) for x in offsets])
+    check(lib.esr_unique_by_owner(ptrs, cnt, off, k, int(world), int(local_rows), _p(ulocal), _p(uidx), _p(sorted_uidx),
+                                  _p(perm), _p(ucounts), _p(ws), ws.numel(), _stream()), "esr_unique_by_owner")
+    return ulocal[:n], ucounts, uidx[:n], sorted_uidx[:n], perm[:n]
+
+
+def segment_sum_rows(rows_out, sorted_ids, perm, grad_rows):
+    """[rows_out, D]: row u = the sum of grad_rows[perm[p]] over the positions p with sorted_ids[p] == u (every u in
+    [0, rows_out) must occur: the distinct-row index of unique_by_owner).  Overwrites grad_rows."""
+    lib = _lib.load()
+    _req(sorted_ids, torch.int32, "sorted_ids"), _req(perm, torch.int32, "perm"), _req(grad_rows, torch.float32, "grad_rows")
+    grad_rows = grad_rows.reshape(grad_rows.shape[0], -1)
+    D = grad_rows.shape[1]
+    out = torch.empty((int(rows_out), D), dtype=torch.float32, device=grad_rows.device)
+    check(lib.esr_segment_sum_rows(_p(out), int(rows_out), D, _p(sorted_ids), _p(perm), sorted_ids.numel(), _p(grad_rows),
+                                   _stream()), "esr_segment_sum_rows")
+    return out
+
+
 def long_run_hint(sorted_ids, chunk, hint, gen):
     """hint[0] = gen when sorted_ids has a run of equal ids longer than `chunk` positions (esr_long_run_hint); `hint` is
     an int32 tensor on the device or in pinned host memory."""
@@ -728,10 +767,13 @@ _RETRIEVE_MODES = {"bf16x3": _lib.RETRIEVE_EXACT, "f16x2": _lib.RETRIEVE_F16X2, 
 
 
 def _retrieve_mode(mode):
-    """"exact" / "f32": the f32-grade brute-force answer -- two fp16 planes per operand (three MFMA terms per product),
-    or, with ESR_RETRIEVE_EXACT=bf16x3, three bf16 planes (six terms)."""
+    """"exact" / "f32": the exact-split path -- every f32 operand as three bf16 planes (24 significand bits, whatever the
+    dynamic range of the matrix), six MFMA terms per product.  "f16x2" must be asked for by name: two fp16 planes of
+    x * 2^e with ONE exponent per matrix (three MFMA terms, 1.6x faster at C5): f32-grade while the matrix's elements
+    lie within ~2^16 of its largest one, absolute (not relative) error below that -- near-tie orderings can then differ
+    from the f32 brute force.  (ESR_RETRIEVE_EXACT=f16x2 restores round 2's mapping.)"""
     if mode in ("exact", "f32"):
-        mode = os.environ.get("ESR_RETRIEVE_EXACT", "f16x2")
+        mode = os.environ.get("ESR_RETRIEVE_EXACT", "bf16x3")
     if mode not in _RETRIEVE_MODES:
         raise ValueError("retrieval mode must be exact / f32 / f16x2 / bf16x3 / bf16, got %r" % (mode,))
     return _RETRIEVE_MODES[mode]
@@ -739,8 +781,9 @@ def _retrieve_mode(mode):
 
 def retrieve_topk(queries, candidates, k, mode="exact", index_base=0, index_step=1):
     """Batched brute-force top-k of queries @ candidates^T (descending, ties -> lower index) on MFMA.
-    mode "exact": f32-grade products ("f16x2": two scaled fp16 planes per operand, the default; "bf16x3": three exact
-    bf16 planes); "bf16": one plane (approximate).
+    mode "exact" = "bf16x3": three exact bf16 planes per operand (exact products in f32 accumulation order);
+    "f16x2": two scaled fp16 planes (f32-grade within a 2^16 dynamic range per matrix, 1.6x faster); "bf16": one
+    plane (approximate).
     Reported indices are index_base + n * index_step for local candidate row n."""
     lib = _lib.load()
     _req(queries, torch.float32, "queries"), _req(candidates, torch.float32, "candidates")

@@ -160,6 +160,13 @@ class DirectExchange:
         stream = torch._C._cuda_getCurrentRawStream(self.device.index)
         _lib.check(self.lib.esr_alltoall_bytes_multi(self.comm, n, sp, sb, rp, rb, stream), "esr_alltoall_bytes_multi")
 
+    def all_gather_into_tensor(self, out, inp):
+        """Same contract as torch.distributed.all_gather_into_tensor (equal blocks), on the current stream."""
+        stream = torch._C._cuda_getCurrentRawStream(self.device.index)
+        _lib.check(self.lib.esr_allgather_bytes(self.comm, inp.data_ptr(), inp.numel() * inp.element_size(),
+                                                out.data_ptr(), stream), "esr_allgather_bytes")
+        return out
+
     def close(self):
         if self.comm:
             self.lib.esr_comm_destroy(self.comm)

@@ -64,16 +64,27 @@ def shard_of(table, world, rank):
 class RoutingPlan:
     """Where the ids of one group lookup go: everything that does not depend on table contents."""
 
-    def __init__(self, group, n, local_rows, perm, send_counts, recv_counts, inv=None):
+    def __init__(self, group, n, local_rows, perm, send_counts, recv_counts, inv=None, unique=None):
         self.group = group
-        self.n = n
-        self.local_rows = local_rows        # int32 [n]: vid // G in bucket (owner-major, stable) order
-        self.perm = perm                    # int32 [n]: bucket order -> original position
+        self.n = n                          # occurrences (looked-up ids) of the batch
+        self.send_counts = send_counts      # python ints per peer: rows this rank asks of that peer
+        self.recv_counts = recv_counts      # python ints per peer: rows that peer asks of this rank
+        self.n_rows = sum(send_counts)      # rows that cross the exchange: n, or the DISTINCT rows of a unique plan
+        self.local_rows = local_rows[:self.n_rows]  # int32: vid // G of the rows asked for, owner-major
+        self.perm = perm                    # int32 [n]: bucket order -> original position (occurrence plans)
         self.inv = inv                      # int32 [n]: original position -> bucket order (inv[perm[k]] = k)
-        self.send_counts = send_counts      # python ints per peer: ids this rank asks of that peer
-        self.recv_counts = recv_counts      # python ints per peer: ids that peer asks of this rank
+        # unique plans (ShardedTableGroup.unique): every distinct row is asked for ONCE; occurrence i reads row uidx[i] of
+        # what comes back, and (sorted_uidx, occ_perm) group the occurrences by distinct row for the segment sum of their
+        # gradient rows -- one summed row per distinct row goes back to the owner
+        self.unique = unique is not None
+        self.uidx, self.sorted_uidx, self.occ_perm = unique if unique is not None else (None, None, None)
         self.recv_local_rows = None         # int32 [sum(recv_counts)]: virtual local rows requested of this rank
         self.owner_sorted = None            # (sorted, permutation) of recv_local_rows, for the update
+
+    @property
+    def index(self):
+        """int32 [n]: the row of the looked-up block (lookup_bucketed) that occurrence i reads."""
+        return self.uidx if self.unique else self.inv
 
     def exchange_ids(self):
         if self.recv_local_rows is None:
@@ -126,8 +137,9 @@ class PendingPlans:
                 else:
                     self.event.synchronize()
             both = self.both_host
-            self.plans = [RoutingPlan(group, n, local_rows, perm, both[0, :, i].tolist(), both[1, :, i].tolist(), inv)
-                          for i, (group, n, local_rows, perm, _, inv) in enumerate(self.parts)]
+            self.plans = [RoutingPlan(group, n, local_rows, perm, both[0, :, i].tolist(), both[1, :, i].tolist(), inv,
+                                      unique=part[6] if len(part) > 6 else None)
+                          for i, part in enumerate(self.parts) for (group, n, local_rows, perm, _, inv) in [part[:6]]]
             if not self._exchange_ids_grouped():
                 for p in self.plans:
                     p.exchange_ids()
@@ -135,34 +147,50 @@ class PendingPlans:
         return self.plans
 
 
+_OWNER_SORT_BATCH_MAX = 32768  # ids per list the batched owner-side sort takes (esr_segment_sort_ids_batched)
+
+
 def _grouped_owner_sort(plans):
     """The ids exchanges of a group of plans of ONE table group, and their owner-side sorts as ONE batched sort
     (esr_segment_sort_ids_batched): the lists a rank is asked for differ in length from batch to batch, so they are
     received into rows of one [L, n_max] buffer pre-filled with a sentinel row id that sorts behind every real one --
-    list b's sorted ids / permutation are the first n_b entries of row b.  Returns False when the kernels, the sizes or
-    the groups do not allow it (the caller then sorts plan by plan)."""
+    list b's sorted ids / permutation are the first n_b entries of row b.  Returns False when the kernels or the groups
+    do not allow it (the caller then goes plan by plan).
+
+    HOW the ids are exchanged (one RCCL group for the L lists, or L exchanges) is decided from what every rank knows
+    alike -- L, the device, the exchange object -- never from this rank's receive sizes: with skewed ids one rank may be
+    asked for more than the batched sort takes while its peers are not, and ranks that issued the same collectives with
+    different group structures would hang.  Only the owner-side SORT falls back per rank."""
     g = plans[0].group
     k = g.k
     L = len(plans)
     dev = plans[0].local_rows.device
-    if L < 2 or L > 8 or dev.type != "cuda" or not hasattr(k, "segment_sort_batched") or any(p.group is not g for p in plans):
+    if L < 2 or L > 8 or not hasattr(k, "segment_sort_batched") or any(p.group is not g for p in plans):
         return False
     ns = [sum(p.recv_counts) for p in plans]
     n_max, sentinel = max(ns), g.loff[-1]
-    if n_max == 0 or n_max > 32768 or sentinel + 1 > (1 << 21):
-        return False
-    buf = torch.full((L, n_max), sentinel, dtype=torch.int32, device=dev)
-    for i, p in enumerate(plans):
-        p.recv_local_rows = buf[i, :ns[i]]
+    # rank-local: how THIS rank sorts what it received
+    batched_sort = 0 < n_max <= _OWNER_SORT_BATCH_MAX and sentinel + 1 <= (1 << 21)
+    if batched_sort:
+        buf = torch.full((L, n_max), sentinel, dtype=torch.int32, device=dev)
+        for i, p in enumerate(plans):
+            p.recv_local_rows = buf[i, :ns[i]]
+    else:
+        for i, p in enumerate(plans):
+            p.recv_local_rows = torch.empty(ns[i], dtype=torch.int32, device=dev)
     x = g.exchange()
     if x is not None and hasattr(x, "all_to_all_multi"):  # the L ids exchanges as one RCCL group (one kernel)
         x.all_to_all_multi([(p.recv_local_rows, p.local_rows, p.recv_counts, p.send_counts) for p in plans])
     else:
         for p in plans:
             _a2a(g, p.recv_local_rows, p.local_rows, p.recv_counts, p.send_counts)
-    srt, prm = k.segment_sort_batched([[buf[i]] for i in range(L)], (0,), sentinel + 1)
-    for i, p in enumerate(plans):
-        p.owner_sorted = (srt[i, :ns[i]], prm[i, :ns[i]]) if ns[i] else None
+    if batched_sort:
+        srt, prm = k.segment_sort_batched([[buf[i]] for i in range(L)], (0,), sentinel + 1)
+        for i, p in enumerate(plans):
+            p.owner_sorted = (srt[i, :ns[i]], prm[i, :ns[i]]) if ns[i] else None
+    else:
+        for p in plans:
+            p.owner_sorted = k.segment_sort(p.recv_local_rows, g.loff[-1]) if p.recv_local_rows.numel() else None
     return True
 
 
@@ -171,7 +199,8 @@ def _bucket_grouped(lookups, both):
     (id tensors, offsets) kind with identical shapes and the kernels provide it; else None.  Fills both[0] ([G, L])."""
     g0 = lookups[0][0]
     k, G, L = g0.k, g0.world, len(lookups)
-    if L < 2 or L > 8 or not hasattr(k, "bucket_ids_by_owner_batched") or not both.is_cuda:
+    if L < 2 or L > 8 or not hasattr(k, "bucket_ids_by_owner_batched") or not both.is_cuda or \
+            any(g.unique for g, _ in lookups):
         return None
     vids = [v if isinstance(v, tuple) else ([v.reshape(-1)], [0]) for _, v in lookups]  # a plain id tensor: one segment
     offs = list(vids[0][1])
@@ -198,6 +227,14 @@ def begin_plans(lookups):
     parts = grouped if grouped is not None else []
     for group, vids in (lookups if grouped is None else []):
         out = both[0, :, 0] if L == 1 else None
+        if group.unique:  # every distinct row asked for once (esr_unique_by_owner)
+            segs, offs = (list(vids[0]), list(vids[1])) if isinstance(vids, tuple) else ([vids.reshape(-1)], [0])
+            n = sum(int(t.numel()) for t in segs)
+            ulocal, ucounts, uidx, sorted_uidx, occ_perm = k.unique_by_owner(segs, G, group.loff[-1], offsets=offs)
+            if out is not None:
+                out.copy_(ucounts)
+            parts.append((group, n, ulocal, None, ucounts, None, (uidx, sorted_uidx, occ_perm)))
+            continue
         if isinstance(vids, tuple):   # (id tensors, virtual offsets): bucketed in place, never concatenated
             n = sum(int(t.numel()) for t in vids[0])
             local_rows, perm, counts, inv = k.bucket_ids_by_owner(list(vids[0]), G, want_inverse=True, offsets=vids[1],
@@ -230,7 +267,7 @@ def make_plans(lookups):
 class ShardedTableGroup:
     """Same-width, same-dtype row-sharded tables that one step looks up and updates together."""
 
-    def __init__(self, tables, group=None, kernels=None):
+    def __init__(self, tables, group=None, kernels=None, unique=None):
         if kernels is None:
             from . import ops as kernels
         self.k = kernels
@@ -245,6 +282,39 @@ class ShardedTableGroup:
         self.loff = [o // G for o in self.voff]  # the same boundaries in virtual LOCAL rows
         self.dim = self.tables[0].local.shape[1] if self.tables[0].local.dim() > 1 else 1
         self._xch = False  # DirectExchange, None (use torch.distributed) or False (not resolved yet)
+        # unique: every distinct row of a batch crosses the exchange once (rows out, ONE summed gradient row back) instead
+        # of once per occurrence.  A sender-side choice -- owners serve whatever list they get -- that pays where bytes
+        # cross xGMI (world > 1) and ids repeat (GloVe's Zipfian stream: wikipedia/make_cooccurrence.py:33-55); at world
+        # 1 it only adds the dedup and segment-sum launches.  ESR_SHARDED_UNIQUE=0 / 1 overrides.
+        env = os.environ.get("ESR_SHARDED_UNIQUE", "")
+        self.unique = (unique if unique is not None else (self.world > 1)) if env == "" else env == "1"
+        if self.unique and not hasattr(kernels, "unique_by_owner"):
+            self.unique = False
+        # A world of ONE rank has nothing to exchange: its steps are the single-GPU steps on the local shard (= the whole
+        # table) -- the one-pass triplet / GloVe steps on double-buffered tables, the in-batch head straight from the
+        # towers -- and no routing plan is made.  ESR_SHARDED_WORLD1_DIRECT=0 keeps the whole exchange machinery running
+        # at world 1 (bucket, self-"exchange", gather, gradient rows, owner-side update): what the world-1 tests and
+        # profiles of that machinery use.
+        self.world1_direct = self.world == 1 and os.environ.get("ESR_SHARDED_WORLD1_DIRECT", "1") == "1" and \
+            hasattr(kernels, "triplet_train_step")
+        self._versions = None
+
+    def versions(self):
+        """RowVersions (second buffer + stamped location bytes, train_state.py) of every table of the group: what the
+        one-pass steps of the world-1 direct path keep.  None when a second buffer does not fit."""
+        if self._versions is None:
+            from .train_state import RowVersions, shadow_fits
+            if not all(shadow_fits(t.local) for t in self.tables):
+                return None
+            self._versions = [RowVersions(t.local) for t in self.tables]
+        return self._versions
+
+    def consolidate(self):
+        """After one-pass steps (world-1 direct path): copy the rows that live in second buffers back, so that
+        ``table.local`` is the plain shard again.  No-op otherwise."""
+        if self._versions is not None:
+            for t, rv in zip(self.tables, self._versions):
+                rv.consolidate(t.local)
 
     def exchange(self):
         if self._xch is False:
@@ -285,20 +355,25 @@ class ShardedTableGroup:
             served = k.gather_rows(self.tables[0].local, recv)
         else:
             served = k.gather_rows_multi([t.local for t in self.tables], self.loff, recv)
-        back = torch.empty((plan.n, self.dim), dtype=served.dtype, device=served.device)
+        back = torch.empty((plan.n_rows, self.dim), dtype=served.dtype, device=served.device)
         _a2a(self, back, served, plan.send_counts, plan.recv_counts)
         return back
 
     def lookup(self, plan):
         """rows[i] = table_of(vid_i)[id_i] for this rank's virtual ids -> [n, D] in the order of the ids."""
+        back = self.lookup_bucketed(plan)
+        if plan.unique:  # one row per distinct id came back: occurrence i reads row uidx[i]
+            return self.k.unpermute_rows_to_f32(self.k.gather_rows(back, plan.uidx), None)
         # bucket order -> id order; bf16 tables (config 4) cross xGMI as bf16 and become f32 here
-        return self.k.unpermute_rows_to_f32(self.lookup_bucketed(plan), plan.perm)
+        return self.k.unpermute_rows_to_f32(back, plan.perm)
 
     def route_grads(self, plan, grad_rows, bucketed=False):
         """Per-occurrence gradient rows (order of the looked-up ids, or already in bucket order) -> rows on their
         owners."""
         k = self.k
-        if not bucketed:
+        if not bucketed and plan.unique:  # one summed row per distinct row (the order the rows were asked for in)
+            grad_rows = k.segment_sum_rows(plan.n_rows, plan.sorted_uidx, plan.occ_perm, grad_rows)
+        elif not bucketed:
             grad_rows = k.gather_rows(grad_rows, plan.perm)                     # id order -> bucket order
         recv = torch.empty((sum(plan.recv_counts), grad_rows.shape[1]), dtype=grad_rows.dtype,
                            device=grad_rows.device)
@@ -367,21 +442,41 @@ def _joined(first, *rest):
     return torch.cat((first,) + rest)
 
 
+def _world1_tables_ok(group):
+    return group.world1_direct and all(t.local.is_cuda for t in group.tables)
+
+
 def sharded_inbatch_step(towers, scene_ids, pos_ids, regularization, global_batch_size, scale, lr, plan=None):
     """Data-parallel in-batch-softmax step on row-sharded towers (group = [scene table, product table]).
     Negatives are the local batch; gradients are normalised by the GLOBAL batch size, so the sum of the
     per-rank losses is the global mean loss."""
     k = towers.k
     B = scene_ids.numel()
+    if _world1_tables_ok(towers) and towers.tables[0].local.shape[1] <= 128 and B % 128 == 0 and \
+            towers.tables[0].local.dtype == towers.tables[1].local.dtype:
+        # world 1: the single-GPU step (score head straight from the towers, one sort, one fused update)
+        towers.consolidate()  # (rows a one-pass triplet step left in the second buffers: this step reads the plain tables)
+        st, pt = towers.tables
+        loss, _, gq, gc = k.inbatch_towers_fwd_bwd(st.local, pt.local, scene_ids, pos_ids, scale, regularization,
+                                                   global_batch_size)
+        Vs = st.local.shape[0]
+        sorted_vids, perm = k.segment_sort_multi([scene_ids, pos_ids], [0, Vs], Vs + pt.local.shape[0])
+        k.sparse_adagrad_multi([st.local, pt.local], [st.accum, pt.accum], [0, Vs, Vs + pt.local.shape[0]], sorted_vids,
+                               perm, _joined(gq, gc), lr, 1e-7)
+        return loss
     plan = plan if plan is not None else plan_inbatch(towers, scene_ids, pos_ids)
     folded = getattr(k, "inbatch_towers_fwd_bwd", None)
-    if folded is not None and plan.inv is not None and (getattr(k, "TOWERS_ANY_SHAPE", False) or
-                                                        (towers.dim == 128 and B % 128 == 0)):
+    if folded is not None and plan.index is not None and (getattr(k, "TOWERS_ANY_SHAPE", False) or
+                                                          (towers.dim == 128 and B % 128 == 0)):
         # The score head reads the exchanged rows where they landed (bucket order, table dtype) through the inverse
         # permutation and writes its gradient rows straight into bucket order: no un-permute, no widening pass, no
         # permute before the gradient all-to-all.
         back = towers.lookup_bucketed(plan)
-        iq, ic = plan.inv[:B], plan.inv[B:]
+        iq, ic = plan.index[:B], plan.index[B:]
+        if plan.unique:  # several occurrences may read one row: per-occurrence gradient rows, summed per distinct row
+            loss, _, gq, gc = folded(back, back, iq, ic, scale, regularization, global_batch_size)
+            towers.apply_sparse_adagrad(plan, _joined(gq, gc), lr)
+            return loss
         loss, _, gbuf, _ = folded(back, back, iq, ic, scale, regularization, global_batch_size,
                                   grad_positions=(iq, ic))
         towers.apply_sparse_adagrad(plan, gbuf, lr, bucketed=True)
@@ -397,12 +492,26 @@ def sharded_triplet_step(towers, scene_ids, pos_ids, neg_ids, regularization, gl
     sum over triplets, so G ranks x B triplets == one device with G*B triplets and batch_size = G*B."""
     k = towers.k
     B = scene_ids.numel()
+    if _world1_tables_ok(towers) and _is_f32(towers) and towers.versions() is not None:
+        # world 1: the one-pass step on the local shards (esr_triplet_train_step), nothing to exchange
+        from .train_state import next_stamp
+        st, pt = towers.tables
+        rs, rp = towers.versions()
+        return k.triplet_train_step(st.local, rs.shadow, rs.loc, st.accum, pt.local, rp.shadow, rp.loc, pt.accum,
+                                    scene_ids, pos_ids, neg_ids, regularization, global_batch_size, lr,
+                                    stamp=next_stamp(rs, rp))
     plan = plan if plan is not None else plan_triplet(towers, scene_ids, pos_ids, neg_ids)
-    if plan.inv is not None and getattr(k, "GRADS_AT_IDS", None) is not None and _is_f32(towers):
+    if plan.index is not None and getattr(k, "GRADS_AT_IDS", None) is not None and _is_f32(towers):
         # the loss kernel indexes the exchanged rows where they landed (bucket order) through the inverse
         # permutation and writes every gradient row back at that position: no un-permute / permute passes
         back = towers.lookup_bucketed(plan)
-        inv = plan.inv
+        inv = plan.index
+        if plan.unique:  # per-occurrence gradient rows in occurrence order, summed per distinct row before they travel
+            loss, _, _, gs, gp, gn = k.triplet_fwd_bwd(back, back, back, inv[:B], inv[B:2 * B], inv[2 * B:], B,
+                                                       regularization, global_batch_size, with_reg=True,
+                                                       want_grads=True, want_scores=False)
+            towers.apply_sparse_adagrad(plan, _joined(gs, gp, gn), lr)
+            return loss
         loss, _, _, gbuf, _, _ = k.triplet_fwd_bwd(back, back, back, inv[:B], inv[B:2 * B], inv[2 * B:], B,
                                                    regularization, global_batch_size, with_reg=True, want_grads=True,
                                                    want_scores=False, grads_at_ids=True)
@@ -421,15 +530,22 @@ def sharded_glove_step(emb_group, bias_group, inputs, target, mode, lr, plan=Non
     same ids, same sharding, different widths); the loss is over the local batch."""
     k = emb_group.k
     B = inputs.shape[1]
+    if _world1_tables_ok(emb_group) and _is_f32(emb_group) and _is_f32(bias_group) and emb_group.versions() is not None:
+        # world 1: the one-pass step on the local shard (esr_glove_train_step), nothing to exchange
+        from .train_state import next_stamp
+        et, bt = emb_group.tables[0], bias_group.tables[0]
+        (rv,) = emb_group.versions()
+        return k.glove_train_step(et.local, rv.shadow, rv.loc, et.accum, bt.local, bt.accum, inputs, target, mode, lr,
+                                  stamp=next_stamp(rv))
     plan = plan if plan is not None else plan_glove(emb_group, inputs)
-    if plan.inv is not None and getattr(k, "GRADS_AT_IDS", None) is not None and _is_f32(emb_group) and \
+    if plan.index is not None and getattr(k, "GRADS_AT_IDS", None) is not None and _is_f32(emb_group) and \
             _is_f32(bias_group):
-        rows = emb_group.lookup_bucketed(plan)      # [2B, D] in exchange order
-        brow = bias_group.lookup_bucketed(plan)     # [2B, 1]
-        loss, grad_rows, grad_bias = k.glove_fwd_bwd(rows, brow, plan.inv.reshape(2, B), target, mode,
-                                                     grads_at_ids=True)
-        emb_group.apply_sparse_adagrad(plan, grad_rows, lr, bucketed=True)
-        bias_group.apply_sparse_adagrad(plan, grad_bias.reshape(-1, 1), lr, bucketed=True)
+        rows = emb_group.lookup_bucketed(plan)      # [2B (or the distinct rows), D] in exchange order
+        brow = bias_group.lookup_bucketed(plan)     # [.., 1]
+        loss, grad_rows, grad_bias = k.glove_fwd_bwd(rows, brow, plan.index.reshape(2, B), target, mode,
+                                                     grads_at_ids=not plan.unique)
+        emb_group.apply_sparse_adagrad(plan, grad_rows, lr, bucketed=not plan.unique)
+        bias_group.apply_sparse_adagrad(plan, grad_bias.reshape(-1, 1), lr, bucketed=not plan.unique)
         return loss
     rows = emb_group.lookup(plan)           # [2B, D]: E[t1] ; E[t2]
     brow = bias_group.lookup(plan)          # [2B, 1]
@@ -440,23 +556,48 @@ def sharded_glove_step(emb_group, bias_group, inputs, target, mode, lr, plan=Non
     return loss
 
 
+class _Collectives:
+    """all_to_all_single / all_gather_into_tensor of a process group on the CURRENT stream through the direct RCCL
+    exchange when there is one (esrecsys_amd/rccl.py), else through torch.distributed."""
+
+    def __init__(self, group, device):
+        self.pg = group
+        self.x = None
+        if device.type == "cuda":
+            from . import rccl
+            self.x = rccl.exchange_for(group, device)
+
+    def all_to_all(self, out, inp, out_splits=None, in_splits=None):
+        if self.x is not None:
+            return self.x.all_to_all_single(out, inp, out_splits, in_splits)
+        return dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.pg)
+
+    def all_gather(self, out, inp):
+        if self.x is not None:
+            return self.x.all_gather_into_tensor(out, inp)
+        return dist.all_gather_into_tensor(out, inp, group=self.pg)
+
+
 def sharded_find_top_k(queries, local_candidates, k, group=None, kernels=None, mode="exact"):
     """Brute-force top-k over candidates that are row-sharded like the tables (this rank holds rows rank,
     rank + G, ...; BASELINE config 5).  Every rank brings its own [nq, D] queries (same nq on every rank):
     all-gather the queries, score ALL of them against the local shard, all-to-all the per-shard answers back to
-    the rank that asked, merge the G lists.  Returns ([nq, k] scores, [nq, k] global row indices)."""
+    the rank that asked, merge the G lists.  Returns ([nq, k] scores, [nq, k] global row indices).  The three
+    collectives run on the compute stream through the direct RCCL exchange (no stream hand-overs), as the training
+    steps' do."""
     if kernels is None:
         from . import ops as kernels
     G, rank = dist.get_world_size(group), dist.get_rank(group)
     nq, D = queries.shape
     if G == 1:
         return kernels.retrieve_topk(queries, local_candidates, k, mode=mode)
+    coll = _Collectives(group, queries.device)
     everyone = torch.empty((G * nq, D), dtype=queries.dtype, device=queries.device)
-    dist.all_gather_into_tensor(everyone, queries.contiguous(), group=group)
+    coll.all_gather(everyone, queries.contiguous())
     s, i = kernels.retrieve_topk(everyone, local_candidates, k, mode=mode, index_base=rank, index_step=G)
     rs, ri = torch.empty_like(s), torch.empty_like(i)        # [G (shard), nq, k] after the exchange
-    dist.all_to_all_single(rs, s, group=group)
-    dist.all_to_all_single(ri, i, group=group)
+    coll.all_to_all(rs, s)
+    coll.all_to_all(ri, i)
     rs = rs.reshape(G, nq, k).permute(1, 0, 2).reshape(nq, G * k).contiguous()
     ri = ri.reshape(G, nq, k).permute(1, 0, 2).reshape(nq, G * k).contiguous()
     return kernels.topk_merge(rs, ri, k)

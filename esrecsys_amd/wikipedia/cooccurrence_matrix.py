@@ -231,6 +231,18 @@ class CooccurrenceGenerator:
             return parts[0], pending
         return tuple(np.concatenate([p[i] for p in parts]) for i in range(3)), pending
 
+    def get_shuffled_items(self, num_items):
+        """cooccurrence_matrix.py:80-87: the item stream shuffled in buffers of `num_items`.  The same draw from the global
+        NumPy RNG as the reference's ``np.random.shuffle(items)`` (one permutation of `num_items` positions per buffer),
+        applied to the decoded array blocks; yields ``(index, other_index, count)`` tuples."""
+        blocks, pending = self.get_item_blocks(), None
+        while True:
+            buf, pending = self._take(blocks, pending, num_items)
+            order = np.arange(num_items)
+            np.random.shuffle(order)
+            for j in order:
+                yield (int(buf[0][j]), int(buf[1][j]), float(buf[2][j]))
+
     def get_batch(self, batch_size, shuffle_size=0):
         """cooccurrence_matrix.py:89-106.  Same batches as the reference's item-at-a-time loop -- including the
         buffer shuffle: fill `shuffle_size` items, np.random.shuffle (global NumPy RNG, one call per buffer: a

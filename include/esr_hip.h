@@ -318,6 +318,12 @@ int esr_sparse_sgd_scatter(void* table, int dtype, int64_t V, int D, const int32
  * (the scatter-add JAX's autodiff performs for nn.Embed, train_cooccurence.py:86-87). */
 int esr_rows_to_dense(float* dense, int64_t V, int D, const int32_t* sorted_ids,
                       const int32_t* perm, int64_t n, float* grad_rows, esr_stream_t stream);
+/* out[id, :] = the left-to-right sum of the gradient rows of the occurrences with sorted id `id`, for every id that
+ * occurs -- esr_rows_to_dense without the zero fill, for callers whose ids cover [0, rows_out) (the distinct-row index
+ * of esr_unique_by_owner: the per-occurrence gradient rows of a batch become ONE row per distinct row before they cross
+ * the exchange).  May overwrite grad_rows (chunk partials of long runs are parked there). */
+int esr_segment_sum_rows(float* out, int64_t rows_out, int D, const int32_t* sorted_ids, const int32_t* perm, int64_t n,
+                         float* grad_rows, esr_stream_t stream);
 /* optax.adam over every element -- wikipedia/train_cooccurence.py:99-101,171.
  * step = the 1-based count AFTER this update. */
 int esr_dense_adam(float* param, float* mu, float* nu, const float* grad, int64_t numel, float lr,
@@ -430,6 +436,17 @@ int esr_bucket_ids_by_owner_batched(const int32_t* const* ids, const int64_t* se
                                     int nseg, int nbatch, int world, int32_t* local_rows, int32_t* perm,
                                     int32_t* inverse, int64_t* counts, void* workspace, size_t workspace_bytes,
                                     esr_stream_t stream);
+/* The same routing with every DISTINCT row asked for once (esr_shard.hip): the occurrence list given as segments (as
+ * esr_bucket_ids_by_owner_multi) -> ulocal [<= n]: the distinct local rows, owner-major and ascending inside an owner
+ * (slice o, ucounts[o] entries, is what this rank asks of owner o and the order the rows come back in); ucounts [world]
+ * (int64, device); uidx [n]: occurrence i reads row uidx[i] of the rows that came back; sorted_uidx / perm [n]: the
+ * occurrences grouped by distinct row (sorted_uidx ascending; perm[p] = the occurrence) for esr_segment_sum_rows.
+ * local_rows = the owner-local row space (max over owners of virtual rows div world, e.g. ceil(total / world)).
+ * Owners need nothing new: they serve the list they are sent and segment-reduce what comes back by row. */
+size_t esr_unique_by_owner_workspace_bytes(int64_t n);
+int esr_unique_by_owner(const int32_t* const* ids, const int64_t* seg_counts, const int64_t* offsets, int nseg, int world,
+                        int64_t local_rows, int32_t* ulocal, int32_t* uidx, int32_t* sorted_uidx, int32_t* perm,
+                        int64_t* ucounts, void* workspace, size_t workspace_bytes, esr_stream_t stream);
 /* out[perm[k], :] = rows[k, :]  (undo the bucket order for rows that came back). */
 int esr_unpermute_rows(const void* rows, int dtype, int D, const int32_t* perm, int64_t n, void* out,
                        esr_stream_t stream);
@@ -468,6 +485,9 @@ int esr_alltoall_bytes(esr_comm_t comm, const void* send, const int64_t* send_by
  * arrays) to peer p and receives slice p of recv[o] from it.  The ids exchanges of a group of routing plans. */
 int esr_alltoall_bytes_multi(esr_comm_t comm, int n_ops, const void* const* send, const int64_t* send_bytes,
                              void* const* recv, const int64_t* recv_bytes, esr_stream_t stream);
+/* All-gather of equal blocks: block r of `recv` (world x bytes) = rank r's `send` (bytes).  The replicated-table mode
+ * gathers every rank's ids and gradient rows with it; the sharded retrieval its queries. */
+int esr_allgather_bytes(esr_comm_t comm, const void* send, int64_t bytes, void* recv, esr_stream_t stream);
 /* int32 virtual local rows -> their owners (step 2 of SURVEY 8e). */
 int esr_alltoall_ids(esr_comm_t comm, const int32_t* send_ids, const int64_t* send_counts, int32_t* recv_ids,
                      const int64_t* recv_counts, esr_stream_t stream);

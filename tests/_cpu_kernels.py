@@ -85,6 +85,8 @@ def sparse_adagrad_multi(tables, accums, row_offsets, sorted_vids, perm, grad_ro
 
 
 def unpermute_rows(rows, perm):
+    if perm is None:
+        return rows
     out = torch.empty_like(rows)
     out[perm.long()] = rows
     return out
@@ -94,9 +96,47 @@ def unpermute_rows_to_f32(rows, perm):
     return unpermute_rows(rows, perm)
 
 
+def unique_by_owner(id_tensors, world, local_rows, offsets=None):
+    """NumPy statement of esr_unique_by_owner: distinct rows owner-major, ascending local row inside an owner."""
+    if isinstance(id_tensors, torch.Tensor):
+        id_tensors = [id_tensors.reshape(-1)]
+    offsets = offsets if offsets is not None else [0] * len(id_tensors)
+    vid = np.concatenate([t.numpy().astype(np.int64) + int(o) for t, o in zip(id_tensors, offsets)])
+    key = (vid % world) * int(local_rows) + vid // world
+    perm = np.argsort(key, kind="stable").astype(np.int32)
+    sk = key[perm]
+    head = np.ones(len(sk), bool)
+    head[1:] = sk[1:] != sk[:-1]
+    sorted_uidx = (np.cumsum(head) - 1).astype(np.int32)
+    ukeys = sk[head]
+    uidx = np.empty(len(sk), np.int32)
+    uidx[perm] = sorted_uidx
+    ucounts = np.bincount(ukeys // int(local_rows), minlength=world).astype(np.int64)
+    ulocal = np.zeros(len(sk), np.int32)
+    ulocal[:len(ukeys)] = (ukeys % int(local_rows)).astype(np.int32)
+    return _t(ulocal), _t(ucounts), _t(uidx), _t(sorted_uidx), _t(perm)
+
+
+def segment_sum_rows(rows_out, sorted_ids, perm, grad_rows):
+    g = grad_rows.numpy().reshape(grad_rows.shape[0], -1)
+    out = np.zeros((int(rows_out), g.shape[1]), g.dtype)
+    np.add.at(out, sorted_ids.numpy().astype(np.int64), g[perm.numpy()])
+    return _t(out)
+
+
 def segment_sort(ids, V):
     order = np.argsort(ids.numpy(), kind="stable").astype(np.int32)
     return _t(ids.numpy()[order]), _t(order)
+
+
+def segment_sort_batched(lists, offsets, V):
+    """[[segment tensors] per list] of equal total length -> (sorted [L, n], perm [L, n]), list by list."""
+    srt, prm = [], []
+    for segs in lists:
+        ids = torch.cat([t + int(o) for t, o in zip(segs, offsets)])
+        a, b = segment_sort(ids, V)
+        srt.append(a), prm.append(b)
+    return torch.stack(srt), torch.stack(prm)
 
 
 def sparse_adagrad(table, accum, sorted_ids, perm, grad_rows, lr, eps=1e-7):

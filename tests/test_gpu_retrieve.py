@@ -74,6 +74,35 @@ def test_retrieve_topk_random_vs_oracle(dev, nq, N_, D, k):
     assert all(len(set(r)) == k for r in got_i)
 
 
+def test_retrieve_exact_survives_an_outlier_row_f16x2_is_range_limited(dev):
+    """One candidate row 10^6 times larger than the rest (and queries spanning five decades): "exact" (three bf16 planes,
+    24 significand bits per element whatever the range) still returns the f64 answer for the ordinary rows to 1e-5 per
+    element; "f16x2" (ONE exponent per matrix) keeps the top hits right (the outlier, large scores) and is allowed its
+    documented absolute error -- 2^-22 of (max |q| x max |c| x D) -- on scores far below the matrix maxima."""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(41)
+    nq, N_, D, k = 64, 20_000, 128, 50
+    q = (rng.standard_normal((nq, D)) * D ** -0.5).astype(np.float32)
+    q *= (10.0 ** rng.uniform(-4, 1, (nq, 1))).astype(np.float32)          # query norms over five decades
+    c = (rng.standard_normal((N_, D)) * D ** -0.5).astype(np.float32)
+    c[777] *= 1e6                                                           # the outlier row
+    full = q.astype(F64) @ c.astype(F64).T
+    es, ei = o_topk.top_k(full, k)
+    s, i = ops.retrieve_topk(T(q, dev), T(c, dev), k, mode="exact")
+    got_s, got_i = N(s), N(i)
+    picked = np.take_along_axis(full, got_i.astype(np.int64), axis=1)
+    assert np.abs(picked - got_s).max() / np.abs(got_s).max() <= 1e-6
+    rel = np.abs(got_s - es) / np.maximum(np.abs(es), 1e-30)
+    assert rel.max() <= 1e-5, rel.max()                                     # ELEMENT-wise: every score of every query
+    assert np.mean(got_i == ei) > 0.99
+    s2, i2 = ops.retrieve_topk(T(q, dev), T(c, dev), k, mode="f16x2")
+    g2, i2 = N(s2), N(i2)
+    bound = 2.0 ** -22 * float(np.abs(q).max()) * float(np.abs(c).max()) * D
+    assert np.abs(g2 - np.take_along_axis(full, i2.astype(np.int64), axis=1)).max() <= bound
+    pos = full[:, 777] > 0
+    assert pos.any() and np.all(i2[pos, 0] == 777)                          # where the outlier scores high it is found
+
+
 def test_topk_merge_vs_lexsort(dev):
     from esrecsys_amd import ops
     rng = np.random.default_rng(3)

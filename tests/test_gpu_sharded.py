@@ -16,8 +16,12 @@ def pg(dev):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29577")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # these tests are about the exchange MACHINERY at world 1 (bucket, self-exchange, gather, gradient rows, owner-side
+    # update); the default at world 1 is the single-GPU step on the shard (test_world1_direct_path... below switches back)
+    os.environ["ESR_SHARDED_WORLD1_DIRECT"] = "0"
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     yield dist
+    os.environ.pop("ESR_SHARDED_WORLD1_DIRECT", None)
     from esrecsys_amd import rccl
     rccl.reset()
     dist.destroy_process_group()
@@ -139,3 +143,51 @@ def test_sharded_routing_plans_made_in_groups(dev, pg, workload):
     assert torch.equal(loss_a, loss_b)
     for a, b in zip(tabs_a, tabs_b):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("unique", ["0", "1"])
+def test_world1_direct_path_and_machinery_agree(dev, pg, unique, monkeypatch):
+    """A world of one rank: the default (single-GPU steps on the shard, no exchange) and the full machinery -- with
+    per-occurrence or per-distinct-row exchange (ESR_SHARDED_UNIQUE) -- leave the same towers for the triplet, in-batch and
+    GloVe steps, hot ids included."""
+    from conftest import rel_err
+    from esrecsys_amd import ops, sharded
+    V, D, B, lam, lr = 6000, 128, 1024, 0.1, 0.05
+    g = torch.Generator().manual_seed(3)
+    t0 = torch.randn((V, D), generator=g) * D ** -0.5
+    t1 = torch.randn((V, D), generator=g) * D ** -0.5
+    e0, b0 = torch.randn((V, 64), generator=g) * 0.12, torch.randn((V, 1), generator=g) * 0.05
+    rng = np.random.default_rng(5)
+
+    def ids(n):  # 6 % of the occurrences on three hot rows: runs of ~20, longer than the triplet step's 8-position chunks
+        # (with a third of a batch on three rows the f32 association noise of their 340-term gradient sums -- 8-position
+        # chunks on one path, 32 on the other -- reaches 1e-4 in the next loss: every occurrence of the batch reads them)
+        return torch.from_numpy(np.where(rng.random(n) < 0.06, rng.integers(0, 3, n), rng.integers(0, V, n)).astype(np.int32)).to(dev)
+    batches = [(ids(B), ids(B), ids(B)) for _ in range(4)]
+    gb = [(torch.stack([ids(B), ids(B)]).contiguous(), torch.from_numpy(rng.uniform(0.1, 300, B).astype(np.float32)).to(dev))
+          for _ in range(3)]
+
+    def run(direct):
+        monkeypatch.setenv("ESR_SHARDED_WORLD1_DIRECT", "1" if direct else "0")
+        monkeypatch.setenv("ESR_SHARDED_UNIQUE", unique)
+        mk = lambda t: sharded.RowShardedTable(t.clone().to(dev), torch.full(t.shape, 0.1, device=dev), V)  # noqa: E731
+        towers = sharded.ShardedTableGroup([mk(t0), mk(t1)], kernels=ops)
+        emb, bias = sharded.ShardedTableGroup([mk(e0)], kernels=ops), sharded.ShardedTableGroup([mk(b0)], kernels=ops)
+        assert towers.world1_direct == direct and (direct or towers.unique == (unique == "1"))
+        losses = []
+        for i, (s_, p_, n_) in enumerate(batches):
+            if i % 2 == 0:
+                losses.append(float(sharded.sharded_triplet_step(towers, s_, p_, n_, lam, float(B), lr)))
+            else:
+                losses.append(float(sharded.sharded_inbatch_step(towers, s_, p_, lam, float(B), 4.0, lr)))
+        for inp, tgt in gb:
+            losses.append(float(sharded.sharded_glove_step(emb, bias, inp, tgt, ops.GLOVE_REFERENCE, lr)))
+        towers.consolidate(), emb.consolidate()
+        return losses, [t.local.clone() for t in towers.tables + emb.tables + bias.tables]
+    la, ta = run(True)
+    lb, tb = run(False)
+    # (the in-batch head sees its rows in a different order on the two paths -- id order against exchange order -- and
+    # its split-precision exponent references follow the order: the same 1e-5 class as against the fp64 oracle)
+    assert np.allclose(la, lb, rtol=2e-5), (la, lb)
+    errs = [rel_err(a.cpu().numpy(), b.cpu().numpy()) for a, b in zip(ta, tb)]  # scene, product, GloVe emb, GloVe bias
+    assert max(errs) <= 2e-5, errs

@@ -105,10 +105,12 @@ def test_inbatch_split_path_resolution(monkeypatch):
 def test_retrieve_mode_resolution(monkeypatch):
     from esrecsys_amd import _lib, ops
     monkeypatch.delenv("ESR_RETRIEVE_EXACT", raising=False)
-    assert ops._retrieve_mode("exact") == _lib.RETRIEVE_F16X2 == 2
+    # "exact" is the exact split (three bf16 planes); the range-limited fp16 x 2 planes are asked for by name
+    assert ops._retrieve_mode("exact") == ops._retrieve_mode("f32") == _lib.RETRIEVE_EXACT
+    assert ops._retrieve_mode("f16x2") == _lib.RETRIEVE_F16X2 == 2
     assert ops._retrieve_mode("bf16") == _lib.RETRIEVE_BF16 and ops._retrieve_mode("bf16x3") == _lib.RETRIEVE_EXACT
-    monkeypatch.setenv("ESR_RETRIEVE_EXACT", "bf16x3")
-    assert ops._retrieve_mode("f32") == _lib.RETRIEVE_EXACT
+    monkeypatch.setenv("ESR_RETRIEVE_EXACT", "f16x2")   # round 2's mapping, on request
+    assert ops._retrieve_mode("f32") == _lib.RETRIEVE_F16X2
     with pytest.raises(ValueError):
         ops._retrieve_mode("int8")
 

@@ -54,6 +54,10 @@ def test_batches_have_the_reference_layout_and_shuffle_semantics():
     items = list(zip(idx[:100].tolist(), oth[:100].tolist(), cnt[:100].tolist()))
     np.random.shuffle(items)
     assert xs[0].tolist() == [i[0] for i in items[:50]] and xs[1].tolist() == [i[1] for i in items[:50]]
+    # the public item-level form of the same shuffle (cooccurrence_matrix.py:80-87): same permutation, item tuples
+    np.random.seed(5)
+    got = [next(it_) for it_ in [g.get_shuffled_items(100)] for _ in range(100)]
+    assert [(a, b) for a, b, _ in got] == [(i[0], i[1]) for i in items] and got[3][2] == pytest.approx(items[3][2])
     # tf.data call shape used by the trainer: get_dataset(B, shuffle).prefetch(AUTOTUNE).as_numpy_iterator()
     it = g.get_dataset(16).prefetch(AUTOTUNE).as_numpy_iterator()
     inputs, targets = next(it)
@@ -122,6 +126,20 @@ def test_checkpoint_chunks_large_arrays(monkeypatch):
     assert raw["w"]["__msgpack_chunked_array__"] is True and len(raw["w"]["chunks"]) == 7
     back = checkpoint.from_bytes({"w": torch.zeros(10, 10)}, data)
     assert torch.equal(back["w"], tree["w"])
+
+
+def test_checkpoint_index_maps_keep_numeric_order(monkeypatch):
+    """Tuples and chunk lists of 11 or more entries: flax writes their index maps '0', '1', ..., '10', '11' -- numeric
+    order, not the '0', '1', '10', '11', '2' a string sort of the keys gives."""
+    from esrecsys_amd import checkpoint
+    monkeypatch.setattr(checkpoint, "_MAX_CHUNK_BYTES", 32)
+    tree = {"w": torch.arange(100, dtype=torch.float32), "t": tuple(float(i) for i in range(12))}
+    raw = msgpack.unpackb(checkpoint.to_bytes(tree), raw=False, strict_map_key=False)
+    assert list(raw["w"]["chunks"]) == [str(i) for i in range(13)]
+    assert list(raw["t"]) == [str(i) for i in range(12)]
+    assert list(raw) == ["t", "w"]  # (real dict nodes are still emitted with sorted keys)
+    back = checkpoint.from_bytes({"w": torch.zeros(100), "t": tuple(0.0 for _ in range(12))}, checkpoint.to_bytes(tree))
+    assert torch.equal(back["w"], tree["w"]) and back["t"] == tree["t"]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -1,0 +1,111 @@
+"""CPU, world_size 2, gloo: the replicated-table mode (esrecsys_amd/replicated.py) -- every rank holds the full towers,
+gathers all ranks' ids + gradient rows and applies ONE global sparse update -- against a single device on the
+concatenated batch, with the oracle-backed kernel double (tests/_cpu_kernels.py).  The replicas must stay identical."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+WORLD = 2
+V_S, V_P, D, B, LAM, LR, STEPS = 101, 203, 8, 24, 0.1, 0.05, 3
+
+
+def _tables():
+    rng = np.random.default_rng(7)
+    return rng.standard_normal((V_S, D)) * 0.4, rng.standard_normal((V_P, D)) * 0.4
+
+
+def _batch(step, rank):
+    rng = np.random.default_rng(1000 * step + rank)
+    sid = rng.integers(0, V_S, B).astype(np.int32)
+    pid = rng.integers(0, V_P, B).astype(np.int32)
+    nid = rng.integers(0, V_P, B).astype(np.int32)
+    sid[:4] = 9       # a row that several occurrences of BOTH ranks update
+    return sid, pid, nid
+
+
+def _worker(rank, port, outdir, workload):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    import _cpu_kernels as K
+    from esrecsys_amd import replicated
+    st, pt = (torch.from_numpy(x.copy()) for x in _tables())
+    rep = replicated.ReplicatedTables([st, pt], [torch.full_like(st, 0.1), torch.full_like(pt, 0.1)], kernels=K)
+    losses = []
+    for step in range(STEPS):
+        sid, pid, nid = (torch.from_numpy(x) for x in _batch(step, rank))
+        if workload == "triplet":
+            loss = replicated.replicated_triplet_step(rep, sid, pid, nid, LAM, float(WORLD * B), LR)
+        else:
+            loss = replicated.replicated_inbatch_step(rep, sid, pid, LAM, float(WORLD * B), 2.0, LR)
+        total = loss.clone()
+        dist.all_reduce(total)
+        losses.append(float(total))
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), scene=st.numpy(), prod=pt.numpy(), acc=rep.accums[0].numpy(),
+             losses=np.array(losses))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(workload):
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(port, d, workload), nprocs=WORLD, join=True)
+        return [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(WORLD)]
+
+
+@pytest.mark.timeout(300)
+def test_replicated_triplet_equals_single_device_and_replicas_agree():
+    from oracle import optim as o_optim
+    from oracle import stl_head as o_stl
+    outs = _run("triplet")
+    st, pt = _tables()
+    a_s, a_p = np.full_like(st, 0.1), np.full_like(pt, 0.1)
+    for step in range(STEPS):
+        parts = [_batch(step, r) for r in range(WORLD)]
+        sid, pid, nid = (np.concatenate([p[i] for p in parts]) for i in range(3))
+        loss, gs, gp, gn = o_stl.triplet_loss_and_grads(st[sid], pt[pid], pt[nid], LAM, WORLD * B, np.float64)
+        assert abs(outs[0]["losses"][step] - loss) <= 1e-12 * max(1.0, abs(loss))
+        st, a_s = o_optim.sparse_adagrad_update(st, a_s, sid, gs, LR, dtype=np.float64)
+        pt, a_p = o_optim.sparse_adagrad_update(pt, a_p, np.concatenate([pid, nid]), np.concatenate([gp, gn]), LR,
+                                                dtype=np.float64)
+    for key in ("scene", "prod", "acc"):
+        assert np.array_equal(outs[0][key], outs[1][key]), "the replicas must be bit-identical"
+    assert np.abs(outs[0]["scene"] - st).max() <= 1e-12 and np.abs(outs[0]["prod"] - pt).max() <= 1e-12
+    assert np.abs(outs[0]["acc"] - a_s).max() <= 1e-12
+
+
+@pytest.mark.timeout(300)
+def test_replicated_inbatch_matches_per_rank_oracle():
+    """In-batch negatives are per rank: the single-device equivalent applies each rank's local-batch gradients
+    (normalised by the global batch) to one shared table -- the sharded step's semantics (tests/test_sharded_gloo.py)."""
+    from oracle import optim as o_optim
+    from oracle import stl_head as o_stl
+    outs = _run("inbatch")
+    st, pt = _tables()
+    a_s, a_p = np.full_like(st, 0.1), np.full_like(pt, 0.1)
+    for step in range(STEPS):
+        ids_s, ids_p, g_s, g_p, total = [], [], [], [], 0.0
+        for r in range(WORLD):
+            sid, pid, _ = _batch(step, r)
+            loss, _, gq, gc = o_stl.inbatch_softmax_loss_and_grads(st[sid], pt[pid], LAM, WORLD * B, 2.0, np.float64)
+            total += loss
+            ids_s.append(sid), ids_p.append(pid), g_s.append(gq), g_p.append(gc)
+        assert abs(outs[0]["losses"][step] - total) <= 1e-12 * max(1.0, abs(total))
+        st, a_s = o_optim.sparse_adagrad_update(st, a_s, np.concatenate(ids_s), np.concatenate(g_s), LR, dtype=np.float64)
+        pt, a_p = o_optim.sparse_adagrad_update(pt, a_p, np.concatenate(ids_p), np.concatenate(g_p), LR, dtype=np.float64)
+    assert np.array_equal(outs[0]["scene"], outs[1]["scene"]) and np.array_equal(outs[0]["prod"], outs[1]["prod"])
+    assert np.abs(outs[0]["scene"] - st).max() <= 1e-12 and np.abs(outs[0]["prod"] - pt).max() <= 1e-12

@@ -27,28 +27,43 @@ def _full_tables():
     return st, pt
 
 
+ZIPF = False  # set (in every process) by the tests that draw Zipf(1) ids: a few rows take most occurrences
+
+
+def _draw(rng, V, n):
+    if not ZIPF:
+        return rng.integers(0, V, n).astype(np.int32)
+    w = 1.0 / np.arange(1, V + 1)
+    return rng.choice(V, size=n, p=w / w.sum()).astype(np.int32)
+
+
 def _batch(step, rank):
     rng = np.random.default_rng(1000 * step + rank)
-    sid = rng.integers(0, V_S, B).astype(np.int32)
-    pid = rng.integers(0, V_P, B).astype(np.int32)
-    nid = rng.integers(0, V_P, B).astype(np.int32)
+    sid, pid, nid = _draw(rng, V_S, B), _draw(rng, V_P, B), _draw(rng, V_P, B)
     sid[:3] = 5  # duplicates that live on one owner
     return sid, pid, nid
 
 
-def _worker(rank, port, outdir, workload, grouped=False):
+def _worker(rank, port, outdir, workload, grouped=False, unique=None, zipf=False, sort_limit=None):
+    global ZIPF
+    ZIPF = zipf
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if unique is not None:
+        os.environ["ESR_SHARDED_UNIQUE"] = "1" if unique else "0"
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     import _cpu_kernels as K
     from esrecsys_amd import sharded
+    if sort_limit is not None:  # only rank 0 may batch its owner-side sorts: the ranks sort differently, exchange alike
+        sharded._OWNER_SORT_BATCH_MAX = sort_limit if rank == 0 else 0
     st, pt = _full_tables()
     mk = lambda full: torch.from_numpy(np.ascontiguousarray(full[rank::WORLD]))  # noqa: E731
     scene = sharded.RowShardedTable(mk(st), torch.full_like(mk(st), 0.1), V_S)
     prod = sharded.RowShardedTable(mk(pt), torch.full_like(mk(pt), 0.1), V_P)
     towers = sharded.ShardedTableGroup([scene, prod], kernels=K)
+    assert towers.unique == (True if unique is None else unique)   # world 2: distinct rows once, unless switched off
     assert scene.local.shape[0] == sharded.RowShardedTable.local_rows_for(V_S, WORLD, rank)
     assert towers.voff[1] % WORLD == 0 and towers.voff[1] >= V_S
-    losses = []
+    losses, rows_sent, occurrences = [], 0, 0
     plans = None
     if grouped:
         # the routing plans of ALL the batches made together (bench_sharded.py, ESR_SHARDED_PLAN_GROUP): one counts
@@ -63,6 +78,11 @@ def _worker(rank, port, outdir, workload, grouped=False):
     for step in range(STEPS):
         sid, pid, nid = (torch.from_numpy(x) for x in _batch(step, rank))
         plan = plans[step] if plans is not None else None
+        if plan is None:  # (made here so that the rows that cross the exchange can be counted)
+            plan = sharded.plan_triplet(towers, sid, pid, nid) if workload == "triplet" else \
+                sharded.plan_inbatch(towers, sid, pid)
+        rows_sent += plan.n_rows
+        occurrences += plan.n
         if workload == "triplet":
             loss = sharded.sharded_triplet_step(towers, sid, pid, nid, LAM, float(WORLD * B), LR, plan=plan)
         else:
@@ -71,18 +91,20 @@ def _worker(rank, port, outdir, workload, grouped=False):
         dist.all_reduce(total)
         losses.append(float(total))
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), scene=scene.local.numpy(), prod=prod.local.numpy(),
-             scene_acc=scene.accum.numpy(), losses=np.array(losses))
+             scene_acc=scene.accum.numpy(), losses=np.array(losses), rows_sent=rows_sent, occurrences=occurrences)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run(workload, grouped=False):
+def _run(workload, grouped=False, unique=None, zipf=False, sort_limit=None):
     import socket
+    global ZIPF
+    ZIPF = zipf  # (the checking side draws the same batches)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(port, d, workload, grouped), nprocs=WORLD, join=True)
+        mp.spawn(_worker, args=(port, d, workload, grouped, unique, zipf, sort_limit), nprocs=WORLD, join=True)
         outs = [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(WORLD)]
     return outs
 
@@ -95,11 +117,21 @@ def _reassemble(outs, key, V):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("grouped", [False, True])
-def test_sharded_triplet_equals_single_device(grouped):
+@pytest.mark.parametrize("grouped,unique,zipf", [(False, None, False), (True, None, False), (False, False, False),
+                                                 (True, False, True), (False, True, True), (True, True, True)])
+def test_sharded_triplet_equals_single_device(grouped, unique, zipf):
+    """unique (the default at world 2): every distinct row crosses the exchange once and ONE summed gradient row goes
+    back -- with Zipf ids far fewer rows than occurrences, and still the single-device tables to 1e-12."""
     from oracle import optim as o_optim
     from oracle import stl_head as o_stl
-    outs = _run("triplet", grouped)
+    outs = _run("triplet", grouped, unique, zipf)
+    for o in outs:
+        if unique is False:
+            assert int(o["rows_sent"]) == int(o["occurrences"]) == 3 * B * STEPS
+        else:
+            assert int(o["rows_sent"]) < int(o["occurrences"])   # (sid[:3] = 5 alone makes two duplicates per batch)
+            if zipf:
+                assert int(o["rows_sent"]) < 0.8 * int(o["occurrences"])
     st, pt = _full_tables()
     a_s, a_p = np.full_like(st, 0.1), np.full_like(pt, 0.1)
     for step in range(STEPS):
@@ -117,13 +149,34 @@ def test_sharded_triplet_equals_single_device(grouped):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("grouped", [False, True])
-def test_sharded_inbatch_matches_per_rank_oracle(grouped):
+def test_grouped_plans_when_ranks_sort_differently():
+    """One rank batches its owner-side sorts, the other (past the batched sort's limit) sorts list by list: both must
+    issue the SAME ids exchanges (the decision how to exchange never looks at rank-local sizes) and the step must still
+    equal the single device."""
+    from oracle import optim as o_optim
+    from oracle import stl_head as o_stl
+    outs = _run("triplet", grouped=True, unique=False, sort_limit=1 << 20)
+    st, pt = _full_tables()
+    a_s, a_p = np.full_like(st, 0.1), np.full_like(pt, 0.1)
+    for step in range(STEPS):
+        parts = [_batch(step, r) for r in range(WORLD)]
+        sid, pid, nid = (np.concatenate([p[i] for p in parts]) for i in range(3))
+        _, gs, gp, gn = o_stl.triplet_loss_and_grads(st[sid], pt[pid], pt[nid], LAM, WORLD * B, np.float64)
+        st, a_s = o_optim.sparse_adagrad_update(st, a_s, sid, gs, LR, dtype=np.float64)
+        pt, a_p = o_optim.sparse_adagrad_update(pt, a_p, np.concatenate([pid, nid]), np.concatenate([gp, gn]), LR,
+                                                dtype=np.float64)
+    assert np.abs(_reassemble(outs, "scene", V_S) - st).max() <= 1e-12
+    assert np.abs(_reassemble(outs, "prod", V_P) - pt).max() <= 1e-12
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("grouped,unique,zipf", [(False, None, False), (True, False, False), (True, True, True)])
+def test_sharded_inbatch_matches_per_rank_oracle(grouped, unique, zipf):
     """In-batch negatives are per rank, so the single-device equivalent is: each rank's local-batch
     gradients (normalised by the global batch), scattered into one shared table."""
     from oracle import optim as o_optim
     from oracle import stl_head as o_stl
-    outs = _run("inbatch", grouped)
+    outs = _run("inbatch", grouped, unique, zipf)
     st, pt = _full_tables()
     a_s, a_p = np.full_like(st, 0.1), np.full_like(pt, 0.1)
     for step in range(STEPS):
@@ -142,8 +195,10 @@ def test_sharded_inbatch_matches_per_rank_oracle(grouped):
     assert np.abs(_reassemble(outs, "prod", V_P) - pt).max() <= 1e-12
 
 
-def _glove_worker(rank, port, outdir):
+def _glove_worker(rank, port, outdir, unique=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if unique is not None:
+        os.environ["ESR_SHARDED_UNIQUE"] = "1" if unique else "0"
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     import _cpu_kernels as K
     from esrecsys_amd import sharded
@@ -172,7 +227,8 @@ def _glove_worker(rank, port, outdir):
 
 
 @pytest.mark.timeout(300)
-def test_sharded_glove_with_prefetched_plans_equals_single_device():
+@pytest.mark.parametrize("unique", [None, False])
+def test_sharded_glove_with_prefetched_plans_equals_single_device(unique):
     """Diagonal-mode GloVe is a sum over pairs with a 1/B factor: G ranks x B pairs with the per-rank 1/B
     equals a single device applying each rank's batch gradients to one table."""
     import socket
@@ -182,7 +238,7 @@ def test_sharded_glove_with_prefetched_plans_equals_single_device():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_glove_worker, args=(port, d), nprocs=WORLD, join=True)
+        mp.spawn(_glove_worker, args=(port, d, unique), nprocs=WORLD, join=True)
         outs = [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(WORLD)]
     rng = np.random.default_rng(11)
     V, Dg, Bg = 97, 8, 20
