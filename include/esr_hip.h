@@ -252,7 +252,16 @@ int esr_inbatch_towers_fwd_bwd_bf16x3(const void* query_table, int64_t Vq, const
  * error (the kernels run at the chip's power limit, so fewer MFMAs is what shortens the step).  fp16's narrow range is
  * handled inside: a per-matrix power-of-two scale from the batch's largest |element|, and an exponent reference tied
  * to the true row maximum.  Pass C reads the B x B probabilities pass Q stored: D <= 128 and a multiple of 4 (narrower
- * rows are zero-padded into the 128-column tiles; gQ / gC are [B, D]), B a multiple of 128 and <= 16384 (workspace ~ 4 B^2 bytes); esr_inbatch2h_workspace_bytes returns 256 for a B it cannot serve. */
+ * rows are zero-padded into the 128-column tiles; gQ / gC are [B, D]), B a multiple of 128 and <= 16384 (workspace ~ 4 B^2 bytes); esr_inbatch2h_workspace_bytes returns 256 for a B it cannot serve.
+ * GUARANTEED ERROR (tests/test_gpu_kernels.py): an operand element x of a matrix whose largest |element| is M enters the
+ * products as x (1 + d) + a with |d| <= 2^-24 and |a| <= 2^-26 M 2^-16 -- relative for elements within 2^-16 of M,
+ * absolute below.  Consequences that are asserted against the fp64 oracle: loss, lse and norm-wise gradients within 1e-5
+ * (every shape / range test); every gradient entry within 1e-4 of max(|entry|, 1e-3 of the largest entry) at C2 size;
+ * with row norms spread over FOUR decades inside each matrix (a few hot rows 100 x the median) every 128-row block of
+ * gQ / gC within 2e-5 of the block's own largest entry and every row within 1e-4 of its own (measured 1.6e-6 / 1.7e-6,
+ * the exact-f32 MFMA path measures 1.5e-6 / 3.5e-6); a 20-step training trajectory at C2 size within 1e-5 on every loss
+ * and norm-wise on tables and accumulators (measured 1e-6).  A matrix whose rows span MORE than ~2^16 in magnitude should
+ * take the bf16x3 entry points, whose three planes are an exact split of every element. */
 size_t esr_inbatch2h_workspace_bytes(int64_t B, int D);
 int esr_inbatch_softmax_fwd_bwd_f16x2(const float* Q, const float* C, int64_t B, int D, float scale,
                                       float regularization, float batch_size, float* loss, float* lse,
