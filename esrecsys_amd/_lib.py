@@ -59,6 +59,7 @@ SIGNATURES = {
     "esr_unique_by_owner_workspace_bytes": (c_size, [c_i64]),
     "esr_unique_by_owner": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_i64, c_i32p, c_i32p, c_i32p, c_i32p, c_vp, c_vp,
                                     c_size, c_vp]),
+    "esr_topk_columns": (c_int, [c_f32p, c_i64, c_int, c_int, c_f32p, c_i32p, c_vp]),
     "esr_long_run_hint": (c_int, [c_i32p, c_i64, c_int, c_vp, c_int32, c_vp]),
     "esr_rows_consolidate": (c_int, [c_f32p, c_f32p, c_vp, c_i64, c_int, c_vp]),
     "esr_rows_restamp": (c_int, [c_vp, c_i64, c_vp]),

@@ -953,6 +953,32 @@ int esr_rescore_candidates(const float* queries, const float* candidates, int64_
   return check_launch("esr_rescore_candidates");
 }
 
+__global__ __launch_bounds__(256) void flip_indices_kernel(int32_t* __restrict__ idx, int64_t n, int32_t last) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) idx[i] = last - idx[i];
+}
+
+// The k LAST rows of the stable ascending argsort of every column of scores [V, T] (find_knn / dump_knn,
+// wikipedia/train_cooccurence.py:91-97,114-126, read the last 10) without sorting the column: the radix select over the
+// column read BACKWARDS -- position c = row V - 1 - c, so among equal scores the select's "lower position first" is the
+// stable argsort's "higher row last" -- then the positions are turned back into rows.  Output [T, k], best first:
+// out[t][j] = argsort(scores[:, t])[V - 1 - j].
+int esr_topk_columns(const float* scores, int64_t V, int T, int k, float* out_scores, int32_t* out_indices,
+                     esr_stream_t stream) {
+  ESR_REQUIRE(V > 0 && T > 0 && k > 0 && k <= V && k <= kSelMaxK && V < ((int64_t)1 << 31),
+              "esr_topk_columns: bad sizes V=%lld T=%d k=%d (k <= %d)", (long long)V, T, k, kSelMaxK);
+  ESR_REQUIRE(scores && out_scores && out_indices, "esr_topk_columns: null pointer");
+  hipStream_t st = as_stream(stream);
+  SelIn in;
+  in.vals = scores + (V - 1) * T; in.vpitch = 1; in.idx = nullptr; in.stride = -T; in.ibase = 0; in.istep = 1;
+  in.n_per_row = nullptr; in.n_fixed = (int)V;
+  SelOut so;
+  so.pairs = nullptr; so.ppitch = 0; so.cnt = nullptr; so.tau = nullptr; so.scores = out_scores; so.indices = out_indices;
+  hipLaunchKernelGGL(topk_select_kernel, dim3(T), dim3(kSelThreads), 0, st, in, k, so, 0);
+  hipLaunchKernelGGL(flip_indices_kernel, dim3((int)std::min<int64_t>(64, cdiv((int64_t)T * k, 256))), dim3(256), 0, st,
+                     out_indices, (int64_t)T * k, (int32_t)(V - 1));
+  return check_launch("esr_topk_columns");
+}
+
 int esr_topk_merge(const float* scores, const int32_t* indices, int64_t nq, int n, int k, float* out_scores,
                    int32_t* out_indices, esr_stream_t stream) {
   ESR_REQUIRE(nq > 0 && n > 0 && k > 0 && k <= n && k <= kSelMaxK, "esr_topk_merge: bad sizes nq=%lld n=%d k=%d",

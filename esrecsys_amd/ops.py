@@ -293,6 +293,18 @@ def segment_sum_rows(rows_out, sorted_ids, perm, grad_rows):
     return out
 
 
+def topk_columns(scores, k):
+    """(values [T, k], rows [T, k]) of the k largest entries of every column of scores [V, T], best first, ties as the
+    stable ascending argsort orders them (the higher row counts as larger): esr_topk_columns, k <= 1024."""
+    lib = _lib.load()
+    _req(scores, torch.float32, "scores")
+    V, T_ = scores.shape
+    out_s = torch.empty((T_, k), dtype=torch.float32, device=scores.device)
+    out_i = torch.empty((T_, k), dtype=torch.int32, device=scores.device)
+    check(lib.esr_topk_columns(_p(scores), V, T_, int(k), _p(out_s), _p(out_i), _stream()), "esr_topk_columns")
+    return out_s, out_i
+
+
 def long_run_hint(sorted_ids, chunk, hint, gen):
     """hint[0] = gen when sorted_ids has a run of equal ids longer than `chunk` positions (esr_long_run_hint); `hint` is
     an int32 tensor on the device or in pinned host memory."""

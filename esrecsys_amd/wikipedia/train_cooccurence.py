@@ -67,11 +67,49 @@ def apply_model(state, inputs, target):
     return grads, loss.reshape(())
 
 
+class ColumnArgsort:
+    """``indices`` of find_knn: the stable ascending argsort of every column of `scores` [V, T], computed ON DEMAND.
+    The reference's only consumer reads the last ten rows (dump_knn, wikipedia/train_cooccurence.py:114-126), so
+    ``indices[-k:]`` (k <= 1024) is a radix select per column (esr_topk_columns) -- exactly the rows the full argsort would
+    put there, ties included -- and the full [V, T] argsort (``indices.full()``, any other indexing, ``.cpu()``) is only
+    run for a caller that really reads all of it."""
+
+    def __init__(self, scores):
+        self._scores = scores
+        self._full = None
+        self.shape = tuple(scores.shape)
+        self.dtype = torch.int32
+        self.device = scores.device
+
+    def top(self, k):
+        """(values [k, T], rows [k, T]) of the k largest entries of every column, best first."""
+        s, i = ops.topk_columns(self._scores, k)
+        return s.t().contiguous(), i.t().contiguous()
+
+    def full(self):
+        if self._full is None:
+            self._full = ops.argsort_columns(self._scores)
+        return self._full
+
+    def __getitem__(self, key):
+        V = self.shape[0]
+        if self._full is None and isinstance(key, slice) and key.step is None and key.stop is None and \
+                isinstance(key.start, int) and key.start < 0 and -key.start <= min(V, 1024):
+            return self.top(-key.start)[1].flip(0)      # rows V - k .. V - 1 of the ascending argsort
+        return self.full()[key]
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getattr__(self, name):  # anything else a tensor can do: on the full argsort
+        return getattr(self.full(), name)
+
+
 def find_knn(model, params, token):
-    """scores [V, T] and the full stable ascending argsort over V (wikipedia/train_cooccurence.py:91-97)."""
+    """scores [V, T] and ``indices``, the stable ascending argsort over V of every column (wikipedia/train_cooccurence.py:
+    91-97) -- as a ColumnArgsort: ``indices[-10:]`` (all the reference reads) costs a radix select, not a sort of V."""
     scores = model.apply({"params": params}, token, method=Glove.score_all)
-    indices = ops.argsort_columns(scores)
-    return scores, indices
+    return scores, ColumnArgsort(scores)
 
 
 def update_model(state, grads):
@@ -464,8 +502,9 @@ def dump_knn(model, params, tokens, token_dictionary):
     """Dumps the 10 nearest neighbours of each probe token (wikipedia/train_cooccurence.py:114-126)."""
     scores, indices = find_knn(model, params, tokens)
     tokens_h = np.asarray(tokens.cpu() if isinstance(tokens, torch.Tensor) else tokens)
-    top = indices[-10:].flip(0).cpu().numpy()                      # rows -1 .. -10
-    top_scores = torch.gather(scores, 0, indices[-10:].flip(0).long()).cpu().numpy()
+    top_scores, top = indices.top(10) if isinstance(indices, ColumnArgsort) else \
+        (torch.gather(scores, 0, indices[-10:].flip(0).long()), indices[-10:].flip(0))   # rows -1 .. -10
+    top, top_scores = top.cpu().numpy(), top_scores.cpu().numpy()
     lines = []
     for i in range(tokens_h.shape[0]):
         query_word = token_dictionary.get_token_from_embedding_index(int(tokens_h[i]))

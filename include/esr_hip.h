@@ -343,6 +343,11 @@ int esr_dense_adam(float* param, float* mu, float* nu, const float* grad, int64_
  * indices = stable ascending argsort of every column ([V, T] int32). */
 int esr_score_all(const float* emb, int64_t V, int D, const int32_t* token, int T, float* scores,
                   esr_stream_t stream);
+/* The k last rows of that argsort without sorting the columns (what dump_knn reads: train_cooccurence.py:114-126 takes
+ * indices[-10:]): a radix select per column, k <= 1024.  out_indices / out_scores [T, k], best first:
+ * out_indices[t][j] = argsort(scores[:, t])[V - 1 - j], ties exactly as the stable ascending argsort leaves them. */
+int esr_topk_columns(const float* scores, int64_t V, int T, int k, float* out_scores, int32_t* out_indices,
+                     esr_stream_t stream);
 size_t esr_argsort_columns_workspace_bytes(int64_t V, int T);
 int esr_argsort_columns(const float* scores, int64_t V, int T, int32_t* indices, void* workspace,
                         size_t workspace_bytes, esr_stream_t stream);

@@ -981,6 +981,25 @@ def test_score_all_and_argsort_vs_golden_with_ties(dev):
     assert idx.dtype == torch.int32 and np.array_equal(N(idx), g["knn_indices"])
 
 
+@pytest.mark.parametrize("V,T_,k", [(500, 5, 10), (465_537, 8, 10), (70_000, 3, 1024), (40, 2, 40), (3000, 1, 1)])
+def test_topk_columns_equals_the_tail_of_the_stable_argsort(dev, V, T_, k):
+    """dump_knn reads indices[-10:] (wikipedia/train_cooccurence.py:114-126): the radix select per column must give exactly
+    the rows the full stable ascending argsort puts last -- ties included (scores on a coarse grid: thousands of them;
+    among equal scores the HIGHER row sorts later) -- through ops.topk_columns and through find_knn's lazy indices."""
+    from esrecsys_amd import ops
+    from esrecsys_amd.wikipedia.train_cooccurence import ColumnArgsort
+    rng = np.random.default_rng(V + k)
+    scores = T((rng.integers(-40, 40, (V, T_)) / 4.0).astype(np.float32), dev)
+    full = N(ops.argsort_columns(scores)).astype(np.int64)
+    s, i = ops.topk_columns(scores, k)
+    assert np.array_equal(N(i).T, full[::-1][:k])
+    assert np.array_equal(N(s).T, np.take_along_axis(N(scores), full[::-1][:k], axis=0))
+    lazy = ColumnArgsort(scores)
+    assert np.array_equal(N(lazy[-k:]), full[-k:]) and lazy._full is None      # no full sort was run for the tail
+    assert np.array_equal(N(lazy[: 7]), full[:7]) and lazy._full is not None   # anything else materialises it
+    assert lazy.shape == (V, T_) and np.array_equal(N(lazy), full)
+
+
 def test_find_top_k_vs_golden_with_ties(dev):
     from esrecsys_amd import ops
     g = load_golden("topk_n500_d8_k10")
