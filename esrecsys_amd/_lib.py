@@ -60,6 +60,17 @@ SIGNATURES = {
     "esr_unique_by_owner": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_i64, c_i32p, c_i32p, c_i32p, c_i32p, c_vp, c_vp,
                                     c_size, c_vp]),
     "esr_topk_columns": (c_int, [c_f32p, c_i64, c_int, c_int, c_f32p, c_i32p, c_vp]),
+    "esr_momentum_catchup_rows": (c_int, [c_f32p, c_f32p, c_i32p, c_i64, c_int, c_i32p, c_i64, c_int, c_int, c_f32, c_f32,
+                                          c_vp]),
+    "esr_sparse_momentum_step": (c_int, [c_f32p, c_f32p, c_i64, c_int, c_i32p, c_i32p, c_i64, c_f32p, c_f32, c_f32, c_vp]),
+    "esr_momentum_flush": (c_int, [c_f32p, c_f32p, c_i32p, c_i64, c_int, c_int, c_f32, c_f32, c_vp]),
+    "esr_momentum_catchup_rows2": (c_int, [c_f32p, c_f32p, c_i32p, c_i32p, c_int, c_f32p, c_f32p, c_i32p, c_i32p, c_int, c_int,
+                                           c_i64, c_int, c_f32, c_f32, c_vp]),
+    "esr_sparse_momentum_step_multi": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_i32p, c_i32p, c_i64, c_f32p, c_f32, c_f32,
+                                               c_vp]),
+    "esr_spotify_train_step_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int]),
+    "esr_spotify_train_step": (c_int, [c_f32p, c_f32p, c_i32p, c_i64, c_f32p, c_f32p, c_i32p, c_i64, c_int, c_i32p, c_i32p,
+                                       c_int, c_int, c_int, c_f32, c_int, c_f32, c_f32, c_f32p, c_vp, c_size, c_vp]),
     "esr_long_run_hint": (c_int, [c_i32p, c_i64, c_int, c_vp, c_int32, c_vp]),
     "esr_rows_consolidate": (c_int, [c_f32p, c_f32p, c_vp, c_i64, c_int, c_vp]),
     "esr_rows_restamp": (c_int, [c_vp, c_i64, c_vp]),

@@ -20,7 +20,7 @@
 
 namespace esr {
 
-enum SegOp { kAdagrad = 0, kSgd = 1, kToDense = 2, kMomentum = 3 };
+enum SegOp { kAdagrad = 0, kSgd = 1, kToDense = 2, kMomentum = 3, kMomentumStep = 4 };
 
 template <int VEC, int NCH>
 __device__ __forceinline__ void param_load(RowRegs<VEC, NCH>& r, const void* table, int dtype, int64_t row, int D,
@@ -115,6 +115,22 @@ __device__ __forceinline__ void seg_apply(const FusedTables& ft, int dtype, int3
       for (int e = 0; e < VEC; ++e) {
         a.v[k][e] += g.v[k][e];
         w.v[k][e] -= lr * g.v[k][e];
+      }
+    row_store(a, accum + id * D, lig, G, nvec);
+    param_store(w, table, dtype, id, D, lig, G, nvec);
+  } else if (OP == kMomentumStep) {
+    // one WHOLE step of optax.sgd(lr, momentum) on a touched row (lazy mode: no dense decay pass runs; the row was
+    // brought up to the previous step by momentum_catchup_kernel): trace = g + momentum * trace ; p -= lr * trace, in
+    // optax's own order and with explicit roundings.  `eps` carries the momentum.
+    RowRegs<VEC, NCH> w, a;
+    param_load(w, table, dtype, id, D, lig, G, nvec);
+    row_load(a, accum + id * D, lig, G, nvec);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        a.v[k][e] = __fadd_rn(g.v[k][e], __fmul_rn(eps, a.v[k][e]));
+        w.v[k][e] = __fsub_rn(w.v[k][e], __fmul_rn(lr, a.v[k][e]));
       }
     row_store(a, accum + id * D, lig, G, nvec);
     param_store(w, table, dtype, id, D, lig, G, nvec);
@@ -448,11 +464,179 @@ __global__ __launch_bounds__(kBlock) void momentum_decay_kernel(float* __restric
   }
 }
 
+// ---- lazy momentum (Spotify step, spotify/train_spotify.py:238-241) ----------------------------------------------------
+// optax.sgd(lr, momentum) moves EVERY element every step (a row without a gradient keeps coasting on its trace), which
+// made the decay half a dense pass over both tables: 80 % of the step's bytes.  A row that gets no gradient for n steps
+// only undergoes  trace *= momentum ; p -= lr * trace  n times -- a function of n alone -- so it can be applied when the
+// row is next READ: last[row] = the step the row is up to date with.  n <= kLazyExact steps are applied one by one (the
+// very operations of the dense pass: bit-identical to it -- rows that are read again soon, the hot part of a playlist
+// stream); longer gaps by the closed form  trace *= m^n ; p -= lr * trace0 * m (1 - m^n) / (1 - m)  (1e-7-close: one
+// rounding instead of n; a walk of thousands of dependent steps per element made the catch-up launch 10 us).
+constexpr int kLazyExact = 64;
+__device__ __forceinline__ void decay_steps(float& p, float& t, int n, float lr, float m) {
+  if (n <= kLazyExact) {
+    for (int i = 0; i < n; ++i) {
+      t = __fmul_rn(t, m);
+      p = __fsub_rn(p, __fmul_rn(lr, t));
+    }
+  } else {
+    const float mn = powf(m, (float)n);
+    p = p - lr * t * (m * (1.0f - mn) / (1.0f - m));
+    t = t * mn;
+  }
+}
+
+struct CatchupTables {  // up to two same-width tables caught up by one launch (blockIdx.y = the table)
+  float* table[2];
+  float* trace[2];
+  int32_t* last[2];
+  const int32_t* ids[2];
+  int modulus[2];
+};
+
+// bring the rows ids[i] % modulus (modulus 0: ids[i]) up to step `now - 1` and mark them as handled for step `now`: the
+// group whose exchange on last[row] returns an older step owns the row, every other occurrence of it skips
+template <int VEC, int NCH>
+__global__ __launch_bounds__(kBlock) void momentum_catchup_kernel(CatchupTables ct, int D, int G, int64_t n, int now,
+                                                                 float lr, float m) {
+  const int y = blockIdx.y;
+  float* __restrict__ table = y ? ct.table[1] : ct.table[0];
+  float* __restrict__ trace = y ? ct.trace[1] : ct.trace[0];
+  int32_t* __restrict__ last = y ? ct.last[1] : ct.last[0];
+  const int32_t* __restrict__ ids = y ? ct.ids[1] : ct.ids[0];
+  const int modulus = y ? ct.modulus[1] : ct.modulus[0];
+  const int lig = threadIdx.x & (G - 1);
+  const int64_t gpb = kBlock / G;
+  const int nvec = D / VEC;
+  for (int64_t i = (int64_t)blockIdx.x * gpb + threadIdx.x / G; i < n; i += (int64_t)gridDim.x * gpb) {
+    const int32_t row = modulus > 0 ? ids[i] % modulus : ids[i];
+    int old = 0;
+    if (lig == 0) old = atomicExch(&last[row], now);
+    old = __shfl(old, (threadIdx.x & 63) & ~(G - 1), kWave);
+    const int steps = now - 1 - old;
+    if (steps <= 0) continue;
+    RowRegs<VEC, NCH> w, a;
+    row_load(w, table + (int64_t)row * D, lig, G, nvec);
+    row_load(a, trace + (int64_t)row * D, lig, G, nvec);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) decay_steps(w.v[k][e], a.v[k][e], steps, lr, m);
+    row_store(w, table + (int64_t)row * D, lig, G, nvec);
+    row_store(a, trace + (int64_t)row * D, lig, G, nvec);
+  }
+}
+
+// every row up to step `now` (before an eval, a checkpoint, or anybody reading the plain tables)
+template <int VEC, int NCH>
+__global__ __launch_bounds__(kBlock) void momentum_flush_kernel(float* __restrict__ table, float* __restrict__ trace,
+                                                               int32_t* __restrict__ last, int64_t V, int D, int G,
+                                                               int now, float lr, float m) {
+  const int lig = threadIdx.x & (G - 1);
+  const int64_t gpb = kBlock / G;
+  const int nvec = D / VEC;
+  for (int64_t row = (int64_t)blockIdx.x * gpb + threadIdx.x / G; row < V; row += (int64_t)gridDim.x * gpb) {
+    const int steps = now - last[row];
+    if (steps <= 0) continue;
+    RowRegs<VEC, NCH> w, a;
+    row_load(w, table + row * D, lig, G, nvec);
+    row_load(a, trace + row * D, lig, G, nvec);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) decay_steps(w.v[k][e], a.v[k][e], steps, lr, m);
+    row_store(w, table + row * D, lig, G, nvec);
+    row_store(a, trace + row * D, lig, G, nvec);
+    if (lig == 0) last[row] = now;
+  }
+}
+
 }  // namespace esr
 
 using namespace esr;
 
 extern "C" {
+
+int esr_momentum_catchup_rows(float* table, float* trace, int32_t* last, int64_t V, int D, const int32_t* ids, int64_t n,
+                              int modulus, int step, float lr, float momentum, esr_stream_t stream) {
+  ESR_REQUIRE(V > 0 && D > 0 && n >= 0 && step >= 1 && modulus >= 0, "esr_momentum_catchup_rows: bad arguments");
+  if (n == 0) return ESR_OK;
+  ESR_REQUIRE(table && trace && last && ids, "esr_momentum_catchup_rows: null pointer");
+  const RowGeom g = row_geom(D);
+  ESR_REQUIRE(g.nch <= kMaxChunksPerLane, "esr_momentum_catchup_rows: D=%d not supported", D);
+  const int grid = grid_for_groups(n, g.G);
+  CatchupTables ct{{table, nullptr}, {trace, nullptr}, {last, nullptr}, {ids, nullptr}, {modulus, 0}};
+  ESR_DISPATCH_ROW(g, hipLaunchKernelGGL((momentum_catchup_kernel<VEC, NCH>), dim3(grid, 1), dim3(kBlock), 0,
+                                         as_stream(stream), ct, D, g.G, n, step, lr, momentum));
+  return check_launch("esr_momentum_catchup_rows");
+}
+
+// two same-width tables, n ids each, one launch (the Spotify step: albums hashed by modulus0, artists as they are)
+int esr_momentum_catchup_rows2(float* table0, float* trace0, int32_t* last0, const int32_t* ids0, int modulus0,
+                               float* table1, float* trace1, int32_t* last1, const int32_t* ids1, int modulus1, int D,
+                               int64_t n, int step, float lr, float momentum, esr_stream_t stream) {
+  ESR_REQUIRE(D > 0 && n >= 0 && step >= 1 && modulus0 >= 0 && modulus1 >= 0, "esr_momentum_catchup_rows2: bad arguments");
+  if (n == 0) return ESR_OK;
+  ESR_REQUIRE(table0 && trace0 && last0 && ids0 && table1 && trace1 && last1 && ids1,
+              "esr_momentum_catchup_rows2: null pointer");
+  const RowGeom g = row_geom(D);
+  ESR_REQUIRE(g.nch <= kMaxChunksPerLane, "esr_momentum_catchup_rows2: D=%d not supported", D);
+  const int grid = grid_for_groups(n, g.G);
+  CatchupTables ct{{table0, table1}, {trace0, trace1}, {last0, last1}, {ids0, ids1}, {modulus0, modulus1}};
+  ESR_DISPATCH_ROW(g, hipLaunchKernelGGL((momentum_catchup_kernel<VEC, NCH>), dim3(grid, 2), dim3(kBlock), 0,
+                                         as_stream(stream), ct, D, g.G, n, step, lr, momentum));
+  return check_launch("esr_momentum_catchup_rows2");
+}
+
+// the whole momentum step on the touched rows of several same-width tables addressed by virtual rows, one launch pair
+int esr_sparse_momentum_step_multi(float* const* tables, float* const* traces, const int64_t* row_offsets, int ntables,
+                                   int D, const int32_t* sorted_vids, const int32_t* perm, int64_t n, float* grad_rows,
+                                   float lr, float momentum, esr_stream_t stream) {
+  ESR_REQUIRE(ntables >= 1 && ntables <= kMaxFusedTables && D > 0 && n >= 0,
+              "esr_sparse_momentum_step_multi: ntables=%d not in [1, %d] or bad sizes", ntables, kMaxFusedTables);
+  if (n == 0) return ESR_OK;
+  ESR_REQUIRE(tables && traces && row_offsets && sorted_vids && perm && grad_rows,
+              "esr_sparse_momentum_step_multi: null pointer");
+  FusedTables ft;
+  ft.n = ntables;
+  for (int i = 0; i < kMaxFusedTables; ++i) {
+    ft.table[i] = i < ntables ? tables[i] : nullptr;
+    ft.accum[i] = i < ntables ? traces[i] : nullptr;
+    ft.row_offset[i] = i <= ntables ? row_offsets[i] : row_offsets[ntables];
+    if (i < ntables) {
+      ESR_REQUIRE(tables[i] && traces[i] && row_offsets[i + 1] >= row_offsets[i],
+                  "esr_sparse_momentum_step_multi: bad table %d", i);
+    }
+  }
+  ft.row_offset[kMaxFusedTables] = row_offsets[ntables];
+  ESR_REQUIRE(row_offsets[ntables] < ((int64_t)1 << 31), "esr_sparse_momentum_step_multi: %lld virtual rows >= 2^31",
+              (long long)row_offsets[ntables]);
+  return launch_segment_tables<kMomentumStep>("esr_sparse_momentum_step_multi", ft, ESR_F32, D, sorted_vids, perm, n,
+                                              grad_rows, lr, momentum, as_stream(stream));
+}
+
+int esr_momentum_flush(float* table, float* trace, int32_t* last, int64_t V, int D, int step, float lr, float momentum,
+                       esr_stream_t stream) {
+  ESR_REQUIRE(V > 0 && D > 0 && step >= 0, "esr_momentum_flush: bad arguments");
+  ESR_REQUIRE(table && trace && last, "esr_momentum_flush: null pointer");
+  const RowGeom g = row_geom(D);
+  ESR_REQUIRE(g.nch <= kMaxChunksPerLane, "esr_momentum_flush: D=%d not supported", D);
+  const int grid = grid_for_groups(V, g.G);
+  ESR_DISPATCH_ROW(g, hipLaunchKernelGGL((momentum_flush_kernel<VEC, NCH>), dim3(grid), dim3(kBlock), 0, as_stream(stream),
+                                         table, trace, last, V, D, g.G, step, lr, momentum));
+  return check_launch("esr_momentum_flush");
+}
+
+int esr_sparse_momentum_step(float* table, float* trace, int64_t V, int D, const int32_t* sorted_ids,
+                             const int32_t* perm, int64_t n, float* grad_rows, float lr, float momentum,
+                             esr_stream_t stream) {
+  ESR_REQUIRE(V > 0 && D > 0 && n >= 0, "esr_sparse_momentum_step: bad sizes V=%lld D=%d n=%lld", (long long)V, D,
+              (long long)n);
+  if (n == 0) return ESR_OK;
+  ESR_REQUIRE(table && trace && sorted_ids && perm && grad_rows, "esr_sparse_momentum_step: null pointer");
+  return launch_segment_update<kMomentumStep>("esr_sparse_momentum_step", table, ESR_F32, trace, D, sorted_ids, perm, n,
+                                              grad_rows, lr, momentum, as_stream(stream));
+}
 
 int esr_dense_momentum_decay(float* param, float* trace, int64_t count, float lr, float momentum,
                              esr_stream_t stream) {

@@ -500,6 +500,71 @@ int esr_spotify_fwd_bwd(const float* album_table, int64_t n_album_rows, const fl
   return check_launch("esr_spotify_fwd_bwd");
 }
 
+// in esr_optim.hip
+extern "C" int esr_momentum_catchup_rows2(float* table0, float* trace0, int32_t* last0, const int32_t* ids0, int modulus0,
+                                          float* table1, float* trace1, int32_t* last1, const int32_t* ids1, int modulus1,
+                                          int D, int64_t n, int step, float lr, float momentum, esr_stream_t stream);
+extern "C" int esr_sparse_momentum_step_multi(float* const* tables, float* const* traces, const int64_t* row_offsets,
+                                              int ntables, int D, const int32_t* sorted_vids, const int32_t* perm, int64_t n,
+                                              float* grad_rows, float lr, float momentum, esr_stream_t stream);
+
+size_t esr_spotify_train_step_workspace_bytes(int n, int m, int o, int F) {
+  if (n <= 0 || m <= 0 || o <= 0 || F <= 0) return 256;
+  const size_t R = (size_t)(n + m + o);
+  return align_up(sp_layout(nullptr, n, m, o, F).total, 256) + align_up(2 * R * F * 4, 256) + 3 * align_up(2 * R * 4, 256) +
+         esr_segment_sort_workspace_bytes(2 * (int64_t)R);
+}
+
+// train_spotify.py:77-111 + 238-241 in ONE call: the playlist's rows caught up (lazy optax.sgd(lr, momentum)), the
+// six-term loss and its per-occurrence gradient rows, one sort of the virtual rows [album mod rows ; n_album_rows + artist]
+// and the whole momentum step on the touched rows of both tables -- eight launches, one foreign call (the step is
+// launch-bound: fourteen launches from Python took ~100 us of host time for ~60 us of kernels).
+int esr_spotify_train_step(float* album_table, float* album_trace, int32_t* album_last, int64_t n_album_rows,
+                           float* artist_table, float* artist_trace, int32_t* artist_last, int64_t n_artists, int F,
+                           const int32_t* album_ids, const int32_t* artist_ids, int n, int m, int o, float regularization,
+                           int step, float lr, float momentum, float* loss, void* workspace, size_t workspace_bytes,
+                           esr_stream_t stream) {
+  if (int rc = sp_check("esr_spotify_train_step", n, m, o, F, n_album_rows, n_artists)) return rc;
+  ESR_REQUIRE(album_table && album_trace && album_last && artist_table && artist_trace && artist_last && album_ids &&
+                  artist_ids && loss && workspace && step >= 1,
+              "esr_spotify_train_step: null pointer or step < 1");
+  ESR_REQUIRE(n_album_rows < ((int64_t)1 << 30) && n_artists < ((int64_t)1 << 30), "esr_spotify_train_step: tables too large");
+  if (workspace_bytes < esr_spotify_train_step_workspace_bytes(n, m, o, F) || ((uintptr_t)workspace & 15)) {
+    set_error("esr_spotify_train_step: workspace %zu bytes < %zu required (or misaligned)", workspace_bytes,
+              esr_spotify_train_step_workspace_bytes(n, m, o, F));
+    return ESR_EWORKSPACE;
+  }
+  const int64_t R = n + m + o;
+  char* base = (char*)workspace;
+  size_t off = align_up(sp_layout(nullptr, n, m, o, F).total, 256);
+  float* grads = (float*)(base + off);             // [2R, F]: album gradient rows, then artist gradient rows
+  off += align_up(2 * (size_t)R * F * 4, 256);
+  int32_t* album_rows = (int32_t*)(base + off);    // [R] hashed album ids (spotify_gather_kernel)
+  off += align_up(2 * (size_t)R * 4, 256);
+  int32_t* sorted = (int32_t*)(base + off);
+  off += align_up(2 * (size_t)R * 4, 256);
+  int32_t* perm = (int32_t*)(base + off);
+  off += align_up(2 * (size_t)R * 4, 256);
+  void* sort_ws = base + off;
+  if (int rc = esr_momentum_catchup_rows2(album_table, album_trace, album_last, album_ids, (int)n_album_rows, artist_table,
+                                          artist_trace, artist_last, artist_ids, 0, F, R, step, lr, momentum, stream))
+    return rc;
+  if (int rc = esr_spotify_fwd_bwd(album_table, n_album_rows, artist_table, n_artists, F, album_ids, artist_ids, n, m, o,
+                                   regularization, loss, album_rows, grads, grads + R * F, workspace,
+                                   sp_layout(nullptr, n, m, o, F).total, stream))
+    return rc;
+  const int32_t* segs[2] = {album_rows, artist_ids};
+  const int64_t counts[2] = {R, R};
+  const int64_t offsets[2] = {0, n_album_rows};
+  if (int rc = esr_segment_sort_ids_multi(segs, counts, offsets, 2, n_album_rows + n_artists, sorted, perm, sort_ws,
+                                          esr_segment_sort_workspace_bytes(2 * R), stream))
+    return rc;
+  float* tables[2] = {album_table, artist_table};
+  float* traces[2] = {album_trace, artist_trace};
+  const int64_t row_offsets[3] = {0, n_album_rows, n_album_rows + n_artists};
+  return esr_sparse_momentum_step_multi(tables, traces, row_offsets, 2, F, sorted, perm, 2 * R, grads, lr, momentum, stream);
+}
+
 int esr_spotify_affinity_all(const float* album_table, int64_t n_album_rows, const float* artist_table,
                              int64_t n_artists, int F, const int32_t* ctx_album, const int32_t* ctx_artist, int n,
                              const int32_t* all_albums, const int32_t* all_artists, int64_t T, float* affinity,

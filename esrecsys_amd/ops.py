@@ -653,6 +653,34 @@ def sparse_momentum(table, trace, sorted_ids, perm, grad_rows, lr):
                                           _p(grad_rows), float(lr), _stream()), "esr_sparse_momentum_scatter")
 
 
+def momentum_catchup_rows(table, trace, last, ids, modulus, step, lr, momentum):
+    """Lazy optax.sgd(lr, momentum): bring the rows ids % modulus (modulus 0: ids) up to step - 1 and mark them `step`."""
+    lib = _lib.load()
+    _req(table, torch.float32, "table"), _req(trace, torch.float32, "trace"), _req(last, torch.int32, "last")
+    ids = _req(ids, torch.int32, "ids")
+    V, D = table.shape
+    check(lib.esr_momentum_catchup_rows(_p(table), _p(trace), _p(last), V, D, _p(ids), ids.numel(), int(modulus), int(step),
+                                        float(lr), float(momentum), _stream()), "esr_momentum_catchup_rows")
+
+
+def sparse_momentum_step(table, trace, sorted_ids, perm, grad_rows, lr, momentum):
+    """In place on the touched rows: trace = g + momentum * trace ; table -= lr * trace (duplicates summed first)."""
+    lib = _lib.load()
+    _req(table, torch.float32, "table"), _req(trace, torch.float32, "trace"), _req(grad_rows, torch.float32, "grad_rows")
+    V, D = table.shape
+    check(lib.esr_sparse_momentum_step(_p(table), _p(trace), V, D, _p(sorted_ids), _p(perm), sorted_ids.numel(),
+                                       _p(grad_rows), float(lr), float(momentum), _stream()), "esr_sparse_momentum_step")
+
+
+def momentum_flush(table, trace, last, step, lr, momentum):
+    """Bring every row of a lazily updated table up to `step`."""
+    lib = _lib.load()
+    _req(table, torch.float32, "table"), _req(trace, torch.float32, "trace"), _req(last, torch.int32, "last")
+    V, D = table.shape
+    check(lib.esr_momentum_flush(_p(table), _p(trace), _p(last), V, D, int(step), float(lr), float(momentum), _stream()),
+          "esr_momentum_flush")
+
+
 def spotify_get_embeddings(album_table, artist_table, album_ids, artist_ids):
     """[count, 2F] = concat(album_table[album mod rows], artist_table[artist]) (spotify/models.py:37-51)."""
     lib = _lib.load()
@@ -698,6 +726,27 @@ def spotify_fwd_bwd(album_table, artist_table, album_ids, artist_ids, n, m, o, r
                                   _p(album_ids), _p(artist_ids), n, m, o, float(regularization), _p(loss), _p(rows),
                                   _p(ga), _p(gr), _p(ws), ws.numel(), _stream()), "esr_spotify_fwd_bwd")
     return loss, rows, ga, gr
+
+
+def spotify_train_step(album_table, album_trace, album_last, artist_table, artist_trace, artist_last, album_ids,
+                       artist_ids, n, m, o, regularization, step, lr, momentum):
+    """One whole Spotify train step under lazy optax.sgd(lr, momentum) by ONE library call (esr_spotify_train_step): catch
+    the playlist's rows up, loss + gradient rows, one sort, the momentum step on the touched rows of both tables.
+    Returns loss[1]."""
+    lib = _lib.load()
+    for t, name in ((album_table, "album_table"), (album_trace, "album_trace"), (artist_table, "artist_table"),
+                    (artist_trace, "artist_trace")):
+        _req(t, torch.float32, name)
+    _req(album_last, torch.int32, "album_last"), _req(artist_last, torch.int32, "artist_last")
+    album_ids, artist_ids = _req(album_ids, torch.int32, "album_ids"), _req(artist_ids, torch.int32, "artist_ids")
+    F, dev = album_table.shape[1], album_table.device
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    ws = _ws(_ws_bytes("esr_spotify_train_step_workspace_bytes", n, m, o, F), dev)
+    check(lib.esr_spotify_train_step(_p(album_table), _p(album_trace), _p(album_last), album_table.shape[0],
+                                     _p(artist_table), _p(artist_trace), _p(artist_last), artist_table.shape[0], F,
+                                     _p(album_ids), _p(artist_ids), n, m, o, float(regularization), int(step), float(lr),
+                                     float(momentum), _p(loss), _p(ws), ws.numel(), _stream()), "esr_spotify_train_step")
+    return loss
 
 
 def spotify_affinity_all(album_table, artist_table, ctx_album, ctx_artist, all_albums, all_artists):

@@ -24,11 +24,31 @@ def _model_of(state):
 def train_step(state, x, regularization):
     """train_spotify.py:77-111: value_and_grad of the six-term loss, then apply_gradients."""
     model = _model_of(state)
-    p = state.params["params"]
+    raw = state.raw_params  # (the hot loop: state.params would bring EVERY row of the lazily updated tables up to date)
+    p = raw["params"]
     at, rt = p["album_embed"]["embedding"], p["artist_embed"]["embedding"]
-    bound = model.apply(state.params, method=lambda m: m)  # bind the tables to read the occurrence ids
+    bound = model.apply(raw, method=lambda m: m)  # bind the tables to read the occurrence ids
     al, ar, n, m, o = bound.occurrence_ids(x["album_context"], x["artist_context"], x["next_album"], x["next_artist"],
                                            x["neg_album"], x["neg_artist"])
+    tx = state.tx
+    if getattr(tx, "lazy", False) and hasattr(tx, "_lazy_state") and at.is_cuda and at.shape[1] == rt.shape[1]:
+        # the reference's optimizer (optax.sgd(lr, momentum), train_spotify.py:238-241) in its lazy form: the whole step --
+        # catch-up of the playlist's rows, loss, gradient rows, one sort, the momentum step on the touched rows of both
+        # tables -- is ONE library call (eight launches; issued from Python the step was host-bound)
+        lz = tx._lazy_state(raw, state.opt_state)
+        lz["step"] += 1
+        tr = state.opt_state["trace"]["params"]
+        loss = ops.spotify_train_step(at, tr["album_embed"]["embedding"], lz["last"][("params", "album_embed", "embedding")],
+                                      rt, tr["artist_embed"]["embedding"],
+                                      lz["last"][("params", "artist_embed", "embedding")], al, ar, n, m, o, regularization,
+                                      lz["step"], tx.lr, tx.momentum)
+        lz["dirty"] = True
+        return state.replace(step=state.step + 1), loss.reshape(())
+    if hasattr(state.tx, "prepare"):
+        # optax.sgd(lr, momentum) in its lazy form: the rows this playlist reads are brought up to date here (albums are
+        # hashed into the table: row = album mod rows, spotify/models.py:37-41), nobody else's are touched
+        state.tx.prepare(raw, state.opt_state, [(("params", "album_embed", "embedding"), al, at.shape[0]),
+                                                (("params", "artist_embed", "embedding"), ar, 0)])
     loss, album_rows, ga, gr = ops.spotify_fwd_bwd(at, rt, al, ar, n, m, o, regularization)
     grads = {"params": {"album_embed": {"embedding": RowGrads([album_rows], ga, at.shape)},
                         "artist_embed": {"embedding": RowGrads([ar], gr, rt.shape)}}}

@@ -293,11 +293,22 @@ class _SparseSgd(GradientTransformation):
 
 class _SgdMomentum(GradientTransformation):
     """optax.sgd(learning_rate, momentum) [upstream] (spotify/train_spotify.py:238-241): trace = g + momentum * trace,
-    p -= lr * trace on EVERY element -- rows without a gradient keep coasting on their trace, so the decay half is
-    a dense pass; the gradient half touches only the rows of the RowGrads (no dense gradient is materialised)."""
+    p -= lr * trace on EVERY element -- rows without a gradient keep coasting on their trace.
 
-    def __init__(self, learning_rate, momentum):
-        self.lr, self.momentum = learning_rate, momentum
+    lazy (default): a row that gets no gradient for n steps only undergoes n times ``trace *= momentum ; p -= lr * trace``,
+    a function of n alone, so it is applied when the row is next READ instead of by a dense pass over the table every
+    step (80 % of the Spotify step's bytes).  ``opt_state['_lazy']`` holds the step counter and, per table, ``last`` (int32
+    [V]): the step each row is up to date with.  A step is ``prepare`` (bring the rows it will read up to date: the train
+    step calls it before its forward pass), the forward / backward, then ``apply`` (the whole momentum step on the touched
+    rows).  ``flush`` brings every row up to date -- ``TrainState.params`` does it, so evals, checkpoints and anybody
+    else who reads the tables through the state see exactly what the dense optimizer would have left (bit-identical for
+    rows whose gaps stay within 2048 steps, 1e-7-close beyond: esr_optim.hip decay_steps).  lazy=False keeps the dense
+    decay pass every step."""
+
+    needs_flush = True
+
+    def __init__(self, learning_rate, momentum, lazy=True):
+        self.lr, self.momentum, self.lazy = learning_rate, momentum, lazy
 
     def init(self, params):
         return {"trace": tree_map(torch.zeros_like, params)}
@@ -309,7 +320,60 @@ class _SgdMomentum(GradientTransformation):
     def from_optax_state(self, tree):
         return {"trace": tree["0"]["trace"]}
 
+    def _lazy_state(self, params, opt_state):
+        lz = opt_state.get("_lazy")
+        if lz is None:
+            lz = opt_state["_lazy"] = {"step": 0, "prepared": False, "dirty": False, "last": {
+                path: torch.zeros(p.shape[0], dtype=torch.int32, device=p.device)
+                for path, p in tree_leaves_with_path(params) if p.dim() == 2 and p.is_cuda}}
+        return lz
+
+    def prepare(self, params, opt_state, lookups):
+        """Start of a lazy step: lookups = [(path, int32 ids, modulus)] -- the rows the step is about to read (row =
+        id % modulus when modulus > 0).  They are brought up to the previous step and marked as handled by this one."""
+        if not self.lazy:
+            return
+        lz = self._lazy_state(params, opt_state)
+        if not lz["prepared"]:
+            lz["step"] += 1
+            lz["prepared"] = True
+        for path, ids, modulus in lookups:
+            path = tuple(path)
+            if path in lz["last"]:
+                ops.momentum_catchup_rows(tree_get(params, path), tree_get(opt_state["trace"], path), lz["last"][path], ids,
+                                          modulus, lz["step"], self.lr, self.momentum)
+
+    def flush(self, params, opt_state):
+        lz = opt_state.get("_lazy") if isinstance(opt_state, dict) else None
+        if lz is None or not lz["dirty"]:
+            return
+        for path, last in lz["last"].items():
+            ops.momentum_flush(tree_get(params, path), tree_get(opt_state["trace"], path), last, lz["step"], self.lr,
+                               self.momentum)
+        lz["dirty"] = False
+
     def apply(self, params, grads, opt_state, step):
+        lazy = self.lazy and all(isinstance(tree_get(grads, path), RowGrads) or tree_get(grads, path) is None
+                                 for path, p in tree_leaves_with_path(params)) and \
+            all(p.dim() == 2 and p.is_cuda for _, p in tree_leaves_with_path(params))
+        if self.lazy and not lazy:
+            self.flush(params, opt_state)  # a dense step on lazily updated tables: bring them up to date first
+        if lazy:
+            lz = self._lazy_state(params, opt_state)
+            if not lz["prepared"]:  # nobody announced the rows: the caller read them through state.params (flushed)
+                self.prepare(params, opt_state, [(path, tree_get(grads, path).index.ids, 0)
+                                                 for path, _ in tree_leaves_with_path(params)
+                                                 if tree_get(grads, path) is not None])
+            for path, p in tree_leaves_with_path(params):
+                g = tree_get(grads, path)
+                if g is None:
+                    continue
+                _consume(g, "RowGrads")
+                sorted_ids, perm = g.index.sorted()
+                ops.sparse_momentum_step(p, tree_get(opt_state["trace"], path), sorted_ids, perm, g.rows, self.lr,
+                                         self.momentum)
+            lz["prepared"], lz["dirty"] = False, True
+            return opt_state
         for path, p in tree_leaves_with_path(params):
             tr = tree_get(opt_state["trace"], path)
             ops.dense_momentum_decay(p, tr, self.lr, self.momentum)
@@ -321,6 +385,10 @@ class _SgdMomentum(GradientTransformation):
             _consume(g, "RowGrads")
             sorted_ids, perm = g.index.sorted()
             ops.sparse_momentum(p, tr, sorted_ids, perm, g.rows, self.lr)
+        if isinstance(opt_state.get("_lazy"), dict):  # (a dense step after lazy ones: everybody is up to date with it)
+            opt_state["_lazy"]["step"] += 1
+            for last in opt_state["_lazy"]["last"].values():
+                last.fill_(opt_state["_lazy"]["step"])
         return opt_state
 
 
@@ -332,9 +400,9 @@ def sparse_adagrad(learning_rate, initial_accumulator_value=0.1, eps=1e-7):
     return _SparseAdagrad(learning_rate, initial_accumulator_value, eps)
 
 
-def sgd(learning_rate, momentum=None):
+def sgd(learning_rate, momentum=None, lazy=True):
     if momentum is not None:
-        return _SgdMomentum(learning_rate, momentum)
+        return _SgdMomentum(learning_rate, momentum, lazy=lazy)
     return _sgd_plain(learning_rate)
 
 
@@ -466,6 +534,8 @@ class TrainState:
     def params(self):
         if self.versions:
             self.consolidate()
+        if getattr(self.tx, "needs_flush", False):  # lazily updated tables (sgd with momentum): every row up to date
+            self.tx.flush(self._params, self.opt_state)
         return self._params
 
     @classmethod
@@ -489,7 +559,10 @@ class TrainState:
     def apply_gradients(self, *, grads, **kwargs):
         """step += 1 and one optimizer update (flax TrainState.apply_gradients).  The tables are updated in
         place in HBM; the returned state shares them."""
-        new_opt = self.tx.apply(self.params, grads, self.opt_state, self.step + 1)
+        if self.versions:
+            self.consolidate()
+        # (raw parameters: a lazily updated optimizer keeps its own books on which rows are current)
+        new_opt = self.tx.apply(self._params, grads, self.opt_state, self.step + 1)
         return self.replace(step=self.step + 1, opt_state=new_opt)
 
 

@@ -426,6 +426,36 @@ int esr_dense_momentum_decay(float* param, float* trace, int64_t count, float lr
 int esr_sparse_momentum_scatter(float* table, float* trace, int64_t V, int D, const int32_t* sorted_ids,
                                 const int32_t* perm, int64_t n, float* grad_rows, float lr,
                                 esr_stream_t stream);
+/* Lazy form of the same optimizer (row-sparse steps): no dense decay pass.  last [V] (int32, zero for a fresh state) is
+ * the step each row is up to date with.  A step t >= 1 is: esr_momentum_catchup_rows on the ids the step will read
+ * (ids[i] % modulus when modulus > 0: the album hash of spotify/models.py:37-41; duplicates welcome) -- the rows are
+ * brought up to step t - 1 (n missed steps of trace *= momentum ; p -= lr * trace: one by one up to 2048, the closed form
+ * beyond) and marked t -- then the forward / backward on current rows, then esr_sparse_momentum_step: trace = g +
+ * momentum * trace ; p -= lr * trace on the touched rows (optax's order).  esr_momentum_flush brings EVERY row up to
+ * `step` (before an eval, a checkpoint, any read of the whole table). */
+int esr_momentum_catchup_rows(float* table, float* trace, int32_t* last, int64_t V, int D, const int32_t* ids, int64_t n,
+                              int modulus, int step, float lr, float momentum, esr_stream_t stream);
+int esr_sparse_momentum_step(float* table, float* trace, int64_t V, int D, const int32_t* sorted_ids,
+                             const int32_t* perm, int64_t n, float* grad_rows, float lr, float momentum,
+                             esr_stream_t stream);
+int esr_momentum_flush(float* table, float* trace, int32_t* last, int64_t V, int D, int step, float lr, float momentum,
+                       esr_stream_t stream);
+int esr_momentum_catchup_rows2(float* table0, float* trace0, int32_t* last0, const int32_t* ids0, int modulus0,
+                               float* table1, float* trace1, int32_t* last1, const int32_t* ids1, int modulus1, int D,
+                               int64_t n, int step, float lr, float momentum, esr_stream_t stream);
+int esr_sparse_momentum_step_multi(float* const* tables, float* const* traces, const int64_t* row_offsets, int ntables,
+                                   int D, const int32_t* sorted_vids, const int32_t* perm, int64_t n, float* grad_rows,
+                                   float lr, float momentum, esr_stream_t stream);
+/* spotify/train_spotify.py:77-111 + 238-241 as ONE call (N1): catch-up of the playlist's rows (both tables, one launch),
+ * esr_spotify_fwd_bwd, one sort of the virtual rows [album mod rows ; n_album_rows + artist], the whole momentum step on
+ * the touched rows of both tables.  album_last / artist_last, step, lr, momentum as for esr_momentum_catchup_rows;
+ * loss [1]. */
+size_t esr_spotify_train_step_workspace_bytes(int n, int m, int o, int F);
+int esr_spotify_train_step(float* album_table, float* album_trace, int32_t* album_last, int64_t n_album_rows,
+                           float* artist_table, float* artist_trace, int32_t* artist_last, int64_t n_artists, int F,
+                           const int32_t* album_ids, const int32_t* artist_ids, int n, int m, int o, float regularization,
+                           int step, float lr, float momentum, float* loss, void* workspace, size_t workspace_bytes,
+                           esr_stream_t stream);
 
 /* ---- 8e: row-shard routing (owner = id mod world, local row = id div world) ---------------
  * Stable bucket of ids by owner: local_rows[k] = ids[perm[k]] / world, counts[g] = #ids owned by g

@@ -116,6 +116,77 @@ def test_spotify_train_step_momentum_vs_oracle(dev):
     assert rel_err(N(state.opt_state["trace"]["params"]["artist_embed"]["embedding"]), tr) <= TOL
 
 
+def _playlist(rng, all_tracks, all_albums, all_artists, n_next=12):
+    pick = rng.integers(0, len(all_tracks), 5 + n_next)
+    return {"track_context": all_tracks[pick[:5]], "album_context": all_albums[pick[:5]],
+            "artist_context": all_artists[pick[:5]], "next_track": all_tracks[pick[5:]],
+            "next_album": all_albums[pick[5:]], "next_artist": all_artists[pick[5:]]}
+
+
+def test_lazy_momentum_equals_flushing_every_step_and_the_dense_oracle(dev):
+    """optim.sgd(lr, momentum) in its lazy form (rows decay when they are next read) over 40 playlists: bit-identical to
+    the same run with every row brought up to date after every step (state.params: the dense form's arithmetic, one
+    step at a time), within 1e-5 of the fp64 oracle's dense update, and the lazy run launches no dense pass."""
+    from esrecsys_amd.spotify.train_spotify import sample_negative, train_step
+    model, params, rng, all_tracks, all_albums, all_artists, TrainState, optim = _small_world(dev)
+    lr, mom, reg, steps = 0.02, 0.9, 0.9, 40
+    clone = lambda tree: {"params": {k: {"embedding": v["embedding"].clone()} for k, v in tree["params"].items()}}  # noqa: E731
+    a = TrainState.create(apply_fn=model.apply, params=clone(params), tx=optim.sgd(lr, mom))
+    b = TrainState.create(apply_fn=model.apply, params=clone(params), tx=optim.sgd(lr, mom))
+    at = N(params["params"]["album_embed"]["embedding"]).astype(F64)
+    rt = N(params["params"]["artist_embed"]["embedding"]).astype(F64)
+    ta, tr = np.zeros_like(at), np.zeros_like(rt)
+    for step in range(steps):
+        x = _playlist(rng, all_tracks, all_albums, all_artists)
+        sample_negative(x, rng, 64, all_tracks, all_albums, all_artists)
+        a, la = train_step(a, x, reg)
+        b, lb = train_step(b, x, reg)
+        _ = b.params                               # flushes: every row of b is current after every step
+        assert float(la) == float(lb), step
+        el, ga, gr = o_sp.dense_grads(at, rt, x, reg)
+        at, ta = o_sp.sgd_momentum_update(at, ta, ga, lr, mom, F64)
+        rt, tr = o_sp.sgd_momentum_update(rt, tr, gr, lr, mom, F64)
+        assert abs(float(la) - el) <= TOL * abs(el), step
+    lz = a.opt_state["_lazy"]
+    assert lz["step"] == steps and lz["dirty"]
+    behind = int((lz["last"][("params", "artist_embed", "embedding")] < steps).sum())
+    assert behind > 0, "most artist rows were not read by the last playlist: they are still behind"
+    for k in ("album_embed", "artist_embed"):
+        assert torch.equal(a.params["params"][k]["embedding"], b.params["params"][k]["embedding"])
+        assert torch.equal(a.opt_state["trace"]["params"][k]["embedding"], b.opt_state["trace"]["params"][k]["embedding"])
+    assert not a.opt_state["_lazy"]["dirty"]
+    assert rel_err(N(a.params["params"]["album_embed"]["embedding"]), at) <= TOL
+    assert rel_err(N(a.params["params"]["artist_embed"]["embedding"]), rt) <= TOL
+    assert rel_err(N(a.opt_state["trace"]["params"]["artist_embed"]["embedding"]), tr) <= TOL
+
+
+def test_lazy_momentum_long_gaps_take_the_closed_form(dev):
+    """A row that nobody reads for more than 2048 steps is caught up by the closed form of the geometric decay
+    (esr_optim.hip decay_steps): against the fp64 statement of n dense steps."""
+    from esrecsys_amd import ops
+    V, D, lr, mom = 1000, 32, 0.01, 0.98
+    g = torch.Generator(device=dev).manual_seed(2)
+    p0 = torch.randn((V, D), generator=g, device=dev)
+    t0 = torch.randn((V, D), generator=g, device=dev) * 0.3
+    for n in (1, 7, 2048, 2049, 5000, 200_000):
+        p, t = p0.clone(), t0.clone()
+        last = torch.zeros(V, dtype=torch.int32, device=dev)
+        ids = torch.arange(0, V, 3, dtype=torch.int32, device=dev).repeat(2)          # every third row, each asked twice
+        ops.momentum_catchup_rows(p, t, last, ids, 0, n + 1, lr, mom)                  # step n + 1 reads them: n missed steps
+        geo = mom * (1.0 - mom ** n) / (1.0 - mom)
+        ep = p0.double() - lr * t0.double() * geo
+        et = t0.double() * mom ** n
+        touched = torch.zeros(V, dtype=torch.bool, device=dev)
+        touched[::3] = True
+        assert rel_err(N(p[touched]), N(ep[touched])) <= 1e-5 and np.abs(N(t[touched]) - N(et[touched])).max() <= 1e-6
+        assert torch.equal(p[~touched], p0[~touched]) and torch.equal(t[~touched], t0[~touched])
+        assert torch.equal(last[touched], torch.full_like(last[touched], n + 1)) and int(last[~touched].sum()) == 0
+        ops.momentum_flush(p, t, last, n + 1, lr, mom)                                  # everybody else: n + 1 steps
+        geo1 = mom * (1.0 - mom ** (n + 1)) / (1.0 - mom)
+        assert rel_err(N(p[~touched]), N((p0.double() - lr * t0.double() * geo1)[~touched])) <= 1e-5
+        assert int((last != n + 1).sum()) == 0
+
+
 def test_spotify_eval_step_vs_oracle(dev):
     from esrecsys_amd.spotify.train_spotify import all_track_top_k, eval_step
     model, params, rng, all_tracks, all_albums, all_artists, TrainState, optim = _small_world(dev, T_=200_003)
