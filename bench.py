@@ -763,6 +763,15 @@ def secondary_legs(args, dev, rank):
                                                        with_cpu=not args.no_cpu_baseline, with_ann=False)
     except Exception as e:
         out["retrieve_c5_n1m_k500"] = {"error": "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")}
+    try:  # config 5's "ANN scoring vs brute force": the IVF index against the exact answer on the same corpus
+        from bench_retrieve import measure_ivf
+        out["retrieve_c5_n1m_ivf_vs_brute_force"] = measure_ivf(dev, corpus="clustered")
+        out["retrieve_c5_n1m_ivf_vs_brute_force"]["iid_corpus_worst_case"] = measure_ivf(dev, ks=(10,), nprobes=(32,),
+                                                                                         steps=2, corpus="iid")
+    except Exception as e:
+        out["retrieve_c5_n1m_ivf_vs_brute_force"] = {"error": "%s: %s" % (type(e).__name__,
+                                                                          str(e).splitlines()[0][:200] if str(e) else "")}
+        torch.cuda.synchronize()
     return out
 
 

@@ -94,6 +94,57 @@ def measure_retrieve(dev, n_local, steps, warmup, mode="f16x2", with_cpu=True, w
     }
 
 
+def measure_ivf(dev, n_local=1_048_576, nq=NQ, ks=(10, 500), nlist=1024, nprobes=(8, 32), steps=3, corpus="clustered"):
+    """Config 5's ANN leg: the IVF index (esrecsys_amd/ivf.py) against the exact brute force on the SAME corpus and
+    queries -- recall@k and queries/s per (k, nprobe).  corpus "clustered": 4096 unit-norm centres + N(0, 0.6^2 / D) noise
+    (embedding tables have cluster structure; that is what an inverted file exploits); "iid": the N(0, 1/D) rows of the
+    brute-force leg (no structure: the worst case, recall then follows the fraction of lists probed)."""
+    from esrecsys_amd import ops
+    from esrecsys_amd.ivf import IVFIndex
+    from esrecsys_amd.pinterest.make_recommendations import recall_at_k
+    g = torch.Generator(device=dev).manual_seed(1701)
+    if corpus == "clustered":
+        centres = torch.randn((4096, D), generator=g, device=dev)
+        centres /= centres.norm(dim=1, keepdim=True)
+        c = centres[torch.randint(0, 4096, (n_local,), generator=g, device=dev)] + \
+            torch.randn((n_local, D), generator=g, device=dev) * (0.6 * D ** -0.5)
+        q = centres[torch.randint(0, 4096, (nq,), generator=g, device=dev)] + \
+            torch.randn((nq, D), generator=g, device=dev) * (0.6 * D ** -0.5)
+    else:
+        c = torch.randn((n_local, D), generator=g, device=dev) * D ** -0.5
+        q = torch.randn((nq, D), generator=g, device=dev) * D ** -0.5
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    index = IVFIndex(c, nlist)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    out = {"corpus": corpus, "N": n_local, "D": D, "queries": nq, "nlist": nlist, "build_s": build_s,
+           "longest_list": index.max_list, "legs": []}
+    for k in ks:
+        ops.retrieve_topk(q, c, k, mode="f16x2")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            _, exact = ops.retrieve_topk(q, c, k, mode="f16x2")
+        torch.cuda.synchronize()
+        brute = (time.perf_counter() - t0) / steps
+        for nprobe in nprobes:
+            index.search(q, k, nprobe)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                _, got = index.search(q, k, nprobe)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            out["legs"].append({"k": k, "nprobe": nprobe, "ms": dt * 1e3, "queries_per_s": nq / dt,
+                                "recall_at_k_vs_brute_force": recall_at_k(got, exact), "brute_force_ms": brute * 1e3,
+                                "speedup_vs_brute_force": brute / dt,
+                                "fraction_of_candidates_scored": nprobe / nlist})
+    del index, c, q
+    torch.cuda.empty_cache()
+    return out
+
+
 def run_retrieve(args, emit):
     from esrecsys_amd import ops, sharded
     from esrecsys_amd.pinterest.make_recommendations import find_top_k_batch, recall_at_k

@@ -71,6 +71,9 @@ SIGNATURES = {
     "esr_spotify_train_step_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int]),
     "esr_spotify_train_step": (c_int, [c_f32p, c_f32p, c_i32p, c_i64, c_f32p, c_f32p, c_i32p, c_i64, c_int, c_i32p, c_i32p,
                                        c_int, c_int, c_int, c_f32, c_int, c_f32, c_f32, c_f32p, c_vp, c_size, c_vp]),
+    "esr_ivf_search_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int, c_int]),
+    "esr_ivf_search": (c_int, [c_f32p, c_i64, c_int, c_f32p, c_i32p, c_i32p, c_int, c_int, c_i32p, c_int, c_int, c_f32p,
+                               c_i32p, c_vp, c_size, c_vp]),
     "esr_long_run_hint": (c_int, [c_i32p, c_i64, c_int, c_vp, c_int32, c_vp]),
     "esr_rows_consolidate": (c_int, [c_f32p, c_f32p, c_vp, c_i64, c_int, c_vp]),
     "esr_rows_restamp": (c_int, [c_vp, c_i64, c_vp]),

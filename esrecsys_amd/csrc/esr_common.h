@@ -24,6 +24,10 @@ constexpr int kSelectMaxK = 1024;
 int select_topk_dense(const float* scores, int64_t pitch, int64_t rows, int n, int k, float* out_scores,
                       int32_t* out_indices, hipStream_t st);
 
+// the same select over ragged rows (row r: n_per_row[r] entries, at most max_n): esr_ivf.hip's per-list candidates
+int select_topk_ragged(const float* scores, int64_t pitch, int64_t rows, const int32_t* n_per_row, int max_n, int k,
+                       float* out_scores, int32_t* out_indices, hipStream_t st);
+
 inline hipStream_t as_stream(esr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 #define ESR_REQUIRE(cond, ...)        \

@@ -820,6 +820,23 @@ int select_topk_dense(const float* scores, int64_t pitch, int64_t rows, int n, i
   return check_launch("select_topk_dense");
 }
 
+// top-k of ragged score rows: row r has n_per_row[r] valid entries at scores[r * pitch + c] (index = column).  Rows
+// shorter than k deliver all they have (the caller pre-fills the outputs).  For esr_ivf.hip.
+int select_topk_ragged(const float* scores, int64_t pitch, int64_t rows, const int32_t* n_per_row, int max_n, int k,
+                       float* out_scores, int32_t* out_indices, hipStream_t st) {
+  if (k > kSelMaxK) return ESR_EINVAL;
+  SelIn in;
+  in.vals = scores; in.vpitch = pitch; in.idx = nullptr; in.stride = 1; in.ibase = 0; in.istep = 1;
+  in.n_per_row = n_per_row; in.n_fixed = 0;
+  SelOut so;
+  so.pairs = nullptr; so.ppitch = 0; so.cnt = nullptr; so.tau = nullptr; so.scores = out_scores; so.indices = out_indices;
+  const int lds_words = max_n > kSelThreads * kSelBatch && max_n <= kSelLdsWords ? kSelLdsWords : 0;
+  hipLaunchKernelGGL(topk_select_kernel, dim3((int)rows), dim3(kSelThreads), lds_words * sizeof(uint32_t), st, in, k, so,
+                     lds_words);
+  return check_launch("select_topk_ragged");
+}
+
+
 template <int P>
 static void launch_split(const float* X, int64_t n_rows, int D, int64_t rows_pad, int Dp, int64_t plane_elems,
                          __bf16* out, hipStream_t st, const int* exp_ptr = nullptr) {

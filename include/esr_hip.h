@@ -389,6 +389,18 @@ int esr_rescore_candidates(const float* queries, const float* candidates, int64_
 int esr_topk_merge(const float* scores, const int32_t* indices, int64_t nq, int n, int k,
                    float* out_scores, int32_t* out_indices, esr_stream_t stream);
 
+/* ---- config 5's ANN leg: IVF search (build-defined; the reference has no ANN index -- esr_retrieve_topk stays the exact
+ * answer and the yardstick for recall).  The index (esrecsys_amd/ivf.py builds it with the kernels above): candidates
+ * grouped by coarse centroid -- cands_sorted [N, D] list after list, list_off int32 [nlist + 1], orig int32 [N] = the
+ * row each one has in the caller's matrix, max_list = the longest list.  probe_lists int32 [nq, nprobe]: the lists each
+ * query looks into (the nprobe best centroids: esr_retrieve_topk of the queries against the centroids).  Scores inside
+ * the probed lists are exact f32 (grouped FP32 GEMM, one 64 x 64 tile per workgroup); out [nq, k], best first, entries a
+ * query's lists could not fill: score -inf, index -1.  k <= 1024. */
+size_t esr_ivf_search_workspace_bytes(int64_t nq, int nlist, int max_list, int nprobe, int k);
+int esr_ivf_search(const float* queries, int64_t nq, int D, const float* cands_sorted, const int32_t* list_off,
+                   const int32_t* orig, int nlist, int max_list, const int32_t* probe_lists, int nprobe, int k,
+                   float* out_scores, int32_t* out_indices, void* workspace, size_t workspace_bytes, esr_stream_t stream);
+
 /* ---- N1: Spotify id-embedding two-tower -- spotify/models.py:27-90, spotify/train_spotify.py:77-131 ----
  * A track embeds as concat(album_table[album mod n_album_rows], artist_table[artist]) ([.., 2F]).  One call is one
  * playlist: album_ids / artist_ids are int32 [n + m + o] = context, next, neg occurrences in that order (raw ids:
