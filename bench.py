@@ -97,7 +97,7 @@ def sustained_bf16_mfma_tflops(dev, iters=100000, f16=False):
     not the 2.4 GHz the 2.5 PFLOP/s data-sheet peak assumes (constant operands do reach 2.45 PFLOP/s)."""
     import ctypes
     from esrecsys_amd import _lib
-    lib = _lib.load()
+    lib = _lib.load_probe()
     sink = torch.zeros(1, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     flops = ctypes.c_double()
@@ -145,7 +145,7 @@ def saturating_gather_scatter(dev, V, D, n=131072, reps=20):
     # reads: the library's own read probe (16 B per lane, 8 loads in flight per lane, 2048 workgroups); torch.sum over
     # the same table reaches only ~4 TB/s and is kept as `torch_sum_GBps` because round-2 notes quoted it as the ceiling
     from esrecsys_amd import _lib
-    lib, sink = _lib.load(), torch.zeros(64, dtype=torch.float32, device=dev)
+    lib, sink = _lib.load_probe(), torch.zeros(64, dtype=torch.float32, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     tp = timed(lambda: _lib.check(lib.esr_probe_hbm_read(table.data_ptr(), table.numel() * 4, 2048, 1, sink.data_ptr(), st),
                                   "esr_probe_hbm_read"))

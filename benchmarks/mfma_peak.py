@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     from esrecsys_amd import _lib
-    lib = _lib.load()
+    lib = _lib.load_probe()
     dev = torch.device("cuda", 0)
     sink = torch.zeros(1, device=dev)
     st = torch.cuda.current_stream().cuda_stream

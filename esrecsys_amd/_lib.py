@@ -36,8 +36,6 @@ SIGNATURES = {
     "esr_version": (c_int, []),
     "esr_device_info": (c_int, [ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_size),
                                 ctypes.c_char_p, c_int]),
-    "esr_probe_mfma": (c_int, [c_int, c_int, c_int, c_f32p, ctypes.POINTER(ctypes.c_double), c_vp]),
-    "esr_probe_hbm_read": (c_int, [c_vp, c_i64, c_int, c_int, c_f32p, c_vp]),
     "esr_gather_rows": (c_int, [c_vp, c_int, c_i64, c_int, c_i32p, c_i64, c_vp, c_vp]),
     "esr_check_ids": (c_int, [c_i32p, c_i64, c_i64, c_vp, c_vp]),
     "esr_unpermute_rows": (c_int, [c_vp, c_int, c_int, c_i32p, c_i64, c_vp, c_vp]),
@@ -198,6 +196,36 @@ def load(path=None):
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    return lib
+
+
+# include/esr_probe.h: the measurement probes live in their own shared object (not part of the product ABI)
+PROBE_LIB_PATH = os.path.join(_HERE, "libesr_probe.so")
+PROBE_SIGNATURES = {
+    "esr_probe_mfma": (c_int, [c_int, c_int, c_int, c_f32p, ctypes.POINTER(ctypes.c_double), c_vp]),
+    "esr_probe_hbm_read": (c_int, [c_vp, c_i64, c_int, c_int, c_f32p, c_vp]),
+}
+_probe = None
+
+
+def load_probe(path=None):
+    """Load libesr_probe.so (once; after libesr_hip.so, whose error helpers it resolves)."""
+    global _probe
+    if _probe is not None:
+        return _probe
+    load()
+    path = path or PROBE_LIB_PATH
+    if not os.path.exists(path):
+        raise EsrLibraryError("%s not found: build it with `python -m esrecsys_amd.build`" % path)
+    try:
+        lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    except OSError as e:  # pragma: no cover
+        raise EsrLibraryError("failed to load %s: %s" % (path, e))
+    for name, (res, args) in PROBE_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _probe = lib
     return lib
 
 

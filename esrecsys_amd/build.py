@@ -12,8 +12,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ_DIR = os.path.join(CSRC, "build")
 LIB_PATH = os.path.join(HERE, "libesr_hip.so")
 SOURCES = ["esr_core.hip", "esr_glove.hip", "esr_triplet.hip", "esr_inbatch.hip", "esr_inbatch3.hip", "esr_inbatch2h.hip", "esr_optim.hip", "esr_sort.hip",
-           "esr_retrieve.hip", "esr_probe.hip", "esr_spotify.hip", "esr_comm.hip", "esr_triplet_step.hip", "esr_shard.hip", "esr_ivf.hip"]
-HEADERS = [os.path.join(CSRC, "esr_common.h"), os.path.join(CSRC, "esr_versioned.h"), os.path.join(CSRC, "esr_inbatch_mfma.h"),
+           "esr_retrieve.hip", "esr_spotify.hip", "esr_comm.hip", "esr_triplet_step.hip", "esr_shard.hip", "esr_ivf.hip"]
+HEADERS = [os.path.join(HERE, "..", "include", "esr_probe.h"), os.path.join(CSRC, "esr_common.h"), os.path.join(CSRC, "esr_versioned.h"), os.path.join(CSRC, "esr_inbatch_mfma.h"),
            os.path.join(HERE, "..", "include", "esr_hip.h")]
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -60,6 +60,30 @@ def build_library(force=False, verbose=False):
     return LIB_PATH
 
 
+PROBE_LIB_PATH = os.path.join(HERE, "libesr_probe.so")
+
+
+def build_probe_library(force=False, verbose=False):
+    """The measurement probes (esr_probe.hip: a register-only MFMA loop, an HBM read stream) as their OWN shared object:
+    they are what bench.py measures ceilings with, not part of the product ABI.  The error helpers they call are
+    libesr_hip.so's (loaded first, RTLD_GLOBAL: esrecsys_amd/_lib.py load_probe)."""
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    obj = _compile("esr_probe.hip") if not force else None
+    if obj is None:
+        o = os.path.join(OBJ_DIR, "esr_probe.o")
+        if os.path.exists(o):
+            os.remove(o)
+        obj = _compile("esr_probe.hip")
+    if force or _stale(PROBE_LIB_PATH, [obj]):
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", PROBE_LIB_PATH, obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    if verbose:
+        print("built", PROBE_LIB_PATH)
+    return PROBE_LIB_PATH
+
+
 IO_LIB_PATH = os.path.join(HERE, "libesr_io.so")
 
 
@@ -78,4 +102,5 @@ def build_io_library(force=False, verbose=False):
 
 if __name__ == "__main__":
     build_library(force="--force" in sys.argv, verbose=True)
+    build_probe_library(force="--force" in sys.argv, verbose=True)
     build_io_library(force="--force" in sys.argv, verbose=True)

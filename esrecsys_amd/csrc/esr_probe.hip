@@ -2,6 +2,7 @@
 // roofline fraction quoted against the data-sheet peak (MI355X_MICROARCH.md) can be read next to the ceiling a
 // register-only MFMA loop reaches under the clocks the part actually holds.
 #include "esr_common.h"
+#include "../../include/esr_probe.h"
 
 namespace esr {
 

@@ -55,20 +55,6 @@ int esr_version(void);
 /* host out-params; arch_len bytes at arch receive e.g. "gfx950". */
 int esr_device_info(int* cu_count, int* wave_size, size_t* hbm_bytes, char* arch, int arch_len);
 
-/* Measurement probe (not on the hot path): `workgroups` x 4 waves each run `iters` rounds of four independent
- * register-only MFMA chains (dtype ESR_BF16: v_mfma_f32_32x32x16_bf16, ESR_F32: v_mfma_f32_32x32x2_f32).
- * *flops_out (host) = flops the launch executes; time it on `stream` to get the matrix ceiling this box sustains.
- * sink: one device float (never written).  dtype | ESR_PROBE_LIVE_DATA feeds the chains full-entropy operands that
- * change every instruction instead of constants: switching activity, and with it the clock the part holds under
- * its power limit, is that of a real GEMM (constants measured 2.44 PFLOP/s bf16; see profiles/). */
-#define ESR_PROBE_LIVE_DATA 0x100
-#define ESR_PROBE_F16 2 /* v_mfma_f32_32x32x16_f16 (with ESR_PROBE_LIVE_DATA): the planes of the f16x2 paths */
-int esr_probe_mfma(int dtype, int workgroups, int iters, float* sink, double* flops_out, esr_stream_t stream);
-/* Measurement probe: `bytes` of x read once by `workgroups` workgroups, each streaming its own contiguous slice with
- * eight 16-byte loads in flight per lane (nontemporal != 0: streaming loads).  Time it with events: the pure-read
- * bandwidth a kernel can reach on this box.  sink: one device float (never written). */
-int esr_probe_hbm_read(const void* x, int64_t bytes, int workgroups, int nontemporal, float* sink, esr_stream_t stream);
-
 /* ---- G2 / S1: embedding-row gather ------------------------------------------------------
  * nn.Embed lookup == jnp.take(table, ids, axis=0): wikipedia/models.py:31-34 (and the id towers
  * that replace pinterest/models.py:64-70).  out[i, :] = table[ids[i], :], bit-exact. */

@@ -1,0 +1,33 @@
+/* libesr_probe.so -- measurement probes of the MI355X build of the ESRecsys hot path.
+ *
+ * NOT part of the product ABI (include/esr_hip.h): two micro-benchmarks that bench.py and benchmarks/ use to put the
+ * data-sheet peaks next to what THIS box sustains -- the matrix pipes under a register-only MFMA loop, the HBM under a
+ * pure read stream.  Built from esrecsys_amd/csrc/esr_probe.hip into its own shared object (it resolves the error
+ * helpers of libesr_hip.so, which must be loaded first).  Same conventions as esr_hip.h: 0 / negative ESR_E* codes,
+ * asynchronous on `stream`. */
+#ifndef ESR_PROBE_H
+#define ESR_PROBE_H
+#include "esr_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Measurement probe (not on the hot path): `workgroups` x 4 waves each run `iters` rounds of four independent
+ * register-only MFMA chains (dtype ESR_BF16: v_mfma_f32_32x32x16_bf16, ESR_F32: v_mfma_f32_32x32x2_f32).
+ * *flops_out (host) = flops the launch executes; time it on `stream` to get the matrix ceiling this box sustains.
+ * sink: one device float (never written).  dtype | ESR_PROBE_LIVE_DATA feeds the chains full-entropy operands that
+ * change every instruction instead of constants: switching activity, and with it the clock the part holds under
+ * its power limit, is that of a real GEMM (constants measured 2.44 PFLOP/s bf16; see profiles/). */
+#define ESR_PROBE_LIVE_DATA 0x100
+#define ESR_PROBE_F16 2 /* v_mfma_f32_32x32x16_f16 (with ESR_PROBE_LIVE_DATA): the planes of the f16x2 paths */
+int esr_probe_mfma(int dtype, int workgroups, int iters, float* sink, double* flops_out, esr_stream_t stream);
+/* Measurement probe: `bytes` of x read once by `workgroups` workgroups, each streaming its own contiguous slice with
+ * eight 16-byte loads in flight per lane (nontemporal != 0: streaming loads).  Time it with events: the pure-read
+ * bandwidth a kernel can reach on this box.  sink: one device float (never written). */
+int esr_probe_hbm_read(const void* x, int64_t bytes, int workgroups, int nontemporal, float* sink, esr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

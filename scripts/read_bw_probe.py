@@ -25,7 +25,7 @@ for mb, dt in [(1024, torch.float32), (268, torch.float32), (4096, torch.float32
 # the library's own read probe: contiguous slice per workgroup, eight 16-byte loads in flight per lane
 import ctypes
 from esrecsys_amd import _lib
-lib = _lib.load()
+lib = _lib.load_probe()
 sink = torch.zeros(1, device=dev)
 for mb in (268, 1024):
     x = torch.ones(mb * 1024 * 1024 // 4, dtype=torch.float32, device=dev)

@@ -34,6 +34,22 @@ def test_header_symbols_all_exported(lib):
     assert sorted(_lib.SIGNATURES) == declared
 
 
+def test_probe_library_is_separate_and_exports_its_header(lib):
+    """The measurement probes are not part of the product ABI: include/esr_probe.h, libesr_probe.so."""
+    from esrecsys_amd import _lib
+    from esrecsys_amd.build import build_probe_library
+    if not os.path.exists(_lib.PROBE_LIB_PATH):
+        build_probe_library()
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "esr_probe.h")).read(), flags=re.S)
+    declared = sorted(set(re.findall(r"\b(esr_[a-z0-9_]+)\s*\(", text)))
+    probe = _lib.load_probe()
+    assert declared == sorted(_lib.PROBE_SIGNATURES) == ["esr_probe_hbm_read", "esr_probe_mfma"]
+    for name in declared:
+        assert hasattr(probe, name) and name not in _lib.SIGNATURES
+        with pytest.raises(AttributeError):
+            getattr(ctypes.CDLL(_lib.LIB_PATH), name)
+
+
 def test_version_and_error_string(lib):
     assert lib.esr_version() >= 100
     assert isinstance(lib.esr_last_error(), bytes)

@@ -195,3 +195,26 @@ def test_train_epoch_batched_sort_equals_in_line_sort(dev, B, K, kind, monkeypat
     assert la == lb
     assert torch.equal(a.params["_token_embedding"]["embedding"], b.params["_token_embedding"]["embedding"])
     assert torch.equal(a.params["_bias"]["embedding"], b.params["_bias"]["embedding"])
+
+
+def test_one_pass_step_is_refused_without_room_for_the_second_buffer(dev, monkeypatch):
+    """The one-pass steps double the memory of the tables they update (train_state.shadow_fits documents the largest V):
+    without room for the second buffer fused_step_available says no, train_step / train_epoch take the gradient-row path
+    (same result), and asking for the second buffer anyway raises ShadowMemoryError instead of running out of memory."""
+    import esrecsys_amd.train_state as ts
+    from esrecsys_amd.wikipedia.train_cooccurence import fused_step_available, train_step
+    V, D, B = 2000, 64, 512
+    rng = np.random.default_rng(1)
+    inputs = _ids("uniform", V, (2, B), rng)
+    target = rng.uniform(0.1, 300.0, B).astype(np.float32)
+    a, b = _make_state(V, D, "reference", dev), _make_state(V, D, "reference", dev)
+    a, la = train_step(a, inputs, target)                      # one-pass
+    monkeypatch.setattr(ts, "shadow_fits", lambda table, reserve=0: False)
+    assert not fused_step_available(b)
+    with pytest.raises(ts.ShadowMemoryError):
+        ts.row_versions(b, ("_token_embedding", "embedding"))
+    b, lb = train_step(b, inputs, target)                      # gradient rows: no second buffer was made
+    assert not b.versions and abs(float(la) - float(lb)) <= 2e-6 * abs(float(lb))
+    assert rel_err(a.params["_token_embedding"]["embedding"].cpu().numpy(),
+                   b.params["_token_embedding"]["embedding"].cpu().numpy()) <= 1e-6
+    assert fused_step_available(a)   # (a table that HAS its second buffer keeps using it)
