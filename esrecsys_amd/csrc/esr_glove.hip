@@ -1206,7 +1206,7 @@ struct GloveTables {
 // one step's launches (arguments validated by the callers)
 static void launch_glove_step(const GloveTables& t, const int32_t* inputs, const float* target, int64_t B, int mode,
                               float lr, float eps, uint32_t stamp, const int32_t* sorted_ids, const int32_t* perm,
-                              void* plan, int long_runs, int blocks_per_cu, float* loss, const StepWs& ws,
+                              void* plan, int long_runs, int blocks_per_cu, void* mark, float* loss, const StepWs& ws,
                               hipStream_t st) {
   const int64_t n = 2 * B;
   const int D = t.D;
@@ -1223,6 +1223,11 @@ static void launch_glove_step(const GloveTables& t, const int32_t* inputs, const
     hipLaunchKernelGGL(glove_resolve_kernel, dim3(nres), dim3(kBlock), 0, st, sorted_ids, perm, inputs, target,
                        (const float*)t.bias, (const uint8_t*)t.emb_loc, B, nstat, ws.own_code, ws.meta_res, ws.stat_part,
                        ws.res_flags);
+    // `mark`: an event of the caller's, recorded BETWEEN the resolve launch and the update kernel: a second stream that
+    // waits for it is released as the update kernel starts, so what it runs (the id sort of a coming batch) arrives
+    // after the update kernel has taken its wave slots.  Arriving first, the sort's workgroups kept part of the
+    // update kernel's single resident wave-set waiting for a slot: 126 against 109 us for the same kernel.
+    if (mark) (void)hipEventRecord((hipEvent_t)mark, st);
     ESR_DISPATCH_ROW(g, {
       static const int resident_all = resident_blocks((const void*)glove_step_resolved_kernel<VEC, NCH>, 0);
       const int resident = blocks_per_cu > 0
@@ -1252,6 +1257,7 @@ static void launch_glove_step(const GloveTables& t, const int32_t* inputs, const
   GlovePlan pl;
   glove_plan_layout(B, (char*)plan, &pl);
   const int nstat = mode == ESR_GLOVE_REFERENCE ? (int)std::min<int64_t>(kStatBlocksStep, cdiv(B, kBlock)) : 0;
+  if (mark) (void)hipEventRecord((hipEvent_t)mark, st);
   ESR_DISPATCH_ROW(g, {
     // one resident wave-set: every group walks a contiguous slice, so a grid larger than what the chip holds at once
     // only adds a second, partly filled round (94 VGPRs -> 5 blocks per CU: 2048 blocks ran as 1280 + 768); the
@@ -1293,8 +1299,8 @@ extern "C" {
 int esr_glove_train_step(float* emb, float* emb_shadow, uint8_t* emb_loc, float* emb_accum, float* bias,
                          float* bias_accum, int64_t V, int D, const int32_t* inputs, const float* target, int64_t B,
                          int mode, float lr, float eps, uint32_t stamp, const int32_t* presorted_ids,
-                         const int32_t* presorted_perm, void* plan, int long_runs, int blocks_per_cu, float* loss,
-                         void* workspace, size_t workspace_bytes, esr_stream_t stream) {
+                         const int32_t* presorted_perm, void* plan, int long_runs, int blocks_per_cu, void* mark_event,
+                         float* loss, void* workspace, size_t workspace_bytes, esr_stream_t stream) {
   ESR_GLOVE_STEP_CHECKS("esr_glove_train_step")
   ESR_REQUIRE(inputs && target && loss, "esr_glove_train_step: null pointer");
   ESR_REQUIRE(stamp >= 1 && stamp <= kStampMax, "esr_glove_train_step: stamp %u not in [1, %u]", stamp, kStampMax);
@@ -1314,8 +1320,8 @@ int esr_glove_train_step(float* emb, float* emb_shadow, uint8_t* emb_loc, float*
     perm = ws.perm;
   }
   const GloveTables t{emb, emb_shadow, emb_loc, emb_accum, bias, bias_accum, D};
-  launch_glove_step(t, inputs, target, B, mode, lr, eps, stamp, sorted_ids, perm, plan, long_runs, blocks_per_cu, loss,
-                    ws, st);
+  launch_glove_step(t, inputs, target, B, mode, lr, eps, stamp, sorted_ids, perm, plan, long_runs, blocks_per_cu,
+                    mark_event, loss, ws, st);
   return check_launch("esr_glove_train_step");
 }
 
@@ -1340,7 +1346,7 @@ int esr_glove_train_steps(float* emb, float* emb_shadow, uint8_t* emb_loc, float
   for (int b = 0; b < nbatch; ++b)
     launch_glove_step(t, inputs[b], targets[b], B, mode, lr, eps, first_stamp + (uint32_t)b,
                       sorted_ids + (int64_t)b * 2 * B, perm + (int64_t)b * 2 * B, (char*)plans + (size_t)b * stride,
-                      long_runs ? long_runs[b] : -1, 0, losses + b, ws, st);
+                      long_runs ? long_runs[b] : -1, 0, nullptr, losses + b, ws, st);
   return check_launch("esr_glove_train_steps");
 }
 

@@ -218,7 +218,7 @@ def glove_train_step(emb, shadow, loc, accum, bias, bias_accum, inputs, target, 
         raise ValueError("plan must be the uint8 record glove_plan made for a batch of this size")
     check(lib.esr_glove_train_step(_p(emb), _p(shadow), _p(loc), _p(accum), _p(bias), _p(bias_accum), V, D, _p(inputs),
                                    _p(target), B, mode, float(lr), float(eps), int(stamp), _p(sid), _p(perm), _p(plan),
-                                   int(long_runs), int(blocks_per_cu), _p(loss), _p(ws), ws.numel(), _stream()),
+                                   int(long_runs), int(blocks_per_cu), None, _p(loss), _p(ws), ws.numel(), _stream()),
           "esr_glove_train_step")
     return loss
 
