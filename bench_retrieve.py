@@ -157,7 +157,7 @@ def run_retrieve(args, emit):
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     # weak scaling would grow the candidate set with N; config 5 fixes it at 1M rows, so at N = 1 one GPU holds
     # the share it would hold in the 8-GPU job (131 072 rows) and N GPUs hold N such shares
-    n_local = N_TOTAL // 8
+    n_local = int(args.rows) if getattr(args, "rows", None) else N_TOTAL // 8   # (--rows 1048576: the whole config on one GPU)
     g = torch.Generator(device=dev).manual_seed(1701 + rank)
     q = torch.randn((NQ, D), generator=g, device=dev) * D ** -0.5
     c = torch.randn((n_local, D), generator=g, device=dev) * D ** -0.5

@@ -46,8 +46,9 @@ SIGNATURES = {
                                   c_f32p, c_vp, c_size, c_vp]),
     "esr_glove_step_workspace_bytes": (c_size, [c_i64, c_int]),
     "esr_glove_train_step": (c_int, [c_f32p, c_f32p, c_vp, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_i32p, c_f32p, c_i64,
-                                     c_int, c_f32, c_f32, c_uint32, c_i32p, c_i32p, c_vp, c_int, c_int, c_vp, c_f32p, c_vp,
-                                     c_size, c_vp]),
+                                     c_int, c_f32, c_f32, c_uint32, c_i32p, c_i32p, c_vp, c_int, c_int, c_vp, c_uint32, c_f32p,
+                                     c_vp, c_size, c_vp]),
+    "esr_stream_gate": (c_int, [c_vp, c_uint32, c_uint32, c_vp]),
     "esr_glove_train_steps": (c_int, [c_f32p, c_f32p, c_vp, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_int, c_vp, c_vp, c_i64,
                                       c_int, c_f32, c_f32, c_uint32, c_i32p, c_i32p, c_vp, c_vp, c_f32p, c_vp, c_size,
                                       c_vp]),

@@ -145,7 +145,29 @@ __global__ __launch_bounds__(kBlock) void check_ids_kernel(const int32_t* __rest
 
 using namespace esr;
 
+namespace esr {
+// One wave that waits until *flag has reached `value` (wrap-safe: the words are sequence numbers), asleep between
+// polls; gives up after timeout_ticks of the 100 MHz constant clock (s_memrealtime), so a producer that never runs
+// cannot hang the queue.  The load is agent-scope: served by the memory side, not by this XCD's L2.
+__global__ __launch_bounds__(64) void stream_gate_kernel(const uint32_t* __restrict__ flag, uint32_t value,
+                                                        unsigned long long timeout_ticks) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long t0 = wall_clock64();
+  while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - value) < 0) {
+    __builtin_amdgcn_s_sleep(16);
+    if (wall_clock64() - t0 > timeout_ticks) break;
+  }
+}
+}  // namespace esr
+
 extern "C" {
+
+int esr_stream_gate(const uint32_t* flag, uint32_t value, uint32_t timeout_us, esr_stream_t stream) {
+  ESR_REQUIRE(flag && !((uintptr_t)flag & 3), "esr_stream_gate: null or misaligned flag");
+  hipLaunchKernelGGL(stream_gate_kernel, dim3(1), dim3(64), 0, as_stream(stream), flag, value,
+                     (unsigned long long)timeout_us * 100ull);
+  return check_launch("esr_stream_gate");
+}
 
 int esr_check_ids(const int32_t* ids, int64_t n, int64_t V, int64_t* report, esr_stream_t stream) {
   ESR_REQUIRE(n >= 0 && V >= 0, "esr_check_ids: n and V must be non-negative");

@@ -453,8 +453,10 @@ __global__ __launch_bounds__(kBlock) void glove_step_kernel(
     const float* __restrict__ bias, int D, int G, const int32_t* __restrict__ sorted_ids,
     const float4* __restrict__ meta, const int32_t* __restrict__ inputs, int64_t n, int64_t B, int mode, uint32_t T,
     int nstat, unsigned long long* __restrict__ stat, float lr, float eps, float* __restrict__ chunk_rows,
-    double2* __restrict__ bias_info, double* __restrict__ pair_part, int* __restrict__ parked) {
+    double2* __restrict__ bias_info, double* __restrict__ pair_part, int* __restrict__ parked,
+    uint32_t* __restrict__ start_flag, uint32_t start_value) {
   __shared__ double sm[16];
+  announce_start(start_flag, start_value);
   const int lig = threadIdx.x & (G - 1);
   const int64_t gpb = kBlock / G;
   const int64_t group = (int64_t)blockIdx.x * gpb + threadIdx.x / G;
@@ -691,8 +693,10 @@ __global__ __launch_bounds__(kBlock) void glove_step_resolved_kernel(
     float* __restrict__ emb0, float* __restrict__ emb1, uint8_t* __restrict__ loc, float* __restrict__ accum, int D,
     int G, const uint32_t* __restrict__ own_code, const float4* __restrict__ meta, int64_t n, int64_t B, int mode,
     int nstat, const double* __restrict__ stat_part, float lr, float eps, float* __restrict__ chunk_rows,
-    double2* __restrict__ bias_info, double* __restrict__ pair_part, int* __restrict__ long_flag) {
+    double2* __restrict__ bias_info, double* __restrict__ pair_part, int* __restrict__ long_flag,
+    uint32_t* __restrict__ start_flag, uint32_t start_value) {
   __shared__ double sm[16];
+  announce_start(start_flag, start_value);
   const int lig = threadIdx.x & (G - 1);
   const int64_t gpb = kBlock / G;
   const int64_t group = (int64_t)blockIdx.x * gpb + threadIdx.x / G;
@@ -1206,8 +1210,8 @@ struct GloveTables {
 // one step's launches (arguments validated by the callers)
 static void launch_glove_step(const GloveTables& t, const int32_t* inputs, const float* target, int64_t B, int mode,
                               float lr, float eps, uint32_t stamp, const int32_t* sorted_ids, const int32_t* perm,
-                              void* plan, int long_runs, int blocks_per_cu, void* mark, float* loss, const StepWs& ws,
-                              hipStream_t st) {
+                              void* plan, int long_runs, int blocks_per_cu, uint32_t* start_flag,
+                              uint32_t start_value, float* loss, const StepWs& ws, hipStream_t st) {
   const int64_t n = 2 * B;
   const int D = t.D;
   const RowGeom g = row_geom(D);
@@ -1223,11 +1227,11 @@ static void launch_glove_step(const GloveTables& t, const int32_t* inputs, const
     hipLaunchKernelGGL(glove_resolve_kernel, dim3(nres), dim3(kBlock), 0, st, sorted_ids, perm, inputs, target,
                        (const float*)t.bias, (const uint8_t*)t.emb_loc, B, nstat, ws.own_code, ws.meta_res, ws.stat_part,
                        ws.res_flags);
-    // `mark`: an event of the caller's, recorded BETWEEN the resolve launch and the update kernel: a second stream that
-    // waits for it is released as the update kernel starts, so what it runs (the id sort of a coming batch) arrives
-    // after the update kernel has taken its wave slots.  Arriving first, the sort's workgroups kept part of the
-    // update kernel's single resident wave-set waiting for a slot: 126 against 109 us for the same kernel.
-    if (mark) (void)hipEventRecord((hipEvent_t)mark, st);
+    // start_flag: the update kernel's first workgroup stores start_value there as it starts.  A second stream gated on
+    // the word (esr_stream_gate) is released as the update kernel runs, so what it brings (the id sort of a coming
+    // batch) arrives after that kernel has taken its wave slots.  Arriving first, the sort's workgroups kept part of
+    // the update kernel's single resident wave-set waiting for a slot: 126 against 109 us for the same kernel.  (An
+    // event recorded here did the same job, but the marker cost the main queue ~7 us between resolve and update.)
     ESR_DISPATCH_ROW(g, {
       static const int resident_all = resident_blocks((const void*)glove_step_resolved_kernel<VEC, NCH>, 0);
       const int resident = blocks_per_cu > 0
@@ -1237,7 +1241,7 @@ static void launch_glove_step(const GloveTables& t, const int32_t* inputs, const
       hipLaunchKernelGGL((glove_step_resolved_kernel<VEC, NCH>), dim3(grid), dim3(kBlock), 0, st, t.emb, t.emb_shadow,
                          t.emb_loc, t.emb_accum, D, g.G, (const uint32_t*)ws.own_code, (const float4*)ws.meta_res, n, B,
                          mode, nstat, (const double*)ws.stat_part, lr, eps, ws.chunk_rows, ws.bias_info, ws.pair_part,
-                         ws.res_flags);
+                         ws.res_flags, start_flag, start_value);
       // (always launched here: its last workgroup reduces the loss partials for the finalize kernel)
       hipLaunchKernelGGL((glove_step_long_kernel<VEC, NCH>), dim3(grid2), dim3(kBlock), 0, st, t.emb, t.emb_shadow,
                          t.emb_loc, t.emb_accum, D, g.G, sorted_ids, n, stamp, lr, eps, (const float*)ws.chunk_rows,
@@ -1257,7 +1261,6 @@ static void launch_glove_step(const GloveTables& t, const int32_t* inputs, const
   GlovePlan pl;
   glove_plan_layout(B, (char*)plan, &pl);
   const int nstat = mode == ESR_GLOVE_REFERENCE ? (int)std::min<int64_t>(kStatBlocksStep, cdiv(B, kBlock)) : 0;
-  if (mark) (void)hipEventRecord((hipEvent_t)mark, st);
   ESR_DISPATCH_ROW(g, {
     // one resident wave-set: every group walks a contiguous slice, so a grid larger than what the chip holds at once
     // only adds a second, partly filled round (94 VGPRs -> 5 blocks per CU: 2048 blocks ran as 1280 + 768); the
@@ -1268,7 +1271,8 @@ static void launch_glove_step(const GloveTables& t, const int32_t* inputs, const
     grid = std::max(nstat, std::min(grid, resident));
     hipLaunchKernelGGL((glove_step_kernel<VEC, NCH>), dim3(grid), dim3(kBlock), 0, st, t.emb, t.emb_shadow, t.emb_loc,
                        t.emb_accum, (const float*)t.bias, D, g.G, sorted_ids, (const float4*)pl.meta, inputs, n, B, mode,
-                       stamp, nstat, pl.stat, lr, eps, ws.chunk_rows, ws.bias_info, ws.pair_part, pl.flags);
+                       stamp, nstat, pl.stat, lr, eps, ws.chunk_rows, ws.bias_info, ws.pair_part, pl.flags, start_flag,
+                       start_value);
     if (long_runs != 0)  // 0 = the caller knows (esr_glove_plan's hint) that no run outgrows its head chunk
       hipLaunchKernelGGL((glove_step_long_kernel<VEC, NCH>), dim3(grid2), dim3(kBlock), 0, st, t.emb, t.emb_shadow,
                          t.emb_loc, t.emb_accum, D, g.G, sorted_ids, n, stamp, lr, eps, (const float*)ws.chunk_rows,
@@ -1299,8 +1303,9 @@ extern "C" {
 int esr_glove_train_step(float* emb, float* emb_shadow, uint8_t* emb_loc, float* emb_accum, float* bias,
                          float* bias_accum, int64_t V, int D, const int32_t* inputs, const float* target, int64_t B,
                          int mode, float lr, float eps, uint32_t stamp, const int32_t* presorted_ids,
-                         const int32_t* presorted_perm, void* plan, int long_runs, int blocks_per_cu, void* mark_event,
-                         float* loss, void* workspace, size_t workspace_bytes, esr_stream_t stream) {
+                         const int32_t* presorted_perm, void* plan, int long_runs, int blocks_per_cu,
+                         uint32_t* start_flag, uint32_t start_value, float* loss, void* workspace,
+                         size_t workspace_bytes, esr_stream_t stream) {
   ESR_GLOVE_STEP_CHECKS("esr_glove_train_step")
   ESR_REQUIRE(inputs && target && loss, "esr_glove_train_step: null pointer");
   ESR_REQUIRE(stamp >= 1 && stamp <= kStampMax, "esr_glove_train_step: stamp %u not in [1, %u]", stamp, kStampMax);
@@ -1321,7 +1326,7 @@ int esr_glove_train_step(float* emb, float* emb_shadow, uint8_t* emb_loc, float*
   }
   const GloveTables t{emb, emb_shadow, emb_loc, emb_accum, bias, bias_accum, D};
   launch_glove_step(t, inputs, target, B, mode, lr, eps, stamp, sorted_ids, perm, plan, long_runs, blocks_per_cu,
-                    mark_event, loss, ws, st);
+                    start_flag, start_value, loss, ws, st);
   return check_launch("esr_glove_train_step");
 }
 
@@ -1346,7 +1351,7 @@ int esr_glove_train_steps(float* emb, float* emb_shadow, uint8_t* emb_loc, float
   for (int b = 0; b < nbatch; ++b)
     launch_glove_step(t, inputs[b], targets[b], B, mode, lr, eps, first_stamp + (uint32_t)b,
                       sorted_ids + (int64_t)b * 2 * B, perm + (int64_t)b * 2 * B, (char*)plans + (size_t)b * stride,
-                      long_runs ? long_runs[b] : -1, 0, nullptr, losses + b, ws, st);
+                      long_runs ? long_runs[b] : -1, 0, nullptr, 0u, losses + b, ws, st);
   return check_launch("esr_glove_train_steps");
 }
 

@@ -345,9 +345,8 @@ constexpr int kRadixMaxPasses = 3;
 
 // FIRST: keys come from the id segments and the value is the position itself; else from (keys_in, vals_in)
 template <int TB, bool FIRST>
-__global__ __launch_bounds__((1 << TB) / 2) void radix_tile_kernel(SortSegs ids, const uint32_t* __restrict__ keys_in,
-                                                                  int n, int shift, uint32_t* __restrict__ tiles,
-                                                                  int32_t* __restrict__ hist) {
+__device__ __forceinline__ void radix_tile_body(const SortSegs& ids, const uint32_t* __restrict__ keys_in, int n,
+                                                int shift, uint32_t* __restrict__ tiles, int32_t* __restrict__ hist) {
   constexpr int kTile = 1 << TB, kThreads = kTile / 2;
   __shared__ uint32_t key[2 * kTile];
   __shared__ int bstart[kTile], bend[kTile];
@@ -386,6 +385,24 @@ __global__ __launch_bounds__((1 << TB) / 2) void radix_tile_kernel(SortSegs ids,
   hist[(int64_t)blockIdx.x * kTile + t] = bend[t] - bstart[t];
   hist[(int64_t)blockIdx.x * kTile + t + kThreads] = bend[t + kThreads] - bstart[t + kThreads];
 }
+template <int TB, bool FIRST>
+__global__ __launch_bounds__((1 << TB) / 2) void radix_tile_kernel(SortSegs ids, const uint32_t* __restrict__ keys_in,
+                                                                  int n, int shift, uint32_t* __restrict__ tiles,
+                                                                  int32_t* __restrict__ hist) {
+  radix_tile_body<TB, FIRST>(ids, keys_in, n, shift, tiles, hist);
+}
+// the same pass over the lists of a batch (blockIdx.y = list): every array of list b lies b * stride words further on
+// (keys_in: b * io_stride)
+template <int TB, bool FIRST>
+__global__ __launch_bounds__((1 << TB) / 2) void radix_tile_batched_kernel(SortSegsBatch sb,
+                                                                          const uint32_t* __restrict__ keys_in,
+                                                                          int64_t io_stride, int n, int shift,
+                                                                          uint32_t* __restrict__ tiles,
+                                                                          int32_t* __restrict__ hist, int64_t stride) {
+  const int b = blockIdx.y;
+  radix_tile_body<TB, FIRST>(sb.b[b], FIRST ? nullptr : keys_in + b * io_stride, n, shift, tiles + b * stride,
+                             hist + b * stride);
+}
 
 // long lists: per-segment column sums of the [tiles][digits] histogram matrix, one workgroup per (segment, 512 digits)
 constexpr int kRadixSeg = 32;
@@ -409,13 +426,11 @@ __global__ __launch_bounds__(kBlock) void radix_segsum_kernel(const int32_t* __r
 }
 
 template <int TB, bool FIRST>
-__global__ __launch_bounds__((1 << TB) / 2) void radix_scatter_kernel(SortSegs ids, const uint32_t* __restrict__ keys_in,
-                                                                     const uint32_t* __restrict__ vals_in, int n,
-                                                                     int ntiles, const uint32_t* __restrict__ tiles,
-                                                                     const int32_t* __restrict__ hist,
-                                                                     uint32_t* __restrict__ keys_out,
-                                                                     uint32_t* __restrict__ vals_out,
-                                                                     const int32_t* __restrict__ segsum = nullptr) {
+__device__ __forceinline__ void radix_scatter_body(const SortSegs& ids, const uint32_t* __restrict__ keys_in,
+                                                   const uint32_t* __restrict__ vals_in, int n, int ntiles,
+                                                   const uint32_t* __restrict__ tiles, const int32_t* __restrict__ hist,
+                                                   uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                   const int32_t* __restrict__ segsum) {
   constexpr int kTile = 1 << TB, kThreads = kTile / 2;
   __shared__ uint32_t comp[kTile];
   __shared__ int offs[kTile], bstart[kTile];
@@ -493,6 +508,28 @@ __global__ __launch_bounds__((1 << TB) / 2) void radix_scatter_kernel(SortSegs i
     }
   }
 }
+template <int TB, bool FIRST>
+__global__ __launch_bounds__((1 << TB) / 2) void radix_scatter_kernel(SortSegs ids, const uint32_t* __restrict__ keys_in,
+                                                                     const uint32_t* __restrict__ vals_in, int n,
+                                                                     int ntiles, const uint32_t* __restrict__ tiles,
+                                                                     const int32_t* __restrict__ hist,
+                                                                     uint32_t* __restrict__ keys_out,
+                                                                     uint32_t* __restrict__ vals_out,
+                                                                     const int32_t* __restrict__ segsum = nullptr) {
+  radix_scatter_body<TB, FIRST>(ids, keys_in, vals_in, n, ntiles, tiles, hist, keys_out, vals_out, segsum);
+}
+// batched (blockIdx.y = list): tiles / hist of list b at b * stride words, keys / values in and out at b * in_stride /
+// b * out_stride (the last pass writes the caller's [nbatch, n] arrays, the others the per-list workspace)
+template <int TB, bool FIRST>
+__global__ __launch_bounds__((1 << TB) / 2) void radix_scatter_batched_kernel(
+    SortSegsBatch sb, const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, int64_t in_stride,
+    int n, int ntiles, const uint32_t* __restrict__ tiles, const int32_t* __restrict__ hist, int64_t stride,
+    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t out_stride) {
+  const int b = blockIdx.y;
+  radix_scatter_body<TB, FIRST>(sb.b[b], FIRST ? nullptr : keys_in + b * in_stride,
+                                FIRST ? nullptr : vals_in + b * in_stride, n, ntiles, tiles + b * stride,
+                                hist + b * stride, keys_out + b * out_stride, vals_out + b * out_stride, nullptr);
+}
 
 struct RadixWs {
   uint32_t* tiles;  // [ntiles << TB]
@@ -556,6 +593,43 @@ static void launch_radix_sort(const SortSegs& sg, int n, int key_bits, const Rad
     }
     kin = kout;
     vin = vout;
+  }
+}
+// the lists of a batch (equal length n <= kRadixMaxN) pass by pass: four launches for all of them.  `base` = nbatch
+// per-list workspaces of radix_ws_layout(n) bytes each.
+template <int TB>
+static void launch_radix_sort_batched(const SortSegsBatch& sb, int nbatch, int n, int key_bits, char* base,
+                                      int32_t* sorted_ids, int32_t* perm, hipStream_t st) {
+  constexpr int kTile = 1 << TB, kThreads = kTile / 2;
+  const int ntiles = (int)cdiv(n, kTile);
+  const int passes = std::max(1, (int)cdiv(key_bits, TB));
+  const int64_t stride = (int64_t)(radix_ws_layout(n, nullptr, nullptr) / 4);  // words between two lists' workspaces
+  RadixWs ws;
+  radix_ws_layout(n, base, &ws);
+  const uint32_t* kin = nullptr;
+  const uint32_t* vin = nullptr;
+  int64_t in_stride = 0;
+  const dim3 grid(ntiles, nbatch);
+  for (int p = 0; p < passes; ++p) {
+    const bool last = p == passes - 1;
+    uint32_t* kout = last ? reinterpret_cast<uint32_t*>(sorted_ids) : ws.keys[p & 1];
+    uint32_t* vout = last ? reinterpret_cast<uint32_t*>(perm) : ws.vals[p & 1];
+    const int64_t out_stride = last ? (int64_t)n : stride;
+    const int shift = p * TB;
+    if (p == 0) {
+      hipLaunchKernelGGL((radix_tile_batched_kernel<TB, true>), grid, dim3(kThreads), 0, st, sb, kin, in_stride, n, shift,
+                         ws.tiles, ws.hist, stride);
+      hipLaunchKernelGGL((radix_scatter_batched_kernel<TB, true>), grid, dim3(kThreads), 0, st, sb, kin, vin, in_stride, n,
+                         ntiles, (const uint32_t*)ws.tiles, (const int32_t*)ws.hist, stride, kout, vout, out_stride);
+    } else {
+      hipLaunchKernelGGL((radix_tile_batched_kernel<TB, false>), grid, dim3(kThreads), 0, st, sb, kin, in_stride, n, shift,
+                         ws.tiles, ws.hist, stride);
+      hipLaunchKernelGGL((radix_scatter_batched_kernel<TB, false>), grid, dim3(kThreads), 0, st, sb, kin, vin, in_stride,
+                         n, ntiles, (const uint32_t*)ws.tiles, (const int32_t*)ws.hist, stride, kout, vout, out_stride);
+    }
+    kin = kout;
+    vin = vout;
+    in_stride = out_stride;
   }
 }
 
@@ -1059,7 +1133,8 @@ size_t esr_segment_sort_batched_workspace_bytes(int64_t n, int nbatch) {
   if (n <= 0 || nbatch <= 0) return 256;
   const size_t one = esr_segment_sort_workspace_bytes(n);  // the fallback sorts list after list in this much
   const size_t mid = n <= kMidSortMax ? align_up((size_t)nbatch * kMidWsWords * 4, 256) : 0;
-  return std::max(one, mid);
+  const size_t radix = n > kMidSortMax && n <= kRadixMaxN ? (size_t)nbatch * radix_ws_layout(n, nullptr, nullptr) : 0;
+  return std::max({one, mid, radix});
 }
 
 int esr_segment_sort_ids_batched(const int32_t* const* ids, const int64_t* counts, const int64_t* offsets, int nseg,
@@ -1110,6 +1185,10 @@ int esr_segment_sort_ids_batched(const int32_t* const* ids, const int64_t* count
     if (n <= 512 * kMidTiles) launch_tile_sort_batched<9>(sb, nbatch, (int)n, tiles, sorted_ids, perm, st);
     else if (n <= 1024 * kMidTiles) launch_tile_sort_batched<10>(sb, nbatch, (int)n, tiles, sorted_ids, perm, st);
     else launch_tile_sort_batched<11>(sb, nbatch, (int)n, tiles, sorted_ids, perm, st);
+    return check_launch("esr_segment_sort_ids_batched");
+  }
+  if (n <= kRadixMaxN && bits_for(V) <= kRadixMaxPasses * 11 && nbatch > 1) {  // four launches per pass pair for all lists
+    launch_radix_sort_batched<11>(sb, nbatch, (int)n, bits_for(V), (char*)workspace, sorted_ids, perm, st);
     return check_launch("esr_segment_sort_ids_batched");
   }
   for (int b = 0; b < nbatch; ++b)  // longer lists: one after the other (stream order: the workspace is reused)

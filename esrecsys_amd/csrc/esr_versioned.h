@@ -129,6 +129,12 @@ __device__ __forceinline__ unsigned long long coherent_load(const unsigned long 
 __device__ __forceinline__ unsigned coherent_load(const unsigned* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// "this kernel runs": its first workgroup stores `value` to *flag (device memory; NULL = nobody asked).  Read by
+// stream_gate_kernel (esr_stream_gate) on another stream.
+__device__ __forceinline__ void announce_start(uint32_t* flag, uint32_t value) {
+  if (flag && blockIdx.x == 0 && threadIdx.x == 0)
+    __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 template <int VEC, int NCH>
 __device__ __forceinline__ void row_zero(RowRegs<VEC, NCH>& r) {

@@ -185,13 +185,14 @@ GRADS_AT_IDS = 0x100  # include/esr_hip.h ESR_GRADS_AT_IDS
 
 
 def glove_train_step(emb, shadow, loc, accum, bias, bias_accum, inputs, target, mode, lr, eps=1e-7, presorted=None,
-                     blocks_per_cu=0, stamp=None, plan=None, long_runs=-1):
+                     blocks_per_cu=0, stamp=None, plan=None, long_runs=-1, start_flag=None, start_value=0):
     """One whole GloVe training step (loss + gradients + sparse Adagrad on both tables) without materialised
     gradients: esr_glove_train_step.  `emb` / `shadow` are the two buffers of the double-buffered embedding table and
     `loc` (uint8 [V]) holds each row's stamped location byte; all three are updated.  `stamp` (1 .. 127): this step's
     stamp on that table (train_state.next_stamp hands them out and clears the bytes' stamps when the counter wraps).
     presorted = (sorted_ids, perm) of inputs.reshape(-1) from segment_sort (computed ahead), else the sort runs here;
     plan = this batch's glove_plan record (needs presorted), long_runs = 0 when its hint said no run is long.
+    start_flag (int32 [1] device tensor) / start_value: the update kernel announces its start there (stream_gate).
     Returns loss[1]."""
     lib = _lib.load()
     for name, t in (("emb", emb), ("shadow", shadow), ("accum", accum), ("bias", bias), ("bias_accum", bias_accum),
@@ -218,9 +219,19 @@ def glove_train_step(emb, shadow, loc, accum, bias, bias_accum, inputs, target, 
         raise ValueError("plan must be the uint8 record glove_plan made for a batch of this size")
     check(lib.esr_glove_train_step(_p(emb), _p(shadow), _p(loc), _p(accum), _p(bias), _p(bias_accum), V, D, _p(inputs),
                                    _p(target), B, mode, float(lr), float(eps), int(stamp), _p(sid), _p(perm), _p(plan),
-                                   int(long_runs), int(blocks_per_cu), None, _p(loss), _p(ws), ws.numel(), _stream()),
+                                   int(long_runs), int(blocks_per_cu), _p(start_flag), int(start_value) & 0xFFFFFFFF,
+                                   _p(loss), _p(ws), ws.numel(), _stream()),
           "esr_glove_train_step")
     return loss
+
+
+def stream_gate(flag, value, timeout_us=1_000_000):
+    """Hold the CURRENT stream (one sleeping wave) until the device word flag[0] has reached `value` (sequence numbers,
+    wrap-safe) or timeout_us have passed: esr_stream_gate."""
+    lib = _lib.load()
+    if not (flag.is_cuda and flag.dtype == torch.int32 and flag.numel() >= 1):
+        raise ValueError("stream_gate: flag must be an int32 device tensor")
+    check(lib.esr_stream_gate(_p(flag), int(value) & 0xFFFFFFFF, int(timeout_us), _stream()), "esr_stream_gate")
 
 
 def _aligned_bytes(nbytes, device, align=256):
@@ -516,13 +527,20 @@ def inbatch_softmax_fwd_bwd(Q, C, scale, regularization, batch_size, precision="
 
 
 # ---------------------------------------------------------------------------------------------
-def segment_sort(ids, V):
-    """Stable sort of occurrence ids.  Returns (sorted_ids, perm) with sorted_ids == ids[perm]."""
+def segment_sort(ids, V, out=None):
+    """Stable sort of occurrence ids.  Returns (sorted_ids, perm) with sorted_ids == ids[perm]; `out` = a pair of int32
+    tensors of ids' size to sort into (a caller that recycles its buffers)."""
     lib = _lib.load()
     ids = _req(ids, torch.int32, "ids")
     n = ids.numel()
-    sorted_ids = torch.empty_like(ids)
-    perm = torch.empty_like(ids)
+    if out is not None:
+        sorted_ids, perm = out
+        _req(sorted_ids, torch.int32, "out[0]"), _req(perm, torch.int32, "out[1]")
+        if sorted_ids.numel() != n or perm.numel() != n:
+            raise ValueError("segment_sort: out tensors must have ids' size")
+    else:
+        sorted_ids = torch.empty_like(ids)
+        perm = torch.empty_like(ids)
     ws = _ws(_ws_bytes("esr_segment_sort_workspace_bytes", n), ids.device)
     check(lib.esr_segment_sort_ids(_p(ids), n, V, _p(sorted_ids), _p(perm), _p(ws), ws.numel(), _stream()),
           "esr_segment_sort_ids")

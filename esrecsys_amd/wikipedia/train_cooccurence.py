@@ -147,10 +147,21 @@ class PresortedInputs:
         self.plan, self.hint, self.target = plan, hint, target
         self._done = event
 
-    def take(self):
-        """(sorted_ids, perm) for the current stream (waits for the side stream's event, once)."""
+    def take(self, host_wait_s=0.0):
+        """(sorted_ids, perm) for the current stream (waits for the side stream's event, once).  host_wait_s > 0 (the
+        epoch loop): the HOST waits up to that long for the event first, and a finished event costs the stream nothing --
+        a wait queued on an unfinished one is a cross-queue barrier in front of the step, ~12 us of idle main queue at
+        C3 although the sort had ended a step earlier by the time the barrier was reached.  The loop sorts two batches
+        ahead, so the host still runs a step or more in front of the GPU."""
         if self.event is not None:
-            torch.cuda.current_stream(self.inputs.device).wait_event(self.event)
+            ev = self.event
+            if host_wait_s > 0.0 and not ev.query():
+                import time
+                t_end = time.perf_counter() + host_wait_s
+                while not ev.query() and time.perf_counter() < t_end:
+                    pass
+            if not ev.query():
+                torch.cuda.current_stream(self.inputs.device).wait_event(ev)
             self.event = None
         return self.sorted_ids, self.perm
 
@@ -167,9 +178,22 @@ _PRESORT = os.environ.get("ESR_GLOVE_PRESORT", "1") == "1"
 _PRESORT_DEPTH = max(1, int(os.environ.get("ESR_GLOVE_PRESORT_DEPTH", "2")))  # batches sorted ahead (train_epoch)
 _SORT_BATCH = min(8, max(1, int(os.environ.get("ESR_GLOVE_SORT_BATCH", "8"))))  # short lists sorted together (train_epoch)
 _STEP_BLOCKS_PER_CU = int(os.environ.get("ESR_GLOVE_STEP_BLOCKS_PER_CU", "0"))
+# train_epoch: how long the host waits for a side-stream sort before it queues a stream wait instead (PresortedInputs.take)
+_HOST_WAIT_S = float(os.environ.get("ESR_GLOVE_HOST_WAIT_US", "0")) * 1e-6
 
 
 _hint_ring = {}  # device -> [pinned int32 [R], next slot, next gen]
+_start_words = {}  # device -> [int32 [1] device word, sequence number of the latest step that announces itself there]
+
+
+def _start_word(dev):
+    """The device word in which the one-pass steps of the epoch loops announce themselves (esr_glove_train_step's
+    start_flag) and its running sequence number; one per device for the life of the process, so a gate left over from
+    an earlier epoch never reads freed memory."""
+    key = (dev.type, dev.index)
+    if key not in _start_words:
+        _start_words[key] = [torch.zeros(1, dtype=torch.int32, device=dev), 0]
+    return _start_words[key]
 _RESOLVE_MIN_IDS = 32768  # esr_glove.hip kResolveMinIds: longer lists resolve their records per step, plans are unused
 
 
@@ -186,10 +210,13 @@ def _hint_slot(dev):
     return ring[0][i:i + 1], gen
 
 
-def presort_inputs(state, inputs, target=None, after=None):
+def presort_inputs(state, inputs, target=None, after=None, out=None):
     """Move `inputs` to the device and sort its occurrence ids on the side stream; with `target` (the batch's counts) the
     step's plan record is made there as well (ops.glove_plan: it needs ids and counts only).  Returns a PresortedInputs
-    to pass as ``train_step(..., inputs=that)``."""
+    to pass as ``train_step(..., inputs=that)``.  `out` = (sorted_ids, perm) buffers of the caller's to sort into: the
+    caller then answers for their lifetime (train_epoch's ring) -- tensors allocated here are handed to the main stream
+    with record_stream, and freeing such a tensor makes the allocator record an event on the main stream: two markers
+    between a step's last kernel and the next step's first, ~11 us of idle queue per step at C3."""
     from ..train_state import _side_stream
     emb = state.raw_params["_token_embedding"]["embedding"]
     V = emb.shape[0]
@@ -197,13 +224,18 @@ def presort_inputs(state, inputs, target=None, after=None):
     tgt = ops.as_f32(target, emb.device) if target is not None else None
     main = torch.cuda.current_stream(emb.device)
     side = _side_stream(emb.device)
-    if after is not None:  # an event of the main stream behind which the ids are ready (train_epoch: the mark a step
-        side.wait_event(after)  # records in front of its update kernel -- the sort then arrives after that kernel)
-    else:
+    if after is None:
         side.wait_stream(main)  # the ids may have been produced (copied) on the main stream
+    elif not isinstance(after, tuple):
+        side.wait_event(after)  # an event of the main stream behind which the ids are ready
     plan = hint = None
     with torch.cuda.stream(side):
-        sorted_ids, perm = ops.segment_sort(ids.reshape(-1), V)
+        if isinstance(after, tuple):
+            # (flag, value): the start word of a step NOT YET ISSUED when the ids were drawn (train_epoch) -- whatever
+            # the main stream still has to do to produce them is queued in front of that step's update kernel, and the
+            # sort arrives after that kernel has taken its wave slots.  No marker on the main queue.
+            ops.stream_gate(after[0], after[1])
+        sorted_ids, perm = ops.segment_sort(ids.reshape(-1), V, out=out)
         if tgt is not None and ids.dim() == 2 and ids.shape[0] == 2 and tgt.numel() == ids.shape[1]:
             # (longer lists: the step resolves its own records in front of its update kernel and makes every launch --
             # its long-run launch also reduces the loss partials -- so neither a plan nor the hint is of use)
@@ -214,8 +246,9 @@ def presort_inputs(state, inputs, target=None, after=None):
         event = torch.cuda.Event()
         event.record(side)
     ids.record_stream(side)
-    sorted_ids.record_stream(main)
-    perm.record_stream(main)
+    if out is None:
+        sorted_ids.record_stream(main)
+        perm.record_stream(main)
     if plan is not None:
         plan.record_stream(main)
     if tgt is not None:
@@ -253,7 +286,10 @@ def train_step(state, inputs, target):
     return state.replace(step=state.step + 1), loss.reshape(())
 
 
-_PRESORT_MIN_IDS = 4096
+# train_epoch: lists of up to _GROUP_SORT_MAX_IDS ids are sorted a group of _SORT_BATCH batches at a time by one batched
+# call on the main stream (esr_segment_sort_ids_batched); longer ones one by one on the side stream, _PRESORT_DEPTH ahead
+_GROUP_SORT_MAX_IDS = int(os.environ.get("ESR_GLOVE_GROUP_SORT_MAX_IDS", str(1 << 18)))
+_PRESORT_MIN_IDS = _GROUP_SORT_MAX_IDS
 
 
 def _ids_count(inputs):
@@ -298,8 +334,11 @@ class _FusedEpoch:
         self.check = _lib.check
         self.losses = torch.empty(max(steps, 1), dtype=torch.float32, device=self.dev)
         self.losses_ptr = self.losses.data_ptr()
+        self.sort_ring = None
+        self.steps_issued = 0
         self.ws, self.ws_B = None, -1
         self.sort_buf = [None, None]  # two sets: a group is sorted and planned while the one before it is stepped
+        self.long_buf = [None, None]  # the same for lists too long for plans (_sort_batch_long)
         self.which = 0
         import ctypes
         self.sort_ptrs = [(ctypes.c_void_p * _SORT_BATCH)(), (ctypes.c_void_p * _SORT_BATCH)()]
@@ -311,10 +350,7 @@ class _FusedEpoch:
         self.hints_known = [None, None]
         self.gen = 0
         self.sort_cnt, self.sort_off = (ctypes.c_int64 * 1)(0), (ctypes.c_int64 * 1)(0)
-        self.marks = [torch.cuda.Event() for _ in range(4)]
-        for ev in self.marks:
-            ev.record()  # (creates the HIP event behind the object: the library re-records it)
-        self.last_mark = None
+        self.start = _start_word(self.dev)  # [int32 [1] device word, sequence number of the latest step issued]
         self.check_ids = os.environ.get("ESR_CHECK_IDS") == "1"
         self.fixed = (self.emb.data_ptr(), self.rv.shadow.data_ptr(), self.rv.loc.data_ptr(), self.acc_e.data_ptr(),
                       self.bias.data_ptr(), self.acc_b.data_ptr(), self.V, self.D)
@@ -325,7 +361,8 @@ class _FusedEpoch:
         (batches of unequal size or longer than the two-launch sort takes: the list as it is, every step on its own)."""
         ids = [ops.as_ids(inp, self.dev, check_range=self.V) for inp, _ in group]
         n = ids[0].numel()
-        if n > 32768 or any(t.numel() != n for t in ids) or any(t.dim() != 2 or t.shape[0] != 2 for t in ids):
+        if n > _GROUP_SORT_MAX_IDS or any(t.numel() != n for t in ids) or \
+                any(t.dim() != 2 or t.shape[0] != 2 for t in ids):
             return [(i, t) for i, (_, t) in zip(ids, group)]  # as they are: every step sorts and plans its own
         if self.check_ids:
             for i in ids:
@@ -334,6 +371,8 @@ class _FusedEpoch:
         self.which ^= 1
         which = self.which
         B = n // 2
+        if n > _RESOLVE_MIN_IDS:
+            return self._sort_batch_long(ids, group, n, which)
         pbytes = ops._ws_bytes("esr_glove_plan_bytes", B)
         if self.sort_buf[which] is None or self.sort_buf[which][0].shape[1] != n:
             self.sort_buf[which] = (torch.empty((_SORT_BATCH, n), dtype=torch.int32, device=self.dev),
@@ -370,6 +409,29 @@ class _FusedEpoch:
         return _Group(nb, B, self.sort_ptrs[which], self.tgt_ptrs[which], srt.data_ptr(), prm.data_ptr(),
                       plans.data_ptr(), which, self.gen, (ids, tgts))
 
+    def _sort_batch_long(self, ids, group, n, which):
+        """Lists of more than _RESOLVE_MIN_IDS ids (the steps resolve their own records: no plans): the lists of the group
+        sorted by ONE batched call on the current stream, each step then issued on its own with its slice.  The sort of
+        one such list is four launches of 64 workgroups -- latency, not work -- so eight lists cost little more than one,
+        the update kernels run with nothing beside them and no second stream is involved (a sort on the side stream
+        shares the chip with the update kernel: at C3 it stretched to the length of a step and held the loop to its own
+        pace, 0.143 ms)."""
+        nb = len(ids)
+        if self.long_buf[which] is None or self.long_buf[which][0].shape[1] != n:
+            self.long_buf[which] = (torch.empty((_SORT_BATCH, n), dtype=torch.int32, device=self.dev),
+                                    torch.empty((_SORT_BATCH, n), dtype=torch.int32, device=self.dev),
+                                    ops._ws(ops._ws_bytes("esr_segment_sort_batched_workspace_bytes", n, _SORT_BATCH),
+                                            self.dev))
+        srt, prm, ws = self.long_buf[which]
+        sort_ptrs = self.sort_ptrs[which]
+        for b, i in enumerate(ids):
+            sort_ptrs[b] = i.data_ptr()
+        self.sort_cnt[0] = n
+        self.check(self.lib.esr_segment_sort_ids_batched(sort_ptrs, self.sort_cnt, self.sort_off, 1, nb, self.V,
+                                                         srt.data_ptr(), prm.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                         ops._stream()), "esr_segment_sort_ids_batched")
+        return [(PresortedInputs(i, srt[b], prm[b], None), t) for b, (i, (_, t)) in enumerate(zip(ids, group))]
+
     def step_group(self, k, gr):
         """Steps k .. k + gr.nb - 1: the batches of a sorted and planned group, issued by one library call."""
         known = self.hints_known[gr.which]
@@ -389,6 +451,17 @@ class _FusedEpoch:
                                                   self.ws.data_ptr(), self.ws.numel(), ops._stream()),
                    "esr_glove_train_steps")
 
+    def sort_slot(self, n, j):
+        """(sorted_ids, perm) buffers for the side-stream sort of the j-th batch drawn: a ring of _PRESORT_DEPTH + 3.
+        The sort of batch j is released by the mark of step j - depth - 1 at the latest (refill runs behind a step and
+        tops the queue up to depth + 1), i.e. after step j - depth - 2 has finished on the main stream -- the last
+        reader of the slot was step j - depth - 3."""
+        R = _PRESORT_DEPTH + 3
+        if self.sort_ring is None or self.sort_ring[0][0].numel() != n:
+            self.sort_ring = [(torch.empty(n, dtype=torch.int32, device=self.dev),
+                               torch.empty(n, dtype=torch.int32, device=self.dev)) for _ in range(R)]
+        return self.sort_ring[j % R]
+
     def step(self, k, inputs, target):
         presorted, plan_ptr, long_runs = None, 0, -1
         if isinstance(inputs, PresortedInputs):
@@ -397,7 +470,7 @@ class _FusedEpoch:
                 plan_ptr = inputs.plan.data_ptr()
             if inputs.target is not None:
                 target = inputs.target
-            presorted, inputs = inputs.take(), inputs.inputs
+            presorted, inputs = inputs.take(_HOST_WAIT_S), inputs.inputs
         if not (type(inputs) is torch.Tensor and inputs.is_cuda and inputs.dtype == torch.int32 and
                 inputs.is_contiguous()):
             inputs = ops.as_ids(inputs, self.dev, check_range=self.V)
@@ -413,14 +486,23 @@ class _FusedEpoch:
             self.ws = ops._ws(ops._ws_bytes("esr_glove_step_workspace_bytes", B, self.D), self.dev)
             self.ws_B = B
         sid, perm = (presorted[0].data_ptr(), presorted[1].data_ptr()) if presorted is not None else (0, 0)
-        # an event recorded in front of the update kernel: the next presort waits for it (see presort_inputs)
-        mark = self.marks[k % len(self.marks)]
+        # the update kernel stores this step's sequence number in the start word: side-stream sorts are gated on it
+        start = self.start
+        start[1] = seq = (start[1] + 1) & 0xFFFFFFFF
         self.check(self.lib.esr_glove_train_step(*self.fixed, inputs.data_ptr(), target.data_ptr(), B, self.mode,
                                                  self.lr, self.eps, self.next_stamp(self.rv), sid, perm, plan_ptr,
-                                                 long_runs, 0, mark.cuda_event, self.losses.data_ptr() + 4 * k,
-                                                 self.ws.data_ptr(), self.ws.numel(), ops._stream()),
+                                                 long_runs, 0, start[0].data_ptr(), seq,
+                                                 self.losses.data_ptr() + 4 * k, self.ws.data_ptr(), self.ws.numel(),
+                                                 ops._stream()),
                    "esr_glove_train_step")
-        self.last_mark = mark
+        self.steps_issued += 1
+
+    def next_start(self):
+        """What gates the sort of a batch drawn NOW: (start word, sequence number of the next step to be issued) once a
+        step of this epoch has been issued, else None (the first batches: the side stream waits for the main one)."""
+        if self.steps_issued == 0:
+            return None
+        return (self.start[0], (self.start[1] + 1) & 0xFFFFFFFF)
 
 
 def train_epoch(state, steps_per_epoch, train_it, consolidate=True):
@@ -470,7 +552,8 @@ def _train_epoch(state, steps_per_epoch, train_it):
                 fetched += 1
                 if _PRESORT and _ids_count(inputs) > _PRESORT_MIN_IDS:
                     grouped = False
-                    queue.append((presort_inputs(state, inputs, targets, after=ctx.last_mark), targets))
+                    queue.append((presort_inputs(state, inputs, targets, after=ctx.next_start(),
+                                                 out=ctx.sort_slot(_ids_count(inputs), fetched)), targets))
                     queued += 1
                 elif _SORT_BATCH > 1 and grouped and k > 0:  # (the first step goes out alone: the GPU starts at once)
                     group = [(inputs, targets)]

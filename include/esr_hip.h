@@ -110,15 +110,24 @@ int esr_glove_fwd_bwd(const float* emb, const float* bias, int64_t V, int D, con
  * here.  long_runs: 0 = the caller knows from esr_glove_plan's hint that no run of equal ids outgrows a 32-position
  * chunk, and the long-run launch is skipped; anything else = launched (it returns at once when nothing was parked).
  * Launches per step with a plan and uniform ids: update, finalize.  blocks_per_cu > 0 caps the update kernel's
- * residency (experiment knob); 0 = fill the chip.  mark_event (optional hipEvent_t): recorded on `stream` just in front
- * of the update kernel -- a second stream that waits for it (the id sort of a coming batch) is released as that kernel
- * starts, i.e. arrives after it has taken its wave slots. */
+ * residency (experiment knob); 0 = fill the chip.  start_flag (optional, device uint32): the update kernel's first
+ * workgroup stores start_value there as it starts -- a second stream gated on the word (esr_stream_gate: the id sort
+ * of a coming batch) is released while that kernel runs, i.e. arrives after it has taken its wave slots, and the main
+ * queue carries no event marker for it. */
 size_t esr_glove_step_workspace_bytes(int64_t B, int D);
 int esr_glove_train_step(float* emb, float* emb_shadow, uint8_t* emb_loc, float* emb_accum, float* bias,
                          float* bias_accum, int64_t V, int D, const int32_t* inputs, const float* target, int64_t B,
                          int mode, float lr, float eps, uint32_t stamp, const int32_t* presorted_ids,
-                         const int32_t* presorted_perm, void* plan, int long_runs, int blocks_per_cu, void* mark_event,
-                         float* loss, void* workspace, size_t workspace_bytes, esr_stream_t stream);
+                         const int32_t* presorted_perm, void* plan, int long_runs, int blocks_per_cu,
+                         uint32_t* start_flag, uint32_t start_value, float* loss, void* workspace,
+                         size_t workspace_bytes, esr_stream_t stream);
+/* Holds `stream` (one sleeping wave) until the device word *flag has reached `value` -- sequence numbers, compared
+ * wrap-safe as (int32)(*flag - value) >= 0 -- or timeout_us have passed (then the stream goes on: the gate orders work
+ * for speed and for producers that are certain to run; it never hangs a queue).  The cheap cross-stream edge of the
+ * training loops: no event marker on the producing stream, whose kernel announces itself with one store
+ * (esr_glove_train_step's start_flag).  Build-defined: the reference's loops are single-stream JAX dispatch
+ * (wikipedia/train_cooccurence.py:103-112). */
+int esr_stream_gate(const uint32_t* flag, uint32_t value, uint32_t timeout_us, esr_stream_t stream);
 /* The steps of nbatch <= 8 planned batches issued by ONE call (a training loop's per-step host work is then one
  * foreign call per group: at the reference's batch of 2048 pairs a step is ~20 us of kernels, less than a ctypes call
  * with 25 arguments plus the Python around it).  inputs / targets / sorted_ids / perm / plans as esr_glove_plan took and
