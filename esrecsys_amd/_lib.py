@@ -113,7 +113,7 @@ SIGNATURES = {
     "esr_concat_offset_ids": (c_int, [c_vp, c_vp, c_vp, c_int, c_i32p, c_vp]),
     "esr_gather_rows_multi": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_i32p, c_i64, c_vp, c_vp]),
     "esr_sparse_adagrad_scatter_multi": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_i32p, c_i32p, c_i64, c_f32p,
-                                                 c_f32, c_f32, c_vp]),
+                                                 c_f32, c_f32, c_int, c_vp]),
     "esr_sparse_sgd_scatter": (c_int, [c_vp, c_int, c_i64, c_int, c_i32p, c_i32p, c_i64, c_f32p, c_f32, c_vp]),
     "esr_rows_to_dense": (c_int, [c_f32p, c_i64, c_int, c_i32p, c_i32p, c_i64, c_f32p, c_vp]),
     "esr_dense_adam": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_f32, c_f32, c_f32, c_f32, c_i64, c_vp]),

@@ -377,7 +377,7 @@ __global__ __launch_bounds__(kBlock) void concat_offset_ids_kernel(IdSegments sg
 template <int OP>
 static int launch_segment_tables(const char* who, const FusedTables& ft, int dtype, int D, const int32_t* sorted_ids,
                                  const int32_t* perm, int64_t n, float* grad_rows, float lr, float eps,
-                                 hipStream_t st) {
+                                 hipStream_t st, bool skip_long = false) {
   const RowGeom g = row_geom(D);
   if (g.nch > kMaxChunksPerLane) {
     set_error("%s: D=%d not supported", who, D);
@@ -388,7 +388,7 @@ static int launch_segment_tables(const char* who, const FusedTables& ft, int dty
   ESR_DISPATCH_ROW(g, {
     hipLaunchKernelGGL((segment_update_kernel<VEC, NCH, OP>), dim3(grid), dim3(kBlock), 0, st, ft, dtype, D, g.G,
                        sorted_ids, perm, n, grad_rows, lr, eps);
-    if (n > kSegChunk)
+    if (n > kSegChunk && !skip_long)
       hipLaunchKernelGGL((segment_long_kernel<VEC, NCH, OP>), dim3(grid2), dim3(kBlock), 0, st, ft, dtype, D, g.G,
                          sorted_ids, perm, n, (const float*)grad_rows, lr, eps);
   });
@@ -762,7 +762,8 @@ int esr_gather_rows_multi(const void* const* tables, const int64_t* row_offsets,
 
 int esr_sparse_adagrad_scatter_multi(void* const* tables, float* const* accums, const int64_t* row_offsets,
                                      int ntables, int dtype, int D, const int32_t* sorted_vids, const int32_t* perm,
-                                     int64_t n, float* grad_rows, float lr, float eps, esr_stream_t stream) {
+                                     int64_t n, float* grad_rows, float lr, float eps, int long_runs,
+                                     esr_stream_t stream) {
   ESR_REQUIRE(ntables >= 1 && ntables <= kMaxFusedTables, "esr_sparse_adagrad_scatter_multi: ntables=%d not in [1, %d]",
               ntables, kMaxFusedTables);
   ESR_REQUIRE(D > 0 && n >= 0, "esr_sparse_adagrad_scatter_multi: bad sizes D=%d n=%lld", D, (long long)n);
@@ -785,7 +786,7 @@ int esr_sparse_adagrad_scatter_multi(void* const* tables, float* const* accums, 
   ESR_REQUIRE(row_offsets[ntables] < ((int64_t)1 << 31), "esr_sparse_adagrad_scatter_multi: %lld virtual rows >= 2^31",
               (long long)row_offsets[ntables]);
   return launch_segment_tables<kAdagrad>("esr_sparse_adagrad_scatter_multi", ft, dtype, D, sorted_vids, perm, n,
-                                         grad_rows, lr, eps, as_stream(stream));
+                                         grad_rows, lr, eps, as_stream(stream), long_runs == 0);
 }
 
 int esr_dense_adam(float* param, float* mu, float* nu, const float* grad, int64_t numel, float lr, float b1,

@@ -619,8 +619,10 @@ def gather_rows_multi(tables, row_offsets, vids, out=None):
     return out
 
 
-def sparse_adagrad_multi(tables, accums, row_offsets, sorted_vids, perm, grad_rows, lr, eps=1e-7):
-    """One launch of row-sparse Adagrad over several same-width tables addressed by virtual rows."""
+def sparse_adagrad_multi(tables, accums, row_offsets, sorted_vids, perm, grad_rows, lr, eps=1e-7, long_runs=-1):
+    """One launch of row-sparse Adagrad over several same-width tables addressed by virtual rows.  long_runs = 0: the
+    caller knows (long_run_hint with chunk 32) that no id has a run the head chunk cannot hold -- the long-run launch
+    is skipped."""
     import ctypes
     lib = _lib.load()
     n_t = len(tables)
@@ -638,7 +640,7 @@ def sparse_adagrad_multi(tables, accums, row_offsets, sorted_vids, perm, grad_ro
     ap = (ctypes.c_void_p * n_t)(*[a.data_ptr() for a in accums])
     ro = (ctypes.c_int64 * (n_t + 1))(*[int(o) for o in row_offsets])
     check(lib.esr_sparse_adagrad_scatter_multi(tp, ap, ro, n_t, dts.pop(), D, _p(sorted_vids), _p(perm), n,
-                                               _p(grad_rows), float(lr), float(eps), _stream()),
+                                               _p(grad_rows), float(lr), float(eps), int(long_runs), _stream()),
           "esr_sparse_adagrad_scatter_multi")
 
 

@@ -70,9 +70,17 @@ class PresortedTriplets:
     on the side stream (``presort_triplets``): pass it as ``train_step(state, that, None, None, ...)``.  The sort needs
     the ids only, so a training loop runs it for batch k + 1 while batch k's kernels are in flight."""
 
-    def __init__(self, scene, pos, neg, sorted_ids, perm, event):
+    def __init__(self, scene, pos, neg, sorted_ids, perm, event, hint=None):
         self.scene, self.pos, self.neg = scene, pos, neg
         self.sorted_ids, self.perm, self.event = sorted_ids, perm, event
+        self.hint = hint  # (pinned int32 [1], gen, event recorded behind the hint kernel) or None
+
+    def long_runs(self):
+        """0 when the long-run hint has reached the host and says no id has a run longer than a 32-position chunk, 1
+        when it says one has, -1 while nobody knows."""
+        if self.hint is None or not self.hint[2].query():
+            return -1
+        return 1 if int(self.hint[0][0]) == self.hint[1] else 0
 
     def take(self):
         if self.event is not None:
@@ -175,6 +183,7 @@ def train_step(state, scene, pos_product, neg_product, regularization, batch_siz
         fused = FusedScatter([sid, pid], [0, 1], [Vs, Vp], None, paths) if sparse else None
         if fused is not None and presorted is not None:
             fused.index._sorted = presorted.take()  # sorted one batch ahead on the side stream (presort_triplets)
+            fused.index.long_runs = presorted.long_runs()
         elif fused is not None and _PRESORT:
             fused.index.presort()
         if precision != "f32" and st.dtype == pt.dtype and \
@@ -358,8 +367,15 @@ class _FusedTripletLoop:
         if _PLAN_ON_SIDE:
             self.main.wait_event(self.hints_event[gr.which])
         known = self.hints_known[gr.which]
-        if known is None and self.hints_event[gr.which].query():
-            known = self.hints_known[gr.which] = self.hints_host[gr.which].tolist()
+        if known is None:
+            # the HOST waits for the group's plan launch: it was queued in front of the steps of the group before, so
+            # the wait ends with those steps (a group's worth of work) still queued -- the device never runs dry, the
+            # host stays at most two groups ahead, and every step knows whether it needs its long-run launch (a loop
+            # that ran further ahead never saw a hint in time and made all of them: 4.8 us per step at B = 8192)
+            if _HINT_WAIT:
+                self.hints_event[gr.which].synchronize()
+            if self.hints_event[gr.which].query():
+                known = self.hints_known[gr.which] = self.hints_host[gr.which].tolist()
         long_runs = None
         if known is not None:  # (else: the hint has not reached the host; the library makes every long-run launch)
             long_runs = self.long_arr
@@ -404,6 +420,8 @@ _SORT_BATCH = min(8, max(1, int(_os.environ.get("ESR_STL_SORT_BATCH", "8"))))
 _SORT_BATCH_MAX_IDS = 32768
 # ESR_STL_PLAN_STREAM=side: the sort + plan of a group on the second stream, beside the steps of the group before it
 _PLAN_ON_SIDE = _os.environ.get("ESR_STL_PLAN_STREAM", "main") == "side"
+# ESR_STL_HINT_WAIT=0: a group whose long-run hints have not reached the host is stepped without them (A/B knob)
+_HINT_WAIT = _os.environ.get("ESR_STL_HINT_WAIT", "1") == "1"
 
 
 def _inbatch_steps(state, it, first, num_steps, regularization, batch_size, scale, precision):
@@ -415,32 +433,59 @@ def _inbatch_steps(state, it, first, num_steps, regularization, batch_size, scal
 
     def ids_of(batch):
         return (ops.as_ids(batch[0], dev, check_range=Vs).reshape(-1), ops.as_ids(batch[1], dev, check_range=Vp).reshape(-1))
-    losses, k, pending, dry = [], 0, [ids_of(first)], False
-    while k < num_steps:
+    losses, pending, dry = [], [ids_of(first)], False
+    drawn = 0  # steps whose batches have been drawn and grouped
+
+    def next_group():
+        """The handles of the next group of steps (None when all have been drawn): batches drawn, their lists sorted
+        and screened for long runs -- launches queued NOW, i.e. in front of the steps of the group before."""
+        nonlocal pending, dry, drawn
+        k0 = drawn
+        if k0 >= num_steps:
+            return None
         if not pending:
             if dry:
-                raise StopIteration("train_steps: the batch iterator ended after %d of %d steps" % (k, num_steps))
+                raise StopIteration("train_steps: the batch iterator ended after %d of %d steps" % (k0, num_steps))
             pending = [ids_of(next(it))]
         # the FIRST step goes out alone, sorting its own list in line: the GPU starts after one batch's worth of host work,
         # and the first group of eight is drawn and sorted while that step runs (drawing eight batches first left the
         # device idle for ~0.2 ms at the head of every call -- 4 % of a 20-step run)
         # (then groups of 2, 4, 8: drawing and sorting a group of eight is ~0.2 ms of host work, more than the one step
         # that is in flight behind it)
-        want = min(_SORT_BATCH, num_steps - k, 1 if k == 0 else (2 if k < 3 else (4 if k < 7 else _SORT_BATCH)))
+        want = min(_SORT_BATCH, num_steps - k0, 1 if k0 == 0 else (2 if k0 < 3 else (4 if k0 < 7 else _SORT_BATCH)))
         while len(pending) < want and not dry:
             try:
                 pending.append(ids_of(next(it)))
             except StopIteration:
                 dry = True
         group, pending = pending[:want], pending[want:]
+        drawn += len(group)
         n = 2 * group[0][0].numel()
         if sparse and _SORT_BATCH > 1 and len(group) > 1 and n <= _SORT_BATCH_MAX_IDS and \
                 all(g[0].numel() == group[0][0].numel() == g[1].numel() for g in group):
             srt, prm = ops.segment_sort_batched([list(g) for g in group], (0, Vs), Vs + Vp)
-            handles = [PresortedTriplets(g[0], g[1], None, srt[j], prm[j], None) for j, g in enumerate(group)]
-        else:
-            handles = [PresortedTriplets(g[0], g[1], None, None, None, None) for g in group]
-        for h in handles:
+            # one screening launch for the whole group (the [nb, n] array as one list: a run across two lists can only
+            # make the answer "long"): hint word in pinned memory, read once its event is complete -- a group without
+            # hot ids then skips the long-run launch of every optimizer step (5 us of 237 at C2)
+            from ..wikipedia.train_cooccurence import _hint_slot
+            hh, gen = _hint_slot(dev)
+            ops.long_run_hint(srt.reshape(-1), 32, hh, gen)
+            ev = torch.cuda.Event()
+            ev.record()
+            hint = (hh, gen, ev)
+            return [PresortedTriplets(g[0], g[1], None, srt[j], prm[j], None, hint) for j, g in enumerate(group)]
+        return [PresortedTriplets(g[0], g[1], None, None, None, None) for g in group]
+
+    cur, head = next_group(), True
+    while cur is not None:
+        # the NEXT group is sorted and screened in front of this group's steps: its hint is then on the host by the time
+        # its first step is issued -- the wait below ends when the group before this one has run, i.e. with this whole
+        # group still queued, so the device never runs dry while the host stays at most two groups ahead
+        # (the very first step is issued before anything else is drawn: the GPU starts at once)
+        nxt = None if head else next_group()
+        if cur[0].hint is not None:
+            cur[0].hint[2].synchronize()
+        for h in cur:
             if h.sorted_ids is None:
                 state, loss = train_step(state, h.scene, h.pos, None, regularization, batch_size, scale=scale,
                                          precision=precision)
@@ -448,7 +493,9 @@ def _inbatch_steps(state, it, first, num_steps, regularization, batch_size, scal
                 state, loss = train_step(state, h, None, None, regularization, batch_size, scale=scale,
                                          precision=precision)
             losses.append(loss)
-            k += 1
+        if head:
+            nxt, head = next_group(), False
+        cur = nxt
     return state, torch.stack(losses)
 
 

@@ -62,6 +62,7 @@ class SegmentIndex:
         self.num_rows = int(num_rows)
         self._sorted = None
         self._event = None
+        self.long_runs = -1  # 0 once somebody knows (ops.long_run_hint) that no run outgrows its 32-position head chunk
 
     @property
     def ids(self):
@@ -255,7 +256,8 @@ class _SparseAdagrad(GradientTransformation):
                 sorted_vids, perm = f.index.sorted()
                 ops.sparse_adagrad_multi([tree_get(params, q) for q in f.paths],
                                          [tree_get(opt_state["sum_of_squares"], q) for q in f.paths],
-                                         f.row_offsets, sorted_vids, perm, f.rows, self.lr, self.eps)
+                                         f.row_offsets, sorted_vids, perm, f.rows, self.lr, self.eps,
+                                         long_runs=f.index.long_runs)
                 continue
             _consume(g, "RowGrads")
             sorted_ids, perm = g.index.sorted()

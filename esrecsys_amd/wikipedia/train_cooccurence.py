@@ -179,6 +179,7 @@ _PRESORT_DEPTH = max(1, int(os.environ.get("ESR_GLOVE_PRESORT_DEPTH", "2")))  # 
 _SORT_BATCH = min(8, max(1, int(os.environ.get("ESR_GLOVE_SORT_BATCH", "8"))))  # short lists sorted together (train_epoch)
 _STEP_BLOCKS_PER_CU = int(os.environ.get("ESR_GLOVE_STEP_BLOCKS_PER_CU", "0"))
 # train_epoch: how long the host waits for a side-stream sort before it queues a stream wait instead (PresortedInputs.take)
+_HINT_WAIT = os.environ.get("ESR_GLOVE_HINT_WAIT", "1") == "1"
 _HOST_WAIT_S = float(os.environ.get("ESR_GLOVE_HOST_WAIT_US", "0")) * 1e-6
 
 
@@ -435,8 +436,14 @@ class _FusedEpoch:
     def step_group(self, k, gr):
         """Steps k .. k + gr.nb - 1: the batches of a sorted and planned group, issued by one library call."""
         known = self.hints_known[gr.which]
-        if known is None and self.hints_event[gr.which].query():
-            known = self.hints_known[gr.which] = self.hints_host[gr.which].tolist()
+        if known is None:
+            # the HOST waits for the group's plan launch (queued in front of the steps of the group before it: the wait
+            # ends with a group's worth of work still queued), so that every step knows whether it needs its long-run
+            # launch -- see pinterest.train_shop_the_look._FusedTripletLoop.step_group
+            if _HINT_WAIT:
+                self.hints_event[gr.which].synchronize()
+            if self.hints_event[gr.which].query():
+                known = self.hints_known[gr.which] = self.hints_host[gr.which].tolist()
         long_runs = None
         if known is not None:  # (else: the hint has not reached the host; the library makes every long-run launch)
             long_runs = self.long_arr

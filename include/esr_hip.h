@@ -306,7 +306,10 @@ int esr_sparse_adagrad_scatter(void* table, int dtype, float* accum, int64_t V, 
  * vid = row_offsets[t] + id of the concatenation of <= 4 tables, so a two-tower step needs one sort chain
  * and one update launch.  tables / accums / row_offsets (ntables + 1 entries) are HOST arrays of device
  * pointers / int64.  esr_concat_offset_ids builds the virtual ids: out = [ids[0] + offsets[0] ; ids[1] + ...]
- * (ids / counts / offsets are host arrays; the id buffers are device memory). */
+ * (ids / counts / offsets are host arrays; the id buffers are device memory).
+ * esr_sparse_adagrad_scatter_multi's long_runs: 0 = the caller knows (esr_long_run_hint with chunk = 32 on the sorted
+ * list) that no id fills a whole 32-position block and the next position, and the launch that combines the chunk
+ * partials of such runs is skipped; anything else = launched (on a list without them it only screens the boundaries). */
 int esr_concat_offset_ids(const int32_t* const* ids, const int64_t* counts, const int64_t* offsets, int nseg,
                           int32_t* out, esr_stream_t stream);
 /* out[i, :] = tables[t][vids[i] - row_offsets[t], :] (row bytes must be a multiple of 16). */
@@ -315,7 +318,7 @@ int esr_gather_rows_multi(const void* const* tables, const int64_t* row_offsets,
 int esr_sparse_adagrad_scatter_multi(void* const* tables, float* const* accums, const int64_t* row_offsets,
                                      int ntables, int dtype, int D, const int32_t* sorted_vids,
                                      const int32_t* perm, int64_t n, float* grad_rows, float lr, float eps,
-                                     esr_stream_t stream);
+                                     int long_runs, esr_stream_t stream);
 /* Row-sparse SGD (p -= lr * G), same segment reduction. */
 int esr_sparse_sgd_scatter(void* table, int dtype, int64_t V, int D, const int32_t* sorted_ids,
                            const int32_t* perm, int64_t n, float* grad_rows, float lr,
