@@ -223,9 +223,9 @@ def roofline_for(workload, kernels, B, D, rows, precision, occ_n=0, uniq=0, bf16
         t = step_s if step_s else kernels["glove_step"]["ms_per_step"] * 1e-3
         alg = STEP_BYTES_PER_UNIT["glove"](D) * B
         moved = (occ_n + 4 * uniq) * D * 4
-        return {"kernel": "esr_glove_train_step (lists > 32768 ids: sort + glove_resolve + glove_step_resolved + "
-                          "glove_step_long + finalize; shorter: sort + plan made ahead for eight batches, then "
-                          "glove_step + finalize per step)",
+        return {"kernel": "esr_glove_train_step (id lists of eight coming batches sorted by one batched call; lists > 32768 "
+                          "ids: glove_resolve + glove_step_resolved + glove_step_long + finalize per step; shorter: "
+                          "plan made ahead with the sort, then glove_step + finalize per step)",
                 "bound": "hbm", "achieved": alg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": alg / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
                 "bytes_the_update_needs_per_step": moved, "those_bytes_GBps": moved / t / 1e9}
@@ -530,9 +530,9 @@ def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True
 
     if workload == "glove" and graphed is None:
         # G5: the reference's own epoch loop (wikipedia/train_cooccurence.py:103-112) is the unit that is timed: it runs
-        # the one-pass step and sorts batch k + 1's ids on a second stream under batch k's update kernel
+        # the one-pass steps and sorts the id lists of eight coming batches by one batched call in front of them
         from esrecsys_amd.wikipedia.train_cooccurence import train_epoch
-        mode = ("eager, train_epoch (ids of the next batches sorted on a side stream)" if 2 * cfg["B"] > 4096 else
+        mode = ("eager, train_epoch (ids of the next batches sorted on a side stream)" if 2 * cfg["B"] > (1 << 18) else
                 "eager, train_epoch (id lists of eight coming batches sorted by one batched call)")
         state, _ = train_epoch(state, warmup, iter(batches[:warmup]))
         torch.cuda.synchronize()
@@ -541,12 +541,12 @@ def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     elif workload == "triplet" and graphed is None and os.environ.get("ESR_STL_LOOP", "1") == "1" and \
-            os.environ.get("ESR_STL_PRESORT", "0") != "1" and cfg["B"] <= 65536:
+            os.environ.get("ESR_STL_PRESORT", "0") != "1" and cfg["B"] <= 262144:
         # the reference's training loop body (pinterest/train_shop_the_look.py:195-204) through the build's loop helper:
         # one-pass steps, the id sort of the coming batches on a second stream, two library calls per step
         from esrecsys_amd.pinterest.train_shop_the_look import train_steps
         mode = ("eager, train_steps (one library call per step; id lists of eight coming batches sorted by one batched call)"
-                if 3 * cfg["B"] <= 32768 else "eager, train_steps (one library call per step)")
+                if 3 * cfg["B"] <= (1 << 20) else "eager, train_steps (one library call per step)")
         state, _ = train_steps(state, iter(batches[:warmup]), warmup, LAM, B)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -727,8 +727,8 @@ def secondary_legs(args, dev, rank):
     w = max(3, min(args.warmup, 10))
     # (the two launch-bound legs -- ~30 us per step, id lists sorted eight batches at a time -- run 400 steps behind two
     # groups of warmup: at 100 steps the empty queue at the start of the timed region was 5 - 8 % of it)
-    # (GloVe C3 at B = 65 536 runs 200 steps too: its loop sorts the ids two batches ahead on a second stream, and in a
-    # 20-step region -- 3 ms -- the unhidden sorts of the first batches and the clock transient were 20 % of it)
+    # (GloVe C3 at B = 65 536 runs 200 steps too: its loop sorts the id lists a group of eight batches at a time, and in
+    # a 20-step region -- 3 ms -- the first step's in-line sort, the group ramp and the clock transient were 20 % of it)
     legs = [("glove_c3_b65536", "glove", {}, max(k, 200), max(w, 10), 6.0, 6.0),
             ("glove_c3_b2048_reference_default_batch", "glove", {"B": 2048}, max(k, 400), max(w, 16), 3.0, 6.0),
             ("triplet_c2_b8192_reference_loss", "triplet", {}, max(k, 400), max(w, 16), 4.0, 6.0),

@@ -99,6 +99,34 @@ int nccl_fail(const char* what, int rc) {
   return ESR_ELAUNCH;
 }
 
+// The slice a rank addresses to itself: one copy launch on the stream.  (hipMemcpyAsync moved the same bytes with a blit
+// kernel of its own, but the call left 7 - 19 us of idle queue on either side of it -- at world 1 two of them per
+// triplet step were a third of the step.)  Unaligned slices (never produced by this package: rows are multiples of 16
+// bytes, ids of 4) take the runtime's copy.
+__global__ __launch_bounds__(256) void self_copy16_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void self_copy4_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+bool self_copy(void* dst, const void* src, size_t bytes, hipStream_t s) {
+  if (bytes == 0 || dst == src) return true;
+  const uintptr_t a = (uintptr_t)dst | (uintptr_t)src | (uintptr_t)bytes;
+  if ((a & 15) == 0) {
+    const size_t n = bytes / 16;
+    hipLaunchKernelGGL(self_copy16_kernel, dim3((unsigned)std::min<size_t>(4096, (n + 255) / 256)), dim3(256), 0, s,
+                       (const uint4*)src, (uint4*)dst, n);
+    return hipGetLastError() == hipSuccess;
+  }
+  if ((a & 3) == 0) {
+    const size_t n = bytes / 4;
+    hipLaunchKernelGGL(self_copy4_kernel, dim3((unsigned)std::min<size_t>(4096, (n + 255) / 256)), dim3(256), 0, s,
+                       (const uint32_t*)src, (uint32_t*)dst, n);
+    return hipGetLastError() == hipSuccess;
+  }
+  return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s) == hipSuccess;
+}
+
 #define ESR_NCCL(call, what)                   \
   do {                                         \
     int rc_ = (call);                          \
@@ -127,7 +155,7 @@ int alltoall(const char* who, esr_comm_t comm_, const void* send, const int64_t*
   hipStream_t s = esr::as_stream(stream);
   const char* sp = static_cast<const char*>(send);
   char* rp = static_cast<char*>(recv);
-  // the slice addressed to this rank itself never enters RCCL (see alltoall_multi): one hipMemcpyAsync on the stream
+  // the slice addressed to this rank itself never enters RCCL (see alltoall_multi): one copy launch on the stream
   {
     size_t so = 0, ro = 0;
     for (int p = 0; p < c->rank; ++p) {
@@ -135,7 +163,7 @@ int alltoall(const char* who, esr_comm_t comm_, const void* send, const int64_t*
       ro += (size_t)(recv_counts[p] * unit);
     }
     const size_t self = (size_t)(send_counts[c->rank] * unit);
-    if (self && hipMemcpyAsync(rp + ro, sp + so, self, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+    if (self && !self_copy(rp + ro, sp + so, self, s)) {
       esr::set_error("%s: self copy failed", who);
       return ESR_ELAUNCH;
     }
@@ -186,8 +214,8 @@ int alltoall_multi(const char* who, esr_comm_t comm_, int n_ops, const void* con
   if (!any) return ESR_OK;
   hipStream_t s = esr::as_stream(stream);
   // The slice a rank addresses to itself never enters RCCL: a send / recv pair to self is a copy kernel that measured
-  // 0.9 TB/s (2 x 134 MB of GloVe rows and gradients in 0.29 ms at world 1); hipMemcpyAsync on the same stream moves it
-  // at the device's copy rate and, at world 1, no RCCL kernel is launched at all.
+  // 0.9 TB/s (2 x 134 MB of GloVe rows and gradients in 0.29 ms at world 1); a plain copy launch on the same stream moves
+  // it at the device's copy rate and, at world 1, no RCCL kernel is launched at all.
   for (int o = 0; o < n_ops; ++o) {
     size_t so = 0, ro = 0;
     for (int p = 0; p < c->rank; ++p) {
@@ -196,10 +224,8 @@ int alltoall_multi(const char* who, esr_comm_t comm_, int n_ops, const void* con
     }
     const size_t self = (size_t)send_bytes[(size_t)o * c->world + c->rank];
     if (self) {
-      const hipError_t e = hipMemcpyAsync(static_cast<char*>(recv[o]) + ro, static_cast<const char*>(send[o]) + so, self,
-                                          hipMemcpyDeviceToDevice, s);
-      if (e != hipSuccess) {
-        esr::set_error("%s: self copy failed: %s", who, hipGetErrorString(e));
+      if (!self_copy(static_cast<char*>(recv[o]) + ro, static_cast<const char*>(send[o]) + so, self, s)) {
+        esr::set_error("%s: self copy failed", who);
         return ESR_ELAUNCH;
       }
     }
@@ -320,8 +346,7 @@ int esr_allgather_bytes(esr_comm_t comm_, const void* send, int64_t bytes, void*
   char* rp = static_cast<char*>(recv);
   // this rank's own block is a plain copy; every other block is one send / recv pair of the same grouped call the
   // all-to-alls use (on the xGMI full mesh each pair rides its own link, exactly like a slice of an all-to-all)
-  if (rp + (size_t)c->rank * bytes != send &&
-      hipMemcpyAsync(rp + (size_t)c->rank * bytes, send, (size_t)bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+  if (rp + (size_t)c->rank * bytes != send && !self_copy(rp + (size_t)c->rank * bytes, send, (size_t)bytes, s)) {
     esr::set_error("esr_allgather_bytes: self copy failed");
     return ESR_ELAUNCH;
   }

@@ -425,12 +425,46 @@ __global__ __launch_bounds__(kBlock) void radix_segsum_kernel(const int32_t* __r
   reinterpret_cast<int2*>(segsum)[(int64_t)seg * (kTile / 2) + d2] = make_int2(a, b);
 }
 
+// Batched sorts (throughput, not one list's latency): between the two launches of a pass, the histogram matrix of every
+// list is scanned down its columns IN PLACE -- hist[tile][digit] becomes the digit's count in the tiles before `tile`,
+// totals[digit] its count over all tiles -- so that a scatter workgroup reads two words per digit pair instead of
+// re-reducing the whole matrix (eight lists of 131 072 ids: 512 workgroups x 512 KB out of L2, 34 us of the pass).
+// One workgroup per (SD digits, list): 256 / SD tile groups x SD digits, the groups' sums combined through LDS
+// (SD = 64: 4 groups, for matrices of up to 128 tiles; SD = 16: 16 groups for the taller ones).
+template <int TB, int kScanDigits>
+__global__ __launch_bounds__(kBlock) void radix_colscan_kernel(int32_t* __restrict__ hist, int ntiles,
+                                                              int32_t* __restrict__ totals, int64_t stride) {
+  constexpr int kTile = 1 << TB, kScanGroups = kBlock / kScanDigits;
+  __shared__ int gsum[kScanGroups][kScanDigits];
+  hist += (int64_t)blockIdx.y * stride;
+  totals += (int64_t)blockIdx.y * stride;
+  const int dg = threadIdx.x & (kScanDigits - 1), tg = threadIdx.x / kScanDigits;
+  const int d = blockIdx.x * kScanDigits + dg;
+  const int per = (ntiles + kScanGroups - 1) / kScanGroups;
+  const int t0 = tg * per, t1 = min(ntiles, t0 + per);
+  int sum = 0;
+#pragma unroll 8
+  for (int t = t0; t < t1; ++t) sum += hist[(int64_t)t * kTile + d];
+  gsum[tg][dg] = sum;
+  __syncthreads();
+  int run = 0;
+  for (int g = 0; g < tg; ++g) run += gsum[g][dg];
+  if (tg == kScanGroups - 1) totals[d] = run + sum;
+#pragma unroll 8
+  for (int t = t0; t < t1; ++t) {
+    const int c = hist[(int64_t)t * kTile + d];
+    hist[(int64_t)t * kTile + d] = run;
+    run += c;
+  }
+}
+
 template <int TB, bool FIRST>
 __device__ __forceinline__ void radix_scatter_body(const SortSegs& ids, const uint32_t* __restrict__ keys_in,
                                                    const uint32_t* __restrict__ vals_in, int n, int ntiles,
                                                    const uint32_t* __restrict__ tiles, const int32_t* __restrict__ hist,
                                                    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                   const int32_t* __restrict__ segsum) {
+                                                   const int32_t* __restrict__ segsum,
+                                                   const int32_t* __restrict__ totals = nullptr) {
   constexpr int kTile = 1 << TB, kThreads = kTile / 2;
   __shared__ uint32_t comp[kTile];
   __shared__ int offs[kTile], bstart[kTile];
@@ -442,7 +476,16 @@ __device__ __forceinline__ void radix_scatter_body(const SortSegs& ids, const ui
   // (unrolled: the loads of a pass over the matrix are independent; one at a time this loop WAS the kernel, 16 us)
   int tot0 = 0, tot1 = 0, pre0 = 0, pre1 = 0;
   const int2* h2 = reinterpret_cast<const int2*>(hist);
-  if (segsum) {
+  if (totals) {
+    // radix_colscan_kernel ran in between: `hist` holds, per digit, the count in the tiles BEFORE each tile, `totals`
+    // the digit's count over all tiles -- two loads instead of a walk over the matrix
+    const int2 tt = reinterpret_cast<const int2*>(totals)[t];
+    const int2 pp = h2[(int64_t)tile * (kTile / 2) + t];
+    tot0 = tt.x;
+    tot1 = tt.y;
+    pre0 = pp.x;
+    pre1 = pp.y;
+  } else if (segsum) {
     // long lists (> kRadixMaxN ids): the histogram matrix is too tall to re-reduce in every workgroup (384 tiles x 8 KB
     // per workgroup at 786 432 ids); radix_segsum_kernel summed it over segments of kRadixSeg tiles first
     const int2* s2 = reinterpret_cast<const int2*>(segsum);
@@ -523,12 +566,14 @@ __global__ __launch_bounds__((1 << TB) / 2) void radix_scatter_kernel(SortSegs i
 template <int TB, bool FIRST>
 __global__ __launch_bounds__((1 << TB) / 2) void radix_scatter_batched_kernel(
     SortSegsBatch sb, const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, int64_t in_stride,
-    int n, int ntiles, const uint32_t* __restrict__ tiles, const int32_t* __restrict__ hist, int64_t stride,
-    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t out_stride) {
+    int n, int ntiles, const uint32_t* __restrict__ tiles, const int32_t* __restrict__ hist,
+    const int32_t* __restrict__ totals, int64_t stride, uint32_t* __restrict__ keys_out,
+    uint32_t* __restrict__ vals_out, int64_t out_stride) {
   const int b = blockIdx.y;
   radix_scatter_body<TB, FIRST>(sb.b[b], FIRST ? nullptr : keys_in + b * in_stride,
                                 FIRST ? nullptr : vals_in + b * in_stride, n, ntiles, tiles + b * stride,
-                                hist + b * stride, keys_out + b * out_stride, vals_out + b * out_stride, nullptr);
+                                hist + b * stride, keys_out + b * out_stride, vals_out + b * out_stride, nullptr,
+                                totals + b * stride);
 }
 
 struct RadixWs {
@@ -595,7 +640,7 @@ static void launch_radix_sort(const SortSegs& sg, int n, int key_bits, const Rad
     vin = vout;
   }
 }
-// the lists of a batch (equal length n <= kRadixMaxN) pass by pass: four launches for all of them.  `base` = nbatch
+// the lists of a batch (equal length n <= kRadixLongN) pass by pass: three launches per pass for all of them.  `base` = nbatch
 // per-list workspaces of radix_ws_layout(n) bytes each.
 template <int TB>
 static void launch_radix_sort_batched(const SortSegsBatch& sb, int nbatch, int n, int key_bits, char* base,
@@ -616,16 +661,28 @@ static void launch_radix_sort_batched(const SortSegsBatch& sb, int nbatch, int n
     uint32_t* vout = last ? reinterpret_cast<uint32_t*>(perm) : ws.vals[p & 1];
     const int64_t out_stride = last ? (int64_t)n : stride;
     const int shift = p * TB;
+    const bool tall = ntiles > 128;
+    const dim3 scan_grid(kTile / (tall ? 16 : 64), nbatch);
+    auto colscan = [&]() {
+      if (tall)
+        hipLaunchKernelGGL((radix_colscan_kernel<TB, 16>), scan_grid, dim3(kBlock), 0, st, ws.hist, ntiles, ws.segsum, stride);
+      else
+        hipLaunchKernelGGL((radix_colscan_kernel<TB, 64>), scan_grid, dim3(kBlock), 0, st, ws.hist, ntiles, ws.segsum, stride);
+    };
     if (p == 0) {
       hipLaunchKernelGGL((radix_tile_batched_kernel<TB, true>), grid, dim3(kThreads), 0, st, sb, kin, in_stride, n, shift,
                          ws.tiles, ws.hist, stride);
+      colscan();
       hipLaunchKernelGGL((radix_scatter_batched_kernel<TB, true>), grid, dim3(kThreads), 0, st, sb, kin, vin, in_stride, n,
-                         ntiles, (const uint32_t*)ws.tiles, (const int32_t*)ws.hist, stride, kout, vout, out_stride);
+                         ntiles, (const uint32_t*)ws.tiles, (const int32_t*)ws.hist, (const int32_t*)ws.segsum, stride,
+                         kout, vout, out_stride);
     } else {
       hipLaunchKernelGGL((radix_tile_batched_kernel<TB, false>), grid, dim3(kThreads), 0, st, sb, kin, in_stride, n, shift,
                          ws.tiles, ws.hist, stride);
+      colscan();
       hipLaunchKernelGGL((radix_scatter_batched_kernel<TB, false>), grid, dim3(kThreads), 0, st, sb, kin, vin, in_stride,
-                         n, ntiles, (const uint32_t*)ws.tiles, (const int32_t*)ws.hist, stride, kout, vout, out_stride);
+                         n, ntiles, (const uint32_t*)ws.tiles, (const int32_t*)ws.hist, (const int32_t*)ws.segsum, stride,
+                         kout, vout, out_stride);
     }
     kin = kout;
     vin = vout;
@@ -1133,7 +1190,7 @@ size_t esr_segment_sort_batched_workspace_bytes(int64_t n, int nbatch) {
   if (n <= 0 || nbatch <= 0) return 256;
   const size_t one = esr_segment_sort_workspace_bytes(n);  // the fallback sorts list after list in this much
   const size_t mid = n <= kMidSortMax ? align_up((size_t)nbatch * kMidWsWords * 4, 256) : 0;
-  const size_t radix = n > kMidSortMax && n <= kRadixMaxN ? (size_t)nbatch * radix_ws_layout(n, nullptr, nullptr) : 0;
+  const size_t radix = n > kMidSortMax && n <= kRadixLongN ? (size_t)nbatch * radix_ws_layout(n, nullptr, nullptr) : 0;
   return std::max({one, mid, radix});
 }
 
@@ -1187,7 +1244,7 @@ int esr_segment_sort_ids_batched(const int32_t* const* ids, const int64_t* count
     else launch_tile_sort_batched<11>(sb, nbatch, (int)n, tiles, sorted_ids, perm, st);
     return check_launch("esr_segment_sort_ids_batched");
   }
-  if (n <= kRadixMaxN && bits_for(V) <= kRadixMaxPasses * 11 && nbatch > 1) {  // four launches per pass pair for all lists
+  if (n <= kRadixLongN && bits_for(V) <= kRadixMaxPasses * 11 && nbatch > 1) {  // four launches per pass pair for all lists
     launch_radix_sort_batched<11>(sb, nbatch, (int)n, bits_for(V), (char*)workspace, sorted_ids, perm, st);
     return check_launch("esr_segment_sort_ids_batched");
   }

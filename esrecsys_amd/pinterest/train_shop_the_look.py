@@ -414,10 +414,11 @@ class _FusedTripletLoop:
 # finding as for the GloVe step, where only filling the gaps BETWEEN steps pays (wikipedia.train_epoch).
 _LOOP_DEPTH = max(0, int(_os.environ.get("ESR_STL_PRESORT_DEPTH", "0")))
 # Batches whose id lists are sorted together, by one library call on the main stream, before the first of them is
-# stepped (esr_segment_sort_ids_batched; ESR_STL_SORT_BATCH=1: every step sorts its own list in line).  Lists beyond the
-# two-launch sort's 32 768 ids gain nothing (they are work, not latency) and stay in line.
+# stepped (esr_segment_sort_ids_batched; ESR_STL_SORT_BATCH=1: every step sorts its own list in line).  Up to 2^20 ids per
+# list (the batched radix passes: the sort of ONE long list is a chain of launches of a few hundred workgroups each --
+# 92 us for the 786 432 ids of a 262 144-triplet batch, latency more than work).
 _SORT_BATCH = min(8, max(1, int(_os.environ.get("ESR_STL_SORT_BATCH", "8"))))
-_SORT_BATCH_MAX_IDS = 32768
+_SORT_BATCH_MAX_IDS = int(_os.environ.get("ESR_STL_SORT_BATCH_MAX_IDS", str(1 << 20)))
 # ESR_STL_PLAN_STREAM=side: the sort + plan of a group on the second stream, beside the steps of the group before it
 _PLAN_ON_SIDE = _os.environ.get("ESR_STL_PLAN_STREAM", "main") == "side"
 # ESR_STL_HINT_WAIT=0: a group whose long-run hints have not reached the host is stepped without them (A/B knob)

@@ -292,7 +292,9 @@ int esr_segment_sort_ids_multi(const int32_t* const* ids, const int64_t* counts,
  * pinterest/train_shop_the_look.py:195-204), and at the reference's batch sizes the two-launch sort is latency, not
  * work -- eight lists cost what one does.  ids[b * nseg + k] = segment k of list b; counts / offsets are the same for
  * every list (n = their sum); sorted_ids / perm are [nbatch][n], list b exactly what esr_segment_sort_ids_multi would
- * give for it (perm indexes list b's own occurrences).  Lists longer than 32 768 ids are sorted one after the other. */
+ * give for it (perm indexes list b's own occurrences).  Up to 2 048 ids: one launch for all lists; up to 32 768: two;
+ * up to 2 097 152 (and V < 2^33: at most three 11-bit digits): three per radix pass; beyond that the lists are sorted
+ * one after the other. */
 size_t esr_segment_sort_batched_workspace_bytes(int64_t n, int nbatch);
 int esr_segment_sort_ids_batched(const int32_t* const* ids, const int64_t* counts, const int64_t* offsets, int nseg,
                                  int nbatch, int64_t V, int32_t* sorted_ids, int32_t* perm, void* workspace,

@@ -1071,7 +1071,8 @@ def test_bucket_ids_by_owner_vs_oracle(dev, world, n):
 @pytest.mark.parametrize("n_seg,nb", [((100, 100, 100), 8), ((683, 683, 682), 5), ((2048,), 3), ((2049,), 2),
                                       ((2048, 2048, 2048), 8), ((8192, 8192, 8192), 8), ((8192, 8192, 8192), 1),
                                       ((10923, 10923, 10922), 4), ((20000, 20000), 3), ((65536, 65536), 8),
-                                      ((131072, 131072), 3), ((50001, 50000), 5), ((131073, 131072), 2)])
+                                      ((131072, 131072), 3), ((50001, 50000), 5), ((131073, 131072), 2),
+                                      ((262144, 262144, 262144), 3), ((400000, 300001), 2)])
 def test_segment_sort_batched_equals_list_by_list(dev, n_seg, nb):
     """esr_segment_sort_ids_batched: one-tile lists (one launch for all), mid lists (two launches for all: the triplet
     step's 24 576 ids; the largest, 32 768), lists up to 262 144 ids (the radix passes over all lists at once: GloVe's
