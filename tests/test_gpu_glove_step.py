@@ -178,11 +178,13 @@ def test_config_c3_full_size_fused_step(dev):
 
 
 @pytest.mark.parametrize("kind", ["uniform", "zipf"])
-@pytest.mark.parametrize("B,K", [(1024, 11), (2048, 8), (16, 3), (3000, 5), (2048, 27), (64, 140)])
+@pytest.mark.parametrize("B,K", [(1024, 11), (2048, 8), (16, 3), (3000, 5), (2048, 27), (64, 140), (20000, 11),
+                                 (40000, 5)])
 def test_train_epoch_batched_sort_equals_in_line_sort(dev, B, K, kind, monkeypatch):
-    """Short id lists (the reference's default batch of 2048 pairs) are sorted eight batches at a time by one batched
-    call (esr_segment_sort_ids_batched); the epoch must be bit-identical to the one that sorts every list inside its
-    own step -- groups of 8 + 3, exactly 8, fewer than a group; 6000 ids (beyond 4096) keep the side-stream sort."""
+    """The id lists of eight coming batches are sorted by one batched call (esr_segment_sort_ids_batched); the epoch must
+    be bit-identical to the one that sorts every list inside its own step -- groups of 8 + 3, exactly 8, fewer than a
+    group; lists with plans (<= 32 768 ids: the reference's default batch of 2048 pairs) and without (40 000 and 80 000
+    ids: the steps resolve their own records, only the sort is grouped)."""
     import esrecsys_amd.wikipedia.train_cooccurence as tc
     V, D = 3000, 64
     rng = np.random.default_rng(B + K)
@@ -218,3 +220,57 @@ def test_one_pass_step_is_refused_without_room_for_the_second_buffer(dev, monkey
     assert rel_err(a.params["_token_embedding"]["embedding"].cpu().numpy(),
                    b.params["_token_embedding"]["embedding"].cpu().numpy()) <= 1e-6
     assert fused_step_available(a)   # (a table that HAS its second buffer keeps using it)
+
+
+@pytest.mark.parametrize("B,K", [(40000, 7), (3000, 6)])
+def test_train_epoch_side_stream_sort_equals_in_line_sort(dev, B, K, monkeypatch):
+    """Lists beyond the grouped sort's limit go to the side stream one by one (ring of sort buffers, gated on the update
+    kernel's start word -- esr_stream_gate): forced here by lowering the limit; bit-identical to the in-line sorts."""
+    import esrecsys_amd.wikipedia.train_cooccurence as tc
+    V, D = 3000, 64
+    rng = np.random.default_rng(B + K)
+    batches = [(_ids("zipf", V, (2, B), rng), rng.uniform(0.1, 300.0, B).astype(np.float32)) for _ in range(K)]
+    monkeypatch.setattr(tc, "_GROUP_SORT_MAX_IDS", 1024)
+    monkeypatch.setattr(tc, "_PRESORT_MIN_IDS", 1024)
+    a, la = tc.train_epoch(_make_state(V, D, "reference", dev), K, iter(batches))
+    monkeypatch.setattr(tc, "_SORT_BATCH", 1)
+    monkeypatch.setattr(tc, "_PRESORT", False)
+    b, lb = tc.train_epoch(_make_state(V, D, "reference", dev), K, iter(batches))
+    assert la == lb
+    assert torch.equal(a.params["_token_embedding"]["embedding"], b.params["_token_embedding"]["embedding"])
+    assert torch.equal(a.params["_bias"]["embedding"], b.params["_bias"]["embedding"])
+
+
+def test_stream_gate_opens_on_the_word_and_on_the_timeout(dev):
+    """esr_stream_gate: a stream behind the gate runs on once the word has reached the value (wrap-safe compare), and
+    after the timeout when it never does."""
+    import time
+    from esrecsys_amd import ops
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    out = torch.zeros(1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        ops.stream_gate(flag, 3, timeout_us=5_000_000)
+        out.fill_(7)
+    time.sleep(0.05)
+    assert not side.query()              # still held: the word is 0
+    flag.fill_(3)                        # (main stream)
+    side.synchronize()
+    assert int(out) == 7
+    flag.fill_(-5)                       # 0xFFFFFFFB: "before" 2 in sequence-number order
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(side):
+        ops.stream_gate(flag, 2, timeout_us=20_000)
+    side.synchronize()
+    dt = time.perf_counter() - t0
+    assert 0.015 < dt < 1.0              # released by the timeout, not at once and not never
+    flag.fill_(2 ** 31 - 1)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        ops.stream_gate(flag, -(2 ** 31) + 5, timeout_us=5_000_000)   # 0x80000005 is AFTER 0x7FFFFFFF: held ...
+    time.sleep(0.02)
+    assert not side.query()
+    flag.fill_(-(2 ** 31) + 5)           # ... until the word wraps past it
+    side.synchronize()

@@ -1116,3 +1116,35 @@ def test_bucket_ids_by_owner_batched_equals_list_by_list(dev, n_seg, nb, world):
         order = np.argsort(virt % world, kind="stable")
         assert np.array_equal(N(perm[b]), order.astype(np.int32))
         assert np.array_equal(N(local[b]), (virt[order] // world).astype(np.int32))
+
+
+def test_sparse_adagrad_multi_long_runs_hint(dev):
+    """esr_sparse_adagrad_scatter_multi(long_runs=0) skips the launch that combines chunk partials: on a list the hint
+    kernel clears (no id with a run beyond 32 positions) tables and accumulators are bit-identical to the full call;
+    esr_long_run_hint says "long" exactly when some id has more than 32 consecutive sorted positions."""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(5)
+    V, D, n = 4000, 64, 6000
+    for hot, expect_long in ((0, False), (33, True), (32, False)):
+        ids = np.concatenate([rng.integers(10, V, n - hot).astype(np.int32) % (V - 10) + 10, np.full(hot, 3, np.int32)])
+        # (ids >= 10 are drawn at random: a few repeats, none near 32; id 3 appears `hot` times)
+        rng.shuffle(ids)
+        a_ids, b_ids = T(ids[:n // 2].copy(), dev), T(ids[n // 2:].copy(), dev)
+        srt, prm = ops.segment_sort_multi([a_ids, b_ids], [0, V], 2 * V)
+        hint = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.long_run_hint(srt, 32, hint, 9)
+        counts = np.bincount(np.concatenate([ids[:n // 2], ids[n // 2:] + V]))
+        assert (int(hint) == 9) == bool(counts.max() > 32)
+        if counts.max() > 32:
+            continue
+        grads = torch.from_numpy(rng.standard_normal((n, D)).astype(np.float32)).to(dev)
+        res = []
+        for long_runs in (-1, 0):
+            t0 = torch.from_numpy(np.random.default_rng(1).standard_normal((V, D)).astype(np.float32)).to(dev)
+            t1 = t0.clone() * 0.5
+            a0, a1 = torch.zeros_like(t0), torch.zeros_like(t1)
+            ops.sparse_adagrad_multi([t0, t1], [a0, a1], [0, V, 2 * V], srt, prm, grads.clone(), 0.05, 1e-7,
+                                     long_runs=long_runs)
+            res.append((t0, t1, a0, a1))
+        for x, y in zip(*res):
+            assert torch.equal(x, y)
