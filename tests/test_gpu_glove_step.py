@@ -274,3 +274,24 @@ def test_stream_gate_opens_on_the_word_and_on_the_timeout(dev):
     assert not side.query()
     flag.fill_(-(2 ** 31) + 5)           # ... until the word wraps past it
     side.synchronize()
+
+
+def test_train_epoch_long_lists_ragged_batch_and_early_end(dev, monkeypatch):
+    """Grouped sort of long lists (no plans): a batch of another size inside the epoch makes its group fall back to
+    per-step sorts, still bit-identical to the in-line loop; an iterator that ends early raises StopIteration."""
+    import esrecsys_amd.wikipedia.train_cooccurence as tc
+    V, D, B, K = 3000, 64, 20000, 12
+    rng = np.random.default_rng(77)
+    sizes = [B] * K
+    sizes[6] = 17001
+    batches = [(_ids("zipf", V, (2, b), rng), rng.uniform(0.1, 300.0, b).astype(np.float32)) for b in sizes]
+    a, la = tc.train_epoch(_make_state(V, D, "reference", dev), K, iter(batches))
+    monkeypatch.setattr(tc, "_SORT_BATCH", 1)
+    monkeypatch.setattr(tc, "_PRESORT", False)
+    b, lb = tc.train_epoch(_make_state(V, D, "reference", dev), K, iter(batches))
+    assert la == lb
+    assert torch.equal(a.params["_token_embedding"]["embedding"], b.params["_token_embedding"]["embedding"])
+    monkeypatch.setattr(tc, "_SORT_BATCH", 8)
+    with pytest.raises(StopIteration):
+        tc.train_epoch(_make_state(V, D, "reference", dev), K + 3, iter(batches))
+    torch.cuda.synchronize()

@@ -109,3 +109,34 @@ def test_train_steps_inbatch_equals_stepwise_train_step(dev, B, D, steps):
         assert torch.equal(a.params["params"][tower]["embedding"], b.params["params"][tower]["embedding"])
         assert torch.equal(a.opt_state["sum_of_squares"]["params"][tower]["embedding"],
                            b.opt_state["sum_of_squares"]["params"][tower]["embedding"])
+
+
+@pytest.mark.parametrize("hot", [False, True])
+def test_train_steps_inbatch_long_run_hint_and_early_end(dev, hot):
+    """In-batch groups are sorted and screened one group ahead; with a hot id (a run far beyond 32 positions) the hint
+    says "long" and the optimizer keeps its long-run launch, without one it is skipped -- both bit-identical to the
+    stepwise loop, with a ragged last batch (sorted on its own) in between; an iterator that ends early raises
+    StopIteration after the steps it fed."""
+    from esrecsys_amd.pinterest.train_shop_the_look import train_step, train_steps
+    Vs, Vp, D, B, steps = 3000, 5000, 64, 256, 19
+    rng = np.random.default_rng(31 + hot)
+
+    def draw(V, n):
+        ids = rng.integers(0, V, n).astype(np.int32)
+        if hot:
+            ids[rng.random(n) < 0.4] = 7
+        return torch.from_numpy(ids).to(dev)
+    batches = [(draw(Vs, B), draw(Vp, B), None) for _ in range(steps)]
+    batches[12] = (draw(Vs, 128), draw(Vp, 128), None)  # ragged: its group falls back to per-step sorts
+    a, b = _state(dev, Vs, Vp, D, 4), _state(dev, Vs, Vp, D, 4)
+    a, losses = train_steps(a, iter(batches), steps, 0.1, float(B), scale=6.0)
+    ref = []
+    for scene, pos, _ in batches:
+        b, l = train_step(b, scene, pos, None, 0.1, float(B), scale=6.0)
+        ref.append(l)
+    assert torch.equal(losses, torch.stack(ref))
+    for tower in ("scene_tower", "product_tower"):
+        assert torch.equal(a.params["params"][tower]["embedding"], b.params["params"][tower]["embedding"])
+    with pytest.raises(StopIteration):
+        train_steps(_state(dev, Vs, Vp, D, 4), iter(batches[:10]), 15, 0.1, float(B), scale=6.0)
+    torch.cuda.synchronize()
