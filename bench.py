@@ -158,6 +158,49 @@ def saturating_gather_scatter(dev, V, D, n=131072, reps=20):
             "box_stream_bytes": tb}
 
 
+def per_kernel_from_profile(workload, path, B, D, cfg):
+    """Per-kernel roofline fractions of the main kernels from the COMMITTED rocprofv3 summary of this workload
+    (profiles/r3/<workload>_kernel_stats.csv: average launch duration), for the configuration that summary was taken on
+    (the default one of each workload) -- None otherwise.  MFMA kernels: executed fp16 flops / duration / 2.5 PF; HBM
+    kernels: the bytes the kernel needs (SURVEY 8d's per-unit figure) / duration / 8 TB/s."""
+    base = WORKLOADS.get(workload, {})
+    if workload not in ("inbatch", "glove", "triplet") or B != base.get("B") or D != base.get("D") or \
+            cfg.get("ids", "uniform") != "uniform" or cfg.get("table_dtype", "f32") != "f32" or \
+            (workload == "inbatch" and path != "f16x2"):
+        return None
+    f = os.path.join(ROOT, "profiles", "r3", "%s_kernel_stats.csv" % workload)
+    if not os.path.exists(f):
+        return None
+    try:
+        import csv
+        rows = {r["Name"]: float(r["AverageNs"]) * 1e-9 for r in csv.DictReader(open(f))}
+    except Exception:
+        return None
+
+    def dur(sub, also=None):
+        for name, t in rows.items():
+            if sub in name and (also is None or also in name):
+                return t
+        return None
+    out = {"source": "profiles/r3/%s_kernel_stats.csv (rocprofv3 --kernel-trace --stats, average launch)" % workload}
+    if workload == "inbatch":
+        unit = 2.0 * B * B * D  # one cross-term GEMM
+        for key, sub, also, terms in (("inbatch2h_q_kernel", "inbatch2h_q_kernelILb0", None, 6),
+                                      ("inbatch2h_pc8_kernel", "inbatch2h_pc8_kernel", None, 3)):
+            t = dur(sub, also)
+            if t:
+                out[key] = {"us": t * 1e6, "executed_fp16_cross_term_gemms": terms,
+                            "TFLOPs": terms * unit / t / 1e12, "frac_of_2.5PF": terms * unit / t / 1e12 / MFMA_BF16_PEAK_TFLOPS}
+    else:
+        name = "glove_step_resolved_kernel" if workload == "glove" else "triplet_step_kernel"
+        t = dur(name)
+        if t:
+            alg = STEP_BYTES_PER_UNIT[workload](D) * B
+            out[name] = {"us": t * 1e6, "algorithmic_bytes": alg, "GBps": alg / t / 1e9,
+                         "frac_of_8TBps": alg / t / 1e9 / HBM_PEAK_GBS}
+    return out if len(out) > 1 else None
+
+
 def roofline_for(workload, kernels, B, D, rows, precision, occ_n=0, uniq=0, bf16_tables=False, rowmax_gemm=False,
                  step_s=None):
     """The `roofline` object for the dominant kernel of one rank's step.  `kernels` = HIP-event ms per step per
@@ -532,7 +575,7 @@ def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True
         # G5: the reference's own epoch loop (wikipedia/train_cooccurence.py:103-112) is the unit that is timed: it runs
         # the one-pass steps and sorts the id lists of eight coming batches by one batched call in front of them
         from esrecsys_amd.wikipedia.train_cooccurence import train_epoch
-        mode = ("eager, train_epoch (ids of the next batches sorted on a side stream)" if 2 * cfg["B"] > (1 << 18) else
+        mode = ("eager, train_epoch (ids of the next batches sorted on a side stream)" if 2 * cfg["B"] > (1 << 21) else
                 "eager, train_epoch (id lists of eight coming batches sorted by one batched call)")
         state, _ = train_epoch(state, warmup, iter(batches[:warmup]))
         torch.cuda.synchronize()
@@ -699,6 +742,10 @@ def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True
             roofline["traffic"] = entry.get(roofline["kernel"]) if isinstance(entry, dict) else entry
         except Exception:
             pass
+    if roofline is not None:
+        pk = per_kernel_from_profile(workload, path, B, D, cfg)
+        if pk:
+            roofline["per_kernel_rocprof"] = pk
     return {
         "value": B * K / dt, "unit": cfg["unit"] + "s/s", "steps": K, "warmup": warmup, "ms_per_step": dt / K * 1e3,
         "config": {"workload": "%s: V=%d x D=%d %s tables, B=%d, sparse Adagrad"

@@ -289,7 +289,7 @@ def train_step(state, inputs, target):
 
 # train_epoch: lists of up to _GROUP_SORT_MAX_IDS ids are sorted a group of _SORT_BATCH batches at a time by one batched
 # call on the main stream (esr_segment_sort_ids_batched); longer ones one by one on the side stream, _PRESORT_DEPTH ahead
-_GROUP_SORT_MAX_IDS = int(os.environ.get("ESR_GLOVE_GROUP_SORT_MAX_IDS", str(1 << 18)))
+_GROUP_SORT_MAX_IDS = int(os.environ.get("ESR_GLOVE_GROUP_SORT_MAX_IDS", str(1 << 21)))
 _PRESORT_MIN_IDS = _GROUP_SORT_MAX_IDS
 
 
