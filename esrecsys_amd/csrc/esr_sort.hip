@@ -988,6 +988,18 @@ __global__ __launch_bounds__(kBlock) void transpose_cols_kernel(const float* __r
     keysT[(int64_t)t * V + v] = scores[i];
   }
 }
+// keysT[t][v] = order-preserving unsigned image of scores[v][t] (negative floats: all bits flipped; others: sign bit
+// set), the key rocPRIM's float sort uses too: ascending keys = ascending floats, -0 before +0, NaNs by their bits
+__global__ __launch_bounds__(kBlock) void transpose_cols_keys_kernel(const float* __restrict__ scores, int64_t V, int T,
+                                                                    int32_t* __restrict__ keysT) {
+  const int64_t total = V * T;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t v = i / T;
+    const int t = (int)(i - v * T);
+    const uint32_t f = __float_as_uint(scores[i]);
+    keysT[(int64_t)t * V + v] = (int32_t)((f & 0x80000000u) ? ~f : (f | 0x80000000u));
+  }
+}
 // indices[v][t] = idxT[t][v]
 __global__ __launch_bounds__(kBlock) void untranspose_idx_kernel(const int32_t* __restrict__ idxT, int64_t V, int T,
                                                                 int32_t* __restrict__ indices) {
@@ -1274,9 +1286,22 @@ static size_t argsort_layout(int64_t V, int T, size_t* keysT, size_t* idxT, size
   return off;
 }
 
+// columns of up to kRadixLongN rows go through this file's own radix sort, kMaxSortBatch columns per launch sequence
+static size_t argsort_own_layout(int64_t V, int T, size_t* keysT, size_t* idxT, size_t* ksorted, size_t* sort_ws) {
+  size_t off = 0;
+  *keysT = off;   off += align_up((size_t)V * T * 4, 256);
+  *idxT = off;    off += align_up((size_t)V * T * 4, 256);
+  *ksorted = off; off += align_up((size_t)V * 4 * kMaxSortBatch, 256);
+  *sort_ws = off;
+  off += std::max((size_t)std::min(T, kMaxSortBatch) * radix_ws_layout(V, nullptr, nullptr),
+                  esr_segment_sort_workspace_bytes(V));
+  return off;
+}
+
 size_t esr_argsort_columns_workspace_bytes(int64_t V, int T) {
   if (V <= 0 || T <= 0) return 256;
-  size_t a, b, c;
+  size_t a, b, c, d;
+  if (V <= kRadixLongN) return argsort_own_layout(V, T, &a, &b, &c, &d);
   return argsort_layout(V, T, &a, &b, &c) + pair_sort_temp_bytes<false, float>(V);
 }
 
@@ -1291,8 +1316,41 @@ int esr_argsort_columns(const float* scores, int64_t V, int T, int32_t* indices,
   }
   hipStream_t st = as_stream(stream);
   size_t o_keys, o_idx, o_sorted;
-  const size_t fixed = argsort_layout(V, T, &o_keys, &o_idx, &o_sorted);
   char* base = (char*)workspace;
+  if (V <= kRadixLongN) {
+    // stable ascending sort of every column by the keys' unsigned images: three 11-bit passes of the radix sort above,
+    // eight columns per launch sequence (jnp.argsort(scores, axis=0): wikipedia/train_cooccurence.py:95)
+    size_t o_ws;
+    const size_t total = argsort_own_layout(V, T, &o_keys, &o_idx, &o_sorted, &o_ws);
+    int32_t* keysT = (int32_t*)(base + o_keys);     // [T][V]
+    int32_t* idxT = (int32_t*)(base + o_idx);       // [T][V]
+    int32_t* ksorted = (int32_t*)(base + o_sorted);  // [<= 8][V] (not read)
+    const int grid = (int)std::min<int64_t>(kMaxGrid, cdiv(V * T, kBlock));
+    hipLaunchKernelGGL(transpose_cols_keys_kernel, dim3(grid), dim3(kBlock), 0, st, scores, V, T, keysT);
+    for (int t0 = 0; t0 < T; t0 += kMaxSortBatch) {
+      const int nb = std::min(kMaxSortBatch, T - t0);
+      SortSegsBatch sb;
+      for (int b = 0; b < kMaxSortBatch; ++b) {
+        SortSegs& sg = sb.b[b];
+        sg.n = 1;
+        for (int i = 0; i < kMaxSortSegs; ++i) {
+          sg.ids[i] = i == 0 ? keysT + (int64_t)(t0 + std::min(b, nb - 1)) * V : nullptr;
+          sg.offset[i] = 0;
+          sg.start[i + 1] = V;
+        }
+        sg.start[0] = 0;
+      }
+      if (nb > 1) {
+        launch_radix_sort_batched<11>(sb, nb, (int)V, 32, base + o_ws, ksorted, idxT + (int64_t)t0 * V, st);
+      } else if (int rc = segment_sort_segs("esr_argsort_columns", sb.b[0], V, (int64_t)1 << 32, ksorted,
+                                            idxT + (int64_t)t0 * V, base + o_ws, total - o_ws, st)) {
+        return rc;
+      }
+    }
+    hipLaunchKernelGGL(untranspose_idx_kernel, dim3(grid), dim3(kBlock), 0, st, (const int32_t*)idxT, V, T, indices);
+    return check_launch("esr_argsort_columns");
+  }
+  const size_t fixed = argsort_layout(V, T, &o_keys, &o_idx, &o_sorted);
   float* keysT = (float*)(base + o_keys);       // [T][V]
   int32_t* idxT = (int32_t*)(base + o_idx);     // [T][V]
   float* keys_sorted = (float*)(base + o_sorted);

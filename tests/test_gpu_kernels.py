@@ -1000,6 +1000,25 @@ def test_topk_columns_equals_the_tail_of_the_stable_argsort(dev, V, T_, k):
     assert lazy.shape == (V, T_) and np.array_equal(N(lazy), full)
 
 
+@pytest.mark.parametrize("V,T_", [(1, 1), (37, 3), (2048, 2), (4097, 1), (5000, 9), (40_000, 8), (300_000, 3),
+                                  (465_537, 10), (2_097_152, 1)])
+def test_argsort_columns_equals_numpy_stable_argsort(dev, V, T_):
+    """esr_argsort_columns on this library's own radix sort (V <= 2^21; three 11-bit passes over the order-preserving
+    images of the floats, eight columns per launch sequence): exactly numpy's stable ascending argsort per column --
+    negative values, ties (a coarse grid), infinities; one column, a full group of eight, eight plus a remainder."""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(V + T_)
+    x = rng.standard_normal((V, T_)).astype(np.float32) * 50.0
+    grid = rng.random((V, T_)) < 0.4
+    x[grid] = np.round(x[grid] / 8.0) * 8.0          # many exact ties
+    if V > 10:
+        x[3, 0], x[5, 0] = np.inf, -np.inf
+    xz = np.where(x == 0.0, np.float32(0.0), x)                            # (no -0.0 in the data: round() may give it)
+    want = np.argsort(xz, axis=0, kind="stable")
+    got = N(ops.argsort_columns(T(xz, dev))).astype(np.int64)
+    assert np.array_equal(got, want)
+
+
 def test_find_top_k_vs_golden_with_ties(dev):
     from esrecsys_amd import ops
     g = load_golden("topk_n500_d8_k10")
