@@ -1051,6 +1051,29 @@ __global__ __launch_bounds__(kBlock) void take_k_kernel(const float* __restrict_
   }
 }
 
+// rows [r0, r0 + nb) of `scores` ([.][pitch] floats, N valid) -> keys[b][N]: images whose ASCENDING unsigned order is the
+// floats' DESCENDING order (the complement of transpose_cols_keys_kernel's image); and the k best of sorted rows back
+__global__ __launch_bounds__(kBlock) void desc_keys_kernel(const float* __restrict__ scores, int64_t pitch, int64_t N,
+                                                          int32_t* __restrict__ keys) {
+  const float* row = scores + (int64_t)blockIdx.y * pitch;
+  int32_t* out = keys + (int64_t)blockIdx.y * N;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += (int64_t)gridDim.x * kBlock) {
+    const uint32_t f = __float_as_uint(row[i]);
+    out[i] = (int32_t)~((f & 0x80000000u) ? ~f : (f | 0x80000000u));
+  }
+}
+__global__ __launch_bounds__(kBlock) void take_k_rows_kernel(const float* __restrict__ scores, int64_t pitch,
+                                                            const int32_t* __restrict__ idx, int64_t N, int k,
+                                                            float* __restrict__ out_s, int32_t* __restrict__ out_i) {
+  const float* row = scores + (int64_t)blockIdx.y * pitch;
+  const int32_t* ix = idx + (int64_t)blockIdx.y * N;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < k; i += gridDim.x * kBlock) {
+    const int32_t j = ix[i];
+    out_i[(int64_t)blockIdx.y * k + i] = j;
+    out_s[(int64_t)blockIdx.y * k + i] = row[j];
+  }
+}
+
 // Queries are staged in <= 48 KB of LDS per launch; more queries = more passes over the candidates.
 static int launch_score_rows(const float* queries, const int32_t* q_ids, int nq, const float* cand, int64_t N,
                              int D, float* out, int64_t out_q_stride, int64_t out_n_stride, hipStream_t st) {
@@ -1377,6 +1400,9 @@ size_t esr_score_topk_workspace_bytes(int64_t nq, int64_t N, int k) {
   (void)k;
   if (nq <= 0 || N <= 0) return 256;
   const size_t row = align_up((size_t)N * 4, 256);
+  if (k > kSelectMaxK && N <= kRadixLongN)  // own radix sort, kMaxSortBatch rows per launch sequence (see esr_score_topk)
+    return row * (size_t)nq + 3 * row * kMaxSortBatch +
+           std::max((size_t)kMaxSortBatch * radix_ws_layout(N, nullptr, nullptr), esr_segment_sort_workspace_bytes(N));
   return row * (size_t)nq + 2 * row + pair_sort_temp_bytes<true, float>(N);
 }
 
@@ -1407,6 +1433,43 @@ int esr_score_topk(const float* queries, const float* candidates, int64_t nq, in
   // launch for all queries; only the k survivors are sorted) instead of a full device sort of all N scores per query
   if (k <= kSelectMaxK)
     return select_topk_dense(scores, (int64_t)(row / 4), nq, (int)N, k, out_scores, out_indices, st);
+  if (N <= kRadixLongN) {
+    // k beyond the select's 1024: every row sorted in full, descending and stable (lower index first among equal scores,
+    // as jax.lax.top_k), by this file's radix sort over the complemented images, eight rows per launch sequence
+    char* p = base + row * nq;
+    int32_t* keys = (int32_t*)p;                                   // [8][row / 4]
+    int32_t* ksorted = (int32_t*)(p + row * kMaxSortBatch);        // [8][N] (not read)
+    int32_t* idx = (int32_t*)(p + 2 * row * kMaxSortBatch);        // [8][N]
+    char* sort_ws = p + 3 * row * kMaxSortBatch;
+    const size_t sort_ws_bytes = workspace_bytes - (size_t)(sort_ws - base);
+    for (int64_t q0 = 0; q0 < nq; q0 += kMaxSortBatch) {
+      const int nb = (int)std::min<int64_t>(kMaxSortBatch, nq - q0);
+      const dim3 kg((unsigned)std::min<int64_t>(1024, cdiv(N, kBlock)), nb);
+      hipLaunchKernelGGL(desc_keys_kernel, kg, dim3(kBlock), 0, st, (const float*)((char*)scores + row * q0),
+                         (int64_t)(row / 4), N, keys);
+      SortSegsBatch sb;
+      for (int b = 0; b < kMaxSortBatch; ++b) {
+        SortSegs& sg = sb.b[b];
+        sg.n = 1;
+        for (int i = 0; i < kMaxSortSegs; ++i) {
+          sg.ids[i] = i == 0 ? keys + (int64_t)std::min(b, nb - 1) * N : nullptr;
+          sg.offset[i] = 0;
+          sg.start[i + 1] = N;
+        }
+        sg.start[0] = 0;
+      }
+      if (nb > 1) {
+        launch_radix_sort_batched<11>(sb, nb, (int)N, 32, sort_ws, ksorted, idx, st);
+      } else if (int rc = segment_sort_segs("esr_score_topk", sb.b[0], N, (int64_t)1 << 32, ksorted, idx, sort_ws,
+                                            sort_ws_bytes, st)) {
+        return rc;
+      }
+      const dim3 tg((unsigned)cdiv(k, kBlock), nb);
+      hipLaunchKernelGGL(take_k_rows_kernel, tg, dim3(kBlock), 0, st, (const float*)((char*)scores + row * q0),
+                         (int64_t)(row / 4), (const int32_t*)idx, N, k, out_scores + q0 * k, out_indices + q0 * k);
+    }
+    return check_launch("esr_score_topk");
+  }
   for (int64_t q = 0; q < nq; ++q) {
     size_t need = temp_bytes;
     hipError_t e = rocprim::radix_sort_pairs_desc(temp, need, (float*)((char*)scores + row * q), keys_sorted,

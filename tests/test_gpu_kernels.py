@@ -1028,7 +1028,8 @@ def test_find_top_k_vs_golden_with_ties(dev):
 
 
 @pytest.mark.parametrize("nq,N_,D,k", [(1, 100_000, 128, 10), (3, 20_000, 512, 500), (5, 999, 96, 999),
-                                       (2, 5_000, 64, 1024), (2, 5_000, 64, 1025), (1, 1_000_000, 32, 500)])
+                                       (2, 5_000, 64, 1024), (2, 5_000, 64, 1025), (1, 1_000_000, 32, 500),
+                                       (11, 60_000, 32, 3000), (1, 300_000, 16, 2048), (9, 3000, 8, 3000)])
 def test_score_topk_random_vs_oracle(dev, nq, N_, D, k):
     from esrecsys_amd import ops
     rng = np.random.default_rng(nq + k)
@@ -1167,3 +1168,19 @@ def test_sparse_adagrad_multi_long_runs_hint(dev):
             res.append((t0, t1, a0, a1))
         for x, y in zip(*res):
             assert torch.equal(x, y)
+
+
+def test_score_topk_beyond_1024_is_stable_on_ties(dev):
+    """k > 1024: full descending sort per query row on the library's radix sort, eight rows per launch sequence -- with
+    scores on a coarse integer grid (exact in f32: thousands of ties) the result must be exactly lax.top_k's order,
+    lower index first among equal scores."""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(12)
+    nq, N_, D, k = 10, 20_000, 4, 1500
+    q = rng.integers(-3, 4, (nq, D)).astype(np.float32)
+    c = rng.integers(-3, 4, (N_, D)).astype(np.float32)
+    s, i = ops.score_topk(T(q, dev), T(c, dev), k)
+    full = q @ c.T
+    order = np.argsort(-full, axis=1, kind="stable")[:, :k]
+    assert np.array_equal(N(i), order.astype(np.int32))
+    assert np.array_equal(N(s), np.take_along_axis(full, order, axis=1))
