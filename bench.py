@@ -779,7 +779,7 @@ def secondary_legs(args, dev, rank):
     legs = [("glove_c3_b65536", "glove", {}, max(k, 200), max(w, 10), 6.0, 6.0),
             ("glove_c3_b2048_reference_default_batch", "glove", {"B": 2048}, max(k, 400), max(w, 16), 3.0, 6.0),
             ("triplet_c2_b8192_reference_loss", "triplet", {}, max(k, 400), max(w, 16), 4.0, 6.0),
-            ("triplet_c2_b262144_saturating", "triplet", {"B": 262144}, min(k, 30), w, 0.0, 0.0)]
+            ("triplet_c2_b262144_saturating", "triplet", {"B": 262144}, max(min(k, 100), 64), max(w, 16), 0.0, 0.0)]
     for name, workload, over, steps, warm, cpu_s, cpu_dense_s in legs:
         cfg = dict(WORKLOADS[workload], table_dtype="f32", ids="uniform", **over)
         try:

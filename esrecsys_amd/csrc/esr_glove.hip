@@ -1242,15 +1242,18 @@ static void launch_glove_step(const GloveTables& t, const int32_t* inputs, const
                          t.emb_loc, t.emb_accum, D, g.G, (const uint32_t*)ws.own_code, (const float4*)ws.meta_res, n, B,
                          mode, nstat, (const double*)ws.stat_part, lr, eps, ws.chunk_rows, ws.bias_info, ws.pair_part,
                          ws.res_flags, start_flag, start_value);
-      // (always launched here: its last workgroup reduces the loss partials for the finalize kernel)
-      hipLaunchKernelGGL((glove_step_long_kernel<VEC, NCH>), dim3(grid2), dim3(kBlock), 0, st, t.emb, t.emb_shadow,
-                         t.emb_loc, t.emb_accum, D, g.G, sorted_ids, n, stamp, lr, eps, (const float*)ws.chunk_rows,
-                         ws.bias_info, (const int*)ws.res_flags, grid, (const double*)ws.pair_part, ws.pair_tot);
+      // (its last workgroup also reduces the loss partials for the finalize kernel; when the caller knows that no run
+      // outgrows its head chunk -- long_runs == 0 -- it is skipped and every finalize workgroup reduces them itself,
+      // the same sums in the same order)
+      if (long_runs != 0)
+        hipLaunchKernelGGL((glove_step_long_kernel<VEC, NCH>), dim3(grid2), dim3(kBlock), 0, st, t.emb, t.emb_shadow,
+                           t.emb_loc, t.emb_accum, D, g.G, sorted_ids, n, stamp, lr, eps, (const float*)ws.chunk_rows,
+                           ws.bias_info, (const int*)ws.res_flags, grid, (const double*)ws.pair_part, ws.pair_tot);
     });
     hipLaunchKernelGGL(glove_step_finalize_kernel, dim3(nfin), dim3(kBlock), 0, st, B, mode,
                        (const unsigned long long*)nullptr, nstat, (const double*)ws.stat_part, grid,
-                       (const double*)ws.pair_part, (const double*)ws.pair_tot, sorted_ids,
-                       (const double2*)ws.bias_info, t.bias, t.bias_accum, lr, eps, loss);
+                       (const double*)ws.pair_part, long_runs != 0 ? (const double*)ws.pair_tot : (const double*)nullptr,
+                       sorted_ids, (const double2*)ws.bias_info, t.bias, t.bias_accum, lr, eps, loss);
     return;
   }
   if (!plan) {  // no plan made ahead: make it here (and nobody told us whether a run is long: screen for it)

@@ -997,7 +997,8 @@ __global__ __launch_bounds__(kBlock) void transpose_cols_keys_kernel(const float
     const int64_t v = i / T;
     const int t = (int)(i - v * T);
     const uint32_t f = __float_as_uint(scores[i]);
-    keysT[(int64_t)t * V + v] = (int32_t)((f & 0x80000000u) ? ~f : (f | 0x80000000u));
+    const uint32_t mask = (uint32_t)((int32_t)f >> 31) | 0x80000000u;  // negative: all ones; else: the sign bit
+    keysT[(int64_t)t * V + v] = (int32_t)(f ^ mask);
   }
 }
 // indices[v][t] = idxT[t][v]
@@ -1059,7 +1060,8 @@ __global__ __launch_bounds__(kBlock) void desc_keys_kernel(const float* __restri
   int32_t* out = keys + (int64_t)blockIdx.y * N;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += (int64_t)gridDim.x * kBlock) {
     const uint32_t f = __float_as_uint(row[i]);
-    out[i] = (int32_t)~((f & 0x80000000u) ? ~f : (f | 0x80000000u));
+    const uint32_t mask = (uint32_t)((int32_t)f >> 31) | 0x80000000u;  // negative: all ones; else: the sign bit
+    out[i] = (int32_t)(f ^ ~mask);                                     // == ~(f ^ mask): descending image
   }
 }
 __global__ __launch_bounds__(kBlock) void take_k_rows_kernel(const float* __restrict__ scores, int64_t pitch,
