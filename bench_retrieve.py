@@ -94,7 +94,7 @@ def measure_retrieve(dev, n_local, steps, warmup, mode="f16x2", with_cpu=True, w
     }
 
 
-def measure_ivf(dev, n_local=1_048_576, nq=NQ, ks=(10, 500), nlist=1024, nprobes=(8, 32), steps=3, corpus="clustered"):
+def measure_ivf(dev, n_local=1_048_576, nq=NQ, ks=(10, 500), nlist=1024, nprobes=(8, 32, 128), steps=3, corpus="clustered"):
     """Config 5's ANN leg: the IVF index (esrecsys_amd/ivf.py) against the exact brute force on the SAME corpus and
     queries -- recall@k and queries/s per (k, nprobe).  corpus "clustered": 4096 unit-norm centres + N(0, 0.6^2 / D) noise
     (embedding tables have cluster structure; that is what an inverted file exploits); "iid": the N(0, 1/D) rows of the

@@ -24,9 +24,20 @@ constexpr int kSelectMaxK = 1024;
 int select_topk_dense(const float* scores, int64_t pitch, int64_t rows, int n, int k, float* out_scores,
                       int32_t* out_indices, hipStream_t st);
 
-// the same select over ragged rows (row r: n_per_row[r] entries, at most max_n): esr_ivf.hip's per-list candidates
+// the same select over ragged rows (row r: n_per_row[r] entries, at most max_n)
 int select_topk_ragged(const float* scores, int64_t pitch, int64_t rows, const int32_t* n_per_row, int max_n, int k,
                        float* out_scores, int32_t* out_indices, hipStream_t st);
+// the two stages of a filtered search (esr_ivf.hip; esr_retrieve_topk drives the same kernel itself).
+// head: dense rows [rows][pitch] of n > k scores (index = column) -> the k best as (score bits, index) records at the
+// head of pairs[row * ppitch ..], cnt[row] = k, tau[row] = the k-th best score.
+// tail: the lists pairs[row * ppitch .. + cnt[row]) -- that head plus what a filtered pass appended -- -> the k best,
+// best first (scores -inf / index -1 where a list holds fewer than k).
+int select_topk_head(const float* scores, int64_t pitch, int64_t rows, int n, int k, int2* pairs, int64_t ppitch,
+                     int32_t* cnt, float* tau, hipStream_t st);
+int select_topk_tail(const int2* pairs, int64_t ppitch, const int32_t* cnt, int64_t rows, int k, float* out_scores,
+                     int32_t* out_indices, hipStream_t st);
+// between two filtered passes: every list cut back to its k best (in place), cnt = min(cnt, k), tau raised
+int select_topk_compact(int2* pairs, int64_t ppitch, int32_t* cnt, int64_t rows, int k, float* tau, hipStream_t st);
 
 inline hipStream_t as_stream(esr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 

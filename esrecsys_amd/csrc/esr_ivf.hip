@@ -9,10 +9,19 @@
 //
 //   sort      the pairs by list (esr_segment_sort_ids)            -> pairs of one list are contiguous
 //   prep      per list: where its pairs start, how many 64-row tiles they make; prefix over the lists
-//   score     grouped FP32 GEMM: a workgroup owns a 64 pairs x 64 candidates tile of ONE list (exact f32 products, fmaf in
-//             k order: what is approximate about the answer is only WHICH lists are looked at)
-//   select    radix select of the k best per pair (ragged rows: a pair's row is as long as its list)
-//   map       position in list -> candidate row; then the nprobe lists of a query are merged (esr_topk_merge)
+//   score     grouped GEMM on the FP32 matrix cores (v_mfma_f32_32x32x2_f32: exact f32 products -- what is approximate
+//             about the answer is only WHICH lists are looked at): a workgroup owns a 64 pairs x 64 candidates tile of
+//             ONE list; a pair's score row is `pitch` long, -inf behind the end of its list
+//   head      the pairs of every query's BEST list(s) first (as many probe slots as hold more than k candidates: one,
+//             usually): dense scores, radix select -> the running top-k of the query and tau = its k-th best score
+//   filter    the other pairs, kIvfRound probe slots at a time: the same GEMM, but a score is kept only if it reaches its
+//             query's tau -- appended to the query's list behind the running top-k (the brute force's filtered
+//             epilogue: tau is a lower bound of the final k-th score, so nothing that belongs to the answer is dropped);
+//             between rounds a select compacts the list to its k best and raises tau
+//   tail      radix select over each query's short list -> the k best, best first
+//   map       position -> (probe slot, position in list) -> candidate row
+// (Measured on the way: per-pair selects + a merge of nprobe x k survivors were 2/3 of a k = 500 search; one select per
+// query over all nprobe x pitch scores streamed 270 KB rows from memory at 0.4 TB/s.)
 //
 // Work: 2 nq nprobe (N / nlist) D flop instead of 2 nq N D: nlist / nprobe times less (64x at nlist 1024, nprobe 16).
 #include "esr_common.h"
@@ -21,6 +30,7 @@ namespace esr {
 
 constexpr int kIvfTile = 64;  // pairs x candidates per workgroup
 constexpr int kIvfK = 16;     // embedding columns per LDS stage
+constexpr int kIvfRound = 8;  // probe slots per filtered round (8192 queries x 8 slots / 1024 lists = full 64-row tiles)
 
 // one workgroup (<= 1024 threads): pair_off[l] = first sorted pair of list l (lower bound), tile_start = exclusive prefix
 // of ceil(pairs of l / 64)
@@ -59,34 +69,37 @@ __global__ __launch_bounds__(1024) void ivf_prep_kernel(const int32_t* __restric
   if (threadIdx.x == 0) tile_start[nlist] = s_carry;
 }
 
-// per pair: the length of its list (the ragged select's row length); outputs pre-filled for lists shorter than k
-__global__ __launch_bounds__(kBlock) void ivf_pairs_kernel(const int32_t* __restrict__ lists, int64_t P,
-                                                          const int32_t* __restrict__ list_off, int32_t* __restrict__ npr,
-                                                          float* __restrict__ pair_scores, int32_t* __restrict__ pair_idx,
-                                                          int k) {
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < P * k; i += (int64_t)gridDim.x * kBlock) {
-    pair_scores[i] = -INFINITY;
-    pair_idx[i] = -1;
-    if (i < P) {
-      const int l = lists[i];
-      npr[i] = list_off[l + 1] - list_off[l];
-    }
-  }
-}
+typedef float ivf_f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ constexpr int ivf_mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// grouped GEMM tile: blockIdx.x = row tile over all lists (tile_start locates its list), blockIdx.y = candidate tile
+// grouped GEMM tile: blockIdx.y = row tile over all lists (tile_start locates its list), blockIdx.x = candidate tile.
+// Four waves, each a 32 x 32 quarter of the tile: per 16-column stage eight v_mfma_f32_32x32x2_f32, operands one
+// ds_read_b32 each from the k-major LDS images (lane = (row % 32, k % 2)).
+// `perm` indexes a SET of pairs laid out [queries][ppq] (ppq probe slots per query, the first of them slot0 of the
+// query's probe list).  FILTER = false: dense scores S[pair][pitch], -inf behind the end of the list.  FILTER = true:
+// scores >= tau[query] are appended to the query's record list as (score, (slot * pitch + position in list)).
+struct IvfFilter {
+  const float* tau;  // [queries of the chunk]
+  int32_t* cnt;      // [queries]: records in the list so far
+  int2* pairs;       // [queries][ppitch]
+  int64_t ppitch;
+};
+template <bool FILTER>
 __global__ __launch_bounds__(kBlock) void ivf_score_kernel(const float* __restrict__ queries, int D,
                                                           const float* __restrict__ cands,
                                                           const int32_t* __restrict__ list_off,
-                                                          const int32_t* __restrict__ perm, int nprobe, int64_t q_base,
-                                                          const int32_t* __restrict__ pair_off,
+                                                          const int32_t* __restrict__ perm, int ppq, int slot0,
+                                                          int64_t q_base, const int32_t* __restrict__ pair_off,
                                                           const int32_t* __restrict__ tile_start, int nlist,
-                                                          float* __restrict__ S, int64_t pitch) {
+                                                          float* __restrict__ S, int64_t pitch, IvfFilter flt) {
   __shared__ float As[kIvfK][kIvfTile + 4];
   __shared__ float Bs[kIvfK][kIvfTile + 4];
   __shared__ int s_pair[kIvfTile];
-  const int rt = blockIdx.x;
-  if (rt >= tile_start[nlist]) return;
+  // blockIdx.x = candidate tile (gridDim.x is a multiple of 8: workgroup b runs on XCD b % 8 = blockIdx.x % 8, so the
+  // same candidate tile of a list -- read by every row tile of the list -- always meets the same L2), blockIdx.y = row
+  // tile: the column tiles of one row tile are dispatched together and share its query rows
+  const int rt = blockIdx.y;
+  if (rt >= tile_start[nlist] || (int64_t)blockIdx.x * kIvfTile >= pitch) return;
   int lo = 0, hi = nlist - 1;  // the last list whose first tile is <= rt and that HAS tiles
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -94,111 +107,175 @@ __global__ __launch_bounds__(kBlock) void ivf_score_kernel(const float* __restri
   }
   const int l = lo;
   const int L = list_off[l + 1] - list_off[l];
-  const int c0 = blockIdx.y * kIvfTile;
-  if (c0 >= L) return;
+  const int c0 = blockIdx.x * kIvfTile;
   const int row0 = pair_off[l] + (rt - tile_start[l]) * kIvfTile;
   const int nrows = min(kIvfTile, pair_off[l + 1] - row0);
   const int t = threadIdx.x;
   if (t < kIvfTile) s_pair[t] = t < nrows ? perm[row0 + t] : -1;
   __syncthreads();
+  const int lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1, l32 = lane & 31, h = lane >> 5;
+  if (c0 >= L) {  // behind the end of the list: the head select reads whole rows
+    if (FILTER) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int p = s_pair[wr * 32 + ivf_mfma_row(r, h)];
+      if (p >= 0) S[(int64_t)p * pitch + c0 + wc * 32 + l32] = -INFINITY;
+    }
+    return;
+  }
   const int lr = t >> 2, seg = t & 3;  // loader: row lr, 4 floats at column 4 * seg of the stage
   const int my_pair = s_pair[lr];
-  const float* qrow = my_pair >= 0 ? queries + (q_base + my_pair / nprobe) * (int64_t)D : nullptr;
+  const float* qrow = my_pair >= 0 ? queries + (q_base + my_pair / ppq) * (int64_t)D : nullptr;
   const float* crow = c0 + lr < L ? cands + ((int64_t)list_off[l] + c0 + lr) * D : nullptr;
-  const int ty = t >> 4, tx = t & 15;  // computer: pairs 4 ty .. + 3, candidates 4 tx .. + 3
-  float acc[4][4] = {};
+  ivf_f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  if (qrow && 4 * seg < D) a = *reinterpret_cast<const float4*>(qrow + 4 * seg);
+  if (crow && 4 * seg < D) b = *reinterpret_cast<const float4*>(crow + 4 * seg);
   for (int k0 = 0; k0 < D; k0 += kIvfK) {
-    const int kc = k0 + 4 * seg;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-    if (qrow && kc < D) a = *reinterpret_cast<const float4*>(qrow + kc);
-    if (crow && kc < D) b = *reinterpret_cast<const float4*>(crow + kc);
     __syncthreads();  // (the previous stage has been consumed)
     As[4 * seg + 0][lr] = a.x; As[4 * seg + 1][lr] = a.y; As[4 * seg + 2][lr] = a.z; As[4 * seg + 3][lr] = a.w;
     Bs[4 * seg + 0][lr] = b.x; Bs[4 * seg + 1][lr] = b.y; Bs[4 * seg + 2][lr] = b.z; Bs[4 * seg + 3][lr] = b.w;
     __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < kIvfK; ++kk) {
-      const float4 av = *reinterpret_cast<const float4*>(&As[kk][4 * ty]);
-      const float4 bv = *reinterpret_cast<const float4*>(&Bs[kk][4 * tx]);
-      const float ar[4] = {av.x, av.y, av.z, av.w}, br[4] = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(ar[i], br[j], acc[i][j]);
+    {  // the next stage's rows travel while this one is multiplied
+      const int kc = k0 + kIvfK + 4 * seg;
+      a = make_float4(0.f, 0.f, 0.f, 0.f);
+      b = a;
+      if (qrow && kc < D) a = *reinterpret_cast<const float4*>(qrow + kc);
+      if (crow && kc < D) b = *reinterpret_cast<const float4*>(crow + kc);
     }
+#pragma unroll
+    for (int kk = 0; kk < kIvfK; kk += 2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kk + h][wr * 32 + l32], Bs[kk + h][wc * 32 + l32], acc, 0, 0, 0);
   }
+  const int c = c0 + wc * 32 + l32;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int p = s_pair[4 * ty + i];
+  for (int r = 0; r < 16; ++r) {
+    const int p = s_pair[wr * 32 + ivf_mfma_row(r, h)];
     if (p < 0) continue;
-    float* out = S + (int64_t)p * pitch + c0 + 4 * tx;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (c0 + 4 * tx + j < L) out[j] = acc[i][j];
+    if (!FILTER) {
+      S[(int64_t)p * pitch + c] = c < L ? acc[r] : -INFINITY;
+    } else if (c < L) {
+      const int q = p / ppq;
+      if (acc[r] >= flt.tau[q]) {
+        const int at = atomicAdd(flt.cnt + q, 1);
+        flt.pairs[(int64_t)q * flt.ppitch + at] =
+            make_int2(__float_as_int(acc[r]), (int)((int64_t)(slot0 + (p - q * ppq)) * pitch + c));
+      }
+    }
   }
 }
 
-// position in list -> candidate row of the caller's matrix, for every (pair, rank)
-__global__ __launch_bounds__(kBlock) void ivf_map_kernel(const int32_t* __restrict__ lists, int64_t P, int k,
-                                                        const int32_t* __restrict__ list_off,
-                                                        const int32_t* __restrict__ orig, int32_t* __restrict__ pair_idx) {
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < P * k; i += (int64_t)gridDim.x * kBlock) {
-    const int32_t c = pair_idx[i];
-    if (c >= 0) pair_idx[i] = orig[list_off[lists[i / k]] + c];
+// out [queries][g] = probe slots s0 .. s0 + g - 1 of lists [queries][nprobe]
+__global__ __launch_bounds__(kBlock) void ivf_take_slots_kernel(const int32_t* __restrict__ lists, int64_t nq, int nprobe,
+                                                               int s0, int g, int32_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nq * g; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t q = i / g;
+    out[i] = lists[q * nprobe + s0 + (int)(i - q * g)];
+  }
+}
+
+// position in a query's nprobe x pitch score row -> candidate row of the caller's matrix (-1 where the lists ran out)
+__global__ __launch_bounds__(kBlock) void ivf_map_kernel(const int32_t* __restrict__ lists, int64_t nq, int nprobe, int k,
+                                                        int64_t pitch, const int32_t* __restrict__ list_off,
+                                                        const int32_t* __restrict__ orig, const float* __restrict__ scores,
+                                                        int32_t* __restrict__ idx) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nq * k; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t q = i / k;
+    const int32_t pos = idx[i];
+    if (scores[i] == -INFINITY || pos < 0) {
+      idx[i] = -1;
+      continue;
+    }
+    const int slot = (int)(pos / pitch), c = (int)(pos - slot * pitch);
+    idx[i] = orig[list_off[lists[q * nprobe + slot]] + c];
   }
 }
 
 struct IvfWs {
-  int32_t* sorted_lists;  // [P]
-  int32_t* perm;          // [P]
+  int32_t* set_lists;     // [cq * max(f, kIvfRound)]  the probe slots of the set being scored
+  int32_t* sorted_lists;  // [the same]
+  int32_t* perm;          // [the same]
   int32_t* pair_off;      // [nlist + 1]
   int32_t* tile_start;    // [nlist + 1]
-  int32_t* npr;           // [P]
-  float* pair_scores;     // [P, k]
-  int32_t* pair_idx;      // [P, k]
-  float* S;               // [P, pitch]
+  float* S;               // [cq * f, pitch]  head scores
+  int2* pairs;            // [cq, ppitch]     running top-k + what the filter lets through
+  int32_t* cnt;           // [cq]
+  float* tau;             // [cq]
   void* sort_ws;
   size_t sort_ws_bytes;
 };
-static size_t ivf_layout(int64_t P, int nlist, int64_t pitch, int k, char* base, IvfWs* out) {
+struct IvfGeom {
+  int64_t pitch;   // a pair's score row: the longest list, and enough that nprobe rows hold more than k entries
+  int f;           // probe slots scored densely first: the fewest whose rows hold more than k entries
+  int64_t ppitch;  // a query's record list: k + everything one round could let through
+  int64_t chunk;   // queries per pass (head scores + record lists stay under ~2 GiB)
+};
+static IvfGeom ivf_geom(int64_t nq, int max_list, int nprobe, int k) {
+  IvfGeom g;
+  g.pitch = (int64_t)align_up((size_t)std::max<int64_t>(max_list, cdiv((int64_t)k + 1, nprobe)), 64);
+  // (as many as the head select still caches in LDS -- 8192 scores: a list with few pairs fills little of a 64-row
+  // tile, so three slots cost the scoring pass what one does, and tau starts tighter)
+  g.f = (int)std::min<int64_t>(nprobe, std::max<int64_t>(k / g.pitch + 1, 8192 / g.pitch));
+  g.ppitch = (int64_t)k + (int64_t)std::min(kIvfRound, nprobe - g.f) * g.pitch;
+  const int64_t per_query = g.f * g.pitch * 4 + g.ppitch * 8;
+  g.chunk = std::min(nq, std::max<int64_t>(64, ((int64_t)1 << 31) / per_query));
+  return g;
+}
+static size_t ivf_layout(const IvfGeom& g, int64_t cq, int nprobe, int nlist, char* base, IvfWs* out) {
   size_t off = 0;
   auto take = [&](size_t bytes) {
     char* p = base ? base + off : nullptr;
     off += align_up(bytes, 256);
     return p;
   };
+  const int64_t P1 = cq * g.f, Pm = cq * std::max(g.f, std::min(kIvfRound, std::max(1, nprobe - g.f)));
   IvfWs w;
-  w.sorted_lists = (int32_t*)take(4 * (size_t)P);
-  w.perm = (int32_t*)take(4 * (size_t)P);
+  w.set_lists = (int32_t*)take(4 * (size_t)Pm);
+  w.sorted_lists = (int32_t*)take(4 * (size_t)Pm);
+  w.perm = (int32_t*)take(4 * (size_t)Pm);
   w.pair_off = (int32_t*)take(4 * (size_t)(nlist + 1));
   w.tile_start = (int32_t*)take(4 * (size_t)(nlist + 1));
-  w.npr = (int32_t*)take(4 * (size_t)P);
-  w.pair_scores = (float*)take(4 * (size_t)P * k);
-  w.pair_idx = (int32_t*)take(4 * (size_t)P * k);
-  w.S = (float*)take(4 * (size_t)P * (size_t)pitch);
-  w.sort_ws_bytes = esr_segment_sort_workspace_bytes(P);
+  w.S = (float*)take(4 * (size_t)P1 * (size_t)g.pitch);
+  w.pairs = (int2*)take(8 * (size_t)cq * (size_t)g.ppitch);
+  w.cnt = (int32_t*)take(4 * (size_t)cq);
+  w.tau = (float*)take(4 * (size_t)cq);
+  w.sort_ws_bytes = esr_segment_sort_workspace_bytes(Pm);
   w.sort_ws = take(w.sort_ws_bytes);
   if (out) *out = w;
   return off;
-}
-
-// queries per pass: the score block [chunk * nprobe, pitch] floats stays under ~1 GiB
-static int64_t ivf_chunk(int64_t nq, int nprobe, int64_t pitch) {
-  const int64_t rows = std::max<int64_t>(1, ((int64_t)1 << 28) / std::max<int64_t>(1, pitch * nprobe));
-  return std::min(nq, std::max<int64_t>(64, rows));
 }
 
 }  // namespace esr
 
 using namespace esr;
 
+// the pairs of one set (lists [P] = cq x ppq probe slots, the first being slot0): sort by list, tile, score
+template <bool FILTER>
+static int ivf_score_set(const float* queries, int D, const float* cands_sorted, const int32_t* list_off, int nlist,
+                         const int32_t* lists, int64_t P, int ppq, int slot0, int64_t q0, const IvfGeom& g,
+                         const IvfWs& ws, esr_stream_t stream) {
+  hipStream_t st = as_stream(stream);
+  if (int rc = esr_segment_sort_ids(lists, P, nlist, ws.sorted_lists, ws.perm, ws.sort_ws, ws.sort_ws_bytes, stream))
+    return rc;
+  hipLaunchKernelGGL(ivf_prep_kernel, dim3(1), dim3(1024), 0, st, (const int32_t*)ws.sorted_lists, P, nlist, ws.pair_off,
+                     ws.tile_start);
+  const int row_tiles = (int)(P / kIvfTile + nlist);  // >= sum over lists of ceil(pairs / 64)
+  IvfFilter flt;
+  flt.tau = ws.tau; flt.cnt = ws.cnt; flt.pairs = ws.pairs; flt.ppitch = g.ppitch;
+  hipLaunchKernelGGL((ivf_score_kernel<FILTER>), dim3((int)align_up((size_t)(g.pitch / kIvfTile), 8), row_tiles),
+                     dim3(kBlock), 0, st, queries, D, cands_sorted, list_off, (const int32_t*)ws.perm, ppq, slot0, q0,
+                     (const int32_t*)ws.pair_off, (const int32_t*)ws.tile_start, nlist, ws.S, g.pitch, flt);
+  return ESR_OK;
+}
+
 extern "C" {
 
 size_t esr_ivf_search_workspace_bytes(int64_t nq, int nlist, int max_list, int nprobe, int k) {
   if (nq <= 0 || nlist <= 0 || max_list <= 0 || nprobe <= 0 || k <= 0) return 256;
-  const int64_t pitch = align_up((size_t)max_list, 64);
-  const int64_t chunk = ivf_chunk(nq, nprobe, pitch);
-  return ivf_layout(chunk * nprobe, nlist, pitch, k, nullptr, nullptr);
+  const IvfGeom g = ivf_geom(nq, max_list, nprobe, k);
+  return ivf_layout(g, g.chunk, nprobe, nlist, nullptr, nullptr);
 }
 
 int esr_ivf_search(const float* queries, int64_t nq, int D, const float* cands_sorted, const int32_t* list_off,
@@ -216,29 +293,40 @@ int esr_ivf_search(const float* queries, int64_t nq, int D, const float* cands_s
     return ESR_EWORKSPACE;
   }
   hipStream_t st = as_stream(stream);
-  const int64_t pitch = align_up((size_t)max_list, 64);
-  const int64_t chunk = ivf_chunk(nq, nprobe, pitch);
+  const IvfGeom g = ivf_geom(nq, max_list, nprobe, k);
+  ESR_REQUIRE((int64_t)nprobe * g.pitch < ((int64_t)1 << 31), "esr_ivf_search: nprobe x longest list exceeds 2^31");
   IvfWs ws;
-  ivf_layout(chunk * nprobe, nlist, pitch, k, (char*)workspace, &ws);
-  for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
-    const int64_t cq = std::min(chunk, nq - q0), P = cq * nprobe;
-    const int32_t* lists = probe_lists + q0 * nprobe;
-    if (int rc = esr_segment_sort_ids(lists, P, nlist, ws.sorted_lists, ws.perm, ws.sort_ws, ws.sort_ws_bytes, stream))
+  ivf_layout(g, g.chunk, nprobe, nlist, (char*)workspace, &ws);
+  const int f = g.f;
+  auto take_slots = [&](int64_t q0, int64_t cq, int s0, int n) {
+    hipLaunchKernelGGL(ivf_take_slots_kernel, dim3((int)std::min<int64_t>(kMaxGrid, cdiv(cq * n, kBlock))), dim3(kBlock),
+                       0, st, probe_lists + q0 * nprobe, cq, nprobe, s0, n, ws.set_lists);
+  };
+  for (int64_t q0 = 0; q0 < nq; q0 += g.chunk) {
+    const int64_t cq = std::min(g.chunk, nq - q0);
+    // head: the best list(s) of every query, dense; their k best open the query's record list and give tau
+    take_slots(q0, cq, 0, f);
+    if (int rc = ivf_score_set<false>(queries, D, cands_sorted, list_off, nlist, ws.set_lists, cq * f, f, 0, q0, g, ws,
+                                      stream))
       return rc;
-    hipLaunchKernelGGL(ivf_prep_kernel, dim3(1), dim3(1024), 0, st, (const int32_t*)ws.sorted_lists, P, nlist, ws.pair_off,
-                       ws.tile_start);
-    hipLaunchKernelGGL(ivf_pairs_kernel, dim3((int)std::min<int64_t>(kMaxGrid, cdiv(P * k, kBlock))), dim3(kBlock), 0, st,
-                       lists, P, list_off, ws.npr, ws.pair_scores, ws.pair_idx, k);
-    const int row_tiles = (int)(P / kIvfTile + nlist);  // >= sum over lists of ceil(pairs / 64)
-    hipLaunchKernelGGL(ivf_score_kernel, dim3(row_tiles, (int)(pitch / kIvfTile)), dim3(kBlock), 0, st, queries, D,
-                       cands_sorted, list_off, (const int32_t*)ws.perm, nprobe, q0, (const int32_t*)ws.pair_off,
-                       (const int32_t*)ws.tile_start, nlist, ws.S, pitch);
-    if (int rc = select_topk_ragged(ws.S, pitch, P, ws.npr, max_list, k, ws.pair_scores, ws.pair_idx, st)) return rc;
-    hipLaunchKernelGGL(ivf_map_kernel, dim3((int)std::min<int64_t>(kMaxGrid, cdiv(P * k, kBlock))), dim3(kBlock), 0, st,
-                       lists, P, k, list_off, orig, ws.pair_idx);
-    if (int rc = esr_topk_merge(ws.pair_scores, ws.pair_idx, cq, nprobe * k, k, out_scores + q0 * k, out_indices + q0 * k,
-                                stream))
+    if (int rc = select_topk_head(ws.S, (int64_t)f * g.pitch, cq, (int)(f * g.pitch), k, ws.pairs, g.ppitch, ws.cnt,
+                                  ws.tau, st))
       return rc;
+    // filter: the other lists, a round of slots at a time, add what reaches tau; a select between rounds compacts
+    for (int s0 = f; s0 < nprobe; s0 += kIvfRound) {
+      const int n = std::min(kIvfRound, nprobe - s0);
+      take_slots(q0, cq, s0, n);
+      if (int rc = ivf_score_set<true>(queries, D, cands_sorted, list_off, nlist, ws.set_lists, cq * n, n, s0, q0, g, ws,
+                                       stream))
+        return rc;
+      if (s0 + n < nprobe)
+        if (int rc = select_topk_compact(ws.pairs, g.ppitch, ws.cnt, cq, k, ws.tau, st)) return rc;
+    }
+    if (int rc = select_topk_tail(ws.pairs, g.ppitch, ws.cnt, cq, k, out_scores + q0 * k, out_indices + q0 * k, st))
+      return rc;
+    hipLaunchKernelGGL(ivf_map_kernel, dim3((int)std::min<int64_t>(kMaxGrid, cdiv(cq * k, kBlock))), dim3(kBlock), 0, st,
+                       probe_lists + q0 * nprobe, cq, nprobe, k, g.pitch, list_off, orig,
+                       (const float*)(out_scores + q0 * k), out_indices + q0 * k);
   }
   return check_launch("esr_ivf_search");
 }

@@ -820,6 +820,46 @@ int select_topk_dense(const float* scores, int64_t pitch, int64_t rows, int n, i
   return check_launch("select_topk_dense");
 }
 
+int select_topk_head(const float* scores, int64_t pitch, int64_t rows, int n, int k, int2* pairs, int64_t ppitch,
+                     int32_t* cnt, float* tau, hipStream_t st) {
+  if (k > kSelMaxK || n <= k) return ESR_EINVAL;
+  SelIn in;
+  in.vals = scores; in.vpitch = pitch; in.idx = nullptr; in.stride = 1; in.ibase = 0; in.istep = 1;
+  in.n_per_row = nullptr; in.n_fixed = n;
+  SelOut so;
+  so.pairs = pairs; so.ppitch = ppitch; so.cnt = cnt; so.tau = tau; so.scores = nullptr; so.indices = nullptr;
+  const int lds_words = n > kSelThreads * kSelBatch && n <= kSelLdsWords ? kSelLdsWords : 0;
+  hipLaunchKernelGGL(topk_select_kernel, dim3((int)rows), dim3(kSelThreads), lds_words * sizeof(uint32_t), st, in, k, so,
+                     lds_words);
+  return check_launch("select_topk_head");
+}
+
+int select_topk_tail(const int2* pairs, int64_t ppitch, const int32_t* cnt, int64_t rows, int k, float* out_scores,
+                     int32_t* out_indices, hipStream_t st) {
+  if (k > kSelMaxK) return ESR_EINVAL;
+  SelIn in;
+  in.vals = (const float*)pairs; in.vpitch = 2 * ppitch; in.idx = (const int32_t*)pairs + 1; in.stride = 2;
+  in.ibase = 0; in.istep = 0; in.n_per_row = cnt; in.n_fixed = 0;
+  SelOut so;
+  so.pairs = nullptr; so.ppitch = 0; so.cnt = nullptr; so.tau = nullptr; so.scores = out_scores; so.indices = out_indices;
+  // (lists longer than the registers hold -- 2048 records -- are cached in LDS up to 4096, streamed beyond)
+  hipLaunchKernelGGL(topk_select_kernel, dim3((int)rows), dim3(kSelThreads), kSelLdsWords * sizeof(uint32_t), st, in, k, so,
+                     kSelLdsWords);
+  return check_launch("select_topk_tail");
+}
+
+int select_topk_compact(int2* pairs, int64_t ppitch, int32_t* cnt, int64_t rows, int k, float* tau, hipStream_t st) {
+  if (k > kSelMaxK) return ESR_EINVAL;
+  SelIn in;
+  in.vals = (const float*)pairs; in.vpitch = 2 * ppitch; in.idx = (const int32_t*)pairs + 1; in.stride = 2;
+  in.ibase = 0; in.istep = 0; in.n_per_row = cnt; in.n_fixed = 0;
+  SelOut so;
+  so.pairs = pairs; so.ppitch = ppitch; so.cnt = cnt; so.tau = tau; so.scores = nullptr; so.indices = nullptr;
+  hipLaunchKernelGGL(topk_select_kernel, dim3((int)rows), dim3(kSelThreads), kSelLdsWords * sizeof(uint32_t), st, in, k, so,
+                     kSelLdsWords);
+  return check_launch("select_topk_compact");
+}
+
 // top-k of ragged score rows: row r has n_per_row[r] valid entries at scores[r * pitch + c] (index = column).  Rows
 // shorter than k deliver all they have (the caller pre-fills the outputs).  For esr_ivf.hip.
 int select_topk_ragged(const float* scores, int64_t pitch, int64_t rows, const int32_t* n_per_row, int max_n, int k,

@@ -395,9 +395,12 @@ int esr_topk_merge(const float* scores, const int32_t* indices, int64_t nq, int 
  * answer and the yardstick for recall).  The index (esrecsys_amd/ivf.py builds it with the kernels above): candidates
  * grouped by coarse centroid -- cands_sorted [N, D] list after list, list_off int32 [nlist + 1], orig int32 [N] = the
  * row each one has in the caller's matrix, max_list = the longest list.  probe_lists int32 [nq, nprobe]: the lists each
- * query looks into (the nprobe best centroids: esr_retrieve_topk of the queries against the centroids).  Scores inside
- * the probed lists are exact f32 (grouped FP32 GEMM, one 64 x 64 tile per workgroup); out [nq, k], best first, entries a
- * query's lists could not fill: score -inf, index -1.  k <= 1024. */
+ * query looks into, best first (the nprobe best centroids: esr_retrieve_topk of the queries against the centroids).
+ * Scores inside the probed lists are exact f32 (grouped GEMM on the FP32 matrix cores, one 64 x 64 tile per workgroup)
+ * and the answer is the exact top-k of the probed lists: the first probe slots are scored densely and give every query
+ * a threshold (its k-th best so far), the others pass through a filtered epilogue in rounds of eight slots with a
+ * compacting select in between -- the scheme of esr_retrieve_topk.  out [nq, k], best first, entries a query's lists
+ * could not fill: score -inf, index -1.  k <= 1024. */
 size_t esr_ivf_search_workspace_bytes(int64_t nq, int nlist, int max_list, int nprobe, int k);
 int esr_ivf_search(const float* queries, int64_t nq, int D, const float* cands_sorted, const int32_t* list_off,
                    const int32_t* orig, int nlist, int max_list, const int32_t* probe_lists, int nprobe, int k,

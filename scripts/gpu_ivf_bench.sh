@@ -1,9 +1,9 @@
-mkdir -p gpurun_out/ivf
-python3 - <<'PY' 2>&1 | grep -v amdgpu.ids | tee gpurun_out/ivf/ivf_bench.jsonl | cut -c1-1500
-import json, torch, sys
+python -m pytest tests/test_gpu_ivf.py -x -q -s 2>&1 | tail -4
+python3 - <<'PY'
+import json, sys, torch
 sys.path.insert(0, '.')
 from bench_retrieve import measure_ivf
-dev = torch.device('cuda', 0)
-for corpus in ("clustered", "iid"):
-    print(json.dumps(measure_ivf(dev, corpus=corpus)), flush=True)
+r = measure_ivf(torch.device('cuda', 0), corpus="clustered")
+for leg in r["legs"]:
+    print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in leg.items()})
 PY

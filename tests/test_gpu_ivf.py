@@ -59,3 +59,33 @@ def test_ivf_few_probes_on_a_clustered_corpus(dev):
         recalls.append(recall_at_k(i, exact))
     print("IVF recall@10 at nprobe 1 / 8 / 32 of 256 lists:", ["%.3f" % r for r in recalls])
     assert recalls[0] <= recalls[1] + 1e-9 <= recalls[2] + 2e-9 and recalls[2] > 0.9
+
+
+@pytest.mark.parametrize("N,D,nlist,k,nprobe", [(30_000, 64, 64, 10, 5), (30_000, 64, 64, 500, 7), (60_000, 128, 32, 1000, 20),
+                                                (4_000, 32, 16, 300, 3)])
+def test_ivf_returns_the_exact_top_k_of_the_probed_lists(dev, N, D, nlist, k, nprobe):
+    """The search is exact INSIDE what it probes: head lists scored densely, the others through the tau filter in rounds
+    of eight probe slots with a compacting select in between -- the answer must be the k best candidates of the union
+    of the query's nprobe lists (k beyond one list's length, lists shorter than k, fewer candidates than k: -inf / -1)."""
+    from esrecsys_amd import ops
+    from esrecsys_amd.ivf import IVFIndex
+    rng = np.random.default_rng(N + k)
+    cands, _ = _clustered(rng, N, D, 150, 0.8)
+    q, _ = _clustered(rng, 200, D, 150, 0.8)
+    cd, qd = torch.from_numpy(cands).to(dev), torch.from_numpy(q).to(dev)
+    index = IVFIndex(cd, nlist, iters=3)
+    s, i = index.search(qd, k, nprobe)
+    gs, gi = s.cpu().numpy(), i.cpu().numpy().astype(np.int64)
+    _, lists = ops.retrieve_topk(qd, index.centroids, nprobe, mode="exact")
+    lists = lists.cpu().numpy()
+    off, orig = index.list_off.cpu().numpy(), index.orig.cpu().numpy()
+    full = q.astype(np.float64) @ cands.astype(np.float64).T
+    for r in range(len(q)):
+        rows = np.concatenate([orig[off[l]:off[l + 1]] for l in lists[r]])
+        best = rows[np.argsort(-full[r, rows], kind="stable")][:k]
+        n = len(best)
+        assert np.all(gi[r, n:] == -1) and np.all(np.isneginf(gs[r, n:]))
+        es = full[r, best]
+        assert np.abs(gs[r, :n] - es).max() <= 1e-5 * max(1.0, np.abs(es).max())
+        assert len(set(gi[r, :n])) == n and set(gi[r, :n]) <= set(rows.tolist())
+        assert np.mean(np.isin(gi[r, :n], best)) > 0.99   # (near-ties in f32 may swap the last entries)
