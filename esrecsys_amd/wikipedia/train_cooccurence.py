@@ -337,6 +337,7 @@ class _FusedEpoch:
         self.losses_ptr = self.losses.data_ptr()
         self.sort_ring = None
         self.steps_issued = 0
+        self.uses_gate = False  # a side-stream sort waits on the start word: every issued step must advance it
         self.ws, self.ws_B = None, -1
         self.sort_buf = [None, None]  # two sets: a group is sorted and planned while the one before it is stepped
         self.long_buf = [None, None]  # the same for lists too long for plans (_sort_batch_long)
@@ -468,6 +469,13 @@ class _FusedEpoch:
                                                   gr.perm_ptr, gr.plans_ptr, long_runs, self.losses_ptr + 4 * k,
                                                   self.ws.data_ptr(), self.ws.numel(), ops._stream()),
                    "esr_glove_train_steps")
+        self.steps_issued += gr.nb
+        if self.uses_gate:
+            # (an epoch that mixes lists beyond the grouped sort's limit with short ones: the group call announces no
+            # start, so the word is advanced behind it -- a gated sort never waits for its timeout)
+            start = self.start
+            start[1] = (start[1] + 1) & 0xFFFFFFFF
+            start[0].fill_(start[1] if start[1] < 2 ** 31 else start[1] - 2 ** 32)
 
     def sort_slot(self, n, j):
         """(sorted_ids, perm) buffers for the side-stream sort of the j-th batch drawn: a ring of _PRESORT_DEPTH + 3.
@@ -525,6 +533,7 @@ class _FusedEpoch:
         step of this epoch has been issued, else None (the first batches: the side stream waits for the main one)."""
         if self.steps_issued == 0:
             return None
+        self.uses_gate = True
         return (self.start[0], (self.start[1] + 1) & 0xFFFFFFFF)
 
 

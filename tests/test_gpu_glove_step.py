@@ -295,3 +295,29 @@ def test_train_epoch_long_lists_ragged_batch_and_early_end(dev, monkeypatch):
     with pytest.raises(StopIteration):
         tc.train_epoch(_make_state(V, D, "reference", dev), K + 3, iter(batches))
     torch.cuda.synchronize()
+
+
+def test_train_epoch_mixed_grouped_and_side_stream_batches(dev, monkeypatch):
+    """An epoch that mixes lists beyond the grouped sort's limit (side stream, gated on the start word) with short ones
+    (grouped, stepped by the group call that announces no start): bit-identical to the in-line loop, and no gate sits
+    out its one-second timeout."""
+    import time
+    import esrecsys_amd.wikipedia.train_cooccurence as tc
+    V, D = 3000, 64
+    rng = np.random.default_rng(123)
+    sizes = [3000, 300, 300, 3000, 300, 300, 300, 3000, 3000, 300, 300, 300, 300, 300, 300, 300, 300, 300, 3000, 300]
+    batches = [(_ids("zipf", V, (2, b), rng), rng.uniform(0.1, 300.0, b).astype(np.float32)) for b in sizes]
+    monkeypatch.setattr(tc, "_GROUP_SORT_MAX_IDS", 1024)
+    monkeypatch.setattr(tc, "_PRESORT_MIN_IDS", 1024)
+    tc.train_epoch(_make_state(V, D, "reference", dev), len(sizes), iter(batches))   # (warm: workspaces, events)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    a, la = tc.train_epoch(_make_state(V, D, "reference", dev), len(sizes), iter(batches))
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 0.9
+    monkeypatch.setattr(tc, "_SORT_BATCH", 1)
+    monkeypatch.setattr(tc, "_PRESORT", False)
+    b, lb = tc.train_epoch(_make_state(V, D, "reference", dev), len(sizes), iter(batches))
+    assert la == lb
+    assert torch.equal(a.params["_token_embedding"]["embedding"], b.params["_token_embedding"]["embedding"])
+    assert torch.equal(a.params["_bias"]["embedding"], b.params["_bias"]["embedding"])
