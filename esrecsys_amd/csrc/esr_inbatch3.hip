@@ -879,12 +879,14 @@ __global__ __launch_bounds__(256) void inbatch3_rowmax_kernel(const __bf16* __re
           sa = ESR_MFMA_BF16(a1, bx0[s], sa);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) m = fmaxf(m, sa[r]);
+        // (a negative temperature turns the maximum of s sl2 into the minimum of s: with max(s) sl2 as the reference a
+        // row with one far-out candidate overflowed exp2 -- inf / nan in that row's lse and gradients)
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, sl2 < 0.f ? -sa[r] : sa[r]);
       }
     }
   }
   m = fmaxf(m, __shfl_xor(m, 32, 64));
-  if (h == 0) part_m[(int64_t)split * B + xrow] = m * sl2;
+  if (h == 0) part_m[(int64_t)split * B + xrow] = m * fabsf(sl2);
 }
 
 struct Inbatch3Ws {

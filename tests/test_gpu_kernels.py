@@ -538,6 +538,27 @@ def test_inbatch_bf16x3_shapes_and_hard_inputs(dev, B):
         assert max(errs[precision]) <= TOL, (precision, errs)
 
 
+@pytest.mark.parametrize("B,D", [(640, 100), (1024, 128), (256, 64)])
+@pytest.mark.parametrize("scale", [-12.0, 12.0])
+def test_inbatch_negative_temperature_with_a_far_out_candidate(dev, B, D, scale):
+    """A negative temperature makes the row maximum of the scores the MINIMUM of the dot products; with one candidate
+    far out on that side (score ~ +150 log2 units) an exponent reference taken from the wrong end overflows exp2 (found
+    by scripts/inbatch_stress.py: the bf16 x 3 row-max pre-pass took max(dot) * scale -- inf / nan in that row).  Every
+    precision, and bf16 tables (which always run the bf16 x 3 kernels), must hold the bound."""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(B + D)
+    q = (rng.standard_normal((B, D)) * 2.97 / np.sqrt(D)).astype(np.float32)
+    c = (rng.standard_normal((B, D)) * 0.99 / np.sqrt(D)).astype(np.float32)
+    c[B - 5] = (3.0 * 0.99) * q[7] / np.linalg.norm(q[7]) * (1 if scale > 0 else -1)
+    el, else_, egq, egc = o_stl.inbatch_softmax_loss_and_grads(q.astype(F64), c.astype(F64), 0.1, 77.0, scale, F64)
+    for precision in ("f32", "bf16x3", "f16x2"):
+        if precision != "f32" and ops.inbatch_split_path(precision, B, D, bf16_tables=False) is None:
+            continue
+        loss, lse, gq, gc = ops.inbatch_softmax_fwd_bwd(T(q, dev), T(c, dev), scale, 0.1, 77.0, precision=precision)
+        errs = (abs(float(loss) - el) / abs(el), rel_err(N(lse), else_), rel_err(N(gq), egq), rel_err(N(gc), egc))
+        assert np.all(np.isfinite(errs)) and max(errs) <= TOL, (precision, errs)
+
+
 @pytest.mark.parametrize("mag_q,mag_c,scale", [(1e-4, 1e-4, 5e6), (3e-3, 40.0, 4.0), (200.0, 150.0, 2e-4),
                                                (0.09, 0.09, 8.0), (0.09, 0.09, 40.0), (0.3, 0.3, 30.0)])
 def test_inbatch_f16x2_operand_and_score_ranges(dev, mag_q, mag_c, scale):
