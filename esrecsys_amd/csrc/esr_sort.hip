@@ -1227,7 +1227,8 @@ size_t esr_segment_sort_batched_workspace_bytes(int64_t n, int nbatch) {
   if (n <= 0 || nbatch <= 0) return 256;
   const size_t one = esr_segment_sort_workspace_bytes(n);  // the fallback sorts list after list in this much
   const size_t mid = n <= kMidSortMax ? align_up((size_t)nbatch * kMidWsWords * 4, 256) : 0;
-  const size_t radix = n > kMidSortMax && n <= kRadixLongN ? (size_t)nbatch * radix_ws_layout(n, nullptr, nullptr) : 0;
+  // (any n: lists of wide ids -- V beyond 2^21 -- take the batched radix passes even when they are short)
+  const size_t radix = n <= kRadixLongN ? (size_t)nbatch * radix_ws_layout(n, nullptr, nullptr) : 0;
   return std::max({one, mid, radix});
 }
 

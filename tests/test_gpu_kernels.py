@@ -1205,3 +1205,23 @@ def test_score_topk_beyond_1024_is_stable_on_ties(dev):
     order = np.argsort(-full, axis=1, kind="stable")[:, :k]
     assert np.array_equal(N(i), order.astype(np.int32))
     assert np.array_equal(N(s), np.take_along_axis(full, order, axis=1))
+
+
+@pytest.mark.parametrize("n_seg,nb", [((16384,), 6), ((3000, 3000, 3000), 8), ((100,), 3), ((40000, 40000), 4), ((2048,), 2)])
+def test_segment_sort_batched_wide_ids(dev, n_seg, nb):
+    """Virtual rows beyond 2^21 (two towers of 3 M rows each; config 4's 100 M rows): the 32-bit (id << 11 | position)
+    composites of the tile sorts do not fit, every batched list goes through the radix passes whatever its length --
+    found by scripts/fuzz_ops.py: the workspace query sized those passes only for lists beyond 32 768 ids and the sort
+    wrote past its workspace."""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(sum(n_seg) + nb)
+    V = 3_000_000
+    offsets = [0, V, V][:len(n_seg)]
+    lists = [[torch.from_numpy(np.where(rng.random(n) < 0.2, rng.integers(0, 5, n), rng.integers(0, V, n)).astype(np.int32)).to(dev)
+              for n in n_seg] for _ in range(nb)]
+    srt, prm = ops.segment_sort_batched(lists, offsets, 2 * V)
+    for b, segs in enumerate(lists):
+        virt = np.concatenate([N(t).astype(np.int64) + o for t, o in zip(segs, offsets)])
+        order = np.argsort(virt, kind="stable")
+        assert np.array_equal(N(prm[b]), order.astype(np.int32))
+        assert np.array_equal(N(srt[b]), virt[order].astype(np.int32))
