@@ -272,6 +272,7 @@ class _FusedTripletLoop:
         self.hints_event = [torch.cuda.Event(), torch.cuda.Event()]
         self.drawn_event = [torch.cuda.Event(), torch.cuda.Event()]
         self.hints_known = [None, None]  # per set: list of long_runs values once the event has been seen complete
+        self.group_ws, self.group_ws_B = None, -1  # esr_triplet_train_steps' workspace, sized for the group it steps
         self.gen = 0
         self.fixed_s = (self.st.data_ptr(), self.rs.shadow.data_ptr(), self.rs.loc.data_ptr(), self.acc_s.data_ptr(),
                         self.Vs)
@@ -381,11 +382,16 @@ class _FusedTripletLoop:
             long_runs = self.long_arr
             for j in range(gr.nb):
                 long_runs[j] = 1 if known[j] == gr.gen else 0
+        # (the group's OWN batch size: the next group -- sorted before this one is stepped -- may have resized self.ws)
+        if gr.B != self.group_ws_B:
+            self.group_ws = ops._ws(ops._ws_bytes("esr_triplet_step_workspace_bytes", gr.B, self.D), self.dev)
+            self.group_ws_B = gr.B
         self.check(self.lib.esr_triplet_train_steps(*self.fixed_s, *self.fixed_p, self.D, gr.nb, gr.ptrs, gr.B,
                                                     regularization, batch_size, self.lr, self.eps,
                                                     self.next_stamp(self.rs, self.rp, count=gr.nb), gr.sorted_ptr,
                                                     gr.perm_ptr, gr.plans_ptr, long_runs, self.losses_ptr + 4 * k,
-                                                    self.ws_ptr, self.ws_n, self.main_raw), "esr_triplet_train_steps")
+                                                    self.group_ws.data_ptr(), self.group_ws.numel(), self.main_raw),
+                   "esr_triplet_train_steps")
 
     def step(self, k, handle, regularization, batch_size):
         slot_index, sid, pid, nid = handle

@@ -140,3 +140,23 @@ def test_train_steps_inbatch_long_run_hint_and_early_end(dev, hot):
     with pytest.raises(StopIteration):
         train_steps(_state(dev, Vs, Vp, D, 4), iter(batches[:10]), 15, 0.1, float(B), scale=6.0)
     torch.cuda.synchronize()
+
+
+def test_train_steps_group_after_a_group_of_larger_batches(dev):
+    """Groups are sorted one ahead of the group being stepped: a group of SMALLER batches sorted while a group of larger
+    ones waits must not leave that group the smaller workspace (found by scripts/fuzz_loops.py: esr_triplet_train_steps
+    refused it)."""
+    from esrecsys_amd.pinterest.train_shop_the_look import train_step, train_steps
+    Vs, Vp, D = 3000, 5000, 64
+    rng = np.random.default_rng(41)
+    sizes = [512] * 16 + [129] * 9 + [1024] * 9
+    batches = [tuple(torch.from_numpy(rng.integers(0, V, b).astype(np.int32)).to(dev) for V in (Vs, Vp, Vp)) for b in sizes]
+    a, b = _state(dev, Vs, Vp, D, 3), _state(dev, Vs, Vp, D, 3)
+    a, losses = train_steps(a, iter(batches), len(sizes), 0.1, 512.0)
+    ref = []
+    for scene, pos, neg in batches:
+        b, l = train_step(b, scene, pos, neg, 0.1, 512.0)
+        ref.append(l)
+    assert torch.equal(losses, torch.stack(ref))
+    for tower in ("scene_tower", "product_tower"):
+        assert torch.equal(a.params["params"][tower]["embedding"], b.params["params"][tower]["embedding"])
