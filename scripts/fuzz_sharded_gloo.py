@@ -63,7 +63,77 @@ def worker(rank, port, outdir, cfg):
     dist.destroy_process_group()
 
 
+def glove_worker(rank, port, outdir, cfg):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ESR_SHARDED_UNIQUE="1" if cfg["unique"] else "0")
+    W, V, D, B = cfg["world"], cfg["Vs"], cfg["D"], cfg["B"]
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    import _cpu_kernels as K
+    from esrecsys_amd import sharded
+    rng = np.random.default_rng(cfg["seed"])
+    emb0, bias0 = rng.standard_normal((V, D)) * 0.3, rng.standard_normal((V, 1)) * 0.05
+    mk = lambda full: torch.from_numpy(np.ascontiguousarray(full[rank::W]))  # noqa: E731
+    emb_t = sharded.RowShardedTable(mk(emb0), torch.full_like(mk(emb0), 0.1), V)
+    bias_t = sharded.RowShardedTable(mk(bias0), torch.full_like(mk(bias0), 0.1), V)
+    emb = sharded.ShardedTableGroup([emb_t], kernels=K)
+    bias = sharded.ShardedTableGroup([bias_t], kernels=K)
+    batches = glove_batches(cfg, rank)
+    cur = sharded.begin_plan_glove(emb, torch.from_numpy(batches[0][0])).finish()
+    pend = sharded.begin_plan_glove(emb, torch.from_numpy(batches[1][0])) if len(batches) > 1 else None
+    for i, (inp, tgt) in enumerate(batches):
+        sharded.sharded_glove_step(emb, bias, torch.from_numpy(inp), torch.from_numpy(tgt), K.GLOVE_DIAGONAL, LR,
+                                   plan=cur if cfg["grouped"] else None)
+        nxt = sharded.begin_plan_glove(emb, torch.from_numpy(batches[i + 2][0])) if i + 2 < len(batches) else None
+        cur = pend.finish() if pend is not None else None
+        pend = nxt
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), emb=emb_t.local.numpy(), bias=bias_t.local.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def glove_batches(cfg, rank):
+    g = np.random.default_rng(cfg["seed"] * 31 + rank)
+    V, B = cfg["Vs"], cfg["B"]
+    def draw():
+        if not cfg["zipf"]:
+            return g.integers(0, V, (2, B)).astype(np.int32)
+        w = 1.0 / np.arange(1, V + 1)
+        return g.choice(V, size=(2, B), p=w / w.sum()).astype(np.int32)
+    return [(draw(), g.uniform(0.1, 300, B)) for _ in range(cfg["steps"])]
+
+
+def run_glove(cfg):
+    from oracle import glove as o_glove
+    from oracle import optim as o_optim
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    W, V, D = cfg["world"], cfg["Vs"], cfg["D"]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(glove_worker, args=(port, d, cfg), nprocs=W, join=True)
+        outs = [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(W)]
+    rng = np.random.default_rng(cfg["seed"])
+    emb, bias = rng.standard_normal((V, D)) * 0.3, rng.standard_normal((V, 1)) * 0.05
+    a_e, a_b = np.full_like(emb, 0.1), np.full_like(bias, 0.1)
+    per_rank = [glove_batches(cfg, r) for r in range(W)]
+    for step in range(cfg["steps"]):
+        ids_all, rows_all, gb_all = [], [], []
+        for r in range(W):
+            inp, tgt = per_rank[r][step]
+            _, gdot, gs = o_glove.loss_and_grads(emb, bias, inp, tgt, "diagonal", np.float64)
+            ids, rows, gb = o_glove.row_grads(emb, inp, gdot, gs, np.float64)
+            ids_all.append(ids), rows_all.append(rows), gb_all.append(gb)
+        ids_c = np.concatenate(ids_all)
+        emb, a_e = o_optim.sparse_adagrad_update(emb, a_e, ids_c, np.concatenate(rows_all), LR, dtype=np.float64)
+        bias, a_b = o_optim.sparse_adagrad_update(bias, a_b, ids_c, np.concatenate(gb_all)[:, None], LR, dtype=np.float64)
+    full_e, full_b = np.zeros((V, D)), np.zeros((V, 1))
+    for r in range(W):
+        full_e[r::W], full_b[r::W] = outs[r]["emb"], outs[r]["bias"]
+    return np.abs(full_e - emb).max() <= 1e-11 and np.abs(full_b - bias).max() <= 1e-11
+
+
 def run_case(cfg):
+    if cfg["workload"] == "glove":
+        return run_glove(cfg)
     from oracle import optim as o_optim
     from oracle import stl_head as o_stl
     with socket.socket() as s:
@@ -110,7 +180,7 @@ if __name__ == "__main__":
         cfg = dict(world=int(rng.integers(2, 5)), Vs=int(rng.choice([5, 37, 101, 1000])), Vp=int(rng.choice([9, 64, 203, 3001])),
                    D=int(rng.choice([4, 8, 16])), B=int(rng.choice([1, 7, 24, 130])), steps=int(rng.integers(1, 4)),
                    zipf=bool(rng.random() < 0.5), unique=bool(rng.random() < 0.6), grouped=bool(rng.random() < 0.5),
-                   workload=str(rng.choice(["triplet", "inbatch"])), seed=int(rng.integers(1, 10000)))
+                   workload=str(rng.choice(["triplet", "inbatch", "glove"])), seed=int(rng.integers(1, 10000)))
         ok = run_case(cfg)
         if os.environ.get("VERBOSE") == "1" or not ok:
             print("ok  " if ok else "MISMATCH", cfg, flush=True)
