@@ -36,6 +36,8 @@ SIGNATURES = {
     "esr_version": (c_int, []),
     "esr_device_info": (c_int, [ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_size),
                                 ctypes.c_char_p, c_int]),
+    "esr_kernel_timing": (c_int, [c_int]),
+    "esr_kernel_timing_read": (ctypes.c_long, [ctypes.c_char_p, c_size]),
     "esr_gather_rows": (c_int, [c_vp, c_int, c_i64, c_int, c_i32p, c_i64, c_vp, c_vp]),
     "esr_check_ids": (c_int, [c_i32p, c_i64, c_i64, c_vp, c_vp]),
     "esr_unpermute_rows": (c_int, [c_vp, c_int, c_int, c_i32p, c_i64, c_vp, c_vp]),

@@ -41,6 +41,18 @@ int select_topk_compact(int2* pairs, int64_t ppitch, int32_t* cnt, int64_t rows,
 
 inline hipStream_t as_stream(esr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Per-kernel launch timing (esr_kernel_timing / esr_kernel_timing_read, esr_core.hip): OFF by default and then one
+// relaxed load per launch site.  When on, a HIP event pair is recorded around the launch on the launch's own stream.
+extern int g_ktimer_on;
+void ktimer_begin(const char* name, hipStream_t st);
+void ktimer_end(hipStream_t st);
+#define ESR_KT(NAME, ST, ...)                                  \
+  do {                                                         \
+    if (esr::g_ktimer_on) esr::ktimer_begin((NAME), (ST));     \
+    __VA_ARGS__;                                               \
+    if (esr::g_ktimer_on) esr::ktimer_end((ST));               \
+  } while (0)
+
 #define ESR_REQUIRE(cond, ...)        \
   do {                                \
     if (!(cond)) {                    \

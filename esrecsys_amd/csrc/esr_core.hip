@@ -1,6 +1,9 @@
 // Error plumbing, device query and the row gather / un-permute kernels.
 #include "esr_common.h"
 #include <string.h>
+#include <mutex>
+#include <string>
+#include <vector>
 
 namespace esr {
 
@@ -20,6 +23,60 @@ int check_launch(const char* what) {
     return ESR_ELAUNCH;
   }
   return ESR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-kernel launch timing: a measurement facility for bench.py's `roofline.achieved` (HIP events on the stream the
+// kernel is launched on).  Records are (static name, start event, stop event); esr_kernel_timing_read waits for them.
+// ---------------------------------------------------------------------------------------------
+int g_ktimer_on = 0;
+namespace {
+struct KtRecord {
+  const char* name;
+  hipEvent_t e0, e1;
+};
+std::mutex g_kt_mu;
+std::vector<KtRecord> g_kt_records;
+std::vector<hipEvent_t> g_kt_pool;  // events are reused across enable / read cycles
+thread_local hipEvent_t g_kt_open_e0 = nullptr;
+thread_local const char* g_kt_open_name = nullptr;
+hipEvent_t kt_event() {
+  if (!g_kt_pool.empty()) {
+    hipEvent_t e = g_kt_pool.back();
+    g_kt_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+}  // namespace
+
+void ktimer_begin(const char* name, hipStream_t st) {
+  std::lock_guard<std::mutex> lock(g_kt_mu);
+  if (g_kt_records.size() >= (size_t)1 << 20) return;  // bounded: a forgotten switch must not eat the host
+  hipEvent_t e0 = kt_event();
+  if (!e0) return;
+  if (hipEventRecord(e0, st) != hipSuccess) {
+    g_kt_pool.push_back(e0);
+    return;
+  }
+  g_kt_open_e0 = e0;
+  g_kt_open_name = name;
+}
+
+void ktimer_end(hipStream_t st) {
+  if (!g_kt_open_e0) return;
+  std::lock_guard<std::mutex> lock(g_kt_mu);
+  hipEvent_t e1 = kt_event();
+  if (e1 && hipEventRecord(e1, st) == hipSuccess) {
+    g_kt_records.push_back(KtRecord{g_kt_open_name, g_kt_open_e0, e1});
+  } else {
+    g_kt_pool.push_back(g_kt_open_e0);
+    if (e1) g_kt_pool.push_back(e1);
+  }
+  g_kt_open_e0 = nullptr;
+  g_kt_open_name = nullptr;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -181,7 +238,65 @@ int esr_check_ids(const int32_t* ids, int64_t n, int64_t V, int64_t* report, esr
 
 const char* esr_last_error(void) { return g_err; }
 
-int esr_version(void) { return 100; }
+int esr_version(void) { return 101; }
+
+int esr_kernel_timing(int enable) {
+  std::lock_guard<std::mutex> lock(g_kt_mu);
+  for (const KtRecord& r : g_kt_records) {  // drop what nobody read
+    g_kt_pool.push_back(r.e0);
+    g_kt_pool.push_back(r.e1);
+  }
+  g_kt_records.clear();
+  g_ktimer_on = enable ? 1 : 0;
+  return ESR_OK;
+}
+
+long esr_kernel_timing_read(char* buf, size_t cap) {
+  std::vector<KtRecord> recs;
+  {
+    std::lock_guard<std::mutex> lock(g_kt_mu);
+    recs.swap(g_kt_records);
+  }
+  struct Agg {
+    const char* name;
+    long calls;
+    double total, mn, mx;
+  };
+  std::vector<Agg> agg;
+  for (const KtRecord& r : recs) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) ms = -1.f;
+    if (ms >= 0.f) {
+      size_t i = 0;
+      for (; i < agg.size(); ++i)
+        if (agg[i].name == r.name || strcmp(agg[i].name, r.name) == 0) break;
+      if (i == agg.size()) agg.push_back(Agg{r.name, 0, 0.0, 1e30, 0.0});
+      agg[i].calls += 1;
+      agg[i].total += ms;
+      agg[i].mn = std::min(agg[i].mn, (double)ms);
+      agg[i].mx = std::max(agg[i].mx, (double)ms);
+    }
+  }
+  {
+    std::lock_guard<std::mutex> lock(g_kt_mu);
+    for (const KtRecord& r : recs) {
+      g_kt_pool.push_back(r.e0);
+      g_kt_pool.push_back(r.e1);
+    }
+  }
+  std::string out;
+  char line[256];
+  for (const Agg& a : agg) {
+    snprintf(line, sizeof(line), "%s\t%ld\t%.6f\t%.6f\t%.6f\n", a.name, a.calls, a.total, a.mn, a.mx);
+    out += line;
+  }
+  if (buf && cap > 0) {
+    const size_t n = std::min(cap - 1, out.size());
+    memcpy(buf, out.data(), n);
+    buf[n] = 0;
+  }
+  return (long)out.size() + 1;
+}
 
 int esr_device_info(int* cu_count, int* wave_size, size_t* hbm_bytes, char* arch, int arch_len) {
   int dev = 0;

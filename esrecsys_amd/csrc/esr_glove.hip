@@ -1224,9 +1224,9 @@ static void launch_glove_step(const GloveTables& t, const int32_t* inputs, const
     // ahead is not used here (its records carry no locations).
     const int nstat = (int)std::min<int64_t>(kStatBlocks, cdiv(B, kBlock));
     const int nres = (int)std::max<int64_t>(nstat, std::min<int64_t>(kMaxGrid, cdiv(n, kBlock)));
-    hipLaunchKernelGGL(glove_resolve_kernel, dim3(nres), dim3(kBlock), 0, st, sorted_ids, perm, inputs, target,
+    ESR_KT("glove_resolve_kernel", st, hipLaunchKernelGGL(glove_resolve_kernel, dim3(nres), dim3(kBlock), 0, st, sorted_ids, perm, inputs, target,
                        (const float*)t.bias, (const uint8_t*)t.emb_loc, B, nstat, ws.own_code, ws.meta_res, ws.stat_part,
-                       ws.res_flags);
+                       ws.res_flags));
     // start_flag: the update kernel's first workgroup stores start_value there as it starts.  A second stream gated on
     // the word (esr_stream_gate) is released as the update kernel runs, so what it brings (the id sort of a coming
     // batch) arrives after that kernel has taken its wave slots.  Arriving first, the sort's workgroups kept part of
@@ -1238,22 +1238,22 @@ static void launch_glove_step(const GloveTables& t, const int32_t* inputs, const
                                ? resident_blocks((const void*)glove_step_resolved_kernel<VEC, NCH>, blocks_per_cu)
                                : resident_all;
       grid = std::min(grid, resident);
-      hipLaunchKernelGGL((glove_step_resolved_kernel<VEC, NCH>), dim3(grid), dim3(kBlock), 0, st, t.emb, t.emb_shadow,
+      ESR_KT("glove_step_resolved_kernel", st, hipLaunchKernelGGL((glove_step_resolved_kernel<VEC, NCH>), dim3(grid), dim3(kBlock), 0, st, t.emb, t.emb_shadow,
                          t.emb_loc, t.emb_accum, D, g.G, (const uint32_t*)ws.own_code, (const float4*)ws.meta_res, n, B,
                          mode, nstat, (const double*)ws.stat_part, lr, eps, ws.chunk_rows, ws.bias_info, ws.pair_part,
-                         ws.res_flags, start_flag, start_value);
+                         ws.res_flags, start_flag, start_value));
       // (its last workgroup also reduces the loss partials for the finalize kernel; when the caller knows that no run
       // outgrows its head chunk -- long_runs == 0 -- it is skipped and every finalize workgroup reduces them itself,
       // the same sums in the same order)
       if (long_runs != 0)
-        hipLaunchKernelGGL((glove_step_long_kernel<VEC, NCH>), dim3(grid2), dim3(kBlock), 0, st, t.emb, t.emb_shadow,
+        ESR_KT("glove_step_long_kernel", st, hipLaunchKernelGGL((glove_step_long_kernel<VEC, NCH>), dim3(grid2), dim3(kBlock), 0, st, t.emb, t.emb_shadow,
                            t.emb_loc, t.emb_accum, D, g.G, sorted_ids, n, stamp, lr, eps, (const float*)ws.chunk_rows,
-                           ws.bias_info, (const int*)ws.res_flags, grid, (const double*)ws.pair_part, ws.pair_tot);
+                           ws.bias_info, (const int*)ws.res_flags, grid, (const double*)ws.pair_part, ws.pair_tot));
     });
-    hipLaunchKernelGGL(glove_step_finalize_kernel, dim3(nfin), dim3(kBlock), 0, st, B, mode,
+    ESR_KT("glove_step_finalize_kernel", st, hipLaunchKernelGGL(glove_step_finalize_kernel, dim3(nfin), dim3(kBlock), 0, st, B, mode,
                        (const unsigned long long*)nullptr, nstat, (const double*)ws.stat_part, grid,
                        (const double*)ws.pair_part, long_runs != 0 ? (const double*)ws.pair_tot : (const double*)nullptr,
-                       sorted_ids, (const double2*)ws.bias_info, t.bias, t.bias_accum, lr, eps, loss);
+                       sorted_ids, (const double2*)ws.bias_info, t.bias, t.bias_accum, lr, eps, loss));
     return;
   }
   if (!plan) {  // no plan made ahead: make it here (and nobody told us whether a run is long: screen for it)
@@ -1272,19 +1272,19 @@ static void launch_glove_step(const GloveTables& t, const int32_t* inputs, const
     const int resident = blocks_per_cu > 0 ? resident_blocks((const void*)glove_step_kernel<VEC, NCH>, blocks_per_cu)
                                            : resident_all;
     grid = std::max(nstat, std::min(grid, resident));
-    hipLaunchKernelGGL((glove_step_kernel<VEC, NCH>), dim3(grid), dim3(kBlock), 0, st, t.emb, t.emb_shadow, t.emb_loc,
+    ESR_KT("glove_step_kernel", st, hipLaunchKernelGGL((glove_step_kernel<VEC, NCH>), dim3(grid), dim3(kBlock), 0, st, t.emb, t.emb_shadow, t.emb_loc,
                        t.emb_accum, (const float*)t.bias, D, g.G, sorted_ids, (const float4*)pl.meta, inputs, n, B, mode,
                        stamp, nstat, pl.stat, lr, eps, ws.chunk_rows, ws.bias_info, ws.pair_part, pl.flags, start_flag,
-                       start_value);
+                       start_value));
     if (long_runs != 0)  // 0 = the caller knows (esr_glove_plan's hint) that no run outgrows its head chunk
-      hipLaunchKernelGGL((glove_step_long_kernel<VEC, NCH>), dim3(grid2), dim3(kBlock), 0, st, t.emb, t.emb_shadow,
+      ESR_KT("glove_step_long_kernel", st, hipLaunchKernelGGL((glove_step_long_kernel<VEC, NCH>), dim3(grid2), dim3(kBlock), 0, st, t.emb, t.emb_shadow,
                          t.emb_loc, t.emb_accum, D, g.G, sorted_ids, n, stamp, lr, eps, (const float*)ws.chunk_rows,
-                         ws.bias_info, (const int*)pl.flags, 0, (const double*)nullptr, (double*)nullptr);
+                         ws.bias_info, (const int*)pl.flags, 0, (const double*)nullptr, (double*)nullptr));
   });
-  hipLaunchKernelGGL(glove_step_finalize_kernel, dim3(nfin), dim3(kBlock), 0, st, B, mode,
+  ESR_KT("glove_step_finalize_kernel", st, hipLaunchKernelGGL(glove_step_finalize_kernel, dim3(nfin), dim3(kBlock), 0, st, B, mode,
                      (const unsigned long long*)pl.stat, 0, (const double*)nullptr, grid, (const double*)ws.pair_part,
                      (const double*)nullptr, sorted_ids, (const double2*)ws.bias_info, t.bias, t.bias_accum, lr, eps,
-                     loss);
+                     loss));
 }
 
 #define ESR_GLOVE_STEP_CHECKS(who)                                                                                    \

@@ -25,6 +25,9 @@
 // Pass C always reads the probabilities pass Q stored (inbatch2h_pc8_kernel): B <= 16384; larger batches and bf16
 // tables take the bf16 x 3 path (bf16 tables are one-plane there already).
 #include "esr_inbatch_mfma.h"
+#include <atomic>
+#include <type_traits>
+#include <time.h>
 
 namespace esr {
 
@@ -270,6 +273,156 @@ __global__ __launch_bounds__(256) void split2h_kernel(RowSrc X0, RowSrc X1, int6
     f16x8* dst = reinterpret_cast<f16x8*>(R + ((int64_t)pl * B + grow) * k3D + d0);
     dst[0] = p[pl][0];
     dst[1] = p[pl][1];
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// prep + split in ONE launch (round 4; the two launches above read the same 8 MB twice, 6.6 + 8.0 us at B = 8192).  One
+// block per 32-row chunk holds its Q rows AND its C rows in registers; the only thing a block needs from the others is
+// the binade of the largest |element| of each matrix (scale_exp uses nothing else), and it gets it without a
+// zero-initialised word, a fence or a second launch: every block PUBLISHES one 64-bit word
+//     (token << 16) | code(max |q| of the chunk) << 8 | code(max |c| of the chunk)
+// with an agent-scope (write-through) store, where `token` is 48 bits the host draws per call -- a word left by an
+// earlier call, or whatever a fresh workspace holds, carries this call's token with probability 2^-48 -- and then every
+// thread polls the word of one chunk with agent-scope loads.  One word, so there is no ordering between two stores to
+// rely on.  All blocks of the grid are resident (B / 32 <= 512 blocks of 256 threads on 256 CUs), so the poll ends when
+// the slowest block has published; it is BOUNDED anyway (kPollTicks of the 100 MHz clock): on a timeout the loss is
+// poisoned (NaN) rather than the queue hung.  code: 0 = all zero (or NaN: fmaxf drops it, as in split2h_kernel; a NaN
+// element shows up in the planes themselves), 255 = infinite, else the frexp exponent + 127.
+// The grid also zeroes the words the merge launches count in.
+// -----------------------------------------------------------------------------------------------------------------
+constexpr unsigned long long kPollTicks = 300000000ull;  // 3 s
+__device__ __forceinline__ unsigned amax_code(float amax) {
+  if (!(amax > 0.f)) return 0u;
+  if (!(amax < INFINITY)) return 255u;
+  int x;
+  frexpf(amax, &x);
+  return (unsigned)min(max(x + 127, 1), 254);
+}
+__device__ __forceinline__ int scale_exp_code(unsigned code) {  // scale_exp of any value with that code
+  if (code == 0u || code == 255u) return 0;
+  const int e = 14 - ((int)code - 127);
+  return e < -100 ? -100 : (e > 100 ? 100 : e);
+}
+
+__global__ __launch_bounds__(256) void prepsplit2h_kernel(RowSrc X0, RowSrc X1, int64_t B, _Float16* __restrict__ R0,
+                                                         _Float16* __restrict__ R1,
+                                                         unsigned long long* __restrict__ ent,
+                                                         unsigned long long token, float* __restrict__ diag,
+                                                         float* __restrict__ nrm, float* __restrict__ sc,
+                                                         unsigned long long* __restrict__ loss_acc,
+                                                         int* __restrict__ flags, int nflags) {
+  __shared__ float red[8];
+  __shared__ unsigned cred[8];
+  const int t = threadIdx.x, chunk = blockIdx.x, nchunks = gridDim.x;
+  if (chunk == 0 && t <= kLossWords) {  // see inbatch3_merge_kernel
+    loss_acc[t * 16] = 0ull;
+    if (t == 0) loss_acc[8] = 0ull;  // poison word
+  }
+  if (chunk == 1 || nchunks == 1)
+    for (int i = t; i < nflags; i += 256) flags[i] = 0;
+  const int row = t >> 3, d0 = (t & 7) * 16;
+  const int64_t grow = (int64_t)chunk * 32 + row;
+  float vq[16], vc[16];
+  {
+    // (rowsrc_load4 per quad re-reads the row's id and branches on the source kind every time: eight dependent
+    // id -> row round trips in a row; here the two ids are read once and the eight row loads are issued together)
+    const int64_t rq = X0.idx ? (int64_t)X0.idx[grow] : grow;
+    const int64_t rc = X1.idx ? (int64_t)X1.idx[grow] : grow;
+    RowSrc Y0 = X0, Y1 = X1;
+    Y0.idx = nullptr; Y1.idx = nullptr;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 f = rowsrc_load4(Y0, rq, d0 + 4 * q);
+      const float4 g = rowsrc_load4(Y1, rc, d0 + 4 * q);
+      vq[4 * q] = f.x; vq[4 * q + 1] = f.y; vq[4 * q + 2] = f.z; vq[4 * q + 3] = f.w;
+      vc[4 * q] = g.x; vc[4 * q + 1] = g.y; vc[4 * q + 2] = g.z; vc[4 * q + 3] = g.w;
+    }
+  }
+  float mq = 0.f, mc = 0.f, dot = 0.f, ssq = 0.f, ssc = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    mq = fmaxf(mq, fabsf(vq[e]));
+    mc = fmaxf(mc, fabsf(vc[e]));
+    dot = fmaf(vq[e], vc[e], dot);
+    ssq = fmaf(vq[e], vq[e], ssq);
+    ssc = fmaf(vc[e], vc[e], ssc);
+  }
+  dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 4, 64);
+  ssq += __shfl_xor(ssq, 1, 64); ssq += __shfl_xor(ssq, 2, 64); ssq += __shfl_xor(ssq, 4, 64);
+  ssc += __shfl_xor(ssc, 1, 64); ssc += __shfl_xor(ssc, 2, 64); ssc += __shfl_xor(ssc, 4, 64);
+  if ((t & 7) == 0) diag[grow] = dot;
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) {
+    ssq = fmaxf(ssq, __shfl_xor(ssq, o, 64));
+    ssc = fmaxf(ssc, __shfl_xor(ssc, o, 64));
+  }
+  if ((t & 63) == 0) {  // largest squared row norm per wave, as split2h_kernel leaves it (the row-max pass reads it)
+    nrm[((int64_t)0 * nchunks + chunk) * 4 + (t >> 6)] = ssq;
+    nrm[((int64_t)1 * nchunks + chunk) * 4 + (t >> 6)] = ssc;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mq = fmaxf(mq, __shfl_xor(mq, o, 64));
+    mc = fmaxf(mc, __shfl_xor(mc, o, 64));
+  }
+  if ((t & 63) == 0) { red[t >> 6] = mq; red[4 + (t >> 6)] = mc; }
+  __syncthreads();
+  if (t == 0) {
+    mq = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    mc = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    __hip_atomic_store(&ent[chunk], (token << 16) | (unsigned long long)(amax_code(mq) << 8 | amax_code(mc)),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  unsigned cq = 0u, cc = 0u;
+  bool timed_out = false;
+  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+  for (int i = t; i < nchunks; i += 256) {
+    unsigned long long v;
+    while (((v = __hip_atomic_load(&ent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 16) != token) {
+      if (__builtin_amdgcn_s_memrealtime() - t_start > kPollTicks) { timed_out = true; break; }
+      __builtin_amdgcn_s_sleep(4);
+    }
+    cq = max(cq, (unsigned)(v >> 8) & 255u);
+    cc = max(cc, (unsigned)v & 255u);
+  }
+  if (timed_out) atomicOr(reinterpret_cast<unsigned*>(loss_acc + 8), 1u);  // poison: the loss comes out NaN
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    cq = max(cq, (unsigned)__shfl_xor((int)cq, o, 64));
+    cc = max(cc, (unsigned)__shfl_xor((int)cc, o, 64));
+  }
+  if ((t & 63) == 0) { cred[t >> 6] = cq; cred[4 + (t >> 6)] = cc; }
+  __syncthreads();
+  cq = max(max(cred[0], cred[1]), max(cred[2], cred[3]));
+  cc = max(max(cred[4], cred[5]), max(cred[6], cred[7]));
+  const int eq = scale_exp_code(cq), ec = scale_exp_code(cc);
+  if (chunk == 0 && t == 0) {
+    sc[0] = ldexpf(1.f, -(eq + ec));
+    sc[1] = ldexpf(1.f, -ec);
+    sc[2] = ldexpf(1.f, -(eq + (int)kHPexp));
+    sc[3] = ldexpf(1.f, eq);
+    sc[4] = ldexpf(1.f, ec);
+  }
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const float mul = ldexpf(1.f, m ? ec : eq);
+    _Float16* R = m ? R1 : R0;
+    f16x8 p[2][2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float xs = (m ? vc[e] : vq[e]) * mul;  // exact (power of two)
+      const _Float16 a = (_Float16)xs;
+      const _Float16 b = (_Float16)(xs - (float)a);
+      p[0][e >> 3][e & 7] = a;
+      p[1][e >> 3][e & 7] = b;
+    }
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      f16x8* dst = reinterpret_cast<f16x8*>(R + ((int64_t)pl * B + grow) * k3D + d0);
+      dst[0] = p[pl][0];
+      dst[1] = p[pl][1];
+    }
   }
 }
 
@@ -553,8 +706,15 @@ __device__ __forceinline__ f16x8 lds_b128(uint32_t addr) {
 //   FIX (second launch of the same grid, one load and exit for unflagged workgroups): the flagged ones sweep their
 //      range for the exact score maximum and run again.  Nothing downstream depends on which launch produced a block:
 //      merge<Q> combines splits with different references, and pass C takes its factors per (row, split).
-template <bool FIX>
-__global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __restrict__ Xr, const _Float16* __restrict__ Yr,
+//   KIND 2 (round 4, the default): ONE launch.  A workgroup that saw a probability leave fp16's range redoes itself on the
+//      spot (the decision is workgroup-wide: the four waves share the ring and its barriers) -- no flags, no redo launch
+//      (6 us for 512 workgroups that load a flag and exit).  [Merging the partials in this kernel's epilogue as well --
+//      the nsplit workgroups of a block waiting for each other and merging a slice each, partials written through and
+//      read at agent scope -- was built and measured in round 4: correct, but 128 us against 102 + 14 for the sweep and
+//      the merge launch (two dependent memory round trips and three atomics per slice at the tail of every workgroup;
+//      with cache-wide release / acquire fences instead of per-access scopes 186 us).  DESIGN_HISTORY.md.]
+template <int KIND>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void inbatch2h_q_kernel(const _Float16* __restrict__ Xr, const _Float16* __restrict__ Yr,
                                                          int64_t B, int nsplit, float sl2_in,
                                                          const float* __restrict__ sc, const float* __restrict__ ref,
                                                          int nsplit_ref, const float* __restrict__ diag, int mode,
@@ -562,11 +722,11 @@ __global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __rest
                                                          float* __restrict__ part_O, float* __restrict__ part_l,
                                                          float* __restrict__ Pmat) {
   __shared__ __attribute__((aligned(16))) char lds[kHBufs * kHBufBytes];
-  if (FIX && flags[blockIdx.x] == 0) return;
+  if (KIND == 1 && flags[blockIdx.x] == 0) return;
   H_TIMING_DECL();
-  const int t = threadIdx.x, lane = t & 63;
+  int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int j = lane & 31, h = lane >> 5;
+  int j = lane & 31, h = lane >> 5;
   H_TR_SETUP();
   const uint32_t lds32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds;
   (void)lds32;
@@ -582,7 +742,7 @@ __global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __rest
   // (jt * B/32 + it) * 4096) is stored as 16-byte pieces [m][h][a] = P'[8 m + 4 h + 0..3][a]: FOUR fully coalesced 1 KB
   // stores per chunk and wave (as 16 dword stores to a [streamed][owned] tile, two 128-byte lines each, the stores cost
   // pass Q 16 us).  The transposition happens on the reading side, in LDS (inbatch2h_pc8_kernel).
-  char* pst_u = reinterpret_cast<char*>(Pmat) + (c0 * nch + (xrow >> 5)) * 4096;
+  char* pst_u = nullptr;
   const uint32_t pst_v = (uint32_t)((h * 32 + j) * 16);
   typedef float f32x4 __attribute__((ext_vector_type(4)));
 #if defined(H_PROBE_Q_NOSTORE)  /* timing probe only: pass Q without its P stores */
@@ -595,16 +755,10 @@ __global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __rest
 #endif
 
   f32x16 acc[4];
-#pragma unroll
-  for (int db = 0; db < 4; ++db)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[db][r] = 0.f;
   f32x2 l2 = {0.f, 0.f};  // even / odd score pairs; added in a fixed order at the end
-
   int dpos = 0;
   const char* const baseY = reinterpret_cast<const char*>(Yr);
-  uint32_t g0 = dmah_off0<0>(B, c0, t), g1 = dmah_off0<1>(B, c0, t), g2 = dmah_off0<2>(B, c0, t),
-           g3 = dmah_off0<3>(B, c0, t);
+  uint32_t g0 = 0, g1 = 0, g2 = 0, g3 = 0;
   f16x8 bx[2][8];
 #pragma unroll
   for (int p = 0; p < 2; ++p)
@@ -619,9 +773,24 @@ __global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __rest
   float refv = -INFINITY;
   const f32x2 sl2v = {sl2, sl2};
   f32x2 nrefv = {0.f, 0.f};
+  // One sweep of the workgroup's chunks as an inlined lambda: KIND 2 calls it a second time, as the redo (fix = true), when
+  // the first sweep overflowed.  (Written as a loop around the sweep the redo cost 37 registers -- what the compiler
+  // hoisted out of the loop stayed live through it -- and with them the second wave per SIMD.)
+  auto sweep = [&](auto fix_tag) __attribute__((always_inline)) {
+  constexpr bool fix = decltype(fix_tag)::value;
+  pst_u = reinterpret_cast<char*>(Pmat) + (c0 * nch + (xrow >> 5)) * 4096;
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[db][r] = 0.f;
+  l2 = f32x2{0.f, 0.f};
+  dpos = 0;
+  g0 = dmah_off0<0>(B, c0, t); g1 = dmah_off0<1>(B, c0, t); g2 = dmah_off0<2>(B, c0, t); g3 = dmah_off0<3>(B, c0, t);
+  emax = 0.f;
+  refv = -INFINITY;
 #pragma unroll
   for (int r = 0; r < 16; ++r) p[r] = 0.f;
-  if (FIX) {
+  if (fix) {
     // exact maximum of s sl2 over this workgroup's chunks (one tile at a time; this path runs for flagged blocks only).
     // The DMA offsets wrap after nc chunks: the ring state is back at chunk 0 afterwards.
     float m = -INFINITY;
@@ -637,7 +806,7 @@ __global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __rest
   }
   H_DMA_CHUNK(lds);
   if (nc > 1) H_DMA_CHUNK(lds + kHBufBytes);
-  if (!FIX && mode == 0) {
+  if (!fix && mode == 0) {
     float rv[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) rv[s] = s < nsplit_ref ? ref[(int64_t)s * B + xrow] : -INFINITY;
@@ -645,13 +814,13 @@ __global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __rest
 #pragma unroll
     for (int s = 1; s < 8; ++s) refv = fmaxf(refv, rv[s]);
   }
-  const float dref = (!FIX && mode == 1) ? diag[xrow] * sl2_in : -INFINITY;
+  const float dref = (!fix && mode == 1) ? diag[xrow] * sl2_in : -INFINITY;
   H_DMA_BARRIER();
 
   H_S_PHASE(lds, sa, false);
 #pragma unroll
   for (int r = 0; r < 16; ++r) p[r] = sa[r];
-  if (!FIX && mode == 1) {
+  if (!fix && mode == 1) {
     float m = dref;
 #pragma unroll
     for (int r = 0; r < 16; ++r) m = fmaxf(m, sa[r] * sl2);
@@ -715,6 +884,19 @@ __global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __rest
     }
     H_O_PHASE(false, lds);
   }
+  };  // sweep
+  if (KIND == 1) {
+    sweep(std::true_type{});
+  } else {
+    sweep(std::false_type{});
+    // (the barrier also ends the last chunk's LDS reads before a redo's first DMA overwrites the ring)
+    if (KIND == 2 && mode != 0 && __syncthreads_or((mode == 2 || !(emax <= kHOverflow)) ? 1 : 0)) {
+      // (the redo starts from opaque copies of the thread coordinates: nothing the first sweep derived from them is kept
+      // alive for it -- the compiler would rather hold 22 registers through the first sweep than recompute them)
+      asm volatile("" : "+v"(t), "+v"(lane), "+v"(j), "+v"(h));
+      sweep(std::true_type{});
+    }
+  }
 #undef H_P_ST4
   H_TIMING_WRITE(H_TIMING_Q);
   float* orow = part_O + ((int64_t)split * B + xrow) * k3D;
@@ -728,7 +910,7 @@ __global__ __launch_bounds__(256) void inbatch2h_q_kernel(const _Float16* __rest
   const float ltot = l + __shfl_xor(l, 32, 64);
   if (h == 0) part_l[(int64_t)split * B + xrow] = ltot;
   // a probability that does not fit fp16 (or a forced redo: mode 2 is the test hook): the FIX launch redoes this block
-  if (!FIX && (mode == 2 || !(emax <= kHOverflow))) flags[blockIdx.x] = 1;
+  if (KIND == 0 && (mode == 2 || !(emax <= kHOverflow))) flags[blockIdx.x] = 1;
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -1303,6 +1485,7 @@ struct InbatchHWs {
   float *part_O, *part_m, *part_mr, *part_l, *lse2, *fac, *Pmat, *nrm, *amax, *sc, *diag;
   int* flags;
   unsigned long long* loss_acc;
+  unsigned long long* ent;  // prepsplit2h_kernel's tagged per-chunk maxima
 };
 constexpr int64_t kHMaxB = 16384;  // B x B x 4 bytes of stored probabilities: 1 GiB
 
@@ -1330,6 +1513,7 @@ static size_t inbatch2h_ws_layout(int64_t B, char* base, InbatchHWs* ws) {
   w.nrm = (float*)take((size_t)2 * (B / k3Chunk) * 4 * sizeof(float));
   w.amax = (float*)take((size_t)2 * (B / k3Chunk) * sizeof(float));
   w.sc = (float*)take(kHScaleWords * sizeof(float));
+  w.ent = (unsigned long long*)take((size_t)(B / k3Chunk) * sizeof(unsigned long long));
   if (ws) *ws = w;
   return off;
 }
@@ -1426,50 +1610,82 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
     nsplit_q = inbatch2h_nsplit(B, qcs ? std::max(1, atoi(qcs)) : 2);
     grid_q = (int)(B / k3Owned) * nsplit_q;
   }
-  hipLaunchKernelGGL(prep2h_kernel, dim3(nchunks), dim3(256), 0, st, Qs, Cs, ws.amax, ws.diag);
-  hipLaunchKernelGGL(split2h_kernel, dim3(nchunks, 2), dim3(256), 0, st, Qs, Cs, B, ws.Qh, ws.Ch, (const float*)ws.amax,
-                     ws.nrm, ws.sc, ws.loss_acc, ws.flags, grid_q);
+  // round 4 (default): prep + split in one launch, pass Q redoes overflowed workgroups itself: five launches.
+  // ESR_IB2H_FUSED=0 (or the row-max reference, or the 64-row pass Q) keeps round 3's seven.
+  const char* fe = getenv("ESR_IB2H_FUSED");
+  const bool fused = !(fe && fe[0] == '0') && mode != 0 && !q2;
   int nsplit_r = 1;
+  if (fused) {
+    static std::atomic<unsigned long long> call_seq{0};
+    static const unsigned long long seed =
+        (unsigned long long)(uintptr_t)&call_seq ^ (unsigned long long)time(nullptr) * 0x9E3779B97F4A7C15ull;
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (call_seq.fetch_add(1) + 1);  // splitmix64: a token per call
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    const unsigned long long token = ((z ^ (z >> 31)) >> 16) | 1ull;  // 48 bits, never 0
+    ESR_KT("prepsplit2h_kernel", st,
+           hipLaunchKernelGGL(prepsplit2h_kernel, dim3(nchunks), dim3(256), 0, st, Qs, Cs, B, ws.Qh, ws.Ch, ws.ent, token,
+                              ws.diag, ws.nrm, ws.sc, ws.loss_acc, ws.flags, grid_q));
+    ESR_KT("inbatch2h_q_kernel", st,
+           hipLaunchKernelGGL((inbatch2h_q_kernel<2>), dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Qh,
+                              (const _Float16*)ws.Ch, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)ws.part_mr, 1,
+                              (const float*)ws.diag, mode, ws.flags, ws.part_m, ws.part_O, ws.part_l, ws.Pmat));
+  } else {
+  ESR_KT("prep2h_kernel", st, hipLaunchKernelGGL(prep2h_kernel, dim3(nchunks), dim3(256), 0, st, Qs, Cs, ws.amax, ws.diag));
+  ESR_KT("split2h_kernel", st,
+         hipLaunchKernelGGL(split2h_kernel, dim3(nchunks, 2), dim3(256), 0, st, Qs, Cs, B, ws.Qh, ws.Ch,
+                            (const float*)ws.amax, ws.nrm, ws.sc, ws.loss_acc, ws.flags, grid_q));
   if (mode == 0) {
     const int rm_blocks = (int)cdiv(B, kHRmOwned);
     for (int sp = 1; sp <= 8; ++sp)
       if (nchunks % sp == 0 && rm_blocks * sp <= 320) nsplit_r = sp;
-    hipLaunchKernelGGL(rowmax2h_kernel, dim3(rm_blocks * nsplit_r), dim3(256), 0, st, (const _Float16*)ws.Qh,
-                       (const _Float16*)ws.Ch, B, nsplit_r, sl2, (const float*)ws.nrm, (const float*)ws.sc, ws.part_mr);
+    ESR_KT("rowmax2h_kernel", st,
+           hipLaunchKernelGGL(rowmax2h_kernel, dim3(rm_blocks * nsplit_r), dim3(256), 0, st, (const _Float16*)ws.Qh,
+                              (const _Float16*)ws.Ch, B, nsplit_r, sl2, (const float*)ws.nrm, (const float*)ws.sc,
+                              ws.part_mr));
   }
   if (q2) {
-    hipLaunchKernelGGL((inbatch2h_q2_kernel<false>), dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Qh,
-                       (const _Float16*)ws.Ch, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)ws.diag, mode,
-                       ws.flags, ws.part_m, ws.part_O, ws.part_l, ws.Pmat);
+    ESR_KT("inbatch2h_q2_kernel", st,
+           hipLaunchKernelGGL((inbatch2h_q2_kernel<false>), dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Qh,
+                              (const _Float16*)ws.Ch, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)ws.diag, mode,
+                              ws.flags, ws.part_m, ws.part_O, ws.part_l, ws.Pmat));
     hipLaunchKernelGGL((inbatch2h_q2_kernel<true>), dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Qh,
                        (const _Float16*)ws.Ch, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)ws.diag, mode,
                        ws.flags, ws.part_m, ws.part_O, ws.part_l, ws.Pmat);
   } else {
-  hipLaunchKernelGGL((inbatch2h_q_kernel<false>), dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Qh,
-                     (const _Float16*)ws.Ch, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)ws.part_mr, nsplit_r,
-                     (const float*)ws.diag, mode, ws.flags, ws.part_m, ws.part_O, ws.part_l, ws.Pmat);
-  if (mode != 0)  // redo launch: workgroups whose block is not flagged (normally all of them) exit after one load
-    hipLaunchKernelGGL((inbatch2h_q_kernel<true>), dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Qh,
-                       (const _Float16*)ws.Ch, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)ws.part_mr, nsplit_r,
-                       (const float*)ws.diag, mode, ws.flags, ws.part_m, ws.part_O, ws.part_l, ws.Pmat);
+    ESR_KT("inbatch2h_q_kernel", st,
+           hipLaunchKernelGGL((inbatch2h_q_kernel<0>), dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Qh,
+                              (const _Float16*)ws.Ch, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)ws.part_mr,
+                              nsplit_r, (const float*)ws.diag, mode, ws.flags, ws.part_m, ws.part_O, ws.part_l, ws.Pmat));
+    if (mode != 0)  // redo launch: workgroups whose block is not flagged (normally all of them) exit after one load
+      ESR_KT("inbatch2h_q_kernel_redo", st,
+             hipLaunchKernelGGL((inbatch2h_q_kernel<1>), dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Qh,
+                                (const _Float16*)ws.Ch, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)ws.part_mr,
+                                nsplit_r, (const float*)ws.diag, mode, ws.flags, ws.part_m, ws.part_O, ws.part_l, ws.Pmat));
   }
+  }  // !fused
   // O_Q' = 2^ec sum p' c, l' = sum p': o / l needs 2^-ec (sc[1]); the stored factors carry pass C's 2^14
-  hipLaunchKernelGGL((inbatch3_merge_kernel<true>), dim3(mgrid), dim3(kBlock), 0, st, Qs, Cs, gq_rows, B, nsplit_q,
-                     (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale, regularization,
-                     inv_bs, ws.lse2, lse, gQ, ws.loss_acc, 1.0 / (double)batch_size, loss, (float*)nullptr,
-                     (const float*)(ws.sc + 1), ldexpf(1.f, (int)kHPexp), ws.fac);
+  ESR_KT("inbatch3_merge_kernel_q", st,
+         hipLaunchKernelGGL((inbatch3_merge_kernel<true>), dim3(mgrid), dim3(kBlock), 0, st, Qs, Cs, gq_rows, B, nsplit_q,
+                            (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale,
+                            regularization, inv_bs, ws.lse2, lse, gQ, ws.loss_acc, 1.0 / (double)batch_size, loss,
+                            (float*)nullptr, (const float*)(ws.sc + 1), ldexpf(1.f, (int)kHPexp), ws.fac));
   const char* pcm = getenv("ESR_IB2H_PC");  // "dma": the P' tiles as LDS-DMAs (one chunk ahead); default: staged loads
-  if (pcm && pcm[0] == 'd')
-    hipLaunchKernelGGL((inbatch2h_pc8_kernel<false>), dim3(grid_c), dim3(512), 0, st, (const _Float16*)ws.Qh, B, nsplit_c,
-                       (const float*)ws.fac, nchunks / nsplit_q, (const float*)ws.Pmat, ws.part_O);
-  else
-    hipLaunchKernelGGL((inbatch2h_pc8_kernel<true>), dim3(grid_c), dim3(512), 0, st, (const _Float16*)ws.Qh, B, nsplit_c,
-                       (const float*)ws.fac, nchunks / nsplit_q, (const float*)ws.Pmat, ws.part_O);
+  if (pcm && pcm[0] == 'd') {
+    ESR_KT("inbatch2h_pc8_kernel", st,
+           hipLaunchKernelGGL((inbatch2h_pc8_kernel<false>), dim3(grid_c), dim3(512), 0, st, (const _Float16*)ws.Qh,
+                              B, nsplit_c, (const float*)ws.fac, nchunks / nsplit_q, (const float*)ws.Pmat, ws.part_O));
+  } else {
+    ESR_KT("inbatch2h_pc8_kernel", st,
+           hipLaunchKernelGGL((inbatch2h_pc8_kernel<true>), dim3(grid_c), dim3(512), 0, st, (const _Float16*)ws.Qh,
+                              B, nsplit_c, (const float*)ws.fac, nchunks / nsplit_q, (const float*)ws.Pmat, ws.part_O));
+  }
   // O_C' = 2^(eq + 14) sum_i (p_ij / l_i) q_i
-  hipLaunchKernelGGL((inbatch3_merge_kernel<false>), dim3(mgrid), dim3(kBlock), 0, st, Cs, Qs, gc_rows, B, nsplit_c,
-                     (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale, regularization,
-                     inv_bs, ws.lse2, (float*)nullptr, gC, ws.loss_acc, 1.0 / (double)batch_size, loss,
-                     (float*)nullptr, (const float*)(ws.sc + 2), 1.0f);
+  ESR_KT("inbatch3_merge_kernel_c", st,
+         hipLaunchKernelGGL((inbatch3_merge_kernel<false>), dim3(mgrid), dim3(kBlock), 0, st, Cs, Qs, gc_rows, B, nsplit_c,
+                            (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale,
+                            regularization, inv_bs, ws.lse2, (float*)nullptr, gC, ws.loss_acc,
+                            1.0 / (double)batch_size, loss, (float*)nullptr, (const float*)(ws.sc + 2), 1.0f));
   return check_launch(who);
 }
 

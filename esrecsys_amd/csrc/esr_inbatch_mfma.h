@@ -262,5 +262,4 @@ __global__ __launch_bounds__(kBlock) void inbatch3_merge_kernel(
   }
 }
 
-
 }  // namespace esr

@@ -264,9 +264,9 @@ static int ivf_score_set(const float* queries, int D, const float* cands_sorted,
   const int row_tiles = (int)(P / kIvfTile + nlist);  // >= sum over lists of ceil(pairs / 64)
   IvfFilter flt;
   flt.tau = ws.tau; flt.cnt = ws.cnt; flt.pairs = ws.pairs; flt.ppitch = g.ppitch;
-  hipLaunchKernelGGL((ivf_score_kernel<FILTER>), dim3((int)align_up((size_t)(g.pitch / kIvfTile), 8), row_tiles),
+  ESR_KT("ivf_score_kernel", st, hipLaunchKernelGGL((ivf_score_kernel<FILTER>), dim3((int)align_up((size_t)(g.pitch / kIvfTile), 8), row_tiles),
                      dim3(kBlock), 0, st, queries, D, cands_sorted, list_off, (const int32_t*)ws.perm, ppq, slot0, q0,
-                     (const int32_t*)ws.pair_off, (const int32_t*)ws.tile_start, nlist, ws.S, g.pitch, flt);
+                     (const int32_t*)ws.pair_off, (const int32_t*)ws.tile_start, nlist, ws.S, g.pitch, flt));
   return ESR_OK;
 }
 

@@ -386,11 +386,11 @@ static int launch_segment_tables(const char* who, const FusedTables& ft, int dty
   const int grid = grid_for_groups(n, g.G);
   const int grid2 = (int)std::min<int64_t>(kMaxGrid, cdiv(cdiv(n, kSegChunk), 4));  // 4 chunk boundaries per pass
   ESR_DISPATCH_ROW(g, {
-    hipLaunchKernelGGL((segment_update_kernel<VEC, NCH, OP>), dim3(grid), dim3(kBlock), 0, st, ft, dtype, D, g.G,
-                       sorted_ids, perm, n, grad_rows, lr, eps);
+    ESR_KT("segment_update_kernel", st, hipLaunchKernelGGL((segment_update_kernel<VEC, NCH, OP>), dim3(grid), dim3(kBlock), 0, st, ft, dtype, D, g.G,
+                       sorted_ids, perm, n, grad_rows, lr, eps));
     if (n > kSegChunk && !skip_long)
-      hipLaunchKernelGGL((segment_long_kernel<VEC, NCH, OP>), dim3(grid2), dim3(kBlock), 0, st, ft, dtype, D, g.G,
-                         sorted_ids, perm, n, (const float*)grad_rows, lr, eps);
+      ESR_KT("segment_long_kernel", st, hipLaunchKernelGGL((segment_long_kernel<VEC, NCH, OP>), dim3(grid2), dim3(kBlock), 0, st, ft, dtype, D, g.G,
+                         sorted_ids, perm, n, (const float*)grad_rows, lr, eps));
   });
   return check_launch(who);
 }

@@ -898,8 +898,8 @@ static void launch_gemm(const __bf16* A, int64_t a_plane, const __bf16* B, int64
   // planes are k-block-major over Mp query rows / n_pad candidate rows (this chunk's padded row count)
   const int tm = (int)(Mp / kGM), tn = (int)(n_pad / kGN);
   const int per = (tm * tn + 7) / 8;
-  hipLaunchKernelGGL((score_gemm_kernel<P, DENSE>), dim3(per * 8), dim3(kGThreads), 0, st, A, a_plane, Mp, B, b_plane, n_pad,
-                     Dp, tm, tn, M, nvalid, o);
+  ESR_KT("score_gemm_kernel", st, hipLaunchKernelGGL((score_gemm_kernel<P, DENSE>), dim3(per * 8), dim3(kGThreads), 0, st, A, a_plane, Mp, B, b_plane, n_pad,
+                     Dp, tm, tn, M, nvalid, o));
 }
 
 }  // namespace esr
@@ -983,8 +983,8 @@ int esr_retrieve_topk(const float* queries, const float* candidates, int64_t nq,
     }
     // long rows only in the first two selects (the dense first chunk; the lists filtered by its weak threshold)
     const int lds_words = ncall < 2 ? kSelLdsWords : 0;
-    hipLaunchKernelGGL(topk_select_kernel, dim3((int)nq), dim3(kSelThreads), lds_words * sizeof(uint32_t), st, in, k, so,
-                       lds_words);
+    ESR_KT("topk_select_kernel", st, hipLaunchKernelGGL(topk_select_kernel, dim3((int)nq), dim3(kSelThreads), lds_words * sizeof(uint32_t), st, in, k, so,
+                       lds_words));
     ++ncall;
     c0 += nc;
     first = false;

@@ -564,12 +564,12 @@ static int launch_trip_step(const TwoTowers& tt, int D, const RowGeom& g, const 
   ESR_DISPATCH_ROW(g, {
     static const int resident = resident_blocks((const void*)triplet_step_kernel<VEC, NCH>);  // (one query per process)
     grid = std::min(grid, resident);
-    hipLaunchKernelGGL((triplet_step_kernel<VEC, NCH>), dim3(grid), dim3(kBlock), 0, st, tt, D, g.G, sorted,
+    ESR_KT("triplet_step_kernel", st, hipLaunchKernelGGL((triplet_step_kernel<VEC, NCH>), dim3(grid), dim3(kBlock), 0, st, tt, D, g.G, sorted,
                        (const uint2*)pl.meta, n, regularization, inv_bs, 1, lr, eps, ws.chunk_rows, pl.flags,
-                       pl.loss_acc, loss_frac_bits(B), 1.0 / (double)batch_size, loss);
+                       pl.loss_acc, loss_frac_bits(B), 1.0 / (double)batch_size, loss));
     if (long_runs != 0)  // 0 = the caller knows (esr_triplet_plan's hint) that no run outgrows its head chunk
-      hipLaunchKernelGGL((triplet_step_long_kernel<VEC, NCH>), dim3(grid2), dim3(kBlock), 0, st, tt, D, g.G, sorted, n,
-                         lr, eps, (const float*)ws.chunk_rows, (const int*)pl.flags);
+      ESR_KT("triplet_step_long_kernel", st, hipLaunchKernelGGL((triplet_step_long_kernel<VEC, NCH>), dim3(grid2), dim3(kBlock), 0, st, tt, D, g.G, sorted, n,
+                         lr, eps, (const float*)ws.chunk_rows, (const int*)pl.flags));
   });
   return ESR_OK;
 }

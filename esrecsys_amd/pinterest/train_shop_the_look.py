@@ -80,7 +80,8 @@ class PresortedTriplets:
         when it says one has, -1 while nobody knows."""
         if self.hint is None or not self.hint[2].query():
             return -1
-        return 1 if int(self.hint[0][0]) == self.hint[1] else 0
+        from ..wikipedia.train_cooccurence import hint_value
+        return hint_value(self.hint)
 
     def take(self):
         if self.event is not None:

@@ -350,6 +350,7 @@ class ShardedTableGroup:
         """The looked-up rows in BUCKET order (row plan.inv[i] belongs to virtual id i), in the tables' dtype --
         for consumers that can index them themselves and so skip the un-permute pass."""
         k = self.k
+        self.consolidate()  # rows a world-1 one-pass step left in the second buffers (no-op when nothing is displaced)
         recv = plan.exchange_ids()
         if len(self.tables) == 1:
             served = k.gather_rows(self.tables[0].local, recv)
@@ -383,6 +384,7 @@ class ShardedTableGroup:
     def apply_sparse_adagrad(self, plan, grad_rows, lr, eps=1e-7, bucketed=False):
         """Route the gradients to their owners and update the local shards: one fused segment-reduce + RMW."""
         k = self.k
+        self.consolidate()  # this update writes the plain shards: displaced rows must be home first (see lookup_bucketed)
         rows = self.route_grads(plan, grad_rows, bucketed=bucketed)
         if rows.shape[0] == 0:
             return

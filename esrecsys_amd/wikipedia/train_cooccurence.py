@@ -169,7 +169,7 @@ class PresortedInputs:
         """0 / 1 from the plan's hint once it has reached the host, -1 while it has not (or without a plan)."""
         if self.hint is None or self._done is None or not self._done.query():
             return -1
-        return 1 if int(self.hint[0][0]) == self.hint[1] else 0
+        return hint_value(self.hint)
 
 
 # ESR_GLOVE_PRESORT=0 sorts in line instead of one batch ahead on the side stream.  ESR_GLOVE_STEP_BLOCKS_PER_CU caps the
@@ -208,7 +208,23 @@ def _hint_slot(dev):
     ring = _hint_ring[key]
     i, gen = ring[1], ring[2]
     ring[1], ring[2] = (i + 1) % R, gen + 1 if gen < 2 ** 31 - 2 else 1
-    return ring[0][i:i + 1], gen
+    word = ring[0][i:i + 1]
+    _hint_owner[word.data_ptr()] = gen  # the slot is this generation's until the ring comes round to it again
+    return word, gen
+
+
+_hint_owner = {}  # address of a ring word -> the generation it was last handed to
+
+
+def hint_value(hint):
+    """1 / 0 = the hint kernel of `hint` = (word, gen, ...) found / did not find a long run -- valid only while the word
+    is still this generation's.  A kernel writes its gen into the word only when it finds a long run, so a word that a
+    LATER hint has been handed (more than a ring's worth of handles outstanding) would read as "no long run" whatever
+    this generation's kernel had found: that case answers -1 (unknown: the step makes its long-run launch)."""
+    word, gen = hint[0], hint[1]
+    if _hint_owner.get(word.data_ptr()) != gen:
+        return -1
+    return 1 if int(word[0]) == gen else 0
 
 
 def presort_inputs(state, inputs, target=None, after=None, out=None):
@@ -278,6 +294,12 @@ def train_step(state, inputs, target):
     target = ops.as_f32(target, emb.device)
     rv = row_versions(state, ("_token_embedding", "embedding"))
     acc = state.opt_state["sum_of_squares"]
+    if presorted is not None and presorted.plan is not None:
+        # a plan's statistics / loss words are zeroed by the plan kernel only: a second step on the same plan would add
+        # to the first step's sums (doubled loss and gradient, nothing to report it)
+        if getattr(presorted, "_consumed", False):
+            raise RuntimeError("this PresortedInputs' plan has already been stepped: presort_inputs again for a second step")
+        presorted._consumed = True
     loss = ops.glove_train_step(emb, rv.shadow, rv.loc, acc["_token_embedding"]["embedding"], bias,
                                 acc["_bias"]["embedding"], inputs, target, mode, state.tx.lr, state.tx.eps,
                                 presorted=presorted.take() if presorted is not None else None,

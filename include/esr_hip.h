@@ -55,6 +55,19 @@ int esr_version(void);
 /* host out-params; arch_len bytes at arch receive e.g. "gfx950". */
 int esr_device_info(int* cu_count, int* wave_size, size_t* hbm_bytes, char* arch, int arch_len);
 
+/* ---- measurement: per-kernel launch durations ("GPU kernel times ... from rocprofv3"; bench.py's
+ * `roofline.achieved` wants the dominant kernel's duration measured live with HIP events on the stream the kernel is
+ * launched on -- the kernels are launched inside the library, so the events are recorded here).  The reference has no
+ * counterpart (it never measures: wikipedia/train_cooccurence.py:185-186 logs the loss only).
+ * esr_kernel_timing(1): from now on the instrumented launch sites record a HIP event pair around their launch (the
+ * in-batch head's kernels, the one-pass GloVe / triplet update kernels, the retrieval GEMM and selects); (0): stop.
+ * Either call drops unread records.  Off by default: one load per launch site.
+ * esr_kernel_timing_read: the ONE entry point that synchronises (it waits for the recorded events): writes
+ * "name\tcalls\ttotal_ms\tmin_ms\tmax_ms\n" per kernel name to the HOST buffer `buf` (NUL-terminated, truncated to cap)
+ * and clears the records; returns the bytes the whole text needs. */
+int esr_kernel_timing(int enable);
+long esr_kernel_timing_read(char* buf, size_t cap);
+
 /* ---- G2 / S1: embedding-row gather ------------------------------------------------------
  * nn.Embed lookup == jnp.take(table, ids, axis=0): wikipedia/models.py:31-34 (and the id towers
  * that replace pinterest/models.py:64-70).  out[i, :] = table[ids[i], :], bit-exact. */

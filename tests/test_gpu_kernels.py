@@ -684,6 +684,59 @@ def test_inbatch_f16x2_exponent_reference_modes(dev, B, ref_mode, monkeypatch):
     assert rel_err(N(gq), egq) <= TOL and rel_err(N(gc), egc) <= TOL
 
 
+@pytest.mark.parametrize("ref_mode", ["opt", "redo"])
+@pytest.mark.parametrize("B", [128, 384, 1024, 2176, 8192, 16384])
+def test_inbatch_f16x2_fused_launches_equal_round3_launches(dev, B, ref_mode, monkeypatch):
+    """Round 4's launches (prep + split in ONE kernel behind a tagged all-gather of the chunk maxima; pass Q redoing its
+    overflowed workgroups itself instead of a flag + redo launch) against round 3's (ESR_IB2H_FUSED=0): the same planes
+    and the same sweeps, so lse and both gradients agree to a rounding per element, on inputs where some workgroups
+    overflow and redo, and the fused path repeats itself bit for bit (the pre-pass polls words other workgroups
+    publish: a stale read would show up as run-to-run differences)."""
+    from esrecsys_amd import ops
+    g = torch.Generator(device=dev).manual_seed(31 * B)
+    D = 128
+    q = torch.randn((B, D), generator=g, device=dev) * D ** -0.5
+    c = torch.randn((B, D), generator=g, device=dev) * D ** -0.5
+    c[B - 24] = 3.0 * q[5] / q[5].norm()          # a late dominant candidate: the optimistic reference overflows
+    c[B // 2 + 40] = 2.5 * q[B // 2] / q[B // 2].norm()
+    monkeypatch.setenv("ESR_IB2H_REF", ref_mode)
+    monkeypatch.setenv("ESR_IB2H_FUSED", "0")
+    ref = [t.clone() for t in ops.inbatch_softmax_fwd_bwd(q, c, 8.0, 0.1, float(B), precision="f16x2")]
+    assert all(bool(torch.isfinite(t).all()) for t in ref)
+    monkeypatch.setenv("ESR_IB2H_FUSED", "1")
+    first = None
+    for rep in range(20 if B >= 8192 else 6):
+        out = [t.clone() for t in ops.inbatch_softmax_fwd_bwd(q, c, 8.0, 0.1, float(B), precision="f16x2")]
+        assert abs(float(out[0]) - float(ref[0])) <= 1e-6 * abs(float(ref[0])), rep
+        for name, a, b in zip(("lse", "gQ", "gC"), ref[1:], out[1:]):
+            # (the merge arithmetic is the same source compiled into two kernels: fused-multiply-add contraction may
+            # differ, so a rounding per element, not bit equality, between the two builds ...)
+            assert rel_err(N(b), N(a)) <= 5e-7, (name, rep)
+            assert float((a - b).abs().max()) <= 4e-6 * float(a.abs().max()), (name, rep)
+        if first is not None:  # ... but the fused path must repeat itself bit for bit
+            assert all(torch.equal(a, b) for a, b in zip(first, out)), rep
+        first = out
+
+
+def test_inbatch_f16x2_fused_towers_with_bf16_and_gathered_rows(dev, monkeypatch):
+    """The fused pre-pass reads its rows through the row source (tower table + ids, f32 or bf16): towers entry point,
+    duplicate ids, against round 3's launches."""
+    from esrecsys_amd import ops
+    g = torch.Generator(device=dev).manual_seed(5)
+    V, D, B = 5000, 128, 1024
+    st = torch.randn((V, D), generator=g, device=dev) * D ** -0.5
+    pt = torch.randn((V, D), generator=g, device=dev) * D ** -0.5
+    sid = torch.randint(0, V, (B,), generator=g, device=dev, dtype=torch.int32)
+    pid = torch.randint(0, 50, (B,), generator=g, device=dev, dtype=torch.int32)  # many duplicates
+    monkeypatch.setenv("ESR_IB2H_FUSED", "0")
+    ref = [t.clone() for t in ops.inbatch_towers_fwd_bwd(st, pt, sid, pid, 4.0, 0.1, float(B), precision="f16x2")]
+    monkeypatch.setenv("ESR_IB2H_FUSED", "1")
+    out = ops.inbatch_towers_fwd_bwd(st, pt, sid, pid, 4.0, 0.1, float(B), precision="f16x2")
+    assert abs(float(out[0]) - float(ref[0])) <= 1e-6 * abs(float(ref[0]))
+    for a, b in zip(ref[1:], out[1:]):
+        assert rel_err(N(b), N(a)) <= 5e-7
+
+
 @pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2"])
 def test_inbatch_repeatable_under_load(dev, precision):
     """Race screen for the LDS-DMA ring: 60 back-to-back launches at the headline size must be bit-identical

@@ -191,3 +191,37 @@ def test_world1_direct_path_and_machinery_agree(dev, pg, unique, monkeypatch):
     assert np.allclose(la, lb, rtol=2e-5), (la, lb)
     errs = [rel_err(a.cpu().numpy(), b.cpu().numpy()) for a, b in zip(ta, tb)]  # scene, product, GloVe emb, GloVe bias
     assert max(errs) <= 2e-5, errs
+
+
+def test_world1_direct_mixed_steps_with_odd_batch(dev, pg, monkeypatch):
+    """with B % 128 != 0 the in-batch step of a world-1 group takes the plan-based path, which reads and
+    updates the PLAIN shards -- after a one-pass triplet step left rows in the second buffers.  Both paths (direct and
+    machinery) must leave the same towers: the plan-based branches consolidate first."""
+    from conftest import rel_err
+    from esrecsys_amd import ops, sharded
+    V, D, B, lam, lr = 5000, 128, 1000, 0.1, 0.05  # 1000 % 128 != 0
+    g = torch.Generator().manual_seed(13)
+    t0 = torch.randn((V, D), generator=g) * D ** -0.5
+    t1 = torch.randn((V, D), generator=g) * D ** -0.5
+    rng = np.random.default_rng(14)
+    batches = [tuple(torch.from_numpy(rng.integers(0, V, B).astype(np.int32)).to(dev) for _ in range(3)) for _ in range(5)]
+
+    def run(direct):
+        monkeypatch.setenv("ESR_SHARDED_WORLD1_DIRECT", "1" if direct else "0")
+        monkeypatch.setenv("ESR_SHARDED_UNIQUE", "0")
+        mk = lambda t: sharded.RowShardedTable(t.clone().to(dev), torch.full(t.shape, 0.1, device=dev), V)  # noqa: E731
+        towers = sharded.ShardedTableGroup([mk(t0), mk(t1)], kernels=ops)
+        assert towers.world1_direct == direct
+        losses = []
+        for i, (s_, p_, n_) in enumerate(batches):
+            if i % 2 == 0:
+                losses.append(float(sharded.sharded_triplet_step(towers, s_, p_, n_, lam, float(B), lr)))
+            else:
+                losses.append(float(sharded.sharded_inbatch_step(towers, s_, p_, lam, float(B), 4.0, lr)))
+        towers.consolidate()
+        return losses, [t.local.clone() for t in towers.tables] + [t.accum.clone() for t in towers.tables]
+    la, ta = run(True)
+    lb, tb = run(False)
+    assert np.allclose(la, lb, rtol=2e-5), (la, lb)
+    errs = [rel_err(a.cpu().numpy(), b.cpu().numpy()) for a, b in zip(ta, tb)]
+    assert max(errs) <= 2e-5, errs

@@ -132,3 +132,28 @@ def test_quiet_gc_parks_and_restores(monkeypatch):
     monkeypatch.setenv("ESR_LOOP_GC_FREEZE", "0")
     with quiet_gc():
         assert gc.get_freeze_count() == 0
+
+
+def test_long_run_hint_words_are_unknown_once_their_slot_is_reused():
+    """the long-run hint words live in a 16-slot ring and a kernel writes its generation only when it FINDS a
+    long run.  A handle whose slot a later hint has been handed must answer "unknown" (-1), never "no long run" (0)."""
+    import torch
+    from esrecsys_amd.wikipedia import train_cooccurence as tc
+    dev = torch.device("cpu")
+    key = (dev.type, dev.index)
+    tc._hint_ring[key] = [torch.zeros(16, dtype=torch.int32), 0, 1]  # (the product ring is pinned host memory)
+    try:
+        first = tc._hint_slot(dev)
+        assert tc.hint_value(first) == 0           # nothing written: no long run
+        first[0][0] = first[1]                     # what the hint kernel stores when it finds one
+        assert tc.hint_value(first) == 1
+        others = [tc._hint_slot(dev) for _ in range(15)]
+        assert tc.hint_value(first) == 1 and all(tc.hint_value(h) == 0 for h in others)
+        again = tc._hint_slot(dev)                 # the ring has come round: `first`'s word now belongs to `again`
+        assert again[0].data_ptr() == first[0].data_ptr()
+        assert tc.hint_value(first) == -1
+        assert tc.hint_value(again) == 0           # the stale generation in the word is not `again`'s
+        again[0][0] = again[1]
+        assert tc.hint_value(again) == 1 and tc.hint_value(first) == -1
+    finally:
+        tc._hint_ring.pop(key, None)
