@@ -158,47 +158,66 @@ def saturating_gather_scatter(dev, V, D, n=131072, reps=20):
             "box_stream_bytes": tb}
 
 
-def per_kernel_from_profile(workload, path, B, D, cfg):
-    """Per-kernel roofline fractions of the main kernels from the COMMITTED rocprofv3 summary of this workload
-    (profiles/r3/<workload>_kernel_stats.csv: average launch duration), for the configuration that summary was taken on
-    (the default one of each workload) -- None otherwise.  MFMA kernels: executed fp16 flops / duration / 2.5 PF; HBM
-    kernels: the bytes the kernel needs (SURVEY 8d's per-unit figure) / duration / 8 TB/s."""
-    base = WORKLOADS.get(workload, {})
-    if workload not in ("inbatch", "glove", "triplet") or B != base.get("B") or D != base.get("D") or \
-            cfg.get("ids", "uniform") != "uniform" or cfg.get("table_dtype", "f32") != "f32" or \
-            (workload == "inbatch" and path != "f16x2"):
-        return None
-    f = os.path.join(ROOT, "profiles", "r3", "%s_kernel_stats.csv" % workload)
-    if not os.path.exists(f):
-        return None
+def pmc_traffic(key):
+    """HBM bytes per step from profiles/pmc_traffic.json (committed --pmc passes), or None when no pass was taken on
+    exactly this (workload, batch, path)."""
     try:
-        import csv
-        rows = {r["Name"]: float(r["AverageNs"]) * 1e-9 for r in csv.DictReader(open(f))}
+        v = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(key)
+        return v if isinstance(v, (int, float)) else None
     except Exception:
         return None
 
-    def dur(sub, also=None):
-        for name, t in rows.items():
-            if sub in name and (also is None or also in name):
-                return t
+
+def library_kernel_times(fn, reps):
+    """Average launch duration (us) of every kernel of libesr_hip.so during `reps` calls of fn(i), measured IN THIS RUN
+    by the library's own HIP events on the stream each kernel is launched on (esr_kernel_timing: one event pair around
+    every launch).  Returns {kernel: {"us": average, "launches_per_step": n}}."""
+    import ctypes
+    from esrecsys_amd import _lib
+    lib = _lib.load()
+    torch.cuda.synchronize()
+    lib.esr_kernel_timing(1)
+    try:
+        for i in range(reps):
+            fn(i)
+        torch.cuda.synchronize()
+        buf = ctypes.create_string_buffer(1 << 16)
+        lib.esr_kernel_timing_read(buf, len(buf))
+    finally:
+        lib.esr_kernel_timing(0)
+    out = {}
+    for line in buf.value.decode().strip().split("\n"):
+        if not line:
+            continue
+        name, calls, total, _mn, _mx = line.split("\t")
+        out[name] = {"us": round(float(total) / int(calls) * 1e3, 2), "launches_per_step": round(int(calls) / reps, 3)}
+    return out
+
+
+def dominant_kernel_roofline(workload, path, per_kernel, B, D):
+    """Roofline fraction of the dominant kernel from its in-run average launch duration: MFMA kernels = executed fp16
+    cross-term GEMM flops / duration / 2.5 PF; HBM kernels = SURVEY 8d's algorithmic bytes of the step / duration / 8 TB/s."""
+    if not per_kernel:
         return None
-    out = {"source": "profiles/r3/%s_kernel_stats.csv (rocprofv3 --kernel-trace --stats, average launch)" % workload}
     if workload == "inbatch":
+        if path != "f16x2":
+            return None
         unit = 2.0 * B * B * D  # one cross-term GEMM
-        for key, sub, also, terms in (("inbatch2h_q_kernel", "inbatch2h_q_kernelILb0", None, 6),
-                                      ("inbatch2h_pc8_kernel", "inbatch2h_pc8_kernel", None, 3)):
-            t = dur(sub, also)
-            if t:
-                out[key] = {"us": t * 1e6, "executed_fp16_cross_term_gemms": terms,
-                            "TFLOPs": terms * unit / t / 1e12, "frac_of_2.5PF": terms * unit / t / 1e12 / MFMA_BF16_PEAK_TFLOPS}
-    else:
-        name = "glove_step_resolved_kernel" if workload == "glove" else "triplet_step_kernel"
-        t = dur(name)
-        if t:
+        out = {}
+        for name, terms in (("inbatch2h_q_kernel", 6), ("inbatch2h_pc8_kernel", 3)):
+            if name in per_kernel:
+                t = per_kernel[name]["us"] * 1e-6
+                out[name] = {"us": per_kernel[name]["us"], "fp16_gemms": terms,
+                             "frac_of_2.5PF": round(terms * unit / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
+        return out or None
+    names = ("glove_step_resolved_kernel", "glove_step_kernel") if workload == "glove" else ("triplet_step_kernel",)
+    for name in names:
+        if name in per_kernel:
+            t = per_kernel[name]["us"] * 1e-6
             alg = STEP_BYTES_PER_UNIT[workload](D) * B
-            out[name] = {"us": t * 1e6, "algorithmic_bytes": alg, "GBps": alg / t / 1e9,
-                         "frac_of_8TBps": alg / t / 1e9 / HBM_PEAK_GBS}
-    return out if len(out) > 1 else None
+            return {name: {"us": per_kernel[name]["us"], "algorithmic_bytes": alg,
+                           "frac_of_8TBps": round(alg / t / 1e9 / HBM_PEAK_GBS, 4)}}
+    return None
 
 
 def roofline_for(workload, kernels, B, D, rows, precision, occ_n=0, uniq=0, bf16_tables=False, rowmax_gemm=False,
@@ -499,6 +518,38 @@ def emit(obj):
     print(json.dumps(obj), flush=True)
 
 
+def emit_leg(name, leg):
+    """A secondary leg's full record as its own JSON line, printed BEFORE the final line (the driver keeps the tail of
+    stdout: the final line stays short and carries a one-line summary of every leg)."""
+    sys.stdout.flush()
+    print(json.dumps({"leg": name, **leg}), flush=True)
+
+
+def _r(x, n=4):
+    return round(x, n) if isinstance(x, float) else x
+
+
+def summarize_leg(leg):
+    """value / ms / roofline fraction of a leg in a few dozen bytes."""
+    if not isinstance(leg, dict) or "error" in leg:
+        return {"error": (leg or {}).get("error", "?")[:80]} if isinstance(leg, dict) else None
+    out = {"value": _r(float(leg["value"]), 1), "unit": leg.get("unit"), "ms": _r(leg.get("ms_per_step"), 5)}
+    rf = leg.get("roofline") or {}
+    if rf:
+        out["bound"] = rf.get("bound")
+        # HBM-bound steps: the whole step against SURVEY 8d's algorithmic bytes; MFMA-bound: executed flops / op time
+        out["frac"] = _r((rf.get("step") or {}).get("frac", rf.get("frac")))
+        dom = rf.get("dominant_kernel")
+        if dom:
+            out["kernel_frac"] = {k: v.get("frac_of_8TBps", v.get("frac_of_2.5PF")) for k, v in dom.items()}
+            out["kernel_us"] = {k: v.get("us") for k, v in dom.items()}
+        out["traffic"] = rf.get("traffic")
+    cb = leg.get("cpu_baseline")
+    if cb:
+        out["cpu"] = _r(float(cb["value"]), 1)
+    return out
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: re-exec this command line under torch.distributed.run, one rank
     per GPU on 127.0.0.1 (the container hostname may not resolve).  exec keeps stdout: rank 0's JSON line is ours."""
@@ -732,20 +783,35 @@ def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True
     torch.cuda.empty_cache()
     if hbm and kernel_timing and saturating:
         hbm["saturating_launch"] = saturating_gather_scatter(dev, min(V, 4_000_000), D)  # own table + accumulator
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc) and roofline is not None:
-        try:  # HBM bytes per launch of the dominant kernel group, from the committed --pmc passes
-            key = workload
-            if workload == "inbatch" and path != "f16x2":  # the committed counters are the default (f16x2) path's
-                key = "inbatch_" + (path or "f32")
-            entry = json.load(open(pmc)).get(key)
-            roofline["traffic"] = entry.get(roofline["kernel"]) if isinstance(entry, dict) else entry
-        except Exception:
-            pass
     if roofline is not None:
-        pk = per_kernel_from_profile(workload, path, B, D, cfg)
-        if pk:
-            roofline["per_kernel_rocprof"] = pk
+        # HBM bytes per step from the committed --pmc passes: only for the exact (workload, batch, path) they were taken on
+        tkey = "%s|B=%d" % (workload, B) + ("|%s" % (path or "f32") if workload == "inbatch" else "")
+        plain = cfg.get("ids", "uniform") == "uniform" and cfg.get("table_dtype", "f32") == "f32" and \
+            V == WORKLOADS[workload]["V"] and D == WORKLOADS[workload]["D"]
+        roofline["traffic"] = pmc_traffic(tkey) if plain else None
+        roofline["traffic_source"] = ("profiles/pmc_traffic.json[%r] (rocprofv3 --pmc passes of this workload and batch, "
+                                      "committed; not collected in this run)" % tkey) if roofline["traffic"] else None
+    per_kernel = None
+    if kernel_timing:
+        # every kernel launch of the library timed by the library's own HIP events, in this run, on a fresh state
+        st2, b2 = make_state_and_batches(workload, cfg, dev, min(K, 40) + 8, rank)
+        holder = {"s": st2}
+
+        def _one(i):
+            holder["s"], _ = run_step(workload, holder["s"], b2[8 + i], B)
+        for i in range(8):
+            holder["s"], _ = run_step(workload, holder["s"], b2[i], B)
+        per_kernel = library_kernel_times(_one, len(b2) - 8)
+        del st2, b2, holder
+        torch.cuda.empty_cache()
+        if roofline is not None:
+            roofline["per_kernel_in_run"] = {"source": "esr_kernel_timing: HIP events around every launch, this run, "
+                                                       "per-step calls of the drop-in train_step",
+                                             "us": {k: v["us"] for k, v in per_kernel.items()},
+                                             "launches_per_step": {k: v["launches_per_step"] for k, v in per_kernel.items()}}
+            dom = dominant_kernel_roofline(workload, path, per_kernel, B, D)
+            if dom:
+                roofline["dominant_kernel"] = dom
     return {
         "value": B * K / dt, "unit": cfg["unit"] + "s/s", "steps": K, "warmup": warmup, "ms_per_step": dt / K * 1e3,
         "config": {"workload": "%s: V=%d x D=%d %s tables, B=%d, sparse Adagrad"
@@ -790,36 +856,48 @@ def secondary_legs(args, dev, rank):
             leg = {"error": "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")}
             torch.cuda.synchronize()
         out[name] = leg
+        emit_leg(name, leg)
     # the headline config on the exact-f32 MFMA score kernel (v_mfma_f32_32x32x2_f32, esr_inbatch.hip): no split-precision
     # caveat at all -- what the f16 x 2 default is to be compared with
     global PRECISION
     keep = PRECISION
+
+    def guarded(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as e:  # a secondary leg must never take the headline line down
+            out[name] = {"error": "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")}
+            torch.cuda.synchronize()
+        emit_leg(name, out[name])
+
     try:
         PRECISION = "f32"
         cfg = dict(WORKLOADS["inbatch"], table_dtype="f32", ids="uniform")
-        out["inbatch_c2_exact_f32"] = measure_training("inbatch", cfg, dev, rank, max(k, 60), max(w, 10),
-                                                       kernel_timing=True, saturating=False)
-    except Exception as e:
-        out["inbatch_c2_exact_f32"] = {"error": "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")}
-        torch.cuda.synchronize()
+        guarded("inbatch_c2_exact_f32", lambda: measure_training("inbatch", cfg, dev, rank, max(k, 60), max(w, 10),
+                                                                 kernel_timing=True, saturating=False))
     finally:
         PRECISION = keep
-    try:
-        from bench_retrieve import measure_retrieve
-        out["retrieve_c5_n1m_k500"] = measure_retrieve(dev, n_local=1_048_576, steps=3, warmup=1, mode="f16x2",
-                                                       with_cpu=not args.no_cpu_baseline, with_ann=False)
-    except Exception as e:
-        out["retrieve_c5_n1m_k500"] = {"error": "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")}
-    try:  # config 5's "ANN scoring vs brute force": the IVF index against the exact answer on the same corpus
-        from bench_retrieve import measure_ivf
-        out["retrieve_c5_n1m_ivf_vs_brute_force"] = measure_ivf(dev, corpus="clustered")
-        out["retrieve_c5_n1m_ivf_vs_brute_force"]["iid_corpus_worst_case"] = measure_ivf(dev, ks=(10,), nprobes=(32,),
-                                                                                         steps=2, corpus="iid")
-    except Exception as e:
-        out["retrieve_c5_n1m_ivf_vs_brute_force"] = {"error": "%s: %s" % (type(e).__name__,
-                                                                          str(e).splitlines()[0][:200] if str(e) else "")}
-        torch.cuda.synchronize()
+    from bench_retrieve import measure_ivf, measure_retrieve
+    # C5 brute force on the library's default ("exact" = three bf16 planes) and on the f32-grade fp16 x 2 planes
+    guarded("retrieve_c5_n1m_k500_exact", lambda: measure_retrieve(dev, n_local=1_048_576, steps=3, warmup=1, mode="exact",
+                                                                   with_cpu=not args.no_cpu_baseline, with_ann=False))
+    guarded("retrieve_c5_n1m_k500_f16x2", lambda: measure_retrieve(dev, n_local=1_048_576, steps=3, warmup=1, mode="f16x2",
+                                                                   with_cpu=False, with_ann=False))
+
+    def ivf():  # config 5's "ANN scoring vs brute force": the IVF index against the EXACT answer on the same corpus
+        r = measure_ivf(dev, corpus="clustered")
+        r["iid_corpus_worst_case"] = measure_ivf(dev, ks=(10,), nprobes=(32,), steps=2, corpus="iid")
+        return r
+    guarded("retrieve_c5_n1m_ivf_vs_brute_force", ivf)
     return out
+
+
+def summarize_ivf(r):
+    if not isinstance(r, dict) or "error" in r:
+        return r
+    return {"corpus": r.get("corpus"), "nlist": r.get("nlist"),
+            "legs": [{"k": x["k"], "nprobe": x.get("nprobe"), "ms": _r(x["ms"], 3), "recall": _r(x["recall_at_k_vs_exact"]),
+                      "x_brute": _r(x["speedup_vs_brute_force"], 2)} for x in r.get("legs", [])]}
 
 
 def main():
@@ -906,22 +984,45 @@ def main():
     else:
         leg = measure_training(args.workload, cfg, dev, rank, args.steps, args.warmup,
                                kernel_timing=not args.no_kernel_timing, graph=args.graph)
+    rf = leg["roofline"] or {}
+    # the final line stays under 6 KB (the driver keeps the tail of stdout); the full record of the headline leg and of
+    # every secondary leg is printed as its own line above it
+    emit_leg("headline_full", {k: leg[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline",
+                                                   "kernels", "hbm_gather_scatter")})
+    keep_rf = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "timed_over",
+               "executed_cross_terms", "f32_equivalent_TFLOPs", "sustained_live_data_TFLOPs", "frac_of_sustained",
+               "dominant_kernel", "step")
+    roof = {k: (_r(v) if not isinstance(v, dict) else v) for k, v in rf.items() if k in keep_rf}
+    if rf.get("per_kernel_in_run"):
+        roof["per_kernel_us_in_run"] = rf["per_kernel_in_run"]["us"]
+    sat = (leg.get("hbm_gather_scatter") or {}).get("saturating_launch") or {}
     out = {"metric": "training pairs/sec", "value": leg["value"], "unit": leg["unit"], "n_gpus": 1,
            "steps": leg["steps"], "warmup": leg["warmup"], "ms_per_step": leg["ms_per_step"],
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": leg["config"], "roofline": leg["roofline"], "kernels": leg["kernels"],
-           "hbm_gather_scatter": leg["hbm_gather_scatter"]}
+           "config": leg["config"], "roofline": roof}
+    if sat:
+        out["hbm_gather_scatter"] = {k: _r(float(sat[k]), 3) for k in ("gather_GBps", "gather_frac_of_8TBps",
+                                                                       "sparse_adagrad_GBps", "sparse_adagrad_frac_of_8TBps",
+                                                                       "box_stream_read_GBps") if k in sat}
+        out["hbm_gather_scatter"]["what"] = "the step's gather / sparse-Adagrad kernels at %d rows per launch" % sat.get("rows_per_launch", 0)
     src = steady if steady is not None else leg
     out["steady_state"] = {"value": src["value"], "unit": src["unit"], "steps": src["steps"], "warmup": src["warmup"],
                            "ms_per_step": src["ms_per_step"],
                            "order": "ran before the headline leg (own state, own batches)" if steady is not None
                            else "the headline leg itself (>= %d steps)" % STEADY_STEPS}
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.workload, cfg)
+        cb = cpu_baseline(args.workload, cfg)
+        emit_leg("headline_cpu_baseline_full", cb)
+        out["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                               "sample": cb["sample"], "cpu_model": cb["cpu_model"],
+                               "dense_reference_faithful_value": cb["dense_reference_faithful"]["value"]}
     plain_headline = (args.workload == "inbatch" and not args.rows and not args.batch and args.ids == "uniform" and
                       args.table_dtype == "f32" and not args.graph)
     if plain_headline and not args.no_secondary and not args.no_kernel_timing:
-        out["secondary"] = secondary_legs(args, dev, rank)
+        sec = secondary_legs(args, dev, rank)
+        out["secondary"] = {name: (summarize_ivf(v) if name.endswith("ivf_vs_brute_force") else summarize_leg(v))
+                            for name, v in sec.items()}
+        out["secondary"]["_note"] = "one-line summaries; each leg's full record is its own JSON line above ({\"leg\": name, ...})"
     emit(out)
 
 
