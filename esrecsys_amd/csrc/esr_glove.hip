@@ -251,9 +251,14 @@ struct GlovePlan {
   int* flags;                  // [0] parked: set by the update kernel when it parks a chunk partial
   unsigned long long* stat;    // 16-byte-apart words at 128 B stride: [0] sum s hi, [16] lo, [32] sum s^2 hi, [48] lo,
                                // [64] arrivals, [80] poison; zero before the update kernel
+  unsigned long long* fin;     // kFinWords: the update kernel's loss sums (fin_arrive) -- six order-free integer
+                               // accumulators, an arrival word and a poison word; zero before the update kernel
   float4* meta;                // [n]  {partner id | side bit (bits), w, log10(1 + c), unused}
 };
 constexpr int kStatWords = 96;
+constexpr int kFinAccs = 6;                                // (sum w, sum w r, sum w q^2) x (hi, lo)
+constexpr int kFinWords = kFinAccs * kFixAccWords + 32;    // + [0] arrivals of finished accumulators, [16] poison
+constexpr int64_t kFinFuseMaxIds = 8192;  // lists up to this long: the update kernel's last workgroup is the finalize step
 static size_t glove_plan_layout(int64_t B, char* base, GlovePlan* out) {
   const int64_t n = 2 * B;
   size_t off = 0;
@@ -265,6 +270,7 @@ static size_t glove_plan_layout(int64_t B, char* base, GlovePlan* out) {
   GlovePlan pl;
   pl.flags = (int*)take(sizeof(int) * 64);
   pl.stat = (unsigned long long*)take(sizeof(unsigned long long) * kStatWords);
+  pl.fin = (unsigned long long*)take(sizeof(unsigned long long) * kFinWords);
   pl.meta = (float4*)take(sizeof(float4) * (size_t)n);
   if (out) *out = pl;
   return off;
@@ -336,10 +342,13 @@ __global__ __launch_bounds__(kBlock) void glove_plan_kernel(GlovePlanBatch pb, c
   char* base = plans + (size_t)list * plan_stride;
   int* flags = (int*)base;
   unsigned long long* stat = (unsigned long long*)(base + 256);
-  float4* meta = (float4*)(base + 256 + align_up(sizeof(unsigned long long) * kStatWords, 256));
+  const size_t kFinOff = 256 + align_up(sizeof(unsigned long long) * kStatWords, 256);
+  unsigned long long* fin = (unsigned long long*)(base + kFinOff);
+  float4* meta = (float4*)(base + kFinOff + align_up(sizeof(unsigned long long) * kFinWords, 256));
   if (blockIdx.x == 0) {
     if (threadIdx.x < 64) flags[threadIdx.x] = 0;
     if (threadIdx.x < kStatWords) stat[threadIdx.x] = 0ull;
+    for (int i = threadIdx.x; i < kFinWords; i += kBlock) fin[i] = 0ull;
   }
   bool long_run = false;
   for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock) {
@@ -442,6 +451,76 @@ __device__ __forceinline__ void glove_rec_tables(const uint8_t* __restrict__ loc
   r.b1 = bias[partner];
 }
 
+// ---- the update kernel's loss sums, order-free and exact, with the arrival of the last workgroup known -----------------
+// Thread a < kFinAccs of every workgroup adds its share of sum (a / 2) to accumulator a -- a hi part at 2^-8 and a lo
+// part at 2^-50 of what the hi part left (both exact integers: the totals do not depend on the order of arrival) --
+// through the two-level counted words of fixed_sum_arrive (esr_versioned.h): one integer atomic per accumulator and
+// workgroup, whose return value says whether the word is complete; the completer forwards the word's total to the
+// accumulator's master word, whose low 11 bits count the words that have arrived: a reader that sees nwords there has
+// the total in the same load (fin_poll).  Data flows through atomic return values and that one word only.
+// Range: |sum| < 2^43 (beyond it, or non-finite: the poison word is raised and the loss comes out NaN).
+__device__ __forceinline__ unsigned fin_nwords(unsigned nblocks) {
+  return nblocks < (unsigned)kFixWords ? nblocks : (unsigned)kFixWords;
+}
+__device__ __forceinline__ void fin_arrive(unsigned long long* fin, int a, double v, unsigned nblocks) {
+  unsigned long long* acc = fin + a * kFixAccWords;
+  unsigned long long* tail = fin + kFinAccs * kFixAccWords;
+  const unsigned wd = blockIdx.x % kFixWords;
+  const unsigned on_word = (nblocks - wd + kFixWords - 1) / kFixWords;
+  const double h = rint(ldexp(v, 8));
+  const double payload = (a & 1) ? rint(ldexp(v - ldexp(h, -8), 50)) : h;  // |v - h 2^-8| <= 2^-9: lo <= 2^41
+  unsigned long long add = ((unsigned long long)__double2ll_rn(payload)) << 11;
+  if (!(fabs(h) < 2251799813685248.0)) {  // 2^51: non-finite or out of range
+    const unsigned r = atomicOr(reinterpret_cast<unsigned*>(tail + 16), 1u);  // raised BEFORE this workgroup is counted
+    add = (unsigned long long)(r >> 1);
+  }
+  const unsigned long long old = atomicAdd(acc + 16 * (1 + wd), add + 1ull);
+  if ((unsigned)(old & 2047ull) != on_word - 1) return;
+  const unsigned long long word_total = ((old + add) >> 11) << 11;
+  atomicAdd(acc, word_total + 1ull);
+}
+// accumulator a's master word once all its words have arrived (the payload is the word's upper 53 bits); false after
+// `ticks` of the 100 MHz clock
+__device__ __forceinline__ bool fin_poll(const unsigned long long* fin, int a, unsigned nblocks, unsigned long long ticks,
+                                         long long* payload) {
+  const unsigned nwords = fin_nwords(nblocks);
+  const unsigned long long t_start = wall_clock64();
+  unsigned long long m;
+  while ((unsigned)((m = coherent_load(fin + a * kFixAccWords)) & 2047ull) != nwords) {
+    __builtin_amdgcn_s_sleep(1);
+    if (wall_clock64() - t_start > ticks) return false;
+  }
+  *payload = ((long long)m) >> 11;  // arithmetic shift: signed
+  return true;
+}
+// sum s (0..2) once every accumulator is complete
+__device__ __forceinline__ double fin_value(const unsigned long long* fin, int s) {  // (a later launch: all words have arrived)
+  const long long hi = ((long long)coherent_load(fin + (2 * s) * kFixAccWords)) >> 11;       // arithmetic shifts: signed
+  const long long lo = ((long long)coherent_load(fin + (2 * s + 1) * kFixAccWords)) >> 11;
+  return ldexp((double)hi, -8) + ldexp((double)lo, -50);
+}
+__device__ __forceinline__ bool fin_poisoned(const unsigned long long* fin) {
+  return coherent_load(reinterpret_cast<const unsigned*>(fin + kFinAccs * kFixAccWords + 16)) != 0u;
+}
+
+// sum w (r - center)^2 from what the update kernel's third accumulator holds: reference mode -- sum w r^2, and
+// sum w (r - sbar)^2 = sum w r^2 - 2 sbar sum w r + sbar^2 sum w with the f32 sbar the gradients used; diagonal mode --
+// the sum itself
+__device__ __forceinline__ double glove_swq(int mode, double Bd, double Sw, double Swr, double S3, double sum_s) {
+  if (mode != ESR_GLOVE_REFERENCE) return S3;
+  const double sb = (double)(float)(sum_s / Bd);
+  const double v = S3 - 2.0 * sb * Swr + sb * sb * Sw;
+  return v < 0.0 ? 0.0 : v;
+}
+// the loss scalar from the batch sums (glove_finalize_kernel's formula)
+__device__ __forceinline__ float glove_loss_value(int mode, double Bd, double Sw, double Swq, double sum_s, double sum_s2,
+                                                  bool poisoned) {
+  if (mode != ESR_GLOVE_REFERENCE) return (float)(poisoned ? __builtin_nan("") : Swq / Bd);
+  double SS = sum_s2 - sum_s * sum_s / Bd;
+  if (SS < 0.0) SS = 0.0;
+  return (float)(poisoned ? __builtin_nan("") : (Bd * Swq + Sw * SS) / (Bd * Bd));
+}
+
 // update: the structure of segment_update_kernel (esr_optim.hip) with the gradient rows produced on the fly.
 // A group's critical path per position is ONE memory round trip: plan records run three positions ahead, the bytes and
 // bias values they point at two, and the own row, its accumulator and the first partner row of the NEXT position are
@@ -453,18 +532,25 @@ __global__ __launch_bounds__(kBlock) void glove_step_kernel(
     const float* __restrict__ bias, int D, int G, const int32_t* __restrict__ sorted_ids,
     const float4* __restrict__ meta, const int32_t* __restrict__ inputs, int64_t n, int64_t B, int mode, uint32_t T,
     int nstat, unsigned long long* __restrict__ stat, float lr, float eps, float* __restrict__ chunk_rows,
-    double2* __restrict__ bias_info, double* __restrict__ pair_part, int* __restrict__ parked,
+    double2* __restrict__ bias_info, unsigned long long* __restrict__ fin, int fuse_fin, float* __restrict__ bias_rw,
+    float* __restrict__ bias_accum, float* __restrict__ loss, int* __restrict__ parked,
     uint32_t* __restrict__ start_flag, uint32_t start_value) {
+  // fuse_fin (the caller knows that no run outgrows its head chunk, and the list is short): the workgroup that arrives
+  // last at the loss sums IS the finalize step -- loss scalar and the bias table's Adagrad -- and no launch follows.
   __shared__ double sm[16];
+  __shared__ int sm_last;
   announce_start(start_flag, start_value);
   const int lig = threadIdx.x & (G - 1);
   const int64_t gpb = kBlock / G;
-  const int64_t group = (int64_t)blockIdx.x * gpb + threadIdx.x / G;
-  const int64_t ngroups = (int64_t)gridDim.x * gpb;
+  // The first nstat workgroups (reference mode) ONLY sum the bias statistics (round 4): they used to walk a slice of
+  // positions afterwards and, two memory round trips and a reduction behind everybody else, were the launch's tail.
+  const int64_t wg = (int64_t)blockIdx.x - nstat;
+  const int64_t group = wg * gpb + threadIdx.x / G;
+  const int64_t ngroups = ((int64_t)gridDim.x - nstat) * gpb;
   const int nvec = D / VEC;
   const int64_t per = (n + ngroups - 1) / ngroups;  // contiguous slices (see segment_update_kernel)
-  const int64_t p_begin = group * per, p_end = min(n, (group + 1) * per);
-  // the records of the first three positions are requested before the statistics are summed
+  const int64_t p_begin = wg < 0 ? 0 : min(n, group * per), p_end = wg < 0 ? 0 : min(n, (group + 1) * per);
+  // the records of the first three positions are requested before anything else
   GloveRec r0{0, make_float4(0.f, 0.f, 0.f, 0.f), 0, 0, 0.f, 0.f}, r1 = r0, r2 = r0;
   uint32_t prev_n = 0xFFFFFFFFu;
   if (p_begin < p_end) {
@@ -484,7 +570,6 @@ __global__ __launch_bounds__(kBlock) void glove_step_kernel(
   // The first nstat workgroups add their partials to two-word integer sums and count themselves in; every workgroup
   // (those too) then waits for the count.  Workgroups are dispatched in index order, so the ones everybody waits for
   // are never behind a waiting one; the data travels in the atomics, so no fence is needed.
-  double sum_s = 0.0;
   if (mode == ESR_GLOVE_REFERENCE) {
     if ((int)blockIdx.x < nstat) {
       double a = 0.0, a2 = 0.0;
@@ -522,24 +607,35 @@ __global__ __launch_bounds__(kBlock) void glove_step_kernel(
         atomicAdd(stat + 64, 1ull);  // (fixed2_add2 returns after its adds have been performed)
       }
     }
-    if (p_begin < p_end) {  // (the first positions' table reads travel while the statistics are awaited)
-      glove_rec_tables(loc, bias, r0);
-      if (p_begin + 1 < n) glove_rec_tables(loc, bias, r1);
-    }
-    if (threadIdx.x == 0) {
-      while (coherent_load(stat + 64) < (unsigned long long)nstat) __builtin_amdgcn_s_sleep(2);
-      const double v = fixed2_value(coherent_load(stat + 0), coherent_load(stat + 16));
-      sm[12] = coherent_load(reinterpret_cast<const unsigned*>(stat + 80)) ? __builtin_nan("") : v;
-    }
-    __syncthreads();
-    sum_s = sm[12];
-  } else if (p_begin < p_end) {
+  }
+  if (p_begin < p_end) {
     glove_rec_tables(loc, bias, r0);
     if (p_begin + 1 < n) glove_rec_tables(loc, bias, r1);
   }
-  const float sbar = (float)(sum_s / (double)B);
+  // Nobody waits for the statistics here (round 4).  In reference mode a row's gradient is
+  //   G = sum_j gdot_j partner_j,  gdot_j = -(2 w_j / B) (r_j - sbar)   =>   G = -(2 / B) (A - sbar C),
+  //   A = sum_j (w_j r_j) partner_j,  C = sum_j w_j partner_j:
+  // the walk accumulates A and C, which need no statistic, and sbar enters when a run is applied (or parked) -- by then
+  // the first workgroups have long published it: the wait (per wave, bounded) no longer sits in front of every row load.
+  // The loss sum follows the same way: sum w (r - sbar)^2 = sum w r^2 - 2 sbar sum w r + sbar^2 sum w (fp64, in finalize).
+  bool have_stats = mode != ESR_GLOVE_REFERENCE;
+  float sbar = 0.f;
+  auto need_stats = [&]() {
+    if (have_stats) return;
+    const unsigned long long t_start = wall_clock64();
+    bool ok = true;
+    while (coherent_load(stat + 64) < (unsigned long long)nstat) {
+      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t_start > 300000000ull) { ok = false; break; }  // 3 s: poison the loss, do not hang the queue
+    }
+    if (!ok && lig == 0) atomicOr(reinterpret_cast<unsigned*>(stat + 80), 1u);
+    const double v = fixed2_value(coherent_load(stat + 0), coherent_load(stat + 16));
+    const bool bad = !ok || coherent_load(reinterpret_cast<const unsigned*>(stat + 80)) != 0u;
+    sbar = (float)((bad ? __builtin_nan("") : v) / (double)B);
+    have_stats = true;
+  };
   const float two_over_B = 2.0f / (float)B;
-  double acc_w = 0.0, acc_wr = 0.0, acc_wq = 0.0;
+  double acc_w = 0.0, acc_wr = 0.0, acc_wq = 0.0;  // acc_wq: sum w r^2 (reference mode) / sum w (r - s)^2 (diagonal)
   auto emb_row = [&](uint32_t id, uint32_t byte) {
     return (loc_at_step_begin(byte, T) ? emb1 : emb0) + (int64_t)id * D;
   };
@@ -547,6 +643,12 @@ __global__ __launch_bounds__(kBlock) void glove_step_kernel(
   // rows of the NEXT position, requested before this position is computed
   bool have_next = false;
   RowRegs<VEC, NCH> nown, nfirst, na;
+  // the first run this group heads, kept for the in-launch finalize (fuse_fin)
+  int64_t h_p = -1;
+  uint32_t h_id = 0;
+  double h_bsum = 0.0, h_cnt = 0.0;
+  float h_w = 0.f, h_ac = 0.f;
+  bool h_more = false;
 
   for (int64_t p = p_begin; p < p_end; ++p) {
     const GloveRec cur = r0, nxt = r1;
@@ -587,26 +689,45 @@ __global__ __launch_bounds__(kBlock) void glove_step_kernel(
       row_load(na, accum + (int64_t)nxt.id * D, lig, G, nvec);
       have_next = true;
     }
+    RowRegs<VEC, NCH> gc;  // reference mode: C = sum w partner (g holds A = sum (w r) partner until the run ends)
     row_zero(g);
+    row_zero(gc);
     double bsum = 0.0;  // fp64: a hot token's bias gradient is a sum over thousands of occurrences
-    // one occurrence: gdot from the dot with its partner row; G += gdot * partner, the product rounded to f32 first
-    // (it used to be stored as a gradient row) and the additions strictly left to right
+    // one occurrence.  Diagonal mode: gdot from the dot with its partner row; G += gdot * partner, the product rounded
+    // to f32 first (it used to be stored as a gradient row), additions strictly left to right.  Reference mode: the two
+    // sbar-free sums A and C, same association.
     auto occ = [&](const GloveRec& r, const RowRegs<VEC, NCH>& part) {
       const float dot = group_sum(row_dot_partial(own, part), G);
       const float rr = r.m.z - dot;
       const float s = r.b0 + r.b1;  // Bias[t1] + Bias[t2] (an f32 addition commutes: either side gives K_A's bits)
-      const float center = (mode == ESR_GLOVE_REFERENCE) ? sbar : s;
-      const float gdot = -(two_over_B * r.m.y) * (rr - center);
+      if (mode == ESR_GLOVE_REFERENCE) {
+        const float wr = __fmul_rn(r.m.y, rr);
 #pragma unroll
-      for (int k = 0; k < NCH; ++k)
+        for (int k = 0; k < NCH; ++k)
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) g.v[k][e] = __fadd_rn(g.v[k][e], __fmul_rn(gdot, part.v[k][e]));
-      bsum += (double)((mode == ESR_GLOVE_REFERENCE) ? s : gdot);
-      if (lig == 0 && !(__float_as_uint(r.m.x) & kSideBit)) {  // every pair is seen from both sides: count it once
-        const double q = (double)rr - (double)center;
-        acc_w += (double)r.m.y;
-        acc_wr += (double)r.m.y * (double)rr;
-        acc_wq += (double)r.m.y * q * q;
+          for (int e = 0; e < VEC; ++e) {
+            g.v[k][e] = __fadd_rn(g.v[k][e], __fmul_rn(wr, part.v[k][e]));
+            gc.v[k][e] = __fadd_rn(gc.v[k][e], __fmul_rn(r.m.y, part.v[k][e]));
+          }
+        bsum += (double)s;
+        if (lig == 0 && !(__float_as_uint(r.m.x) & kSideBit)) {  // every pair is seen from both sides: count it once
+          acc_w += (double)r.m.y;
+          acc_wr += (double)r.m.y * (double)rr;
+          acc_wq += (double)r.m.y * (double)rr * (double)rr;
+        }
+      } else {
+        const float gdot = -(two_over_B * r.m.y) * (rr - s);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) g.v[k][e] = __fadd_rn(g.v[k][e], __fmul_rn(gdot, part.v[k][e]));
+        bsum += (double)gdot;
+        if (lig == 0 && !(__float_as_uint(r.m.x) & kSideBit)) {
+          const double q = (double)rr - (double)s;
+          acc_w += (double)r.m.y;
+          acc_wr += (double)r.m.y * (double)rr;
+          acc_wq += (double)r.m.y * q * q;
+        }
       }
     };
     occ(cur, first);
@@ -643,6 +764,26 @@ __global__ __launch_bounds__(kBlock) void glove_step_kernel(
     // (a run of one ends at p + 1, whose id is already in a register)
     const bool ends = q == n || (q == p + 1 ? nxt.id : (uint32_t)sorted_ids[q]) != id;
     if (lig == 0) bias_info[p] = make_double2(bsum, (double)(e_run - p));
+    if (head) {  // (fuse_fin: no run outgrows its head chunk -- every head holds its whole run)
+      if (h_p < 0) {
+        h_p = p;
+        h_id = id;
+        h_bsum = bsum;
+        h_cnt = (double)(e_run - p);
+        h_w = cur.b0;  // the bias value read at the start: nobody writes the table before the grid-wide wait
+        h_ac = (fuse_fin && lig == 0) ? bias_accum[id] : 0.f;
+      } else {
+        h_more = true;
+      }
+    }
+    if (mode == ESR_GLOVE_REFERENCE) {  // G = -(2 / B) (A - sbar C): the statistics enter here
+      need_stats();
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          g.v[k][e] = __fmul_rn(-two_over_B, __fsub_rn(g.v[k][e], __fmul_rn(sbar, gc.v[k][e])));
+    }
     if (head && ends) {
       step_apply<VEC, NCH>(emb0, emb1, loc, accum, code, T, own, a, g, D, lig, G, nvec, lr, eps);
     } else {  // a chunk of a long run: park the partial sum for glove_step_long_kernel
@@ -651,13 +792,62 @@ __global__ __launch_bounds__(kBlock) void glove_step_kernel(
       if (lig == 0) *parked = 1;  // (every writer stores the same value)
     }
   }
+  if (threadIdx.x == 0) sm_last = 0;
   const double tw = block_sum_d(acc_w, sm);
   const double twr = block_sum_d(acc_wr, sm + 4);
   const double twq = block_sum_d(acc_wq, sm + 8);
-  if (threadIdx.x == 0) {
-    pair_part[3 * blockIdx.x] = tw;
-    pair_part[3 * blockIdx.x + 1] = twr;
-    pair_part[3 * blockIdx.x + 2] = twq;
+  if (threadIdx.x == 0) {  // (block_sum_d hands the total to thread 0 only)
+    sm[12] = tw;
+    sm[13] = twr;
+    sm[14] = twq;
+  }
+  __syncthreads();
+  if (threadIdx.x < kFinAccs) fin_arrive(fin, threadIdx.x, sm[12 + (threadIdx.x >> 1)], gridDim.x);
+  if (!fuse_fin) return;
+  // ---- finalize inside this launch: every workgroup waits until the six accumulators are complete (the grid is one
+  // resident wave-set -- the prologue's statistics rely on the same -- so everybody arrives), then steps the bias rows of
+  // the runs ITS groups headed: their sums are its own, nothing crosses workgroups but the three totals.  The wait is
+  // bounded: on a timeout the loss is poisoned instead of the queue hung.
+  if (threadIdx.x < kFinAccs) {
+    long long pay = 0;
+    const bool ok = fin_poll(fin, threadIdx.x, gridDim.x, 300000000ull, &pay);  // 3 s
+    sm[threadIdx.x] = (double)pay;
+    if (!ok) sm_last = 1;  // (zeroed above, in front of the reductions' barriers)
+  }
+  __syncthreads();
+  const double Sw = ldexp(sm[0], -8) + ldexp(sm[1], -50), Swr = ldexp(sm[2], -8) + ldexp(sm[3], -50),
+               S3 = ldexp(sm[4], -8) + ldexp(sm[5], -50);
+  const bool timed_out = sm_last != 0;
+  const double Bd = (double)B;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const bool poisoned = timed_out || fin_poisoned(fin) ||
+                          (mode == ESR_GLOVE_REFERENCE && coherent_load(reinterpret_cast<const unsigned*>(stat + 80)) != 0u);
+    const double s1 = mode == ESR_GLOVE_REFERENCE ? fixed2_value(coherent_load(stat + 0), coherent_load(stat + 16)) : 0.0;
+    const double s2 = mode == ESR_GLOVE_REFERENCE ? fixed2_value(coherent_load(stat + 32), coherent_load(stat + 48)) : 0.0;
+    loss[0] = glove_loss_value(mode, Bd, Sw, glove_swq(mode, Bd, Sw, Swr, S3, s1), s1, s2, poisoned);
+  }
+  if (timed_out) return;
+  const double kk = 2.0 / (Bd * Bd);
+  if (lig == 0) {
+    auto bias_step = [&](uint32_t id, double vx, double vy, float w, float ac) {
+      const float gb = (float)((mode == ESR_GLOVE_REFERENCE) ? -kk * (vy * Swr - Sw * vx) : vx);
+      adagrad_elem(w, ac, gb, lr, eps);
+      bias_rw[id] = w;
+      bias_accum[id] = ac;
+    };
+    // the first run this group headed: everything but the totals was in registers before the wait
+    if (h_p >= 0) bias_step(h_id, h_bsum, h_cnt, h_w, h_ac);
+    if (h_more) {  // further heads of the slice (several positions per group: larger batches): from memory
+      uint32_t prev = (uint32_t)sorted_ids[h_p];
+      for (int64_t p = h_p + 1; p < p_end; ++p) {
+        const uint32_t id = (uint32_t)sorted_ids[p];
+        const bool head = prev != id;
+        prev = id;
+        if (!head) continue;
+        const double2 v = bias_info[p];
+        bias_step(id, v.x, v.y, bias_rw[id], bias_accum[id]);
+      }
+    }
   }
 }
 
@@ -970,8 +1160,11 @@ __global__ __launch_bounds__(kBlock) void glove_step_long_kernel(
 __global__ __launch_bounds__(kBlock) void glove_step_finalize_kernel(
     int64_t B, int mode, const unsigned long long* __restrict__ stat, int nstat, const double* __restrict__ stat_part,
     int npair, const double* __restrict__ pair_part, const double* __restrict__ pair_tot,
-    const int32_t* __restrict__ sorted_ids, const double2* __restrict__ bias_info, float* __restrict__ bias,
-    float* __restrict__ bias_accum, float lr, float eps, float* __restrict__ loss) {
+    const unsigned long long* __restrict__ fin, const int32_t* __restrict__ sorted_ids,
+    const double2* __restrict__ bias_info, float* __restrict__ bias, float* __restrict__ bias_accum, float lr, float eps,
+    float* __restrict__ loss) {
+  // fin (short lists): the update kernel left the three loss sums in its integer accumulators (fin_arrive) -- the same
+  // totals its own last workgroup uses when it is the finalize step itself
   __shared__ double sm[16];
   // this thread's position: everything it needs from memory is requested before the reductions below
   const int64_t n = 2 * B;
@@ -990,7 +1183,12 @@ __global__ __launch_bounds__(kBlock) void glove_step_finalize_kernel(
     }
   }
   double Sw, Swr, Swq;
-  if (pair_tot) {  // reduced by the long-run launch
+  if (fin) {
+    Sw = fin_value(fin, 0);
+    Swr = fin_value(fin, 1);
+    Swq = glove_swq(mode, (double)B, Sw, Swr, fin_value(fin, 2),
+                    mode == ESR_GLOVE_REFERENCE ? fixed2_value(stat[0], stat[16]) : 0.0);
+  } else if (pair_tot) {  // reduced by the long-run launch
     Sw = pair_tot[0];
     Swr = pair_tot[1];
     Swq = pair_tot[2];
@@ -1021,14 +1219,14 @@ __global__ __launch_bounds__(kBlock) void glove_step_finalize_kernel(
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     double L;
     if (mode == ESR_GLOVE_REFERENCE) {
-      const bool poisoned = !stat_part && *reinterpret_cast<const unsigned*>(stat + 80) != 0u;
+      const bool poisoned = (!stat_part && *reinterpret_cast<const unsigned*>(stat + 80) != 0u) || (fin && fin_poisoned(fin));
       const double sum_s = stat_part ? rs : fixed2_value(stat[0], stat[16]);
       const double sum_s2 = stat_part ? rs2 : fixed2_value(stat[32], stat[48]);
       double SS = sum_s2 - sum_s * sum_s / Bd;
       if (SS < 0.0) SS = 0.0;
       L = poisoned ? __builtin_nan("") : (Bd * Swq + Sw * SS) / (Bd * Bd);
     } else {
-      L = Swq / Bd;
+      L = (fin && fin_poisoned(fin)) ? __builtin_nan("") : Swq / Bd;
     }
     loss[0] = (float)L;
   }
@@ -1253,7 +1451,8 @@ static void launch_glove_step(const GloveTables& t, const int32_t* inputs, const
     ESR_KT("glove_step_finalize_kernel", st, hipLaunchKernelGGL(glove_step_finalize_kernel, dim3(nfin), dim3(kBlock), 0, st, B, mode,
                        (const unsigned long long*)nullptr, nstat, (const double*)ws.stat_part, grid,
                        (const double*)ws.pair_part, long_runs != 0 ? (const double*)ws.pair_tot : (const double*)nullptr,
-                       sorted_ids, (const double2*)ws.bias_info, t.bias, t.bias_accum, lr, eps, loss));
+                       (const unsigned long long*)nullptr, sorted_ids, (const double2*)ws.bias_info, t.bias, t.bias_accum,
+                       lr, eps, loss));
     return;
   }
   if (!plan) {  // no plan made ahead: make it here (and nobody told us whether a run is long: screen for it)
@@ -1264,6 +1463,11 @@ static void launch_glove_step(const GloveTables& t, const int32_t* inputs, const
   GlovePlan pl;
   glove_plan_layout(B, (char*)plan, &pl);
   const int nstat = mode == ESR_GLOVE_REFERENCE ? (int)std::min<int64_t>(kStatBlocksStep, cdiv(B, kBlock)) : 0;
+  // no run outgrows its head chunk (the plan's hint) and the list is short: the update kernel's last workgroup is the
+  // finalize step (ESR_GLOVE_FIN_FUSED=0 keeps the launch)
+  const char* fin_env = getenv("ESR_GLOVE_FIN_FUSED");
+  const bool fin_fused_on = !(fin_env && fin_env[0] == '0');
+  const bool fuse_fin = fin_fused_on && long_runs == 0 && n <= kFinFuseMaxIds;
   ESR_DISPATCH_ROW(g, {
     // one resident wave-set: every group walks a contiguous slice, so a grid larger than what the chip holds at once
     // only adds a second, partly filled round (94 VGPRs -> 5 blocks per CU: 2048 blocks ran as 1280 + 768); the
@@ -1271,20 +1475,21 @@ static void launch_glove_step(const GloveTables& t, const int32_t* inputs, const
     static const int resident_all = resident_blocks((const void*)glove_step_kernel<VEC, NCH>, 0);  // (one query)
     const int resident = blocks_per_cu > 0 ? resident_blocks((const void*)glove_step_kernel<VEC, NCH>, blocks_per_cu)
                                            : resident_all;
-    grid = std::max(nstat, std::min(grid, resident));
+    grid = std::min(grid + nstat, std::max(resident, nstat + 1));  // nstat statistics-only workgroups in front
     ESR_KT("glove_step_kernel", st, hipLaunchKernelGGL((glove_step_kernel<VEC, NCH>), dim3(grid), dim3(kBlock), 0, st, t.emb, t.emb_shadow, t.emb_loc,
                        t.emb_accum, (const float*)t.bias, D, g.G, sorted_ids, (const float4*)pl.meta, inputs, n, B, mode,
-                       stamp, nstat, pl.stat, lr, eps, ws.chunk_rows, ws.bias_info, ws.pair_part, pl.flags, start_flag,
-                       start_value));
+                       stamp, nstat, pl.stat, lr, eps, ws.chunk_rows, ws.bias_info, pl.fin, fuse_fin ? 1 : 0, t.bias,
+                       t.bias_accum, loss, pl.flags, start_flag, start_value));
     if (long_runs != 0)  // 0 = the caller knows (esr_glove_plan's hint) that no run outgrows its head chunk
       ESR_KT("glove_step_long_kernel", st, hipLaunchKernelGGL((glove_step_long_kernel<VEC, NCH>), dim3(grid2), dim3(kBlock), 0, st, t.emb, t.emb_shadow,
                          t.emb_loc, t.emb_accum, D, g.G, sorted_ids, n, stamp, lr, eps, (const float*)ws.chunk_rows,
                          ws.bias_info, (const int*)pl.flags, 0, (const double*)nullptr, (double*)nullptr));
   });
-  ESR_KT("glove_step_finalize_kernel", st, hipLaunchKernelGGL(glove_step_finalize_kernel, dim3(nfin), dim3(kBlock), 0, st, B, mode,
-                     (const unsigned long long*)pl.stat, 0, (const double*)nullptr, grid, (const double*)ws.pair_part,
-                     (const double*)nullptr, sorted_ids, (const double2*)ws.bias_info, t.bias, t.bias_accum, lr, eps,
-                     loss));
+  if (!fuse_fin)
+    ESR_KT("glove_step_finalize_kernel", st, hipLaunchKernelGGL(glove_step_finalize_kernel, dim3(nfin), dim3(kBlock), 0, st, B, mode,
+                       (const unsigned long long*)pl.stat, 0, (const double*)nullptr, grid, (const double*)nullptr,
+                       (const double*)nullptr, (const unsigned long long*)pl.fin, sorted_ids,
+                       (const double2*)ws.bias_info, t.bias, t.bias_accum, lr, eps, loss));
 }
 
 #define ESR_GLOVE_STEP_CHECKS(who)                                                                                    \

@@ -1685,7 +1685,8 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
          hipLaunchKernelGGL((inbatch3_merge_kernel<false>), dim3(mgrid), dim3(kBlock), 0, st, Cs, Qs, gc_rows, B, nsplit_c,
                             (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale,
                             regularization, inv_bs, ws.lse2, (float*)nullptr, gC, ws.loss_acc,
-                            1.0 / (double)batch_size, loss, (float*)nullptr, (const float*)(ws.sc + 2), 1.0f));
+                            1.0 / (double)batch_size, loss, (float*)nullptr, (const float*)(ws.sc + 2), 1.0f,
+                            (float*)nullptr, fused ? ws.ent : (unsigned long long*)nullptr, nchunks));
   return check_launch(who);
 }
 

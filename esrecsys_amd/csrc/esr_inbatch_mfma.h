@@ -141,12 +141,17 @@ __global__ __launch_bounds__(kBlock) void inbatch3_merge_kernel(
     float* __restrict__ lse2, float* __restrict__ lse_nat, float* __restrict__ gX,
     unsigned long long* __restrict__ loss_acc, double loss_scale, float* __restrict__ loss_out,
     float* __restrict__ invl, const float* __restrict__ oscale_ptr = nullptr, float invl_scale = 1.0f,
-    float* __restrict__ fac = nullptr) {
+    float* __restrict__ fac = nullptr, unsigned long long* __restrict__ zero_words = nullptr, int nzero = 0) {
+  // zero_words (fp16 x 2 path, the op's LAST launch): prepsplit2h_kernel's tagged per-chunk words are cleared for the next
+  // call on this workspace -- a replayed hipGraph repeats the call's token, and a word left by the previous replay would
+  // pass for this one's
   // fac (fp16 x 2 path, QSIDE): [nsplit][B] factors invl_scale * 2^(M_split - M) / l for the stored-P pass C, whose
   // probabilities carry the reference of the split that wrote them
   // oscale_ptr (fp16 x 2 path): a power of two that undoes the plane scaling of the partial O rows (device-side: it
   // depends on the largest |element| of the batch); invl_scale: a power of two folded into the stored 1 / l_i
   __shared__ double sm[4];
+  if (zero_words && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < nzero; i += kBlock) zero_words[i] = 0ull;
   const float oscale = oscale_ptr ? oscale_ptr[0] : 1.0f;
   constexpr int G = 32;
   const int lig = threadIdx.x & (G - 1);

@@ -321,3 +321,24 @@ def test_train_epoch_mixed_grouped_and_side_stream_batches(dev, monkeypatch):
     assert la == lb
     assert torch.equal(a.params["_token_embedding"]["embedding"], b.params["_token_embedding"]["embedding"])
     assert torch.equal(a.params["_bias"]["embedding"], b.params["_bias"]["embedding"])
+
+
+@pytest.mark.parametrize("mode", ["reference", "diagonal"])
+@pytest.mark.parametrize("V,D,B,K", [(465_537, 256, 2048, 120), (3000, 64, 4096, 40), (100_000, 128, 300, 64)])
+def test_last_workgroup_finalize_equals_finalize_launch(dev, mode, V, D, B, K, monkeypatch):
+    """Short lists whose plan says that no run outgrows its head chunk: the update kernel's last-arriving workgroup is the
+    finalize step (loss scalar + the bias table's Adagrad read the other workgroups' sums through the memory side).  Bit
+    for bit the epoch that keeps the finalize launch (ESR_GLOVE_FIN_FUSED=0), over enough steps and workgroups (1024
+    across the eight XCDs at the reference's default batch on the C3 table) that a stale read would show."""
+    import esrecsys_amd.wikipedia.train_cooccurence as tc
+    g = torch.Generator(device=dev).manual_seed(B + K)
+    batches = [(torch.randint(0, V, (2, B), generator=g, device=dev, dtype=torch.int32),
+                torch.exp(np.log(0.1) + torch.rand(B, generator=g, device=dev) * np.log(1e4))) for _ in range(K)]
+    monkeypatch.setenv("ESR_GLOVE_FIN_FUSED", "1")
+    a, la = tc.train_epoch(_make_state(V, D, mode, dev), K, iter(batches))
+    monkeypatch.setenv("ESR_GLOVE_FIN_FUSED", "0")
+    b, lb = tc.train_epoch(_make_state(V, D, mode, dev), K, iter(batches))
+    assert la == lb and np.isfinite(la)
+    assert torch.equal(a.params["_token_embedding"]["embedding"], b.params["_token_embedding"]["embedding"])
+    assert torch.equal(a.params["_bias"]["embedding"], b.params["_bias"]["embedding"])
+    assert torch.equal(a.opt_state["sum_of_squares"]["_bias"]["embedding"], b.opt_state["sum_of_squares"]["_bias"]["embedding"])
