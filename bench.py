@@ -306,7 +306,17 @@ def roofline_for(workload, kernels, B, D, rows, precision, occ_n=0, uniq=0, bf16
     fused_name = "triplet_fused" if workload == "triplet" else "glove_fused"
     fused_bytes = rows * B * D * 4 * 2  # reads `rows` rows and writes `rows` gradient rows per unit
     ada_bytes = (occ_n + 4 * uniq) * D * 4  # grad row read per occurrence + param/accum RMW per distinct row
-    cands = {fused_name: fused_bytes, "sparse_adagrad": ada_bytes}
+    cands = {fused_name: fused_bytes, "sparse_adagrad": ada_bytes,
+             # row-sharded steps: the update half as one library call ([segment sum ->] exchange -> segment-reduce + Adagrad)
+             "sharded_update": ada_bytes}
+    cands = {k: v for k, v in cands.items() if k in kernels}
+    if not cands:  # a row-sharded step issued as ONE library call: the whole step against SURVEY 8d's bytes
+        t = step_s if step_s else kernels["sharded_step"]["ms_per_step"] * 1e-3
+        alg = STEP_BYTES_PER_UNIT[workload](D) * B
+        return {"kernel": "esr_sharded_%s_step (lookup + loss kernel + [segment sum +] gradient exchange + owner-side "
+                          "segment-reduce + Adagrad, one library call)" % workload,
+                "bound": "hbm", "achieved": alg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": alg / t / 1e9 / HBM_PEAK_GBS, "traffic": None}
     name = max(cands, key=lambda k: kernels[k]["ms_per_step"])
     t = kernels[name]["ms_per_step"] * 1e-3
     return {"kernel": name, "bound": "hbm", "achieved": cands[name] / t / 1e9, "peak": HBM_PEAK_GBS,
@@ -324,6 +334,9 @@ TIMED_GROUPS = {
     "triplet_step": ["triplet_train_step"],
     "segment_sort": ["segment_sort", "segment_sort_multi"],
     "sparse_adagrad": ["sparse_adagrad", "sparse_adagrad_multi"],
+    "sharded_lookup": ["sharded_lookup"],
+    "sharded_update": ["sharded_update"],
+    "sharded_step": ["sharded_triplet_step", "sharded_glove_step"],
 }
 
 

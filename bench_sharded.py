@@ -104,18 +104,11 @@ def run_sharded(args, cfg, dev, rank, world):
                 for i in range(lo, hi):
                     loss = step(batches[i], None)
                 return loss
-        if plan_group > 1:
-            with quiet_gc():
-                groups = [(a, min(a + plan_group, hi)) for a in range(lo, hi, plan_group)]
-                pend = sharded.begin_plans([lookup(batches[i]) for i in range(*groups[0])])
-                loss = None
-                for gi, (a, b_) in enumerate(groups):
-                    plans = pend.finish()  # ids all-to-alls + owner-side sorts of the whole group, ahead of its steps
-                    pend = sharded.begin_plans([lookup(batches[i]) for i in range(*groups[gi + 1])]) \
-                        if gi + 1 < len(groups) else None
-                    for i in range(a, b_):
-                        loss = step(batches[i], plans[i - a])
-                return loss
+        if plan_group > 1:  # the library's loop helper (plans of plan_group coming batches made together)
+            grps = (emb, bias) if args.workload == "glove" else (towers,)
+            return sharded.sharded_train_steps(args.workload, grps, batches[lo:hi], regularization=LAM,
+                                               global_batch_size=gb, scale=SCALE, lr=LR, mode=ops.GLOVE_REFERENCE,
+                                               plan_group=plan_group)[-1]
         with quiet_gc():  # as the loop helpers: a full cyclic collection inside the loop is a 40 ms hole in the launches
             cur = begin(batches[lo]).finish()
             pend = begin(batches[lo + 1]) if lo + 1 < hi else None
@@ -189,7 +182,9 @@ def run_sharded(args, cfg, dev, rank, world):
             par = "row-sharded x1: a world of one rank takes the single-GPU steps on its shard (nothing is exchanged)"
         else:
             par = "row-sharded x%d, all-to-all ids/rows/grads over RCCL%s" % (
-                world, ", every distinct row once (unique plans)" if grp0.unique else "")
+                world, {"on": ", every distinct row once (unique plans)", "off": ", one row per occurrence",
+                        "auto": ", unique plans while this rank's measured distinct / occurrences < %.2f (now: %s)"
+                                % (sharded._UNIQUE_KEEP_BELOW, "unique" if grp0.unique else "per occurrence")}[grp0.unique_mode])
         emit({
             "metric": "training pairs/sec", "value": world * B * K / dt, "unit": cfg["unit"] + "s/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": dt / K * 1e3,

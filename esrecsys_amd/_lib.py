@@ -162,7 +162,28 @@ SIGNATURES = {
     "esr_alltoall_ids": (c_int, [c_vp, c_i32p, c_vp, c_i32p, c_vp, c_vp]),
     "esr_alltoall_rows": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "esr_alltoall_grads": (c_int, [c_vp, c_f32p, c_int, c_vp, c_f32p, c_vp, c_vp]),
+    "esr_sharded_lookup": (c_int, [c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "esr_sharded_update": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp,
+                                   c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_int, c_vp]),
+    "esr_sharded_triplet_step_workspace_bytes": (c_size, [c_vp, c_vp, c_i64]),
+    "esr_sharded_triplet_step": (c_int, [c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_size, c_vp]),
+    "esr_sharded_glove_step_workspace_bytes": (c_size, [c_vp, c_vp, c_vp, c_i64]),
+    "esr_sharded_glove_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_f32, c_f32, c_vp, c_vp, c_size, c_vp]),
 }
+
+
+class ShardGroupStruct(ctypes.Structure):
+    """esr_shard_group_t (include/esr_hip.h)"""
+    _fields_ = [("comm", ctypes.c_void_p), ("world", ctypes.c_int), ("tables", ctypes.c_void_p),
+                ("accums", ctypes.c_void_p), ("row_offsets", ctypes.c_void_p), ("ntables", ctypes.c_int),
+                ("dtype", ctypes.c_int), ("D", ctypes.c_int), ("grad_dtype", ctypes.c_int)]
+
+
+class RoutingPlanStruct(ctypes.Structure):
+    """esr_routing_plan_t (include/esr_hip.h)"""
+    _fields_ = [("asked_rows", ctypes.c_void_p), ("asked_counts", ctypes.c_void_p), ("ask_counts", ctypes.c_void_p),
+                ("index", ctypes.c_void_p), ("sorted_uidx", ctypes.c_void_p), ("occ_perm", ctypes.c_void_p),
+                ("owner_sorted", ctypes.c_void_p), ("owner_perm", ctypes.c_void_p), ("long_runs", ctypes.c_int)]
 
 
 class EsrLibraryError(RuntimeError):

@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ_DIR = os.path.join(CSRC, "build")
 LIB_PATH = os.path.join(HERE, "libesr_hip.so")
 SOURCES = ["esr_core.hip", "esr_glove.hip", "esr_triplet.hip", "esr_inbatch.hip", "esr_inbatch3.hip", "esr_inbatch2h.hip", "esr_optim.hip", "esr_sort.hip",
-           "esr_retrieve.hip", "esr_spotify.hip", "esr_comm.hip", "esr_triplet_step.hip", "esr_shard.hip", "esr_ivf.hip"]
+           "esr_retrieve.hip", "esr_spotify.hip", "esr_comm.hip", "esr_triplet_step.hip", "esr_shard.hip", "esr_shard_step.hip", "esr_ivf.hip"]
 HEADERS = [os.path.join(HERE, "..", "include", "esr_probe.h"), os.path.join(CSRC, "esr_common.h"), os.path.join(CSRC, "esr_versioned.h"), os.path.join(CSRC, "esr_inbatch_mfma.h"),
            os.path.join(HERE, "..", "include", "esr_hip.h")]
 ARCH = "gfx950"

@@ -1040,3 +1040,83 @@ def bucket_ids_by_owner(ids, world, want_inverse=False, offsets=None, counts_out
     if want_inverse:
         return local_rows, perm, counts, inverse
     return local_rows, perm, counts
+
+
+# ---- a row-sharded step's exchange halves, one library call each (esr_shard_step.hip) ----------------------------------
+def i64_array(values):
+    """host int64 array for the count / offset arguments of the sharded calls (made once per plan / group, reused)."""
+    import ctypes
+    return (ctypes.c_int64 * len(values))(*[int(v) for v in values])
+
+
+def ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def sharded_lookup(comm, world, tables_c, loff_c, ntables, dtype, D, asked_rows, asked_c, ask_c, served, back):
+    """esr_sharded_lookup: gather the rows asked of this rank + the rows exchange, on the current stream.  `comm`: the
+    DirectExchange communicator (ctypes.c_void_p) or None at world 1; served may be None at world 1."""
+    lib = _lib.load()
+    check(lib.esr_sharded_lookup(comm, world, tables_c, loff_c, ntables, dtype, D, _p(asked_rows), asked_c, ask_c,
+                                 _p(served) if served is not None else None, _p(back), _stream()),
+          "esr_sharded_lookup")
+    return back
+
+
+def sharded_update(comm, world, tables_c, accums_c, loff_c, ntables, dtype, D, grad_rows, sorted_uidx, occ_perm, summed,
+                   ask_c, asked_c, grad_dtype, send_bf16, recv_raw, recv_grads, owner_sorted, owner_perm, lr, eps=1e-7,
+                   long_runs=-1):
+    """esr_sharded_update: [per-distinct-row sum ->] gradient rows to their owners -> the owner's fused segment-reduce +
+    Adagrad, on the current stream."""
+    lib = _lib.load()
+    q = lambda t: _p(t) if t is not None else None  # noqa: E731
+    check(lib.esr_sharded_update(comm, world, tables_c, accums_c, loff_c, ntables, dtype, D, _p(grad_rows),
+                                 int(grad_rows.shape[0]), q(sorted_uidx), q(occ_perm), q(summed), ask_c, asked_c,
+                                 grad_dtype, q(send_bf16), q(recv_raw), q(recv_grads), q(owner_sorted), q(owner_perm),
+                                 float(lr), float(eps), int(long_runs), _stream()), "esr_sharded_update")
+
+
+def shard_group_struct(comm, world, tables_c, accums_c, loff_c, ntables, dtype, D, grad_dtype):
+    """esr_shard_group_t over the host arrays of ptr_array / i64_array (the caller keeps them -- and the tensors -- alive)."""
+    import ctypes
+    cast = lambda a: ctypes.cast(a, ctypes.c_void_p)  # noqa: E731
+    comm = getattr(comm, "value", comm)
+    return _lib.ShardGroupStruct(comm, world, cast(tables_c), cast(accums_c), cast(loff_c), ntables, dtype, D, grad_dtype)
+
+
+def routing_plan_struct(asked_rows, asked_c, ask_c, index, sorted_uidx, occ_perm, owner_sorted, owner_perm, long_runs=-1):
+    """esr_routing_plan_t of one batch (device tensors + the host count arrays; the caller keeps them alive)."""
+    import ctypes
+    cast = lambda a: ctypes.cast(a, ctypes.c_void_p)  # noqa: E731
+    q = lambda t: t.data_ptr() if t is not None and t.numel() else None  # noqa: E731
+    return _lib.RoutingPlanStruct(q(asked_rows), cast(asked_c), cast(ask_c), q(index), q(sorted_uidx), q(occ_perm),
+                                  q(owner_sorted), q(owner_perm), int(long_runs))
+
+
+def sharded_triplet_step(group_s, plan_s, B, regularization, batch_size, lr, eps, device):
+    """esr_sharded_triplet_step: lookup -> triplet loss on the rows where they landed -> update, one library call.
+    Returns loss [1] (this rank's share)."""
+    import ctypes
+    lib = _lib.load()
+    nb = int(lib.esr_sharded_triplet_step_workspace_bytes(ctypes.byref(group_s), ctypes.byref(plan_s), B))
+    ws = _ws(nb, device)
+    loss = torch.empty(1, dtype=torch.float32, device=device)
+    check(lib.esr_sharded_triplet_step(ctypes.byref(group_s), ctypes.byref(plan_s), B, float(regularization),
+                                       float(batch_size), float(lr), float(eps), _p(loss), _p(ws), ws.numel(), _stream()),
+          "esr_sharded_triplet_step")
+    return loss
+
+
+def sharded_glove_step(emb_s, bias_s, plan_s, target, B, mode, lr, eps):
+    """esr_sharded_glove_step: both lookups -> GloVe loss -> both updates, one library call.  Returns loss [1]."""
+    import ctypes
+    lib = _lib.load()
+    _req(target, torch.float32, "target")
+    nb = int(lib.esr_sharded_glove_step_workspace_bytes(ctypes.byref(emb_s), ctypes.byref(bias_s), ctypes.byref(plan_s), B))
+    ws = _ws(nb, target.device)
+    loss = torch.empty(1, dtype=torch.float32, device=target.device)
+    check(lib.esr_sharded_glove_step(ctypes.byref(emb_s), ctypes.byref(bias_s), ctypes.byref(plan_s), _p(target), B,
+                                     int(mode), float(lr), float(eps), _p(loss), _p(ws), ws.numel(), _stream()),
+          "esr_sharded_glove_step")
+    return loss

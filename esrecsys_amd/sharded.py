@@ -80,6 +80,23 @@ class RoutingPlan:
         self.uidx, self.sorted_uidx, self.occ_perm = unique if unique is not None else (None, None, None)
         self.recv_local_rows = None         # int32 [sum(recv_counts)]: virtual local rows requested of this rank
         self.owner_sorted = None            # (sorted, permutation) of recv_local_rows, for the update
+        self._c_counts = None               # (ask, asked) host int64 arrays for the one-call exchange halves
+        self._c_struct = None
+
+    def c_counts(self, k):
+        if self._c_counts is None:
+            self._c_counts = (k.i64_array(self.send_counts), k.i64_array(self.recv_counts))
+        return self._c_counts
+
+    def c_struct(self, k):
+        """esr_routing_plan_t of this plan (ids exchanged and sorted on the owner) for the one-call steps."""
+        if self._c_struct is None:
+            ask_c, asked_c = self.c_counts(k)
+            recv = self.exchange_ids()
+            srt, prm = self.owner_sorted if self.owner_sorted is not None else (None, None)
+            self._c_struct = k.routing_plan_struct(recv, asked_c, ask_c, self.index, self.sorted_uidx if self.unique else None,
+                                                   self.occ_perm if self.unique else None, srt, prm)
+        return self._c_struct
 
     @property
     def index(self):
@@ -140,6 +157,9 @@ class PendingPlans:
             self.plans = [RoutingPlan(group, n, local_rows, perm, both[0, :, i].tolist(), both[1, :, i].tolist(), inv,
                                       unique=part[6] if len(part) > 6 else None)
                           for i, part in enumerate(self.parts) for (group, n, local_rows, perm, _, inv) in [part[:6]]]
+            for p in self.plans:
+                if p.unique:
+                    p.group.observe_unique(p.n_rows, p.n)
             if not self._exchange_ids_grouped():
                 for p in self.plans:
                     p.exchange_ids()
@@ -147,6 +167,8 @@ class PendingPlans:
         return self.plans
 
 
+_UNIQUE_KEEP_BELOW = 0.8     # auto mode keeps asking for distinct rows while distinct / occurrences is below this
+_UNIQUE_PROBE_EVERY = 32     # ... and otherwise measures again after this many plan groups
 _OWNER_SORT_BATCH_MAX = 32768  # ids per list the batched owner-side sort takes (esr_segment_sort_ids_batched)
 
 
@@ -220,6 +242,8 @@ def begin_plans(lookups):
     g0 = lookups[0][0]
     k, G, L = g0.k, g0.world, len(lookups)
     dev = g0.tables[0].local.device
+    for g in {id(g): g for g, _ in lookups}.values():
+        g.planning()
     # [send | recv][peer][lookup]: all_to_all_single hands every peer its L counts; with one lookup (every step of this
     # package) the bucket kernel writes its counts straight into the send half -- no stack / cat / copy launches
     both = torch.empty((2, G, L), dtype=torch.int64, device=dev)
@@ -267,7 +291,7 @@ def make_plans(lookups):
 class ShardedTableGroup:
     """Same-width, same-dtype row-sharded tables that one step looks up and updates together."""
 
-    def __init__(self, tables, group=None, kernels=None, unique=None):
+    def __init__(self, tables, group=None, kernels=None, unique=None, grad_dtype=None):
         if kernels is None:
             from . import ops as kernels
         self.k = kernels
@@ -286,10 +310,19 @@ class ShardedTableGroup:
         # of once per occurrence.  A sender-side choice -- owners serve whatever list they get -- that pays where bytes
         # cross xGMI (world > 1) and ids repeat (GloVe's Zipfian stream: wikipedia/make_cooccurrence.py:33-55); at world
         # 1 it only adds the dedup and segment-sum launches.  ESR_SHARDED_UNIQUE=0 / 1 overrides.
+        # Default at world > 1: AUTO, a sender-side choice made per rank from the duplicate rate its own plans measure --
+        # the first plans are unique ones (they report distinct rows / occurrences); while that ratio stays above
+        # _UNIQUE_KEEP_BELOW (uniform ids at C2: 0.99 -- the dedup launches cost more than the rows they save) the rank
+        # asks per occurrence and probes again every _UNIQUE_PROBE_EVERY plan groups.  Owners never need to know.
         env = os.environ.get("ESR_SHARDED_UNIQUE", "")
-        self.unique = (unique if unique is not None else (self.world > 1)) if env == "" else env == "1"
-        if self.unique and not hasattr(kernels, "unique_by_owner"):
-            self.unique = False
+        can = hasattr(kernels, "unique_by_owner")
+        if env in ("0", "1"):
+            self.unique_mode = "on" if env == "1" and can else "off"
+        elif unique is not None:
+            self.unique_mode = "on" if unique and can else "off"
+        else:
+            self.unique_mode = "auto" if self.world > 1 and can else "off"
+        self._auto_unique, self._auto_skip = True, 0
         # A world of ONE rank has nothing to exchange: its steps are the single-GPU steps on the local shard (= the whole
         # table) -- the one-pass triplet / GloVe steps on double-buffered tables, the in-batch head straight from the
         # towers -- and no routing plan is made.  ESR_SHARDED_WORLD1_DIRECT=0 keeps the whole exchange machinery running
@@ -298,6 +331,71 @@ class ShardedTableGroup:
         self.world1_direct = self.world == 1 and os.environ.get("ESR_SHARDED_WORLD1_DIRECT", "1") == "1" and \
             hasattr(kernels, "triplet_train_step")
         self._versions = None
+        # gradient rows cross the exchange as f32, or as bf16 (rounded after the per-distinct-row sum, widened on the owner:
+        # element error <= 2^-9 relative; SURVEY 8d budgets bf16-sized gradients for config 4).  ESR_SHARDED_GRAD_DTYPE=bf16
+        self.grad_dtype = grad_dtype if grad_dtype is not None else os.environ.get("ESR_SHARDED_GRAD_DTYPE", "f32")
+        if self.grad_dtype not in ("f32", "bf16"):
+            raise ValueError("grad_dtype must be 'f32' or 'bf16', got %r" % (self.grad_dtype,))
+        self._c_tables = None
+        self._c_group_cache = None
+
+    @property
+    def unique(self):
+        """Does the NEXT plan of this group ask for every distinct row once?"""
+        return self.unique_mode == "on" or (self.unique_mode == "auto" and self._auto_unique)
+
+    def planning(self):
+        """begin_plans is about to make a group of plans for this group (auto mode: count down to the next probe)."""
+        if self.unique_mode == "auto" and not self._auto_unique:
+            self._auto_skip -= 1
+            if self._auto_skip <= 0:
+                self._auto_unique = True  # probe: the next plans are unique ones and report their duplicate rate
+
+    def observe_unique(self, n_rows, n_occ):
+        """A unique plan of this group came back with n_rows distinct rows for n_occ occurrences."""
+        if self.unique_mode == "auto" and n_occ > 0 and n_rows >= _UNIQUE_KEEP_BELOW * n_occ:
+            self._auto_unique, self._auto_skip = False, _UNIQUE_PROBE_EVERY
+
+    def _fused(self):
+        """(comm, tables_c, accums_c, loff_c, dtype code) when the exchange halves of a step run as ONE library call each
+        (esr_sharded_lookup / esr_sharded_update): CUDA shards and either a world of one rank or the direct RCCL exchange.
+        None: op by op through `kernels` and torch.distributed (the CPU doubles of the gloo tests, ESR_SHARDED_FUSED=0)."""
+        k = self.k
+        if not hasattr(k, "sharded_lookup") or os.environ.get("ESR_SHARDED_FUSED", "1") != "1" or \
+                not all(t.local.is_cuda for t in self.tables):
+            return None
+        comm = None
+        if self.world > 1:
+            x = self.exchange()
+            if x is None or not getattr(x, "comm", None):
+                return None
+            comm = x.comm
+        key = tuple(t.local.data_ptr() for t in self.tables) + tuple(t.accum.data_ptr() for t in self.tables)
+        if self._c_tables is None or self._c_tables[0] != key:
+            dts = {t.local.dtype for t in self.tables}
+            if len(dts) != 1 or not all(t.local.is_contiguous() and t.accum.is_contiguous() for t in self.tables):
+                return None
+            if len(self.tables) > 1 and (self.dim * self.tables[0].local.element_size()) % 16:
+                return None  # (the fused multi-table kernels move whole 16-byte chunks)
+            code = k.ESR_BF16 if dts.pop() == torch.bfloat16 else k.ESR_F32
+            self._c_tables = (key, k.ptr_array([t.local for t in self.tables]), k.ptr_array([t.accum for t in self.tables]),
+                              k.i64_array(self.loff), code)
+        _, tc, ac, lc, code = self._c_tables
+        return comm, tc, ac, lc, code
+
+    def _c_group(self):
+        """esr_shard_group_t of this group for the one-call steps, or None (see _fused)."""
+        fused = self._fused()
+        if fused is None or not hasattr(self.k, "shard_group_struct"):
+            return None
+        comm, tc, ac, lc, code = fused
+        key = (self._c_tables[0], comm.value if hasattr(comm, "value") else comm, self.grad_dtype)
+        if self._c_group_cache is None or self._c_group_cache[0] != key:
+            k = self.k
+            gd = k.ESR_BF16 if self.grad_dtype == "bf16" else k.ESR_F32
+            self._c_group_cache = (key, k.shard_group_struct(comm, self.world, tc, ac, lc, len(self.tables), code,
+                                                             self.dim, gd))
+        return self._c_group_cache[1]
 
     def versions(self):
         """RowVersions (second buffer + stamped location bytes, train_state.py) of every table of the group: what the
@@ -352,6 +450,15 @@ class ShardedTableGroup:
         k = self.k
         self.consolidate()  # rows a world-1 one-pass step left in the second buffers (no-op when nothing is displaced)
         recv = plan.exchange_ids()
+        fused = self._fused()
+        if fused is not None:  # gather + rows exchange as one library call
+            comm, tc, _, lc, code = fused
+            ask_c, asked_c = plan.c_counts(k)
+            dt, dev = self.tables[0].local.dtype, recv.device
+            back = torch.empty((plan.n_rows, self.dim), dtype=dt, device=dev)
+            served = torch.empty((recv.numel(), self.dim), dtype=dt, device=dev) if self.world > 1 else None
+            return k.sharded_lookup(comm, self.world, tc, lc, len(self.tables), code, self.dim, recv, asked_c, ask_c,
+                                    served, back)
         if len(self.tables) == 1:
             served = k.gather_rows(self.tables[0].local, recv)
         else:
@@ -376,6 +483,11 @@ class ShardedTableGroup:
             grad_rows = k.segment_sum_rows(plan.n_rows, plan.sorted_uidx, plan.occ_perm, grad_rows)
         elif not bucketed:
             grad_rows = k.gather_rows(grad_rows, plan.perm)                     # id order -> bucket order
+        if self.grad_dtype == "bf16" and self.world > 1:  # rounded after the per-row sum, widened on the owner
+            half = grad_rows.to(torch.bfloat16).contiguous().view(torch.uint8)  # (bytes: every backend moves them)
+            raw = torch.empty((sum(plan.recv_counts), 2 * grad_rows.shape[1]), dtype=torch.uint8, device=grad_rows.device)
+            _a2a(self, raw, half, plan.recv_counts, plan.send_counts)
+            return raw.view(torch.bfloat16).to(grad_rows.dtype)
         recv = torch.empty((sum(plan.recv_counts), grad_rows.shape[1]), dtype=grad_rows.dtype,
                            device=grad_rows.device)
         _a2a(self, recv, grad_rows, plan.recv_counts, plan.send_counts)
@@ -385,6 +497,25 @@ class ShardedTableGroup:
         """Route the gradients to their owners and update the local shards: one fused segment-reduce + RMW."""
         k = self.k
         self.consolidate()  # this update writes the plain shards: displaced rows must be home first (see lookup_bucketed)
+        fused = self._fused() if (bucketed or plan.unique) and grad_rows.dtype == torch.float32 and \
+            grad_rows.is_contiguous() else None
+        if fused is not None:  # [segment sum ->] gradient exchange -> owner-side update as one library call
+            comm, tc, ac, lc, code = fused
+            ask_c, asked_c = plan.c_counts(k)
+            plan.exchange_ids()
+            n_recv, dev = sum(plan.recv_counts), grad_rows.device
+            uniq = plan.unique and not bucketed
+            summed = torch.empty((plan.n_rows, self.dim), dtype=torch.float32, device=dev) if uniq else None
+            remote = self.world > 1
+            bf16 = remote and self.grad_dtype == "bf16" and self.dim % 8 == 0  # (the bias column stays f32)
+            recv = torch.empty((n_recv, self.dim), dtype=torch.float32, device=dev) if remote else None
+            send_h = torch.empty((plan.n_rows, self.dim), dtype=torch.bfloat16, device=dev) if bf16 else None
+            recv_h = torch.empty((n_recv, self.dim), dtype=torch.bfloat16, device=dev) if bf16 else None
+            srt, prm = plan.owner_sorted if plan.owner_sorted is not None else (None, None)
+            k.sharded_update(comm, self.world, tc, ac, lc, len(self.tables), code, self.dim, grad_rows,
+                             plan.sorted_uidx if uniq else None, plan.occ_perm if uniq else None, summed, ask_c, asked_c,
+                             k.ESR_BF16 if bf16 else k.ESR_F32, send_h, recv_h, recv, srt, prm, lr, eps)
+            return
         rows = self.route_grads(plan, grad_rows, bucketed=bucketed)
         if rows.shape[0] == 0:
             return
@@ -503,6 +634,12 @@ def sharded_triplet_step(towers, scene_ids, pos_ids, neg_ids, regularization, gl
                                     scene_ids, pos_ids, neg_ids, regularization, global_batch_size, lr,
                                     stamp=next_stamp(rs, rp))
     plan = plan if plan is not None else plan_triplet(towers, scene_ids, pos_ids, neg_ids)
+    if plan.index is not None and _is_f32(towers) and hasattr(k, "sharded_triplet_step"):
+        gs_ = towers._c_group()
+        if gs_ is not None:  # lookup -> loss -> update as ONE library call (esr_sharded_triplet_step)
+            towers.consolidate()
+            return k.sharded_triplet_step(gs_, plan.c_struct(k), B, regularization, global_batch_size, lr, 1e-7,
+                                          scene_ids.device)
     if plan.index is not None and getattr(k, "GRADS_AT_IDS", None) is not None and _is_f32(towers):
         # the loss kernel indexes the exchanged rows where they landed (bucket order) through the inverse
         # permutation and writes every gradient row back at that position: no un-permute / permute passes
@@ -540,6 +677,11 @@ def sharded_glove_step(emb_group, bias_group, inputs, target, mode, lr, plan=Non
         return k.glove_train_step(et.local, rv.shadow, rv.loc, et.accum, bt.local, bt.accum, inputs, target, mode, lr,
                                   stamp=next_stamp(rv))
     plan = plan if plan is not None else plan_glove(emb_group, inputs)
+    if plan.index is not None and _is_f32(emb_group) and _is_f32(bias_group) and hasattr(k, "sharded_glove_step"):
+        ge, gb_ = emb_group._c_group(), bias_group._c_group()
+        if ge is not None and gb_ is not None:  # both lookups -> loss -> both updates as ONE library call
+            emb_group.consolidate()
+            return k.sharded_glove_step(ge, gb_, plan.c_struct(k), target, B, mode, lr, 1e-7)
     if plan.index is not None and getattr(k, "GRADS_AT_IDS", None) is not None and _is_f32(emb_group) and \
             _is_f32(bias_group):
         rows = emb_group.lookup_bucketed(plan)      # [2B (or the distinct rows), D] in exchange order
@@ -556,6 +698,61 @@ def sharded_glove_step(emb_group, bias_group, inputs, target, mode, lr, plan=Non
     emb_group.apply_sparse_adagrad(plan, grad_rows, lr)
     bias_group.apply_sparse_adagrad(plan, grad_bias.reshape(-1, 1), lr)
     return loss
+
+
+def sharded_train_steps(workload, groups, batches, *, regularization=0.0, global_batch_size=None, scale=1.0, lr=0.05,
+                        mode=None, plan_group=None):
+    """The loop helper of the row-sharded API (what train_steps / train_epoch are to the single-GPU steps): every batch of
+    `batches` stepped in order, the routing plans of `plan_group` coming batches made together -- one bucket / unique
+    launch set, ONE counts all-to-all, ONE copy to pinned memory and ONE host wait per group, the group's ids exchanges
+    as one RCCL group and its owner-side sorts as one batched sort -- and the NEXT group's plans enqueued in front of this
+    group's steps, so the host's wait never finds an idle GPU.  Every step is then three library calls: esr_sharded_lookup,
+    the loss kernel, esr_sharded_update.
+
+    workload "inbatch": groups = (towers,), batches of (scene_ids, pos_ids[, ...]);  "triplet": groups = (towers,),
+    batches of (scene_ids, pos_ids, neg_ids);  "glove": groups = (emb_group, bias_group), batches of (inputs [2, B],
+    target [B]) and `mode` = the loss mode.  Returns the list of per-step loss tensors (this rank's share: all-reduce for
+    the global loss).  The reference's loops being sharded: pinterest/train_shop_the_look.py:190-221,
+    wikipedia/train_cooccurence.py:103-112."""
+    from .train_state import quiet_gc
+    if workload not in ("inbatch", "triplet", "glove"):
+        raise ValueError("workload must be 'inbatch', 'triplet' or 'glove', got %r" % (workload,))
+    g0 = groups[0]
+    if plan_group is None:
+        plan_group = max(1, int(os.environ.get("ESR_SHARDED_PLAN_GROUP", "8")))
+    batches = list(batches)
+
+    def lookup(b):
+        if workload == "glove":
+            return (g0, g0.virtual_id_segments([b[0].reshape(-1)], [0]))
+        if workload == "inbatch":
+            return (g0, g0.virtual_id_segments([b[0], b[1]], [0, 1]))
+        return (g0, g0.virtual_id_segments([b[0], b[1], b[2]], [0, 1, 1]))
+
+    def step(b, plan):
+        if workload == "glove":
+            return sharded_glove_step(g0, groups[1], b[0], b[1], mode, lr, plan=plan)
+        gbs = global_batch_size if global_batch_size is not None else float(g0.world * b[0].numel())
+        if workload == "inbatch":
+            return sharded_inbatch_step(g0, b[0], b[1], regularization, gbs, scale, lr, plan=plan)
+        return sharded_triplet_step(g0, b[0], b[1], b[2], regularization, gbs, lr, plan=plan)
+
+    losses = []
+    if not batches:
+        return losses
+    with quiet_gc():  # a full cyclic collection inside the loop is a 40 ms hole in the launch stream
+        if g0.world1_direct:  # a world of one rank takes the single-GPU steps: nothing is routed
+            for b in batches:
+                losses.append(step(b, None))
+            return losses
+        spans = [(a, min(a + plan_group, len(batches))) for a in range(0, len(batches), plan_group)]
+        pend = begin_plans([lookup(batches[i]) for i in range(*spans[0])])
+        for gi, (a, e) in enumerate(spans):
+            plans = pend.finish()  # ids exchanges + owner-side sorts of the whole group, ahead of its steps
+            pend = begin_plans([lookup(batches[i]) for i in range(*spans[gi + 1])]) if gi + 1 < len(spans) else None
+            for i in range(a, e):
+                losses.append(step(batches[i], plans[i - a]))
+    return losses
 
 
 class _Collectives:

@@ -572,6 +572,76 @@ int esr_alltoall_rows(esr_comm_t comm, const void* send_rows, int dtype, int D, 
 int esr_alltoall_grads(esr_comm_t comm, const float* send_grads, int D, const int64_t* send_counts,
                        float* recv_grads, const int64_t* recv_counts, esr_stream_t stream);
 
+/* ---- a row-sharded step's exchange halves as ONE call each (esr_shard_step.hip; the loss kernel sits between them) ----
+ * The steps being sharded: pinterest/train_shop_the_look.py:93-109, wikipedia/train_cooccurence.py:71-101 (the reference
+ * is single-device and has no counterpart).  Count arrays are host int64 [world], peer-major, as in esr_alltoall_*:
+ *   asked_counts[p]  rows peer p asks of THIS rank (their virtual local rows: asked_rows, concatenated peer by peer)
+ *   ask_counts[p]    rows this rank asks of peer p (the routing plan's send counts)
+ * esr_sharded_lookup: gather asked_rows from this rank's shards (esr_gather_rows_multi) into `served`
+ *   [sum asked_counts, D], exchange (esr_alltoall_rows) into `back` [sum ask_counts, D], both in the tables' dtype.
+ * esr_sharded_update: unique plans (sorted_uidx / occ_perm of esr_unique_by_owner non-NULL): ONE summed row per distinct
+ *   row (esr_segment_sum_rows into `summed` [sum ask_counts, D]; grad_rows [n_occ, D] may be overwritten), else grad_rows
+ *   are already one row per exchanged row; rows to their owners (esr_alltoall_grads into recv_grads [sum asked_counts,
+ *   D]); the owner's fused segment-reduce + Adagrad (esr_sparse_adagrad_scatter_multi) with the sort of asked_rows the
+ *   plan phase made (owner_sorted / owner_perm).  grad_dtype ESR_BF16: the rows cross the exchange as bf16 (rounded to
+ *   nearest-even after the per-row sum into send_bf16 [sum ask_counts, D], received into recv_raw, widened into
+ *   recv_grads; element error <= 2^-9 relative; D % 8 == 0) -- SURVEY 8d's config-4 budget of bf16-sized gradients.
+ * world == 1 (comm may be NULL): nothing is exchanged or copied -- the gather writes into `back`, the update reads the
+ * asker's rows in place; served / recv_grads / send_bf16 / recv_raw are not touched. */
+int esr_sharded_lookup(esr_comm_t comm, int world, const void* const* tables, const int64_t* row_offsets, int ntables,
+                       int dtype, int D, const int32_t* asked_rows, const int64_t* asked_counts,
+                       const int64_t* ask_counts, void* served, void* back, esr_stream_t stream);
+int esr_sharded_update(esr_comm_t comm, int world, void* const* tables, float* const* accums,
+                       const int64_t* row_offsets, int ntables, int dtype, int D, float* grad_rows, int64_t n_occ,
+                       const int32_t* sorted_uidx, const int32_t* occ_perm, float* summed, const int64_t* ask_counts,
+                       const int64_t* asked_counts, int grad_dtype, void* send_bf16, void* recv_raw, float* recv_grads,
+                       const int32_t* owner_sorted, const int32_t* owner_perm, float lr, float eps, int long_runs,
+                       esr_stream_t stream);
+
+/* ---- a whole row-sharded step -- lookup, loss kernel, update -- as ONE call (esr_shard_step.hip) -----------------------
+ * A group = the same-width tables a step looks up and updates together, as this rank holds them (host struct of host
+ * arrays of device pointers); a routing plan = what esrecsys_amd/sharded.py's plan phase made for one batch: */
+typedef struct {
+  esr_comm_t comm;              /* esr_comm_init's communicator; may be NULL at world 1 */
+  int world;
+  void* const* tables;          /* [ntables] this rank's shards */
+  float* const* accums;         /* [ntables] their Adagrad accumulators */
+  const int64_t* row_offsets;   /* [ntables + 1] virtual LOCAL row boundaries of the concatenated shards */
+  int ntables;
+  int dtype;                    /* ESR_F32 / ESR_BF16 (whole steps: ESR_F32) */
+  int D;
+  int grad_dtype;               /* ESR_F32, or ESR_BF16: gradient rows cross the exchange as bf16 (esr_sharded_update) */
+} esr_shard_group_t;
+typedef struct {
+  const int32_t* asked_rows;    /* device [sum asked_counts]: virtual local rows the peers ask of this rank */
+  const int64_t* asked_counts;  /* host [world] */
+  const int64_t* ask_counts;    /* host [world]: rows this rank asks of each peer */
+  const int32_t* index;         /* device [occurrences]: occurrence i reads row index[i] of the rows that come back */
+  const int32_t* sorted_uidx;   /* device [occurrences] -- esr_unique_by_owner's grouping of the occurrences by distinct */
+  const int32_t* occ_perm;      /*   row; both NULL for a per-occurrence plan (index = the inverse bucket permutation) */
+  const int32_t* owner_sorted;  /* device [sum asked_counts]: esr_segment_sort_ids of asked_rows ... */
+  const int32_t* owner_perm;    /*   ... and its permutation, for the owner-side update */
+  int long_runs;                /* esr_sparse_adagrad_scatter_multi's hint (-1: unknown) */
+} esr_routing_plan_t;
+/* esr_sharded_triplet_step: the reference triplet loss (pinterest/train_shop_the_look.py:93-109) on row-sharded towers
+ * (group = [scene table, product table]; occurrences = [scene ; pos ; neg] ids, 3 B of them): esr_sharded_lookup ->
+ * esr_triplet_fwd_bwd on the rows where they landed -> esr_sharded_update.  loss [1] = this rank's share (a sum over
+ * triplets / batch_size: all-reduce for the global value).
+ * esr_sharded_glove_step: wikipedia/train_cooccurence.py:71-101 on a row-sharded embedding table and its [V, 1] bias table
+ * (two single-table groups, ONE plan: same ids, same sharding; occurrences = inputs [2, B] flattened): both lookups ->
+ * esr_glove_fwd_bwd -> both updates.  The loss is over the local batch.
+ * Workspace: caller-owned, 256-byte aligned, at least the *_workspace_bytes of the SAME group(s), plan and B. */
+size_t esr_sharded_triplet_step_workspace_bytes(const esr_shard_group_t* towers, const esr_routing_plan_t* plan,
+                                                int64_t B);
+int esr_sharded_triplet_step(const esr_shard_group_t* towers, const esr_routing_plan_t* plan, int64_t B,
+                             float regularization, float batch_size, float lr, float eps, float* loss, void* workspace,
+                             size_t workspace_bytes, esr_stream_t stream);
+size_t esr_sharded_glove_step_workspace_bytes(const esr_shard_group_t* emb, const esr_shard_group_t* bias,
+                                              const esr_routing_plan_t* plan, int64_t B);
+int esr_sharded_glove_step(const esr_shard_group_t* emb, const esr_shard_group_t* bias, const esr_routing_plan_t* plan,
+                           const float* target, int64_t B, int mode, float lr, float eps, float* loss, void* workspace,
+                           size_t workspace_bytes, esr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -297,3 +297,58 @@ def test_sharded_top_k_equals_single_device():
         queries = np.round(np.random.default_rng(50 + r).standard_normal((7, 16)) * 4) / 4
         es, ei = o_topk.batched_top_k(queries, cands, 9)
         assert np.array_equal(outs[r]["i"], ei) and np.array_equal(outs[r]["s"], es)
+
+
+def _helper_worker(rank, port, outdir):
+    """(a) sharded_train_steps (plans of a group of batches made together, next group's enqueued ahead) against the
+    per-step calls; (b) the same steps with the gradient rows crossing the exchange as bf16."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    import _cpu_kernels as K
+    from esrecsys_amd import sharded
+    st, pt = _full_tables()
+    mk = lambda full: torch.from_numpy(np.ascontiguousarray(full[rank::WORLD]))  # noqa: E731
+
+    def towers(grad_dtype=None):
+        scene = sharded.RowShardedTable(mk(st), torch.full_like(mk(st), 0.1), V_S)
+        prod = sharded.RowShardedTable(mk(pt), torch.full_like(mk(pt), 0.1), V_P)
+        return sharded.ShardedTableGroup([scene, prod], kernels=K, grad_dtype=grad_dtype)
+    n_steps = 7  # groups of 3 + 3 + 1
+    batches = [tuple(torch.from_numpy(x) for x in _batch(step, rank)) for step in range(n_steps)]
+    out = {}
+    for name, grad_dtype, helper in (("steps", None, False), ("helper", None, True), ("bf16", "bf16", True)):
+        tw = towers(grad_dtype)
+        if helper:
+            losses = sharded.sharded_train_steps("triplet", (tw,), batches, regularization=LAM,
+                                                 global_batch_size=float(WORLD * B), lr=LR, plan_group=3)
+        else:
+            losses = [sharded.sharded_triplet_step(tw, *b, LAM, float(WORLD * B), LR) for b in batches]
+        out[name + "_scene"] = tw.tables[0].local.numpy().copy()
+        out[name + "_prod"] = tw.tables[1].local.numpy().copy()
+        out[name + "_loss"] = np.array([float(l) for l in losses])
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_loop_helper_equals_per_step_calls_and_bf16_gradient_exchange_error():
+    """sharded_train_steps is the per-step loop, bit for bit.  With the gradient rows crossing the exchange as bf16
+    (config 4's budget) every gradient element is rounded to 8 significant bits after the per-distinct-row sum:
+    the tables stay within 2^-7 of the f32 exchange's update over these steps -- and do differ (the option is live)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_helper_worker, args=(port, d), nprocs=WORLD, join=True)
+        outs = [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(WORLD)]
+    st, pt = _full_tables()
+    for r, o in enumerate(outs):
+        assert np.array_equal(o["steps_scene"], o["helper_scene"]) and np.array_equal(o["steps_prod"], o["helper_prod"])
+        assert np.array_equal(o["steps_loss"], o["helper_loss"])
+        for key, full in (("scene", st), ("prod", pt)):
+            exact, half, start = o["helper_" + key], o["bf16_" + key], full[r::WORLD]
+            moved = np.abs(exact - start).max()
+            err = np.abs(half - exact).max()
+            assert 0.0 < err <= 2.0 ** -7 * moved, (key, err, moved)
