@@ -899,6 +899,7 @@ def secondary_legs(args, dev, rank):
 
     def ivf():  # config 5's "ANN scoring vs brute force": the IVF index against the EXACT answer on the same corpus
         r = measure_ivf(dev, corpus="clustered")
+        r["hierarchical_corpus"] = measure_ivf(dev, ks=(500,), nprobes=(16, 32, 64), steps=2, corpus="hierarchical")
         r["iid_corpus_worst_case"] = measure_ivf(dev, ks=(10,), nprobes=(32,), steps=2, corpus="iid")
         return r
     guarded("retrieve_c5_n1m_ivf_vs_brute_force", ivf)
@@ -908,9 +909,13 @@ def secondary_legs(args, dev, rank):
 def summarize_ivf(r):
     if not isinstance(r, dict) or "error" in r:
         return r
-    return {"corpus": r.get("corpus"), "nlist": r.get("nlist"),
-            "legs": [{"k": x["k"], "nprobe": x.get("nprobe"), "ms": _r(x["ms"], 3), "recall": _r(x["recall_at_k_vs_exact"]),
-                      "x_brute": _r(x["speedup_vs_brute_force"], 2)} for x in r.get("legs", [])]}
+    legs = lambda d: [{"k": x["k"], "nprobe": x.get("nprobe"), "ms": _r(x["ms"], 3),  # noqa: E731
+                       "recall": _r(x["recall_at_k_vs_exact"]), "x_brute": _r(x["speedup_vs_brute_force"], 2)}
+                      for x in d.get("legs", [])]
+    out = {"corpus": r.get("corpus"), "nlist": r.get("nlist"), "legs": legs(r)}
+    if isinstance(r.get("hierarchical_corpus"), dict):
+        out["hierarchical_corpus_legs"] = legs(r["hierarchical_corpus"])
+    return out
 
 
 def main():

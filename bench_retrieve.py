@@ -97,8 +97,20 @@ def measure_ivf(dev, n_local=1_048_576, nq=NQ, ks=(10, 500), nlist=1024, nprobes
     from esrecsys_amd.ivf import IVFIndex
     from esrecsys_amd.pinterest.make_recommendations import recall_at_k
     g = torch.Generator(device=dev).manual_seed(1701)
-    if corpus == "clustered":
-        centres = torch.randn((4096, D), generator=g, device=dev)
+    if corpus in ("clustered", "hierarchical"):
+        if corpus == "clustered":
+            centres = torch.randn((4096, D), generator=g, device=dev)
+        else:
+            # two scales: 64 topics, 4096 sub-centres scattered around them (unit topic + 0.5-norm offset), then the rows.
+            # In the flat corpus a row's cluster has N / 4096 = 256 members: of a query's true top-500 the other ~244 are
+            # the far tail of a million unrelated rows, spread evenly over ALL lists -- no inverted file can find them
+            # without scanning (recall ceiling at a fraction f of the candidates scored ~ (256 + 244 f) / 500).  Here
+            # the neighbours beyond the own sub-cluster are the sibling sub-clusters of the topic: what the lists near
+            # a query hold.
+            topics = torch.randn((64, D), generator=g, device=dev)
+            topics /= topics.norm(dim=1, keepdim=True)
+            centres = topics[torch.randint(0, 64, (4096,), generator=g, device=dev)] + \
+                torch.randn((4096, D), generator=g, device=dev) * (0.5 * D ** -0.5)
         centres /= centres.norm(dim=1, keepdim=True)
         c = centres[torch.randint(0, 4096, (n_local,), generator=g, device=dev)] + \
             torch.randn((n_local, D), generator=g, device=dev) * (0.6 * D ** -0.5)

@@ -59,10 +59,17 @@ def pytest_sessionfinish(session, exitstatus):
         import json
         out = os.path.join(ROOT, "gpurun_out")
         os.makedirs(out, exist_ok=True)
+        path = os.path.join(out, "parity_errors.json")
+        tests = {}
+        try:  # several pytest invocations of one box session add up (a later run of a test replaces its entry)
+            tests = json.load(open(path)).get("tests", {})
+        except Exception:
+            pass
+        tests.update(_ERRORS)
         doc = {"what": "largest error each GPU parity test measured against the oracle (rel_err: max|a-b| / max|b|; "
                        "elem_rel_err: element-wise with a floor of 1e-3 x the largest entry unless the test says otherwise)",
-               "device": torch.cuda.get_device_name(0), "exitstatus": int(exitstatus), "tests": _ERRORS}
-        with open(os.path.join(out, "parity_errors.json"), "w") as f:
+               "device": torch.cuda.get_device_name(0), "exitstatus": int(exitstatus), "tests": tests}
+        with open(path, "w") as f:
             json.dump(doc, f, indent=1, sort_keys=True)
     except Exception:
         pass
