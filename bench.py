@@ -647,6 +647,28 @@ def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True
         state, final_loss = train_epoch(state, steps, iter(batches[warmup:]))  # returns the epoch's mean loss (syncs)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+    elif workload == "triplet" and graphed is None and (cfg.get("loop") == "reference_shape" or
+                                                        os.environ.get("ESR_STL_LOOP") == "presorted"):
+        # the reference's loop AS WRITTEN (pinterest/train_shop_the_look.py:190-221): train_step per iteration, over the
+        # presorted() iterator adapter (id lists of eight coming batches sorted and planned together, one call per step)
+        from esrecsys_amd.pinterest.train_shop_the_look import presorted, train_step
+        from esrecsys_amd.train_state import quiet_gc
+        mode = "eager, the reference's loop shape: train_step per iteration over presorted(state, batches)"
+
+        def run(lo, hi):
+            nonlocal state
+            l = None
+            for scene, pos, neg in presorted(state, iter(batches[lo:hi])):
+                state, l = train_step(state, scene, pos, neg, LAM, B)
+            return l
+        run(0, warmup)
+        torch.cuda.synchronize()
+        with quiet_gc():
+            t0 = time.perf_counter()
+            loss = run(warmup, n_batches)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        final_loss = float(loss)
     elif workload == "triplet" and graphed is None and os.environ.get("ESR_STL_LOOP", "1") == "1" and \
             os.environ.get("ESR_STL_PRESORT", "0") != "1" and cfg["B"] <= 262144:
         # the reference's training loop body (pinterest/train_shop_the_look.py:195-204) through the build's loop helper:
@@ -858,6 +880,8 @@ def secondary_legs(args, dev, rank):
     legs = [("glove_c3_b65536", "glove", {}, max(k, 200), max(w, 10), 6.0, 6.0),
             ("glove_c3_b2048_reference_default_batch", "glove", {"B": 2048}, max(k, 400), max(w, 16), 3.0, 6.0),
             ("triplet_c2_b8192_reference_loss", "triplet", {}, max(k, 400), max(w, 16), 4.0, 6.0),
+            ("triplet_c2_b8192_reference_loop_shape", "triplet", {"loop": "reference_shape"}, max(k, 400), max(w, 16),
+             0.0, 0.0),
             ("triplet_c2_b262144_saturating", "triplet", {"B": 262144}, max(min(k, 100), 64), max(w, 16), 0.0, 0.0)]
     for name, workload, over, steps, warm, cpu_s, cpu_dense_s in legs:
         cfg = dict(WORKLOADS[workload], table_dtype="f32", ids="uniform", **over)

@@ -158,6 +158,8 @@ def train_step(state, scene, pos_product, neg_product, regularization, batch_siz
     gathers the three rows per triplet, scores them and writes the three gradient rows; the optimizer
     update is sort + segment-reduce + RMW.  ``neg_product=None``: in-batch softmax (north_star) with
     temperature ``scale``; ``precision`` picks its MFMA path (see ops.inbatch_softmax_fwd_bwd)."""
+    if isinstance(scene, PlannedTriplets):  # a batch of ``presorted(state, batches)``: sorted and planned with its group
+        return scene.step(state, regularization, batch_size)
     presorted = None
     if isinstance(scene, PresortedTriplets):
         presorted, scene, pos_product, neg_product = scene, scene.scene, scene.pos, scene.neg
@@ -412,6 +414,119 @@ class _FusedTripletLoop:
                    "esr_triplet_train_step")
         if slot is not None:
             slot["free"].record(self.main)
+
+
+class PlannedTriplets:
+    """One batch of a group that ``presorted`` drew from the iterator, sorted and planned together (esr_segment_sort_ids_batched
+    + esr_triplet_plan, one call pair per group of up to eight batches).  ``train_step(state, handle, None, None,
+    regularization, batch_size)`` -- or with the ids it carries -- steps it with ONE library call (esr_triplet_train_step
+    on the group's sorted ids and plan record)."""
+    __slots__ = ("ctx", "group", "j", "scene", "pos", "neg", "used")
+
+    def __init__(self, ctx, group, j):
+        self.ctx, self.group, self.j = ctx, group, j
+        self.scene, self.pos, self.neg = group.keep[j]
+        self.used = False
+
+    def __iter__(self):  # ``for scene, pos, neg in presorted(...)`` -- the reference's loop shape: scene IS the handle
+        return iter((self, self.pos, self.neg))
+
+    def step(self, state, regularization, batch_size):
+        if self.used:
+            raise RuntimeError("a planned batch feeds exactly one train_step (its plan holds the step's accumulators)")
+        self.used = True
+        ctx, gr, j = self.ctx, self.group, self.j
+        if ctx.group_of[gr.which] is not gr:
+            raise RuntimeError("this planned batch is two groups old: its sorted ids and plan have been overwritten "
+                               "(step the batches of presorted() in the order it yields them)")
+        k = ctx.next_loss_slot()
+        n = 3 * gr.B
+        known = ctx.hints_known[gr.which]
+        if known is None:
+            # the group's plan launch was queued a whole group ahead of this step (see presorted): the wait ends with that
+            # group's steps still in the queue, and every step then knows whether it needs its long-run launch
+            if _HINT_WAIT:
+                ctx.hints_event[gr.which].synchronize()
+            if ctx.hints_event[gr.which].query():
+                known = ctx.hints_known[gr.which] = ctx.hints_host[gr.which].tolist()
+        long_runs = -1 if known is None else (1 if known[j] == gr.gen else 0)
+        if gr.B != ctx.group_ws_B:
+            ctx.group_ws = ops._ws(ops._ws_bytes("esr_triplet_step_workspace_bytes", gr.B, ctx.D), ctx.dev)
+            ctx.group_ws_B = gr.B
+        pb = ops._ws_bytes("esr_triplet_plan_bytes", gr.B)
+        ctx.check(ctx.lib.esr_triplet_train_step(*ctx.fixed_s, *ctx.fixed_p, ctx.D, self.scene.data_ptr(),
+                                                 self.pos.data_ptr(), self.neg.data_ptr(), gr.B, float(regularization),
+                                                 float(batch_size), ctx.lr, ctx.eps, ctx.next_stamp(ctx.rs, ctx.rp),
+                                                 gr.sorted_ptr + 4 * n * j, gr.perm_ptr + 4 * n * j,
+                                                 gr.plans_ptr + pb * j, long_runs, ctx.losses_ptr + 4 * k,
+                                                 ctx.group_ws.data_ptr(), ctx.group_ws.numel(), ops._stream()),
+                  "esr_triplet_train_step")
+        return state.replace(step=state.step + 1), ctx.losses[k]
+
+
+def presorted(state, batches):
+    """Iterator adapter for the reference's OWN loop shape (pinterest/train_shop_the_look.py:190-221):
+
+        for scene, pos, neg in presorted(state, train_it):
+            state, loss = train_step(state, scene, pos, neg, regularization, batch_size)
+
+    at the rate of ``train_steps``: the batches are drawn from `batches` up to eight at a time, their id lists sorted and
+    planned by one call pair per group -- the NEXT group's before this group's first step is issued, as in train_steps --
+    and what the loop receives as ``scene`` is a PlannedTriplets handle that train_step steps with one library call.
+    Needs the one-pass triplet step (sparse Adagrad, fp32 towers with room for their second buffers); otherwise, and for
+    in-batch batches (neg = None), the batches pass through unchanged.  Each loss is a view into a ring of 4096 slots:
+    read (or copy) it before 4096 further steps."""
+    it = iter(batches)
+    if not fused_triplet_step_available(state):
+        yield from it
+        return
+    ctx = _FusedTripletLoop(state, 4096, 0)
+    ctx.group_of = [None, None]
+    ctx.loss_k = -1
+
+    def next_loss_slot():
+        ctx.loss_k = (ctx.loss_k + 1) % 4096
+        return ctx.loss_k
+    ctx.next_loss_slot = next_loss_slot
+    which = 0
+
+    def draw():
+        """('group', _Group) of 2 .. 8 equal-sized triplet batches, or ('plain', [batches]) to pass through, or None."""
+        nonlocal which
+        first = next(it, None)
+        if first is None:
+            return None
+        if first[2] is None:
+            return ("plain", [first])
+        group = [ctx.ids(*first)]
+        plain_tail = []
+        while len(group) < _SORT_BATCH:
+            b = next(it, None)
+            if b is None:
+                break
+            if b[2] is None:
+                plain_tail.append(b)
+                break
+            group.append(ctx.ids(*b))
+        B = group[0][0].numel()
+        if len(group) == 1 or any(g[0].numel() != B for g in group) or 3 * B > _SORT_BATCH_MAX_IDS:
+            return ("plain", [g for g in group] + plain_tail)  # (own sorts inside their steps)
+        which ^= 1
+        gr = ctx.sort_batch(group, which)
+        ctx.group_of[which] = gr
+        return ("group", gr, plain_tail)
+
+    cur = draw()
+    while cur is not None:
+        nxt = draw()  # sorted and planned BEFORE this group's steps are issued: its hints reach the host a group ahead
+        if cur[0] == "group":
+            gr = cur[1]
+            for j in range(gr.nb):
+                yield PlannedTriplets(ctx, gr, j)
+            yield from cur[2]
+        else:
+            yield from cur[1]
+        cur = nxt
 
 
 # Batches whose ids are sorted ahead on the side stream; 0 = the sort runs in line, inside the step's library call.

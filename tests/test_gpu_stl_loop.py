@@ -160,3 +160,42 @@ def test_train_steps_group_after_a_group_of_larger_batches(dev):
     assert torch.equal(losses, torch.stack(ref))
     for tower in ("scene_tower", "product_tower"):
         assert torch.equal(a.params["params"][tower]["embedding"], b.params["params"][tower]["embedding"])
+
+
+@pytest.mark.parametrize("B,steps,ids", [(256, 7, "uniform"), (2048, 19, "hot"), (8192, 9, "uniform"), (128, 150, "hot"),
+                                         (512, 27, "mixed")])
+def test_reference_shaped_loop_over_presorted_equals_train_steps(dev, B, steps, ids):
+    """The reference's own loop (pinterest/train_shop_the_look.py:190-221) -- ``for scene, pos, neg in it: state, loss =
+    train_step(state, scene, pos, neg, reg, bs)`` -- over ``presorted(state, it)``: the id lists of eight coming batches
+    are sorted and planned together and train_step steps each handle with one library call.  Bit for bit train_steps; an
+    in-batch batch in the middle passes through; a handle steps once."""
+    from esrecsys_amd.pinterest.train_shop_the_look import PlannedTriplets, presorted, train_step, train_steps
+    Vs, Vp, D = 3000, 5000, 64
+    rng = np.random.default_rng(B + steps)
+
+    def draw(V):
+        if ids == "hot" or (ids == "mixed" and rng.random() < 0.5):
+            return np.where(rng.random(B) < 0.4, rng.integers(0, 3, B), rng.integers(0, V, B)).astype(np.int32)
+        return rng.integers(0, V, B).astype(np.int32)
+    batches = [(torch.from_numpy(draw(Vs)).to(dev), torch.from_numpy(draw(Vp)).to(dev),
+                torch.from_numpy(draw(Vp)).to(dev)) for _ in range(steps)]
+    a, b = _state(dev, Vs, Vp, D, 3), _state(dev, Vs, Vp, D, 3)
+    a, want = train_steps(a, iter(batches), steps, 0.1, float(B))
+    got, handles = [], 0
+    last = None
+    for scene, pos, neg in presorted(b, iter(batches)):
+        handles += isinstance(scene, PlannedTriplets)
+        last = scene
+        b, loss = train_step(b, scene, pos, neg, 0.1, float(B))
+        got.append(loss.clone())
+    assert handles >= steps - 1 and int(b.step) == steps     # (a single left-over batch sorts inside its own step)
+    assert torch.equal(torch.stack(got), want)
+    for tower in ("scene_tower", "product_tower"):
+        assert torch.equal(a.params["params"][tower]["embedding"], b.params["params"][tower]["embedding"])
+    if isinstance(last, PlannedTriplets):
+        with pytest.raises(RuntimeError):
+            train_step(b, last, None, None, 0.1, float(B))
+    # an in-batch batch between triplet batches goes through unchanged
+    mixed = batches[:3] + [(batches[0][0], batches[0][1], None)] + batches[3:5]
+    kinds = [isinstance(s, PlannedTriplets) for s, _, _ in presorted(b, iter(mixed))]
+    assert kinds.count(False) >= 1 and len(kinds) == len(mixed)
