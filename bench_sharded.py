@@ -28,13 +28,19 @@ def run_sharded(args, cfg, dev, rank, world):
 
     # ESR_BENCH_PARALLELISM=replicated: every rank holds the FULL tables, gathers all ranks' ids + gradient rows and
     # applies one global sparse update (esrecsys_amd/replicated.py) -- SURVEY 8e's other mode, for tables that fit a GPU
-    replicated_mode = os.environ.get("ESR_BENCH_PARALLELISM", "sharded") == "replicated" and args.workload != "glove"
-    rep = None
+    replicated_mode = os.environ.get("ESR_BENCH_PARALLELISM", "sharded") == "replicated"
+    rep = rep_bias = None
     if replicated_mode:
         from esrecsys_amd import replicated
         g_all = torch.Generator(device=dev).manual_seed(SEED)  # the SAME tables on every rank
-        full = [torch.randn((V, D), generator=g_all, device=dev).mul_(D ** -0.5) for _ in range(2)]
-        rep = replicated.ReplicatedTables(full, [torch.full((V, D), 0.1, device=dev) for _ in range(2)], kernels=ops)
+        if args.workload == "glove":
+            full = [torch.randn((V, D), generator=g_all, device=dev).mul_(D ** -0.5)]
+            rep = replicated.ReplicatedTables(full, [torch.full((V, D), 0.1, device=dev)], kernels=ops)
+            rep_bias = replicated.ReplicatedTables([torch.zeros((V, 1), device=dev)], [torch.full((V, 1), 0.1, device=dev)],
+                                                   kernels=ops)
+        else:
+            full = [torch.randn((V, D), generator=g_all, device=dev).mul_(D ** -0.5) for _ in range(2)]
+            rep = replicated.ReplicatedTables(full, [torch.full((V, D), 0.1, device=dev) for _ in range(2)], kernels=ops)
     elif args.workload == "glove":
         emb_t, bias_t = shard(V, D), shard(V, 1)
         bias_t.local.zero_()
@@ -82,6 +88,8 @@ def run_sharded(args, cfg, dev, rank, world):
 
     def step(b, plans):
         if replicated_mode:
+            if args.workload == "glove":
+                return replicated.replicated_glove_step(rep, rep_bias, b[0], b[1], ops.GLOVE_REFERENCE, LR)
             if args.workload == "inbatch":
                 return replicated.replicated_inbatch_step(rep, b[0], b[1], LAM, gb, SCALE, LR)
             return replicated.replicated_triplet_step(rep, b[0], b[1], b[2], LAM, gb, LR)

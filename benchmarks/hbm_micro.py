@@ -66,7 +66,7 @@ def main():
             emit("sparse_adagrad", n, D, (n + 4 * uniq) * D * 4, t,
                  "grad rows read once + param/accum RMW of %d distinct rows" % uniq)
             t = timed(lambda: ops.segment_sort(ids, V), args.reps)
-            emit("segment_sort", n, 1, 0, t, "stable sort of (id, occurrence) pairs: tile sort up to 32768 ids, rocPRIM radix sort beyond")
+            emit("segment_sort", n, 1, 0, t, "stable sort of (id, occurrence) pairs: one-launch bitonic up to 2048 ids, tile sort + rank up to 32768, own 11-bit LSD radix sort up to 2^21 ids (rocPRIM only beyond that)")
             if D == 128 and n <= (1 << 20):
                 t3 = timed(lambda: ops.triplet_fwd_bwd(table, table, table, ids[: n // 3], ids[n // 3: 2 * (n // 3)],
                                                        ids[2 * (n // 3): 3 * (n // 3)], n // 3, 0.1, n // 3,

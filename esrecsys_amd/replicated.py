@@ -39,21 +39,37 @@ class ReplicatedTables:
         for t in self.tables:
             self.row_offsets.append(self.row_offsets[-1] + int(t.shape[0]))
 
+    def gather_ids(self, id_tensors, slots):
+        """Every rank's occurrence ids of one batch as virtual rows, sorted: (sorted ids, permutation, ids per rank).
+        Depends on the ids only -- tables indexed by the same ids (GloVe's embedding and bias) share one."""
+        k, G = self.k, self.world
+        vids = k.concat_offset_ids(list(id_tensors), [self.row_offsets[s] for s in slots])
+        n = vids.numel()
+        all_ids = vids
+        if G > 1:
+            all_ids = torch.empty(G * n, dtype=vids.dtype, device=vids.device)
+            self.coll.all_gather(all_ids, vids)
+        sorted_vids, perm = k.segment_sort(all_ids, self.row_offsets[-1])
+        return sorted_vids, perm, n
+
+    def apply_rows(self, gathered, grad_rows, lr, eps=1e-7):
+        """All-gather this rank's per-occurrence gradient rows and apply the ONE global update (`gathered` from
+        gather_ids of this or of an identically indexed ReplicatedTables)."""
+        k, G = self.k, self.world
+        sorted_vids, perm, n = gathered
+        all_rows = grad_rows
+        if G > 1:
+            all_rows = torch.empty((G * n, grad_rows.shape[1]), dtype=grad_rows.dtype, device=grad_rows.device)
+            self.coll.all_gather(all_rows, grad_rows.contiguous())
+        if len(self.tables) == 1:  # (any row width: the GloVe bias column is one float)
+            k.sparse_adagrad(self.tables[0], self.accums[0], sorted_vids, perm, all_rows, lr, eps)
+        else:
+            k.sparse_adagrad_multi(self.tables, self.accums, self.row_offsets, sorted_vids, perm, all_rows, lr, eps)
+
     def apply_global(self, id_tensors, slots, grad_rows, lr, eps=1e-7):
         """id_tensors[i] indexes table slots[i]; grad_rows = their per-occurrence gradient rows, concatenated.  Gathers
         every rank's (virtual ids, rows) and applies the one global update."""
-        k, G = self.k, self.world
-        vids = k.concat_offset_ids(list(id_tensors), [self.row_offsets[s] for s in slots])
-        n, D = vids.numel(), grad_rows.shape[1]
-        if G > 1:
-            all_ids = torch.empty(G * n, dtype=vids.dtype, device=vids.device)
-            all_rows = torch.empty((G * n, D), dtype=grad_rows.dtype, device=grad_rows.device)
-            self.coll.all_gather(all_ids, vids)
-            self.coll.all_gather(all_rows, grad_rows.contiguous())
-        else:
-            all_ids, all_rows = vids, grad_rows
-        sorted_vids, perm = k.segment_sort(all_ids, self.row_offsets[-1])
-        k.sparse_adagrad_multi(self.tables, self.accums, self.row_offsets, sorted_vids, perm, all_rows, lr, eps)
+        self.apply_rows(self.gather_ids(id_tensors, slots), grad_rows, lr, eps)
 
 
 def replicated_inbatch_step(rep, scene_ids, pos_ids, regularization, global_batch_size, scale, lr):
@@ -82,4 +98,18 @@ def replicated_triplet_step(rep, scene_ids, pos_ids, neg_ids, regularization, gl
     loss, _, _, gs, gp, gn = k.triplet_fwd_bwd(st, pt, pt, scene_ids, pos_ids, neg_ids, B, regularization,
                                                global_batch_size, with_reg=True, want_grads=True, want_scores=False)
     rep.apply_global([scene_ids, pos_ids, neg_ids], [0, 1, 1], _joined(gs, gp, gn), lr)
+    return loss
+
+
+def replicated_glove_step(rep_emb, rep_bias, inputs, target, mode, lr):
+    """GloVe step (wikipedia/train_cooccurence.py:71-101 with the build's sparse Adagrad) on a replicated embedding table
+    and its [V, 1] bias table (two single-table ReplicatedTables over the same group): the loss is over this rank's
+    batch, as in sharded.sharded_glove_step; every rank's occurrence ids are gathered and sorted ONCE and both tables take
+    their one global update from it."""
+    k = rep_emb.k
+    ids = inputs.reshape(-1)
+    gathered = rep_emb.gather_ids([ids], [0])   # (before the loss kernel: the sort needs the ids only)
+    loss, grad_rows, grad_bias = k.glove_fwd_bwd(rep_emb.tables[0], rep_bias.tables[0], inputs, target, mode)
+    rep_emb.apply_rows(gathered, grad_rows, lr)
+    rep_bias.apply_rows(gathered, grad_bias.reshape(-1, 1), lr)
     return loss

@@ -109,3 +109,57 @@ def test_replicated_inbatch_matches_per_rank_oracle():
         pt, a_p = o_optim.sparse_adagrad_update(pt, a_p, np.concatenate(ids_p), np.concatenate(g_p), LR, dtype=np.float64)
     assert np.array_equal(outs[0]["scene"], outs[1]["scene"]) and np.array_equal(outs[0]["prod"], outs[1]["prod"])
     assert np.abs(outs[0]["scene"] - st).max() <= 1e-12 and np.abs(outs[0]["prod"] - pt).max() <= 1e-12
+
+
+def _glove_worker(rank, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    import _cpu_kernels as K
+    from esrecsys_amd import replicated
+    rng = np.random.default_rng(11)
+    V, Dg, Bg = 97, 8, 20
+    emb = torch.from_numpy(rng.standard_normal((V, Dg)) * 0.3)
+    bias = torch.from_numpy(rng.standard_normal((V, 1)) * 0.05)
+    rep_e = replicated.ReplicatedTables([emb], [torch.full_like(emb, 0.1)], kernels=K)
+    rep_b = replicated.ReplicatedTables([bias], [torch.full_like(bias, 0.1)], kernels=K)
+    brng = np.random.default_rng(100 + rank)
+    for _ in range(3):
+        inp, tgt = brng.integers(0, V, (2, Bg)).astype(np.int32), brng.uniform(0.1, 300, Bg)
+        replicated.replicated_glove_step(rep_e, rep_b, torch.from_numpy(inp), torch.from_numpy(tgt), K.GLOVE_DIAGONAL, 0.05)
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), emb=emb.numpy(), bias=bias.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_replicated_glove_equals_single_device_and_replicas_agree():
+    """Diagonal-mode GloVe is a sum over pairs with a 1 / B factor: G ranks x B pairs with the per-rank 1 / B equals a
+    single device applying each rank's batch gradients to one table (the check of the sharded GloVe step); the replicas
+    end bit-identical."""
+    import socket
+    from oracle import glove as o_glove
+    from oracle import optim as o_optim
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_glove_worker, args=(port, d), nprocs=WORLD, join=True)
+        outs = [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(WORLD)]
+    assert np.array_equal(outs[0]["emb"], outs[1]["emb"]) and np.array_equal(outs[0]["bias"], outs[1]["bias"])
+    rng = np.random.default_rng(11)
+    V, Dg, Bg = 97, 8, 20
+    emb, bias = rng.standard_normal((V, Dg)) * 0.3, rng.standard_normal((V, 1)) * 0.05
+    a_e, a_b = np.full_like(emb, 0.1), np.full_like(bias, 0.1)
+    brngs = [np.random.default_rng(100 + r) for r in range(WORLD)]
+    for _ in range(3):
+        ids_all, rows_all, gb_all = [], [], []
+        for r in range(WORLD):
+            inp, tgt = brngs[r].integers(0, V, (2, Bg)).astype(np.int32), brngs[r].uniform(0.1, 300, Bg)
+            _, gdot, gs = o_glove.loss_and_grads(emb, bias, inp, tgt, "diagonal", np.float64)
+            ids, rows, gb = o_glove.row_grads(emb, inp, gdot, gs, np.float64)
+            ids_all.append(ids), rows_all.append(rows), gb_all.append(gb)
+        ids_c = np.concatenate(ids_all)
+        emb, a_e = o_optim.sparse_adagrad_update(emb, a_e, ids_c, np.concatenate(rows_all), 0.05, dtype=np.float64)
+        bias, a_b = o_optim.sparse_adagrad_update(bias, a_b, ids_c, np.concatenate(gb_all)[:, None], 0.05,
+                                                  dtype=np.float64)
+    assert np.abs(outs[0]["emb"] - emb).max() <= 1e-12 and np.abs(outs[0]["bias"] - bias).max() <= 1e-12
