@@ -923,7 +923,8 @@ def secondary_legs(args, dev, rank):
 
     def ivf():  # config 5's "ANN scoring vs brute force": the IVF index against the EXACT answer on the same corpus
         r = measure_ivf(dev, corpus="clustered")
-        r["hierarchical_corpus"] = measure_ivf(dev, ks=(500,), nprobes=(16, 32, 64), steps=2, corpus="hierarchical")
+        r["hierarchical_corpus"] = measure_ivf(dev, ks=(500,), nprobes=(16, 32, 64), nlist=4096, steps=2,
+                                               corpus="hierarchical")
         r["iid_corpus_worst_case"] = measure_ivf(dev, ks=(10,), nprobes=(32,), steps=2, corpus="iid")
         return r
     guarded("retrieve_c5_n1m_ivf_vs_brute_force", ivf)

@@ -37,7 +37,8 @@ int select_topk_head(const float* scores, int64_t pitch, int64_t rows, int n, in
 int select_topk_tail(const int2* pairs, int64_t ppitch, const int32_t* cnt, int64_t rows, int k, float* out_scores,
                      int32_t* out_indices, hipStream_t st);
 // between two filtered passes: every list cut back to its k best (in place), cnt = min(cnt, k), tau raised
-int select_topk_compact(int2* pairs, int64_t ppitch, int32_t* cnt, int64_t rows, int k, float* tau, hipStream_t st);
+int select_topk_compact(int2* pairs, int64_t ppitch, int32_t* cnt, int64_t rows, int k, float* tau, hipStream_t st,
+                        int skip_upto = 0);
 
 inline hipStream_t as_stream(esr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 

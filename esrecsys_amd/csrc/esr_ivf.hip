@@ -211,6 +211,7 @@ struct IvfGeom {
   int f;           // probe slots scored densely first: the fewest whose rows hold more than k entries
   int64_t ppitch;  // a query's record list: k + everything one round could let through
   int64_t chunk;   // queries per pass (head scores + record lists stay under ~2 GiB)
+  int mark;        // lazy compaction: lists up to this long are not selected down between rounds
 };
 static IvfGeom ivf_geom(int64_t nq, int max_list, int nprobe, int k) {
   IvfGeom g;
@@ -218,7 +219,10 @@ static IvfGeom ivf_geom(int64_t nq, int max_list, int nprobe, int k) {
   // (as many as the head select still caches in LDS -- 8192 scores: a list with few pairs fills little of a 64-row
   // tile, so three slots cost the scoring pass what one does, and tau starts tighter)
   g.f = (int)std::min<int64_t>(nprobe, std::max<int64_t>(k / g.pitch + 1, 8192 / g.pitch));
-  g.ppitch = (int64_t)k + (int64_t)std::min(kIvfRound, nprobe - g.f) * g.pitch;
+  // (lazy compaction, as in esr_retrieve_topk: a list is selected down to its k best between rounds only once it holds
+  // more than `mark` records -- the select was 27 % of a k = 500 search in round 3)
+  g.mark = (int)std::max<int64_t>(3 * (int64_t)k, 1536);
+  g.ppitch = std::max<int64_t>(k, g.mark) + (int64_t)std::min(kIvfRound, nprobe - g.f) * g.pitch;
   const int64_t per_query = g.f * g.pitch * 4 + g.ppitch * 8;
   g.chunk = std::min(nq, std::max<int64_t>(64, ((int64_t)1 << 31) / per_query));
   return g;
@@ -320,7 +324,7 @@ int esr_ivf_search(const float* queries, int64_t nq, int D, const float* cands_s
                                        stream))
         return rc;
       if (s0 + n < nprobe)
-        if (int rc = select_topk_compact(ws.pairs, g.ppitch, ws.cnt, cq, k, ws.tau, st)) return rc;
+        if (int rc = select_topk_compact(ws.pairs, g.ppitch, ws.cnt, cq, k, ws.tau, st, g.mark)) return rc;
     }
     if (int rc = select_topk_tail(ws.pairs, g.ppitch, ws.cnt, cq, k, out_scores + q0 * k, out_indices + q0 * k, st))
       return rc;

@@ -858,11 +858,13 @@ int select_topk_tail(const int2* pairs, int64_t ppitch, const int32_t* cnt, int6
   return check_launch("select_topk_tail");
 }
 
-int select_topk_compact(int2* pairs, int64_t ppitch, int32_t* cnt, int64_t rows, int k, float* tau, hipStream_t st) {
+int select_topk_compact(int2* pairs, int64_t ppitch, int32_t* cnt, int64_t rows, int k, float* tau, hipStream_t st,
+                        int skip_upto) {
   if (k > kSelMaxK) return ESR_EINVAL;
   SelIn in;
   in.vals = (const float*)pairs; in.vpitch = 2 * ppitch; in.idx = (const int32_t*)pairs + 1; in.stride = 2;
   in.ibase = 0; in.istep = 0; in.n_per_row = cnt; in.n_fixed = 0;
+  in.skip_upto = skip_upto;  // lazy compaction: shorter lists are left to grow (their tau stays a valid lower bound)
   SelOut so;
   so.pairs = pairs; so.ppitch = ppitch; so.cnt = cnt; so.tau = tau; so.scores = nullptr; so.indices = nullptr;
   hipLaunchKernelGGL(topk_select_kernel, dim3((int)rows), dim3(kSelThreads), kSelLdsWords * sizeof(uint32_t), st, in, k, so,
