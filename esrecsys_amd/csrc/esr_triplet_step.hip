@@ -64,9 +64,13 @@ __device__ __forceinline__ uint32_t code_of(uint32_t vid, uint32_t byte, uint32_
 
 // ---- the plan of one batch: everything the update kernel needs besides the tables, from the ids alone ----------------
 struct TripPlan {
-  int* flags;                   // [0] parked: set by the update kernel when it parks a chunk partial; [1 .. 63] unused
+  int* flags;                   // [0] parked: set by the update kernel when it parks a chunk partial; [1] direct mode:
+                                //     number of long runs (= entries of long_heads); [2 .. 63] unused
   unsigned long long* loss_acc; // [kFixAccWords]  fixed-point loss accumulator, zero before the update kernel
-  uint2* meta;                  // [n]  {partner A | slot << 30, partner B}
+  uint2* meta;                  // [n]  stamped mode: {partner A | slot << 30, partner B} per sorted position;
+                                //      direct mode: the occurrence codes (see triplet_direct_plan_kernel) per OCCURRENCE
+  uint32_t* cnt;                // [n]  direct mode: arrivals per run, at the run's head position; zero before the step
+  int32_t* long_heads;          // [n / 9 + 1]  direct mode: head positions of the runs longer than kDirectMaxRun
 };
 static size_t trip_plan_layout(int64_t B, char* base, TripPlan* out) {
   const int64_t n = 3 * B;
@@ -80,6 +84,8 @@ static size_t trip_plan_layout(int64_t B, char* base, TripPlan* out) {
   pl.flags = (int*)take(sizeof(int) * 64);
   pl.loss_acc = (unsigned long long*)take(sizeof(unsigned long long) * kFixAccWords);
   pl.meta = (uint2*)take(sizeof(uint2) * (size_t)n);
+  pl.cnt = (uint32_t*)take(sizeof(uint32_t) * (size_t)n);
+  pl.long_heads = (int32_t*)take(sizeof(int32_t) * (size_t)(n / 9 + 1));
   if (out) *out = pl;
   return off;
 }
@@ -87,7 +93,8 @@ static size_t trip_plan_layout(int64_t B, char* base, TripPlan* out) {
 struct TripWs {
   int32_t* sorted_ids;  // [n]
   int32_t* perm;        // [n]
-  float* chunk_rows;    // [2 * ceil(n / 8)][D]
+  float* chunk_rows;    // [n][D]  stamped mode: [2 * ceil(n / 8)][D] partial sums of long runs; direct mode: the gradient
+                        //         row of every occurrence of a DUPLICATED row, at its sorted position
   char* plan;           // trip_plan_layout(B) bytes: the in-line plan of a call that brings none
   void* sort_ws;
   size_t sort_ws_bytes;
@@ -104,7 +111,7 @@ static size_t trip_ws_layout(int64_t B, int D, char* base, TripWs* ws) {
   TripWs w;
   w.sorted_ids = (int32_t*)take(sizeof(int32_t) * (size_t)n);
   w.perm = (int32_t*)take(sizeof(int32_t) * (size_t)n);
-  w.chunk_rows = (float*)take(sizeof(float) * 2 * (size_t)cdiv(n, kTripChunk) * (size_t)D);
+  w.chunk_rows = (float*)take(sizeof(float) * (size_t)n * (size_t)D);
   w.plan = take(trip_plan_layout(B, nullptr, nullptr));
   w.sort_ws_bytes = esr_segment_sort_workspace_bytes(n);
   w.sort_ws = take(w.sort_ws_bytes);
@@ -481,6 +488,380 @@ __global__ __launch_bounds__(kBlock) void rows_restamp_kernel(uint8_t* __restric
     for (int64_t i = nv * 16 + threadIdx.x; i < V; i += kBlock) loc[i] &= 1;
 }
 
+// =====================================================================================================================
+// DIRECT mode (round 4, the default): the step walks the TRIPLETS, not the sorted occurrences, and updates rows in place.
+//
+// The stamped kernel above reads, per occurrence, its own row, its accumulator and BOTH partner rows: 3 x (4 reads + 2
+// writes) = 18 row transfers per triplet (measured 9.8 KB per triplet at D = 128), although a triplet only has three rows.
+// Here one row group owns one triplet: its three rows are read ONCE, the three gradient rows are formed on chip, and
+//   * a row that occurs once in the batch (nearly every row of a uniform batch at the reference's sizes) is stepped on the
+//     spot: accumulator read, Adagrad, row + accumulator written IN PLACE -- 4 transfers per row, the fused minimum.
+//     Nobody else reads that row during the step (only its own triplet holds it), so there is nothing to double-buffer:
+//     no shadow table, no location bytes, no stamp -- and one dependent round trip fewer per row than the stamped walk
+//     (ids -> rows instead of record -> location bytes -> rows);
+//   * a row with 2 .. kDirectMaxRun occurrences is stepped by whichever of its triplets finishes LAST: every occurrence
+//     writes its gradient row to the side buffer at its sorted position (written through to the memory side), then counts
+//     itself in at the run's head position with one atomic; the arrival that completes the run has thereby seen every
+//     other occurrence finish its READ of the row, sums the run's gradient rows in sorted order (the association of the
+//     segment kernels: left to right from zero) and does the row's one read-modify-write;
+//   * longer runs (hot rows: Zipfian ids) leave their gradient rows in the side buffer for triplet_direct_long_kernel --
+//     launched only when the plan found such a run (the long-run hint, as before).
+// The plan (from the sorted ids alone, made ahead for eight batches): per occurrence its sorted position, "duplicated?",
+// "long?", the run's head and length; the counters zeroed; the list of long runs.
+// Same element arithmetic (trip_grad, adagrad_elem) as esr_triplet_fwd_bwd + esr_sparse_adagrad_scatter_multi; rows with
+// up to kDirectMaxRun occurrences get the same bits as that path, longer runs a different (fixed) association.
+// =====================================================================================================================
+constexpr int kDirectMaxRun = 8;
+constexpr uint32_t kDupBit = 0x80000000u, kLongBit = 0x40000000u, kPosMask = 0x3FFFFFFFu;
+constexpr uint32_t kHeadMask = 0x1FFFFFFFu;  // code.y = head position | (run length - 1) << 29
+
+__global__ __launch_bounds__(kBlock) void triplet_direct_plan_kernel(const int32_t* __restrict__ sorted_all,
+                                                                    const int32_t* __restrict__ perm_all, int64_t B,
+                                                                    char* __restrict__ plans, size_t plan_stride,
+                                                                    int* __restrict__ hints, int gen) {
+  const int list = blockIdx.y;
+  const int64_t n = 3 * B;
+  const int32_t* __restrict__ sorted = sorted_all + (int64_t)list * n;
+  const int32_t* __restrict__ perm = perm_all + (int64_t)list * n;
+  char* base = plans + (size_t)list * plan_stride;
+  int* flags = (int*)base;
+  unsigned long long* loss_acc = (unsigned long long*)(base + 256);
+  char* q = base + 256 + align_up(sizeof(unsigned long long) * kFixAccWords, 256);
+  uint2* code = (uint2*)q;
+  q += align_up(sizeof(uint2) * (size_t)n, 256);
+  uint32_t* cnt = (uint32_t*)q;
+  q += align_up(sizeof(uint32_t) * (size_t)n, 256);
+  int32_t* long_heads = (int32_t*)q;
+  if (blockIdx.x == 0) {
+    // (flags[1], the long-run count, is zeroed by the host side before this launch: other workgroups add to it)
+    if (threadIdx.x < 64 && threadIdx.x != 1) flags[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < kFixAccWords; i += kBlock) loss_acc[i] = 0ull;
+  }
+  bool any_long = false;
+  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock) {
+    const int32_t id = sorted[p];
+    int lb = 0, lf = 0;
+    while (lb < kDirectMaxRun && p - lb - 1 >= 0 && sorted[p - lb - 1] == id) ++lb;
+    while (lf < kDirectMaxRun && p + lf + 1 < n && sorted[p + lf + 1] == id) ++lf;
+    const int len = lb + lf + 1;
+    const bool is_long = lb == kDirectMaxRun || lf == kDirectMaxRun || len > kDirectMaxRun;
+    uint2 c;
+    c.x = (uint32_t)p | (len > 1 ? kDupBit : 0u) | (is_long ? kLongBit : 0u);
+    c.y = is_long ? 0u : ((uint32_t)(p - lb) | ((uint32_t)(len - 1) << 29));
+    code[perm[p]] = c;
+    cnt[p] = 0u;
+    if (is_long) {
+      any_long = true;
+      if (lb == 0) long_heads[atomicAdd(&flags[1], 1)] = (int32_t)p;  // the run's first position (order-free list)
+    }
+  }
+  if (hints && __any(any_long) && (threadIdx.x & 63) == 0) hints[list] = gen;  // (every writer stores the same value)
+}
+
+struct DirectTowers {
+  float* s;     // scene tower, updated in place           virtual rows [0, Vs)
+  float* p;     // product tower                           virtual rows [Vs, Vs + Vp)
+  float* sacc;
+  float* pacc;
+};
+
+// gradient rows written through to the memory side / read from it (another workgroup of the SAME launch is the reader):
+// 8-byte agent-scope accesses, two per float4 chunk
+template <int VEC, int NCH>
+__device__ __forceinline__ void side_store(const RowRegs<VEC, NCH>& r, float* __restrict__ dst, int lig, int G, int nvec) {
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int c = lig + k * G;
+    if (c < nvec) {
+      if constexpr (VEC == 4) {
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(dst + 4 * c);
+        const unsigned long long lo = (unsigned long long)__float_as_uint(r.v[k][0]) |
+                                      ((unsigned long long)__float_as_uint(r.v[k][1]) << 32);
+        const unsigned long long hi = (unsigned long long)__float_as_uint(r.v[k][2]) |
+                                      ((unsigned long long)__float_as_uint(r.v[k][3]) << 32);
+        __hip_atomic_store(d, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(d + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        __hip_atomic_store(reinterpret_cast<unsigned*>(dst + c), __float_as_uint(r.v[k][0]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+template <int VEC, int NCH>
+__device__ __forceinline__ void side_load(RowRegs<VEC, NCH>& r, const float* __restrict__ src, int lig, int G, int nvec) {
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int c = lig + k * G;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) r.v[k][e] = 0.f;
+    if (c < nvec) {
+      if constexpr (VEC == 4) {
+        const unsigned long long* d = reinterpret_cast<const unsigned long long*>(src + 4 * c);
+        const unsigned long long lo = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long hi = __hip_atomic_load(d + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r.v[k][0] = __uint_as_float((uint32_t)lo);
+        r.v[k][1] = __uint_as_float((uint32_t)(lo >> 32));
+        r.v[k][2] = __uint_as_float((uint32_t)hi);
+        r.v[k][3] = __uint_as_float((uint32_t)(hi >> 32));
+      } else {
+        r.v[k][0] = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(src + c), __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT));
+      }
+    }
+  }
+}
+
+template <int VEC, int NCH>
+__global__ __launch_bounds__(kBlock) void triplet_direct_kernel(DirectTowers tt, int D, int G,
+                                                               const int32_t* __restrict__ scene_ids,
+                                                               const int32_t* __restrict__ pos_ids,
+                                                               const int32_t* __restrict__ neg_ids,
+                                                               const uint2* __restrict__ code, int64_t B, float lam,
+                                                               float inv_bs, int with_reg, float lr, float eps,
+                                                               float* __restrict__ side, uint32_t* __restrict__ cnt,
+                                                               int* __restrict__ parked,
+                                                               unsigned long long* __restrict__ loss_acc, int frac,
+                                                               double inv_batch_size, float* __restrict__ loss) {
+  __shared__ double sm[8];
+  const int lig = threadIdx.x & (G - 1);
+  const int lane = threadIdx.x & 63;
+  const int glane0 = lane & ~(G - 1);  // first lane of this row group inside the wave
+  const int64_t gpb = kBlock / G;
+  const int64_t group = (int64_t)blockIdx.x * gpb + threadIdx.x / G;
+  const int64_t ngroups = (int64_t)gridDim.x * gpb;
+  const int nvec = D / VEC;
+  const int64_t per = (B + ngroups - 1) / ngroups;
+  const int64_t b_begin = min(B, group * per), b_end = min(B, (group + 1) * per);
+  double acc_loss = 0.0;
+  // ids and codes of the triplet AFTER the current one are requested while the current one's rows travel
+  int32_t n_sid = 0, n_pid = 0, n_nid = 0;
+  uint2 n_cs = make_uint2(0, 0), n_cp = n_cs, n_cn = n_cs;
+  auto fetch = [&](int64_t b) {
+    n_sid = scene_ids[b];
+    n_pid = pos_ids[b];
+    n_nid = neg_ids[b];
+    n_cs = code[b];
+    n_cp = code[B + b];
+    n_cn = code[2 * B + b];
+  };
+  if (b_begin < b_end) fetch(b_begin);
+  for (int64_t b = b_begin; b < b_end; ++b) {
+    const int64_t sid = n_sid, pid = n_pid, nid = n_nid;
+    const uint2 cs = n_cs, cp = n_cp, cn = n_cn;
+    float* const srow = tt.s + sid * D;
+    float* const prow = tt.p + pid * D;
+    float* const nrow = tt.p + nid * D;
+    RowRegs<VEC, NCH> S, P, N, aS, aP, aN;
+    row_load(S, srow, lig, G, nvec);
+    row_load(P, prow, lig, G, nvec);
+    row_load(N, nrow, lig, G, nvec);
+    // accumulators of the rows this group steps itself (a duplicated row's is read by the arrival that completes its run)
+    if (!(cs.x & kDupBit)) row_load(aS, tt.sacc + sid * D, lig, G, nvec);
+    if (!(cp.x & kDupBit)) row_load(aP, tt.pacc + pid * D, lig, G, nvec);
+    if (!(cn.x & kDupBit)) row_load(aN, tt.pacc + nid * D, lig, G, nvec);
+    if (b + 1 < b_end) fetch(b + 1);
+    // scores and norms: the expressions (and roundings) of triplet_step_kernel's occ()
+    const float d_sp = group_sum(row_dot_partial(S, P), G);
+    const float d_sn = group_sum(row_dot_partial(S, N), G);
+    float ns = 0.f, np_ = 0.f, nn = 0.f, c_s = 0.f, c_p = 0.f, c_n = 0.f;
+    if (with_reg) {
+      ns = sqrtf(group_sum(row_dot_partial(S, S), G));
+      np_ = sqrtf(group_sum(row_dot_partial(P, P), G));
+      nn = sqrtf(group_sum(row_dot_partial(N, N), G));
+      c_s = ns > 1.f ? lam / ns : 0.f;
+      c_p = np_ > 1.f ? lam / np_ : 0.f;
+      c_n = nn > 1.f ? lam / nn : 0.f;
+    }
+    const float margin = 1.0f + d_sn - d_sp;
+    const float mk = margin > 0.f ? 1.f : 0.f;
+    RowRegs<VEC, NCH> gS, gP, gN;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        // (0 + g: the segment kernels start every row sum from zero)
+        gS.v[k][e] = __fadd_rn(0.f, trip_grad(mk, __fsub_rn(N.v[k][e], P.v[k][e]), c_s, S.v[k][e], inv_bs));
+        gP.v[k][e] = __fadd_rn(0.f, trip_grad(-mk, S.v[k][e], c_p, P.v[k][e], inv_bs));
+        gN.v[k][e] = __fadd_rn(0.f, trip_grad(mk, S.v[k][e], c_n, N.v[k][e], inv_bs));
+      }
+    {
+      float loss_b = fmaxf(margin, 0.f);
+      if (with_reg) loss_b += lam * (fmaxf(ns - 1.f, 0.f) + fmaxf(np_ - 1.f, 0.f) + fmaxf(nn - 1.f, 0.f));
+      if (lig == 0) acc_loss += (double)loss_b;
+    }
+    // the three occurrences.  Unique rows are stepped on the spot.  Duplicated rows: all gradient rows of the triplet go
+    // to the side buffer first, ONE wait covers them, the (up to three) arrivals are counted by atomics issued together
+    // -- two dependent round trips per triplet however many of its rows are duplicated -- and only then does an arrival
+    // that completed its run sum it.
+    auto step_here = [&](float* row, float* accrow, RowRegs<VEC, NCH>& own, RowRegs<VEC, NCH>& a,
+                         const RowRegs<VEC, NCH>& g) {
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) adagrad_elem(own.v[k][e], a.v[k][e], g.v[k][e], lr, eps);
+      row_store(a, accrow, lig, G, nvec);
+      row_store(own, row, lig, G, nvec);
+    };
+    auto park = [&](uint2 c, const RowRegs<VEC, NCH>& g) {  // a duplicated row's gradient row -> side buffer
+      const int64_t pos = c.x & kPosMask;
+      if (c.x & kLongBit) {
+        row_store(g, side + pos * D, lig, G, nvec);
+        if (lig == 0) *parked = 1;  // (every writer stores the same value)
+      } else {
+        side_store(g, side + pos * D, lig, G, nvec);
+      }
+    };
+    const bool dS = (cs.x & kDupBit) != 0, dP = (cp.x & kDupBit) != 0, dN = (cn.x & kDupBit) != 0;
+    if (!dS) step_here(srow, tt.sacc + sid * D, S, aS, gS);
+    if (!dP) step_here(prow, tt.pacc + pid * D, P, aP, gP);
+    if (!dN) step_here(nrow, tt.pacc + nid * D, N, aN, gN);
+    if (dS | dP | dN) {
+      if (dS) park(cs, gS);
+      if (dP) park(cp, gP);
+      if (dN) park(cn, gN);
+      // this group's gradient rows are at the memory side before it is counted in (the wave waits for its lanes' stores)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const bool sS = dS && !(cs.x & kLongBit), sP = dP && !(cp.x & kLongBit), sN = dN && !(cn.x & kLongBit);
+      uint32_t oS = 0xFFFFFFFFu, oP = 0xFFFFFFFFu, oN = 0xFFFFFFFFu;
+      if (lig == 0) {
+        if (sS) oS = atomicAdd(cnt + (cs.y & kHeadMask), 1u);
+        if (sP) oP = atomicAdd(cnt + (cp.y & kHeadMask), 1u);
+        if (sN) oN = atomicAdd(cnt + (cn.y & kHeadMask), 1u);
+      }
+      oS = (uint32_t)__shfl((int)oS, glane0, 64);
+      oP = (uint32_t)__shfl((int)oP, glane0, 64);
+      oN = (uint32_t)__shfl((int)oN, glane0, 64);
+      // an arrival that completed its run: every other occurrence has read the row and left its gradient row -- sum them
+      // in sorted order and do the row's one read-modify-write
+      auto complete = [&](uint2 c, float* row, float* accrow, RowRegs<VEC, NCH>& own, RowRegs<VEC, NCH>& a) {
+        const int64_t head = c.y & kHeadMask;
+        const uint32_t len = (c.y >> 29) + 1u;
+        RowRegs<VEC, NCH> sum;
+        row_zero(sum);
+        row_load(a, accrow, lig, G, nvec);
+        for (uint32_t j = 0; j < len; ++j) {
+          RowRegs<VEC, NCH> t;
+          side_load(t, side + (head + j) * D, lig, G, nvec);
+#pragma unroll
+          for (int k = 0; k < NCH; ++k)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) sum.v[k][e] = __fadd_rn(sum.v[k][e], t.v[k][e]);
+        }
+        step_here(row, accrow, own, a, sum);
+      };
+      if (sS && oS == (cs.y >> 29)) complete(cs, srow, tt.sacc + sid * D, S, aS);
+      if (sP && oP == (cp.y >> 29)) complete(cp, prow, tt.pacc + pid * D, P, aP);
+      if (sN && oN == (cn.y >> 29)) complete(cn, nrow, tt.pacc + nid * D, N, aN);
+    }
+  }
+  const double t = block_sum_d(acc_loss, sm);
+  if (threadIdx.x == 0) {
+    double total;
+    unsigned flags;
+    if (fixed_sum_arrive(loss_acc, t, frac, gridDim.x, &total, &flags))
+      loss[0] = (flags & 1u) ? __builtin_nanf("") : ((flags & 2u) ? __builtin_inff() : (float)(total * inv_batch_size));
+  }
+}
+
+// the runs longer than kDirectMaxRun: one workgroup per run (the plan's list).  The association of the segment kernels
+// (esr_optim.hip), cut point for cut point: partial 0 = the head chunk [head, the chunk boundary after the next one),
+// partial i >= 1 = the 32 positions from boundary nxt + 32 (i - 1), each summed left to right from zero; row group gi
+// adds partials gi, gi + NG, ... in order; the groups' sums are combined in group order.  With the same lanes per row
+// (row_geom) a hot row gets the bits esr_sparse_adagrad_scatter_multi gives it.
+template <int VEC, int NCH>
+__global__ __launch_bounds__(kBlock) void triplet_direct_long_kernel(DirectTowers tt, int D, int G, int64_t Vs,
+                                                                    const int32_t* __restrict__ sorted_ids, int64_t n,
+                                                                    float lr, float eps, const float* __restrict__ side,
+                                                                    const int* __restrict__ flags,
+                                                                    const int32_t* __restrict__ long_heads) {
+  if (flags[0] == 0) return;  // nothing was parked
+  __shared__ float red[kBlock * VEC * NCH];
+  const int tid = threadIdx.x, lig = tid & (G - 1), gidx = tid / G, NG = kBlock / G;
+  const int nvec = D / VEC;
+  const int nlong = flags[1];
+  for (int li = blockIdx.x; li < nlong; li += gridDim.x) {
+    const int64_t head = long_heads[li];
+    const uint32_t id = (uint32_t)sorted_ids[head];
+    int64_t len = 0;  // run length
+    for (int64_t k0 = 0;; k0 += kBlock) {
+      const int64_t pos = head + k0 + tid;
+      const int c = __syncthreads_count(pos < n && (uint32_t)sorted_ids[pos] == id);
+      len += c;
+      if (c < kBlock) break;
+    }
+    const int64_t end = head + len;
+    const int64_t nxt = min(end, ((head + 2 * kStepChunk - 1) / kStepChunk) * kStepChunk);  // end of the head chunk
+    const int64_t K = (end - nxt + kStepChunk - 1) / kStepChunk;                          // continuation chunks
+    RowRegs<VEC, NCH> acc;
+    row_zero(acc);
+    for (int64_t i = gidx; i <= K; i += NG) {
+      const int64_t q0 = i == 0 ? head : nxt + (i - 1) * kStepChunk;
+      const int64_t q1 = i == 0 ? nxt : min(end, q0 + kStepChunk);
+      RowRegs<VEC, NCH> c;
+      row_zero(c);
+      int64_t q = q0;
+      for (; q + 4 <= q1; q += 4) {  // four rows in flight, added in order
+        RowRegs<VEC, NCH> t0, t1, t2, t3;
+        row_load(t0, side + q * D, lig, G, nvec);
+        row_load(t1, side + (q + 1) * D, lig, G, nvec);
+        row_load(t2, side + (q + 2) * D, lig, G, nvec);
+        row_load(t3, side + (q + 3) * D, lig, G, nvec);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e)
+            c.v[k][e] = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(c.v[k][e], t0.v[k][e]), t1.v[k][e]), t2.v[k][e]), t3.v[k][e]);
+      }
+      for (; q < q1; ++q) {
+        RowRegs<VEC, NCH> t;
+        row_load(t, side + q * D, lig, G, nvec);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) c.v[k][e] = __fadd_rn(c.v[k][e], t.v[k][e]);
+      }
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc.v[k][e] += c.v[k][e];
+    }
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) red[((gidx * G + lig) * NCH + k) * VEC + e] = acc.v[k][e];
+    __syncthreads();
+    if (gidx == 0) {
+      const int used = (int)min<int64_t>(NG, K + 1);
+      for (int gg = 1; gg < used; ++gg)
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc.v[k][e] += red[((gg * G + lig) * NCH + k) * VEC + e];
+      const bool prod = (int64_t)id >= Vs;
+      const int64_t r = prod ? (int64_t)id - Vs : (int64_t)id;
+      float* row = (prod ? tt.p : tt.s) + r * D;
+      float* accrow = (prod ? tt.pacc : tt.sacc) + r * D;
+      RowRegs<VEC, NCH> own, a;
+      row_load(own, row, lig, G, nvec);
+      row_load(a, accrow, lig, G, nvec);
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) adagrad_elem(own.v[k][e], a.v[k][e], acc.v[k][e], lr, eps);
+      row_store(a, accrow, lig, G, nvec);
+      row_store(own, row, lig, G, nvec);
+    }
+    __syncthreads();
+  }
+}
+
+// ESR_TRIPLET_STEP=stamped keeps the double-buffered walk over the sorted occurrences (rounds 2-3); default: direct
+static bool trip_direct_mode() {
+  const char* e = getenv("ESR_TRIPLET_STEP");
+  return !(e && e[0] == 's');
+}
+
 static int launch_trip_plan(const int32_t* const* ids, int nbatch, const int32_t* sorted_ids, const int32_t* perm,
                             int64_t B, int64_t Vs, char* plans, size_t stride, int* hints, int gen, hipStream_t st) {
   PlanBatch pb;
@@ -492,6 +873,14 @@ static int launch_trip_plan(const int32_t* const* ids, int nbatch, const int32_t
   }
   const int64_t n = 3 * B;
   const int gx = (int)std::min<int64_t>(kMaxGrid, cdiv(n, kBlock));
+  if (trip_direct_mode()) {
+    // (the long-run counters are zeroed in front of the plan launch: its workgroups add to them in any order)
+    for (int b = 0; b < nbatch; ++b)
+      if (hipMemsetAsync(plans + (size_t)b * stride + sizeof(int), 0, sizeof(int), st) != hipSuccess) return ESR_ELAUNCH;
+    hipLaunchKernelGGL(triplet_direct_plan_kernel, dim3(gx, nbatch), dim3(kBlock), 0, st, sorted_ids, perm, B, plans, stride,
+                       hints, gen);
+    return ESR_OK;
+  }
   hipLaunchKernelGGL(triplet_plan_kernel, dim3(gx, nbatch), dim3(kBlock), 0, st, pb, sorted_ids, perm, B, Vs, plans, stride,
                      hints, gen);
   return ESR_OK;
@@ -561,6 +950,28 @@ static int launch_trip_step(const TwoTowers& tt, int D, const RowGeom& g, const 
   int grid = grid_for_groups(n, g.G);
   const int grid2 = (int)std::min<int64_t>(kMaxGrid, cdiv(cdiv(n, kTripChunk), 4));
   const float inv_bs = 1.0f / batch_size;
+  if (trip_direct_mode()) {
+    // rows are stepped in place in the primary buffers (the second buffers and location bytes are not touched: the
+    // caller's rows never leave home)
+    const DirectTowers dt{tt.s0, tt.p0, tt.sacc, tt.pacc};
+    // lanes per row: a triplet's five dot products are a small part of its work (the stamped walk had six per occurrence
+    // and wanted few lanes); ESR_TRIPLET_DIRECT_LANES=few keeps step_geom_few_lanes
+    const char* le = getenv("ESR_TRIPLET_DIRECT_LANES");
+    const RowGeom gd = (le && le[0] == 'f') ? g : row_geom(D);
+    const RowGeom& g = gd;
+    ESR_DISPATCH_ROW(g, {
+      static const int resident = resident_blocks((const void*)triplet_direct_kernel<VEC, NCH>);
+      const int gridd = std::min(grid_for_groups(B, g.G), resident);
+      ESR_KT("triplet_direct_kernel", st, hipLaunchKernelGGL((triplet_direct_kernel<VEC, NCH>), dim3(gridd), dim3(kBlock), 0, st, dt, D, g.G, scene_ids,
+                         pos_ids, neg_ids, (const uint2*)pl.meta, B, regularization, inv_bs, 1, lr, eps, ws.chunk_rows,
+                         pl.cnt, pl.flags, pl.loss_acc, loss_frac_bits(B), 1.0 / (double)batch_size, loss));
+      if (long_runs != 0)  // 0 = the caller knows (the plan's hint) that no run is longer than kDirectMaxRun
+        ESR_KT("triplet_direct_long_kernel", st, hipLaunchKernelGGL((triplet_direct_long_kernel<VEC, NCH>), dim3(256), dim3(kBlock), 0, st, dt, D, g.G,
+                           tt.Vs, sorted, n, lr, eps, (const float*)ws.chunk_rows, (const int*)pl.flags,
+                           (const int32_t*)pl.long_heads));
+    });
+    return ESR_OK;
+  }
   ESR_DISPATCH_ROW(g, {
     static const int resident = resident_blocks((const void*)triplet_step_kernel<VEC, NCH>);  // (one query per process)
     grid = std::min(grid, resident);
@@ -579,10 +990,12 @@ static int launch_trip_step(const TwoTowers& tt, int D, const RowGeom& g, const 
               (long long)Vp, D, (long long)B);                                                                         \
   ESR_REQUIRE(Vs + Vp <= (int64_t)kIdMask, who ": %lld virtual rows exceed 2^30 - 1", (long long)(Vs + Vp));           \
   ESR_REQUIRE(3 * B < ((int64_t)1 << 31), who ": B=%lld too large", (long long)B);                                     \
-  ESR_REQUIRE(scene && scene_shadow && scene_loc && scene_accum && product && product_shadow && product_loc &&        \
-                  product_accum,                                                                                       \
-              who ": null table pointer");                                                                             \
-  ESR_REQUIRE(scene != scene_shadow && product != product_shadow, who ": a shadow table must be a second buffer");     \
+  ESR_REQUIRE(scene && scene_accum && product && product_accum, who ": null table pointer");                           \
+  /* direct mode (the default) steps rows in place: the second buffers and location bytes are not used, may be NULL */ \
+  ESR_REQUIRE(trip_direct_mode() || (scene_shadow && scene_loc && product_shadow && product_loc),                      \
+              who ": null second buffer / location bytes (ESR_TRIPLET_STEP=stamped needs them)");                      \
+  ESR_REQUIRE(trip_direct_mode() || (scene != scene_shadow && product != product_shadow),                              \
+              who ": a shadow table must be a second buffer");                                                         \
   ESR_REQUIRE(batch_size != 0.f, who ": batch_size must be non-zero");                                                 \
   const RowGeom g = step_geom_few_lanes(D);                                                                            \
   ESR_REQUIRE(g.nch <= kMaxChunksPerLane, who ": D=%d not supported", D);                                              \
@@ -603,7 +1016,8 @@ int esr_triplet_train_step(float* scene, float* scene_shadow, uint8_t* scene_loc
                            esr_stream_t stream) {
   ESR_TRIP_STEP_CHECKS("esr_triplet_train_step")
   ESR_REQUIRE(scene_ids && pos_ids && neg_ids && loss, "esr_triplet_train_step: null pointer");
-  ESR_REQUIRE(stamp >= 1 && stamp <= kStampMax, "esr_triplet_train_step: stamp %u not in [1, %u]", stamp, kStampMax);
+  ESR_REQUIRE(trip_direct_mode() || (stamp >= 1 && stamp <= kStampMax), "esr_triplet_train_step: stamp %u not in [1, %u]",
+              stamp, kStampMax);
   ESR_REQUIRE((presorted_ids == nullptr) == (presorted_perm == nullptr),
               "esr_triplet_train_step: presorted_ids and presorted_perm must both be set or both be NULL");
   ESR_REQUIRE(!plan || presorted_ids, "esr_triplet_train_step: a plan goes with the sorted ids it was made from");
@@ -640,7 +1054,7 @@ int esr_triplet_train_steps(float* scene, float* scene_shadow, uint8_t* scene_lo
   ESR_REQUIRE(nbatch >= 1 && nbatch <= kMaxPlanBatch && ids && sorted_ids && perm && plans && losses &&
                   !((uintptr_t)plans & 255),
               "esr_triplet_train_steps: nbatch=%d not in [1, %d], or a null / misaligned pointer", nbatch, kMaxPlanBatch);
-  ESR_REQUIRE(first_stamp >= 1 && first_stamp + (uint32_t)nbatch - 1 <= kStampMax,
+  ESR_REQUIRE(trip_direct_mode() || (first_stamp >= 1 && first_stamp + (uint32_t)nbatch - 1 <= kStampMax),
               "esr_triplet_train_steps: stamps %u .. %u leave [1, %u]", first_stamp, first_stamp + nbatch - 1, kStampMax);
   for (int i = 0; i < 3 * nbatch; ++i) ESR_REQUIRE(ids[i], "esr_triplet_train_steps: null id list %d", i);
   hipStream_t st = as_stream(stream);

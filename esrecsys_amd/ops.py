@@ -351,6 +351,12 @@ def triplet_plan(id_lists, Vs, sorted_ids, perm, hints=None, gen=0):
     return plans
 
 
+def triplet_direct_mode():
+    """True (default) when the one-pass triplet step walks the TRIPLETS and steps rows in place (esr_triplet_step.hip,
+    "DIRECT mode"); ESR_TRIPLET_STEP=stamped: the double-buffered walk over the sorted occurrences of rounds 2-3."""
+    return not os.environ.get("ESR_TRIPLET_STEP", "direct").startswith("s")
+
+
 def triplet_train_step(scene, scene_shadow, scene_loc, scene_accum, product, product_shadow, product_loc,
                        product_accum, scene_ids, pos_ids, neg_ids, regularization, batch_size, lr, eps=1e-7,
                        presorted=None, stamp=None, plan=None, long_runs=-1):
@@ -359,22 +365,28 @@ def triplet_train_step(scene, scene_shadow, scene_loc, scene_accum, product, pro
     (sorted virtual ids, perm) of [scene ; Vs + pos ; Vs + neg] from segment_sort_multi, else the sort runs here; plan /
     long_runs as for glove_train_step (triplet_plan).  Returns loss[1]."""
     lib = _lib.load()
-    for name, t in (("scene", scene), ("scene_shadow", scene_shadow), ("scene_accum", scene_accum),
-                    ("product", product), ("product_shadow", product_shadow), ("product_accum", product_accum)):
+    direct = triplet_direct_mode()  # rows stepped in place: no second buffers, location bytes or stamp
+    for name, t in (("scene", scene), ("scene_accum", scene_accum), ("product", product), ("product_accum", product_accum)):
         _req(t, torch.float32, name)
-    _req(scene_loc, torch.uint8, "scene_loc"), _req(product_loc, torch.uint8, "product_loc")
+    if not direct or scene_shadow is not None:
+        _req(scene_shadow, torch.float32, "scene_shadow"), _req(product_shadow, torch.float32, "product_shadow")
+        _req(scene_loc, torch.uint8, "scene_loc"), _req(product_loc, torch.uint8, "product_loc")
     for name, t in (("scene_ids", scene_ids), ("pos_ids", pos_ids), ("neg_ids", neg_ids)):
         _req(t, torch.int32, name)
     if stamp is None:
-        raise ValueError("triplet_train_step needs the step's stamp (train_state.next_stamp(row_versions...))")
+        if not direct:
+            raise ValueError("triplet_train_step needs the step's stamp (train_state.next_stamp(row_versions...))")
+        stamp = 1
     Vs, D = scene.shape
     Vp = product.shape[0]
     B = scene_ids.numel()
     if product.shape[1] != D or pos_ids.numel() != B or neg_ids.numel() != B:
         raise ValueError("tower dims / id counts differ")
-    if scene_shadow.shape != scene.shape or scene_accum.shape != scene.shape or scene_loc.numel() != Vs or \
-            product_shadow.shape != product.shape or product_accum.shape != product.shape or product_loc.numel() != Vp:
-        raise ValueError("shadow / accum / loc shapes do not match their towers")
+    if scene_accum.shape != scene.shape or product_accum.shape != product.shape:
+        raise ValueError("accumulator shapes do not match their towers")
+    if scene_shadow is not None and (scene_shadow.shape != scene.shape or scene_loc.numel() != Vs or
+                                     product_shadow.shape != product.shape or product_loc.numel() != Vp):
+        raise ValueError("shadow / loc shapes do not match their towers")
     sid = perm = None
     if presorted is not None:
         sid, perm = _req(presorted[0], torch.int32, "sorted_ids"), _req(presorted[1], torch.int32, "perm")

@@ -104,7 +104,9 @@ def fused_triplet_step_available(state):
     if not (st.is_cuda and st.dtype == torch.float32 and pt.dtype == torch.float32 and st.shape[1] == pt.shape[1] and
             st.shape[0] + pt.shape[0] < (1 << 30)):
         return False
-    # the one-pass step keeps both towers double-buffered: without room for the second buffers the six-launch path runs
+    if ops.triplet_direct_mode():  # rows are stepped in place: nothing to double-buffer
+        return True
+    # the stamped step keeps both towers double-buffered: without room for the second buffers the six-launch path runs
     from ..train_state import can_double_buffer
     prefix = ("params",) if "params" in state.raw_params else ()
     return can_double_buffer(state, [prefix + ("scene_tower", "embedding"), prefix + ("product_tower", "embedding")])
@@ -143,6 +145,13 @@ def _fused_triplet_step(state, sid, pid, nid, regularization, batch_size, presor
     st, pt = p["scene_tower"]["embedding"], p["product_tower"]["embedding"]
     acc = state.opt_state["sum_of_squares"]
     acc = acc["params"] if prefix else acc
+    if ops.triplet_direct_mode():  # in place: no second buffers, no stamps
+        if state.versions:  # (rows an earlier stamped step left in second buffers go home first)
+            state.consolidate()
+        loss = ops.triplet_train_step(st, None, None, acc["scene_tower"]["embedding"], pt, None, None,
+                                      acc["product_tower"]["embedding"], sid, pid, nid, regularization, batch_size,
+                                      state.tx.lr, state.tx.eps, presorted=presorted)
+        return state.replace(step=state.step + 1), loss.reshape(())
     rs = row_versions(state, prefix + ("scene_tower", "embedding"))
     rp = row_versions(state, prefix + ("product_tower", "embedding"))
     loss = ops.triplet_train_step(st, rs.shadow, rs.loc, acc["scene_tower"]["embedding"], pt, rp.shadow, rp.loc,
@@ -249,8 +258,11 @@ class _FusedTripletLoop:
         acc = state.opt_state["sum_of_squares"]
         acc = acc["params"] if prefix else acc
         self.st, self.pt = p["scene_tower"]["embedding"], p["product_tower"]["embedding"]
-        self.rs = row_versions(state, prefix + ("scene_tower", "embedding"))
-        self.rp = row_versions(state, prefix + ("product_tower", "embedding"))
+        self.direct = ops.triplet_direct_mode()  # rows stepped in place: no second buffers, location bytes or stamps
+        if self.direct and state.versions:  # (rows an earlier stamped step left in second buffers go home first)
+            state.consolidate()
+        self.rs = None if self.direct else row_versions(state, prefix + ("scene_tower", "embedding"))
+        self.rp = None if self.direct else row_versions(state, prefix + ("product_tower", "embedding"))
         self.acc_s, self.acc_p = acc["scene_tower"]["embedding"], acc["product_tower"]["embedding"]
         self.Vs, self.D = self.st.shape
         self.Vp = self.pt.shape[0]
@@ -277,10 +289,18 @@ class _FusedTripletLoop:
         self.hints_known = [None, None]  # per set: list of long_runs values once the event has been seen complete
         self.group_ws, self.group_ws_B = None, -1  # esr_triplet_train_steps' workspace, sized for the group it steps
         self.gen = 0
-        self.fixed_s = (self.st.data_ptr(), self.rs.shadow.data_ptr(), self.rs.loc.data_ptr(), self.acc_s.data_ptr(),
-                        self.Vs)
-        self.fixed_p = (self.pt.data_ptr(), self.rp.shadow.data_ptr(), self.rp.loc.data_ptr(), self.acc_p.data_ptr(),
-                        self.Vp)
+        if self.direct:
+            self.fixed_s = (self.st.data_ptr(), None, None, self.acc_s.data_ptr(), self.Vs)
+            self.fixed_p = (self.pt.data_ptr(), None, None, self.acc_p.data_ptr(), self.Vp)
+        else:
+            self.fixed_s = (self.st.data_ptr(), self.rs.shadow.data_ptr(), self.rs.loc.data_ptr(), self.acc_s.data_ptr(),
+                            self.Vs)
+            self.fixed_p = (self.pt.data_ptr(), self.rp.shadow.data_ptr(), self.rp.loc.data_ptr(), self.acc_p.data_ptr(),
+                            self.Vp)
+
+    def stamp(self, count=1):
+        """The (first) stamp of the next `count` steps on both towers; direct mode has none."""
+        return 1 if self.direct else self.next_stamp(self.rs, self.rp, count=count)
 
     def _sized(self, B):
         if B == self.B:
@@ -391,7 +411,7 @@ class _FusedTripletLoop:
             self.group_ws_B = gr.B
         self.check(self.lib.esr_triplet_train_steps(*self.fixed_s, *self.fixed_p, self.D, gr.nb, gr.ptrs, gr.B,
                                                     regularization, batch_size, self.lr, self.eps,
-                                                    self.next_stamp(self.rs, self.rp, count=gr.nb), gr.sorted_ptr,
+                                                    self.stamp(gr.nb), gr.sorted_ptr,
                                                     gr.perm_ptr, gr.plans_ptr, long_runs, self.losses_ptr + 4 * k,
                                                     self.group_ws.data_ptr(), self.group_ws.numel(), self.main_raw),
                    "esr_triplet_train_steps")
@@ -408,7 +428,7 @@ class _FusedTripletLoop:
             self._sized(sid.numel())
         self.check(self.lib.esr_triplet_train_step(*self.fixed_s, *self.fixed_p, self.D, sid.data_ptr(), pid.data_ptr(),
                                                    nid.data_ptr(), self.B, float(regularization), float(batch_size),
-                                                   self.lr, self.eps, self.next_stamp(self.rs, self.rp), sorted_ptr,
+                                                   self.lr, self.eps, self.stamp(), sorted_ptr,
                                                    perm_ptr, 0, -1, self.losses.data_ptr() + 4 * k,
                                                    self.ws.data_ptr(), self.ws.numel(), self.main.cuda_stream),
                    "esr_triplet_train_step")
@@ -456,7 +476,7 @@ class PlannedTriplets:
         pb = ops._ws_bytes("esr_triplet_plan_bytes", gr.B)
         ctx.check(ctx.lib.esr_triplet_train_step(*ctx.fixed_s, *ctx.fixed_p, ctx.D, self.scene.data_ptr(),
                                                  self.pos.data_ptr(), self.neg.data_ptr(), gr.B, float(regularization),
-                                                 float(batch_size), ctx.lr, ctx.eps, ctx.next_stamp(ctx.rs, ctx.rp),
+                                                 float(batch_size), ctx.lr, ctx.eps, ctx.stamp(),
                                                  gr.sorted_ptr + 4 * n * j, gr.perm_ptr + 4 * n * j,
                                                  gr.plans_ptr + pb * j, long_runs, ctx.losses_ptr + 4 * k,
                                                  ctx.group_ws.data_ptr(), ctx.group_ws.numel(), ops._stream()),

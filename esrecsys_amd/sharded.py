@@ -625,6 +625,12 @@ def sharded_triplet_step(towers, scene_ids, pos_ids, neg_ids, regularization, gl
     sum over triplets, so G ranks x B triplets == one device with G*B triplets and batch_size = G*B."""
     k = towers.k
     B = scene_ids.numel()
+    if _world1_tables_ok(towers) and _is_f32(towers) and getattr(k, "triplet_direct_mode", lambda: False)():
+        # world 1: the one-pass step on the local shards, rows stepped in place (esr_triplet_train_step, direct mode)
+        towers.consolidate()  # (rows an earlier stamped step left in second buffers)
+        st, pt = towers.tables
+        return k.triplet_train_step(st.local, None, None, st.accum, pt.local, None, None, pt.accum, scene_ids, pos_ids,
+                                    neg_ids, regularization, global_batch_size, lr)
     if _world1_tables_ok(towers) and _is_f32(towers) and towers.versions() is not None:
         # world 1: the one-pass step on the local shards (esr_triplet_train_step), nothing to exchange
         from .train_state import next_stamp

@@ -196,7 +196,15 @@ int esr_triplet_fwd_bwd(const float* scene_table, int64_t Vs, const float* pos_t
  * step is ONE launch: the loss leaves the update kernel through an exact integer reduction (a mean loss beyond 2048
  * comes out +inf).  Same element arithmetic (trip_grad, adagrad_elem), same sort and the same association of every row
  * sum as esr_triplet_fwd_bwd + esr_sparse_adagrad_scatter_multi.
- * loss [1] = (sum_b relu(1 + neg_b - pos_b) + regularization * reg) / batch_size. */
+ * loss [1] = (sum_b relu(1 + neg_b - pos_b) + regularization * reg) / batch_size.
+ *
+ * DIRECT mode (round 4, the default; ESR_TRIPLET_STEP=stamped keeps the walk described above): one row group per TRIPLET
+ * reads its three rows once and steps every row that occurs once in the batch IN PLACE (row + accumulator read and
+ * written once: the fused minimum of 4 row transfers per row, against 6 per occurrence for the stamped walk); a row with
+ * 2 .. 8 occurrences is stepped by whichever of its triplets finishes last (gradient rows parked at their sorted
+ * positions, one atomic arrival per occurrence); longer runs by a second launch, made only when the plan's hint says
+ * one exists.  Nothing is double-buffered: the *_shadow / *_loc arguments and `stamp` are ignored and may be NULL / 0,
+ * rows never leave `scene` / `product`.  Same sums, same association as the stamped walk and the six-launch path. */
 size_t esr_triplet_step_workspace_bytes(int64_t B, int D);
 int esr_triplet_train_step(float* scene, float* scene_shadow, uint8_t* scene_loc, float* scene_accum, int64_t Vs,
                            float* product, float* product_shadow, uint8_t* product_loc, float* product_accum,
