@@ -210,7 +210,8 @@ def dominant_kernel_roofline(workload, path, per_kernel, B, D):
                 out[name] = {"us": per_kernel[name]["us"], "fp16_gemms": terms,
                              "frac_of_2.5PF": round(terms * unit / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
         return out or None
-    names = ("glove_step_resolved_kernel", "glove_step_kernel") if workload == "glove" else ("triplet_step_kernel",)
+    names = ("glove_step_resolved_kernel", "glove_step_kernel") if workload == "glove" else \
+        ("triplet_direct_kernel", "triplet_step_kernel")
     for name in names:
         if name in per_kernel:
             t = per_kernel[name]["us"] * 1e-6
@@ -297,9 +298,12 @@ def roofline_for(workload, kernels, B, D, rows, precision, occ_n=0, uniq=0, bf16
         # rows and per distinct row the own-row read, the rewrite and the accumulator RMW
         t = step_s if step_s else kernels["triplet_step"]["ms_per_step"] * 1e-3
         alg = STEP_BYTES_PER_UNIT["triplet"](D) * B
-        moved = (2 * occ_n + 4 * uniq) * D * 4
-        return {"kernel": "esr_triplet_train_step (sort + triplet_plan made ahead for eight batches; per step "
-                          "triplet_step, + triplet_step_long only when a run of equal ids is long)",
+        # direct mode: every distinct row read + written once with its accumulator; an occurrence of a duplicated row
+        # also parks and re-reads its gradient row
+        moved = (4 * uniq + 2 * (occ_n - uniq)) * D * 4
+        return {"kernel": "esr_triplet_train_step, direct mode (sort + plan made ahead for eight batches; per step "
+                          "triplet_direct: one row group per triplet, unique rows stepped in place, + "
+                          "triplet_direct_long only when a run of equal ids is longer than 8)",
                 "bound": "hbm", "achieved": alg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": alg / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
                 "bytes_the_update_needs_per_step": moved, "those_bytes_GBps": moved / t / 1e9}
