@@ -109,6 +109,12 @@ __global__ __launch_bounds__(kSmallSortThreads) void segment_sort_small_kernel(S
 // -- sixteen workgroups sort instead of eight and every one of the rank kernel's 16 lanes per element has a tile to
 // search; 2048-key tiles at every size left half of them idle there: 10.9 + 6.3 us -> see profiles/).
 constexpr int kMidTiles = 16, kMaxTileBits = 11;
+// element slots per 16-lane group of the rank kernels (see tile_rank_body): as many (<= 8) as leave >= 2048 workgroups
+static inline int rank_reps(int64_t blocks) {
+  int r = 8;
+  while (r > 1 && blocks / r < 2048) r >>= 1;
+  return r;
+}
 constexpr int kSplitEvery = 32;  // one splitter (its last key) per 32-key block of a sorted tile
 constexpr int kMidSortMax = (1 << kMaxTileBits) * kMidTiles;
 // Bitonic network over kTile = 2^TB keys held two per thread: thread t holds positions t (k0) and t + kTile / 2 (k1).
@@ -245,12 +251,16 @@ template <int TB>
 __device__ __forceinline__ void tile_rank_body(const uint32_t* __restrict__ tiles,
                                                const uint32_t* __restrict__ splitters, int n, int ntiles,
                                                int32_t* __restrict__ sorted_ids, int32_t* __restrict__ perm,
-                                               uint32_t* spl, int bx) {
+                                               uint32_t* spl, int bx, int kRankReps) {
   constexpr int kTile = 1 << TB, kSplitPerTile = kTile / kSplitEvery;
   for (int i = threadIdx.x; i < ntiles * kSplitPerTile; i += kBlock) spl[i] = splitters[i] >> TB;
   __syncthreads();
   const int u = threadIdx.x & (kMidTiles - 1);                                 // the tile this lane searches
-  const int g = (bx * kBlock + threadIdx.x) / kMidTiles;                        // slot g of the tiled array
+  // kRankReps element slots per 16-lane group: the splitters are staged once per workgroup for 128 elements instead of
+  // 16 (round 4: the eight 24 576-id lists of a group of triplet batches were 12 288 workgroups staging 3 KB each)
+#pragma unroll 1
+  for (int rep = 0; rep < kRankReps; ++rep) {
+  const int g = ((bx * kRankReps + rep) * kBlock + threadIdx.x) / kMidTiles;   // slot g of the tiled array
   const int mine = g / kTile;
   const bool live = g < ntiles * kTile && g - mine * kTile < n - mine * kTile;  // not padding
   const uint32_t c = live ? tiles[g] : 0u;
@@ -279,25 +289,26 @@ __device__ __forceinline__ void tile_rank_body(const uint32_t* __restrict__ tile
     sorted_ids[rank] = (int32_t)id;
     perm[rank] = mine * kTile + (int)(c & (kTile - 1));
   }
+  }  // rep
 }
 template <int TB>
 __global__ __launch_bounds__(kBlock) void tile_rank_kernel(const uint32_t* __restrict__ tiles,
                                                           const uint32_t* __restrict__ splitters, int n, int ntiles,
                                                           int32_t* __restrict__ sorted_ids,
-                                                          int32_t* __restrict__ perm) {
+                                                          int32_t* __restrict__ perm, int reps) {
   __shared__ uint32_t spl[kMidTiles * ((1 << TB) / kSplitEvery)];
-  tile_rank_body<TB>(tiles, splitters, n, ntiles, sorted_ids, perm, spl, blockIdx.x);
+  tile_rank_body<TB>(tiles, splitters, n, ntiles, sorted_ids, perm, spl, blockIdx.x, reps);
 }
 template <int TB>
 __global__ __launch_bounds__(kBlock) void tile_rank_batched_kernel(const uint32_t* __restrict__ tiles,
                                                                   const uint32_t* __restrict__ splitters, int n,
                                                                   int ntiles, int64_t ws_stride,
                                                                   int32_t* __restrict__ sorted_ids,
-                                                                  int32_t* __restrict__ perm) {
+                                                                  int32_t* __restrict__ perm, int reps) {
   __shared__ uint32_t spl[kMidTiles * ((1 << TB) / kSplitEvery)];
   const int y = blockIdx.y;
   tile_rank_body<TB>(tiles + y * ws_stride, splitters + y * ws_stride, n, ntiles, sorted_ids + (int64_t)y * n,
-                     perm + (int64_t)y * n, spl, blockIdx.x);
+                     perm + (int64_t)y * n, spl, blockIdx.x, reps);
 }
 template <int TB>
 static void launch_tile_sort(const SortSegs& sg, int n, uint32_t* tiles, int32_t* sorted_ids, int32_t* perm,
@@ -306,8 +317,10 @@ static void launch_tile_sort(const SortSegs& sg, int n, uint32_t* tiles, int32_t
   const int ntiles = (int)cdiv(n, kTile);
   uint32_t* splitters = tiles + kMidSortMax;  // [ntiles][kTile / 32], behind the tiles
   hipLaunchKernelGGL((tile_sort_kernel<TB>), dim3(ntiles), dim3(kTile / 2), 0, st, sg, n, tiles, splitters);
-  hipLaunchKernelGGL((tile_rank_kernel<TB>), dim3((int)cdiv((int64_t)ntiles * kTile * kMidTiles, kBlock)), dim3(kBlock), 0,
-                     st, (const uint32_t*)tiles, (const uint32_t*)splitters, n, ntiles, sorted_ids, perm);
+  const int64_t blocks = cdiv((int64_t)ntiles * kTile * kMidTiles, kBlock);
+  const int reps = rank_reps(blocks);
+  hipLaunchKernelGGL((tile_rank_kernel<TB>), dim3((int)cdiv(blocks, reps)), dim3(kBlock), 0, st, (const uint32_t*)tiles,
+                     (const uint32_t*)splitters, n, ntiles, sorted_ids, perm, reps);
 }
 
 constexpr int64_t kMidWsWords = kMidSortMax + kMidSortMax / kSplitEvery;  // one list's (tiles | splitters) area
@@ -319,9 +332,10 @@ static void launch_tile_sort_batched(const SortSegsBatch& sb, int nbatch, int n,
   uint32_t* splitters = tiles + kMidSortMax;
   hipLaunchKernelGGL((tile_sort_batched_kernel<TB>), dim3(ntiles, nbatch), dim3(kTile / 2), 0, st, sb, n, tiles,
                      splitters, kMidWsWords);
-  hipLaunchKernelGGL((tile_rank_batched_kernel<TB>), dim3((int)cdiv((int64_t)ntiles * kTile * kMidTiles, kBlock), nbatch),
-                     dim3(kBlock), 0, st, (const uint32_t*)tiles, (const uint32_t*)splitters, n, ntiles, kMidWsWords,
-                     sorted_ids, perm);
+  const int64_t blocks = cdiv((int64_t)ntiles * kTile * kMidTiles, kBlock);
+  const int reps = rank_reps(blocks * nbatch);
+  hipLaunchKernelGGL((tile_rank_batched_kernel<TB>), dim3((int)cdiv(blocks, reps), nbatch), dim3(kBlock), 0, st,
+                     (const uint32_t*)tiles, (const uint32_t*)splitters, n, ntiles, kMidWsWords, sorted_ids, perm, reps);
 }
 
 // Long lists (32 768 < n <= 262 144: the 131 072 occurrence ids of a GloVe step at B = 65 536, the 196 608 of a triplet

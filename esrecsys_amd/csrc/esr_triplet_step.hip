@@ -991,6 +991,8 @@ static int launch_trip_step(const TwoTowers& tt, int D, const RowGeom& g, const 
               (long long)Vp, D, (long long)B);                                                                         \
   ESR_REQUIRE(Vs + Vp <= (int64_t)kIdMask, who ": %lld virtual rows exceed 2^30 - 1", (long long)(Vs + Vp));           \
   ESR_REQUIRE(3 * B < ((int64_t)1 << 31), who ": B=%lld too large", (long long)B);                                     \
+  ESR_REQUIRE(!trip_direct_mode() || 3 * B < ((int64_t)1 << 29),                                                       \
+              who ": B=%lld too large for the direct step's 29-bit run heads (ESR_TRIPLET_STEP=stamped)", (long long)B); \
   ESR_REQUIRE(scene && scene_accum && product && product_accum, who ": null table pointer");                           \
   /* direct mode (the default) steps rows in place: the second buffers and location bytes are not used, may be NULL */ \
   ESR_REQUIRE(trip_direct_mode() || (scene_shadow && scene_loc && product_shadow && product_loc),                      \
