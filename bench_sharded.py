@@ -114,9 +114,10 @@ def run_sharded(args, cfg, dev, rank, world):
                 return loss
         if plan_group > 1:  # the library's loop helper (plans of plan_group coming batches made together)
             grps = (emb, bias) if args.workload == "glove" else (towers,)
-            return sharded.sharded_train_steps(args.workload, grps, batches[lo:hi], regularization=LAM,
-                                               global_batch_size=gb, scale=SCALE, lr=LR, mode=ops.GLOVE_REFERENCE,
-                                               plan_group=plan_group)[-1]
+            out = sharded.sharded_train_steps(args.workload, grps, batches[lo:hi], regularization=LAM,
+                                              global_batch_size=gb, scale=SCALE, lr=LR, mode=ops.GLOVE_REFERENCE,
+                                              plan_group=plan_group)
+            return out[-1] if out else None
         with quiet_gc():  # as the loop helpers: a full cyclic collection inside the loop is a 40 ms hole in the launches
             cur = begin(batches[lo]).finish()
             pend = begin(batches[lo + 1]) if lo + 1 < hi else None
