@@ -213,7 +213,7 @@ struct IvfGeom {
   int64_t chunk;   // queries per pass (head scores + record lists stay under ~2 GiB)
   int mark;        // lazy compaction: lists up to this long are not selected down between rounds
 };
-static IvfGeom ivf_geom(int64_t nq, int max_list, int nprobe, int k) {
+static IvfGeom ivf_geom(int64_t nq, int max_list, int nprobe, int k, int nlist) {
   IvfGeom g;
   g.pitch = (int64_t)align_up((size_t)std::max<int64_t>(max_list, cdiv((int64_t)k + 1, nprobe)), 64);
   // (as many as the head select still caches in LDS -- 8192 scores: a list with few pairs fills little of a 64-row
@@ -225,6 +225,9 @@ static IvfGeom ivf_geom(int64_t nq, int max_list, int nprobe, int k) {
   g.ppitch = std::max<int64_t>(k, g.mark) + (int64_t)std::min(kIvfRound, nprobe - g.f) * g.pitch;
   const int64_t per_query = g.f * g.pitch * 4 + g.ppitch * 8;
   g.chunk = std::min(nq, std::max<int64_t>(64, ((int64_t)1 << 31) / per_query));
+  // the score kernel's row tiles are gridDim.y (<= 65 535): pairs of a set / 64 + one partly filled tile per list
+  const int64_t max_pairs = ((int64_t)65535 - nlist) * kIvfTile;
+  g.chunk = std::max<int64_t>(1, std::min(g.chunk, max_pairs / std::max(g.f, kIvfRound)));
   return g;
 }
 static size_t ivf_layout(const IvfGeom& g, int64_t cq, int nprobe, int nlist, char* base, IvfWs* out) {
@@ -278,13 +281,14 @@ extern "C" {
 
 size_t esr_ivf_search_workspace_bytes(int64_t nq, int nlist, int max_list, int nprobe, int k) {
   if (nq <= 0 || nlist <= 0 || max_list <= 0 || nprobe <= 0 || k <= 0) return 256;
-  const IvfGeom g = ivf_geom(nq, max_list, nprobe, k);
+  const IvfGeom g = ivf_geom(nq, max_list, nprobe, k, nlist);
   return ivf_layout(g, g.chunk, nprobe, nlist, nullptr, nullptr);
 }
 
 int esr_ivf_search(const float* queries, int64_t nq, int D, const float* cands_sorted, const int32_t* list_off,
                    const int32_t* orig, int nlist, int max_list, const int32_t* probe_lists, int nprobe, int k,
                    float* out_scores, int32_t* out_indices, void* workspace, size_t workspace_bytes, esr_stream_t stream) {
+  ESR_REQUIRE(nlist <= 32768, "esr_ivf_search: nlist=%d exceeds 32768 (the score kernel's row tiles are a grid dimension)", nlist);
   ESR_REQUIRE(nq > 0 && D > 0 && D % 4 == 0 && nlist > 0 && max_list > 0 && nprobe > 0 && nprobe <= nlist && k > 0 &&
                   k <= kSelectMaxK && (int64_t)nprobe * k < ((int64_t)1 << 24),
               "esr_ivf_search: bad sizes nq=%lld D=%d nlist=%d max_list=%d nprobe=%d k=%d", (long long)nq, D, nlist,
@@ -297,7 +301,7 @@ int esr_ivf_search(const float* queries, int64_t nq, int D, const float* cands_s
     return ESR_EWORKSPACE;
   }
   hipStream_t st = as_stream(stream);
-  const IvfGeom g = ivf_geom(nq, max_list, nprobe, k);
+  const IvfGeom g = ivf_geom(nq, max_list, nprobe, k, nlist);
   ESR_REQUIRE((int64_t)nprobe * g.pitch < ((int64_t)1 << 31), "esr_ivf_search: nprobe x longest list exceeds 2^31");
   IvfWs ws;
   ivf_layout(g, g.chunk, nprobe, nlist, (char*)workspace, &ws);

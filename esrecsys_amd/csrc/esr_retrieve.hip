@@ -818,7 +818,10 @@ static RetrievePlan retrieve_plan(int64_t nq, int64_t N, int D, int k, int mode)
 static_assert(kSelectMaxK == kSelMaxK, "esr_common.h advertises the select kernel's k limit");
 int select_topk_dense(const float* scores, int64_t pitch, int64_t rows, int n, int k, float* out_scores,
                       int32_t* out_indices, hipStream_t st) {
-  if (k > kSelMaxK) return ESR_EINVAL;
+  if (k > kSelMaxK) {
+    set_error("top-k select: k=%d exceeds %d", k, kSelMaxK);
+    return ESR_EINVAL;
+  }
   SelIn in;
   in.vals = scores; in.vpitch = pitch; in.idx = nullptr; in.stride = 1; in.ibase = 0; in.istep = 1;
   in.n_per_row = nullptr; in.n_fixed = n;
@@ -832,7 +835,10 @@ int select_topk_dense(const float* scores, int64_t pitch, int64_t rows, int n, i
 
 int select_topk_head(const float* scores, int64_t pitch, int64_t rows, int n, int k, int2* pairs, int64_t ppitch,
                      int32_t* cnt, float* tau, hipStream_t st) {
-  if (k > kSelMaxK || n <= k) return ESR_EINVAL;
+  if (k > kSelMaxK || n <= k) {
+    set_error("top-k select: k=%d must be below the row length %d and at most %d", k, n, kSelMaxK);
+    return ESR_EINVAL;
+  }
   SelIn in;
   in.vals = scores; in.vpitch = pitch; in.idx = nullptr; in.stride = 1; in.ibase = 0; in.istep = 1;
   in.n_per_row = nullptr; in.n_fixed = n;
@@ -846,7 +852,10 @@ int select_topk_head(const float* scores, int64_t pitch, int64_t rows, int n, in
 
 int select_topk_tail(const int2* pairs, int64_t ppitch, const int32_t* cnt, int64_t rows, int k, float* out_scores,
                      int32_t* out_indices, hipStream_t st) {
-  if (k > kSelMaxK) return ESR_EINVAL;
+  if (k > kSelMaxK) {
+    set_error("top-k select: k=%d exceeds %d", k, kSelMaxK);
+    return ESR_EINVAL;
+  }
   SelIn in;
   in.vals = (const float*)pairs; in.vpitch = 2 * ppitch; in.idx = (const int32_t*)pairs + 1; in.stride = 2;
   in.ibase = 0; in.istep = 0; in.n_per_row = cnt; in.n_fixed = 0;
@@ -860,7 +869,10 @@ int select_topk_tail(const int2* pairs, int64_t ppitch, const int32_t* cnt, int6
 
 int select_topk_compact(int2* pairs, int64_t ppitch, int32_t* cnt, int64_t rows, int k, float* tau, hipStream_t st,
                         int skip_upto) {
-  if (k > kSelMaxK) return ESR_EINVAL;
+  if (k > kSelMaxK) {
+    set_error("top-k select: k=%d exceeds %d", k, kSelMaxK);
+    return ESR_EINVAL;
+  }
   SelIn in;
   in.vals = (const float*)pairs; in.vpitch = 2 * ppitch; in.idx = (const int32_t*)pairs + 1; in.stride = 2;
   in.ibase = 0; in.istep = 0; in.n_per_row = cnt; in.n_fixed = 0;
@@ -876,7 +888,10 @@ int select_topk_compact(int2* pairs, int64_t ppitch, int32_t* cnt, int64_t rows,
 // shorter than k deliver all they have (the caller pre-fills the outputs).  For esr_ivf.hip.
 int select_topk_ragged(const float* scores, int64_t pitch, int64_t rows, const int32_t* n_per_row, int max_n, int k,
                        float* out_scores, int32_t* out_indices, hipStream_t st) {
-  if (k > kSelMaxK) return ESR_EINVAL;
+  if (k > kSelMaxK) {
+    set_error("top-k select: k=%d exceeds %d", k, kSelMaxK);
+    return ESR_EINVAL;
+  }
   SelIn in;
   in.vals = scores; in.vpitch = pitch; in.idx = nullptr; in.stride = 1; in.ibase = 0; in.istep = 1;
   in.n_per_row = n_per_row; in.n_fixed = 0;

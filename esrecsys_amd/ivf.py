@@ -22,6 +22,8 @@ class IVFIndex:
         c = ops._req(candidates, torch.float32, "candidates")
         N, D = c.shape
         nlist = int(min(nlist, N))
+        if not 1 <= nlist <= 32768:
+            raise ValueError("IVFIndex: nlist must be in [1, 32768], got %d" % nlist)
         if D % 4:
             raise ValueError("IVFIndex needs D % 4 == 0")
         g = torch.Generator(device=c.device).manual_seed(seed)

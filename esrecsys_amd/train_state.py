@@ -304,7 +304,8 @@ class _SgdMomentum(GradientTransformation):
     step calls it before its forward pass), the forward / backward, then ``apply`` (the whole momentum step on the touched
     rows).  ``flush`` brings every row up to date -- ``TrainState.params`` does it, so evals, checkpoints and anybody
     else who reads the tables through the state see exactly what the dense optimizer would have left (bit-identical for
-    rows whose gaps stay within 2048 steps, 1e-7-close beyond: esr_optim.hip decay_steps).  lazy=False keeps the dense
+    rows whose gaps stay within 64 steps -- kLazyExact, replayed one by one -- and 1e-7-close beyond, where the closed form
+    is used: esr_optim.hip decay_steps).  lazy=False keeps the dense
     decay pass every step."""
 
     needs_flush = True
