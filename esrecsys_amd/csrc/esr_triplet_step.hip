@@ -71,6 +71,7 @@ struct TripPlan {
                                 //      direct mode: the occurrence codes (see triplet_direct_plan_kernel) per OCCURRENCE
   uint32_t* cnt;                // [n]  direct mode: arrivals per run, at the run's head position; zero before the step
   int32_t* long_heads;          // [n / 9 + 1]  direct mode: head positions of the runs longer than kDirectMaxRun
+  double* loss_part;            // [kMaxGrid]  direct mode: the update kernel's loss partial per workgroup
 };
 static size_t trip_plan_layout(int64_t B, char* base, TripPlan* out) {
   const int64_t n = 3 * B;
@@ -86,6 +87,7 @@ static size_t trip_plan_layout(int64_t B, char* base, TripPlan* out) {
   pl.meta = (uint2*)take(sizeof(uint2) * (size_t)n);
   pl.cnt = (uint32_t*)take(sizeof(uint32_t) * (size_t)n);
   pl.long_heads = (int32_t*)take(sizeof(int32_t) * (size_t)(n / 9 + 1));
+  pl.loss_part = (double*)take(sizeof(double) * kMaxGrid);
   if (out) *out = pl;
   return off;
 }
@@ -621,8 +623,7 @@ __global__ __launch_bounds__(kBlock) void triplet_direct_kernel(DirectTowers tt,
                                                                float inv_bs, int with_reg, float lr, float eps,
                                                                float* __restrict__ side, uint32_t* __restrict__ cnt,
                                                                int* __restrict__ parked,
-                                                               unsigned long long* __restrict__ loss_acc, int frac,
-                                                               double inv_batch_size, float* __restrict__ loss) {
+                                                               double* __restrict__ loss_part) {
   __shared__ double sm[8];
   const int lig = threadIdx.x & (G - 1);
   const int lane = threadIdx.x & 63;
@@ -755,13 +756,23 @@ __global__ __launch_bounds__(kBlock) void triplet_direct_kernel(DirectTowers tt,
       if (sN && oN == (cn.y >> 29)) complete(cn, nrow, tt.pacc + nid * D, N, aN);
     }
   }
+  // the workgroup's loss partial, fire and forget: triplet_direct_loss_kernel adds the partials of a step in a fixed order
+  // (the counted integer reduction of the stamped kernel put two dependent atomic round trips at the tail of every
+  // workgroup -- ~2 us of an 18 us launch at B = 8192)
   const double t = block_sum_d(acc_loss, sm);
-  if (threadIdx.x == 0) {
-    double total;
-    unsigned flags;
-    if (fixed_sum_arrive(loss_acc, t, frac, gridDim.x, &total, &flags))
-      loss[0] = (flags & 1u) ? __builtin_nanf("") : ((flags & 2u) ? __builtin_inff() : (float)(total * inv_batch_size));
-  }
+  if (threadIdx.x == 0) loss_part[blockIdx.x] = t;
+}
+
+// losses[b] = (sum of step b's workgroup partials, fixed order) / batch_size: one workgroup per step of a group
+__global__ __launch_bounds__(kBlock) void triplet_direct_loss_kernel(const char* __restrict__ plans, size_t stride,
+                                                                    size_t part_off, int nparts, double inv_batch_size,
+                                                                    float* __restrict__ losses) {
+  __shared__ double sm[8];
+  const double* part = reinterpret_cast<const double*>(plans + (size_t)blockIdx.x * stride + part_off);
+  double a = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += kBlock) a += part[i];
+  const double t = block_sum_d(a, sm);
+  if (threadIdx.x == 0) losses[blockIdx.x] = (float)(t * inv_batch_size);
 }
 
 // the runs longer than kDirectMaxRun: one workgroup per run (the plan's list).  The association of the segment kernels
@@ -935,10 +946,23 @@ int esr_rows_restamp(uint8_t* loc, int64_t V, esr_stream_t stream) {
 }  // extern "C"
 
 // one step's launches (arguments validated by the callers)
+// what a direct step leaves for its caller: where its loss partials are (triplet_direct_loss_kernel turns them into losses)
+struct DirectLoss {
+  int nparts = 0;
+  const char* plan = nullptr;
+  size_t part_off = 0;
+};
+static void launch_direct_losses(const DirectLoss& d, size_t stride, int nb, float batch_size, float* losses,
+                                 hipStream_t st) {
+  ESR_KT("triplet_direct_loss_kernel", st,
+         hipLaunchKernelGGL(triplet_direct_loss_kernel, dim3(nb), dim3(kBlock), 0, st, d.plan, stride, d.part_off, d.nparts,
+                            1.0 / (double)batch_size, losses));
+}
+
 static int launch_trip_step(const TwoTowers& tt, int D, const RowGeom& g, const int32_t* scene_ids, const int32_t* pos_ids,
                             const int32_t* neg_ids, int64_t B, float regularization, float batch_size, float lr, float eps,
                             const int32_t* sorted, const int32_t* perm, void* plan, int long_runs, float* loss,
-                            const TripWs& ws, hipStream_t st) {
+                            const TripWs& ws, hipStream_t st, DirectLoss* direct = nullptr) {
   const int64_t n = 3 * B;
   if (!plan) {  // no plan made ahead: make it here (and nobody told us whether a run is long: screen for it)
     const int32_t* ids3[3] = {scene_ids, pos_ids, neg_ids};
@@ -965,7 +989,12 @@ static int launch_trip_step(const TwoTowers& tt, int D, const RowGeom& g, const 
       const int gridd = std::min(grid_for_groups(B, g.G), resident);
       ESR_KT("triplet_direct_kernel", st, hipLaunchKernelGGL((triplet_direct_kernel<VEC, NCH>), dim3(gridd), dim3(kBlock), 0, st, dt, D, g.G, scene_ids,
                          pos_ids, neg_ids, (const uint2*)pl.meta, B, regularization, inv_bs, 1, lr, eps, ws.chunk_rows,
-                         pl.cnt, pl.flags, pl.loss_acc, loss_frac_bits(B), 1.0 / (double)batch_size, loss));
+                         pl.cnt, pl.flags, pl.loss_part));
+      if (direct) {  // the caller adds the partials up (one launch for a whole group of steps)
+        direct->nparts = gridd;
+        direct->plan = (const char*)plan;
+        direct->part_off = (size_t)((const char*)pl.loss_part - (const char*)plan);
+      }
       if (long_runs != 0)  // 0 = the caller knows (the plan's hint) that no run is longer than kDirectMaxRun
         ESR_KT("triplet_direct_long_kernel", st, hipLaunchKernelGGL((triplet_direct_long_kernel<VEC, NCH>), dim3(256), dim3(kBlock), 0, st, dt, D, g.G,
                            tt.Vs, sorted, n, lr, eps, (const float*)ws.chunk_rows, (const int*)pl.flags,
@@ -1042,8 +1071,10 @@ int esr_triplet_train_step(float* scene, float* scene_shadow, uint8_t* scene_loc
   }
   TwoTowers tt{scene, scene_shadow, product, product_shadow, scene_loc, product_loc, scene_accum, product_accum, Vs,
                stamp};
+  DirectLoss dl;
   launch_trip_step(tt, D, g, scene_ids, pos_ids, neg_ids, B, regularization, batch_size, lr, eps, sorted, perm, plan,
-                   long_runs, loss, ws, st);
+                   long_runs, loss, ws, st, &dl);
+  if (dl.nparts) launch_direct_losses(dl, 0, 1, batch_size, loss, st);
   return check_launch("esr_triplet_train_step");
 }
 
@@ -1064,13 +1095,18 @@ int esr_triplet_train_steps(float* scene, float* scene_shadow, uint8_t* scene_lo
   TripWs ws;
   trip_ws_layout(B, D, (char*)workspace, &ws);
   const size_t stride = esr_triplet_plan_bytes(B);
+  DirectLoss first;
   for (int b = 0; b < nbatch; ++b) {
     TwoTowers tt{scene, scene_shadow, product, product_shadow, scene_loc, product_loc, scene_accum, product_accum, Vs,
                  first_stamp + (uint32_t)b};
+    DirectLoss dl;
     launch_trip_step(tt, D, g, ids[3 * b], ids[3 * b + 1], ids[3 * b + 2], B, regularization, batch_size, lr, eps,
                      sorted_ids + (int64_t)b * 3 * B, perm + (int64_t)b * 3 * B, (char*)plans + (size_t)b * stride,
-                     long_runs ? long_runs[b] : -1, losses + b, ws, st);
+                     long_runs ? long_runs[b] : -1, losses + b, ws, st, &dl);
+    if (b == 0) first = dl;
   }
+  // direct mode: the losses of the whole group by ONE launch (plans are `stride` apart, same grid for every step)
+  if (first.nparts) launch_direct_losses(first, stride, nbatch, batch_size, losses, st);
   return check_launch("esr_triplet_train_steps");
 }
 
