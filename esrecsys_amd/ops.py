@@ -235,8 +235,10 @@ def stream_gate(flag, value, timeout_us=1_000_000):
 
 
 def _aligned_bytes(nbytes, device, align=256):
-    """uint8 tensor of nbytes whose data pointer is `align`-aligned (torch's allocator hands out 512-byte blocks)."""
-    t = torch.empty(nbytes + align, dtype=torch.uint8, device=device)
+    """ZEROED uint8 tensor of nbytes whose data pointer is `align`-aligned (torch's allocator hands out 512-byte blocks).
+    Plan buffers come from here: the direct triplet plan's long-run counter is tagged with the plan call's generation
+    (esr_triplet_step.hip) -- a fresh buffer must not hold a word that happens to carry a live tag."""
+    t = torch.zeros(nbytes + align, dtype=torch.uint8, device=device)
     off = (-t.data_ptr()) % align
     return t[off:off + nbytes]
 
