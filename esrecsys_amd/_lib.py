@@ -162,6 +162,7 @@ SIGNATURES = {
     "esr_alltoall_ids": (c_int, [c_vp, c_i32p, c_vp, c_i32p, c_vp, c_vp]),
     "esr_alltoall_rows": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "esr_alltoall_grads": (c_int, [c_vp, c_f32p, c_int, c_vp, c_f32p, c_vp, c_vp]),
+    "esr_rows_f32_to_bf16": (c_int, [c_f32p, c_i64, c_int, c_vp, c_vp]),
     "esr_sharded_lookup": (c_int, [c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "esr_sharded_update": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp,
                                    c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_int, c_vp]),

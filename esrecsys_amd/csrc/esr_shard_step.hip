@@ -60,6 +60,16 @@ using namespace esr;
 
 extern "C" {
 
+int esr_rows_f32_to_bf16(const float* rows, int64_t n, int D, void* rows_bf16, esr_stream_t stream) {
+  ESR_REQUIRE(n >= 0 && D > 0 && D % 8 == 0, "esr_rows_f32_to_bf16: bad sizes n=%lld D=%d (D %% 8 == 0)", (long long)n, D);
+  if (n == 0) return ESR_OK;
+  ESR_REQUIRE(rows && rows_bf16 && !(((uintptr_t)rows | (uintptr_t)rows_bf16) & 15), "esr_rows_f32_to_bf16: null or misaligned pointer");
+  const int64_t n8 = n * D / 8;
+  hipLaunchKernelGGL(rows_f32_to_bf16_kernel, dim3((unsigned)std::min<int64_t>(kMaxGrid, cdiv(n8, kBlock))), dim3(kBlock), 0,
+                     as_stream(stream), (const float4*)rows, (uint4*)rows_bf16, n8);
+  return check_launch("esr_rows_f32_to_bf16");
+}
+
 int esr_sharded_lookup(esr_comm_t comm, int world, const void* const* tables, const int64_t* row_offsets, int ntables,
                        int dtype, int D, const int32_t* asked_rows, const int64_t* asked_counts,
                        const int64_t* ask_counts, void* served, void* back, esr_stream_t stream) {
@@ -110,12 +120,7 @@ int esr_sharded_update(esr_comm_t comm, int world, void* const* tables, float* c
       ESR_REQUIRE(D % 8 == 0, "esr_sharded_update: bf16 gradient rows need D %% 8 == 0 (D=%d)", D);
       ESR_REQUIRE((n_rows == 0 || send_bf16) && (n_recv == 0 || recv_raw),
                   "esr_sharded_update: bf16 gradient exchange without its scratch buffers");
-      if (n_rows > 0) {
-        const int64_t n8 = n_rows * D / 8;
-        hipLaunchKernelGGL(rows_f32_to_bf16_kernel, dim3((unsigned)std::min<int64_t>(kMaxGrid, cdiv(n8, kBlock))),
-                           dim3(kBlock), 0, as_stream(stream), (const float4*)out_rows, (uint4*)send_bf16, n8);
-        if (int rc = check_launch("esr_sharded_update")) return rc;
-      }
+      if (int rc = esr_rows_f32_to_bf16(out_rows, n_rows, D, send_bf16, stream)) return rc;
       if (int rc = esr_alltoall_rows(comm, send_bf16, ESR_BF16, D, ask_counts, recv_raw, asked_counts, stream)) return rc;
       if (n_recv > 0)
         if (int rc = esr_unpermute_rows_bf16_to_f32(recv_raw, D, nullptr, n_recv, recv_grads, stream)) return rc;

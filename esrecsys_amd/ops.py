@@ -1134,3 +1134,12 @@ def sharded_glove_step(emb_s, bias_s, plan_s, target, B, mode, lr, eps):
                                      int(mode), float(lr), float(eps), _p(loss), _p(ws), ws.numel(), _stream()),
           "esr_sharded_glove_step")
     return loss
+
+
+def rows_f32_to_bf16(rows):
+    """[n, D] f32 -> bf16, round to nearest even (esr_rows_f32_to_bf16: what the bf16 gradient exchange sends)."""
+    lib = _lib.load()
+    _req(rows, torch.float32, "rows")
+    out = torch.empty(rows.shape, dtype=torch.bfloat16, device=rows.device)
+    check(lib.esr_rows_f32_to_bf16(_p(rows), rows.shape[0], rows.shape[1], _p(out), _stream()), "esr_rows_f32_to_bf16")
+    return out

@@ -600,6 +600,9 @@ int esr_alltoall_grads(esr_comm_t comm, const float* send_grads, int D, const in
  *   recv_grads; element error <= 2^-9 relative; D % 8 == 0) -- SURVEY 8d's config-4 budget of bf16-sized gradients.
  * world == 1 (comm may be NULL): nothing is exchanged or copied -- the gather writes into `back`, the update reads the
  * asker's rows in place; served / recv_grads / send_bf16 / recv_raw are not touched. */
+/* rows [n, D] f32 -> bf16, round to nearest even (NaN stays NaN); D % 8 == 0.  The narrowing half of the bf16 gradient
+ * exchange (esr_unpermute_rows_bf16_to_f32 with perm = NULL is the widening half). */
+int esr_rows_f32_to_bf16(const float* rows, int64_t n, int D, void* rows_bf16, esr_stream_t stream);
 int esr_sharded_lookup(esr_comm_t comm, int world, const void* const* tables, const int64_t* row_offsets, int ntables,
                        int dtype, int D, const int32_t* asked_rows, const int64_t* asked_counts,
                        const int64_t* ask_counts, void* served, void* back, esr_stream_t stream);

@@ -225,3 +225,60 @@ def test_world1_direct_mixed_steps_with_odd_batch(dev, pg, monkeypatch):
     assert np.allclose(la, lb, rtol=2e-5), (la, lb)
     errs = [rel_err(a.cpu().numpy(), b.cpu().numpy()) for a, b in zip(ta, tb)]
     assert max(errs) <= 2e-5, errs
+
+
+def test_bf16_gradient_rows_narrow_and_widen_like_torch(dev):
+    """The two conversions of the bf16 gradient exchange (esr_rows_f32_to_bf16 on the asker, esr_unpermute_rows_bf16_to_f32
+    on the owner): round-to-nearest-even like torch's, NaN / inf / signed zero / subnormals kept, widening exact."""
+    from esrecsys_amd import ops
+    g = torch.Generator(device=dev).manual_seed(4)
+    x = torch.randn((1001, 128), generator=g, device=dev) * torch.exp(torch.randn((1001, 1), generator=g, device=dev) * 8)
+    x[0, :8] = torch.tensor([0.0, -0.0, float("inf"), -float("inf"), float("nan"), 1e-40, -1e-40, 3.3895314e38], device=dev)
+    x[1, :4] = torch.tensor([1.00390625, 1.01171875, 1.0039062, 1.0039064], device=dev)  # ties: to even; just below / above
+    got = ops.rows_f32_to_bf16(x)
+    want = x.to(torch.bfloat16)
+    assert torch.equal(got.view(torch.int16)[~torch.isnan(x)], want.view(torch.int16)[~torch.isnan(x)])
+    assert bool(torch.isnan(got.float()[torch.isnan(x)]).all())
+    back = ops.unpermute_rows_to_f32(got, None)
+    assert torch.equal(back[~torch.isnan(x)], want.float()[~torch.isnan(x)])
+
+
+@pytest.mark.parametrize("workload", ["triplet", "glove", "inbatch"])
+def test_sharded_train_steps_equals_per_step_calls_on_the_gpu(dev, pg, workload):
+    """sharded_train_steps (plans of a group of batches made together, the next group's ahead; every step through the
+    esr_sharded_* library calls) against the per-step calls with in-line plans, world-1 machinery: the same tables, bit for
+    bit."""
+    from esrecsys_amd import ops, sharded
+    V, D, B, K = 5000, 128, 1024, 11
+    g = torch.Generator(device=dev).manual_seed(9)
+
+    def groups():
+        gg = torch.Generator(device=dev).manual_seed(1)
+        def tab(d):
+            t = torch.randn((V, d), generator=gg, device=dev) * d ** -0.5
+            return sharded.RowShardedTable(t, torch.full((V, d), 0.1, device=dev), V)
+        if workload == "glove":
+            return (sharded.ShardedTableGroup([tab(D)], kernels=ops), sharded.ShardedTableGroup([tab(1)], kernels=ops))
+        return (sharded.ShardedTableGroup([tab(D), tab(D)], kernels=ops),)
+    if workload == "glove":
+        batches = [(torch.randint(0, V, (2, B), generator=g, device=dev, dtype=torch.int32),
+                    torch.exp(torch.rand(B, generator=g, device=dev) * 6 - 2)) for _ in range(K)]
+    else:
+        batches = [tuple(torch.randint(0, V, (B,), generator=g, device=dev, dtype=torch.int32) for _ in range(3))
+                   for _ in range(K)]
+    kw = dict(regularization=0.1, global_batch_size=float(B), scale=4.0, lr=0.05, mode=ops.GLOVE_REFERENCE)
+    a = groups()
+    la = sharded.sharded_train_steps(workload, a, batches, plan_group=4, **kw)
+    b = groups()
+    lb = []
+    for bt in batches:
+        if workload == "glove":
+            lb.append(sharded.sharded_glove_step(b[0], b[1], bt[0], bt[1], ops.GLOVE_REFERENCE, 0.05))
+        elif workload == "inbatch":
+            lb.append(sharded.sharded_inbatch_step(b[0], bt[0], bt[1], 0.1, float(B), 4.0, 0.05))
+        else:
+            lb.append(sharded.sharded_triplet_step(b[0], bt[0], bt[1], bt[2], 0.1, float(B), 0.05))
+    assert len(la) == K and torch.equal(torch.stack([x.reshape(()) for x in la]), torch.stack([x.reshape(()) for x in lb]))
+    for ga, gb in zip(a, b):
+        for ta, tb in zip(ga.tables, gb.tables):
+            assert torch.equal(ta.local, tb.local) and torch.equal(ta.accum, tb.accum)
