@@ -461,6 +461,8 @@ class PlannedTriplets:
                                "(step the batches of presorted() in the order it yields them)")
         k = ctx.next_loss_slot()
         n = 3 * gr.B
+        if _PLAN_ON_SIDE and j == 0:  # (the group's sort + plan ran on the second stream: its first step waits for them)
+            ctx.main.wait_event(ctx.hints_event[gr.which])
         known = ctx.hints_known[gr.which]
         if known is None:
             # the group's plan launch was queued a whole group ahead of this step (see presorted): the wait ends with that
