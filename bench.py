@@ -539,7 +539,10 @@ def emit_leg(name, leg):
     """A secondary leg's full record as its own JSON line, printed BEFORE the final line (the driver keeps the tail of
     stdout: the final line stays short and carries a one-line summary of every leg)."""
     sys.stdout.flush()
-    print(json.dumps({"leg": name, **leg}), flush=True)
+    # (only the FINAL line carries the keys "metric" / "value" at its top level: a reader that looks for the bench line by
+    # its keys finds exactly one)
+    rec = {("leg_" + k if k in ("metric", "value", "unit", "n_gpus") else k): v for k, v in leg.items()}
+    print(json.dumps({"leg": name, **rec}), flush=True)
 
 
 def _r(x, n=4):
