@@ -206,6 +206,10 @@ def run_sharded(args, cfg, dev, rank, world):
                        "routing_plans": ("made for %d coming batches at a time (one bucket launch pair, one counts "
                                          "all-to-all, one RCCL group of ids exchanges, one owner-side sort per group)"
                                          % plan_group) if plan_group > 1 else "one per step, pipelined two batches deep",
+                       "overlap": ("next batch's gather + rows exchange on a side stream / second communicator under this "
+                                   "batch's loss kernel and update; stale rows served again (ESR_SHARDED_OVERLAP=1)")
+                       if os.environ.get("ESR_SHARDED_OVERLAP", "0") == "1" and plan_group > 1 and not replicated_mode
+                       and not grp0.world1_direct else "off",
                        "loss": float(total)},
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
         })

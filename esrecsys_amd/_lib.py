@@ -170,6 +170,12 @@ SIGNATURES = {
     "esr_sharded_triplet_step": (c_int, [c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_size, c_vp]),
     "esr_sharded_glove_step_workspace_bytes": (c_size, [c_vp, c_vp, c_vp, c_i64]),
     "esr_sharded_glove_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_f32, c_f32, c_vp, c_vp, c_size, c_vp]),
+    "esr_sharded_step_overlap_workspace_bytes": (c_size, [c_vp, c_vp]),
+    "esr_sharded_overlap_release": (None, [c_vp]),
+    "esr_sharded_triplet_step_overlapped": (c_int, [c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_size,
+                                                    c_vp]),
+    "esr_sharded_glove_step_overlapped": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_f32, c_f32, c_vp, c_vp,
+                                                  c_size, c_vp]),
 }
 
 
@@ -185,6 +191,14 @@ class RoutingPlanStruct(ctypes.Structure):
     _fields_ = [("asked_rows", ctypes.c_void_p), ("asked_counts", ctypes.c_void_p), ("ask_counts", ctypes.c_void_p),
                 ("index", ctypes.c_void_p), ("sorted_uidx", ctypes.c_void_p), ("occ_perm", ctypes.c_void_p),
                 ("owner_sorted", ctypes.c_void_p), ("owner_perm", ctypes.c_void_p), ("long_runs", ctypes.c_int)]
+
+
+class StepOverlapStruct(ctypes.Structure):
+    """esr_step_overlap_t (include/esr_hip.h)"""
+    _fields_ = [("back", ctypes.c_void_p * 2), ("ready", ctypes.c_void_p), ("stale_rows", ctypes.c_void_p),
+                ("stale_asked", ctypes.c_void_p), ("stale_pos", ctypes.c_void_p), ("stale_ask", ctypes.c_void_p),
+                ("next_plan", ctypes.c_void_p), ("next_back", ctypes.c_void_p * 2), ("next_served", ctypes.c_void_p * 2),
+                ("comm2", ctypes.c_void_p), ("side", ctypes.c_void_p), ("next_ready", ctypes.c_void_p)]
 
 
 class EsrLibraryError(RuntimeError):

@@ -204,6 +204,94 @@ int group_update(const esr_shard_group_t* g, const esr_routing_plan_t* plan, flo
                             summed, plan->ask_counts, plan->asked_counts, bf16 ? ESR_BF16 : ESR_F32, send_h, recv_h, recv,
                             plan->owner_sorted, plan->owner_perm, lr, eps, plan->long_runs, stream);
 }
+#define ESR_HIP(call)                                                                  \
+  do {                                                                                 \
+    const hipError_t e_ = (call);                                                      \
+    if (e_ != hipSuccess) {                                                            \
+      set_error("sharded step (overlapped): %s: %s", #call, hipGetErrorString(e_));   \
+      return ESR_ELAUNCH;                                                              \
+    }                                                                                  \
+  } while (0)
+
+// ---- the overlap of SURVEY 8e: this batch's rows were looked up by the PREVIOUS call, under its kernels ---------------
+int64_t stale_out(const esr_shard_group_t* g, const esr_step_overlap_t* ov) { return sum_counts(ov->stale_asked, g->world); }
+int64_t stale_in(const esr_shard_group_t* g, const esr_step_overlap_t* ov) { return sum_counts(ov->stale_ask, g->world); }
+size_t patch_scratch_bytes(const esr_shard_group_t* g, const esr_step_overlap_t* ov) {
+  if (!ov || !ov->stale_asked || !ov->stale_ask) return 0;
+  const size_t es = g->dtype == ESR_BF16 ? 2 : 4;
+  return align_up((size_t)stale_out(g, ov) * g->D * es, 256) + (g->world > 1 ? align_up((size_t)stale_in(g, ov) * g->D * es, 256) : 0);
+}
+// The rows of `back` that the previous step's update wrote after they were fetched: served again (gather -> rows exchange
+// on the FIRST communicator and the main stream -> scatter to their places).  Every rank calls the exchange, also with
+// nothing to send.
+int group_patch(const esr_shard_group_t* g, const esr_step_overlap_t* ov, void* back, StepScratch& sc, esr_stream_t stream) {
+  ESR_REQUIRE(ov->stale_asked && ov->stale_ask, "sharded step (overlapped): rows looked up ahead need the stale-row lists");
+  const int64_t n_out = stale_out(g, ov), n_in = stale_in(g, ov);
+  const size_t es = g->dtype == ESR_BF16 ? 2 : 4;
+  ESR_REQUIRE((n_out == 0 || ov->stale_rows) && (n_in == 0 || ov->stale_pos), "sharded step (overlapped): null stale-row list");
+  void* served = sc.take((size_t)n_out * g->D * es);
+  void* got = g->world > 1 ? sc.take((size_t)n_in * g->D * es) : served;
+  if (!served || !got) {
+    set_error("sharded step (overlapped): workspace too small for the stale rows");
+    return ESR_EWORKSPACE;
+  }
+  if (n_out > 0)
+    if (int rc = gather_any(g->tables, g->row_offsets, g->ntables, g->dtype, g->D, ov->stale_rows, n_out, served, stream)) return rc;
+  if (g->world > 1) {
+    ESR_REQUIRE(g->comm, "sharded step (overlapped): null communicator at world %d", g->world);
+    if (int rc = esr_alltoall_rows(g->comm, served, g->dtype, g->D, ov->stale_asked, got, ov->stale_ask, stream)) return rc;
+  } else {
+    ESR_REQUIRE(n_out == n_in, "sharded step (overlapped): a world of one rank re-serves %lld rows and expects %lld",
+                (long long)n_out, (long long)n_in);
+  }
+  if (n_in == 0) return ESR_OK;
+  return esr_unpermute_rows(got, g->dtype, g->D, ov->stale_pos, n_in, back, stream);
+}
+// this batch's rows of group `gi`: patched if they came from the previous call, else looked up in line
+int group_rows(const esr_shard_group_t* g, const esr_routing_plan_t* plan, const esr_step_overlap_t* ov, int gi,
+               int64_t n_rows, int64_t n_recv, StepScratch& sc, void** back, esr_stream_t stream) {
+  if (ov && ov->back[gi]) {
+    *back = ov->back[gi];
+    return group_patch(g, ov, *back, sc, stream);
+  }
+  return group_lookup(g, plan, n_rows, n_recv, sc, back, stream);
+}
+// main stream: wait for the lookup the previous call left on the side stream
+int overlap_enter(esr_step_overlap_t* ov, esr_stream_t stream) {
+  if (!ov) return ESR_OK;
+  ov->next_ready = nullptr;
+  if (ov->ready) {
+    hipEvent_t ev = (hipEvent_t)ov->ready;
+    ESR_HIP(hipStreamWaitEvent(as_stream(stream), ev, 0));
+    ESR_HIP(hipEventDestroy(ev));  // (released when the wait has been consumed)
+    ov->ready = nullptr;
+  }
+  return ESR_OK;
+}
+// The NEXT batch's lookups: on the side stream, behind everything the main stream holds now (the previous update and this
+// batch's patch), on the second communicator -- they run under this batch's loss kernel, gradient exchange and update.
+int overlap_prefetch(const esr_shard_group_t* const* groups, int ngroups, esr_step_overlap_t* ov, esr_stream_t stream) {
+  if (!ov || !ov->next_plan) return ESR_OK;
+  const esr_routing_plan_t* np = ov->next_plan;
+  ESR_REQUIRE(ov->side && np->asked_counts && np->ask_counts, "sharded step (overlapped): next plan without a side stream / counts");
+  hipEvent_t here = nullptr, done = nullptr;
+  ESR_HIP(hipEventCreateWithFlags(&here, hipEventDisableTiming));
+  ESR_HIP(hipEventRecord(here, as_stream(stream)));
+  ESR_HIP(hipStreamWaitEvent(as_stream(ov->side), here, 0));
+  ESR_HIP(hipEventDestroy(here));
+  for (int gi = 0; gi < ngroups; ++gi) {
+    const esr_shard_group_t* g = groups[gi];
+    ESR_REQUIRE(g->world == 1 || ov->comm2, "sharded step (overlapped): null second communicator at world %d", g->world);
+    if (int rc = esr_sharded_lookup(ov->comm2, g->world, g->tables, g->row_offsets, g->ntables, g->dtype, g->D,
+                                    np->asked_rows, np->asked_counts, np->ask_counts, ov->next_served[gi], ov->next_back[gi],
+                                    ov->side))
+      return rc;
+  }
+  ESR_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+  ESR_HIP(hipEventRecord(done, as_stream(ov->side)));
+  ov->next_ready = done;
+  return ESR_OK;
+}
 }  // namespace
 
 size_t esr_sharded_triplet_step_workspace_bytes(const esr_shard_group_t* towers, const esr_routing_plan_t* plan,
@@ -215,23 +303,39 @@ size_t esr_sharded_triplet_step_workspace_bytes(const esr_shard_group_t* towers,
          align_up((size_t)3 * B * towers->D * 4, 256) + align_up(esr_triplet_workspace_bytes(B), 256) + 1024;
 }
 
+size_t esr_sharded_step_overlap_workspace_bytes(const esr_shard_group_t* group, const esr_step_overlap_t* overlap) {
+  return group && group->world >= 1 ? patch_scratch_bytes(group, overlap) : 0;
+}
+
+void esr_sharded_overlap_release(void* ready) {
+  if (ready) (void)hipEventDestroy((hipEvent_t)ready);
+}
+
 int esr_sharded_triplet_step(const esr_shard_group_t* towers, const esr_routing_plan_t* plan, int64_t B,
                              float regularization, float batch_size, float lr, float eps, float* loss, void* workspace,
                              size_t workspace_bytes, esr_stream_t stream) {
+  return esr_sharded_triplet_step_overlapped(towers, plan, nullptr, B, regularization, batch_size, lr, eps, loss, workspace,
+                                             workspace_bytes, stream);
+}
+
+int esr_sharded_triplet_step_overlapped(const esr_shard_group_t* towers, const esr_routing_plan_t* plan,
+                                        esr_step_overlap_t* ov, int64_t B, float regularization, float batch_size, float lr,
+                                        float eps, float* loss, void* workspace, size_t workspace_bytes, esr_stream_t stream) {
   int64_t n_rows = 0, n_recv = 0;
   if (int rc = plan_counts("esr_sharded_triplet_step", towers, plan, &n_rows, &n_recv)) return rc;
   ESR_REQUIRE(B > 0 && loss && plan->index, "esr_sharded_triplet_step: B=%lld, or null loss / plan index", (long long)B);
   ESR_REQUIRE(towers->dtype == ESR_F32, "esr_sharded_triplet_step: f32 tables only (bf16 towers: lookup + the f32 head)");
-  ESR_REQUIRE(workspace && !((uintptr_t)workspace & 255) &&
-                  workspace_bytes >= esr_sharded_triplet_step_workspace_bytes(towers, plan, B),
-              "esr_sharded_triplet_step: workspace %zu bytes < %zu required (or not 256-byte aligned)", workspace_bytes,
-              esr_sharded_triplet_step_workspace_bytes(towers, plan, B));
+  const size_t need = esr_sharded_triplet_step_workspace_bytes(towers, plan, B) + patch_scratch_bytes(towers, ov);
+  ESR_REQUIRE(workspace && !((uintptr_t)workspace & 255) && workspace_bytes >= need,
+              "esr_sharded_triplet_step: workspace %zu bytes < %zu required (or not 256-byte aligned)", workspace_bytes, need);
   const bool unique = plan->sorted_uidx != nullptr;
   ESR_REQUIRE(unique || n_rows == 3 * B, "esr_sharded_triplet_step: a per-occurrence plan of %lld rows for B=%lld",
               (long long)n_rows, (long long)B);
   StepScratch sc{(char*)workspace, workspace_bytes};
   void* back = nullptr;
-  if (int rc = group_lookup(towers, plan, n_rows, n_recv, sc, &back, stream)) return rc;
+  if (int rc = overlap_enter(ov, stream)) return rc;
+  if (int rc = group_rows(towers, plan, ov, 0, n_rows, n_recv, sc, &back, stream)) return rc;
+  if (int rc = overlap_prefetch(&towers, 1, ov, stream)) return rc;
   float* grads = (float*)sc.take((size_t)3 * B * towers->D * 4);
   const size_t tws_bytes = esr_triplet_workspace_bytes(B);
   void* tws = sc.take(tws_bytes);
@@ -266,6 +370,14 @@ size_t esr_sharded_glove_step_workspace_bytes(const esr_shard_group_t* emb, cons
 int esr_sharded_glove_step(const esr_shard_group_t* emb, const esr_shard_group_t* bias, const esr_routing_plan_t* plan,
                            const float* target, int64_t B, int mode, float lr, float eps, float* loss, void* workspace,
                            size_t workspace_bytes, esr_stream_t stream) {
+  return esr_sharded_glove_step_overlapped(emb, bias, plan, nullptr, target, B, mode, lr, eps, loss, workspace,
+                                           workspace_bytes, stream);
+}
+
+int esr_sharded_glove_step_overlapped(const esr_shard_group_t* emb, const esr_shard_group_t* bias,
+                                      const esr_routing_plan_t* plan, esr_step_overlap_t* ov, const float* target, int64_t B,
+                                      int mode, float lr, float eps, float* loss, void* workspace, size_t workspace_bytes,
+                                      esr_stream_t stream) {
   int64_t n_rows = 0, n_recv = 0;
   if (int rc = plan_counts("esr_sharded_glove_step", emb, plan, &n_rows, &n_recv)) return rc;
   ESR_REQUIRE(bias && bias->world == emb->world && bias->D == 1 && bias->ntables == 1 && emb->ntables == 1,
@@ -273,17 +385,20 @@ int esr_sharded_glove_step(const esr_shard_group_t* emb, const esr_shard_group_t
   ESR_REQUIRE(B > 0 && loss && target && plan->index, "esr_sharded_glove_step: B=%lld, or a null pointer", (long long)B);
   ESR_REQUIRE(emb->dtype == ESR_F32 && bias->dtype == ESR_F32, "esr_sharded_glove_step: f32 tables only");
   ESR_REQUIRE(mode == ESR_GLOVE_REFERENCE || mode == ESR_GLOVE_DIAGONAL, "esr_sharded_glove_step: bad mode %d", mode);
-  ESR_REQUIRE(workspace && !((uintptr_t)workspace & 255) &&
-                  workspace_bytes >= esr_sharded_glove_step_workspace_bytes(emb, bias, plan, B),
-              "esr_sharded_glove_step: workspace %zu bytes < %zu required (or not 256-byte aligned)", workspace_bytes,
-              esr_sharded_glove_step_workspace_bytes(emb, bias, plan, B));
+  const size_t need = esr_sharded_glove_step_workspace_bytes(emb, bias, plan, B) + patch_scratch_bytes(emb, ov) +
+                      patch_scratch_bytes(bias, ov);
+  ESR_REQUIRE(workspace && !((uintptr_t)workspace & 255) && workspace_bytes >= need,
+              "esr_sharded_glove_step: workspace %zu bytes < %zu required (or not 256-byte aligned)", workspace_bytes, need);
   const bool unique = plan->sorted_uidx != nullptr;
   ESR_REQUIRE(unique || n_rows == 2 * B, "esr_sharded_glove_step: a per-occurrence plan of %lld rows for B=%lld",
               (long long)n_rows, (long long)B);
   StepScratch sc{(char*)workspace, workspace_bytes};
   void *rows = nullptr, *brow = nullptr;
-  if (int rc = group_lookup(emb, plan, n_rows, n_recv, sc, &rows, stream)) return rc;
-  if (int rc = group_lookup(bias, plan, n_rows, n_recv, sc, &brow, stream)) return rc;
+  if (int rc = overlap_enter(ov, stream)) return rc;
+  if (int rc = group_rows(emb, plan, ov, 0, n_rows, n_recv, sc, &rows, stream)) return rc;
+  if (int rc = group_rows(bias, plan, ov, 1, n_rows, n_recv, sc, &brow, stream)) return rc;
+  const esr_shard_group_t* both[2] = {emb, bias};
+  if (int rc = overlap_prefetch(both, 2, ov, stream)) return rc;
   float* grad_rows = (float*)sc.take((size_t)2 * B * emb->D * 4);
   float* grad_bias = (float*)sc.take((size_t)2 * B * 4);
   const size_t gws_bytes = esr_glove_workspace_bytes(B);

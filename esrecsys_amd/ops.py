@@ -1108,31 +1108,71 @@ def routing_plan_struct(asked_rows, asked_c, ask_c, index, sorted_uidx, occ_perm
                                   q(owner_sorted), q(owner_perm), int(long_runs))
 
 
-def sharded_triplet_step(group_s, plan_s, B, regularization, batch_size, lr, eps, device):
+def step_overlap_struct(backs, ready, stale, next_plan_s, next_backs, next_serveds, comm2, side_stream):
+    """esr_step_overlap_t of one overlapped step (include/esr_hip.h).  backs: this batch's rows per group as the previous
+    call fetched them (None: look up in line) with `ready`, that call's next_ready; stale = (rows, asked host array, pos, ask
+    host array) of esrecsys_amd.sharded.StaleRows; next_*: the coming batch's plan struct and its buffers per group (None:
+    last step); side_stream: a torch.cuda.Stream.  The caller keeps every tensor / array alive until the NEXT call."""
+    import ctypes
+    ov = _lib.StepOverlapStruct()
+    q = lambda t: t.data_ptr() if t is not None and t.numel() else None  # noqa: E731
+    for i, b in enumerate(backs or ()):
+        ov.back[i] = b.data_ptr()
+    ov.ready = ready
+    if backs and stale is not None:
+        rows, asked_c, pos, ask_c = stale
+        ov.stale_rows, ov.stale_pos = q(rows), q(pos)
+        ov.stale_asked, ov.stale_ask = ctypes.cast(asked_c, ctypes.c_void_p), ctypes.cast(ask_c, ctypes.c_void_p)
+    if next_plan_s is not None:
+        ov.next_plan = ctypes.cast(ctypes.pointer(next_plan_s), ctypes.c_void_p)
+        for i, b in enumerate(next_backs):
+            ov.next_back[i] = b.data_ptr()
+        for i, b in enumerate(next_serveds):
+            ov.next_served[i] = q(b)
+    ov.comm2 = getattr(comm2, "value", comm2)
+    ov.side = side_stream.cuda_stream if side_stream is not None else None
+    return ov
+
+
+def overlap_release(ready):
+    """Release a next_ready event that no call will consume (a loop that stopped early)."""
+    if ready:
+        _lib.load().esr_sharded_overlap_release(ready)
+
+
+def sharded_triplet_step(group_s, plan_s, B, regularization, batch_size, lr, eps, device, overlap=None):
     """esr_sharded_triplet_step: lookup -> triplet loss on the rows where they landed -> update, one library call.
-    Returns loss [1] (this rank's share)."""
+    Returns loss [1] (this rank's share).  overlap: a step_overlap_struct (esr_sharded_triplet_step_overlapped)."""
     import ctypes
     lib = _lib.load()
     nb = int(lib.esr_sharded_triplet_step_workspace_bytes(ctypes.byref(group_s), ctypes.byref(plan_s), B))
+    ov = ctypes.byref(overlap) if overlap is not None else None
+    if ov is not None:
+        nb += int(lib.esr_sharded_step_overlap_workspace_bytes(ctypes.byref(group_s), ov))
     ws = _ws(nb, device)
     loss = torch.empty(1, dtype=torch.float32, device=device)
-    check(lib.esr_sharded_triplet_step(ctypes.byref(group_s), ctypes.byref(plan_s), B, float(regularization),
-                                       float(batch_size), float(lr), float(eps), _p(loss), _p(ws), ws.numel(), _stream()),
-          "esr_sharded_triplet_step")
+    check(lib.esr_sharded_triplet_step_overlapped(ctypes.byref(group_s), ctypes.byref(plan_s), ov, B, float(regularization),
+                                                  float(batch_size), float(lr), float(eps), _p(loss), _p(ws), ws.numel(),
+                                                  _stream()), "esr_sharded_triplet_step")
     return loss
 
 
-def sharded_glove_step(emb_s, bias_s, plan_s, target, B, mode, lr, eps):
-    """esr_sharded_glove_step: both lookups -> GloVe loss -> both updates, one library call.  Returns loss [1]."""
+def sharded_glove_step(emb_s, bias_s, plan_s, target, B, mode, lr, eps, overlap=None):
+    """esr_sharded_glove_step: both lookups -> GloVe loss -> both updates, one library call.  Returns loss [1].
+    overlap: a step_overlap_struct (esr_sharded_glove_step_overlapped)."""
     import ctypes
     lib = _lib.load()
     _req(target, torch.float32, "target")
     nb = int(lib.esr_sharded_glove_step_workspace_bytes(ctypes.byref(emb_s), ctypes.byref(bias_s), ctypes.byref(plan_s), B))
+    ov = ctypes.byref(overlap) if overlap is not None else None
+    if ov is not None:
+        nb += int(lib.esr_sharded_step_overlap_workspace_bytes(ctypes.byref(emb_s), ov)) + \
+            int(lib.esr_sharded_step_overlap_workspace_bytes(ctypes.byref(bias_s), ov))
     ws = _ws(nb, target.device)
     loss = torch.empty(1, dtype=torch.float32, device=target.device)
-    check(lib.esr_sharded_glove_step(ctypes.byref(emb_s), ctypes.byref(bias_s), ctypes.byref(plan_s), _p(target), B,
-                                     int(mode), float(lr), float(eps), _p(loss), _p(ws), ws.numel(), _stream()),
-          "esr_sharded_glove_step")
+    check(lib.esr_sharded_glove_step_overlapped(ctypes.byref(emb_s), ctypes.byref(bias_s), ctypes.byref(plan_s), ov,
+                                                _p(target), B, int(mode), float(lr), float(eps), _p(loss), _p(ws),
+                                                ws.numel(), _stream()), "esr_sharded_glove_step")
     return loss
 
 

@@ -185,12 +185,15 @@ def reset():
     _cache.clear()
 
 
-def exchange_for(group, device):
+def exchange_for(group, device, lane=0):
     """The DirectExchange of (group, device), or None when disabled / unavailable (then use torch.distributed).
-    Every rank returns the same answer: the bootstrap phases agree through the process group."""
+    Every rank returns the same answer: the bootstrap phases agree through the process group.  lane 1 is a SECOND
+    communicator over the same ranks: collectives of one communicator are serialised, so the rows exchange that a
+    training loop runs on a side stream under the previous step's kernels (sharded.sharded_train_steps, overlap) needs
+    its own."""
     if os.environ.get("ESR_RCCL_DIRECT", "1") != "1" or device.type != "cuda" or dist.get_backend(group) != "nccl":
         return None
-    key = (id(group), device.index)
+    key = (id(group), device.index, lane)
     if key not in _cache:
         try:
             _cache[key] = DirectExchange(group, device)

@@ -34,13 +34,15 @@ import torch
 import torch.distributed as dist
 
 
-def _a2a(group, out, inp, out_splits=None, in_splits=None):
+def _a2a(group, out, inp, out_splits=None, in_splits=None, lane=0):
     """all_to_all_single of a ShardedTableGroup: RCCL send / recv on the current stream when available
-    (esrecsys_amd/rccl.py: no stream hand-overs), else torch.distributed."""
-    x = group.exchange()
+    (esrecsys_amd/rccl.py: no stream hand-overs), else torch.distributed.  lane 1: the second communicator, for the rows
+    exchange that runs on a side stream under the previous step's kernels (sharded_train_steps, overlap)."""
+    x = group.exchange(lane)
     if x is not None:
         return x.all_to_all_single(out, inp, out_splits, in_splits)
-    return dist.all_to_all_single(out, inp, out_splits, in_splits, group=group.pg)
+    pg = group.prefetch_pg if lane and group.prefetch_pg is not None else group.pg
+    return dist.all_to_all_single(out, inp, out_splits, in_splits, group=pg)
 
 
 class RowShardedTable:
@@ -82,6 +84,8 @@ class RoutingPlan:
         self.owner_sorted = None            # (sorted, permutation) of recv_local_rows, for the update
         self._c_counts = None               # (ask, asked) host int64 arrays for the one-call exchange halves
         self._c_struct = None
+        self.dev_counts = None              # (send, recv) int64 [G] on the device: the same counts, for begin_stale_sets
+        self.stale = None                   # StaleRows: what the PREVIOUS step of a loop updates of this lookup (overlap)
 
     def c_counts(self, k):
         if self._c_counts is None:
@@ -157,7 +161,8 @@ class PendingPlans:
             self.plans = [RoutingPlan(group, n, local_rows, perm, both[0, :, i].tolist(), both[1, :, i].tolist(), inv,
                                       unique=part[6] if len(part) > 6 else None)
                           for i, part in enumerate(self.parts) for (group, n, local_rows, perm, _, inv) in [part[:6]]]
-            for p in self.plans:
+            for i, p in enumerate(self.plans):
+                p.dev_counts = (self.both_dev[0, :, i], self.both_dev[1, :, i])
                 if p.unique:
                     p.group.observe_unique(p.n_rows, p.n)
             if not self._exchange_ids_grouped():
@@ -210,6 +215,7 @@ def _grouped_owner_sort(plans):
         srt, prm = k.segment_sort_batched([[buf[i]] for i in range(L)], (0,), sentinel + 1)
         for i, p in enumerate(plans):
             p.owner_sorted = (srt[i, :ns[i]], prm[i, :ns[i]]) if ns[i] else None
+            p._batch = (buf, srt, i)  # (begin_stale_sets searches these matrices as they are)
     else:
         for p in plans:
             p.owner_sorted = k.segment_sort(p.recv_local_rows, g.loff[-1]) if p.recv_local_rows.numel() else None
@@ -288,15 +294,161 @@ def make_plans(lookups):
     return begin_plans(lookups).finish()
 
 
+class StaleRows:
+    """Of one lookup of a training loop: the rows that the step BEFORE it updates -- on whichever rank that step's batch
+    named them.  A lookup issued ahead of that update (the overlap of sharded_train_steps) carries old values in exactly
+    these rows; ShardedTableGroup.patch_rows serves them again once the update is done."""
+
+    def __init__(self, ids, send_counts, recv_counts, pos):
+        self.ids = ids                    # int32: virtual local rows this rank serves AGAIN, requester-major
+        self.send_counts = send_counts    # python ints per requester (rows of `ids`)
+        self.recv_counts = recv_counts    # python ints per owner: rows that come back to this rank
+        self.pos = pos                    # int32 [sum(recv_counts)]: the rows of the looked-up block they replace
+        self._c = None
+
+    def c_parts(self, k):
+        """(rows, asked host array, pos, ask host array) for esr_step_overlap_t."""
+        if self._c is None:
+            self._c = (self.ids, k.i64_array(self.send_counts), self.pos, k.i64_array(self.recv_counts))
+        return self._c
+
+
+class PendingStale:
+    """begin_stale_sets, enqueued: ``finish()`` waits for its counts copy (a loop calls it a group of steps later) and
+    cuts the per-plan StaleRows out of the group's matrices -- no further device work."""
+
+    def __init__(self, plans, ids_sorted, pos_sorted, both_host, event):
+        self.plans, self.ids_sorted, self.pos_sorted, self.both_host, self.event = plans, ids_sorted, pos_sorted, both_host, event
+
+    def finish(self):
+        if self.plans is None:
+            return
+        if self.event is not None:
+            self.event.synchronize()
+        host = self.both_host
+        for i, p in enumerate(self.plans):
+            out_c, in_c = host[0, :, i].tolist(), host[1, :, i].tolist()
+            p.stale = StaleRows(self.ids_sorted[i, :sum(out_c)], out_c, in_c, self.pos_sorted[i, :sum(in_c)])
+        self.plans = None
+
+
+def _padded_lists(plans, sentinel):
+    """([L, n_max] lists asked of this rank, the same lists sorted), rows padded with `sentinel`: the matrices the batched
+    owner-side sort left behind when there was one (_grouped_owner_sort), else assembled here."""
+    first = getattr(plans[0], "_batch", None)
+    if first is not None and first[0].shape[0] == len(plans) and \
+            all(getattr(p, "_batch", (None, None, -1))[0] is first[0] and p._batch[2] == i for i, p in enumerate(plans)):
+        return first[0], first[1]
+    dev = plans[0].recv_local_rows.device
+    n_max = max([int(p.recv_local_rows.numel()) for p in plans] + [1])
+    cur = torch.full((len(plans), n_max), sentinel, dtype=torch.int32, device=dev)
+    srt = torch.full((len(plans), n_max), sentinel, dtype=torch.int32, device=dev)
+    for i, p in enumerate(plans):
+        n = int(p.recv_local_rows.numel())
+        if n:
+            cur[i, :n] = p.recv_local_rows
+            srt[i, :n] = p.owner_sorted[0]
+    return cur, srt
+
+
+def _row_sums(x, chunk=512):
+    """cumsum along dim 1 of x [L, n] int64.  torch scans a row with ONE workgroup and a group of plans has 8 rows: cut
+    into chunks the same scan has hundreds of rows to spread over the CUs (1 M flags: 150 -> 15 us)."""
+    L, n = x.shape
+    if n <= 4 * chunk:
+        return x.cumsum(1)
+    pad = (-n) % chunk
+    y = (torch.nn.functional.pad(x, (0, pad)) if pad else x).view(L, -1, chunk).cumsum(2)
+    ends = y[:, :, -1]
+    return (y + (ends.cumsum(1) - ends)[:, :, None]).view(L, -1)[:, :n]
+
+
+def _flagged_first(flags, values):
+    """Every row of `values` [L, n] with its flagged entries first, order kept (a stable partition by one prefix sum and
+    one scatter -- a stable sort of the flags costs several times that), and the prefix sums of the flags [L, n + 1]."""
+    L, n = flags.shape
+    cs = _row_sums(flags.to(torch.int64))
+    at = torch.arange(n, dtype=torch.int64, device=flags.device).expand(L, n)
+    dest = torch.where(flags, cs - 1, cs[:, -1:] + at - cs)
+    out = torch.empty_like(values).scatter_(1, dest, values)
+    return out, torch.cat([torch.zeros((L, 1), dtype=torch.int64, device=flags.device), cs], dim=1)
+
+
+def _per_peer(counts, sums):
+    """[L, G] numbers of flagged entries in consecutive slices of lengths counts [L, G] (the plans' counts, already on
+    the device), from the prefix sums of _flagged_first."""
+    ends = counts.cumsum(1).clamp_(max=sums.shape[1] - 1)
+    return sums.gather(1, ends) - sums.gather(1, (ends - counts).clamp_(min=0))
+
+
+def begin_stale_sets(plans, prev):
+    """For consecutive lookups of ONE table group in a training loop -- plans[i] follows plans[i - 1], plans[0] follows
+    `prev` (the last plan of the group of batches before; None: nothing precedes) -- find, on the owner, the rows of every
+    lookup that its predecessor's step updates: positions of the list asked of this rank whose row is in the predecessor's
+    list.  Ids only, like the routing plans, so it runs ahead with them and batched over the group: a membership search of
+    the asked lists in the predecessors' sorted lists; the 0 / 1 answers go back to the askers (one byte per asked row: the
+    sizes are the plans' own, ONE RCCL group for the group's plans), so that owner and asker each derive their half --
+    the rows to serve again, per asker; the places they go to, per owner -- and ONE copy of the two count matrices to
+    pinned memory.  SURVEY 8e: the exchange of batch k + 1 under batch k's kernels."""
+    g = plans[0].group
+    G, L = g.world, len(plans)
+    for p in plans:
+        p.exchange_ids()
+    sentinel = g.loff[-1]  # beyond every virtual local row
+    cur, srt = _padded_lists(plans, sentinel)
+    dev = cur.device
+    n_max = cur.shape[1]
+    first = prev.owner_sorted[0] if prev is not None and prev.owner_sorted is not None else None
+    m = max(n_max, int(first.numel()) if first is not None else 0)
+    seq = torch.full((L, m), sentinel + 1, dtype=torch.int32, device=dev)  # row i: what plan i's predecessor updates
+    if L > 1:
+        seq[1:, :n_max] = srt[:-1]
+    if first is not None and first.numel():
+        seq[0, :first.numel()] = first
+    hit = (seq.gather(1, torch.searchsorted(seq, cur).clamp_(max=m - 1)) == cur) & (cur != sentinel)
+    # owner: the rows to serve again, asker by asker (the order of the asked list is kept)
+    ids_sorted, sums = _flagged_first(hit, cur)
+    out_counts = _per_peer(torch.stack([p.dev_counts[1] for p in plans]), sums)
+    # asker: which rows of its looked-up block those are
+    r_max = max([p.n_rows for p in plans] + [1])
+    hit8 = hit.to(torch.uint8)
+    if G == 1:
+        mask = hit8  # (a world of one rank asks itself: block order == asked order)
+    else:
+        mask = torch.zeros((L, r_max), dtype=torch.uint8, device=dev)
+        moves = [(mask[i, :p.n_rows], hit8[i, :p.recv_local_rows.numel()], p.send_counts, p.recv_counts)
+                 for i, p in enumerate(plans)]
+        x = g.exchange()
+        if x is not None and hasattr(x, "all_to_all_multi"):
+            x.all_to_all_multi(moves)
+        else:
+            for mv in moves:
+                _a2a(g, *mv)
+    pos_sorted, sums = _flagged_first(mask != 0, torch.arange(mask.shape[1], dtype=torch.int32, device=dev).expand(
+        L, mask.shape[1]))
+    in_counts = _per_peer(torch.stack([p.dev_counts[0] for p in plans]), sums)
+    both = torch.stack([out_counts.t(), in_counts.t()])  # [2, G, L]
+    if both.is_cuda:
+        host = _pinned_like(both)
+        host.copy_(both, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return PendingStale(list(plans), ids_sorted, pos_sorted, host, ev)
+    return PendingStale(list(plans), ids_sorted, pos_sorted, both, None)
+
+
 class ShardedTableGroup:
     """Same-width, same-dtype row-sharded tables that one step looks up and updates together."""
 
-    def __init__(self, tables, group=None, kernels=None, unique=None, grad_dtype=None):
+    def __init__(self, tables, group=None, kernels=None, unique=None, grad_dtype=None, prefetch_group=None):
         if kernels is None:
             from . import ops as kernels
         self.k = kernels
         self.tables = list(tables)
         self.pg = group
+        # a second process group over the same ranks for lane 1 when the exchange runs on torch.distributed (whose
+        # collectives of one group are serialised); the direct RCCL exchange makes its own second communicator
+        self.prefetch_pg = prefetch_group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         G = self.world
@@ -305,7 +457,7 @@ class ShardedTableGroup:
             self.voff.append(self.voff[-1] + G * ((t.num_rows + G - 1) // G))
         self.loff = [o // G for o in self.voff]  # the same boundaries in virtual LOCAL rows
         self.dim = self.tables[0].local.shape[1] if self.tables[0].local.dim() > 1 else 1
-        self._xch = False  # DirectExchange, None (use torch.distributed) or False (not resolved yet)
+        self._xch = [False, False]  # per lane: DirectExchange, None (use torch.distributed) or False (not resolved yet)
         # unique: every distinct row of a batch crosses the exchange once (rows out, ONE summed gradient row back) instead
         # of once per occurrence.  A sender-side choice -- owners serve whatever list they get -- that pays where bytes
         # cross xGMI (world > 1) and ids repeat (GloVe's Zipfian stream: wikipedia/make_cooccurrence.py:33-55); at world
@@ -356,7 +508,7 @@ class ShardedTableGroup:
         if self.unique_mode == "auto" and n_occ > 0 and n_rows >= _UNIQUE_KEEP_BELOW * n_occ:
             self._auto_unique, self._auto_skip = False, _UNIQUE_PROBE_EVERY
 
-    def _fused(self):
+    def _fused(self, lane=0):
         """(comm, tables_c, accums_c, loff_c, dtype code) when the exchange halves of a step run as ONE library call each
         (esr_sharded_lookup / esr_sharded_update): CUDA shards and either a world of one rank or the direct RCCL exchange.
         None: op by op through `kernels` and torch.distributed (the CPU doubles of the gloo tests, ESR_SHARDED_FUSED=0)."""
@@ -366,7 +518,7 @@ class ShardedTableGroup:
             return None
         comm = None
         if self.world > 1:
-            x = self.exchange()
+            x = self.exchange(lane)
             if x is None or not getattr(x, "comm", None):
                 return None
             comm = x.comm
@@ -414,15 +566,15 @@ class ShardedTableGroup:
             for t, rv in zip(self.tables, self._versions):
                 rv.consolidate(t.local)
 
-    def exchange(self):
-        if self._xch is False:
+    def exchange(self, lane=0):
+        if self._xch[lane] is False:
             dev = self.tables[0].local.device
             if dev.type == "cuda":
                 from . import rccl
-                self._xch = rccl.exchange_for(self.pg, dev)
+                self._xch[lane] = rccl.exchange_for(self.pg, dev, lane)
             else:
-                self._xch = None
-        return self._xch
+                self._xch[lane] = None
+        return self._xch[lane]
 
     def virtual_ids(self, id_tensors, slots):
         """[ids_i + voff[slots[i]]] concatenated: id_tensors[i] indexes table slots[i]."""
@@ -444,32 +596,58 @@ class ShardedTableGroup:
     def plan(self, vids):
         return make_plans([(self, vids)])[0]
 
-    def lookup_bucketed(self, plan):
+    def lookup_buffers(self, plan):
+        """(back, served) of lookup_bucketed, allocated by the caller: a lookup issued on a side stream takes buffers made
+        on the main stream (and kept until the main stream has waited for it)."""
+        recv = plan.exchange_ids()
+        dt, dev = self.tables[0].local.dtype, recv.device
+        back = torch.empty((plan.n_rows, self.dim), dtype=dt, device=dev)
+        served = torch.empty((recv.numel(), self.dim), dtype=dt, device=dev) if self.world > 1 else None
+        return back, served
+
+    def _gather(self, rows, out=None):
+        k = self.k
+        kw = {} if out is None else {"out": out}
+        if len(self.tables) == 1:
+            return k.gather_rows(self.tables[0].local, rows, **kw)
+        return k.gather_rows_multi([t.local for t in self.tables], self.loff, rows, **kw)
+
+    def lookup_bucketed(self, plan, lane=0, buffers=None):
         """The looked-up rows in BUCKET order (row plan.inv[i] belongs to virtual id i), in the tables' dtype --
-        for consumers that can index them themselves and so skip the un-permute pass."""
+        for consumers that can index them themselves and so skip the un-permute pass.  lane 1 / buffers: the lookup of
+        the NEXT batch on a side stream and the second communicator (sharded_train_steps, overlap)."""
         k = self.k
         self.consolidate()  # rows a world-1 one-pass step left in the second buffers (no-op when nothing is displaced)
         recv = plan.exchange_ids()
-        fused = self._fused()
+        back, served = buffers if buffers is not None else self.lookup_buffers(plan)
+        fused = self._fused(lane)
         if fused is not None:  # gather + rows exchange as one library call
             comm, tc, _, lc, code = fused
             ask_c, asked_c = plan.c_counts(k)
-            dt, dev = self.tables[0].local.dtype, recv.device
-            back = torch.empty((plan.n_rows, self.dim), dtype=dt, device=dev)
-            served = torch.empty((recv.numel(), self.dim), dtype=dt, device=dev) if self.world > 1 else None
             return k.sharded_lookup(comm, self.world, tc, lc, len(self.tables), code, self.dim, recv, asked_c, ask_c,
                                     served, back)
-        if len(self.tables) == 1:
-            served = k.gather_rows(self.tables[0].local, recv)
-        else:
-            served = k.gather_rows_multi([t.local for t in self.tables], self.loff, recv)
-        back = torch.empty((plan.n_rows, self.dim), dtype=served.dtype, device=served.device)
-        _a2a(self, back, served, plan.send_counts, plan.recv_counts)
+        served = self._gather(recv, served if recv.numel() else None)
+        _a2a(self, back, served, plan.send_counts, plan.recv_counts, lane=lane)
         return back
 
-    def lookup(self, plan):
+    def patch_rows(self, plan, back):
+        """`back` = lookup_bucketed(plan) issued BEFORE the previous step's update: serve the rows that update wrote
+        (plan.stale, begin_stale_sets) again and put them in their places.  Main stream, first communicator."""
+        st = plan.stale
+        k = self.k
+        served = self._gather(st.ids) if st.ids.numel() else torch.empty((0, self.dim), dtype=back.dtype, device=back.device)
+        if self.world == 1:
+            got = served
+        else:
+            got = torch.empty((st.pos.numel(), self.dim), dtype=back.dtype, device=back.device)
+            _a2a(self, got, served, st.recv_counts, st.send_counts)
+        if got.shape[0]:
+            k.unpermute_rows(got, st.pos, out=back)
+        return back
+
+    def lookup(self, plan, back=None):
         """rows[i] = table_of(vid_i)[id_i] for this rank's virtual ids -> [n, D] in the order of the ids."""
-        back = self.lookup_bucketed(plan)
+        back = back if back is not None else self.lookup_bucketed(plan)
         if plan.unique:  # one row per distinct id came back: occurrence i reads row uidx[i]
             return self.k.unpermute_rows_to_f32(self.k.gather_rows(back, plan.uidx), None)
         # bucket order -> id order; bf16 tables (config 4) cross xGMI as bf16 and become f32 here
@@ -579,10 +757,10 @@ def _world1_tables_ok(group):
     return group.world1_direct and all(t.local.is_cuda for t in group.tables)
 
 
-def sharded_inbatch_step(towers, scene_ids, pos_ids, regularization, global_batch_size, scale, lr, plan=None):
+def sharded_inbatch_step(towers, scene_ids, pos_ids, regularization, global_batch_size, scale, lr, plan=None, rows=None):
     """Data-parallel in-batch-softmax step on row-sharded towers (group = [scene table, product table]).
     Negatives are the local batch; gradients are normalised by the GLOBAL batch size, so the sum of the
-    per-rank losses is the global mean loss."""
+    per-rank losses is the global mean loss.  rows: lookup_bucketed(plan) when the caller has it already (overlap)."""
     k = towers.k
     B = scene_ids.numel()
     if _world1_tables_ok(towers) and towers.tables[0].local.shape[1] <= 128 and B % 128 == 0 and \
@@ -604,7 +782,7 @@ def sharded_inbatch_step(towers, scene_ids, pos_ids, regularization, global_batc
         # The score head reads the exchanged rows where they landed (bucket order, table dtype) through the inverse
         # permutation and writes its gradient rows straight into bucket order: no un-permute, no widening pass, no
         # permute before the gradient all-to-all.
-        back = towers.lookup_bucketed(plan)
+        back = rows if rows is not None else towers.lookup_bucketed(plan)
         iq, ic = plan.index[:B], plan.index[B:]
         if plan.unique:  # several occurrences may read one row: per-occurrence gradient rows, summed per distinct row
             loss, _, gq, gc = folded(back, back, iq, ic, scale, regularization, global_batch_size)
@@ -614,15 +792,16 @@ def sharded_inbatch_step(towers, scene_ids, pos_ids, regularization, global_batc
                                   grad_positions=(iq, ic))
         towers.apply_sparse_adagrad(plan, gbuf, lr, bucketed=True)
         return loss
-    rows = towers.lookup(plan)                     # [q ; c]
+    rows = towers.lookup(plan, back=rows)          # [q ; c]
     loss, _, gq, gc = k.inbatch_softmax_fwd_bwd(rows[:B], rows[B:], scale, regularization, global_batch_size)
     towers.apply_sparse_adagrad(plan, _joined(gq, gc), lr)
     return loss
 
 
-def sharded_triplet_step(towers, scene_ids, pos_ids, neg_ids, regularization, global_batch_size, lr, plan=None):
+def sharded_triplet_step(towers, scene_ids, pos_ids, neg_ids, regularization, global_batch_size, lr, plan=None, rows=None):
     """Reference triplet loss (pinterest/train_shop_the_look.py:93-109) on row-sharded towers.  The loss is a
-    sum over triplets, so G ranks x B triplets == one device with G*B triplets and batch_size = G*B."""
+    sum over triplets, so G ranks x B triplets == one device with G*B triplets and batch_size = G*B.
+    rows: lookup_bucketed(plan) when the caller has it already (overlap)."""
     k = towers.k
     B = scene_ids.numel()
     if _world1_tables_ok(towers) and _is_f32(towers) and getattr(k, "triplet_direct_mode", lambda: False)():
@@ -640,7 +819,7 @@ def sharded_triplet_step(towers, scene_ids, pos_ids, neg_ids, regularization, gl
                                     scene_ids, pos_ids, neg_ids, regularization, global_batch_size, lr,
                                     stamp=next_stamp(rs, rp))
     plan = plan if plan is not None else plan_triplet(towers, scene_ids, pos_ids, neg_ids)
-    if plan.index is not None and _is_f32(towers) and hasattr(k, "sharded_triplet_step"):
+    if rows is None and plan.index is not None and _is_f32(towers) and hasattr(k, "sharded_triplet_step"):
         gs_ = towers._c_group()
         if gs_ is not None:  # lookup -> loss -> update as ONE library call (esr_sharded_triplet_step)
             towers.consolidate()
@@ -649,7 +828,7 @@ def sharded_triplet_step(towers, scene_ids, pos_ids, neg_ids, regularization, gl
     if plan.index is not None and getattr(k, "GRADS_AT_IDS", None) is not None and _is_f32(towers):
         # the loss kernel indexes the exchanged rows where they landed (bucket order) through the inverse
         # permutation and writes every gradient row back at that position: no un-permute / permute passes
-        back = towers.lookup_bucketed(plan)
+        back = rows if rows is not None else towers.lookup_bucketed(plan)
         inv = plan.index
         if plan.unique:  # per-occurrence gradient rows in occurrence order, summed per distinct row before they travel
             loss, _, _, gs, gp, gn = k.triplet_fwd_bwd(back, back, back, inv[:B], inv[B:2 * B], inv[2 * B:], B,
@@ -662,7 +841,7 @@ def sharded_triplet_step(towers, scene_ids, pos_ids, neg_ids, regularization, gl
                                                    want_scores=False, grads_at_ids=True)
         towers.apply_sparse_adagrad(plan, gbuf, lr, bucketed=True)
         return loss
-    rows = towers.lookup(plan)                     # [scene ; pos ; neg]
+    rows = towers.lookup(plan, back=rows)          # [scene ; pos ; neg]
     loss, _, _, gs, gp, gn = k.triplet_fwd_bwd(rows[:B], rows[B:2 * B], rows[2 * B:], None, None, None, B,
                                                regularization, global_batch_size, with_reg=True, want_grads=True,
                                                want_scores=False)
@@ -670,9 +849,10 @@ def sharded_triplet_step(towers, scene_ids, pos_ids, neg_ids, regularization, gl
     return loss
 
 
-def sharded_glove_step(emb_group, bias_group, inputs, target, mode, lr, plan=None):
+def sharded_glove_step(emb_group, bias_group, inputs, target, mode, lr, plan=None, rows=None):
     """GloVe step on row-sharded embedding + bias tables (two single-table groups sharing one routing plan:
-    same ids, same sharding, different widths); the loss is over the local batch."""
+    same ids, same sharding, different widths); the loss is over the local batch.  rows: (lookup_bucketed of the
+    embedding group, of the bias group) when the caller has them already (overlap)."""
     k = emb_group.k
     B = inputs.shape[1]
     if _world1_tables_ok(emb_group) and _is_f32(emb_group) and _is_f32(bias_group) and emb_group.versions() is not None:
@@ -683,22 +863,25 @@ def sharded_glove_step(emb_group, bias_group, inputs, target, mode, lr, plan=Non
         return k.glove_train_step(et.local, rv.shadow, rv.loc, et.accum, bt.local, bt.accum, inputs, target, mode, lr,
                                   stamp=next_stamp(rv))
     plan = plan if plan is not None else plan_glove(emb_group, inputs)
-    if plan.index is not None and _is_f32(emb_group) and _is_f32(bias_group) and hasattr(k, "sharded_glove_step"):
+    if rows is None and plan.index is not None and _is_f32(emb_group) and _is_f32(bias_group) and \
+            hasattr(k, "sharded_glove_step"):
         ge, gb_ = emb_group._c_group(), bias_group._c_group()
         if ge is not None and gb_ is not None:  # both lookups -> loss -> both updates as ONE library call
             emb_group.consolidate()
             return k.sharded_glove_step(ge, gb_, plan.c_struct(k), target, B, mode, lr, 1e-7)
     if plan.index is not None and getattr(k, "GRADS_AT_IDS", None) is not None and _is_f32(emb_group) and \
             _is_f32(bias_group):
-        rows = emb_group.lookup_bucketed(plan)      # [2B (or the distinct rows), D] in exchange order
-        brow = bias_group.lookup_bucketed(plan)     # [.., 1]
+        erow, brow = rows if rows is not None else (None, None)
+        rows = erow if erow is not None else emb_group.lookup_bucketed(plan)   # [2B (or the distinct rows), D], exchange order
+        brow = brow if brow is not None else bias_group.lookup_bucketed(plan)  # [.., 1]
         loss, grad_rows, grad_bias = k.glove_fwd_bwd(rows, brow, plan.index.reshape(2, B), target, mode,
                                                      grads_at_ids=not plan.unique)
         emb_group.apply_sparse_adagrad(plan, grad_rows, lr, bucketed=not plan.unique)
         bias_group.apply_sparse_adagrad(plan, grad_bias.reshape(-1, 1), lr, bucketed=not plan.unique)
         return loss
-    rows = emb_group.lookup(plan)           # [2B, D]: E[t1] ; E[t2]
-    brow = bias_group.lookup(plan)          # [2B, 1]
+    erow, brow = rows if rows is not None else (None, None)
+    rows = emb_group.lookup(plan, back=erow)    # [2B, D]: E[t1] ; E[t2]
+    brow = bias_group.lookup(plan, back=brow)   # [2B, 1]
     local_inputs = torch.arange(2 * B, dtype=torch.int32, device=rows.device).reshape(2, B)
     loss, grad_rows, grad_bias = k.glove_fwd_bwd(rows, brow, local_inputs, target, mode)
     emb_group.apply_sparse_adagrad(plan, grad_rows, lr)
@@ -707,7 +890,7 @@ def sharded_glove_step(emb_group, bias_group, inputs, target, mode, lr, plan=Non
 
 
 def sharded_train_steps(workload, groups, batches, *, regularization=0.0, global_batch_size=None, scale=1.0, lr=0.05,
-                        mode=None, plan_group=None):
+                        mode=None, plan_group=None, overlap=None):
     """The loop helper of the row-sharded API (what train_steps / train_epoch are to the single-GPU steps): every batch of
     `batches` stepped in order, the routing plans of `plan_group` coming batches made together -- one bucket / unique
     launch set, ONE counts all-to-all, ONE copy to pinned memory and ONE host wait per group, the group's ids exchanges
@@ -719,7 +902,14 @@ def sharded_train_steps(workload, groups, batches, *, regularization=0.0, global
     batches of (scene_ids, pos_ids, neg_ids);  "glove": groups = (emb_group, bias_group), batches of (inputs [2, B],
     target [B]) and `mode` = the loss mode.  Returns the list of per-step loss tensors (this rank's share: all-reduce for
     the global loss).  The reference's loops being sharded: pinterest/train_shop_the_look.py:190-221,
-    wikipedia/train_cooccurence.py:103-112."""
+    wikipedia/train_cooccurence.py:103-112.
+
+    overlap (ESR_SHARDED_OVERLAP=1): batch k + 1's gather + rows exchange is issued on a side stream and a
+    second communicator BEFORE batch k's loss kernel, so it runs under that kernel, the gradient exchange and the update.
+    Rows that batch k's update writes reach it too early; they are known from the ids alone (begin_stale_sets: the
+    intersection of two owner-side lists, made with the plans a group ahead), and after the update they are served again
+    in a second, small exchange (patch_rows) -- results equal the sequential loop's bit for bit.  Each step is then
+    lookup-patch, loss kernel, esr_sharded_update on the main stream + the next esr_sharded_lookup beside them."""
     from .train_state import quiet_gc
     if workload not in ("inbatch", "triplet", "glove"):
         raise ValueError("workload must be 'inbatch', 'triplet' or 'glove', got %r" % (workload,))
@@ -735,23 +925,110 @@ def sharded_train_steps(workload, groups, batches, *, regularization=0.0, global
             return (g0, g0.virtual_id_segments([b[0], b[1]], [0, 1]))
         return (g0, g0.virtual_id_segments([b[0], b[1], b[2]], [0, 1, 1]))
 
-    def step(b, plan):
+    def step(b, plan, rows=None):
         if workload == "glove":
-            return sharded_glove_step(g0, groups[1], b[0], b[1], mode, lr, plan=plan)
+            return sharded_glove_step(g0, groups[1], b[0], b[1], mode, lr, plan=plan, rows=rows)
         gbs = global_batch_size if global_batch_size is not None else float(g0.world * b[0].numel())
+        rows = rows[0] if rows is not None else None
         if workload == "inbatch":
-            return sharded_inbatch_step(g0, b[0], b[1], regularization, gbs, scale, lr, plan=plan)
-        return sharded_triplet_step(g0, b[0], b[1], b[2], regularization, gbs, lr, plan=plan)
+            return sharded_inbatch_step(g0, b[0], b[1], regularization, gbs, scale, lr, plan=plan, rows=rows)
+        return sharded_triplet_step(g0, b[0], b[1], b[2], regularization, gbs, lr, plan=plan, rows=rows)
 
     losses = []
     if not batches:
         return losses
+    if overlap is None:
+        overlap = os.environ.get("ESR_SHARDED_OVERLAP", "0") == "1"
     with quiet_gc():  # a full cyclic collection inside the loop is a 40 ms hole in the launch stream
         if g0.world1_direct:  # a world of one rank takes the single-GPU steps: nothing is routed
             for b in batches:
                 losses.append(step(b, None))
             return losses
         spans = [(a, min(a + plan_group, len(batches))) for a in range(0, len(batches), plan_group)]
+        if overlap:
+            looked = tuple(groups[:2]) if workload == "glove" else (g0,)
+            dev = g0.tables[0].local.device
+            main = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+            side = _side_stream(dev) if main is not None else None
+
+            def early(plan):
+                """The next batch's lookups behind everything the main stream holds NOW (the previous update included):
+                buffers from the main stream's pool, work on the side stream and lane 1."""
+                bufs = [g.lookup_buffers(plan) for g in looked]
+                if side is None:
+                    return [g.lookup_bucketed(plan, lane=1, buffers=b) for g, b in zip(looked, bufs)], bufs, None
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    backs = [g.lookup_bucketed(plan, lane=1, buffers=b) for g, b in zip(looked, bufs)]
+                    done = torch.cuda.Event()
+                    done.record(side)
+                return backs, bufs, done
+
+            # one library call per step (esr_sharded_*_step_overlapped: patch, next lookup on the side stream, loss kernel,
+            # update) where there is a one-call step at all; else the same sequence op by op from here
+            k = g0.k
+            c_groups = None
+            if workload != "inbatch" and side is not None and hasattr(k, "step_overlap_struct") and \
+                    all(_is_f32(g) for g in looked) and os.environ.get("ESR_SHARDED_OVERLAP_CALLS", "one") == "one":
+                c_groups = [g._c_group() for g in looked]
+                x2 = g0.exchange(1) if g0.world > 1 else None
+                if any(c is None for c in c_groups) or (g0.world > 1 and (x2 is None or not getattr(x2, "comm", None))):
+                    c_groups = None
+                comm2 = x2.comm if c_groups is not None and x2 is not None else None
+
+            def fused_step(b, plan, nxt, prev):
+                """prev / returns: (backs, serveds, ready) of the lookup made ahead for this / the next batch."""
+                nb = [g.lookup_buffers(nxt) for g in looked] if nxt is not None else []
+                ov = k.step_overlap_struct([x for x in prev[0]] if prev else None, prev[2] if prev else None,
+                                           plan.stale.c_parts(k) if prev else None,
+                                           nxt.c_struct(k) if nxt is not None else None, [x[0] for x in nb],
+                                           [x[1] for x in nb], comm2, side)
+                if prev:
+                    prev[2] = None  # (consumed -- or released -- by the call)
+                if workload == "glove":
+                    loss = k.sharded_glove_step(c_groups[0], c_groups[1], plan.c_struct(k), b[1], b[0].shape[1], mode, lr,
+                                                1e-7, overlap=ov)
+                else:
+                    gbs = global_batch_size if global_batch_size is not None else float(g0.world * b[0].numel())
+                    loss = k.sharded_triplet_step(c_groups[0], plan.c_struct(k), b[0].numel(), regularization, gbs, lr,
+                                                  1e-7, b[0].device, overlap=ov)
+                return loss, ([x[0] for x in nb], [x[1] for x in nb], ov.next_ready) if nxt is not None else None
+
+            plans = {0: begin_plans([lookup(batches[i]) for i in range(*spans[0])]).finish()}
+            stale = {0: begin_stale_sets(plans[0], None)}
+            pend = {1: begin_plans([lookup(batches[i]) for i in range(*spans[1])])} if len(spans) > 1 else {}
+            ahead = None
+            try:
+                for gi, (a, e) in enumerate(spans):
+                    if gi + 1 < len(spans):  # the next group: its plans finished and its stale sets begun a group ahead
+                        plans[gi + 1] = pend.pop(gi + 1).finish()
+                        stale[gi + 1] = begin_stale_sets(plans[gi + 1], plans[gi][-1])
+                        if gi + 2 < len(spans):
+                            pend[gi + 2] = begin_plans([lookup(batches[i]) for i in range(*spans[gi + 2])])
+                    stale.pop(gi).finish()
+                    cur = plans.pop(gi)
+                    for i in range(a, e):
+                        plan = cur[i - a]
+                        nxt = cur[i - a + 1] if i + 1 < e else (plans[gi + 1][0] if gi + 1 < len(spans) else None)
+                        if c_groups is not None:
+                            for g in looked:
+                                g.consolidate()
+                            loss, ahead = fused_step(batches[i], plan, nxt, list(ahead) if ahead else None)
+                            losses.append(loss)
+                            continue
+                        if ahead is None:
+                            rows = [g.lookup_bucketed(plan) for g in looked]
+                        else:
+                            backs, _, done = ahead  # (the exchange buffers stay referenced until the main stream has waited)
+                            if done is not None:
+                                main.wait_event(done)
+                            rows = [g.patch_rows(plan, b) for g, b in zip(looked, backs)]
+                        ahead = early(nxt) if nxt is not None else None
+                        losses.append(step(batches[i], plan, rows=rows))
+            finally:
+                if c_groups is not None and ahead and ahead[2]:
+                    k.overlap_release(ahead[2])
+            return losses
         pend = begin_plans([lookup(batches[i]) for i in range(*spans[0])])
         for gi, (a, e) in enumerate(spans):
             plans = pend.finish()  # ids exchanges + owner-side sorts of the whole group, ahead of its steps
@@ -759,6 +1036,17 @@ def sharded_train_steps(workload, groups, batches, *, regularization=0.0, global
             for i in range(a, e):
                 losses.append(step(batches[i], plans[i - a]))
     return losses
+
+
+_side_streams = {}
+
+
+def _side_stream(dev):
+    """One side stream per device for the overlapped lookups (creating a stream per call costs a driver round trip)."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=dev)
+    return _side_streams[key]
 
 
 class _Collectives:

@@ -657,6 +657,46 @@ int esr_sharded_glove_step(const esr_shard_group_t* emb, const esr_shard_group_t
                            const float* target, int64_t B, int mode, float lr, float eps, float* loss, void* workspace,
                            size_t workspace_bytes, esr_stream_t stream);
 
+/* ---- the same steps with the NEXT batch's lookup overlapped (build-defined) ---------------------------------
+ * A training loop knows its coming batches (the plans are made a group ahead), so batch k + 1's gather + rows exchange
+ * need not wait for batch k: call k issues them on `side` with the second communicator `comm2` right after batch k's own
+ * rows are in place -- they run under batch k's loss kernel, gradient exchange and update -- and call k + 1 receives the
+ * buffers as `back`.  Rows that batch k's update writes were fetched too early; which ones is a function of the ids alone
+ * (owner side: the rows of batch k + 1's asked list that are in batch k's; esrecsys_amd/sharded.py begin_stale_sets),
+ * and call k + 1 serves exactly those again on the main stream before its loss kernel: gather stale_rows -> rows
+ * exchange (first communicator; counts stale_asked / stale_ask) -> scatter to rows stale_pos of `back`.  The results
+ * equal the plain steps' bit for bit (tests/test_gpu_sharded.py, tests/test_sharded_gloo.py).
+ * One struct per call; `ready` / `next_ready` hand the side stream's completion event from call to call (the consumer
+ * releases it; esr_sharded_overlap_release for one that is never consumed).  Buffers in next_back / next_served belong to
+ * the caller and must stay untouched until the call that takes them as `back` has been issued. */
+typedef struct {
+  void* back[2];                /* in: THIS batch's rows per group (GloVe: embedding, bias) = the previous call's next_back;
+                                   NULL: look them up in line (first step of a loop) */
+  void* ready;                  /* in: the previous call's next_ready (waited for on `stream`, then released), or NULL */
+  const int32_t* stale_rows;    /* device [sum stale_asked]: virtual local rows this rank serves again, asker by asker */
+  const int64_t* stale_asked;   /* host [world] */
+  const int32_t* stale_pos;     /* device [sum stale_ask]: the rows of `back` that come again, owner by owner */
+  const int64_t* stale_ask;     /* host [world] */
+  const esr_routing_plan_t* next_plan; /* the NEXT batch's plan, or NULL (last step) */
+  void* next_back[2];           /* per group: [sum next ask_counts, D], filled on `side` */
+  void* next_served[2];         /* per group: scratch [sum next asked_counts, D] (world > 1) */
+  esr_comm_t comm2;             /* a second esr_comm_init communicator over the same ranks (may be NULL at world 1) */
+  esr_stream_t side;            /* the stream the next lookup runs on */
+  void* next_ready;             /* out: recorded on `side` behind the next lookup (NULL when next_plan is NULL) */
+} esr_step_overlap_t;
+/* extra workspace of ONE group for its stale rows (add it to the step's *_workspace_bytes for every group of the step) */
+size_t esr_sharded_step_overlap_workspace_bytes(const esr_shard_group_t* group, const esr_step_overlap_t* overlap);
+void esr_sharded_overlap_release(void* ready);
+/* overlap == NULL: exactly esr_sharded_triplet_step / esr_sharded_glove_step */
+int esr_sharded_triplet_step_overlapped(const esr_shard_group_t* towers, const esr_routing_plan_t* plan,
+                                        esr_step_overlap_t* overlap, int64_t B, float regularization, float batch_size,
+                                        float lr, float eps, float* loss, void* workspace, size_t workspace_bytes,
+                                        esr_stream_t stream);
+int esr_sharded_glove_step_overlapped(const esr_shard_group_t* emb, const esr_shard_group_t* bias,
+                                      const esr_routing_plan_t* plan, esr_step_overlap_t* overlap, const float* target,
+                                      int64_t B, int mode, float lr, float eps, float* loss, void* workspace,
+                                      size_t workspace_bytes, esr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,6 +1,7 @@
 """CPU, gloo: randomised check of the row-sharded steps at world sizes 2..4 (kernels replaced by the NumPy doubles of
 tests/_cpu_kernels.py) against the single-device oracle: random table sizes (uneven shards), widths, batch sizes, Zipf
-ids, per-occurrence and per-distinct-row exchange, routing plans made per step or for all steps together.  SEED, CASES."""
+ids, per-occurrence and per-distinct-row exchange, routing plans made per step or for all steps together, the loop helper
+with overlapped lookups (next batch's rows fetched before the current update, stale rows re-served).  SEED, CASES."""
 import os, sys, socket, tempfile
 import numpy as np, torch
 import torch.distributed as dist
@@ -48,7 +49,18 @@ def worker(rank, port, outdir, cfg):
             lookups.append((towers, towers.virtual_id_segments(*segs)))
         plans = sharded.begin_plans(lookups).finish()
     losses = []
-    for step in range(cfg["steps"]):
+    if cfg.get("overlap"):  # the loop helper with the next lookup issued before the current update (+ stale-row patch)
+        bs = [tuple(torch.from_numpy(x) for x in batch(cfg, step, rank)) for step in range(cfg["steps"])]
+        kw = dict(regularization=LAM, global_batch_size=float(W * cfg["B"]), lr=LR, plan_group=cfg["plan_group"], overlap=True)
+        if cfg["workload"] == "triplet":
+            ls = sharded.sharded_train_steps("triplet", (towers,), bs, **kw)
+        else:
+            ls = sharded.sharded_train_steps("inbatch", (towers,), [b[:2] for b in bs], scale=2.0, **kw)
+        for loss in ls:
+            total = loss.clone()
+            dist.all_reduce(total)
+            losses.append(float(total))
+    for step in range(0 if cfg.get("overlap") else cfg["steps"]):
         sid, pid, nid = (torch.from_numpy(x) for x in batch(cfg, step, rank))
         plan = plans[step] if plans is not None else None
         if cfg["workload"] == "triplet":
@@ -77,7 +89,11 @@ def glove_worker(rank, port, outdir, cfg):
     emb = sharded.ShardedTableGroup([emb_t], kernels=K)
     bias = sharded.ShardedTableGroup([bias_t], kernels=K)
     batches = glove_batches(cfg, rank)
-    cur = sharded.begin_plan_glove(emb, torch.from_numpy(batches[0][0])).finish()
+    if cfg.get("overlap"):
+        sharded.sharded_train_steps("glove", (emb, bias), [(torch.from_numpy(a), torch.from_numpy(b)) for a, b in batches],
+                                    mode=K.GLOVE_DIAGONAL, lr=LR, plan_group=cfg["plan_group"], overlap=True)
+        batches = []
+    cur = sharded.begin_plan_glove(emb, torch.from_numpy(batches[0][0])).finish() if batches else None
     pend = sharded.begin_plan_glove(emb, torch.from_numpy(batches[1][0])) if len(batches) > 1 else None
     for i, (inp, tgt) in enumerate(batches):
         sharded.sharded_glove_step(emb, bias, torch.from_numpy(inp), torch.from_numpy(tgt), K.GLOVE_DIAGONAL, LR,
@@ -178,7 +194,8 @@ if __name__ == "__main__":
     bad = 0
     for case in range(N):
         cfg = dict(world=int(rng.integers(2, 5)), Vs=int(rng.choice([5, 37, 101, 1000])), Vp=int(rng.choice([9, 64, 203, 3001])),
-                   D=int(rng.choice([4, 8, 16])), B=int(rng.choice([1, 7, 24, 130])), steps=int(rng.integers(1, 4)),
+                   D=int(rng.choice([4, 8, 16])), B=int(rng.choice([1, 7, 24, 130])), steps=int(rng.integers(1, 6)),
+                   overlap=bool(rng.random() < 0.5), plan_group=int(rng.integers(1, 4)),
                    zipf=bool(rng.random() < 0.5), unique=bool(rng.random() < 0.6), grouped=bool(rng.random() < 0.5),
                    workload=str(rng.choice(["triplet", "inbatch", "glove"])), seed=int(rng.integers(1, 10000)))
         ok = run_case(cfg)

@@ -48,8 +48,12 @@ def inbatch_towers_fwd_bwd(query_table, cand_table, query_ids, cand_ids, scale, 
     return _t(np.array([loss])), _t(lse), _t(buf), None
 
 
-def gather_rows(table, ids):
-    return table[ids.long()].contiguous()
+def gather_rows(table, ids, out=None):
+    rows = table[ids.long()].contiguous()
+    if out is None:
+        return rows
+    out.copy_(rows)
+    return out
 
 
 def concat_offset_ids(id_tensors, offsets):
@@ -63,9 +67,10 @@ def _locate(row_offsets, vids):
     return t, v - np.asarray(row_offsets, np.int64)[t]
 
 
-def gather_rows_multi(tables, row_offsets, vids):
+def gather_rows_multi(tables, row_offsets, vids, out=None):
     t, r = _locate(row_offsets, vids)
-    out = torch.empty((len(t), tables[0].shape[1]), dtype=tables[0].dtype)
+    if out is None:
+        out = torch.empty((len(t), tables[0].shape[1]), dtype=tables[0].dtype)
     for k, tab in enumerate(tables):
         m = torch.from_numpy(t == k)
         out[m] = tab[torch.from_numpy(r[t == k])]
@@ -84,10 +89,11 @@ def sparse_adagrad_multi(tables, accums, row_offsets, sorted_vids, perm, grad_ro
         acc.copy_(_t(a))
 
 
-def unpermute_rows(rows, perm):
+def unpermute_rows(rows, perm, out=None):
     if perm is None:
         return rows
-    out = torch.empty_like(rows)
+    if out is None:
+        out = torch.empty_like(rows)
     out[perm.long()] = rows
     return out
 

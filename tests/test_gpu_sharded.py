@@ -282,3 +282,84 @@ def test_sharded_train_steps_equals_per_step_calls_on_the_gpu(dev, pg, workload)
     for ga, gb in zip(a, b):
         for ta, tb in zip(ga.tables, gb.tables):
             assert torch.equal(ta.local, tb.local) and torch.equal(ta.accum, tb.accum)
+
+
+@pytest.mark.parametrize("calls", ["one", "ops"])
+@pytest.mark.parametrize("unique", [False, True])
+@pytest.mark.parametrize("workload", ["triplet", "glove", "inbatch"])
+def test_overlapped_lookups_equal_the_sequential_loop_on_the_gpu(dev, pg, workload, unique, calls, monkeypatch):
+    """sharded_train_steps(overlap=True) -- the next batch's gather + rows exchange on a side stream, issued before the
+    current batch's loss kernel, its stale rows served again after the update -- against the same steps with
+    every lookup made in line: the same tables and losses, bit for bit.  World-1 machinery: the side stream, the event
+    hand-overs, the membership search of begin_stale_sets and the patch scatter are all the real ones.  Zipf-like ids: a
+    third of every lookup names rows the step before it writes; the control (no patch) must differ.
+    calls "one": every step ONE library call (esr_sharded_*_step_overlapped) against the one-call steps without overlap;
+    "ops": lookup / patch / loss kernel / update issued from Python (the in-batch head's only form)."""
+    from esrecsys_amd import ops, sharded
+    if calls == "one" and workload == "inbatch":
+        pytest.skip("the in-batch step has no one-call form")
+    monkeypatch.setenv("ESR_SHARDED_OVERLAP_CALLS", calls)
+    V, D, B, K = 5000, 128, 1024, 11
+    g = torch.Generator(device=dev).manual_seed(19)
+
+    def ids(*shape):  # (a few hot rows + a uniform tail)
+        u = torch.rand(shape, generator=g, device=dev)
+        return (u * u * u * V).to(torch.int32).clamp_(max=V - 1)
+
+    def groups():
+        gg = torch.Generator(device=dev).manual_seed(1)
+        def tab(d):
+            t = torch.randn((V, d), generator=gg, device=dev) * d ** -0.5
+            return sharded.RowShardedTable(t, torch.full((V, d), 0.1, device=dev), V)
+        if workload == "glove":
+            return (sharded.ShardedTableGroup([tab(D)], kernels=ops, unique=unique),
+                    sharded.ShardedTableGroup([tab(1)], kernels=ops, unique=unique))
+        return (sharded.ShardedTableGroup([tab(D), tab(D)], kernels=ops, unique=unique),)
+    if workload == "glove":
+        batches = [(ids(2, B), torch.exp(torch.rand(B, generator=g, device=dev) * 6 - 2)) for _ in range(K)]
+    else:
+        batches = [tuple(ids(B) for _ in range(3)) for _ in range(K)]
+    kw = dict(regularization=0.1, global_batch_size=float(B), scale=4.0, lr=0.05, mode=ops.GLOVE_REFERENCE)
+    stack = lambda ls: torch.stack([x.reshape(()) for x in ls])  # noqa: E731
+
+    a = groups()
+    la = sharded.sharded_train_steps(workload, a, batches, plan_group=4, overlap=True, **kw)
+    b = groups()
+    if calls == "one":  # the one-call steps, every lookup in line
+        lb = sharded.sharded_train_steps(workload, b, batches, plan_group=4, overlap=False, **kw)
+    else:  # the sequential loop through the same kernels: plan, lookup, step on the looked-up rows
+        lb = []
+        for bt in batches:
+            if workload == "glove":
+                plan = sharded.plan_glove(b[0], bt[0])
+                rows = (b[0].lookup_bucketed(plan), b[1].lookup_bucketed(plan))
+                lb.append(sharded.sharded_glove_step(b[0], b[1], bt[0], bt[1], ops.GLOVE_REFERENCE, 0.05, plan=plan, rows=rows))
+            elif workload == "inbatch":
+                plan = sharded.plan_inbatch(b[0], bt[0], bt[1])
+                lb.append(sharded.sharded_inbatch_step(b[0], bt[0], bt[1], 0.1, float(B), 4.0, 0.05, plan=plan,
+                                                       rows=b[0].lookup_bucketed(plan)))
+            else:
+                plan = sharded.plan_triplet(b[0], *bt)
+                lb.append(sharded.sharded_triplet_step(b[0], *bt, 0.1, float(B), 0.05, plan=plan,
+                                                       rows=b[0].lookup_bucketed(plan)))
+    torch.cuda.synchronize()
+    assert len(la) == K and torch.equal(stack(la), stack(lb))
+    for ga, gb in zip(a, b):
+        for ta, tb in zip(ga.tables, gb.tables):
+            assert torch.equal(ta.local, tb.local) and torch.equal(ta.accum, tb.accum)
+    # control: without the stale rows served again, the early lookups change the result
+    real = sharded.ShardedTableGroup.patch_rows
+    real_struct = ops.step_overlap_struct
+
+    def no_stale(backs, ready, stale, *rest):
+        if stale is not None:
+            zero = ops.i64_array([0])
+            stale = (stale[0], zero, stale[2], zero)
+        return real_struct(backs, ready, stale, *rest)
+    monkeypatch.setattr(sharded.ShardedTableGroup, "patch_rows", lambda self, plan, back: back)
+    monkeypatch.setattr(ops, "step_overlap_struct", no_stale)
+    d = groups()
+    sharded.sharded_train_steps(workload, d, batches, plan_group=4, overlap=True, **kw)
+    monkeypatch.setattr(sharded.ShardedTableGroup, "patch_rows", real)
+    monkeypatch.setattr(ops, "step_overlap_struct", real_struct)
+    assert not all(torch.equal(ta.local, td.local) for ga, gd in zip(a, d) for ta, td in zip(ga.tables, gd.tables))

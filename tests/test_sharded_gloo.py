@@ -352,3 +352,91 @@ def test_loop_helper_equals_per_step_calls_and_bf16_gradient_exchange_error():
             moved = np.abs(exact - start).max()
             err = np.abs(half - exact).max()
             assert 0.0 < err <= 2.0 ** -7 * moved, (key, err, moved)
+
+
+def _overlap_worker(rank, port, outdir):
+    """sharded_train_steps with the next batch's lookup issued BEFORE the current batch's update against the
+    sequential loop: all three workloads, Zipf ids (most lookups name rows the step before them writes), distinct-row
+    and per-occurrence plans, groups of 3 + 3 + 1 plans.  Under gloo there is no side stream -- the early lookup simply
+    executes first, so every stale row really is read too early and only the patch makes the results equal."""
+    global ZIPF
+    ZIPF = True
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    import _cpu_kernels as K
+    from esrecsys_amd import sharded
+    st, pt = _full_tables()
+    mk = lambda full: torch.from_numpy(np.ascontiguousarray(full[rank::WORLD]))  # noqa: E731
+    n_steps = 7
+    trip = [tuple(torch.from_numpy(x) for x in _batch(step, rank)) for step in range(n_steps)]
+    grng = np.random.default_rng(300 + rank)
+    Vg, Bg = 97, 20
+    glove = [(torch.from_numpy(np.stack([_draw(grng, Vg, Bg), _draw(grng, Vg, Bg)])),
+              torch.from_numpy(grng.uniform(0.1, 300, Bg))) for _ in range(n_steps)]
+    erng = np.random.default_rng(11)
+    emb0, bias0 = erng.standard_normal((Vg, 8)) * 0.3, erng.standard_normal((Vg, 1)) * 0.05
+
+    def groups(workload, unique):
+        if workload == "glove":
+            e = sharded.RowShardedTable(mk(emb0), torch.full_like(mk(emb0), 0.1), Vg)
+            b = sharded.RowShardedTable(mk(bias0), torch.full_like(mk(bias0), 0.1), Vg)
+            return (sharded.ShardedTableGroup([e], kernels=K, unique=unique),
+                    sharded.ShardedTableGroup([b], kernels=K, unique=unique))
+        scene = sharded.RowShardedTable(mk(st), torch.full_like(mk(st), 0.1), V_S)
+        prod = sharded.RowShardedTable(mk(pt), torch.full_like(mk(pt), 0.1), V_P)
+        return (sharded.ShardedTableGroup([scene, prod], kernels=K, unique=unique),)
+
+    def run(workload, unique, overlap):
+        gs = groups(workload, unique)
+        kw = dict(mode=K.GLOVE_DIAGONAL) if workload == "glove" else dict(regularization=LAM, global_batch_size=float(WORLD * B))
+        batches = glove if workload == "glove" else ([b[:2] for b in trip] if workload == "inbatch" else trip)
+        losses = sharded.sharded_train_steps(workload, gs, batches, lr=LR, plan_group=3, overlap=overlap, **kw)
+        tabs = [t.local.numpy().copy() for g in gs for t in g.tables] + [t.accum.numpy().copy() for g in gs for t in g.tables]
+        return tabs, np.array([float(l) for l in losses])
+
+    out = {}
+    patched = [0, 0]
+    real_patch = sharded.ShardedTableGroup.patch_rows
+
+    def counting_patch(self, plan, back):
+        patched[0] += int(plan.stale.ids.numel())
+        patched[1] += int(plan.stale.pos.numel())
+        return real_patch(self, plan, back)
+
+    for workload in ("triplet", "inbatch", "glove"):
+        for unique in (True, False):
+            key = "%s_%d" % (workload, unique)
+            want_t, want_l = run(workload, unique, False)
+            sharded.ShardedTableGroup.patch_rows = counting_patch
+            patched[:] = [0, 0]
+            got_t, got_l = run(workload, unique, True)
+            out[key + "_equal"] = np.array(all(np.array_equal(a, b) for a, b in zip(want_t, got_t)) and
+                                           np.array_equal(want_l, got_l))
+            out[key + "_patched"] = np.array(patched)
+            # the control: the same loop WITHOUT the patch must differ (the early lookups do read rows too early)
+            sharded.ShardedTableGroup.patch_rows = lambda self, plan, back: back
+            bad_t, _ = run(workload, unique, True)
+            out[key + "_control_differs"] = np.array(not all(np.array_equal(a, b) for a, b in zip(want_t, bad_t)))
+            sharded.ShardedTableGroup.patch_rows = real_patch
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_overlapped_lookups_equal_the_sequential_loop_bit_for_bit():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_overlap_worker, args=(port, d), nprocs=WORLD, join=True)
+        outs = [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(WORLD)]
+    for workload in ("triplet", "inbatch", "glove"):
+        for unique in (1, 0):
+            key = "%s_%d" % (workload, unique)
+            assert all(bool(o[key + "_equal"]) for o in outs), key
+            # rows were re-served (sent == received over the ranks) and leaving them out changes the tables
+            sent = sum(int(o[key + "_patched"][0]) for o in outs)
+            assert sent > 0 and sent == sum(int(o[key + "_patched"][1]) for o in outs), key
+            assert any(bool(o[key + "_control_differs"]) for o in outs), key
