@@ -750,8 +750,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #else
 // streaming (non-temporal) stores: the B x B probabilities are written once and read once, and at 268 MB (B = 8192) do
 // not fit the 256 MB Infinity Cache anyway
+#if defined(H_PROBE_P34)  /* timing probe only: three quarters of the P traffic (what a 3-byte P would move) */
+#define H_P_ST4(M, V0, V1, V2, V3) \
+  if ((M) != 3) __builtin_nontemporal_store(f32x4{(V0), (V1), (V2), (V3)}, reinterpret_cast<f32x4*>(pst_u + (M) * 1024 + pst_v))
+#else
 #define H_P_ST4(M, V0, V1, V2, V3) \
   __builtin_nontemporal_store(f32x4{(V0), (V1), (V2), (V3)}, reinterpret_cast<f32x4*>(pst_u + (M) * 1024 + pst_v))
+#endif
 #endif
 
   f32x16 acc[4];
@@ -1302,6 +1307,12 @@ __global__ __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __re
   }
   typedef float pf4 __attribute__((ext_vector_type(4)));
   pf4 stg0[4], stg1[4];  // STAGE: the P' tiles of two coming chunks, as loaded (lane-linear 16-byte pieces)
+#if defined(H_PROBE_P34)
+  constexpr int kStgLoads = 3;
+  stg0[3] = stg1[3] = pf4{0.f, 0.f, 0.f, 0.f};
+#else
+  constexpr int kStgLoads = 4;
+#endif
 // chunk CH of this wave's tile column (clamped: past the end the last tile is loaded again and never used)
 // (inline assembly: as compiler-visible loads hipcc waited vmcnt(0) in front of the LDS write that consumes them -- it
 // does not order plain loads against the LDS-DMAs in flight -- which drained the loads issued a moment earlier; the
@@ -1309,11 +1320,15 @@ __global__ __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __re
 #define H8S_LOAD(STG, CH)                                                                                 \
   {                                                                                                       \
     const char* src_ = pw_base + (int64_t)min((int)(CH), nc - 1) * 4096;                                  \
-    _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_)                                                      \
+    _Pragma("unroll") for (int g_ = 0; g_ < kStgLoads; ++g_)                                              \
       asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(STG[g_]) : "v"(p_off[g_]), "s"(src_));      \
   }
 // the set loaded ONE iteration ago has landed: behind it are only this iteration's 3 DMAs and 4 staged loads
+#if defined(H_PROBE_P34)
+#define H8S_WAIT_WR() { H_SB(); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); H_SB(); }
+#else
 #define H8S_WAIT_WR() { H_SB(); asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); H_SB(); }
+#endif
 #define H8S_WRITE(STG)                                                                                    \
   _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_)                                                        \
     *reinterpret_cast<pf4*>(lds + kPArea + w * 4096 + g_ * 1024 + lane * 16) = STG[g_];
@@ -1406,7 +1421,11 @@ __global__ __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __re
 // landed.  With STAGE the chunk read next was fetched two iterations ago, in front of the staged loads that
 // H8S_WAIT_WR has just waited for: everything the previous iteration issued (3 DMAs + 4 loads) stays in flight
 #ifndef H8_BAR_VM
+#if defined(H_PROBE_P34)
+#define H8_BAR_VM 6
+#else
 #define H8_BAR_VM 7
+#endif
 #endif
 // (STAGE: the barrier instruction itself -- __syncthreads() carries a fence for which hipcc waits vmcnt(0))
 #define H8_BARRIER()                                                                        \
