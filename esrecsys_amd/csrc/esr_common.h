@@ -153,6 +153,37 @@ __device__ __forceinline__ double block_sum_d(double v, double* smem) {
   return t;
 }
 
+// Lazy momentum (esr_optim.hip momentum_catchup_kernel / momentum_flush_kernel, esr_spotify.hip's fused step): n missed
+// steps of  trace *= m ; p -= lr * trace.  n <= kLazyExact: one by one, the dense pass's own operations (bit-identical to
+// it); longer gaps: the closed form (one rounding instead of n).
+constexpr int kLazyExact = 64;
+struct DecayCoef {  // of a gap of n steps: a function of n and m alone -- formed ONCE per row (powf), applied per element
+  int n;
+  float mn, geo;
+};
+__device__ __forceinline__ DecayCoef decay_coef(int n, float m) {
+  DecayCoef k{n, 0.f, 0.f};
+  if (n > kLazyExact) {
+    k.mn = powf(m, (float)n);
+    k.geo = m * (1.0f - k.mn) / (1.0f - m);
+  }
+  return k;
+}
+__device__ __forceinline__ void decay_apply(float& p, float& t, const DecayCoef& k, float lr, float m) {
+  if (k.n <= kLazyExact) {
+    for (int i = 0; i < k.n; ++i) {
+      t = __fmul_rn(t, m);
+      p = __fsub_rn(p, __fmul_rn(lr, t));
+    }
+  } else {
+    p = __fsub_rn(p, __fmul_rn(__fmul_rn(lr, t), k.geo));
+    t = __fmul_rn(t, k.mn);
+  }
+}
+__device__ __forceinline__ void decay_steps(float& p, float& t, int n, float lr, float m) {
+  decay_apply(p, t, decay_coef(n, m), lr, m);
+}
+
 // A row held in registers by its G-lane group: chunk k of this lane is row chunk lig + k*G.
 // All indices are compile-time so the arrays stay in VGPRs (no scratch).
 template <int VEC, int NCH>

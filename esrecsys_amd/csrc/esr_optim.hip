@@ -20,7 +20,7 @@
 
 namespace esr {
 
-enum SegOp { kAdagrad = 0, kSgd = 1, kToDense = 2, kMomentum = 3, kMomentumStep = 4 };
+enum SegOp { kAdagrad = 0, kSgd = 1, kToDense = 2, kMomentum = 3, kMomentumStep = 4, kMomentumStepLazy = 5 };
 
 template <int VEC, int NCH>
 __device__ __forceinline__ void param_load(RowRegs<VEC, NCH>& r, const void* table, int dtype, int64_t row, int D,
@@ -134,6 +134,31 @@ __device__ __forceinline__ void seg_apply(const FusedTables& ft, int dtype, int3
       }
     row_store(a, accum + id * D, lig, G, nvec);
     param_store(w, table, dtype, id, D, lig, G, nvec);
+  } else if (OP == kMomentumStepLazy) {
+    // kMomentumStep on a row that is still `now - 1 - last[row]` steps behind (lazy optax.sgd(lr, momentum), see decay_steps
+    // in esr_common.h): the catch-up first -- the very operations momentum_catchup_kernel applies -- then the step, and the
+    // row is marked current.  Saves the catch-up launch in front of the Spotify step (three dependent memory round trips: 12
+    // of its 60 us).  At most two tables; their `last` arrays ride in the unused table slots 2 and 3, `now` in the unused
+    // last row offset (sparse_momentum_step_lazy2 below).
+    int32_t* last = (int32_t*)ft.table[2];
+    if (1 < ft.n && (int64_t)vid >= ft.row_offset[1]) last = (int32_t*)ft.table[3];
+    const int now = (int)ft.row_offset[kMaxFusedTables];
+    const int steps = now - 1 - last[id];
+    RowRegs<VEC, NCH> w, a;
+    param_load(w, table, dtype, id, D, lig, G, nvec);
+    row_load(a, accum + id * D, lig, G, nvec);
+    const DecayCoef dk = decay_coef(steps, eps);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        if (steps > 0) decay_apply(w.v[k][e], a.v[k][e], dk, lr, eps);
+        a.v[k][e] = __fadd_rn(g.v[k][e], __fmul_rn(eps, a.v[k][e]));
+        w.v[k][e] = __fsub_rn(w.v[k][e], __fmul_rn(lr, a.v[k][e]));
+      }
+    row_store(a, accum + id * D, lig, G, nvec);
+    param_store(w, table, dtype, id, D, lig, G, nvec);
+    if (lig == 0) last[id] = now;
   } else if (OP == kSgd) {
     RowRegs<VEC, NCH> w;
     param_load(w, table, dtype, id, D, lig, G, nvec);
@@ -472,19 +497,7 @@ __global__ __launch_bounds__(kBlock) void momentum_decay_kernel(float* __restric
 // very operations of the dense pass: bit-identical to it -- rows that are read again soon, the hot part of a playlist
 // stream); longer gaps by the closed form  trace *= m^n ; p -= lr * trace0 * m (1 - m^n) / (1 - m)  (1e-7-close: one
 // rounding instead of n; a walk of thousands of dependent steps per element made the catch-up launch 10 us).
-constexpr int kLazyExact = 64;
-__device__ __forceinline__ void decay_steps(float& p, float& t, int n, float lr, float m) {
-  if (n <= kLazyExact) {
-    for (int i = 0; i < n; ++i) {
-      t = __fmul_rn(t, m);
-      p = __fsub_rn(p, __fmul_rn(lr, t));
-    }
-  } else {
-    const float mn = powf(m, (float)n);
-    p = p - lr * t * (m * (1.0f - mn) / (1.0f - m));
-    t = t * mn;
-  }
-}
+// (decay_coef / decay_apply / kLazyExact: esr_common.h -- esr_spotify.hip reads rows through the same catch-up)
 
 struct CatchupTables {  // up to two same-width tables caught up by one launch (blockIdx.y = the table)
   float* table[2];
@@ -518,10 +531,11 @@ __global__ __launch_bounds__(kBlock) void momentum_catchup_kernel(CatchupTables 
     RowRegs<VEC, NCH> w, a;
     row_load(w, table + (int64_t)row * D, lig, G, nvec);
     row_load(a, trace + (int64_t)row * D, lig, G, nvec);
+    const DecayCoef dk = decay_coef(steps, m);
 #pragma unroll
     for (int k = 0; k < NCH; ++k)
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) decay_steps(w.v[k][e], a.v[k][e], steps, lr, m);
+      for (int e = 0; e < VEC; ++e) decay_apply(w.v[k][e], a.v[k][e], dk, lr, m);
     row_store(w, table + (int64_t)row * D, lig, G, nvec);
     row_store(a, trace + (int64_t)row * D, lig, G, nvec);
   }
@@ -541,10 +555,11 @@ __global__ __launch_bounds__(kBlock) void momentum_flush_kernel(float* __restric
     RowRegs<VEC, NCH> w, a;
     row_load(w, table + row * D, lig, G, nvec);
     row_load(a, trace + row * D, lig, G, nvec);
+    const DecayCoef dk = decay_coef(steps, m);
 #pragma unroll
     for (int k = 0; k < NCH; ++k)
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) decay_steps(w.v[k][e], a.v[k][e], steps, lr, m);
+      for (int e = 0; e < VEC; ++e) decay_apply(w.v[k][e], a.v[k][e], dk, lr, m);
     row_store(w, table + row * D, lig, G, nvec);
     row_store(a, trace + row * D, lig, G, nvec);
     if (lig == 0) last[row] = now;
@@ -614,6 +629,36 @@ int esr_sparse_momentum_step_multi(float* const* tables, float* const* traces, c
   return launch_segment_tables<kMomentumStep>("esr_sparse_momentum_step_multi", ft, ESR_F32, D, sorted_vids, perm, n,
                                               grad_rows, lr, momentum, as_stream(stream));
 }
+
+}  // extern "C"
+
+namespace esr {
+// esr_sparse_momentum_step_multi for one or two tables whose rows may be behind (last[t][row] = the step the row is current
+// with): catch-up + step + mark, in the update kernel itself (kMomentumStepLazy).  Internal: esr_spotify_train_step.
+int sparse_momentum_step_lazy2(float* const* tables, float* const* traces, int32_t* const* lasts, const int64_t* row_offsets,
+                               int ntables, int D, const int32_t* sorted_vids, const int32_t* perm, int64_t n, float* grad_rows,
+                               float lr, float momentum, int now, hipStream_t st) {
+  if (!(ntables >= 1 && ntables <= 2 && D > 0 && n >= 0 && now >= 1)) {
+    set_error("sparse_momentum_step_lazy2: ntables=%d not in [1, 2] or bad sizes", ntables);
+    return ESR_EINVAL;
+  }
+  if (n == 0) return ESR_OK;
+  FusedTables ft;
+  ft.n = ntables;
+  for (int i = 0; i < kMaxFusedTables; ++i) {
+    ft.table[i] = i < ntables ? (void*)tables[i] : nullptr;
+    ft.accum[i] = i < ntables ? traces[i] : nullptr;
+    ft.row_offset[i] = i <= ntables ? row_offsets[i] : row_offsets[ntables];
+  }
+  ft.table[2] = lasts[0];
+  ft.table[3] = ntables > 1 ? lasts[1] : nullptr;
+  ft.row_offset[kMaxFusedTables] = now;
+  return launch_segment_tables<kMomentumStepLazy>("sparse_momentum_step_lazy2", ft, ESR_F32, D, sorted_vids, perm, n,
+                                                  grad_rows, lr, momentum, st);
+}
+}  // namespace esr
+
+extern "C" {
 
 int esr_momentum_flush(float* table, float* trace, int32_t* last, int64_t V, int D, int step, float lr, float momentum,
                        esr_stream_t stream) {

@@ -15,6 +15,8 @@
 #include "esr_common.h"
 
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 
 namespace esr {
 
@@ -26,11 +28,9 @@ struct SpShape {
   int n, m, o, F;  // R = n + m + o rows, D2 = 2F
 };
 
-__device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+// (DPP / ds_swizzle / v_permlane32_swap butterflies: as __shfl_xor steps -- ds_bpermute with a computed address each -- the
+// six steps per dot product were most of the row-gradient kernel once its rows came from LDS)
+__device__ __forceinline__ float wave_sum_f(float v) { return group_sum(v, 64); }
 
 // E[r][0:F] = album_table[album[r] mod A], E[r][F:2F] = artist_table[artist[r]]; l2[r]; hashed[r]
 __global__ __launch_bounds__(kBlock) void spotify_gather_kernel(const float* __restrict__ album_table, int64_t A,
@@ -47,6 +47,51 @@ __global__ __launch_bounds__(kBlock) void spotify_gather_kernel(const float* __r
   float ss = 0.f;
   for (int d = lane; d < D2; d += 64) {
     const float v = d < F ? album_table[ha * F + d] : artist_table[ar * F + (d - F)];
+    E[(int64_t)r * D2 + d] = v;
+    ss = fmaf(v, v, ss);
+  }
+  ss = wave_sum_f(ss);
+  if (lane == 0) {
+    l2[r] = sqrtf(ss);
+    if (hashed) hashed[r] = (int32_t)ha;
+  }
+}
+
+// The same for tables under LAZY optax.sgd(lr, momentum) (train_spotify.py:238-241; decay_steps in esr_common.h): a row
+// whose last[row] is behind step `now` - 1 is read as if the missed decay steps had been applied -- every occurrence
+// computes the caught-up parameter row for itself (identical values: a function of the stored row, its trace and the
+// gap), nothing is written.  The write-back happens where the row is written anyway, in the momentum step at the end of
+// the train step (kMomentumStepLazy, esr_optim.hip).  Replaces the catch-up launch in front of the step: claim by
+// atomicExch -> load -> decay -> store, three dependent memory round trips (12 us) ahead of everything else.
+struct SpLazy {
+  const float *album_trace, *artist_trace;
+  const int32_t *album_last, *artist_last;
+  int now;
+  float lr, momentum;
+};
+__global__ __launch_bounds__(kBlock) void spotify_gather_lazy_kernel(const float* __restrict__ album_table, int64_t A,
+                                                                    const float* __restrict__ artist_table, int F,
+                                                                    const int32_t* __restrict__ album,
+                                                                    const int32_t* __restrict__ artist, int R, SpLazy lz,
+                                                                    float* __restrict__ E, float* __restrict__ l2,
+                                                                    int32_t* __restrict__ hashed) {
+  const int lane = threadIdx.x & 63;
+  const int r = (int)((blockIdx.x * (int64_t)kBlock + threadIdx.x) >> 6);
+  if (r >= R) return;
+  const int64_t ha = (int64_t)album[r] % A, ar = artist[r];
+  const int gap_a = lz.now - 1 - lz.album_last[ha], gap_r = lz.now - 1 - lz.artist_last[ar];
+  const int D2 = 2 * F;
+  const DecayCoef dk_a = decay_coef(gap_a, lz.momentum), dk_r = decay_coef(gap_r, lz.momentum);
+  float ss = 0.f;
+  for (int d = lane; d < D2; d += 64) {
+    const bool alb = d < F;
+    const int64_t at = alb ? ha * F + d : ar * F + (d - F);
+    float v = alb ? album_table[at] : artist_table[at];
+    const int gap = alb ? gap_a : gap_r;
+    if (gap > 0) {
+      float tv = alb ? lz.album_trace[at] : lz.artist_trace[at];
+      decay_apply(v, tv, alb ? dk_a : dk_r, lz.lr, lz.momentum);
+    }
     E[(int64_t)r * D2 + d] = v;
     ss = fmaf(v, v, ss);
   }
@@ -175,23 +220,158 @@ __global__ __launch_bounds__(kBlock) void spotify_affinity_kernel(const float* _
   }
 }
 
+// The same, for playlists whose rows fit LDS (round 4): the kernel above gives every scored row one thread, which walks its
+// row out of global memory 16 bytes at a time -- two waves, sixteen exposed load latencies: 16 us for 104 rows.  Here all
+// 1024 threads stage E into LDS in one sweep (rows padded to 2F + 1 floats: a thread per row and a lane per dimension
+// both read without bank conflicts), every (scored row, context row) pair is a thread's dot product (terms added d = 0,
+// 1, 2, ...: the same values), and the per-row maxima / boosts / tie counts follow from LDS.
+constexpr int kSpAffThreads = 1024;
+__host__ __device__ inline size_t sp_aff_lds_bytes(int n, int m, int o, int F) {
+  return ((size_t)(n + m + o) * (2 * F + 1) + (size_t)(m + o) * n) * 4 + 1024;
+}
+__global__ __launch_bounds__(kSpAffThreads) void spotify_affinity_lds_kernel(const float* __restrict__ Eg, SpShape sh,
+                                                                            const int32_t* __restrict__ album,
+                                                                            const int32_t* __restrict__ artist,
+                                                                            float* __restrict__ raw_out, float* __restrict__ aff,
+                                                                            float* __restrict__ W, double* __restrict__ head) {
+  extern __shared__ __attribute__((aligned(16))) char sp_aff_lds[];
+  const int n = sh.n, m = sh.m, o = sh.o, D2 = 2 * sh.F, S = m + o, R = n + S, EP = D2 + 1, t = threadIdx.x;
+  const int lane = t & 63, wv = t >> 6;
+  constexpr int T = kSpAffThreads, NW = T / 64;
+  double* red = reinterpret_cast<double*>(sp_aff_lds);                 // [0, 256): 2 x 16 doubles
+  float* redf = reinterpret_cast<float*>(sp_aff_lds + 256);            // 36 floats
+  int* redi = reinterpret_cast<int*>(sp_aff_lds + 512);                // 34 ints
+  float* E = reinterpret_cast<float*>(sp_aff_lds + 1024);
+  float* raw = E + (size_t)R * EP;
+  for (int e = t; e < R * D2; e += T) {
+    const int r = e / D2;
+    E[r * EP + (e - r * D2)] = Eg[e];
+  }
+  __syncthreads();
+  for (int e = t; e < S * n; e += T) {
+    const int i = e / n, c = e - i * n;
+    const float* z = E + (n + i) * EP;
+    const float* x = E + c * EP;
+    float sc = 0.f;
+    int d = 0;
+    for (; d + 8 <= D2; d += 8) {
+      float zv[8], xv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { zv[q] = z[d + q]; xv[q] = x[d + q]; }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) sc = fmaf(zv[q], xv[q], sc);
+    }
+    for (; d < D2; ++d) sc = fmaf(z[d], x[d], sc);
+    raw[e] = sc;
+    if (raw_out) raw_out[e] = sc;
+  }
+  __syncthreads();
+  double sum_pos = 0.0, sum_neg = 0.0;
+  float mn = INFINITY, mx = -INFINITY;
+  int cmn = 0, cmx = 0;
+  for (int i = t; i < S; i += T) {
+    float best = -INFINITY;
+    bool in_album = false, in_artist = false;
+    const int32_t al = album[n + i], ar = artist[n + i];
+    for (int c = 0; c < n; ++c) {
+      best = fmaxf(best, raw[i * n + c]);
+      in_album |= al == album[c];
+      in_artist |= ar == artist[c];
+    }
+    const float av = best + (in_album ? kSpBoost : 0.f) + (in_artist ? kSpBoost : 0.f);
+    aff[i] = av;
+    if (i < m) {
+      sum_pos += av;
+      if (av < mn) { mn = av; cmn = 1; } else if (av == mn) ++cmn;
+    } else {
+      sum_neg += av;
+      if (av > mx) { mx = av; cmx = 1; } else if (av == mx) ++cmx;
+    }
+  }
+  sum_pos = wave_sum_d(sum_pos);
+  sum_neg = wave_sum_d(sum_neg);
+#pragma unroll
+  for (int sft = 32; sft > 0; sft >>= 1) {
+    const float omn = __shfl_xor(mn, sft, 64), omx = __shfl_xor(mx, sft, 64);
+    const int ocmn = __shfl_xor(cmn, sft, 64), ocmx = __shfl_xor(cmx, sft, 64);
+    if (omn < mn) { mn = omn; cmn = ocmn; } else if (omn == mn) cmn += ocmn;
+    if (omx > mx) { mx = omx; cmx = ocmx; } else if (omx == mx) cmx += ocmx;
+  }
+  if (lane == 0) {
+    red[wv] = sum_pos; red[NW + wv] = sum_neg;
+    redf[wv] = mn; redf[NW + wv] = mx;
+    redi[wv] = cmn; redi[NW + wv] = cmx;
+  }
+  __syncthreads();
+  if (t == 0) {
+    double sp = 0.0, sn = 0.0;
+    for (int w = 0; w < NW; ++w) { sp += red[w]; sn += red[NW + w]; }
+    mn = redf[0]; cmn = redi[0]; mx = redf[NW]; cmx = redi[NW];
+    for (int w = 1; w < NW; ++w) {
+      if (redf[w] < mn) { mn = redf[w]; cmn = redi[w]; } else if (redf[w] == mn) cmn += redi[w];
+      if (redf[NW + w] > mx) { mx = redf[NW + w]; cmx = redi[NW + w]; } else if (redf[NW + w] == mx) cmx += redi[NW + w];
+    }
+    const float mt = 1.0f + (float)(sn / o) - (float)(sp / m);
+    const float et = 1.0f + mx - mn;
+    head[0] = (double)fmaxf(mt, 0.f) + (double)fmaxf(et, 0.f);
+    redf[2 * NW] = mt; redf[2 * NW + 1] = et; redf[2 * NW + 2] = mn; redf[2 * NW + 3] = mx;
+    redi[2 * NW] = cmn; redi[2 * NW + 1] = cmx;
+  }
+  if (!W) return;
+  __syncthreads();
+  const float mt_arg = redf[2 * NW], et_arg = redf[2 * NW + 1], s_min_pos = redf[2 * NW + 2], s_max_neg = redf[2 * NW + 3];
+  const int s_cnt_min = redi[2 * NW], s_cnt_max = redi[2 * NW + 1];
+  for (int i = t; i < S; i += T) {
+    const float av = aff[i];
+    float d = 0.f;
+    if (i < m) {
+      if (mt_arg > 0.f) d -= 1.0f / m;
+      if (et_arg > 0.f && av == s_min_pos) d -= 1.0f / s_cnt_min;
+    } else {
+      if (mt_arg > 0.f) d += 1.0f / o;
+      if (et_arg > 0.f && av == s_max_neg) d += 1.0f / s_cnt_max;
+    }
+    float best = -INFINITY;
+    for (int c = 0; c < n; ++c) best = fmaxf(best, raw[i * n + c]);
+    int ties = 0;
+    for (int c = 0; c < n; ++c) ties += raw[i * n + c] == best;
+    for (int c = 0; c < n; ++c) W[i * n + c] = raw[i * n + c] == best ? d / ties : 0.f;
+  }
+}
+
 // one wave per row b; lane holds dims lane, lane + 64, ... (NCH = ceil(2F / 64) of them)
-template <int NCH>
-__global__ __launch_bounds__(kBlock) void spotify_rowgrad_kernel(const float* __restrict__ E, SpShape sh,
+// STAGED (round 4): every workgroup first copies ALL rows of the playlist into its LDS (one sweep, one round trip: 29 KB
+// from L2) and takes the partner rows from there.  Read from global memory four rows at a time, a negative's 64 partners
+// were sixteen dependent round trips: 16-24 us for a launch whose arithmetic is 2 us.
+template <int NCH, bool STAGED>
+__global__ __launch_bounds__(kBlock) void spotify_rowgrad_kernel(const float* __restrict__ Eg, SpShape sh,
                                                                 const float* __restrict__ l2,
                                                                 const float* __restrict__ W, float regularization,
                                                                 float* __restrict__ g_album,
                                                                 float* __restrict__ g_artist,
                                                                 double* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) char sp_rg_lds[];
   const int n = sh.n, m = sh.m, o = sh.o, F = sh.F, D2 = 2 * F, R = n + m + o;
   const int lane = threadIdx.x & 63;
+  const float* E = Eg;
+  if (STAGED) {
+    float* El = reinterpret_cast<float*>(sp_rg_lds);
+    if ((D2 & 3) == 0) {
+      for (int e = threadIdx.x; e < R * D2 / 4; e += kBlock)
+        reinterpret_cast<float4*>(El)[e] = reinterpret_cast<const float4*>(Eg)[e];
+    } else {
+      for (int e = threadIdx.x; e < R * D2; e += kBlock) El[e] = Eg[e];
+    }
+    __syncthreads();
+    E = El;
+  }
   const int b = (int)((blockIdx.x * (int64_t)kBlock + threadIdx.x) >> 6);
   if (b >= R) return;
   auto load = [&](int r, float (&v)[NCH]) {
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
       const int d = lane + 64 * k;
-      v[k] = d < D2 ? E[(int64_t)r * D2 + d] : 0.f;
+      v[k] = d < D2 ? E[r * D2 + d] : 0.f;
     }
   };
   auto dot = [&](const float (&x)[NCH], const float (&y)[NCH]) {
@@ -231,13 +411,27 @@ __global__ __launch_bounds__(kBlock) void spotify_rowgrad_kernel(const float* __
   double part = lsum / ((double)Rg * (double)Rg);
   // ---- affinity terms through W = d loss / d raw
   if (b < n) {
-    for (int i = 0; i < m + o; ++i) {
-      const float w = W[i * n + b];
-      if (w == 0.f) continue;  // wave-uniform
-      float x[NCH];
-      load(n + i, x);
+    // a context row collects from the scored rows whose maximum it is (about (m + o) / n of them): 64 weights per read, only
+    // the nonzero ones visited, in ascending order.  (Probing all m + o one by one was a chain of 104 dependent loads:
+    // the n context waves finished 10 us after everybody else -- two thirds of this launch.)
+    const int S = m + o;
+    for (int i0 = 0; i0 < S; i0 += 64) {
+      const float wl = i0 + lane < S ? W[(i0 + lane) * n + b] : 0.f;
+      unsigned long long todo = __ballot(wl != 0.f);
+      while (todo) {  // eight rows per trip: their loads leave together (one at a time each was an exposed round trip)
+        float wq[8], x[8][NCH];
 #pragma unroll
-      for (int k = 0; k < NCH; ++k) acc[k] = fmaf(w, x[k], acc[k]);
+        for (int q = 0; q < 8; ++q) {
+          const int u = todo ? __builtin_ctzll(todo) : 0;
+          wq[q] = todo ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), u)) : 0.f;
+          todo &= todo - (todo ? 1 : 0);
+          load(n + i0 + u, x[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+          for (int k = 0; k < NCH; ++k) acc[k] = fmaf(wq[q], x[q][k], acc[k]);  // (w = 0 behind the last: acc unchanged)
+      }
     }
   } else {
     for (int c = 0; c < n; ++c) {
@@ -404,6 +598,34 @@ static SpWs sp_layout(char* base, int n, int m, int o, int F) {
   return w;
 }
 
+// spotify_affinity_lds_kernel when the playlist's rows fit LDS, else spotify_affinity_kernel
+static bool sp_affinity_in_lds(SpShape sh) {
+  const char* e = getenv("ESR_SPOTIFY_AFFINITY");  // "global": the first kernel (A/B)
+  return sp_aff_lds_bytes(sh.n, sh.m, sh.o, sh.F) <= 150 * 1024 && !(e && strcmp(e, "global") == 0);
+}
+static int sp_launch_affinity(const SpWs& w, SpShape sh, const int32_t* album_ids, const int32_t* artist_ids, float* W,
+                              double* head, hipStream_t st) {
+  constexpr size_t kMaxLds = 150 * 1024;
+  const size_t lds = sp_aff_lds_bytes(sh.n, sh.m, sh.o, sh.F);
+  if (sp_affinity_in_lds(sh)) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)spotify_affinity_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)kMaxLds) != hipSuccess) {
+        set_error("spotify affinity: cannot raise the LDS limit");
+        return ESR_ELAUNCH;
+      }
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(spotify_affinity_lds_kernel, dim3(1), dim3(kSpAffThreads), lds, st, (const float*)w.E, sh, album_ids,
+                       artist_ids, w.raw, w.aff, W, head);
+  } else {
+    hipLaunchKernelGGL(spotify_affinity_kernel, dim3(1), dim3(kBlock), 0, st, (const float*)w.E, sh, album_ids, artist_ids,
+                       w.raw, w.aff, W, head);
+  }
+  return ESR_OK;
+}
+
 static int sp_check(const char* who, int n, int m, int o, int F, int64_t A, int64_t n_artists) {
   if (!(n > 0 && m > 0 && o > 0 && F > 0 && A > 0 && n_artists > 0 && n <= kSpMaxCtx && 2 * F <= kSpMaxDim)) {
     set_error("%s: bad sizes n=%d m=%d o=%d F=%d (n <= %d, 2F <= %d)", who, n, m, o, F, kSpMaxCtx, kSpMaxDim);
@@ -411,6 +633,11 @@ static int sp_check(const char* who, int n, int m, int o, int F, int64_t A, int6
   }
   return ESR_OK;
 }
+
+// in esr_optim.hip
+int sparse_momentum_step_lazy2(float* const* tables, float* const* traces, int32_t* const* lasts, const int64_t* row_offsets,
+                               int ntables, int D, const int32_t* sorted_vids, const int32_t* perm, int64_t n, float* grad_rows,
+                               float lr, float momentum, int now, hipStream_t st);
 
 }  // namespace esr
 
@@ -454,8 +681,7 @@ int esr_spotify_forward(const float* album_table, int64_t n_album_rows, const fl
   const SpShape sh{n, m, o, F};
   hipLaunchKernelGGL(spotify_gather_kernel, dim3((int)cdiv(R, kBlock / 64)), dim3(kBlock), 0, st, album_table,
                      n_album_rows, artist_table, F, album_ids, artist_ids, R, w.E, l2, (int32_t*)nullptr);
-  hipLaunchKernelGGL(spotify_affinity_kernel, dim3(1), dim3(kBlock), 0, st, (const float*)w.E, sh, album_ids, artist_ids,
-                     w.raw, w.aff, (float*)nullptr, w.partial + R);
+  if (int rc = sp_launch_affinity(w, sh, album_ids, artist_ids, nullptr, w.partial + R, st)) return rc;
   (void)hipMemcpyAsync(pos, w.aff, sizeof(float) * m, hipMemcpyDeviceToDevice, st);
   (void)hipMemcpyAsync(neg, w.aff + m, sizeof(float) * o, hipMemcpyDeviceToDevice, st);
   const int g0s[3] = {0, n, n + m}, rgs[3] = {n, m, o};
@@ -468,10 +694,24 @@ int esr_spotify_forward(const float* album_table, int64_t n_album_rows, const fl
   return check_launch("esr_spotify_forward");
 }
 
+static int sp_fwd_bwd(const float* album_table, int64_t n_album_rows, const float* artist_table, int64_t n_artists, int F,
+                      const int32_t* album_ids, const int32_t* artist_ids, int n, int m, int o, float regularization,
+                      float* loss, int32_t* album_rows, float* g_album_rows, float* g_artist_rows, void* workspace,
+                      size_t workspace_bytes, esr_stream_t stream, const SpLazy* lazy);
+
 int esr_spotify_fwd_bwd(const float* album_table, int64_t n_album_rows, const float* artist_table, int64_t n_artists,
                         int F, const int32_t* album_ids, const int32_t* artist_ids, int n, int m, int o,
                         float regularization, float* loss, int32_t* album_rows, float* g_album_rows,
                         float* g_artist_rows, void* workspace, size_t workspace_bytes, esr_stream_t stream) {
+  return sp_fwd_bwd(album_table, n_album_rows, artist_table, n_artists, F, album_ids, artist_ids, n, m, o, regularization,
+                    loss, album_rows, g_album_rows, g_artist_rows, workspace, workspace_bytes, stream, nullptr);
+}
+
+// lazy != null: the tables are under lazy momentum -- rows are read through spotify_gather_lazy_kernel
+static int sp_fwd_bwd(const float* album_table, int64_t n_album_rows, const float* artist_table, int64_t n_artists, int F,
+                      const int32_t* album_ids, const int32_t* artist_ids, int n, int m, int o, float regularization,
+                      float* loss, int32_t* album_rows, float* g_album_rows, float* g_artist_rows, void* workspace,
+                      size_t workspace_bytes, esr_stream_t stream, const SpLazy* lazy) {
   if (int rc = sp_check("esr_spotify_fwd_bwd", n, m, o, F, n_album_rows, n_artists)) return rc;
   ESR_REQUIRE(album_table && artist_table && album_ids && artist_ids && loss && album_rows && g_album_rows &&
                   g_artist_rows && workspace, "esr_spotify_fwd_bwd: null pointer");
@@ -484,14 +724,28 @@ int esr_spotify_fwd_bwd(const float* album_table, int64_t n_album_rows, const fl
   const int R = n + m + o, D2 = 2 * F;
   const SpShape sh{n, m, o, F};
   const int wgrid = (int)cdiv(R, kBlock / 64);
-  hipLaunchKernelGGL(spotify_gather_kernel, dim3(wgrid), dim3(kBlock), 0, st, album_table, n_album_rows, artist_table, F,
-                     album_ids, artist_ids, R, w.E, w.l2, album_rows);
-  hipLaunchKernelGGL(spotify_affinity_kernel, dim3(1), dim3(kBlock), 0, st, (const float*)w.E, sh, album_ids, artist_ids,
-                     w.raw, w.aff, w.W, w.partial + R);
+  if (lazy)
+    hipLaunchKernelGGL(spotify_gather_lazy_kernel, dim3(wgrid), dim3(kBlock), 0, st, album_table, n_album_rows, artist_table,
+                       F, album_ids, artist_ids, R, *lazy, w.E, w.l2, album_rows);
+  else
+    hipLaunchKernelGGL(spotify_gather_kernel, dim3(wgrid), dim3(kBlock), 0, st, album_table, n_album_rows, artist_table, F,
+                       album_ids, artist_ids, R, w.E, w.l2, album_rows);
+  if (int rc = sp_launch_affinity(w, sh, album_ids, artist_ids, w.W, w.partial + R, st)) return rc;
   const int nch = (int)cdiv(D2, 64);
+  const size_t rg_lds = (size_t)R * D2 * 4;
+  const char* rg_env = getenv("ESR_SPOTIFY_ROWGRAD");  // "global": partner rows from global memory (A/B)
+  const bool staged = rg_lds <= 64 * 1024 && !(rg_env && strcmp(rg_env, "global") == 0);
 #define ESR_SP_ROWGRAD(NCH)                                                                                         \
-  hipLaunchKernelGGL((spotify_rowgrad_kernel<NCH>), dim3(wgrid), dim3(kBlock), 0, st, (const float*)w.E, sh,         \
-                     (const float*)w.l2, (const float*)w.W, regularization, g_album_rows, g_artist_rows, w.partial)
+  do {                                                                                                              \
+    if (staged)                                                                                                     \
+      hipLaunchKernelGGL((spotify_rowgrad_kernel<NCH, true>), dim3(wgrid), dim3(kBlock), rg_lds, st, (const float*)w.E, \
+                         sh, (const float*)w.l2, (const float*)w.W, regularization, g_album_rows, g_artist_rows,   \
+                         w.partial);                                                                                \
+    else                                                                                                            \
+      hipLaunchKernelGGL((spotify_rowgrad_kernel<NCH, false>), dim3(wgrid), dim3(kBlock), 0, st, (const float*)w.E, \
+                         sh, (const float*)w.l2, (const float*)w.W, regularization, g_album_rows, g_artist_rows,   \
+                         w.partial);                                                                                \
+  } while (0)
   if (nch == 1) ESR_SP_ROWGRAD(1);
   else if (nch == 2) ESR_SP_ROWGRAD(2);
   else ESR_SP_ROWGRAD(4);
@@ -546,12 +800,19 @@ int esr_spotify_train_step(float* album_table, float* album_trace, int32_t* albu
   int32_t* perm = (int32_t*)(base + off);
   off += align_up(2 * (size_t)R * 4, 256);
   void* sort_ws = base + off;
-  if (int rc = esr_momentum_catchup_rows2(album_table, album_trace, album_last, album_ids, (int)n_album_rows, artist_table,
-                                          artist_trace, artist_last, artist_ids, 0, F, R, step, lr, momentum, stream))
-    return rc;
-  if (int rc = esr_spotify_fwd_bwd(album_table, n_album_rows, artist_table, n_artists, F, album_ids, artist_ids, n, m, o,
-                                   regularization, loss, album_rows, grads, grads + R * F, workspace,
-                                   sp_layout(nullptr, n, m, o, F).total, stream))
+  // ESR_SPOTIFY_CATCHUP=launch: the catch-up as its own launch in front (round 3's sequence; A/B and the equality test);
+  // default: rows are read caught-up by the gather and written caught-up by the momentum step -- one launch and three
+  // dependent memory round trips less
+  const char* cu_env = getenv("ESR_SPOTIFY_CATCHUP");
+  const bool inline_catchup = !(cu_env && strcmp(cu_env, "launch") == 0);
+  const SpLazy lz{album_trace, artist_trace, album_last, artist_last, step, lr, momentum};
+  if (!inline_catchup)
+    if (int rc = esr_momentum_catchup_rows2(album_table, album_trace, album_last, album_ids, (int)n_album_rows, artist_table,
+                                            artist_trace, artist_last, artist_ids, 0, F, R, step, lr, momentum, stream))
+      return rc;
+  if (int rc = sp_fwd_bwd(album_table, n_album_rows, artist_table, n_artists, F, album_ids, artist_ids, n, m, o,
+                          regularization, loss, album_rows, grads, grads + R * F, workspace,
+                          sp_layout(nullptr, n, m, o, F).total, stream, inline_catchup ? &lz : nullptr))
     return rc;
   const int32_t* segs[2] = {album_rows, artist_ids};
   const int64_t counts[2] = {R, R};
@@ -561,7 +822,11 @@ int esr_spotify_train_step(float* album_table, float* album_trace, int32_t* albu
     return rc;
   float* tables[2] = {album_table, artist_table};
   float* traces[2] = {album_trace, artist_trace};
+  int32_t* lasts[2] = {album_last, artist_last};
   const int64_t row_offsets[3] = {0, n_album_rows, n_album_rows + n_artists};
+  if (inline_catchup)
+    return sparse_momentum_step_lazy2(tables, traces, lasts, row_offsets, 2, F, sorted, perm, 2 * R, grads, lr, momentum, step,
+                                      as_stream(stream));
   return esr_sparse_momentum_step_multi(tables, traces, row_offsets, 2, F, sorted, perm, 2 * R, grads, lr, momentum, stream);
 }
 

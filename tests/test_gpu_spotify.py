@@ -224,3 +224,65 @@ def test_spotify_model_call_matches_reference_tuple(dev):
         assert rel_err(N(got), e) <= TOL
     emb = model.apply(params, f(all_albums, c), f(all_artists, c), method=SpotifyModel.get_embeddings)
     assert np.array_equal(N(emb), o_sp.get_embeddings(at, rt, x["album_context"], x["artist_context"]).astype(np.float32))
+
+
+@pytest.mark.parametrize("n_next,F", [(12, 32), (40, 32), (1, 16), (100, 64), (250, 32)])
+def test_affinity_from_lds_equals_affinity_from_global_memory(dev, n_next, F, monkeypatch):
+    """spotify_affinity_lds_kernel (rows staged in LDS, a thread per (scored row, context row) pair) against
+    spotify_affinity_kernel (ESR_SPOTIFY_AFFINITY=global): every dot product adds its terms in the same order, so the
+    per-occurrence gradient rows agree to the last bit or two (only the fp64 loss sums associate differently); and the
+    row-gradient kernel's ballot walk over a context row's weights visits them in the old order."""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(5 + n_next)
+    A, n_art, n, o = 3000, 800, 5, 64
+    g = torch.Generator(device=dev).manual_seed(3)
+    at = torch.randn((A, F), generator=g, device=dev) * 0.2
+    rt = torch.randn((n_art, F), generator=g, device=dev) * 0.2
+    R = n + n_next + o
+    for trial in range(4):
+        albums = rng.integers(0, 50_000, R).astype(np.int32)
+        artists = rng.integers(0, n_art if trial % 2 else 40, R).astype(np.int32)
+        albums[n:n + 2] = albums[0]
+        artists[n:n + 2] = artists[0]                                   # "in context" boosts; two equal context rows: ties
+        albums[1], artists[1] = albums[0], artists[0]
+        al, ar = T(albums, dev), T(artists, dev)
+        monkeypatch.setenv("ESR_SPOTIFY_AFFINITY", "global")
+        lb, rb, gab, grb = ops.spotify_fwd_bwd(at, rt, al, ar, n, n_next, o, 0.9)
+        monkeypatch.setenv("ESR_SPOTIFY_AFFINITY", "lds")
+        la, ra, gaa, gra = ops.spotify_fwd_bwd(at, rt, al, ar, n, n_next, o, 0.9)
+        assert torch.equal(ra, rb)
+        assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(lb))
+        assert float((gaa - gab).abs().max()) <= 1e-6 * float(gab.abs().max())
+        assert float((gra - grb).abs().max()) <= 1e-6 * float(grb.abs().max())
+
+
+def test_inline_catch_up_equals_the_catch_up_launch(dev, monkeypatch):
+    """The train step reads rows that are behind through spotify_gather_lazy_kernel and writes them caught-up in the
+    momentum step itself (kMomentumStepLazy); ESR_SPOTIFY_CATCHUP=launch keeps round 3's catch-up launch in front.  Same
+    operations on the same values: losses, tables, traces and step marks are bit-identical over 30 steps of a playlist
+    stream in which rows sleep for a few steps, for more than 64 steps (closed-form gaps), and repeat inside a playlist."""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(77)
+    A, n_art, F, n, m, o = 3000, 800, 32, 5, 20, 64
+    R = n + m + o
+
+    def fresh():
+        gg = torch.Generator(device=dev).manual_seed(3)
+        at = torch.randn((A, F), generator=gg, device=dev) * 0.2
+        rt = torch.randn((n_art, F), generator=gg, device=dev) * 0.2
+        return [at, torch.randn((A, F), generator=gg, device=dev) * 0.01, torch.zeros(A, dtype=torch.int32, device=dev),
+                rt, torch.randn((n_art, F), generator=gg, device=dev) * 0.01, torch.zeros(n_art, dtype=torch.int32, device=dev)]
+    a, b = fresh(), fresh()
+    step = 0
+    for it in range(30):
+        step += 1 if it % 7 else 90          # now and then a long pause: gaps beyond kLazyExact take the closed form
+        albums = rng.integers(0, 50_000, R).astype(np.int32)
+        artists = rng.integers(0, n_art if it % 3 else 30, R).astype(np.int32)
+        al, ar = T(albums, dev), T(artists, dev)
+        monkeypatch.setenv("ESR_SPOTIFY_CATCHUP", "launch")
+        lb = ops.spotify_train_step(b[0], b[1], b[2], b[3], b[4], b[5], al, ar, n, m, o, 0.9, step, 0.05, 0.9)
+        monkeypatch.setenv("ESR_SPOTIFY_CATCHUP", "inline")
+        la = ops.spotify_train_step(a[0], a[1], a[2], a[3], a[4], a[5], al, ar, n, m, o, 0.9, step, 0.05, 0.9)
+        assert float(la) == float(lb), it
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
