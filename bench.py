@@ -994,6 +994,14 @@ def main():
         from bench_retrieve import run_retrieve
         return run_retrieve(args, emit)
     assert torch.cuda.is_available(), "bench.py needs an MI355X: there is no CPU fallback for the product path"
+    # ESR_WIRE_ONE_GPU=1 (with ESR_RCCL_LIB = tests/wire's loopback wire): a DRY RUN of the N > 1 command on a one-GPU
+    # box -- every rank on cuda:0, gloo process group, the library's exchange code over sockets.  It exercises the code
+    # path of the driver's --gpus N run (plans, one-call sharded steps, max-over-ranks timing, the JSON line); its
+    # numbers say nothing about xGMI and the line says so.
+    one_gpu_wire = world > 1 and os.environ.get("ESR_WIRE_ONE_GPU") == "1"
+    if one_gpu_wire:
+        assert os.environ.get("ESR_RCCL_LIB"), "ESR_WIRE_ONE_GPU=1 needs ESR_RCCL_LIB (tests/wire/build_wire.py)"
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -1012,7 +1020,10 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_gpu_wire:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         from bench_sharded import run_sharded  # row-sharded step with RCCL all-to-all
         return run_sharded(args, cfg, dev, rank, world)
 

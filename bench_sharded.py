@@ -142,9 +142,11 @@ def run_sharded(args, cfg, dev, rank, world):
         print("sharded loop: %.1f us per step wall, %.1f us of it waiting for the routing-plan copy (%d waits)" % (
             (time.perf_counter() - t0) / args.steps * 1e6, sharded._trace[0] / max(1, sharded._trace[1]) * 1e6,
             sharded._trace[1]), file=sys.stderr)
-    dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    # (host tensors under the one-GPU wire dry run, whose process group is gloo: bench.py, ESR_WIRE_ONE_GPU)
+    red_dev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+    dt = torch.tensor([time.perf_counter() - t0], device=red_dev, dtype=torch.float64)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    total = loss.clone()
+    total = loss.detach().to(red_dev).clone()
     dist.all_reduce(total)
     dt = float(dt)
 
@@ -173,6 +175,9 @@ def run_sharded(args, cfg, dev, rank, world):
     xch = grp0.exchange() if grp0 is not None else rep.coll.x
     exchange = "direct RCCL: grouped ncclSend/ncclRecv on the compute stream (esr_alltoall_*, esrecsys_amd/rccl.py)" \
         if xch is not None else "fallback: torch.distributed all_to_all_single"
+    if os.environ.get("ESR_RCCL_LIB"):
+        exchange = ("DRY RUN over %s (every rank on ONE GPU, bytes over sockets): the library's grouped send / recv code "
+                    "path, NOT RCCL / xGMI -- the value is not a scaling measurement" % os.path.basename(os.environ["ESR_RCCL_LIB"]))
     rccl_ranks = xch.ranks_seen()[0] if xch is not None else None  # ncclCommCount of the exchange communicator
     if rank == 0:
         K = args.steps

@@ -13,6 +13,11 @@ the same path: (1) bind librccl (local, can fail on one rank only), (2) ncclComm
 self-test all-to-all with known contents, WAITED FOR WITH A TIMEOUT: a rank whose peers never post their half
 aborts its communicator (ncclCommAbort terminates the enqueued operations) instead of hanging in a device sync,
 so the agreement all-reduce that follows is always reached.
+
+``ESR_RCCL_LIB=/path/to/lib.so`` binds that library instead of torch's librccl (any library exporting the twelve
+nccl* symbols esr_comm.hip binds).  With it set the direct exchange is also built over a process group that is not
+"nccl" (the bootstrap bytes then travel as CPU tensors).  Used by tests/test_gpu_rccl_world2.py to run the world-2
+branches of the library as two processes on ONE GPU over tests/wire's loopback wire; nothing in the package sets it.
 """
 import ctypes
 import os
@@ -37,15 +42,17 @@ class DirectExchange:
         self.timeout = float(os.environ.get("ESR_RCCL_SELFTEST_TIMEOUT", "60")) if selftest_timeout_s is None \
             else float(selftest_timeout_s)
         self._cnt = (ctypes.c_int64 * self.world)
+        # the bootstrap's own collectives run on the process group: device tensors under nccl, host tensors otherwise
+        self._boot_dev = self.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
         # phase 1: bind librccl -- torch's bundled copy, the one ProcessGroupNCCL already runs on
-        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        path = os.environ.get("ESR_RCCL_LIB") or os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         self._agree(lambda: _lib.check(self.lib.esr_comm_load(path.encode() if os.path.exists(path) else None),
                                        "esr_comm_load"), "bind librccl")
         # phase 2: the communicator (collective)
         uid = (ctypes.c_byte * 128)()
         if self.rank == 0:
             _lib.check(self.lib.esr_comm_unique_id(uid), "esr_comm_unique_id")
-        raw = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).to(self.device)
+        raw = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).to(self._boot_dev)
         dist.broadcast(raw, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         ctypes.memmove(uid, raw.cpu().numpy().tobytes(), 128)
 
@@ -64,7 +71,7 @@ class DirectExchange:
             fn()
         except Exception as e:  # noqa: BLE001 -- whatever went wrong locally must reach the agreement below
             err = e
-        ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=self.device)
+        ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=self._boot_dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.pg)
         if int(ok) != 1:
             self._abort()
@@ -191,7 +198,8 @@ def exchange_for(group, device, lane=0):
     communicator over the same ranks: collectives of one communicator are serialised, so the rows exchange that a
     training loop runs on a side stream under the previous step's kernels (sharded.sharded_train_steps, overlap) needs
     its own."""
-    if os.environ.get("ESR_RCCL_DIRECT", "1") != "1" or device.type != "cuda" or dist.get_backend(group) != "nccl":
+    if os.environ.get("ESR_RCCL_DIRECT", "1") != "1" or device.type != "cuda" or \
+            (dist.get_backend(group) != "nccl" and not os.environ.get("ESR_RCCL_LIB")):
         return None
     key = (id(group), device.index, lane)
     if key not in _cache:

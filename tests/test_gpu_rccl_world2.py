@@ -2,6 +2,15 @@
 esrecsys_amd/rccl.py): sharded_{triplet,inbatch,glove}_step with the real HIP kernels against the fp64 oracle applied
 to the unsharded tables.  Skips cleanly on a box with fewer than two GPUs (RCCL refuses two ranks on one device).
 
+The same three comparisons also run as TWO PROCESSES ON ONE GPU, on a box where RCCL cannot form a two-rank
+communicator -- every HIP kernel of the sharded steps at world 2 (uneven shards, remote rows, owner-side sorts, segment
+sums over received gradient rows); only the wire is substituted:
+* "loop1": the library's OWN exchange code (esr_comm.hip's grouped send / recv, the one-call sharded steps of
+  esr_shard_step.hip, the group-of-plans exchanges) bound to tests/wire's loopback wire through ESR_RCCL_LIB -- the
+  code path of an N-GPU run with the bytes carried by sockets instead of xGMI;
+* "gloo1": no direct exchange at all: the op-by-op path over torch.distributed's gloo backend (the fallback a rank takes
+  when the RCCL bootstrap fails).
+
 Also here: the BASELINE config-4-shaped step (bf16 towers, one rank's 12.5 M-row share per tower, B = 8192) through
 the same RCCL path at world 1, which every 1-GPU box can run."""
 import os
@@ -50,13 +59,20 @@ def _glove_batch(step, rank):
     return rng.integers(0, V_G, (2, B_G)).astype(np.int32), rng.uniform(0.1, 300.0, B_G).astype(np.float32)
 
 
-def _worker(rank, port, outdir):
+def _worker(rank, port, outdir, transport="rccl", wire_lib=None):
+    direct = transport in ("rccl", "loop1")  # the library's own exchange (esr_comm.hip) is the path under test
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
-                      ESR_RCCL_DIRECT="1")
+                      ESR_RCCL_DIRECT="1" if direct else "0")
+    if transport == "loop1":
+        os.environ["ESR_RCCL_LIB"] = wire_lib
     import torch.distributed as dist
-    torch.cuda.set_device(rank)
-    dev = torch.device("cuda", rank)
-    dist.init_process_group("nccl", rank=rank, world_size=WORLD, device_id=dev)
+    index = rank if transport == "rccl" else 0  # "loop1" / "gloo1": both ranks share cuda:0
+    torch.cuda.set_device(index)
+    dev = torch.device("cuda", index)
+    if transport == "rccl":
+        dist.init_process_group("nccl", rank=rank, world_size=WORLD, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     from esrecsys_amd import ops, sharded
 
     def shard(full):
@@ -69,8 +85,12 @@ def _worker(rank, port, outdir):
         scene, prod = shard(st), shard(pt)
         towers = sharded.ShardedTableGroup([scene, prod], kernels=ops)
         x = towers.exchange()
-        assert x is not None, "the direct RCCL exchange must be the path under test"
-        assert x.ranks_seen() == (WORLD, rank)
+        if direct:
+            assert x is not None, "the direct exchange (esr_comm.hip) must be the path under test"
+            assert x.ranks_seen() == (WORLD, rank)
+            assert towers._fused() is not None, "the one-call sharded steps must be the path under test"
+        else:
+            assert x is None and towers.world == WORLD
         losses = []
         plans = None
         if workload == "inbatch":
@@ -84,7 +104,7 @@ def _worker(rank, port, outdir):
                 loss = sharded.sharded_triplet_step(towers, sid, pid, nid, LAM, float(WORLD * B), LR)
             else:
                 loss = sharded.sharded_inbatch_step(towers, sid, pid, LAM, float(WORLD * B), SCALE, LR, plan=plans[step])
-            total = loss.clone()
+            total = loss.detach().clone() if transport == "rccl" else loss.detach().cpu().clone()
             dist.all_reduce(total)
             losses.append(float(total))
         out[workload + "_scene"] = scene.local.cpu().numpy()
@@ -96,7 +116,7 @@ def _worker(rank, port, outdir):
     emb_t, bias_t = shard(emb0), shard(bias0)
     emb = sharded.ShardedTableGroup([emb_t], kernels=ops)
     bias = sharded.ShardedTableGroup([bias_t], kernels=ops)
-    assert emb.exchange() is not None
+    assert (emb.exchange() is not None) == direct
     batches = [_glove_batch(s, rank) for s in range(STEPS)]
     dv = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
     cur = sharded.begin_plan_glove(emb, dv(batches[0][0])).finish()
@@ -121,18 +141,33 @@ def _reassemble(outs, key, V, width):
     return full
 
 
-@pytest.fixture(scope="module")
-def world2_outputs():
-    if not torch.cuda.is_available() or torch.cuda.device_count() < WORLD:
+_OUTPUTS = {}
+
+
+@pytest.fixture(scope="module", params=["rccl", "loop1", "gloo1"])
+def world2_outputs(request):
+    transport = request.param
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    if transport == "rccl" and torch.cuda.device_count() < WORLD:
         pytest.skip("needs %d GPUs (RCCL refuses two ranks on one device); this box has %d"
-                    % (WORLD, torch.cuda.device_count() if torch.cuda.is_available() else 0))
-    import torch.multiprocessing as mp
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(port, d), nprocs=WORLD, join=True)
-        return [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(WORLD)]
+                    % (WORLD, torch.cuda.device_count()))
+    if transport not in _OUTPUTS:
+        import torch.multiprocessing as mp
+        wire_lib = None
+        if transport == "loop1":
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("build_wire", os.path.join(ROOT, "tests", "wire", "build_wire.py"))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            wire_lib = mod.build()
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        with tempfile.TemporaryDirectory() as d:
+            mp.spawn(_worker, args=(port, d, transport, wire_lib), nprocs=WORLD, join=True)
+            _OUTPUTS[transport] = [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(WORLD)]
+    return _OUTPUTS[transport]
 
 
 TOL = 1e-5
