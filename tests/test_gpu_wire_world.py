@@ -1,0 +1,289 @@
+"""GPU, world_size 2 and 4 as processes sharing ONE GPU, the REAL HIP kernels, the library's own exchange code
+(esr_comm.hip, esr_shard.hip, esr_shard_step.hip) bound to tests/wire's loopback wire through ESR_RCCL_LIB -- RCCL
+refuses two ranks on one device and the boxes have one.  What tests/test_sharded_gloo.py proves with CPU doubles of the
+kernels, proved here with the kernels themselves and the library's world > 1 branches:
+
+* the loop helper (plans of a group of batches made together, one library call per exchange half) equals the per-step
+  calls bit for bit, and the bf16 gradient-row exchange (config 4's budget) stays inside its error bound;
+* the overlapped loop (batch k + 1's lookup on a side stream and a second communicator under batch k's loss
+  kernel and update, stale rows served again) equals the sequential loop bit for bit on Zipf ids -- here with a real side
+  stream, real events and two communicators (the control -- the same loop without the patch differs -- is the gloo
+  test's: with a real side stream, how early the early lookup reads is a race, not a fact to assert);
+* world 4: the triplet steps against the fp64 oracle on the unsharded tables (uneven shards), and config 5's
+  sharded_find_top_k (all-gather of queries, per-shard top-k with global indices, all-to-all, 4-way merge) against
+  brute force over the full candidate set, ties included.
+
+The wire is test infrastructure (tests/wire/loopback_wire.cpp): it carries bytes, nothing else is substituted."""
+import importlib.util
+import os
+import socket
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+V_S, V_P, D, B, LAM, LR, SCALE = 4001, 6003, 128, 256, 0.1, 0.05, 4.0  # odd V: uneven shards
+V_G, D_G, B_G = 1501, 64, 384
+N_STEPS = 7  # plan groups of 3 + 3 + 1
+
+
+def _towers_full():
+    rng = np.random.default_rng(7)
+    return (rng.standard_normal((V_S, D)) * 0.12).astype(np.float32), \
+           (rng.standard_normal((V_P, D)) * 0.12).astype(np.float32)
+
+
+def _glove_full():
+    rng = np.random.default_rng(11)
+    return (rng.standard_normal((V_G, D_G)) * D_G ** -0.5).astype(np.float32), \
+           (rng.standard_normal((V_G, 1)) * 0.05).astype(np.float32)
+
+
+def _draw(rng, V, n, zipf):
+    if not zipf:
+        return rng.integers(0, V, n).astype(np.int32)
+    w = 1.0 / np.arange(1, V + 1)
+    return rng.choice(V, size=n, p=w / w.sum()).astype(np.int32)
+
+
+def _batch(step, rank, zipf=False):
+    rng = np.random.default_rng(1000 * step + rank)
+    sid, pid, nid = _draw(rng, V_S, B, zipf), _draw(rng, V_P, B, zipf), _draw(rng, V_P, B, zipf)
+    sid[:3] = 5  # duplicates that live on one owner
+    return sid, pid, nid
+
+
+def _glove_batch(step, rank, zipf=False):
+    rng = np.random.default_rng(5000 + 10 * step + rank)
+    return np.stack([_draw(rng, V_G, B_G, zipf), _draw(rng, V_G, B_G, zipf)]), \
+        rng.uniform(0.1, 300.0, B_G).astype(np.float32)
+
+
+def _grid(rng, shape, levels=8):
+    return (rng.integers(-levels, levels + 1, shape) / 4.0).astype(np.float32)
+
+
+def _init(rank, world, port, wire_lib):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      ESR_RCCL_DIRECT="1", ESR_RCCL_LIB=wire_lib)
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dist, torch.device("cuda", 0)
+
+
+def _finish(dist):
+    dist.barrier()
+    from esrecsys_amd import rccl
+    rccl.reset()
+    dist.destroy_process_group()
+
+
+def _loops_worker(rank, port, outdir, wire_lib):
+    world = 2
+    dist, dev = _init(rank, world, port, wire_lib)
+    from esrecsys_amd import ops, sharded
+    st, pt = _towers_full()
+    e0, b0 = _glove_full()
+    mk = lambda full: torch.from_numpy(np.ascontiguousarray(full[rank::world])).to(dev)  # noqa: E731
+
+    def groups(workload, unique=None, grad_dtype=None):
+        if workload == "glove":
+            e = sharded.RowShardedTable(mk(e0), torch.full_like(mk(e0), 0.1), V_G)
+            b = sharded.RowShardedTable(mk(b0), torch.full_like(mk(b0), 0.1), V_G)
+            return (sharded.ShardedTableGroup([e], kernels=ops, unique=unique),
+                    sharded.ShardedTableGroup([b], kernels=ops, unique=unique))
+        scene = sharded.RowShardedTable(mk(st), torch.full_like(mk(st), 0.1), V_S)
+        prod = sharded.RowShardedTable(mk(pt), torch.full_like(mk(pt), 0.1), V_P)
+        return (sharded.ShardedTableGroup([scene, prod], kernels=ops, unique=unique, grad_dtype=grad_dtype),)
+
+    def tables_of(gs):
+        return [t.local.cpu().numpy().copy() for g in gs for t in g.tables] + \
+               [t.accum.cpu().numpy().copy() for g in gs for t in g.tables]
+
+    out = {}
+    # ---- (a) loop helper == per-step calls; bf16 gradient rows over the exchange ---------------------------------
+    trip = [tuple(torch.from_numpy(x).to(dev) for x in _batch(s, rank)) for s in range(N_STEPS)]
+    for name, grad_dtype, helper in (("steps", None, False), ("helper", None, True), ("bf16", "bf16", True)):
+        gs = groups("triplet", grad_dtype=grad_dtype)
+        assert gs[0].exchange() is not None and gs[0]._fused() is not None, "the library's exchange must be under test"
+        if helper:
+            losses = sharded.sharded_train_steps("triplet", gs, trip, regularization=LAM,
+                                                 global_batch_size=float(world * B), lr=LR, plan_group=3)
+        else:
+            losses = [sharded.sharded_triplet_step(gs[0], *b, LAM, float(world * B), LR) for b in trip]
+        tabs = tables_of(gs)
+        out[name + "_scene"], out[name + "_prod"] = tabs[0], tabs[1]
+        out[name + "_loss"] = np.array([float(l) for l in losses])
+    # ---- (b) overlapped loop == sequential loop, Zipf ids --------------------------------------------------------
+    ztrip = [tuple(torch.from_numpy(x).to(dev) for x in _batch(s, rank, True)) for s in range(N_STEPS)]
+    zglove = []
+    for s in range(N_STEPS):
+        inp, tgt = _glove_batch(s, rank, True)
+        zglove.append((torch.from_numpy(inp).to(dev), torch.from_numpy(tgt).to(dev)))
+    patched = [0, 0]
+    real_patch = sharded.ShardedTableGroup.patch_rows
+
+    real_parts = sharded.StaleRows.c_parts
+
+    def counting_patch(self, plan, back):  # (in-batch: the patch is issued from Python)
+        patched[0] += int(plan.stale.ids.numel())
+        patched[1] += int(plan.stale.pos.numel())
+        return real_patch(self, plan, back)
+
+    def counting_parts(self, k):  # (triplet / GloVe: the patch is part of esr_sharded_*_step_overlapped)
+        patched[0] += int(self.ids.numel())
+        patched[1] += int(self.pos.numel())
+        return real_parts(self, k)
+
+    def run(workload, unique, overlap):
+        gs = groups(workload, unique=unique)
+        kw = dict(mode=ops.GLOVE_DIAGONAL) if workload == "glove" else \
+            dict(regularization=LAM, global_batch_size=float(world * B), scale=SCALE)
+        batches = zglove if workload == "glove" else ([b[:2] for b in ztrip] if workload == "inbatch" else ztrip)
+        losses = sharded.sharded_train_steps(workload, gs, batches, lr=LR, plan_group=3, overlap=overlap, **kw)
+        torch.cuda.synchronize()
+        return tables_of(gs), np.array([float(l) for l in losses])
+
+    for workload in ("triplet", "inbatch", "glove"):
+        for unique in (True, False):
+            key = "%s_%d" % (workload, unique)
+            want_t, want_l = run(workload, unique, False)
+            sharded.ShardedTableGroup.patch_rows, sharded.StaleRows.c_parts = counting_patch, counting_parts
+            patched[:] = [0, 0]
+            got_t, got_l = run(workload, unique, True)
+            sharded.ShardedTableGroup.patch_rows, sharded.StaleRows.c_parts = real_patch, real_parts
+            out[key + "_equal"] = np.array(all(np.array_equal(a, b) for a, b in zip(want_t, got_t)) and
+                                           np.array_equal(want_l, got_l))
+            out[key + "_patched"] = np.array(patched)
+            out[key + "_finite"] = np.array(all(np.isfinite(a).all() for a in got_t) and np.isfinite(got_l).all())
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), **out)
+    _finish(dist)
+
+
+def _w4_worker(rank, port, outdir, wire_lib):
+    world = 4
+    dist, dev = _init(rank, world, port, wire_lib)
+    from esrecsys_amd import ops, sharded
+    st, pt = _towers_full()
+    mk = lambda full: torch.from_numpy(np.ascontiguousarray(full[rank::world])).to(dev)  # noqa: E731
+    scene = sharded.RowShardedTable(mk(st), torch.full_like(mk(st), 0.1), V_S)
+    prod = sharded.RowShardedTable(mk(pt), torch.full_like(mk(pt), 0.1), V_P)
+    towers = sharded.ShardedTableGroup([scene, prod], kernels=ops)
+    x = towers.exchange()
+    assert x is not None and x.ranks_seen() == (world, rank)
+    trip = [tuple(torch.from_numpy(a).to(dev) for a in _batch(s, rank)) for s in range(3)]
+    losses = sharded.sharded_train_steps("triplet", (towers,), trip, regularization=LAM,
+                                         global_batch_size=float(world * B), lr=LR, plan_group=2)
+    tot = []
+    for l in losses:
+        t = l.detach().cpu().clone()
+        dist.all_reduce(t)
+        tot.append(float(t))
+    out = {"scene": scene.local.cpu().numpy(), "prod": prod.local.cpu().numpy(), "scene_acc": scene.accum.cpu().numpy(),
+           "losses": np.array(tot)}
+    # config 5: candidates row-sharded id mod 4, every rank asks its own queries
+    rng = np.random.default_rng(21)
+    cands = _grid(rng, (30_001, 64))
+    queries = _grid(np.random.default_rng(50 + rank), (33, 64))
+    s, i = sharded.sharded_find_top_k(torch.from_numpy(queries).to(dev),
+                                      torch.from_numpy(np.ascontiguousarray(cands[rank::world])).to(dev), 50)
+    out["topk_s"], out["topk_i"] = s.cpu().numpy(), i.cpu().numpy()
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), **out)
+    _finish(dist)
+
+
+def _spawn(worker, world):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    spec = importlib.util.spec_from_file_location("build_wire", os.path.join(ROOT, "tests", "wire", "build_wire.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    wire_lib = mod.build()
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(worker, args=(port, d, wire_lib), nprocs=world, join=True)
+        return [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(world)]
+
+
+@pytest.fixture(scope="module")
+def loops_outputs():
+    return _spawn(_loops_worker, 2)
+
+
+@pytest.fixture(scope="module")
+def w4_outputs():
+    return _spawn(_w4_worker, 4)
+
+
+@pytest.mark.timeout(900)
+def test_world2_loop_helper_equals_per_step_calls_and_bf16_gradient_exchange(loops_outputs):
+    st, pt = _towers_full()
+    for r, o in enumerate(loops_outputs):
+        assert np.array_equal(o["steps_scene"], o["helper_scene"]) and np.array_equal(o["steps_prod"], o["helper_prod"])
+        assert np.array_equal(o["steps_loss"], o["helper_loss"])
+        for key, full in (("scene", st), ("prod", pt)):
+            exact, half, start = o["helper_" + key], o["bf16_" + key], full[r::2]
+            moved = np.abs(exact - start).max()
+            err = np.abs(half - exact).max()
+            assert 0.0 < err <= 2.0 ** -7 * moved, (key, err, moved)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("workload", ["triplet", "inbatch", "glove"])
+def test_world2_overlapped_loop_equals_sequential_loop_bit_for_bit(loops_outputs, workload):
+    for unique in (1, 0):
+        key = "%s_%d" % (workload, unique)
+        assert all(bool(o[key + "_finite"]) for o in loops_outputs), key
+        assert all(bool(o[key + "_equal"]) for o in loops_outputs), key
+        sent = sum(int(o[key + "_patched"][0]) for o in loops_outputs)  # rows were re-served: sent == received
+        assert sent > 0 and sent == sum(int(o[key + "_patched"][1]) for o in loops_outputs), key
+
+
+@pytest.mark.timeout(900)
+def test_world4_triplet_equals_single_device(w4_outputs):
+    from oracle import optim as o_optim
+    from oracle import stl_head as o_stl
+    outs, world = w4_outputs, 4
+    st, pt = (t.astype(np.float64) for t in _towers_full())
+    a_s, a_p = np.full_like(st, 0.1), np.full_like(pt, 0.1)
+    for step in range(3):
+        parts = [_batch(step, r) for r in range(world)]
+        sid, pid, nid = (np.concatenate([p[i] for p in parts]) for i in range(3))
+        loss, gs, gp, gn = o_stl.triplet_loss_and_grads(st[sid], pt[pid], pt[nid], LAM, world * B, np.float64)
+        assert abs(outs[0]["losses"][step] - loss) <= 1e-5 * abs(loss)
+        st, a_s = o_optim.sparse_adagrad_update(st, a_s, sid, gs, LR, dtype=np.float64)
+        pt, a_p = o_optim.sparse_adagrad_update(pt, a_p, np.concatenate([pid, nid]), np.concatenate([gp, gn]), LR,
+                                                dtype=np.float64)
+
+    def full(key, V, width):
+        f = np.zeros((V, width))
+        for r in range(world):
+            f[r::world] = outs[r][key]
+        return f
+    for key, V, exp in (("scene", V_S, st), ("prod", V_P, pt), ("scene_acc", V_S, a_s)):
+        got = full(key, V, D)
+        assert np.abs(got - exp).max() <= 1e-5 * np.abs(exp).max(), key
+    assert all(o["losses"].tolist() == outs[0]["losses"].tolist() for o in outs)
+
+
+@pytest.mark.timeout(900)
+def test_world4_sharded_top_k_equals_brute_force(w4_outputs):
+    from oracle import topk as o_topk
+    cands = _grid(np.random.default_rng(21), (30_001, 64))
+    for r, o in enumerate(w4_outputs):
+        queries = _grid(np.random.default_rng(50 + r), (33, 64))
+        es, ei = o_topk.batched_top_k(queries, cands, 50, np.float64)
+        assert np.array_equal(o["topk_i"], ei)  # every tie: lower GLOBAL index first, across shards
+        assert np.array_equal(o["topk_s"], es.astype(np.float32))
