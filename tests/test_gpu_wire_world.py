@@ -287,3 +287,143 @@ def test_world4_sharded_top_k_equals_brute_force(w4_outputs):
         es, ei = o_topk.batched_top_k(queries, cands, 50, np.float64)
         assert np.array_equal(o["topk_i"], ei)  # every tie: lower GLOBAL index first, across shards
         assert np.array_equal(o["topk_s"], es.astype(np.float32))
+
+
+# ---- BASELINE config 4 at FULL size: 8 ranks x 12.5 M-row shards of two 100 M-row bf16 towers, all on one GPU -------
+C4_V, C4_B, C4_LAM, C4_LR, C4_SCALE, C4_WORLD = 100_000_000, 8192, 0.1, 0.05, 8.0, 8
+C4_NORM = 64.0  # the step's gradient normaliser (the reference divides by the batch size; 65 536 would leave most bf16
+#                 elements where they were -- updates far below one bf16 step -- and the comparison without teeth)
+
+
+def _c4_ids(rank):
+    ids = np.random.default_rng(900 + rank).integers(0, C4_V, (2, C4_B)).astype(np.int32)
+    ids[0, :4] = ids[0, 4]   # a few duplicates inside a batch
+    if rank > 0:
+        ids[1, :8] = _c4_ids(0)[1, :8]  # ... and rows that several ranks touch in the same step
+    return ids
+
+
+def _config4_worker(rank, port, outdir, wire_lib, grad_dtype):
+    world = C4_WORLD
+    dist, dev = _init(rank, world, port, wire_lib)
+    from esrecsys_amd import ops, sharded
+    n_local = sharded.RowShardedTable.local_rows_for(C4_V, world, rank)
+    g = torch.Generator(device=dev).manual_seed(1701 + rank)
+    tabs = []
+    for _ in range(2):
+        t = torch.empty((n_local, D), device=dev, dtype=torch.bfloat16)
+        for lo in range(0, n_local, 2_500_000):  # fill in slices: no 6.4 GB fp32 temporary
+            n = min(2_500_000, n_local - lo)
+            t[lo:lo + n] = (torch.randn((n, D), generator=g, device=dev) * D ** -0.5).to(torch.bfloat16)
+        tabs.append(sharded.RowShardedTable(t, torch.full((n_local, D), 0.1, device=dev), C4_V))
+    towers = sharded.ShardedTableGroup(tabs, kernels=ops, grad_dtype=grad_dtype)
+    assert towers.exchange() is not None and towers.exchange().ranks_seen() == (world, rank)
+    every = [_c4_ids(r) for r in range(world)]
+    out = {}
+    mine = []
+    for t in range(2):
+        touched = np.unique(np.concatenate([e[t] for e in every]))
+        own = touched[touched % world == rank]
+        mine.append(torch.from_numpy(own // world).to(dev).long())
+        out["ids%d" % t] = own
+        out["before%d" % t] = tabs[t].local[mine[t]].float().cpu().numpy()
+    sums0 = [tb.local.view(torch.int16).sum(dtype=torch.int64) for tb in tabs]
+    sid, pid = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in every[rank])
+    loss = sharded.sharded_inbatch_step(towers, sid, pid, C4_LAM, C4_NORM, C4_SCALE, C4_LR)
+    torch.cuda.synchronize()
+    out["loss"] = np.array(float(loss))
+    for t in range(2):
+        after = tabs[t].local[mine[t]]
+        out["after%d" % t] = after.float().cpu().numpy()
+        out["acc%d" % t] = tabs[t].accum[mine[t]].cpu().numpy()
+        # rows nobody touched are bit-untouched: the shard's sum of bf16 bit patterns moves by the touched rows' change only
+        before_bits = torch.from_numpy(out["before%d" % t]).to(torch.bfloat16).to(dev).view(torch.int16).sum(dtype=torch.int64)
+        delta = after.view(torch.int16).sum(dtype=torch.int64) - before_bits
+        out["checksum_ok%d" % t] = np.array(int(tabs[t].local.view(torch.int16).sum(dtype=torch.int64) - sums0[t]) == int(delta))
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), **out)
+    _finish(dist)
+
+
+def _spawn_c4(grad_dtype):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    free, _total = torch.cuda.mem_get_info()
+    if free < 200 * 2 ** 30:
+        pytest.skip("config 4 at full size needs ~160 GB of HBM on one device (free: %.0f GB)" % (free / 2 ** 30))
+    torch.cuda.empty_cache()
+    spec = importlib.util.spec_from_file_location("build_wire", os.path.join(ROOT, "tests", "wire", "build_wire.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_config4_worker, args=(port, d, mod.build(), grad_dtype), nprocs=C4_WORLD, join=True)
+        return [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(C4_WORLD)]
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("grad_dtype", ["f32", "bf16"])
+def test_config4_full_size_eight_shards_on_one_gpu(grad_dtype):
+    """BASELINE configs[3] -- two 100 M-row x 128 bf16 towers (fp32 Adagrad accumulators) row-sharded id mod 8, B = 8192
+    in-batch pairs per rank -- as EIGHT processes on one GPU (154 GB of its 288 GB), the library's exchange over the
+    loopback wire: ids -> bucket -> ids exchange -> gather -> rows exchange -> one-plane score kernels -> gradient exchange
+    (f32, or bf16: SURVEY 8d's 910 B/pair budget) -> owner-side segment sum + Adagrad with RNE rounding to bf16.  Every
+    row any rank touches is checked against the fp64 oracle of the UNSHARDED step (per-rank in-batch negatives, one
+    gradient normaliser, one global sparse update); every other row of all sixteen shards is bit-untouched."""
+    from oracle import optim as o_optim
+    from oracle import stl_head as o_stl
+    from conftest import _log_err
+    outs = _spawn_c4(grad_dtype)
+    world = C4_WORLD
+    rows, accs, afters = [{}, {}], [{}, {}], [{}, {}]
+    for o in outs:
+        for t in range(2):
+            assert bool(o["checksum_ok%d" % t])
+            for gid, b, a, c in zip(o["ids%d" % t], o["before%d" % t], o["after%d" % t], o["acc%d" % t]):
+                rows[t][int(gid)], afters[t][int(gid)], accs[t][int(gid)] = b.astype(np.float64), a, c
+    ids_all, grads_all = [[], []], [[], []]
+    for r in range(world):
+        ids = _c4_ids(r)
+        q = np.stack([rows[0][int(i)] for i in ids[0]])
+        c = np.stack([rows[1][int(i)] for i in ids[1]])
+        el, _, gq, gc = o_stl.inbatch_softmax_loss_and_grads(q, c, C4_LAM, C4_NORM, C4_SCALE, np.float64)
+        assert abs(float(outs[r]["loss"]) - el) <= 1e-5 * abs(el), (r, float(outs[r]["loss"]), el)
+        for t, (i, g) in enumerate(((ids[0], gq), (ids[1], gc))):
+            ids_all[t].append(i), grads_all[t].append(g)
+    worst = {}
+    for t in range(2):
+        ih = np.concatenate(ids_all[t])
+        uniq = np.unique(ih)
+        assert len(uniq) == len(rows[t])
+        start = np.stack([rows[t][int(i)] for i in uniq])
+        new_rows, new_acc = o_optim.sparse_adagrad_update(start, np.full(start.shape, 0.1), np.searchsorted(uniq, ih),
+                                                          np.concatenate(grads_all[t]), C4_LR, dtype=np.float64)
+        got = np.stack([afters[t][int(i)] for i in uniq])
+        acc = np.stack([accs[t][int(i)] for i in uniq])
+        exp_bf16 = torch.from_numpy(new_rows).to(torch.bfloat16).float().numpy()
+        same = float(np.mean(got == exp_bf16))
+        # one bf16 step at the scale of the OPERANDS (an element that cancels to ~0 carries the f32 error of its operands,
+        # many steps of its own tiny exponent: 17 M elements per tower always hold a few of those)
+        ulp = np.maximum(np.abs(exp_bf16), np.abs(start)) * 2.0 ** -7 + 1e-30
+        allowed = ulp  # RNE of an fp32 update vs the fp64 one may land on the neighbouring bf16 value, never further away
+        if grad_dtype == "bf16":
+            # every gradient row crosses the exchange rounded to bf16 (2^-9 per element, per sender): the summed gradient G
+            # of an element is off by <= 2^-9 sum_r |g_r| -- more than 2^-9 |G| where the ranks' contributions cancel, as
+            # on the rows all eight ranks touch -- and u = lr G / sqrt(acc) moves by <= lr / sqrt(acc) times that
+            remap = np.searchsorted(uniq, ih)
+            A = np.zeros_like(start)
+            np.add.at(A, remap, np.abs(np.concatenate(grads_all[t])))
+            allowed = ulp + 2.0 * C4_LR * 2.0 ** -9 * A / np.sqrt(new_acc)
+        worst_ulps = float((np.abs(got - exp_bf16) / allowed).max())
+        acc_err = float(np.abs(acc - new_acc).max() / np.abs(new_acc).max())
+        worst["tower%d" % t] = (same, worst_ulps, acc_err)
+        assert worst_ulps <= 1.0, worst
+        assert same > (0.999 if grad_dtype == "f32" else 0.95), worst
+        assert acc_err <= (1e-5 if grad_dtype == "f32" else 2.0 ** -7), worst
+        assert float(np.mean(got != start.astype(np.float32))) > 0.5  # the step did move the touched rows
+    for k, v in worst.items():  # -> gpurun_out/parity_errors.json
+        _log_err(k + "_rows_not_equal_to_rne_bf16_of_fp64_frac", 1.0 - v[0], len(rows[0]) * D)
+        _log_err(k + "_worst_row_error_over_allowed", v[1], len(rows[0]) * D)
+        _log_err(k + "_accumulator_rel_err", v[2], len(rows[0]) * D)
