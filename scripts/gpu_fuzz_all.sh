@@ -5,3 +5,4 @@ for f in "fuzz_ops.py 80" "fuzz_loops.py 45" "fuzz_steps.py 60" "fuzz_routing.py
   echo "$1: $(SEED=$S CASES=$2 timeout 900 python scripts/$1 2>&1 | grep -E "MISMATCH|BEYOND|cases|Error|error|fault" | tail -3)"
 done
 echo "fuzz_sharded_w1.py: $(SEED=$S CASES=16 timeout 900 python scripts/fuzz_sharded_w1.py 2>&1 | grep -E "MISMATCH|cases|Error|fault" | tail -3)"
+echo "fuzz_sharded_gloo.py WIRE=1 (world 2-4 on this GPU, real kernels, loopback wire): $(WIRE=1 SEED=$S CASES=14 PYTHONPATH=$PWD timeout 900 python scripts/fuzz_sharded_gloo.py 2>&1 | grep -E "MISMATCH|cases|Error|fault" | tail -3)"
