@@ -341,7 +341,11 @@ __global__ __launch_bounds__(kGThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
     const float* tau_w = tau_s + wm * 64 + 4 * h;
     const bool c_ok0 = n0 + wn * 64 + l31 < nvalid, c_ok1 = n0 + wn * 64 + 32 + l31 < nvalid;
     const int mrow = m0 + wm * 64 + 4 * h;  // + i*32 + 8*(e/4) + e%4
+    // Most (row pair, wave) cells hold no survivor once the thresholds have tightened (k of N candidates pass): pass 1
+    // tests a row pair with two compares and one wave-wide OR, and only a cell with a survivor pays for the ballots and
+    // counts; `rows` remembers those cells (bit i*16 + e), so pass 2 revisits them alone.
     int my_cnt = 0;
+    uint32_t rows = 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       float tau_r[16];  // 16 thresholds at a time: the kernel must stay within 128 VGPRs (two workgroups per CU)
@@ -349,28 +353,30 @@ __global__ __launch_bounds__(kGThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
       for (int e = 0; e < 16; ++e) tau_r[e] = tau_w[i * 32 + 8 * (e >> 2) + (e & 3)];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const unsigned long long b0 = __ballot(c_ok0 && acc[i][0][e] >= tau_r[e]);
-        const unsigned long long b1 = __ballot(c_ok1 && acc[i][1][e] >= tau_r[e]);
+        const bool p0 = c_ok0 && acc[i][0][e] >= tau_r[e];
+        const bool p1 = c_ok1 && acc[i][1][e] >= tau_r[e];
+        if (__ballot(p0 || p1) == 0) continue;  // wave-uniform
+        rows |= 1u << (i * 16 + e);
+        const unsigned long long b0 = __ballot(p0), b1 = __ballot(p1);
         const int c = __popc((uint32_t)(b0 >> (32 * h))) + __popc((uint32_t)(b1 >> (32 * h)));
         if (l31 == i * 16 + e) my_cnt = c;
       }
     }
-    const int my_m = mrow + (l31 >> 4) * 32 + 8 * ((l31 & 15) >> 2) + (l31 & 3);
-    int my_slot = 0;
-    if (my_cnt > 0) my_slot = atomicAdd(o.cnt + my_m, my_cnt);
-    if (__ballot(my_cnt > 0)) {
+    rows = __builtin_amdgcn_readfirstlane(rows);
+    if (rows) {
+      const int my_m = mrow + (l31 >> 4) * 32 + 8 * ((l31 & 15) >> 2) + (l31 & 3);
+      int my_slot = 0;
+      if (my_cnt > 0) my_slot = atomicAdd(o.cnt + my_m, my_cnt);
       const uint32_t below = (1u << l31) - 1u;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        float tau_r[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) tau_r[e] = tau_w[i * 32 + 8 * (e >> 2) + (e & 3)];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const bool p0 = c_ok0 && acc[i][0][e] >= tau_r[e];
-          const bool p1 = c_ok1 && acc[i][1][e] >= tau_r[e];
+          if (!((rows >> (i * 16 + e)) & 1u)) continue;  // wave-uniform
+          const float tau = tau_w[i * 32 + 8 * (e >> 2) + (e & 3)];
+          const bool p0 = c_ok0 && acc[i][0][e] >= tau;
+          const bool p1 = c_ok1 && acc[i][1][e] >= tau;
           const unsigned long long b0 = __ballot(p0), b1 = __ballot(p1);
-          if ((b0 | b1) == 0) continue;  // wave-uniform
           const uint32_t h0 = (uint32_t)(b0 >> (32 * h)), h1 = (uint32_t)(b1 >> (32 * h));
           const int slot = __shfl(my_slot, 32 * h + i * 16 + e, 64);
           const int m = mrow + i * 32 + 8 * (e >> 2) + (e & 3);
