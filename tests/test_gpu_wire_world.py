@@ -347,10 +347,12 @@ def _config4_worker(rank, port, outdir, wire_lib, grad_dtype):
 def _spawn_c4(grad_dtype):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()  # what earlier tests of this process left in torch's caching allocator
     free, _total = torch.cuda.mem_get_info()
-    if free < 200 * 2 ** 30:
+    if free < 180 * 2 ** 30:
         pytest.skip("config 4 at full size needs ~160 GB of HBM on one device (free: %.0f GB)" % (free / 2 ** 30))
-    torch.cuda.empty_cache()
     spec = importlib.util.spec_from_file_location("build_wire", os.path.join(ROOT, "tests", "wire", "build_wire.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
