@@ -429,3 +429,41 @@ def test_config4_full_size_eight_shards_on_one_gpu(grad_dtype):
         _log_err(k + "_rows_not_equal_to_rne_bf16_of_fp64_frac", 1.0 - v[0], len(rows[0]) * D)
         _log_err(k + "_worst_row_error_over_allowed", v[1], len(rows[0]) * D)
         _log_err(k + "_accumulator_rel_err", v[2], len(rows[0]) * D)
+
+
+# ---- the driver's N > 1 command, end to end ------------------------------------------------------------------------
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("n,workload,overlap", [(2, "inbatch", "0"), (4, "triplet", "1"), (2, "glove", "0")])
+def test_bench_gpus_n_command_dry_run(n, workload, overlap):
+    """`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` -- the command the driver times on an
+    N-GPU node -- run here with every rank on cuda:0 over the loopback wire (ESR_WIRE_ONE_GPU=1): plans in groups, the
+    one-call sharded steps (overlap=1: the overlapped loop), barrier + max-over-ranks timing, rank 0's ONE JSON line.
+    The value is not a measurement; that the line comes out, carries the contract's keys and a finite loss is the test."""
+    import json
+    import subprocess
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    spec = importlib.util.spec_from_file_location("build_wire", os.path.join(ROOT, "tests", "wire", "build_wire.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, ESR_WIRE_ONE_GPU="1", ESR_RCCL_LIB=mod.build(), ESR_SHARDED_OVERLAP=overlap,
+               HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    args = ["--batch", "16384"] if workload == "glove" else []  # (the C3 batch works too; this keeps the test short)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "6",
+           "--warmup", "3", "--workload", workload, "--no-cpu-baseline"] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == n and d["steps"] == 6 and d["warmup"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["rccl_ranks"] == n and d["config"]["world_size"] == n
+    assert np.isfinite(d["config"]["loss"])
+    assert ("DRY RUN" in d["config"]["exchange"]) and (d["config"]["overlap"] != "off") == (overlap == "1")
