@@ -163,11 +163,16 @@ def run_retrieve(args, emit):
     from esrecsys_amd.pinterest.make_recommendations import find_top_k_batch, recall_at_k
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    # (ESR_WIRE_ONE_GPU=1 + ESR_RCCL_LIB: the dry run of bench.py -- every rank on cuda:0, gloo, the loopback wire)
+    one_gpu_wire = world > 1 and os.environ.get("ESR_WIRE_ONE_GPU") == "1" and bool(os.environ.get("ESR_RCCL_LIB"))
+    dev = torch.device("cuda", 0 if one_gpu_wire else int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_gpu_wire:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     # weak scaling would grow the candidate set with N; config 5 fixes it at 1M rows, so at N = 1 one GPU holds
     # the share it would hold in the 8-GPU job (131 072 rows) and N GPUs hold N such shares
     n_local = int(args.rows) if getattr(args, "rows", None) else N_TOTAL // 8   # (--rows 1048576: the whole config on one GPU)
@@ -197,7 +202,7 @@ def run_retrieve(args, emit):
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
     # dominant kernel = the score GEMM; HIP events around the op on the launch stream (rank 0)
@@ -246,7 +251,9 @@ def run_retrieve(args, emit):
             "config": {"workload": "retrieve: %d queries/GPU x %d candidates (%d per GPU, id mod N) x D=%d, k=%d"
                                    % (NQ, n_local * world, n_local, D, K), "mode": mode,
                        "parallelism": "single" if world == 1 else "candidates row-sharded x%d, all-gather queries + "
-                                                                  "all-to-all partial top-k" % world, **extra},
+                                                                  "all-to-all partial top-k" % world,
+                       **({"exchange": "DRY RUN over the loopback wire (every rank on ONE GPU): not a scaling measurement"}
+                          if one_gpu_wire else {}), **extra},
             "roofline": {"kernel": "score_gemm_kernel (+ split, select)", "bound": "mfma",
                          "achieved": planes * flops / t_op / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": planes * flops / t_op / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,

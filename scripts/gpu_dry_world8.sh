@@ -16,3 +16,4 @@ BARGS="--workload inbatch" run w2_inbatch_overlap 2 ESR_SHARDED_OVERLAP=1
 BARGS="--workload triplet" run w4_triplet_overlap 4 ESR_SHARDED_OVERLAP=1
 BARGS="--workload glove" run w2_glove_overlap 2 ESR_SHARDED_OVERLAP=1
 BARGS="--workload inbatch --rows 100000000 --table-dtype bf16" run w8_config4_full 8 ESR_SHARDED_GRAD_DTYPE=bf16
+BARGS="--workload retrieve --steps 2 --warmup 1" run w8_config5_retrieve 8 A=1

@@ -467,3 +467,95 @@ def test_bench_gpus_n_command_dry_run(n, workload, overlap):
     assert d["config"]["rccl_ranks"] == n and d["config"]["world_size"] == n
     assert np.isfinite(d["config"]["loss"])
     assert ("DRY RUN" in d["config"]["exchange"]) and (d["config"]["overlap"] != "off") == (overlap == "1")
+
+
+# ---- replicated mode (SURVEY 8e's other mode: full tables per rank, all-gather of ids + gradient rows) at world 2 -----
+def _replicated_worker(rank, port, outdir, wire_lib):
+    world = 2
+    dist, dev = _init(rank, world, port, wire_lib)
+    from esrecsys_amd import ops, replicated
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    out = {}
+    for workload in ("triplet", "inbatch"):
+        st, pt = (T(x) for x in _towers_full())
+        rep = replicated.ReplicatedTables([st, pt], [torch.full_like(st, 0.1), torch.full_like(pt, 0.1)], kernels=ops)
+        assert rep.coll.x is not None and rep.coll.x.ranks_seen() == (world, rank), "the library's exchange must be under test"
+        losses = []
+        for step in range(3):
+            sid, pid, nid = (T(a) for a in _batch(step, rank))
+            if workload == "triplet":
+                loss = replicated.replicated_triplet_step(rep, sid, pid, nid, LAM, float(world * B), LR)
+            else:
+                loss = replicated.replicated_inbatch_step(rep, sid, pid, LAM, float(world * B), SCALE, LR)
+            t = loss.detach().cpu().clone()
+            dist.all_reduce(t)
+            losses.append(float(t))
+        out[workload + "_scene"], out[workload + "_prod"] = st.cpu().numpy(), pt.cpu().numpy()
+        out[workload + "_acc"] = rep.accums[0].cpu().numpy()
+        out[workload + "_losses"] = np.array(losses)
+    e0, b0 = _glove_full()
+    emb, bias = T(e0), T(b0)
+    rep_e = replicated.ReplicatedTables([emb], [torch.full_like(emb, 0.1)], kernels=ops)
+    rep_b = replicated.ReplicatedTables([bias], [torch.full_like(bias, 0.1)], kernels=ops)
+    for step in range(3):
+        inp, tgt = _glove_batch(step, rank)
+        replicated.replicated_glove_step(rep_e, rep_b, T(inp), T(tgt), ops.GLOVE_DIAGONAL, LR)
+    out["glove_emb"], out["glove_bias"] = emb.cpu().numpy(), bias.cpu().numpy()
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), **out)
+    _finish(dist)
+
+
+@pytest.fixture(scope="module")
+def replicated_outputs():
+    return _spawn(_replicated_worker, 2)
+
+
+@pytest.mark.timeout(900)
+def test_world2_replicated_steps_equal_single_device_and_replicas_agree(replicated_outputs):
+    from oracle import glove as o_glove
+    from oracle import optim as o_optim
+    from oracle import stl_head as o_stl
+    outs, world = replicated_outputs, 2
+    for key in outs[0]:
+        assert np.array_equal(outs[0][key], outs[1][key]), "the replicas must be bit-identical: " + key
+    close = lambda got, exp: np.abs(got - exp).max() <= 1e-5 * max(np.abs(exp).max(), 1e-30)  # noqa: E731
+    # triplet: one global step over the concatenated batch
+    st, pt = (t.astype(np.float64) for t in _towers_full())
+    a_s, a_p = np.full_like(st, 0.1), np.full_like(pt, 0.1)
+    for step in range(3):
+        parts = [_batch(step, r) for r in range(world)]
+        sid, pid, nid = (np.concatenate([p[i] for p in parts]) for i in range(3))
+        loss, gs, gp, gn = o_stl.triplet_loss_and_grads(st[sid], pt[pid], pt[nid], LAM, world * B, np.float64)
+        assert abs(outs[0]["triplet_losses"][step] - loss) <= 1e-5 * abs(loss)
+        st, a_s = o_optim.sparse_adagrad_update(st, a_s, sid, gs, LR, dtype=np.float64)
+        pt, a_p = o_optim.sparse_adagrad_update(pt, a_p, np.concatenate([pid, nid]), np.concatenate([gp, gn]), LR,
+                                                dtype=np.float64)
+    assert close(outs[0]["triplet_scene"], st) and close(outs[0]["triplet_prod"], pt) and close(outs[0]["triplet_acc"], a_s)
+    # in-batch: per-rank negatives, one shared table
+    st, pt = (t.astype(np.float64) for t in _towers_full())
+    a_s, a_p = np.full_like(st, 0.1), np.full_like(pt, 0.1)
+    for step in range(3):
+        ids_s, ids_p, g_s, g_p, total = [], [], [], [], 0.0
+        for r in range(world):
+            sid, pid, _ = _batch(step, r)
+            loss, _, gq, gc = o_stl.inbatch_softmax_loss_and_grads(st[sid], pt[pid], LAM, world * B, SCALE, np.float64)
+            total += loss
+            ids_s.append(sid), ids_p.append(pid), g_s.append(gq), g_p.append(gc)
+        assert abs(outs[0]["inbatch_losses"][step] - total) <= 1e-5 * abs(total)
+        st, a_s = o_optim.sparse_adagrad_update(st, a_s, np.concatenate(ids_s), np.concatenate(g_s), LR, dtype=np.float64)
+        pt, a_p = o_optim.sparse_adagrad_update(pt, a_p, np.concatenate(ids_p), np.concatenate(g_p), LR, dtype=np.float64)
+    assert close(outs[0]["inbatch_scene"], st) and close(outs[0]["inbatch_prod"], pt)
+    # GloVe, diagonal mode: each rank's batch gradients applied to one table
+    emb, bias = (t.astype(np.float64) for t in _glove_full())
+    a_e, a_b = np.full_like(emb, 0.1), np.full_like(bias, 0.1)
+    for step in range(3):
+        ids_all, rows_all, gb_all = [], [], []
+        for r in range(world):
+            inp, tgt = _glove_batch(step, r)
+            _, gdot, gs = o_glove.loss_and_grads(emb, bias, inp, tgt.astype(np.float64), "diagonal", np.float64)
+            ids, rows, gb = o_glove.row_grads(emb, inp, gdot, gs, np.float64)
+            ids_all.append(ids), rows_all.append(rows), gb_all.append(gb)
+        ids_c = np.concatenate(ids_all)
+        emb, a_e = o_optim.sparse_adagrad_update(emb, a_e, ids_c, np.concatenate(rows_all), LR, dtype=np.float64)
+        bias, a_b = o_optim.sparse_adagrad_update(bias, a_b, ids_c, np.concatenate(gb_all)[:, None], LR, dtype=np.float64)
+    assert close(outs[0]["glove_emb"], emb) and close(outs[0]["glove_bias"], bias)
