@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/socket.h>
+#include <sys/time.h>
 #include <sys/un.h>
 #include <time.h>
 #include <unistd.h>
@@ -174,6 +175,15 @@ int post(bool send, void* p, size_t n, int peer, Comm* c, hipStream_t s) {
   return kOk;
 }
 
+// a peer that stops reading (or writing) must not hang a GPU box: both directions of every connection time out
+void set_timeouts(int fd) {
+  timeval tv;
+  tv.tv_sec = timeout_ms() / 1000;
+  tv.tv_usec = 0;
+  setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
+  setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+}
+
 void close_all(Comm* c) {
   for (int f : c->fd)
     if (f >= 0) close(f);
@@ -227,6 +237,7 @@ int ncclCommInitRank(Comm** out, int world, Uid uid, int rank) {
       delete c;
       return kSystemError;
     }
+    set_timeouts(f);
     c->fd[p] = f;
   }
   for (int k = rank + 1; k < world; ++k) {  // accept every higher rank (in whatever order they arrive)
@@ -240,6 +251,7 @@ int ncclCommInitRank(Comm** out, int world, Uid uid, int rank) {
       delete c;
       return kSystemError;
     }
+    set_timeouts(f);
     c->fd[who] = f;
   }
   *out = c;
