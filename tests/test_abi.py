@@ -145,3 +145,25 @@ def test_io_library_exports_its_header():
     for name in declared:
         assert hasattr(lib, name)
     assert lib.esr_io_version() >= 100
+
+
+def test_loopback_wire_exports_what_esr_comm_binds():
+    """tests/wire's loopback wire (TEST INFRASTRUCTURE: world > 1 on a one-GPU box) stands in for librccl through
+    ESR_RCCL_LIB: it must export exactly the symbols esr_comm.hip looks up (ESR_SYM list), no more of RCCL's surface."""
+    import importlib.util
+    import subprocess
+    text = open(os.path.join(ROOT, "esrecsys_amd", "csrc", "esr_comm.hip")).read()
+    bound = sorted(set(re.findall(r'ESR_SYM\(\w+,\s*\w+,\s*"(nccl\w+)"\)', text)))
+    assert len(bound) == 12
+    spec = importlib.util.spec_from_file_location("build_wire", os.path.join(ROOT, "tests", "wire", "build_wire.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lib_path = mod.build()
+    out = subprocess.run(["nm", "-D", "--defined-only", lib_path], capture_output=True, text=True, check=True).stdout
+    exported = sorted(l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("nccl"))
+    assert exported == bound
+    # and nothing under esrecsys_amd/ names it: the product binds torch's librccl unless ESR_RCCL_LIB says otherwise
+    for root, _dirs, files in os.walk(os.path.join(ROOT, "esrecsys_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".c")):
+                assert "loopback_wire" not in open(os.path.join(root, f), errors="ignore").read(), os.path.join(root, f)
