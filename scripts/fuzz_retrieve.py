@@ -23,7 +23,11 @@ for case in range(N_):
         c[rng.integers(0, N, max(1, N // 50))] *= 30.0     # outlier rows
     full = q.astype(np.float64) @ c.astype(np.float64).T
     kth = -np.sort(-full, axis=1)[:, k - 1]
-    scale = np.abs(full).max()
+    # the error of a dot product scales with |q| |c|, not with the score: with one query and one candidate the only score
+    # can cancel to far below that (seed 505: nq = N = k = 1, D = 96 in the one-plane bf16 mode) -- never let the yardstick
+    # fall below the typical score of such a pair
+    scale = max(np.abs(full).max(), np.linalg.norm(q.astype(np.float64), axis=1).max() *
+                np.linalg.norm(c.astype(np.float64), axis=1).max() / np.sqrt(D))
     base, step = int(rng.integers(0, 100)), int(rng.choice([1, 2, 8]))
     for mode in ("exact", "f16x2", "bf16x3", "bf16"):
         s, i = ops.retrieve_topk(torch.from_numpy(q).to(dev), torch.from_numpy(c).to(dev), k, mode=mode, index_base=base, index_step=step)
