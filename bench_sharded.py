@@ -47,7 +47,10 @@ def run_sharded(args, cfg, dev, rank, world):
         emb = sharded.ShardedTableGroup([emb_t], kernels=ops)
         bias = sharded.ShardedTableGroup([bias_t], kernels=ops)
     else:
-        towers = sharded.ShardedTableGroup([shard(V, D), shard(V, D)], kernels=ops)  # scene, product
+        # bf16 towers (BASELINE config 4): the gradient rows cross the exchange as bf16 too -- SURVEY 8d's 910 B/pair budget;
+        # a bf16 row keeps 8 significant bits of its update anyway (ESR_SHARDED_GRAD_DTYPE=f32 to send them wide)
+        gd = os.environ.get("ESR_SHARDED_GRAD_DTYPE") or ("bf16" if cfg.get("table_dtype") == "bf16" else "f32")
+        towers = sharded.ShardedTableGroup([shard(V, D), shard(V, D)], kernels=ops, grad_dtype=gd)  # scene, product
     grp0 = None if replicated_mode else (emb if args.workload == "glove" else towers)
     # no routing plans where nothing is routed: the replicated mode, and a world of one rank taking the single-GPU steps
     no_plans = replicated_mode or grp0.world1_direct
@@ -208,6 +211,7 @@ def run_sharded(args, cfg, dev, rank, world):
                                       world, B),
                        "parallelism": par,
                        "exchange": exchange, "rccl_ranks": rccl_ranks, "world_size": world,
+                       "gradient_rows_on_the_wire": getattr(grp0, "grad_dtype", "f32") if grp0 is not None else "f32",
                        "routing_plans": ("made for %d coming batches at a time (one bucket launch pair, one counts "
                                          "all-to-all, one RCCL group of ids exchanges, one owner-side sort per group)"
                                          % plan_group) if plan_group > 1 else "one per step, pipelined two batches deep",
