@@ -1447,7 +1447,11 @@ __global__ __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __re
       const int nxt = cur == kRing - 1 ? 0 : cur + 1;
       const int nn = (cur + kAheadSlots) % kRing;
       H_TICK(tk0);
+#if defined(H_PROBE_PC_NOBAR)
+      if (it > 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(H8_BAR_VM) : "memory");
+#else
       if (it > 0) H8_BARRIER();
+#endif
       H_TICK(tk1);
       const char* buf = lds + cur * kBuf;
       const char* nbuf = lds + nxt * kBuf;
@@ -1460,7 +1464,13 @@ __global__ __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __re
       const int nxt = cur == kRing - 1 ? 0 : cur + 1;
       const int nn = (cur + kAheadSlots) % kRing;
       H_TICK(tk0);
+#if defined(H_PROBE_PC_HALFBAR) || defined(H_PROBE_PC_NOBAR)
+      /* timing probes only (results wrong: ring slots are overwritten under their readers): what would a loop with half
+         the workgroup barriers -- two chunks per barrier, a deeper ring -- or with none cost? */
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(H8_BAR_VM) : "memory");
+#else
       H8_BARRIER();
+#endif
       H_TICK(tk1);
       const char* buf = lds + cur * kBuf;
       const char* nbuf = lds + nxt * kBuf;
