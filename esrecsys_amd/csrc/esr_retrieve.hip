@@ -278,6 +278,14 @@ __global__ __launch_bounds__(kGThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
     for (int p = 0; p < P; ++p)
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
+#if defined(ESR_PROBE_GEMM_HALF_FRAG)  /* timing probe only (results wrong): half the LDS fragment reads per MFMA -- what a
+                                          128 x 64 wave tile would buy at best */
+        if (r == 1) {
+          a[p][1] = a[p][0];
+          b[p][1] = b[p][0];
+          continue;
+        }
+#endif
         a[p][r] = *reinterpret_cast<const bf16x8*>(st + p * kPlaneStage + fragA + r * 32 * kTileRowBytes);
         b[p][r] = *reinterpret_cast<const bf16x8*>(st + p * kPlaneStage + fragB + r * 32 * kTileRowBytes);
       }
