@@ -64,12 +64,14 @@ __device__ __forceinline__ uint32_t code_of(uint32_t vid, uint32_t byte, uint32_
 
 // ---- the plan of one batch: everything the update kernel needs besides the tables, from the ids alone ----------------
 struct TripPlan {
-  int* flags;                   // [0] parked: set by the update kernel when it parks a chunk partial; [1] direct mode:
-                                //     number of long runs (= entries of long_heads); [2 .. 63] unused
+  int* flags;                   // [0] parked: set by the update kernel when it parks a chunk partial; [2..3] direct mode:
+                                //     one 8-byte word, plan generation << 32 | number of long runs (= entries of
+                                //     long_heads); the rest unused
   unsigned long long* loss_acc; // [kFixAccWords]  fixed-point loss accumulator, zero before the update kernel
   uint2* meta;                  // [n]  stamped mode: {partner A | slot << 30, partner B} per sorted position;
                                 //      direct mode: the occurrence codes (see triplet_direct_plan_kernel) per OCCURRENCE
   uint32_t* cnt;                // [n]  direct mode: arrivals per run, at the run's head position; zero before the step
+                                //      (zeroed by the plan kernel, and again by the arrival that completes a run)
   int32_t* long_heads;          // [n / 9 + 1]  direct mode: head positions of the runs longer than kDirectMaxRun
   double* loss_part;            // [kMaxGrid]  direct mode: the update kernel's loss partial per workgroup
 };
@@ -535,8 +537,8 @@ __global__ __launch_bounds__(kBlock) void triplet_direct_plan_kernel(const int32
   q += align_up(sizeof(uint32_t) * (size_t)n, 256);
   int32_t* long_heads = (int32_t*)q;
   if (blockIdx.x == 0) {
-    // (flags[1], the tagged long-run count, is claimed by whichever workgroup finds the first long run)
-    if (threadIdx.x < 64 && threadIdx.x != 1) flags[threadIdx.x] = 0;
+    // (flags[2..3], the generation-tagged long-run count, is claimed by whichever workgroup finds the first long run)
+    if (threadIdx.x < 64 && (threadIdx.x >> 1) != 1) flags[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < kFixAccWords; i += kBlock) loss_acc[i] = 0ull;
   }
   bool any_long = false;
@@ -555,26 +557,25 @@ __global__ __launch_bounds__(kBlock) void triplet_direct_plan_kernel(const int32
     if (is_long) {
       any_long = true;
       if (lb == 0) {  // the run's first position joins the (order-free) list of long runs
-        // flags[1] = tag << 20 | count, tag = this plan call's generation: a count left by an earlier plan in this buffer
-        // (another tag) is replaced, not added to -- no fill launch in front of the plan kernel
-        unsigned* word = reinterpret_cast<unsigned*>(flags + 1);
-        const unsigned tag = ((unsigned)gen & 0xFFFu) << 20;
+        // the 8-byte word at flags[2..3] = generation << 32 | count, generation = this plan call's FULL 32-bit `gen`: a
+        // count left by an earlier plan in this buffer (another generation) is replaced, not added to -- no fill launch
+        // in front of the plan kernel, and no generation of a run (2^32 plan calls) can be mistaken for another (a
+        // 12-bit tag, rounds 3-4, came round again after 4096 groups)
+        unsigned long long* word = reinterpret_cast<unsigned long long*>(flags + 2);
+        const unsigned long long tag = (unsigned long long)(unsigned)gen << 32;
         unsigned slot;
         for (;;) {
-          const unsigned old = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((old & 0xFFF00000u) != tag) {
-            unsigned expect = old;
-            if (__hip_atomic_compare_exchange_strong(word, &expect, tag | 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+          const unsigned long long old = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((old >> 32) != (unsigned long long)(unsigned)gen) {
+            unsigned long long expect = old;
+            if (__hip_atomic_compare_exchange_strong(word, &expect, tag | 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_AGENT)) {
               slot = 0;
               break;
             }
-          } else {
-            const unsigned r = atomicAdd(word, 1u);
-            if ((r & 0xFFF00000u) == tag) {  // (always: once the tag is this call's, nobody replaces it)
-              slot = r & 0xFFFFFu;
-              break;
-            }
+          } else {  // (once the generation is this call's, nobody replaces it)
+            slot = (unsigned)__hip_atomic_fetch_add(word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
           }
         }
         if ((int64_t)slot < n / 9 + 1) long_heads[slot] = (int32_t)p;  // (always, for a buffer zeroed before its first plan)
@@ -773,6 +774,9 @@ __global__ __launch_bounds__(kBlock) void triplet_direct_kernel(DirectTowers tt,
 #pragma unroll
             for (int e = 0; e < VEC; ++e) sum.v[k][e] = __fadd_rn(sum.v[k][e], t.v[k][e]);
         }
+        // every arrival of the run has been counted (this one completed it): the counter goes back to zero, so the plan
+        // can feed another step (the same batch stepped again: ops.triplet_train_step(plan=...))
+        if (lig == 0) cnt[head] = 0u;
         step_here(row, accrow, own, a, sum);
       };
       if (sS && oS == (cs.y >> 29)) complete(cs, srow, tt.sacc + sid * D, S, aS);
@@ -814,7 +818,9 @@ __global__ __launch_bounds__(kBlock) void triplet_direct_long_kernel(DirectTower
   __shared__ float red[kBlock * VEC * NCH];
   const int tid = threadIdx.x, lig = tid & (G - 1), gidx = tid / G, NG = kBlock / G;
   const int nvec = D / VEC;
-  const int nlong = flags[1] & 0xFFFFF;  // (tag << 20 | count: something was parked, so the count is this plan's)
+  // (generation << 32 | count in flags[2..3]: something was parked, so the count is this plan's)
+  const int nlong = (int)min<unsigned long long>(*reinterpret_cast<const unsigned long long*>(flags + 2) & 0xFFFFFFFFull,
+                                                 (unsigned long long)(n / 9 + 1));
   for (int li = blockIdx.x; li < nlong; li += gridDim.x) {
     const int64_t head = long_heads[li];
     const uint32_t id = (uint32_t)sorted_ids[head];
@@ -909,12 +915,12 @@ static int launch_trip_plan(const int32_t* const* ids, int nbatch, const int32_t
   const int64_t n = 3 * B;
   const int gx = (int)std::min<int64_t>(kMaxGrid, cdiv(n, kBlock));
   if (trip_direct_mode()) {
-    // The long-run counters carry the plan call's generation as a tag (see the kernel): nothing to clear in front of it.
-    // gen == 0 (a plan made in line, inside a step call, in scratch memory that may hold anything -- also a word tagged 0):
-    // the word is cleared first.
+    // The long-run counters carry the plan call's full 32-bit generation (see the kernel): nothing to clear in front of
+    // it.  gen == 0 (a plan made in line, inside a step call, in scratch memory that may hold anything -- also a word of
+    // generation 0): the word is cleared first.
     // (same box, alternating runs at B = 8192: 23.56-23.62 us per step without the fill, 23.81-23.93 with it)
     if (gen == 0 &&
-        hipMemset2DAsync(plans + sizeof(int), stride ? stride : sizeof(int), 0, sizeof(int), (size_t)nbatch, st) != hipSuccess)
+        hipMemset2DAsync(plans + 2 * sizeof(int), stride ? stride : 2 * sizeof(int), 0, 2 * sizeof(int), (size_t)nbatch, st) != hipSuccess)
       return ESR_ELAUNCH;
     hipLaunchKernelGGL(triplet_direct_plan_kernel, dim3(gx, nbatch), dim3(kBlock), 0, st, sorted_ids, perm, B, plans, stride,
                        hints, gen);

@@ -559,22 +559,24 @@ class _FusedEpoch:
         return (self.start[0], (self.start[1] + 1) & 0xFFFFFFFF)
 
 
-def train_epoch(state, steps_per_epoch, train_it, consolidate=True):
+def train_epoch(state, steps_per_epoch, train_it, consolidate=True, losses_out=None):
     """Trains for an epoch (wikipedia/train_cooccurence.py:103-112).  Losses stay on the device until the
     epoch mean is taken, so the loop never synchronises.  With the build's sparse Adagrad every step is the
     one-pass step (``train_step``'s kernels, driven through a per-epoch context that keeps the per-step Python to one
     library call per group of steps); with the reference's dense Adam it is apply_model + update_model as there.
     consolidate (default): rows the one-pass steps left in the embedding table's second buffer are copied back before
-    the epoch returns, so every holder of the table tensor sees current rows (one launch over the displaced rows)."""
+    the epoch returns, so every holder of the table tensor sees current rows (one launch over the displaced rows).
+    losses_out: a list that receives the per-step losses as one device tensor [steps_per_epoch] (the reference keeps
+    them in ``losses`` before taking their mean, train_cooccurence.py:105-112)."""
     from ..train_state import quiet_gc
     with quiet_gc():  # (a full cyclic collection inside the loop is a 40 ms hole in the launch stream)
-        state, loss = _train_epoch(state, steps_per_epoch, train_it)
+        state, loss = _train_epoch(state, steps_per_epoch, train_it, losses_out)
     if consolidate:
         state.consolidate()
     return state, loss
 
 
-def _train_epoch(state, steps_per_epoch, train_it):
+def _train_epoch(state, steps_per_epoch, train_it, losses_out=None):
     if fused_step_available(state) and steps_per_epoch > 0:
         ctx = _FusedEpoch(state, steps_per_epoch)
         # Batches are fetched _PRESORT_DEPTH ahead so that their ids can be sorted on the side stream under the update
@@ -651,6 +653,8 @@ def _train_epoch(state, steps_per_epoch, train_it):
             logging.warning("train_epoch: host issued %d steps in %.1f us each (no sync yet)", steps_per_epoch,
                             (time.perf_counter() - t_host) / steps_per_epoch * 1e6)
         state = state.replace(step=state.step + steps_per_epoch)
+        if losses_out is not None:
+            losses_out.append(ctx.losses[:steps_per_epoch].clone())
         return state, float(ctx.losses[:steps_per_epoch].mean())
     epoch_loss = []
     for _ in range(steps_per_epoch):
@@ -659,6 +663,8 @@ def _train_epoch(state, steps_per_epoch, train_it):
         state = update_model(state, grads)
         epoch_loss.append(loss)
     train_loss = float(torch.stack(epoch_loss).mean()) if epoch_loss else float("nan")
+    if losses_out is not None and epoch_loss:
+        losses_out.append(torch.stack(epoch_loss))
     return state, train_loss
 
 

@@ -224,10 +224,12 @@ int esr_triplet_train_steps(float* scene, float* scene_shadow, uint8_t* scene_lo
 /* Plans of nbatch <= 8 coming batches of B triplets in one launch: ids[3 b + {0, 1, 2}] = scene / pos / neg id lists
  * of batch b, sorted_ids / perm = [nbatch, 3B] (esr_segment_sort_ids_batched layout), plans = nbatch x
  * esr_triplet_plan_bytes(B) bytes, 256-byte aligned; hints / gen as for esr_glove_plan (runs longer than 8 positions).
- * Direct mode: gen != 0 also tags the plan's long-run counter (a count left in the buffer by an earlier plan call is
- * replaced, no fill launch): pass a generation that differs, modulo 4096, from the one the buffer was last planned with
- * (a counter that grows by one per call does), and ZERO a plan buffer before its first use.  gen == 0: the counter is
- * cleared by a fill in front of the launch. */
+ * Direct mode: gen != 0 also tags the plan's long-run counter with the full 32-bit value (a count left in the buffer by
+ * an earlier plan call is replaced, no fill launch): pass a generation that differs from the one the buffer was last
+ * planned with (a counter that grows by one per call does), and ZERO a plan buffer before its first use.  gen == 0: the
+ * counter is cleared by a fill in front of the launch.  A direct-mode plan is left as planned by the step it feeds
+ * (the arrival that completes a run clears the run's counter), so it may feed another step of the SAME batch; a
+ * stamped-mode plan (ESR_TRIPLET_STEP=stamped) feeds exactly one step. */
 size_t esr_triplet_plan_bytes(int64_t B);
 int esr_triplet_plan(const int32_t* const* ids, int nbatch, int64_t B, int64_t Vs, const int32_t* sorted_ids,
                      const int32_t* perm, void* plans, int32_t* hints, int32_t gen, esr_stream_t stream);

@@ -85,3 +85,21 @@ def sgd_momentum_update(param, trace, grad, lr, momentum=0.9, dtype=None):
     dtype = dtype or param.dtype.type
     tr = grad.astype(dtype) + dtype(momentum) * trace.astype(dtype)
     return param.astype(dtype) - dtype(lr) * tr, tr
+
+
+def sparse_adagrad_update_inplace(param, accum, ids, rows, lr, eps=1e-7):
+    """``sparse_adagrad_update`` for config-size tables: same rule, the (fp64) ``param`` / ``accum`` arrays are
+    stepped IN PLACE on the distinct rows only and the per-id sums are one ``np.add.reduceat`` over the stably
+    sorted occurrences (same left-to-right order per id as ``segment_sum_rows``; pairwise inside NumPy, which in
+    fp64 is ~1e-16 of the sum).  Returns the distinct ids.  tests/test_oracle.py pins it to the plain function."""
+    ids = np.asarray(ids, np.int64)
+    order = np.argsort(ids, kind="stable")
+    sid = ids[order]
+    uniq, start = np.unique(sid, return_index=True)
+    g = np.add.reduceat(np.asarray(rows, param.dtype)[order], start, axis=0)
+    acc = accum[uniq] + g * g
+    with np.errstate(divide="ignore"):
+        inv = np.where(acc > 0, 1.0 / np.sqrt(acc + param.dtype.type(eps)), 0.0)
+    param[uniq] -= param.dtype.type(lr) * g * inv
+    accum[uniq] = acc
+    return uniq

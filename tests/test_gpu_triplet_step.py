@@ -174,3 +174,65 @@ def test_direct_step_equals_stamped_step_and_six_launch_path(dev, monkeypatch, V
             assert rel_err(x.cpu().numpy(), y.cpu().numpy()) <= 1e-6
         for la, lb in zip(outs[0][0], other[0]):
             assert abs(la - lb) <= 2e-6 * abs(lb)
+
+
+def _plan_into(buf, ids3, Vs, gen, dev, Vp=2500):
+    """esr_triplet_plan of ONE batch into an existing (zeroed-once) plan buffer; returns (sorted, perm) for the step."""
+    import ctypes
+    from esrecsys_amd import _lib, ops
+    sid, pid, nid = ids3
+    B = sid.numel()
+    srt, prm = ops.segment_sort_multi([sid, pid, nid], [0, Vs, Vs], Vs + Vp)
+    ptrs = (ctypes.c_void_p * 3)(sid.data_ptr(), pid.data_ptr(), nid.data_ptr())
+    _lib.check(_lib.load().esr_triplet_plan(ptrs, 1, B, int(Vs), srt.data_ptr(), prm.data_ptr(), buf.data_ptr(), None,
+                                            int(gen), ops._stream()), "esr_triplet_plan")
+    return srt, prm
+
+
+def test_direct_plan_generation_is_32_bits_and_a_plan_feeds_repeated_steps(dev, monkeypatch):
+    """(1) A plan buffer planned at generation g and again at g + 4096 (a run of more than 4096 groups of train_steps:
+    the buffers are reused for the whole run) -- the long-run count of the first plan must not be continued by the
+    second (rounds 3-4 kept a 12-bit tag: the stale heads then got an extra Adagrad step from whatever the side buffer
+    held).  (2) The arrival that completes a run clears its counter, so a direct plan can feed the same batch's step
+    twice.  Both against steps on fresh plans, bit for bit; Zipf ids (runs of 2-8 AND long runs)."""
+    from esrecsys_amd import ops
+    monkeypatch.setenv("ESR_TRIPLET_STEP", "direct")
+    Vs, Vp, D, B = 3000, 2500, 128, 2048
+    rng = np.random.default_rng(77)
+
+    def batch():
+        return tuple(torch.as_tensor(x, device=dev) for x in
+                     (_ids("zipf", Vs, B, rng), _ids("zipf", Vp, B, rng), _ids("uniform", Vp, B, rng)))
+
+    def towers():
+        g = torch.Generator(device=dev).manual_seed(5)
+        t = [torch.randn((V, D), generator=g, device=dev) * 0.3 for V in (Vs, Vp)]
+        return t[0], torch.full_like(t[0], 0.1), t[1], torch.full_like(t[1], 0.1)
+
+    def step(tw, ids3, srt, prm, plan):
+        return ops.triplet_train_step(tw[0], None, None, tw[1], tw[2], None, None, tw[3], *ids3, 0.1, float(B), 0.05,
+                                      presorted=(srt, prm), plan=plan, long_runs=-1)
+    b1, b2 = batch(), batch()
+    pb = ops._ws_bytes("esr_triplet_plan_bytes", B)
+    for g1, g2 in ((7, 7 + 4096), (1, 1 + (1 << 20)), (4095, 4096)):
+        X, Y = towers(), towers()
+        buf = ops._aligned_bytes(pb, dev)
+        lx = [step(X, b1, *_plan_into(buf, b1, Vs, g1, dev), buf)]
+        lx.append(step(X, b2, *_plan_into(buf, b2, Vs, g2, dev), buf))
+        ly = []
+        for b, gen in ((b1, 3), (b2, 4)):
+            fresh = ops._aligned_bytes(pb, dev)
+            ly.append(step(Y, b, *_plan_into(fresh, b, Vs, gen, dev), fresh))
+        assert all(torch.equal(a, b) for a, b in zip(lx, ly)), (g1, g2)
+        assert all(torch.equal(a, b) for a, b in zip(X, Y)), (g1, g2)
+    # (2) one plan, two steps of the same batch
+    X, Y = towers(), towers()
+    buf = ops._aligned_bytes(pb, dev)
+    srt, prm = _plan_into(buf, b1, Vs, 9, dev)
+    lx = [step(X, b1, srt, prm, buf), step(X, b1, srt, prm, buf)]
+    ly = []
+    for gen in (1, 2):
+        fresh = ops._aligned_bytes(pb, dev)
+        ly.append(step(Y, b1, *_plan_into(fresh, b1, Vs, gen, dev), fresh))
+    assert all(torch.equal(a, b) for a, b in zip(lx, ly)) and float(lx[0]) != float(lx[1])
+    assert all(torch.equal(a, b) for a, b in zip(X, Y))

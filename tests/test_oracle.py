@@ -102,6 +102,27 @@ def test_sparse_adagrad_equals_dense_adagrad():
     assert np.array_equal(p[untouched], p0[untouched])
 
 
+def test_inplace_sparse_adagrad_equals_the_plain_one():
+    """The config-size form the GPU trajectory tests use (in place, reduceat sums) against sparse_adagrad_update:
+    three steps with heavy duplication, zero rows and a zero accumulator."""
+    rng = np.random.default_rng(6)
+    V, D, n = 60, 5, 400
+    p0 = rng.standard_normal((V, D))
+    a0 = optim.adagrad_init(p0)
+    a0[3] = 0.0
+    p, a = p0.copy(), a0.copy()
+    q, b = p0.copy(), a0.copy()
+    for k in range(3):
+        ids = rng.integers(0, V // 2, n)
+        rows = rng.standard_normal((n, D))
+        rows[ids == 3] = 0.0
+        p, a = optim.sparse_adagrad_update(p, a, ids, rows, 0.05, dtype=F64)
+        uniq = optim.sparse_adagrad_update_inplace(q, b, ids, rows, 0.05)
+        assert np.array_equal(uniq, np.unique(ids))
+    assert np.abs(p - q).max() <= 1e-13 and np.abs(a - b).max() <= 1e-12
+    assert np.array_equal(q[V // 2:], p0[V // 2:]) and np.all(np.isfinite(q))
+
+
 def test_topk_and_knn_golden_with_ties():
     g = load_golden("topk_n500_d8_k10")
     vals, idx = topk.find_top_k(g["query"], g["cand"], int(g["k"]), F64)
