@@ -38,7 +38,6 @@ WORKLOADS = {
     "glove": dict(V=400_000 + 65_537, D=256, B=65_536, rows_per_unit=2, unit="pair"),
 }
 LAM, SCALE, LR, SEED = 0.1, 8.0, 0.05, 1701
-PREWARM_STEPS = 100  # untimed steps in front of a short headline leg's warmup (see main)
 STEADY_STEPS = 200  # the steady-state leg of a run whose --steps is shorter (see main)
 
 
@@ -600,18 +599,16 @@ def kernel_timer():
     return _TIMER
 
 
-def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True, graph=False, saturating=True, prewarm=0):
+def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True, graph=False, saturating=True,
+                     prepared=None, then=None):
     """One leg: W untimed + exactly K timed steps of the whole hot path of `workload` on cfg (inputs resident in HBM),
     then the same K steps again with a HIP-event pair around every ops.* call.  Returns the fields of a bench line.
-    prewarm (in-batch loop only): that many further untimed steps of the same loop on the same state, issued back to back
-    in FRONT of the W warmup steps -- see main()."""
+    prepared: (state, batches) made ahead by make_state_and_batches (a leg that must start right behind another leg's
+    timed region: its tables are initialised before that leg runs).  then: called once, right after this leg's timed
+    region (before its HIP-event passes) -- main() runs the short headline leg there."""
     V, D, B = cfg["V"], cfg["D"], cfg["B"]
-    if not (workload == "inbatch" and not graph and os.environ.get("ESR_INBATCH_LOOP", "1") == "1" and
-            os.environ.get("ESR_INBATCH_AHEAD", "0") != "1"):
-        prewarm = 0
     n_batches = steps + warmup
-    state, batches = make_state_and_batches(workload, cfg, dev, n_batches + prewarm, rank)
-    pre_batches, batches = batches[:prewarm], batches[prewarm:]
+    state, batches = prepared if prepared is not None else make_state_and_batches(workload, cfg, dev, n_batches, rank)
     needs_rowmax = False
     path = None
     if workload == "inbatch":
@@ -704,9 +701,6 @@ def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True
         from esrecsys_amd.pinterest.train_shop_the_look import train_steps
         mode = "eager, train_steps (train_step per batch; id lists of eight coming batches sorted by one batched call)"
         wb = [(b[0], b[1], None) for b in batches]
-        if prewarm:  # untimed, no synchronisation behind it: the W warmup steps follow at once
-            state, _ = train_steps(state, iter([(b[0], b[1], None) for b in pre_batches]), prewarm, LAM, B, scale=SCALE,
-                                   precision=PRECISION)
         state, _ = train_steps(state, iter(wb[:warmup]), warmup, LAM, B, scale=SCALE, precision=PRECISION)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -781,6 +775,8 @@ def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True
             dt = time.perf_counter() - t0
         final_loss = float(loss)
     assert np.isfinite(final_loss), "non-finite loss"
+    if then is not None:
+        then()
 
     # ---- per-kernel HIP-event timing: the same K steps launched eagerly on the same stream (events
     # cannot be recorded inside a replayed graph; kernel durations are the same either way) ---------
@@ -870,12 +866,7 @@ def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True
                                % (workload, V, D, "bf16" if cfg.get("table_dtype") == "bf16" else "fp32", B),
                    "score_precision": PRECISION if workload != "inbatch" else "%s -> %s" % (PRECISION, path or "f32"),
                    "ids": cfg.get("ids", "uniform"),
-                   "parallelism": "single", "launch": mode, "loss": final_loss,
-                   **({"prewarm_steps": prewarm,
-                       "prewarm": "%d further UNTIMED steps of the same loop on the same state, back to back in front of the "
-                                  "%d warmup steps (the package's power transient: a cold %d-step call is 3-15 %% slower; "
-                                  "the timed region is exactly the %d steps behind warmup + synchronize)"
-                                  % (prewarm, warmup, steps, steps)} if prewarm else {})},
+                   "parallelism": "single", "launch": mode, "loss": final_loss},
         "roofline": roofline, "kernels": kernels, "hbm_gather_scatter": hbm,
     }
 
@@ -1044,24 +1035,31 @@ def main():
 
     # A short timed region (the driver's --steps 20 --warmup 5 is 6 ms) started on an idle chip sits inside the power
     # manager's transient: the first steps run at boost clock (0.232 ms), the package overshoots its cap, is clamped
-    # (0.30 ms per step around step 12) and settles after ~10 ms (profiles/r3/startup_probe_inbatch.jsonl).  So the
-    # steady-state leg (>= 200 steps, its own warmup) runs FIRST and carries the per-kernel timing pass; the headline leg
-    # -- exactly W warmup + K timed steps on a fresh state -- follows on a chip that is already at its managed clock.
-    # The steady-state leg alone does not do it: between it and the headline leg lie the fresh state's table
-    # initialisation and an idle host, and the package is back in its transient when the W + K steps start (measured with
-    # an event in front of every step, scripts/startup_probe.py: 0.240 - 0.278 ms per step cold, box to box and run to run;
-    # 0.232 with 100 steps of the same loop directly in front -- the 200-step figure).  So the headline leg issues
-    # PREWARM_STEPS further untimed steps of its own loop on its own state back to back in front of the W warmup steps; the
-    # timed region is still exactly K steps behind W warmup steps and a synchronize, and `config.prewarm_steps` says so.
+    # (0.30 ms per step around step 12) and settles after ~10 ms (profiles/r3/startup_probe_inbatch.jsonl).  Rounds 3-4
+    # put 100 untimed steps in front of the W warmup steps while the line said "warmup": W; round 5 does not: the line
+    # reports what ran.  Two complete legs, back to back: the steady-state leg (>= 200 timed steps behind its own warmup,
+    # its own state; it carries the HIP-event passes) runs FIRST, and the headline leg -- exactly W warmup + K timed steps
+    # on ITS OWN state, whose tables were initialised before the steady leg started -- begins right behind the steady
+    # leg's timed region.  Both results are on the line (`roofline.legs.steady_state`), `config.order` says what preceded
+    # the timed region, and `roofline.frac` is executed flops / the headline's own ms_per_step.
     steady = None
     if args.steps < STEADY_STEPS and not args.graph and not args.no_steady:
+        prepared = make_state_and_batches(args.workload, cfg, dev, args.steps + args.warmup, rank)
+        holder = {}
+
+        def headline():
+            holder["leg"] = measure_training(args.workload, cfg, dev, rank, args.steps, args.warmup, kernel_timing=False,
+                                             saturating=False, prepared=prepared)
         steady = measure_training(args.workload, cfg, dev, rank, STEADY_STEPS, max(args.warmup, 20),
-                                  kernel_timing=not args.no_kernel_timing)
-        leg = measure_training(args.workload, cfg, dev, rank, args.steps, args.warmup, kernel_timing=False,
-                               saturating=False, prewarm=PREWARM_STEPS)
+                                  kernel_timing=not args.no_kernel_timing, then=headline)
+        leg = holder["leg"]
+        del prepared
+        leg["config"]["order"] = ("right behind the %d-step steady_state leg's timed region (that leg has its own state "
+                                  "and batches; no untimed steps besides the %d warmup steps)" % (steady["steps"], args.warmup))
         for key in ("roofline", "kernels", "hbm_gather_scatter"):  # HIP-event pass of the 200-step leg, same kernels
             leg[key] = steady[key]
         if leg["roofline"] is not None:
+            leg["roofline"] = dict(leg["roofline"])
             leg["roofline"]["timed_over"] = "the steady_state leg's %d steps (HIP events)" % steady["steps"]
     else:
         leg = measure_training(args.workload, cfg, dev, rank, args.steps, args.warmup,
@@ -1071,27 +1069,56 @@ def main():
     # every secondary leg is printed as its own line above it
     emit_leg("headline_full", {k: leg[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline",
                                                    "kernels", "hbm_gather_scatter")})
-    keep_rf = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "timed_over",
-               "executed_cross_terms", "f32_equivalent_TFLOPs", "sustained_live_data_TFLOPs", "frac_of_sustained",
-               "dominant_kernel", "step")
-    roof = {k: (_r(v) if not isinstance(v, dict) else v) for k, v in rf.items() if k in keep_rf}
-    if rf.get("per_kernel_in_run"):
-        roof["per_kernel_us_in_run"] = rf["per_kernel_in_run"]["us"]
+    # `roofline` on the final line (the driver keeps this object and truncates long strings): frac / achieved are LITERAL
+    # for the driver-timed number -- executed flops (or SURVEY 8d's algorithmic bytes) of one step / this line's
+    # ms_per_step -- so frac x peak x ms_per_step = the step's executed flops; what the HIP events of the steady leg say
+    # about the kernels alone sits beside it (kernel_group_frac, dominant_kernel), as do the metric's second half
+    # (hbm_gather_scatter, measured in this run) and the other configs' legs (legs, filled in below).
+    step_s = leg["ms_per_step"] * 1e-3
+    roof = {}
+    if rf:
+        B_, D_ = cfg["B"], cfg["D"]
+        if rf.get("bound") == "mfma":
+            terms = rf.get("executed_cross_terms")
+            work = (terms * 2.0 * B_ * B_ * D_) if terms else 6.0 * B_ * B_ * D_   # executed flops per step
+            lit = work / step_s / 1e12
+            roof = {"bound": "mfma", "achieved": _r(lit, 2), "peak": rf["peak"], "unit": "TFLOP/s",
+                    "frac": _r(lit / rf["peak"]), "traffic": rf.get("traffic"),
+                    "what": "executed MFMA flops of one step / ms_per_step of THIS line",
+                    "executed_flops_per_step": work, "executed_gemms": terms,
+                    "algorithmic_flops_per_step": 6.0 * B_ * B_ * D_,
+                    "kernel_group_frac": _r(rf["frac"]), "kernel_group_TFLOPs": _r(rf["achieved"], 2),
+                    "kernel_group": "MFMA kernels only, HIP events, steady leg"}
+            for k in ("sustained_live_data_TFLOPs", "f32_equivalent_TFLOPs"):
+                if k in rf:
+                    roof[k] = _r(rf[k], 1)
+        else:
+            alg = STEP_BYTES_PER_UNIT[args.workload](D_) * B_
+            lit = alg / step_s / 1e9
+            roof = {"bound": "hbm", "achieved": _r(lit, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": _r(lit / HBM_PEAK_GBS), "traffic": rf.get("traffic"),
+                    "what": "SURVEY 8d algorithmic bytes of one step / ms_per_step of THIS line",
+                    "algorithmic_bytes_per_step": alg}
+        roof["step_frac_driver_timed"] = roof["frac"]
+        if rf.get("dominant_kernel"):
+            roof["dominant_kernel"] = rf["dominant_kernel"]
+        if rf.get("per_kernel_in_run"):
+            roof["per_kernel_us_in_run"] = rf["per_kernel_in_run"]["us"]
+        roof["traffic_source"] = "profiles/pmc_traffic.json (committed --pmc passes)" if rf.get("traffic") else None
     sat = (leg.get("hbm_gather_scatter") or {}).get("saturating_launch") or {}
+    if sat:  # the metric's second half: achieved HBM GB/s of the gather and the sparse-Adagrad scatter, measured in this run
+        roof["hbm_gather_scatter"] = {k: _r(float(sat[k]), 3) for k in
+                                      ("gather_GBps", "gather_frac_of_8TBps", "sparse_adagrad_GBps",
+                                       "sparse_adagrad_frac_of_8TBps", "box_stream_read_GBps") if k in sat}
+        roof["hbm_gather_scatter"]["rows_per_launch"] = sat.get("rows_per_launch", 0)
+    src = steady if steady is not None else leg
+    roof["legs"] = {"steady_state": {"value": _r(float(src["value"]), 1), "ms": _r(src["ms_per_step"], 5),
+                                     "steps": src["steps"], "warmup": src["warmup"],
+                                     "frac": _r(roof["frac"] * leg["ms_per_step"] / src["ms_per_step"]) if rf else None}}
     out = {"metric": "training pairs/sec", "value": leg["value"], "unit": leg["unit"], "n_gpus": 1,
            "steps": leg["steps"], "warmup": leg["warmup"], "ms_per_step": leg["ms_per_step"],
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": leg["config"], "roofline": roof}
-    if sat:
-        out["hbm_gather_scatter"] = {k: _r(float(sat[k]), 3) for k in ("gather_GBps", "gather_frac_of_8TBps",
-                                                                       "sparse_adagrad_GBps", "sparse_adagrad_frac_of_8TBps",
-                                                                       "box_stream_read_GBps") if k in sat}
-        out["hbm_gather_scatter"]["what"] = "the step's gather / sparse-Adagrad kernels at %d rows per launch" % sat.get("rows_per_launch", 0)
-    src = steady if steady is not None else leg
-    out["steady_state"] = {"value": src["value"], "unit": src["unit"], "steps": src["steps"], "warmup": src["warmup"],
-                           "ms_per_step": src["ms_per_step"],
-                           "order": "ran before the headline leg (own state, own batches)" if steady is not None
-                           else "the headline leg itself (>= %d steps)" % STEADY_STEPS}
     if not args.no_cpu_baseline:
         cb = cpu_baseline(args.workload, cfg)
         emit_leg("headline_cpu_baseline_full", cb)
@@ -1105,6 +1132,15 @@ def main():
         out["secondary"] = {name: (summarize_ivf(v) if name.endswith("ivf_vs_brute_force") else summarize_leg(v))
                             for name, v in sec.items()}
         out["secondary"]["_note"] = "one-line summaries; each leg's full record is its own JSON line above ({\"leg\": name, ...})"
+        # value / ms / frac of the other configs' legs where the driver keeps them (it drops unknown top-level keys)
+        short = {"glove_c3_b65536": "glove_c3_b65536", "glove_c3_b2048_reference_default_batch": "glove_c3_b2048",
+                 "triplet_c2_b8192_reference_loss": "triplet_c2_b8192", "triplet_c2_b262144_saturating": "triplet_c2_b262144",
+                 "retrieve_c5_n1m_k500_f16x2": "retrieve_c5_f16x2", "retrieve_c5_n1m_k500_exact": "retrieve_c5_exact"}
+        for name, key in short.items():
+            v = out["secondary"].get(name)
+            if isinstance(v, dict) and "value" in v:
+                roof["legs"][key] = {"value": v["value"], "ms": v.get("ms"), "bound": v.get("bound"), "frac": v.get("frac"),
+                                     **({"kernel_frac": v["kernel_frac"]} if v.get("kernel_frac") else {})}
     emit(out)
 
 

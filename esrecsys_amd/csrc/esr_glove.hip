@@ -826,7 +826,16 @@ __global__ __launch_bounds__(kBlock) void glove_step_kernel(
     const double s2 = mode == ESR_GLOVE_REFERENCE ? fixed2_value(coherent_load(stat + 32), coherent_load(stat + 48)) : 0.0;
     loss[0] = glove_loss_value(mode, Bd, Sw, glove_swq(mode, Bd, Sw, Swr, S3, s1), s1, s2, poisoned);
   }
-  if (timed_out) return;
+  if (timed_out) {
+    // this workgroup skips its bias rows: the step is incomplete WHICHEVER workgroup gave up, so the shared poison word
+    // goes up (workgroup 0 reads it in front of its loss store; later launches -- consolidate, the next plan's
+    // statistics -- see it too) and the loss is overwritten with NaN in case workgroup 0 has stored it already
+    if (threadIdx.x == 0) {
+      atomicOr(reinterpret_cast<unsigned*>(fin + kFinAccs * kFixAccWords + 16), 1u);
+      __hip_atomic_store(reinterpret_cast<unsigned*>(loss), 0x7FC00000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
   const double kk = 2.0 / (Bd * Bd);
   if (lig == 0) {
     auto bias_step = [&](uint32_t id, double vx, double vy, float w, float ac) {

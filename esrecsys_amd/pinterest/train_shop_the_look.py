@@ -298,6 +298,28 @@ class _FusedTripletLoop:
             self.fixed_p = (self.pt.data_ptr(), self.rp.shadow.data_ptr(), self.rp.loc.data_ptr(), self.acc_p.data_ptr(),
                             self.Vp)
 
+    def check_state(self, state):
+        """Raise unless `state` holds the towers / accumulators / optimizer settings this context stepped so far and the
+        current stream is the one its launches are ordered on."""
+        prefix = ("params",) if "params" in state.raw_params else ()
+        p = state.raw_params["params"] if prefix else state.raw_params
+        acc = state.opt_state["sum_of_squares"]
+        acc = acc["params"] if prefix else acc
+        same = (p["scene_tower"]["embedding"].data_ptr() == self.st.data_ptr() and
+                p["product_tower"]["embedding"].data_ptr() == self.pt.data_ptr() and
+                acc["scene_tower"]["embedding"].data_ptr() == self.acc_s.data_ptr() and
+                acc["product_tower"]["embedding"].data_ptr() == self.acc_p.data_ptr())
+        if not same:
+            raise RuntimeError("this planned batch belongs to another state: the towers / accumulators of the state passed "
+                               "to train_step are not the ones presorted() was given (after a restore or a swap, make a "
+                               "new presorted() iterator)")
+        if float(state.tx.lr) != self.lr or float(state.tx.eps) != self.eps:
+            raise RuntimeError("the optimizer's learning rate / eps changed since presorted() was called: make a new "
+                               "presorted() iterator (the loop context keeps them)")
+        if torch.cuda.current_stream(self.dev).cuda_stream != self.main_raw:
+            raise RuntimeError("planned batches are ordered on the stream presorted() was called under: step them under "
+                               "that stream")
+
     def stamp(self, count=1):
         """The (first) stamp of the next `count` steps on both towers; direct mode has none."""
         return 1 if self.direct else self.next_stamp(self.rs, self.rp, count=count)
@@ -454,8 +476,12 @@ class PlannedTriplets:
     def step(self, state, regularization, batch_size):
         if self.used:
             raise RuntimeError("a planned batch feeds exactly one train_step (its plan holds the step's accumulators)")
-        self.used = True
         ctx, gr, j = self.ctx, self.group, self.j
+        # the loop context captured the towers, accumulators, learning rate and stream of the state ``presorted`` was given:
+        # a state swapped mid-iteration (checkpoint restore, another learning rate, other tables) must not step the OLD
+        # tables while the returned state claims step + 1
+        ctx.check_state(state)
+        self.used = True
         if ctx.group_of[gr.which] is not gr:
             raise RuntimeError("this planned batch is two groups old: its sorted ids and plan have been overwritten "
                                "(step the batches of presorted() in the order it yields them)")
@@ -481,7 +507,7 @@ class PlannedTriplets:
                                                  float(batch_size), ctx.lr, ctx.eps, ctx.stamp(),
                                                  gr.sorted_ptr + 4 * n * j, gr.perm_ptr + 4 * n * j,
                                                  gr.plans_ptr + pb * j, long_runs, ctx.losses_ptr + 4 * k,
-                                                 ctx.group_ws.data_ptr(), ctx.group_ws.numel(), ops._stream()),
+                                                 ctx.group_ws.data_ptr(), ctx.group_ws.numel(), ctx.main_raw),
                   "esr_triplet_train_step")
         return state.replace(step=state.step + 1), ctx.losses[k]
 

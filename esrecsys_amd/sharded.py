@@ -985,13 +985,21 @@ def sharded_train_steps(workload, groups, batches, *, regularization=0.0, global
                                            [x[1] for x in nb], comm2, side)
                 if prev:
                     prev[2] = None  # (consumed -- or released -- by the call)
-                if workload == "glove":
-                    loss = k.sharded_glove_step(c_groups[0], c_groups[1], plan.c_struct(k), b[1], b[0].shape[1], mode, lr,
-                                                1e-7, overlap=ov)
-                else:
-                    gbs = global_batch_size if global_batch_size is not None else float(g0.world * b[0].numel())
-                    loss = k.sharded_triplet_step(c_groups[0], plan.c_struct(k), b[0].numel(), regularization, gbs, lr,
-                                                  1e-7, b[0].device, overlap=ov)
+                try:
+                    if workload == "glove":
+                        loss = k.sharded_glove_step(c_groups[0], c_groups[1], plan.c_struct(k), b[1], b[0].shape[1], mode,
+                                                    lr, 1e-7, overlap=ov)
+                    else:
+                        gbs = global_batch_size if global_batch_size is not None else float(g0.world * b[0].numel())
+                        loss = k.sharded_triplet_step(c_groups[0], plan.c_struct(k), b[0].numel(), regularization, gbs,
+                                                      lr, 1e-7, b[0].device, overlap=ov)
+                except BaseException:
+                    # a call that failed AFTER its side-stream lookup recorded next_ready: nobody will consume the event
+                    # (the loop's ``finally`` only knows the event of the step before)
+                    if ov.next_ready:
+                        k.overlap_release(ov.next_ready)
+                        ov.next_ready = None
+                    raise
                 return loss, ([x[0] for x in nb], [x[1] for x in nb], ov.next_ready) if nxt is not None else None
 
             plans = {0: begin_plans([lookup(batches[i]) for i in range(*spans[0])]).finish()}

@@ -199,3 +199,27 @@ def test_reference_shaped_loop_over_presorted_equals_train_steps(dev, B, steps, 
     mixed = batches[:3] + [(batches[0][0], batches[0][1], None)] + batches[3:5]
     kinds = [isinstance(s, PlannedTriplets) for s, _, _ in presorted(b, iter(mixed))]
     assert kinds.count(False) >= 1 and len(kinds) == len(mixed)
+
+
+def test_planned_batch_refuses_another_state(dev):
+    """A PlannedTriplets handle steps the towers its presorted() context captured: handing train_step a state with other
+    tables (a restore, a swap) or another learning rate must raise instead of stepping the old tables, and the handle
+    stays usable for the right state."""
+    from esrecsys_amd import optim
+    from esrecsys_amd.pinterest.train_shop_the_look import PlannedTriplets, presorted, train_step
+    Vs, Vp, D, B = 3000, 5000, 64, 256
+    rng = np.random.default_rng(1)
+    batches = [tuple(torch.from_numpy(rng.integers(0, V, B).astype(np.int32)).to(dev) for V in (Vs, Vp, Vp))
+               for _ in range(4)]
+    a, other = _state(dev, Vs, Vp, D, 3), _state(dev, Vs, Vp, D, 3)
+    it = presorted(a, iter(batches))
+    scene, pos, neg = next(it)
+    assert isinstance(scene, PlannedTriplets)
+    before = other.params["params"]["scene_tower"]["embedding"].clone()
+    with pytest.raises(RuntimeError, match="another state"):
+        train_step(other, scene, pos, neg, 0.1, float(B))
+    with pytest.raises(RuntimeError, match="learning rate"):
+        train_step(a.replace(tx=optim.sparse_adagrad(0.01)), scene, pos, neg, 0.1, float(B))
+    assert torch.equal(other.params["params"]["scene_tower"]["embedding"], before)
+    a, loss = train_step(a, scene, pos, neg, 0.1, float(B))     # the refused calls did not consume the handle
+    assert np.isfinite(float(loss)) and int(a.step) == 1
