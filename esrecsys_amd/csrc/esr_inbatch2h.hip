@@ -311,7 +311,10 @@ __global__ __launch_bounds__(256) void prepsplit2h_kernel(RowSrc X0, RowSrc X1, 
                                                          unsigned long long token, float* __restrict__ diag,
                                                          float* __restrict__ nrm, float* __restrict__ sc,
                                                          unsigned long long* __restrict__ loss_acc,
-                                                         int* __restrict__ flags, int nflags) {
+                                                         int* __restrict__ flags, int nflags,
+                                                         float* __restrict__ copy0, float* __restrict__ copy1) {
+  // copy0 / copy1 (optional): the gathered rows as dense f32 [B, ld] matrices.  The overlapped train step updates a tower
+  // while the merge launch of the OTHER side still needs that tower's old rows: the merges then read these copies
   __shared__ float red[8];
   __shared__ unsigned cred[8];
   const int t = threadIdx.x, chunk = blockIdx.x, nchunks = gridDim.x;
@@ -337,6 +340,8 @@ __global__ __launch_bounds__(256) void prepsplit2h_kernel(RowSrc X0, RowSrc X1, 
       const float4 g = rowsrc_load4(Y1, rc, d0 + 4 * q);
       vq[4 * q] = f.x; vq[4 * q + 1] = f.y; vq[4 * q + 2] = f.z; vq[4 * q + 3] = f.w;
       vc[4 * q] = g.x; vc[4 * q + 1] = g.y; vc[4 * q + 2] = g.z; vc[4 * q + 3] = g.w;
+      if (copy0 && d0 + 4 * q < X0.ld) *reinterpret_cast<float4*>(copy0 + grow * X0.ld + d0 + 4 * q) = f;
+      if (copy1 && d0 + 4 * q < X1.ld) *reinterpret_cast<float4*>(copy1 + grow * X1.ld + d0 + 4 * q) = g;
     }
   }
   float mq = 0.f, mc = 0.f, dot = 0.f, ssq = 0.f, ssc = 0.f;
@@ -1509,9 +1514,43 @@ __global__ __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __re
   }
 }
 
+// The factors pass C needs from pass Q's per-split references and normalisers -- fac[s][i] = 2^14 2^(M_s - M) / l_i --
+// as a launch of their own (one thread per row, 16 loads each): merge<Q> computes the same numbers with the same
+// operations in the same order (the factors are bit-identical), but also reads the 8 x 4 MB of partial O rows and the
+// tower rows and writes gQ; with this launch in front of pass C, merge<Q> leaves the critical path and runs beside
+// pass C on a second stream (inbatch2h_run, overlapped form).
+__global__ __launch_bounds__(256) void fac2h_kernel(int64_t B, int nsplit, const float* __restrict__ part_m,
+                                                   const float* __restrict__ part_l, float invl_scale,
+                                                   float* __restrict__ fac) {
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= B) return;
+  float pm[8], pl[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    pm[s] = -INFINITY; pl[s] = 0.f;
+    if (s < nsplit) {
+      pm[s] = part_m[(int64_t)s * B + row];
+      pl[s] = part_l[(int64_t)s * B + row];
+    }
+  }
+  float M = pm[0], L = 0.f;
+  float wt[8];
+#pragma unroll
+  for (int s = 1; s < 8; ++s) M = fmaxf(M, pm[s]);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    wt[s] = pm[s] == M ? 1.f : __builtin_amdgcn_exp2f(pm[s] - M);
+    L = __fmaf_rn(pl[s], wt[s], L);  // (explicit, as in inbatch3_merge_kernel: the two kernels must round alike)
+  }
+  const float invL1 = __fdiv_rn(1.0f, L);
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+    if (s < nsplit) fac[(int64_t)s * B + row] = __fmul_rn(__fmul_rn(invL1, invl_scale), wt[s]);
+}
+
 struct InbatchHWs {
   _Float16 *Qh, *Ch;
-  float *part_O, *part_m, *part_mr, *part_l, *lse2, *fac, *Pmat, *nrm, *amax, *sc, *diag;
+  float *part_O, *part_O2, *fac_side, *Qcopy, *Ccopy, *part_m, *part_mr, *part_l, *lse2, *fac, *Pmat, *nrm, *amax, *sc, *diag;
   int* flags;
   unsigned long long* loss_acc;
   unsigned long long* ent;  // prepsplit2h_kernel's tagged per-chunk maxima
@@ -1530,6 +1569,10 @@ static size_t inbatch2h_ws_layout(int64_t B, char* base, InbatchHWs* ws) {
   w.Qh = (_Float16*)take(planes);
   w.Ch = (_Float16*)take(planes);
   w.part_O = (float*)take((size_t)8 * B * k3D * 4);
+  w.part_O2 = (float*)take((size_t)8 * B * k3D * 4);  // pass C's partials when merge<Q> runs beside pass C (overlapped form)
+  w.fac_side = (float*)take((size_t)8 * B * 4);       // merge<Q>'s own copy of the factors there (pass C reads fac2h_kernel's)
+  w.Qcopy = (float*)take((size_t)B * k3D * 4);        // the gathered rows as f32 matrices (overlapped train step: the merges
+  w.Ccopy = (float*)take((size_t)B * k3D * 4);        // read them instead of tables that are being updated beside them)
   w.part_m = (float*)take((size_t)8 * B * 4);
   w.part_mr = (float*)take((size_t)8 * B * 4);
   w.part_l = (float*)take((size_t)8 * B * 4);
@@ -1556,6 +1599,39 @@ static int inbatch2h_nsplit(int64_t B, int per_cu) {
   return best;
 }
 
+// the sparse-Adagrad tail of a whole train step (esr_inbatch_train_step_f16x2): both towers as one virtual table, the
+// occurrence list [query ids ; Vq + candidate ids] sorted by virtual row, the gradient rows [gQ ; gC] in occurrence order
+struct InbatchUpdate {
+  void* tables[2];
+  float* accums[2];
+  int64_t row_offsets[3];
+  int dtype;
+  const int32_t* sorted_vids;
+  const int32_t* perm;
+  float* grad_rows;
+  float lr, eps;
+  bool skip_long;
+};
+
+// in esr_optim.hip
+int sparse_adagrad_range(void* const* tables, float* const* accums, const int64_t* row_offsets, int ntables, int dtype,
+                         int D, const int32_t* sorted_vids, const int32_t* perm, int64_t n, float* grad_rows, float lr,
+                         float eps, bool skip_long, hipStream_t st);
+
+// fork / join events of the overlapped form: one pair per host thread and device, made on first use (an event may be
+// recorded again while an earlier wait on it is still queued: a wait binds to the record that preceded it)
+static bool inbatch_events(hipEvent_t* fork, hipEvent_t* join) {
+  constexpr int kMaxDev = 16;
+  static thread_local hipEvent_t ev[kMaxDev][2] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return false;
+  for (int i = 0; i < 2; ++i)
+    if (!ev[dev][i] && hipEventCreateWithFlags(&ev[dev][i], hipEventDisableTiming) != hipSuccess) return false;
+  *fork = ev[dev][0];
+  *join = ev[dev][1];
+  return true;
+}
+
 }  // namespace esr
 
 using namespace esr;
@@ -1576,7 +1652,8 @@ size_t esr_inbatch2h_workspace_bytes(int64_t B, int D) {
 
 static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* gq_rows, const int32_t* gc_rows, int64_t B,
                          int D, float scale, float regularization, float batch_size, float* loss, float* lse,
-                         float* gQ, float* gC, void* workspace, size_t workspace_bytes, esr_stream_t stream) {
+                         float* gQ, float* gC, void* workspace, size_t workspace_bytes, esr_stream_t stream,
+                         hipStream_t side = nullptr, const InbatchUpdate* upd = nullptr) {
   if (!(B > 0 && B % k3Owned == 0 && B <= kHMaxB)) {
     set_error("%s: B=%lld must be a positive multiple of 128, at most %lld (larger batches: the bf16x3 entry point)",
               who, (long long)B, (long long)kHMaxB);
@@ -1644,6 +1721,14 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
   const char* fe = getenv("ESR_IB2H_FUSED");
   const bool fused = !(fe && fe[0] == '0') && mode != 0 && !q2;
   int nsplit_r = 1;
+  // Overlapped form (`side` given; round 5): pass C needs nothing of merge<Q> but the factors, so fac2h_kernel makes
+  // those (2 us) and merge<Q> -- 14 us of partial-O reads at B = 8192 -- runs on `side` beside pass C, followed there by
+  // the query tower's Adagrad update when this is a whole train step; pass C then writes its partials to a second buffer,
+  // and both merges read the rows from the f32 copies prepsplit2h_kernel left (merge<C> needs the query tower's OLD rows
+  // after the side stream may have updated them, and vice versa).  Same kernels, same arithmetic: results are
+  // bit-identical to the sequential form (the loss is an order-free integer sum).
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  const bool overlapped = fused && side != nullptr && side != st && inbatch_events(&ev_fork, &ev_join);
   if (fused) {
     static std::atomic<unsigned long long> call_seq{0};
     static const unsigned long long seed =
@@ -1654,7 +1739,8 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
     const unsigned long long token = ((z ^ (z >> 31)) >> 16) | 1ull;  // 48 bits, never 0
     ESR_KT("prepsplit2h_kernel", st,
            hipLaunchKernelGGL(prepsplit2h_kernel, dim3(nchunks), dim3(256), 0, st, Qs, Cs, B, ws.Qh, ws.Ch, ws.ent, token,
-                              ws.diag, ws.nrm, ws.sc, ws.loss_acc, ws.flags, grid_q));
+                              ws.diag, ws.nrm, ws.sc, ws.loss_acc, ws.flags, grid_q, overlapped ? ws.Qcopy : (float*)nullptr,
+                              overlapped ? ws.Ccopy : (float*)nullptr));
     ESR_KT("inbatch2h_q_kernel", st,
            hipLaunchKernelGGL((inbatch2h_q_kernel<2>), dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Qh,
                               (const _Float16*)ws.Ch, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)ws.part_mr, 1,
@@ -1694,28 +1780,66 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
   }
   }  // !fused
   // O_Q' = 2^ec sum p' c, l' = sum p': o / l needs 2^-ec (sc[1]); the stored factors carry pass C's 2^14
-  ESR_KT("inbatch3_merge_kernel_q", st,
-         hipLaunchKernelGGL((inbatch3_merge_kernel<true>), dim3(mgrid), dim3(kBlock), 0, st, Qs, Cs, gq_rows, B, nsplit_q,
+  hipStream_t st_q = overlapped ? side : st;
+  float* const part_O_c = overlapped ? ws.part_O2 : ws.part_O;
+  // the rows the merges read: the towers themselves, or (overlapped) their gathered copies
+  const RowSrc Qm = overlapped ? RowSrc{ws.Qcopy, nullptr, 0, Qs.ld} : Qs;
+  const RowSrc Cm = overlapped ? RowSrc{ws.Ccopy, nullptr, 0, Cs.ld} : Cs;
+  if (overlapped) {
+    if (hipEventRecord(ev_fork, st) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess) {
+      set_error("%s: could not fork the side stream", who);
+      return ESR_ELAUNCH;
+    }
+    ESR_KT("fac2h_kernel", st,
+           hipLaunchKernelGGL(fac2h_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, B, nsplit_q,
+                              (const float*)ws.part_m, (const float*)ws.part_l, ldexpf(1.f, (int)kHPexp), ws.fac));
+  }
+  ESR_KT("inbatch3_merge_kernel_q", st_q,
+         hipLaunchKernelGGL((inbatch3_merge_kernel<true>), dim3(mgrid), dim3(kBlock), 0, st_q, Qm, Cm, gq_rows, B, nsplit_q,
                             (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale,
                             regularization, inv_bs, ws.lse2, lse, gQ, ws.loss_acc, 1.0 / (double)batch_size, loss,
-                            (float*)nullptr, (const float*)(ws.sc + 1), ldexpf(1.f, (int)kHPexp), ws.fac));
+                            (float*)nullptr, (const float*)(ws.sc + 1), ldexpf(1.f, (int)kHPexp),
+                            overlapped ? ws.fac_side : ws.fac));
+  if (overlapped) {
+    if (upd) {  // the query tower's rows: positions [0, B) of the sorted occurrence list
+      const int rc = sparse_adagrad_range(upd->tables, upd->accums, upd->row_offsets, 2, upd->dtype, D, upd->sorted_vids,
+                                          upd->perm, B, upd->grad_rows, upd->lr, upd->eps, upd->skip_long, side);
+      if (rc != ESR_OK) return rc;
+    }
+    if (hipEventRecord(ev_join, side) != hipSuccess) {
+      set_error("%s: could not record the join event", who);
+      return ESR_ELAUNCH;
+    }
+  }
   const char* pcm = getenv("ESR_IB2H_PC");  // "dma": the P' tiles as LDS-DMAs (one chunk ahead); default: staged loads
   if (pcm && pcm[0] == 'd') {
     ESR_KT("inbatch2h_pc8_kernel", st,
            hipLaunchKernelGGL((inbatch2h_pc8_kernel<false>), dim3(grid_c), dim3(512), 0, st, (const _Float16*)ws.Qh,
-                              B, nsplit_c, (const float*)ws.fac, nchunks / nsplit_q, (const float*)ws.Pmat, ws.part_O));
+                              B, nsplit_c, (const float*)ws.fac, nchunks / nsplit_q, (const float*)ws.Pmat, part_O_c));
   } else {
     ESR_KT("inbatch2h_pc8_kernel", st,
            hipLaunchKernelGGL((inbatch2h_pc8_kernel<true>), dim3(grid_c), dim3(512), 0, st, (const _Float16*)ws.Qh,
-                              B, nsplit_c, (const float*)ws.fac, nchunks / nsplit_q, (const float*)ws.Pmat, ws.part_O));
+                              B, nsplit_c, (const float*)ws.fac, nchunks / nsplit_q, (const float*)ws.Pmat, part_O_c));
   }
   // O_C' = 2^(eq + 14) sum_i (p_ij / l_i) q_i
   ESR_KT("inbatch3_merge_kernel_c", st,
-         hipLaunchKernelGGL((inbatch3_merge_kernel<false>), dim3(mgrid), dim3(kBlock), 0, st, Cs, Qs, gc_rows, B, nsplit_c,
-                            (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale,
+         hipLaunchKernelGGL((inbatch3_merge_kernel<false>), dim3(mgrid), dim3(kBlock), 0, st, Cm, Qm, gc_rows, B, nsplit_c,
+                            (const float*)part_O_c, (const float*)ws.part_m, (const float*)ws.part_l, scale,
                             regularization, inv_bs, ws.lse2, (float*)nullptr, gC, ws.loss_acc,
                             1.0 / (double)batch_size, loss, (float*)nullptr, (const float*)(ws.sc + 2), 1.0f,
                             (float*)nullptr, fused ? ws.ent : (unsigned long long*)nullptr, nchunks));
+  if (upd) {
+    // the candidate tower's rows: positions [B, 2B) (sequential form: the whole list, one launch for both towers)
+    const int64_t off = overlapped ? B : 0;
+    const int rc = sparse_adagrad_range(upd->tables, upd->accums, upd->row_offsets, 2, upd->dtype, D,
+                                        upd->sorted_vids + off, upd->perm + off, 2 * B - off, upd->grad_rows, upd->lr,
+                                        upd->eps, upd->skip_long, st);
+    if (rc != ESR_OK) return rc;
+  }
+  if (overlapped && hipStreamWaitEvent(st, ev_join, 0) != hipSuccess) {
+    set_error("%s: could not join the side stream", who);
+    return ESR_ELAUNCH;
+  }
   return check_launch(who);
 }
 
@@ -1737,6 +1861,86 @@ int esr_inbatch_towers_fwd_bwd_f16x2(const void* query_table, int64_t Vq, const 
   return inbatch2h_run("esr_inbatch_towers_fwd_bwd_f16x2", RowSrc{query_table, query_ids, dtype == ESR_BF16, D},
                        RowSrc{cand_table, cand_ids, dtype == ESR_BF16, D}, gq_rows, gc_rows, B, D, scale, regularization,
                        batch_size, loss, lse, gQ, gC, workspace, workspace_bytes, stream);
+}
+
+// ---- the whole in-batch training step as ONE call (round 5) ---------------------------------------------------------------
+static size_t inbatch_step_ws_layout(int64_t B, int D, char* base, char** head, float** grads, int32_t** sorted,
+                                     int32_t** perm, char** sort_ws, size_t* sort_ws_bytes) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += align_up(bytes, 256);
+    return p;
+  };
+  const size_t hb = esr_inbatch2h_workspace_bytes(B, D);
+  const size_t sb = esr_segment_sort_workspace_bytes(2 * B);
+  char* h = take(hb);
+  float* g = (float*)take((size_t)2 * B * D * sizeof(float));
+  int32_t* so = (int32_t*)take((size_t)2 * B * sizeof(int32_t));
+  int32_t* pe = (int32_t*)take((size_t)2 * B * sizeof(int32_t));
+  char* sw = take(sb);
+  if (head) *head = h;
+  if (grads) *grads = g;
+  if (sorted) *sorted = so;
+  if (perm) *perm = pe;
+  if (sort_ws) *sort_ws = sw;
+  if (sort_ws_bytes) *sort_ws_bytes = sb;
+  return off;
+}
+
+size_t esr_inbatch_train_step_workspace_bytes(int64_t B, int D) {
+  if (B <= 0 || B > kHMaxB || D <= 0) return 256;
+  return inbatch_step_ws_layout(B, D, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+int esr_inbatch_train_step_f16x2(void* query_table, float* query_accum, int64_t Vq, void* cand_table, float* cand_accum,
+                                 int64_t Vc, int dtype, int D, const int32_t* query_ids, const int32_t* cand_ids,
+                                 int64_t B, float scale, float regularization, float batch_size, float lr, float eps,
+                                 const int32_t* presorted_vids, const int32_t* presorted_perm, int long_runs, float* loss,
+                                 float* lse, void* workspace, size_t workspace_bytes, esr_stream_t stream,
+                                 esr_stream_t side_stream) {
+  const char* who = "esr_inbatch_train_step_f16x2";
+  ESR_REQUIRE(Vq > 0 && Vc > 0 && query_table && cand_table && query_accum && cand_accum && query_ids && cand_ids,
+              "%s: bad tables / ids", who);
+  ESR_REQUIRE(dtype == ESR_F32 || dtype == ESR_BF16, "%s: bad dtype %d", who, dtype);
+  ESR_REQUIRE(Vq + Vc < ((int64_t)1 << 31), "%s: %lld virtual rows >= 2^31", who, (long long)(Vq + Vc));
+  ESR_REQUIRE((presorted_vids == nullptr) == (presorted_perm == nullptr), "%s: presorted ids and perm come together", who);
+  ESR_REQUIRE(B > 0 && B % k3Owned == 0 && B <= kHMaxB, "%s: B=%lld must be a positive multiple of 128, at most %lld", who,
+              (long long)B, (long long)kHMaxB);
+  ESR_REQUIRE(workspace && !((uintptr_t)workspace & 255) && workspace_bytes >= esr_inbatch_train_step_workspace_bytes(B, D),
+              "%s: workspace %zu bytes < %zu required (or not 256-byte aligned)", who, workspace_bytes,
+              esr_inbatch_train_step_workspace_bytes(B, D));
+  char *head, *sort_ws;
+  float* grads;
+  int32_t *sorted, *perm;
+  size_t sort_ws_bytes;
+  inbatch_step_ws_layout(B, D, (char*)workspace, &head, &grads, &sorted, &perm, &sort_ws, &sort_ws_bytes);
+  InbatchUpdate upd;
+  upd.tables[0] = query_table; upd.tables[1] = cand_table;
+  upd.accums[0] = query_accum; upd.accums[1] = cand_accum;
+  upd.row_offsets[0] = 0; upd.row_offsets[1] = Vq; upd.row_offsets[2] = Vq + Vc;
+  upd.dtype = dtype;
+  upd.grad_rows = grads;
+  upd.lr = lr; upd.eps = eps;
+  upd.skip_long = long_runs == 0;
+  if (presorted_vids) {
+    upd.sorted_vids = presorted_vids;
+    upd.perm = presorted_perm;
+  } else {  // the occurrence list [query ids ; Vq + candidate ids] sorted here (a loop sorts eight batches ahead instead)
+    const void* ptrs[2] = {query_ids, cand_ids};
+    const int64_t cnt[2] = {B, B}, off[2] = {0, Vq};
+    const int rc = esr_segment_sort_ids_multi((const int32_t* const*)ptrs, cnt, off, 2, Vq + Vc, sorted, perm, sort_ws,
+                                              sort_ws_bytes, stream);
+    if (rc != ESR_OK) return rc;
+    upd.sorted_vids = sorted;
+    upd.perm = perm;
+    upd.skip_long = false;
+  }
+  // gradient rows in occurrence order: gQ = rows [0, B), gC = rows [B, 2B) of one buffer
+  return inbatch2h_run(who, RowSrc{query_table, query_ids, dtype == ESR_BF16, D},
+                       RowSrc{cand_table, cand_ids, dtype == ESR_BF16, D}, nullptr, nullptr, B, D, scale, regularization,
+                       batch_size, loss, lse, grads, grads + (size_t)B * D, head, esr_inbatch2h_workspace_bytes(B, D), stream,
+                       as_stream(side_stream), &upd);
 }
 
 }  // extern "C"

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(kBlock) void inbatch3_merge_kernel(
         // (fac == null: the bf16 x 3 path -- part_m[s] is split s's share of the row maximum there, and every split
         // exponentiated against the maximum of them: weight 1)
         wt[s] = (fac == nullptr || pm[s] == M) ? 1.f : __builtin_amdgcn_exp2f(pm[s] - M);
-        L += pl[s] * wt[s];
+        L = __fmaf_rn(pl[s], wt[s], L);  // (explicit roundings here and for the factors: fac2h_kernel must agree bit for bit)
       }
     }
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void inbatch3_merge_kernel(
         o.x += po[s].x * wt[s]; o.y += po[s].y * wt[s]; o.z += po[s].z * wt[s]; o.w += po[s].w * wt[s];
       }
     }
-    const float invL1 = 1.0f / L;
+    const float invL1 = __fdiv_rn(1.0f, L);
     const float invL = invL1 * oscale;  // (exact: oscale is a power of two)
     const float xn2 = group_sum(x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w, G);
     const float xnorm = sqrtf(xn2);
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kBlock) void inbatch3_merge_kernel(
         if (fac) {
 #pragma unroll
           for (int s = 0; s < 8; ++s)
-            if (s < nsplit) fac[(int64_t)s * B + row] = invL1 * invl_scale * wt[s];
+            if (s < nsplit) fac[(int64_t)s * B + row] = __fmul_rn(__fmul_rn(invL1, invl_scale), wt[s]);
         }
         if (lse_nat) lse_nat[row] = l2v * k3Ln2;
       }

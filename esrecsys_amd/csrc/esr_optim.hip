@@ -633,6 +633,31 @@ int esr_sparse_momentum_step_multi(float* const* tables, float* const* traces, c
 }  // extern "C"
 
 namespace esr {
+// esr_sparse_adagrad_scatter_multi over a SUB-RANGE of a sorted occurrence list (sorted_vids / perm already advanced to the
+// range's first position, n = its length; perm still indexes the whole grad_rows buffer).  A range that starts where the
+// virtual ids change table (and at a multiple of kSegChunk: the chunk boundaries of long runs are absolute positions)
+// gives every row the bits the whole-list launch gives it.  Internal: the in-batch train step updates the scene tower on
+// a side stream while pass C runs (esr_inbatch2h.hip).
+int sparse_adagrad_range(void* const* tables, float* const* accums, const int64_t* row_offsets, int ntables, int dtype,
+                         int D, const int32_t* sorted_vids, const int32_t* perm, int64_t n, float* grad_rows, float lr,
+                         float eps, bool skip_long, hipStream_t st) {
+  if (!(ntables >= 1 && ntables <= kMaxFusedTables && D > 0 && n >= 0)) {
+    set_error("sparse_adagrad_range: bad arguments");
+    return ESR_EINVAL;
+  }
+  if (n == 0) return ESR_OK;
+  FusedTables ft;
+  ft.n = ntables;
+  for (int i = 0; i < kMaxFusedTables; ++i) {
+    ft.table[i] = i < ntables ? tables[i] : nullptr;
+    ft.accum[i] = i < ntables ? accums[i] : nullptr;
+    ft.row_offset[i] = i <= ntables ? row_offsets[i] : row_offsets[ntables];
+  }
+  ft.row_offset[kMaxFusedTables] = row_offsets[ntables];
+  return launch_segment_tables<kAdagrad>("sparse_adagrad_range", ft, dtype, D, sorted_vids, perm, n, grad_rows, lr, eps, st,
+                                         skip_long);
+}
+
 // esr_sparse_momentum_step_multi for one or two tables whose rows may be behind (last[t][row] = the step the row is current
 // with): catch-up + step + mark, in the update kernel itself (kMomentumStepLazy).  Internal: esr_spotify_train_step.
 int sparse_momentum_step_lazy2(float* const* tables, float* const* traces, int32_t* const* lasts, const int64_t* row_offsets,

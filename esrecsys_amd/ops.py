@@ -958,6 +958,46 @@ def inbatch_towers_fwd_bwd(query_table, cand_table, query_ids, cand_ids, scale, 
     return loss, lse, gQC[:B], gQC[B:]
 
 
+def inbatch_train_step(query_table, query_accum, cand_table, cand_accum, query_ids, cand_ids, scale, regularization,
+                       batch_size, lr, eps=1e-7, presorted=None, long_runs=-1, side_stream=None, want_lse=False):
+    """One whole in-batch training step of the two towers (esr_inbatch_train_step_f16x2): gather + fp16 x 2 score passes +
+    row-sparse Adagrad on both towers, in place.  presorted = (sorted virtual ids, perm) of [query_ids ; Vq + cand_ids]
+    (segment_sort_multi / segment_sort_batched), else the list is sorted here; long_runs: 0 when long_run_hint said no id
+    occurs more than 32 times.  side_stream (a torch.cuda.Stream of the same device): merge<Q> and the query tower's
+    update run on it beside pass C (bit-identical results).  Returns loss[1] (and lse[B] with want_lse)."""
+    lib = _lib.load()
+    dt = _table_dtype(query_table, "query_table")
+    if _table_dtype(cand_table, "cand_table") != dt:
+        raise TypeError("both tower tables must have the same dtype")
+    _req(query_accum, torch.float32, "query_accum"), _req(cand_accum, torch.float32, "cand_accum")
+    query_ids, cand_ids = _req(query_ids, torch.int32, "query_ids"), _req(cand_ids, torch.int32, "cand_ids")
+    B, D, dev = query_ids.numel(), query_table.shape[1], query_table.device
+    if cand_ids.numel() != B or cand_table.shape[1] != D:
+        raise ValueError("id counts / tower widths differ")
+    if query_accum.shape != query_table.shape or cand_accum.shape != cand_table.shape:
+        raise ValueError("accumulator shapes do not match their towers")
+    if not (D % 4 == 0 and 0 < D <= 128 and B % 128 == 0 and 0 < B <= INBATCH_F16X2_MAX_B):
+        raise ValueError("inbatch_train_step needs D <= 128 (a multiple of 4), B %% 128 == 0 and B <= %d (got B=%d, D=%d)"
+                         % (INBATCH_F16X2_MAX_B, B, D))
+    sid = perm = None
+    if presorted is not None:
+        sid, perm = _req(presorted[0], torch.int32, "sorted_ids"), _req(presorted[1], torch.int32, "perm")
+        if sid.numel() != 2 * B or perm.numel() != 2 * B:
+            raise ValueError("presorted ids / perm must have 2 B entries")
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    lse = torch.empty(B, dtype=torch.float32, device=dev) if want_lse else None
+    ws = _ws(_ws_bytes("esr_inbatch_train_step_workspace_bytes", B, D), dev)
+    side = side_stream.cuda_stream if side_stream is not None else None
+    check(lib.esr_inbatch_train_step_f16x2(_p(query_table), _p(query_accum), query_table.shape[0], _p(cand_table),
+                                           _p(cand_accum), cand_table.shape[0], dt, D, _p(query_ids), _p(cand_ids), B,
+                                           float(scale), float(regularization), float(batch_size), float(lr), float(eps),
+                                           _p(sid), _p(perm), int(long_runs), _p(loss), _p(lse), _p(ws), ws.numel(),
+                                           _stream(), side), "esr_inbatch_train_step_f16x2")
+    if side_stream is not None:
+        ws.record_stream(side_stream)  # (the call joined the streams; this only tells torch's allocator who used the block)
+    return (loss, lse) if want_lse else loss
+
+
 def bucket_ids_by_owner_batched(id_lists, world, offsets):
     """bucket_ids_by_owner for the lists of several coming batches in one launch pair (esr_bucket_ids_by_owner_batched).
     id_lists: per batch, the int32 segments of its virtual list [ids_k + offsets[k]] (same lengths in every batch).

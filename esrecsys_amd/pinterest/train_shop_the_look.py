@@ -65,6 +65,29 @@ import os as _os
 _PRESORT = _os.environ.get("ESR_INBATCH_PRESORT", "0") == "1"
 
 
+# ESR_INBATCH_ONECALL=0: the in-batch step as fwd_bwd + apply_gradients (rounds 1-4).  ESR_INBATCH_OVERLAP=1: the one call
+# with merge<Q> and the scene tower's update on a second stream beside pass C.  Bit-identical, and measured SLOWER at C2
+# (same box, alternating runs: 0.2424-0.2447 ms per step against 0.2347-0.2351 in line): pass C loses 9 us to the traffic
+# beside it (74 -> 83 us), the factor launch pass C then needs is 7 us and the row copies the merges must read add 4 us
+# to the gather + split -- more than the 15 + 7 us that left the critical path.  Off by default; kept because the
+# one-call step is what a multi-GPU exchange would hide behind pass C.
+_INBATCH_ONECALL = _os.environ.get("ESR_INBATCH_ONECALL", "1") == "1"
+_INBATCH_OVERLAP = _os.environ.get("ESR_INBATCH_OVERLAP", "0") == "1"
+
+
+def _inbatch_one_call(state, st, pt, B, precision):
+    """True when an in-batch step can be the one library call: the build's row-sparse Adagrad, towers of one dtype and
+    width on the fp16 x 2 score path."""
+    from ..train_state import _SparseAdagrad
+    if not _INBATCH_ONECALL or not isinstance(state.tx, _SparseAdagrad) or not st.is_cuda or st.dtype != pt.dtype or \
+            st.shape[1] != pt.shape[1] or precision == "f32" or st.shape[0] + pt.shape[0] >= (1 << 31):
+        return False
+    try:
+        return ops.inbatch_split_path(precision, B, st.shape[1], bf16_tables=st.dtype == torch.bfloat16) == "f16x2"
+    except ValueError:
+        return False
+
+
 class PresortedTriplets:
     """The ids of one triplet batch on the device with their occurrence list [scene ; Vs + pos ; Vs + neg] already sorted
     on the side stream (``presort_triplets``): pass it as ``train_step(state, that, None, None, ...)``.  The sort needs
@@ -191,6 +214,19 @@ def train_step(state, scene, pos_product, neg_product, regularization, batch_siz
     prefix = ("params",) if "params" in state.params else ()
     paths = [prefix + ("scene_tower", "embedding"), prefix + ("product_tower", "embedding")]
     Vs, Vp = st.shape[0], pt.shape[0]
+    if neg_product is None and _inbatch_one_call(state, st, pt, B, precision):
+        # the whole step -- gather + split, pass Q, [merge<Q> + scene-tower Adagrad] beside [pass C, merge<C>, product-tower
+        # Adagrad] -- as ONE library call (esr_inbatch_train_step_f16x2; round 5)
+        from ..train_state import _side_stream
+        acc = state.opt_state["sum_of_squares"]
+        acc = acc["params"] if prefix else acc
+        srt, long_runs = None, -1
+        if presorted is not None and presorted.sorted_ids is not None:
+            srt, long_runs = presorted.take(), presorted.long_runs()
+        loss = ops.inbatch_train_step(st, acc["scene_tower"]["embedding"], pt, acc["product_tower"]["embedding"], sid, pid,
+                                      scale, regularization, batch_size, state.tx.lr, state.tx.eps, presorted=srt,
+                                      long_runs=long_runs, side_stream=_side_stream(dev) if _INBATCH_OVERLAP else None)
+        return state.replace(step=state.step + 1), loss.reshape(())
     if neg_product is None:
         fused = FusedScatter([sid, pid], [0, 1], [Vs, Vp], None, paths) if sparse else None
         if fused is not None and presorted is not None:

@@ -223,3 +223,57 @@ def test_planned_batch_refuses_another_state(dev):
     assert torch.equal(other.params["params"]["scene_tower"]["embedding"], before)
     a, loss = train_step(a, scene, pos, neg, 0.1, float(B))     # the refused calls did not consume the handle
     assert np.isfinite(float(loss)) and int(a.step) == 1
+
+
+@pytest.mark.parametrize("B,D,ids", [(1024, 128, "uniform"), (2048, 128, "hot"), (512, 64, "hot"), (8192, 128, "uniform")])
+def test_inbatch_one_call_step_equals_fwd_bwd_plus_update(dev, monkeypatch, B, D, ids):
+    """The in-batch step as ONE library call (esr_inbatch_train_step_f16x2) -- with merge<Q> and the scene tower's
+    Adagrad on a second stream beside pass C, and without the second stream -- against rounds 1-4's
+    esr_inbatch_towers_fwd_bwd_f16x2 + esr_sparse_adagrad_scatter_multi: same kernels on the same values, so losses, towers
+    and accumulators are bit-identical; through train_step alone (sort inside the call) and through train_steps (lists of
+    eight batches sorted ahead, long-run hints).  "hot": 40 % of the ids are three rows (runs of hundreds: the update's
+    long-run launch on each half of the occurrence list)."""
+    import esrecsys_amd.pinterest.train_shop_the_look as stl
+    from esrecsys_amd import TrainState, optim
+    from esrecsys_amd.pinterest.models import STLModel
+    Vs, Vp, steps = 5000, 7000, 5
+    rng = np.random.default_rng(B + D)
+
+    def draw(V):
+        if ids == "hot":
+            return np.where(rng.random(B) < 0.4, rng.integers(0, 3, B), rng.integers(0, V, B)).astype(np.int32)
+        return rng.integers(0, V, B).astype(np.int32)
+    batches = [(torch.from_numpy(draw(Vs)).to(dev), torch.from_numpy(draw(Vp)).to(dev), None) for _ in range(steps)]
+
+    def state():
+        g = torch.Generator(device=dev).manual_seed(3)
+        params = {"params": {"scene_tower": {"embedding": torch.randn((Vs, D), generator=g, device=dev) * 0.3},
+                             "product_tower": {"embedding": torch.randn((Vp, D), generator=g, device=dev) * 0.3}}}
+        model = STLModel(output_size=D, num_scenes=Vs, num_products=Vp, device=dev)
+        return TrainState.create(apply_fn=model.apply, params=params, tx=optim.sparse_adagrad(0.05))
+
+    def run(onecall, overlap, loop):
+        monkeypatch.setattr(stl, "_INBATCH_ONECALL", onecall)
+        monkeypatch.setattr(stl, "_INBATCH_OVERLAP", overlap)
+        st = state()
+        if loop:
+            st, losses = stl.train_steps(st, iter(batches), steps, 0.1, float(B), scale=4.0, precision="f16x2")
+        else:
+            losses = []
+            for b in batches:
+                st, l = stl.train_step(st, b[0], b[1], None, 0.1, float(B), scale=4.0, precision="f16x2")
+                losses.append(l.clone())
+            losses = torch.stack(losses)
+        torch.cuda.synchronize()
+        p, a = st.params["params"], st.opt_state["sum_of_squares"]["params"]
+        return [losses] + [t[k]["embedding"] for t in (p, a) for k in ("scene_tower", "product_tower")]
+    want = run(False, False, False)
+    assert np.isfinite(want[0].cpu().numpy()).all() and int(want[0].numel()) == steps
+    bad = []
+    names = ("losses", "scene tower", "product tower", "scene accumulator", "product accumulator")
+    for onecall, overlap, loop in ((True, True, False), (True, False, False), (True, True, True), (False, False, True)):
+        got = run(onecall, overlap, loop)
+        for name, x, y in zip(names, got, want):
+            if not torch.equal(x, y):
+                bad.append((onecall, overlap, loop, name, float((x.float() - y.float()).abs().max())))
+    assert not bad, bad
