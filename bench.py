@@ -1028,12 +1028,17 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        from bench_sharded import Watchdog, run_sharded  # row-sharded step with RCCL all-to-all
+        # a rendezvous or RCCL bootstrap that never completes prints ONE diagnostic JSON line and exits (status 3) instead
+        # of hanging the node (ESR_BENCH_PREFLIGHT_TIMEOUT seconds per phase, default 240)
+        watchdog = Watchdog(rank, world)
+        watchdog.arm("torch.distributed rendezvous (init_process_group)")
         if one_gpu_wire:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        from bench_sharded import run_sharded  # row-sharded step with RCCL all-to-all
-        return run_sharded(args, cfg, dev, rank, world)
+        watchdog.disarm()
+        return run_sharded(args, cfg, dev, rank, world, watchdog)
 
     # A short timed region (the driver's --steps 20 --warmup 5 is 6 ms) started on an idle chip sits inside the power
     # manager's transient: the first steps run at boost clock (0.232 ms), the package overshoots its cap, is clamped

@@ -13,8 +13,65 @@ import torch.distributed as dist
 LAM, SCALE, LR, SEED = 0.1, 8.0, 0.05, 1701
 
 
-def run_sharded(args, cfg, dev, rank, world):
+class Watchdog:
+    """A phase of the N > 1 run that must not hang a GPU node silently (process-group rendezvous, the RCCL bootstrap and its
+    self-test): if `arm(what)` is not followed by `disarm()` within the limit, ONE diagnostic JSON line goes to stdout
+    and the process exits with status 3 -- the driver then has a record instead of a timeout."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world, self.timer = rank, world, None
+        self.limit = float(os.environ.get("ESR_BENCH_PREFLIGHT_TIMEOUT", "240"))
+
+    def arm(self, what):
+        import threading
+        self.disarm()
+
+        def fire():
+            print(json.dumps({"preflight": {"ok": False, "rank": self.rank, "world_size": self.world, "hung_in": what,
+                                            "after_s": self.limit,
+                                            "hint": "a peer never reached this phase, or RCCL could not open its links "
+                                                    "(HSA_ENABLE_IPC_MODE_LEGACY=0? MASTER_ADDR=127.0.0.1?)"}}), flush=True)
+            os._exit(3)
+        self.timer = threading.Timer(self.limit, fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+
+def preflight(dev, rank, world, watchdog):
+    """Before anything is timed: the exchange communicator is built (rccl.py: bind, ncclCommInitRank, a bounded self-test
+    all-to-all with known contents, every phase agreed over the process group) under the watchdog, and rank 0 prints one
+    JSON line saying what the run will exchange through.  Returns the record."""
+    from esrecsys_amd import rccl
+    t0 = time.perf_counter()
+    watchdog.arm("RCCL bootstrap + self-test (esrecsys_amd/rccl.py)")
+    x = rccl.exchange_for(None, dev)
+    x2 = rccl.exchange_for(None, dev, lane=1) if x is not None and os.environ.get("ESR_SHARDED_OVERLAP", "0") == "1" else None
+    watchdog.disarm()
+    wire = os.environ.get("ESR_RCCL_LIB")
+    kind = "torch.distributed" if x is None else ("loopback" if wire else "rccl")
+    rec = {"ok": True, "world_size": world, "backend": dist.get_backend(), "exchange": kind,
+           "rccl_ranks": x.ranks_seen()[0] if x is not None else None,
+           "second_communicator": x2 is not None, "bootstrap_and_selftest_s": round(time.perf_counter() - t0, 3),
+           "library": os.path.basename(wire) if wire else "torch's librccl"}
+    if x is not None and rec["rccl_ranks"] != world:
+        rec["ok"] = False
+        rec["error"] = "the communicator reports %s ranks, the launch has %d" % (rec["rccl_ranks"], world)
+    if rank == 0:
+        print(json.dumps({"preflight": rec}), flush=True)
+    if not rec["ok"]:
+        raise SystemExit(3)
+    return rec
+
+
+def run_sharded(args, cfg, dev, rank, world, watchdog=None):
     from esrecsys_amd import ops, sharded
+    watchdog = watchdog or Watchdog(rank, world)
+    pre = preflight(dev, rank, world, watchdog) if world > 1 else None
     V, D, B = cfg["V"], cfg["D"], cfg["B"]
     gen = torch.Generator(device=dev)
     gen.manual_seed(SEED + 17 * rank)
@@ -182,6 +239,22 @@ def run_sharded(args, cfg, dev, rank, world):
         exchange = ("DRY RUN over %s (every rank on ONE GPU, bytes over sockets): the library's grouped send / recv code "
                     "path, NOT RCCL / xGMI -- the value is not a scaling measurement" % os.path.basename(os.environ["ESR_RCCL_LIB"]))
     rccl_ranks = xch.ranks_seen()[0] if xch is not None else None  # ncclCommCount of the exchange communicator
+    exchange_kind = "torch.distributed" if xch is None else ("loopback" if os.environ.get("ESR_RCCL_LIB") else "rccl")
+    # what this rank puts on the wire per unit of work, from the LAST batch's routing plan (rows addressed to other ranks)
+    wire = None
+    if not no_plans:
+        p_last = begin(batches[-1]).finish()
+        out_rows = sum(c for peer, c in enumerate(p_last.send_counts) if peer != rank)
+        s_b = 2 if cfg.get("table_dtype") == "bf16" else 4
+        g_name = getattr(grp0, "grad_dtype", "f32") or "f32"
+        g_b = 2 if g_name == "bf16" else 4
+        wire = {"rows_to_other_ranks_per_step": out_rows, "of_rows_per_step": int(p_last.n_rows),
+                "ids_int32": round(4.0 * out_rows / B, 1),
+                "rows_%s" % ("bf16" if s_b == 2 else "f32"): round(float(s_b * D * out_rows) / B, 1),
+                "grads_%s" % g_name: round(float(g_b * D * out_rows) / B, 1)}
+        wire["total_per_unit_each_way"] = round(wire["ids_int32"] + (s_b + g_b) * D * out_rows / B, 1)
+        wire["note"] = "bytes this rank sends (ids, gradient rows) or receives (rows) per %s; SURVEY 8d budgets 910 for " \
+                       "config 4 (bf16 rows + bf16 gradients, G = 8)" % cfg["unit"]
     if rank == 0:
         K = args.steps
         from bench import emit, sustained_bf16_mfma_tflops, MFMA_BF16_PEAK_TFLOPS
@@ -210,7 +283,8 @@ def run_sharded(args, cfg, dev, rank, world):
                                    % (args.workload, V, D, "bf16" if cfg.get("table_dtype") == "bf16" else "fp32",
                                       world, B),
                        "parallelism": par,
-                       "exchange": exchange, "rccl_ranks": rccl_ranks, "world_size": world,
+                       "exchange": exchange, "exchange_kind": exchange_kind, "rccl_ranks": rccl_ranks, "world_size": world,
+                       "wire_bytes_per_unit": wire, "preflight": pre,
                        "gradient_rows_on_the_wire": getattr(grp0, "grad_dtype", "f32") if grp0 is not None else "f32",
                        "routing_plans": ("made for %d coming batches at a time (one bucket launch pair, one counts "
                                          "all-to-all, one RCCL group of ids exchanges, one owner-side sort per group)"

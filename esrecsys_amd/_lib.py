@@ -38,6 +38,7 @@ SIGNATURES = {
                                 ctypes.c_char_p, c_int]),
     "esr_kernel_timing": (c_int, [c_int]),
     "esr_kernel_timing_read": (ctypes.c_long, [ctypes.c_char_p, c_size]),
+    "esr_trace_markers": (c_int, [c_int]),
     "esr_gather_rows": (c_int, [c_vp, c_int, c_i64, c_int, c_i32p, c_i64, c_vp, c_vp]),
     "esr_check_ids": (c_int, [c_i32p, c_i64, c_i64, c_vp, c_vp]),
     "esr_unpermute_rows": (c_int, [c_vp, c_int, c_int, c_i32p, c_i64, c_vp, c_vp]),
@@ -134,6 +135,7 @@ SIGNATURES = {
     "esr_rescore_candidates": (c_int, [c_f32p, c_f32p, c_i64, c_i64, c_int, c_i32p, c_int, ctypes.c_int32,
                                        ctypes.c_int32, c_f32p, c_vp]),
     "esr_topk_merge": (c_int, [c_f32p, c_i32p, c_i64, c_int, c_int, c_f32p, c_i32p, c_vp]),
+    "esr_recall_at_k": (c_int, [c_i32p, c_i64, c_int, c_i32p, c_int, c_vp, c_vp]),
     "esr_spotify_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int]),
     "esr_spotify_get_embeddings": (c_int, [c_f32p, c_i64, c_f32p, c_i64, c_int, c_i32p, c_i32p, c_i64, c_f32p, c_f32p,
                                            c_vp]),

@@ -47,11 +47,29 @@ inline hipStream_t as_stream(esr_stream_t s) { return reinterpret_cast<hipStream
 extern int g_ktimer_on;
 void ktimer_begin(const char* name, hipStream_t st);
 void ktimer_end(hipStream_t st);
+// rocprofv3 markers (tracing row): OFF by default (one relaxed load per site); ESR_ROCTX=1 in the
+// environment or esr_trace_markers(1) turns every ESR_KT launch site and every step entry point into a roctx range
+// (roctxRangePushA / roctxRangePop of the rocprofiler-sdk roctx library, bound with dlopen on first use), so a
+// `rocprofv3 --marker-trace --kernel-trace` timeline shows which step phase each kernel belongs to.
+extern int g_trace_on;
+void trace_push(const char* name);
+void trace_pop();
+struct TraceScope {
+  bool on;
+  explicit TraceScope(const char* name) : on(g_trace_on != 0) {
+    if (on) trace_push(name);
+  }
+  ~TraceScope() {
+    if (on) trace_pop();
+  }
+};
 #define ESR_KT(NAME, ST, ...)                                  \
   do {                                                         \
+    if (esr::g_trace_on) esr::trace_push((NAME));              \
     if (esr::g_ktimer_on) esr::ktimer_begin((NAME), (ST));     \
     __VA_ARGS__;                                               \
     if (esr::g_ktimer_on) esr::ktimer_end((ST));               \
+    if (esr::g_trace_on) esr::trace_pop();                     \
   } while (0)
 
 #define ESR_REQUIRE(cond, ...)        \

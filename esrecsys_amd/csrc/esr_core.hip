@@ -1,4 +1,7 @@
 // Error plumbing, device query and the row gather / un-permute kernels.
+#include <dlfcn.h>
+#include <stdlib.h>
+
 #include "esr_common.h"
 #include <string.h>
 #include <mutex>
@@ -30,6 +33,40 @@ int check_launch(const char* what) {
 // kernel is launched on).  Records are (static name, start event, stop event); esr_kernel_timing_read waits for them.
 // ---------------------------------------------------------------------------------------------
 int g_ktimer_on = 0;
+
+// ---- roctx markers ----------------------------------------------------------------------------------------------------
+namespace {
+typedef int (*fn_roctx_push)(const char*);
+typedef int (*fn_roctx_pop)(void);
+fn_roctx_push g_roctx_push = nullptr;
+fn_roctx_pop g_roctx_pop = nullptr;
+bool roctx_bind() {
+  static const bool ok = [] {
+    const char* libs[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"};
+    for (const char* l : libs) {
+      void* h = dlopen(l, RTLD_NOW | RTLD_GLOBAL);
+      if (!h) continue;
+      g_roctx_push = reinterpret_cast<fn_roctx_push>(dlsym(h, "roctxRangePushA"));
+      g_roctx_pop = reinterpret_cast<fn_roctx_pop>(dlsym(h, "roctxRangePop"));
+      if (g_roctx_push && g_roctx_pop) return true;
+    }
+    return false;
+  }();
+  return ok;
+}
+int trace_env() {
+  const char* e = getenv("ESR_ROCTX");
+  return (e && e[0] == '1' && roctx_bind()) ? 1 : 0;
+}
+}  // namespace
+int g_trace_on = trace_env();
+void trace_push(const char* name) {
+  if (g_roctx_push) g_roctx_push(name);
+}
+void trace_pop() {
+  if (g_roctx_pop) g_roctx_pop();
+}
+
 namespace {
 struct KtRecord {
   const char* name;
@@ -239,6 +276,16 @@ int esr_check_ids(const int32_t* ids, int64_t n, int64_t V, int64_t* report, esr
 const char* esr_last_error(void) { return g_err; }
 
 int esr_version(void) { return 101; }
+
+int esr_trace_markers(int enable) {
+  if (enable && !roctx_bind()) {
+    set_error("esr_trace_markers: no roctx library (librocprofiler-sdk-roctx.so.1 / libroctx64.so.4) on the loader path");
+    g_trace_on = 0;
+    return ESR_ENODEVICE;
+  }
+  g_trace_on = enable ? 1 : 0;
+  return ESR_OK;
+}
 
 int esr_kernel_timing(int enable) {
   std::lock_guard<std::mutex> lock(g_kt_mu);

@@ -1310,6 +1310,7 @@ int esr_glove_forward(const float* emb, const float* bias, int64_t V, int D, con
 int esr_glove_fwd_bwd(const float* emb, const float* bias, int64_t V, int D, const int32_t* inputs,
                       const float* target, int64_t B, int mode, float* loss, float* grad_rows,
                       float* grad_bias, void* workspace, size_t workspace_bytes, esr_stream_t stream) {
+  TraceScope trace_scope_("esr_glove_fwd_bwd");
   ESR_REQUIRE(B > 0 && V > 0 && D > 0, "esr_glove_fwd_bwd: bad sizes V=%lld D=%d B=%lld", (long long)V, D,
               (long long)B);
   ESR_REQUIRE((mode & ~ESR_GRADS_AT_IDS) == ESR_GLOVE_REFERENCE || (mode & ~ESR_GRADS_AT_IDS) == ESR_GLOVE_DIAGONAL,
@@ -1392,6 +1393,7 @@ int esr_long_run_hint(const int32_t* sorted_ids, int64_t n, int chunk, int32_t* 
 int esr_glove_plan(const int32_t* const* inputs, const float* const* targets, int nbatch, int64_t B,
                    const int32_t* sorted_ids, const int32_t* perm, void* plans, int32_t* hints, int32_t gen,
                    esr_stream_t stream) {
+  TraceScope trace_scope_("esr_glove_plan");
   ESR_REQUIRE(nbatch >= 1 && nbatch <= kMaxGlovePlanBatch && B > 0 && 2 * B < ((int64_t)1 << 31),
               "esr_glove_plan: nbatch=%d not in [1, %d] or bad B=%lld", nbatch, kMaxGlovePlanBatch, (long long)B);
   ESR_REQUIRE(inputs && targets && sorted_ids && perm && plans && !((uintptr_t)plans & 255),
@@ -1523,6 +1525,7 @@ int esr_glove_train_step(float* emb, float* emb_shadow, uint8_t* emb_loc, float*
                          const int32_t* presorted_perm, void* plan, int long_runs, int blocks_per_cu,
                          uint32_t* start_flag, uint32_t start_value, float* loss, void* workspace,
                          size_t workspace_bytes, esr_stream_t stream) {
+  TraceScope trace_scope_("esr_glove_train_step");
   ESR_GLOVE_STEP_CHECKS("esr_glove_train_step")
   ESR_REQUIRE(inputs && target && loss, "esr_glove_train_step: null pointer");
   ESR_REQUIRE(stamp >= 1 && stamp <= kStampMax, "esr_glove_train_step: stamp %u not in [1, %u]", stamp, kStampMax);
@@ -1552,6 +1555,7 @@ int esr_glove_train_steps(float* emb, float* emb_shadow, uint8_t* emb_loc, float
                           const float* const* targets, int64_t B, int mode, float lr, float eps, uint32_t first_stamp,
                           const int32_t* sorted_ids, const int32_t* perm, void* plans, const int32_t* long_runs,
                           float* losses, void* workspace, size_t workspace_bytes, esr_stream_t stream) {
+  TraceScope trace_scope_("esr_glove_train_steps");
   ESR_GLOVE_STEP_CHECKS("esr_glove_train_steps")
   ESR_REQUIRE(nbatch >= 1 && nbatch <= kMaxGlovePlanBatch && inputs && targets && sorted_ids && perm && plans && losses &&
                   !((uintptr_t)plans & 255),

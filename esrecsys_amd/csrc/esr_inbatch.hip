@@ -525,6 +525,7 @@ size_t esr_inbatch_workspace_bytes(int64_t B, int D) {
 int esr_inbatch_softmax_fwd_bwd(const float* Q, const float* C, int64_t B, int D, float scale, float regularization,
                                 float batch_size, float* loss, float* lse, float* gQ, float* gC, void* workspace,
                                 size_t workspace_bytes, esr_stream_t stream) {
+  TraceScope trace_scope_("esr_inbatch_softmax_fwd_bwd");
   ESR_REQUIRE(B > 0, "esr_inbatch_softmax_fwd_bwd: B=%lld must be positive", (long long)B);
   ESR_REQUIRE(D > 0 && D <= 512 && D % 4 == 0, "esr_inbatch_softmax_fwd_bwd: D=%d not supported (a multiple of 4, at most 512)", D);
   ESR_REQUIRE(Q && C && loss && gQ && gC, "esr_inbatch_softmax_fwd_bwd: null pointer");

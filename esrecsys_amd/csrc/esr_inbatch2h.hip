@@ -1846,6 +1846,7 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
 int esr_inbatch_softmax_fwd_bwd_f16x2(const float* Q, const float* C, int64_t B, int D, float scale,
                                       float regularization, float batch_size, float* loss, float* lse, float* gQ,
                                       float* gC, void* workspace, size_t workspace_bytes, esr_stream_t stream) {
+  TraceScope trace_scope_("esr_inbatch_softmax_fwd_bwd_f16x2");
   return inbatch2h_run("esr_inbatch_softmax_fwd_bwd_f16x2", RowSrc{Q, nullptr, 0, D}, RowSrc{C, nullptr, 0, D}, nullptr,
                        nullptr, B, D, scale, regularization, batch_size, loss, lse, gQ, gC, workspace, workspace_bytes,
                        stream);
@@ -1856,6 +1857,7 @@ int esr_inbatch_towers_fwd_bwd_f16x2(const void* query_table, int64_t Vq, const 
                                      const int32_t* gc_rows, int64_t B, float scale, float regularization,
                                      float batch_size, float* loss, float* lse, float* gQ, float* gC, void* workspace,
                                      size_t workspace_bytes, esr_stream_t stream) {
+  TraceScope trace_scope_("esr_inbatch_towers_fwd_bwd_f16x2");
   ESR_REQUIRE(Vq > 0 && Vc > 0 && query_ids && cand_ids, "esr_inbatch_towers_fwd_bwd_f16x2: bad tables / ids");
   ESR_REQUIRE(dtype == ESR_F32 || dtype == ESR_BF16, "esr_inbatch_towers_fwd_bwd_f16x2: bad dtype %d", dtype);
   return inbatch2h_run("esr_inbatch_towers_fwd_bwd_f16x2", RowSrc{query_table, query_ids, dtype == ESR_BF16, D},
@@ -1899,6 +1901,7 @@ int esr_inbatch_train_step_f16x2(void* query_table, float* query_accum, int64_t 
                                  const int32_t* presorted_vids, const int32_t* presorted_perm, int long_runs, float* loss,
                                  float* lse, void* workspace, size_t workspace_bytes, esr_stream_t stream,
                                  esr_stream_t side_stream) {
+  TraceScope trace_scope_("esr_inbatch_train_step_f16x2");
   const char* who = "esr_inbatch_train_step_f16x2";
   ESR_REQUIRE(Vq > 0 && Vc > 0 && query_table && cand_table && query_accum && cand_accum && query_ids && cand_ids,
               "%s: bad tables / ids", who);

@@ -1040,6 +1040,7 @@ static int inbatch3_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* gq
 int esr_inbatch_softmax_fwd_bwd_bf16x3(const float* Q, const float* C, int64_t B, int D, float scale,
                                        float regularization, float batch_size, float* loss, float* lse, float* gQ,
                                        float* gC, void* workspace, size_t workspace_bytes, esr_stream_t stream) {
+  TraceScope trace_scope_("esr_inbatch_softmax_fwd_bwd_bf16x3");
   return inbatch3_run("esr_inbatch_softmax_fwd_bwd_bf16x3", RowSrc{Q, nullptr, 0, D}, RowSrc{C, nullptr, 0, D}, nullptr, nullptr,
                       B, D, scale,
                       regularization, batch_size, loss, lse, gQ, gC, workspace, workspace_bytes, stream);
@@ -1051,6 +1052,7 @@ int esr_inbatch_towers_fwd_bwd_bf16x3(const void* query_table, int64_t Vq, const
                                       float scale, float regularization, float batch_size, float* loss, float* lse,
                                       float* gQ, float* gC, void* workspace, size_t workspace_bytes,
                                       esr_stream_t stream) {
+  TraceScope trace_scope_("esr_inbatch_towers_fwd_bwd_bf16x3");
   ESR_REQUIRE(Vq > 0 && Vc > 0 && query_ids && cand_ids, "esr_inbatch_towers_fwd_bwd_bf16x3: bad tables / ids");
   ESR_REQUIRE(dtype == ESR_F32 || dtype == ESR_BF16, "esr_inbatch_towers_fwd_bwd_bf16x3: bad dtype %d", dtype);
   return inbatch3_run("esr_inbatch_towers_fwd_bwd_bf16x3", RowSrc{query_table, query_ids, dtype == ESR_BF16, D},

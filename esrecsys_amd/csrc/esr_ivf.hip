@@ -288,6 +288,7 @@ size_t esr_ivf_search_workspace_bytes(int64_t nq, int nlist, int max_list, int n
 int esr_ivf_search(const float* queries, int64_t nq, int D, const float* cands_sorted, const int32_t* list_off,
                    const int32_t* orig, int nlist, int max_list, const int32_t* probe_lists, int nprobe, int k,
                    float* out_scores, int32_t* out_indices, void* workspace, size_t workspace_bytes, esr_stream_t stream) {
+  TraceScope trace_scope_("esr_ivf_search");
   ESR_REQUIRE(nlist <= 32768, "esr_ivf_search: nlist=%d exceeds 32768 (the score kernel's row tiles are a grid dimension)", nlist);
   ESR_REQUIRE(nq > 0 && D > 0 && D % 4 == 0 && nlist > 0 && max_list > 0 && nprobe > 0 && nprobe <= nlist && k > 0 &&
                   k <= kSelectMaxK && (int64_t)nprobe * k < ((int64_t)1 << 24),

@@ -834,6 +834,7 @@ int esr_sparse_adagrad_scatter_multi(void* const* tables, float* const* accums, 
                                      int ntables, int dtype, int D, const int32_t* sorted_vids, const int32_t* perm,
                                      int64_t n, float* grad_rows, float lr, float eps, int long_runs,
                                      esr_stream_t stream) {
+  TraceScope trace_scope_("esr_sparse_adagrad_scatter_multi");
   ESR_REQUIRE(ntables >= 1 && ntables <= kMaxFusedTables, "esr_sparse_adagrad_scatter_multi: ntables=%d not in [1, %d]",
               ntables, kMaxFusedTables);
   ESR_REQUIRE(D > 0 && n >= 0, "esr_sparse_adagrad_scatter_multi: bad sizes D=%d n=%lld", D, (long long)n);

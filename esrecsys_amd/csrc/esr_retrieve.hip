@@ -943,6 +943,48 @@ static void launch_gemm(const __bf16* A, int64_t a_plane, const __bf16* B, int64
                      Dp, tm, tn, M, nvalid, o));
 }
 
+
+// recall of an approximate top-k against the exact one, O(ka + ke) per query: one workgroup per query puts the approximate
+// ids into an open-addressing table in LDS and probes it with the exact ids; the hits of all queries are added to ONE
+// 64-bit word (integer: order-free).  (The torch form -- an [Q, ka, ke] boolean cube -- was 2 GB at 8192 x 500 x 500.)
+constexpr int kRecallMaxK = 8192;
+__global__ __launch_bounds__(256) void recall_at_k_kernel(const int32_t* __restrict__ approx, int ka,
+                                                         const int32_t* __restrict__ exact, int ke, int cap,
+                                                         unsigned long long* __restrict__ hits) {
+  extern __shared__ int32_t tab[];  // cap slots, cap = a power of two >= 2 ka; empty = INT32_MIN
+  __shared__ int s_hits;
+  const int64_t q = blockIdx.x;
+  for (int i = threadIdx.x; i < cap; i += 256) tab[i] = INT32_MIN;
+  if (threadIdx.x == 0) s_hits = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < ka; i += 256) {
+    const int32_t v = approx[q * ka + i];
+    if (v == INT32_MIN) continue;
+    unsigned h = ((unsigned)v * 2654435761u) & (unsigned)(cap - 1);
+    for (;;) {
+      const int32_t old = atomicCAS(&tab[h], INT32_MIN, v);
+      if (old == INT32_MIN || old == v) break;
+      h = (h + 1) & (unsigned)(cap - 1);
+    }
+  }
+  __syncthreads();
+  int mine = 0;
+  for (int j = threadIdx.x; j < ke; j += 256) {
+    const int32_t v = exact[q * ke + j];
+    if (v == INT32_MIN) continue;
+    unsigned h = ((unsigned)v * 2654435761u) & (unsigned)(cap - 1);
+    for (;;) {
+      const int32_t t = tab[h];
+      if (t == v) { ++mine; break; }
+      if (t == INT32_MIN) break;
+      h = (h + 1) & (unsigned)(cap - 1);
+    }
+  }
+  if (mine) atomicAdd(&s_hits, mine);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_hits) atomicAdd(hits, (unsigned long long)s_hits);
+}
+
 }  // namespace esr
 
 using namespace esr;
@@ -957,6 +999,7 @@ size_t esr_retrieve_workspace_bytes(int64_t nq, int64_t N, int D, int k, int mod
 int esr_retrieve_topk(const float* queries, const float* candidates, int64_t nq, int64_t N, int D, int k, int mode,
                       int32_t index_base, int32_t index_step, float* out_scores, int32_t* out_indices, void* workspace,
                       size_t workspace_bytes, esr_stream_t stream) {
+  TraceScope trace_scope_("esr_retrieve_topk");
   ESR_REQUIRE(nq > 0 && N > 0 && D > 0 && k > 0 && k <= N && k <= kSelMaxK && N < ((int64_t)1 << 31) &&
                   nq < ((int64_t)1 << 24),
               "esr_retrieve_topk: bad sizes nq=%lld N=%lld D=%d k=%d (k <= min(N, %d))", (long long)nq, (long long)N, D,
@@ -1094,6 +1137,23 @@ int esr_topk_merge(const float* scores, const int32_t* indices, int64_t nq, int 
   hipLaunchKernelGGL(topk_select_kernel, dim3((int)nq), dim3(kSelThreads), lds_words * sizeof(uint32_t),
                      as_stream(stream), in, k, so, lds_words);
   return check_launch("esr_topk_merge");
+}
+
+
+int esr_recall_at_k(const int32_t* approx, int64_t nq, int ka, const int32_t* exact, int ke, unsigned long long* hits,
+                    esr_stream_t stream) {
+  TraceScope trace_scope_("esr_recall_at_k");
+  ESR_REQUIRE(nq >= 0 && ka > 0 && ke > 0 && ka <= kRecallMaxK, "esr_recall_at_k: bad sizes nq=%lld ka=%d ke=%d (ka <= %d)",
+              (long long)nq, ka, ke, kRecallMaxK);
+  ESR_REQUIRE(hits && (nq == 0 || (approx && exact)), "esr_recall_at_k: null pointer");
+  hipStream_t st = as_stream(stream);
+  if (hipMemsetAsync(hits, 0, sizeof(unsigned long long), st) != hipSuccess) return check_launch("esr_recall_at_k");
+  if (nq == 0) return ESR_OK;
+  int cap = 64;
+  while (cap < 2 * ka) cap <<= 1;
+  hipLaunchKernelGGL(recall_at_k_kernel, dim3((unsigned)nq), dim3(256), (size_t)cap * sizeof(int32_t), st, approx, ka, exact,
+                     ke, cap, hits);
+  return check_launch("esr_recall_at_k");
 }
 
 }  // extern "C"

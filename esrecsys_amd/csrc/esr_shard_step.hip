@@ -73,6 +73,7 @@ int esr_rows_f32_to_bf16(const float* rows, int64_t n, int D, void* rows_bf16, e
 int esr_sharded_lookup(esr_comm_t comm, int world, const void* const* tables, const int64_t* row_offsets, int ntables,
                        int dtype, int D, const int32_t* asked_rows, const int64_t* asked_counts,
                        const int64_t* ask_counts, void* served, void* back, esr_stream_t stream) {
+  TraceScope trace_scope_("esr_sharded_lookup");
   ESR_REQUIRE(world >= 1 && asked_counts && ask_counts, "esr_sharded_lookup: world=%d, or null count arrays", world);
   for (int p = 0; p < world; ++p)
     ESR_REQUIRE(asked_counts[p] >= 0 && ask_counts[p] >= 0, "esr_sharded_lookup: negative count for peer %d", p);
@@ -95,6 +96,7 @@ int esr_sharded_update(esr_comm_t comm, int world, void* const* tables, float* c
                        const int64_t* asked_counts, int grad_dtype, void* send_bf16, void* recv_raw, float* recv_grads,
                        const int32_t* owner_sorted, const int32_t* owner_perm, float lr, float eps, int long_runs,
                        esr_stream_t stream) {
+  TraceScope trace_scope_("esr_sharded_update");
   ESR_REQUIRE(world >= 1 && asked_counts && ask_counts, "esr_sharded_update: world=%d, or null count arrays", world);
   ESR_REQUIRE(grad_dtype == ESR_F32 || grad_dtype == ESR_BF16, "esr_sharded_update: grad_dtype must be ESR_F32 or ESR_BF16");
   ESR_REQUIRE(D > 0 && n_occ >= 0, "esr_sharded_update: bad sizes D=%d n=%lld", D, (long long)n_occ);
@@ -321,6 +323,7 @@ int esr_sharded_triplet_step(const esr_shard_group_t* towers, const esr_routing_
 int esr_sharded_triplet_step_overlapped(const esr_shard_group_t* towers, const esr_routing_plan_t* plan,
                                         esr_step_overlap_t* ov, int64_t B, float regularization, float batch_size, float lr,
                                         float eps, float* loss, void* workspace, size_t workspace_bytes, esr_stream_t stream) {
+  TraceScope trace_scope_("esr_sharded_triplet_step_overlapped");
   int64_t n_rows = 0, n_recv = 0;
   if (int rc = plan_counts("esr_sharded_triplet_step", towers, plan, &n_rows, &n_recv)) return rc;
   ESR_REQUIRE(B > 0 && loss && plan->index, "esr_sharded_triplet_step: B=%lld, or null loss / plan index", (long long)B);
@@ -378,6 +381,7 @@ int esr_sharded_glove_step_overlapped(const esr_shard_group_t* emb, const esr_sh
                                       const esr_routing_plan_t* plan, esr_step_overlap_t* ov, const float* target, int64_t B,
                                       int mode, float lr, float eps, float* loss, void* workspace, size_t workspace_bytes,
                                       esr_stream_t stream) {
+  TraceScope trace_scope_("esr_sharded_glove_step_overlapped");
   int64_t n_rows = 0, n_recv = 0;
   if (int rc = plan_counts("esr_sharded_glove_step", emb, plan, &n_rows, &n_recv)) return rc;
   ESR_REQUIRE(bias && bias->world == emb->world && bias->D == 1 && bias->ntables == 1 && emb->ntables == 1,

@@ -1217,6 +1217,7 @@ int esr_segment_sort_ids(const int32_t* ids, int64_t n, int64_t V, int32_t* sort
 int esr_segment_sort_ids_multi(const int32_t* const* ids, const int64_t* counts, const int64_t* offsets, int nseg,
                                int64_t V, int32_t* sorted_ids, int32_t* perm, void* workspace, size_t workspace_bytes,
                                esr_stream_t stream) {
+  TraceScope trace_scope_("esr_segment_sort_ids_multi");
   ESR_REQUIRE(nseg >= 1 && nseg <= kMaxSortSegs && ids && counts && offsets && V > 0,
               "esr_segment_sort_ids_multi: nseg=%d not in [1, %d] or null argument", nseg, kMaxSortSegs);
   SortSegs sg;
@@ -1249,6 +1250,7 @@ size_t esr_segment_sort_batched_workspace_bytes(int64_t n, int nbatch) {
 int esr_segment_sort_ids_batched(const int32_t* const* ids, const int64_t* counts, const int64_t* offsets, int nseg,
                                  int nbatch, int64_t V, int32_t* sorted_ids, int32_t* perm, void* workspace,
                                  size_t workspace_bytes, esr_stream_t stream) {
+  TraceScope trace_scope_("esr_segment_sort_ids_batched");
   ESR_REQUIRE(nseg >= 1 && nseg <= kMaxSortSegs && nbatch >= 1 && nbatch <= kMaxSortBatch && ids && counts && offsets &&
                   V > 0,
               "esr_segment_sort_ids_batched: nseg=%d not in [1, %d], nbatch=%d not in [1, %d], or null argument", nseg,
@@ -1310,6 +1312,7 @@ int esr_segment_sort_ids_batched(const int32_t* const* ids, const int64_t* count
 // ------------------------------------------------------------------------------------------------
 int esr_score_all(const float* emb, int64_t V, int D, const int32_t* token, int T, float* scores,
                   esr_stream_t stream) {
+  TraceScope trace_scope_("esr_score_all");
   ESR_REQUIRE(V > 0 && D > 0 && T > 0, "esr_score_all: bad sizes V=%lld D=%d T=%d", (long long)V, D, T);
   ESR_REQUIRE(emb && token && scores, "esr_score_all: null pointer");
   const RowGeom g = row_geom(D);

@@ -778,6 +778,7 @@ int esr_spotify_train_step(float* album_table, float* album_trace, int32_t* albu
                            const int32_t* album_ids, const int32_t* artist_ids, int n, int m, int o, float regularization,
                            int step, float lr, float momentum, float* loss, void* workspace, size_t workspace_bytes,
                            esr_stream_t stream) {
+  TraceScope trace_scope_("esr_spotify_train_step");
   if (int rc = sp_check("esr_spotify_train_step", n, m, o, F, n_album_rows, n_artists)) return rc;
   ESR_REQUIRE(album_table && album_trace && album_last && artist_table && artist_trace && artist_last && album_ids &&
                   artist_ids && loss && workspace && step >= 1,

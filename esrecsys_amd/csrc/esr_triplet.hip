@@ -101,6 +101,7 @@ int esr_triplet_fwd_bwd(const float* scene_table, int64_t Vs, const float* pos_t
                         int with_reg, float* loss, float* pos_score, float* neg_score,
                         float* g_scene, float* g_pos, float* g_neg, void* workspace,
                         size_t workspace_bytes, esr_stream_t stream) {
+  TraceScope trace_scope_("esr_triplet_fwd_bwd");
   ESR_REQUIRE(B > 0 && D > 0 && Vs > 0 && Vp > 0 && Vn > 0,
               "esr_triplet_fwd_bwd: bad sizes Vs=%lld Vp=%lld Vn=%lld D=%d B=%lld", (long long)Vs, (long long)Vp,
               (long long)Vn, D, (long long)B);

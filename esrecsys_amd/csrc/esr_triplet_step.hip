@@ -957,6 +957,7 @@ size_t esr_triplet_plan_bytes(int64_t B) {
 
 int esr_triplet_plan(const int32_t* const* ids, int nbatch, int64_t B, int64_t Vs, const int32_t* sorted_ids,
                      const int32_t* perm, void* plans, int32_t* hints, int32_t gen, esr_stream_t stream) {
+  TraceScope trace_scope_("esr_triplet_plan");
   ESR_REQUIRE(nbatch >= 1 && nbatch <= kMaxPlanBatch && B > 0 && Vs > 0 && 3 * B < ((int64_t)1 << 31),
               "esr_triplet_plan: nbatch=%d not in [1, %d] or bad sizes B=%lld Vs=%lld", nbatch, kMaxPlanBatch,
               (long long)B, (long long)Vs);
@@ -1079,6 +1080,7 @@ int esr_triplet_train_step(float* scene, float* scene_shadow, uint8_t* scene_loc
                            float eps, uint32_t stamp, const int32_t* presorted_ids, const int32_t* presorted_perm,
                            void* plan, int long_runs, float* loss, void* workspace, size_t workspace_bytes,
                            esr_stream_t stream) {
+  TraceScope trace_scope_("esr_triplet_train_step");
   ESR_TRIP_STEP_CHECKS("esr_triplet_train_step")
   ESR_REQUIRE(scene_ids && pos_ids && neg_ids && loss, "esr_triplet_train_step: null pointer");
   ESR_REQUIRE(trip_direct_mode() || (stamp >= 1 && stamp <= kStampMax), "esr_triplet_train_step: stamp %u not in [1, %u]",
@@ -1117,6 +1119,7 @@ int esr_triplet_train_steps(float* scene, float* scene_shadow, uint8_t* scene_lo
                             float batch_size, float lr, float eps, uint32_t first_stamp, const int32_t* sorted_ids,
                             const int32_t* perm, void* plans, const int32_t* long_runs, float* losses, void* workspace,
                             size_t workspace_bytes, esr_stream_t stream) {
+  TraceScope trace_scope_("esr_triplet_train_steps");
   ESR_TRIP_STEP_CHECKS("esr_triplet_train_steps")
   ESR_REQUIRE(nbatch >= 1 && nbatch <= kMaxPlanBatch && ids && sorted_ids && perm && plans && losses &&
                   !((uintptr_t)plans & 255),

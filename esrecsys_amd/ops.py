@@ -998,6 +998,20 @@ def inbatch_train_step(query_table, query_accum, cand_table, cand_accum, query_i
     return (loss, lse) if want_lse else loss
 
 
+def recall_at_k(approx_indices, exact_indices):
+    """hits / (Q * ke): the fraction of exact_indices [Q, ke] that also occur in the same row of approx_indices [Q, ka]
+    (esr_recall_at_k).  Synchronises to read the one counter back."""
+    lib = _lib.load()
+    a = approx_indices if approx_indices.dtype == torch.int32 else approx_indices.to(torch.int32)
+    e = exact_indices if exact_indices.dtype == torch.int32 else exact_indices.to(torch.int32)
+    a, e = _req(a.contiguous(), torch.int32, "approx_indices"), _req(e.contiguous(), torch.int32, "exact_indices")
+    if a.dim() != 2 or e.dim() != 2 or a.shape[0] != e.shape[0]:
+        raise ValueError("approx_indices [Q, ka] and exact_indices [Q, ke] must have the same number of rows")
+    hits = torch.empty(1, dtype=torch.int64, device=a.device)
+    check(lib.esr_recall_at_k(_p(a), a.shape[0], a.shape[1], _p(e), e.shape[1], _p(hits), _stream()), "esr_recall_at_k")
+    return float(int(hits.item())) / max(1, e.numel())
+
+
 def bucket_ids_by_owner_batched(id_lists, world, offsets):
     """bucket_ids_by_owner for the lists of several coming batches in one launch pair (esr_bucket_ids_by_owner_batched).
     id_lists: per batch, the int32 segments of its virtual list [ids_k + offsets[k]] (same lengths in every batch).

@@ -67,6 +67,12 @@ int esr_device_info(int* cu_count, int* wave_size, size_t* hbm_bytes, char* arch
  * and clears the records; returns the bytes the whole text needs. */
 int esr_kernel_timing(int enable);
 long esr_kernel_timing_read(char* buf, size_t cap);
+/* rocprofv3 markers ("tracing / profiling": absent in the reference -- only a commented-out
+ * jax_debug_nans toggle, spotify/train_spotify.py:162-163): esr_trace_markers(1), or ESR_ROCTX=1 in the environment when the
+ * library is loaded, makes every instrumented launch site and every step entry point a roctx range (push / pop on the
+ * calling thread), so `rocprofv3 --marker-trace --kernel-trace` shows which phase of which step a kernel belongs to;
+ * (0): off, the default (one load per site).  ESR_ENODEVICE when no roctx library can be loaded. */
+int esr_trace_markers(int enable);
 
 /* ---- G2 / S1: embedding-row gather ------------------------------------------------------
  * nn.Embed lookup == jnp.take(table, ids, axis=0): wikipedia/models.py:31-34 (and the id towers
@@ -437,6 +443,11 @@ int esr_rescore_candidates(const float* queries, const float* candidates, int64_
  * of the shards' answers (after an all-gather) and of re-scored candidate lists. */
 int esr_topk_merge(const float* scores, const int32_t* indices, int64_t nq, int n, int k,
                    float* out_scores, int32_t* out_indices, esr_stream_t stream);
+/* hits[0] = sum over queries of |{j : exact[q, j] occurs in approx[q, :]}| (the word is zeroed by the call): recall@k of an
+ * approximate answer against the brute-force one is hits / (nq * ke).  approx int32 [nq, ka], exact int32 [nq, ke], ka <=
+ * 8192; O(ka + ke) per query (a hash set in LDS).  Build-defined: the reference has no ANN path to measure. */
+int esr_recall_at_k(const int32_t* approx, int64_t nq, int ka, const int32_t* exact, int ke, unsigned long long* hits,
+                    esr_stream_t stream);
 
 /* ---- config 5's ANN leg: IVF search (build-defined; the reference has no ANN index -- esr_retrieve_topk stays the exact
  * answer and the yardstick for recall).  The index (esrecsys_amd/ivf.py builds it with the kernels above): candidates

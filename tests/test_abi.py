@@ -167,3 +167,14 @@ def test_loopback_wire_exports_what_esr_comm_binds():
         for f in files:
             if f.endswith((".py", ".hip", ".h", ".c")):
                 assert "loopback_wire" not in open(os.path.join(root, f), errors="ignore").read(), os.path.join(root, f)
+
+
+def test_trace_markers_switch(lib):
+    """SURVEY section 5's tracing row: esr_trace_markers binds a roctx library at run time (ROCm images carry one) and
+    turns the launch-site / step-entry ranges on and off; with markers on, an entry point that fails validation still pops
+    the range it pushed (a scope object), i.e. the call simply returns its error code."""
+    rc = lib.esr_trace_markers(1)
+    assert rc in (0, -4), rc   # ESR_OK, or ESR_ENODEVICE on a box without any roctx library
+    if rc == 0:
+        assert lib.esr_triplet_plan(None, 0, 0, 0, None, None, None, None, 0, None) != 0   # validated, no device touched
+        assert lib.esr_trace_markers(0) == 0

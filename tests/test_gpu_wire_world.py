@@ -217,9 +217,22 @@ def _spawn(worker, world):
         return [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(world)]
 
 
-@pytest.fixture(scope="module")
-def loops_outputs():
-    return _spawn(_loops_worker, 2)
+@pytest.fixture(scope="module", params=["blocking", "async"])
+def loops_outputs(request):
+    """Both forms of the wire: "blocking" (ncclGroupEnd waits for the stream and moves the bytes before it returns: the two
+    streams of the overlapped loop are serialised) and "async" (ESR_WIRE_ASYNC=1, round 5: the group is enqueued on its
+    stream as RCCL's is -- the side-stream lookup on the second communicator then really runs beside the main stream's
+    exchanges and kernels -- and the enqueue order of the two communicators is checked across ranks)."""
+    old = os.environ.get("ESR_WIRE_ASYNC")
+    os.environ["ESR_WIRE_ASYNC"] = "1" if request.param == "async" else "0"
+    os.environ.setdefault("ESR_WIRE_TIMEOUT_S", "45")  # (a stuck exchange fails in under two minutes, not after four)
+    try:
+        return _spawn(_loops_worker, 2)
+    finally:
+        if old is None:
+            os.environ.pop("ESR_WIRE_ASYNC", None)
+        else:
+            os.environ["ESR_WIRE_ASYNC"] = old
 
 
 @pytest.fixture(scope="module")
@@ -559,3 +572,70 @@ def test_world2_replicated_steps_equal_single_device_and_replicas_agree(replicat
         emb, a_e = o_optim.sparse_adagrad_update(emb, a_e, ids_c, np.concatenate(rows_all), LR, dtype=np.float64)
         bias, a_b = o_optim.sparse_adagrad_update(bias, a_b, ids_c, np.concatenate(gb_all)[:, None], LR, dtype=np.float64)
     assert close(outs[0]["glove_emb"], emb) and close(outs[0]["glove_bias"], bias)
+
+
+# ---- the asynchronous wire reports what RCCL would deadlock on --------------------------------------------------------------
+def _order_worker(rank, port, outdir, wire_lib):
+    world = 2
+    dist, dev = _init(rank, world, port, wire_lib)
+    from esrecsys_amd import _lib, rccl
+    x0, x1 = rccl.exchange_for(None, dev, 0), rccl.exchange_for(None, dev, 1)
+    assert x0 is not None and x1 is not None
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    out = {}
+
+    def a2a(x, stream, tag):
+        send = torch.full((world * 4, 8), 100 * rank + tag, dtype=torch.int32, device=dev)
+        recv = torch.full_like(send, -1)
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            x.all_to_all_single(recv, send)
+        return recv, send
+
+    # (1) both ranks enqueue communicator 0's group, then communicator 1's, on two streams: legal everywhere
+    r0, k0 = a2a(x0, sa, 1)
+    r1, k1 = a2a(x1, sb, 2)
+    torch.cuda.synchronize()
+    errs = [int(_lib.load().esr_comm_async_error(x.comm)) for x in (x0, x1)]
+    want0 = torch.cat([torch.full((4, 8), 100 * p + 1, dtype=torch.int32) for p in range(world)])
+    want1 = torch.cat([torch.full((4, 8), 100 * p + 2, dtype=torch.int32) for p in range(world)])
+    out["same_order_ok"] = np.array([errs == [0, 0] and torch.equal(r0.cpu(), want0) and torch.equal(r1.cpu(), want1)])
+    dist.barrier()
+    # (2) rank 1 enqueues them the other way round: on RCCL a potential deadlock, on this wire an error
+    raised = False
+    try:
+        if rank == 0:
+            a2a(x0, sa, 3), a2a(x1, sb, 4)
+        else:
+            a2a(x1, sb, 4), a2a(x0, sa, 3)
+        torch.cuda.synchronize()
+        for x in (x0, x1):
+            _lib.check(_lib.load().esr_comm_async_error(x.comm), "esr_comm_async_error")
+    except Exception as e:  # noqa: BLE001
+        raised = "nccl" in str(e).lower() or "order" in str(e).lower() or "loopback" in str(e).lower()
+    out["violation_reported"] = np.array([raised])
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), **out)
+    dist.barrier()
+    rccl.reset()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_async_wire_reports_communicators_enqueued_in_different_orders():
+    """Two communicators driven from two streams (the overlapped loop's shape): with the same enqueue order on both ranks
+    the exchanges complete with the right bytes; with opposite orders -- which works on a wire that gives every
+    communicator its own sockets, and can deadlock RCCL's point-to-point kernels -- the asynchronous wire fails loudly
+    on both ranks instead of working."""
+    old = os.environ.get("ESR_WIRE_ASYNC")
+    os.environ["ESR_WIRE_ASYNC"] = "1"
+    os.environ["ESR_WIRE_TIMEOUT_S"] = "30"
+    try:
+        outs = _spawn(_order_worker, 2)
+    finally:
+        os.environ.pop("ESR_WIRE_TIMEOUT_S", None)
+        if old is None:
+            os.environ.pop("ESR_WIRE_ASYNC", None)
+        else:
+            os.environ["ESR_WIRE_ASYNC"] = old
+    assert all(bool(o["same_order_ok"][0]) for o in outs)
+    assert all(bool(o["violation_reported"][0]) for o in outs)
