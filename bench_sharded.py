@@ -61,10 +61,12 @@ def preflight(dev, rank, world, watchdog):
     if x is not None and rec["rccl_ranks"] != world:
         rec["ok"] = False
         rec["error"] = "the communicator reports %s ranks, the launch has %d" % (rec["rccl_ranks"], world)
-    if rank == 0:
-        print(json.dumps({"preflight": rec}), flush=True)
-    if not rec["ok"]:
+    if not rec["ok"]:  # the one line of a run that will not produce a bench line
+        if rank == 0:
+            print(json.dumps({"preflight": rec}), flush=True)
         raise SystemExit(3)
+    if rank == 0:  # (a run that goes on prints its ONE JSON line at the end, with this record under config.preflight)
+        print(json.dumps({"preflight": rec}), file=sys.stderr, flush=True)
     return rec
 
 

@@ -1,15 +1,14 @@
-// Everything that needs a device-wide stable radix sort (rocPRIM, header-only, ships with ROCm):
+// Everything that needs a device-wide stable sort -- all of it this file's own kernels (round 5: the four call sites of the
+// ROCm device-library radix sort that served lists beyond 2 M ids are gone; no library sort is left):
 //   esr_segment_sort_ids      occurrence ids -> (sorted ids, permutation) for the sparse optimizers
 //   esr_argsort_columns       find_knn's jnp.argsort(scores, axis=0)  (train_cooccurence.py:96)
 //   esr_score_topk            find_top_k's jax.lax.top_k              (make_recommendations.py:64)
 //   esr_bucket_ids_by_owner   row-shard routing (owner = id mod world)
-// The sort itself is a library primitive; the kernels around it are hand-written.
+// One workgroup (bitonic), tile sort + rank merge, or a least-significant-digit radix sort with 11-bit digits -- by size.
 #include "esr_common.h"
 
 #include <algorithm>
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
 
 namespace esr {
 
@@ -17,27 +16,6 @@ static inline int bits_for(int64_t n_values) {  // bits needed to represent valu
   int b = 1;
   while (b < 32 && ((int64_t)1 << b) < n_values) ++b;
   return b;
-}
-
-// rocPRIM temp-storage size for an n-element (32-bit key, 32-bit value) pair sort.  The query
-// needs a device; without one (CPU-only build check) fall back to a generous closed-form bound.
-template <bool DESC, typename Key>
-static size_t pair_sort_temp_bytes(int64_t n) {
-  size_t bytes = 0;
-  hipError_t e;
-  Key* kn = nullptr;
-  int32_t* vn = nullptr;
-  if (DESC)
-    e = rocprim::radix_sort_pairs_desc(nullptr, bytes, kn, kn, rocprim::counting_iterator<int32_t>(0), vn,
-                                       (size_t)n, 0, 8 * sizeof(Key), (hipStream_t)0, false);
-  else
-    e = rocprim::radix_sort_pairs(nullptr, bytes, kn, kn, rocprim::counting_iterator<int32_t>(0), vn, (size_t)n,
-                                  0, 8 * sizeof(Key), (hipStream_t)0, false);
-  if (e != hipSuccess || bytes == 0) {
-    (void)hipGetLastError();
-    bytes = (size_t)n * 16 + (1u << 20);
-  }
-  return align_up(bytes + 256, 256);
 }
 
 // The occurrence ids may come as up to four segments [ids_k + offset_k] (the towers of one step as virtual rows of
@@ -340,7 +318,7 @@ static void launch_tile_sort_batched(const SortSegsBatch& sb, int nbatch, int n,
 
 // Long lists (32 768 < n <= 262 144: the 131 072 occurrence ids of a GloVe step at B = 65 536, the 196 608 of a triplet
 // step at that batch): least-significant-digit radix sort with 11-bit digits, two launches per pass, two passes for ids
-// below 2^22.  rocPRIM's device sort is a chain of ~10 short launches here (55 us for 131 072 keys, all launch latency).
+// below 2^22.  The ROCm library's device sort is a chain of ~10 short launches here (55 us for 131 072 keys, all launch latency).
 //   pass launch 1: every workgroup bitonic-sorts its 2048-key tile by (digit << 11 | position in tile) -- stable -- writes
 //                  the sorted composites and the tile's digit histogram (from the run boundaries: no atomics);
 //   pass launch 2: every workgroup turns the histograms into its own digit offsets (digits below + same digit in earlier
@@ -992,18 +970,8 @@ __global__ __launch_bounds__(kBlock) void local_rows_kernel(const int32_t* __res
   }
 }
 
-// keysT[t][v] = scores[v][t]
-__global__ __launch_bounds__(kBlock) void transpose_cols_kernel(const float* __restrict__ scores, int64_t V, int T,
-                                                               float* __restrict__ keysT) {
-  const int64_t total = V * T;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
-    const int64_t v = i / T;
-    const int t = (int)(i - v * T);
-    keysT[(int64_t)t * V + v] = scores[i];
-  }
-}
 // keysT[t][v] = order-preserving unsigned image of scores[v][t] (negative floats: all bits flipped; others: sign bit
-// set), the key rocPRIM's float sort uses too: ascending keys = ascending floats, -0 before +0, NaNs by their bits
+// set), the key device-library float sorts use too: ascending keys = ascending floats, -0 before +0, NaNs by their bits
 __global__ __launch_bounds__(kBlock) void transpose_cols_keys_kernel(const float* __restrict__ scores, int64_t V, int T,
                                                                     int32_t* __restrict__ keysT) {
   const int64_t total = V * T;
@@ -1058,14 +1026,6 @@ __global__ __launch_bounds__(kBlock) void score_rows_kernel(const float* __restr
   }
 }
 
-__global__ __launch_bounds__(kBlock) void take_k_kernel(const float* __restrict__ keys, const int32_t* __restrict__ idx,
-                                                       int k, float* __restrict__ out_s, int32_t* __restrict__ out_i) {
-  for (int i = threadIdx.x; i < k; i += kBlock) {
-    out_s[i] = keys[i];
-    out_i[i] = idx[i];
-  }
-}
-
 // rows [r0, r0 + nb) of `scores` ([.][pitch] floats, N valid) -> keys[b][N]: images whose ASCENDING unsigned order is the
 // floats' DESCENDING order (the complement of transpose_cols_keys_kernel's image); and the k best of sorted rows back
 __global__ __launch_bounds__(kBlock) void desc_keys_kernel(const float* __restrict__ scores, int64_t pitch, int64_t N,
@@ -1108,6 +1068,24 @@ static int launch_score_rows(const float* queries, const int32_t* q_ids, int nq,
   return check_launch("score_rows");
 }
 
+// A list of ANY length (below 2^30) through this file's radix sort: up to kRadixLongN ids the single-list form (a scatter
+// workgroup re-reduces the histogram matrix, or its segment sums, itself: fewest launches), beyond it the batched form with
+// one list -- the histogram matrix is scanned down its columns by its own launch between the two launches of a pass, so
+// no workgroup walks a matrix of thousands of tiles.  Workspace: radix_ws_layout(n) bytes.
+constexpr int64_t kSortMaxN = (int64_t)1 << 30;
+static void radix_any(const SortSegs& sg, int64_t n, int key_bits, char* workspace, int32_t* sorted_ids, int32_t* perm,
+                      hipStream_t st) {
+  if (n <= kRadixLongN) {
+    RadixWs ws;
+    radix_ws_layout(n, workspace, &ws);
+    launch_radix_sort<11>(sg, (int)n, key_bits, ws, sorted_ids, perm, st);
+    return;
+  }
+  SortSegsBatch sb;
+  for (int b = 0; b < kMaxSortBatch; ++b) sb.b[b] = sg;
+  launch_radix_sort_batched<11>(sb, 1, (int)n, key_bits, workspace, sorted_ids, perm, st);
+}
+
 }  // namespace esr
 
 using namespace esr;
@@ -1118,9 +1096,7 @@ extern "C" {
 size_t esr_segment_sort_workspace_bytes(int64_t n) {
   if (n <= 0) return 256;
   const size_t tiles = n <= kMidSortMax ? align_up((size_t)(kMidSortMax + kMidSortMax / kSplitEvery) * 4, 256) : 0;
-  const size_t radix = n <= kRadixLongN ? radix_ws_layout(n, nullptr, nullptr) : 0;
-  // + one column for the concatenated ids of a segmented list on the device-sort path
-  return std::max({pair_sort_temp_bytes<false, uint32_t>(n) + align_up((size_t)n * 4, 256), tiles, radix});
+  return std::max(tiles, radix_ws_layout(n, nullptr, nullptr));
 }
 
 static int segment_sort_segs(const char* who, const SortSegs& sg, int64_t n, int64_t V, int32_t* sorted_ids,
@@ -1147,52 +1123,15 @@ static int segment_sort_segs(const char* who, const SortSegs& sg, int64_t n, int
     else launch_tile_sort<11>(sg, (int)n, tiles, sorted_ids, perm, st);
     return check_launch(who);
   }
-  if (n <= kRadixLongN && bits_for(V) <= kRadixMaxPasses * 11) {
-    if (radix_ws_layout(n, nullptr, nullptr) > workspace_bytes || ((uintptr_t)workspace & 15)) {
-      set_error("%s: workspace %zu bytes too small (or misaligned)", who, workspace_bytes);
-      return ESR_EWORKSPACE;
-    }
-    RadixWs ws;
-    radix_ws_layout(n, (char*)workspace, &ws);
-    launch_radix_sort<11>(sg, (int)n, bits_for(V), ws, sorted_ids, perm, st);
-    return check_launch(who);
+  if (n > kSortMaxN) {
+    set_error("%s: n=%lld ids exceed 2^30", who, (long long)n);
+    return ESR_EINVAL;
   }
-  // device radix sort: needs the ids as one array (materialised at the head of the workspace when segmented)
-  const uint32_t* kin = reinterpret_cast<const uint32_t*>(sg.ids[0]);
-  char* temp = (char*)workspace;
-  size_t temp_bytes = workspace_bytes;
-  if (sg.n > 1 || sg.offset[0] != 0) {
-    const size_t col = align_up((size_t)n * 4, 256);
-    if (col > workspace_bytes || ((uintptr_t)workspace & 15)) {
-      set_error("%s: workspace %zu bytes too small (or misaligned)", who, workspace_bytes);
-      return ESR_EWORKSPACE;
-    }
-    hipLaunchKernelGGL(concat_segs_kernel, dim3((int)std::min<int64_t>(kMaxGrid, cdiv(n, kBlock))), dim3(kBlock), 0, st,
-                       sg, n, (int32_t*)workspace);
-    kin = (const uint32_t*)workspace;
-    temp += col;
-    temp_bytes -= col;
-  }
-  size_t need = 0;
-  const int end_bit = bits_for(V);
-  uint32_t* kout = reinterpret_cast<uint32_t*>(sorted_ids);
-  hipError_t e = rocprim::radix_sort_pairs(nullptr, need, kin, kout, rocprim::counting_iterator<int32_t>(0), perm,
-                                           (size_t)n, 0, end_bit, st, false);
-  if (e != hipSuccess) {
-    set_error("%s: rocprim size query: %s", who, hipGetErrorString(e));
-    return ESR_ELAUNCH;
-  }
-  if (need > temp_bytes || ((uintptr_t)temp & 15)) {
-    set_error("%s: workspace %zu bytes < %zu required (or misaligned)", who, workspace_bytes,
-              need + (size_t)(temp - (char*)workspace));
+  if (radix_ws_layout(n, nullptr, nullptr) > workspace_bytes || ((uintptr_t)workspace & 15)) {
+    set_error("%s: workspace %zu bytes too small (or misaligned)", who, workspace_bytes);
     return ESR_EWORKSPACE;
   }
-  e = rocprim::radix_sort_pairs(temp, need, kin, kout, rocprim::counting_iterator<int32_t>(0), perm, (size_t)n, 0,
-                                end_bit, st, false);
-  if (e != hipSuccess) {
-    set_error("%s: rocprim sort: %s", who, hipGetErrorString(e));
-    return ESR_ELAUNCH;
-  }
+  radix_any(sg, n, bits_for(V), (char*)workspace, sorted_ids, perm, st);
   return check_launch(who);
 }
 
@@ -1243,7 +1182,7 @@ size_t esr_segment_sort_batched_workspace_bytes(int64_t n, int nbatch) {
   const size_t one = esr_segment_sort_workspace_bytes(n);  // the fallback sorts list after list in this much
   const size_t mid = n <= kMidSortMax ? align_up((size_t)nbatch * kMidWsWords * 4, 256) : 0;
   // (any n: lists of wide ids -- V beyond 2^21 -- take the batched radix passes even when they are short)
-  const size_t radix = n <= kRadixLongN ? (size_t)nbatch * radix_ws_layout(n, nullptr, nullptr) : 0;
+  const size_t radix = n <= kRadixLongN ? (size_t)nbatch * radix_ws_layout(n, nullptr, nullptr) : 0;  // (longer: list by list)
   return std::max({one, mid, radix});
 }
 
@@ -1321,13 +1260,6 @@ int esr_score_all(const float* emb, int64_t V, int D, const int32_t* token, int 
   return launch_score_rows(emb, token, T, emb, V, D, scores, 1, T, as_stream(stream));
 }
 
-static size_t argsort_layout(int64_t V, int T, size_t* keysT, size_t* idxT, size_t* ksorted) {
-  size_t off = 0;
-  *keysT = off;   off += align_up((size_t)V * T * 4, 256);
-  *idxT = off;    off += align_up((size_t)V * T * 4, 256);
-  *ksorted = off; off += align_up((size_t)V * 4, 256);
-  return off;
-}
 
 // columns of up to kRadixLongN rows go through this file's own radix sort, kMaxSortBatch columns per launch sequence
 static size_t argsort_own_layout(int64_t V, int T, size_t* keysT, size_t* idxT, size_t* ksorted, size_t* sort_ws) {
@@ -1344,13 +1276,12 @@ static size_t argsort_own_layout(int64_t V, int T, size_t* keysT, size_t* idxT, 
 size_t esr_argsort_columns_workspace_bytes(int64_t V, int T) {
   if (V <= 0 || T <= 0) return 256;
   size_t a, b, c, d;
-  if (V <= kRadixLongN) return argsort_own_layout(V, T, &a, &b, &c, &d);
-  return argsort_layout(V, T, &a, &b, &c) + pair_sort_temp_bytes<false, float>(V);
+  return argsort_own_layout(V, T, &a, &b, &c, &d);
 }
 
 int esr_argsort_columns(const float* scores, int64_t V, int T, int32_t* indices, void* workspace,
                         size_t workspace_bytes, esr_stream_t stream) {
-  ESR_REQUIRE(V > 0 && T > 0 && V < ((int64_t)1 << 31), "esr_argsort_columns: bad sizes V=%lld T=%d", (long long)V, T);
+  ESR_REQUIRE(V > 0 && T > 0 && V <= kSortMaxN, "esr_argsort_columns: bad sizes V=%lld T=%d", (long long)V, T);
   ESR_REQUIRE(scores && indices && workspace, "esr_argsort_columns: null pointer");
   if (workspace_bytes < esr_argsort_columns_workspace_bytes(V, T) || ((uintptr_t)workspace & 15)) {
     set_error("esr_argsort_columns: workspace %zu bytes < %zu required (or misaligned)", workspace_bytes,
@@ -1360,7 +1291,7 @@ int esr_argsort_columns(const float* scores, int64_t V, int T, int32_t* indices,
   hipStream_t st = as_stream(stream);
   size_t o_keys, o_idx, o_sorted;
   char* base = (char*)workspace;
-  if (V <= kRadixLongN) {
+  {
     // stable ascending sort of every column by the keys' unsigned images: three 11-bit passes of the radix sort above,
     // eight columns per launch sequence (jnp.argsort(scores, axis=0): wikipedia/train_cooccurence.py:95)
     size_t o_ws;
@@ -1393,26 +1324,6 @@ int esr_argsort_columns(const float* scores, int64_t V, int T, int32_t* indices,
     hipLaunchKernelGGL(untranspose_idx_kernel, dim3(grid), dim3(kBlock), 0, st, (const int32_t*)idxT, V, T, indices);
     return check_launch("esr_argsort_columns");
   }
-  const size_t fixed = argsort_layout(V, T, &o_keys, &o_idx, &o_sorted);
-  float* keysT = (float*)(base + o_keys);       // [T][V]
-  int32_t* idxT = (int32_t*)(base + o_idx);     // [T][V]
-  float* keys_sorted = (float*)(base + o_sorted);
-  void* temp = base + fixed;
-  const size_t temp_bytes = workspace_bytes - fixed;
-  const int grid = (int)std::min<int64_t>(kMaxGrid, cdiv(V * T, kBlock));
-  hipLaunchKernelGGL(transpose_cols_kernel, dim3(grid), dim3(kBlock), 0, st, scores, V, T, keysT);
-  for (int t = 0; t < T; ++t) {
-    size_t need = temp_bytes;
-    hipError_t e = rocprim::radix_sort_pairs(temp, need, keysT + (int64_t)t * V, keys_sorted,
-                                             rocprim::counting_iterator<int32_t>(0), idxT + (int64_t)t * V,
-                                             (size_t)V, 0, 32, st, false);
-    if (e != hipSuccess) {
-      set_error("esr_argsort_columns: rocprim sort: %s", hipGetErrorString(e));
-      return ESR_ELAUNCH;
-    }
-  }
-  hipLaunchKernelGGL(untranspose_idx_kernel, dim3(grid), dim3(kBlock), 0, st, (const int32_t*)idxT, V, T, indices);
-  return check_launch("esr_argsort_columns");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1420,16 +1331,16 @@ size_t esr_score_topk_workspace_bytes(int64_t nq, int64_t N, int k) {
   (void)k;
   if (nq <= 0 || N <= 0) return 256;
   const size_t row = align_up((size_t)N * 4, 256);
-  if (k > kSelectMaxK && N <= kRadixLongN)  // own radix sort, kMaxSortBatch rows per launch sequence (see esr_score_topk)
+  if (k > kSelectMaxK)  // own radix sort, kMaxSortBatch rows per launch sequence (see esr_score_topk)
     return row * (size_t)nq + 3 * row * kMaxSortBatch +
            std::max((size_t)kMaxSortBatch * radix_ws_layout(N, nullptr, nullptr), esr_segment_sort_workspace_bytes(N));
-  return row * (size_t)nq + 2 * row + pair_sort_temp_bytes<true, float>(N);
+  return row * (size_t)nq + 2 * row;
 }
 
 int esr_score_topk(const float* queries, const float* candidates, int64_t nq, int64_t N, int D, int k,
                    float* out_scores, int32_t* out_indices, void* workspace, size_t workspace_bytes,
                    esr_stream_t stream) {
-  ESR_REQUIRE(nq > 0 && N > 0 && D > 0 && k > 0 && k <= N && N < ((int64_t)1 << 31),
+  ESR_REQUIRE(nq > 0 && N > 0 && D > 0 && k > 0 && k <= N && N <= kSortMaxN,
               "esr_score_topk: bad sizes nq=%lld N=%lld D=%d k=%d", (long long)nq, (long long)N, D, k);
   ESR_REQUIRE(queries && candidates && out_scores && out_indices && workspace, "esr_score_topk: null pointer");
   const RowGeom g = row_geom(D);
@@ -1443,17 +1354,13 @@ int esr_score_topk(const float* queries, const float* candidates, int64_t nq, in
   const size_t row = align_up((size_t)N * 4, 256);
   char* base = (char*)workspace;
   float* scores = (float*)base;  // [nq][row/4]
-  float* keys_sorted = (float*)(base + row * nq);
-  int32_t* idx_sorted = (int32_t*)(base + row * nq + row);
-  void* temp = base + row * nq + 2 * row;
-  size_t temp_bytes = workspace_bytes - (row * nq + 2 * row);
   if (int rc = launch_score_rows(queries, nullptr, (int)nq, candidates, N, D, scores, (int64_t)(row / 4), 1, st))
     return rc;
   // jax.lax.top_k (pinterest/make_recommendations.py:64) asks for the k best only: a radix select per query row (one
   // launch for all queries; only the k survivors are sorted) instead of a full device sort of all N scores per query
   if (k <= kSelectMaxK)
     return select_topk_dense(scores, (int64_t)(row / 4), nq, (int)N, k, out_scores, out_indices, st);
-  if (N <= kRadixLongN) {
+  {
     // k beyond the select's 1024: every row sorted in full, descending and stable (lower index first among equal scores,
     // as jax.lax.top_k), by this file's radix sort over the complemented images, eight rows per launch sequence
     char* p = base + row * nq;
@@ -1490,29 +1397,16 @@ int esr_score_topk(const float* queries, const float* candidates, int64_t nq, in
     }
     return check_launch("esr_score_topk");
   }
-  for (int64_t q = 0; q < nq; ++q) {
-    size_t need = temp_bytes;
-    hipError_t e = rocprim::radix_sort_pairs_desc(temp, need, (float*)((char*)scores + row * q), keys_sorted,
-                                                  rocprim::counting_iterator<int32_t>(0), idx_sorted, (size_t)N, 0,
-                                                  32, st, false);
-    if (e != hipSuccess) {
-      set_error("esr_score_topk: rocprim sort: %s", hipGetErrorString(e));
-      return ESR_ELAUNCH;
-    }
-    hipLaunchKernelGGL(take_k_kernel, dim3(1), dim3(kBlock), 0, st, (const float*)keys_sorted,
-                       (const int32_t*)idx_sorted, k, out_scores + q * k, out_indices + q * k);
-  }
-  return check_launch("esr_score_topk");
 }
 
 // ------------------------------------------------------------------------------------------------
-// Workspace: the larger of the tiled path's counts and the radix path's key columns + rocPRIM temp, behind a column
+// Workspace: the larger of the tiled path's counts and the radix path's key columns + sort workspace, behind a column
 // for the concatenated ids of the segmented entry point when it has to fall back to the radix path.
 size_t esr_bucket_workspace_bytes(int64_t n) {
   if (n <= 0) return 256;
   const size_t tiled = (size_t)cdiv(n, kBucketThreads) * (kBucketThreads / 64 + 1) * kBucketMaxWorld * sizeof(int);
   return align_up((size_t)n * 4, 256) +
-         std::max(tiled, align_up((size_t)n * 4, 256) * 2 + pair_sort_temp_bytes<false, uint32_t>(n));
+         std::max(tiled, align_up((size_t)n * 4, 256) * 2 + radix_ws_layout(n, nullptr, nullptr));
 }
 
 // tiled two-launch path; false when it does not apply (then nothing was launched)
@@ -1543,7 +1437,7 @@ static int bucket_plain(const char* who, const int32_t* ids, int64_t n, int worl
   if (hipMemsetAsync(counts, 0, sizeof(int64_t) * world, st) != hipSuccess) return check_launch(who);
   if (n == 0) return ESR_OK;
   const size_t col = align_up((size_t)n * 4, 256);
-  const size_t need = 2 * col + pair_sort_temp_bytes<false, uint32_t>(n);
+  const size_t need = 2 * col + radix_ws_layout(n, nullptr, nullptr);
   if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) {
     set_error("%s: workspace %zu bytes < %zu required (or misaligned)", who, workspace_bytes, need);
     return ESR_EWORKSPACE;
@@ -1551,17 +1445,20 @@ static int bucket_plain(const char* who, const int32_t* ids, int64_t n, int worl
   char* base = (char*)workspace;
   uint32_t* keys = (uint32_t*)base;
   uint32_t* keys_sorted = (uint32_t*)(base + col);
-  void* temp = base + 2 * col;
-  size_t temp_bytes = workspace_bytes - 2 * col;
   const int grid = (int)std::min<int64_t>(kMaxGrid, cdiv(n, kBlock));
   hipLaunchKernelGGL(owner_keys_kernel, dim3(grid), dim3(kBlock), 0, st, ids, n, world, keys,
                      reinterpret_cast<unsigned long long*>(counts));
-  hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_sorted, rocprim::counting_iterator<int32_t>(0),
-                                           perm, (size_t)n, 0, bits_for(world), st, false);
-  if (e != hipSuccess) {
-    set_error("%s: rocprim sort: %s", who, hipGetErrorString(e));
-    return ESR_ELAUNCH;
+  // stable sort of the owner keys (the permutation is what is wanted): this file's radix sort, one 11-bit pass for up to
+  // 2048 ranks
+  if (n > kSortMaxN) {
+    set_error("%s: n=%lld ids exceed 2^30", who, (long long)n);
+    return ESR_EINVAL;
   }
+  SortSegs ks = {};
+  ks.n = 1;
+  ks.ids[0] = reinterpret_cast<const int32_t*>(keys);
+  for (int i = 1; i <= kMaxSortSegs; ++i) ks.start[i] = n;
+  radix_any(ks, n, bits_for(world), base + 2 * col, reinterpret_cast<int32_t*>(keys_sorted), perm, st);
   hipLaunchKernelGGL(local_rows_kernel, dim3(grid), dim3(kBlock), 0, st, ids, (const int32_t*)perm, n, world,
                      local_rows, inverse);
   return check_launch(who);

@@ -327,7 +327,9 @@ int esr_inbatch_train_step_f16x2(void* query_table, float* query_accum, int64_t 
 /* ---- G4 (build's production optimizer): sort + segment-reduce + sparse Adagrad -----------
  * Replaces the dense V x D gradient + dense optimizer sweep of
  * wikipedia/train_cooccurence.py:86-101 with a row-sparse update.
- * esr_segment_sort_ids: stable sort of occurrence ids; perm[k] = original occurrence index.
+ * esr_segment_sort_ids: stable sort of occurrence ids; perm[k] = original occurrence index.  Every size runs this
+ * library's own kernels (one-workgroup bitonic sort, tile sort + rank merge, 11-bit LSD radix passes; no device-library
+ * sort): n up to 2^30 ids.
  * The scatter entry points below may OVERWRITE grad_rows: runs of equal ids that cross a 32-position boundary are
  * summed chunk-wise, the partial sums parked in the gradient rows themselves, and combined in a fixed order. */
 size_t esr_segment_sort_workspace_bytes(int64_t n);

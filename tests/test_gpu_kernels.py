@@ -794,12 +794,13 @@ def test_segment_sort_is_stable_sort(dev, kind, n):
 @pytest.mark.parametrize("n,V", [(131_072, 465_537), (196_608 + 5, 2_000_000), (262_144, 1_000), (262_145, 465_537),
                                  (40_001, 2_047), (50_000, 2_048), (100_000, 30_000_000), (2_049 + 32_768, 2 ** 22 + 1),
                                  (786_432, 2_000_000), (300_001, 1_500), (2 ** 21, 465_537), (2 ** 21 + 1, 465_537),
-                                 (1_000_003, 2 ** 31 - 1)])
+                                 (1_000_003, 2 ** 31 - 1), (5_000_003, 1_000_000), (3_000_000, 2 ** 31 - 1)])
 @pytest.mark.parametrize("kind", ["uniform", "same", "zipf"])
 def test_segment_sort_hand_written_radix_path(dev, kind, n, V):
     """32 768 < n <= 262 144: the two-launches-per-pass LSD radix sort (11-bit digits; 1, 2 or 3 passes by the id range);
     up to 2 097 152 ids (the 786 432 of a triplet step at B = 262 144) the same with the histogram matrix summed over
-    32-tile segments first; one more falls through to the device sort.  Stable: perm == numpy's stable argsort."""
+    32-tile segments first; longer lists (round 5: no device-library sort is left) the three-launch passes with the
+    histogram matrix scanned down its columns in between.  Stable: perm == numpy's stable argsort."""
     from esrecsys_amd import ops
     rng = np.random.default_rng(n % 1000 + 1)
     if kind == "zipf" and V > 5_000_000:
@@ -1075,7 +1076,7 @@ def test_topk_columns_equals_the_tail_of_the_stable_argsort(dev, V, T_, k):
 
 
 @pytest.mark.parametrize("V,T_", [(1, 1), (37, 3), (2048, 2), (4097, 1), (5000, 9), (40_000, 8), (300_000, 3),
-                                  (465_537, 10), (2_097_152, 1)])
+                                  (465_537, 10), (2_097_152, 1), (2_097_153, 2), (3_000_001, 1)])
 def test_argsort_columns_equals_numpy_stable_argsort(dev, V, T_):
     """esr_argsort_columns on this library's own radix sort (V <= 2^21; three 11-bit passes over the order-preserving
     images of the floats, eight columns per launch sequence): exactly numpy's stable ascending argsort per column --
@@ -1148,9 +1149,10 @@ def test_bucket_ids_by_owner_segments_vs_oracle(dev, world, sizes):
 
 @pytest.mark.parametrize("world,n", [(1, 16_389), (2, 16_389), (3, 16_389), (8, 16_389), (8, 7), (8, 2048), (8, 2049),
                                      (5, 3000), (8, 65_536), (8, 100_003), (7, 1_048_576), (8, 1_048_577),
-                                     (16, 16_389)])
+                                     (16, 16_389), (16, 3_000_001), (8, 2_500_000)])
 def test_bucket_ids_by_owner_vs_oracle(dev, world, n):
-    """one-workgroup kernel (n <= 2048), tiled two-launch path (<= 1 Mi ids, world <= 8), device radix sort beyond"""
+    """one-workgroup kernel (n <= 2048), tiled two-launch path (<= 1 Mi ids, world <= 8), the library's radix sort of the
+    owner keys beyond (more ranks than the tiled path counts, or longer lists)"""
     from esrecsys_amd import ops
     rng = np.random.default_rng(world)
     ids = rng.integers(0, 1_000_000, n).astype(np.int32)
@@ -1244,13 +1246,14 @@ def test_sparse_adagrad_multi_long_runs_hint(dev):
             assert torch.equal(x, y)
 
 
-def test_score_topk_beyond_1024_is_stable_on_ties(dev):
+@pytest.mark.parametrize("nq,N_", [(10, 20_000), (9, 2 ** 21 + 5), (1, 2 ** 21 + 5)])
+def test_score_topk_beyond_1024_is_stable_on_ties(dev, nq, N_):
     """k > 1024: full descending sort per query row on the library's radix sort, eight rows per launch sequence -- with
     scores on a coarse integer grid (exact in f32: thousands of ties) the result must be exactly lax.top_k's order,
     lower index first among equal scores."""
     from esrecsys_amd import ops
     rng = np.random.default_rng(12)
-    nq, N_, D, k = 10, 20_000, 4, 1500
+    D, k = 4, 1500   # (beyond 2 097 152 candidates: the lists that took the device-library sort before round 5)
     q = rng.integers(-3, 4, (nq, D)).astype(np.float32)
     c = rng.integers(-3, 4, (N_, D)).astype(np.float32)
     s, i = ops.score_topk(T(q, dev), T(c, dev), k)
