@@ -204,7 +204,8 @@ def dominant_kernel_roofline(workload, path, per_kernel, B, D):
             return None
         unit = 2.0 * B * B * D  # one cross-term GEMM
         out = {}
-        for name, terms in (("inbatch2h_q_kernel", 6), ("inbatch2h_pc8_kernel", 3)):
+        for name, terms in (("inbatch2h_q_kernel", 6), ("inbatch2h_pc8_kernel", 3), ("inbatch1h_kernel_q", 3),
+                            ("inbatch1h_kernel_c", 3)):
             if name in per_kernel:
                 t = per_kernel[name]["us"] * 1e-6
                 out[name] = {"us": per_kernel[name]["us"], "fp16_gemms": terms,
@@ -233,6 +234,18 @@ def roofline_for(workload, kernels, B, D, rows, precision, occ_n=0, uniq=0, bf16
         if D == 128 and B % 128 == 0:
             from esrecsys_amd import ops as _ops
             split_path = _ops.inbatch_split_path(precision, B, D, bf16_tables=bf16_tables)
+        if split_path == "f16x2" and bf16_tables:
+            # bf16 tables on the fp16 ONE-plane kernels (esr_inbatch2h.hip, inbatch1h_kernel; round 5): S^T one term, O^T two
+            # (the probabilities keep two planes), pass C recomputes S^T: 2 x (1 + 2) = 6 executed fp16 GEMMs, no stored P
+            executed = 6 * 2.0 * B * B * D
+            return {"kernel": "prepsplit2h + inbatch1h_kernel<Q> + merge + inbatch1h_kernel<C> + merge",
+                    "pass_c": "recomputes S^T (one MFMA term)", "bound": "mfma", "achieved": executed / t / 1e12,
+                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": executed / t / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                    "traffic": None, "dtype": "fp16, one plane per operand (bf16 tables are exact in it), two for the "
+                                              "probabilities; f32 accumulate",
+                    "executed_cross_terms": 6, "executed_cross_terms_of_the_bf16x3_path": 8,
+                    "f32_equivalent_TFLOPs": alg / t / 1e12,
+                    "f32_equivalent_vs_f32_mfma_peak": alg / t / 1e12 / MFMA_F32_PEAK_TFLOPS}
         if split_path == "f16x2":
             # fp16 x 2 path (esr_inbatch2h.hip): three MFMA terms per f32-grade product, pass C reads the stored
             # probabilities: 3 GEMM units x 3 terms x 2 B^2 D executed fp16 flops (+ one hi-plane term for the row
@@ -929,6 +942,10 @@ def secondary_legs(args, dev, rank):
                                                                  kernel_timing=True, saturating=False))
     finally:
         PRECISION = keep
+    # the headline config with bf16 tables (BASELINE config 4's dtype, one rank's view): fp16 one-plane kernels, 6 GEMMs
+    cfg16 = dict(WORKLOADS["inbatch"], table_dtype="bf16", ids="uniform")
+    guarded("inbatch_c2_bf16_tables", lambda: measure_training("inbatch", cfg16, dev, rank, max(k, 100), max(w, 10),
+                                                               kernel_timing=True, saturating=False))
     from bench_retrieve import measure_ivf, measure_retrieve
     # C5 brute force on the library's default ("exact" = three bf16 planes) and on the f32-grade fp16 x 2 planes
     guarded("retrieve_c5_n1m_k500_exact", lambda: measure_retrieve(dev, n_local=1_048_576, steps=3, warmup=1, mode="exact",
@@ -1141,6 +1158,7 @@ def main():
         out["secondary"]["_note"] = "one-line summaries; each leg's full record is its own JSON line above ({\"leg\": name, ...})"
         # value / ms / frac of the other configs' legs where the driver keeps them (it drops unknown top-level keys)
         short = {"glove_c3_b65536": "glove_c3_b65536", "glove_c3_b2048_reference_default_batch": "glove_c3_b2048",
+                 "inbatch_c2_bf16_tables": "inbatch_c2_bf16_tables",
                  "triplet_c2_b8192_reference_loss": "triplet_c2_b8192", "triplet_c2_b262144_saturating": "triplet_c2_b262144",
                  "retrieve_c5_n1m_k500_f16x2": "retrieve_c5_f16x2", "retrieve_c5_n1m_k500_exact": "retrieve_c5_exact"}
         for name, key in short.items():

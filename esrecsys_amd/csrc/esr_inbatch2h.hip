@@ -102,9 +102,12 @@ __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
   asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
+// (the leading s_nop: the operands are usually fresh v_exp_f32 results, and a VALU instruction that reads a transcendental's
+// result needs one wait state in front of it -- hipcc inserts it for its own instructions, not for inline assembly.  The
+// one-plane kernel's schedule put this add right behind the second v_exp_f32: every row's normaliser was garbage.)
 __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
   f32x2 r;
-  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  asm("s_nop 0\n\tv_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
 
@@ -1190,6 +1193,270 @@ __global__ __launch_bounds__(256) void inbatch2h_q2_kernel(const _Float16* __res
 }
 
 // -----------------------------------------------------------------------------------------------------------------
+// ONE fp16 plane per operand (round 5): bf16 tables (BASELINE config 4's dtype).  A bf16 element has 8 significant bits, so
+// x * 2^e is EXACT in fp16's 11 (elements below 2^-28 of the matrix maximum fall into fp16's subnormals and are rounded to
+// multiples of 2^-38 of that maximum): the second plane of both operands is identically zero and so are two of the three
+// cross terms of S^T and one of the three of O^T.  S^T is then ONE MFMA per k-step -- cheap enough that pass C RECOMPUTES
+// it instead of reading stored probabilities:
+//     pass Q:  S^T (1 term) + O^T = C^T P'^T (P' in two fp16 planes: 2 terms)           3 GEMMs
+//     pass C:  S^T (1 term) + O^T = Q^T P   (true probabilities * 2^14, two planes)     3 GEMMs
+// six executed fp16 GEMMs (the bf16 x 3 one-plane kernels: eight), no B x B matrix in memory at all (the fp32-table path
+// above moves 2 x 268 MB of it per step at B = 8192).  Same skeleton as inbatch2h_q_kernel -- 3-slot LDS ring by
+// LDS-DMA, S^T of chunk t + 1 threaded with the exp / split of chunk t, transposing LDS reads for the O^T A fragments --
+// one kernel for both sides:
+//   QSIDE: owned = Q rows; per-row optimistic exponent reference, overflow -> the workgroup redoes itself against the
+//          exact maximum of its range (KIND 2 of inbatch2h_q_kernel); leaves part_m, part_l, part_O.
+//   CSIDE: owned = C rows, streamed = Q rows i; p = exp2(s sl2 - lse2_i + 14) with the row's final lse2_i (merge<Q>),
+//          DMA'd per chunk beside the plane tile; leaves part_O.
+// -----------------------------------------------------------------------------------------------------------------
+constexpr int kH1BufBytes = kPlaneBytes + 4 * 256;  // one plane tile + per-wave 256 B of streamed-row references
+#define H1_DP(K, G, BUF) dmah_piece<K>(baseY, G, (BUF), w)
+#define H1_DMA_REF(BUF)                                                                                   \
+  __builtin_amdgcn_global_load_lds((gptr_t)(ref + (c0 + dpos) * 32 + (lane & 31)),                        \
+                                   (lptr_t)((BUF) + kPlaneBytes + w * 256), 4, 0, 0)
+#define H1_DMA_ADVANCE()                                                                   \
+  {                                                                                        \
+    const uint32_t step_ = (dpos + 1 == nc) ? (uint32_t)(8192 - nc * 8192) : 8192u;        \
+    dpos = (dpos + 1 == nc) ? 0 : dpos + 1;                                                \
+    g0 += step_; g1 += step_;                                                              \
+  }
+#define H1_DMA_CHUNK(BUF) { if (!QSIDE) { H1_DMA_REF(BUF); } H1_DP(0, g0, BUF); H1_DP(1, g1, BUF); H1_DMA_ADVANCE(); }
+// the references of the chunk in BUF for this lane's 16 accumulator registers (streamed rows 8 m + 4 h + 0..3)
+// (assembly reads + one explicit wait: hipcc's own lgkmcnt bookkeeping does not count the assembly LDS reads of the S^T
+// phase that follow, and would let these four be consumed before they have returned)
+#define H1_LOAD_REFS(BUF)                                                                                 \
+  if (!QSIDE) {                                                                                           \
+    f16x8 raw_[4];                                                                                        \
+    _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_)                                                      \
+      raw_[m_] = lds_b128<0>(lds32 + (uint32_t)((BUF) - lds) + (uint32_t)(kPlaneBytes + w * 256 + (8 * m_ + 4 * h) * 4)); \
+    H_TR_WAIT();                                                                                          \
+    _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_) {                                                    \
+      const float4 lv_ = __builtin_bit_cast(float4, raw_[m_]);                                            \
+      rf[4 * m_] = kHPexp - lv_.x; rf[4 * m_ + 1] = kHPexp - lv_.y;                                       \
+      rf[4 * m_ + 2] = kHPexp - lv_.z; rf[4 * m_ + 3] = kHPexp - lv_.w;                                   \
+    }                                                                                                     \
+  }
+#define H1_EXP_PAIR(S)                                                                                    \
+  {                                                                                                       \
+    const f32x2 arg_ = pk_fma(f32x2{p[2 * (S)], p[2 * (S) + 1]}, sl2v,                                    \
+                              QSIDE ? nrefv : f32x2{rf[2 * (S)], rf[2 * (S) + 1]});                        \
+    const float e0_ = __builtin_amdgcn_exp2f(arg_[0]), e1_ = __builtin_amdgcn_exp2f(arg_[1]);             \
+    const f16x2 pa_ = pk_f16(e0_, e1_);                                                                   \
+    if (QSIDE) {                                                                                          \
+      l2 = pk_add(l2, f32x2{e0_, e1_});                                                                   \
+      emax = __builtin_fmaxf(emax, __builtin_fmaxf(e0_, e1_));                                            \
+    }                                                                                                     \
+    const f16x2 pq_ = pk_f16(resid_lo(e0_, pa_), resid_hi(e1_, pa_));                                     \
+    pw[0][(S)] = __builtin_bit_cast(uint32_t, pa_);                                                       \
+    pw[1][(S)] = __builtin_bit_cast(uint32_t, pq_);                                                       \
+  }
+// LDS operations return in order; before the MFMA of k-step s the outstanding ones are, oldest first: fragment s, the two
+// transposing reads a preceding EVEN k-step issued (VALU_ON), fragment s + 1 (s < 7): everything but fragment s stays
+// in flight
+#define H1_S_PHASE(NBUF, SA, VALU_ON)                                                                     \
+  {                                                                                                       \
+    _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) SA[r_] = 0.f;                                       \
+    const uint32_t ap32_ = lds32 + (uint32_t)((NBUF) - lds) + (uint32_t)(j * 256);                        \
+    const int sw_ = swz16(j);                                                                             \
+    f16x8 a1_ = lds_b128<0>(ap32_ + (uint32_t)((h ^ sw_) << 4));                                          \
+    _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) {                                                    \
+      f16x8 n1_ = a1_;                                                                                    \
+      if (s_ < 7) n1_ = lds_b128<0>(ap32_ + (uint32_t)(((2 * (s_ + 1) + h) ^ sw_) << 4));                 \
+      H_SB();                                                                                             \
+      H_S_WAIT((s_ < 7 ? 1 : 0) + (((VALU_ON) && s_ >= 1 && ((s_ - 1) & 1) == 0) ? 2 : 0));               \
+      H_SB();                                                                                             \
+      SA = H_MFMA(a1_, bx[s_], SA);                                                                       \
+      H_SB();                                                                                             \
+      if (VALU_ON) {                                                                                      \
+        if ((s_ & 1) == 0) trh_frag_n<0>(4 + (s_ >> 1), ta2_, trc_); /* the four G = 0 fragments of the O^T phase */ \
+        H1_EXP_PAIR(s_);                                                                                  \
+      }                                                                                                   \
+      H_SB();                                                                                             \
+      a1_ = n1_;                                                                                          \
+    }                                                                                                     \
+  }
+#define H1_O_ROW(PL_P, G)                                                                                 \
+  _Pragma("unroll") for (int db_ = 0; db_ < 4; ++db_)                                                     \
+    acc[db_] = H_MFMA(ta2_[G][db_][0], pb[PL_P][G], acc[db_]);
+#define H1_O_G1(F0, F1) { _Pragma("unroll") for (int f_ = (F0); f_ < (F1); ++f_) trh_frag_n<1>(f_, ta2_, trc_); }
+#define H1_O_PHASE(DMA_ON, DBUF)                                                                          \
+  {                                                                                                       \
+    H_PB();                                                                                               \
+    H_TR_WAIT(); /* the G = 0 fragments were requested during the S^T phase (or by the burst of the last chunk) */ \
+    H_SB(); H1_O_ROW(1, 0); H_SB(); H1_O_G1(4, 6); if (DMA_ON) { H1_DP(0, g0, DBUF); }                    \
+    H_SB(); H1_O_ROW(0, 0); H_SB(); H1_O_G1(6, 8); if (DMA_ON) { H1_DP(1, g1, DBUF); if (!QSIDE) { H1_DMA_REF(DBUF); } } \
+    H_TR_WAIT();                                                                                          \
+    H_SB(); H1_O_ROW(1, 1); H_SB();                                                                       \
+    H_SB(); H1_O_ROW(0, 1); H_SB();                                                                       \
+    if (DMA_ON) H1_DMA_ADVANCE();                                                                         \
+  }
+template <bool QSIDE, int DBG = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void inbatch1h_kernel(
+    const _Float16* __restrict__ Xr, const _Float16* __restrict__ Yr, int64_t B, int nsplit, float sl2_in,
+    const float* __restrict__ sc, const float* __restrict__ diag, const float* __restrict__ ref, int mode,
+    float* __restrict__ part_m, float* __restrict__ part_O, float* __restrict__ part_l) {
+  __shared__ __attribute__((aligned(16))) char lds[kHBufs * kH1BufBytes];
+  int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  int j = lane & 31, h = lane >> 5;
+  H_TR_SETUP();
+  const uint32_t lds32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds;
+  const int ob = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
+  const int64_t xrow = (int64_t)ob * k3Owned + w * 32 + j;
+  const int nc = (int)(B / k3Chunk) / nsplit;
+  const int64_t c0 = (int64_t)split * nc;
+  const float sl2 = sl2_in * sc[0];  // the planes carry 2^(eq + ec) S
+  f32x16 acc[4];
+  f32x2 l2 = {0.f, 0.f};
+  int dpos = 0;
+  const char* const baseY = reinterpret_cast<const char*>(Yr);
+  uint32_t g0 = 0, g1 = 0;
+  f16x8 bx[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) bx[s] = *reinterpret_cast<const f16x8*>(Xr + xrow * k3D + 16 * s + 8 * h);
+  f32x16 sa;
+  float p[16], rf[16];
+  uint32_t pw[2][8];
+  f16x8 ta2_[2][4][2];
+  float emax = 0.f, refv = -INFINITY;
+  const f32x2 sl2v = {sl2, sl2};
+  f32x2 nrefv = {0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < 16; ++r) rf[r] = 0.f;
+  auto sweep = [&](auto fix_tag) __attribute__((always_inline)) {
+    constexpr bool fix = decltype(fix_tag)::value;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[db][r] = 0.f;
+    l2 = f32x2{0.f, 0.f};
+    dpos = 0;
+    g0 = dmah_off0<0>(B, c0, t);
+    g1 = dmah_off0<1>(B, c0, t);
+    emax = 0.f;
+    refv = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[r] = 0.f;
+    if (QSIDE && fix) {  // exact maximum of s sl2 over this workgroup's chunks (flagged workgroups only)
+      float m = -INFINITY;
+      for (int c = 0; c < nc; ++c) {
+        H1_DMA_CHUNK(lds);
+        H_DMA_BARRIER();
+        H1_S_PHASE(lds, sa, false);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, sa[r] * sl2);
+        __syncthreads();  // the next tile overwrites this one
+      }
+      refv = fmaxf(m, __shfl_xor(m, 32, 64)) - kHPexp;
+    }
+    if (DBG == 1) {  // debugging aid: one chunk at a time, nothing pipelined
+      const float dref0 = (QSIDE && !fix) ? diag[xrow] * sl2_in : -INFINITY;
+      for (int c = 0; c < nc; ++c) {
+        H1_DMA_CHUNK(lds);
+        H_DMA_BARRIER();
+        H1_S_PHASE(lds, sa, false);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[r] = sa[r];
+        if (QSIDE && c == 0) {
+          if (!fix) {
+            float m = dref0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = fmaxf(m, sa[r] * sl2);
+            refv = fmaxf(m, __shfl_xor(m, 32, 64)) - kHOptHead;
+          }
+          if (h == 0) part_m[(int64_t)split * B + xrow] = refv;
+          nrefv = f32x2{-refv, -refv};
+        }
+        H_TR_BASES(lds);
+        H1_LOAD_REFS(lds);
+#pragma unroll
+        for (int f = 4; f < 8; ++f) trh_frag_n<0>(f, ta2_, trc_);
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) H1_EXP_PAIR(s2);
+        H1_O_PHASE(false, lds);
+        __syncthreads();
+      }
+      return;
+    }
+    H1_DMA_CHUNK(lds);
+    if (nc > 1) H1_DMA_CHUNK(lds + kH1BufBytes);
+    const float dref = (QSIDE && !fix) ? diag[xrow] * sl2_in : -INFINITY;
+    H_DMA_BARRIER();
+    H1_S_PHASE(lds, sa, false);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[r] = sa[r];
+    if (QSIDE) {
+      if (!fix) {
+        float m = dref;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, sa[r] * sl2);
+        refv = fmaxf(m, __shfl_xor(m, 32, 64)) - kHOptHead;
+      }
+      if (h == 0) part_m[(int64_t)split * B + xrow] = refv;  // what merge<Q> adds back
+      nrefv = f32x2{-refv, -refv};
+    }
+    int cur = 0;
+    for (int it = 0; it + 2 < nc; ++it) {
+      const int nxt = cur == kHBufs - 1 ? 0 : cur + 1;
+      const int nn = nxt == kHBufs - 1 ? 0 : nxt + 1;
+      H_DMA_BARRIER();
+      const char* buf = lds + cur * kH1BufBytes;
+      const char* nbuf = lds + nxt * kH1BufBytes;
+      char* dbuf = lds + nn * kH1BufBytes;
+      H_TR_BASES(buf);
+      H1_LOAD_REFS(buf);
+      H1_S_PHASE(nbuf, sa, true);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) p[r] = sa[r];
+      H1_O_PHASE(true, dbuf);
+      cur = nxt;
+    }
+    if (nc >= 2) {
+      const int nxt = cur == kHBufs - 1 ? 0 : cur + 1;
+      H_DMA_BARRIER();
+      const char* buf = lds + cur * kH1BufBytes;
+      const char* nbuf = lds + nxt * kH1BufBytes;
+      H_TR_BASES(buf);
+      H1_LOAD_REFS(buf);
+      H1_S_PHASE(nbuf, sa, true);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) p[r] = sa[r];
+      H1_O_PHASE(false, lds);
+      cur = nxt;
+    }
+    {  // last chunk: nothing left to prefetch; its exp / split alone
+      H_DMA_BARRIER();
+      const char* buf = lds + cur * kH1BufBytes;
+      H_TR_BASES(buf);
+      H1_LOAD_REFS(buf);
+#pragma unroll
+      for (int f = 4; f < 8; ++f) trh_frag_n<0>(f, ta2_, trc_);
+#pragma unroll
+      for (int s = 0; s < 8; ++s) H1_EXP_PAIR(s);
+      H1_O_PHASE(false, lds);
+    }
+  };
+  sweep(std::false_type{});
+  // (the barrier also ends the last chunk's LDS reads before a redo's first DMA overwrites the ring)
+  if (QSIDE && __syncthreads_or((mode == 2 || !(emax <= kHOverflow)) ? 1 : 0)) {
+    asm volatile("" : "+v"(t), "+v"(lane), "+v"(j), "+v"(h));
+    sweep(std::true_type{});
+  }
+  float* orow = part_O + ((int64_t)split * B + xrow) * k3D;
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float4*>(orow + 32 * db + 8 * q + 4 * h) =
+          make_float4(acc[db][4 * q], acc[db][4 * q + 1], acc[db][4 * q + 2], acc[db][4 * q + 3]);
+  if (QSIDE) {
+    const float l = l2[0] + l2[1];
+    const float ltot = l + __shfl_xor(l, 32, 64);
+    if (h == 0) part_l[(int64_t)split * B + xrow] = ltot;
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------------------
 // Pass C: owned = C rows j, streamed = Q rows i; reads the P' tiles of pass Q and the factors 2^14 2^(M_split - M) / l'_i
 // of merge<Q>, forms the true probabilities * 2^14 in two fp16 planes and runs the O^T phase alone (24 MFMAs per chunk
 // and wave), software-pipelined like inbatch3_pc_kernel.  One 512-thread workgroup owns 256 rows: a plane tile is
@@ -1728,7 +1995,10 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
   // after the side stream may have updated them, and vice versa).  Same kernels, same arithmetic: results are
   // bit-identical to the sequential form (the loss is an order-free integer sum).
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  const bool overlapped = fused && side != nullptr && side != st && inbatch_events(&ev_fork, &ev_join);
+  // bf16 tables (both towers): the one-plane kernels (ESR_IB2H_BF16=two keeps two planes, whose second is all zero)
+  const char* b16e = getenv("ESR_IB2H_BF16");
+  const bool one_plane = fused && Qs.bf16 && Cs.bf16 && !(b16e && b16e[0] == 't');
+  const bool overlapped = fused && !one_plane && side != nullptr && side != st && inbatch_events(&ev_fork, &ev_join);
   if (fused) {
     static std::atomic<unsigned long long> call_seq{0};
     static const unsigned long long seed =
@@ -1741,6 +2011,45 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
            hipLaunchKernelGGL(prepsplit2h_kernel, dim3(nchunks), dim3(256), 0, st, Qs, Cs, B, ws.Qh, ws.Ch, ws.ent, token,
                               ws.diag, ws.nrm, ws.sc, ws.loss_acc, ws.flags, grid_q, overlapped ? ws.Qcopy : (float*)nullptr,
                               overlapped ? ws.Ccopy : (float*)nullptr));
+    if (one_plane) {
+      // bf16 tables: one fp16 plane per operand, S^T recomputed by pass C -- six GEMMs, no stored probabilities
+      const char* dbg1h = getenv("ESR_IB1H_DBG");
+      if (dbg1h && dbg1h[0] == '1') {
+        hipLaunchKernelGGL((inbatch1h_kernel<true, 1>), dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Qh,
+                           (const _Float16*)ws.Ch, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)ws.diag,
+                           (const float*)nullptr, mode, ws.part_m, ws.part_O, ws.part_l);
+      } else
+      ESR_KT("inbatch1h_kernel_q", st,
+             hipLaunchKernelGGL((inbatch1h_kernel<true>), dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Qh,
+                                (const _Float16*)ws.Ch, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)ws.diag,
+                                (const float*)nullptr, mode, ws.part_m, ws.part_O, ws.part_l));
+      ESR_KT("inbatch3_merge_kernel_q", st,
+             hipLaunchKernelGGL((inbatch3_merge_kernel<true>), dim3(mgrid), dim3(kBlock), 0, st, Qs, Cs, gq_rows, B,
+                                nsplit_q, (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale,
+                                regularization, inv_bs, ws.lse2, lse, gQ, ws.loss_acc, 1.0 / (double)batch_size, loss,
+                                (float*)nullptr, (const float*)(ws.sc + 1), ldexpf(1.f, (int)kHPexp), ws.fac));
+      if (dbg1h && (dbg1h[0] == '1' || dbg1h[0] == '2')) {
+        hipLaunchKernelGGL((inbatch1h_kernel<false, 1>), dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Ch,
+                           (const _Float16*)ws.Qh, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)nullptr,
+                           (const float*)ws.lse2, mode, (float*)nullptr, ws.part_O, (float*)nullptr);
+      } else
+      ESR_KT("inbatch1h_kernel_c", st,
+             hipLaunchKernelGGL((inbatch1h_kernel<false>), dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Ch,
+                                (const _Float16*)ws.Qh, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)nullptr,
+                                (const float*)ws.lse2, mode, (float*)nullptr, ws.part_O, (float*)nullptr));
+      ESR_KT("inbatch3_merge_kernel_c", st,
+             hipLaunchKernelGGL((inbatch3_merge_kernel<false>), dim3(mgrid), dim3(kBlock), 0, st, Cs, Qs, gc_rows, B,
+                                nsplit_q, (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale,
+                                regularization, inv_bs, ws.lse2, (float*)nullptr, gC, ws.loss_acc,
+                                1.0 / (double)batch_size, loss, (float*)nullptr, (const float*)(ws.sc + 2), 1.0f,
+                                (float*)nullptr, ws.ent, nchunks));
+      if (upd) {
+        const int rc = sparse_adagrad_range(upd->tables, upd->accums, upd->row_offsets, 2, upd->dtype, D, upd->sorted_vids,
+                                            upd->perm, 2 * B, upd->grad_rows, upd->lr, upd->eps, upd->skip_long, st);
+        if (rc != ESR_OK) return rc;
+      }
+      return check_launch(who);
+    }
     ESR_KT("inbatch2h_q_kernel", st,
            hipLaunchKernelGGL((inbatch2h_q_kernel<2>), dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Qh,
                               (const _Float16*)ws.Ch, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)ws.part_mr, 1,

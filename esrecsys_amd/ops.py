@@ -489,7 +489,11 @@ def inbatch_split_path(precision, B, D, bf16_tables=False):
     if precision not in INBATCH_PRECISIONS:
         raise ValueError("precision must be one of %s" % (INBATCH_PRECISIONS,))
     shape_ok = D % 4 == 0 and 0 < D <= 128 and B % 128 == 0 and B > 0
-    h_ok = shape_ok and B <= INBATCH_F16X2_MAX_B and not bf16_tables
+    # bf16 tables (round 5): the fp16 entry points run their ONE-plane kernels on them (a bf16 element is exact in one
+    # fp16 plane of x * 2^e): six GEMMs with S^T recomputed by pass C, against eight on the bf16 x 3 one-plane kernels.
+    # ESR_INBATCH_BF16_TABLES=bf16x3 keeps the older path.
+    h_ok = shape_ok and B <= INBATCH_F16X2_MAX_B and \
+        (not bf16_tables or os.environ.get("ESR_INBATCH_BF16_TABLES", "f16") != "bf16x3")
     if precision == "f32":
         return None
     if precision == "bf16x3":
@@ -499,7 +503,7 @@ def inbatch_split_path(precision, B, D, bf16_tables=False):
         return "bf16x3"
     if precision == "f16x2":
         if not h_ok:
-            raise ValueError("precision='f16x2' needs D <= 128 (a multiple of 4), B %% 128 == 0, B <= %d and fp32 rows "
+            raise ValueError("precision='f16x2' needs D <= 128 (a multiple of 4), B %% 128 == 0 and B <= %d "
                              "(got B=%d, D=%d)" % (INBATCH_F16X2_MAX_B, B, D))
         return "f16x2"
     if not shape_ok or D < int(os.environ.get("ESR_INBATCH_SPLIT_MIN_D", "64")):

@@ -435,7 +435,9 @@ def test_inbatch_towers_gather_folded_in(dev, dtype, precision):
     q = ops.unpermute_rows_to_f32(ops.gather_rows(qt, T(qi, dev)), None)
     c = ops.unpermute_rows_to_f32(ops.gather_rows(ct, T(ci, dev)), None)
     l2, lse2, gq2, gc2 = ops.inbatch_softmax_fwd_bwd(q, c, 6.0, 0.1, float(B),
-                                                     precision="bf16x3" if precision == "auto" else precision)
+                                                     precision="f16x2" if precision == "auto" else precision)
+    # ("auto" on bf16 towers: the fp16 ONE-plane kernels -- the dense head on the same bf16-valued rows runs the two-plane
+    # ones, whose second operand planes are all zero: the same products in the same order)
     assert torch.equal(loss, l2) and torch.equal(lse, lse2) and torch.equal(gq, gq2)
     # pass C: bf16 towers recompute S^T (one-plane kernels), f32 rows take the stored-P kernel, which normalises p / l
     # instead of forming exp2(s - lse): the same probabilities to an f32 rounding
@@ -455,7 +457,7 @@ def test_inbatch_one_plane_kernels_equal_the_full_ones(dev, B):
     ct = T((rng.standard_normal((V, D)) * 0.12).astype(np.float32), dev, torch.bfloat16)
     qi = T(rng.integers(0, V, B).astype(np.int32), dev)
     ci = T(rng.integers(0, V, B).astype(np.int32), dev)
-    loss, lse, gq, gc = ops.inbatch_towers_fwd_bwd(qt, ct, qi, ci, 7.0, 0.1, float(B))
+    loss, lse, gq, gc = ops.inbatch_towers_fwd_bwd(qt, ct, qi, ci, 7.0, 0.1, float(B), precision="bf16x3")
     l2, lse2, gq2, gc2 = ops.inbatch_towers_fwd_bwd(qt.float(), ct.float(), qi, ci, 7.0, 0.1, float(B),
                                                     precision="bf16x3")
     assert torch.equal(loss, l2) and torch.equal(lse, lse2) and torch.equal(gq, gq2)
@@ -464,6 +466,60 @@ def test_inbatch_one_plane_kernels_equal_the_full_ones(dev, B):
         q, c = N(qt.float())[N(qi)].astype(F64), N(ct.float())[N(ci)].astype(F64)
         el, _, egq, egc = o_stl.inbatch_softmax_loss_and_grads(q, c, 0.1, B, 7.0, F64)
         assert abs(float(loss) - el) / abs(el) <= TOL and rel_err(N(gq), egq) <= TOL and rel_err(N(gc), egc) <= TOL
+
+
+@pytest.mark.parametrize("B,hot", [(128, False), (512, True), (1024, False), (2176, True), (8192, False), (8192, True)])
+def test_inbatch_bf16_tables_on_one_fp16_plane(dev, B, hot, monkeypatch):
+    """bf16 towers (BASELINE config 4's dtype) on the fp16 entry points (round 5, the default for them): ONE fp16 plane
+    per operand -- a bf16 element is exact in it -- two for the probabilities, S^T recomputed by pass C: six GEMMs, no
+    stored probabilities (inbatch1h_kernel).  Against the fp64 oracle on the same (bf16-valued) rows at the 1e-5 bound --
+    with row norms spread over four decades and a few hot rows ("hot"), every 128-row block within 2e-5 of its own
+    largest entry -- against the two-plane kernels on the same rows (whose second operand planes are all zero: the same
+    products, pass C from stored probabilities instead), and with every workgroup forced through its redo."""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(B + hot)
+    V, D = 6000, 128
+
+    def table():
+        x = rng.standard_normal((V, D))
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        # (not exactly 1: bf16-rounded unit rows would sit within an f32 rounding of the regulariser's kink at |x| = 1)
+        norms = 10.0 ** rng.uniform(-4, 0, V) if hot else np.where(rng.random(V) < 0.5, 0.8, 1.3)
+        if hot:
+            norms[rng.choice(V, 16, replace=False)] = 3.0
+        return T((x * norms[:, None]).astype(np.float32), dev, torch.bfloat16)
+    qt, ct = table(), table()
+    qi = T(rng.integers(0, V, B).astype(np.int32), dev)
+    ci = T(rng.integers(0, V, B).astype(np.int32), dev)
+    assert ops.inbatch_split_path("auto", B, D, bf16_tables=True) == "f16x2"
+    out = [t.clone() for t in ops.inbatch_towers_fwd_bwd(qt, ct, qi, ci, 8.0, 0.1, float(B))]
+    assert all(bool(torch.isfinite(t).all()) for t in out)
+    q, c = N(qt.float())[N(qi)].astype(F64), N(ct.float())[N(ci)].astype(F64)
+    el, else_, egq, egc = o_stl.inbatch_softmax_loss_and_grads(q, c, 0.1, B, 8.0, F64)
+    assert abs(float(out[0]) - el) <= TOL * abs(el) and rel_err(N(out[1]), else_) <= TOL
+    assert rel_err(N(out[2]), egq) <= TOL and rel_err(N(out[3]), egc) <= TOL
+    worst = 0.0
+    for got, exp in ((N(out[2]), egq), (N(out[3]), egc)):
+        for b0 in range(0, B, 128):
+            g, e = got[b0:b0 + 128].astype(F64), exp[b0:b0 + 128]
+            worst = max(worst, float(np.abs(g - e).max() / np.abs(e).max()))
+    print("bf16 towers, one fp16 plane, B = %d%s: worst 128-row block error %.2e" % (B, " (mixed norms)" if hot else "", worst))
+    assert worst <= 2e-5
+    monkeypatch.setenv("ESR_IB2H_BF16", "two")   # two planes per operand (the second all zero), stored probabilities
+    two = ops.inbatch_towers_fwd_bwd(qt, ct, qi, ci, 8.0, 0.1, float(B), precision="f16x2")
+    monkeypatch.delenv("ESR_IB2H_BF16")
+    assert torch.equal(out[0], two[0]) and torch.equal(out[1], two[1]) and torch.equal(out[2], two[2])
+    assert rel_err(N(out[3]), N(two[3])) <= 1e-6
+    monkeypatch.setenv("ESR_IB2H_REF", "redo")   # every pass-Q workgroup redoes itself against its exact maximum
+    redo = ops.inbatch_towers_fwd_bwd(qt, ct, qi, ci, 8.0, 0.1, float(B))
+    monkeypatch.delenv("ESR_IB2H_REF")
+    assert abs(float(redo[0]) - el) <= TOL * abs(el) and rel_err(N(redo[2]), egq) <= TOL and rel_err(N(redo[3]), egc) <= TOL
+    again = ops.inbatch_towers_fwd_bwd(qt, ct, qi, ci, 8.0, 0.1, float(B))
+    assert all(torch.equal(a, b) for a, b in zip(out, again))   # repeatable bit for bit
+    monkeypatch.setenv("ESR_IB1H_DBG", "1")      # test hook: the same phases one chunk at a time, nothing pipelined
+    plain = ops.inbatch_towers_fwd_bwd(qt, ct, qi, ci, 8.0, 0.1, float(B))
+    monkeypatch.delenv("ESR_IB1H_DBG")
+    assert all(torch.equal(a, b) for a, b in zip(out, plain))
 
 
 @pytest.mark.parametrize("B", [128, 256, 1024, 2176, 8192, 16384])
@@ -544,7 +600,7 @@ def test_inbatch_negative_temperature_with_a_far_out_candidate(dev, B, D, scale)
     """A negative temperature makes the row maximum of the scores the MINIMUM of the dot products; with one candidate
     far out on that side (score ~ +150 log2 units) an exponent reference taken from the wrong end overflows exp2 (found
     by scripts/inbatch_stress.py: the bf16 x 3 row-max pre-pass took max(dot) * scale -- inf / nan in that row).  Every
-    precision, and bf16 tables (which always run the bf16 x 3 kernels), must hold the bound."""
+    precision, and bf16 tables (the fp16 one-plane kernels by default), must hold the bound."""
     from esrecsys_amd import ops
     rng = np.random.default_rng(B + D)
     q = (rng.standard_normal((B, D)) * 2.97 / np.sqrt(D)).astype(np.float32)

@@ -225,8 +225,9 @@ def test_planned_batch_refuses_another_state(dev):
     assert np.isfinite(float(loss)) and int(a.step) == 1
 
 
-@pytest.mark.parametrize("B,D,ids", [(1024, 128, "uniform"), (2048, 128, "hot"), (512, 64, "hot"), (8192, 128, "uniform")])
-def test_inbatch_one_call_step_equals_fwd_bwd_plus_update(dev, monkeypatch, B, D, ids):
+@pytest.mark.parametrize("B,D,ids,dt", [(1024, 128, "uniform", "f32"), (2048, 128, "hot", "f32"), (512, 64, "hot", "f32"),
+                                        (8192, 128, "uniform", "f32"), (1024, 128, "hot", "bf16")])
+def test_inbatch_one_call_step_equals_fwd_bwd_plus_update(dev, monkeypatch, B, D, ids, dt):
     """The in-batch step as ONE library call (esr_inbatch_train_step_f16x2) -- with merge<Q> and the scene tower's
     Adagrad on a second stream beside pass C, and without the second stream -- against rounds 1-4's
     esr_inbatch_towers_fwd_bwd_f16x2 + esr_sparse_adagrad_scatter_multi: same kernels on the same values, so losses, towers
@@ -247,8 +248,9 @@ def test_inbatch_one_call_step_equals_fwd_bwd_plus_update(dev, monkeypatch, B, D
 
     def state():
         g = torch.Generator(device=dev).manual_seed(3)
-        params = {"params": {"scene_tower": {"embedding": torch.randn((Vs, D), generator=g, device=dev) * 0.3},
-                             "product_tower": {"embedding": torch.randn((Vp, D), generator=g, device=dev) * 0.3}}}
+        tdt = torch.bfloat16 if dt == "bf16" else torch.float32  # (bf16 towers: the fp16 one-plane kernels, both paths)
+        params = {"params": {"scene_tower": {"embedding": (torch.randn((Vs, D), generator=g, device=dev) * 0.3).to(tdt)},
+                             "product_tower": {"embedding": (torch.randn((Vp, D), generator=g, device=dev) * 0.3).to(tdt)}}}
         model = STLModel(output_size=D, num_scenes=Vs, num_products=Vp, device=dev)
         return TrainState.create(apply_fn=model.apply, params=params, tx=optim.sparse_adagrad(0.05))
 
@@ -276,4 +278,5 @@ def test_inbatch_one_call_step_equals_fwd_bwd_plus_update(dev, monkeypatch, B, D
         for name, x, y in zip(names, got, want):
             if not torch.equal(x, y):
                 bad.append((onecall, overlap, loop, name, float((x.float() - y.float()).abs().max())))
+    assert want[1].dtype == (torch.bfloat16 if dt == "bf16" else torch.float32)
     assert not bad, bad
