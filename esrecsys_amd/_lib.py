@@ -136,6 +136,11 @@ SIGNATURES = {
                                        ctypes.c_int32, c_f32p, c_vp]),
     "esr_topk_merge": (c_int, [c_f32p, c_i32p, c_i64, c_int, c_int, c_f32p, c_i32p, c_vp]),
     "esr_recall_at_k": (c_int, [c_i32p, c_i64, c_int, c_i32p, c_int, c_vp, c_vp]),
+    "esr_run_offsets": (c_int, [c_i32p, c_i64, c_int, c_i32p, c_i32p, c_vp]),
+    "esr_ivf_centroids": (c_int, [c_f32p, c_i32p, c_f32p, c_i32p, c_int, c_int, c_f32p, c_vp]),
+    "esr_sorted_membership": (c_int, [c_i32p, c_i64, c_i32p, c_i64, c_int, c_int, c_vp, c_vp]),
+    "esr_flagged_first_workspace_bytes": (c_size, [c_i64, c_int]),
+    "esr_flagged_first": (c_int, [c_vp, c_i32p, c_i64, c_int, c_vp, c_int, c_i32p, c_vp, c_i64, c_i64, c_vp, c_size, c_vp]),
     "esr_spotify_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int]),
     "esr_spotify_get_embeddings": (c_int, [c_f32p, c_i64, c_f32p, c_i64, c_int, c_i32p, c_i32p, c_i64, c_f32p, c_f32p,
                                            c_vp]),

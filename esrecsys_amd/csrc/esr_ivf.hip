@@ -254,6 +254,44 @@ static size_t ivf_layout(const IvfGeom& g, int64_t cq, int nprobe, int nlist, ch
   return off;
 }
 
+
+// ---- index build (esrecsys_amd/ivf.py; round 5: torch.bincount / searchsorted / norm there are gone) --------------------------
+// list_off[v] = first position of the ascending `sorted` [n] whose value is >= v, v = 0 .. nvalues (list_off[nvalues] = n);
+// max_len[0] = the longest run.  One thread per position fills the offsets of the values between its predecessor's and
+// its own.
+__global__ __launch_bounds__(kBlock) void run_offsets_kernel(const int32_t* __restrict__ sorted, int64_t n, int nvalues,
+                                                            int32_t* __restrict__ off, int32_t* __restrict__ max_len) {
+  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p <= n; p += (int64_t)gridDim.x * kBlock) {
+    const int32_t prev = p == 0 ? -1 : min(sorted[p - 1], nvalues - 1);
+    const int32_t cur = p == n ? nvalues : min(max(sorted[p], 0), nvalues);
+    for (int32_t v = prev + 1; v <= cur; ++v) off[v] = (int32_t)p;
+  }
+}
+__global__ __launch_bounds__(kBlock) void run_max_kernel(const int32_t* __restrict__ off, int nvalues,
+                                                        int32_t* __restrict__ max_len) {
+  int m = 0;
+  for (int v = blockIdx.x * kBlock + threadIdx.x; v < nvalues; v += gridDim.x * kBlock) m = max(m, off[v + 1] - off[v]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(max_len, m);
+}
+// cent[v] = sums[v] / |sums[v]| for a list that has members (off[v + 1] > off[v]), else the unit vector of training row
+// fallback[v] (spherical k-means: an empty list takes a random training row).  One 64-lane wave per list.
+__global__ __launch_bounds__(kBlock) void ivf_centroids_kernel(const float* __restrict__ sums, const int32_t* __restrict__ off,
+                                                              const float* __restrict__ train,
+                                                              const int32_t* __restrict__ fallback, int nlist, int D,
+                                                              float* __restrict__ cent) {
+  const int v = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (v >= nlist) return;
+  const float* src = (off == nullptr || off[v + 1] > off[v]) ? sums + (int64_t)v * D : train + (int64_t)fallback[v] * D;
+  float ss = 0.f;
+  for (int d = lane; d < D; d += 64) ss = fmaf(src[d], src[d], ss);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-30f);
+  for (int d = lane; d < D; d += 64) cent[(int64_t)v * D + d] = src[d] * inv;
+}
+
 }  // namespace esr
 
 using namespace esr;
@@ -338,6 +376,33 @@ int esr_ivf_search(const float* queries, int64_t nq, int D, const float* cands_s
                        (const float*)(out_scores + q0 * k), out_indices + q0 * k);
   }
   return check_launch("esr_ivf_search");
+}
+
+
+int esr_run_offsets(const int32_t* sorted, int64_t n, int nvalues, int32_t* off, int32_t* max_len, esr_stream_t stream) {
+  TraceScope trace_scope_("esr_run_offsets");
+  ESR_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) && nvalues >= 1, "esr_run_offsets: bad sizes n=%lld nvalues=%d", (long long)n,
+              nvalues);
+  ESR_REQUIRE(off && (n == 0 || sorted), "esr_run_offsets: null pointer");
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(run_offsets_kernel, dim3((unsigned)std::min<int64_t>(kMaxGrid, cdiv(n + 1, kBlock))), dim3(kBlock), 0, st,
+                     sorted, n, nvalues, off, max_len);
+  if (max_len) {
+    if (hipMemsetAsync(max_len, 0, sizeof(int32_t), st) != hipSuccess) return check_launch("esr_run_offsets");
+    hipLaunchKernelGGL(run_max_kernel, dim3((unsigned)std::min<int64_t>(256, cdiv(nvalues, kBlock))), dim3(kBlock), 0, st,
+                       (const int32_t*)off, nvalues, max_len);
+  }
+  return check_launch("esr_run_offsets");
+}
+
+int esr_ivf_centroids(const float* sums, const int32_t* list_off, const float* train, const int32_t* fallback_rows,
+                      int nlist, int D, float* centroids, esr_stream_t stream) {
+  TraceScope trace_scope_("esr_ivf_centroids");
+  ESR_REQUIRE(nlist >= 1 && D >= 1 && sums && centroids, "esr_ivf_centroids: bad arguments");
+  ESR_REQUIRE(list_off == nullptr || (train && fallback_rows), "esr_ivf_centroids: empty lists need training rows to fall back on");
+  hipLaunchKernelGGL(ivf_centroids_kernel, dim3((unsigned)cdiv(nlist, kBlock / 64)), dim3(kBlock), 0, as_stream(stream), sums,
+                     list_off, train, fallback_rows, nlist, D, centroids);
+  return check_launch("esr_ivf_centroids");
 }
 
 }  // extern "C"

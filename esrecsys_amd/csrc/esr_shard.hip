@@ -24,6 +24,7 @@ namespace esr {
 
 constexpr int kUqTile = 1024;  // positions per workgroup of the heads / scatter kernels (4 per thread)
 constexpr int kUqMaxSegs = 4;
+constexpr int kBucketMaxWorldShard = 64;  // most ranks of one exchange group the plan-phase kernels count for
 
 struct UqSegs {
   const int32_t* ids[kUqMaxSegs];
@@ -143,6 +144,96 @@ static size_t uq_ws_layout(int64_t n, char* base, UqWs* out) {
   return off;
 }
 
+
+// ---- the overlapped loop's plan phase (esrecsys_amd/sharded.py begin_stale_sets; round 5: torch.searchsorted / cumsum /
+// scatter_ / gather there are gone) -------------------------------------------------------------------------------------------
+// sorted_membership: flags[l][j] = 1 iff cur[l][j] != sentinel and cur[l][j] occurs in the ascending list seq[l][0 .. m).
+__global__ __launch_bounds__(kBlock) void sorted_membership_kernel(const int32_t* __restrict__ cur, int64_t n,
+                                                                  const int32_t* __restrict__ seq, int64_t m,
+                                                                  int32_t sentinel, uint8_t* __restrict__ flags) {
+  const int l = blockIdx.y;
+  const int32_t* s = seq + (int64_t)l * m;
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += (int64_t)gridDim.x * kBlock) {
+    const int32_t v = cur[(int64_t)l * n + j];
+    int64_t lo = 0, hi = m;  // first position with s[pos] >= v
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (s[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    flags[(int64_t)l * n + j] = (v != sentinel && lo < m && s[lo] == v) ? 1 : 0;
+  }
+}
+// flagged_first: every row of `values` [L][n] (values == NULL: the positions 0 .. n - 1) with its flagged entries FIRST,
+// order kept (a stable partition; only the flagged prefix is written), and, per row, the number of flagged entries inside
+// each of G consecutive slices of lengths slice_len[l][0 .. G).  Two launches over 1024-entry tiles: flagged entries per
+// tile; then every workgroup adds up the tiles before its own, ranks its flagged entries by ballots and counts them per
+// slice (integer atomics on zeroed words: order-free).
+constexpr int kFfTile = 1024;
+__global__ __launch_bounds__(kBlock) void flagged_count_kernel(const uint8_t* __restrict__ flags, int64_t n, int ntiles,
+                                                              int32_t* __restrict__ tile_cnt) {
+  __shared__ int wsum[kBlock / 64];
+  const int l = blockIdx.y, tile = blockIdx.x, t = threadIdx.x;
+  int c = 0;
+#pragma unroll
+  for (int q = 0; q < kFfTile / kBlock; ++q) {
+    const int64_t j = (int64_t)tile * kFfTile + q * kBlock + t;
+    c += (j < n && flags[(int64_t)l * n + j]) ? 1 : 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((t & 63) == 0) wsum[t >> 6] = c;
+  __syncthreads();
+  if (t == 0) tile_cnt[(int64_t)l * ntiles + tile] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ __launch_bounds__(kBlock) void flagged_scatter_kernel(const uint8_t* __restrict__ flags,
+                                                                const int32_t* __restrict__ values, int64_t n, int ntiles,
+                                                                const int32_t* __restrict__ tile_cnt,
+                                                                const int64_t* __restrict__ slice_len, int G,
+                                                                int32_t* __restrict__ out,
+                                                                unsigned long long* __restrict__ counts,
+                                                                int64_t cstride_l, int64_t cstride_g) {
+  __shared__ int red[kBlock / 64];
+  __shared__ int wave_base[kBlock / 64];
+  __shared__ int64_t ends[kBucketMaxWorldShard];
+  __shared__ int scount[kBucketMaxWorldShard];
+  const int l = blockIdx.y, tile = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  int before = 0;
+  for (int u = t; u < tile; u += kBlock) before += tile_cnt[(int64_t)l * ntiles + u];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+  if (lane == 0) red[w] = before;
+  if (t < G) scount[t] = 0;
+  if (t == 0) {
+    int64_t e = 0;
+    for (int g = 0; g < G; ++g) {
+      e += slice_len[(int64_t)l * G + g];
+      ends[g] = e;
+    }
+  }
+  __syncthreads();
+  int base = red[0] + red[1] + red[2] + red[3];
+  for (int q = 0; q < kFfTile / kBlock; ++q) {  // 256 consecutive entries per round: ranks by ballot, in order
+    const int64_t j = (int64_t)tile * kFfTile + q * kBlock + t;
+    const bool f = j < n && flags[(int64_t)l * n + j] != 0;
+    const unsigned long long b = __ballot(f);
+    const int rank_in_wave = __popcll(b & ((1ull << lane) - 1ull));
+    __syncthreads();  // (wave_base of the previous round has been read)
+    if (lane == 0) wave_base[w] = __popcll(b);
+    __syncthreads();
+    int wb = 0;
+    for (int k = 0; k < w; ++k) wb += wave_base[k];
+    if (f) {
+      out[(int64_t)l * n + base + wb + rank_in_wave] = values ? values[(int64_t)l * n + j] : (int32_t)j;
+      int g = 0;
+      while (g < G - 1 && j >= ends[g]) ++g;
+      atomicAdd(&scount[g], 1);
+    }
+    base += wave_base[0] + wave_base[1] + wave_base[2] + wave_base[3];
+  }
+  __syncthreads();
+  if (t < G && scount[t]) atomicAdd(counts + (int64_t)l * cstride_l + (int64_t)t * cstride_g, (unsigned long long)scount[t]);
+}
+
 }  // namespace esr
 
 using namespace esr;
@@ -200,6 +291,50 @@ int esr_unique_by_owner(const int32_t* const* ids, const int64_t* seg_counts, co
                      (const int32_t*)perm, n, local_rows, (const int32_t*)ws.tile_heads, ulocal, uidx, sorted_uidx,
                      ucounts, world);
   return check_launch("esr_unique_by_owner");
+}
+
+
+int esr_sorted_membership(const int32_t* cur, int64_t n, const int32_t* seq, int64_t m, int nlists, int32_t sentinel,
+                          uint8_t* flags, esr_stream_t stream) {
+  TraceScope trace_scope_("esr_sorted_membership");
+  ESR_REQUIRE(n >= 0 && m >= 0 && nlists >= 1 && nlists <= 65535, "esr_sorted_membership: bad sizes n=%lld m=%lld nlists=%d",
+              (long long)n, (long long)m, nlists);
+  if (n == 0) return ESR_OK;
+  ESR_REQUIRE(cur && flags && (m == 0 || seq), "esr_sorted_membership: null pointer");
+  const dim3 grid((unsigned)std::min<int64_t>(1024, cdiv(n, kBlock)), nlists);
+  hipLaunchKernelGGL(sorted_membership_kernel, grid, dim3(kBlock), 0, as_stream(stream), cur, n, seq, m, sentinel, flags);
+  return check_launch("esr_sorted_membership");
+}
+
+size_t esr_flagged_first_workspace_bytes(int64_t n, int nlists) {
+  if (n <= 0 || nlists <= 0) return 256;
+  return align_up((size_t)nlists * (size_t)cdiv(n, kFfTile) * sizeof(int32_t), 256);
+}
+
+int esr_flagged_first(const uint8_t* flags, const int32_t* values, int64_t n, int nlists, const int64_t* slice_len, int G,
+                      int32_t* out, int64_t* counts, int64_t counts_stride_list, int64_t counts_stride_slice,
+                      void* workspace, size_t workspace_bytes, esr_stream_t stream) {
+  TraceScope trace_scope_("esr_flagged_first");
+  ESR_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) && nlists >= 1 && nlists <= 65535 && G >= 1 && G <= kBucketMaxWorldShard,
+              "esr_flagged_first: bad sizes n=%lld nlists=%d G=%d (G <= %d)", (long long)n, nlists, G, kBucketMaxWorldShard);
+  ESR_REQUIRE(counts && slice_len, "esr_flagged_first: null counts / slice lengths");
+  hipStream_t st = as_stream(stream);
+  // the caller's count words (any strides) are zeroed here: nlists x G of them
+  for (int l = 0; l < nlists; ++l)
+    if (hipMemset2DAsync(counts + (int64_t)l * counts_stride_list, (size_t)counts_stride_slice * sizeof(int64_t), 0,
+                         sizeof(int64_t), (size_t)G, st) != hipSuccess)
+      return check_launch("esr_flagged_first");
+  if (n == 0) return ESR_OK;
+  ESR_REQUIRE(flags && out && workspace && !((uintptr_t)workspace & 3) &&
+                  workspace_bytes >= esr_flagged_first_workspace_bytes(n, nlists),
+              "esr_flagged_first: null pointer or workspace too small");
+  const int ntiles = (int)cdiv(n, kFfTile);
+  const dim3 grid(ntiles, nlists);
+  hipLaunchKernelGGL(flagged_count_kernel, grid, dim3(kBlock), 0, st, flags, n, ntiles, (int32_t*)workspace);
+  hipLaunchKernelGGL(flagged_scatter_kernel, grid, dim3(kBlock), 0, st, flags, values, n, ntiles,
+                     (const int32_t*)workspace, slice_len, G, out, reinterpret_cast<unsigned long long*>(counts),
+                     counts_stride_list, counts_stride_slice);
+  return check_launch("esr_flagged_first");
 }
 
 }  // extern "C"

@@ -1002,6 +1002,62 @@ def inbatch_train_step(query_table, query_accum, cand_table, cand_accum, query_i
     return (loss, lse) if want_lse else loss
 
 
+def sorted_membership(cur, seq, sentinel):
+    """flags uint8 [L, n]: cur[l, j] != sentinel and cur[l, j] occurs in the ascending row seq[l] (esr_sorted_membership)."""
+    lib = _lib.load()
+    cur, seq = _req(cur, torch.int32, "cur"), _req(seq, torch.int32, "seq")
+    L, n = cur.shape
+    flags = torch.empty((L, n), dtype=torch.uint8, device=cur.device)
+    check(lib.esr_sorted_membership(_p(cur), n, _p(seq), seq.shape[1], L, int(sentinel), _p(flags), _stream()),
+          "esr_sorted_membership")
+    return flags
+
+
+def flagged_first(flags, values, slice_len, counts_out):
+    """Stable partition of every row of `values` [L, n] (None: the positions 0 .. n - 1) by flags uint8 [L, n]: returns
+    int32 [L, n] whose rows START with the flagged entries in order (the rest is unspecified); counts_out int64 [G, L]
+    (any strides) receives, per row, the flagged entries inside each of G consecutive slices of lengths slice_len int64
+    [L, G] (esr_flagged_first)."""
+    lib = _lib.load()
+    flags = _req(flags, torch.uint8, "flags")
+    L, n = flags.shape
+    slice_len = _req(slice_len, torch.int64, "slice_len")
+    G = slice_len.shape[1]
+    if values is not None:
+        values = _req(values, torch.int32, "values")
+    if counts_out.dtype != torch.int64 or tuple(counts_out.shape) != (G, L):
+        raise ValueError("counts_out must be an int64 [G, L] view")
+    out = torch.empty((L, n), dtype=torch.int32, device=flags.device)
+    ws = _ws(_ws_bytes("esr_flagged_first_workspace_bytes", n, L), flags.device)
+    check(lib.esr_flagged_first(_p(flags), _p(values), n, L, _p(slice_len), G, _p(out), counts_out.data_ptr(),
+                                counts_out.stride(1), counts_out.stride(0), _p(ws), ws.numel(), _stream()),
+          "esr_flagged_first")
+    return out
+
+
+def run_offsets(sorted_ids, nvalues, want_max=False):
+    """int32 [nvalues + 1]: the first position of each value in the ascending int32 list (esr_run_offsets); with want_max
+    also the longest run as an int32 [1] device tensor."""
+    lib = _lib.load()
+    sorted_ids = _req(sorted_ids, torch.int32, "sorted_ids")
+    off = torch.empty(nvalues + 1, dtype=torch.int32, device=sorted_ids.device)
+    mx = torch.empty(1, dtype=torch.int32, device=sorted_ids.device) if want_max else None
+    check(lib.esr_run_offsets(_p(sorted_ids), sorted_ids.numel(), int(nvalues), _p(off), _p(mx), _stream()), "esr_run_offsets")
+    return (off, mx) if want_max else off
+
+
+def ivf_centroids(sums, list_off=None, train=None, fallback_rows=None):
+    """Unit-length centroids from per-list sums [nlist, D]; a list without members (list_off) takes training row
+    fallback_rows[v] instead (esr_ivf_centroids)."""
+    lib = _lib.load()
+    sums = _req(sums, torch.float32, "sums")
+    nlist, D = sums.shape
+    out = torch.empty_like(sums)
+    check(lib.esr_ivf_centroids(_p(sums), _p(list_off), _p(train), _p(fallback_rows), nlist, D, _p(out), _stream()),
+          "esr_ivf_centroids")
+    return out
+
+
 def recall_at_k(approx_indices, exact_indices):
     """hits / (Q * ke): the fraction of exact_indices [Q, ke] that also occur in the same row of approx_indices [Q, ka]
     (esr_recall_at_k).  Synchronises to read the one counter back."""

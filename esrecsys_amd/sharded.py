@@ -351,36 +351,6 @@ def _padded_lists(plans, sentinel):
     return cur, srt
 
 
-def _row_sums(x, chunk=512):
-    """cumsum along dim 1 of x [L, n] int64.  torch scans a row with ONE workgroup and a group of plans has 8 rows: cut
-    into chunks the same scan has hundreds of rows to spread over the CUs (1 M flags: 150 -> 15 us)."""
-    L, n = x.shape
-    if n <= 4 * chunk:
-        return x.cumsum(1)
-    pad = (-n) % chunk
-    y = (torch.nn.functional.pad(x, (0, pad)) if pad else x).view(L, -1, chunk).cumsum(2)
-    ends = y[:, :, -1]
-    return (y + (ends.cumsum(1) - ends)[:, :, None]).view(L, -1)[:, :n]
-
-
-def _flagged_first(flags, values):
-    """Every row of `values` [L, n] with its flagged entries first, order kept (a stable partition by one prefix sum and
-    one scatter -- a stable sort of the flags costs several times that), and the prefix sums of the flags [L, n + 1]."""
-    L, n = flags.shape
-    cs = _row_sums(flags.to(torch.int64))
-    at = torch.arange(n, dtype=torch.int64, device=flags.device).expand(L, n)
-    dest = torch.where(flags, cs - 1, cs[:, -1:] + at - cs)
-    out = torch.empty_like(values).scatter_(1, dest, values)
-    return out, torch.cat([torch.zeros((L, 1), dtype=torch.int64, device=flags.device), cs], dim=1)
-
-
-def _per_peer(counts, sums):
-    """[L, G] numbers of flagged entries in consecutive slices of lengths counts [L, G] (the plans' counts, already on
-    the device), from the prefix sums of _flagged_first."""
-    ends = counts.cumsum(1).clamp_(max=sums.shape[1] - 1)
-    return sums.gather(1, ends) - sums.gather(1, (ends - counts).clamp_(min=0))
-
-
 def begin_stale_sets(plans, prev):
     """For consecutive lookups of ONE table group in a training loop -- plans[i] follows plans[i - 1], plans[0] follows
     `prev` (the last plan of the group of batches before; None: nothing precedes) -- find, on the owner, the rows of every
@@ -389,7 +359,9 @@ def begin_stale_sets(plans, prev):
     the asked lists in the predecessors' sorted lists; the 0 / 1 answers go back to the askers (one byte per asked row: the
     sizes are the plans' own, ONE RCCL group for the group's plans), so that owner and asker each derive their half --
     the rows to serve again, per asker; the places they go to, per owner -- and ONE copy of the two count matrices to
-    pinned memory.  SURVEY 8e: the exchange of batch k + 1 under batch k's kernels."""
+    pinned memory.  SURVEY 8e: the exchange of batch k + 1 under batch k's kernels.  The search and the two stable
+    partitions are the library's own launches (esr_sorted_membership, esr_flagged_first; round 5), batched over the
+    group's plans."""
     g = plans[0].group
     G, L = g.world, len(plans)
     for p in plans:
@@ -405,13 +377,13 @@ def begin_stale_sets(plans, prev):
         seq[1:, :n_max] = srt[:-1]
     if first is not None and first.numel():
         seq[0, :first.numel()] = first
-    hit = (seq.gather(1, torch.searchsorted(seq, cur).clamp_(max=m - 1)) == cur) & (cur != sentinel)
+    k = g.k
+    both = torch.zeros((2, G, L), dtype=torch.int64, device=dev)  # [0]: rows to serve again per asker, [1]: rows coming back
+    hit8 = k.sorted_membership(cur, seq, sentinel)                # uint8 [L, n_max]
     # owner: the rows to serve again, asker by asker (the order of the asked list is kept)
-    ids_sorted, sums = _flagged_first(hit, cur)
-    out_counts = _per_peer(torch.stack([p.dev_counts[1] for p in plans]), sums)
+    ids_sorted = k.flagged_first(hit8, cur, torch.stack([p.dev_counts[1] for p in plans]), both[0])
     # asker: which rows of its looked-up block those are
     r_max = max([p.n_rows for p in plans] + [1])
-    hit8 = hit.to(torch.uint8)
     if G == 1:
         mask = hit8  # (a world of one rank asks itself: block order == asked order)
     else:
@@ -424,10 +396,7 @@ def begin_stale_sets(plans, prev):
         else:
             for mv in moves:
                 _a2a(g, *mv)
-    pos_sorted, sums = _flagged_first(mask != 0, torch.arange(mask.shape[1], dtype=torch.int32, device=dev).expand(
-        L, mask.shape[1]))
-    in_counts = _per_peer(torch.stack([p.dev_counts[0] for p in plans]), sums)
-    both = torch.stack([out_counts.t(), in_counts.t()])  # [2, G, L]
+    pos_sorted = k.flagged_first(mask, None, torch.stack([p.dev_counts[0] for p in plans]), both[1])
     if both.is_cuda:
         host = _pinned_like(both)
         host.copy_(both, non_blocking=True)

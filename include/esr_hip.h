@@ -465,6 +465,14 @@ size_t esr_ivf_search_workspace_bytes(int64_t nq, int nlist, int max_list, int n
 int esr_ivf_search(const float* queries, int64_t nq, int D, const float* cands_sorted, const int32_t* list_off,
                    const int32_t* orig, int nlist, int max_list, const int32_t* probe_lists, int nprobe, int k,
                    float* out_scores, int32_t* out_indices, void* workspace, size_t workspace_bytes, esr_stream_t stream);
+/* Index build helpers (esrecsys_amd/ivf.py).  esr_run_offsets: list_off[v] = first position of the ASCENDING list
+ * sorted [n] whose value is >= v, for v = 0 .. nvalues (int32 [nvalues + 1]: the inverted lists' boundaries from the sorted
+ * assignments); max_len (optional, int32 [1]) = the longest run.  esr_ivf_centroids: centroids[v] = the unit vector of
+ * sums[v] [nlist, D] where list v has members (list_off[v + 1] > list_off[v]; list_off NULL: every list), else of training
+ * row fallback_rows[v] -- the centroid step of spherical k-means. */
+int esr_run_offsets(const int32_t* sorted, int64_t n, int nvalues, int32_t* list_off, int32_t* max_len, esr_stream_t stream);
+int esr_ivf_centroids(const float* sums, const int32_t* list_off, const float* train, const int32_t* fallback_rows,
+                      int nlist, int D, float* centroids, esr_stream_t stream);
 
 /* ---- N1: Spotify id-embedding two-tower -- spotify/models.py:27-90, spotify/train_spotify.py:77-131 ----
  * A track embeds as concat(album_table[album mod n_album_rows], artist_table[artist]) ([.., 2F]).  One call is one
@@ -568,6 +576,19 @@ size_t esr_unique_by_owner_workspace_bytes(int64_t n);
 int esr_unique_by_owner(const int32_t* const* ids, const int64_t* seg_counts, const int64_t* offsets, int nseg, int world,
                         int64_t local_rows, int32_t* ulocal, int32_t* uidx, int32_t* sorted_uidx, int32_t* perm,
                         int64_t* ucounts, void* workspace, size_t workspace_bytes, esr_stream_t stream);
+/* The plan phase of the overlapped row-sharded loop (esrecsys_amd/sharded.py begin_stale_sets), batched over nlists lists:
+ * esr_sorted_membership: flags[l][j] = 1 iff cur[l][j] != sentinel and it occurs in the ascending list seq[l][0 .. m)
+ *   (cur int32 [nlists][n], seq int32 [nlists][m], flags uint8 [nlists][n]).
+ * esr_flagged_first: out[l][0 .. c_l) = the flagged entries of values[l] (values NULL: their positions) in order -- a
+ *   stable partition, only the flagged prefix is written -- and counts[l * counts_stride_list + g * counts_stride_slice]
+ *   = flagged entries inside the g-th of G consecutive slices of lengths slice_len[l][g] (int64 [nlists][G], device; G
+ *   <= 64); the count words are zeroed by the call.  Workspace: esr_flagged_first_workspace_bytes. */
+int esr_sorted_membership(const int32_t* cur, int64_t n, const int32_t* seq, int64_t m, int nlists, int32_t sentinel,
+                          uint8_t* flags, esr_stream_t stream);
+size_t esr_flagged_first_workspace_bytes(int64_t n, int nlists);
+int esr_flagged_first(const uint8_t* flags, const int32_t* values, int64_t n, int nlists, const int64_t* slice_len, int G,
+                      int32_t* out, int64_t* counts, int64_t counts_stride_list, int64_t counts_stride_slice,
+                      void* workspace, size_t workspace_bytes, esr_stream_t stream);
 /* out[perm[k], :] = rows[k, :]  (undo the bucket order for rows that came back). */
 int esr_unpermute_rows(const void* rows, int dtype, int D, const int32_t* perm, int64_t n, void* out,
                        esr_stream_t stream);

@@ -202,3 +202,29 @@ def topk_merge(scores, indices, k):
     s, i = scores.numpy(), indices.numpy().astype(np.int64)
     order = np.lexsort((i, -s), axis=-1)[:, :k]        # score descending, then index ascending
     return _t(np.take_along_axis(s, order, -1)), _t(np.take_along_axis(i, order, -1), torch.int32)
+
+
+def sorted_membership(cur, seq, sentinel):
+    """CPU double of ops.sorted_membership (esr_sorted_membership): uint8 [L, n]."""
+    m = seq.shape[1]
+    pos = torch.searchsorted(seq.contiguous(), cur.contiguous()).clamp_(max=max(m - 1, 0))
+    hit = (seq.gather(1, pos) == cur) & (cur != sentinel) if m else torch.zeros_like(cur, dtype=torch.bool)
+    return hit.to(torch.uint8)
+
+
+def flagged_first(flags, values, slice_len, counts_out):
+    """CPU double of ops.flagged_first (esr_flagged_first): stable partition per row + flagged entries per slice."""
+    L, n = flags.shape
+    f = flags != 0
+    vals = values if values is not None else torch.arange(n, dtype=torch.int32).expand(L, n)
+    out = torch.zeros((L, n), dtype=torch.int32)
+    G = slice_len.shape[1]
+    for l in range(L):
+        sel = vals[l][f[l]]
+        out[l, :sel.numel()] = sel
+        e = 0
+        for g in range(G):
+            w = int(slice_len[l, g])
+            counts_out[g, l] = int(f[l, e:e + w].sum())
+            e += w
+    return out

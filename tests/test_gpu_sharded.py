@@ -363,3 +363,61 @@ def test_overlapped_lookups_equal_the_sequential_loop_on_the_gpu(dev, pg, worklo
     monkeypatch.setattr(sharded.ShardedTableGroup, "patch_rows", real)
     monkeypatch.setattr(ops, "step_overlap_struct", real_struct)
     assert not all(torch.equal(ta.local, td.local) for ga, gd in zip(a, d) for ta, td in zip(ga.tables, gd.tables))
+
+
+@pytest.mark.parametrize("L,n,m,G", [(1, 1, 1, 1), (8, 5000, 7000, 8), (3, 1024, 1, 2), (8, 100_003, 90_001, 8),
+                                     (2, 2049, 4096, 64)])
+def test_plan_phase_kernels_membership_and_stable_partition(dev, L, n, m, G):
+    """esr_sorted_membership + esr_flagged_first (the overlapped loop's plan phase: which asked rows does the previous
+    step update, served again asker by asker) against NumPy: flags, the flagged entries first in order, per-slice counts
+    through a strided [G, L] view; values = None gives positions."""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(L * n + m)
+    sentinel = 1_000_000
+    cur = rng.integers(0, 3 * m + 5, (L, n)).astype(np.int32)
+    cur[:, -max(1, n // 7):] = sentinel                                  # padding
+    seq = np.sort(rng.integers(0, 3 * m + 5, (L, m)).astype(np.int32), axis=1)
+    seq[:, -max(1, m // 5):] = sentinel + 1                              # padding of the sorted lists
+    flags = ops.sorted_membership(torch.from_numpy(cur).to(dev), torch.from_numpy(seq).to(dev), sentinel)
+    want = np.stack([np.isin(cur[l], seq[l]) & (cur[l] != sentinel) for l in range(L)])
+    assert np.array_equal(flags.cpu().numpy().astype(bool), want)
+    cuts = np.sort(rng.integers(0, n + 1, (L, G - 1)), axis=1)
+    lens = np.diff(np.concatenate([np.zeros((L, 1), np.int64), cuts, np.full((L, 1), n)], axis=1), axis=1).astype(np.int64)
+    both = torch.full((2, G, L), -7, dtype=torch.int64, device=dev)
+    for values, slot in ((cur, 0), (None, 1)):
+        out = ops.flagged_first(flags, None if values is None else torch.from_numpy(values).to(dev),
+                                torch.from_numpy(lens).to(dev), both[slot])
+        got = out.cpu().numpy()
+        for l in range(L):
+            sel = (cur[l] if values is not None else np.arange(n, dtype=np.int32))[want[l]]
+            assert np.array_equal(got[l, :sel.size], sel), (l, slot)
+            e = np.concatenate([[0], np.cumsum(lens[l])])
+            assert [int(x) for x in both[slot, :, l].cpu()] == [int(want[l, e[g]:e[g + 1]].sum()) for g in range(G)]
+
+
+def test_ivf_build_kernels_run_offsets_and_centroids(dev):
+    """esr_run_offsets (list boundaries + longest run from the sorted assignments, absent values included) and
+    esr_ivf_centroids (unit vectors; empty lists take their fallback training row) against NumPy."""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(5)
+    for n, nv in ((0, 3), (1, 1), (10_000, 257), (100_001, 4096), (50, 1000)):
+        a = np.sort(rng.integers(0, nv, n).astype(np.int32))
+        if n > 10:
+            a = a[a != a[n // 2]]                                    # a value of the middle goes missing entirely
+        off, mx = ops.run_offsets(torch.from_numpy(a).to(dev), nv, want_max=True)
+        want = np.searchsorted(a, np.arange(nv + 1), side="left").astype(np.int32)
+        assert np.array_equal(off.cpu().numpy(), want)
+        assert int(mx) == int(np.diff(want).max())
+    nlist, D, nt = 300, 64, 1000
+    sums = rng.standard_normal((nlist, D)).astype(np.float32) * 5
+    train = rng.standard_normal((nt, D)).astype(np.float32)
+    off = np.arange(nlist + 1, dtype=np.int32)
+    off[101:] -= 1                                                   # list 100 is empty
+    fb = rng.integers(0, nt, nlist).astype(np.int32)
+    T = lambda x: torch.from_numpy(x).to(dev)  # noqa: E731
+    cent = ops.ivf_centroids(T(sums), T(off), T(train), T(fb)).cpu().numpy()
+    src = sums.copy()
+    src[100] = train[fb[100]]
+    want = src / np.linalg.norm(src, axis=1, keepdims=True)
+    assert np.abs(cent - want).max() <= 1e-6
+    assert np.abs(ops.ivf_centroids(T(sums)).cpu().numpy() - sums / np.linalg.norm(sums, axis=1, keepdims=True)).max() <= 1e-6
