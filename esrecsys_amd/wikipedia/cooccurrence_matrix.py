@@ -108,6 +108,49 @@ def parse_cooccurrence_row(serialized):
     return index, others, counts
 
 
+class CooccurrenceMatrix:
+    """The whole co-occurrence file as a sparse matrix in host memory -- the reference's debug consumer
+    (wikipedia/cooccurrence_matrix.py:18-55): ``CooccurrenceMatrix(input_file)`` loads, ``debug_print(max_rows,
+    token_dictionary, num_terms)`` prints, per token, its num_terms heaviest partners.  Rows are kept as the reference
+    keeps them (one list of (other_index, count) per row index, in file order; repeated row indices append), decoded by
+    the C line decoder instead of protobuf."""
+
+    def __init__(self, input_file):
+        self.load(input_file)
+
+    def _reset(self):
+        self._matrix = {}
+
+    def load(self, input_file):
+        """Loads a co-occurrence file (``*.cooccur.pb.b64.bz2``: one base64 CooccurrenceRow per line)."""
+        import bz2
+        self._reset()
+        with bz2.open(input_file, "rb") as f:
+            text = f.read()
+        if text and not text.endswith(b"\n"):
+            text += b"\n"
+        t1, t2, cnt, _ = decode_lines(text)
+        for i, j, c in zip(t1.tolist(), t2.tolist(), cnt.tolist()):
+            self._matrix.setdefault(i, []).append((j, c))
+
+    def rows(self):
+        """{row index: [(other index, count), ...]} -- what the reference holds in its private ``__matrix``."""
+        return self._matrix
+
+    def debug_print(self, max_rows, token_dictionary, num_terms):
+        count = 0
+        for key in self._matrix.keys():
+            row = sorted(self._matrix[key], key=lambda x: x[1], reverse=True)
+            token = token_dictionary.get_token_from_embedding_index(key)
+            print("Token [%s]" % token)
+            for i in range(min(num_terms, len(row))):
+                token = token_dictionary.get_token_from_embedding_index(row[i][0])
+                print(" %s : %f" % (token, row[i][1]))
+            count = count + 1
+            if count > max_rows:  # (the reference's own off-by-one: max_rows + 1 tokens are printed)
+                break
+
+
 class _Dataset:
     """The slice of the tf.data API the reference's trainer touches (train_cooccurence.py:165-166)."""
 

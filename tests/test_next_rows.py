@@ -29,6 +29,31 @@ def test_reader_decodes_reference_written_file():
         assert np.array_equal(np.array([g[2] for g in got], np.float32), cnt)  # bit-exact floats
 
 
+def test_cooccurrence_matrix_debug_consumer(capsys):
+    """CooccurrenceMatrix (wikipedia/cooccurrence_matrix.py:18-55): the whole file as {row: [(other, count)]} on the
+    reference-written fixture, and debug_print's output (partners by descending count, max_rows + 1 tokens as there)."""
+    from esrecsys_amd.wikipedia.cooccurrence_matrix import CooccurrenceMatrix
+    idx, oth, cnt = _expected()
+    m = CooccurrenceMatrix(FIXTURE)
+    want = {}
+    for i, j, c in zip(idx.tolist(), oth.tolist(), cnt.tolist()):
+        want.setdefault(i, []).append((j, c))
+    assert m.rows() == want
+
+    class Names:
+        def get_token_from_embedding_index(self, k):
+            return "tok%d" % k
+    m.debug_print(1, Names(), 2)
+    lines = capsys.readouterr().out.strip().splitlines()
+    keys = list(want)[:2]
+    exp = []
+    for k in keys:
+        exp.append("Token [tok%d]" % k)
+        for j, c in sorted(want[k], key=lambda x: x[1], reverse=True)[:2]:
+            exp.append(" tok%d : %f" % (j, c))
+    assert lines == exp
+
+
 def test_known_wire_bytes():
     """The serialisation of CooccurrenceRow{index=300, other=[1,128,70000], count=[.5,1.25,3]} produced by the
     reference's generated class in the build container, plus the unpacked (proto2-style) encoding."""
