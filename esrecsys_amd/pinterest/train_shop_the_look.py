@@ -270,11 +270,12 @@ def train_step(state, scene, pos_product, neg_product, regularization, batch_siz
 
 class _Group:
     """A group of batches whose id lists were sorted and planned together (``_FusedTripletLoop.sort_batch``)."""
-    __slots__ = ("nb", "B", "ptrs", "sorted_ptr", "perm_ptr", "plans_ptr", "which", "gen", "keep")
+    __slots__ = ("nb", "B", "ptrs", "sorted_ptr", "perm_ptr", "plans_ptr", "which", "gen", "keep", "side")
 
-    def __init__(self, nb, B, ptrs, sorted_ptr, perm_ptr, plans_ptr, which, gen, keep):
+    def __init__(self, nb, B, ptrs, sorted_ptr, perm_ptr, plans_ptr, which, gen, keep, side=False):
         self.nb, self.B, self.ptrs, self.sorted_ptr, self.perm_ptr = nb, B, ptrs, sorted_ptr, perm_ptr
         self.plans_ptr, self.which, self.gen, self.keep = plans_ptr, which, gen, keep  # keep: the id tensors, alive
+        self.side = side  # sorted + planned on the second stream: the group's first step waits for its event
 
 
 class _FusedTripletLoop:
@@ -325,6 +326,7 @@ class _FusedTripletLoop:
         self.hints_known = [None, None]  # per set: list of long_runs values once the event has been seen complete
         self.group_ws, self.group_ws_B = None, -1  # esr_triplet_train_steps' workspace, sized for the group it steps
         self.gen = 0
+        self.allow_side = True  # (presorted()'s per-step calls keep sort + plan on the main stream: see _plan_on_side)
         if self.direct:
             self.fixed_s = (self.st.data_ptr(), None, None, self.acc_s.data_ptr(), self.Vs)
             self.fixed_p = (self.pt.data_ptr(), None, None, self.acc_p.data_ptr(), self.Vp)
@@ -423,7 +425,8 @@ class _FusedTripletLoop:
             ptrs[i], ptrs[i + 1], ptrs[i + 2] = g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr()
             i += 3
         stream, raw = self.main, self.main_raw
-        if _PLAN_ON_SIDE:
+        on_side = _plan_on_side(B) and self.allow_side
+        if on_side:
             # sort + plan of group g + 1 beside the steps of group g: the side stream waits for what the main stream held
             # when the group was drawn (the steps of group g - 1, whose buffers this set reuses; id copies), the main
             # stream waits for the plan before the group's first step (step_group)
@@ -442,11 +445,11 @@ class _FusedTripletLoop:
         # the whole group is stepped by ONE library call (esr_triplet_train_steps): at the reference's own batch sizes
         # (16 - 128 triplets: train_shop_the_look.py:60) a step is ~12 us of kernels, at 8192 it is 21 us -- less than
         # a 29-argument foreign call plus the Python around it
-        return _Group(nb, B, ptrs, srt.data_ptr(), prm.data_ptr(), plans.data_ptr(), which, self.gen, group)
+        return _Group(nb, B, ptrs, srt.data_ptr(), prm.data_ptr(), plans.data_ptr(), which, self.gen, group, on_side)
 
     def step_group(self, k, gr, regularization, batch_size):
         """Steps k .. k + gr.nb - 1: the batches of a sorted and planned group, issued by one library call."""
-        if _PLAN_ON_SIDE:
+        if gr.side:
             self.main.wait_event(self.hints_event[gr.which])
         known = self.hints_known[gr.which]
         if known is None:
@@ -523,7 +526,7 @@ class PlannedTriplets:
                                "(step the batches of presorted() in the order it yields them)")
         k = ctx.next_loss_slot()
         n = 3 * gr.B
-        if _PLAN_ON_SIDE and j == 0:  # (the group's sort + plan ran on the second stream: its first step waits for them)
+        if gr.side and j == 0:  # (the group's sort + plan ran on the second stream: its first step waits for them)
             ctx.main.wait_event(ctx.hints_event[gr.which])
         known = ctx.hints_known[gr.which]
         if known is None:
@@ -565,6 +568,7 @@ def presorted(state, batches):
         yield from it
         return
     ctx = _FusedTripletLoop(state, 4096, 0)
+    ctx.allow_side = _PLAN_STREAM == "side"
     ctx.group_of = [None, None]
     ctx.loss_k = -1
 
@@ -626,7 +630,18 @@ _LOOP_DEPTH = max(0, int(_os.environ.get("ESR_STL_PRESORT_DEPTH", "0")))
 _SORT_BATCH = min(8, max(1, int(_os.environ.get("ESR_STL_SORT_BATCH", "8"))))
 _SORT_BATCH_MAX_IDS = int(_os.environ.get("ESR_STL_SORT_BATCH_MAX_IDS", str(1 << 20)))
 # ESR_STL_PLAN_STREAM=side: the sort + plan of a group on the second stream, beside the steps of the group before it
-_PLAN_ON_SIDE = _os.environ.get("ESR_STL_PLAN_STREAM", "main") == "side"
+# Default "auto" (round 5): on the second stream for groups of 4096 .. 131072 triplets stepped by train_steps' group calls --
+# same box, alternating runs: B = 8192 333 -> 365 M triplets/s (the 41 us of sort + plan per group leave the steps'
+# stream), B = 65536 556 -> 574 M; at B = 2048 the cross-stream hand-over costs more than the 10 us it hides (132 -> 111 M),
+# at B = 262144 the sort steals bandwidth from the HBM-bound step kernel (555 -> 540 M), and the per-step calls of
+# presorted() pay an event wait per group for nothing (296 -> 272 M): those stay on the main stream.
+_PLAN_STREAM = _os.environ.get("ESR_STL_PLAN_STREAM", "auto")
+
+
+def _plan_on_side(B):
+    if _PLAN_STREAM == "auto":
+        return 4096 <= B <= 131072
+    return _PLAN_STREAM == "side"
 # ESR_STL_HINT_WAIT=0: a group whose long-run hints have not reached the host is stepped without them (A/B knob)
 _HINT_WAIT = _os.environ.get("ESR_STL_HINT_WAIT", "1") == "1"
 
