@@ -848,9 +848,10 @@ def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True
         hbm["saturating_launch"] = saturating_gather_scatter(dev, min(V, 4_000_000), D)  # own table + accumulator
     if roofline is not None:
         # HBM bytes per step from the committed --pmc passes: only for the exact (workload, batch, path) they were taken on
-        tkey = "%s|B=%d" % (workload, B) + ("|%s" % (path or "f32") if workload == "inbatch" else "")
-        plain = cfg.get("ids", "uniform") == "uniform" and cfg.get("table_dtype", "f32") == "f32" and \
-            V == WORKLOADS[workload]["V"] and D == WORKLOADS[workload]["D"]
+        bf16t = cfg.get("table_dtype", "f32") == "bf16"
+        tkey = "%s|B=%d" % (workload, B) + ("|%s" % (path or "f32") if workload == "inbatch" else "") + \
+            ("|bf16_tables" if bf16t else "")
+        plain = cfg.get("ids", "uniform") == "uniform" and V == WORKLOADS[workload]["V"] and D == WORKLOADS[workload]["D"]
         roofline["traffic"] = pmc_traffic(tkey) if plain else None
         roofline["traffic_source"] = ("profiles/pmc_traffic.json[%r] (rocprofv3 --pmc passes of this workload and batch, "
                                       "committed; not collected in this run)" % tkey) if roofline["traffic"] else None
