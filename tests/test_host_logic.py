@@ -71,14 +71,23 @@ def test_flag_defaults_match_the_reference():
 
 
 def test_inbatch_split_path_resolution(monkeypatch):
-    """which MFMA path a precision string selects (host logic only): the two-plane fp16 path needs fp32 rows, D = 128,
-    B % 128 == 0 and B <= 16384; bf16 tables and larger batches fall to the three-plane bf16 path; other shapes to f32"""
+    """which MFMA path a precision string selects (host logic only): the fp16 path needs D <= 128, B % 128 == 0 and
+    B <= 16384 (round 5: bf16 tables take it too -- its one-plane kernels; ESR_INBATCH_BF16_TABLES=bf16x3 keeps the older
+    path); larger batches fall to the three-plane bf16 path; other shapes to f32"""
     from esrecsys_amd import ops
     monkeypatch.delenv("ESR_INBATCH_AUTO", raising=False)
+    monkeypatch.delenv("ESR_INBATCH_BF16_TABLES", raising=False)
     assert ops.inbatch_split_path("auto", 8192, 128) == "f16x2"
     assert ops.inbatch_split_path("auto", 16384, 128) == "f16x2"
     assert ops.inbatch_split_path("auto", 16512, 128) == "bf16x3"
+    assert ops.inbatch_split_path("auto", 8192, 128, bf16_tables=True) == "f16x2"
+    assert ops.inbatch_split_path("auto", 16512, 128, bf16_tables=True) == "bf16x3"
+    monkeypatch.setenv("ESR_INBATCH_BF16_TABLES", "bf16x3")
     assert ops.inbatch_split_path("auto", 8192, 128, bf16_tables=True) == "bf16x3"
+    with pytest.raises(ValueError):
+        ops.inbatch_split_path("f16x2", 256, 128, bf16_tables=True)
+    monkeypatch.delenv("ESR_INBATCH_BF16_TABLES")
+    assert ops.inbatch_split_path("f16x2", 256, 128, bf16_tables=True) == "f16x2"
     assert ops.inbatch_split_path("auto", 8200, 128) is None
     # narrower rows ride in the 128-column tiles from D = 64 up; below (and for wider or odd widths) the exact-f32 kernel
     assert ops.inbatch_split_path("auto", 8192, 64) == "f16x2" and ops.inbatch_split_path("auto", 8192, 96) == "f16x2"
@@ -89,8 +98,6 @@ def test_inbatch_split_path_resolution(monkeypatch):
     assert ops.inbatch_split_path("bf16x3", 256, 128) == "bf16x3"
     with pytest.raises(ValueError):
         ops.inbatch_split_path("f16x2", 32768, 128)
-    with pytest.raises(ValueError):
-        ops.inbatch_split_path("f16x2", 256, 128, bf16_tables=True)
     with pytest.raises(ValueError):
         ops.inbatch_split_path("bf16x3", 100, 128)
     with pytest.raises(ValueError):
