@@ -1167,6 +1167,7 @@ def main():
             if isinstance(v, dict) and "value" in v:
                 roof["legs"][key] = {"value": v["value"], "ms": v.get("ms"), "bound": v.get("bound"), "frac": v.get("frac"),
                                      **({"kernel_frac": v["kernel_frac"]} if v.get("kernel_frac") else {})}
+                out["secondary"][name] = {"see": "roofline.legs." + key}  # (one copy on the line: it stays under 6 KB)
     emit(out)
 
 
