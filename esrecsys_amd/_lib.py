@@ -254,6 +254,7 @@ PROBE_LIB_PATH = os.path.join(_HERE, "libesr_probe.so")
 PROBE_SIGNATURES = {
     "esr_probe_mfma": (c_int, [c_int, c_int, c_int, c_f32p, ctypes.POINTER(ctypes.c_double), c_vp]),
     "esr_probe_hbm_read": (c_int, [c_vp, c_i64, c_int, c_int, c_f32p, c_vp]),
+    "esr_probe_mfma_valu": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_f32p, c_vp]),
 }
 _probe = None
 

@@ -63,6 +63,14 @@ struct TraceScope {
     if (on) trace_pop();
   }
 };
+// A kernel whose VALU work runs beside MFMAs must not use the packed-f32 instructions (v_pk_fma_f32, v_pk_add_f32,
+// v_pk_mul_f32): they do not run beside the matrix pipe (scripts/mfma_valu_probe.py; esr_inbatch2h.hip pk_fma).  The
+// target attribute exists in the device compilation only.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ESR_NO_PK __attribute__((target("no-packed-fp32-ops")))
+#else
+#define ESR_NO_PK
+#endif
 #define ESR_KT(NAME, ST, ...)                                  \
   do {                                                         \
     if (esr::g_trace_on) esr::trace_push((NAME));              \

@@ -62,14 +62,20 @@ __device__ unsigned long long esr_ib2h_dbg[8192];
 #define H_TIMING_START() { tstart = __builtin_readcyclecounter(); rstart = __builtin_amdgcn_s_memrealtime(); }
 #define H_TIMING_ACC() { tacc0 += tk1 - tk0; tacc1 += tk2 - tk1; tacc2 += tk3 - tk2; }
 #define H_TIMING_WRITE(ON)                                                                  \
-  if (lane == 0 && blockIdx.x < 256 && (ON)) {                                              \
-    unsigned long long* d = esr_ib2h_dbg + ((blockIdx.x * 4 + w) * 4);                      \
+  if (lane == 0 && w < 4 && (blockIdx.x & 1) == 0 && blockIdx.x < 512 && (ON)) { /* every other workgroup */  \
+    unsigned long long* d = esr_ib2h_dbg + (((blockIdx.x >> 1) * 4 + w) * 4);               \
     d[0] = tacc0; d[1] = tacc1; d[2] = tacc2; d[3] = __builtin_readcyclecounter() - tstart; \
-    unsigned long long* e = esr_ib2h_dbg + 4096 + ((blockIdx.x * 4 + w) * 4);               \
+    unsigned long long* e = esr_ib2h_dbg + 4096 + (((blockIdx.x >> 1) * 4 + w) * 4);        \
     e[0] = rentry; e[1] = rstart; e[2] = __builtin_amdgcn_s_memrealtime(); e[3] = e[2];     \
+  }
+// (the one-plane kernel: realtime at the end of the sweep's last chunk and after the output stores)
+#define H_TIMING_MARK(SLOT, ON)                                                             \
+  if (lane == 0 && w < 4 && (blockIdx.x & 1) == 0 && blockIdx.x < 512 && (ON)) {            \
+    esr_ib2h_dbg[4096 + (((blockIdx.x >> 1) * 4 + w) * 4) + (SLOT)] = __builtin_amdgcn_s_memrealtime(); \
   }
 #else
 #define H_TICK(VAR)
+#define H_TIMING_MARK(SLOT, ON)
 #define H_TIMING_DECL()
 #define H_TIMING_START()
 #define H_TIMING_ACC()
@@ -96,19 +102,66 @@ __device__ __forceinline__ float resid_hi(float x, f16x2 pk) {
   asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(x));
   return r;
 }
-// packed f32 arithmetic on register pairs (the compiler scalarises the vector form when the pair is not already adjacent)
+// Arithmetic on register pairs WITHOUT the packed-f32 instructions.  scripts/mfma_valu_probe.py (round 5): behind every
+// MFMA four v_fma_f32 / v_fma_mix_f32 / v_max3_f32 are almost free with two waves per SIMD (a round of four MFMAs 217 ->
+// 224 cycles), four v_pk_fma_f32 or v_pk_add_f32 nearly double it (396): the packed pair does not run beside the matrix
+// pipe, its two scalar halves do.  These kernels' VALU work is written with scalar instructions, and ESR_NO_PK keeps the
+// compiler from pairing them up again.
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
-  f32x2 r;
-  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
+  float r0, r1;
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r0) : "v"(a[0]), "v"(b[0]), "v"(c[0]));
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r1) : "v"(a[1]), "v"(b[1]), "v"(c[1]));
+  return f32x2{r0, r1};
 }
 // (the leading s_nop: the operands are usually fresh v_exp_f32 results, and a VALU instruction that reads a transcendental's
 // result needs one wait state in front of it -- hipcc inserts it for its own instructions, not for inline assembly.  The
-// one-plane kernel's schedule put this add right behind the second v_exp_f32: every row's normaliser was garbage.)
+// one-plane kernel's first schedule put this add right behind the second v_exp_f32: every row's normaliser was garbage.)
 __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
-  f32x2 r;
-  asm("s_nop 0\n\tv_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  float r0, r1;
+  asm("s_nop 0\n\tv_add_f32 %0, %2, %4\n\tv_add_f32 %1, %3, %5"
+      : "=&v"(r0), "=&v"(r1)
+      : "v"(a[0]), "v"(a[1]), "v"(b[0]), "v"(b[1]));
+  return f32x2{r0, r1};
+}
+__device__ __forceinline__ float fma_s(float a, float b, float c) {
+  float r;
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
+}
+// la += e0, lb += e1, m = max(m, e0, e1) for two fresh v_exp_f32 results (the wait state: see pk_add)
+__device__ __forceinline__ void sum_max(float& la, float& lb, float& m, float e0, float e1) {
+  asm("s_nop 0\n\tv_add_f32 %0, %0, %3\n\tv_add_f32 %1, %1, %4\n\tv_max3_f32 %2, %2, %3, %4"
+      : "+v"(la), "+v"(lb), "+v"(m)
+      : "v"(e0), "v"(e1));
+}
+
+// A wave's 32 x 128 fp32 output tile (acc[db][4 q + e] = O[row j][32 db + 8 q + 4 h + e]: the MFMA's layout) to global
+// rows of stride k3D THROUGH LDS.  Stored straight from the accumulators every instruction touches 32 rows with 32
+// contiguous bytes each; the one-plane kernel spent ~14 us of its 55 between its last MFMA and its end on the 33 MB of
+// partial rows that way (scripts/gpu_ib1h_timing.sh).  Here the tile crosses a wave-private 8.5 KB of LDS in two halves
+// of 64 columns (rows padded to 272 B: the eight lanes a ds_write_b128 serves per cycle then fall on 32 different
+// banks) and leaves as 256-byte row segments, four rows per instruction.  The caller has made sure (a workgroup
+// barrier) that nobody still reads what `wave_lds` overlays.
+constexpr int kTileLdsBytes = 32 * 272;
+template <class ACC>
+__device__ __forceinline__ void store_tile_via_lds(char* wave_lds, const ACC& acc, float* __restrict__ tile_base, int lane) {
+  const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int dbl = 0; dbl < 2; ++dbl)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(wave_lds + j * 272 + (32 * dbl + 8 * q + 4 * h) * 4) =
+            make_float4(acc[2 * half + dbl][4 * q], acc[2 * half + dbl][4 * q + 1], acc[2 * half + dbl][4 * q + 2],
+                        acc[2 * half + dbl][4 * q + 3]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = 4 * i + (lane >> 4), piece = lane & 15;
+      const float4 v = *reinterpret_cast<const float4*>(wave_lds + row * 272 + piece * 16);
+      *reinterpret_cast<float4*>(tile_base + (int64_t)row * k3D + 64 * half + piece * 4) = v;
+    }
+  }
 }
 
 // A fragment F (0..7: plane (F / 4 + 1) % 2 -- the order the O^T rows use them -- column block F % 4) of k-step G
@@ -722,7 +775,7 @@ __device__ __forceinline__ f16x8 lds_b128(uint32_t addr) {
 //      the merge launch (two dependent memory round trips and three atomics per slice at the tail of every workgroup;
 //      with cache-wide release / acquire fences instead of per-access scopes 186 us).  DESIGN_HISTORY.md.]
 template <int KIND>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void inbatch2h_q_kernel(const _Float16* __restrict__ Xr, const _Float16* __restrict__ Yr,
+__global__ ESR_NO_PK __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void inbatch2h_q_kernel(const _Float16* __restrict__ Xr, const _Float16* __restrict__ Yr,
                                                          int64_t B, int nsplit, float sl2_in,
                                                          const float* __restrict__ sc, const float* __restrict__ ref,
                                                          int nsplit_ref, const float* __restrict__ diag, int mode,
@@ -1020,7 +1073,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (DMA_ON) H_DMA_ADVANCE();                                                                          \
   }
 template <bool FIX>
-__global__ __launch_bounds__(256) void inbatch2h_q2_kernel(const _Float16* __restrict__ Xr, const _Float16* __restrict__ Yr,
+__global__ ESR_NO_PK __launch_bounds__(256) void inbatch2h_q2_kernel(const _Float16* __restrict__ Xr, const _Float16* __restrict__ Yr,
                                                           int64_t B, int nsplit, float sl2_in,
                                                           const float* __restrict__ sc, const float* __restrict__ diag,
                                                           int mode, int* __restrict__ flags, float* __restrict__ part_m,
@@ -1209,7 +1262,19 @@ __global__ __launch_bounds__(256) void inbatch2h_q2_kernel(const _Float16* __res
 //   CSIDE: owned = C rows, streamed = Q rows i; p = exp2(s sl2 - lse2_i + 14) with the row's final lse2_i (merge<Q>),
 //          DMA'd per chunk beside the plane tile; leaves part_O.
 // -----------------------------------------------------------------------------------------------------------------
-constexpr int kH1BufBytes = kPlaneBytes + 4 * 256;  // one plane tile + per-wave 256 B of streamed-row references
+// DMA offset of thread t of a 512-thread workgroup: plane K, one 16-byte piece of the 32 x 128 tile each
+template <int K>
+__device__ __forceinline__ uint32_t dmah8_off0(int64_t B, int64_t chunk, int t) {  // piece K = plane K, 512 threads
+  const int row = t >> 4, seg = (t & 15) ^ swz16(row);
+  return (uint32_t)((((int64_t)K * B + chunk * 32 + row) * k3D + seg * 8) * 2);
+}
+// One 512-thread workgroup owns 256 rows (32 per wave), one workgroup per CU: the two waves of a SIMD belong to the SAME
+// workgroup and meet at its barrier every chunk.  (As two 256-thread workgroups per CU nothing coupled the pair: the
+// stamps showed the older workgroup of every CU done 37 us into the kernel and the younger one 53 us in -- the issue
+// arbiter prefers the older wave, the younger runs its second half alone on its SIMD.)  The plane tile is fetched once
+// for eight waves: one LDS-DMA instruction per wave and chunk.
+constexpr int kH1Waves = 8, kH1Owned = 32 * kH1Waves;
+constexpr int kH1BufBytes = kPlaneBytes + kH1Waves * 256;  // one plane tile + per-wave 256 B of streamed-row references
 #define H1_DP(K, G, BUF) dmah_piece<K>(baseY, G, (BUF), w)
 #define H1_DMA_REF(BUF)                                                                                   \
   __builtin_amdgcn_global_load_lds((gptr_t)(ref + (c0 + dpos) * 32 + (lane & 31)),                        \
@@ -1218,9 +1283,9 @@ constexpr int kH1BufBytes = kPlaneBytes + 4 * 256;  // one plane tile + per-wave
   {                                                                                        \
     const uint32_t step_ = (dpos + 1 == nc) ? (uint32_t)(8192 - nc * 8192) : 8192u;        \
     dpos = (dpos + 1 == nc) ? 0 : dpos + 1;                                                \
-    g0 += step_; g1 += step_;                                                              \
+    g0 += step_;                                                                           \
   }
-#define H1_DMA_CHUNK(BUF) { if (!QSIDE) { H1_DMA_REF(BUF); } H1_DP(0, g0, BUF); H1_DP(1, g1, BUF); H1_DMA_ADVANCE(); }
+#define H1_DMA_CHUNK(BUF) { if (!QSIDE) { H1_DMA_REF(BUF); } H1_DP(0, g0, BUF); H1_DMA_ADVANCE(); }
 // the references of the chunk in BUF for this lane's 16 accumulator registers (streamed rows 8 m + 4 h + 0..3)
 // (assembly reads + one explicit wait: hipcc's own lgkmcnt bookkeeping does not count the assembly LDS reads of the S^T
 // phase that follow, and would let these four be consumed before they have returned)
@@ -1236,103 +1301,266 @@ constexpr int kH1BufBytes = kPlaneBytes + 4 * 256;  // one plane tile + per-wave
       rf[4 * m_ + 2] = kHPexp - lv_.z; rf[4 * m_ + 3] = kHPexp - lv_.w;                                   \
     }                                                                                                     \
   }
-#define H1_EXP_PAIR(S)                                                                                    \
+// (no packed-f32 instructions: see pk_fma)
+#define H1_EXP_PAIR(S, PN)                                                                                \
   {                                                                                                       \
-    const f32x2 arg_ = pk_fma(f32x2{p[2 * (S)], p[2 * (S) + 1]}, sl2v,                                    \
-                              QSIDE ? nrefv : f32x2{rf[2 * (S)], rf[2 * (S) + 1]});                        \
-    const float e0_ = __builtin_amdgcn_exp2f(arg_[0]), e1_ = __builtin_amdgcn_exp2f(arg_[1]);             \
+    const float a0_ = fma_s(p[2 * (S)], sl2, QSIDE ? nref1 : rf[2 * (S)]);                                \
+    const float a1_ = fma_s(p[2 * (S) + 1], sl2, QSIDE ? nref1 : rf[2 * (S) + 1]);                        \
+    const float e0_ = __builtin_amdgcn_exp2f(a0_), e1_ = __builtin_amdgcn_exp2f(a1_);                     \
     const f16x2 pa_ = pk_f16(e0_, e1_);                                                                   \
-    if (QSIDE) {                                                                                          \
-      l2 = pk_add(l2, f32x2{e0_, e1_});                                                                   \
-      emax = __builtin_fmaxf(emax, __builtin_fmaxf(e0_, e1_));                                            \
-    }                                                                                                     \
+    if (QSIDE) { sum_max(l2a, l2b, emax, e0_, e1_); }                                                     \
     const f16x2 pq_ = pk_f16(resid_lo(e0_, pa_), resid_hi(e1_, pa_));                                     \
-    pw[0][(S)] = __builtin_bit_cast(uint32_t, pa_);                                                       \
-    pw[1][(S)] = __builtin_bit_cast(uint32_t, pq_);                                                       \
+    PN[0][(S)] = __builtin_bit_cast(uint32_t, pa_);                                                       \
+    PN[1][(S)] = __builtin_bit_cast(uint32_t, pq_);                                                       \
   }
-// LDS operations return in order; before the MFMA of k-step s the outstanding ones are, oldest first: fragment s, the two
-// transposing reads a preceding EVEN k-step issued (VALU_ON), fragment s + 1 (s < 7): everything but fragment s stays
-// in flight
-#define H1_S_PHASE(NBUF, SA, VALU_ON)                                                                     \
+// The S^T phase: all eight A fragments of the chunk are requested at its top (32 registers; one plane leaves room for
+// them), then its eight MFMAs run back to back with NOTHING between them.  LDS operations return in order; before the
+// MFMA of k-step s the operations younger than fragment s are the 7 - s later fragments: they stay in flight.
+// (Round 5, measured with the phase stamps of scripts/gpu_ib1h_timing.sh: the first form of this kernel threaded the
+// exp / split of the previous chunk between these eight MFMAs like the two-plane kernel does between its 24 -- 1843 of an
+// iteration's 2727 cycles went by in this phase and 648 in the O^T phase with its 16 MFMAs.  Eight MFMAs are 256 pipe
+// cycles: no cover for ~130 VALU instructions.  The VALU work now rides in the O^T phase: H1_O_PHASE.)
+#define H1_S_PHASE(NBUF, SA)                                                                              \
   {                                                                                                       \
     _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) SA[r_] = 0.f;                                       \
     const uint32_t ap32_ = lds32 + (uint32_t)((NBUF) - lds) + (uint32_t)(j * 256);                        \
     const int sw_ = swz16(j);                                                                             \
-    f16x8 a1_ = lds_b128<0>(ap32_ + (uint32_t)((h ^ sw_) << 4));                                          \
+    f16x8 af_[8];                                                                                         \
+    _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_)                                                      \
+      af_[s_] = lds_b128<0>(ap32_ + (uint32_t)(((2 * s_ + h) ^ sw_) << 4));                               \
     _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) {                                                    \
-      f16x8 n1_ = a1_;                                                                                    \
-      if (s_ < 7) n1_ = lds_b128<0>(ap32_ + (uint32_t)(((2 * (s_ + 1) + h) ^ sw_) << 4));                 \
       H_SB();                                                                                             \
-      H_S_WAIT((s_ < 7 ? 1 : 0) + (((VALU_ON) && s_ >= 1 && ((s_ - 1) & 1) == 0) ? 2 : 0));               \
+      H_S_WAIT(7 - s_);                                                                                   \
       H_SB();                                                                                             \
-      SA = H_MFMA(a1_, bx[s_], SA);                                                                       \
+      SA = H_MFMA(af_[s_], bx[s_], SA);                                                                   \
       H_SB();                                                                                             \
-      if (VALU_ON) {                                                                                      \
-        if ((s_ & 1) == 0) trh_frag_n<0>(4 + (s_ >> 1), ta2_, trc_); /* the four G = 0 fragments of the O^T phase */ \
-        H1_EXP_PAIR(s_);                                                                                  \
-      }                                                                                                   \
-      H_SB();                                                                                             \
-      a1_ = n1_;                                                                                          \
     }                                                                                                     \
   }
-#define H1_O_ROW(PL_P, G)                                                                                 \
-  _Pragma("unroll") for (int db_ = 0; db_ < 4; ++db_)                                                     \
-    acc[db_] = H_MFMA(ta2_[G][db_][0], pb[PL_P][G], acc[db_]);
+#define H1_O_G0() { _Pragma("unroll") for (int f_ = 4; f_ < 8; ++f_) trh_frag_n<0>(f_, ta2_, trc_); }
 #define H1_O_G1(F0, F1) { _Pragma("unroll") for (int f_ = (F0); f_ < (F1); ++f_) trh_frag_n<1>(f_, ta2_, trc_); }
-#define H1_O_PHASE(DMA_ON, DBUF)                                                                          \
+#define H1_PB(PC)                                                                                         \
+  f16x8 pb[2][2];                                                                                         \
+  _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_)                                                        \
+    _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_) {                                                    \
+      const u32x4 u_ = {PC[q_][4 * g_], PC[q_][4 * g_ + 1], PC[q_][4 * g_ + 2], PC[q_][4 * g_ + 3]};      \
+      pb[q_][g_] = __builtin_bit_cast(f16x8, u_);                                                         \
+    }
+// one row of the O^T phase (four MFMAs, one per 32-column block of the owned rows' output) hosting the exp / split of two
+// pairs A = S0, B = S0 + 1 of the NEXT chunk's scores (EXP_ON), the two pairs' dependent chains interleaved and spread
+// behind all four MFMAs (the probe: a chain of dependent VALU instructions behind an MFMA costs what four times as many
+// independent ones do)
+#define H1_O_ROW(PL_P, G, S0, EXP_ON, PN)                                                                 \
   {                                                                                                       \
-    H_PB();                                                                                               \
-    H_TR_WAIT(); /* the G = 0 fragments were requested during the S^T phase (or by the burst of the last chunk) */ \
-    H_SB(); H1_O_ROW(1, 0); H_SB(); H1_O_G1(4, 6); if (DMA_ON) { H1_DP(0, g0, DBUF); }                    \
-    H_SB(); H1_O_ROW(0, 0); H_SB(); H1_O_G1(6, 8); if (DMA_ON) { H1_DP(1, g1, DBUF); if (!QSIDE) { H1_DMA_REF(DBUF); } } \
+    float aA0_ = 0.f, aA1_ = 0.f, aB0_ = 0.f, aB1_ = 0.f, eA0_ = 0.f, eA1_ = 0.f, eB0_ = 0.f, eB1_ = 0.f; \
+    float rA0_ = 0.f, rA1_ = 0.f;                                                                         \
+    f16x2 paA_ = {0, 0}, paB_ = {0, 0};                                                                   \
+    H_SB(); acc[0] = H_MFMA(ta2_[G][0][0], pb[PL_P][G], acc[0]); H_SB();                                  \
+    if (EXP_ON) {                                                                                         \
+      aA0_ = fma_s(p[2 * (S0)], sl2, QSIDE ? nref1 : rf[2 * (S0)]);                                       \
+      aA1_ = fma_s(p[2 * (S0) + 1], sl2, QSIDE ? nref1 : rf[2 * (S0) + 1]);                               \
+      aB0_ = fma_s(p[2 * (S0) + 2], sl2, QSIDE ? nref1 : rf[2 * (S0) + 2]);                               \
+      aB1_ = fma_s(p[2 * (S0) + 3], sl2, QSIDE ? nref1 : rf[2 * (S0) + 3]);                               \
+      eA0_ = __builtin_amdgcn_exp2f(aA0_); eA1_ = __builtin_amdgcn_exp2f(aA1_);                           \
+    }                                                                                                     \
+    H_SB(); acc[1] = H_MFMA(ta2_[G][1][0], pb[PL_P][G], acc[1]); H_SB();                                  \
+    if (EXP_ON) {                                                                                         \
+      eB0_ = __builtin_amdgcn_exp2f(aB0_); eB1_ = __builtin_amdgcn_exp2f(aB1_);                           \
+      if (QSIDE) { sum_max(l2a, l2b, emax, eA0_, eA1_); }                                                 \
+      paA_ = pk_f16(eA0_, eA1_);                                                                          \
+    }                                                                                                     \
+    H_SB(); acc[2] = H_MFMA(ta2_[G][2][0], pb[PL_P][G], acc[2]); H_SB();                                  \
+    if (EXP_ON) {                                                                                         \
+      if (QSIDE) { sum_max(l2a, l2b, emax, eB0_, eB1_); }                                                 \
+      paB_ = pk_f16(eB0_, eB1_);                                                                          \
+      rA0_ = resid_lo(eA0_, paA_); rA1_ = resid_hi(eA1_, paA_);                                           \
+    }                                                                                                     \
+    H_SB(); acc[3] = H_MFMA(ta2_[G][3][0], pb[PL_P][G], acc[3]); H_SB();                                  \
+    if (EXP_ON) {                                                                                         \
+      const f16x2 pqA_ = pk_f16(rA0_, rA1_);                                                              \
+      const f16x2 pqB_ = pk_f16(resid_lo(eB0_, paB_), resid_hi(eB1_, paB_));                              \
+      PN[0][(S0)] = __builtin_bit_cast(uint32_t, paA_); PN[1][(S0)] = __builtin_bit_cast(uint32_t, pqA_); \
+      PN[0][(S0) + 1] = __builtin_bit_cast(uint32_t, paB_); PN[1][(S0) + 1] = __builtin_bit_cast(uint32_t, pqB_); \
+    }                                                                                                     \
+    H_SB();                                                                                               \
+  }
+// O^T += Y_chunk^T P^T of the CURRENT chunk (its probabilities in PC, the G = 0 fragments requested before the S^T
+// phase) while the scores in p -- the NEXT chunk's -- become that chunk's probabilities in PN.  G1A / G1B: the requests
+// for the G = 1 fragments (first and second half).
+#define H1_O_PHASE_X(DMA_ON, DBUF, EXP_ON, PC, PN, G1A, G1B)                                              \
+  {                                                                                                       \
+    H1_PB(PC);                                                                                            \
     H_TR_WAIT();                                                                                          \
-    H_SB(); H1_O_ROW(1, 1); H_SB();                                                                       \
-    H_SB(); H1_O_ROW(0, 1); H_SB();                                                                       \
+    H1_O_ROW(1, 0, 0, EXP_ON, PN); G1A; if (DMA_ON) { H1_DP(0, g0, DBUF); }                               \
+    H1_O_ROW(0, 0, 2, EXP_ON, PN); G1B; if (DMA_ON) { if (!QSIDE) { H1_DMA_REF(DBUF); } }                 \
+    H_TR_WAIT();                                                                                          \
+    H1_O_ROW(1, 1, 4, EXP_ON, PN);                                                                        \
+    H1_O_ROW(0, 1, 6, EXP_ON, PN);                                                                        \
     if (DMA_ON) H1_DMA_ADVANCE();                                                                         \
   }
+#define H1_O_PHASE(DMA_ON, DBUF, EXP_ON, PC, PN) H1_O_PHASE_X(DMA_ON, DBUF, EXP_ON, PC, PN, H1_O_G1(4, 6), H1_O_G1(6, 8))
+// --- the same iteration with the ring slot a COMPILE-TIME constant (the steady loop is unrolled by the ring's four
+// slots): every LDS address of the iteration is then a per-lane base computed once before the loop plus an immediate
+// offset, and the probabilities alternate between two register sets instead of being copied.  (The loop with a run-time
+// slot spent 20 v_add_u32 and 33 v_mov_b32 per iteration on exactly that, beside the ~80 instructions of the exp / split
+// itself; scripts/mfma_valu_probe.py: with two waves per SIMD more than ~6.5 VALU instructions per MFMA are exposed.)
+template <int G, int DB, int SLOTOFF, class TA>
+__device__ __forceinline__ void trh1_frag(TA& ta, const uint32_t (&tb)[4][2]) {
+  constexpr int OFF = SLOTOFF + 16 * G * 256;
+  const s16x4 lo = tr_read<OFF>(tb[DB][0]), hi = tr_read<OFF>(tb[DB][1]);
+  const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  ta[G][DB][0] = __builtin_bit_cast(f16x8, both);
+}
+#define H1C_OFF(SLOT) ((SLOT) * kH1BufBytes)
+#define H1C_G0(SLOT)                                                                                      \
+  {                                                                                                       \
+    trh1_frag<0, 0, H1C_OFF(SLOT)>(ta2_, trb_); trh1_frag<0, 1, H1C_OFF(SLOT)>(ta2_, trb_);               \
+    trh1_frag<0, 2, H1C_OFF(SLOT)>(ta2_, trb_); trh1_frag<0, 3, H1C_OFF(SLOT)>(ta2_, trb_);               \
+  }
+#define H1C_G1A(SLOT) { trh1_frag<1, 0, H1C_OFF(SLOT)>(ta2_, trb_); trh1_frag<1, 1, H1C_OFF(SLOT)>(ta2_, trb_); }
+#define H1C_G1B(SLOT) { trh1_frag<1, 2, H1C_OFF(SLOT)>(ta2_, trb_); trh1_frag<1, 3, H1C_OFF(SLOT)>(ta2_, trb_); }
+#define H1C_LOAD_REFS(SLOT)                                                                               \
+  if (!QSIDE) {                                                                                           \
+    f16x8 raw_[4];                                                                                        \
+    raw_[0] = lds_b128<H1C_OFF(SLOT) + kPlaneBytes>(rbase);                                               \
+    raw_[1] = lds_b128<H1C_OFF(SLOT) + kPlaneBytes + 32>(rbase);                                          \
+    raw_[2] = lds_b128<H1C_OFF(SLOT) + kPlaneBytes + 64>(rbase);                                          \
+    raw_[3] = lds_b128<H1C_OFF(SLOT) + kPlaneBytes + 96>(rbase);                                          \
+    H_TR_WAIT();                                                                                          \
+    _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_) {                                                    \
+      const float4 lv_ = __builtin_bit_cast(float4, raw_[m_]);                                            \
+      rf[4 * m_] = kHPexp - lv_.x; rf[4 * m_ + 1] = kHPexp - lv_.y;                                       \
+      rf[4 * m_ + 2] = kHPexp - lv_.z; rf[4 * m_ + 3] = kHPexp - lv_.w;                                   \
+    }                                                                                                     \
+  }
+#if defined(H1_PROBE_NO_SLD)
+#define H1C_SLD(SLOT, S) bx[S]
+#else
+#define H1C_SLD(SLOT, S) lds_b128<H1C_OFF(SLOT)>(sbase[S])
+#endif
+#define H1C_S_PHASE(SLOT, SA)                                                                             \
+  {                                                                                                       \
+    _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) SA[r_] = 0.f;                                       \
+    f16x8 af_[8];                                                                                         \
+    _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) af_[s_] = H1C_SLD(SLOT, s_);                         \
+    _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) {                                                    \
+      H_SB();                                                                                             \
+      H_S_WAIT(7 - s_);                                                                                   \
+      H_SB();                                                                                             \
+      SA = H_MFMA(af_[s_], bx[s_], SA);                                                                   \
+      H_SB();                                                                                             \
+    }                                                                                                     \
+  }
+// iteration on chunk `it` in slot CUR (probabilities in PC) with chunk it + 3 requested into slot CUR + 3
+// (timing probes, results wrong: -DH1_PROBE_NO_DMA / NO_TR / NO_EXP / NO_SLD leave out the LDS-DMAs, the transposing
+// reads, the exp / split, the S^T phase's fragment reads: scripts/gpu_ib1h_probe.sh)
+#if defined(H1_PROBE_NO_DMA)
+#define H1C_DMA_ON false
+#else
+#define H1C_DMA_ON true
+#endif
+#if defined(H1_PROBE_NO_EXP)
+#define H1C_EXP_ON false
+#else
+#define H1C_EXP_ON true
+#endif
+#if defined(H1_PROBE_NO_TR)
+#define H1C_TR(X)
+#else
+#define H1C_TR(X) X
+#endif
+// WAIT_PARTIAL: the previous iteration requested a chunk (its LDS-DMAs may stay in flight across the barrier: the chunk
+// needed now is the one before it); DMA_RT: this iteration requests chunk it + 3 (both run-time, wave-uniform)
+#if defined(H1_PRIO) && H1_PRIO == 1   /* S^T phase (MFMAs only) above the O^T phase */
+#define H1_PRIO_S() __builtin_amdgcn_s_setprio(3)
+#define H1_PRIO_O() __builtin_amdgcn_s_setprio(0)
+#elif defined(H1_PRIO) && H1_PRIO == 2 /* the other way round */
+#define H1_PRIO_S() __builtin_amdgcn_s_setprio(0)
+#define H1_PRIO_O() __builtin_amdgcn_s_setprio(3)
+#else
+#define H1_PRIO_S()
+#define H1_PRIO_O()
+#endif
+#define H1C_ITER(CUR, PC, PN, WAIT_PARTIAL, DMA_RT)                                                       \
+  {                                                                                                       \
+    H_TICK(tk0);                                                                                          \
+    if (WAIT_PARTIAL) { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kDmaPerChunk) : "memory"); } \
+    else { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }                     \
+    H_TICK(tk1);                                                                                          \
+    H1C_TR(H1C_G0(CUR));                                                                                  \
+    H1C_LOAD_REFS(((CUR) + 1) & 3);                                                                       \
+    H1_PRIO_S();                                                                                          \
+    H1C_S_PHASE(((CUR) + 1) & 3, sa);                                                                     \
+    H1_PRIO_O();                                                                                          \
+    H_TICK(tk2);                                                                                          \
+    H1_TAKE_SCORES();                                                                                     \
+    H1_O_PHASE_X(H1C_DMA_ON && (DMA_RT), lds + H1C_OFF(((CUR) + 3) & 3), H1C_EXP_ON, PC, PN,              \
+                 H1C_TR(H1C_G1A(CUR)), H1C_TR(H1C_G1B(CUR)));                                             \
+    H_TICK(tk3);                                                                                          \
+    H_TIMING_ACC();                                                                                       \
+  }
 template <bool QSIDE, int DBG = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void inbatch1h_kernel(
+__global__ ESR_NO_PK __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void inbatch1h_kernel(
     const _Float16* __restrict__ Xr, const _Float16* __restrict__ Yr, int64_t B, int nsplit, float sl2_in,
     const float* __restrict__ sc, const float* __restrict__ diag, const float* __restrict__ ref, int mode,
     float* __restrict__ part_m, float* __restrict__ part_O, float* __restrict__ part_l) {
-  __shared__ __attribute__((aligned(16))) char lds[kHBufs * kH1BufBytes];
+  // A FOUR-slot ring, tiles fetched THREE chunks ahead: an iteration of this kernel is 24 MFMAs per wave (~1.8 us), about
+  // one LDS-DMA round trip under load.  The loop-top wait leaves the youngest chunk's DMAs in flight.
+  // Schedule of iteration `it` (chunk it = "current", its probabilities already in pw):
+  //   barrier | G = 0 fragments of chunk it, references of chunk it + 1 | S^T of chunk it + 1 (8 MFMAs, nothing else) |
+  //   O^T of chunk it (16 MFMAs) with the exp / split of chunk it + 1 between them -> pwn | pw = pwn
+  constexpr int kRing = 4;
+  constexpr int kDmaPerChunk = QSIDE ? 1 : 2;  // DMA instructions per wave and chunk (C side: + the references)
+  constexpr int kLdsBytes = kRing * kH1BufBytes > kH1Waves * kTileLdsBytes ? kRing * kH1BufBytes : kH1Waves * kTileLdsBytes;
+  __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];  // the ring; at the end the waves' output tiles
   int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   int j = lane & 31, h = lane >> 5;
   H_TR_SETUP();
   const uint32_t lds32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds;
   const int ob = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
-  const int64_t xrow = (int64_t)ob * k3Owned + w * 32 + j;
+  const int64_t wrow = (int64_t)ob * kH1Owned + w * 32;
+  const bool live = wrow < B;  // B is a multiple of 128: the last workgroup's upper four waves may own nothing
+  const int64_t xrow = (live ? wrow : 0) + j;  // (idle waves work on block 0's rows: valid addresses, results dropped)
   const int nc = (int)(B / k3Chunk) / nsplit;
   const int64_t c0 = (int64_t)split * nc;
   const float sl2 = sl2_in * sc[0];  // the planes carry 2^(eq + ec) S
   f32x16 acc[4];
-  f32x2 l2 = {0.f, 0.f};
+  float l2a = 0.f, l2b = 0.f;
   int dpos = 0;
   const char* const baseY = reinterpret_cast<const char*>(Yr);
-  uint32_t g0 = 0, g1 = 0;
+  uint32_t g0 = 0;
   f16x8 bx[8];
 #pragma unroll
   for (int s = 0; s < 8; ++s) bx[s] = *reinterpret_cast<const f16x8*>(Xr + xrow * k3D + 16 * s + 8 * h);
   f32x16 sa;
   float p[16], rf[16];
-  uint32_t pw[2][8];
+  uint32_t pw[2][8], pwn[2][8];
   f16x8 ta2_[2][4][2];
   float emax = 0.f, refv = -INFINITY;
-  const f32x2 sl2v = {sl2, sl2};
-  f32x2 nrefv = {0.f, 0.f};
+  H_TIMING_DECL();
+  float nref1 = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) rf[r] = 0.f;
-  auto sweep = [&](auto fix_tag) __attribute__((always_inline)) {
-    constexpr bool fix = decltype(fix_tag)::value;
+  // per-lane LDS bases of the constant-slot iterations (slot 0; the slot is an immediate offset there)
+  uint32_t sbase[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) sbase[s] = lds32 + (uint32_t)(j * 256) + (uint32_t)(((2 * s + h) ^ swz16(j)) << 4);
+  const uint32_t rbase = lds32 + (uint32_t)(w * 256 + 16 * h);
+  (void)rbase;
+#define H1_TAKE_SCORES() { _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) p[r_] = sa[r_]; }
+#define H1_ROTATE_P()                                                                          \
+  {                                                                                            \
+    _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_)                                           \
+      _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) pw[q_][s_] = pwn[q_][s_];               \
+  }
+  auto sweep = [&](const bool fix) __attribute__((always_inline)) {
 #pragma unroll
     for (int db = 0; db < 4; ++db)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[db][r] = 0.f;
-    l2 = f32x2{0.f, 0.f};
+    l2a = l2b = 0.f;
     dpos = 0;
-    g0 = dmah_off0<0>(B, c0, t);
-    g1 = dmah_off0<1>(B, c0, t);
+    g0 = dmah8_off0<0>(B, c0, t);
     emax = 0.f;
     refv = -INFINITY;
 #pragma unroll
@@ -1342,117 +1570,129 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int c = 0; c < nc; ++c) {
         H1_DMA_CHUNK(lds);
         H_DMA_BARRIER();
-        H1_S_PHASE(lds, sa, false);
+        H1_S_PHASE(lds, sa);
 #pragma unroll
         for (int r = 0; r < 16; ++r) m = fmaxf(m, sa[r] * sl2);
         __syncthreads();  // the next tile overwrites this one
       }
       refv = fmaxf(m, __shfl_xor(m, 32, 64)) - kHPexp;
     }
+    // the reference of the owned rows from their first chunk's scores (Q side), what merge<Q> adds back
+#define H1_FIRST_CHUNK_REF(DREF)                                                               \
+  if (QSIDE) {                                                                                 \
+    if (!fix) {                                                                                \
+      float m_ = (DREF);                                                                       \
+      _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) m_ = fmaxf(m_, sa[r_] * sl2);          \
+      refv = fmaxf(m_, __shfl_xor(m_, 32, 64)) - kHOptHead;                                    \
+    }                                                                                          \
+    if (h == 0 && live) part_m[(int64_t)split * B + xrow] = refv;                              \
+    nref1 = -refv;                                                                             \
+  }
     if (DBG == 1) {  // debugging aid: one chunk at a time, nothing pipelined
       const float dref0 = (QSIDE && !fix) ? diag[xrow] * sl2_in : -INFINITY;
       for (int c = 0; c < nc; ++c) {
         H1_DMA_CHUNK(lds);
         H_DMA_BARRIER();
-        H1_S_PHASE(lds, sa, false);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) p[r] = sa[r];
-        if (QSIDE && c == 0) {
-          if (!fix) {
-            float m = dref0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) m = fmaxf(m, sa[r] * sl2);
-            refv = fmaxf(m, __shfl_xor(m, 32, 64)) - kHOptHead;
-          }
-          if (h == 0) part_m[(int64_t)split * B + xrow] = refv;
-          nrefv = f32x2{-refv, -refv};
-        }
+        H1_S_PHASE(lds, sa);
+        H1_TAKE_SCORES();
+        if (c == 0) { H1_FIRST_CHUNK_REF(dref0); }
         H_TR_BASES(lds);
         H1_LOAD_REFS(lds);
+        H1_O_G0();
 #pragma unroll
-        for (int f = 4; f < 8; ++f) trh_frag_n<0>(f, ta2_, trc_);
-#pragma unroll
-        for (int s2 = 0; s2 < 8; ++s2) H1_EXP_PAIR(s2);
-        H1_O_PHASE(false, lds);
+        for (int s2 = 0; s2 < 8; ++s2) H1_EXP_PAIR(s2, pw);
+        H1_O_PHASE(false, lds, false, pw, pwn);
         __syncthreads();
       }
       return;
     }
     H1_DMA_CHUNK(lds);
     if (nc > 1) H1_DMA_CHUNK(lds + kH1BufBytes);
+    if (nc > 2) H1_DMA_CHUNK(lds + 2 * kH1BufBytes);
     const float dref = (QSIDE && !fix) ? diag[xrow] * sl2_in : -INFINITY;
     H_DMA_BARRIER();
-    H1_S_PHASE(lds, sa, false);
+    H1_S_PHASE(lds, sa);
+    H1_TAKE_SCORES();
+    H1_FIRST_CHUNK_REF(dref);
+    H1_LOAD_REFS(lds);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) p[r] = sa[r];
-    if (QSIDE) {
-      if (!fix) {
-        float m = dref;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) m = fmaxf(m, sa[r] * sl2);
-        refv = fmaxf(m, __shfl_xor(m, 32, 64)) - kHOptHead;
-      }
-      if (h == 0) part_m[(int64_t)split * B + xrow] = refv;  // what merge<Q> adds back
-      nrefv = f32x2{-refv, -refv};
+    for (int s2 = 0; s2 < 8; ++s2) H1_EXP_PAIR(s2, pw);  // chunk 0's probabilities, alone
+    int cur = 0, it = 0;
+    H_TIMING_START();
+    // steady state: chunk it + 3 is requested while chunk it is worked on -- four iterations, the ring's slots 0..3 in
+    // turn as compile-time constants (H1C_ITER), the probabilities alternating between pw and pwn
+    for (; it + 6 < nc; it += 4) {
+      H1C_ITER(0, pw, pwn, true, true);
+      H1C_ITER(1, pwn, pw, true, true);
+      H1C_ITER(2, pw, pwn, true, true);
+      H1C_ITER(3, pwn, pw, true, true);
     }
-    int cur = 0;
-    for (int it = 0; it + 2 < nc; ++it) {
-      const int nxt = cur == kHBufs - 1 ? 0 : cur + 1;
-      const int nn = nxt == kHBufs - 1 ? 0 : nxt + 1;
-      H_DMA_BARRIER();
+    H_TIMING_WRITE(QSIDE && !fix);
+    // the 3..6 chunks left (fewer when nc < 3), slot by run-time index (cur = it % 4 = 0 here; ~50 more VALU
+    // instructions per iteration on addresses and on moving pwn to pw)
+    for (; it + 3 < nc; ++it) {
+      const int nxt = (cur + 1) & (kRing - 1);
+      const int nn = (cur + 3) & (kRing - 1);  // held chunk it - 1: every wave left it at the barrier below
+      // chunk it + 1 has landed (everything but the youngest chunk's DMAs) and everyone is done with iteration it - 1
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kDmaPerChunk) : "memory");
       const char* buf = lds + cur * kH1BufBytes;
       const char* nbuf = lds + nxt * kH1BufBytes;
       char* dbuf = lds + nn * kH1BufBytes;
       H_TR_BASES(buf);
-      H1_LOAD_REFS(buf);
-      H1_S_PHASE(nbuf, sa, true);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) p[r] = sa[r];
-      H1_O_PHASE(true, dbuf);
+      H1_O_G0();
+      H1_LOAD_REFS(nbuf);
+      H1_S_PHASE(nbuf, sa);
+      H1_TAKE_SCORES();
+      H1_O_PHASE(true, dbuf, true, pw, pwn);
+      H1_ROTATE_P();
       cur = nxt;
     }
-    if (nc >= 2) {
-      const int nxt = cur == kHBufs - 1 ? 0 : cur + 1;
+    for (; it + 1 < nc; ++it) {  // the last tiles are on their way or here: nothing left to request
+      const int nxt = (cur + 1) & (kRing - 1);
       H_DMA_BARRIER();
       const char* buf = lds + cur * kH1BufBytes;
       const char* nbuf = lds + nxt * kH1BufBytes;
       H_TR_BASES(buf);
-      H1_LOAD_REFS(buf);
-      H1_S_PHASE(nbuf, sa, true);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) p[r] = sa[r];
-      H1_O_PHASE(false, lds);
+      H1_O_G0();
+      H1_LOAD_REFS(nbuf);
+      H1_S_PHASE(nbuf, sa);
+      H1_TAKE_SCORES();
+      H1_O_PHASE(false, lds, true, pw, pwn);
+      H1_ROTATE_P();
       cur = nxt;
     }
-    {  // last chunk: nothing left to prefetch; its exp / split alone
-      H_DMA_BARRIER();
+    {  // last chunk: its probabilities are in pw, nothing follows
       const char* buf = lds + cur * kH1BufBytes;
       H_TR_BASES(buf);
-      H1_LOAD_REFS(buf);
-#pragma unroll
-      for (int f = 4; f < 8; ++f) trh_frag_n<0>(f, ta2_, trc_);
-#pragma unroll
-      for (int s = 0; s < 8; ++s) H1_EXP_PAIR(s);
-      H1_O_PHASE(false, lds);
+      H1_O_G0();
+      H1_O_PHASE(false, lds, false, pw, pwn);
     }
+    H_TIMING_MARK(3, QSIDE && !fix);
   };
-  sweep(std::false_type{});
-  // (the barrier also ends the last chunk's LDS reads before a redo's first DMA overwrites the ring)
-  if (QSIDE && __syncthreads_or((mode == 2 || !(emax <= kHOverflow)) ? 1 : 0)) {
+  sweep(false);
+  if (QSIDE && __syncthreads_or((mode == 2 || (live && !(emax <= kHOverflow))) ? 1 : 0)) {
     asm volatile("" : "+v"(t), "+v"(lane), "+v"(j), "+v"(h));
-    sweep(std::true_type{});
+    sweep(true);
   }
+#if defined(H1_PROBE_NO_STORE)
+  if (mode == 77) part_O[xrow] = acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0];
+#elif defined(H1_PROBE_DIRECT_STORE)
   float* orow = part_O + ((int64_t)split * B + xrow) * k3D;
+  if (live)
 #pragma unroll
   for (int db = 0; db < 4; ++db)
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       *reinterpret_cast<float4*>(orow + 32 * db + 8 * q + 4 * h) =
           make_float4(acc[db][4 * q], acc[db][4 * q + 1], acc[db][4 * q + 2], acc[db][4 * q + 3]);
+#else
+  __syncthreads();  // the ring is free: every wave is past its last chunk
+  if (live) store_tile_via_lds(lds + w * kTileLdsBytes, acc, part_O + ((int64_t)split * B + wrow) * k3D, lane);
+#endif
   if (QSIDE) {
-    const float l = l2[0] + l2[1];
+    const float l = l2a + l2b;
     const float ltot = l + __shfl_xor(l, 32, 64);
-    if (h == 0) part_l[(int64_t)split * B + xrow] = ltot;
+    if (h == 0 && live) part_l[(int64_t)split * B + xrow] = ltot;
   }
 }
 
@@ -1488,11 +1728,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
 constexpr int kPc8Wave = 4096 + 256;  // without STAGE: three ring slots of 2 planes + 8 of these are 150 KB of the CU's 160
 constexpr int kPc8Owned = 256;
-template <int K>
-__device__ __forceinline__ uint32_t dmah8_off0(int64_t B, int64_t chunk, int t) {  // piece K = plane K, 512 threads
-  const int row = t >> 4, seg = (t & 15) ^ swz16(row);
-  return (uint32_t)((((int64_t)K * B + chunk * 32 + row) * k3D + seg * 8) * 2);
-}
 // STAGE (default): the P' tiles go through REGISTERS on their way to LDS -- four coalesced 16-byte loads per lane and
 // chunk issued three chunks ahead, written to a wave-private 4 KB LDS tile one chunk before use.  As LDS-DMAs into the
 // 3-slot ring they could only be one chunk ahead (the slot of chunk it + 1 is read during iteration it), every barrier
@@ -1501,7 +1736,7 @@ __device__ __forceinline__ uint32_t dmah8_off0(int64_t B, int64_t chunk, int t) 
 // planes and factors only, has four slots (fetched three chunks ahead) and its barrier waits vmcnt(7): everything the
 // previous iteration issued stays in flight across it.
 template <bool STAGE>
-__global__ __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __restrict__ Yr, int64_t B, int nsplit,
+__global__ ESR_NO_PK __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __restrict__ Yr, int64_t B, int nsplit,
                                                            const float* __restrict__ fac, int nc_q,
                                                            const float* __restrict__ Pmat,
                                                            float* __restrict__ part_O) {
@@ -1997,7 +2232,8 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // bf16 tables (both towers): the one-plane kernels (ESR_IB2H_BF16=two keeps two planes, whose second is all zero)
   const char* b16e = getenv("ESR_IB2H_BF16");
-  const bool one_plane = fused && Qs.bf16 && Cs.bf16 && !(b16e && b16e[0] == 't');
+  // (ESR_IB2H_BF16=force: timing probes run the one-plane kernels on any input -- values then lack the second plane)
+  const bool one_plane = fused && ((Qs.bf16 && Cs.bf16 && !(b16e && b16e[0] == 't')) || (b16e && b16e[0] == 'f'));
   const bool overlapped = fused && !one_plane && side != nullptr && side != st && inbatch_events(&ev_fork, &ev_join);
   if (fused) {
     static std::atomic<unsigned long long> call_seq{0};
@@ -2012,15 +2248,21 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
                               ws.diag, ws.nrm, ws.sc, ws.loss_acc, ws.flags, grid_q, overlapped ? ws.Qcopy : (float*)nullptr,
                               overlapped ? ws.Ccopy : (float*)nullptr));
     if (one_plane) {
-      // bf16 tables: one fp16 plane per operand, S^T recomputed by pass C -- six GEMMs, no stored probabilities
+      // bf16 tables: one fp16 plane per operand, S^T recomputed by pass C -- six GEMMs, no stored probabilities.
+      // 512-thread workgroups of 256 owned rows, one per CU
+      const int blocks1 = (int)cdiv(B, kH1Owned);
+      nsplit_q = 1;
+      for (int sp = 1; sp <= 8; ++sp)
+        if (nchunks % sp == 0 && blocks1 * sp <= 320) nsplit_q = sp;
+      grid_q = blocks1 * nsplit_q;
       const char* dbg1h = getenv("ESR_IB1H_DBG");
       if (dbg1h && dbg1h[0] == '1') {
-        hipLaunchKernelGGL((inbatch1h_kernel<true, 1>), dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Qh,
+        hipLaunchKernelGGL((inbatch1h_kernel<true, 1>), dim3(grid_q), dim3(512), 0, st, (const _Float16*)ws.Qh,
                            (const _Float16*)ws.Ch, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)ws.diag,
                            (const float*)nullptr, mode, ws.part_m, ws.part_O, ws.part_l);
       } else
       ESR_KT("inbatch1h_kernel_q", st,
-             hipLaunchKernelGGL((inbatch1h_kernel<true>), dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Qh,
+             hipLaunchKernelGGL((inbatch1h_kernel<true>), dim3(grid_q), dim3(512), 0, st, (const _Float16*)ws.Qh,
                                 (const _Float16*)ws.Ch, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)ws.diag,
                                 (const float*)nullptr, mode, ws.part_m, ws.part_O, ws.part_l));
       ESR_KT("inbatch3_merge_kernel_q", st,
@@ -2029,12 +2271,12 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
                                 regularization, inv_bs, ws.lse2, lse, gQ, ws.loss_acc, 1.0 / (double)batch_size, loss,
                                 (float*)nullptr, (const float*)(ws.sc + 1), ldexpf(1.f, (int)kHPexp), ws.fac));
       if (dbg1h && (dbg1h[0] == '1' || dbg1h[0] == '2')) {
-        hipLaunchKernelGGL((inbatch1h_kernel<false, 1>), dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Ch,
+        hipLaunchKernelGGL((inbatch1h_kernel<false, 1>), dim3(grid_q), dim3(512), 0, st, (const _Float16*)ws.Ch,
                            (const _Float16*)ws.Qh, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)nullptr,
                            (const float*)ws.lse2, mode, (float*)nullptr, ws.part_O, (float*)nullptr);
       } else
       ESR_KT("inbatch1h_kernel_c", st,
-             hipLaunchKernelGGL((inbatch1h_kernel<false>), dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Ch,
+             hipLaunchKernelGGL((inbatch1h_kernel<false>), dim3(grid_q), dim3(512), 0, st, (const _Float16*)ws.Ch,
                                 (const _Float16*)ws.Qh, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)nullptr,
                                 (const float*)ws.lse2, mode, (float*)nullptr, ws.part_O, (float*)nullptr));
       ESR_KT("inbatch3_merge_kernel_c", st,

@@ -272,7 +272,7 @@ __device__ unsigned long long esr_ib3_dbg[8192];
 // PMODE 1 (pass Q only): the unnormalised probabilities p_ij = exp2(s_ij sl2 - ref_i) are also written to
 // Pmat[i][j] (B x B f32) as they are formed, so that pass C need not recompute S^T (inbatch3_pc_kernel below).
 template <bool QSIDE, bool ONEP = false, int PMODE = 0>
-__global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict__ Xr, const __bf16* __restrict__ Yr,
+__global__ ESR_NO_PK __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict__ Xr, const __bf16* __restrict__ Yr,
                                                       const __bf16* __restrict__ Yt, int64_t B, int nsplit, float sl2,
                                                       const float* __restrict__ ref, float* __restrict__ part_O,
                                                       float* __restrict__ part_l, float* __restrict__ Pmat) {
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256) void inbatch3_kernel(const __bf16* __restrict_
 // chunk it and consumed after the next barrier, whose vmcnt(0) they share with the tile DMAs -- no extra drain.
 // `ref` = the normalisers 1 / l_i (they ride into LDS like the lse block of the recompute path).
 template <bool ONEP>
-__global__ __launch_bounds__(256) void inbatch3_pc_kernel(const __bf16* __restrict__ Yr, const __bf16* __restrict__ Yt,
+__global__ ESR_NO_PK __launch_bounds__(256) void inbatch3_pc_kernel(const __bf16* __restrict__ Yr, const __bf16* __restrict__ Yt,
                                                          int64_t B, int nsplit, const float* __restrict__ ref,
                                                          const float* __restrict__ Pmat, float* __restrict__ part_O) {
   constexpr bool QSIDE = false;

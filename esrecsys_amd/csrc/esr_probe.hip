@@ -102,6 +102,129 @@ __global__ __launch_bounds__(256) void mfma_f32_probe_kernel(int iters, float* _
   if (s == 12345.678f) sink[0] = s;
 }
 
+// Does the vector ALU run beside the matrix pipe?  Every wave: `iters` rounds of 4 MFMAs (v_mfma_f32_32x32x16_f16, four
+// independent chains), each followed by NV plain VALU instructions (v_fma_f32 on eight independent registers) and NT
+// transcendentals (v_exp_f32); GROUPED: the four MFMAs first, then the 4 (NV + NT) VALU instructions.  Per-wave cycles
+// of the loop go to cycles[global wave].  Launched with 256 or 512 threads per workgroup (one or two waves per SIMD).
+// (Round 5: the one-plane in-batch kernel spends as long in ~130 VALU instructions per chunk as in its 24 MFMAs, and the
+// probes that removed either shortened it by that part's full length.)
+template <int NV, int NT, bool GROUPED>
+__global__ __launch_bounds__(512) void mfma_valu_probe_kernel(int iters, unsigned long long* __restrict__ cycles,
+                                                              float* __restrict__ sink) {
+  f16x8 a[4], b[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const uint32_t ha = probe_hash((blockIdx.x * 512 + threadIdx.x) * 64 + q * 16 + e);
+      const uint32_t hb = probe_hash(ha + 0x9e3779b9u);
+      a[q][e] = (_Float16)((float)(int)(ha & 0xffff) * (1.0f / 32768.f) - 1.0f);
+      b[q][e] = (_Float16)((float)(int)(hb & 0xffff) * (1.0f / 32768.f) - 1.0f);
+    }
+  f32x16 c[4] = {};
+  float v[8], x[4];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 1.0f + 0.01f * (float)((threadIdx.x + e) & 15);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) x[e] = 0.001f * (float)((threadIdx.x + e) & 15);
+  const float m = 0.999f, d = 0.001f;
+#define PROBE_VALU(Q)                                                                                      \
+  {                                                                                                        \
+    _Pragma("unroll") for (int n_ = 0; n_ < NV; ++n_)                                                      \
+      asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[((Q) * NV + n_) & 7]) : "v"(m), "v"(d));            \
+    _Pragma("unroll") for (int n_ = 0; n_ < NT; ++n_)                                                      \
+      asm volatile("v_exp_f32 %0, %0" : "+v"(x[((Q) * NT + n_) & 3]));                                     \
+  }
+  __builtin_amdgcn_s_barrier();
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      __builtin_amdgcn_sched_barrier(0);
+      c[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[q], b[(q + 1) & 3], c[q], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!GROUPED) PROBE_VALU(q);
+    }
+    if (GROUPED) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) PROBE_VALU(q);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+#undef PROBE_VALU
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s += c[0][e] + c[1][e] + c[2][e] + c[3][e];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s += v[e];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) s += x[e];
+  if (s == 12345.678f) sink[0] = s;
+  if ((threadIdx.x & 63) == 0) cycles[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+}
+
+// The same question per instruction KIND (four of them behind every MFMA, independent registers unless noted):
+//   0 v_fma_f32   1 v_pk_fma_f32   2 v_fma_mix_f32   3 v_cvt_pk_f16_f32   4 v_max3_f32   5 v_pk_add_f32   6 v_exp_f32
+//   7 v_fma_f32, all four on ONE register (a dependent chain)   8 v_pk_fma_f32 dependent chain   9 v_exp_f32 -> v_fma_f32 chains
+template <int KIND>
+__global__ __launch_bounds__(512) void mfma_kind_probe_kernel(int iters, unsigned long long* __restrict__ cycles,
+                                                              float* __restrict__ sink) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f16x8 a[4], b[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const uint32_t ha = probe_hash((blockIdx.x * 512 + threadIdx.x) * 64 + q * 16 + e);
+      const uint32_t hb = probe_hash(ha + 0x9e3779b9u);
+      a[q][e] = (_Float16)((float)(int)(ha & 0xffff) * (1.0f / 32768.f) - 1.0f);
+      b[q][e] = (_Float16)((float)(int)(hb & 0xffff) * (1.0f / 32768.f) - 1.0f);
+    }
+  f32x16 c[4] = {};
+  f32x2 v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = f32x2{1.0f + 0.01f * (float)((threadIdx.x + e) & 15), 0.5f};
+  const f32x2 m = {0.999f, 0.999f}, d = {0.001f, 0.001f};
+  uint32_t hsink = 0;
+  __builtin_amdgcn_s_barrier();
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      __builtin_amdgcn_sched_barrier(0);
+      c[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[q], b[(q + 1) & 3], c[q], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        f32x2& r = v[(q * 4 + n) & 7];
+        if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r[0]) : "v"(m[0]), "v"(d[0]));
+        if (KIND == 1) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(r) : "v"(m), "v"(d));
+        if (KIND == 2) asm volatile("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(r[0]) : "v"(hsink));
+        if (KIND == 3) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hsink) : "v"(r[0]), "v"(r[1]));
+        if (KIND == 4) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(r[0]) : "v"(m[0]), "v"(d[0]));
+        if (KIND == 5) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(r) : "v"(d));
+        if (KIND == 6) asm volatile("v_exp_f32 %0, %0" : "+v"(r[0]));
+        if (KIND == 7) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[0][0]) : "v"(m[0]), "v"(d[0]));
+        if (KIND == 8) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(v[0]) : "v"(m), "v"(d));
+        if (KIND == 9) {
+          if (n & 1) asm volatile("s_nop 0\n\tv_fma_f32 %0, %0, %1, %2" : "+v"(v[q & 1][0]) : "v"(m[0]), "v"(d[0]));
+          else asm volatile("v_exp_f32 %0, %0" : "+v"(v[q & 1][0]));
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  float s = (float)hsink;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s += c[0][e] + c[1][e] + c[2][e] + c[3][e];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s += v[e][0] + v[e][1];
+  if (s == 12345.678f) sink[0] = s;
+  if ((threadIdx.x & 63) == 0) cycles[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+}
+
 // Pure-read HBM bandwidth: every workgroup streams its own contiguous slice with `UNROLL` 16-byte loads in flight per
 // lane (nt = streaming loads).  What a read-only kernel can reach on this box (pass C of the fp16 in-batch path reads the
 // B x B probabilities at 3.8 TB/s).
@@ -161,6 +284,33 @@ int esr_probe_hbm_read(const void* x, int64_t bytes, int workgroups, int nontemp
     hipLaunchKernelGGL((hbm_read_probe_kernel<8, false>), dim3(workgroups), dim3(256), 0, as_stream(stream),
                        (const pf4*)x, n16, sink);
   return check_launch("esr_probe_hbm_read");
+}
+
+int esr_probe_mfma_valu(int nv, int nt, int grouped, int waves_per_simd, int workgroups, int iters,
+                        unsigned long long* cycles, float* sink, esr_stream_t stream) {
+  ESR_REQUIRE(workgroups > 0 && iters > 0 && cycles && sink && (waves_per_simd == 1 || waves_per_simd == 2),
+              "esr_probe_mfma_valu: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(workgroups), block(256 * waves_per_simd);
+#define PROBE_CASE(NV, NT)                                                                                   \
+  if (nv == NV && nt == NT) {                                                                                \
+    if (grouped) mfma_valu_probe_kernel<NV, NT, true><<<grid, block, 0, st>>>(iters, cycles, sink);          \
+    else mfma_valu_probe_kernel<NV, NT, false><<<grid, block, 0, st>>>(iters, cycles, sink);                 \
+    return check_launch("esr_probe_mfma_valu");                                                              \
+  }
+  PROBE_CASE(0, 0) PROBE_CASE(1, 0) PROBE_CASE(2, 0) PROBE_CASE(4, 0) PROBE_CASE(6, 0) PROBE_CASE(7, 0)
+  PROBE_CASE(8, 0) PROBE_CASE(12, 0) PROBE_CASE(0, 1) PROBE_CASE(0, 2) PROBE_CASE(4, 1) PROBE_CASE(3, 1)
+#undef PROBE_CASE
+#define PROBE_KIND(K)                                                                                        \
+  if (nv == -1 && nt == K) {                                                                                 \
+    mfma_kind_probe_kernel<K><<<grid, block, 0, st>>>(iters, cycles, sink);                                  \
+    return check_launch("esr_probe_mfma_valu");                                                              \
+  }
+  PROBE_KIND(0) PROBE_KIND(1) PROBE_KIND(2) PROBE_KIND(3) PROBE_KIND(4) PROBE_KIND(5) PROBE_KIND(6) PROBE_KIND(7)
+  PROBE_KIND(8) PROBE_KIND(9)
+#undef PROBE_KIND
+  ESR_REQUIRE(false, "esr_probe_mfma_valu: no instance for nv = %d, nt = %d", nv, nt);
+  return 0;
 }
 
 }  // extern "C"

@@ -27,6 +27,16 @@ int esr_probe_mfma(int dtype, int workgroups, int iters, float* sink, double* fl
  * bandwidth a kernel can reach on this box.  sink: one device float (never written). */
 int esr_probe_hbm_read(const void* x, int64_t bytes, int workgroups, int nontemporal, float* sink, esr_stream_t stream);
 
+/* Measurement probe: does the vector ALU run beside the matrix pipe?  `workgroups` workgroups of 4 * waves_per_simd waves
+ * (waves_per_simd 1 or 2) run `iters` rounds of four independent v_mfma_f32_32x32x16_f16, each followed by `nv` plain
+ * VALU instructions and `nt` v_exp_f32 (grouped != 0: the four MFMAs first, then all the VALU work).  cycles (device,
+ * one word per wave): shader-clock cycles of the loop.  Instances: (nv, nt) in {0,1,2,4,6,7,8,12} x {0}, (0,1), (0,2),
+ * (4,1), (3,1).  nv = -1: four instructions of ONE kind behind every MFMA, nt = the kind (0 v_fma_f32, 1 v_pk_fma_f32,
+ * 2 v_fma_mix_f32, 3 v_cvt_pk_f16_f32, 4 v_max3_f32, 5 v_pk_add_f32, 6 v_exp_f32, 7 / 8 a dependent chain of v_fma_f32 /
+ * v_pk_fma_f32, 9 v_exp_f32 -> v_fma_f32 chains). */
+int esr_probe_mfma_valu(int nv, int nt, int grouped, int waves_per_simd, int workgroups, int iters,
+                        unsigned long long* cycles, float* sink, esr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,10 +23,28 @@ torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 8192)()
 lib.esr_ib2h_debug_read(buf)
 e = np.array(buf[4096:], dtype=np.float64).reshape(1024, 4)
-a = np.array(buf[:4096], dtype=np.float64).reshape(256, 4, 4)
+a = np.array(buf[:4096], dtype=np.float64).reshape(1024, 4)
+keep = e[:, 0] > 0   # (slots of workgroups / waves that do not exist stay zero)
+e, a = e[keep], a[keep]
+print("%d waves stamped" % len(e))
 rt = e[:, 2] - e[:, 1]
 print("total per iteration %.0f cycles" % (a[..., 3].mean() / ITERS))
 print("per-iteration cycles: barrier %.0f  phase1 %.0f  phase2 %.0f  (sum %.0f); loop %.1f us at %.0f MHz; kernel entry->loop end %.1f..%.1f us"
       % (a[..., 0].mean() / ITERS, a[..., 1].mean() / ITERS, a[..., 2].mean() / ITERS, a[..., :3].sum(-1).mean() / ITERS,
          rt.mean() / 100, a[..., 3].mean() / (rt.mean() / 100), (e[:, 2] - e[:, 0].min()).min() / 100,
          (e[:, 2] - e[:, 0].min()).max() / 100))
+tail = e[:, 3] - e[:, 2]
+if tail.max() > 0:
+    print("loop end -> end of the sweep's last chunk: %.1f us (min %.1f, max %.1f); kernel entry -> that point %.1f..%.1f us"
+          % (tail.mean() / 100, tail.min() / 100, tail.max() / 100, (e[:, 3] - e[:, 0].min()).min() / 100,
+             (e[:, 3] - e[:, 0].min()).max() / 100))
+    print("kernel entry -> loop start: %.1f us (mean)" % ((e[:, 1] - e[:, 0]).mean() / 100))
+ent = e[:, 0]
+print("workgroup entry spread: %.1f us; by quarter of the grid (mean entry - first): %s" % (
+    (ent.max() - ent.min()) / 100, ["%.1f" % ((q.mean() - ent.min()) / 100) for q in np.array_split(ent, 4)]))
+end = e[:, 3] if tail.max() > 0 else e[:, 2]
+print("entry (us after the first): min %.1f  median %.1f  max %.1f;  end: min %.1f  median %.1f  max %.1f" % (
+    0.0, (np.median(ent) - ent.min()) / 100, (ent.max() - ent.min()) / 100, (end.min() - ent.min()) / 100,
+    (np.median(end) - ent.min()) / 100, (end.max() - ent.min()) / 100))
+h, edges = np.histogram((ent - ent.min()) / 100, bins=8)
+print("entry histogram (us):", [("%.0f-%.0f" % (edges[i], edges[i + 1]), int(h[i])) for i in range(8)])

@@ -43,7 +43,7 @@ def test_probe_library_is_separate_and_exports_its_header(lib):
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "esr_probe.h")).read(), flags=re.S)
     declared = sorted(set(re.findall(r"\b(esr_[a-z0-9_]+)\s*\(", text)))
     probe = _lib.load_probe()
-    assert declared == sorted(_lib.PROBE_SIGNATURES) == ["esr_probe_hbm_read", "esr_probe_mfma"]
+    assert declared == sorted(_lib.PROBE_SIGNATURES) == ["esr_probe_hbm_read", "esr_probe_mfma", "esr_probe_mfma_valu"]
     for name in declared:
         assert hasattr(probe, name) and name not in _lib.SIGNATURES
         with pytest.raises(AttributeError):

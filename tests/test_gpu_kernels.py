@@ -508,7 +508,14 @@ def test_inbatch_bf16_tables_on_one_fp16_plane(dev, B, hot, monkeypatch):
     monkeypatch.setenv("ESR_IB2H_BF16", "two")   # two planes per operand (the second all zero), stored probabilities
     two = ops.inbatch_towers_fwd_bwd(qt, ct, qi, ci, 8.0, 0.1, float(B), precision="f16x2")
     monkeypatch.delenv("ESR_IB2H_BF16")
-    assert torch.equal(out[0], two[0]) and torch.equal(out[1], two[1]) and torch.equal(out[2], two[2])
+    if hot:
+        # a workgroup whose optimistic exponent reference overflows redoes its rows against their exact maxima: the
+        # one-plane kernel's workgroups own 256 rows, the two-plane kernel's 128 -- other rows take the redo, whose
+        # probabilities are rounded on another grid
+        assert abs(float(out[0]) - float(two[0])) <= 1e-6 * abs(float(two[0]))
+        assert rel_err(N(out[1]), N(two[1])) <= 1e-6 and rel_err(N(out[2]), N(two[2])) <= 1e-6
+    else:
+        assert torch.equal(out[0], two[0]) and torch.equal(out[1], two[1]) and torch.equal(out[2], two[2])
     assert rel_err(N(out[3]), N(two[3])) <= 1e-6
     monkeypatch.setenv("ESR_IB2H_REF", "redo")   # every pass-Q workgroup redoes itself against its exact maximum
     redo = ops.inbatch_towers_fwd_bwd(qt, ct, qi, ci, 8.0, 0.1, float(B))
