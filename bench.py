@@ -844,8 +844,6 @@ def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True
         hbm["sparse_adagrad_GBps"] = adagrad_bytes / t / 1e9
     del state, batches, graphed
     torch.cuda.empty_cache()
-    if hbm and kernel_timing and saturating:
-        hbm["saturating_launch"] = saturating_gather_scatter(dev, min(V, 4_000_000), D)  # own table + accumulator
     if roofline is not None:
         # HBM bytes per step from the committed --pmc passes: only for the exact (workload, batch, path) they were taken on
         bf16t = cfg.get("table_dtype", "f32") == "bf16"
@@ -876,6 +874,17 @@ def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True
             dom = dominant_kernel_roofline(workload, path, per_kernel, B, D)
             if dom:
                 roofline["dominant_kernel"] = dom
+    if kernel_timing and saturating:
+        if per_kernel and "sparse_adagrad_GBps" not in hbm:
+            # the one-call train step has no gather / sparse-Adagrad launches of its own: the gather is folded into the
+            # split and merge kernels, the update is the segment_* kernels of the same launch sequence
+            upd = [k for k in per_kernel if k.startswith("segment_")]
+            if upd:
+                t = sum(per_kernel[k]["us"] * per_kernel[k]["launches_per_step"] for k in upd) * 1e-6
+                hbm["sparse_adagrad_GBps"] = adagrad_bytes / t / 1e9
+                hbm["sparse_adagrad_kernels"] = upd
+                hbm["gather"] = "folded into the op's first and merge kernels (no launch of its own)"
+        hbm["saturating_launch"] = saturating_gather_scatter(dev, min(V, 4_000_000), D)  # own table + accumulator
     return {
         "value": B * K / dt, "unit": cfg["unit"] + "s/s", "steps": K, "warmup": warmup, "ms_per_step": dt / K * 1e3,
         "config": {"workload": "%s: V=%d x D=%d %s tables, B=%d, sparse Adagrad"
@@ -1136,6 +1145,9 @@ def main():
                                       ("gather_GBps", "gather_frac_of_8TBps", "sparse_adagrad_GBps",
                                        "sparse_adagrad_frac_of_8TBps", "box_stream_read_GBps") if k in sat}
         roof["hbm_gather_scatter"]["rows_per_launch"] = sat.get("rows_per_launch", 0)
+        in_step = leg.get("hbm_gather_scatter") or {}
+        if "sparse_adagrad_GBps" in in_step:  # the same kernels inside one step (2 B rows: inside the launch ramp)
+            roof["hbm_gather_scatter"]["in_step_sparse_adagrad_GBps"] = _r(float(in_step["sparse_adagrad_GBps"]), 1)
     src = steady if steady is not None else leg
     roof["legs"] = {"steady_state": {"value": _r(float(src["value"]), 1), "ms": _r(src["ms_per_step"], 5),
                                      "steps": src["steps"], "warmup": src["warmup"],
