@@ -168,17 +168,18 @@ def pmc_traffic(key):
         return None
 
 
-def library_kernel_times(fn, reps):
-    """Average launch duration (us) of every kernel of libesr_hip.so during `reps` calls of fn(i), measured IN THIS RUN
-    by the library's own HIP events on the stream each kernel is launched on (esr_kernel_timing: one event pair around
-    every launch).  Returns {kernel: {"us": average, "launches_per_step": n}}."""
+def library_kernel_times(fn, reps, once=False):
+    """Average launch duration (us) of every kernel of libesr_hip.so during `reps` calls of fn(i) (once: ONE call fn(0)
+    that runs `reps` steps -- a loop helper), measured IN THIS RUN by the library's own HIP events on the stream each
+    kernel is launched on (esr_kernel_timing: one event pair around every launch).
+    Returns {kernel: {"us": average, "launches_per_step": n}}."""
     import ctypes
     from esrecsys_amd import _lib
     lib = _lib.load()
     torch.cuda.synchronize()
     lib.esr_kernel_timing(1)
     try:
-        for i in range(reps):
+        for i in range(1 if once else reps):
             fn(i)
         torch.cuda.synchronize()
         buf = ctypes.create_string_buffer(1 << 16)
@@ -863,12 +864,23 @@ def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True
             holder["s"], _ = run_step(workload, holder["s"], b2[8 + i], B)
         for i in range(8):
             holder["s"], _ = run_step(workload, holder["s"], b2[i], B)
-        per_kernel = library_kernel_times(_one, len(b2) - 8)
+        how = "per-step calls of the drop-in train_step"
+        if workload == "inbatch" and mode.startswith("eager, train_steps"):
+            # the loop the timed region ran (its steps know their id lists' long-run hints: other kernels than a lone
+            # train_step call launches)
+            from esrecsys_amd.pinterest.train_shop_the_look import train_steps as _ts
+            wb2 = [(b[0], b[1], None) for b in b2[8:]]
+
+            def _loop(_i):
+                holder["s"], _ = _ts(holder["s"], iter(wb2), len(wb2), LAM, B, scale=SCALE, precision=PRECISION)
+            per_kernel = library_kernel_times(_loop, len(wb2), once=True)
+            how = "the train_steps loop of the timed region"
+        else:
+            per_kernel = library_kernel_times(_one, len(b2) - 8)
         del st2, b2, holder
         torch.cuda.empty_cache()
         if roofline is not None:
-            roofline["per_kernel_in_run"] = {"source": "esr_kernel_timing: HIP events around every launch, this run, "
-                                                       "per-step calls of the drop-in train_step",
+            roofline["per_kernel_in_run"] = {"source": "esr_kernel_timing: HIP events around every launch, this run, " + how,
                                              "us": {k: v["us"] for k, v in per_kernel.items()},
                                              "launches_per_step": {k: v["launches_per_step"] for k, v in per_kernel.items()}}
             dom = dominant_kernel_roofline(workload, path, per_kernel, B, D)
@@ -879,6 +891,12 @@ def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True
             # the one-call train step has no gather / sparse-Adagrad launches of its own: the gather is folded into the
             # split and merge kernels, the update is the segment_* kernels of the same launch sequence
             upd = [k for k in per_kernel if k.startswith("segment_")]
+            if "inbatch_merge_update_kernel" in per_kernel:  # merges + update in one launch: its own bytes (part_O reads)
+                upd = []
+                t = per_kernel["inbatch_merge_update_kernel"]["us"] * 1e-6
+                mu_bytes = adagrad_bytes + rows * B * D * 4 * 9  # + 8 partial O rows and the partner row per occurrence
+                hbm["merge_update_GBps"] = mu_bytes / t / 1e9
+                hbm["merge_update_bytes"] = mu_bytes
             if upd:
                 t = sum(per_kernel[k]["us"] * per_kernel[k]["launches_per_step"] for k in upd) * 1e-6
                 hbm["sparse_adagrad_GBps"] = adagrad_bytes / t / 1e9

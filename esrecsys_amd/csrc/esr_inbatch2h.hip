@@ -2023,7 +2023,10 @@ __global__ ESR_NO_PK __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Flo
 // pass C on a second stream (inbatch2h_run, overlapped form).
 __global__ __launch_bounds__(256) void fac2h_kernel(int64_t B, int nsplit, const float* __restrict__ part_m,
                                                    const float* __restrict__ part_l, float invl_scale,
-                                                   float* __restrict__ fac) {
+                                                   float* __restrict__ fac, float* __restrict__ lse2 = nullptr,
+                                                   float* __restrict__ lse_nat = nullptr) {
+  // lse2 / lse_nat (the merging update's form of the step: no merge<Q> launch): the row's log-sum-exp in binary and
+  // natural units, as merge<Q> leaves them
   const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (row >= B) return;
   float pm[8], pl[8];
@@ -2042,12 +2045,17 @@ __global__ __launch_bounds__(256) void fac2h_kernel(int64_t B, int nsplit, const
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     wt[s] = pm[s] == M ? 1.f : __builtin_amdgcn_exp2f(pm[s] - M);
-    L = __fmaf_rn(pl[s], wt[s], L);  // (explicit, as in inbatch3_merge_kernel: the two kernels must round alike)
+    L = __fmaf_rn(pl[s], wt[s], L);  // (explicit, as in merge_row: the two must round alike)
   }
   const float invL1 = __fdiv_rn(1.0f, L);
 #pragma unroll
   for (int s = 0; s < 8; ++s)
     if (s < nsplit) fac[(int64_t)s * B + row] = __fmul_rn(__fmul_rn(invL1, invl_scale), wt[s]);
+  if (lse2) {
+    const float l2v = __fadd_rn(M, __builtin_amdgcn_logf(L));
+    lse2[row] = l2v;
+    if (lse_nat) lse_nat[row] = l2v * k3Ln2;
+  }
 }
 
 struct InbatchHWs {
@@ -2116,6 +2124,9 @@ struct InbatchUpdate {
 };
 
 // in esr_optim.hip
+int inbatch_merge_update(void* const* tables, float* const* accums, const int64_t* row_offsets, int dtype,
+                         const int32_t* sorted_vids, const int32_t* perm, const InbatchMergeArgs& a, float lr, float eps,
+                         hipStream_t st);
 int sparse_adagrad_range(void* const* tables, float* const* accums, const int64_t* row_offsets, int ntables, int dtype,
                          int D, const int32_t* sorted_vids, const int32_t* perm, int64_t n, float* grad_rows, float lr,
                          float eps, bool skip_long, hipStream_t st);
@@ -2235,6 +2246,27 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
   // (ESR_IB2H_BF16=force: timing probes run the one-plane kernels on any input -- values then lack the second plane)
   const bool one_plane = fused && ((Qs.bf16 && Cs.bf16 && !(b16e && b16e[0] == 't')) || (b16e && b16e[0] == 'f'));
   const bool overlapped = fused && !one_plane && side != nullptr && side != st && inbatch_events(&ev_fork, &ev_join);
+  // The merging update (round 5; ESR_IB2H_MERGE_UPDATE=0: off): a train step whose occurrence list has no run that
+  // outgrows its head chunk ends with ONE launch that merges the partial O rows of both passes on the fly and applies
+  // Adagrad (esr_optim.hip inbatch_merge_update_kernel) -- no merge launches, no gradient rows in memory; merge<Q>'s
+  // other products (lse, pass C's factors) come from fac2h_kernel.  Same bits as merge + update.
+  const char* mue = getenv("ESR_IB2H_MERGE_UPDATE");
+  const bool merge_upd = fused && !overlapped && upd != nullptr && upd->skip_long && D == k3D && Qs.ld == k3D &&
+                         Cs.ld == k3D && !(mue && mue[0] == '0');
+  auto merging_update = [&](int nsplit_of_c, const float* part_O_of_c) -> int {
+    InbatchMergeArgs a;
+    a.part_O[0] = ws.part_O; a.part_O[1] = part_O_of_c;
+    a.nsplit[0] = nsplit_q; a.nsplit[1] = nsplit_of_c;
+    a.oscale[0] = ws.sc + 1; a.oscale[1] = ws.sc + 2;
+    a.partner[0] = ws.Ccopy; a.partner[1] = ws.Qcopy;
+    a.part_m = ws.part_m; a.part_l = ws.part_l;
+    a.B = B;
+    a.scale = scale; a.lam = regularization; a.inv_bs = inv_bs;
+    a.loss_acc = ws.loss_acc; a.loss_scale = 1.0 / (double)batch_size; a.loss_out = loss;
+    a.zero_words = ws.ent; a.nzero = nchunks;
+    return inbatch_merge_update(upd->tables, upd->accums, upd->row_offsets, upd->dtype, upd->sorted_vids, upd->perm, a,
+                                upd->lr, upd->eps, st);
+  };
   if (fused) {
     static std::atomic<unsigned long long> call_seq{0};
     static const unsigned long long seed =
@@ -2245,8 +2277,8 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
     const unsigned long long token = ((z ^ (z >> 31)) >> 16) | 1ull;  // 48 bits, never 0
     ESR_KT("prepsplit2h_kernel", st,
            hipLaunchKernelGGL(prepsplit2h_kernel, dim3(nchunks), dim3(256), 0, st, Qs, Cs, B, ws.Qh, ws.Ch, ws.ent, token,
-                              ws.diag, ws.nrm, ws.sc, ws.loss_acc, ws.flags, grid_q, overlapped ? ws.Qcopy : (float*)nullptr,
-                              overlapped ? ws.Ccopy : (float*)nullptr));
+                              ws.diag, ws.nrm, ws.sc, ws.loss_acc, ws.flags, grid_q, (overlapped || merge_upd) ? ws.Qcopy : (float*)nullptr,
+                              (overlapped || merge_upd) ? ws.Ccopy : (float*)nullptr));
     if (one_plane) {
       // bf16 tables: one fp16 plane per operand, S^T recomputed by pass C -- six GEMMs, no stored probabilities.
       // 512-thread workgroups of 256 owned rows, one per CU
@@ -2265,20 +2297,28 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
              hipLaunchKernelGGL((inbatch1h_kernel<true>), dim3(grid_q), dim3(512), 0, st, (const _Float16*)ws.Qh,
                                 (const _Float16*)ws.Ch, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)ws.diag,
                                 (const float*)nullptr, mode, ws.part_m, ws.part_O, ws.part_l));
+      if (merge_upd) {
+        ESR_KT("fac2h_kernel", st,
+               hipLaunchKernelGGL(fac2h_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, B, nsplit_q,
+                                  (const float*)ws.part_m, (const float*)ws.part_l, ldexpf(1.f, (int)kHPexp), ws.fac,
+                                  ws.lse2, lse));
+      } else
       ESR_KT("inbatch3_merge_kernel_q", st,
              hipLaunchKernelGGL((inbatch3_merge_kernel<true>), dim3(mgrid), dim3(kBlock), 0, st, Qs, Cs, gq_rows, B,
                                 nsplit_q, (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale,
                                 regularization, inv_bs, ws.lse2, lse, gQ, ws.loss_acc, 1.0 / (double)batch_size, loss,
                                 (float*)nullptr, (const float*)(ws.sc + 1), ldexpf(1.f, (int)kHPexp), ws.fac));
+      float* const part_O_1c = merge_upd ? ws.part_O2 : ws.part_O;  // (the merging update still needs pass Q's rows)
       if (dbg1h && (dbg1h[0] == '1' || dbg1h[0] == '2')) {
         hipLaunchKernelGGL((inbatch1h_kernel<false, 1>), dim3(grid_q), dim3(512), 0, st, (const _Float16*)ws.Ch,
                            (const _Float16*)ws.Qh, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)nullptr,
-                           (const float*)ws.lse2, mode, (float*)nullptr, ws.part_O, (float*)nullptr);
+                           (const float*)ws.lse2, mode, (float*)nullptr, part_O_1c, (float*)nullptr);
       } else
       ESR_KT("inbatch1h_kernel_c", st,
              hipLaunchKernelGGL((inbatch1h_kernel<false>), dim3(grid_q), dim3(512), 0, st, (const _Float16*)ws.Ch,
                                 (const _Float16*)ws.Qh, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)nullptr,
-                                (const float*)ws.lse2, mode, (float*)nullptr, ws.part_O, (float*)nullptr));
+                                (const float*)ws.lse2, mode, (float*)nullptr, part_O_1c, (float*)nullptr));
+      if (merge_upd) return merging_update(nsplit_q, part_O_1c);
       ESR_KT("inbatch3_merge_kernel_c", st,
              hipLaunchKernelGGL((inbatch3_merge_kernel<false>), dim3(mgrid), dim3(kBlock), 0, st, Cs, Qs, gc_rows, B,
                                 nsplit_q, (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale,
@@ -2332,7 +2372,7 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
   }  // !fused
   // O_Q' = 2^ec sum p' c, l' = sum p': o / l needs 2^-ec (sc[1]); the stored factors carry pass C's 2^14
   hipStream_t st_q = overlapped ? side : st;
-  float* const part_O_c = overlapped ? ws.part_O2 : ws.part_O;
+  float* const part_O_c = (overlapped || merge_upd) ? ws.part_O2 : ws.part_O;
   // the rows the merges read: the towers themselves, or (overlapped) their gathered copies
   const RowSrc Qm = overlapped ? RowSrc{ws.Qcopy, nullptr, 0, Qs.ld} : Qs;
   const RowSrc Cm = overlapped ? RowSrc{ws.Ccopy, nullptr, 0, Cs.ld} : Cs;
@@ -2345,6 +2385,12 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
            hipLaunchKernelGGL(fac2h_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, B, nsplit_q,
                               (const float*)ws.part_m, (const float*)ws.part_l, ldexpf(1.f, (int)kHPexp), ws.fac));
   }
+  if (merge_upd) {
+    ESR_KT("fac2h_kernel", st,
+           hipLaunchKernelGGL(fac2h_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, B, nsplit_q,
+                              (const float*)ws.part_m, (const float*)ws.part_l, ldexpf(1.f, (int)kHPexp), ws.fac, ws.lse2,
+                              lse));
+  } else
   ESR_KT("inbatch3_merge_kernel_q", st_q,
          hipLaunchKernelGGL((inbatch3_merge_kernel<true>), dim3(mgrid), dim3(kBlock), 0, st_q, Qm, Cm, gq_rows, B, nsplit_q,
                             (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale,
@@ -2372,6 +2418,7 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
            hipLaunchKernelGGL((inbatch2h_pc8_kernel<true>), dim3(grid_c), dim3(512), 0, st, (const _Float16*)ws.Qh,
                               B, nsplit_c, (const float*)ws.fac, nchunks / nsplit_q, (const float*)ws.Pmat, part_O_c));
   }
+  if (merge_upd) return merging_update(nsplit_c, part_O_c);
   // O_C' = 2^(eq + 14) sum_i (p_ij / l_i) q_i
   ESR_KT("inbatch3_merge_kernel_c", st,
          hipLaunchKernelGGL((inbatch3_merge_kernel<false>), dim3(mgrid), dim3(kBlock), 0, st, Cm, Qm, gc_rows, B, nsplit_c,

@@ -132,6 +132,139 @@ typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 // ---------------------------------------------------------------------------------------------------
+// One owned row's merge: partial O rows of the splits -> gradient row, loss term, normaliser.  ONE definition with
+// explicit roundings for the merge launches and for the update kernel that merges on the fly
+// (esr_optim.hip inbatch_merge_update_kernel): the two produce the same bits.
+//   po / pm / pl: the splits' partial O quads (this lane's four columns), exponent references and normalisers (entries at
+//   s >= nsplit: 0 / -inf / 0);  x / y: the lane's quad of the owned row and of its partner row;  shared_ref: every split
+//   exponentiated against one reference (the bf16 x 3 path; weights 1).
+// Returns the gradient quad; row_loss, M, L, invL1 and the split weights wt[] come back by reference.
+// ---------------------------------------------------------------------------------------------------
+template <bool QSIDE>
+__device__ __forceinline__ float4 merge_row(const float4 (&po)[8], const float (&pm)[8], const float (&pl)[8], int nsplit,
+                                            bool shared_ref, float4 x, float4 y, float oscale, float scale, float lam,
+                                            float inv_bs, int G, float& row_loss, float& M, float& L, float& invL1,
+                                            float (&wt)[8]) {
+  M = 0.f;
+  L = 1.f;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) wt[s] = 1.f;
+  if (QSIDE) {  // fp16 x 2 path: split s used the fixed reference pm[s]; the row's is the largest of them
+    M = pm[0];
+    L = 0.f;
+#pragma unroll
+    for (int s = 1; s < 8; ++s) M = fmaxf(M, pm[s]);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      wt[s] = (shared_ref || pm[s] == M) ? 1.f : __builtin_amdgcn_exp2f(pm[s] - M);
+      L = __fmaf_rn(pl[s], wt[s], L);  // (fac2h_kernel must agree bit for bit)
+    }
+  }
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    if (s < nsplit) {
+      o.x = __fmaf_rn(po[s].x, wt[s], o.x); o.y = __fmaf_rn(po[s].y, wt[s], o.y);
+      o.z = __fmaf_rn(po[s].z, wt[s], o.z); o.w = __fmaf_rn(po[s].w, wt[s], o.w);
+    }
+  }
+  invL1 = __fdiv_rn(1.0f, L);
+  const float invL = __fmul_rn(invL1, oscale);  // (exact: oscale is a power of two)
+  const float xn2 =
+      group_sum(__fmaf_rn(x.w, x.w, __fmaf_rn(x.z, x.z, __fmaf_rn(x.y, x.y, __fmul_rn(x.x, x.x)))), G);
+  const float xnorm = __fsqrt_rn(xn2);
+  const float creg = xnorm > 1.f ? __fdiv_rn(lam, xnorm) : 0.f;
+  float4 g;
+  g.x = __fmul_rn(__fmaf_rn(scale, __fmaf_rn(o.x, invL, -y.x), __fmul_rn(creg, x.x)), inv_bs);
+  g.y = __fmul_rn(__fmaf_rn(scale, __fmaf_rn(o.y, invL, -y.y), __fmul_rn(creg, x.y)), inv_bs);
+  g.z = __fmul_rn(__fmaf_rn(scale, __fmaf_rn(o.z, invL, -y.z), __fmul_rn(creg, x.z)), inv_bs);
+  g.w = __fmul_rn(__fmaf_rn(scale, __fmaf_rn(o.w, invL, -y.w), __fmul_rn(creg, x.w)), inv_bs);
+  row_loss = __fmul_rn(lam, fmaxf(__fsub_rn(xnorm, 1.f), 0.f));
+  if (QSIDE) {
+    const float diag =
+        group_sum(__fmaf_rn(x.w, y.w, __fmaf_rn(x.z, y.z, __fmaf_rn(x.y, y.y, __fmul_rn(x.x, y.x)))), G);
+    const float l2v = __fadd_rn(M, __builtin_amdgcn_logf(L));
+    row_loss = __fadd_rn(row_loss, __fmaf_rn(l2v, k3Ln2, -__fmul_rn(scale, diag)));
+  }
+  return g;
+}
+// the loss term of one row in 2^-28 fixed point: integer sums of these do not depend on how rows are grouped into
+// workgroups or launches (the merge launches and the merging update kernel add up to the same word)
+__device__ __forceinline__ long long loss_fixed(float row_loss, bool& bad) {
+  if (!(fabsf(row_loss) < 16777216.0f)) {
+    bad = true;
+    return 0ll;
+  }
+  return __double2ll_rn((double)row_loss * 268435456.0);
+}
+// sum of one long long per thread over the workgroup (kBlock threads; smem: 4 words)
+__device__ __forceinline__ long long block_sum_ll(long long v, long long* smem) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int lo = __shfl_xor((int)(v & 0xffffffffll), o, 64), hi = __shfl_xor((int)(v >> 32), o, 64);
+    v += (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = v;
+  __syncthreads();
+  long long t = 0;
+  for (int w = 0; w < kBlock / 64; ++w) t += smem[w];
+  return t;
+}
+// One workgroup's loss sum (2^-28 fixed point; `bad`: some row's term was non-finite or out of range) into the counted
+// words of loss_acc; the last of `arrivals_per_word`-counted arrivals forwards and the very last writes the loss.
+// Integer addition is exact and order-free, so the sum is bit-reproducible, and the atomic's return value tells the
+// workgroup whether it was the last to arrive.  Two levels, because 2048 atomics on one address serialise (measured:
+// +15 us): kLossWords words 128 B apart take workgroups blockIdx % kLossWords; the last arrival of a word forwards that
+// word's total to the master word; the last arrival there writes the loss.  Data flows only through atomic return
+// values, so no ordering between addresses is needed.  The words were zeroed by the op's first launch.  (A ticket +
+// __threadfence() reduction of double partials was 7 us slower than a finalize launch: the agent-scope release writes
+// the XCD's L2 back.)  Range: |sum| < 2^24 = 1.6e7 nats (beyond it, or non-finite: NaN); resolution 3.7e-9 per row.
+// launches: how many launches of THIS grid add to the words (the two merge launches: 2; the merging update: 1).
+__device__ __forceinline__ void loss_arrive(long long tsum, bool bad, int launches, unsigned long long* loss_acc,
+                                            double loss_scale, float* loss_out) {
+  const unsigned wd = blockIdx.x % kLossWords;
+  const unsigned per_launch = (gridDim.x - wd + kLossWords - 1) / kLossWords;  // workgroups of one launch on word wd
+  const unsigned nwords = gridDim.x < (unsigned)kLossWords ? gridDim.x : (unsigned)kLossWords;
+  unsigned long long add = ((unsigned long long)tsum << 11);
+  if (bad || !(tsum < (1ll << 52) && tsum > -(1ll << 52))) {  // the loss must come out NaN, not a wrapped number
+    // raise the poison word BEFORE this workgroup is counted: the add below consumes the atomic's return value, so
+    // it cannot be issued until the OR has been performed (r is 0 or 1; r >> 1 is the dependence, not a value)
+    const unsigned r = atomicOr(reinterpret_cast<unsigned*>(loss_acc + 8), 1u);
+    add = (unsigned long long)(r >> 1);
+  }
+  const unsigned long long old = atomicAdd(loss_acc + 16 * (1 + wd), add + 1ull);
+  if ((unsigned)(old & 2047ull) == (unsigned)launches * per_launch - 1) {
+    const unsigned long long word_total = ((old + add) >> 11) << 11;  // this word's sum, count bits cleared
+    const unsigned long long m = atomicAdd(loss_acc, word_total + 1ull);
+    if ((unsigned)(m & 2047ull) == nwords - 1) {
+      const long long tot = ((long long)(m + word_total)) >> 11;  // arithmetic shift: signed sum
+      // every workgroup was counted before this branch was taken, hence after its OR (if any) was performed
+      const bool poisoned = atomicOr(reinterpret_cast<unsigned*>(loss_acc + 8), 0u) != 0u;
+      loss_out[0] = poisoned ? __builtin_nanf("") : (float)((double)tot * (1.0 / 268435456.0) * loss_scale);
+    }
+  }
+}
+
+// What the in-batch train step hands the MERGING update (esr_optim.hip inbatch_merge_update) instead of gradient rows:
+// side 0 = the query tower's occurrences (positions of the occurrence list below B), side 1 = the candidate tower's.
+struct InbatchMergeArgs {
+  const float* part_O[2];   // the side's partial O rows, [nsplit][B][128]
+  int nsplit[2];
+  const float* oscale[2];   // device: the power of two that undoes the planes' scaling of the side's partial rows
+  const float* partner[2];  // the OTHER tower's gathered rows as dense f32 [B][128]: copies taken before any update
+  const float* part_m;      // pass Q's exponent references and normalisers, [nsplit[0]][B]
+  const float* part_l;
+  int64_t B;
+  float scale, lam, inv_bs;
+  unsigned long long* loss_acc;
+  double loss_scale;
+  float* loss_out;
+  unsigned long long* zero_words;  // cleared for the next call (see inbatch3_merge_kernel)
+  int nzero;
+};
+
+// ---------------------------------------------------------------------------------------------------
 // merge: one 32-lane group per owned row
 // ---------------------------------------------------------------------------------------------------
 template <bool QSIDE>
@@ -149,7 +282,7 @@ __global__ __launch_bounds__(kBlock) void inbatch3_merge_kernel(
   // probabilities carry the reference of the split that wrote them
   // oscale_ptr (fp16 x 2 path): a power of two that undoes the plane scaling of the partial O rows (device-side: it
   // depends on the largest |element| of the batch); invl_scale: a power of two folded into the stored 1 / l_i
-  __shared__ double sm[4];
+  __shared__ long long sm[4];
   if (zero_words && blockIdx.x == 0)
     for (int i = threadIdx.x; i < nzero; i += kBlock) zero_words[i] = 0ull;
   const float oscale = oscale_ptr ? oscale_ptr[0] : 1.0f;
@@ -158,7 +291,8 @@ __global__ __launch_bounds__(kBlock) void inbatch3_merge_kernel(
   const int64_t gpb = kBlock / G;
   const int64_t group = (int64_t)blockIdx.x * gpb + threadIdx.x / G;
   const int64_t ngroups = (int64_t)gridDim.x * gpb;
-  double acc_loss = 0.0;
+  long long acc_loss = 0;
+  bool bad = false;
   for (int64_t row = group; row < B; row += ngroups) {
     // every load of the row is issued before the first use (nsplit <= 8 is a run-time value: the plain loops waited
     // for one memory latency per split and array, ~12 in a row); the sums keep the split order
@@ -177,46 +311,16 @@ __global__ __launch_bounds__(kBlock) void inbatch3_merge_kernel(
     }
     const float4 x = rowsrc_load4(X, row, 4 * lig);
     const float4 y = rowsrc_load4(Y, row, 4 * lig);
-    float M = 0.f, L = 1.f;
+    float M, L, invL1, row_loss;
     float wt[8];  // 2^(M_s - M): 1 for every split when they shared one reference (the bf16 x 3 path), 0 for s >= nsplit
-#pragma unroll
-    for (int s = 0; s < 8; ++s) wt[s] = 1.f;
-    if (QSIDE) {  // fp16 x 2 path: split s used the fixed reference part_m[s][row]; the row's is the largest of them
-      M = pm[0];
-      L = 0.f;
-#pragma unroll
-      for (int s = 1; s < 8; ++s) M = fmaxf(M, pm[s]);
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        // (fac == null: the bf16 x 3 path -- part_m[s] is split s's share of the row maximum there, and every split
-        // exponentiated against the maximum of them: weight 1)
-        wt[s] = (fac == nullptr || pm[s] == M) ? 1.f : __builtin_amdgcn_exp2f(pm[s] - M);
-        L = __fmaf_rn(pl[s], wt[s], L);  // (explicit roundings here and for the factors: fac2h_kernel must agree bit for bit)
-      }
-    }
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      if (s < nsplit) {
-        o.x += po[s].x * wt[s]; o.y += po[s].y * wt[s]; o.z += po[s].z * wt[s]; o.w += po[s].w * wt[s];
-      }
-    }
-    const float invL1 = __fdiv_rn(1.0f, L);
-    const float invL = invL1 * oscale;  // (exact: oscale is a power of two)
-    const float xn2 = group_sum(x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w, G);
-    const float xnorm = sqrtf(xn2);
-    const float creg = xnorm > 1.f ? lam / xnorm : 0.f;
-    float4 g;
-    g.x = (scale * (o.x * invL - y.x) + creg * x.x) * inv_bs;
-    g.y = (scale * (o.y * invL - y.y) + creg * x.y) * inv_bs;
-    g.z = (scale * (o.z * invL - y.z) + creg * x.z) * inv_bs;
-    g.w = (scale * (o.w * invL - y.w) + creg * x.w) * inv_bs;
+    // (fac == null: the bf16 x 3 path -- part_m[s] is split s's share of the row maximum there, and every split
+    // exponentiated against the maximum of them: weight 1)
+    const float4 g = merge_row<QSIDE>(po, pm, pl, nsplit, fac == nullptr, x, y, oscale, scale, lam, inv_bs, G, row_loss, M, L,
+                                      invL1, wt);
     if (4 * lig < X.ld)  // gradient rows have the source's width
       *reinterpret_cast<float4*>(gX + (out_idx ? (int64_t)out_idx[row] : row) * X.ld + 4 * lig) = g;
-    float row_loss = lam * fmaxf(xnorm - 1.f, 0.f);
     if (QSIDE) {
-      const float diag = group_sum(x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w, G);
-      const float l2v = M + __builtin_amdgcn_logf(L);
+      const float l2v = __fadd_rn(M, __builtin_amdgcn_logf(L));
       if (lig == 0) {
         lse2[row] = l2v;
         if (invl) invl[row] = invL1 * invl_scale;  // the stored-P pass C normalises with it
@@ -227,44 +331,13 @@ __global__ __launch_bounds__(kBlock) void inbatch3_merge_kernel(
         }
         if (lse_nat) lse_nat[row] = l2v * k3Ln2;
       }
-      row_loss += l2v * k3Ln2 - scale * diag;
     }
-    if (lig == 0) acc_loss += (double)row_loss;
+    if (lig == 0) acc_loss += loss_fixed(row_loss, bad);
   }
-  const double tsum = block_sum_d(acc_loss, sm);
-  // The loss scalar without a finalize launch and without a fence.  Every workgroup of both merge launches adds
-  // (its partial in 2^-28 fixed point) << 11 | 1 to a 64-bit word with ONE atomic -- integer addition is exact and
-  // order-free, so the sum is bit-reproducible, and the atomic's return value tells the workgroup whether it was the
-  // last to arrive.  Two levels, because 2048 atomics on one address serialise (measured: +15 us): kLossWords words
-  // 128 B apart take workgroups blockIdx % kLossWords; the last arrival of a word forwards that word's total to the
-  // master word; the last arrival there writes the loss.  Data flows only through atomic return values, so no
-  // ordering between addresses is needed.  split3_kernel zeroed the words.  (A ticket + __threadfence() reduction of
-  // double partials was 7 us slower than the finalize launch: the agent-scope release writes the XCD's L2 back.)
-  // Range: |sum| < 2^24 = 1.6e7 nats (a partial beyond it, or a non-finite one, poisons the result: NaN); resolution
-  // 3.7e-9 per workgroup partial.
-  if (threadIdx.x == 0) {
-    const unsigned wd = blockIdx.x % kLossWords;
-    const unsigned per_launch = (gridDim.x - wd + kLossWords - 1) / kLossWords;  // workgroups of one launch on word wd
-    const unsigned nwords = gridDim.x < (unsigned)kLossWords ? gridDim.x : (unsigned)kLossWords;
-    unsigned long long add = ((unsigned long long)__double2ll_rn(tsum * 268435456.0) << 11);
-    if (!(fabs(tsum) < 16777216.0)) {  // non-finite or out of range: the loss must come out NaN, not a wrapped number
-      // raise the poison word BEFORE this workgroup is counted: the add below consumes the atomic's return value, so
-      // it cannot be issued until the OR has been performed (r is 0 or 1; r >> 1 is the dependence, not a value)
-      const unsigned r = atomicOr(reinterpret_cast<unsigned*>(loss_acc + 8), 1u);
-      add = (unsigned long long)(r >> 1);
-    }
-    const unsigned long long old = atomicAdd(loss_acc + 16 * (1 + wd), add + 1ull);
-    if ((unsigned)(old & 2047ull) == 2 * per_launch - 1) {
-      const unsigned long long word_total = ((old + add) >> 11) << 11;  // this word's sum, count bits cleared
-      const unsigned long long m = atomicAdd(loss_acc, word_total + 1ull);
-      if ((unsigned)(m & 2047ull) == nwords - 1) {
-        const long long tot = ((long long)(m + word_total)) >> 11;  // arithmetic shift: signed sum
-        // every workgroup was counted before this branch was taken, hence after its OR (if any) was performed
-        const bool poisoned = atomicOr(reinterpret_cast<unsigned*>(loss_acc + 8), 0u) != 0u;
-        loss_out[0] = poisoned ? __builtin_nanf("") : (float)((double)tot * (1.0 / 268435456.0) * loss_scale);
-      }
-    }
-  }
+  const long long tsum = block_sum_ll(acc_loss, sm);
+  const bool any_bad = __syncthreads_or(bad ? 1 : 0) != 0;
+  // both merge launches of a call have this grid and add to the same words (see loss_arrive)
+  if (threadIdx.x == 0) loss_arrive(tsum, any_bad, 2, loss_acc, loss_scale, loss_out);
 }
 
 }  // namespace esr

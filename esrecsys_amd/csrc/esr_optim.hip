@@ -15,6 +15,7 @@
 // produces for nn.Embed (wikipedia/train_cooccurence.py:86-87) and esr_dense_adam applies
 // optax.adam to every element (train_cooccurence.py:99-101,171) [upstream optax 0.1.2].
 #include "esr_common.h"
+#include "esr_inbatch_mfma.h"
 
 #include <algorithm>
 
@@ -656,6 +657,124 @@ int sparse_adagrad_range(void* const* tables, float* const* accums, const int64_
   ft.row_offset[kMaxFusedTables] = row_offsets[ntables];
   return launch_segment_tables<kAdagrad>("sparse_adagrad_range", ft, dtype, D, sorted_vids, perm, n, grad_rows, lr, eps, st,
                                          skip_long);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The in-batch step's merge launches AND its sparse Adagrad update in one kernel (round 5).  The step used to end with
+// merge<Q> (8 partial O rows per query row -> gQ, 16 us at B = 8192), merge<C> (-> gC, 13 us) and the update (gQ / gC rows
+// in sorted order -> tables, 13 us): 8 MB of gradient rows written and read back and two launches whose only product
+// they were.  Here the group at the head of a run of equal ids produces each occurrence's gradient row on the fly --
+// merge_row, the merge kernels' own arithmetic -- adds them left to right and applies Adagrad once: the same bits as
+// merge + update.  The partner rows come from copies the op's first launch took (the other tower is being updated by
+// this very launch); the owned row is the table row the update reads anyway.  Needs a list without runs that outgrow
+// their head chunk (the caller's long-run hint says so; a continuation chunk met anyway poisons the loss) and D = 128.
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool QSIDE>
+__device__ __forceinline__ float4 merged_occurrence(const InbatchMergeArgs& a, int64_t r, float4 x, float oscale, int lig,
+                                                    float& row_loss) {
+  constexpr int side = QSIDE ? 0 : 1;
+  const int nsplit = a.nsplit[side];
+  float pm[8], pl[8];
+  float4 po[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    pm[s] = -INFINITY; pl[s] = 0.f; po[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s < nsplit) {
+      if (QSIDE) {
+        pm[s] = a.part_m[(int64_t)s * a.B + r];
+        pl[s] = a.part_l[(int64_t)s * a.B + r];
+      }
+      po[s] = *reinterpret_cast<const float4*>(a.part_O[side] + ((int64_t)s * a.B + r) * k3D + 4 * lig);
+    }
+  }
+  const float4 y = *reinterpret_cast<const float4*>(a.partner[side] + r * k3D + 4 * lig);
+  float M, L, invL1, wt[8];
+  return merge_row<QSIDE>(po, pm, pl, nsplit, false, x, y, oscale, a.scale, a.lam, a.inv_bs, 32, row_loss, M, L, invL1, wt);
+}
+
+__global__ __launch_bounds__(kBlock) void inbatch_merge_update_kernel(FusedTables ft, int dtype,
+                                                                     const int32_t* __restrict__ sorted_ids,
+                                                                     const int32_t* __restrict__ perm, int64_t n,
+                                                                     InbatchMergeArgs a, float lr, float eps) {
+  constexpr int G = 32, D = k3D, nvec = k3D / 4;
+  __shared__ long long sm[4];
+  if (a.zero_words && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < a.nzero; i += kBlock) a.zero_words[i] = 0ull;
+  const int lig = threadIdx.x & (G - 1);
+  const int64_t gpb = kBlock / G;
+  const int64_t group = (int64_t)blockIdx.x * gpb + threadIdx.x / G;
+  const int64_t ngroups = (int64_t)gridDim.x * gpb;
+  const int64_t per = (n + ngroups - 1) / ngroups;  // contiguous slices, as segment_update_kernel
+  const int64_t p_end = min(n, (group + 1) * per);
+  const float osc_q = a.oscale[0][0], osc_c = a.oscale[1][0];
+  long long acc_loss = 0;
+  bool bad = false;
+  for (int64_t p = group * per; p < p_end; ++p) {
+    const int32_t vid = sorted_ids[p];
+    const bool head = p == 0 || sorted_ids[p - 1] != vid;
+    if (!head) {
+      // a continuation chunk (segment_update_kernel's rule) cannot exist in a list the hint cleared
+      if ((p & (kSegChunk - 1)) == 0 && p >= kSegChunk && sorted_ids[p - kSegChunk] == vid) bad = true;
+      continue;
+    }
+    const int64_t stop = min(((p + 2 * kSegChunk - 1) / kSegChunk) * kSegChunk, n);
+    void* table = ft.table[0];
+    float* accum = ft.accum[0];
+    const bool qside = (int64_t)vid < ft.row_offset[1];
+    int64_t id = vid;
+    if (!qside) {
+      table = ft.table[1];
+      accum = ft.accum[1];
+      id = (int64_t)vid - ft.row_offset[1];
+    }
+    RowRegs<4, 1> w, ac;
+    param_load(w, table, dtype, id, D, lig, G, nvec);
+    row_load(ac, accum + id * D, lig, G, nvec);
+    const float4 x = make_float4(w.v[0][0], w.v[0][1], w.v[0][2], w.v[0][3]);
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t q = p; q < stop; ++q) {
+      if (q > p && sorted_ids[q] != vid) break;
+      const int64_t o = perm[q];
+      float row_loss;
+      const float4 t = qside ? merged_occurrence<true>(a, o, x, osc_q, lig, row_loss)
+                             : merged_occurrence<false>(a, o - a.B, x, osc_c, lig, row_loss);
+      if (q == p) {
+        g = t;
+      } else {
+        g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+      }
+      if (lig == 0) acc_loss += loss_fixed(row_loss, bad);
+      if (q + 1 == stop && q + 1 < n && sorted_ids[q + 1] == vid) bad = true;  // the run outgrew its head chunk
+    }
+    adagrad_elem(w.v[0][0], ac.v[0][0], g.x, lr, eps);
+    adagrad_elem(w.v[0][1], ac.v[0][1], g.y, lr, eps);
+    adagrad_elem(w.v[0][2], ac.v[0][2], g.z, lr, eps);
+    adagrad_elem(w.v[0][3], ac.v[0][3], g.w, lr, eps);
+    row_store(ac, accum + id * D, lig, G, nvec);
+    param_store(w, table, dtype, id, D, lig, G, nvec);
+  }
+  const long long tsum = block_sum_ll(acc_loss, sm);
+  const bool any_bad = __syncthreads_or(bad ? 1 : 0) != 0;
+  if (threadIdx.x == 0) loss_arrive(tsum, any_bad, 1, a.loss_acc, a.loss_scale, a.loss_out);
+}
+
+int inbatch_merge_update(void* const* tables, float* const* accums, const int64_t* row_offsets, int dtype,
+                         const int32_t* sorted_vids, const int32_t* perm, const InbatchMergeArgs& a, float lr, float eps,
+                         hipStream_t st) {
+  FusedTables ft;
+  ft.n = 2;
+  for (int i = 0; i < kMaxFusedTables; ++i) {
+    ft.table[i] = i < 2 ? tables[i] : nullptr;
+    ft.accum[i] = i < 2 ? accums[i] : nullptr;
+    ft.row_offset[i] = i <= 2 ? row_offsets[i] : row_offsets[2];
+  }
+  ft.row_offset[kMaxFusedTables] = row_offsets[2];
+  const int64_t n = 2 * a.B;
+  const int grid = grid_for_groups(n, 32);
+  ESR_KT("inbatch_merge_update_kernel", st,
+         hipLaunchKernelGGL(inbatch_merge_update_kernel, dim3(grid), dim3(kBlock), 0, st, ft, dtype, sorted_vids, perm, n, a,
+                            lr, eps));
+  return check_launch("inbatch_merge_update");
 }
 
 // esr_sparse_momentum_step_multi for one or two tables whose rows may be behind (last[t][row] = the step the row is current
