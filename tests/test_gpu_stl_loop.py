@@ -226,7 +226,7 @@ def test_planned_batch_refuses_another_state(dev):
 
 
 @pytest.mark.parametrize("B,D,ids,dt", [(1024, 128, "uniform", "f32"), (2048, 128, "hot", "f32"), (512, 64, "hot", "f32"),
-                                        (8192, 128, "uniform", "f32"), (1024, 128, "hot", "bf16")])
+                                        (8192, 128, "uniform", "f32"), (1024, 128, "hot", "bf16"), (1024, 128, "uniform", "bf16")])
 def test_inbatch_one_call_step_equals_fwd_bwd_plus_update(dev, monkeypatch, B, D, ids, dt):
     """The in-batch step as ONE library call (esr_inbatch_train_step_f16x2) -- with merge<Q> and the scene tower's
     Adagrad on a second stream beside pass C, and without the second stream -- against rounds 1-4's
@@ -273,10 +273,53 @@ def test_inbatch_one_call_step_equals_fwd_bwd_plus_update(dev, monkeypatch, B, D
     assert np.isfinite(want[0].cpu().numpy()).all() and int(want[0].numel()) == steps
     bad = []
     names = ("losses", "scene tower", "product tower", "scene accumulator", "product accumulator")
-    for onecall, overlap, loop in ((True, True, False), (True, False, False), (True, True, True), (False, False, True)):
+    # (one call, no second stream, loop: the lists' long-run hints are known -- "uniform" steps end with the merging update
+    # (inbatch_merge_update_kernel at D = 128: merges + Adagrad in one launch), "hot" ones fall back to merge + update)
+    for onecall, overlap, loop in ((True, True, False), (True, False, False), (True, True, True), (True, False, True),
+                                   (False, False, True)):
         got = run(onecall, overlap, loop)
         for name, x, y in zip(names, got, want):
             if not torch.equal(x, y):
                 bad.append((onecall, overlap, loop, name, float((x.float() - y.float()).abs().max())))
+    monkeypatch.setenv("ESR_IB2H_MERGE_UPDATE", "0")   # the same loop without the merging update
+    for name, x, y in zip(names, run(True, False, True), want):
+        if not torch.equal(x, y):
+            bad.append(("merge + update", name, float((x.float() - y.float()).abs().max())))
+    monkeypatch.delenv("ESR_IB2H_MERGE_UPDATE")
     assert want[1].dtype == (torch.bfloat16 if dt == "bf16" else torch.float32)
     assert not bad, bad
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_inbatch_merging_update_lse_and_a_false_hint(dev, monkeypatch, dt):
+    """esr_inbatch_train_step_f16x2 with long_runs = 0 ends with the merging update (merges + Adagrad in one launch, lse from
+    fac2h_kernel): loss, lse, towers and accumulators equal the merge + update launches bit for bit.  A caller whose hint is
+    wrong -- a run of 70 equal ids handed over as "no long run" -- gets a NaN loss, not a silently partial update."""
+    from esrecsys_amd import ops
+    Vq, Vc, B, D = 3000, 4000, 1024, 128
+    rng = np.random.default_rng(11)
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float32
+
+    def towers():
+        g = torch.Generator(device=dev).manual_seed(5)
+        return [(torch.randn((Vq, D), generator=g, device=dev) * 0.3).to(tdt), torch.full((Vq, D), 0.1, device=dev),
+                (torch.randn((Vc, D), generator=g, device=dev) * 0.3).to(tdt), torch.full((Vc, D), 0.1, device=dev)]
+    qi = torch.from_numpy(rng.integers(0, Vq, B).astype(np.int32)).to(dev)
+    ci = torch.from_numpy(rng.integers(0, Vc, B).astype(np.int32)).to(dev)
+    srt, prm = ops.segment_sort_batched([[qi, ci]], (0, Vq), Vq + Vc)
+
+    def step(mu, q=qi, c=ci, pre=(srt[0], prm[0])):
+        monkeypatch.setenv("ESR_IB2H_MERGE_UPDATE", mu)
+        t = towers()
+        loss, lse = ops.inbatch_train_step(t[0], t[1], t[2], t[3], q, c, 4.0, 0.1, float(B), 0.05, presorted=pre,
+                                           long_runs=0, want_lse=True)
+        torch.cuda.synchronize()
+        return [loss, lse] + t
+    a, b = step("1"), step("0")
+    assert np.isfinite(float(a[0])) and all(torch.equal(x, y) for x, y in zip(a, b))
+    hot = qi.clone()
+    hot[:70] = 7                                            # a run that outgrows its head chunk
+    hs, hp = ops.segment_sort_batched([[hot, ci]], (0, Vq), Vq + Vc)
+    lied = step("1", q=hot, pre=(hs[0], hp[0]))
+    assert np.isnan(float(lied[0]))
+    monkeypatch.delenv("ESR_IB2H_MERGE_UPDATE")
