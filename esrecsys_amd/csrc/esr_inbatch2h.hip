@@ -1735,8 +1735,13 @@ constexpr int kPc8Owned = 256;
 // (esr_probe_hbm_read): a burst per iteration, then the wait for its tail.  With the staged loads the ring holds
 // planes and factors only, has four slots (fetched three chunks ahead) and its barrier waits vmcnt(7): everything the
 // previous iteration issued stays in flight across it.
+#if defined(H_PC8_ALLOW_PK)
+#define ESR_PC8_PK
+#else
+#define ESR_PC8_PK ESR_NO_PK
+#endif
 template <bool STAGE>
-__global__ ESR_NO_PK __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __restrict__ Yr, int64_t B, int nsplit,
+__global__ ESR_PC8_PK __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __restrict__ Yr, int64_t B, int nsplit,
                                                            const float* __restrict__ fac, int nc_q,
                                                            const float* __restrict__ Pmat,
                                                            float* __restrict__ part_O) {

@@ -16,6 +16,6 @@ fi
 mkdir -p gpurun_out
 for v in $VARIANTS; do
   rm -rf gpurun_out/prof/pr
-  ESR_IB2H_BF16=force IB2H_LIB=libib1h_$v.so timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/pr -o t -- python scripts/ib2h_probe.py 2>&1 | grep "op "
-  echo "== $v"; python scripts/prof_stats.py gpurun_out/prof/pr | grep -E "1h" | cut -c1-44,100-140
+  env ${IB1H_ENV-ESR_IB2H_BF16=force} IB2H_LIB=libib1h_$v.so timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/pr -o t -- python scripts/ib2h_probe.py 2>&1 | grep "op "
+  echo "== $v"; python scripts/prof_stats.py gpurun_out/prof/pr | grep -E "${IB1H_GREP:-1h}" | cut -c1-44,100-140
 done 2>&1 | tee gpurun_out/ib1h_probe.log
