@@ -48,3 +48,18 @@ print("entry (us after the first): min %.1f  median %.1f  max %.1f;  end: min %.
     (np.median(end) - ent.min()) / 100, (end.max() - ent.min()) / 100))
 h, edges = np.histogram((ent - ent.min()) / 100, bins=8)
 print("entry histogram (us):", [("%.0f-%.0f" % (edges[i], edges[i + 1]), int(h[i])) for i in range(8)])
+if os.environ.get("IB2H_BY_BLOCK"):
+    # pass C: is a workgroup whose P' tiles pass Q wrote LAST (still in the Infinity Cache) faster than one whose tiles were
+    # written first?  Stamped: waves 0..3 of every even workgroup; workgroup = 256-row block x split (IB2H_BY_BLOCK = nsplit)
+    ns = int(os.environ["IB2H_BY_BLOCK"])
+    raw = np.array(buf[4096:], dtype=np.float64).reshape(1024, 4)
+    idx = np.nonzero(raw[:, 0] > 0)[0]
+    blk = 2 * (idx // 4)
+    ob, w = blk // ns, idx % 4
+    jt = 8 * ob + w                       # the wave's owned 32-row tile = pass Q's streamed chunk index
+    dur = (raw[idx, 2] - raw[idx, 1]) / 100
+    for cls in range(4):
+        m = (jt % 32) // 8 == cls
+        if m.any():
+            print("tiles pass Q wrote in its iterations %2d..%2d of 32: loop %.1f us (min %.1f max %.1f, %d waves)"
+                  % (8 * cls, 8 * cls + 7, dur[m].mean(), dur[m].min(), dur[m].max(), int(m.sum())))
