@@ -447,14 +447,18 @@ int enqueue(std::vector<Op>& ops) {
     if (ops[i].send && ops[i].n &&
         hipMemcpyAsync(sl->send + g->off[i], ops[i].p, ops[i].n, hipMemcpyDeviceToHost, s) != hipSuccess)
       return kSystemError;
-  const uint32_t ticket = g->ticket;  // (g belongs to the worker from the hand-over on)
+  // g belongs to the worker from the hand-over on -- it deletes the group as soon as the bytes have moved, which on an
+  // idle stream can be before this thread has queued the copies below: what they need is copied out first.  (Reading
+  // g->off after the hand-over was a use-after-free that took a rank down with SIGSEGV once in a few full test runs.)
+  const uint32_t ticket = g->ticket;
+  const std::vector<size_t> off = g->off;
   if (hipLaunchHostFunc(s, host_handover, g) != hipSuccess) return kSystemError;
   hipLaunchKernelGGL(wire_wait_kernel, dim3(1), dim3(1), 0, s, (const uint32_t*)c->ticket_done, ticket,
                      (unsigned long long)(timeout_ms() / 1000 + 30) * 100000000ull);
   if (hipGetLastError() != hipSuccess) return kSystemError;
   for (size_t i = 0; i < ops.size(); ++i)
     if (!ops[i].send && ops[i].n &&
-        hipMemcpyAsync(ops[i].p, sl->recv + g->off[i], ops[i].n, hipMemcpyHostToDevice, s) != hipSuccess)
+        hipMemcpyAsync(ops[i].p, sl->recv + off[i], ops[i].n, hipMemcpyHostToDevice, s) != hipSuccess)
       return kSystemError;
   sl->used = true;
   return hipEventRecord(sl->done, s) == hipSuccess ? kOk : kSystemError;
@@ -490,6 +494,10 @@ void close_all(Comm* c) {
       g_ctrl_world = 0;
     }
   }
+  // every enqueued group has run to its end (host function, wait kernel, copies) before the worker is told to stop: a
+  // host function that ran later would hand its group to a communicator that no longer exists
+  for (Slot& sl : c->slot)
+    if (sl.used && sl.done) hipEventSynchronize(sl.done);
   if (c->worker.joinable()) {
     {
       std::lock_guard<std::mutex> lk(c->mu);
