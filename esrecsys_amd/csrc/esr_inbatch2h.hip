@@ -1470,16 +1470,6 @@ __device__ __forceinline__ void trh1_frag(TA& ta, const uint32_t (&tb)[4][2]) {
 #endif
 // WAIT_PARTIAL: the previous iteration requested a chunk (its LDS-DMAs may stay in flight across the barrier: the chunk
 // needed now is the one before it); DMA_RT: this iteration requests chunk it + 3 (both run-time, wave-uniform)
-#if defined(H1_PRIO) && H1_PRIO == 1   /* S^T phase (MFMAs only) above the O^T phase */
-#define H1_PRIO_S() __builtin_amdgcn_s_setprio(3)
-#define H1_PRIO_O() __builtin_amdgcn_s_setprio(0)
-#elif defined(H1_PRIO) && H1_PRIO == 2 /* the other way round */
-#define H1_PRIO_S() __builtin_amdgcn_s_setprio(0)
-#define H1_PRIO_O() __builtin_amdgcn_s_setprio(3)
-#else
-#define H1_PRIO_S()
-#define H1_PRIO_O()
-#endif
 #define H1C_ITER(CUR, PC, PN, WAIT_PARTIAL, DMA_RT)                                                       \
   {                                                                                                       \
     H_TICK(tk0);                                                                                          \
@@ -1488,9 +1478,7 @@ __device__ __forceinline__ void trh1_frag(TA& ta, const uint32_t (&tb)[4][2]) {
     H_TICK(tk1);                                                                                          \
     H1C_TR(H1C_G0(CUR));                                                                                  \
     H1C_LOAD_REFS(((CUR) + 1) & 3);                                                                       \
-    H1_PRIO_S();                                                                                          \
     H1C_S_PHASE(((CUR) + 1) & 3, sa);                                                                     \
-    H1_PRIO_O();                                                                                          \
     H_TICK(tk2);                                                                                          \
     H1_TAKE_SCORES();                                                                                     \
     H1_O_PHASE_X(H1C_DMA_ON && (DMA_RT), lds + H1C_OFF(((CUR) + 3) & 3), H1C_EXP_ON, PC, PN,              \
