@@ -468,7 +468,8 @@ def test_inbatch_one_plane_kernels_equal_the_full_ones(dev, B):
         assert abs(float(loss) - el) / abs(el) <= TOL and rel_err(N(gq), egq) <= TOL and rel_err(N(gc), egc) <= TOL
 
 
-@pytest.mark.parametrize("B,hot", [(128, False), (512, True), (1024, False), (2176, True), (8192, False), (8192, True)])
+@pytest.mark.parametrize("B,hot", [(128, False), (384, False), (512, True), (1024, False), (2176, True), (8192, False),
+                                   (8192, True), (16384, False)])
 def test_inbatch_bf16_tables_on_one_fp16_plane(dev, B, hot, monkeypatch):
     """bf16 towers (BASELINE config 4's dtype) on the fp16 entry points (round 5, the default for them): ONE fp16 plane
     per operand -- a bf16 element is exact in it -- two for the probabilities, S^T recomputed by pass C: six GEMMs, no

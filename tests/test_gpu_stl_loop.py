@@ -226,7 +226,8 @@ def test_planned_batch_refuses_another_state(dev):
 
 
 @pytest.mark.parametrize("B,D,ids,dt", [(1024, 128, "uniform", "f32"), (2048, 128, "hot", "f32"), (512, 64, "hot", "f32"),
-                                        (8192, 128, "uniform", "f32"), (1024, 128, "hot", "bf16"), (1024, 128, "uniform", "bf16")])
+                                        (8192, 128, "uniform", "f32"), (1024, 128, "hot", "bf16"), (1024, 128, "uniform", "bf16"),
+                                        (16384, 128, "uniform", "f32"), (384, 128, "uniform", "bf16")])
 def test_inbatch_one_call_step_equals_fwd_bwd_plus_update(dev, monkeypatch, B, D, ids, dt):
     """The in-batch step as ONE library call (esr_inbatch_train_step_f16x2) -- with merge<Q> and the scene tower's
     Adagrad on a second stream beside pass C, and without the second stream -- against rounds 1-4's
