@@ -1757,13 +1757,16 @@ __global__ ESR_PC8_PK __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Fl
   const int64_t jt = live ? (wrow >> 5) : 0;  // (idle waves fetch block 0's tiles: valid addresses, results dropped)
   const float* ref = fac + (int64_t)(jt / nc_q) * B;
   const char* const pw_base = reinterpret_cast<const char*>(Pmat) + (jt * nch + c0) * 4096;
-  // LDS piece u = mh * 32 + x holds tile piece (mh, a = x ^ 2 mh) (mh = 2 m + h of pass Q): DMA instruction G4 writes
-  // pieces u = 64 G4 + lane, i.e. mh = 2 G4 + lane / 32, x = lane % 32
+  // LDS piece u = mh * 32 + x holds tile piece (mh, a = x ^ mh) (mh = 2 m + h of pass Q): DMA instruction G4 writes
+  // pieces u = 64 G4 + lane, i.e. mh = 2 G4 + lane / 32, x = lane % 32.  (The swizzle was x ^ 2 mh until round 5: right
+  // for 64 banks, but a ds_read_b32 sees 32 -- the eight pieces of a 128-byte window -- and 2 mh mod 8 takes four values
+  // for the eight mh of a half wave: every one of the 16 reads per lane and chunk was a two-way bank conflict,
+  // SQ_LDS_BANK_CONFLICT = 2.1 M cycles per launch.)
   uint32_t p_off[4];
 #pragma unroll
   for (int g4 = 0; g4 < 4; ++g4) {
     const int mh = 2 * g4 + (lane >> 5);
-    p_off[g4] = (uint32_t)((mh * 32 + ((lane & 31) ^ (2 * mh))) * 16);
+    p_off[g4] = (uint32_t)((mh * 32 + ((lane & 31) ^ mh)) * 16);
   }
   const int wave_off = 2 * kPlaneBytes + w * kWaveArea;
   const uint32_t lds32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds;
@@ -1841,10 +1844,10 @@ __global__ ESR_PC8_PK __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Fl
   f16x8 ta2_[2][4][2];
   uint32_t trn_[4][2];
   // this lane's 16 probabilities of the chunk in BUF: component j % 4 of pieces (mh = j / 4, a = 8 g + 4 h + e), at LDS
-  // piece mh * 32 + (a ^ 2 mh); and their 16 factors
+  // piece mh * 32 + (a ^ mh); and their 16 factors
   const int p_mh = j >> 2;
   const int p_rd = (STAGE ? kPArea + w * 4096 : wave_off) + p_mh * 512 + (j & 3) * 4;
-  const int p_x = (4 * h) ^ (2 * p_mh);  // (8 g + e) ^ p_x == (8 g + 4 h + e) ^ 2 mh: the three fields do not overlap
+  const int p_x = (4 * h) ^ p_mh;  // (8 g + e) ^ p_x == (8 g + 4 h + e) ^ mh: 8 g + e has no bit 2
 #define H8_LOAD_P(BUF)                                                                                    \
   _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_)                                                       \
     p1[r_] = *reinterpret_cast<const float*>((STAGE ? lds : (BUF)) + p_rd + (((8 * (r_ >> 2) + (r_ & 3)) ^ p_x) << 4));
