@@ -231,7 +231,11 @@ __device__ __forceinline__ void tile_rank_body(const uint32_t* __restrict__ tile
                                                int32_t* __restrict__ sorted_ids, int32_t* __restrict__ perm,
                                                uint32_t* spl, int bx, int kRankReps) {
   constexpr int kTile = 1 << TB, kSplitPerTile = kTile / kSplitEvery;
-  for (int i = threadIdx.x; i < ntiles * kSplitPerTile; i += kBlock) spl[i] = splitters[i] >> TB;
+  // (rows padded by one word: the 16 lanes of a group search 16 tiles at the same depth -- with a stride of 32 or 64 words
+  // every probe of every level was a 16-way bank conflict, 77 % of the kernel's LDS cycles)
+  constexpr int kSplStride = kSplitPerTile + 1;
+  for (int i = threadIdx.x; i < ntiles * kSplitPerTile; i += kBlock)
+    spl[(i / kSplitPerTile) * kSplStride + (i % kSplitPerTile)] = splitters[i] >> TB;
   __syncthreads();
   const int u = threadIdx.x & (kMidTiles - 1);                                 // the tile this lane searches
   // kRankReps element slots per 16-lane group: the splitters are staged once per workgroup for 128 elements instead of
@@ -248,7 +252,7 @@ __device__ __forceinline__ void tile_rank_body(const uint32_t* __restrict__ tile
     int lo = 0, hi = kSplitPerTile;  // level 1 (LDS): whole 32-key blocks that precede this element
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
-      const uint32_t x = spl[u * kSplitPerTile + mid];
+      const uint32_t x = spl[u * kSplStride + mid];
       if (u < mine ? x <= id : x < id) lo = mid + 1; else hi = mid;  // earlier tiles win ties
     }
     const int base = lo * kSplitEvery;
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(kBlock) void tile_rank_kernel(const uint32_t* __res
                                                           const uint32_t* __restrict__ splitters, int n, int ntiles,
                                                           int32_t* __restrict__ sorted_ids,
                                                           int32_t* __restrict__ perm, int reps) {
-  __shared__ uint32_t spl[kMidTiles * ((1 << TB) / kSplitEvery)];
+  __shared__ uint32_t spl[kMidTiles * ((1 << TB) / kSplitEvery + 1)];
   tile_rank_body<TB>(tiles, splitters, n, ntiles, sorted_ids, perm, spl, blockIdx.x, reps);
 }
 template <int TB>
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(kBlock) void tile_rank_batched_kernel(const uint32_
                                                                   int ntiles, int64_t ws_stride,
                                                                   int32_t* __restrict__ sorted_ids,
                                                                   int32_t* __restrict__ perm, int reps) {
-  __shared__ uint32_t spl[kMidTiles * ((1 << TB) / kSplitEvery)];
+  __shared__ uint32_t spl[kMidTiles * ((1 << TB) / kSplitEvery + 1)];
   const int y = blockIdx.y;
   tile_rank_body<TB>(tiles + y * ws_stride, splitters + y * ws_stride, n, ntiles, sorted_ids + (int64_t)y * n,
                      perm + (int64_t)y * n, spl, blockIdx.x, reps);
