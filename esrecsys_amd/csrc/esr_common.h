@@ -212,6 +212,13 @@ __device__ __forceinline__ void decay_steps(float& p, float& t, int n, float lr,
 
 // A row held in registers by its G-lane group: chunk k of this lane is row chunk lig + k*G.
 // All indices are compile-time so the arrays stay in VGPRs (no scratch).
+// -DESR_ROW_STORE_NT=1: row stores (table rows, accumulators, gradient rows) as streaming (non-temporal) stores.  The idea:
+// a step's dirty rows sit in the XCD's write-back L2 until the kernel ends and are written back at the release in front of
+// the next step's launch.  Measured (round 5, scripts/gpu_nt_ab.sh, alternating runs): GloVe B = 2048 +2.5 %, triplet
+// B = 8192 -2 %, GloVe B = 65 536 -1.5 %, triplet B = 262 144 -1 %, in-batch equal -- off.
+#ifndef ESR_ROW_STORE_NT
+#define ESR_ROW_STORE_NT 0
+#endif
 template <int VEC, int NCH>
 struct RowRegs {
   float v[NCH][VEC];
@@ -243,7 +250,13 @@ __device__ __forceinline__ void row_store(const RowRegs<VEC, NCH>& r, float* __r
     const int c = lig + k * G;
     if (c < nvec) {
       if constexpr (VEC == 4) {
+#if ESR_ROW_STORE_NT
+        typedef float esr_f32x4_ __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(esr_f32x4_{r.v[k][0], r.v[k][1], r.v[k][2], r.v[k][3]},
+                                    reinterpret_cast<esr_f32x4_*>(p + 4 * c));
+#else
         *reinterpret_cast<float4*>(p + 4 * c) = make_float4(r.v[k][0], r.v[k][1], r.v[k][2], r.v[k][3]);
+#endif
       } else {
         p[c] = r.v[k][0];
       }
