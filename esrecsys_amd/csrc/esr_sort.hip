@@ -89,11 +89,15 @@ __global__ __launch_bounds__(kSmallSortThreads) void segment_sort_small_kernel(S
 constexpr int kMidTiles = 16, kMaxTileBits = 11;
 // element slots per 16-lane group of the rank kernels (see tile_rank_body): as many (<= 8) as leave >= 2048 workgroups
 static inline int rank_reps(int64_t blocks) {
-  int r = 8;
-  while (r > 1 && blocks / r < 2048) r >>= 1;
+  int r = 16;
+  while (r > 1 && blocks / r < 1024) r >>= 1;
   return r;
 }
-constexpr int kSplitEvery = 32;  // one splitter (its last key) per 32-key block of a sorted tile
+// One splitter (its last key) per 8-key block of a sorted tile.  (32-key blocks until round 5: the rank kernel then
+// finished every search with five DEPENDENT probes of global memory inside the block; with 8-key blocks the level
+// staged in LDS is four times as long -- 16 KB for sixteen 2048-key tiles -- and what is left is one 32-byte block,
+// fetched by two loads that are in flight together and counted without a search.)
+constexpr int kSplitEvery = 8;
 constexpr int kMidSortMax = (1 << kMaxTileBits) * kMidTiles;
 // Bitonic network over kTile = 2^TB keys held two per thread: thread t holds positions t (k0) and t + kTile / 2 (k1).
 // A compare-exchange with stride < 64 has its partner in the same wave (lane ^ stride) and is one cross-lane move per key
@@ -238,8 +242,8 @@ __device__ __forceinline__ void tile_rank_body(const uint32_t* __restrict__ tile
     spl[(i / kSplitPerTile) * kSplStride + (i % kSplitPerTile)] = splitters[i] >> TB;
   __syncthreads();
   const int u = threadIdx.x & (kMidTiles - 1);                                 // the tile this lane searches
-  // kRankReps element slots per 16-lane group: the splitters are staged once per workgroup for 128 elements instead of
-  // 16 (round 4: the eight 24 576-id lists of a group of triplet batches were 12 288 workgroups staging 3 KB each)
+  // kRankReps element slots per 16-lane group: the splitters are staged once per workgroup for up to 256 elements instead
+  // of 16 (round 4: the eight 24 576-id lists of a group of triplet batches were 12 288 workgroups staging 3 KB each)
 #pragma unroll 1
   for (int rep = 0; rep < kRankReps; ++rep) {
   const int g = ((bx * kRankReps + rep) * kBlock + threadIdx.x) / kMidTiles;   // slot g of the tiled array
@@ -249,18 +253,21 @@ __device__ __forceinline__ void tile_rank_body(const uint32_t* __restrict__ tile
   const uint32_t id = c >> TB;
   int cnt = 0;
   if (live && u < ntiles && u != mine) {
-    int lo = 0, hi = kSplitPerTile;  // level 1 (LDS): whole 32-key blocks that precede this element
+    int lo = 0, hi = kSplitPerTile;  // level 1 (LDS): whole 8-key blocks that precede this element
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
       const uint32_t x = spl[u * kSplStride + mid];
       if (u < mine ? x <= id : x < id) lo = mid + 1; else hi = mid;  // earlier tiles win ties
     }
     const int base = lo * kSplitEvery;
-    int lo2 = 0, hi2 = base < kTile ? kSplitEvery : 0;  // level 2 (global): inside that block, one 128-B line
-    while (lo2 < hi2) {
-      const int mid = (lo2 + hi2) >> 1;
-      const uint32_t x = tiles[u * kTile + base + mid] >> TB;
-      if (u < mine ? x <= id : x < id) lo2 = mid + 1; else hi2 = mid;
+    int lo2 = 0;  // level 2 (global): the keys of that block that precede the element -- the block is sorted: a count
+    if (base < kTile) {
+      const uint4 a = *reinterpret_cast<const uint4*>(tiles + u * kTile + base);
+      const uint4 b = *reinterpret_cast<const uint4*>(tiles + u * kTile + base + 4);
+      const uint32_t lim = u < mine ? id : id - 1u;  // x <= id, or x < id  <=>  x <= id - 1 (id == 0: nothing precedes)
+      if (u < mine || id != 0u)
+        lo2 = (int)((a.x >> TB) <= lim) + (int)((a.y >> TB) <= lim) + (int)((a.z >> TB) <= lim) + (int)((a.w >> TB) <= lim) +
+              (int)((b.x >> TB) <= lim) + (int)((b.y >> TB) <= lim) + (int)((b.z >> TB) <= lim) + (int)((b.w >> TB) <= lim);
     }
     cnt = min(base + lo2, n - u * kTile);  // never count the padding
   }
