@@ -381,9 +381,15 @@ class _FusedTripletLoop:
         self.B = B
 
     def ids(self, scene, pos, neg):
-        sid = ops.as_ids(scene, self.dev, check_range=self.Vs).reshape(-1)
-        pid = ops.as_ids(pos, self.dev, check_range=self.Vp).reshape(-1)
-        nid = ops.as_ids(neg, self.dev, check_range=self.Vp).reshape(-1)
+        sid = ops.as_ids(scene, self.dev, check_range=self.Vs)
+        pid = ops.as_ids(pos, self.dev, check_range=self.Vp)
+        nid = ops.as_ids(neg, self.dev, check_range=self.Vp)
+        if sid.dim() != 1:
+            sid = sid.reshape(-1)
+        if pid.dim() != 1:
+            pid = pid.reshape(-1)
+        if nid.dim() != 1:
+            nid = nid.reshape(-1)
         return sid, pid, nid
 
     def presort(self, slot_index, sid, pid, nid):
@@ -449,9 +455,8 @@ class _FusedTripletLoop:
 
     def step_group(self, k, gr, regularization, batch_size):
         """Steps k .. k + gr.nb - 1: the batches of a sorted and planned group, issued by one library call."""
-        if gr.side:
-            self.main.wait_event(self.hints_event[gr.which])
         known = self.hints_known[gr.which]
+        done = known is not None
         if known is None:
             # the HOST waits for the group's plan launch: it was queued in front of the steps of the group before, so
             # the wait ends with those steps (a group's worth of work) still queued -- the device never runs dry, the
@@ -460,7 +465,13 @@ class _FusedTripletLoop:
             if _HINT_WAIT:
                 self.hints_event[gr.which].synchronize()
             if self.hints_event[gr.which].query():
+                done = True
                 known = self.hints_known[gr.which] = self.hints_host[gr.which].tolist()
+        if gr.side and not done:
+            # (the plan was made on the second stream: the steps wait for it ON THE DEVICE only when the host has not seen
+            # its event complete -- a stream wait is a barrier packet in front of the group's first step, ~5 us of idle
+            # main stream per group for an event that has long fired)
+            self.main.wait_event(self.hints_event[gr.which])
         long_runs = None
         if known is not None:  # (else: the hint has not reached the host; the library makes every long-run launch)
             long_runs = self.long_arr
