@@ -225,6 +225,137 @@ __global__ __launch_bounds__(512) void mfma_kind_probe_kernel(int iters, unsigne
   if ((threadIdx.x & 63) == 0) cycles[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
 }
 
+// The exp / split of the one-plane in-batch kernel as it sits between the MFMAs of an O^T row (esr_inbatch2h.hip H1_O_ROW):
+// one round = four MFMAs with the four stages of two pairs of probabilities behind them (22 VALU instructions).
+// VARIANT: 0 as in the kernel; 1 the fp16 conversions as v_fma_mixlo / mixhi_f16 instead of v_cvt_pk_f16_f32; 2 v_exp_f32
+// replaced by v_fma_f32; 3 without the two sums and the running maximum; 4 the same number of independent v_fma_f32;
+// 5 the MFMAs alone; 6 = 0 with all 22 instructions behind the fourth MFMA.
+template <int VARIANT>
+__global__ __launch_bounds__(512) void mfma_mix_probe_kernel(int iters, unsigned long long* __restrict__ cycles,
+                                                             float* __restrict__ sink) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  f16x8 a[4], b[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const uint32_t ha = probe_hash((blockIdx.x * 512 + threadIdx.x) * 64 + q * 16 + e);
+      const uint32_t hb = probe_hash(ha + 0x9e3779b9u);
+      a[q][e] = (_Float16)((float)(int)(ha & 0xffff) * (1.0f / 32768.f) - 1.0f);
+      b[q][e] = (_Float16)((float)(int)(hb & 0xffff) * (1.0f / 32768.f) - 1.0f);
+    }
+  f32x16 c[4] = {};
+  float p[4], la = 0.f, lb = 0.f, mx = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) p[e] = 0.25f * (float)((threadIdx.x + e) & 15) - 2.0f;
+  const float sl2 = 0.7f, nref = -0.3f;
+  uint32_t keep = 0;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 1.0f + 0.01f * (float)e;
+  auto ex = [](float x) -> float {
+    float r;
+    if (VARIANT == 2) asm volatile("v_fma_f32 %0, %1, %1, %1" : "=v"(r) : "v"(x));
+    else asm volatile("v_exp_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+  };
+  auto fm = [&](float x) -> float {
+    float r;
+    asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(sl2), "v"(nref));
+    return r;
+  };
+  auto cvt = [](float x, float y) -> uint32_t {
+    uint32_t r;
+    if (VARIANT == 1) {
+      asm volatile("v_fma_mixlo_f16 %0, %1, 1.0, 0" : "=v"(r) : "v"(x));
+      asm volatile("v_fma_mixhi_f16 %0, %1, 1.0, 0" : "+v"(r) : "v"(y));
+    } else if (VARIANT == 7 || VARIANT == 9) {
+      asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    } else {
+      asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    }
+    return r;
+  };
+  auto mixlo = [](float x, uint32_t pk) -> float {
+    float r;
+    asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(x));
+    return r;
+  };
+  auto mixhi = [](float x, uint32_t pk) -> float {
+    float r;
+    asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(x));
+    return r;
+  };
+  auto summax = [&](float e0, float e1) {
+    if (VARIANT == 3) return;
+    asm volatile("s_nop 0\n\tv_add_f32 %0, %0, %3\n\tv_add_f32 %1, %1, %4\n\tv_max3_f32 %2, %2, %3, %4"
+                 : "+v"(la), "+v"(lb), "+v"(mx) : "v"(e0), "v"(e1));
+  };
+#define MFMA_Q(Q) { __builtin_amdgcn_sched_barrier(0); c[Q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[Q], b[(Q + 1) & 3], c[Q], 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
+#define PLAIN(N) { _Pragma("unroll") for (int n_ = 0; n_ < (N); ++n_) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[n_ & 7]) : "v"(sl2), "v"(nref)); }
+  __builtin_amdgcn_s_barrier();
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  // variants 8 / 9: every consumer reads what the round BEFORE produced (arguments -> exps -> planes across three rounds)
+  float qa[4] = {0.f, 0.f, 0.f, 0.f}, qe[4] = {1.f, 1.f, 1.f, 1.f};
+  for (int i = 0; i < iters; ++i) {
+    if (VARIANT == 8 || VARIANT == 9) {
+      float na[4], ne[4];
+      MFMA_Q(0)
+      na[0] = fm(p[0]); na[1] = fm(p[1]); na[2] = fm(p[2]); na[3] = fm(p[3]);
+      ne[0] = ex(qa[0]); ne[1] = ex(qa[1]);
+      MFMA_Q(1)
+      ne[2] = ex(qa[2]); ne[3] = ex(qa[3]);
+      summax(qe[0], qe[1]);
+      const uint32_t paA = cvt(qe[0], qe[1]);
+      MFMA_Q(2)
+      summax(qe[2], qe[3]);
+      const uint32_t paB = cvt(qe[2], qe[3]);
+      const float rA0 = mixlo(qe[0], paA), rA1 = mixhi(qe[1], paA);
+      MFMA_Q(3)
+      const float rB0 = mixlo(qe[2], paB), rB1 = mixhi(qe[3], paB);
+      const uint32_t pqA = cvt(rA0, rA1);
+      const uint32_t pqB = cvt(rB0, rB1);
+      keep ^= paA ^ paB ^ pqA ^ pqB;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { qa[e] = na[e]; qe[e] = ne[e]; }
+    } else if (VARIANT == 5) {
+      MFMA_Q(0) MFMA_Q(1) MFMA_Q(2) MFMA_Q(3)
+    } else if (VARIANT == 4) {
+      MFMA_Q(0) PLAIN(6) MFMA_Q(1) PLAIN(6) MFMA_Q(2) PLAIN(6) MFMA_Q(3) PLAIN(4)
+    } else {
+      float aA0, aA1, aB0, aB1, eA0, eA1, eB0, eB1, rA0, rA1;
+      uint32_t paA, paB;
+      MFMA_Q(0)
+      if (VARIANT == 6) { MFMA_Q(1) MFMA_Q(2) MFMA_Q(3) }
+      aA0 = fm(p[0]); aA1 = fm(p[1]); aB0 = fm(p[2]); aB1 = fm(p[3]);
+      eA0 = ex(aA0); eA1 = ex(aA1);
+      if (VARIANT != 6) MFMA_Q(1)
+      eB0 = ex(aB0); eB1 = ex(aB1);
+      summax(eA0, eA1);
+      paA = cvt(eA0, eA1);
+      if (VARIANT != 6) MFMA_Q(2)
+      summax(eB0, eB1);
+      paB = cvt(eB0, eB1);
+      rA0 = mixlo(eA0, paA); rA1 = mixhi(eA1, paA);
+      if (VARIANT != 6) MFMA_Q(3)
+      const uint32_t pqA = cvt(rA0, rA1);
+      const uint32_t pqB = cvt(mixlo(eB0, paB), mixhi(eB1, paB));
+      keep ^= paA ^ paB ^ pqA ^ pqB;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+#undef MFMA_Q
+#undef PLAIN
+  float s = (float)keep + la + lb + mx;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s += c[0][e] + c[1][e] + c[2][e] + c[3][e];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s += v[e];
+  if (s == 12345.678f) sink[0] = s;
+  if ((threadIdx.x & 63) == 0) cycles[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+}
+
 // Pure-read HBM bandwidth: every workgroup streams its own contiguous slice with `UNROLL` 16-byte loads in flight per
 // lane (nt = streaming loads).  What a read-only kernel can reach on this box (pass C of the fp16 in-batch path reads the
 // B x B probabilities at 3.8 TB/s).
@@ -301,6 +432,14 @@ int esr_probe_mfma_valu(int nv, int nt, int grouped, int waves_per_simd, int wor
   PROBE_CASE(0, 0) PROBE_CASE(1, 0) PROBE_CASE(2, 0) PROBE_CASE(4, 0) PROBE_CASE(6, 0) PROBE_CASE(7, 0)
   PROBE_CASE(8, 0) PROBE_CASE(12, 0) PROBE_CASE(0, 1) PROBE_CASE(0, 2) PROBE_CASE(4, 1) PROBE_CASE(3, 1)
 #undef PROBE_CASE
+#define PROBE_MIX(K)                                                                                         \
+  if (nv == -2 && nt == K) {                                                                                 \
+    mfma_mix_probe_kernel<K><<<grid, block, 0, st>>>(iters, cycles, sink);                                   \
+    return check_launch("esr_probe_mfma_valu");                                                              \
+  }
+  PROBE_MIX(0) PROBE_MIX(1) PROBE_MIX(2) PROBE_MIX(3) PROBE_MIX(4) PROBE_MIX(5) PROBE_MIX(6) PROBE_MIX(7) PROBE_MIX(8)
+  PROBE_MIX(9)
+#undef PROBE_MIX
 #define PROBE_KIND(K)                                                                                        \
   if (nv == -1 && nt == K) {                                                                                 \
     mfma_kind_probe_kernel<K><<<grid, block, 0, st>>>(iters, cycles, sink);                                  \

@@ -33,7 +33,9 @@ int esr_probe_hbm_read(const void* x, int64_t bytes, int workgroups, int nontemp
  * one word per wave): shader-clock cycles of the loop.  Instances: (nv, nt) in {0,1,2,4,6,7,8,12} x {0}, (0,1), (0,2),
  * (4,1), (3,1).  nv = -1: four instructions of ONE kind behind every MFMA, nt = the kind (0 v_fma_f32, 1 v_pk_fma_f32,
  * 2 v_fma_mix_f32, 3 v_cvt_pk_f16_f32, 4 v_max3_f32, 5 v_pk_add_f32, 6 v_exp_f32, 7 / 8 a dependent chain of v_fma_f32 /
- * v_pk_fma_f32, 9 v_exp_f32 -> v_fma_f32 chains). */
+ * v_pk_fma_f32, 9 v_exp_f32 -> v_fma_f32 chains).  nv = -2: the exp / split of the one-plane in-batch kernel between the
+ * four MFMAs of a round, nt = variant (0 as in the kernel, 1 conversions by v_fma_mixlo / mixhi_f16, 2 no v_exp_f32, 3 no
+ * sums / maximum, 4 as many independent v_fma_f32, 5 MFMAs alone, 6 all of it behind the fourth MFMA). */
 int esr_probe_mfma_valu(int nv, int nt, int grouped, int waves_per_simd, int workgroups, int iters,
                         unsigned long long* cycles, float* sink, esr_stream_t stream);
 

@@ -36,3 +36,17 @@ for kind, name in enumerate(names):
         torch.cuda.synchronize()
         row.append(cyc.double().mean().item() / iters)
     print("%-32s %10.1f %10.1f" % (name, row[0], row[1]))
+
+mix = ["as in inbatch1h_kernel (22 VALU per round)", "conversions by v_fma_mixlo / mixhi_f16", "v_exp_f32 -> v_fma_f32",
+       "without the sums and the maximum", "22 independent v_fma_f32", "the four MFMAs alone", "all 22 behind the fourth MFMA",
+       "conversions by v_cvt_pkrtz_f16_f32", "every consumer one round behind its producer", "one round behind + pkrtz"]
+print("the one-plane kernel's exp / split between the four MFMAs of a round:")
+for kind, name in enumerate(mix):
+    row = []
+    for wps in (1, 2):
+        cyc = torch.zeros(256 * 4 * wps, dtype=torch.int64, device=dev)
+        for _ in range(2):
+            _lib.check(lib.esr_probe_mfma_valu(-2, kind, 0, wps, 256, iters, cyc.data_ptr(), sink.data_ptr(), st), "probe")
+        torch.cuda.synchronize()
+        row.append(cyc.double().mean().item() / iters)
+    print("%-46s %10.1f %10.1f" % (name, row[0], row[1]))
