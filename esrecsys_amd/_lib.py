@@ -106,6 +106,7 @@ SIGNATURES = {
     "esr_inbatch_towers_fwd_bwd_f16x2": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_i32p, c_i32p, c_i32p, c_i32p,
                                                  c_i64, c_f32, c_f32, c_f32, c_f32p, c_f32p, c_f32p, c_f32p, c_vp,
                                                  c_size, c_vp]),
+    "esr_inbatch2h_pass_c_forms": (c_int, [c_vp, c_size, c_i64, c_i32p, c_vp]),
     "esr_inbatch_train_step_workspace_bytes": (c_size, [c_i64, c_int]),
     "esr_inbatch_train_step_f16x2": (c_int, [c_vp, c_f32p, c_i64, c_vp, c_f32p, c_i64, c_int, c_int, c_i32p, c_i32p, c_i64,
                                              c_f32, c_f32, c_f32, c_f32, c_f32, c_i32p, c_i32p, c_int, c_f32p, c_f32p,

@@ -143,7 +143,8 @@ __device__ __forceinline__ void sum_max(float& la, float& lb, float& m, float e0
 // banks) and leaves as 256-byte row segments, four rows per instruction.  The caller has made sure (a workgroup
 // barrier) that nobody still reads what `wave_lds` overlays.
 constexpr int kTileLdsBytes = 32 * 272;
-template <class ACC>
+// PERM: tile row n is global row pi(n) = n with bits 2 and 3 swapped (inbatch2h_pct_kernel's tile columns).
+template <bool PERM = false, class ACC>
 __device__ __forceinline__ void store_tile_via_lds(char* wave_lds, const ACC& acc, float* __restrict__ tile_base, int lane) {
   const int j = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -159,7 +160,8 @@ __device__ __forceinline__ void store_tile_via_lds(char* wave_lds, const ACC& ac
     for (int i = 0; i < 8; ++i) {
       const int row = 4 * i + (lane >> 4), piece = lane & 15;
       const float4 v = *reinterpret_cast<const float4*>(wave_lds + row * 272 + piece * 16);
-      *reinterpret_cast<float4*>(tile_base + (int64_t)row * k3D + 64 * half + piece * 4) = v;
+      const int grow = PERM ? ((row & ~12) | ((row & 4) << 1) | ((row & 8) >> 1)) : row;
+      *reinterpret_cast<float4*>(tile_base + (int64_t)grow * k3D + 64 * half + piece * 4) = v;
     }
   }
 }
@@ -368,7 +370,8 @@ __global__ __launch_bounds__(256) void prepsplit2h_kernel(RowSrc X0, RowSrc X1, 
                                                          float* __restrict__ nrm, float* __restrict__ sc,
                                                          unsigned long long* __restrict__ loss_acc,
                                                          int* __restrict__ flags, int nflags,
-                                                         float* __restrict__ copy0, float* __restrict__ copy1) {
+                                                         float* __restrict__ copy0, float* __restrict__ copy1,
+                                                         float* __restrict__ qmax, unsigned* __restrict__ czero) {
   // copy0 / copy1 (optional): the gathered rows as dense f32 [B, ld] matrices.  The overlapped train step updates a tower
   // while the merge launch of the OTHER side still needs that tower's old rows: the merges then read these copies
   __shared__ float red[8];
@@ -380,6 +383,8 @@ __global__ __launch_bounds__(256) void prepsplit2h_kernel(RowSrc X0, RowSrc X1, 
   }
   if (chunk == 1 || nchunks == 1)
     for (int i = t; i < nflags; i += 256) flags[i] = 0;
+  // czero: the per-copy maxima and flags of the scaled-Q copies (fac2h_kernel, scaleq2h_kernel), 16 words
+  if (czero && chunk == 0 && t < 16) czero[t] = 0u;
   const int row = t >> 3, d0 = (t & 7) * 16;
   const int64_t grow = (int64_t)chunk * 32 + row;
   float vq[16], vc[16];
@@ -413,6 +418,12 @@ __global__ __launch_bounds__(256) void prepsplit2h_kernel(RowSrc X0, RowSrc X1, 
   ssq += __shfl_xor(ssq, 1, 64); ssq += __shfl_xor(ssq, 2, 64); ssq += __shfl_xor(ssq, 4, 64);
   ssc += __shfl_xor(ssc, 1, 64); ssc += __shfl_xor(ssc, 2, 64); ssc += __shfl_xor(ssc, 4, 64);
   if ((t & 7) == 0) diag[grow] = dot;
+  if (qmax) {  // largest |element| of the Q row (fac2h_kernel: the scaled copies' exponents)
+    float rq = fmaxf(mq, __shfl_xor(mq, 1, 64));
+    rq = fmaxf(rq, __shfl_xor(rq, 2, 64));
+    rq = fmaxf(rq, __shfl_xor(rq, 4, 64));
+    if ((t & 7) == 0) qmax[grow] = rq;
+  }
 #pragma unroll
   for (int o = 8; o < 64; o <<= 1) {
     ssq = fmaxf(ssq, __shfl_xor(ssq, o, 64));
@@ -662,7 +673,6 @@ __device__ __forceinline__ f16x8 lds_b128(uint32_t addr) {
     const int sw_ = swz16(j);                                                                             \
     f16x8 a1_ = H_S_LD(0, (h ^ sw_) << 4);                                                                \
     f16x8 a2_ = H_S_LD(1, (h ^ sw_) << 4);                                                                \
-    float ek0_ = 0.f, ek1_ = 0.f;                                                                         \
     _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) {                                                    \
       f16x8 n1_ = a1_, n2_ = a2_;                                                                         \
       if (s_ < 7) {                                                                                       \
@@ -690,8 +700,8 @@ __device__ __forceinline__ f16x8 lds_b128(uint32_t addr) {
         pa_ = pk_f16(e0_, e1_);                                                                           \
         l2 = pk_add(l2, f32x2{e0_, e1_});                                                                 \
         emax = __builtin_fmaxf(emax, __builtin_fmaxf(e0_, e1_)); /* v_max3_f32 */                          \
-        /* four consecutive streamed rows (k-steps 2m, 2m + 1) leave as one 16-byte store: see H_P_ST4 */   \
-        if ((s_ & 1) == 0) { ek0_ = e0_; ek1_ = e1_; } else { H_P_ST4(s_ >> 1, ek0_, ek1_, e0_, e1_); }      \
+        /* the lo-plane piece of k-steps 0..3, complete since the previous k-step: see H_P_ST */            \
+        if (s_ == 4) { H_P_ST(1, pw[1][0], pw[1][1], pw[1][2], pw[1][3]); }                                 \
       }                                                                                                   \
       H_SB();                                                                                             \
       SA = H_MFMA(a1_, bx[0][s_], SA);                                                                    \
@@ -700,6 +710,11 @@ __device__ __forceinline__ f16x8 lds_b128(uint32_t addr) {
         const f16x2 pq_ = pk_f16(resid_lo(e0_, pa_), resid_hi(e1_, pa_));                                 \
         pw[0][s_] = __builtin_bit_cast(uint32_t, pa_);                                                    \
         pw[1][s_] = __builtin_bit_cast(uint32_t, pq_);                                                    \
+        if (s_ == 3) { H_P_ST(0, pw[0][0], pw[0][1], pw[0][2], pw[0][3]); }                                 \
+        if (s_ == 7) {                                                                                    \
+          H_P_ST(2, pw[0][4], pw[0][5], pw[0][6], pw[0][7]);                                                \
+          H_P_ST(3, pw[1][4], pw[1][5], pw[1][6], pw[1][7]);                                                \
+        }                                                                                                 \
       }                                                                                                   \
       H_SB();                                                                                             \
       a1_ = n1_; a2_ = n2_;                                                                               \
@@ -798,26 +813,23 @@ __global__ ESR_NO_PK __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2
   const int64_t nch = B / 32;
   const float sl2 = sl2_in * sc[0];  // the planes carry 2^(eq + ec) S
 
-  // The probabilities leave for pass C in the S^T accumulator's own order: lane (a = owned row, h) holds streamed rows
-  // 8 m + 4 h + 0..3 in registers 4 m .. 4 m + 3, so a 32 x 32 tile (streamed chunk jt, owned block it; 4 KB at
-  // (jt * B/32 + it) * 4096) is stored as 16-byte pieces [m][h][a] = P'[8 m + 4 h + 0..3][a]: FOUR fully coalesced 1 KB
-  // stores per chunk and wave (as 16 dword stores to a [streamed][owned] tile, two 128-byte lines each, the stores cost
-  // pass Q 16 us).  The transposition happens on the reading side, in LDS (inbatch2h_pc8_kernel).
+  // The probabilities leave for pass C as the two fp16 planes this kernel forms for its own O^T product (round 6; until
+  // then: the f32 values, multiplied by the row's factor and split again by pass C's VALU).  Lane (a = owned row, h) holds
+  // in pw[plane][4 m' .. 4 m' + 3] the plane's values of streamed rows 16 m' + 8 b + 4 h + c (b = 0, 1, c = 0..3): one
+  // 16-byte piece.  A 32 x 32 tile (streamed chunk jt, owned block it; 4 KB at (jt * B/32 + it) * 4096) is stored as four
+  // 1 KB blocks M = 2 m' + plane, the piece of lane (a, h) at position (a / 8) * 16 + (2 h + a / 4 % 2) * 4 + a % 4 of its
+  // block: FOUR fully coalesced 1 KB stores per chunk and wave (every aligned quad of lanes writes one 64-byte segment).
+  // Pass C copies the blocks to LDS as they are (contiguous 1 KB requests) and takes its MFMA operand from them with the
+  // transposing read: the position formula is what makes those reads bank-conflict-free (inbatch2h_pct_kernel).
   char* pst_u = nullptr;
-  const uint32_t pst_v = (uint32_t)((h * 32 + j) * 16);
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const uint32_t pst_v = (uint32_t)((((j >> 3) * 16) + ((2 * h + ((j >> 2) & 1)) * 4) + (j & 3)) * 16);
 #if defined(H_PROBE_Q_NOSTORE)  /* timing probe only: pass Q without its P stores */
-#define H_P_ST4(M, V0, V1, V2, V3)
+#define H_P_ST(M, V0, V1, V2, V3)
 #else
 // streaming (non-temporal) stores: the B x B probabilities are written once and read once, and at 268 MB (B = 8192) do
 // not fit the 256 MB Infinity Cache anyway
-#if defined(H_PROBE_P34)  /* timing probe only: three quarters of the P traffic (what a 3-byte P would move) */
-#define H_P_ST4(M, V0, V1, V2, V3) \
-  if ((M) != 3) __builtin_nontemporal_store(f32x4{(V0), (V1), (V2), (V3)}, reinterpret_cast<f32x4*>(pst_u + (M) * 1024 + pst_v))
-#else
-#define H_P_ST4(M, V0, V1, V2, V3) \
-  __builtin_nontemporal_store(f32x4{(V0), (V1), (V2), (V3)}, reinterpret_cast<f32x4*>(pst_u + (M) * 1024 + pst_v))
-#endif
+#define H_P_ST(M, V0, V1, V2, V3) \
+  __builtin_nontemporal_store(u32x4{(V0), (V1), (V2), (V3)}, reinterpret_cast<u32x4*>(pst_u + (M) * 1024 + pst_v))
 #endif
 
   f32x16 acc[4];
@@ -870,6 +882,18 @@ __global__ ESR_NO_PK __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2
     }
     refv = fmaxf(m, __shfl_xor(m, 32, 64)) - kHPexp;
   }
+  // The optimistic reference is the SAME for every split of a row (round 6): max(diagonal score, scores against chunk 0)
+  // - 4 -- chunk 0 being split 0's first chunk, the other splits fetch it into the ring's third slot beside their own
+  // first two.  (Until round 6 every split took its own first chunk: as robust, but the splits' references differed and
+  // with them the factor a probability needs in pass C.  With one reference per row the factor is per row, and pass C
+  // streams ONE scaled copy of Q: inbatch2h_pct_kernel.  A workgroup that redoes itself still gets its own reference:
+  // fac2h_kernel / scaleq2h_kernel flag that split.)
+  const bool sample = !fix && mode == 1 && c0 != 0;
+  if (sample) {
+    char* sbuf = lds + 2 * kHBufBytes;
+    H_DP(0, dmah_off0<0>(B, 0, t), sbuf); H_DP(1, dmah_off0<1>(B, 0, t), sbuf);
+    H_DP(2, dmah_off0<2>(B, 0, t), sbuf); H_DP(3, dmah_off0<3>(B, 0, t), sbuf);
+  }
   H_DMA_CHUNK(lds);
   if (nc > 1) H_DMA_CHUNK(lds + kHBufBytes);
   if (!fix && mode == 0) {
@@ -883,13 +907,21 @@ __global__ ESR_NO_PK __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2
   const float dref = (!fix && mode == 1) ? diag[xrow] * sl2_in : -INFINITY;
   H_DMA_BARRIER();
 
+  float msample = dref;
+  if (sample) {
+    H_S_PHASE(lds + 2 * kHBufBytes, sa, false);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) msample = fmaxf(msample, sa[r] * sl2);
+  }
   H_S_PHASE(lds, sa, false);
 #pragma unroll
   for (int r = 0; r < 16; ++r) p[r] = sa[r];
   if (!fix && mode == 1) {
-    float m = dref;
+    float m = msample;
+    if (!sample) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) m = fmaxf(m, sa[r] * sl2);
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, sa[r] * sl2);
+    }
     refv = fmaxf(m, __shfl_xor(m, 32, 64)) - kHOptHead;
   }
   if (h == 0) part_m[(int64_t)split * B + xrow] = refv;  // what merge<Q> adds back
@@ -934,7 +966,6 @@ __global__ ESR_NO_PK __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2
     H_TR_BASES(buf);
 #pragma unroll
     for (int f = 0; f < 8; ++f) trh_frag_n<0>(f, ta2_, trc_);
-    float ek0 = 0.f, ek1 = 0.f;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const f32x2 arg = f32x2{p[2 * s], p[2 * s + 1]} * sl2v + nrefv;
@@ -946,8 +977,13 @@ __global__ ESR_NO_PK __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2
       const f16x2 pq = pk_f16(resid_lo(e0, pa), resid_hi(e1, pa));
       pw[0][s] = __builtin_bit_cast(uint32_t, pa);
       pw[1][s] = __builtin_bit_cast(uint32_t, pq);
-      if ((s & 1) == 0) { ek0 = e0; ek1 = e1; } else { H_P_ST4(s >> 1, ek0, ek1, e0, e1); }
     }
+#pragma unroll
+    for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        H_P_ST(2 * m2 + pl, pw[pl][4 * m2], pw[pl][4 * m2 + 1], pw[pl][4 * m2 + 2], pw[pl][4 * m2 + 3]);
+      }
     H_O_PHASE(false, lds);
   }
   };  // sweep
@@ -963,7 +999,7 @@ __global__ ESR_NO_PK __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2
       sweep(std::true_type{});
     }
   }
-#undef H_P_ST4
+#undef H_P_ST
   H_TIMING_WRITE(H_TIMING_Q);
   float* orow = part_O + ((int64_t)split * B + xrow) * k3D;
 #pragma unroll
@@ -977,272 +1013,6 @@ __global__ ESR_NO_PK __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2
   if (h == 0) part_l[(int64_t)split * B + xrow] = ltot;
   // a probability that does not fit fp16 (or a forced redo: mode 2 is the test hook): the FIX launch redoes this block
   if (KIND == 0 && (mode == 2 || !(emax <= kHOverflow))) flags[blockIdx.x] = 1;
-}
-
-// -----------------------------------------------------------------------------------------------------------------
-// Pass Q, 64 owned rows per wave (inbatch2h_q2_kernel; B % 256 == 0): two 32-row sets u = 0, 1 share every A fragment
-// read from LDS -- S^T: 6 MFMAs per pair of ds_read_b128, O^T: 8 per fragment -- and the four waves of a workgroup (256
-// rows) share a plane tile, so LDS reads and DMA traffic per MFMA are half those of inbatch2h_q_kernel.  The step runs at
-// the package power cap: bytes moved per MFMA are time.  One wave per SIMD (B operands 128, O^T
-// accumulators 128 registers), everything else as in inbatch2h_q_kernel.
-// -----------------------------------------------------------------------------------------------------------------
-#define Q2_S_PHASE(NBUF, VALU_ON)                                                                         \
-  {                                                                                                       \
-    _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_)                                                      \
-      _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) sa[u_][r_] = 0.f;                                 \
-    const uint32_t ap32_ = lds32 + (uint32_t)((NBUF) - lds) + (uint32_t)(j * 256);                        \
-    const int sw_ = swz16(j);                                                                             \
-    f16x8 a1_ = lds_b128<0>(ap32_ + (uint32_t)((h ^ sw_) << 4));                                          \
-    f16x8 a2_ = lds_b128<kPlaneBytes>(ap32_ + (uint32_t)((h ^ sw_) << 4));                                \
-    float ek_[2][2] = {{0.f, 0.f}, {0.f, 0.f}};                                                           \
-    _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) {                                                    \
-      f16x8 n1_ = a1_, n2_ = a2_;                                                                         \
-      if (s_ < 7) {                                                                                       \
-        const uint32_t off_ = (uint32_t)(((2 * (s_ + 1) + h) ^ sw_) << 4);                                \
-        n1_ = lds_b128<0>(ap32_ + off_);                                                                  \
-        n2_ = lds_b128<kPlaneBytes>(ap32_ + off_);                                                        \
-      }                                                                                                   \
-      float e_[2][2] = {{0.f, 0.f}, {0.f, 0.f}};                                                          \
-      f16x2 pa_[2] = {{0, 0}, {0, 0}};                                                                    \
-      H_SB();                                                                                             \
-      H_S_WAIT((s_ < 7 ? 2 : 0) + (((VALU_ON) && s_ >= 1) ? 2 : 0));                                      \
-      H_SB();                                                                                             \
-      sa[0] = H_MFMA(a2_, bx[0][0][s_], sa[0]);                                                           \
-      sa[1] = H_MFMA(a2_, bx[1][0][s_], sa[1]);                                                           \
-      H_SB();                                                                                             \
-      if (VALU_ON) {                                                                                      \
-        _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_) {                                                \
-          const f32x2 arg_ = pk_fma(f32x2{p[u_][2 * s_], p[u_][2 * s_ + 1]}, sl2v, nrefv[u_]);            \
-          e_[u_][0] = __builtin_amdgcn_exp2f(arg_[0]);                                                    \
-          e_[u_][1] = __builtin_amdgcn_exp2f(arg_[1]);                                                    \
-        }                                                                                                 \
-        trh_frag_n<0>(s_, ta2_, trc_);                                                                    \
-      }                                                                                                   \
-      H_SB();                                                                                             \
-      sa[0] = H_MFMA(a1_, bx[0][1][s_], sa[0]);                                                           \
-      sa[1] = H_MFMA(a1_, bx[1][1][s_], sa[1]);                                                           \
-      H_SB();                                                                                             \
-      if (VALU_ON) {                                                                                      \
-        _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_) {                                                \
-          pa_[u_] = pk_f16(e_[u_][0], e_[u_][1]);                                                         \
-          l2[u_] = pk_add(l2[u_], f32x2{e_[u_][0], e_[u_][1]});                                           \
-          emax = __builtin_fmaxf(emax, __builtin_fmaxf(e_[u_][0], e_[u_][1]));                            \
-          if ((s_ & 1) == 0) { ek_[u_][0] = e_[u_][0]; ek_[u_][1] = e_[u_][1]; }                          \
-          else { Q2_P_ST4(u_, s_ >> 1, ek_[u_][0], ek_[u_][1], e_[u_][0], e_[u_][1]); }                   \
-        }                                                                                                 \
-      }                                                                                                   \
-      H_SB();                                                                                             \
-      sa[0] = H_MFMA(a1_, bx[0][0][s_], sa[0]);                                                           \
-      sa[1] = H_MFMA(a1_, bx[1][0][s_], sa[1]);                                                           \
-      H_SB();                                                                                             \
-      if (VALU_ON) {                                                                                      \
-        _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_) {                                                \
-          const f16x2 pq_ = pk_f16(resid_lo(e_[u_][0], pa_[u_]), resid_hi(e_[u_][1], pa_[u_]));           \
-          pw[u_][0][s_] = __builtin_bit_cast(uint32_t, pa_[u_]);                                          \
-          pw[u_][1][s_] = __builtin_bit_cast(uint32_t, pq_);                                              \
-        }                                                                                                 \
-      }                                                                                                   \
-      H_SB();                                                                                             \
-      a1_ = n1_; a2_ = n2_;                                                                               \
-    }                                                                                                     \
-    if (VALU_ON) { pst_u[0] += nch * 4096; pst_u[1] += nch * 4096; }                                      \
-  }
-#define Q2_O_ROW(PL_A, PL_P, G)                                                                           \
-  _Pragma("unroll") for (int db_ = 0; db_ < 4; ++db_) {                                                   \
-    acc[0][db_] = H_MFMA(ta2_[G][db_][PL_A], pb[0][PL_P][G], acc[0][db_]);                                \
-    acc[1][db_] = H_MFMA(ta2_[G][db_][PL_A], pb[1][PL_P][G], acc[1][db_]);                                \
-  }
-#define Q2_O_PHASE(DMA_ON, DBUF)                                                                          \
-  {                                                                                                       \
-    f16x8 pb[2][2][2];                                                                                    \
-    _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_)                                                      \
-      _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_)                                                    \
-        _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_) {                                                \
-          const u32x4 v_ = {pw[u_][q_][4 * g_], pw[u_][q_][4 * g_ + 1], pw[u_][q_][4 * g_ + 2],           \
-                            pw[u_][q_][4 * g_ + 3]};                                                      \
-          pb[u_][q_][g_] = __builtin_bit_cast(f16x8, v_);                                                 \
-        }                                                                                                 \
-    H_TR_WAIT();                                                                                          \
-    H_SB(); Q2_O_ROW(1, 0, 0); H_SB(); H_O_G1(0, 3); if (DMA_ON) { H_DP(0, g0, DBUF); }                   \
-    H_SB(); Q2_O_ROW(0, 1, 0); H_SB(); H_O_G1(3, 6); if (DMA_ON) { H_DP(1, g1, DBUF); }                   \
-    H_SB(); Q2_O_ROW(0, 0, 0); H_SB(); H_O_G1(6, 8); if (DMA_ON) { H_DP(2, g2, DBUF); }                   \
-    H_TR_WAIT();                                                                                          \
-    H_SB(); Q2_O_ROW(1, 0, 1); H_SB(); if (DMA_ON) { H_DP(3, g3, DBUF); }                                 \
-    H_SB(); Q2_O_ROW(0, 1, 1); H_SB();                                                                    \
-    H_SB(); Q2_O_ROW(0, 0, 1); H_SB();                                                                    \
-    if (DMA_ON) H_DMA_ADVANCE();                                                                          \
-  }
-template <bool FIX>
-__global__ ESR_NO_PK __launch_bounds__(256) void inbatch2h_q2_kernel(const _Float16* __restrict__ Xr, const _Float16* __restrict__ Yr,
-                                                          int64_t B, int nsplit, float sl2_in,
-                                                          const float* __restrict__ sc, const float* __restrict__ diag,
-                                                          int mode, int* __restrict__ flags, float* __restrict__ part_m,
-                                                          float* __restrict__ part_O, float* __restrict__ part_l,
-                                                          float* __restrict__ Pmat) {
-  __shared__ __attribute__((aligned(16))) char lds[kHBufs * kHBufBytes];
-  if (FIX && flags[blockIdx.x] == 0) return;
-  const int t = threadIdx.x, lane = t & 63;
-  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int j = lane & 31, h = lane >> 5;
-  H_TR_SETUP();
-  const uint32_t lds32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds;
-  const int ob = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
-  int64_t xrow[2];
-  xrow[0] = (int64_t)ob * 256 + w * 64 + j;
-  xrow[1] = xrow[0] + 32;
-  const int nc = (int)(B / k3Chunk) / nsplit;
-  const int64_t c0 = (int64_t)split * nc;
-  const int64_t nch = B / 32;
-  const float sl2 = sl2_in * sc[0];
-  char* pst_u[2];
-  pst_u[0] = reinterpret_cast<char*>(Pmat) + (c0 * nch + (xrow[0] >> 5)) * 4096;
-  pst_u[1] = pst_u[0] + 4096;
-  const uint32_t pst_v = (uint32_t)((h * 32 + j) * 16);
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
-#define Q2_P_ST4(U, M, V0, V1, V2, V3) \
-  __builtin_nontemporal_store(f32x4{(V0), (V1), (V2), (V3)}, reinterpret_cast<f32x4*>(pst_u[U] + (M) * 1024 + pst_v))
-
-  f32x16 acc[2][4];
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[u][db][r] = 0.f;
-  f32x2 l2[2] = {{0.f, 0.f}, {0.f, 0.f}};
-
-  int dpos = 0;
-  const char* const baseY = reinterpret_cast<const char*>(Yr);
-  uint32_t g0 = dmah_off0<0>(B, c0, t), g1 = dmah_off0<1>(B, c0, t), g2 = dmah_off0<2>(B, c0, t),
-           g3 = dmah_off0<3>(B, c0, t);
-  f16x8 bx[2][2][8];
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-      for (int s = 0; s < 8; ++s)
-        bx[u][p][s] = *reinterpret_cast<const f16x8*>(Xr + ((int64_t)p * B + xrow[u]) * k3D + 16 * s + 8 * h);
-  f32x16 sa[2];
-  float p[2][16];
-  uint32_t pw[2][2][8];
-  f16x8 ta2_[2][4][2];
-  float emax = 0.f;
-  float refv[2] = {-INFINITY, -INFINITY};
-  const f32x2 sl2v = {sl2, sl2};
-  f32x2 nrefv[2] = {{0.f, 0.f}, {0.f, 0.f}};
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) p[u][r] = 0.f;
-  if (FIX) {
-    float m[2] = {-INFINITY, -INFINITY};
-    for (int c = 0; c < nc; ++c) {
-      H_DMA_CHUNK(lds);
-      H_DMA_BARRIER();
-      Q2_S_PHASE(lds, false);
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) m[u] = fmaxf(m[u], sa[u][r] * sl2);
-      __syncthreads();
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) refv[u] = fmaxf(m[u], __shfl_xor(m[u], 32, 64)) - kHPexp;
-  }
-  H_DMA_CHUNK(lds);
-  if (nc > 1) H_DMA_CHUNK(lds + kHBufBytes);
-  float dref[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) dref[u] = (!FIX) ? diag[xrow[u]] * sl2_in : -INFINITY;
-  H_DMA_BARRIER();
-
-  Q2_S_PHASE(lds, false);
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) p[u][r] = sa[u][r];
-    if (!FIX) {
-      float m = dref[u];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) m = fmaxf(m, sa[u][r] * sl2);
-      refv[u] = fmaxf(m, __shfl_xor(m, 32, 64)) - kHOptHead;
-    }
-    if (h == 0) part_m[(int64_t)split * B + xrow[u]] = refv[u];
-    nrefv[u] = f32x2{-refv[u], -refv[u]};
-  }
-
-  int cur = 0;
-  for (int it = 0; it + 2 < nc; ++it) {
-    const int nxt = cur == kHBufs - 1 ? 0 : cur + 1;
-    const int nn = nxt == kHBufs - 1 ? 0 : nxt + 1;
-    H_DMA_BARRIER();
-    const char* buf = lds + cur * kHBufBytes;
-    const char* nbuf = lds + nxt * kHBufBytes;
-    char* dbuf = lds + nn * kHBufBytes;
-    H_TR_BASES(buf);
-    Q2_S_PHASE(nbuf, true);
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) p[u][r] = sa[u][r];
-    Q2_O_PHASE(true, dbuf);
-    cur = nxt;
-  }
-  if (nc >= 2) {
-    const int nxt = cur == kHBufs - 1 ? 0 : cur + 1;
-    H_DMA_BARRIER();
-    const char* buf = lds + cur * kHBufBytes;
-    const char* nbuf = lds + nxt * kHBufBytes;
-    H_TR_BASES(buf);
-    Q2_S_PHASE(nbuf, true);
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) p[u][r] = sa[u][r];
-    Q2_O_PHASE(false, lds);
-    cur = nxt;
-  }
-  {  // last chunk: nothing left to prefetch; run its exp / split alone
-    H_DMA_BARRIER();
-    const char* buf = lds + cur * kHBufBytes;
-    H_TR_BASES(buf);
-#pragma unroll
-    for (int f = 0; f < 8; ++f) trh_frag_n<0>(f, ta2_, trc_);
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      float ek0 = 0.f, ek1 = 0.f;
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const f32x2 arg = f32x2{p[u][2 * s], p[u][2 * s + 1]} * sl2v + nrefv[u];
-        const float e0 = __builtin_amdgcn_exp2f(arg[0]);
-        const float e1 = __builtin_amdgcn_exp2f(arg[1]);
-        l2[u] += f32x2{e0, e1};
-        emax = fmaxf(emax, fmaxf(e0, e1));
-        const f16x2 pa = pk_f16(e0, e1);
-        const f16x2 pq = pk_f16(resid_lo(e0, pa), resid_hi(e1, pa));
-        pw[u][0][s] = __builtin_bit_cast(uint32_t, pa);
-        pw[u][1][s] = __builtin_bit_cast(uint32_t, pq);
-        if ((s & 1) == 0) { ek0 = e0; ek1 = e1; } else { Q2_P_ST4(u, s >> 1, ek0, ek1, e0, e1); }
-      }
-    }
-    Q2_O_PHASE(false, lds);
-  }
-#undef Q2_P_ST4
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    float* orow = part_O + ((int64_t)split * B + xrow[u]) * k3D;
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4*>(orow + 32 * db + 8 * q + 4 * h) =
-            make_float4(acc[u][db][4 * q], acc[u][db][4 * q + 1], acc[u][db][4 * q + 2], acc[u][db][4 * q + 3]);
-    const float l = l2[u][0] + l2[u][1];
-    const float ltot = l + __shfl_xor(l, 32, 64);
-    if (h == 0) part_l[(int64_t)split * B + xrow[u]] = ltot;
-  }
-  if (!FIX && (mode == 2 || !(emax <= kHOverflow))) flags[blockIdx.x] = 1;
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -1570,14 +1340,30 @@ __global__ ESR_NO_PK __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2
   if (QSIDE) {                                                                                 \
     if (!fix) {                                                                                \
       float m_ = (DREF);                                                                       \
-      _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) m_ = fmaxf(m_, sa[r_] * sl2);          \
+      if (!sample) {                                                                           \
+        _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) m_ = fmaxf(m_, sa[r_] * sl2);        \
+      }                                                                                        \
       refv = fmaxf(m_, __shfl_xor(m_, 32, 64)) - kHOptHead;                                    \
     }                                                                                          \
     if (h == 0 && live) part_m[(int64_t)split * B + xrow] = refv;                              \
     nref1 = -refv;                                                                             \
   }
+    // the optimistic reference of a row is the same for every split: max(diagonal score, scores against chunk 0) - 4
+    // (inbatch2h_q_kernel: the two kernels agree bit for bit on bf16-valued rows); splits other than 0 fetch chunk 0 too
+    const bool sample = QSIDE && !fix && c0 != 0;
+#define H1_SAMPLE_MAX(BUF, M)                                                                  \
+  {                                                                                            \
+    H1_S_PHASE(BUF, sa);                                                                       \
+    _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) M = fmaxf(M, sa[r_] * sl2);              \
+  }
     if (DBG == 1) {  // debugging aid: one chunk at a time, nothing pipelined
-      const float dref0 = (QSIDE && !fix) ? diag[xrow] * sl2_in : -INFINITY;
+      float dref0 = (QSIDE && !fix) ? diag[xrow] * sl2_in : -INFINITY;
+      if (sample) {
+        H1_DP(0, dmah8_off0<0>(B, 0, t), lds);
+        H_DMA_BARRIER();
+        H1_SAMPLE_MAX(lds, dref0);
+        __syncthreads();
+      }
       for (int c = 0; c < nc; ++c) {
         H1_DMA_CHUNK(lds);
         H_DMA_BARRIER();
@@ -1597,8 +1383,10 @@ __global__ ESR_NO_PK __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2
     H1_DMA_CHUNK(lds);
     if (nc > 1) H1_DMA_CHUNK(lds + kH1BufBytes);
     if (nc > 2) H1_DMA_CHUNK(lds + 2 * kH1BufBytes);
-    const float dref = (QSIDE && !fix) ? diag[xrow] * sl2_in : -INFINITY;
+    if (sample) H1_DP(0, dmah8_off0<0>(B, 0, t), lds + 3 * kH1BufBytes);  // (the ring's fourth slot: free until chunk 3)
+    float dref = (QSIDE && !fix) ? diag[xrow] * sl2_in : -INFINITY;
     H_DMA_BARRIER();
+    if (sample) H1_SAMPLE_MAX(lds + 3 * kH1BufBytes, dref);
     H1_S_PHASE(lds, sa);
     H1_TAKE_SCORES();
     H1_FIRST_CHUNK_REF(dref);
@@ -1685,331 +1473,342 @@ __global__ ESR_NO_PK __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2
 }
 
 // -----------------------------------------------------------------------------------------------------------------
-// Pass C: owned = C rows j, streamed = Q rows i; reads the P' tiles of pass Q and the factors 2^14 2^(M_split - M) / l'_i
-// of merge<Q>, forms the true probabilities * 2^14 in two fp16 planes and runs the O^T phase alone (24 MFMAs per chunk
-// and wave), software-pipelined like inbatch3_pc_kernel.  One 512-thread workgroup owns 256 rows: a plane tile is
-// fetched once for eight waves (two DMA instructions per wave and chunk).  The P' tiles come through LDS too: pass Q
-// stored them in ITS register order (16-byte pieces [m][h][a] = P'[streamed 8 m + 4 h + 0..3][owned a]); here the
-// roles are swapped -- this lane's owned row j is pass Q's streamed row (m, h, c) = (j / 8, j / 4 % 2, j % 4), and it
-// needs the 16 values of pass Q's owned rows a = 8 g + 4 h' + e.  The tile lands in LDS as 16-byte pieces (piece index
-// XOR-swizzled on the source side so that the 32 lanes of a half wave, which differ in (m, h, c), fall on 32 banks) and
-// the transposition is sixteen ds_read_b32.  Two ways into LDS (template parameter STAGE, see the kernel).
-// Clock and phases: scripts/gpu_ib2h_timing.sh (-DH_TIMING=2); read ceiling of the box: esr_probe_hbm_read (7.0-7.2
-// TB/s -- the "4.0 TB/s read bound" of earlier notes was torch.sum's rate).
+// Pass C (round 6): owned = C rows j, streamed = Q rows i:  dC_j = sum_i p_ij q_i,  p_ij = P'_ij f_{i,s}  with P' the
+// probabilities pass Q stored and f_{i,s} = 2^14 2^(M_s - M) / l_i the factor of streamed row i for the pass-Q split s
+// that row j lies in (fac2h_kernel).  Until round 6 this pass multiplied every P' by its factor and split the product
+// into two fp16 planes again -- 16 ds_read_b32, 16 multiplies and 48 conversion instructions per chunk and wave beside
+// 24 MFMAs, matrix pipes 33 % busy.  Now the factor sits on the OTHER operand:
+//     dC_j = sum_i P'_ij (f_{i,s} q_i)
+// scaleq2h_kernel leaves one scaled copy of Q per pass-Q split, x' = f_{.,s} q 2^E_s in two fp16 planes (E_s from the
+// copy's largest |element|), a workgroup's 256 owned rows lie in ONE pass-Q split (host: nc_q % 8 == 0, else the general
+// form below), and the stored planes of P' ARE the MFMA's B operand:
+//   * the P' tile of (this wave's 32 owned rows, chunk) -- wave-private, 4 KB -- comes by LDS-DMA into a 3-slot ring of the
+//     wave's own as four contiguous 1 KB blocks (plane, m') in pass Q's piece order (with every lane fetching the piece
+//     that makes the LDS image a plain row-major matrix -- 16-byte pieces 512 B apart from neighbouring lanes -- the pass
+//     took 65 us against 56 with contiguous requests), and is read with ds_read_b64_tr_b16: 8 reads per chunk, no VALU
+//     instruction at all.  A transposing read touches 4 rows i x 2 m' x 2 h_q pieces per half wave: pass Q's position
+//     formula puts the (h_q, i / 4 % 2) combinations on the four 64-byte columns of a 256-byte row, and the m' = 1 blocks
+//     sit 64 bytes further on in LDS -- the 32 lanes cover all 64 banks;
+//   * the slot is free as soon as those 8 reads have returned: the tile of chunk it + 3 is requested into it -- three
+//     tiles (96 KB per CU) in flight or waiting, which is what keeps the 268 MB stream at the HBM rate;
+//   * tile column n holds owned row pi(n) = n with bits 2 and 3 swapped (the order pass Q's accumulators hold them in):
+//     the output tile is stored with its rows permuted.
+// The partial O' rows are rescaled to the unit the merges expect (2^(eq + 14) sum p q) by one exact power of two per
+// workgroup (cexp).
+// GENERAL form (GEN, chosen per workgroup at run time): streams the UNSCALED planes of Q and applies the factors to the
+// B fragments in registers (hi + lo is exact in f32; multiply, split again -- the arithmetic of the round-5 kernel).  Taken
+// when the geometry does not give a workgroup one split (small batches), and when scaleq2h_kernel raised the copy's flag:
+// a live row of the copy lies more than ~17 binades under the copy's largest element, where its second plane would fall
+// into fp16's subnormals (rows with very different normalisers in one batch).
 // -----------------------------------------------------------------------------------------------------------------
-#if defined(H_PROBE_PC_NOSPLIT)  /* timing probe only: pass C without the fp16 split of its probabilities */
-#define H_PC_SPLIT1(PW, S) { PW[0][S] = __float_as_uint(p1[2 * (S)]); PW[1][S] = __float_as_uint(rf[2 * (S) + 1]); }
+#if defined(CT_PROBE_P_DUMMY)  /* timing probe only (values wrong): no P' stream, every tile request hits the cache */
+#define CT_PROBE_DUMMY 1
 #else
-#define H_PC_SPLIT1(PW, S)                                                                                \
-  {                                                                                                       \
-    const float e0_ = p1[2 * (S)] * rf[2 * (S)], e1_ = p1[2 * (S) + 1] * rf[2 * (S) + 1];                 \
-    const f16x2 pa_ = pk_f16(e0_, e1_);                                                                   \
-    const f16x2 pq_ = pk_f16(resid_lo(e0_, pa_), resid_hi(e1_, pa_));                                     \
-    PW[0][S] = __builtin_bit_cast(uint32_t, pa_);                                                         \
-    PW[1][S] = __builtin_bit_cast(uint32_t, pq_);                                                         \
+#define CT_PROBE_DUMMY 0
+#endif
+#if defined(CT_PROBE_NO_P) || defined(CT_PROBE_NO_DMA)  /* timing probes only (values wrong): no tile requests / none at all */
+#define CT_PROBE_NOP 1
+#else
+#define CT_PROBE_NOP 0
+#endif
+#if defined(CT_PROBE_NO_DMA)
+#define CT_PROBE_NOY 1
+#else
+#define CT_PROBE_NOY 0
+#endif
+#ifndef CT_P_IN_LOAD
+#define CT_P_IN_LOAD 4  /* how many of a chunk's four tile requests LOAD issues (the rest: between COMPUTE's rows) */
+#endif
+constexpr int kCtRing = 3;
+constexpr int kCtYSlot = 2 * kPlaneBytes + 8 * 256;  // two planes + 256 B of factors per wave (general form)
+constexpr int kCtPOff = kCtRing * kCtYSlot;          // the waves' private P' rings behind the plane ring
+constexpr int kCtPSlot = 4096 + 64;                  // a P' tile: blocks at 0, 1024, 2048 + 64, 3072 + 64 (see above)
+constexpr int kCtPWave = kCtRing * kCtPSlot;
+constexpr int kCtLds = kCtPOff + 8 * kCtPWave;       // 150 KB of the CU's 160
+constexpr int kCtOwned = 256;
+constexpr float kCtLive = 0.0625f;                   // a row's largest |x'| below 2^-4: second plane subnormal (see above)
+#ifndef H_P_LOAD_AUX
+#define H_P_LOAD_AUX 2  /* cache-policy bits of the P' tile loads: nt (see H_P_ST); 0 for an A/B build */
+#endif
+
+// A fragment F (0..7: plane (F / 4 + 1) % 2, column block F % 4) of k-step G from the plane tile at SLOTOFF
+template <int G, int F, int SLOTOFF, class TA>
+__device__ __forceinline__ void ct_frag(TA& ta, const uint32_t (&tb)[4][2]) {
+  constexpr int PL = (F / 4 + 1) % 2, DB = F % 4, OFF = SLOTOFF + PL * kPlaneBytes + 16 * G * 256;
+  const s16x4 lo = tr_read<OFF>(tb[DB][0]), hi = tr_read<OFF>(tb[DB][1]);
+  const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  ta[G][DB][PL] = __builtin_bit_cast(f16x8, both);
+}
+template <int G, int SLOTOFF, class TA>
+__device__ __forceinline__ void ct_frag_n(int f, TA& ta, const uint32_t (&tb)[4][2]) {  // f is an unrolled constant
+  switch (f) {
+    case 0: ct_frag<G, 0, SLOTOFF>(ta, tb); break;
+    case 1: ct_frag<G, 1, SLOTOFF>(ta, tb); break;
+    case 2: ct_frag<G, 2, SLOTOFF>(ta, tb); break;
+    case 3: ct_frag<G, 3, SLOTOFF>(ta, tb); break;
+    case 4: ct_frag<G, 4, SLOTOFF>(ta, tb); break;
+    case 5: ct_frag<G, 5, SLOTOFF>(ta, tb); break;
+    case 6: ct_frag<G, 6, SLOTOFF>(ta, tb); break;
+    default: ct_frag<G, 7, SLOTOFF>(ta, tb); break;
   }
-#endif
-#if defined(H_PROBE_PC_NOFRAG)  /* timing probe only: pass C without the transposing fragment reads (stale A operands) */
-#define H_PC_NEXT_G0(F0, F1)
-#else
-#define H_PC_NEXT_G0(F0, F1) { _Pragma("unroll") for (int f_ = (F0); f_ < (F1); ++f_) trh_frag_n<0>(f_, ta2_, trn_); }
-#endif
-constexpr int kPc8Wave = 4096 + 256;  // without STAGE: three ring slots of 2 planes + 8 of these are 150 KB of the CU's 160
-constexpr int kPc8Owned = 256;
-// STAGE (default): the P' tiles go through REGISTERS on their way to LDS -- four coalesced 16-byte loads per lane and
-// chunk issued three chunks ahead, written to a wave-private 4 KB LDS tile one chunk before use.  As LDS-DMAs into the
-// 3-slot ring they could only be one chunk ahead (the slot of chunk it + 1 is read during iteration it), every barrier
-// waited for them (vmcnt(0)), and the pass ran at 3.8 TB/s of the 7.0-7.2 TB/s a read-only kernel reaches on the box
-// (esr_probe_hbm_read): a burst per iteration, then the wait for its tail.  With the staged loads the ring holds
-// planes and factors only, has four slots (fetched three chunks ahead) and its barrier waits vmcnt(7): everything the
-// previous iteration issued stays in flight across it.
-#if defined(H_PC8_ALLOW_PK)
-#define ESR_PC8_PK
-#else
-#define ESR_PC8_PK ESR_NO_PK
-#endif
-template <bool STAGE>
-__global__ ESR_PC8_PK __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Float16* __restrict__ Yr, int64_t B, int nsplit,
-                                                           const float* __restrict__ fac, int nc_q,
-                                                           const float* __restrict__ Pmat,
-                                                           float* __restrict__ part_O) {
-  constexpr int kWaveArea = STAGE ? 256 : kPc8Wave;               // per-wave part of a ring slot: factors (+ P' tile)
-  constexpr int kBuf = 2 * kPlaneBytes + 8 * kWaveArea;           // ring slot
-  constexpr int kFacOff = STAGE ? 0 : 4096;                       // factors inside the per-wave part
-  // STAGE: a 4-slot ring, planes and factors fetched THREE chunks ahead.  Two ahead (3 slots), the DMAs issued during
-  // iteration it were needed right after the barrier that ends it: the stamps (H_TIMING=2) showed 1042 of 3001 cycles
-  // per iteration waiting there.
-  constexpr int kRing = STAGE ? 4 : kHBufs;
-  constexpr int kAheadSlots = kRing - 1;
-  constexpr int kPArea = kRing * kBuf;                            // STAGE: the wave-private P' tiles behind the ring
-  __shared__ __attribute__((aligned(16))) char lds[kRing * kBuf + (STAGE ? 8 * 4096 : 0)];
+}
+// B fragment (plane PL, k-step G) of the P' tile in ring slot offset SLOTOFF: rows 16 G + 4 h + 0..3 and + 8
+template <int PL, int G, int SLOTOFF>
+__device__ __forceinline__ f16x8 ct_pfrag(uint32_t pbase) {
+  constexpr int OFF = SLOTOFF + PL * 1024 + G * 512;  // (rows 8 r + 4 h + 0..3 of k-step G: 256-byte row 2 G + r of a block)
+  const s16x4 lo = tr_read<OFF>(pbase), hi = tr_read<OFF + 256>(pbase);
+  const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(f16x8, both);
+}
+
+__global__ ESR_NO_PK __launch_bounds__(512) void inbatch2h_pct_kernel(
+    const _Float16* __restrict__ Yt, const _Float16* __restrict__ Yh, int64_t B, int nsplit,
+    const float* __restrict__ fac, int nc_q, const char* __restrict__ Pt, const float* __restrict__ cexp,
+    const int* __restrict__ cflags, int force_general, float* __restrict__ part_O) {
+  constexpr int kLdsBytes = kCtLds > 8 * kTileLdsBytes ? kCtLds : 8 * kTileLdsBytes;
+  __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];  // the rings; at the end the waves' output tiles
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int j = lane & 31, h = lane >> 5;
+  (void)j;
   H_TR_SETUP();
+  (void)trc_;
   const int ob = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
-  const int64_t wrow = (int64_t)ob * kPc8Owned + w * 32;
+  const int64_t wrow = (int64_t)ob * kCtOwned + w * 32;
   const bool live = wrow < B;  // B is a multiple of 128: the last block's upper four waves may own nothing
-  const int64_t xrow = wrow + j;
   const int nc = (int)(B / k3Chunk) / nsplit;
   const int64_t c0 = (int64_t)split * nc;
   const int64_t nch = B / 32;
   const int64_t jt = live ? (wrow >> 5) : 0;  // (idle waves fetch block 0's tiles: valid addresses, results dropped)
-  const float* ref = fac + (int64_t)(jt / nc_q) * B;
-  const char* const pw_base = reinterpret_cast<const char*>(Pmat) + (jt * nch + c0) * 4096;
-  // LDS piece u = mh * 32 + x holds tile piece (mh, a = x ^ mh) (mh = 2 m + h of pass Q): DMA instruction G4 writes
-  // pieces u = 64 G4 + lane, i.e. mh = 2 G4 + lane / 32, x = lane % 32.  (The swizzle was x ^ 2 mh until round 5: right
-  // for 64 banks, but a ds_read_b32 sees 32 -- the eight pieces of a 128-byte window -- and 2 mh mod 8 takes four values
-  // for the eight mh of a half wave: every one of the 16 reads per lane and chunk was a two-way bank conflict,
-  // SQ_LDS_BANK_CONFLICT = 2.1 M cycles per launch.)
+  // workgroup-uniform: the flags of the pass-Q splits its eight waves' rows lie in
+  bool general = force_general != 0;
+  if (!general) {
+    const int s_lo = (int)(((int64_t)ob * (kCtOwned / 32)) / nc_q);
+    const int s_hi = (int)(min((int64_t)ob * (kCtOwned / 32) + (kCtOwned / 32 - 1), nch - 1) / nc_q);
+    for (int sq = s_lo; sq <= s_hi; ++sq) general = general || cflags[sq] != 0;
+  }
+  const float* ref = fac + (int64_t)(jt / nc_q) * B;               // general form: this WAVE's factors
+  const char* const pw_base = Pt + (jt * nch + c0) * 4096;
+  const uint32_t lds32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds;
+  // tile block G4 = 2 m' + plane: 1 KB, lane-linear
   uint32_t p_off[4];
 #pragma unroll
-  for (int g4 = 0; g4 < 4; ++g4) {
-    const int mh = 2 * g4 + (lane >> 5);
-    p_off[g4] = (uint32_t)((mh * 32 + ((lane & 31) ^ mh)) * 16);
-  }
-  const int wave_off = 2 * kPlaneBytes + w * kWaveArea;
-  const uint32_t lds32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds;
-  (void)lds32;
+  for (int g4 = 0; g4 < 4; ++g4) p_off[g4] = (uint32_t)(g4 * 1024 + lane * 16);
+  // transposing reads of the tile: lane 16 (2 h + jb) + 4 a + e reads 8 bytes (half e % 2) of piece (row 16 G + 8 r +
+  // 4 h + a, m' = jb, h_q = e / 2): block m' (2048 + 64 bytes apart), 256-byte row 2 G + r (the immediate offset),
+  // 64-byte column 2 h_q + h, 16-byte piece a
+  const uint32_t pbase = lds32 + (uint32_t)(kCtPOff + w * kCtPWave + ((lane >> 4) & 1) * (2048 + 64) +
+                                            (2 * ((lane & 3) >> 1) + h) * 64 + tr_a * 16 + (lane & 1) * 8);
+  const uint32_t rbase = lds32 + (uint32_t)(2 * kPlaneBytes + w * 256 + 16 * h);  // general form: factors of a slot
 
   f32x16 acc[4];
 #pragma unroll
   for (int db = 0; db < 4; ++db)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[db][r] = 0.f;
-
-  int dpos = 0;
-  const char* const baseY = reinterpret_cast<const char*>(Yr);
-  uint32_t g0 = dmah8_off0<0>(B, c0, t), g1 = dmah8_off0<1>(B, c0, t);
-#if defined(H_PROBE_PC_NOPLANES)  /* timing probe only: no plane tiles (stale LDS), only the P stream */
-#define H8_DP(K, G, BUF)
-#else
-#define H8_DP(K, G, BUF) \
-  __builtin_amdgcn_global_load_lds((gptr_t)(baseY + (G)), (lptr_t)((BUF) + (K) * kPlaneBytes + w * 1024), 16, 0, 0)
-#endif
-#ifndef H_P_LOAD_AUX
-#define H_P_LOAD_AUX 2  /* cache-policy bits of the P tile loads: nt (see H_P_ST); 0 for an A/B build */
-#endif
-#define H8_DMA_P(G4, BUF)                                                                                 \
-  __builtin_amdgcn_global_load_lds((gptr_t)(pw_base + (int64_t)dpos * 4096 + p_off[G4]),                  \
-                                   (lptr_t)((BUF) + wave_off + (G4) * 1024), 16, 0, H_P_LOAD_AUX)
-#define H8_DMA_FAC(BUF)                                                                                   \
-  __builtin_amdgcn_global_load_lds((gptr_t)(ref + (c0 + dpos) * 32 + (lane & 31)),                        \
-                                   (lptr_t)((BUF) + wave_off + kFacOff), 4, 0, 0)
-#define H8_ADVANCE()                                                                                      \
-  {                                                                                                       \
-    const uint32_t step_ = (dpos + 1 == nc) ? (uint32_t)(8192 - nc * 8192) : 8192u;                       \
-    dpos = (dpos + 1 == nc) ? 0 : dpos + 1;                                                               \
-    g0 += step_; g1 += step_;                                                                             \
-  }
-#define H8_DMA_ALL(BUF)                                                                                   \
-  {                                                                                                       \
-    H8_DMA_FAC(BUF); H8_DP(0, g0, BUF); H8_DP(1, g1, BUF);                                                \
-    if (!STAGE) { H8_DMA_P(0, BUF); H8_DMA_P(1, BUF); H8_DMA_P(2, BUF); H8_DMA_P(3, BUF); }               \
-    H8_ADVANCE();                                                                                         \
-  }
-  typedef float pf4 __attribute__((ext_vector_type(4)));
-  pf4 stg0[4], stg1[4];  // STAGE: the P' tiles of two coming chunks, as loaded (lane-linear 16-byte pieces)
-#if defined(H_PROBE_P34)
-  constexpr int kStgLoads = 3;
-  stg0[3] = stg1[3] = pf4{0.f, 0.f, 0.f, 0.f};
-#else
-  constexpr int kStgLoads = 4;
-#endif
-// chunk CH of this wave's tile column (clamped: past the end the last tile is loaded again and never used)
-// (inline assembly: as compiler-visible loads hipcc waited vmcnt(0) in front of the LDS write that consumes them -- it
-// does not order plain loads against the LDS-DMAs in flight -- which drained the loads issued a moment earlier; the
-// waits are written by hand: H8S_WAIT_WR below and the vmcnt(4) of the iteration barrier.  Loads return in order.)
-#define H8S_LOAD(STG, CH)                                                                                 \
-  {                                                                                                       \
-    const char* src_ = pw_base + (int64_t)min((int)(CH), nc - 1) * 4096;                                  \
-    _Pragma("unroll") for (int g_ = 0; g_ < kStgLoads; ++g_)                                              \
-      asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(STG[g_]) : "v"(p_off[g_]), "s"(src_));      \
-  }
-// the set loaded ONE iteration ago has landed: behind it are only this iteration's 3 DMAs and 4 staged loads
-#if defined(H_PROBE_P34)
-#define H8S_WAIT_WR() { H_SB(); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); H_SB(); }
-#else
-#define H8S_WAIT_WR() { H_SB(); asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); H_SB(); }
-#endif
-#define H8S_WRITE(STG)                                                                                    \
-  _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_)                                                        \
-    *reinterpret_cast<pf4*>(lds + kPArea + w * 4096 + g_ * 1024 + lane * 16) = STG[g_];
-  H8_DMA_ALL(lds);
-  if (nc > 1) H8_DMA_ALL(lds + kBuf);
-  if (STAGE && nc > 2) H8_DMA_ALL(lds + 2 * kBuf);
-  if (STAGE) { H8S_LOAD(stg0, 0); H8S_LOAD(stg1, 1); }
-  float p1[16], rf[16];
-  uint32_t pw[2][8], pwn[2][8];
   f16x8 ta2_[2][4][2];
-  uint32_t trn_[4][2];
-  // this lane's 16 probabilities of the chunk in BUF: component j % 4 of pieces (mh = j / 4, a = 8 g + 4 h + e), at LDS
-  // piece mh * 32 + (a ^ mh); and their 16 factors
-  const int p_mh = j >> 2;
-  const int p_rd = (STAGE ? kPArea + w * 4096 : wave_off) + p_mh * 512 + (j & 3) * 4;
-  const int p_x = (4 * h) ^ p_mh;  // (8 g + e) ^ p_x == (8 g + 4 h + e) ^ mh: 8 g + e has no bit 2
-#define H8_LOAD_P(BUF)                                                                                    \
-  _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_)                                                       \
-    p1[r_] = *reinterpret_cast<const float*>((STAGE ? lds : (BUF)) + p_rd + (((8 * (r_ >> 2) + (r_ & 3)) ^ p_x) << 4));
-// (STAGE: inline-assembly reads, valid after the H_TR_WAIT() that follows in H8_ITER -- hipcc puts s_waitcnt vmcnt(0) in
-// front of a plain read of LDS that an LDS-DMA may have written, which would drain the staged loads in flight)
-#define H8_LOAD_REFS(BUF)                                                                                 \
-  _Pragma("unroll") for (int g4_ = 0; g4_ < 4; ++g4_) {                                                   \
-    float4 lv_;                                                                                           \
-    if (STAGE) {                                                                                          \
-      const f16x8 raw_ = lds_b128<0>(lds32 + (uint32_t)((BUF) - lds) + (uint32_t)(wave_off + kFacOff + (8 * g4_ + 4 * h) * 4)); \
-      lv_ = __builtin_bit_cast(float4, raw_);                                                             \
-    } else {                                                                                              \
-      lv_ = *reinterpret_cast<const float4*>((BUF) + wave_off + kFacOff + (8 * g4_ + 4 * h) * 4);          \
-    }                                                                                                     \
-    rf[4 * g4_] = lv_.x; rf[4 * g4_ + 1] = lv_.y; rf[4 * g4_ + 2] = lv_.z; rf[4 * g4_ + 3] = lv_.w;       \
-  }
-#define H8_ITER(NBUF, N2BUF, DBUF, DMA_ON, NEXT_ON, STG_LD, STG_WR, IT)                                          \
-  {                                                                                                       \
-    H_PB();                                                                                               \
-    if (NEXT_ON) {                                                                                        \
-      if (!STAGE) { H8_LOAD_P(NBUF); H8_LOAD_REFS(NBUF); }                                                \
-      const uint32_t slot_ = (uint32_t)((NBUF) - lds);                                                    \
-      _Pragma("unroll") for (int db_ = 0; db_ < 4; ++db_) { trn_[db_][0] = trb_[db_][0] + slot_; trn_[db_][1] = trb_[db_][1] + slot_; } \
-    }                                                                                                     \
-    if (DMA_ON) { H8_DMA_FAC(DBUF); }                                                                     \
-    if (!STAGE) { H_TR_WAIT(); }                                                                          \
-    if (DMA_ON) { H_TICK(tk2); }                                                                          \
-    H_SB(); H_O_ROW(1, 0, 0); H_SB(); H_O_G1(0, 3); if (DMA_ON) { H8_DP(0, g0, DBUF); }                   \
-    if (NEXT_ON) { H_PC_SPLIT1(pwn, 0); H_PC_SPLIT1(pwn, 1); }                                            \
-    H_SB(); H_O_ROW(0, 1, 0); H_SB(); H_O_G1(3, 6); if (DMA_ON) { H8_DP(1, g1, DBUF); }                   \
-    if (NEXT_ON) { H_PC_SPLIT1(pwn, 2); H_PC_SPLIT1(pwn, 3); }                                            \
-    H_SB(); H_O_ROW(0, 0, 0); H_SB(); H_O_G1(6, 8);                                                       \
-    if ((DMA_ON) && !STAGE) { H8_DMA_P(0, DBUF); H8_DMA_P(1, DBUF); }                                     \
-    if (NEXT_ON) { H_PC_SPLIT1(pwn, 4); H_PC_SPLIT1(pwn, 5); }                                            \
-    H_TR_WAIT();                                                                                          \
-    if (DMA_ON) { H_TICK(tk3); H_TIMING_ACC(); }                                                          \
-    H_SB(); H_O_ROW(1, 0, 1); H_SB();                                                                     \
-    if ((DMA_ON) && !STAGE) { H8_DMA_P(2, DBUF); H8_DMA_P(3, DBUF); }                                     \
-    if ((DMA_ON) && STAGE) { H8S_LOAD(STG_LD, (IT) + 3); } /* behind this iteration's plane DMAs: vmcnt order */ \
-    if (NEXT_ON) { H_PC_NEXT_G0(0, 4); H_PC_SPLIT1(pwn, 6); }                                             \
-    H_SB(); H_O_ROW(0, 1, 1); H_SB();                                                                     \
-    if (NEXT_ON) { H_PC_SPLIT1(pwn, 7); }                                                                 \
-    H_SB(); H_O_ROW(0, 0, 1); H_SB();                                                                     \
-    if (NEXT_ON) { H_PC_NEXT_G0(4, 8); }                                                                  \
-    if (DMA_ON) H8_ADVANCE();                                                                             \
-    if (NEXT_ON) {                                                                                        \
-      _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_)                                                    \
-        _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) pw[q_][s_] = pwn[q_][s_];                        \
-    }                                                                                                     \
-    /* the tile of chunk IT + 2 (loaded one iteration ago) replaces the one read at the top of this iteration */ \
-    /* ... and is read back at once, with the factors of that chunk (both wave-private: no barrier in between), so   \
-       that the LDS latency of these 20 reads falls into the wait at the barrier, not behind it where all eight      \
-       waves would sit it out together (stamps: 515 cycles per iteration) */                                        \
-    if (STAGE && (DMA_ON)) { H8S_WAIT_WR(); H8S_WRITE(STG_WR); H8_LOAD_P(lds); H8_LOAD_REFS(N2BUF); H_TR_WAIT(); } \
-  }
-  H_DMA_BARRIER();
-  H_TR_BASES(lds);
+  f16x8 pb[2][2];
+  float rf[16];
 #pragma unroll
-  for (int f = 0; f < 8; ++f) trh_frag_n<0>(f, ta2_, trc_);
-  if (STAGE) { H8S_WRITE(stg0); }  // chunk 0's tile
-  H8_LOAD_P(lds);
-  H8_LOAD_REFS(lds);
-  H_TR_WAIT();  // (the assembly reads above: fragments and, with STAGE, the factors)
-#pragma unroll
-  for (int s = 0; s < 8; ++s) H_PC_SPLIT1(pw, s);
-  if (STAGE) {  // chunk 1's tile takes its place (LDS operations of a wave execute in order); chunk 2's starts its way
-    H8S_WRITE(stg1);
-    H8S_LOAD(stg1, 2);
-    H8_LOAD_P(lds);
-    H8_LOAD_REFS(lds + kBuf);
-    H_TR_WAIT();
-  }
-// the barrier that opens an iteration.  Without STAGE: the plane / factor / tile DMAs of the previous iteration have
-// landed.  With STAGE the chunk read next was fetched two iterations ago, in front of the staged loads that
-// H8S_WAIT_WR has just waited for: everything the previous iteration issued (3 DMAs + 4 loads) stays in flight
-#ifndef H8_BAR_VM
-#if defined(H_PROBE_P34)
-#define H8_BAR_VM 6
-#else
-#define H8_BAR_VM 7
-#endif
-#endif
-// (STAGE: the barrier instruction itself -- __syncthreads() carries a fence for which hipcc waits vmcnt(0))
-#define H8_BARRIER()                                                                        \
-  {                                                                                         \
-    if (STAGE) {                                                                            \
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(H8_BAR_VM) : "memory"); \
-    } else {                                                                                \
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
-      __syncthreads();                                                                      \
-    }                                                                                       \
-  }
+  for (int r = 0; r < 16; ++r) rf[r] = 0.f;
 
-  H_TIMING_DECL();
-  H_TIMING_START();
-  int cur = 0;
-  // (two iterations per trip: the staging sets swap roles -- even iterations load into stg0 and hand stg1 to LDS)
-  for (int it = 0; it + 2 < nc; it += 2) {
-    {
-      const int nxt = cur == kRing - 1 ? 0 : cur + 1;
-      const int nn = (cur + kAheadSlots) % kRing;
-      H_TICK(tk0);
-#if defined(H_PROBE_PC_NOBAR)
-      if (it > 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(H8_BAR_VM) : "memory");
+  auto sweep = [&](auto gen_tag) __attribute__((always_inline)) {
+    constexpr bool GEN = decltype(gen_tag)::value;
+    // DMA instructions per wave and chunk: 2 (+ 1) for the planes (and factors), 4 for the P' tile.  In front of
+    // LOAD(k) the requests younger than chunk k's planes are: tile k + 1, planes k + 1, tile k + 2
+    constexpr int kWaitTop = CT_PROBE_NOP ? (CT_PROBE_NOY ? 0 : 2) : 4 + (GEN ? 3 : 2) + 4;
+    const char* const baseY = reinterpret_cast<const char*>(GEN ? Yh : Yt);
+    const char* const dummy = reinterpret_cast<const char*>(Yh);  // source of requests past the end: cache-resident, unused
+    int dpos = 0;
+    uint32_t g0 = dmah8_off0<0>(B, c0, t), g1 = dmah8_off0<1>(B, c0, t);
+    const int wq = w & 3;
+// plane (and factor) requests of the next chunk in the request order, piece by piece (CT_COMPUTE spreads them between
+// its MFMA rows): I = 0, 1 the two planes, I = 2 the factors and the advance of the request position
+#define CT_DMA_Y_PIECE(SLOT, I)                                                                           \
+  if (!CT_PROBE_NOY) {                                                                                    \
+    if ((I) == 0)                                                                                         \
+      __builtin_amdgcn_global_load_lds((gptr_t)(baseY + g0), (lptr_t)(lds + (SLOT) * kCtYSlot + w * 1024), 16, 0, 0); \
+    if ((I) == 1)                                                                                         \
+      __builtin_amdgcn_global_load_lds((gptr_t)(baseY + g1),                                              \
+                                       (lptr_t)(lds + (SLOT) * kCtYSlot + kPlaneBytes + w * 1024), 16, 0, 0); \
+    if ((I) == 2) {                                                                                       \
+      if (GEN)                                                                                            \
+        __builtin_amdgcn_global_load_lds((gptr_t)(ref + (c0 + dpos) * 32 + (lane & 31)),                 \
+                                         (lptr_t)(lds + (SLOT) * kCtYSlot + 2 * kPlaneBytes + w * 256), 4, 0, 0); \
+      const uint32_t step_ = (dpos + 1 == nc) ? (uint32_t)(8192 - nc * 8192) : 8192u;                     \
+      dpos = (dpos + 1 == nc) ? 0 : dpos + 1;                                                             \
+      g0 += step_; g1 += step_;                                                                           \
+    }                                                                                                     \
+  }
+#define CT_DMA_Y(SLOT) { CT_DMA_Y_PIECE(SLOT, 0); CT_DMA_Y_PIECE(SLOT, 1); CT_DMA_Y_PIECE(SLOT, 2); }
+#define CT_DMA_P_PIECE(SLOT, CH, G4)                                                                      \
+  if (!CT_PROBE_NOP) {                                                                                    \
+    const char* src_ = (!CT_PROBE_DUMMY && (CH) < nc) ? pw_base + (int64_t)(CH) * 4096 : dummy;           \
+    __builtin_amdgcn_global_load_lds((gptr_t)(src_ + p_off[G4]),                                          \
+                                     (lptr_t)(lds + kCtPOff + w * kCtPWave + (SLOT) * kCtPSlot + (G4) * 1024 +  \
+                                              ((G4) >> 1) * 64), 16, 0,                                   \
+                                     H_P_LOAD_AUX);                                                       \
+  }
+#define CT_DMA_P(SLOT, CH) \
+  { CT_DMA_P_PIECE(SLOT, CH, 0); CT_DMA_P_PIECE(SLOT, CH, 1); CT_DMA_P_PIECE(SLOT, CH, 2); CT_DMA_P_PIECE(SLOT, CH, 3); }
+// general form: this lane's 16 factors of the chunk in plane slot SLOT (rf[8 g + e]: row 16 g + 8 (e / 4) + 4 h + e % 4)
+#define CT_LOAD_REFS(SLOT)                                                                                \
+  if (GEN) {                                                                                              \
+    f16x8 raw_[4];                                                                                        \
+    raw_[0] = lds_b128<(SLOT) * kCtYSlot>(rbase);                                                         \
+    raw_[1] = lds_b128<(SLOT) * kCtYSlot + 32>(rbase);                                                    \
+    raw_[2] = lds_b128<(SLOT) * kCtYSlot + 64>(rbase);                                                    \
+    raw_[3] = lds_b128<(SLOT) * kCtYSlot + 96>(rbase);                                                    \
+    H_TR_WAIT();                                                                                          \
+    _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_) {                                                    \
+      const float4 lv_ = __builtin_bit_cast(float4, raw_[m_]);                                            \
+      rf[4 * m_] = lv_.x; rf[4 * m_ + 1] = lv_.y; rf[4 * m_ + 2] = lv_.z; rf[4 * m_ + 3] = lv_.w;         \
+    }                                                                                                     \
+  }
+// general form: p = (hi + lo) f, split into two planes again, in place
+#define CT_APPLY_FAC()                                                                                    \
+  if (GEN) {                                                                                              \
+    _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_)                                                      \
+      _Pragma("unroll") for (int e_ = 0; e_ < 8; e_ += 2) {                                               \
+        const float x0_ = ((float)pb[0][g_][e_] + (float)pb[1][g_][e_]) * rf[8 * g_ + e_];                \
+        const float x1_ = ((float)pb[0][g_][e_ + 1] + (float)pb[1][g_][e_ + 1]) * rf[8 * g_ + e_ + 1];    \
+        const f16x2 pa_ = pk_f16(x0_, x1_);                                                               \
+        const f16x2 pq_ = pk_f16(resid_lo(x0_, pa_), resid_hi(x1_, pa_));                                 \
+        pb[0][g_][e_] = pa_[0]; pb[0][g_][e_ + 1] = pa_[1];                                               \
+        pb[1][g_][e_] = pq_[0]; pb[1][g_][e_ + 1] = pq_[1];                                               \
+      }                                                                                                   \
+  }
+#define CT_G0(SLOT) { _Pragma("unroll") for (int f_ = 0; f_ < 8; ++f_) ct_frag_n<0, (SLOT) * kCtYSlot>(f_, ta2_, trb_); }
+#define CT_G1(SLOT, F0, F1) \
+  { _Pragma("unroll") for (int f_ = (F0); f_ < (F1); ++f_) ct_frag_n<1, (SLOT) * kCtYSlot>(f_, ta2_, trb_); }
+// The two waves of a SIMD (w and w + 4) take turns on the matrix pipe.  (The first form of this kernel ran all eight
+// waves through "barrier, 24 LDS reads, wait, 4 DMA issues, 24 MFMAs" together: with the P' stream replaced by cached
+// reads it still took 58 us, 2400 cycles per chunk at 1.38 GHz for 1536 cycles of MFMAs per SIMD -- every SIMD idle
+// while both its waves loaded.)  LOAD(k): all 40 transposing reads of chunk k into registers.  COMPUTE(k): the chunk's
+// 24 MFMAs, and between their rows the seven requests a chunk costs a wave: planes k + 2 (the slot chunk k - 1 left)
+// and tile k + 3 (into the slot LOAD(k) has just emptied).  [With the requests in LOAD -- six LDS-DMA issues of four
+// waves at once in front of and behind the reads -- LOAD took 1000 cycles against COMPUTE's 745 (stamps: 278 for the two
+// plane requests, 422 for the reads, 310 for the four tile requests), 2470 cycles per chunk.]  Segments are separated
+// by workgroup barriers; waves 0-3 run LOAD(k) | COMPUTE(k), waves 4-7 one segment later:
+//     segment 2k    : waves 0-3 LOAD(k)     waves 4-7 COMPUTE(k - 1)
+//     segment 2k + 1: waves 0-3 COMPUTE(k)  waves 4-7 LOAD(k)
+// The plane slot of chunk k - 1 is last read in segment 2k - 1 and refilled from segment 2k + 1 on.  Chunk k's planes
+// have landed for every wave before the barrier that opens segment 2k: the requests younger than them are tile k + 1,
+// planes k + 1, tile k + 2 for waves 0-3 (vmcnt(kWaitTop)) and tile k + 1 alone for waves 4-7, whose COMPUTE(k - 1)
+// comes after that barrier (vmcnt(4)).
+#define CT_LOAD(S, IT)                                                                                    \
+  {                                                                                                       \
+    pb[0][0] = ct_pfrag<0, 0, (S) * kCtPSlot>(pbase); pb[1][0] = ct_pfrag<1, 0, (S) * kCtPSlot>(pbase);   \
+    pb[0][1] = ct_pfrag<0, 1, (S) * kCtPSlot>(pbase); pb[1][1] = ct_pfrag<1, 1, (S) * kCtPSlot>(pbase);   \
+    CT_G0(S);                                                                                             \
+    CT_G1(S, 0, 8);                                                                                       \
+    CT_LOAD_REFS(S);                                                                                      \
+    H_TR_WAIT();                                                                                          \
+    if (CT_P_IN_LOAD >= 1) CT_DMA_P_PIECE(S, (IT) + 3, 0);                                                \
+    if (CT_P_IN_LOAD >= 2) CT_DMA_P_PIECE(S, (IT) + 3, 1);                                                \
+    if (CT_P_IN_LOAD >= 3) CT_DMA_P_PIECE(S, (IT) + 3, 2);                                                \
+    if (CT_P_IN_LOAD >= 4) CT_DMA_P_PIECE(S, (IT) + 3, 3);                                                \
+    CT_APPLY_FAC();                                                                                       \
+  }
+// COMPUTE of the chunk loaded from slots S (chunk IT).  The four waves of a half run it in lockstep behind the barrier: a
+// request issued by all four at the same point queues behind the other three in the CU's address unit (16 cycles per
+// 1 KB request; with the seven requests after whole rows the stamps showed COMPUTE at 1131 cycles against 745 without
+// them).  Wave q = w % 4 issues its request of a row behind the row's MFMA q: the four waves' requests are 32 cycles
+// apart and cost the issuing wave nothing but the issue slot.
+#define CT_ROW_DMA(PL_A, PL_P, G, DMA)                                                                    \
+  _Pragma("unroll") for (int db_ = 0; db_ < 4; ++db_) {                                                   \
+    acc[db_] = H_MFMA(ta2_[G][db_][PL_A], pb[PL_P][G], acc[db_]);                                         \
+    if (db_ == wq) { DMA; }                                                                               \
+  }
+#define CT_COMPUTE(S, IT)                                                                                 \
+  {                                                                                                       \
+    H_SB(); CT_ROW_DMA(1, 0, 0, CT_DMA_Y_PIECE(((S) + 2) % 3, 0));                                        \
+    H_SB(); CT_ROW_DMA(0, 1, 0, CT_DMA_Y_PIECE(((S) + 2) % 3, 1); CT_DMA_Y_PIECE(((S) + 2) % 3, 2));      \
+    H_SB(); CT_ROW_DMA(0, 0, 0, if (CT_P_IN_LOAD < 1) CT_DMA_P_PIECE(S, (IT) + 3, 0));                    \
+    H_SB(); CT_ROW_DMA(1, 0, 1, if (CT_P_IN_LOAD < 2) CT_DMA_P_PIECE(S, (IT) + 3, 1));                    \
+    H_SB(); CT_ROW_DMA(0, 1, 1, if (CT_P_IN_LOAD < 3) CT_DMA_P_PIECE(S, (IT) + 3, 2));                    \
+    H_SB(); CT_ROW_DMA(0, 0, 1, if (CT_P_IN_LOAD < 4) CT_DMA_P_PIECE(S, (IT) + 3, 3));                    \
+    H_SB();                                                                                               \
+  }
+#define CT_BAR_TOP() asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kWaitTop) : "memory")
+#define CT_BAR_TOP_B() asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(CT_PROBE_NOP ? 0 : 4) : "memory")
+#define CT_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    CT_DMA_P(0, 0);
+    CT_DMA_Y(0);
+    CT_DMA_P(1, 1);
+    CT_DMA_Y(1);
+    CT_DMA_P(2, 2);
+    if (w < 4) {
+#ifdef H_TIMING  /* scripts/ct_timing.py, -DH_TIMING=2: cycles in front of the top barrier / LOAD / middle barrier / COMPUTE */
+      unsigned long long tk_[5] = {0, 0, 0, 0, 0}, ta_[4] = {0, 0, 0, 0};
+      const unsigned long long rentry_ = __builtin_amdgcn_s_memrealtime(), tstart_ = __builtin_readcyclecounter();
+#define CT_T(I) { H_SB(); tk_[I] = __builtin_readcyclecounter(); H_SB(); }
+#define CT_TACC() { ta_[0] += tk_[1] - tk_[0]; ta_[1] += tk_[2] - tk_[1]; ta_[2] += tk_[3] - tk_[2]; ta_[3] += tk_[4] - tk_[3]; }
 #else
-      if (it > 0) H8_BARRIER();
+#define CT_T(I)
+#define CT_TACC()
 #endif
-      H_TICK(tk1);
-      const char* buf = lds + cur * kBuf;
-      const char* nbuf = lds + nxt * kBuf;
-      char* dbuf = lds + nn * kBuf;
-      H_TR_BASES(buf);
-      H8_ITER(nbuf, lds + ((cur + 2) % kRing) * kBuf, dbuf, true, true, stg0, stg1, it);
-      cur = nxt;
-    }
-    if (it + 3 < nc) {
-      const int nxt = cur == kRing - 1 ? 0 : cur + 1;
-      const int nn = (cur + kAheadSlots) % kRing;
-      H_TICK(tk0);
-#if defined(H_PROBE_PC_HALFBAR) || defined(H_PROBE_PC_NOBAR)
-      /* timing probes only (results wrong: ring slots are overwritten under their readers): what would a loop with half
-         the workgroup barriers -- two chunks per barrier, a deeper ring -- or with none cost? */
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(H8_BAR_VM) : "memory");
-#else
-      H8_BARRIER();
+#define CT_STEP_A(S, IT) \
+  { CT_T(0); CT_BAR_TOP(); CT_T(1); CT_LOAD(S, IT); CT_T(2); CT_BAR(); CT_T(3); CT_COMPUTE(S, IT); CT_T(4); CT_TACC(); }
+      for (int it = 0; it < nc; it += 3) {
+        CT_STEP_A(0, it);
+        if (it + 1 < nc) { CT_STEP_A(1, it + 1); }
+        if (it + 2 < nc) { CT_STEP_A(2, it + 2); }
+      }
+#ifdef H_TIMING
+      if (lane == 0 && (blockIdx.x & 1) == 0 && blockIdx.x < 512) {
+        unsigned long long* d = esr_ib2h_dbg + (((blockIdx.x >> 1) * 4 + w) * 4);
+        d[0] = ta_[0]; d[1] = ta_[1]; d[2] = ta_[2] + ta_[3]; d[3] = __builtin_readcyclecounter() - tstart_;
+        unsigned long long* e = esr_ib2h_dbg + 4096 + (((blockIdx.x >> 1) * 4 + w) * 4);
+        e[0] = rentry_; e[1] = rentry_; e[2] = __builtin_amdgcn_s_memrealtime(); e[3] = ta_[3];
+      }
 #endif
-      H_TICK(tk1);
-      const char* buf = lds + cur * kBuf;
-      const char* nbuf = lds + nxt * kBuf;
-      char* dbuf = lds + nn * kBuf;
-      H_TR_BASES(buf);
-      H8_ITER(nbuf, lds + ((cur + 2) % kRing) * kBuf, dbuf, true, true, stg1, stg0, it + 1);
-      cur = nxt;
+#undef CT_STEP_A
+#undef CT_T
+#undef CT_TACC
+      CT_BAR_TOP();  // (the barrier in front of the other half's last COMPUTE)
+    } else {
+      // (the slot and chunk of the COMPUTE in a step are the previous step's)
+      for (int it = 0; it < nc; it += 3) {
+        CT_BAR_TOP_B(); if (it > 0) { CT_COMPUTE(2, it - 1); } CT_BAR(); CT_LOAD(0, it);
+        if (it + 1 < nc) { CT_BAR_TOP_B(); CT_COMPUTE(0, it); CT_BAR(); CT_LOAD(1, it + 1); }
+        if (it + 2 < nc) { CT_BAR_TOP_B(); CT_COMPUTE(1, it + 1); CT_BAR(); CT_LOAD(2, it + 2); }
+      }
+      CT_BAR_TOP_B();
+      switch ((nc - 1) % 3) {  // the last chunk's slot
+        case 0: CT_COMPUTE(0, nc - 1); break;
+        case 1: CT_COMPUTE(1, nc - 1); break;
+        default: CT_COMPUTE(2, nc - 1); break;
+      }
     }
-  }
-  // The staged loads of the last steady iteration (and the prologue's, for nc <= 2) are past the end and never used:
-  // they must land before their registers are given to anything else.
-  if (STAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (nc >= 2) {
-    const int nxt = cur == kRing - 1 ? 0 : cur + 1;
-    if (nc > 2) H8_BARRIER();
-    const char* buf = lds + cur * kBuf;
-    const char* nbuf = lds + nxt * kBuf;
-    H_TR_BASES(buf);
-    H8_ITER(nbuf, lds, lds, false, true, stg0, stg0, 0);
-    cur = nxt;
-  }
-  {
-    const char* buf = lds + cur * kBuf;
-    H_TR_BASES(buf);
-    H8_ITER(buf, lds, lds, false, false, stg0, stg0, 0);
-  }
-  H_TIMING_WRITE(!H_TIMING_Q && w < 4);
-  if (live) {
-    float* orow = part_O + ((int64_t)split * B + xrow) * k3D;
+#undef CT_ROW_DMA
+#undef CT_BAR
+#undef CT_BAR_TOP_B
+#undef CT_BAR_TOP
+#undef CT_COMPUTE
+#undef CT_LOAD
+#undef CT_G1
+#undef CT_G0
+#undef CT_APPLY_FAC
+#undef CT_LOAD_REFS
+#undef CT_DMA_P
+#undef CT_DMA_P_PIECE
+#undef CT_DMA_Y
+#undef CT_DMA_Y_PIECE
+  };
+  if (general) {
+    sweep(std::true_type{});
+  } else {
+    sweep(std::false_type{});
+    const float ce = cexp[0];  // exact power of two: the copy's exponent against the planes' common one
 #pragma unroll
     for (int db = 0; db < 4; ++db)
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4*>(orow + 32 * db + 8 * q + 4 * h) =
-            make_float4(acc[db][4 * q], acc[db][4 * q + 1], acc[db][4 * q + 2], acc[db][4 * q + 3]);
+      for (int r = 0; r < 16; ++r) acc[db][r] *= ce;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the requests past the end
+  __syncthreads();                                   // the rings are free: every wave is past its last chunk
+  if (live) store_tile_via_lds<true>(lds + w * kTileLdsBytes, acc, part_O + ((int64_t)split * B + wrow) * k3D, lane);
 }
 
 // The factors pass C needs from pass Q's per-split references and normalisers -- fac[s][i] = 2^14 2^(M_s - M) / l_i --
@@ -2020,16 +1819,25 @@ __global__ ESR_PC8_PK __launch_bounds__(512) void inbatch2h_pc8_kernel(const _Fl
 __global__ __launch_bounds__(256) void fac2h_kernel(int64_t B, int nsplit, const float* __restrict__ part_m,
                                                    const float* __restrict__ part_l, float invl_scale,
                                                    float* __restrict__ fac, float* __restrict__ lse2 = nullptr,
-                                                   float* __restrict__ lse_nat = nullptr) {
+                                                   float* __restrict__ lse_nat = nullptr,
+                                                   const float* __restrict__ qmax = nullptr,
+                                                   float* __restrict__ fac_row = nullptr,
+                                                   unsigned* __restrict__ cmax = nullptr) {
   // lse2 / lse_nat (the merging update's form of the step: no merge<Q> launch): the row's log-sum-exp in binary and
   // natural units, as merge<Q> leaves them
+  // qmax / fac_row / cmax (round 6, pass C's scaled copy of Q): fac_row[i] = invl_scale / l_i -- the factor of every split
+  // that used the row's reference (weight 1: all of them unless a pass-Q workgroup redid itself) -- and
+  // cmax[0] = bits of max_i fac_row[i] max_d |q_id|, the largest |element| of the copy scaleq2h_kernel writes (rounding is
+  // monotone: the largest product is the product of the largest |q_id|); one atomic per workgroup on a word
+  // prepsplit2h_kernel zeroed (non-negative floats order like their bits)
+  __shared__ unsigned red[4];
   const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (row >= B) return;
+  const bool in = row < B;
   float pm[8], pl[8];
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     pm[s] = -INFINITY; pl[s] = 0.f;
-    if (s < nsplit) {
+    if (in && s < nsplit) {
       pm[s] = part_m[(int64_t)s * B + row];
       pl[s] = part_l[(int64_t)s * B + row];
     }
@@ -2044,13 +1852,86 @@ __global__ __launch_bounds__(256) void fac2h_kernel(int64_t B, int nsplit, const
     L = __fmaf_rn(pl[s], wt[s], L);  // (explicit, as in merge_row: the two must round alike)
   }
   const float invL1 = __fdiv_rn(1.0f, L);
+  const float f1 = __fmul_rn(invL1, invl_scale);
 #pragma unroll
   for (int s = 0; s < 8; ++s)
-    if (s < nsplit) fac[(int64_t)s * B + row] = __fmul_rn(__fmul_rn(invL1, invl_scale), wt[s]);
-  if (lse2) {
+    if (in && s < nsplit) fac[(int64_t)s * B + row] = __fmul_rn(f1, wt[s]);
+  if (in && lse2) {
     const float l2v = __fadd_rn(M, __builtin_amdgcn_logf(L));
     lse2[row] = l2v;
     if (lse_nat) lse_nat[row] = l2v * k3Ln2;
+  }
+  if (cmax) {
+    float cm = 0.f;
+    if (in) {
+      fac_row[row] = f1;
+      cm = __fmul_rn(fabsf(f1), qmax[row]);
+    }
+    // (a NaN product -- a row without a finite normaliser -- must reach the word: fmaxf would drop it)
+    unsigned u = cm == cm ? __float_as_uint(cm) : 0x7fc00000u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      u = max(max(red[0], red[1]), max(red[2], red[3]));
+      if (u) atomicMax(cmax, u);
+    }
+  }
+}
+
+// The scaled copy of Q for inbatch2h_pct_kernel (round 6): two fp16 planes of x' = (f_i q_i) 2^E, f_i = fac_row[i], E from
+// the copy's largest |element| (cmax[0], fac2h_kernel): max |x'| in [2^13, 2^14).  One 256-thread block per 32-row chunk.
+// cexp[0] = 2^(eq - E): what brings pass C's partial rows to the unit the merges undo (sc[2]).
+// cflags[s] != 0: pass C's workgroups on pass-Q split s must take the general form, because
+//   * some row's factor for split s is not fac_row (a pass-Q workgroup of that split redid itself against its own
+//     maximum: its probabilities carry another reference), or
+//   * (every split) some row with a non-zero factor has its largest |x'| under 2^-4 -- more than 17 binades under the
+//     copy's largest element: its second plane would lose bits to fp16's subnormals.
+__global__ __launch_bounds__(256) void scaleq2h_kernel(RowSrc X, int64_t B, int nsplit, const float* __restrict__ fac,
+                                                      const float* __restrict__ fac_row,
+                                                      const unsigned* __restrict__ cmax, const float* __restrict__ sc,
+                                                      _Float16* __restrict__ Yt, float* __restrict__ cexp,
+                                                      int* __restrict__ cflags) {
+  const int t = threadIdx.x, chunk = blockIdx.x;
+  const int row = t >> 3, d0 = (t & 7) * 16;
+  const int64_t grow = (int64_t)chunk * 32 + row;
+  float v[16];
+  {
+    const int64_t r = X.idx ? (int64_t)X.idx[grow] : grow;
+    RowSrc Y0 = X;
+    Y0.idx = nullptr;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 f = rowsrc_load4(Y0, r, d0 + 4 * q);
+      v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+    }
+  }
+  const float f = fac_row[grow];
+  if ((t & 7) < nsplit && fac[(int64_t)(t & 7) * B + grow] != f) cflags[t & 7] = 1;  // (NaN factors flag themselves)
+  const int E = scale_exp(__uint_as_float(cmax[0]));
+  if (chunk == 0 && t == 0) cexp[0] = sc[3] * ldexpf(1.f, -E);
+  const float mul = ldexpf(1.f, E);
+  float m = 0.f;
+  f16x8 p[2][2];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const float xs = __fmul_rn(v[e], f) * mul;  // (the scaling is exact: a power of two)
+    m = fmaxf(m, fabsf(xs));
+    const _Float16 a = (_Float16)xs;
+    const _Float16 b = (_Float16)(xs - (float)a);
+    p[0][e >> 3][e & 7] = a;
+    p[1][e >> 3][e & 7] = b;
+  }
+  m = fmaxf(m, __shfl_xor(m, 1, 64));
+  m = fmaxf(m, __shfl_xor(m, 2, 64));
+  m = fmaxf(m, __shfl_xor(m, 4, 64));
+  if (f != 0.f && m < kCtLive && (t & 7) < nsplit) cflags[t & 7] = 1;
+#pragma unroll
+  for (int pl = 0; pl < 2; ++pl) {
+    f16x8* dst = reinterpret_cast<f16x8*>(Yt + ((int64_t)pl * B + grow) * k3D + d0);
+    dst[0] = p[pl][0];
+    dst[1] = p[pl][1];
   }
 }
 
@@ -2060,6 +1941,10 @@ struct InbatchHWs {
   int* flags;
   unsigned long long* loss_acc;
   unsigned long long* ent;  // prepsplit2h_kernel's tagged per-chunk maxima
+  _Float16* Qt;             // the scaled copy of Q (scaleq2h_kernel): [2][B][128]
+  float *qmax, *fac_row, *cexp;  // largest |element| per Q row; the rows' factors; 2^(eq - E) of the copy
+  unsigned* cmax;           // 16 words zeroed by prepsplit2h_kernel: [0] the copy's largest |element| (float bits),
+  int* cflags;              // [8, 16) the pass-Q splits' flags
 };
 constexpr int64_t kHMaxB = 16384;  // B x B x 4 bytes of stored probabilities: 1 GiB
 
@@ -2092,6 +1977,12 @@ static size_t inbatch2h_ws_layout(int64_t B, char* base, InbatchHWs* ws) {
   w.amax = (float*)take((size_t)2 * (B / k3Chunk) * sizeof(float));
   w.sc = (float*)take(kHScaleWords * sizeof(float));
   w.ent = (unsigned long long*)take((size_t)(B / k3Chunk) * sizeof(unsigned long long));
+  w.Qt = (_Float16*)take(planes);
+  w.qmax = (float*)take((size_t)B * 4);
+  w.fac_row = (float*)take((size_t)B * 4);
+  w.cexp = (float*)take(8 * sizeof(float));
+  w.cmax = (unsigned*)take(16 * sizeof(unsigned));
+  w.cflags = reinterpret_cast<int*>(w.cmax ? w.cmax + 8 : nullptr);
   if (ws) *ws = w;
   return off;
 }
@@ -2195,40 +2086,23 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
   const float inv_bs = 1.0f / batch_size, sl2 = scale * k3Log2e;
   const int nchunks = (int)(B / k3Chunk);
   const char* qcs = getenv("ESR_IB2H_Q_PER_CU");
-  int nsplit_q = inbatch2h_nsplit(B, qcs ? std::max(1, atoi(qcs)) : 2);  // 252 registers, 50 KB of LDS: two per CU
+  const int nsplit_q = inbatch2h_nsplit(B, qcs ? std::max(1, atoi(qcs)) : 2);  // 252 registers, 50 KB of LDS: two per CU
   // pass C: 8-wave workgroups, 256 owned rows each
-  const int pc_blocks = (int)cdiv(B, kPc8Owned);
+  const int pc_blocks = (int)cdiv(B, kCtOwned);
   int nsplit_c = 1;
   for (int sp = 1; sp <= 8; ++sp)
     if (nchunks % sp == 0 && pc_blocks * sp <= 320) nsplit_c = sp;
   const int grid_c = pc_blocks * nsplit_c;
-  int grid_q = (int)(B / k3Owned) * nsplit_q;
-  // pass Q with 64 owned rows per wave (256 per workgroup, one workgroup per CU): ESR_IB2H_Q=64; needs B % 256 == 0 and
-  // the optimistic reference
-  const char* qf = getenv("ESR_IB2H_Q");
-  const bool q2_env = qf && qf[0] == '6';
-  bool q2 = q2_env && B % 256 == 0;
-  if (q2) {
-    const int blocks = (int)(B / 256);
-    nsplit_q = 1;
-    for (int sp = 1; sp <= 8; ++sp)
-      if (nchunks % sp == 0 && blocks * sp <= 320) nsplit_q = sp;
-    grid_q = blocks * nsplit_q;
-  }
+  const int grid_q = (int)(B / k3Owned) * nsplit_q;
   const int mgrid = (int)std::min<int64_t>(k3MergeBlocks, cdiv(B, kBlock / 32));
   // exponent reference of pass Q: optimistic + redo launch (default), or the row-max pass (ESR_IB2H_REF=rowmax);
   // ESR_IB2H_REF=redo forces every block through the redo launch (test hook)
   const char* refe = getenv("ESR_IB2H_REF");
   const int mode = (refe && refe[0] == 'r' && refe[1] == 'o') ? 0 : ((refe && refe[0] == 'r' && refe[1] == 'e') ? 2 : 1);
-  if (mode == 0) q2 = false;
-  if (!q2 && q2_env) {  // fell back: restore the 32-row geometry
-    nsplit_q = inbatch2h_nsplit(B, qcs ? std::max(1, atoi(qcs)) : 2);
-    grid_q = (int)(B / k3Owned) * nsplit_q;
-  }
   // round 4 (default): prep + split in one launch, pass Q redoes overflowed workgroups itself: five launches.
-  // ESR_IB2H_FUSED=0 (or the row-max reference, or the 64-row pass Q) keeps round 3's seven.
+  // ESR_IB2H_FUSED=0 (or the row-max reference) keeps round 3's seven.
   const char* fe = getenv("ESR_IB2H_FUSED");
-  const bool fused = !(fe && fe[0] == '0') && mode != 0 && !q2;
+  const bool fused = !(fe && fe[0] == '0') && mode != 0;
   int nsplit_r = 1;
   // Overlapped form (`side` given; round 5): pass C needs nothing of merge<Q> but the factors, so fac2h_kernel makes
   // those (2 us) and merge<Q> -- 14 us of partial-O reads at B = 8192 -- runs on `side` beside pass C, followed there by
@@ -2274,15 +2148,15 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
     ESR_KT("prepsplit2h_kernel", st,
            hipLaunchKernelGGL(prepsplit2h_kernel, dim3(nchunks), dim3(256), 0, st, Qs, Cs, B, ws.Qh, ws.Ch, ws.ent, token,
                               ws.diag, ws.nrm, ws.sc, ws.loss_acc, ws.flags, grid_q, (overlapped || merge_upd) ? ws.Qcopy : (float*)nullptr,
-                              (overlapped || merge_upd) ? ws.Ccopy : (float*)nullptr));
+                              (overlapped || merge_upd) ? ws.Ccopy : (float*)nullptr, ws.qmax, ws.cmax));
     if (one_plane) {
       // bf16 tables: one fp16 plane per operand, S^T recomputed by pass C -- six GEMMs, no stored probabilities.
       // 512-thread workgroups of 256 owned rows, one per CU
       const int blocks1 = (int)cdiv(B, kH1Owned);
-      nsplit_q = 1;
+      int nsplit_1 = 1;
       for (int sp = 1; sp <= 8; ++sp)
-        if (nchunks % sp == 0 && blocks1 * sp <= 320) nsplit_q = sp;
-      grid_q = blocks1 * nsplit_q;
+        if (nchunks % sp == 0 && blocks1 * sp <= 320) nsplit_1 = sp;
+      const int nsplit_q = nsplit_1, grid_q = blocks1 * nsplit_1;  // (shadow the two-plane geometry)
       const char* dbg1h = getenv("ESR_IB1H_DBG");
       if (dbg1h && dbg1h[0] == '1') {
         hipLaunchKernelGGL((inbatch1h_kernel<true, 1>), dim3(grid_q), dim3(512), 0, st, (const _Float16*)ws.Qh,
@@ -2346,15 +2220,7 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
                               (const _Float16*)ws.Ch, B, nsplit_r, sl2, (const float*)ws.nrm, (const float*)ws.sc,
                               ws.part_mr));
   }
-  if (q2) {
-    ESR_KT("inbatch2h_q2_kernel", st,
-           hipLaunchKernelGGL((inbatch2h_q2_kernel<false>), dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Qh,
-                              (const _Float16*)ws.Ch, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)ws.diag, mode,
-                              ws.flags, ws.part_m, ws.part_O, ws.part_l, ws.Pmat));
-    hipLaunchKernelGGL((inbatch2h_q2_kernel<true>), dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Qh,
-                       (const _Float16*)ws.Ch, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)ws.diag, mode,
-                       ws.flags, ws.part_m, ws.part_O, ws.part_l, ws.Pmat);
-  } else {
+  {
     ESR_KT("inbatch2h_q_kernel", st,
            hipLaunchKernelGGL((inbatch2h_q_kernel<0>), dim3(grid_q), dim3(256), 0, st, (const _Float16*)ws.Qh,
                               (const _Float16*)ws.Ch, B, nsplit_q, sl2, (const float*)ws.sc, (const float*)ws.part_mr,
@@ -2372,21 +2238,32 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
   // the rows the merges read: the towers themselves, or (overlapped) their gathered copies
   const RowSrc Qm = overlapped ? RowSrc{ws.Qcopy, nullptr, 0, Qs.ld} : Qs;
   const RowSrc Cm = overlapped ? RowSrc{ws.Ccopy, nullptr, 0, Cs.ld} : Cs;
+  // Pass C's form (round 6): the scaled copy of Q (fac2h_kernel -> scaleq2h_kernel); with ESR_IB2H_PC=general (the test
+  // hook) and on the unfused path every workgroup takes the general form (unscaled planes, factors applied to the B
+  // fragments in registers).
+  const int nc_q = nchunks / nsplit_q;
+  const char* pcm = getenv("ESR_IB2H_PC");
+  const int force_general = (!fused || (pcm && pcm[0] == 'g')) ? 1 : 0;
   if (overlapped) {
     if (hipEventRecord(ev_fork, st) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess) {
       set_error("%s: could not fork the side stream", who);
       return ESR_ELAUNCH;
     }
-    ESR_KT("fac2h_kernel", st,
-           hipLaunchKernelGGL(fac2h_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, B, nsplit_q,
-                              (const float*)ws.part_m, (const float*)ws.part_l, ldexpf(1.f, (int)kHPexp), ws.fac));
   }
-  if (merge_upd) {
+  if (overlapped || merge_upd || !force_general)
     ESR_KT("fac2h_kernel", st,
            hipLaunchKernelGGL(fac2h_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, B, nsplit_q,
-                              (const float*)ws.part_m, (const float*)ws.part_l, ldexpf(1.f, (int)kHPexp), ws.fac, ws.lse2,
-                              lse));
-  } else
+                              (const float*)ws.part_m, (const float*)ws.part_l, ldexpf(1.f, (int)kHPexp), ws.fac,
+                              merge_upd ? ws.lse2 : (float*)nullptr, merge_upd ? lse : (float*)nullptr,
+                              force_general ? (const float*)nullptr : (const float*)ws.qmax,
+                              force_general ? (float*)nullptr : ws.fac_row, force_general ? (unsigned*)nullptr : ws.cmax));
+  if (!force_general)
+    ESR_KT("scaleq2h_kernel", st,
+           hipLaunchKernelGGL(scaleq2h_kernel, dim3(nchunks), dim3(256), 0, st,
+                              (overlapped || merge_upd) ? RowSrc{ws.Qcopy, nullptr, 0, Qs.ld} : Qs, B, nsplit_q,
+                              (const float*)ws.fac, (const float*)ws.fac_row, (const unsigned*)ws.cmax,
+                              (const float*)ws.sc, ws.Qt, ws.cexp, ws.cflags));
+  if (!merge_upd)
   ESR_KT("inbatch3_merge_kernel_q", st_q,
          hipLaunchKernelGGL((inbatch3_merge_kernel<true>), dim3(mgrid), dim3(kBlock), 0, st_q, Qm, Cm, gq_rows, B, nsplit_q,
                             (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale,
@@ -2404,16 +2281,10 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
       return ESR_ELAUNCH;
     }
   }
-  const char* pcm = getenv("ESR_IB2H_PC");  // "dma": the P' tiles as LDS-DMAs (one chunk ahead); default: staged loads
-  if (pcm && pcm[0] == 'd') {
-    ESR_KT("inbatch2h_pc8_kernel", st,
-           hipLaunchKernelGGL((inbatch2h_pc8_kernel<false>), dim3(grid_c), dim3(512), 0, st, (const _Float16*)ws.Qh,
-                              B, nsplit_c, (const float*)ws.fac, nchunks / nsplit_q, (const float*)ws.Pmat, part_O_c));
-  } else {
-    ESR_KT("inbatch2h_pc8_kernel", st,
-           hipLaunchKernelGGL((inbatch2h_pc8_kernel<true>), dim3(grid_c), dim3(512), 0, st, (const _Float16*)ws.Qh,
-                              B, nsplit_c, (const float*)ws.fac, nchunks / nsplit_q, (const float*)ws.Pmat, part_O_c));
-  }
+  ESR_KT("inbatch2h_pct_kernel", st,
+         hipLaunchKernelGGL(inbatch2h_pct_kernel, dim3(grid_c), dim3(512), 0, st, (const _Float16*)ws.Qt,
+                            (const _Float16*)ws.Qh, B, nsplit_c, (const float*)ws.fac, nc_q, (const char*)ws.Pmat,
+                            (const float*)ws.cexp, (const int*)ws.cflags, force_general, part_O_c));
   if (merge_upd) return merging_update(nsplit_c, part_O_c);
   // O_C' = 2^(eq + 14) sum_i (p_ij / l_i) q_i
   ESR_KT("inbatch3_merge_kernel_c", st,
@@ -2457,6 +2328,20 @@ int esr_inbatch_towers_fwd_bwd_f16x2(const void* query_table, int64_t Vq, const 
   return inbatch2h_run("esr_inbatch_towers_fwd_bwd_f16x2", RowSrc{query_table, query_ids, dtype == ESR_BF16, D},
                        RowSrc{cand_table, cand_ids, dtype == ESR_BF16, D}, gq_rows, gc_rows, B, D, scale, regularization,
                        batch_size, loss, lse, gQ, gC, workspace, workspace_bytes, stream);
+}
+
+int esr_inbatch2h_pass_c_forms(const void* workspace, size_t workspace_bytes, int64_t B, int32_t* forms,
+                               esr_stream_t stream) {
+  ESR_REQUIRE(workspace && forms && B > 0 && B % k3Owned == 0 && B <= kHMaxB &&
+                  workspace_bytes >= esr_inbatch2h_workspace_bytes(B, k3D),
+              "esr_inbatch2h_pass_c_forms: bad workspace / B");
+  InbatchHWs ws;
+  inbatch2h_ws_layout(B, (char*)const_cast<void*>(workspace), &ws);
+  if (hipMemcpyAsync(forms, ws.cflags, 8 * sizeof(int32_t), hipMemcpyDeviceToDevice, as_stream(stream)) != hipSuccess) {
+    set_error("esr_inbatch2h_pass_c_forms: copy failed");
+    return ESR_ELAUNCH;
+  }
+  return ESR_OK;
 }
 
 // ---- the whole in-batch training step as ONE call (round 5) ---------------------------------------------------------------

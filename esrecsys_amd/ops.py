@@ -514,7 +514,7 @@ def inbatch_split_path(precision, B, D, bf16_tables=False):
     return "f16x2" if h_ok and _inbatch_auto_split() == "f16x2" else "bf16x3"
 
 
-def inbatch_softmax_fwd_bwd(Q, C, scale, regularization, batch_size, precision="auto"):
+def inbatch_softmax_fwd_bwd(Q, C, scale, regularization, batch_size, precision="auto", pass_c_forms=None):
     """In-batch-negative softmax on the matrix cores.  Returns (loss[1], lse[B], gQ, gC).
 
     precision "f32": exact-f32 MFMA (v_mfma_f32_32x32x2_f32).  "bf16x3": f32-equivalent products from three
@@ -544,6 +544,12 @@ def inbatch_softmax_fwd_bwd(Q, C, scale, regularization, batch_size, precision="
         fn, name = lib.esr_inbatch_softmax_fwd_bwd, "esr_inbatch_softmax_fwd_bwd"
     check(fn(_p(Q), _p(C), B, D, float(scale), float(regularization), float(batch_size), _p(loss), _p(lse), _p(gQ),
              _p(gC), _p(ws), ws.numel(), _stream()), name)
+    if pass_c_forms is not None:  # diagnostics: which form pass C took per pass-Q split (include/esr_hip.h)
+        if path != "f16x2":
+            raise ValueError("pass_c_forms: only the f16x2 path has them (this call took %r)" % path)
+        _req(pass_c_forms, torch.int32, "pass_c_forms")
+        check(lib.esr_inbatch2h_pass_c_forms(_p(ws), ws.numel(), B, _p(pass_c_forms), _stream()),
+              "esr_inbatch2h_pass_c_forms")
     return loss, lse, gQ, gC
 
 

@@ -281,7 +281,8 @@ int esr_inbatch_towers_fwd_bwd_bf16x3(const void* query_table, int64_t Vq, const
  * product instead of six bf16 ones, i.e. half the matrix-core work of the bf16x3 entry points at the same f32-grade
  * error (the kernels run at the chip's power limit, so fewer MFMAs is what shortens the step).  fp16's narrow range is
  * handled inside: a per-matrix power-of-two scale from the batch's largest |element|, and an exponent reference tied
- * to the true row maximum.  Pass C reads the B x B probabilities pass Q stored: D <= 128 and a multiple of 4 (narrower
+ * to the true row maximum.  Pass C reads the B x B probabilities pass Q stored (as the two fp16 planes pass Q forms for
+ * its own product; their per-row factors ride on per-split scaled copies of Q -- esr_inbatch2h_pass_c_forms): D <= 128 and a multiple of 4 (narrower
  * rows are zero-padded into the 128-column tiles; gQ / gC are [B, D]), B a multiple of 128 and <= 16384 (workspace ~ 4 B^2 bytes); esr_inbatch2h_workspace_bytes returns 256 for a B it cannot serve.
  * GUARANTEED ERROR (tests/test_gpu_kernels.py): an operand element x of a matrix whose largest |element| is M enters the
  * products as x (1 + d) + a with |d| <= 2^-24 and |a| <= 2^-26 M 2^-16 -- relative for elements within 2^-16 of M,
@@ -303,6 +304,14 @@ int esr_inbatch_towers_fwd_bwd_f16x2(const void* query_table, int64_t Vq, const 
                                      float regularization, float batch_size, float* loss, float* lse,
                                      float* gQ, float* gC, void* workspace, size_t workspace_bytes,
                                      esr_stream_t stream);
+/* Which form pass C of the LAST f16x2 call on `workspace` took, per pass-Q split (forms[8], device memory, copied on
+ * `stream`): 0 = the scaled copy of Q for that split fed the matrix cores as stored (round 6: dC_j = sum_i P'_ij (f_is q_i),
+ * the stored fp16 planes of P' are the MFMA operand, no VALU work on probabilities), non-zero = some row of the copy lay
+ * more than ~17 binades under the copy's largest element and the workgroups of that split applied the factors to the
+ * probabilities in registers instead (the general form; also taken for every split when B / 32 / splits is not a
+ * multiple of 8, where the words stay 0).  Diagnostics and tests; no reference counterpart. */
+int esr_inbatch2h_pass_c_forms(const void* workspace, size_t workspace_bytes, int64_t B, int32_t* forms,
+                               esr_stream_t stream);
 
 /* The whole in-batch training step of the two towers as ONE call (fp16 x 2 score path + the build's row-sparse Adagrad;
  * what train_step(state, scene, pos, None, ...) of esrecsys_amd/pinterest/train_shop_the_look.py issues per batch):

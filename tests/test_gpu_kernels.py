@@ -17,6 +17,7 @@ from oracle import topk as o_topk
 pytestmark = pytest.mark.gpu
 TOL = 1e-5  # fp32 loss / grad tolerance stated by north_star
 F64 = np.float64
+F32 = np.float32
 
 
 def T(x, dev, dtype=None):
@@ -657,52 +658,106 @@ def test_inbatch_f16x2_operand_and_score_ranges(dev, mag_q, mag_c, scale):
         assert max(errs["f16x2"]) <= 4 * max(errs["f32"]), errs
 
 
-@pytest.mark.parametrize("B", [256, 1024, 8192])
-def test_inbatch_f16x2_64_row_waves_equal_32_row_waves(dev, B, monkeypatch):
-    """ESR_IB2H_Q=64: pass Q with two 32-row sets per wave (half the LDS reads and DMA traffic per MFMA; measured the
-    same 111-113 us -- the pass is bound by MFMA energy at the power cap).  Same arithmetic per row, different split
-    geometry: equal to the default to f32 roundings of the split merge."""
-    from esrecsys_amd import ops
-    g = torch.Generator(device=dev).manual_seed(B)
-    D = 128
-    q = torch.randn((B, D), generator=g, device=dev) * D ** -0.5
-    c = torch.randn((B, D), generator=g, device=dev) * D ** -0.5
-    c[B - 40] = 3.0 * q[7] / q[7].norm()   # a late dominant candidate: the redo launch of the 64-row kernel too
-    monkeypatch.delenv("ESR_IB2H_Q", raising=False)
-    ref = [t.clone() for t in ops.inbatch_softmax_fwd_bwd(q, c, 8.0, 0.1, float(B), precision="f16x2")]
-    monkeypatch.setenv("ESR_IB2H_Q", "64")
-    out = ops.inbatch_softmax_fwd_bwd(q, c, 8.0, 0.1, float(B), precision="f16x2")
-    for a, b in zip(ref, out):
-        assert bool(torch.isfinite(b).all()) and rel_err(N(b), N(a)) <= 2e-6
-
-
-@pytest.mark.parametrize("B", [128, 256, 384, 768, 1280, 1664, 4096])
+@pytest.mark.parametrize("B", [128, 256, 384, 768, 1280, 1664, 2048, 2304, 4096])
 def test_inbatch_f16x2_pass_c_forms_agree(dev, B, monkeypatch):
-    """Pass C streams the stored probabilities either through registers three chunks ahead (default) or as LDS-DMAs one
-    chunk ahead (ESR_IB2H_PC=dma): the same values reach the same MFMAs in the same order, so the two forms must agree
-    BIT FOR BIT -- at chunk counts per split of 1, 2, 3, 5, 13 and 16 (prologue only, one or two tail iterations, odd and
-    even trips of the two-iteration loop) -- and both with the exact-f32 kernel to the path's tolerance.  A staged load
-    left in flight past the end of a column once corrupted the epilogue of the 1- and 2-chunk launches."""
+    """Pass C (round 6) takes the stored fp16 planes of the probabilities as its MFMA operand and streams the scaled
+    copy of Q (f_i q_i), or -- the general form: ESR_IB2H_PC=general, a flagged split -- applies the factors to the
+    probabilities in registers.  Different roundings (f (hi + lo) vs P' (f q)), same bound: both forms against the
+    exact-f32 kernel to the path's tolerance and against each other -- at chunk counts per split of 1, 2, 3, 5, 8, 9, 13 and
+    16 (the three-slot rings' prologue, every remainder of the three-step loop, half-empty last workgroups) -- and each
+    form bit-stable from run to run (a request left in flight past the end of a column once corrupted the epilogue of
+    the 1- and 2-chunk launches)."""
     from esrecsys_amd import ops
     g = torch.Generator(device=dev).manual_seed(7 * B)
     D = 128
     q = torch.randn((B, D), generator=g, device=dev) * D ** -0.5
     c = torch.randn((B, D), generator=g, device=dev) * D ** -0.5
     outs = {}
-    for form in ("stage", "dma"):
-        monkeypatch.setenv("ESR_IB2H_PC", form)
-        for rep in range(3):  # repeated: a dangling load shows up as run-to-run differences
-            cur = [t.clone() for t in ops.inbatch_softmax_fwd_bwd(q, c, -6.0, 0.1, 77.0, precision="f16x2")]
+    forms = torch.full((8,), -1, dtype=torch.int32, device=dev)
+    for form in ("copy", "general"):
+        if form == "general":
+            monkeypatch.setenv("ESR_IB2H_PC", "general")
+        else:
+            monkeypatch.delenv("ESR_IB2H_PC", raising=False)
+        for rep in range(3):  # repeated: a dangling request shows up as run-to-run differences
+            cur = [t.clone() for t in ops.inbatch_softmax_fwd_bwd(q, c, -6.0, 0.1, 77.0, precision="f16x2",
+                                                                  pass_c_forms=forms)]
             assert all(bool(torch.isfinite(t).all()) for t in cur)
+            assert int(forms.abs().sum()) == 0   # benign rows: one reference per row, no split is flagged
             if form in outs:
                 assert all(torch.equal(a, b) for a, b in zip(outs[form], cur)), (form, rep)
             outs[form] = cur
-    for a, b in zip(outs["stage"], outs["dma"]):
-        assert torch.equal(a, b)
     monkeypatch.delenv("ESR_IB2H_PC", raising=False)
     ref = ops.inbatch_softmax_fwd_bwd(q, c, -6.0, 0.1, 77.0, precision="f32")
-    for a, b in zip(outs["stage"], ref):
-        assert rel_err(N(a), N(b)) <= 1e-5
+    for name in outs:
+        for a, b in zip(outs[name], ref):
+            assert rel_err(N(a), N(b)) <= 1e-5, name
+    for a, b in zip(outs["copy"], outs["general"]):
+        assert rel_err(N(a), N(b)) <= 2e-6
+
+
+@pytest.mark.parametrize("B", [2048, 8192])
+def test_inbatch_f16x2_pass_c_redone_split_vs_oracle(dev, B):
+    """A pass-Q workgroup that overflows its optimistic reference redoes itself against the exact maximum of ITS range:
+    its rows' probabilities then carry a reference of their own for that split, the row factor no longer fits, and
+    scaleq2h_kernel must flag the split (esr_inbatch2h_pass_c_forms) so that pass C applies the per-(row, split) factors
+    in registers there.  Row 5 is dominated by a candidate of the last split (score 36 against ~0): against the fp64 oracle,
+    element-wise on gC."""
+    from esrecsys_amd import ops
+    from oracle import stl_head as o_stl
+    rng = np.random.default_rng(B)
+    D = 128
+    q = (rng.standard_normal((B, D)) * D ** -0.5).astype(F32)
+    c = (rng.standard_normal((B, D)) * D ** -0.5).astype(F32)
+    u = rng.standard_normal(D).astype(F32)
+    u /= np.linalg.norm(u)
+    q[5] = 6.0 * u
+    c[B - 100] = 6.0 * u
+    el, else_, egq, egc = o_stl.inbatch_softmax_loss_and_grads(q.astype(F64), c.astype(F64), 0.1, float(B), 1.0, F64)
+    forms = torch.full((8,), -1, dtype=torch.int32, device=dev)
+    loss, lse, gq, gc = ops.inbatch_softmax_fwd_bwd(T(q, dev), T(c, dev), 1.0, 0.1, float(B), precision="f16x2",
+                                                    pass_c_forms=forms)
+    f = forms.cpu().numpy()
+    assert f.min() >= 0 and f.any(), f
+    assert abs(float(loss) - el) <= 1e-5 * abs(el)
+    assert rel_err(N(lse), else_) <= 1e-5 and rel_err(N(gq), egq) <= 1e-5 and rel_err(N(gc), egc) <= 1e-5
+    tol = 1e-4 * np.maximum(np.abs(egc), 1e-3 * np.abs(egc).max())
+    assert (np.abs(N(gc).astype(F64) - egc) <= tol).all()
+
+
+@pytest.mark.parametrize("B", [1024, 8192])
+def test_inbatch_f16x2_pass_c_range_guard_vs_oracle(dev, B):
+    """The range guard of pass C's scaled copy of Q.  Every row but one is sharply peaked on its positive (normaliser ~16,
+    factor ~2^10); row `hot` sees ~B candidates 2^15 above its reference (normaliser ~2^28, factor ~2^-14): f q of that
+    row lies ~20 binades under the copy's largest element, its second fp16 plane would be subnormal.  scaleq2h_kernel
+    must flag every split, and the result must hold the oracle's bound INCLUDING column 0 of gC, which only the hot row
+    feeds (q[:, 0] is zero elsewhere): its entries are p_hot,j q_hot / B -- exactly what the copy form would have lost."""
+    from esrecsys_amd import ops
+    from oracle import stl_head as o_stl
+    rng = np.random.default_rng(3 * B)
+    D = 128
+    q = (rng.standard_normal((B, D)) * D ** -0.5).astype(F32)
+    q[:, 0] = 0.0
+    c = (30.0 * q / np.linalg.norm(q, axis=1, keepdims=True)).astype(F32)   # peaked rows: diagonal score ~30
+    hot = 77
+    alpha = 2.76                                   # alpha^2 log2(e) = 11 bits above the reference's 2^4
+    q[hot] = 0.0
+    q[hot, 0] = alpha
+    c[:, 0] = alpha
+    c[:32, 0] = 0.0                                # chunk 0 (the reference's sample) and the positive: score 0
+    c[hot] = 0.0
+    el, else_, egq, egc = o_stl.inbatch_softmax_loss_and_grads(q.astype(F64), c.astype(F64), 0.1, float(B), 1.0, F64)
+    forms = torch.full((8,), -1, dtype=torch.int32, device=dev)
+    loss, lse, gq, gc = ops.inbatch_softmax_fwd_bwd(T(q, dev), T(c, dev), 1.0, 0.1, float(B), precision="f16x2",
+                                                    pass_c_forms=forms)
+    f = forms.cpu().numpy()
+    nsplit = 8 if B >= 1024 else 4
+    assert f.min() >= 0 and (f[:nsplit] != 0).all(), f
+    assert abs(float(loss) - el) <= 1e-5 * abs(el)
+    assert rel_err(N(lse), else_) <= 1e-5 and rel_err(N(gq), egq) <= 1e-5 and rel_err(N(gc), egc) <= 1e-5
+    col = N(gc)[:, 0].astype(F64)
+    assert np.abs(egc[:, 0]).max() > 0
+    assert (np.abs(col - egc[:, 0]) <= 1e-4 * np.abs(egc[:, 0]) + 1e-12).all()
 
 
 def test_inbatch_f16x2_largest_batch_against_exact_f32(dev):
