@@ -48,11 +48,11 @@ SIGNATURES = {
     "esr_glove_fwd_bwd": (c_int, [c_f32p, c_f32p, c_i64, c_int, c_i32p, c_f32p, c_i64, c_int, c_f32p, c_f32p,
                                   c_f32p, c_vp, c_size, c_vp]),
     "esr_glove_step_workspace_bytes": (c_size, [c_i64, c_int]),
-    "esr_glove_train_step": (c_int, [c_f32p, c_f32p, c_vp, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_i32p, c_f32p, c_i64,
+    "esr_glove_train_step": (c_int, [c_vp, c_vp, c_vp, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_int, c_i32p, c_f32p, c_i64,
                                      c_int, c_f32, c_f32, c_uint32, c_i32p, c_i32p, c_vp, c_int, c_int, c_vp, c_uint32, c_f32p,
                                      c_vp, c_size, c_vp]),
     "esr_stream_gate": (c_int, [c_vp, c_uint32, c_uint32, c_vp]),
-    "esr_glove_train_steps": (c_int, [c_f32p, c_f32p, c_vp, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_int, c_vp, c_vp, c_i64,
+    "esr_glove_train_steps": (c_int, [c_vp, c_vp, c_vp, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_i64,
                                       c_int, c_f32, c_f32, c_uint32, c_i32p, c_i32p, c_vp, c_vp, c_f32p, c_vp, c_size,
                                       c_vp]),
     "esr_glove_plan_bytes": (c_size, [c_i64]),
@@ -77,16 +77,16 @@ SIGNATURES = {
     "esr_ivf_search": (c_int, [c_f32p, c_i64, c_int, c_f32p, c_i32p, c_i32p, c_int, c_int, c_i32p, c_int, c_int, c_f32p,
                                c_i32p, c_vp, c_size, c_vp]),
     "esr_long_run_hint": (c_int, [c_i32p, c_i64, c_int, c_vp, c_int32, c_vp]),
-    "esr_rows_consolidate": (c_int, [c_f32p, c_f32p, c_vp, c_i64, c_int, c_vp]),
+    "esr_rows_consolidate": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     "esr_rows_restamp": (c_int, [c_vp, c_i64, c_vp]),
     "esr_triplet_workspace_bytes": (c_size, [c_i64]),
     "esr_triplet_fwd_bwd": (c_int, [c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_int, c_i32p, c_i32p, c_i32p, c_i64, c_f32, c_f32,
                                     c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_vp, c_size, c_vp]),
     "esr_triplet_step_workspace_bytes": (c_size, [c_i64, c_int]),
-    "esr_triplet_train_step": (c_int, [c_f32p, c_f32p, c_vp, c_f32p, c_i64, c_f32p, c_f32p, c_vp, c_f32p, c_i64, c_int,
+    "esr_triplet_train_step": (c_int, [c_vp, c_vp, c_vp, c_f32p, c_i64, c_vp, c_vp, c_vp, c_f32p, c_i64, c_int, c_int,
                                        c_i32p, c_i32p, c_i32p, c_i64, c_f32, c_f32, c_f32, c_f32, c_uint32, c_i32p,
                                        c_i32p, c_vp, c_int, c_f32p, c_vp, c_size, c_vp]),
-    "esr_triplet_train_steps": (c_int, [c_f32p, c_f32p, c_vp, c_f32p, c_i64, c_f32p, c_f32p, c_vp, c_f32p, c_i64, c_int,
+    "esr_triplet_train_steps": (c_int, [c_vp, c_vp, c_vp, c_f32p, c_i64, c_vp, c_vp, c_vp, c_f32p, c_i64, c_int, c_int,
                                         c_int, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_uint32, c_i32p, c_i32p, c_vp,
                                         c_vp, c_f32p, c_vp, c_size, c_vp]),
     "esr_triplet_plan_bytes": (c_size, [c_i64]),
@@ -226,7 +226,7 @@ def load(path=None):
     global _lib
     if _lib is not None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get("ESR_HIP_LIB") or LIB_PATH  # (ESR_HIP_LIB: another build of the library, for A/B runs)
     if not os.path.exists(path):
         raise EsrLibraryError(
             "%s not found: build it with `python -m esrecsys_amd.build` (hipcc, gfx950). "

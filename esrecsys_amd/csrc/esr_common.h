@@ -263,6 +263,47 @@ __device__ __forceinline__ void row_store(const RowRegs<VEC, NCH>& r, float* __r
     }
   }
 }
+// bf16 table rows (config 4's dtype): the register image stays f32 -- a load widens (exact), a store rounds to nearest
+// even (f32_to_bf16 below).  A float4 chunk of a row is 8 bytes here.
+__device__ __forceinline__ uint16_t f32_to_bf16(float f);
+template <int VEC, int NCH>
+__device__ __forceinline__ void row_load(RowRegs<VEC, NCH>& r, const uint16_t* __restrict__ p, int lig,
+                                         int G, int nvec) {
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int c = lig + k * G;
+    if (c < nvec) {
+      if constexpr (VEC == 4) {
+        const uint2 a = *reinterpret_cast<const uint2*>(p + 4 * c);
+        r.v[k][0] = __uint_as_float(a.x << 16); r.v[k][1] = __uint_as_float(a.x & 0xFFFF0000u);
+        r.v[k][2] = __uint_as_float(a.y << 16); r.v[k][3] = __uint_as_float(a.y & 0xFFFF0000u);
+      } else {
+        r.v[k][0] = __uint_as_float(((uint32_t)p[c]) << 16);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) r.v[k][e] = 0.f;
+    }
+  }
+}
+template <int VEC, int NCH>
+__device__ __forceinline__ void row_store(const RowRegs<VEC, NCH>& r, uint16_t* __restrict__ p, int lig,
+                                          int G, int nvec) {
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int c = lig + k * G;
+    if (c < nvec) {
+      if constexpr (VEC == 4) {
+        uint2 a;
+        a.x = (uint32_t)f32_to_bf16(r.v[k][0]) | ((uint32_t)f32_to_bf16(r.v[k][1]) << 16);
+        a.y = (uint32_t)f32_to_bf16(r.v[k][2]) | ((uint32_t)f32_to_bf16(r.v[k][3]) << 16);
+        *reinterpret_cast<uint2*>(p + 4 * c) = a;
+      } else {
+        p[c] = f32_to_bf16(r.v[k][0]);
+      }
+    }
+  }
+}
 template <int VEC, int NCH>
 __device__ __forceinline__ float row_dot_partial(const RowRegs<VEC, NCH>& a, const RowRegs<VEC, NCH>& b) {
   float acc = 0.f;

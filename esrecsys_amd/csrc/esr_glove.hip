@@ -418,8 +418,10 @@ __global__ __launch_bounds__(kBlock) void glove_resolve_kernel(const int32_t* __
 // the versioned read-modify-write of one row with its summed gradient g: the row was read where `code` says it lived
 // when the step began (`own`), its new value goes to the OTHER buffer and the byte takes this step's stamp.
 // `a` = the row's accumulator, loaded by the caller next to `own`.
-template <int VEC, int NCH>
-__device__ __forceinline__ void step_apply(float* __restrict__ emb0, float* __restrict__ emb1, uint8_t* __restrict__ loc,
+// TR: the embedding table's element type -- float, or uint16_t for bf16 rows (round 6; the register image stays f32: loads
+// widen, stores round to nearest even; accumulators and the bias table are fp32 either way)
+template <int VEC, int NCH, class TR>
+__device__ __forceinline__ void step_apply(TR* __restrict__ emb0, TR* __restrict__ emb1, uint8_t* __restrict__ loc,
                                            float* __restrict__ accum, uint32_t code, uint32_t T,
                                            const RowRegs<VEC, NCH>& own, RowRegs<VEC, NCH>& a,
                                            const RowRegs<VEC, NCH>& g, int D, int lig, int G, int nvec, float lr,
@@ -526,9 +528,9 @@ __device__ __forceinline__ float glove_loss_value(int mode, double Bd, double Sw
 // bias values they point at two, and the own row, its accumulator and the first partner row of the NEXT position are
 // requested before the current one is computed.  Written naively -- record, then bytes, then rows, then accumulator --
 // the loop is a chain of dependent round trips and ran at 3.2 TB/s.
-template <int VEC, int NCH>
+template <int VEC, int NCH, class TR>
 __global__ __launch_bounds__(kBlock) void glove_step_kernel(
-    float* __restrict__ emb0, float* __restrict__ emb1, uint8_t* __restrict__ loc, float* __restrict__ accum,
+    TR* __restrict__ emb0, TR* __restrict__ emb1, uint8_t* __restrict__ loc, float* __restrict__ accum,
     const float* __restrict__ bias, int D, int G, const int32_t* __restrict__ sorted_ids,
     const float4* __restrict__ meta, const int32_t* __restrict__ inputs, int64_t n, int64_t B, int mode, uint32_t T,
     int nstat, unsigned long long* __restrict__ stat, float lr, float eps, float* __restrict__ chunk_rows,
@@ -785,7 +787,7 @@ __global__ __launch_bounds__(kBlock) void glove_step_kernel(
           g.v[k][e] = __fmul_rn(-two_over_B, __fsub_rn(g.v[k][e], __fmul_rn(sbar, gc.v[k][e])));
     }
     if (head && ends) {
-      step_apply<VEC, NCH>(emb0, emb1, loc, accum, code, T, own, a, g, D, lig, G, nvec, lr, eps);
+      step_apply<VEC, NCH, TR>(emb0, emb1, loc, accum, code, T, own, a, g, D, lig, G, nvec, lr, eps);
     } else {  // a chunk of a long run: park the partial sum for glove_step_long_kernel
       const int64_t slot = 2 * (p / kStepChunk) + (head ? 1 : 0);
       row_store(g, chunk_rows + slot * D, lig, G, nvec);
@@ -863,8 +865,8 @@ __global__ __launch_bounds__(kBlock) void glove_step_kernel(
 // the versioned read-modify-write of one row with its summed gradient g: the row was read where `code` says it lives
 // (`own`), its new value goes to the OTHER buffer and the byte flips (nobody reads `loc` during this launch: the plan
 // kernel resolved every address).  `a` = the row's accumulator, loaded by the caller next to `own`.
-template <int VEC, int NCH>
-__device__ __forceinline__ void step_apply_resolved(float* __restrict__ emb0, float* __restrict__ emb1, uint8_t* __restrict__ loc,
+template <int VEC, int NCH, class TR>
+__device__ __forceinline__ void step_apply_resolved(TR* __restrict__ emb0, TR* __restrict__ emb1, uint8_t* __restrict__ loc,
                                            float* __restrict__ accum, uint32_t code, const RowRegs<VEC, NCH>& own,
                                            RowRegs<VEC, NCH>& a, const RowRegs<VEC, NCH>& g, int D, int lig, int G,
                                            int nvec, float lr, float eps) {
@@ -887,9 +889,9 @@ __device__ __forceinline__ void step_apply_resolved(float* __restrict__ emb0, fl
 // iteration ahead, and the own row, its accumulator and the first partner row are requested together (the accumulator
 // speculatively: a chunk of a long run does not need it).  Written naively -- code, then own row and record, then
 // partner row, then accumulator -- the same loop was four dependent round trips and ran at 3.2 TB/s.
-template <int VEC, int NCH>
+template <int VEC, int NCH, class TR>
 __global__ __launch_bounds__(kBlock) void glove_step_resolved_kernel(
-    float* __restrict__ emb0, float* __restrict__ emb1, uint8_t* __restrict__ loc, float* __restrict__ accum, int D,
+    TR* __restrict__ emb0, TR* __restrict__ emb1, uint8_t* __restrict__ loc, float* __restrict__ accum, int D,
     int G, const uint32_t* __restrict__ own_code, const float4* __restrict__ meta, int64_t n, int64_t B, int mode,
     int nstat, const double* __restrict__ stat_part, float lr, float eps, float* __restrict__ chunk_rows,
     double2* __restrict__ bias_info, double* __restrict__ pair_part, int* __restrict__ long_flag,
@@ -1013,7 +1015,7 @@ __global__ __launch_bounds__(kBlock) void glove_step_resolved_kernel(
     const bool ends = q == n || ((q == p + 1 ? code_n : own_code[q]) & kIdMask) != id;
     if (lig == 0) bias_info[p] = make_double2(bsum, (double)(e_run - p));
     if (head && ends) {
-      step_apply_resolved<VEC, NCH>(emb0, emb1, loc, accum, code, own, a, g, D, lig, G, nvec, lr, eps);
+      step_apply_resolved<VEC, NCH, TR>(emb0, emb1, loc, accum, code, own, a, g, D, lig, G, nvec, lr, eps);
     } else {  // a chunk of a long run: park the partial sum for glove_step_long_kernel
       const int64_t slot = 2 * (p / kStepChunk) + (head ? 1 : 0);
       row_store(g, chunk_rows + slot * D, lig, G, nvec);
@@ -1032,9 +1034,9 @@ __global__ __launch_bounds__(kBlock) void glove_step_resolved_kernel(
 
 // long: segment_long_kernel's screening and fixed-order combination over the parked chunk partials; also folds the
 // chunks' bias sums into the head's bias_info entry.  Launched only when a run may have outgrown its head chunk.
-template <int VEC, int NCH>
+template <int VEC, int NCH, class TR>
 __global__ __launch_bounds__(kBlock) void glove_step_long_kernel(
-    float* __restrict__ emb0, float* __restrict__ emb1, uint8_t* __restrict__ loc, float* __restrict__ accum, int D,
+    TR* __restrict__ emb0, TR* __restrict__ emb1, uint8_t* __restrict__ loc, float* __restrict__ accum, int D,
     int G, const int32_t* __restrict__ sorted_ids, int64_t n, uint32_t T, float lr, float eps,
     const float* __restrict__ chunk_rows, double2* __restrict__ bias_info, const int* __restrict__ parked, int npair,
     const double* __restrict__ pair_part, double* __restrict__ pair_tot) {
@@ -1155,7 +1157,7 @@ __global__ __launch_bounds__(kBlock) void glove_step_long_kernel(
         RowRegs<VEC, NCH> own, a;
         row_load(own, ((code & kLocBit) ? emb1 : emb0) + (int64_t)id * D, lig, G, nvec);
         row_load(a, accum + (int64_t)id * D, lig, G, nvec);
-        step_apply<VEC, NCH>(emb0, emb1, loc, accum, code, T, own, a, acc, D, lig, G, nvec, lr, eps);
+        step_apply<VEC, NCH, TR>(emb0, emb1, loc, accum, code, T, own, a, acc, D, lig, G, nvec, lr, eps);
       }
       __syncthreads();
     }
@@ -1407,17 +1409,19 @@ int esr_glove_plan(const int32_t* const* inputs, const float* const* targets, in
 }  // extern "C"
 
 struct GloveTables {
-  float* emb;
-  float* emb_shadow;
+  void* emb;         // f32 or bf16 rows (dtype)
+  void* emb_shadow;
   uint8_t* emb_loc;
   float* emb_accum;
   float* bias;
   float* bias_accum;
   int D;
+  int dtype;
 };
 
-// one step's launches (arguments validated by the callers)
-static void launch_glove_step(const GloveTables& t, const int32_t* inputs, const float* target, int64_t B, int mode,
+// one step's launches (arguments validated by the callers); T: the embedding rows' element type (GloveTables::dtype)
+template <class T>
+static void launch_glove_step_t(const GloveTables& t, const int32_t* inputs, const float* target, int64_t B, int mode,
                               float lr, float eps, uint32_t stamp, const int32_t* sorted_ids, const int32_t* perm,
                               void* plan, int long_runs, int blocks_per_cu, uint32_t* start_flag,
                               uint32_t start_value, float* loss, const StepWs& ws, hipStream_t st) {
@@ -1442,12 +1446,12 @@ static void launch_glove_step(const GloveTables& t, const int32_t* inputs, const
     // the update kernel's single resident wave-set waiting for a slot: 126 against 109 us for the same kernel.  (An
     // event recorded here did the same job, but the marker cost the main queue ~7 us between resolve and update.)
     ESR_DISPATCH_ROW(g, {
-      static const int resident_all = resident_blocks((const void*)glove_step_resolved_kernel<VEC, NCH>, 0);
+      static const int resident_all = resident_blocks((const void*)glove_step_resolved_kernel<VEC, NCH, T>, 0);
       const int resident = blocks_per_cu > 0
-                               ? resident_blocks((const void*)glove_step_resolved_kernel<VEC, NCH>, blocks_per_cu)
+                               ? resident_blocks((const void*)glove_step_resolved_kernel<VEC, NCH, T>, blocks_per_cu)
                                : resident_all;
       grid = std::min(grid, resident);
-      ESR_KT("glove_step_resolved_kernel", st, hipLaunchKernelGGL((glove_step_resolved_kernel<VEC, NCH>), dim3(grid), dim3(kBlock), 0, st, t.emb, t.emb_shadow,
+      ESR_KT("glove_step_resolved_kernel", st, hipLaunchKernelGGL((glove_step_resolved_kernel<VEC, NCH, T>), dim3(grid), dim3(kBlock), 0, st, (T*)t.emb, (T*)t.emb_shadow,
                          t.emb_loc, t.emb_accum, D, g.G, (const uint32_t*)ws.own_code, (const float4*)ws.meta_res, n, B,
                          mode, nstat, (const double*)ws.stat_part, lr, eps, ws.chunk_rows, ws.bias_info, ws.pair_part,
                          ws.res_flags, start_flag, start_value));
@@ -1455,7 +1459,7 @@ static void launch_glove_step(const GloveTables& t, const int32_t* inputs, const
       // outgrows its head chunk -- long_runs == 0 -- it is skipped and every finalize workgroup reduces them itself,
       // the same sums in the same order)
       if (long_runs != 0)
-        ESR_KT("glove_step_long_kernel", st, hipLaunchKernelGGL((glove_step_long_kernel<VEC, NCH>), dim3(grid2), dim3(kBlock), 0, st, t.emb, t.emb_shadow,
+        ESR_KT("glove_step_long_kernel", st, hipLaunchKernelGGL((glove_step_long_kernel<VEC, NCH, T>), dim3(grid2), dim3(kBlock), 0, st, (T*)t.emb, (T*)t.emb_shadow,
                            t.emb_loc, t.emb_accum, D, g.G, sorted_ids, n, stamp, lr, eps, (const float*)ws.chunk_rows,
                            ws.bias_info, (const int*)ws.res_flags, grid, (const double*)ws.pair_part, ws.pair_tot));
     });
@@ -1483,16 +1487,16 @@ static void launch_glove_step(const GloveTables& t, const int32_t* inputs, const
     // one resident wave-set: every group walks a contiguous slice, so a grid larger than what the chip holds at once
     // only adds a second, partly filled round (94 VGPRs -> 5 blocks per CU: 2048 blocks ran as 1280 + 768); the
     // prologue's wait also relies on the workgroups it waits for having been dispatched (they have: index order)
-    static const int resident_all = resident_blocks((const void*)glove_step_kernel<VEC, NCH>, 0);  // (one query)
-    const int resident = blocks_per_cu > 0 ? resident_blocks((const void*)glove_step_kernel<VEC, NCH>, blocks_per_cu)
+    static const int resident_all = resident_blocks((const void*)glove_step_kernel<VEC, NCH, T>, 0);  // (one query)
+    const int resident = blocks_per_cu > 0 ? resident_blocks((const void*)glove_step_kernel<VEC, NCH, T>, blocks_per_cu)
                                            : resident_all;
     grid = std::min(grid + nstat, std::max(resident, nstat + 1));  // nstat statistics-only workgroups in front
-    ESR_KT("glove_step_kernel", st, hipLaunchKernelGGL((glove_step_kernel<VEC, NCH>), dim3(grid), dim3(kBlock), 0, st, t.emb, t.emb_shadow, t.emb_loc,
+    ESR_KT("glove_step_kernel", st, hipLaunchKernelGGL((glove_step_kernel<VEC, NCH, T>), dim3(grid), dim3(kBlock), 0, st, (T*)t.emb, (T*)t.emb_shadow, t.emb_loc,
                        t.emb_accum, (const float*)t.bias, D, g.G, sorted_ids, (const float4*)pl.meta, inputs, n, B, mode,
                        stamp, nstat, pl.stat, lr, eps, ws.chunk_rows, ws.bias_info, pl.fin, fuse_fin ? 1 : 0, t.bias,
                        t.bias_accum, loss, pl.flags, start_flag, start_value));
     if (long_runs != 0)  // 0 = the caller knows (esr_glove_plan's hint) that no run outgrows its head chunk
-      ESR_KT("glove_step_long_kernel", st, hipLaunchKernelGGL((glove_step_long_kernel<VEC, NCH>), dim3(grid2), dim3(kBlock), 0, st, t.emb, t.emb_shadow,
+      ESR_KT("glove_step_long_kernel", st, hipLaunchKernelGGL((glove_step_long_kernel<VEC, NCH, T>), dim3(grid2), dim3(kBlock), 0, st, (T*)t.emb, (T*)t.emb_shadow,
                          t.emb_loc, t.emb_accum, D, g.G, sorted_ids, n, stamp, lr, eps, (const float*)ws.chunk_rows,
                          ws.bias_info, (const int*)pl.flags, 0, (const double*)nullptr, (double*)nullptr));
   });
@@ -1503,6 +1507,18 @@ static void launch_glove_step(const GloveTables& t, const int32_t* inputs, const
                        (const double2*)ws.bias_info, t.bias, t.bias_accum, lr, eps, loss));
 }
 
+static void launch_glove_step(const GloveTables& t, const int32_t* inputs, const float* target, int64_t B, int mode,
+                              float lr, float eps, uint32_t stamp, const int32_t* sorted_ids, const int32_t* perm,
+                              void* plan, int long_runs, int blocks_per_cu, uint32_t* start_flag,
+                              uint32_t start_value, float* loss, const StepWs& ws, hipStream_t st) {
+  if (t.dtype == ESR_BF16)
+    launch_glove_step_t<uint16_t>(t, inputs, target, B, mode, lr, eps, stamp, sorted_ids, perm, plan, long_runs,
+                                  blocks_per_cu, start_flag, start_value, loss, ws, st);
+  else
+    launch_glove_step_t<float>(t, inputs, target, B, mode, lr, eps, stamp, sorted_ids, perm, plan, long_runs,
+                               blocks_per_cu, start_flag, start_value, loss, ws, st);
+}
+
 #define ESR_GLOVE_STEP_CHECKS(who)                                                                                    \
   ESR_REQUIRE(B > 0 && V > 0 && D > 0, who ": bad sizes V=%lld D=%d B=%lld", (long long)V, D, (long long)B);          \
   ESR_REQUIRE(V <= (int64_t)kIdMask, who ": V=%lld exceeds 2^30 - 1 rows", (long long)V);                             \
@@ -1510,6 +1526,9 @@ static void launch_glove_step(const GloveTables& t, const int32_t* inputs, const
   ESR_REQUIRE(mode == ESR_GLOVE_REFERENCE || mode == ESR_GLOVE_DIAGONAL, who ": bad mode %d", mode);                  \
   ESR_REQUIRE(emb && emb_shadow && emb_loc && emb_accum && bias && bias_accum, who ": null table pointer");           \
   ESR_REQUIRE(emb != emb_shadow, who ": the shadow table must be a second buffer");                                   \
+  ESR_REQUIRE(dtype == ESR_F32 || dtype == ESR_BF16, who ": bad dtype %d", dtype);                                    \
+  ESR_REQUIRE(dtype == ESR_F32 || D % 4 != 0 || !(((uintptr_t)emb | (uintptr_t)emb_shadow) & 7),                      \
+              who ": bf16 tables must be 8-byte aligned");                                                            \
   if (int rc = check_dim(who, D)) return rc;                                                                          \
   if (!workspace || workspace_bytes < esr_glove_step_workspace_bytes(B, D) || ((uintptr_t)workspace & 15)) {          \
     set_error(who ": workspace %zu bytes < %zu required (or misaligned)", workspace_bytes,                            \
@@ -1519,8 +1538,8 @@ static void launch_glove_step(const GloveTables& t, const int32_t* inputs, const
 
 extern "C" {
 
-int esr_glove_train_step(float* emb, float* emb_shadow, uint8_t* emb_loc, float* emb_accum, float* bias,
-                         float* bias_accum, int64_t V, int D, const int32_t* inputs, const float* target, int64_t B,
+int esr_glove_train_step(void* emb, void* emb_shadow, uint8_t* emb_loc, float* emb_accum, float* bias,
+                         float* bias_accum, int64_t V, int dtype, int D, const int32_t* inputs, const float* target, int64_t B,
                          int mode, float lr, float eps, uint32_t stamp, const int32_t* presorted_ids,
                          const int32_t* presorted_perm, void* plan, int long_runs, int blocks_per_cu,
                          uint32_t* start_flag, uint32_t start_value, float* loss, void* workspace,
@@ -1544,14 +1563,14 @@ int esr_glove_train_step(float* emb, float* emb_shadow, uint8_t* emb_loc, float*
     sorted_ids = ws.sorted_ids;
     perm = ws.perm;
   }
-  const GloveTables t{emb, emb_shadow, emb_loc, emb_accum, bias, bias_accum, D};
+  const GloveTables t{emb, emb_shadow, emb_loc, emb_accum, bias, bias_accum, D, dtype};
   launch_glove_step(t, inputs, target, B, mode, lr, eps, stamp, sorted_ids, perm, plan, long_runs, blocks_per_cu,
                     start_flag, start_value, loss, ws, st);
   return check_launch("esr_glove_train_step");
 }
 
-int esr_glove_train_steps(float* emb, float* emb_shadow, uint8_t* emb_loc, float* emb_accum, float* bias,
-                          float* bias_accum, int64_t V, int D, int nbatch, const int32_t* const* inputs,
+int esr_glove_train_steps(void* emb, void* emb_shadow, uint8_t* emb_loc, float* emb_accum, float* bias,
+                          float* bias_accum, int64_t V, int dtype, int D, int nbatch, const int32_t* const* inputs,
                           const float* const* targets, int64_t B, int mode, float lr, float eps, uint32_t first_stamp,
                           const int32_t* sorted_ids, const int32_t* perm, void* plans, const int32_t* long_runs,
                           float* losses, void* workspace, size_t workspace_bytes, esr_stream_t stream) {
@@ -1568,7 +1587,7 @@ int esr_glove_train_steps(float* emb, float* emb_shadow, uint8_t* emb_loc, float
   StepWs ws;
   step_ws_layout(B, D, (char*)workspace, &ws);
   const size_t stride = esr_glove_plan_bytes(B);
-  const GloveTables t{emb, emb_shadow, emb_loc, emb_accum, bias, bias_accum, D};
+  const GloveTables t{emb, emb_shadow, emb_loc, emb_accum, bias, bias_accum, D, dtype};
   for (int b = 0; b < nbatch; ++b)
     launch_glove_step(t, inputs[b], targets[b], B, mode, lr, eps, first_stamp + (uint32_t)b,
                       sorted_ids + (int64_t)b * 2 * B, perm + (int64_t)b * 2 * B, (char*)plans + (size_t)b * stride,
@@ -1576,21 +1595,32 @@ int esr_glove_train_steps(float* emb, float* emb_shadow, uint8_t* emb_loc, float
   return check_launch("esr_glove_train_steps");
 }
 
-int esr_rows_consolidate(float* primary, const float* shadow, uint8_t* loc, int64_t V, int D, esr_stream_t stream) {
+int esr_rows_consolidate(void* primary, const void* shadow, uint8_t* loc, int64_t V, int dtype, int D,
+                         esr_stream_t stream) {
   ESR_REQUIRE(V >= 0 && D > 0, "esr_rows_consolidate: bad sizes V=%lld D=%d", (long long)V, D);
+  ESR_REQUIRE(dtype == ESR_F32 || dtype == ESR_BF16, "esr_rows_consolidate: bad dtype %d", dtype);
   if (V == 0) return ESR_OK;
   ESR_REQUIRE(primary && shadow && loc, "esr_rows_consolidate: null pointer");
-  const bool vec = D % 4 == 0;
+  const bool vec = D % 4 == 0;  // four elements per lane: 16 bytes of an f32 row, 8 of a bf16 row
   const int nchunk = vec ? D / 4 : D;
   int G = 1;
   while (G < nchunk && G < kWave) G <<= 1;
   const int grid = grid_for_groups(V, G);
-  if (vec)
-    hipLaunchKernelGGL(rows_consolidate_kernel<float4>, dim3(grid), dim3(kBlock), 0, as_stream(stream), (float4*)primary,
+  hipStream_t st = as_stream(stream);
+  if (dtype == ESR_BF16) {
+    if (vec)
+      hipLaunchKernelGGL(rows_consolidate_kernel<uint2>, dim3(grid), dim3(kBlock), 0, st, (uint2*)primary,
+                         (const uint2*)shadow, loc, V, nchunk, G);
+    else
+      hipLaunchKernelGGL(rows_consolidate_kernel<uint16_t>, dim3(grid), dim3(kBlock), 0, st, (uint16_t*)primary,
+                         (const uint16_t*)shadow, loc, V, nchunk, G);
+  } else if (vec) {
+    hipLaunchKernelGGL(rows_consolidate_kernel<float4>, dim3(grid), dim3(kBlock), 0, st, (float4*)primary,
                        (const float4*)shadow, loc, V, nchunk, G);
-  else
-    hipLaunchKernelGGL(rows_consolidate_kernel<float>, dim3(grid), dim3(kBlock), 0, as_stream(stream), primary, shadow,
-                       loc, V, nchunk, G);
+  } else {
+    hipLaunchKernelGGL(rows_consolidate_kernel<float>, dim3(grid), dim3(kBlock), 0, st, (float*)primary,
+                       (const float*)shadow, loc, V, nchunk, G);
+  }
   return check_launch("esr_rows_consolidate");
 }
 

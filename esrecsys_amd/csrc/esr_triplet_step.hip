@@ -585,9 +585,13 @@ __global__ __launch_bounds__(kBlock) void triplet_direct_plan_kernel(const int32
   if (hints && __any(any_long) && (threadIdx.x & 63) == 0) hints[list] = gen;  // (every writer stores the same value)
 }
 
+// T: the table's element type -- float, or uint16_t for bf16 rows (BASELINE config 4's dtype: the register image stays
+// f32, loads widen, stores round to nearest even; accumulators are fp32 either way).  A triplet then moves 3 x (2 + 2 + 4
+// + 4) D = 5 376 bytes at D = 128 instead of 7 680.
+template <class T>
 struct DirectTowers {
-  float* s;     // scene tower, updated in place           virtual rows [0, Vs)
-  float* p;     // product tower                           virtual rows [Vs, Vs + Vp)
+  T* s;         // scene tower, updated in place           virtual rows [0, Vs)
+  T* p;         // product tower                           virtual rows [Vs, Vs + Vp)
   float* sacc;
   float* pacc;
 };
@@ -639,8 +643,8 @@ __device__ __forceinline__ void side_load(RowRegs<VEC, NCH>& r, const float* __r
   }
 }
 
-template <int VEC, int NCH>
-__global__ __launch_bounds__(kBlock) void triplet_direct_kernel(DirectTowers tt, int D, int G,
+template <int VEC, int NCH, class T>
+__global__ __launch_bounds__(kBlock) void triplet_direct_kernel(DirectTowers<T> tt, int D, int G,
                                                                const int32_t* __restrict__ scene_ids,
                                                                const int32_t* __restrict__ pos_ids,
                                                                const int32_t* __restrict__ neg_ids,
@@ -675,9 +679,9 @@ __global__ __launch_bounds__(kBlock) void triplet_direct_kernel(DirectTowers tt,
   for (int64_t b = b_begin; b < b_end; ++b) {
     const int64_t sid = n_sid, pid = n_pid, nid = n_nid;
     const uint2 cs = n_cs, cp = n_cp, cn = n_cn;
-    float* const srow = tt.s + sid * D;
-    float* const prow = tt.p + pid * D;
-    float* const nrow = tt.p + nid * D;
+    T* const srow = tt.s + sid * D;
+    T* const prow = tt.p + pid * D;
+    T* const nrow = tt.p + nid * D;
     RowRegs<VEC, NCH> S, P, N, aS, aP, aN;
     row_load(S, srow, lig, G, nvec);
     row_load(P, prow, lig, G, nvec);
@@ -720,7 +724,7 @@ __global__ __launch_bounds__(kBlock) void triplet_direct_kernel(DirectTowers tt,
     // to the side buffer first, ONE wait covers them, the (up to three) arrivals are counted by atomics issued together
     // -- two dependent round trips per triplet however many of its rows are duplicated -- and only then does an arrival
     // that completed its run sum it.
-    auto step_here = [&](float* row, float* accrow, RowRegs<VEC, NCH>& own, RowRegs<VEC, NCH>& a,
+    auto step_here = [&](T* row, float* accrow, RowRegs<VEC, NCH>& own, RowRegs<VEC, NCH>& a,
                          const RowRegs<VEC, NCH>& g) {
 #pragma unroll
       for (int k = 0; k < NCH; ++k)
@@ -760,7 +764,7 @@ __global__ __launch_bounds__(kBlock) void triplet_direct_kernel(DirectTowers tt,
       oN = (uint32_t)__shfl((int)oN, glane0, 64);
       // an arrival that completed its run: every other occurrence has read the row and left its gradient row -- sum them
       // in sorted order and do the row's one read-modify-write
-      auto complete = [&](uint2 c, float* row, float* accrow, RowRegs<VEC, NCH>& own, RowRegs<VEC, NCH>& a) {
+      auto complete = [&](uint2 c, T* row, float* accrow, RowRegs<VEC, NCH>& own, RowRegs<VEC, NCH>& a) {
         const int64_t head = c.y & kHeadMask;
         const uint32_t len = (c.y >> 29) + 1u;
         RowRegs<VEC, NCH> sum;
@@ -808,8 +812,8 @@ __global__ __launch_bounds__(kBlock) void triplet_direct_loss_kernel(const char*
 // partial i >= 1 = the 32 positions from boundary nxt + 32 (i - 1), each summed left to right from zero; row group gi
 // adds partials gi, gi + NG, ... in order; the groups' sums are combined in group order.  With the same lanes per row
 // (row_geom) a hot row gets the bits esr_sparse_adagrad_scatter_multi gives it.
-template <int VEC, int NCH>
-__global__ __launch_bounds__(kBlock) void triplet_direct_long_kernel(DirectTowers tt, int D, int G, int64_t Vs,
+template <int VEC, int NCH, class T>
+__global__ __launch_bounds__(kBlock) void triplet_direct_long_kernel(DirectTowers<T> tt, int D, int G, int64_t Vs,
                                                                     const int32_t* __restrict__ sorted_ids, int64_t n,
                                                                     float lr, float eps, const float* __restrict__ side,
                                                                     const int* __restrict__ flags,
@@ -881,7 +885,7 @@ __global__ __launch_bounds__(kBlock) void triplet_direct_long_kernel(DirectTower
           for (int e = 0; e < VEC; ++e) acc.v[k][e] += red[((gg * G + lig) * NCH + k) * VEC + e];
       const bool prod = (int64_t)id >= Vs;
       const int64_t r = prod ? (int64_t)id - Vs : (int64_t)id;
-      float* row = (prod ? tt.p : tt.s) + r * D;
+      T* row = (prod ? tt.p : tt.s) + r * D;
       float* accrow = (prod ? tt.pacc : tt.sacc) + r * D;
       RowRegs<VEC, NCH> own, a;
       row_load(own, row, lig, G, nvec);
@@ -993,7 +997,7 @@ static void launch_direct_losses(const DirectLoss& d, size_t stride, int nb, flo
                             1.0 / (double)batch_size, losses));
 }
 
-static int launch_trip_step(const TwoTowers& tt, int D, const RowGeom& g, const int32_t* scene_ids, const int32_t* pos_ids,
+static int launch_trip_step(const TwoTowers& tt, int dtype, int D, const RowGeom& g, const int32_t* scene_ids, const int32_t* pos_ids,
                             const int32_t* neg_ids, int64_t B, float regularization, float batch_size, float lr, float eps,
                             const int32_t* sorted, const int32_t* perm, void* plan, int long_runs, float* loss,
                             const TripWs& ws, hipStream_t st, DirectLoss* direct = nullptr) {
@@ -1012,28 +1016,35 @@ static int launch_trip_step(const TwoTowers& tt, int D, const RowGeom& g, const 
   if (trip_direct_mode()) {
     // rows are stepped in place in the primary buffers (the second buffers and location bytes are not touched: the
     // caller's rows never leave home)
-    const DirectTowers dt{tt.s0, tt.p0, tt.sacc, tt.pacc};
     // lanes per row: a triplet's five dot products are a small part of its work (the stamped walk had six per occurrence
     // and wanted few lanes); ESR_TRIPLET_DIRECT_LANES=few keeps step_geom_few_lanes
     const char* le = getenv("ESR_TRIPLET_DIRECT_LANES");
     const RowGeom gd = (le && le[0] == 'f') ? g : row_geom(D);
     const RowGeom& g = gd;
-    ESR_DISPATCH_ROW(g, {
-      static const int resident = resident_blocks((const void*)triplet_direct_kernel<VEC, NCH>);
-      const int gridd = std::min(grid_for_groups(B, g.G), resident);
-      ESR_KT("triplet_direct_kernel", st, hipLaunchKernelGGL((triplet_direct_kernel<VEC, NCH>), dim3(gridd), dim3(kBlock), 0, st, dt, D, g.G, scene_ids,
-                         pos_ids, neg_ids, (const uint2*)pl.meta, B, regularization, inv_bs, 1, lr, eps, ws.chunk_rows,
-                         pl.cnt, pl.flags, pl.loss_part));
-      if (direct) {  // the caller adds the partials up (one launch for a whole group of steps)
-        direct->nparts = gridd;
-        direct->plan = (const char*)plan;
-        direct->part_off = (size_t)((const char*)pl.loss_part - (const char*)plan);
-      }
-      if (long_runs != 0)  // 0 = the caller knows (the plan's hint) that no run is longer than kDirectMaxRun
-        ESR_KT("triplet_direct_long_kernel", st, hipLaunchKernelGGL((triplet_direct_long_kernel<VEC, NCH>), dim3(256), dim3(kBlock), 0, st, dt, D, g.G,
-                           tt.Vs, sorted, n, lr, eps, (const float*)ws.chunk_rows, (const int*)pl.flags,
-                           (const int32_t*)pl.long_heads));
-    });
+#define ESR_TRIP_DIRECT_LAUNCH(T)                                                                                      \
+    ESR_DISPATCH_ROW(g, {                                                                                              \
+      const DirectTowers<T> dt{(T*)tt.s0, (T*)tt.p0, tt.sacc, tt.pacc};                                                \
+      static const int resident = resident_blocks((const void*)triplet_direct_kernel<VEC, NCH, T>);                    \
+      const int gridd = std::min(grid_for_groups(B, g.G), resident);                                                   \
+      ESR_KT("triplet_direct_kernel", st, hipLaunchKernelGGL((triplet_direct_kernel<VEC, NCH, T>), dim3(gridd), dim3(kBlock), 0, st, dt, D, g.G, scene_ids, \
+                         pos_ids, neg_ids, (const uint2*)pl.meta, B, regularization, inv_bs, 1, lr, eps, ws.chunk_rows, \
+                         pl.cnt, pl.flags, pl.loss_part));                                                             \
+      if (direct) {  /* the caller adds the partials up (one launch for a whole group of steps) */                     \
+        direct->nparts = gridd;                                                                                        \
+        direct->plan = (const char*)plan;                                                                              \
+        direct->part_off = (size_t)((const char*)pl.loss_part - (const char*)plan);                                    \
+      }                                                                                                                \
+      if (long_runs != 0)  /* 0 = the caller knows (the plan's hint) that no run is longer than kDirectMaxRun */       \
+        ESR_KT("triplet_direct_long_kernel", st, hipLaunchKernelGGL((triplet_direct_long_kernel<VEC, NCH, T>), dim3(256), dim3(kBlock), 0, st, dt, D, g.G, \
+                           tt.Vs, sorted, n, lr, eps, (const float*)ws.chunk_rows, (const int*)pl.flags,               \
+                           (const int32_t*)pl.long_heads));                                                            \
+    })
+    if (dtype == ESR_BF16) {
+      ESR_TRIP_DIRECT_LAUNCH(uint16_t);
+    } else {
+      ESR_TRIP_DIRECT_LAUNCH(float);
+    }
+#undef ESR_TRIP_DIRECT_LAUNCH
     return ESR_OK;
   }
   ESR_DISPATCH_ROW(g, {
@@ -1063,6 +1074,10 @@ static int launch_trip_step(const TwoTowers& tt, int D, const RowGeom& g, const 
   ESR_REQUIRE(trip_direct_mode() || (scene != scene_shadow && product != product_shadow),                              \
               who ": a shadow table must be a second buffer");                                                         \
   ESR_REQUIRE(batch_size != 0.f, who ": batch_size must be non-zero");                                                 \
+  ESR_REQUIRE(dtype == ESR_F32 || (dtype == ESR_BF16 && trip_direct_mode()),                                           \
+              who ": dtype %d (f32, or bf16 rows in the direct step)", dtype);                                         \
+  ESR_REQUIRE(dtype == ESR_F32 || D % 4 != 0 || !(((uintptr_t)scene | (uintptr_t)product) & 7),                        \
+              who ": bf16 tables must be 8-byte aligned");                                                             \
   const RowGeom g = step_geom_few_lanes(D);                                                                            \
   ESR_REQUIRE(g.nch <= kMaxChunksPerLane, who ": D=%d not supported", D);                                              \
   if (!workspace || workspace_bytes < esr_triplet_step_workspace_bytes(B, D) || ((uintptr_t)workspace & 15)) {         \
@@ -1073,9 +1088,9 @@ static int launch_trip_step(const TwoTowers& tt, int D, const RowGeom& g, const 
 
 extern "C" {
 
-int esr_triplet_train_step(float* scene, float* scene_shadow, uint8_t* scene_loc, float* scene_accum, int64_t Vs,
-                           float* product, float* product_shadow, uint8_t* product_loc, float* product_accum,
-                           int64_t Vp, int D, const int32_t* scene_ids, const int32_t* pos_ids,
+int esr_triplet_train_step(void* scene, void* scene_shadow, uint8_t* scene_loc, float* scene_accum, int64_t Vs,
+                           void* product, void* product_shadow, uint8_t* product_loc, float* product_accum,
+                           int64_t Vp, int dtype, int D, const int32_t* scene_ids, const int32_t* pos_ids,
                            const int32_t* neg_ids, int64_t B, float regularization, float batch_size, float lr,
                            float eps, uint32_t stamp, const int32_t* presorted_ids, const int32_t* presorted_perm,
                            void* plan, int long_runs, float* loss, void* workspace, size_t workspace_bytes,
@@ -1104,18 +1119,18 @@ int esr_triplet_train_step(float* scene, float* scene_shadow, uint8_t* scene_loc
     sorted = ws.sorted_ids;
     perm = ws.perm;
   }
-  TwoTowers tt{scene, scene_shadow, product, product_shadow, scene_loc, product_loc, scene_accum, product_accum, Vs,
-               stamp};
+  TwoTowers tt{(float*)scene, (float*)scene_shadow, (float*)product, (float*)product_shadow, scene_loc, product_loc,
+               scene_accum, product_accum, Vs, stamp};
   DirectLoss dl;
-  launch_trip_step(tt, D, g, scene_ids, pos_ids, neg_ids, B, regularization, batch_size, lr, eps, sorted, perm, plan,
+  launch_trip_step(tt, dtype, D, g, scene_ids, pos_ids, neg_ids, B, regularization, batch_size, lr, eps, sorted, perm, plan,
                    long_runs, loss, ws, st, &dl);
   if (dl.nparts) launch_direct_losses(dl, 0, 1, batch_size, loss, st);
   return check_launch("esr_triplet_train_step");
 }
 
-int esr_triplet_train_steps(float* scene, float* scene_shadow, uint8_t* scene_loc, float* scene_accum, int64_t Vs,
-                            float* product, float* product_shadow, uint8_t* product_loc, float* product_accum,
-                            int64_t Vp, int D, int nbatch, const int32_t* const* ids, int64_t B, float regularization,
+int esr_triplet_train_steps(void* scene, void* scene_shadow, uint8_t* scene_loc, float* scene_accum, int64_t Vs,
+                            void* product, void* product_shadow, uint8_t* product_loc, float* product_accum,
+                            int64_t Vp, int dtype, int D, int nbatch, const int32_t* const* ids, int64_t B, float regularization,
                             float batch_size, float lr, float eps, uint32_t first_stamp, const int32_t* sorted_ids,
                             const int32_t* perm, void* plans, const int32_t* long_runs, float* losses, void* workspace,
                             size_t workspace_bytes, esr_stream_t stream) {
@@ -1133,10 +1148,10 @@ int esr_triplet_train_steps(float* scene, float* scene_shadow, uint8_t* scene_lo
   const size_t stride = esr_triplet_plan_bytes(B);
   DirectLoss first;
   for (int b = 0; b < nbatch; ++b) {
-    TwoTowers tt{scene, scene_shadow, product, product_shadow, scene_loc, product_loc, scene_accum, product_accum, Vs,
-                 first_stamp + (uint32_t)b};
+    TwoTowers tt{(float*)scene, (float*)scene_shadow, (float*)product, (float*)product_shadow, scene_loc, product_loc,
+                 scene_accum, product_accum, Vs, first_stamp + (uint32_t)b};
     DirectLoss dl;
-    launch_trip_step(tt, D, g, ids[3 * b], ids[3 * b + 1], ids[3 * b + 2], B, regularization, batch_size, lr, eps,
+    launch_trip_step(tt, dtype, D, g, ids[3 * b], ids[3 * b + 1], ids[3 * b + 2], B, regularization, batch_size, lr, eps,
                      sorted_ids + (int64_t)b * 3 * B, perm + (int64_t)b * 3 * B, (char*)plans + (size_t)b * stride,
                      long_runs ? long_runs[b] : -1, losses + b, ws, st, &dl);
     if (b == 0) first = dl;

@@ -198,8 +198,10 @@ def glove_train_step(emb, shadow, loc, accum, bias, bias_accum, inputs, target, 
     start_flag (int32 [1] device tensor) / start_value: the update kernel announces its start there (stream_gate).
     Returns loss[1]."""
     lib = _lib.load()
-    for name, t in (("emb", emb), ("shadow", shadow), ("accum", accum), ("bias", bias), ("bias_accum", bias_accum),
-                    ("target", target)):
+    dt = _table_dtype(emb, "emb")  # f32, or bf16 rows (both buffers) with fp32 accumulator and bias tables
+    if _table_dtype(shadow, "shadow") != dt:
+        raise TypeError("emb and shadow must have the same dtype")
+    for name, t in (("accum", accum), ("bias", bias), ("bias_accum", bias_accum), ("target", target)):
         _req(t, torch.float32, name)
     _req(loc, torch.uint8, "loc"), _req(inputs, torch.int32, "inputs")
     if stamp is None:
@@ -220,7 +222,7 @@ def glove_train_step(emb, shadow, loc, accum, bias, bias_accum, inputs, target, 
             raise ValueError("presorted ids / perm must have 2 B entries")
     if plan is not None and (plan.dtype != torch.uint8 or plan.numel() < _ws_bytes("esr_glove_plan_bytes", B)):
         raise ValueError("plan must be the uint8 record glove_plan made for a batch of this size")
-    check(lib.esr_glove_train_step(_p(emb), _p(shadow), _p(loc), _p(accum), _p(bias), _p(bias_accum), V, D, _p(inputs),
+    check(lib.esr_glove_train_step(_p(emb), _p(shadow), _p(loc), _p(accum), _p(bias), _p(bias_accum), V, dt, D, _p(inputs),
                                    _p(target), B, mode, float(lr), float(eps), int(stamp), _p(sid), _p(perm), _p(plan),
                                    int(long_runs), int(blocks_per_cu), _p(start_flag), int(start_value) & 0xFFFFFFFF,
                                    _p(loss), _p(ws), ws.numel(), _stream()),
@@ -371,7 +373,12 @@ def triplet_train_step(scene, scene_shadow, scene_loc, scene_accum, product, pro
     long_runs as for glove_train_step (triplet_plan).  Returns loss[1]."""
     lib = _lib.load()
     direct = triplet_direct_mode()  # rows stepped in place: no second buffers, location bytes or stamp
-    for name, t in (("scene", scene), ("scene_accum", scene_accum), ("product", product), ("product_accum", product_accum)):
+    dt = _table_dtype(scene, "scene")   # f32, or bf16 rows with fp32 accumulators (direct mode only)
+    if _table_dtype(product, "product") != dt:
+        raise TypeError("scene and product towers must have the same dtype")
+    if dt != ESR_F32 and not direct:
+        raise TypeError("bf16 towers need the direct step (ESR_TRIPLET_STEP=stamped is set)")
+    for name, t in (("scene_accum", scene_accum), ("product_accum", product_accum)):
         _req(t, torch.float32, name)
     if not direct or scene_shadow is not None:
         _req(scene_shadow, torch.float32, "scene_shadow"), _req(product_shadow, torch.float32, "product_shadow")
@@ -402,7 +409,7 @@ def triplet_train_step(scene, scene_shadow, scene_loc, scene_accum, product, pro
     loss = torch.empty(1, dtype=torch.float32, device=scene.device)
     ws = _ws(_ws_bytes("esr_triplet_step_workspace_bytes", B, D), scene.device)
     check(lib.esr_triplet_train_step(_p(scene), _p(scene_shadow), _p(scene_loc), _p(scene_accum), Vs, _p(product),
-                                     _p(product_shadow), _p(product_loc), _p(product_accum), Vp, D, _p(scene_ids),
+                                     _p(product_shadow), _p(product_loc), _p(product_accum), Vp, dt, D, _p(scene_ids),
                                      _p(pos_ids), _p(neg_ids), B, float(regularization), float(batch_size), float(lr),
                                      float(eps), int(stamp), _p(sid), _p(perm), _p(plan), int(long_runs), _p(loss),
                                      _p(ws), ws.numel(), _stream()),
@@ -414,9 +421,12 @@ def rows_consolidate(primary, shadow, loc):
     """Copy the rows of a double-buffered table whose current value lives in `shadow` (loc[row] == 1) back into
     `primary` and clear their bytes: afterwards `primary` is the plain [V, D] table."""
     lib = _lib.load()
-    _req(primary, torch.float32, "primary"), _req(shadow, torch.float32, "shadow"), _req(loc, torch.uint8, "loc")
+    dt = _table_dtype(primary, "primary")
+    if _table_dtype(shadow, "shadow") != dt:
+        raise TypeError("primary and shadow must have the same dtype")
+    _req(loc, torch.uint8, "loc")
     V, D = primary.shape
-    check(lib.esr_rows_consolidate(_p(primary), _p(shadow), _p(loc), V, D, _stream()), "esr_rows_consolidate")
+    check(lib.esr_rows_consolidate(_p(primary), _p(shadow), _p(loc), V, dt, D, _stream()), "esr_rows_consolidate")
 
 
 def rows_restamp(loc):

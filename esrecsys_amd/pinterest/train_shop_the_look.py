@@ -124,8 +124,10 @@ def fused_triplet_step_available(state):
         st, pt = p["scene_tower"]["embedding"], p["product_tower"]["embedding"]
     except (KeyError, TypeError):
         return False
-    if not (st.is_cuda and st.dtype == torch.float32 and pt.dtype == torch.float32 and st.shape[1] == pt.shape[1] and
-            st.shape[0] + pt.shape[0] < (1 << 30)):
+    # (bf16 towers -- BASELINE config 4's dtype, fp32 accumulators -- are stepped by the direct kernels only)
+    ok_dtype = (st.dtype == torch.float32 and pt.dtype == torch.float32) or (
+        st.dtype == torch.bfloat16 and pt.dtype == torch.bfloat16 and ops.triplet_direct_mode())
+    if not (st.is_cuda and ok_dtype and st.shape[1] == pt.shape[1] and st.shape[0] + pt.shape[0] < (1 << 30)):
         return False
     if ops.triplet_direct_mode():  # rows are stepped in place: nothing to double-buffer
         return True
@@ -303,6 +305,7 @@ class _FusedTripletLoop:
         self.acc_s, self.acc_p = acc["scene_tower"]["embedding"], acc["product_tower"]["embedding"]
         self.Vs, self.D = self.st.shape
         self.Vp = self.pt.shape[0]
+        self.dt = ops._table_dtype(self.st, "scene tower")
         self.dev = self.st.device
         self.lr, self.eps = float(state.tx.lr), float(state.tx.eps)
         self.lib, self.check, self.ct = _lib.load(), _lib.check, ctypes
@@ -481,7 +484,7 @@ class _FusedTripletLoop:
         if gr.B != self.group_ws_B:
             self.group_ws = ops._ws(ops._ws_bytes("esr_triplet_step_workspace_bytes", gr.B, self.D), self.dev)
             self.group_ws_B = gr.B
-        self.check(self.lib.esr_triplet_train_steps(*self.fixed_s, *self.fixed_p, self.D, gr.nb, gr.ptrs, gr.B,
+        self.check(self.lib.esr_triplet_train_steps(*self.fixed_s, *self.fixed_p, self.dt, self.D, gr.nb, gr.ptrs, gr.B,
                                                     regularization, batch_size, self.lr, self.eps,
                                                     self.stamp(gr.nb), gr.sorted_ptr,
                                                     gr.perm_ptr, gr.plans_ptr, long_runs, self.losses_ptr + 4 * k,
@@ -498,7 +501,7 @@ class _FusedTripletLoop:
             sorted_ptr, perm_ptr = slot["sorted"].data_ptr(), slot["perm"].data_ptr()
         else:
             self._sized(sid.numel())
-        self.check(self.lib.esr_triplet_train_step(*self.fixed_s, *self.fixed_p, self.D, sid.data_ptr(), pid.data_ptr(),
+        self.check(self.lib.esr_triplet_train_step(*self.fixed_s, *self.fixed_p, self.dt, self.D, sid.data_ptr(), pid.data_ptr(),
                                                    nid.data_ptr(), self.B, float(regularization), float(batch_size),
                                                    self.lr, self.eps, self.stamp(), sorted_ptr,
                                                    perm_ptr, 0, -1, self.losses.data_ptr() + 4 * k,
@@ -552,7 +555,7 @@ class PlannedTriplets:
             ctx.group_ws = ops._ws(ops._ws_bytes("esr_triplet_step_workspace_bytes", gr.B, ctx.D), ctx.dev)
             ctx.group_ws_B = gr.B
         pb = ops._ws_bytes("esr_triplet_plan_bytes", gr.B)
-        ctx.check(ctx.lib.esr_triplet_train_step(*ctx.fixed_s, *ctx.fixed_p, ctx.D, self.scene.data_ptr(),
+        ctx.check(ctx.lib.esr_triplet_train_step(*ctx.fixed_s, *ctx.fixed_p, ctx.dt, ctx.D, self.scene.data_ptr(),
                                                  self.pos.data_ptr(), self.neg.data_ptr(), gr.B, float(regularization),
                                                  float(batch_size), ctx.lr, ctx.eps, ctx.stamp(),
                                                  gr.sorted_ptr + 4 * n * j, gr.perm_ptr + 4 * n * j,

@@ -713,6 +713,10 @@ def _is_f32(group):
     return all(t.local.dtype == torch.float32 for t in group.tables)
 
 
+def _is_bf16(group):
+    return all(t.local.dtype == torch.bfloat16 for t in group.tables)
+
+
 def _joined(first, *rest):
     """The single buffer the gradient slices are views of, else their concatenation."""
     base = getattr(first, "_base", None)
@@ -773,7 +777,8 @@ def sharded_triplet_step(towers, scene_ids, pos_ids, neg_ids, regularization, gl
     rows: lookup_bucketed(plan) when the caller has it already (overlap)."""
     k = towers.k
     B = scene_ids.numel()
-    if _world1_tables_ok(towers) and _is_f32(towers) and getattr(k, "triplet_direct_mode", lambda: False)():
+    if (_world1_tables_ok(towers) and (_is_f32(towers) or _is_bf16(towers)) and
+            getattr(k, "triplet_direct_mode", lambda: False)()):
         # world 1: the one-pass step on the local shards, rows stepped in place (esr_triplet_train_step, direct mode)
         towers.consolidate()  # (rows an earlier stamped step left in second buffers)
         st, pt = towers.tables

@@ -128,7 +128,9 @@ def fused_step_available(state):
         emb, bias = p["_token_embedding"]["embedding"], p["_bias"]["embedding"]
     except (KeyError, TypeError):
         return False
-    if not (emb.is_cuda and emb.dtype == torch.float32 and bias.dtype == torch.float32 and emb.shape[0] < (1 << 30)):
+    # (bf16 embedding rows -- BASELINE config 4's dtype -- keep fp32 accumulators and an fp32 bias table)
+    if not (emb.is_cuda and emb.dtype in (torch.float32, torch.bfloat16) and bias.dtype == torch.float32 and
+            emb.shape[0] < (1 << 30)):
         return False
     # the one-pass step keeps the embedding table double-buffered: without room for the second buffer (a table that
     # fills the card) the gradient-row path runs instead
@@ -377,7 +379,8 @@ class _FusedEpoch:
         self.start = _start_word(self.dev)  # [int32 [1] device word, sequence number of the latest step issued]
         self.check_ids = os.environ.get("ESR_CHECK_IDS") == "1"
         self.fixed = (self.emb.data_ptr(), self.rv.shadow.data_ptr(), self.rv.loc.data_ptr(), self.acc_e.data_ptr(),
-                      self.bias.data_ptr(), self.acc_b.data_ptr(), self.V, self.D)
+                      self.bias.data_ptr(), self.acc_b.data_ptr(), self.V, ops._table_dtype(self.emb, "embedding table"),
+                      self.D)
 
     def sort_batch(self, group):
         """[(inputs, target), ...] of the coming batches -> a _Group: their id lists sorted by one batched call and their

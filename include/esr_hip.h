@@ -132,10 +132,13 @@ int esr_glove_fwd_bwd(const float* emb, const float* bias, int64_t V, int D, con
  * residency (experiment knob); 0 = fill the chip.  start_flag (optional, device uint32): the update kernel's first
  * workgroup stores start_value there as it starts -- a second stream gated on the word (esr_stream_gate: the id sort
  * of a coming batch) is released while that kernel runs, i.e. arrives after it has taken its wave slots, and the main
- * queue carries no event marker for it. */
+ * queue carries no event marker for it.
+ * dtype (round 6): the embedding rows' type -- ESR_F32, or ESR_BF16 (BASELINE config 4's dtype: both buffers bf16 [V, D],
+ * fp32 accumulator, fp32 bias tables): rows are widened on the load (exact), stepped in f32 and rounded to nearest even on
+ * their one store; ~7 200 instead of 10 292 bytes per pair at D = 256. */
 size_t esr_glove_step_workspace_bytes(int64_t B, int D);
-int esr_glove_train_step(float* emb, float* emb_shadow, uint8_t* emb_loc, float* emb_accum, float* bias,
-                         float* bias_accum, int64_t V, int D, const int32_t* inputs, const float* target, int64_t B,
+int esr_glove_train_step(void* emb, void* emb_shadow, uint8_t* emb_loc, float* emb_accum, float* bias,
+                         float* bias_accum, int64_t V, int dtype, int D, const int32_t* inputs, const float* target, int64_t B,
                          int mode, float lr, float eps, uint32_t stamp, const int32_t* presorted_ids,
                          const int32_t* presorted_perm, void* plan, int long_runs, int blocks_per_cu,
                          uint32_t* start_flag, uint32_t start_value, float* loss, void* workspace,
@@ -152,8 +155,8 @@ int esr_stream_gate(const uint32_t* flag, uint32_t value, uint32_t timeout_us, e
  * with 25 arguments plus the Python around it).  inputs / targets / sorted_ids / perm / plans as esr_glove_plan took and
  * made them; stamps first_stamp, first_stamp + 1, ... (all <= 127); long_runs: host int32 [nbatch] (0 / 1 / -1 as above)
  * or NULL = unknown; losses [nbatch]. */
-int esr_glove_train_steps(float* emb, float* emb_shadow, uint8_t* emb_loc, float* emb_accum, float* bias,
-                          float* bias_accum, int64_t V, int D, int nbatch, const int32_t* const* inputs,
+int esr_glove_train_steps(void* emb, void* emb_shadow, uint8_t* emb_loc, float* emb_accum, float* bias,
+                          float* bias_accum, int64_t V, int dtype, int D, int nbatch, const int32_t* const* inputs,
                           const float* const* targets, int64_t B, int mode, float lr, float eps, uint32_t first_stamp,
                           const int32_t* sorted_ids, const int32_t* perm, void* plans, const int32_t* long_runs,
                           float* losses, void* workspace, size_t workspace_bytes, esr_stream_t stream);
@@ -170,7 +173,8 @@ int esr_glove_plan(const int32_t* const* inputs, const float* const* targets, in
  * then ignores `plan`): hint[0] = gen when sorted_ids [n] has a run of equal ids longer than `chunk` positions (32 for
  * the GloVe step, 8 for the triplet step).  `hint` may be device memory or pinned host memory. */
 int esr_long_run_hint(const int32_t* sorted_ids, int64_t n, int chunk, int32_t* hint, int32_t gen, esr_stream_t stream);
-int esr_rows_consolidate(float* primary, const float* shadow, uint8_t* loc, int64_t V, int D, esr_stream_t stream);
+int esr_rows_consolidate(void* primary, const void* shadow, uint8_t* loc, int64_t V, int dtype, int D,
+                         esr_stream_t stream);
 /* loc[r] &= 1 for every row: forget the stamps, keep the locations (see esr_glove_train_step's `stamp`). */
 int esr_rows_restamp(uint8_t* loc, int64_t V, esr_stream_t stream);
 
@@ -210,20 +214,23 @@ int esr_triplet_fwd_bwd(const float* scene_table, int64_t Vs, const float* pos_t
  * 2 .. 8 occurrences is stepped by whichever of its triplets finishes last (gradient rows parked at their sorted
  * positions, one atomic arrival per occurrence); longer runs by a second launch, made only when the plan's hint says
  * one exists.  Nothing is double-buffered: the *_shadow / *_loc arguments and `stamp` are ignored and may be NULL / 0,
- * rows never leave `scene` / `product`.  Same sums, same association as the stamped walk and the six-launch path. */
+ * rows never leave `scene` / `product`.  Same sums, same association as the stamped walk and the six-launch path.
+ * dtype (round 6): ESR_F32, or ESR_BF16 -- bf16 table rows [V, D] with fp32 accumulators (BASELINE config 4's dtype;
+ * direct mode only): a row is widened on the load (exact), stepped in f32 and rounded to nearest even on its one store,
+ * as esr_sparse_adagrad_scatter does; 5 376 instead of 7 680 bytes per triplet at D = 128. */
 size_t esr_triplet_step_workspace_bytes(int64_t B, int D);
-int esr_triplet_train_step(float* scene, float* scene_shadow, uint8_t* scene_loc, float* scene_accum, int64_t Vs,
-                           float* product, float* product_shadow, uint8_t* product_loc, float* product_accum,
-                           int64_t Vp, int D, const int32_t* scene_ids, const int32_t* pos_ids,
+int esr_triplet_train_step(void* scene, void* scene_shadow, uint8_t* scene_loc, float* scene_accum, int64_t Vs,
+                           void* product, void* product_shadow, uint8_t* product_loc, float* product_accum,
+                           int64_t Vp, int dtype, int D, const int32_t* scene_ids, const int32_t* pos_ids,
                            const int32_t* neg_ids, int64_t B, float regularization, float batch_size, float lr,
                            float eps, uint32_t stamp, const int32_t* presorted_ids, const int32_t* presorted_perm,
                            void* plan, int long_runs, float* loss, void* workspace, size_t workspace_bytes,
                            esr_stream_t stream);
 /* The steps of nbatch <= 8 planned batches by one call (see esr_glove_train_steps): ids[3 b + {0, 1, 2}] as for
  * esr_triplet_plan, losses [nbatch]. */
-int esr_triplet_train_steps(float* scene, float* scene_shadow, uint8_t* scene_loc, float* scene_accum, int64_t Vs,
-                            float* product, float* product_shadow, uint8_t* product_loc, float* product_accum,
-                            int64_t Vp, int D, int nbatch, const int32_t* const* ids, int64_t B, float regularization,
+int esr_triplet_train_steps(void* scene, void* scene_shadow, uint8_t* scene_loc, float* scene_accum, int64_t Vs,
+                            void* product, void* product_shadow, uint8_t* product_loc, float* product_accum,
+                            int64_t Vp, int dtype, int D, int nbatch, const int32_t* const* ids, int64_t B, float regularization,
                             float batch_size, float lr, float eps, uint32_t first_stamp, const int32_t* sorted_ids,
                             const int32_t* perm, void* plans, const int32_t* long_runs, float* losses, void* workspace,
                             size_t workspace_bytes, esr_stream_t stream);

@@ -103,3 +103,16 @@ def sparse_adagrad_update_inplace(param, accum, ids, rows, lr, eps=1e-7):
     param[uniq] -= param.dtype.type(lr) * g * inv
     accum[uniq] = acc
     return uniq
+
+
+def round_bf16(x):
+    """Round fp64 / fp32 values to the nearest bfloat16 (8 significant bits, ties to even), returned in x's dtype.
+
+    What a bf16 table holds after a step computed at higher precision (BASELINE config 4's dtype: the build steps bf16
+    rows in f32 and rounds once, on the row's store).  Directly from the input precision -- no double rounding through
+    f32 -- and without a bfloat16 type: m 2^e = x with m in [0.5, 1) (frexp), m rounded to 8 bits (numpy rounds half to
+    even).  bf16's subnormals (|x| < 2^-126) do not occur in embedding tables and are not modelled.
+    """
+    x = np.asarray(x)
+    m, e = np.frexp(x)
+    return np.ldexp(np.round(m * 256.0) / 256.0, e).astype(x.dtype)

@@ -242,3 +242,18 @@ def test_cpu_port_dense_adam_variants_match_oracle():
     el, _, gq, gc = stl_head.inbatch_softmax_loss_and_grads(st0[sid], pt0[pid], lam, B, 2.0, F64)
     es, _ = optim.adam_update(st0, dense(sid, gq, st0.shape), optim.adam_init(st0), lr, dtype=F64)
     assert abs(float(loss) - el) <= 1e-12 and np.abs(ds.p.numpy() - es).max() <= 1e-12
+
+
+def test_round_bf16_matches_torch_rne():
+    """oracle.optim.round_bf16 (RNE to 8 significant bits, straight from fp64) against torch's float32 -> bfloat16
+    conversion on f32-representable inputs, ties included."""
+    import torch
+    from oracle import optim as o_optim
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.standard_normal(20000) * 10.0 ** rng.uniform(-6, 6, 20000), [0.0, -0.0, 1.0, -1.5],
+                        # exact ties: 1 + k 2^-8 for odd k (halfway between two bf16 neighbours)
+                        1.0 + (2 * np.arange(64) + 1) * 2.0 ** -8, -(2.0 + (2 * np.arange(64) + 1) * 2.0 ** -7)])
+    x = x.astype(np.float32)
+    want = torch.from_numpy(x).to(torch.bfloat16).float().numpy()
+    got = o_optim.round_bf16(x.astype(np.float64))
+    assert np.array_equal(got, want.astype(np.float64))
