@@ -195,7 +195,7 @@ def library_kernel_times(fn, reps, once=False):
     return out
 
 
-def dominant_kernel_roofline(workload, path, per_kernel, B, D):
+def dominant_kernel_roofline(workload, path, per_kernel, B, D, elt=4):
     """Roofline fraction of the dominant kernel from its in-run average launch duration: MFMA kernels = executed fp16
     cross-term GEMM flops / duration / 2.5 PF; HBM kernels = SURVEY 8d's algorithmic bytes of the step / duration / 8 TB/s."""
     if not per_kernel:
@@ -205,7 +205,7 @@ def dominant_kernel_roofline(workload, path, per_kernel, B, D):
             return None
         unit = 2.0 * B * B * D  # one cross-term GEMM
         out = {}
-        for name, terms in (("inbatch2h_q_kernel", 6), ("inbatch2h_pc8_kernel", 3), ("inbatch1h_kernel_q", 3),
+        for name, terms in (("inbatch2h_q_kernel", 6), ("inbatch2h_pct_kernel", 3), ("inbatch1h_kernel_q", 3),
                             ("inbatch1h_kernel_c", 3)):
             if name in per_kernel:
                 t = per_kernel[name]["us"] * 1e-6
@@ -217,7 +217,7 @@ def dominant_kernel_roofline(workload, path, per_kernel, B, D):
     for name in names:
         if name in per_kernel:
             t = per_kernel[name]["us"] * 1e-6
-            alg = STEP_BYTES_PER_UNIT[workload](D) * B
+            alg = STEP_BYTES_PER_UNIT[workload](D, elt) * B
             return {name: {"us": per_kernel[name]["us"], "algorithmic_bytes": alg,
                            "frac_of_8TBps": round(alg / t / 1e9 / HBM_PEAK_GBS, 4)}}
     return None
@@ -256,9 +256,10 @@ def roofline_for(workload, kernels, B, D, rows, precision, occ_n=0, uniq=0, bf16
             rowmax_pass = os.environ.get("ESR_IB2H_REF", "") == "rowmax" and rowmax_gemm
             terms = 3 * 3 + (1 if rowmax_pass else 0)
             executed = terms * 2.0 * B * B * D
-            return {"kernel": "prep2h + split2h + " + ("rowmax2h + " if rowmax_pass else "") +
-                              "inbatch2h_q_kernel (+ redo launch) + merge + inbatch2h_pc8_kernel + merge",
-                    "pass_c": "reads stored P (B*B*4 bytes written by pass Q)",
+            return {"kernel": "prepsplit2h + " + ("rowmax2h + " if rowmax_pass else "") +
+                              "inbatch2h_q_kernel + fac2h + scaleq2h + inbatch2h_pct_kernel + merging update",
+                    "pass_c": "reads the stored P' (two fp16 planes, B*B*4 bytes written by pass Q) as its MFMA operand; "
+                              "the per-row factors ride on a scaled copy of Q",
                     "bound": "mfma", "achieved": executed / t / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": executed / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
                     "dtype": "fp16 x2 split, f32 accumulate (f32-grade products; the dense fp16 MFMA peak equals the "
@@ -298,8 +299,9 @@ def roofline_for(workload, kernels, B, D, rows, precision, occ_n=0, uniq=0, bf16
         # time = the timed region's step (the one-pass op IS the step; its HIP-event time in the second pass, taken
         # with a spin kernel ahead of every step, is reported next to it)
         t = step_s if step_s else kernels["glove_step"]["ms_per_step"] * 1e-3
-        alg = STEP_BYTES_PER_UNIT["glove"](D) * B
-        moved = (occ_n + 4 * uniq) * D * 4
+        elt = 2 if bf16_tables else 4
+        alg = STEP_BYTES_PER_UNIT["glove"](D, elt) * B
+        moved = (occ_n * elt + uniq * (2 * elt + 8)) * D
         return {"kernel": "esr_glove_train_step (id lists of eight coming batches sorted by one batched call; lists > 32768 "
                           "ids: glove_resolve + glove_step_resolved + glove_step_long + finalize per step; shorter: "
                           "plan made ahead with the sort, then glove_step + finalize per step)",
@@ -311,10 +313,11 @@ def roofline_for(workload, kernels, B, D, rows, precision, occ_n=0, uniq=0, bf16
         # stream): against SURVEY 8d's algorithmic bytes; the update kernel itself needs per occurrence its two partner
         # rows and per distinct row the own-row read, the rewrite and the accumulator RMW
         t = step_s if step_s else kernels["triplet_step"]["ms_per_step"] * 1e-3
-        alg = STEP_BYTES_PER_UNIT["triplet"](D) * B
+        elt = 2 if bf16_tables else 4
+        alg = STEP_BYTES_PER_UNIT["triplet"](D, elt) * B
         # direct mode: every distinct row read + written once with its accumulator; an occurrence of a duplicated row
-        # also parks and re-reads its gradient row
-        moved = (4 * uniq + 2 * (occ_n - uniq)) * D * 4
+        # also parks and re-reads its (f32) gradient row
+        moved = (uniq * (2 * elt + 8) + 2 * (occ_n - uniq) * 4) * D
         return {"kernel": "esr_triplet_train_step, direct mode (sort + plan made ahead for eight batches; per step "
                           "triplet_direct: one row group per triplet, unique rows stepped in place, + "
                           "triplet_direct_long only when a run of equal ids is longer than 8)",
@@ -374,16 +377,13 @@ def make_state_and_batches(workload, cfg, dev, n_batches, rank):
     if workload == "glove":
         from esrecsys_amd.wikipedia.models import Glove
         model = Glove(num_embeddings=V, features=D, device=dev)
-        params = {"_token_embedding": {"embedding": synth_tables(V, D, dev, gen)},
+        params = {"_token_embedding": {"embedding": synth_tables(V, D, dev, gen, cfg.get("table_dtype", "f32"))},
                   "_bias": {"embedding": torch.zeros((V, 1), device=dev)}}
         state = TrainState.create(apply_fn=model.apply, params=params, tx=optim.sparse_adagrad(LR))
     else:
         from esrecsys_amd.pinterest.models import STLModel
         model = STLModel(output_size=D, num_scenes=V, num_products=V, device=dev)
         td = cfg.get("table_dtype", "f32")
-        if td == "bf16" and workload != "inbatch":
-            raise SystemExit("bf16 tables: the fused triplet / GloVe kernels read fp32 tables; use --workload inbatch "
-                             "or the row-sharded leg (--gpus N / ESR_BENCH_SHARDED=1)")
         params = {"params": {"scene_tower": {"embedding": synth_tables(V, D, dev, gen, td)},
                              "product_tower": {"embedding": synth_tables(V, D, dev, gen, td)}}}
         state = TrainState.create(apply_fn=model.apply, params=params, tx=optim.sparse_adagrad(LR))
@@ -833,8 +833,9 @@ def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True
             roofline["frac_of_sustained"] = roofline["achieved"] / live
         if roofline.get("bound") == "hbm":
             # the whole step against SURVEY 8d's per-unit algorithmic bytes (the figure the judge divides by)
-            step_bytes = STEP_BYTES_PER_UNIT[workload](D) * B
-            roofline["step"] = {"algorithmic_bytes_per_unit": STEP_BYTES_PER_UNIT[workload](D),
+            elt = 2 if cfg.get("table_dtype") == "bf16" else 4
+            step_bytes = STEP_BYTES_PER_UNIT[workload](D, elt) * B
+            roofline["step"] = {"algorithmic_bytes_per_unit": STEP_BYTES_PER_UNIT[workload](D, elt),
                                 "GBps": step_bytes / (dt / K) / 1e9, "frac": step_bytes / (dt / K) / 1e9 / HBM_PEAK_GBS}
     hbm = {}
     if "gather" in kernels:
@@ -883,7 +884,7 @@ def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True
             roofline["per_kernel_in_run"] = {"source": "esr_kernel_timing: HIP events around every launch, this run, " + how,
                                              "us": {k: v["us"] for k, v in per_kernel.items()},
                                              "launches_per_step": {k: v["launches_per_step"] for k, v in per_kernel.items()}}
-            dom = dominant_kernel_roofline(workload, path, per_kernel, B, D)
+            dom = dominant_kernel_roofline(workload, path, per_kernel, B, D, 2 if cfg.get("table_dtype") == "bf16" else 4)
             if dom:
                 roofline["dominant_kernel"] = dom
     if kernel_timing and saturating:
@@ -915,10 +916,11 @@ def measure_training(workload, cfg, dev, rank, steps, warmup, kernel_timing=True
 
 
 # algorithmic HBM bytes per unit of the WHOLE step = rows_per_unit x D x (3 s + 2 a) (+ bias / inputs for GloVe)
+# (s = bytes per table element: 4, or 2 for bf16 rows -- BASELINE config 4's dtype; a = 4, the fp32 accumulator)
 STEP_BYTES_PER_UNIT = {
-    "inbatch": lambda D: 2 * D * 20,
-    "triplet": lambda D: 3 * D * 20,
-    "glove": lambda D: 2 * D * 20 + 40 + 12,
+    "inbatch": lambda D, s=4: 2 * D * (3 * s + 8),
+    "triplet": lambda D, s=4: 3 * D * (3 * s + 8),
+    "glove": lambda D, s=4: 2 * D * (3 * s + 8) + 40 + 12,
 }
 
 
@@ -938,9 +940,13 @@ def secondary_legs(args, dev, rank):
             ("triplet_c2_b8192_reference_loss", "triplet", {}, max(k, 400), max(w, 16), 4.0, 6.0),
             ("triplet_c2_b8192_reference_loop_shape", "triplet", {"loop": "reference_shape"}, max(k, 400), max(w, 16),
              0.0, 0.0),
-            ("triplet_c2_b262144_saturating", "triplet", {"B": 262144}, max(min(k, 100), 64), max(w, 16), 0.0, 0.0)]
+            ("triplet_c2_b262144_saturating", "triplet", {"B": 262144}, max(min(k, 100), 64), max(w, 16), 0.0, 0.0),
+            # bf16 rows + fp32 accumulators (BASELINE config 4's dtype; round 6): 5 376 B / triplet, 7 220 B / pair
+            ("triplet_c2_b262144_bf16", "triplet", {"B": 262144, "table_dtype": "bf16"}, max(min(k, 100), 64), max(w, 16),
+             0.0, 0.0),
+            ("glove_c3_b65536_bf16", "glove", {"table_dtype": "bf16"}, max(k, 200), max(w, 10), 0.0, 0.0)]
     for name, workload, over, steps, warm, cpu_s, cpu_dense_s in legs:
-        cfg = dict(WORKLOADS[workload], table_dtype="f32", ids="uniform", **over)
+        cfg = dict(dict(WORKLOADS[workload], table_dtype="f32", ids="uniform"), **over)
         try:
             leg = measure_training(workload, cfg, dev, rank, steps, warm, kernel_timing=True, saturating=False)
             leg["cpu_baseline"] = cpu_baseline(workload, cfg, cpu_s, cpu_dense_s) \
@@ -1023,7 +1029,7 @@ def main():
                     help="id distribution of the synthetic batches: uniform (headline) or Zipf(s=1) over a random "
                          "permutation of the rows (SURVEY 8d secondary: stresses duplicate ids in the sparse update)")
     ap.add_argument("--table-dtype", default="f32", choices=["f32", "bf16"],
-                    help="table storage (accumulators stay fp32); bf16 needs the in-batch workload or the sharded leg")
+                    help="table storage (accumulators stay fp32): bf16 = BASELINE config 4's dtype")
     ap.add_argument("--precision", default="auto", choices=["auto", "f32", "bf16x3", "f16x2"],
                     help="MFMA path of the in-batch score kernel (both are f32-grade; see DESIGN.md 2.2)")
     ap.add_argument("--no-kernel-timing", action="store_true",
@@ -1145,7 +1151,7 @@ def main():
                 if k in rf:
                     roof[k] = _r(rf[k], 1)
         else:
-            alg = STEP_BYTES_PER_UNIT[args.workload](D_) * B_
+            alg = STEP_BYTES_PER_UNIT[args.workload](D_, 2 if args.table_dtype == "bf16" else 4) * B_
             lit = alg / step_s / 1e9
             roof = {"bound": "hbm", "achieved": _r(lit, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": _r(lit / HBM_PEAK_GBS), "traffic": rf.get("traffic"),
@@ -1170,10 +1176,44 @@ def main():
     roof["legs"] = {"steady_state": {"value": _r(float(src["value"]), 1), "ms": _r(src["ms_per_step"], 5),
                                      "steps": src["steps"], "warmup": src["warmup"],
                                      "frac": _r(roof["frac"] * leg["ms_per_step"] / src["ms_per_step"]) if rf else None}}
-    out = {"metric": "training pairs/sec", "value": leg["value"], "unit": leg["unit"], "n_gpus": 1,
-           "steps": leg["steps"], "warmup": leg["warmup"], "ms_per_step": leg["ms_per_step"],
+    # Flat scalars (round 6: the driver keeps `roofline`'s scalars and drops nested objects and unknown top-level keys).
+    # value / ms_per_step of the LINE are the steady-state leg's when --steps is shorter than it -- the rate a training
+    # run sees; the K-step leg (exactly W warmup + K timed steps right behind the steady leg's timed region, where the
+    # chip still holds its boost clock for a few ms) is printed beside it as k_step_*.
+    if sat:
+        roof["hbm_gather_GBps"] = roof["hbm_gather_scatter"].get("gather_GBps")
+        roof["hbm_scatter_GBps"] = roof["hbm_gather_scatter"].get("sparse_adagrad_GBps")
+        roof["hbm_gather_frac"] = roof["hbm_gather_scatter"].get("gather_frac_of_8TBps")
+        roof["hbm_scatter_frac"] = roof["hbm_gather_scatter"].get("sparse_adagrad_frac_of_8TBps")
+    roof["steady_ms_per_step"] = _r(src["ms_per_step"], 5)
+    roof["steady_value"] = _r(float(src["value"]), 1)
+    roof["k_step_ms_per_step"] = _r(leg["ms_per_step"], 5)
+    roof["k_step_value"] = _r(float(leg["value"]), 1)
+    dk = roof.get("dominant_kernel") or {}
+    if dk:
+        name = max(dk, key=lambda k: dk[k].get("us", 0.0))
+        roof["dominant_kernel_name"] = name
+        roof["dominant_kernel_us"] = dk[name].get("us")
+        roof["dominant_kernel_frac"] = dk[name].get("frac_of_2.5PF", dk[name].get("frac_of_8TBps"))
+    for kname, us in (roof.get("per_kernel_us_in_run") or {}).items():  # every kernel of the step, flat
+        roof["us_" + kname] = us
+    use_steady = steady is not None
+    if use_steady and rf:  # frac / achieved follow the value they describe
+        ratio = leg["ms_per_step"] / src["ms_per_step"]
+        roof["k_step_frac"] = roof["frac"]
+        roof["frac"] = _r(roof["frac"] * ratio)
+        roof["achieved"] = _r(roof["achieved"] * ratio, 2)
+        roof["step_frac_driver_timed"] = roof["frac"]
+        roof["what"] = roof["what"].replace("THIS line", "THIS line (= the steady_state leg's)")
+    out = {"metric": "training pairs/sec", "value": src["value"] if use_steady else leg["value"], "unit": leg["unit"],
+           "n_gpus": 1, "steps": leg["steps"], "warmup": leg["warmup"],
+           "ms_per_step": src["ms_per_step"] if use_steady else leg["ms_per_step"],
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": leg["config"], "roofline": roof}
+    if use_steady:
+        out["config"]["value_from"] = ("the steady_state leg (%d timed steps behind %d warmup steps, own state); the leg of "
+                                       "exactly --steps / --warmup that follows it: roofline.k_step_value / "
+                                       "k_step_ms_per_step" % (src["steps"], src["warmup"]))
     if not args.no_cpu_baseline:
         cb = cpu_baseline(args.workload, cfg)
         emit_leg("headline_cpu_baseline_full", cb)
@@ -1191,13 +1231,21 @@ def main():
         short = {"glove_c3_b65536": "glove_c3_b65536", "glove_c3_b2048_reference_default_batch": "glove_c3_b2048",
                  "inbatch_c2_bf16_tables": "inbatch_c2_bf16_tables",
                  "triplet_c2_b8192_reference_loss": "triplet_c2_b8192", "triplet_c2_b262144_saturating": "triplet_c2_b262144",
+                 "triplet_c2_b262144_bf16": "triplet_c2_b262144_bf16", "glove_c3_b65536_bf16": "glove_c3_b65536_bf16",
                  "retrieve_c5_n1m_k500_f16x2": "retrieve_c5_f16x2", "retrieve_c5_n1m_k500_exact": "retrieve_c5_exact"}
         for name, key in short.items():
             v = out["secondary"].get(name)
             if isinstance(v, dict) and "value" in v:
                 roof["legs"][key] = {"value": v["value"], "ms": v.get("ms"), "bound": v.get("bound"), "frac": v.get("frac"),
                                      **({"kernel_frac": v["kernel_frac"]} if v.get("kernel_frac") else {})}
+                roof[key + "_value"] = v["value"]   # (flat copies: see above)
+                roof[key + "_ms"] = v.get("ms")
+                roof[key + "_frac"] = v.get("frac")
                 out["secondary"][name] = {"see": "roofline.legs." + key}  # (one copy on the line: it stays under 6 KB)
+        ex = out["secondary"].get("inbatch_c2_exact_f32")
+        if isinstance(ex, dict) and "value" in ex:
+            roof["exact_f32_pairs_per_s"] = ex["value"]
+            roof["exact_f32_frac_of_f32_mfma_peak"] = ex.get("frac")
     emit(out)
 
 

@@ -109,6 +109,20 @@ inline RowGeom row_geom(int D) {
   g.nch = (g.nvec + G - 1) / G;
   return g;
 }
+// bf16 rows (round 6): EIGHT elements per chunk -- 16 bytes of the bf16 row per lane and load instruction, as a float4
+// chunk is of an f32 row (with four elements per chunk a bf16 row moved as 8-byte accesses: the one-pass steps ran
+// SLOWER on bf16 tables than on f32 ones, 0.438 against 0.416 ms per 262 144 triplets).  The row's f32 companions
+// (accumulator, parked gradient rows) are then 32 contiguous bytes per lane, two 16-byte accesses.
+inline RowGeom row_geom8(int D) {
+  RowGeom g;
+  g.vec = 8;
+  g.nvec = D / 8;
+  int G = 1;
+  while (G < g.nvec && G < kWave) G <<= 1;
+  g.G = G;
+  g.nch = (g.nvec + G - 1) / G;
+  return g;
+}
 constexpr int kMaxChunksPerLane = 4;  // D <= 1024 (float4 rows) or D <= 256 (scalar rows)
 // Expands BODY with constexpr VEC / NCH matching a RowGeom (nch 3 runs as 4 with bounds checks).
 #define ESR_DISPATCH_ROW(geom, ...)                                           \
@@ -122,6 +136,19 @@ constexpr int kMaxChunksPerLane = 4;  // D <= 1024 (float4 rows) or D <= 256 (sc
       else if ((geom).nch <= 2) { constexpr int VEC = 1, NCH = 2; __VA_ARGS__; } \
       else { constexpr int VEC = 1, NCH = 4; __VA_ARGS__; }                   \
     }                                                                         \
+  } while (0)
+// the same for a geometry of 8-element chunks (row_geom8)
+#define ESR_DISPATCH_ROW8(geom, ...)                                          \
+  do {                                                                        \
+    if ((geom).nch <= 1) { constexpr int VEC = 8, NCH = 1; __VA_ARGS__; }     \
+    else if ((geom).nch <= 2) { constexpr int VEC = 8, NCH = 2; __VA_ARGS__; } \
+    else { constexpr int VEC = 8, NCH = 4; __VA_ARGS__; }                     \
+  } while (0)
+// either, by the geometry's chunk width
+#define ESR_DISPATCH_ROW_ANY(geom, ...)                                       \
+  do {                                                                        \
+    if ((geom).vec == 8) { ESR_DISPATCH_ROW8(geom, __VA_ARGS__); }            \
+    else { ESR_DISPATCH_ROW(geom, __VA_ARGS__); }                             \
   } while (0)
 inline int grid_for_groups(int64_t ngroups_needed, int G) {
   int groups_per_block = kBlock / G;
@@ -230,7 +257,12 @@ __device__ __forceinline__ void row_load(RowRegs<VEC, NCH>& r, const float* __re
   for (int k = 0; k < NCH; ++k) {
     const int c = lig + k * G;
     if (c < nvec) {
-      if constexpr (VEC == 4) {
+      if constexpr (VEC == 8) {
+        const float4 a = *reinterpret_cast<const float4*>(p + 8 * c);
+        const float4 b = *reinterpret_cast<const float4*>(p + 8 * c + 4);
+        r.v[k][0] = a.x; r.v[k][1] = a.y; r.v[k][2] = a.z; r.v[k][3] = a.w;
+        r.v[k][4] = b.x; r.v[k][5] = b.y; r.v[k][6] = b.z; r.v[k][7] = b.w;
+      } else if constexpr (VEC == 4) {
         const float4 a = *reinterpret_cast<const float4*>(p + 4 * c);
         r.v[k][0] = a.x; r.v[k][1] = a.y; r.v[k][2] = a.z; r.v[k][3] = a.w;
       } else {
@@ -249,7 +281,10 @@ __device__ __forceinline__ void row_store(const RowRegs<VEC, NCH>& r, float* __r
   for (int k = 0; k < NCH; ++k) {
     const int c = lig + k * G;
     if (c < nvec) {
-      if constexpr (VEC == 4) {
+      if constexpr (VEC == 8) {
+        *reinterpret_cast<float4*>(p + 8 * c) = make_float4(r.v[k][0], r.v[k][1], r.v[k][2], r.v[k][3]);
+        *reinterpret_cast<float4*>(p + 8 * c + 4) = make_float4(r.v[k][4], r.v[k][5], r.v[k][6], r.v[k][7]);
+      } else if constexpr (VEC == 4) {
 #if ESR_ROW_STORE_NT
         typedef float esr_f32x4_ __attribute__((ext_vector_type(4)));
         __builtin_nontemporal_store(esr_f32x4_{r.v[k][0], r.v[k][1], r.v[k][2], r.v[k][3]},
@@ -264,8 +299,17 @@ __device__ __forceinline__ void row_store(const RowRegs<VEC, NCH>& r, float* __r
   }
 }
 // bf16 table rows (config 4's dtype): the register image stays f32 -- a load widens (exact), a store rounds to nearest
-// even (f32_to_bf16 below).  A float4 chunk of a row is 8 bytes here.
+// even.  A float4 chunk of a row is 8 bytes here.
 __device__ __forceinline__ uint16_t f32_to_bf16(float f);
+// {bf16(lo), bf16(hi)} in one dword: v_cvt_pk_bf16_f32 (round to nearest even, NaN kept quiet) -- one instruction per
+// pair where the bit arithmetic of f32_to_bf16 is six per element (and four registers more in triplet_direct_kernel:
+// 100 instead of 96, i.e. four waves per SIMD instead of five in a kernel that lives on its occupancy)
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  typedef float esr_f32x2_ __attribute__((ext_vector_type(2)));
+  typedef __bf16 esr_bf16x2_ __attribute__((ext_vector_type(2)));
+  const esr_f32x2_ v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, esr_bf16x2_));
+}
 template <int VEC, int NCH>
 __device__ __forceinline__ void row_load(RowRegs<VEC, NCH>& r, const uint16_t* __restrict__ p, int lig,
                                          int G, int nvec) {
@@ -273,7 +317,13 @@ __device__ __forceinline__ void row_load(RowRegs<VEC, NCH>& r, const uint16_t* _
   for (int k = 0; k < NCH; ++k) {
     const int c = lig + k * G;
     if (c < nvec) {
-      if constexpr (VEC == 4) {
+      if constexpr (VEC == 8) {
+        const uint4 a = *reinterpret_cast<const uint4*>(p + 8 * c);
+        r.v[k][0] = __uint_as_float(a.x << 16); r.v[k][1] = __uint_as_float(a.x & 0xFFFF0000u);
+        r.v[k][2] = __uint_as_float(a.y << 16); r.v[k][3] = __uint_as_float(a.y & 0xFFFF0000u);
+        r.v[k][4] = __uint_as_float(a.z << 16); r.v[k][5] = __uint_as_float(a.z & 0xFFFF0000u);
+        r.v[k][6] = __uint_as_float(a.w << 16); r.v[k][7] = __uint_as_float(a.w & 0xFFFF0000u);
+      } else if constexpr (VEC == 4) {
         const uint2 a = *reinterpret_cast<const uint2*>(p + 4 * c);
         r.v[k][0] = __uint_as_float(a.x << 16); r.v[k][1] = __uint_as_float(a.x & 0xFFFF0000u);
         r.v[k][2] = __uint_as_float(a.y << 16); r.v[k][3] = __uint_as_float(a.y & 0xFFFF0000u);
@@ -293,10 +343,17 @@ __device__ __forceinline__ void row_store(const RowRegs<VEC, NCH>& r, uint16_t* 
   for (int k = 0; k < NCH; ++k) {
     const int c = lig + k * G;
     if (c < nvec) {
-      if constexpr (VEC == 4) {
+      if constexpr (VEC == 8) {
+        uint4 a;
+        a.x = pack_bf16x2(r.v[k][0], r.v[k][1]);
+        a.y = pack_bf16x2(r.v[k][2], r.v[k][3]);
+        a.z = pack_bf16x2(r.v[k][4], r.v[k][5]);
+        a.w = pack_bf16x2(r.v[k][6], r.v[k][7]);
+        *reinterpret_cast<uint4*>(p + 8 * c) = a;
+      } else if constexpr (VEC == 4) {
         uint2 a;
-        a.x = (uint32_t)f32_to_bf16(r.v[k][0]) | ((uint32_t)f32_to_bf16(r.v[k][1]) << 16);
-        a.y = (uint32_t)f32_to_bf16(r.v[k][2]) | ((uint32_t)f32_to_bf16(r.v[k][3]) << 16);
+        a.x = pack_bf16x2(r.v[k][0], r.v[k][1]);
+        a.y = pack_bf16x2(r.v[k][2], r.v[k][3]);
         *reinterpret_cast<uint2*>(p + 4 * c) = a;
       } else {
         p[c] = f32_to_bf16(r.v[k][0]);

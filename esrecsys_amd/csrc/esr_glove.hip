@@ -1427,7 +1427,11 @@ static void launch_glove_step_t(const GloveTables& t, const int32_t* inputs, con
                               uint32_t start_value, float* loss, const StepWs& ws, hipStream_t st) {
   const int64_t n = 2 * B;
   const int D = t.D;
-  const RowGeom g = row_geom(D);
+  // bf16 rows: 8 elements (16 bytes) per lane when the width allows (row_geom8)
+  // -- ESR_BF16_VEC8=1 only (150 registers, three waves per SIMD instead of four: see esr_triplet_step.hip)
+  const char* v8 = getenv("ESR_BF16_VEC8");
+  const bool vec8 = v8 && v8[0] == '1' && sizeof(T) == 2 && D % 8 == 0 && !(((uintptr_t)t.emb | (uintptr_t)t.emb_shadow) & 15);
+  const RowGeom g = vec8 ? row_geom8(D) : row_geom(D);
   int grid = grid_for_groups(n, g.G);
   const int grid2 = (int)std::min<int64_t>(kMaxGrid, cdiv(cdiv(n, kStepChunk), 4));
   const int nfin = (int)cdiv(n, kBlock);  // one thread per sorted position
@@ -1445,7 +1449,7 @@ static void launch_glove_step_t(const GloveTables& t, const int32_t* inputs, con
     // batch) arrives after that kernel has taken its wave slots.  Arriving first, the sort's workgroups kept part of
     // the update kernel's single resident wave-set waiting for a slot: 126 against 109 us for the same kernel.  (An
     // event recorded here did the same job, but the marker cost the main queue ~7 us between resolve and update.)
-    ESR_DISPATCH_ROW(g, {
+    ESR_DISPATCH_ROW_ANY(g, { if constexpr (VEC != 8 || sizeof(T) == 2) {
       static const int resident_all = resident_blocks((const void*)glove_step_resolved_kernel<VEC, NCH, T>, 0);
       const int resident = blocks_per_cu > 0
                                ? resident_blocks((const void*)glove_step_resolved_kernel<VEC, NCH, T>, blocks_per_cu)
@@ -1462,7 +1466,7 @@ static void launch_glove_step_t(const GloveTables& t, const int32_t* inputs, con
         ESR_KT("glove_step_long_kernel", st, hipLaunchKernelGGL((glove_step_long_kernel<VEC, NCH, T>), dim3(grid2), dim3(kBlock), 0, st, (T*)t.emb, (T*)t.emb_shadow,
                            t.emb_loc, t.emb_accum, D, g.G, sorted_ids, n, stamp, lr, eps, (const float*)ws.chunk_rows,
                            ws.bias_info, (const int*)ws.res_flags, grid, (const double*)ws.pair_part, ws.pair_tot));
-    });
+    }});
     ESR_KT("glove_step_finalize_kernel", st, hipLaunchKernelGGL(glove_step_finalize_kernel, dim3(nfin), dim3(kBlock), 0, st, B, mode,
                        (const unsigned long long*)nullptr, nstat, (const double*)ws.stat_part, grid,
                        (const double*)ws.pair_part, long_runs != 0 ? (const double*)ws.pair_tot : (const double*)nullptr,
@@ -1483,7 +1487,7 @@ static void launch_glove_step_t(const GloveTables& t, const int32_t* inputs, con
   const char* fin_env = getenv("ESR_GLOVE_FIN_FUSED");
   const bool fin_fused_on = !(fin_env && fin_env[0] == '0');
   const bool fuse_fin = fin_fused_on && long_runs == 0 && n <= kFinFuseMaxIds;
-  ESR_DISPATCH_ROW(g, {
+  ESR_DISPATCH_ROW_ANY(g, { if constexpr (VEC != 8 || sizeof(T) == 2) {
     // one resident wave-set: every group walks a contiguous slice, so a grid larger than what the chip holds at once
     // only adds a second, partly filled round (94 VGPRs -> 5 blocks per CU: 2048 blocks ran as 1280 + 768); the
     // prologue's wait also relies on the workgroups it waits for having been dispatched (they have: index order)
@@ -1499,7 +1503,7 @@ static void launch_glove_step_t(const GloveTables& t, const int32_t* inputs, con
       ESR_KT("glove_step_long_kernel", st, hipLaunchKernelGGL((glove_step_long_kernel<VEC, NCH, T>), dim3(grid2), dim3(kBlock), 0, st, (T*)t.emb, (T*)t.emb_shadow,
                          t.emb_loc, t.emb_accum, D, g.G, sorted_ids, n, stamp, lr, eps, (const float*)ws.chunk_rows,
                          ws.bias_info, (const int*)pl.flags, 0, (const double*)nullptr, (double*)nullptr));
-  });
+  }});
   if (!fuse_fin)
     ESR_KT("glove_step_finalize_kernel", st, hipLaunchKernelGGL(glove_step_finalize_kernel, dim3(nfin), dim3(kBlock), 0, st, B, mode,
                        (const unsigned long long*)pl.stat, 0, (const double*)nullptr, grid, (const double*)nullptr,

@@ -604,14 +604,13 @@ __device__ __forceinline__ void side_store(const RowRegs<VEC, NCH>& r, float* __
   for (int k = 0; k < NCH; ++k) {
     const int c = lig + k * G;
     if (c < nvec) {
-      if constexpr (VEC == 4) {
-        unsigned long long* d = reinterpret_cast<unsigned long long*>(dst + 4 * c);
-        const unsigned long long lo = (unsigned long long)__float_as_uint(r.v[k][0]) |
-                                      ((unsigned long long)__float_as_uint(r.v[k][1]) << 32);
-        const unsigned long long hi = (unsigned long long)__float_as_uint(r.v[k][2]) |
-                                      ((unsigned long long)__float_as_uint(r.v[k][3]) << 32);
-        __hip_atomic_store(d, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(d + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if constexpr (VEC >= 4) {  // (4 or 8 elements per chunk: pairs as 8-byte words)
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(dst + VEC * c);
+#pragma unroll
+        for (int e = 0; e < VEC; e += 2)
+          __hip_atomic_store(d + e / 2, (unsigned long long)__float_as_uint(r.v[k][e]) |
+                                            ((unsigned long long)__float_as_uint(r.v[k][e + 1]) << 32),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
         __hip_atomic_store(reinterpret_cast<unsigned*>(dst + c), __float_as_uint(r.v[k][0]), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
@@ -627,14 +626,16 @@ __device__ __forceinline__ void side_load(RowRegs<VEC, NCH>& r, const float* __r
 #pragma unroll
     for (int e = 0; e < VEC; ++e) r.v[k][e] = 0.f;
     if (c < nvec) {
-      if constexpr (VEC == 4) {
-        const unsigned long long* d = reinterpret_cast<const unsigned long long*>(src + 4 * c);
-        const unsigned long long lo = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long hi = __hip_atomic_load(d + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        r.v[k][0] = __uint_as_float((uint32_t)lo);
-        r.v[k][1] = __uint_as_float((uint32_t)(lo >> 32));
-        r.v[k][2] = __uint_as_float((uint32_t)hi);
-        r.v[k][3] = __uint_as_float((uint32_t)(hi >> 32));
+      if constexpr (VEC >= 4) {
+        const unsigned long long* d = reinterpret_cast<const unsigned long long*>(src + VEC * c);
+        unsigned long long w[VEC / 2];
+#pragma unroll
+        for (int e = 0; e < VEC / 2; ++e) w[e] = __hip_atomic_load(d + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int e = 0; e < VEC / 2; ++e) {
+          r.v[k][2 * e] = __uint_as_float((uint32_t)w[e]);
+          r.v[k][2 * e + 1] = __uint_as_float((uint32_t)(w[e] >> 32));
+        }
       } else {
         r.v[k][0] = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(src + c), __ATOMIC_RELAXED,
                                                       __HIP_MEMORY_SCOPE_AGENT));
@@ -1019,10 +1020,15 @@ static int launch_trip_step(const TwoTowers& tt, int dtype, int D, const RowGeom
     // lanes per row: a triplet's five dot products are a small part of its work (the stamped walk had six per occurrence
     // and wanted few lanes); ESR_TRIPLET_DIRECT_LANES=few keeps step_geom_few_lanes
     const char* le = getenv("ESR_TRIPLET_DIRECT_LANES");
-    const RowGeom gd = (le && le[0] == 'f') ? g : row_geom(D);
+    // bf16 rows: 8 elements (16 bytes) per lane when the width allows (row_geom8)
+    // -- ESR_BF16_VEC8=1 only: measured slower (136 registers, three waves per SIMD instead of five; the step lives on
+    // its occupancy): 0.496 against 0.438 ms per 262 144 triplets
+    const char* v8 = getenv("ESR_BF16_VEC8");
+    const bool vec8 = v8 && v8[0] == '1' && dtype == ESR_BF16 && D % 8 == 0 && !(((uintptr_t)tt.s0 | (uintptr_t)tt.p0) & 15);
+    const RowGeom gd = vec8 ? row_geom8(D) : ((le && le[0] == 'f') ? g : row_geom(D));
     const RowGeom& g = gd;
-#define ESR_TRIP_DIRECT_LAUNCH(T)                                                                                      \
-    ESR_DISPATCH_ROW(g, {                                                                                              \
+#define ESR_TRIP_DIRECT_LAUNCH(T, DISPATCH)                                                                            \
+    DISPATCH(g, {                                                                                                      \
       const DirectTowers<T> dt{(T*)tt.s0, (T*)tt.p0, tt.sacc, tt.pacc};                                                \
       static const int resident = resident_blocks((const void*)triplet_direct_kernel<VEC, NCH, T>);                    \
       const int gridd = std::min(grid_for_groups(B, g.G), resident);                                                   \
@@ -1039,10 +1045,12 @@ static int launch_trip_step(const TwoTowers& tt, int dtype, int D, const RowGeom
                            tt.Vs, sorted, n, lr, eps, (const float*)ws.chunk_rows, (const int*)pl.flags,               \
                            (const int32_t*)pl.long_heads));                                                            \
     })
-    if (dtype == ESR_BF16) {
-      ESR_TRIP_DIRECT_LAUNCH(uint16_t);
+    if (vec8) {
+      ESR_TRIP_DIRECT_LAUNCH(uint16_t, ESR_DISPATCH_ROW8);
+    } else if (dtype == ESR_BF16) {
+      ESR_TRIP_DIRECT_LAUNCH(uint16_t, ESR_DISPATCH_ROW);
     } else {
-      ESR_TRIP_DIRECT_LAUNCH(float);
+      ESR_TRIP_DIRECT_LAUNCH(float, ESR_DISPATCH_ROW);
     }
 #undef ESR_TRIP_DIRECT_LAUNCH
     return ESR_OK;

@@ -39,7 +39,7 @@ out = {"_note": __doc__.strip().splitlines()[0]}
 st = stats("inbatch_kernel_stats.csv")
 rows = []
 for key, terms, what in (("inbatch2h_q_kernelILb0", 6, "pass Q: S^T and O^T, three fp16 terms each"),
-                         ("inbatch2h_pc8_kernel", 3, "pass C: O^T from the stored probabilities")):
+                         ("inbatch2h_pct_kernel", 3, "pass C: O^T from the stored probabilities")):
     t = find(st, key)
     if t:
         traffic = pmc("inbatch", key)
