@@ -19,6 +19,7 @@ GLOVE_DIAGONAL = 1
 RETRIEVE_EXACT = 0
 RETRIEVE_BF16 = 1
 RETRIEVE_F16X2 = 2
+RETRIEVE_F16R = 3
 
 c_i32p = ctypes.c_void_p
 c_f32p = ctypes.c_void_p

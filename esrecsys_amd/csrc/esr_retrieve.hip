@@ -46,6 +46,10 @@ constexpr int kFirstChunk = 8192;
 // esr_inbatch2h.hip).  e is one exponent per matrix, from its largest |element| (max |x * 2^e| in [2^13, 2^14)):
 // absmax_part_kernel -> slots, absmax_exp_kernel -> the exponent word the split and the GEMM epilogue read.
 // ---------------------------------------------------------------------------------------------------
+// Plane code P of the split and GEMM templates: 1 = one bf16 plane, 3 = three exact bf16 planes, 2 = two scaled fp16
+// planes, 4 (round 6) = ONE scaled fp16 plane -- the hi plane of code 2 alone: the one-term filter of mode 3.
+__host__ __device__ constexpr int plane_count(int P) { return P == 4 ? 1 : P; }
+__host__ __device__ constexpr bool plane_f16(int P) { return P == 2 || P == 4; }
 constexpr int kAbsBlocks = 1024;
 __global__ __launch_bounds__(kBlock) void absmax_part_kernel(const float* __restrict__ X, int64_t n,
                                                             float* __restrict__ slots) {
@@ -92,6 +96,65 @@ __global__ __launch_bounds__(kBlock) void absmax_exp_kernel(const float* __restr
   }
 }
 
+// Row statistics for mode 3 (the one-term filter, round 6): one wave per row -- the row's 2-norm (norms[r], optional) and,
+// per workgroup, the largest |element| (slots_abs) and the largest row norm (slots_nrm) it saw: what the exponent of the
+// scaled planes and the error bound of a one-plane score need from a matrix, in ONE read of it.
+__global__ __launch_bounds__(kBlock) void rowstat_kernel(const float* __restrict__ X, int64_t n_rows, int D,
+                                                        float* __restrict__ norms, float* __restrict__ slots_abs,
+                                                        float* __restrict__ slots_nrm) {
+  __shared__ float red[2][kBlock / 64];
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
+  const bool vec = (D & 3) == 0 && ((uintptr_t)X & 15) == 0;
+  float amax = 0.f, nmax = 0.f;
+  for (int64_t r = wave; r < n_rows; r += nwaves) {
+    const float* x = X + r * D;
+    float ss = 0.f;
+    if (vec) {
+      for (int d = lane * 4; d < D; d += 256) {
+        const float4 f = *reinterpret_cast<const float4*>(x + d);
+        ss = fmaf(f.x, f.x, fmaf(f.y, f.y, fmaf(f.z, f.z, fmaf(f.w, f.w, ss))));
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(f.x), fabsf(f.y)), fmaxf(fabsf(f.z), fabsf(f.w))));
+      }
+    } else {
+      for (int d = lane; d < D; d += 64) {
+        ss = fmaf(x[d], x[d], ss);
+        amax = fmaxf(amax, fabsf(x[d]));
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float nr = sqrtf(ss);
+    if (norms && lane == 0) norms[r] = nr;
+    nmax = fmaxf(nmax, nr);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  if (lane == 0) { red[0][threadIdx.x >> 6] = amax; red[1][threadIdx.x >> 6] = nmax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = red[0][0], b = red[1][0];
+    for (int i = 1; i < kBlock / 64; ++i) { a = fmaxf(a, red[0][i]); b = fmaxf(b, red[1][i]); }
+    slots_abs[blockIdx.x] = a;
+    slots_nrm[blockIdx.x] = b;
+  }
+}
+// max over slots -> out[0] (one workgroup)
+__global__ __launch_bounds__(kBlock) void slots_max_kernel(const float* __restrict__ slots, int nslots, float* __restrict__ out) {
+  __shared__ float red[kBlock / 64];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < nslots; i += kBlock) m = fmaxf(m, slots[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = red[0];
+    for (int i = 1; i < kBlock / 64; ++i) t = fmaxf(t, red[i]);
+    out[0] = t;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // f32 rows -> P bf16 planes, zero padded (rows >= n_rows, cols >= D), K-BLOCK-MAJOR: plane[kb][row][16] with
 // kb = d / 16 -- the 32 rows x 16 k that one DMA instruction moves are 1 KiB of contiguous global memory
@@ -101,7 +164,7 @@ __global__ __launch_bounds__(kBlock) void split_planes_kernel(const float* __res
                                                              int64_t rows_pad, int Dp, int64_t plane_elems,
                                                              __bf16* __restrict__ out,
                                                              const int* __restrict__ exp_ptr = nullptr) {
-  const float mul = (P == 2) ? ldexpf(1.f, exp_ptr[0]) : 1.f;
+  const float mul = plane_f16(P) ? ldexpf(1.f, exp_ptr[0]) : 1.f;
   const int quads = Dp >> 2;
   const int64_t total = rows_pad * quads;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
@@ -119,7 +182,7 @@ __global__ __launch_bounds__(kBlock) void split_planes_kernel(const float* __res
       }
     }
     __bf16* dst = out + ((int64_t)(c >> 4) * rows_pad + r) * 16 + (c & 15);
-    if (P == 2) {
+    if (plane_f16(P)) {
       f16x4 h1, h2;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -129,7 +192,7 @@ __global__ __launch_bounds__(kBlock) void split_planes_kernel(const float* __res
         h2[e] = (_Float16)(xs - (float)a);
       }
       *reinterpret_cast<f16x4*>(dst) = h1;
-      *reinterpret_cast<f16x4*>(dst + plane_elems) = h2;
+      if (P == 2) *reinterpret_cast<f16x4*>(dst + plane_elems) = h2;
       continue;
     }
     bf16x4 p1, p2, p3;
@@ -188,9 +251,11 @@ __global__ __launch_bounds__(kGThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
                                                                  int64_t a_rows, const __bf16* __restrict__ Bp,
                                                                  int64_t b_plane, int64_t b_rows, int Dp, int tm,
                                                                  int tn, int M, int nvalid, GemmOut o) {
-  constexpr int NS = (P == 3) ? 2 : (P == 2 ? 3 : 4);  // LDS stages (one 16-wide k-step each)
-  constexpr int kStage = P * kPlaneStage;         // 36864 / 24576 / 12288 B -> two workgroups per CU
-  constexpr int kPieces = P * kPiecesPerPlane;    // DMA instructions per stage, dealt round-robin to the 8 waves
+  constexpr int NP = plane_count(P);              // planes per operand
+  constexpr bool F16 = plane_f16(P);              // scaled fp16 planes (else bf16)
+  constexpr int NS = (NP == 3) ? 2 : (NP == 2 ? 3 : 4);  // LDS stages (one 16-wide k-step each)
+  constexpr int kStage = NP * kPlaneStage;        // 36864 / 24576 / 12288 B -> two workgroups per CU
+  constexpr int kPieces = NP * kPiecesPerPlane;   // DMA instructions per stage, dealt round-robin to the 8 waves
   constexpr int NPW = (kPieces + 7) / 8;          // 5 / 3 / 2: waves below kLastWaves issue NPW, the others NPW - 1
   constexpr int kLastWaves = kPieces - 8 * (NPW - 1);  // 4 (P = 3, 1) or 8 (P = 2: every wave issues NPW)
   __shared__ __attribute__((aligned(16))) char lds[NS * kStage];
@@ -261,9 +326,9 @@ __global__ __launch_bounds__(kGThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
 #pragma unroll
     for (int j = 0; j < NPW; ++j) issue_piece(j, s);
 
-  constexpr int kTerms = (P == 3) ? 6 : (P == 2 ? 3 : 1);
-  constexpr int kPieceEvery = (P == 1) ? 2 : 4;  // a DMA piece after MFMA 1, 5, 9, ... (P = 3, 2) / 0, 2 (P = 1)
-  constexpr int kPieceFirst = (P == 1) ? 0 : 1;
+  constexpr int kTerms = (NP == 3) ? 6 : (NP == 2 ? 3 : 1);
+  constexpr int kPieceEvery = (NP == 1) ? 2 : 4;  // a DMA piece after MFMA 1, 5, 9, ... (3, 2 planes) / 0, 2 (one plane)
+  constexpr int kPieceFirst = (NP == 1) ? 0 : 1;
   for (int kt = 0; kt < nk; ++kt) {
     // stage kt has landed once at most the NS-2 younger stages' DMAs are outstanding; after the barrier it is
     // visible to every wave and every wave is done with stage kt-1's ring slot (refilled below with kt+NS-1)
@@ -273,9 +338,9 @@ __global__ __launch_bounds__(kGThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
     if (kt == 0) ESR_GT(g1);
 #endif
     const char* st = lds + (kt % NS) * kStage;
-    bf16x8 a[P][2], b[P][2];
+    bf16x8 a[NP][2], b[NP][2];
 #pragma unroll
-    for (int p = 0; p < P; ++p)
+    for (int p = 0; p < NP; ++p)
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
 #if defined(ESR_PROBE_GEMM_HALF_FRAG)  /* timing probe only (results wrong): half the LDS fragment reads per MFMA -- what a
@@ -293,11 +358,11 @@ __global__ __launch_bounds__(kGThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
 #pragma unroll
     for (int term = 0; term < kTerms; ++term) {
       // P = 3: a3 b1, a1 b3, a2 b2, a2 b1, a1 b2, a1 b1;  P = 2 (fp16 planes): a2 b1, a1 b2, a1 b1
-      const int pa = (P == 3) ? (term == 0 ? 2 : term == 2 || term == 3 ? 1 : 0) : (P == 2 ? (term == 0 ? 1 : 0) : 0);
-      const int pb = (P == 3) ? (term == 1 ? 2 : term == 2 || term == 4 ? 1 : 0) : (P == 2 ? (term == 1 ? 1 : 0) : 0);
+      const int pa = (NP == 3) ? (term == 0 ? 2 : term == 2 || term == 3 ? 1 : 0) : (NP == 2 ? (term == 0 ? 1 : 0) : 0);
+      const int pb = (NP == 3) ? (term == 1 ? 2 : term == 2 || term == 4 ? 1 : 0) : (NP == 2 ? (term == 1 ? 1 : 0) : 0);
 #pragma unroll
       for (int ij = 0; ij < 4; ++ij) {
-        if (P == 2)
+        if (F16)
           acc[ij >> 1][ij & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
               __builtin_bit_cast(f16x8, a[pa][ij >> 1]), __builtin_bit_cast(f16x8, b[pb][ij & 1]), acc[ij >> 1][ij & 1],
               0, 0, 0);
@@ -320,8 +385,8 @@ __global__ __launch_bounds__(kGThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
   // P == 2: the accumulators carry 2^(eq + ec) x the scores.  The factor is undone where a score leaves the kernel
   // and the thresholds are scaled UP for the comparisons instead (exact either way: a power of two) -- scaling the 64
   // accumulators in place made hipcc spill 80 registers in the filtered epilogue (1.3 GB of scratch writes per launch).
-  const float sscale = (P == 2) ? ldexpf(1.f, -(o.exps[0] + o.exps[1])) : 1.f;
-  const float tscale = (P == 2) ? ldexpf(1.f, o.exps[0] + o.exps[1]) : 1.f;
+  const float sscale = F16 ? ldexpf(1.f, -(o.exps[0] + o.exps[1])) : 1.f;
+  const float tscale = F16 ? ldexpf(1.f, o.exps[0] + o.exps[1]) : 1.f;
   if (DENSE) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -430,6 +495,21 @@ struct SelIn {
   int n_fixed;
   int skip_upto = 0;   // > 0: a row whose list holds at most this many records is left as it is (lazy compaction: the
                        // caller's list has room for it to grow by another chunk; its tau stays the older, weaker bound)
+  // BAND mode (round 6, mode 3's one-term filter; band_qnorm != null): the scores are one-plane scores whose error is
+  // bounded by b = band_coef |q| max|c|.  The true top-k lies among the records with score >= (k-th best score) - 2 b
+  // (see esr_retrieve_topk): the call keeps ALL of those in out.pairs (in place when the source is that list), sets
+  // out.cnt to their number and out.tau to that threshold; nothing is sorted or delivered.
+  // A row whose band holds more than band_cap records cannot stay in band mode (its list must always have room for a
+  // whole chunk): it becomes an EXACT row -- band_nexact[row] = -1 here, then (the caller's next two launches) all its
+  // records are re-scored in f32 and the plain select cuts the list to its k best; from then on band_nexact[row] = the
+  // number of leading records that carry exact scores, the caller re-scores what a chunk appended before every select,
+  // and the row's threshold is (exact k-th best) - b.  only_pending: the launch handles rows marked -1 alone.
+  const float* band_qnorm = nullptr;  // [rows] |q|
+  const float* band_cmax = nullptr;   // [1] the largest candidate norm
+  float band_coef = 0.f;
+  int32_t* band_nexact = nullptr;     // [rows] 0 = band row, -1 = turns exact now, > 0 = exact row
+  int band_cap = 0;
+  int only_pending = 0;
 };
 struct SelOut {
   int2* pairs;         // running top-k list head [rows][ppitch], or null
@@ -486,10 +566,16 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(4, 
   const int n = in.n_per_row ? in.n_per_row[row] : in.n_fixed;
   if (in.skip_upto > 0 && n <= in.skip_upto) return;  // (uniform over the workgroup)
   const bool final = out.scores != nullptr;
-  if (n <= k && !final) {  // nothing was appended (or the list is still short): the running state stands
+  const int nex = in.band_nexact ? in.band_nexact[row] : 0;
+  if (in.only_pending && nex != -1) return;
+  const bool band = in.band_qnorm != nullptr && nex == 0 && !final;  // (exact rows take the plain path below)
+  const float band_b = in.band_qnorm ? in.band_coef * in.band_qnorm[row] * in.band_cmax[0] : 0.f;
+  const bool src_is_list = in.stride == 2 && reinterpret_cast<const int2*>(in.vals) == out.pairs;
+  if (n <= k && !final && (!band || src_is_list)) {  // nothing was appended (or the list is still short): the running state stands
     if (t == 0) {
       if (out.cnt) out.cnt[row] = n;
       if (out.tau && n < k) out.tau[row] = -INFINITY;
+      if (in.band_nexact && nex != 0) in.band_nexact[row] = n;
     }
     return;
   }
@@ -688,6 +774,49 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(4, 
     }
     thr = lo + (prefix << (L - bits_done));
   }
+  if (band) {
+    // the k-th best score = the smallest composite >= thr; then every record within the band of it stays, in list order.
+    // In place (source == out.pairs) this is safe block by block: a block's records are all read before any of them is
+    // written, and they are written to positions not beyond the block's own start + its size.
+    unsigned long long mn = ~0ull;
+    if (n > k) {
+      sweep([&](unsigned long long C, bool valid) { mn = (valid && C >= thr && C < mn) ? C : mn; });
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long a = __shfl_xor(mn, o, 64);
+        mn = a < mn ? a : mn;
+      }
+      if ((t & 63) == 0) atomicMin(&s_min, mn);
+    }
+    __syncthreads();
+    const float kth = n > k ? key_score((uint32_t)(s_min >> 32)) : -INFINITY;
+    const float keep_thr = n > k ? kth - 2.0f * band_b : -INFINITY;
+    int base = 0;
+    for (int c0 = 0; c0 < n; c0 += kSelThreads) {
+      const int c = c0 + t;
+      const bool valid = c < n;
+      const unsigned long long C = valid ? comp(c) : 0ull;
+      const float sc = key_score((uint32_t)(C >> 32));
+      const bool pass = valid && sc >= keep_thr;
+      const unsigned long long mask = __ballot(pass);
+      if ((t & 63) == 0) part4[t >> 6] = __popcll(mask);
+      __syncthreads();  // (every record of the block has been read)
+      int off = base;
+      for (int j = 0; j < (t >> 6); ++j) off += part4[j];
+      const int total = part4[0] + part4[1] + part4[2] + part4[3];
+      if (pass)
+        out.pairs[(int64_t)row * out.ppitch + off + __popcll(mask & ((1ull << (t & 63)) - 1ull))] =
+            make_int2(__float_as_int(sc), (int32_t)(0xFFFFFFFFu - (uint32_t)C));
+      base += total;
+      __syncthreads();  // (part4 is reused by the next block)
+    }
+    if (t == 0) {
+      out.cnt[row] = base;
+      out.tau[row] = keep_thr;
+      if (base > in.band_cap) in.band_nexact[row] = -1;  // too wide a band for the list: the row turns exact
+    }
+    return;
+  }
   // compact the composites >= thr (exactly nsel of them) into LDS: one slot reservation per wave instruction
   // (a same-address LDS atomic per element serialises: 500 survivors cost more than the whole radix select)
   unsigned long long my_min = ~0ull;
@@ -744,8 +873,9 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(4, 
     if (out.indices) out.indices[(int64_t)row * k + c] = gi;
   }
   if (t == 0) {
+    if (in.band_nexact && nex != 0 && !final) in.band_nexact[row] = nsel;  // an exact row of mode 3: its k best, all exact
     if (out.cnt) out.cnt[row] = nsel;
-    if (out.tau) out.tau[row] = (n >= k) ? key_score((uint32_t)(s_min >> 32)) : -INFINITY;
+    if (out.tau) out.tau[row] = (n >= k) ? key_score((uint32_t)(s_min >> 32)) - band_b : -INFINITY;  // (band_b: exact rows of mode 3)
   }
 }
 
@@ -784,27 +914,74 @@ __global__ __launch_bounds__(kBlock) void rescore_kernel(const float* __restrict
   }
 }
 
+// the same over ragged per-query lists of (score, index) records (mode 3: the survivors of the one-term filter): the
+// record's score is REPLACED by the f32 dot product.  One workgroup per query (its row staged in LDS), sixteen lanes
+// per candidate row (four candidates per wave instruction, 16-byte loads).
+// which = 0: exact rows (nexact > 0), the records a chunk appended behind the nexact exact ones (nexact := the list's
+// length afterwards); 1: rows that turn exact now (nexact == -1), every record; 2 (after the last chunk): band rows
+// (nexact == 0), every record.
+__global__ __launch_bounds__(kBlock) void rescore_lists_kernel(const float* __restrict__ Q, const float* __restrict__ C,
+                                                              int D, int2* __restrict__ pairs, int64_t ppitch,
+                                                              const int32_t* __restrict__ cnt, int32_t base,
+                                                              int32_t step, int32_t* __restrict__ nexact, int which) {
+  extern __shared__ __attribute__((aligned(16))) float qrow[];  // D floats
+  const int64_t q = blockIdx.x;
+  const int nex = nexact[q];
+  if (which == 0 ? nex <= 0 : (which == 1 ? nex != -1 : nex != 0)) return;
+  const int n = cnt[q];
+  const int jfirst = which == 0 ? min(nex, n) : 0;
+  if (jfirst >= n) return;
+  for (int d = threadIdx.x; d < D; d += kBlock) qrow[d] = Q[q * D + d];
+  __syncthreads();
+  const int lig = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  int2* list = pairs + q * ppitch;
+  const bool vec = (D & 3) == 0 && ((uintptr_t)C & 15) == 0;
+  for (int j0 = jfirst; j0 < n; j0 += kBlock / 16) {
+    const int j = j0 + grp;
+    float acc = 0.f;
+    if (j < n) {
+      const int64_t r = ((int64_t)list[j].y - base) / step;
+      const float* ca = C + r * D;
+      if (vec) {
+        for (int d = lig * 4; d < D; d += 64) {
+          const float4 y = *reinterpret_cast<const float4*>(ca + d);
+          const float4 x = *reinterpret_cast<const float4*>(qrow + d);
+          acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
+        }
+      } else {
+        for (int d = lig; d < D; d += 16) acc = fmaf(qrow[d], ca[d], acc);
+      }
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    acc += __shfl_xor(acc, 8, 64);
+    if (j < n && lig == 0) list[j].x = __float_as_int(acc);
+  }
+  if (which == 0 && threadIdx.x == 0) nexact[q] = n;  // (every record of the list is exact now)
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
 struct RetrievePlan {
   int P, Dp;
   int64_t Mp, chunk, chunk_pad, first;
-  size_t off_A, off_B, off_S, off_pairs, off_cnt, off_tau, off_abs, total;
+  size_t off_A, off_B, off_S, off_pairs, off_cnt, off_tau, off_abs, off_band, off_nexact, total;
   int64_t ppitch;
   int skip_upto;  // running lists up to this long are not compacted between chunks
 };
 
 static RetrievePlan retrieve_plan(int64_t nq, int64_t N, int D, int k, int mode) {
   RetrievePlan p;
-  p.P = (mode == 0) ? 3 : (mode == 2 ? 2 : 1);
+  p.P = (mode == 0) ? 3 : (mode == 2 ? 2 : (mode == 3 ? 4 : 1));
   p.Dp = (int)(cdiv(D, kGK) * kGK);
   p.Mp = cdiv(nq, kGM) * kGM;
   p.first = std::min<int64_t>(N, std::max<int64_t>(kFirstChunk, 16 * (int64_t)k));
   // later chunks: the per-query append list must hold a whole chunk (worst case every candidate passes tau);
   // keep the list buffer around 2 GiB and the 32-bit DMA offsets inside one plane set
   int64_t chunk = ((int64_t)1 << 28) / std::max<int64_t>(nq, 1);
-  chunk = std::min<int64_t>(chunk, ((int64_t)1 << 30) / ((int64_t)p.Dp * 2 * p.P));
+  chunk = std::min<int64_t>(chunk, ((int64_t)1 << 30) / ((int64_t)p.Dp * 2 * plane_count(p.P)));
   chunk = std::max<int64_t>(kGN, std::min<int64_t>(65536, chunk / kGN * kGN));
   p.chunk = chunk;
   p.chunk_pad = std::max(cdiv(p.chunk, kGN) * kGN, cdiv(p.first, kGN) * kGN);
@@ -816,13 +993,15 @@ static RetrievePlan retrieve_plan(int64_t nq, int64_t N, int D, int k, int mode)
   p.skip_upto = (int)std::max<int64_t>(3 * (int64_t)k, 1536);
   p.ppitch = std::max<int64_t>(k, p.skip_upto) + p.chunk;
   size_t o = 0;
-  p.off_A = o; o += align_up((size_t)p.P * p.Mp * p.Dp * 2, 256);
-  p.off_B = o; o += align_up((size_t)p.P * p.chunk_pad * p.Dp * 2, 256);
+  p.off_A = o; o += align_up((size_t)plane_count(p.P) * p.Mp * p.Dp * 2, 256);
+  p.off_B = o; o += align_up((size_t)plane_count(p.P) * p.chunk_pad * p.Dp * 2, 256);
   p.off_S = o; o += align_up((size_t)nq * p.first * 4, 256);
   p.off_pairs = o; o += align_up((size_t)nq * p.ppitch * 8, 256);
   p.off_cnt = o; o += align_up((size_t)nq * 4, 256);
   p.off_tau = o; o += align_up((size_t)nq * 4, 256);
   p.off_abs = o; o += align_up((size_t)(kAbsBlocks + 64) * 4, 256);  // absmax slots, then the two exponent words
+  p.off_band = o; o += align_up((size_t)(kAbsBlocks + 64 + nq) * 4, 256);  // mode 3: norm slots, max |c|, then |q| per query
+  p.off_nexact = o; o += align_up((size_t)nq * 4, 256);                    //         exact-row marks
   p.total = o;
   return p;
 }
@@ -1004,8 +1183,9 @@ int esr_retrieve_topk(const float* queries, const float* candidates, int64_t nq,
                   nq < ((int64_t)1 << 24),
               "esr_retrieve_topk: bad sizes nq=%lld N=%lld D=%d k=%d (k <= min(N, %d))", (long long)nq, (long long)N, D,
               k, kSelMaxK);
-  ESR_REQUIRE(mode == 0 || mode == 1 || mode == 2,
-              "esr_retrieve_topk: mode %d (0 = exact bf16x3, 1 = bf16, 2 = exact-grade f16x2)", mode);
+  ESR_REQUIRE(mode >= 0 && mode <= 3,
+              "esr_retrieve_topk: mode %d (0 = exact bf16x3, 1 = bf16, 2 = exact-grade f16x2, 3 = f16 filter + f32 re-score)",
+              mode);
   ESR_REQUIRE(index_step > 0 && (int64_t)index_base + (N - 1) * (int64_t)index_step < ((int64_t)1 << 31),
               "esr_retrieve_topk: index_base/index_step overflow int32");
   ESR_REQUIRE(queries && candidates && out_scores && out_indices && workspace, "esr_retrieve_topk: null pointer");
@@ -1025,11 +1205,30 @@ int esr_retrieve_topk(const float* queries, const float* candidates, int64_t nq,
   const int64_t a_plane = p.Mp * p.Dp, b_plane = p.chunk_pad * p.Dp;
   float* abs_slots = (float*)(base + p.off_abs);
   int* exps = (int*)(abs_slots + kAbsBlocks);  // {eq, ec}
+  // mode 3: norm slots [kAbsBlocks], the largest candidate norm [1] (+ padding), |q| per query [nq], nexact [nq]
+  float* nrm_slots = (float*)(base + p.off_band);
+  float* cmax = nrm_slots + kAbsBlocks;
+  float* qnorm = nrm_slots + kAbsBlocks + 64;
+  int32_t* nexact = (int32_t*)(base + p.off_nexact);
+  const bool band = p.P == 4;
+  const float band_coef = 1.02f * 0.0009765625f;  // 2^-10 (1 + slack): see the header's mode-3 note
   if (p.P == 2) {
     // one exponent per matrix; the candidates' covers ALL chunks (one 4 N D-byte read, ~1 % of the call at N = 1 M)
     launch_absmax(queries, nq * (int64_t)D, abs_slots, exps, st);
     launch_absmax(candidates, N * (int64_t)D, abs_slots, exps + 1, st);
     launch_split<2>(queries, nq, D, p.Mp, p.Dp, a_plane, A, st, exps);
+  } else if (band) {
+    // exponents as above, and in the same read of each matrix the row norms the error bound of a one-plane score needs
+    auto rowstat = [&](const float* X, int64_t rows, float* norms, int* exp_out, float* nmax_out) {
+      const int grid = (int)std::min<int64_t>(kAbsBlocks, std::max<int64_t>(1, cdiv(rows, kBlock / 64)));
+      hipLaunchKernelGGL(rowstat_kernel, dim3(grid), dim3(kBlock), 0, st, X, rows, D, norms, abs_slots, nrm_slots);
+      hipLaunchKernelGGL(absmax_exp_kernel, dim3(1), dim3(kBlock), 0, st, (const float*)abs_slots, grid, exp_out);
+      if (nmax_out) hipLaunchKernelGGL(slots_max_kernel, dim3(1), dim3(kBlock), 0, st, (const float*)nrm_slots, grid, nmax_out);
+    };
+    rowstat(queries, nq, qnorm, exps, nullptr);
+    rowstat(candidates, N, nullptr, exps + 1, cmax);
+    if (hipMemsetAsync(nexact, 0, (size_t)nq * sizeof(int32_t), st) != hipSuccess) return check_launch("esr_retrieve_topk");
+    launch_split<4>(queries, nq, D, p.Mp, p.Dp, a_plane, A, st, exps);
   } else if (p.P == 3) launch_split<3>(queries, nq, D, p.Mp, p.Dp, a_plane, A, st);
   else launch_split<1>(queries, nq, D, p.Mp, p.Dp, a_plane, A, st);
 
@@ -1043,6 +1242,7 @@ int esr_retrieve_topk(const float* queries, const float* candidates, int64_t nq,
     const int64_t n_pad = cdiv(nc, kGN) * kGN;
     const bool last = (c0 + nc == N);
     if (p.P == 2) launch_split<2>(candidates + c0 * D, nc, D, n_pad, p.Dp, b_plane, B, st, exps + 1);
+    else if (band) launch_split<4>(candidates + c0 * D, nc, D, n_pad, p.Dp, b_plane, B, st, exps + 1);
     else if (p.P == 3) launch_split<3>(candidates + c0 * D, nc, D, n_pad, p.Dp, b_plane, B, st);
     else launch_split<1>(candidates + c0 * D, nc, D, n_pad, p.Dp, b_plane, B, st);
     GemmOut o;
@@ -1052,16 +1252,18 @@ int esr_retrieve_topk(const float* queries, const float* candidates, int64_t nq,
     SelIn in;
     SelOut so;
     so.pairs = pairs; so.ppitch = p.ppitch; so.cnt = cnt; so.tau = tau;
-    so.scores = last ? out_scores : nullptr;
-    so.indices = last ? out_indices : nullptr;
+    so.scores = (last && !band) ? out_scores : nullptr;   // (mode 3 delivers after its re-score, below)
+    so.indices = (last && !band) ? out_indices : nullptr;
     if (first) {
       if (p.P == 2) launch_gemm<2, true>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
+      else if (band) launch_gemm<4, true>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
       else if (p.P == 3) launch_gemm<3, true>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
       else launch_gemm<1, true>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
       in.vals = S; in.vpitch = p.first; in.idx = nullptr; in.stride = 1; in.ibase = o.gbase; in.istep = index_step;
       in.n_per_row = nullptr; in.n_fixed = (int)nc;
     } else {
       if (p.P == 2) launch_gemm<2, false>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
+      else if (band) launch_gemm<4, false>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
       else if (p.P == 3) launch_gemm<3, false>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
       else launch_gemm<1, false>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
       in.vals = (const float*)pairs; in.vpitch = 2 * p.ppitch; in.idx = (const int32_t*)pairs + 1; in.stride = 2;
@@ -1070,11 +1272,37 @@ int esr_retrieve_topk(const float* queries, const float* candidates, int64_t nq,
     }
     // rows beyond what a workgroup's registers hold (2048 records) are cached in LDS (up to 4096 records)
     const int lds_words = kSelLdsWords;
+    auto rescore_lists = [&](int which) {
+      ESR_KT("rescore_lists_kernel", st,
+             hipLaunchKernelGGL(rescore_lists_kernel, dim3((int)nq), dim3(kBlock), (size_t)D * sizeof(float), st, queries,
+                                candidates, D, pairs, p.ppitch, (const int32_t*)cnt, index_base, index_step, nexact, which));
+    };
+    if (band) {
+      in.band_qnorm = qnorm; in.band_cmax = cmax; in.band_coef = band_coef; in.band_nexact = nexact;
+      in.band_cap = p.skip_upto;
+      if (!first) rescore_lists(0);  // exact rows: what this chunk appended
+    }
     ESR_KT("topk_select_kernel", st, hipLaunchKernelGGL(topk_select_kernel, dim3((int)nq), dim3(kSelThreads), lds_words * sizeof(uint32_t), st, in, k, so,
                        lds_words));
+    if (band) {  // rows whose band outgrew the list turn exact at once: re-score everything they hold, cut to the k best
+      rescore_lists(1);
+      SelIn in2 = in;
+      in2.vals = (const float*)pairs; in2.vpitch = 2 * p.ppitch; in2.idx = (const int32_t*)pairs + 1; in2.stride = 2;
+      in2.ibase = 0; in2.istep = 0; in2.n_per_row = cnt; in2.n_fixed = 0; in2.skip_upto = 0; in2.only_pending = 1;
+      ESR_KT("topk_select_kernel", st, hipLaunchKernelGGL(topk_select_kernel, dim3((int)nq), dim3(kSelThreads), lds_words * sizeof(uint32_t), st, in2, k, so,
+                         lds_words));
+    }
     ++ncall;
     c0 += nc;
     first = false;
+  }
+  if (band) {
+    // the survivors of the one-term filter (band rows: every record; exact rows are exact already) in f32, then the
+    // k best of every list, best first
+    ESR_KT("rescore_lists_kernel", st,
+           hipLaunchKernelGGL(rescore_lists_kernel, dim3((int)nq), dim3(kBlock), (size_t)D * sizeof(float), st, queries,
+                              candidates, D, pairs, p.ppitch, (const int32_t*)cnt, index_base, index_step, nexact, 2));
+    if (int rc = select_topk_tail(pairs, p.ppitch, cnt, nq, k, out_scores, out_indices, st)) return rc;
   }
   return check_launch("esr_retrieve_topk");
 }

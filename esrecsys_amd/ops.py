@@ -881,7 +881,8 @@ def score_topk(queries, candidates, k):
     return out_s, out_i
 
 
-_RETRIEVE_MODES = {"bf16x3": _lib.RETRIEVE_EXACT, "f16x2": _lib.RETRIEVE_F16X2, "bf16": _lib.RETRIEVE_BF16}
+_RETRIEVE_MODES = {"bf16x3": _lib.RETRIEVE_EXACT, "f16x2": _lib.RETRIEVE_F16X2, "bf16": _lib.RETRIEVE_BF16,
+                   "f16r": _lib.RETRIEVE_F16R}
 
 
 def _retrieve_mode(mode):
@@ -893,15 +894,16 @@ def _retrieve_mode(mode):
     if mode in ("exact", "f32"):
         mode = os.environ.get("ESR_RETRIEVE_EXACT", "bf16x3")
     if mode not in _RETRIEVE_MODES:
-        raise ValueError("retrieval mode must be exact / f32 / f16x2 / bf16x3 / bf16, got %r" % (mode,))
+        raise ValueError("retrieval mode must be exact / f32 / f16x2 / f16r / bf16x3 / bf16, got %r" % (mode,))
     return _RETRIEVE_MODES[mode]
 
 
 def retrieve_topk(queries, candidates, k, mode="exact", index_base=0, index_step=1):
     """Batched brute-force top-k of queries @ candidates^T (descending, ties -> lower index) on MFMA.
     mode "exact" = "bf16x3": three exact bf16 planes per operand (exact products in f32 accumulation order);
-    "f16x2": two scaled fp16 planes (f32-grade within a 2^16 dynamic range per matrix, 1.6x faster); "bf16": one
-    plane (approximate).
+    "f16x2": two scaled fp16 planes (f32-grade within a 2^16 dynamic range per matrix, 1.6x faster); "f16r": one scaled
+    fp16 plane as a filter with a proven error band, its survivors re-scored in f32 -- the exact top-k of the f32 scores
+    at a third of f16x2's matrix work (include/esr_hip.h ESR_RETRIEVE_F16R); "bf16": one plane (approximate).
     Reported indices are index_base + n * index_step for local candidate row n."""
     lib = _lib.load()
     _req(queries, torch.float32, "queries"), _req(candidates, torch.float32, "candidates")

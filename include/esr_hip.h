@@ -444,10 +444,20 @@ int esr_score_topk(const float* queries, const float* candidates, int64_t nq, in
  *   esr_rescore_candidates + esr_topk_merge for an exact re-rank of k' > k candidates.
  * mode ESR_RETRIEVE_F16X2: products from two fp16 planes of x * 2^e per operand (e per matrix, from its largest
  *   |element|; three MFMA cross terms, f32 accumulate) -- f32-grade scores (<= ~3 * 2^-24 |a||b| per elementary product)
- *   at half the matrix-core work of ESR_RETRIEVE_EXACT; one extra read of both matrices for the scales. */
+ *   at half the matrix-core work of ESR_RETRIEVE_EXACT; one extra read of both matrices for the scales.
+ * mode ESR_RETRIEVE_F16R (round 6): the EXACT top-k of the f32 scores from a ONE-term filter.  Every candidate is scored
+ *   with the hi fp16 plane alone (one MFMA term instead of three); that score is off by at most b = 2^-10 (1 + 2 %) |q|
+ *   max |c| (two roundings to 11 bits, Cauchy-Schwarz; row norms from the scaling pass), so the true top-k lies among
+ *   the candidates whose one-term score reaches (k-th best one-term score) - 2 b: k of them have true scores >= that
+ *   k-th best - b, and a member of the true top-k cannot score lower than those in truth.  The filter keeps exactly that
+ *   band per query; the survivors (~1.2 k at N = 1 M, D = 512, k = 500) are re-scored as f32 dot products and selected.
+ *   A query whose band outgrows its list (near-equal scores for thousands of candidates) is switched to exact scores on
+ *   the spot and filtered against (exact k-th best) - b from then on: the answer never depends on the band being small.
+ *   Scores are the f32 dot products (fmaf over 16 lanes + tree), ties -> lower index, like ESR_RETRIEVE_EXACT. */
 #define ESR_RETRIEVE_EXACT 0
 #define ESR_RETRIEVE_BF16 1
 #define ESR_RETRIEVE_F16X2 2
+#define ESR_RETRIEVE_F16R 3
 size_t esr_retrieve_workspace_bytes(int64_t nq, int64_t N, int D, int k, int mode);
 int esr_retrieve_topk(const float* queries, const float* candidates, int64_t nq, int64_t N, int D, int k,
                       int mode, int32_t index_base, int32_t index_step, float* out_scores,

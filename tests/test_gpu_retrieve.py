@@ -30,7 +30,7 @@ def _grid(rng, shape, levels=8):
     return (rng.integers(-levels, levels + 1, shape) / 4.0).astype(np.float32)
 
 
-@pytest.mark.parametrize("mode", ["exact", "bf16"])
+@pytest.mark.parametrize("mode", ["exact", "bf16", "f16r"])
 @pytest.mark.parametrize("nq,N_,D,k", [(37, 5_000, 128, 10),      # one dense chunk, ragged query tile
                                        (300, 30_000, 512, 50),    # dense chunk + filtered chunks, 2 query tiles
                                        (9, 150_000, 64, 500),     # several filtered chunks, k = 500
@@ -46,23 +46,26 @@ def test_retrieve_topk_exact_arithmetic_bit_exact(dev, mode, nq, N_, D, k):
     assert np.array_equal(N(s), es.astype(np.float32))
 
 
-def test_retrieve_topk_all_equal_scores(dev):
-    """zero queries: every score ties; the answer is indices 0..k-1 (and base + step * n when sharded)"""
+@pytest.mark.parametrize("mode", ["exact", "f16r"])
+def test_retrieve_topk_all_equal_scores(dev, mode):
+    """zero queries: every score ties; the answer is indices 0..k-1 (and base + step * n when sharded).  (f16r: the band
+    of a zero query is zero wide and still holds every candidate -- the rows turn exact.)"""
     from esrecsys_amd import ops
     q = torch.zeros((3, 64), device=dev)
     c = torch.randn((20_000, 64), device=dev)
-    s, i = ops.retrieve_topk(q, c, 17, mode="exact", index_base=5, index_step=8)
+    s, i = ops.retrieve_topk(q, c, 17, mode=mode, index_base=5, index_step=8)
     assert np.array_equal(N(i), np.tile(5 + 8 * np.arange(17, dtype=np.int32), (3, 1)))
     assert np.all(N(s) == 0)
 
 
+@pytest.mark.parametrize("mode", ["exact", "f16r"])
 @pytest.mark.parametrize("nq,N_,D,k", [(64, 40_000, 128, 10), (33, 70_000, 512, 500), (257, 12_345, 96, 100)])
-def test_retrieve_topk_random_vs_oracle(dev, nq, N_, D, k):
+def test_retrieve_topk_random_vs_oracle(dev, nq, N_, D, k, mode):
     from esrecsys_amd import ops
     rng = np.random.default_rng(nq + k)
     q = (rng.standard_normal((nq, D)) * D ** -0.5).astype(np.float32)
     c = (rng.standard_normal((N_, D)) * D ** -0.5).astype(np.float32)
-    s, i = ops.retrieve_topk(T(q, dev), T(c, dev), k, mode="exact")
+    s, i = ops.retrieve_topk(T(q, dev), T(c, dev), k, mode=mode)
     full = q.astype(F64) @ c.astype(F64).T
     es, ei = o_topk.top_k(full, k)
     got_s, got_i = N(s), N(i)
@@ -170,3 +173,78 @@ def test_retrieve_full_size_properties(dev):
     # a second call returns the same bits (the append order inside the filter is not deterministic, the answer is)
     s2, i2 = ops.retrieve_topk(q, c, k, mode="exact")
     assert torch.equal(s, s2) and torch.equal(i, i2)
+
+
+# ---- the one-term filter of mode "f16r" (ESR_RETRIEVE_F16R): adversarial inputs --------------------------------------------
+def _f16r_vs_exact(dev, q, c, k):
+    """f16r against the fp64 ranking: identical index SETS per query wherever the k-th and (k+1)-th true scores are apart
+    by more than an f32 rounding of a D-term dot product, reported scores = the f32 dot products of the reported indices."""
+    from esrecsys_amd import ops
+    s, i = ops.retrieve_topk(T(q, dev), T(c, dev), k, mode="f16r")
+    full = q.astype(F64) @ c.astype(F64).T
+    es, ei = o_topk.top_k(full, k)
+    got_s, got_i = N(s), N(i)
+    assert all(len(set(r)) == k for r in got_i)
+    assert np.all(np.diff(got_s, axis=1) <= 0)
+    picked = np.take_along_axis(full, got_i.astype(np.int64), axis=1)
+    scale = np.abs(full).max()
+    assert np.abs(picked - got_s).max() <= 1e-5 * scale
+    srt = np.sort(full, axis=1)[:, ::-1]
+    gap = srt[:, k - 1] - srt[:, k] if full.shape[1] > k else np.full(full.shape[0], np.inf)
+    clear = gap > 1e-5 * scale
+    for r in np.nonzero(clear)[0]:
+        assert set(got_i[r]) == set(ei[r]), r
+    # where the cut is a near-tie the sets may differ -- but only by candidates whose true scores are that close to it
+    for r in np.nonzero(~clear)[0]:
+        worst = full[r, list(set(got_i[r]) - set(ei[r]))]
+        assert worst.size == 0 or (srt[r, k - 1] - worst).max() <= 1e-5 * scale
+    return got_s, got_i, full
+
+
+def test_retrieve_f16r_near_ties_straddling_the_cut(dev):
+    """Thousands of candidates whose TRUE scores lie within a fraction of the one-term error band of the k-th best, on both
+    sides of it, with fp16-unfriendly components (their one-plane scores are scrambled against the true order): the true
+    top-k must come out, which it can only if every candidate of the band is re-scored."""
+    rng = np.random.default_rng(11)
+    nq, N_, D, k = 24, 60_000, 256, 100
+    q = (rng.standard_normal((nq, D)) * D ** -0.5).astype(np.float32)
+    c = (rng.standard_normal((N_, D)) * D ** -0.5).astype(np.float32)
+    # 3 000 candidates = (a strong common direction) + noise whose projection on the queries is ~1e-4: their scores
+    # against every query agree to ~1e-4 relative, far inside the band 2^-9 |q| |c|
+    u = rng.standard_normal(D).astype(np.float32)
+    u /= np.linalg.norm(u)
+    q += 0.7 * u                                       # every query has a component along u
+    hot = rng.choice(N_, 3000, replace=False)
+    c[hot] = 2.0 * u + (rng.standard_normal((3000, D)) * 2e-4).astype(np.float32)
+    _f16r_vs_exact(dev, q, c, k)
+
+
+def test_retrieve_f16r_one_query_with_a_band_of_thousands(dev):
+    """One query sees 6 000 candidates at (almost) its k-th best score -- its band outgrows the list and the row must turn
+    exact -- while its neighbours stay in band mode; a second query is exactly zero (every score ties)."""
+    rng = np.random.default_rng(12)
+    nq, N_, D, k = 40, 200_000, 128, 500
+    q = (rng.standard_normal((nq, D)) * D ** -0.5).astype(np.float32)
+    c = (rng.standard_normal((N_, D)) * D ** -0.5).astype(np.float32)
+    q[7] = 0.0
+    q[7, 0] = 1.0                                      # query 7 reads coordinate 0 of the candidates ...
+    plateau = rng.choice(N_, 6000, replace=False)
+    c[plateau, 0] = 0.5 + rng.uniform(-1e-5, 1e-5, 6000).astype(np.float32)   # ... and 6 000 of them sit on a plateau
+    c[rng.choice(np.setdiff1d(np.arange(N_), plateau), 300, replace=False), 0] = 0.9   # 300 clear winners above it
+    q[3] = 0.0
+    _f16r_vs_exact(dev, q, c, k)
+
+
+def test_retrieve_f16r_equals_exact_mode_indices_at_c5_shape(dev):
+    """D = 512, k = 500 (config 5's shape, fewer rows): the f16r answer against the exact three-plane path -- same index
+    sets, scores within an f32 rounding of a 512-term sum."""
+    from esrecsys_amd import ops
+    g = torch.Generator(device=dev).manual_seed(5)
+    nq, N_, D, k = 512, 300_000, 512, 500
+    q = torch.randn((nq, D), generator=g, device=dev) * D ** -0.5
+    c = torch.randn((N_, D), generator=g, device=dev) * D ** -0.5
+    s0, i0 = ops.retrieve_topk(q, c, k, mode="exact")
+    s1, i1 = ops.retrieve_topk(q, c, k, mode="f16r")
+    assert rel_err(N(s1), N(s0)) <= 2e-6
+    same = np.mean([len(set(a) & set(b)) / float(k) for a, b in zip(N(i0), N(i1))])
+    assert same >= 0.9999, same     # (a candidate within an f32 rounding of the cut may swap with its neighbour)
