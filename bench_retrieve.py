@@ -16,7 +16,8 @@ MFMA_F32_PEAK_TFLOPS = 157.3
 def _planes(mode):
     """MFMA cross terms per product and whether the planes are fp16, for a retrieve_topk mode name."""
     m = os.environ.get("ESR_RETRIEVE_EXACT", "bf16x3") if mode in ("exact", "f32") else mode
-    return {"f16x2": (3, True), "bf16x3": (6, False), "bf16": (1, False)}[m] + (m,)
+    # (f16r: one fp16 term per candidate as a FILTER, survivors re-scored in f32 -- exact top-k of the f32 scores)
+    return {"f16x2": (3, True), "bf16x3": (6, False), "bf16": (1, False), "f16r": (1, True)}[m] + (m,)
 
 
 def measure_retrieve(dev, n_local, steps, warmup, mode="f16x2", with_cpu=True, with_ann=True, nq=NQ, k=K):
@@ -74,7 +75,9 @@ def measure_retrieve(dev, n_local, steps, warmup, mode="f16x2", with_cpu=True, w
         "metric": "retrieval queries/sec (top-%d of N candidates, brute force)" % k,
         "value": nq * steps / dt, "unit": "queries/s", "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
         "dtype": exact_path + (" (f32-grade: two fp16 planes of x 2^e, one exponent per matrix)" if exact_path == "f16x2" else
-                               " (exact split: three bf16 planes)" if exact_path == "bf16x3" else ""),
+                               " (exact split: three bf16 planes)" if exact_path == "bf16x3" else
+                               " (one fp16 plane as a filter with a proven error band, survivors re-scored as f32 dot "
+                               "products: the exact top-k of the f32 scores)" if exact_path == "f16r" else ""),
         "config": {"workload": "retrieve: %d queries x %d candidates x D=%d, k=%d, one GPU" % (nq, n_local, D, k),
                    "mode": mode, **extra},
         "roofline": {"kernel": "score_gemm_kernel (+ split, select)", "bound": "mfma",

@@ -510,6 +510,11 @@ struct SelIn {
   int32_t* band_nexact = nullptr;     // [rows] 0 = band row, -1 = turns exact now, > 0 = exact row
   int band_cap = 0;
   int only_pending = 0;
+  // what the exact rows' re-score needs (done by the row's workgroup itself, in front of its select: rescore_rows)
+  const float* rs_Q = nullptr;
+  const float* rs_C = nullptr;
+  int rs_D = 0;
+  int32_t rs_base = 0, rs_step = 1;
 };
 struct SelOut {
   int2* pairs;         // running top-k list head [rows][ppitch], or null
@@ -519,6 +524,40 @@ struct SelOut {
   float* scores;       // [rows][k] or null
   int32_t* indices;    // [rows][k] or null
 };
+
+// scores of records [jfirst, n) of one query's (score, index) list := f32 dot products with the query row, by the
+// query's workgroup (256 threads: sixteen lanes per candidate row, 16-byte loads); qrow: D floats of LDS
+__device__ __forceinline__ void rescore_rows(const float* __restrict__ Qrow, const float* __restrict__ C, int D,
+                                             int2* __restrict__ list, int jfirst, int n, int32_t base, int32_t step,
+                                             float* qrow) {
+  for (int d = threadIdx.x; d < D; d += kBlock) qrow[d] = Qrow[d];
+  __syncthreads();
+  const int lig = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const bool vec = (D & 3) == 0 && ((uintptr_t)C & 15) == 0;
+  for (int j0 = jfirst; j0 < n; j0 += kBlock / 16) {
+    const int j = j0 + grp;
+    float acc = 0.f;
+    if (j < n) {
+      const int64_t r = ((int64_t)list[j].y - base) / step;
+      const float* ca = C + r * D;
+      if (vec) {
+        for (int d = lig * 4; d < D; d += 64) {
+          const float4 y = *reinterpret_cast<const float4*>(ca + d);
+          const float4 x = *reinterpret_cast<const float4*>(qrow + d);
+          acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
+        }
+      } else {
+        for (int d = lig; d < D; d += 16) acc = fmaf(qrow[d], ca[d], acc);
+      }
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    acc += __shfl_xor(acc, 8, 64);
+    if (j < n && lig == 0) list[j].x = __float_as_int(acc);
+  }
+  __syncthreads();  // (the list is read back by the whole workgroup; qrow's LDS is reused)
+}
 
 // inclusive scan over the 256 threads of the block (wave shuffles + 4 partials)
 __device__ __forceinline__ int block_incl_scan(int v, int* part4, int t) {
@@ -571,6 +610,14 @@ __global__ __launch_bounds__(kSelThreads) __attribute__((amdgpu_waves_per_eu(4, 
   const bool band = in.band_qnorm != nullptr && nex == 0 && !final;  // (exact rows take the plain path below)
   const float band_b = in.band_qnorm ? in.band_coef * in.band_qnorm[row] * in.band_cmax[0] : 0.f;
   const bool src_is_list = in.stride == 2 && reinterpret_cast<const int2*>(in.vals) == out.pairs;
+  if (in.rs_Q && src_is_list && nex != 0 && !final) {
+    // an exact row of mode 3: what the chunk appended behind its nex exact records (nex = -1: the row turns exact now,
+    // every record) gets its f32 score before the select looks at the list
+    const int jfirst = nex > 0 ? min(nex, n) : 0;
+    if (jfirst < n)
+      rescore_rows(in.rs_Q + (int64_t)row * in.rs_D, in.rs_C, in.rs_D, out.pairs + (int64_t)row * out.ppitch, jfirst, n,
+                   in.rs_base, in.rs_step, reinterpret_cast<float*>(lrow));
+  }
   if (n <= k && !final && (!band || src_is_list)) {  // nothing was appended (or the list is still short): the running state stands
     if (t == 0) {
       if (out.cnt) out.cnt[row] = n;
@@ -914,51 +961,17 @@ __global__ __launch_bounds__(kBlock) void rescore_kernel(const float* __restrict
   }
 }
 
-// the same over ragged per-query lists of (score, index) records (mode 3: the survivors of the one-term filter): the
-// record's score is REPLACED by the f32 dot product.  One workgroup per query (its row staged in LDS), sixteen lanes
-// per candidate row (four candidates per wave instruction, 16-byte loads).
-// which = 0: exact rows (nexact > 0), the records a chunk appended behind the nexact exact ones (nexact := the list's
-// length afterwards); 1: rows that turn exact now (nexact == -1), every record; 2 (after the last chunk): band rows
-// (nexact == 0), every record.
+// the same over ragged per-query lists of (score, index) records (mode 3, after the last chunk: the survivors of the
+// one-term filter): the records' scores are REPLACED by the f32 dot products.  One workgroup per query; rows that turned
+// exact earlier (nexact != 0) are exact already.
 __global__ __launch_bounds__(kBlock) void rescore_lists_kernel(const float* __restrict__ Q, const float* __restrict__ C,
                                                               int D, int2* __restrict__ pairs, int64_t ppitch,
                                                               const int32_t* __restrict__ cnt, int32_t base,
-                                                              int32_t step, int32_t* __restrict__ nexact, int which) {
+                                                              int32_t step, const int32_t* __restrict__ nexact) {
   extern __shared__ __attribute__((aligned(16))) float qrow[];  // D floats
   const int64_t q = blockIdx.x;
-  const int nex = nexact[q];
-  if (which == 0 ? nex <= 0 : (which == 1 ? nex != -1 : nex != 0)) return;
-  const int n = cnt[q];
-  const int jfirst = which == 0 ? min(nex, n) : 0;
-  if (jfirst >= n) return;
-  for (int d = threadIdx.x; d < D; d += kBlock) qrow[d] = Q[q * D + d];
-  __syncthreads();
-  const int lig = threadIdx.x & 15, grp = threadIdx.x >> 4;
-  int2* list = pairs + q * ppitch;
-  const bool vec = (D & 3) == 0 && ((uintptr_t)C & 15) == 0;
-  for (int j0 = jfirst; j0 < n; j0 += kBlock / 16) {
-    const int j = j0 + grp;
-    float acc = 0.f;
-    if (j < n) {
-      const int64_t r = ((int64_t)list[j].y - base) / step;
-      const float* ca = C + r * D;
-      if (vec) {
-        for (int d = lig * 4; d < D; d += 64) {
-          const float4 y = *reinterpret_cast<const float4*>(ca + d);
-          const float4 x = *reinterpret_cast<const float4*>(qrow + d);
-          acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
-        }
-      } else {
-        for (int d = lig; d < D; d += 16) acc = fmaf(qrow[d], ca[d], acc);
-      }
-    }
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    acc += __shfl_xor(acc, 4, 64);
-    acc += __shfl_xor(acc, 8, 64);
-    if (j < n && lig == 0) list[j].x = __float_as_int(acc);
-  }
-  if (which == 0 && threadIdx.x == 0) nexact[q] = n;  // (every record of the list is exact now)
+  if (nexact[q] != 0) return;
+  rescore_rows(Q + q * D, C, D, pairs + q * ppitch, 0, cnt[q], base, step, qrow);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1189,6 +1202,7 @@ int esr_retrieve_topk(const float* queries, const float* candidates, int64_t nq,
   ESR_REQUIRE(index_step > 0 && (int64_t)index_base + (N - 1) * (int64_t)index_step < ((int64_t)1 << 31),
               "esr_retrieve_topk: index_base/index_step overflow int32");
   ESR_REQUIRE(queries && candidates && out_scores && out_indices && workspace, "esr_retrieve_topk: null pointer");
+  ESR_REQUIRE(mode != 3 || D <= kSelLdsWords, "esr_retrieve_topk: mode 3 takes D <= %d", kSelLdsWords);
   const RetrievePlan p = retrieve_plan(nq, N, D, k, mode);
   if (workspace_bytes < p.total || ((uintptr_t)workspace & 15)) {
     set_error("esr_retrieve_topk: workspace %zu bytes < %zu required (or misaligned)", workspace_bytes, p.total);
@@ -1272,20 +1286,15 @@ int esr_retrieve_topk(const float* queries, const float* candidates, int64_t nq,
     }
     // rows beyond what a workgroup's registers hold (2048 records) are cached in LDS (up to 4096 records)
     const int lds_words = kSelLdsWords;
-    auto rescore_lists = [&](int which) {
-      ESR_KT("rescore_lists_kernel", st,
-             hipLaunchKernelGGL(rescore_lists_kernel, dim3((int)nq), dim3(kBlock), (size_t)D * sizeof(float), st, queries,
-                                candidates, D, pairs, p.ppitch, (const int32_t*)cnt, index_base, index_step, nexact, which));
-    };
     if (band) {
       in.band_qnorm = qnorm; in.band_cmax = cmax; in.band_coef = band_coef; in.band_nexact = nexact;
       in.band_cap = p.skip_upto;
-      if (!first) rescore_lists(0);  // exact rows: what this chunk appended
+      // (exact rows: their workgroup re-scores what this chunk appended, in front of its select)
+      in.rs_Q = queries; in.rs_C = candidates; in.rs_D = D; in.rs_base = index_base; in.rs_step = index_step;
     }
     ESR_KT("topk_select_kernel", st, hipLaunchKernelGGL(topk_select_kernel, dim3((int)nq), dim3(kSelThreads), lds_words * sizeof(uint32_t), st, in, k, so,
                        lds_words));
     if (band) {  // rows whose band outgrew the list turn exact at once: re-score everything they hold, cut to the k best
-      rescore_lists(1);
       SelIn in2 = in;
       in2.vals = (const float*)pairs; in2.vpitch = 2 * p.ppitch; in2.idx = (const int32_t*)pairs + 1; in2.stride = 2;
       in2.ibase = 0; in2.istep = 0; in2.n_per_row = cnt; in2.n_fixed = 0; in2.skip_upto = 0; in2.only_pending = 1;
@@ -1301,7 +1310,8 @@ int esr_retrieve_topk(const float* queries, const float* candidates, int64_t nq,
     // k best of every list, best first
     ESR_KT("rescore_lists_kernel", st,
            hipLaunchKernelGGL(rescore_lists_kernel, dim3((int)nq), dim3(kBlock), (size_t)D * sizeof(float), st, queries,
-                              candidates, D, pairs, p.ppitch, (const int32_t*)cnt, index_base, index_step, nexact, 2));
+                              candidates, D, pairs, p.ppitch, (const int32_t*)cnt, index_base, index_step,
+                              (const int32_t*)nexact));
     if (int rc = select_topk_tail(pairs, p.ppitch, cnt, nq, k, out_scores, out_indices, st)) return rc;
   }
   return check_launch("esr_retrieve_topk");
