@@ -184,6 +184,7 @@ def run_retrieve(args, emit):
     c = torch.randn((n_local, D), generator=g, device=dev) * D ** -0.5
     # auto: the f32-grade fp16 x 2 planes (asked for by name); f32: the exact split (three bf16 planes); else one plane
     mode = {"auto": "f16x2", "f16x2": "f16x2", "f32": "exact", "bf16x3": "bf16x3"}.get(args.precision, "bf16")
+    mode = os.environ.get("ESR_BENCH_RETRIEVE_MODE", mode)   # (e.g. f16r: the one-term filter + f32 re-score)
 
     def step():
         if world == 1:

@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void prepsplit2h_kernel(RowSrc X0, RowSrc X1, 
                                                          unsigned long long* __restrict__ loss_acc,
                                                          int* __restrict__ flags, int nflags,
                                                          float* __restrict__ copy0, float* __restrict__ copy1,
-                                                         float* __restrict__ qmax, unsigned* __restrict__ czero) {
+                                                         unsigned* __restrict__ czero) {
   // copy0 / copy1 (optional): the gathered rows as dense f32 [B, ld] matrices.  The overlapped train step updates a tower
   // while the merge launch of the OTHER side still needs that tower's old rows: the merges then read these copies
   __shared__ float red[8];
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void prepsplit2h_kernel(RowSrc X0, RowSrc X1, 
   }
   if (chunk == 1 || nchunks == 1)
     for (int i = t; i < nflags; i += 256) flags[i] = 0;
-  // czero: the per-copy maxima and flags of the scaled-Q copies (fac2h_kernel, scaleq2h_kernel), 16 words
+  // czero: the pass-Q splits' flags of pass C's form (facscale2h_kernel), 16 words
   if (czero && chunk == 0 && t < 16) czero[t] = 0u;
   const int row = t >> 3, d0 = (t & 7) * 16;
   const int64_t grow = (int64_t)chunk * 32 + row;
@@ -418,12 +418,6 @@ __global__ __launch_bounds__(256) void prepsplit2h_kernel(RowSrc X0, RowSrc X1, 
   ssq += __shfl_xor(ssq, 1, 64); ssq += __shfl_xor(ssq, 2, 64); ssq += __shfl_xor(ssq, 4, 64);
   ssc += __shfl_xor(ssc, 1, 64); ssc += __shfl_xor(ssc, 2, 64); ssc += __shfl_xor(ssc, 4, 64);
   if ((t & 7) == 0) diag[grow] = dot;
-  if (qmax) {  // largest |element| of the Q row (fac2h_kernel: the scaled copies' exponents)
-    float rq = fmaxf(mq, __shfl_xor(mq, 1, 64));
-    rq = fmaxf(rq, __shfl_xor(rq, 2, 64));
-    rq = fmaxf(rq, __shfl_xor(rq, 4, 64));
-    if ((t & 7) == 0) qmax[grow] = rq;
-  }
 #pragma unroll
   for (int o = 8; o < 64; o <<= 1) {
     ssq = fmaxf(ssq, __shfl_xor(ssq, o, 64));
@@ -887,7 +881,7 @@ __global__ ESR_NO_PK __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2
   // first two.  (Until round 6 every split took its own first chunk: as robust, but the splits' references differed and
   // with them the factor a probability needs in pass C.  With one reference per row the factor is per row, and pass C
   // streams ONE scaled copy of Q: inbatch2h_pct_kernel.  A workgroup that redoes itself still gets its own reference:
-  // fac2h_kernel / scaleq2h_kernel flag that split.)
+  // facscale2h_kernel flags that split.)
   const bool sample = !fix && mode == 1 && c0 != 0;
   if (sample) {
     char* sbuf = lds + 2 * kHBufBytes;
@@ -1479,9 +1473,8 @@ __global__ ESR_NO_PK __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2
 // into two fp16 planes again -- 16 ds_read_b32, 16 multiplies and 48 conversion instructions per chunk and wave beside
 // 24 MFMAs, matrix pipes 33 % busy.  Now the factor sits on the OTHER operand:
 //     dC_j = sum_i P'_ij (f_{i,s} q_i)
-// scaleq2h_kernel leaves one scaled copy of Q per pass-Q split, x' = f_{.,s} q 2^E_s in two fp16 planes (E_s from the
-// copy's largest |element|), a workgroup's 256 owned rows lie in ONE pass-Q split (host: nc_q % 8 == 0, else the general
-// form below), and the stored planes of P' ARE the MFMA's B operand:
+// with one reference per row for all pass-Q splits (inbatch2h_q_kernel) f_{i,s} = f_i, facscale2h_kernel leaves ONE scaled
+// copy of Q, x' = (f_i q_i) 2^(eq - 11) in two fp16 planes, and the stored planes of P' ARE the MFMA's B operand:
 //   * the P' tile of (this wave's 32 owned rows, chunk) -- wave-private, 4 KB -- comes by LDS-DMA into a 3-slot ring of the
 //     wave's own as four contiguous 1 KB blocks (plane, m') in pass Q's piece order (with every lane fetching the piece
 //     that makes the LDS image a plain row-major matrix -- 16-byte pieces 512 B apart from neighbouring lanes -- the pass
@@ -1493,13 +1486,13 @@ __global__ ESR_NO_PK __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2
 //     tiles (96 KB per CU) in flight or waiting, which is what keeps the 268 MB stream at the HBM rate;
 //   * tile column n holds owned row pi(n) = n with bits 2 and 3 swapped (the order pass Q's accumulators hold them in):
 //     the output tile is stored with its rows permuted.
-// The partial O' rows are rescaled to the unit the merges expect (2^(eq + 14) sum p q) by one exact power of two per
-// workgroup (cexp).
+// The partial O' rows are rescaled to the unit the merges expect (2^(eq + 14) sum p q) by one exact power of two (cexp =
+// 2^11).
 // GENERAL form (GEN, chosen per workgroup at run time): streams the UNSCALED planes of Q and applies the factors to the
 // B fragments in registers (hi + lo is exact in f32; multiply, split again -- the arithmetic of the round-5 kernel).  Taken
-// when the geometry does not give a workgroup one split (small batches), and when scaleq2h_kernel raised the copy's flag:
-// a live row of the copy lies more than ~17 binades under the copy's largest element, where its second plane would fall
-// into fp16's subnormals (rows with very different normalisers in one batch).
+// for a pass-Q split that facscale2h_kernel flagged: a pass-Q workgroup of it redid itself (its rows carry their own
+// reference), or a live row of the copy lies more than ~17 binades under the largest possible element, where its second
+// plane would fall into fp16's subnormals (a normaliser beyond ~2^20).
 // -----------------------------------------------------------------------------------------------------------------
 #if defined(CT_PROBE_P_DUMMY)  /* timing probe only (values wrong): no P' stream, every tile request hits the cache */
 #define CT_PROBE_DUMMY 1
@@ -1563,7 +1556,7 @@ __device__ __forceinline__ f16x8 ct_pfrag(uint32_t pbase) {
 
 __global__ ESR_NO_PK __launch_bounds__(512) void inbatch2h_pct_kernel(
     const _Float16* __restrict__ Yt, const _Float16* __restrict__ Yh, int64_t B, int nsplit,
-    const float* __restrict__ fac, int nc_q, const char* __restrict__ Pt, const float* __restrict__ cexp,
+    const float* __restrict__ fac, int nc_q, const char* __restrict__ Pt, float cexp,
     const int* __restrict__ cflags, int force_general, float* __restrict__ part_O) {
   constexpr int kLdsBytes = kCtLds > 8 * kTileLdsBytes ? kCtLds : 8 * kTileLdsBytes;
   __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];  // the rings; at the end the waves' output tiles
@@ -1800,7 +1793,7 @@ __global__ ESR_NO_PK __launch_bounds__(512) void inbatch2h_pct_kernel(
     sweep(std::true_type{});
   } else {
     sweep(std::false_type{});
-    const float ce = cexp[0];  // exact power of two: the copy's exponent against the planes' common one
+    const float ce = cexp;  // exact power of two: the copy's exponent against the planes' common one
 #pragma unroll
     for (int db = 0; db < 4; ++db)
 #pragma unroll
@@ -1819,25 +1812,17 @@ __global__ ESR_NO_PK __launch_bounds__(512) void inbatch2h_pct_kernel(
 __global__ __launch_bounds__(256) void fac2h_kernel(int64_t B, int nsplit, const float* __restrict__ part_m,
                                                    const float* __restrict__ part_l, float invl_scale,
                                                    float* __restrict__ fac, float* __restrict__ lse2 = nullptr,
-                                                   float* __restrict__ lse_nat = nullptr,
-                                                   const float* __restrict__ qmax = nullptr,
-                                                   float* __restrict__ fac_row = nullptr,
-                                                   unsigned* __restrict__ cmax = nullptr) {
+                                                   float* __restrict__ lse_nat = nullptr) {
   // lse2 / lse_nat (the merging update's form of the step: no merge<Q> launch): the row's log-sum-exp in binary and
-  // natural units, as merge<Q> leaves them
-  // qmax / fac_row / cmax (round 6, pass C's scaled copy of Q): fac_row[i] = invl_scale / l_i -- the factor of every split
-  // that used the row's reference (weight 1: all of them unless a pass-Q workgroup redid itself) -- and
-  // cmax[0] = bits of max_i fac_row[i] max_d |q_id|, the largest |element| of the copy scaleq2h_kernel writes (rounding is
-  // monotone: the largest product is the product of the largest |q_id|); one atomic per workgroup on a word
-  // prepsplit2h_kernel zeroed (non-negative floats order like their bits)
-  __shared__ unsigned red[4];
+  // natural units, as merge<Q> leaves them.  (Launched only when pass C takes the general form everywhere --
+  // ESR_IB2H_PC=general --, else facscale2h_kernel does this and the scaled copy of Q in one launch.)
   const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const bool in = row < B;
+  if (row >= B) return;
   float pm[8], pl[8];
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     pm[s] = -INFINITY; pl[s] = 0.f;
-    if (in && s < nsplit) {
+    if (s < nsplit) {
       pm[s] = part_m[(int64_t)s * B + row];
       pl[s] = part_l[(int64_t)s * B + row];
     }
@@ -1852,49 +1837,42 @@ __global__ __launch_bounds__(256) void fac2h_kernel(int64_t B, int nsplit, const
     L = __fmaf_rn(pl[s], wt[s], L);  // (explicit, as in merge_row: the two must round alike)
   }
   const float invL1 = __fdiv_rn(1.0f, L);
-  const float f1 = __fmul_rn(invL1, invl_scale);
 #pragma unroll
   for (int s = 0; s < 8; ++s)
-    if (in && s < nsplit) fac[(int64_t)s * B + row] = __fmul_rn(f1, wt[s]);
-  if (in && lse2) {
+    if (s < nsplit) fac[(int64_t)s * B + row] = __fmul_rn(__fmul_rn(invL1, invl_scale), wt[s]);
+  if (lse2) {
     const float l2v = __fadd_rn(M, __builtin_amdgcn_logf(L));
     lse2[row] = l2v;
     if (lse_nat) lse_nat[row] = l2v * k3Ln2;
   }
-  if (cmax) {
-    float cm = 0.f;
-    if (in) {
-      fac_row[row] = f1;
-      cm = __fmul_rn(fabsf(f1), qmax[row]);
-    }
-    // (a NaN product -- a row without a finite normaliser -- must reach the word: fmaxf would drop it)
-    unsigned u = cm == cm ? __float_as_uint(cm) : 0x7fc00000u;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, o, 64));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = u;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      u = max(max(red[0], red[1]), max(red[2], red[3]));
-      if (u) atomicMax(cmax, u);
-    }
-  }
 }
 
-// The scaled copy of Q for inbatch2h_pct_kernel (round 6): two fp16 planes of x' = (f_i q_i) 2^E, f_i = fac_row[i], E from
-// the copy's largest |element| (cmax[0], fac2h_kernel): max |x'| in [2^13, 2^14).  One 256-thread block per 32-row chunk.
-// cexp[0] = 2^(eq - E): what brings pass C's partial rows to the unit the merges undo (sc[2]).
-// cflags[s] != 0: pass C's workgroups on pass-Q split s must take the general form, because
-//   * some row's factor for split s is not fac_row (a pass-Q workgroup of that split redid itself against its own
-//     maximum: its probabilities carry another reference), or
-//   * (every split) some row with a non-zero factor has its largest |x'| under 2^-4 -- more than 17 binades under the
-//     copy's largest element: its second plane would lose bits to fp16's subnormals.
-__global__ __launch_bounds__(256) void scaleq2h_kernel(RowSrc X, int64_t B, int nsplit, const float* __restrict__ fac,
-                                                      const float* __restrict__ fac_row,
-                                                      const unsigned* __restrict__ cmax, const float* __restrict__ sc,
-                                                      _Float16* __restrict__ Yt, float* __restrict__ cexp,
-                                                      int* __restrict__ cflags) {
+// Factors AND the scaled copy of Q for inbatch2h_pct_kernel in one launch (round 6).  One 256-thread block per 32-row
+// chunk, eight lanes per row:
+//   * lane s of a row reads split s's reference and normaliser, the eight pairs are passed round by shuffles and every
+//     lane runs fac2h_kernel's arithmetic (same operations, same order: the factors, lse and the merges' normalisers agree
+//     bit for bit): fac[s][i] = f_i w_s, f_i = 2^14 / l_i ;
+//   * x' = (f_i q_i) 2^E in two fp16 planes (Yt) with the FIXED exponent E = eq - 11, eq the exponent of Q's own planes
+//     (2^eq max |q| in [2^13, 2^14)): the optimistic reference puts the row's best candidate at p' = 16, so l_i >= 16 (1 -
+//     2^-10) and f_i <= 2^10 (1 + 2^-9) -- max |x'| < 2^13.01, no overflow whatever the batch holds, and no grid-wide
+//     maximum to wait for (the first form of this step took the copy's exponent from its largest element: a second
+//     launch behind an atomic maximum, 5 us).  Pass C's partial rows are 2^(E + 14) sum p q: one multiplication by 2^11
+//     brings them to the unit the merges undo;
+//   * cflags[s] != 0: pass C's workgroups on pass-Q split s must take the general form, because
+//       - some row's factor for split s is not f_i (a pass-Q workgroup of that split redid itself against its own
+//         maximum: its probabilities carry another reference), or
+//       - (every split) some row with a non-zero factor has its largest |x'| under 2^-4 -- more than 17 binades under the
+//         largest possible element: its second plane would lose bits to fp16's subnormals (a row whose normaliser is
+//         beyond ~2^20: the reference's 33 samples all lie 2^16 under the bulk of its scores).
+constexpr int kCtExpShift = 11;
+__global__ __launch_bounds__(256) void facscale2h_kernel(RowSrc X, int64_t B, int nsplit,
+                                                        const float* __restrict__ part_m,
+                                                        const float* __restrict__ part_l, float invl_scale,
+                                                        const float* __restrict__ sc, float* __restrict__ fac,
+                                                        float* __restrict__ lse2, float* __restrict__ lse_nat,
+                                                        _Float16* __restrict__ Yt, int* __restrict__ cflags) {
   const int t = threadIdx.x, chunk = blockIdx.x;
-  const int row = t >> 3, d0 = (t & 7) * 16;
+  const int row = t >> 3, sl = t & 7, d0 = sl * 16;
   const int64_t grow = (int64_t)chunk * 32 + row;
   float v[16];
   {
@@ -1907,16 +1885,45 @@ __global__ __launch_bounds__(256) void scaleq2h_kernel(RowSrc X, int64_t B, int 
       v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
     }
   }
-  const float f = fac_row[grow];
-  if ((t & 7) < nsplit && fac[(int64_t)(t & 7) * B + grow] != f) cflags[t & 7] = 1;  // (NaN factors flag themselves)
-  const int E = scale_exp(__uint_as_float(cmax[0]));
-  if (chunk == 0 && t == 0) cexp[0] = sc[3] * ldexpf(1.f, -E);
-  const float mul = ldexpf(1.f, E);
+  const float pm_l = sl < nsplit ? part_m[(int64_t)sl * B + grow] : -INFINITY;
+  const float pl_l = sl < nsplit ? part_l[(int64_t)sl * B + grow] : 0.f;
+  float pm[8], pl[8];
+  const int lane0 = (t & 63) & ~7;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    pm[s] = __shfl(pm_l, lane0 + s, 64);
+    pl[s] = __shfl(pl_l, lane0 + s, 64);
+  }
+  float M = pm[0], L = 0.f;
+  float wt[8];
+#pragma unroll
+  for (int s = 1; s < 8; ++s) M = fmaxf(M, pm[s]);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    wt[s] = pm[s] == M ? 1.f : __builtin_amdgcn_exp2f(pm[s] - M);
+    L = __fmaf_rn(pl[s], wt[s], L);  // (explicit, as in merge_row and fac2h_kernel: they must round alike)
+  }
+  const float invL1 = __fdiv_rn(1.0f, L);
+  const float f1 = __fmul_rn(invL1, invl_scale);
+  float wmine = 1.f;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) wmine = s == sl ? wt[s] : wmine;
+  const float fs = __fmul_rn(f1, wmine);
+  if (sl < nsplit) {
+    fac[(int64_t)sl * B + grow] = fs;
+    if (fs != f1) cflags[sl] = 1;  // (a NaN factor flags itself)
+  }
+  if (sl == 0 && lse2) {
+    const float l2v = __fadd_rn(M, __builtin_amdgcn_logf(L));
+    lse2[grow] = l2v;
+    if (lse_nat) lse_nat[grow] = l2v * k3Ln2;
+  }
+  const float mul = sc[3] * ldexpf(1.f, -kCtExpShift);  // 2^(eq - 11)
   float m = 0.f;
   f16x8 p[2][2];
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
-    const float xs = __fmul_rn(v[e], f) * mul;  // (the scaling is exact: a power of two)
+    const float xs = __fmul_rn(v[e], f1) * mul;  // (the scaling is exact: a power of two)
     m = fmaxf(m, fabsf(xs));
     const _Float16 a = (_Float16)xs;
     const _Float16 b = (_Float16)(xs - (float)a);
@@ -1926,12 +1933,12 @@ __global__ __launch_bounds__(256) void scaleq2h_kernel(RowSrc X, int64_t B, int 
   m = fmaxf(m, __shfl_xor(m, 1, 64));
   m = fmaxf(m, __shfl_xor(m, 2, 64));
   m = fmaxf(m, __shfl_xor(m, 4, 64));
-  if (f != 0.f && m < kCtLive && (t & 7) < nsplit) cflags[t & 7] = 1;
+  if (sl < nsplit && (!(m < 60000.f) || (f1 != 0.f && m < kCtLive))) cflags[sl] = 1;
 #pragma unroll
-  for (int pl = 0; pl < 2; ++pl) {
-    f16x8* dst = reinterpret_cast<f16x8*>(Yt + ((int64_t)pl * B + grow) * k3D + d0);
-    dst[0] = p[pl][0];
-    dst[1] = p[pl][1];
+  for (int pl2 = 0; pl2 < 2; ++pl2) {
+    f16x8* dst = reinterpret_cast<f16x8*>(Yt + ((int64_t)pl2 * B + grow) * k3D + d0);
+    dst[0] = p[pl2][0];
+    dst[1] = p[pl2][1];
   }
 }
 
@@ -1941,10 +1948,9 @@ struct InbatchHWs {
   int* flags;
   unsigned long long* loss_acc;
   unsigned long long* ent;  // prepsplit2h_kernel's tagged per-chunk maxima
-  _Float16* Qt;             // the scaled copy of Q (scaleq2h_kernel): [2][B][128]
-  float *qmax, *fac_row, *cexp;  // largest |element| per Q row; the rows' factors; 2^(eq - E) of the copy
-  unsigned* cmax;           // 16 words zeroed by prepsplit2h_kernel: [0] the copy's largest |element| (float bits),
-  int* cflags;              // [8, 16) the pass-Q splits' flags
+  _Float16* Qt;             // the scaled copy of Q (facscale2h_kernel): [2][B][128]
+  unsigned* czero;          // 16 words zeroed by prepsplit2h_kernel, of which
+  int* cflags;              // [8, 16) the pass-Q splits' flags of pass C's form
 };
 constexpr int64_t kHMaxB = 16384;  // B x B x 4 bytes of stored probabilities: 1 GiB
 
@@ -1978,11 +1984,8 @@ static size_t inbatch2h_ws_layout(int64_t B, char* base, InbatchHWs* ws) {
   w.sc = (float*)take(kHScaleWords * sizeof(float));
   w.ent = (unsigned long long*)take((size_t)(B / k3Chunk) * sizeof(unsigned long long));
   w.Qt = (_Float16*)take(planes);
-  w.qmax = (float*)take((size_t)B * 4);
-  w.fac_row = (float*)take((size_t)B * 4);
-  w.cexp = (float*)take(8 * sizeof(float));
-  w.cmax = (unsigned*)take(16 * sizeof(unsigned));
-  w.cflags = reinterpret_cast<int*>(w.cmax ? w.cmax + 8 : nullptr);
+  w.czero = (unsigned*)take(16 * sizeof(unsigned));
+  w.cflags = reinterpret_cast<int*>(w.czero ? w.czero + 8 : nullptr);
   if (ws) *ws = w;
   return off;
 }
@@ -2148,7 +2151,7 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
     ESR_KT("prepsplit2h_kernel", st,
            hipLaunchKernelGGL(prepsplit2h_kernel, dim3(nchunks), dim3(256), 0, st, Qs, Cs, B, ws.Qh, ws.Ch, ws.ent, token,
                               ws.diag, ws.nrm, ws.sc, ws.loss_acc, ws.flags, grid_q, (overlapped || merge_upd) ? ws.Qcopy : (float*)nullptr,
-                              (overlapped || merge_upd) ? ws.Ccopy : (float*)nullptr, ws.qmax, ws.cmax));
+                              (overlapped || merge_upd) ? ws.Ccopy : (float*)nullptr, ws.czero));
     if (one_plane) {
       // bf16 tables: one fp16 plane per operand, S^T recomputed by pass C -- six GEMMs, no stored probabilities.
       // 512-thread workgroups of 256 owned rows, one per CU
@@ -2238,7 +2241,7 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
   // the rows the merges read: the towers themselves, or (overlapped) their gathered copies
   const RowSrc Qm = overlapped ? RowSrc{ws.Qcopy, nullptr, 0, Qs.ld} : Qs;
   const RowSrc Cm = overlapped ? RowSrc{ws.Ccopy, nullptr, 0, Cs.ld} : Cs;
-  // Pass C's form (round 6): the scaled copy of Q (fac2h_kernel -> scaleq2h_kernel); with ESR_IB2H_PC=general (the test
+  // Pass C's form (round 6): the scaled copy of Q (facscale2h_kernel); with ESR_IB2H_PC=general (the test
   // hook) and on the unfused path every workgroup takes the general form (unscaled planes, factors applied to the B
   // fragments in registers).
   const int nc_q = nchunks / nsplit_q;
@@ -2250,19 +2253,18 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
       return ESR_ELAUNCH;
     }
   }
-  if (overlapped || merge_upd || !force_general)
+  if (!force_general)
+    ESR_KT("facscale2h_kernel", st,
+           hipLaunchKernelGGL(facscale2h_kernel, dim3(nchunks), dim3(256), 0, st,
+                              (overlapped || merge_upd) ? RowSrc{ws.Qcopy, nullptr, 0, Qs.ld} : Qs, B, nsplit_q,
+                              (const float*)ws.part_m, (const float*)ws.part_l, ldexpf(1.f, (int)kHPexp),
+                              (const float*)ws.sc, ws.fac, merge_upd ? ws.lse2 : (float*)nullptr,
+                              merge_upd ? lse : (float*)nullptr, ws.Qt, ws.cflags));
+  else if (overlapped || merge_upd)
     ESR_KT("fac2h_kernel", st,
            hipLaunchKernelGGL(fac2h_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, B, nsplit_q,
                               (const float*)ws.part_m, (const float*)ws.part_l, ldexpf(1.f, (int)kHPexp), ws.fac,
-                              merge_upd ? ws.lse2 : (float*)nullptr, merge_upd ? lse : (float*)nullptr,
-                              force_general ? (const float*)nullptr : (const float*)ws.qmax,
-                              force_general ? (float*)nullptr : ws.fac_row, force_general ? (unsigned*)nullptr : ws.cmax));
-  if (!force_general)
-    ESR_KT("scaleq2h_kernel", st,
-           hipLaunchKernelGGL(scaleq2h_kernel, dim3(nchunks), dim3(256), 0, st,
-                              (overlapped || merge_upd) ? RowSrc{ws.Qcopy, nullptr, 0, Qs.ld} : Qs, B, nsplit_q,
-                              (const float*)ws.fac, (const float*)ws.fac_row, (const unsigned*)ws.cmax,
-                              (const float*)ws.sc, ws.Qt, ws.cexp, ws.cflags));
+                              merge_upd ? ws.lse2 : (float*)nullptr, merge_upd ? lse : (float*)nullptr));
   if (!merge_upd)
   ESR_KT("inbatch3_merge_kernel_q", st_q,
          hipLaunchKernelGGL((inbatch3_merge_kernel<true>), dim3(mgrid), dim3(kBlock), 0, st_q, Qm, Cm, gq_rows, B, nsplit_q,
@@ -2284,7 +2286,7 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
   ESR_KT("inbatch2h_pct_kernel", st,
          hipLaunchKernelGGL(inbatch2h_pct_kernel, dim3(grid_c), dim3(512), 0, st, (const _Float16*)ws.Qt,
                             (const _Float16*)ws.Qh, B, nsplit_c, (const float*)ws.fac, nc_q, (const char*)ws.Pmat,
-                            (const float*)ws.cexp, (const int*)ws.cflags, force_general, part_O_c));
+                            ldexpf(1.f, kCtExpShift), (const int*)ws.cflags, force_general, part_O_c));
   if (merge_upd) return merging_update(nsplit_c, part_O_c);
   // O_C' = 2^(eq + 14) sum_i (p_ij / l_i) q_i
   ESR_KT("inbatch3_merge_kernel_c", st,

@@ -1,7 +1,7 @@
-# same-box A/B of the whole in-batch train step: round 5's kernels (scripts/libib2h_R5.so) against this tree's, alternating
+# same-box A/B of the whole in-batch train step: other builds of the library (scripts/libib2h_*.so) against this tree's
 mkdir -p gpurun_out
 for r in 1 2; do
-for lib in scripts/libib2h_R5.so esrecsys_amd/libesr_hip.so; do
+for lib in ${AB_LIBS:-scripts/libib2h_R5.so esrecsys_amd/libesr_hip.so}; do
   ESR_HIP_LIB=$PWD/$lib timeout 600 python bench.py --steps 200 --warmup 20 --no-secondary --no-cpu-baseline --no-kernel-timing 2>gpurun_out/r6_ab.err | grep '^{"metric"' | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('$lib', round(d['ms_per_step'],5), round(d['value']/1e6,2))"
 done
