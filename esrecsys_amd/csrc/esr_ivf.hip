@@ -258,12 +258,13 @@ static size_t ivf_layout(const IvfGeom& g, int64_t cq, int nprobe, int nlist, ch
 // ---- index build (esrecsys_amd/ivf.py; round 5: torch.bincount / searchsorted / norm there are gone) --------------------------
 // list_off[v] = first position of the ascending `sorted` [n] whose value is >= v, v = 0 .. nvalues (list_off[nvalues] = n);
 // max_len[0] = the longest run.  One thread per position fills the offsets of the values between its predecessor's and
-// its own.
+// its own.  Values are expected in [0, nvalues); one outside is counted with the nearest list (both ends clamped, so no
+// offset outside off[0 .. nvalues] is written and off[nvalues] has ONE writer, the p == n thread).
 __global__ __launch_bounds__(kBlock) void run_offsets_kernel(const int32_t* __restrict__ sorted, int64_t n, int nvalues,
                                                             int32_t* __restrict__ off, int32_t* __restrict__ max_len) {
   for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p <= n; p += (int64_t)gridDim.x * kBlock) {
-    const int32_t prev = p == 0 ? -1 : min(sorted[p - 1], nvalues - 1);
-    const int32_t cur = p == n ? nvalues : min(max(sorted[p], 0), nvalues);
+    const int32_t prev = p == 0 ? -1 : min(max(sorted[p - 1], 0), nvalues - 1);
+    const int32_t cur = p == n ? nvalues : min(max(sorted[p], 0), nvalues - 1);
     for (int32_t v = prev + 1; v <= cur; ++v) off[v] = (int32_t)p;
   }
 }

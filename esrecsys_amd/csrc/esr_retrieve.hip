@@ -1139,8 +1139,10 @@ static void launch_gemm(const __bf16* A, int64_t a_plane, const __bf16* B, int64
 // recall of an approximate top-k against the exact one, O(ka + ke) per query: one workgroup per query puts the approximate
 // ids into an open-addressing table in LDS and probes it with the exact ids; the hits of all queries are added to ONE
 // 64-bit word (integer: order-free).  (The torch form -- an [Q, ka, ke] boolean cube -- was 2 GB at 8192 x 500 x 500.)
-constexpr int kRecallMaxK = 8192;
-__global__ __launch_bounds__(256) void recall_at_k_kernel(const int32_t* __restrict__ approx, int ka,
+// Lists longer than kRecallChunk go through the table a chunk per launch (32 KB of LDS at most: fits any workgroup
+// limit); the ids of one approximate list are distinct (a top-k result), so no exact id is counted in two chunks.
+constexpr int kRecallChunk = 4096;
+__global__ __launch_bounds__(256) void recall_at_k_kernel(const int32_t* __restrict__ approx, int lda, int ka,
                                                          const int32_t* __restrict__ exact, int ke, int cap,
                                                          unsigned long long* __restrict__ hits) {
   extern __shared__ int32_t tab[];  // cap slots, cap = a power of two >= 2 ka; empty = INT32_MIN
@@ -1150,7 +1152,7 @@ __global__ __launch_bounds__(256) void recall_at_k_kernel(const int32_t* __restr
   if (threadIdx.x == 0) s_hits = 0;
   __syncthreads();
   for (int i = threadIdx.x; i < ka; i += 256) {
-    const int32_t v = approx[q * ka + i];
+    const int32_t v = approx[q * lda + i];
     if (v == INT32_MIN) continue;
     unsigned h = ((unsigned)v * 2654435761u) & (unsigned)(cap - 1);
     for (;;) {
@@ -1381,16 +1383,18 @@ int esr_topk_merge(const float* scores, const int32_t* indices, int64_t nq, int 
 int esr_recall_at_k(const int32_t* approx, int64_t nq, int ka, const int32_t* exact, int ke, unsigned long long* hits,
                     esr_stream_t stream) {
   TraceScope trace_scope_("esr_recall_at_k");
-  ESR_REQUIRE(nq >= 0 && ka > 0 && ke > 0 && ka <= kRecallMaxK, "esr_recall_at_k: bad sizes nq=%lld ka=%d ke=%d (ka <= %d)",
-              (long long)nq, ka, ke, kRecallMaxK);
+  ESR_REQUIRE(nq >= 0 && ka > 0 && ke > 0, "esr_recall_at_k: bad sizes nq=%lld ka=%d ke=%d", (long long)nq, ka, ke);
   ESR_REQUIRE(hits && (nq == 0 || (approx && exact)), "esr_recall_at_k: null pointer");
   hipStream_t st = as_stream(stream);
   if (hipMemsetAsync(hits, 0, sizeof(unsigned long long), st) != hipSuccess) return check_launch("esr_recall_at_k");
   if (nq == 0) return ESR_OK;
-  int cap = 64;
-  while (cap < 2 * ka) cap <<= 1;
-  hipLaunchKernelGGL(recall_at_k_kernel, dim3((unsigned)nq), dim3(256), (size_t)cap * sizeof(int32_t), st, approx, ka, exact,
-                     ke, cap, hits);
+  for (int a0 = 0; a0 < ka; a0 += kRecallChunk) {
+    const int len = std::min(kRecallChunk, ka - a0);
+    int cap = 64;
+    while (cap < 2 * len) cap <<= 1;
+    hipLaunchKernelGGL(recall_at_k_kernel, dim3((unsigned)nq), dim3(256), (size_t)cap * sizeof(int32_t), st, approx + a0, ka,
+                       len, exact, ke, cap, hits);
+  }
   return check_launch("esr_recall_at_k");
 }
 

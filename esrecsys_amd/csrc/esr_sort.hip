@@ -1351,7 +1351,8 @@ size_t esr_score_topk_workspace_bytes(int64_t nq, int64_t N, int k) {
 int esr_score_topk(const float* queries, const float* candidates, int64_t nq, int64_t N, int D, int k,
                    float* out_scores, int32_t* out_indices, void* workspace, size_t workspace_bytes,
                    esr_stream_t stream) {
-  ESR_REQUIRE(nq > 0 && N > 0 && D > 0 && k > 0 && k <= N && N <= kSortMaxN,
+  // (the 2^30 bound belongs to the sort: the select path, k <= kSelectMaxK, takes any 32-bit row length)
+  ESR_REQUIRE(nq > 0 && N > 0 && D > 0 && k > 0 && k <= N && N < ((int64_t)1 << 31) && (k <= kSelectMaxK || N <= kSortMaxN),
               "esr_score_topk: bad sizes nq=%lld N=%lld D=%d k=%d", (long long)nq, (long long)N, D, k);
   ESR_REQUIRE(queries && candidates && out_scores && out_indices && workspace, "esr_score_topk: null pointer");
   const RowGeom g = row_geom(D);

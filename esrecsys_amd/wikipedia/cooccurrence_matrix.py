@@ -112,8 +112,8 @@ class CooccurrenceMatrix:
     """The whole co-occurrence file as a sparse matrix in host memory -- the reference's debug consumer
     (wikipedia/cooccurrence_matrix.py:18-55): ``CooccurrenceMatrix(input_file)`` loads, ``debug_print(max_rows,
     token_dictionary, num_terms)`` prints, per token, its num_terms heaviest partners.  Rows are kept as the reference
-    keeps them (one list of (other_index, count) per row index, in file order; repeated row indices append), decoded by
-    the C line decoder instead of protobuf."""
+    keeps them (one list of (other_index, count) per row index, in file order; repeated row indices append; a row without
+    pairs keeps its empty list), decoded by parse_cooccurrence_row instead of protobuf."""
 
     def __init__(self, input_file):
         self.load(input_file)
@@ -122,16 +122,17 @@ class CooccurrenceMatrix:
         self._matrix = {}
 
     def load(self, input_file):
-        """Loads a co-occurrence file (``*.cooccur.pb.b64.bz2``: one base64 CooccurrenceRow per line)."""
+        """Loads a co-occurrence file (``*.cooccur.pb.b64.bz2``: one base64 CooccurrenceRow per line), line by line as the
+        reference does (cooccurrence_matrix.py:38-52): EVERY row registers its index, also one without pairs (the block
+        decoder yields pairs only, so it cannot stand in here), and the file is never held in memory whole."""
+        import base64
         import bz2
         self._reset()
         with bz2.open(input_file, "rb") as f:
-            text = f.read()
-        if text and not text.endswith(b"\n"):
-            text += b"\n"
-        t1, t2, cnt, _ = decode_lines(text)
-        for i, j, c in zip(t1.tolist(), t2.tolist(), cnt.tolist()):
-            self._matrix.setdefault(i, []).append((j, c))
+            for line in f:
+                index, others, counts = parse_cooccurrence_row(base64.b64decode(line.rstrip(b"\n")))
+                row = self._matrix.setdefault(index, [])
+                row.extend(zip(others, counts))
 
     def rows(self):
         """{row index: [(other index, count), ...]} -- what the reference holds in its private ``__matrix``."""

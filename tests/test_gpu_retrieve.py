@@ -248,3 +248,19 @@ def test_retrieve_f16r_equals_exact_mode_indices_at_c5_shape(dev):
     assert rel_err(N(s1), N(s0)) <= 2e-6
     same = np.mean([len(set(a) & set(b)) / float(k) for a, b in zip(N(i0), N(i1))])
     assert same >= 0.9999, same     # (a candidate within an f32 rounding of the cut may swap with its neighbour)
+
+
+@pytest.mark.gpu
+def test_recall_at_k_long_lists_in_chunks(dev):
+    """esr_recall_at_k with approximate lists longer than one LDS table (4096 ids a launch): hit counts against NumPy sets,
+    the -2^31 padding sentinel ignored"""
+    from esrecsys_amd import ops
+    rng = np.random.default_rng(77)
+    for nq, ka, ke in ((3, 10_000, 700), (2, 4097, 4096), (5, 4096, 9000), (4, 17, 5)):
+        a = np.stack([rng.permutation(40_000)[:ka] for _ in range(nq)]).astype(np.int32)
+        e = np.stack([rng.permutation(40_000)[:ke] for _ in range(nq)]).astype(np.int32)
+        a[0, -3:] = -2 ** 31
+        e[-1, :2] = -2 ** 31
+        want = sum(len((set(a[q].tolist()) & set(e[q].tolist())) - {-2 ** 31}) for q in range(nq)) / e.size
+        got = ops.recall_at_k(torch.from_numpy(a).to(dev), torch.from_numpy(e).to(dev))
+        assert abs(got - want) < 1e-12

@@ -408,6 +408,12 @@ def test_ivf_build_kernels_run_offsets_and_centroids(dev):
         want = np.searchsorted(a, np.arange(nv + 1), side="left").astype(np.int32)
         assert np.array_equal(off.cpu().numpy(), want)
         assert int(mx) == int(np.diff(want).max())
+    # values outside [0, nvalues) are counted with the nearest list -- nothing is written outside off[0 .. nvalues]
+    a = np.array([-7, -1, 0, 2, 2, 5, 9, 12], np.int32)
+    guard = torch.full((5 + 1 + 64,), -99, dtype=torch.int32, device=dev)
+    off, _ = ops.run_offsets(torch.from_numpy(a).to(dev), 5, want_max=True)
+    assert off.cpu().tolist() == np.searchsorted(np.clip(a, 0, 4), np.arange(6), side="left").tolist()
+    assert off.cpu().tolist()[-1] == len(a) and bool((guard == -99).all())
     nlist, D, nt = 300, 64, 1000
     sums = rng.standard_normal((nlist, D)).astype(np.float32) * 5
     train = rng.standard_normal((nt, D)).astype(np.float32)

@@ -38,7 +38,11 @@ def test_cooccurrence_matrix_debug_consumer(capsys):
     want = {}
     for i, j, c in zip(idx.tolist(), oth.tolist(), cnt.tolist()):
         want.setdefault(i, []).append((j, c))
-    assert m.rows() == want
+    # the fixture's generator also writes rows without pairs: the reference keeps their keys (with empty lists)
+    assert {k: v for k, v in m.rows().items() if v} == want
+    empties = [k for k, v in m.rows().items() if not v]
+    assert len(empties) == 2 and all(k not in want for k in empties)
+    want = dict(m.rows())
 
     class Names:
         def get_token_from_embedding_index(self, k):
@@ -52,6 +56,23 @@ def test_cooccurrence_matrix_debug_consumer(capsys):
         for j, c in sorted(want[k], key=lambda x: x[1], reverse=True)[:2]:
             exp.append(" tok%d : %f" % (j, c))
     assert lines == exp
+
+
+def test_cooccurrence_matrix_keeps_rows_without_pairs(tmp_path):
+    """a CooccurrenceRow with no other_index entries still creates its key (cooccurrence_matrix.py:49-50), rows that
+    repeat an index append, a last line without a newline is a line"""
+    import base64
+    import bz2
+    from esrecsys_amd.wikipedia.cooccurrence_matrix import CooccurrenceMatrix
+    rows = [bytes.fromhex("08ac021206018001f0a2041a0c0000003f0000a03f00004040"),   # 300: three pairs
+            bytes.fromhex("0807"),                                                   # 7: none
+            bytes.fromhex("08ac02" "1005" "1d00000040")]                             # 300 again: (5, 2.0)
+    path = tmp_path / "m.cooccur.pb.b64.bz2"
+    with bz2.open(path, "wb") as f:
+        f.write(b"\n".join(base64.b64encode(r) for r in rows))
+    m = CooccurrenceMatrix(str(path))
+    assert m.rows() == {300: [(1, 0.5), (128, 1.25), (70000, 3.0), (5, 2.0)], 7: []}
+    assert list(m.rows()) == [300, 7]
 
 
 def test_known_wire_bytes():
