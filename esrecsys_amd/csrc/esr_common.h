@@ -176,6 +176,11 @@ __device__ __forceinline__ uint32_t xor_lane(uint32_t v, int stride) {
     default: return (uint32_t)__shfl_xor((int)v, stride, 64);
   }
 }
+// NOTE on "explicit" roundings: hipcc's __fmul_rn / __fadd_rn / __fsub_rn are plain `*` / `+` / `-` (the rounded OCML
+// forms sit behind OCML_BASIC_ROUNDED_OPERATIONS) and the default -ffp-contract=fast-honor-pragmas may fuse such a
+// product into a following sum; only __fmaf_rn (= __builtin_fmaf) is what it says.  Two kernels that must agree bit for bit
+// therefore have to present the SAME expression to the compiler -- or cut it where one of them goes through memory
+// (asm volatile("" : "+v"(x)) on the finished value: esr_optim.hip inbatch_merge_update_kernel).
 // Sum across the G (power of two) lanes of a row group, butterfly from stride 1 up; every lane gets the total.
 __device__ __forceinline__ float group_sum(float v, int G) {
   if (G > 1) v += __uint_as_float(xor_lane(__float_as_uint(v), 1));

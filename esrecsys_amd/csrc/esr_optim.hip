@@ -741,7 +741,11 @@ __global__ __launch_bounds__(kBlock) void inbatch_merge_update_kernel(FusedTable
       if (q == p) {
         g = t;
       } else {
-        g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+        // t is a FINISHED gradient row (what merge<Q / C> stores and segment_update_kernel reads back): its last
+        // operation, the multiplication by 1 / batch_size, must not be contracted into this addition
+        float4 tt = t;
+        asm volatile("" : "+v"(tt.x), "+v"(tt.y), "+v"(tt.z), "+v"(tt.w));
+        g.x += tt.x; g.y += tt.y; g.z += tt.z; g.w += tt.w;
       }
       if (lig == 0) acc_loss += loss_fixed(row_loss, bad);
       if (q + 1 == stop && q + 1 < n && sorted_ids[q + 1] == vid) bad = true;  // the run outgrew its head chunk

@@ -10,7 +10,7 @@ dev = torch.device("cuda", 0)
 rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
 N_ = int(os.environ.get("CASES", "40"))
 bad = 0
-TOL = {"exact": 2e-6, "f32": 2e-6, "f16x2": 2e-6, "bf16x3": 2e-6, "bf16": 2e-2}
+TOL = {"exact": 2e-6, "f32": 2e-6, "f16x2": 2e-6, "f16r": 2e-6, "bf16x3": 2e-6, "bf16": 2e-2}
 for case in range(N_):
     nq = int(rng.choice([1, 37, 255, 256, 257, 1000]))
     N = int(rng.choice([1, 127, 128, 129, 8000, 8001, 40000, 70001, 200000]))
@@ -29,7 +29,7 @@ for case in range(N_):
     scale = max(np.abs(full).max(), np.linalg.norm(q.astype(np.float64), axis=1).max() *
                 np.linalg.norm(c.astype(np.float64), axis=1).max() / np.sqrt(D))
     base, step = int(rng.integers(0, 100)), int(rng.choice([1, 2, 8]))
-    for mode in ("exact", "f16x2", "bf16x3", "bf16"):
+    for mode in ("exact", "f16x2", "f16r", "bf16x3", "bf16"):
         s, i = ops.retrieve_topk(torch.from_numpy(q).to(dev), torch.from_numpy(c).to(dev), k, mode=mode, index_base=base, index_step=step)
         gs, gi = s.cpu().numpy().astype(np.float64), i.cpu().numpy().astype(np.int64)
         rows = (gi - base) // step

@@ -227,14 +227,18 @@ def test_planned_batch_refuses_another_state(dev):
 
 @pytest.mark.parametrize("B,D,ids,dt", [(1024, 128, "uniform", "f32"), (2048, 128, "hot", "f32"), (512, 64, "hot", "f32"),
                                         (8192, 128, "uniform", "f32"), (1024, 128, "hot", "bf16"), (1024, 128, "uniform", "bf16"),
-                                        (16384, 128, "uniform", "f32"), (384, 128, "uniform", "bf16")])
+                                        (16384, 128, "uniform", "f32"), (384, 128, "uniform", "bf16"),
+                                        (384, 128, "uniform", "f32"), (640, 128, "uniform", "f32"), (640, 64, "hot", "f32")])
 def test_inbatch_one_call_step_equals_fwd_bwd_plus_update(dev, monkeypatch, B, D, ids, dt):
     """The in-batch step as ONE library call (esr_inbatch_train_step_f16x2) -- with merge<Q> and the scene tower's
     Adagrad on a second stream beside pass C, and without the second stream -- against rounds 1-4's
     esr_inbatch_towers_fwd_bwd_f16x2 + esr_sparse_adagrad_scatter_multi: same kernels on the same values, so losses, towers
     and accumulators are bit-identical; through train_step alone (sort inside the call) and through train_steps (lists of
     eight batches sorted ahead, long-run hints).  "hot": 40 % of the ids are three rows (runs of hundreds: the update's
-    long-run launch on each half of the occurrence list)."""
+    long-run launch on each half of the occurrence list).  B = 384 / 640 with f32 towers: the sizes at which the loop takes
+    the merging update and the single step does not -- rows that occur twice in a batch came out one ulp apart until the
+    merging update stopped the compiler from contracting a gradient row's last multiplication into the run sum
+    (scripts/fuzz_loops.py, seed 717)."""
     import esrecsys_amd.pinterest.train_shop_the_look as stl
     from esrecsys_amd import TrainState, optim
     from esrecsys_amd.pinterest.models import STLModel
