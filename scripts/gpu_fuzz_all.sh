@@ -1,6 +1,6 @@
 # every fuzzer once with the seed given (SEED=n bash scripts/gpu_fuzz_all.sh): a few minutes on one GPU
 S=${SEED:-101}
-for f in "fuzz_ops.py 80" "fuzz_loops.py 45" "fuzz_steps.py 60" "fuzz_routing.py 100" "fuzz_retrieve.py 30" "fuzz_towers.py 60" "fuzz_optim.py 60" "fuzz_ivf.py 20" "inbatch_stress.py 100"; do
+for f in "fuzz_ops.py 80" "fuzz_loops.py 45" "fuzz_steps.py 60" "fuzz_routing.py 100" "fuzz_retrieve.py 30" "fuzz_towers.py 60" "fuzz_optim.py 60" "fuzz_bf16_steps.py 50" "fuzz_ivf.py 20" "inbatch_stress.py 100"; do
   set -- $f
   echo "$1: $(SEED=$S CASES=$2 timeout 900 python scripts/$1 2>&1 | grep -E "MISMATCH|BEYOND|cases|Error|error|fault" | tail -3)"
 done
