@@ -52,6 +52,11 @@ for case in range(N_):
             p -= lr * (mu / (1 - 0.9 ** step)) / (np.sqrt(nu / (1 - 0.999 ** step)) + 1e-8)
     got = state.params["t"]["embedding"].float().cpu().numpy().astype(np.float64)
     tol = 2e-2 if bf16 else (2e-5 if kind != "adam" else 1e-4)
+    if kind == "adam" and steps == 1:
+        # Adam's first step is lr * g / (|g| + 1e-8): where a row's gradients cancel to |G| < 1e-6 the f32 sum's last bits
+        # decide the step (seed 919: 1.2e-4 of the table's scale on one such element) -- those elements are not compared
+        keep = np.abs(G) >= 1e-6
+        got, p = np.where(keep, got, 0.0), np.where(keep, p, 0.0)
     e = rel(got, p)
     ok = np.isfinite(e) and e <= tol
     if os.environ.get("VERBOSE") == "1" or not ok:
