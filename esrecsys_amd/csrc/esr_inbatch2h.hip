@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void prepsplit2h_kernel(RowSrc X0, RowSrc X1, 
                                                          unsigned long long* __restrict__ loss_acc,
                                                          int* __restrict__ flags, int nflags,
                                                          float* __restrict__ copy0, float* __restrict__ copy1,
-                                                         unsigned* __restrict__ czero) {
+                                                         unsigned* __restrict__ czero, int two_level) {
   // copy0 / copy1 (optional): the gathered rows as dense f32 [B, ld] matrices.  The overlapped train step updates a tower
   // while the merge launch of the OTHER side still needs that tower's old rows: the merges then read these copies
   __shared__ float red[8];
@@ -443,7 +443,11 @@ __global__ __launch_bounds__(256) void prepsplit2h_kernel(RowSrc X0, RowSrc X1, 
   unsigned cq = 0u, cc = 0u;
   bool timed_out = false;
   const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-  for (int i = t; i < nchunks; i += 256) {
+  // Two levels (round 6): workgroup 0 gathers the chunks' words -- one poller per word -- and publishes the two maxima in
+  // ONE more tagged word, which is all the other workgroups poll (one lane each).  With every workgroup polling every
+  // word, 65 536 agent-scope requests a round queued on 32 lines at the memory side: the poll was 5 of the kernel's 16 us.
+  const bool gatherer = chunk == 0 || !two_level;
+  for (int i = gatherer ? t : (t == 0 ? nchunks : nchunks + 1); i < (gatherer ? nchunks : nchunks + 1); i += 256) {
     unsigned long long v;
     while (((v = __hip_atomic_load(&ent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 16) != token) {
       if (__builtin_amdgcn_s_memrealtime() - t_start > kPollTicks) { timed_out = true; break; }
@@ -462,6 +466,9 @@ __global__ __launch_bounds__(256) void prepsplit2h_kernel(RowSrc X0, RowSrc X1, 
   __syncthreads();
   cq = max(max(cred[0], cred[1]), max(cred[2], cred[3]));
   cc = max(max(cred[4], cred[5]), max(cred[6], cred[7]));
+  if (two_level && chunk == 0 && t == 0)
+    __hip_atomic_store(&ent[nchunks], (token << 16) | (unsigned long long)(cq << 8 | cc), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
   const int eq = scale_exp_code(cq), ec = scale_exp_code(cc);
   if (chunk == 0 && t == 0) {
     sc[0] = ldexpf(1.f, -(eq + ec));
@@ -1982,7 +1989,7 @@ static size_t inbatch2h_ws_layout(int64_t B, char* base, InbatchHWs* ws) {
   w.nrm = (float*)take((size_t)2 * (B / k3Chunk) * 4 * sizeof(float));
   w.amax = (float*)take((size_t)2 * (B / k3Chunk) * sizeof(float));
   w.sc = (float*)take(kHScaleWords * sizeof(float));
-  w.ent = (unsigned long long*)take((size_t)(B / k3Chunk) * sizeof(unsigned long long));
+  w.ent = (unsigned long long*)take((size_t)(B / k3Chunk + 1) * sizeof(unsigned long long));  // (+ the maxima's word)
   w.Qt = (_Float16*)take(planes);
   w.czero = (unsigned*)take(16 * sizeof(unsigned));
   w.cflags = reinterpret_cast<int*>(w.czero ? w.czero + 8 : nullptr);
@@ -2136,7 +2143,7 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
     a.B = B;
     a.scale = scale; a.lam = regularization; a.inv_bs = inv_bs;
     a.loss_acc = ws.loss_acc; a.loss_scale = 1.0 / (double)batch_size; a.loss_out = loss;
-    a.zero_words = ws.ent; a.nzero = nchunks;
+    a.zero_words = ws.ent; a.nzero = nchunks + 1;
     return inbatch_merge_update(upd->tables, upd->accums, upd->row_offsets, upd->dtype, upd->sorted_vids, upd->perm, a,
                                 upd->lr, upd->eps, st);
   };
@@ -2148,10 +2155,12 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     const unsigned long long token = ((z ^ (z >> 31)) >> 16) | 1ull;  // 48 bits, never 0
+    const char* tle = getenv("ESR_IB2H_POLL");  // "flat": every workgroup polls every chunk's word (rounds 4 - 5)
+    const int two_level = (tle && tle[0] == 'f') ? 0 : 1;
     ESR_KT("prepsplit2h_kernel", st,
            hipLaunchKernelGGL(prepsplit2h_kernel, dim3(nchunks), dim3(256), 0, st, Qs, Cs, B, ws.Qh, ws.Ch, ws.ent, token,
                               ws.diag, ws.nrm, ws.sc, ws.loss_acc, ws.flags, grid_q, (overlapped || merge_upd) ? ws.Qcopy : (float*)nullptr,
-                              (overlapped || merge_upd) ? ws.Ccopy : (float*)nullptr, ws.czero));
+                              (overlapped || merge_upd) ? ws.Ccopy : (float*)nullptr, ws.czero, two_level));
     if (one_plane) {
       // bf16 tables: one fp16 plane per operand, S^T recomputed by pass C -- six GEMMs, no stored probabilities.
       // 512-thread workgroups of 256 owned rows, one per CU
@@ -2197,7 +2206,7 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
                                 nsplit_q, (const float*)ws.part_O, (const float*)ws.part_m, (const float*)ws.part_l, scale,
                                 regularization, inv_bs, ws.lse2, (float*)nullptr, gC, ws.loss_acc,
                                 1.0 / (double)batch_size, loss, (float*)nullptr, (const float*)(ws.sc + 2), 1.0f,
-                                (float*)nullptr, ws.ent, nchunks));
+                                (float*)nullptr, ws.ent, nchunks + 1));
       if (upd) {
         const int rc = sparse_adagrad_range(upd->tables, upd->accums, upd->row_offsets, 2, upd->dtype, D, upd->sorted_vids,
                                             upd->perm, 2 * B, upd->grad_rows, upd->lr, upd->eps, upd->skip_long, st);
@@ -2294,7 +2303,7 @@ static int inbatch2h_run(const char* who, RowSrc Qs, RowSrc Cs, const int32_t* g
                             (const float*)part_O_c, (const float*)ws.part_m, (const float*)ws.part_l, scale,
                             regularization, inv_bs, ws.lse2, (float*)nullptr, gC, ws.loss_acc,
                             1.0 / (double)batch_size, loss, (float*)nullptr, (const float*)(ws.sc + 2), 1.0f,
-                            (float*)nullptr, fused ? ws.ent : (unsigned long long*)nullptr, nchunks));
+                            (float*)nullptr, fused ? ws.ent : (unsigned long long*)nullptr, nchunks + 1));
   if (upd) {
     // the candidate tower's rows: positions [B, 2B) (sequential form: the whole list, one launch for both towers)
     const int64_t off = overlapped ? B : 0;
