@@ -46,6 +46,8 @@ for case in range(N):
         Vs, Vp = int(rng.choice([5, 300, 5000, 60000])), int(rng.choice([9, 700, 7000, 90000]))
         D = int(rng.choice([4, 8, 20, 32, 64, 100, 128, 256]))
         B = int(rng.choice([1, 16, 31, 33, 128, 683, 2048, 8192, 11000]))
+        if 8 * min(Vs, Vp) <= B:  # rows that take many occurrences a step: a self-amplifying trajectory -- two steps at most
+            steps = min(steps, 2)
         lam, lr, norm = 0.1, 0.2, float(max(1, B // 128))
         g = torch.Generator(device=dev).manual_seed(case)
         st = (torch.randn((Vs, D), generator=g, device=dev) * (2.0 / np.sqrt(D))).to(torch.bfloat16)
@@ -82,6 +84,8 @@ for case in range(N):
         B = int(rng.choice([1, 31, 32, 33, 64, 777, 1000, 2048, 2049, 4096, 16384, 16385, 40000]))
         mode = str(rng.choice(["reference", "diagonal"]))
         lr = float(rng.choice([0.5, 4.0])) if kind != "same" else 0.5
+        if 8 * V <= 2 * B:  # (as above)
+            steps, lr = min(steps, 2), 0.5
         model = Glove(num_embeddings=V, features=D, loss_mode=mode, device=dev)
         params = model.init(case + 11, None)["params"]
         g = torch.Generator(device=dev).manual_seed(case)
