@@ -993,9 +993,17 @@ static RetrievePlan retrieve_plan(int64_t nq, int64_t N, int D, int k, int mode)
   p.first = std::min<int64_t>(N, std::max<int64_t>(kFirstChunk, 16 * (int64_t)k));
   // later chunks: the per-query append list must hold a whole chunk (worst case every candidate passes tau);
   // keep the list buffer around 2 GiB and the 32-bit DMA offsets inside one plane set
-  int64_t chunk = ((int64_t)1 << 28) / std::max<int64_t>(nq, 1);
+  // (mode 3's one-plane GEMM is short enough for the per-chunk ends -- a GEMM tail, a split and two select launches --
+  // to show: with 65 536-row chunks (a 4.4 GB list buffer at 8192 queries) the call is 14.22 against 14.47 ms; 131 072
+  // is slower again, the filter's threshold being a chunk old: 14.85.  The three-term modes lose with larger chunks.
+  // ESR_RETRIEVE_LIST_LOG2 / ESR_RETRIEVE_CHUNK_CAP: measuring hooks.)
+  const char* lb = getenv("ESR_RETRIEVE_LIST_LOG2");
+  const int list_log2 = lb ? std::min(31, std::max(20, atoi(lb))) : (mode == 3 ? 29 : 28);
+  int64_t chunk = ((int64_t)1 << list_log2) / std::max<int64_t>(nq, 1);
   chunk = std::min<int64_t>(chunk, ((int64_t)1 << 30) / ((int64_t)p.Dp * 2 * plane_count(p.P)));
-  chunk = std::max<int64_t>(kGN, std::min<int64_t>(65536, chunk / kGN * kGN));
+  const char* cc = getenv("ESR_RETRIEVE_CHUNK_CAP");  // (measuring hook)
+  const int64_t chunk_cap = cc ? std::max<int64_t>(kGN, atoll(cc)) : 65536;
+  chunk = std::max<int64_t>(kGN, std::min<int64_t>(chunk_cap, chunk / kGN * kGN));
   p.chunk = chunk;
   p.chunk_pad = std::max(cdiv(p.chunk, kGN) * kGN, cdiv(p.first, kGN) * kGN);
   // Lazy compaction (round 4): between chunks a query's list is selected down to its k best -- and its tau raised --
