@@ -586,13 +586,37 @@ def summarize_leg(leg):
     return out
 
 
+def _free_port():
+    """A TCP port for a rendezvous that starts a few seconds from now.  Drawn OUTSIDE the kernel's ephemeral range: a
+    port handed out by bind(("", 0)) comes from that range and can be given to somebody's outgoing connection before rank
+    0 listens on it (EADDRINUSE once in ~500 spawns of the fuzzers -- seen in scripts/fuzz_sharded_gloo.py)."""
+    import random
+    import socket
+    lo, hi = 20000, 32000
+    try:
+        with open("/proc/sys/net/ipv4/ip_local_port_range") as f:
+            hi = max(lo + 1000, min(hi, int(f.read().split()[0]) - 1))
+    except (OSError, ValueError, IndexError):
+        pass
+    rnd = random.SystemRandom()  # (never the seeded global generator of a test)
+    for _ in range(64):
+        p = rnd.randrange(lo, hi)
+        with socket.socket() as s:
+            try:
+                s.bind(("127.0.0.1", p))
+                return p
+            except OSError:
+                continue
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: re-exec this command line under torch.distributed.run, one rank
     per GPU on 127.0.0.1 (the container hostname may not resolve).  exec keeps stdout: rank 0's JSON line is ours."""
     import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = _free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]

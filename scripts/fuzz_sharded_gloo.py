@@ -19,6 +19,32 @@ WIRE = os.environ.get("WIRE") == "1"
 TOL = 1e-5 if WIRE else 1e-11
 
 
+def _free_port():
+    """A TCP port for a rendezvous that starts a few seconds from now.  Drawn OUTSIDE the kernel's ephemeral range: a
+    port handed out by bind(("", 0)) comes from that range and can be given to somebody's outgoing connection before rank
+    0 listens on it (EADDRINUSE once in ~500 spawns of the fuzzers -- seen in scripts/fuzz_sharded_gloo.py)."""
+    import random
+    import socket
+    lo, hi = 20000, 32000
+    try:
+        with open("/proc/sys/net/ipv4/ip_local_port_range") as f:
+            hi = max(lo + 1000, min(hi, int(f.read().split()[0]) - 1))
+    except (OSError, ValueError, IndexError):
+        pass
+    rnd = random.SystemRandom()  # (never the seeded global generator of a test)
+    for _ in range(64):
+        p = rnd.randrange(lo, hi)
+        with socket.socket() as s:
+            try:
+                s.bind(("127.0.0.1", p))
+                return p
+            except OSError:
+                continue
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def setup(rank, W, port, cfg):
     """(kernels module, numpy -> tensor on the device under test, tensor -> numpy)"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ESR_SHARDED_UNIQUE="1" if cfg["unique"] else "0")
@@ -151,9 +177,7 @@ def glove_batches(cfg, rank):
 def run_glove(cfg):
     from oracle import glove as o_glove
     from oracle import optim as o_optim
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = _free_port()
     W, V, D = cfg["world"], cfg["Vs"], cfg["D"]
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(glove_worker, args=(port, d, cfg), nprocs=W, join=True)
@@ -184,9 +208,7 @@ def run_case(cfg):
         return run_glove(cfg)
     from oracle import optim as o_optim
     from oracle import stl_head as o_stl
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = _free_port()
     W = cfg["world"]
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(worker, args=(port, d, cfg), nprocs=W, join=True)

@@ -14,6 +14,32 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def free_port():
+    """A TCP port for a rendezvous that starts a few seconds from now.  Drawn OUTSIDE the kernel's ephemeral range: a
+    port handed out by bind(("", 0)) comes from that range and can be given to somebody's outgoing connection before rank
+    0 listens on it (EADDRINUSE once in ~500 spawns of the fuzzers -- a 4 % flake per run of this suite)."""
+    import random
+    import socket
+    lo, hi = 20000, 32000
+    try:
+        with open("/proc/sys/net/ipv4/ip_local_port_range") as f:
+            hi = max(lo + 1000, min(hi, int(f.read().split()[0]) - 1))
+    except (OSError, ValueError, IndexError):
+        pass
+    rnd = random.SystemRandom()  # (never the seeded global generator of a test)
+    for _ in range(64):
+        p = rnd.randrange(lo, hi)
+        with socket.socket() as s:
+            try:
+                s.bind(("127.0.0.1", p))
+                return p
+            except OSError:
+                continue
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def load_golden(name):
     with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
         return {k: z[k] for k in z.files}

@@ -22,6 +22,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import free_port  # noqa: E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -161,9 +163,7 @@ def world2_outputs(request):
             mod = importlib.util.module_from_spec(spec)
             spec.loader.exec_module(mod)
             wire_lib = mod.build()
-        with socket.socket() as s:
-            s.bind(("127.0.0.1", 0))
-            port = s.getsockname()[1]
+        port = free_port()
         with tempfile.TemporaryDirectory() as d:
             mp.spawn(_worker, args=(port, d, transport, wire_lib), nprocs=WORLD, join=True)
             _OUTPUTS[transport] = [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(WORLD)]

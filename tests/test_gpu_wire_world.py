@@ -24,6 +24,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import free_port
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -209,9 +211,7 @@ def _spawn(worker, world):
     spec.loader.exec_module(mod)
     wire_lib = mod.build()
     import torch.multiprocessing as mp
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = free_port()
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(worker, args=(port, d, wire_lib), nprocs=world, join=True)
         return [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(world)]
@@ -370,9 +370,7 @@ def _spawn_c4(grad_dtype):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     import torch.multiprocessing as mp
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = free_port()
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_config4_worker, args=(port, d, mod.build(), grad_dtype), nprocs=C4_WORLD, join=True)
         return [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(C4_WORLD)]
@@ -459,9 +457,7 @@ def test_bench_gpus_n_command_dry_run(n, workload, overlap):
     spec = importlib.util.spec_from_file_location("build_wire", os.path.join(ROOT, "tests", "wire", "build_wire.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = free_port()
     env = dict(os.environ, ESR_WIRE_ONE_GPU="1", ESR_RCCL_LIB=mod.build(), ESR_SHARDED_OVERLAP=overlap,
                HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
     args = ["--batch", "16384"] if workload == "glove" else []  # (the C3 batch works too; this keeps the test short)

@@ -8,6 +8,8 @@ import tempfile
 import numpy as np
 import pytest
 import torch
+
+from conftest import free_port  # noqa: E402
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
@@ -59,9 +61,7 @@ def _worker(rank, port, outdir, workload):
 
 def _run(workload):
     import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = free_port()
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(port, d, workload), nprocs=WORLD, join=True)
         return [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(WORLD)]
@@ -139,9 +139,7 @@ def test_replicated_glove_equals_single_device_and_replicas_agree():
     import socket
     from oracle import glove as o_glove
     from oracle import optim as o_optim
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = free_port()
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_glove_worker, args=(port, d), nprocs=WORLD, join=True)
         outs = [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(WORLD)]

@@ -8,6 +8,8 @@ import tempfile
 import numpy as np
 import pytest
 import torch
+
+from conftest import free_port  # noqa: E402
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
@@ -100,9 +102,7 @@ def _run(workload, grouped=False, unique=None, zipf=False, sort_limit=None):
     import socket
     global ZIPF
     ZIPF = zipf  # (the checking side draws the same batches)
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = free_port()
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(port, d, workload, grouped, unique, zipf, sort_limit), nprocs=WORLD, join=True)
         outs = [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(WORLD)]
@@ -234,9 +234,7 @@ def test_sharded_glove_with_prefetched_plans_equals_single_device(unique):
     import socket
     from oracle import glove as o_glove
     from oracle import optim as o_optim
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = free_port()
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_glove_worker, args=(port, d, unique), nprocs=WORLD, join=True)
         outs = [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(WORLD)]
@@ -285,9 +283,7 @@ def test_sharded_top_k_equals_single_device():
     over the full candidate set, including the tie rule (lower GLOBAL index first) across shards."""
     import socket
     from oracle import topk as o_topk
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = free_port()
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_topk_worker, args=(port, d), nprocs=WORLD, join=True)
         outs = [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(WORLD)]
@@ -337,9 +333,7 @@ def test_loop_helper_equals_per_step_calls_and_bf16_gradient_exchange_error():
     (config 4's budget) every gradient element is rounded to 8 significant bits after the per-distinct-row sum:
     the tables stay within 2^-7 of the f32 exchange's update over these steps -- and do differ (the option is live)."""
     import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = free_port()
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_helper_worker, args=(port, d), nprocs=WORLD, join=True)
         outs = [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(WORLD)]
@@ -426,9 +420,7 @@ def _overlap_worker(rank, port, outdir):
 @pytest.mark.timeout(600)
 def test_overlapped_lookups_equal_the_sequential_loop_bit_for_bit():
     import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = free_port()
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_overlap_worker, args=(port, d), nprocs=WORLD, join=True)
         outs = [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(WORLD)]
