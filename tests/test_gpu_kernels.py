@@ -696,6 +696,30 @@ def test_inbatch_f16x2_pass_c_forms_agree(dev, B, monkeypatch):
         assert rel_err(N(a), N(b)) <= 2e-6
 
 
+@pytest.mark.parametrize("B", [128, 384, 8192, 16384])
+def test_inbatch_exponent_poll_two_levels_equals_flat(dev, B, monkeypatch):
+    """prepsplit2h_kernel learns the two matrix maxima from tagged per-chunk words: workgroup 0 gathers them and the others
+    poll ONE word (round 6), or every workgroup polls every word (ESR_IB2H_POLL=flat, rounds 4 - 5).  Same maxima, so
+    every output is bit-identical -- at 4, 12, 256 and 512 chunks (two words per gathering thread), repeated calls on one
+    workspace (the words are cleared for the next call)."""
+    from esrecsys_amd import ops
+    g = torch.Generator(device=dev).manual_seed(B + 1)
+    D = 128
+    q = torch.randn((B, D), generator=g, device=dev) * 0.3
+    c = torch.randn((B, D), generator=g, device=dev) * 0.05
+    c[B // 2] *= 40.0   # the candidates' maximum sits in one chunk in the middle of the grid
+    outs = {}
+    for form in ("two", "flat", "two"):
+        monkeypatch.setenv("ESR_IB2H_POLL", form)
+        for rep in range(2):
+            cur = [t.clone() for t in ops.inbatch_softmax_fwd_bwd(q, c, 4.0, 0.1, float(B), precision="f16x2")]
+            assert all(bool(torch.isfinite(t).all()) for t in cur)
+            if outs:
+                assert all(torch.equal(a, b) for a, b in zip(outs["first"], cur)), (form, rep)
+            outs.setdefault("first", cur)
+    monkeypatch.delenv("ESR_IB2H_POLL", raising=False)
+
+
 @pytest.mark.parametrize("B", [2048, 8192])
 def test_inbatch_f16x2_pass_c_redone_split_vs_oracle(dev, B):
     """A pass-Q workgroup that overflows its optimistic reference redoes itself against the exact maximum of ITS range:
