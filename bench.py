@@ -1010,6 +1010,8 @@ def secondary_legs(args, dev, rank):
                                                                    with_cpu=not args.no_cpu_baseline, with_ann=False))
     guarded("retrieve_c5_n1m_k500_f16r", lambda: measure_retrieve(dev, n_local=1_048_576, steps=3, warmup=1, mode="f16r",
                                                                   with_cpu=False, with_ann=False))
+    guarded("retrieve_c5_n1m_k500_f16r_prepared", lambda: measure_retrieve(dev, n_local=1_048_576, steps=3, warmup=1, mode="f16r",
+                                                                           with_cpu=False, with_ann=False, prepared=True))
     guarded("retrieve_c5_n1m_k500_f16x2", lambda: measure_retrieve(dev, n_local=1_048_576, steps=3, warmup=1, mode="f16x2",
                                                                    with_cpu=False, with_ann=False))
 
@@ -1259,7 +1261,8 @@ def main():
                  "triplet_c2_b8192_reference_loss": "triplet_c2_b8192", "triplet_c2_b262144_saturating": "triplet_c2_b262144",
                  "triplet_c2_b262144_bf16": "triplet_c2_b262144_bf16", "glove_c3_b65536_bf16": "glove_c3_b65536_bf16",
                  "retrieve_c5_n1m_k500_f16x2": "retrieve_c5_f16x2", "retrieve_c5_n1m_k500_exact": "retrieve_c5_exact",
-                 "retrieve_c5_n1m_k500_f16r": "retrieve_c5_f16r"}
+                 "retrieve_c5_n1m_k500_f16r": "retrieve_c5_f16r",
+                 "retrieve_c5_n1m_k500_f16r_prepared": "retrieve_c5_f16r_prepared"}
         for name, key in short.items():
             v = out["secondary"].get(name)
             if isinstance(v, dict) and "value" in v:

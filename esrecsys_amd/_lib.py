@@ -134,6 +134,10 @@ SIGNATURES = {
     "esr_retrieve_workspace_bytes": (c_size, [c_i64, c_i64, c_int, c_int, c_int]),
     "esr_retrieve_topk": (c_int, [c_f32p, c_f32p, c_i64, c_i64, c_int, c_int, c_int, ctypes.c_int32, ctypes.c_int32,
                                   c_f32p, c_i32p, c_vp, c_size, c_vp]),
+    "esr_retrieve_prepared_bytes": (c_size, [c_i64, c_int, c_int]),
+    "esr_retrieve_prepare": (c_int, [c_f32p, c_i64, c_int, c_int, c_vp, c_size, c_vp]),
+    "esr_retrieve_topk_prepared": (c_int, [c_f32p, c_f32p, c_vp, c_i64, c_i64, c_int, c_int, c_int, ctypes.c_int32,
+                                           ctypes.c_int32, c_f32p, c_i32p, c_vp, c_size, c_vp]),
     "esr_rescore_candidates": (c_int, [c_f32p, c_f32p, c_i64, c_i64, c_int, c_i32p, c_int, ctypes.c_int32,
                                        ctypes.c_int32, c_f32p, c_vp]),
     "esr_topk_merge": (c_int, [c_f32p, c_i32p, c_i64, c_int, c_int, c_f32p, c_i32p, c_vp]),

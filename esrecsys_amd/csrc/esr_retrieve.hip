@@ -1135,12 +1135,13 @@ static void launch_absmax(const float* X, int64_t n, float* slots, int* exp_out,
 
 template <int P, bool DENSE>
 static void launch_gemm(const __bf16* A, int64_t a_plane, const __bf16* B, int64_t b_plane, int Dp, int64_t Mp,
-                        int64_t n_pad, int M, int nvalid, const GemmOut& o, hipStream_t st) {
-  // planes are k-block-major over Mp query rows / n_pad candidate rows (this chunk's padded row count)
+                        int64_t n_pad, int M, int nvalid, const GemmOut& o, hipStream_t st, int64_t b_rows = 0) {
+  // planes are k-block-major over Mp query rows / b_rows candidate rows (default: this chunk's padded row count n_pad;
+  // a prepared corpus: ALL its rows, B pointing at the chunk's first row -- esr_retrieve_prepare)
   const int tm = (int)(Mp / kGM), tn = (int)(n_pad / kGN);
   const int per = (tm * tn + 7) / 8;
-  ESR_KT("score_gemm_kernel", st, hipLaunchKernelGGL((score_gemm_kernel<P, DENSE>), dim3(per * 8), dim3(kGThreads), 0, st, A, a_plane, Mp, B, b_plane, n_pad,
-                     Dp, tm, tn, M, nvalid, o));
+  ESR_KT("score_gemm_kernel", st, hipLaunchKernelGGL((score_gemm_kernel<P, DENSE>), dim3(per * 8), dim3(kGThreads), 0, st, A, a_plane, Mp, B, b_plane,
+                     b_rows ? b_rows : n_pad, Dp, tm, tn, M, nvalid, o));
 }
 
 
@@ -1193,15 +1194,56 @@ using namespace esr;
 
 extern "C" {
 
+// ---- a prepared corpus (mode 3): what a call does with the candidates before it looks at a query, done once -----------
+// [0, 256): header words -- [0] the candidates' exponent code (int), [1] their largest row norm (float), [2..3] N,
+// [4] D; [256, 256 + 2 * kAbsBlocks * 4): the statistics pass's slots; then ONE scaled fp16 plane, k-block-major over
+// ALL rows (rows_pad = N rounded up to the tile + one tile: a chunk's last tile may start anywhere).
+static int64_t prepared_rows_pad(int64_t N) { return cdiv(N, kGN) * kGN + kGN; }
+static size_t prepared_planes_off() { return align_up(256 + 2 * (size_t)kAbsBlocks * sizeof(float), 256); }
+size_t esr_retrieve_prepared_bytes(int64_t N, int D, int mode) {
+  if (N <= 0 || D <= 0 || mode != 3) return 0;
+  const int64_t Dp = cdiv(D, kGK) * kGK;
+  return prepared_planes_off() + align_up((size_t)prepared_rows_pad(N) * Dp * 2, 256);
+}
+
+int esr_retrieve_prepare(const float* candidates, int64_t N, int D, int mode, void* prepared, size_t prepared_bytes,
+                         esr_stream_t stream) {
+  TraceScope trace_scope_("esr_retrieve_prepare");
+  ESR_REQUIRE(mode == 3, "esr_retrieve_prepare: mode %d (only ESR_RETRIEVE_F16R = 3 takes a prepared corpus)", mode);
+  ESR_REQUIRE(N > 0 && D > 0 && N < ((int64_t)1 << 31) && D <= kSelLdsWords, "esr_retrieve_prepare: bad sizes N=%lld D=%d",
+              (long long)N, D);
+  ESR_REQUIRE(candidates && prepared && !((uintptr_t)prepared & 255), "esr_retrieve_prepare: null or misaligned pointer");
+  const int Dp = (int)(cdiv(D, kGK) * kGK);
+  const int64_t rows_pad = prepared_rows_pad(N);
+  ESR_REQUIRE((int64_t)Dp / kGK * rows_pad * 32 < ((int64_t)1 << 32),
+              "esr_retrieve_prepare: N=%lld x D=%d exceeds the 32-bit tile offsets of one plane (4 GiB)", (long long)N, D);
+  if (prepared_bytes < esr_retrieve_prepared_bytes(N, D, mode)) {
+    set_error("esr_retrieve_prepare: buffer %zu bytes < %zu required", prepared_bytes, esr_retrieve_prepared_bytes(N, D, mode));
+    return ESR_EWORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  char* base = (char*)prepared;
+  int* hdr = (int*)base;
+  float* abs_slots = (float*)(base + 256);
+  float* nrm_slots = abs_slots + kAbsBlocks;
+  const int grid = (int)std::min<int64_t>(kAbsBlocks, std::max<int64_t>(1, cdiv(N, kBlock / 64)));
+  hipLaunchKernelGGL(rowstat_kernel, dim3(grid), dim3(kBlock), 0, st, candidates, N, D, (float*)nullptr, abs_slots, nrm_slots);
+  hipLaunchKernelGGL(absmax_exp_kernel, dim3(1), dim3(kBlock), 0, st, (const float*)abs_slots, grid, hdr);
+  hipLaunchKernelGGL(slots_max_kernel, dim3(1), dim3(kBlock), 0, st, (const float*)nrm_slots, grid, (float*)(hdr + 1));
+  const int64_t meta[2] = {N, (int64_t)D};
+  if (hipMemcpyAsync(hdr + 2, meta, sizeof(meta), hipMemcpyHostToDevice, st) != hipSuccess) return check_launch("esr_retrieve_prepare");
+  launch_split<4>(candidates, N, D, rows_pad, Dp, rows_pad * Dp, (__bf16*)(base + prepared_planes_off()), st, hdr);
+  return check_launch("esr_retrieve_prepare");
+}
+
 size_t esr_retrieve_workspace_bytes(int64_t nq, int64_t N, int D, int k, int mode) {
   if (nq <= 0 || N <= 0 || D <= 0 || k <= 0) return 256;
   return retrieve_plan(nq, N, D, k, mode).total;
 }
 
-int esr_retrieve_topk(const float* queries, const float* candidates, int64_t nq, int64_t N, int D, int k, int mode,
-                      int32_t index_base, int32_t index_step, float* out_scores, int32_t* out_indices, void* workspace,
-                      size_t workspace_bytes, esr_stream_t stream) {
-  TraceScope trace_scope_("esr_retrieve_topk");
+static int retrieve_topk_impl(const float* queries, const float* candidates, const char* prepared, int64_t nq, int64_t N,
+                              int D, int k, int mode, int32_t index_base, int32_t index_step, float* out_scores,
+                              int32_t* out_indices, void* workspace, size_t workspace_bytes, esr_stream_t stream) {
   ESR_REQUIRE(nq > 0 && N > 0 && D > 0 && k > 0 && k <= N && k <= kSelMaxK && N < ((int64_t)1 << 31) &&
                   nq < ((int64_t)1 << 24),
               "esr_retrieve_topk: bad sizes nq=%lld N=%lld D=%d k=%d (k <= min(N, %d))", (long long)nq, (long long)N, D,
@@ -1250,7 +1292,13 @@ int esr_retrieve_topk(const float* queries, const float* candidates, int64_t nq,
       if (nmax_out) hipLaunchKernelGGL(slots_max_kernel, dim3(1), dim3(kBlock), 0, st, (const float*)nrm_slots, grid, nmax_out);
     };
     rowstat(queries, nq, qnorm, exps, nullptr);
-    rowstat(candidates, N, nullptr, exps + 1, cmax);
+    if (prepared) {  // the candidates' exponent and largest norm were found when the corpus was prepared
+      if (hipMemcpyAsync(exps + 1, prepared, sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+          hipMemcpyAsync(cmax, prepared + sizeof(int), sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return check_launch("esr_retrieve_topk_prepared");
+    } else {
+      rowstat(candidates, N, nullptr, exps + 1, cmax);
+    }
     if (hipMemsetAsync(nexact, 0, (size_t)nq * sizeof(int32_t), st) != hipSuccess) return check_launch("esr_retrieve_topk");
     launch_split<4>(queries, nq, D, p.Mp, p.Dp, a_plane, A, st, exps);
   } else if (p.P == 3) launch_split<3>(queries, nq, D, p.Mp, p.Dp, a_plane, A, st);
@@ -1265,7 +1313,14 @@ int esr_retrieve_topk(const float* queries, const float* candidates, int64_t nq,
     const int64_t nc = std::min<int64_t>(first ? p.first : p.chunk, N - c0);
     const int64_t n_pad = cdiv(nc, kGN) * kGN;
     const bool last = (c0 + nc == N);
-    if (p.P == 2) launch_split<2>(candidates + c0 * D, nc, D, n_pad, p.Dp, b_plane, B, st, exps + 1);
+    // a prepared corpus: the chunk's rows inside the plane over ALL rows (k-block-major: a row is 16 elements per k-block)
+    const __bf16* Bc = B;
+    int64_t bc_plane = b_plane, bc_rows = 0;
+    if (prepared) {
+      bc_rows = prepared_rows_pad(N);
+      bc_plane = bc_rows * p.Dp;
+      Bc = (const __bf16*)(prepared + prepared_planes_off()) + c0 * kGK;
+    } else if (p.P == 2) launch_split<2>(candidates + c0 * D, nc, D, n_pad, p.Dp, b_plane, B, st, exps + 1);
     else if (band) launch_split<4>(candidates + c0 * D, nc, D, n_pad, p.Dp, b_plane, B, st, exps + 1);
     else if (p.P == 3) launch_split<3>(candidates + c0 * D, nc, D, n_pad, p.Dp, b_plane, B, st);
     else launch_split<1>(candidates + c0 * D, nc, D, n_pad, p.Dp, b_plane, B, st);
@@ -1280,14 +1335,14 @@ int esr_retrieve_topk(const float* queries, const float* candidates, int64_t nq,
     so.indices = (last && !band) ? out_indices : nullptr;
     if (first) {
       if (p.P == 2) launch_gemm<2, true>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
-      else if (band) launch_gemm<4, true>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
+      else if (band) launch_gemm<4, true>(A, a_plane, Bc, bc_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st, bc_rows);
       else if (p.P == 3) launch_gemm<3, true>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
       else launch_gemm<1, true>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
       in.vals = S; in.vpitch = p.first; in.idx = nullptr; in.stride = 1; in.ibase = o.gbase; in.istep = index_step;
       in.n_per_row = nullptr; in.n_fixed = (int)nc;
     } else {
       if (p.P == 2) launch_gemm<2, false>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
-      else if (band) launch_gemm<4, false>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
+      else if (band) launch_gemm<4, false>(A, a_plane, Bc, bc_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st, bc_rows);
       else if (p.P == 3) launch_gemm<3, false>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
       else launch_gemm<1, false>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
       in.vals = (const float*)pairs; in.vpitch = 2 * p.ppitch; in.idx = (const int32_t*)pairs + 1; in.stride = 2;
@@ -1325,6 +1380,26 @@ int esr_retrieve_topk(const float* queries, const float* candidates, int64_t nq,
     if (int rc = select_topk_tail(pairs, p.ppitch, cnt, nq, k, out_scores, out_indices, st)) return rc;
   }
   return check_launch("esr_retrieve_topk");
+}
+
+int esr_retrieve_topk(const float* queries, const float* candidates, int64_t nq, int64_t N, int D, int k, int mode,
+                      int32_t index_base, int32_t index_step, float* out_scores, int32_t* out_indices, void* workspace,
+                      size_t workspace_bytes, esr_stream_t stream) {
+  TraceScope trace_scope_("esr_retrieve_topk");
+  return retrieve_topk_impl(queries, candidates, nullptr, nq, N, D, k, mode, index_base, index_step, out_scores, out_indices,
+                            workspace, workspace_bytes, stream);
+}
+
+int esr_retrieve_topk_prepared(const float* queries, const float* candidates, const void* prepared, int64_t nq, int64_t N,
+                               int D, int k, int mode, int32_t index_base, int32_t index_step, float* out_scores,
+                               int32_t* out_indices, void* workspace, size_t workspace_bytes, esr_stream_t stream) {
+  TraceScope trace_scope_("esr_retrieve_topk_prepared");
+  ESR_REQUIRE(mode == 3, "esr_retrieve_topk_prepared: mode %d (only ESR_RETRIEVE_F16R = 3 takes a prepared corpus)", mode);
+  ESR_REQUIRE(prepared && !((uintptr_t)prepared & 255), "esr_retrieve_topk_prepared: null or misaligned prepared corpus");
+  ESR_REQUIRE(N > 0 && D > 0 && (int64_t)(cdiv(D, kGK)) * prepared_rows_pad(N) * 32 < ((int64_t)1 << 32),
+              "esr_retrieve_topk_prepared: bad sizes N=%lld D=%d", (long long)N, D);
+  return retrieve_topk_impl(queries, candidates, (const char*)prepared, nq, N, D, k, mode, index_base, index_step,
+                            out_scores, out_indices, workspace, workspace_bytes, stream);
 }
 
 #ifdef ESR_GEMM_TIMING

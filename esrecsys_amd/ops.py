@@ -898,13 +898,30 @@ def _retrieve_mode(mode):
     return _RETRIEVE_MODES[mode]
 
 
-def retrieve_topk(queries, candidates, k, mode="exact", index_base=0, index_step=1):
+def retrieve_prepare(candidates, mode="f16r"):
+    """The per-corpus half of retrieve_topk(mode="f16r") done once (esr_retrieve_prepare): the candidates' scaling statistics
+    and their scaled fp16 plane, as a uint8 tensor to pass as retrieve_topk(..., prepared=...) for as long as `candidates`
+    is unchanged (a product table that serves many scene batches: pinterest/make_recommendations.py:123-132)."""
+    lib = _lib.load()
+    _req(candidates, torch.float32, "candidates")
+    N, D = candidates.shape
+    m = _retrieve_mode(mode)
+    nbytes = lib.esr_retrieve_prepared_bytes(N, D, m)
+    if nbytes == 0:
+        raise ValueError("retrieve_prepare: mode %r takes no prepared corpus (only 'f16r' does)" % (mode,))
+    blob = _aligned_bytes(nbytes, candidates.device)
+    check(lib.esr_retrieve_prepare(_p(candidates), N, D, m, _p(blob), blob.numel(), _stream()), "esr_retrieve_prepare")
+    return blob
+
+
+def retrieve_topk(queries, candidates, k, mode="exact", index_base=0, index_step=1, prepared=None):
     """Batched brute-force top-k of queries @ candidates^T (descending, ties -> lower index) on MFMA.
     mode "exact" = "bf16x3": three exact bf16 planes per operand (exact products in f32 accumulation order);
     "f16x2": two scaled fp16 planes (f32-grade within a 2^16 dynamic range per matrix, 1.6x faster); "f16r": one scaled
     fp16 plane as a filter with a proven error band, its survivors re-scored in f32 -- the exact top-k of the f32 scores
     at a third of f16x2's matrix work (include/esr_hip.h ESR_RETRIEVE_F16R); "bf16": one plane (approximate).
-    Reported indices are index_base + n * index_step for local candidate row n."""
+    Reported indices are index_base + n * index_step for local candidate row n.
+    prepared: retrieve_prepare(candidates, mode) -- the candidates' statistics and planes made once (mode "f16r")."""
     lib = _lib.load()
     _req(queries, torch.float32, "queries"), _req(candidates, torch.float32, "candidates")
     nq, D = queries.shape
@@ -913,6 +930,14 @@ def retrieve_topk(queries, candidates, k, mode="exact", index_base=0, index_step
     out_s = torch.empty((nq, k), dtype=torch.float32, device=queries.device)
     out_i = torch.empty((nq, k), dtype=torch.int32, device=queries.device)
     ws = _ws(_ws_bytes("esr_retrieve_workspace_bytes", nq, N, D, k, m), queries.device)
+    if prepared is not None:
+        if prepared.dtype != torch.uint8 or prepared.numel() < lib.esr_retrieve_prepared_bytes(N, D, m) or \
+                prepared.numel() == 0:
+            raise ValueError("prepared must be retrieve_prepare(candidates, mode) of THIS candidate matrix and mode")
+        check(lib.esr_retrieve_topk_prepared(_p(queries), _p(candidates), _p(prepared), nq, N, D, k, m, index_base,
+                                             index_step, _p(out_s), _p(out_i), _p(ws), ws.numel(), _stream()),
+              "esr_retrieve_topk_prepared")
+        return out_s, out_i
     check(lib.esr_retrieve_topk(_p(queries), _p(candidates), nq, N, D, k, m, index_base, index_step, _p(out_s),
                                 _p(out_i), _p(ws), ws.numel(), _stream()), "esr_retrieve_topk")
     return out_s, out_i
