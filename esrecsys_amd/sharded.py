@@ -1053,23 +1053,26 @@ class _Collectives:
         return dist.all_gather_into_tensor(out, inp, group=self.pg)
 
 
-def sharded_find_top_k(queries, local_candidates, k, group=None, kernels=None, mode="exact"):
+def sharded_find_top_k(queries, local_candidates, k, group=None, kernels=None, mode="exact", prepared=None):
     """Brute-force top-k over candidates that are row-sharded like the tables (this rank holds rows rank,
     rank + G, ...; BASELINE config 5).  Every rank brings its own [nq, D] queries (same nq on every rank):
     all-gather the queries, score ALL of them against the local shard, all-to-all the per-shard answers back to
     the rank that asked, merge the G lists.  Returns ([nq, k] scores, [nq, k] global row indices).  The three
     collectives run on the compute stream through the direct RCCL exchange (no stream hand-overs), as the training
-    steps' do."""
+    steps' do.  prepared: ops.retrieve_prepare(local_candidates) -- this rank's shard prepared once (mode "f16r")."""
+    kw = {} if prepared is None else {"prepared": prepared}
+    if prepared is not None:
+        mode = "f16r"
     if kernels is None:
         from . import ops as kernels
     G, rank = dist.get_world_size(group), dist.get_rank(group)
     nq, D = queries.shape
     if G == 1:
-        return kernels.retrieve_topk(queries, local_candidates, k, mode=mode)
+        return kernels.retrieve_topk(queries, local_candidates, k, mode=mode, **kw)
     coll = _Collectives(group, queries.device)
     everyone = torch.empty((G * nq, D), dtype=queries.dtype, device=queries.device)
     coll.all_gather(everyone, queries.contiguous())
-    s, i = kernels.retrieve_topk(everyone, local_candidates, k, mode=mode, index_base=rank, index_step=G)
+    s, i = kernels.retrieve_topk(everyone, local_candidates, k, mode=mode, index_base=rank, index_step=G, **kw)
     rs, ri = torch.empty_like(s), torch.empty_like(i)        # [G (shard), nq, k] after the exchange
     coll.all_to_all(rs, s)
     coll.all_to_all(ri, i)

@@ -199,6 +199,10 @@ def _w4_worker(rank, port, outdir, wire_lib):
     s, i = sharded.sharded_find_top_k(torch.from_numpy(queries).to(dev),
                                       torch.from_numpy(np.ascontiguousarray(cands[rank::world])).to(dev), 50)
     out["topk_s"], out["topk_i"] = s.cpu().numpy(), i.cpu().numpy()
+    # the same with this rank's shard prepared once (round 6: mode f16r on a prepared corpus)
+    shard = torch.from_numpy(np.ascontiguousarray(cands[rank::world])).to(dev)
+    s2, i2 = sharded.sharded_find_top_k(torch.from_numpy(queries).to(dev), shard, 50, prepared=ops.retrieve_prepare(shard))
+    out["topk_s_prep"], out["topk_i_prep"] = s2.cpu().numpy(), i2.cpu().numpy()
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), **out)
     _finish(dist)
 
@@ -300,6 +304,7 @@ def test_world4_sharded_top_k_equals_brute_force(w4_outputs):
         es, ei = o_topk.batched_top_k(queries, cands, 50, np.float64)
         assert np.array_equal(o["topk_i"], ei)  # every tie: lower GLOBAL index first, across shards
         assert np.array_equal(o["topk_s"], es.astype(np.float32))
+        assert np.array_equal(o["topk_i_prep"], ei) and np.array_equal(o["topk_s_prep"], es.astype(np.float32))
 
 
 # ---- BASELINE config 4 at FULL size: 8 ranks x 12.5 M-row shards of two 100 M-row bf16 towers, all on one GPU -------
