@@ -1194,24 +1194,26 @@ using namespace esr;
 
 extern "C" {
 
-// ---- a prepared corpus (mode 3): what a call does with the candidates before it looks at a query, done once -----------
-// [0, 256): header words -- [0] the candidates' exponent code (int), [1] their largest row norm (float), [2..3] N,
-// [4] D; [256, 256 + 2 * kAbsBlocks * 4): the statistics pass's slots; then ONE scaled fp16 plane, k-block-major over
-// ALL rows (rows_pad = N rounded up to the tile + one tile: a chunk's last tile may start anywhere).
+// ---- a prepared corpus: what a call does with the candidates before it looks at a query, done once --------------------
+// [0, 256): header words -- [0] the candidates' exponent code (int; the scaled fp16 modes), [1] their largest row norm
+// (float; mode 3), [2..3] N, [4] D; [256, 256 + 2 * kAbsBlocks * 4): the statistics pass's slots; then the mode's planes
+// (1, 2 or 3), each k-block-major over ALL rows (rows_pad = N rounded up to the tile + one tile: a chunk's last tile may
+// start anywhere).
 static int64_t prepared_rows_pad(int64_t N) { return cdiv(N, kGN) * kGN + kGN; }
 static size_t prepared_planes_off() { return align_up(256 + 2 * (size_t)kAbsBlocks * sizeof(float), 256); }
+static int mode_planes(int mode) { return (mode == 0) ? 3 : (mode == 2 ? 2 : (mode == 3 ? 4 : 1)); }  // (retrieve_plan's P)
 size_t esr_retrieve_prepared_bytes(int64_t N, int D, int mode) {
-  if (N <= 0 || D <= 0 || mode != 3) return 0;
+  if (N <= 0 || D <= 0 || mode < 0 || mode > 3) return 0;
   const int64_t Dp = cdiv(D, kGK) * kGK;
-  return prepared_planes_off() + align_up((size_t)prepared_rows_pad(N) * Dp * 2, 256);
+  return prepared_planes_off() + align_up((size_t)plane_count(mode_planes(mode)) * prepared_rows_pad(N) * Dp * 2, 256);
 }
 
 int esr_retrieve_prepare(const float* candidates, int64_t N, int D, int mode, void* prepared, size_t prepared_bytes,
                          esr_stream_t stream) {
   TraceScope trace_scope_("esr_retrieve_prepare");
-  ESR_REQUIRE(mode == 3, "esr_retrieve_prepare: mode %d (only ESR_RETRIEVE_F16R = 3 takes a prepared corpus)", mode);
-  ESR_REQUIRE(N > 0 && D > 0 && N < ((int64_t)1 << 31) && D <= kSelLdsWords, "esr_retrieve_prepare: bad sizes N=%lld D=%d",
-              (long long)N, D);
+  ESR_REQUIRE(mode >= 0 && mode <= 3, "esr_retrieve_prepare: mode %d", mode);
+  ESR_REQUIRE(N > 0 && D > 0 && N < ((int64_t)1 << 31) && (mode != 3 || D <= kSelLdsWords),
+              "esr_retrieve_prepare: bad sizes N=%lld D=%d", (long long)N, D);
   ESR_REQUIRE(candidates && prepared && !((uintptr_t)prepared & 255), "esr_retrieve_prepare: null or misaligned pointer");
   const int Dp = (int)(cdiv(D, kGK) * kGK);
   const int64_t rows_pad = prepared_rows_pad(N);
@@ -1226,13 +1228,24 @@ int esr_retrieve_prepare(const float* candidates, int64_t N, int D, int mode, vo
   int* hdr = (int*)base;
   float* abs_slots = (float*)(base + 256);
   float* nrm_slots = abs_slots + kAbsBlocks;
-  const int grid = (int)std::min<int64_t>(kAbsBlocks, std::max<int64_t>(1, cdiv(N, kBlock / 64)));
-  hipLaunchKernelGGL(rowstat_kernel, dim3(grid), dim3(kBlock), 0, st, candidates, N, D, (float*)nullptr, abs_slots, nrm_slots);
-  hipLaunchKernelGGL(absmax_exp_kernel, dim3(1), dim3(kBlock), 0, st, (const float*)abs_slots, grid, hdr);
-  hipLaunchKernelGGL(slots_max_kernel, dim3(1), dim3(kBlock), 0, st, (const float*)nrm_slots, grid, (float*)(hdr + 1));
   const int64_t meta[2] = {N, (int64_t)D};
   if (hipMemcpyAsync(hdr + 2, meta, sizeof(meta), hipMemcpyHostToDevice, st) != hipSuccess) return check_launch("esr_retrieve_prepare");
-  launch_split<4>(candidates, N, D, rows_pad, Dp, rows_pad * Dp, (__bf16*)(base + prepared_planes_off()), st, hdr);
+  __bf16* planes = (__bf16*)(base + prepared_planes_off());
+  const int P = mode_planes(mode);
+  if (P == 4) {
+    const int grid = (int)std::min<int64_t>(kAbsBlocks, std::max<int64_t>(1, cdiv(N, kBlock / 64)));
+    hipLaunchKernelGGL(rowstat_kernel, dim3(grid), dim3(kBlock), 0, st, candidates, N, D, (float*)nullptr, abs_slots, nrm_slots);
+    hipLaunchKernelGGL(absmax_exp_kernel, dim3(1), dim3(kBlock), 0, st, (const float*)abs_slots, grid, hdr);
+    hipLaunchKernelGGL(slots_max_kernel, dim3(1), dim3(kBlock), 0, st, (const float*)nrm_slots, grid, (float*)(hdr + 1));
+    launch_split<4>(candidates, N, D, rows_pad, Dp, rows_pad * Dp, planes, st, hdr);
+  } else if (P == 2) {
+    launch_absmax(candidates, N * (int64_t)D, abs_slots, hdr, st);
+    launch_split<2>(candidates, N, D, rows_pad, Dp, rows_pad * Dp, planes, st, hdr);
+  } else if (P == 3) {
+    launch_split<3>(candidates, N, D, rows_pad, Dp, rows_pad * Dp, planes, st);
+  } else {
+    launch_split<1>(candidates, N, D, rows_pad, Dp, rows_pad * Dp, planes, st);
+  }
   return check_launch("esr_retrieve_prepare");
 }
 
@@ -1281,7 +1294,12 @@ static int retrieve_topk_impl(const float* queries, const float* candidates, con
   if (p.P == 2) {
     // one exponent per matrix; the candidates' covers ALL chunks (one 4 N D-byte read, ~1 % of the call at N = 1 M)
     launch_absmax(queries, nq * (int64_t)D, abs_slots, exps, st);
-    launch_absmax(candidates, N * (int64_t)D, abs_slots, exps + 1, st);
+    if (prepared) {
+      if (hipMemcpyAsync(exps + 1, prepared, sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return check_launch("esr_retrieve_topk_prepared");
+    } else {
+      launch_absmax(candidates, N * (int64_t)D, abs_slots, exps + 1, st);
+    }
     launch_split<2>(queries, nq, D, p.Mp, p.Dp, a_plane, A, st, exps);
   } else if (band) {
     // exponents as above, and in the same read of each matrix the row norms the error bound of a one-plane score needs
@@ -1334,17 +1352,17 @@ static int retrieve_topk_impl(const float* queries, const float* candidates, con
     so.scores = (last && !band) ? out_scores : nullptr;   // (mode 3 delivers after its re-score, below)
     so.indices = (last && !band) ? out_indices : nullptr;
     if (first) {
-      if (p.P == 2) launch_gemm<2, true>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
+      if (p.P == 2) launch_gemm<2, true>(A, a_plane, Bc, bc_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st, bc_rows);
       else if (band) launch_gemm<4, true>(A, a_plane, Bc, bc_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st, bc_rows);
-      else if (p.P == 3) launch_gemm<3, true>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
-      else launch_gemm<1, true>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
+      else if (p.P == 3) launch_gemm<3, true>(A, a_plane, Bc, bc_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st, bc_rows);
+      else launch_gemm<1, true>(A, a_plane, Bc, bc_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st, bc_rows);
       in.vals = S; in.vpitch = p.first; in.idx = nullptr; in.stride = 1; in.ibase = o.gbase; in.istep = index_step;
       in.n_per_row = nullptr; in.n_fixed = (int)nc;
     } else {
-      if (p.P == 2) launch_gemm<2, false>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
+      if (p.P == 2) launch_gemm<2, false>(A, a_plane, Bc, bc_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st, bc_rows);
       else if (band) launch_gemm<4, false>(A, a_plane, Bc, bc_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st, bc_rows);
-      else if (p.P == 3) launch_gemm<3, false>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
-      else launch_gemm<1, false>(A, a_plane, B, b_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st);
+      else if (p.P == 3) launch_gemm<3, false>(A, a_plane, Bc, bc_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st, bc_rows);
+      else launch_gemm<1, false>(A, a_plane, Bc, bc_plane, p.Dp, p.Mp, n_pad, (int)nq, (int)nc, o, st, bc_rows);
       in.vals = (const float*)pairs; in.vpitch = 2 * p.ppitch; in.idx = (const int32_t*)pairs + 1; in.stride = 2;
       in.ibase = 0; in.istep = 0; in.n_per_row = cnt; in.n_fixed = 0;
       in.skip_upto = last ? 0 : lazy_mark;  // the last chunk's select delivers the answer: every row
@@ -1394,7 +1412,7 @@ int esr_retrieve_topk_prepared(const float* queries, const float* candidates, co
                                int D, int k, int mode, int32_t index_base, int32_t index_step, float* out_scores,
                                int32_t* out_indices, void* workspace, size_t workspace_bytes, esr_stream_t stream) {
   TraceScope trace_scope_("esr_retrieve_topk_prepared");
-  ESR_REQUIRE(mode == 3, "esr_retrieve_topk_prepared: mode %d (only ESR_RETRIEVE_F16R = 3 takes a prepared corpus)", mode);
+  ESR_REQUIRE(mode >= 0 && mode <= 3, "esr_retrieve_topk_prepared: mode %d", mode);
   ESR_REQUIRE(prepared && !((uintptr_t)prepared & 255), "esr_retrieve_topk_prepared: null or misaligned prepared corpus");
   ESR_REQUIRE(N > 0 && D > 0 && (int64_t)(cdiv(D, kGK)) * prepared_rows_pad(N) * 32 < ((int64_t)1 << 32),
               "esr_retrieve_topk_prepared: bad sizes N=%lld D=%d", (long long)N, D);

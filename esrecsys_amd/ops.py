@@ -898,20 +898,29 @@ def _retrieve_mode(mode):
     return _RETRIEVE_MODES[mode]
 
 
+class PreparedCorpus:
+    """What retrieve_prepare made of a candidate matrix: the buffer esr_retrieve_topk_prepared reads, and what it was made
+    for (mode, shape, the matrix's storage) so that a call cannot be handed another corpus's or another mode's planes."""
+    __slots__ = ("blob", "mode", "N", "D", "data_ptr")
+
+    def __init__(self, blob, mode, N, D, data_ptr):
+        self.blob, self.mode, self.N, self.D, self.data_ptr = blob, mode, N, D, data_ptr
+
+
 def retrieve_prepare(candidates, mode="f16r"):
-    """The per-corpus half of retrieve_topk(mode="f16r") done once (esr_retrieve_prepare): the candidates' scaling statistics
-    and their scaled fp16 plane, as a uint8 tensor to pass as retrieve_topk(..., prepared=...) for as long as `candidates`
-    is unchanged (a product table that serves many scene batches: pinterest/make_recommendations.py:123-132)."""
+    """The per-corpus half of retrieve_topk done once (esr_retrieve_prepare): the candidates' scaling statistics and their
+    planes in the mode's format, to pass as retrieve_topk(..., prepared=...) for as long as `candidates` is unchanged (a
+    product table that serves many scene batches: pinterest/make_recommendations.py:123-132)."""
     lib = _lib.load()
     _req(candidates, torch.float32, "candidates")
     N, D = candidates.shape
     m = _retrieve_mode(mode)
     nbytes = lib.esr_retrieve_prepared_bytes(N, D, m)
     if nbytes == 0:
-        raise ValueError("retrieve_prepare: mode %r takes no prepared corpus (only 'f16r' does)" % (mode,))
+        raise ValueError("retrieve_prepare: bad shape %s / mode %r" % (tuple(candidates.shape), mode))
     blob = _aligned_bytes(nbytes, candidates.device)
     check(lib.esr_retrieve_prepare(_p(candidates), N, D, m, _p(blob), blob.numel(), _stream()), "esr_retrieve_prepare")
-    return blob
+    return PreparedCorpus(blob, m, N, D, candidates.data_ptr())
 
 
 def retrieve_topk(queries, candidates, k, mode="exact", index_base=0, index_step=1, prepared=None):
@@ -921,7 +930,7 @@ def retrieve_topk(queries, candidates, k, mode="exact", index_base=0, index_step
     fp16 plane as a filter with a proven error band, its survivors re-scored in f32 -- the exact top-k of the f32 scores
     at a third of f16x2's matrix work (include/esr_hip.h ESR_RETRIEVE_F16R); "bf16": one plane (approximate).
     Reported indices are index_base + n * index_step for local candidate row n.
-    prepared: retrieve_prepare(candidates, mode) -- the candidates' statistics and planes made once (mode "f16r")."""
+    prepared: retrieve_prepare(candidates, mode) -- the candidates' statistics and planes made once."""
     lib = _lib.load()
     _req(queries, torch.float32, "queries"), _req(candidates, torch.float32, "candidates")
     nq, D = queries.shape
@@ -931,10 +940,10 @@ def retrieve_topk(queries, candidates, k, mode="exact", index_base=0, index_step
     out_i = torch.empty((nq, k), dtype=torch.int32, device=queries.device)
     ws = _ws(_ws_bytes("esr_retrieve_workspace_bytes", nq, N, D, k, m), queries.device)
     if prepared is not None:
-        if prepared.dtype != torch.uint8 or prepared.numel() < lib.esr_retrieve_prepared_bytes(N, D, m) or \
-                prepared.numel() == 0:
+        if not isinstance(prepared, PreparedCorpus) or (prepared.mode, prepared.N, prepared.D, prepared.data_ptr) != \
+                (m, N, D, candidates.data_ptr()):
             raise ValueError("prepared must be retrieve_prepare(candidates, mode) of THIS candidate matrix and mode")
-        check(lib.esr_retrieve_topk_prepared(_p(queries), _p(candidates), _p(prepared), nq, N, D, k, m, index_base,
+        check(lib.esr_retrieve_topk_prepared(_p(queries), _p(candidates), _p(prepared.blob), nq, N, D, k, m, index_base,
                                              index_step, _p(out_s), _p(out_i), _p(ws), ws.numel(), _stream()),
               "esr_retrieve_topk_prepared")
         return out_s, out_i

@@ -19,13 +19,14 @@ def find_top_k(scene_embedding, product_embeddings, k):
     return (s[0], i[0]) if single else (s, i)
 
 
-def prepare_products(product_embeddings):
-    """The per-corpus half of the ``"f16r"`` brute force done once for a product table that serves many scene batches (the
-    reference scores every scene against the same ``product_embeddings``: make_recommendations.py:123-132): pass the
-    result as ``find_top_k_batch(..., prepared=...)`` for as long as the table is unchanged (ops.retrieve_prepare)."""
+def prepare_products(product_embeddings, mode="f16r"):
+    """The per-corpus half of the brute force done once for a product table that serves many scene batches (the reference
+    scores every scene against the same ``product_embeddings``: make_recommendations.py:123-132): pass the result as
+    ``find_top_k_batch(..., prepared=...)`` for as long as the table is unchanged (ops.retrieve_prepare).  The table
+    must already be a float32 device tensor (the prepared planes belong to THAT storage)."""
     dev = product_embeddings.device if isinstance(product_embeddings, torch.Tensor) and product_embeddings.is_cuda \
         else torch.device("cuda", torch.cuda.current_device())
-    return ops.retrieve_prepare(ops.as_f32(product_embeddings, dev), mode="f16r")
+    return ops.retrieve_prepare(ops.as_f32(product_embeddings, dev), mode=mode)
 
 
 def find_top_k_batch(scene_embeddings, product_embeddings, k, approximate=False, probe=None, mode="exact", prepared=None):
@@ -47,7 +48,8 @@ def find_top_k_batch(scene_embeddings, product_embeddings, k, approximate=False,
     k = int(k)
     if not approximate:
         if prepared is not None:
-            return ops.retrieve_topk(q, p, k, mode="f16r", prepared=prepared)
+            return ops.retrieve_topk(q, p, k, mode=next(n for n, c in ops._RETRIEVE_MODES.items() if c == prepared.mode),
+                                     prepared=prepared)
         return ops.retrieve_topk(q, p, k, mode=mode)
     probe = min(p.shape[0], 1024, max(k, int(probe) if probe is not None else k + max(64, k // 2)))
     _, cand = ops.retrieve_topk(q, p, probe, mode="bf16")

@@ -1059,12 +1059,12 @@ def sharded_find_top_k(queries, local_candidates, k, group=None, kernels=None, m
     all-gather the queries, score ALL of them against the local shard, all-to-all the per-shard answers back to
     the rank that asked, merge the G lists.  Returns ([nq, k] scores, [nq, k] global row indices).  The three
     collectives run on the compute stream through the direct RCCL exchange (no stream hand-overs), as the training
-    steps' do.  prepared: ops.retrieve_prepare(local_candidates) -- this rank's shard prepared once (mode "f16r")."""
-    kw = {} if prepared is None else {"prepared": prepared}
-    if prepared is not None:
-        mode = "f16r"
+    steps' do.  prepared: ops.retrieve_prepare(local_candidates, mode) -- this rank's shard prepared once."""
     if kernels is None:
         from . import ops as kernels
+    kw = {} if prepared is None else {"prepared": prepared}
+    if prepared is not None:
+        mode = next(n for n, c in kernels._RETRIEVE_MODES.items() if c == prepared.mode)
     G, rank = dist.get_world_size(group), dist.get_rank(group)
     nq, D = queries.shape
     if G == 1:

@@ -462,13 +462,14 @@ size_t esr_retrieve_workspace_bytes(int64_t nq, int64_t N, int D, int k, int mod
 int esr_retrieve_topk(const float* queries, const float* candidates, int64_t nq, int64_t N, int D, int k,
                       int mode, int32_t index_base, int32_t index_step, float* out_scores,
                       int32_t* out_indices, void* workspace, size_t workspace_bytes, esr_stream_t stream);
-/* A PREPARED corpus (round 6; mode ESR_RETRIEVE_F16R): everything a call does with the candidates before it looks at a
- * query -- the statistics pass (exponent, largest row norm) and the split into the scaled fp16 plane, 3 N D bytes of
- * reads and 2 N D of writes -- done ONCE for a corpus that serves many calls (the reference scores every batch of
+/* A PREPARED corpus (round 6; every mode): everything a call does with the candidates before it looks at a query -- the
+ * statistics pass (exponent, largest row norm: the scaled fp16 modes) and the split into the mode's planes, up to
+ * 2 x 4 N D bytes of reads and 2 P N D of writes -- done ONCE for a corpus that serves many calls (the reference scores every batch of
  * scenes against the same product embeddings: pinterest/make_recommendations.py:123-132).  esr_retrieve_prepare fills
  * `prepared` (esr_retrieve_prepared_bytes(N, D, mode) bytes, 256-byte aligned, the caller's; valid while the candidate
- * matrix is unchanged); esr_retrieve_topk_prepared is esr_retrieve_topk with those two passes left out -- the same
- * filter, band, re-score (from the f32 `candidates`, still an argument) and answer, bit for bit. */
+ * matrix is unchanged; made for ONE mode); esr_retrieve_topk_prepared is esr_retrieve_topk of that mode with those passes
+ * left out -- the same products, filter, band, re-score (from the f32 `candidates`, still an argument) and answer, bit for
+ * bit. */
 size_t esr_retrieve_prepared_bytes(int64_t N, int D, int mode);
 int esr_retrieve_prepare(const float* candidates, int64_t N, int D, int mode, void* prepared, size_t prepared_bytes,
                          esr_stream_t stream);

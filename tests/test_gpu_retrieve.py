@@ -267,29 +267,32 @@ def test_recall_at_k_long_lists_in_chunks(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f16r", "f16x2", "bf16x3", "bf16"])
 @pytest.mark.parametrize("nq,N,D,k", [(37, 70_001, 128, 10), (300, 200_000, 96, 601), (1000, 40_000, 512, 500),
                                       (5, 127, 64, 100), (256, 140_000, 130, 1024)])
-def test_retrieve_f16r_prepared_corpus_equals_the_plain_call(dev, nq, N, D, k):
-    """esr_retrieve_prepare + esr_retrieve_topk_prepared (the candidates' statistics pass and fp16 plane made once, as ONE
-    plane over all rows in which every chunk is a row range) against esr_retrieve_topk(mode f16r): scores and indices bit
-    for bit -- first chunks of 8192 and of 16 k = 9616 rows (not a multiple of the 128-row tile: the second chunk starts
-    inside a tile), a corpus shorter than a tile, widths that are padded to the k-block, two query batches on one
-    prepared corpus, index_base / index_step, and through find_top_k_batch(prepared=...)."""
+def test_retrieve_prepared_corpus_equals_the_plain_call(dev, nq, N, D, k, mode):
+    """esr_retrieve_prepare + esr_retrieve_topk_prepared (the candidates' statistics pass and planes made once, every plane
+    over ALL rows, in which a chunk is a row range) against esr_retrieve_topk, every mode: scores and indices bit for bit
+    -- first chunks of 8192 and of 16 k = 9616 rows (not a multiple of the 128-row tile: the second chunk starts inside a
+    tile), a corpus shorter than a tile, widths that are padded to the k-block, two query batches on one prepared
+    corpus, index_base / index_step, through find_top_k_batch(prepared=...); a corpus prepared for another mode or another
+    matrix is refused."""
     from esrecsys_amd import ops
     from esrecsys_amd.pinterest.make_recommendations import find_top_k_batch, prepare_products
     g = torch.Generator(device=dev).manual_seed(nq + N)
     c = torch.randn((N, D), generator=g, device=dev) * 0.2
     c[N // 3] *= 9.0                                   # the largest norm and the exponent come from one row
-    prep = ops.retrieve_prepare(c, mode="f16r")
+    prep = ops.retrieve_prepare(c, mode=mode)
     for rep in range(2):
         q = torch.randn((nq, D), generator=g, device=dev) * (0.5 + rep)
-        s0, i0 = ops.retrieve_topk(q, c, k, mode="f16r", index_base=3, index_step=2)
-        s1, i1 = ops.retrieve_topk(q, c, k, mode="f16r", index_base=3, index_step=2, prepared=prep)
+        s0, i0 = ops.retrieve_topk(q, c, k, mode=mode, index_base=3, index_step=2)
+        s1, i1 = ops.retrieve_topk(q, c, k, mode=mode, index_base=3, index_step=2, prepared=prep)
         assert torch.equal(i0, i1) and torch.equal(s0, s1)
-    s2, i2 = find_top_k_batch(q, c, k, prepared=prepare_products(c))
-    s3, i3 = find_top_k_batch(q, c, k, mode="f16r")
+    s2, i2 = find_top_k_batch(q, c, k, prepared=prepare_products(c, mode=mode))
+    s3, i3 = find_top_k_batch(q, c, k, mode=mode)
     assert torch.equal(i2, i3) and torch.equal(s2, s3)
+    other = "f16x2" if mode != "f16x2" else "f16r"
     with pytest.raises(ValueError):
-        ops.retrieve_prepare(c, mode="f16x2")
+        ops.retrieve_topk(q, c, k, mode=other, prepared=prep)
     with pytest.raises(ValueError):
-        ops.retrieve_topk(q, c[: N // 2].contiguous(), min(k, N // 2), mode="f16r", prepared=prep[:1024])
+        ops.retrieve_topk(q, c.clone(), k, mode=mode, prepared=prep)
